@@ -1,0 +1,339 @@
+// ORACLE — test infrastructure only (see oracle.hpp).  Flat C entry points so that tests/ (ctypes),
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg can drive the restatement.
+#include <cstring>
+#include <map>
+#include <stdexcept>
+
+#include "oracle.hpp"
+
+using namespace dpo;
+
+namespace {
+thread_local std::string g_err;
+template <class F>
+int guard(F f) {
+    try {
+        f();
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+SeedSequence* mkSeq(Arena& a, const i64* seg, i64 n) {
+    SeedSequence* s = a.make();
+    s->store = std::make_shared<std::vector<i64>>(seg, seg + n);
+    s->lo = 0;
+    s->n = (size_t)n;
+    return s;
+}
+IntSet seedSetLikeIndex(const SeedSequence* s) {  // SeedIndex.AddSequence seeds.go:272-285
+    i64 mx = s->getMaxSeed();
+    IntSet st(mx + 1);
+    for (i64 i = 0; i < s->numSeeds(); i++) st.add((u64)s->getSeed(i));
+    return st;
+}
+void flatten(const std::vector<SeedMatch>& ms, i64* outCounts, i64* outA, i64* outB, i64 cap, i64* nMatches) {
+    i64 pos = 0;
+    *nMatches = (i64)ms.size();
+    for (size_t i = 0; i < ms.size(); i++) {
+        outCounts[i] = (i64)ms[i].MatchA.size();
+        for (size_t j = 0; j < ms[i].MatchA.size(); j++) {
+            if (pos >= cap) throw std::runtime_error("oracle capi: output capacity");
+            outA[pos] = ms[i].MatchA[j];
+            outB[pos] = ms[i].MatchB[j];
+            pos++;
+        }
+    }
+}
+}  // namespace
+
+extern "C" {
+
+const char* dpo_last_error() { return g_err.c_str(); }
+
+// ---- sequences -------------------------------------------------------------------------------
+void* dpo_seq_new(const char* s, int64_t n) { return new PackedSeq(newPackedSequence(0, std::string(s, (size_t)n), nullptr)); }
+void dpo_seq_free(void* h) { delete (PackedSeq*)h; }
+void* dpo_seq_sub(void* h, int64_t start, int64_t end) { return new PackedSeq(((PackedSeq*)h)->subSequence(start, end)); }
+void* dpo_seq_rc(void* h) { return new PackedSeq(((PackedSeq*)h)->reverseComplement()); }
+int64_t dpo_seq_str(void* h, char* out, int64_t cap) {
+    std::string s = ((PackedSeq*)h)->str();
+    if ((int64_t)s.size() > cap) return -1;
+    memcpy(out, s.data(), s.size());
+    return (int64_t)s.size();
+}
+// out: nbytes, firstLen, finalLen, offset, inset, length
+void dpo_seq_meta(void* h, int64_t* out) {
+    PackedSeq* p = (PackedSeq*)h;
+    out[0] = (int64_t)p->nbytes();
+    out[1] = p->firstLen;
+    out[2] = p->finalLen;
+    out[3] = p->offset;
+    out[4] = p->inset;
+    out[5] = p->length;
+}
+void dpo_seq_bytes(void* h, uint8_t* out) { memcpy(out, ((PackedSeq*)h)->data(), ((PackedSeq*)h)->nbytes()); }
+int64_t dpo_seq_kmer_at(void* h, int64_t i, int k) { return ((PackedSeq*)h)->kmerAt(i, k); }
+int64_t dpo_seq_next_kmer(void* h, int64_t cur, int64_t mask, int64_t idx) { return ((PackedSeq*)h)->nextKmer(cur, mask, idx); }
+int64_t dpo_seq_count_kmers(void* h, int64_t upTo, int k, const uint8_t* seeds) { return ((PackedSeq*)h)->countKmers(upTo, k, seeds); }
+int64_t dpo_seq_count_kmers_between(void* h, int64_t from, int64_t to, int64_t upTo, int k, const uint8_t* seeds) {
+    return ((PackedSeq*)h)->countKmersBetween(from, to, upTo, k, seeds);
+}
+int64_t dpo_seq_write_segments(void* h, int k, const uint8_t* seeds, int64_t* out) {
+    PackedSeq* p = (PackedSeq*)h;
+    return packedWriteSegmentsAsm(p->data(), (i64)p->nbytes(), 4 - p->firstLen, 4 - p->finalLen, k, seeds, out);
+}
+int64_t dpo_byte_count_kmers(const char* s, int64_t n, int64_t upTo, int k, const uint8_t* seeds) {
+    return byteCountKmers(std::string(s, (size_t)n), upTo, k, seeds);
+}
+int64_t dpo_byte_write_segments(const char* s, int64_t n, int k, const uint8_t* seeds, int64_t* out) {
+    return byteWriteSegments(std::string(s, (size_t)n), k, seeds, out);
+}
+void dpo_pack_bytes(const uint8_t* s, int64_t n, uint8_t* out) { packBytesAsm(s, (size_t)n, out); }
+uint64_t dpo_rc_kmer(uint64_t kmer, int k) { return reverseComplementKmer(kmer, k); }
+
+// ---- IntSet ----------------------------------------------------------------------------------
+void* dpo_set_new() { return new IntSet(); }
+void* dpo_set_new_cap(int64_t cap) { return new IntSet(cap); }
+void dpo_set_free(void* h) { delete (IntSet*)h; }
+void dpo_set_add(void* h, uint64_t x) { ((IntSet*)h)->add(x); }
+void dpo_set_clear(void* h) { ((IntSet*)h)->clear(); }
+int dpo_set_contains(void* h, uint64_t x) { return ((IntSet*)h)->contains(x) ? 1 : 0; }
+uint64_t dpo_set_size(void* h) { return ((IntSet*)h)->size(); }
+// out: start, end, len(vs)
+void dpo_set_window(void* h, uint64_t* out) {
+    IntSet* s = (IntSet*)h;
+    out[0] = s->start;
+    out[1] = s->end;
+    out[2] = (uint64_t)s->vs.size();
+}
+void dpo_set_words(void* h, uint64_t* out) { memcpy(out, ((IntSet*)h)->vs.data(), ((IntSet*)h)->vs.size() * 8); }
+uint64_t dpo_set_count_intersection(void* a, void* b) { return ((IntSet*)a)->countIntersection(*(IntSet*)b); }
+int64_t dpo_set_count_intersection_to(void* a, void* b, int64_t maxCount) {
+    int64_t r = -1;
+    guard([&] { r = (int64_t)((IntSet*)a)->countIntersectionTo(*(IntSet*)b, maxCount); });
+    return r;
+}
+int64_t dpo_shared_ids(void** sets, int64_t n, int64_t minCount, int fast, uint64_t* out, int64_t cap) {
+    std::vector<const IntSet*> v;
+    for (int64_t i = 0; i < n; i++) v.push_back((IntSet*)sets[i]);
+    std::vector<u64> ids = getSharedIDs(v, minCount, fast != 0);
+    if ((int64_t)ids.size() > cap) return -1;
+    memcpy(out, ids.data(), ids.size() * 8);
+    return (int64_t)ids.size();
+}
+void dpo_soft_union(int which, const uint64_t* vs, int64_t n, uint64_t* out4) {
+    if (which == 4) softUnion4(vs, n, out4);
+    else if (which == 8) softUnion8(vs, n, out4);
+    else softUnion16(vs, n, out4);
+}
+void dpo_gap_range(int64_t gap, int k, int64_t* out2) { gapRange(gap, k, &out2[0], &out2[1]); }
+
+// ---- chaining on raw segment arrays ----------------------------------------------------------
+// Calls PairwiseAlignments exactly as matchWorker does (overlap/overlap.go:351-365): aSet = seeds of a
+// (NewIntSet), bSet = SeedIndex.AddSequence's seed set of b.  Matches come back in the reference's order.
+int dpo_pairwise(const int64_t* aSeg, int64_t aN, const int64_t* bSeg, int64_t bN, int64_t minMatches, int k,
+                 int64_t maxLength, int64_t* outCounts, int64_t* outA, int64_t* outB, int64_t cap, int64_t* nMatches) {
+    return guard([&] {
+        Arena ar;
+        SeedSequence* a = mkSeq(ar, aSeg, aN);
+        SeedSequence* b = mkSeq(ar, bSeg, bN);
+        IntSet aSet;
+        for (i64 i = 0; i < a->numSeeds(); i++) aSet.add((u64)a->getSeed(i));
+        IntSet bSet = seedSetLikeIndex(b);
+        SeedAligner al(maxLength);
+        std::vector<SeedMatch> ms = al.pairwiseAlignments(a, b, aSet, bSet, minMatches, k);
+        flatten(ms, outCounts, outA, outB, cap, nMatches);
+    });
+}
+// SeedSequence.Match as performMapping calls it (mapping/mapping.go:514-526): seq = target, query.
+int dpo_match(const int64_t* seqSeg, int64_t sN, const int64_t* qSeg, int64_t qN, int64_t minMatch, int k,
+              int64_t* outCounts, int64_t* outA, int64_t* outB, int64_t cap, int64_t* nMatches) {
+    return guard([&] {
+        Arena ar;
+        SeedSequence* s = mkSeq(ar, seqSeg, sN);
+        SeedSequence* q = mkSeq(ar, qSeg, qN);
+        IntSet qSet = seedSetLikeIndex(q);
+        IntSet sSet = seedSetLikeIndex(s);
+        std::vector<SeedMatch> ms = ssMatch(ar, s, q, &qSet, &sSet, minMatch, k);
+        flatten(ms, outCounts, outA, outB, cap, nMatches);
+    });
+}
+
+// ---- k-mer value table -----------------------------------------------------------------------
+struct ReadSetH {
+    FastaSet set;
+};
+void* dpo_reads_from_fasta(const char* path, int64_t minLen, int himem) {
+    return new ReadSetH{FastaSet::fromFile(path, minLen, himem != 0)};
+}
+// concatenated ASCII reads + offsets (n+1)
+void* dpo_reads_from_arrays(const char* bases, const int64_t* off, int64_t n, int64_t minLen, int himem) {
+    std::vector<std::string> names, seqs;
+    char nm[32];
+    for (int64_t i = 0; i < n; i++) {
+        snprintf(nm, sizeof nm, ">r%07lld", (long long)i);
+        names.push_back(nm);
+        seqs.emplace_back(bases + off[i], (size_t)(off[i + 1] - off[i]));
+    }
+    return new ReadSetH{FastaSet::fromReads(names, seqs, minLen, himem != 0)};
+}
+void dpo_reads_free(void* h) { delete (ReadSetH*)h; }
+int64_t dpo_reads_count(void* h) { return (int64_t)((ReadSetH*)h)->set.size(); }
+void dpo_reads_reset_ignore(void* h) {
+    auto& ig = ((ReadSetH*)h)->set.ignore;
+    std::fill(ig.begin(), ig.end(), 0);
+}
+void dpo_reads_get_ignore(void* h, uint8_t* out) {
+    auto& ig = ((ReadSetH*)h)->set.ignore;
+    memcpy(out, ig.data(), ig.size());
+}
+// values must hold 4^k doubles
+int dpo_kmer_values(void* h, int k, double* values) {
+    return guard([&] {
+        std::vector<u64> counts = kmerOccurrences(((ReadSetH*)h)->set.cached, k);
+        std::vector<double> v = kmerValues(counts, k);
+        memcpy(values, v.data(), v.size() * sizeof(double));
+    });
+}
+int dpo_kmer_counts(void* h, int k, uint64_t* counts) {
+    return guard([&] {
+        std::vector<u64> c = kmerOccurrences(((ReadSetH*)h)->set.cached, k);
+        memcpy(counts, c.data(), c.size() * 8);
+    });
+}
+
+// ---- overlap command -------------------------------------------------------------------------
+struct OverlapH {
+    OverlapResult res;
+    std::map<std::pair<int64_t, int>, std::vector<int64_t>> cache;
+};
+// params: overlapSize,k,numSeeds,seedBatchSize,chunkSize,queryBatchSize,himem ; minHits separately
+void* dpo_overlap_run(void* reads, const int64_t* params, double minHits, const double* valuesOrNull, int64_t maxRounds,
+                      int keepTraces) {
+    OverlapH* h = new OverlapH();
+    int rc = guard([&] {
+        OverlapParams p;
+        p.overlapSize = params[0];
+        p.k = (int)params[1];
+        p.numSeeds = params[2];
+        p.seedBatchSize = params[3];
+        p.chunkSize = params[4];
+        p.queryBatchSize = params[5];
+        p.himem = params[6] != 0;
+        p.minHits = minHits;
+        ((ReadSetH*)reads)->set.himem = p.himem;
+        h->res = runOverlap(((ReadSetH*)reads)->set, p, valuesOrNull, maxRounds, keepTraces != 0);
+    });
+    if (rc != 0) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+void dpo_overlap_free(void* h) { delete (OverlapH*)h; }
+int64_t dpo_overlap_rounds(void* h) { return ((OverlapH*)h)->res.rounds; }
+const char* dpo_overlap_paf(void* h, int64_t* n) {
+    *n = (int64_t)((OverlapH*)h)->res.paf.size();
+    return ((OverlapH*)h)->res.paf.data();
+}
+const char* dpo_overlap_err(void* h, int64_t* n) {
+    *n = (int64_t)((OverlapH*)h)->res.err.size();
+    return ((OverlapH*)h)->res.err.data();
+}
+// Trace fields.  Nested fields come as (flat, offsets) pairs: field f = flat data, f+100 = offsets.
+//  0 seedKmers | 1 queryIDs | 2 querySeqIDs | 3 indexedIds | 4 indexedLength | 5 indexedOffset | 6 indexedInset
+//  7 matchQueryIndex | 8 matchTarget | 9 newlyIgnored | 10 scalars {firstSequence,numQuerySeqs,hits,qHits}
+//  20 querySegments | 21 indexedSegments | 22 candidates | 23 matchA | 24 matchB
+static void flat(const std::vector<std::vector<i64>>& v, std::vector<i64>& data, std::vector<i64>& off) {
+    off.push_back(0);
+    for (auto& x : v) {
+        data.insert(data.end(), x.begin(), x.end());
+        off.push_back((i64)data.size());
+    }
+}
+const int64_t* dpo_overlap_trace(void* hh, int64_t round, int field, int64_t* n) {
+    OverlapH* h = (OverlapH*)hh;
+    if (round < 0 || round >= (int64_t)h->res.traces.size()) {
+        *n = -1;
+        return nullptr;
+    }
+    auto key = std::make_pair(round, field);
+    auto it = h->cache.find(key);
+    if (it == h->cache.end()) {
+        const RoundTrace& t = h->res.traces[(size_t)round];
+        std::vector<i64> d, o;
+        int base = field >= 100 ? field - 100 : field;
+        switch (base) {
+            case 0: d = t.seedKmers; break;
+            case 1: d = t.queryIDs; break;
+            case 2: d = t.querySeqIDs; break;
+            case 3: d = t.indexedIds; break;
+            case 4: d = t.indexedLength; break;
+            case 5: d = t.indexedOffset; break;
+            case 6: d = t.indexedInset; break;
+            case 7: d = t.matchQueryIndex; break;
+            case 8: d = t.matchTarget; break;
+            case 9: d = t.newlyIgnored; break;
+            case 10: d = {t.firstSequence, t.numQuerySeqs, t.hits, t.qHits}; break;
+            case 20: flat(t.querySegments, d, o); break;
+            case 21: flat(t.indexedSegments, d, o); break;
+            case 22: {
+                std::vector<std::vector<i64>> c;
+                for (auto& x : t.candidates) c.emplace_back(x.begin(), x.end());
+                flat(c, d, o);
+                break;
+            }
+            case 23: flat(t.matchA, d, o); break;
+            case 24: flat(t.matchB, d, o); break;
+            default: *n = -1; return nullptr;
+        }
+        h->cache[std::make_pair(round, base)] = d;
+        h->cache[std::make_pair(round, base + 100)] = o;
+        it = h->cache.find(key);
+    }
+    *n = (int64_t)it->second.size();
+    return it->second.data();
+}
+const char* dpo_overlap_trace_paf(void* hh, int64_t round, int64_t* n) {
+    OverlapH* h = (OverlapH*)hh;
+    const std::string& s = h->res.traces[(size_t)round].paf;
+    *n = (int64_t)s.size();
+    return s.data();
+}
+
+// ---- map command -----------------------------------------------------------------------------
+struct MapH {
+    MapResult res;
+};
+// params: circular,k,querySize,minLength(unused here: applied when the read set was loaded),chunkSize,seedRate
+void* dpo_map_run(void* refSet, void* reads, const int64_t* params) {
+    MapH* h = new MapH();
+    int rc = guard([&] {
+        MapParams p;
+        p.circular = params[0] != 0;
+        p.k = (int)params[1];
+        p.querySize = params[2];
+        p.minLength = params[3];
+        p.chunkSize = params[4];
+        p.seedRate = params[5];
+        h->res = runMap(((ReadSetH*)refSet)->set, ((ReadSetH*)reads)->set, p);
+    });
+    if (rc != 0) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+void dpo_map_free(void* h) { delete (MapH*)h; }
+const char* dpo_map_paf(void* h, int64_t* n) {
+    *n = (int64_t)((MapH*)h)->res.paf.size();
+    return ((MapH*)h)->res.paf.data();
+}
+const char* dpo_map_err(void* h, int64_t* n) {
+    *n = (int64_t)((MapH*)h)->res.err.size();
+    return ((MapH*)h)->res.err.data();
+}
+
+}  // extern "C"
