@@ -1,0 +1,104 @@
+// Internal declarations shared by the translation units of libdownpore_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "downpore_hip.h"
+
+#define DP_WAVE 64
+
+// Growable device / pinned-host buffers owned by a context.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct dp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::string err;
+
+    // ---- reads (A1)
+    uint32_t n_reads = 0;
+    uint64_t total_bases = 0;
+    uint64_t packed_bytes = 0;  // incl. alignment padding, excl. tail pad
+    DevBuf d_packed;            // 2-bit packed reads, each read starting on a 16-byte boundary
+    DevBuf d_boff;              // uint64 byte offset of each read in d_packed  [n_reads+1]
+    DevBuf d_len;               // uint32 length in bases                      [n_reads]
+    std::vector<uint64_t> h_boff;
+    std::vector<uint32_t> h_len;
+
+    // ---- round state
+    int k = 0;
+    int table_k = 0;            // k the dense tables are currently sized/zeroed for
+    DevBuf d_bits;              // 4^k-bit membership table (uint32 words)
+    DevBuf d_kmap;              // int32 k-mer -> seed id
+    DevBuf d_seeds;             // uint32 seed k-mers of this round
+    uint32_t n_seeds = 0;
+    bool round_open = false;
+
+    // ---- scan (A2+A10)
+    DevBuf d_items, d_counts, d_segoff, d_segs, d_total;
+    PinBuf h_counts, h_segoff, h_segs, h_total;
+    uint64_t n_segs = 0;
+    uint32_t scan_items = 0;
+
+    // ---- index (A13)
+    uint32_t n_seqs = 0, W = 0, SW = 0;
+    DevBuf d_seqrefs, d_posting, d_seedsets, d_pmeta;  // pmeta: uint32 {count,start,end,lens} per seed
+
+    // ---- overlaps (A14..A8)
+    DevBuf d_qsegs, d_qoff, d_qsets, d_qmeta, d_cand, d_pool, d_mrec, d_ma, d_mb, d_cursor, d_sched;
+    PinBuf h_mrec, h_ma, h_mb, h_cursor, h_cand, h_cand_off, h_cand_list, h_mq, h_mt, h_moff;
+};
+
+int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess);
+int dev_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
+int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
+
+#define DP_HIP(call)                                                          \
+    do {                                                                      \
+        hipError_t _e = (call);                                               \
+        if (_e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, #call, _e);     \
+    } while (0)
+
+// kernels implemented in other translation units
+int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs);
+int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,
+                          uint32_t max_query_len, int want_candidates, dp_match_batch* out);
+int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, uint32_t nw, int k,
+                        dp_chain_batch* out);
+
+// ---- device helpers ---------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int dp_lane() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_incl_sum(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (dp_lane() >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_max(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (dp_lane() >= d) v = max(v, t);
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+#endif

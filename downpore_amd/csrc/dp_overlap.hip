@@ -1,0 +1,903 @@
+// libdownpore_hip.so — seed index build (A13), index query = soft-union of posting bitsets (A14 + A5), exact
+// intersection prefilter (A6) and overlap chaining with the per-query ratchet (A7 + A8).  CDNA4 / gfx950 only.
+//
+// HBM layout
+//   posting  : uint64 [n_seeds][W]      row s = set of indexed-sequence indices containing seed s  (W = ceil(M/64))
+//   seedsets : uint64 [M][SW]           row i = set of seeds of indexed sequence i                (SW = ceil(S/64))
+//   pmeta    : uint32 [n_seeds][4]      {popcount, first non-zero word, last non-zero word, last+1} — exactly the
+//                                       count/start/end an Add()-only util.IntSet carries (util/bitset.go:74-108);
+//                                       an untouched set keeps NewIntSet's start=1,end=0 (:20-23).
+//   cand     : uint64 [n_queries][W]    Matches() result as a bit mask (ascending bit order == ascending ids)
+// Index query kernel: one wave per query; lanes own consecutive word indices, so each posting row is read as one
+// coalesced 512-byte segment per wave step.  The counting ladder (util/asm_amd64.s:121-509) is held in registers.
+#include <algorithm>
+#include <cstring>
+
+#include "dp_common.h"
+
+typedef uint64_t u64;
+
+// ---------------------------------------------------------------------------------------------------------------
+// A13
+
+__global__ void index_fill_kernel(const dp_seq_ref* __restrict__ refs, uint32_t n_seqs, const int32_t* __restrict__ segs,
+                                  u64* __restrict__ posting, u64* __restrict__ seedsets, uint32_t W, uint32_t SW) {
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = dp_lane();
+    for (uint32_t idx = gw; idx < n_seqs; idx += waves) {
+        const dp_seq_ref r = refs[idx];
+        for (uint32_t i = lane; i < r.n_seeds; i += 64) {
+            uint32_t seed = (uint32_t)segs[r.seg_off + 2 * (uint64_t)i + 1];
+            atomicOr(&posting[(uint64_t)seed * W + (idx >> 6)], 1ull << (idx & 63));
+            atomicOr(&seedsets[(uint64_t)idx * SW + (seed >> 6)], 1ull << (seed & 63));
+        }
+    }
+}
+
+__global__ void posting_meta_kernel(const u64* __restrict__ posting, uint32_t n_seeds, uint32_t W, uint32_t* __restrict__ pmeta) {
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = dp_lane();
+    for (uint32_t s = gw; s < n_seeds; s += waves) {
+        int cnt = 0, first = 0x7fffffff, last = -1;
+        for (uint32_t w = lane; w < W; w += 64) {
+            u64 v = posting[(uint64_t)s * W + w];
+            if (v) {
+                cnt += __popcll(v);
+                first = min(first, (int)w);
+                last = max(last, (int)w);
+            }
+        }
+        cnt = wave_sum(cnt);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            first = min(first, __shfl_xor(first, d, 64));
+            last = max(last, __shfl_xor(last, d, 64));
+        }
+        if (lane == 0) {
+            uint32_t st = 1, en = 0;  // NewIntSet(): start 1, end 0
+            if (last >= 0) {
+                st = (uint32_t)first;
+                en = (uint32_t)last;
+            }
+            pmeta[4 * s + 0] = (uint32_t)cnt;
+            pmeta[4 * s + 1] = st;
+            pmeta[4 * s + 2] = en;
+            pmeta[4 * s + 3] = en + 1;
+        }
+    }
+}
+
+int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
+    if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_index_build before dp_round_begin");
+    hipSetDevice(ctx->device);
+    for (uint32_t i = 0; i < n_seqs; i++)
+        if (seqs[i].seg_off + 2ull * seqs[i].n_seeds + 1 > ctx->n_segs)
+            return dp_fail(ctx, DP_ERR_ARG, "dp_index_build: sequence view outside the scan output");
+    const uint32_t S = ctx->n_seeds;
+    const uint32_t W = std::max<uint32_t>(1, (n_seqs + 63) / 64), SW = std::max<uint32_t>(1, (S + 63) / 64);
+    ctx->n_seqs = n_seqs;
+    ctx->W = W;
+    ctx->SW = SW;
+    if (dev_reserve(ctx, ctx->d_seqrefs, (size_t)n_seqs * sizeof(dp_seq_ref) + 16)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_posting, (size_t)S * W * 8 + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_seedsets, (size_t)n_seqs * SW * 8 + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_pmeta, (size_t)S * 16 + 16)) return DP_ERR_HIP;
+    DP_HIP(hipMemsetAsync(ctx->d_posting.p, 0, (size_t)S * W * 8 + 64, ctx->stream));
+    DP_HIP(hipMemsetAsync(ctx->d_seedsets.p, 0, (size_t)n_seqs * SW * 8 + 64, ctx->stream));
+    if (n_seqs) {
+        DP_HIP(hipMemcpyAsync(ctx->d_seqrefs.p, seqs, (size_t)n_seqs * sizeof(dp_seq_ref), hipMemcpyHostToDevice, ctx->stream));
+        uint32_t blocks = std::min<uint32_t>(2048, (n_seqs + 3) / 4);
+        hipLaunchKernelGGL(index_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const dp_seq_ref*)ctx->d_seqrefs.p, n_seqs,
+                           (const int32_t*)ctx->d_segs.p, (u64*)ctx->d_posting.p, (u64*)ctx->d_seedsets.p, W, SW);
+        DP_HIP(hipGetLastError());
+    }
+    if (S) {
+        uint32_t blocks = std::min<uint32_t>(2048, (S + 3) / 4);
+        hipLaunchKernelGGL(posting_meta_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const u64*)ctx->d_posting.p, S, W,
+                           (uint32_t*)ctx->d_pmeta.p);
+        DP_HIP(hipGetLastError());
+    }
+    DP_HIP(hipStreamSynchronize(ctx->stream));  // seqs is borrowed only for the duration of the call
+    return DP_OK;
+}
+
+extern "C" int dp_index_build(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
+    if (!ctx || (n_seqs && !seqs)) return DP_ERR_ARG;
+    return dp_index_build_impl(ctx, seqs, n_seqs);
+}
+
+extern "C" int dp_index_posting_row(dp_ctx* ctx, uint32_t seed, u64* words, uint32_t cap_words, uint32_t* n_words,
+                                    uint32_t* count, uint32_t* start, uint32_t* end) {
+    if (!ctx || seed >= ctx->n_seeds || cap_words < ctx->W) return DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    uint32_t meta[4];
+    DP_HIP(hipMemcpy(words, (u64*)ctx->d_posting.p + (uint64_t)seed * ctx->W, (size_t)ctx->W * 8, hipMemcpyDeviceToHost));
+    DP_HIP(hipMemcpy(meta, (uint32_t*)ctx->d_pmeta.p + 4 * (size_t)seed, 16, hipMemcpyDeviceToHost));
+    if (n_words) *n_words = ctx->W;
+    if (count) *count = meta[0];
+    if (start) *start = meta[1];
+    if (end) *end = meta[2];
+    return DP_OK;
+}
+extern "C" int dp_index_seedset_row(dp_ctx* ctx, uint32_t seq, u64* words, uint32_t cap_words, uint32_t* n_words) {
+    if (!ctx || seq >= ctx->n_seqs || cap_words < ctx->SW) return DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    DP_HIP(hipMemcpy(words, (u64*)ctx->d_seedsets.p + (uint64_t)seq * ctx->SW, (size_t)ctx->SW * 8, hipMemcpyDeviceToHost));
+    if (n_words) *n_words = ctx->SW;
+    return DP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// queries: seed bitsets of the queries (matchWorker's seedSet, overlap/overlap.go:351-354)
+
+__global__ void qsets_kernel(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff, uint32_t nq,
+                             u64* __restrict__ qsets, uint32_t SW) {
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = dp_lane();
+    for (uint32_t q = gw; q < nq; q += waves) {
+        uint32_t ns = (uint32_t)((qoff[q + 1] - qoff[q]) / 2);
+        for (uint32_t i = lane; i < ns; i += 64) {
+            uint32_t seed = (uint32_t)qsegs[qoff[q] + 2 * (uint64_t)i + 1];
+            atomicOr(&qsets[(uint64_t)q * SW + (seed >> 6)], 1ull << (seed & 63));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A14 + A5: SeedIndex.Matches -> util.GetSharedIDs
+
+#define Q_MAXSETS 512
+#define Q_WAVES 4
+
+struct QWave {
+    uint32_t setid[Q_MAXSETS];
+    uint32_t lens[Q_MAXSETS];
+    uint32_t tmp_id[Q_MAXSETS];   // working copy for the order simulation
+    uint32_t tmp_len[Q_MAXSETS];
+    uint32_t ev_word[Q_MAXSETS + 2];
+    uint16_t ev_first8[Q_MAXSETS + 2][8];
+    uint32_t n_ev;
+};
+
+// qmeta per query: {n_sets, minCount, status}; status bit0 = too many sets
+__global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
+                                                             uint32_t nq, const u64* __restrict__ posting,
+                                                             const uint32_t* __restrict__ pmeta, uint32_t n_seqs, uint32_t W,
+                                                             const int32_t* __restrict__ mc, uint32_t mc_n,
+                                                             u64* __restrict__ cand, uint32_t* __restrict__ qmeta,
+                                                             u64* __restrict__ words_read) {
+    __shared__ QWave sh[Q_WAVES];
+    QWave& S = sh[threadIdx.x >> 6];
+    const int lane = dp_lane();
+    const uint32_t q = blockIdx.x * Q_WAVES + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int32_t* seg = qsegs + qoff[q];
+    const uint32_t ns = (uint32_t)((qoff[q + 1] - qoff[q]) / 2);
+
+    // --- Matches(): filtered list of posting sets (seeds/seeds.go:336-347); sequential in the accepted-seed chain
+    uint32_t n = 0, start = 0xffffffffu, end = 0, status = 0;
+    if (lane == 0) {
+        int32_t prevSeed = -1;
+        for (uint32_t i = 0; i < ns; i++) {
+            int32_t seed = seg[2 * i + 1];
+            if (seed != prevSeed && pmeta[4 * (uint32_t)seed] < n_seqs) {
+                if (n < Q_MAXSETS) {
+                    S.setid[n] = (uint32_t)seed;
+                    S.lens[n] = pmeta[4 * (uint32_t)seed + 3];
+                    start = min(start, pmeta[4 * (uint32_t)seed + 1]);
+                    end = max(end, pmeta[4 * (uint32_t)seed + 2]);
+                    n++;
+                } else {
+                    status |= 1;
+                }
+                prevSeed = seed;
+            }
+        }
+    }
+    n = __shfl(n, 0, 64);
+    start = __shfl(start, 0, 64);
+    end = __shfl(end, 0, 64);
+    status = __shfl(status, 0, 64);
+    int minCount = 0;
+    if (n >= 5 && n < mc_n) minCount = mc[n];
+    if (lane == 0) {
+        qmeta[4 * q + 0] = n;
+        qmeta[4 * q + 1] = (uint32_t)minCount;
+        qmeta[4 * q + 2] = status | (n >= mc_n ? 2u : 0u);
+        qmeta[4 * q + 3] = ns;
+    }
+    if (n < 5 || status || n >= mc_n) return;  // cand row stays zero
+    __builtin_amdgcn_wave_barrier();
+
+    // --- early return of GetSharedIDs (util/bitset.go:335-342): the (n-minCount+1)-th drop ends the scan
+    //     before its word is gathered.  d-th drop happens at word max(start, d-th smallest lens).
+    int64_t i_last = end;  // last word index that is processed
+    {
+        const int dstar = (int)n - minCount + 1;  // >= 1
+        // d-th smallest of lens: rank selection with all lanes
+        uint32_t cutLens = 0xffffffffu;
+        for (uint32_t j = lane; j < n; j += 64) {
+            uint32_t lj = S.lens[j];
+            int less = 0, eq_before = 0;
+            for (uint32_t t = 0; t < n; t++) {
+                uint32_t lt = S.lens[t];
+                less += lt < lj;
+                eq_before += (lt == lj) && (t < j);
+            }
+            if (less + eq_before == dstar - 1) cutLens = lj;  // this element has rank dstar (1-based)
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) cutLens = min(cutLens, (uint32_t)__shfl_xor((int)cutLens, d, 64));
+        if (cutLens != 0xffffffffu) {
+            int64_t icut = max((int64_t)start, (int64_t)cutLens);
+            if (icut - 1 < i_last) i_last = icut - 1;
+        }
+    }
+
+    // --- for the 16-ladder the order of the gathered words matters (8th word never reaches v1): simulate the
+    //     swap-removals of util/bitset.go:333-353 and record the first eight sets after every event.
+    const bool ladder16 = minCount >= 13;
+    if (ladder16) {
+        if (lane == 0) {
+            uint32_t cn = n;
+            for (uint32_t j = 0; j < n; j++) {
+                S.tmp_id[j] = j;
+                S.tmp_len[j] = S.lens[j];
+            }
+            uint32_t shortest = 0xffffffffu;
+            for (uint32_t j = 0; j < n; j++) shortest = min(shortest, S.tmp_len[j]);
+            uint32_t nev = 0;
+            // entry 0: order valid from `start` (after the drops performed at i == start, if any)
+            int64_t i = start;
+            bool first = true;
+            while (i <= i_last) {
+                if (shortest <= (uint32_t)i) {
+                    uint32_t nextShortest = end;
+                    for (uint32_t j = 0; j < cn; j++) {
+                        if (S.tmp_len[j] <= (uint32_t)i) {
+                            uint32_t last = cn - 1;
+                            S.tmp_id[j] = S.tmp_id[last];
+                            S.tmp_len[j] = S.tmp_len[last];
+                            cn = last;
+                            j--;
+                        } else if (S.tmp_len[j] < nextShortest) {
+                            nextShortest = S.tmp_len[j];
+                        }
+                    }
+                    shortest = nextShortest;
+                    first = true;
+                }
+                if (first) {
+                    S.ev_word[nev] = (uint32_t)i;
+                    for (int t = 0; t < 8; t++) S.ev_first8[nev][t] = (uint16_t)S.tmp_id[t];
+                    nev++;
+                    first = false;
+                }
+                // jump to the next word at which something is dropped
+                int64_t nxt = (int64_t)shortest;
+                if (nxt <= i) nxt = i + 1;
+                i = nxt;
+            }
+            S.n_ev = nev;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t n_ev = ladder16 ? S.n_ev : 0;
+    const bool exact = minCount > 24;  // fast=false (util/bitset.go:309-311)
+
+    u64 gathered = 0;
+    for (int64_t ib = start; ib <= i_last; ib += 64) {
+        const int64_t i = ib + lane;
+        if (i > i_last) continue;
+        const uint32_t iw = (uint32_t)i;
+        u64 v = 0;
+        if (!ladder16) {
+            // 4- and 8-ladders (asm:121-314) are order independent: v_t = bits present in >= t of the live sets
+            u64 l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0, l8 = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                if (S.lens[j] <= iw) continue;
+                u64 m = posting[(uint64_t)S.setid[j] * W + iw];
+                gathered++;
+                l8 |= l7 & m;
+                l7 |= l6 & m;
+                l6 |= l5 & m;
+                l5 |= l4 & m;
+                l4 |= l3 & m;
+                l3 |= l2 & m;
+                l2 |= l1 & m;
+                l1 |= m;
+            }
+            switch (minCount) {
+                case 0:
+                case 1: v = l1; break;
+                case 2: v = l2; break;
+                case 3: v = l3; break;
+                case 4: v = l4; break;
+                case 5: v = l5; break;
+                case 6: v = l6; break;
+                case 7: v = l7; break;
+                default: v = l8; break;  // 8, and 9..12 saturate at 8 (bitset.go:369-372)
+            }
+        } else {
+            // 16-ladder (asm:317-509) in the exact gather order
+            uint32_t t = 0;
+            while (t + 1 < n_ev && S.ev_word[t + 1] <= iw) t++;
+            u64 L[17];
+#pragma unroll
+            for (int x = 0; x < 17; x++) L[x] = 0;
+            u64 inFirst8[Q_MAXSETS / 64];
+#pragma unroll
+            for (int x = 0; x < Q_MAXSETS / 64; x++) inFirst8[x] = 0;
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                uint32_t j = S.ev_first8[t][p];
+                inFirst8[j >> 6] |= 1ull << (j & 63);
+                u64 m = posting[(uint64_t)S.setid[j] * W + iw];
+                gathered++;
+#pragma unroll
+                for (int x = 16; x >= 2; x--) L[x] |= L[x - 1] & m;
+                if (p != 7) L[1] |= m;  // step 8 omits "ORQ DX, R8" (asm:407-428)
+            }
+            u64 planes[8];
+#pragma unroll
+            for (int x = 0; x < 8; x++) planes[x] = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                if (S.lens[j] <= iw) continue;
+                if ((inFirst8[j >> 6] >> (j & 63)) & 1) continue;
+                u64 m = posting[(uint64_t)S.setid[j] * W + iw];
+                gathered++;
+#pragma unroll
+                for (int x = 16; x >= 2; x--) L[x] |= L[x - 1] & m;
+                L[1] |= m;
+            }
+            v = minCount >= 16 ? L[16] : minCount == 15 ? L[15] : minCount == 14 ? L[14] : L[13];
+            if (exact && v) {
+                // addSoftUnionIDs (bitset.go:509-538): keep a bit only if its true count over the live sets
+                // reaches minCount.  Bit-sliced counter, 8 planes.
+                for (uint32_t j = 0; j < n; j++) {
+                    if (S.lens[j] <= iw) continue;
+                    u64 c = posting[(uint64_t)S.setid[j] * W + iw];
+#pragma unroll
+                    for (int x = 0; x < 8; x++) {
+                        u64 nc = planes[x] & c;
+                        planes[x] ^= c;
+                        c = nc;
+                    }
+                }
+                // ge = (count >= minCount), most significant plane first
+                u64 gt = 0, eq = ~0ull;
+#pragma unroll
+                for (int x = 7; x >= 0; x--) {
+                    u64 bit = ((minCount >> x) & 1) ? ~0ull : 0ull;
+                    gt |= eq & planes[x] & ~bit;
+                    eq &= ~(planes[x] ^ bit);
+                }
+                v &= (gt | eq);
+            }
+        }
+        cand[(uint64_t)q * W + iw] = v;
+    }
+    gathered = (u64)wave_sum((int)gathered);
+    if (lane == 0) words_read[q] = gathered;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A6 + A7 + A8: matchWorker body
+
+#define C_WAVES 4
+#define C_OPEN 500       // len(align.open)          seeds/alignment.go:299
+#define C_RESULTS 500    // len(align.results)
+#define C_POOLSTATES 10000
+#define C_NODES (1u << 16)
+
+struct CNode {  // one link of a chain (pairState.prev history), written once
+    uint16_t a, b;
+    int32_t prev;
+};
+
+struct CWave {
+    int32_t aRed[512];
+    int32_t aMap[256];
+    int32_t o_aPos[C_OPEN], o_bPos[C_OPEN], o_aGap[C_OPEN], o_bGap[C_OPEN], o_aGapIndex[C_OPEN], o_len[C_OPEN], o_node[C_OPEN];
+};
+
+__device__ __forceinline__ bool bs_contains(const u64* __restrict__ set, int32_t x) { return (set[x >> 6] >> (x & 63)) & 1ull; }
+
+__device__ __forceinline__ void gap_range(int gap, int k, int& mn, int& mx) {  // seeds/alignment.go:411-424
+    mn = (gap * 2) / 3 - k;
+    mx = (gap * 3) / 2 + k + 1;
+    if (mn < 0) {
+        mn = -k;
+        if (mx < 0) mx = 0;
+    } else if (mx < 20) {
+        mx = 20;
+        mn = 0;
+    }
+}
+
+// seedAligner.PairwiseAlignments (seeds/alignment.go:426-616), executed by ONE lane.  Returns the length of
+// results[0] (the chain matchWorker keeps, overlap/overlap.go:368-375) or 0; *resNode = its last node.
+// err: 1 reduced buffer overflow, 2 state pool, 4 results overflow, 8 node pool
+__device__ int pairwise_align(const int32_t* __restrict__ aSeg, int aN, const int32_t* __restrict__ bSeg, int bN,
+                              const u64* __restrict__ aSet, const u64* __restrict__ bSet, int minMatches, int k, int maxLength,
+                              CWave& L, CNode* __restrict__ nodes, int* resNode, uint32_t* err) {
+    if (minMatches == 0) minMatches = 1;
+    int nNodes = 0;
+    int live = 0;
+    // prepareInitial :341-388
+    int maxAIndex = aN - minMatches * 2 + 1;
+    int aLen = 0, offset = -k, startSize = 0, prevSeedA = -1;
+    for (int i = 1; i < aN; i += 2) {
+        int aSeed = aSeg[i];
+        if (!bs_contains(bSet, aSeed)) {
+            offset += aSeg[i - 1] + k;
+            maxAIndex--;
+            continue;
+        }
+        if (aSeed == prevSeedA && (i >= aN - 2 || aSeg[i + 2] == prevSeedA)) {
+            offset += aSeg[i - 1] + k;
+            maxAIndex--;
+            continue;
+        }
+        prevSeedA = aSeed;
+        offset += aSeg[i - 1] + k;
+        if (aLen * 2 + 1 >= maxLength || aLen >= maxLength / 2 || aLen * 2 + 2 >= 512) {
+            *err |= 1;
+            return 0;
+        }
+        L.aRed[aLen * 2] = offset;
+        L.aRed[aLen * 2 + 1] = aSeed;
+        L.aMap[aLen] = i / 2;
+        offset = -k;
+        if (aLen <= maxAIndex) {
+            startSize++;
+            live++;
+        }
+        aLen++;
+    }
+    if (aLen * 2 >= maxLength) {
+        *err |= 1;
+        return 0;
+    }
+    L.aRed[aLen * 2] = 0;
+    while (startSize > 0 && (2 * (startSize - 1) + 1) > maxAIndex) {
+        startSize--;
+        live--;
+    }
+    const int initialSize = startSize;
+    const int aRedLen = aLen * 2 + 1;
+    int openSize = 0, resultsSize = 0, firstLen = 0, firstNode = -1;
+
+#define REMOVE_OPEN(i_)                                                            \
+    {                                                                              \
+        int sl_ = L.o_len[i_], sn_ = L.o_node[i_];                                 \
+        int last_ = openSize - 1;                                                  \
+        L.o_aPos[i_] = L.o_aPos[last_];                                            \
+        L.o_bPos[i_] = L.o_bPos[last_];                                            \
+        L.o_aGap[i_] = L.o_aGap[last_];                                            \
+        L.o_bGap[i_] = L.o_bGap[last_];                                            \
+        L.o_aGapIndex[i_] = L.o_aGapIndex[last_];                                  \
+        L.o_len[i_] = L.o_len[last_];                                              \
+        L.o_node[i_] = L.o_node[last_];                                            \
+        openSize--;                                                                \
+        if (sl_ >= minMatches) {                                                   \
+            if ((sl_ * 2) / 3 > minMatches) minMatches = (sl_ * 2) / 3;            \
+            if (resultsSize >= C_RESULTS) {                                        \
+                *err |= 4;                                                         \
+                return 0;                                                          \
+            }                                                                      \
+            if (resultsSize == 0) {                                                \
+                firstLen = sl_;                                                    \
+                firstNode = sn_;                                                   \
+            }                                                                      \
+            resultsSize++;                                                         \
+        } else {                                                                   \
+            live -= sl_;                                                           \
+        }                                                                          \
+    }
+
+    int maxBIndex = bN - minMatches * 2 + 1;
+    int bOffset = 0, prevSeed = -1;
+    for (int bIndex = 1; bIndex < bN; bIndex += 2) {
+        const int bSeed = bSeg[bIndex];
+        if (!bs_contains(aSet, bSeed)) {
+            bOffset += bSeg[bIndex + 1] + k;
+            continue;
+        }
+        if (bSeed == prevSeed && (bIndex >= bN - 2 || bSeg[bIndex + 2] == prevSeed)) {
+            bOffset += bSeg[bIndex + 1] + k;
+            continue;
+        }
+        prevSeed = bSeed;
+        int found = -1;
+        for (int i = openSize - 1; i >= 0; i--) {  // searchMatch :465-547
+            int bGap = L.o_bGap[i] + bOffset;
+            L.o_bGap[i] = bGap;
+            int minGap, maxGap;
+            gap_range(bGap, k, minGap, maxGap);
+            int aGap = L.o_aGap[i], aGapIndex = L.o_aGapIndex[i];
+            bool ended = false;
+            while (aGap < minGap) {
+                if (aGapIndex >= aRedLen) {
+                    ended = true;
+                    break;
+                }
+                aGap += L.aRed[aGapIndex + 1] + k;
+                aGapIndex += 2;
+            }
+            L.o_aGap[i] = aGap;
+            L.o_aGapIndex[i] = aGapIndex;
+            if (ended) {
+                REMOVE_OPEN(i);
+                break;
+            }
+            bool extended = false;
+            if (aGap <= maxGap) {
+                int g = aGap;
+                for (int j = aGapIndex; j < aRedLen && g <= maxGap; j += 2) {
+                    if (L.aRed[j] == bSeed) {
+                        found = j;
+                        if (nNodes >= (int)C_NODES) {
+                            *err |= 8;
+                            return 0;
+                        }
+                        if (++live > C_POOLSTATES) {
+                            *err |= 2;
+                            return 0;
+                        }
+                        CNode nd;
+                        nd.a = (uint16_t)L.aMap[j / 2];
+                        nd.b = (uint16_t)(bIndex / 2);
+                        nd.prev = L.o_node[i];
+                        nodes[nNodes] = nd;
+                        const int nl = L.o_len[i] + 1;
+                        L.o_aPos[i] = j;
+                        L.o_bPos[i] = bIndex;
+                        L.o_aGapIndex[i] = j + 2;
+                        L.o_aGap[i] = L.aRed[j + 1];
+                        L.o_bGap[i] = bSeg[bIndex + 1];
+                        L.o_len[i] = nl;
+                        L.o_node[i] = nNodes++;
+                        if ((nl * 2) / 3 > minMatches) {
+                            minMatches = (nl * 2) / 3;
+                            maxBIndex = bN - minMatches * 2 + 1;
+                        }
+                        extended = true;
+                        break;
+                    }
+                    g += L.aRed[j + 1] + k;
+                }
+            }
+            if (extended) break;
+            if (L.o_len[i] + (bN - bIndex) < minMatches) {
+                REMOVE_OPEN(i);
+            } else {
+                L.o_bGap[i] += bSeg[bIndex + 1] + k;
+            }
+        }
+        bOffset = 0;
+        if (bIndex <= maxBIndex) {  // :550-587
+            for (int i = 0; i < initialSize; i++) {
+                const int aPos = 2 * i + 1;
+                if (aPos != found && L.aRed[aPos] == bSeed) {
+                    if (found != -1) {
+                        for (int j = 0; j < openSize; j++) {
+                            if (L.o_bPos[j] == bIndex && L.o_aPos[j] == aPos) {
+                                found = aPos;
+                                break;
+                            }
+                        }
+                    }
+                    if (found == aPos || openSize >= C_OPEN) continue;
+                    if (nNodes >= (int)C_NODES) {
+                        *err |= 8;
+                        return 0;
+                    }
+                    if (++live > C_POOLSTATES) {
+                        *err |= 2;
+                        return 0;
+                    }
+                    CNode nd;
+                    nd.a = (uint16_t)L.aMap[i];
+                    nd.b = (uint16_t)(bIndex / 2);
+                    nd.prev = -1;
+                    nodes[nNodes] = nd;
+                    L.o_aPos[openSize] = aPos;
+                    L.o_bPos[openSize] = bIndex;
+                    L.o_aGapIndex[openSize] = aPos + 2;
+                    L.o_aGap[openSize] = L.aRed[aPos + 1];
+                    L.o_bGap[openSize] = bSeg[bIndex + 1];
+                    L.o_len[openSize] = 1;
+                    L.o_node[openSize] = nNodes++;
+                    openSize++;
+                }
+            }
+        }
+    }
+    for (int i = 0; i < openSize; i++) {  // :597-604
+        if (L.o_len[i] >= minMatches) {
+            if (resultsSize >= C_RESULTS) {
+                *err |= 4;
+                return 0;
+            }
+            if (resultsSize == 0) {
+                firstLen = L.o_len[i];
+                firstNode = L.o_node[i];
+            }
+            resultsSize++;
+        }
+    }
+#undef REMOVE_OPEN
+    *resNode = firstNode;
+    return resultsSize ? firstLen : 0;
+}
+
+struct MRec {
+    uint32_t q, t;
+    uint32_t off, len;
+};
+
+// cursor: [0] records, [1] ints, [2] error bits, [3] overflow flag
+__global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
+                                                             uint32_t nq, const u64* __restrict__ qsets,
+                                                             const uint32_t* __restrict__ qmeta, const u64* __restrict__ cand,
+                                                             const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs,
+                                                             const u64* __restrict__ seedsets, uint32_t W, uint32_t SW,
+                                                             const int32_t* __restrict__ mc, uint32_t mc_n, int k, int maxLength,
+                                                             CNode* __restrict__ pool, MRec* __restrict__ recs, uint32_t rec_cap,
+                                                             int32_t* __restrict__ ma, int32_t* __restrict__ mb, uint32_t int_cap,
+                                                             uint32_t* __restrict__ cursor) {
+    __shared__ CWave sh[C_WAVES];
+    CWave& L = sh[threadIdx.x >> 6];
+    const int lane = dp_lane();
+    const uint32_t waves = gridDim.x * C_WAVES;
+    const uint32_t gw = blockIdx.x * C_WAVES + (threadIdx.x >> 6);
+    CNode* nodes = pool + (uint64_t)gw * C_NODES;
+    for (uint32_t q = gw; q < nq; q += waves) {
+        const uint32_t nsets = qmeta[4 * q + 0];
+        if (nsets < 5 || qmeta[4 * q + 2]) continue;
+        const int32_t* aSeg = qsegs + qoff[q];
+        const int aN = (int)(qoff[q + 1] - qoff[q]);
+        const uint32_t nSeeds = (uint32_t)aN / 2;
+        const u64* qset = qsets + (uint64_t)q * SW;
+        int minMatches = nSeeds < mc_n ? mc[nSeeds] : 0x7fffffff;  // int(hitFraction*numSeeds+0.5), overlap.go:356
+        for (uint32_t wi = 0; wi < W; wi++) {
+            u64 mask = cand[(uint64_t)q * W + wi];
+            while (mask) {
+                const int b = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const uint32_t t = wi * 64 + (uint32_t)b;
+                const u64* tset = seedsets + (uint64_t)t * SW;
+                // CountIntersectionTo(seedSet, minMatches) < minMatches  (overlap.go:359; the asm's early exit only
+                // ever returns a value >= maxCount, so the comparison equals the one on the full popcount)
+                int c = 0;
+                for (uint32_t w = lane; w < SW; w += 64) c += __popcll(tset[w] & qset[w]);
+                c = wave_sum(c);
+                if (c < minMatches) continue;
+                const dp_seq_ref r = refs[t];
+                int resLen = 0, resNode = -1;
+                uint32_t err = 0;
+                if (lane == 0)
+                    resLen = pairwise_align(aSeg, aN, segs + r.seg_off, (int)(2 * r.n_seeds + 1), qset, tset, minMatches, k,
+                                            maxLength, L, nodes, &resNode, &err);
+                resLen = __shfl(resLen, 0, 64);
+                if (lane == 0 && err) atomicOr(&cursor[2], err);
+                if (resLen > 0) {
+                    if (lane == 0) {
+                        uint32_t ri = atomicAdd(&cursor[0], 1u);
+                        uint32_t off = atomicAdd(&cursor[1], (uint32_t)resLen);
+                        if (ri < rec_cap && off + (uint32_t)resLen <= int_cap) {
+                            MRec rec = {q, t, off, (uint32_t)resLen};
+                            recs[ri] = rec;
+                            int node = resNode;
+                            for (int x = resLen - 1; x >= 0 && node >= 0; x--) {  // extractMatch :326-335
+                                CNode nd = nodes[node];
+                                ma[off + x] = nd.a;
+                                mb[off + x] = nd.b;
+                                node = nd.prev;
+                            }
+                        } else {
+                            cursor[3] = 1;
+                        }
+                    }
+                    if (resLen * 2 > minMatches * 3) minMatches = (resLen * 2) / 3;  // ratchet, overlap.go:380-382
+                }
+            }
+        }
+    }
+}
+
+int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,
+                          uint32_t max_query_len, int want_candidates, dp_match_batch* out) {
+    if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_find_overlaps before dp_round_begin");
+    hipSetDevice(ctx->device);
+    memset(out, 0, sizeof(*out));
+    out->n_queries = nq;
+    const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
+    const uint64_t nseg = nq ? q_off[nq] : 0;
+    if (pin_reserve(ctx, ctx->h_cursor, 64)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_cand_off, ((size_t)nq + 1) * 8)) return DP_ERR_HIP;
+    ((uint64_t*)ctx->h_cand_off.p)[0] = 0;
+    out->cand_off = (const uint64_t*)ctx->h_cand_off.p;
+    if (pin_reserve(ctx, ctx->h_moff, 16)) return DP_ERR_HIP;
+    ((uint64_t*)ctx->h_moff.p)[0] = 0;
+    out->off = (const uint64_t*)ctx->h_moff.p;
+    if (nq == 0 || M == 0) {
+        for (uint32_t q = 0; q <= nq; q++) ((uint64_t*)ctx->h_cand_off.p)[q] = 0;
+        return DP_OK;
+    }
+    // int(hitFraction*float64(n)+0.5) for every n that can occur (seeds/seeds.go:351, overlap/overlap.go:356);
+    // evaluated on the host in IEEE double (this file is built with -ffp-contract=off)
+    uint32_t maxSeeds = 0;
+    for (uint32_t q = 0; q < nq; q++) maxSeeds = std::max<uint32_t>(maxSeeds, (uint32_t)((q_off[q + 1] - q_off[q]) / 2));
+    const uint32_t mc_n = std::max<uint32_t>(maxSeeds + 1, 8);
+    std::vector<int32_t> mc(mc_n);
+    for (uint32_t n = 0; n < mc_n; n++) {
+        volatile double prod = hf * (double)n;
+        volatile double sum = prod + 0.5;
+        mc[n] = (int32_t)sum;
+    }
+    if (dev_reserve(ctx, ctx->d_qsegs, nseg * 4 + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_qoff, ((size_t)nq + 1) * 8)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_qsets, (size_t)nq * SW * 8 + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_qmeta, (size_t)nq * 16 + (size_t)nq * 8 + (size_t)mc_n * 4 + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_cand, (size_t)nq * W * 8 + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_cursor, 64)) return DP_ERR_HIP;
+    uint32_t* d_qmeta = (uint32_t*)ctx->d_qmeta.p;
+    u64* d_words = (u64*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 16);
+    int32_t* d_mc = (int32_t*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 16 + (size_t)nq * 8);
+    DP_HIP(hipMemcpyAsync(ctx->d_qsegs.p, q_segs, nseg * 4, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->d_qoff.p, q_off, ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(d_mc, mc.data(), (size_t)mc_n * 4, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemsetAsync(ctx->d_qsets.p, 0, (size_t)nq * SW * 8, ctx->stream));
+    DP_HIP(hipMemsetAsync(ctx->d_cand.p, 0, (size_t)nq * W * 8, ctx->stream));
+    DP_HIP(hipMemsetAsync(d_qmeta, 0, (size_t)nq * 16 + (size_t)nq * 8, ctx->stream));
+    hipLaunchKernelGGL(qsets_kernel, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), 0, ctx->stream,
+                       (const int32_t*)ctx->d_qsegs.p, (const u64*)ctx->d_qoff.p, nq, (u64*)ctx->d_qsets.p, SW);
+    DP_HIP(hipGetLastError());
+    DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    hipLaunchKernelGGL(query_kernel, dim3((nq + Q_WAVES - 1) / Q_WAVES), dim3(64 * Q_WAVES), 0, ctx->stream,
+                       (const int32_t*)ctx->d_qsegs.p, (const u64*)ctx->d_qoff.p, nq, (const u64*)ctx->d_posting.p,
+                       (const uint32_t*)ctx->d_pmeta.p, M, W, (const int32_t*)d_mc, mc_n, (u64*)ctx->d_cand.p, d_qmeta, d_words);
+    DP_HIP(hipGetLastError());
+    DP_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+
+    // chaining; output buffers grow and the kernel re-runs if they overflow (deterministic)
+    const uint32_t chain_blocks = std::min<uint32_t>(512, (nq + C_WAVES - 1) / C_WAVES);
+    if (dev_reserve(ctx, ctx->d_pool, (size_t)chain_blocks * C_WAVES * C_NODES * sizeof(CNode))) return DP_ERR_HIP;
+    uint32_t rec_cap = std::max<uint32_t>(1u << 16, (uint32_t)(ctx->d_mrec.cap / sizeof(MRec)));
+    uint32_t int_cap = std::max<uint32_t>(1u << 21, (uint32_t)(ctx->d_ma.cap / 4));
+    uint32_t cur[16];
+    float chain_ms = 0;
+    for (;;) {
+        if (dev_reserve(ctx, ctx->d_mrec, (size_t)rec_cap * sizeof(MRec))) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_ma, (size_t)int_cap * 4)) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_mb, (size_t)int_cap * 4)) return DP_ERR_HIP;
+        DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 64, ctx->stream));
+        DP_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
+        hipLaunchKernelGGL(chain_kernel, dim3(chain_blocks), dim3(64 * C_WAVES), 0, ctx->stream, (const int32_t*)ctx->d_qsegs.p,
+                           (const u64*)ctx->d_qoff.p, nq, (const u64*)ctx->d_qsets.p, (const uint32_t*)d_qmeta,
+                           (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p,
+                           (const u64*)ctx->d_seedsets.p, W, SW, (const int32_t*)d_mc, mc_n, k, (int)max_query_len,
+                           (CNode*)ctx->d_pool.p, (MRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p,
+                           int_cap, (uint32_t*)ctx->d_cursor.p);
+        DP_HIP(hipGetLastError());
+        DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+        DP_HIP(hipMemcpyAsync(cur, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipStreamSynchronize(ctx->stream));
+        float ms = 0;
+        hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]);
+        chain_ms += ms;
+        if (cur[3] || cur[0] > rec_cap || cur[1] > int_cap) {
+            rec_cap = std::max(rec_cap * 2, cur[0] + 1024);
+            int_cap = std::max(int_cap * 2, cur[1] + 1024);
+            continue;
+        }
+        break;
+    }
+    float qms = 0;
+    hipEventElapsedTime(&qms, ctx->ev[4], ctx->ev[5]);
+    out->query_kernel_ms = qms;
+    out->chain_kernel_ms = chain_ms;
+    if (cur[2]) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "overlap chaining hit a reference capacity limit (bits %u: 1 reduced buffer, 2 state pool, 4 results, 8 nodes)", cur[2]);
+        return dp_fail(ctx, DP_ERR_CAPACITY, msg);
+    }
+    // fetch + canonical order: queries ascending, targets ascending (each query was walked by one wave in order)
+    const uint32_t nm = cur[0], ni = cur[1];
+    if (pin_reserve(ctx, ctx->h_mrec, (size_t)nm * sizeof(MRec) + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_ma, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_mb, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_mq, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_mt, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_moff, ((size_t)nm + 1) * 8)) return DP_ERR_HIP;
+    std::vector<uint32_t> qm((size_t)nq * 4);
+    std::vector<u64> words(nq);
+    DP_HIP(hipMemcpyAsync(qm.data(), d_qmeta, (size_t)nq * 16, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(hipMemcpyAsync(words.data(), d_words, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int32_t> ta(ni), tb(ni);
+    if (nm) {
+        DP_HIP(hipMemcpyAsync(ctx->h_mrec.p, ctx->d_mrec.p, (size_t)nm * sizeof(MRec), hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipMemcpyAsync(ta.data(), ctx->d_ma.p, (size_t)ni * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipMemcpyAsync(tb.data(), ctx->d_mb.p, (size_t)ni * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (want_candidates) {
+        if (pin_reserve(ctx, ctx->h_cand, (size_t)nq * W * 8 + 16)) return DP_ERR_HIP;
+        DP_HIP(hipMemcpyAsync(ctx->h_cand.p, ctx->d_cand.p, (size_t)nq * W * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    DP_HIP(hipStreamSynchronize(ctx->stream));
+    for (uint32_t q = 0; q < nq; q++) {
+        if (qm[4 * q + 2] & 1) return dp_fail(ctx, DP_ERR_CAPACITY, "query with more than 512 usable seeds");
+        out->query_bytes += words[q] * 8;
+    }
+    MRec* recs = (MRec*)ctx->h_mrec.p;
+    std::vector<uint32_t> order(nm);
+    for (uint32_t i = 0; i < nm; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        if (recs[a].q != recs[b].q) return recs[a].q < recs[b].q;
+        return recs[a].t < recs[b].t;
+    });
+    uint32_t* mq = (uint32_t*)ctx->h_mq.p;
+    uint32_t* mt = (uint32_t*)ctx->h_mt.p;
+    uint64_t* moff = (uint64_t*)ctx->h_moff.p;
+    int32_t* fa = (int32_t*)ctx->h_ma.p;
+    int32_t* fb = (int32_t*)ctx->h_mb.p;
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < nm; i++) {
+        const MRec& r = recs[order[i]];
+        mq[i] = r.q;
+        mt[i] = r.t;
+        moff[i] = pos;
+        memcpy(fa + pos, ta.data() + r.off, (size_t)r.len * 4);
+        memcpy(fb + pos, tb.data() + r.off, (size_t)r.len * 4);
+        pos += r.len;
+    }
+    moff[nm] = pos;
+    out->n_matches = nm;
+    out->query = mq;
+    out->target = mt;
+    out->off = moff;
+    out->match_a = fa;
+    out->match_b = fb;
+    if (want_candidates) {
+        const u64* cm = (const u64*)ctx->h_cand.p;
+        uint64_t total = 0;
+        for (uint64_t i = 0; i < (uint64_t)nq * W; i++) total += (uint64_t)__builtin_popcountll(cm[i]);
+        if (pin_reserve(ctx, ctx->h_cand_list, total * 4 + 16)) return DP_ERR_HIP;
+        uint32_t* cl = (uint32_t*)ctx->h_cand_list.p;
+        uint64_t* co = (uint64_t*)ctx->h_cand_off.p;
+        uint64_t p = 0;
+        for (uint32_t q = 0; q < nq; q++) {
+            co[q] = p;
+            for (uint32_t w = 0; w < W; w++) {
+                u64 m = cm[(uint64_t)q * W + w];
+                while (m) {
+                    cl[p++] = w * 64 + (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                }
+            }
+        }
+        co[nq] = p;
+        out->cand = cl;
+    } else {
+        for (uint32_t q = 0; q <= nq; q++) ((uint64_t*)ctx->h_cand_off.p)[q] = 0;
+    }
+    return DP_OK;
+}
+
+extern "C" int dp_find_overlaps(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t n_queries,
+                                double hit_fraction, int k, uint32_t max_query_len, int want_candidates, dp_match_batch* out) {
+    if (!ctx || !out || (n_queries && (!q_segs || !q_off))) return DP_ERR_ARG;
+    return dp_find_overlaps_impl(ctx, q_segs, q_off, n_queries, hit_fraction, k, max_query_len, want_candidates, out);
+}
+
+// A19/A20 map flavour: implemented in dp_map.hip
+extern "C" int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, uint32_t n_windows, int k,
+                              dp_chain_batch* out) {
+    if (!ctx || !out || (n_windows && (!w_segs || !w_off))) return DP_ERR_ARG;
+    return dp_map_windows_impl(ctx, w_segs, w_off, n_windows, k, out);
+}

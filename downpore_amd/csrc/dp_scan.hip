@@ -1,0 +1,584 @@
+// libdownpore_hip.so — context, read packing (A1), k-mer histogram (A22), per-round seed tables and the batched
+// packed k-mer scan (A2 + A10).  CDNA4 / gfx950 only.
+//
+// Data layout in HBM
+//   d_packed : all reads, 2 bit/base, first base in the two top bits of each byte (the reference's packedSequence
+//              encoding, sequence/sequence.go:43-93).  Every read starts on a 16-byte boundary; padding and a 64-byte
+//              tail are zero.  A k-mer start position is addressed by its ABSOLUTE base index a = 4*boff[read] + p.
+//   d_bits   : 4^k-bit membership table (8 MiB at k=13; the reference uses a 4^k-BYTE []bool, seeds/seeds.go:13).
+//   d_kmap   : dense int32 k-mer -> seed id (reference kmerMap, seeds/seeds.go:17); touched only on true hits.
+//
+// Scan kernel (one 1024-thread workgroup per CU, persistent; one WAVE owns one item at a time)
+//   * the workgroup first builds a 1 Mbit (128 KiB) prefix filter of the round's seeds in LDS: bit = the first
+//     min(k,10) bases of a seed.  Random sequence => ~n_seeds/2^20 pass rate, so only ~1 % of the k-mers go on to
+//     the exact 4^k-bit table in L2/Infinity Cache.
+//   * a lane handles one aligned group of 32 k-mer start positions: 12 bytes of packed read (three big-endian
+//     dwords), 32 funnel-shift extractions, 32 one-byte LDS probes, then the (rare) exact probes.
+//   * count pass -> per-item hit count; offsets pass -> exclusive scan of 2*count+1 over surviving items; write
+//     pass -> wave prefix sums place each hit, a wave prefix-max supplies the previous hit for the gap.
+// Algorithmic bytes per scan: packed bytes of the items + 4^k/8 + 8 B per written hit.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include "dp_common.h"
+
+static std::string g_create_err;
+
+int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e) {
+    std::string s = what;
+    if (e != hipSuccess) {
+        s += ": ";
+        s += hipGetErrorString(e);
+    }
+    if (ctx) ctx->err = s;
+    else g_create_err = s;
+    return code;
+}
+
+int dev_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes, bool keep) {
+    if (bytes <= b.cap) return 0;
+    size_t ncap = std::max(bytes, b.cap + b.cap / 2);
+    ncap = (ncap + 255) & ~(size_t)255;
+    void* np = nullptr;
+    DP_HIP(hipMalloc(&np, ncap));
+    if (b.p) {
+        if (keep) DP_HIP(hipMemcpyAsync(np, b.p, b.cap, hipMemcpyDeviceToDevice, ctx->stream));
+        DP_HIP(hipStreamSynchronize(ctx->stream));
+        DP_HIP(hipFree(b.p));
+    }
+    b.p = np;
+    b.cap = ncap;
+    return 0;
+}
+int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    size_t ncap = std::max(bytes, b.cap + b.cap / 2);
+    ncap = (ncap + 4095) & ~(size_t)4095;
+    void* np = nullptr;
+    DP_HIP(hipHostMalloc(&np, ncap, hipHostMallocDefault));
+    if (b.p) {
+        DP_HIP(hipStreamSynchronize(ctx->stream));
+        DP_HIP(hipHostFree(b.p));
+    }
+    b.p = np;
+    b.cap = ncap;
+    return 0;
+}
+
+extern "C" const char* dp_version(void) { return "downpore_hip 0.1 (gfx950)"; }
+
+extern "C" const char* dp_last_error(const dp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int dp_ctx_create(int device, dp_ctx** out) {
+    if (!out) return DP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return dp_fail(nullptr, DP_ERR_NODEVICE, "no HIP device (this library has no CPU fallback)", e);
+    if (device < 0 || device >= n) return dp_fail(nullptr, DP_ERR_ARG, "device index out of range");
+    dp_ctx* ctx = new dp_ctx();
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+        dp_fail(nullptr, DP_ERR_HIP, "hipSetDevice/hipStreamCreate", e);
+        delete ctx;
+        return DP_ERR_HIP;
+    }
+    for (auto& ev : ctx->ev) hipEventCreate(&ev);
+    *out = ctx;
+    return DP_OK;
+}
+
+extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    DevBuf* dbs[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len, &ctx->d_bits, &ctx->d_kmap, &ctx->d_seeds, &ctx->d_items,
+                     &ctx->d_counts, &ctx->d_segoff, &ctx->d_segs, &ctx->d_total, &ctx->d_seqrefs, &ctx->d_posting,
+                     &ctx->d_seedsets, &ctx->d_pmeta, &ctx->d_qsegs, &ctx->d_qoff, &ctx->d_qsets, &ctx->d_qmeta,
+                     &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched};
+    for (auto* b : dbs)
+        if (b->p) hipFree(b->p);
+    PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
+                     &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff};
+    for (auto* b : pbs)
+        if (b->p) hipHostFree(b->p);
+    for (auto& ev : ctx->ev)
+        if (ev) hipEventDestroy(ev);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" uint32_t dp_reads_count(const dp_ctx* ctx) { return ctx ? ctx->n_reads : 0; }
+extern "C" uint64_t dp_reads_total_bases(const dp_ctx* ctx) { return ctx ? ctx->total_bases : 0; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// A1: 2-bit packing on the device.  One thread produces one packed dword (16 bases).
+
+__global__ void pack_kernel(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ aoff,
+                            const uint64_t* __restrict__ boff, uint32_t n_reads, uint32_t* __restrict__ packed,
+                            uint64_t n_dwords) {
+    uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_dwords) return;
+    uint64_t byte = d * 4;
+    // binary search: last read with boff[r] <= byte
+    uint32_t lo = 0, hi = n_reads;  // boff has n_reads+1 entries; boff[n_reads] = total
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (boff[mid] <= byte) lo = mid;
+        else hi = mid;
+    }
+    int64_t len = aoff[lo + 1] - aoff[lo];
+    int64_t base0 = (int64_t)(byte - boff[lo]) * 4;
+    const uint8_t* src = ascii + aoff[lo] + base0;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int64_t p = base0 + b * 4 + j;
+            uint32_t c = 0;
+            if (p < len) {
+                uint32_t ch = src[b * 4 + j];
+                c = ((ch >> 1) ^ ((ch & 4) >> 2)) & 3;  // sequence/sequence.go:59,80
+            }
+            v = (v << 2) | c;
+        }
+        out |= v << (8 * b);
+    }
+    packed[d] = out;
+}
+
+extern "C" int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads) {
+    if (!ctx || !bases || !off) return DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    ctx->n_reads = n_reads;
+    ctx->h_boff.assign((size_t)n_reads + 1, 0);
+    ctx->h_len.assign(n_reads, 0);
+    uint64_t pos = 0;
+    for (uint32_t r = 0; r < n_reads; r++) {
+        int64_t len = off[r + 1] - off[r];
+        if (len < 0 || len > 0x7fffffff) return dp_fail(ctx, DP_ERR_ARG, "read length out of range");
+        ctx->h_boff[r] = pos;
+        ctx->h_len[r] = (uint32_t)len;
+        pos += ((uint64_t)(len + 3) / 4 + 15) & ~(uint64_t)15;
+    }
+    ctx->h_boff[n_reads] = pos;
+    ctx->packed_bytes = pos;
+    ctx->total_bases = (uint64_t)(off[n_reads] - off[0]);
+    if (dev_reserve(ctx, ctx->d_packed, pos + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_boff, (n_reads + 1) * 8)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_len, (size_t)n_reads * 4 + 4)) return DP_ERR_HIP;
+    DP_HIP(hipMemcpyAsync(ctx->d_boff.p, ctx->h_boff.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->d_len.p, ctx->h_len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemsetAsync((uint8_t*)ctx->d_packed.p + pos, 0, 64, ctx->stream));
+    if (n_reads == 0 || pos == 0) {
+        DP_HIP(hipStreamSynchronize(ctx->stream));
+        return DP_OK;
+    }
+    void* d_ascii = nullptr;
+    void* d_aoff = nullptr;
+    uint64_t nascii = ctx->total_bases;
+    DP_HIP(hipMalloc(&d_ascii, nascii + 16));
+    DP_HIP(hipMalloc(&d_aoff, (n_reads + 1) * 8));
+    std::vector<int64_t> rel((size_t)n_reads + 1);
+    for (uint32_t r = 0; r <= n_reads; r++) rel[r] = off[r] - off[0];
+    DP_HIP(hipMemcpyAsync(d_ascii, bases + off[0], nascii, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(d_aoff, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t n_dwords = pos / 4;
+    uint32_t blocks = (uint32_t)((n_dwords + 255) / 256);
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)d_ascii, (const int64_t*)d_aoff,
+                       (const uint64_t*)ctx->d_boff.p, n_reads, (uint32_t*)ctx->d_packed.p, n_dwords);
+    DP_HIP(hipGetLastError());
+    DP_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(d_ascii);
+    hipFree(d_aoff);
+    return DP_OK;
+}
+
+extern "C" int dp_reads_packed(dp_ctx* ctx, uint32_t read, uint8_t* out, uint64_t cap, uint64_t* n_bytes) {
+    if (!ctx || read >= ctx->n_reads) return DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    uint64_t nb = ((uint64_t)ctx->h_len[read] + 3) / 4;
+    if (n_bytes) *n_bytes = nb;
+    if (nb > cap) return dp_fail(ctx, DP_ERR_ARG, "dp_reads_packed: buffer too small");
+    DP_HIP(hipMemcpy(out, (uint8_t*)ctx->d_packed.p + ctx->h_boff[read], nb, hipMemcpyDeviceToHost));
+    return DP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// shared device code: window of 32 k-mer start positions
+
+struct Win {
+    uint32_t w0, w1, w2;
+};
+__device__ __forceinline__ Win load_win(const uint8_t* __restrict__ packed, uint64_t g) {
+    const uint32_t* p = (const uint32_t*)(packed + g * 8);
+    Win w;
+    w.w0 = __builtin_bswap32(p[0]);
+    w.w1 = __builtin_bswap32(p[1]);
+    w.w2 = __builtin_bswap32(p[2]);
+    return w;
+}
+// 32-bit window whose top bits are the k-mer starting at position J (0..31) of the group
+template <int J>
+__device__ __forceinline__ uint32_t win_at(const Win& w) {
+    constexpr int q = J >> 4, r = J & 15;
+    uint32_t hi = q ? w.w1 : w.w0, lo = q ? w.w2 : w.w1;
+    if (r == 0) return hi;
+    return __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * r);
+}
+__device__ __forceinline__ uint32_t win_at_rt(const Win& w, int j) {
+    int q = j >> 4, r = j & 15;
+    uint32_t hi = q ? w.w1 : w.w0, lo = q ? w.w2 : w.w1;
+    return r ? __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * r) : hi;
+}
+// bit mask of the positions of group g that lie inside [a0, a1)
+__device__ __forceinline__ uint32_t valid_mask(uint64_t g, uint64_t a0, uint64_t a1) {
+    int64_t lo = (int64_t)a0 - (int64_t)(g * 32), hi = (int64_t)a1 - (int64_t)(g * 32);
+    if (lo < 0) lo = 0;
+    if (hi > 32) hi = 32;
+    if (hi <= lo) return 0u;
+    uint32_t mh = hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u);
+    uint32_t ml = (1u << lo) - 1u;  // lo < 32 here
+    return mh & ~ml;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A22: histogram of every k-mer of every read (util/sequtil/kmers.go:53-69): positions 0..len-k.
+
+__global__ void hist_kernel(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ boff,
+                            const uint32_t* __restrict__ len, uint32_t n_reads, int k, uint32_t* __restrict__ counts) {
+    const int lane = dp_lane();
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int sh = 32 - 2 * k;
+    for (uint32_t r = gw; r < n_reads; r += waves) {
+        uint32_t L = len[r];
+        if (L < (uint32_t)k) continue;  // the reference would index out of range here; nothing to count
+        uint64_t a0 = boff[r] * 4, a1 = a0 + (L - k + 1);
+        uint64_t g0 = a0 >> 5, g1 = (a1 - 1) >> 5;
+        for (uint64_t gb = g0; gb <= g1; gb += 64) {
+            uint64_t g = gb + lane;
+            if (g > g1) continue;
+            Win w = load_win(packed, g);
+            uint32_t vm = valid_mask(g, a0, a1);
+            for (int j = 0; j < 32; j++)
+                if ((vm >> j) & 1) atomicAdd(&counts[win_at_rt(w, j) >> sh], 1u);
+        }
+    }
+}
+
+extern "C" int dp_kmer_histogram(dp_ctx* ctx, int k, uint64_t* counts_out) {
+    if (!ctx || !counts_out || k < 1 || k > 15) return DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    size_t n = (size_t)1 << (2 * k);
+    void* d = nullptr;
+    DP_HIP(hipMalloc(&d, n * 4));
+    DP_HIP(hipMemsetAsync(d, 0, n * 4, ctx->stream));
+    if (ctx->n_reads) {
+        hipLaunchKernelGGL(hist_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
+                           (const uint64_t*)ctx->d_boff.p, (const uint32_t*)ctx->d_len.p, ctx->n_reads, k, (uint32_t*)d);
+        DP_HIP(hipGetLastError());
+    }
+    std::vector<uint32_t> tmp(n);
+    DP_HIP(hipMemcpyAsync(tmp.data(), d, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(d);
+    for (size_t i = 0; i < n; i++) counts_out[i] = tmp[i];
+    return DP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// round state
+
+__global__ void seeds_apply_kernel(const uint32_t* __restrict__ seeds, uint32_t n, uint32_t* __restrict__ bits,
+                                   int32_t* __restrict__ kmap, int set) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t kmer = seeds[i];
+    if (set) {
+        atomicOr(&bits[kmer >> 5], 1u << (kmer & 31));
+        kmap[kmer] = (int32_t)i;
+    } else {
+        bits[kmer >> 5] = 0;  // whole word: every bit in it belongs to a seed of the same (previous) round
+        kmap[kmer] = 0;
+    }
+}
+
+extern "C" int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, uint32_t n_seeds) {
+    if (!ctx || k < 4 || k > 15 || (n_seeds && !seed_kmers)) return DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    size_t nk = (size_t)1 << (2 * k);
+    if (ctx->table_k != k) {
+        if (dev_reserve(ctx, ctx->d_bits, nk / 8 + 64)) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_kmap, nk * 4)) return DP_ERR_HIP;
+        DP_HIP(hipMemsetAsync(ctx->d_bits.p, 0, nk / 8 + 64, ctx->stream));
+        DP_HIP(hipMemsetAsync(ctx->d_kmap.p, 0, nk * 4, ctx->stream));
+        ctx->table_k = k;
+        ctx->n_seeds = 0;
+    } else if (ctx->n_seeds) {
+        hipLaunchKernelGGL(seeds_apply_kernel, dim3((ctx->n_seeds + 255) / 256), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (uint32_t*)ctx->d_bits.p, (int32_t*)ctx->d_kmap.p, 0);
+    }
+    for (uint32_t i = 0; i < n_seeds; i++)
+        if (seed_kmers[i] >= nk) return dp_fail(ctx, DP_ERR_ARG, "seed k-mer out of range for k");
+    if (dev_reserve(ctx, ctx->d_seeds, (size_t)n_seeds * 4 + 4)) return DP_ERR_HIP;
+    if (n_seeds) {
+        DP_HIP(hipMemcpyAsync(ctx->d_seeds.p, seed_kmers, (size_t)n_seeds * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(seeds_apply_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)ctx->d_seeds.p, n_seeds, (uint32_t*)ctx->d_bits.p, (int32_t*)ctx->d_kmap.p, 1);
+        DP_HIP(hipGetLastError());
+    }
+    DP_HIP(hipStreamSynchronize(ctx->stream));  // seed_kmers is borrowed only for the duration of the call
+    ctx->k = k;
+    ctx->n_seeds = n_seeds;
+    ctx->round_open = true;
+    ctx->n_seqs = 0;
+    return DP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A2 + A10 scan
+
+#define SCAN_THREADS 1024
+#define BLOOM_LOG2 20
+#define BLOOM_BYTES (1u << (BLOOM_LOG2 - 3))
+
+template <int J>
+struct ProbeLoop {
+    static __device__ __forceinline__ uint32_t run(const Win& w, const uint8_t* bloom, int pshift) {
+        uint32_t win = win_at<J>(w);
+        uint32_t idx = win >> pshift;
+        uint32_t byte = bloom[idx >> 3];
+        uint32_t hit = (byte >> (idx & 7)) & 1u;
+        return (hit << J) | ProbeLoop<J + 1>::run(w, bloom, pshift);
+    }
+};
+template <>
+struct ProbeLoop<32> {
+    static __device__ __forceinline__ uint32_t run(const Win&, const uint8_t*, int) { return 0u; }
+};
+
+template <int MODE>  // 0 = count pass, 1 = write pass
+__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const uint8_t* __restrict__ packed,
+                                                            const uint64_t* __restrict__ boff,
+                                                            const dp_scan_item* __restrict__ items, uint32_t n_items, int k,
+                                                            const uint32_t* __restrict__ seeds, uint32_t n_seeds,
+                                                            const uint32_t* __restrict__ bits, const int32_t* __restrict__ kmap,
+                                                            uint32_t* __restrict__ counts, const uint64_t* __restrict__ segoff,
+                                                            int32_t* __restrict__ segs) {
+    extern __shared__ uint8_t bloom[];
+    const int pb = k < 10 ? k : 10;       // prefix bases used by the LDS filter
+    const int pshift = 32 - 2 * pb;       // window -> filter index
+    const int ksh = 32 - 2 * k;           // window -> k-mer
+    {
+        uint4* z = (uint4*)bloom;
+        for (uint32_t i = threadIdx.x; i < BLOOM_BYTES / 16; i += SCAN_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        uint32_t* bw = (uint32_t*)bloom;
+        for (uint32_t s = threadIdx.x; s < n_seeds; s += SCAN_THREADS) {
+            uint32_t idx = seeds[s] >> (2 * (k - pb));
+            atomicOr(&bw[idx >> 5], 1u << (idx & 31));
+        }
+        __syncthreads();
+    }
+    const int lane = dp_lane();
+    const uint32_t waves = gridDim.x * (SCAN_THREADS / 64);
+    const uint32_t gw = blockIdx.x * (SCAN_THREADS / 64) + (threadIdx.x >> 6);
+    for (uint32_t it = gw; it < n_items; it += waves) {
+        const dp_scan_item item = items[it];
+        if (MODE == 1 && counts[it] < item.min_seeds) continue;
+        const uint64_t a0 = boff[item.read] * 4 + item.start;
+        const uint64_t a1 = a0 + item.n_kmers;
+        int cnt = 0;
+        int carry = -k;  // position of the last hit so far ("-k": the first gap is the hit's own index)
+        int written = 0;
+        uint64_t outbase = 0;
+        if (MODE == 1) outbase = segoff[it];
+        if (item.n_kmers > 0) {
+            const uint64_t g0 = a0 >> 5, g1 = (a1 - 1) >> 5;
+            for (uint64_t gb = g0; gb <= g1; gb += 64) {
+                const uint64_t g = gb + lane;
+                uint32_t exact = 0;
+                Win w = {0, 0, 0};
+                if (g <= g1) {
+                    w = load_win(packed, g);
+                    uint32_t m = ProbeLoop<0>::run(w, bloom, pshift) & valid_mask(g, a0, a1);
+                    while (m) {
+                        int j = __builtin_ctz(m);
+                        m &= m - 1;
+                        uint32_t kmer = win_at_rt(w, j) >> ksh;
+                        if ((bits[kmer >> 5] >> (kmer & 31)) & 1u) exact |= 1u << j;
+                    }
+                }
+                if (MODE == 0) {
+                    cnt += __builtin_popcount(exact);
+                } else {
+                    int c = __builtin_popcount(exact);
+                    int incl = wave_incl_sum(c);
+                    int excl = incl - c;
+                    int total = __shfl(incl, 63, 64);
+                    int lastpos = exact ? (int)((int64_t)(g * 32 + 31 - __builtin_clz(exact)) - (int64_t)a0) : -0x40000000;
+                    int pm = wave_incl_max(lastpos);
+                    int up = __shfl_up(pm, 1, 64);
+                    int prev = lane == 0 ? carry : max(carry, up);
+                    int t = 0;
+                    uint32_t e = exact;
+                    while (e) {
+                        int j = __builtin_ctz(e);
+                        e &= e - 1;
+                        uint32_t kmer = win_at_rt(w, j) >> ksh;
+                        int p = (int)((int64_t)(g * 32 + j) - (int64_t)a0);
+                        uint64_t o = outbase + 2 * (uint64_t)(written + excl + t);
+                        segs[o] = p - (prev + k);
+                        segs[o + 1] = kmap[kmer];
+                        prev = p;
+                        t++;
+                    }
+                    carry = max(carry, __shfl(pm, 63, 64));
+                    written += total;
+                }
+            }
+        }
+        if (MODE == 0) {
+            cnt = wave_sum(cnt);
+            if (lane == 0) counts[it] = (uint32_t)cnt;
+        } else if (lane == 0) {
+            // final gap (sequence/asm_amd64.s:387-392): examined k-mers - last hit - 1; no hit: n_kmers + k - 1
+            segs[outbase + 2 * (uint64_t)written] = (int)item.n_kmers - carry - 1;
+        }
+    }
+}
+
+// exclusive scan of (count >= min_seeds ? 2*count+1 : 0) over the items; single workgroup
+__global__ __launch_bounds__(1024) void scan_offsets_kernel(const dp_scan_item* __restrict__ items,
+                                                            const uint32_t* __restrict__ counts, uint32_t n,
+                                                            uint64_t* __restrict__ segoff, uint64_t* __restrict__ total) {
+    __shared__ uint64_t part[1024];
+    uint32_t per = (n + 1023) / 1024;
+    uint32_t b = threadIdx.x * per, e = min(n, b + per);
+    uint64_t s = 0;
+    for (uint32_t i = b; i < e; i++) s += counts[i] >= items[i].min_seeds ? 2ull * counts[i] + 1 : 0ull;
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; i++) {
+            uint64_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        *total = run;
+        segoff[n] = run;
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (uint32_t i = b; i < e; i++) {
+        segoff[i] = run;
+        run += counts[i] >= items[i].min_seeds ? 2ull * counts[i] + 1 : 0ull;
+    }
+}
+
+extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items, dp_seedseq_batch* out) {
+    if (!ctx || !out || (n_items && !items)) return DP_ERR_ARG;
+    if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_scan before dp_round_begin");
+    hipSetDevice(ctx->device);
+    const int k = ctx->k;
+    uint64_t bases = 0;
+    for (uint32_t i = 0; i < n_items; i++) {
+        const dp_scan_item& it = items[i];
+        if (it.read >= ctx->n_reads) return dp_fail(ctx, DP_ERR_ARG, "scan item: read index out of range");
+        // the examined k-mers may run past the read end only in the reference's over-scan corner cases (<~8+k bases),
+        // which the caller must not batch; enforce that every examined base lies inside the read
+        if ((uint64_t)it.start + it.n_kmers + (it.n_kmers ? k - 1 : 0) > ctx->h_len[it.read])
+            return dp_fail(ctx, DP_ERR_ARG, "scan item: k-mer range exceeds the read");
+        bases += it.n_kmers ? (uint64_t)it.n_kmers + k - 1 : 0;
+    }
+    if (dev_reserve(ctx, ctx->d_items, (size_t)n_items * sizeof(dp_scan_item) + 16)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_counts, (size_t)n_items * 4 + 16)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_segoff, ((size_t)n_items + 1) * 8)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_total, 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_counts, (size_t)n_items * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_segoff, ((size_t)n_items + 1) * 8)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_total, 16)) return DP_ERR_HIP;
+    out->n_items = n_items;
+    out->kernel_ms = 0;
+    out->bases_scanned = bases;
+    ctx->scan_items = n_items;
+    if (n_items == 0) {
+        ((uint64_t*)ctx->h_segoff.p)[0] = 0;
+        out->n_seeds = (const uint32_t*)ctx->h_counts.p;
+        out->seg_off = (const uint64_t*)ctx->h_segoff.p;
+        out->segs = nullptr;
+        out->n_segs = 0;
+        ctx->n_segs = 0;
+        return DP_OK;
+    }
+    DP_HIP(hipMemcpyAsync(ctx->d_items.p, items, (size_t)n_items * sizeof(dp_scan_item), hipMemcpyHostToDevice, ctx->stream));
+    int dev_cus = 256;
+    hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus, ((uint64_t)n_items + 15) / 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        DP_HIP(hipFuncSetAttribute((const void*)scan_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, BLOOM_BYTES));
+        DP_HIP(hipFuncSetAttribute((const void*)scan_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, BLOOM_BYTES));
+        attr_set = true;
+    }
+    DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(scan_kernel<0>, dim3(grid), dim3(SCAN_THREADS), BLOOM_BYTES, ctx->stream, (const uint8_t*)ctx->d_packed.p,
+                       (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p, n_items, k,
+                       (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
+                       (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr);
+    DP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const dp_scan_item*)ctx->d_items.p,
+                       (const uint32_t*)ctx->d_counts.p, n_items, (uint64_t*)ctx->d_segoff.p, (uint64_t*)ctx->d_total.p);
+    DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->h_total.p, ctx->d_total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->h_counts.p, ctx->d_counts.p, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->h_segoff.p, ctx->d_segoff.p, ((size_t)n_items + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t n_segs = *(uint64_t*)ctx->h_total.p;
+    if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
+    float ms0 = 0, ms1 = 0;
+    hipEventElapsedTime(&ms0, ctx->ev[0], ctx->ev[1]);
+    if (n_segs) {
+        DP_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+        hipLaunchKernelGGL(scan_kernel<1>, dim3(grid), dim3(SCAN_THREADS), BLOOM_BYTES, ctx->stream,
+                           (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p,
+                           n_items, k, (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
+                           (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
+                           (int32_t*)ctx->d_segs.p);
+        DP_HIP(hipGetLastError());
+        DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+        DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipStreamSynchronize(ctx->stream));
+        hipEventElapsedTime(&ms1, ctx->ev[2], ctx->ev[3]);
+    }
+    ctx->n_segs = n_segs;
+    out->n_seeds = (const uint32_t*)ctx->h_counts.p;
+    out->seg_off = (const uint64_t*)ctx->h_segoff.p;
+    out->segs = (const int32_t*)ctx->h_segs.p;
+    out->n_segs = n_segs;
+    out->kernel_ms = (double)ms0 + (double)ms1;
+    return DP_OK;
+}
+
+extern "C" int dp_scan_device_buffers(dp_ctx* ctx, void** segs_dev, uint64_t* n_segs) {
+    if (!ctx) return DP_ERR_ARG;
+    if (segs_dev) *segs_dev = ctx->d_segs.p;
+    if (n_segs) *n_segs = ctx->n_segs;
+    return DP_OK;
+}
+
+extern "C" int dp_scan_import_segments(dp_ctx* ctx, const int32_t* segs, uint64_t n_segs) {
+    if (!ctx || (n_segs && !segs)) return DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
+    if (n_segs) DP_HIP(hipMemcpyAsync(ctx->d_segs.p, segs, n_segs * 4, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->n_segs = n_segs;
+    return DP_OK;
+}

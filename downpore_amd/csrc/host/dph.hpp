@@ -1,0 +1,236 @@
+// Host side of the product: a C++ mirror of the reference's Go layers that sit ABOVE the C ABI
+// (include/downpore_hip.h).  Go is not available in this image, so what would be a cgo-backed Go implementation of
+// overlap.Overlapper / mapping.Mapper is written here in C++ with the same names, argument meaning and order of
+// operations (see INTEGRATION.md for the Go-side stub).  Everything data-parallel goes through the C ABI to the GPU;
+// what stays on the host is the sequential / control logic SURVEY §8(a) marks "host": FASTA rules (A23), value table
+// arithmetic (A22, float64), seed selection (A9), query preparation (A15), chunking (A12), consensus (A16), PAF (A17).
+//
+// This code does not include, link or call anything under oracle/.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "downpore_hip.h"
+
+namespace dph {
+
+typedef int64_t i64;
+
+// ---- read set (sequence/seqio.go fastaSequenceSet, FASTA subset) -------------------------------------------------
+struct ReadSet {
+    std::vector<std::string> names;
+    std::vector<i64> off;          // offsets into bases (n+1)
+    std::string bases;             // concatenated ASCII of the kept reads
+    std::vector<uint8_t> ignore;   // SetIgnore flags (seqio.go:375)
+    bool himem = true;             // cached views (seqio.go:115) vs top-level re-reads (:158)
+    size_t size() const { return names.size(); }
+    i64 length(size_t r) const { return off[r + 1] - off[r]; }
+    const char* seq(size_t r) const { return bases.data() + off[r]; }
+    void addLine(const std::string& lastName, const char* line, size_t len, i64 minLen);
+    static bool fromFile(const std::string& path, i64 minLen, bool himem, ReadSet& out, std::string& err);
+    static ReadSet fromArrays(const char* bases, const i64* off, size_t n, i64 minLen, bool himem);
+    // k-mers the reference's scan examines for the view a later pass receives
+    i64 scanKmers(size_t r, int k) const;
+    // GetInset() of the served view: SubSequence's inset is one too large (sequence.go:365)
+    i64 servedInset() const { return himem ? 1 : 0; }
+};
+
+static inline uint32_t baseCode(unsigned char b) { return ((b >> 1) ^ ((b & 4) >> 2)) & 3; }
+uint32_t reverseComplementKmer(uint32_t kmer, int k);  // seeds/sequence.go:125-132
+
+// ---- value table (commands/overlap.go:39-94, util/sequtil/kmers.go:87-112) ---------------------------------------
+std::vector<double> kmerValuesFromCounts(std::vector<uint64_t>& counts, int k);
+
+// ---- seed space ---------------------------------------------------------------------------------------------------
+// SeedSequence (seeds/sequence.go:10-20).  Segments live in a shared int32 pool owned by the round.
+struct SeedSeq {
+    const int32_t* seg = nullptr;  // [gap, seed, gap, ..., gap]
+    int n = 0;                     // number of ints
+    int id = 0;
+    i64 length = 0, offset = 0, inset = 0;
+    bool rc = false;
+    SeedSeq* parent = nullptr;
+    SeedSeq* reverseComplement = nullptr;
+    int numSeeds() const { return n / 2; }
+    i64 seedOffset(int index, int k) const;         // GetSeedOffset        :1239
+    i64 seedOffsetFromEnd(int index, int k) const;  // GetSeedOffsetFromEnd :1269
+    i64 nextSeedOffset(int index, int k) const { return (i64)seg[index * 2 + 2] + k; }
+    int maxSeed() const;
+};
+
+struct SeedMatch {  // seeds/sequence.go:24-32
+    std::vector<int32_t> MatchA, MatchB;
+    SeedSeq* SeqA = nullptr;
+    SeedSeq* SeqB = nullptr;
+    int QueryID = 0;
+    bool ReverseComplementQuery = false;
+};
+
+// per-round arena (Go GC stand-in)
+struct Arena {
+    std::vector<std::unique_ptr<SeedSeq>> seqs;
+    std::vector<std::unique_ptr<std::vector<int32_t>>> stores;
+    SeedSeq* make() {
+        seqs.emplace_back(new SeedSeq());
+        return seqs.back().get();
+    }
+    int32_t* alloc(size_t n) {
+        stores.emplace_back(new std::vector<int32_t>(n, 0));
+        return stores.back()->data();
+    }
+    void clear() {
+        seqs.clear();
+        stores.clear();
+    }
+};
+
+// Host mirror of seeds.SeedIndex (seeds/seeds.go:11-21): the seed <-> k-mer maps and the list of indexed sequences.
+// The posting sets / seed sets themselves live on the GPU (dp_index_build).
+struct SeedIndex {
+    int k;
+    std::vector<uint64_t> kmerBits;                 // 4^k-bit membership, sparse-reset between rounds
+    std::unordered_map<uint32_t, int32_t> kmerMap;  // k-mer -> seed id
+    std::vector<uint32_t> seedMap;                  // seed id -> k-mer
+    std::vector<SeedSeq*> sequences;                // indexed sequences (chunks), index == GPU sequence index
+    std::vector<dp_seq_ref> refs;                   // their views into the device-resident scan output
+    Arena arena;
+    explicit SeedIndex(int k_);
+    void reset();
+    int size() const { return (int)seedMap.size(); }
+    bool isSeed(uint32_t kmer) const { return (kmerBits[kmer >> 6] >> (kmer & 63)) & 1; }
+    void addSeedKmer(uint32_t kmer);                                     // seeds.go:132-141
+    void addSeeds(const char* s, i64 len, int minSeeds, const double* ranks);  // AddSeeds :62-156
+    int32_t seedOfRcKmer(int32_t seed) const;                            // kmerMap[rc(seedMap[seed])]
+};
+
+SeedSeq* seqReverseComplement(Arena& a, SeedSeq* s, const SeedIndex& ix);  // seeds/sequence.go:134-159
+SeedSeq* seqSubSequence(Arena& a, SeedSeq* s, int start, int end, i64 length, i64 offset, i64 inset);  // :46
+SeedSeq* seqTrimmed(Arena& a, SeedSeq* s, i64 startOffset, int startSeed, i64 endOffset, int endSeed, int k);  // :54
+SeedSeq* seqReduced(Arena& a, SeedSeq* s, const std::vector<uint64_t>& whitelist, int k, int minSeeds,
+                    std::vector<int>* index);                                                              // :85
+void matchReverseComplement(Arena& a, SeedMatch& m, const SeedIndex& ix);   // :800
+void matchBasesCovered(const SeedMatch& m, int k, i64* a, i64* b, bool* wouldPanic);  // :830
+void matchBaseIndex(const SeedMatch& m, int aIndex, int k, i64* index, i64* bases, i64* distance);  // :1190
+void gapRange(i64 gap, int k, i64* mn, i64* mx);                          // seeds/alignment.go:411
+
+// seeds/alignment.go:23-268
+SeedSeq* multiAlignerConsensus(Arena& a, std::vector<SeedSeq*>& seqs, int k, std::vector<std::unique_ptr<SeedMatch>>& out);
+
+// overlap/combine.go
+struct SeedContig {
+    std::vector<int> Parts;
+    std::vector<i64> Offsets, Lengths, SeqLengths;
+    std::vector<uint8_t> ReverseComplement, Approximate;
+    std::vector<SeedMatch*> Matches;
+    std::vector<std::unique_ptr<SeedMatch>> owned;
+};
+std::unique_ptr<SeedContig> buildConsensus(Arena& a, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, i64* badBack);
+
+// ---- overlap.Overlapper (overlap/overlap.go:24-29) ----------------------------------------------------------------
+struct SeedQuery {  // overlap/overlap.go:10-16
+    int ID = 0, SequenceID = 0;
+    SeedSeq* Query = nullptr;
+    bool AtStart = true, ReverseComplement = false;
+};
+
+struct OverlapParams {  // flag table commands/overlap.go:24-25
+    i64 overlapSize = 1000;
+    int k = 10;
+    int numSeeds = 15;
+    i64 seedBatchSize = 10000, chunkSize = 10000, queryBatchSize = 20000;
+    double minHits = 0.25;
+    int numWorkers = 4;  // accepted for compatibility; the GPU path is batch-parallel
+    bool himem = true;
+};
+
+struct RoundStats {
+    double t_prepare = 0, t_scan = 0, t_index = 0, t_query = 0, t_consensus = 0;  // host wall seconds
+    double k_scan_ms = 0, k_query_ms = 0, k_chain_ms = 0;                         // device kernel ms
+    uint64_t scan_bases = 0, scan_items = 0, scan_bytes = 0, query_bytes = 0;
+    uint64_t n_queries = 0, n_indexed = 0, n_hits = 0, n_matches = 0, n_paf = 0, n_seeds = 0;
+};
+
+// Survivor exchange hook for multi-GPU runs: after the local scan, the caller may replace the local
+// survivor list by the rank-ordered concatenation over all ranks.
+struct Survivors {
+    std::vector<uint32_t> read;      // read id per survivor (ascending)
+    std::vector<uint32_t> n_seeds;
+    std::vector<uint64_t> seg_off;   // n+1
+    std::vector<int32_t> segs;
+};
+
+class Overlapper {
+   public:
+    Overlapper(dp_ctx* ctx, ReadSet& reads, SeedIndex& index, i64 chunkSize, int numWorkers, i64 overlap, int minSeeds,
+               double hitFraction);
+    // PrepareQueries (:157): seed selection over the query windows; returns the windows (queries are completed by
+    // AddSequences, which scans them on the GPU together with the reads)
+    int PrepareQueries(int numSeeds, i64 seedLimit, const double* kmerValues, i64 firstSequence, i64 maxSeqs);
+    // AddSequences (:217): GPU scan of every non-ignored read in [shardLo, shardHi) + all query windows
+    int ScanLocal(size_t shardLo, size_t shardHi, Survivors& local, RoundStats& st);
+    // chunkWorker (:253) + IndexSequences on the GPU, from the (possibly all-gathered) survivors
+    int IndexSurvivors(const Survivors& all, RoundStats& st);
+    // FindOverlaps (:320): Matches + prefilter + chaining + ratchet on the GPU
+    int FindOverlaps(std::vector<std::unique_ptr<SeedMatch>>& out, RoundStats& st);
+    void SetOverlapSize(i64 size) { overlap_ = size; }
+    std::vector<SeedQuery> queries;
+    std::string err;
+
+   private:
+    void chunkAndAdd(SeedSeq* s, uint64_t segBase);
+    dp_ctx* ctx_;
+    ReadSet& reads_;
+    SeedIndex& index_;
+    i64 chunkSize_, overlap_;
+    int minSeeds_;
+    double hitFraction_;
+    struct Window {
+        uint32_t read, start, len;
+    };
+    std::vector<Window> windows_;
+    std::vector<int32_t> querySegs_;       // fwd/rc query segments (host)
+    std::vector<uint64_t> queryOff_;
+    std::vector<int32_t> winSegs_;         // scan output of the windows
+    std::vector<uint64_t> winOff_;
+    std::vector<int32_t> allSegs_;         // survivors' segments (host copy; device copy is what the index references)
+};
+
+// ---- command driver (commands/overlap.go:96-233) ------------------------------------------------------------------
+struct OverlapRun {
+    dp_ctx* ctx = nullptr;
+    ReadSet* reads = nullptr;
+    OverlapParams p;
+    std::vector<double> values;
+    std::unique_ptr<SeedIndex> index;
+    std::unique_ptr<Overlapper> lap;
+    i64 firstSequence = 0;
+    i64 round = 0;
+    i64 numQuerySeqs = 0;
+    i64 badBack = 0, emptyMatch = 0;
+    bool done = false;
+    std::string paf;      // PAF text of the last finished round
+    std::string errText;  // stderr progress lines accumulated
+    std::string error;    // failure text
+    RoundStats last;
+    Survivors local;
+    // shard of reads this process scans: [shardLo, shardHi)
+    size_t shardLo = 0, shardHi = 0;
+
+    int init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const double* valuesOrNull);
+    // one round = prepare -> scan -> (exchange) -> finish.  Returns 1 when a round was started, 0 when finished, <0 error
+    int roundPrepareAndScan();
+    int roundFinish(const Survivors& all);
+};
+
+// ---- flag table helpers (commands/command.go:18-74, downpore.go:34-51) -------------------------------------------
+struct ArgTable {
+    std::vector<std::string> names, defaults, descriptions;
+    std::unordered_map<std::string, std::string> args, alias;
+    void make(const std::vector<std::string>& n, const std::vector<std::string>& d, const std::vector<std::string>& desc);
+    bool parse(int argc, char** argv, std::string& err);
+};
+
+}  // namespace dph

@@ -1,0 +1,172 @@
+/*
+ * downpore_hip.h — C ABI of libdownpore_hip.so: the MI355X (gfx950) implementation of downpore's
+ * seed-index + seed-chaining overlap/map hot path.
+ *
+ * This is the drop-in boundary.  The reference's native boundary is a set of
+ * per-slice Plan-9 assembly routines called millions of times (util/bitset.go:197,248-254;
+ * sequence/sequence.go:65,326,327,438) — far too fine for a GPU — so the boundary moves one level up,
+ * to the batched bodies of the Go interfaces `overlap.Overlapper` (overlap/overlap.go:24-29),
+ * `mapping.Mapper` (mapping/mapping.go:22-26) and `seeds.SeedIndex` (seeds/seeds.go:11-21).  A Go type
+ * implementing those interfaces marshals to the calls below through cgo.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative dp_status on failure; dp_last_error(ctx) gives text.
+ *   - plain pointers and sizes only.  Inputs are borrowed for the duration of the call (the library copies;
+ *     no caller pointer is retained — cgo-safe).  Output pointers inside the *_batch structs point into
+ *     library-owned pinned host buffers that stay valid until the next call of the SAME function on the same
+ *     context (or dp_ctx_destroy).
+ *   - one host thread per context; a context owns one HIP stream on one device.
+ *   - all results are bit-exact restatements of the reference's arithmetic (integer / bitset work only).
+ */
+#ifndef DOWNPORE_HIP_H
+#define DOWNPORE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dp_ctx dp_ctx;
+
+enum dp_status {
+    DP_OK = 0,
+    DP_ERR_HIP = -1,       /* a HIP runtime call failed */
+    DP_ERR_ARG = -2,       /* invalid argument */
+    DP_ERR_STATE = -3,     /* call order violated (e.g. dp_scan before dp_round_begin) */
+    DP_ERR_CAPACITY = -4,  /* a reference capacity limit was hit (the reference would panic) */
+    DP_ERR_NODEVICE = -5   /* no usable GPU */
+};
+
+/* Library/ABI version and the code-object architecture this build targets ("gfx950"). */
+const char* dp_version(void);
+
+/* Create a context on HIP device `device`.  Fails (DP_ERR_NODEVICE) when no GPU is present: there is no CPU
+ * fallback. */
+int dp_ctx_create(int device, dp_ctx** out);
+void dp_ctx_destroy(dp_ctx* ctx);
+const char* dp_last_error(const dp_ctx* ctx); /* ctx may be NULL: error of the last failed dp_ctx_create */
+
+/* ---- A1: reads resident in HBM ------------------------------------------------------------------------
+ * Replaces NewPackedSequence/packBytes (sequence/sequence.go:67-93, sequence/asm_amd64.s:33-78) for the whole
+ * read set: `bases` is the concatenated ASCII of all reads, read r = bases[off[r] .. off[r+1]).  Packing
+ * (2 bit/base, ((b>>1)^((b&4)>>2))&3, first base in the top bits of each byte) runs on the device.  Reads stay
+ * resident for every later round. */
+int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads);
+/* Copy back the packed bytes of one read (ceil(len/4) bytes) — test hook. */
+int dp_reads_packed(dp_ctx* ctx, uint32_t read, uint8_t* out, uint64_t cap, uint64_t* n_bytes);
+uint32_t dp_reads_count(const dp_ctx* ctx);
+uint64_t dp_reads_total_bases(const dp_ctx* ctx);
+
+/* ---- A22: k-mer histogram -----------------------------------------------------------------------------
+ * Replaces sequtil.KmerOccurrences/countWorker (util/sequtil/kmers.go:34-69): counts_out[kmer] (4^k entries)
+ * = occurrences of every k-mer over all uploaded reads. */
+int dp_kmer_histogram(dp_ctx* ctx, int k, uint64_t* counts_out);
+
+/* ---- round state: the seed set --------------------------------------------------------------------------
+ * Mirrors the per-round SeedIndex tables kmers/kmerMap/seedMap (seeds/seeds.go:13-18): seed id = position in
+ * seed_kmers.  Builds the 4^k-bit membership table and the k-mer -> seed-id map on the device (sparse
+ * set/clear: only the entries of the previous round's seeds are touched). */
+int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, uint32_t n_seeds);
+
+/* ---- A2 + A10: batched packed k-mer scan ---------------------------------------------------------------
+ * Replaces SeedIndex.NewSeedSequence = packedCountKmers + packedWriteSegments + kmerMap translate
+ * (seeds/seeds.go:33-50; sequence/asm_amd64.s:81-203,206-394) for MANY sequence views in one call.
+ * An item is the run of k-mers that the reference's scan examines for one view:
+ *     k-mer start positions [start, start + n_kmers) of read `read` (0 = the read's first base).
+ * For a cached whole read view (seqio.go:115) n_kmers = len-k+1; for a top-level read with len%4==0 the
+ * reference examines 4 fewer k-mers and the caller passes n_kmers = len-k+1-4.
+ * Items whose hit count is >= min_seeds get their seed sequence written out as the reference's interleaved
+ * segments array [gap0, seed0, gap1, ..., gapN] (int32); others only report their count. */
+typedef struct {
+    uint32_t read;
+    uint32_t start;
+    uint32_t n_kmers;
+    uint32_t min_seeds;
+} dp_scan_item;
+
+typedef struct {
+    uint32_t n_items;
+    const uint32_t* n_seeds; /* [n_items] hits per item */
+    const uint64_t* seg_off; /* [n_items+1] offsets into segs (int32 units); empty range if below min_seeds */
+    const int32_t* segs;     /* host copy of all written segments */
+    uint64_t n_segs;
+    double kernel_ms;        /* device time of the scan kernels of this call (HIP events) */
+    uint64_t bases_scanned;  /* sum of n_kmers + k - 1 over items */
+} dp_seedseq_batch;
+
+int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items, dp_seedseq_batch* out);
+
+/* ---- A13: seed index build ------------------------------------------------------------------------------
+ * Replaces SeedIndex.AddSequence + IndexSequences/index (seeds/seeds.go:272-305,372-384).  Indexed sequence i
+ * is a view segs[seg_off .. seg_off + 2*n_seeds + 1) into the device-resident output of the last dp_scan
+ * (the chunks produced by overlap.chunkWorker are exactly such views, overlap/overlap.go:253-318).  Builds the
+ * posting bit-matrix (seed -> set of sequence indices) and the per-sequence seed bitsets. */
+typedef struct {
+    uint64_t seg_off;
+    uint32_t n_seeds;
+    uint32_t reserved;
+} dp_seq_ref;
+
+int dp_index_build(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs);
+
+/* ---- A14 + A5 + A6 + A7 + A8: index query and overlap chaining ---------------------------------------------
+ * Replaces overlapper.matchWorker (overlap/overlap.go:346-387) for all queries of a round:
+ *   SeedIndex.Matches -> util.GetSharedIDs (+ getSoftUnion{4,8,16}Asm semantics incl. threshold saturation and
+ *   the 16-ladder's step-8 behaviour) -> IntSet.CountIntersectionTo prefilter -> seedAligner.PairwiseAlignments
+ *   -> best-chain pick and the minMatches ratchet, candidates in ascending index order.
+ * Query q has segments q_segs[q_off[q] .. q_off[q+1]) (reference layout).  max_query_len is the aligner's buffer
+ * size NewSeedAligner(overlap/2) (overlap/overlap.go:349). */
+typedef struct {
+    uint32_t n_matches;
+    const uint32_t* query;    /* [n_matches] query index, ascending */
+    const uint32_t* target;   /* [n_matches] indexed-sequence index, ascending within a query */
+    const uint64_t* off;      /* [n_matches+1] offsets into match_a / match_b */
+    const int32_t* match_a;   /* query seed indices of the chain */
+    const int32_t* match_b;   /* target seed indices of the chain */
+    /* test hooks */
+    uint32_t n_queries;
+    const uint64_t* cand_off; /* [n_queries+1] */
+    const uint32_t* cand;     /* SeedIndex.Matches() output per query (ascending ids) */
+    double query_kernel_ms;   /* device time of the soft-union (index query) kernel */
+    double chain_kernel_ms;   /* device time of the prefilter+chaining kernel */
+    uint64_t query_bytes;     /* algorithmic bytes of the index query (posting words inside windows * 8) */
+} dp_match_batch;
+
+int dp_find_overlaps(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t n_queries,
+                     double hit_fraction, int k, uint32_t max_query_len, int want_candidates, dp_match_batch* out);
+
+/* ---- A19 + A20: map-flavour query (mapping.performMapping core) -----------------------------------------------
+ * For each window: Matches(0.25) candidates, CountIntersectionTo prefilter and SeedSequence.Match
+ * (Reduced x2 -> dynamicMatch -> extendChain; seeds/sequence.go:361-576) with the minMatches ratchet of
+ * mapping/mapping.go:494-549 (window pairs fwd/rc are linked: the fwd ratchet also raises the rc threshold).
+ * Windows come in (fwd, rc) pairs: window 2i is the forward query, 2i+1 its reverse complement. */
+typedef struct {
+    uint32_t n_chains;
+    const uint32_t* window;  /* [n_chains] window index */
+    const uint32_t* target;  /* [n_chains] indexed-sequence (reference chunk) index */
+    const uint64_t* off;     /* [n_chains+1] */
+    const int32_t* match_a;  /* window seed indices */
+    const int32_t* match_b;  /* target seed indices */
+    double kernel_ms;
+} dp_chain_batch;
+
+int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, uint32_t n_windows, int k,
+                   dp_chain_batch* out);
+
+/* ---- introspection for tests ---------------------------------------------------------------------------------- */
+/* posting row of `seed` (n_words = ceil(n_seqs/64)) and its popcount/start/end as the reference's IntSet holds. */
+int dp_index_posting_row(dp_ctx* ctx, uint32_t seed, uint64_t* words, uint32_t cap_words, uint32_t* n_words,
+                         uint32_t* count, uint32_t* start, uint32_t* end);
+int dp_index_seedset_row(dp_ctx* ctx, uint32_t seq, uint64_t* words, uint32_t cap_words, uint32_t* n_words);
+
+/* Device pointers of the last dp_scan output, for a multi-GPU exchange driven by the caller (RCCL all-gather of
+ * the survivors).  segs_dev: int32[n_segs]. */
+int dp_scan_device_buffers(dp_ctx* ctx, void** segs_dev, uint64_t* n_segs);
+/* Replace the device-resident scan output with externally gathered segments (host pointer). */
+int dp_scan_import_segments(dp_ctx* ctx, const int32_t* segs, uint64_t n_segs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOWNPORE_HIP_H */

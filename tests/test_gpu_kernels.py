@@ -1,0 +1,188 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): every HIP stage called through the C ABI
+(include/downpore_hip.h) is compared bit-for-bit with the ORACLE's per-round trace on the same seeded inputs.
+"""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import downpore_amd
+    c = downpore_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _case(seed, G, N, L, k, e=0.0, variable=False, rounds=2, **kw):
+    bases, off = O.gen_reads(seed, G, N, L, e, variable)
+    rs = O.ReadSet(bases, off, min_len=kw.get("overlap_size", 1000))
+    values = rs.kmer_values(k)
+    run = O.OverlapRun(rs, k=k, values=values, max_rounds=rounds, traces=True, **kw)
+    return bases, off, rs, values, run
+
+
+def _expected_segments(read_str, k, seed_kmers, start=None, end=None):
+    table = np.zeros(4 ** k, dtype=np.uint8)
+    table[seed_kmers] = 1
+    kmap = {int(km): i for i, km in enumerate(seed_kmers)}
+    s = O.Seq(read_str)
+    v = s.sub(0 if start is None else start, len(read_str) if end is None else end)
+    seg = v.write_segments(k, table)
+    seg[1::2] = [kmap[int(x)] for x in seg[1::2]]
+    return seg
+
+
+def test_pack_matches_reference_encoding(ctx):
+    bases, off = O.gen_reads(11, 20000, 37, 777, 0.0, True)
+    ctx.upload_reads(bases, off)
+    for r in (0, 1, 17, 36):
+        s = bases[off[r]:off[r + 1]].tobytes().decode()
+        want = O.Seq(s).bytes()
+        got = ctx.packed_read(r)
+        assert np.array_equal(want, got), r
+
+
+def test_histogram(ctx):
+    bases, off = O.gen_reads(12, 50000, 200, 1500, 0.01, True)
+    ctx.upload_reads(bases, off)
+    rs = O.ReadSet(bases, off, min_len=0)
+    for k in (6, 10):
+        assert np.array_equal(ctx.kmer_histogram(k), rs.kmer_counts(k))
+
+
+@pytest.mark.parametrize("k,G,N,L,e", [(10, 100000, 400, 5000, 0.0), (10, 60000, 300, 4000, 0.02),
+                                       (13, 1500000, 3000, 10000, 0.0)])
+def test_scan_index_query_chain(ctx, k, G, N, L, e):
+    bases, off, rs, values, run = _case(21 + k, G, N, L, k, e, rounds=2)
+    assert run.rounds >= 1
+    ctx.upload_reads(bases, off)
+    ignore = np.zeros(N, dtype=np.uint8)
+    for rnd in range(run.rounds):
+        seed_kmers = run.trace(rnd, "seedKmers")
+        ctx.round_begin(k, seed_kmers)
+
+        # ---- A2 + A10: whole reads (cached views) and the query windows
+        reads = [r for r in range(N) if not ignore[r]]
+        sample = reads[:: max(1, len(reads) // 60)]
+        items = [(r, 0, int(off[r + 1] - off[r]) - k + 1, 0) for r in sample]
+        qsegs, qoffs = run.trace(rnd, "querySegments")
+        qseq = run.trace(rnd, "querySeqIDs")
+        # forward queries are the even entries; windows = first/last 1000 bases of each read >= 2000 (overlap.go:61-80)
+        qitems, qexp = [], []
+        seen = {}
+        for qi in range(0, len(qseq), 2):
+            r = int(qseq[qi])
+            Lr = int(off[r + 1] - off[r])
+            n = seen.get(r, 0)
+            seen[r] = n + 1
+            if Lr < 2000:
+                st, en = 0, Lr
+            else:
+                st, en = (0, 1000) if n == 0 else (Lr - 1000, Lr)
+            qitems.append((r, st, en - st - k + 1, 0))
+            qexp.append(qsegs[qoffs[qi]:qoffs[qi + 1]])
+        res = ctx.scan(items + qitems)
+        so, sg = res["seg_off"], res["segs"]
+        for n, r in enumerate(sample):
+            want = _expected_segments(bases[off[r]:off[r + 1]].tobytes().decode(), k, seed_kmers)
+            got = sg[int(so[n]):int(so[n + 1])]
+            assert np.array_equal(want, got), ("read", r)
+            assert res["n_seeds"][n] == len(want) // 2
+        base = len(sample)
+        for n, want in enumerate(qexp):
+            got = sg[int(so[base + n]):int(so[base + n + 1])]
+            assert np.array_equal(want, got), ("query", n)
+
+        # min_seeds filter: counts reported, segments withheld
+        res2 = ctx.scan([(r, 0, int(off[r + 1] - off[r]) - k + 1, 15) for r in sample])
+        for n, r in enumerate(sample):
+            c = int(res2["n_seeds"][n])
+            ln = int(res2["seg_off"][n + 1] - res2["seg_off"][n])
+            assert ln == (2 * c + 1 if c >= 15 else 0)
+
+        # ---- A13: index over the oracle's indexed (chunked) sequences
+        isegs, ioffs = run.trace(rnd, "indexedSegments")
+        M = len(ioffs) - 1
+        ctx.import_segments(isegs)
+        nseeds = ((ioffs[1:] - ioffs[:-1]) // 2).astype(np.uint32)
+        ctx.index_build(ioffs[:-1].astype(np.uint64), nseeds)
+        S = len(seed_kmers)
+        post = [set() for _ in range(S)]
+        for i in range(M):
+            for s in isegs[ioffs[i] + 1:ioffs[i + 1]:2]:
+                post[int(s)].add(i)
+        for s in list(range(0, S, max(1, S // 40))):
+            words, cnt, st, en = ctx.posting_row(s)
+            ids = sorted(post[s])
+            got = [w * 64 + b for w in range(len(words)) for b in range(64) if (int(words[w]) >> b) & 1]
+            assert got == ids
+            assert cnt == len(ids)
+            if ids:
+                assert (st, en) == (ids[0] // 64, ids[-1] // 64)
+            else:
+                assert (st, en) == (1, 0)
+        for i in range(0, M, max(1, M // 20)):
+            words = ctx.seedset_row(i)
+            got = sorted(w * 64 + b for w in range(len(words)) for b in range(64) if (int(words[w]) >> b) & 1)
+            assert got == sorted(set(int(x) for x in isegs[ioffs[i] + 1:ioffs[i + 1]:2]))
+
+        # ---- A14/A5 candidates, A6/A7/A8 matches
+        out = ctx.find_overlaps(qsegs, qoffs.astype(np.uint64), 0.25, k, 500, want_candidates=True)
+        cdata, coffs = run.trace(rnd, "candidates")
+        assert np.array_equal(out["cand_off"].astype(np.int64), coffs)
+        assert np.array_equal(out["cand"].astype(np.int64), cdata)
+        mq = run.trace(rnd, "matchQueryIndex")
+        mt = run.trace(rnd, "matchTarget")
+        ma, mao = run.trace(rnd, "matchA")
+        mb, _ = run.trace(rnd, "matchB")
+        assert np.array_equal(out["query"].astype(np.int64), mq)
+        assert np.array_equal(out["target"].astype(np.int64), mt)
+        assert np.array_equal(out["off"].astype(np.int64), mao)
+        assert np.array_equal(out["match_a"].astype(np.int64), ma)
+        assert np.array_equal(out["match_b"].astype(np.int64), mb)
+
+        for r in run.trace(rnd, "newlyIgnored"):
+            ignore[int(r)] = 1
+
+
+def test_scan_top_level_len_mod4_quirk(ctx):
+    """himem=false re-reads are top-level sequences: with len%4==0 the reference examines 4 fewer k-mers
+    (SURVEY §8(a) A2(i)); the caller encodes that in n_kmers and the final gap follows."""
+    k = 10
+    bases, off = O.gen_reads(5, 30000, 50, 1200, 0.0, False)  # 1200 % 4 == 0
+    ctx.upload_reads(bases, off)
+    rng = np.random.default_rng(1)
+    seed_kmers = np.unique(rng.integers(1, 4 ** k, 4000)).astype(np.int64)
+    ctx.round_begin(k, seed_kmers)
+    table = np.zeros(4 ** k, dtype=np.uint8)
+    table[seed_kmers] = 1
+    kmap = {int(km): i for i, km in enumerate(seed_kmers)}
+    items = [(r, 0, 1200 - k + 1 - 4, 0) for r in range(50)]
+    res = ctx.scan(items)
+    for r in range(50):
+        s = O.Seq(bases[off[r]:off[r + 1]].tobytes().decode())  # top level, finalLen == 0
+        want = s.write_segments(k, table)
+        want[1::2] = [kmap[int(x)] for x in want[1::2]]
+        got = res["segs"][int(res["seg_off"][r]):int(res["seg_off"][r + 1])]
+        assert np.array_equal(want, got)
+
+
+def test_empty_and_ragged(ctx):
+    k = 10
+    bases, off = O.gen_reads(6, 30000, 20, 900, 0.0, True)
+    ctx.upload_reads(bases, off)
+    ctx.round_begin(k, np.zeros(0, dtype=np.uint32))
+    res = ctx.scan(np.zeros((0, 4), dtype=np.uint32))
+    assert len(res["n_seeds"]) == 0
+    items = [(r, 0, int(off[r + 1] - off[r]) - k + 1, 0) for r in range(20)]
+    res = ctx.scan(items)
+    assert res["n_seeds"].sum() == 0
+    for r in range(20):  # no seeds: single gap = bases scanned
+        assert res["segs"][int(res["seg_off"][r])] == off[r + 1] - off[r]
+    ctx.index_build(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+    out = ctx.find_overlaps(np.array([5], dtype=np.int32), np.array([0, 1], dtype=np.uint64), 0.25, k, 500, True)
+    assert len(out["query"]) == 0
