@@ -198,6 +198,14 @@ class Overlapper {
     std::vector<int32_t> allSegs_;         // survivors' segments (host copy; device copy is what the index references)
 };
 
+// finalCheckWorker (commands/overlap.go:197-233) over the collated matches of a round: consensus, SetIgnore, PAF text.
+struct FinalCheckStats {
+    i64 badBack = 0, emptyMatch = 0;
+    uint64_t lines = 0, hits = 0, qHits = 0;
+};
+void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vector<std::unique_ptr<SeedMatch>>& matches,
+                i64 numQuerySeqs, i64 overlapSize, std::string& paf, FinalCheckStats& fs);
+
 // ---- command driver (commands/overlap.go:96-233) ------------------------------------------------------------------
 struct OverlapRun {
     dp_ctx* ctx = nullptr;

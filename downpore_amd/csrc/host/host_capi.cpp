@@ -1,0 +1,229 @@
+// C entry points of libdownpore_host.so: lets Python (bench.py, tests) drive the product's host pipeline round by
+// round, interposing the multi-GPU survivor exchange between the local scan and the index build.
+#include <cstring>
+
+#include "dph.hpp"
+
+using namespace dph;
+
+namespace {
+struct ReadsH {
+    ReadSet set;
+};
+struct OverlapH {
+    OverlapRun run;
+    dp_ctx* ctx = nullptr;
+    std::string err;
+    std::string allPaf;
+};
+thread_local std::string g_err;
+}  // namespace
+
+extern "C" {
+
+const char* dph_last_error(void* h) { return h ? ((OverlapH*)h)->err.c_str() : g_err.c_str(); }
+
+void* dph_reads_from_arrays(const char* bases, const int64_t* off, int64_t n, int64_t minLen, int himem) {
+    return new ReadsH{ReadSet::fromArrays(bases, off, (size_t)n, minLen, himem != 0)};
+}
+void* dph_reads_from_fasta(const char* path, int64_t minLen, int himem) {
+    ReadsH* h = new ReadsH();
+    if (!ReadSet::fromFile(path, minLen, himem != 0, h->set, g_err)) {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+void dph_reads_free(void* h) { delete (ReadsH*)h; }
+int64_t dph_reads_count(void* h) { return (int64_t)((ReadsH*)h)->set.size(); }
+void dph_reads_get_ignore(void* h, uint8_t* out) {
+    auto& ig = ((ReadsH*)h)->set.ignore;
+    memcpy(out, ig.data(), ig.size());
+}
+void dph_reads_reset_ignore(void* h) {
+    auto& ig = ((ReadsH*)h)->set.ignore;
+    std::fill(ig.begin(), ig.end(), 0);
+}
+int64_t dph_reads_total_bases(void* h) { return (int64_t)((ReadsH*)h)->set.bases.size(); }
+
+// params: overlapSize,k,numSeeds,seedBatchSize,chunkSize,queryBatchSize,himem
+void* dph_overlap_create(void* reads, int device, const int64_t* params, double minHits, const double* valuesOrNull) {
+    OverlapH* h = new OverlapH();
+    ReadSet& rs = ((ReadsH*)reads)->set;
+    int rc = dp_ctx_create(device, &h->ctx);
+    if (rc != 0) {
+        g_err = dp_last_error(nullptr);
+        delete h;
+        return nullptr;
+    }
+    OverlapParams p;
+    p.overlapSize = params[0];
+    p.k = (int)params[1];
+    p.numSeeds = (int)params[2];
+    p.seedBatchSize = params[3];
+    p.chunkSize = params[4];
+    p.queryBatchSize = params[5];
+    p.himem = params[6] != 0;
+    p.minHits = minHits;
+    rc = dp_reads_upload(h->ctx, (const uint8_t*)rs.bases.data(), rs.off.data(), (uint32_t)rs.size());
+    if (rc == 0) rc = h->run.init(h->ctx, &rs, p, valuesOrNull);
+    if (rc != 0) {
+        g_err = h->run.error.empty() ? dp_last_error(h->ctx) : h->run.error;
+        dp_ctx_destroy(h->ctx);
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+void dph_overlap_destroy(void* hh) {
+    OverlapH* h = (OverlapH*)hh;
+    if (!h) return;
+    h->run.lap.reset();
+    h->run.index.reset();
+    dp_ctx_destroy(h->ctx);
+    delete h;
+}
+void dph_overlap_set_shard(void* hh, int64_t lo, int64_t hi) {
+    OverlapH* h = (OverlapH*)hh;
+    h->run.shardLo = (size_t)lo;
+    h->run.shardHi = (size_t)hi;
+}
+const double* dph_overlap_values(void* hh, int64_t* n) {
+    OverlapH* h = (OverlapH*)hh;
+    *n = (int64_t)h->run.values.size();
+    return h->run.values.data();
+}
+// 1 = a round was prepared and the local shard scanned; 0 = no more rounds; <0 error
+int dph_overlap_round_scan(void* hh) {
+    OverlapH* h = (OverlapH*)hh;
+    int rc = h->run.roundPrepareAndScan();
+    if (rc < 0) h->err = h->run.error;
+    return rc;
+}
+void dph_overlap_local(void* hh, const uint32_t** read, const uint32_t** nseeds, const uint64_t** segoff,
+                       const int32_t** segs, uint64_t* n, uint64_t* nsegs) {
+    Survivors& s = ((OverlapH*)hh)->run.local;
+    *read = s.read.data();
+    *nseeds = s.n_seeds.data();
+    *segoff = s.seg_off.data();
+    *segs = s.segs.data();
+    *n = s.read.size();
+    *nsegs = s.segs.size();
+}
+// survivors == all ranks' lists concatenated in rank order (read ids ascending); read == NULL: use the local list
+int dph_overlap_round_finish(void* hh, const uint32_t* read, const uint32_t* nseeds, const int32_t* segs, uint64_t n) {
+    OverlapH* h = (OverlapH*)hh;
+    int rc;
+    if (!read) {
+        rc = h->run.roundFinish(h->run.local);
+    } else {
+        Survivors all;
+        all.read.assign(read, read + n);
+        all.n_seeds.assign(nseeds, nseeds + n);
+        all.seg_off.assign(1, 0);
+        uint64_t pos = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            pos += 2ull * nseeds[i] + 1;
+            all.seg_off.push_back(pos);
+        }
+        all.segs.assign(segs, segs + pos);
+        rc = h->run.roundFinish(all);
+    }
+    if (rc < 0) h->err = h->run.error;
+    else h->allPaf += h->run.paf;
+    return rc;
+}
+const char* dph_overlap_round_paf(void* hh, int64_t* n) {
+    OverlapH* h = (OverlapH*)hh;
+    *n = (int64_t)h->run.paf.size();
+    return h->run.paf.data();
+}
+const char* dph_overlap_all_paf(void* hh, int64_t* n) {
+    OverlapH* h = (OverlapH*)hh;
+    *n = (int64_t)h->allPaf.size();
+    return h->allPaf.data();
+}
+const char* dph_overlap_errtext(void* hh, int64_t* n) {
+    OverlapH* h = (OverlapH*)hh;
+    *n = (int64_t)h->run.errText.size();
+    return h->run.errText.data();
+}
+// out[0..] t_prepare,t_scan,t_index,t_query,t_consensus,k_scan_ms,k_query_ms,k_chain_ms,scan_bases,scan_items,
+// scan_bytes,query_bytes,n_queries,n_indexed,n_hits,n_matches,n_paf,n_seeds,round,badBack,emptyMatch
+void dph_overlap_stats(void* hh, double* out) {
+    OverlapH* h = (OverlapH*)hh;
+    const RoundStats& s = h->run.last;
+    double v[] = {s.t_prepare, s.t_scan, s.t_index, s.t_query, s.t_consensus, s.k_scan_ms, s.k_query_ms, s.k_chain_ms,
+                  (double)s.scan_bases, (double)s.scan_items, (double)s.scan_bytes, (double)s.query_bytes, (double)s.n_queries,
+                  (double)s.n_indexed, (double)s.n_hits, (double)s.n_matches, (double)s.n_paf, (double)s.n_seeds,
+                  (double)h->run.round, (double)h->run.badBack, (double)h->run.emptyMatch};
+    memcpy(out, v, sizeof v);
+}
+void* dph_overlap_ctx(void* hh) { return ((OverlapH*)hh)->ctx; }
+
+}  // extern "C"
+
+// ---- host-logic test hook (no GPU needed): finalCheckWorker over externally supplied matches ----------------------
+// Queries and indexed sequences come as flat arrays in the reference's segment layout; matches as (query index,
+// target index, MatchA, MatchB).  Returns the PAF text of the round and applies SetIgnore to `reads`.
+extern "C" const char* dph_finalcheck(void* readsH, int k, int64_t overlapSize, const uint32_t* seedKmers, int64_t nSeeds,
+                                      const int32_t* qSegs, const int64_t* qOff, const int64_t* qId, const int64_t* qSeqId,
+                                      const int64_t* qLen, const int64_t* qOffset, const int64_t* qInset, int64_t nQ,
+                                      const int32_t* iSegs, const int64_t* iOff, const int64_t* iId, const int64_t* iLen,
+                                      const int64_t* iOffset, const int64_t* iInset, int64_t nI, const int64_t* mQuery,
+                                      const int64_t* mTarget, const int64_t* mOff, const int32_t* mA, const int32_t* mB,
+                                      int64_t nM, int64_t numQuerySeqs, int64_t* outLen, int64_t* outStats) {
+    static thread_local std::string paf;
+    ReadSet& reads = ((ReadsH*)readsH)->set;
+    SeedIndex index(k);
+    for (int64_t i = 0; i < nSeeds; i++) index.addSeedKmer(seedKmers[i]);
+    Arena& ar = index.arena;
+    std::vector<SeedSeq*> qs, is;
+    for (int64_t q = 0; q < nQ; q++) {
+        SeedSeq* s = ar.make();
+        s->seg = qSegs + qOff[q];
+        s->n = (int)(qOff[q + 1] - qOff[q]);
+        s->id = (int)qSeqId[q];
+        s->length = qLen[q];
+        s->offset = qOffset[q];
+        s->inset = qInset[q];
+        s->rc = (q & 1) != 0;
+        qs.push_back(s);
+    }
+    for (int64_t q = 0; q + 1 < nQ; q += 2) qs[(size_t)q + 1]->reverseComplement = qs[(size_t)q];  // rc query -> fwd (sequence.go:157)
+    for (int64_t i = 0; i < nI; i++) {
+        SeedSeq* root = ar.make();
+        root->length = reads.length((size_t)iId[i]);
+        root->id = (int)iId[i];
+        SeedSeq* s = ar.make();
+        s->seg = iSegs + iOff[i];
+        s->n = (int)(iOff[i + 1] - iOff[i]);
+        s->id = (int)iId[i];
+        s->length = iLen[i];
+        s->offset = iOffset[i];
+        s->inset = iInset[i];
+        s->parent = root;
+        is.push_back(s);
+    }
+    std::vector<std::unique_ptr<SeedMatch>> matches;
+    for (int64_t m = 0; m < nM; m++) {
+        std::unique_ptr<SeedMatch> sm(new SeedMatch());
+        sm->MatchA.assign(mA + mOff[m], mA + mOff[m + 1]);
+        sm->MatchB.assign(mB + mOff[m], mB + mOff[m + 1]);
+        sm->SeqA = qs[(size_t)mQuery[m]];
+        sm->SeqB = is[(size_t)mTarget[m]];
+        sm->QueryID = (int)qId[mQuery[m]];
+        sm->ReverseComplementQuery = (mQuery[m] & 1) != 0;
+        matches.push_back(std::move(sm));
+    }
+    FinalCheckStats fs;
+    paf.clear();
+    finalCheck(ar, index, reads, matches, numQuerySeqs, overlapSize, paf, fs);
+    if (outStats) {
+        outStats[0] = fs.badBack;
+        outStats[1] = fs.emptyMatch;
+        outStats[2] = (int64_t)fs.lines;
+    }
+    *outLen = (int64_t)paf.size();
+    return paf.data();
+}

@@ -1,0 +1,440 @@
+// Product host side: overlap.Overlapper (overlap/overlap.go) and the overlap command's round loop
+// (commands/overlap.go:96-233) above the C ABI.  Canonical single-worker order (DESIGN.md §canonical semantics).
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+#include "dph.hpp"
+
+namespace dph {
+
+static double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+Overlapper::Overlapper(dp_ctx* ctx, ReadSet& reads, SeedIndex& index, i64 chunkSize, int, i64 overlap, int minSeeds,
+                       double hitFraction)
+    : ctx_(ctx), reads_(reads), index_(index), chunkSize_(chunkSize), overlap_(overlap), minSeeds_(minSeeds),
+      hitFraction_(hitFraction) {}
+
+// PrepareQueries :157-214 with getEdges :55-89 (QueryEdges): seed selection is sequential and stays on the host.
+// Returns the number of query windows.
+int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values, i64 firstSequence, i64 maxSeqs) {
+    windows_.clear();
+    queries.clear();
+    i64 sent = 0;
+    if (!(firstSequence != 0 && firstSequence >= (i64)reads_.size())) {  // seqio.go:279
+        for (size_t r = (size_t)firstSequence; r < reads_.size() && sent < maxSeqs; r++) {
+            if (reads_.ignore[r]) continue;
+            sent++;
+            if (index_.size() >= seedLimit) break;  // overlap.go:58
+            const i64 L = reads_.length(r);
+            const char* s = reads_.seq(r);
+            if (L < overlap_ * 2) {
+                index_.addSeeds(s, L, numSeeds, values);
+                windows_.push_back({(uint32_t)r, 0u, (uint32_t)L});
+            } else {
+                index_.addSeeds(s, overlap_, numSeeds, values);
+                index_.addSeeds(s + (L - overlap_), overlap_, numSeeds, values);
+                windows_.push_back({(uint32_t)r, 0u, (uint32_t)overlap_});
+                windows_.push_back({(uint32_t)r, (uint32_t)(L - overlap_), (uint32_t)overlap_});
+            }
+        }
+    }
+    return (int)windows_.size();
+}
+
+// AddSequences :217 (scan part).  One dp_scan call: every non-ignored read of this process's shard (segments only for
+// reads with >= minSeeds hits: chunkWorker drops the others, :259-261) followed by all query windows.
+int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st) {
+    const int k = index_.k;
+    std::vector<dp_scan_item> items;
+    std::vector<uint32_t> itemRead;
+    for (size_t r = lo; r < hi; r++) {
+        if (reads_.ignore[r]) continue;
+        dp_scan_item it;
+        it.read = (uint32_t)r;
+        it.start = 0;
+        it.n_kmers = (uint32_t)reads_.scanKmers(r, k);
+        it.min_seeds = (uint32_t)minSeeds_;
+        items.push_back(it);
+        itemRead.push_back((uint32_t)r);
+    }
+    const size_t nReads = items.size();
+    for (const Window& w : windows_) {
+        dp_scan_item it;
+        it.read = w.read;
+        it.start = w.start;
+        // a window is a SubSequence view (finalLen in 1..4): the scan examines len-k+1 k-mers; the whole-read window of a
+        // short read served top-level (himem=false) inherits the len%4 quirk
+        i64 nk = (i64)w.len - k + 1;
+        if (!reads_.himem && w.start == 0 && (i64)w.len == reads_.length(w.read) && (w.len % 4) == 0) nk -= 4;
+        it.n_kmers = (uint32_t)std::max<i64>(0, nk);
+        it.min_seeds = 0;
+        items.push_back(it);
+    }
+    dp_seedseq_batch b;
+    int rc = dp_scan(ctx_, items.data(), (uint32_t)items.size(), &b);
+    if (rc != 0) {
+        err = dp_last_error(ctx_);
+        return rc;
+    }
+    st.k_scan_ms += b.kernel_ms;
+    st.scan_bases += b.bases_scanned;
+    st.scan_items += items.size();
+    // survivors of the local shard (ascending read id)
+    local.read.clear();
+    local.n_seeds.clear();
+    local.seg_off.assign(1, 0);
+    local.segs.clear();
+    for (size_t i = 0; i < nReads; i++) {
+        if (b.n_seeds[i] < (uint32_t)minSeeds_) continue;
+        local.read.push_back(itemRead[i]);
+        local.n_seeds.push_back(b.n_seeds[i]);
+        local.segs.insert(local.segs.end(), b.segs + b.seg_off[i], b.segs + b.seg_off[i + 1]);
+        local.seg_off.push_back(local.segs.size());
+    }
+    // query windows
+    winSegs_.clear();
+    winOff_.assign(1, 0);
+    for (size_t i = nReads; i < items.size(); i++) {
+        winSegs_.insert(winSegs_.end(), b.segs + b.seg_off[i], b.segs + b.seg_off[i + 1]);
+        winOff_.push_back(winSegs_.size());
+    }
+    // hits written this scan, for the roofline's algorithmic bytes
+    st.n_hits += (b.n_segs - (uint64_t)0) / 2;
+    return 0;
+}
+
+// chunkWorker :253-318 for one seed sequence whose segments start at device offset segBase
+void Overlapper::chunkAndAdd(SeedSeq* s, uint64_t segBase) {
+    const int k = index_.k;
+    Arena& ar = index_.arena;
+    auto add = [&](SeedSeq* q) {
+        index_.sequences.push_back(q);
+        dp_seq_ref r;
+        r.seg_off = segBase + (uint64_t)(q->seg - s->seg);
+        r.n_seeds = (uint32_t)q->numSeeds();
+        r.reserved = 0;
+        index_.refs.push_back(r);
+    };
+    const i64 numChunks = s->length / chunkSize_ + 1;
+    if (numChunks == 1 || s->numSeeds() < minSeeds_ * 3) {
+        if (s->numSeeds() >= minSeeds_) add(s);
+        return;
+    }
+    int prevSeedIndex = 0;
+    i64 totalOffset = s->seedOffset(0, k);
+    i64 lengthInBases = 0;
+    for (;;) {
+        int seedCount = 0;
+        if (prevSeedIndex >= s->numSeeds() - 150) {
+            if (prevSeedIndex == 0) {
+                add(s);
+            } else {
+                const i64 newFirstGap = s->nextSeedOffset(prevSeedIndex - 1, k) - k;
+                lengthInBases += s->seedOffsetFromEnd(prevSeedIndex, k) + k + newFirstGap;
+                add(seqSubSequence(ar, s, prevSeedIndex, s->numSeeds() - 1, lengthInBases, totalOffset - newFirstGap, 0));
+            }
+            break;
+        }
+        for (; lengthInBases < chunkSize_ && seedCount < 100 && prevSeedIndex + seedCount < s->numSeeds(); seedCount++)
+            lengthInBases += s->nextSeedOffset(prevSeedIndex + seedCount, k);
+        if (seedCount >= minSeeds_) {
+            const i64 newFirstGap = s->nextSeedOffset(prevSeedIndex - 1, k) - k;
+            lengthInBases += newFirstGap;
+            add(seqSubSequence(ar, s, prevSeedIndex, prevSeedIndex + seedCount - 1, lengthInBases, totalOffset - newFirstGap,
+                               s->length - totalOffset - lengthInBases + newFirstGap));
+            totalOffset += lengthInBases - newFirstGap;
+            lengthInBases = 0;
+            prevSeedIndex += seedCount;
+            if (prevSeedIndex >= s->numSeeds()) break;
+            for (seedCount = 0; seedCount < 5 && lengthInBases < overlap_ / 2 && prevSeedIndex > 0; seedCount++) {
+                prevSeedIndex--;
+                const i64 step = s->nextSeedOffset(prevSeedIndex, k);
+                lengthInBases += step;
+                totalOffset -= step;
+            }
+            lengthInBases = 0;
+        } else {
+            prevSeedIndex += seedCount;
+            for (seedCount = 0; lengthInBases < overlap_ / 2 && prevSeedIndex > 0; seedCount++) {
+                prevSeedIndex--;
+                const i64 step = s->nextSeedOffset(prevSeedIndex, k);
+                lengthInBases += step;
+                totalOffset -= step;
+            }
+            lengthInBases = 0;
+        }
+    }
+}
+
+// AddSequences :217 (chunk + index part) from the complete survivor list (file order).
+int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
+    allSegs_ = all.segs;
+    // the device-resident scan output the index refers to must be exactly this survivor array
+    int rc = dp_scan_import_segments(ctx_, allSegs_.data(), allSegs_.size());
+    if (rc != 0) {
+        err = dp_last_error(ctx_);
+        return rc;
+    }
+    index_.sequences.clear();
+    index_.refs.clear();
+    for (size_t i = 0; i < all.read.size(); i++) {
+        const uint32_t r = all.read[i];
+        SeedSeq* s = index_.arena.make();
+        s->seg = allSegs_.data() + all.seg_off[i];
+        s->n = (int)(all.seg_off[i + 1] - all.seg_off[i]);
+        s->id = (int)r;
+        s->length = reads_.length(r);
+        s->offset = 0;
+        s->inset = reads_.servedInset();
+        chunkAndAdd(s, all.seg_off[i]);
+    }
+    rc = dp_index_build(ctx_, index_.refs.data(), (uint32_t)index_.refs.size());
+    if (rc != 0) {
+        err = dp_last_error(ctx_);
+        return rc;
+    }
+    st.n_indexed = index_.refs.size();
+    // queries: [fwd, rc] per window (PrepareQueries :189-201)
+    queries.clear();
+    int queryID = 0;
+    for (size_t w = 0; w < windows_.size(); w++) {
+        const Window& win = windows_[w];
+        SeedSeq* s = index_.arena.make();
+        s->seg = winSegs_.data() + winOff_[w];
+        s->n = (int)(winOff_[w + 1] - winOff_[w]);
+        s->id = (int)win.read;
+        s->length = win.len;
+        const i64 L = reads_.length(win.read);
+        if (win.start == 0 && (i64)win.len == L) {  // the served view itself
+            s->offset = 0;
+            s->inset = reads_.servedInset();
+        } else {  // SubSequence(start, start+len) of the served view (sequence.go:353-370)
+            s->offset = win.start;
+            s->inset = reads_.servedInset() + L - ((i64)win.start + win.len - 1);
+        }
+        SeedQuery q;
+        q.ID = queryID;
+        q.SequenceID = s->id;
+        q.Query = s;
+        q.ReverseComplement = false;
+        queries.push_back(q);
+        SeedQuery rcq = q;
+        rcq.Query = seqReverseComplement(index_.arena, s, index_);
+        rcq.ReverseComplement = true;
+        queries.push_back(rcq);
+        queryID++;
+    }
+    st.n_queries = queries.size();
+    return 0;
+}
+
+// FindOverlaps :320 + matchWorker :346
+int Overlapper::FindOverlaps(std::vector<std::unique_ptr<SeedMatch>>& out, RoundStats& st) {
+    querySegs_.clear();
+    queryOff_.assign(1, 0);
+    for (const SeedQuery& q : queries) {
+        querySegs_.insert(querySegs_.end(), q.Query->seg, q.Query->seg + q.Query->n);
+        queryOff_.push_back(querySegs_.size());
+    }
+    dp_match_batch mb;
+    int rc = dp_find_overlaps(ctx_, querySegs_.data(), queryOff_.data(), (uint32_t)queries.size(), hitFraction_, index_.k,
+                              (uint32_t)(overlap_ / 2), 0, &mb);
+    if (rc != 0) {
+        err = dp_last_error(ctx_);
+        return rc;
+    }
+    st.k_query_ms += mb.query_kernel_ms;
+    st.k_chain_ms += mb.chain_kernel_ms;
+    st.query_bytes += mb.query_bytes;
+    out.clear();
+    out.reserve(mb.n_matches);
+    for (uint32_t i = 0; i < mb.n_matches; i++) {
+        std::unique_ptr<SeedMatch> m(new SeedMatch());
+        const SeedQuery& q = queries[mb.query[i]];
+        m->MatchA.assign(mb.match_a + mb.off[i], mb.match_a + mb.off[i + 1]);
+        m->MatchB.assign(mb.match_b + mb.off[i], mb.match_b + mb.off[i + 1]);
+        m->SeqA = q.Query;
+        m->SeqB = index_.sequences[mb.target[i]];
+        m->QueryID = q.ID;
+        m->ReverseComplementQuery = q.ReverseComplement;
+        out.push_back(std::move(m));
+    }
+    st.n_matches = out.size();
+    return 0;
+}
+
+// finalCheckWorker commands/overlap.go:197-233 (+ collation :158-173)
+void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vector<std::unique_ptr<SeedMatch>>& matches,
+                i64 numQuerySeqs, i64 overlapSize, std::string& paf, FinalCheckStats& fs) {
+    // collate by QueryID (:158-173)
+    std::vector<std::vector<SeedMatch*>> queryResults((size_t)numQuerySeqs);
+    i64 hits = 0, qHits = 0;
+    for (auto& m : matches) {
+        hits++;
+        auto& qr = queryResults[(size_t)m->QueryID];
+        if (qr.size() == 1) qHits++;
+        qr.push_back(m.get());
+    }
+    // finalCheckWorker :197-233
+    const int k = index.k;
+    uint64_t lines = 0;
+    for (auto& results : queryResults) {
+        if (results.size() <= 1) continue;
+        std::unique_ptr<SeedContig> contig = buildConsensus(arena, index, results, &fs.badBack);
+        if (!contig || contig->Parts.size() <= 1) continue;
+        if (contig->SeqLengths[0] <= overlapSize * 2) reads.ignore[(size_t)contig->Parts[0]] = 1;
+        const i64 queryStart = contig->Offsets[0], queryEnd = queryStart + contig->Lengths[0];
+        for (size_t i = 0; i + 1 < contig->Parts.size(); i++) {
+            const size_t id = i + 1;
+            const int part = contig->Parts[id];
+            const i64 start = contig->Offsets[id], end = start + contig->Lengths[id];
+            const char* rcs = contig->ReverseComplement[0] != contig->ReverseComplement[id] ? "-" : "+";
+            i64 covered = overlapSize;
+            if (end - start > overlapSize) covered = end - start;
+            if (contig->SeqLengths[id] * 9 <= covered * 10) reads.ignore[(size_t)part] = 1;
+            i64 ident = 0, identB = 0;
+            bool panic = false;
+            matchBasesCovered(*contig->Matches[i], k, &ident, &identB, &panic);
+            if (panic) fs.emptyMatch++;  // the reference panics here; canonical: ident 0
+            paf += reads.names[(size_t)contig->Parts[0]];
+            paf += '\t';
+            paf += std::to_string(contig->SeqLengths[0]);
+            paf += '\t';
+            paf += std::to_string(queryStart);
+            paf += '\t';
+            paf += std::to_string(queryEnd);
+            paf += '\t';
+            paf += rcs;
+            paf += '\t';
+            paf += reads.names[(size_t)part];
+            paf += '\t';
+            paf += std::to_string(contig->SeqLengths[id]);
+            paf += '\t';
+            paf += std::to_string(start);
+            paf += '\t';
+            paf += std::to_string(end);
+            paf += '\t';
+            paf += std::to_string(ident);
+            paf += "\t0\t255\n";
+            lines++;
+        }
+    }
+    fs.lines = lines;
+    fs.hits = (uint64_t)hits;
+    fs.qHits = (uint64_t)qHits;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// commands/overlap.go Run :96-195
+
+int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const double* valuesOrNull) {
+    ctx = c;
+    reads = r;
+    p = params;
+    reads->himem = p.himem;
+    char line[160];
+    snprintf(line, sizeof line, "Counting all %d-mers in the input...\n", p.k);
+    errText += line;
+    if (valuesOrNull) {
+        values.assign(valuesOrNull, valuesOrNull + ((size_t)1 << (2 * p.k)));
+    } else {
+        std::vector<uint64_t> counts((size_t)1 << (2 * p.k));
+        int rc = dp_kmer_histogram(ctx, p.k, counts.data());  // KmerOccurrences on the GPU
+        if (rc != 0) {
+            error = dp_last_error(ctx);
+            return rc;
+        }
+        values = kmerValuesFromCounts(counts, p.k);
+    }
+    errText += "Counting complete. Starting indexing and querying...";
+    index.reset(new SeedIndex(p.k));
+    firstSequence = 0;
+    round = 0;
+    done = false;
+    shardLo = 0;
+    shardHi = reads->size();
+    return 0;
+}
+
+int OverlapRun::roundPrepareAndScan() {
+    if (done) return 0;
+    last = RoundStats();
+    paf.clear();
+    double t0 = now();
+    index->reset();  // seeds.NewSeedIndex(k) per round (:125) — sparse reset instead of reallocating 4^k tables
+    lap.reset(new Overlapper(ctx, *reads, *index, p.chunkSize, p.numWorkers, p.overlapSize, p.numSeeds, p.minHits));
+    int nw = lap->PrepareQueries(p.numSeeds, p.seedBatchSize, values.data(), firstSequence, p.queryBatchSize);
+    if (nw == 0) {  // len(queries) == 0 (:130)
+        done = true;
+        return 0;
+    }
+    int rc = dp_round_begin(ctx, p.k, index->seedMap.data(), (uint32_t)index->seedMap.size());
+    if (rc != 0) {
+        error = dp_last_error(ctx);
+        return rc;
+    }
+    last.n_seeds = index->seedMap.size();
+    double t1 = now();
+    last.t_prepare = t1 - t0;
+    rc = lap->ScanLocal(shardLo, shardHi, local, last);
+    if (rc != 0) {
+        error = lap->err;
+        return rc;
+    }
+    last.t_scan = now() - t1;
+    return 1;
+}
+
+int OverlapRun::roundFinish(const Survivors& all) {
+    double t0 = now();
+    int rc = lap->IndexSurvivors(all, last);
+    if (rc != 0) {
+        error = lap->err;
+        return rc;
+    }
+    // firstSequence / numQuerySeqs (:134-143)
+    numQuerySeqs = 0;
+    firstSequence = lap->queries.back().SequenceID + 1;
+    for (const SeedQuery& q : lap->queries) {
+        if (q.ID >= numQuerySeqs) numQuerySeqs = q.ID + 1;
+        if (q.SequenceID >= firstSequence) firstSequence = q.SequenceID + 1;
+    }
+    char line[200];
+    if (round == 0)
+        snprintf(line, sizeof line, "Using query sets of around %lld sequences against %lld sequences.\n", (long long)firstSequence,
+                 (long long)reads->size());
+    else
+        snprintf(line, sizeof line, "Using query set with %lld  sequences starting from %lld sequences against %lld sequences.\n",
+                 (long long)numQuerySeqs, (long long)firstSequence, (long long)reads->size());
+    errText += line;
+    double t1 = now();
+    last.t_index = t1 - t0;
+    std::vector<std::unique_ptr<SeedMatch>> matches;
+    rc = lap->FindOverlaps(matches, last);
+    if (rc != 0) {
+        error = lap->err;
+        return rc;
+    }
+    double t2 = now();
+    last.t_query = t2 - t1;
+    FinalCheckStats fs;
+    finalCheck(index->arena, *index, *reads, matches, numQuerySeqs, p.overlapSize, paf, fs);
+    badBack += fs.badBack;
+    emptyMatch += fs.emptyMatch;
+    snprintf(line, sizeof line, "Total %lld hits across %lld overlaps.\n", (long long)fs.hits, (long long)fs.qHits);
+    errText += line;
+    const int k = p.k;
+    const uint64_t lines = fs.lines;
+    last.n_paf = lines;
+    last.t_consensus = now() - t2;
+    // algorithmic bytes of the scan: packed bytes of the scanned items + bit table + 8 B per hit
+    last.scan_bytes = last.scan_bases / 4 + (((uint64_t)1 << (2 * k)) / 8) + 8 * last.n_hits;
+    round++;
+    return 0;
+}
+
+}  // namespace dph

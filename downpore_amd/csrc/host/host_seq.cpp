@@ -1,0 +1,811 @@
+// Host-side seed space for the product (see dph.hpp): read set, value table, seed selection, SeedSequence
+// operations, seed-space consensus and contig building.  File:line citations are into the reference.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "dph.hpp"
+
+namespace dph {
+
+// ---------------------------------------------------------------------------------------------------------------
+// sequence/seqio.go readFasta :106-276 (FASTA subset: single-line sequences)
+
+static std::string trimSpace(const std::string& s) {
+    size_t a = 0, b = s.size();
+    auto sp = [](unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; };
+    while (a < b && sp((unsigned char)s[a])) a++;
+    while (b > a && sp((unsigned char)s[b - 1])) b--;
+    return s.substr(a, b - a);
+}
+
+// `line` is one ReadBytes('\n') result including its last byte; kept iff len(line) >= minLen; the stored sequence
+// drops the last byte (seqio.go:210-219).
+void ReadSet::addLine(const std::string& lastName, const char* line, size_t len, i64 minLen) {
+    if ((i64)len >= minLen) {
+        if (off.empty()) off.push_back(0);
+        names.push_back(trimSpace(lastName));
+        bases.append(line, len - 1);
+        off.push_back((i64)bases.size());
+        ignore.push_back(0);
+    }
+}
+
+bool ReadSet::fromFile(const std::string& path, i64 minLen, bool himem, ReadSet& f, std::string& err) {
+    f = ReadSet();
+    f.himem = himem;
+    f.off.push_back(0);
+    std::ifstream in(path, std::ios::binary);
+    if (!in) {
+        err = "cannot open " + path;
+        return false;
+    }
+    std::stringstream ss;
+    ss << in.rdbuf();
+    const std::string all = ss.str();
+    size_t pos = 0;
+    auto next = [&](size_t& b, size_t& e) -> bool {
+        if (pos >= all.size()) return false;
+        size_t nl = all.find('\n', pos);
+        b = pos;
+        e = (nl == std::string::npos) ? all.size() : nl + 1;
+        pos = e;
+        return true;
+    };
+    size_t b, e;
+    if (!next(b, e) || all[e - 1] != '\n') return true;  // :191-196 first line is always a name line
+    std::string lastName = all.substr(b + 1, e - b - 1);
+    while (next(b, e)) {
+        bool eof = all[e - 1] != '\n';
+        unsigned char c = (unsigned char)all[b];
+        if (c >= 'A' && c <= 'T') f.addLine(lastName, all.data() + b, e - b, minLen);
+        else lastName = all.substr(b + 1, e - b - 1);
+        if (eof) break;
+    }
+    return true;
+}
+
+ReadSet ReadSet::fromArrays(const char* bases, const i64* off, size_t n, i64 minLen, bool himem) {
+    ReadSet f;
+    f.himem = himem;
+    f.off.push_back(0);
+    char nm[32];
+    std::string line;
+    for (size_t i = 0; i < n; i++) {
+        snprintf(nm, sizeof nm, "r%07zu\n", i);
+        line.assign(bases + off[i], (size_t)(off[i + 1] - off[i]));
+        line.push_back('\n');
+        f.addLine(nm, line.data(), line.size(), minLen);
+    }
+    return f;
+}
+
+i64 ReadSet::scanKmers(size_t r, int k) const {
+    i64 L = length(r);
+    i64 n = L - k + 1;
+    if (!himem && (L % 4) == 0) n -= 4;  // top-level re-read: finalLen == 0 (sequence.go:70,88; asm:88-96)
+    return n < 0 ? 0 : n;
+}
+
+uint32_t reverseComplementKmer(uint32_t seed, int k) {
+    uint32_t rc = 0;
+    for (int j = 0; j < k; j++) {
+        rc = (rc << 2) | ((seed ^ 3) & 3);
+        seed >>= 2;
+    }
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// commands/overlap.go:55-93 + util/sequtil/kmers.go:87-112.  float64, no contraction (built with -ffp-contract=off).
+// Tie rule for the unstable 4^k-element sort: ascending (count, k-mer id); top-N = last N.
+
+std::vector<double> kmerValuesFromCounts(std::vector<uint64_t>& counts, int k) {
+    const size_t n = counts.size();
+    std::vector<double> values(n, 0.0);
+    uint64_t tot = 0;
+    for (uint64_t c : counts) tot += c;
+    const double tf = (double)tot;
+    const double targetFreq = 0.000005;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t count = counts[i];
+        const double freq = (double)count / tf;
+        if (count < 3) values[i] = 0;
+        else if (freq <= targetFreq) values[i] = 1.0 - (targetFreq - freq);
+        else values[i] = 1.0 - (freq - targetFreq);
+    }
+    for (size_t i = 0; i < n; i++) {  // in-place fwd+rc merge, sequential semantics (kmers.go:90-96)
+        const size_t rc = reverseComplementKmer((uint32_t)i, k);
+        const uint64_t c = counts[i] + counts[rc];
+        counts[i] = c;
+        counts[rc] = c;
+    }
+    const size_t topN = n / 100;
+    if (topN > 0) {
+        std::vector<uint64_t> tmp(counts);
+        std::nth_element(tmp.begin(), tmp.begin() + (n - topN), tmp.end());
+        const uint64_t T = tmp[n - topN];
+        size_t above = 0;
+        for (uint64_t c : counts) above += c > T;
+        size_t ties = topN - above;
+        for (size_t i = n; i-- > 0;) {
+            if (counts[i] > T) values[i] = 0;
+            else if (counts[i] == T && ties > 0) {
+                values[i] = 0;
+                ties--;
+            }
+        }
+    }
+    values[0] = 0;
+    return values;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// seeds.SeedIndex host mirror
+
+SeedIndex::SeedIndex(int k_) : k(k_) { kmerBits.assign(((size_t)1 << (2 * k_)) / 64 + 1, 0); }
+
+void SeedIndex::reset() {
+    for (uint32_t km : seedMap) kmerBits[km >> 6] = 0;  // every set bit belongs to a seed of this round
+    kmerMap.clear();
+    seedMap.clear();
+    sequences.clear();
+    refs.clear();
+    arena.clear();
+}
+
+void SeedIndex::addSeedKmer(uint32_t kmer) {
+    if (!isSeed(kmer)) {
+        kmerBits[kmer >> 6] |= 1ull << (kmer & 63);
+        kmerMap[kmer] = (int32_t)seedMap.size();
+        seedMap.push_back(kmer);
+    }
+}
+
+int32_t SeedIndex::seedOfRcKmer(int32_t seed) const {
+    uint32_t rc = reverseComplementKmer(seedMap[(size_t)seed], k);
+    auto it = kmerMap.find(rc);
+    return it == kmerMap.end() ? 0 : it->second;  // kmerMap[] of a non-seed is the zero value (seeds.go:17)
+}
+
+// AddSeeds seeds/seeds.go:62-156 on an ASCII window (firstLen == 4 views behave like plain strings).
+void SeedIndex::addSeeds(const char* s, i64 L, int minSeeds, const double* ranks) {
+    const uint32_t mask = (uint32_t)(((uint64_t)1 << (2 * k)) - 1);
+    std::vector<uint32_t> topN((size_t)minSeeds, 0);
+    std::vector<double> topV((size_t)minSeeds, 0.0);
+    auto kmerAt = [&](i64 p) {
+        uint32_t v = 0;
+        for (int j = 0; j < k; j++) v = (v << 2) | baseCode((unsigned char)s[p + j]);
+        return v;
+    };
+    uint32_t kmer = kmerAt(0);
+    i64 nextIndex = k;
+    while (nextIndex < L - k) {
+        bool reset = false;
+        double bestValue = 0.0;
+        uint32_t bestSeed = 0;
+        for (int i = 0; nextIndex < L && i < k; i++) {
+            kmer = ((kmer << 2) | baseCode((unsigned char)s[nextIndex])) & mask;
+            nextIndex++;
+            if (isSeed(kmer)) {
+                reset = true;
+                break;
+            }
+            const double value = ranks[kmer];
+            if (value > bestValue) {
+                bestValue = value;
+                bestSeed = kmer;
+            }
+        }
+        if (!reset) {
+            size_t n = 0;
+            for (; n < topV.size() && topV[n] < bestValue; n++) {
+                if (n > 0) {
+                    topV[n - 1] = topV[n];
+                    topN[n - 1] = topN[n];
+                }
+            }
+            if (n > 0) {
+                topV[n - 1] = bestValue;
+                topN[n - 1] = bestSeed;
+            }
+        }
+        nextIndex += k;
+        if (nextIndex < L - k) kmer = kmerAt(nextIndex);
+        nextIndex += k;
+    }
+    for (uint32_t km : topN) {
+        addSeedKmer(km);
+        addSeedKmer(reverseComplementKmer(km, k));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SeedSequence operations (seeds/sequence.go)
+
+i64 SeedSeq::seedOffset(int index, int k) const {
+    index = index * 2 + 1;
+    i64 o = seg[0];
+    for (int i = 2; i < index; i += 2) o += seg[i] + k;
+    return o;
+}
+i64 SeedSeq::seedOffsetFromEnd(int index, int k) const {
+    index = index * 2 + 1;
+    i64 o = seg[n - 1];
+    for (int i = n - 3; i > index; i -= 2) o += seg[i] + k;
+    return o;
+}
+int SeedSeq::maxSeed() const {
+    int m = 0;
+    for (int i = 1; i < n; i += 2) m = std::max(m, (int)seg[i]);
+    return m;
+}
+
+SeedSeq* seqReverseComplement(Arena& a, SeedSeq* s, const SeedIndex& ix) {
+    if (s->reverseComplement) return s->reverseComplement;
+    int32_t* d = a.alloc((size_t)s->n);
+    for (int i = 0; i < s->n; i++) d[s->n - 1 - i] = (i & 1) ? ix.seedOfRcKmer(s->seg[i]) : s->seg[i];
+    SeedSeq* r = a.make();
+    r->seg = d;
+    r->n = s->n;
+    r->id = s->id;
+    r->length = s->length;
+    r->offset = s->offset;
+    r->inset = s->inset;
+    r->reverseComplement = s;
+    r->rc = !s->rc;
+    r->parent = s->parent;
+    return r;
+}
+
+SeedSeq* seqSubSequence(Arena& a, SeedSeq* s, int start, int end, i64 length, i64 offset, i64 inset) {
+    SeedSeq* r = a.make();
+    r->seg = s->seg + start * 2;
+    r->n = end * 2 + 3 - start * 2;
+    r->length = length;
+    r->offset = offset;
+    r->inset = inset;
+    r->rc = s->rc;
+    r->id = s->id;
+    r->parent = s;
+    return r;
+}
+
+SeedSeq* seqTrimmed(Arena& a, SeedSeq* s, i64 startOffset, int startSeed, i64 endOffset, int endSeed, int k) {
+    while (startSeed > 0 && startOffset >= s->seg[startSeed * 2] + k) {
+        startOffset -= s->seg[startSeed * 2] + k;
+        startSeed--;
+    }
+    const int numSeeds = s->n / 2;
+    while (endSeed < numSeeds - 1 && endOffset >= s->seg[endSeed * 2 + 2] + k) {
+        endOffset -= s->seg[endSeed * 2 + 2] + k;
+        endSeed++;
+    }
+    const i64 offset = s->seedOffset(startSeed, k) - startOffset;
+    const i64 inset = s->seedOffsetFromEnd(endSeed, k) - endOffset;
+    SeedSeq* t = s->rc ? seqSubSequence(a, s, startSeed, endSeed, s->length - offset - inset, s->offset + inset, s->inset + offset)
+                       : seqSubSequence(a, s, startSeed, endSeed, s->length - offset - inset, s->offset + offset, s->inset + inset);
+    int32_t* d = a.alloc((size_t)t->n);
+    memcpy(d, t->seg, (size_t)t->n * 4);
+    d[0] = (int32_t)startOffset;
+    d[t->n - 1] = (int32_t)endOffset;
+    t->seg = d;
+    return t;
+}
+
+static inline bool wlContains(const std::vector<uint64_t>& w, int x) {
+    size_t i = (size_t)x >> 6;
+    return i < w.size() && ((w[i] >> (x & 63)) & 1);
+}
+
+SeedSeq* seqReduced(Arena& a, SeedSeq* s, const std::vector<uint64_t>& whitelist, int k, int minSeeds, std::vector<int>* index) {
+    int count = 0, prev = -1;
+    for (int i = 1; i < s->n; i += 2) {
+        int next = s->seg[i];
+        if (next != prev && wlContains(whitelist, next)) {
+            count++;
+            prev = next;
+        }
+    }
+    if (count < minSeeds) return nullptr;
+    int32_t* d = a.alloc((size_t)count * 2 + 1);
+    i64 offset = s->seg[0];
+    if (index) index->assign((size_t)count, 0);
+    prev = -1;
+    int j = 0;
+    for (int i = 1; i < s->n; i += 2) {
+        int seed = s->seg[i];
+        if (prev != seed && wlContains(whitelist, seed)) {
+            d[j] = (int32_t)offset;
+            d[j + 1] = seed;
+            if (index) (*index)[(size_t)(j / 2)] = i / 2;
+            j += 2;
+            offset = s->seg[i + 1];
+            prev = seed;
+        } else {
+            offset += s->seg[i + 1] + k;
+        }
+    }
+    d[j] = (int32_t)offset;
+    SeedSeq* r = a.make();
+    r->seg = d;
+    r->n = count * 2 + 1;
+    r->length = s->length;
+    r->offset = s->offset;
+    r->inset = s->inset;
+    r->rc = s->rc;
+    r->id = s->id;
+    r->parent = s;
+    return r;
+}
+
+void matchReverseComplement(Arena& a, SeedMatch& m, const SeedIndex& ix) {
+    m.SeqA = seqReverseComplement(a, m.SeqA, ix);
+    m.SeqB = seqReverseComplement(a, m.SeqB, ix);
+    const int lengthA = m.SeqA->n / 2 - 1, lengthB = m.SeqB->n / 2 - 1;
+    std::reverse(m.MatchA.begin(), m.MatchA.end());
+    std::reverse(m.MatchB.begin(), m.MatchB.end());
+    for (size_t i = 0; i < m.MatchA.size(); i++) {
+        m.MatchA[i] = lengthA - m.MatchA[i];
+        m.MatchB[i] = lengthB - m.MatchB[i];
+    }
+}
+
+void matchBasesCovered(const SeedMatch& m, int k, i64* a, i64* b, bool* wouldPanic) {
+    if (m.MatchA.empty()) {  // the reference indexes MatchA[0] and panics
+        if (wouldPanic) *wouldPanic = true;
+        *a = *b = 0;
+        return;
+    }
+    i64 countA = (i64)m.MatchA.size() * k, countB = countA;
+    int prevA = m.MatchA[0], prevB = m.MatchB[0];
+    const int32_t* sa = m.SeqA->seg;
+    const int32_t* sb = m.SeqB->seg;
+    const int na = m.SeqA->n, nb = m.SeqB->n;
+    for (size_t i = 1; i < m.MatchA.size(); i++) {
+        const int s = m.MatchA[i], s2 = m.MatchB[i];
+        if (s * 2 >= na || s2 * 2 >= nb || prevA * 2 + 2 >= na || prevB * 2 + 2 >= nb || prevA < 0 || prevB < 0) {
+            if (wouldPanic) *wouldPanic = true;  // index out of range in the reference
+            *a = *b = 0;
+            return;
+        }
+        i64 d1 = sa[prevA * 2 + 2], d2 = sb[prevB * 2 + 2];
+        for (int j = prevA + 2; j <= s; j++) d1 += sa[j * 2] + k;
+        for (int j = prevB + 2; j <= s2; j++) d2 += sb[j * 2] + k;
+        if (d1 < 0) countA += d1;
+        if (d2 < 0) countB += d2;
+        prevB = s2;
+        prevA = s;
+    }
+    *a = countA;
+    *b = countB;
+}
+
+void matchBaseIndex(const SeedMatch& m, int aIndex, int k, i64* indexOut, i64* basesOut, i64* distOut) {
+    const int32_t* sa = m.SeqA->seg;
+    const int32_t* sb = m.SeqB->seg;
+    const int nb = m.SeqB->n;
+    int before = 0;
+    while (before < (int)m.MatchA.size() && m.MatchA[(size_t)before] <= aIndex) before++;
+    if (before == 0) {
+        i64 offset = 0;
+        for (int i = m.MatchA[0]; i > aIndex; i--) offset += sa[i * 2] + k;
+        int bIndex = m.MatchB[0];
+        i64 distance = 0;
+        for (int i = bIndex * 2; i > 0 && offset > 0; i -= 2) {
+            offset -= sb[i] + k;
+            distance += sb[i] + k;
+            bIndex--;
+        }
+        *indexOut = bIndex == 0 ? 0 : bIndex;
+        *basesOut = -offset;
+        *distOut = bIndex == 0 ? distance + offset : distance;
+        return;
+    }
+    before--;
+    int bIndex = m.MatchB[(size_t)before];
+    if (aIndex == m.MatchA[(size_t)before]) {
+        *indexOut = bIndex;
+        *basesOut = 0;
+        *distOut = 0;
+        return;
+    }
+    i64 offset = 0;
+    for (int i = m.MatchA[(size_t)before] + 1; i <= aIndex; i++) offset += sa[i * 2] + k;
+    i64 distance = 0;
+    for (int i = bIndex * 2 + 2; i < nb && offset >= sb[i]; i += 2) {
+        offset -= sb[i] + k;
+        distance += sb[i] + k;
+        bIndex++;
+    }
+    *indexOut = bIndex >= nb / 2 ? bIndex - 1 : bIndex;
+    *basesOut = offset;
+    *distOut = distance + offset;
+}
+
+void gapRange(i64 gap, int k, i64* mn, i64* mx) {
+    i64 minGap = (gap * 2) / 3 - k, maxGap = (gap * 3) / 2 + k + 1;
+    if (minGap < 0) {
+        minGap = -k;
+        if (maxGap < 0) maxGap = 0;
+    } else if (maxGap < 20) {
+        maxGap = 20;
+        minGap = 0;
+    }
+    *mn = minGap;
+    *mx = maxGap;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// util.GetSharedIDs(sets, 2, true) as multiAligner.Consensus uses it (alignment.go:45): seeds present in >= 2 of
+// the sequences.  With minCount == 2 the 4-ladder's v2 is exact and order independent, and the early-return rule
+// (bitset.go:338-342) fires when fewer than 2 sets reach a word — equivalent to "count >= 2" word by word.
+static std::vector<uint64_t> seedsSharedByTwo(const std::vector<SeedSeq*>& seqs) {
+    int maxSeed = 100;
+    for (auto* s : seqs) maxSeed = std::max(maxSeed, s->maxSeed());
+    const size_t W = (size_t)maxSeed / 64 + 1;
+    std::vector<uint64_t> v1(W, 0), v2(W, 0), row(W, 0);
+    for (auto* s : seqs) {
+        std::fill(row.begin(), row.end(), 0);
+        for (int j = 1; j < s->n; j += 2) row[(size_t)s->seg[j] >> 6] |= 1ull << (s->seg[j] & 63);
+        for (size_t w = 0; w < W; w++) {
+            v2[w] |= v1[w] & row[w];
+            v1[w] |= row[w];
+        }
+    }
+    return v2;
+}
+
+// seeds/alignment.go:23-268
+SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k, std::vector<std::unique_ptr<SeedMatch>>& matchesOut) {
+    const size_t ns = seqs.size();
+    const std::vector<uint64_t> useSeeds = seedsSharedByTwo(seqs);
+    std::vector<std::vector<int>> seedMap(ns);
+    std::vector<SeedSeq*> red(ns, nullptr);
+    for (size_t i = 0; i < ns; i++) red[i] = seqReduced(arena, seqs[i], useSeeds, k, 1, &seedMap[i]);
+    auto S = [&](size_t i) -> const int32_t* { return red[i] ? red[i]->seg : nullptr; };
+    auto N = [&](size_t i) -> i64 { return red[i] ? red[i]->n : 0; };
+    std::vector<i64> pos(ns, -1), offs(ns, 0), gaps(ns, 50), supported(ns, 0), dist(ns, 0);
+    std::vector<int32_t> consensus;
+    std::vector<std::unique_ptr<SeedMatch>> matches(ns);
+    for (size_t i = 0; i < ns; i++)
+        if (red[i]) {
+            matches[i].reset(new SeedMatch());
+            matches[i]->SeqB = seqs[i];
+        }
+    bool finished = false;
+    while (!finished) {
+        i64 fCount = 0, near = 100000;
+        for (size_t i = 0; i < ns; i++) {
+            const int32_t* segment = S(i);
+            const i64 sl = N(i), p = pos[i];
+            supported[i] = 0;
+            if (!segment || p >= (sl - 1) / 2 - 1) {
+                fCount++;
+                continue;
+            }
+            const i64 d = segment[p * 2 + 2] - offs[i];
+            dist[i] = d;
+            if (d < near && d > -k) {
+                const int32_t nextSeed = segment[p * 2 + 3];
+                i64 minD, maxD;
+                gapRange(d + gaps[i], k, &minD, &maxD);
+                minD -= gaps[i];
+                maxD -= gaps[i];
+                if (near > maxD) near = maxD;
+                supported[i] = 1;
+                for (size_t j = 0; j < ns; j++) {
+                    const int32_t* s2 = S(j);
+                    const i64 sl2 = N(j);
+                    if (!s2 || j == i) continue;
+                    i64 p2 = pos[j] + 1;
+                    if (p2 < sl2 / 2) {
+                        i64 min2, max2;
+                        gapRange(d + gaps[j], k, &min2, &max2);
+                        if (min2 > minD) min2 = minD;
+                        if (max2 < maxD) max2 = maxD;
+                        i64 otherD = s2[p2 * 2] - offs[j];
+                        while (otherD < min2 && p2 < sl2 / 2) {
+                            p2++;
+                            otherD += s2[p2 * 2] + k;
+                        }
+                        while (otherD < max2 && p2 < sl2 / 2) {
+                            if (s2[p2 * 2 + 1] == nextSeed) {
+                                supported[i]++;
+                                dist[i] += otherD;
+                                break;
+                            }
+                            p2++;
+                            otherD += s2[p2 * 2] + k;
+                        }
+                    }
+                }
+            }
+        }
+        if (fCount >= (i64)ns) break;
+        i64 minseed = -1, mindist = 0, minsup = 0, minD = 0, maxD = 0;
+        for (size_t i = 0; i < ns; i++) {
+            if (supported[i] > 1) {
+                const i64 d = dist[i] / supported[i];
+                const i64 seed = S(i)[pos[i] * 2 + 3];
+                if (minseed == -1 || (minseed == seed && supported[i] > minsup) || (minseed != seed && mindist > d)) {
+                    minsup = supported[i];
+                    mindist = d;
+                    minseed = seed;
+                    gapRange(d + gaps[i], k, &minD, &maxD);
+                    minD -= gaps[i];
+                    maxD -= gaps[i];
+                }
+            }
+        }
+        if (minseed == -1) {
+            i64 minIndex = -1, minDist = 100000;
+            for (size_t i = 0; i < ns; i++) {
+                i64 d = dist[i];
+                if (supported[i] > 1) d = d / supported[i];
+                if (S(i) && pos[i] < (i64)ns / 2 && d < minDist) {  // len(segments)/2 is len(seqs)/2 (:170)
+                    minDist = d;
+                    minIndex = (i64)i;
+                }
+            }
+            if (minIndex == -1) break;
+            for (size_t i = 0; i < ns; i++)
+                if (S(i)) {
+                    gaps[i] += minDist;
+                    offs[i] += minDist;
+                }
+            gaps[(size_t)minIndex] = 0;
+            offs[(size_t)minIndex] = 0;
+            pos[(size_t)minIndex]++;
+            continue;
+        }
+        consensus.push_back((int32_t)mindist);
+        consensus.push_back((int32_t)minseed);
+        fCount = 0;
+        for (size_t i = 0; i < ns; i++) {
+            const int32_t* segment = S(i);
+            const i64 sl = N(i);
+            if (!segment) {
+                fCount++;
+                continue;
+            }
+            i64 matchDex = pos[i] + 1;
+            if (matchDex < sl / 2) {
+                i64 min2, max2;
+                gapRange(mindist + gaps[i], k, &min2, &max2);
+                if (min2 > minD) min2 = minD;
+                if (max2 < maxD) max2 = maxD;
+                i64 otherD = segment[matchDex * 2] - offs[i];
+                while (otherD < min2 && matchDex < sl / 2) {
+                    matchDex++;
+                    otherD += segment[matchDex * 2] + k;
+                }
+                bool found = false;
+                while (otherD < max2 && matchDex < sl / 2) {
+                    if (segment[matchDex * 2 + 1] == minseed) {
+                        pos[i] = matchDex;
+                        offs[i] = 0;
+                        gaps[i] = 0;
+                        matches[i]->MatchA.push_back((int32_t)(consensus.size() / 2 - 1));
+                        matches[i]->MatchB.push_back(seedMap[i][(size_t)matchDex]);
+                        found = true;
+                        break;
+                    }
+                    matchDex++;
+                    otherD += segment[matchDex * 2] + k;
+                }
+                if (!found) {
+                    gaps[i] += mindist;
+                    offs[i] += mindist;
+                    i64 p = pos[i];
+                    while (p < sl / 2 && offs[i] > segment[p * 2 + 2] + 50) {
+                        offs[i] -= segment[p * 2 + 2] + k;
+                        p++;
+                        pos[i]++;
+                    }
+                    if (p >= sl / 2) fCount++;
+                }
+            } else {
+                fCount++;
+            }
+        }
+        finished = fCount >= (i64)ns;
+    }
+    consensus.push_back(0);
+    SeedSeq* cons = arena.make();
+    int32_t* d = arena.alloc(consensus.size());
+    memcpy(d, consensus.data(), consensus.size() * 4);
+    cons->seg = d;
+    cons->n = (int)consensus.size();
+    cons->length = -k;
+    for (size_t i = 0; i < consensus.size(); i += 2) cons->length += consensus[i] + k;  // LoadSequence :35-42
+    for (i64 i = (i64)matches.size() - 1; i >= 0; i--) {
+        SeedMatch* m = matches[(size_t)i].get();
+        if (!m || m->MatchA.size() < 3) {
+            matches[(size_t)i] = std::move(matches.back());
+            matches.pop_back();
+        } else {
+            m->SeqA = cons;
+        }
+    }
+    matchesOut = std::move(matches);
+    return cons;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// overlap/combine.go
+
+static void trimToBestSeed(Arena& ar, int upto, std::vector<SeedMatch*>& ms, int minMatch, int k, std::vector<SeedSeq*>& parts,
+                           std::vector<uint8_t>& cantTrim, i64* badBack) {  // :21-111
+    parts.assign(ms.size(), nullptr);
+    cantTrim.assign(ms.size(), 0);
+    int bestCount = 0, bestScore = 0, bestIndex = upto, backCount = 0, backScore = 0;
+    const int length = ms[0]->SeqA->numSeeds();
+    int backIndex = length - upto - 1;
+    for (int i = 0; i < upto; i++) {
+        int count = 0, bCount = 0;
+        for (SeedMatch* match : ms) {
+            for (int index : match->MatchA) {
+                if (index == i) count++;
+                if (index >= i) break;
+            }
+            for (int j = (int)match->MatchA.size() - 1; j > 0; j--) {
+                const int index = match->MatchA[(size_t)j];
+                if (index == length - 1 - i) bCount++;
+                if (index <= length - 1 - i) break;
+            }
+        }
+        if (count - i >= bestScore || (bestCount < minMatch && count >= minMatch)) {
+            bestCount = count;
+            bestScore = count - i;
+            bestIndex = i;
+        }
+        if (bCount - i >= backScore || (backCount < minMatch && bCount >= minMatch)) {
+            backCount = bCount;
+            backScore = bCount - i;
+            backIndex = length - 1 - i;
+        }
+    }
+    SeedSeq* consensus = seqTrimmed(ar, ms[0]->SeqA, 0, bestIndex, 0, backIndex, k);
+    for (size_t j = 0; j < ms.size(); j++) {
+        SeedMatch* match = ms[j];
+        i64 index, bases, frontDistance, bIndex, backBases, backDistance;
+        matchBaseIndex(*match, bestIndex, k, &index, &bases, &frontDistance);
+        matchBaseIndex(*match, backIndex, k, &bIndex, &backBases, &backDistance);
+        cantTrim[j] = frontDistance > 50 || frontDistance < -50 || backDistance > 50 || backDistance < -50;
+        if (bases > -k && index < match->SeqB->numSeeds() - 1) {
+            bases = match->SeqB->nextSeedOffset((int)index, k) - bases;
+            index++;
+        } else if (bases < 0) {
+            bases = -bases + k;
+        }
+        parts[j] = seqTrimmed(ar, match->SeqB, bases, (int)index, backBases, (int)bIndex, k);
+        match->SeqB = parts[j];
+        match->SeqA = consensus;
+        int front = 0;
+        while (front < (int)match->MatchB.size() && match->MatchB[(size_t)front] < index) front++;
+        int back = (int)match->MatchB.size() - 1;
+        while (back >= 0 && match->MatchB[(size_t)back] > bIndex) back--;
+        if (front < 0 || back + 1 > (int)match->MatchA.size() || back < front) {
+            // "Bad back:" diagnostic (:93-102) is suppressed (it prints Go pointers); the match becomes empty.
+            if (badBack) (*badBack)++;
+            if (back + 1 < front) back = front - 1;
+        }
+        std::vector<int32_t> na(match->MatchA.begin() + front, match->MatchA.begin() + back + 1);
+        std::vector<int32_t> nb(match->MatchB.begin() + front, match->MatchB.begin() + back + 1);
+        match->MatchA.swap(na);
+        match->MatchB.swap(nb);
+        for (size_t n = 0; n < match->MatchB.size(); n++) {
+            match->MatchA[n] -= bestIndex;
+            match->MatchB[n] -= (int32_t)index;
+        }
+    }
+}
+
+static std::unique_ptr<SeedContig> newSeedContig(Arena& ar, std::vector<SeedMatch*>& ms, int k, i64* badBack) {  // :113-133
+    const int minMatch = ms.size() < 5 ? (int)ms.size() : 5;
+    std::vector<SeedSeq*> parts;
+    std::vector<uint8_t> trimFailed;
+    trimToBestSeed(ar, ms[0]->SeqA->numSeeds() / 4, ms, minMatch, k, parts, trimFailed, badBack);
+    std::unique_ptr<SeedContig> c(new SeedContig());
+    const size_t n = ms.size();
+    c->Parts.assign(n, 0);
+    c->ReverseComplement.assign(n, 0);
+    c->Offsets.assign(n, 0);
+    c->Lengths.assign(n, 0);
+    c->SeqLengths.assign(n, 0);
+    c->Approximate = trimFailed;
+    c->Matches = ms;
+    for (size_t i = 0; i < n; i++) {
+        SeedSeq* part = parts[i];
+        c->Parts[i] = part->id;
+        c->ReverseComplement[i] = part->rc;
+        SeedSeq* parent = part;
+        while (parent->parent) parent = parent->parent;
+        c->SeqLengths[i] = parent->length;
+        c->Offsets[i] = part->offset;
+        c->Lengths[i] = parent->length - part->offset - part->inset;
+    }
+    return c;
+}
+
+std::unique_ptr<SeedContig> buildConsensus(Arena& ar, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, i64* badBack) {  // :163-193
+    const int k = sg.k;
+    std::vector<SeedSeq*> seqs;
+    for (SeedMatch* lap : overlaps)
+        if (lap->ReverseComplementQuery) matchReverseComplement(ar, *lap, sg);
+    for (SeedMatch* lap : overlaps) {
+        i64 ca, cb;
+        matchBasesCovered(*lap, k, &ca, &cb, nullptr);
+        if (ca < 25 || cb < 25) continue;
+        seqs.push_back(seqTrimmed(ar, lap->SeqB, overlaps[0]->SeqA->seedOffset(lap->MatchA[0], k), lap->MatchB[0],
+                                  overlaps[0]->SeqA->seedOffsetFromEnd(lap->MatchA.back(), k), lap->MatchB.back(), k));
+    }
+    if (seqs.size() > 1) {
+        std::vector<std::unique_ptr<SeedMatch>> overlap;
+        multiAlignerConsensus(ar, seqs, k, overlap);
+        if (overlap.size() > 1) {
+            std::vector<SeedMatch*> ms;
+            for (auto& m : overlap) ms.push_back(m.get());
+            std::unique_ptr<SeedContig> c = newSeedContig(ar, ms, k, badBack);
+            c->owned = std::move(overlap);
+            return c;
+        }
+    }
+    return nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// commands/command.go:18-56 MakeArgs (unique-prefix aliases) and downpore.go:34-51 parseArgs
+
+void ArgTable::make(const std::vector<std::string>& n, const std::vector<std::string>& d, const std::vector<std::string>& desc) {
+    names = n;
+    defaults = d;
+    descriptions = desc;
+    for (size_t i = 0; i < n.size(); i++) args[n[i]] = d[i];
+    std::vector<std::string> s = n;
+    std::sort(s.begin(), s.end());
+    for (size_t i = 0; i < s.size(); i++) {
+        if (i == s.size() - 1 || s[i][0] != s[i + 1][0]) {
+            alias[s[i]] = s[i].substr(0, 1);
+        } else {
+            size_t j = i + 1, minLen = 1;
+            while (j < s.size() && s[j][0] == s[i][0]) {
+                size_t same = 1;
+                while (same < s[j].size() && same < s[j - 1].size() && s[j][same] == s[j - 1][same]) same++;
+                if (same >= minLen) minLen = same + 1;
+                j++;
+            }
+            if (minLen < 4)
+                for (size_t t = i; t < j; t++) alias[s[t]] = s[t].substr(0, minLen);
+            i = j - 1;
+        }
+    }
+}
+
+bool ArgTable::parse(int argc, char** argv, std::string& err) {
+    std::unordered_map<std::string, std::string> inv;
+    for (auto& kv : alias) inv[kv.second] = kv.first;
+    for (int i = 2; i < argc; i += 2) {
+        std::string name = argv[i];
+        size_t p = 0;
+        while (p < name.size() && name[p] == '-') p++;
+        name = name.substr(p);
+        auto it = inv.find(name);
+        if (it != inv.end()) name = it->second;
+        if (!args.count(name)) {
+            err = "Unrecognised argument:" + name;
+            return false;
+        }
+        if (i + 1 >= argc) {
+            err = "Missing value for argument:" + name;  // the reference panics on os.Args[i+1]
+            return false;
+        }
+        args[name] = argv[i + 1];
+    }
+    return true;
+}
+
+}  // namespace dph

@@ -1,0 +1,227 @@
+"""Python driver of the product's overlap pipeline (libdownpore_host.so) + the multi-GPU survivor exchange.
+
+One process per GPU.  Each rank keeps the whole read set resident and scans only its contiguous shard of reads per
+round (the scan is >95 % of the bytes); the survivors (reads with >= num_seeds seed hits, a few MB at
+k=13) are all-gathered in rank order — ranks own ascending contiguous read ranges, so the concatenation is file order —
+and every rank then builds the identical (small) index and produces the identical PAF.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .hip import DpError, lib_path, load_library
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_host = None
+
+STAT_FIELDS = ["t_prepare", "t_scan", "t_index", "t_query", "t_consensus", "k_scan_ms", "k_query_ms", "k_chain_ms",
+               "scan_bases", "scan_items", "scan_bytes", "query_bytes", "n_queries", "n_indexed", "n_hits", "n_matches",
+               "n_paf", "n_seeds", "round", "bad_back", "empty_match"]
+
+
+def host_lib_path():
+    return os.path.join(_HERE, "lib", "libdownpore_host.so")
+
+
+def load_host():
+    global _host
+    if _host is not None:
+        return _host
+    load_library()  # the HIP library must exist; no fallback
+    p = host_lib_path()
+    if not os.path.exists(p):
+        raise DpError("libdownpore_host.so is not built (%s): run __graft_entry__.build()" % p)
+    H = C.CDLL(p)
+    vp = C.c_void_p
+    H.dph_last_error.restype = C.c_char_p
+    H.dph_last_error.argtypes = [vp]
+    H.dph_reads_from_arrays.restype = vp
+    H.dph_reads_from_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+    H.dph_reads_from_fasta.restype = vp
+    H.dph_reads_from_fasta.argtypes = [C.c_char_p, C.c_int64, C.c_int]
+    H.dph_reads_free.argtypes = [vp]
+    H.dph_reads_count.restype = C.c_int64
+    H.dph_reads_count.argtypes = [vp]
+    H.dph_reads_total_bases.restype = C.c_int64
+    H.dph_reads_total_bases.argtypes = [vp]
+    H.dph_reads_get_ignore.argtypes = [vp, C.c_void_p]
+    H.dph_reads_reset_ignore.argtypes = [vp]
+    H.dph_overlap_create.restype = vp
+    H.dph_overlap_create.argtypes = [vp, C.c_int, C.c_void_p, C.c_double, C.c_void_p]
+    H.dph_overlap_destroy.argtypes = [vp]
+    H.dph_overlap_set_shard.argtypes = [vp, C.c_int64, C.c_int64]
+    H.dph_overlap_values.restype = C.POINTER(C.c_double)
+    H.dph_overlap_values.argtypes = [vp, C.POINTER(C.c_int64)]
+    H.dph_overlap_round_scan.argtypes = [vp]
+    H.dph_overlap_local.argtypes = [vp] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_uint64)] * 2
+    H.dph_overlap_round_finish.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    for f in (H.dph_overlap_round_paf, H.dph_overlap_all_paf, H.dph_overlap_errtext):
+        f.restype = C.POINTER(C.c_char)
+        f.argtypes = [vp, C.POINTER(C.c_int64)]
+    H.dph_overlap_stats.argtypes = [vp, C.c_void_p]
+    H.dph_overlap_ctx.restype = vp
+    H.dph_overlap_ctx.argtypes = [vp]
+    _host = H
+    return H
+
+
+def shard_bounds(n_reads, rank, world):
+    """Ascending contiguous read ranges, one per rank (SURVEY §8(e) ordering caveat)."""
+    per = (n_reads + world - 1) // world
+    lo = min(n_reads, rank * per)
+    return lo, min(n_reads, lo + per)
+
+
+def allgather_survivors(local, world, device=None):
+    """All-gather of the variable-size survivor lists with torch.distributed (backend nccl == RCCL over xGMI on the
+    GPU box; gloo in the CPU tests).  `local` = dict(read u32[n], n_seeds u32[n], segs i32[m]).  Returns the rank-ordered
+    concatenation."""
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None else torch.device("cpu")
+    sizes = torch.tensor([len(local["read"]), len(local["segs"])], dtype=torch.int64, device=dev)
+    all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes)
+    all_sizes = torch.stack(all_sizes).cpu().numpy()
+    max_n, max_m = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
+    # one padded int32 payload per rank: [read ids | n_seeds | segs]
+    pay = np.zeros(2 * max_n + max_m, dtype=np.int32)
+    n, m = len(local["read"]), len(local["segs"])
+    pay[:n] = local["read"].astype(np.int32)
+    pay[max_n:max_n + n] = local["n_seeds"].astype(np.int32)
+    pay[2 * max_n:2 * max_n + m] = local["segs"]
+    t = torch.from_numpy(pay).to(dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    reads, nseeds, segs = [], [], []
+    for r in range(world):
+        o = out[r].cpu().numpy()
+        rn, rm = int(all_sizes[r, 0]), int(all_sizes[r, 1])
+        reads.append(o[:rn].astype(np.uint32))
+        nseeds.append(o[max_n:max_n + rn].astype(np.uint32))
+        segs.append(o[2 * max_n:2 * max_n + rm])
+    return dict(read=np.concatenate(reads), n_seeds=np.concatenate(nseeds), segs=np.concatenate(segs).astype(np.int32))
+
+
+class Reads:
+    def __init__(self, bases=None, off=None, min_len=1000, himem=True, fasta=None):
+        H = load_host()
+        if fasta is not None:
+            self.h = H.dph_reads_from_fasta(fasta.encode(), min_len, 1 if himem else 0)
+            if not self.h:
+                raise DpError(H.dph_last_error(None).decode())
+        else:
+            b = np.ascontiguousarray(bases, dtype=np.uint8)
+            o = np.ascontiguousarray(off, dtype=np.int64)
+            self.h = H.dph_reads_from_arrays(b.ctypes.data, o.ctypes.data, len(o) - 1, min_len, 1 if himem else 0)
+        self.H = H
+
+    def __len__(self):
+        return self.H.dph_reads_count(self.h)
+
+    def total_bases(self):
+        return self.H.dph_reads_total_bases(self.h)
+
+    def ignore(self):
+        out = np.zeros(len(self), dtype=np.uint8)
+        self.H.dph_reads_get_ignore(self.h, out.ctypes.data)
+        return out
+
+    def reset_ignore(self):
+        self.H.dph_reads_reset_ignore(self.h)
+
+
+class OverlapPipeline:
+    """`downpore overlap` on one GPU (or one rank of a multi-GPU job)."""
+
+    def __init__(self, reads, device=0, k=10, overlap_size=1000, num_seeds=15, seed_batch_size=10000, chunk_size=10000,
+                 query_batch_size=20000, min_hits=0.25, himem=True, values=None, rank=0, world=1, torch_device=None):
+        self.H = load_host()
+        p = np.array([overlap_size, k, num_seeds, seed_batch_size, chunk_size, query_batch_size, 1 if himem else 0],
+                     dtype=np.int64)
+        vptr = values.ctypes.data if values is not None else None
+        self._values_keepalive = values
+        self.h = self.H.dph_overlap_create(reads.h, device, p.ctypes.data, float(min_hits), vptr)
+        if not self.h:
+            raise DpError("dph_overlap_create: " + self.H.dph_last_error(None).decode())
+        self.reads = reads
+        self.rank, self.world = rank, world
+        self.torch_device = torch_device
+        lo, hi = shard_bounds(len(reads), rank, world)
+        self.H.dph_overlap_set_shard(self.h, lo, hi)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.H.dph_overlap_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self):
+        return DpError(self.H.dph_last_error(self.h).decode())
+
+    def values(self):
+        n = C.c_int64(0)
+        p = self.H.dph_overlap_values(self.h, C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def local_survivors(self):
+        ptrs = [C.c_void_p() for _ in range(4)]
+        n, m = C.c_uint64(0), C.c_uint64(0)
+        self.H.dph_overlap_local(self.h, *[C.byref(x) for x in ptrs], C.byref(n), C.byref(m))
+
+        def arr(p, cnt, ct, dt):
+            if cnt == 0:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(cnt,)).astype(dt, copy=True)
+        return dict(read=arr(ptrs[0], n.value, C.c_uint32, np.uint32), n_seeds=arr(ptrs[1], n.value, C.c_uint32, np.uint32),
+                    segs=arr(ptrs[3], m.value, C.c_int32, np.int32))
+
+    def step(self):
+        """One round.  Returns False when the command has finished."""
+        rc = self.H.dph_overlap_round_scan(self.h)
+        if rc < 0:
+            raise self._err()
+        if rc == 0:
+            return False
+        if self.world > 1:
+            allv = allgather_survivors(self.local_survivors(), self.world, self.torch_device)
+            r = np.ascontiguousarray(allv["read"], dtype=np.uint32)
+            ns = np.ascontiguousarray(allv["n_seeds"], dtype=np.uint32)
+            sg = np.ascontiguousarray(allv["segs"], dtype=np.int32)
+            rc = self.H.dph_overlap_round_finish(self.h, r.ctypes.data, ns.ctypes.data, sg.ctypes.data, len(r))
+        else:
+            rc = self.H.dph_overlap_round_finish(self.h, None, None, None, 0)
+        if rc < 0:
+            raise self._err()
+        return True
+
+    def stats(self):
+        out = np.zeros(len(STAT_FIELDS), dtype=np.float64)
+        self.H.dph_overlap_stats(self.h, out.ctypes.data)
+        return dict(zip(STAT_FIELDS, out.tolist()))
+
+    def _text(self, fn):
+        n = C.c_int64(0)
+        p = fn(self.h, C.byref(n))
+        return C.string_at(p, n.value).decode()
+
+    def round_paf(self):
+        return self._text(self.H.dph_overlap_round_paf)
+
+    def all_paf(self):
+        return self._text(self.H.dph_overlap_all_paf)
+
+    def err_text(self):
+        return self._text(self.H.dph_overlap_errtext)
+
+    def run(self, max_rounds=-1):
+        n = 0
+        while (max_rounds < 0 or n < max_rounds) and self.step():
+            n += 1
+        return n

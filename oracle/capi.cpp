@@ -173,7 +173,7 @@ void* dpo_reads_from_arrays(const char* bases, const int64_t* off, int64_t n, in
     std::vector<std::string> names, seqs;
     char nm[32];
     for (int64_t i = 0; i < n; i++) {
-        snprintf(nm, sizeof nm, ">r%07lld", (long long)i);
+        snprintf(nm, sizeof nm, "r%07lld", (long long)i);
         names.push_back(nm);
         seqs.emplace_back(bases + off[i], (size_t)(off[i + 1] - off[i]));
     }
@@ -276,6 +276,9 @@ const int64_t* dpo_overlap_trace(void* hh, int64_t round, int field, int64_t* n)
             case 7: d = t.matchQueryIndex; break;
             case 8: d = t.matchTarget; break;
             case 9: d = t.newlyIgnored; break;
+            case 11: d = t.queryLength; break;
+            case 12: d = t.queryOffset; break;
+            case 13: d = t.queryInset; break;
             case 10: d = {t.firstSequence, t.numQuerySeqs, t.hits, t.qHits}; break;
             case 20: flat(t.querySegments, d, o); break;
             case 21: flat(t.indexedSegments, d, o); break;

@@ -382,7 +382,7 @@ std::vector<Mapping*> Mapper::performMapping(const PackedSeq& query) {
             qOffset += seedQuery->offset;
             qInset += seedQuery->inset;
             i64 ca, ids;
-            smGetBasesCovered(sm, k, &ca, &ids);
+            if (!smGetBasesCovered(sm, k, &ca, &ids)) throw std::runtime_error("oracle: performMapping GetBasesCovered (reference would panic)");
             Mapping* mp = mk();
             mp->Start = start;
             mp->End = end;
@@ -413,7 +413,7 @@ std::vector<Mapping*> Mapper::performMapping(const PackedSeq& query) {
             qInset += rcQuery->offset;
             qOffset += rcQuery->inset;
             i64 ca, ids;
-            smGetBasesCovered(sm, k, &ca, &ids);
+            if (!smGetBasesCovered(sm, k, &ca, &ids)) throw std::runtime_error("oracle: performMapping GetBasesCovered (reference would panic)");
             Mapping* mp = mk();
             mp->Start = start;
             mp->End = end;

@@ -25,8 +25,9 @@
 //     util/asm_amd64.s:200-207) is restated zero-initialised.
 //   * overlap/combine.go:93-102 prints a "Bad back:" diagnostic into the PAF stream whose text contains
 //     Go pointer values; it is suppressed (counted in OverlapResult.badBack).  A part whose match
-//     becomes empty there makes commands/overlap.go:224 panic (GetBasesCovered indexes MatchA[0]);
-//     canonically that PAF line is still printed with ident = 0 (counted in emptyMatchPanics).
+//     becomes empty there — or whose (off-by-one, commands/overlap.go:224) match indexes past the trimmed
+//     consensus — makes GetBasesCovered panic with an index out of range; canonically that PAF line is still
+//     printed, with ident = 0 (counted in emptyMatchPanics).
 //   * 8-byte loads that run past the end of a read's packed bytes see zero bytes (the reference
 //     reads whatever follows on the Go heap).
 #pragma once
@@ -168,7 +169,7 @@ SeedSequence* ssTrimmed(Arena& a, SeedSequence* s, i64 startOffset, i64 startSee
 SeedSequence* ssReduced(Arena& a, SeedSequence* s, const IntSet& whitelist, int k, i64 minSeeds,
                         std::vector<i64>* index);                              // :85-123
 void smReverseComplement(SeedMatch& m, int k, SeedIndex& index);               // :800-816
-void smGetBasesCovered(const SeedMatch& m, int k, i64* a, i64* b);             // :830-858
+bool smGetBasesCovered(const SeedMatch& m, int k, i64* a, i64* b);             // :830-858; false = reference panics
 void smGetBaseIndex(const SeedMatch& m, i64 aIndex, int k, i64* index, i64* bases, i64* distance);  // :1190-1237
 
 // seeds/alignment.go:274-616
@@ -254,7 +255,7 @@ struct RoundTrace {
     std::vector<i64> seedKmers;                    // seedMap after PrepareQueries
     i64 firstSequence = 0, numQuerySeqs = 0;
     std::vector<std::vector<i64>> querySegments;   // per SeedQuery
-    std::vector<i64> queryIDs, querySeqIDs;
+    std::vector<i64> queryIDs, querySeqIDs, queryLength, queryOffset, queryInset;
     std::vector<std::vector<i64>> indexedSegments; // per indexed sequence (after chunking)
     std::vector<i64> indexedIds, indexedLength, indexedOffset, indexedInset;
     std::vector<std::vector<u64>> candidates;      // per query: Matches() output

@@ -277,7 +277,7 @@ std::vector<std::unique_ptr<SeedMatch>> Overlapper::findOverlaps(const std::vect
                 i64 bestCount = 0;  // never updated in the reference (:369-375)
                 for (auto& sm : sMatches) {
                     i64 ca, c;
-                    smGetBasesCovered(sm, k, &ca, &c);
+                    if (!smGetBasesCovered(sm, k, &ca, &c)) throw std::runtime_error("oracle: matchWorker GetBasesCovered (reference would panic)");
                     if (c > bestCount) best = &sm;
                 }
                 if (best == nullptr) throw std::runtime_error("oracle: matchWorker best==nil (reference would panic)");
@@ -411,7 +411,7 @@ std::unique_ptr<SeedContig> buildConsensus(SeedIndex& sg, std::vector<SeedMatch*
     for (SeedMatch* lap : overlaps) {
         SeedSequence* s = lap->SeqB;
         i64 ca, cb;
-        smGetBasesCovered(*lap, k, &ca, &cb);
+        if (!smGetBasesCovered(*lap, k, &ca, &cb)) throw std::runtime_error("oracle: BuildConsensus GetBasesCovered (reference would panic)");
         if (ca < 25 || cb < 25) continue;
         s = ssTrimmed(ar, s, overlaps[0]->SeqA->getSeedOffset(lap->MatchA[0], k), lap->MatchB[0],
                       overlaps[0]->SeqA->getSeedOffsetFromEnd(lap->MatchA.back(), k), lap->MatchB.back(), k, nullptr);
@@ -489,6 +489,9 @@ OverlapResult runOverlap(FastaSet& set, const OverlapParams& p, const double* va
                 tr.querySegments.emplace_back(q.Query->seg(), q.Query->seg() + q.Query->n);
                 tr.queryIDs.push_back(q.ID);
                 tr.querySeqIDs.push_back(q.SequenceID);
+                tr.queryLength.push_back(q.Query->length);
+                tr.queryOffset.push_back(q.Query->offset);
+                tr.queryInset.push_back(q.Query->inset);
                 tr.candidates.push_back(seedIndex.matches(q.Query, p.minHits));
             }
             for (auto* s : seedIndex.sequences) {
@@ -550,12 +553,10 @@ OverlapResult runOverlap(FastaSet& set, const OverlapParams& p, const double* va
                     if (end - start > p.overlapSize) covered = end - start;
                     if (contig->SeqLengths[id] * 9 <= covered * 10) setIgnore(part);
                     i64 ident, identB;
-                    if (contig->Matches[i]->MatchA.empty()) {
-                        // the reference panics here (GetBasesCovered indexes MatchA[0]); canonical: ident 0
+                    if (!smGetBasesCovered(*contig->Matches[i], k, &ident, &identB)) {
+                        // the reference panics here (index out of range); canonical: ident 0
                         ident = 0;
                         res.emptyMatchPanics++;
-                    } else {
-                        smGetBasesCovered(*contig->Matches[i], k, &ident, &identB);
                     }
                     std::string s = set.names[(size_t)contig->Parts[0]] + "\t" + std::to_string(contig->SeqLengths[0]) + "\t" +
                                     std::to_string(queryStart) + "\t" + std::to_string(queryEnd) + "\t" + rc + "\t" +

@@ -351,16 +351,22 @@ void smReverseComplement(SeedMatch& m, int k, SeedIndex& index) {
 }
 
 // :830-858
-void smGetBasesCovered(const SeedMatch& m, int k, i64* a, i64* b) {
-    if (m.MatchA.empty()) throw std::runtime_error("oracle: GetBasesCovered on empty match (reference would panic)");
+// Returns false (a = b = 0) where the reference would panic with an index out of range.
+bool smGetBasesCovered(const SeedMatch& m, int k, i64* a, i64* b) {
+    *a = *b = 0;
+    if (m.MatchA.empty()) return false;
     i64 countA = (i64)m.MatchA.size() * k;
     i64 countB = countA;
     i64 prevA = m.MatchA[0];
     i64 prevB = m.MatchB[0];
     const i64* sa = m.SeqA->seg();
     const i64* sb = m.SeqB->seg();
+    const i64 naSeg = (i64)m.SeqA->n, nbSeg = (i64)m.SeqB->n;
     for (size_t i = 1; i < m.MatchA.size(); i++) {
         i64 s = m.MatchA[i];
+        if (s * 2 >= naSeg || m.MatchB[i] * 2 >= nbSeg || prevA * 2 + 2 >= naSeg || prevB * 2 + 2 >= nbSeg || prevA < 0 ||
+            prevB < 0)
+            return false;
         i64 d1 = sa[prevA * 2 + 2];
         i64 d2 = sb[prevB * 2 + 2];
         for (i64 j = prevA + 2; j <= s; j++) d1 += sa[j * 2] + k;
@@ -373,6 +379,7 @@ void smGetBasesCovered(const SeedMatch& m, int k, i64* a, i64* b) {
     }
     *a = countA;
     *b = countB;
+    return true;
 }
 
 // :1190-1237

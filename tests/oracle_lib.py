@@ -338,7 +338,7 @@ def _bytes(fn, h, *a):
 
 class OverlapRun:
     FIELDS = dict(seedKmers=0, queryIDs=1, querySeqIDs=2, indexedIds=3, indexedLength=4, indexedOffset=5,
-                  indexedInset=6, matchQueryIndex=7, matchTarget=8, newlyIgnored=9, scalars=10, querySegments=20,
+                  indexedInset=6, matchQueryIndex=7, matchTarget=8, newlyIgnored=9, scalars=10, queryLength=11, queryOffset=12, queryInset=13, querySegments=20,
                   indexedSegments=21, candidates=22, matchA=23, matchB=24)
 
     def __init__(self, reads, k=10, overlap_size=1000, num_seeds=15, seed_batch_size=10000, chunk_size=10000,

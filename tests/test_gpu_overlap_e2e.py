@@ -1,0 +1,88 @@
+"""End-to-end GPU parity: the product's `overlap` pipeline (host C++ above the C ABI + HIP kernels) must print the
+same PAF as the ORACLE, round by round, and flag the same reads as ignored."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def first_diff(a, b):
+    """None if equal; otherwise a short description (never hand two huge strings to pytest's differ)."""
+    if a == b:
+        return None
+    la, lb = a.split("\n"), b.split("\n")
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            return "line %d:\n  got  %s\n  want %s" % (i, x, y)
+    return "line counts differ: got %d want %d" % (len(la), len(lb))
+
+
+def _run_both(seed, G, N, L, k, e=0.0, variable=False, himem=True, max_rounds=-1, **kw):
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(seed, G, N, L, e, variable)
+    rs = O.ReadSet(bases, off, min_len=kw.get("overlap_size", 1000), himem=himem)
+    orun = O.OverlapRun(rs, k=k, himem=himem, max_rounds=max_rounds, traces=True, **kw)
+    reads = Reads(bases, off, min_len=kw.get("overlap_size", 1000), himem=himem)
+    pipe = OverlapPipeline(reads, k=k, himem=himem, **kw)
+    rounds = 0
+    while (max_rounds < 0 or rounds < max_rounds) and pipe.step():
+        d = first_diff(pipe.round_paf(), orun.trace_paf(rounds))
+        assert d is None, "PAF differs in round %d: %s" % (rounds, d)
+        rounds += 1
+    assert rounds == orun.rounds
+    assert first_diff(pipe.all_paf(), orun.paf) is None
+    assert np.array_equal(reads.ignore(), rs.ignore())
+    st = pipe.stats()
+    pipe.close()
+    return orun, st
+
+
+@pytest.mark.parametrize("k,G,N,L,e,variable", [(10, 100000, 400, 5000, 0.0, False), (10, 80000, 300, 6000, 0.03, True),
+                                                 (13, 1500000, 3000, 10000, 0.0, False),
+                                                 (13, 1200000, 2000, 12000, 0.002, True)])
+def test_overlap_paf_bit_exact(k, G, N, L, e, variable):
+    orun, st = _run_both(100 + k, G, N, L, k, e, variable, max_rounds=4)
+    assert orun.paf.count("\n") > 0
+
+
+def test_overlap_full_run_config1_k10():
+    """BASELINE config 1 shape (1k reads x 5 kb) at the command's default k=10, all rounds."""
+    orun, st = _run_both(1, 250000, 1000, 5000, 10)
+    assert orun.rounds >= 5
+
+
+def test_overlap_himem_false_top_level_reads():
+    """himem=false: reads are re-read as top-level sequences, len%4==0 scan quirk included."""
+    _run_both(7, 100000, 300, 4000, 10, himem=False, max_rounds=3)
+
+
+def test_values_table_matches_oracle():
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(3, 200000, 500, 4000, 0.01, True)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    want = rs.kmer_values(10)
+    reads = Reads(bases, off, min_len=1000)
+    pipe = OverlapPipeline(reads, k=10)
+    assert np.array_equal(pipe.values(), want)
+    pipe.close()
+
+
+def test_cli_matches_oracle_cli(tmp_path):
+    bases, off = O.gen_reads(9, 120000, 400, 5000, 0.0, False)
+    fa = str(tmp_path / "reads.fa")
+    O.write_fasta(fa, bases, off)
+    a = subprocess.run([os.path.join(ROOT, "downpore_amd", "bin", "downpore"), "overlap", "-input", fa, "-k", "10"],
+                       capture_output=True, check=True)
+    b = subprocess.run([os.path.join(ROOT, "oracle", "_build", "dp_oracle"), "overlap", "-input", fa, "-k", "10"],
+                       capture_output=True, check=True)
+    assert first_diff(a.stdout.decode(), b.stdout.decode()) is None and len(a.stdout) > 0
+    # aliases: -i / -k (commands/command.go:26-54)
+    c = subprocess.run([os.path.join(ROOT, "downpore_amd", "bin", "downpore"), "overlap", "-i", fa, "--k", "10"],
+                       capture_output=True, check=True)
+    assert first_diff(c.stdout.decode(), a.stdout.decode()) is None
