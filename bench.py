@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py — overlaps/sec of the all-vs-all overlap hot path on synthetic long reads (BASELINE.json metric).
+
+A "step" is one round of the overlap command (commands/overlap.go:115-194): seed selection for the next query batch,
+GPU scan of every non-ignored read, survivor exchange (N>1), index build, index query + chaining, consensus, PAF.
+Workload (N=1 default): BASELINE config 2 — 100 000 synthetic reads x 10 kb, genome 50 Mb (20x), k=13, error-free
+(the error-free set is the throughput default at k=13).  Inputs are resident in HBM before the timed
+region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=100000)
+    ap.add_argument("--read-len", type=int, default=10000)
+    ap.add_argument("--k", type=int, default=13)
+    ap.add_argument("--error", type=float, default=0.0)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--seed-batch-size", type=int, default=10000)
+    ap.add_argument("--cpu-rounds", type=int, default=2, help="oracle rounds timed for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    torch_device = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        torch_device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=torch_device)
+    else:
+        dist = None
+
+    from tools.synth import gen_reads
+    from downpore_amd.overlap import OverlapPipeline, Reads
+
+    N, L = args.reads, args.read_len
+    G = N * L // 20
+    t0 = time.time()
+    bases, off = gen_reads(args.seed, G, N, L, args.error, False)
+    reads = Reads(bases, off, min_len=1000)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    pipe = OverlapPipeline(reads, device=local_rank, k=args.k, seed_batch_size=args.seed_batch_size, rank=rank, world=world,
+                           torch_device=torch_device)
+    t_setup = time.time() - t0
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        if not pipe.step():
+            break
+    sync()
+    acc = {}
+    lines = 0
+    steps_done = 0
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        if not pipe.step():
+            break
+        st = pipe.stats()
+        for key, v in st.items():
+            acc[key] = acc.get(key, 0.0) + v
+        lines += int(st["n_paf"])
+        steps_done += 1
+    sync()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        n = max(1, steps_done)
+        count_ms = acc.get("k_count_ms", 0.0) / n
+        count_bytes = acc.get("count_bytes", 0.0) / n
+        achieved = (count_bytes / 1e9) / (count_ms / 1e3) if count_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "overlaps/sec (all-vs-all PAF)", "value": lines / elapsed if elapsed > 0 else 0.0, "unit": "overlaps/s",
+            "n_gpus": world, "steps": steps_done, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / n,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%d synthetic reads x %d bp, genome %d bp (20x), error %.3g, k=%d, overlap rounds "
+                                   "(BASELINE config 2)" % (N, L, G, args.error, args.k),
+                       "reads": N, "read_len": L, "k": args.k, "seed_batch_size": args.seed_batch_size,
+                       "parallelism": "scan sharded by read over %d GPU(s), survivors all-gathered" % world},
+            "roofline": {"bound": "hbm", "kernel": "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": count_bytes, "launch_ms": count_ms},
+            "paf_lines": lines, "rounds_per_s": steps_done / elapsed if elapsed > 0 else 0.0,
+            "reads_scanned_per_s": acc.get("scan_items", 0.0) / elapsed if elapsed > 0 else 0.0,
+            "phase_ms_per_step": {kk: 1e3 * acc.get(kk, 0.0) / n for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
+            "kernel_ms_per_step": {kk: acc.get(kk, 0.0) / n for kk in ("k_count_ms", "k_write_ms", "k_scan_ms", "k_query_ms", "k_chain_ms")},
+            "index_query": {"bytes_per_step": acc.get("query_bytes", 0.0) / n,
+                            "achieved_GBs": (acc.get("query_bytes", 0.0) / 1e9) / (acc.get("k_query_ms", 1e-9) / 1e3) if acc.get("k_query_ms", 0) > 0 else 0.0},
+            "setup_s": {"generate": t_gen, "upload_pack_histogram_values": t_setup},
+        }
+        if world == 1 and args.cpu_rounds > 0:
+            out["cpu_baseline"] = cpu_baseline(bases, off, args, pipe.values())
+        print(json.dumps(out))
+    pipe.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(bases, off, args, values):
+    """The oracle (a quirk-exact C++ port of the reference's CPU algorithm incl. its two-pass scan over a 4^k-byte
+    table) timed single-threaded on the host for the first rounds of the same workload."""
+    from tests import oracle_lib as O
+    O.build_oracle()
+    rs = O.ReadSet(bases, off, min_len=1000)
+    t0 = time.perf_counter()
+    run = O.OverlapRun(rs, k=args.k, seed_batch_size=args.seed_batch_size, values=np.ascontiguousarray(values),
+                       max_rounds=args.cpu_rounds, traces=False)
+    dt = time.perf_counter() - t0
+    lines = run.paf.count("\n")
+    return {"value": lines / dt if dt > 0 else 0.0, "unit": "overlaps/s", "cores": 1, "kind": "port",
+            "sample": "first %d rounds of the same workload (value table supplied), %.1f s, %d PAF lines" % (run.rounds, dt, lines),
+            "ms_per_step": 1e3 * dt / max(1, run.rounds)}
+
+
+if __name__ == "__main__":
+    main()

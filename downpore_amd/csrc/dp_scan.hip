@@ -505,6 +505,8 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     if (pin_reserve(ctx, ctx->h_total, 16)) return DP_ERR_HIP;
     out->n_items = n_items;
     out->kernel_ms = 0;
+    out->count_kernel_ms = 0;
+    out->write_kernel_ms = 0;
     out->bases_scanned = bases;
     ctx->scan_items = n_items;
     if (n_items == 0) {
@@ -532,9 +534,10 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
                        (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
                        (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr);
     DP_HIP(hipGetLastError());
+    DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const dp_scan_item*)ctx->d_items.p,
                        (const uint32_t*)ctx->d_counts.p, n_items, (uint64_t*)ctx->d_segoff.p, (uint64_t*)ctx->d_total.p);
-    DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->h_total.p, ctx->d_total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->h_counts.p, ctx->d_counts.p, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->h_segoff.p, ctx->d_segoff.p, ((size_t)n_items + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -542,8 +545,9 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     const uint64_t n_segs = *(uint64_t*)ctx->h_total.p;
     if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
-    float ms0 = 0, ms1 = 0;
+    float ms0 = 0, ms1 = 0, msoff = 0;
     hipEventElapsedTime(&ms0, ctx->ev[0], ctx->ev[1]);
+    hipEventElapsedTime(&msoff, ctx->ev[1], ctx->ev[4]);
     if (n_segs) {
         DP_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
         hipLaunchKernelGGL(scan_kernel<1>, dim3(grid), dim3(SCAN_THREADS), BLOOM_BYTES, ctx->stream,
@@ -562,7 +566,9 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     out->seg_off = (const uint64_t*)ctx->h_segoff.p;
     out->segs = (const int32_t*)ctx->h_segs.p;
     out->n_segs = n_segs;
-    out->kernel_ms = (double)ms0 + (double)ms1;
+    out->kernel_ms = (double)ms0 + (double)msoff + (double)ms1;
+    out->count_kernel_ms = ms0;
+    out->write_kernel_ms = ms1;
     return DP_OK;
 }
 

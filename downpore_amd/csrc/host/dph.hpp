@@ -149,6 +149,8 @@ struct OverlapParams {  // flag table commands/overlap.go:24-25
 struct RoundStats {
     double t_prepare = 0, t_scan = 0, t_index = 0, t_query = 0, t_consensus = 0;  // host wall seconds
     double k_scan_ms = 0, k_query_ms = 0, k_chain_ms = 0;                         // device kernel ms
+    double k_count_ms = 0, k_write_ms = 0;                                        // scan passes
+    uint64_t count_bytes = 0;                                                     // algorithmic bytes of the count pass
     uint64_t scan_bases = 0, scan_items = 0, scan_bytes = 0, query_bytes = 0;
     uint64_t n_queries = 0, n_indexed = 0, n_hits = 0, n_matches = 0, n_paf = 0, n_seeds = 0;
 };

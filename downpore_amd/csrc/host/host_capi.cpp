@@ -149,14 +149,16 @@ const char* dph_overlap_errtext(void* hh, int64_t* n) {
     return h->run.errText.data();
 }
 // out[0..] t_prepare,t_scan,t_index,t_query,t_consensus,k_scan_ms,k_query_ms,k_chain_ms,scan_bases,scan_items,
-// scan_bytes,query_bytes,n_queries,n_indexed,n_hits,n_matches,n_paf,n_seeds,round,badBack,emptyMatch
+// scan_bytes,query_bytes,n_queries,n_indexed,n_hits,n_matches,n_paf,n_seeds,round,badBack,emptyMatch,k_count_ms,
+// k_write_ms,count_bytes
 void dph_overlap_stats(void* hh, double* out) {
     OverlapH* h = (OverlapH*)hh;
     const RoundStats& s = h->run.last;
     double v[] = {s.t_prepare, s.t_scan, s.t_index, s.t_query, s.t_consensus, s.k_scan_ms, s.k_query_ms, s.k_chain_ms,
                   (double)s.scan_bases, (double)s.scan_items, (double)s.scan_bytes, (double)s.query_bytes, (double)s.n_queries,
                   (double)s.n_indexed, (double)s.n_hits, (double)s.n_matches, (double)s.n_paf, (double)s.n_seeds,
-                  (double)h->run.round, (double)h->run.badBack, (double)h->run.emptyMatch};
+                  (double)h->run.round, (double)h->run.badBack, (double)h->run.emptyMatch, s.k_count_ms, s.k_write_ms,
+                  (double)s.count_bytes};
     memcpy(out, v, sizeof v);
 }
 void* dph_overlap_ctx(void* hh) { return ((OverlapH*)hh)->ctx; }

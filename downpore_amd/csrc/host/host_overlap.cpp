@@ -81,6 +81,8 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
         return rc;
     }
     st.k_scan_ms += b.kernel_ms;
+    st.k_count_ms += b.count_kernel_ms;
+    st.k_write_ms += b.write_kernel_ms;
     st.scan_bases += b.bases_scanned;
     st.scan_items += items.size();
     // survivors of the local shard (ascending read id)
@@ -433,6 +435,7 @@ int OverlapRun::roundFinish(const Survivors& all) {
     last.t_consensus = now() - t2;
     // algorithmic bytes of the scan: packed bytes of the scanned items + bit table + 8 B per hit
     last.scan_bytes = last.scan_bases / 4 + (((uint64_t)1 << (2 * k)) / 8) + 8 * last.n_hits;
+    last.count_bytes = last.scan_bases / 4 + (((uint64_t)1 << (2 * k)) / 8);
     round++;
     return 0;
 }

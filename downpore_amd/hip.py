@@ -18,7 +18,7 @@ class DpError(RuntimeError):
 class SeedSeqBatch(C.Structure):
     _fields_ = [("n_items", C.c_uint32), ("n_seeds", C.POINTER(C.c_uint32)), ("seg_off", C.POINTER(C.c_uint64)),
                 ("segs", C.POINTER(C.c_int32)), ("n_segs", C.c_uint64), ("kernel_ms", C.c_double),
-                ("bases_scanned", C.c_uint64)]
+                ("count_kernel_ms", C.c_double), ("write_kernel_ms", C.c_double), ("bases_scanned", C.c_uint64)]
 
 
 class MatchBatch(C.Structure):
@@ -148,7 +148,8 @@ class Context:
         self._chk(self.L.dp_scan(self.h, it.ctypes.data, len(it), C.byref(b)))
         n = b.n_items
         return dict(n_seeds=_arr(b.n_seeds, n, np.uint32), seg_off=_arr(b.seg_off, n + 1, np.uint64),
-                    segs=_arr(b.segs, b.n_segs, np.int32), kernel_ms=b.kernel_ms, bases_scanned=b.bases_scanned)
+                    segs=_arr(b.segs, b.n_segs, np.int32), kernel_ms=b.kernel_ms, count_kernel_ms=b.count_kernel_ms,
+                    write_kernel_ms=b.write_kernel_ms, bases_scanned=b.bases_scanned)
 
     def import_segments(self, segs):
         s = np.ascontiguousarray(segs, dtype=np.int32)

@@ -91,7 +91,9 @@ typedef struct {
     const uint64_t* seg_off; /* [n_items+1] offsets into segs (int32 units); empty range if below min_seeds */
     const int32_t* segs;     /* host copy of all written segments */
     uint64_t n_segs;
-    double kernel_ms;        /* device time of the scan kernels of this call (HIP events) */
+    double kernel_ms;        /* device time of all scan kernels of this call (HIP events on the context's stream) */
+    double count_kernel_ms;  /* ... of the count pass alone (the kernel that streams every item once) */
+    double write_kernel_ms;  /* ... of the write pass alone (survivors only) */
     uint64_t bases_scanned;  /* sum of n_kmers + k - 1 over items */
 } dp_seedseq_batch;
 

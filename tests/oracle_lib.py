@@ -136,18 +136,14 @@ def ptr(a, t):
 
 def gen_reads(seed, G, N, L, e=0.0, variable=False):
     """Returns (bases uint8 array (ASCII), offsets int64[N+1])."""
-    cap = int(N * (L * (2 if (variable or e > 0) else 1) + 16))
-    bases = np.zeros(cap, dtype=np.uint8)
-    off = np.zeros(N + 1, dtype=np.int64)
-    n = synth().dps_reads(seed, G, N, L, float(e), 1 if variable else 0, bases.ctypes.data, cap, ptr(off, i64p), None, None)
-    assert n >= 0
-    return bases[:n].copy(), off
+    from tools.synth import gen_reads as _g
+    b, off = _g(seed, G, N, L, e, variable)
+    return b.copy(), off
 
 
 def gen_genome(seed, G):
-    buf = C.create_string_buffer(G)
-    synth().dps_genome(seed, G, buf)
-    return buf.raw
+    from tools.synth import gen_genome as _g
+    return _g(seed, G)
 
 
 def write_fasta(path, bases, off, prefix="r"):
