@@ -452,33 +452,74 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const uint8_t* __res
     }
 }
 
-// exclusive scan of (count >= min_seeds ? 2*count+1 : 0) over the items; single workgroup
-__global__ __launch_bounds__(1024) void scan_offsets_kernel(const dp_scan_item* __restrict__ items,
-                                                            const uint32_t* __restrict__ counts, uint32_t n,
-                                                            uint64_t* __restrict__ segoff, uint64_t* __restrict__ total) {
+// exclusive scan of (count >= min_seeds ? 2*count+1 : 0) over the items: tile sums -> scan of the tile sums -> offsets
+#define OFF_TILE 1024
+__device__ __forceinline__ uint32_t seg_len(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ counts, uint32_t i) {
+    const uint32_t c = counts[i];
+    return c >= items[i].min_seeds ? 2u * c + 1u : 0u;
+}
+__device__ __forceinline__ uint32_t block_incl_scan_1024(uint32_t v, uint32_t* sh /*16*/) {
+    const int lane = dp_lane(), wave = threadIdx.x >> 6;
+    uint32_t x = (uint32_t)wave_incl_sum((int)v);
+    if (lane == 63) sh[wave] = x;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < 16 ? sh[lane] : 0u;
+        w = (uint32_t)wave_incl_sum((int)w);
+        if (lane < 16) sh[lane] = w;
+    }
+    __syncthreads();
+    if (wave > 0) x += sh[wave - 1];
+    return x;
+}
+__global__ __launch_bounds__(OFF_TILE) void offsets_tile_sums(const dp_scan_item* __restrict__ items,
+                                                             const uint32_t* __restrict__ counts, uint32_t n,
+                                                             uint64_t* __restrict__ tile_sum) {
+    __shared__ uint32_t sh[16];
+    const uint32_t i = blockIdx.x * OFF_TILE + threadIdx.x;
+    uint32_t v = i < n ? seg_len(items, counts, i) : 0u;
+    uint32_t x = block_incl_scan_1024(v, sh);
+    if (threadIdx.x == OFF_TILE - 1) tile_sum[blockIdx.x] = x;
+}
+__global__ __launch_bounds__(1024) void offsets_scan_tiles(uint64_t* __restrict__ tile_sum, uint32_t n_tiles,
+                                                           uint64_t* __restrict__ total, uint64_t* __restrict__ segoff,
+                                                           uint32_t n) {
+    // single workgroup; tiles are few (n/1024): serial carry over chunks of 1024 tiles
     __shared__ uint64_t part[1024];
-    uint32_t per = (n + 1023) / 1024;
-    uint32_t b = threadIdx.x * per, e = min(n, b + per);
-    uint64_t s = 0;
-    for (uint32_t i = b; i < e; i++) s += counts[i] >= items[i].min_seeds ? 2ull * counts[i] + 1 : 0ull;
-    part[threadIdx.x] = s;
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < 1024; i++) {
-            uint64_t v = part[i];
-            part[i] = run;
-            run += v;
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        const uint32_t t = base + threadIdx.x;
+        part[threadIdx.x] = t < n_tiles ? tile_sum[t] : 0ull;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t run = carry;
+            const uint32_t m = min(1024u, n_tiles - base);
+            for (uint32_t j = 0; j < m; j++) {
+                const uint64_t v = part[j];
+                part[j] = run;
+                run += v;
+            }
+            carry = run;
         }
-        *total = run;
-        segoff[n] = run;
+        __syncthreads();
+        if (t < n_tiles) tile_sum[t] = part[threadIdx.x];
+        __syncthreads();
     }
-    __syncthreads();
-    uint64_t run = part[threadIdx.x];
-    for (uint32_t i = b; i < e; i++) {
-        segoff[i] = run;
-        run += counts[i] >= items[i].min_seeds ? 2ull * counts[i] + 1 : 0ull;
+    if (threadIdx.x == 0) {
+        *total = carry;
+        segoff[n] = carry;
     }
+}
+__global__ __launch_bounds__(OFF_TILE) void offsets_write(const dp_scan_item* __restrict__ items,
+                                                         const uint32_t* __restrict__ counts, uint32_t n,
+                                                         const uint64_t* __restrict__ tile_base, uint64_t* __restrict__ segoff) {
+    __shared__ uint32_t sh[16];
+    const uint32_t i = blockIdx.x * OFF_TILE + threadIdx.x;
+    uint32_t v = i < n ? seg_len(items, counts, i) : 0u;
+    uint32_t x = block_incl_scan_1024(v, sh);
+    if (i < n) segoff[i] = tile_base[blockIdx.x] + (uint64_t)(x - v);
 }
 
 extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items, dp_seedseq_batch* out) {
@@ -499,7 +540,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     if (dev_reserve(ctx, ctx->d_items, (size_t)n_items * sizeof(dp_scan_item) + 16)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_counts, (size_t)n_items * 4 + 16)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_segoff, ((size_t)n_items + 1) * 8)) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_total, 16)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_total, 16 + ((size_t)n_items / OFF_TILE + 2) * 8)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_counts, (size_t)n_items * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_segoff, ((size_t)n_items + 1) * 8)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_total, 16)) return DP_ERR_HIP;
@@ -535,8 +576,17 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
                        (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr);
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-    hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const dp_scan_item*)ctx->d_items.p,
-                       (const uint32_t*)ctx->d_counts.p, n_items, (uint64_t*)ctx->d_segoff.p, (uint64_t*)ctx->d_total.p);
+    {
+        const uint32_t n_tiles = (n_items + OFF_TILE - 1) / OFF_TILE;
+        uint64_t* tiles = (uint64_t*)ctx->d_total.p + 2;
+        hipLaunchKernelGGL(offsets_tile_sums, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)ctx->d_items.p,
+                           (const uint32_t*)ctx->d_counts.p, n_items, tiles);
+        hipLaunchKernelGGL(offsets_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tiles, n_tiles, (uint64_t*)ctx->d_total.p,
+                           (uint64_t*)ctx->d_segoff.p, n_items);
+        hipLaunchKernelGGL(offsets_write, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)ctx->d_items.p,
+                           (const uint32_t*)ctx->d_counts.p, n_items, (const uint64_t*)tiles, (uint64_t*)ctx->d_segoff.p);
+        DP_HIP(hipGetLastError());
+    }
     DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->h_total.p, ctx->d_total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->h_counts.p, ctx->d_counts.p, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));

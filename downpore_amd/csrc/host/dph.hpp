@@ -91,8 +91,11 @@ struct Arena {
 // The posting sets / seed sets themselves live on the GPU (dp_index_build).
 struct SeedIndex {
     int k;
-    std::vector<uint64_t> kmerBits;                 // 4^k-bit membership, sparse-reset between rounds
-    std::unordered_map<uint32_t, int32_t> kmerMap;  // k-mer -> seed id
+    // k-mer -> seed id: a small open-addressing table (<= ~20k seeds per round) that stays cache resident, instead of the
+    // reference's 4^k-entry kmers/kmerMap arrays (seeds/seeds.go:13,17)
+    std::vector<uint32_t> hkeys;                    // 0xffffffff = empty
+    std::vector<int32_t> hvals;
+    uint32_t hmask = 0;
     std::vector<uint32_t> seedMap;                  // seed id -> k-mer
     std::vector<SeedSeq*> sequences;                // indexed sequences (chunks), index == GPU sequence index
     std::vector<dp_seq_ref> refs;                   // their views into the device-resident scan output
@@ -100,9 +103,30 @@ struct SeedIndex {
     explicit SeedIndex(int k_);
     void reset();
     int size() const { return (int)seedMap.size(); }
-    bool isSeed(uint32_t kmer) const { return (kmerBits[kmer >> 6] >> (kmer & 63)) & 1; }
+    static uint32_t hash(uint32_t x) { return (x * 2654435761u) >> 7; }
+    int32_t find(uint32_t kmer) const {             // seed id or -1
+        uint32_t h = hash(kmer) & hmask;
+        for (;;) {
+            const uint32_t kk = hkeys[h];
+            if (kk == kmer) return hvals[h];
+            if (kk == 0xffffffffu) return -1;
+            h = (h + 1) & hmask;
+        }
+    }
+    // L1-resident 2^18-bit pre-filter in front of the hash (a miss is the common case during seed selection)
+    std::vector<uint64_t> pre;
+    static uint32_t preHash(uint32_t x) { return (x * 2246822519u) >> 14; }  // 18 bits
+    bool isSeed(uint32_t kmer) const {
+        const uint32_t b = preHash(kmer);
+        if (!((pre[b >> 6] >> (b & 63)) & 1)) return false;
+        return find(kmer) >= 0;
+    }
+    void grow();
     void addSeedKmer(uint32_t kmer);                                     // seeds.go:132-141
     void addSeeds(const char* s, i64 len, int minSeeds, const double* ranks);  // AddSeeds :62-156
+    void selectSeeds(const char* s, i64 len, int minSeeds, const double* ranks, uint32_t* topN, bool checkIndex) const;
+    bool touchesSeed(const char* s, i64 len) const;
+    void commitSeeds(const uint32_t* topN, int n);
     int32_t seedOfRcKmer(int32_t seed) const;                            // kmerMap[rc(seedMap[seed])]
 };
 
@@ -200,6 +224,7 @@ class Overlapper {
     std::vector<int32_t> allSegs_;         // survivors' segments (host copy; device copy is what the index references)
 };
 
+unsigned hostThreads();  // DP_HOST_THREADS or hardware_concurrency (<= 32)
 // finalCheckWorker (commands/overlap.go:197-233) over the collated matches of a round: consensus, SetIgnore, PAF text.
 struct FinalCheckStats {
     i64 badBack = 0, emptyMatch = 0;

@@ -1,7 +1,10 @@
 // Product host side: overlap.Overlapper (overlap/overlap.go) and the overlap command's round loop
 // (commands/overlap.go:96-233) above the C ABI.  Canonical single-worker order (DESIGN.md §canonical semantics).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 
@@ -23,24 +26,79 @@ Overlapper::Overlapper(dp_ctx* ctx, ReadSet& reads, SeedIndex& index, i64 chunkS
 int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values, i64 firstSequence, i64 maxSeqs) {
     windows_.clear();
     queries.clear();
+    // Candidate windows in file order.  The seed-budget cut-off (overlap.go:58) is applied in the sequential commit loop
+    // below; a window contributes at most 2*numSeeds seeds, so seedLimit/(2*numSeeds) windows are certainly needed and a
+    // modest surplus is selected speculatively.  (Selection = the rank-table lookups = the expensive part.)
+    struct Cand {
+        uint32_t read, start, len;
+        bool lastOfRead;
+    };
+    std::vector<Cand> cand;
+    const size_t want = (size_t)(seedLimit / std::max(1, 2 * numSeeds)) + 96;
     i64 sent = 0;
-    if (!(firstSequence != 0 && firstSequence >= (i64)reads_.size())) {  // seqio.go:279
-        for (size_t r = (size_t)firstSequence; r < reads_.size() && sent < maxSeqs; r++) {
-            if (reads_.ignore[r]) continue;
+    size_t rNext = (size_t)firstSequence;
+    auto moreCands = [&](size_t upTo) {
+        if (firstSequence != 0 && firstSequence >= (i64)reads_.size()) return;  // seqio.go:279
+        for (; rNext < reads_.size() && sent < maxSeqs && cand.size() < upTo; rNext++) {
+            if (reads_.ignore[rNext]) continue;
             sent++;
-            if (index_.size() >= seedLimit) break;  // overlap.go:58
-            const i64 L = reads_.length(r);
-            const char* s = reads_.seq(r);
+            const i64 L = reads_.length(rNext);
             if (L < overlap_ * 2) {
-                index_.addSeeds(s, L, numSeeds, values);
-                windows_.push_back({(uint32_t)r, 0u, (uint32_t)L});
+                cand.push_back({(uint32_t)rNext, 0u, (uint32_t)L, true});
             } else {
-                index_.addSeeds(s, overlap_, numSeeds, values);
-                index_.addSeeds(s + (L - overlap_), overlap_, numSeeds, values);
-                windows_.push_back({(uint32_t)r, 0u, (uint32_t)overlap_});
-                windows_.push_back({(uint32_t)r, (uint32_t)(L - overlap_), (uint32_t)overlap_});
+                cand.push_back({(uint32_t)rNext, 0u, (uint32_t)overlap_, false});
+                cand.push_back({(uint32_t)rNext, (uint32_t)(L - overlap_), (uint32_t)overlap_, true});
             }
         }
+    };
+    std::vector<uint32_t> spec;
+    size_t specDone = 0;
+    auto speculate = [&](size_t upTo) {  // thread-parallel selection assuming no evaluated k-mer is a seed yet
+        moreCands(upTo);
+        const size_t n = cand.size();
+        spec.resize(n * (size_t)numSeeds);
+        const size_t first = specDone;
+        if (n <= first) return;
+        unsigned nt = std::min<unsigned>(hostThreads(), (unsigned)((n - first + 7) / 8));
+        std::atomic<size_t> next(first);
+        auto worker = [&]() {
+            for (;;) {
+                const size_t w = next.fetch_add(1);
+                if (w >= n) break;
+                const Cand& c = cand[w];
+                index_.selectSeeds(reads_.seq(c.read) + c.start, c.len, numSeeds, values, &spec[w * (size_t)numSeeds], false);
+            }
+        };
+        if (nt <= 1) {
+            worker();
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++) th.emplace_back(worker);
+            for (auto& x : th) x.join();
+        }
+        specDone = n;
+    };
+    speculate(want);
+    std::vector<uint32_t> tmp((size_t)numSeeds);
+    size_t w = 0;
+    for (;;) {
+        if (w >= cand.size()) {
+            speculate(cand.size() + 64);
+            if (w >= cand.size()) break;  // input exhausted
+        }
+        // getEdges tests the budget once per READ, before its first window (overlap.go:57-60)
+        const bool firstOfRead = (w == 0) || cand[w - 1].lastOfRead;
+        if (firstOfRead && index_.size() >= seedLimit) break;
+        const Cand& c = cand[w];
+        const char* s = reads_.seq(c.read) + c.start;
+        if (index_.touchesSeed(s, c.len)) {  // speculation invalid: redo this window against the current seed set
+            index_.selectSeeds(s, c.len, numSeeds, values, tmp.data(), true);
+            index_.commitSeeds(tmp.data(), numSeeds);
+        } else {
+            index_.commitSeeds(&spec[w * (size_t)numSeeds], numSeeds);
+        }
+        windows_.push_back({c.read, c.start, c.len});
+        w++;
     }
     return (int)windows_.size();
 }
@@ -269,7 +327,57 @@ int Overlapper::FindOverlaps(std::vector<std::unique_ptr<SeedMatch>>& out, Round
     return 0;
 }
 
-// finalCheckWorker commands/overlap.go:197-233 (+ collation :158-173)
+// finalCheckWorker commands/overlap.go:197-233 (+ collation :158-173).  Queries are independent (the reference runs
+// num_workers finalCheckWorkers); they are spread over host threads here, and the PAF text and SetIgnore effects are
+// applied in query order afterwards, so the result is the canonical single-worker output.
+static void finalCheckOne(Arena& arena, const SeedIndex& index, const ReadSet& reads, std::vector<SeedMatch*>& results,
+                          i64 overlapSize, std::string& paf, std::vector<int>& ignoreIds, FinalCheckStats& fs) {
+    const int k = index.k;
+    std::unique_ptr<SeedContig> contig = buildConsensus(arena, index, results, &fs.badBack);
+    if (!contig || contig->Parts.size() <= 1) return;
+    if (contig->SeqLengths[0] <= overlapSize * 2) ignoreIds.push_back(contig->Parts[0]);
+    const i64 queryStart = contig->Offsets[0], queryEnd = queryStart + contig->Lengths[0];
+    char num[32];
+    auto app = [&](i64 v) {
+        int n = snprintf(num, sizeof num, "%lld", (long long)v);
+        paf.append(num, (size_t)n);
+    };
+    for (size_t i = 0; i + 1 < contig->Parts.size(); i++) {
+        const size_t id = i + 1;
+        const int part = contig->Parts[id];
+        const i64 start = contig->Offsets[id], end = start + contig->Lengths[id];
+        const char* rcs = contig->ReverseComplement[0] != contig->ReverseComplement[id] ? "-" : "+";
+        i64 covered = overlapSize;
+        if (end - start > overlapSize) covered = end - start;
+        if (contig->SeqLengths[id] * 9 <= covered * 10) ignoreIds.push_back(part);
+        i64 ident = 0, identB = 0;
+        bool panic = false;
+        matchBasesCovered(*contig->Matches[i], k, &ident, &identB, &panic);
+        if (panic) fs.emptyMatch++;  // the reference panics here; canonical: ident 0
+        paf += reads.names[(size_t)contig->Parts[0]];
+        paf += '\t';
+        app(contig->SeqLengths[0]);
+        paf += '\t';
+        app(queryStart);
+        paf += '\t';
+        app(queryEnd);
+        paf += '\t';
+        paf += rcs;
+        paf += '\t';
+        paf += reads.names[(size_t)part];
+        paf += '\t';
+        app(contig->SeqLengths[id]);
+        paf += '\t';
+        app(start);
+        paf += '\t';
+        app(end);
+        paf += '\t';
+        app(ident);
+        paf += "\t0\t255\n";
+        fs.lines++;
+    }
+}
+
 void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vector<std::unique_ptr<SeedMatch>>& matches,
                 i64 numQuerySeqs, i64 overlapSize, std::string& paf, FinalCheckStats& fs) {
     // collate by QueryID (:158-173)
@@ -281,53 +389,54 @@ void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vecto
         if (qr.size() == 1) qHits++;
         qr.push_back(m.get());
     }
-    // finalCheckWorker :197-233
-    const int k = index.k;
-    uint64_t lines = 0;
-    for (auto& results : queryResults) {
-        if (results.size() <= 1) continue;
-        std::unique_ptr<SeedContig> contig = buildConsensus(arena, index, results, &fs.badBack);
-        if (!contig || contig->Parts.size() <= 1) continue;
-        if (contig->SeqLengths[0] <= overlapSize * 2) reads.ignore[(size_t)contig->Parts[0]] = 1;
-        const i64 queryStart = contig->Offsets[0], queryEnd = queryStart + contig->Lengths[0];
-        for (size_t i = 0; i + 1 < contig->Parts.size(); i++) {
-            const size_t id = i + 1;
-            const int part = contig->Parts[id];
-            const i64 start = contig->Offsets[id], end = start + contig->Lengths[id];
-            const char* rcs = contig->ReverseComplement[0] != contig->ReverseComplement[id] ? "-" : "+";
-            i64 covered = overlapSize;
-            if (end - start > overlapSize) covered = end - start;
-            if (contig->SeqLengths[id] * 9 <= covered * 10) reads.ignore[(size_t)part] = 1;
-            i64 ident = 0, identB = 0;
-            bool panic = false;
-            matchBasesCovered(*contig->Matches[i], k, &ident, &identB, &panic);
-            if (panic) fs.emptyMatch++;  // the reference panics here; canonical: ident 0
-            paf += reads.names[(size_t)contig->Parts[0]];
-            paf += '\t';
-            paf += std::to_string(contig->SeqLengths[0]);
-            paf += '\t';
-            paf += std::to_string(queryStart);
-            paf += '\t';
-            paf += std::to_string(queryEnd);
-            paf += '\t';
-            paf += rcs;
-            paf += '\t';
-            paf += reads.names[(size_t)part];
-            paf += '\t';
-            paf += std::to_string(contig->SeqLengths[id]);
-            paf += '\t';
-            paf += std::to_string(start);
-            paf += '\t';
-            paf += std::to_string(end);
-            paf += '\t';
-            paf += std::to_string(ident);
-            paf += "\t0\t255\n";
-            lines++;
+    std::vector<size_t> work;
+    for (size_t q = 0; q < queryResults.size(); q++)
+        if (queryResults[q].size() > 1) work.push_back(q);
+    const size_t nw = work.size();
+    std::vector<std::string> outs(nw);
+    std::vector<std::vector<int>> ign(nw);
+    unsigned nt = hostThreads();
+    if (nt > nw) nt = (unsigned)std::max<size_t>(1, nw);
+    std::vector<FinalCheckStats> tfs(nt);
+    std::atomic<size_t> next(0);
+    auto worker = [&](unsigned t) {
+        Arena local;  // scratch SeedSeqs of this worker; nothing outlives finalCheck
+        for (;;) {
+            const size_t w = next.fetch_add(1);
+            if (w >= nw) break;
+            finalCheckOne(local, index, reads, queryResults[work[w]], overlapSize, outs[w], ign[w], tfs[t]);
+            local.clear();
         }
+    };
+    (void)arena;
+    if (nt <= 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(worker, t);
+        for (auto& x : th) x.join();
     }
-    fs.lines = lines;
+    for (size_t w = 0; w < nw; w++) {
+        paf += outs[w];
+        for (int id : ign[w]) reads.ignore[(size_t)id] = 1;
+    }
+    for (auto& t : tfs) {
+        fs.badBack += t.badBack;
+        fs.emptyMatch += t.emptyMatch;
+        fs.lines += t.lines;
+    }
     fs.hits = (uint64_t)hits;
     fs.qHits = (uint64_t)qHits;
+}
+
+unsigned hostThreads() {
+    static unsigned n = [] {
+        const char* e = getenv("DP_HOST_THREADS");
+        unsigned v = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+        if (v == 0) v = 1;
+        return std::min(v, 32u);
+    }();
+    return n;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -145,36 +145,71 @@ std::vector<double> kmerValuesFromCounts(std::vector<uint64_t>& counts, int k) {
 // ---------------------------------------------------------------------------------------------------------------
 // seeds.SeedIndex host mirror
 
-SeedIndex::SeedIndex(int k_) : k(k_) { kmerBits.assign(((size_t)1 << (2 * k_)) / 64 + 1, 0); }
+SeedIndex::SeedIndex(int k_) : k(k_) {
+    hkeys.assign(1u << 16, 0xffffffffu);
+    hvals.assign(1u << 16, -1);
+    hmask = (1u << 16) - 1;
+    pre.assign((1u << 18) / 64, 0);
+}
 
 void SeedIndex::reset() {
-    for (uint32_t km : seedMap) kmerBits[km >> 6] = 0;  // every set bit belongs to a seed of this round
-    kmerMap.clear();
+    std::fill(hkeys.begin(), hkeys.end(), 0xffffffffu);
+    std::fill(pre.begin(), pre.end(), 0);
     seedMap.clear();
     sequences.clear();
     refs.clear();
     arena.clear();
 }
 
+void SeedIndex::grow() {
+    const size_t ncap = hkeys.size() * 2;
+    hkeys.assign(ncap, 0xffffffffu);
+    hvals.assign(ncap, -1);
+    hmask = (uint32_t)ncap - 1;
+    for (size_t i = 0; i < seedMap.size(); i++) {
+        uint32_t h = hash(seedMap[i]) & hmask;
+        while (hkeys[h] != 0xffffffffu) h = (h + 1) & hmask;
+        hkeys[h] = seedMap[i];
+        hvals[h] = (int32_t)i;
+    }
+}
+
 void SeedIndex::addSeedKmer(uint32_t kmer) {
     if (!isSeed(kmer)) {
-        kmerBits[kmer >> 6] |= 1ull << (kmer & 63);
-        kmerMap[kmer] = (int32_t)seedMap.size();
+        if ((seedMap.size() + 1) * 2 > hkeys.size()) grow();
+        uint32_t h = hash(kmer) & hmask;
+        while (hkeys[h] != 0xffffffffu) h = (h + 1) & hmask;
+        hkeys[h] = kmer;
+        hvals[h] = (int32_t)seedMap.size();
         seedMap.push_back(kmer);
+        const uint32_t b = preHash(kmer);
+        pre[b >> 6] |= 1ull << (b & 63);
     }
 }
 
 int32_t SeedIndex::seedOfRcKmer(int32_t seed) const {
-    uint32_t rc = reverseComplementKmer(seedMap[(size_t)seed], k);
-    auto it = kmerMap.find(rc);
-    return it == kmerMap.end() ? 0 : it->second;  // kmerMap[] of a non-seed is the zero value (seeds.go:17)
+    const int32_t id = find(reverseComplementKmer(seedMap[(size_t)seed], k));
+    return id < 0 ? 0 : id;  // kmerMap[] of a non-seed is the zero value (seeds.go:17)
 }
 
 // AddSeeds seeds/seeds.go:62-156 on an ASCII window (firstLen == 4 views behave like plain strings).
-void SeedIndex::addSeeds(const char* s, i64 L, int minSeeds, const double* ranks) {
+// selectSeeds() is the selection loop; with checkIndex=false it assumes no evaluated k-mer is a seed yet (the
+// speculative, thread-parallel form used by Overlapper::PrepareQueries), touchesSeed() tests exactly that assumption.
+template <bool CHECK>
+static void selectSeedsT(const SeedIndex& ix, const char* s, i64 L, int minSeeds, const double* ranks, uint32_t* topN) {
+    const int k = ix.k;
     const uint32_t mask = (uint32_t)(((uint64_t)1 << (2 * k)) - 1);
-    std::vector<uint32_t> topN((size_t)minSeeds, 0);
-    std::vector<double> topV((size_t)minSeeds, 0.0);
+    double topVbuf[64];
+    std::vector<double> topVdyn;
+    double* topV = topVbuf;
+    if (minSeeds > 64) {
+        topVdyn.assign((size_t)minSeeds, 0.0);
+        topV = topVdyn.data();
+    }
+    for (int i = 0; i < minSeeds; i++) {
+        topN[i] = 0;
+        topV[i] = 0.0;
+    }
     auto kmerAt = [&](i64 p) {
         uint32_t v = 0;
         for (int j = 0; j < k; j++) v = (v << 2) | baseCode((unsigned char)s[p + j]);
@@ -186,10 +221,17 @@ void SeedIndex::addSeeds(const char* s, i64 L, int minSeeds, const double* ranks
         bool reset = false;
         double bestValue = 0.0;
         uint32_t bestSeed = 0;
+        {  // the block's k rank lookups hit a 4^k-entry table at random: issue them together (prefetch only)
+            uint32_t pk = kmer;
+            for (i64 pi = nextIndex, i = 0; pi < L && i < k; i++, pi++) {
+                pk = ((pk << 2) | baseCode((unsigned char)s[pi])) & mask;
+                __builtin_prefetch(&ranks[pk], 0, 0);
+            }
+        }
         for (int i = 0; nextIndex < L && i < k; i++) {
             kmer = ((kmer << 2) | baseCode((unsigned char)s[nextIndex])) & mask;
             nextIndex++;
-            if (isSeed(kmer)) {
+            if (CHECK && ix.isSeed(kmer)) {
                 reset = true;
                 break;
             }
@@ -200,8 +242,8 @@ void SeedIndex::addSeeds(const char* s, i64 L, int minSeeds, const double* ranks
             }
         }
         if (!reset) {
-            size_t n = 0;
-            for (; n < topV.size() && topV[n] < bestValue; n++) {
+            int n = 0;
+            for (; n < minSeeds && topV[n] < bestValue; n++) {
                 if (n > 0) {
                     topV[n - 1] = topV[n];
                     topN[n - 1] = topN[n];
@@ -216,10 +258,47 @@ void SeedIndex::addSeeds(const char* s, i64 L, int minSeeds, const double* ranks
         if (nextIndex < L - k) kmer = kmerAt(nextIndex);
         nextIndex += k;
     }
-    for (uint32_t km : topN) {
-        addSeedKmer(km);
-        addSeedKmer(reverseComplementKmer(km, k));
+}
+
+void SeedIndex::selectSeeds(const char* s, i64 L, int minSeeds, const double* ranks, uint32_t* topN, bool checkIndex) const {
+    if (checkIndex) selectSeedsT<true>(*this, s, L, minSeeds, ranks, topN);
+    else selectSeedsT<false>(*this, s, L, minSeeds, ranks, topN);
+}
+
+// true iff one of the k-mers AddSeeds would evaluate (with no reset so far) is already a seed
+bool SeedIndex::touchesSeed(const char* s, i64 L) const {
+    const uint32_t mask = (uint32_t)(((uint64_t)1 << (2 * k)) - 1);
+    auto kmerAt = [&](i64 p) {
+        uint32_t v = 0;
+        for (int j = 0; j < k; j++) v = (v << 2) | baseCode((unsigned char)s[p + j]);
+        return v;
+    };
+    uint32_t kmer = kmerAt(0);
+    i64 nextIndex = k;
+    while (nextIndex < L - k) {
+        for (int i = 0; nextIndex < L && i < k; i++) {
+            kmer = ((kmer << 2) | baseCode((unsigned char)s[nextIndex])) & mask;
+            nextIndex++;
+            if (isSeed(kmer)) return true;
+        }
+        nextIndex += k;
+        if (nextIndex < L - k) kmer = kmerAt(nextIndex);
+        nextIndex += k;
     }
+    return false;
+}
+
+void SeedIndex::commitSeeds(const uint32_t* topN, int n) {  // seeds.go:130-154
+    for (int i = 0; i < n; i++) {
+        addSeedKmer(topN[i]);
+        addSeedKmer(reverseComplementKmer(topN[i], k));
+    }
+}
+
+void SeedIndex::addSeeds(const char* s, i64 L, int minSeeds, const double* ranks) {
+    std::vector<uint32_t> topN((size_t)minSeeds, 0);
+    selectSeeds(s, L, minSeeds, ranks, topN.data(), true);
+    commitSeeds(topN.data(), minSeeds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
