@@ -74,8 +74,10 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
 int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs);
 int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,
                           uint32_t max_query_len, int want_candidates, dp_match_batch* out);
-int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, uint32_t nw, int k,
+int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t nw, int k,
                         dp_chain_batch* out);
+int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
+                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out);
 
 // ---- device helpers ---------------------------------------------------------------------------------------
 #ifdef __HIPCC__

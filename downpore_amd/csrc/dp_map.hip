@@ -1,6 +1,441 @@
-// libdownpore_hip.so — map-flavour query (A19 + A20).  Placeholder until the map kernels land.
+// libdownpore_hip.so — map-flavour query (A19 + A20): the candidate loop of mapping.performMapping
+// (mapping/mapping.go:494-589) for batches of (forward, reverse-complement) window pairs.  CDNA4 / gfx950 only.
+//
+// Per pair, one persistent wave:
+//   Matches(0.25) for both windows comes from the shared index-query stage (query_kernel, dp_overlap.hip).
+//   For each candidate chunk (ascending): exact-intersection prefilter (wave-parallel popcount), then
+//   SeedSequence.Match (seeds/sequence.go:361-394) on lane 0: Reduced(target | query seeds), Reduced(query | target
+//   seeds), dynamicMatch (:401-471) with extendChain (:476-576), indices mapped back through the reduction maps.
+//   Every returned chain whose unmatched query flanks are <= 2/3 of the window is emitted and ratchets
+//   minMatches / minRCMatches by 4/5 of its length (:536-549, 576-586); the forward ratchet also raises the reverse
+//   threshold.
+// LDS per wave: reduced query/target segments + index maps + per-query-seed chain heads.  Chain storage (Go slices
+// sharing backing arrays) lives in an HBM scratch pool: one fixed-stride slot per started chain.
+#include <algorithm>
+#include <cstring>
+
 #include "dp_common.h"
 
-int dp_map_windows_impl(dp_ctx* ctx, const int32_t*, const uint64_t*, uint32_t, int, dp_chain_batch*) {
-    return dp_fail(ctx, DP_ERR_STATE, "dp_map_windows: not implemented yet");
+typedef uint64_t u64;
+
+#define M_WAVES 4
+#define M_QMAX 256        // reduced query seeds held in LDS
+#define M_TMAX 2048       // reduced target seeds held in LDS
+#define M_CHAINS 1024     // chains that may be started per candidate (pool slots per wave)
+#define M_GOOD 512
+
+struct MWave {
+    int32_t q[2 * M_QMAX + 1];
+    int32_t t[2 * M_TMAX + 1];
+    uint16_t qIdx[M_QMAX];
+    uint16_t tIdx[M_TMAX];
+    int32_t headChain[M_QMAX];  // chain slot recorded for each reduced query seed (-1 none)
+    uint16_t headLen[M_QMAX];   // its length at that seed (the Go slice header's len)
+    int32_t good[M_GOOD];
+};
+
+__device__ __forceinline__ bool m_contains(const u64* __restrict__ set, int32_t x) { return (set[x >> 6] >> (x & 63)) & 1ull; }
+
+// SeedSequence.Reduced (seeds/sequence.go:85-123).  Returns the number of reduced seeds or -1 if < minSeeds.
+// err bit 1: LDS capacity.
+template <typename IDX>
+__device__ int m_reduce(const int32_t* __restrict__ seg, int n, const u64* __restrict__ whitelist, int k, int minSeeds,
+                        int32_t* out, IDX* index, int cap, uint32_t* err) {
+    int count = 0, prev = -1;
+    for (int i = 1; i < n; i += 2) {
+        const int next = seg[i];
+        if (next != prev && m_contains(whitelist, next)) {
+            count++;
+            prev = next;
+        }
+    }
+    if (count < minSeeds) return -1;
+    if (count > cap) {
+        *err |= 1;
+        return -1;
+    }
+    int offset = seg[0];
+    prev = -1;
+    int j = 0;
+    for (int i = 1; i < n; i += 2) {
+        const int seed = seg[i];
+        if (prev != seed && m_contains(whitelist, seed)) {
+            out[j] = offset;
+            out[j + 1] = seed;
+            index[j / 2] = (IDX)(i / 2);
+            j += 2;
+            offset = seg[i + 1];
+            prev = seed;
+        } else {
+            offset += seg[i + 1] + k;
+        }
+    }
+    out[j] = offset;
+    return count;
+}
+
+struct MChainPool {
+    uint16_t* a;  // [M_CHAINS][M_QMAX]
+    uint16_t* b;
+    __device__ __forceinline__ uint16_t* A(int c) const { return a + (size_t)c * M_QMAX; }
+    __device__ __forceinline__ uint16_t* B(int c) const { return b + (size_t)c * M_QMAX; }
+};
+
+// extendChain (seeds/sequence.go:476-576); a = reduced query, b = reduced target.  Returns the chain's final length.
+__device__ int m_extend(MWave& L, int an, int bn, int aIndex, int bIndex, int k, int cur, int curLen, const MChainPool& P) {
+    const int32_t* as = L.q;
+    const int32_t* bs = L.t;
+    uint16_t* ca = P.A(cur);
+    uint16_t* cb = P.B(cur);
+    int offsetA = as[aIndex + 1], offsetB = bs[bIndex + 1];
+    aIndex += 2;
+    bIndex += 2;
+    while (aIndex < an && bIndex < bn) {
+        int aSeedIndex = aIndex / 2;
+        int minBOffset, maxBOffset;
+        if (offsetA < 0) {
+            minBOffset = -k;
+            maxBOffset = 0;
+        } else {
+            minBOffset = (offsetA * 2) / 3 - k;
+            maxBOffset = (offsetA * 3) / 2 + k;
+        }
+        while (maxBOffset < offsetB) {
+            offsetA += as[aIndex + 1] + k;
+            aIndex += 2;
+            if (aIndex >= an) return curLen;
+            aSeedIndex = aIndex / 2;
+            minBOffset = (offsetA * 2) / 3 - k;
+            maxBOffset = (offsetA * 3) / 2 + k;
+        }
+        while (offsetB < minBOffset) {
+            offsetB += bs[bIndex + 1] + k;
+            bIndex += 2;
+            if (bIndex >= bn) return curLen;
+        }
+        const int oldBIndex = bIndex, oldBOffset = offsetB;
+        bool matched = false;
+        const int seedA = as[aIndex];
+        while (offsetB <= maxBOffset) {
+            if (seedA == bs[bIndex]) {
+                const int hc = L.headChain[aSeedIndex];
+                if (hc >= 0) {
+                    const int hl = L.headLen[aSeedIndex];
+                    if (bIndex / 2 == (int)P.B(hc)[hl - 1] && hl > curLen) return curLen;  // they have a better chain already
+                }
+                ca[curLen] = (uint16_t)aSeedIndex;
+                cb[curLen] = (uint16_t)(bIndex / 2);
+                curLen++;
+                L.headChain[aSeedIndex] = cur;
+                L.headLen[aSeedIndex] = (uint16_t)curLen;
+                offsetA = as[aIndex + 1];
+                offsetB = bs[bIndex + 1];
+                aIndex += 2;
+                bIndex += 2;
+                matched = true;
+                break;
+            } else {
+                offsetB += bs[bIndex + 1] + k;
+                bIndex += 2;
+                if (bIndex >= bn) break;
+            }
+        }
+        if (!matched) {
+            offsetA += as[aIndex + 1] + k;
+            aIndex += 2;
+            offsetB = oldBOffset;
+            bIndex = oldBIndex;
+        }
+    }
+    return curLen;
+}
+
+// dynamicMatch (seeds/sequence.go:401-471).  seq = reduced target (L.t, sn ints), query = reduced query (L.q, qn ints).
+// Fills L.good with chain slots (in the reference's allGoodChains order) and their lengths in goodLen; returns count.
+// err bit 2: chain pool exhausted, bit 4: good list overflow.
+__device__ int m_dynamic_match(MWave& L, int qn, int sn, int minMatch, int k, const MChainPool& P, uint16_t* chainLen,
+                               uint32_t* err) {
+    if (minMatch == 0) minMatch = 1;
+    const int nq = qn / 2;
+    for (int i = 0; i < nq; i++) L.headChain[i] = -1;
+    int nChains = 0, nGood = 0;
+    const int32_t* qs = L.q;
+    const int32_t* ss = L.t;
+    for (int qIndex = 1; qIndex < qn - minMatch * 2 + 2; qIndex += 2) {
+        if (qs[qIndex - 1] < 0 && qIndex > 1 && qs[qIndex + 1] < 0 && qs[qIndex] == qs[qIndex - 2] && qs[qIndex] == qs[qIndex + 2])
+            continue;
+        const int qsi = qIndex / 2;
+        if (L.headChain[qsi] >= 0) continue;
+        int prevSeed = -1;
+        for (int i = 1; i < sn - minMatch * 2 + 2; i += 2) {
+            const int nextSeed = ss[i];
+            const int hc = L.headChain[qsi];
+            if (nextSeed == qs[qIndex] && nextSeed != prevSeed && (hc < 0 || (int)P.B(hc)[L.headLen[qsi] - 1] != i / 2)) {
+                if (nChains >= M_CHAINS) {
+                    *err |= 2;
+                    return nGood;
+                }
+                const int c = nChains++;
+                P.A(c)[0] = (uint16_t)qsi;
+                P.B(c)[0] = (uint16_t)(i / 2);
+                L.headChain[qsi] = c;
+                L.headLen[qsi] = 1;
+                const int len = m_extend(L, qn, sn, qIndex, i, k, c, 1, P);
+                chainLen[c] = (uint16_t)len;
+                if (len >= minMatch) {
+                    const int nextLength = (len * 2) / 3;
+                    if (nextLength > minMatch) {
+                        minMatch = nextLength;
+                        for (int j = nGood - 1; j >= 0; j--) {
+                            if ((int)chainLen[L.good[j]] < nextLength) {
+                                L.good[j] = L.good[nGood - 1];
+                                nGood--;
+                            }
+                        }
+                    }
+                    if (nGood >= M_GOOD) {
+                        *err |= 4;
+                        return nGood;
+                    }
+                    L.good[nGood++] = c;
+                    int remaining = 0;
+                    for (int x = 0; x < nq; x++) remaining += L.headChain[x] < 0;
+                    if (remaining < len) return nGood;
+                }
+            }
+            prevSeed = nextSeed;
+        }
+    }
+    return nGood;
+}
+
+struct MapRec {
+    uint32_t window, target, off, len, seq;
+};
+
+// GetSeedOffset / GetSeedOffsetFromEnd on the ORIGINAL window segments (seeds/sequence.go:1239-1276)
+__device__ __forceinline__ int m_seed_offset(const int32_t* seg, int index, int k) {
+    index = index * 2 + 1;
+    int o = seg[0];
+    for (int i = 2; i < index; i += 2) o += seg[i] + k;
+    return o;
+}
+__device__ __forceinline__ int m_seed_offset_from_end(const int32_t* seg, int n, int index, int k) {
+    index = index * 2 + 1;
+    int o = seg[n - 1];
+    for (int i = n - 3; i > index; i -= 2) o += seg[i] + k;
+    return o;
+}
+
+// cursor: [0] records, [1] ints, [2] error bits, [3] overflow flag
+__global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __restrict__ wsegs, const u64* __restrict__ woff,
+                                                           const uint32_t* __restrict__ wlen, uint32_t n_pairs,
+                                                           const u64* __restrict__ wsets, const uint32_t* __restrict__ qmeta,
+                                                           const u64* __restrict__ cand, const dp_seq_ref* __restrict__ refs,
+                                                           const int32_t* __restrict__ segs, const u64* __restrict__ seedsets,
+                                                           uint32_t W, uint32_t SW, int k, uint16_t* __restrict__ poolA,
+                                                           uint16_t* __restrict__ poolB, uint16_t* __restrict__ poolLen,
+                                                           MapRec* __restrict__ recs, uint32_t rec_cap, int32_t* __restrict__ ma,
+                                                           int32_t* __restrict__ mb, uint32_t int_cap, uint32_t* __restrict__ cursor) {
+    __shared__ MWave sh[M_WAVES];
+    MWave& L = sh[threadIdx.x >> 6];
+    const int lane = dp_lane();
+    const uint32_t waves = gridDim.x * M_WAVES;
+    const uint32_t gw = blockIdx.x * M_WAVES + (threadIdx.x >> 6);
+    MChainPool P;
+    P.a = poolA + (size_t)gw * M_CHAINS * M_QMAX;
+    P.b = poolB + (size_t)gw * M_CHAINS * M_QMAX;
+    uint16_t* chainLen = poolLen + (size_t)gw * M_CHAINS;
+    for (uint32_t pair = gw; pair < n_pairs; pair += waves) {
+        // performMapping :494-501
+        int thr[2];
+        for (int s = 0; s < 2; s++) {
+            const uint32_t w = 2 * pair + s;
+            const int ns = (int)((woff[w + 1] - woff[w]) / 2);
+            thr[s] = ns / 5 < 5 ? 5 : ns / 5;
+        }
+        uint32_t seq = 0;
+        for (int s = 0; s < 2; s++) {
+            const uint32_t w = 2 * pair + s;
+            const int32_t* qSeg = wsegs + woff[w];
+            const int qN = (int)(woff[w + 1] - woff[w]);
+            const int qLen = (int)wlen[w];
+            const u64* qset = wsets + (uint64_t)w * SW;
+            if (qmeta[4 * w + 0] < 5 || qmeta[4 * w + 2]) continue;  // Matches() returned nothing
+            for (uint32_t wi = 0; wi < W; wi++) {
+                u64 mask = cand[(uint64_t)w * W + wi];
+                while (mask) {
+                    const int b = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const uint32_t t = wi * 64 + (uint32_t)b;
+                    const u64* tset = seedsets + (uint64_t)t * SW;
+                    int c = 0;
+                    for (uint32_t x = lane; x < SW; x += 64) c += __popcll(tset[x] & qset[x]);
+                    c = wave_sum(c);
+                    if (c < thr[s]) continue;  // CountIntersectionTo(seedSet, min) < min (:521, :560)
+                    const dp_seq_ref r = refs[t];
+                    const int32_t* tSeg = segs + r.seg_off;
+                    const int tN = (int)(2 * r.n_seeds + 1);
+                    int thrS = thr[s], thrOther = thr[1 - s];
+                    uint32_t err = 0;
+                    if (lane == 0) {
+                        // Match (:361-394): s = seq.Reduced(querySet), q = query.Reduced(seqSet)
+                        const int minMatch = thr[s];
+                        const int nT = m_reduce<uint16_t>(tSeg, tN, qset, k, minMatch, L.t, L.tIdx, M_TMAX, &err);
+                        const int nQ = nT < 0 ? -1 : m_reduce<uint16_t>(qSeg, qN, tset, k, minMatch, L.q, L.qIdx, M_QMAX, &err);
+                        if (nT >= 0 && nQ >= 0) {
+                            const int nGood = m_dynamic_match(L, 2 * nQ + 1, 2 * nT + 1, minMatch, k, P, chainLen, &err);
+                            for (int g = 0; g < nGood; g++) {
+                                const int ch = L.good[g];
+                                const int len = chainLen[ch];
+                                const uint16_t* ca = P.A(ch);
+                                const uint16_t* cb = P.B(ch);
+                                const int a0 = L.qIdx[ca[0]], aL = L.qIdx[ca[len - 1]];
+                                // qOffset+qInset > (Len*2)/3 -> skipped, and does not ratchet (:536-538, 576-578)
+                                const int qOffset = m_seed_offset(qSeg, a0, k);
+                                const int qInset = m_seed_offset_from_end(qSeg, qN, aL, k);
+                                if (qOffset + qInset > (qLen * 2) / 3) continue;
+                                const uint32_t ri = atomicAdd(&cursor[0], 1u);
+                                const uint32_t off = atomicAdd(&cursor[1], (uint32_t)len);
+                                if (ri < rec_cap && off + (uint32_t)len <= int_cap) {
+                                    MapRec rec = {w, t, off, (uint32_t)len, seq};
+                                    recs[ri] = rec;
+                                    for (int x = 0; x < len; x++) {
+                                        ma[off + x] = L.qIdx[ca[x]];
+                                        mb[off + x] = L.tIdx[cb[x]];
+                                    }
+                                } else {
+                                    cursor[3] = 1;
+                                }
+                                seq++;
+                                const int limit = (len * 4) / 5;
+                                if (limit > thrS) thrS = limit;
+                                if (s == 0 && limit > thrOther) thrOther = limit;  // forward also raises minRCMatches (:547-549)
+                            }
+                        }
+                        if (err) atomicOr(&cursor[2], err);
+                    }
+                    thr[s] = __shfl(thrS, 0, 64);
+                    thr[1 - s] = __shfl(thrOther, 0, 64);
+                    seq = (uint32_t)__shfl((int)seq, 0, 64);
+                }
+            }
+        }
+    }
+}
+
+int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t nw, int k,
+                        dp_chain_batch* out) {
+    if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_map_windows before dp_round_begin");
+    if (nw & 1) return dp_fail(ctx, DP_ERR_ARG, "dp_map_windows: windows come in (forward, reverse-complement) pairs");
+    hipSetDevice(ctx->device);
+    memset(out, 0, sizeof(*out));
+    if (pin_reserve(ctx, ctx->h_moff, 16)) return DP_ERR_HIP;
+    ((uint64_t*)ctx->h_moff.p)[0] = 0;
+    out->off = (const uint64_t*)ctx->h_moff.p;
+    const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
+    if (nw == 0 || M == 0) return DP_OK;
+    uint32_t* d_qmeta = nullptr;
+    u64* d_words = nullptr;
+    int32_t* d_mc = nullptr;
+    uint32_t mc_n = 0;
+    int rc = dp_query_stage(ctx, w_segs, w_off, nw, 0.25, &d_qmeta, &d_words, &d_mc, &mc_n);  // Matches(.., 0.25) :502-503
+    if (rc != 0) return rc;
+    if (dev_reserve(ctx, ctx->d_cursor, 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_sched, (size_t)nw * 4 + 16)) return DP_ERR_HIP;
+    DP_HIP(hipMemcpyAsync(ctx->d_sched.p, w_len, (size_t)nw * 4, hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t n_pairs = nw / 2;
+    const uint32_t blocks = std::min<uint32_t>(256, (n_pairs + M_WAVES - 1) / M_WAVES);
+    const size_t waves = (size_t)blocks * M_WAVES;
+    const size_t poolElems = waves * M_CHAINS * M_QMAX;
+    if (dev_reserve(ctx, ctx->d_pool, poolElems * 2 * 2 + waves * M_CHAINS * 2 + 64)) return DP_ERR_HIP;
+    uint16_t* poolA = (uint16_t*)ctx->d_pool.p;
+    uint16_t* poolB = poolA + poolElems;
+    uint16_t* poolLen = poolB + poolElems;
+    uint32_t rec_cap = std::max<uint32_t>(1u << 16, (uint32_t)(ctx->d_mrec.cap / sizeof(MapRec)));
+    uint32_t int_cap = std::max<uint32_t>(1u << 21, (uint32_t)(ctx->d_ma.cap / 4));
+    uint32_t cur[16];
+    float total_ms = 0;
+    for (;;) {
+        if (dev_reserve(ctx, ctx->d_mrec, (size_t)rec_cap * sizeof(MapRec))) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_ma, (size_t)int_cap * 4)) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_mb, (size_t)int_cap * 4)) return DP_ERR_HIP;
+        DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 64, ctx->stream));
+        DP_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
+        hipLaunchKernelGGL(map_kernel, dim3(blocks), dim3(64 * M_WAVES), 0, ctx->stream, (const int32_t*)ctx->d_qsegs.p,
+                           (const u64*)ctx->d_qoff.p, (const uint32_t*)ctx->d_sched.p, n_pairs, (const u64*)ctx->d_qsets.p,
+                           (const uint32_t*)d_qmeta, (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p,
+                           (const int32_t*)ctx->d_segs.p, (const u64*)ctx->d_seedsets.p, W, SW, k, poolA, poolB, poolLen,
+                           (MapRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p, int_cap,
+                           (uint32_t*)ctx->d_cursor.p);
+        DP_HIP(hipGetLastError());
+        DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+        DP_HIP(hipMemcpyAsync(cur, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipStreamSynchronize(ctx->stream));
+        float ms = 0;
+        hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]);
+        total_ms += ms;
+        if (cur[3] || cur[0] > rec_cap || cur[1] > int_cap) {
+            rec_cap = std::max(rec_cap * 2, cur[0] + 1024);
+            int_cap = std::max(int_cap * 2, cur[1] + 1024);
+            continue;
+        }
+        break;
+    }
+    float qms = 0;
+    hipEventElapsedTime(&qms, ctx->ev[4], ctx->ev[5]);
+    out->kernel_ms = (double)total_ms + (double)qms;
+    if (cur[2]) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "map chaining exceeded a device capacity (bits %u: 1 reduced sequence, 2 chain pool, 4 good-chain list)", cur[2]);
+        return dp_fail(ctx, DP_ERR_CAPACITY, msg);
+    }
+    std::vector<uint32_t> qm((size_t)nw * 4);
+    DP_HIP(hipMemcpy(qm.data(), d_qmeta, (size_t)nw * 16, hipMemcpyDeviceToHost));
+    for (uint32_t w = 0; w < nw; w++)
+        if (qm[4 * w + 2] & 1) return dp_fail(ctx, DP_ERR_CAPACITY, "window with more than 512 usable seeds");
+    const uint32_t nm = cur[0], ni = cur[1];
+    if (pin_reserve(ctx, ctx->h_mrec, (size_t)nm * sizeof(MapRec) + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_ma, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_mb, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_mq, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_mt, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_moff, ((size_t)nm + 1) * 8)) return DP_ERR_HIP;
+    std::vector<int32_t> ta(ni), tb(ni);
+    if (nm) {
+        DP_HIP(hipMemcpyAsync(ctx->h_mrec.p, ctx->d_mrec.p, (size_t)nm * sizeof(MapRec), hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipMemcpyAsync(ta.data(), ctx->d_ma.p, (size_t)ni * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipMemcpyAsync(tb.data(), ctx->d_mb.p, (size_t)ni * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    MapRec* recs = (MapRec*)ctx->h_mrec.p;
+    std::vector<uint32_t> order(nm);
+    for (uint32_t i = 0; i < nm; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        if (recs[a].window != recs[b].window) return recs[a].window < recs[b].window;
+        return recs[a].seq < recs[b].seq;
+    });
+    uint32_t* mw = (uint32_t*)ctx->h_mq.p;
+    uint32_t* mt = (uint32_t*)ctx->h_mt.p;
+    uint64_t* moff = (uint64_t*)ctx->h_moff.p;
+    int32_t* fa = (int32_t*)ctx->h_ma.p;
+    int32_t* fb = (int32_t*)ctx->h_mb.p;
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < nm; i++) {
+        const MapRec& r = recs[order[i]];
+        mw[i] = r.window;
+        mt[i] = r.target;
+        moff[i] = pos;
+        memcpy(fa + pos, ta.data() + r.off, (size_t)r.len * 4);
+        memcpy(fb + pos, tb.data() + r.off, (size_t)r.len * 4);
+        pos += r.len;
+    }
+    moff[nm] = pos;
+    out->n_chains = nm;
+    out->window = mw;
+    out->target = mt;
+    out->off = moff;
+    out->match_a = fa;
+    out->match_b = fb;
+    return DP_OK;
 }

@@ -710,25 +710,12 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
     }
 }
 
-int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,
-                          uint32_t max_query_len, int want_candidates, dp_match_batch* out) {
-    if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_find_overlaps before dp_round_begin");
-    hipSetDevice(ctx->device);
-    memset(out, 0, sizeof(*out));
-    out->n_queries = nq;
+// Uploads the queries, builds their seed bitsets and runs the index query (Matches -> GetSharedIDs) for all of them.
+// Leaves d_qsegs/d_qoff/d_qsets/d_cand/d_qmeta on the device.  Events ev[4]/ev[5] bracket the query kernel.
+int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
+                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out) {
     const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
     const uint64_t nseg = nq ? q_off[nq] : 0;
-    if (pin_reserve(ctx, ctx->h_cursor, 64)) return DP_ERR_HIP;
-    if (pin_reserve(ctx, ctx->h_cand_off, ((size_t)nq + 1) * 8)) return DP_ERR_HIP;
-    ((uint64_t*)ctx->h_cand_off.p)[0] = 0;
-    out->cand_off = (const uint64_t*)ctx->h_cand_off.p;
-    if (pin_reserve(ctx, ctx->h_moff, 16)) return DP_ERR_HIP;
-    ((uint64_t*)ctx->h_moff.p)[0] = 0;
-    out->off = (const uint64_t*)ctx->h_moff.p;
-    if (nq == 0 || M == 0) {
-        for (uint32_t q = 0; q <= nq; q++) ((uint64_t*)ctx->h_cand_off.p)[q] = 0;
-        return DP_OK;
-    }
     // int(hitFraction*float64(n)+0.5) for every n that can occur (seeds/seeds.go:351, overlap/overlap.go:356);
     // evaluated on the host in IEEE double (this file is built with -ffp-contract=off)
     uint32_t maxSeeds = 0;
@@ -745,7 +732,6 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     if (dev_reserve(ctx, ctx->d_qsets, (size_t)nq * SW * 8 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_qmeta, (size_t)nq * 16 + (size_t)nq * 8 + (size_t)mc_n * 4 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_cand, (size_t)nq * W * 8 + 64)) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_cursor, 64)) return DP_ERR_HIP;
     uint32_t* d_qmeta = (uint32_t*)ctx->d_qmeta.p;
     u64* d_words = (u64*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 16);
     int32_t* d_mc = (int32_t*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 16 + (size_t)nq * 8);
@@ -764,6 +750,41 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
                        (const uint32_t*)ctx->d_pmeta.p, M, W, (const int32_t*)d_mc, mc_n, (u64*)ctx->d_cand.p, d_qmeta, d_words);
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+
+    *d_qmeta_out = d_qmeta;
+    *d_words_out = d_words;
+    *d_mc_out = d_mc;
+    *mc_n_out = mc_n;
+    return DP_OK;
+}
+
+int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,
+                          uint32_t max_query_len, int want_candidates, dp_match_batch* out) {
+    if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_find_overlaps before dp_round_begin");
+    hipSetDevice(ctx->device);
+    memset(out, 0, sizeof(*out));
+    out->n_queries = nq;
+    const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
+    if (pin_reserve(ctx, ctx->h_cursor, 64)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_cand_off, ((size_t)nq + 1) * 8)) return DP_ERR_HIP;
+    ((uint64_t*)ctx->h_cand_off.p)[0] = 0;
+    out->cand_off = (const uint64_t*)ctx->h_cand_off.p;
+    if (pin_reserve(ctx, ctx->h_moff, 16)) return DP_ERR_HIP;
+    ((uint64_t*)ctx->h_moff.p)[0] = 0;
+    out->off = (const uint64_t*)ctx->h_moff.p;
+    if (nq == 0 || M == 0) {
+        for (uint32_t q = 0; q <= nq; q++) ((uint64_t*)ctx->h_cand_off.p)[q] = 0;
+        return DP_OK;
+    }
+    uint32_t* d_qmeta = nullptr;
+    u64* d_words = nullptr;
+    int32_t* d_mc = nullptr;
+    uint32_t mc_n = 0;
+    {
+        int rc = dp_query_stage(ctx, q_segs, q_off, nq, hf, &d_qmeta, &d_words, &d_mc, &mc_n);
+        if (rc != 0) return rc;
+    }
+    if (dev_reserve(ctx, ctx->d_cursor, 64)) return DP_ERR_HIP;
 
     // chaining; output buffers grow and the kernel re-runs if they overflow (deterministic)
     const uint32_t chain_blocks = std::min<uint32_t>(512, (nq + C_WAVES - 1) / C_WAVES);
@@ -896,8 +917,8 @@ extern "C" int dp_find_overlaps(dp_ctx* ctx, const int32_t* q_segs, const uint64
 }
 
 // A19/A20 map flavour: implemented in dp_map.hip
-extern "C" int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, uint32_t n_windows, int k,
-                              dp_chain_batch* out) {
-    if (!ctx || !out || (n_windows && (!w_segs || !w_off))) return DP_ERR_ARG;
-    return dp_map_windows_impl(ctx, w_segs, w_off, n_windows, k, out);
+extern "C" int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len,
+                              uint32_t n_windows, int k, dp_chain_batch* out) {
+    if (!ctx || !out || (n_windows && (!w_segs || !w_off || !w_len))) return DP_ERR_ARG;
+    return dp_map_windows_impl(ctx, w_segs, w_off, w_len, n_windows, k, out);
 }

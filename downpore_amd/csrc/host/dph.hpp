@@ -260,6 +260,22 @@ struct OverlapRun {
     int roundFinish(const Survivors& all);
 };
 
+// ---- mapping.Mapper / `downpore map` (mapping/mapping.go, commands/map.go) ----------------------------------------
+struct MapParams {  // flag table commands/map.go:19-20
+    bool circular = true;
+    int k = 11;
+    i64 querySize = 1000, minLength = 500, chunkSize = 10000, seedRate = 40;
+    int numWorkers = 4;
+};
+struct MapStats {
+    uint64_t n_chunks = 0, n_seeds = 0, n_windows = 0, n_chains = 0, n_batches = 0;
+    double k_scan_ms = 0, k_map_ms = 0;
+};
+// Runs the whole command on HIP device `device`: reference = first sequence of refSet (top-level, cache=false), reads
+// top-level.  paf receives the PAF lines (read order), errText the reference's stderr lines.
+int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int device, std::string& paf, std::string& errText,
+           MapStats* stats, std::string& error);
+
 // ---- flag table helpers (commands/command.go:18-74, downpore.go:34-51) -------------------------------------------
 struct ArgTable {
     std::vector<std::string> names, defaults, descriptions;

@@ -229,3 +229,46 @@ extern "C" const char* dph_finalcheck(void* readsH, int k, int64_t overlapSize, 
     *outLen = (int64_t)paf.size();
     return paf.data();
 }
+
+// ---- `downpore map` ------------------------------------------------------------------------------------------------
+// params: circular,k,querySize,minLength,chunkSize,seedRate.  Returns a handle holding paf/err text, or NULL.
+namespace {
+struct MapH {
+    std::string paf, err;
+    MapStats st;
+};
+}  // namespace
+extern "C" void* dph_map_run(void* refH, void* readsH, const int64_t* params, int device) {
+    MapH* h = new MapH();
+    MapParams p;
+    p.circular = params[0] != 0;
+    p.k = (int)params[1];
+    p.querySize = params[2];
+    p.minLength = params[3];
+    p.chunkSize = params[4];
+    p.seedRate = params[5];
+    std::string error;
+    int rc = runMap(((ReadsH*)refH)->set, ((ReadsH*)readsH)->set, p, device, h->paf, h->err, &h->st, error);
+    if (rc != 0) {
+        g_err = error;
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+extern "C" void dph_map_free(void* h) { delete (MapH*)h; }
+extern "C" const char* dph_map_paf(void* h, int64_t* n) {
+    *n = (int64_t)((MapH*)h)->paf.size();
+    return ((MapH*)h)->paf.data();
+}
+extern "C" const char* dph_map_errtext(void* h, int64_t* n) {
+    *n = (int64_t)((MapH*)h)->err.size();
+    return ((MapH*)h)->err.data();
+}
+// out: n_chunks,n_seeds,n_windows,n_chains,n_batches,k_scan_ms,k_map_ms
+extern "C" void dph_map_stats(void* h, double* out) {
+    const MapStats& s = ((MapH*)h)->st;
+    double v[] = {(double)s.n_chunks, (double)s.n_seeds, (double)s.n_windows, (double)s.n_chains, (double)s.n_batches, s.k_scan_ms,
+                  s.k_map_ms};
+    memcpy(out, v, sizeof v);
+}

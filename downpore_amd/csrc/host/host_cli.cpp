@@ -120,8 +120,34 @@ int main(int argc, char** argv) {
         return runOverlap(ov);
     }
     if (cmd == "map") {
-        fprintf(stderr, "downpore map: the GPU map path is not wired into this CLI yet\n");
-        return 1;
+        if (!mp.parse(argc, argv, err)) {
+            fprintf(stderr, "%s\n", err.c_str());
+            return 1;
+        }
+        bool ok = true;
+        MapParams p;
+        p.k = (int)parseInt(mp.args["k"], ok);
+        p.numWorkers = (int)parseInt(mp.args["num_workers"], ok);
+        p.minLength = parseInt(mp.args["min_length"], ok);
+        p.circular = parseBool(mp.args["circular"]);
+        p.querySize = parseInt(mp.args["query_size"], ok);
+        p.chunkSize = parseInt(mp.args["chunk_size"], ok);
+        p.seedRate = parseInt(mp.args["seed_rate"], ok);
+        if (!ok) return 1;
+        ReadSet ref, reads;
+        if (!ReadSet::fromFile(mp.args["reference"], 0, false, ref, err) || !ReadSet::fromFile(mp.args["input"], p.minLength, false, reads, err)) {
+            fprintf(stderr, "%s\n", err.c_str());
+            return 1;
+        }
+        std::string paf, errText, error;
+        int rc = runMap(ref, reads, p, 0, paf, errText, nullptr, error);
+        if (rc != 0) {
+            fprintf(stderr, "downpore: %s\n", error.c_str());
+            return 2;
+        }
+        fwrite(paf.data(), 1, paf.size(), stdout);
+        fwrite(errText.data(), 1, errText.size(), stderr);
+        return 0;
     }
     printf("Available commands:\n help <command> Describe the command and its arguments\n");
     return 0;

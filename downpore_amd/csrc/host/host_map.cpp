@@ -1,0 +1,820 @@
+// Product host side of `downpore map` (mapping/mapping.go, commands/map.go:33-116) above the C ABI.
+//
+// mapping.Mapper.Map is adaptive per read (ends -> one/two steps in -> binary split search), every step being a
+// performMapping of one window.  To batch windows of MANY reads into each GPU call while keeping Map()'s control flow
+// written exactly as the reference's sequential code, each read's Map() runs as a stackful coroutine (ucontext):
+// performMapping() files a window request and yields; when every live coroutine is waiting, the scheduler scans all
+// requested windows (dp_scan), runs the candidate/chaining stage (dp_map_windows) and resumes the coroutines with
+// their chains.  Results are emitted in read order (the canonical single-worker order).
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include "dph.hpp"
+
+namespace dph {
+
+namespace {
+
+struct Mapping {  // mapping/mapping.go:11-20
+    i64 queryLen = 0;  // Query.Len() of the sequence updateQuery() attached (the whole read)
+    bool hasQuery = false;
+    i64 Start = 0, End = 0, QueryOffset = 0, QueryInset = 0;
+    bool RC = false;
+    i64 ids = 0;
+};
+
+// Go sort.Sort stand-in (DESIGN.md canonical semantics): insertion sort <= 12 elements, stable sort above.
+template <class T, class Less>
+void goSort(std::vector<T>& v, Less less) {
+    if (v.size() <= 12) {
+        for (size_t i = 1; i < v.size(); i++)
+            for (size_t j = i; j > 0 && less(v[j], v[j - 1]); j--) std::swap(v[j], v[j - 1]);
+    } else {
+        std::stable_sort(v.begin(), v.end(), less);
+    }
+}
+
+struct Chunk {  // an indexed reference chunk (seeds.SeedSequence of a reference.SubSequence)
+    const int32_t* seg = nullptr;
+    int n = 0;
+    i64 offset = 0, inset = 0;
+};
+
+struct WindowReq {
+    uint32_t read = 0;  // index into the read set
+    i64 a = 0, b = 0;   // view [a, b) of the top-level read
+    bool whole = false; // the top-level read itself (len <= 2*edge)
+};
+
+struct WindowResult {
+    // forward / reverse-complement seed sequences of the window and the chains the GPU kept
+    std::vector<int32_t> seg[2];
+    struct ChainRef {
+        uint32_t target;
+        std::vector<int32_t> a, b;
+    };
+    std::vector<ChainRef> chains[2];
+};
+
+struct Task;
+struct Sched;
+
+struct MapperImpl {
+    dp_ctx* ctx = nullptr;
+    int k = 11;
+    i64 edgeSize = 1000;
+    bool circular = true;
+    i64 refLen = 0;
+    std::string refName;
+    std::vector<Chunk> chunks;
+    std::vector<int32_t> chunkSegs;  // host copy of the chunk scan
+    Sched* sched = nullptr;
+    std::string err;
+
+    bool isConsistent(const Mapping* l, const Mapping* r) const;
+    void matchPairs(std::vector<Mapping*>& openA, std::vector<Mapping*>& openB, std::vector<Mapping*>& matched, bool& matchedNil,
+                    Task& t);
+    void findSplitPoint(Task& t, std::vector<Mapping*>& openA, std::vector<Mapping*>& openB, i64 left, i64 right);
+    void mapNext(Task& t, std::vector<Mapping*>& openA, std::vector<Mapping*>& openB, std::vector<Mapping*>& newA,
+                 std::vector<Mapping*>& newB, std::vector<Mapping*>& matched, bool& matchedNil);
+    std::vector<Mapping*> map(Task& t);
+    std::vector<Mapping*> performMapping(Task& t, i64 a, i64 b, bool whole);
+    std::string asString(const Mapping& m, const std::string& qname, i64 qlen) const;
+};
+
+struct Task {
+    ucontext_t uc;
+    std::vector<char> stack;
+    uint32_t read = 0;
+    i64 L = 0;
+    bool done = false, waiting = false;
+    WindowReq req;
+    WindowResult res;
+    std::vector<std::unique_ptr<Mapping>> pool;
+    std::vector<Mapping*> results;
+    MapperImpl* m = nullptr;
+    Mapping* mk() {
+        pool.emplace_back(new Mapping());
+        return pool.back().get();
+    }
+};
+
+struct Sched {
+    ucontext_t main;
+    Task* cur = nullptr;
+};
+
+void taskEntry(unsigned lo, unsigned hi) {
+    Task* t = (Task*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    t->results = t->m->map(*t);
+    t->done = true;
+    swapcontext(&t->uc, &t->m->sched->main);
+}
+
+// ---- mapping.go:131-160
+bool MapperImpl::isConsistent(const Mapping* left, const Mapping* right) const {
+    if (left->RC != right->RC) return false;
+    const i64 expectedDistance = right->QueryOffset - left->queryLen + left->QueryInset;
+    i64 distance = !left->RC ? right->Start - left->End : left->Start - right->End;
+    if (circular && distance < -50) distance += refLen;
+    if (distance < 50 && expectedDistance < 50 && distance > -50) return true;
+    if (distance < 500) return (expectedDistance < (distance * 3) / 2 && expectedDistance > (distance * 2) / 3);
+    if (distance > 5000) return (expectedDistance < (distance * 10) / 9 && expectedDistance > (distance * 9) / 10);
+    double ratio = (double)(distance - 500) / 4500.0;
+    ratio = 3.0 / 2.0 + ratio * (10.0 / 9.0 - 3.0 / 2.0);
+    return distance < (i64)((double)expectedDistance * ratio) && distance > (i64)((double)expectedDistance / ratio);
+}
+
+// ---- removeDominated mapping.go:387-428 (open and extended are the same slice at every call site)
+std::vector<Mapping*> removeDominated(std::vector<Mapping*> open, i64 queryLen) {
+    if (open.empty()) return open;
+    goSort(open, [](Mapping* a, Mapping* b) { return a->QueryOffset < b->QueryOffset; });
+    const std::vector<Mapping*>& extended = open;
+    size_t j = 0;
+    std::vector<uint8_t> toRemove(open.size(), 0);
+    for (size_t i = 0; i < open.size(); i++) {
+        Mapping* next = open[i];
+        while (j < extended.size() && queryLen - extended[j]->QueryInset < next->QueryOffset) j++;
+        if (j == extended.size()) return open;
+        bool dominated = false;
+        for (size_t kk = j; !dominated && kk < extended.size() && extended[kk]->QueryOffset < queryLen - next->QueryInset; kk++) {
+            if (extended[kk]->ids * 4 > next->ids * 5) {
+                i64 start = next->QueryOffset;
+                if (extended[kk]->QueryOffset > start) start = extended[kk]->QueryOffset;
+                i64 end = queryLen - next->QueryInset;
+                if (extended[kk]->QueryInset > next->QueryInset) end = queryLen - extended[kk]->QueryInset;
+                dominated = ((end - start) * 10 > (queryLen - next->QueryOffset - next->QueryInset) * 9);
+            }
+        }
+        toRemove[i] = dominated;
+    }
+    i64 last = (i64)open.size() - 1;
+    for (i64 i = last; i >= 0; i--)
+        if (toRemove[(size_t)i]) {
+            open[(size_t)i] = open[(size_t)last];
+            last--;
+        }
+    open.resize((size_t)(last + 1));
+    return open;
+}
+
+void updateQuery(std::vector<Mapping*>& ms, i64 len) {
+    for (Mapping* m : ms) {
+        m->queryLen = len;
+        m->hasQuery = true;
+    }
+}
+void appendAll(std::vector<Mapping*>& d, const std::vector<Mapping*>& s) { d.insert(d.end(), s.begin(), s.end()); }
+
+// ---- matchPairs mapping.go:174-203
+void MapperImpl::matchPairs(std::vector<Mapping*>& openA, std::vector<Mapping*>& openB, std::vector<Mapping*>& matched,
+                            bool& matchedNil, Task& t) {
+    matched.clear();
+    matchedNil = true;
+    for (i64 i = (i64)openA.size() - 1; i >= 0; i--) {
+        Mapping* ra = openA[(size_t)i];
+        for (i64 j = (i64)openB.size() - 1; j >= 0; j--) {
+            Mapping* rb = openB[(size_t)j];
+            if (isConsistent(ra, rb)) {
+                const i64 qOffset = ra->QueryOffset, qInset = rb->QueryInset;
+                if (ra->RC) std::swap(ra, rb);
+                Mapping* c = t.mk();
+                c->Start = ra->Start;
+                c->End = rb->End;
+                c->queryLen = ra->queryLen;
+                c->hasQuery = ra->hasQuery;
+                c->QueryOffset = qOffset;
+                c->QueryInset = qInset;
+                c->RC = ra->RC;
+                c->ids = ra->ids + rb->ids;
+                matchedNil = false;
+                matched.push_back(c);
+                openA[(size_t)i] = openA.back();
+                openA.pop_back();
+                openB[(size_t)j] = openB.back();
+                openB.pop_back();
+                break;
+            }
+        }
+    }
+}
+
+// ---- findSplitPoint mapping.go:207-288
+void MapperImpl::findSplitPoint(Task& t, std::vector<Mapping*>& openA, std::vector<Mapping*>& openB, i64 left, i64 right) {
+    const i64 qLen = t.L;
+    while (right - left >= edgeSize) {
+        const i64 start = (right + left - edgeSize) / 2, end = start + edgeSize;
+        std::vector<Mapping*> mid = performMapping(t, start, end, false);
+        i64 newLeft = left, newRight = right, afterA = 0, afterB = 0;
+        for (Mapping* mm : mid) {
+            mm->queryLen = qLen;
+            mm->hasQuery = true;
+            for (Mapping* ma : openA) {
+                if (isConsistent(ma, mm)) {
+                    ma->QueryInset = mm->QueryInset;
+                    ma->ids += mm->ids;
+                    if (ma->RC) ma->Start = mm->Start;
+                    else ma->End = mm->End;
+                    const i64 midMatched = qLen - mm->QueryInset - mm->QueryOffset;
+                    if (midMatched > afterA) afterA = midMatched;
+                    if (qLen - mm->QueryInset > newLeft) newLeft = qLen - mm->QueryInset;
+                    break;
+                }
+            }
+            if (afterA < (edgeSize * 2) / 3) {
+                for (Mapping* mb : openB) {
+                    if (isConsistent(mm, mb)) {
+                        mb->QueryOffset = mm->QueryOffset;
+                        mb->ids += mm->ids;
+                        if (mb->RC) mb->End = mm->End;
+                        else mb->Start = mm->Start;
+                        const i64 midMatched = qLen - mm->QueryInset - mm->QueryOffset;
+                        if (midMatched > afterB) afterB = midMatched;
+                        if (mm->QueryOffset < newRight) newRight = mm->QueryOffset;
+                        break;
+                    }
+                }
+            }
+        }
+        if (afterA > 0 && afterB > 0) {
+            std::vector<Mapping*> empty;
+            if (newLeft - left > edgeSize * 2) findSplitPoint(t, openA, empty, newLeft - edgeSize * 2, newLeft - edgeSize);
+            if (right - newRight > edgeSize * 2) findSplitPoint(t, empty, openB, newRight + edgeSize, newRight + edgeSize * 2);
+            return;
+        }
+        if (afterA == 0 && afterB == 0) {
+            std::vector<Mapping*> empty;
+            if (!openA.empty()) findSplitPoint(t, openA, empty, left, start);
+            if (!openB.empty()) findSplitPoint(t, empty, openB, end, right);
+            return;
+        }
+        left = newLeft;
+        right = newRight;
+    }
+}
+
+// ---- mapNext mapping.go:305-383 (Go slice aliasing reproduced with value copies, cf. oracle/mapping.cpp notes)
+void MapperImpl::mapNext(Task& t, std::vector<Mapping*>& openA, std::vector<Mapping*>& openB, std::vector<Mapping*>& newA,
+                         std::vector<Mapping*>& newB, std::vector<Mapping*>& matched, bool& matchedNil) {
+    const i64 qLen = t.L;
+    std::vector<Mapping*> extended;
+    bool extNil;
+    if (qLen < edgeSize * 4) {
+        newA = removeDominated(performMapping(t, edgeSize, qLen - edgeSize, false), qLen);
+        updateQuery(newA, qLen);
+        matchPairs(openA, newA, extended, extNil, t);
+        if (!extNil) {
+            std::vector<Mapping*> tmp = newA;
+            appendAll(tmp, extended);
+            openA = tmp;
+        } else {
+            appendAll(openA, newA);
+        }
+        matchPairs(openA, openB, matched, matchedNil, t);
+        newA = openA;
+        newB = openB;
+        if (matchedNil) return;
+        newA.clear();
+        newB.clear();
+        return;
+    }
+    newA = removeDominated(performMapping(t, edgeSize, edgeSize * 2, false), qLen);
+    updateQuery(newA, qLen);
+    matchPairs(openA, newA, extended, extNil, t);
+    appendAll(openA, newA);
+    if (!extNil) appendAll(openA, extended);
+    newB = removeDominated(performMapping(t, qLen - edgeSize * 2, qLen - edgeSize, false), qLen);
+    updateQuery(newB, qLen);
+    {
+        std::vector<Mapping*> a = newB, b = openB;
+        matchPairs(a, b, extended, extNil, t);
+        openB = a;
+        newB = b;
+    }
+    appendAll(openB, newB);
+    if (!extNil) appendAll(openB, extended);
+    {
+        std::vector<Mapping*> a = openA, b = openB;
+        matchPairs(a, b, matched, matchedNil, t);
+        newA = a;
+        newB = b;
+    }
+    if (matchedNil) {
+        if (qLen > edgeSize * 5) {
+            openA = removeDominated(performMapping(t, edgeSize * 2, edgeSize * 3, false), qLen);
+            updateQuery(openA, qLen);
+            {
+                std::vector<Mapping*> a = newA, b = openA;
+                matchPairs(a, b, extended, extNil, t);
+                openA = a;
+                newA = b;
+            }
+            if (!extNil) appendAll(openA, extended);
+            appendAll(openA, newA);
+        }
+        if (qLen > edgeSize * 6) {
+            openB = removeDominated(performMapping(t, qLen - edgeSize * 3, qLen - edgeSize * 2, false), qLen);
+            updateQuery(openB, qLen);
+            {
+                std::vector<Mapping*> a = openB, b = newB;
+                matchPairs(a, b, extended, extNil, t);
+                openB = a;
+                newB = b;
+            }
+            if (!extNil) appendAll(openB, extended);
+            appendAll(openB, newB);
+        } else {
+            openB = newB;
+        }
+        if (qLen > edgeSize * 5) {
+            std::vector<Mapping*> a = openA, b = openB;
+            matchPairs(a, b, matched, matchedNil, t);
+            newA = a;
+            newB = b;
+        }
+    }
+}
+
+// ---- Map mapping.go:430-487
+std::vector<Mapping*> MapperImpl::map(Task& t) {
+    const i64 qLen = t.L;
+    std::vector<Mapping*> results;
+    if (qLen <= edgeSize * 2) {
+        results = removeDominated(performMapping(t, 0, qLen, true), qLen);
+        updateQuery(results, qLen);
+        return results;
+    }
+    std::vector<Mapping*> openA = performMapping(t, 0, edgeSize, false);           // mapEnds :164-172
+    std::vector<Mapping*> openB = performMapping(t, qLen - edgeSize, qLen, false);
+    openA = removeDominated(openA, qLen);
+    openB = removeDominated(openB, qLen);
+    updateQuery(openA, qLen);
+    updateQuery(openB, qLen);
+    std::vector<Mapping*> matched;
+    bool matchedNil;
+    matchPairs(openA, openB, matched, matchedNil, t);
+    if (!matchedNil) return matched;
+    if (qLen < edgeSize * 3) {
+        results = openA;
+        appendAll(results, openB);
+        return results;
+    }
+    std::vector<Mapping*> nA, nB;
+    mapNext(t, openA, openB, nA, nB, matched, matchedNil);
+    openA = nA;
+    openB = nB;
+    if (!matchedNil) return matched;
+    i64 left = edgeSize * 2, right = qLen - edgeSize * 2;
+    for (Mapping* a : openA)
+        if (a->QueryInset > left) left = a->QueryInset;
+    left = qLen - right;  // sic (:461)
+    for (Mapping* b : openB)
+        if (b->QueryOffset < right) right = b->QueryOffset;
+    findSplitPoint(t, openA, openB, left, right);
+    const i64 size = qLen - edgeSize;
+    for (i64 i = (i64)openA.size() - 1; i >= 0; i--)
+        if (openA[(size_t)i]->QueryInset >= size) {
+            openA[(size_t)i] = openA.back();
+            openA.pop_back();
+        }
+    for (i64 i = (i64)openB.size() - 1; i >= 0; i--)
+        if (openB[(size_t)i]->QueryOffset >= size) {
+            openB[(size_t)i] = openB.back();
+            openB.pop_back();
+        }
+    results = openA;
+    appendAll(results, openB);
+    return results;
+}
+
+i64 segSeedOffset(const int32_t* seg, int index, int k) {
+    index = index * 2 + 1;
+    i64 o = seg[0];
+    for (int i = 2; i < index; i += 2) o += seg[i] + k;
+    return o;
+}
+i64 segSeedOffsetFromEnd(const int32_t* seg, int n, int index, int k) {
+    index = index * 2 + 1;
+    i64 o = seg[n - 1];
+    for (int i = n - 3; i > index; i -= 2) o += seg[i] + k;
+    return o;
+}
+// GetBasesCovered second return (target side), seeds/sequence.go:830-858
+i64 basesCoveredB(const int32_t* sb, const std::vector<int32_t>& mb, int k) {
+    i64 countB = (i64)mb.size() * k;
+    int prevB = mb[0];
+    for (size_t i = 1; i < mb.size(); i++) {
+        const int s2 = mb[i];
+        i64 d2 = sb[prevB * 2 + 2];
+        for (int j = prevB + 2; j <= s2; j++) d2 += sb[j * 2] + k;
+        if (d2 < 0) countB += d2;
+        prevB = s2;
+    }
+    return countB;
+}
+
+// ---- performMapping mapping.go:489-611: the window is sent to the GPU batch; this coroutine resumes with the chains.
+std::vector<Mapping*> MapperImpl::performMapping(Task& t, i64 a, i64 b, bool whole) {
+    if (b > t.L) b = t.L;  // SubSequence clamps end (sequence.go:354)
+    t.req.read = t.read;
+    t.req.a = a;
+    t.req.b = b;
+    t.req.whole = whole;
+    t.waiting = true;
+    swapcontext(&t.uc, &sched->main);  // yield until the batch has been processed
+    t.waiting = false;
+    const WindowResult& R = t.res;
+    const i64 qlen = b - a;
+    // view metadata: SubSequence of a top-level read (offset a, inset L-(b-1)); the RC view swaps them (sequence.go:196)
+    i64 vOffset = whole ? 0 : a, vInset = whole ? 0 : t.L - (b - 1);
+    std::vector<Mapping*> results;
+    for (int s = 0; s < 2; s++) {
+        const int32_t* qseg = R.seg[s].data();
+        const int qn = (int)R.seg[s].size();
+        const i64 sqOffset = s == 0 ? vOffset : vInset, sqInset = s == 0 ? vInset : vOffset;
+        for (const auto& ch : R.chains[s]) {
+            const Chunk& c = chunks[ch.target];
+            i64 start = c.offset + segSeedOffset(c.seg, ch.b[0], k);
+            const i64 end = refLen - c.inset - segSeedOffsetFromEnd(c.seg, c.n, ch.b.back(), k);
+            if (circular && start > refLen) start -= refLen;
+            Mapping* mp = t.mk();
+            if (s == 0) {
+                i64 qOffset = segSeedOffset(qseg, ch.a[0], k) + sqOffset;
+                i64 qInset = segSeedOffsetFromEnd(qseg, qn, ch.a.back(), k) + sqInset;
+                mp->QueryOffset = qOffset;
+                mp->QueryInset = qInset;
+            } else {  // offsets/insets are swapped: they are based on the reverse-complement query (:569-580)
+                i64 qInset = segSeedOffset(qseg, ch.a[0], k) + sqOffset;
+                i64 qOffset = segSeedOffsetFromEnd(qseg, qn, ch.a.back(), k) + sqInset;
+                mp->QueryOffset = qOffset;
+                mp->QueryInset = qInset;
+            }
+            mp->Start = start;
+            mp->End = end;
+            mp->RC = s == 1;
+            mp->ids = basesCoveredB(c.seg, ch.b, k);
+            results.push_back(mp);
+        }
+    }
+    (void)qlen;
+    if (results.size() > 1) {  // :590-608
+        goSort(results, [](Mapping* x, Mapping* y) { return x->Start < y->Start; });
+        for (i64 i = (i64)results.size() - 1; i > 0; i--) {
+            Mapping* ra = results[(size_t)(i - 1)];
+            Mapping* rb = results[(size_t)i];
+            if (ra->RC == rb->RC && rb->Start < ra->End) {
+                if (ra->End - ra->Start > rb->End - rb->Start) {
+                    results[(size_t)i] = results.back();
+                    results.pop_back();
+                } else {
+                    results[(size_t)(i - 1)] = results[(size_t)i];
+                    results[(size_t)i] = results.back();
+                    results.pop_back();
+                }
+            }
+        }
+    }
+    return results;
+}
+
+// ---- AsString mapping.go:112-122
+std::string MapperImpl::asString(const Mapping& m, const std::string& qname, i64 qlen) const {
+    i64 mappedLength = m.End - m.Start;
+    if (circular && mappedLength < 0) mappedLength = refLen - m.Start + m.End;
+    char buf[512];
+    snprintf(buf, sizeof buf, "\t%lld\t%lld\t%lld\t%s\t", (long long)qlen, (long long)m.QueryOffset, (long long)(qlen - m.QueryInset),
+             m.RC ? "-" : "+");
+    std::string s = qname + buf + refName;
+    snprintf(buf, sizeof buf, "\t%lld\t%lld\t%lld\t%lld\t%lld\t255", (long long)refLen, (long long)m.Start, (long long)m.End,
+             (long long)m.ids, (long long)mappedLength);
+    return s + buf;
+}
+
+std::string revcomp(const char* s, size_t n) {
+    std::string r(n, 'A');
+    for (size_t i = 0; i < n; i++) {
+        static const char C[4] = {'A', 'C', 'G', 'T'};
+        r[n - 1 - i] = C[3 - baseCode((unsigned char)s[i])];
+    }
+    return r;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// commands/map.go:33-116 + NewMapper mapping.go:67-109
+
+int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int device, std::string& paf, std::string& errText,
+           MapStats* stats, std::string& error) {
+    if (refSet.size() == 0) {
+        error = "empty reference";
+        return -1;
+    }
+    const int k = p.k;
+    const i64 refLen = refSet.length(0);
+    const char* ref = refSet.seq(0);
+    dp_ctx* ctx = nullptr;
+    if (dp_ctx_create(device, &ctx) != 0) {
+        error = dp_last_error(nullptr);
+        return DP_ERR_NODEVICE;
+    }
+    auto fail = [&](int rc) {
+        error = dp_last_error(ctx);
+        dp_ctx_destroy(ctx);
+        return rc;
+    };
+    // ---- value table from every sequence of the reference file (map.go:45-71); KmerOccurrences on the GPU
+    int rc = dp_reads_upload(ctx, (const uint8_t*)refSet.bases.data(), refSet.off.data(), (uint32_t)refSet.size());
+    if (rc) return fail(rc);
+    std::vector<uint64_t> counts((size_t)1 << (2 * k));
+    rc = dp_kmer_histogram(ctx, k, counts.data());
+    if (rc) return fail(rc);
+    std::vector<double> values = kmerValuesFromCounts(counts, k);
+    counts.clear();
+    counts.shrink_to_fit();
+    errText += "K-mer counting complete. Preparing to start indexing and querying...\n";
+
+    // ---- AddSingleSeeds seeds/seeds.go:160-200 on the (top-level) reference, host, sequential
+    SeedIndex index(k);
+    {
+        const uint32_t mask = (uint32_t)(((uint64_t)1 << (2 * k)) - 1);
+        const int finalLen = (int)(refLen % 4);  // top-level sequence: 0 when len%4 == 0 (sequence.go:70,88)
+        const i64 skipBack = 4 - finalLen;
+        auto code = [&](i64 pos) -> uint32_t { return pos < refLen ? baseCode((unsigned char)ref[pos]) : 0u; };  // zero padding
+        auto kmerAt = [&](i64 pos) {
+            uint32_t v = 0;
+            for (int j = 0; j < k; j++) v = (v << 2) | code(pos + j);
+            return v;
+        };
+        for (i64 i = 0; i < refLen - p.seedRate; i += p.seedRate) {
+            // CountKmersBetween(i, i+seedRate, 1, ...) == 0 ?  (sequence.go:332-337 + asm:81-203: whole bytes only,
+            // parent's skipBack, do-while group loop)
+            const i64 startB = (i + 3) / 4, endB = (i + p.seedRate) / 4;
+            const i64 nb = endB - startB;
+            const i64 nk = 4 * (nb - 1) - skipBack - k + 1;
+            i64 groups = (nk & ~(i64)3) / 4;
+            if (groups < 1) groups = 1;
+            const i64 P = 4 + 4 * groups + (nk & 3);
+            bool any = false;
+            {
+                const i64 p0 = startB * 4;
+                uint32_t km = kmerAt(p0);
+                for (i64 j = 0; j < P; j++) {
+                    if (j) km = ((km << 2) | code(p0 + j + k - 1)) & mask;
+                    if (index.isSeed(km)) {
+                        any = true;
+                        break;
+                    }
+                }
+            }
+            if (!any) {
+                const i64 end = i + p.seedRate;
+                uint32_t km = kmerAt(i);
+                double bestValue = values[km];
+                uint32_t best = km;
+                for (i64 j = i + k; j < end; j++) {
+                    km = ((km << 2) | code(j)) & mask;
+                    const double v = values[km];
+                    if (v > bestValue) {
+                        bestValue = v;
+                        best = km;
+                    }
+                }
+                index.addSeedKmer(best);
+            }
+        }
+    }
+    // ---- device read set: [0] reference, [1] circular join chunk, then (forward, reverse complement) of every read
+    std::string bases;
+    std::vector<i64> off(1, 0);
+    auto addRead = [&](const char* s, size_t n) {
+        bases.append(s, n);
+        off.push_back((i64)bases.size());
+    };
+    addRead(ref, (size_t)refLen);
+    std::string join;
+    if (p.circular) join = std::string(ref + (refLen - p.querySize), (size_t)p.querySize) + std::string(ref, (size_t)p.querySize);
+    addRead(join.data(), join.size());
+    for (size_t r = 0; r < reads.size(); r++) {
+        addRead(reads.seq(r), (size_t)reads.length(r));
+        std::string rcs = revcomp(reads.seq(r), (size_t)reads.length(r));
+        addRead(rcs.data(), rcs.size());
+    }
+    rc = dp_reads_upload(ctx, (const uint8_t*)bases.data(), off.data(), (uint32_t)(off.size() - 1));
+    if (rc) return fail(rc);
+    bases.clear();
+    bases.shrink_to_fit();
+    rc = dp_round_begin(ctx, k, index.seedMap.data(), (uint32_t)index.seedMap.size());
+    if (rc) return fail(rc);
+
+    // ---- chunk schedule mapping.go:79-96, canonical generation order
+    MapperImpl M;
+    M.ctx = ctx;
+    M.k = k;
+    M.edgeSize = p.querySize;
+    M.circular = p.circular;
+    M.refLen = refLen;
+    M.refName = refSet.names[0];
+    std::vector<dp_scan_item> items;
+    std::vector<std::pair<i64, i64>> meta;  // offset, inset per chunk
+    for (i64 j = 0; j < 10; j++) {
+        const i64 start = j * p.chunkSize, step = p.chunkSize * 10 - p.querySize;
+        for (i64 i = start; i < refLen - p.chunkSize / 2; i += step) {
+            i64 end = i + p.chunkSize;
+            if (i >= refLen) end = refLen;
+            if (end > refLen) end = refLen;  // SubSequence clamps
+            dp_scan_item it;
+            it.read = 0;
+            it.start = (uint32_t)i;
+            it.n_kmers = (uint32_t)std::max<i64>(0, (end - i) - k + 1);
+            it.min_seeds = 0;
+            items.push_back(it);
+            meta.push_back({i, refLen - (end - 1)});  // SubSequence: offset+start, inset + length - (end-1)
+        }
+    }
+    if (p.circular) {
+        // Append(...) is a fresh top-level sequence of 2*edge bases: len%4==0 loses its last 4 k-mers (asm:88-96)
+        const i64 jl = (i64)join.size();
+        i64 nk = jl - k + 1;
+        if (jl % 4 == 0) nk -= 4;
+        dp_scan_item it;
+        it.read = 1;
+        it.start = 0;
+        it.n_kmers = (uint32_t)std::max<i64>(0, nk);
+        it.min_seeds = 0;
+        items.push_back(it);
+        meta.push_back({refLen - p.querySize, refLen - (p.querySize - 1)});  // offset of the first part, inset of the second
+    }
+    dp_seedseq_batch sb;
+    rc = dp_scan(ctx, items.data(), (uint32_t)items.size(), &sb);
+    if (rc) return fail(rc);
+    M.chunkSegs.assign(sb.segs, sb.segs + sb.n_segs);
+    std::vector<dp_seq_ref> refs(items.size());
+    M.chunks.resize(items.size());
+    for (size_t i = 0; i < items.size(); i++) {
+        refs[i].seg_off = sb.seg_off[i];
+        refs[i].n_seeds = sb.n_seeds[i];
+        refs[i].reserved = 0;
+        M.chunks[i].seg = M.chunkSegs.data() + sb.seg_off[i];
+        M.chunks[i].n = (int)(sb.seg_off[i + 1] - sb.seg_off[i]);
+        M.chunks[i].offset = meta[i].first;
+        M.chunks[i].inset = meta[i].second;
+    }
+    rc = dp_index_build(ctx, refs.data(), (uint32_t)refs.size());
+    if (rc) return fail(rc);
+    // dp_scan below reuses the device scan buffer: keep the chunk segments in a dedicated import
+    // (dp_index_build references the device-resident scan output, so windows must not overwrite it)
+    if (stats) stats->n_chunks = items.size(), stats->n_seeds = index.seedMap.size();
+
+    // ---- Map every read: coroutines + batched windows
+    Sched sched;
+    M.sched = &sched;
+    const size_t inflight = 4096, stackBytes = 256 * 1024;
+    std::vector<std::string> out(reads.size());
+    std::vector<int> nmaps(reads.size(), 0);
+    std::vector<std::unique_ptr<Task>> live;
+    size_t nextRead = 0;
+    i64 unmapped = 0, mapped = 0, multiple = 0, total = 0;
+    std::vector<dp_scan_item> witems;
+    std::vector<int32_t> wsegs;
+    std::vector<uint64_t> woff;
+    std::vector<uint32_t> wlen;
+    while (nextRead < reads.size() || !live.empty()) {
+        while (live.size() < inflight && nextRead < reads.size()) {
+            std::unique_ptr<Task> t(new Task());
+            t->m = &M;
+            t->read = (uint32_t)nextRead;
+            t->L = reads.length(nextRead);
+            t->stack.resize(stackBytes);
+            getcontext(&t->uc);
+            t->uc.uc_stack.ss_sp = t->stack.data();
+            t->uc.uc_stack.ss_size = t->stack.size();
+            t->uc.uc_link = &sched.main;
+            uintptr_t ptr = (uintptr_t)t.get();
+            makecontext(&t->uc, (void (*)())taskEntry, 2, (unsigned)(ptr & 0xffffffffu), (unsigned)(ptr >> 32));
+            nextRead++;
+            swapcontext(&sched.main, &t->uc);  // run until the first window request (or completion)
+            live.push_back(std::move(t));
+        }
+        // retire finished tasks
+        for (size_t i = 0; i < live.size();) {
+            if (live[i]->done) {
+                Task& t = *live[i];
+                std::string& o = out[t.read];
+                for (Mapping* mm : t.results) o += M.asString(*mm, reads.names[t.read], t.L) + "\n";
+                nmaps[t.read] = (int)t.results.size();
+                live[i] = std::move(live.back());
+                live.pop_back();
+            } else {
+                i++;
+            }
+        }
+        if (live.empty()) continue;
+        // ---- batch: scan the requested windows (forward, reverse complement) ...
+        witems.clear();
+        for (auto& tp : live) {
+            Task& t = *tp;
+            const WindowReq& q = t.req;
+            const uint32_t fr = 2 + 2 * q.read, rr = fr + 1;
+            const i64 L = t.L, wl = q.b - q.a;
+            dp_scan_item f, r;
+            f.read = fr;
+            r.read = rr;
+            f.min_seeds = r.min_seeds = 0;
+            i64 nk = wl - k + 1;
+            if (q.whole && (L % 4) == 0) {
+                // top-level query with finalLen == 0: the forward scan loses 4 k-mers; its ReverseComplement() has
+                // firstLen == 0 and the scan starts 4 bases in (sequence.go:196, asm:109-132) — fixed up below
+                f.start = 0;
+                f.n_kmers = (uint32_t)std::max<i64>(0, nk - 4);
+                r.start = 4;
+                r.n_kmers = (uint32_t)std::max<i64>(0, nk - 4);
+            } else {
+                f.start = (uint32_t)q.a;
+                f.n_kmers = (uint32_t)std::max<i64>(0, nk);
+                r.start = (uint32_t)(L - q.b);
+                r.n_kmers = (uint32_t)std::max<i64>(0, nk);
+            }
+            witems.push_back(f);
+            witems.push_back(r);
+        }
+        // the chunk segments live in the device scan buffer; window scans must not clobber them -> the window scan uses a
+        // second context-independent path: scan, then re-import the chunk segments before the map stage
+        dp_seedseq_batch wb;
+        rc = dp_scan(ctx, witems.data(), (uint32_t)witems.size(), &wb);
+        if (rc) return fail(rc);
+        if (stats) stats->k_scan_ms += wb.kernel_ms, stats->n_windows += witems.size() / 2;
+        wsegs.clear();
+        woff.assign(1, 0);
+        wlen.clear();
+        for (size_t w = 0; w < witems.size(); w++) {
+            Task& t = *live[w / 2];
+            const bool rcside = (w & 1) != 0;
+            const size_t base = wsegs.size();
+            wsegs.insert(wsegs.end(), wb.segs + wb.seg_off[w], wb.segs + wb.seg_off[w + 1]);
+            if (rcside && t.req.whole && (t.L % 4) == 0) {
+                // firstLen==0 quirk: k-mer index 0 duplicates the k-mer at base 4, every later index is shifted by one
+                int32_t* sg = wsegs.data() + base;
+                const size_t n = wsegs.size() - base;
+                if (n >= 3 && sg[0] == 0) {  // the duplicated k-mer is a seed: it appears twice, 1-k apart
+                    std::vector<int32_t> fix;
+                    fix.push_back(0);
+                    fix.push_back(sg[1]);
+                    fix.push_back(1 - k);
+                    fix.insert(fix.end(), sg + 1, sg + n);
+                    wsegs.resize(base);
+                    wsegs.insert(wsegs.end(), fix.begin(), fix.end());
+                } else {
+                    sg[0] += 1;  // all indices shift by one (no hits: the single gap counts the extra k-mer too)
+                }
+            }
+            woff.push_back(wsegs.size());
+            wlen.push_back((uint32_t)(t.req.b - t.req.a));
+        }
+        rc = dp_scan_import_segments(ctx, M.chunkSegs.data(), M.chunkSegs.size());
+        if (rc) return fail(rc);
+        dp_chain_batch cb;
+        rc = dp_map_windows(ctx, wsegs.data(), woff.data(), wlen.data(), (uint32_t)witems.size(), k, &cb);
+        if (rc) return fail(rc);
+        if (stats) stats->k_map_ms += cb.kernel_ms, stats->n_chains += cb.n_chains, stats->n_batches++;
+        // ---- ... distribute and resume
+        for (auto& tp : live) {
+            tp->res.seg[0].clear();
+            tp->res.seg[1].clear();
+            tp->res.chains[0].clear();
+            tp->res.chains[1].clear();
+        }
+        for (size_t w = 0; w < witems.size(); w++)
+            live[w / 2]->res.seg[w & 1].assign(wsegs.begin() + (i64)woff[w], wsegs.begin() + (i64)woff[w + 1]);
+        for (uint32_t c = 0; c < cb.n_chains; c++) {
+            const uint32_t w = cb.window[c];
+            WindowResult::ChainRef cr;
+            cr.target = cb.target[c];
+            cr.a.assign(cb.match_a + cb.off[c], cb.match_a + cb.off[c + 1]);
+            cr.b.assign(cb.match_b + cb.off[c], cb.match_b + cb.off[c + 1]);
+            live[w / 2]->res.chains[w & 1].push_back(std::move(cr));
+        }
+        for (auto& tp : live) swapcontext(&sched.main, &tp->uc);
+    }
+    for (size_t r = 0; r < reads.size(); r++) {
+        paf += out[r];
+        if (nmaps[r] > 0) {
+            if (nmaps[r] == 1) mapped++;
+            else multiple++;
+            total += nmaps[r];
+        } else {
+            unmapped++;
+        }
+    }
+    char line[160];
+    snprintf(line, sizeof line, "Uniquely mapped: %lld\nMultiple mappings: %lld\ntotal: %lld\nUnmapped: %lld\n", (long long)mapped,
+             (long long)multiple, (long long)total, (long long)unmapped);
+    errText += line;
+    dp_ctx_destroy(ctx);
+    return 0;
+}
+
+}  // namespace dph

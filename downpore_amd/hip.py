@@ -71,7 +71,7 @@ def load_library():
     L.dp_index_build.argtypes = [vp, C.c_void_p, C.c_uint32]
     L.dp_find_overlaps.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_int, C.c_uint32, C.c_int,
                                    C.POINTER(MatchBatch)]
-    L.dp_map_windows.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(ChainBatch)]
+    L.dp_map_windows.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(ChainBatch)]
     L.dp_index_posting_row.argtypes = [vp, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32),
                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.dp_index_seedset_row.argtypes = [vp, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -204,11 +204,12 @@ class Context:
         return res
 
     # ---- A19 + A20
-    def map_windows(self, w_segs, w_off, k):
+    def map_windows(self, w_segs, w_off, w_len, k):
         ws = np.ascontiguousarray(w_segs, dtype=np.int32)
         wo = np.ascontiguousarray(w_off, dtype=np.uint64)
+        wl = np.ascontiguousarray(w_len, dtype=np.uint32)
         b = ChainBatch()
-        self._chk(self.L.dp_map_windows(self.h, ws.ctypes.data, wo.ctypes.data, len(wo) - 1, k, C.byref(b)))
+        self._chk(self.L.dp_map_windows(self.h, ws.ctypes.data, wo.ctypes.data, wl.ctypes.data, len(wo) - 1, k, C.byref(b)))
         n = b.n_chains
         off = _arr(b.off, n + 1, np.uint64)
         tot = int(off[-1]) if n else 0

@@ -142,7 +142,9 @@ int dp_find_overlaps(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, 
  * For each window: Matches(0.25) candidates, CountIntersectionTo prefilter and SeedSequence.Match
  * (Reduced x2 -> dynamicMatch -> extendChain; seeds/sequence.go:361-576) with the minMatches ratchet of
  * mapping/mapping.go:494-549 (window pairs fwd/rc are linked: the fwd ratchet also raises the rc threshold).
- * Windows come in (fwd, rc) pairs: window 2i is the forward query, 2i+1 its reverse complement. */
+ * Windows come in (fwd, rc) pairs: window 2i is the forward query, 2i+1 its reverse complement; w_len[w] is the
+ * window's length in bases (SeedSequence.Len(), used by the 2/3 flank test mapping.go:536,576).  Only chains that pass
+ * that test are returned, in the order performMapping appends them. */
 typedef struct {
     uint32_t n_chains;
     const uint32_t* window;  /* [n_chains] window index */
@@ -153,8 +155,8 @@ typedef struct {
     double kernel_ms;
 } dp_chain_batch;
 
-int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, uint32_t n_windows, int k,
-                   dp_chain_batch* out);
+int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t n_windows,
+                   int k, dp_chain_batch* out);
 
 /* ---- introspection for tests ---------------------------------------------------------------------------------- */
 /* posting row of `seed` (n_words = ceil(n_seqs/64)) and its popcount/start/end as the reference's IntSet holds. */

@@ -1,0 +1,61 @@
+"""GPU parity of the `map` path (A18-A21): reference seeding + chunk index + window scans + Matches + SeedSequence.Match
+chaining + mapper control flow must print the ORACLE's PAF line for line (read order)."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def first_diff(a, b):
+    if a == b:
+        return None
+    la, lb = a.split("\n"), b.split("\n")
+    for i, (x, y) in enumerate(zip(la, lb)):
+        if x != y:
+            return "line %d:\n  got  %s\n  want %s" % (i, x, y)
+    return "line counts differ: got %d want %d" % (len(la), len(lb))
+
+
+def _case(seed, G, N, L, e, variable, circular, k=11, short_reads=False):
+    from downpore_amd.mapping import map_reads
+    from downpore_amd.overlap import Reads
+    genome = np.frombuffer(O.gen_genome(seed, G), dtype=np.uint8)
+    goff = np.array([0, G], dtype=np.int64)
+    bases, off = O.gen_reads(seed, G, N, L, e, variable)
+    if short_reads:  # append reads <= 2*query_size, some with len % 4 == 0 (top-level scan quirks on both strands)
+        extra_b, extra_o = O.gen_reads(seed, G, 40, 1400, e, True)
+        cut = [1200, 1600, 1996, 2000, 900, 1333]
+        parts, offs = [bases], [off]
+        b2, o2 = [], [0]
+        for i in range(40):
+            ln = min(int(extra_o[i + 1] - extra_o[i]), cut[i % len(cut)])
+            b2.append(extra_b[extra_o[i]:extra_o[i] + ln])
+            o2.append(o2[-1] + ln)
+        bases = np.concatenate([bases] + b2)
+        off = np.concatenate([off, off[-1] + np.array(o2[1:], dtype=np.int64)])
+    oref = O.ReadSet(genome, goff, min_len=0, himem=False)
+    oreads = O.ReadSet(bases, off, min_len=500, himem=False)
+    want, werr = O.map_run(oref, oreads, circular=circular, k=k)
+    ref = Reads(genome, goff, min_len=0, himem=False)
+    reads = Reads(bases, off, min_len=500, himem=False)
+    got, gerr, st = map_reads(ref, reads, circular=circular, k=k)
+    d = first_diff(got, want)
+    assert d is None, d
+    assert gerr == werr
+    return want, st
+
+
+@pytest.mark.parametrize("seed,G,N,L,e,variable,circular", [(3, 200000, 300, 8000, 0.0, False, True),
+                                                           (4, 150000, 300, 6000, 0.05, True, True),
+                                                           (5, 300000, 200, 9000, 0.10, True, False)])
+def test_map_paf_bit_exact(seed, G, N, L, e, variable, circular):
+    want, st = _case(seed, G, N, L, e, variable, circular)
+    assert want.count("\n") > N // 2
+    assert st["n_windows"] >= N
+
+
+def test_map_short_reads_and_len_mod4_quirks():
+    want, st = _case(6, 120000, 100, 5000, 0.02, True, True, short_reads=True)
+    assert want.count("\n") > 50
