@@ -19,6 +19,7 @@
 // Algorithmic bytes per scan: packed bytes of the items + 4^k/8 + 8 B per written hit.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "dp_common.h"
@@ -361,26 +362,63 @@ struct ProbeLoop<32> {
     static __device__ __forceinline__ uint32_t run(const Win&, const uint8_t*, int) { return 0u; }
 };
 
-template <int MODE>  // 0 = count pass, 1 = write pass
-__global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const uint8_t* __restrict__ packed,
+// ---- filter v2 (k >= 9): one LDS byte probe serves TWO adjacent k-mer positions.
+// T1[c] for an 8-base core c: bit x     = some seed has 9-mer prefix  x.c  (x = the base before the core)
+//                             bit 4 + y = some seed has 9-mer prefix  c.y  (y = the base after the core)
+// The probe at the core that starts one base after position p answers position p (left extension by base p) and
+// position p+1 (right extension by base p+9).  T2 is a second-level 2^19-bit filter on the k-mer's last 19 bits,
+// consulted only for first-level hits, so the exact 4^k-bit table in L2 is reached by ~0.1 % of the k-mers.
+#define T1_BYTES 65536u
+#define T2_BYTES 16384u
+#define T2_MASK 0x1FFFFu  // 2^17 bits
+template <int T>
+struct PairLoop {
+    static __device__ __forceinline__ uint32_t run(const Win& w, const uint8_t* t1) {
+        const uint32_t win = win_at<2 * T>(w);
+        const uint32_t core = __builtin_amdgcn_ubfe(win, 14, 16);  // bases +1 .. +8
+        const uint32_t byte = t1[core];
+        const uint32_t hitA = __builtin_amdgcn_ubfe(byte, win >> 30, 1);
+        const uint32_t hitB = __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(win, 12, 2) | 4u, 1);
+        return ((hitA | (hitB << 1)) << (2 * T)) | PairLoop<T + 1>::run(w, t1);
+    }
+};
+template <>
+struct PairLoop<16> {
+    static __device__ __forceinline__ uint32_t run(const Win&, const uint8_t*) { return 0u; }
+};
+
+template <int MODE, int FILTER>  // MODE 0 = count pass, 1 = write pass; FILTER 1 = 10-mer prefix filter, 2 = paired 9-mer filter
+__global__ __launch_bounds__(SCAN_THREADS, FILTER == 2 ? 8 : 4) void scan_kernel(const uint8_t* __restrict__ packed,
                                                             const uint64_t* __restrict__ boff,
                                                             const dp_scan_item* __restrict__ items, uint32_t n_items, int k,
                                                             const uint32_t* __restrict__ seeds, uint32_t n_seeds,
                                                             const uint32_t* __restrict__ bits, const int32_t* __restrict__ kmap,
                                                             uint32_t* __restrict__ counts, const uint64_t* __restrict__ segoff,
                                                             int32_t* __restrict__ segs) {
-    extern __shared__ uint8_t bloom[];
-    const int pb = k < 10 ? k : 10;       // prefix bases used by the LDS filter
+    constexpr uint32_t LDS_BYTES = FILTER == 1 ? BLOOM_BYTES : (T1_BYTES + T2_BYTES);  // v2: 80 KiB -> two workgroups per CU
+    __shared__ __attribute__((aligned(16))) uint8_t bloom[LDS_BYTES];  // FILTER 2: T1 | T2
+    const int pb = k < 10 ? k : 10;       // prefix bases used by the v1 LDS filter
     const int pshift = 32 - 2 * pb;       // window -> filter index
     const int ksh = 32 - 2 * k;           // window -> k-mer
     {
         uint4* z = (uint4*)bloom;
-        for (uint32_t i = threadIdx.x; i < BLOOM_BYTES / 16; i += SCAN_THREADS) z[i] = make_uint4(0, 0, 0, 0);
+        for (uint32_t i = threadIdx.x; i < LDS_BYTES / 16; i += SCAN_THREADS) z[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
         uint32_t* bw = (uint32_t*)bloom;
         for (uint32_t s = threadIdx.x; s < n_seeds; s += SCAN_THREADS) {
-            uint32_t idx = seeds[s] >> (2 * (k - pb));
-            atomicOr(&bw[idx >> 5], 1u << (idx & 31));
+            const uint32_t kmer = seeds[s];
+            if (FILTER == 1) {
+                uint32_t idx = kmer >> (2 * (k - pb));
+                atomicOr(&bw[idx >> 5], 1u << (idx & 31));
+            } else {
+                const uint32_t P = kmer >> (2 * (k - 9));  // 9-mer prefix (18 bits)
+                const uint32_t cl = P & 0xFFFFu, x = P >> 16;
+                atomicOr(&bw[cl >> 2], (1u << x) << ((cl & 3) * 8));
+                const uint32_t cr = P >> 2, y = P & 3u;
+                atomicOr(&bw[cr >> 2], (16u << y) << ((cr & 3) * 8));
+                const uint32_t h = kmer & T2_MASK;
+                atomicOr(&bw[(T1_BYTES >> 2) + (h >> 5)], 1u << (h & 31));
+            }
         }
         __syncthreads();
     }
@@ -399,17 +437,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_kernel(const uint8_t* __res
         if (MODE == 1) outbase = segoff[it];
         if (item.n_kmers > 0) {
             const uint64_t g0 = a0 >> 5, g1 = (a1 - 1) >> 5;
+            Win wn = {0, 0, 0};
+            if (g0 + lane <= g1) wn = load_win(packed, g0 + lane);
             for (uint64_t gb = g0; gb <= g1; gb += 64) {
                 const uint64_t g = gb + lane;
                 uint32_t exact = 0;
-                Win w = {0, 0, 0};
+                const Win w = wn;
+                if (g + 64 <= g1) wn = load_win(packed, g + 64);  // software prefetch of the wave's next block
                 if (g <= g1) {
-                    w = load_win(packed, g);
-                    uint32_t m = ProbeLoop<0>::run(w, bloom, pshift) & valid_mask(g, a0, a1);
+                    uint32_t m = (FILTER == 1 ? ProbeLoop<0>::run(w, bloom, pshift) : PairLoop<0>::run(w, bloom)) & valid_mask(g, a0, a1);
                     while (m) {
                         int j = __builtin_ctz(m);
                         m &= m - 1;
                         uint32_t kmer = win_at_rt(w, j) >> ksh;
+                        if (FILTER == 2) {
+                            const uint32_t h = kmer & T2_MASK;
+                            if (!((bloom[T1_BYTES + (h >> 3)] >> (h & 7)) & 1u)) continue;
+                        }
                         if ((bits[kmer >> 5] >> (kmer & 31)) & 1u) exact |= 1u << j;
                     }
                 }
@@ -562,15 +606,10 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     DP_HIP(hipMemcpyAsync(ctx->d_items.p, items, (size_t)n_items * sizeof(dp_scan_item), hipMemcpyHostToDevice, ctx->stream));
     int dev_cus = 256;
     hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus, ((uint64_t)n_items + 15) / 16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        DP_HIP(hipFuncSetAttribute((const void*)scan_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, BLOOM_BYTES));
-        DP_HIP(hipFuncSetAttribute((const void*)scan_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, BLOOM_BYTES));
-        attr_set = true;
-    }
+    const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus * (v2 ? 2 : 1), ((uint64_t)n_items + 15) / 16);
     DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(scan_kernel<0>, dim3(grid), dim3(SCAN_THREADS), BLOOM_BYTES, ctx->stream, (const uint8_t*)ctx->d_packed.p,
+    hipLaunchKernelGGL((v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
                        (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p, n_items, k,
                        (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
                        (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr);
@@ -600,7 +639,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     hipEventElapsedTime(&msoff, ctx->ev[1], ctx->ev[4]);
     if (n_segs) {
         DP_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-        hipLaunchKernelGGL(scan_kernel<1>, dim3(grid), dim3(SCAN_THREADS), BLOOM_BYTES, ctx->stream,
+        hipLaunchKernelGGL((v2 ? scan_kernel<1, 2> : scan_kernel<1, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
                            (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p,
                            n_items, k, (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
                            (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
