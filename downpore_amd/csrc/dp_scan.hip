@@ -371,31 +371,31 @@ struct ProbeLoop<32> {
 #define T1_BYTES 65536u
 #define T2_BYTES 16384u
 #define T2_MASK 0x1FFFFu  // 2^17 bits
-template <int T>
+template <int T, bool NOLDS = false>
 struct PairLoop {
     static __device__ __forceinline__ uint32_t run(const Win& w, const uint8_t* t1) {
         const uint32_t win = win_at<2 * T>(w);
         const uint32_t core = __builtin_amdgcn_ubfe(win, 14, 16);  // bases +1 .. +8
-        const uint32_t byte = t1[core];
+        const uint32_t byte = NOLDS ? (core & 0x11u) : t1[core];
         const uint32_t hitA = __builtin_amdgcn_ubfe(byte, win >> 30, 1);
         const uint32_t hitB = __builtin_amdgcn_ubfe(byte, __builtin_amdgcn_ubfe(win, 12, 2) | 4u, 1);
-        return ((hitA | (hitB << 1)) << (2 * T)) | PairLoop<T + 1>::run(w, t1);
+        return ((hitA | (hitB << 1)) << (2 * T)) | PairLoop<T + 1, NOLDS>::run(w, t1);
     }
 };
-template <>
-struct PairLoop<16> {
+template <bool NOLDS>
+struct PairLoop<16, NOLDS> {
     static __device__ __forceinline__ uint32_t run(const Win&, const uint8_t*) { return 0u; }
 };
 
 template <int MODE, int FILTER>  // MODE 0 = count pass, 1 = write pass; FILTER 1 = 10-mer prefix filter, 2 = paired 9-mer filter
-__global__ __launch_bounds__(SCAN_THREADS, FILTER == 2 ? 8 : 4) void scan_kernel(const uint8_t* __restrict__ packed,
+__global__ __launch_bounds__(SCAN_THREADS, FILTER >= 2 ? 8 : 4) void scan_kernel(const uint8_t* __restrict__ packed,
                                                             const uint64_t* __restrict__ boff,
                                                             const dp_scan_item* __restrict__ items, uint32_t n_items, int k,
                                                             const uint32_t* __restrict__ seeds, uint32_t n_seeds,
                                                             const uint32_t* __restrict__ bits, const int32_t* __restrict__ kmap,
                                                             uint32_t* __restrict__ counts, const uint64_t* __restrict__ segoff,
-                                                            int32_t* __restrict__ segs) {
-    constexpr uint32_t LDS_BYTES = FILTER == 1 ? BLOOM_BYTES : (T1_BYTES + T2_BYTES);  // v2: 80 KiB -> two workgroups per CU
+                                                            int32_t* __restrict__ segs, uint32_t dbg) {
+    constexpr uint32_t LDS_BYTES = FILTER == 1 ? BLOOM_BYTES : (T1_BYTES + T2_BYTES);  // FILTER 3 = timing experiment (no LDS probes)  // v2: 80 KiB -> two workgroups per CU
     __shared__ __attribute__((aligned(16))) uint8_t bloom[LDS_BYTES];  // FILTER 2: T1 | T2
     const int pb = k < 10 ? k : 10;       // prefix bases used by the v1 LDS filter
     const int pshift = 32 - 2 * pb;       // window -> filter index
@@ -445,12 +445,16 @@ __global__ __launch_bounds__(SCAN_THREADS, FILTER == 2 ? 8 : 4) void scan_kernel
                 const Win w = wn;
                 if (g + 64 <= g1) wn = load_win(packed, g + 64);  // software prefetch of the wave's next block
                 if (g <= g1) {
-                    uint32_t m = (FILTER == 1 ? ProbeLoop<0>::run(w, bloom, pshift) : PairLoop<0>::run(w, bloom)) & valid_mask(g, a0, a1);
+                    uint32_t m = (FILTER == 1 ? ProbeLoop<0>::run(w, bloom, pshift) : FILTER == 3 ? PairLoop<0, true>::run(w, bloom) : PairLoop<0>::run(w, bloom)) & valid_mask(g, a0, a1);
+                    if (dbg & 1) {  // timing experiments only (DP_SCAN_DEBUG): drop the candidate loop
+                        cnt += __builtin_popcount(m);
+                        m = 0;
+                    }
                     while (m) {
                         int j = __builtin_ctz(m);
                         m &= m - 1;
                         uint32_t kmer = win_at_rt(w, j) >> ksh;
-                        if (FILTER == 2) {
+                        if (FILTER >= 2) {
                             const uint32_t h = kmer & T2_MASK;
                             if (!((bloom[T1_BYTES + (h >> 3)] >> (h & 7)) & 1u)) continue;
                         }
@@ -608,11 +612,12 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus * (v2 ? 2 : 1), ((uint64_t)n_items + 15) / 16);
+    const uint32_t dbg = getenv("DP_SCAN_DEBUG") ? (uint32_t)atoi(getenv("DP_SCAN_DEBUG")) : 0u;
     DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL((v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
+    hipLaunchKernelGGL(((dbg & 2) ? scan_kernel<0, 3> : v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
                        (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p, n_items, k,
                        (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
-                       (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr);
+                       (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr, dbg);
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     {
@@ -643,7 +648,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
                            (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p,
                            n_items, k, (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
                            (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
-                           (int32_t*)ctx->d_segs.p);
+                           (int32_t*)ctx->d_segs.p, 0u);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -8,6 +8,7 @@
 // This code does not include, link or call anything under oracle/.
 #pragma once
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -204,18 +205,23 @@ class Overlapper {
     void SetOverlapSize(i64 size) { overlap_ = size; }
     std::vector<SeedQuery> queries;
     std::string err;
+    struct Window {
+        uint32_t read, start, len;
+    };
+    const std::vector<Window>& windows() const { return windows_; }
+    void setWindows(const std::vector<Window>& w) { windows_ = w; }
+    // which reads count as ignored for PrepareQueries / ScanLocal (default: the read set's live flags)
+    void setIgnoreView(const uint8_t* ig) { ignore_ = ig; }
 
    private:
     void chunkAndAdd(SeedSeq* s, uint64_t segBase);
+    const uint8_t* ignore_ = nullptr;
     dp_ctx* ctx_;
     ReadSet& reads_;
     SeedIndex& index_;
     i64 chunkSize_, overlap_;
     int minSeeds_;
     double hitFraction_;
-    struct Window {
-        uint32_t read, start, len;
-    };
     std::vector<Window> windows_;
     std::vector<int32_t> querySegs_;       // fwd/rc query segments (host)
     std::vector<uint64_t> queryOff_;
@@ -230,34 +236,91 @@ struct FinalCheckStats {
     i64 badBack = 0, emptyMatch = 0;
     uint64_t lines = 0, hits = 0, qHits = 0;
 };
+// SetIgnore calls are returned in ignoreOut (query order) when it is non-null, otherwise applied to reads.ignore.
 void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vector<std::unique_ptr<SeedMatch>>& matches,
-                i64 numQuerySeqs, i64 overlapSize, std::string& paf, FinalCheckStats& fs);
+                i64 numQuerySeqs, i64 overlapSize, std::string& paf, FinalCheckStats& fs, std::vector<int>* ignoreOut = nullptr);
 
 // ---- command driver (commands/overlap.go:96-233) ------------------------------------------------------------------
+// One round's query batch, produced by seed selection alone (PrepareQueries): it depends on the read set, the value
+// table, the ignore flags of reads >= firstIn and on nothing the GPU computes, so it can run ahead of the execution.
+struct RoundPlan {
+    i64 round = 0;
+    i64 firstIn = 0, firstOut = 0;  // firstSequence before / after this round (commands/overlap.go:135-142)
+    bool empty = true;              // len(queries) == 0 -> the command ends (:130)
+    std::vector<Overlapper::Window> windows;
+    std::vector<uint32_t> seedMap;  // seed id -> k-mer
+};
+
+// Runs the PrepareQueries chain ahead of the executing rounds on its own thread.  Plans are speculative with respect
+// to ignore flags set by rounds that have not been committed yet; applyIgnores() discards every cached plan that a
+// newly ignored read could have influenced (any plan whose firstIn <= that read id), so get() always returns what the
+// sequential command would compute.
+class Planner {
+   public:
+    Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded);
+    ~Planner();
+    std::shared_ptr<const RoundPlan> get(i64 round);
+    // commit-time: set the flags; returns the first round whose cached plan was discarded (or -1)
+    i64 applyIgnores(const std::vector<int>& ids, i64 committedRound);
+    void dropBefore(i64 round);
+
+   private:
+    std::shared_ptr<RoundPlan> compute(i64 round, i64 firstIn);
+    void threadMain();
+    struct Impl;
+    std::unique_ptr<Impl> d;
+};
+
+struct RoundResult {
+    i64 round = 0;
+    bool empty = true;
+    i64 firstIn = 0, firstOut = 0, numQuerySeqs = 0;
+    std::string paf;
+    std::vector<int> ignores;            // SetIgnore calls of this round, in order
+    std::vector<uint32_t> indexedReads;  // read ids that entered the index (for speculation checks)
+    FinalCheckStats fs;
+    RoundStats st;
+};
+
 struct OverlapRun {
     dp_ctx* ctx = nullptr;
     ReadSet* reads = nullptr;
     OverlapParams p;
     std::vector<double> values;
-    std::unique_ptr<SeedIndex> index;
+    std::unique_ptr<SeedIndex> index;  // executor-side seed maps of the running round
     std::unique_ptr<Overlapper> lap;
+    std::unique_ptr<Planner> planner;
     i64 firstSequence = 0;
-    i64 round = 0;
+    i64 round = 0;  // next round to commit
     i64 numQuerySeqs = 0;
     i64 badBack = 0, emptyMatch = 0;
     bool done = false;
-    std::string paf;      // PAF text of the last finished round
+    std::string paf;      // PAF text of the last committed round(s)
     std::string errText;  // stderr progress lines accumulated
     std::string error;    // failure text
     RoundStats last;
     Survivors local;
-    // shard of reads this process scans: [shardLo, shardHi)
+    std::shared_ptr<const RoundPlan> curPlan;
+    RoundResult cur;
+    // shard of reads this process scans in scan-shard mode: [shardLo, shardHi)
     size_t shardLo = 0, shardHi = 0;
 
     int init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const double* valuesOrNull);
-    // one round = prepare -> scan -> (exchange) -> finish.  Returns 1 when a round was started, 0 when finished, <0 error
+    // ---- whole round on this process: plan (prefetched) -> execute -> commit.  1 = a round ran, 0 = finished, <0 error
+    int step();
+    // ---- scan-shard mode (survivor all-gather between the two halves)
     int roundPrepareAndScan();
     int roundFinish(const Survivors& all);
+    // ---- round-parallel mode: execute round `r` speculatively against the current flags, commit gathered results
+    int executeRound(i64 r, RoundResult& out);
+    // returns the number of rounds committed from `results` (in order, all consecutive from `round`), stopping at the
+    // first one invalidated by an earlier round's ignores; sets done when an empty round is reached
+    int commitResults(std::vector<RoundResult>& results);
+
+   private:
+    int beginRound(const RoundPlan& plan);
+    int finishRound(const Survivors& all, RoundResult& out);
+    void commitOne(RoundResult& r);
 };
 
 // ---- mapping.Mapper / `downpore map` (mapping/mapping.go, commands/map.go) ----------------------------------------

@@ -1,5 +1,6 @@
 // C entry points of libdownpore_host.so: lets Python (bench.py, tests) drive the product's host pipeline round by
 // round, interposing the multi-GPU survivor exchange between the local scan and the index build.
+#include <algorithm>
 #include <cstring>
 
 #include "dph.hpp"
@@ -78,6 +79,7 @@ void* dph_overlap_create(void* reads, int device, const int64_t* params, double 
 void dph_overlap_destroy(void* hh) {
     OverlapH* h = (OverlapH*)hh;
     if (!h) return;
+    h->run.planner.reset();
     h->run.lap.reset();
     h->run.index.reset();
     dp_ctx_destroy(h->ctx);
@@ -162,6 +164,79 @@ void dph_overlap_stats(void* hh, double* out) {
     memcpy(out, v, sizeof v);
 }
 void* dph_overlap_ctx(void* hh) { return ((OverlapH*)hh)->ctx; }
+
+// ---- whole round on this process (planner thread prefetches the next query batches): 1 ran, 0 finished, <0 error
+int dph_overlap_step(void* hh) {
+    OverlapH* h = (OverlapH*)hh;
+    int rc = h->run.step();
+    if (rc < 0) h->err = h->run.error;
+    else if (rc > 0) h->allPaf += h->run.paf;
+    return rc;
+}
+int64_t dph_overlap_round(void* hh) { return ((OverlapH*)hh)->run.round; }
+
+// ---- round-parallel mode: a rank executes ONE round speculatively and serialises the result; every rank then commits
+// the gathered results in round order with the speculation check (OverlapRun::commitResults).
+static void putv(std::string& b, const void* p, size_t n) { b.append((const char*)p, n); }
+const uint8_t* dph_overlap_exec_round(void* hh, int64_t r, uint64_t* n) {
+    OverlapH* h = (OverlapH*)hh;
+    static thread_local std::string blob;
+    RoundResult res;
+    int rc = h->run.executeRound(r, res);
+    if (rc < 0) {
+        h->err = h->run.error;
+        *n = 0;
+        return nullptr;
+    }
+    blob.clear();
+    int64_t hdr[16] = {res.round, res.empty ? 1 : 0, res.firstIn, res.firstOut, res.numQuerySeqs, (int64_t)res.ignores.size(),
+                       (int64_t)res.indexedReads.size(), (int64_t)res.paf.size(), res.fs.badBack, res.fs.emptyMatch,
+                       (int64_t)res.fs.lines, (int64_t)res.fs.hits, (int64_t)res.fs.qHits, 0, 0, 0};
+    putv(blob, hdr, sizeof hdr);
+    putv(blob, &res.st, sizeof(RoundStats));
+    putv(blob, res.ignores.data(), res.ignores.size() * sizeof(int));
+    putv(blob, res.indexedReads.data(), res.indexedReads.size() * 4);
+    putv(blob, res.paf.data(), res.paf.size());
+    *n = blob.size();
+    return (const uint8_t*)blob.data();
+}
+// blobs: concatenation; sizes[i] bytes each.  Returns the number of rounds committed (0..count) or <0.
+int dph_overlap_commit_blobs(void* hh, const uint8_t* blobs, const uint64_t* sizes, int count) {
+    OverlapH* h = (OverlapH*)hh;
+    std::vector<RoundResult> rs;
+    const uint8_t* p = blobs;
+    for (int i = 0; i < count; i++) {
+        const uint8_t* q = p;
+        int64_t hdr[16];
+        memcpy(hdr, q, sizeof hdr);
+        q += sizeof hdr;
+        RoundResult r;
+        r.round = hdr[0];
+        r.empty = hdr[1] != 0;
+        r.firstIn = hdr[2];
+        r.firstOut = hdr[3];
+        r.numQuerySeqs = hdr[4];
+        memcpy(&r.st, q, sizeof(RoundStats));
+        q += sizeof(RoundStats);
+        r.ignores.assign((const int*)q, (const int*)q + hdr[5]);
+        q += hdr[5] * sizeof(int);
+        r.indexedReads.assign((const uint32_t*)q, (const uint32_t*)q + hdr[6]);
+        q += hdr[6] * 4;
+        r.paf.assign((const char*)q, (size_t)hdr[7]);
+        r.fs.badBack = hdr[8];
+        r.fs.emptyMatch = hdr[9];
+        r.fs.lines = (uint64_t)hdr[10];
+        r.fs.hits = (uint64_t)hdr[11];
+        r.fs.qHits = (uint64_t)hdr[12];
+        rs.push_back(std::move(r));
+        p += sizes[i];
+    }
+    std::sort(rs.begin(), rs.end(), [](const RoundResult& a, const RoundResult& b) { return a.round < b.round; });
+    int c = h->run.commitResults(rs);
+    if (c > 0) h->allPaf += h->run.paf;
+    return c;
+}
+int dph_overlap_done(void* hh) { return ((OverlapH*)hh)->run.done ? 1 : 0; }
 
 }  // extern "C"
 

@@ -56,9 +56,8 @@ static int runOverlap(ArgTable& t) {
     }
     size_t shown = 0;
     for (;;) {
-        rc = run.roundPrepareAndScan();
+        rc = run.step();
         if (rc == 0) break;
-        if (rc > 0) rc = run.roundFinish(run.local);
         if (rc < 0) {
             fprintf(stderr, "downpore: %s\n", run.error.c_str());
             return 2;
@@ -70,6 +69,7 @@ static int runOverlap(ArgTable& t) {
     fwrite(run.errText.data() + shown, 1, run.errText.size() - shown, stderr);
     fprintf(stderr, "[downpore_amd] rounds=%lld bad_back_suppressed=%lld empty_match_panics_avoided=%lld\n", (long long)run.round,
             (long long)run.badBack, (long long)run.emptyMatch);
+    run.planner.reset();
     run.lap.reset();
     run.index.reset();
     dp_ctx_destroy(ctx);

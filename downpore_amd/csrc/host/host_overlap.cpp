@@ -3,7 +3,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
+#include <mutex>
 #include <thread>
 #include <cstdio>
 #include <cstring>
@@ -19,7 +21,9 @@ static double now() {
 Overlapper::Overlapper(dp_ctx* ctx, ReadSet& reads, SeedIndex& index, i64 chunkSize, int, i64 overlap, int minSeeds,
                        double hitFraction)
     : ctx_(ctx), reads_(reads), index_(index), chunkSize_(chunkSize), overlap_(overlap), minSeeds_(minSeeds),
-      hitFraction_(hitFraction) {}
+      hitFraction_(hitFraction) {
+    ignore_ = reads.ignore.data();
+}
 
 // PrepareQueries :157-214 with getEdges :55-89 (QueryEdges): seed selection is sequential and stays on the host.
 // Returns the number of query windows.
@@ -40,7 +44,7 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values
     auto moreCands = [&](size_t upTo) {
         if (firstSequence != 0 && firstSequence >= (i64)reads_.size()) return;  // seqio.go:279
         for (; rNext < reads_.size() && sent < maxSeqs && cand.size() < upTo; rNext++) {
-            if (reads_.ignore[rNext]) continue;
+            if (ignore_[rNext]) continue;
             sent++;
             const i64 L = reads_.length(rNext);
             if (L < overlap_ * 2) {
@@ -110,7 +114,7 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
     std::vector<dp_scan_item> items;
     std::vector<uint32_t> itemRead;
     for (size_t r = lo; r < hi; r++) {
-        if (reads_.ignore[r]) continue;
+        if (ignore_[r]) continue;
         dp_scan_item it;
         it.read = (uint32_t)r;
         it.start = 0;
@@ -379,7 +383,7 @@ static void finalCheckOne(Arena& arena, const SeedIndex& index, const ReadSet& r
 }
 
 void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vector<std::unique_ptr<SeedMatch>>& matches,
-                i64 numQuerySeqs, i64 overlapSize, std::string& paf, FinalCheckStats& fs) {
+                i64 numQuerySeqs, i64 overlapSize, std::string& paf, FinalCheckStats& fs, std::vector<int>* ignoreOut) {
     // collate by QueryID (:158-173)
     std::vector<std::vector<SeedMatch*>> queryResults((size_t)numQuerySeqs);
     i64 hits = 0, qHits = 0;
@@ -418,7 +422,10 @@ void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vecto
     }
     for (size_t w = 0; w < nw; w++) {
         paf += outs[w];
-        for (int id : ign[w]) reads.ignore[(size_t)id] = 1;
+        for (int id : ign[w]) {
+            if (ignoreOut) ignoreOut->push_back(id);
+            else reads.ignore[(size_t)id] = 1;
+        }
     }
     for (auto& t : tfs) {
         fs.badBack += t.badBack;
@@ -437,6 +444,176 @@ unsigned hostThreads() {
         return std::min(v, 32u);
     }();
     return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Planner: the PrepareQueries chain (overlap.go:157-214 seed selection + commands/overlap.go:128-143 bookkeeping)
+
+struct Planner::Impl {
+    ReadSet& reads;
+    OverlapParams p;
+    const double* values;
+    bool threaded;
+    SeedIndex index;  // selection-side seed set of the plan being computed
+    std::mutex mu;
+    std::condition_variable cv;
+    std::map<i64, std::shared_ptr<RoundPlan>> cache;
+    i64 wantUpTo = -1;        // prefetch target (highest requested round + depth)
+    i64 base = 0;             // rounds below are committed and gone
+    uint64_t epoch = 0;       // bumped whenever an ignore flag is set
+    i64 epochMinId = -1;      // smallest read id flagged in the last bump(s) while a compute was running
+    bool stop = false;
+    std::thread th;
+    Impl(ReadSet& r, const OverlapParams& pp, const double* v, bool t) : reads(r), p(pp), values(v), threaded(t), index(pp.k) {}
+};
+
+Planner::Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded) : d(new Impl(reads, p, values, threaded)) {
+    if (threaded) d->th = std::thread([this] { threadMain(); });
+}
+
+Planner::~Planner() {
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        d->stop = true;
+    }
+    d->cv.notify_all();
+    if (d->th.joinable()) d->th.join();
+}
+
+std::shared_ptr<RoundPlan> Planner::compute(i64 round, i64 firstIn) {
+    auto plan = std::make_shared<RoundPlan>();
+    plan->round = round;
+    plan->firstIn = firstIn;
+    d->index.reset();
+    Overlapper lap(nullptr, d->reads, d->index, d->p.chunkSize, d->p.numWorkers, d->p.overlapSize, d->p.numSeeds, d->p.minHits);
+    const int nw = lap.PrepareQueries(d->p.numSeeds, d->p.seedBatchSize, d->values, firstIn, d->p.queryBatchSize);
+    plan->empty = nw == 0;
+    plan->windows = lap.windows();
+    plan->seedMap = d->index.seedMap;
+    // firstSequence = max query SequenceID + 1 (commands/overlap.go:135-142); windows are in ascending read order
+    plan->firstOut = nw ? (i64)plan->windows.back().read + 1 : firstIn;
+    return plan;
+}
+
+void Planner::threadMain() {
+    std::unique_lock<std::mutex> lk(d->mu);
+    for (;;) {
+        if (d->stop) return;
+        // next plan of the chain that is missing
+        i64 m = d->base;
+        i64 firstIn = -1;
+        bool can = false;
+        while (m <= d->wantUpTo) {
+            auto it = d->cache.find(m);
+            if (it == d->cache.end()) {
+                if (m == 0) {
+                    firstIn = 0;
+                    can = true;
+                } else {
+                    auto pr = d->cache.find(m - 1);
+                    if (pr != d->cache.end() && !pr->second->empty) {
+                        firstIn = pr->second->firstOut;
+                        can = true;
+                    }
+                }
+                break;
+            }
+            if (it->second->empty) break;  // chain ends here
+            m++;
+        }
+        if (!can) {
+            d->cv.wait(lk);
+            continue;
+        }
+        const uint64_t e0 = d->epoch;
+        d->epochMinId = -1;
+        lk.unlock();
+        std::shared_ptr<RoundPlan> plan = compute(m, firstIn);
+        lk.lock();
+        if (d->stop) return;
+        // discard if flags that could matter changed meanwhile, or if the chain below was invalidated
+        bool ok = true;
+        if (d->epoch != e0 && d->epochMinId >= 0 && d->epochMinId >= firstIn) ok = false;
+        if (m > 0 && m > d->base) {
+            auto pr = d->cache.find(m - 1);
+            if (pr == d->cache.end() || pr->second->firstOut != firstIn) ok = false;
+        }
+        if (m < d->base) ok = false;
+        if (ok && !d->cache.count(m)) d->cache[m] = plan;
+        d->cv.notify_all();
+    }
+}
+
+std::shared_ptr<const RoundPlan> Planner::get(i64 round) {
+    std::unique_lock<std::mutex> lk(d->mu);
+    if (!d->threaded) {  // inline chain: compute the first missing plan until `round` is there (or the chain has ended)
+        for (;;) {
+            auto it = d->cache.find(round);
+            if (it != d->cache.end()) return it->second;
+            i64 m = d->base, firstIn = 0;
+            for (;;) {
+                auto e = d->cache.find(m);
+                if (e == d->cache.end()) break;
+                if (e->second->empty) return e->second;
+                firstIn = e->second->firstOut;
+                m++;
+            }
+            if (m > round) return nullptr;
+            if (m > 0 && !d->cache.count(m - 1)) return nullptr;  // predecessor must be cached (dropBefore keeps it)
+            lk.unlock();
+            auto plan = compute(m, m == 0 ? 0 : firstIn);
+            lk.lock();
+            d->cache[m] = plan;
+        }
+    }
+    const i64 depth = 6;
+    if (round + depth > d->wantUpTo) d->wantUpTo = round + depth;
+    d->cv.notify_all();
+    for (;;) {
+        auto it = d->cache.find(round);
+        if (it != d->cache.end()) return it->second;
+        // the chain may have ended before `round`
+        for (i64 m = d->base; m < round; m++) {
+            auto e = d->cache.find(m);
+            if (e == d->cache.end()) break;
+            if (e->second->empty) return e->second;
+        }
+        d->cv.wait(lk);
+    }
+}
+
+i64 Planner::applyIgnores(const std::vector<int>& ids, i64 committedRound) {
+    std::lock_guard<std::mutex> lk(d->mu);
+    i64 maxNew = -1, minNew = -1;
+    for (int id : ids) {
+        if (!d->reads.ignore[(size_t)id]) {
+            d->reads.ignore[(size_t)id] = 1;
+            if (id > maxNew) maxNew = id;
+            if (minNew < 0 || id < minNew) minNew = id;
+        }
+    }
+    if (maxNew < 0) return -1;
+    d->epoch++;
+    if (d->epochMinId < 0 || minNew < d->epochMinId) d->epochMinId = minNew;
+    // every cached plan of a later round that starts at or before a newly flagged read may change
+    i64 firstBad = -1;
+    for (auto it = d->cache.begin(); it != d->cache.end(); ++it) {
+        if (it->first > committedRound && it->second->firstIn <= maxNew) {
+            firstBad = it->first;
+            break;
+        }
+    }
+    if (firstBad >= 0) d->cache.erase(d->cache.lower_bound(firstBad), d->cache.end());
+    d->cv.notify_all();
+    return firstBad;
+}
+
+void Planner::dropBefore(i64 round) {
+    std::lock_guard<std::mutex> lk(d->mu);
+    // keep round-1: it carries firstOut for the chain
+    d->cache.erase(d->cache.begin(), d->cache.lower_bound(round - 1));
+    if (round - 1 > d->base) d->base = round - 1;
+    if (d->base < 0) d->base = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -463,6 +640,8 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     }
     errText += "Counting complete. Starting indexing and querying...";
     index.reset(new SeedIndex(p.k));
+    const char* nothread = getenv("DP_NO_PLANNER_THREAD");
+    planner.reset(new Planner(*reads, p, values.data(), !(nothread && nothread[0] == '1')));
     firstSequence = 0;
     round = 0;
     done = false;
@@ -471,50 +650,83 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     return 0;
 }
 
-int OverlapRun::roundPrepareAndScan() {
-    if (done) return 0;
-    last = RoundStats();
-    paf.clear();
-    double t0 = now();
+// seeds.NewSeedIndex + the plan's seeds on host and device; queries are built after the scan
+int OverlapRun::beginRound(const RoundPlan& plan) {
     index->reset();  // seeds.NewSeedIndex(k) per round (:125) — sparse reset instead of reallocating 4^k tables
+    for (uint32_t km : plan.seedMap) index->addSeedKmer(km);
     lap.reset(new Overlapper(ctx, *reads, *index, p.chunkSize, p.numWorkers, p.overlapSize, p.numSeeds, p.minHits));
-    int nw = lap->PrepareQueries(p.numSeeds, p.seedBatchSize, values.data(), firstSequence, p.queryBatchSize);
-    if (nw == 0) {  // len(queries) == 0 (:130)
-        done = true;
-        return 0;
-    }
+    lap->setWindows(plan.windows);
     int rc = dp_round_begin(ctx, p.k, index->seedMap.data(), (uint32_t)index->seedMap.size());
     if (rc != 0) {
         error = dp_last_error(ctx);
         return rc;
     }
-    last.n_seeds = index->seedMap.size();
-    double t1 = now();
-    last.t_prepare = t1 - t0;
-    rc = lap->ScanLocal(shardLo, shardHi, local, last);
-    if (rc != 0) {
-        error = lap->err;
-        return rc;
-    }
-    last.t_scan = now() - t1;
-    return 1;
+    return 0;
 }
 
-int OverlapRun::roundFinish(const Survivors& all) {
+int OverlapRun::finishRound(const Survivors& all, RoundResult& out) {
+    RoundStats& st = out.st;
     double t0 = now();
-    int rc = lap->IndexSurvivors(all, last);
+    int rc = lap->IndexSurvivors(all, st);
     if (rc != 0) {
         error = lap->err;
         return rc;
     }
-    // firstSequence / numQuerySeqs (:134-143)
-    numQuerySeqs = 0;
-    firstSequence = lap->queries.back().SequenceID + 1;
-    for (const SeedQuery& q : lap->queries) {
-        if (q.ID >= numQuerySeqs) numQuerySeqs = q.ID + 1;
-        if (q.SequenceID >= firstSequence) firstSequence = q.SequenceID + 1;
+    out.indexedReads = all.read;
+    out.numQuerySeqs = 0;
+    for (const SeedQuery& q : lap->queries)
+        if (q.ID >= out.numQuerySeqs) out.numQuerySeqs = q.ID + 1;
+    double t1 = now();
+    st.t_index = t1 - t0;
+    std::vector<std::unique_ptr<SeedMatch>> matches;
+    rc = lap->FindOverlaps(matches, st);
+    if (rc != 0) {
+        error = lap->err;
+        return rc;
     }
+    double t2 = now();
+    st.t_query = t2 - t1;
+    finalCheck(index->arena, *index, *reads, matches, out.numQuerySeqs, p.overlapSize, out.paf, out.fs, &out.ignores);
+    st.n_paf = out.fs.lines;
+    st.t_consensus = now() - t2;
+    const int k = p.k;
+    // algorithmic bytes of the scan (SURVEY §8(d)): packed bytes of the scanned items + bit table + 8 B per hit
+    st.scan_bytes = st.scan_bases / 4 + (((uint64_t)1 << (2 * k)) / 8) + 8 * st.n_hits;
+    st.count_bytes = st.scan_bases / 4 + (((uint64_t)1 << (2 * k)) / 8);
+    return 0;
+}
+
+int OverlapRun::executeRound(i64 r, RoundResult& out) {
+    out = RoundResult();
+    out.round = r;
+    double t0 = now();
+    std::shared_ptr<const RoundPlan> plan = planner->get(r);
+    if (!plan || plan->empty || plan->round != r) {
+        out.empty = true;
+        if (plan) out.firstIn = out.firstOut = plan->firstOut;
+        return 0;
+    }
+    out.empty = false;
+    out.firstIn = plan->firstIn;
+    out.firstOut = plan->firstOut;
+    int rc = beginRound(*plan);
+    if (rc) return rc;
+    out.st.n_seeds = plan->seedMap.size();
+    double t1 = now();
+    out.st.t_prepare = t1 - t0;
+    rc = lap->ScanLocal(0, reads->size(), local, out.st);
+    if (rc != 0) {
+        error = lap->err;
+        return rc;
+    }
+    out.st.t_scan = now() - t1;
+    return finishRound(local, out);
+}
+
+void OverlapRun::commitOne(RoundResult& r) {
     char line[200];
+    firstSequence = r.firstOut;
+    numQuerySeqs = r.numQuerySeqs;
     if (round == 0)
         snprintf(line, sizeof line, "Using query sets of around %lld sequences against %lld sequences.\n", (long long)firstSequence,
                  (long long)reads->size());
@@ -522,30 +734,108 @@ int OverlapRun::roundFinish(const Survivors& all) {
         snprintf(line, sizeof line, "Using query set with %lld  sequences starting from %lld sequences against %lld sequences.\n",
                  (long long)numQuerySeqs, (long long)firstSequence, (long long)reads->size());
     errText += line;
+    snprintf(line, sizeof line, "Total %lld hits across %lld overlaps.\n", (long long)r.fs.hits, (long long)r.fs.qHits);
+    errText += line;
+    badBack += r.fs.badBack;
+    emptyMatch += r.fs.emptyMatch;
+    paf += r.paf;
+    last = r.st;
+    planner->applyIgnores(r.ignores, round);
+    round++;
+    planner->dropBefore(round);
+}
+
+int OverlapRun::commitResults(std::vector<RoundResult>& results) {
+    paf.clear();
+    int committed = 0;
+    std::vector<uint8_t> newly;  // flags set by rounds committed in THIS call
+    std::vector<int> newIds;
+    for (RoundResult& r : results) {
+        if (r.round != round) break;
+        if (r.empty) {
+            done = true;
+            break;
+        }
+        // speculation check: the round ran against the flags at the start of this batch.  It is exact iff no read
+        // flagged by the earlier rounds of the batch could have been one of its queries (id >= firstIn) or entered
+        // its index.
+        bool ok = true;
+        if (!newIds.empty()) {
+            for (int id : newIds)
+                if (id >= r.firstIn) {
+                    ok = false;
+                    break;
+                }
+            if (ok) {
+                if (newly.empty()) {
+                    newly.assign(reads->size(), 0);
+                    for (int id : newIds) newly[(size_t)id] = 1;
+                }
+                for (uint32_t rd : r.indexedReads)
+                    if (newly[rd]) {
+                        ok = false;
+                        break;
+                    }
+            }
+        }
+        if (!ok) break;
+        for (int id : r.ignores)
+            if (!reads->ignore[(size_t)id]) {
+                newIds.push_back(id);
+                if (!newly.empty()) newly[(size_t)id] = 1;
+            }
+        commitOne(r);
+        committed++;
+    }
+    return committed;
+}
+
+int OverlapRun::step() {
+    if (done) return 0;
+    int rc = executeRound(round, cur);
+    if (rc < 0) return rc;
+    if (cur.empty) {
+        done = true;
+        return 0;
+    }
+    paf.clear();
+    commitOne(cur);
+    return 1;
+}
+
+// ---- scan-shard mode: plan + local scan, then (after the survivor exchange) the rest of the round
+int OverlapRun::roundPrepareAndScan() {
+    if (done) return 0;
+    cur = RoundResult();
+    cur.round = round;
+    double t0 = now();
+    curPlan = planner->get(round);
+    if (!curPlan || curPlan->empty) {
+        done = true;
+        return 0;
+    }
+    cur.empty = false;
+    cur.firstIn = curPlan->firstIn;
+    cur.firstOut = curPlan->firstOut;
+    int rc = beginRound(*curPlan);
+    if (rc) return rc;
+    cur.st.n_seeds = curPlan->seedMap.size();
     double t1 = now();
-    last.t_index = t1 - t0;
-    std::vector<std::unique_ptr<SeedMatch>> matches;
-    rc = lap->FindOverlaps(matches, last);
+    cur.st.t_prepare = t1 - t0;
+    rc = lap->ScanLocal(shardLo, shardHi, local, cur.st);
     if (rc != 0) {
         error = lap->err;
         return rc;
     }
-    double t2 = now();
-    last.t_query = t2 - t1;
-    FinalCheckStats fs;
-    finalCheck(index->arena, *index, *reads, matches, numQuerySeqs, p.overlapSize, paf, fs);
-    badBack += fs.badBack;
-    emptyMatch += fs.emptyMatch;
-    snprintf(line, sizeof line, "Total %lld hits across %lld overlaps.\n", (long long)fs.hits, (long long)fs.qHits);
-    errText += line;
-    const int k = p.k;
-    const uint64_t lines = fs.lines;
-    last.n_paf = lines;
-    last.t_consensus = now() - t2;
-    // algorithmic bytes of the scan (SURVEY §8(d)): packed bytes of the scanned items + bit table + 8 B per hit
-    last.scan_bytes = last.scan_bases / 4 + (((uint64_t)1 << (2 * k)) / 8) + 8 * last.n_hits;
-    last.count_bytes = last.scan_bases / 4 + (((uint64_t)1 << (2 * k)) / 8);
-    round++;
+    cur.st.t_scan = now() - t1;
+    return 1;
+}
+
+int OverlapRun::roundFinish(const Survivors& all) {
+    int rc = finishRound(all, cur);
+    if (rc) return rc;
+    paf.clear();
+    commitOne(cur);
     return 0;
 }
 

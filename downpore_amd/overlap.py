@@ -62,6 +62,13 @@ def load_host():
     H.dph_overlap_stats.argtypes = [vp, C.c_void_p]
     H.dph_overlap_ctx.restype = vp
     H.dph_overlap_ctx.argtypes = [vp]
+    H.dph_overlap_step.argtypes = [vp]
+    H.dph_overlap_round.restype = C.c_int64
+    H.dph_overlap_round.argtypes = [vp]
+    H.dph_overlap_exec_round.restype = C.POINTER(C.c_uint8)
+    H.dph_overlap_exec_round.argtypes = [vp, C.c_int64, C.POINTER(C.c_uint64)]
+    H.dph_overlap_commit_blobs.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_int]
+    H.dph_overlap_done.argtypes = [vp]
     _host = H
     return H
 
@@ -104,6 +111,24 @@ def allgather_survivors(local, world, device=None):
     return dict(read=np.concatenate(reads), n_seeds=np.concatenate(nseeds), segs=np.concatenate(segs).astype(np.int32))
 
 
+def allgather_bytes(blob, world, device=None):
+    """All-gather of one variable-size byte string per rank (torch.distributed; nccl == RCCL on the GPU box)."""
+    import torch
+    import torch.distributed as dist
+    dev = device if device is not None else torch.device("cpu")
+    n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    mx = max(max(sizes), 1)
+    buf = np.zeros(mx, dtype=np.uint8)
+    buf[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+    t = torch.from_numpy(buf).to(dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [out[r].cpu().numpy()[:sizes[r]].tobytes() for r in range(world)]
+
+
 class Reads:
     def __init__(self, bases=None, off=None, min_len=1000, himem=True, fasta=None):
         H = load_host()
@@ -136,7 +161,11 @@ class OverlapPipeline:
     """`downpore overlap` on one GPU (or one rank of a multi-GPU job)."""
 
     def __init__(self, reads, device=0, k=10, overlap_size=1000, num_seeds=15, seed_batch_size=10000, chunk_size=10000,
-                 query_batch_size=20000, min_hits=0.25, himem=True, values=None, rank=0, world=1, torch_device=None):
+                 query_batch_size=20000, min_hits=0.25, himem=True, values=None, rank=0, world=1, torch_device=None,
+                 mode="round"):
+        """mode (world > 1): "round" = round-parallel (rank r executes round base+r speculatively, results are
+        all-gathered and committed in order with a speculation check); "scan-shard" = every rank runs every round, the
+        scan is sharded by read and the survivors are all-gathered."""
         self.H = load_host()
         p = np.array([overlap_size, k, num_seeds, seed_batch_size, chunk_size, query_batch_size, 1 if himem else 0],
                      dtype=np.int64)
@@ -148,8 +177,10 @@ class OverlapPipeline:
         self.reads = reads
         self.rank, self.world = rank, world
         self.torch_device = torch_device
-        lo, hi = shard_bounds(len(reads), rank, world)
-        self.H.dph_overlap_set_shard(self.h, lo, hi)
+        self.mode = mode if world > 1 else "single"
+        if self.mode == "scan-shard":
+            lo, hi = shard_bounds(len(reads), rank, world)
+            self.H.dph_overlap_set_shard(self.h, lo, hi)
 
     def close(self):
         if getattr(self, "h", None):
@@ -183,23 +214,63 @@ class OverlapPipeline:
                     segs=arr(ptrs[3], m.value, C.c_int32, np.int32))
 
     def step(self):
-        """One round.  Returns False when the command has finished."""
+        """Advances the command.  Returns the number of rounds committed by this call (0 = finished)."""
+        if self.mode == "single":
+            rc = self.H.dph_overlap_step(self.h)
+            if rc < 0:
+                raise self._err()
+            return rc
+        if self.mode == "round":
+            if self.H.dph_overlap_done(self.h):
+                return 0
+            base = self.H.dph_overlap_round(self.h)
+            n = C.c_uint64(0)
+            p = self.H.dph_overlap_exec_round(self.h, base + self.rank, C.byref(n))
+            if not p:
+                raise self._err()
+            blobs = allgather_bytes(C.string_at(p, n.value), self.world, self.torch_device)
+            sizes = np.array([len(b) for b in blobs], dtype=np.uint64)
+            cat = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+            c = self.H.dph_overlap_commit_blobs(self.h, cat.ctypes.data, sizes.ctypes.data, len(blobs))
+            if c < 0:
+                raise self._err()
+            return c
+        # scan-shard
         rc = self.H.dph_overlap_round_scan(self.h)
         if rc < 0:
             raise self._err()
         if rc == 0:
-            return False
-        if self.world > 1:
-            allv = allgather_survivors(self.local_survivors(), self.world, self.torch_device)
-            r = np.ascontiguousarray(allv["read"], dtype=np.uint32)
-            ns = np.ascontiguousarray(allv["n_seeds"], dtype=np.uint32)
-            sg = np.ascontiguousarray(allv["segs"], dtype=np.int32)
-            rc = self.H.dph_overlap_round_finish(self.h, r.ctypes.data, ns.ctypes.data, sg.ctypes.data, len(r))
-        else:
-            rc = self.H.dph_overlap_round_finish(self.h, None, None, None, 0)
+            return 0
+        allv = allgather_survivors(self.local_survivors(), self.world, self.torch_device)
+        r = np.ascontiguousarray(allv["read"], dtype=np.uint32)
+        ns = np.ascontiguousarray(allv["n_seeds"], dtype=np.uint32)
+        sg = np.ascontiguousarray(allv["segs"], dtype=np.int32)
+        rc = self.H.dph_overlap_round_finish(self.h, r.ctypes.data, ns.ctypes.data, sg.ctypes.data, len(r))
         if rc < 0:
             raise self._err()
-        return True
+        return 1
+
+    # ---- round-parallel building blocks (also used by the single-GPU simulation test)
+    def committed_rounds(self):
+        return self.H.dph_overlap_round(self.h)
+
+    def finished(self):
+        return bool(self.H.dph_overlap_done(self.h))
+
+    def exec_round_blob(self, rnd):
+        n = C.c_uint64(0)
+        p = self.H.dph_overlap_exec_round(self.h, rnd, C.byref(n))
+        if not p:
+            raise self._err()
+        return C.string_at(p, n.value)
+
+    def commit_blobs(self, blobs):
+        sizes = np.array([len(b) for b in blobs], dtype=np.uint64)
+        cat = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+        c = self.H.dph_overlap_commit_blobs(self.h, cat.ctypes.data, sizes.ctypes.data, len(blobs))
+        if c < 0:
+            raise self._err()
+        return c
 
     def stats(self):
         out = np.zeros(len(STAT_FIELDS), dtype=np.float64)
@@ -222,6 +293,9 @@ class OverlapPipeline:
 
     def run(self, max_rounds=-1):
         n = 0
-        while (max_rounds < 0 or n < max_rounds) and self.step():
-            n += 1
+        while max_rounds < 0 or n < max_rounds:
+            c = self.step()
+            if c == 0:
+                break
+            n += c
         return n

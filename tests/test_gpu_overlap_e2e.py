@@ -86,3 +86,34 @@ def test_cli_matches_oracle_cli(tmp_path):
     c = subprocess.run([os.path.join(ROOT, "downpore_amd", "bin", "downpore"), "overlap", "-i", fa, "--k", "10"],
                        capture_output=True, check=True)
     assert first_diff(c.stdout.decode(), a.stdout.decode()) is None
+
+
+@pytest.mark.parametrize("world,seed,G,N,L,variable", [(4, 31, 100000, 400, 5000, False), (3, 32, 60000, 500, 1500, True)])
+def test_round_parallel_protocol_matches_oracle(world, seed, G, N, L, variable):
+    """Round-parallel multi-GPU mode, simulated with `world` contexts on one GPU: rank r executes round base+r
+    speculatively, results are exchanged and committed in order with the speculation check.  The second case has many
+    reads <= 2*overlap_size, so rounds DO flag reads as ignored and later speculative rounds must be discarded."""
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(seed, G, N, L, 0.0, variable)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    orun = O.OverlapRun(rs, k=10)
+    readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
+    pipes = [OverlapPipeline(readsets[r], k=10, rank=r, world=world, mode="round") for r in range(world)]
+    supersteps = 0
+    short_commits = 0
+    while not pipes[0].finished():
+        base = pipes[0].committed_rounds()
+        blobs = [pipes[r].exec_round_blob(base + r) for r in range(world)]
+        cs = [pipes[r].commit_blobs(blobs) for r in range(world)]
+        assert len(set(cs)) == 1
+        if 0 < cs[0] < world and not pipes[0].finished():
+            short_commits += 1
+        supersteps += 1
+        assert supersteps < 10 * orun.rounds + 10
+    for r in range(world):
+        assert first_diff(pipes[r].all_paf(), orun.paf) is None
+        assert pipes[r].committed_rounds() == orun.rounds
+        assert np.array_equal(readsets[r].ignore(), rs.ignore())
+        pipes[r].close()
+    if variable:
+        assert rs.ignore().sum() > 0
