@@ -33,18 +33,29 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--seed-batch-size", type=int, default=10000)
     ap.add_argument("--cpu-rounds", type=int, default=2, help="oracle rounds timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--mode", default="round", choices=["round", "scan-shard"], help="multi-GPU decomposition (N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and "DP_HOST_THREADS" not in os.environ:  # ranks share the node's cores
+        os.environ["DP_HOST_THREADS"] = str(max(2, min(32, (os.cpu_count() or 8) // world)))
     import torch
     torch_device = None
     if world > 1:
         import torch.distributed as dist
+        # test hooks for a 1-GPU box: DP_BENCH_SAME_DEVICE=1 puts every rank on GPU 0, DP_BENCH_BACKEND=gloo exchanges on
+        # the host (RCCL refuses two ranks on one GPU).  The driver's multi-GPU runs use neither.
+        if os.environ.get("DP_BENCH_SAME_DEVICE") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        torch_device = torch.device("cuda", local_rank)
-        dist.init_process_group("nccl", device_id=torch_device)
+        if os.environ.get("DP_BENCH_BACKEND", "nccl") == "gloo":
+            dist.init_process_group("gloo")
+            torch_device = None
+        else:
+            torch_device = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=torch_device)
     else:
         dist = None
 
@@ -59,7 +70,7 @@ def main():
     t_gen = time.time() - t0
     t0 = time.time()
     pipe = OverlapPipeline(reads, device=local_rank, k=args.k, seed_batch_size=args.seed_batch_size, rank=rank, world=world,
-                           torch_device=torch_device)
+                           torch_device=torch_device, mode=args.mode)
     t_setup = time.time() - t0
 
     def sync():
@@ -68,31 +79,37 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        if not pipe.step():
+    warm = 0
+    while warm < args.warmup:
+        c = pipe.step()
+        if c == 0:
             break
+        warm += c
     sync()
     acc = {}
     lines = 0
-    steps_done = 0
+    steps_done = 0   # rounds committed in the timed region (a step = one round; with N ranks a call commits up to N)
+    samples = 0
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        if not pipe.step():
+    while steps_done < args.steps:
+        c = pipe.step()
+        if c == 0:
             break
-        st = pipe.stats()
+        st = pipe.stats()  # stats of the last committed round
         for key, v in st.items():
             acc[key] = acc.get(key, 0.0) + v
-        lines += int(st["n_paf"])
-        steps_done += 1
+        samples += 1
+        lines += pipe.round_paf().count("\n")
+        steps_done += c
     sync()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch_device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch_device if torch_device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
-        n = max(1, steps_done)
+        n = max(1, samples)
         count_ms = acc.get("k_count_ms", 0.0) / n
         count_bytes = acc.get("count_bytes", 0.0) / n
         achieved = (count_bytes / 1e9) / (count_ms / 1e3) if count_ms > 0 else 0.0
@@ -105,17 +122,20 @@ def main():
                 traffic = None
         out = {
             "metric": "overlaps/sec (all-vs-all PAF)", "value": lines / elapsed if elapsed > 0 else 0.0, "unit": "overlaps/s",
-            "n_gpus": world, "steps": steps_done, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / n,
+            "n_gpus": world, "steps": steps_done, "warmup": warm, "ms_per_step": 1e3 * elapsed / max(1, steps_done),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%d synthetic reads x %d bp, genome %d bp (20x), error %.3g, k=%d, overlap rounds "
                                    "(BASELINE config 2)" % (N, L, G, args.error, args.k),
                        "reads": N, "read_len": L, "k": args.k, "seed_batch_size": args.seed_batch_size,
-                       "parallelism": "scan sharded by read over %d GPU(s), survivors all-gathered" % world},
+                       "parallelism": ("single GPU" if world == 1 else
+                                       "round-parallel over %d GPUs: rank r executes round base+r speculatively, results all-gathered "
+                                       "(RCCL) and committed in order" % world if args.mode == "round" else
+                                       "scan sharded by read over %d GPUs, survivors all-gathered (RCCL)" % world)},
             "roofline": {"bound": "hbm", "kernel": "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": count_bytes, "launch_ms": count_ms},
             "paf_lines": lines, "rounds_per_s": steps_done / elapsed if elapsed > 0 else 0.0,
-            "reads_scanned_per_s": acc.get("scan_items", 0.0) / elapsed if elapsed > 0 else 0.0,
+            "reads_scanned_per_s": (acc.get("scan_items", 0.0) / n) * steps_done / elapsed if elapsed > 0 else 0.0,
             "phase_ms_per_step": {kk: 1e3 * acc.get(kk, 0.0) / n for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
             "kernel_ms_per_step": {kk: acc.get(kk, 0.0) / n for kk in ("k_count_ms", "k_write_ms", "k_scan_ms", "k_query_ms", "k_chain_ms")},
             "index_query": {"bytes_per_step": acc.get("query_bytes", 0.0) / n,
