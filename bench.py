@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--seed-batch-size", type=int, default=10000)
     ap.add_argument("--cpu-rounds", type=int, default=2, help="oracle rounds timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--slots", type=int, default=4, help="rounds executed concurrently per GPU (executor slots)")
     ap.add_argument("--mode", default="round", choices=["round", "scan-shard"], help="multi-GPU decomposition (N > 1)")
     args = ap.parse_args()
 
@@ -70,7 +71,7 @@ def main():
     t_gen = time.time() - t0
     t0 = time.time()
     pipe = OverlapPipeline(reads, device=local_rank, k=args.k, seed_batch_size=args.seed_batch_size, rank=rank, world=world,
-                           torch_device=torch_device, mode=args.mode)
+                           torch_device=torch_device, mode=args.mode, slots=args.slots)
     t_setup = time.time() - t0
 
     def sync():
@@ -126,7 +127,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%d synthetic reads x %d bp, genome %d bp (20x), error %.3g, k=%d, overlap rounds "
                                    "(BASELINE config 2)" % (N, L, G, args.error, args.k),
-                       "reads": N, "read_len": L, "k": args.k, "seed_batch_size": args.seed_batch_size,
+                       "reads": N, "read_len": L, "k": args.k, "seed_batch_size": args.seed_batch_size, "executor_slots_per_gpu": args.slots,
                        "parallelism": ("single GPU" if world == 1 else
                                        "round-parallel over %d GPUs: rank r executes round base+r speculatively, results all-gathered "
                                        "(RCCL) and committed in order" % world if args.mode == "round" else

@@ -25,6 +25,7 @@ struct dp_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string err;
+    bool borrowed_reads = false;  // d_packed/d_boff/d_len belong to another context
 
     // ---- reads (A1)
     uint32_t n_reads = 0;

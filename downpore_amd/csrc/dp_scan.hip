@@ -21,10 +21,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "dp_common.h"
 
 static std::string g_create_err;
+// The scan kernels are persistent and fill every CU: two of them running at once (several contexts on one device) only
+// slow each other down, so the device part of dp_scan is serialised per process.
+static std::mutex g_scan_mu;
 
 int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e) {
     std::string s = what;
@@ -90,10 +94,28 @@ extern "C" int dp_ctx_create(int device, dp_ctx** out) {
     return DP_OK;
 }
 
+extern "C" int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out) {
+    if (!src || !out) return DP_ERR_ARG;
+    int rc = dp_ctx_create(src->device, out);
+    if (rc != 0) return rc;
+    dp_ctx* c = *out;
+    c->borrowed_reads = true;
+    c->n_reads = src->n_reads;
+    c->total_bases = src->total_bases;
+    c->packed_bytes = src->packed_bytes;
+    c->d_packed = src->d_packed;
+    c->d_boff = src->d_boff;
+    c->d_len = src->d_len;
+    c->h_boff = src->h_boff;
+    c->h_len = src->h_len;
+    return DP_OK;
+}
+
 extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->borrowed_reads) ctx->d_packed.p = ctx->d_boff.p = ctx->d_len.p = nullptr;
     DevBuf* dbs[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len, &ctx->d_bits, &ctx->d_kmap, &ctx->d_seeds, &ctx->d_items,
                      &ctx->d_counts, &ctx->d_segoff, &ctx->d_segs, &ctx->d_total, &ctx->d_seqrefs, &ctx->d_posting,
                      &ctx->d_seedsets, &ctx->d_pmeta, &ctx->d_qsegs, &ctx->d_qoff, &ctx->d_qsets, &ctx->d_qmeta,
@@ -153,6 +175,7 @@ __global__ void pack_kernel(const uint8_t* __restrict__ ascii, const int64_t* __
 
 extern "C" int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads) {
     if (!ctx || !bases || !off) return DP_ERR_ARG;
+    if (ctx->borrowed_reads) return dp_fail(ctx, DP_ERR_STATE, "dp_reads_upload on a context that borrows its reads");
     hipSetDevice(ctx->device);
     ctx->n_reads = n_reads;
     ctx->h_boff.assign((size_t)n_reads + 1, 0);
@@ -613,6 +636,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus * (v2 ? 2 : 1), ((uint64_t)n_items + 15) / 16);
     const uint32_t dbg = getenv("DP_SCAN_DEBUG") ? (uint32_t)atoi(getenv("DP_SCAN_DEBUG")) : 0u;
+    std::unique_lock<std::mutex> scan_lock(g_scan_mu);
     DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(((dbg & 2) ? scan_kernel<0, 3> : v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
                        (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p, n_items, k,
@@ -655,6 +679,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
         DP_HIP(hipStreamSynchronize(ctx->stream));
         hipEventElapsedTime(&ms1, ctx->ev[2], ctx->ev[3]);
     }
+    scan_lock.unlock();
     ctx->n_segs = n_segs;
     out->n_seeds = (const uint32_t*)ctx->h_counts.p;
     out->seg_off = (const uint64_t*)ctx->h_segoff.p;

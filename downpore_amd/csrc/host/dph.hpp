@@ -230,7 +230,8 @@ class Overlapper {
     std::vector<int32_t> allSegs_;         // survivors' segments (host copy; device copy is what the index references)
 };
 
-unsigned hostThreads();  // DP_HOST_THREADS or hardware_concurrency (<= 32)
+unsigned hostThreads();  // DP_HOST_THREADS or hardware_concurrency, split between concurrent executor slots (<= 32 each)
+void setHostThreadShare(unsigned concurrentUsers);
 // finalCheckWorker (commands/overlap.go:197-233) over the collated matches of a round: consensus, SetIgnore, PAF text.
 struct FinalCheckStats {
     i64 badBack = 0, emptyMatch = 0;
@@ -282,13 +283,22 @@ struct RoundResult {
     RoundStats st;
 };
 
+// Per-executor state: one GPU context (stream + per-round device buffers) and the host mirror of the running round.
+struct ExecSlot {
+    dp_ctx* ctx = nullptr;
+    bool ownsCtx = false;
+    std::unique_ptr<SeedIndex> index;  // executor-side seed maps of the running round
+    std::unique_ptr<Overlapper> lap;
+    Survivors local;
+    std::string error;
+};
+
 struct OverlapRun {
     dp_ctx* ctx = nullptr;
     ReadSet* reads = nullptr;
     OverlapParams p;
     std::vector<double> values;
-    std::unique_ptr<SeedIndex> index;  // executor-side seed maps of the running round
-    std::unique_ptr<Overlapper> lap;
+    std::vector<std::unique_ptr<ExecSlot>> slots;  // slot 0 drives `ctx`; further slots use contexts that borrow its reads
     std::unique_ptr<Planner> planner;
     i64 firstSequence = 0;
     i64 round = 0;  // next round to commit
@@ -299,15 +309,20 @@ struct OverlapRun {
     std::string errText;  // stderr progress lines accumulated
     std::string error;    // failure text
     RoundStats last;
-    Survivors local;
     std::shared_ptr<const RoundPlan> curPlan;
     RoundResult cur;
     // shard of reads this process scans in scan-shard mode: [shardLo, shardHi)
     size_t shardLo = 0, shardHi = 0;
 
-    int init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const double* valuesOrNull);
-    // ---- whole round on this process: plan (prefetched) -> execute -> commit.  1 = a round ran, 0 = finished, <0 error
+    int init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const double* valuesOrNull, int nSlots = 1);
+    ~OverlapRun();
+    void shutdown();
+    Survivors& local() { return slots[0]->local; }
+    // ---- whole rounds on this process: plans (prefetched) -> execute (one round per slot, concurrently) -> commit in order.
+    // Returns the number of rounds committed, 0 = finished, <0 error
     int step();
+    // executes rounds[i] on slot i concurrently (host threads); outs[i] receives the result
+    int executeRounds(const std::vector<i64>& rounds, std::vector<RoundResult>& outs);
     // ---- scan-shard mode (survivor all-gather between the two halves)
     int roundPrepareAndScan();
     int roundFinish(const Survivors& all);
@@ -318,8 +333,9 @@ struct OverlapRun {
     int commitResults(std::vector<RoundResult>& results);
 
    private:
-    int beginRound(const RoundPlan& plan);
-    int finishRound(const Survivors& all, RoundResult& out);
+    int executeRoundOn(ExecSlot& s, i64 r, RoundResult& out);
+    int beginRound(ExecSlot& s, const RoundPlan& plan);
+    int finishRound(ExecSlot& s, const Survivors& all, RoundResult& out);
     void commitOne(RoundResult& r);
 };
 

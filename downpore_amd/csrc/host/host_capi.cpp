@@ -47,8 +47,9 @@ void dph_reads_reset_ignore(void* h) {
 }
 int64_t dph_reads_total_bases(void* h) { return (int64_t)((ReadsH*)h)->set.bases.size(); }
 
-// params: overlapSize,k,numSeeds,seedBatchSize,chunkSize,queryBatchSize,himem
+// params: overlapSize,k,numSeeds,seedBatchSize,chunkSize,queryBatchSize,himem,nSlots
 void* dph_overlap_create(void* reads, int device, const int64_t* params, double minHits, const double* valuesOrNull) {
+    const int nSlots = (int)params[7];
     OverlapH* h = new OverlapH();
     ReadSet& rs = ((ReadsH*)reads)->set;
     int rc = dp_ctx_create(device, &h->ctx);
@@ -67,7 +68,7 @@ void* dph_overlap_create(void* reads, int device, const int64_t* params, double 
     p.himem = params[6] != 0;
     p.minHits = minHits;
     rc = dp_reads_upload(h->ctx, (const uint8_t*)rs.bases.data(), rs.off.data(), (uint32_t)rs.size());
-    if (rc == 0) rc = h->run.init(h->ctx, &rs, p, valuesOrNull);
+    if (rc == 0) rc = h->run.init(h->ctx, &rs, p, valuesOrNull, nSlots);
     if (rc != 0) {
         g_err = h->run.error.empty() ? dp_last_error(h->ctx) : h->run.error;
         dp_ctx_destroy(h->ctx);
@@ -79,9 +80,7 @@ void* dph_overlap_create(void* reads, int device, const int64_t* params, double 
 void dph_overlap_destroy(void* hh) {
     OverlapH* h = (OverlapH*)hh;
     if (!h) return;
-    h->run.planner.reset();
-    h->run.lap.reset();
-    h->run.index.reset();
+    h->run.shutdown();
     dp_ctx_destroy(h->ctx);
     delete h;
 }
@@ -104,7 +103,7 @@ int dph_overlap_round_scan(void* hh) {
 }
 void dph_overlap_local(void* hh, const uint32_t** read, const uint32_t** nseeds, const uint64_t** segoff,
                        const int32_t** segs, uint64_t* n, uint64_t* nsegs) {
-    Survivors& s = ((OverlapH*)hh)->run.local;
+    Survivors& s = ((OverlapH*)hh)->run.local();
     *read = s.read.data();
     *nseeds = s.n_seeds.data();
     *segoff = s.seg_off.data();
@@ -117,7 +116,7 @@ int dph_overlap_round_finish(void* hh, const uint32_t* read, const uint32_t* nse
     OverlapH* h = (OverlapH*)hh;
     int rc;
     if (!read) {
-        rc = h->run.roundFinish(h->run.local);
+        rc = h->run.roundFinish(h->run.local());
     } else {
         Survivors all;
         all.read.assign(read, read + n);
@@ -178,35 +177,49 @@ int64_t dph_overlap_round(void* hh) { return ((OverlapH*)hh)->run.round; }
 // ---- round-parallel mode: a rank executes ONE round speculatively and serialises the result; every rank then commits
 // the gathered results in round order with the speculation check (OverlapRun::commitResults).
 static void putv(std::string& b, const void* p, size_t n) { b.append((const char*)p, n); }
-const uint8_t* dph_overlap_exec_round(void* hh, int64_t r, uint64_t* n) {
+static void serialise(const RoundResult& res, std::string& blob) {
+    int64_t hdr[16] = {res.round, res.empty ? 1 : 0, res.firstIn, res.firstOut, res.numQuerySeqs, (int64_t)res.ignores.size(),
+                       (int64_t)res.indexedReads.size(), (int64_t)res.paf.size(), res.fs.badBack, res.fs.emptyMatch,
+                       (int64_t)res.fs.lines, (int64_t)res.fs.hits, (int64_t)res.fs.qHits, 0, 0, 0};
+    int64_t total = (int64_t)(sizeof hdr + sizeof(RoundStats) + res.ignores.size() * sizeof(int) + res.indexedReads.size() * 4 +
+                              res.paf.size());
+    hdr[13] = total;
+    putv(blob, hdr, sizeof hdr);
+    putv(blob, &res.st, sizeof(RoundStats));
+    putv(blob, res.ignores.data(), res.ignores.size() * sizeof(int));
+    putv(blob, res.indexedReads.data(), res.indexedReads.size() * 4);
+    putv(blob, res.paf.data(), res.paf.size());
+}
+// Executes rounds first, first+1, ... (one per executor slot of this process, concurrently) and returns their
+// serialised results back to back (each record carries its own length in hdr[13]).
+const uint8_t* dph_overlap_exec_round(void* hh, int64_t first, uint64_t* n) {
     OverlapH* h = (OverlapH*)hh;
     static thread_local std::string blob;
-    RoundResult res;
-    int rc = h->run.executeRound(r, res);
+    std::vector<i64> rounds;
+    for (size_t i = 0; i < h->run.slots.size(); i++) rounds.push_back(first + (i64)i);
+    std::vector<RoundResult> outs;
+    int rc = h->run.executeRounds(rounds, outs);
     if (rc < 0) {
         h->err = h->run.error;
         *n = 0;
         return nullptr;
     }
     blob.clear();
-    int64_t hdr[16] = {res.round, res.empty ? 1 : 0, res.firstIn, res.firstOut, res.numQuerySeqs, (int64_t)res.ignores.size(),
-                       (int64_t)res.indexedReads.size(), (int64_t)res.paf.size(), res.fs.badBack, res.fs.emptyMatch,
-                       (int64_t)res.fs.lines, (int64_t)res.fs.hits, (int64_t)res.fs.qHits, 0, 0, 0};
-    putv(blob, hdr, sizeof hdr);
-    putv(blob, &res.st, sizeof(RoundStats));
-    putv(blob, res.ignores.data(), res.ignores.size() * sizeof(int));
-    putv(blob, res.indexedReads.data(), res.indexedReads.size() * 4);
-    putv(blob, res.paf.data(), res.paf.size());
+    for (const RoundResult& r : outs) serialise(r, blob);
     *n = blob.size();
     return (const uint8_t*)blob.data();
 }
+int dph_overlap_slots(void* hh) { return (int)((OverlapH*)hh)->run.slots.size(); }
 // blobs: concatenation; sizes[i] bytes each.  Returns the number of rounds committed (0..count) or <0.
 int dph_overlap_commit_blobs(void* hh, const uint8_t* blobs, const uint64_t* sizes, int count) {
     OverlapH* h = (OverlapH*)hh;
     std::vector<RoundResult> rs;
-    const uint8_t* p = blobs;
-    for (int i = 0; i < count; i++) {
-        const uint8_t* q = p;
+    uint64_t totalBytes = 0;
+    for (int i = 0; i < count; i++) totalBytes += sizes[i];
+    const uint8_t* q = blobs;
+    const uint8_t* end = blobs + totalBytes;
+    while (q < end) {
+        const uint8_t* rec = q;
         int64_t hdr[16];
         memcpy(hdr, q, sizeof hdr);
         q += sizeof hdr;
@@ -229,7 +242,7 @@ int dph_overlap_commit_blobs(void* hh, const uint8_t* blobs, const uint64_t* siz
         r.fs.hits = (uint64_t)hdr[11];
         r.fs.qHits = (uint64_t)hdr[12];
         rs.push_back(std::move(r));
-        p += sizes[i];
+        q = rec + hdr[13];
     }
     std::sort(rs.begin(), rs.end(), [](const RoundResult& a, const RoundResult& b) { return a.round < b.round; });
     int c = h->run.commitResults(rs);

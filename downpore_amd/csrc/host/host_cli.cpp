@@ -49,7 +49,8 @@ static int runOverlap(ArgTable& t) {
     }
     int rc = dp_reads_upload(ctx, (const uint8_t*)reads.bases.data(), reads.off.data(), (uint32_t)reads.size());
     OverlapRun run;
-    if (rc == 0) rc = run.init(ctx, &reads, p, nullptr);
+    const char* ns = getenv("DP_EXEC_SLOTS");
+    if (rc == 0) rc = run.init(ctx, &reads, p, nullptr, ns ? atoi(ns) : 4);
     if (rc != 0) {
         fprintf(stderr, "downpore: %s\n", run.error.empty() ? dp_last_error(ctx) : run.error.c_str());
         return 2;
@@ -69,9 +70,7 @@ static int runOverlap(ArgTable& t) {
     fwrite(run.errText.data() + shown, 1, run.errText.size() - shown, stderr);
     fprintf(stderr, "[downpore_amd] rounds=%lld bad_back_suppressed=%lld empty_match_panics_avoided=%lld\n", (long long)run.round,
             (long long)run.badBack, (long long)run.emptyMatch);
-    run.planner.reset();
-    run.lap.reset();
-    run.index.reset();
+    run.shutdown();
     dp_ctx_destroy(ctx);
     return 0;
 }

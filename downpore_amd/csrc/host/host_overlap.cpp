@@ -436,14 +436,18 @@ void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vecto
     fs.qHits = (uint64_t)qHits;
 }
 
+static std::atomic<unsigned> g_threadShare(1);
+void setHostThreadShare(unsigned concurrentUsers) { g_threadShare = std::max(1u, concurrentUsers); }
 unsigned hostThreads() {
     static unsigned n = [] {
         const char* e = getenv("DP_HOST_THREADS");
         unsigned v = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
         if (v == 0) v = 1;
-        return std::min(v, 32u);
+        return std::min(v, 64u);
     }();
-    return n;
+    // several executor slots run finalCheck at the same time: split the cores between them
+    unsigned share = std::max(2u, n / g_threadShare.load());
+    return std::min(share, 32u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -619,7 +623,20 @@ void Planner::dropBefore(i64 round) {
 // ---------------------------------------------------------------------------------------------------------------
 // commands/overlap.go Run :96-195
 
-int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const double* valuesOrNull) {
+OverlapRun::~OverlapRun() { shutdown(); }
+
+void OverlapRun::shutdown() {
+    planner.reset();
+    for (auto& sl : slots) {
+        sl->lap.reset();
+        sl->index.reset();
+        if (sl->ownsCtx && sl->ctx) dp_ctx_destroy(sl->ctx);
+        sl->ctx = nullptr;
+    }
+    slots.clear();
+}
+
+int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const double* valuesOrNull, int nSlots) {
     ctx = c;
     reads = r;
     p = params;
@@ -639,7 +656,23 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         values = kmerValuesFromCounts(counts, p.k);
     }
     errText += "Counting complete. Starting indexing and querying...";
-    index.reset(new SeedIndex(p.k));
+    slots.clear();
+    setHostThreadShare((unsigned)std::max(1, nSlots));
+    for (int i = 0; i < std::max(1, nSlots); i++) {
+        std::unique_ptr<ExecSlot> sl(new ExecSlot());
+        if (i == 0) {
+            sl->ctx = ctx;
+        } else {
+            int rc = dp_ctx_create_shared(ctx, &sl->ctx);
+            if (rc != 0) {
+                error = dp_last_error(nullptr);
+                return rc;
+            }
+            sl->ownsCtx = true;
+        }
+        sl->index.reset(new SeedIndex(p.k));
+        slots.push_back(std::move(sl));
+    }
     const char* nothread = getenv("DP_NO_PLANNER_THREAD");
     planner.reset(new Planner(*reads, p, values.data(), !(nothread && nothread[0] == '1')));
     firstSequence = 0;
@@ -651,42 +684,42 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
 }
 
 // seeds.NewSeedIndex + the plan's seeds on host and device; queries are built after the scan
-int OverlapRun::beginRound(const RoundPlan& plan) {
-    index->reset();  // seeds.NewSeedIndex(k) per round (:125) — sparse reset instead of reallocating 4^k tables
-    for (uint32_t km : plan.seedMap) index->addSeedKmer(km);
-    lap.reset(new Overlapper(ctx, *reads, *index, p.chunkSize, p.numWorkers, p.overlapSize, p.numSeeds, p.minHits));
-    lap->setWindows(plan.windows);
-    int rc = dp_round_begin(ctx, p.k, index->seedMap.data(), (uint32_t)index->seedMap.size());
+int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
+    sl.index->reset();  // seeds.NewSeedIndex(k) per round (:125) — sparse reset instead of reallocating 4^k tables
+    for (uint32_t km : plan.seedMap) sl.index->addSeedKmer(km);
+    sl.lap.reset(new Overlapper(sl.ctx, *reads, *sl.index, p.chunkSize, p.numWorkers, p.overlapSize, p.numSeeds, p.minHits));
+    sl.lap->setWindows(plan.windows);
+    int rc = dp_round_begin(sl.ctx, p.k, sl.index->seedMap.data(), (uint32_t)sl.index->seedMap.size());
     if (rc != 0) {
-        error = dp_last_error(ctx);
+        sl.error = dp_last_error(sl.ctx);
         return rc;
     }
     return 0;
 }
 
-int OverlapRun::finishRound(const Survivors& all, RoundResult& out) {
+int OverlapRun::finishRound(ExecSlot& sl, const Survivors& all, RoundResult& out) {
     RoundStats& st = out.st;
     double t0 = now();
-    int rc = lap->IndexSurvivors(all, st);
+    int rc = sl.lap->IndexSurvivors(all, st);
     if (rc != 0) {
-        error = lap->err;
+        sl.error = sl.lap->err;
         return rc;
     }
     out.indexedReads = all.read;
     out.numQuerySeqs = 0;
-    for (const SeedQuery& q : lap->queries)
+    for (const SeedQuery& q : sl.lap->queries)
         if (q.ID >= out.numQuerySeqs) out.numQuerySeqs = q.ID + 1;
     double t1 = now();
     st.t_index = t1 - t0;
     std::vector<std::unique_ptr<SeedMatch>> matches;
-    rc = lap->FindOverlaps(matches, st);
+    rc = sl.lap->FindOverlaps(matches, st);
     if (rc != 0) {
-        error = lap->err;
+        sl.error = sl.lap->err;
         return rc;
     }
     double t2 = now();
     st.t_query = t2 - t1;
-    finalCheck(index->arena, *index, *reads, matches, out.numQuerySeqs, p.overlapSize, out.paf, out.fs, &out.ignores);
+    finalCheck(sl.index->arena, *sl.index, *reads, matches, out.numQuerySeqs, p.overlapSize, out.paf, out.fs, &out.ignores);
     st.n_paf = out.fs.lines;
     st.t_consensus = now() - t2;
     const int k = p.k;
@@ -696,7 +729,7 @@ int OverlapRun::finishRound(const Survivors& all, RoundResult& out) {
     return 0;
 }
 
-int OverlapRun::executeRound(i64 r, RoundResult& out) {
+int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     out = RoundResult();
     out.round = r;
     double t0 = now();
@@ -709,18 +742,43 @@ int OverlapRun::executeRound(i64 r, RoundResult& out) {
     out.empty = false;
     out.firstIn = plan->firstIn;
     out.firstOut = plan->firstOut;
-    int rc = beginRound(*plan);
+    int rc = beginRound(sl, *plan);
     if (rc) return rc;
     out.st.n_seeds = plan->seedMap.size();
     double t1 = now();
     out.st.t_prepare = t1 - t0;
-    rc = lap->ScanLocal(0, reads->size(), local, out.st);
+    rc = sl.lap->ScanLocal(0, reads->size(), sl.local, out.st);
     if (rc != 0) {
-        error = lap->err;
+        sl.error = sl.lap->err;
         return rc;
     }
     out.st.t_scan = now() - t1;
-    return finishRound(local, out);
+    return finishRound(sl, sl.local, out);
+}
+
+int OverlapRun::executeRound(i64 r, RoundResult& out) {
+    int rc = executeRoundOn(*slots[0], r, out);
+    if (rc) error = slots[0]->error;
+    return rc;
+}
+
+int OverlapRun::executeRounds(const std::vector<i64>& rounds, std::vector<RoundResult>& outs) {
+    const size_t n = std::min(rounds.size(), slots.size());
+    outs.assign(n, RoundResult());
+    std::vector<int> rcs(n, 0);
+    if (n == 1) {
+        rcs[0] = executeRoundOn(*slots[0], rounds[0], outs[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < n; i++) th.emplace_back([&, i] { rcs[i] = executeRoundOn(*slots[i], rounds[i], outs[i]); });
+        for (auto& t : th) t.join();
+    }
+    for (size_t i = 0; i < n; i++)
+        if (rcs[i]) {
+            error = slots[i]->error;
+            return rcs[i];
+        }
+    return 0;
 }
 
 void OverlapRun::commitOne(RoundResult& r) {
@@ -792,15 +850,12 @@ int OverlapRun::commitResults(std::vector<RoundResult>& results) {
 
 int OverlapRun::step() {
     if (done) return 0;
-    int rc = executeRound(round, cur);
+    std::vector<i64> rounds;
+    for (size_t i = 0; i < slots.size(); i++) rounds.push_back(round + (i64)i);
+    std::vector<RoundResult> outs;
+    int rc = executeRounds(rounds, outs);
     if (rc < 0) return rc;
-    if (cur.empty) {
-        done = true;
-        return 0;
-    }
-    paf.clear();
-    commitOne(cur);
-    return 1;
+    return commitResults(outs);
 }
 
 // ---- scan-shard mode: plan + local scan, then (after the survivor exchange) the rest of the round
@@ -817,14 +872,18 @@ int OverlapRun::roundPrepareAndScan() {
     cur.empty = false;
     cur.firstIn = curPlan->firstIn;
     cur.firstOut = curPlan->firstOut;
-    int rc = beginRound(*curPlan);
-    if (rc) return rc;
+    ExecSlot& sl = *slots[0];
+    int rc = beginRound(sl, *curPlan);
+    if (rc) {
+        error = sl.error;
+        return rc;
+    }
     cur.st.n_seeds = curPlan->seedMap.size();
     double t1 = now();
     cur.st.t_prepare = t1 - t0;
-    rc = lap->ScanLocal(shardLo, shardHi, local, cur.st);
+    rc = sl.lap->ScanLocal(shardLo, shardHi, sl.local, cur.st);
     if (rc != 0) {
-        error = lap->err;
+        error = sl.lap->err;
         return rc;
     }
     cur.st.t_scan = now() - t1;
@@ -832,8 +891,11 @@ int OverlapRun::roundPrepareAndScan() {
 }
 
 int OverlapRun::roundFinish(const Survivors& all) {
-    int rc = finishRound(all, cur);
-    if (rc) return rc;
+    int rc = finishRound(*slots[0], all, cur);
+    if (rc) {
+        error = slots[0]->error;
+        return rc;
+    }
     paf.clear();
     commitOne(cur);
     return 0;

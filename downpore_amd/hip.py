@@ -35,7 +35,7 @@ class ChainBatch(C.Structure):
 
 
 #: every entry point include/downpore_hip.h declares (checked by the CPU-side symbol test)
-SYMBOLS = ["dp_version", "dp_ctx_create", "dp_ctx_destroy", "dp_last_error", "dp_reads_upload", "dp_reads_packed",
+SYMBOLS = ["dp_version", "dp_ctx_create", "dp_ctx_create_shared", "dp_ctx_destroy", "dp_last_error", "dp_reads_upload", "dp_reads_packed",
            "dp_reads_count", "dp_reads_total_bases", "dp_kmer_histogram", "dp_round_begin", "dp_scan", "dp_index_build",
            "dp_find_overlaps", "dp_map_windows", "dp_index_posting_row", "dp_index_seedset_row", "dp_scan_device_buffers",
            "dp_scan_import_segments"]
@@ -58,6 +58,7 @@ def load_library():
     L.dp_last_error.restype = C.c_char_p
     L.dp_last_error.argtypes = [vp]
     L.dp_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.dp_ctx_create_shared.argtypes = [vp, C.POINTER(vp)]
     L.dp_ctx_destroy.argtypes = [vp]
     L.dp_reads_upload.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_uint32]
     L.dp_reads_packed.argtypes = [vp, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]

@@ -162,13 +162,18 @@ class OverlapPipeline:
 
     def __init__(self, reads, device=0, k=10, overlap_size=1000, num_seeds=15, seed_batch_size=10000, chunk_size=10000,
                  query_batch_size=20000, min_hits=0.25, himem=True, values=None, rank=0, world=1, torch_device=None,
-                 mode="round"):
+                 mode="round", slots=1):
         """mode (world > 1): "round" = round-parallel (rank r executes round base+r speculatively, results are
         all-gathered and committed in order with a speculation check); "scan-shard" = every rank runs every round, the
-        scan is sharded by read and the survivors are all-gathered."""
+        scan is sharded by read and the survivors are all-gathered.
+        slots: executor slots of this process = rounds it runs concurrently on its GPU (each slot has its own stream and
+        per-round buffers; the resident reads are shared)."""
         self.H = load_host()
-        p = np.array([overlap_size, k, num_seeds, seed_batch_size, chunk_size, query_batch_size, 1 if himem else 0],
+        if mode == "scan-shard" and world > 1:
+            slots = 1
+        p = np.array([overlap_size, k, num_seeds, seed_batch_size, chunk_size, query_batch_size, 1 if himem else 0, slots],
                      dtype=np.int64)
+        self.slots = slots
         vptr = values.ctypes.data if values is not None else None
         self._values_keepalive = values
         self.h = self.H.dph_overlap_create(reads.h, device, p.ctypes.data, float(min_hits), vptr)
@@ -225,7 +230,7 @@ class OverlapPipeline:
                 return 0
             base = self.H.dph_overlap_round(self.h)
             n = C.c_uint64(0)
-            p = self.H.dph_overlap_exec_round(self.h, base + self.rank, C.byref(n))
+            p = self.H.dph_overlap_exec_round(self.h, base + self.rank * self.slots, C.byref(n))
             if not p:
                 raise self._err()
             blobs = allgather_bytes(C.string_at(p, n.value), self.world, self.torch_device)
@@ -258,6 +263,7 @@ class OverlapPipeline:
         return bool(self.H.dph_overlap_done(self.h))
 
     def exec_round_blob(self, rnd):
+        """Executes rounds rnd .. rnd+slots-1 concurrently on this process's slots; returns their serialised results."""
         n = C.c_uint64(0)
         p = self.H.dph_overlap_exec_round(self.h, rnd, C.byref(n))
         if not p:

@@ -44,6 +44,9 @@ const char* dp_version(void);
 /* Create a context on HIP device `device`.  Fails (DP_ERR_NODEVICE) when no GPU is present: there is no CPU
  * fallback. */
 int dp_ctx_create(int device, dp_ctx** out);
+/* A second context on the same device that BORROWS the resident reads of `src` (no copy): lets several host threads
+ * drive independent rounds concurrently, each with its own stream and per-round state.  Destroy it before `src`. */
+int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out);
 void dp_ctx_destroy(dp_ctx* ctx);
 const char* dp_last_error(const dp_ctx* ctx); /* ctx may be NULL: error of the last failed dp_ctx_create */
 

@@ -23,18 +23,22 @@ def first_diff(a, b):
     return "line counts differ: got %d want %d" % (len(la), len(lb))
 
 
-def _run_both(seed, G, N, L, k, e=0.0, variable=False, himem=True, max_rounds=-1, **kw):
+def _run_both(seed, G, N, L, k, e=0.0, variable=False, himem=True, max_rounds=-1, slots=1, **kw):
     from downpore_amd.overlap import OverlapPipeline, Reads
     bases, off = O.gen_reads(seed, G, N, L, e, variable)
     rs = O.ReadSet(bases, off, min_len=kw.get("overlap_size", 1000), himem=himem)
     orun = O.OverlapRun(rs, k=k, himem=himem, max_rounds=max_rounds, traces=True, **kw)
     reads = Reads(bases, off, min_len=kw.get("overlap_size", 1000), himem=himem)
-    pipe = OverlapPipeline(reads, k=k, himem=himem, **kw)
+    pipe = OverlapPipeline(reads, k=k, himem=himem, slots=slots, **kw)
     rounds = 0
-    while (max_rounds < 0 or rounds < max_rounds) and pipe.step():
-        d = first_diff(pipe.round_paf(), orun.trace_paf(rounds))
-        assert d is None, "PAF differs in round %d: %s" % (rounds, d)
-        rounds += 1
+    while max_rounds < 0 or rounds < max_rounds:
+        c = pipe.step()
+        if c == 0:
+            break
+        want = "".join(orun.trace_paf(r) for r in range(rounds, min(rounds + c, orun.rounds)))
+        d = first_diff(pipe.round_paf(), want)
+        assert d is None, "PAF differs in rounds %d..%d: %s" % (rounds, rounds + c - 1, d)
+        rounds += c
     assert rounds == orun.rounds
     assert first_diff(pipe.all_paf(), orun.paf) is None
     assert np.array_equal(reads.ignore(), rs.ignore())
@@ -51,10 +55,18 @@ def test_overlap_paf_bit_exact(k, G, N, L, e, variable):
     assert orun.paf.count("\n") > 0
 
 
-def test_overlap_full_run_config1_k10():
-    """BASELINE config 1 shape (1k reads x 5 kb) at the command's default k=10, all rounds."""
-    orun, st = _run_both(1, 250000, 1000, 5000, 10)
+@pytest.mark.parametrize("slots", [1, 4])
+def test_overlap_full_run_config1_k10(slots):
+    """BASELINE config 1 shape (1k reads x 5 kb) at the command's default k=10, all rounds; with 4 executor slots the
+    rounds run concurrently (speculating on ignore flags) and are committed in order."""
+    orun, st = _run_both(1, 250000, 1000, 5000, 10, slots=slots)
     assert orun.rounds >= 5
+
+
+def test_overlap_slots_with_ignores():
+    """Short reads get flagged as ignored by earlier rounds: concurrent slots must discard invalidated speculation."""
+    orun, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
+    assert orun.rounds >= 2
 
 
 def test_overlap_himem_false_top_level_reads():
