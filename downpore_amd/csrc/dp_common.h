@@ -51,6 +51,12 @@ struct dp_ctx {
     PinBuf h_counts, h_segoff, h_segs, h_total;
     uint64_t n_segs = 0;
     uint32_t scan_items = 0;
+    DevBuf d_ignore, d_surv;          // dp_scan_reads: ignore mask; compacted survivor lists
+    PinBuf h_surv;
+    uint64_t ignore_epoch = ~0ull;
+    uint64_t cached_bases = 0;
+    uint32_t cached_reads = 0, cached_lo = 0, cached_hi = 0;
+    int cached_top = -1, cached_k = 0;
 
     // ---- index (A13)
     uint32_t n_seqs = 0, W = 0, SW = 0;

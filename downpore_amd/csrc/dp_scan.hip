@@ -119,11 +119,11 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     DevBuf* dbs[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len, &ctx->d_bits, &ctx->d_kmap, &ctx->d_seeds, &ctx->d_items,
                      &ctx->d_counts, &ctx->d_segoff, &ctx->d_segs, &ctx->d_total, &ctx->d_seqrefs, &ctx->d_posting,
                      &ctx->d_seedsets, &ctx->d_pmeta, &ctx->d_qsegs, &ctx->d_qoff, &ctx->d_qsets, &ctx->d_qmeta,
-                     &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched};
+                     &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched, &ctx->d_ignore, &ctx->d_surv};
     for (auto* b : dbs)
         if (b->p) hipFree(b->p);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
-                     &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff};
+                     &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv};
     for (auto* b : pbs)
         if (b->p) hipHostFree(b->p);
     for (auto& ev : ctx->ev)
@@ -683,6 +683,199 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     ctx->n_segs = n_segs;
     out->n_seeds = (const uint32_t*)ctx->h_counts.p;
     out->seg_off = (const uint64_t*)ctx->h_segoff.p;
+    out->segs = (const int32_t*)ctx->h_segs.p;
+    out->n_segs = n_segs;
+    out->kernel_ms = (double)ms0 + (double)msoff + (double)ms1;
+    out->count_kernel_ms = ms0;
+    out->write_kernel_ms = ms1;
+    return DP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// dp_scan_reads: items generated and survivors compacted on the device
+
+__global__ void make_read_items_kernel(const uint32_t* __restrict__ len, const uint8_t* __restrict__ ignore, uint32_t lo,
+                                       uint32_t hi, int k, int top_level, uint32_t min_seeds, dp_scan_item* __restrict__ items) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lo + i >= hi) return;
+    const uint32_t r = lo + i;
+    const uint32_t L = len[r];
+    int64_t n = (int64_t)L - k + 1;
+    if (top_level && (L & 3u) == 0) n -= 4;  // top-level sequence with finalLen == 0 (asm:88-96)
+    if (n < 0) n = 0;
+    dp_scan_item it;
+    it.read = r;
+    it.start = 0;
+    if (ignore[r]) {
+        it.n_kmers = 0;
+        it.min_seeds = 0xffffffffu;  // never a survivor
+    } else {
+        it.n_kmers = (uint32_t)n;
+        it.min_seeds = min_seeds;
+    }
+    items[i] = it;
+}
+
+// tile sums / compaction of the survivor FLAG (count >= min_seeds), same tiling as the offsets scan
+__global__ __launch_bounds__(OFF_TILE) void flag_tile_sums(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ counts,
+                                                          uint32_t n, uint64_t* __restrict__ tile_sum) {
+    __shared__ uint32_t sh[16];
+    const uint32_t i = blockIdx.x * OFF_TILE + threadIdx.x;
+    uint32_t v = (i < n && counts[i] >= items[i].min_seeds) ? 1u : 0u;
+    uint32_t x = block_incl_scan_1024(v, sh);
+    if (threadIdx.x == OFF_TILE - 1) tile_sum[blockIdx.x] = x;
+}
+__global__ __launch_bounds__(OFF_TILE) void compact_write(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ counts,
+                                                         uint32_t n, const uint64_t* __restrict__ tile_base,
+                                                         const uint64_t* __restrict__ segoff, uint32_t* __restrict__ s_item,
+                                                         uint32_t* __restrict__ s_count, uint64_t* __restrict__ s_off) {
+    __shared__ uint32_t sh[16];
+    const uint32_t i = blockIdx.x * OFF_TILE + threadIdx.x;
+    uint32_t v = (i < n && counts[i] >= items[i].min_seeds) ? 1u : 0u;
+    uint32_t x = block_incl_scan_1024(v, sh);
+    if (v) {
+        const uint64_t slot = tile_base[blockIdx.x] + (uint64_t)(x - 1);
+        s_item[slot] = i;
+        s_count[slot] = counts[i];
+        s_off[slot] = segoff[i];
+    }
+}
+
+extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
+                             uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out) {
+    if (!ctx || !out || !ignore || lo > hi || hi > ctx->n_reads || (n_extra && !extra)) return DP_ERR_ARG;
+    if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_scan_reads before dp_round_begin");
+    hipSetDevice(ctx->device);
+    memset(out, 0, sizeof(*out));
+    const int k = ctx->k;
+    const uint32_t n_read_items = hi - lo, n_items = n_read_items + n_extra;
+    for (uint32_t i = 0; i < n_extra; i++) {
+        const dp_scan_item& it = extra[i];
+        if (it.read >= ctx->n_reads) return dp_fail(ctx, DP_ERR_ARG, "scan item: read index out of range");
+        if ((uint64_t)it.start + it.n_kmers + (it.n_kmers ? k - 1 : 0) > ctx->h_len[it.read])
+            return dp_fail(ctx, DP_ERR_ARG, "scan item: k-mer range exceeds the read");
+    }
+    // bases examined over the non-ignored reads: recomputed only when the flags (epoch) or the range change
+    if (ctx->ignore_epoch != ignore_epoch || ctx->cached_lo != lo || ctx->cached_hi != hi || ctx->cached_top != top_level ||
+        ctx->cached_k != k) {
+        uint64_t b = 0;
+        uint32_t nr = 0;
+        for (uint32_t r = lo; r < hi; r++) {
+            if (ignore[r]) continue;
+            int64_t n = (int64_t)ctx->h_len[r] - k + 1;
+            if (top_level && (ctx->h_len[r] & 3u) == 0) n -= 4;
+            if (n > 0) b += (uint64_t)n + k - 1;
+            nr++;
+        }
+        ctx->cached_bases = b;
+        ctx->cached_reads = nr;
+        if (dev_reserve(ctx, ctx->d_ignore, (size_t)ctx->n_reads + 16)) return DP_ERR_HIP;
+        DP_HIP(hipMemcpyAsync(ctx->d_ignore.p, ignore, ctx->n_reads, hipMemcpyHostToDevice, ctx->stream));
+        ctx->ignore_epoch = ignore_epoch;
+        ctx->cached_lo = lo;
+        ctx->cached_hi = hi;
+        ctx->cached_top = top_level;
+        ctx->cached_k = k;
+    }
+    uint64_t bases = ctx->cached_bases;
+    for (uint32_t i = 0; i < n_extra; i++) bases += extra[i].n_kmers ? (uint64_t)extra[i].n_kmers + k - 1 : 0;
+    out->bases_scanned = bases;
+    out->reads_scanned = ctx->cached_reads;
+    out->n_extra = n_extra;
+    ctx->scan_items = n_items;
+    if (pin_reserve(ctx, ctx->h_total, 32)) return DP_ERR_HIP;
+    if (n_items == 0) {
+        ctx->n_segs = 0;
+        return DP_OK;
+    }
+    const uint32_t n_tiles = (n_items + OFF_TILE - 1) / OFF_TILE;
+    if (dev_reserve(ctx, ctx->d_items, (size_t)n_items * sizeof(dp_scan_item) + 16)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_counts, (size_t)n_items * 4 + 16)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_segoff, ((size_t)n_items + 1) * 8)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_total, 64 + ((size_t)n_tiles + 2) * 16)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_surv, (size_t)n_items * 16 + 64)) return DP_ERR_HIP;
+    dp_scan_item* d_items = (dp_scan_item*)ctx->d_items.p;
+    if (n_read_items)
+        hipLaunchKernelGGL(make_read_items_kernel, dim3((n_read_items + 255) / 256), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)ctx->d_len.p, (const uint8_t*)ctx->d_ignore.p, lo, hi, k, top_level, min_seeds, d_items);
+    if (n_extra)
+        DP_HIP(hipMemcpyAsync(d_items + n_read_items, extra, (size_t)n_extra * sizeof(dp_scan_item), hipMemcpyHostToDevice, ctx->stream));
+    int dev_cus = 256;
+    hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus * (v2 ? 2 : 1), ((uint64_t)n_items + 15) / 16);
+    uint64_t* totals = (uint64_t*)ctx->d_total.p;  // [0] n_segs, [1] n_survivors
+    uint64_t* tilesA = totals + 4;
+    uint64_t* tilesB = tilesA + n_tiles + 1;
+    uint32_t* s_item = (uint32_t*)ctx->d_surv.p;
+    uint32_t* s_count = s_item + n_items;
+    uint64_t* s_off = (uint64_t*)(s_count + n_items + (n_items & 1));
+    std::unique_lock<std::mutex> scan_lock(g_scan_mu);
+    DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL((v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
+                       (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)d_items, n_items, k,
+                       (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
+                       (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr, 0u);
+    DP_HIP(hipGetLastError());
+    DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    hipLaunchKernelGGL(offsets_tile_sums, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
+                       (const uint32_t*)ctx->d_counts.p, n_items, tilesA);
+    hipLaunchKernelGGL(offsets_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tilesA, n_tiles, totals, (uint64_t*)ctx->d_segoff.p, n_items);
+    hipLaunchKernelGGL(offsets_write, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
+                       (const uint32_t*)ctx->d_counts.p, n_items, (const uint64_t*)tilesA, (uint64_t*)ctx->d_segoff.p);
+    hipLaunchKernelGGL(flag_tile_sums, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
+                       (const uint32_t*)ctx->d_counts.p, n_items, tilesB);
+    hipLaunchKernelGGL(offsets_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tilesB, n_tiles, totals + 1, tilesB + n_tiles, 0u);
+    hipLaunchKernelGGL(compact_write, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
+                       (const uint32_t*)ctx->d_counts.p, n_items, (const uint64_t*)tilesB, (const uint64_t*)ctx->d_segoff.p, s_item,
+                       s_count, s_off);
+    DP_HIP(hipGetLastError());
+    DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->h_total.p, totals, 16, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t n_segs = ((uint64_t*)ctx->h_total.p)[0];
+    const uint64_t n_surv_all = ((uint64_t*)ctx->h_total.p)[1];  // surviving reads + all extra items
+    if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_surv, n_surv_all * 16 + 64)) return DP_ERR_HIP;
+    float ms0 = 0, ms1 = 0, msoff = 0;
+    hipEventElapsedTime(&ms0, ctx->ev[0], ctx->ev[1]);
+    hipEventElapsedTime(&msoff, ctx->ev[1], ctx->ev[4]);
+    uint32_t* h_item = (uint32_t*)ctx->h_surv.p;
+    uint32_t* h_count = h_item + n_surv_all;
+    uint64_t* h_off = (uint64_t*)(h_count + n_surv_all + (n_surv_all & 1));
+    if (n_surv_all) {
+        DP_HIP(hipMemcpyAsync(h_item, s_item, n_surv_all * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipMemcpyAsync(h_count, s_count, n_surv_all * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipMemcpyAsync(h_off, s_off, n_surv_all * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (n_segs) {
+        DP_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+        hipLaunchKernelGGL((v2 ? scan_kernel<1, 2> : scan_kernel<1, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
+                           (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)d_items, n_items, k,
+                           (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
+                           (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
+                           (int32_t*)ctx->d_segs.p, 0u);
+        DP_HIP(hipGetLastError());
+        DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+        DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    DP_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_segs) hipEventElapsedTime(&ms1, ctx->ev[2], ctx->ev[3]);
+    scan_lock.unlock();
+    ctx->n_segs = n_segs;
+    // survivors of the read range come first (item index < n_read_items), the extra items after them (all present)
+    uint64_t ns = 0;
+    while (ns < n_surv_all && h_item[ns] < n_read_items) ns++;
+    if (n_surv_all - ns != n_extra) return dp_fail(ctx, DP_ERR_STATE, "dp_scan_reads: internal compaction mismatch");
+    for (uint64_t i = 0; i < ns; i++) h_item[i] += lo;  // item index -> read id
+    out->n_survivors = (uint32_t)ns;
+    out->read = h_item;
+    out->n_seeds = h_count;
+    out->seg_off = h_off;
+    out->extra_n_seeds = h_count + ns;
+    out->extra_seg_off = h_off + ns;
     out->segs = (const int32_t*)ctx->h_segs.p;
     out->n_segs = n_segs;
     out->kernel_ms = (double)ms0 + (double)msoff + (double)ms1;

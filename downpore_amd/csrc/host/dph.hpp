@@ -187,6 +187,7 @@ struct Survivors {
     std::vector<uint32_t> n_seeds;
     std::vector<uint64_t> seg_off;   // n+1
     std::vector<int32_t> segs;
+    bool deviceResident = false;     // the device scan buffer of the producing context holds exactly `segs` at the same offsets
 };
 
 class Overlapper {
@@ -211,11 +212,15 @@ class Overlapper {
     const std::vector<Window>& windows() const { return windows_; }
     void setWindows(const std::vector<Window>& w) { windows_ = w; }
     // which reads count as ignored for PrepareQueries / ScanLocal (default: the read set's live flags)
-    void setIgnoreView(const uint8_t* ig) { ignore_ = ig; }
+    void setIgnoreView(const uint8_t* ig, uint64_t epoch = 0) {
+        ignore_ = ig;
+        ignoreEpoch_ = epoch;
+    }
 
    private:
     void chunkAndAdd(SeedSeq* s, uint64_t segBase);
     const uint8_t* ignore_ = nullptr;
+    uint64_t ignoreEpoch_ = 0;
     dp_ctx* ctx_;
     ReadSet& reads_;
     SeedIndex& index_;
@@ -263,6 +268,7 @@ class Planner {
     std::shared_ptr<const RoundPlan> get(i64 round);
     // commit-time: set the flags; returns the first round whose cached plan was discarded (or -1)
     i64 applyIgnores(const std::vector<int>& ids, i64 committedRound);
+    uint64_t ignoreEpoch();  // bumped whenever a flag is set
     void dropBefore(i64 round);
 
    private:

@@ -111,19 +111,8 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values
 // reads with >= minSeeds hits: chunkWorker drops the others, :259-261) followed by all query windows.
 int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st) {
     const int k = index_.k;
-    std::vector<dp_scan_item> items;
-    std::vector<uint32_t> itemRead;
-    for (size_t r = lo; r < hi; r++) {
-        if (ignore_[r]) continue;
-        dp_scan_item it;
-        it.read = (uint32_t)r;
-        it.start = 0;
-        it.n_kmers = (uint32_t)reads_.scanKmers(r, k);
-        it.min_seeds = (uint32_t)minSeeds_;
-        items.push_back(it);
-        itemRead.push_back((uint32_t)r);
-    }
-    const size_t nReads = items.size();
+    std::vector<dp_scan_item> items;  // the query windows; the reads themselves are enumerated on the device
+    items.reserve(windows_.size());
     for (const Window& w : windows_) {
         dp_scan_item it;
         it.read = w.read;
@@ -136,8 +125,9 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
         it.min_seeds = 0;
         items.push_back(it);
     }
-    dp_seedseq_batch b;
-    int rc = dp_scan(ctx_, items.data(), (uint32_t)items.size(), &b);
+    dp_survivor_batch b;
+    int rc = dp_scan_reads(ctx_, ignore_, ignoreEpoch_, (uint32_t)lo, (uint32_t)hi, reads_.himem ? 0 : 1, (uint32_t)minSeeds_,
+                           items.data(), (uint32_t)items.size(), &b);
     if (rc != 0) {
         err = dp_last_error(ctx_);
         return rc;
@@ -146,28 +136,25 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
     st.k_count_ms += b.count_kernel_ms;
     st.k_write_ms += b.write_kernel_ms;
     st.scan_bases += b.bases_scanned;
-    st.scan_items += items.size();
-    // survivors of the local shard (ascending read id)
-    local.read.clear();
-    local.n_seeds.clear();
-    local.seg_off.assign(1, 0);
-    local.segs.clear();
-    for (size_t i = 0; i < nReads; i++) {
-        if (b.n_seeds[i] < (uint32_t)minSeeds_) continue;
-        local.read.push_back(itemRead[i]);
-        local.n_seeds.push_back(b.n_seeds[i]);
-        local.segs.insert(local.segs.end(), b.segs + b.seg_off[i], b.segs + b.seg_off[i + 1]);
-        local.seg_off.push_back(local.segs.size());
-    }
+    st.scan_items += b.reads_scanned + items.size();
+    // survivors of the local shard (ascending read id); their segments are the leading part of the scan output
+    local.read.assign(b.read, b.read + b.n_survivors);
+    local.n_seeds.assign(b.n_seeds, b.n_seeds + b.n_survivors);
+    local.seg_off.assign(b.seg_off, b.seg_off + b.n_survivors);
+    uint64_t survEnd = 0;
+    if (b.n_survivors) survEnd = b.seg_off[b.n_survivors - 1] + 2ull * b.n_seeds[b.n_survivors - 1] + 1;
+    local.seg_off.push_back(survEnd);
+    local.segs.assign(b.segs, b.segs + survEnd);
+    local.deviceResident = true;
     // query windows
     winSegs_.clear();
     winOff_.assign(1, 0);
-    for (size_t i = nReads; i < items.size(); i++) {
-        winSegs_.insert(winSegs_.end(), b.segs + b.seg_off[i], b.segs + b.seg_off[i + 1]);
+    for (uint32_t i = 0; i < b.n_extra; i++) {
+        const uint64_t o = b.extra_seg_off[i];
+        winSegs_.insert(winSegs_.end(), b.segs + o, b.segs + o + 2ull * b.extra_n_seeds[i] + 1);
         winOff_.push_back(winSegs_.size());
     }
-    // hits written this scan, for the roofline's algorithmic bytes
-    st.n_hits += (b.n_segs - (uint64_t)0) / 2;
+    st.n_hits += b.n_segs / 2;  // hits written this scan, for the roofline's algorithmic bytes
     return 0;
 }
 
@@ -237,8 +224,10 @@ void Overlapper::chunkAndAdd(SeedSeq* s, uint64_t segBase) {
 // AddSequences :217 (chunk + index part) from the complete survivor list (file order).
 int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
     allSegs_ = all.segs;
-    // the device-resident scan output the index refers to must be exactly this survivor array
-    int rc = dp_scan_import_segments(ctx_, allSegs_.data(), allSegs_.size());
+    // the device-resident scan output the index refers to must hold exactly this survivor array at the same offsets:
+    // true right after a local full scan; after a multi-GPU exchange the gathered array is imported
+    int rc = 0;
+    if (!all.deviceResident) rc = dp_scan_import_segments(ctx_, allSegs_.data(), allSegs_.size());
     if (rc != 0) {
         err = dp_last_error(ctx_);
         return rc;
@@ -612,6 +601,11 @@ i64 Planner::applyIgnores(const std::vector<int>& ids, i64 committedRound) {
     return firstBad;
 }
 
+uint64_t Planner::ignoreEpoch() {
+    std::lock_guard<std::mutex> lk(d->mu);
+    return d->epoch;
+}
+
 void Planner::dropBefore(i64 round) {
     std::lock_guard<std::mutex> lk(d->mu);
     // keep round-1: it carries firstOut for the chain
@@ -689,6 +683,7 @@ int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
     for (uint32_t km : plan.seedMap) sl.index->addSeedKmer(km);
     sl.lap.reset(new Overlapper(sl.ctx, *reads, *sl.index, p.chunkSize, p.numWorkers, p.overlapSize, p.numSeeds, p.minHits));
     sl.lap->setWindows(plan.windows);
+    sl.lap->setIgnoreView(reads->ignore.data(), planner->ignoreEpoch());
     int rc = dp_round_begin(sl.ctx, p.k, sl.index->seedMap.data(), (uint32_t)sl.index->seedMap.size());
     if (rc != 0) {
         sl.error = dp_last_error(sl.ctx);

@@ -21,6 +21,14 @@ class SeedSeqBatch(C.Structure):
                 ("count_kernel_ms", C.c_double), ("write_kernel_ms", C.c_double), ("bases_scanned", C.c_uint64)]
 
 
+class SurvivorBatch(C.Structure):
+    _fields_ = [("n_survivors", C.c_uint32), ("read", C.POINTER(C.c_uint32)), ("n_seeds", C.POINTER(C.c_uint32)),
+                ("seg_off", C.POINTER(C.c_uint64)), ("n_extra", C.c_uint32), ("extra_n_seeds", C.POINTER(C.c_uint32)),
+                ("extra_seg_off", C.POINTER(C.c_uint64)), ("segs", C.POINTER(C.c_int32)), ("n_segs", C.c_uint64),
+                ("kernel_ms", C.c_double), ("count_kernel_ms", C.c_double), ("write_kernel_ms", C.c_double),
+                ("bases_scanned", C.c_uint64), ("reads_scanned", C.c_uint32)]
+
+
 class MatchBatch(C.Structure):
     _fields_ = [("n_matches", C.c_uint32), ("query", C.POINTER(C.c_uint32)), ("target", C.POINTER(C.c_uint32)),
                 ("off", C.POINTER(C.c_uint64)), ("match_a", C.POINTER(C.c_int32)), ("match_b", C.POINTER(C.c_int32)),
@@ -36,7 +44,7 @@ class ChainBatch(C.Structure):
 
 #: every entry point include/downpore_hip.h declares (checked by the CPU-side symbol test)
 SYMBOLS = ["dp_version", "dp_ctx_create", "dp_ctx_create_shared", "dp_ctx_destroy", "dp_last_error", "dp_reads_upload", "dp_reads_packed",
-           "dp_reads_count", "dp_reads_total_bases", "dp_kmer_histogram", "dp_round_begin", "dp_scan", "dp_index_build",
+           "dp_reads_count", "dp_reads_total_bases", "dp_kmer_histogram", "dp_round_begin", "dp_scan", "dp_scan_reads", "dp_index_build",
            "dp_find_overlaps", "dp_map_windows", "dp_index_posting_row", "dp_index_seedset_row", "dp_scan_device_buffers",
            "dp_scan_import_segments"]
 
@@ -69,6 +77,8 @@ def load_library():
     L.dp_kmer_histogram.argtypes = [vp, C.c_int, C.c_void_p]
     L.dp_round_begin.argtypes = [vp, C.c_int, C.c_void_p, C.c_uint32]
     L.dp_scan.argtypes = [vp, C.c_void_p, C.c_uint32, C.POINTER(SeedSeqBatch)]
+    L.dp_scan_reads.argtypes = [vp, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_uint32,
+                                C.POINTER(SurvivorBatch)]
     L.dp_index_build.argtypes = [vp, C.c_void_p, C.c_uint32]
     L.dp_find_overlaps.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_uint32, C.c_double, C.c_int, C.c_uint32, C.c_int,
                                    C.POINTER(MatchBatch)]
@@ -151,6 +161,18 @@ class Context:
         return dict(n_seeds=_arr(b.n_seeds, n, np.uint32), seg_off=_arr(b.seg_off, n + 1, np.uint64),
                     segs=_arr(b.segs, b.n_segs, np.int32), kernel_ms=b.kernel_ms, count_kernel_ms=b.count_kernel_ms,
                     write_kernel_ms=b.write_kernel_ms, bases_scanned=b.bases_scanned)
+
+    def scan_reads(self, ignore, epoch, lo, hi, top_level, min_seeds, extra=None):
+        ig = np.ascontiguousarray(ignore, dtype=np.uint8)
+        ex = np.ascontiguousarray(extra if extra is not None else np.zeros((0, 4)), dtype=np.uint32).reshape(-1, 4)
+        b = SurvivorBatch()
+        self._chk(self.L.dp_scan_reads(self.h, ig.ctypes.data, epoch, lo, hi, 1 if top_level else 0, min_seeds, ex.ctypes.data,
+                                       len(ex), C.byref(b)))
+        ns, ne = b.n_survivors, b.n_extra
+        return dict(read=_arr(b.read, ns, np.uint32), n_seeds=_arr(b.n_seeds, ns, np.uint32), seg_off=_arr(b.seg_off, ns, np.uint64),
+                    extra_n_seeds=_arr(b.extra_n_seeds, ne, np.uint32), extra_seg_off=_arr(b.extra_seg_off, ne, np.uint64),
+                    segs=_arr(b.segs, b.n_segs, np.int32), bases_scanned=b.bases_scanned, reads_scanned=b.reads_scanned,
+                    kernel_ms=b.kernel_ms)
 
     def import_segments(self, segs):
         s = np.ascontiguousarray(segs, dtype=np.int32)

@@ -102,6 +102,30 @@ typedef struct {
 
 int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items, dp_seedseq_batch* out);
 
+/* AddSequences-level form of the scan (overlap.go:217-250): every read r in [lo, hi) whose ignore[r] is 0 is scanned
+ * as the view a later pass receives (top_level != 0: re-read top-level sequences incl. the len%4==0 quirk; 0: cached
+ * views) and only the SURVIVORS (>= min_seeds hits; chunkWorker drops the rest, overlap.go:259-261) come back, compacted
+ * on the device; `extra` items (the query windows) are appended and always returned.  The ignore array is uploaded only
+ * when ignore_epoch differs from the previous call on this context.  The device-resident segments keep the layout of
+ * `segs` (survivors in read order, then the extra items), so dp_index_build can reference them directly. */
+typedef struct {
+    uint32_t n_survivors;
+    const uint32_t* read;          /* [n_survivors] ascending read ids */
+    const uint32_t* n_seeds;       /* [n_survivors] */
+    const uint64_t* seg_off;       /* [n_survivors] offset of each survivor's segments in segs */
+    uint32_t n_extra;
+    const uint32_t* extra_n_seeds; /* [n_extra] */
+    const uint64_t* extra_seg_off; /* [n_extra] */
+    const int32_t* segs;
+    uint64_t n_segs;
+    double kernel_ms, count_kernel_ms, write_kernel_ms;
+    uint64_t bases_scanned;
+    uint32_t reads_scanned;
+} dp_survivor_batch;
+
+int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
+                  uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out);
+
 /* ---- A13: seed index build ------------------------------------------------------------------------------
  * Replaces SeedIndex.AddSequence + IndexSequences/index (seeds/seeds.go:272-305,372-384).  Indexed sequence i
  * is a view segs[seg_off .. seg_off + 2*n_seeds + 1) into the device-resident output of the last dp_scan

@@ -186,3 +186,40 @@ def test_empty_and_ragged(ctx):
     ctx.index_build(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint32))
     out = ctx.find_overlaps(np.array([5], dtype=np.int32), np.array([0, 1], dtype=np.uint64), 0.25, k, 500, True)
     assert len(out["query"]) == 0
+
+
+def test_scan_reads_compaction_matches_itemwise_scan(ctx):
+    """dp_scan_reads (items generated and survivors compacted on the device) == dp_scan item by item + host filter."""
+    k = 10
+    bases, off = O.gen_reads(15, 80000, 300, 3000, 0.01, True)
+    N = 300
+    ctx.upload_reads(bases, off)
+    rng = np.random.default_rng(2)
+    seeds = np.unique(rng.integers(1, 4 ** k, 9000)).astype(np.uint32)
+    ctx.round_begin(k, seeds)
+    ignore = (rng.random(N) < 0.2).astype(np.uint8)
+    lens = np.diff(off)
+    for top_level in (False, True):
+        for (lo, hi) in ((0, N), (37, 211)):
+            items = []
+            for r in range(lo, hi):
+                n = int(lens[r]) - k + 1
+                if top_level and lens[r] % 4 == 0:
+                    n -= 4
+                items.append((r, 0, max(n, 0), 25))
+            full = ctx.scan(items)
+            extra = [(5, 100, 500, 0), (9, 0, 300, 0)]
+            got = ctx.scan_reads(ignore, 7 if top_level else 3, lo, hi, top_level, 25, extra)
+            want_reads = [r for i, r in enumerate(range(lo, hi)) if not ignore[r] and full["n_seeds"][i] >= 25]
+            assert list(got["read"]) == want_reads
+            for j, r in enumerate(want_reads):
+                i = r - lo
+                a = full["segs"][int(full["seg_off"][i]):int(full["seg_off"][i + 1])]
+                o = int(got["seg_off"][j])
+                b = got["segs"][o:o + 2 * int(got["n_seeds"][j]) + 1]
+                assert np.array_equal(a, b)
+            ex = ctx.scan(extra)
+            for j in range(2):
+                o = int(got["extra_seg_off"][j])
+                b = got["segs"][o:o + 2 * int(got["extra_n_seeds"][j]) + 1]
+                assert np.array_equal(b, ex["segs"][int(ex["seg_off"][j]):int(ex["seg_off"][j + 1])])
