@@ -398,32 +398,55 @@ struct CNode {  // one link of a chain (pairState.prev history), written once
     int32_t prev;
 };
 
+#define C_ACAP 512       // query segments staged in LDS (ints)
+#define C_BCAP 1056      // target segments staged in LDS (ints); larger targets take the one-lane path
+#define C_LNODES 512     // chain links kept in LDS before spilling to the global pool
+
 struct CWave {
     int32_t aRed[512];
     int32_t aMap[256];
+    int32_t aSegL[C_ACAP];
+    int32_t bSegL[C_BCAP];
+    u64 aFlag[C_ACAP / 128];      // bit i: seed i of a is in bSet
+    u64 bFlag[C_BCAP / 128 + 1];  // bit j: seed j of b is in aSet
     int32_t o_aPos[C_OPEN], o_bPos[C_OPEN], o_aGap[C_OPEN], o_bGap[C_OPEN], o_aGapIndex[C_OPEN], o_len[C_OPEN], o_node[C_OPEN];
+    int32_t evOff[C_BCAP / 2];    // b seeds that reach the chain walk: accumulated bOffset ...
+    uint16_t evIdx[C_BCAP / 2];   // ... and bIndex
+    CNode lnodes[C_LNODES];
 };
+
+__device__ __forceinline__ void node_put(CWave& L, CNode* __restrict__ nodes, int idx, CNode nd) {
+    if (idx < C_LNODES)
+        L.lnodes[idx] = nd;
+    else
+        nodes[idx] = nd;
+}
+__device__ __forceinline__ CNode node_get(const CWave& L, const CNode* __restrict__ nodes, int idx) {
+    return idx < C_LNODES ? L.lnodes[idx] : nodes[idx];
+}
 
 __device__ __forceinline__ bool bs_contains(const u64* __restrict__ set, int32_t x) { return (set[x >> 6] >> (x & 63)) & 1ull; }
 
-__device__ __forceinline__ void gap_range(int gap, int k, int& mn, int& mx) {  // seeds/alignment.go:411-424
-    mn = (gap * 2) / 3 - k;
-    mx = (gap * 3) / 2 + k + 1;
-    if (mn < 0) {
-        mn = -k;
-        if (mx < 0) mx = 0;
-    } else if (mx < 20) {
-        mx = 20;
-        mn = 0;
+// seeds/alignment.go:411-424; written with selects only (reference parameters made the compiler keep minGap/maxGap
+// in scratch memory inside the chain loops)
+#define gap_range(gap_, k_, mn_, mx_)                                        \
+    {                                                                        \
+        const int g__ = (gap_);                                              \
+        const int m0__ = (g__ * 2) / 3 - (k_);                               \
+        const int x0__ = (g__ * 3) / 2 + (k_) + 1;                           \
+        const bool neg__ = m0__ < 0;                                         \
+        const bool small__ = !neg__ && x0__ < 20;                            \
+        mx_ = neg__ ? (x0__ < 0 ? 0 : x0__) : (small__ ? 20 : x0__);         \
+        mn_ = neg__ ? -(k_) : (small__ ? 0 : m0__);                          \
     }
-}
 
 // seedAligner.PairwiseAlignments (seeds/alignment.go:426-616), executed by ONE lane.  Returns the length of
 // results[0] (the chain matchWorker keeps, overlap/overlap.go:368-375) or 0; *resNode = its last node.
 // err: 1 reduced buffer overflow, 2 state pool, 4 results overflow, 8 node pool
-__device__ int pairwise_align(const int32_t* __restrict__ aSeg, int aN, const int32_t* __restrict__ bSeg, int bN,
-                              const u64* __restrict__ aSet, const u64* __restrict__ bSet, int minMatches, int k, int maxLength,
-                              CWave& L, CNode* __restrict__ nodes, int* resNode, uint32_t* err) {
+// aFlag/bFlag (LDS, may be null): membership bits precomputed by the whole wave, replacing the bitset probes.
+__device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, int bN, const u64* __restrict__ aSet,
+                              const u64* __restrict__ bSet, const u64* aFlag, const u64* bFlag, int minMatches, int k,
+                              int maxLength, CWave& L, CNode* __restrict__ nodes, int* resNode, uint32_t* err) {
     if (minMatches == 0) minMatches = 1;
     int nNodes = 0;
     int live = 0;
@@ -432,7 +455,8 @@ __device__ int pairwise_align(const int32_t* __restrict__ aSeg, int aN, const in
     int aLen = 0, offset = -k, startSize = 0, prevSeedA = -1;
     for (int i = 1; i < aN; i += 2) {
         int aSeed = aSeg[i];
-        if (!bs_contains(bSet, aSeed)) {
+        const bool inB = aFlag ? ((aFlag[i >> 7] >> ((i >> 1) & 63)) & 1ull) : bs_contains(bSet, aSeed);
+        if (!inB) {
             offset += aSeg[i - 1] + k;
             maxAIndex--;
             continue;
@@ -503,7 +527,8 @@ __device__ int pairwise_align(const int32_t* __restrict__ aSeg, int aN, const in
     int bOffset = 0, prevSeed = -1;
     for (int bIndex = 1; bIndex < bN; bIndex += 2) {
         const int bSeed = bSeg[bIndex];
-        if (!bs_contains(aSet, bSeed)) {
+        const bool inA = bFlag ? ((bFlag[bIndex >> 7] >> ((bIndex >> 1) & 63)) & 1ull) : bs_contains(aSet, bSeed);
+        if (!inA) {
             bOffset += bSeg[bIndex + 1] + k;
             continue;
         }
@@ -552,7 +577,7 @@ __device__ int pairwise_align(const int32_t* __restrict__ aSeg, int aN, const in
                         nd.a = (uint16_t)L.aMap[j / 2];
                         nd.b = (uint16_t)(bIndex / 2);
                         nd.prev = L.o_node[i];
-                        nodes[nNodes] = nd;
+                        node_put(L, nodes, nNodes, nd);
                         const int nl = L.o_len[i] + 1;
                         L.o_aPos[i] = j;
                         L.o_bPos[i] = bIndex;
@@ -604,7 +629,7 @@ __device__ int pairwise_align(const int32_t* __restrict__ aSeg, int aN, const in
                     nd.a = (uint16_t)L.aMap[i];
                     nd.b = (uint16_t)(bIndex / 2);
                     nd.prev = -1;
-                    nodes[nNodes] = nd;
+                    node_put(L, nodes, nNodes, nd);
                     L.o_aPos[openSize] = aPos;
                     L.o_bPos[openSize] = bIndex;
                     L.o_aGapIndex[openSize] = aPos + 2;
@@ -635,6 +660,349 @@ __device__ int pairwise_align(const int32_t* __restrict__ aSeg, int aN, const in
     return resultsSize ? firstLen : 0;
 }
 
+// The same function executed by the whole wave (a and b staged in L.aSegL / L.bSegL with their membership bits).
+// Control flow is wave-uniform; the three data-parallel parts are
+//   * prepareInitial: run collapse, gap prefix sums and ranks of the kept seeds via ballots/shuffles;
+//   * the b walk is compacted to the seeds that reach searchMatch ("events") with their accumulated bOffset;
+//   * per event every open chain is evaluated by its own lane; the reference's last-to-first order with its
+//     `break`s is restored afterwards: the highest chain that ended or extended stops the walk, chains above it
+//     apply their updates/removals (swap-with-last, descending), chains below it stay untouched (stale bGap).
+// Chains evaluated in one step cannot influence each other: removals above the break never reach minMatches
+// (length + remaining < minMatches), so minMatches is constant until the break itself.
+__device__ int pairwise_align_wave(int aN, int bN, int minMatches, int k, int maxLength, CWave& L, CNode* __restrict__ nodes,
+                                   int* resNode, uint32_t* err, bool prof, u64* tp) {
+    const int lane = dp_lane();
+    u64 t0 = prof ? wall_clock64() : 0;
+    const u64 lanesBelow = (1ull << lane) - 1ull;
+    if (minMatches == 0) minMatches = 1;
+    const int nA = aN >> 1, nB = bN >> 1;
+    int nNodes = 0;
+
+    // ---- prepareInitial :341-388
+    int aLen = 0, startSize = 0;
+    {
+        const int C0 = aN - minMatches * 2 + 1;
+        int prevSeed = -1, P = 0, PatKept = 0;
+        bool bad = false;
+        for (int base = 0; base < nA; base += 64) {
+            const int s = base + lane;
+            const bool valid = s < nA;
+            const int seed = valid ? L.aSegL[2 * s + 1] : -2;
+            const int gap = valid ? L.aSegL[2 * s] : 0;
+            const bool inB = valid && ((L.aFlag[base >> 6] >> lane) & 1ull);
+            const u64 inBmask = __ballot(inB);
+            const u64 below = inBmask & lanesBelow;
+            const int pl = below ? 63 - __builtin_clzll(below) : 0;
+            int pseed = __shfl(seed, pl, 64);
+            if (!below) pseed = prevSeed;
+            const bool last = s >= nA - 1;
+            const int nextRaw = (valid && !last) ? L.aSegL[2 * s + 3] : 0;
+            const bool keep = inB && !(seed == pseed && (last || nextRaw == pseed));
+            const u64 keepMask = __ballot(keep);
+            const int Pin = P + wave_incl_sum(valid ? gap + k : 0);
+            const u64 kb = keepMask & lanesBelow;
+            const int kl = kb ? 63 - __builtin_clzll(kb) : 0;
+            int Pk = __shfl(Pin, kl, 64);
+            if (!kb) Pk = PatKept;
+            const int rank = aLen + __popcll(kb);
+            bool isStart = false;
+            if (keep) {
+                if (rank * 2 + 1 >= maxLength || rank >= maxLength / 2 || rank * 2 + 2 >= 512) {
+                    bad = true;
+                } else {
+                    L.aRed[2 * rank] = Pin - Pk - k;
+                    L.aRed[2 * rank + 1] = seed;
+                    L.aMap[rank] = s;
+                    isStart = rank <= C0 - (s - rank);
+                }
+            }
+            if (__ballot(bad)) {
+                *err |= 1;
+                return 0;
+            }
+            startSize += __popcll(__ballot(isStart));
+            if (inBmask) prevSeed = __shfl(seed, 63 - __builtin_clzll(inBmask), 64);
+            if (keepMask) PatKept = __shfl(Pin, 63 - __builtin_clzll(keepMask), 64);
+            P = __shfl(Pin, 63, 64);
+            aLen += __popcll(keepMask);
+        }
+        if (aLen * 2 >= maxLength) {
+            *err |= 1;
+            return 0;
+        }
+        if (lane == 0) L.aRed[aLen * 2] = 0;
+        const int maxAIndex = C0 - (nA - aLen);
+        while (startSize > 0 && (2 * (startSize - 1) + 1) > maxAIndex) startSize--;
+    }
+    int live = startSize;
+    const int initialSize = startSize;
+    const int aRedLen = aLen * 2 + 1;
+    if (prof) {
+        u64 t1 = wall_clock64();
+        tp[0] += t1 - t0;
+        t0 = t1;
+    }
+
+    // ---- b seeds that reach searchMatch (:449-457), with the bOffset accumulated since the previous one
+    int nE = 0;
+    {
+        int prevSeed = -1, Q = 0, QatEvent = 0;
+        for (int base = 0; base < nB; base += 64) {
+            const int s = base + lane;
+            const bool valid = s < nB;
+            const int seed = valid ? L.bSegL[2 * s + 1] : -2;
+            const int gapAfter = valid ? L.bSegL[2 * s + 2] : 0;
+            const bool inA = valid && ((L.bFlag[base >> 6] >> lane) & 1ull);
+            const u64 inAmask = __ballot(inA);
+            const u64 below = inAmask & lanesBelow;
+            const int pl = below ? 63 - __builtin_clzll(below) : 0;
+            int pseed = __shfl(seed, pl, 64);
+            if (!below) pseed = prevSeed;
+            const bool last = s >= nB - 1;
+            const int nextRaw = (valid && !last) ? L.bSegL[2 * s + 3] : 0;
+            const bool ev = inA && !(seed == pseed && (last || nextRaw == pseed));
+            const u64 evMask = __ballot(ev);
+            const int Qin = Q + wave_incl_sum((valid && !ev) ? gapAfter + k : 0);
+            const u64 eb = evMask & lanesBelow;
+            const int el = eb ? 63 - __builtin_clzll(eb) : 0;
+            int Qe = __shfl(Qin, el, 64);
+            if (!eb) Qe = QatEvent;
+            if (ev) {
+                const int idx = nE + __popcll(eb);
+                L.evIdx[idx] = (uint16_t)(2 * s + 1);
+                L.evOff[idx] = Qin - Qe;
+            }
+            if (inAmask) prevSeed = __shfl(seed, 63 - __builtin_clzll(inAmask), 64);
+            if (evMask) QatEvent = __shfl(Qin, 63 - __builtin_clzll(evMask), 64);
+            Q = __shfl(Qin, 63, 64);
+            nE += __popcll(evMask);
+        }
+    }
+
+    // reduced a seeds, one per lane and 64-position block, for the per-event equality masks
+    int myA[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int j = c * 64 + lane;
+        myA[c] = j < aLen ? L.aRed[2 * j + 1] : -1;
+    }
+
+    int openSize = 0, resultsSize = 0, firstLen = 0, firstNode = -1;
+    int maxBIndex = bN - minMatches * 2 + 1;
+    if (prof) {
+        u64 t1 = wall_clock64();
+        tp[1] += t1 - t0;
+        tp[2] += (u64)nE;
+    }
+
+    // removeOpenState :390-409 for chain i_ (wave-uniform)
+#define REMOVE_OPEN_W(i_)                                                          \
+    {                                                                              \
+        const int ri_ = (i_);                                                      \
+        const int sl_ = L.o_len[ri_], sn_ = L.o_node[ri_];                         \
+        const int last_ = openSize - 1;                                            \
+        if (lane == 0) {                                                           \
+            L.o_aPos[ri_] = L.o_aPos[last_];                                       \
+            L.o_bPos[ri_] = L.o_bPos[last_];                                       \
+            L.o_aGap[ri_] = L.o_aGap[last_];                                       \
+            L.o_bGap[ri_] = L.o_bGap[last_];                                       \
+            L.o_aGapIndex[ri_] = L.o_aGapIndex[last_];                             \
+            L.o_len[ri_] = L.o_len[last_];                                         \
+            L.o_node[ri_] = L.o_node[last_];                                       \
+        }                                                                          \
+        openSize--;                                                                \
+        if (sl_ >= minMatches) {                                                   \
+            if ((sl_ * 2) / 3 > minMatches) minMatches = (sl_ * 2) / 3;            \
+            if (resultsSize >= C_RESULTS) {                                        \
+                *err |= 4;                                                         \
+                return 0;                                                          \
+            }                                                                      \
+            if (resultsSize == 0) {                                                \
+                firstLen = sl_;                                                    \
+                firstNode = sn_;                                                   \
+            }                                                                      \
+            resultsSize++;                                                         \
+        } else {                                                                   \
+            live -= sl_;                                                           \
+        }                                                                          \
+    }
+
+    for (int e = 0; e < nE; e++) {
+        const int bIndex = L.evIdx[e];
+        const int bOffset = L.evOff[e];
+        const int bSeed = L.bSegL[bIndex];
+        const int gapAfter = L.bSegL[bIndex + 1];
+        int found = -1;
+        // searchMatch :465-547
+        int hi = openSize;
+        while (hi > 0) {
+            const int lo = hi > 64 ? hi - 64 : 0;
+            const int i = lo + lane;
+            const bool act = i < hi;
+            int outcome = 0;  // 1 keep, 2 too short, 3 ran off the end of a, 4 extends
+            int bGap = 0, aGap = 0, aGapIndex = 0, xj = -1;
+            if (act) {
+                bGap = L.o_bGap[i] + bOffset;
+                int minGap, maxGap;
+                gap_range(bGap, k, minGap, maxGap);
+                aGap = L.o_aGap[i];
+                aGapIndex = L.o_aGapIndex[i];
+                bool ended = false;
+                while (aGap < minGap) {
+                    if (aGapIndex >= aRedLen) {
+                        ended = true;
+                        break;
+                    }
+                    aGap += L.aRed[aGapIndex + 1] + k;
+                    aGapIndex += 2;
+                }
+                if (ended) {
+                    outcome = 3;
+                } else {
+                    if (aGap <= maxGap) {
+                        int g = aGap;
+                        for (int j = aGapIndex; j < aRedLen && g <= maxGap; j += 2) {
+                            if (L.aRed[j] == bSeed) {
+                                xj = j;
+                                break;
+                            }
+                            g += L.aRed[j + 1] + k;
+                        }
+                    }
+                    if (xj >= 0)
+                        outcome = 4;
+                    else
+                        outcome = (L.o_len[i] + (bN - bIndex) < minMatches) ? 2 : 1;
+                }
+            }
+            const u64 brk = __ballot(outcome >= 3);
+            const int ibLane = brk ? 63 - __builtin_clzll(brk) : -1;
+            if (outcome == 1 && lane > ibLane) {
+                L.o_bGap[i] = bGap + gapAfter + k;
+                L.o_aGap[i] = aGap;
+                L.o_aGapIndex[i] = aGapIndex;
+            }
+            u64 shortMask = __ballot(outcome == 2 && lane > ibLane);
+            while (shortMask) {
+                const int ln = 63 - __builtin_clzll(shortMask);
+                shortMask &= ~(1ull << ln);
+                REMOVE_OPEN_W(lo + ln);
+            }
+            if (ibLane < 0) {
+                hi = lo;
+                continue;
+            }
+            const int bi = lo + ibLane;
+            if (__shfl(outcome, ibLane, 64) == 3) {
+                REMOVE_OPEN_W(bi);
+            } else {
+                const int j = __shfl(xj, ibLane, 64);
+                found = j;
+                if (nNodes >= (int)C_NODES) {
+                    *err |= 8;
+                    return 0;
+                }
+                if (++live > C_POOLSTATES) {
+                    *err |= 2;
+                    return 0;
+                }
+                const int nl = L.o_len[bi] + 1;
+                if (lane == 0) {
+                    CNode nd;
+                    nd.a = (uint16_t)L.aMap[j / 2];
+                    nd.b = (uint16_t)(bIndex / 2);
+                    nd.prev = L.o_node[bi];
+                    node_put(L, nodes, nNodes, nd);
+                    L.o_aPos[bi] = j;
+                    L.o_bPos[bi] = bIndex;
+                    L.o_aGapIndex[bi] = j + 2;
+                    L.o_aGap[bi] = L.aRed[j + 1];
+                    L.o_bGap[bi] = gapAfter;
+                    L.o_len[bi] = nl;
+                    L.o_node[bi] = nNodes;
+                }
+                nNodes++;
+                if ((nl * 2) / 3 > minMatches) {
+                    minMatches = (nl * 2) / 3;
+                    maxBIndex = bN - minMatches * 2 + 1;
+                }
+            }
+            break;
+        }
+        // new chains :550-587
+        if (bIndex <= maxBIndex) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (c * 64 >= initialSize) break;
+                u64 m = __ballot(myA[c] == bSeed && c * 64 + lane < initialSize);
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int i = c * 64 + bit;
+                    const int aPos = 2 * i + 1;
+                    if (aPos == found) continue;
+                    if (found != -1) {
+                        bool dup = false;
+                        for (int base = 0; base < openSize; base += 64) {
+                            const int j = base + lane;
+                            if (__ballot(j < openSize && L.o_bPos[j] == bIndex && L.o_aPos[j] == aPos)) {
+                                dup = true;
+                                break;
+                            }
+                        }
+                        if (dup) found = aPos;
+                    }
+                    if (found == aPos || openSize >= C_OPEN) continue;
+                    if (nNodes >= (int)C_NODES) {
+                        *err |= 8;
+                        return 0;
+                    }
+                    if (++live > C_POOLSTATES) {
+                        *err |= 2;
+                        return 0;
+                    }
+                    if (lane == 0) {
+                        CNode nd;
+                        nd.a = (uint16_t)L.aMap[i];
+                        nd.b = (uint16_t)(bIndex / 2);
+                        nd.prev = -1;
+                        node_put(L, nodes, nNodes, nd);
+                        L.o_aPos[openSize] = aPos;
+                        L.o_bPos[openSize] = bIndex;
+                        L.o_aGapIndex[openSize] = aPos + 2;
+                        L.o_aGap[openSize] = L.aRed[aPos + 1];
+                        L.o_bGap[openSize] = gapAfter;
+                        L.o_len[openSize] = 1;
+                        L.o_node[openSize] = nNodes;
+                    }
+                    nNodes++;
+                    openSize++;
+                }
+            }
+        }
+    }
+#undef REMOVE_OPEN_W
+    // :597-604
+    for (int base = 0; base < openSize; base += 64) {
+        const int i = base + lane;
+        const u64 okMask = __ballot(i < openSize && L.o_len[i] >= minMatches);
+        if (!okMask) continue;
+        const int cnt = __popcll(okMask);
+        if (resultsSize + cnt > C_RESULTS) {
+            *err |= 4;
+            return 0;
+        }
+        if (resultsSize == 0) {
+            const int f = base + __builtin_ctzll(okMask);
+            firstLen = L.o_len[f];
+            firstNode = L.o_node[f];
+        }
+        resultsSize += cnt;
+    }
+    *resNode = firstNode;
+    return resultsSize ? firstLen : 0;
+}
+
 struct MRec {
     uint32_t q, t;
     uint32_t off, len;
@@ -649,7 +1017,7 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                                                              const int32_t* __restrict__ mc, uint32_t mc_n, int k, int maxLength,
                                                              CNode* __restrict__ pool, MRec* __restrict__ recs, uint32_t rec_cap,
                                                              int32_t* __restrict__ ma, int32_t* __restrict__ mb, uint32_t int_cap,
-                                                             uint32_t* __restrict__ cursor) {
+                                                             uint32_t* __restrict__ cursor, u64* __restrict__ dbg) {
     __shared__ CWave sh[C_WAVES];
     CWave& L = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
@@ -663,7 +1031,13 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
         const int aN = (int)(qoff[q + 1] - qoff[q]);
         const uint32_t nSeeds = (uint32_t)aN / 2;
         const u64* qset = qsets + (uint64_t)q * SW;
+        const bool aStaged = aN <= C_ACAP;
+        if (aStaged) {
+            for (int i = lane; i < aN; i += 64) L.aSegL[i] = aSeg[i];
+        }
         int minMatches = nSeeds < mc_n ? mc[nSeeds] : 0x7fffffff;  // int(hitFraction*numSeeds+0.5), overlap.go:356
+        u64 tq0 = dbg ? wall_clock64() : 0, tAlign = 0, tExtract = 0, tStage = 0, nCand = 0, nPairs = 0;
+        u64 tp[3] = {0, 0, 0};
         for (uint32_t wi = 0; wi < W; wi++) {
             u64 mask = cand[(uint64_t)q * W + wi];
             while (mask) {
@@ -671,6 +1045,8 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                 mask &= mask - 1;
                 const uint32_t t = wi * 64 + (uint32_t)b;
                 const u64* tset = seedsets + (uint64_t)t * SW;
+                nCand++;
+                u64 ts0 = dbg ? wall_clock64() : 0;
                 // CountIntersectionTo(seedSet, minMatches) < minMatches  (overlap.go:359; the asm's early exit only
                 // ever returns a value >= maxCount, so the comparison equals the one on the full popcount)
                 int c = 0;
@@ -678,12 +1054,42 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                 c = wave_sum(c);
                 if (c < minMatches) continue;
                 const dp_seq_ref r = refs[t];
+                const int32_t* bSeg = segs + r.seg_off;
+                const int bN = (int)(2 * r.n_seeds + 1);
+                const bool staged = aStaged && bN <= C_BCAP;
+                if (staged) {  // stage b and both membership bit vectors with the whole wave
+                    for (int i = lane; i < bN; i += 64) L.bSegL[i] = bSeg[i];
+                    for (int base = 0; base < (int)nSeeds; base += 64) {
+                        const int s = base + lane;
+                        bool f = false;
+                        if (s < (int)nSeeds) f = bs_contains(tset, aSeg[2 * s + 1]);
+                        const u64 m = __ballot(f);
+                        if (lane == 0) L.aFlag[base >> 6] = m;
+                    }
+                    for (int base = 0; base < (int)r.n_seeds; base += 64) {
+                        const int s = base + lane;
+                        bool f = false;
+                        if (s < (int)r.n_seeds) f = bs_contains(qset, bSeg[2 * s + 1]);
+                        const u64 m = __ballot(f);
+                        if (lane == 0) L.bFlag[base >> 6] = m;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
                 int resLen = 0, resNode = -1;
                 uint32_t err = 0;
-                if (lane == 0)
-                    resLen = pairwise_align(aSeg, aN, segs + r.seg_off, (int)(2 * r.n_seeds + 1), qset, tset, minMatches, k,
-                                            maxLength, L, nodes, &resNode, &err);
+                nPairs++;
+                u64 ta0 = dbg ? wall_clock64() : 0;
+                tStage += ta0 - ts0;
+                if (staged) {
+                    resLen = pairwise_align_wave(aN, bN, minMatches, k, maxLength, L, nodes, &resNode, &err, dbg != nullptr, tp);
+                } else if (lane == 0) {
+                    resLen = pairwise_align(aSeg, aN, bSeg, bN, qset, tset, nullptr, nullptr, minMatches, k, maxLength, L, nodes,
+                                            &resNode, &err);
+                }
                 resLen = __shfl(resLen, 0, 64);
+                u64 ta1 = dbg ? wall_clock64() : 0;
+                tAlign += ta1 - ta0;
                 if (lane == 0 && err) atomicOr(&cursor[2], err);
                 if (resLen > 0) {
                     if (lane == 0) {
@@ -694,7 +1100,7 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                             recs[ri] = rec;
                             int node = resNode;
                             for (int x = resLen - 1; x >= 0 && node >= 0; x--) {  // extractMatch :326-335
-                                CNode nd = nodes[node];
+                                CNode nd = node_get(L, nodes, node);
                                 ma[off + x] = nd.a;
                                 mb[off + x] = nd.b;
                                 node = nd.prev;
@@ -704,8 +1110,19 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                         }
                     }
                     if (resLen * 2 > minMatches * 3) minMatches = (resLen * 2) / 3;  // ratchet, overlap.go:380-382
+                    if (dbg) tExtract += wall_clock64() - ta1;
                 }
             }
+        }
+        if (dbg && lane == 0) {
+            dbg[8 * q + 0] = wall_clock64() - tq0;
+            dbg[8 * q + 1] = tAlign;
+            dbg[8 * q + 2] = tExtract;
+            dbg[8 * q + 3] = tStage;
+            dbg[8 * q + 4] = nCand;
+            dbg[8 * q + 5] = nPairs;
+            dbg[8 * q + 6] = (tp[0] << 32) | tp[1];
+            dbg[8 * q + 7] = tp[2];
         }
     }
 }
@@ -793,6 +1210,12 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     uint32_t int_cap = std::max<uint32_t>(1u << 21, (uint32_t)(ctx->d_ma.cap / 4));
     uint32_t cur[16];
     float chain_ms = 0;
+    static const bool chain_debug = getenv("DP_CHAIN_DEBUG") != nullptr;
+    u64* d_dbg = nullptr;
+    if (chain_debug) {
+        DP_HIP(hipMalloc((void**)&d_dbg, (size_t)nq * 64));
+        DP_HIP(hipMemsetAsync(d_dbg, 0, (size_t)nq * 64, ctx->stream));
+    }
     for (;;) {
         if (dev_reserve(ctx, ctx->d_mrec, (size_t)rec_cap * sizeof(MRec))) return DP_ERR_HIP;
         if (dev_reserve(ctx, ctx->d_ma, (size_t)int_cap * 4)) return DP_ERR_HIP;
@@ -804,7 +1227,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
                            (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p,
                            (const u64*)ctx->d_seedsets.p, W, SW, (const int32_t*)d_mc, mc_n, k, (int)max_query_len,
                            (CNode*)ctx->d_pool.p, (MRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p,
-                           int_cap, (uint32_t*)ctx->d_cursor.p);
+                           int_cap, (uint32_t*)ctx->d_cursor.p, d_dbg);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         DP_HIP(hipMemcpyAsync(cur, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -818,6 +1241,27 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
             continue;
         }
         break;
+    }
+    if (chain_debug) {  // per-query timing breakdown in 10 ns ticks (wall_clock64 = 100 MHz)
+        std::vector<u64> h((size_t)nq * 8);
+        hipMemcpy(h.data(), d_dbg, (size_t)nq * 64, hipMemcpyDeviceToHost);
+        hipFree(d_dbg);
+        u64 sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0}, p1 = 0, p2 = 0, ne = 0;
+        for (uint32_t q = 0; q < nq; q++) {
+            for (int j = 0; j < 6; j++) {
+                sum[j] += h[8 * q + j];
+                mx[j] = std::max(mx[j], h[8 * q + j]);
+            }
+            p1 += h[8 * q + 6] >> 32;
+            p2 += h[8 * q + 6] & 0xffffffffull;
+            ne += h[8 * q + 7];
+        }
+        fprintf(stderr, "[chain] prepareInitial %.1f us, events prep %.1f us, events %llu\n", p1 / 100.0, p2 / 100.0,
+                (unsigned long long)ne);
+        fprintf(stderr, "[chain] nq %u kernel %.3f ms | sum(us) total %.1f align %.1f extract %.1f stage %.1f cand %llu pairs %llu | max total %.1f align %.1f extract %.1f stage %.1f cand %llu pairs %llu\n",
+                nq, chain_ms, sum[0] / 100.0, sum[1] / 100.0, sum[2] / 100.0, sum[3] / 100.0, (unsigned long long)sum[4],
+                (unsigned long long)sum[5], mx[0] / 100.0, mx[1] / 100.0, mx[2] / 100.0, mx[3] / 100.0,
+                (unsigned long long)mx[4], (unsigned long long)mx[5]);
     }
     float qms = 0;
     hipEventElapsedTime(&qms, ctx->ev[4], ctx->ev[5]);
