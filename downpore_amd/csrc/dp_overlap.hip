@@ -401,6 +401,8 @@ struct CNode {  // one link of a chain (pairState.prev history), written once
 #define C_ACAP 512       // query segments staged in LDS (ints)
 #define C_BCAP 1056      // target segments staged in LDS (ints); larger targets take the one-lane path
 #define C_LNODES 512     // chain links kept in LDS before spilling to the global pool
+#define C_REV 256        // b events of the reg tier
+#define C_QSW 256        // query bitset words staged in LDS
 
 struct CWave {
     int32_t aRed[512];
@@ -409,10 +411,22 @@ struct CWave {
     int32_t bSegL[C_BCAP];
     u64 aFlag[C_ACAP / 128];      // bit i: seed i of a is in bSet
     u64 bFlag[C_BCAP / 128 + 1];  // bit j: seed j of b is in aSet
-    int32_t o_aPos[C_OPEN], o_bPos[C_OPEN], o_aGap[C_OPEN], o_bGap[C_OPEN], o_aGapIndex[C_OPEN], o_len[C_OPEN], o_node[C_OPEN];
-    int32_t evOff[C_BCAP / 2];    // b seeds that reach the chain walk: accumulated bOffset ...
-    uint16_t evIdx[C_BCAP / 2];   // ... and bIndex
-    CNode lnodes[C_LNODES];
+    u64 qsetL[C_QSW];             // the query's seed bitset when it fits
+    union {
+        struct {  // lds / one-lane tiers
+            int32_t o_aPos[C_OPEN], o_bPos[C_OPEN], o_aGap[C_OPEN], o_bGap[C_OPEN], o_aGapIndex[C_OPEN], o_len[C_OPEN],
+                o_node[C_OPEN];
+            int32_t evOff[C_BCAP / 2];   // b seeds that reach the chain walk: accumulated bOffset ...
+            uint16_t evIdx[C_BCAP / 2];  // ... and bIndex
+            CNode lnodes[C_LNODES];
+        };
+        struct {  // reg tier
+            uint32_t col[64][64];  // matched pairs of open chain i: reducedA | bSeedIndex << 16
+            int4 ev[C_REV];
+            int32_t ps[64];
+            uint32_t rescol[64];
+        };
+    };
 };
 
 __device__ __forceinline__ void node_put(CWave& L, CNode* __restrict__ nodes, int idx, CNode nd) {
@@ -660,124 +674,329 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
     return resultsSize ? firstLen : 0;
 }
 
-// The same function executed by the whole wave (a and b staged in L.aSegL / L.bSegL with their membership bits).
-// Control flow is wave-uniform; the three data-parallel parts are
-//   * prepareInitial: run collapse, gap prefix sums and ranks of the kept seeds via ballots/shuffles;
-//   * the b walk is compacted to the seeds that reach searchMatch ("events") with their accumulated bOffset;
-//   * per event every open chain is evaluated by its own lane; the reference's last-to-first order with its
-//     `break`s is restored afterwards: the highest chain that ended or extended stops the walk, chains above it
-//     apply their updates/removals (swap-with-last, descending), chains below it stay untouched (stale bGap).
-// Chains evaluated in one step cannot influence each other: removals above the break never reach minMatches
+// ---- wave-cooperative PairwiseAlignments -----------------------------------------------------------------------
+// a and b are staged in L.aSegL / L.bSegL with their membership bits; control flow is wave-uniform.  Three tiers share
+// the parallel prepareInitial:
+//   reg  (aLen <= 64, <= 256 b events, <= 64 open chains): chain i lives in the registers of lane i and keeps its
+//        matched pairs in an LDS column, so an event costs a ballot plus register arithmetic;
+//   lds  (anything staged): open chains in the LDS arrays, one lane per chain, history as linked nodes;
+//   lane (operands too large to stage): the scalar transcription above.
+// In both parallel tiers the reference's last-to-first walk over the open chains with its `break`s is restored after
+// the lanes have evaluated their chains independently: the highest chain that ended or extended stops the walk,
+// chains above it apply their updates/removals (swap-with-last, descending), chains below it stay untouched (stale
+// bGap).  Chains evaluated in one step cannot influence each other: removals above the break never reach minMatches
 // (length + remaining < minMatches), so minMatches is constant until the break itself.
-__device__ int pairwise_align_wave(int aN, int bN, int minMatches, int k, int maxLength, CWave& L, CNode* __restrict__ nodes,
-                                   int* resNode, uint32_t* err, bool prof, u64* tp) {
-    const int lane = dp_lane();
-    u64 t0 = prof ? wall_clock64() : 0;
-    const u64 lanesBelow = (1ull << lane) - 1ull;
-    if (minMatches == 0) minMatches = 1;
-    const int nA = aN >> 1, nB = bN >> 1;
-    int nNodes = 0;
 
-    // ---- prepareInitial :341-388
+// prepareInitial :341-388.  Returns false when the reference would overrun `reduced` (err bit 1).
+__device__ bool wave_prepare_initial(int aN, int minMatches, int k, int maxLength, CWave& L, int* aLenOut, int* startOut) {
+    const int lane = dp_lane();
+    const u64 lanesBelow = (1ull << lane) - 1ull;
+    const int nA = aN >> 1;
     int aLen = 0, startSize = 0;
-    {
-        const int C0 = aN - minMatches * 2 + 1;
-        int prevSeed = -1, P = 0, PatKept = 0;
-        bool bad = false;
-        for (int base = 0; base < nA; base += 64) {
-            const int s = base + lane;
-            const bool valid = s < nA;
-            const int seed = valid ? L.aSegL[2 * s + 1] : -2;
-            const int gap = valid ? L.aSegL[2 * s] : 0;
-            const bool inB = valid && ((L.aFlag[base >> 6] >> lane) & 1ull);
-            const u64 inBmask = __ballot(inB);
-            const u64 below = inBmask & lanesBelow;
-            const int pl = below ? 63 - __builtin_clzll(below) : 0;
-            int pseed = __shfl(seed, pl, 64);
-            if (!below) pseed = prevSeed;
-            const bool last = s >= nA - 1;
-            const int nextRaw = (valid && !last) ? L.aSegL[2 * s + 3] : 0;
-            const bool keep = inB && !(seed == pseed && (last || nextRaw == pseed));
-            const u64 keepMask = __ballot(keep);
-            const int Pin = P + wave_incl_sum(valid ? gap + k : 0);
-            const u64 kb = keepMask & lanesBelow;
-            const int kl = kb ? 63 - __builtin_clzll(kb) : 0;
-            int Pk = __shfl(Pin, kl, 64);
-            if (!kb) Pk = PatKept;
-            const int rank = aLen + __popcll(kb);
-            bool isStart = false;
-            if (keep) {
-                if (rank * 2 + 1 >= maxLength || rank >= maxLength / 2 || rank * 2 + 2 >= 512) {
-                    bad = true;
+    const int C0 = aN - minMatches * 2 + 1;
+    int prevSeed = -1, P = 0, PatKept = 0;
+    bool bad = false;
+    for (int base = 0; base < nA; base += 64) {
+        const int s = base + lane;
+        const bool valid = s < nA;
+        const int seed = valid ? L.aSegL[2 * s + 1] : -2;
+        const int gap = valid ? L.aSegL[2 * s] : 0;
+        const bool inB = valid && ((L.aFlag[base >> 6] >> lane) & 1ull);
+        const u64 inBmask = __ballot(inB);
+        const u64 below = inBmask & lanesBelow;
+        const int pl = below ? 63 - __builtin_clzll(below) : 0;
+        int pseed = __shfl(seed, pl, 64);
+        if (!below) pseed = prevSeed;
+        const bool last = s >= nA - 1;
+        const int nextRaw = (valid && !last) ? L.aSegL[2 * s + 3] : 0;
+        const bool keep = inB && !(seed == pseed && (last || nextRaw == pseed));
+        const u64 keepMask = __ballot(keep);
+        const int Pin = P + wave_incl_sum(valid ? gap + k : 0);
+        const u64 kb = keepMask & lanesBelow;
+        const int kl = kb ? 63 - __builtin_clzll(kb) : 0;
+        int Pk = __shfl(Pin, kl, 64);
+        if (!kb) Pk = PatKept;
+        const int rank = aLen + __popcll(kb);
+        bool isStart = false;
+        if (keep) {
+            if (rank * 2 + 1 >= maxLength || rank >= maxLength / 2 || rank * 2 + 2 >= 512) {
+                bad = true;
+            } else {
+                L.aRed[2 * rank] = Pin - Pk - k;
+                L.aRed[2 * rank + 1] = seed;
+                L.aMap[rank] = s;
+                isStart = rank <= C0 - (s - rank);
+            }
+        }
+        if (__ballot(bad)) return false;
+        startSize += __popcll(__ballot(isStart));
+        if (inBmask) prevSeed = __shfl(seed, 63 - __builtin_clzll(inBmask), 64);
+        if (keepMask) PatKept = __shfl(Pin, 63 - __builtin_clzll(keepMask), 64);
+        P = __shfl(Pin, 63, 64);
+        aLen += __popcll(keepMask);
+    }
+    if (aLen * 2 >= maxLength) return false;
+    if (lane == 0) L.aRed[aLen * 2] = 0;
+    const int maxAIndex = C0 - (nA - aLen);
+    while (startSize > 0 && (2 * (startSize - 1) + 1) > maxAIndex) startSize--;
+    *aLenOut = aLen;
+    *startOut = startSize;
+    return true;
+}
+
+// b seeds that reach searchMatch (:449-457) with the bOffset accumulated since the previous one.  WIDE: 16-byte
+// records {bIndex, bOffset, seed, gap after} for the reg tier, else evIdx/evOff.  Returns the number of events
+// (records beyond `cap` are not stored).
+template <bool WIDE>
+__device__ int wave_b_events(int bN, int k, CWave& L, int cap) {
+    const int lane = dp_lane();
+    const u64 lanesBelow = (1ull << lane) - 1ull;
+    const int nB = bN >> 1;
+    int nE = 0, prevSeed = -1, Q = 0, QatEvent = 0;
+    for (int base = 0; base < nB; base += 64) {
+        const int s = base + lane;
+        const bool valid = s < nB;
+        const int seed = valid ? L.bSegL[2 * s + 1] : -2;
+        const int gapAfter = valid ? L.bSegL[2 * s + 2] : 0;
+        const bool inA = valid && ((L.bFlag[base >> 6] >> lane) & 1ull);
+        const u64 inAmask = __ballot(inA);
+        const u64 below = inAmask & lanesBelow;
+        const int pl = below ? 63 - __builtin_clzll(below) : 0;
+        int pseed = __shfl(seed, pl, 64);
+        if (!below) pseed = prevSeed;
+        const bool last = s >= nB - 1;
+        const int nextRaw = (valid && !last) ? L.bSegL[2 * s + 3] : 0;
+        const bool ev = inA && !(seed == pseed && (last || nextRaw == pseed));
+        const u64 evMask = __ballot(ev);
+        const int Qin = Q + wave_incl_sum((valid && !ev) ? gapAfter + k : 0);
+        const u64 eb = evMask & lanesBelow;
+        const int el = eb ? 63 - __builtin_clzll(eb) : 0;
+        int Qe = __shfl(Qin, el, 64);
+        if (!eb) Qe = QatEvent;
+        if (ev) {
+            const int idx = nE + __popcll(eb);
+            if (idx < cap) {
+                if (WIDE) {
+                    L.ev[idx] = make_int4(2 * s + 1, Qin - Qe, seed, gapAfter);
                 } else {
-                    L.aRed[2 * rank] = Pin - Pk - k;
-                    L.aRed[2 * rank + 1] = seed;
-                    L.aMap[rank] = s;
-                    isStart = rank <= C0 - (s - rank);
+                    L.evIdx[idx] = (uint16_t)(2 * s + 1);
+                    L.evOff[idx] = Qin - Qe;
                 }
             }
-            if (__ballot(bad)) {
-                *err |= 1;
-                return 0;
-            }
-            startSize += __popcll(__ballot(isStart));
-            if (inBmask) prevSeed = __shfl(seed, 63 - __builtin_clzll(inBmask), 64);
-            if (keepMask) PatKept = __shfl(Pin, 63 - __builtin_clzll(keepMask), 64);
-            P = __shfl(Pin, 63, 64);
-            aLen += __popcll(keepMask);
         }
-        if (aLen * 2 >= maxLength) {
-            *err |= 1;
-            return 0;
-        }
-        if (lane == 0) L.aRed[aLen * 2] = 0;
-        const int maxAIndex = C0 - (nA - aLen);
-        while (startSize > 0 && (2 * (startSize - 1) + 1) > maxAIndex) startSize--;
+        if (inAmask) prevSeed = __shfl(seed, 63 - __builtin_clzll(inAmask), 64);
+        if (evMask) QatEvent = __shfl(Qin, 63 - __builtin_clzll(evMask), 64);
+        Q = __shfl(Qin, 63, 64);
+        nE += __popcll(evMask);
     }
+    return nE;
+}
+
+#define RL(v_, l_) __builtin_amdgcn_readlane((v_), (l_))
+#define RFL(v_) __builtin_amdgcn_readfirstlane(v_)
+
+// reg tier.  Returns the length of results[0] (its pairs are left in L.rescol as reducedA | bSeed<<16), 0, or -1 when
+// the pair needs the lds tier.
+__device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, int k, CWave& L, uint32_t* err, bool prof,
+                              u64* tp) {
+    const int lane = dp_lane();
+    if (startSize == 0) return 0;  // no initial position: no chain can ever start
     int live = startSize;
     const int initialSize = startSize;
     const int aRedLen = aLen * 2 + 1;
-    if (prof) {
-        u64 t1 = wall_clock64();
-        tp[0] += t1 - t0;
-        t0 = t1;
+    const int nE = wave_b_events<true>(bN, k, L, C_REV);
+    if (nE > C_REV) return -1;
+    if (prof) tp[2] += (u64)nE;
+    const int myA = lane < aLen ? L.aRed[2 * lane + 1] : -1;
+    {
+        const int myOff = lane < aLen ? L.aRed[2 * lane] : 0;
+        L.ps[lane] = wave_incl_sum(lane < aLen ? myOff + k : 0);  // g(r) - g(r0) = ps[r] - ps[r0]
+    }
+    int st_aPos = 0, st_bPos = 0, st_aGap = 0, st_bGap = 0, st_aGapIndex = 0, st_len = 0;
+    int openSize = 0, resultsSize = 0, firstLen = 0;
+    int maxBIndex = bN - minMatches * 2 + 1;
+    const u64 initMask = initialSize >= 64 ? ~0ull : ((1ull << initialSize) - 1ull);
+
+    // removeOpenState :390-409 for chain i_ (uniform): results[0] keeps a copy of its column
+#define REMOVE_OPEN_R(i_)                                                          \
+    {                                                                              \
+        const int ri_ = (i_);                                                      \
+        const int last_ = openSize - 1;                                            \
+        const int sl_ = RL(st_len, ri_);                                           \
+        if (sl_ >= minMatches) {                                                   \
+            if ((sl_ * 2) / 3 > minMatches) minMatches = (sl_ * 2) / 3;            \
+            if (resultsSize >= C_RESULTS) {                                        \
+                *err |= 4;                                                         \
+                return 0;                                                          \
+            }                                                                      \
+            if (resultsSize == 0) {                                                \
+                firstLen = sl_;                                                    \
+                if (lane < sl_) L.rescol[lane] = L.col[ri_][lane];                 \
+            }                                                                      \
+            resultsSize++;                                                         \
+        } else {                                                                   \
+            live -= sl_;                                                           \
+        }                                                                          \
+        if (ri_ != last_) {                                                        \
+            const int ll_ = RL(st_len, last_);                                     \
+            if (lane < ll_) L.col[ri_][lane] = L.col[last_][lane];                 \
+            const int m0_ = RL(st_aPos, last_), m1_ = RL(st_bPos, last_), m2_ = RL(st_aGap, last_),        \
+                      m3_ = RL(st_bGap, last_), m4_ = RL(st_aGapIndex, last_);     \
+            if (lane == ri_) {                                                     \
+                st_aPos = m0_;                                                     \
+                st_bPos = m1_;                                                     \
+                st_aGap = m2_;                                                     \
+                st_bGap = m3_;                                                     \
+                st_aGapIndex = m4_;                                                \
+                st_len = ll_;                                                      \
+            }                                                                      \
+        }                                                                          \
+        openSize--;                                                                \
     }
 
-    // ---- b seeds that reach searchMatch (:449-457), with the bOffset accumulated since the previous one
-    int nE = 0;
-    {
-        int prevSeed = -1, Q = 0, QatEvent = 0;
-        for (int base = 0; base < nB; base += 64) {
-            const int s = base + lane;
-            const bool valid = s < nB;
-            const int seed = valid ? L.bSegL[2 * s + 1] : -2;
-            const int gapAfter = valid ? L.bSegL[2 * s + 2] : 0;
-            const bool inA = valid && ((L.bFlag[base >> 6] >> lane) & 1ull);
-            const u64 inAmask = __ballot(inA);
-            const u64 below = inAmask & lanesBelow;
-            const int pl = below ? 63 - __builtin_clzll(below) : 0;
-            int pseed = __shfl(seed, pl, 64);
-            if (!below) pseed = prevSeed;
-            const bool last = s >= nB - 1;
-            const int nextRaw = (valid && !last) ? L.bSegL[2 * s + 3] : 0;
-            const bool ev = inA && !(seed == pseed && (last || nextRaw == pseed));
-            const u64 evMask = __ballot(ev);
-            const int Qin = Q + wave_incl_sum((valid && !ev) ? gapAfter + k : 0);
-            const u64 eb = evMask & lanesBelow;
-            const int el = eb ? 63 - __builtin_clzll(eb) : 0;
-            int Qe = __shfl(Qin, el, 64);
-            if (!eb) Qe = QatEvent;
-            if (ev) {
-                const int idx = nE + __popcll(eb);
-                L.evIdx[idx] = (uint16_t)(2 * s + 1);
-                L.evOff[idx] = Qin - Qe;
+    int4 evNext = L.ev[0];
+    for (int e = 0; e < nE; e++) {
+        const int4 evc = evNext;
+        if (e + 1 < nE) evNext = L.ev[e + 1];
+        const int bIndex = RFL(evc.x), bOffset = RFL(evc.y), bSeed = RFL(evc.z), gapAfter = RFL(evc.w);
+        const u64 m = __ballot(myA == bSeed);  // reduced a positions holding this seed
+        int found = -1;
+        if (openSize > 0) {  // searchMatch :465-547
+            int outcome = 0;  // 1 keep, 2 too short, 3 ran off the end of a, 4 extends
+            int bGap = 0, aGap = 0, aGapIndex = 0, xj = -1;
+            if (lane < openSize) {
+                bGap = st_bGap + bOffset;
+                int minGap, maxGap;
+                gap_range(bGap, k, minGap, maxGap);
+                aGap = st_aGap;
+                aGapIndex = st_aGapIndex;
+                bool ended = false;
+                while (aGap < minGap) {
+                    if (aGapIndex >= aRedLen) {
+                        ended = true;
+                        break;
+                    }
+                    aGap += L.aRed[aGapIndex + 1] + k;
+                    aGapIndex += 2;
+                }
+                if (ended) {
+                    outcome = 3;
+                } else {
+                    if (aGap <= maxGap) {
+                        // first reduced position >= the cursor with this seed; gaps grow strictly, so it is the
+                        // window hit iff its cumulative gap is still <= maxGap
+                        const int r0 = aGapIndex >> 1;
+                        const u64 mm = r0 < 64 ? (m >> r0) : 0ull;
+                        if (mm) {
+                            const int r = r0 + __builtin_ctzll(mm);
+                            if (r == r0 || aGap + L.ps[r] - L.ps[r0] <= maxGap) xj = 2 * r + 1;
+                        }
+                    }
+                    if (xj >= 0)
+                        outcome = 4;
+                    else
+                        outcome = (st_len + (bN - bIndex) < minMatches) ? 2 : 1;
+                }
             }
-            if (inAmask) prevSeed = __shfl(seed, 63 - __builtin_clzll(inAmask), 64);
-            if (evMask) QatEvent = __shfl(Qin, 63 - __builtin_clzll(evMask), 64);
-            Q = __shfl(Qin, 63, 64);
-            nE += __popcll(evMask);
+            const u64 brk = __ballot(outcome >= 3);
+            const int ibLane = brk ? 63 - __builtin_clzll(brk) : -1;
+            if (outcome == 1 && lane > ibLane) {
+                st_bGap = bGap + gapAfter + k;
+                st_aGap = aGap;
+                st_aGapIndex = aGapIndex;
+            }
+            u64 shortMask = __ballot(outcome == 2 && lane > ibLane);
+            while (shortMask) {
+                const int ln = 63 - __builtin_clzll(shortMask);
+                shortMask &= ~(1ull << ln);
+                REMOVE_OPEN_R(ln);
+            }
+            if (ibLane >= 0) {
+                if (RL(outcome, ibLane) == 3) {
+                    REMOVE_OPEN_R(ibLane);
+                } else {
+                    const int j = RL(xj, ibLane);
+                    found = j;
+                    if (++live > C_POOLSTATES) {
+                        *err |= 2;
+                        return 0;
+                    }
+                    const int nl = RL(st_len, ibLane) + 1;
+                    const int nextGap = L.aRed[j + 1];
+                    if (lane == ibLane) {
+                        L.col[ibLane][nl - 1] = (uint32_t)(j >> 1) | ((uint32_t)(bIndex >> 1) << 16);
+                        st_aPos = j;
+                        st_bPos = bIndex;
+                        st_aGapIndex = j + 2;
+                        st_aGap = nextGap;
+                        st_bGap = gapAfter;
+                        st_len = nl;
+                    }
+                    if ((nl * 2) / 3 > minMatches) {
+                        minMatches = (nl * 2) / 3;
+                        maxBIndex = bN - minMatches * 2 + 1;
+                    }
+                }
+            }
+        }
+        if (bIndex <= maxBIndex) {  // new chains :550-587
+            u64 mi = m & initMask;
+            while (mi) {
+                const int i = __builtin_ctzll(mi);
+                mi &= mi - 1;
+                const int aPos = 2 * i + 1;
+                if (aPos == found) continue;
+                if (found != -1) {
+                    if (__ballot(lane < openSize && st_bPos == bIndex && st_aPos == aPos)) found = aPos;
+                }
+                if (found == aPos) continue;
+                if (openSize >= 64) return -1;  // the reference keeps up to 500 open chains: lds tier
+                if (++live > C_POOLSTATES) {
+                    *err |= 2;
+                    return 0;
+                }
+                const int nextGap = L.aRed[aPos + 1];
+                if (lane == openSize) {
+                    L.col[openSize][0] = (uint32_t)i | ((uint32_t)(bIndex >> 1) << 16);
+                    st_aPos = aPos;
+                    st_bPos = bIndex;
+                    st_aGapIndex = aPos + 2;
+                    st_aGap = nextGap;
+                    st_bGap = gapAfter;
+                    st_len = 1;
+                }
+                openSize++;
+            }
         }
     }
+#undef REMOVE_OPEN_R
+    // :597-604
+    const u64 okMask = __ballot(lane < openSize && st_len >= minMatches);
+    if (okMask) {
+        const int cnt = __popcll(okMask);
+        if (resultsSize + cnt > C_RESULTS) {
+            *err |= 4;
+            return 0;
+        }
+        if (resultsSize == 0) {
+            const int f = __builtin_ctzll(okMask);
+            firstLen = RL(st_len, f);
+            if (lane < firstLen) L.rescol[lane] = L.col[f][lane];
+        }
+        resultsSize += cnt;
+    }
+    return resultsSize ? firstLen : 0;
+}
+
+// lds tier.  Returns the length of results[0] or 0; *resNode = its last node.
+__device__ int wave_chain_lds(int aLen, int startSize, int bN, int minMatches, int k, CWave& L, CNode* __restrict__ nodes,
+                              int* resNode, uint32_t* err) {
+    const int lane = dp_lane();
+    int nNodes = 0;
+    int live = startSize;
+    const int initialSize = startSize;
+    const int aRedLen = aLen * 2 + 1;
+    const int nE = wave_b_events<false>(bN, k, L, C_BCAP / 2);
 
     // reduced a seeds, one per lane and 64-position block, for the per-event equality masks
     int myA[4];
@@ -789,11 +1008,6 @@ __device__ int pairwise_align_wave(int aN, int bN, int minMatches, int k, int ma
 
     int openSize = 0, resultsSize = 0, firstLen = 0, firstNode = -1;
     int maxBIndex = bN - minMatches * 2 + 1;
-    if (prof) {
-        u64 t1 = wall_clock64();
-        tp[1] += t1 - t0;
-        tp[2] += (u64)nE;
-    }
 
     // removeOpenState :390-409 for chain i_ (wave-uniform)
 #define REMOVE_OPEN_W(i_)                                                          \
@@ -1003,12 +1217,14 @@ __device__ int pairwise_align_wave(int aN, int bN, int minMatches, int k, int ma
     return resultsSize ? firstLen : 0;
 }
 
+
 struct MRec {
     uint32_t q, t;
     uint32_t off, len;
 };
 
-// cursor: [0] records, [1] ints, [2] error bits, [3] overflow flag
+// cursor: u64 at [0..1] = ints (low) | record slots (high); [2] error bits, [3] overflow flag.
+// tier: 0 automatic, 2 forces the lds tier, 3 the one-lane tier (tests).
 __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
                                                              uint32_t nq, const u64* __restrict__ qsets,
                                                              const uint32_t* __restrict__ qmeta, const u64* __restrict__ cand,
@@ -1017,7 +1233,7 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                                                              const int32_t* __restrict__ mc, uint32_t mc_n, int k, int maxLength,
                                                              CNode* __restrict__ pool, MRec* __restrict__ recs, uint32_t rec_cap,
                                                              int32_t* __restrict__ ma, int32_t* __restrict__ mb, uint32_t int_cap,
-                                                             uint32_t* __restrict__ cursor, u64* __restrict__ dbg) {
+                                                             uint32_t* __restrict__ cursor, int tier, u64* __restrict__ dbg) {
     __shared__ CWave sh[C_WAVES];
     CWave& L = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
@@ -1031,10 +1247,14 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
         const int aN = (int)(qoff[q + 1] - qoff[q]);
         const uint32_t nSeeds = (uint32_t)aN / 2;
         const u64* qset = qsets + (uint64_t)q * SW;
-        const bool aStaged = aN <= C_ACAP;
+        const bool aStaged = aN <= C_ACAP && tier != 3;
         if (aStaged) {
             for (int i = lane; i < aN; i += 64) L.aSegL[i] = aSeg[i];
+            if (SW <= C_QSW) {
+                for (uint32_t i = lane; i < SW; i += 64) L.qsetL[i] = qset[i];
+            }
         }
+        const u64* qs = (aStaged && SW <= C_QSW) ? (const u64*)L.qsetL : qset;
         int minMatches = nSeeds < mc_n ? mc[nSeeds] : 0x7fffffff;  // int(hitFraction*numSeeds+0.5), overlap.go:356
         u64 tq0 = dbg ? wall_clock64() : 0, tAlign = 0, tExtract = 0, tStage = 0, nCand = 0, nPairs = 0;
         u64 tp[3] = {0, 0, 0};
@@ -1050,65 +1270,102 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                 // CountIntersectionTo(seedSet, minMatches) < minMatches  (overlap.go:359; the asm's early exit only
                 // ever returns a value >= maxCount, so the comparison equals the one on the full popcount)
                 int c = 0;
-                for (uint32_t w = lane; w < SW; w += 64) c += __popcll(tset[w] & qset[w]);
+                for (uint32_t w = lane; w < SW; w += 64) c += __popcll(tset[w] & qs[w]);
                 c = wave_sum(c);
                 if (c < minMatches) continue;
                 const dp_seq_ref r = refs[t];
                 const int32_t* bSeg = segs + r.seg_off;
                 const int bN = (int)(2 * r.n_seeds + 1);
                 const bool staged = aStaged && bN <= C_BCAP;
+                int bound = (int)nSeeds;  // upper bound of the chain length: a seeds present in b
                 if (staged) {  // stage b and both membership bit vectors with the whole wave
                     for (int i = lane; i < bN; i += 64) L.bSegL[i] = bSeg[i];
+                    bound = 0;
                     for (int base = 0; base < (int)nSeeds; base += 64) {
                         const int s = base + lane;
                         bool f = false;
-                        if (s < (int)nSeeds) f = bs_contains(tset, aSeg[2 * s + 1]);
+                        if (s < (int)nSeeds) f = bs_contains(tset, L.aSegL[2 * s + 1]);
                         const u64 m = __ballot(f);
+                        bound += __popcll(m);
                         if (lane == 0) L.aFlag[base >> 6] = m;
                     }
                     for (int base = 0; base < (int)r.n_seeds; base += 64) {
                         const int s = base + lane;
                         bool f = false;
-                        if (s < (int)r.n_seeds) f = bs_contains(qset, bSeg[2 * s + 1]);
+                        if (s < (int)r.n_seeds) f = bs_contains(qs, L.bSegL[2 * s + 1]);
                         const u64 m = __ballot(f);
                         if (lane == 0) L.bFlag[base >> 6] = m;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
                 }
-                int resLen = 0, resNode = -1;
+                // reserve one record slot and `bound` ints now; the reply is only needed after the chaining
+                u64 slot = 0;
+                if (lane == 0) slot = atomicAdd((unsigned long long*)cursor, (1ull << 32) | (u64)(uint32_t)bound);
+                int resLen = 0, resNode = -1, usedTier = 3;
                 uint32_t err = 0;
                 nPairs++;
                 u64 ta0 = dbg ? wall_clock64() : 0;
                 tStage += ta0 - ts0;
                 if (staged) {
-                    resLen = pairwise_align_wave(aN, bN, minMatches, k, maxLength, L, nodes, &resNode, &err, dbg != nullptr, tp);
-                } else if (lane == 0) {
-                    resLen = pairwise_align(aSeg, aN, bSeg, bN, qset, tset, nullptr, nullptr, minMatches, k, maxLength, L, nodes,
-                                            &resNode, &err);
+                    int mm = minMatches == 0 ? 1 : minMatches;
+                    int aLen = 0, startSize = 0;
+                    u64 t0 = dbg ? wall_clock64() : 0;
+                    if (!wave_prepare_initial(aN, mm, k, maxLength, L, &aLen, &startSize)) {
+                        err |= 1;
+                        usedTier = 0;
+                    } else {
+                        if (dbg) tp[0] += wall_clock64() - t0;
+                        resLen = -1;
+                        if (aLen <= 64 && tier == 0) {
+                            resLen = wave_chain_reg(aLen, startSize, bN, mm, k, L, &err, dbg != nullptr, tp);
+                            usedTier = 1;
+                        }
+                        if (resLen < 0) {
+                            resLen = wave_chain_lds(aLen, startSize, bN, mm, k, L, nodes, &resNode, &err);
+                            usedTier = 2;
+                        }
+                    }
+                } else {
+                    if (lane == 0)
+                        resLen = pairwise_align(aSeg, aN, bSeg, bN, qset, tset, nullptr, nullptr, minMatches, k, maxLength, L, nodes,
+                                                &resNode, &err);
+                    resLen = __shfl(resLen, 0, 64);
+                    resNode = __shfl(resNode, 0, 64);
                 }
-                resLen = __shfl(resLen, 0, 64);
                 u64 ta1 = dbg ? wall_clock64() : 0;
                 tAlign += ta1 - ta0;
                 if (lane == 0 && err) atomicOr(&cursor[2], err);
-                if (resLen > 0) {
-                    if (lane == 0) {
-                        uint32_t ri = atomicAdd(&cursor[0], 1u);
-                        uint32_t off = atomicAdd(&cursor[1], (uint32_t)resLen);
-                        if (ri < rec_cap && off + (uint32_t)resLen <= int_cap) {
-                            MRec rec = {q, t, off, (uint32_t)resLen};
+                if (err) resLen = 0;
+                {
+                    const uint32_t s_lo = (uint32_t)__shfl((int)(uint32_t)slot, 0, 64);
+                    const uint32_t s_hi = (uint32_t)__shfl((int)(uint32_t)(slot >> 32), 0, 64);
+                    const uint32_t off = s_lo, ri = s_hi;
+                    if (ri < rec_cap && (u64)off + (u64)bound <= (u64)int_cap) {
+                        if (lane == 0) {
+                            MRec rec = {q, t, off, (uint32_t)(resLen > 0 ? resLen : 0)};
                             recs[ri] = rec;
-                            int node = resNode;
-                            for (int x = resLen - 1; x >= 0 && node >= 0; x--) {  // extractMatch :326-335
-                                CNode nd = node_get(L, nodes, node);
-                                ma[off + x] = nd.a;
-                                mb[off + x] = nd.b;
-                                node = nd.prev;
-                            }
-                        } else {
-                            cursor[3] = 1;
                         }
+                        if (resLen > 0) {
+                            if (usedTier == 1) {  // pairs sit in the result column
+                                if (lane < resLen) {
+                                    const uint32_t v = L.rescol[lane];
+                                    ma[off + lane] = L.aMap[v & 0xffffu];
+                                    mb[off + lane] = (int32_t)(v >> 16);
+                                }
+                            } else if (lane == 0) {
+                                int node = resNode;
+                                for (int x = resLen - 1; x >= 0 && node >= 0; x--) {  // extractMatch :326-335
+                                    CNode nd = node_get(L, nodes, node);
+                                    ma[off + x] = nd.a;
+                                    mb[off + x] = nd.b;
+                                    node = nd.prev;
+                                }
+                            }
+                        }
+                    } else if (lane == 0) {
+                        cursor[3] = 1;
                     }
+                }
+                if (resLen > 0) {
                     if (resLen * 2 > minMatches * 3) minMatches = (resLen * 2) / 3;  // ratchet, overlap.go:380-382
                     if (dbg) tExtract += wall_clock64() - ta1;
                 }
@@ -1211,6 +1468,8 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     uint32_t cur[16];
     float chain_ms = 0;
     static const bool chain_debug = getenv("DP_CHAIN_DEBUG") != nullptr;
+    const char* tier_env = getenv("DP_CHAIN_TIER");  // tests: 2 = lds tier, 3 = one-lane tier for every pair
+    const int chain_tier = tier_env ? atoi(tier_env) : 0;
     u64* d_dbg = nullptr;
     if (chain_debug) {
         DP_HIP(hipMalloc((void**)&d_dbg, (size_t)nq * 64));
@@ -1227,7 +1486,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
                            (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p,
                            (const u64*)ctx->d_seedsets.p, W, SW, (const int32_t*)d_mc, mc_n, k, (int)max_query_len,
                            (CNode*)ctx->d_pool.p, (MRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p,
-                           int_cap, (uint32_t*)ctx->d_cursor.p, d_dbg);
+                           int_cap, (uint32_t*)ctx->d_cursor.p, chain_tier, d_dbg);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         DP_HIP(hipMemcpyAsync(cur, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -1235,9 +1494,9 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         float ms = 0;
         hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]);
         chain_ms += ms;
-        if (cur[3] || cur[0] > rec_cap || cur[1] > int_cap) {
-            rec_cap = std::max(rec_cap * 2, cur[0] + 1024);
-            int_cap = std::max(int_cap * 2, cur[1] + 1024);
+        if (cur[3] || cur[1] > rec_cap || cur[0] > int_cap) {  // [0] ints reserved, [1] record slots
+            rec_cap = std::max(rec_cap * 2, cur[1] + 1024);
+            int_cap = std::max(int_cap * 2, cur[0] + 1024);
             continue;
         }
         break;
@@ -1273,22 +1532,23 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         return dp_fail(ctx, DP_ERR_CAPACITY, msg);
     }
     // fetch + canonical order: queries ascending, targets ascending (each query was walked by one wave in order)
-    const uint32_t nm = cur[0], ni = cur[1];
-    if (pin_reserve(ctx, ctx->h_mrec, (size_t)nm * sizeof(MRec) + 16)) return DP_ERR_HIP;
-    if (pin_reserve(ctx, ctx->h_ma, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
-    if (pin_reserve(ctx, ctx->h_mb, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
-    if (pin_reserve(ctx, ctx->h_mq, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
-    if (pin_reserve(ctx, ctx->h_mt, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
-    if (pin_reserve(ctx, ctx->h_moff, ((size_t)nm + 1) * 8)) return DP_ERR_HIP;
-    std::vector<uint32_t> qm((size_t)nq * 4);
-    std::vector<u64> words(nq);
-    DP_HIP(hipMemcpyAsync(qm.data(), d_qmeta, (size_t)nq * 16, hipMemcpyDeviceToHost, ctx->stream));
-    DP_HIP(hipMemcpyAsync(words.data(), d_words, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<int32_t> ta(ni), tb(ni);
-    if (nm) {
-        DP_HIP(hipMemcpyAsync(ctx->h_mrec.p, ctx->d_mrec.p, (size_t)nm * sizeof(MRec), hipMemcpyDeviceToHost, ctx->stream));
-        DP_HIP(hipMemcpyAsync(ta.data(), ctx->d_ma.p, (size_t)ni * 4, hipMemcpyDeviceToHost, ctx->stream));
-        DP_HIP(hipMemcpyAsync(tb.data(), ctx->d_mb.p, (size_t)ni * 4, hipMemcpyDeviceToHost, ctx->stream));
+    const uint32_t nslots = cur[1], ni = cur[0];  // one slot per chained pair; len 0 = no chain
+    if (pin_reserve(ctx, ctx->h_mrec, (size_t)nslots * sizeof(MRec) + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_ta, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_tb, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_qm, (size_t)nq * 24 + 16)) return DP_ERR_HIP;
+    uint32_t* qm = (uint32_t*)ctx->h_qm.p;
+    u64* words = (u64*)((uint8_t*)ctx->h_qm.p + (size_t)nq * 16);
+    DP_HIP(hipMemcpyAsync(qm, d_qmeta, (size_t)nq * 16, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(hipMemcpyAsync(words, d_words, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    const int32_t* ta = (const int32_t*)ctx->h_ta.p;
+    const int32_t* tb = (const int32_t*)ctx->h_tb.p;
+    if (nslots) {
+        DP_HIP(hipMemcpyAsync(ctx->h_mrec.p, ctx->d_mrec.p, (size_t)nslots * sizeof(MRec), hipMemcpyDeviceToHost, ctx->stream));
+        if (ni) {
+            DP_HIP(hipMemcpyAsync(ctx->h_ta.p, ctx->d_ma.p, (size_t)ni * 4, hipMemcpyDeviceToHost, ctx->stream));
+            DP_HIP(hipMemcpyAsync(ctx->h_tb.p, ctx->d_mb.p, (size_t)ni * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
     }
     if (want_candidates) {
         if (pin_reserve(ctx, ctx->h_cand, (size_t)nq * W * 8 + 16)) return DP_ERR_HIP;
@@ -1300,8 +1560,20 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         out->query_bytes += words[q] * 8;
     }
     MRec* recs = (MRec*)ctx->h_mrec.p;
-    std::vector<uint32_t> order(nm);
-    for (uint32_t i = 0; i < nm; i++) order[i] = i;
+    std::vector<uint32_t> order;
+    order.reserve(nslots);
+    uint64_t total_len = 0;
+    for (uint32_t i = 0; i < nslots; i++)
+        if (recs[i].len) {
+            order.push_back(i);
+            total_len += recs[i].len;
+        }
+    const uint32_t nm = (uint32_t)order.size();
+    if (pin_reserve(ctx, ctx->h_ma, (size_t)total_len * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_mb, (size_t)total_len * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_mq, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_mt, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_moff, ((size_t)nm + 1) * 8)) return DP_ERR_HIP;
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         if (recs[a].q != recs[b].q) return recs[a].q < recs[b].q;
         return recs[a].t < recs[b].t;
@@ -1317,8 +1589,8 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         mq[i] = r.q;
         mt[i] = r.t;
         moff[i] = pos;
-        memcpy(fa + pos, ta.data() + r.off, (size_t)r.len * 4);
-        memcpy(fb + pos, tb.data() + r.off, (size_t)r.len * 4);
+        memcpy(fa + pos, ta + r.off, (size_t)r.len * 4);
+        memcpy(fb + pos, tb + r.off, (size_t)r.len * 4);
         pos += r.len;
     }
     moff[nm] = pos;

@@ -1,6 +1,8 @@
 """GPU parity tests (run with `-m gpu` on an MI355X): every HIP stage called through the C ABI
 (include/downpore_hip.h) is compared bit-for-bit with the ORACLE's per-round trace on the same seeded inputs.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -144,6 +146,15 @@ def test_scan_index_query_chain(ctx, k, G, N, L, e):
         assert np.array_equal(out["off"].astype(np.int64), mao)
         assert np.array_equal(out["match_a"].astype(np.int64), ma)
         assert np.array_equal(out["match_b"].astype(np.int64), mb)
+        # the chain kernel's slower tiers (open chains in LDS; one-lane transcription) must give the same chains
+        for tier in ("2", "3"):
+            os.environ["DP_CHAIN_TIER"] = tier
+            try:
+                o2 = ctx.find_overlaps(qsegs, qoffs.astype(np.uint64), 0.25, k, 500, want_candidates=False)
+            finally:
+                del os.environ["DP_CHAIN_TIER"]
+            for key in ("query", "target", "off", "match_a", "match_b"):
+                assert np.array_equal(np.asarray(o2[key]), np.asarray(out[key])), (tier, key)
 
         for r in run.trace(rnd, "newlyIgnored"):
             ignore[int(r)] = 1
