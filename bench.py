@@ -86,6 +86,7 @@ def main():
         if c == 0:
             break
         warm += c
+    pipe.drain()  # rounds the executor pipeline has in flight are thrown away: the timed region starts from an empty pipeline
     sync()
     acc = {}
     lines = 0

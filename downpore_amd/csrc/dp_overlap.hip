@@ -1409,9 +1409,16 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     uint32_t* d_qmeta = (uint32_t*)ctx->d_qmeta.p;
     u64* d_words = (u64*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 16);
     int32_t* d_mc = (int32_t*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 16 + (size_t)nq * 8);
-    DP_HIP(hipMemcpyAsync(ctx->d_qsegs.p, q_segs, nseg * 4, hipMemcpyHostToDevice, ctx->stream));
-    DP_HIP(hipMemcpyAsync(ctx->d_qoff.p, q_off, ((size_t)nq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    DP_HIP(hipMemcpyAsync(d_mc, mc.data(), (size_t)mc_n * 4, hipMemcpyHostToDevice, ctx->stream));
+    // stage through pinned memory: copies from pageable buffers stall the stream
+    const size_t up_segs = nseg * 4, up_off = ((size_t)nq + 1) * 8, up_mc = (size_t)mc_n * 4;
+    if (pin_reserve(ctx, ctx->h_qup, up_segs + up_off + up_mc + 64)) return DP_ERR_HIP;
+    uint8_t* up = (uint8_t*)ctx->h_qup.p;
+    memcpy(up, q_off, up_off);
+    memcpy(up + up_off, q_segs, up_segs);
+    memcpy(up + up_off + up_segs, mc.data(), up_mc);
+    DP_HIP(hipMemcpyAsync(ctx->d_qoff.p, up, up_off, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->d_qsegs.p, up + up_off, up_segs, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(d_mc, up + up_off + up_segs, up_mc, hipMemcpyHostToDevice, ctx->stream));
     DP_HIP(hipMemsetAsync(ctx->d_qsets.p, 0, (size_t)nq * SW * 8, ctx->stream));
     DP_HIP(hipMemsetAsync(ctx->d_cand.p, 0, (size_t)nq * W * 8, ctx->stream));
     DP_HIP(hipMemsetAsync(d_qmeta, 0, (size_t)nq * 16 + (size_t)nq * 8, ctx->stream));
@@ -1489,8 +1496,9 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
                            int_cap, (uint32_t*)ctx->d_cursor.p, chain_tier, d_dbg);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
-        DP_HIP(hipMemcpyAsync(cur, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipMemcpyAsync(ctx->h_cursor.p, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(hipStreamSynchronize(ctx->stream));
+        memcpy(cur, ctx->h_cursor.p, 64);
         float ms = 0;
         hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]);
         chain_ms += ms;
@@ -1574,10 +1582,23 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     if (pin_reserve(ctx, ctx->h_mq, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_mt, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_moff, ((size_t)nm + 1) * 8)) return DP_ERR_HIP;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        if (recs[a].q != recs[b].q) return recs[a].q < recs[b].q;
-        return recs[a].t < recs[b].t;
-    });
+    {  // canonical order: queries ascending, targets ascending.  A query's slots were reserved by one wave in candidate
+       // order, so a stable bucket pass over the query id is enough; verified below (falls back to a full sort).
+        std::vector<uint32_t> start((size_t)nq + 1, 0), sorted(nm);
+        for (uint32_t i : order) start[recs[i].q + 1]++;
+        for (uint32_t q = 0; q < nq; q++) start[q + 1] += start[q];
+        for (uint32_t i : order) sorted[start[recs[i].q]++] = i;
+        order.swap(sorted);
+        bool ok = true;
+        for (uint32_t i = 1; i < nm && ok; i++)
+            ok = recs[order[i - 1]].q < recs[order[i]].q ||
+                 (recs[order[i - 1]].q == recs[order[i]].q && recs[order[i - 1]].t < recs[order[i]].t);
+        if (!ok)
+            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+                if (recs[a].q != recs[b].q) return recs[a].q < recs[b].q;
+                return recs[a].t < recs[b].t;
+            });
+    }
     uint32_t* mq = (uint32_t*)ctx->h_mq.p;
     uint32_t* mt = (uint32_t*)ctx->h_mt.p;
     uint64_t* moff = (uint64_t*)ctx->h_moff.p;

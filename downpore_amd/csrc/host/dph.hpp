@@ -10,6 +10,14 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <cstring>
+#include <new>
+#include <algorithm>
+#include <deque>
+#include <mutex>
+#include <condition_variable>
+#include <thread>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -70,21 +78,41 @@ struct SeedMatch {  // seeds/sequence.go:24-32
     bool ReverseComplementQuery = false;
 };
 
-// per-round arena (Go GC stand-in)
+// per-round arena (Go GC stand-in): bump allocation out of slabs that are kept across clear()
 struct Arena {
-    std::vector<std::unique_ptr<SeedSeq>> seqs;
-    std::vector<std::unique_ptr<std::vector<int32_t>>> stores;
-    SeedSeq* make() {
-        seqs.emplace_back(new SeedSeq());
-        return seqs.back().get();
+    struct Slab {
+        std::unique_ptr<char[]> p;
+        size_t cap = 0, used = 0;
+    };
+    std::vector<Slab> slabs;
+    size_t cur = 0;
+    void* raw(size_t bytes, size_t align) {
+        for (;;) {
+            if (cur < slabs.size()) {
+                Slab& s = slabs[cur];
+                const size_t at = (s.used + align - 1) & ~(align - 1);
+                if (at + bytes <= s.cap) {
+                    s.used = at + bytes;
+                    return s.p.get() + at;
+                }
+                cur++;
+                continue;
+            }
+            Slab s;
+            s.cap = std::max<size_t>(bytes + align, (size_t)1 << 20);
+            s.p.reset(new char[s.cap]);
+            slabs.push_back(std::move(s));
+        }
     }
+    SeedSeq* make() { return new (raw(sizeof(SeedSeq), alignof(SeedSeq))) SeedSeq(); }
     int32_t* alloc(size_t n) {
-        stores.emplace_back(new std::vector<int32_t>(n, 0));
-        return stores.back()->data();
+        int32_t* p = (int32_t*)raw(n * sizeof(int32_t) + 4, alignof(int32_t));
+        memset(p, 0, n * sizeof(int32_t));
+        return p;
     }
     void clear() {
-        seqs.clear();
-        stores.clear();
+        for (Slab& s : slabs) s.used = 0;
+        cur = 0;
     }
 };
 
@@ -202,7 +230,8 @@ class Overlapper {
     // chunkWorker (:253) + IndexSequences on the GPU, from the (possibly all-gathered) survivors
     int IndexSurvivors(const Survivors& all, RoundStats& st);
     // FindOverlaps (:320): Matches + prefilter + chaining + ratchet on the GPU
-    int FindOverlaps(std::vector<std::unique_ptr<SeedMatch>>& out, RoundStats& st);
+    // `pool` is storage reused across rounds (its SeedMatch objects keep their vector capacity); out points into it
+    int FindOverlaps(std::vector<SeedMatch>& pool, std::vector<SeedMatch*>& out, RoundStats& st);
     void SetOverlapSize(i64 size) { overlap_ = size; }
     std::vector<SeedQuery> queries;
     std::string err;
@@ -235,14 +264,20 @@ class Overlapper {
     std::vector<int32_t> allSegs_;         // survivors' segments (host copy; device copy is what the index references)
 };
 
-unsigned hostThreads();  // DP_HOST_THREADS or hardware_concurrency, split between concurrent executor slots (<= 32 each)
+unsigned hostThreads();  // DP_HOST_THREADS or hardware_concurrency (<= 96): size of the shared worker pool
 void setHostThreadShare(unsigned concurrentUsers);
+void profilePrint();  // DPH_PROFILE counters to stderr
+// Runs fn(i) for every i in [0, n) on the process-wide worker pool plus the calling thread and returns when all calls
+// have finished.  Concurrent callers (executor slots, the planner) share the pool; jobs are served oldest first.
+void parallelFor(size_t n, const std::function<void(size_t)>& fn);
 // finalCheckWorker (commands/overlap.go:197-233) over the collated matches of a round: consensus, SetIgnore, PAF text.
 struct FinalCheckStats {
     i64 badBack = 0, emptyMatch = 0;
     uint64_t lines = 0, hits = 0, qHits = 0;
 };
 // SetIgnore calls are returned in ignoreOut (query order) when it is non-null, otherwise applied to reads.ignore.
+void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, const std::vector<SeedMatch*>& matches, i64 numQuerySeqs,
+                i64 overlapSize, std::string& paf, FinalCheckStats& fs, std::vector<int>* ignoreOut = nullptr);
 void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vector<std::unique_ptr<SeedMatch>>& matches,
                 i64 numQuerySeqs, i64 overlapSize, std::string& paf, FinalCheckStats& fs, std::vector<int>* ignoreOut = nullptr);
 
@@ -285,6 +320,8 @@ struct RoundResult {
     std::string paf;
     std::vector<int> ignores;            // SetIgnore calls of this round, in order
     std::vector<uint32_t> indexedReads;  // read ids that entered the index (for speculation checks)
+    std::vector<uint32_t> queryReads;    // read ids of the query windows
+    i64 snapshot = 0;                    // rounds committed when the execution started (pipeline mode)
     FinalCheckStats fs;
     RoundStats st;
 };
@@ -296,6 +333,8 @@ struct ExecSlot {
     std::unique_ptr<SeedIndex> index;  // executor-side seed maps of the running round
     std::unique_ptr<Overlapper> lap;
     Survivors local;
+    std::vector<SeedMatch> matchPool;  // reused across rounds
+    std::vector<SeedMatch*> matches;
     std::string error;
 };
 
@@ -327,6 +366,8 @@ struct OverlapRun {
     // ---- whole rounds on this process: plans (prefetched) -> execute (one round per slot, concurrently) -> commit in order.
     // Returns the number of rounds committed, 0 = finished, <0 error
     int step();
+    // discards everything the executor pipeline has in flight (bench: start the timed region from an empty pipeline)
+    void drain();
     // executes rounds[i] on slot i concurrently (host threads); outs[i] receives the result
     int executeRounds(const std::vector<i64>& rounds, std::vector<RoundResult>& outs);
     // ---- scan-shard mode (survivor all-gather between the two halves)
@@ -343,6 +384,22 @@ struct OverlapRun {
     int beginRound(ExecSlot& s, const RoundPlan& plan);
     int finishRound(ExecSlot& s, const Survivors& all, RoundResult& out);
     void commitOne(RoundResult& r);
+    // executor pipeline behind step(): every slot has a worker thread that keeps executing the next uncommitted round
+    // speculatively; step() commits finished rounds in order and re-queues the ones a later-arriving ignore flag
+    // invalidated
+    void startWorkers();
+    void workerMain(size_t slot);
+    bool resultValid(const RoundResult& r) const;
+    std::vector<std::thread> workers_;
+    std::mutex pmu_;
+    std::condition_variable cvWork_, cvDone_;
+    std::map<i64, RoundResult> ready_;
+    std::deque<i64> redo_;
+    i64 nextIssue_ = 0;
+    int inflight_ = 0, workerRc_ = 0;
+    bool stopWorkers_ = false, issueEnd_ = false, draining_ = false;
+    std::string workerErr_;
+    std::vector<int32_t> flagRound_;  // round whose commit flagged each read, -1 = not flagged by this run
 };
 
 // ---- mapping.Mapper / `downpore map` (mapping/mapping.go, commands/map.go) ----------------------------------------

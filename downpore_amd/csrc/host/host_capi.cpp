@@ -173,6 +173,9 @@ int dph_overlap_step(void* hh) {
     return rc;
 }
 int64_t dph_overlap_round(void* hh) { return ((OverlapH*)hh)->run.round; }
+void dph_profile_print() { profilePrint(); }
+// discards the executor pipeline's in-flight rounds (they are re-executed): a timed region then starts from an empty pipeline
+void dph_overlap_drain(void* hh) { ((OverlapH*)hh)->run.drain(); }
 
 // ---- round-parallel mode: a rank executes ONE round speculatively and serialises the result; every rank then commits
 // the gathered results in round order with the speculation check (OverlapRun::commitResults).

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <thread>
+#include <sys/resource.h>
 #include <cstdio>
 #include <cstring>
 
@@ -17,6 +18,42 @@ namespace dph {
 static double now() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+unsigned hostThreads();
+// DPH_PROFILE=1: pipeline counters printed to stderr when a run shuts down
+struct PipeProfile {
+    std::atomic<long long> executed{0}, committed{0}, rejected{0}, discarded{0}, ignores{0}, planComputes{0}, planErased{0},
+        planDiscarded{0};
+    std::atomic<long long> planUs{0}, getWaitUs{0}, execUs{0}, commitUs{0}, consensusCpuUs{0};
+    std::atomic<long long> sub[16];
+    const char* subName[16] = {"prep.indexReset", "prep.newOverlapper", "prep.roundBegin", "scan.call", "scan.copy", "idx.copy",
+                               "idx.chunk", "idx.build", "idx.queries", "qry.call", "qry.matches", "fc.collate", "fc.parallel",
+                               "fc.merge", "round.total", "round.tail"};
+    PipeProfile() {
+        for (auto& x : sub) x = 0;
+    }
+    void add(int i, double sec) { sub[i] += (long long)(sec * 1e6); }
+    bool on = getenv("DPH_PROFILE") != nullptr;
+    void print() {
+        if (!on) return;
+        fprintf(stderr,
+                "[pipe] rounds executed %lld committed %lld rejected %lld discarded %lld | new ignores %lld | plans computed %lld "
+                "(%.2f ms each) erased %lld thrown away %lld | plan wait %.1f ms, execute %.1f ms, commit %.1f ms\n",
+                executed.load(), committed.load(), rejected.load(), discarded.load(), ignores.load(), planComputes.load(),
+                planComputes.load() ? planUs.load() / 1e3 / planComputes.load() : 0.0, planErased.load(), planDiscarded.load(),
+                getWaitUs.load() / 1e3, execUs.load() / 1e3, commitUs.load() / 1e3);
+        const double n = (double)std::max<long long>(1, executed.load());
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        fprintf(stderr, "[pipe] host threads %u, process CPU time user %.2f s sys %.2f s\n", hostThreads(),
+                ru.ru_utime.tv_sec + ru.ru_utime.tv_usec / 1e6, ru.ru_stime.tv_sec + ru.ru_stime.tv_usec / 1e6);
+        fprintf(stderr, "[pipe] consensus CPU per round %.2f ms\n", consensusCpuUs.load() / 1e3 / std::max<long long>(1, executed.load()));
+        fprintf(stderr, "[pipe] per executed round (ms):");
+        for (int i = 0; i < 16; i++) fprintf(stderr, " %s %.3f", subName[i], sub[i].load() / 1e3 / n);
+        fprintf(stderr, "\n");
+    }
+};
+static PipeProfile g_prof;
 
 Overlapper::Overlapper(dp_ctx* ctx, ReadSet& reads, SeedIndex& index, i64 chunkSize, int, i64 overlap, int minSeeds,
                        double hitFraction)
@@ -63,23 +100,11 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values
         spec.resize(n * (size_t)numSeeds);
         const size_t first = specDone;
         if (n <= first) return;
-        unsigned nt = std::min<unsigned>(hostThreads(), (unsigned)((n - first + 7) / 8));
-        std::atomic<size_t> next(first);
-        auto worker = [&]() {
-            for (;;) {
-                const size_t w = next.fetch_add(1);
-                if (w >= n) break;
-                const Cand& c = cand[w];
-                index_.selectSeeds(reads_.seq(c.read) + c.start, c.len, numSeeds, values, &spec[w * (size_t)numSeeds], false);
-            }
-        };
-        if (nt <= 1) {
-            worker();
-        } else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; t++) th.emplace_back(worker);
-            for (auto& x : th) x.join();
-        }
+        parallelFor(n - first, [&](size_t i) {
+            const size_t w = first + i;
+            const Cand& c = cand[w];
+            index_.selectSeeds(reads_.seq(c.read) + c.start, c.len, numSeeds, values, &spec[w * (size_t)numSeeds], false);
+        });
         specDone = n;
     };
     speculate(want);
@@ -126,12 +151,15 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
         items.push_back(it);
     }
     dp_survivor_batch b;
+    const double ts0 = now();
     int rc = dp_scan_reads(ctx_, ignore_, ignoreEpoch_, (uint32_t)lo, (uint32_t)hi, reads_.himem ? 0 : 1, (uint32_t)minSeeds_,
                            items.data(), (uint32_t)items.size(), &b);
     if (rc != 0) {
         err = dp_last_error(ctx_);
         return rc;
     }
+    const double ts1 = now();
+    g_prof.add(3, ts1 - ts0);
     st.k_scan_ms += b.kernel_ms;
     st.k_count_ms += b.count_kernel_ms;
     st.k_write_ms += b.write_kernel_ms;
@@ -155,6 +183,7 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
         winOff_.push_back(winSegs_.size());
     }
     st.n_hits += b.n_segs / 2;  // hits written this scan, for the roofline's algorithmic bytes
+    g_prof.add(4, now() - ts1);
     return 0;
 }
 
@@ -223,6 +252,7 @@ void Overlapper::chunkAndAdd(SeedSeq* s, uint64_t segBase) {
 
 // AddSequences :217 (chunk + index part) from the complete survivor list (file order).
 int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
+    double tp0 = now();
     allSegs_ = all.segs;
     // the device-resident scan output the index refers to must hold exactly this survivor array at the same offsets:
     // true right after a local full scan; after a multi-GPU exchange the gathered array is imported
@@ -234,6 +264,8 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
     }
     index_.sequences.clear();
     index_.refs.clear();
+    double tp1 = now();
+    g_prof.add(5, tp1 - tp0);
     for (size_t i = 0; i < all.read.size(); i++) {
         const uint32_t r = all.read[i];
         SeedSeq* s = index_.arena.make();
@@ -245,11 +277,15 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
         s->inset = reads_.servedInset();
         chunkAndAdd(s, all.seg_off[i]);
     }
+    double tp2 = now();
+    g_prof.add(6, tp2 - tp1);
     rc = dp_index_build(ctx_, index_.refs.data(), (uint32_t)index_.refs.size());
     if (rc != 0) {
         err = dp_last_error(ctx_);
         return rc;
     }
+    double tp3 = now();
+    g_prof.add(7, tp3 - tp2);
     st.n_indexed = index_.refs.size();
     // queries: [fwd, rc] per window (PrepareQueries :189-201)
     queries.clear();
@@ -282,11 +318,12 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
         queryID++;
     }
     st.n_queries = queries.size();
+    g_prof.add(8, now() - tp3);
     return 0;
 }
 
 // FindOverlaps :320 + matchWorker :346
-int Overlapper::FindOverlaps(std::vector<std::unique_ptr<SeedMatch>>& out, RoundStats& st) {
+int Overlapper::FindOverlaps(std::vector<SeedMatch>& pool, std::vector<SeedMatch*>& out, RoundStats& st) {
     querySegs_.clear();
     queryOff_.assign(1, 0);
     for (const SeedQuery& q : queries) {
@@ -294,19 +331,23 @@ int Overlapper::FindOverlaps(std::vector<std::unique_ptr<SeedMatch>>& out, Round
         queryOff_.push_back(querySegs_.size());
     }
     dp_match_batch mb;
+    const double tq0 = now();
     int rc = dp_find_overlaps(ctx_, querySegs_.data(), queryOff_.data(), (uint32_t)queries.size(), hitFraction_, index_.k,
                               (uint32_t)(overlap_ / 2), 0, &mb);
     if (rc != 0) {
         err = dp_last_error(ctx_);
         return rc;
     }
+    const double tq1 = now();
+    g_prof.add(9, tq1 - tq0);
     st.k_query_ms += mb.query_kernel_ms;
     st.k_chain_ms += mb.chain_kernel_ms;
     st.query_bytes += mb.query_bytes;
     out.clear();
     out.reserve(mb.n_matches);
+    if (pool.size() < mb.n_matches) pool.resize(mb.n_matches);
     for (uint32_t i = 0; i < mb.n_matches; i++) {
-        std::unique_ptr<SeedMatch> m(new SeedMatch());
+        SeedMatch* m = &pool[i];
         const SeedQuery& q = queries[mb.query[i]];
         m->MatchA.assign(mb.match_a + mb.off[i], mb.match_a + mb.off[i + 1]);
         m->MatchB.assign(mb.match_b + mb.off[i], mb.match_b + mb.off[i + 1]);
@@ -314,9 +355,10 @@ int Overlapper::FindOverlaps(std::vector<std::unique_ptr<SeedMatch>>& out, Round
         m->SeqB = index_.sequences[mb.target[i]];
         m->QueryID = q.ID;
         m->ReverseComplementQuery = q.ReverseComplement;
-        out.push_back(std::move(m));
+        out.push_back(m);
     }
     st.n_matches = out.size();
+    g_prof.add(10, now() - tq1);
     return 0;
 }
 
@@ -373,14 +415,23 @@ static void finalCheckOne(Arena& arena, const SeedIndex& index, const ReadSet& r
 
 void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vector<std::unique_ptr<SeedMatch>>& matches,
                 i64 numQuerySeqs, i64 overlapSize, std::string& paf, FinalCheckStats& fs, std::vector<int>* ignoreOut) {
+    std::vector<SeedMatch*> ptrs;
+    ptrs.reserve(matches.size());
+    for (auto& m : matches) ptrs.push_back(m.get());
+    finalCheck(arena, index, reads, ptrs, numQuerySeqs, overlapSize, paf, fs, ignoreOut);
+}
+
+void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, const std::vector<SeedMatch*>& matches, i64 numQuerySeqs,
+                i64 overlapSize, std::string& paf, FinalCheckStats& fs, std::vector<int>* ignoreOut) {
     // collate by QueryID (:158-173)
+    const double tf0 = now();
     std::vector<std::vector<SeedMatch*>> queryResults((size_t)numQuerySeqs);
     i64 hits = 0, qHits = 0;
-    for (auto& m : matches) {
+    for (SeedMatch* m : matches) {
         hits++;
         auto& qr = queryResults[(size_t)m->QueryID];
         if (qr.size() == 1) qHits++;
-        qr.push_back(m.get());
+        qr.push_back(m);
     }
     std::vector<size_t> work;
     for (size_t q = 0; q < queryResults.size(); q++)
@@ -388,27 +439,21 @@ void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vecto
     const size_t nw = work.size();
     std::vector<std::string> outs(nw);
     std::vector<std::vector<int>> ign(nw);
-    unsigned nt = hostThreads();
-    if (nt > nw) nt = (unsigned)std::max<size_t>(1, nw);
-    std::vector<FinalCheckStats> tfs(nt);
-    std::atomic<size_t> next(0);
-    auto worker = [&](unsigned t) {
-        Arena local;  // scratch SeedSeqs of this worker; nothing outlives finalCheck
-        for (;;) {
-            const size_t w = next.fetch_add(1);
-            if (w >= nw) break;
-            finalCheckOne(local, index, reads, queryResults[work[w]], overlapSize, outs[w], ign[w], tfs[t]);
-            local.clear();
-        }
-    };
+    std::vector<FinalCheckStats> tfs(nw);
     (void)arena;
-    if (nt <= 1) {
-        worker(0);
-    } else {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++) th.emplace_back(worker, t);
-        for (auto& x : th) x.join();
-    }
+    const double tf1 = now();
+    g_prof.add(11, tf1 - tf0);
+    std::atomic<long long> cpuUs(0);
+    parallelFor(nw, [&](size_t w) {
+        static thread_local Arena local;  // scratch SeedSeqs of this worker; nothing outlives the call
+        const double tw = g_prof.on ? now() : 0;
+        finalCheckOne(local, index, reads, queryResults[work[w]], overlapSize, outs[w], ign[w], tfs[w]);
+        local.clear();
+        if (g_prof.on) cpuUs += (long long)((now() - tw) * 1e6);
+    });
+    g_prof.consensusCpuUs += cpuUs.load();
+    const double tf2 = now();
+    g_prof.add(12, tf2 - tf1);
     for (size_t w = 0; w < nw; w++) {
         paf += outs[w];
         for (int id : ign[w]) {
@@ -423,21 +468,132 @@ void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vecto
     }
     fs.hits = (uint64_t)hits;
     fs.qHits = (uint64_t)qHits;
+    g_prof.add(13, now() - tf2);
 }
 
-static std::atomic<unsigned> g_threadShare(1);
-void setHostThreadShare(unsigned concurrentUsers) { g_threadShare = std::max(1u, concurrentUsers); }
+void profilePrint() { g_prof.print(); }
+void setHostThreadShare(unsigned) {}  // kept for callers; the shared pool needs no per-slot split
+// CPUs this process may actually use: the cgroup CPU quota (containers often expose every host CPU but cap the CPU
+// time; exceeding the cap gets the whole process throttled for the rest of the scheduler period) or the CPU count.
+static unsigned cpuBudget() {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    double quota = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char a[64] = {0};
+        long long period = 0;
+        if (fscanf(f, "%63s %lld", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) quota = atof(a) / (double)period;
+        fclose(f);
+    } else {
+        long long q = -1, per = 0;
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lld", &q) != 1) q = -1;
+            fclose(g);
+        }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(g, "%lld", &per) != 1) per = 0;
+            fclose(g);
+        }
+        if (q > 0 && per > 0) quota = (double)q / (double)per;
+    }
+    if (quota >= 1.0 && quota < (double)hw) hw = (unsigned)quota;
+    return hw;
+}
+
 unsigned hostThreads() {
     static unsigned n = [] {
         const char* e = getenv("DP_HOST_THREADS");
-        unsigned v = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+        unsigned v = e ? (unsigned)atoi(e) : cpuBudget();
         if (v == 0) v = 1;
-        return std::min(v, 64u);
+        return std::min(v, 96u);
     }();
-    // several executor slots run finalCheck at the same time: split the cores between them
-    unsigned share = std::max(2u, n / g_threadShare.load());
-    return std::min(share, 32u);
+    return n;
 }
+
+namespace {
+struct PoolJob {
+    size_t n = 0;
+    const std::function<void(size_t)>* fn = nullptr;
+    std::atomic<size_t> next{0}, done{0};
+    std::mutex mu;
+    std::condition_variable cv;
+};
+class WorkPool {
+   public:
+    static WorkPool& get() {
+        static WorkPool* p = new WorkPool();  // intentionally leaked: workers may outlive static destruction order
+        return *p;
+    }
+    void run(size_t n, const std::function<void(size_t)>& fn) {
+        if (n == 0) return;
+        if (n == 1 || threads_.empty()) {
+            for (size_t i = 0; i < n; i++) fn(i);
+            return;
+        }
+        auto job = std::make_shared<PoolJob>();
+        job->n = n;
+        job->fn = &fn;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            jobs_.push_back(job);
+        }
+        cv_.notify_all();
+        work(*job);
+        if (job->done.load(std::memory_order_acquire) < n) {  // items still running on pool threads
+            std::unique_lock<std::mutex> jl(job->mu);
+            job->cv.wait(jl, [&] { return job->done.load(std::memory_order_acquire) >= n; });
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        for (auto it = jobs_.begin(); it != jobs_.end(); ++it)
+            if (it->get() == job.get()) {
+                jobs_.erase(it);
+                break;
+            }
+    }
+
+   private:
+    WorkPool() {
+        const unsigned n = hostThreads();
+        for (unsigned i = 1; i < n; i++) threads_.emplace_back([this] { loop(); });
+        for (auto& t : threads_) t.detach();
+    }
+    static void work(PoolJob& j) {
+        for (;;) {
+            const size_t i = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j.n) return;
+            (*j.fn)(i);
+            if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 == j.n) {
+                std::lock_guard<std::mutex> jl(j.mu);
+                j.cv.notify_all();
+            }
+        }
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            std::shared_ptr<PoolJob> job;
+            for (auto& j : jobs_)
+                if (j->next.load(std::memory_order_relaxed) < j->n) {
+                    job = j;
+                    break;
+                }
+            if (!job) {
+                cv_.wait(lk);
+                continue;
+            }
+            lk.unlock();
+            work(*job);
+            lk.lock();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::shared_ptr<PoolJob>> jobs_;
+    std::vector<std::thread> threads_;
+};
+}  // namespace
+
+void parallelFor(size_t n, const std::function<void(size_t)>& fn) { WorkPool::get().run(n, fn); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Planner: the PrepareQueries chain (overlap.go:157-214 seed selection + commands/overlap.go:128-143 bookkeeping)
@@ -474,6 +630,14 @@ Planner::~Planner() {
 }
 
 std::shared_ptr<RoundPlan> Planner::compute(i64 round, i64 firstIn) {
+    const double tc0 = now();
+    struct Tick {
+        double t0;
+        ~Tick() {
+            g_prof.planComputes++;
+            g_prof.planUs += (long long)((now() - t0) * 1e6);
+        }
+    } tick{tc0};
     auto plan = std::make_shared<RoundPlan>();
     plan->round = round;
     plan->firstIn = firstIn;
@@ -533,6 +697,7 @@ void Planner::threadMain() {
         }
         if (m < d->base) ok = false;
         if (ok && !d->cache.count(m)) d->cache[m] = plan;
+        else g_prof.planDiscarded++;
         d->cv.notify_all();
     }
 }
@@ -596,7 +761,11 @@ i64 Planner::applyIgnores(const std::vector<int>& ids, i64 committedRound) {
             break;
         }
     }
-    if (firstBad >= 0) d->cache.erase(d->cache.lower_bound(firstBad), d->cache.end());
+    if (firstBad >= 0) {
+        auto lb = d->cache.lower_bound(firstBad);
+        g_prof.planErased += (long long)std::distance(lb, d->cache.end());
+        d->cache.erase(lb, d->cache.end());
+    }
     d->cv.notify_all();
     return firstBad;
 }
@@ -620,6 +789,17 @@ void Planner::dropBefore(i64 round) {
 OverlapRun::~OverlapRun() { shutdown(); }
 
 void OverlapRun::shutdown() {
+    {
+        std::lock_guard<std::mutex> lk(pmu_);
+        stopWorkers_ = true;
+    }
+    cvWork_.notify_all();
+    for (auto& t : workers_)
+        if (t.joinable()) t.join();
+    workers_.clear();
+    ready_.clear();
+    redo_.clear();
+    if (planner) g_prof.print();
     planner.reset();
     for (auto& sl : slots) {
         sl->lap.reset();
@@ -672,6 +852,10 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     firstSequence = 0;
     round = 0;
     done = false;
+    stopWorkers_ = issueEnd_ = draining_ = false;
+    nextIssue_ = 0;
+    inflight_ = workerRc_ = 0;
+    flagRound_.assign(reads->size(), -1);
     shardLo = 0;
     shardHi = reads->size();
     return 0;
@@ -679,16 +863,22 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
 
 // seeds.NewSeedIndex + the plan's seeds on host and device; queries are built after the scan
 int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
+    const double tb0 = now();
     sl.index->reset();  // seeds.NewSeedIndex(k) per round (:125) — sparse reset instead of reallocating 4^k tables
     for (uint32_t km : plan.seedMap) sl.index->addSeedKmer(km);
+    const double tb1 = now();
+    g_prof.add(0, tb1 - tb0);
     sl.lap.reset(new Overlapper(sl.ctx, *reads, *sl.index, p.chunkSize, p.numWorkers, p.overlapSize, p.numSeeds, p.minHits));
     sl.lap->setWindows(plan.windows);
     sl.lap->setIgnoreView(reads->ignore.data(), planner->ignoreEpoch());
+    const double tb2 = now();
+    g_prof.add(1, tb2 - tb1);
     int rc = dp_round_begin(sl.ctx, p.k, sl.index->seedMap.data(), (uint32_t)sl.index->seedMap.size());
     if (rc != 0) {
         sl.error = dp_last_error(sl.ctx);
         return rc;
     }
+    g_prof.add(2, now() - tb2);
     return 0;
 }
 
@@ -706,8 +896,8 @@ int OverlapRun::finishRound(ExecSlot& sl, const Survivors& all, RoundResult& out
         if (q.ID >= out.numQuerySeqs) out.numQuerySeqs = q.ID + 1;
     double t1 = now();
     st.t_index = t1 - t0;
-    std::vector<std::unique_ptr<SeedMatch>> matches;
-    rc = sl.lap->FindOverlaps(matches, st);
+    std::vector<SeedMatch*>& matches = sl.matches;
+    rc = sl.lap->FindOverlaps(sl.matchPool, matches, st);
     if (rc != 0) {
         sl.error = sl.lap->err;
         return rc;
@@ -729,6 +919,7 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     out.round = r;
     double t0 = now();
     std::shared_ptr<const RoundPlan> plan = planner->get(r);
+    g_prof.getWaitUs += (long long)((now() - t0) * 1e6);
     if (!plan || plan->empty || plan->round != r) {
         out.empty = true;
         if (plan) out.firstIn = out.firstOut = plan->firstOut;
@@ -737,6 +928,8 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     out.empty = false;
     out.firstIn = plan->firstIn;
     out.firstOut = plan->firstOut;
+    out.queryReads.reserve(plan->windows.size());
+    for (const auto& w : plan->windows) out.queryReads.push_back(w.read);
     int rc = beginRound(sl, *plan);
     if (rc) return rc;
     out.st.n_seeds = plan->seedMap.size();
@@ -748,7 +941,11 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
         return rc;
     }
     out.st.t_scan = now() - t1;
-    return finishRound(sl, sl.local, out);
+    rc = finishRound(sl, sl.local, out);
+    const double t2 = now();
+    g_prof.add(14, t2 - t0);
+    g_prof.add(15, (t2 - t0) - (out.st.t_prepare + out.st.t_scan + out.st.t_index + out.st.t_query + out.st.t_consensus));
+    return rc;
 }
 
 int OverlapRun::executeRound(i64 r, RoundResult& out) {
@@ -793,6 +990,9 @@ void OverlapRun::commitOne(RoundResult& r) {
     emptyMatch += r.fs.emptyMatch;
     paf += r.paf;
     last = r.st;
+    g_prof.ignores += (long long)r.ignores.size();
+    for (int id : r.ignores)
+        if (!reads->ignore[(size_t)id] && flagRound_[(size_t)id] < 0) flagRound_[(size_t)id] = (int32_t)round;
     planner->applyIgnores(r.ignores, round);
     round++;
     planner->dropBefore(round);
@@ -843,14 +1043,111 @@ int OverlapRun::commitResults(std::vector<RoundResult>& results) {
     return committed;
 }
 
+void OverlapRun::startWorkers() {
+    if (!workers_.empty()) return;
+    nextIssue_ = round;
+    for (size_t i = 0; i < slots.size(); i++) workers_.emplace_back([this, i] { workerMain(i); });
+}
+
+void OverlapRun::workerMain(size_t si) {
+    ExecSlot& sl = *slots[si];
+    const i64 window = (i64)slots.size() + 2;  // rounds issued ahead of the commit point
+    std::unique_lock<std::mutex> lk(pmu_);
+    for (;;) {
+        cvWork_.wait(lk, [&] {
+            return stopWorkers_ || (!draining_ && workerRc_ == 0 && (!redo_.empty() || (!issueEnd_ && nextIssue_ < round + window)));
+        });
+        if (stopWorkers_) return;
+        i64 r;
+        if (!redo_.empty()) {
+            r = redo_.front();
+            redo_.pop_front();
+        } else {
+            r = nextIssue_++;
+        }
+        const i64 snap = round;
+        inflight_++;
+        lk.unlock();
+        RoundResult res;
+        const int rc = executeRoundOn(sl, r, res);
+        res.snapshot = snap;
+        res.round = r;
+        lk.lock();
+        inflight_--;
+        if (rc != 0 && workerRc_ == 0) {
+            workerRc_ = rc;
+            workerErr_ = sl.error;
+        }
+        if (rc == 0) {
+            if (res.empty) issueEnd_ = true;  // flags only accumulate: an exhausted input stays exhausted
+            if (!draining_) ready_[r] = std::move(res);
+        }
+        cvDone_.notify_all();
+    }
+}
+
+// A round executed against a flag snapshot is exact iff no read flagged since then is one of its queries or entered
+// its index, and its plan continues the committed chain.
+bool OverlapRun::resultValid(const RoundResult& r) const {
+    if (r.firstIn != firstSequence) return false;
+    for (uint32_t id : r.queryReads)
+        if (flagRound_[id] >= r.snapshot) return false;
+    for (uint32_t id : r.indexedReads)
+        if (flagRound_[id] >= r.snapshot) return false;
+    return true;
+}
+
 int OverlapRun::step() {
     if (done) return 0;
-    std::vector<i64> rounds;
-    for (size_t i = 0; i < slots.size(); i++) rounds.push_back(round + (i64)i);
-    std::vector<RoundResult> outs;
-    int rc = executeRounds(rounds, outs);
-    if (rc < 0) return rc;
-    return commitResults(outs);
+    startWorkers();
+    const double t0 = now();
+    std::unique_lock<std::mutex> lk(pmu_);
+    paf.clear();
+    int committed = 0;
+    for (;;) {
+        if (workerRc_ != 0) {
+            error = workerErr_;
+            return workerRc_;
+        }
+        auto it = ready_.find(round);
+        if (it == ready_.end()) {
+            if (committed) break;
+            cvDone_.wait(lk);
+            continue;
+        }
+        RoundResult res = std::move(it->second);
+        ready_.erase(it);
+        if (res.empty) {
+            done = true;
+            break;
+        }
+        g_prof.executed++;
+        if (!resultValid(res)) {
+            g_prof.rejected++;
+            redo_.push_back(round);
+            cvWork_.notify_all();
+            continue;
+        }
+        commitOne(res);
+        committed++;
+        g_prof.committed++;
+        cvWork_.notify_all();
+    }
+    g_prof.execUs += (long long)((now() - t0) * 1e6);
+    return committed;
+}
+
+void OverlapRun::drain() {
+    std::unique_lock<std::mutex> lk(pmu_);
+    if (workers_.empty()) return;
+    draining_ = true;
+    cvDone_.wait(lk, [&] { return inflight_ == 0; });
+    ready_.clear();
+    redo_.clear();
+    nextIssue_ = round;
+    issueEnd_ = false;
+    draining_ = false;
+    cvWork_.notify_all();
 }
 
 // ---- scan-shard mode: plan + local scan, then (after the survivor exchange) the rest of the round

@@ -537,6 +537,65 @@ static std::vector<uint64_t> seedsSharedByTwo(const std::vector<SeedSeq*>& seqs)
     return v2;
 }
 
+// One support-scan pass of multiAligner.Consensus over all other sequences j for a proposing sequence (alignment.go:
+// 101-131), restricted to what the first candidate seed of j decides: found there (count/sum), nothing in the window,
+// or `slow` (the reference's walk has to advance: done by the caller with the scalar code).  32-bit, branch free.
+// The proposing sequence itself is NOT excluded here (the caller subtracts it), so one pass serves every proposer with
+// the same (d, seed, window) — in a clean pile-up that is all of them.
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+__attribute__((target_clones("avx2", "default")))
+#endif
+static void pairScan(int ns, const int32_t* __restrict__ ok, const int32_t* __restrict__ od, const int32_t* __restrict__ sd,
+                     const int32_t* __restrict__ gp, int32_t d, int32_t minD, int32_t maxD, int32_t nextSeed, int k,
+                     uint8_t* __restrict__ slow, uint8_t* __restrict__ fnd, int* cntOut, i64* sumOut) {
+    int cnt = 0;
+    int32_t sum = 0;
+    for (int j = 0; j < ns; j++) {
+        const int32_t t = d + gp[j];
+        const int32_t m0 = (t * 2) / 3 - k, x0 = (t * 3) / 2 + k + 1;  // gapRange :411-424
+        const bool neg = m0 < 0, small = !neg && x0 < 20;
+        int32_t mx = neg ? (x0 < 0 ? 0 : x0) : (small ? 20 : x0);
+        int32_t mn = neg ? -k : (small ? 0 : m0);
+        mn = mn > minD ? minD : mn;
+        mx = mx < maxD ? maxD : mx;
+        const int32_t o = od[j];
+        const bool valid = ok[j] != 0;
+        const bool inWin = o >= mn && o < mx;
+        const bool found = valid && inWin && sd[j] == nextSeed;
+        const bool walk = valid && !found && o < mx;  // below the window, or inside it on another seed
+        cnt += found ? 1 : 0;
+        sum += found ? o : 0;
+        slow[j] = walk ? 1 : 0;
+        fnd[j] = found ? 1 : 0;
+    }
+    *cntOut = cnt;
+    *sumOut = sum;
+}
+
+// The same pass when every other sequence has gaps[j] == 0 (all in step, the common state): the window is one pair of
+// constants and the loop is compares only.
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+__attribute__((target_clones("avx2", "default")))
+#endif
+static void pairScanInStep(int ns, const int32_t* __restrict__ ok, const int32_t* __restrict__ od, const int32_t* __restrict__ sd,
+                           int32_t mn, int32_t mx, int32_t nextSeed, uint8_t* __restrict__ slow, uint8_t* __restrict__ fnd,
+                           int* cntOut, i64* sumOut) {
+    int cnt = 0;
+    int32_t sum = 0;
+    for (int j = 0; j < ns; j++) {
+        const int32_t o = od[j];
+        const bool valid = ok[j] != 0;
+        const bool found = valid && o >= mn && o < mx && sd[j] == nextSeed;
+        const bool walk = valid && !found && o < mx;
+        cnt += found ? 1 : 0;
+        sum += found ? o : 0;
+        slow[j] = walk ? 1 : 0;
+        fnd[j] = found ? 1 : 0;
+    }
+    *cntOut = cnt;
+    *sumOut = sum;
+}
+
 // seeds/alignment.go:23-268
 SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k, std::vector<std::unique_ptr<SeedMatch>>& matchesOut) {
     const size_t ns = seqs.size();
@@ -555,8 +614,28 @@ SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k,
             matches[i]->SeqB = seqs[i];
         }
     bool finished = false;
+    const i64 kNarrow = (i64)1 << 28;  // all quantities below this: 32-bit arithmetic is exact
+    std::vector<int32_t> okv(ns), odv(ns), sdv(ns), gpv(ns);
+    std::vector<uint8_t> slowv(ns), fndv(ns);
     while (!finished) {
         i64 fCount = 0, near = 100000;
+        bool memoOk = false, memoSlow = false;  // last support scan of this step: (d, seed, window) -> totals
+        i64 memoD = 0, memoMin = 0, memoMax = 0, memoSum = 0;
+        int32_t memoSeed = 0;
+        int memoCnt = 0;
+        bool narrow = true, inStep = true;
+        for (size_t j = 0; j < ns; j++) {  // state of every sequence's next seed (constant during the support scan)
+            const int32_t* s2 = S(j);
+            const i64 p2 = pos[j] + 1;
+            const bool ok = s2 && p2 < N(j) / 2;
+            const i64 o = ok ? (i64)s2[p2 * 2] - offs[j] : 0;
+            if (o >= kNarrow || o <= -kNarrow || gaps[j] >= kNarrow || gaps[j] <= -kNarrow) narrow = false;
+            if (ok && gaps[j] != 0) inStep = false;
+            okv[j] = ok ? 1 : 0;
+            odv[j] = (int32_t)o;
+            sdv[j] = ok ? s2[p2 * 2 + 1] : -1;
+            gpv[j] = (int32_t)gaps[j];
+        }
         for (size_t i = 0; i < ns; i++) {
             const int32_t* segment = S(i);
             const i64 sl = N(i), p = pos[i];
@@ -575,10 +654,10 @@ SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k,
                 maxD -= gaps[i];
                 if (near > maxD) near = maxD;
                 supported[i] = 1;
-                for (size_t j = 0; j < ns; j++) {
+                auto scanOne = [&](size_t j) {  // alignment.go:101-131 for one other sequence
                     const int32_t* s2 = S(j);
                     const i64 sl2 = N(j);
-                    if (!s2 || j == i) continue;
+                    if (!s2 || j == i) return;
                     i64 p2 = pos[j] + 1;
                     if (p2 < sl2 / 2) {
                         i64 min2, max2;
@@ -600,6 +679,37 @@ SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k,
                             otherD += s2[p2 * 2] + k;
                         }
                     }
+                };
+                if (narrow && d < kNarrow && d > -kNarrow && minD > -kNarrow && maxD < kNarrow) {
+                    // the other sequences' next seeds were snapshotted for this step: one branch-free (vectorised)
+                    // pass settles every pair whose answer is decided by that first seed; the rest take scanOne
+                    if (!(memoOk && memoD == d && memoSeed == nextSeed && memoMin == minD && memoMax == maxD)) {
+                        if (inStep) {
+                            i64 mn0, mx0;
+                            gapRange(d, k, &mn0, &mx0);
+                            if (mn0 > minD) mn0 = minD;
+                            if (mx0 < maxD) mx0 = maxD;
+                            pairScanInStep((int)ns, okv.data(), odv.data(), sdv.data(), (int32_t)mn0, (int32_t)mx0, nextSeed,
+                                           slowv.data(), fndv.data(), &memoCnt, &memoSum);
+                        } else {
+                            pairScan((int)ns, okv.data(), odv.data(), sdv.data(), gpv.data(), (int32_t)d, (int32_t)minD,
+                                     (int32_t)maxD, nextSeed, k, slowv.data(), fndv.data(), &memoCnt, &memoSum);
+                        }
+                        memoOk = true;
+                        memoD = d;
+                        memoSeed = nextSeed;
+                        memoMin = minD;
+                        memoMax = maxD;
+                        memoSlow = false;
+                        for (size_t j = 0; j < ns; j++) memoSlow |= slowv[j] != 0;
+                    }
+                    supported[i] += memoCnt - fndv[i];
+                    dist[i] += memoSum - (fndv[i] ? odv[i] : 0);
+                    if (memoSlow)
+                        for (size_t j = 0; j < ns; j++)
+                            if (slowv[j] && j != i) scanOne(j);
+                } else {
+                    for (size_t j = 0; j < ns; j++) scanOne(j);
                 }
             }
         }

@@ -63,6 +63,8 @@ def load_host():
     H.dph_overlap_ctx.restype = vp
     H.dph_overlap_ctx.argtypes = [vp]
     H.dph_overlap_step.argtypes = [vp]
+    H.dph_overlap_drain.restype = None
+    H.dph_overlap_drain.argtypes = [vp]
     H.dph_overlap_round.restype = C.c_int64
     H.dph_overlap_round.argtypes = [vp]
     H.dph_overlap_exec_round.restype = C.POINTER(C.c_uint8)
@@ -269,6 +271,10 @@ class OverlapPipeline:
         if not p:
             raise self._err()
         return C.string_at(p, n.value)
+
+    def drain(self):
+        """Discards the rounds the executor pipeline has in flight (they are executed again later)."""
+        self.H.dph_overlap_drain(self.h)
 
     def commit_blobs(self, blobs):
         sizes = np.array([len(b) for b in blobs], dtype=np.uint64)
