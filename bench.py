@@ -88,6 +88,17 @@ def main():
         warm += c
     pipe.drain()  # rounds the executor pipeline has in flight are thrown away: the timed region starts from an empty pipeline
     sync()
+    def cpu_stat():
+        out = {}
+        try:
+            for ln in open("/sys/fs/cgroup/cpu.stat"):
+                k_, v_ = ln.split()
+                out[k_] = int(v_)
+        except Exception:
+            pass
+        return out
+
+    cs0 = cpu_stat()
     acc = {}
     lines = 0
     steps_done = 0   # rounds committed in the timed region (a step = one round; with N ranks a call commits up to N)
@@ -105,6 +116,7 @@ def main():
         steps_done += c
     sync()
     elapsed = time.perf_counter() - t_start
+    cs1 = cpu_stat()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch_device if torch_device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -143,6 +155,10 @@ def main():
             "index_query": {"bytes_per_step": acc.get("query_bytes", 0.0) / n,
                             "achieved_GBs": (acc.get("query_bytes", 0.0) / 1e9) / (acc.get("k_query_ms", 1e-9) / 1e3) if acc.get("k_query_ms", 0) > 0 else 0.0},
             "setup_s": {"generate": t_gen, "upload_pack_histogram_values": t_setup},
+            # host side of the timed region: CPU seconds used by this container and time it spent throttled by its CPU quota
+            "host_cpu": {"cpu_s": (cs1.get("usage_usec", 0) - cs0.get("usage_usec", 0)) / 1e6,
+                         "throttled_s": (cs1.get("throttled_usec", 0) - cs0.get("throttled_usec", 0)) / 1e6,
+                         "wall_s": elapsed},
         }
         if world == 1 and args.cpu_rounds > 0:
             out["cpu_baseline"] = cpu_baseline(bases, off, args, pipe.values())

@@ -24,6 +24,7 @@ struct dp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_sync = nullptr;  // blocking-sync event: waiting host threads sleep instead of polling
     std::string err;
     bool borrowed_reads = false;  // d_packed/d_boff/d_len belong to another context
 
@@ -68,6 +69,9 @@ struct dp_ctx {
 };
 
 int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess);
+// Waits for everything queued on the context's stream.  The host thread blocks on an interrupt (several executor
+// contexts share few host cores); DP_SPIN_SYNC=1 restores the runtime's polling wait.
+hipError_t dp_stream_sync(dp_ctx* ctx);
 int dev_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
 int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
 

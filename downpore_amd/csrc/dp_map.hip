@@ -371,7 +371,7 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         DP_HIP(hipMemcpyAsync(cur, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
-        DP_HIP(hipStreamSynchronize(ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
         float ms = 0;
         hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]);
         total_ms += ms;
@@ -406,7 +406,7 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
         DP_HIP(hipMemcpyAsync(ctx->h_mrec.p, ctx->d_mrec.p, (size_t)nm * sizeof(MapRec), hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(hipMemcpyAsync(ta.data(), ctx->d_ma.p, (size_t)ni * 4, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(hipMemcpyAsync(tb.data(), ctx->d_mb.p, (size_t)ni * 4, hipMemcpyDeviceToHost, ctx->stream));
-        DP_HIP(hipStreamSynchronize(ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
     }
     MapRec* recs = (MapRec*)ctx->h_mrec.p;
     std::vector<uint32_t> order(nm);

@@ -99,7 +99,7 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
                            (uint32_t*)ctx->d_pmeta.p);
         DP_HIP(hipGetLastError());
     }
-    DP_HIP(hipStreamSynchronize(ctx->stream));  // seqs is borrowed only for the duration of the call
+    DP_HIP(dp_stream_sync(ctx));  // seqs is borrowed only for the duration of the call
     return DP_OK;
 }
 
@@ -1497,7 +1497,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_cursor.p, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
-        DP_HIP(hipStreamSynchronize(ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
         memcpy(cur, ctx->h_cursor.p, 64);
         float ms = 0;
         hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]);
@@ -1562,7 +1562,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         if (pin_reserve(ctx, ctx->h_cand, (size_t)nq * W * 8 + 16)) return DP_ERR_HIP;
         DP_HIP(hipMemcpyAsync(ctx->h_cand.p, ctx->d_cand.p, (size_t)nq * W * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
-    DP_HIP(hipStreamSynchronize(ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
     for (uint32_t q = 0; q < nq; q++) {
         if (qm[4 * q + 2] & 1) return dp_fail(ctx, DP_ERR_CAPACITY, "query with more than 512 usable seeds");
         out->query_bytes += words[q] * 8;

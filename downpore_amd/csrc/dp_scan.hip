@@ -30,6 +30,17 @@ static std::string g_create_err;
 // slow each other down, so the device part of dp_scan is serialised per process.
 static std::mutex g_scan_mu;
 
+hipError_t dp_stream_sync(dp_ctx* ctx) {
+    static const bool spin = [] {
+        const char* e = getenv("DP_SPIN_SYNC");
+        return e && e[0] == '1';
+    }();
+    if (spin || !ctx->ev_sync) return hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipEventRecord(ctx->ev_sync, ctx->stream);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(ctx->ev_sync);
+}
+
 int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e) {
     std::string s = what;
     if (e != hipSuccess) {
@@ -49,7 +60,7 @@ int dev_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes, bool keep) {
     DP_HIP(hipMalloc(&np, ncap));
     if (b.p) {
         if (keep) DP_HIP(hipMemcpyAsync(np, b.p, b.cap, hipMemcpyDeviceToDevice, ctx->stream));
-        DP_HIP(hipStreamSynchronize(ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
         DP_HIP(hipFree(b.p));
     }
     b.p = np;
@@ -63,7 +74,7 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes) {
     void* np = nullptr;
     DP_HIP(hipHostMalloc(&np, ncap, hipHostMallocDefault));
     if (b.p) {
-        DP_HIP(hipStreamSynchronize(ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
         DP_HIP(hipHostFree(b.p));
     }
     b.p = np;
@@ -90,6 +101,7 @@ extern "C" int dp_ctx_create(int device, dp_ctx** out) {
         return DP_ERR_HIP;
     }
     for (auto& ev : ctx->ev) hipEventCreate(&ev);
+    hipEventCreateWithFlags(&ctx->ev_sync, hipEventBlockingSync | hipEventDisableTiming);
     *out = ctx;
     return DP_OK;
 }
@@ -114,7 +126,7 @@ extern "C" int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out) {
 extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    dp_stream_sync(ctx);
     if (ctx->borrowed_reads) ctx->d_packed.p = ctx->d_boff.p = ctx->d_len.p = nullptr;
     DevBuf* dbs[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len, &ctx->d_bits, &ctx->d_kmap, &ctx->d_seeds, &ctx->d_items,
                      &ctx->d_counts, &ctx->d_segoff, &ctx->d_segs, &ctx->d_total, &ctx->d_seqrefs, &ctx->d_posting,
@@ -128,6 +140,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
         if (b->p) hipHostFree(b->p);
     for (auto& ev : ctx->ev)
         if (ev) hipEventDestroy(ev);
+    if (ctx->ev_sync) hipEventDestroy(ctx->ev_sync);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -198,7 +211,7 @@ extern "C" int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t*
     DP_HIP(hipMemcpyAsync(ctx->d_len.p, ctx->h_len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
     DP_HIP(hipMemsetAsync((uint8_t*)ctx->d_packed.p + pos, 0, 64, ctx->stream));
     if (n_reads == 0 || pos == 0) {
-        DP_HIP(hipStreamSynchronize(ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
         return DP_OK;
     }
     void* d_ascii = nullptr;
@@ -215,7 +228,7 @@ extern "C" int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t*
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)d_ascii, (const int64_t*)d_aoff,
                        (const uint64_t*)ctx->d_boff.p, n_reads, (uint32_t*)ctx->d_packed.p, n_dwords);
     DP_HIP(hipGetLastError());
-    DP_HIP(hipStreamSynchronize(ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
     hipFree(d_ascii);
     hipFree(d_aoff);
     return DP_OK;
@@ -308,7 +321,7 @@ extern "C" int dp_kmer_histogram(dp_ctx* ctx, int k, uint64_t* counts_out) {
     }
     std::vector<uint32_t> tmp(n);
     DP_HIP(hipMemcpyAsync(tmp.data(), d, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    DP_HIP(hipStreamSynchronize(ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
     hipFree(d);
     for (size_t i = 0; i < n; i++) counts_out[i] = tmp[i];
     return DP_OK;
@@ -355,7 +368,7 @@ extern "C" int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, ui
                            (const uint32_t*)ctx->d_seeds.p, n_seeds, (uint32_t*)ctx->d_bits.p, (int32_t*)ctx->d_kmap.p, 1);
         DP_HIP(hipGetLastError());
     }
-    DP_HIP(hipStreamSynchronize(ctx->stream));  // seed_kmers is borrowed only for the duration of the call
+    DP_HIP(dp_stream_sync(ctx));  // seed_kmers is borrowed only for the duration of the call
     ctx->k = k;
     ctx->n_seeds = n_seeds;
     ctx->round_open = true;
@@ -659,7 +672,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     DP_HIP(hipMemcpyAsync(ctx->h_total.p, ctx->d_total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->h_counts.p, ctx->d_counts.p, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->h_segoff.p, ctx->d_segoff.p, ((size_t)n_items + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-    DP_HIP(hipStreamSynchronize(ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
     const uint64_t n_segs = *(uint64_t*)ctx->h_total.p;
     if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
@@ -676,7 +689,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));
-        DP_HIP(hipStreamSynchronize(ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
         hipEventElapsedTime(&ms1, ctx->ev[2], ctx->ev[3]);
     }
     scan_lock.unlock();
@@ -833,7 +846,7 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->h_total.p, totals, 16, hipMemcpyDeviceToHost, ctx->stream));
-    DP_HIP(hipStreamSynchronize(ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
     const uint64_t n_segs = ((uint64_t*)ctx->h_total.p)[0];
     const uint64_t n_surv_all = ((uint64_t*)ctx->h_total.p)[1];  // surviving reads + all extra items
     if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
@@ -861,7 +874,7 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
         DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    DP_HIP(hipStreamSynchronize(ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
     if (n_segs) hipEventElapsedTime(&ms1, ctx->ev[2], ctx->ev[3]);
     scan_lock.unlock();
     ctx->n_segs = n_segs;
@@ -896,7 +909,7 @@ extern "C" int dp_scan_import_segments(dp_ctx* ctx, const int32_t* segs, uint64_
     hipSetDevice(ctx->device);
     if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     if (n_segs) DP_HIP(hipMemcpyAsync(ctx->d_segs.p, segs, n_segs * 4, hipMemcpyHostToDevice, ctx->stream));
-    DP_HIP(hipStreamSynchronize(ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
     ctx->n_segs = n_segs;
     return DP_OK;
 }

@@ -157,6 +157,9 @@ struct SeedIndex {
     bool touchesSeed(const char* s, i64 len) const;
     void commitSeeds(const uint32_t* topN, int n);
     int32_t seedOfRcKmer(int32_t seed) const;                            // kmerMap[rc(seedMap[seed])]
+    // seed id -> seed id of its reverse complement for the complete seed set (call once all seeds of the round are in)
+    void buildRcTable();
+    std::vector<int32_t> rcOf;
 };
 
 SeedSeq* seqReverseComplement(Arena& a, SeedSeq* s, const SeedIndex& ix);  // seeds/sequence.go:134-159
@@ -342,7 +345,18 @@ struct OverlapRun {
     dp_ctx* ctx = nullptr;
     ReadSet* reads = nullptr;
     OverlapParams p;
-    std::vector<double> values;
+    // k-mer value table (4^k doubles, 512 MiB at k=13).  Seed selection probes it at random, so it sits on transparent
+    // huge pages (TLB reach) when the kernel allows it.
+    struct HugeTable {
+        double* p = nullptr;
+        size_t n = 0, bytes = 0, mapped_ = 0;
+        void* base_ = nullptr;
+        void assign(const double* src, size_t count);
+        void clear();
+        ~HugeTable() { clear(); }
+        const double* data() const { return p; }
+        size_t size() const { return n; }
+    } values;
     std::vector<std::unique_ptr<ExecSlot>> slots;  // slot 0 drives `ctx`; further slots use contexts that borrow its reads
     std::unique_ptr<Planner> planner;
     i64 firstSequence = 0;

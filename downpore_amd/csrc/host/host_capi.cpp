@@ -270,6 +270,7 @@ extern "C" const char* dph_finalcheck(void* readsH, int k, int64_t overlapSize, 
     ReadSet& reads = ((ReadsH*)readsH)->set;
     SeedIndex index(k);
     for (int64_t i = 0; i < nSeeds; i++) index.addSeedKmer(seedKmers[i]);
+    index.buildRcTable();
     Arena& ar = index.arena;
     std::vector<SeedSeq*> qs, is;
     for (int64_t q = 0; q < nQ; q++) {

@@ -8,6 +8,11 @@
 #include <mutex>
 #include <thread>
 #include <sys/resource.h>
+#include <sys/mman.h>
+#include <pthread.h>
+#include <sched.h>
+#include <unistd.h>
+#include <time.h>
 #include <cstdio>
 #include <cstring>
 
@@ -18,17 +23,22 @@ namespace dph {
 static double now() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+static double threadCpuNow() {  // CPU time consumed by the calling thread
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 unsigned hostThreads();
 // DPH_PROFILE=1: pipeline counters printed to stderr when a run shuts down
 struct PipeProfile {
     std::atomic<long long> executed{0}, committed{0}, rejected{0}, discarded{0}, ignores{0}, planComputes{0}, planErased{0},
         planDiscarded{0};
-    std::atomic<long long> planUs{0}, getWaitUs{0}, execUs{0}, commitUs{0}, consensusCpuUs{0};
-    std::atomic<long long> sub[16];
-    const char* subName[16] = {"prep.indexReset", "prep.newOverlapper", "prep.roundBegin", "scan.call", "scan.copy", "idx.copy",
+    std::atomic<long long> planUs{0}, getWaitUs{0}, execUs{0}, commitUs{0}, consensusCpuUs{0}, selectCpuUs{0}, slotCpuUs{0}, plannerCpuUs{0};
+    std::atomic<long long> sub[18];
+    const char* subName[18] = {"prep.indexReset", "prep.newOverlapper", "prep.roundBegin", "scan.call", "scan.copy", "idx.copy",
                                "idx.chunk", "idx.build", "idx.queries", "qry.call", "qry.matches", "fc.collate", "fc.parallel",
-                               "fc.merge", "round.total", "round.tail"};
+                               "fc.merge", "round.total", "round.tail", "plan.speculate", "plan.commitLoop"};
     PipeProfile() {
         for (auto& x : sub) x = 0;
     }
@@ -47,9 +57,14 @@ struct PipeProfile {
         getrusage(RUSAGE_SELF, &ru);
         fprintf(stderr, "[pipe] host threads %u, process CPU time user %.2f s sys %.2f s\n", hostThreads(),
                 ru.ru_utime.tv_sec + ru.ru_utime.tv_usec / 1e6, ru.ru_stime.tv_sec + ru.ru_stime.tv_usec / 1e6);
-        fprintf(stderr, "[pipe] consensus CPU per round %.2f ms\n", consensusCpuUs.load() / 1e3 / std::max<long long>(1, executed.load()));
+        {
+            const double nn = (double)std::max<long long>(1, executed.load());
+            fprintf(stderr, "[pipe] thread CPU per round (ms): consensus items %.2f, seed-selection items %.2f, slot threads %.2f, planner thread %.2f\n",
+                    consensusCpuUs.load() / 1e3 / nn, selectCpuUs.load() / 1e3 / nn, slotCpuUs.load() / 1e3 / nn,
+                    plannerCpuUs.load() / 1e3 / nn);
+        }
         fprintf(stderr, "[pipe] per executed round (ms):");
-        for (int i = 0; i < 16; i++) fprintf(stderr, " %s %.3f", subName[i], sub[i].load() / 1e3 / n);
+        for (int i = 0; i < 18; i++) fprintf(stderr, " %s %.3f", subName[i], sub[i].load() / 1e3 / n);
         fprintf(stderr, "\n");
     }
 };
@@ -100,14 +115,25 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values
         spec.resize(n * (size_t)numSeeds);
         const size_t first = specDone;
         if (n <= first) return;
+        std::atomic<long long> selUs(0);
         parallelFor(n - first, [&](size_t i) {
             const size_t w = first + i;
             const Cand& c = cand[w];
+            const double tw = g_prof.on ? threadCpuNow() : 0;
             index_.selectSeeds(reads_.seq(c.read) + c.start, c.len, numSeeds, values, &spec[w * (size_t)numSeeds], false);
+            if (g_prof.on) selUs += (long long)((threadCpuNow() - tw) * 1e6);
         });
+        g_prof.selectCpuUs += selUs.load();
         specDone = n;
     };
+    const double tsp0 = now();
     speculate(want);
+    const double tsp1 = now();
+    g_prof.add(16, tsp1 - tsp0);
+    struct CommitTick {
+        double t0;
+        ~CommitTick() { g_prof.add(17, now() - t0); }
+    } commitTick{tsp1};
     std::vector<uint32_t> tmp((size_t)numSeeds);
     size_t w = 0;
     for (;;) {
@@ -372,10 +398,17 @@ static void finalCheckOne(Arena& arena, const SeedIndex& index, const ReadSet& r
     if (!contig || contig->Parts.size() <= 1) return;
     if (contig->SeqLengths[0] <= overlapSize * 2) ignoreIds.push_back(contig->Parts[0]);
     const i64 queryStart = contig->Offsets[0], queryEnd = queryStart + contig->Lengths[0];
-    char num[32];
-    auto app = [&](i64 v) {
-        int n = snprintf(num, sizeof num, "%lld", (long long)v);
-        paf.append(num, (size_t)n);
+    char num[24];
+    auto app = [&](i64 v) {  // %d
+        char* e = num + sizeof num;
+        char* p = e;
+        uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+        do {
+            *--p = (char)('0' + u % 10);
+            u /= 10;
+        } while (u);
+        if (v < 0) *--p = '-';
+        paf.append(p, (size_t)(e - p));
     };
     for (size_t i = 0; i + 1 < contig->Parts.size(); i++) {
         const size_t id = i + 1;
@@ -446,10 +479,19 @@ void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, const std:
     std::atomic<long long> cpuUs(0);
     parallelFor(nw, [&](size_t w) {
         static thread_local Arena local;  // scratch SeedSeqs of this worker; nothing outlives the call
-        const double tw = g_prof.on ? now() : 0;
-        finalCheckOne(local, index, reads, queryResults[work[w]], overlapSize, outs[w], ign[w], tfs[w]);
+        const double tw = g_prof.on ? threadCpuNow() : 0;
+        // results are built in worker-local objects and published once: neighbouring outs[]/ign[]/tfs[] elements share
+        // cache lines, and finalCheckOne appends to them per PAF field
+        std::string pafLocal;
+        std::vector<int> ignLocal;
+        FinalCheckStats fsLocal;
+        pafLocal.reserve(2048);
+        finalCheckOne(local, index, reads, queryResults[work[w]], overlapSize, pafLocal, ignLocal, fsLocal);
+        outs[w] = std::move(pafLocal);
+        ign[w] = std::move(ignLocal);
+        tfs[w] = fsLocal;
         local.clear();
-        if (g_prof.on) cpuUs += (long long)((now() - tw) * 1e6);
+        if (g_prof.on) cpuUs += (long long)((threadCpuNow() - tw) * 1e6);
     });
     g_prof.consensusCpuUs += cpuUs.load();
     const double tf2 = now();
@@ -554,7 +596,41 @@ class WorkPool {
    private:
     WorkPool() {
         const unsigned n = hostThreads();
-        for (unsigned i = 1; i < n; i++) threads_.emplace_back([this] { loop(); });
+        // Workers sleep between jobs and are woken together by the submitting thread; the scheduler tends to leave such
+        // short bursts stacked on the waker's CPU.  Each worker is therefore pinned to its own CPU of the allowed set
+        // (spread evenly) when DP_PIN_WORKERS=1.
+        std::vector<int> cpus;
+        const char* pin = getenv("DP_PIN_WORKERS");
+        if (pin && pin[0] != '0') {  // 1: one worker per physical core, spread over all cores; 2: the same within NUMA node 0
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            if (sched_getaffinity(0, sizeof set, &set) == 0)
+                for (int c = 0; c < CPU_SETSIZE; c++) {
+                    if (!CPU_ISSET(c, &set)) continue;
+                    char path[128];
+                    int first = c, node0 = 1;
+                    snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+                    if (FILE* f = fopen(path, "r")) {
+                        if (fscanf(f, "%d", &first) != 1) first = c;
+                        fclose(f);
+                    }
+                    if (first != c) continue;  // SMT sibling of a lower-numbered CPU
+                    if (pin[0] == '2') {
+                        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/node0", c);
+                        node0 = access(path, F_OK) == 0;
+                    }
+                    if (node0) cpus.push_back(c);
+                }
+        }
+        for (unsigned i = 1; i < n; i++) {
+            threads_.emplace_back([this] { loop(); });
+            if (cpus.size() >= n) {
+                cpu_set_t one;
+                CPU_ZERO(&one);
+                CPU_SET(cpus[(size_t)i * cpus.size() / n], &one);
+                pthread_setaffinity_np(threads_.back().native_handle(), sizeof one, &one);
+            }
+        }
         for (auto& t : threads_) t.detach();
     }
     static void work(PoolJob& j) {
@@ -632,12 +708,13 @@ Planner::~Planner() {
 std::shared_ptr<RoundPlan> Planner::compute(i64 round, i64 firstIn) {
     const double tc0 = now();
     struct Tick {
-        double t0;
+        double t0, c0;
         ~Tick() {
             g_prof.planComputes++;
             g_prof.planUs += (long long)((now() - t0) * 1e6);
+            g_prof.plannerCpuUs += (long long)((threadCpuNow() - c0) * 1e6);
         }
-    } tick{tc0};
+    } tick{tc0, threadCpuNow()};
     auto plan = std::make_shared<RoundPlan>();
     plan->round = round;
     plan->firstIn = firstIn;
@@ -788,6 +865,27 @@ void Planner::dropBefore(i64 round) {
 
 OverlapRun::~OverlapRun() { shutdown(); }
 
+void OverlapRun::HugeTable::assign(const double* src, size_t count) {
+    clear();
+    const size_t huge = (size_t)2 << 20;
+    bytes = (count * sizeof(double) + huge - 1) / huge * huge;
+    void* m = mmap(nullptr, bytes + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) throw std::bad_alloc();
+    base_ = m;
+    mapped_ = bytes + huge;
+    p = (double*)(((uintptr_t)m + huge - 1) / huge * huge);
+    madvise(p, bytes, MADV_HUGEPAGE);  // advisory: falls back to small pages silently
+    memcpy(p, src, count * sizeof(double));
+    n = count;
+}
+
+void OverlapRun::HugeTable::clear() {
+    if (base_) munmap(base_, mapped_);
+    base_ = nullptr;
+    p = nullptr;
+    n = bytes = mapped_ = 0;
+}
+
 void OverlapRun::shutdown() {
     {
         std::lock_guard<std::mutex> lk(pmu_);
@@ -819,7 +917,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     snprintf(line, sizeof line, "Counting all %d-mers in the input...\n", p.k);
     errText += line;
     if (valuesOrNull) {
-        values.assign(valuesOrNull, valuesOrNull + ((size_t)1 << (2 * p.k)));
+        values.assign(valuesOrNull, (size_t)1 << (2 * p.k));
     } else {
         std::vector<uint64_t> counts((size_t)1 << (2 * p.k));
         int rc = dp_kmer_histogram(ctx, p.k, counts.data());  // KmerOccurrences on the GPU
@@ -827,7 +925,8 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
             error = dp_last_error(ctx);
             return rc;
         }
-        values = kmerValuesFromCounts(counts, p.k);
+        std::vector<double> v = kmerValuesFromCounts(counts, p.k);
+        values.assign(v.data(), v.size());
     }
     errText += "Counting complete. Starting indexing and querying...";
     slots.clear();
@@ -866,6 +965,7 @@ int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
     const double tb0 = now();
     sl.index->reset();  // seeds.NewSeedIndex(k) per round (:125) — sparse reset instead of reallocating 4^k tables
     for (uint32_t km : plan.seedMap) sl.index->addSeedKmer(km);
+    sl.index->buildRcTable();
     const double tb1 = now();
     g_prof.add(0, tb1 - tb0);
     sl.lap.reset(new Overlapper(sl.ctx, *reads, *sl.index, p.chunkSize, p.numWorkers, p.overlapSize, p.numSeeds, p.minHits));
@@ -918,6 +1018,13 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     out = RoundResult();
     out.round = r;
     double t0 = now();
+    const double tc0 = g_prof.on ? threadCpuNow() : 0;
+    struct SlotCpu {
+        double t0;
+        ~SlotCpu() {
+            if (g_prof.on) g_prof.slotCpuUs += (long long)((threadCpuNow() - t0) * 1e6);
+        }
+    } slotCpu{tc0};
     std::shared_ptr<const RoundPlan> plan = planner->get(r);
     g_prof.getWaitUs += (long long)((now() - t0) * 1e6);
     if (!plan || plan->empty || plan->round != r) {

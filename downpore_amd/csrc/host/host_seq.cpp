@@ -156,6 +156,7 @@ void SeedIndex::reset() {
     std::fill(hkeys.begin(), hkeys.end(), 0xffffffffu);
     std::fill(pre.begin(), pre.end(), 0);
     seedMap.clear();
+    rcOf.clear();
     sequences.clear();
     refs.clear();
     arena.clear();
@@ -175,6 +176,7 @@ void SeedIndex::grow() {
 }
 
 void SeedIndex::addSeedKmer(uint32_t kmer) {
+    if (!rcOf.empty()) rcOf.clear();
     if (!isSeed(kmer)) {
         if ((seedMap.size() + 1) * 2 > hkeys.size()) grow();
         uint32_t h = hash(kmer) & hmask;
@@ -187,7 +189,15 @@ void SeedIndex::addSeedKmer(uint32_t kmer) {
     }
 }
 
+void SeedIndex::buildRcTable() {
+    rcOf.clear();
+    std::vector<int32_t> t(seedMap.size());
+    for (size_t i = 0; i < seedMap.size(); i++) t[i] = seedOfRcKmer((int32_t)i);
+    rcOf.swap(t);
+}
+
 int32_t SeedIndex::seedOfRcKmer(int32_t seed) const {
+    if ((size_t)seed < rcOf.size()) return rcOf[(size_t)seed];
     const int32_t id = find(reverseComplementKmer(seedMap[(size_t)seed], k));
     return id < 0 ? 0 : id;  // kmerMap[] of a non-seed is the zero value (seeds.go:17)
 }
@@ -521,18 +531,29 @@ void gapRange(i64 gap, int k, i64* mn, i64* mx) {
 // util.GetSharedIDs(sets, 2, true) as multiAligner.Consensus uses it (alignment.go:45): seeds present in >= 2 of
 // the sequences.  With minCount == 2 the 4-ladder's v2 is exact and order independent, and the early-return rule
 // (bitset.go:338-342) fires when fewer than 2 sets reach a word — equivalent to "count >= 2" word by word.
-static std::vector<uint64_t> seedsSharedByTwo(const std::vector<SeedSeq*>& seqs) {
+static const std::vector<uint64_t>& seedsSharedByTwo(const std::vector<SeedSeq*>& seqs) {
     int maxSeed = 100;
     for (auto* s : seqs) maxSeed = std::max(maxSeed, s->maxSeed());
     const size_t W = (size_t)maxSeed / 64 + 1;
-    std::vector<uint64_t> v1(W, 0), v2(W, 0), row(W, 0);
+    // sparse form of the word-wise ladder: a seed is shared once a SECOND sequence shows it (row = seen in this sequence)
+    static thread_local std::vector<uint64_t> v1, v2, row;
+    static thread_local std::vector<uint32_t> touched;
+    v1.assign(W, 0);
+    v2.assign(W, 0);
+    if (row.size() < W) row.resize(W, 0);
     for (auto* s : seqs) {
-        std::fill(row.begin(), row.end(), 0);
-        for (int j = 1; j < s->n; j += 2) row[(size_t)s->seg[j] >> 6] |= 1ull << (s->seg[j] & 63);
-        for (size_t w = 0; w < W; w++) {
-            v2[w] |= v1[w] & row[w];
-            v1[w] |= row[w];
+        touched.clear();
+        for (int j = 1; j < s->n; j += 2) {
+            const uint32_t sd = (uint32_t)s->seg[j];
+            const uint64_t bit = 1ull << (sd & 63);
+            uint64_t& r = row[sd >> 6];
+            if (r & bit) continue;
+            if (r == 0) touched.push_back(sd >> 6);
+            r |= bit;
+            if (v1[sd >> 6] & bit) v2[sd >> 6] |= bit;
+            else v1[sd >> 6] |= bit;
         }
+        for (uint32_t w : touched) row[w] = 0;
     }
     return v2;
 }
@@ -599,24 +620,40 @@ static void pairScanInStep(int ns, const int32_t* __restrict__ ok, const int32_t
 // seeds/alignment.go:23-268
 SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k, std::vector<std::unique_ptr<SeedMatch>>& matchesOut) {
     const size_t ns = seqs.size();
-    const std::vector<uint64_t> useSeeds = seedsSharedByTwo(seqs);
-    std::vector<std::vector<int>> seedMap(ns);
-    std::vector<SeedSeq*> red(ns, nullptr);
+    const std::vector<uint64_t>& useSeeds = seedsSharedByTwo(seqs);
+    // scratch that keeps its capacity between calls (one set per worker thread)
+    static thread_local std::vector<std::vector<int>> seedMap;
+    static thread_local std::vector<SeedSeq*> red;
+    static thread_local std::vector<i64> pos, offs, gaps, supported, dist;
+    static thread_local std::vector<int32_t> consensus, okv, odv, sdv, gpv;
+    static thread_local std::vector<uint8_t> slowv, fndv;
+    if (seedMap.size() < ns) seedMap.resize(ns);
+    red.assign(ns, nullptr);
     for (size_t i = 0; i < ns; i++) red[i] = seqReduced(arena, seqs[i], useSeeds, k, 1, &seedMap[i]);
     auto S = [&](size_t i) -> const int32_t* { return red[i] ? red[i]->seg : nullptr; };
     auto N = [&](size_t i) -> i64 { return red[i] ? red[i]->n : 0; };
-    std::vector<i64> pos(ns, -1), offs(ns, 0), gaps(ns, 50), supported(ns, 0), dist(ns, 0);
-    std::vector<int32_t> consensus;
+    pos.assign(ns, -1);
+    offs.assign(ns, 0);
+    gaps.assign(ns, 50);
+    supported.assign(ns, 0);
+    dist.assign(ns, 0);
+    consensus.clear();
     std::vector<std::unique_ptr<SeedMatch>> matches(ns);
     for (size_t i = 0; i < ns; i++)
         if (red[i]) {
             matches[i].reset(new SeedMatch());
             matches[i]->SeqB = seqs[i];
+            matches[i]->MatchA.reserve((size_t)red[i]->n / 2);
+            matches[i]->MatchB.reserve((size_t)red[i]->n / 2);
         }
     bool finished = false;
     const i64 kNarrow = (i64)1 << 28;  // all quantities below this: 32-bit arithmetic is exact
-    std::vector<int32_t> okv(ns), odv(ns), sdv(ns), gpv(ns);
-    std::vector<uint8_t> slowv(ns), fndv(ns);
+    okv.assign(ns, 0);
+    odv.assign(ns, 0);
+    sdv.assign(ns, 0);
+    gpv.assign(ns, 0);
+    slowv.assign(ns, 0);
+    fndv.assign(ns, 0);
     while (!finished) {
         i64 fCount = 0, near = 100000;
         bool memoOk = false, memoSlow = false;  // last support scan of this step: (d, seed, window) -> totals
@@ -753,6 +790,8 @@ SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k,
         consensus.push_back((int32_t)mindist);
         consensus.push_back((int32_t)minseed);
         fCount = 0;
+        bool cWinOk = false;
+        i64 cMin = 0, cMax = 0;
         for (size_t i = 0; i < ns; i++) {
             const int32_t* segment = S(i);
             const i64 sl = N(i);
@@ -763,9 +802,20 @@ SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k,
             i64 matchDex = pos[i] + 1;
             if (matchDex < sl / 2) {
                 i64 min2, max2;
-                gapRange(mindist + gaps[i], k, &min2, &max2);
-                if (min2 > minD) min2 = minD;
-                if (max2 < maxD) max2 = maxD;
+                if (gaps[i] == 0) {  // in step: one window for all such sequences
+                    if (!cWinOk) {
+                        gapRange(mindist, k, &cMin, &cMax);
+                        if (cMin > minD) cMin = minD;
+                        if (cMax < maxD) cMax = maxD;
+                        cWinOk = true;
+                    }
+                    min2 = cMin;
+                    max2 = cMax;
+                } else {
+                    gapRange(mindist + gaps[i], k, &min2, &max2);
+                    if (min2 > minD) min2 = minD;
+                    if (max2 < maxD) max2 = maxD;
+                }
                 i64 otherD = segment[matchDex * 2] - offs[i];
                 while (otherD < min2 && matchDex < sl / 2) {
                     matchDex++;
