@@ -35,6 +35,10 @@ struct dp_ctx {
     DevBuf d_packed;            // 2-bit packed reads, each read starting on a 16-byte boundary
     DevBuf d_boff;              // uint64 byte offset of each read in d_packed  [n_reads+1]
     DevBuf d_len;               // uint32 length in bases                      [n_reads]
+    DevBuf d_values;            // 4^k doubles (kmerRanks) for dp_select_seeds; shared like the reads
+    uint64_t n_values = 0;
+    DevBuf d_selwin, d_seltop;
+    PinBuf h_seltop;
     std::vector<uint64_t> h_boff;
     std::vector<uint32_t> h_len;
 

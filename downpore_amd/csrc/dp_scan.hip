@@ -120,6 +120,8 @@ extern "C" int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out) {
     c->d_len = src->d_len;
     c->h_boff = src->h_boff;
     c->h_len = src->h_len;
+    c->d_values = src->d_values;
+    c->n_values = src->n_values;
     return DP_OK;
 }
 
@@ -127,15 +129,15 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     dp_stream_sync(ctx);
-    if (ctx->borrowed_reads) ctx->d_packed.p = ctx->d_boff.p = ctx->d_len.p = nullptr;
+    if (ctx->borrowed_reads) ctx->d_packed.p = ctx->d_boff.p = ctx->d_len.p = ctx->d_values.p = nullptr;
     DevBuf* dbs[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len, &ctx->d_bits, &ctx->d_kmap, &ctx->d_seeds, &ctx->d_items,
                      &ctx->d_counts, &ctx->d_segoff, &ctx->d_segs, &ctx->d_total, &ctx->d_seqrefs, &ctx->d_posting,
                      &ctx->d_seedsets, &ctx->d_pmeta, &ctx->d_qsegs, &ctx->d_qoff, &ctx->d_qsets, &ctx->d_qmeta,
-                     &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched, &ctx->d_ignore, &ctx->d_surv};
+                     &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched, &ctx->d_ignore, &ctx->d_surv, &ctx->d_values, &ctx->d_selwin, &ctx->d_seltop};
     for (auto* b : dbs)
         if (b->p) hipFree(b->p);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
-                     &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup};
+                     &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop};
     for (auto* b : pbs)
         if (b->p) hipHostFree(b->p);
     for (auto& ev : ctx->ev)
@@ -280,6 +282,113 @@ __device__ __forceinline__ uint32_t valid_mask(uint64_t g, uint64_t a0, uint64_t
     uint32_t mh = hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u);
     uint32_t ml = (1u << lo) - 1u;  // lo < 32 here
     return mh & ~ml;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A9 selection: one wave per window, one lane per block of k evaluated k-mers (seeds/seeds.go:84-128)
+
+#define SEL_MAXTOP 64
+__global__ __launch_bounds__(64) void select_kernel(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ boff,
+                                                    const dp_scan_item* __restrict__ win, uint32_t n, int k, int numSeeds,
+                                                    const double* __restrict__ values, uint32_t* __restrict__ top) {
+    __shared__ double bestV[64];
+    __shared__ uint32_t bestS[64];
+    __shared__ double topV[SEL_MAXTOP];
+    __shared__ uint32_t topN[SEL_MAXTOP];
+    const int lane = dp_lane();
+    const uint32_t w = blockIdx.x;
+    if (w >= n) return;
+    const dp_scan_item it = win[w];
+    const int64_t L = (int64_t)it.n_kmers;  // window length in bases
+    const uint64_t A0 = boff[it.read] * 4 + it.start;
+    const int sh = 32 - 2 * k;
+    if (lane < numSeeds) {
+        topV[lane] = 0.0;
+        topN[lane] = 0u;
+    }
+    // block b starts evaluating at nextIndex = k + 3k*b and exists while nextIndex < L - k
+    const int64_t period = 3 * (int64_t)k;
+    const int64_t nBlocks = (L - 2 * (int64_t)k) > 0 ? ((L - 2 * (int64_t)k) + period - 1) / period : 0;
+    for (int64_t b0 = 0; b0 < nBlocks; b0 += 64) {
+        const int64_t b = b0 + lane;
+        double bv = 0.0;
+        uint32_t bs = 0u;
+        if (b < nBlocks) {
+            const int64_t next0 = (int64_t)k + period * b;
+            for (int i = 0; i < k; i++) {
+                const int64_t ni = next0 + i;  // index of the base that completes the k-mer
+                if (ni >= L) break;
+                const uint64_t a = A0 + (uint64_t)(ni - k + 1);
+                const Win wv = load_win(packed, a >> 5);
+                const uint32_t kmer = win_at_rt(wv, (int)(a & 31)) >> sh;
+                const double v = values[kmer];
+                if (v > bv) {
+                    bv = v;
+                    bs = kmer;
+                }
+            }
+        }
+        bestV[lane] = bv;
+        bestS[lane] = bs;
+        __syncthreads();
+        if (lane == 0) {  // ascending insertion list, blocks in order (:107-120)
+            const int64_t cnt = nBlocks - b0 < 64 ? nBlocks - b0 : 64;
+            for (int64_t j = 0; j < cnt; j++) {
+                const double v = bestV[j];
+                int m = 0;
+                for (; m < numSeeds && topV[m] < v; m++) {
+                    if (m > 0) {
+                        topV[m - 1] = topV[m];
+                        topN[m - 1] = topN[m];
+                    }
+                }
+                if (m > 0) {
+                    topV[m - 1] = v;
+                    topN[m - 1] = bestS[j];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (lane < numSeeds) top[(uint64_t)w * (uint32_t)numSeeds + lane] = topN[lane];
+}
+
+extern "C" int dp_values_upload(dp_ctx* ctx, const double* values, uint64_t n) {
+    if (!ctx || !values || n == 0) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_values_upload: bad arguments") : DP_ERR_ARG;
+    if (ctx->borrowed_reads) return dp_fail(ctx, DP_ERR_STATE, "dp_values_upload on a borrowing context");
+    hipSetDevice(ctx->device);
+    if (dev_reserve(ctx, ctx->d_values, n * sizeof(double))) return DP_ERR_HIP;
+    DP_HIP(hipMemcpyAsync(ctx->d_values.p, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    ctx->n_values = n;
+    return DP_OK;
+}
+
+extern "C" int dp_select_seeds(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out) {
+    if (!ctx || (n && (!win || !top_out))) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_select_seeds: bad arguments") : DP_ERR_ARG;
+    if (k < 1 || k > 16 || num_seeds < 1 || num_seeds > SEL_MAXTOP) return dp_fail(ctx, DP_ERR_ARG, "dp_select_seeds: k in 1..16, num_seeds in 1..64");
+    if (!ctx->d_values.p || ctx->n_values != ((uint64_t)1 << (2 * k))) return dp_fail(ctx, DP_ERR_STATE, "dp_select_seeds: value table for this k not uploaded");
+    if (n == 0) return DP_OK;
+    hipSetDevice(ctx->device);
+    for (uint32_t i = 0; i < n; i++) {
+        if (win[i].read >= ctx->n_reads || (uint64_t)win[i].start + win[i].n_kmers > ctx->h_len[win[i].read])
+            return dp_fail(ctx, DP_ERR_ARG, "dp_select_seeds: window outside its read");
+    }
+    const size_t wb = (size_t)n * sizeof(dp_scan_item), tb = (size_t)n * (size_t)num_seeds * 4;
+    if (dev_reserve(ctx, ctx->d_selwin, wb)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_seltop, tb)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_seltop, wb + tb)) return DP_ERR_HIP;
+    memcpy(ctx->h_seltop.p, win, wb);
+    DP_HIP(hipMemcpyAsync(ctx->d_selwin.p, ctx->h_seltop.p, wb, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(select_kernel, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
+                       (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_selwin.p, n, k, num_seeds,
+                       (const double*)ctx->d_values.p, (uint32_t*)ctx->d_seltop.p);
+    DP_HIP(hipGetLastError());
+    DP_HIP(hipMemcpyAsync((uint8_t*)ctx->h_seltop.p + wb, ctx->d_seltop.p, tb, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    memcpy(top_out, (uint8_t*)ctx->h_seltop.p + wb, tb);
+    return DP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

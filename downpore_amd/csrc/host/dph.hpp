@@ -293,6 +293,8 @@ struct RoundPlan {
     bool empty = true;              // len(queries) == 0 -> the command ends (:130)
     std::vector<Overlapper::Window> windows;
     std::vector<uint32_t> seedMap;  // seed id -> k-mer
+    bool failed = false;            // a device call of the planner failed; `error` holds the text
+    std::string error;
 };
 
 // Runs the PrepareQueries chain ahead of the executing rounds on its own thread.  Plans are speculative with respect
@@ -301,7 +303,8 @@ struct RoundPlan {
 // sequential command would compute.
 class Planner {
    public:
-    Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded);
+    // selCtx (may be null): device context whose resident reads + value table serve the speculative seed selection
+    Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded, dp_ctx* selCtx = nullptr);
     ~Planner();
     std::shared_ptr<const RoundPlan> get(i64 round);
     // commit-time: set the flags; returns the first round whose cached plan was discarded (or -1)
@@ -359,6 +362,7 @@ struct OverlapRun {
     } values;
     std::vector<std::unique_ptr<ExecSlot>> slots;  // slot 0 drives `ctx`; further slots use contexts that borrow its reads
     std::unique_ptr<Planner> planner;
+    dp_ctx* plannerCtx = nullptr;  // borrows the reads and the value table of `ctx`
     i64 firstSequence = 0;
     i64 round = 0;  // next round to commit
     i64 numQuerySeqs = 0;

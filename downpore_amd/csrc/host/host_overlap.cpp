@@ -109,25 +109,44 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values
     };
     std::vector<uint32_t> spec;
     size_t specDone = 0;
+    bool specFailed = false;
     auto speculate = [&](size_t upTo) {  // thread-parallel selection assuming no evaluated k-mer is a seed yet
         moreCands(upTo);
         const size_t n = cand.size();
         spec.resize(n * (size_t)numSeeds);
         const size_t first = specDone;
         if (n <= first) return;
-        std::atomic<long long> selUs(0);
-        parallelFor(n - first, [&](size_t i) {
-            const size_t w = first + i;
-            const Cand& c = cand[w];
-            const double tw = g_prof.on ? threadCpuNow() : 0;
-            index_.selectSeeds(reads_.seq(c.read) + c.start, c.len, numSeeds, values, &spec[w * (size_t)numSeeds], false);
-            if (g_prof.on) selUs += (long long)((threadCpuNow() - tw) * 1e6);
-        });
-        g_prof.selectCpuUs += selUs.load();
+        if (ctx_) {  // device-side selection over the resident reads (dp_select_seeds); ctx_ is the planner's context
+            std::vector<dp_scan_item> items(n - first);
+            for (size_t w = first; w < n; w++) {
+                dp_scan_item& it = items[w - first];
+                it.read = cand[w].read;
+                it.start = cand[w].start;
+                it.n_kmers = cand[w].len;  // window length in bases
+                it.min_seeds = 0;
+            }
+            const int rc = dp_select_seeds(ctx_, items.data(), (uint32_t)items.size(), index_.k, numSeeds,
+                                           &spec[first * (size_t)numSeeds]);
+            if (rc != 0) {
+                err = dp_last_error(ctx_);
+                specFailed = true;
+            }
+        } else {
+            std::atomic<long long> selUs(0);
+            parallelFor(n - first, [&](size_t i) {
+                const size_t w = first + i;
+                const Cand& c = cand[w];
+                const double tw = g_prof.on ? threadCpuNow() : 0;
+                index_.selectSeeds(reads_.seq(c.read) + c.start, c.len, numSeeds, values, &spec[w * (size_t)numSeeds], false);
+                if (g_prof.on) selUs += (long long)((threadCpuNow() - tw) * 1e6);
+            });
+            g_prof.selectCpuUs += selUs.load();
+}
         specDone = n;
     };
     const double tsp0 = now();
     speculate(want);
+    if (specFailed) return -1;
     const double tsp1 = now();
     g_prof.add(16, tsp1 - tsp0);
     struct CommitTick {
@@ -139,6 +158,7 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values
     for (;;) {
         if (w >= cand.size()) {
             speculate(cand.size() + 64);
+            if (specFailed) return -1;
             if (w >= cand.size()) break;  // input exhausted
         }
         // getEdges tests the budget once per READ, before its first window (overlap.go:57-60)
@@ -679,6 +699,7 @@ struct Planner::Impl {
     OverlapParams p;
     const double* values;
     bool threaded;
+    dp_ctx* selCtx;
     SeedIndex index;  // selection-side seed set of the plan being computed
     std::mutex mu;
     std::condition_variable cv;
@@ -689,10 +710,12 @@ struct Planner::Impl {
     i64 epochMinId = -1;      // smallest read id flagged in the last bump(s) while a compute was running
     bool stop = false;
     std::thread th;
-    Impl(ReadSet& r, const OverlapParams& pp, const double* v, bool t) : reads(r), p(pp), values(v), threaded(t), index(pp.k) {}
+    Impl(ReadSet& r, const OverlapParams& pp, const double* v, bool t, dp_ctx* sc)
+        : reads(r), p(pp), values(v), threaded(t), selCtx(sc), index(pp.k) {}
 };
 
-Planner::Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded) : d(new Impl(reads, p, values, threaded)) {
+Planner::Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded, dp_ctx* selCtx)
+    : d(new Impl(reads, p, values, threaded, selCtx)) {
     if (threaded) d->th = std::thread([this] { threadMain(); });
 }
 
@@ -719,9 +742,15 @@ std::shared_ptr<RoundPlan> Planner::compute(i64 round, i64 firstIn) {
     plan->round = round;
     plan->firstIn = firstIn;
     d->index.reset();
-    Overlapper lap(nullptr, d->reads, d->index, d->p.chunkSize, d->p.numWorkers, d->p.overlapSize, d->p.numSeeds, d->p.minHits);
+    // the device path needs the window in the resident (cached-view) form and at most 64 list slots
+    dp_ctx* sel = (d->selCtx && d->p.numSeeds <= 64) ? d->selCtx : nullptr;
+    Overlapper lap(sel, d->reads, d->index, d->p.chunkSize, d->p.numWorkers, d->p.overlapSize, d->p.numSeeds, d->p.minHits);
     const int nw = lap.PrepareQueries(d->p.numSeeds, d->p.seedBatchSize, d->values, firstIn, d->p.queryBatchSize);
-    plan->empty = nw == 0;
+    if (nw < 0) {
+        plan->error = lap.err;
+        plan->failed = true;
+    }
+    plan->empty = nw <= 0;
     plan->windows = lap.windows();
     plan->seedMap = d->index.seedMap;
     // firstSequence = max query SequenceID + 1 (commands/overlap.go:135-142); windows are in ascending read order
@@ -899,6 +928,8 @@ void OverlapRun::shutdown() {
     redo_.clear();
     if (planner) g_prof.print();
     planner.reset();
+    if (plannerCtx) dp_ctx_destroy(plannerCtx);
+    plannerCtx = nullptr;
     for (auto& sl : slots) {
         sl->lap.reset();
         sl->index.reset();
@@ -929,6 +960,16 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         values.assign(v.data(), v.size());
     }
     errText += "Counting complete. Starting indexing and querying...";
+    {
+        const char* hostsel = getenv("DP_HOST_SELECT");
+        if (!(hostsel && hostsel[0] == '1') && p.numSeeds <= 64) {  // value table resident for dp_select_seeds
+            int rc = dp_values_upload(ctx, values.data(), values.size());
+            if (rc != 0) {
+                error = dp_last_error(ctx);
+                return rc;
+            }
+        }
+    }
     slots.clear();
     setHostThreadShare((unsigned)std::max(1, nSlots));
     for (int i = 0; i < std::max(1, nSlots); i++) {
@@ -947,7 +988,15 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         slots.push_back(std::move(sl));
     }
     const char* nothread = getenv("DP_NO_PLANNER_THREAD");
-    planner.reset(new Planner(*reads, p, values.data(), !(nothread && nothread[0] == '1')));
+    const char* hostsel = getenv("DP_HOST_SELECT");  // 1: keep the speculative seed selection on the host threads
+    if (!(hostsel && hostsel[0] == '1') && p.numSeeds <= 64) {
+        int rc = dp_ctx_create_shared(ctx, &plannerCtx);
+        if (rc != 0) {
+            error = dp_last_error(nullptr);
+            return rc;
+        }
+    }
+    planner.reset(new Planner(*reads, p, values.data(), !(nothread && nothread[0] == '1'), plannerCtx));
     firstSequence = 0;
     round = 0;
     done = false;
@@ -1027,6 +1076,10 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     } slotCpu{tc0};
     std::shared_ptr<const RoundPlan> plan = planner->get(r);
     g_prof.getWaitUs += (long long)((now() - t0) * 1e6);
+    if (plan && plan->failed) {
+        sl.error = "seed selection failed: " + plan->error;
+        return -1;
+    }
     if (!plan || plan->empty || plan->round != r) {
         out.empty = true;
         if (plan) out.firstIn = out.firstOut = plan->firstOut;
@@ -1264,6 +1317,10 @@ int OverlapRun::roundPrepareAndScan() {
     cur.round = round;
     double t0 = now();
     curPlan = planner->get(round);
+    if (curPlan && curPlan->failed) {
+        error = "seed selection failed: " + curPlan->error;
+        return -1;
+    }
     if (!curPlan || curPlan->empty) {
         done = true;
         return 0;

@@ -46,7 +46,7 @@ class ChainBatch(C.Structure):
 SYMBOLS = ["dp_version", "dp_ctx_create", "dp_ctx_create_shared", "dp_ctx_destroy", "dp_last_error", "dp_reads_upload", "dp_reads_packed",
            "dp_reads_count", "dp_reads_total_bases", "dp_kmer_histogram", "dp_round_begin", "dp_scan", "dp_scan_reads", "dp_index_build",
            "dp_find_overlaps", "dp_map_windows", "dp_index_posting_row", "dp_index_seedset_row", "dp_scan_device_buffers",
-           "dp_scan_import_segments"]
+           "dp_scan_import_segments", "dp_values_upload", "dp_select_seeds"]
 
 _lib = None
 
@@ -173,6 +173,22 @@ class Context:
                     extra_n_seeds=_arr(b.extra_n_seeds, ne, np.uint32), extra_seg_off=_arr(b.extra_seg_off, ne, np.uint64),
                     segs=_arr(b.segs, b.n_segs, np.int32), bases_scanned=b.bases_scanned, reads_scanned=b.reads_scanned,
                     kernel_ms=b.kernel_ms)
+
+    # ---- A9 selection
+    def values_upload(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self.L.dp_values_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        self._chk(self.L.dp_values_upload(self.h, v.ctypes.data, len(v)))
+
+    def select_seeds(self, windows, k, num_seeds):
+        """windows: (read, start, length in bases) rows -> uint32 [n, num_seeds] k-mers in insertion-list order."""
+        w = np.zeros((len(windows), 4), dtype=np.uint32)
+        if len(windows):
+            w[:, :3] = np.asarray(windows, dtype=np.uint32).reshape(-1, 3)
+        out = np.zeros((len(windows), num_seeds), dtype=np.uint32)
+        self.L.dp_select_seeds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        self._chk(self.L.dp_select_seeds(self.h, w.ctypes.data, len(w), k, num_seeds, out.ctypes.data))
+        return out
 
     def import_segments(self, segs):
         s = np.ascontiguousarray(segs, dtype=np.int32)

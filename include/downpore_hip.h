@@ -126,6 +126,21 @@ typedef struct {
 int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
                   uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out);
 
+/* ---- A9 (selection part): AddSeeds' block-winner / top-N selection on the device -------------------------
+ * seeds.AddSeeds (seeds/seeds.go:62-129) walks a query window in blocks of k rolling k-mers followed by 2k skipped
+ * bases, looks every evaluated k-mer up in the 4^k-entry value table (`kmerRanks`), keeps the block maximum
+ * (strict >, first wins, initial 0.0 / k-mer 0) and feeds it to an ascending top-`num_seeds` insertion list.  The
+ * table probes are random 8-byte reads over 4^k*8 bytes (512 MiB at k=13): latency-bound on a CPU, cheap in HBM.
+ * dp_values_upload keeps the table resident (borrowing contexts created AFTERWARDS share it); dp_select_seeds runs
+ * the selection for `n` windows assuming no evaluated k-mer is a seed yet ("speculative" form: the caller re-runs a
+ * window on the host when that assumption fails, i.e. when AddSeeds would have abandoned a block, seeds.go:94-97)
+ * and writes num_seeds k-mers per window to `top_out` in list order (untouched slots hold k-mer 0, as in the
+ * reference).  win[i].read/start/n_kmers describe the window (n_kmers = window length in BASES here); min_seeds is
+ * ignored.  num_seeds <= 64. */
+int dp_values_upload(dp_ctx* ctx, const double* values, uint64_t n);
+int dp_select_seeds(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out);
+
+
 /* ---- A13: seed index build ------------------------------------------------------------------------------
  * Replaces SeedIndex.AddSequence + IndexSequences/index (seeds/seeds.go:272-305,372-384).  Indexed sequence i
  * is a view segs[seg_off .. seg_off + 2*n_seeds + 1) into the device-resident output of the last dp_scan

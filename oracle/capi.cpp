@@ -204,6 +204,32 @@ int dpo_kmer_counts(void* h, int k, uint64_t* counts) {
     });
 }
 
+// AddSeeds (seeds/seeds.go:62-156) of each sequence into an EMPTY index: out receives the resulting seedMap (k-mers in
+// seed-id order) per sequence, off[i]..off[i+1].  Test hook for the product's device-side selection.
+int dpo_add_seeds_each(void** seqs, int64_t n, int k, int64_t numSeeds, const double* values, int64_t* out, int64_t cap,
+                       int64_t* off) {
+    return guard([&] {
+        SeedIndex index(k);
+        int64_t pos = 0;
+        off[0] = 0;
+        for (int64_t i = 0; i < n; i++) {
+            index.addSeeds(*(PackedSeq*)seqs[i], numSeeds, values);
+            for (i64 km : index.seedMap) {
+                if (pos >= cap) throw std::runtime_error("dpo_add_seeds_each: output too small");
+                out[pos++] = km;
+            }
+            off[i + 1] = pos;
+            for (i64 km : index.seedMap) {  // back to the empty index
+                index.kmers[(size_t)km] = 0;
+                index.kmerMap[(size_t)km] = 0;
+            }
+            index.seedMap.clear();
+            index.sequenceSets.clear();  // grown in lock step with seedMap (addSeedKmer)
+            index.size = 0;
+        }
+    });
+}
+
 // ---- overlap command -------------------------------------------------------------------------
 struct OverlapH {
     OverlapResult res;

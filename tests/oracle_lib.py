@@ -211,6 +211,24 @@ def byte_write_segments(s, k, seeds):
     return out[:n].copy()
 
 
+def add_seeds_each(seqs, k, num_seeds, values):
+    """AddSeeds of every Seq into an empty index: list of seedMaps (k-mers in seed-id order)."""
+    L = lib()
+    L.dpo_add_seeds_each.restype = C.c_int
+    L.dpo_add_seeds_each.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_void_p]
+    n = len(seqs)
+    hs = (C.c_void_p * n)(*[s.h for s in seqs])
+    cap = n * num_seeds * 2 + 16
+    out = np.zeros(cap, dtype=np.int64)
+    off = np.zeros(n + 1, dtype=np.int64)
+    vals = np.ascontiguousarray(values, dtype=np.float64)
+    rc = L.dpo_add_seeds_each(hs, n, k, num_seeds, vals.ctypes.data, out.ctypes.data, cap, off.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(L.dpo_last_error().decode())
+    return [out[off[i]:off[i + 1]].copy() for i in range(n)]
+
+
 def kmer_value(s):
     v = 0
     for ch in s.encode():

@@ -234,3 +234,44 @@ def test_scan_reads_compaction_matches_itemwise_scan(ctx):
                 o = int(got["extra_seg_off"][j])
                 b = got["segs"][o:o + 2 * int(got["extra_n_seeds"][j]) + 1]
                 assert np.array_equal(b, ex["segs"][int(ex["seg_off"][j]):int(ex["seg_off"][j + 1])])
+
+
+def _rc_kmer(km, k):
+    r = 0
+    for _ in range(k):
+        r = (r << 2) | (3 - (km & 3))
+        km >>= 2
+    return r
+
+
+@pytest.mark.parametrize("k,L,e", [(13, 10000, 0.0), (10, 3000, 0.02)])
+def test_select_seeds_matches_addseeds(ctx, k, L, e):
+    """dp_select_seeds (A9 selection on the device) against the oracle's AddSeeds into an empty index."""
+    N = 120
+    bases, off = O.gen_reads(77 + k, N * L // 10, N, L, e, True)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    values = rs.kmer_values(k)
+    ctx.upload_reads(bases, off)
+    ctx.values_upload(values)
+    wins, seqs = [], []
+    rng = np.random.default_rng(5)
+    for r in range(0, N, 2):
+        Lr = int(off[r + 1] - off[r])
+        text = bases[off[r]:off[r + 1]].tobytes().decode()
+        view = O.Seq(text).sub(0, Lr)  # the cached view a later pass is served (seqio.go:115)
+        for st, ln in ((0, min(1000, Lr)), (max(0, Lr - 1000), min(1000, Lr)), (int(rng.integers(0, Lr - 60)), 0)):
+            if ln == 0:
+                ln = int(rng.integers(2 * k - 1, min(Lr - st, 2600)))  # incl. windows shorter than one block and > 64 blocks
+            wins.append((r, st, ln))
+            seqs.append(view if (st == 0 and ln == Lr) else view.sub(st, st + ln))
+    for num_seeds in (15, 7):
+        top = ctx.select_seeds(wins, k, num_seeds)
+        want = O.add_seeds_each(seqs, k, num_seeds, values)
+        for i in range(len(wins)):
+            got, seen = [], set()
+            for km in top[i].tolist():  # AddSeeds :130-154: every list slot (incl. untouched zeros), then its RC
+                for x in (km, _rc_kmer(km, k)):
+                    if x not in seen:
+                        seen.add(x)
+                        got.append(x)
+            assert got == want[i].tolist(), (num_seeds, wins[i])
