@@ -539,7 +539,8 @@ __global__ __launch_bounds__(SCAN_THREADS, FILTER >= 2 ? 8 : 4) void scan_kernel
                                                             const uint32_t* __restrict__ seeds, uint32_t n_seeds,
                                                             const uint32_t* __restrict__ bits, const int32_t* __restrict__ kmap,
                                                             uint32_t* __restrict__ counts, const uint64_t* __restrict__ segoff,
-                                                            int32_t* __restrict__ segs, uint32_t dbg) {
+                                                            int32_t* __restrict__ segs, uint32_t dbg,
+                                                            const uint32_t* __restrict__ sel, uint32_t n_sel) {
     constexpr uint32_t LDS_BYTES = FILTER == 1 ? BLOOM_BYTES : (T1_BYTES + T2_BYTES);  // FILTER 3 = timing experiment (no LDS probes)  // v2: 80 KiB -> two workgroups per CU
     __shared__ __attribute__((aligned(16))) uint8_t bloom[LDS_BYTES];  // FILTER 2: T1 | T2
     const int pb = k < 10 ? k : 10;       // prefix bases used by the v1 LDS filter
@@ -570,9 +571,13 @@ __global__ __launch_bounds__(SCAN_THREADS, FILTER >= 2 ? 8 : 4) void scan_kernel
     const int lane = dp_lane();
     const uint32_t waves = gridDim.x * (SCAN_THREADS / 64);
     const uint32_t gw = blockIdx.x * (SCAN_THREADS / 64) + (threadIdx.x >> 6);
-    for (uint32_t it = gw; it < n_items; it += waves) {
+    // sel (write pass of dp_scan_reads): the compacted list of surviving items, one per wave, instead of a strided walk
+    // over all items that skips the non-survivors
+    const uint32_t n_loop = sel ? n_sel : n_items;
+    for (uint32_t li = gw; li < n_loop; li += waves) {
+        const uint32_t it = sel ? sel[li] : li;
         const dp_scan_item item = items[it];
-        if (MODE == 1 && counts[it] < item.min_seeds) continue;
+        if (MODE == 1 && !sel && counts[it] < item.min_seeds) continue;
         const uint64_t a0 = boff[item.read] * 4 + item.start;
         const uint64_t a1 = a0 + item.n_kmers;
         int cnt = 0;
@@ -763,7 +768,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     hipLaunchKernelGGL(((dbg & 2) ? scan_kernel<0, 3> : v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
                        (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p, n_items, k,
                        (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
-                       (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr, dbg);
+                       (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr, dbg, (const uint32_t*)nullptr, 0u);
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     {
@@ -794,7 +799,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
                            (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p,
                            n_items, k, (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
                            (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
-                           (int32_t*)ctx->d_segs.p, 0u);
+                           (int32_t*)ctx->d_segs.p, 0u, (const uint32_t*)nullptr, 0u);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -938,7 +943,7 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     hipLaunchKernelGGL((v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
                        (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)d_items, n_items, k,
                        (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
-                       (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr, 0u);
+                       (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr, 0u, (const uint32_t*)nullptr, 0u);
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     hipLaunchKernelGGL(offsets_tile_sums, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
@@ -974,11 +979,13 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     }
     if (n_segs) {
         DP_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-        hipLaunchKernelGGL((v2 ? scan_kernel<1, 2> : scan_kernel<1, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
+        // one wave per SURVIVOR (the compacted list), not a strided walk over every item
+        const uint32_t wgrid = (uint32_t)std::min<uint64_t>(grid, (n_surv_all + 15) / 16);
+        hipLaunchKernelGGL((v2 ? scan_kernel<1, 2> : scan_kernel<1, 1>), dim3(std::max(1u, wgrid)), dim3(SCAN_THREADS), 0, ctx->stream,
                            (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)d_items, n_items, k,
                            (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
                            (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
-                           (int32_t*)ctx->d_segs.p, 0u);
+                           (int32_t*)ctx->d_segs.p, 0u, (const uint32_t*)s_item, (uint32_t)n_surv_all);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));

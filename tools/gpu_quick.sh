@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 nproc > gpurun_out/nproc.txt; lscpu | grep "Model name" >> gpurun_out/nproc.txt
 timeout 600 python -m pytest tests -m gpu -x -q --timeout=300 --timeout-method=thread > gpurun_out/gpu_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/gpu_tests.log
-timeout 600 python bench.py --steps 20 --warmup 3 ${BENCH_ARGS} > gpurun_out/bench_q.json 2> gpurun_out/bench_q.err; echo "bench rc=$?" >> gpurun_out/bench_q.err
+timeout 600 python bench.py ${BENCH_ARGS} > gpurun_out/bench_q.json 2> gpurun_out/bench_q.err; echo "bench rc=$?" >> gpurun_out/bench_q.err
 tail -5 gpurun_out/gpu_tests.log; cat gpurun_out/nproc.txt
 python - <<'PY'
 import json
