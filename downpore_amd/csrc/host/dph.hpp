@@ -217,8 +217,12 @@ struct Survivors {
     std::vector<uint32_t> read;      // read id per survivor (ascending)
     std::vector<uint32_t> n_seeds;
     std::vector<uint64_t> seg_off;   // n+1
-    std::vector<int32_t> segs;
-    bool deviceResident = false;     // the device scan buffer of the producing context holds exactly `segs` at the same offsets
+    std::vector<int32_t> segs;       // owned copy (after a multi-GPU exchange) ...
+    const int32_t* segsView = nullptr;  // ... or a view of the producing context's pinned scan output (valid until that
+    uint64_t segsViewLen = 0;           // context scans again): the dense-seed regime moves ~80 MB per round here
+    bool deviceResident = false;     // the device scan buffer of the producing context holds exactly these ints at the same offsets
+    const int32_t* segData() const { return segsView ? segsView : segs.data(); }
+    uint64_t segCount() const { return segsView ? segsViewLen : (uint64_t)segs.size(); }
 };
 
 class Overlapper {
@@ -264,7 +268,7 @@ class Overlapper {
     std::vector<uint64_t> queryOff_;
     std::vector<int32_t> winSegs_;         // scan output of the windows
     std::vector<uint64_t> winOff_;
-    std::vector<int32_t> allSegs_;         // survivors' segments (host copy; device copy is what the index references)
+    const int32_t* allSegs_ = nullptr;     // survivors' segments on the host (device copy is what the index references)
 };
 
 unsigned hostThreads();  // DP_HOST_THREADS or hardware_concurrency (<= 96): size of the shared worker pool

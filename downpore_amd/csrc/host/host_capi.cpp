@@ -107,9 +107,9 @@ void dph_overlap_local(void* hh, const uint32_t** read, const uint32_t** nseeds,
     *read = s.read.data();
     *nseeds = s.n_seeds.data();
     *segoff = s.seg_off.data();
-    *segs = s.segs.data();
+    *segs = s.segData();
     *n = s.read.size();
-    *nsegs = s.segs.size();
+    *nsegs = s.segCount();
 }
 // survivors == all ranks' lists concatenated in rank order (read ids ascending); read == NULL: use the local list
 int dph_overlap_round_finish(void* hh, const uint32_t* read, const uint32_t* nseeds, const int32_t* segs, uint64_t n) {
@@ -127,7 +127,8 @@ int dph_overlap_round_finish(void* hh, const uint32_t* read, const uint32_t* nse
             pos += 2ull * nseeds[i] + 1;
             all.seg_off.push_back(pos);
         }
-        all.segs.assign(segs, segs + pos);
+        all.segsView = segs;  // the caller's gathered array outlives the call
+        all.segsViewLen = pos;
         rc = h->run.roundFinish(all);
     }
     if (rc < 0) h->err = h->run.error;

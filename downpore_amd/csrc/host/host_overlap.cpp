@@ -218,7 +218,9 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
     uint64_t survEnd = 0;
     if (b.n_survivors) survEnd = b.seg_off[b.n_survivors - 1] + 2ull * b.n_seeds[b.n_survivors - 1] + 1;
     local.seg_off.push_back(survEnd);
-    local.segs.assign(b.segs, b.segs + survEnd);
+    local.segs.clear();
+    local.segsView = b.segs;  // pinned output of this context, untouched until its next scan (= this slot's next round)
+    local.segsViewLen = survEnd;
     local.deviceResident = true;
     // query windows
     winSegs_.clear();
@@ -299,11 +301,11 @@ void Overlapper::chunkAndAdd(SeedSeq* s, uint64_t segBase) {
 // AddSequences :217 (chunk + index part) from the complete survivor list (file order).
 int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
     double tp0 = now();
-    allSegs_ = all.segs;
+    allSegs_ = all.segData();
     // the device-resident scan output the index refers to must hold exactly this survivor array at the same offsets:
     // true right after a local full scan; after a multi-GPU exchange the gathered array is imported
     int rc = 0;
-    if (!all.deviceResident) rc = dp_scan_import_segments(ctx_, allSegs_.data(), allSegs_.size());
+    if (!all.deviceResident) rc = dp_scan_import_segments(ctx_, allSegs_, all.segCount());
     if (rc != 0) {
         err = dp_last_error(ctx_);
         return rc;
@@ -315,7 +317,7 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
     for (size_t i = 0; i < all.read.size(); i++) {
         const uint32_t r = all.read[i];
         SeedSeq* s = index_.arena.make();
-        s->seg = allSegs_.data() + all.seg_off[i];
+        s->seg = allSegs_ + all.seg_off[i];
         s->n = (int)(all.seg_off[i + 1] - all.seg_off[i]);
         s->id = (int)r;
         s->length = reads_.length(r);
