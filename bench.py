@@ -161,25 +161,42 @@ def main():
                          "wall_s": elapsed},
         }
         if world == 1 and args.cpu_rounds > 0:
-            out["cpu_baseline"] = cpu_baseline(bases, off, args, pipe.values())
+            vals = pipe.values()
+            out["cpu_baseline"] = cpu_baseline(bases, off, args, vals, threads=1)
+            # the same port with its per-read scans spread over the host cores this container may use
+            out["cpu_baseline_all_cores"] = cpu_baseline(bases, off, args, vals, threads=cpu_budget())
         print(json.dumps(out))
     pipe.close()
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(bases, off, args, values):
+def cpu_budget():
+    """CPUs this container may use: the cgroup quota when there is one, else the CPU count."""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(bases, off, args, values, threads=1):
     """The oracle (a quirk-exact C++ port of the reference's CPU algorithm incl. its two-pass scan over a 4^k-byte
-    table) timed single-threaded on the host for the first rounds of the same workload."""
+    table) timed on the host for the first rounds of the same workload; threads > 1 spreads the per-read scans (the
+    part the reference parallelises with num_workers) over that many threads."""
     from tests import oracle_lib as O
     O.build_oracle()
+    os.environ["DPO_SCAN_THREADS"] = str(threads)
     rs = O.ReadSet(bases, off, min_len=1000)
     t0 = time.perf_counter()
     run = O.OverlapRun(rs, k=args.k, seed_batch_size=args.seed_batch_size, values=np.ascontiguousarray(values),
                        max_rounds=args.cpu_rounds, traces=False)
     dt = time.perf_counter() - t0
     lines = run.paf.count("\n")
-    return {"value": lines / dt if dt > 0 else 0.0, "unit": "overlaps/s", "cores": 1, "kind": "port",
+    return {"value": lines / dt if dt > 0 else 0.0, "unit": "overlaps/s", "cores": threads, "kind": "port",
             "sample": "first %d rounds of the same workload (value table supplied), %.1f s, %d PAF lines" % (run.rounds, dt, lines),
             "ms_per_step": 1e3 * dt / max(1, run.rounds)}
 

@@ -200,6 +200,7 @@ struct OverlapParams {  // flag table commands/overlap.go:24-25
     double minHits = 0.25;
     int numWorkers = 4;  // accepted for compatibility; the GPU path is batch-parallel
     bool himem = true;
+    int queryType = 1;   // overlap.QueryEdges | QueryCentre | QueryAll (+ WeightEdges), overlap.go:18-21
 };
 
 struct RoundStats {
@@ -231,7 +232,7 @@ class Overlapper {
                double hitFraction);
     // PrepareQueries (:157): seed selection over the query windows; returns the windows (queries are completed by
     // AddSequences, which scans them on the GPU together with the reads)
-    int PrepareQueries(int numSeeds, i64 seedLimit, const double* kmerValues, i64 firstSequence, i64 maxSeqs);
+    int PrepareQueries(int numSeeds, i64 seedLimit, const double* kmerValues, i64 firstSequence, i64 maxSeqs, int queryType = 1);
     // AddSequences (:217): GPU scan of every non-ignored read in [shardLo, shardHi) + all query windows
     int ScanLocal(size_t shardLo, size_t shardHi, Survivors& local, RoundStats& st);
     // chunkWorker (:253) + IndexSequences on the GPU, from the (possibly all-gathered) survivors

@@ -65,7 +65,8 @@ void* dph_overlap_create(void* reads, int device, const int64_t* params, double 
     p.seedBatchSize = params[3];
     p.chunkSize = params[4];
     p.queryBatchSize = params[5];
-    p.himem = params[6] != 0;
+    p.himem = (params[6] & 1) != 0;
+    p.queryType = (int)(params[6] >> 8) ? (int)(params[6] >> 8) : 1;  // bits 8.. of the himem word: overlap.Query* flags
     p.minHits = minHits;
     rc = dp_reads_upload(h->ctx, (const uint8_t*)rs.bases.data(), rs.off.data(), (uint32_t)rs.size());
     if (rc == 0) rc = h->run.init(h->ctx, &rs, p, valuesOrNull, nSlots);

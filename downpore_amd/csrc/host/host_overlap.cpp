@@ -79,40 +79,84 @@ Overlapper::Overlapper(dp_ctx* ctx, ReadSet& reads, SeedIndex& index, i64 chunkS
 
 // PrepareQueries :157-214 with getEdges :55-89 (QueryEdges): seed selection is sequential and stays on the host.
 // Returns the number of query windows.
-int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values, i64 firstSequence, i64 maxSeqs) {
+int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values, i64 firstSequence, i64 maxSeqs, int queryType) {
     windows_.clear();
     queries.clear();
-    // Candidate windows in file order.  The seed-budget cut-off (overlap.go:58) is applied in the sequential commit loop
-    // below; a window contributes at most 2*numSeeds seeds, so seedLimit/(2*numSeeds) windows are certainly needed and a
-    // modest surplus is selected speculatively.  (Selection = the rank-table lookups = the expensive part.)
+    const bool weightSides = (queryType & 8) != 0;  // WeightEdges: seeds come from the two 200-base sides of a window
+    if (weightSides) numSeeds /= 2;                  // overlap.go:161-163
+    if (numSeeds < 1) return 0;
+    // Query windows in file order (getEdges :55-89 / getCentres :91-117 / getAll :119-155), each with the one or two
+    // sub-windows AddSeeds actually sees (addWeighted :45-53).  The seed-budget cut-off (tested once per read) is applied
+    // in the sequential commit loop below; a sub-window contributes at most 2*numSeeds seeds, so
+    // seedLimit/(2*numSeeds) of them are certainly needed and a modest surplus is selected speculatively.
+    // (Selection = the rank-table lookups = the expensive part.)
+    struct Sel {
+        uint32_t read, start, len;
+    };
     struct Cand {
         uint32_t read, start, len;
-        bool lastOfRead;
+        uint32_t selFirst, selCount;
+        bool firstOfRead;
     };
     std::vector<Cand> cand;
+    std::vector<Sel> sel;
     const size_t want = (size_t)(seedLimit / std::max(1, 2 * numSeeds)) + 96;
     i64 sent = 0;
     size_t rNext = (size_t)firstSequence;
+    auto addWindow = [&](uint32_t read, i64 start, i64 end, bool firstOfRead) {
+        Cand c{read, (uint32_t)start, (uint32_t)(end - start), (uint32_t)sel.size(), 0u, firstOfRead};
+        const i64 len = end - start, sideSize = 200;
+        if (weightSides && len > 400) {
+            sel.push_back({read, (uint32_t)start, (uint32_t)sideSize});
+            sel.push_back({read, (uint32_t)(end - sideSize), (uint32_t)sideSize});
+            c.selCount = 2;
+        } else {
+            sel.push_back({read, (uint32_t)start, (uint32_t)len});
+            c.selCount = 1;
+        }
+        cand.push_back(c);
+    };
     auto moreCands = [&](size_t upTo) {
         if (firstSequence != 0 && firstSequence >= (i64)reads_.size()) return;  // seqio.go:279
-        for (; rNext < reads_.size() && sent < maxSeqs && cand.size() < upTo; rNext++) {
+        for (; rNext < reads_.size() && sent < maxSeqs && sel.size() < upTo; rNext++) {
             if (ignore_[rNext]) continue;
             sent++;
+            const uint32_t r = (uint32_t)rNext;
             const i64 L = reads_.length(rNext);
-            if (L < overlap_ * 2) {
-                cand.push_back({(uint32_t)rNext, 0u, (uint32_t)L, true});
-            } else {
-                cand.push_back({(uint32_t)rNext, 0u, (uint32_t)overlap_, false});
-                cand.push_back({(uint32_t)rNext, (uint32_t)(L - overlap_), (uint32_t)overlap_, true});
+            if (queryType & 1) {  // QueryEdges
+                if (L < overlap_ * 2) {
+                    addWindow(r, 0, L, true);
+                } else {
+                    addWindow(r, 0, overlap_, true);
+                    addWindow(r, L - overlap_, L, false);
+                }
+            } else if (queryType & 2) {  // QueryCentre
+                i64 start = (L - overlap_) / 2;
+                if (start < 0) start = 0;
+                i64 end = start + overlap_;
+                if (end >= L) end = L - 1;
+                addWindow(r, start, end, true);
+            } else {  // QueryAll
+                if (L < overlap_ * 2) {
+                    addWindow(r, 0, L, true);
+                } else {
+                    const i64 slices = L / overlap_;
+                    for (i64 i = 0; i < slices; i++) {
+                        const i64 start = (i * L) / slices;
+                        i64 end = ((i + 1) * L) / slices;
+                        if (i == slices - 1) end = L;
+                        addWindow(r, start, end, i == 0);
+                    }
+                }
             }
         }
     };
     std::vector<uint32_t> spec;
     size_t specDone = 0;
     bool specFailed = false;
-    auto speculate = [&](size_t upTo) {  // thread-parallel selection assuming no evaluated k-mer is a seed yet
+    auto speculate = [&](size_t upTo) {  // selection of every sub-window assuming no evaluated k-mer is a seed yet
         moreCands(upTo);
-        const size_t n = cand.size();
+        const size_t n = sel.size();
         spec.resize(n * (size_t)numSeeds);
         const size_t first = specDone;
         if (n <= first) return;
@@ -120,9 +164,9 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values
             std::vector<dp_scan_item> items(n - first);
             for (size_t w = first; w < n; w++) {
                 dp_scan_item& it = items[w - first];
-                it.read = cand[w].read;
-                it.start = cand[w].start;
-                it.n_kmers = cand[w].len;  // window length in bases
+                it.read = sel[w].read;
+                it.start = sel[w].start;
+                it.n_kmers = sel[w].len;  // window length in bases
                 it.min_seeds = 0;
             }
             const int rc = dp_select_seeds(ctx_, items.data(), (uint32_t)items.size(), index_.k, numSeeds,
@@ -135,13 +179,13 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values
             std::atomic<long long> selUs(0);
             parallelFor(n - first, [&](size_t i) {
                 const size_t w = first + i;
-                const Cand& c = cand[w];
+                const Sel& c = sel[w];
                 const double tw = g_prof.on ? threadCpuNow() : 0;
                 index_.selectSeeds(reads_.seq(c.read) + c.start, c.len, numSeeds, values, &spec[w * (size_t)numSeeds], false);
                 if (g_prof.on) selUs += (long long)((threadCpuNow() - tw) * 1e6);
             });
             g_prof.selectCpuUs += selUs.load();
-}
+        }
         specDone = n;
     };
     const double tsp0 = now();
@@ -157,20 +201,22 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values
     size_t w = 0;
     for (;;) {
         if (w >= cand.size()) {
-            speculate(cand.size() + 64);
+            speculate(sel.size() + 64);
             if (specFailed) return -1;
             if (w >= cand.size()) break;  // input exhausted
         }
-        // getEdges tests the budget once per READ, before its first window (overlap.go:57-60)
-        const bool firstOfRead = (w == 0) || cand[w - 1].lastOfRead;
-        if (firstOfRead && index_.size() >= seedLimit) break;
+        // the budget is tested once per READ, before its first window (overlap.go:57-60, 93-96, 121-127)
+        if (cand[w].firstOfRead && index_.size() >= seedLimit) break;
         const Cand& c = cand[w];
-        const char* s = reads_.seq(c.read) + c.start;
-        if (index_.touchesSeed(s, c.len)) {  // speculation invalid: redo this window against the current seed set
-            index_.selectSeeds(s, c.len, numSeeds, values, tmp.data(), true);
-            index_.commitSeeds(tmp.data(), numSeeds);
-        } else {
-            index_.commitSeeds(&spec[w * (size_t)numSeeds], numSeeds);
+        for (uint32_t si = c.selFirst; si < c.selFirst + c.selCount; si++) {
+            const Sel& sw = sel[si];
+            const char* s = reads_.seq(sw.read) + sw.start;
+            if (index_.touchesSeed(s, sw.len)) {  // speculation invalid: redo this window against the current seed set
+                index_.selectSeeds(s, sw.len, numSeeds, values, tmp.data(), true);
+                index_.commitSeeds(tmp.data(), numSeeds);
+            } else {
+                index_.commitSeeds(&spec[si * (size_t)numSeeds], numSeeds);
+            }
         }
         windows_.push_back({c.read, c.start, c.len});
         w++;
@@ -747,7 +793,7 @@ std::shared_ptr<RoundPlan> Planner::compute(i64 round, i64 firstIn) {
     // the device path needs the window in the resident (cached-view) form and at most 64 list slots
     dp_ctx* sel = (d->selCtx && d->p.numSeeds <= 64) ? d->selCtx : nullptr;
     Overlapper lap(sel, d->reads, d->index, d->p.chunkSize, d->p.numWorkers, d->p.overlapSize, d->p.numSeeds, d->p.minHits);
-    const int nw = lap.PrepareQueries(d->p.numSeeds, d->p.seedBatchSize, d->values, firstIn, d->p.queryBatchSize);
+    const int nw = lap.PrepareQueries(d->p.numSeeds, d->p.seedBatchSize, d->values, firstIn, d->p.queryBatchSize, d->p.queryType);
     if (nw < 0) {
         plan->error = lap.err;
         plan->failed = true;

@@ -164,7 +164,7 @@ class OverlapPipeline:
 
     def __init__(self, reads, device=0, k=10, overlap_size=1000, num_seeds=15, seed_batch_size=10000, chunk_size=10000,
                  query_batch_size=20000, min_hits=0.25, himem=True, values=None, rank=0, world=1, torch_device=None,
-                 mode="round", slots=1):
+                 mode="round", slots=1, query_type=1):
         """mode (world > 1): "round" = round-parallel (rank r executes round base+r speculatively, results are
         all-gathered and committed in order with a speculation check); "scan-shard" = every rank runs every round, the
         scan is sharded by read and the survivors are all-gathered.
@@ -173,8 +173,9 @@ class OverlapPipeline:
         self.H = load_host()
         if mode == "scan-shard" and world > 1:
             slots = 1
-        p = np.array([overlap_size, k, num_seeds, seed_batch_size, chunk_size, query_batch_size, 1 if himem else 0, slots],
-                     dtype=np.int64)
+        # query_type: overlap.QueryEdges=1 (the overlap command), QueryCentre=2, QueryAll=4 (the correct command), +8 WeightEdges
+        p = np.array([overlap_size, k, num_seeds, seed_batch_size, chunk_size, query_batch_size,
+                      (1 if himem else 0) | (query_type << 8), slots], dtype=np.int64)
         self.slots = slots
         vptr = values.ctypes.data if values is not None else None
         self._values_keepalive = values

@@ -247,7 +247,8 @@ void* dpo_overlap_run(void* reads, const int64_t* params, double minHits, const 
         p.seedBatchSize = params[3];
         p.chunkSize = params[4];
         p.queryBatchSize = params[5];
-        p.himem = params[6] != 0;
+        p.himem = (params[6] & 1) != 0;
+        p.queryType = (int)(params[6] >> 8) ? (int)(params[6] >> 8) : 1;  // bits 8.. of the himem word: overlap.Query* flags
         p.minHits = minHits;
         ((ReadSetH*)reads)->set.himem = p.himem;
         h->res = runOverlap(((ReadSetH*)reads)->set, p, valuesOrNull, maxRounds, keepTraces != 0);

@@ -154,6 +154,8 @@ struct SeedIndex {
 
     explicit SeedIndex(int k);
     SeedSequence* newSeedSequence(const PackedSeq& seq);                       // :33-50
+    std::shared_ptr<std::vector<i64>> scanSegments(const PackedSeq& seq) const;  // its CountKmers+WriteSegments half
+    SeedSequence* newSeedSequence(const PackedSeq& seq, std::shared_ptr<std::vector<i64>> store);
     void addSeeds(const PackedSeq& seq, i64 minSeeds, const double* ranks);    // :62-156
     void addSingleSeeds(const PackedSeq& seq, i64 seedRate, const double* ranks);  // :160-200
     void addSequence(SeedSequence* s);                                         // :272-290
@@ -225,6 +227,7 @@ struct OverlapParams {
     i64 numSeeds = 15, seedBatchSize = 10000, chunkSize = 10000, queryBatchSize = 20000;
     double minHits = 0.25;
     bool himem = true;
+    int queryType = 1;  // overlap.QueryEdges (overlap.go:18-21): 1 edges, 2 centre, 4 all, +8 weight edges
 };
 struct Overlapper {
     SeedIndex& index;
@@ -233,7 +236,7 @@ struct Overlapper {
     Overlapper(SeedIndex& ix, i64 chunk, i64 ov, i64 minS, double hf)
         : index(ix), chunkSize(chunk), overlap(ov), minSeeds(minS), hitFraction(hf) {}
     std::vector<SeedQuery> prepareQueries(i64 numSeeds, i64 seedLimit, const double* values,
-                                          const std::vector<PackedSeq>& seqs);   // :157 (QueryEdges)
+                                          const std::vector<PackedSeq>& seqs, int queryType = 1);   // :157
     void chunkAndAdd(SeedSequence* s);                                          // chunkWorker :253-318
     void addSequences(const std::vector<PackedSeq>& seqs);                      // :217
     std::vector<std::unique_ptr<SeedMatch>> findOverlaps(const std::vector<SeedQuery>& queries);  // :320 + matchWorker :346

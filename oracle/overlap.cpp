@@ -2,6 +2,9 @@
 // sequence/seqio.go (FASTA rules), util/sequtil/kmers.go, overlap/overlap.go, overlap/combine.go,
 // commands/overlap.go.
 #include "oracle.hpp"
+#include <mutex>
+#include <atomic>
+#include <thread>
 
 #include <algorithm>
 #include <cmath>
@@ -161,22 +164,59 @@ std::vector<double> kmerValues(std::vector<u64>& counts, int k) {
 // ---------------------------------------------------------------------------------------------
 // overlap/overlap.go
 
-// PrepareQueries :157-214 with getEdges :55-89 (QueryEdges, no WeightEdges), canonical synchronous order.
+// PrepareQueries :157-214 with getEdges :55-89 / getCentres :91-117 / getAll :119-155 and addWeighted :45-53, canonical
+// synchronous order (every window's AddSeeds completes before the next budget test).
 std::vector<SeedQuery> Overlapper::prepareQueries(i64 numSeeds, i64 seedLimit, const double* values,
-                                                  const std::vector<PackedSeq>& seqs) {
+                                                  const std::vector<PackedSeq>& seqs, int queryType) {
+    const bool weightSides = (queryType & 8) != 0;
+    if (weightSides) numSeeds /= 2;  // :161-163
+    auto feed = [&](const PackedSeq& sub) {  // what reaches AddSeedsWorker for one query window
+        const i64 sideSize = 200;
+        if (weightSides && sub.length > 400) {
+            index.addSeeds(sub.subSequence(0, sideSize), numSeeds, values);
+            index.addSeeds(sub.subSequence(sub.length - sideSize, sub.length), numSeeds, values);
+        } else {
+            index.addSeeds(sub, numSeeds, values);
+        }
+    };
     std::vector<PackedSeq> cached;
     for (const auto& s : seqs) {
         if (index.size >= seedLimit) break;
-        if (s.length < overlap * 2) {
-            index.addSeeds(s, numSeeds, values);
-            cached.push_back(s);
-        } else {
-            PackedSeq s1 = s.subSequence(0, overlap);
-            PackedSeq s2 = s.subSequence(s.length - overlap, s.length);
-            index.addSeeds(s1, numSeeds, values);
-            index.addSeeds(s2, numSeeds, values);
-            cached.push_back(s1);
-            cached.push_back(s2);
+        if (queryType & 1) {  // QueryEdges
+            if (s.length < overlap * 2) {
+                feed(s);
+                cached.push_back(s);
+            } else {
+                PackedSeq s1 = s.subSequence(0, overlap);
+                PackedSeq s2 = s.subSequence(s.length - overlap, s.length);
+                feed(s1);
+                feed(s2);
+                cached.push_back(s1);
+                cached.push_back(s2);
+            }
+        } else if (queryType & 2) {  // QueryCentre
+            i64 start = (s.length - overlap) / 2;
+            if (start < 0) start = 0;
+            i64 end = start + overlap;
+            if (end >= s.length) end = s.length - 1;
+            PackedSeq centre = s.subSequence(start, end);
+            feed(centre);
+            cached.push_back(centre);
+        } else {  // QueryAll
+            if (s.length < overlap * 2) {
+                feed(s);
+                cached.push_back(s);
+            } else {
+                const i64 slices = s.length / overlap;
+                for (i64 i = 0; i < slices; i++) {
+                    const i64 start = (i * s.length) / slices;
+                    i64 end = ((i + 1) * s.length) / slices;
+                    if (i == slices - 1) end = s.length;
+                    PackedSeq sub = s.subSequence(start, end);
+                    feed(sub);
+                    cached.push_back(sub);
+                }
+            }
         }
     }
     std::vector<SeedQuery> queries;
@@ -252,7 +292,35 @@ void Overlapper::chunkAndAdd(SeedSequence* s) {
 
 // AddSequences :217-250
 void Overlapper::addSequences(const std::vector<PackedSeq>& seqs) {
-    for (const auto& s : seqs) chunkAndAdd(index.newSeedSequence(s));
+    // DPO_SCAN_THREADS=n (bench's all-cores CPU baseline only): the per-read scans run on n threads, everything else
+    // stays sequential and in file order, so the output is unchanged
+    const char* te = getenv("DPO_SCAN_THREADS");
+    const int nt = te ? atoi(te) : 1;
+    if (nt > 1 && seqs.size() > 1) {
+        std::vector<std::shared_ptr<std::vector<i64>>> stores(seqs.size());
+        std::atomic<size_t> next(0);
+        std::vector<std::thread> th;
+        std::string failure;
+        std::mutex fmu;
+        for (int t = 0; t < nt; t++)
+            th.emplace_back([&] {
+                try {
+                    for (;;) {
+                        const size_t i0 = next.fetch_add(64);
+                        if (i0 >= seqs.size()) break;
+                        for (size_t i = i0; i < std::min(seqs.size(), i0 + 64); i++) stores[i] = index.scanSegments(seqs[i]);
+                    }
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> lk(fmu);
+                    failure = e.what();
+                }
+            });
+        for (auto& x : th) x.join();
+        if (!failure.empty()) throw std::runtime_error(failure);
+        for (size_t i = 0; i < seqs.size(); i++) chunkAndAdd(index.newSeedSequence(seqs[i], stores[i]));
+    } else {
+        for (const auto& s : seqs) chunkAndAdd(index.newSeedSequence(s));
+    }
     index.indexSequences();
 }
 
@@ -460,7 +528,7 @@ OverlapResult runOverlap(FastaSet& set, const OverlapParams& p, const double* va
             for (size_t id = (size_t)firstSequence; id < set.size() && (i64)qseqs.size() < p.queryBatchSize; id++)
                 if (!set.ignore[id]) qseqs.push_back(set.served(id));
         }
-        std::vector<SeedQuery> queries = lap.prepareQueries(p.numSeeds, p.seedBatchSize, values, qseqs);
+        std::vector<SeedQuery> queries = lap.prepareQueries(p.numSeeds, p.seedBatchSize, values, qseqs, p.queryType);
         if (queries.empty()) break;
         i64 numQuerySeqs = 0;
         firstSequence = queries.back().SequenceID + 1;

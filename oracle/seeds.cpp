@@ -18,7 +18,9 @@ SeedIndex::SeedIndex(int k) : seedSize(k) {  // :23-31
 }
 
 // seeds/seeds.go:33-50
-SeedSequence* SeedIndex::newSeedSequence(const PackedSeq& seq) {
+// The scan half of NewSeedSequence: reads only kmers/kmerMap, so several reads can be scanned by different threads
+// (bench's all-cores CPU baseline; the reference does the same with num_workers goroutines).
+std::shared_ptr<std::vector<i64>> SeedIndex::scanSegments(const PackedSeq& seq) const {
     int k = seedSize;
     i64 count = seq.countKmers(seq.length, k, kmers.data());
     auto store = std::make_shared<std::vector<i64>>((size_t)(count * 2 + 1), 0);
@@ -30,6 +32,12 @@ SeedSequence* SeedIndex::newSeedSequence(const PackedSeq& seq) {
     if (wrote != count * 2 + 1) throw std::runtime_error("oracle: WriteSegments overflow (reference would panic)");
     std::copy(tmp.begin(), tmp.begin() + wrote, store->begin());
     for (size_t i = 1; i < store->size(); i += 2) (*store)[i] = (i64)kmerMap[(size_t)(*store)[i]];
+    return store;
+}
+
+SeedSequence* SeedIndex::newSeedSequence(const PackedSeq& seq) { return newSeedSequence(seq, scanSegments(seq)); }
+
+SeedSequence* SeedIndex::newSeedSequence(const PackedSeq& seq, std::shared_ptr<std::vector<i64>> store) {
     SeedSequence* s = arena.make();
     s->store = store;
     s->lo = 0;

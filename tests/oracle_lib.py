@@ -356,9 +356,9 @@ class OverlapRun:
                   indexedSegments=21, candidates=22, matchA=23, matchB=24)
 
     def __init__(self, reads, k=10, overlap_size=1000, num_seeds=15, seed_batch_size=10000, chunk_size=10000,
-                 query_batch_size=20000, min_hits=0.25, himem=True, values=None, max_rounds=-1, traces=False):
-        p = np.array([overlap_size, k, num_seeds, seed_batch_size, chunk_size, query_batch_size, 1 if himem else 0],
-                     dtype=np.int64)
+                 query_batch_size=20000, min_hits=0.25, himem=True, values=None, max_rounds=-1, traces=False, query_type=1):
+        p = np.array([overlap_size, k, num_seeds, seed_batch_size, chunk_size, query_batch_size,
+                      (1 if himem else 0) | (query_type << 8)], dtype=np.int64)
         vp = values.ctypes.data_as(C.POINTER(C.c_double)) if values is not None else None
         self.h = lib().dpo_overlap_run(reads.h, ptr(p, i64p), float(min_hits), vp, max_rounds, 1 if traces else 0)
         if not self.h:

@@ -63,6 +63,15 @@ def test_overlap_full_run_config1_k10(slots):
     assert orun.rounds >= 5
 
 
+@pytest.mark.parametrize("query_type,slots", [(4, 1), (4, 3), (2, 1), (9, 1), (12, 2)])
+def test_overlap_other_query_types(query_type, slots):
+    """PrepareQueries' other window layouts behind the same boundary (overlap.go:18-21,91-155): QueryAll=4 is what the
+    `correct` command uses (commands/correct.go:97,169), QueryCentre=2, and WeightEdges=8 (seeds from the two 200-base
+    sides of each window, numSeeds halved)."""
+    orun, st = _run_both(58, 90000, 350, 4200, 10, e=0.01, variable=True, max_rounds=3, slots=slots, query_type=query_type)
+    assert orun.rounds >= 1
+
+
 def test_overlap_slots_with_ignores():
     """Short reads get flagged as ignored by earlier rounds: concurrent slots must discard invalidated speculation."""
     orun, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
