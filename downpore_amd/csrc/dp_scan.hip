@@ -155,7 +155,7 @@ extern "C" uint64_t dp_reads_total_bases(const dp_ctx* ctx) { return ctx ? ctx->
 
 __global__ void pack_kernel(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ aoff,
                             const uint64_t* __restrict__ boff, uint32_t n_reads, uint32_t* __restrict__ packed,
-                            uint64_t n_dwords) {
+                            uint64_t n_dwords, const uint32_t* __restrict__ srcmap) {
     uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_dwords) return;
     uint64_t byte = d * 4;
@@ -166,9 +166,12 @@ __global__ void pack_kernel(const uint8_t* __restrict__ ascii, const int64_t* __
         if (boff[mid] <= byte) lo = mid;
         else hi = mid;
     }
-    int64_t len = aoff[lo + 1] - aoff[lo];
+    // srcmap (dp_reads_upload_rc): device read lo is host read srcmap>>1, reverse-complemented when bit 0 is set
+    const uint32_t src_read = srcmap ? (srcmap[lo] >> 1) : lo;
+    const bool rc = srcmap ? (srcmap[lo] & 1u) != 0 : false;
+    int64_t len = aoff[src_read + 1] - aoff[src_read];
     int64_t base0 = (int64_t)(byte - boff[lo]) * 4;
-    const uint8_t* src = ascii + aoff[lo] + base0;
+    const uint8_t* src = ascii + aoff[src_read];
     uint32_t out = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
@@ -178,38 +181,53 @@ __global__ void pack_kernel(const uint8_t* __restrict__ ascii, const int64_t* __
             int64_t p = base0 + b * 4 + j;
             uint32_t c = 0;
             if (p < len) {
-                uint32_t ch = src[b * 4 + j];
+                uint32_t ch = src[rc ? (len - 1 - p) : p];
                 c = ((ch >> 1) ^ ((ch & 4) >> 2)) & 3;  // sequence/sequence.go:59,80
+                if (rc) c = 3u - c;                      // complement (sequence.go:185-189)
             }
             v = (v << 2) | c;
         }
-        out |= v << (8 * b);
+        out |= v << (8 * b);  // little-endian dword: byte b of the packed stream
     }
     packed[d] = out;
 }
 
-extern "C" int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads) {
+// Shared body of dp_reads_upload / dp_reads_upload_rc.  With first_paired < n_reads every host read r >= first_paired
+// becomes TWO device reads: first_paired + 2*(r - first_paired) (forward) and the next id (its reverse complement,
+// produced by the pack kernel; nothing but the forward ASCII crosses PCIe).
+static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_host, uint32_t first_paired) {
     if (!ctx || !bases || !off) return DP_ERR_ARG;
     if (ctx->borrowed_reads) return dp_fail(ctx, DP_ERR_STATE, "dp_reads_upload on a context that borrows its reads");
+    if (first_paired > n_host) first_paired = n_host;
     hipSetDevice(ctx->device);
+    const uint64_t nd64 = (uint64_t)first_paired + 2ull * (n_host - first_paired);
+    if (nd64 > 0x7fffffffull) return dp_fail(ctx, DP_ERR_ARG, "too many reads");
+    const uint32_t n_reads = (uint32_t)nd64;
+    const bool paired = first_paired < n_host;
     ctx->n_reads = n_reads;
     ctx->h_boff.assign((size_t)n_reads + 1, 0);
     ctx->h_len.assign(n_reads, 0);
-    uint64_t pos = 0;
-    for (uint32_t r = 0; r < n_reads; r++) {
+    std::vector<uint32_t> srcmap;
+    if (paired) srcmap.resize(n_reads);
+    uint64_t pos = 0, total = 0;
+    for (uint32_t d = 0; d < n_reads; d++) {
+        const uint32_t r = d < first_paired ? d : first_paired + (d - first_paired) / 2;
+        const uint32_t isrc = d < first_paired ? 0u : ((d - first_paired) & 1u);
         int64_t len = off[r + 1] - off[r];
         if (len < 0 || len > 0x7fffffff) return dp_fail(ctx, DP_ERR_ARG, "read length out of range");
-        ctx->h_boff[r] = pos;
-        ctx->h_len[r] = (uint32_t)len;
+        ctx->h_boff[d] = pos;
+        ctx->h_len[d] = (uint32_t)len;
+        if (paired) srcmap[d] = (r << 1) | isrc;
         pos += ((uint64_t)(len + 3) / 4 + 15) & ~(uint64_t)15;
+        total += (uint64_t)len;
     }
     ctx->h_boff[n_reads] = pos;
     ctx->packed_bytes = pos;
-    ctx->total_bases = (uint64_t)(off[n_reads] - off[0]);
+    ctx->total_bases = total;
     if (dev_reserve(ctx, ctx->d_packed, pos + 64)) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_boff, (n_reads + 1) * 8)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_boff, ((size_t)n_reads + 1) * 8)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_len, (size_t)n_reads * 4 + 4)) return DP_ERR_HIP;
-    DP_HIP(hipMemcpyAsync(ctx->d_boff.p, ctx->h_boff.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->d_boff.p, ctx->h_boff.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->d_len.p, ctx->h_len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
     DP_HIP(hipMemsetAsync((uint8_t*)ctx->d_packed.p + pos, 0, 64, ctx->stream));
     if (n_reads == 0 || pos == 0) {
@@ -218,22 +236,36 @@ extern "C" int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t*
     }
     void* d_ascii = nullptr;
     void* d_aoff = nullptr;
-    uint64_t nascii = ctx->total_bases;
+    void* d_map = nullptr;
+    const uint64_t nascii = (uint64_t)(off[n_host] - off[0]);
     DP_HIP(hipMalloc(&d_ascii, nascii + 16));
-    DP_HIP(hipMalloc(&d_aoff, (n_reads + 1) * 8));
-    std::vector<int64_t> rel((size_t)n_reads + 1);
-    for (uint32_t r = 0; r <= n_reads; r++) rel[r] = off[r] - off[0];
+    DP_HIP(hipMalloc(&d_aoff, ((size_t)n_host + 1) * 8));
+    std::vector<int64_t> rel((size_t)n_host + 1);
+    for (uint32_t r = 0; r <= n_host; r++) rel[r] = off[r] - off[0];
     DP_HIP(hipMemcpyAsync(d_ascii, bases + off[0], nascii, hipMemcpyHostToDevice, ctx->stream));
-    DP_HIP(hipMemcpyAsync(d_aoff, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(d_aoff, rel.data(), ((size_t)n_host + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (paired) {
+        DP_HIP(hipMalloc(&d_map, (size_t)n_reads * 4));
+        DP_HIP(hipMemcpyAsync(d_map, srcmap.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     uint64_t n_dwords = pos / 4;
     uint32_t blocks = (uint32_t)((n_dwords + 255) / 256);
     hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)d_ascii, (const int64_t*)d_aoff,
-                       (const uint64_t*)ctx->d_boff.p, n_reads, (uint32_t*)ctx->d_packed.p, n_dwords);
+                       (const uint64_t*)ctx->d_boff.p, n_reads, (uint32_t*)ctx->d_packed.p, n_dwords, (const uint32_t*)d_map);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_stream_sync(ctx));
     hipFree(d_ascii);
     hipFree(d_aoff);
+    if (d_map) hipFree(d_map);
     return DP_OK;
+}
+
+extern "C" int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads) {
+    return reads_upload_impl(ctx, bases, off, n_reads, n_reads);
+}
+
+extern "C" int dp_reads_upload_rc(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads, uint32_t first_paired) {
+    return reads_upload_impl(ctx, bases, off, n_reads, first_paired);
 }
 
 extern "C" int dp_reads_packed(dp_ctx* ctx, uint32_t read, uint8_t* out, uint64_t cap, uint64_t* n_bytes) {

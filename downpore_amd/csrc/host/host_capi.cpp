@@ -363,6 +363,6 @@ extern "C" const char* dph_map_errtext(void* h, int64_t* n) {
 extern "C" void dph_map_stats(void* h, double* out) {
     const MapStats& s = ((MapH*)h)->st;
     double v[] = {(double)s.n_chunks, (double)s.n_seeds, (double)s.n_windows, (double)s.n_chains, (double)s.n_batches, s.k_scan_ms,
-                  s.k_map_ms};
+                  s.k_map_ms, s.t_setup_s, s.t_scan_s, s.t_chain_s, s.t_host_s};
     memcpy(out, v, sizeof v);
 }

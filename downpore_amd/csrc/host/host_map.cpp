@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstring>
 
+#include <chrono>
+
 #include "dph.hpp"
 
 namespace dph {
@@ -87,7 +89,7 @@ struct MapperImpl {
 
 struct Task {
     ucontext_t uc;
-    std::vector<char> stack;
+    char* stack = nullptr;  // from the scheduler's stack pool (uninitialised memory, reused by later reads)
     uint32_t read = 0;
     i64 L = 0;
     bool done = false, waiting = false;
@@ -493,14 +495,6 @@ std::string MapperImpl::asString(const Mapping& m, const std::string& qname, i64
     return s + buf;
 }
 
-std::string revcomp(const char* s, size_t n) {
-    std::string r(n, 'A');
-    for (size_t i = 0; i < n; i++) {
-        static const char C[4] = {'A', 'C', 'G', 'T'};
-        r[n - 1 - i] = C[3 - baseCode((unsigned char)s[i])];
-    }
-    return r;
-}
 
 }  // namespace
 
@@ -509,6 +503,7 @@ std::string revcomp(const char* s, size_t n) {
 
 int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int device, std::string& paf, std::string& errText,
            MapStats* stats, std::string& error) {
+    const double tRun0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (refSet.size() == 0) {
         error = "empty reference";
         return -1;
@@ -598,12 +593,11 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     std::string join;
     if (p.circular) join = std::string(ref + (refLen - p.querySize), (size_t)p.querySize) + std::string(ref, (size_t)p.querySize);
     addRead(join.data(), join.size());
-    for (size_t r = 0; r < reads.size(); r++) {
-        addRead(reads.seq(r), (size_t)reads.length(r));
-        std::string rcs = revcomp(reads.seq(r), (size_t)reads.length(r));
-        addRead(rcs.data(), rcs.size());
-    }
-    rc = dp_reads_upload(ctx, (const uint8_t*)bases.data(), off.data(), (uint32_t)(off.size() - 1));
+    bases.reserve(bases.size() + reads.bases.size());
+    for (size_t r = 0; r < reads.size(); r++) addRead(reads.seq(r), (size_t)reads.length(r));
+    // device ids: 0 reference, 1 join chunk, then (forward, reverse complement) per read; the reverse strands are made
+    // on the device
+    rc = dp_reads_upload_rc(ctx, (const uint8_t*)bases.data(), off.data(), (uint32_t)(off.size() - 1), 2);
     if (rc) return fail(rc);
     bases.clear();
     bases.shrink_to_fit();
@@ -670,12 +664,20 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     if (stats) stats->n_chunks = items.size(), stats->n_seeds = index.seedMap.size();
 
     // ---- Map every read: coroutines + batched windows
+    auto wallNow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tLoop0 = wallNow();
+    if (stats) stats->t_setup_s = tLoop0 - tRun0;
+    double tScan = 0, tChain = 0;
     Sched sched;
     M.sched = &sched;
     const size_t inflight = 4096, stackBytes = 256 * 1024;
     std::vector<std::string> out(reads.size());
     std::vector<int> nmaps(reads.size(), 0);
     std::vector<std::unique_ptr<Task>> live;
+    // coroutine stacks: allocated once (never zero-filled) and recycled — 50 k reads x 256 KiB of fresh zeroed vectors
+    // used to be most of the run time
+    std::vector<std::unique_ptr<char[]>> stackStore;
+    std::vector<char*> freeStacks;
     size_t nextRead = 0;
     i64 unmapped = 0, mapped = 0, multiple = 0, total = 0;
     std::vector<dp_scan_item> witems;
@@ -688,10 +690,15 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             t->m = &M;
             t->read = (uint32_t)nextRead;
             t->L = reads.length(nextRead);
-            t->stack.resize(stackBytes);
+            if (freeStacks.empty()) {
+                stackStore.emplace_back(new char[stackBytes]);
+                freeStacks.push_back(stackStore.back().get());
+            }
+            t->stack = freeStacks.back();
+            freeStacks.pop_back();
             getcontext(&t->uc);
-            t->uc.uc_stack.ss_sp = t->stack.data();
-            t->uc.uc_stack.ss_size = t->stack.size();
+            t->uc.uc_stack.ss_sp = t->stack;
+            t->uc.uc_stack.ss_size = stackBytes;
             t->uc.uc_link = &sched.main;
             uintptr_t ptr = (uintptr_t)t.get();
             makecontext(&t->uc, (void (*)())taskEntry, 2, (unsigned)(ptr & 0xffffffffu), (unsigned)(ptr >> 32));
@@ -706,6 +713,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
                 std::string& o = out[t.read];
                 for (Mapping* mm : t.results) o += M.asString(*mm, reads.names[t.read], t.L) + "\n";
                 nmaps[t.read] = (int)t.results.size();
+                freeStacks.push_back(t.stack);
                 live[i] = std::move(live.back());
                 live.pop_back();
             } else {
@@ -744,8 +752,10 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         // the chunk segments live in the device scan buffer; window scans must not clobber them -> the window scan uses a
         // second context-independent path: scan, then re-import the chunk segments before the map stage
         dp_seedseq_batch wb;
+        const double ts0 = wallNow();
         rc = dp_scan(ctx, witems.data(), (uint32_t)witems.size(), &wb);
         if (rc) return fail(rc);
+        tScan += wallNow() - ts0;
         if (stats) stats->k_scan_ms += wb.kernel_ms, stats->n_windows += witems.size() / 2;
         wsegs.clear();
         woff.assign(1, 0);
@@ -777,8 +787,10 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         rc = dp_scan_import_segments(ctx, M.chunkSegs.data(), M.chunkSegs.size());
         if (rc) return fail(rc);
         dp_chain_batch cb;
+        const double tc0 = wallNow();
         rc = dp_map_windows(ctx, wsegs.data(), woff.data(), wlen.data(), (uint32_t)witems.size(), k, &cb);
         if (rc) return fail(rc);
+        tChain += wallNow() - tc0;
         if (stats) stats->k_map_ms += cb.kernel_ms, stats->n_chains += cb.n_chains, stats->n_batches++;
         // ---- ... distribute and resume
         for (auto& tp : live) {
@@ -798,6 +810,11 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             live[w / 2]->res.chains[w & 1].push_back(std::move(cr));
         }
         for (auto& tp : live) swapcontext(&sched.main, &tp->uc);
+    }
+    if (stats) {
+        stats->t_scan_s = tScan;
+        stats->t_chain_s = tChain;
+        stats->t_host_s = (wallNow() - tLoop0) - tScan - tChain;
     }
     for (size_t r = 0; r < reads.size(); r++) {
         paf += out[r];

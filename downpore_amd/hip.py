@@ -46,7 +46,7 @@ class ChainBatch(C.Structure):
 SYMBOLS = ["dp_version", "dp_ctx_create", "dp_ctx_create_shared", "dp_ctx_destroy", "dp_last_error", "dp_reads_upload", "dp_reads_packed",
            "dp_reads_count", "dp_reads_total_bases", "dp_kmer_histogram", "dp_round_begin", "dp_scan", "dp_scan_reads", "dp_index_build",
            "dp_find_overlaps", "dp_map_windows", "dp_index_posting_row", "dp_index_seedset_row", "dp_scan_device_buffers",
-           "dp_scan_import_segments", "dp_values_upload", "dp_select_seeds"]
+           "dp_scan_import_segments", "dp_values_upload", "dp_select_seeds", "dp_reads_upload_rc"]
 
 _lib = None
 
@@ -130,6 +130,15 @@ class Context:
         off = np.ascontiguousarray(off, dtype=np.int64)
         self._chk(self.L.dp_reads_upload(self.h, bases.ctypes.data, off.ctypes.data, len(off) - 1))
         self.read_len = np.diff(off).astype(np.int64)
+
+    def upload_reads_rc(self, bases, off, first_paired):
+        """Reads >= first_paired are stored as (forward, reverse complement) pairs; the device makes the second strand."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        self.L.dp_reads_upload_rc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        self._chk(self.L.dp_reads_upload_rc(self.h, bases.ctypes.data, off.ctypes.data, len(off) - 1, first_paired))
+        ln = np.diff(off).astype(np.int64)
+        self.read_len = np.concatenate([ln[:first_paired], np.repeat(ln[first_paired:], 2)])
 
     def packed_read(self, r):
         nb = (int(self.read_len[r]) + 3) // 4

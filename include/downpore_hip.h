@@ -56,6 +56,11 @@ const char* dp_last_error(const dp_ctx* ctx); /* ctx may be NULL: error of the l
  * (2 bit/base, ((b>>1)^((b&4)>>2))&3, first base in the top bits of each byte) runs on the device.  Reads stay
  * resident for every later round. */
 int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads);
+/* The same, but every read r >= first_paired is stored TWICE: as device read first_paired + 2*(r - first_paired) and,
+ * reverse-complemented (sequence.go:179-198: reversed, 3 - code per base), as the next id.  `downpore map` scans every
+ * query window on both strands (mapping.go:497-499); the reverse strands are produced by the pack kernel instead of
+ * being built on the host and sent over PCIe. */
+int dp_reads_upload_rc(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads, uint32_t first_paired);
 /* Copy back the packed bytes of one read (ceil(len/4) bytes) — test hook. */
 int dp_reads_packed(dp_ctx* ctx, uint32_t read, uint8_t* out, uint64_t cap, uint64_t* n_bytes);
 uint32_t dp_reads_count(const dp_ctx* ctx);

@@ -48,6 +48,26 @@ def test_pack_matches_reference_encoding(ctx):
         assert np.array_equal(want, got), r
 
 
+def test_pack_reverse_complement_pairs(ctx):
+    """dp_reads_upload_rc: the device-made reverse strands equal the oracle's packed ReverseComplement()."""
+    reads = ["ACGTTGCAAGGCTTAACCGGA", "T" * 33 + "ACG", "GATTACA" * 9 + "C", "ACGT" * 16, "NNACGTRYACG"]
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    off = np.cumsum([0] + [len(r) for r in reads]).astype(np.int64)
+    ctx.upload_reads_rc(bases, off, 2)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    dev = 0
+    for i, r in enumerate(reads):
+        strands = [r] if i < 2 else [r, None]
+        for st in strands:
+            got = ctx.packed_read(dev)
+            if st is None:  # 3 - code per base, reversed (what the host built before): compare via the oracle's packer
+                codes = [3 - (((ord(c) >> 1) ^ ((ord(c) & 4) >> 2)) & 3) for c in reversed(r)]
+                st = "".join("ACGT"[c] for c in codes)
+            want = O.Seq(st).bytes()
+            assert bytes(got) == bytes(want[:len(got)]), (i, dev)
+            dev += 1
+
+
 def test_histogram(ctx):
     bases, off = O.gen_reads(12, 50000, 200, 1500, 0.01, True)
     ctx.upload_reads(bases, off)
