@@ -60,6 +60,9 @@ def main():
     else:
         dist = None
 
+    if os.environ.get("DP_BENCH_DEBUG"):  # hung-run diagnosis: Python stacks of every rank every 40 s
+        import faulthandler
+        faulthandler.dump_traceback_later(40, repeat=True)
     from tools.synth import gen_reads
     from downpore_amd.overlap import OverlapPipeline, Reads
 

@@ -315,7 +315,8 @@ class Planner {
     // commit-time: set the flags; returns the first round whose cached plan was discarded (or -1)
     i64 applyIgnores(const std::vector<int>& ids, i64 committedRound);
     uint64_t ignoreEpoch();  // bumped whenever a flag is set
-    void dropBefore(i64 round);
+    // rounds < round are committed; `round` starts at firstInOfRound (the committed firstSequence)
+    void dropBefore(i64 round, i64 firstInOfRound);
 
    private:
     std::shared_ptr<RoundPlan> compute(i64 round, i64 firstIn);

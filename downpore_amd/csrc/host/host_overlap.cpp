@@ -754,6 +754,7 @@ struct Planner::Impl {
     std::map<i64, std::shared_ptr<RoundPlan>> cache;
     i64 wantUpTo = -1;        // prefetch target (highest requested round + depth)
     i64 base = 0;             // rounds below are committed and gone
+    i64 startFirstIn = 0;     // firstSequence of round `base` (the committed state): the chain can always restart here
     uint64_t epoch = 0;       // bumped whenever an ignore flag is set
     i64 epochMinId = -1;      // smallest read id flagged in the last bump(s) while a compute was running
     bool stop = false;
@@ -817,8 +818,8 @@ void Planner::threadMain() {
         while (m <= d->wantUpTo) {
             auto it = d->cache.find(m);
             if (it == d->cache.end()) {
-                if (m == 0) {
-                    firstIn = 0;
+                if (m == d->base) {  // first uncommitted round: its firstSequence is the committed state
+                    firstIn = d->startFirstIn;
                     can = true;
                 } else {
                     auto pr = d->cache.find(m - 1);
@@ -839,17 +840,23 @@ void Planner::threadMain() {
         const uint64_t e0 = d->epoch;
         d->epochMinId = -1;
         lk.unlock();
+        static const bool dbg = getenv("DPH_DEBUG_PLANNER") != nullptr;
+        if (dbg) fprintf(stderr, "[planner] computing plan %lld (firstIn %lld, wantUpTo %lld, base %lld)\n", (long long)m, (long long)firstIn, (long long)d->wantUpTo, (long long)d->base);
         std::shared_ptr<RoundPlan> plan = compute(m, firstIn);
+        if (dbg) fprintf(stderr, "[planner] plan %lld done: %zu windows, %zu seeds, empty %d failed %d\n", (long long)m, plan->windows.size(), plan->seedMap.size(), (int)plan->empty, (int)plan->failed);
         lk.lock();
         if (d->stop) return;
         // discard if flags that could matter changed meanwhile, or if the chain below was invalidated
         bool ok = true;
         if (d->epoch != e0 && d->epochMinId >= 0 && d->epochMinId >= firstIn) ok = false;
-        if (m > 0 && m > d->base) {
+        if (m > d->base) {
             auto pr = d->cache.find(m - 1);
             if (pr == d->cache.end() || pr->second->firstOut != firstIn) ok = false;
+        } else if (m == d->base) {
+            if (firstIn != d->startFirstIn) ok = false;
+        } else {
+            ok = false;  // committed meanwhile
         }
-        if (m < d->base) ok = false;
         if (ok && !d->cache.count(m)) d->cache[m] = plan;
         else g_prof.planDiscarded++;
         d->cv.notify_all();
@@ -862,7 +869,7 @@ std::shared_ptr<const RoundPlan> Planner::get(i64 round) {
         for (;;) {
             auto it = d->cache.find(round);
             if (it != d->cache.end()) return it->second;
-            i64 m = d->base, firstIn = 0;
+            i64 m = d->base, firstIn = d->startFirstIn;
             for (;;) {
                 auto e = d->cache.find(m);
                 if (e == d->cache.end()) break;
@@ -871,9 +878,8 @@ std::shared_ptr<const RoundPlan> Planner::get(i64 round) {
                 m++;
             }
             if (m > round) return nullptr;
-            if (m > 0 && !d->cache.count(m - 1)) return nullptr;  // predecessor must be cached (dropBefore keeps it)
             lk.unlock();
-            auto plan = compute(m, m == 0 ? 0 : firstIn);
+            auto plan = compute(m, firstIn);
             lk.lock();
             d->cache[m] = plan;
         }
@@ -929,12 +935,16 @@ uint64_t Planner::ignoreEpoch() {
     return d->epoch;
 }
 
-void Planner::dropBefore(i64 round) {
+void Planner::dropBefore(i64 round, i64 firstInOfRound) {
     std::lock_guard<std::mutex> lk(d->mu);
-    // keep round-1: it carries firstOut for the chain
-    d->cache.erase(d->cache.begin(), d->cache.lower_bound(round - 1));
-    if (round - 1 > d->base) d->base = round - 1;
-    if (d->base < 0) d->base = 0;
+    // `round` is the first uncommitted round and starts at firstInOfRound whatever this planner has cached (in a
+    // multi-rank run other ranks executed rounds this planner never looked at)
+    d->cache.erase(d->cache.begin(), d->cache.lower_bound(round));
+    d->base = round;
+    d->startFirstIn = firstInOfRound;
+    auto it = d->cache.find(round);
+    if (it != d->cache.end() && it->second->firstIn != firstInOfRound) d->cache.erase(it, d->cache.end());  // stale chain
+    d->cv.notify_all();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1122,7 +1132,10 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
             if (g_prof.on) g_prof.slotCpuUs += (long long)((threadCpuNow() - t0) * 1e6);
         }
     } slotCpu{tc0};
+    static const bool dbgExec = getenv("DPH_DEBUG_PLANNER") != nullptr;
+    if (dbgExec) fprintf(stderr, "[exec] round %lld waiting for its plan\n", (long long)r);
     std::shared_ptr<const RoundPlan> plan = planner->get(r);
+    if (dbgExec) fprintf(stderr, "[exec] round %lld got plan\n", (long long)r);
     g_prof.getWaitUs += (long long)((now() - t0) * 1e6);
     if (plan && plan->failed) {
         sl.error = "seed selection failed: " + plan->error;
@@ -1150,6 +1163,7 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     }
     out.st.t_scan = now() - t1;
     rc = finishRound(sl, sl.local, out);
+    if (dbgExec) fprintf(stderr, "[exec] round %lld finished rc %d\n", (long long)r, rc);
     const double t2 = now();
     g_prof.add(14, t2 - t0);
     g_prof.add(15, (t2 - t0) - (out.st.t_prepare + out.st.t_scan + out.st.t_index + out.st.t_query + out.st.t_consensus));
@@ -1203,7 +1217,7 @@ void OverlapRun::commitOne(RoundResult& r) {
         if (!reads->ignore[(size_t)id] && flagRound_[(size_t)id] < 0) flagRound_[(size_t)id] = (int32_t)round;
     planner->applyIgnores(r.ignores, round);
     round++;
-    planner->dropBefore(round);
+    planner->dropBefore(round, firstSequence);
 }
 
 int OverlapRun::commitResults(std::vector<RoundResult>& results) {

@@ -72,6 +72,32 @@ def test_overlap_other_query_types(query_type, slots):
     assert orun.rounds >= 1
 
 
+def test_round_parallel_commits_beyond_local_plans():
+    """A rank commits rounds that OTHER ranks executed: its own planner never computed their plans and must restart the
+    chain from the committed firstSequence (4 ranks x 4 slots = 16 rounds per superstep, more than the planner's
+    prefetch depth; this configuration used to hang)."""
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    world, slots = 4, 4
+    bases, off = O.gen_reads(9, 500000, 2000, 5000, 0.0, False)
+    kw = dict(k=10, seed_batch_size=1500)  # small seed budget: ~25 reads per round, many rounds
+    readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
+    pipes = [OverlapPipeline(readsets[r], rank=r, world=world, mode="round", slots=slots, **kw) for r in range(world)]
+    committed = 0
+    while committed < 48 and not pipes[0].finished():
+        base = pipes[0].committed_rounds()
+        blobs = [pipes[r].exec_round_blob(base + r * slots) for r in range(world)]
+        cs = [pipes[r].commit_blobs(blobs) for r in range(world)]
+        assert len(set(cs)) == 1 and cs[0] > 0
+        committed += cs[0]
+    rs = O.ReadSet(bases, off, min_len=1000)
+    orun = O.OverlapRun(rs, max_rounds=committed, **kw)
+    assert orun.rounds == committed
+    for r in range(world):
+        assert first_diff(pipes[r].all_paf(), orun.paf) is None
+        assert pipes[r].committed_rounds() == committed
+        pipes[r].close()
+
+
 def test_overlap_slots_with_ignores():
     """Short reads get flagged as ignored by earlier rounds: concurrent slots must discard invalidated speculation."""
     orun, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
