@@ -165,7 +165,8 @@ def main():
         }
         if world == 1 and args.cpu_rounds > 0:
             vals = pipe.values()
-            out["cpu_baseline"] = cpu_baseline(bases, off, args, vals, threads=1)
+            gpu_paf = pipe.all_paf()  # every committed round so far, in round order
+            out["cpu_baseline"] = cpu_baseline(bases, off, args, vals, threads=1, check_against=gpu_paf)
             # the same port with its per-read scans spread over the host cores this container may use
             out["cpu_baseline_all_cores"] = cpu_baseline(bases, off, args, vals, threads=cpu_budget())
         print(json.dumps(out))
@@ -186,7 +187,7 @@ def cpu_budget():
     return n
 
 
-def cpu_baseline(bases, off, args, values, threads=1):
+def cpu_baseline(bases, off, args, values, threads=1, check_against=None):
     """The oracle (a quirk-exact C++ port of the reference's CPU algorithm incl. its two-pass scan over a 4^k-byte
     table) timed on the host for the first rounds of the same workload; threads > 1 spreads the per-read scans (the
     part the reference parallelises with num_workers) over that many threads."""
@@ -199,7 +200,12 @@ def cpu_baseline(bases, off, args, values, threads=1):
                        max_rounds=args.cpu_rounds, traces=False)
     dt = time.perf_counter() - t0
     lines = run.paf.count("\n")
-    return {"value": lines / dt if dt > 0 else 0.0, "unit": "overlaps/s", "cores": threads, "kind": "port",
+    res = {}
+    if check_against is not None:
+        # the oracle doubles as the checker at the full BASELINE size: its first rounds must be the exact prefix of what
+        # the GPU pipeline printed for the same rounds
+        res["paf_identical_to_gpu_rounds"] = bool(check_against.startswith(run.paf)) and lines > 0
+    return {**res, "value": lines / dt if dt > 0 else 0.0, "unit": "overlaps/s", "cores": threads, "kind": "port",
             "sample": "first %d rounds of the same workload (value table supplied), %.1f s, %d PAF lines" % (run.rounds, dt, lines),
             "ms_per_step": 1e3 * dt / max(1, run.rounds)}
 
