@@ -60,6 +60,9 @@ def main():
     else:
         dist = None
 
+    if world > 1 and "DP_HOST_THREADS" not in os.environ:
+        # one process per GPU on ONE host: the ranks share the container's CPU quota, so each gets its share of worker threads
+        os.environ["DP_HOST_THREADS"] = str(max(2, cpu_budget() // world))
     if os.environ.get("DP_BENCH_DEBUG"):  # hung-run diagnosis: Python stacks of every rank every 40 s
         import faulthandler
         faulthandler.dump_traceback_later(40, repeat=True)

@@ -1244,7 +1244,9 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
         const uint32_t nsets = qmeta[4 * q + 0];
         if (nsets < 5 || qmeta[4 * q + 2]) continue;
         const int32_t* aSeg = qsegs + qoff[q];
-        const int aN = (int)(qoff[q + 1] - qoff[q]);
+        // wave-uniform by construction; readfirstlane tells the compiler, so the chaining code below branches on SGPRs
+        // instead of predicating every block on "divergent" loads
+        const int aN = RFL((int)(qoff[q + 1] - qoff[q]));
         const uint32_t nSeeds = (uint32_t)aN / 2;
         const u64* qset = qsets + (uint64_t)q * SW;
         const bool aStaged = aN <= C_ACAP && tier != 3;
@@ -1255,7 +1257,7 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
             }
         }
         const u64* qs = (aStaged && SW <= C_QSW) ? (const u64*)L.qsetL : qset;
-        int minMatches = nSeeds < mc_n ? mc[nSeeds] : 0x7fffffff;  // int(hitFraction*numSeeds+0.5), overlap.go:356
+        int minMatches = RFL(nSeeds < mc_n ? mc[nSeeds] : 0x7fffffff);  // int(hitFraction*numSeeds+0.5), overlap.go:356
         u64 tq0 = dbg ? wall_clock64() : 0, tAlign = 0, tExtract = 0, tStage = 0, nCand = 0, nPairs = 0;
         u64 tp[3] = {0, 0, 0};
         for (uint32_t wi = 0; wi < W; wi++) {
@@ -1271,12 +1273,13 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                 // ever returns a value >= maxCount, so the comparison equals the one on the full popcount)
                 int c = 0;
                 for (uint32_t w = lane; w < SW; w += 64) c += __popcll(tset[w] & qs[w]);
-                c = wave_sum(c);
+                c = RFL(wave_sum(c));
                 if (c < minMatches) continue;
                 const dp_seq_ref r = refs[t];
                 const int32_t* bSeg = segs + r.seg_off;
-                const int bN = (int)(2 * r.n_seeds + 1);
+                const int bN = RFL((int)(2 * r.n_seeds + 1));
                 const bool staged = aStaged && bN <= C_BCAP;
+                const int nBSeeds = bN >> 1;
                 int bound = (int)nSeeds;  // upper bound of the chain length: a seeds present in b
                 if (staged) {  // stage b and both membership bit vectors with the whole wave
                     for (int i = lane; i < bN; i += 64) L.bSegL[i] = bSeg[i];
@@ -1289,10 +1292,10 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                         bound += __popcll(m);
                         if (lane == 0) L.aFlag[base >> 6] = m;
                     }
-                    for (int base = 0; base < (int)r.n_seeds; base += 64) {
+                    for (int base = 0; base < nBSeeds; base += 64) {
                         const int s = base + lane;
                         bool f = false;
-                        if (s < (int)r.n_seeds) f = bs_contains(qs, L.bSegL[2 * s + 1]);
+                        if (s < nBSeeds) f = bs_contains(qs, L.bSegL[2 * s + 1]);
                         const u64 m = __ballot(f);
                         if (lane == 0) L.bFlag[base >> 6] = m;
                     }
