@@ -295,3 +295,75 @@ def test_select_seeds_matches_addseeds(ctx, k, L, e):
                         seen.add(x)
                         got.append(x)
             assert got == want[i].tolist(), (num_seeds, wins[i])
+
+
+def _index_from_sets(ctx, k, member):
+    """member[s][i] truthy <=> sequence i holds seed s.  Builds the device index for it; returns the oracle IntSets."""
+    S, M = len(member), len(member[0])
+    ctx.round_begin(k, np.arange(S, dtype=np.uint32) * 37 + 5)  # any S distinct k-mers
+    segs, offs, nseeds = [], [0], []
+    for i in range(M):
+        mine = [s for s in range(S) if member[s][i]]
+        row = [3]
+        for s in mine:
+            row += [s, 2]
+        segs += row
+        offs.append(len(segs))
+        nseeds.append(len(mine))
+    ctx.import_segments(np.array(segs, dtype=np.int32))
+    ctx.index_build(np.array(offs[:-1], dtype=np.uint64), np.array(nseeds, dtype=np.uint32))
+    sets = [O.IntSet() for _ in range(S)]
+    for s in range(S):
+        for i in reversed(range(M)):  # IndexSequences adds in descending sequence order (seeds.go:373-381)
+            if member[s][i]:
+                sets[s].add(i)
+    return sets
+
+
+def _all_seed_query(S):
+    q = [1]
+    for s in range(S):
+        q += [s, 1]
+    return np.array(q, dtype=np.int32), np.array([0, len(q)], dtype=np.uint64)
+
+
+def test_matches_reference_test2sharedids_vectors(ctx):
+    """The reference's own GetSharedIDs known answers (util/bitset_test.go:38-161: 20 sets over 500 ids with
+    multiplicities 16/8/4/2, minCount 16, 15, 8, 4, 2) driven through dp_index_build + dp_find_overlaps."""
+    k = 10
+    reads = ["ACGT" * 30]
+    ctx.upload_reads(np.frombuffer(reads[0].encode(), dtype=np.uint8), np.array([0, len(reads[0])], dtype=np.int64))
+    counts = np.zeros(500, dtype=np.int64)
+    for i in range(500):
+        counts[i] = 16 if i % 7 == 0 else 8 if i % 5 == 0 else 4 if i % 3 == 0 else 2 if i % 2 == 0 else 0
+    member = [[j < counts[i] for i in range(500)] for j in range(20)]
+    _index_from_sets(ctx, k, member)
+    qs, qo = _all_seed_query(20)
+    for hf, min_count, expect in ((0.8, 16, 16), (0.75, 15, 16), (0.4, 8, 8), (0.2, 4, 4), (0.1, 2, 2)):
+        assert int(hf * 20 + 0.5) == min_count
+        out = ctx.find_overlaps(qs, qo, hf, k, 500, want_candidates=True)
+        want = [i for i in range(500) if counts[i] >= expect]
+        assert out["cand"].tolist() == want, (min_count,)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_matches_all_ladder_regimes_vs_oracle(ctx, seed):
+    """Matches -> GetSharedIDs(fast=true) for every threshold regime (<=1, 2-8 exact, 9-12 -> 8, 13-16 exact incl. the
+    16-ladder's step-8 defect, 17-24 -> 16, > 24 exact-validated) against the oracle, sets in query-seed order."""
+    k = 10
+    ctx.upload_reads(np.frombuffer(b"ACGT" * 30, dtype=np.uint8), np.array([0, 120], dtype=np.int64))
+    rng = np.random.default_rng(seed)
+    S, M = 48, 700
+    dens = rng.choice([0.05, 0.2, 0.45, 0.7], size=M)  # sequences with very different numbers of the query's seeds
+    member = [[bool(rng.random() < dens[i]) for i in range(M)] for _ in range(S)]
+    for s in range(S):  # uneven windows: some sets live in a narrow id range (early-return / swap-removal paths)
+        if s % 5 == 0:
+            lo = int(rng.integers(0, M - 150))
+            member[s] = [member[s][i] and lo <= i < lo + 150 for i in range(M)]
+    sets = _index_from_sets(ctx, k, member)
+    qs, qo = _all_seed_query(S)
+    for hf in (0.01, 0.03, 0.1, 0.16, 0.2, 0.24, 0.27, 0.32, 0.36, 0.41, 0.5, 0.52, 0.62, 0.8):
+        min_count = int(hf * S + 0.5)
+        out = ctx.find_overlaps(qs, qo, hf, k, 500, want_candidates=True)
+        want = O.shared_ids(sets, min_count, True)
+        assert out["cand"].tolist() == [int(x) for x in want], (seed, hf, min_count)
