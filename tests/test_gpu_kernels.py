@@ -367,3 +367,39 @@ def test_matches_all_ladder_regimes_vs_oracle(ctx, seed):
         out = ctx.find_overlaps(qs, qo, hf, k, 500, want_candidates=True)
         want = O.shared_ids(sets, min_count, True)
         assert out["cand"].tolist() == [int(x) for x in want], (seed, hf, min_count)
+
+
+def test_reference_sequence_test_vectors_on_device(ctx):
+    """sequence/sequence_test.go on the device: packBytes("CGGT") = 0x6B (Test9Packing), CountKmers = 27 for k=6 on the
+    70-base test sequence with the test's kmerSet (Test6CountKmers), the k=8/k=11 counts on SubSequence(7, len-7), and
+    WriteSegments on the full sequence and on SubSequence(2, len-2) (Test8Segments)."""
+    from tests.test_oracle_known_answers import S70, kmer_set
+    reads = [S70, "CGGT" * 5]
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    off = np.array([0, len(S70), len(S70) + 20], dtype=np.int64)
+    ctx.upload_reads(bases, off)
+    assert bytes(ctx.packed_read(1)) == bytes([0x6B] * 5)
+
+    def seeds_of(ks):
+        return np.nonzero(ks)[0].astype(np.uint32)
+
+    def scan_view(start, end, k, seeds):
+        ctx.round_begin(k, seeds)
+        res = ctx.scan([(0, start, (end - start) - k + 1, 0)])
+        segs = res["segs"][int(res["seg_off"][0]):int(res["seg_off"][1])]
+        # device seed ids are positions in `seeds`; the reference's arrays hold k-mers at this level
+        out = segs.astype(np.int64).copy()
+        out[1::2] = seeds[segs[1::2]]
+        return int(res["n_seeds"][0]), out
+
+    ks, count = kmer_set(S70, 6)
+    n, segs = scan_view(0, len(S70), 6, seeds_of(ks))
+    assert n == count == 27
+    assert np.array_equal(segs, O.byte_write_segments(S70, 6, ks))
+    n2, segs2 = scan_view(2, len(S70) - 2, 6, seeds_of(ks))
+    assert np.array_equal(segs2, O.byte_write_segments(S70[2:len(S70) - 2], 6, ks))
+    sub = S70[7:len(S70) - 7]
+    for k in (8, 11):
+        ksk, cnt = kmer_set(sub, k)
+        n, _ = scan_view(7, len(S70) - 7, k, seeds_of(ksk))
+        assert n == cnt == O.byte_count_kmers(sub, 100, k, ksk)
