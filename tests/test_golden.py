@@ -12,7 +12,8 @@ import pytest
 from tests import oracle_lib as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.json")))
+FIXTURES = sorted(p for p in glob.glob(os.path.join(ROOT, "tests", "golden", "*.json")) if not os.path.basename(p).startswith("map_"))
+MAP_FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "map_*.json")))
 
 
 def _sha(a):
@@ -29,7 +30,7 @@ def _load(path):
 
 
 def test_fixtures_exist():
-    assert len(FIXTURES) >= 6
+    assert len(FIXTURES) >= 6 and len(MAP_FIXTURES) >= 3
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-5] for p in FIXTURES])
@@ -78,3 +79,34 @@ def test_gpu_pipeline_matches_golden(path, slots):
     assert paf.count("\n") == fx["paf_lines"]
     assert hashlib.sha256(paf.encode()).hexdigest() == fx["paf_sha256"]
     pipe.close()
+
+
+def _map_inputs(fx):
+    g = fx["generator"]
+    genome = np.frombuffer(O.gen_genome(g["seed"], g["genome"]), dtype=np.uint8)
+    goff = np.array([0, g["genome"]], dtype=np.int64)
+    bases, off = O.gen_reads(g["seed"], g["genome"], g["reads"], g["read_len"], g["error"], g["variable"])
+    return genome, goff, bases, off
+
+
+@pytest.mark.parametrize("path", MAP_FIXTURES, ids=[os.path.basename(p)[:-5] for p in MAP_FIXTURES])
+def test_oracle_map_reproduces_golden(path):
+    fx = json.load(open(path))
+    genome, goff, bases, off = _map_inputs(fx)
+    paf, err = O.map_run(O.ReadSet(genome, goff, min_len=0, himem=False), O.ReadSet(bases, off, min_len=500, himem=False),
+                         circular=fx["circular"], k=fx["k"])
+    assert paf.count("\n") == fx["paf_lines"] and hashlib.sha256(paf.encode()).hexdigest() == fx["paf_sha256"]
+    assert err == fx["stderr"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", MAP_FIXTURES, ids=[os.path.basename(p)[:-5] for p in MAP_FIXTURES])
+def test_gpu_map_matches_golden(path):
+    from downpore_amd.mapping import map_reads
+    from downpore_amd.overlap import Reads
+    fx = json.load(open(path))
+    genome, goff, bases, off = _map_inputs(fx)
+    paf, err, st = map_reads(Reads(genome, goff, min_len=0, himem=False), Reads(bases, off, min_len=500, himem=False),
+                             circular=fx["circular"], k=fx["k"])
+    assert paf.count("\n") == fx["paf_lines"] and hashlib.sha256(paf.encode()).hexdigest() == fx["paf_sha256"]
+    assert err == fx["stderr"]

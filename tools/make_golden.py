@@ -30,6 +30,26 @@ CASES = {
 }
 
 
+MAP_CASES = {
+    # name: (seed, genome, reads, read_len, error, variable_length, circular, k)
+    "map_circular_k11": (3, 200000, 300, 8000, 0.0, False, True, 11),
+    "map_noisy_variable_k11": (4, 150000, 300, 6000, 0.05, True, True, 11),
+    "map_linear_10pct_k11": (5, 300000, 200, 9000, 0.10, True, False, 11),
+}
+
+
+def build_map(name):
+    seed, G, N, L, e, var, circular, k = MAP_CASES[name]
+    genome = np.frombuffer(O.gen_genome(seed, G), dtype=np.uint8)
+    bases, off = O.gen_reads(seed, G, N, L, e, var)
+    oref = O.ReadSet(genome, np.array([0, G], dtype=np.int64), min_len=0, himem=False)
+    oreads = O.ReadSet(bases, off, min_len=500, himem=False)
+    paf, err = O.map_run(oref, oreads, circular=circular, k=k)
+    return {"case": name, "generator": {"seed": seed, "genome": G, "reads": N, "read_len": L, "error": e, "variable": var},
+            "circular": circular, "k": k, "paf_lines": paf.count("\n"), "paf_sha256": hashlib.sha256(paf.encode()).hexdigest(),
+            "paf_head": paf.split("\n")[:8], "stderr": err}
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -69,4 +89,8 @@ if __name__ == "__main__":
     for name in CASES:
         with open(os.path.join(out, name + ".json"), "w") as f:
             json.dump(build(name), f, indent=1)
+        print("wrote", name)
+    for name in MAP_CASES:
+        with open(os.path.join(out, name + ".json"), "w") as f:
+            json.dump(build_map(name), f, indent=1)
         print("wrote", name)
