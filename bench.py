@@ -154,6 +154,16 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": count_bytes, "launch_ms": count_ms},
+            # the other kernels of a round, same convention (algorithmic bytes / HIP-event time); chain_kernel is a
+            # latency-bound per-query state machine, its byte rate is reported for completeness only
+            "other_kernels": {
+                "scan_write_pass": {"ms": acc.get("k_write_ms", 0.0) / n,
+                                    "algorithmic_bytes": (acc.get("scan_bytes", 0.0) - acc.get("count_bytes", 0.0)) / n},
+                "index_query": {"ms": acc.get("k_query_ms", 0.0) / n, "algorithmic_bytes": acc.get("query_bytes", 0.0) / n,
+                                "GBs": (acc.get("query_bytes", 0.0) / 1e9) / (acc.get("k_query_ms", 0.0) / 1e3) if acc.get("k_query_ms", 0) > 0 else 0.0},
+                "chain_kernel": {"ms": acc.get("k_chain_ms", 0.0) / n, "bound": "latency (sequential ratchet per query)",
+                                 "matches_per_step": acc.get("n_matches", 0.0) / n},
+            },
             "paf_lines": lines, "rounds_per_s": steps_done / elapsed if elapsed > 0 else 0.0,
             "reads_scanned_per_s": (acc.get("scan_items", 0.0) / n) * steps_done / elapsed if elapsed > 0 else 0.0,
             "phase_ms_per_step": {kk: 1e3 * acc.get(kk, 0.0) / n for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
