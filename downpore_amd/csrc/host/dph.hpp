@@ -181,9 +181,9 @@ struct SeedContig {
     std::vector<i64> Offsets, Lengths, SeqLengths;
     std::vector<uint8_t> ReverseComplement, Approximate;
     std::vector<SeedMatch*> Matches;
-    std::vector<std::unique_ptr<SeedMatch>> owned;
 };
-std::unique_ptr<SeedContig> buildConsensus(Arena& a, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, i64* badBack);
+// Returns a contig in per-thread storage (valid until the calling thread's next buildConsensus) or nullptr.
+SeedContig* buildConsensus(Arena& a, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, i64* badBack);
 
 // ---- overlap.Overlapper (overlap/overlap.go:24-29) ----------------------------------------------------------------
 struct SeedQuery {  // overlap/overlap.go:10-16

@@ -462,7 +462,7 @@ int Overlapper::FindOverlaps(std::vector<SeedMatch>& pool, std::vector<SeedMatch
 static void finalCheckOne(Arena& arena, const SeedIndex& index, const ReadSet& reads, std::vector<SeedMatch*>& results,
                           i64 overlapSize, std::string& paf, std::vector<int>& ignoreIds, FinalCheckStats& fs) {
     const int k = index.k;
-    std::unique_ptr<SeedContig> contig = buildConsensus(arena, index, results, &fs.badBack);
+    SeedContig* contig = buildConsensus(arena, index, results, &fs.badBack);
     if (!contig || contig->Parts.size() <= 1) return;
     if (contig->SeqLengths[0] <= overlapSize * 2) ignoreIds.push_back(contig->Parts[0]);
     const i64 queryStart = contig->Offsets[0], queryEnd = queryStart + contig->Lengths[0];

@@ -618,7 +618,9 @@ static void pairScanInStep(int ns, const int32_t* __restrict__ ok, const int32_t
 }
 
 // seeds/alignment.go:23-268
-SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k, std::vector<std::unique_ptr<SeedMatch>>& matchesOut) {
+// matchesOut receives pointers into a per-thread pool of SeedMatch objects (their vectors keep their capacity between
+// calls); they stay valid until the calling thread's next call.
+SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k, std::vector<SeedMatch*>& matchesOut) {
     const size_t ns = seqs.size();
     const std::vector<uint64_t>& useSeeds = seedsSharedByTwo(seqs);
     // scratch that keeps its capacity between calls (one set per worker thread)
@@ -638,13 +640,20 @@ SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k,
     supported.assign(ns, 0);
     dist.assign(ns, 0);
     consensus.clear();
-    std::vector<std::unique_ptr<SeedMatch>> matches(ns);
+    static thread_local std::vector<SeedMatch> matchPool;
+    static thread_local std::vector<SeedMatch*> matches;
+    if (matchPool.size() < ns) matchPool.resize(ns);
+    matches.assign(ns, nullptr);
     for (size_t i = 0; i < ns; i++)
         if (red[i]) {
-            matches[i].reset(new SeedMatch());
-            matches[i]->SeqB = seqs[i];
-            matches[i]->MatchA.reserve((size_t)red[i]->n / 2);
-            matches[i]->MatchB.reserve((size_t)red[i]->n / 2);
+            SeedMatch* m = &matchPool[i];
+            m->MatchA.clear();
+            m->MatchB.clear();
+            m->SeqA = nullptr;
+            m->SeqB = seqs[i];
+            m->QueryID = 0;
+            m->ReverseComplementQuery = false;
+            matches[i] = m;
         }
     bool finished = false;
     const i64 kNarrow = (i64)1 << 28;  // all quantities below this: 32-bit arithmetic is exact
@@ -861,15 +870,15 @@ SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k,
     cons->length = -k;
     for (size_t i = 0; i < consensus.size(); i += 2) cons->length += consensus[i] + k;  // LoadSequence :35-42
     for (i64 i = (i64)matches.size() - 1; i >= 0; i--) {
-        SeedMatch* m = matches[(size_t)i].get();
+        SeedMatch* m = matches[(size_t)i];
         if (!m || m->MatchA.size() < 3) {
-            matches[(size_t)i] = std::move(matches.back());
+            matches[(size_t)i] = matches.back();
             matches.pop_back();
         } else {
             m->SeqA = cons;
         }
     }
-    matchesOut = std::move(matches);
+    matchesOut.assign(matches.begin(), matches.end());
     return cons;
 }
 
@@ -943,12 +952,13 @@ static void trimToBestSeed(Arena& ar, int upto, std::vector<SeedMatch*>& ms, int
     }
 }
 
-static std::unique_ptr<SeedContig> newSeedContig(Arena& ar, std::vector<SeedMatch*>& ms, int k, i64* badBack) {  // :113-133
+static SeedContig* newSeedContig(Arena& ar, std::vector<SeedMatch*>& ms, int k, i64* badBack) {  // :113-133
     const int minMatch = ms.size() < 5 ? (int)ms.size() : 5;
-    std::vector<SeedSeq*> parts;
-    std::vector<uint8_t> trimFailed;
+    static thread_local std::vector<SeedSeq*> parts;
+    static thread_local std::vector<uint8_t> trimFailed;
+    static thread_local SeedContig contig;  // one contig per worker thread at a time
     trimToBestSeed(ar, ms[0]->SeqA->numSeeds() / 4, ms, minMatch, k, parts, trimFailed, badBack);
-    std::unique_ptr<SeedContig> c(new SeedContig());
+    SeedContig* c = &contig;
     const size_t n = ms.size();
     c->Parts.assign(n, 0);
     c->ReverseComplement.assign(n, 0);
@@ -970,9 +980,11 @@ static std::unique_ptr<SeedContig> newSeedContig(Arena& ar, std::vector<SeedMatc
     return c;
 }
 
-std::unique_ptr<SeedContig> buildConsensus(Arena& ar, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, i64* badBack) {  // :163-193
+SeedContig* buildConsensus(Arena& ar, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, i64* badBack) {  // :163-193
     const int k = sg.k;
-    std::vector<SeedSeq*> seqs;
+    static thread_local std::vector<SeedSeq*> seqs;
+    static thread_local std::vector<SeedMatch*> overlap;
+    seqs.clear();
     for (SeedMatch* lap : overlaps)
         if (lap->ReverseComplementQuery) matchReverseComplement(ar, *lap, sg);
     for (SeedMatch* lap : overlaps) {
@@ -983,15 +995,8 @@ std::unique_ptr<SeedContig> buildConsensus(Arena& ar, const SeedIndex& sg, std::
                                   overlaps[0]->SeqA->seedOffsetFromEnd(lap->MatchA.back(), k), lap->MatchB.back(), k));
     }
     if (seqs.size() > 1) {
-        std::vector<std::unique_ptr<SeedMatch>> overlap;
         multiAlignerConsensus(ar, seqs, k, overlap);
-        if (overlap.size() > 1) {
-            std::vector<SeedMatch*> ms;
-            for (auto& m : overlap) ms.push_back(m.get());
-            std::unique_ptr<SeedContig> c = newSeedContig(ar, ms, k, badBack);
-            c->owned = std::move(overlap);
-            return c;
-        }
+        if (overlap.size() > 1) return newSeedContig(ar, overlap, k, badBack);
     }
     return nullptr;
 }
