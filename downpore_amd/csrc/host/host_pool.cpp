@@ -1,0 +1,175 @@
+// Process-wide worker pool (sized from the cgroup CPU quota) and the DPH_PROFILE counters.
+#include <pthread.h>
+#include <sched.h>
+#include <unistd.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "host_util.hpp"
+
+namespace dph {
+
+PipeProfile g_prof;
+
+void profilePrint() { g_prof.print(); }
+void setHostThreadShare(unsigned) {}  // kept for callers; the shared pool needs no per-slot split
+// CPUs this process may actually use: the cgroup CPU quota (containers often expose every host CPU but cap the CPU
+// time; exceeding the cap gets the whole process throttled for the rest of the scheduler period) or the CPU count.
+static unsigned cpuBudget() {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    double quota = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char a[64] = {0};
+        long long period = 0;
+        if (fscanf(f, "%63s %lld", a, &period) == 2 && strcmp(a, "max") != 0 && period > 0) quota = atof(a) / (double)period;
+        fclose(f);
+    } else {
+        long long q = -1, per = 0;
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lld", &q) != 1) q = -1;
+            fclose(g);
+        }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(g, "%lld", &per) != 1) per = 0;
+            fclose(g);
+        }
+        if (q > 0 && per > 0) quota = (double)q / (double)per;
+    }
+    if (quota >= 1.0 && quota < (double)hw) hw = (unsigned)quota;
+    return hw;
+}
+
+unsigned hostThreads() {
+    static unsigned n = [] {
+        const char* e = getenv("DP_HOST_THREADS");
+        unsigned v = e ? (unsigned)atoi(e) : cpuBudget();
+        if (v == 0) v = 1;
+        return std::min(v, 96u);
+    }();
+    return n;
+}
+
+namespace {
+struct PoolJob {
+    size_t n = 0;
+    const std::function<void(size_t)>* fn = nullptr;
+    std::atomic<size_t> next{0}, done{0};
+    std::mutex mu;
+    std::condition_variable cv;
+};
+class WorkPool {
+   public:
+    static WorkPool& get() {
+        static WorkPool* p = new WorkPool();  // intentionally leaked: workers may outlive static destruction order
+        return *p;
+    }
+    void run(size_t n, const std::function<void(size_t)>& fn) {
+        if (n == 0) return;
+        if (n == 1 || threads_.empty()) {
+            for (size_t i = 0; i < n; i++) fn(i);
+            return;
+        }
+        auto job = std::make_shared<PoolJob>();
+        job->n = n;
+        job->fn = &fn;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            jobs_.push_back(job);
+        }
+        cv_.notify_all();
+        work(*job);
+        if (job->done.load(std::memory_order_acquire) < n) {  // items still running on pool threads
+            std::unique_lock<std::mutex> jl(job->mu);
+            job->cv.wait(jl, [&] { return job->done.load(std::memory_order_acquire) >= n; });
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        for (auto it = jobs_.begin(); it != jobs_.end(); ++it)
+            if (it->get() == job.get()) {
+                jobs_.erase(it);
+                break;
+            }
+    }
+
+   private:
+    WorkPool() {
+        const unsigned n = hostThreads();
+        // Workers sleep between jobs and are woken together by the submitting thread; the scheduler tends to leave such
+        // short bursts stacked on the waker's CPU.  Each worker is therefore pinned to its own CPU of the allowed set
+        // (spread evenly) when DP_PIN_WORKERS=1.
+        std::vector<int> cpus;
+        const char* pin = getenv("DP_PIN_WORKERS");
+        if (pin && pin[0] != '0') {  // 1: one worker per physical core, spread over all cores; 2: the same within NUMA node 0
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            if (sched_getaffinity(0, sizeof set, &set) == 0)
+                for (int c = 0; c < CPU_SETSIZE; c++) {
+                    if (!CPU_ISSET(c, &set)) continue;
+                    char path[128];
+                    int first = c, node0 = 1;
+                    snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+                    if (FILE* f = fopen(path, "r")) {
+                        if (fscanf(f, "%d", &first) != 1) first = c;
+                        fclose(f);
+                    }
+                    if (first != c) continue;  // SMT sibling of a lower-numbered CPU
+                    if (pin[0] == '2') {
+                        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/node0", c);
+                        node0 = access(path, F_OK) == 0;
+                    }
+                    if (node0) cpus.push_back(c);
+                }
+        }
+        for (unsigned i = 1; i < n; i++) {
+            threads_.emplace_back([this] { loop(); });
+            if (cpus.size() >= n) {
+                cpu_set_t one;
+                CPU_ZERO(&one);
+                CPU_SET(cpus[(size_t)i * cpus.size() / n], &one);
+                pthread_setaffinity_np(threads_.back().native_handle(), sizeof one, &one);
+            }
+        }
+        for (auto& t : threads_) t.detach();
+    }
+    static void work(PoolJob& j) {
+        for (;;) {
+            const size_t i = j.next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j.n) return;
+            (*j.fn)(i);
+            if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 == j.n) {
+                std::lock_guard<std::mutex> jl(j.mu);
+                j.cv.notify_all();
+            }
+        }
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            std::shared_ptr<PoolJob> job;
+            for (auto& j : jobs_)
+                if (j->next.load(std::memory_order_relaxed) < j->n) {
+                    job = j;
+                    break;
+                }
+            if (!job) {
+                cv_.wait(lk);
+                continue;
+            }
+            lk.unlock();
+            work(*job);
+            lk.lock();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::shared_ptr<PoolJob>> jobs_;
+    std::vector<std::thread> threads_;
+};
+}  // namespace
+
+void parallelFor(size_t n, const std::function<void(size_t)>& fn) { WorkPool::get().run(n, fn); }
+
+}  // namespace dph

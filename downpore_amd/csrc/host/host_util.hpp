@@ -1,0 +1,65 @@
+// Internal helpers shared by the host translation units (not part of the mirrored reference interface).
+#pragma once
+#include <sys/resource.h>
+#include <time.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+#include "dph.hpp"
+
+namespace dph {
+
+static inline double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static inline double threadCpuNow() {  // CPU time consumed by the calling thread
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// DPH_PROFILE=1: pipeline counters printed to stderr when a run shuts down
+struct PipeProfile {
+    std::atomic<long long> executed{0}, committed{0}, rejected{0}, discarded{0}, ignores{0}, planComputes{0}, planErased{0},
+        planDiscarded{0};
+    std::atomic<long long> planUs{0}, getWaitUs{0}, execUs{0}, commitUs{0}, consensusCpuUs{0}, selectCpuUs{0}, slotCpuUs{0}, plannerCpuUs{0};
+    std::atomic<long long> sub[18];
+    const char* subName[18] = {"prep.indexReset", "prep.newOverlapper", "prep.roundBegin", "scan.call", "scan.copy", "idx.copy",
+                               "idx.chunk", "idx.build", "idx.queries", "qry.call", "qry.matches", "fc.collate", "fc.parallel",
+                               "fc.merge", "round.total", "round.tail", "plan.speculate", "plan.commitLoop"};
+    PipeProfile() {
+        for (auto& x : sub) x = 0;
+    }
+    void add(int i, double sec) { sub[i] += (long long)(sec * 1e6); }
+    bool on = getenv("DPH_PROFILE") != nullptr;
+    void print() {
+        if (!on) return;
+        fprintf(stderr,
+                "[pipe] rounds executed %lld committed %lld rejected %lld discarded %lld | new ignores %lld | plans computed %lld "
+                "(%.2f ms each) erased %lld thrown away %lld | plan wait %.1f ms, execute %.1f ms, commit %.1f ms\n",
+                executed.load(), committed.load(), rejected.load(), discarded.load(), ignores.load(), planComputes.load(),
+                planComputes.load() ? planUs.load() / 1e3 / planComputes.load() : 0.0, planErased.load(), planDiscarded.load(),
+                getWaitUs.load() / 1e3, execUs.load() / 1e3, commitUs.load() / 1e3);
+        const double n = (double)std::max<long long>(1, executed.load());
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        fprintf(stderr, "[pipe] host threads %u, process CPU time user %.2f s sys %.2f s\n", hostThreads(),
+                ru.ru_utime.tv_sec + ru.ru_utime.tv_usec / 1e6, ru.ru_stime.tv_sec + ru.ru_stime.tv_usec / 1e6);
+        {
+            const double nn = (double)std::max<long long>(1, executed.load());
+            fprintf(stderr, "[pipe] thread CPU per round (ms): consensus items %.2f, seed-selection items %.2f, slot threads %.2f, planner thread %.2f\n",
+                    consensusCpuUs.load() / 1e3 / nn, selectCpuUs.load() / 1e3 / nn, slotCpuUs.load() / 1e3 / nn,
+                    plannerCpuUs.load() / 1e3 / nn);
+        }
+        fprintf(stderr, "[pipe] per executed round (ms):");
+        for (int i = 0; i < 18; i++) fprintf(stderr, " %s %.3f", subName[i], sub[i].load() / 1e3 / n);
+        fprintf(stderr, "\n");
+    }
+};
+extern PipeProfile g_prof;  // defined in host_pool.cpp
+
+}  // namespace dph
