@@ -176,6 +176,14 @@ int dph_overlap_step(void* hh) {
 }
 int64_t dph_overlap_round(void* hh) { return ((OverlapH*)hh)->run.round; }
 void dph_profile_print() { profilePrint(); }
+// host-logic test hook: the value table (commands/overlap.go:55-92) from a k-mer histogram; counts is overwritten with the
+// merged forward + reverse-complement counts like the reference's in-place loop
+void dph_values_from_counts(uint64_t* counts, int k, double* out) {
+    std::vector<uint64_t> c(counts, counts + ((size_t)1 << (2 * k)));
+    std::vector<double> v = kmerValuesFromCounts(c, k);
+    memcpy(out, v.data(), v.size() * sizeof(double));
+    memcpy(counts, c.data(), c.size() * sizeof(uint64_t));
+}
 // discards the executor pipeline's in-flight rounds (they are re-executed): a timed region then starts from an empty pipeline
 void dph_overlap_drain(void* hh) { ((OverlapH*)hh)->run.drain(); }
 

@@ -504,6 +504,14 @@ std::string MapperImpl::asString(const Mapping& m, const std::string& qname, i64
 int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int device, std::string& paf, std::string& errText,
            MapStats* stats, std::string& error) {
     const double tRun0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    const bool prof = getenv("DPH_PROFILE") != nullptr;
+    double tMark = tRun0;
+    auto mark = [&](const char* what) {
+        if (!prof) return;
+        const double t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        fprintf(stderr, "[map setup] %-28s %.1f ms\n", what, 1e3 * (t - tMark));
+        tMark = t;
+    };
     if (refSet.size() == 0) {
         error = "empty reference";
         return -1;
@@ -521,13 +529,16 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         dp_ctx_destroy(ctx);
         return rc;
     };
+    mark("context");
     // ---- value table from every sequence of the reference file (map.go:45-71); KmerOccurrences on the GPU
     int rc = dp_reads_upload(ctx, (const uint8_t*)refSet.bases.data(), refSet.off.data(), (uint32_t)refSet.size());
     if (rc) return fail(rc);
     std::vector<uint64_t> counts((size_t)1 << (2 * k));
     rc = dp_kmer_histogram(ctx, k, counts.data());
     if (rc) return fail(rc);
+    mark("reference upload + histogram");
     std::vector<double> values = kmerValuesFromCounts(counts, k);
+    mark("value table");
     counts.clear();
     counts.shrink_to_fit();
     errText += "K-mer counting complete. Preparing to start indexing and querying...\n";
@@ -582,6 +593,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             }
         }
     }
+    mark("AddSingleSeeds");
     // ---- device read set: [0] reference, [1] circular join chunk, then (forward, reverse complement) of every read
     std::string bases;
     std::vector<i64> off(1, 0);
@@ -597,8 +609,10 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     for (size_t r = 0; r < reads.size(); r++) addRead(reads.seq(r), (size_t)reads.length(r));
     // device ids: 0 reference, 1 join chunk, then (forward, reverse complement) per read; the reverse strands are made
     // on the device
+    mark("concatenate reads");
     rc = dp_reads_upload_rc(ctx, (const uint8_t*)bases.data(), off.data(), (uint32_t)(off.size() - 1), 2);
     if (rc) return fail(rc);
+    mark("upload + pack (both strands)");
     bases.clear();
     bases.shrink_to_fit();
     rc = dp_round_begin(ctx, k, index.seedMap.data(), (uint32_t)index.seedMap.size());
@@ -663,6 +677,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // (dp_index_build references the device-resident scan output, so windows must not overwrite it)
     if (stats) stats->n_chunks = items.size(), stats->n_seeds = index.seedMap.size();
 
+    mark("round begin + chunk scan + index");
     // ---- Map every read: coroutines + batched windows
     auto wallNow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tLoop0 = wallNow();

@@ -89,13 +89,12 @@ i64 ReadSet::scanKmers(size_t r, int k) const {
     return n < 0 ? 0 : n;
 }
 
-uint32_t reverseComplementKmer(uint32_t seed, int k) {
-    uint32_t rc = 0;
-    for (int j = 0; j < k; j++) {
-        rc = (rc << 2) | ((seed ^ 3) & 3);
-        seed >>= 2;
-    }
-    return rc;
+uint32_t reverseComplementKmer(uint32_t seed, int k) {  // complement every 2-bit code, reverse their order (k <= 16)
+    uint32_t x = ~seed;
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = __builtin_bswap32(x);
+    return k >= 16 ? x : (x >> (32 - 2 * k));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -105,16 +104,27 @@ uint32_t reverseComplementKmer(uint32_t seed, int k) {
 std::vector<double> kmerValuesFromCounts(std::vector<uint64_t>& counts, int k) {
     const size_t n = counts.size();
     std::vector<double> values(n, 0.0);
-    uint64_t tot = 0;
-    for (uint64_t c : counts) tot += c;
+    uint64_t tot = 0, maxCount = 0;
+    for (uint64_t c : counts) {
+        tot += c;
+        maxCount = std::max(maxCount, c);
+    }
     const double tf = (double)tot;
     const double targetFreq = 0.000005;
-    for (size_t i = 0; i < n; i++) {
-        const uint64_t count = counts[i];
+    auto valueOf = [&](uint64_t count) -> double {
         const double freq = (double)count / tf;
-        if (count < 3) values[i] = 0;
-        else if (freq <= targetFreq) values[i] = 1.0 - (targetFreq - freq);
-        else values[i] = 1.0 - (freq - targetFreq);
+        if (count < 3) return 0.0;
+        if (freq <= targetFreq) return 1.0 - (targetFreq - freq);
+        return 1.0 - (freq - targetFreq);
+    };
+    // the value is a function of the count alone: one exact evaluation per distinct count, 4^k table lookups
+    const uint64_t kLut = (uint64_t)1 << 22;
+    if (maxCount < kLut) {
+        std::vector<double> lut((size_t)maxCount + 1);
+        for (uint64_t c = 0; c <= maxCount; c++) lut[(size_t)c] = valueOf(c);
+        for (size_t i = 0; i < n; i++) values[i] = lut[(size_t)counts[i]];
+    } else {
+        for (size_t i = 0; i < n; i++) values[i] = valueOf(counts[i]);
     }
     for (size_t i = 0; i < n; i++) {  // in-place fwd+rc merge, sequential semantics (kmers.go:90-96)
         const size_t rc = reverseComplementKmer((uint32_t)i, k);
@@ -124,9 +134,25 @@ std::vector<double> kmerValuesFromCounts(std::vector<uint64_t>& counts, int k) {
     }
     const size_t topN = n / 100;
     if (topN > 0) {
-        std::vector<uint64_t> tmp(counts);
-        std::nth_element(tmp.begin(), tmp.begin() + (n - topN), tmp.end());
-        const uint64_t T = tmp[n - topN];
+        // T = the (n - topN)-th smallest merged count (what nth_element would put there)
+        uint64_t T = 0, maxMerged = 0;
+        for (uint64_t c : counts) maxMerged = std::max(maxMerged, c);
+        if (maxMerged < kLut) {
+            std::vector<uint64_t> hist((size_t)maxMerged + 1, 0);
+            for (uint64_t c : counts) hist[(size_t)c]++;
+            uint64_t cum = 0;
+            for (uint64_t v = 0; v <= maxMerged; v++) {
+                cum += hist[(size_t)v];
+                if (cum > (uint64_t)(n - topN)) {
+                    T = v;
+                    break;
+                }
+            }
+        } else {
+            std::vector<uint64_t> tmp(counts);
+            std::nth_element(tmp.begin(), tmp.begin() + (n - topN), tmp.end());
+            T = tmp[n - topN];
+        }
         size_t above = 0;
         for (uint64_t c : counts) above += c > T;
         size_t ties = topN - above;

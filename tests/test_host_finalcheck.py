@@ -64,3 +64,22 @@ def test_product_finalcheck_matches_oracle(seed, G, N, L, k, e, variable):
         d = first_diff(paf, want)
         assert d is None, "round %d %s" % (rnd, d)
     assert np.array_equal(reads.ignore(), rs.ignore())
+
+
+@pytest.mark.parametrize("k,G,N,L", [(8, 30000, 200, 3000), (10, 200000, 500, 4000), (11, 400000, 300, 6000)])
+def test_product_value_table_matches_oracle(k, G, N, L):
+    """kmerValuesFromCounts (histogram -> value table, incl. the top-1 % blacklist and its tie rule) against the oracle,
+    from the oracle's own k-mer counts."""
+    from downpore_amd.overlap import load_host
+    H = load_host()
+    bases, off = O.gen_reads(40 + k, G, N, L, 0.01, True)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    counts = rs.kmer_counts(k)
+    want = rs.kmer_values(k)
+    got = np.zeros(4 ** k, dtype=np.float64)
+    c = np.ascontiguousarray(counts, dtype=np.uint64).copy()
+    H.dph_values_from_counts.restype = None
+    H.dph_values_from_counts.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    H.dph_values_from_counts(c.ctypes.data, k, got.ctypes.data)
+    assert np.array_equal(got, want)
+    assert (got > 0).sum() > 0
