@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--k", type=int, default=13)
     ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--error", type=float, default=0.0)
+    ap.add_argument("--max-rounds", type=int, default=-1)
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r01", "full_job_parity.json"))
@@ -32,11 +34,11 @@ def main():
     from tests import oracle_lib as O
     from tools.synth import gen_reads
     N, L = a.reads, a.read_len
-    bases, off = gen_reads(a.seed, N * L // 20, N, L, 0.0, False)
+    bases, off = gen_reads(a.seed, N * L // 20, N, L, a.error, False)
     reads = Reads(bases, off, min_len=1000)
     pipe = OverlapPipeline(reads, k=a.k, slots=a.slots)
     t0 = time.time()
-    rounds = pipe.run()
+    rounds = pipe.run(a.max_rounds)
     t_gpu = time.time() - t0
     gpu_paf = pipe.all_paf()
     values = pipe.values().copy()
@@ -46,10 +48,10 @@ def main():
     os.environ["DPO_SCAN_THREADS"] = str(a.threads or cpu_budget())
     rs = O.ReadSet(bases, off, min_len=1000)
     t0 = time.time()
-    run = O.OverlapRun(rs, k=a.k, values=np.ascontiguousarray(values), traces=False)
+    run = O.OverlapRun(rs, k=a.k, values=np.ascontiguousarray(values), traces=False, max_rounds=rounds if a.max_rounds >= 0 else -1)
     t_cpu = time.time() - t0
     same = gpu_paf == run.paf
-    out = {"workload": "%d reads x %d bp, k=%d, every round" % (N, L, a.k), "rounds_gpu": rounds, "rounds_oracle": run.rounds,
+    out = {"workload": "%d reads x %d bp, error %.3g, k=%d, %s" % (N, L, a.error, a.k, "every round" if a.max_rounds < 0 else "first %d rounds" % rounds), "rounds_gpu": rounds, "rounds_oracle": run.rounds,
            "paf_lines": gpu_paf.count("\n"), "paf_sha256_gpu": hashlib.sha256(gpu_paf.encode()).hexdigest(),
            "paf_sha256_oracle": hashlib.sha256(run.paf.encode()).hexdigest(), "paf_identical": bool(same),
            "ignore_flags_identical": bool(np.array_equal(gpu_ignore, rs.ignore())),
