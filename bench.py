@@ -118,7 +118,7 @@ def main():
         for key, v in st.items():
             acc[key] = acc.get(key, 0.0) + v
         samples += 1
-        lines += pipe.round_paf().count("\n")
+        lines += pipe.step_lines()
         steps_done += c
     sync()
     elapsed = time.perf_counter() - t_start

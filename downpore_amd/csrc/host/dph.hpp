@@ -375,6 +375,7 @@ struct OverlapRun {
     i64 badBack = 0, emptyMatch = 0;
     bool done = false;
     std::string paf;      // PAF text of the last committed round(s)
+    i64 pafLines = 0;     // ... and its number of lines
     std::string errText;  // stderr progress lines accumulated
     std::string error;    // failure text
     RoundStats last;

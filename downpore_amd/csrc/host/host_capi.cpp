@@ -176,6 +176,7 @@ int dph_overlap_step(void* hh) {
 }
 int64_t dph_overlap_round(void* hh) { return ((OverlapH*)hh)->run.round; }
 void dph_profile_print() { profilePrint(); }
+int64_t dph_overlap_step_lines(void* hh) { return ((OverlapH*)hh)->run.pafLines; }  // PAF lines of the last step
 // host-logic test hook: the value table (commands/overlap.go:55-92) from a k-mer histogram; counts is overwritten with the
 // merged forward + reverse-complement counts like the reference's in-place loop
 void dph_values_from_counts(uint64_t* counts, int k, double* out) {

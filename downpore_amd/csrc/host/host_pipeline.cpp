@@ -484,6 +484,7 @@ void OverlapRun::commitOne(RoundResult& r) {
     badBack += r.fs.badBack;
     emptyMatch += r.fs.emptyMatch;
     paf += r.paf;
+    pafLines += (i64)r.fs.lines;
     last = r.st;
     g_prof.ignores += (long long)r.ignores.size();
     for (int id : r.ignores)
@@ -495,6 +496,7 @@ void OverlapRun::commitOne(RoundResult& r) {
 
 int OverlapRun::commitResults(std::vector<RoundResult>& results) {
     paf.clear();
+    pafLines = 0;
     int committed = 0;
     std::vector<uint8_t> newly;  // flags set by rounds committed in THIS call
     std::vector<int> newIds;
@@ -598,6 +600,7 @@ int OverlapRun::step() {
     const double t0 = now();
     std::unique_lock<std::mutex> lk(pmu_);
     paf.clear();
+    pafLines = 0;
     int committed = 0;
     for (;;) {
         if (workerRc_ != 0) {
@@ -688,6 +691,7 @@ int OverlapRun::roundFinish(const Survivors& all) {
         return rc;
     }
     paf.clear();
+    pafLines = 0;
     commitOne(cur);
     return 0;
 }

@@ -273,6 +273,12 @@ class OverlapPipeline:
             raise self._err()
         return C.string_at(p, n.value)
 
+    def step_lines(self):
+        """PAF lines printed by the rounds the last step() committed."""
+        self.H.dph_overlap_step_lines.restype = C.c_int64
+        self.H.dph_overlap_step_lines.argtypes = [C.c_void_p]
+        return int(self.H.dph_overlap_step_lines(self.h))
+
     def drain(self):
         """Discards the rounds the executor pipeline has in flight (they are executed again later)."""
         self.H.dph_overlap_drain(self.h)
