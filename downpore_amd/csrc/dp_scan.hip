@@ -627,20 +627,34 @@ __global__ __launch_bounds__(SCAN_THREADS, FILTER >= 2 ? 8 : 4) void scan_kernel
                 const Win w = wn;
                 if (g + 64 <= g1) wn = load_win(packed, g + 64);  // software prefetch of the wave's next block
                 if (g <= g1) {
-                    uint32_t m = (FILTER == 1 ? ProbeLoop<0>::run(w, bloom, pshift) : FILTER == 3 ? PairLoop<0, true>::run(w, bloom) : PairLoop<0>::run(w, bloom)) & valid_mask(g, a0, a1);
+                    uint32_t m = (FILTER == 1 ? ProbeLoop<0>::run(w, bloom, pshift) : FILTER == 3 ? PairLoop<0, true>::run(w, bloom) : PairLoop<0>::run(w, bloom));
+                    if (g == g0 || g == g1) m &= valid_mask(g, a0, a1);  // only the item's first / last group is partial
                     if (dbg & 1) {  // timing experiments only (DP_SCAN_DEBUG): drop the candidate loop
                         cnt += __builtin_popcount(m);
                         m = 0;
                     }
-                    while (m) {
-                        int j = __builtin_ctz(m);
-                        m &= m - 1;
-                        uint32_t kmer = win_at_rt(w, j) >> ksh;
+                    // candidates of the low / high 16 positions separately: each half reads a fixed pair of window words
+                    const uint64_t s01 = ((uint64_t)w.w0 << 32) | w.w1, s12 = ((uint64_t)w.w1 << 32) | w.w2;
+                    uint32_t mlo = m & 0xffffu, mhi = m >> 16;
+                    while (mlo) {
+                        const int j = __builtin_ctz(mlo);
+                        mlo &= mlo - 1;
+                        const uint32_t kmer = (uint32_t)((s01 << (2 * j)) >> 32) >> ksh;
                         if (FILTER >= 2) {
                             const uint32_t h = kmer & T2_MASK;
                             if (!((bloom[T1_BYTES + (h >> 3)] >> (h & 7)) & 1u)) continue;
                         }
                         if ((bits[kmer >> 5] >> (kmer & 31)) & 1u) exact |= 1u << j;
+                    }
+                    while (mhi) {
+                        const int j = __builtin_ctz(mhi);
+                        mhi &= mhi - 1;
+                        const uint32_t kmer = (uint32_t)((s12 << (2 * j)) >> 32) >> ksh;
+                        if (FILTER >= 2) {
+                            const uint32_t h = kmer & T2_MASK;
+                            if (!((bloom[T1_BYTES + (h >> 3)] >> (h & 7)) & 1u)) continue;
+                        }
+                        if ((bits[kmer >> 5] >> (kmer & 31)) & 1u) exact |= 1u << (16 + j);
                     }
                 }
                 if (MODE == 0) {
