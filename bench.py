@@ -40,8 +40,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and "DP_HOST_THREADS" not in os.environ:  # ranks share the node's cores
-        os.environ["DP_HOST_THREADS"] = str(max(2, min(32, (os.cpu_count() or 8) // world)))
+    if world > 1 and "DP_HOST_THREADS" not in os.environ:
+        # one process per GPU on ONE host: the ranks share the container's CPU quota, so each gets its share of worker threads
+        os.environ["DP_HOST_THREADS"] = str(max(2, cpu_budget() // world))
     import torch
     torch_device = None
     if world > 1:
@@ -60,9 +61,6 @@ def main():
     else:
         dist = None
 
-    if world > 1 and "DP_HOST_THREADS" not in os.environ:
-        # one process per GPU on ONE host: the ranks share the container's CPU quota, so each gets its share of worker threads
-        os.environ["DP_HOST_THREADS"] = str(max(2, cpu_budget() // world))
     if os.environ.get("DP_BENCH_DEBUG"):  # hung-run diagnosis: Python stacks of every rank every 40 s
         import faulthandler
         faulthandler.dump_traceback_later(40, repeat=True)
