@@ -1034,11 +1034,16 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
                            (int32_t*)ctx->d_segs.p, 0u, (const uint32_t*)s_item, (uint32_t)n_surv_all);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+        if (n_segs * 4 > ((uint64_t)8 << 20)) {
+            // dense-seed regime: tens of MB go back to the host; let the next slot's scan start while they travel
+            DP_HIP(hipEventSynchronize(ctx->ev[3]));
+            scan_lock.unlock();
+        }
         DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     DP_HIP(dp_stream_sync(ctx));
     if (n_segs) hipEventElapsedTime(&ms1, ctx->ev[2], ctx->ev[3]);
-    scan_lock.unlock();
+    if (scan_lock.owns_lock()) scan_lock.unlock();
     ctx->n_segs = n_segs;
     // survivors of the read range come first (item index < n_read_items), the extra items after them (all present)
     uint64_t ns = 0;

@@ -160,6 +160,7 @@ struct SeedIndex {
     // seed id -> seed id of its reverse complement for the complete seed set (call once all seeds of the round are in)
     void buildRcTable();
     std::vector<int32_t> rcOf;
+    std::vector<Arena> chunkArenas;  // one per block of survivors when chunking runs on the worker pool (kept across rounds)
 };
 
 SeedSeq* seqReverseComplement(Arena& a, SeedSeq* s, const SeedIndex& ix);  // seeds/sequence.go:134-159
@@ -255,7 +256,7 @@ class Overlapper {
     }
 
    private:
-    void chunkAndAdd(SeedSeq* s, uint64_t segBase);
+    void chunkAndAdd(SeedSeq* s, uint64_t segBase, Arena& ar, std::vector<SeedSeq*>& seqOut, std::vector<dp_seq_ref>& refOut);
     const uint8_t* ignore_ = nullptr;
     uint64_t ignoreEpoch_ = 0;
     dp_ctx* ctx_;

@@ -221,16 +221,16 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
 }
 
 // chunkWorker :253-318 for one seed sequence whose segments start at device offset segBase
-void Overlapper::chunkAndAdd(SeedSeq* s, uint64_t segBase) {
+void Overlapper::chunkAndAdd(SeedSeq* s, uint64_t segBase, Arena& ar, std::vector<SeedSeq*>& seqOut,
+                            std::vector<dp_seq_ref>& refOut) {
     const int k = index_.k;
-    Arena& ar = index_.arena;
     auto add = [&](SeedSeq* q) {
-        index_.sequences.push_back(q);
+        seqOut.push_back(q);
         dp_seq_ref r;
         r.seg_off = segBase + (uint64_t)(q->seg - s->seg);
         r.n_seeds = (uint32_t)q->numSeeds();
         r.reserved = 0;
-        index_.refs.push_back(r);
+        refOut.push_back(r);
     };
     const i64 numChunks = s->length / chunkSize_ + 1;
     if (numChunks == 1 || s->numSeeds() < minSeeds_ * 3) {
@@ -299,16 +299,39 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
     index_.refs.clear();
     double tp1 = now();
     g_prof.add(5, tp1 - tp0);
-    for (size_t i = 0; i < all.read.size(); i++) {
-        const uint32_t r = all.read[i];
-        SeedSeq* s = index_.arena.make();
-        s->seg = allSegs_ + all.seg_off[i];
-        s->n = (int)(all.seg_off[i + 1] - all.seg_off[i]);
-        s->id = (int)r;
-        s->length = reads_.length(r);
-        s->offset = 0;
-        s->inset = reads_.servedInset();
-        chunkAndAdd(s, all.seg_off[i]);
+    auto chunkRange = [&](size_t lo, size_t hi, Arena& ar, std::vector<SeedSeq*>& seqOut, std::vector<dp_seq_ref>& refOut) {
+        for (size_t i = lo; i < hi; i++) {
+            const uint32_t r = all.read[i];
+            SeedSeq* s = ar.make();
+            s->seg = allSegs_ + all.seg_off[i];
+            s->n = (int)(all.seg_off[i + 1] - all.seg_off[i]);
+            s->id = (int)r;
+            s->length = reads_.length(r);
+            s->offset = 0;
+            s->inset = reads_.servedInset();
+            chunkAndAdd(s, all.seg_off[i], ar, seqOut, refOut);
+        }
+    };
+    const size_t nSurv = all.read.size(), block = 1024;
+    if (nSurv <= 2 * block) {
+        chunkRange(0, nSurv, index_.arena, index_.sequences, index_.refs);
+    } else {  // chunkWorker is per sequence: blocks of survivors on the worker pool, results concatenated in file order
+        const size_t nb = (nSurv + block - 1) / block;
+        if (index_.chunkArenas.size() < nb) index_.chunkArenas.resize(nb);
+        std::vector<std::vector<SeedSeq*>> seqB(nb);
+        std::vector<std::vector<dp_seq_ref>> refB(nb);
+        parallelFor(nb, [&](size_t b) {
+            index_.chunkArenas[b].clear();
+            chunkRange(b * block, std::min(nSurv, (b + 1) * block), index_.chunkArenas[b], seqB[b], refB[b]);
+        });
+        size_t total = 0;
+        for (auto& v : seqB) total += v.size();
+        index_.sequences.reserve(total);
+        index_.refs.reserve(total);
+        for (size_t b = 0; b < nb; b++) {
+            index_.sequences.insert(index_.sequences.end(), seqB[b].begin(), seqB[b].end());
+            index_.refs.insert(index_.refs.end(), refB[b].begin(), refB[b].end());
+        }
     }
     double tp2 = now();
     g_prof.add(6, tp2 - tp1);

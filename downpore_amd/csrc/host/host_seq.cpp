@@ -186,6 +186,7 @@ void SeedIndex::reset() {
     sequences.clear();
     refs.clear();
     arena.clear();
+    for (Arena& a : chunkArenas) a.clear();
 }
 
 void SeedIndex::grow() {
