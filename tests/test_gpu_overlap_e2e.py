@@ -98,6 +98,59 @@ def test_round_parallel_commits_beyond_local_plans():
         pipes[r].close()
 
 
+def _run_arrays(bases, off, k=10, slots=1, max_rounds=-1, **kw):
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    rs = O.ReadSet(bases, off, min_len=1000)
+    orun = O.OverlapRun(rs, k=k, max_rounds=max_rounds, **kw)
+    reads = Reads(bases, off, min_len=1000)
+    pipe = OverlapPipeline(reads, k=k, slots=slots, **kw)
+    n = pipe.run(max_rounds)
+    d = first_diff(pipe.all_paf(), orun.paf)
+    assert d is None, d
+    assert np.array_equal(reads.ignore(), rs.ignore())
+    if max_rounds < 0:
+        assert n == orun.rounds
+    pipe.close()
+    return orun
+
+
+def test_overlap_degenerate_inputs():
+    """Edge cases of the input set: nothing survives the length filter, a single read, two reads."""
+    bases, off = O.gen_reads(5, 30000, 6, 3000, 0.0, False)
+    short = np.ascontiguousarray(bases[:off[3]])
+    # every read shorter than min_len (1000): the read set is empty
+    cut_off = np.array([0, 400, 900, 1300], dtype=np.int64)
+    orun = _run_arrays(short[:1300], cut_off)
+    assert orun.paf == ""
+    for n in (1, 2):
+        _run_arrays(np.ascontiguousarray(bases[:off[n]]), np.ascontiguousarray(off[:n + 1]))
+
+
+@pytest.mark.parametrize("slots", [1, 2])
+def test_overlap_identical_and_repetitive_reads(slots):
+    """Collisions: many copies of the same read plus tandem repeats — every query matches every target with many
+    equally good chains (long open-chain lists, the chain kernel's lds tier, capacity rules)."""
+    rng = np.random.default_rng(3)
+    unit = "".join("ACGT"[i] for i in rng.integers(0, 4, 700))
+    base_read = "".join("ACGT"[i] for i in rng.integers(0, 4, 3000))
+    reads = [base_read] * 25 + [unit * 5] * 10 + [base_read[500:] + unit] * 5
+    other, ooff = O.gen_reads(8, 40000, 60, 3000, 0.01, True)
+    texts = reads + [other[ooff[i]:ooff[i + 1]].tobytes().decode() for i in range(60)]
+    bases = np.frombuffer("".join(texts).encode(), dtype=np.uint8)
+    off = np.cumsum([0] + [len(t) for t in texts]).astype(np.int64)
+    _run_arrays(bases, off, slots=slots)
+
+
+def test_overlap_non_acgt_letters():
+    """IUPAC / lower-case letters go through the same 2-bit code as in the reference (sequence.go:59): no special casing."""
+    bases, off = O.gen_reads(21, 60000, 150, 3000, 0.0, False)
+    b = bases.copy()
+    rng = np.random.default_rng(4)
+    pos = rng.integers(0, len(b), 3000)
+    b[pos] = np.frombuffer(b"NRYKMSWnacgt", dtype=np.uint8)[rng.integers(0, 12, 3000)]
+    _run_arrays(b, off)
+
+
 def test_overlap_slots_with_ignores():
     """Short reads get flagged as ignored by earlier rounds: concurrent slots must discard invalidated speculation."""
     orun, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
