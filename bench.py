@@ -165,7 +165,7 @@ def main():
             "paf_lines": lines, "rounds_per_s": steps_done / elapsed if elapsed > 0 else 0.0,
             "reads_scanned_per_s": (acc.get("scan_items", 0.0) / n) * steps_done / elapsed if elapsed > 0 else 0.0,
             "phase_ms_per_step": {kk: 1e3 * acc.get(kk, 0.0) / n for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
-            "kernel_ms_per_step": {kk: acc.get(kk, 0.0) / n for kk in ("k_count_ms", "k_write_ms", "k_scan_ms", "k_query_ms", "k_chain_ms")},
+            "kernel_ms_per_step": {kk: acc.get(kk, 0.0) / n for kk in ("k_count_ms", "k_write_ms", "k_scan_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
             "index_query": {"bytes_per_step": acc.get("query_bytes", 0.0) / n,
                             "achieved_GBs": (acc.get("query_bytes", 0.0) / 1e9) / (acc.get("k_query_ms", 1e-9) / 1e3) if acc.get("k_query_ms", 0) > 0 else 0.0},
             "setup_s": {"generate": t_gen, "upload_pack_histogram_values": t_setup},

@@ -39,6 +39,8 @@ struct dp_ctx {
     uint64_t n_values = 0;
     DevBuf d_selwin, d_seltop;
     PinBuf h_seltop;
+    DevBuf d_cin, d_cout;       // dp_consensus_align
+    PinBuf h_cin, h_cout;
     std::vector<uint64_t> h_boff;
     std::vector<uint32_t> h_len;
 

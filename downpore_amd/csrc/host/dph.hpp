@@ -86,6 +86,7 @@ struct Arena {
     };
     std::vector<Slab> slabs;
     size_t cur = 0;
+    size_t slabBytes = (size_t)1 << 20;  // minimum size of a new slab
     void* raw(size_t bytes, size_t align) {
         for (;;) {
             if (cur < slabs.size()) {
@@ -99,7 +100,7 @@ struct Arena {
                 continue;
             }
             Slab s;
-            s.cap = std::max<size_t>(bytes + align, (size_t)1 << 20);
+            s.cap = std::max<size_t>(bytes + align, slabBytes);
             s.p.reset(new char[s.cap]);
             slabs.push_back(std::move(s));
         }
@@ -186,6 +187,21 @@ struct SeedContig {
 // Returns a contig in per-thread storage (valid until the calling thread's next buildConsensus) or nullptr.
 SeedContig* buildConsensus(Arena& a, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, i64* badBack);
 
+// BuildConsensus in two halves so that the seed-space alignment in the middle can run on the device for all query
+// windows of a round at once (dp_consensus_align).  consensusPrepare: un-RC, trim the matched targets, Reduced() to the
+// seeds shared by >= 2 of them.  consensusFinish: consensus + per-sequence matches (from the device batch, or computed
+// here when `batch` is null / the group was flagged) -> trimToBestSeed -> contig.
+struct ConsJob {
+    ConsJob() { arena.slabBytes = (size_t)1 << 16; }
+    Arena arena;                          // everything the job allocates; cleared by consensusPrepare
+    std::vector<SeedSeq*> seqs, red;      // trimmed targets and their reduced forms (null = no shared seed)
+    std::vector<std::vector<int>> seedMap;  // reduced index -> index in seqs[i]
+    bool aligned = false;                 // seqs.size() > 1: takes part in the alignment
+    uint32_t group = 0, firstSeq = 0;     // position in the flattened device batch
+};
+void consensusPrepare(ConsJob& job, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps);
+SeedContig* consensusFinish(ConsJob& job, const SeedIndex& sg, const dp_consensus_batch* batch, const uint64_t* seqOff, i64* badBack);
+
 // ---- overlap.Overlapper (overlap/overlap.go:24-29) ----------------------------------------------------------------
 struct SeedQuery {  // overlap/overlap.go:10-16
     int ID = 0, SequenceID = 0;
@@ -208,6 +224,7 @@ struct RoundStats {
     double t_prepare = 0, t_scan = 0, t_index = 0, t_query = 0, t_consensus = 0;  // host wall seconds
     double k_scan_ms = 0, k_query_ms = 0, k_chain_ms = 0;                         // device kernel ms
     double k_count_ms = 0, k_write_ms = 0;                                        // scan passes
+    double k_cons_ms = 0;                                                         // consensus alignment kernel
     uint64_t count_bytes = 0;                                                     // algorithmic bytes of the count pass
     uint64_t scan_bases = 0, scan_items = 0, scan_bytes = 0, query_bytes = 0;
     uint64_t n_queries = 0, n_indexed = 0, n_hits = 0, n_matches = 0, n_paf = 0, n_seeds = 0;
@@ -285,8 +302,11 @@ struct FinalCheckStats {
     uint64_t lines = 0, hits = 0, qHits = 0;
 };
 // SetIgnore calls are returned in ignoreOut (query order) when it is non-null, otherwise applied to reads.ignore.
-void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, const std::vector<SeedMatch*>& matches, i64 numQuerySeqs,
-                i64 overlapSize, std::string& paf, FinalCheckStats& fs, std::vector<int>* ignoreOut = nullptr);
+// ctx + jobs (optional): run the consensus alignment of all query windows on the device (dp_consensus_align); jobs is
+// per-executor scratch kept across rounds.  Returns 0, or the device call's error code (text in *errOut).
+int finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, const std::vector<SeedMatch*>& matches, i64 numQuerySeqs,
+               i64 overlapSize, std::string& paf, FinalCheckStats& fs, std::vector<int>* ignoreOut = nullptr,
+               dp_ctx* ctx = nullptr, std::vector<ConsJob>* jobs = nullptr, std::string* errOut = nullptr, RoundStats* st = nullptr);
 void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vector<std::unique_ptr<SeedMatch>>& matches,
                 i64 numQuerySeqs, i64 overlapSize, std::string& paf, FinalCheckStats& fs, std::vector<int>* ignoreOut = nullptr);
 
@@ -348,6 +368,7 @@ struct ExecSlot {
     Survivors local;
     std::vector<SeedMatch> matchPool;  // reused across rounds
     std::vector<SeedMatch*> matches;
+    std::vector<ConsJob> consJobs;     // consensus scratch per query window, reused across rounds
     std::string error;
 };
 

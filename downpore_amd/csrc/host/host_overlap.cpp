@@ -421,10 +421,18 @@ int Overlapper::FindOverlaps(std::vector<SeedMatch>& pool, std::vector<SeedMatch
 // finalCheckWorker commands/overlap.go:197-233 (+ collation :158-173).  Queries are independent (the reference runs
 // num_workers finalCheckWorkers); they are spread over host threads here, and the PAF text and SetIgnore effects are
 // applied in query order afterwards, so the result is the canonical single-worker output.
+static void finalCheckEmit(SeedContig* contig, const SeedIndex& index, const ReadSet& reads, i64 overlapSize, std::string& paf,
+                           std::vector<int>& ignoreIds, FinalCheckStats& fs);
+
 static void finalCheckOne(Arena& arena, const SeedIndex& index, const ReadSet& reads, std::vector<SeedMatch*>& results,
                           i64 overlapSize, std::string& paf, std::vector<int>& ignoreIds, FinalCheckStats& fs) {
+    finalCheckEmit(buildConsensus(arena, index, results, &fs.badBack), index, reads, overlapSize, paf, ignoreIds, fs);
+}
+
+// the PAF lines and SetIgnore decisions of one contig (commands/overlap.go:199-231)
+static void finalCheckEmit(SeedContig* contig, const SeedIndex& index, const ReadSet& reads, i64 overlapSize, std::string& paf,
+                           std::vector<int>& ignoreIds, FinalCheckStats& fs) {
     const int k = index.k;
-    SeedContig* contig = buildConsensus(arena, index, results, &fs.badBack);
     if (!contig || contig->Parts.size() <= 1) return;
     if (contig->SeqLengths[0] <= overlapSize * 2) ignoreIds.push_back(contig->Parts[0]);
     const i64 queryStart = contig->Offsets[0], queryEnd = queryStart + contig->Lengths[0];
@@ -484,8 +492,9 @@ void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, std::vecto
     finalCheck(arena, index, reads, ptrs, numQuerySeqs, overlapSize, paf, fs, ignoreOut);
 }
 
-void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, const std::vector<SeedMatch*>& matches, i64 numQuerySeqs,
-                i64 overlapSize, std::string& paf, FinalCheckStats& fs, std::vector<int>* ignoreOut) {
+int finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, const std::vector<SeedMatch*>& matches, i64 numQuerySeqs,
+               i64 overlapSize, std::string& paf, FinalCheckStats& fs, std::vector<int>* ignoreOut, dp_ctx* ctx,
+               std::vector<ConsJob>* jobs, std::string* errOut, RoundStats* st) {
     // collate by QueryID (:158-173)
     const double tf0 = now();
     std::vector<std::vector<SeedMatch*>> queryResults((size_t)numQuerySeqs);
@@ -507,6 +516,65 @@ void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, const std:
     const double tf1 = now();
     g_prof.add(11, tf1 - tf0);
     std::atomic<long long> cpuUs(0);
+    // DP_DEVICE_CONSENSUS=1: run the seed-space alignment in the middle of BuildConsensus on the device
+    // (dp_consensus_align).  Off by default: measured on config 2 it takes 1.7 core-ms per round off the host (of 13.6)
+    // but adds a 0.22 ms kernel and a second fork/join to every round, a net loss (5.6 M -> 4.6 M overlaps/s) until the
+    // trimming before it and trimToBestSeed after it move to the device too.  Read per call so tests can toggle it.
+    const char* devCons = getenv("DP_DEVICE_CONSENSUS");
+    if (ctx && jobs && devCons && devCons[0] == '1' && nw > 0) {
+        // ---- phase 1 (pool): trim the matched targets and reduce them, per query window
+        if (jobs->size() < nw) jobs->resize(nw);
+        parallelFor(nw, [&](size_t w) {
+            const double tw = g_prof.on ? threadCpuNow() : 0;
+            consensusPrepare((*jobs)[w], index, queryResults[work[w]]);
+            if (g_prof.on) cpuUs += (long long)((threadCpuNow() - tw) * 1e6);
+        });
+        // ---- the seed-space alignment of every window in one device call
+        static thread_local std::vector<int32_t> segs;
+        static thread_local std::vector<uint64_t> seqOff;
+        static thread_local std::vector<uint32_t> groupOff;
+        segs.clear();
+        seqOff.assign(1, 0);
+        groupOff.assign(1, 0);
+        for (size_t w = 0; w < nw; w++) {
+            ConsJob& job = (*jobs)[w];
+            if (!job.aligned) continue;
+            job.group = (uint32_t)groupOff.size() - 1;
+            job.firstSeq = (uint32_t)seqOff.size() - 1;
+            for (SeedSeq* r : job.red) {
+                if (r) segs.insert(segs.end(), r->seg, r->seg + r->n);
+                seqOff.push_back(segs.size());
+            }
+            groupOff.push_back((uint32_t)seqOff.size() - 1);
+        }
+        dp_consensus_batch batch;
+        memset(&batch, 0, sizeof batch);
+        const uint32_t nGroups = (uint32_t)groupOff.size() - 1;
+        if (nGroups) {
+            const int rc = dp_consensus_align(ctx, segs.data(), seqOff.data(), groupOff.data(), nGroups, index.k, &batch);
+            if (rc != 0) {
+                if (errOut) *errOut = dp_last_error(ctx);
+                return rc;
+            }
+            if (st) st->k_cons_ms += batch.kernel_ms;
+        }
+        // ---- phase 2 (pool): trimToBestSeed, contig, PAF
+        const uint64_t* seqOffPtr = seqOff.data();  // (the vector is thread_local: name it here, not inside the workers)
+        const dp_consensus_batch* batchPtr = nGroups ? &batch : nullptr;
+        parallelFor(nw, [&, seqOffPtr, batchPtr](size_t w) {
+            const double tw = g_prof.on ? threadCpuNow() : 0;
+            std::string pafLocal;
+            std::vector<int> ignLocal;
+            FinalCheckStats fsLocal;
+            pafLocal.reserve(2048);
+            SeedContig* contig = consensusFinish((*jobs)[w], index, batchPtr, seqOffPtr, &fsLocal.badBack);
+            finalCheckEmit(contig, index, reads, overlapSize, pafLocal, ignLocal, fsLocal);
+            outs[w] = std::move(pafLocal);
+            ign[w] = std::move(ignLocal);
+            tfs[w] = fsLocal;
+            if (g_prof.on) cpuUs += (long long)((threadCpuNow() - tw) * 1e6);
+        });
+    } else {
     parallelFor(nw, [&](size_t w) {
         static thread_local Arena local;  // scratch SeedSeqs of this worker; nothing outlives the call
         const double tw = g_prof.on ? threadCpuNow() : 0;
@@ -523,6 +591,7 @@ void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, const std:
         local.clear();
         if (g_prof.on) cpuUs += (long long)((threadCpuNow() - tw) * 1e6);
     });
+    }
     g_prof.consensusCpuUs += cpuUs.load();
     const double tf2 = now();
     g_prof.add(12, tf2 - tf1);
@@ -541,6 +610,7 @@ void finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, const std:
     fs.hits = (uint64_t)hits;
     fs.qHits = (uint64_t)qHits;
     g_prof.add(13, now() - tf2);
+    return 0;
 }
 
 }  // namespace dph

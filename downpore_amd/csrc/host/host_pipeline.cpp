@@ -384,7 +384,9 @@ int OverlapRun::finishRound(ExecSlot& sl, const Survivors& all, RoundResult& out
     }
     double t2 = now();
     st.t_query = t2 - t1;
-    finalCheck(sl.index->arena, *sl.index, *reads, matches, out.numQuerySeqs, p.overlapSize, out.paf, out.fs, &out.ignores);
+    rc = finalCheck(sl.index->arena, *sl.index, *reads, matches, out.numQuerySeqs, p.overlapSize, out.paf, out.fs, &out.ignores,
+                    sl.ctx, &sl.consJobs, &sl.error, &st);
+    if (rc != 0) return rc;
     st.n_paf = out.fs.lines;
     st.t_consensus = now() - t2;
     const int k = p.k;

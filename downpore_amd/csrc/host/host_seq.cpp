@@ -647,18 +647,40 @@ static void pairScanInStep(int ns, const int32_t* __restrict__ ok, const int32_t
 // seeds/alignment.go:23-268
 // matchesOut receives pointers into a per-thread pool of SeedMatch objects (their vectors keep their capacity between
 // calls); they stay valid until the calling thread's next call.
-SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k, std::vector<SeedMatch*>& matchesOut) {
+// Reduced() of every sequence to the seeds shared by >= 2 of them (alignment.go:45-50)
+static void reduceForConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k, std::vector<SeedSeq*>& red,
+                               std::vector<std::vector<int>>& seedMap) {
     const size_t ns = seqs.size();
     const std::vector<uint64_t>& useSeeds = seedsSharedByTwo(seqs);
-    // scratch that keeps its capacity between calls (one set per worker thread)
-    static thread_local std::vector<std::vector<int>> seedMap;
-    static thread_local std::vector<SeedSeq*> red;
-    static thread_local std::vector<i64> pos, offs, gaps, supported, dist;
-    static thread_local std::vector<int32_t> consensus, okv, odv, sdv, gpv;
-    static thread_local std::vector<uint8_t> slowv, fndv;
     if (seedMap.size() < ns) seedMap.resize(ns);
     red.assign(ns, nullptr);
     for (size_t i = 0; i < ns; i++) red[i] = seqReduced(arena, seqs[i], useSeeds, k, 1, &seedMap[i]);
+}
+
+static SeedSeq* multiAlignerCore(Arena& arena, std::vector<SeedSeq*>& seqs, std::vector<SeedSeq*>& red,
+                                 std::vector<std::vector<int>>& seedMap, int k, std::vector<SeedMatch*>& matchesOut);
+
+SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k, std::vector<SeedMatch*>& matchesOut) {
+    // scratch that keeps its capacity between calls (one set per worker thread)
+    static thread_local std::vector<std::vector<int>> seedMap;
+    static thread_local std::vector<SeedSeq*> red;
+    reduceForConsensus(arena, seqs, k, red, seedMap);
+    return multiAlignerCore(arena, seqs, red, seedMap, k, matchesOut);
+}
+
+// per-thread pool of SeedMatch objects for the consensus matches (their vectors keep their capacity)
+static std::vector<SeedMatch>& consensusMatchPool(size_t ns) {
+    static thread_local std::vector<SeedMatch> matchPool;
+    if (matchPool.size() < ns) matchPool.resize(ns);
+    return matchPool;
+}
+
+static SeedSeq* multiAlignerCore(Arena& arena, std::vector<SeedSeq*>& seqs, std::vector<SeedSeq*>& red,
+                                 std::vector<std::vector<int>>& seedMap, int k, std::vector<SeedMatch*>& matchesOut) {
+    const size_t ns = seqs.size();
+    static thread_local std::vector<i64> pos, offs, gaps, supported, dist;
+    static thread_local std::vector<int32_t> consensus, okv, odv, sdv, gpv;
+    static thread_local std::vector<uint8_t> slowv, fndv;
     auto S = [&](size_t i) -> const int32_t* { return red[i] ? red[i]->seg : nullptr; };
     auto N = [&](size_t i) -> i64 { return red[i] ? red[i]->n : 0; };
     pos.assign(ns, -1);
@@ -667,9 +689,8 @@ SeedSeq* multiAlignerConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k,
     supported.assign(ns, 0);
     dist.assign(ns, 0);
     consensus.clear();
-    static thread_local std::vector<SeedMatch> matchPool;
+    std::vector<SeedMatch>& matchPool = consensusMatchPool(ns);
     static thread_local std::vector<SeedMatch*> matches;
-    if (matchPool.size() < ns) matchPool.resize(ns);
     matches.assign(ns, nullptr);
     for (size_t i = 0; i < ns; i++)
         if (red[i]) {
@@ -1007,10 +1028,10 @@ static SeedContig* newSeedContig(Arena& ar, std::vector<SeedMatch*>& ms, int k, 
     return c;
 }
 
-SeedContig* buildConsensus(Arena& ar, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, i64* badBack) {  // :163-193
+// BuildConsensus :163-182: un-RC the rc-query matches, drop matches covering < 25 bases, trim each target to the
+// query-aligned span.  Fills `seqs`.
+static void consensusTrimTargets(Arena& ar, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, std::vector<SeedSeq*>& seqs) {
     const int k = sg.k;
-    static thread_local std::vector<SeedSeq*> seqs;
-    static thread_local std::vector<SeedMatch*> overlap;
     seqs.clear();
     for (SeedMatch* lap : overlaps)
         if (lap->ReverseComplementQuery) matchReverseComplement(ar, *lap, sg);
@@ -1021,10 +1042,77 @@ SeedContig* buildConsensus(Arena& ar, const SeedIndex& sg, std::vector<SeedMatch
         seqs.push_back(seqTrimmed(ar, lap->SeqB, overlaps[0]->SeqA->seedOffset(lap->MatchA[0], k), lap->MatchB[0],
                                   overlaps[0]->SeqA->seedOffsetFromEnd(lap->MatchA.back(), k), lap->MatchB.back(), k));
     }
+}
+
+SeedContig* buildConsensus(Arena& ar, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, i64* badBack) {  // :163-193
+    const int k = sg.k;
+    static thread_local std::vector<SeedSeq*> seqs;
+    static thread_local std::vector<SeedMatch*> overlap;
+    consensusTrimTargets(ar, sg, overlaps, seqs);
     if (seqs.size() > 1) {
         multiAlignerConsensus(ar, seqs, k, overlap);
         if (overlap.size() > 1) return newSeedContig(ar, overlap, k, badBack);
     }
+    return nullptr;
+}
+
+void consensusPrepare(ConsJob& job, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps) {
+    job.arena.clear();
+    consensusTrimTargets(job.arena, sg, overlaps, job.seqs);
+    job.aligned = job.seqs.size() > 1;
+    if (job.aligned) reduceForConsensus(job.arena, job.seqs, sg.k, job.red, job.seedMap);
+    else job.red.clear();
+}
+
+SeedContig* consensusFinish(ConsJob& job, const SeedIndex& sg, const dp_consensus_batch* batch, const uint64_t* seqOff, i64* badBack) {
+    if (!job.aligned) return nullptr;
+    const int k = sg.k;
+    static thread_local std::vector<SeedMatch*> overlap;
+    if (!batch || batch->flags[job.group]) {  // not on the device (or refused there): the host loop
+        multiAlignerCore(job.arena, job.seqs, job.red, job.seedMap, k, overlap);
+    } else {
+        // consensus sequence (LoadSequence :35-42) and the per-sequence matches from the device batch
+        const size_t ns = job.seqs.size();
+        const uint32_t clen = batch->cons_len[job.group];
+        const int32_t* c = batch->cons + batch->cons_off[job.group];
+        SeedSeq* cons = job.arena.make();
+        int32_t* d = job.arena.alloc(clen);
+        memcpy(d, c, (size_t)clen * 4);
+        cons->seg = d;
+        cons->n = (int)clen;
+        cons->length = -k;
+        for (uint32_t i = 0; i < clen; i += 2) cons->length += d[i] + k;
+        std::vector<SeedMatch>& pool = consensusMatchPool(ns);
+        static thread_local std::vector<SeedMatch*> matches;
+        matches.assign(ns, nullptr);
+        for (size_t i = 0; i < ns; i++) {
+            if (!job.red[i]) continue;
+            SeedMatch* m = &pool[i];
+            const uint32_t sq = job.firstSeq + (uint32_t)i;
+            const uint32_t n = batch->match_len[sq];
+            const int32_t* a = batch->match_a + seqOff[sq];
+            const int32_t* b = batch->match_b + seqOff[sq];
+            m->MatchA.assign(a, a + n);
+            m->MatchB.resize(n);
+            for (uint32_t t = 0; t < n; t++) m->MatchB[t] = job.seedMap[i][(size_t)b[t]];
+            m->SeqA = nullptr;
+            m->SeqB = job.seqs[i];
+            m->QueryID = 0;
+            m->ReverseComplementQuery = false;
+            matches[i] = m;
+        }
+        for (i64 i = (i64)matches.size() - 1; i >= 0; i--) {  // :258-266 swap-with-last removal
+            SeedMatch* m = matches[(size_t)i];
+            if (!m || m->MatchA.size() < 3) {
+                matches[(size_t)i] = matches.back();
+                matches.pop_back();
+            } else {
+                m->SeqA = cons;
+            }
+        }
+        overlap.assign(matches.begin(), matches.end());
+    }
+    if (overlap.size() > 1) return newSeedContig(job.arena, overlap, k, badBack);
     return nullptr;
 }
 

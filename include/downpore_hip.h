@@ -205,6 +205,30 @@ typedef struct {
 int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t n_windows,
                    int k, dp_chain_batch* out);
 
+/* ---- A16 (part): seed-space multiple alignment of multiAligner.Consensus (seeds/alignment.go:52-247) ------------
+ * For each of `n_groups` groups (one per query window) the caller passes the Reduced() seed sequences of the trimmed
+ * matched targets (seeds shared by >= 2 of them, alignment.go:45-50), flattened: sequence s = segs[seq_off[s] ..
+ * seq_off[s+1]) in the usual [gap, seed, ..., gap] layout (an empty range = the sequence has no shared seed), group g =
+ * sequences group_off[g] .. group_off[g+1].  The device grows each group's consensus ([dist, seed, ..., 0]) and, per
+ * sequence, the list of (consensus index, index into the REDUCED sequence) pairs; the caller maps the second component
+ * back through Reduced()'s index map, drops sequences with < 3 pairs (alignment.go:258-266) and goes on with
+ * trimToBestSeed.  Sequence s owns match_a/match_b[seq_off[s] .. +match_len[s]).  flags[g] != 0: the group was not
+ * computed (more than 64 sequences, more than 6144 ints, or a value outside the 32-bit safe range) and must be done
+ * by the caller. */
+typedef struct dp_consensus_batch {
+    uint32_t n_groups;
+    const int32_t* cons;        /* consensus of group g: cons[cons_off[g] .. + cons_len[g]) */
+    const uint64_t* cons_off;
+    const uint32_t* cons_len;
+    const int32_t* match_a;
+    const int32_t* match_b;
+    const uint32_t* match_len;  /* per sequence */
+    const uint32_t* flags;      /* per group */
+    double kernel_ms;
+} dp_consensus_batch;
+int dp_consensus_align(dp_ctx* ctx, const int32_t* segs, const uint64_t* seq_off, const uint32_t* group_off, uint32_t n_groups,
+                       int k, dp_consensus_batch* out);
+
 /* ---- introspection for tests ---------------------------------------------------------------------------------- */
 /* posting row of `seed` (n_words = ceil(n_seqs/64)) and its popcount/start/end as the reference's IntSet holds. */
 int dp_index_posting_row(dp_ctx* ctx, uint32_t seed, uint64_t* words, uint32_t cap_words, uint32_t* n_words,

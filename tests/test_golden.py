@@ -56,10 +56,19 @@ def test_oracle_reproduces_golden(path):
     assert int(rs.ignore().sum()) == fx["ignored_reads"]
 
 
+@pytest.fixture(params=["host-consensus", "device-consensus"])
+def consensus_mode(request):
+    """The optional device-side consensus alignment (dp_consensus_align, DP_DEVICE_CONSENSUS=1) must not change a byte."""
+    if request.param == "device-consensus":
+        os.environ["DP_DEVICE_CONSENSUS"] = "1"
+    yield request.param
+    os.environ.pop("DP_DEVICE_CONSENSUS", None)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("slots", [1, 3])
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-5] for p in FIXTURES])
-def test_gpu_pipeline_matches_golden(path, slots):
+def test_gpu_pipeline_matches_golden(path, slots, consensus_mode):
     from downpore_amd.overlap import OverlapPipeline, Reads
     fx, bases, off = _load(path)
     reads = Reads(bases, off, min_len=1000)
