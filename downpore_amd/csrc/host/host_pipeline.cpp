@@ -23,6 +23,7 @@ struct Planner::Impl {
     dp_ctx* selCtx;
     SeedIndex index;  // selection-side seed set of the plan being computed
     std::mutex mu;
+    std::mutex computeMu;     // inline mode: one caller at a time extends the chain (the selection index is shared)
     std::condition_variable cv;
     std::map<i64, std::shared_ptr<RoundPlan>> cache;
     i64 wantUpTo = -1;        // prefetch target (highest requested round + depth)
@@ -139,6 +140,9 @@ void Planner::threadMain() {
 std::shared_ptr<const RoundPlan> Planner::get(i64 round) {
     std::unique_lock<std::mutex> lk(d->mu);
     if (!d->threaded) {  // inline chain: compute the first missing plan until `round` is there (or the chain has ended)
+        lk.unlock();
+        std::lock_guard<std::mutex> cl(d->computeMu);  // executor slots call concurrently
+        lk.lock();
         for (;;) {
             auto it = d->cache.find(round);
             if (it != d->cache.end()) return it->second;

@@ -151,6 +151,18 @@ def test_overlap_non_acgt_letters():
     _run_arrays(b, off)
 
 
+@pytest.mark.parametrize("env", ["DP_NO_PLANNER_THREAD", "DP_HOST_SELECT"])
+def test_overlap_planner_variants(env):
+    """The planner without its own thread (executor slots extend the plan chain themselves, one at a time) and with the
+    seed selection on the host threads instead of dp_select_seeds."""
+    os.environ[env] = "1"
+    try:
+        _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
+        _run_both(113, 1500000, 3000, 10000, 13, max_rounds=3, slots=2)
+    finally:
+        del os.environ[env]
+
+
 def test_overlap_slots_with_ignores():
     """Short reads get flagged as ignored by earlier rounds: concurrent slots must discard invalidated speculation."""
     orun, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
