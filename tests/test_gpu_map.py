@@ -59,3 +59,24 @@ def test_map_paf_bit_exact(seed, G, N, L, e, variable, circular):
 def test_map_short_reads_and_len_mod4_quirks():
     want, st = _case(6, 120000, 100, 5000, 0.02, True, True, short_reads=True)
     assert want.count("\n") > 50
+
+
+def test_map_cli_matches_oracle_cli(tmp_path):
+    """`downpore map -input reads.fa -reference ref.fa` (product CLI, reference flag names and aliases, commands/map.go:17-22)
+    against the oracle's CLI on the same FASTA files."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    G = 150000
+    genome = np.frombuffer(O.gen_genome(8, G), dtype=np.uint8)
+    bases, off = O.gen_reads(8, G, 120, 6000, 0.03, True)
+    ref_fa, reads_fa = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fa")
+    O.write_fasta(ref_fa, genome, np.array([0, G], dtype=np.int64), prefix="chr")
+    O.write_fasta(reads_fa, bases, off)
+    prod = os.path.join(root, "downpore_amd", "bin", "downpore")
+    orac = os.path.join(root, "oracle", "_build", "dp_oracle")
+    a = subprocess.run([prod, "map", "-input", reads_fa, "-reference", ref_fa], capture_output=True, check=True)
+    b = subprocess.run([orac, "map", "-input", reads_fa, "-reference", ref_fa], capture_output=True, check=True)
+    assert first_diff(a.stdout.decode(), b.stdout.decode()) is None and a.stdout.count(b"\n") > 60
+    c = subprocess.run([prod, "map", "-i", reads_fa, "-r", ref_fa, "-k", "11"], capture_output=True, check=True)
+    assert first_diff(c.stdout.decode(), a.stdout.decode()) is None
