@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--seed-batch-size", type=int, default=10000)
     ap.add_argument("--cpu-rounds", type=int, default=2, help="oracle rounds timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--slots", type=int, default=4, help="rounds executed concurrently per GPU (executor slots)")
+    ap.add_argument("--slots", type=int, default=5, help="rounds executed concurrently per GPU (executor slots)")
     ap.add_argument("--mode", default="round", choices=["round", "scan-shard"], help="multi-GPU decomposition (N > 1)")
     args = ap.parse_args()
 
