@@ -989,10 +989,11 @@ static void trimToBestSeed(Arena& ar, int upto, std::vector<SeedMatch*>& ms, int
             if (badBack) (*badBack)++;
             if (back + 1 < front) back = front - 1;
         }
-        std::vector<int32_t> na(match->MatchA.begin() + front, match->MatchA.begin() + back + 1);
-        std::vector<int32_t> nb(match->MatchB.begin() + front, match->MatchB.begin() + back + 1);
-        match->MatchA.swap(na);
-        match->MatchB.swap(nb);
+        // keep [front, back] in place (no reallocation: this runs for every part of every query)
+        match->MatchA.erase(match->MatchA.begin() + back + 1, match->MatchA.end());
+        match->MatchA.erase(match->MatchA.begin(), match->MatchA.begin() + front);
+        match->MatchB.erase(match->MatchB.begin() + back + 1, match->MatchB.end());
+        match->MatchB.erase(match->MatchB.begin(), match->MatchB.begin() + front);
         for (size_t n = 0; n < match->MatchB.size(); n++) {
             match->MatchA[n] -= bestIndex;
             match->MatchB[n] -= (int32_t)index;
