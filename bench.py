@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--seed-batch-size", type=int, default=10000)
     ap.add_argument("--cpu-rounds", type=int, default=2, help="oracle rounds timed for cpu_baseline (0 = skip)")
     ap.add_argument("--slots", type=int, default=5, help="rounds executed concurrently per GPU (executor slots)")
-    ap.add_argument("--mode", default="round", choices=["round", "scan-shard"], help="multi-GPU decomposition (N > 1)")
+    ap.add_argument("--mode", default="round", choices=["round", "round-batch", "scan-shard"], help="multi-GPU decomposition (N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,8 +146,8 @@ def main():
                                    "(BASELINE config 2)" % (N, L, G, args.error, args.k),
                        "reads": N, "read_len": L, "k": args.k, "seed_batch_size": args.seed_batch_size, "executor_slots_per_gpu": args.slots,
                        "parallelism": ("single GPU" if world == 1 else
-                                       "round-parallel over %d GPUs: rank r executes round base+r speculatively, results all-gathered "
-                                       "(RCCL) and committed in order" % world if args.mode == "round" else
+                                       "round-parallel over %d GPUs: rank r's executor pipeline runs the rounds r, r+N, ...; one round "
+                                       "per rank all-gathered (RCCL) per superstep and committed in order" % world if args.mode.startswith("round") else
                                        "scan sharded by read over %d GPUs, survivors all-gathered (RCCL)" % world)},
             "roofline": {"bound": "hbm", "kernel": "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

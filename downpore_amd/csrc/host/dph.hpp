@@ -415,6 +415,12 @@ struct OverlapRun {
     int step();
     // discards everything the executor pipeline has in flight (bench: start the timed region from an empty pipeline)
     void drain();
+    // ---- pipelined round-parallel mode (several ranks): this rank's executor pipeline works on the rounds r with
+    // r % world == rank; per superstep every rank contributes its next owned round (waitOwned), the results are
+    // exchanged and commitGathered commits them in round order on every rank
+    void setRanks(int rank, int world);
+    int waitOwned(RoundResult& out);                     // blocks until the owned round in [round, round+world) is ready
+    int commitGathered(std::vector<RoundResult>& results);  // rounds committed; rejected owned rounds are re-queued
     // executes rounds[i] on slot i concurrently (host threads); outs[i] receives the result
     int executeRounds(const std::vector<i64>& rounds, std::vector<RoundResult>& outs);
     // ---- scan-shard mode (survivor all-gather between the two halves)
@@ -443,6 +449,7 @@ struct OverlapRun {
     std::map<i64, RoundResult> ready_;
     std::deque<i64> redo_;
     i64 nextIssue_ = 0;
+    int rank_ = 0, world_ = 1;
     int inflight_ = 0, workerRc_ = 0;
     bool stopWorkers_ = false, issueEnd_ = false, draining_ = false;
     std::string workerErr_;

@@ -194,15 +194,17 @@ static void putv(std::string& b, const void* p, size_t n) { b.append((const char
 static void serialise(const RoundResult& res, std::string& blob) {
     int64_t hdr[16] = {res.round, res.empty ? 1 : 0, res.firstIn, res.firstOut, res.numQuerySeqs, (int64_t)res.ignores.size(),
                        (int64_t)res.indexedReads.size(), (int64_t)res.paf.size(), res.fs.badBack, res.fs.emptyMatch,
-                       (int64_t)res.fs.lines, (int64_t)res.fs.hits, (int64_t)res.fs.qHits, 0, 0, 0};
+                       (int64_t)res.fs.lines, (int64_t)res.fs.hits, (int64_t)res.fs.qHits, 0, res.snapshot,
+                       (int64_t)res.queryReads.size()};
     int64_t total = (int64_t)(sizeof hdr + sizeof(RoundStats) + res.ignores.size() * sizeof(int) + res.indexedReads.size() * 4 +
-                              res.paf.size());
+                              res.paf.size() + res.queryReads.size() * 4);
     hdr[13] = total;
     putv(blob, hdr, sizeof hdr);
     putv(blob, &res.st, sizeof(RoundStats));
     putv(blob, res.ignores.data(), res.ignores.size() * sizeof(int));
     putv(blob, res.indexedReads.data(), res.indexedReads.size() * 4);
     putv(blob, res.paf.data(), res.paf.size());
+    putv(blob, res.queryReads.data(), res.queryReads.size() * 4);
 }
 // Executes rounds first, first+1, ... (one per executor slot of this process, concurrently) and returns their
 // serialised results back to back (each record carries its own length in hdr[13]).
@@ -225,9 +227,7 @@ const uint8_t* dph_overlap_exec_round(void* hh, int64_t first, uint64_t* n) {
 }
 int dph_overlap_slots(void* hh) { return (int)((OverlapH*)hh)->run.slots.size(); }
 // blobs: concatenation; sizes[i] bytes each.  Returns the number of rounds committed (0..count) or <0.
-int dph_overlap_commit_blobs(void* hh, const uint8_t* blobs, const uint64_t* sizes, int count) {
-    OverlapH* h = (OverlapH*)hh;
-    std::vector<RoundResult> rs;
+static void deserialise(const uint8_t* blobs, const uint64_t* sizes, int count, std::vector<RoundResult>& rs) {
     uint64_t totalBytes = 0;
     for (int i = 0; i < count; i++) totalBytes += sizes[i];
     const uint8_t* q = blobs;
@@ -250,6 +250,9 @@ int dph_overlap_commit_blobs(void* hh, const uint8_t* blobs, const uint64_t* siz
         r.indexedReads.assign((const uint32_t*)q, (const uint32_t*)q + hdr[6]);
         q += hdr[6] * 4;
         r.paf.assign((const char*)q, (size_t)hdr[7]);
+        q += hdr[7];
+        r.snapshot = hdr[14];
+        r.queryReads.assign((const uint32_t*)q, (const uint32_t*)q + hdr[15]);
         r.fs.badBack = hdr[8];
         r.fs.emptyMatch = hdr[9];
         r.fs.lines = (uint64_t)hdr[10];
@@ -258,6 +261,39 @@ int dph_overlap_commit_blobs(void* hh, const uint8_t* blobs, const uint64_t* siz
         rs.push_back(std::move(r));
         q = rec + hdr[13];
     }
+}
+
+// ---- pipelined round-parallel mode: rank `rank` of `world` owns the rounds r % world == rank
+void dph_overlap_set_ranks(void* hh, int rank, int world) { ((OverlapH*)hh)->run.setRanks(rank, world); }
+// serialised result of this rank's owned round of the current superstep (blocks until its executor pipeline has it)
+const uint8_t* dph_overlap_wait_owned(void* hh, uint64_t* n) {
+    OverlapH* h = (OverlapH*)hh;
+    static thread_local std::string blob;
+    RoundResult res;
+    int rc = h->run.waitOwned(res);
+    if (rc != 0) {
+        h->err = h->run.error;
+        *n = 0;
+        return nullptr;
+    }
+    blob.clear();
+    serialise(res, blob);
+    *n = blob.size();
+    return (const uint8_t*)blob.data();
+}
+int dph_overlap_commit_gathered(void* hh, const uint8_t* blobs, const uint64_t* sizes, int count) {
+    OverlapH* h = (OverlapH*)hh;
+    std::vector<RoundResult> rs;
+    deserialise(blobs, sizes, count, rs);
+    int c = h->run.commitGathered(rs);
+    if (c > 0) h->allPaf += h->run.paf;
+    return c;
+}
+
+int dph_overlap_commit_blobs(void* hh, const uint8_t* blobs, const uint64_t* sizes, int count) {
+    OverlapH* h = (OverlapH*)hh;
+    std::vector<RoundResult> rs;
+    deserialise(blobs, sizes, count, rs);
     std::sort(rs.begin(), rs.end(), [](const RoundResult& a, const RoundResult& b) { return a.round < b.round; });
     int c = h->run.commitResults(rs);
     if (c > 0) h->allPaf += h->run.paf;

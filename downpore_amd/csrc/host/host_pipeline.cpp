@@ -546,19 +546,28 @@ int OverlapRun::commitResults(std::vector<RoundResult>& results) {
     return committed;
 }
 
+void OverlapRun::setRanks(int rank, int world) {
+    rank_ = rank;
+    world_ = std::max(1, world);
+}
+
 void OverlapRun::startWorkers() {
     if (!workers_.empty()) return;
     nextIssue_ = round;
+    while (nextIssue_ % world_ != rank_) nextIssue_++;  // first round this rank owns
     for (size_t i = 0; i < slots.size(); i++) workers_.emplace_back([this, i] { workerMain(i); });
 }
 
 void OverlapRun::workerMain(size_t si) {
     ExecSlot& sl = *slots[si];
-    const i64 window = (i64)slots.size() + 2;  // rounds issued ahead of the commit point
+    const i64 window = ((i64)slots.size() + 2) * world_;  // rounds issued ahead of the commit point (owned ones only)
     std::unique_lock<std::mutex> lk(pmu_);
     for (;;) {
         cvWork_.wait(lk, [&] {
-            return stopWorkers_ || (!draining_ && workerRc_ == 0 && (!redo_.empty() || (!issueEnd_ && nextIssue_ < round + window)));
+            // after the end of the input was seen, only the owned round of the current superstep is still issued (it
+            // comes back empty and lets every rank finish the same superstep)
+            const bool more = nextIssue_ < round + window && (!issueEnd_ || nextIssue_ < round + world_);
+            return stopWorkers_ || (!draining_ && workerRc_ == 0 && (!redo_.empty() || more));
         });
         if (stopWorkers_) return;
         i64 r;
@@ -566,7 +575,8 @@ void OverlapRun::workerMain(size_t si) {
             r = redo_.front();
             redo_.pop_front();
         } else {
-            r = nextIssue_++;
+            r = nextIssue_;
+            nextIssue_ += world_;
         }
         const i64 snap = round;
         inflight_++;
@@ -641,6 +651,52 @@ int OverlapRun::step() {
     return committed;
 }
 
+int OverlapRun::waitOwned(RoundResult& out) {
+    startWorkers();
+    std::unique_lock<std::mutex> lk(pmu_);
+    i64 mine = round;
+    while (mine % world_ != rank_) mine++;
+    cvWork_.notify_all();
+    cvDone_.wait(lk, [&] { return workerRc_ != 0 || ready_.count(mine) != 0; });
+    if (workerRc_ != 0) {
+        error = workerErr_;
+        return workerRc_;
+    }
+    out = ready_[mine];  // a copy: the result stays here until it is committed or rejected
+    return 0;
+}
+
+int OverlapRun::commitGathered(std::vector<RoundResult>& results) {
+    std::unique_lock<std::mutex> lk(pmu_);
+    paf.clear();
+    pafLines = 0;
+    std::sort(results.begin(), results.end(), [](const RoundResult& a, const RoundResult& b) { return a.round < b.round; });
+    int committed = 0;
+    for (RoundResult& r : results) {
+        if (r.round != round) break;
+        const bool owned = r.round % world_ == rank_;
+        if (r.empty) {
+            done = true;
+            break;
+        }
+        g_prof.executed++;
+        if (!resultValid(r)) {  // every rank takes the same decision; the owner executes the round again
+            g_prof.rejected++;
+            if (owned) {
+                ready_.erase(r.round);
+                redo_.push_back(r.round);
+            }
+            break;
+        }
+        if (owned) ready_.erase(r.round);
+        commitOne(r);
+        committed++;
+        g_prof.committed++;
+    }
+    cvWork_.notify_all();
+    return committed;
+}
+
 void OverlapRun::drain() {
     std::unique_lock<std::mutex> lk(pmu_);
     if (workers_.empty()) return;
@@ -649,6 +705,7 @@ void OverlapRun::drain() {
     ready_.clear();
     redo_.clear();
     nextIssue_ = round;
+    while (nextIssue_ % world_ != rank_) nextIssue_++;
     issueEnd_ = false;
     draining_ = false;
     cvWork_.notify_all();

@@ -165,9 +165,11 @@ class OverlapPipeline:
     def __init__(self, reads, device=0, k=10, overlap_size=1000, num_seeds=15, seed_batch_size=10000, chunk_size=10000,
                  query_batch_size=20000, min_hits=0.25, himem=True, values=None, rank=0, world=1, torch_device=None,
                  mode="round", slots=1, query_type=1):
-        """mode (world > 1): "round" = round-parallel (rank r executes round base+r speculatively, results are
-        all-gathered and committed in order with a speculation check); "scan-shard" = every rank runs every round, the
-        scan is sharded by read and the survivors are all-gathered.
+        """mode (world > 1): "round" = pipelined round-parallel (rank r's executor pipeline works on the rounds
+        r, r+world, ...; per superstep every rank contributes its next round, results are all-gathered and committed in
+        order with the speculation check); "round-batch" = the same exchange with batch-synchronous supersteps (every rank
+        executes `slots` consecutive rounds, then all wait); "scan-shard" = every rank runs every round, the scan is
+        sharded by read and the survivors are all-gathered.
         slots: executor slots of this process = rounds it runs concurrently on its GPU (each slot has its own stream and
         per-round buffers; the resident reads are shared)."""
         self.H = load_host()
@@ -186,6 +188,14 @@ class OverlapPipeline:
         self.rank, self.world = rank, world
         self.torch_device = torch_device
         self.mode = mode if world > 1 else "single"
+        if self.mode == "round":
+            self.H.dph_overlap_set_ranks.restype = None
+            self.H.dph_overlap_set_ranks.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            self.H.dph_overlap_wait_owned.restype = C.c_void_p
+            self.H.dph_overlap_wait_owned.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+            self.H.dph_overlap_commit_gathered.restype = C.c_int
+            self.H.dph_overlap_commit_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+            self.H.dph_overlap_set_ranks(self.h, rank, world)
         if self.mode == "scan-shard":
             lo, hi = shard_bounds(len(reads), rank, world)
             self.H.dph_overlap_set_shard(self.h, lo, hi)
@@ -229,6 +239,24 @@ class OverlapPipeline:
                 raise self._err()
             return rc
         if self.mode == "round":
+            # pipelined: this rank's executor slots keep working on the rounds r % world == rank; one superstep = every
+            # rank contributes its next owned round, all-gather, commit in round order on every rank
+            while True:
+                if self.H.dph_overlap_done(self.h):
+                    return 0
+                n = C.c_uint64(0)
+                p = self.H.dph_overlap_wait_owned(self.h, C.byref(n))
+                if not p:
+                    raise self._err()
+                blobs = allgather_bytes(C.string_at(p, n.value), self.world, self.torch_device)
+                sizes = np.array([len(b) for b in blobs], dtype=np.uint64)
+                cat = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+                c = self.H.dph_overlap_commit_gathered(self.h, cat.ctypes.data, sizes.ctypes.data, len(blobs))
+                if c < 0:
+                    raise self._err()
+                if c > 0:
+                    return c  # 0 = the superstep's first round was rejected and is being executed again
+        if self.mode == "round-batch":
             if self.H.dph_overlap_done(self.h):
                 return 0
             base = self.H.dph_overlap_round(self.h)
@@ -278,6 +306,21 @@ class OverlapPipeline:
         self.H.dph_overlap_step_lines.restype = C.c_int64
         self.H.dph_overlap_step_lines.argtypes = [C.c_void_p]
         return int(self.H.dph_overlap_step_lines(self.h))
+
+    def wait_owned_blob(self):
+        n = C.c_uint64(0)
+        p = self.H.dph_overlap_wait_owned(self.h, C.byref(n))
+        if not p:
+            raise self._err()
+        return C.string_at(p, n.value)
+
+    def commit_gathered(self, blobs):
+        sizes = np.array([len(b) for b in blobs], dtype=np.uint64)
+        cat = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+        c = self.H.dph_overlap_commit_gathered(self.h, cat.ctypes.data, sizes.ctypes.data, len(blobs))
+        if c < 0:
+            raise self._err()
+        return c
 
     def drain(self):
         """Discards the rounds the executor pipeline has in flight (they are executed again later)."""

@@ -81,7 +81,7 @@ def test_round_parallel_commits_beyond_local_plans():
     bases, off = O.gen_reads(9, 500000, 2000, 5000, 0.0, False)
     kw = dict(k=10, seed_batch_size=1500)  # small seed budget: ~25 reads per round, many rounds
     readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
-    pipes = [OverlapPipeline(readsets[r], rank=r, world=world, mode="round", slots=slots, **kw) for r in range(world)]
+    pipes = [OverlapPipeline(readsets[r], rank=r, world=world, mode="round-batch", slots=slots, **kw) for r in range(world)]
     committed = 0
     while committed < 48 and not pipes[0].finished():
         base = pipes[0].committed_rounds()
@@ -163,6 +163,37 @@ def test_overlap_planner_variants(env):
         del os.environ[env]
 
 
+@pytest.mark.parametrize("world,slots,seed,G,N,L,variable", [(2, 2, 31, 100000, 400, 5000, False), (4, 2, 31, 100000, 400, 5000, False),
+                                                              (3, 2, 32, 60000, 500, 1500, True), (4, 1, 9, 500000, 2000, 5000, False)])
+def test_round_pipelined_ranks_match_oracle(world, slots, seed, G, N, L, variable):
+    """The pipelined round-parallel mode with `world` simulated ranks on one GPU: every rank's executor pipeline works on its
+    residue class of rounds, one round per rank is exchanged per superstep and committed in order with the speculation
+    check (the third case flags reads as ignored, so rounds get rejected and re-executed by their owners)."""
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(seed, G, N, L, 0.0, variable)
+    kw = dict(k=10, seed_batch_size=1500) if seed == 9 else dict(k=10)
+    max_rounds = 40 if seed == 9 else -1
+    readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
+    pipes = [OverlapPipeline(readsets[r], rank=r, world=world, mode="round", slots=slots, **kw) for r in range(world)]
+    committed, supersteps = 0, 0
+    while not pipes[0].finished() and (max_rounds < 0 or committed < max_rounds):
+        blobs = [pipes[r].wait_owned_blob() for r in range(world)]
+        cs = [pipes[r].commit_gathered(blobs) for r in range(world)]
+        assert len(set(cs)) == 1
+        committed += cs[0]
+        supersteps += 1
+        assert supersteps < 5000
+    rs = O.ReadSet(bases, off, min_len=1000)
+    orun = O.OverlapRun(rs, max_rounds=committed if max_rounds >= 0 else -1, **kw)
+    assert orun.rounds == committed
+    for r in range(world):
+        assert first_diff(pipes[r].all_paf(), orun.paf) is None
+        assert np.array_equal(readsets[r].ignore(), rs.ignore())
+        pipes[r].close()
+    if variable:
+        assert rs.ignore().sum() > 0
+
+
 def test_overlap_slots_with_ignores():
     """Short reads get flagged as ignored by earlier rounds: concurrent slots must discard invalidated speculation."""
     orun, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
@@ -210,7 +241,7 @@ def test_round_parallel_protocol_matches_oracle(world, seed, G, N, L, variable):
     rs = O.ReadSet(bases, off, min_len=1000)
     orun = O.OverlapRun(rs, k=10)
     readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
-    pipes = [OverlapPipeline(readsets[r], k=10, rank=r, world=world, mode="round") for r in range(world)]
+    pipes = [OverlapPipeline(readsets[r], k=10, rank=r, world=world, mode="round-batch") for r in range(world)]
     supersteps = 0
     short_commits = 0
     while not pipes[0].finished():
