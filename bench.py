@@ -126,6 +126,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    stream_gbs = None
+    if rank == 0:
+        try:  # measured HBM stream rate of this device (device-to-device copy, read + write counted), SURVEY 8(d)
+            nb = 1 << 30
+            a_ = torch.empty(nb, dtype=torch.uint8, device="cuda")
+            b_ = torch.empty(nb, dtype=torch.uint8, device="cuda")
+            b_.copy_(a_)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                b_.copy_(a_)
+            e1.record()
+            torch.cuda.synchronize()
+            stream_gbs = 2.0 * nb * 10 / (e0.elapsed_time(e1) / 1e3) / 1e9
+            del a_, b_
+        except Exception:
+            stream_gbs = None
     if rank == 0:
         n = max(1, samples)
         count_ms = acc.get("k_count_ms", 0.0) / n
@@ -151,7 +169,9 @@ def main():
                                        "scan sharded by read over %d GPUs, survivors all-gathered (RCCL)" % world)},
             "roofline": {"bound": "hbm", "kernel": "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": count_bytes, "launch_ms": count_ms},
+                         "traffic": traffic, "algorithmic_bytes_per_launch": count_bytes, "launch_ms": count_ms,
+                         "measured_stream_GBs": stream_gbs,
+                         "frac_of_measured_stream": (achieved / stream_gbs) if stream_gbs else None},
             # the other kernels of a round, same convention (algorithmic bytes / HIP-event time); chain_kernel is a
             # latency-bound per-query state machine, its byte rate is reported for completeness only
             "other_kernels": {
