@@ -190,6 +190,7 @@ def main():
                             "achieved_GBs": (acc.get("query_bytes", 0.0) / 1e9) / (acc.get("k_query_ms", 1e-9) / 1e3) if acc.get("k_query_ms", 0) > 0 else 0.0},
             "setup_s": {"generate": t_gen, "upload_pack_histogram_values": t_setup},
             # host side of the timed region: CPU seconds used by this container and time it spent throttled by its CPU quota
+            "host": host_info(),
             "host_cpu": {"cpu_s": (cs1.get("usage_usec", 0) - cs0.get("usage_usec", 0)) / 1e6,
                          "throttled_s": (cs1.get("throttled_usec", 0) - cs0.get("throttled_usec", 0)) / 1e6,
                          "wall_s": elapsed},
@@ -204,6 +205,18 @@ def main():
     pipe.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def host_info():
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "cpu_quota_cores": cpu_budget()}
 
 
 def cpu_budget():
