@@ -21,6 +21,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
+def count_bytes_scan_mode(acc, samples):
+    return acc.get("count_bytes", 0.0) / max(1, samples)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,6 +38,9 @@ def main():
     ap.add_argument("--seed-batch-size", type=int, default=10000)
     ap.add_argument("--cpu-rounds", type=int, default=2, help="oracle rounds timed for cpu_baseline (0 = skip)")
     ap.add_argument("--slots", type=int, default=5, help="rounds executed concurrently per GPU (executor slots)")
+    ap.add_argument("--index-steps", type=int, default=100,
+                    help="N=1: after the timed region, time this many further rounds with the resident k-mer position index "
+                         "instead of the scan (reported as index_mode; 0 = skip)")
     ap.add_argument("--mode", default="round", choices=["round", "round-batch", "scan-shard"], help="multi-GPU decomposition (N > 1)")
     args = ap.parse_args()
 
@@ -126,6 +133,50 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Same job continued with the scan replaced by the resident k-mer position index (dp_kindex.hip; the default from
+    # 3 Gbase up).  Reported next to the headline number, never instead of it.
+    index_mode = None
+    if world == 1 and args.index_steps > 0 and "DP_SCAN_INDEX" not in os.environ and not acc.get("idx_rounds"):
+        pipe.drain()
+        os.environ["DP_SCAN_INDEX"] = "1"
+        tb0 = time.perf_counter()
+        got = pipe.step()  # builds the index (one-off) and runs a round
+        tb1 = time.perf_counter()
+        w2 = got
+        while got and w2 < args.warmup:
+            got = pipe.step()
+            w2 += got
+        pipe.drain()
+        sync()
+        iacc, ilines, isteps, isamples = {}, 0, 0, 0
+        ti0 = time.perf_counter()
+        while got and isteps < args.index_steps:
+            got = pipe.step()
+            if got == 0:
+                break
+            for key, v in pipe.stats().items():
+                iacc[key] = iacc.get(key, 0.0) + v
+            isamples += 1
+            ilines += pipe.step_lines()
+            isteps += got
+        sync()
+        iel = time.perf_counter() - ti0
+        del os.environ["DP_SCAN_INDEX"]
+        pipe.drain()
+        if isteps:
+            m = max(1, isamples)
+            index_mode = {"value": ilines / iel, "unit": "overlaps/s", "steps": isteps, "ms_per_step": 1e3 * iel / isteps,
+                          "first_round_incl_index_build_s": tb1 - tb0,
+                          "rounds_served_by_index": iacc.get("idx_rounds", 0.0),
+                          "seed_occurrences_per_step": iacc.get("idx_hits", 0.0) / m,
+                          "resident_bytes": 8 * int(reads.total_bases()) + 8 * (4 ** args.k + 1),
+                          "kernel_ms_per_step": {kk: iacc.get(kk, 0.0) / m for kk in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms")},
+                          "count_step_algorithmic_bytes": iacc.get("count_bytes", 0.0) / m,
+                          "scan_equivalent_GBs": (count_bytes_scan_mode(acc, samples) / 1e9) / (iacc.get("k_count_ms", 0.0) / m / 1e3)
+                          if iacc.get("k_count_ms", 0) > 0 else None,
+                          "note": "no kernel of this mode streams the reads; scan_equivalent_GBs = bytes the scan would have "
+                                  "read / time of the index counting step, an effective rate and not a roofline figure"}
+
     stream_gbs = None
     if rank == 0:
         try:  # measured HBM stream rate of this device (device-to-device copy, read + write counted), SURVEY 8(d)
@@ -151,7 +202,7 @@ def main():
         achieved = (count_bytes / 1e9) / (count_ms / 1e3) if count_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not acc.get("idx_rounds"):  # the PMC figure is the scan kernel's
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             except Exception:
@@ -167,7 +218,10 @@ def main():
                                        "round-parallel over %d GPUs: rank r's executor pipeline runs the rounds r, r+N, ...; one round "
                                        "per rank all-gathered (RCCL) per superstep and committed in order" % world if args.mode.startswith("round") else
                                        "scan sharded by read over %d GPUs, survivors all-gathered (RCCL)" % world)},
-            "roofline": {"bound": "hbm", "kernel": "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)",
+            "roofline": {"bound": "hbm", "kernel": ("index counting step (seed lookups, occurrence sort, per-item cuts; dp_kindex.hip) "
+                                                    "- the run used the resident k-mer position index, no kernel streams the reads"
+                                                    if acc.get("idx_rounds") else
+                                                    "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": count_bytes, "launch_ms": count_ms,
                          "measured_stream_GBs": stream_gbs,
@@ -182,6 +236,7 @@ def main():
                 "chain_kernel": {"ms": acc.get("k_chain_ms", 0.0) / n, "bound": "latency (sequential ratchet per query)",
                                  "matches_per_step": acc.get("n_matches", 0.0) / n},
             },
+            "index_mode": index_mode,
             "paf_lines": lines, "rounds_per_s": steps_done / elapsed if elapsed > 0 else 0.0,
             "reads_scanned_per_s": (acc.get("scan_items", 0.0) / n) * steps_done / elapsed if elapsed > 0 else 0.0,
             "phase_ms_per_step": {kk: 1e3 * acc.get(kk, 0.0) / n for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},

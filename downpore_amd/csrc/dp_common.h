@@ -20,8 +20,14 @@ struct PinBuf {
     size_t cap = 0;
 };
 
+struct dp_kindex;
+
 struct dp_ctx {
     int device = 0;
+    dp_ctx* owner = nullptr;     // context whose reads (and k-mer position index) this one borrows
+    dp_kindex* kidx = nullptr;   // resident k-mer position index (dp_kindex.hip), owned by the reads' owner
+    DevBuf d_kx_sz, d_kx_lo, d_kx_tmp, d_kx_keys, d_kx_vals;  // per-round scratch of the index path
+    uint32_t kx_hits = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_sync = nullptr;  // blocking-sync event: waiting host threads sleep instead of polling
@@ -86,6 +92,13 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
         hipError_t _e = (call);                                               \
         if (_e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, #call, _e);     \
     } while (0)
+
+// resident k-mer position index (dp_kindex.hip)
+int dp_kindex_ensure(dp_ctx* ctx, int k);
+void dp_kindex_free(dp_ctx* ctx);
+int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t n_items, uint32_t* d_counts, float* ms);
+int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, const uint32_t* d_sel, uint32_t n_sel, const uint32_t* d_counts,
+                    const uint64_t* d_segoff, int32_t* d_segs);
 
 // kernels implemented in other translation units
 int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs);

@@ -60,7 +60,6 @@ __global__ __launch_bounds__(64 * CA_WAVES) void consensus_align_kernel(const in
         const int p2s = pos + 1;
         const bool okS = sl > 0 && p2s < sl / 2;
         const int od = okS ? S[b + p2s * 2] - offs : 0;
-        const int sd = okS ? S[b + p2s * 2 + 1] : -1;
         supported = 0;
         const bool fin = !mine || sl == 0 || pos >= (sl - 1) / 2 - 1;
         int fCount = __popcll(__ballot(fin && mine));

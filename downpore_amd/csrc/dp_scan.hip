@@ -112,6 +112,7 @@ extern "C" int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out) {
     if (rc != 0) return rc;
     dp_ctx* c = *out;
     c->borrowed_reads = true;
+    c->owner = src->owner ? src->owner : src;
     c->n_reads = src->n_reads;
     c->total_bases = src->total_bases;
     c->packed_bytes = src->packed_bytes;
@@ -130,10 +131,12 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     hipSetDevice(ctx->device);
     dp_stream_sync(ctx);
     if (ctx->borrowed_reads) ctx->d_packed.p = ctx->d_boff.p = ctx->d_len.p = ctx->d_values.p = nullptr;
+    dp_kindex_free(ctx);
     DevBuf* dbs[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len, &ctx->d_bits, &ctx->d_kmap, &ctx->d_seeds, &ctx->d_items,
                      &ctx->d_counts, &ctx->d_segoff, &ctx->d_segs, &ctx->d_total, &ctx->d_seqrefs, &ctx->d_posting,
                      &ctx->d_seedsets, &ctx->d_pmeta, &ctx->d_qsegs, &ctx->d_qoff, &ctx->d_qsets, &ctx->d_qmeta,
-                     &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched, &ctx->d_ignore, &ctx->d_surv, &ctx->d_values, &ctx->d_selwin, &ctx->d_seltop, &ctx->d_cin, &ctx->d_cout};
+                     &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched, &ctx->d_ignore, &ctx->d_surv, &ctx->d_values, &ctx->d_selwin, &ctx->d_seltop, &ctx->d_cin, &ctx->d_cout,
+                     &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals};
     for (auto* b : dbs)
         if (b->p) hipFree(b->p);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
@@ -200,6 +203,7 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
     if (ctx->borrowed_reads) return dp_fail(ctx, DP_ERR_STATE, "dp_reads_upload on a context that borrows its reads");
     if (first_paired > n_host) first_paired = n_host;
     hipSetDevice(ctx->device);
+    dp_kindex_free(ctx);  // a position index of the previous read set is void
     const uint64_t nd64 = (uint64_t)first_paired + 2ull * (n_host - first_paired);
     if (nd64 > 0x7fffffffull) return dp_fail(ctx, DP_ERR_ARG, "too many reads");
     const uint32_t n_reads = (uint32_t)nd64;
@@ -956,6 +960,8 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     out->bases_scanned = bases;
     out->reads_scanned = ctx->cached_reads;
     out->n_extra = n_extra;
+    out->index_mode = 0;
+    out->index_hits = 0;
     ctx->scan_items = n_items;
     if (pin_reserve(ctx, ctx->h_total, 32)) return DP_ERR_HIP;
     if (n_items == 0) {
@@ -984,14 +990,34 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     uint32_t* s_item = (uint32_t*)ctx->d_surv.p;
     uint32_t* s_count = s_item + n_items;
     uint64_t* s_off = (uint64_t*)(s_count + n_items + (n_items & 1));
-    std::unique_lock<std::mutex> scan_lock(g_scan_mu);
-    DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL((v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
-                       (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)d_items, n_items, k,
-                       (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
-                       (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr, 0u, (const uint32_t*)nullptr, 0u);
-    DP_HIP(hipGetLastError());
-    DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    // Resident k-mer position index instead of scanning (dp_kindex.hip): DP_SCAN_INDEX=1 forces it, =0 forbids it; by
+    // default it is used from 3 Gbase up, where the scan is what bounds a round (its one-off build costs about as much as
+    // all the scans of a config-2 sized job together).
+    bool use_index = ctx->total_bases >= 3000000000ull || (ctx->owner && ctx->owner->total_bases >= 3000000000ull);
+    if (const char* e = getenv("DP_SCAN_INDEX")) use_index = e[0] == '1';
+    std::unique_lock<std::mutex> scan_lock(g_scan_mu, std::defer_lock);
+    if (use_index) {
+        int rc = dp_kindex_ensure(ctx, k);
+        if (rc < 0) return rc;
+        if (rc > 0) use_index = false;  // k > 14 or not enough free HBM for 8 B per base: scan
+    }
+    out->index_mode = use_index ? 1u : 0u;
+    out->index_hits = 0;
+    if (use_index) {
+        int rc = dp_kindex_count(ctx, k, d_items, n_items, (uint32_t*)ctx->d_counts.p, nullptr);
+        if (rc != 0) return rc;
+        out->index_hits = ctx->kx_hits;
+    } else {
+        scan_lock.lock();
+        DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+        hipLaunchKernelGGL((v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
+                           (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)d_items, n_items, k,
+                           (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
+                           (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr, 0u,
+                           (const uint32_t*)nullptr, 0u);
+        DP_HIP(hipGetLastError());
+        DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    }
     hipLaunchKernelGGL(offsets_tile_sums, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
                        (const uint32_t*)ctx->d_counts.p, n_items, tilesA);
     hipLaunchKernelGGL(offsets_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tilesA, n_tiles, totals, (uint64_t*)ctx->d_segoff.p, n_items);
@@ -1025,19 +1051,25 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     }
     if (n_segs) {
         DP_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-        // one wave per SURVIVOR (the compacted list), not a strided walk over every item
-        const uint32_t wgrid = (uint32_t)std::min<uint64_t>(grid, (n_surv_all + 15) / 16);
-        hipLaunchKernelGGL((v2 ? scan_kernel<1, 2> : scan_kernel<1, 1>), dim3(std::max(1u, wgrid)), dim3(SCAN_THREADS), 0, ctx->stream,
-                           (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)d_items, n_items, k,
-                           (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
-                           (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
-                           (int32_t*)ctx->d_segs.p, 0u, (const uint32_t*)s_item, (uint32_t)n_surv_all);
+        if (use_index) {
+            int rc = dp_kindex_write(ctx, k, (const dp_scan_item*)d_items, (const uint32_t*)s_item, (uint32_t)n_surv_all,
+                                     (const uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p, (int32_t*)ctx->d_segs.p);
+            if (rc != 0) return rc;
+        } else {
+            // one wave per SURVIVOR (the compacted list), not a strided walk over every item
+            const uint32_t wgrid = (uint32_t)std::min<uint64_t>(grid, (n_surv_all + 15) / 16);
+            hipLaunchKernelGGL((v2 ? scan_kernel<1, 2> : scan_kernel<1, 1>), dim3(std::max(1u, wgrid)), dim3(SCAN_THREADS), 0, ctx->stream,
+                               (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)d_items, n_items, k,
+                               (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
+                               (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
+                               (int32_t*)ctx->d_segs.p, 0u, (const uint32_t*)s_item, (uint32_t)n_surv_all);
+        }
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
         if (n_segs * 4 > ((uint64_t)8 << 20)) {
             // dense-seed regime: tens of MB go back to the host; let the next slot's scan start while they travel
             DP_HIP(hipEventSynchronize(ctx->ev[3]));
-            scan_lock.unlock();
+            if (scan_lock.owns_lock()) scan_lock.unlock();
         }
         DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));
     }

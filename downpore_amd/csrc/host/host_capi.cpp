@@ -153,7 +153,7 @@ const char* dph_overlap_errtext(void* hh, int64_t* n) {
 }
 // out[0..] t_prepare,t_scan,t_index,t_query,t_consensus,k_scan_ms,k_query_ms,k_chain_ms,scan_bases,scan_items,
 // scan_bytes,query_bytes,n_queries,n_indexed,n_hits,n_matches,n_paf,n_seeds,round,badBack,emptyMatch,k_count_ms,
-// k_write_ms,count_bytes
+// k_write_ms,count_bytes,k_cons_ms,idx_rounds,idx_hits
 void dph_overlap_stats(void* hh, double* out) {
     OverlapH* h = (OverlapH*)hh;
     const RoundStats& s = h->run.last;
@@ -161,7 +161,7 @@ void dph_overlap_stats(void* hh, double* out) {
                   (double)s.scan_bases, (double)s.scan_items, (double)s.scan_bytes, (double)s.query_bytes, (double)s.n_queries,
                   (double)s.n_indexed, (double)s.n_hits, (double)s.n_matches, (double)s.n_paf, (double)s.n_seeds,
                   (double)h->run.round, (double)h->run.badBack, (double)h->run.emptyMatch, s.k_count_ms, s.k_write_ms,
-                  (double)s.count_bytes, s.k_cons_ms};
+                  (double)s.count_bytes, s.k_cons_ms, (double)s.idx_rounds, (double)s.idx_hits};
     memcpy(out, v, sizeof v);
 }
 void* dph_overlap_ctx(void* hh) { return ((OverlapH*)hh)->ctx; }

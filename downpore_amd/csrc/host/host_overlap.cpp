@@ -196,6 +196,8 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
     st.k_write_ms += b.write_kernel_ms;
     st.scan_bases += b.bases_scanned;
     st.scan_items += b.reads_scanned + items.size();
+    st.idx_rounds += b.index_mode;
+    st.idx_hits += b.index_hits;
     // survivors of the local shard (ascending read id); their segments are the leading part of the scan output
     local.read.assign(b.read, b.read + b.n_survivors);
     local.n_seeds.assign(b.n_seeds, b.n_seeds + b.n_survivors);

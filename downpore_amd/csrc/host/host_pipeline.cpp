@@ -397,6 +397,12 @@ int OverlapRun::finishRound(ExecSlot& sl, const Survivors& all, RoundResult& out
     // algorithmic bytes of the scan: packed bytes of the scanned items + bit table + 8 B per hit
     st.scan_bytes = st.scan_bases / 4 + (((uint64_t)1 << (2 * k)) / 8) + 8 * st.n_hits;
     st.count_bytes = st.scan_bases / 4 + (((uint64_t)1 << (2 * k)) / 8);
+    if (st.idx_rounds) {
+        // served by the resident k-mer position index: no read is streamed.  Minimum traffic = two table entries per seed
+        // k-mer + each occurrence once (8 B) + one count per item
+        st.count_bytes = 16 * st.n_seeds + 8 * st.idx_hits + 4 * st.scan_items;
+        st.scan_bytes = st.count_bytes + 8 * st.n_hits;
+    }
     return 0;
 }
 

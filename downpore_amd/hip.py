@@ -26,7 +26,8 @@ class SurvivorBatch(C.Structure):
                 ("seg_off", C.POINTER(C.c_uint64)), ("n_extra", C.c_uint32), ("extra_n_seeds", C.POINTER(C.c_uint32)),
                 ("extra_seg_off", C.POINTER(C.c_uint64)), ("segs", C.POINTER(C.c_int32)), ("n_segs", C.c_uint64),
                 ("kernel_ms", C.c_double), ("count_kernel_ms", C.c_double), ("write_kernel_ms", C.c_double),
-                ("bases_scanned", C.c_uint64), ("reads_scanned", C.c_uint32)]
+                ("bases_scanned", C.c_uint64), ("reads_scanned", C.c_uint32), ("index_mode", C.c_uint32),
+                ("index_hits", C.c_uint64)]
 
 
 class MatchBatch(C.Structure):

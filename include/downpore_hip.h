@@ -126,6 +126,8 @@ typedef struct {
     double kernel_ms, count_kernel_ms, write_kernel_ms;
     uint64_t bases_scanned;
     uint32_t reads_scanned;
+    uint32_t index_mode;           /* 1: counts and segments came from the resident k-mer position index, not a scan */
+    uint64_t index_hits;           /* index mode: occurrences of this round's seed k-mers in the whole read set */
 } dp_survivor_batch;
 
 int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,

@@ -201,6 +201,37 @@ def test_round_pipelined_ranks_match_oracle(world, slots, seed, G, N, L, variabl
         assert rs.ignore().sum() > 0
 
 
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_overlap_kmer_index_mode(mode):
+    """DP_SCAN_INDEX=1: counts and segments come from the resident k-mer position index (dp_kindex.hip) instead of the
+    scan kernels; =0 forbids it.  Same PAF, same ignore flags either way - whole runs, concurrent slots, the len%4==0
+    top-level quirk (himem=false), the noisy k=13 regime and a non-default query type."""
+    os.environ["DP_SCAN_INDEX"] = mode
+    try:
+        _, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
+        assert (st["idx_rounds"] > 0) == (mode == "1")
+        _run_both(7, 100000, 300, 4000, 10, himem=False, max_rounds=3)
+        _, st = _run_both(114, 1200000, 2000, 12000, 13, 0.002, True, max_rounds=4, slots=2)
+        assert (st["idx_rounds"] > 0) == (mode == "1")
+        assert (st["idx_hits"] > 0) == (mode == "1")
+        _run_both(41, 100000, 400, 5000, 10, max_rounds=3, slots=2, query_type=4)
+    finally:
+        del os.environ["DP_SCAN_INDEX"]
+
+
+def test_overlap_kmer_index_unavailable_falls_back_to_scan():
+    """k above the direct-addressed table's limit (14; lowered here through DP_KINDEX_MAX_K) or too little free HBM: the
+    index reports itself unavailable and the rounds scan."""
+    os.environ["DP_SCAN_INDEX"] = "1"
+    os.environ["DP_KINDEX_MAX_K"] = "9"
+    try:
+        _, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=2)
+        assert st["idx_rounds"] == 0
+    finally:
+        del os.environ["DP_SCAN_INDEX"]
+        del os.environ["DP_KINDEX_MAX_K"]
+
+
 def test_overlap_slots_with_ignores():
     """Short reads get flagged as ignored by earlier rounds: concurrent slots must discard invalidated speculation."""
     orun, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
