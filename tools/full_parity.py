@@ -43,6 +43,7 @@ def main():
     gpu_paf = pipe.all_paf()
     values = pipe.values().copy()
     gpu_ignore = reads.ignore().copy()
+    last = pipe.stats()
     pipe.close()
     O.build_oracle()
     os.environ["DPO_SCAN_THREADS"] = str(a.threads or cpu_budget())
@@ -55,7 +56,8 @@ def main():
            "paf_lines": gpu_paf.count("\n"), "paf_sha256_gpu": hashlib.sha256(gpu_paf.encode()).hexdigest(),
            "paf_sha256_oracle": hashlib.sha256(run.paf.encode()).hexdigest(), "paf_identical": bool(same),
            "ignore_flags_identical": bool(np.array_equal(gpu_ignore, rs.ignore())),
-           "gpu_pipeline_s": t_gpu, "oracle_s": t_cpu, "oracle_scan_threads": int(os.environ["DPO_SCAN_THREADS"])}
+           "last_round_served_by_kmer_index": bool(last.get("idx_rounds", 0)),
+           "total_bases": int(off[-1]), "gpu_pipeline_s": t_gpu, "oracle_s": t_cpu, "oracle_scan_threads": int(os.environ["DPO_SCAN_THREADS"])}
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
     print(json.dumps(out))
