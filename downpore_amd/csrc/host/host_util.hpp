@@ -28,13 +28,23 @@ struct PipeProfile {
         planDiscarded{0};
     std::atomic<long long> planUs{0}, getWaitUs{0}, execUs{0}, commitUs{0}, consensusCpuUs{0}, selectCpuUs{0}, slotCpuUs{0}, plannerCpuUs{0};
     std::atomic<long long> sub[18];
+    std::atomic<long long> subCpu[18];  // CPU time of the calling thread since its previous add(): the sections are consecutive
     const char* subName[18] = {"prep.indexReset", "prep.newOverlapper", "prep.roundBegin", "scan.call", "scan.copy", "idx.copy",
                                "idx.chunk", "idx.build", "idx.queries", "qry.call", "qry.matches", "fc.collate", "fc.parallel",
                                "fc.merge", "round.total", "round.tail", "plan.speculate", "plan.commitLoop"};
     PipeProfile() {
         for (auto& x : sub) x = 0;
+        for (auto& x : subCpu) x = 0;
     }
-    void add(int i, double sec) { sub[i] += (long long)(sec * 1e6); }
+    void add(int i, double sec) {
+        sub[i] += (long long)(sec * 1e6);
+        if (on) {
+            static thread_local double last = 0;
+            const double c = threadCpuNow();
+            if (last > 0) subCpu[i] += (long long)((c - last) * 1e6);
+            last = c;
+        }
+    }
     bool on = getenv("DPH_PROFILE") != nullptr;
     void print() {
         if (!on) return;
@@ -57,6 +67,8 @@ struct PipeProfile {
         }
         fprintf(stderr, "[pipe] per executed round (ms):");
         for (int i = 0; i < 18; i++) fprintf(stderr, " %s %.3f", subName[i], sub[i].load() / 1e3 / n);
+        fprintf(stderr, "\n[pipe] thread CPU up to the end of each section (ms):");
+        for (int i = 0; i < 18; i++) fprintf(stderr, " %s %.3f", subName[i], subCpu[i].load() / 1e3 / n);
         fprintf(stderr, "\n");
     }
 };
