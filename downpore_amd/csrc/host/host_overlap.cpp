@@ -436,6 +436,7 @@ static void finalCheckEmit(SeedContig* contig, const SeedIndex& index, const Rea
                            std::vector<int>& ignoreIds, FinalCheckStats& fs) {
     const int k = index.k;
     if (!contig || contig->Parts.size() <= 1) return;
+    FINE(7);
     if (contig->SeqLengths[0] <= overlapSize * 2) ignoreIds.push_back(contig->Parts[0]);
     const i64 queryStart = contig->Offsets[0], queryEnd = queryStart + contig->Lengths[0];
     char num[24];

@@ -13,6 +13,9 @@
 namespace dph {
 
 PipeProfile g_prof;
+#ifdef DPH_FINE
+FineProfile g_fine;
+#endif
 
 void profilePrint() { g_prof.print(); }
 void setHostThreadShare(unsigned) {}  // kept for callers; the shared pool needs no per-slot split

@@ -6,7 +6,7 @@
 #include <fstream>
 #include <sstream>
 
-#include "dph.hpp"
+#include "host_util.hpp"
 
 namespace dph {
 
@@ -651,7 +651,13 @@ static void pairScanInStep(int ns, const int32_t* __restrict__ ok, const int32_t
 static void reduceForConsensus(Arena& arena, std::vector<SeedSeq*>& seqs, int k, std::vector<SeedSeq*>& red,
                                std::vector<std::vector<int>>& seedMap) {
     const size_t ns = seqs.size();
-    const std::vector<uint64_t>& useSeeds = seedsSharedByTwo(seqs);
+    const std::vector<uint64_t>* shared;
+    {
+        FINE(2);
+        shared = &seedsSharedByTwo(seqs);
+    }
+    const std::vector<uint64_t>& useSeeds = *shared;
+    FINE(3);
     if (seedMap.size() < ns) seedMap.resize(ns);
     red.assign(ns, nullptr);
     for (size_t i = 0; i < ns; i++) red[i] = seqReduced(arena, seqs[i], useSeeds, k, 1, &seedMap[i]);
@@ -677,6 +683,7 @@ static std::vector<SeedMatch>& consensusMatchPool(size_t ns) {
 
 static SeedSeq* multiAlignerCore(Arena& arena, std::vector<SeedSeq*>& seqs, std::vector<SeedSeq*>& red,
                                  std::vector<std::vector<int>>& seedMap, int k, std::vector<SeedMatch*>& matchesOut) {
+    FINE(4);
     const size_t ns = seqs.size();
     static thread_local std::vector<i64> pos, offs, gaps, supported, dist;
     static thread_local std::vector<int32_t> consensus, okv, odv, sdv, gpv;
@@ -1006,7 +1013,11 @@ static SeedContig* newSeedContig(Arena& ar, std::vector<SeedMatch*>& ms, int k, 
     static thread_local std::vector<SeedSeq*> parts;
     static thread_local std::vector<uint8_t> trimFailed;
     static thread_local SeedContig contig;  // one contig per worker thread at a time
-    trimToBestSeed(ar, ms[0]->SeqA->numSeeds() / 4, ms, minMatch, k, parts, trimFailed, badBack);
+    {
+        FINE(5);
+        trimToBestSeed(ar, ms[0]->SeqA->numSeeds() / 4, ms, minMatch, k, parts, trimFailed, badBack);
+    }
+    FINE(6);
     SeedContig* c = &contig;
     const size_t n = ms.size();
     c->Parts.assign(n, 0);
@@ -1034,8 +1045,12 @@ static SeedContig* newSeedContig(Arena& ar, std::vector<SeedMatch*>& ms, int k, 
 static void consensusTrimTargets(Arena& ar, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, std::vector<SeedSeq*>& seqs) {
     const int k = sg.k;
     seqs.clear();
-    for (SeedMatch* lap : overlaps)
-        if (lap->ReverseComplementQuery) matchReverseComplement(ar, *lap, sg);
+    {
+        FINE(0);
+        for (SeedMatch* lap : overlaps)
+            if (lap->ReverseComplementQuery) matchReverseComplement(ar, *lap, sg);
+    }
+    FINE(1);
     for (SeedMatch* lap : overlaps) {
         i64 ca, cb;
         matchBasesCovered(*lap, k, &ca, &cb, nullptr);

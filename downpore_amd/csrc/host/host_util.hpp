@@ -1,6 +1,9 @@
 // Internal helpers shared by the host translation units (not part of the mirrored reference interface).
 #pragma once
 #include <sys/resource.h>
+#ifdef DPH_FINE
+#include <x86intrin.h>
+#endif
 #include <time.h>
 
 #include <algorithm>
@@ -21,6 +24,36 @@ static inline double threadCpuNow() {  // CPU time consumed by the calling threa
     clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
+
+// -DDPH_FINE: cycle counters around the phases of the consensus stage (tools/host_consensus_profile.py); compiled out otherwise
+#ifdef DPH_FINE
+struct FineProfile {
+    std::atomic<long long> cyc[16];
+    const char* name[16] = {"unRC", "basesCovered+trim", "sharedByTwo", "reduced", "alignCore", "trimToBestSeed", "contig",
+                            "pafEmit", "", "", "", "", "", "", "", ""};
+    FineProfile() {
+        for (auto& c : cyc) c = 0;
+    }
+    ~FineProfile() {
+        long long tot = 0;
+        for (auto& c : cyc) tot += c.load();
+        if (!tot) return;
+        fprintf(stderr, "[fine]");
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", name[i], 100.0 * cyc[i].load() / tot);
+        fprintf(stderr, " | total %.3f Gcycles\n", tot / 1e9);
+    }
+};
+extern FineProfile g_fine;
+struct FineScope {
+    int i;
+    unsigned long long t0;
+    explicit FineScope(int i_) : i(i_), t0(__rdtsc()) {}
+    ~FineScope() { g_fine.cyc[i] += (long long)(__rdtsc() - t0); }
+};
+#define FINE(i) FineScope fineScope##i(i)
+#else
+#define FINE(i)
+#endif
 
 // DPH_PROFILE=1: pipeline counters printed to stderr when a run shuts down
 struct PipeProfile {
