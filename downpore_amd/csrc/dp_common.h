@@ -94,6 +94,7 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
     } while (0)
 
 // resident k-mer position index (dp_kindex.hip)
+int dp_histogram_device(dp_ctx* ctx, int k, uint32_t* d_counts);  // dp_scan.hip
 int dp_kindex_ensure(dp_ctx* ctx, int k);
 void dp_kindex_free(dp_ctx* ctx);
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t n_items, uint32_t* d_counts, float* ms);

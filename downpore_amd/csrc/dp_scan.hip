@@ -475,6 +475,16 @@ __global__ void hist_kernel(const uint8_t* __restrict__ packed, const uint64_t* 
     }
 }
 
+// adds the k-mer counts of the resident reads to d_counts (4^k zero-initialised uint32 on the device), on the context's stream
+int dp_histogram_device(dp_ctx* ctx, int k, uint32_t* d_counts) {
+    if (ctx->n_reads) {
+        hipLaunchKernelGGL(hist_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
+                           (const uint64_t*)ctx->d_boff.p, (const uint32_t*)ctx->d_len.p, ctx->n_reads, k, d_counts);
+        DP_HIP(hipGetLastError());
+    }
+    return DP_OK;
+}
+
 extern "C" int dp_kmer_histogram(dp_ctx* ctx, int k, uint64_t* counts_out) {
     if (!ctx || !counts_out || k < 1 || k > 15) return DP_ERR_ARG;
     hipSetDevice(ctx->device);
@@ -482,10 +492,9 @@ extern "C" int dp_kmer_histogram(dp_ctx* ctx, int k, uint64_t* counts_out) {
     void* d = nullptr;
     DP_HIP(hipMalloc(&d, n * 4));
     DP_HIP(hipMemsetAsync(d, 0, n * 4, ctx->stream));
-    if (ctx->n_reads) {
-        hipLaunchKernelGGL(hist_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
-                           (const uint64_t*)ctx->d_boff.p, (const uint32_t*)ctx->d_len.p, ctx->n_reads, k, (uint32_t*)d);
-        DP_HIP(hipGetLastError());
+    if (dp_histogram_device(ctx, k, (uint32_t*)d) != 0) {
+        hipFree(d);
+        return DP_ERR_HIP;
     }
     std::vector<uint32_t> tmp(n);
     DP_HIP(hipMemcpyAsync(tmp.data(), d, n * 4, hipMemcpyDeviceToHost, ctx->stream));

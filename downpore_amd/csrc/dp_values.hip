@@ -1,0 +1,169 @@
+// libdownpore_hip.so — the k-mer value table of `downpore overlap` / `downpore map` on the device.
+// commands/overlap.go:55-93 (value per k-mer from its frequency) + util/sequtil/kmers.go:87-112 (fwd+rc merge, the 1 %
+// most frequent k-mers get value 0).  On the host this is ~8 passes over 4^k-entry arrays with a random-access merge
+// (1.8 s at k=13); here it is a histogram, one radix sort and two streaming kernels, and the table stays resident for
+// dp_select_seeds.  Bit-identical to the host function (float64, no contraction).
+#include <cstdlib>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include "dp_common.h"
+
+__device__ __forceinline__ uint32_t values_rc_kmer(uint32_t seed, int k) {
+    uint32_t x = ~seed;
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = __builtin_bswap32(x);
+    return k >= 16 ? x : (x >> (32 - 2 * k));
+}
+
+struct ValuesToU64 {
+    __host__ __device__ uint64_t operator()(uint32_t c) const { return (uint64_t)c; }
+};
+struct ValuesIsTie {
+    uint64_t T;
+    __host__ __device__ uint32_t operator()(uint64_t m) const { return m == T ? 1u : 0u; }
+};
+
+// value of every k-mer from its own count (overlap.go:73-88) and the merged fwd+rc count the 1 % cut looks at.
+// kmers.go:90-96 merges in place while it walks the table: a pair (i, rc) is visited twice, so both entries end at
+// 2*(count[i] + count[rc]); a palindrome is visited once and ends at 2*count[i].
+__global__ void values_kernel(const uint32_t* __restrict__ counts, uint64_t n, int k, double tf, double* __restrict__ values,
+                              uint64_t* __restrict__ merged) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = counts[i];
+    const uint32_t rc = values_rc_kmer((uint32_t)i, k);
+    merged[i] = rc == (uint32_t)i ? 2ull * a : 2ull * ((uint64_t)a + counts[rc]);
+    const double targetFreq = 0.000005;
+    const double freq = (double)a / tf;
+    double v;
+    if (a < 3) v = 0.0;
+    else if (freq <= targetFreq) v = 1.0 - (targetFreq - freq);
+    else v = 1.0 - (freq - targetFreq);
+    values[i] = v;
+}
+
+// [0] = first index with sorted[i] >= T, [1] = first index with sorted[i] > T
+__global__ void values_bounds_kernel(const uint64_t* __restrict__ sorted, uint64_t n, uint64_t T, uint64_t* __restrict__ out) {
+    if (threadIdx.x > 1 || blockIdx.x) return;
+    const bool upper = threadIdx.x == 1;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const uint64_t v = sorted[mid];
+        if (upper ? v <= T : v < T) lo = mid + 1;
+        else hi = mid;
+    }
+    out[threadIdx.x] = lo;
+}
+
+// the most frequent k-mers lose their value: every merged count above T, and of those equal to T the ones with the
+// highest k-mer ids (tie rank counted from the top; DESIGN.md 2, "tie rule")
+__global__ void values_cut_kernel(const uint64_t* __restrict__ merged, const uint32_t* __restrict__ tieRank, uint64_t n, uint64_t T,
+                                  uint32_t keepTies, double* __restrict__ values) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t m = merged[i];
+    if (m > T || (m == T && tieRank[i] >= keepTies) || i == 0) values[i] = 0.0;
+}
+
+__global__ void values_zero_first(double* __restrict__ values) { values[0] = 0.0; }
+
+extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
+    if (!ctx || k < 1 || k > 15) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_kmer_values: k in 1..15") : DP_ERR_ARG;
+    if (ctx->borrowed_reads) return dp_fail(ctx, DP_ERR_STATE, "dp_kmer_values on a borrowing context");
+    hipSetDevice(ctx->device);
+    const uint64_t n = (uint64_t)1 << (2 * k);
+    void *d_counts = nullptr, *d_merged = nullptr, *d_sorted = nullptr, *d_rank = nullptr, *d_tmp = nullptr, *d_small = nullptr;
+    auto cleanup = [&] {
+        for (void* p : {d_counts, d_merged, d_sorted, d_rank, d_tmp, d_small})
+            if (p) hipFree(p);
+    };
+#define DPV(x)                                                      \
+    do {                                                            \
+        hipError_t e_ = (x);                                        \
+        if (e_ != hipSuccess) {                                     \
+            cleanup();                                              \
+            return dp_fail(ctx, DP_ERR_HIP, "dp_kmer_values: " #x, e_); \
+        }                                                           \
+    } while (0)
+    if (dev_reserve(ctx, ctx->d_values, n * sizeof(double))) return DP_ERR_HIP;
+    ctx->n_values = 0;
+    double* values = (double*)ctx->d_values.p;
+    DPV(hipMalloc(&d_counts, n * 4));
+    DPV(hipMalloc(&d_merged, n * 8));
+    DPV(hipMalloc(&d_small, 64));
+    DPV(hipMemsetAsync(d_counts, 0, n * 4, ctx->stream));
+    int rc = dp_histogram_device(ctx, k, (uint32_t*)d_counts);
+    if (rc != 0) {
+        cleanup();
+        return rc;
+    }
+    // tot (overlap.go:60-63)
+    size_t tb = 0;
+    auto in64 = rocprim::make_transform_iterator((const uint32_t*)d_counts, ValuesToU64());
+    DPV(rocprim::reduce(nullptr, tb, in64, (uint64_t*)d_small, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), ctx->stream));
+    size_t tmpCap = tb + 64;
+    DPV(hipMalloc(&d_tmp, tmpCap));
+    DPV(rocprim::reduce(d_tmp, tb, in64, (uint64_t*)d_small, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), ctx->stream));
+    uint64_t tot = 0;
+    DPV(hipMemcpyAsync(&tot, d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DPV(dp_stream_sync(ctx));
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(values_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_counts, n, k, (double)tot, values,
+                       (uint64_t*)d_merged);
+    DPV(hipGetLastError());
+    const uint64_t topN = n / 100;
+    if (topN > 0) {
+        DPV(hipMalloc(&d_sorted, n * 8));
+        size_t sb = 0;
+        DPV(rocprim::radix_sort_keys(nullptr, sb, (const uint64_t*)d_merged, (uint64_t*)d_sorted, (size_t)n, 0u, 34u, ctx->stream));
+        if (sb + 64 > tmpCap) {
+            hipFree(d_tmp);
+            d_tmp = nullptr;
+            tmpCap = sb + 64;
+            DPV(hipMalloc(&d_tmp, tmpCap));
+        }
+        DPV(rocprim::radix_sort_keys(d_tmp, sb, (const uint64_t*)d_merged, (uint64_t*)d_sorted, (size_t)n, 0u, 34u, ctx->stream));
+        uint64_t T = 0;
+        DPV(hipMemcpyAsync(&T, (const uint64_t*)d_sorted + (n - topN), 8, hipMemcpyDeviceToHost, ctx->stream));
+        DPV(dp_stream_sync(ctx));
+        hipLaunchKernelGGL(values_bounds_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t*)d_sorted, n, T, (uint64_t*)d_small);
+        uint64_t bounds[2] = {0, 0};
+        DPV(hipMemcpyAsync(bounds, d_small, 16, hipMemcpyDeviceToHost, ctx->stream));
+        DPV(dp_stream_sync(ctx));
+        hipFree(d_sorted);
+        d_sorted = nullptr;
+        const uint64_t totalTies = bounds[1] - bounds[0], above = n - bounds[1];
+        const uint64_t zeroTies = topN - above;                       // >= 1: sorted[n - topN] == T
+        const uint32_t keepTies = (uint32_t)(totalTies - zeroTies);   // ties with a rank (from index 0) below this keep their value
+        DPV(hipMalloc(&d_rank, n * 4));
+        auto flags = rocprim::make_transform_iterator((const uint64_t*)d_merged, ValuesIsTie{T});
+        size_t xb = 0;
+        DPV(rocprim::exclusive_scan(nullptr, xb, flags, (uint32_t*)d_rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
+        if (xb + 64 > tmpCap) {
+            hipFree(d_tmp);
+            d_tmp = nullptr;
+            tmpCap = xb + 64;
+            DPV(hipMalloc(&d_tmp, tmpCap));
+        }
+        DPV(rocprim::exclusive_scan(d_tmp, xb, flags, (uint32_t*)d_rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
+        hipLaunchKernelGGL(values_cut_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint64_t*)d_merged,
+                           (const uint32_t*)d_rank, n, T, keepTies, values);
+        DPV(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(values_zero_first, dim3(1), dim3(1), 0, ctx->stream, values);
+    }
+    if (values_out) DPV(hipMemcpyAsync(values_out, values, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DPV(dp_stream_sync(ctx));
+    cleanup();
+    ctx->n_values = n;
+#undef DPV
+    return DP_OK;
+}

@@ -384,6 +384,7 @@ struct OverlapRun {
         size_t n = 0, bytes = 0, mapped_ = 0;
         void* base_ = nullptr;
         void assign(const double* src, size_t count);
+        double* reserve(size_t count);  // uninitialised table of `count` entries (filled by the caller)
         void clear();
         ~HugeTable() { clear(); }
         const double* data() const { return p; }

@@ -3,7 +3,7 @@
 #include <algorithm>
 #include <cstring>
 
-#include "dph.hpp"
+#include "host_util.hpp"
 
 using namespace dph;
 
@@ -52,6 +52,7 @@ void* dph_overlap_create(void* reads, int device, const int64_t* params, double 
     const int nSlots = (int)params[7];
     OverlapH* h = new OverlapH();
     ReadSet& rs = ((ReadsH*)reads)->set;
+    const double tc0 = now();
     int rc = dp_ctx_create(device, &h->ctx);
     if (rc != 0) {
         g_err = dp_last_error(nullptr);
@@ -68,7 +69,9 @@ void* dph_overlap_create(void* reads, int device, const int64_t* params, double 
     p.himem = (params[6] & 1) != 0;
     p.queryType = (int)(params[6] >> 8) ? (int)(params[6] >> 8) : 1;  // bits 8.. of the himem word: overlap.Query* flags
     p.minHits = minHits;
+    const double tc1 = now();
     rc = dp_reads_upload(h->ctx, (const uint8_t*)rs.bases.data(), rs.off.data(), (uint32_t)rs.size());
+    if (g_prof.on) fprintf(stderr, "[setup] context %.1f ms, upload + pack %.1f ms\n", 1e3 * (tc1 - tc0), 1e3 * (now() - tc1));
     if (rc == 0) rc = h->run.init(h->ctx, &rs, p, valuesOrNull, nSlots);
     if (rc != 0) {
         g_err = h->run.error.empty() ? dp_last_error(h->ctx) : h->run.error;

@@ -533,14 +533,10 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // ---- value table from every sequence of the reference file (map.go:45-71); KmerOccurrences on the GPU
     int rc = dp_reads_upload(ctx, (const uint8_t*)refSet.bases.data(), refSet.off.data(), (uint32_t)refSet.size());
     if (rc) return fail(rc);
-    std::vector<uint64_t> counts((size_t)1 << (2 * k));
-    rc = dp_kmer_histogram(ctx, k, counts.data());
+    std::vector<double> values((size_t)1 << (2 * k));
+    rc = dp_kmer_values(ctx, k, values.data());  // KmerOccurrences + value table + 1 % cut on the GPU
     if (rc) return fail(rc);
-    mark("reference upload + histogram");
-    std::vector<double> values = kmerValuesFromCounts(counts, k);
-    mark("value table");
-    counts.clear();
-    counts.shrink_to_fit();
+    mark("reference upload + value table");
     errText += "K-mer counting complete. Preparing to start indexing and querying...\n";
 
     // ---- AddSingleSeeds seeds/seeds.go:160-200 on the (top-level) reference, host, sequential

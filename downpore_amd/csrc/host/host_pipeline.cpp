@@ -230,6 +230,10 @@ void Planner::dropBefore(i64 round, i64 firstInOfRound) {
 OverlapRun::~OverlapRun() { shutdown(); }
 
 void OverlapRun::HugeTable::assign(const double* src, size_t count) {
+    memcpy(reserve(count), src, count * sizeof(double));
+}
+
+double* OverlapRun::HugeTable::reserve(size_t count) {
     clear();
     const size_t huge = (size_t)2 << 20;
     bytes = (count * sizeof(double) + huge - 1) / huge * huge;
@@ -239,8 +243,8 @@ void OverlapRun::HugeTable::assign(const double* src, size_t count) {
     mapped_ = bytes + huge;
     p = (double*)(((uintptr_t)m + huge - 1) / huge * huge);
     madvise(p, bytes, MADV_HUGEPAGE);  // advisory: falls back to small pages silently
-    memcpy(p, src, count * sizeof(double));
     n = count;
+    return p;
 }
 
 void OverlapRun::HugeTable::clear() {
@@ -282,22 +286,41 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     char line[160];
     snprintf(line, sizeof line, "Counting all %d-mers in the input...\n", p.k);
     errText += line;
+    bool valuesOnDevice = false;
+    double tm = now();
+    auto mark = [&](const char* what) {
+        if (!g_prof.on) return;
+        const double t = now();
+        fprintf(stderr, "[setup] %-28s %.1f ms\n", what, 1e3 * (t - tm));
+        tm = t;
+    };
     if (valuesOrNull) {
         values.assign(valuesOrNull, (size_t)1 << (2 * p.k));
-    } else {
+    } else if (const char* hv = getenv("DP_HOST_VALUES"); hv && hv[0] == '1') {  // histogram on the GPU, table on the host
         std::vector<uint64_t> counts((size_t)1 << (2 * p.k));
-        int rc = dp_kmer_histogram(ctx, p.k, counts.data());  // KmerOccurrences on the GPU
+        int rc = dp_kmer_histogram(ctx, p.k, counts.data());
         if (rc != 0) {
             error = dp_last_error(ctx);
             return rc;
         }
+        mark("k-mer histogram");
         std::vector<double> v = kmerValuesFromCounts(counts, p.k);
+        mark("value table (host)");
         values.assign(v.data(), v.size());
+    } else {  // KmerOccurrences + value table + 1 % cut on the GPU; the table stays resident for dp_select_seeds
+        int rc = dp_kmer_values(ctx, p.k, values.reserve((size_t)1 << (2 * p.k)));
+        if (rc != 0) {
+            error = dp_last_error(ctx);
+            return rc;
+        }
+        valuesOnDevice = true;
+        mark("value table (device) + copy");
     }
+    mark("values copy");
     errText += "Counting complete. Starting indexing and querying...";
     {
         const char* hostsel = getenv("DP_HOST_SELECT");
-        if (!(hostsel && hostsel[0] == '1') && p.numSeeds <= 64) {  // value table resident for dp_select_seeds
+        if (!(hostsel && hostsel[0] == '1') && p.numSeeds <= 64 && !valuesOnDevice) {  // value table resident for dp_select_seeds
             int rc = dp_values_upload(ctx, values.data(), values.size());
             if (rc != 0) {
                 error = dp_last_error(ctx);
@@ -305,6 +328,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
             }
         }
     }
+    mark("values upload");
     slots.clear();
     setHostThreadShare((unsigned)std::max(1, nSlots));
     for (int i = 0; i < std::max(1, nSlots); i++) {
@@ -322,6 +346,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         sl->index.reset(new SeedIndex(p.k));
         slots.push_back(std::move(sl));
     }
+    mark("executor slots");
     const char* nothread = getenv("DP_NO_PLANNER_THREAD");
     const char* hostsel = getenv("DP_HOST_SELECT");  // 1: keep the speculative seed selection on the host threads
     if (!(hostsel && hostsel[0] == '1') && p.numSeeds <= 64) {
@@ -332,6 +357,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         }
     }
     planner.reset(new Planner(*reads, p, values.data(), !(nothread && nothread[0] == '1'), plannerCtx));
+    mark("planner");
     firstSequence = 0;
     round = 0;
     done = false;

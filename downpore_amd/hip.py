@@ -45,7 +45,7 @@ class ChainBatch(C.Structure):
 
 #: every entry point include/downpore_hip.h declares (checked by the CPU-side symbol test)
 SYMBOLS = ["dp_version", "dp_ctx_create", "dp_ctx_create_shared", "dp_ctx_destroy", "dp_last_error", "dp_reads_upload", "dp_reads_packed",
-           "dp_reads_count", "dp_reads_total_bases", "dp_kmer_histogram", "dp_round_begin", "dp_scan", "dp_scan_reads", "dp_index_build",
+           "dp_reads_count", "dp_reads_total_bases", "dp_kmer_histogram", "dp_kmer_values", "dp_round_begin", "dp_scan", "dp_scan_reads", "dp_index_build",
            "dp_find_overlaps", "dp_map_windows", "dp_index_posting_row", "dp_index_seedset_row", "dp_scan_device_buffers",
            "dp_scan_import_segments", "dp_values_upload", "dp_select_seeds", "dp_reads_upload_rc", "dp_consensus_align"]
 
@@ -76,6 +76,7 @@ def load_library():
     L.dp_reads_total_bases.restype = C.c_uint64
     L.dp_reads_total_bases.argtypes = [vp]
     L.dp_kmer_histogram.argtypes = [vp, C.c_int, C.c_void_p]
+    L.dp_kmer_values.argtypes = [vp, C.c_int, C.c_void_p]
     L.dp_round_begin.argtypes = [vp, C.c_int, C.c_void_p, C.c_uint32]
     L.dp_scan.argtypes = [vp, C.c_void_p, C.c_uint32, C.POINTER(SeedSeqBatch)]
     L.dp_scan_reads.argtypes = [vp, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_uint32,
@@ -152,6 +153,12 @@ class Context:
     def kmer_histogram(self, k):
         out = np.zeros(4 ** k, dtype=np.uint64)
         self._chk(self.L.dp_kmer_histogram(self.h, k, out.ctypes.data))
+        return out
+
+    # ---- A22 + A23: value table computed (and left resident) on the device
+    def kmer_values(self, k):
+        out = np.zeros(4 ** k, dtype=np.float64)
+        self._chk(self.L.dp_kmer_values(self.h, k, out.ctypes.data))
         return out
 
     # ---- round

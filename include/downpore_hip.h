@@ -71,6 +71,16 @@ uint64_t dp_reads_total_bases(const dp_ctx* ctx);
  * = occurrences of every k-mer over all uploaded reads. */
 int dp_kmer_histogram(dp_ctx* ctx, int k, uint64_t* counts_out);
 
+/* ---- A22 + A23: the k-mer value table -----------------------------------------------------------------------
+ * Replaces the block between "Counting all k-mers" and "Counting complete" of the commands (commands/overlap.go:55-93,
+ * commands/map.go:45-71): KmerOccurrences, value = 1 - |frequency - 0.000005| for k-mers seen at least 3 times,
+ * then util/sequtil/kmers.go:87-112: counts merged with their reverse complements (in place, so every pair ends at
+ * twice its sum) and the n/100 k-mers with the highest merged counts set to 0 (ties at the threshold: highest k-mer id
+ * first), values[0] = 0.  Everything runs on the device; the table stays resident as the context's value table (what
+ * dp_values_upload would have installed) and is copied to values_out (4^k doubles) unless that is NULL.  float64,
+ * bit-identical to the host computation. */
+int dp_kmer_values(dp_ctx* ctx, int k, double* values_out);
+
 /* ---- round state: the seed set --------------------------------------------------------------------------
  * Mirrors the per-round SeedIndex tables kmers/kmerMap/seedMap (seeds/seeds.go:13-18): seed id = position in
  * seed_kmers.  Builds the 4^k-bit membership table and the k-mer -> seed-id map on the device (sparse

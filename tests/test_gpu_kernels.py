@@ -76,6 +76,34 @@ def test_histogram(ctx):
         assert np.array_equal(ctx.kmer_histogram(k), rs.kmer_counts(k))
 
 
+@pytest.mark.parametrize("k,G,N,L,e", [(3, 20000, 100, 1500, 0.0), (6, 50000, 200, 1500, 0.01), (8, 30000, 200, 3000, 0.01),
+                                       (10, 200000, 500, 4000, 0.01), (11, 400000, 300, 6000, 0.0),
+                                       (12, 1000000, 2000, 10000, 0.0), (13, 1500000, 3000, 10000, 0.0)])
+def test_value_table_on_device(ctx, k, G, N, L, e):
+    """dp_kmer_values (histogram, value per k-mer, fwd+rc merge, top-1 % cut with its tie rule, all on the device) is
+    bit-identical to the oracle's table (overlap.go:55-93, kmers.go:87-112) - even k has palindromic k-mers, every
+    table is full of tied counts, k=3 is below the n/100 cut - and it is the table dp_select_seeds then uses."""
+    bases, off = O.gen_reads(60 + k, G, N, L, e, True)
+    ctx.upload_reads(bases, off)
+    rs = O.ReadSet(bases, off, min_len=0)
+    want = rs.kmer_values(k)
+    got = ctx.kmer_values(k)
+    assert got.dtype == np.float64 and got.shape == want.shape
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert (got > 0).sum() > 0
+    if k >= 8:  # the resident copy: selection with it equals selection with an uploaded oracle table
+        wins = [(r, 0, min(int(off[r + 1] - off[r]), 1000)) for r in range(0, N, max(1, N // 40))]
+        a = ctx.select_seeds(wins, k, 15)
+        ctx.values_upload(want)
+        b = ctx.select_seeds(wins, k, 15)
+        assert np.array_equal(a, b)
+
+
+def test_value_table_no_reads(ctx):
+    ctx.upload_reads(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.int64))
+    assert not ctx.kmer_values(6).any()
+
+
 @pytest.mark.parametrize("k,G,N,L,e", [(10, 100000, 400, 5000, 0.0), (10, 60000, 300, 4000, 0.02),
                                        (13, 1500000, 3000, 10000, 0.0)])
 def test_scan_index_query_chain(ctx, k, G, N, L, e):
