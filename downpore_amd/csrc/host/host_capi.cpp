@@ -36,6 +36,21 @@ void* dph_reads_from_fasta(const char* path, int64_t minLen, int himem) {
     return h;
 }
 void dph_reads_free(void* h) { delete (ReadsH*)h; }
+// "name\tACGT...\n" per read, bases spelled from their 2-bit codes: lets tests compare this reader with the oracle's
+const char* dph_reads_dump(void* h, int64_t* n) {
+    static thread_local std::string out;
+    out.clear();
+    ReadSet& s = ((ReadsH*)h)->set;
+    for (size_t i = 0; i < s.size(); i++) {
+        out += s.names[i];
+        out += '\t';
+        const char* b = s.seq(i);
+        for (i64 j = 0; j < s.length(i); j++) out += "ACGT"[baseCode((unsigned char)b[j])];
+        out += '\n';
+    }
+    *n = (int64_t)out.size();
+    return out.data();
+}
 int64_t dph_reads_count(void* h) { return (int64_t)((ReadsH*)h)->set.size(); }
 void dph_reads_get_ignore(void* h, uint8_t* out) {
     auto& ig = ((ReadsH*)h)->set.ignore;

@@ -4,7 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "dph.hpp"
+#include "host_util.hpp"
 
 using namespace dph;
 
@@ -38,10 +38,19 @@ static int runOverlap(ArgTable& t) {
     }
     ReadSet reads;
     std::string err;
+    const bool prof = getenv("DPH_PROFILE") != nullptr;
+    double tm = now();
+    auto mark = [&](const char* what) {
+        if (!prof) return;
+        const double tn = now();
+        fprintf(stderr, "[cli] %-24s %.1f ms\n", what, 1e3 * (tn - tm));
+        tm = tn;
+    };
     if (!ReadSet::fromFile(t.args["input"], p.overlapSize, p.himem, reads, err)) {
         fprintf(stderr, "%s\n", err.c_str());
         return 1;
     }
+    mark("read input");
     dp_ctx* ctx = nullptr;
     if (dp_ctx_create(0, &ctx) != 0) {
         fprintf(stderr, "downpore: %s\n", dp_last_error(nullptr));
@@ -55,6 +64,7 @@ static int runOverlap(ArgTable& t) {
         fprintf(stderr, "downpore: %s\n", run.error.empty() ? dp_last_error(ctx) : run.error.c_str());
         return 2;
     }
+    mark("set-up (device)");
     size_t shown = 0;
     for (;;) {
         rc = run.step();
@@ -68,6 +78,7 @@ static int runOverlap(ArgTable& t) {
         shown = run.errText.size();
     }
     fwrite(run.errText.data() + shown, 1, run.errText.size() - shown, stderr);
+    mark("rounds + output");
     fprintf(stderr, "[downpore_amd] rounds=%lld bad_back_suppressed=%lld empty_match_panics_avoided=%lld\n", (long long)run.round,
             (long long)run.badBack, (long long)run.emptyMatch);
     run.shutdown();

@@ -1,5 +1,10 @@
 // Host-side seed space for the product (see dph.hpp): read set, value table, seed selection, SeedSequence
 // operations, seed-space consensus and contig building.  File:line citations are into the reference.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -37,33 +42,53 @@ bool ReadSet::fromFile(const std::string& path, i64 minLen, bool himem, ReadSet&
     f = ReadSet();
     f.himem = himem;
     f.off.push_back(0);
-    std::ifstream in(path, std::ios::binary);
-    if (!in) {
+    // the file is mapped, not copied: one pass of memchr over the page cache, one copy of the bases into the read set
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) {
         err = "cannot open " + path;
         return false;
     }
-    std::stringstream ss;
-    ss << in.rdbuf();
-    const std::string all = ss.str();
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        close(fd);
+        err = "cannot stat " + path;
+        return false;
+    }
+    const size_t size = (size_t)st.st_size;
+    if (size == 0) {
+        close(fd);
+        return true;
+    }
+    void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+        err = "cannot map " + path;
+        return false;
+    }
+    madvise(m, size, MADV_SEQUENTIAL);
+    const char* all = (const char*)m;
+    f.bases.reserve(size);
     size_t pos = 0;
     auto next = [&](size_t& b, size_t& e) -> bool {
-        if (pos >= all.size()) return false;
-        size_t nl = all.find('\n', pos);
+        if (pos >= size) return false;
+        const void* nl = memchr(all + pos, '\n', size - pos);
         b = pos;
-        e = (nl == std::string::npos) ? all.size() : nl + 1;
+        e = nl ? (size_t)((const char*)nl - all) + 1 : size;
         pos = e;
         return true;
     };
     size_t b, e;
-    if (!next(b, e) || all[e - 1] != '\n') return true;  // :191-196 first line is always a name line
-    std::string lastName = all.substr(b + 1, e - b - 1);
-    while (next(b, e)) {
-        bool eof = all[e - 1] != '\n';
-        unsigned char c = (unsigned char)all[b];
-        if (c >= 'A' && c <= 'T') f.addLine(lastName, all.data() + b, e - b, minLen);
-        else lastName = all.substr(b + 1, e - b - 1);
-        if (eof) break;
+    if (next(b, e) && all[e - 1] == '\n') {  // :191-196 first line is always a name line
+        std::string lastName(all + b + 1, e - b - 1);
+        while (next(b, e)) {
+            const bool eof = all[e - 1] != '\n';
+            const unsigned char c = (unsigned char)all[b];
+            if (c >= 'A' && c <= 'T') f.addLine(lastName, all + b, e - b, minLen);
+            else lastName.assign(all + b + 1, e - b - 1);
+            if (eof) break;
+        }
     }
+    munmap(m, size);
     return true;
 }
 

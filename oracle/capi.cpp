@@ -180,6 +180,20 @@ void* dpo_reads_from_arrays(const char* bases, const int64_t* off, int64_t n, in
     return new ReadSetH{FastaSet::fromReads(names, seqs, minLen, himem != 0)};
 }
 void dpo_reads_free(void* h) { delete (ReadSetH*)h; }
+// "name\tACGT...\n" per read (the 2-bit content spelled back): lets tests compare FASTA readers
+const char* dpo_reads_dump(void* h, int64_t* n) {
+    static thread_local std::string out;
+    out.clear();
+    FastaSet& s = ((ReadSetH*)h)->set;
+    for (size_t i = 0; i < s.size(); i++) {
+        out += s.names[i];
+        out += '\t';
+        out += s.cached[i].str();
+        out += '\n';
+    }
+    *n = (int64_t)out.size();
+    return out.data();
+}
 int64_t dpo_reads_count(void* h) { return (int64_t)((ReadSetH*)h)->set.size(); }
 void dpo_reads_reset_ignore(void* h) {
     auto& ig = ((ReadSetH*)h)->set.ignore;
