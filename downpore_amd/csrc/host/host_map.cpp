@@ -593,24 +593,36 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // ---- device read set: [0] reference, [1] circular join chunk, then (forward, reverse complement) of every read
     std::string bases;
     std::vector<i64> off(1, 0);
-    auto addRead = [&](const char* s, size_t n) {
-        bases.append(s, n);
-        off.push_back((i64)bases.size());
-    };
-    addRead(ref, (size_t)refLen);
     std::string join;
     if (p.circular) join = std::string(ref + (refLen - p.querySize), (size_t)p.querySize) + std::string(ref, (size_t)p.querySize);
-    addRead(join.data(), join.size());
-    bases.reserve(bases.size() + reads.bases.size());
-    for (size_t r = 0; r < reads.size(); r++) addRead(reads.seq(r), (size_t)reads.length(r));
+    // one staging buffer [reference | join chunk | all reads]; the reads are one contiguous block of the read set, copied
+    // (and its pages first touched) by the worker pool in 4 MiB pieces
+    const size_t head = (size_t)refLen + join.size();
+    const size_t readBytes = reads.size() ? (size_t)(reads.off[reads.size()] - reads.off[0]) : 0;
+    std::unique_ptr<char[]> staging(new char[head + readBytes + 1]);
+    memcpy(staging.get(), ref, (size_t)refLen);
+    memcpy(staging.get() + refLen, join.data(), join.size());
+    off.push_back((i64)refLen);
+    off.push_back((i64)head);
+    {
+        const char* src = reads.size() ? reads.seq(0) : nullptr;
+        const size_t piece = (size_t)4 << 20, nPieces = (readBytes + piece - 1) / piece;
+        char* dst = staging.get() + head;
+        parallelFor(nPieces, [&](size_t i) {
+            const size_t b = i * piece, e = std::min(readBytes, b + piece);
+            memcpy(dst + b, src + b, e - b);
+        });
+        const i64 shift = (i64)head - (reads.size() ? reads.off[0] : 0);
+        for (size_t r = 0; r < reads.size(); r++) off.push_back(reads.off[r + 1] + shift);
+    }
+    (void)bases;
     // device ids: 0 reference, 1 join chunk, then (forward, reverse complement) per read; the reverse strands are made
     // on the device
     mark("concatenate reads");
-    rc = dp_reads_upload_rc(ctx, (const uint8_t*)bases.data(), off.data(), (uint32_t)(off.size() - 1), 2);
+    rc = dp_reads_upload_rc(ctx, (const uint8_t*)staging.get(), off.data(), (uint32_t)(off.size() - 1), 2);
     if (rc) return fail(rc);
     mark("upload + pack (both strands)");
-    bases.clear();
-    bases.shrink_to_fit();
+    staging.reset();
     rc = dp_round_begin(ctx, k, index.seedMap.data(), (uint32_t)index.seedMap.size());
     if (rc) return fail(rc);
 
