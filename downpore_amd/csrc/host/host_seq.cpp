@@ -1067,16 +1067,96 @@ static SeedContig* newSeedContig(Arena& ar, std::vector<SeedMatch*>& ms, int k, 
 
 // BuildConsensus :163-182: un-RC the rc-query matches, drop matches covering < 25 bases, trim each target to the
 // query-aligned span.  Fills `seqs`.
+// What matchReverseComplement + Trimmed() leave behind for a match of the reverse-complemented query, without spelling the
+// whole reverse complement of the target out: a target is a chunk of up to chunk_size bases (~770 seeds at k=13) of which
+// a match touches ~75, and the full copy with its seed-id translation was a sixth of the consensus stage.  `S` is the
+// forward target, the match's index lists are already reversed.  R = rc(S) is created with only the slice
+// [2*startSeed, 2*endSeed+2] of its segments filled in (Trimmed()'s final range, which contains every matched seed);
+// offsets come from the forward sequence: R.seedOffset(i) = S.seedOffsetFromEnd(ns-1-i) and vice versa.
+static SeedSeq* trimmedRcTarget(Arena& a, SeedSeq* S, const SeedIndex& ix, i64 startOffset, int startSeed, i64 endOffset,
+                                int endSeed, int k, int fillLo, int fillHi, SeedSeq** rcOut) {
+    const int n = S->n, numSeeds = n / 2;
+    auto gapR = [&](int t) -> i64 { return S->seg[2 * (numSeeds - t)]; };  // R.seg[2t]
+    while (startSeed > 0 && startOffset >= gapR(startSeed) + k) {
+        startOffset -= gapR(startSeed) + k;
+        startSeed--;
+    }
+    while (endSeed < numSeeds - 1 && endOffset >= gapR(endSeed + 1) + k) {
+        endOffset -= gapR(endSeed + 1) + k;
+        endSeed++;
+    }
+    const i64 offset = S->seedOffsetFromEnd(numSeeds - 1 - startSeed, k) - startOffset;  // R.seedOffset(startSeed)
+    const i64 inset = S->seedOffset(numSeeds - 1 - endSeed, k) - endOffset;              // R.seedOffsetFromEnd(endSeed)
+    SeedSeq* R = a.make();
+    int32_t* d = a.alloc((size_t)n);
+    const int lo = std::max(0, std::min(2 * startSeed, 2 * fillLo)), hi = std::min(n - 1, std::max(2 * endSeed + 2, 2 * fillHi + 2));
+    for (int j = lo; j <= hi; j++) d[j] = (j & 1) ? ix.seedOfRcKmer(S->seg[n - 1 - j]) : S->seg[n - 1 - j];
+    R->seg = d;
+    R->n = n;
+    R->id = S->id;
+    R->length = S->length;
+    R->offset = S->offset;
+    R->inset = S->inset;
+    R->reverseComplement = S;
+    R->rc = !S->rc;
+    R->parent = S->parent;
+    *rcOut = R;
+    SeedSeq* t = R->rc ? seqSubSequence(a, R, startSeed, endSeed, R->length - offset - inset, R->offset + inset, R->inset + offset)
+                       : seqSubSequence(a, R, startSeed, endSeed, R->length - offset - inset, R->offset + offset, R->inset + inset);
+    int32_t* c = a.alloc((size_t)t->n);
+    memcpy(c, t->seg, (size_t)t->n * 4);
+    c[0] = (int32_t)startOffset;
+    c[t->n - 1] = (int32_t)endOffset;
+    t->seg = c;
+    return t;
+}
+
 static void consensusTrimTargets(Arena& ar, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, std::vector<SeedSeq*>& seqs) {
     const int k = sg.k;
     seqs.clear();
+    static const bool fullRc = [] {  // DP_FULL_RC=1: the literal matchReverseComplement + Trimmed() sequence
+        const char* e = getenv("DP_FULL_RC");
+        return e && e[0] == '1';
+    }();
     {
         FINE(0);
-        for (SeedMatch* lap : overlaps)
-            if (lap->ReverseComplementQuery) matchReverseComplement(ar, *lap, sg);
+        for (SeedMatch* lap : overlaps) {
+            if (!lap->ReverseComplementQuery) continue;
+            if (fullRc || lap->MatchA.empty()) {
+                matchReverseComplement(ar, *lap, sg);
+                lap->ReverseComplementQuery = false;  // (done: the second pass takes the forward path)
+                continue;
+            }
+            // the index lists and the query now; the target in the second pass, once the query of overlaps[0] is forward
+            lap->SeqA = seqReverseComplement(ar, lap->SeqA, sg);
+            const int lengthA = lap->SeqA->n / 2 - 1, lengthB = lap->SeqB->n / 2 - 1;
+            std::reverse(lap->MatchA.begin(), lap->MatchA.end());
+            std::reverse(lap->MatchB.begin(), lap->MatchB.end());
+            for (size_t i = 0; i < lap->MatchA.size(); i++) {
+                lap->MatchA[i] = lengthA - lap->MatchA[i];
+                lap->MatchB[i] = lengthB - lap->MatchB[i];
+            }
+        }
     }
     FINE(1);
     for (SeedMatch* lap : overlaps) {
+        if (lap->ReverseComplementQuery) {
+            int fillLo = lap->MatchB[0], fillHi = lap->MatchB[0];
+            for (int32_t b : lap->MatchB) {
+                fillLo = std::min(fillLo, (int)b);
+                fillHi = std::max(fillHi, (int)b);
+            }
+            SeedSeq* R = nullptr;
+            SeedSeq* t = trimmedRcTarget(ar, lap->SeqB, sg, overlaps[0]->SeqA->seedOffset(lap->MatchA[0], k), lap->MatchB[0],
+                                         overlaps[0]->SeqA->seedOffsetFromEnd(lap->MatchA.back(), k), lap->MatchB.back(), k, fillLo,
+                                         fillHi, &R);
+            lap->SeqB = R;
+            i64 ca, cb;
+            matchBasesCovered(*lap, k, &ca, &cb, nullptr);
+            if (ca < 25 || cb < 25) continue;
+            seqs.push_back(t);
+            continue;
+        }
         i64 ca, cb;
         matchBasesCovered(*lap, k, &ca, &cb, nullptr);
         if (ca < 25 || cb < 25) continue;
