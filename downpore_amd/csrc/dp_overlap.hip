@@ -1223,6 +1223,41 @@ struct MRec {
     uint32_t off, len;
 };
 
+// Anchors of a chain on its target: base offset of the first matched target seed from the target's start
+// (SeedSequence.GetSeedOffset, seeds/sequence.go) and of the last one from its end (GetSeedOffsetFromEnd).  Trimmed()
+// (overlap/combine.go:171-181) needs both for every match; summing the gaps on the host means streaming the whole chunk
+// (~6 KB of pinned memory) per match, here it is one wave per match over segments that are resident anyway.
+// anchors[2*slot] = seg[0] + sum_{t=1..first}(seg[2t]+k), anchors[2*slot+1] = seg[n-1] + sum_{t=last+1..ns-1}(seg[2t]+k);
+// -1 when the chain's indices are not inside the target (the host then sums itself).
+__global__ __launch_bounds__(256) void match_anchor_kernel(const MRec* __restrict__ recs, uint32_t nslots, const int32_t* __restrict__ mb,
+                                                           const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, int k,
+                                                           int32_t* __restrict__ anchors) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (slot >= nslots) return;
+    const MRec r = recs[slot];
+    if (r.len == 0) return;
+    const int first = mb[r.off], last = mb[r.off + r.len - 1];
+    const dp_seq_ref ref = refs[r.t];
+    const int ns = (int)ref.n_seeds;
+    const int32_t* s = segs + ref.seg_off;
+    if (first < 0 || last < 0 || first >= ns || last >= ns) {
+        if (lane == 0) anchors[2 * slot] = anchors[2 * slot + 1] = -1;
+        return;
+    }
+    int a = 0, b = 0;
+    for (int t = 1 + lane; t <= first; t += 64) a += s[2 * t] + k;
+    for (int t = last + 1 + lane; t <= ns - 1; t += 64) b += s[2 * t] + k;
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+    }
+    if (lane == 0) {
+        anchors[2 * slot] = s[0] + a;
+        anchors[2 * slot + 1] = s[2 * ns] + b;
+    }
+}
+
 // cursor: u64 at [0..1] = ints (low) | record slots (high); [2] error bits, [3] overflow flag.
 // tier: 0 automatic, 2 forces the lds tier, 3 the one-lane tier (tests).
 __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
@@ -1548,6 +1583,8 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     if (pin_reserve(ctx, ctx->h_ta, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_tb, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_qm, (size_t)nq * 24 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
     uint32_t* qm = (uint32_t*)ctx->h_qm.p;
     u64* words = (u64*)((uint8_t*)ctx->h_qm.p + (size_t)nq * 16);
     DP_HIP(hipMemcpyAsync(qm, d_qmeta, (size_t)nq * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1555,6 +1592,11 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     const int32_t* ta = (const int32_t*)ctx->h_ta.p;
     const int32_t* tb = (const int32_t*)ctx->h_tb.p;
     if (nslots) {
+        hipLaunchKernelGGL(match_anchor_kernel, dim3((nslots + 3) / 4), dim3(256), 0, ctx->stream, (const MRec*)ctx->d_mrec.p, nslots,
+                           (const int32_t*)ctx->d_mb.p, (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, k,
+                           (int32_t*)ctx->d_manchor.p);
+        DP_HIP(hipGetLastError());
+        DP_HIP(hipMemcpyAsync(ctx->h_manchor.p, ctx->d_manchor.p, (size_t)nslots * 8, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_mrec.p, ctx->d_mrec.p, (size_t)nslots * sizeof(MRec), hipMemcpyDeviceToHost, ctx->stream));
         if (ni) {
             DP_HIP(hipMemcpyAsync(ctx->h_ta.p, ctx->d_ma.p, (size_t)ni * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1585,6 +1627,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     if (pin_reserve(ctx, ctx->h_mq, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_mt, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_moff, ((size_t)nm + 1) * 8)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_manout, (size_t)nm * 8 + 16)) return DP_ERR_HIP;
     {  // canonical order: queries ascending, targets ascending.  A query's slots were reserved by one wave in candidate
        // order, so a stable bucket pass over the query id is enough; verified below (falls back to a full sort).
         std::vector<uint32_t> start((size_t)nq + 1, 0), sorted(nm);
@@ -1607,11 +1650,15 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     uint64_t* moff = (uint64_t*)ctx->h_moff.p;
     int32_t* fa = (int32_t*)ctx->h_ma.p;
     int32_t* fb = (int32_t*)ctx->h_mb.p;
+    const int32_t* anch = (const int32_t*)ctx->h_manchor.p;
+    int32_t* anchOut = (int32_t*)ctx->h_manout.p;
     uint64_t pos = 0;
     for (uint32_t i = 0; i < nm; i++) {
         const MRec& r = recs[order[i]];
         mq[i] = r.q;
         mt[i] = r.t;
+        anchOut[2 * i] = anch[2 * (size_t)order[i]];
+        anchOut[2 * i + 1] = anch[2 * (size_t)order[i] + 1];
         moff[i] = pos;
         memcpy(fa + pos, ta + r.off, (size_t)r.len * 4);
         memcpy(fb + pos, tb + r.off, (size_t)r.len * 4);
@@ -1624,6 +1671,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     out->off = moff;
     out->match_a = fa;
     out->match_b = fb;
+    out->target_anchor = anchOut;
     if (want_candidates) {
         const u64* cm = (const u64*)ctx->h_cand.p;
         uint64_t total = 0;

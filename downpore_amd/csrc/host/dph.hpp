@@ -76,6 +76,9 @@ struct SeedMatch {  // seeds/sequence.go:24-32
     SeedSeq* SeqB = nullptr;
     int QueryID = 0;
     bool ReverseComplementQuery = false;
+    // from the device (dp_match_batch.target_anchor), in the FORWARD target's coordinates: GetSeedOffset(MatchB[0]) and
+    // GetSeedOffsetFromEnd(MatchB.back()) as the chain came back; -1 = unknown (Trimmed() then sums the gaps itself)
+    i64 anchorFirstB = -1, anchorLastFromEndB = -1;
 };
 
 // per-round arena (Go GC stand-in): bump allocation out of slabs that are kept across clear()
@@ -166,7 +169,8 @@ struct SeedIndex {
 
 SeedSeq* seqReverseComplement(Arena& a, SeedSeq* s, const SeedIndex& ix);  // seeds/sequence.go:134-159
 SeedSeq* seqSubSequence(Arena& a, SeedSeq* s, int start, int end, i64 length, i64 offset, i64 inset);  // :46
-SeedSeq* seqTrimmed(Arena& a, SeedSeq* s, i64 startOffset, int startSeed, i64 endOffset, int endSeed, int k);  // :54
+SeedSeq* seqTrimmed(Arena& a, SeedSeq* s, i64 startOffset, int startSeed, i64 endOffset, int endSeed, int k, i64 anchorStart = -1,
+                    i64 anchorEnd = -1);  // :54
 SeedSeq* seqReduced(Arena& a, SeedSeq* s, const std::vector<uint64_t>& whitelist, int k, int minSeeds,
                     std::vector<int>* index);                                                              // :85
 void matchReverseComplement(Arena& a, SeedMatch& m, const SeedIndex& ix);   // :800

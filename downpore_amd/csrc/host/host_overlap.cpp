@@ -413,6 +413,8 @@ int Overlapper::FindOverlaps(std::vector<SeedMatch>& pool, std::vector<SeedMatch
         m->SeqB = index_.sequences[mb.target[i]];
         m->QueryID = q.ID;
         m->ReverseComplementQuery = q.ReverseComplement;
+        m->anchorFirstB = mb.target_anchor ? mb.target_anchor[2 * (size_t)i] : -1;
+        m->anchorLastFromEndB = mb.target_anchor ? mb.target_anchor[2 * (size_t)i + 1] : -1;
         out.push_back(m);
     }
     st.n_matches = out.size();

@@ -414,18 +414,24 @@ SeedSeq* seqSubSequence(Arena& a, SeedSeq* s, int start, int end, i64 length, i6
     return r;
 }
 
-SeedSeq* seqTrimmed(Arena& a, SeedSeq* s, i64 startOffset, int startSeed, i64 endOffset, int endSeed, int k) {
+// anchorStart / anchorEnd: seedOffset(startSeed) / seedOffsetFromEnd(endSeed) of the seeds passed in, when the caller knows
+// them (>= 0); they follow the two walks below, so the whole-sequence sums are not needed
+SeedSeq* seqTrimmed(Arena& a, SeedSeq* s, i64 startOffset, int startSeed, i64 endOffset, int endSeed, int k, i64 anchorStart,
+                    i64 anchorEnd) {
     while (startSeed > 0 && startOffset >= s->seg[startSeed * 2] + k) {
         startOffset -= s->seg[startSeed * 2] + k;
+        anchorStart -= s->seg[startSeed * 2] + k;
         startSeed--;
     }
     const int numSeeds = s->n / 2;
     while (endSeed < numSeeds - 1 && endOffset >= s->seg[endSeed * 2 + 2] + k) {
         endOffset -= s->seg[endSeed * 2 + 2] + k;
+        anchorEnd -= s->seg[endSeed * 2 + 2] + k;
         endSeed++;
     }
-    const i64 offset = s->seedOffset(startSeed, k) - startOffset;
-    const i64 inset = s->seedOffsetFromEnd(endSeed, k) - endOffset;
+    const bool known = anchorStart >= 0 && anchorEnd >= 0;
+    const i64 offset = (known ? anchorStart : s->seedOffset(startSeed, k)) - startOffset;
+    const i64 inset = (known ? anchorEnd : s->seedOffsetFromEnd(endSeed, k)) - endOffset;
     SeedSeq* t = s->rc ? seqSubSequence(a, s, startSeed, endSeed, s->length - offset - inset, s->offset + inset, s->inset + offset)
                        : seqSubSequence(a, s, startSeed, endSeed, s->length - offset - inset, s->offset + offset, s->inset + inset);
     int32_t* d = a.alloc((size_t)t->n);
@@ -1073,20 +1079,25 @@ static SeedContig* newSeedContig(Arena& ar, std::vector<SeedMatch*>& ms, int k, 
 // forward target, the match's index lists are already reversed.  R = rc(S) is created with only the slice
 // [2*startSeed, 2*endSeed+2] of its segments filled in (Trimmed()'s final range, which contains every matched seed);
 // offsets come from the forward sequence: R.seedOffset(i) = S.seedOffsetFromEnd(ns-1-i) and vice versa.
+// anchorStart / anchorEnd (>= 0 when known): R.seedOffset(startSeed) / R.seedOffsetFromEnd(endSeed) of the seeds passed in,
+// i.e. the forward target's GetSeedOffsetFromEnd(last matched) / GetSeedOffset(first matched) from the device.
 static SeedSeq* trimmedRcTarget(Arena& a, SeedSeq* S, const SeedIndex& ix, i64 startOffset, int startSeed, i64 endOffset,
-                                int endSeed, int k, int fillLo, int fillHi, SeedSeq** rcOut) {
+                                int endSeed, int k, int fillLo, int fillHi, i64 anchorStart, i64 anchorEnd, SeedSeq** rcOut) {
     const int n = S->n, numSeeds = n / 2;
     auto gapR = [&](int t) -> i64 { return S->seg[2 * (numSeeds - t)]; };  // R.seg[2t]
     while (startSeed > 0 && startOffset >= gapR(startSeed) + k) {
         startOffset -= gapR(startSeed) + k;
+        anchorStart -= gapR(startSeed) + k;
         startSeed--;
     }
     while (endSeed < numSeeds - 1 && endOffset >= gapR(endSeed + 1) + k) {
         endOffset -= gapR(endSeed + 1) + k;
+        anchorEnd -= gapR(endSeed + 1) + k;
         endSeed++;
     }
-    const i64 offset = S->seedOffsetFromEnd(numSeeds - 1 - startSeed, k) - startOffset;  // R.seedOffset(startSeed)
-    const i64 inset = S->seedOffset(numSeeds - 1 - endSeed, k) - endOffset;              // R.seedOffsetFromEnd(endSeed)
+    const bool known = anchorStart >= 0 && anchorEnd >= 0;
+    const i64 offset = (known ? anchorStart : S->seedOffsetFromEnd(numSeeds - 1 - startSeed, k)) - startOffset;  // R.seedOffset(startSeed)
+    const i64 inset = (known ? anchorEnd : S->seedOffset(numSeeds - 1 - endSeed, k)) - endOffset;                // R.seedOffsetFromEnd(endSeed)
     SeedSeq* R = a.make();
     int32_t* d = a.alloc((size_t)n);
     const int lo = std::max(0, std::min(2 * startSeed, 2 * fillLo)), hi = std::min(n - 1, std::max(2 * endSeed + 2, 2 * fillHi + 2));
@@ -1117,6 +1128,10 @@ static void consensusTrimTargets(Arena& ar, const SeedIndex& sg, std::vector<See
     static const bool fullRc = [] {  // DP_FULL_RC=1: the literal matchReverseComplement + Trimmed() sequence
         const char* e = getenv("DP_FULL_RC");
         return e && e[0] == '1';
+    }();
+    static const bool useAnchors = [] {  // DP_NO_ANCHORS=1: ignore the device's target anchors, sum the gaps here
+        const char* e = getenv("DP_NO_ANCHORS");
+        return !(e && e[0] == '1') && !fullRc;
     }();
     {
         FINE(0);
@@ -1149,7 +1164,7 @@ static void consensusTrimTargets(Arena& ar, const SeedIndex& sg, std::vector<See
             SeedSeq* R = nullptr;
             SeedSeq* t = trimmedRcTarget(ar, lap->SeqB, sg, overlaps[0]->SeqA->seedOffset(lap->MatchA[0], k), lap->MatchB[0],
                                          overlaps[0]->SeqA->seedOffsetFromEnd(lap->MatchA.back(), k), lap->MatchB.back(), k, fillLo,
-                                         fillHi, &R);
+                                         fillHi, useAnchors ? lap->anchorLastFromEndB : -1, useAnchors ? lap->anchorFirstB : -1, &R);
             lap->SeqB = R;
             i64 ca, cb;
             matchBasesCovered(*lap, k, &ca, &cb, nullptr);
@@ -1161,7 +1176,8 @@ static void consensusTrimTargets(Arena& ar, const SeedIndex& sg, std::vector<See
         matchBasesCovered(*lap, k, &ca, &cb, nullptr);
         if (ca < 25 || cb < 25) continue;
         seqs.push_back(seqTrimmed(ar, lap->SeqB, overlaps[0]->SeqA->seedOffset(lap->MatchA[0], k), lap->MatchB[0],
-                                  overlaps[0]->SeqA->seedOffsetFromEnd(lap->MatchA.back(), k), lap->MatchB.back(), k));
+                                  overlaps[0]->SeqA->seedOffsetFromEnd(lap->MatchA.back(), k), lap->MatchB.back(), k,
+                                  useAnchors ? lap->anchorFirstB : -1, useAnchors ? lap->anchorLastFromEndB : -1));
     }
 }
 

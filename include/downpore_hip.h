@@ -185,6 +185,10 @@ typedef struct {
     const uint64_t* off;      /* [n_matches+1] offsets into match_a / match_b */
     const int32_t* match_a;   /* query seed indices of the chain */
     const int32_t* match_b;   /* target seed indices of the chain */
+    const int32_t* target_anchor; /* [2*n_matches]: base offset of the chain's first target seed from the target's start
+                                   * (GetSeedOffset(match_b[first])) and of its last one from the end
+                                   * (GetSeedOffsetFromEnd(match_b[last])), seeds/sequence.go - what Trimmed()
+                                   * (overlap/combine.go:171-181) would otherwise sum over the whole chunk; -1 = not computed */
     /* test hooks */
     uint32_t n_queries;
     const uint64_t* cand_off; /* [n_queries+1] */

@@ -194,6 +194,15 @@ def test_scan_index_query_chain(ctx, k, G, N, L, e):
         assert np.array_equal(out["off"].astype(np.int64), mao)
         assert np.array_equal(out["match_a"].astype(np.int64), ma)
         assert np.array_equal(out["match_b"].astype(np.int64), mb)
+        # target anchors of every chain: GetSeedOffset(first matched target seed), GetSeedOffsetFromEnd(last one)
+        anchors = out["target_anchor"]
+        assert anchors.shape == (len(mt), 2)
+        for i in range(len(mt)):
+            seg = isegs[ioffs[int(mt[i])]:ioffs[int(mt[i]) + 1]].astype(np.int64)
+            first, last = int(mb[mao[i]]), int(mb[mao[i + 1] - 1])
+            want_first = int(seg[0] + (seg[2:2 * first + 1:2] + k).sum())
+            want_last = int(seg[-1] + (seg[2 * last + 2:len(seg) - 1:2] + k).sum())
+            assert (int(anchors[i, 0]), int(anchors[i, 1])) == (want_first, want_last), ("anchor", i)
         # the chain kernel's slower tiers (open chains in LDS; one-lane transcription) must give the same chains
         for tier in ("2", "3"):
             os.environ["DP_CHAIN_TIER"] = tier
