@@ -742,6 +742,10 @@ static SeedSeq* multiAlignerCore(Arena& arena, std::vector<SeedSeq*>& seqs, std:
             matches[i] = m;
         }
     bool finished = false;
+    static const bool uniformFast = [] {  // DP_NO_UNIFORM_STEP=1: always take the general step
+        const char* e = getenv("DP_NO_UNIFORM_STEP");
+        return !(e && e[0] == '1');
+    }();
     const i64 kNarrow = (i64)1 << 28;  // all quantities below this: 32-bit arithmetic is exact
     okv.assign(ns, 0);
     odv.assign(ns, 0);
@@ -755,7 +759,9 @@ static SeedSeq* multiAlignerCore(Arena& arena, std::vector<SeedSeq*>& seqs, std:
         i64 memoD = 0, memoMin = 0, memoMax = 0, memoSum = 0;
         int32_t memoSeed = 0;
         int memoCnt = 0;
-        bool narrow = true, inStep = true;
+        bool narrow = true, inStep = true, uniform = true;
+        i64 nValid = 0, o0 = 0;
+        int32_t sd0 = -1;
         for (size_t j = 0; j < ns; j++) {  // state of every sequence's next seed (constant during the support scan)
             const int32_t* s2 = S(j);
             const i64 p2 = pos[j] + 1;
@@ -767,6 +773,36 @@ static SeedSeq* multiAlignerCore(Arena& arena, std::vector<SeedSeq*>& seqs, std:
             odv[j] = (int32_t)o;
             sdv[j] = ok ? s2[p2 * 2 + 1] : -1;
             gpv[j] = (int32_t)gaps[j];
+            if (ok) {
+                if (nValid == 0) {
+                    o0 = o;
+                    sd0 = s2[p2 * 2 + 1];
+                } else if (o != o0 || s2[p2 * 2 + 1] != sd0) {
+                    uniform = false;
+                }
+                nValid++;
+            }
+        }
+        if (uniformFast && uniform && inStep && narrow && nValid >= 2 && o0 > -k && o0 < 100000) {
+            // Every sequence that still has a seed is in step (gap 0) and shows the same seed at the same distance.  Then
+            // the general code below does nothing but agree: each of them proposes (d = o0 < near, which only drops to
+            // maxD(o0) > o0), finds the seed in every other one at once (o0 lies inside gapRange(o0) for every -k < o0),
+            // so supported = nValid >= 2 and dist/supported = o0 exactly; the first proposer wins the selection, and the
+            // update loop finds the seed at pos+1 of every sequence.  Same state, same consensus, same matches.
+            consensus.push_back((int32_t)o0);
+            consensus.push_back(sd0);
+            const int32_t ci = (int32_t)(consensus.size() / 2 - 1);
+            for (size_t i = 0; i < ns; i++)
+                if (okv[i]) {
+                    const i64 md = pos[i] + 1;
+                    pos[i] = md;
+                    offs[i] = 0;
+                    dist[i] = nValid * o0;  // what the support scan leaves behind (a later step may read it once
+                                            // the sequence has ended: the reference's distances persist, :170-176)
+                    matches[i]->MatchA.push_back(ci);
+                    matches[i]->MatchB.push_back(seedMap[i][(size_t)md]);
+                }
+            continue;  // finished would be false: nValid >= 2 sequences go on
         }
         for (size_t i = 0; i < ns; i++) {
             const int32_t* segment = S(i);
