@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--seed-batch-size", type=int, default=10000)
     ap.add_argument("--cpu-rounds", type=int, default=2, help="oracle rounds timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--slots", type=int, default=5, help="rounds executed concurrently per GPU (executor slots)")
+    ap.add_argument("--slots", type=int, default=6, help="rounds executed concurrently per GPU (executor slots)")
     ap.add_argument("--index-steps", type=int, default=100,
                     help="N=1: after the timed region, time this many further rounds with the resident k-mer position index "
                          "instead of the scan (reported as index_mode; 0 = skip)")

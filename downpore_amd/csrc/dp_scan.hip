@@ -20,6 +20,7 @@
 #include <sys/prctl.h>
 #include <time.h>
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,7 +31,29 @@
 static std::string g_create_err;
 // The scan kernels are persistent and fill every CU: two of them running at once (several contexts on one device) only
 // slow each other down, so the device part of dp_scan is serialised per process.
-static std::mutex g_scan_mu;
+// (a counting gate: DP_SCAN_CONCURRENCY scans may be in flight, default 1; it has the lock()/unlock() of a mutex)
+struct ScanGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int avail = [] {
+        const char* e = getenv("DP_SCAN_CONCURRENCY");
+        const int n = e ? atoi(e) : 1;
+        return n < 1 ? 1 : n;
+    }();
+    void lock() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return avail > 0; });
+        avail--;
+    }
+    void unlock() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            avail++;
+        }
+        cv.notify_one();
+    }
+};
+static ScanGate g_scan_mu;
 
 // Waiting for the context's stream.  The runtime's own waits (hipStreamSynchronize, and hipEventSynchronize even on a
 // blocking-sync event) spin on the completion signal for up to 100 us before they sleep; a round has about ten waits of
@@ -845,7 +868,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus * (v2 ? 2 : 1), ((uint64_t)n_items + 15) / 16);
     const uint32_t dbg = getenv("DP_SCAN_DEBUG") ? (uint32_t)atoi(getenv("DP_SCAN_DEBUG")) : 0u;
-    std::unique_lock<std::mutex> scan_lock(g_scan_mu);
+    std::unique_lock<ScanGate> scan_lock(g_scan_mu);
     DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(((dbg & 2) ? scan_kernel<0, 3> : v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
                        (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p, n_items, k,
@@ -1027,7 +1050,7 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     // all the scans of a config-2 sized job together).
     bool use_index = ctx->total_bases >= 3000000000ull || (ctx->owner && ctx->owner->total_bases >= 3000000000ull);
     if (const char* e = getenv("DP_SCAN_INDEX")) use_index = e[0] == '1';
-    std::unique_lock<std::mutex> scan_lock(g_scan_mu, std::defer_lock);
+    std::unique_lock<ScanGate> scan_lock(g_scan_mu, std::defer_lock);
     if (use_index) {
         int rc = dp_kindex_ensure(ctx, k);
         if (rc < 0) return rc;
@@ -1065,6 +1088,16 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->h_total.p, totals, 16, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
+    {
+        // DP_SCAN_RELEASE_EARLY=1 opens the gate here, after the count pass, so that the short write pass overlaps the
+        // next slot's count pass.  Measured: it does not - the count pass is a persistent grid that owns every CU's LDS, so
+        // the write pass queues behind it (0.08 -> 0.2 ms) and the slot only gets slower.  Off by default.
+        static const bool early = [] {
+            const char* e = getenv("DP_SCAN_RELEASE_EARLY");
+            return e && e[0] == '1';
+        }();
+        if (early && scan_lock.owns_lock()) scan_lock.unlock();
+    }
     const uint64_t n_segs = ((uint64_t*)ctx->h_total.p)[0];
     const uint64_t n_surv_all = ((uint64_t*)ctx->h_total.p)[1];  // surviving reads + all extra items
     if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;

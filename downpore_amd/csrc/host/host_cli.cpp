@@ -59,7 +59,7 @@ static int runOverlap(ArgTable& t) {
     int rc = dp_reads_upload(ctx, (const uint8_t*)reads.bases.data(), reads.off.data(), (uint32_t)reads.size());
     OverlapRun run;
     const char* ns = getenv("DP_EXEC_SLOTS");
-    if (rc == 0) rc = run.init(ctx, &reads, p, nullptr, ns ? atoi(ns) : 5);
+    if (rc == 0) rc = run.init(ctx, &reads, p, nullptr, ns ? atoi(ns) : 6);
     if (rc != 0) {
         fprintf(stderr, "downpore: %s\n", run.error.empty() ? dp_last_error(ctx) : run.error.c_str());
         return 2;

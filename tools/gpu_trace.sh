@@ -2,7 +2,7 @@
 # kernel trace of a short bench run: per-kernel totals, GPU busy time (union of intervals) vs wall of the traced region
 mkdir -p gpurun_out; cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 rm -rf gpurun_out/trace
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/trace -- python3 bench.py --steps ${STEPS:-200} --warmup 8 --cpu-rounds 0 > gpurun_out/trace_bench.json 2> gpurun_out/trace_bench.err; echo "rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/trace -- python3 bench.py --steps ${STEPS:-200} --warmup 8 --cpu-rounds 0 --index-steps 0 > gpurun_out/trace_bench.json 2> gpurun_out/trace_bench.err; echo "rc=$?"
 python3 - <<'PY'
 import csv, glob, collections, json
 f = glob.glob("gpurun_out/trace/*/*kernel_trace.csv")
