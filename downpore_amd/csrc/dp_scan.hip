@@ -1038,7 +1038,14 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     int dev_cus = 256;
     hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus * (v2 ? 2 : 1), ((uint64_t)n_items + 15) / 16);
+    // persistent workgroups per CU: 2 fill every wave slot and all LDS of the CU (fastest scan in isolation) - and keep every
+    // other slot's kernels out until the scan is done; DP_SCAN_WG_PER_CU=1 leaves half of each CU to them
+    static const int wg_per_cu = [] {
+        const char* e = getenv("DP_SCAN_WG_PER_CU");
+        const int n = e ? atoi(e) : 2;
+        return n < 1 ? 1 : (n > 2 ? 2 : n);
+    }();
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus * (v2 ? wg_per_cu : 1), ((uint64_t)n_items + 15) / 16);
     uint64_t* totals = (uint64_t*)ctx->d_total.p;  // [0] n_segs, [1] n_survivors
     uint64_t* tilesA = totals + 4;
     uint64_t* tilesB = tilesA + n_tiles + 1;
