@@ -21,15 +21,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-def count_bytes_scan_mode(acc, samples):
-    return acc.get("count_bytes", 0.0) / max(1, samples)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--reads", type=int, default=100000)
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--k", type=int, default=13)
@@ -39,8 +35,8 @@ def main():
     ap.add_argument("--cpu-rounds", type=int, default=2, help="oracle rounds timed for cpu_baseline (0 = skip)")
     ap.add_argument("--slots", type=int, default=6, help="rounds executed concurrently per GPU (executor slots)")
     ap.add_argument("--index-steps", type=int, default=100,
-                    help="N=1: after the timed region, time this many further rounds with the resident k-mer position index "
-                         "instead of the scan (reported as index_mode; 0 = skip)")
+                    help="N=1: after the timed region, time this many further rounds in the other scan mode (index <-> scan "
+                         "kernels; reported as scan_kernels_leg / index_mode; 0 = skip)")
     ap.add_argument("--mode", default="round", choices=["round", "round-batch", "scan-shard"], help="multi-GPU decomposition (N > 1)")
     args = ap.parse_args()
 
@@ -49,7 +45,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and "DP_HOST_THREADS" not in os.environ:
         # one process per GPU on ONE host: the ranks share the container's CPU quota, so each gets its share of worker threads
-        os.environ["DP_HOST_THREADS"] = str(max(2, cpu_budget() // world))
+        os.environ["DP_HOST_THREADS"] = str(max(2, cpu_budget() // world - (1 if cpu_budget() // world > 3 else 0)))
     import torch
     torch_device = None
     if world > 1:
@@ -133,14 +129,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # Same job continued with the scan replaced by the resident k-mer position index (dp_kindex.hip; the default from
-    # 3 Gbase up).  Reported next to the headline number, never instead of it.
-    index_mode = None
-    if world == 1 and args.index_steps > 0 and "DP_SCAN_INDEX" not in os.environ and not acc.get("idx_rounds"):
+    # Same job continued in the OTHER scan mode (dp_scan_reads answers either from the resident k-mer position index,
+    # dp_kindex.hip - the default from 1 Gbase up - or by streaming the packed reads through scan_kernel).  Reported next
+    # to the headline number, never instead of it.
+    main_index = bool(acc.get("idx_rounds"))
+    alt = None
+    if world == 1 and args.index_steps > 0 and "DP_SCAN_INDEX" not in os.environ:
         pipe.drain()
-        os.environ["DP_SCAN_INDEX"] = "1"
+        os.environ["DP_SCAN_INDEX"] = "0" if main_index else "1"
         tb0 = time.perf_counter()
-        got = pipe.step()  # builds the index (one-off) and runs a round
+        got = pipe.step()  # (index mode: builds the index, one-off, and runs a round)
         tb1 = time.perf_counter()
         w2 = got
         while got and w2 < args.warmup:
@@ -165,17 +163,21 @@ def main():
         pipe.drain()
         if isteps:
             m = max(1, isamples)
-            index_mode = {"value": ilines / iel, "unit": "overlaps/s", "steps": isteps, "ms_per_step": 1e3 * iel / isteps,
-                          "first_round_incl_index_build_s": tb1 - tb0,
-                          "rounds_served_by_index": iacc.get("idx_rounds", 0.0),
-                          "seed_occurrences_per_step": iacc.get("idx_hits", 0.0) / m,
-                          "resident_bytes": 8 * int(reads.total_bases()) + 8 * (4 ** args.k + 1),
-                          "kernel_ms_per_step": {kk: iacc.get(kk, 0.0) / m for kk in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms")},
-                          "count_step_algorithmic_bytes": iacc.get("count_bytes", 0.0) / m,
-                          "scan_equivalent_GBs": (count_bytes_scan_mode(acc, samples) / 1e9) / (iacc.get("k_count_ms", 0.0) / m / 1e3)
-                          if iacc.get("k_count_ms", 0) > 0 else None,
-                          "note": "no kernel of this mode streams the reads; scan_equivalent_GBs = bytes the scan would have "
-                                  "read / time of the index counting step, an effective rate and not a roofline figure"}
+            alt = {"value": ilines / iel, "unit": "overlaps/s", "steps": isteps, "ms_per_step": 1e3 * iel / isteps,
+                   "kernel_ms_per_step": {kk: iacc.get(kk, 0.0) / m for kk in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms")},
+                   "count_step_algorithmic_bytes": iacc.get("count_bytes", 0.0) / m}
+            if main_index:  # the alternative leg streamed the reads: its count pass is the HBM-streaming kernel of the path
+                cms = iacc.get("k_count_ms", 0.0) / m
+                cb = iacc.get("count_bytes", 0.0) / m
+                alt["scan_count_pass"] = {"kernel": "scan_kernel<0>", "launch_ms": cms, "algorithmic_bytes_per_launch": cb,
+                                          "achieved_GBs": (cb / 1e9) / (cms / 1e3) if cms > 0 else 0.0,
+                                          "frac_of_hbm_peak": ((cb / 1e9) / (cms / 1e3)) / HBM_PEAK_GBS if cms > 0 else 0.0}
+            else:
+                alt.update({"first_round_incl_index_build_s": tb1 - tb0,
+                            "rounds_served_by_index": iacc.get("idx_rounds", 0.0),
+                            "seed_occurrences_per_step": iacc.get("idx_hits", 0.0) / m,
+                            "resident_bytes": 8 * int(reads.total_bases()) + 8 * (4 ** args.k + 1),
+                            "note": "no kernel of this mode streams the reads"})
 
     stream_gbs = None
     if rank == 0:
@@ -199,14 +201,27 @@ def main():
         n = max(1, samples)
         count_ms = acc.get("k_count_ms", 0.0) / n
         count_bytes = acc.get("count_bytes", 0.0) / n
-        achieved = (count_bytes / 1e9) / (count_ms / 1e3) if count_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
-        if os.path.exists(tpath) and not acc.get("idx_rounds"):  # the PMC figure is the scan kernel's
+        chain_ms = acc.get("k_chain_ms", 0.0) / n
+        chain_bytes = acc.get("chain_bytes", 0.0) / n
+
+        def pmc_traffic(name):
+            tpath = os.path.join(ROOT, "profiles", name)
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                return json.load(open(tpath)).get("hbm_bytes_per_launch") if os.path.exists(tpath) else None
             except Exception:
-                traffic = None
+                return None
+
+        if main_index:
+            # no kernel of the run streams the reads; the dominant kernel (by time, in the run and in the rocprofv3 trace) is
+            # chain_kernel: prefilter + seed chaining of every (query, candidate) pair, one wave per query, sequential over its
+            # candidates because of the minMatches ratchet (overlap.go:380-382) - latency-bound, priced against HBM all the same
+            rl_kernel = ("chain_kernel (A5 prefilter + A6/A7/A8 chaining; latency-bound: one wave walks a query's candidates in "
+                         "order) - the run used the resident k-mer position index, no kernel streams the reads")
+            rl_bytes, rl_ms, traffic = chain_bytes, chain_ms, pmc_traffic("chain_traffic.json")
+        else:
+            rl_kernel = "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)"
+            rl_bytes, rl_ms, traffic = count_bytes, count_ms, pmc_traffic("scan_traffic.json")
+        achieved = (rl_bytes / 1e9) / (rl_ms / 1e3) if rl_ms > 0 else 0.0
         out = {
             "metric": "overlaps/sec (all-vs-all PAF)", "value": lines / elapsed if elapsed > 0 else 0.0, "unit": "overlaps/s",
             "n_gpus": world, "steps": steps_done, "warmup": warm, "ms_per_step": 1e3 * elapsed / max(1, steps_done),
@@ -218,25 +233,28 @@ def main():
                                        "round-parallel over %d GPUs: rank r's executor pipeline runs the rounds r, r+N, ...; one round "
                                        "per rank all-gathered (RCCL) per superstep and committed in order" % world if args.mode.startswith("round") else
                                        "scan sharded by read over %d GPUs, survivors all-gathered (RCCL)" % world)},
-            "roofline": {"bound": "hbm", "kernel": ("index counting step (seed lookups, occurrence sort, per-item cuts; dp_kindex.hip) "
-                                                    "- the run used the resident k-mer position index, no kernel streams the reads"
-                                                    if acc.get("idx_rounds") else
-                                                    "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)"),
+            "roofline": {"bound": "hbm", "kernel": rl_kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": count_bytes, "launch_ms": count_ms,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": rl_bytes, "launch_ms": rl_ms,
                          "measured_stream_GBs": stream_gbs,
                          "frac_of_measured_stream": (achieved / stream_gbs) if stream_gbs else None},
             # the other kernels of a round, same convention (algorithmic bytes / HIP-event time); chain_kernel is a
             # latency-bound per-query state machine, its byte rate is reported for completeness only
             "other_kernels": {
-                "scan_write_pass": {"ms": acc.get("k_write_ms", 0.0) / n,
-                                    "algorithmic_bytes": (acc.get("scan_bytes", 0.0) - acc.get("count_bytes", 0.0)) / n},
+                ("index_counting_step" if main_index else "scan_count_pass"): {
+                    "ms": count_ms, "algorithmic_bytes": count_bytes,
+                    "GBs": (count_bytes / 1e9) / (count_ms / 1e3) if count_ms > 0 else 0.0},
+                ("index_write" if main_index else "scan_write_pass"): {
+                    "ms": acc.get("k_write_ms", 0.0) / n,
+                    "algorithmic_bytes": (acc.get("scan_bytes", 0.0) - acc.get("count_bytes", 0.0)) / n},
                 "index_query": {"ms": acc.get("k_query_ms", 0.0) / n, "algorithmic_bytes": acc.get("query_bytes", 0.0) / n,
                                 "GBs": (acc.get("query_bytes", 0.0) / 1e9) / (acc.get("k_query_ms", 0.0) / 1e3) if acc.get("k_query_ms", 0) > 0 else 0.0},
-                "chain_kernel": {"ms": acc.get("k_chain_ms", 0.0) / n, "bound": "latency (sequential ratchet per query)",
+                "chain_kernel": {"ms": chain_ms, "bound": "latency (sequential ratchet per query)", "algorithmic_bytes": chain_bytes,
+                                 "GBs": (chain_bytes / 1e9) / (chain_ms / 1e3) if chain_ms > 0 else 0.0,
                                  "matches_per_step": acc.get("n_matches", 0.0) / n},
             },
-            "index_mode": index_mode,
+            "scan_mode": "resident k-mer position index" if main_index else "scan kernels",
+            ("scan_kernels_leg" if main_index else "index_mode"): alt,
             "paf_lines": lines, "rounds_per_s": steps_done / elapsed if elapsed > 0 else 0.0,
             "reads_scanned_per_s": (acc.get("scan_items", 0.0) / n) * steps_done / elapsed if elapsed > 0 else 0.0,
             "phase_ms_per_step": {kk: 1e3 * acc.get(kk, 0.0) / n for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},

@@ -1295,6 +1295,9 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
         int minMatches = RFL(nSeeds < mc_n ? mc[nSeeds] : 0x7fffffff);  // int(hitFraction*numSeeds+0.5), overlap.go:356
         u64 tq0 = dbg ? wall_clock64() : 0, tAlign = 0, tExtract = 0, tStage = 0, nCand = 0, nPairs = 0;
         u64 tp[3] = {0, 0, 0};
+        // algorithmic bytes of this query's share: two bitset rows per candidate (the exact-intersection
+        // prefilter), both segment arrays per chained pair (4-byte ints here), the chain written out
+        u64 algBytes = 0;
         for (uint32_t wi = 0; wi < W; wi++) {
             u64 mask = cand[(uint64_t)q * W + wi];
             while (mask) {
@@ -1303,6 +1306,7 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                 const uint32_t t = wi * 64 + (uint32_t)b;
                 const u64* tset = seedsets + (uint64_t)t * SW;
                 nCand++;
+                algBytes += 16ull * SW;
                 u64 ts0 = dbg ? wall_clock64() : 0;
                 // CountIntersectionTo(seedSet, minMatches) < minMatches  (overlap.go:359; the asm's early exit only
                 // ever returns a value >= maxCount, so the comparison equals the one on the full popcount)
@@ -1341,6 +1345,7 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                 int resLen = 0, resNode = -1, usedTier = 3;
                 uint32_t err = 0;
                 nPairs++;
+                algBytes += 4ull * (u64)(aN + bN);
                 u64 ta0 = dbg ? wall_clock64() : 0;
                 tStage += ta0 - ts0;
                 if (staged) {
@@ -1404,11 +1409,13 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
                     }
                 }
                 if (resLen > 0) {
+                    algBytes += 8ull * (u64)resLen;
                     if (resLen * 2 > minMatches * 3) minMatches = (resLen * 2) / 3;  // ratchet, overlap.go:380-382
                     if (dbg) tExtract += wall_clock64() - ta1;
                 }
             }
         }
+        if (lane == 0 && algBytes) atomicAdd((unsigned long long*)(cursor + 4), (unsigned long long)algBytes);
         if (dbg && lane == 0) {
             dbg[8 * q + 0] = wall_clock64() - tq0;
             dbg[8 * q + 1] = tAlign;
@@ -1572,6 +1579,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     hipEventElapsedTime(&qms, ctx->ev[4], ctx->ev[5]);
     out->query_kernel_ms = qms;
     out->chain_kernel_ms = chain_ms;
+    out->chain_bytes = (uint64_t)cur[4] | ((uint64_t)cur[5] << 32);
     if (cur[2]) {
         char msg[160];
         snprintf(msg, sizeof msg, "overlap chaining hit a reference capacity limit (bits %u: 1 reduced buffer, 2 state pool, 4 results, 8 nodes)", cur[2]);

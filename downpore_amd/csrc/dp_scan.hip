@@ -98,31 +98,47 @@ int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e) {
     return code;
 }
 
+// Growing a buffer: twice the request (rounds vary in size and every growth is a hipMalloc / hipHostMalloc of megabytes),
+// and the outgrown buffer is NOT freed here - hipFree / hipHostFree wait for the whole device, i.e. for every other
+// executor slot's kernels, which showed up as 20-30 ms stalls a few times per hundred rounds.  Old buffers go to the
+// context's retired list and are released with the context (their total is below the live size: geometric growth).
+// DP_ALLOC_TRACE=1: one stderr line per growth (what, bytes, how long the allocation call took)
+static bool alloc_trace() {
+    static const bool on = getenv("DP_ALLOC_TRACE") != nullptr;
+    return on;
+}
+static double alloc_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int dev_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes, bool keep) {
     if (bytes <= b.cap) return 0;
-    size_t ncap = std::max(bytes, b.cap + b.cap / 2);
+    const double t0 = alloc_trace() ? alloc_now() : 0;
+    // (per-round buffers get head room; the big resident ones - packed reads, k-mer index - are sized exactly)
+    size_t ncap = bytes > ((size_t)256 << 20) ? bytes : std::max(bytes + bytes / 2, b.cap * 2);
     ncap = (ncap + 255) & ~(size_t)255;
     void* np = nullptr;
     DP_HIP(hipMalloc(&np, ncap));
     if (b.p) {
         if (keep) DP_HIP(hipMemcpyAsync(np, b.p, b.cap, hipMemcpyDeviceToDevice, ctx->stream));
-        DP_HIP(dp_stream_sync(ctx));
-        DP_HIP(hipFree(b.p));
+        ctx->retired_dev.push_back(b.p);  // (work already queued on the stream may still read it)
     }
+    if (alloc_trace()) fprintf(stderr, "[alloc] device %zu -> %zu bytes, %.3f ms\n", b.cap, ncap, 1e3 * (alloc_now() - t0));
     b.p = np;
     b.cap = ncap;
     return 0;
 }
 int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;
-    size_t ncap = std::max(bytes, b.cap + b.cap / 2);
+    size_t ncap = bytes > ((size_t)256 << 20) ? bytes : std::max(bytes + bytes / 2, b.cap * 2);
     ncap = (ncap + 4095) & ~(size_t)4095;
     void* np = nullptr;
+    const double t0 = alloc_trace() ? alloc_now() : 0;
     DP_HIP(hipHostMalloc(&np, ncap, hipHostMallocDefault));
-    if (b.p) {
-        DP_HIP(dp_stream_sync(ctx));
-        DP_HIP(hipHostFree(b.p));
-    }
+    if (alloc_trace()) fprintf(stderr, "[alloc] pinned %zu -> %zu bytes, %.3f ms\n", b.cap, ncap, 1e3 * (alloc_now() - t0));
+    if (b.p) ctx->retired_pin.push_back(b.p);
     b.p = np;
     b.cap = ncap;
     return 0;
@@ -185,6 +201,8 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
                      &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals, &ctx->d_manchor};
     for (auto* b : dbs)
         if (b->p) hipFree(b->p);
+    for (void* q : ctx->retired_dev) hipFree(q);
+    for (void* q : ctx->retired_pin) hipHostFree(q);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
                      &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
     for (auto* b : pbs)
@@ -1053,9 +1071,9 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     uint32_t* s_count = s_item + n_items;
     uint64_t* s_off = (uint64_t*)(s_count + n_items + (n_items & 1));
     // Resident k-mer position index instead of scanning (dp_kindex.hip): DP_SCAN_INDEX=1 forces it, =0 forbids it; by
-    // default it is used from 3 Gbase up, where the scan is what bounds a round (its one-off build costs about as much as
-    // all the scans of a config-2 sized job together).
-    bool use_index = ctx->total_bases >= 3000000000ull || (ctx->owner && ctx->owner->total_bases >= 3000000000ull);
+    // default it is used from 1 Gbase up.  That is the break-even of a whole job: the build costs ~0.13 s per Gbase, a
+    // round saves (scan 0.5 ms per Gbase) - (index step 0.25 ms), and a job has ~600 rounds per Gbase of 10 kb reads.
+    bool use_index = ctx->total_bases >= 1000000000ull || (ctx->owner && ctx->owner->total_bases >= 1000000000ull);
     if (const char* e = getenv("DP_SCAN_INDEX")) use_index = e[0] == '1';
     std::unique_lock<ScanGate> scan_lock(g_scan_mu, std::defer_lock);
     if (use_index) {

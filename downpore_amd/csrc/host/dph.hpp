@@ -232,6 +232,7 @@ struct RoundStats {
     uint64_t count_bytes = 0;                                                     // algorithmic bytes of the count pass
     uint64_t scan_bases = 0, scan_items = 0, scan_bytes = 0, query_bytes = 0;
     uint64_t n_queries = 0, n_indexed = 0, n_hits = 0, n_matches = 0, n_paf = 0, n_seeds = 0;
+    uint64_t chain_bytes = 0;               // algorithmic bytes of the prefilter + chaining kernel
     uint64_t idx_rounds = 0, idx_hits = 0;  // rounds served by the resident k-mer position index, and their seed occurrences
 };
 

@@ -15,7 +15,24 @@ struct OverlapH {
     OverlapRun run;
     dp_ctx* ctx = nullptr;
     std::string err;
-    std::string allPaf;
+    // PAF of every committed round so far.  Kept as one chunk per commit and joined only when somebody asks for the
+    // whole text: appending to one growing std::string re-copied up to 128 MB at every doubling (20-30 ms stalls of the
+    // committing thread at rounds ~80, ~165, ~330 of a config-2 job).
+    std::vector<std::string> pafChunks;
+    std::string allPafJoined;
+    void addPaf(const std::string& s) {
+        if (!s.empty()) pafChunks.push_back(s);
+    }
+    const std::string& allPaf() {
+        if (!pafChunks.empty()) {
+            size_t n = allPafJoined.size();
+            for (const std::string& c : pafChunks) n += c.size();
+            allPafJoined.reserve(n);
+            for (const std::string& c : pafChunks) allPafJoined += c;
+            pafChunks.clear();
+        }
+        return allPafJoined;
+    }
 };
 thread_local std::string g_err;
 }  // namespace
@@ -151,7 +168,7 @@ int dph_overlap_round_finish(void* hh, const uint32_t* read, const uint32_t* nse
         rc = h->run.roundFinish(all);
     }
     if (rc < 0) h->err = h->run.error;
-    else h->allPaf += h->run.paf;
+    else h->addPaf(h->run.paf);
     return rc;
 }
 const char* dph_overlap_round_paf(void* hh, int64_t* n) {
@@ -161,8 +178,9 @@ const char* dph_overlap_round_paf(void* hh, int64_t* n) {
 }
 const char* dph_overlap_all_paf(void* hh, int64_t* n) {
     OverlapH* h = (OverlapH*)hh;
-    *n = (int64_t)h->allPaf.size();
-    return h->allPaf.data();
+    const std::string& all = h->allPaf();
+    *n = (int64_t)all.size();
+    return all.data();
 }
 const char* dph_overlap_errtext(void* hh, int64_t* n) {
     OverlapH* h = (OverlapH*)hh;
@@ -171,7 +189,7 @@ const char* dph_overlap_errtext(void* hh, int64_t* n) {
 }
 // out[0..] t_prepare,t_scan,t_index,t_query,t_consensus,k_scan_ms,k_query_ms,k_chain_ms,scan_bases,scan_items,
 // scan_bytes,query_bytes,n_queries,n_indexed,n_hits,n_matches,n_paf,n_seeds,round,badBack,emptyMatch,k_count_ms,
-// k_write_ms,count_bytes,k_cons_ms,idx_rounds,idx_hits
+// k_write_ms,count_bytes,k_cons_ms,idx_rounds,idx_hits,chain_bytes
 void dph_overlap_stats(void* hh, double* out) {
     OverlapH* h = (OverlapH*)hh;
     const RoundStats& s = h->run.last;
@@ -179,7 +197,7 @@ void dph_overlap_stats(void* hh, double* out) {
                   (double)s.scan_bases, (double)s.scan_items, (double)s.scan_bytes, (double)s.query_bytes, (double)s.n_queries,
                   (double)s.n_indexed, (double)s.n_hits, (double)s.n_matches, (double)s.n_paf, (double)s.n_seeds,
                   (double)h->run.round, (double)h->run.badBack, (double)h->run.emptyMatch, s.k_count_ms, s.k_write_ms,
-                  (double)s.count_bytes, s.k_cons_ms, (double)s.idx_rounds, (double)s.idx_hits};
+                  (double)s.count_bytes, s.k_cons_ms, (double)s.idx_rounds, (double)s.idx_hits, (double)s.chain_bytes};
     memcpy(out, v, sizeof v);
 }
 void* dph_overlap_ctx(void* hh) { return ((OverlapH*)hh)->ctx; }
@@ -189,7 +207,7 @@ int dph_overlap_step(void* hh) {
     OverlapH* h = (OverlapH*)hh;
     int rc = h->run.step();
     if (rc < 0) h->err = h->run.error;
-    else if (rc > 0) h->allPaf += h->run.paf;
+    else if (rc > 0) h->addPaf(h->run.paf);
     return rc;
 }
 int64_t dph_overlap_round(void* hh) { return ((OverlapH*)hh)->run.round; }
@@ -304,7 +322,7 @@ int dph_overlap_commit_gathered(void* hh, const uint8_t* blobs, const uint64_t* 
     std::vector<RoundResult> rs;
     deserialise(blobs, sizes, count, rs);
     int c = h->run.commitGathered(rs);
-    if (c > 0) h->allPaf += h->run.paf;
+    if (c > 0) h->addPaf(h->run.paf);
     return c;
 }
 
@@ -314,7 +332,7 @@ int dph_overlap_commit_blobs(void* hh, const uint8_t* blobs, const uint64_t* siz
     deserialise(blobs, sizes, count, rs);
     std::sort(rs.begin(), rs.end(), [](const RoundResult& a, const RoundResult& b) { return a.round < b.round; });
     int c = h->run.commitResults(rs);
-    if (c > 0) h->allPaf += h->run.paf;
+    if (c > 0) h->addPaf(h->run.paf);
     return c;
 }
 int dph_overlap_done(void* hh) { return ((OverlapH*)hh)->run.done ? 1 : 0; }

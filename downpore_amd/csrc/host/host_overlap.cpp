@@ -401,6 +401,7 @@ int Overlapper::FindOverlaps(std::vector<SeedMatch>& pool, std::vector<SeedMatch
     st.k_query_ms += mb.query_kernel_ms;
     st.k_chain_ms += mb.chain_kernel_ms;
     st.query_bytes += mb.query_bytes;
+    st.chain_bytes += mb.chain_bytes;
     out.clear();
     out.reserve(mb.n_matches);
     if (pool.size() < mb.n_matches) pool.resize(mb.n_matches);

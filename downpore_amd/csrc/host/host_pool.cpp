@@ -42,7 +42,14 @@ static unsigned cpuBudget() {
         }
         if (q > 0 && per > 0) quota = (double)q / (double)per;
     }
-    if (quota >= 1.0 && quota < (double)hw) hw = (unsigned)quota;
+    if (quota >= 1.0 && quota < (double)hw) {
+        // Under a quota the pool must not be able to use all of it: the executor-slot threads, the planner and the HIP
+        // runtime's own threads run next to it, and a process that overdraws its quota is stopped whole for the rest of
+        // the 100 ms scheduler period (seen as 15-30 ms stalls of every slot a few times per hundred rounds, GPU idle).
+        hw = (unsigned)quota;
+        const unsigned reserve = std::max(2u, hw / 5);
+        hw = hw > reserve + 1 ? hw - reserve : 1;
+    }
     return hw;
 }
 

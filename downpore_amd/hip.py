@@ -34,7 +34,8 @@ class MatchBatch(C.Structure):
     _fields_ = [("n_matches", C.c_uint32), ("query", C.POINTER(C.c_uint32)), ("target", C.POINTER(C.c_uint32)),
                 ("off", C.POINTER(C.c_uint64)), ("match_a", C.POINTER(C.c_int32)), ("match_b", C.POINTER(C.c_int32)),
                 ("target_anchor", C.POINTER(C.c_int32)), ("n_queries", C.c_uint32), ("cand_off", C.POINTER(C.c_uint64)), ("cand", C.POINTER(C.c_uint32)),
-                ("query_kernel_ms", C.c_double), ("chain_kernel_ms", C.c_double), ("query_bytes", C.c_uint64)]
+                ("query_kernel_ms", C.c_double), ("chain_kernel_ms", C.c_double), ("query_bytes", C.c_uint64),
+                ("chain_bytes", C.c_uint64)]
 
 
 class ChainBatch(C.Structure):
@@ -253,7 +254,8 @@ class Context:
         res = dict(query=_arr(b.query, nm, np.uint32), target=_arr(b.target, nm, np.uint32), off=off,
                    match_a=_arr(b.match_a, tot, np.int32), match_b=_arr(b.match_b, tot, np.int32),
                    target_anchor=_arr(b.target_anchor, 2 * nm, np.int32).reshape(-1, 2),
-                   query_kernel_ms=b.query_kernel_ms, chain_kernel_ms=b.chain_kernel_ms, query_bytes=b.query_bytes)
+                   query_kernel_ms=b.query_kernel_ms, chain_kernel_ms=b.chain_kernel_ms, query_bytes=b.query_bytes,
+                   chain_bytes=b.chain_bytes)
         if want_candidates:
             co = _arr(b.cand_off, b.n_queries + 1, np.uint64)
             res["cand_off"] = co

@@ -196,6 +196,8 @@ typedef struct {
     double query_kernel_ms;   /* device time of the soft-union (index query) kernel */
     double chain_kernel_ms;   /* device time of the prefilter+chaining kernel */
     uint64_t query_bytes;     /* algorithmic bytes of the index query (posting words inside windows * 8) */
+    uint64_t chain_bytes;     /* ... of the prefilter + chaining kernel: 2 bitset rows per candidate, both segment arrays
+                               * per chained pair, the chains written (counted by the kernel itself) */
 } dp_match_batch;
 
 int dp_find_overlaps(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t n_queries,
