@@ -188,6 +188,19 @@ extern "C" int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out) {
     return DP_OK;
 }
 
+extern "C" int dp_ctx_set_priority(dp_ctx* ctx, int high) {
+    if (!ctx) return DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    int least = 0, greatest = 0;
+    DP_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));  // numerically lower = higher priority
+    DP_HIP(hipStreamSynchronize(ctx->stream));
+    hipStream_t s = nullptr;
+    DP_HIP(hipStreamCreateWithPriority(&s, hipStreamDefault, high ? greatest : least));
+    hipStreamDestroy(ctx->stream);
+    ctx->stream = s;
+    return DP_OK;
+}
+
 extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);

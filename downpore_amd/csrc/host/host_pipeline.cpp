@@ -355,6 +355,11 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
             error = dp_last_error(nullptr);
             return rc;
         }
+        // the plan chain is sequential and waits for one small selection kernel per plan: it should not queue behind the
+        // executor slots' kernels.  (Measured neutral on config 2 - there the planner's wait grows because the process is
+        // at its CPU quota, not because of the GPU queue - kept because it is the right order of service.)
+        const char* np = getenv("DP_PLANNER_PRIORITY");
+        if (!(np && np[0] == '0')) dp_ctx_set_priority(plannerCtx, 1);
     }
     planner.reset(new Planner(*reads, p, values.data(), !(nothread && nothread[0] == '1'), plannerCtx));
     mark("planner");

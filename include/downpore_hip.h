@@ -47,6 +47,10 @@ int dp_ctx_create(int device, dp_ctx** out);
 /* A second context on the same device that BORROWS the resident reads of `src` (no copy): lets several host threads
  * drive independent rounds concurrently, each with its own stream and per-round state.  Destroy it before `src`. */
 int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out);
+/* Give the context's stream the device's highest (high != 0) or default scheduling priority.  For the context of a
+ * latency-critical caller next to throughput work - the goroutine that runs PrepareQueries (overlap/overlap.go:157) and
+ * waits for dp_select_seeds while other contexts keep the GPU busy with whole rounds.  Call it while the context is idle. */
+int dp_ctx_set_priority(dp_ctx* ctx, int high);
 void dp_ctx_destroy(dp_ctx* ctx);
 const char* dp_last_error(const dp_ctx* ctx); /* ctx may be NULL: error of the last failed dp_ctx_create */
 
