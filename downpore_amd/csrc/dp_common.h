@@ -76,6 +76,8 @@ struct dp_ctx {
     DevBuf d_seqrefs, d_posting, d_seedsets, d_pmeta;  // pmeta: uint32 {count,start,end,lens} per seed
 
     // ---- overlaps (A14..A8)
+    void* d_kcounts = nullptr;  // k-mer histogram (uint32 [4^kcounts_k]) left behind by dp_kmer_values for the k-mer index build
+    int kcounts_k = 0;
     std::vector<void*> retired_dev, retired_pin;  // outgrown buffers, released with the context (dev_reserve / pin_reserve)
     DevBuf d_qsegs, d_qoff, d_qsets, d_qmeta, d_cand, d_pool, d_mrec, d_ma, d_mb, d_cursor, d_sched, d_manchor;
     PinBuf h_mrec, h_ma, h_mb, h_ta, h_tb, h_qm, h_qup, h_cursor, h_cand, h_cand_off, h_cand_list, h_mq, h_mt, h_moff, h_manchor, h_manout;

@@ -117,12 +117,18 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
     }
     // count -> offsets -> scatter, on the CALLER's stream (the owner's buffers are only written here, under the mutex)
     void* d_counts = nullptr;
-    DP_HIP(hipMalloc(&d_counts, nk * 4));
-    DP_HIP(hipMemsetAsync(d_counts, 0, nk * 4, ctx->stream));
-    if (ow->n_reads)
-        hipLaunchKernelGGL(kidx_count_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint8_t*)ow->d_packed.p,
-                           (const uint64_t*)ow->d_boff.p, (const uint32_t*)ow->d_len.p, ow->n_reads, k, (uint32_t*)d_counts);
-    DP_HIP(hipGetLastError());
+    if (ow->d_kcounts && ow->kcounts_k == k) {  // dp_kmer_values counted exactly these k-mers already
+        d_counts = ow->d_kcounts;
+        ow->d_kcounts = nullptr;
+        ow->kcounts_k = 0;
+    } else {
+        DP_HIP(hipMalloc(&d_counts, nk * 4));
+        DP_HIP(hipMemsetAsync(d_counts, 0, nk * 4, ctx->stream));
+        if (ow->n_reads)
+            hipLaunchKernelGGL(kidx_count_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint8_t*)ow->d_packed.p,
+                               (const uint64_t*)ow->d_boff.p, (const uint32_t*)ow->d_len.p, ow->n_reads, k, (uint32_t*)d_counts);
+        DP_HIP(hipGetLastError());
+    }
     if (dev_reserve(ctx, ix->off, (nk + 1) * 8)) return DP_ERR_HIP;
     size_t tmp_bytes = 0;
     rocprim::exclusive_scan(nullptr, tmp_bytes, (uint32_t*)d_counts, (uint64_t*)ix->off.p, (uint64_t)0, nk + 1, rocprim::plus<uint64_t>(),

@@ -214,6 +214,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
                      &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals, &ctx->d_manchor};
     for (auto* b : dbs)
         if (b->p) hipFree(b->p);
+    if (ctx->d_kcounts) hipFree(ctx->d_kcounts);
     for (void* q : ctx->retired_dev) hipFree(q);
     for (void* q : ctx->retired_pin) hipHostFree(q);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
@@ -281,6 +282,11 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
     if (first_paired > n_host) first_paired = n_host;
     hipSetDevice(ctx->device);
     dp_kindex_free(ctx);  // a position index of the previous read set is void
+    if (ctx->d_kcounts) {   // ... and so is its k-mer histogram
+        hipFree(ctx->d_kcounts);
+        ctx->d_kcounts = nullptr;
+        ctx->kcounts_k = 0;
+    }
     const uint64_t nd64 = (uint64_t)first_paired + 2ull * (n_host - first_paired);
     if (nd64 > 0x7fffffffull) return dp_fail(ctx, DP_ERR_ARG, "too many reads");
     const uint32_t n_reads = (uint32_t)nd64;

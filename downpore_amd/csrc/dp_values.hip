@@ -162,6 +162,12 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     }
     if (values_out) DPV(hipMemcpyAsync(values_out, values, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DPV(dp_stream_sync(ctx));
+    // the histogram is what the k-mer position index build counts first (dp_kindex_ensure): keep it (4^k * 4 bytes) until
+    // the index has used it or the reads are replaced
+    if (ctx->d_kcounts) hipFree(ctx->d_kcounts);
+    ctx->d_kcounts = d_counts;
+    ctx->kcounts_k = k;
+    d_counts = nullptr;
     cleanup();
     ctx->n_values = n;
 #undef DPV
