@@ -783,6 +783,13 @@ static SeedSeq* multiAlignerCore(Arena& arena, std::vector<SeedSeq*>& seqs, std:
                 nValid++;
             }
         }
+#ifdef DPH_FINE
+        g_fine.cyc[8] += 1;                                                 // steps
+        if (uniform && inStep && nValid >= 2) g_fine.cyc[9] += 1;            // ... taken by the fast path
+        if (!inStep) g_fine.cyc[10] += 1;                                   // ... with a sequence out of step
+        else if (!uniform) g_fine.cyc[11] += 1;                             // ... in step but disagreeing
+        else if (nValid < 2) g_fine.cyc[12] += 1;                           // ... fewer than 2 live sequences
+#endif
         if (uniformFast && uniform && inStep && narrow && nValid >= 2 && o0 > -k && o0 < 100000) {
             // Every sequence that still has a seed is in step (gap 0) and shows the same seed at the same distance.  Then
             // the general code below does nothing but agree: each of them proposes (d = o0 < near, which only drops to

@@ -36,11 +36,15 @@ struct FineProfile {
     }
     ~FineProfile() {
         long long tot = 0;
-        for (auto& c : cyc) tot += c.load();
+        for (int i = 0; i < 8; i++) tot += cyc[i].load();
         if (!tot) return;
         fprintf(stderr, "[fine]");
         for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", name[i], 100.0 * cyc[i].load() / tot);
         fprintf(stderr, " | total %.3f Gcycles\n", tot / 1e9);
+        if (cyc[8].load())
+            fprintf(stderr, "[fine] consensus steps %lld: uniform %.1f%%, out of step %.1f%%, in step but disagreeing %.1f%%, <2 live %.1f%%\n",
+                    cyc[8].load(), 100.0 * cyc[9].load() / cyc[8].load(), 100.0 * cyc[10].load() / cyc[8].load(),
+                    100.0 * cyc[11].load() / cyc[8].load(), 100.0 * cyc[12].load() / cyc[8].load());
     }
 };
 extern FineProfile g_fine;
