@@ -442,8 +442,9 @@ static void finalCheckEmit(SeedContig* contig, const SeedIndex& index, const Rea
     FINE(7);
     if (contig->SeqLengths[0] <= overlapSize * 2) ignoreIds.push_back(contig->Parts[0]);
     const i64 queryStart = contig->Offsets[0], queryEnd = queryStart + contig->Lengths[0];
-    char num[24];
-    auto app = [&](i64 v) {  // %d
+    // one line = 12 tab-separated fields (commands/overlap.go:223-228): written into the string's own storage in one go
+    auto put = [](char* w, i64 v) -> char* {  // %d
+        char num[24];
         char* e = num + sizeof num;
         char* p = e;
         uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
@@ -452,8 +453,10 @@ static void finalCheckEmit(SeedContig* contig, const SeedIndex& index, const Rea
             u /= 10;
         } while (u);
         if (v < 0) *--p = '-';
-        paf.append(p, (size_t)(e - p));
+        memcpy(w, p, (size_t)(e - p));
+        return w + (e - p);
     };
+    const std::string& qName = reads.names[(size_t)contig->Parts[0]];
     for (size_t i = 0; i + 1 < contig->Parts.size(); i++) {
         const size_t id = i + 1;
         const int part = contig->Parts[id];
@@ -466,26 +469,35 @@ static void finalCheckEmit(SeedContig* contig, const SeedIndex& index, const Rea
         bool panic = false;
         matchBasesCovered(*contig->Matches[i], k, &ident, &identB, &panic);
         if (panic) fs.emptyMatch++;  // the reference panics here; canonical: ident 0
-        paf += reads.names[(size_t)contig->Parts[0]];
-        paf += '\t';
-        app(contig->SeqLengths[0]);
-        paf += '\t';
-        app(queryStart);
-        paf += '\t';
-        app(queryEnd);
-        paf += '\t';
-        paf += rcs;
-        paf += '\t';
-        paf += reads.names[(size_t)part];
-        paf += '\t';
-        app(contig->SeqLengths[id]);
-        paf += '\t';
-        app(start);
-        paf += '\t';
-        app(end);
-        paf += '\t';
-        app(ident);
-        paf += "\t0\t255\n";
+        const std::string& tName = reads.names[(size_t)part];
+        const size_t old = paf.size(), need = qName.size() + tName.size() + 7 * 21 + 24;
+        if (paf.capacity() < old + need) paf.reserve(std::max(old + need, paf.capacity() * 2));
+        paf.resize(old + need);
+        char* w = &paf[old];
+        memcpy(w, qName.data(), qName.size());
+        w += qName.size();
+        *w++ = '\t';
+        w = put(w, contig->SeqLengths[0]);
+        *w++ = '\t';
+        w = put(w, queryStart);
+        *w++ = '\t';
+        w = put(w, queryEnd);
+        *w++ = '\t';
+        *w++ = rcs[0];
+        *w++ = '\t';
+        memcpy(w, tName.data(), tName.size());
+        w += tName.size();
+        *w++ = '\t';
+        w = put(w, contig->SeqLengths[id]);
+        *w++ = '\t';
+        w = put(w, start);
+        *w++ = '\t';
+        w = put(w, end);
+        *w++ = '\t';
+        w = put(w, ident);
+        memcpy(w, "\t0\t255\n", 7);
+        w += 7;
+        paf.resize((size_t)(w - paf.data()));
         fs.lines++;
     }
 }

@@ -593,25 +593,48 @@ static const std::vector<uint64_t>& seedsSharedByTwo(const std::vector<SeedSeq*>
     int maxSeed = 100;
     for (auto* s : seqs) maxSeed = std::max(maxSeed, s->maxSeed());
     const size_t W = (size_t)maxSeed / 64 + 1;
-    // sparse form of the word-wise ladder: a seed is shared once a SECOND sequence shows it (row = seen in this sequence)
-    static thread_local std::vector<uint64_t> v1, v2, row;
-    static thread_local std::vector<uint32_t> touched;
-    v1.assign(W, 0);
+    // sparse form of the word-wise ladder: a seed is shared once a SECOND sequence shows it.  Per seed id one 32-bit
+    // stamp (sequence number that touched it last, in this call) and a flag "already shared"; the stamps are never
+    // cleared, a call counter makes old ones stale.
+    static thread_local std::vector<uint64_t> v2;
+    static thread_local std::vector<uint32_t> stamp;  // (call << 8 | sequence + 1) truncated: see below
+    static thread_local uint32_t call = 0;
     v2.assign(W, 0);
-    if (row.size() < W) row.resize(W, 0);
+    if (stamp.size() < W * 64) stamp.resize(W * 64, 0);
+    const size_t ns = seqs.size();
+    if (ns >= 0xffff || ++call >= 0xffff) {  // stamps hold 16 bits of call and 16 bits of sequence number
+        std::fill(stamp.begin(), stamp.end(), 0u);
+        call = 1;
+    }
+    if (ns >= 0xffff) {  // (never in practice) fall back to the three-bitset form
+        static thread_local std::vector<uint64_t> v1, row;
+        v1.assign(W, 0);
+        row.assign(W, 0);
+        for (auto* s : seqs) {
+            for (int j = 1; j < s->n; j += 2) {
+                const uint32_t sd = (uint32_t)s->seg[j];
+                const uint64_t bit = 1ull << (sd & 63);
+                if (row[sd >> 6] & bit) continue;
+                row[sd >> 6] |= bit;
+                if (v1[sd >> 6] & bit) v2[sd >> 6] |= bit;
+                else v1[sd >> 6] |= bit;
+            }
+            for (int j = 1; j < s->n; j += 2) row[(uint32_t)s->seg[j] >> 6] = 0;
+        }
+        return v2;
+    }
+    const uint32_t base = call << 16;
+    uint32_t q = 0;
     for (auto* s : seqs) {
-        touched.clear();
+        q++;
+        const uint32_t mine = base | q;
         for (int j = 1; j < s->n; j += 2) {
             const uint32_t sd = (uint32_t)s->seg[j];
-            const uint64_t bit = 1ull << (sd & 63);
-            uint64_t& r = row[sd >> 6];
-            if (r & bit) continue;
-            if (r == 0) touched.push_back(sd >> 6);
-            r |= bit;
-            if (v1[sd >> 6] & bit) v2[sd >> 6] |= bit;
-            else v1[sd >> 6] |= bit;
+            const uint32_t st = stamp[sd];
+            if (st == mine) continue;                 // seen in this sequence already
+            if ((st >> 16) == call) v2[sd >> 6] |= 1ull << (sd & 63);  // an earlier sequence of this call showed it
+            stamp[sd] = mine;
         }
-        for (uint32_t w : touched) row[w] = 0;
     }
     return v2;
 }
