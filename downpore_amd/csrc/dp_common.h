@@ -76,6 +76,9 @@ struct dp_ctx {
     DevBuf d_seqrefs, d_posting, d_seedsets, d_pmeta;  // pmeta: uint32 {count,start,end,lens} per seed
 
     // ---- overlaps (A14..A8)
+    DevBuf d_seeds_applied;     // the seed list currently written into d_bits / d_kmap (they are brought up to date lazily)
+    uint32_t n_applied = 0;
+    bool tables_dirty = false;
     void* d_kcounts = nullptr;  // k-mer histogram (uint32 [4^kcounts_k]) left behind by dp_kmer_values for the k-mer index build
     int kcounts_k = 0;
     std::vector<void*> retired_dev, retired_pin;  // outgrown buffers, released with the context (dev_reserve / pin_reserve)

@@ -211,7 +211,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
                      &ctx->d_counts, &ctx->d_segoff, &ctx->d_segs, &ctx->d_total, &ctx->d_seqrefs, &ctx->d_posting,
                      &ctx->d_seedsets, &ctx->d_pmeta, &ctx->d_qsegs, &ctx->d_qoff, &ctx->d_qsets, &ctx->d_qmeta,
                      &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched, &ctx->d_ignore, &ctx->d_surv, &ctx->d_values, &ctx->d_selwin, &ctx->d_seltop, &ctx->d_cin, &ctx->d_cout,
-                     &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals, &ctx->d_manchor};
+                     &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals, &ctx->d_manchor, &ctx->d_seeds_applied};
     for (auto* b : dbs)
         if (b->p) hipFree(b->p);
     if (ctx->d_kcounts) hipFree(ctx->d_kcounts);
@@ -581,6 +581,24 @@ __global__ void seeds_apply_kernel(const uint32_t* __restrict__ seeds, uint32_t 
     }
 }
 
+// d_bits / d_kmap := the current seed list (clear the list applied last, set this one); called before a scan kernel
+static int seed_tables_ensure(dp_ctx* ctx) {
+    if (!ctx->tables_dirty) return DP_OK;
+    if (ctx->n_applied)
+        hipLaunchKernelGGL(seeds_apply_kernel, dim3((ctx->n_applied + 255) / 256), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)ctx->d_seeds_applied.p, ctx->n_applied, (uint32_t*)ctx->d_bits.p, (int32_t*)ctx->d_kmap.p, 0);
+    if (dev_reserve(ctx, ctx->d_seeds_applied, (size_t)ctx->n_seeds * 4 + 4)) return DP_ERR_HIP;
+    if (ctx->n_seeds) {
+        DP_HIP(hipMemcpyAsync(ctx->d_seeds_applied.p, ctx->d_seeds.p, (size_t)ctx->n_seeds * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(seeds_apply_kernel, dim3((ctx->n_seeds + 255) / 256), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (uint32_t*)ctx->d_bits.p, (int32_t*)ctx->d_kmap.p, 1);
+    }
+    DP_HIP(hipGetLastError());
+    ctx->n_applied = ctx->n_seeds;
+    ctx->tables_dirty = false;
+    return DP_OK;
+}
+
 extern "C" int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, uint32_t n_seeds) {
     if (!ctx || k < 4 || k > 15 || (n_seeds && !seed_kmers)) return DP_ERR_ARG;
     hipSetDevice(ctx->device);
@@ -592,19 +610,15 @@ extern "C" int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, ui
         DP_HIP(hipMemsetAsync(ctx->d_kmap.p, 0, nk * 4, ctx->stream));
         ctx->table_k = k;
         ctx->n_seeds = 0;
-    } else if (ctx->n_seeds) {
-        hipLaunchKernelGGL(seeds_apply_kernel, dim3((ctx->n_seeds + 255) / 256), dim3(256), 0, ctx->stream,
-                           (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (uint32_t*)ctx->d_bits.p, (int32_t*)ctx->d_kmap.p, 0);
+        ctx->n_applied = 0;
     }
     for (uint32_t i = 0; i < n_seeds; i++)
         if (seed_kmers[i] >= nk) return dp_fail(ctx, DP_ERR_ARG, "seed k-mer out of range for k");
     if (dev_reserve(ctx, ctx->d_seeds, (size_t)n_seeds * 4 + 4)) return DP_ERR_HIP;
-    if (n_seeds) {
-        DP_HIP(hipMemcpyAsync(ctx->d_seeds.p, seed_kmers, (size_t)n_seeds * 4, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(seeds_apply_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, ctx->stream,
-                           (const uint32_t*)ctx->d_seeds.p, n_seeds, (uint32_t*)ctx->d_bits.p, (int32_t*)ctx->d_kmap.p, 1);
-        DP_HIP(hipGetLastError());
-    }
+    if (n_seeds) DP_HIP(hipMemcpyAsync(ctx->d_seeds.p, seed_kmers, (size_t)n_seeds * 4, hipMemcpyHostToDevice, ctx->stream));
+    // the membership bits and the k-mer -> seed-id map are only read by the scan kernels: they are brought up to date by
+    // seed_tables_ensure() when a scan actually runs (a round served by the k-mer position index never needs them)
+    ctx->tables_dirty = true;
     DP_HIP(dp_stream_sync(ctx));  // seed_kmers is borrowed only for the duration of the call
     ctx->k = k;
     ctx->n_seeds = n_seeds;
@@ -905,6 +919,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus * (v2 ? 2 : 1), ((uint64_t)n_items + 15) / 16);
     const uint32_t dbg = getenv("DP_SCAN_DEBUG") ? (uint32_t)atoi(getenv("DP_SCAN_DEBUG")) : 0u;
+    if (int rc = seed_tables_ensure(ctx)) return rc;
     std::unique_lock<ScanGate> scan_lock(g_scan_mu);
     DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(((dbg & 2) ? scan_kernel<0, 3> : v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
@@ -1107,6 +1122,7 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
         if (rc != 0) return rc;
         out->index_hits = ctx->kx_hits;
     } else {
+        if (int rc = seed_tables_ensure(ctx)) return rc;
         scan_lock.lock();
         DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
         hipLaunchKernelGGL((v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
