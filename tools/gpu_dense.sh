@@ -2,7 +2,7 @@
 # dense-seed regime (k=10, error-free and 3 % error): index query / chaining carry real traffic here
 mkdir -p gpurun_out
 for e in 0.0 0.03; do
-DPH_PROFILE=1 timeout 900 python bench.py --k 10 --error $e --steps 12 --warmup 4 --cpu-rounds 0 > gpurun_out/bench_k10_$e.json 2> gpurun_out/bench_k10_$e.err; echo "k10 e=$e rc=$?"
+DPH_PROFILE=1 timeout 900 python bench.py --k 10 --error $e --steps 40 --warmup 12 --cpu-rounds 0 --index-steps 20 > gpurun_out/bench_k10_$e.json 2> gpurun_out/bench_k10_$e.err; echo "k10 e=$e rc=$?"
 python - <<PY
 import json
 d=json.loads(open('gpurun_out/bench_k10_$e.json').read().strip().split('\n')[-1])
