@@ -1026,6 +1026,23 @@ __global__ __launch_bounds__(OFF_TILE) void compact_write(const dp_scan_item* __
     }
 }
 
+// does dp_scan_reads answer from the resident k-mer position index (when that can be built) rather than by scanning?
+static bool scan_wants_index(const dp_ctx* ctx) {
+    bool use_index = ctx->total_bases >= 1000000000ull || (ctx->owner && ctx->owner->total_bases >= 1000000000ull);
+    if (const char* e = getenv("DP_SCAN_INDEX")) use_index = e[0] == '1';
+    return use_index;
+}
+
+extern "C" int dp_scan_prepare(dp_ctx* ctx, int k) {
+    if (!ctx || k < 4 || k > 15) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_scan_prepare: k in 4..15") : DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    if (scan_wants_index(ctx)) {
+        const int rc = dp_kindex_ensure(ctx, k);  // > 0: cannot be used for this k / read set, the rounds will scan
+        if (rc < 0) return rc;
+    }
+    return DP_OK;
+}
+
 extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
                              uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out) {
     if (!ctx || !out || !ignore || lo > hi || hi > ctx->n_reads || (n_extra && !extra)) return DP_ERR_ARG;
@@ -1107,8 +1124,7 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     // Resident k-mer position index instead of scanning (dp_kindex.hip): DP_SCAN_INDEX=1 forces it, =0 forbids it; by
     // default it is used from 1 Gbase up.  That is the break-even of a whole job: the build costs ~0.13 s per Gbase, a
     // round saves (scan 0.5 ms per Gbase) - (index step 0.25 ms), and a job has ~600 rounds per Gbase of 10 kb reads.
-    bool use_index = ctx->total_bases >= 1000000000ull || (ctx->owner && ctx->owner->total_bases >= 1000000000ull);
-    if (const char* e = getenv("DP_SCAN_INDEX")) use_index = e[0] == '1';
+    bool use_index = scan_wants_index(ctx);
     std::unique_lock<ScanGate> scan_lock(g_scan_mu, std::defer_lock);
     if (use_index) {
         int rc = dp_kindex_ensure(ctx, k);

@@ -317,6 +317,14 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         mark("value table (device) + copy");
     }
     mark("values copy");
+    {
+        int rc = dp_scan_prepare(ctx, p.k);  // the k-mer position index, when this read set gets one (reuses the histogram)
+        if (rc != 0) {
+            error = dp_last_error(ctx);
+            return rc;
+        }
+        mark("k-mer position index");
+    }
     errText += "Counting complete. Starting indexing and querying...";
     {
         const char* hostsel = getenv("DP_HOST_SELECT");

@@ -144,6 +144,10 @@ typedef struct {
     uint64_t index_hits;           /* index mode: occurrences of this round's seed k-mers in the whole read set */
 } dp_survivor_batch;
 
+/* Optional, once per read set and k before the rounds: does the one-off work dp_scan_reads would otherwise do inside its
+ * first call - building the resident k-mer position index when the read set is large enough for it (>= 1 Gbase, or
+ * DP_SCAN_INDEX=1).  Right after dp_kmer_values the build reuses that call's k-mer histogram. */
+int dp_scan_prepare(dp_ctx* ctx, int k);
 int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
                   uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out);
 
