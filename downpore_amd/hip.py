@@ -180,6 +180,15 @@ class Context:
                     segs=_arr(b.segs, b.n_segs, np.int32), kernel_ms=b.kernel_ms, count_kernel_ms=b.count_kernel_ms,
                     write_kernel_ms=b.write_kernel_ms, bases_scanned=b.bases_scanned)
 
+    def scan_prepare(self, k):
+        """One-off work of dp_scan_reads (the resident k-mer position index, when this read set gets one) done now."""
+        self.L.dp_scan_prepare.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self.L.dp_scan_prepare(self.h, k))
+
+    def set_priority(self, high=True):
+        self.L.dp_ctx_set_priority.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self.L.dp_ctx_set_priority(self.h, 1 if high else 0))
+
     def scan_reads(self, ignore, epoch, lo, hi, top_level, min_seeds, extra=None):
         ig = np.ascontiguousarray(ignore, dtype=np.uint8)
         ex = np.ascontiguousarray(extra if extra is not None else np.zeros((0, 4)), dtype=np.uint32).reshape(-1, 4)
@@ -190,7 +199,7 @@ class Context:
         return dict(read=_arr(b.read, ns, np.uint32), n_seeds=_arr(b.n_seeds, ns, np.uint32), seg_off=_arr(b.seg_off, ns, np.uint64),
                     extra_n_seeds=_arr(b.extra_n_seeds, ne, np.uint32), extra_seg_off=_arr(b.extra_seg_off, ne, np.uint64),
                     segs=_arr(b.segs, b.n_segs, np.int32), bases_scanned=b.bases_scanned, reads_scanned=b.reads_scanned,
-                    kernel_ms=b.kernel_ms)
+                    kernel_ms=b.kernel_ms, index_mode=int(b.index_mode), index_hits=int(b.index_hits))
 
     # ---- A9 selection
     def values_upload(self, values):

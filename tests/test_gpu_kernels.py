@@ -256,6 +256,44 @@ def test_empty_and_ragged(ctx):
     assert len(out["query"]) == 0
 
 
+def test_scan_prepare_index_and_scan_modes_agree(ctx):
+    """dp_scan_prepare builds the k-mer position index ahead of the rounds (right after dp_kmer_values it starts from that
+    call's histogram); dp_scan_reads then answers from it and returns byte for byte what the scan kernels return - also
+    after the stream was moved to the highest priority (dp_ctx_set_priority) and across a mid-run switch of the mode."""
+    k = 10
+    bases, off = O.gen_reads(16, 80000, 300, 3000, 0.01, True)
+    N = 300
+    ctx.upload_reads(bases, off)
+    ctx.kmer_values(k)  # leaves the histogram for the index build
+    rng = np.random.default_rng(3)
+    ignore = (rng.random(N) < 0.1).astype(np.uint8)
+    extra = [(5, 100, 500, 0), (9, 0, 300, 0)]
+    os.environ["DP_SCAN_INDEX"] = "1"
+    try:
+        ctx.scan_prepare(k)
+        ctx.set_priority(True)
+        outs = {}
+        for rnd in range(3):
+            seeds = np.unique(rng.integers(1, 4 ** k, 6000)).astype(np.uint32)
+            ctx.round_begin(k, seeds)
+            for mode in ("1", "0", "1"):
+                os.environ["DP_SCAN_INDEX"] = mode
+                got = ctx.scan_reads(ignore, 11, 0, N, False, 20, extra)
+                assert got["index_mode"] == int(mode)
+                key = (rnd, mode)
+                if key in outs:  # the second pass in index mode after a scan-mode pass
+                    prev = outs[key]
+                    assert all(np.array_equal(prev[f], got[f]) for f in ("read", "n_seeds", "seg_off", "extra_n_seeds", "segs"))
+                outs[key] = {f: np.array(got[f]).copy() for f in ("read", "n_seeds", "seg_off", "extra_n_seeds", "segs")}
+            a, b = outs[(rnd, "1")], outs[(rnd, "0")]
+            assert len(a["read"]) > 0
+            for f in a:
+                assert np.array_equal(a[f], b[f]), (rnd, f)
+    finally:
+        del os.environ["DP_SCAN_INDEX"]
+        ctx.set_priority(False)
+
+
 def test_scan_reads_compaction_matches_itemwise_scan(ctx):
     """dp_scan_reads (items generated and survivors compacted on the device) == dp_scan item by item + host filter."""
     k = 10
