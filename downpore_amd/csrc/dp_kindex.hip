@@ -116,7 +116,14 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
         }
     }
     // count -> offsets -> scatter, on the CALLER's stream (the owner's buffers are only written here, under the mutex)
-    void* d_counts = nullptr;
+    void *d_counts = nullptr, *d_tmp = nullptr, *d_counts1 = nullptr;
+    struct Temps {  // released on every way out, error returns included
+        void **a, **b, **c;
+        ~Temps() {
+            for (void** p : {a, b, c})
+                if (*p) hipFree(*p);
+        }
+    } temps{&d_counts, &d_tmp, &d_counts1};
     if (ow->d_kcounts && ow->kcounts_k == k) {  // dp_kmer_values counted exactly these k-mers already
         d_counts = ow->d_kcounts;
         ow->d_kcounts = nullptr;
@@ -133,10 +140,8 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
     size_t tmp_bytes = 0;
     rocprim::exclusive_scan(nullptr, tmp_bytes, (uint32_t*)d_counts, (uint64_t*)ix->off.p, (uint64_t)0, nk + 1, rocprim::plus<uint64_t>(),
                             ctx->stream);
-    void* d_tmp = nullptr;
     DP_HIP(hipMalloc(&d_tmp, tmp_bytes + 16));
     // nk + 1 outputs: the extra input element is never added into an output, but it must be readable -> the buffer holds nk+1
-    void* d_counts1 = nullptr;
     DP_HIP(hipMalloc(&d_counts1, (nk + 1) * 4));
     DP_HIP(hipMemcpyAsync(d_counts1, d_counts, nk * 4, hipMemcpyDeviceToDevice, ctx->stream));
     DP_HIP(hipMemsetAsync((uint8_t*)d_counts1 + nk * 4, 0, 4, ctx->stream));
@@ -153,9 +158,6 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
                            (uint32_t*)d_counts, (uint64_t*)ix->pos.p);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_stream_sync(ctx));
-    hipFree(d_counts);
-    hipFree(d_counts1);
-    hipFree(d_tmp);
     ix->n_pos = total;
     ix->k = k;
     ix->built = true;
