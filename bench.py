@@ -2,7 +2,9 @@
 """bench.py — overlaps/sec of the all-vs-all overlap hot path on synthetic long reads (BASELINE.json metric).
 
 A "step" is one round of the overlap command (commands/overlap.go:115-194): seed selection for the next query batch,
-GPU scan of every non-ignored read, survivor exchange (N>1), index build, index query + chaining, consensus, PAF.
+the seed occurrences of every non-ignored read (from the resident k-mer position index at this size, by the scan kernels
+below 1 Gbase or with DP_SCAN_INDEX=0), survivor exchange (N>1), index build, index query + chaining, consensus, PAF.
+`roofline` describes the dominant kernel of the mode that ran; a second, shorter leg times the other mode.
 Workload (N=1 default): BASELINE config 2 — 100 000 synthetic reads x 10 kb, genome 50 Mb (20x), k=13, error-free
 (the error-free set is the throughput default at k=13).  Inputs are resident in HBM before the timed
 region.  Prints ONE JSON line on rank 0.
