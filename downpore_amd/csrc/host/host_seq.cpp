@@ -1044,17 +1044,45 @@ static void trimToBestSeed(Arena& ar, int upto, std::vector<SeedMatch*>& ms, int
     int bestCount = 0, bestScore = 0, bestIndex = upto, backCount = 0, backScore = 0;
     const int length = ms[0]->SeqA->numSeeds();
     int backIndex = length - upto - 1;
+    // count[i] = matches whose MatchA holds consensus seed i; bCount[i] = ... holds seed length-1-i at a position j >= 1
+    // (the reference's backward walk stops before j = 0, :40-46).  MatchA is strictly ascending, so one pass over the
+    // first / last `upto` consensus seeds of every match gives all counts the per-i walks of :30-47 produce.
+    static thread_local std::vector<int> frontCount, backCountV;
+    frontCount.assign((size_t)std::max(upto, 0), 0);
+    backCountV.assign((size_t)std::max(upto, 0), 0);
+    bool ascending = true;
+    for (SeedMatch* match : ms) {
+        const std::vector<int32_t>& A = match->MatchA;
+        for (size_t j = 1; j < A.size() && ascending; j++) ascending = A[j] > A[j - 1];
+    }
+    if (ascending) {
+        for (SeedMatch* match : ms) {
+            const std::vector<int32_t>& A = match->MatchA;
+            for (size_t j = 0; j < A.size() && A[j] < upto; j++)
+                if (A[j] >= 0) frontCount[(size_t)A[j]]++;
+            for (size_t j = A.size(); j-- > 1;) {
+                const int back = length - 1 - A[j];
+                if (back >= upto) break;
+                if (back >= 0) backCountV[(size_t)back]++;
+            }
+        }
+    }
     for (int i = 0; i < upto; i++) {
         int count = 0, bCount = 0;
-        for (SeedMatch* match : ms) {
-            for (int index : match->MatchA) {
-                if (index == i) count++;
-                if (index >= i) break;
-            }
-            for (int j = (int)match->MatchA.size() - 1; j > 0; j--) {
-                const int index = match->MatchA[(size_t)j];
-                if (index == length - 1 - i) bCount++;
-                if (index <= length - 1 - i) break;
+        if (ascending) {
+            count = frontCount[(size_t)i];
+            bCount = backCountV[(size_t)i];
+        } else {  // (never seen: the literal walks)
+            for (SeedMatch* match : ms) {
+                for (int index : match->MatchA) {
+                    if (index == i) count++;
+                    if (index >= i) break;
+                }
+                for (int j = (int)match->MatchA.size() - 1; j > 0; j--) {
+                    const int index = match->MatchA[(size_t)j];
+                    if (index == length - 1 - i) bCount++;
+                    if (index <= length - 1 - i) break;
+                }
             }
         }
         if (count - i >= bestScore || (bestCount < minMatch && count >= minMatch)) {
