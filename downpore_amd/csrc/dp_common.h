@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,7 @@ struct dp_kindex;
 struct dp_ctx {
     int device = 0;
     dp_ctx* owner = nullptr;     // context whose reads (and k-mer position index) this one borrows
+    std::atomic<int> n_borrowers{0};  // live contexts created from this one with dp_ctx_create_shared
     dp_kindex* kidx = nullptr;   // resident k-mer position index (dp_kindex.hip), owned by the reads' owner
     DevBuf d_kx_sz, d_kx_lo, d_kx_tmp, d_kx_keys, d_kx_vals;  // per-round scratch of the index path
     uint32_t kx_hits = 0;

@@ -182,14 +182,14 @@ __global__ void kidx_seed_sizes(const uint32_t* __restrict__ seeds, uint32_t n_s
 }
 
 __global__ void kidx_emit(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
-                          const uint64_t* __restrict__ pos, const uint32_t* __restrict__ base, uint64_t* __restrict__ keys,
+                          const uint64_t* __restrict__ pos, const uint64_t* __restrict__ base, uint64_t* __restrict__ keys,
                           uint32_t* __restrict__ vals) {
     const int lane = dp_lane();
     const uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (s >= n_seeds) return;
     const uint64_t o = off[seeds[s]];
     const uint32_t n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
-    const uint32_t b = base[s];
+    const uint64_t b = base[s];
     for (uint32_t i = lane; i < n; i += 64) {
         keys[b + i] = pos[o + i];
         vals[b + i] = s;
@@ -251,24 +251,30 @@ __global__ void kidx_write(const dp_scan_item* __restrict__ items, const uint32_
 }
 
 // Counting step of a round from the index: fills counts (and the per-item slice starts) for all items.
+// Returns 1 (nothing written) when the round's seeds have more than 2^31 occurrences in the read set - the sort keys and
+// the per-item slices are 32-bit indexed; the caller then answers this round with the scan kernels.
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t n_items, uint32_t* d_counts, float* ms) {
     dp_kindex* ix = kidx_owner(ctx)->kidx;
     const uint32_t S = ctx->n_seeds;
-    if (dev_reserve(ctx, ctx->d_kx_sz, ((size_t)S + 2) * 4 * 2)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_kx_sz, ((size_t)S + 2) * 12 + 16)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_kx_lo, (size_t)n_items * 4 + 16)) return DP_ERR_HIP;
-    uint32_t* sz = (uint32_t*)ctx->d_kx_sz.p;
-    uint32_t* base = sz + S + 2;
+    uint64_t* base = (uint64_t*)ctx->d_kx_sz.p;  // 64-bit running totals: dense seed batches over tens of Gbase pass 2^32
+    uint32_t* sz = (uint32_t*)(base + S + 2);
     DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(kidx_seed_sizes, dim3((S + 1 + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
                        (const uint64_t*)ix->off.p, sz);
     size_t tb = 0;
-    rocprim::exclusive_scan(nullptr, tb, sz, base, 0u, (size_t)S + 1, rocprim::plus<uint32_t>(), ctx->stream);
+    rocprim::exclusive_scan(nullptr, tb, sz, base, (uint64_t)0, (size_t)S + 1, rocprim::plus<uint64_t>(), ctx->stream);
     if (dev_reserve(ctx, ctx->d_kx_tmp, tb + 64)) return DP_ERR_HIP;
-    DP_HIP(rocprim::exclusive_scan(ctx->d_kx_tmp.p, tb, sz, base, 0u, (size_t)S + 1, rocprim::plus<uint32_t>(), ctx->stream));
+    DP_HIP(rocprim::exclusive_scan(ctx->d_kx_tmp.p, tb, sz, base, (uint64_t)0, (size_t)S + 1, rocprim::plus<uint64_t>(), ctx->stream));
     if (pin_reserve(ctx, ctx->h_total, 32)) return DP_ERR_HIP;
-    DP_HIP(hipMemcpyAsync((uint8_t*)ctx->h_total.p + 16, base + S, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(hipMemcpyAsync((uint8_t*)ctx->h_total.p + 16, base + S, 8, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
-    const uint32_t H = *(const uint32_t*)((const uint8_t*)ctx->h_total.p + 16);
+    const uint64_t H64 = *(const uint64_t*)((const uint8_t*)ctx->h_total.p + 16);
+    uint64_t cap = (uint64_t)1 << 31;
+    if (const char* e = getenv("DP_KINDEX_MAX_HITS")) cap = std::min<uint64_t>(cap, strtoull(e, nullptr, 10));  // (tests)
+    if (H64 > cap) return 1;
+    const uint32_t H = (uint32_t)H64;
     ctx->kx_hits = H;
     if (dev_reserve(ctx, ctx->d_kx_keys, ((size_t)H + 16) * 8 * 2)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_kx_vals, ((size_t)H + 16) * 4 * 2)) return DP_ERR_HIP;
@@ -278,7 +284,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t n_
     uint32_t* vals2 = vals + H + 16;
     if (H) {
         hipLaunchKernelGGL(kidx_emit, dim3((S + 3) / 4), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
-                           (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, (const uint32_t*)base, keys, vals);
+                           (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, (const uint64_t*)base, keys, vals);
         // positions are below packed_bytes*4: sort only the bits that can differ
         unsigned bits = 1;
         while (bits < 64 && ((kidx_owner(ctx)->packed_bytes * 4) >> bits) != 0) bits++;

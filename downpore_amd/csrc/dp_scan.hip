@@ -175,6 +175,7 @@ extern "C" int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out) {
     dp_ctx* c = *out;
     c->borrowed_reads = true;
     c->owner = src->owner ? src->owner : src;
+    c->owner->n_borrowers++;
     c->n_reads = src->n_reads;
     c->total_bases = src->total_bases;
     c->packed_bytes = src->packed_bytes;
@@ -206,6 +207,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     hipSetDevice(ctx->device);
     dp_stream_sync(ctx);
     if (ctx->borrowed_reads) ctx->d_packed.p = ctx->d_boff.p = ctx->d_len.p = ctx->d_values.p = nullptr;
+    if (ctx->owner) ctx->owner->n_borrowers--;
     dp_kindex_free(ctx);
     DevBuf* dbs[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len, &ctx->d_bits, &ctx->d_kmap, &ctx->d_seeds, &ctx->d_items,
                      &ctx->d_counts, &ctx->d_segoff, &ctx->d_segs, &ctx->d_total, &ctx->d_seqrefs, &ctx->d_posting,
@@ -279,6 +281,8 @@ __global__ void pack_kernel(const uint8_t* __restrict__ ascii, const int64_t* __
 static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_host, uint32_t first_paired) {
     if (!ctx || !bases || !off) return DP_ERR_ARG;
     if (ctx->borrowed_reads) return dp_fail(ctx, DP_ERR_STATE, "dp_reads_upload on a context that borrows its reads");
+    // contexts made with dp_ctx_create_shared hold plain copies of the resident buffers' addresses
+    if (ctx->n_borrowers.load() > 0) return dp_fail(ctx, DP_ERR_STATE, "dp_reads_upload while contexts borrowing these reads exist");
     if (first_paired > n_host) first_paired = n_host;
     hipSetDevice(ctx->device);
     dp_kindex_free(ctx);  // a position index of the previous read set is void
@@ -291,9 +295,8 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
     if (nd64 > 0x7fffffffull) return dp_fail(ctx, DP_ERR_ARG, "too many reads");
     const uint32_t n_reads = (uint32_t)nd64;
     const bool paired = first_paired < n_host;
-    ctx->n_reads = n_reads;
-    ctx->h_boff.assign((size_t)n_reads + 1, 0);
-    ctx->h_len.assign(n_reads, 0);
+    std::vector<uint64_t> h_boff((size_t)n_reads + 1, 0);
+    std::vector<uint32_t> h_len(n_reads, 0);
     std::vector<uint32_t> srcmap;
     if (paired) srcmap.resize(n_reads);
     uint64_t pos = 0, total = 0;
@@ -302,13 +305,30 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
         const uint32_t isrc = d < first_paired ? 0u : ((d - first_paired) & 1u);
         int64_t len = off[r + 1] - off[r];
         if (len < 0 || len > 0x7fffffff) return dp_fail(ctx, DP_ERR_ARG, "read length out of range");
-        ctx->h_boff[d] = pos;
-        ctx->h_len[d] = (uint32_t)len;
+        h_boff[d] = pos;
+        h_len[d] = (uint32_t)len;
         if (paired) srcmap[d] = (r << 1) | isrc;
         pos += ((uint64_t)(len + 3) / 4 + 15) & ~(uint64_t)15;
         total += (uint64_t)len;
     }
-    ctx->h_boff[n_reads] = pos;
+    h_boff[n_reads] = pos;
+    // A resident buffer the new read set outgrows is released here and now (this call waits for the stream anyway) instead
+    // of joining the retired list: a previous read set's gigabytes must not stay in HBM for the context's lifetime, and
+    // they count against the k-mer index's free-memory test.
+    DP_HIP(dp_stream_sync(ctx));
+    {
+        DevBuf* res[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len};
+        const size_t need[] = {(size_t)pos + 64, ((size_t)n_reads + 1) * 8, (size_t)n_reads * 4 + 4};
+        for (int i = 0; i < 3; i++)
+            if (res[i]->p && need[i] > res[i]->cap) {
+                hipFree(res[i]->p);
+                res[i]->p = nullptr;
+                res[i]->cap = 0;
+            }
+    }
+    ctx->n_reads = n_reads;
+    ctx->h_boff.swap(h_boff);
+    ctx->h_len.swap(h_len);
     ctx->packed_bytes = pos;
     ctx->total_bases = total;
     if (dev_reserve(ctx, ctx->d_packed, pos + 64)) return DP_ERR_HIP;
@@ -324,6 +344,15 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
     void* d_ascii = nullptr;
     void* d_aoff = nullptr;
     void* d_map = nullptr;
+    struct Temps {  // staging copies: released on every way out, error returns included (after the stream has drained)
+        dp_ctx* c;
+        void **a, **b, **m;
+        ~Temps() {
+            hipStreamSynchronize(c->stream);
+            for (void** p : {a, b, m})
+                if (*p) hipFree(*p);
+        }
+    } temps{ctx, &d_ascii, &d_aoff, &d_map};
     const uint64_t nascii = (uint64_t)(off[n_host] - off[0]);
     DP_HIP(hipMalloc(&d_ascii, nascii + 16));
     DP_HIP(hipMalloc(&d_aoff, ((size_t)n_host + 1) * 8));
@@ -341,9 +370,6 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
                        (const uint64_t*)ctx->d_boff.p, n_reads, (uint32_t*)ctx->d_packed.p, n_dwords, (const uint32_t*)d_map);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_stream_sync(ctx));
-    hipFree(d_ascii);
-    hipFree(d_aoff);
-    if (d_map) hipFree(d_map);
     return DP_OK;
 }
 
@@ -1131,13 +1157,15 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
         if (rc < 0) return rc;
         if (rc > 0) use_index = false;  // k > 14 or not enough free HBM for 8 B per base: scan
     }
-    out->index_mode = use_index ? 1u : 0u;
     out->index_hits = 0;
     if (use_index) {
         int rc = dp_kindex_count(ctx, k, d_items, n_items, (uint32_t*)ctx->d_counts.p, nullptr);
-        if (rc != 0) return rc;
-        out->index_hits = ctx->kx_hits;
-    } else {
+        if (rc < 0) return rc;
+        if (rc > 0) use_index = false;  // more seed occurrences than the 32-bit sort handles: this round is scanned
+        else out->index_hits = ctx->kx_hits;
+    }
+    out->index_mode = use_index ? 1u : 0u;
+    if (!use_index) {
         if (int rc = seed_tables_ensure(ctx)) return rc;
         scan_lock.lock();
         DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));

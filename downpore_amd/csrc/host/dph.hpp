@@ -361,6 +361,8 @@ struct RoundResult {
     std::vector<uint32_t> indexedReads;  // read ids that entered the index (for speculation checks)
     std::vector<uint32_t> queryReads;    // read ids of the query windows
     i64 snapshot = 0;                    // rounds committed when the execution started (pipeline mode)
+    i64 planRound = -2;                  // round of the plan this result was executed from (an empty result may come from
+                                         // an EARLIER empty plan of a speculative chain); -2 = no plan at all
     FinalCheckStats fs;
     RoundStats st;
 };
@@ -450,6 +452,7 @@ struct OverlapRun {
     void startWorkers();
     void workerMain(size_t slot);
     bool resultValid(const RoundResult& r) const;
+    bool emptyResultValid(const RoundResult& r) const;
     std::vector<std::thread> workers_;
     std::mutex pmu_;
     std::condition_variable cvWork_, cvDone_;

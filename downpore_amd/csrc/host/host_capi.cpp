@@ -1,5 +1,7 @@
 // C entry points of libdownpore_host.so: lets Python (bench.py, tests) drive the product's host pipeline round by
 // round, interposing the multi-GPU survivor exchange between the local scan and the index build.
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstring>
 
@@ -228,10 +230,10 @@ void dph_overlap_drain(void* hh) { ((OverlapH*)hh)->run.drain(); }
 // the gathered results in round order with the speculation check (OverlapRun::commitResults).
 static void putv(std::string& b, const void* p, size_t n) { b.append((const char*)p, n); }
 static void serialise(const RoundResult& res, std::string& blob) {
-    int64_t hdr[16] = {res.round, res.empty ? 1 : 0, res.firstIn, res.firstOut, res.numQuerySeqs, (int64_t)res.ignores.size(),
+    int64_t hdr[18] = {res.round, res.empty ? 1 : 0, res.firstIn, res.firstOut, res.numQuerySeqs, (int64_t)res.ignores.size(),
                        (int64_t)res.indexedReads.size(), (int64_t)res.paf.size(), res.fs.badBack, res.fs.emptyMatch,
                        (int64_t)res.fs.lines, (int64_t)res.fs.hits, (int64_t)res.fs.qHits, 0, res.snapshot,
-                       (int64_t)res.queryReads.size()};
+                       (int64_t)res.queryReads.size(), res.planRound, 0};
     int64_t total = (int64_t)(sizeof hdr + sizeof(RoundStats) + res.ignores.size() * sizeof(int) + res.indexedReads.size() * 4 +
                               res.paf.size() + res.queryReads.size() * 4);
     hdr[13] = total;
@@ -270,7 +272,7 @@ static void deserialise(const uint8_t* blobs, const uint64_t* sizes, int count, 
     const uint8_t* end = blobs + totalBytes;
     while (q < end) {
         const uint8_t* rec = q;
-        int64_t hdr[16];
+        int64_t hdr[18];
         memcpy(hdr, q, sizeof hdr);
         q += sizeof hdr;
         RoundResult r;
@@ -288,6 +290,7 @@ static void deserialise(const uint8_t* blobs, const uint64_t* sizes, int count, 
         r.paf.assign((const char*)q, (size_t)hdr[7]);
         q += hdr[7];
         r.snapshot = hdr[14];
+        r.planRound = hdr[16];
         r.queryReads.assign((const uint32_t*)q, (const uint32_t*)q + hdr[15]);
         r.fs.badBack = hdr[8];
         r.fs.emptyMatch = hdr[9];
@@ -338,6 +341,32 @@ int dph_overlap_commit_blobs(void* hh, const uint8_t* blobs, const uint64_t* siz
 int dph_overlap_done(void* hh) { return ((OverlapH*)hh)->run.done ? 1 : 0; }
 
 }  // extern "C"
+
+// ---- host-logic test hook (no GPU needed): ignore flags that arrive while the planner thread holds a finished plan in
+// its hands (set DPH_TEST_PLAN_DELAY_US).  A commit flags one read below the next plan's firstIn and one of that plan's own
+// query reads; the plan must be thrown away and recomputed.  Returns 0 = the plan handed out is current, 1 = stale plan,
+// <0 = the scenario could not be set up.
+extern "C" int dph_selftest_planner_flags(void* readsH, int k, int64_t seedBatchSize, const double* values) {
+    ReadSet& reads = ((ReadsH*)readsH)->set;
+    OverlapParams p;
+    p.k = k;
+    p.seedBatchSize = seedBatchSize;
+    Planner pl(reads, p, values, true, nullptr);
+    std::shared_ptr<const RoundPlan> p0 = pl.get(0);  // the thread goes on with plan 1 (prefetch depth)
+    if (!p0 || p0->empty || p0->firstOut <= 1 || p0->firstOut >= (i64)reads.size()) return -1;
+    const char* e = getenv("DPH_TEST_PLAN_DELAY_US");
+    const long delay = e ? atol(e) : 0;
+    if (delay <= 0) return -2;
+    usleep((useconds_t)(delay / 2));  // plan 1 is computed by now and sits in the hook's sleep
+    const int small = 0, big = (int)p0->firstOut;  // big = first query read of plan 1
+    pl.applyIgnores({small, big}, 0);
+    pl.dropBefore(1, p0->firstOut);
+    std::shared_ptr<const RoundPlan> p1 = pl.get(1);
+    if (!p1 || p1->firstIn != p0->firstOut) return -3;
+    for (const auto& w : p1->windows)
+        if ((int)w.read == big || (int)w.read == small) return 1;
+    return 0;
+}
 
 // ---- host-logic test hook (no GPU needed): finalCheckWorker over externally supplied matches ----------------------
 // Queries and indexed sequences come as flat arrays in the reference's segment layout; matches as (query index,

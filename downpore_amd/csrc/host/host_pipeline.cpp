@@ -2,6 +2,7 @@
 // execution), executor slots (speculative rounds), in-order commit with the speculation check; plus the multi-rank
 // entry points (round-parallel supersteps, scan-shard halves).
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include <condition_variable>
 #include <cstring>
@@ -30,8 +31,9 @@ struct Planner::Impl {
     i64 base = 0;             // rounds below are committed and gone
     i64 startFirstIn = 0;     // firstSequence of round `base` (the committed state): the chain can always restart here
     uint64_t epoch = 0;       // bumped whenever an ignore flag is set
-    i64 epochMinId = -1;      // smallest read id flagged in the last bump(s) while a compute was running
+    i64 epochMaxId = -1;      // largest read id flagged since the running compute started (-1: none)
     bool stop = false;
+    long testDelayUs = 0;     // DPH_TEST_PLAN_DELAY_US: sleep before every compute (tests/test_planner_epoch.py)
     std::thread th;
     Impl(ReadSet& r, const OverlapParams& pp, const double* v, bool t, dp_ctx* sc)
         : reads(r), p(pp), values(v), threaded(t), selCtx(sc), index(pp.k) {}
@@ -39,6 +41,7 @@ struct Planner::Impl {
 
 Planner::Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded, dp_ctx* selCtx)
     : d(new Impl(reads, p, values, threaded, selCtx)) {
+    if (const char* e = getenv("DPH_TEST_PLAN_DELAY_US")) d->testDelayUs = atol(e);
     if (threaded) d->th = std::thread([this] { threadMain(); });
 }
 
@@ -112,17 +115,20 @@ void Planner::threadMain() {
             continue;
         }
         const uint64_t e0 = d->epoch;
-        d->epochMinId = -1;
+        d->epochMaxId = -1;
         lk.unlock();
         static const bool dbg = getenv("DPH_DEBUG_PLANNER") != nullptr;
         if (dbg) fprintf(stderr, "[planner] computing plan %lld (firstIn %lld, wantUpTo %lld, base %lld)\n", (long long)m, (long long)firstIn, (long long)d->wantUpTo, (long long)d->base);
         std::shared_ptr<RoundPlan> plan = compute(m, firstIn);
+        if (d->testDelayUs > 0) usleep((useconds_t)d->testDelayUs);  // test hook: flags arrive after this plan has read them
         if (dbg) fprintf(stderr, "[planner] plan %lld done: %zu windows, %zu seeds, empty %d failed %d\n", (long long)m, plan->windows.size(), plan->seedMap.size(), (int)plan->empty, (int)plan->failed);
         lk.lock();
         if (d->stop) return;
-        // discard if flags that could matter changed meanwhile, or if the chain below was invalidated
+        // discard if flags that could matter changed meanwhile, or if the chain below was invalidated.  PrepareQueries
+        // looks at ignore[r] for every r >= firstIn, so the plan is stale as soon as ANY read flagged during the compute
+        // has id >= firstIn - i.e. when the largest one does (a commit usually flags ids on both sides of firstIn).
         bool ok = true;
-        if (d->epoch != e0 && d->epochMinId >= 0 && d->epochMinId >= firstIn) ok = false;
+        if (d->epoch != e0 && d->epochMaxId >= firstIn) ok = false;
         if (m > d->base) {
             auto pr = d->cache.find(m - 1);
             if (pr == d->cache.end() || pr->second->firstOut != firstIn) ok = false;
@@ -179,17 +185,16 @@ std::shared_ptr<const RoundPlan> Planner::get(i64 round) {
 
 i64 Planner::applyIgnores(const std::vector<int>& ids, i64 committedRound) {
     std::lock_guard<std::mutex> lk(d->mu);
-    i64 maxNew = -1, minNew = -1;
+    i64 maxNew = -1;
     for (int id : ids) {
         if (!d->reads.ignore[(size_t)id]) {
             d->reads.ignore[(size_t)id] = 1;
             if (id > maxNew) maxNew = id;
-            if (minNew < 0 || id < minNew) minNew = id;
         }
     }
     if (maxNew < 0) return -1;
     d->epoch++;
-    if (d->epochMinId < 0 || minNew < d->epochMinId) d->epochMinId = minNew;
+    if (maxNew > d->epochMaxId) d->epochMaxId = maxNew;
     // every cached plan of a later round that starts at or before a newly flagged read may change
     i64 firstBad = -1;
     for (auto it = d->cache.begin(); it != d->cache.end(); ++it) {
@@ -465,6 +470,7 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
         sl.error = "seed selection failed: " + plan->error;
         return -1;
     }
+    out.planRound = plan ? plan->round : -2;
     if (!plan || plan->empty || plan->round != r) {
         out.empty = true;
         if (plan) out.firstIn = out.firstOut = plan->firstOut;
@@ -554,7 +560,7 @@ int OverlapRun::commitResults(std::vector<RoundResult>& results) {
     for (RoundResult& r : results) {
         if (r.round != round) break;
         if (r.empty) {
-            done = true;
+            if (emptyResultValid(r)) done = true;  // (a stale one is not committed: the caller executes `round` again)
             break;
         }
         // speculation check: the round ran against the flags at the start of this batch.  It is exact iff no read
@@ -646,6 +652,15 @@ void OverlapRun::workerMain(size_t si) {
 
 // A round executed against a flag snapshot is exact iff no read flagged since then is one of its queries or entered
 // its index, and its plan continues the committed chain.
+// "No more queries" ends the command (commands/overlap.go:130), so an empty result is checked like any other: it must
+// come from the plan of THIS round (planner->get() hands out an earlier empty plan of a speculative chain when there is
+// one, and that chain may have been erased by applyIgnores since) and that plan must start at the committed
+// firstSequence.  Flags only accumulate, so an empty plan computed from the right firstIn stays empty.
+bool OverlapRun::emptyResultValid(const RoundResult& r) const {
+    if (r.planRound == -2) return true;  // inline planner with nothing left to compute
+    return r.planRound == round && r.firstIn == firstSequence;
+}
+
 bool OverlapRun::resultValid(const RoundResult& r) const {
     if (r.firstIn != firstSequence) return false;
     for (uint32_t id : r.queryReads)
@@ -677,8 +692,15 @@ int OverlapRun::step() {
         RoundResult res = std::move(it->second);
         ready_.erase(it);
         if (res.empty) {
-            done = true;
-            break;
+            if (emptyResultValid(res)) {
+                done = true;
+                break;
+            }
+            g_prof.rejected++;
+            redo_.push_back(round);
+            issueEnd_ = false;
+            cvWork_.notify_all();
+            continue;
         }
         g_prof.executed++;
         if (!resultValid(res)) {
@@ -721,7 +743,16 @@ int OverlapRun::commitGathered(std::vector<RoundResult>& results) {
         if (r.round != round) break;
         const bool owned = r.round % world_ == rank_;
         if (r.empty) {
-            done = true;
+            if (emptyResultValid(r)) {
+                done = true;
+                break;
+            }
+            g_prof.rejected++;  // stale "end of input": every rank takes the same decision, the owner executes it again
+            issueEnd_ = false;
+            if (owned) {
+                ready_.erase(r.round);
+                redo_.push_back(r.round);
+            }
             break;
         }
         g_prof.executed++;

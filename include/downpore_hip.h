@@ -27,6 +27,10 @@
 extern "C" {
 #endif
 
+/* Only the entry points declared here are exported from libdownpore_hip.so (the library is built with
+ * -fvisibility=hidden; tests/test_abi_symbols.py checks the dynamic symbol table against this header). */
+#define DP_API __attribute__((visibility("default")))
+
 typedef struct dp_ctx dp_ctx;
 
 enum dp_status {
@@ -39,41 +43,41 @@ enum dp_status {
 };
 
 /* Library/ABI version and the code-object architecture this build targets ("gfx950"). */
-const char* dp_version(void);
+DP_API const char* dp_version(void);
 
 /* Create a context on HIP device `device`.  Fails (DP_ERR_NODEVICE) when no GPU is present: there is no CPU
  * fallback. */
-int dp_ctx_create(int device, dp_ctx** out);
+DP_API int dp_ctx_create(int device, dp_ctx** out);
 /* A second context on the same device that BORROWS the resident reads of `src` (no copy): lets several host threads
  * drive independent rounds concurrently, each with its own stream and per-round state.  Destroy it before `src`. */
-int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out);
+DP_API int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out);
 /* Give the context's stream the device's highest (high != 0) or default scheduling priority.  For the context of a
  * latency-critical caller next to throughput work - the goroutine that runs PrepareQueries (overlap/overlap.go:157) and
  * waits for dp_select_seeds while other contexts keep the GPU busy with whole rounds.  Call it while the context is idle. */
-int dp_ctx_set_priority(dp_ctx* ctx, int high);
-void dp_ctx_destroy(dp_ctx* ctx);
-const char* dp_last_error(const dp_ctx* ctx); /* ctx may be NULL: error of the last failed dp_ctx_create */
+DP_API int dp_ctx_set_priority(dp_ctx* ctx, int high);
+DP_API void dp_ctx_destroy(dp_ctx* ctx);
+DP_API const char* dp_last_error(const dp_ctx* ctx); /* ctx may be NULL: error of the last failed dp_ctx_create */
 
 /* ---- A1: reads resident in HBM ------------------------------------------------------------------------
  * Replaces NewPackedSequence/packBytes (sequence/sequence.go:67-93, sequence/asm_amd64.s:33-78) for the whole
  * read set: `bases` is the concatenated ASCII of all reads, read r = bases[off[r] .. off[r+1]).  Packing
  * (2 bit/base, ((b>>1)^((b&4)>>2))&3, first base in the top bits of each byte) runs on the device.  Reads stay
  * resident for every later round. */
-int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads);
+DP_API int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads);
 /* The same, but every read r >= first_paired is stored TWICE: as device read first_paired + 2*(r - first_paired) and,
  * reverse-complemented (sequence.go:179-198: reversed, 3 - code per base), as the next id.  `downpore map` scans every
  * query window on both strands (mapping.go:497-499); the reverse strands are produced by the pack kernel instead of
  * being built on the host and sent over PCIe. */
-int dp_reads_upload_rc(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads, uint32_t first_paired);
+DP_API int dp_reads_upload_rc(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads, uint32_t first_paired);
 /* Copy back the packed bytes of one read (ceil(len/4) bytes) — test hook. */
-int dp_reads_packed(dp_ctx* ctx, uint32_t read, uint8_t* out, uint64_t cap, uint64_t* n_bytes);
-uint32_t dp_reads_count(const dp_ctx* ctx);
-uint64_t dp_reads_total_bases(const dp_ctx* ctx);
+DP_API int dp_reads_packed(dp_ctx* ctx, uint32_t read, uint8_t* out, uint64_t cap, uint64_t* n_bytes);
+DP_API uint32_t dp_reads_count(const dp_ctx* ctx);
+DP_API uint64_t dp_reads_total_bases(const dp_ctx* ctx);
 
 /* ---- A22: k-mer histogram -----------------------------------------------------------------------------
  * Replaces sequtil.KmerOccurrences/countWorker (util/sequtil/kmers.go:34-69): counts_out[kmer] (4^k entries)
  * = occurrences of every k-mer over all uploaded reads. */
-int dp_kmer_histogram(dp_ctx* ctx, int k, uint64_t* counts_out);
+DP_API int dp_kmer_histogram(dp_ctx* ctx, int k, uint64_t* counts_out);
 
 /* ---- A22 + A23: the k-mer value table -----------------------------------------------------------------------
  * Replaces the block between "Counting all k-mers" and "Counting complete" of the commands (commands/overlap.go:55-93,
@@ -83,13 +87,13 @@ int dp_kmer_histogram(dp_ctx* ctx, int k, uint64_t* counts_out);
  * first), values[0] = 0.  Everything runs on the device; the table stays resident as the context's value table (what
  * dp_values_upload would have installed) and is copied to values_out (4^k doubles) unless that is NULL.  float64,
  * bit-identical to the host computation. */
-int dp_kmer_values(dp_ctx* ctx, int k, double* values_out);
+DP_API int dp_kmer_values(dp_ctx* ctx, int k, double* values_out);
 
 /* ---- round state: the seed set --------------------------------------------------------------------------
  * Mirrors the per-round SeedIndex tables kmers/kmerMap/seedMap (seeds/seeds.go:13-18): seed id = position in
  * seed_kmers.  Builds the 4^k-bit membership table and the k-mer -> seed-id map on the device (sparse
  * set/clear: only the entries of the previous round's seeds are touched). */
-int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, uint32_t n_seeds);
+DP_API int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, uint32_t n_seeds);
 
 /* ---- A2 + A10: batched packed k-mer scan ---------------------------------------------------------------
  * Replaces SeedIndex.NewSeedSequence = packedCountKmers + packedWriteSegments + kmerMap translate
@@ -119,7 +123,7 @@ typedef struct {
     uint64_t bases_scanned;  /* sum of n_kmers + k - 1 over items */
 } dp_seedseq_batch;
 
-int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items, dp_seedseq_batch* out);
+DP_API int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items, dp_seedseq_batch* out);
 
 /* AddSequences-level form of the scan (overlap.go:217-250): every read r in [lo, hi) whose ignore[r] is 0 is scanned
  * as the view a later pass receives (top_level != 0: re-read top-level sequences incl. the len%4==0 quirk; 0: cached
@@ -147,8 +151,8 @@ typedef struct {
 /* Optional, once per read set and k before the rounds: does the one-off work dp_scan_reads would otherwise do inside its
  * first call - building the resident k-mer position index when the read set is large enough for it (>= 1 Gbase, or
  * DP_SCAN_INDEX=1).  Right after dp_kmer_values the build reuses that call's k-mer histogram. */
-int dp_scan_prepare(dp_ctx* ctx, int k);
-int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
+DP_API int dp_scan_prepare(dp_ctx* ctx, int k);
+DP_API int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
                   uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out);
 
 /* ---- A9 (selection part): AddSeeds' block-winner / top-N selection on the device -------------------------
@@ -162,8 +166,8 @@ int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uin
  * and writes num_seeds k-mers per window to `top_out` in list order (untouched slots hold k-mer 0, as in the
  * reference).  win[i].read/start/n_kmers describe the window (n_kmers = window length in BASES here); min_seeds is
  * ignored.  num_seeds <= 64. */
-int dp_values_upload(dp_ctx* ctx, const double* values, uint64_t n);
-int dp_select_seeds(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out);
+DP_API int dp_values_upload(dp_ctx* ctx, const double* values, uint64_t n);
+DP_API int dp_select_seeds(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out);
 
 
 /* ---- A13: seed index build ------------------------------------------------------------------------------
@@ -177,7 +181,7 @@ typedef struct {
     uint32_t reserved;
 } dp_seq_ref;
 
-int dp_index_build(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs);
+DP_API int dp_index_build(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs);
 
 /* ---- A14 + A5 + A6 + A7 + A8: index query and overlap chaining ---------------------------------------------
  * Replaces overlapper.matchWorker (overlap/overlap.go:346-387) for all queries of a round:
@@ -208,7 +212,7 @@ typedef struct {
                                * per chained pair, the chains written (counted by the kernel itself) */
 } dp_match_batch;
 
-int dp_find_overlaps(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t n_queries,
+DP_API int dp_find_overlaps(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t n_queries,
                      double hit_fraction, int k, uint32_t max_query_len, int want_candidates, dp_match_batch* out);
 
 /* ---- A19 + A20: map-flavour query (mapping.performMapping core) -----------------------------------------------
@@ -228,7 +232,7 @@ typedef struct {
     double kernel_ms;
 } dp_chain_batch;
 
-int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t n_windows,
+DP_API int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t n_windows,
                    int k, dp_chain_batch* out);
 
 /* ---- A16 (part): seed-space multiple alignment of multiAligner.Consensus (seeds/alignment.go:52-247) ------------
@@ -252,20 +256,20 @@ typedef struct dp_consensus_batch {
     const uint32_t* flags;      /* per group */
     double kernel_ms;
 } dp_consensus_batch;
-int dp_consensus_align(dp_ctx* ctx, const int32_t* segs, const uint64_t* seq_off, const uint32_t* group_off, uint32_t n_groups,
+DP_API int dp_consensus_align(dp_ctx* ctx, const int32_t* segs, const uint64_t* seq_off, const uint32_t* group_off, uint32_t n_groups,
                        int k, dp_consensus_batch* out);
 
 /* ---- introspection for tests ---------------------------------------------------------------------------------- */
 /* posting row of `seed` (n_words = ceil(n_seqs/64)) and its popcount/start/end as the reference's IntSet holds. */
-int dp_index_posting_row(dp_ctx* ctx, uint32_t seed, uint64_t* words, uint32_t cap_words, uint32_t* n_words,
+DP_API int dp_index_posting_row(dp_ctx* ctx, uint32_t seed, uint64_t* words, uint32_t cap_words, uint32_t* n_words,
                          uint32_t* count, uint32_t* start, uint32_t* end);
-int dp_index_seedset_row(dp_ctx* ctx, uint32_t seq, uint64_t* words, uint32_t cap_words, uint32_t* n_words);
+DP_API int dp_index_seedset_row(dp_ctx* ctx, uint32_t seq, uint64_t* words, uint32_t cap_words, uint32_t* n_words);
 
 /* Device pointers of the last dp_scan output, for a multi-GPU exchange driven by the caller (RCCL all-gather of
  * the survivors).  segs_dev: int32[n_segs]. */
-int dp_scan_device_buffers(dp_ctx* ctx, void** segs_dev, uint64_t* n_segs);
+DP_API int dp_scan_device_buffers(dp_ctx* ctx, void** segs_dev, uint64_t* n_segs);
 /* Replace the device-resident scan output with externally gathered segments (host pointer). */
-int dp_scan_import_segments(dp_ctx* ctx, const int32_t* segs, uint64_t n_segs);
+DP_API int dp_scan_import_segments(dp_ctx* ctx, const int32_t* segs, uint64_t n_segs);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,16 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in L.dp_version()
 
 
+def test_library_exports_nothing_else():
+    """The dynamic symbol table holds the C ABI only (version script + -fvisibility=hidden): no kernel launch stubs, no
+    C++ template instantiations, no internal helpers."""
+    import subprocess
+    import downpore_amd.hip as h
+    out = subprocess.check_output(["nm", "-D", "--defined-only", h.lib_path()], text=True)
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported == _header_symbols()
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
