@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """bench.py — overlaps/sec of the all-vs-all overlap hot path on synthetic long reads (BASELINE.json metric).
 
-A "step" is one round of the overlap command (commands/overlap.go:115-194): seed selection for the next query batch,
-the seed occurrences of every non-ignored read (from the resident k-mer position index at this size, by the scan kernels
-below 1 Gbase or with DP_SCAN_INDEX=0), survivor exchange (N>1), index build, index query + chaining, consensus, PAF.
-`roofline` describes the dominant kernel of the mode that ran; a second, shorter leg times the other mode.
-Workload (N=1 default): BASELINE config 2 — 100 000 synthetic reads x 10 kb, genome 50 Mb (20x), k=13, error-free
-(the error-free set is the throughput default at k=13).  Inputs are resident in HBM before the timed
-region.  Prints ONE JSON line on rank 0.
+A "step" is ONE WHOLE JOB: one pass of the hot path over the batch of synthetic input, i.e. everything `downpore overlap`
+does (commands/overlap.go:39-195) for BASELINE config 2 — 100 000 synthetic reads x 10 kb, genome 50 Mb (20x), k=13,
+error-free (the error-free set is the throughput default at k=13) — from "packed reads resident in HBM" to
+"last PAF line formatted": the k-mer value table (dp_kmer_values), the resident k-mer position index (dp_scan_prepare),
+executor slots + planner, then EVERY round (599): seed selection, seed occurrences of every non-ignored read, survivor
+exchange (N>1), index build, index query + chaining, consensus, PAF.  Nothing is carried over between steps except the
+packed reads; the timed region is K consecutive jobs between two barriers.  `value` = PAF lines / wall time.
+The PCIe-inclusive rate (upload + packing of the ASCII reads added to every job) is reported beside it as
+`value_incl_upload`; the steady-state rate of the rounds alone as `rounds_only`.
+The PAF of the first job is checked against the committed oracle fixture (tests/golden_full/config2.json: SHA-256 over all
+3.9 M lines); every timed job must print the same number of lines.
+`roofline` describes the kernel with the largest accumulated time of a job.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,20 +32,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=3, help="timed whole jobs")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed whole jobs before them")
     ap.add_argument("--reads", type=int, default=100000)
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--k", type=int, default=13)
     ap.add_argument("--error", type=float, default=0.0)
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--seed-batch-size", type=int, default=10000)
+    ap.add_argument("--max-rounds", type=int, default=-1, help="cut every job after this many rounds (experiments only)")
     ap.add_argument("--cpu-rounds", type=int, default=2, help="oracle rounds timed for cpu_baseline (0 = skip)")
     ap.add_argument("--slots", type=int, default=6, help="rounds executed concurrently per GPU (executor slots)")
-    ap.add_argument("--index-steps", type=int, default=100,
-                    help="N=1: after the timed region, time this many further rounds in the other scan mode (index <-> scan "
-                         "kernels; reported as scan_kernels_leg / index_mode; 0 = skip)")
-    ap.add_argument("--mode", default="round", choices=["round", "round-batch", "scan-shard"], help="multi-GPU decomposition (N > 1)")
+    ap.add_argument("--scan-leg-rounds", type=int, default=60,
+                    help="N=1: after the timed region, this many rounds with the scan kernels instead of the k-mer index "
+                         "(reported as scan_kernels_leg with the count pass's achieved GB/s; 0 = skip)")
+    ap.add_argument("--dense-leg-rounds", type=int, default=12,
+                    help="N=1: after the timed region, this many rounds of the dense-seed regime (k=10) where the index query "
+                         "carries real traffic (reported as index_query_dense; 0 = skip)")
+    ap.add_argument("--mode", default="scan-shard", choices=["round", "round-batch", "scan-shard"], help="multi-GPU decomposition (N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -78,10 +88,9 @@ def main():
     bases, off = gen_reads(args.seed, G, N, L, args.error, False)
     reads = Reads(bases, off, min_len=1000)
     t_gen = time.time() - t0
-    t0 = time.time()
     pipe = OverlapPipeline(reads, device=local_rank, k=args.k, seed_batch_size=args.seed_batch_size, rank=rank, world=world,
-                           torch_device=torch_device, mode=args.mode, slots=args.slots)
-    t_setup = time.time() - t0
+                           torch_device=torch_device, mode=args.mode, slots=args.slots, defer_init=True)
+    upload = pipe.setup_times()
 
     def sync():
         torch.cuda.synchronize()
@@ -89,14 +98,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    warm = 0
-    while warm < args.warmup:
-        c = pipe.step()
-        if c == 0:
-            break
-        warm += c
-    pipe.drain()  # rounds the executor pipeline has in flight are thrown away: the timed region starts from an empty pipeline
+    golden = golden_fixture(args)
+    checks = {"fixture": golden["case"] if golden else None, "paf_sha256_matches_oracle_fixture": None, "jobs_with_equal_line_count": 0}
+
+    def job(verify=False):
+        """One whole job on the resident reads.  Returns (PAF lines, rounds, per-job kernel/phase totals, seconds of init)."""
+        pipe.init()
+        lines = rounds = 0
+        while args.max_rounds < 0 or rounds < args.max_rounds:
+            c = pipe.step()
+            if c == 0:
+                break
+            rounds += c
+            lines += pipe.step_lines()
+        tot = pipe.stats_total()
+        t_init = pipe.setup_times()["init_s"]
+        if verify and rank == 0:
+            paf = pipe.all_paf()
+            res["first_job_paf"] = paf if args.cpu_rounds > 0 and world == 1 else None
+            res["values"] = pipe.values() if args.cpu_rounds > 0 and world == 1 else None
+            if golden is not None and args.max_rounds < 0:
+                checks["paf_sha256_matches_oracle_fixture"] = bool(hashlib.sha256(paf.encode()).hexdigest() == golden["paf_sha256"] and
+                                                                   lines == golden["paf_lines"] and rounds == golden["rounds"])
+        pipe.reset()
+        return lines, rounds, tot, t_init
+
+    res = {}
+    verified = False
+    for _ in range(args.warmup):
+        job(verify=not verified)
+        verified = True
     sync()
+
     def cpu_stat():
         out = {}
         try:
@@ -108,21 +141,19 @@ def main():
         return out
 
     cs0 = cpu_stat()
-    acc = {}
-    lines = 0
-    steps_done = 0   # rounds committed in the timed region (a step = one round; with N ranks a call commits up to N)
-    samples = 0
+    acc, lines, rounds, t_init_sum, per_job = {}, 0, 0, 0.0, []
     t_start = time.perf_counter()
-    while steps_done < args.steps:
-        c = pipe.step()
-        if c == 0:
-            break
-        st = pipe.stats()  # stats of the last committed round
-        for key, v in st.items():
+    for _ in range(args.steps):
+        tj = time.perf_counter()
+        jl, jr, tot, ti = job()
+        per_job.append(time.perf_counter() - tj)
+        lines += jl
+        rounds += jr
+        t_init_sum += ti
+        for key, v in tot.items():
             acc[key] = acc.get(key, 0.0) + v
-        samples += 1
-        lines += pipe.step_lines()
-        steps_done += c
+        if lines == jl * len(per_job):
+            checks["jobs_with_equal_line_count"] = len(per_job)
     sync()
     elapsed = time.perf_counter() - t_start
     cs1 = cpu_stat()
@@ -130,56 +161,23 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch_device if torch_device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if not verified:  # --warmup 0: the fixture check runs on an extra, untimed job
+        job(verify=True)
 
-    # Same job continued in the OTHER scan mode (dp_scan_reads answers either from the resident k-mer position index,
-    # dp_kindex.hip - the default from 1 Gbase up - or by streaming the packed reads through scan_kernel).  Reported next
-    # to the headline number, never instead of it.
-    main_index = bool(acc.get("idx_rounds"))
-    alt = None
-    if world == 1 and args.index_steps > 0 and "DP_SCAN_INDEX" not in os.environ:
-        pipe.drain()
-        os.environ["DP_SCAN_INDEX"] = "0" if main_index else "1"
-        tb0 = time.perf_counter()
-        got = pipe.step()  # (index mode: builds the index, one-off, and runs a round)
-        tb1 = time.perf_counter()
-        w2 = got
-        while got and w2 < args.warmup:
-            got = pipe.step()
-            w2 += got
-        pipe.drain()
-        sync()
-        iacc, ilines, isteps, isamples = {}, 0, 0, 0
-        ti0 = time.perf_counter()
-        while got and isteps < args.index_steps:
-            got = pipe.step()
-            if got == 0:
-                break
-            for key, v in pipe.stats().items():
-                iacc[key] = iacc.get(key, 0.0) + v
-            isamples += 1
-            ilines += pipe.step_lines()
-            isteps += got
-        sync()
-        iel = time.perf_counter() - ti0
+    # ---- secondary legs (N=1, after the timed region, never part of `value`)
+    scan_leg = dense_leg = None
+    if world == 1 and args.scan_leg_rounds > 0 and "DP_SCAN_INDEX" not in os.environ and acc.get("idx_rounds"):
+        os.environ["DP_SCAN_INDEX"] = "0"
+        scan_leg = rounds_leg(pipe, args.scan_leg_rounds, torch)
         del os.environ["DP_SCAN_INDEX"]
-        pipe.drain()
-        if isteps:
-            m = max(1, isamples)
-            alt = {"value": ilines / iel, "unit": "overlaps/s", "steps": isteps, "ms_per_step": 1e3 * iel / isteps,
-                   "kernel_ms_per_step": {kk: iacc.get(kk, 0.0) / m for kk in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms")},
-                   "count_step_algorithmic_bytes": iacc.get("count_bytes", 0.0) / m}
-            if main_index:  # the alternative leg streamed the reads: its count pass is the HBM-streaming kernel of the path
-                cms = iacc.get("k_count_ms", 0.0) / m
-                cb = iacc.get("count_bytes", 0.0) / m
-                alt["scan_count_pass"] = {"kernel": "scan_kernel<0>", "launch_ms": cms, "algorithmic_bytes_per_launch": cb,
-                                          "achieved_GBs": (cb / 1e9) / (cms / 1e3) if cms > 0 else 0.0,
-                                          "frac_of_hbm_peak": ((cb / 1e9) / (cms / 1e3)) / HBM_PEAK_GBS if cms > 0 else 0.0}
-            else:
-                alt.update({"first_round_incl_index_build_s": tb1 - tb0,
-                            "rounds_served_by_index": iacc.get("idx_rounds", 0.0),
-                            "seed_occurrences_per_step": iacc.get("idx_hits", 0.0) / m,
-                            "resident_bytes": 8 * int(reads.total_bases()) + 8 * (4 ** args.k + 1),
-                            "note": "no kernel of this mode streams the reads"})
+        m = max(1.0, scan_leg.pop("_rounds"))
+        cms, cb = scan_leg["kernel_ms_per_round"]["k_count_ms"], scan_leg.pop("_count_bytes") / m
+        scan_leg["scan_count_pass"] = {"kernel": "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)", "launch_ms": cms,
+                                       "algorithmic_bytes_per_launch": cb, "achieved_GBs": (cb / 1e9) / (cms / 1e3) if cms > 0 else 0.0,
+                                       "frac_of_hbm_peak": ((cb / 1e9) / (cms / 1e3)) / HBM_PEAK_GBS if cms > 0 else 0.0}
+    pipe.close()
+    if world == 1 and args.dense_leg_rounds > 0:
+        dense_leg = dense_regime_leg(reads, args, torch)
 
     stream_gbs = None
     if rank == 0:
@@ -200,11 +198,12 @@ def main():
         except Exception:
             stream_gbs = None
     if rank == 0:
-        n = max(1, samples)
-        count_ms = acc.get("k_count_ms", 0.0) / n
-        count_bytes = acc.get("count_bytes", 0.0) / n
-        chain_ms = acc.get("k_chain_ms", 0.0) / n
-        chain_bytes = acc.get("chain_bytes", 0.0) / n
+        n_jobs = max(1, args.steps)
+        n = max(1.0, float(rounds))  # per-round averages over every round of every timed job
+        main_index = bool(acc.get("idx_rounds"))
+
+        def per_round(key):
+            return acc.get(key, 0.0) / n
 
         def pmc_traffic(name):
             tpath = os.path.join(ROOT, "profiles", name)
@@ -213,73 +212,135 @@ def main():
             except Exception:
                 return None
 
+        # kernels of a job that are launched once per round, with their algorithmic bytes and HIP-event times
+        kern = {
+            "chain_kernel": (per_round("k_chain_ms"), per_round("chain_bytes"), "chain_traffic.json",
+                             "chain kernels (A6 prefilter + A7 chaining + A8 ratchet of every (query, candidate) pair)"),
+            "query_kernel": (per_round("k_query_ms"), per_round("query_bytes"), "query_traffic.json",
+                             "query_kernel (A14 + A5: soft union of the posting bitsets)"),
+        }
         if main_index:
-            # no kernel of the run streams the reads; the dominant kernel (by time, in the run and in the rocprofv3 trace) is
-            # chain_kernel: prefilter + seed chaining of every (query, candidate) pair, one wave per query, sequential over its
-            # candidates because of the minMatches ratchet (overlap.go:380-382) - latency-bound, priced against HBM all the same
-            rl_kernel = ("chain_kernel (A5 prefilter + A6/A7/A8 chaining; latency-bound: one wave walks a query's candidates in "
-                         "order) - the run used the resident k-mer position index, no kernel streams the reads")
-            rl_bytes, rl_ms, traffic = chain_bytes, chain_ms, pmc_traffic("chain_traffic.json")
+            kern["index_counting_step"] = (per_round("k_count_ms"), per_round("count_bytes"), "kindex_traffic.json",
+                                           "k-mer position index lookup of the round's seeds (A2/A10 without a scan)")
         else:
-            rl_kernel = "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)"
-            rl_bytes, rl_ms, traffic = count_bytes, count_ms, pmc_traffic("scan_traffic.json")
+            kern["scan_kernel<0>"] = (per_round("k_count_ms"), per_round("count_bytes"), "scan_traffic.json",
+                                      "scan_kernel<0> (count pass of the packed k-mer scan, A2/A10)")
+        dom = max(kern, key=lambda kk: kern[kk][0])
+        rl_ms, rl_bytes, rl_file, rl_desc = kern[dom]
         achieved = (rl_bytes / 1e9) / (rl_ms / 1e3) if rl_ms > 0 else 0.0
+        job_s = elapsed / n_jobs
         out = {
             "metric": "overlaps/sec (all-vs-all PAF)", "value": lines / elapsed if elapsed > 0 else 0.0, "unit": "overlaps/s",
-            "n_gpus": world, "steps": steps_done, "warmup": warm, "ms_per_step": 1e3 * elapsed / max(1, steps_done),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * job_s,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%d synthetic reads x %d bp, genome %d bp (20x), error %.3g, k=%d, overlap rounds "
-                                   "(BASELINE config 2)" % (N, L, G, args.error, args.k),
+            "config": {"workload": "whole `overlap` job per step: %d synthetic reads x %d bp, genome %d bp (20x), error %.3g, k=%d, all %d "
+                                   "rounds from packed reads resident in HBM to the last PAF line (BASELINE config 2)"
+                                   % (N, L, G, args.error, args.k, rounds // n_jobs),
                        "reads": N, "read_len": L, "k": args.k, "seed_batch_size": args.seed_batch_size, "executor_slots_per_gpu": args.slots,
+                       "rounds_per_step": rounds / n_jobs, "paf_lines_per_step": lines / n_jobs,
                        "parallelism": ("single GPU" if world == 1 else
+                                       "scan sharded by read over %d GPUs, survivors all-gathered (RCCL), identical index on every rank" % world
+                                       if args.mode == "scan-shard" else
                                        "round-parallel over %d GPUs: rank r's executor pipeline runs the rounds r, r+N, ...; one round "
-                                       "per rank all-gathered (RCCL) per superstep and committed in order" % world if args.mode.startswith("round") else
-                                       "scan sharded by read over %d GPUs, survivors all-gathered (RCCL)" % world)},
-            "roofline": {"bound": "hbm", "kernel": rl_kernel,
+                                       "per rank all-gathered (RCCL) per superstep and committed in order" % world)},
+            "roofline": {"bound": "hbm", "kernel": rl_desc + " - largest accumulated kernel time of a job",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": rl_bytes, "launch_ms": rl_ms,
-                         "measured_stream_GBs": stream_gbs,
-                         "frac_of_measured_stream": (achieved / stream_gbs) if stream_gbs else None},
-            # the other kernels of a round, same convention (algorithmic bytes / HIP-event time); chain_kernel is a
-            # latency-bound per-query state machine, its byte rate is reported for completeness only
-            "other_kernels": {
-                ("index_counting_step" if main_index else "scan_count_pass"): {
-                    "ms": count_ms, "algorithmic_bytes": count_bytes,
-                    "GBs": (count_bytes / 1e9) / (count_ms / 1e3) if count_ms > 0 else 0.0},
-                ("index_write" if main_index else "scan_write_pass"): {
-                    "ms": acc.get("k_write_ms", 0.0) / n,
-                    "algorithmic_bytes": (acc.get("scan_bytes", 0.0) - acc.get("count_bytes", 0.0)) / n},
-                "index_query": {"ms": acc.get("k_query_ms", 0.0) / n, "algorithmic_bytes": acc.get("query_bytes", 0.0) / n,
-                                "GBs": (acc.get("query_bytes", 0.0) / 1e9) / (acc.get("k_query_ms", 0.0) / 1e3) if acc.get("k_query_ms", 0) > 0 else 0.0},
-                "chain_kernel": {"ms": chain_ms, "bound": "latency (sequential ratchet per query)", "algorithmic_bytes": chain_bytes,
-                                 "GBs": (chain_bytes / 1e9) / (chain_ms / 1e3) if chain_ms > 0 else 0.0,
-                                 "matches_per_step": acc.get("n_matches", 0.0) / n},
-            },
+                         "traffic": pmc_traffic(rl_file), "algorithmic_bytes_per_launch": rl_bytes, "launch_ms": rl_ms,
+                         "launches_per_step": rounds / n_jobs, "measured_stream_GBs": stream_gbs},
+            "parity": checks,
+            # the PCIe-inclusive rate: the ASCII reads cross PCIe and are packed on the device once per job (never `value`)
+            "value_incl_upload": lines / (elapsed + n_jobs * upload["upload_pack_s"]) if elapsed > 0 else 0.0,
+            "rounds_only": {"value": lines / max(1e-9, elapsed - t_init_sum), "unit": "overlaps/s",
+                            "ms_per_round": 1e3 * (elapsed - t_init_sum) / n,
+                            "note": "the same timed jobs without their set-up (value table, k-mer index, slots, planner)"},
+            "job_breakdown_s": {"whole_job": job_s, "setup_value_table_kmer_index_slots": t_init_sum / n_jobs,
+                                "rounds": (elapsed - t_init_sum) / n_jobs, "upload_pack_once": upload["upload_pack_s"],
+                                "context_once": upload["context_s"], "per_job": per_job},
+            "kernels_per_round": {kk: {"ms": v[0], "algorithmic_bytes": v[1], "GBs": (v[1] / 1e9) / (v[0] / 1e3) if v[0] > 0 else 0.0,
+                                       "frac_of_hbm_peak": ((v[1] / 1e9) / (v[0] / 1e3)) / HBM_PEAK_GBS if v[0] > 0 else 0.0}
+                                  for kk, v in kern.items()},
             "scan_mode": "resident k-mer position index" if main_index else "scan kernels",
-            ("scan_kernels_leg" if main_index else "index_mode"): alt,
-            "paf_lines": lines, "rounds_per_s": steps_done / elapsed if elapsed > 0 else 0.0,
-            "reads_scanned_per_s": (acc.get("scan_items", 0.0) / n) * steps_done / elapsed if elapsed > 0 else 0.0,
-            "phase_ms_per_step": {kk: 1e3 * acc.get(kk, 0.0) / n for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
-            "kernel_ms_per_step": {kk: acc.get(kk, 0.0) / n for kk in ("k_count_ms", "k_write_ms", "k_scan_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
-            "index_query": {"bytes_per_step": acc.get("query_bytes", 0.0) / n,
-                            "achieved_GBs": (acc.get("query_bytes", 0.0) / 1e9) / (acc.get("k_query_ms", 1e-9) / 1e3) if acc.get("k_query_ms", 0) > 0 else 0.0},
-            "setup_s": {"generate": t_gen, "upload_pack_histogram_values": t_setup},
+            "scan_kernels_leg": scan_leg, "index_query_dense": dense_leg,
+            "paf_lines": lines, "rounds_per_s": rounds / elapsed if elapsed > 0 else 0.0,
+            "phase_ms_per_round": {kk: 1e3 * per_round(kk) for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
+            "kernel_ms_per_round": {kk: per_round(kk) for kk in ("k_count_ms", "k_write_ms", "k_scan_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
+            "setup_s": {"generate": t_gen},
             # host side of the timed region: CPU seconds used by this container and time it spent throttled by its CPU quota
             "host": host_info(),
             "host_cpu": {"cpu_s": (cs1.get("usage_usec", 0) - cs0.get("usage_usec", 0)) / 1e6,
                          "throttled_s": (cs1.get("throttled_usec", 0) - cs0.get("throttled_usec", 0)) / 1e6,
                          "wall_s": elapsed},
         }
-        if world == 1 and args.cpu_rounds > 0:
-            vals = pipe.values()
-            gpu_paf = pipe.all_paf()  # every committed round so far, in round order
-            out["cpu_baseline"] = cpu_baseline(bases, off, args, vals, threads=1, check_against=gpu_paf)
+        if world == 1 and args.cpu_rounds > 0 and res.get("values") is not None:
+            out["cpu_baseline"] = cpu_baseline(bases, off, args, res["values"], threads=1, check_against=res["first_job_paf"])
             # the same port with its per-read scans spread over the host cores this container may use
-            out["cpu_baseline_all_cores"] = cpu_baseline(bases, off, args, vals, threads=cpu_budget())
+            out["cpu_baseline_all_cores"] = cpu_baseline(bases, off, args, res["values"], threads=cpu_budget())
         print(json.dumps(out))
-    pipe.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def rounds_leg(pipe, n_rounds, torch, warm=8):
+    """`n_rounds` rounds of a fresh job on `pipe` (after `warm` untimed ones): rate and per-round kernel times."""
+    pipe.init()
+    got = w = 0
+    while w < warm:
+        c = pipe.step()
+        if c == 0:
+            break
+        w += c
+    pipe.drain()
+    torch.cuda.synchronize()
+    base = pipe.stats_total()
+    t0 = time.perf_counter()
+    lines = 0
+    while got < n_rounds:
+        c = pipe.step()
+        if c == 0:
+            break
+        got += c
+        lines += pipe.step_lines()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tot = pipe.stats_total()
+    pipe.reset()
+    m = max(1, got)
+    d = {kk: tot.get(kk, 0.0) - base.get(kk, 0.0) for kk in tot}
+    return {"value": lines / dt if dt > 0 else 0.0, "unit": "overlaps/s", "rounds": got, "ms_per_round": 1e3 * dt / m,
+            "kernel_ms_per_round": {kk: d.get(kk, 0.0) / m for kk in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms")},
+            "query_bytes_per_round": d.get("query_bytes", 0.0) / m, "n_indexed_per_round": d.get("n_indexed", 0.0) / m,
+            "_rounds": float(got), "_count_bytes": d.get("count_bytes", 0.0)}
+
+
+def dense_regime_leg(reads, args, torch):
+    """The dense-seed regime of SURVEY 8(a) (`-k 10`, the command's default k): every read is indexed (~190 k sequences per
+    round, W ~ 3 k words), so the index query streams hundreds of MB of posting words per round - the regime in which the
+    north star's "HBM roofline during index-query" is a meaningful number.  Same reads, same code path."""
+    from downpore_amd.overlap import OverlapPipeline
+    pipe = OverlapPipeline(reads, device=0, k=10, seed_batch_size=args.seed_batch_size, slots=args.slots, defer_init=True)
+    leg = rounds_leg(pipe, args.dense_leg_rounds, torch, warm=4)
+    pipe.close()
+    m = max(1.0, leg.pop("_rounds"))
+    leg.pop("_count_bytes")
+    qms, qb = leg["kernel_ms_per_round"]["k_query_ms"], leg["query_bytes_per_round"]
+    leg["query_kernel"] = {"launch_ms": qms, "algorithmic_bytes_per_launch": qb,
+                           "achieved_GBs": (qb / 1e9) / (qms / 1e3) if qms > 0 else 0.0,
+                           "frac_of_hbm_peak": ((qb / 1e9) / (qms / 1e3)) / HBM_PEAK_GBS if qms > 0 else 0.0}
+    leg["workload"] = "same reads, k=10 (dense seeds): %d rounds" % int(m)
+    return leg
+
+
+def golden_fixture(args):
+    """tests/golden_full/config2.json (tools/make_golden_full.py: the oracle alone, every round) when the workload is config 2."""
+    path = os.path.join(ROOT, "tests", "golden_full", "config2.json")
+    try:
+        g = json.load(open(path))
+    except Exception:
+        return None
+    gen = g["generator"]
+    same = (gen["seed"] == args.seed and gen["reads"] == args.reads and gen["read_len"] == args.read_len and
+            gen["error"] == args.error and g["k"] == args.k and args.seed_batch_size == 10000)
+    return g if same else None
 
 
 def host_info():

@@ -85,6 +85,8 @@ struct dp_ctx {
     int kcounts_k = 0;
     std::vector<void*> retired_dev, retired_pin;  // outgrown buffers, released with the context (dev_reserve / pin_reserve)
     DevBuf d_qsegs, d_qoff, d_qsets, d_qmeta, d_cand, d_pool, d_mrec, d_ma, d_mb, d_cursor, d_sched, d_manchor;
+    DevBuf d_pbase, d_pspec, d_clist, d_sa, d_sb;  // chaining stage: pair offsets, proposals, candidate lists, scratch columns
+    uint32_t n_pairs = 0;                          // (query, candidate) pair slots of the last dp_find_overlaps
     PinBuf h_mrec, h_ma, h_mb, h_ta, h_tb, h_qm, h_qup, h_cursor, h_cand, h_cand_off, h_cand_list, h_mq, h_mt, h_moff, h_manchor, h_manout;
 };
 
@@ -116,7 +118,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
 int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t nw, int k,
                         dp_chain_batch* out);
 int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
-                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out);
+                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out = nullptr);
 
 // ---- device helpers ---------------------------------------------------------------------------------------
 #ifdef __HIPCC__

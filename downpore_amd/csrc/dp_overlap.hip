@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
                                                              const uint32_t* __restrict__ pmeta, uint32_t n_seqs, uint32_t W,
                                                              const int32_t* __restrict__ mc, uint32_t mc_n,
                                                              u64* __restrict__ cand, uint32_t* __restrict__ qmeta,
-                                                             u64* __restrict__ words_read) {
+                                                             u64* __restrict__ words_read, uint32_t* __restrict__ qcnt) {
     __shared__ QWave sh[Q_WAVES];
     QWave& S = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
@@ -289,6 +289,7 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
     const bool exact = minCount > 24;  // fast=false (util/bitset.go:309-311)
 
     u64 gathered = 0;
+    int nCand = 0;  // Matches() result size of this query (bits set in its cand row)
     for (int64_t ib = start; ib <= i_last; ib += 64) {
         const int64_t i = ib + lane;
         if (i > i_last) continue;
@@ -379,9 +380,14 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
             }
         }
         cand[(uint64_t)q * W + iw] = v;
+        nCand += __popcll(v);
     }
     gathered = (u64)wave_sum((int)gathered);
-    if (lane == 0) words_read[q] = gathered;
+    nCand = wave_sum(nCand);
+    if (lane == 0) {
+        words_read[q] = gathered;
+        qcnt[q] = (uint32_t)nCand;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -405,6 +411,8 @@ struct CNode {  // one link of a chain (pairState.prev history), written once
 #define C_QSW 256        // query bitset words staged in LDS
 
 struct CWave {
+    typedef uint32_t col_t;
+    enum { COLN = 64, EVN = C_REV, ACAP = C_ACAP, RSEEDS = 255, SLIM = 0 };
     int32_t aRed[512];
     int32_t aMap[256];
     int32_t aSegL[C_ACAP];
@@ -421,12 +429,32 @@ struct CWave {
             CNode lnodes[C_LNODES];
         };
         struct {  // reg tier
-            uint32_t col[64][64];  // matched pairs of open chain i: reducedA | bSeedIndex << 16
+            col_t col[64][COLN];  // matched pairs of open chain i: reducedA | bSeedIndex << 6
             int4 ev[C_REV];
             int32_t ps[64];
             uint32_t rescol[64];
         };
     };
+};
+
+// The reg tier's working set alone, a quarter of CWave: the proposal pass (chain_spec_kernel) runs one wave per PAIR and is
+// bound by how many waves a CU holds.  Pairs that do not fit (query > 128 seeds, reduced a > 64, > 128 b events, a chain
+// longer than 32, more than 64 open chains, target > C_BCAP ints) are left to the final walk, which has the full CWave.
+struct CSlim {
+    typedef uint16_t col_t;
+    enum { COLN = 32, EVN = 128, ACAP = 256, RSEEDS = 64, SLIM = 1 };
+    int32_t aRed[2 * 64 + 2];
+    int32_t aMap[64];
+    int32_t aSegL[256];
+    u64 aFlag[2];
+    u64 bFlag[C_BCAP / 128 + 1];
+    union {
+        int32_t bSegL[C_BCAP];  // dead once the b events are built
+        col_t col[64][COLN];
+    };
+    int4 ev[EVN];
+    int32_t ps[64];
+    uint32_t rescol[64];
 };
 
 __device__ __forceinline__ void node_put(CWave& L, CNode* __restrict__ nodes, int idx, CNode nd) {
@@ -687,8 +715,10 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
 // bGap).  Chains evaluated in one step cannot influence each other: removals above the break never reach minMatches
 // (length + remaining < minMatches), so minMatches is constant until the break itself.
 
-// prepareInitial :341-388.  Returns false when the reference would overrun `reduced` (err bit 1).
-__device__ bool wave_prepare_initial(int aN, int minMatches, int k, int maxLength, CWave& L, int* aLenOut, int* startOut) {
+// prepareInitial :341-388.  Returns 0, or 1 when the reference would overrun `reduced` (err bit 1) / the staging arrays
+// are too small (CSlim: the pair is left to the full-size path).
+template <class LW>
+__device__ int wave_prepare_initial(int aN, int minMatches, int k, int maxLength, LW& L, int* aLenOut, int* startOut) {
     const int lane = dp_lane();
     const u64 lanesBelow = (1ull << lane) - 1ull;
     const int nA = aN >> 1;
@@ -719,7 +749,7 @@ __device__ bool wave_prepare_initial(int aN, int minMatches, int k, int maxLengt
         const int rank = aLen + __popcll(kb);
         bool isStart = false;
         if (keep) {
-            if (rank * 2 + 1 >= maxLength || rank >= maxLength / 2 || rank * 2 + 2 >= 512) {
+            if (rank * 2 + 1 >= maxLength || rank >= maxLength / 2 || rank >= (int)LW::RSEEDS) {
                 bad = true;
             } else {
                 L.aRed[2 * rank] = Pin - Pk - k;
@@ -728,27 +758,27 @@ __device__ bool wave_prepare_initial(int aN, int minMatches, int k, int maxLengt
                 isStart = rank <= C0 - (s - rank);
             }
         }
-        if (__ballot(bad)) return false;
+        if (__ballot(bad)) return 1;
         startSize += __popcll(__ballot(isStart));
         if (inBmask) prevSeed = __shfl(seed, 63 - __builtin_clzll(inBmask), 64);
         if (keepMask) PatKept = __shfl(Pin, 63 - __builtin_clzll(keepMask), 64);
         P = __shfl(Pin, 63, 64);
         aLen += __popcll(keepMask);
     }
-    if (aLen * 2 >= maxLength) return false;
+    if (aLen * 2 >= maxLength) return 1;
     if (lane == 0) L.aRed[aLen * 2] = 0;
     const int maxAIndex = C0 - (nA - aLen);
     while (startSize > 0 && (2 * (startSize - 1) + 1) > maxAIndex) startSize--;
     *aLenOut = aLen;
     *startOut = startSize;
-    return true;
+    return 0;
 }
 
 // b seeds that reach searchMatch (:449-457) with the bOffset accumulated since the previous one.  WIDE: 16-byte
 // records {bIndex, bOffset, seed, gap after} for the reg tier, else evIdx/evOff.  Returns the number of events
 // (records beyond `cap` are not stored).
-template <bool WIDE>
-__device__ int wave_b_events(int bN, int k, CWave& L, int cap) {
+template <bool WIDE, class LW>
+__device__ int wave_b_events(int bN, int k, LW& L, int cap) {
     const int lane = dp_lane();
     const u64 lanesBelow = (1ull << lane) - 1ull;
     const int nB = bN >> 1;
@@ -776,7 +806,7 @@ __device__ int wave_b_events(int bN, int k, CWave& L, int cap) {
         if (ev) {
             const int idx = nE + __popcll(eb);
             if (idx < cap) {
-                if (WIDE) {
+                if constexpr (WIDE) {
                     L.ev[idx] = make_int4(2 * s + 1, Qin - Qe, seed, gapAfter);
                 } else {
                     L.evIdx[idx] = (uint16_t)(2 * s + 1);
@@ -795,17 +825,19 @@ __device__ int wave_b_events(int bN, int k, CWave& L, int cap) {
 #define RL(v_, l_) __builtin_amdgcn_readlane((v_), (l_))
 #define RFL(v_) __builtin_amdgcn_readfirstlane(v_)
 
-// reg tier.  Returns the length of results[0] (its pairs are left in L.rescol as reducedA | bSeed<<16), 0, or -1 when
+// reg tier.  Returns the length of results[0] (its pairs are left in L.rescol as reducedA | bSeed<<6), 0, or -1 when
 // the pair needs the lds tier.
-__device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, int k, CWave& L, uint32_t* err, bool prof,
+template <class LW>
+__device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, int k, LW& L, uint32_t* err, bool prof,
                               u64* tp) {
     const int lane = dp_lane();
     if (startSize == 0) return 0;  // no initial position: no chain can ever start
     int live = startSize;
     const int initialSize = startSize;
     const int aRedLen = aLen * 2 + 1;
-    const int nE = wave_b_events<true>(bN, k, L, C_REV);
-    if (nE > C_REV) return -1;
+    const int nE = wave_b_events<true>(bN, k, L, (int)LW::EVN);
+    if (nE > (int)LW::EVN) return -1;
+    __builtin_amdgcn_wave_barrier();  // (CSlim: the columns below reuse b's staging area)
     if (prof) tp[2] += (u64)nE;
     const int myA = lane < aLen ? L.aRed[2 * lane + 1] : -1;
     {
@@ -922,9 +954,10 @@ __device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, i
                         return 0;
                     }
                     const int nl = RL(st_len, ibLane) + 1;
+                    if (nl > (int)LW::COLN) return -1;  // (CSlim) longer than a column
                     const int nextGap = L.aRed[j + 1];
                     if (lane == ibLane) {
-                        L.col[ibLane][nl - 1] = (uint32_t)(j >> 1) | ((uint32_t)(bIndex >> 1) << 16);
+                        L.col[ibLane][nl - 1] = (typename LW::col_t)((uint32_t)(j >> 1) | ((uint32_t)(bIndex >> 1) << 6));
                         st_aPos = j;
                         st_bPos = bIndex;
                         st_aGapIndex = j + 2;
@@ -957,7 +990,7 @@ __device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, i
                 }
                 const int nextGap = L.aRed[aPos + 1];
                 if (lane == openSize) {
-                    L.col[openSize][0] = (uint32_t)i | ((uint32_t)(bIndex >> 1) << 16);
+                    L.col[openSize][0] = (typename LW::col_t)((uint32_t)i | ((uint32_t)(bIndex >> 1) << 6));
                     st_aPos = aPos;
                     st_bPos = bIndex;
                     st_aGapIndex = aPos + 2;
@@ -1229,202 +1262,516 @@ struct MRec {
 // (~6 KB of pinned memory) per match, here it is one wave per match over segments that are resident anyway.
 // anchors[2*slot] = seg[0] + sum_{t=1..first}(seg[2t]+k), anchors[2*slot+1] = seg[n-1] + sum_{t=last+1..ns-1}(seg[2t]+k);
 // -1 when the chain's indices are not inside the target (the host then sums itself).
-__global__ __launch_bounds__(256) void match_anchor_kernel(const MRec* __restrict__ recs, uint32_t nslots, const int32_t* __restrict__ mb,
+__global__ __launch_bounds__(256) void match_anchor_kernel(const MRec* __restrict__ recs, const uint32_t* __restrict__ n_pairs,
+                                                           uint32_t pair_cap, const int32_t* __restrict__ mb,
                                                            const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, int k,
                                                            int32_t* __restrict__ anchors) {
     const int lane = threadIdx.x & 63;
-    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (slot >= nslots) return;
-    const MRec r = recs[slot];
-    if (r.len == 0) return;
-    const int first = mb[r.off], last = mb[r.off + r.len - 1];
-    const dp_seq_ref ref = refs[r.t];
-    const int ns = (int)ref.n_seeds;
-    const int32_t* s = segs + ref.seg_off;
-    if (first < 0 || last < 0 || first >= ns || last >= ns) {
-        if (lane == 0) anchors[2 * slot] = anchors[2 * slot + 1] = -1;
-        return;
-    }
-    int a = 0, b = 0;
-    for (int t = 1 + lane; t <= first; t += 64) a += s[2 * t] + k;
-    for (int t = last + 1 + lane; t <= ns - 1; t += 64) b += s[2 * t] + k;
-    for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_xor(a, o);
-        b += __shfl_xor(b, o);
-    }
-    if (lane == 0) {
-        anchors[2 * slot] = s[0] + a;
-        anchors[2 * slot + 1] = s[2 * ns] + b;
+    const uint32_t nslots = min(*n_pairs, pair_cap);
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); slot < nslots; slot += waves) {
+        const MRec r = recs[slot];
+        if (r.len == 0) continue;
+        const int first = mb[r.off], last = mb[r.off + r.len - 1];
+        const dp_seq_ref ref = refs[r.t];
+        const int ns = (int)ref.n_seeds;
+        const int32_t* s = segs + ref.seg_off;
+        if (first < 0 || last < 0 || first >= ns || last >= ns) {
+            if (lane == 0) anchors[2 * slot] = anchors[2 * slot + 1] = -1;
+            continue;
+        }
+        int a = 0, b = 0;
+        for (int t = 1 + lane; t <= first; t += 64) a += s[2 * t] + k;
+        for (int t = last + 1 + lane; t <= ns - 1; t += 64) b += s[2 * t] + k;
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o);
+            b += __shfl_xor(b, o);
+        }
+        if (lane == 0) {
+            anchors[2 * slot] = s[0] + a;
+            anchors[2 * slot + 1] = s[2 * ns] + b;
+        }
     }
 }
 
-// cursor: u64 at [0..1] = ints (low) | record slots (high); [2] error bits, [3] overflow flag.
-// tier: 0 automatic, 2 forces the lds tier, 3 the one-lane tier (tests).
-__global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
-                                                             uint32_t nq, const u64* __restrict__ qsets,
-                                                             const uint32_t* __restrict__ qmeta, const u64* __restrict__ cand,
-                                                             const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs,
-                                                             const u64* __restrict__ seedsets, uint32_t W, uint32_t SW,
-                                                             const int32_t* __restrict__ mc, uint32_t mc_n, int k, int maxLength,
-                                                             CNode* __restrict__ pool, MRec* __restrict__ recs, uint32_t rec_cap,
-                                                             int32_t* __restrict__ ma, int32_t* __restrict__ mb, uint32_t int_cap,
-                                                             uint32_t* __restrict__ cursor, int tier, u64* __restrict__ dbg) {
+// ---- the chaining stage: matchWorker's candidate loop (overlap/overlap.go:357-383) without its serial latency -------------
+// A query's candidates are chained in ascending order because of the ratchet: a chain longer than 3/2 minMatches raises
+// minMatches for the candidates after it (:380-382), and minMatches goes into PairwiseAlignments.  One wave walking a
+// query's ~10 candidates one after the other (round 1) leaves the GPU idle: 668 waves, ~15 us of dependent LDS/ballot steps
+// per pair.  The ratchet, however, almost always moves exactly once - at the query's first hit.  So:
+//   every (query, candidate) PAIR gets a fixed slot: pair p = pbase[q] + rank of the candidate (pbase = exclusive scan of the
+//   per-query candidate counts the query kernel leaves behind), a record MRec[p] and a scratch column for its chain;
+//   walk(0)  one wave per query: candidates in order until the first pair that is actually chained (one chain per query);
+//   spec     one wave per remaining PAIR, all in parallel, chained with the minMatches the query has reached so far; the
+//            result is only a proposal: it is stored with the minMatches it was computed for;
+//   walk(1)  one wave per query again: replays the ratchet over the proposals in candidate order - a proposal is taken iff
+//            it was computed with the minMatches in force at its turn - and stops at the first pair that needs another value;
+//   spec, walk(2)  the same once more for the queries whose ratchet moved again; walk(2) chains what is still open itself.
+// Every pair ends up with exactly the chain the serial loop produces (bit-identical: tests force 0 passes as well).
+struct PSpec {
+    int32_t c;    // CountIntersectionTo result of the pair (-1: not computed yet)
+    int32_t mm;   // minMatches the proposal below was chained with (-1: none)
+    int32_t len;  // its chain length (pairs in the pair's scratch column)
+    uint32_t pad;
+};
+struct QState {
+    int32_t mm;      // minMatches in force for the query's next candidate
+    uint32_t next;   // rank of the first candidate that is not final yet
+};
+
+struct ChainArgs {
+    const int32_t* qsegs;
+    const u64* qoff;
+    uint32_t nq;
+    const u64* qsets;
+    const uint32_t* qmeta;
+    const uint32_t* qcnt;
+    const u64* cand;
+    const dp_seq_ref* refs;
+    const int32_t* segs;
+    const u64* seedsets;
+    uint32_t W, SW;
+    const int32_t* mc;
+    uint32_t mc_n;
+    int k, maxLength, tier;
+    CNode* pool;
+    uint32_t* pbase;     // [nq + 1] first pair of each query
+    u64* ibase;          // [nq + 1] first scratch int of each query (a pair's column holds nSeeds(q) ints)
+    uint32_t* clist;     // [pairs] candidate (indexed-sequence index) of each pair, ascending within a query
+    uint32_t* pq;        // [pairs] query of each pair
+    int pass;            // proposal pass this launch belongs to (cursor[8 + pass] counts the queries it leaves open)
+    PSpec* pspec;        // [pairs]
+    QState* qstate;      // [nq]
+    MRec* recs;          // [pairs] final record of each pair; len 0 = no match
+    int32_t *sa, *sb;    // scratch columns
+    int32_t *ma, *mb;    // packed chains of the final records
+    uint32_t pair_cap;
+    u64 sint_cap;
+    uint32_t int_cap;
+    uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [4..5] algorithmic bytes (u64)
+};
+
+// per-query candidate counts -> pair / scratch offsets (one workgroup; a round has a few hundred to a few ten thousand queries)
+__global__ __launch_bounds__(1024) void pair_scan_kernel(const uint32_t* __restrict__ qcnt, const u64* __restrict__ qoff, uint32_t nq,
+                                                          uint32_t* __restrict__ pbase, u64* __restrict__ ibase, u64* __restrict__ totals) {
+    __shared__ u64 shp[1024], shi[1024];
+    const uint32_t per = (nq + 1023) / 1024;
+    const uint32_t lo = min(nq, threadIdx.x * per), hi = min(nq, lo + per);
+    u64 sp = 0, si = 0;
+    for (uint32_t q = lo; q < hi; q++) {
+        sp += qcnt[q];
+        si += (u64)qcnt[q] * ((qoff[q + 1] - qoff[q]) / 2);
+    }
+    shp[threadIdx.x] = sp;
+    shi[threadIdx.x] = si;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        u64 ap = 0, ai = 0;
+        if ((int)threadIdx.x >= d) {
+            ap = shp[threadIdx.x - d];
+            ai = shi[threadIdx.x - d];
+        }
+        __syncthreads();
+        shp[threadIdx.x] += ap;
+        shi[threadIdx.x] += ai;
+        __syncthreads();
+    }
+    u64 bp = shp[threadIdx.x] - sp, bi = shi[threadIdx.x] - si;
+    for (uint32_t q = lo; q < hi; q++) {
+        pbase[q] = (uint32_t)bp;
+        ibase[q] = bi;
+        bp += qcnt[q];
+        bi += (u64)qcnt[q] * ((qoff[q + 1] - qoff[q]) / 2);
+    }
+    if (threadIdx.x == 1023) {
+        pbase[nq] = (uint32_t)shp[1023];
+        ibase[nq] = shi[1023];
+        totals[0] = shp[1023];
+        totals[1] = shi[1023];
+    }
+}
+
+// Load that goes to L2: for words another lane of this wave has just stored (a plain load may be served from a stale line of
+// the CU's vector L1).
+__device__ __forceinline__ int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// a (the query) into LDS: segments and, when it fits, its seed bitset.  Returns the bitset to probe (LDS or global).
+template <class LW>
+__device__ __forceinline__ const u64* chain_stage_a(LW& L, const int32_t* __restrict__ aSeg, int aN, const u64* __restrict__ qset,
+                                                    uint32_t SW, bool aStaged) {
+    const int lane = dp_lane();
+    if (aStaged) {
+        for (int i = lane; i < aN; i += 64) L.aSegL[i] = aSeg[i];
+        if constexpr (!LW::SLIM) {
+            if (SW <= C_QSW) {
+                for (uint32_t i = lane; i < SW; i += 64) L.qsetL[i] = qset[i];
+            }
+        }
+    }
+    if constexpr (!LW::SLIM) {
+        if (aStaged && SW <= C_QSW) return (const u64*)L.qsetL;
+    }
+    return qset;
+}
+
+// CountIntersectionTo(seedSet, minMatches) (overlap.go:359): the asm's early exit only ever returns a value >= maxCount,
+// so comparing the full popcount with minMatches is the same test
+__device__ __forceinline__ int chain_prefilter(const u64* __restrict__ tset, const u64* qs, uint32_t SW) {
+    int c = 0;
+    for (uint32_t w = dp_lane(); w < SW; w += 64) c += __popcll(tset[w] & qs[w]);
+    return RFL(wave_sum(c));
+}
+
+// PairwiseAlignments(a, b = candidate t, minMatches) by the whole wave; the chain (results[0], the one matchWorker keeps,
+// overlap.go:368-375) goes to the pair's scratch column.  Returns its length (0: none); CSlim only: -1 = does not fit here.
+template <class LW>
+__device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, const int32_t* __restrict__ aSeg, int aN, bool aStaged,
+                          const u64* qs, const u64* __restrict__ qset, uint32_t t, int minMatches, int32_t* __restrict__ ca,
+                          int32_t* __restrict__ cb) {
+    const int lane = dp_lane();
+    const u64* tset = A.seedsets + (uint64_t)t * A.SW;
+    const dp_seq_ref r = A.refs[t];
+    const int32_t* bSeg = A.segs + r.seg_off;
+    const int bN = RFL((int)(2 * r.n_seeds + 1));
+    const bool staged = aStaged && bN <= C_BCAP;
+    const int nSeeds = aN >> 1, nBSeeds = bN >> 1;
+    const int k = A.k;
+    if (LW::SLIM && (!staged || A.tier != 0)) return -1;  // (a forced tier is the full-size path's business)
+    if (staged) {  // stage b and both membership bit vectors with the whole wave
+        for (int i = lane; i < bN; i += 64) L.bSegL[i] = bSeg[i];
+        for (int base = 0; base < nSeeds; base += 64) {
+            const int s = base + lane;
+            bool f = false;
+            if (s < nSeeds) f = bs_contains(tset, L.aSegL[2 * s + 1]);
+            const u64 m = __ballot(f);
+            if (lane == 0) L.aFlag[base >> 6] = m;
+        }
+        for (int base = 0; base < nBSeeds; base += 64) {
+            const int s = base + lane;
+            bool f = false;
+            if (s < nBSeeds) f = bs_contains(qs, L.bSegL[2 * s + 1]);
+            const u64 m = __ballot(f);
+            if (lane == 0) L.bFlag[base >> 6] = m;
+        }
+    }
+    int resLen = 0, resNode = -1, usedTier = 3;
+    uint32_t err = 0;
+    u64 tp[3] = {0, 0, 0};
+    if (staged) {
+        const int mm = minMatches == 0 ? 1 : minMatches;
+        int aLen = 0, startSize = 0;
+        if (wave_prepare_initial(aN, mm, k, A.maxLength, L, &aLen, &startSize)) {
+            if (LW::SLIM) return -1;
+            err |= 1;
+            usedTier = 0;
+        } else {
+            resLen = -1;
+            if (aLen <= 64 && (A.tier == 0 || LW::SLIM)) {
+                resLen = wave_chain_reg(aLen, startSize, bN, mm, k, L, &err, false, tp);
+                usedTier = 1;
+            }
+            if constexpr (LW::SLIM) {
+                if (resLen < 0 || err) return -1;  // (capacity errors are the full-size path's to report)
+            } else {
+                if (resLen < 0) {
+                    resLen = wave_chain_lds(aLen, startSize, bN, mm, k, L, nodes, &resNode, &err);
+                    usedTier = 2;
+                }
+            }
+        }
+    } else {
+        if constexpr (!LW::SLIM) {
+            if (lane == 0)
+                resLen = pairwise_align(aSeg, aN, bSeg, bN, qset, tset, nullptr, nullptr, minMatches, k, A.maxLength, L, nodes, &resNode, &err);
+            resLen = __shfl(resLen, 0, 64);
+            resNode = __shfl(resNode, 0, 64);
+        }
+    }
+    if (lane == 0 && err) atomicOr(&A.cursor[2], err);
+    if (err) resLen = 0;
+    if (resLen > 0) {
+        if (usedTier == 1) {  // pairs sit in the result column
+            if (lane < resLen) {
+                const uint32_t v = L.rescol[lane];
+                ca[lane] = L.aMap[v & 63u];
+                cb[lane] = (int32_t)(v >> 6);
+            }
+        } else if (lane == 0) {
+            if constexpr (!LW::SLIM) {
+                int node = resNode;
+                for (int x = resLen - 1; x >= 0 && node >= 0; x--) {  // extractMatch :326-335
+                    CNode nd = node_get(L, nodes, node);
+                    ca[x] = nd.a;
+                    cb[x] = nd.b;
+                    node = nd.prev;
+                }
+            }
+        }
+    }
+    return resLen > 0 ? resLen : 0;
+}
+
+// mode 0: from the query's first candidate up to and including the first pair that is chained; 2 (last kernel of the stage):
+// whatever chain_resolve_kernel left open - proposals are taken where they fit, the rest is chained here, serially.
+// (mode 1 = mode 2 that stops instead of chaining: kept for experiments.)
+__global__ __launch_bounds__(64 * C_WAVES) void chain_walk_kernel(const ChainArgs A, const int mode) {
     __shared__ CWave sh[C_WAVES];
     CWave& L = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
     const uint32_t waves = gridDim.x * C_WAVES;
     const uint32_t gw = blockIdx.x * C_WAVES + (threadIdx.x >> 6);
-    CNode* nodes = pool + (uint64_t)gw * C_NODES;
-    for (uint32_t q = gw; q < nq; q += waves) {
-        const uint32_t nsets = qmeta[4 * q + 0];
-        if (nsets < 5 || qmeta[4 * q + 2]) continue;
-        const int32_t* aSeg = qsegs + qoff[q];
-        // wave-uniform by construction; readfirstlane tells the compiler, so the chaining code below branches on SGPRs
-        // instead of predicating every block on "divergent" loads
-        const int aN = RFL((int)(qoff[q + 1] - qoff[q]));
+    CNode* nodes = A.pool + (uint64_t)gw * C_NODES;
+    if (mode != 0 && (A.cursor[3] != 0 || (A.pass > 0 && A.cursor[8 + A.pass] == 0))) return;  // overflow / every query closed already
+    for (uint32_t q = gw; q < A.nq; q += waves) {
+        const uint32_t cnt = A.qcnt[q];
+        if (cnt == 0) continue;
+        const uint32_t pb = A.pbase[q];
+        const int aN = RFL((int)(A.qoff[q + 1] - A.qoff[q]));
         const uint32_t nSeeds = (uint32_t)aN / 2;
-        const u64* qset = qsets + (uint64_t)q * SW;
-        const bool aStaged = aN <= C_ACAP && tier != 3;
-        if (aStaged) {
-            for (int i = lane; i < aN; i += 64) L.aSegL[i] = aSeg[i];
-            if (SW <= C_QSW) {
-                for (uint32_t i = lane; i < SW; i += 64) L.qsetL[i] = qset[i];
-            }
+        const u64 ib = A.ibase[q];
+        if ((u64)pb + cnt > (u64)A.pair_cap || ib + (u64)cnt * nSeeds > A.sint_cap) {
+            if (lane == 0) A.cursor[3] = 1;
+            continue;
         }
-        const u64* qs = (aStaged && SW <= C_QSW) ? (const u64*)L.qsetL : qset;
-        int minMatches = RFL(nSeeds < mc_n ? mc[nSeeds] : 0x7fffffff);  // int(hitFraction*numSeeds+0.5), overlap.go:356
-        u64 tq0 = dbg ? wall_clock64() : 0, tAlign = 0, tExtract = 0, tStage = 0, nCand = 0, nPairs = 0;
-        u64 tp[3] = {0, 0, 0};
-        // algorithmic bytes of this query's share (SURVEY 8(d)): two bitset rows per candidate (the exact-intersection
-        // prefilter), both segment arrays per chained pair (4-byte ints here), the chain written out
-        u64 algBytes = 0;
-        for (uint32_t wi = 0; wi < W; wi++) {
-            u64 mask = cand[(uint64_t)q * W + wi];
-            while (mask) {
-                const int b = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const uint32_t t = wi * 64 + (uint32_t)b;
-                const u64* tset = seedsets + (uint64_t)t * SW;
-                nCand++;
-                algBytes += 16ull * SW;
-                u64 ts0 = dbg ? wall_clock64() : 0;
-                // CountIntersectionTo(seedSet, minMatches) < minMatches  (overlap.go:359; the asm's early exit only
-                // ever returns a value >= maxCount, so the comparison equals the one on the full popcount)
-                int c = 0;
-                for (uint32_t w = lane; w < SW; w += 64) c += __popcll(tset[w] & qs[w]);
-                c = RFL(wave_sum(c));
-                if (c < minMatches) continue;
-                const dp_seq_ref r = refs[t];
-                const int32_t* bSeg = segs + r.seg_off;
-                const int bN = RFL((int)(2 * r.n_seeds + 1));
-                const bool staged = aStaged && bN <= C_BCAP;
-                const int nBSeeds = bN >> 1;
-                int bound = (int)nSeeds;  // upper bound of the chain length: a seeds present in b
-                if (staged) {  // stage b and both membership bit vectors with the whole wave
-                    for (int i = lane; i < bN; i += 64) L.bSegL[i] = bSeg[i];
-                    bound = 0;
-                    for (int base = 0; base < (int)nSeeds; base += 64) {
-                        const int s = base + lane;
-                        bool f = false;
-                        if (s < (int)nSeeds) f = bs_contains(tset, L.aSegL[2 * s + 1]);
-                        const u64 m = __ballot(f);
-                        bound += __popcll(m);
-                        if (lane == 0) L.aFlag[base >> 6] = m;
-                    }
-                    for (int base = 0; base < nBSeeds; base += 64) {
-                        const int s = base + lane;
-                        bool f = false;
-                        if (s < nBSeeds) f = bs_contains(qs, L.bSegL[2 * s + 1]);
-                        const u64 m = __ballot(f);
-                        if (lane == 0) L.bFlag[base >> 6] = m;
-                    }
+        int mm;
+        uint32_t next;
+        if (mode == 0) {
+            // Matches() result as a list: the set bits of the query's cand row in ascending order
+            uint32_t running = 0;
+            for (uint32_t wb = 0; wb < A.W; wb += 64) {
+                const uint32_t w = wb + lane;
+                u64 m = w < A.W ? A.cand[(uint64_t)q * A.W + w] : 0ull;
+                const int pc = __popcll(m);
+                const int incl = wave_incl_sum(pc);
+                uint32_t at = running + (uint32_t)(incl - pc);
+                while (m) {
+                    A.pq[pb + at] = q;
+                    A.clist[pb + at++] = w * 64 + (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
                 }
-                // reserve one record slot and `bound` ints now; the reply is only needed after the chaining
-                u64 slot = 0;
-                if (lane == 0) slot = atomicAdd((unsigned long long*)cursor, (1ull << 32) | (u64)(uint32_t)bound);
-                int resLen = 0, resNode = -1, usedTier = 3;
-                uint32_t err = 0;
-                nPairs++;
-                algBytes += 4ull * (u64)(aN + bN);
-                u64 ta0 = dbg ? wall_clock64() : 0;
-                tStage += ta0 - ts0;
-                if (staged) {
-                    int mm = minMatches == 0 ? 1 : minMatches;
-                    int aLen = 0, startSize = 0;
-                    u64 t0 = dbg ? wall_clock64() : 0;
-                    if (!wave_prepare_initial(aN, mm, k, maxLength, L, &aLen, &startSize)) {
-                        err |= 1;
-                        usedTier = 0;
-                    } else {
-                        if (dbg) tp[0] += wall_clock64() - t0;
-                        resLen = -1;
-                        if (aLen <= 64 && tier == 0) {
-                            resLen = wave_chain_reg(aLen, startSize, bN, mm, k, L, &err, dbg != nullptr, tp);
-                            usedTier = 1;
-                        }
-                        if (resLen < 0) {
-                            resLen = wave_chain_lds(aLen, startSize, bN, mm, k, L, nodes, &resNode, &err);
-                            usedTier = 2;
-                        }
+                running += (uint32_t)__shfl(incl, 63, 64);
+            }
+            for (uint32_t i = lane; i < cnt; i += 64) {
+                PSpec e = {-1, -1, 0, 0};
+                A.pspec[pb + i] = e;
+            }
+            __threadfence_block();
+            mm = RFL(nSeeds < A.mc_n ? A.mc[nSeeds] : 0x7fffffff);  // int(hitFraction*numSeeds+0.5), overlap.go:356
+            next = 0;
+        } else {
+            const QState st = A.qstate[q];
+            mm = RFL(st.mm);
+            next = (uint32_t)RFL((int)st.next);
+            if (next >= cnt) continue;
+        }
+        const int32_t* aSeg = A.qsegs + A.qoff[q];
+        const u64* qset = A.qsets + (uint64_t)q * A.SW;
+        const bool aStaged = aN <= (int)CWave::ACAP && A.tier != 3;
+        const u64* qs = chain_stage_a(L, aSeg, aN, qset, A.SW, aStaged);
+        // algorithmic bytes of this query's share (SURVEY 8(d)): two bitset rows per candidate (the exact-intersection
+        // prefilter), both segment arrays per chained pair (4-byte ints here), the chain written out - counted once per
+        // pair, when it becomes final
+        u64 algBytes = 0;
+        uint32_t i = next;
+        for (; i < cnt; i++) {
+            const uint32_t p = pb + i;
+            const uint32_t t = mode == 0 ? ld_agent(&A.clist[p]) : A.clist[p];
+            int32_t* ca = A.sa + ib + (u64)i * nSeeds;
+            int32_t* cb = A.sb + ib + (u64)i * nSeeds;
+            PSpec sp = {-1, -1, 0, 0};
+            if (mode != 0) sp = A.pspec[p];
+            int c = RFL(sp.c);
+            const int spmm = RFL(sp.mm);
+            int len;
+            bool chained = false;
+            if (c < 0) c = chain_prefilter(A.seedsets + (uint64_t)t * A.SW, qs, A.SW);
+            if (c < mm) {
+                len = 0;
+            } else if (spmm == mm) {
+                len = RFL(sp.len);
+            } else if (mode == 1) {
+                break;  // needs chaining with a minMatches nobody proposed for: the next spec pass does it
+            } else {
+                len = chain_pair(L, nodes, A, aSeg, aN, aStaged, qs, qset, t, mm, ca, cb);
+                chained = true;
+            }
+            algBytes += 16ull * A.SW;
+            if (c >= mm) algBytes += 4ull * (u64)(aN + (int)(2 * A.refs[t].n_seeds + 1));
+            uint32_t off = 0;
+            if (len > 0) {
+                if (lane == 0) off = atomicAdd(&A.cursor[0], (uint32_t)len);
+                off = (uint32_t)__shfl((int)off, 0, 64);
+                if ((u64)off + (u64)len <= (u64)A.int_cap) {
+                    __threadfence_block();
+                    for (int x = lane; x < len; x += 64) {
+                        A.ma[off + x] = ld_agent(&ca[x]);
+                        A.mb[off + x] = ld_agent(&cb[x]);
                     }
                 } else {
-                    if (lane == 0)
-                        resLen = pairwise_align(aSeg, aN, bSeg, bN, qset, tset, nullptr, nullptr, minMatches, k, maxLength, L, nodes,
-                                                &resNode, &err);
-                    resLen = __shfl(resLen, 0, 64);
-                    resNode = __shfl(resNode, 0, 64);
+                    if (lane == 0) A.cursor[3] = 1;
+                    len = 0;
                 }
-                u64 ta1 = dbg ? wall_clock64() : 0;
-                tAlign += ta1 - ta0;
-                if (lane == 0 && err) atomicOr(&cursor[2], err);
-                if (err) resLen = 0;
-                {
-                    const uint32_t s_lo = (uint32_t)__shfl((int)(uint32_t)slot, 0, 64);
-                    const uint32_t s_hi = (uint32_t)__shfl((int)(uint32_t)(slot >> 32), 0, 64);
-                    const uint32_t off = s_lo, ri = s_hi;
-                    if (ri < rec_cap && (u64)off + (u64)bound <= (u64)int_cap) {
-                        if (lane == 0) {
-                            MRec rec = {q, t, off, (uint32_t)(resLen > 0 ? resLen : 0)};
-                            recs[ri] = rec;
-                        }
-                        if (resLen > 0) {
-                            if (usedTier == 1) {  // pairs sit in the result column
-                                if (lane < resLen) {
-                                    const uint32_t v = L.rescol[lane];
-                                    ma[off + lane] = L.aMap[v & 0xffffu];
-                                    mb[off + lane] = (int32_t)(v >> 16);
-                                }
-                            } else if (lane == 0) {
-                                int node = resNode;
-                                for (int x = resLen - 1; x >= 0 && node >= 0; x--) {  // extractMatch :326-335
-                                    CNode nd = node_get(L, nodes, node);
-                                    ma[off + x] = nd.a;
-                                    mb[off + x] = nd.b;
-                                    node = nd.prev;
-                                }
-                            }
-                        }
-                    } else if (lane == 0) {
-                        cursor[3] = 1;
-                    }
-                }
-                if (resLen > 0) {
-                    algBytes += 8ull * (u64)resLen;
-                    if (resLen * 2 > minMatches * 3) minMatches = (resLen * 2) / 3;  // ratchet, overlap.go:380-382
-                    if (dbg) tExtract += wall_clock64() - ta1;
-                }
+                algBytes += 8ull * (u64)len;
+            }
+            if (lane == 0) {
+                MRec rec = {q, t, off, (uint32_t)len};
+                A.recs[p] = rec;
+            }
+            if (len > 0 && len * 2 > mm * 3) mm = (len * 2) / 3;  // ratchet, overlap.go:380-382
+            if (mode == 0 && chained) {
+                i++;
+                break;
             }
         }
-        if (lane == 0 && algBytes) atomicAdd((unsigned long long*)(cursor + 4), (unsigned long long)algBytes);
-        if (dbg && lane == 0) {
-            dbg[8 * q + 0] = wall_clock64() - tq0;
-            dbg[8 * q + 1] = tAlign;
-            dbg[8 * q + 2] = tExtract;
-            dbg[8 * q + 3] = tStage;
-            dbg[8 * q + 4] = nCand;
-            dbg[8 * q + 5] = nPairs;
-            dbg[8 * q + 6] = (tp[0] << 32) | tp[1];
-            dbg[8 * q + 7] = tp[2];
+        if (lane == 0) {
+            QState st = {mm, i};
+            A.qstate[q] = st;
+            if (algBytes) atomicAdd((unsigned long long*)(A.cursor + 4), (unsigned long long)algBytes);
+            if (mode == 0 && i < cnt) atomicAdd(&A.cursor[8], 1u);  // open queries ahead of proposal pass 0
+        }
+    }
+}
+
+// one wave per open pair: prefilter + chain with the minMatches its query has reached; stored as a proposal
+#define S_WAVES 4
+__global__ __launch_bounds__(64 * S_WAVES) void chain_spec_kernel(const ChainArgs A, const u64* __restrict__ totals) {
+    __shared__ CSlim sh[S_WAVES];
+    CSlim& L = sh[threadIdx.x >> 6];
+    const int lane = dp_lane();
+    const uint32_t waves = gridDim.x * S_WAVES;
+    const uint32_t gw = blockIdx.x * S_WAVES + (threadIdx.x >> 6);
+    // (a query that did not fit the buffers left its pairs' pq / clist unwritten: the host repeats the stage with larger ones)
+    if (A.cursor[3] != 0 || A.cursor[8 + A.pass] == 0) return;  // ... or no query is open any more
+    const uint32_t total = (uint32_t)min(totals[0], (u64)A.pair_cap);
+    for (uint32_t p = gw; p < total; p += waves) {
+        const uint32_t q = A.pq[p];
+        const uint32_t i = p - A.pbase[q];
+        if (i >= A.qcnt[q]) continue;  // (beyond a capped query)
+        const QState st = A.qstate[q];
+        if (i < st.next) continue;  // final already
+        PSpec sp = A.pspec[p];
+        const int mm = RFL(st.mm);
+        if (RFL(sp.mm) == mm) continue;
+        const int aN = RFL((int)(A.qoff[q + 1] - A.qoff[q]));
+        const uint32_t nSeeds = (uint32_t)aN / 2;
+        const u64 ib = A.ibase[q];
+        if (ib + (u64)A.qcnt[q] * nSeeds > A.sint_cap) continue;  // (flagged by the walk)
+        const uint32_t t = A.clist[p];
+        const int32_t* aSeg = A.qsegs + A.qoff[q];
+        const u64* qset = A.qsets + (uint64_t)q * A.SW;
+        const bool aStaged = aN <= (int)CSlim::ACAP;
+        const u64* qs = chain_stage_a(L, aSeg, aN, qset, A.SW, aStaged);
+        int c = RFL(sp.c);
+        if (c < 0) c = chain_prefilter(A.seedsets + (uint64_t)t * A.SW, qs, A.SW);
+        int len = 0, pmm = mm;
+        if (c >= mm) {
+            len = chain_pair(L, (CNode*)nullptr, A, aSeg, aN, aStaged, qs, qset, t, mm, A.sa + ib + (u64)i * nSeeds, A.sb + ib + (u64)i * nSeeds);
+            if (len < 0) {  // does not fit the slim layout: no proposal, the final walk chains it
+                len = 0;
+                pmm = -1;
+            }
+        }
+        if (lane == 0) {
+            PSpec o = {c, pmm, len, 0};
+            A.pspec[p] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// One wave per query: replays the ratchet over the proposals of its open pairs - 64 pairs at a time, one per lane, the
+// serial part is a register loop - and makes every pair up to the first one that needs another minMatches final: packed
+// chain, record, algorithmic bytes.  Everything that touches memory is lane-parallel.
+__global__ __launch_bounds__(256) void chain_resolve_kernel(const ChainArgs A) {
+    const int lane = dp_lane();
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    if (A.cursor[3] != 0 || A.cursor[8 + A.pass] == 0) return;  // buffers overflowed (stage is repeated) / no query was open before this pass
+    for (uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q < A.nq; q += waves) {
+        const uint32_t cnt = A.qcnt[q];
+        if (cnt == 0) continue;
+        const QState st = A.qstate[q];
+        int mm = RFL(st.mm);
+        uint32_t next = (uint32_t)RFL((int)st.next);
+        if (next >= cnt) continue;
+        const uint32_t pb = A.pbase[q];
+        const int aN = RFL((int)(A.qoff[q + 1] - A.qoff[q]));
+        const uint32_t nSeeds = (uint32_t)aN / 2;
+        const u64 ib = A.ibase[q];
+        if ((u64)pb + cnt > (u64)A.pair_cap || ib + (u64)cnt * nSeeds > A.sint_cap) continue;  // (flagged by walk 0)
+        u64 algBytes = 0;
+        bool stopped = false;
+        while (next < cnt && !stopped) {
+            const uint32_t i = next + lane;
+            const bool valid = i < cnt;
+            PSpec sp = {-1, -1, 0, 0};
+            uint32_t t = 0;
+            if (valid) {
+                sp = A.pspec[pb + i];
+                t = A.clist[pb + i];
+            }
+            const int nHere = (int)min(64u, cnt - next);
+            int stop = nHere;  // lanes [0, stop) become final
+            u64 chainedMask = 0, hitMask = 0;
+            for (int l = 0; l < nHere; l++) {
+                const int c = RL(sp.c, l);
+                if (c < 0) {
+                    stop = l;
+                    break;
+                }
+                if (c < mm) continue;
+                if (RL(sp.mm, l) != mm) {
+                    stop = l;
+                    break;
+                }
+                chainedMask |= 1ull << l;
+                const int len = RL(sp.len, l);
+                if (len > 0) {
+                    hitMask |= 1ull << l;
+                    if (len * 2 > mm * 3) mm = (len * 2) / 3;  // ratchet, overlap.go:380-382
+                }
+            }
+            const bool fin = lane < stop;
+            const bool hit = fin && ((hitMask >> lane) & 1ull);
+            const int myLen = hit ? sp.len : 0;
+            const int incl = wave_incl_sum(myLen);
+            const int totalLen = __shfl(incl, 63, 64);
+            uint32_t off0 = 0;
+            if (totalLen > 0) {
+                if (lane == 0) off0 = atomicAdd(&A.cursor[0], (uint32_t)totalLen);
+                off0 = (uint32_t)__shfl((int)off0, 0, 64);
+            }
+            const uint32_t myOff = off0 + (uint32_t)(incl - myLen);
+            const bool room = (u64)off0 + (u64)totalLen <= (u64)A.int_cap;
+            if (!room && lane == 0) A.cursor[3] = 1;
+            if (fin) {
+                int wlen = 0;
+                if (hit && room) {
+                    const int32_t* ca = A.sa + ib + (u64)i * nSeeds;
+                    const int32_t* cb = A.sb + ib + (u64)i * nSeeds;
+                    for (int x = 0; x < myLen; x++) {
+                        A.ma[myOff + x] = ca[x];
+                        A.mb[myOff + x] = cb[x];
+                    }
+                    wlen = myLen;
+                }
+                MRec rec = {q, t, hit && room ? myOff : 0u, (uint32_t)wlen};
+                A.recs[pb + i] = rec;
+                algBytes += 16ull * A.SW + 8ull * (u64)wlen;
+                if ((chainedMask >> lane) & 1ull) algBytes += 4ull * (u64)(aN + (int)(2 * A.refs[t].n_seeds + 1));
+            }
+            next += (uint32_t)stop;
+            stopped = stop < nHere;
+        }
+        // algBytes is per lane here: reduce
+        unsigned long long ab = algBytes;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) ab += __shfl_xor(ab, d, 64);
+        if (lane == 0) {
+            QState o = {mm, next};
+            A.qstate[q] = o;
+            if (ab) atomicAdd((unsigned long long*)(A.cursor + 4), ab);
+            if (next < cnt) atomicAdd(&A.cursor[9 + A.pass], 1u);  // still open: the next pass has work
         }
     }
 }
@@ -1432,7 +1779,7 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_kernel(const int32_t* __re
 // Uploads the queries, builds their seed bitsets and runs the index query (Matches -> GetSharedIDs) for all of them.
 // Leaves d_qsegs/d_qoff/d_qsets/d_cand/d_qmeta on the device.  Events ev[4]/ev[5] bracket the query kernel.
 int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
-                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out) {
+                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out) {
     const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
     const uint64_t nseg = nq ? q_off[nq] : 0;
     // int(hitFraction*float64(n)+0.5) for every n that can occur (seeds/seeds.go:351, overlap/overlap.go:356);
@@ -1449,11 +1796,12 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     if (dev_reserve(ctx, ctx->d_qsegs, nseg * 4 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_qoff, ((size_t)nq + 1) * 8)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_qsets, (size_t)nq * SW * 8 + 64)) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_qmeta, (size_t)nq * 16 + (size_t)nq * 8 + (size_t)mc_n * 4 + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_qmeta, (size_t)nq * 16 + (size_t)nq * 8 + (size_t)nq * 4 + (size_t)mc_n * 4 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_cand, (size_t)nq * W * 8 + 64)) return DP_ERR_HIP;
     uint32_t* d_qmeta = (uint32_t*)ctx->d_qmeta.p;
     u64* d_words = (u64*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 16);
-    int32_t* d_mc = (int32_t*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 16 + (size_t)nq * 8);
+    uint32_t* d_qcnt = (uint32_t*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 24);
+    int32_t* d_mc = (int32_t*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 28);
     // stage through pinned memory: copies from pageable buffers stall the stream
     const size_t up_segs = nseg * 4, up_off = ((size_t)nq + 1) * 8, up_mc = (size_t)mc_n * 4;
     if (pin_reserve(ctx, ctx->h_qup, up_segs + up_off + up_mc + 64)) return DP_ERR_HIP;
@@ -1466,14 +1814,14 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     DP_HIP(hipMemcpyAsync(d_mc, up + up_off + up_segs, up_mc, hipMemcpyHostToDevice, ctx->stream));
     DP_HIP(hipMemsetAsync(ctx->d_qsets.p, 0, (size_t)nq * SW * 8, ctx->stream));
     DP_HIP(hipMemsetAsync(ctx->d_cand.p, 0, (size_t)nq * W * 8, ctx->stream));
-    DP_HIP(hipMemsetAsync(d_qmeta, 0, (size_t)nq * 16 + (size_t)nq * 8, ctx->stream));
+    DP_HIP(hipMemsetAsync(d_qmeta, 0, (size_t)nq * 28, ctx->stream));
     hipLaunchKernelGGL(qsets_kernel, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), 0, ctx->stream,
                        (const int32_t*)ctx->d_qsegs.p, (const u64*)ctx->d_qoff.p, nq, (u64*)ctx->d_qsets.p, SW);
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     hipLaunchKernelGGL(query_kernel, dim3((nq + Q_WAVES - 1) / Q_WAVES), dim3(64 * Q_WAVES), 0, ctx->stream,
                        (const int32_t*)ctx->d_qsegs.p, (const u64*)ctx->d_qoff.p, nq, (const u64*)ctx->d_posting.p,
-                       (const uint32_t*)ctx->d_pmeta.p, M, W, (const int32_t*)d_mc, mc_n, (u64*)ctx->d_cand.p, d_qmeta, d_words);
+                       (const uint32_t*)ctx->d_pmeta.p, M, W, (const int32_t*)d_mc, mc_n, (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt);
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
 
@@ -1481,6 +1829,7 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     *d_words_out = d_words;
     *d_mc_out = d_mc;
     *mc_n_out = mc_n;
+    if (d_qcnt_out) *d_qcnt_out = d_qcnt;
     return DP_OK;
 }
 
@@ -1491,7 +1840,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     memset(out, 0, sizeof(*out));
     out->n_queries = nq;
     const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
-    if (pin_reserve(ctx, ctx->h_cursor, 64)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_cursor, 128)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_cand_off, ((size_t)nq + 1) * 8)) return DP_ERR_HIP;
     ((uint64_t*)ctx->h_cand_off.p)[0] = 0;
     out->cand_off = (const uint64_t*)ctx->h_cand_off.p;
@@ -1505,75 +1854,122 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     uint32_t* d_qmeta = nullptr;
     u64* d_words = nullptr;
     int32_t* d_mc = nullptr;
+    uint32_t* d_qcnt = nullptr;
     uint32_t mc_n = 0;
     {
-        int rc = dp_query_stage(ctx, q_segs, q_off, nq, hf, &d_qmeta, &d_words, &d_mc, &mc_n);
+        int rc = dp_query_stage(ctx, q_segs, q_off, nq, hf, &d_qmeta, &d_words, &d_mc, &mc_n, &d_qcnt);
         if (rc != 0) return rc;
     }
-    if (dev_reserve(ctx, ctx->d_cursor, 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_cursor, 128)) return DP_ERR_HIP;
+    // [0..63] cursor words, [64..] totals (u64 pairs, u64 scratch ints)
+    uint32_t* d_cur = (uint32_t*)ctx->d_cursor.p;
+    u64* d_totals = (u64*)((uint8_t*)ctx->d_cursor.p + 64);
 
-    // chaining; output buffers grow and the kernel re-runs if they overflow (deterministic)
-    const uint32_t chain_blocks = std::min<uint32_t>(512, (nq + C_WAVES - 1) / C_WAVES);
-    if (dev_reserve(ctx, ctx->d_pool, (size_t)chain_blocks * C_WAVES * C_NODES * sizeof(CNode))) return DP_ERR_HIP;
-    uint32_t rec_cap = std::max<uint32_t>(1u << 16, (uint32_t)(ctx->d_mrec.cap / sizeof(MRec)));
-    uint32_t int_cap = std::max<uint32_t>(1u << 21, (uint32_t)(ctx->d_ma.cap / 4));
-    uint32_t cur[16];
-    float chain_ms = 0;
-    static const bool chain_debug = getenv("DP_CHAIN_DEBUG") != nullptr;
     const char* tier_env = getenv("DP_CHAIN_TIER");  // tests: 2 = lds tier, 3 = one-lane tier for every pair
     const int chain_tier = tier_env ? atoi(tier_env) : 0;
-    u64* d_dbg = nullptr;
-    if (chain_debug) {
-        DP_HIP(hipMalloc((void**)&d_dbg, (size_t)nq * 64));
-        DP_HIP(hipMemsetAsync(d_dbg, 0, (size_t)nq * 64, ctx->stream));
-    }
-    for (;;) {
-        if (dev_reserve(ctx, ctx->d_mrec, (size_t)rec_cap * sizeof(MRec))) return DP_ERR_HIP;
-        if (dev_reserve(ctx, ctx->d_ma, (size_t)int_cap * 4)) return DP_ERR_HIP;
-        if (dev_reserve(ctx, ctx->d_mb, (size_t)int_cap * 4)) return DP_ERR_HIP;
-        DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 64, ctx->stream));
+    const char* pass_env = getenv("DP_CHAIN_PASSES");  // proposal passes (0 = the serial walk alone: the round-1 behaviour)
+    const int passes = pass_env ? std::max(0, std::min(6, atoi(pass_env))) : 3;
+    const uint32_t walk_blocks = std::min<uint32_t>(256, (nq + C_WAVES - 1) / C_WAVES);
+    const uint32_t spec_blocks = 1024;  // 4096 persistent waves, 16 per CU: what CSlim's 8.5 KB per wave lets a CU hold
+    if (dev_reserve(ctx, ctx->d_pool, (size_t)walk_blocks * C_WAVES * C_NODES * sizeof(CNode))) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_pbase, ((size_t)nq + 1) * 4 + ((size_t)nq + 1) * 8 + (size_t)nq * sizeof(QState) + 64)) return DP_ERR_HIP;
+    u64* d_ibase = (u64*)ctx->d_pbase.p;  // (8-byte aligned first)
+    uint32_t* d_pbase = (uint32_t*)(d_ibase + nq + 1);
+    QState* d_qstate = (QState*)(d_pbase + nq + 1 + ((nq + 1) & 1));
+    // capacities: what the buffers hold now (at least a floor); a run that needs more reports its totals and is repeated
+    // with larger buffers (deterministic: same results)
+    uint64_t want_pairs = std::max<uint64_t>(1u << 14, ctx->d_mrec.cap / sizeof(MRec));
+    uint64_t want_sints = std::max<uint64_t>(1u << 18, ctx->d_sa.cap / 4);
+    uint64_t want_ints = std::max<uint64_t>(1u << 18, ctx->d_ma.cap / 4);
+    uint32_t cur[32];
+    float chain_ms = 0;
+    for (int attempt = 0;; attempt++) {
+        if (attempt > 8) return dp_fail(ctx, DP_ERR_STATE, "dp_find_overlaps: output buffers keep overflowing");
+        if (dev_reserve(ctx, ctx->d_mrec, (size_t)want_pairs * sizeof(MRec))) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_pspec, (size_t)want_pairs * sizeof(PSpec))) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_clist, (size_t)want_pairs * 8)) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_sa, (size_t)want_sints * 4)) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_sb, (size_t)want_sints * 4)) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_ma, (size_t)want_ints * 4)) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_mb, (size_t)want_ints * 4)) return DP_ERR_HIP;
+        const uint32_t pair_cap = (uint32_t)std::min<uint64_t>(0xfffffff0ull, want_pairs);
+        const uint64_t sint_cap = want_sints;
+        const uint32_t int_cap = (uint32_t)std::min<uint64_t>(0xfffffff0ull, want_ints);
+        ChainArgs A;
+        A.qsegs = (const int32_t*)ctx->d_qsegs.p;
+        A.qoff = (const u64*)ctx->d_qoff.p;
+        A.nq = nq;
+        A.qsets = (const u64*)ctx->d_qsets.p;
+        A.qmeta = d_qmeta;
+        A.qcnt = d_qcnt;
+        A.cand = (const u64*)ctx->d_cand.p;
+        A.refs = (const dp_seq_ref*)ctx->d_seqrefs.p;
+        A.segs = (const int32_t*)ctx->d_segs.p;
+        A.seedsets = (const u64*)ctx->d_seedsets.p;
+        A.W = W;
+        A.SW = SW;
+        A.mc = d_mc;
+        A.mc_n = mc_n;
+        A.k = k;
+        A.maxLength = (int)max_query_len;
+        A.tier = chain_tier;
+        A.pool = (CNode*)ctx->d_pool.p;
+        A.pbase = d_pbase;
+        A.ibase = d_ibase;
+        A.clist = (uint32_t*)ctx->d_clist.p;
+        A.pq = A.clist + pair_cap;
+        A.pass = 0;
+        A.pspec = (PSpec*)ctx->d_pspec.p;
+        A.qstate = d_qstate;
+        A.recs = (MRec*)ctx->d_mrec.p;
+        A.sa = (int32_t*)ctx->d_sa.p;
+        A.sb = (int32_t*)ctx->d_sb.p;
+        A.ma = (int32_t*)ctx->d_ma.p;
+        A.mb = (int32_t*)ctx->d_mb.p;
+        A.pair_cap = pair_cap;
+        A.sint_cap = sint_cap;
+        A.int_cap = int_cap;
+        A.cursor = d_cur;
+        DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 128, ctx->stream));
         DP_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-        hipLaunchKernelGGL(chain_kernel, dim3(chain_blocks), dim3(64 * C_WAVES), 0, ctx->stream, (const int32_t*)ctx->d_qsegs.p,
-                           (const u64*)ctx->d_qoff.p, nq, (const u64*)ctx->d_qsets.p, (const uint32_t*)d_qmeta,
-                           (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p,
-                           (const u64*)ctx->d_seedsets.p, W, SW, (const int32_t*)d_mc, mc_n, k, (int)max_query_len,
-                           (CNode*)ctx->d_pool.p, (MRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p,
-                           int_cap, (uint32_t*)ctx->d_cursor.p, chain_tier, d_dbg);
+        hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)d_qcnt, (const u64*)ctx->d_qoff.p, nq,
+                           d_pbase, d_ibase, d_totals);
+        hipLaunchKernelGGL(chain_walk_kernel, dim3(walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 0);
+        for (int ps = 0; ps < passes; ps++) {
+            A.pass = ps;
+            hipLaunchKernelGGL(chain_spec_kernel, dim3(spec_blocks), dim3(64 * S_WAVES), 0, ctx->stream, A, (const u64*)d_totals);
+            hipLaunchKernelGGL(chain_resolve_kernel, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), 0, ctx->stream, A);
+        }
+        A.pass = passes;
+        hipLaunchKernelGGL(chain_walk_kernel, dim3(walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 2);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
-        DP_HIP(hipMemcpyAsync(ctx->h_cursor.p, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipMemcpyAsync(ctx->h_cursor.p, ctx->d_cursor.p, 128, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(dp_stream_sync(ctx));
-        memcpy(cur, ctx->h_cursor.p, 64);
+        memcpy(cur, ctx->h_cursor.p, 128);
         float ms = 0;
         hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]);
         chain_ms += ms;
-        if (cur[3] || cur[1] > rec_cap || cur[0] > int_cap) {  // [0] ints reserved, [1] record slots
-            rec_cap = std::max(rec_cap * 2, cur[1] + 1024);
-            int_cap = std::max(int_cap * 2, cur[0] + 1024);
-            continue;
+        uint64_t tot_pairs, tot_sints;
+        memcpy(&tot_pairs, &cur[16], 8);
+        memcpy(&tot_sints, &cur[18], 8);
+        if (tot_pairs > 0xfffffff0ull) return dp_fail(ctx, DP_ERR_CAPACITY, "more than 2^32 (query, candidate) pairs in one round");
+        bool grow = false;
+        if (tot_pairs > pair_cap) {
+            want_pairs = tot_pairs + tot_pairs / 2 + 1024;
+            grow = true;
         }
+        if (tot_sints > sint_cap) {
+            want_sints = tot_sints + tot_sints / 2 + 1024;
+            grow = true;
+        }
+        if ((uint64_t)cur[0] > int_cap) {
+            want_ints = std::max<uint64_t>(want_ints * 2, (uint64_t)cur[0] + 1024);
+            grow = true;
+        }
+        if (grow) continue;
+        if (cur[3]) return dp_fail(ctx, DP_ERR_STATE, "dp_find_overlaps: overflow flag without a total that exceeds a buffer");
         break;
-    }
-    if (chain_debug) {  // per-query timing breakdown in 10 ns ticks (wall_clock64 = 100 MHz)
-        std::vector<u64> h((size_t)nq * 8);
-        hipMemcpy(h.data(), d_dbg, (size_t)nq * 64, hipMemcpyDeviceToHost);
-        hipFree(d_dbg);
-        u64 sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0}, p1 = 0, p2 = 0, ne = 0;
-        for (uint32_t q = 0; q < nq; q++) {
-            for (int j = 0; j < 6; j++) {
-                sum[j] += h[8 * q + j];
-                mx[j] = std::max(mx[j], h[8 * q + j]);
-            }
-            p1 += h[8 * q + 6] >> 32;
-            p2 += h[8 * q + 6] & 0xffffffffull;
-            ne += h[8 * q + 7];
-        }
-        fprintf(stderr, "[chain] prepareInitial %.1f us, events prep %.1f us, events %llu\n", p1 / 100.0, p2 / 100.0,
-                (unsigned long long)ne);
-        fprintf(stderr, "[chain] nq %u kernel %.3f ms | sum(us) total %.1f align %.1f extract %.1f stage %.1f cand %llu pairs %llu | max total %.1f align %.1f extract %.1f stage %.1f cand %llu pairs %llu\n",
-                nq, chain_ms, sum[0] / 100.0, sum[1] / 100.0, sum[2] / 100.0, sum[3] / 100.0, (unsigned long long)sum[4],
-                (unsigned long long)sum[5], mx[0] / 100.0, mx[1] / 100.0, mx[2] / 100.0, mx[3] / 100.0,
-                (unsigned long long)mx[4], (unsigned long long)mx[5]);
     }
     float qms = 0;
     hipEventElapsedTime(&qms, ctx->ev[4], ctx->ev[5]);
@@ -1585,24 +1981,25 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         snprintf(msg, sizeof msg, "overlap chaining hit a reference capacity limit (bits %u: 1 reduced buffer, 2 state pool, 4 results, 8 nodes)", cur[2]);
         return dp_fail(ctx, DP_ERR_CAPACITY, msg);
     }
-    // fetch + canonical order: queries ascending, targets ascending (each query was walked by one wave in order)
-    const uint32_t nslots = cur[1], ni = cur[0];  // one slot per chained pair; len 0 = no chain
+    // fetch.  Pair slots are in canonical order already: queries ascending, candidates ascending within a query.
+    const uint32_t nslots = (uint32_t)*(const uint64_t*)&cur[16], ni = cur[0];
+    ctx->n_pairs = nslots;
     if (pin_reserve(ctx, ctx->h_mrec, (size_t)nslots * sizeof(MRec) + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_ta, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_tb, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
-    if (pin_reserve(ctx, ctx->h_qm, (size_t)nq * 24 + 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_qm, (size_t)nq * 28 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
     uint32_t* qm = (uint32_t*)ctx->h_qm.p;
     u64* words = (u64*)((uint8_t*)ctx->h_qm.p + (size_t)nq * 16);
-    DP_HIP(hipMemcpyAsync(qm, d_qmeta, (size_t)nq * 16, hipMemcpyDeviceToHost, ctx->stream));
-    DP_HIP(hipMemcpyAsync(words, d_words, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t* h_qcnt = (uint32_t*)((uint8_t*)ctx->h_qm.p + (size_t)nq * 24);
+    DP_HIP(hipMemcpyAsync(qm, d_qmeta, (size_t)nq * 28, hipMemcpyDeviceToHost, ctx->stream));
     const int32_t* ta = (const int32_t*)ctx->h_ta.p;
     const int32_t* tb = (const int32_t*)ctx->h_tb.p;
     if (nslots) {
-        hipLaunchKernelGGL(match_anchor_kernel, dim3((nslots + 3) / 4), dim3(256), 0, ctx->stream, (const MRec*)ctx->d_mrec.p, nslots,
-                           (const int32_t*)ctx->d_mb.p, (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, k,
-                           (int32_t*)ctx->d_manchor.p);
+        hipLaunchKernelGGL(match_anchor_kernel, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256), 0, ctx->stream,
+                           (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
+                           (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, k, (int32_t*)ctx->d_manchor.p);
         DP_HIP(hipGetLastError());
         DP_HIP(hipMemcpyAsync(ctx->h_manchor.p, ctx->d_manchor.p, (size_t)nslots * 8, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_mrec.p, ctx->d_mrec.p, (size_t)nslots * sizeof(MRec), hipMemcpyDeviceToHost, ctx->stream));
@@ -1612,8 +2009,8 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         }
     }
     if (want_candidates) {
-        if (pin_reserve(ctx, ctx->h_cand, (size_t)nq * W * 8 + 16)) return DP_ERR_HIP;
-        DP_HIP(hipMemcpyAsync(ctx->h_cand.p, ctx->d_cand.p, (size_t)nq * W * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (pin_reserve(ctx, ctx->h_cand_list, (size_t)nslots * 4 + 16)) return DP_ERR_HIP;
+        if (nslots) DP_HIP(hipMemcpyAsync(ctx->h_cand_list.p, ctx->d_clist.p, (size_t)nslots * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     DP_HIP(dp_stream_sync(ctx));
     for (uint32_t q = 0; q < nq; q++) {
@@ -1621,38 +2018,19 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         out->query_bytes += words[q] * 8;
     }
     MRec* recs = (MRec*)ctx->h_mrec.p;
-    std::vector<uint32_t> order;
-    order.reserve(nslots);
+    uint32_t nm = 0;
     uint64_t total_len = 0;
     for (uint32_t i = 0; i < nslots; i++)
         if (recs[i].len) {
-            order.push_back(i);
+            nm++;
             total_len += recs[i].len;
         }
-    const uint32_t nm = (uint32_t)order.size();
     if (pin_reserve(ctx, ctx->h_ma, (size_t)total_len * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_mb, (size_t)total_len * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_mq, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_mt, (size_t)nm * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_moff, ((size_t)nm + 1) * 8)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_manout, (size_t)nm * 8 + 16)) return DP_ERR_HIP;
-    {  // canonical order: queries ascending, targets ascending.  A query's slots were reserved by one wave in candidate
-       // order, so a stable bucket pass over the query id is enough; verified below (falls back to a full sort).
-        std::vector<uint32_t> start((size_t)nq + 1, 0), sorted(nm);
-        for (uint32_t i : order) start[recs[i].q + 1]++;
-        for (uint32_t q = 0; q < nq; q++) start[q + 1] += start[q];
-        for (uint32_t i : order) sorted[start[recs[i].q]++] = i;
-        order.swap(sorted);
-        bool ok = true;
-        for (uint32_t i = 1; i < nm && ok; i++)
-            ok = recs[order[i - 1]].q < recs[order[i]].q ||
-                 (recs[order[i - 1]].q == recs[order[i]].q && recs[order[i - 1]].t < recs[order[i]].t);
-        if (!ok)
-            std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-                if (recs[a].q != recs[b].q) return recs[a].q < recs[b].q;
-                return recs[a].t < recs[b].t;
-            });
-    }
     uint32_t* mq = (uint32_t*)ctx->h_mq.p;
     uint32_t* mt = (uint32_t*)ctx->h_mt.p;
     uint64_t* moff = (uint64_t*)ctx->h_moff.p;
@@ -1661,16 +2039,19 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     const int32_t* anch = (const int32_t*)ctx->h_manchor.p;
     int32_t* anchOut = (int32_t*)ctx->h_manout.p;
     uint64_t pos = 0;
-    for (uint32_t i = 0; i < nm; i++) {
-        const MRec& r = recs[order[i]];
-        mq[i] = r.q;
-        mt[i] = r.t;
-        anchOut[2 * i] = anch[2 * (size_t)order[i]];
-        anchOut[2 * i + 1] = anch[2 * (size_t)order[i] + 1];
-        moff[i] = pos;
+    uint32_t j = 0;
+    for (uint32_t i = 0; i < nslots; i++) {
+        const MRec& r = recs[i];
+        if (!r.len) continue;
+        mq[j] = r.q;
+        mt[j] = r.t;
+        anchOut[2 * j] = anch[2 * (size_t)i];
+        anchOut[2 * j + 1] = anch[2 * (size_t)i + 1];
+        moff[j] = pos;
         memcpy(fa + pos, ta + r.off, (size_t)r.len * 4);
         memcpy(fb + pos, tb + r.off, (size_t)r.len * 4);
         pos += r.len;
+        j++;
     }
     moff[nm] = pos;
     out->n_matches = nm;
@@ -1680,28 +2061,17 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     out->match_a = fa;
     out->match_b = fb;
     out->target_anchor = anchOut;
+    uint64_t* co = (uint64_t*)ctx->h_cand_off.p;
     if (want_candidates) {
-        const u64* cm = (const u64*)ctx->h_cand.p;
-        uint64_t total = 0;
-        for (uint64_t i = 0; i < (uint64_t)nq * W; i++) total += (uint64_t)__builtin_popcountll(cm[i]);
-        if (pin_reserve(ctx, ctx->h_cand_list, total * 4 + 16)) return DP_ERR_HIP;
-        uint32_t* cl = (uint32_t*)ctx->h_cand_list.p;
-        uint64_t* co = (uint64_t*)ctx->h_cand_off.p;
-        uint64_t p = 0;
+        uint64_t p2 = 0;
         for (uint32_t q = 0; q < nq; q++) {
-            co[q] = p;
-            for (uint32_t w = 0; w < W; w++) {
-                u64 m = cm[(uint64_t)q * W + w];
-                while (m) {
-                    cl[p++] = w * 64 + (uint32_t)__builtin_ctzll(m);
-                    m &= m - 1;
-                }
-            }
+            co[q] = p2;
+            p2 += h_qcnt[q];
         }
-        co[nq] = p;
-        out->cand = cl;
+        co[nq] = p2;
+        out->cand = (const uint32_t*)ctx->h_cand_list.p;
     } else {
-        for (uint32_t q = 0; q <= nq; q++) ((uint64_t*)ctx->h_cand_off.p)[q] = 0;
+        for (uint32_t q = 0; q <= nq; q++) co[q] = 0;
     }
     return DP_OK;
 }

@@ -213,7 +213,8 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
                      &ctx->d_counts, &ctx->d_segoff, &ctx->d_segs, &ctx->d_total, &ctx->d_seqrefs, &ctx->d_posting,
                      &ctx->d_seedsets, &ctx->d_pmeta, &ctx->d_qsegs, &ctx->d_qoff, &ctx->d_qsets, &ctx->d_qmeta,
                      &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched, &ctx->d_ignore, &ctx->d_surv, &ctx->d_values, &ctx->d_selwin, &ctx->d_seltop, &ctx->d_cin, &ctx->d_cout,
-                     &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals, &ctx->d_manchor, &ctx->d_seeds_applied};
+                     &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals, &ctx->d_manchor, &ctx->d_seeds_applied,
+                     &ctx->d_pbase, &ctx->d_pspec, &ctx->d_clist, &ctx->d_sa, &ctx->d_sb};
     for (auto* b : dbs)
         if (b->p) hipFree(b->p);
     if (ctx->d_kcounts) hipFree(ctx->d_kcounts);
@@ -1065,6 +1066,20 @@ extern "C" int dp_scan_prepare(dp_ctx* ctx, int k) {
     if (scan_wants_index(ctx)) {
         const int rc = dp_kindex_ensure(ctx, k);  // > 0: cannot be used for this k / read set, the rounds will scan
         if (rc < 0) return rc;
+    }
+    return DP_OK;
+}
+
+extern "C" int dp_scan_release(dp_ctx* ctx) {
+    if (!ctx) return DP_ERR_ARG;
+    if (ctx->borrowed_reads) return dp_fail(ctx, DP_ERR_STATE, "dp_scan_release on a context that borrows its reads");
+    hipSetDevice(ctx->device);
+    DP_HIP(dp_stream_sync(ctx));
+    dp_kindex_free(ctx);
+    if (ctx->d_kcounts) {
+        hipFree(ctx->d_kcounts);
+        ctx->d_kcounts = nullptr;
+        ctx->kcounts_k = 0;
     }
     return DP_OK;
 }

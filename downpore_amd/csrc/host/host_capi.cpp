@@ -16,6 +16,8 @@ struct ReadsH {
 struct OverlapH {
     OverlapRun run;
     dp_ctx* ctx = nullptr;
+    ReadSet* reads = nullptr;
+    double tCtx = 0, tUpload = 0, tInit = 0;
     std::string err;
     // PAF of every committed round so far.  Kept as one chunk per commit and joined only when somebody asks for the
     // whole text: appending to one growing std::string re-copied up to 128 MB at every doubling (20-30 ms stalls of the
@@ -81,18 +83,7 @@ void dph_reads_reset_ignore(void* h) {
 }
 int64_t dph_reads_total_bases(void* h) { return (int64_t)((ReadsH*)h)->set.bases.size(); }
 
-// params: overlapSize,k,numSeeds,seedBatchSize,chunkSize,queryBatchSize,himem,nSlots
-void* dph_overlap_create(void* reads, int device, const int64_t* params, double minHits, const double* valuesOrNull) {
-    const int nSlots = (int)params[7];
-    OverlapH* h = new OverlapH();
-    ReadSet& rs = ((ReadsH*)reads)->set;
-    const double tc0 = now();
-    int rc = dp_ctx_create(device, &h->ctx);
-    if (rc != 0) {
-        g_err = dp_last_error(nullptr);
-        delete h;
-        return nullptr;
-    }
+static OverlapParams paramsFrom(const int64_t* params, double minHits) {
     OverlapParams p;
     p.overlapSize = params[0];
     p.k = (int)params[1];
@@ -103,17 +94,75 @@ void* dph_overlap_create(void* reads, int device, const int64_t* params, double 
     p.himem = (params[6] & 1) != 0;
     p.queryType = (int)(params[6] >> 8) ? (int)(params[6] >> 8) : 1;  // bits 8.. of the himem word: overlap.Query* flags
     p.minHits = minHits;
+    return p;
+}
+
+// The command in two halves, so that a caller can keep the reads resident and run (or time) whole jobs on them:
+// dph_overlap_open = device context + the reads uploaded and packed; dph_overlap_init = everything `downpore overlap`
+// does between "Counting all k-mers" and its first round (value table, k-mer position index, executor slots, planner);
+// dph_overlap_reset = back to the state after dph_overlap_open (the job's resident tables are released).
+void* dph_overlap_open(void* reads, int device) {
+    OverlapH* h = new OverlapH();
+    ReadSet& rs = ((ReadsH*)reads)->set;
+    h->reads = &rs;
+    const double tc0 = now();
+    int rc = dp_ctx_create(device, &h->ctx);
+    if (rc != 0) {
+        g_err = dp_last_error(nullptr);
+        delete h;
+        return nullptr;
+    }
     const double tc1 = now();
     rc = dp_reads_upload(h->ctx, (const uint8_t*)rs.bases.data(), rs.off.data(), (uint32_t)rs.size());
-    if (g_prof.on) fprintf(stderr, "[setup] context %.1f ms, upload + pack %.1f ms\n", 1e3 * (tc1 - tc0), 1e3 * (now() - tc1));
-    if (rc == 0) rc = h->run.init(h->ctx, &rs, p, valuesOrNull, nSlots);
+    h->tCtx = tc1 - tc0;
+    h->tUpload = now() - tc1;
+    if (g_prof.on) fprintf(stderr, "[setup] context %.1f ms, upload + pack %.1f ms\n", 1e3 * h->tCtx, 1e3 * h->tUpload);
     if (rc != 0) {
-        g_err = h->run.error.empty() ? dp_last_error(h->ctx) : h->run.error;
+        g_err = dp_last_error(h->ctx);
         dp_ctx_destroy(h->ctx);
         delete h;
         return nullptr;
     }
     return h;
+}
+// params: overlapSize,k,numSeeds,seedBatchSize,chunkSize,queryBatchSize,himem,nSlots
+int dph_overlap_init(void* hh, const int64_t* params, double minHits, const double* valuesOrNull) {
+    OverlapH* h = (OverlapH*)hh;
+    const double t0 = now();
+    int rc = h->run.init(h->ctx, h->reads, paramsFrom(params, minHits), valuesOrNull, (int)params[7]);
+    h->tInit = now() - t0;
+    if (rc != 0) h->err = h->run.error.empty() ? dp_last_error(h->ctx) : h->run.error;
+    return rc;
+}
+int dph_overlap_reset(void* hh) {
+    OverlapH* h = (OverlapH*)hh;
+    h->run.shutdown();
+    h->pafChunks.clear();
+    h->allPafJoined.clear();
+    std::fill(h->reads->ignore.begin(), h->reads->ignore.end(), 0);
+    int rc = dp_scan_release(h->ctx);
+    if (rc != 0) h->err = dp_last_error(h->ctx);
+    return rc;
+}
+// out: seconds spent creating the context, uploading + packing the reads, and in the last dph_overlap_init
+void dph_overlap_setup_times(void* hh, double* out) {
+    OverlapH* h = (OverlapH*)hh;
+    out[0] = h->tCtx;
+    out[1] = h->tUpload;
+    out[2] = h->tInit;
+}
+void* dph_overlap_create(void* reads, int device, const int64_t* params, double minHits, const double* valuesOrNull) {
+    void* hh = dph_overlap_open(reads, device);
+    if (!hh) return nullptr;
+    if (dph_overlap_init(hh, params, minHits, valuesOrNull) != 0) {
+        OverlapH* h = (OverlapH*)hh;
+        g_err = h->err;
+        h->run.shutdown();
+        dp_ctx_destroy(h->ctx);
+        delete h;
+        return nullptr;
+    }
+    return hh;
 }
 void dph_overlap_destroy(void* hh) {
     OverlapH* h = (OverlapH*)hh;
@@ -192,9 +241,11 @@ const char* dph_overlap_errtext(void* hh, int64_t* n) {
 // out[0..] t_prepare,t_scan,t_index,t_query,t_consensus,k_scan_ms,k_query_ms,k_chain_ms,scan_bases,scan_items,
 // scan_bytes,query_bytes,n_queries,n_indexed,n_hits,n_matches,n_paf,n_seeds,round,badBack,emptyMatch,k_count_ms,
 // k_write_ms,count_bytes,k_cons_ms,idx_rounds,idx_hits,chain_bytes
-void dph_overlap_stats(void* hh, double* out) {
-    OverlapH* h = (OverlapH*)hh;
-    const RoundStats& s = h->run.last;
+static void statsOut(OverlapH* h, const RoundStats& s, double* out);
+void dph_overlap_stats(void* hh, double* out) { statsOut((OverlapH*)hh, ((OverlapH*)hh)->run.last, out); }
+// the same fields summed over every committed round of the job
+void dph_overlap_stats_total(void* hh, double* out) { statsOut((OverlapH*)hh, ((OverlapH*)hh)->run.total, out); }
+static void statsOut(OverlapH* h, const RoundStats& s, double* out) {
     double v[] = {s.t_prepare, s.t_scan, s.t_index, s.t_query, s.t_consensus, s.k_scan_ms, s.k_query_ms, s.k_chain_ms,
                   (double)s.scan_bases, (double)s.scan_items, (double)s.scan_bytes, (double)s.query_bytes, (double)s.n_queries,
                   (double)s.n_indexed, (double)s.n_hits, (double)s.n_matches, (double)s.n_paf, (double)s.n_seeds,

@@ -288,6 +288,14 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     reads = r;
     p = params;
     reads->himem = p.himem;
+    errText.clear();
+    error.clear();
+    paf.clear();
+    pafLines = 0;
+    badBack = emptyMatch = 0;
+    numQuerySeqs = 0;
+    last = RoundStats();
+    total = RoundStats();
     char line[160];
     snprintf(line, sizeof line, "Counting all %d-mers in the input...\n", p.k);
     errText += line;
@@ -543,6 +551,7 @@ void OverlapRun::commitOne(RoundResult& r) {
     paf += r.paf;
     pafLines += (i64)r.fs.lines;
     last = r.st;
+    total.add(r.st);
     g_prof.ignores += (long long)r.ignores.size();
     for (int id : r.ignores)
         if (!reads->ignore[(size_t)id] && flagRound_[(size_t)id] < 0) flagRound_[(size_t)id] = (int32_t)round;

@@ -50,6 +50,13 @@ def load_host():
     H.dph_overlap_create.restype = vp
     H.dph_overlap_create.argtypes = [vp, C.c_int, C.c_void_p, C.c_double, C.c_void_p]
     H.dph_overlap_destroy.argtypes = [vp]
+    H.dph_overlap_open.restype = vp
+    H.dph_overlap_open.argtypes = [vp, C.c_int]
+    H.dph_overlap_init.argtypes = [vp, C.c_void_p, C.c_double, C.c_void_p]
+    H.dph_overlap_reset.argtypes = [vp]
+    H.dph_overlap_setup_times.restype = None
+    H.dph_overlap_setup_times.argtypes = [vp, C.c_void_p]
+    H.dph_overlap_stats_total.argtypes = [vp, C.c_void_p]
     H.dph_overlap_set_shard.argtypes = [vp, C.c_int64, C.c_int64]
     H.dph_overlap_values.restype = C.POINTER(C.c_double)
     H.dph_overlap_values.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -164,14 +171,17 @@ class OverlapPipeline:
 
     def __init__(self, reads, device=0, k=10, overlap_size=1000, num_seeds=15, seed_batch_size=10000, chunk_size=10000,
                  query_batch_size=20000, min_hits=0.25, himem=True, values=None, rank=0, world=1, torch_device=None,
-                 mode="round", slots=1, query_type=1):
+                 mode="round", slots=1, query_type=1, defer_init=False):
         """mode (world > 1): "round" = pipelined round-parallel (rank r's executor pipeline works on the rounds
         r, r+world, ...; per superstep every rank contributes its next round, results are all-gathered and committed in
         order with the speculation check); "round-batch" = the same exchange with batch-synchronous supersteps (every rank
         executes `slots` consecutive rounds, then all wait); "scan-shard" = every rank runs every round, the scan is
         sharded by read and the survivors are all-gathered.
         slots: executor slots of this process = rounds it runs concurrently on its GPU (each slot has its own stream and
-        per-round buffers; the resident reads are shared)."""
+        per-round buffers; the resident reads are shared).
+        defer_init: only create the device context and upload + pack the reads; init() then does what `downpore overlap`
+        does before its first round (value table, k-mer position index, executor slots, planner) and reset() returns to
+        this state, so whole jobs can be run - and timed - repeatedly on resident reads."""
         self.H = load_host()
         if mode == "scan-shard" and world > 1:
             slots = 1
@@ -179,15 +189,25 @@ class OverlapPipeline:
         p = np.array([overlap_size, k, num_seeds, seed_batch_size, chunk_size, query_batch_size,
                       (1 if himem else 0) | (query_type << 8), slots], dtype=np.int64)
         self.slots = slots
-        vptr = values.ctypes.data if values is not None else None
         self._values_keepalive = values
-        self.h = self.H.dph_overlap_create(reads.h, device, p.ctypes.data, float(min_hits), vptr)
+        self._params, self._min_hits = p, float(min_hits)
+        self.h = self.H.dph_overlap_open(reads.h, device)
         if not self.h:
-            raise DpError("dph_overlap_create: " + self.H.dph_last_error(None).decode())
+            raise DpError("dph_overlap_open: " + self.H.dph_last_error(None).decode())
         self.reads = reads
         self.rank, self.world = rank, world
         self.torch_device = torch_device
         self.mode = mode if world > 1 else "single"
+        self._lo_hi = shard_bounds(len(reads), rank, world) if self.mode == "scan-shard" else None
+        if not defer_init:
+            self.init()
+
+    def init(self):
+        values = self._values_keepalive
+        vptr = values.ctypes.data if values is not None else None
+        if self.H.dph_overlap_init(self.h, self._params.ctypes.data, self._min_hits, vptr) != 0:
+            raise DpError("dph_overlap_init: " + self.H.dph_last_error(self.h).decode())
+        rank, world = self.rank, self.world
         if self.mode == "round":
             self.H.dph_overlap_set_ranks.restype = None
             self.H.dph_overlap_set_ranks.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -197,8 +217,23 @@ class OverlapPipeline:
             self.H.dph_overlap_commit_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             self.H.dph_overlap_set_ranks(self.h, rank, world)
         if self.mode == "scan-shard":
-            lo, hi = shard_bounds(len(reads), rank, world)
-            self.H.dph_overlap_set_shard(self.h, lo, hi)
+            self.H.dph_overlap_set_shard(self.h, *self._lo_hi)
+
+    def reset(self):
+        """Ends the job (executor slots, planner, value table, k-mer index released; ignore flags cleared); the reads stay
+        resident and init() starts the next job."""
+        if self.H.dph_overlap_reset(self.h) != 0:
+            raise self._err()
+
+    def setup_times(self):
+        out = np.zeros(3, dtype=np.float64)
+        self.H.dph_overlap_setup_times(self.h, out.ctypes.data)
+        return dict(context_s=out[0], upload_pack_s=out[1], init_s=out[2])
+
+    def stats_total(self):
+        out = np.zeros(len(STAT_FIELDS), dtype=np.float64)
+        self.H.dph_overlap_stats_total(self.h, out.ctypes.data)
+        return dict(zip(STAT_FIELDS, out.tolist()))
 
     def close(self):
         if getattr(self, "h", None):

@@ -152,6 +152,11 @@ typedef struct {
  * first call - building the resident k-mer position index when the read set is large enough for it (>= 1 Gbase, or
  * DP_SCAN_INDEX=1).  Right after dp_kmer_values the build reuses that call's k-mer histogram. */
 DP_API int dp_scan_prepare(dp_ctx* ctx, int k);
+/* Releases what dp_scan_prepare / dp_scan_reads / dp_kmer_values left resident for the rounds of ONE job on the context
+ * that owns the reads: the k-mer position index (8 B per base) and the k-mer histogram.  The reads stay.  For a caller
+ * that is done with `overlap` and goes on to something else, or runs another job (other k) on the same reads.  No
+ * borrowing context may be inside a dp_scan_reads call. */
+DP_API int dp_scan_release(dp_ctx* ctx);
 DP_API int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
                   uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out);
 

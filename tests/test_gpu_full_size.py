@@ -1,0 +1,83 @@
+"""GPU parity at the FULL size of the BASELINE configs (what the driver's `pytest -m gpu` run proves, not a builder-side
+script): config 2 — every one of the 599 rounds of the 100k x 10 kb job against the SHA-256 the oracle alone produced
+(tests/golden_full/config2.json, tools/make_golden_full.py); config 3 — 50k x 8 kb `map` against the oracle run right here
+(1.6 s on one core); config 4 — the first rounds of the 1M x 10 kb set (10 Gbase resident, k-mer index 80 GB) against
+the oracle's fixture for the same rounds."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _golden(name):
+    return json.load(open(os.path.join(ROOT, "tests", "golden_full", name + ".json")))
+
+
+def _overlap_against_fixture(g, slots, max_rounds=-1):
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    gen = g["generator"]
+    bases, off = O.gen_reads(gen["seed"], gen["genome"], gen["reads"], gen["read_len"], gen["error"], gen["variable"])
+    reads = Reads(bases, off, min_len=1000)
+    del bases
+    pipe = OverlapPipeline(reads, device=0, k=g["k"], slots=slots)
+    rounds = pipe.run(max_rounds)
+    paf = pipe.all_paf()
+    st = pipe.stats()
+    pipe.close()
+    assert rounds == g["rounds"]
+    assert paf.count("\n") == g["paf_lines"]
+    assert paf.split("\n")[:4] == g["paf_head"]
+    assert hashlib.sha256(paf.encode()).hexdigest() == g["paf_sha256"]
+    assert hashlib.sha256(reads.ignore().tobytes()).hexdigest() == g["ignore_sha256"]
+    return st
+
+
+def test_config2_whole_job_matches_oracle_fixture():
+    """BASELINE config 2, all rounds, executor pipeline with 6 slots (what bench.py times)."""
+    g = _golden("config2")
+    assert g["rounds"] > 500 and g["paf_lines"] > 3000000
+    st = _overlap_against_fixture(g, slots=6)
+    assert st["idx_rounds"] == 1  # 1 Gbase: served by the resident k-mer position index
+
+
+def test_config2_whole_job_scan_kernels(monkeypatch):
+    """The same job with the scan kernels instead of the k-mer index (first 150 rounds would not tell the two modes apart
+    less than all of them do, and the whole job takes a second)."""
+    monkeypatch.setenv("DP_SCAN_INDEX", "0")
+    st = _overlap_against_fixture(_golden("config2"), slots=4)
+    assert st["idx_rounds"] == 0
+
+
+def test_config3_full_size_map_matches_oracle():
+    """BASELINE config 3: 50 000 reads x 8 kb (10 % error) against a 4.6 Mb circular reference, k=11."""
+    from downpore_amd.mapping import map_reads
+    from downpore_amd.overlap import Reads
+    G, N, L, e, seed = 4600000, 50000, 8000, 0.1, 3
+    genome = np.frombuffer(O.gen_genome(seed, G), dtype=np.uint8)
+    goff = np.array([0, G], dtype=np.int64)
+    bases, off = O.gen_reads(seed, G, N, L, e, False)
+    want, werr = O.map_run(O.ReadSet(genome, goff, min_len=0, himem=False), O.ReadSet(bases, off, min_len=500, himem=False),
+                           circular=True, k=11)
+    got, gerr, st = map_reads(Reads(genome, goff, min_len=0, himem=False), Reads(bases, off, min_len=500, himem=False),
+                              circular=True, k=11)
+    assert want.count("\n") > N // 2
+    assert hashlib.sha256(got.encode()).hexdigest() == hashlib.sha256(want.encode()).hexdigest()
+    assert got == want and gerr == werr
+
+
+def test_config4_first_rounds_match_oracle_fixture():
+    """BASELINE config 4's read set (1 M x 10 kb = 10 Gbase resident on ONE GPU, positions beyond 2^32, 80 GB k-mer index):
+    the first rounds against the oracle's fixture.  (The 8-GPU form of config 4 is the driver's to run.)"""
+    path = os.path.join(ROOT, "tests", "golden_full")
+    names = [f[:-5] for f in os.listdir(path) if f.startswith("config4_first_") and f.endswith(".json")]
+    assert names, "no config-4 fixture committed"
+    g = _golden(sorted(names)[0])
+    st = _overlap_against_fixture(g, slots=3, max_rounds=g["max_rounds"])
+    assert st["idx_rounds"] == 1

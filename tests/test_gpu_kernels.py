@@ -213,6 +213,16 @@ def test_scan_index_query_chain(ctx, k, G, N, L, e):
             for key in ("query", "target", "off", "match_a", "match_b"):
                 assert np.array_equal(np.asarray(o2[key]), np.asarray(out[key])), (tier, key)
 
+        # the chaining stage with 0 (serial walk alone), 1 and 3 proposal passes instead of the default 2: same records
+        for passes in ("0", "1", "3"):
+            os.environ["DP_CHAIN_PASSES"] = passes
+            try:
+                o3 = ctx.find_overlaps(qsegs, qoffs.astype(np.uint64), 0.25, k, 500, want_candidates=False)
+            finally:
+                del os.environ["DP_CHAIN_PASSES"]
+            for key in ("query", "target", "off", "match_a", "match_b", "target_anchor"):
+                assert np.array_equal(np.asarray(o3[key]), np.asarray(out[key])), ("passes", passes, key)
+
         for r in run.trace(rnd, "newlyIgnored"):
             ignore[int(r)] = 1
 

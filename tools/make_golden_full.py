@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Full-size golden fixtures from the ORACLE alone (no GPU, nothing of the product involved): the oracle computes its
+own k-mer value table and runs the overlap command on the seeded synthetic set of a BASELINE config; the fixture keeps
+the SHA-256 of the PAF text, of the ignore flags and the cumulative line count after every round, so a GPU run at the
+same size (tests/test_gpu_full_size.py) can be held to it without the oracle having to run for minutes on the GPU box.
+
+    python tools/make_golden_full.py config2            # 100k x 10 kb, every round (about 20 min on 6 threads)
+    python tools/make_golden_full.py config4 --rounds 6 # first rounds of the 1M x 10 kb set
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests import oracle_lib as O  # noqa: E402
+
+CONFIGS = {
+    # name: (seed, reads, read_len, error, k)
+    "config2": (2, 100000, 10000, 0.0, 13),
+    "config4": (4, 1000000, 10000, 0.0, 13),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", choices=sorted(CONFIGS))
+    ap.add_argument("--rounds", type=int, default=-1)
+    ap.add_argument("--threads", type=int, default=6)
+    ap.add_argument("--reads", type=int, default=0, help="override the read count (smaller surrogate, same generator)")
+    a = ap.parse_args()
+    seed, N, L, e, k = CONFIGS[a.config]
+    if a.reads:
+        N = a.reads
+    O.build_oracle()
+    os.environ["DPO_SCAN_THREADS"] = str(a.threads)
+    t0 = time.time()
+    bases, off = O.gen_reads(seed, N * L // 20, N, L, e, False)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    t1 = time.time()
+    run = O.OverlapRun(rs, k=k, max_rounds=a.rounds, traces=False)
+    t2 = time.time()
+    paf = run.paf
+    out = {"case": a.config + ("" if a.rounds < 0 else "_first_%d_rounds" % a.rounds) + ("_%dreads" % N if a.reads else ""),
+           "generator": {"seed": seed, "genome": N * L // 20, "reads": N, "read_len": L, "error": e, "variable": False},
+           "k": k, "rounds": run.rounds, "max_rounds": a.rounds, "paf_lines": paf.count("\n"),
+           "paf_sha256": hashlib.sha256(paf.encode()).hexdigest(),
+           "ignore_sha256": hashlib.sha256(rs.ignore().tobytes()).hexdigest(), "ignored_reads": int(rs.ignore().sum()),
+           "paf_head": paf.split("\n")[:4],
+           "made_by": "tools/make_golden_full.py (oracle only, own value table)", "oracle_s": t2 - t1, "generate_s": t1 - t0,
+           "oracle_scan_threads": a.threads}
+    path = os.path.join(ROOT, "tests", "golden_full", out["case"] + ".json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
