@@ -87,6 +87,9 @@ struct dp_ctx {
     DevBuf d_qsegs, d_qoff, d_qsets, d_qmeta, d_cand, d_pool, d_mrec, d_ma, d_mb, d_cursor, d_sched, d_manchor;
     DevBuf d_pbase, d_pspec, d_clist, d_sa, d_sb;  // chaining stage: pair offsets, proposals, candidate lists, scratch columns
     uint32_t n_pairs = 0;                          // (query, candidate) pair slots of the last dp_find_overlaps
+    uint32_t last_nq = 0, last_ni = 0;             // its queries / packed chain ints
+    int last_k = 0;
+    bool find_valid = false;                       // the device still holds that call's records
     PinBuf h_mrec, h_ma, h_mb, h_ta, h_tb, h_qm, h_qup, h_cursor, h_cand, h_cand_off, h_cand_list, h_mq, h_mt, h_moff, h_manchor, h_manout;
 };
 

@@ -11,6 +11,8 @@
 #define CA_CAP 6144  // ints of one group staged in LDS
 
 #define CA_RL(v_, l_) __builtin_amdgcn_readlane((v_), (l_))
+#define RFLc(v_) __builtin_amdgcn_readfirstlane(v_)
+typedef uint64_t u64;
 
 // gapRange seeds/alignment.go:411-424
 __device__ __forceinline__ void ca_gap_range(int gap, int k, int& mn, int& mx) {
@@ -290,4 +292,779 @@ extern "C" int dp_consensus_align(dp_ctx* ctx, const int32_t* segs, const uint64
     out->flags = (const uint32_t*)(hout + b_cons + b_clen + 2 * b_m + b_mlen);
     out->cons_off = (const uint64_t*)(hout + out_bytes);
     return DP_OK;
+}
+
+// =====================================================================================================================
+// A16 + A17 on the device: BuildConsensus (overlap/combine.go:163-193), multiAligner.Consensus (seeds/alignment.go:23-268),
+// NewSeedContig / trimToBestSeed (combine.go:21-133) and the numbers of finalCheckWorker's PAF lines
+// (commands/overlap.go:197-233) for every query window of a round, straight from the device-resident output of the
+// chaining stage.  One wave per query window ("group": forward query 2g, reverse-complement query 2g+1).
+//   1. matches of the group in arrival order (forward query's, then the rc query's; targets ascending);
+//   2. per match: un-reverse-complement (rc query), GetBasesCovered filter (< 25 bases on either side drops it), Trimmed()
+//      of the target to the query-aligned span -> the trimmed sequences of the group, in LDS;
+//   3. seeds shared by >= 2 of them (GetSharedIDs(.., 2, true)), Reduced() of every sequence;
+//   4. the seed-space multiple alignment (same loop as consensus_align_kernel above: lane i owns sequence i);
+//   5. parts with < 3 matched seeds removed (swap with last, :258-266), trimToBestSeed, contig fields, PAF numbers,
+//      SetIgnore decisions.
+// What does not fit the LDS layout (more than 64 sequences, more than CF_T ints, values outside the 32-bit safe range)
+// is flagged and left to the host path, which then fetches the matches.
+#define CF_T 4096      // ints of trimmed sequences per group
+#define CF_R 4096      // ints of reduced sequences per group
+#define CF_CONS 1024   // ints of the consensus
+#define CF_A 256       // seeds of the query window
+#define CF_M 256       // matches of a group before the 25-base filter
+#define CF_HASH 4096
+
+struct CFWave {
+    int32_t T[CF_T];
+    int32_t R[CF_R];
+    uint16_t Rmap[CF_R / 2];
+    union {
+        uint32_t hash[CF_HASH];  // (seed + 1) << 8 | shared << 7 | first sequence
+        struct {
+            uint16_t cmA[CF_R / 2], cmB[CF_R / 2];  // consensus matches of sequence s at [rb[s]/2 .. ): consensus index, index in T_s
+            int32_t cons[CF_CONS + 2];
+            int32_t front[CF_CONS / 8 + 2], backc[CF_CONS / 8 + 2];
+        };
+    };
+    int32_t GA[CF_A + 2];     // G(i) = sum_{j=1..i} (a[2j] + k) over the forward query
+    uint32_t mpair[CF_M];     // pair slot of every match of the group
+    int32_t tb[64], tN[64], tLen[64], tOff[64], tIns[64], tId[64], rb[64], rN[64], mLen[64];
+    uint8_t tRc[64], ord[64];
+};
+
+
+// seeds/sequence.go:1190 GetBaseIndex for one part: MA/MB = its consensus matches, sa = consensus, sb = trimmed target
+__device__ __forceinline__ void cf_base_index(const uint16_t* MA, const uint16_t* MB, int L, int aIndex, const int32_t* sa,
+                                              const int32_t* sb, int nb, int k, int& indexOut, int& basesOut) {
+    int before = 0;
+    while (before < L && (int)MA[before] <= aIndex) before++;
+    if (before == 0) {
+        int offset = 0;
+        for (int i = MA[0]; i > aIndex; i--) offset += sa[i * 2] + k;
+        int bIndex = MB[0];
+        for (int i = bIndex * 2; i > 0 && offset > 0; i -= 2) {
+            offset -= sb[i] + k;
+            bIndex--;
+        }
+        indexOut = bIndex;
+        basesOut = -offset;
+        return;
+    }
+    before--;
+    int bIndex = MB[before];
+    if (aIndex == (int)MA[before]) {
+        indexOut = bIndex;
+        basesOut = 0;
+        return;
+    }
+    int offset = 0;
+    for (int i = MA[before] + 1; i <= aIndex; i++) offset += sa[i * 2] + k;
+    for (int i = bIndex * 2 + 2; i < nb && offset >= sb[i]; i += 2) {
+        offset -= sb[i] + k;
+        bIndex++;
+    }
+    indexOut = bIndex >= nb / 2 ? bIndex - 1 : bIndex;
+    basesOut = offset;
+}
+
+struct ConsFullArgs {
+    const uint32_t* recs;      // MRec[pairs] as 4 x u32: q, t, off, len
+    const int32_t *ma, *mb;
+    const uint32_t* pbase;     // [nq + 1]
+    const int32_t* qsegs;
+    const uint64_t* qoff;
+    uint32_t n_groups;
+    const dp_seq_ref* refs;
+    const int32_t* segs;
+    const dp_seq_meta* smeta;
+    const int32_t* rc_of;
+    const uint32_t* read_len;
+    int k, overlap_size;
+    dp_paf_rec* paf;           // [pairs]: lines of group g start at slot pbase[2g]
+    uint32_t* ignore_ids;      // [pairs]: likewise
+    dp_group_meta* gmeta;      // [n_groups]
+};
+
+__global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A) {
+    __shared__ CFWave L;
+    const int lane = dp_lane();
+    const int k = A.k;
+    const u64 lanesBelow = (1ull << lane) - 1ull;
+    for (uint32_t g = blockIdx.x; g < A.n_groups; g += gridDim.x) {
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t qf = 2 * g, qr = 2 * g + 1;
+        const uint32_t P0 = A.pbase[qf], P1 = A.pbase[qr + 1];
+        dp_group_meta gm = {P0, 0, 0, 0, 0, 0, 0, 0};
+        // ---- 1. matches of the group
+        int nm = 0;
+        bool tooMany = false;
+        for (uint32_t pb = P0; pb < P1; pb += 64) {
+            const uint32_t p = pb + lane;
+            const bool has = p < P1 && A.recs[4 * (size_t)p + 3] != 0;
+            const u64 m = __ballot(has);
+            if (has) {
+                const int at = nm + __popcll(m & lanesBelow);
+                if (at < CF_M) L.mpair[at] = p;
+            }
+            nm += __popcll(m);
+        }
+        gm.n_matches = (uint32_t)nm;
+        if (nm > CF_M) tooMany = true;
+        if (nm <= 1) {  // the reference only builds a consensus for queries with more than one hit (commands/overlap.go:170)
+            if (lane == 0) A.gmeta[g] = gm;
+            continue;
+        }
+        // ---- forward query: prefix sums of its gaps
+        const int32_t* aSeg = A.qsegs + A.qoff[qf];
+        const int nA = RFLc((int)(A.qoff[qf + 1] - A.qoff[qf]));
+        const int sA = nA >> 1;
+        if (sA > CF_A || sA < 1) tooMany = true;
+        if (tooMany) {
+            gm.flag = 1;
+            if (lane == 0) A.gmeta[g] = gm;
+            continue;
+        }
+        {
+            int run = 0;
+            for (int base = 0; base < sA; base += 64) {
+                const int i = base + lane;  // G(i) for i >= 1 adds a[2i] + k
+                const int v = (i >= 1 && i < sA) ? aSeg[2 * i] + k : 0;
+                const int incl = wave_incl_sum(v);
+                if (i < sA) L.GA[i] = run + incl;
+                run += __shfl(incl, 63, 64);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int a_first = aSeg[0], a_last = aSeg[nA - 1], GA_end = L.GA[sA - 1];
+        // ---- 2. per match: filter + Trimmed()
+        int nseq = 0, tUsed = 0;
+        bool bad = false;
+        for (int mi = 0; mi < nm && !bad; mi++) {
+            const uint32_t p = L.mpair[mi];
+            const uint32_t rq = A.recs[4 * (size_t)p], t = A.recs[4 * (size_t)p + 1], off = A.recs[4 * (size_t)p + 2];
+            const int len = RFLc((int)A.recs[4 * (size_t)p + 3]);
+            const bool isRc = rq == qr;
+            const int32_t* MA = A.ma + off;
+            const int32_t* MB = A.mb + off;
+            const dp_seq_ref ref = A.refs[t];
+            const int32_t* S = A.segs + ref.seg_off;
+            const int ns = RFLc((int)ref.n_seeds), nB = 2 * ns + 1;
+            // GetBasesCovered on both sides (seeds/sequence.go:830): len*k plus the negative gaps between consecutive matched
+            // seeds; reversing both sequences (rc query) leaves the set of gaps unchanged, so the lists are used as they came
+            int ca = 0, cb = 0;
+            bool oob = false;
+            for (int base = 1; base < len; base += 64) {
+                const int i = base + lane;
+                if (i < len) {
+                    const int a1 = MA[i], a0 = MA[i - 1], b1 = MB[i], b0 = MB[i - 1];
+                    if (a1 >= sA || a0 >= sA || a1 < 0 || a0 < 0 || b1 >= ns || b0 >= ns || b0 < 0 || b1 < 0) {
+                        oob = true;
+                    } else {
+                        const int dA = isRc ? L.GA[sA - 1 - a0] - L.GA[sA - 1 - a1] - k : L.GA[a1] - L.GA[a0] - k;
+                        int dB = -k;
+                        for (int j = b0 + 1; j <= b1; j++) dB += S[2 * j] + k;
+                        if (dA < 0) ca += dA;
+                        if (dB < 0) cb += dB;
+                    }
+                }
+            }
+            if (__ballot(oob)) {  // the reference would panic inside GetBasesCovered: leave the group to the host path
+                bad = true;
+                break;
+            }
+            ca = RFLc(wave_sum(ca)) + len * k;
+            cb = RFLc(wave_sum(cb)) + len * k;
+            if (ca < 25 || cb < 25) continue;
+            // indices in the forward query / in X (X = the target, or its reverse complement for a match of the rc query)
+            const int m_first = MA[0], m_last = MA[len - 1], t_first = MB[0], t_last = MB[len - 1];
+            const int a0 = isRc ? sA - 1 - m_last : m_first, aL = isRc ? sA - 1 - m_first : m_last;
+            int startSeed = isRc ? ns - 1 - t_last : t_first, endSeed = isRc ? ns - 1 - t_first : t_last;
+            int startOffset = a_first + L.GA[a0];                  // forward query's GetSeedOffset(MatchA[0])
+            int endOffset = a_last + GA_end - L.GA[aL];            // ... GetSeedOffsetFromEnd(MatchA[last])
+            // X.seg[2t] = S[2t] (forward) or S[2(ns - t)] (reverse complement)
+            while (startSeed > 0) {
+                const int gp = (isRc ? S[2 * (ns - startSeed)] : S[2 * startSeed]) + k;
+                if (startOffset < gp) break;
+                startOffset -= gp;
+                startSeed--;
+            }
+            while (endSeed < ns - 1) {
+                const int gp = (isRc ? S[2 * (ns - endSeed - 1)] : S[2 * endSeed + 2]) + k;
+                if (endOffset < gp) break;
+                endOffset -= gp;
+                endSeed++;
+            }
+            if (startSeed > endSeed) {
+                bad = true;
+                break;
+            }
+            // X.GetSeedOffset(startSeed), X.GetSeedOffsetFromEnd(endSeed): sums over the forward target
+            int so = 0, se = 0;
+            if (!isRc) {
+                for (int j = 1 + lane; j <= startSeed; j += 64) so += S[2 * j] + k;
+                for (int j = endSeed + 1 + lane; j <= ns - 1; j += 64) se += S[2 * j] + k;
+                so = RFLc(wave_sum(so)) + S[0];
+                se = RFLc(wave_sum(se)) + S[nB - 1];
+            } else {  // R.seedOffset(i) = S.seedOffsetFromEnd(ns-1-i), R.seedOffsetFromEnd(i) = S.seedOffset(ns-1-i)
+                const int fs = ns - 1 - startSeed, fe = ns - 1 - endSeed;
+                for (int j = fs + 1 + lane; j <= ns - 1; j += 64) so += S[2 * j] + k;
+                for (int j = 1 + lane; j <= fe; j += 64) se += S[2 * j] + k;
+                so = RFLc(wave_sum(so)) + S[nB - 1];
+                se = RFLc(wave_sum(se)) + S[0];
+            }
+            const int offset = so - startOffset, inset = se - endOffset;
+            const dp_seq_meta sm = A.smeta[t];
+            const int nT = 2 * (endSeed - startSeed) + 3;
+            if (nseq >= 64 || tUsed + nT > CF_T) {
+                bad = true;
+                break;
+            }
+            for (int j = lane; j < nT; j += 64) {
+                const int x = 2 * startSeed + j;  // index in X
+                int v;
+                if (!isRc) v = S[x];
+                else v = (x & 1) ? A.rc_of[S[nB - 1 - x]] : S[nB - 1 - x];
+                if (j == 0) v = startOffset;
+                if (j == nT - 1) v = endOffset;
+                L.T[tUsed + j] = v;
+            }
+            if (lane == 0) {
+                L.tb[nseq] = tUsed;
+                L.tN[nseq] = nT;
+                L.tLen[nseq] = sm.length - offset - inset;
+                L.tOff[nseq] = isRc ? sm.offset + inset : sm.offset + offset;
+                L.tIns[nseq] = isRc ? sm.inset + offset : sm.inset + inset;
+                L.tId[nseq] = (int32_t)sm.read;
+                L.tRc[nseq] = isRc ? 1 : 0;
+            }
+            tUsed += nT;
+            nseq++;
+        }
+        if (bad) {
+            gm.flag = 1;
+            if (lane == 0) A.gmeta[g] = gm;
+            continue;
+        }
+        if (nseq <= 1) {  // BuildConsensus needs more than one sequence (combine.go:183)
+            if (lane == 0) A.gmeta[g] = gm;
+            continue;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- 3. seeds shared by >= 2 sequences, Reduced()
+        for (int i = lane; i < CF_HASH; i += 64) L.hash[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int s = 0; s < nseq; s++) {
+            const int b = L.tb[s], nsT = L.tN[s] >> 1;
+            for (int i = lane; i < nsT; i += 64) {
+                const uint32_t seed = (uint32_t)L.T[b + 2 * i + 1];
+                uint32_t h = (seed * 2654435761u) >> 20;  // 12 bits
+                for (;;) {
+                    const uint32_t e = L.hash[h];
+                    if (e == 0) {
+                        const uint32_t old = atomicCAS(&L.hash[h], 0u, ((seed + 1) << 8) | (uint32_t)s);
+                        if (old == 0) break;
+                        continue;  // somebody else took the slot: look at it again
+                    }
+                    if ((e >> 8) == seed + 1) {
+                        if ((e & 63u) != (uint32_t)s && !(e & 128u)) atomicOr(&L.hash[h], 128u);
+                        break;
+                    }
+                    h = (h + 1) & (CF_HASH - 1);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        int rUsed = 0;
+        for (int s = 0; s < nseq; s++) {
+            const int b = L.tb[s], nT = L.tN[s], nsT = nT >> 1;
+            int kept = 0, prevWl = -1, H = 0, Hkept = 0;  // H = sum_{j=1..i}(T[2j]+k) up to the block start; Hkept = H at the last kept seed
+            bool any = false;
+            for (int base = 0; base < nsT; base += 64) {
+                const int i = base + lane;
+                const bool valid = i < nsT;
+                const int seed = valid ? L.T[b + 2 * i + 1] : -2;
+                bool wl = false;
+                if (valid) {
+                    uint32_t h = ((uint32_t)seed * 2654435761u) >> 20;
+                    for (;;) {
+                        const uint32_t e = L.hash[h];
+                        if (e == 0) break;
+                        if ((e >> 8) == (uint32_t)seed + 1) {
+                            wl = (e & 128u) != 0;
+                            break;
+                        }
+                        h = (h + 1) & (CF_HASH - 1);
+                    }
+                }
+                const u64 wlMask = __ballot(wl);
+                const u64 below = wlMask & lanesBelow;
+                int pseed = __shfl(seed, below ? 63 - __builtin_clzll(below) : 0, 64);
+                if (!below) pseed = prevWl;
+                const bool keep = wl && seed != pseed;  // Reduced(): a whitelisted seed equal to the previous whitelisted one is dropped
+                const u64 keepMask = __ballot(keep);
+                const int Hin = H + wave_incl_sum((valid && i >= 1) ? L.T[b + 2 * i] + k : 0);  // H(i)
+                const u64 kb = keepMask & lanesBelow;
+                int Hq = __shfl(Hin, kb ? 63 - __builtin_clzll(kb) : 0, 64);
+                const bool firstKept = !kb && !any;
+                if (!kb) Hq = Hkept;
+                if (keep) {
+                    const int r = kept + __popcll(kb);
+                    if (rUsed + 2 * r + 2 < CF_R) {
+                        L.R[rUsed + 2 * r] = firstKept ? L.T[b] + Hin : Hin - Hq - k;
+                        L.R[rUsed + 2 * r + 1] = seed;
+                        L.Rmap[(rUsed >> 1) + r] = (uint16_t)i;
+                    }
+                }
+                if (wlMask) prevWl = __shfl(seed, 63 - __builtin_clzll(wlMask), 64);
+                if (keepMask) {
+                    Hkept = __shfl(Hin, 63 - __builtin_clzll(keepMask), 64);
+                    any = true;
+                }
+                H = __shfl(Hin, 63, 64);
+                kept += __popcll(keepMask);
+            }
+            if (rUsed + 2 * kept + 2 >= CF_R) {
+                bad = true;
+                break;
+            }
+            if (kept >= 1) {
+                // final offset: gap after the last kept seed q up to the end = H(nsT) - H(q) - k, H(nsT) includes the final gap
+                const int Hend = H + L.T[b + nT - 1] + k;
+                if (lane == 0) {
+                    L.R[rUsed + 2 * kept] = Hend - Hkept - k;
+                    L.rb[s] = rUsed;
+                    L.rN[s] = 2 * kept + 1;
+                }
+                rUsed += 2 * kept + 2;  // (even: Rmap / cm arrays are indexed by rUsed >> 1)
+            } else if (lane == 0) {
+                L.rb[s] = rUsed;
+                L.rN[s] = 0;
+            }
+        }
+        if (bad) {
+            gm.flag = 1;
+            if (lane == 0) A.gmeta[g] = gm;
+            continue;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- 4. the alignment (multiAligner.Consensus :52-247); lane i owns sequence i.  hash[] is dead from here on.
+        const bool mine = lane < nseq;
+        const int b = mine ? L.rb[lane] : 0;
+        const int sl = mine ? L.rN[lane] : 0;
+        const int mbase = b >> 1;
+        const int32_t* S = L.R;
+        int pos = -1, offs = 0, gaps = 50, supported = 0, dist = 0, mlen = 0, clen = 0;
+        const int kLim = 1 << 28;
+        const int ns = nseq;
+        for (;;) {
+            int near = 100000;
+            const int p2s = pos + 1;
+            const bool okS = sl > 0 && p2s < sl / 2;
+            const int od = okS ? S[b + p2s * 2] - offs : 0;
+            supported = 0;
+            const bool fin = !mine || sl == 0 || pos >= (sl - 1) / 2 - 1;
+            int fCount = __popcll(__ballot(fin && mine));
+            int d = 0, nextSeed = 0, minD = 0, maxD = 0;
+            if (!fin) {
+                d = S[b + pos * 2 + 2] - offs;
+                dist = d;
+                nextSeed = S[b + pos * 2 + 3];
+                ca_gap_range(d + gaps, k, minD, maxD);
+                minD -= gaps;
+                maxD -= gaps;
+            }
+            if (od >= kLim || od <= -kLim || gaps >= kLim || d >= kLim || d <= -kLim || dist >= kLim || dist <= -kLim) bad = true;
+            if (__ballot(bad)) break;
+            unsigned long long cand = __ballot(!fin);
+            bool memoOk = false;
+            int memoD = 0, memoSeed = 0, memoMin = 0, memoMax = 0, memoCnt = 0, memoSum = 0;
+            bool fnd = false;
+            int val = 0;
+            while (cand) {
+                const int i = __builtin_ctzll(cand);
+                cand &= cand - 1;
+                const int di = CA_RL(d, i);
+                if (!(di < near && di > -k)) continue;
+                const int seedI = CA_RL(nextSeed, i), minI = CA_RL(minD, i), maxI = CA_RL(maxD, i);
+                if (near > maxI) near = maxI;
+                if (!(memoOk && memoD == di && memoSeed == seedI && memoMin == minI && memoMax == maxI)) {
+                    fnd = false;
+                    val = 0;
+                    if (okS) {
+                        int min2, max2;
+                        ca_gap_range(di + gaps, k, min2, max2);
+                        if (min2 > minI) min2 = minI;
+                        if (max2 < maxI) max2 = maxI;
+                        int p2 = p2s, otherD = od;
+                        while (otherD < min2 && p2 < sl / 2) {
+                            p2++;
+                            otherD += S[b + p2 * 2] + k;
+                        }
+                        while (otherD < max2 && p2 < sl / 2) {
+                            if (S[b + p2 * 2 + 1] == seedI) {
+                                fnd = true;
+                                val = otherD;
+                                break;
+                            }
+                            p2++;
+                            otherD += S[b + p2 * 2] + k;
+                        }
+                    }
+                    memoCnt = __popcll(__ballot(fnd));
+                    memoSum = wave_sum(fnd ? val : 0);
+                    memoOk = true;
+                    memoD = di;
+                    memoSeed = seedI;
+                    memoMin = minI;
+                    memoMax = maxI;
+                }
+                if (lane == i) {
+                    supported = 1 + memoCnt - (fnd ? 1 : 0);
+                    dist += memoSum - (fnd ? val : 0);
+                }
+            }
+            if (fCount >= ns) break;
+            int minseed = -1, mindist = 0, minsup = 0, selMin = 0, selMax = 0;
+            {
+                unsigned long long sup = __ballot(supported > 1);
+                while (sup) {
+                    const int i = __builtin_ctzll(sup);
+                    sup &= sup - 1;
+                    const int si = CA_RL(supported, i);
+                    const int dv = CA_RL(dist, i) / si;
+                    const int seed = CA_RL(nextSeed, i);
+                    if (minseed == -1 || (minseed == seed && si > minsup) || (minseed != seed && mindist > dv)) {
+                        minsup = si;
+                        mindist = dv;
+                        minseed = seed;
+                        const int gi = CA_RL(gaps, i);
+                        ca_gap_range(dv + gi, k, selMin, selMax);
+                        selMin -= gi;
+                        selMax -= gi;
+                    }
+                }
+            }
+            if (minseed == -1) {
+                const int dvv = supported > 1 ? dist / supported : dist;
+                const bool can = mine && sl > 0 && pos < ns / 2;
+                int best = can ? dvv : 0x7fffffff;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+                if (best >= 100000) break;
+                const int minIndex = __builtin_ctzll(__ballot(can && dvv == best));
+                if (mine && sl > 0) {
+                    gaps += best;
+                    offs += best;
+                }
+                if (lane == minIndex) {
+                    gaps = 0;
+                    offs = 0;
+                    pos++;
+                }
+                continue;
+            }
+            if (clen + 2 >= CF_CONS) {
+                bad = true;
+                break;
+            }
+            if (lane == 0) {
+                L.cons[clen] = mindist;
+                L.cons[clen + 1] = minseed;
+            }
+            clen += 2;
+            bool finC = true;
+            if (mine && sl > 0) {
+                int matchDex = pos + 1;
+                if (matchDex < sl / 2) {
+                    int min2, max2;
+                    ca_gap_range(mindist + gaps, k, min2, max2);
+                    if (min2 > selMin) min2 = selMin;
+                    if (max2 < selMax) max2 = selMax;
+                    int otherD = S[b + matchDex * 2] - offs;
+                    while (otherD < min2 && matchDex < sl / 2) {
+                        matchDex++;
+                        otherD += S[b + matchDex * 2] + k;
+                    }
+                    bool found = false;
+                    while (otherD < max2 && matchDex < sl / 2) {
+                        if (S[b + matchDex * 2 + 1] == minseed) {
+                            pos = matchDex;
+                            offs = 0;
+                            gaps = 0;
+                            L.cmA[mbase + mlen] = (uint16_t)(clen / 2 - 1);
+                            L.cmB[mbase + mlen] = L.Rmap[mbase + matchDex];  // index in the trimmed sequence
+                            mlen++;
+                            found = true;
+                            break;
+                        }
+                        matchDex++;
+                        otherD += S[b + matchDex * 2] + k;
+                    }
+                    finC = false;
+                    if (!found) {
+                        gaps += mindist;
+                        offs += mindist;
+                        int p = pos;
+                        while (p < sl / 2 && offs > S[b + p * 2 + 2] + 50) {
+                            offs -= S[b + p * 2 + 2] + k;
+                            p++;
+                            pos++;
+                        }
+                        if (p >= sl / 2) finC = true;
+                    }
+                }
+            }
+            if (__popcll(__ballot(finC && mine)) >= ns) break;
+        }
+        if (__ballot(bad)) {
+            gm.flag = 1;
+            if (lane == 0) A.gmeta[g] = gm;
+            continue;
+        }
+        if (lane == 0) L.cons[clen] = 0;
+        if (mine) L.mLen[lane] = mlen;
+        __builtin_amdgcn_wave_barrier();
+        // ---- 5. parts with fewer than 3 matched seeds leave by swap-with-last, from the back (:258-266)
+        int np = nseq;
+        if (lane == 0) {
+            for (int i = 0; i < nseq; i++) L.ord[i] = (uint8_t)i;
+            for (int i = nseq - 1; i >= 0; i--) {
+                const int s = L.ord[i];
+                if (L.rN[s] == 0 || L.mLen[s] < 3) {
+                    L.ord[i] = L.ord[np - 1];
+                    np--;
+                }
+            }
+        }
+        np = __shfl(np, 0, 64);
+        __builtin_amdgcn_wave_barrier();
+        if (np <= 1) {
+            if (lane == 0) A.gmeta[g] = gm;
+            continue;
+        }
+        // trimToBestSeed (combine.go:21-111)
+        const int cS = clen / 2;                  // ms[0].SeqA.GetNumSeeds()
+        const int upto = cS / 4;
+        const int minMatch = np < 5 ? np : 5;
+        for (int i = lane; i < upto; i += 64) {
+            L.front[i] = 0;
+            L.backc[i] = 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const bool part = lane < np;
+        const int sq = part ? L.ord[lane] : 0;
+        const int mb0 = part ? (L.rb[sq] >> 1) : 0;
+        int pl = part ? L.mLen[sq] : 0;
+        if (part) {
+            for (int j = 0; j < pl; j++) {
+                const int a = L.cmA[mb0 + j];
+                if (a < upto) atomicAdd(&L.front[a], 1);
+                if (j >= 1 && cS - 1 - a < upto && cS - 1 - a >= 0) atomicAdd(&L.backc[cS - 1 - a], 1);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        int bestCount = 0, bestScore = 0, bestIndex = upto, backCount = 0, backScore = 0, backIndex = cS - upto - 1;
+        for (int i = 0; i < upto; i++) {
+            const int count = L.front[i], bCount = L.backc[i];
+            if (count - i >= bestScore || (bestCount < minMatch && count >= minMatch)) {
+                bestCount = count;
+                bestScore = count - i;
+                bestIndex = i;
+            }
+            if (bCount - i >= backScore || (backCount < minMatch && bCount >= minMatch)) {
+                backCount = bCount;
+                backScore = bCount - i;
+                backIndex = cS - 1 - i;
+            }
+        }
+        // consensus := Trimmed(0, bestIndex, 0, backIndex): only its extent matters below (gaps at both ends become 0)
+        int cStart = bestIndex, cEnd = backIndex;
+        while (cStart > 0 && 0 >= L.cons[2 * cStart] + k) cStart--;
+        while (cEnd < cS - 1 && 0 >= L.cons[2 * cEnd + 2] + k) cEnd++;
+        const int naC = 2 * cEnd + 3 - 2 * cStart;  // ints of the trimmed consensus
+        int pOffset = 0, pInset = 0, pN = 0, ident = 0, badBack = 0;
+        bool panic = false, partBad = false;
+        if (part) {
+            const uint16_t* MA = L.cmA + mb0;
+            const uint16_t* MB = L.cmB + mb0;
+            const int32_t* sb = L.T + L.tb[sq];
+            const int nT = L.tN[sq], nsT = nT >> 1;
+            int index, bases, bIndex, backBases;
+            cf_base_index(MA, MB, pl, bestIndex, L.cons, sb, nT, k, index, bases);
+            cf_base_index(MA, MB, pl, backIndex, L.cons, sb, nT, k, bIndex, backBases);
+            if (bases > -k && index < nsT - 1) {
+                bases = (sb[2 * index + 2] + k) - bases;
+                index++;
+            } else if (bases < 0) {
+                bases = -bases + k;
+            }
+            // parts[j] = match.SeqB.Trimmed(bases, index, backBases, bIndex)
+            int startSeed = index, endSeed = bIndex, startOffset = bases, endOffset = backBases;
+            while (startSeed > 0 && startOffset >= sb[2 * startSeed] + k) {
+                startOffset -= sb[2 * startSeed] + k;
+                startSeed--;
+            }
+            while (endSeed < nsT - 1 && endOffset >= sb[2 * endSeed + 2] + k) {
+                endOffset -= sb[2 * endSeed + 2] + k;
+                endSeed++;
+            }
+            if (startSeed < 0 || endSeed >= nsT || startSeed > endSeed) {
+                partBad = true;
+            } else {
+                int so = sb[0], se = sb[nT - 1];
+                for (int j = 1; j <= startSeed; j++) so += sb[2 * j] + k;
+                for (int j = endSeed + 1; j <= nsT - 1; j++) se += sb[2 * j] + k;
+                const int o2 = so - startOffset, i2 = se - endOffset;
+                const bool rc = L.tRc[sq] != 0;
+                pOffset = rc ? L.tOff[sq] + i2 : L.tOff[sq] + o2;
+                pInset = rc ? L.tIns[sq] + o2 : L.tIns[sq] + i2;
+                pN = 2 * (endSeed - startSeed) + 3;
+                // the part's matches: keep [front, back], rebase (combine.go:84-110)
+                int front = 0;
+                while (front < pl && (int)MB[front] < index) front++;
+                int back = pl - 1;
+                while (back >= 0 && (int)MB[back] > bIndex) back--;
+                if (back + 1 > pl || back < front) {  // "Bad back:" diagnostic, suppressed and counted
+                    badBack = 1;
+                    if (back + 1 < front) back = front - 1;
+                }
+                // GetBasesCovered(k) of the trimmed match, consensus side (commands/overlap.go:214): this part's line uses the
+                // PREVIOUS part's match (Matches[id-1]); computed here, handed to the next lane below
+                const int Ln = back - front + 1;
+                if (Ln <= 0) {
+                    panic = true;
+                } else {
+                    int countA = Ln * k;
+                    int prevA = (int)MA[front] - bestIndex, prevB = (int)MB[front] - index;
+                    for (int j = front + 1; j <= back && !panic; j++) {
+                        const int s = (int)MA[j] - bestIndex, s2 = (int)MB[j] - index;
+                        if (s * 2 >= naC || s2 * 2 >= pN || prevA * 2 + 2 >= naC || prevB * 2 + 2 >= pN || prevA < 0 || prevB < 0) {
+                            panic = true;
+                            break;
+                        }
+                        // trimmed consensus ints: tc[x] = cons[2*cStart + x], tc[0] = tc[naC-1] = 0
+                        int d1 = 0;
+                        {
+                            const int x = prevA * 2 + 2;
+                            d1 = (x == 0 || x == naC - 1) ? 0 : L.cons[2 * cStart + x];
+                        }
+                        for (int jj = prevA + 2; jj <= s; jj++) {
+                            const int x = jj * 2;
+                            d1 += ((x == 0 || x == naC - 1) ? 0 : L.cons[2 * cStart + x]) + k;
+                        }
+                        if (d1 < 0) countA += d1;
+                        prevA = s;
+                        prevB = s2;
+                    }
+                    ident = panic ? 0 : countA;
+                }
+            }
+        }
+        if (__ballot(partBad)) {
+            gm.flag = 1;
+            if (lane == 0) A.gmeta[g] = gm;
+            continue;
+        }
+        // contig + PAF numbers (combine.go:113-133, commands/overlap.go:199-231)
+        const int myId = part ? L.tId[sq] : 0;
+        const int myRc = part ? L.tRc[sq] : 0;
+        const int mySeqLen = part ? (int)A.read_len[myId] : 0;
+        const int myStart = pOffset, myLen = mySeqLen - pOffset - pInset;
+        const int q_id = __shfl(myId, 0, 64), q_rc = __shfl(myRc, 0, 64), q_len = __shfl(mySeqLen, 0, 64);
+        const int q_start = __shfl(myStart, 0, 64), q_l = __shfl(myLen, 0, 64);
+        const int identPrev = __shfl_up(ident, 1, 64);
+        const bool panicPrev = __shfl_up(panic ? 1 : 0, 1, 64) != 0;
+        const bool line = part && lane >= 1;
+        bool ign = false;
+        if (lane == 0) ign = q_len <= A.overlap_size * 2;
+        if (line) {
+            const int start = myStart, end = myStart + myLen;
+            int covered = A.overlap_size;
+            if (end - start > A.overlap_size) covered = end - start;
+            ign = (long long)mySeqLen * 9 <= (long long)covered * 10;
+            dp_paf_rec r;
+            r.q_read = (uint32_t)q_id;
+            r.t_read = (uint32_t)myId;
+            r.q_len = q_len;
+            r.q_start = q_start;
+            r.q_end = q_start + q_l;
+            r.t_len = mySeqLen;
+            r.t_start = start;
+            r.t_end = end;
+            r.ident = identPrev;
+            r.minus = (q_rc != myRc) ? 1u : 0u;
+            A.paf[P0 + (uint32_t)(lane - 1)] = r;
+        }
+        const u64 ignMask = __ballot(ign && part);
+        if (ign && part) A.ignore_ids[P0 + (uint32_t)__popcll(ignMask & lanesBelow)] = (uint32_t)myId;
+        gm.n_lines = (uint32_t)(np - 1);
+        gm.n_ignore = (uint32_t)__popcll(ignMask);
+        gm.bad_back = (uint32_t)__popcll(__ballot(badBack != 0));
+        gm.empty_match = (uint32_t)__popcll(__ballot(line && panicPrev));
+        if (lane == 0) A.gmeta[g] = gm;
+    }
+}
+
+// Device consensus of the round whose chaining stage (dp_find_overlaps) last ran on this context.
+int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs, const int32_t* rc_of, uint32_t n_seeds, int k,
+                          int overlap_size, dp_paf_batch* out) {
+    memset(out, 0, sizeof(*out));
+    hipSetDevice(ctx->device);
+    const uint32_t nq = ctx->last_nq, ng = nq / 2, np = ctx->n_pairs;
+    out->n_groups = ng;
+    if (n_seqs != ctx->n_seqs || n_seeds != ctx->n_seeds) return dp_fail(ctx, DP_ERR_ARG, "dp_consensus_paf: metas / rc_of do not match the round's index");
+    if (nq & 1) return dp_fail(ctx, DP_ERR_ARG, "dp_consensus_paf: queries must come in (forward, reverse complement) pairs");
+    if (ng == 0 || !ctx->find_valid) {
+        if (!ctx->find_valid && ng) return dp_fail(ctx, DP_ERR_STATE, "dp_consensus_paf before dp_find_overlaps");
+        return DP_OK;
+    }
+    const size_t b_meta = (size_t)n_seqs * sizeof(dp_seq_meta), b_rc = (size_t)n_seeds * 4;
+    if (pin_reserve(ctx, ctx->h_cin, b_meta + b_rc + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_cin, b_meta + b_rc + 64)) return DP_ERR_HIP;
+    memcpy(ctx->h_cin.p, metas, b_meta);
+    memcpy((uint8_t*)ctx->h_cin.p + b_meta, rc_of, b_rc);
+    DP_HIP(hipMemcpyAsync(ctx->d_cin.p, ctx->h_cin.p, b_meta + b_rc, hipMemcpyHostToDevice, ctx->stream));
+    const size_t b_paf = (size_t)np * sizeof(dp_paf_rec), b_ign = (size_t)np * 4, b_gm = (size_t)ng * sizeof(dp_group_meta);
+    if (dev_reserve(ctx, ctx->d_cout, b_paf + b_ign + b_gm + 64)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_cout, b_paf + b_ign + b_gm + 64)) return DP_ERR_HIP;
+    uint8_t* dout = (uint8_t*)ctx->d_cout.p;
+    ConsFullArgs A;
+    A.recs = (const uint32_t*)ctx->d_mrec.p;
+    A.ma = (const int32_t*)ctx->d_ma.p;
+    A.mb = (const int32_t*)ctx->d_mb.p;
+    A.pbase = (const uint32_t*)((const uint64_t*)ctx->d_pbase.p + nq + 1);
+    A.qsegs = (const int32_t*)ctx->d_qsegs.p;
+    A.qoff = (const uint64_t*)ctx->d_qoff.p;
+    A.n_groups = ng;
+    A.refs = (const dp_seq_ref*)ctx->d_seqrefs.p;
+    A.segs = (const int32_t*)ctx->d_segs.p;
+    A.smeta = (const dp_seq_meta*)ctx->d_cin.p;
+    A.rc_of = (const int32_t*)((const uint8_t*)ctx->d_cin.p + b_meta);
+    A.read_len = (const uint32_t*)ctx->d_len.p;
+    A.k = k;
+    A.overlap_size = overlap_size;
+    A.gmeta = (dp_group_meta*)dout;
+    A.paf = (dp_paf_rec*)(dout + b_gm);
+    A.ignore_ids = (uint32_t*)(dout + b_gm + b_paf);
+    DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(consensus_full_kernel, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), 0, ctx->stream, A);
+    DP_HIP(hipGetLastError());
+    DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->h_cout.p, dout, b_paf + b_ign + b_gm, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    float ms = 0;
+    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+    out->kernel_ms = ms;
+    const uint8_t* h = (const uint8_t*)ctx->h_cout.p;
+    out->groups = (const dp_group_meta*)h;
+    out->paf = (const dp_paf_rec*)(h + b_gm);
+    out->ignore_ids = (const uint32_t*)(h + b_gm + b_paf);
+    return DP_OK;
+}
+
+extern "C" int dp_consensus_paf(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs, const int32_t* rc_of, uint32_t n_seeds, int k,
+                                int overlap_size, dp_paf_batch* out) {
+    if (!ctx || !out || (n_seqs && !metas) || (n_seeds && !rc_of)) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_consensus_paf: bad arguments") : DP_ERR_ARG;
+    return dp_consensus_paf_impl(ctx, metas, n_seqs, rc_of, n_seeds, k, overlap_size, out);
 }

@@ -1833,12 +1833,17 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     return DP_OK;
 }
 
+int dp_fetch_overlaps_impl(dp_ctx* ctx, int want_candidates, dp_match_batch* out);
+
 int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,
                           uint32_t max_query_len, int want_candidates, dp_match_batch* out) {
     if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_find_overlaps before dp_round_begin");
     hipSetDevice(ctx->device);
     memset(out, 0, sizeof(*out));
     out->n_queries = nq;
+    ctx->find_valid = false;
+    ctx->n_pairs = 0;
+    ctx->last_nq = nq;
     const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
     if (pin_reserve(ctx, ctx->h_cursor, 128)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_cand_off, ((size_t)nq + 1) * 8)) return DP_ERR_HIP;
@@ -1981,19 +1986,57 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         snprintf(msg, sizeof msg, "overlap chaining hit a reference capacity limit (bits %u: 1 reduced buffer, 2 state pool, 4 results, 8 nodes)", cur[2]);
         return dp_fail(ctx, DP_ERR_CAPACITY, msg);
     }
-    // fetch.  Pair slots are in canonical order already: queries ascending, candidates ascending within a query.
-    const uint32_t nslots = (uint32_t)*(const uint64_t*)&cur[16], ni = cur[0];
-    ctx->n_pairs = nslots;
+    // status words, per-query posting-word counts and candidate counts come back in any case (a few KB)
+    if (pin_reserve(ctx, ctx->h_qm, (size_t)nq * 28 + 16)) return DP_ERR_HIP;
+    DP_HIP(hipMemcpyAsync(ctx->h_qm.p, d_qmeta, (size_t)nq * 28, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    {
+        const uint32_t* qm = (const uint32_t*)ctx->h_qm.p;
+        const u64* words = (const u64*)((const uint8_t*)ctx->h_qm.p + (size_t)nq * 16);
+        for (uint32_t q = 0; q < nq; q++) {
+            if (qm[4 * q + 2] & 1) return dp_fail(ctx, DP_ERR_CAPACITY, "query with more than 512 usable seeds");
+            out->query_bytes += words[q] * 8;
+        }
+    }
+    uint64_t tp = 0;
+    memcpy(&tp, &cur[16], 8);
+    ctx->n_pairs = (uint32_t)tp;
+    ctx->last_nq = nq;
+    ctx->last_ni = cur[0];
+    ctx->last_k = k;
+    ctx->find_valid = true;
+    if (want_candidates & 2) {
+        for (uint32_t q = 0; q <= nq; q++) ((uint64_t*)ctx->h_cand_off.p)[q] = 0;
+        return DP_OK;
+    }
+    const double qk = out->query_kernel_ms, ck = out->chain_kernel_ms;
+    const uint64_t qb = out->query_bytes, cb = out->chain_bytes;
+    int rc = dp_fetch_overlaps_impl(ctx, want_candidates & 1, out);
+    out->query_kernel_ms = qk;
+    out->chain_kernel_ms = ck;
+    out->query_bytes = qb;
+    out->chain_bytes = cb;
+    return rc;
+}
+
+// Download of the chaining stage's records.  Pair slots are in canonical order already: queries ascending, candidates
+// ascending within a query.
+int dp_fetch_overlaps_impl(dp_ctx* ctx, int want_candidates, dp_match_batch* out) {
+    if (!ctx->find_valid) return dp_fail(ctx, DP_ERR_STATE, "dp_fetch_overlaps: no chaining stage output on this context");
+    hipSetDevice(ctx->device);
+    memset(out, 0, sizeof(*out));
+    const uint32_t nq = ctx->last_nq, nslots = ctx->n_pairs, ni = ctx->last_ni;
+    const int k = ctx->last_k;
+    out->n_queries = nq;
+    const u64* d_totals = (const u64*)((const uint8_t*)ctx->d_cursor.p + 64);
+    if (pin_reserve(ctx, ctx->h_cand_off, ((size_t)nq + 1) * 8)) return DP_ERR_HIP;
+    out->cand_off = (const uint64_t*)ctx->h_cand_off.p;
     if (pin_reserve(ctx, ctx->h_mrec, (size_t)nslots * sizeof(MRec) + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_ta, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_tb, (size_t)ni * 4 + 16)) return DP_ERR_HIP;
-    if (pin_reserve(ctx, ctx->h_qm, (size_t)nq * 28 + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
-    uint32_t* qm = (uint32_t*)ctx->h_qm.p;
-    u64* words = (u64*)((uint8_t*)ctx->h_qm.p + (size_t)nq * 16);
-    uint32_t* h_qcnt = (uint32_t*)((uint8_t*)ctx->h_qm.p + (size_t)nq * 24);
-    DP_HIP(hipMemcpyAsync(qm, d_qmeta, (size_t)nq * 28, hipMemcpyDeviceToHost, ctx->stream));
+    const uint32_t* h_qcnt = (const uint32_t*)((const uint8_t*)ctx->h_qm.p + (size_t)nq * 24);
     const int32_t* ta = (const int32_t*)ctx->h_ta.p;
     const int32_t* tb = (const int32_t*)ctx->h_tb.p;
     if (nslots) {
@@ -2013,10 +2056,6 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         if (nslots) DP_HIP(hipMemcpyAsync(ctx->h_cand_list.p, ctx->d_clist.p, (size_t)nslots * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     DP_HIP(dp_stream_sync(ctx));
-    for (uint32_t q = 0; q < nq; q++) {
-        if (qm[4 * q + 2] & 1) return dp_fail(ctx, DP_ERR_CAPACITY, "query with more than 512 usable seeds");
-        out->query_bytes += words[q] * 8;
-    }
     MRec* recs = (MRec*)ctx->h_mrec.p;
     uint32_t nm = 0;
     uint64_t total_len = 0;
@@ -2074,6 +2113,11 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         for (uint32_t q = 0; q <= nq; q++) co[q] = 0;
     }
     return DP_OK;
+}
+
+extern "C" int dp_fetch_overlaps(dp_ctx* ctx, dp_match_batch* out) {
+    if (!ctx || !out) return DP_ERR_ARG;
+    return dp_fetch_overlaps_impl(ctx, 0, out);
 }
 
 extern "C" int dp_find_overlaps(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t n_queries,

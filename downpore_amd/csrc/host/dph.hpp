@@ -258,6 +258,11 @@ struct Survivors {
     uint64_t segCount() const { return segsView ? segsViewLen : (uint64_t)segs.size(); }
 };
 
+struct FinalCheckStats {
+    i64 badBack = 0, emptyMatch = 0;
+    uint64_t lines = 0, hits = 0, qHits = 0;
+};
+
 class Overlapper {
    public:
     Overlapper(dp_ctx* ctx, ReadSet& reads, SeedIndex& index, i64 chunkSize, int numWorkers, i64 overlap, int minSeeds,
@@ -272,6 +277,11 @@ class Overlapper {
     // FindOverlaps (:320): Matches + prefilter + chaining + ratchet on the GPU
     // `pool` is storage reused across rounds (its SeedMatch objects keep their vector capacity); out points into it
     int FindOverlaps(std::vector<SeedMatch>& pool, std::vector<SeedMatch*>& out, RoundStats& st);
+    // The same with everything after the chaining kept on the device (dp_find_overlaps without download + dp_consensus_paf):
+    // FindOverlaps + the collation and finalCheckWorker of commands/overlap.go:158-233 for all query windows of the round.
+    // Windows the device flags (they do not fit its layout) are done by the host path on fetched matches.
+    int FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 overlapSize, std::string& paf, FinalCheckStats& fs,
+                                  std::vector<int>* ignoreOut, RoundStats& st);
     void SetOverlapSize(i64 size) { overlap_ = size; }
     std::vector<SeedQuery> queries;
     std::string err;
@@ -311,10 +321,6 @@ void profilePrint();  // DPH_PROFILE counters to stderr
 // have finished.  Concurrent callers (executor slots, the planner) share the pool; jobs are served oldest first.
 void parallelFor(size_t n, const std::function<void(size_t)>& fn);
 // finalCheckWorker (commands/overlap.go:197-233) over the collated matches of a round: consensus, SetIgnore, PAF text.
-struct FinalCheckStats {
-    i64 badBack = 0, emptyMatch = 0;
-    uint64_t lines = 0, hits = 0, qHits = 0;
-};
 // SetIgnore calls are returned in ignoreOut (query order) when it is non-null, otherwise applied to reads.ignore.
 // ctx + jobs (optional): run the consensus alignment of all query windows on the device (dp_consensus_align); jobs is
 // per-executor scratch kept across rounds.  Returns 0, or the device call's error code (text in *errOut).

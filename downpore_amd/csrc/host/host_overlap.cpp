@@ -423,6 +423,179 @@ int Overlapper::FindOverlaps(std::vector<SeedMatch>& pool, std::vector<SeedMatch
     return 0;
 }
 
+static void finalCheckOne(Arena& arena, const SeedIndex& index, const ReadSet& reads, std::vector<SeedMatch*>& results,
+                          i64 overlapSize, std::string& paf, std::vector<int>& ignoreIds, FinalCheckStats& fs);
+
+static inline char* putInt(char* w, i64 v) {  // %d
+    char num[24];
+    char* e = num + sizeof num;
+    char* p = e;
+    uint64_t u = v < 0 ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+    do {
+        *--p = (char)('0' + u % 10);
+        u /= 10;
+    } while (u);
+    if (v < 0) *--p = '-';
+    memcpy(w, p, (size_t)(e - p));
+    return w + (e - p);
+}
+
+int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 overlapSize, std::string& paf, FinalCheckStats& fs,
+                                          std::vector<int>* ignoreOut, RoundStats& st) {
+    querySegs_.clear();
+    queryOff_.assign(1, 0);
+    for (const SeedQuery& q : queries) {
+        querySegs_.insert(querySegs_.end(), q.Query->seg, q.Query->seg + q.Query->n);
+        queryOff_.push_back(querySegs_.size());
+    }
+    dp_match_batch mb;
+    const double tq0 = now();
+    int rc = dp_find_overlaps(ctx_, querySegs_.data(), queryOff_.data(), (uint32_t)queries.size(), hitFraction_, index_.k,
+                              (uint32_t)(overlap_ / 2), 2, &mb);
+    if (rc != 0) {
+        err = dp_last_error(ctx_);
+        return rc;
+    }
+    const double tq1 = now();
+    g_prof.add(9, tq1 - tq0);
+    st.k_query_ms += mb.query_kernel_ms;
+    st.k_chain_ms += mb.chain_kernel_ms;
+    st.query_bytes += mb.query_bytes;
+    st.chain_bytes += mb.chain_bytes;
+    if (index_.sequences.empty() || queries.empty()) return 0;  // nothing indexed: no candidate, no line
+    // SeedSequence fields of the indexed sequences and the seed -> reverse-complement-seed table of the round
+    static thread_local std::vector<dp_seq_meta> metas;
+    metas.resize(index_.sequences.size());
+    for (size_t i = 0; i < metas.size(); i++) {
+        const SeedSeq* s = index_.sequences[i];
+        metas[i].read = (uint32_t)s->id;
+        metas[i].length = (int32_t)s->length;
+        metas[i].offset = (int32_t)s->offset;
+        metas[i].inset = (int32_t)s->inset;
+    }
+    if (index_.rcOf.size() != index_.seedMap.size()) index_.buildRcTable();
+    dp_paf_batch pb;
+    rc = dp_consensus_paf(ctx_, metas.data(), (uint32_t)metas.size(), index_.rcOf.data(), (uint32_t)index_.rcOf.size(), index_.k,
+                          (int)overlapSize, &pb);
+    if (rc != 0) {
+        err = dp_last_error(ctx_);
+        return rc;
+    }
+    st.k_cons_ms += pb.kernel_ms;
+    const double tq2 = now();
+    g_prof.add(10, tq2 - tq1);
+    // windows the device left to the host: BuildConsensus + finalCheckWorker on the fetched matches, one window at a time
+    std::vector<std::string> hostPaf;
+    std::vector<std::vector<int>> hostIgn;
+    std::vector<uint32_t> hostOf(pb.n_groups, 0xffffffffu);
+    uint32_t nFlag = 0;
+    for (uint32_t g = 0; g < pb.n_groups; g++)
+        if (pb.groups[g].flag) hostOf[g] = nFlag++;
+    if (nFlag) {
+        dp_match_batch fb;
+        rc = dp_fetch_overlaps(ctx_, &fb);
+        if (rc != 0) {
+            err = dp_last_error(ctx_);
+            return rc;
+        }
+        hostPaf.resize(nFlag);
+        hostIgn.resize(nFlag);
+        std::vector<std::vector<SeedMatch*>> res(nFlag);
+        size_t used = 0;
+        for (uint32_t i = 0; i < fb.n_matches; i++) {
+            const uint32_t g = fb.query[i] / 2;
+            if (hostOf[g] == 0xffffffffu) continue;
+            if (pool.size() <= used) pool.resize(used + 64);
+            used++;
+        }
+        used = 0;
+        for (uint32_t i = 0; i < fb.n_matches; i++) {  // (second pass: pool no longer moves)
+            const uint32_t g = fb.query[i] / 2;
+            if (hostOf[g] == 0xffffffffu) continue;
+            SeedMatch* m = &pool[used++];
+            const SeedQuery& q = queries[fb.query[i]];
+            m->MatchA.assign(fb.match_a + fb.off[i], fb.match_a + fb.off[i + 1]);
+            m->MatchB.assign(fb.match_b + fb.off[i], fb.match_b + fb.off[i + 1]);
+            m->SeqA = q.Query;
+            m->SeqB = index_.sequences[fb.target[i]];
+            m->QueryID = q.ID;
+            m->ReverseComplementQuery = q.ReverseComplement;
+            m->anchorFirstB = fb.target_anchor ? fb.target_anchor[2 * (size_t)i] : -1;
+            m->anchorLastFromEndB = fb.target_anchor ? fb.target_anchor[2 * (size_t)i + 1] : -1;
+            res[hostOf[g]].push_back(m);
+        }
+        Arena local;
+        for (uint32_t h = 0; h < nFlag; h++) {
+            if (res[h].size() > 1) finalCheckOne(local, index_, reads_, res[h], overlapSize, hostPaf[h], hostIgn[h], fs);
+            local.clear();
+        }
+        g_prof.hostGroups += nFlag;
+    }
+    // the text: one line per part after the first (commands/overlap.go:223-228), windows in query order
+    uint64_t hits = 0, qHits = 0;
+    size_t need = 0;
+    for (uint32_t g = 0; g < pb.n_groups; g++) need += (size_t)pb.groups[g].n_lines * 96;
+    paf.reserve(paf.size() + need);
+    for (uint32_t g = 0; g < pb.n_groups; g++) {
+        const dp_group_meta& gm = pb.groups[g];
+        hits += gm.n_matches;
+        if (gm.n_matches >= 2) qHits++;
+        if (gm.flag) {
+            paf += hostPaf[hostOf[g]];
+            for (int id : hostIgn[hostOf[g]]) {
+                if (ignoreOut) ignoreOut->push_back(id);
+                else reads_.ignore[(size_t)id] = 1;
+            }
+            continue;
+        }
+        fs.badBack += gm.bad_back;
+        fs.emptyMatch += gm.empty_match;
+        for (uint32_t j = 0; j < gm.n_ignore; j++) {
+            const int id = (int)pb.ignore_ids[gm.slot + j];
+            if (ignoreOut) ignoreOut->push_back(id);
+            else reads_.ignore[(size_t)id] = 1;
+        }
+        for (uint32_t j = 0; j < gm.n_lines; j++) {
+            const dp_paf_rec& r = pb.paf[gm.slot + j];
+            const std::string& qName = reads_.names[r.q_read];
+            const std::string& tName = reads_.names[r.t_read];
+            const size_t old = paf.size(), cap = qName.size() + tName.size() + 7 * 21 + 24;
+            paf.resize(old + cap);
+            char* w = &paf[old];
+            memcpy(w, qName.data(), qName.size());
+            w += qName.size();
+            *w++ = '\t';
+            w = putInt(w, r.q_len);
+            *w++ = '\t';
+            w = putInt(w, r.q_start);
+            *w++ = '\t';
+            w = putInt(w, r.q_end);
+            *w++ = '\t';
+            *w++ = r.minus ? '-' : '+';
+            *w++ = '\t';
+            memcpy(w, tName.data(), tName.size());
+            w += tName.size();
+            *w++ = '\t';
+            w = putInt(w, r.t_len);
+            *w++ = '\t';
+            w = putInt(w, r.t_start);
+            *w++ = '\t';
+            w = putInt(w, r.t_end);
+            *w++ = '\t';
+            w = putInt(w, r.ident);
+            memcpy(w, "\t0\t255\n", 7);
+            w += 7;
+            paf.resize((size_t)(w - paf.data()));
+            fs.lines++;
+        }
+    }
+    fs.hits = hits;
+    fs.qHits = qHits;
+    st.n_matches = hits;
+    g_prof.add(12, now() - tq2);
+    return 0;
+}
+
 // finalCheckWorker commands/overlap.go:197-233 (+ collation :158-173).  Queries are independent (the reference runs
 // num_workers finalCheckWorkers); they are spread over host threads here, and the PAF text and SetIgnore effects are
 // applied in query order afterwards, so the result is the canonical single-worker output.

@@ -432,17 +432,34 @@ int OverlapRun::finishRound(ExecSlot& sl, const Survivors& all, RoundResult& out
         if (q.ID >= out.numQuerySeqs) out.numQuerySeqs = q.ID + 1;
     double t1 = now();
     st.t_index = t1 - t0;
-    std::vector<SeedMatch*>& matches = sl.matches;
-    rc = sl.lap->FindOverlaps(sl.matchPool, matches, st);
-    if (rc != 0) {
-        sl.error = sl.lap->err;
-        return rc;
+    // DP_DEVICE_CONSENSUS=0: matches come back to the host, BuildConsensus / finalCheckWorker run on the worker pool (the
+    // round-1 path, still what a window the device flags falls back to)
+    static const bool deviceConsensus = [] {
+        const char* e = getenv("DP_DEVICE_CONSENSUS");
+        return !(e && e[0] == '0');
+    }();
+    double t2;
+    if (deviceConsensus && (sl.lap->queries.size() % 2) == 0) {
+        rc = sl.lap->FindOverlapsAndFinalCheck(sl.matchPool, p.overlapSize, out.paf, out.fs, &out.ignores, st);
+        if (rc != 0) {
+            sl.error = sl.lap->err;
+            return rc;
+        }
+        t2 = now();
+        st.t_query = t2 - t1;
+    } else {
+        std::vector<SeedMatch*>& matches = sl.matches;
+        rc = sl.lap->FindOverlaps(sl.matchPool, matches, st);
+        if (rc != 0) {
+            sl.error = sl.lap->err;
+            return rc;
+        }
+        t2 = now();
+        st.t_query = t2 - t1;
+        rc = finalCheck(sl.index->arena, *sl.index, *reads, matches, out.numQuerySeqs, p.overlapSize, out.paf, out.fs, &out.ignores,
+                        sl.ctx, &sl.consJobs, &sl.error, &st);
+        if (rc != 0) return rc;
     }
-    double t2 = now();
-    st.t_query = t2 - t1;
-    rc = finalCheck(sl.index->arena, *sl.index, *reads, matches, out.numQuerySeqs, p.overlapSize, out.paf, out.fs, &out.ignores,
-                    sl.ctx, &sl.consJobs, &sl.error, &st);
-    if (rc != 0) return rc;
     st.n_paf = out.fs.lines;
     st.t_consensus = now() - t2;
     const int k = p.k;

@@ -217,6 +217,8 @@ typedef struct {
                                * per chained pair, the chains written (counted by the kernel itself) */
 } dp_match_batch;
 
+/* want_candidates: bit 0 = also return Matches()' candidate lists (test hook); bit 1 = leave the matches on the device
+ * (only the kernel times / byte counts of `out` are filled in): for dp_consensus_paf, or a later dp_fetch_overlaps. */
 DP_API int dp_find_overlaps(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t n_queries,
                      double hit_fraction, int k, uint32_t max_query_len, int want_candidates, dp_match_batch* out);
 
@@ -263,6 +265,50 @@ typedef struct dp_consensus_batch {
 } dp_consensus_batch;
 DP_API int dp_consensus_align(dp_ctx* ctx, const int32_t* segs, const uint64_t* seq_off, const uint32_t* group_off, uint32_t n_groups,
                        int k, dp_consensus_batch* out);
+
+/* ---- A16 + A17 on the device: BuildConsensus (overlap/combine.go:163-193) with multiAligner.Consensus
+ * (seeds/alignment.go:23-268), NewSeedContig / trimToBestSeed (combine.go:21-133) and the numbers finalCheckWorker prints
+ * (commands/overlap.go:197-233), for every query window of the round whose chaining stage ran last on this context
+ * (dp_find_overlaps with bit 1 of want_candidates set keeps the matches on the device and skips their download).  Queries
+ * must be (forward, reverse complement) pairs 2g, 2g+1 as PrepareQueries emits them (overlap.go:189-201); a "group" is
+ * one such window.  metas[i] = id (read), Len(), GetOffset(), GetInset() of indexed sequence i as AddSequences built it
+ * (overlap.go:253-318); rc_of[s] = kmerMap[ReverseComplement(seedMap[s], k)] (seeds/sequence.go:125-159).
+ * Per group the caller gets the lines of the contig's parts in order - everything `Fprintf` prints except the names -
+ * and the reads finalCheckWorker passes to SetIgnore (:203-205, 217-223), in call order.  flag != 0: the group does not
+ * fit the device layout (> 64 trimmed sequences, > 4096 ints, a value beyond 2^28, or a state in which the reference
+ * itself would panic); the caller then runs the host path for that group on the matches of dp_fetch_overlaps. */
+typedef struct {
+    uint32_t read;                   /* SeedSequence.id */
+    int32_t length, offset, inset;   /* Len(), GetOffset(), GetInset() */
+} dp_seq_meta;
+typedef struct {
+    uint32_t q_read, t_read;         /* Parts[0], Parts[id]: names are the caller's */
+    int32_t q_len, q_start, q_end;   /* SeqLengths[0], Offsets[0], Offsets[0] + Lengths[0] */
+    int32_t t_len, t_start, t_end;   /* SeqLengths[id], Offsets[id], Offsets[id] + Lengths[id] */
+    int32_t ident;                   /* Matches[id-1].GetBasesCovered(k), consensus side; 0 where the reference would panic */
+    uint32_t minus;                  /* ReverseComplement[0] != ReverseComplement[id] */
+} dp_paf_rec;
+typedef struct {
+    uint32_t slot;                   /* lines of the group: paf[slot .. slot + n_lines), ignores: ignore_ids[slot .. slot + n_ignore) */
+    uint32_t n_lines, n_ignore;
+    uint32_t bad_back;               /* "Bad back:" diagnostics suppressed (combine.go:93-102) */
+    uint32_t empty_match;            /* lines whose GetBasesCovered would have panicked (ident printed as 0) */
+    uint32_t flag;
+    uint32_t n_matches;              /* hits of the two queries of the window (commands/overlap.go:158-173) */
+    uint32_t reserved;
+} dp_group_meta;
+typedef struct {
+    uint32_t n_groups;
+    const dp_group_meta* groups;
+    const dp_paf_rec* paf;
+    const uint32_t* ignore_ids;
+    double kernel_ms;
+} dp_paf_batch;
+DP_API int dp_consensus_paf(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs, const int32_t* rc_of, uint32_t n_seeds, int k,
+                            int overlap_size, dp_paf_batch* out);
+/* The match lists of the last dp_find_overlaps on this context (what that call returns itself unless bit 1 of
+ * want_candidates asked it not to). */
+DP_API int dp_fetch_overlaps(dp_ctx* ctx, dp_match_batch* out);
 
 /* ---- introspection for tests ---------------------------------------------------------------------------------- */
 /* posting row of `seed` (n_words = ceil(n_seqs/64)) and its popcount/start/end as the reference's IntSet holds. */
