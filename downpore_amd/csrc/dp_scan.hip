@@ -436,7 +436,8 @@ __device__ __forceinline__ uint32_t valid_mask(uint64_t g, uint64_t a0, uint64_t
 #define SEL_MAXTOP 64
 __global__ __launch_bounds__(64) void select_kernel(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ boff,
                                                     const dp_scan_item* __restrict__ win, uint32_t n, int k, int numSeeds,
-                                                    const double* __restrict__ values, uint32_t* __restrict__ top) {
+                                                    const double* __restrict__ values, uint32_t* __restrict__ top,
+                                                    uint32_t* __restrict__ evald, uint32_t stride) {
     __shared__ double bestV[64];
     __shared__ uint32_t bestS[64];
     __shared__ double topV[SEL_MAXTOP];
@@ -455,6 +456,9 @@ __global__ __launch_bounds__(64) void select_kernel(const uint8_t* __restrict__ 
     // block b starts evaluating at nextIndex = k + 3k*b and exists while nextIndex < L - k
     const int64_t period = 3 * (int64_t)k;
     const int64_t nBlocks = (L - 2 * (int64_t)k) > 0 ? ((L - 2 * (int64_t)k) + period - 1) / period : 0;
+    // evald (optional): every k-mer the loop below evaluates, slot = block * k + position in the block; unused slots ~0
+    if (evald)
+        for (uint32_t i = lane; i < stride; i += 64) evald[(uint64_t)w * stride + i] = 0xffffffffu;
     for (int64_t b0 = 0; b0 < nBlocks; b0 += 64) {
         const int64_t b = b0 + lane;
         double bv = 0.0;
@@ -467,6 +471,7 @@ __global__ __launch_bounds__(64) void select_kernel(const uint8_t* __restrict__ 
                 const uint64_t a = A0 + (uint64_t)(ni - k + 1);
                 const Win wv = load_win(packed, a >> 5);
                 const uint32_t kmer = win_at_rt(wv, (int)(a & 31)) >> sh;
+                if (evald && (uint64_t)(b * k + i) < stride) evald[(uint64_t)w * stride + (uint64_t)(b * k + i)] = kmer;
                 const double v = values[kmer];
                 if (v > bv) {
                     bv = v;
@@ -511,8 +516,8 @@ extern "C" int dp_values_upload(dp_ctx* ctx, const double* values, uint64_t n) {
     return DP_OK;
 }
 
-extern "C" int dp_select_seeds(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out) {
-    if (!ctx || (n && (!win || !top_out))) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_select_seeds: bad arguments") : DP_ERR_ARG;
+static int select_impl(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out,
+                       const uint32_t** evaluated_out, uint32_t stride) {
     if (k < 1 || k > 16 || num_seeds < 1 || num_seeds > SEL_MAXTOP) return dp_fail(ctx, DP_ERR_ARG, "dp_select_seeds: k in 1..16, num_seeds in 1..64");
     if (!ctx->d_values.p || ctx->n_values != ((uint64_t)1 << (2 * k))) return dp_fail(ctx, DP_ERR_STATE, "dp_select_seeds: value table for this k not uploaded");
     if (n == 0) return DP_OK;
@@ -521,20 +526,34 @@ extern "C" int dp_select_seeds(dp_ctx* ctx, const dp_scan_item* win, uint32_t n,
         if (win[i].read >= ctx->n_reads || (uint64_t)win[i].start + win[i].n_kmers > ctx->h_len[win[i].read])
             return dp_fail(ctx, DP_ERR_ARG, "dp_select_seeds: window outside its read");
     }
-    const size_t wb = (size_t)n * sizeof(dp_scan_item), tb = (size_t)n * (size_t)num_seeds * 4;
+    const size_t wb = (size_t)n * sizeof(dp_scan_item), tb = (size_t)n * (size_t)num_seeds * 4, eb = (size_t)n * stride * 4;
     if (dev_reserve(ctx, ctx->d_selwin, wb)) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_seltop, tb)) return DP_ERR_HIP;
-    if (pin_reserve(ctx, ctx->h_seltop, wb + tb)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_seltop, tb + eb)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_seltop, wb + tb + eb)) return DP_ERR_HIP;
     memcpy(ctx->h_seltop.p, win, wb);
     DP_HIP(hipMemcpyAsync(ctx->d_selwin.p, ctx->h_seltop.p, wb, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t* d_ev = stride ? (uint32_t*)((uint8_t*)ctx->d_seltop.p + tb) : nullptr;
     hipLaunchKernelGGL(select_kernel, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
                        (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_selwin.p, n, k, num_seeds,
-                       (const double*)ctx->d_values.p, (uint32_t*)ctx->d_seltop.p);
+                       (const double*)ctx->d_values.p, (uint32_t*)ctx->d_seltop.p, d_ev, stride);
     DP_HIP(hipGetLastError());
-    DP_HIP(hipMemcpyAsync((uint8_t*)ctx->h_seltop.p + wb, ctx->d_seltop.p, tb, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(hipMemcpyAsync((uint8_t*)ctx->h_seltop.p + wb, ctx->d_seltop.p, tb + eb, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     memcpy(top_out, (uint8_t*)ctx->h_seltop.p + wb, tb);
+    if (evaluated_out) *evaluated_out = (const uint32_t*)((uint8_t*)ctx->h_seltop.p + wb + tb);
     return DP_OK;
+}
+
+extern "C" int dp_select_seeds(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out) {
+    if (!ctx || (n && (!win || !top_out))) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_select_seeds: bad arguments") : DP_ERR_ARG;
+    return select_impl(ctx, win, n, k, num_seeds, top_out, nullptr, 0);
+}
+
+extern "C" int dp_select_windows(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out,
+                                 const uint32_t** evaluated_out, uint32_t stride) {
+    if (!ctx || (n && (!win || !top_out || !evaluated_out)) || stride == 0)
+        return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_select_windows: bad arguments") : DP_ERR_ARG;
+    return select_impl(ctx, win, n, k, num_seeds, top_out, evaluated_out, stride);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -35,6 +35,7 @@ struct ReadSet {
     std::string bases;             // concatenated ASCII of the kept reads
     std::vector<uint8_t> ignore;   // SetIgnore flags (seqio.go:375)
     bool himem = true;             // cached views (seqio.go:115) vs top-level re-reads (:158)
+    size_t maxNameLen = 0;         // longest name (PAF line buffers are sized from it)
     size_t size() const { return names.size(); }
     i64 length(size_t r) const { return off[r + 1] - off[r]; }
     const char* seq(size_t r) const { return bases.data() + off[r]; }
@@ -159,6 +160,17 @@ struct SeedIndex {
     void addSeeds(const char* s, i64 len, int minSeeds, const double* ranks);  // AddSeeds :62-156
     void selectSeeds(const char* s, i64 len, int minSeeds, const double* ranks, uint32_t* topN, bool checkIndex) const;
     bool touchesSeed(const char* s, i64 len) const;
+    bool touchesSeed(const uint32_t* kmers, uint32_t n) const {  // the same test on the window's evaluated k-mers
+        bool hit = false;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t b = preHash(kmers[i]);
+            hit |= (pre[b >> 6] >> (b & 63)) & 1;
+        }
+        if (!hit) return false;
+        for (uint32_t i = 0; i < n; i++)
+            if (kmers[i] != 0xffffffffu && isSeed(kmers[i])) return true;
+        return false;
+    }
     void commitSeeds(const uint32_t* topN, int n);
     int32_t seedOfRcKmer(int32_t seed) const;                            // kmerMap[rc(seedMap[seed])]
     // seed id -> seed id of its reverse complement for the complete seed set (call once all seeds of the round are in)
@@ -263,6 +275,32 @@ struct FinalCheckStats {
     uint64_t lines = 0, hits = 0, qHits = 0;
 };
 
+// The query windows of the `overlap` command (getEdges, overlap.go:55-89: the first and last overlap_size bases of every
+// read, the whole read when it is shorter than two of them) with everything about them that does not depend on the round:
+// the selection AddSeeds makes when no evaluated k-mer is a seed yet, and the evaluated k-mers themselves
+// (dp_select_windows).  Produced on the device in read order by a thread that runs ahead of the planner; the plan chain
+// then never waits for the GPU and its "did the speculation hold" test probes resident k-mers.
+class WindowCache {
+   public:
+    struct Win {
+        uint32_t read, start, len;
+    };
+    WindowCache(dp_ctx* ctx, const ReadSet& reads, i64 overlap, int k, int numSeeds);
+    ~WindowCache();
+    std::vector<uint32_t> first;  // windows of read r: [first[r], first[r + 1])
+    std::vector<Win> wins;
+    uint32_t stride = 0;          // evaluated k-mers per window (0xffffffff = unused slot)
+    int numSeeds = 0;
+    // Blocks until window w has been produced.  The pointers stay valid until release() passes w's read.
+    bool get(uint32_t w, const uint32_t** spec, const uint32_t** kmers, std::string* err);
+    void release(size_t belowRead);  // reads below are committed: their windows will not be asked for again
+
+   private:
+    void producer();
+    struct Impl;
+    std::unique_ptr<Impl> d;
+};
+
 class Overlapper {
    public:
     Overlapper(dp_ctx* ctx, ReadSet& reads, SeedIndex& index, i64 chunkSize, int numWorkers, i64 overlap, int minSeeds,
@@ -295,11 +333,14 @@ class Overlapper {
         ignore_ = ig;
         ignoreEpoch_ = epoch;
     }
+    void setWindowCache(WindowCache* c) { cache_ = c; }
 
    private:
     void chunkAndAdd(SeedSeq* s, uint64_t segBase, Arena& ar, std::vector<SeedSeq*>& seqOut, std::vector<dp_seq_ref>& refOut);
     const uint8_t* ignore_ = nullptr;
     uint64_t ignoreEpoch_ = 0;
+    WindowCache* cache_ = nullptr;
+    int prepareFromCache(int numSeeds, i64 seedLimit, const double* values, i64 firstSequence, i64 maxSeqs);
     dp_ctx* ctx_;
     ReadSet& reads_;
     SeedIndex& index_;
@@ -350,7 +391,8 @@ struct RoundPlan {
 class Planner {
    public:
     // selCtx (may be null): device context whose resident reads + value table serve the speculative seed selection
-    Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded, dp_ctx* selCtx = nullptr);
+    Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded, dp_ctx* selCtx = nullptr,
+            WindowCache* cache = nullptr);
     ~Planner();
     std::shared_ptr<const RoundPlan> get(i64 round);
     // commit-time: set the flags; returns the first round whose cached plan was discarded (or -1)
@@ -412,6 +454,7 @@ struct OverlapRun {
         size_t size() const { return n; }
     } values;
     std::vector<std::unique_ptr<ExecSlot>> slots;  // slot 0 drives `ctx`; further slots use contexts that borrow its reads
+    std::unique_ptr<WindowCache> winCache;  // QueryEdges: the windows' round-independent part, produced ahead of the planner
     std::unique_ptr<Planner> planner;
     dp_ctx* plannerCtx = nullptr;  // borrows the reads and the value table of `ctx`
     i64 firstSequence = 0;

@@ -18,12 +18,43 @@ Overlapper::Overlapper(dp_ctx* ctx, ReadSet& reads, SeedIndex& index, i64 chunkS
 
 // PrepareQueries :157-214 with getEdges :55-89 (QueryEdges): seed selection is sequential and stays on the host.
 // Returns the number of query windows.
+// PrepareQueries for QueryEdges from the window cache: per window the evaluated k-mers are probed against the seeds
+// committed so far; untouched, the cached selection is what AddSeeds would pick and is committed as is; touched, AddSeeds
+// runs for real (the block that contains the seed is abandoned, seeds.go:94-97, and the walk goes on from there).
+int Overlapper::prepareFromCache(int numSeeds, i64 seedLimit, const double* values, i64 firstSequence, i64 maxSeqs) {
+    if (firstSequence != 0 && firstSequence >= (i64)reads_.size()) return 0;  // seqio.go:279
+    const double t0 = now();
+    std::vector<uint32_t> tmp((size_t)numSeeds);
+    i64 sent = 0;
+    for (size_t r = (size_t)firstSequence; r < reads_.size() && sent < maxSeqs; r++) {
+        if (ignore_[r]) continue;
+        sent++;
+        if (index_.size() >= seedLimit) break;  // the budget is tested once per read, before its first window (overlap.go:57-60)
+        for (uint32_t w = cache_->first[r]; w < cache_->first[r + 1]; w++) {
+            const WindowCache::Win& win = cache_->wins[w];
+            const uint32_t *spec = nullptr, *kmers = nullptr;
+            if (!cache_->get(w, &spec, &kmers, &err)) return -1;
+            if (index_.touchesSeed(kmers, cache_->stride)) {
+                index_.selectSeeds(reads_.seq(win.read) + win.start, win.len, numSeeds, values, tmp.data(), true);
+                index_.commitSeeds(tmp.data(), numSeeds);
+                g_prof.reselected++;
+            } else {
+                index_.commitSeeds(spec, numSeeds);
+            }
+            windows_.push_back({win.read, win.start, win.len});
+        }
+    }
+    g_prof.add(17, now() - t0);
+    return (int)windows_.size();
+}
+
 int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values, i64 firstSequence, i64 maxSeqs, int queryType) {
     windows_.clear();
     queries.clear();
     const bool weightSides = (queryType & 8) != 0;  // WeightEdges: seeds come from the two 200-base sides of a window
     if (weightSides) numSeeds /= 2;                  // overlap.go:161-163
     if (numSeeds < 1) return 0;
+    if (cache_ && (queryType & 1) && !weightSides && numSeeds == cache_->numSeeds) return prepareFromCache(numSeeds, seedLimit, values, firstSequence, maxSeqs);
     // Query windows in file order (getEdges :55-89 / getCentres :91-117 / getAll :119-155), each with the one or two
     // sub-windows AddSeeds actually sees (addWeighted :45-53).  The seed-budget cut-off (tested once per read) is applied
     // in the sequential commit loop below; a sub-window contributes at most 2*numSeeds seeds, so
@@ -533,15 +564,21 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
     }
     // the text: one line per part after the first (commands/overlap.go:223-228), windows in query order
     uint64_t hits = 0, qHits = 0;
-    size_t need = 0;
-    for (uint32_t g = 0; g < pb.n_groups; g++) need += (size_t)pb.groups[g].n_lines * 96;
-    paf.reserve(paf.size() + need);
+    size_t nLines = 0, hostBytes = 0;
+    for (uint32_t g = 0; g < pb.n_groups; g++) nLines += pb.groups[g].n_lines;
+    for (const std::string& hp : hostPaf) hostBytes += hp.size();
+    const size_t lineCap = 2 * reads_.maxNameLen + 7 * 21 + 24;  // two names + 7 numbers + fixed text
+    const size_t base = paf.size();
+    paf.resize(base + nLines * lineCap + hostBytes);  // one allocation, one fill; shrunk to what was written below
+    char* w = &paf[base];
     for (uint32_t g = 0; g < pb.n_groups; g++) {
         const dp_group_meta& gm = pb.groups[g];
         hits += gm.n_matches;
         if (gm.n_matches >= 2) qHits++;
         if (gm.flag) {
-            paf += hostPaf[hostOf[g]];
+            const std::string& hp = hostPaf[hostOf[g]];
+            memcpy(w, hp.data(), hp.size());
+            w += hp.size();
             for (int id : hostIgn[hostOf[g]]) {
                 if (ignoreOut) ignoreOut->push_back(id);
                 else reads_.ignore[(size_t)id] = 1;
@@ -557,11 +594,9 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
         }
         for (uint32_t j = 0; j < gm.n_lines; j++) {
             const dp_paf_rec& r = pb.paf[gm.slot + j];
+            if (j + 4 < gm.n_lines) __builtin_prefetch(&reads_.names[pb.paf[gm.slot + j + 4].t_read], 0, 1);  // names are hit at random
             const std::string& qName = reads_.names[r.q_read];
             const std::string& tName = reads_.names[r.t_read];
-            const size_t old = paf.size(), cap = qName.size() + tName.size() + 7 * 21 + 24;
-            paf.resize(old + cap);
-            char* w = &paf[old];
             memcpy(w, qName.data(), qName.size());
             w += qName.size();
             *w++ = '\t';
@@ -585,10 +620,10 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
             w = putInt(w, r.ident);
             memcpy(w, "\t0\t255\n", 7);
             w += 7;
-            paf.resize((size_t)(w - paf.data()));
             fs.lines++;
         }
     }
+    paf.resize((size_t)(w - paf.data()));
     fs.hits = hits;
     fs.qHits = qHits;
     st.n_matches = hits;

@@ -14,6 +14,144 @@
 namespace dph {
 
 // ---------------------------------------------------------------------------------------------------------------
+// WindowCache
+
+struct WindowCache::Impl {
+    dp_ctx* ctx;
+    int k;
+    static constexpr uint32_t CW = 8192;     // windows per chunk
+    static constexpr uint32_t SOFT_CAP = 8;  // chunks kept ahead of the release point unless somebody waits for more
+    struct Chunk {
+        std::vector<uint32_t> spec, kmers;
+    };
+    std::mutex mu;
+    std::condition_variable cvProduced, cvSpace;
+    std::map<uint32_t, std::unique_ptr<Chunk>> live;  // produced chunks by number
+    std::vector<std::unique_ptr<Chunk>> pool;         // recycled buffers
+    uint32_t produced = 0, released = 0, nChunks = 0, wanted = 0;
+    bool stop = false, failed = false;
+    std::string error;
+    std::thread th;
+};
+
+WindowCache::WindowCache(dp_ctx* ctx, const ReadSet& reads, i64 overlap, int k, int numSeeds_) : d(new Impl()) {
+    d->ctx = ctx;
+    d->k = k;
+    numSeeds = numSeeds_;
+    first.resize(reads.size() + 1);
+    wins.reserve(reads.size() * 2);
+    i64 maxLen = 0;
+    for (size_t r = 0; r < reads.size(); r++) {
+        first[r] = (uint32_t)wins.size();
+        const i64 L = reads.length(r);
+        if (L < overlap * 2) {
+            wins.push_back({(uint32_t)r, 0u, (uint32_t)L});
+            maxLen = std::max(maxLen, L);
+        } else {
+            wins.push_back({(uint32_t)r, 0u, (uint32_t)overlap});
+            wins.push_back({(uint32_t)r, (uint32_t)(L - overlap), (uint32_t)overlap});
+            maxLen = std::max(maxLen, overlap);
+        }
+    }
+    first[reads.size()] = (uint32_t)wins.size();
+    const i64 blocks = maxLen - 2 * k > 0 ? (maxLen - 2 * k + 3 * k - 1) / (3 * k) : 0;
+    stride = (uint32_t)std::max<i64>(1, blocks * k);
+    d->nChunks = (uint32_t)((wins.size() + Impl::CW - 1) / Impl::CW);
+    d->th = std::thread([this] { producer(); });
+}
+
+WindowCache::~WindowCache() {
+    {
+        std::lock_guard<std::mutex> lk(d->mu);
+        d->stop = true;
+    }
+    d->cvSpace.notify_all();
+    d->cvProduced.notify_all();
+    if (d->th.joinable()) d->th.join();
+}
+
+void WindowCache::producer() {
+    std::vector<dp_scan_item> items;
+    for (uint32_t c = 0; c < d->nChunks; c++) {
+        std::unique_ptr<Impl::Chunk> ch;
+        {
+            std::unique_lock<std::mutex> lk(d->mu);
+            d->cvSpace.wait(lk, [&] { return d->stop || c < d->released + Impl::SOFT_CAP || d->wanted >= c; });
+            if (d->stop) return;
+            if (c < d->released) {  // everything in it is committed already (a job restarted far ahead): nothing to produce
+                d->produced = c + 1;
+                d->cvProduced.notify_all();
+                continue;
+            }
+            if (!d->pool.empty()) {
+                ch = std::move(d->pool.back());
+                d->pool.pop_back();
+            }
+        }
+        if (!ch) ch.reset(new Impl::Chunk());
+        const size_t w0 = (size_t)c * Impl::CW, w1 = std::min(wins.size(), w0 + Impl::CW), n = w1 - w0;
+        items.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            items[i].read = wins[w0 + i].read;
+            items[i].start = wins[w0 + i].start;
+            items[i].n_kmers = wins[w0 + i].len;  // window length in bases
+            items[i].min_seeds = 0;
+        }
+        ch->spec.resize(n * (size_t)numSeeds);
+        ch->kmers.resize(n * (size_t)stride);
+        const uint32_t* ev = nullptr;
+        const int rc = dp_select_windows(d->ctx, items.data(), (uint32_t)n, d->k, numSeeds, ch->spec.data(), &ev, stride);
+        if (rc == 0) memcpy(ch->kmers.data(), ev, n * (size_t)stride * 4);
+        std::lock_guard<std::mutex> lk(d->mu);
+        if (rc != 0) {
+            d->failed = true;
+            d->error = dp_last_error(d->ctx);
+            d->cvProduced.notify_all();
+            return;
+        }
+        d->live[c] = std::move(ch);
+        d->produced = c + 1;
+        d->cvProduced.notify_all();
+    }
+}
+
+bool WindowCache::get(uint32_t w, const uint32_t** spec, const uint32_t** kmers, std::string* err) {
+    const uint32_t c = w / Impl::CW;
+    std::unique_lock<std::mutex> lk(d->mu);
+    if (c >= d->produced) {
+        if (c > d->wanted) {
+            d->wanted = c;
+            d->cvSpace.notify_all();
+        }
+        const double t0 = now();
+        d->cvProduced.wait(lk, [&] { return d->failed || d->stop || c < d->produced; });
+        g_prof.cacheWaitUs += (long long)((now() - t0) * 1e6);
+    }
+    auto it = d->live.find(c);
+    if (d->failed || it == d->live.end()) {
+        if (err) *err = d->failed ? d->error : "window cache: chunk released before use";
+        return false;
+    }
+    const size_t i = w - (size_t)c * Impl::CW;
+    *spec = it->second->spec.data() + i * (size_t)numSeeds;
+    *kmers = it->second->kmers.data() + i * (size_t)stride;
+    return true;
+}
+
+void WindowCache::release(size_t belowRead) {
+    const uint32_t w = belowRead < first.size() ? first[belowRead] : (uint32_t)wins.size();
+    const uint32_t c = w / Impl::CW;
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (c <= d->released) return;
+    d->released = c;
+    for (auto it = d->live.begin(); it != d->live.end() && it->first < c;) {
+        d->pool.push_back(std::move(it->second));
+        it = d->live.erase(it);
+    }
+    d->cvSpace.notify_all();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Planner: the PrepareQueries chain (overlap.go:157-214 seed selection + commands/overlap.go:128-143 bookkeeping)
 
 struct Planner::Impl {
@@ -22,6 +160,7 @@ struct Planner::Impl {
     const double* values;
     bool threaded;
     dp_ctx* selCtx;
+    WindowCache* winCache = nullptr;
     SeedIndex index;  // selection-side seed set of the plan being computed
     std::mutex mu;
     std::mutex computeMu;     // inline mode: one caller at a time extends the chain (the selection index is shared)
@@ -39,8 +178,9 @@ struct Planner::Impl {
         : reads(r), p(pp), values(v), threaded(t), selCtx(sc), index(pp.k) {}
 };
 
-Planner::Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded, dp_ctx* selCtx)
+Planner::Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded, dp_ctx* selCtx, WindowCache* cache)
     : d(new Impl(reads, p, values, threaded, selCtx)) {
+    d->winCache = cache;
     if (const char* e = getenv("DPH_TEST_PLAN_DELAY_US")) d->testDelayUs = atol(e);
     if (threaded) d->th = std::thread([this] { threadMain(); });
 }
@@ -71,6 +211,7 @@ std::shared_ptr<RoundPlan> Planner::compute(i64 round, i64 firstIn) {
     // the device path needs the window in the resident (cached-view) form and at most 64 list slots
     dp_ctx* sel = (d->selCtx && d->p.numSeeds <= 64) ? d->selCtx : nullptr;
     Overlapper lap(sel, d->reads, d->index, d->p.chunkSize, d->p.numWorkers, d->p.overlapSize, d->p.numSeeds, d->p.minHits);
+    lap.setWindowCache(d->winCache);
     const int nw = lap.PrepareQueries(d->p.numSeeds, d->p.seedBatchSize, d->values, firstIn, d->p.queryBatchSize, d->p.queryType);
     if (nw < 0) {
         plan->error = lap.err;
@@ -224,6 +365,7 @@ void Planner::dropBefore(i64 round, i64 firstInOfRound) {
     d->cache.erase(d->cache.begin(), d->cache.lower_bound(round));
     d->base = round;
     d->startFirstIn = firstInOfRound;
+    if (d->winCache) d->winCache->release((size_t)firstInOfRound);
     auto it = d->cache.find(round);
     if (it != d->cache.end() && it->second->firstIn != firstInOfRound) d->cache.erase(it, d->cache.end());  // stale chain
     d->cv.notify_all();
@@ -272,6 +414,7 @@ void OverlapRun::shutdown() {
     redo_.clear();
     if (planner) g_prof.print();
     planner.reset();
+    winCache.reset();
     if (plannerCtx) dp_ctx_destroy(plannerCtx);
     plannerCtx = nullptr;
     for (auto& sl : slots) {
@@ -382,7 +525,16 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         const char* np = getenv("DP_PLANNER_PRIORITY");
         if (!(np && np[0] == '0')) dp_ctx_set_priority(plannerCtx, 1);
     }
-    planner.reset(new Planner(*reads, p, values.data(), !(nothread && nothread[0] == '1'), plannerCtx));
+    winCache.reset();
+    {
+        // QueryEdges without WeightEdges (the overlap command): the windows' speculative selection and evaluated k-mers come
+        // from a producer thread that runs ahead of the plan chain on the planner's context.  DP_WINDOW_CACHE=0: per-plan
+        // dp_select_seeds calls and base-by-base speculation checks (the round-1 path).
+        const char* wc = getenv("DP_WINDOW_CACHE");
+        if (plannerCtx && p.queryType == 1 && !(wc && wc[0] == '0'))
+            winCache.reset(new WindowCache(plannerCtx, *reads, p.overlapSize, p.k, p.numSeeds));
+    }
+    planner.reset(new Planner(*reads, p, values.data(), !(nothread && nothread[0] == '1'), plannerCtx, winCache.get()));
     mark("planner");
     firstSequence = 0;
     round = 0;

@@ -32,6 +32,7 @@ void ReadSet::addLine(const std::string& lastName, const char* line, size_t len,
     if ((i64)len >= minLen) {
         if (off.empty()) off.push_back(0);
         names.push_back(trimSpace(lastName));
+        maxNameLen = std::max(maxNameLen, names.back().size());
         bases.append(line, len - 1);
         off.push_back((i64)bases.size());
         ignore.push_back(0);

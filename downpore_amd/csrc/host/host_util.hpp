@@ -62,7 +62,8 @@ struct FineScope {
 // DPH_PROFILE=1: pipeline counters printed to stderr when a run shuts down
 struct PipeProfile {
     std::atomic<long long> executed{0}, committed{0}, rejected{0}, discarded{0}, ignores{0}, planComputes{0}, planErased{0},
-        planDiscarded{0}, hostGroups{0};  // hostGroups: query windows the device consensus left to the host path
+        planDiscarded{0}, hostGroups{0}, reselected{0};  // hostGroups: query windows the device consensus left to the host path
+    std::atomic<long long> cacheWaitUs{0};  // planner waiting for the window cache's producer
     std::atomic<long long> planUs{0}, getWaitUs{0}, execUs{0}, commitUs{0}, consensusCpuUs{0}, selectCpuUs{0}, slotCpuUs{0}, plannerCpuUs{0};
     std::atomic<long long> sub[18];
     std::atomic<long long> subCpu[18];  // CPU time of the calling thread since its previous add(): the sections are consecutive
@@ -91,7 +92,9 @@ struct PipeProfile {
                 executed.load(), committed.load(), rejected.load(), discarded.load(), ignores.load(), planComputes.load(),
                 planComputes.load() ? planUs.load() / 1e3 / planComputes.load() : 0.0, planErased.load(), planDiscarded.load(),
                 getWaitUs.load() / 1e3, execUs.load() / 1e3, commitUs.load() / 1e3);
-        fprintf(stderr, "[pipe] query windows done by the host consensus path: %lld\n", hostGroups.load());
+        fprintf(stderr, "[pipe] query windows done by the host consensus path: %lld; planner waited %.1f ms for the window cache\n",
+                hostGroups.load(), cacheWaitUs.load() / 1e3);
+        fprintf(stderr, "[pipe] windows re-selected on the host (speculation did not hold): %lld\n", reselected.load());
         const double n = (double)std::max<long long>(1, executed.load());
         struct rusage ru;
         getrusage(RUSAGE_SELF, &ru);

@@ -173,6 +173,13 @@ DP_API int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epo
  * ignored.  num_seeds <= 64. */
 DP_API int dp_values_upload(dp_ctx* ctx, const double* values, uint64_t n);
 DP_API int dp_select_seeds(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out);
+/* dp_select_seeds that also hands back every k-mer the selection loop evaluated, `stride` slots per window (slot = block *
+ * k + position inside the block; unused slots are 0xffffffff): exactly the k-mers AddSeeds tests against the seed set
+ * (seeds.go:94-97), so the caller's "did the speculation hold" test is a run of probes of resident k-mers instead of a
+ * re-walk of the window's bases.  *evaluated_out points into a library-owned pinned buffer (valid until the next
+ * selection call on this context).  A window of L bases evaluates at most ceil((L - 2k) / 3k) * k k-mers. */
+DP_API int dp_select_windows(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out,
+                             const uint32_t** evaluated_out, uint32_t stride);
 
 
 /* ---- A13: seed index build ------------------------------------------------------------------------------

@@ -15,6 +15,23 @@ for r in rows:
 for n, v in sorted(tot.items(), key=lambda x: -x[1])[:24]:
     s = sorted(seq[n])
     print("  %-46s %6d calls  %9.3f ms total  %8.1f us avg  %8.1f us median  %8.1f us max" % (n, cnt[n], v/1e6, v/1e3/cnt[n], s[len(s)//2]/1e3, s[-1]/1e3))
+# GPU busy time (union of kernel intervals) over the rounds (from the first to the last chain_walk_kernel)
+ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows)
+cw = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if r["Kernel_Name"].startswith("chain_walk_kernel"))
+if cw:
+    t0, t1 = cw[0][0], cw[-1][1]
+    busy = 0; cs = ce = None; ksum = 0
+    for s_, e_ in ev:
+        if e_ < t0 or s_ > t1: continue
+        ksum += e_ - s_
+        if ce is None or s_ > ce:
+            if ce is not None: busy += ce - cs
+            cs, ce = s_, e_
+        else:
+            ce = max(ce, e_)
+    busy += ce - cs
+    nr = len(cw) // 2
+    print("  rounds window %.1f ms, %d rounds (%.3f ms/round): GPU busy (union) %.1f ms = %.0f%%, sum of kernel times %.1f ms (%.3f ms/round)" % ((t1-t0)/1e6, nr, (t1-t0)/1e6/max(1,nr), busy/1e6, 100.0*busy/(t1-t0), ksum/1e6, ksum/1e6/max(1,nr)))
 # chain_walk_kernel is launched 3x per round (modes 0,1,2): split by position
 w = seq.get("chain_walk_kernel", [])
 for m in range(3):

@@ -1,10 +1,11 @@
 #!/bin/bash
+# whole-job bench for several executor-slot counts
 mkdir -p gpurun_out
-for s in 1 2 4 8; do
-timeout 600 python bench.py --steps 32 --warmup 8 --cpu-rounds 0 --slots $s > gpurun_out/bench_s$s.json 2>/dev/null
-python - <<PY
+for s in ${SLOTS_LIST:-6 8 12 16}; do
+  timeout 600 python3 bench.py --steps 3 --warmup 1 --cpu-rounds 0 --scan-leg-rounds 0 --dense-leg-rounds 0 --slots $s > gpurun_out/slots_$s.json 2> gpurun_out/slots_$s.err
+  python3 - <<PY
 import json
-d=json.loads(open('gpurun_out/bench_s$s.json').read().strip().split('\n')[-1])
-print('slots=$s value',round(d['value']),'ms/step',round(d['ms_per_step'],2),'steps',d['steps'],'count_ms',round(d['kernel_ms_per_step']['k_count_ms'],3),'frac',round(d['roofline']['frac'],4), 'phase', {k:round(v,2) for k,v in d['phase_ms_per_step'].items()})
+d=json.load(open("gpurun_out/slots_$s.json"))
+print("slots $s: value %.2f M/s, job %.3f s, setup %.3f s, rounds %.3f s (%.3f ms/round), parity %s, cpu %.1f s/%.2f s" % (d["value"]/1e6, d["job_breakdown_s"]["whole_job"], d["job_breakdown_s"]["setup_value_table_kmer_index_slots"], d["job_breakdown_s"]["rounds"], d["rounds_only"]["ms_per_round"], d["parity"]["paf_sha256_matches_oracle_fixture"], d["host_cpu"]["cpu_s"], d["host_cpu"]["wall_s"]))
 PY
 done
