@@ -115,6 +115,7 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, const uint3
                     const uint64_t* d_segoff, int32_t* d_segs);
 
 // kernels implemented in other translation units
+int dp_match_anchors_launch(dp_ctx* ctx);  // dp_overlap.hip: GetSeedOffset / GetSeedOffsetFromEnd anchors of the last chaining stage's records
 int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs);
 int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,
                           uint32_t max_query_len, int want_candidates, dp_match_batch* out);

@@ -3,7 +3,10 @@
 // (its cursor pos/offs/gaps, its support counters and its match list), the consensus grows one seed per iteration.
 // The host keeps what surrounds it (trimming the matched targets, Reduced(), trimToBestSeed, PAF): see host_overlap.cpp.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "dp_common.h"
 
@@ -379,11 +382,13 @@ struct ConsFullArgs {
     const int32_t* segs;
     const dp_seq_meta* smeta;
     const int32_t* rc_of;
+    const int32_t* anchors;    // [2 * pairs] match_anchor_kernel
     const uint32_t* read_len;
     int k, overlap_size;
     dp_paf_rec* paf;           // [pairs]: lines of group g start at slot pbase[2g]
     uint32_t* ignore_ids;      // [pairs]: likewise
     dp_group_meta* gmeta;      // [n_groups]
+    unsigned long long* dbg;   // DP_CONS_DEBUG: per group 8 time stamps (wall_clock64, 100 MHz)
 };
 
 __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A) {
@@ -396,6 +401,8 @@ __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A
         const uint32_t qf = 2 * g, qr = 2 * g + 1;
         const uint32_t P0 = A.pbase[qf], P1 = A.pbase[qr + 1];
         dp_group_meta gm = {P0, 0, 0, 0, 0, 0, 0, 0};
+#define CF_TICK(i_) if (A.dbg && lane == 0) A.dbg[8 * (size_t)g + (i_)] = wall_clock64()
+        CF_TICK(0);
         // ---- 1. matches of the group
         int nm = 0;
         bool tooMany = false;
@@ -437,109 +444,118 @@ __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A
         }
         __builtin_amdgcn_wave_barrier();
         const int a_first = aSeg[0], a_last = aSeg[nA - 1], GA_end = L.GA[sA - 1];
-        // ---- 2. per match: filter + Trimmed()
+        CF_TICK(1);
+        // ---- 2. per match: filter + Trimmed().  One lane per match; everything a lane does is its own little loop.
         int nseq = 0, tUsed = 0;
         bool bad = false;
-        for (int mi = 0; mi < nm && !bad; mi++) {
-            const uint32_t p = L.mpair[mi];
-            const uint32_t rq = A.recs[4 * (size_t)p], t = A.recs[4 * (size_t)p + 1], off = A.recs[4 * (size_t)p + 2];
-            const int len = RFLc((int)A.recs[4 * (size_t)p + 3]);
-            const bool isRc = rq == qr;
-            const int32_t* MA = A.ma + off;
-            const int32_t* MB = A.mb + off;
-            const dp_seq_ref ref = A.refs[t];
-            const int32_t* S = A.segs + ref.seg_off;
-            const int ns = RFLc((int)ref.n_seeds), nB = 2 * ns + 1;
-            // GetBasesCovered on both sides (seeds/sequence.go:830): len*k plus the negative gaps between consecutive matched
-            // seeds; reversing both sequences (rc query) leaves the set of gaps unchanged, so the lists are used as they came
-            int ca = 0, cb = 0;
-            bool oob = false;
-            for (int base = 1; base < len; base += 64) {
-                const int i = base + lane;
-                if (i < len) {
-                    const int a1 = MA[i], a0 = MA[i - 1], b1 = MB[i], b0 = MB[i - 1];
-                    if (a1 >= sA || a0 >= sA || a1 < 0 || a0 < 0 || b1 >= ns || b0 >= ns || b0 < 0 || b1 < 0) {
-                        oob = true;
-                    } else {
-                        const int dA = isRc ? L.GA[sA - 1 - a0] - L.GA[sA - 1 - a1] - k : L.GA[a1] - L.GA[a0] - k;
-                        int dB = -k;
-                        for (int j = b0 + 1; j <= b1; j++) dB += S[2 * j] + k;
-                        if (dA < 0) ca += dA;
-                        if (dB < 0) cb += dB;
+        for (int m0 = 0; m0 < nm; m0 += 64) {
+            const int mi = m0 + lane;
+            bool keep = false, laneBad = false;
+            int nT = 0, startSeed = 0, startOffset = 0, endOffset = 0, offset = 0, inset = 0, ns = 0;
+            bool isRc = false;
+            const int32_t* S = nullptr;
+            uint32_t t = 0;
+            if (mi < nm) {
+                const uint32_t p = L.mpair[mi];
+                const uint32_t rq = A.recs[4 * (size_t)p], off = A.recs[4 * (size_t)p + 2];
+                t = A.recs[4 * (size_t)p + 1];
+                const int len = (int)A.recs[4 * (size_t)p + 3];
+                isRc = rq == qr;
+                const int32_t* MA = A.ma + off;
+                const int32_t* MB = A.mb + off;
+                const dp_seq_ref ref = A.refs[t];
+                S = A.segs + ref.seg_off;
+                ns = (int)ref.n_seeds;
+                // GetBasesCovered on both sides (seeds/sequence.go:830): len*k plus the negative gaps between consecutive
+                // matched seeds; reversing both sequences (rc query) leaves the set of gaps unchanged, so the lists are used
+                // as they came
+                int ca = len * k, cb = len * k;
+                int prevA = MA[0], prevB = MB[0];
+                if (prevA < 0 || prevA >= sA || prevB < 0 || prevB >= ns) laneBad = true;
+                for (int i = 1; i < len && !laneBad; i++) {
+                    const int a1 = MA[i], b1 = MB[i];
+                    if (a1 >= sA || a1 < 0 || b1 >= ns || b1 < 0) {
+                        laneBad = true;  // the reference would panic inside GetBasesCovered: leave the group to the host path
+                        break;
                     }
+                    const int dA = isRc ? L.GA[sA - 1 - prevA] - L.GA[sA - 1 - a1] - k : L.GA[a1] - L.GA[prevA] - k;
+                    int dB = -k;
+                    for (int j = prevB + 1; j <= b1; j++) dB += S[2 * j] + k;
+                    if (dA < 0) ca += dA;
+                    if (dB < 0) cb += dB;
+                    prevA = a1;
+                    prevB = b1;
+                }
+                if (!laneBad && ca >= 25 && cb >= 25) {
+                    // indices in the forward query / in X (X = the target, or its reverse complement for a match of the rc query)
+                    const int m_first = MA[0], m_last = MA[len - 1], t_first = MB[0], t_last = MB[len - 1];
+                    const int a0 = isRc ? sA - 1 - m_last : m_first, aL = isRc ? sA - 1 - m_first : m_last;
+                    startSeed = isRc ? ns - 1 - t_last : t_first;
+                    int endSeed = isRc ? ns - 1 - t_first : t_last;
+                    startOffset = a_first + L.GA[a0];          // forward query's GetSeedOffset(MatchA[0])
+                    endOffset = a_last + GA_end - L.GA[aL];    // ... GetSeedOffsetFromEnd(MatchA[last])
+                    // X.GetSeedOffset(startSeed) / X.GetSeedOffsetFromEnd(endSeed) from the match's anchors on the forward
+                    // target (match_anchor_kernel): R.seedOffset(i) = S.seedOffsetFromEnd(ns-1-i) and vice versa
+                    int anchorStart = A.anchors[2 * (size_t)p + (isRc ? 1 : 0)], anchorEnd = A.anchors[2 * (size_t)p + (isRc ? 0 : 1)];
+                    if (anchorStart < 0 || anchorEnd < 0) laneBad = true;
+                    // X.seg[2t] = S[2t] (forward) or S[2(ns - t)] (reverse complement)
+                    while (startSeed > 0) {
+                        const int gp = (isRc ? S[2 * (ns - startSeed)] : S[2 * startSeed]) + k;
+                        if (startOffset < gp) break;
+                        startOffset -= gp;
+                        anchorStart -= gp;
+                        startSeed--;
+                    }
+                    while (endSeed < ns - 1) {
+                        const int gp = (isRc ? S[2 * (ns - endSeed - 1)] : S[2 * endSeed + 2]) + k;
+                        if (endOffset < gp) break;
+                        endOffset -= gp;
+                        anchorEnd -= gp;
+                        endSeed++;
+                    }
+                    if (startSeed > endSeed) laneBad = true;
+                    offset = anchorStart - startOffset;
+                    inset = anchorEnd - endOffset;
+                    nT = 2 * (endSeed - startSeed) + 3;
+                    keep = !laneBad;
                 }
             }
-            if (__ballot(oob)) {  // the reference would panic inside GetBasesCovered: leave the group to the host path
+            if (__ballot(laneBad)) {
                 bad = true;
                 break;
             }
-            ca = RFLc(wave_sum(ca)) + len * k;
-            cb = RFLc(wave_sum(cb)) + len * k;
-            if (ca < 25 || cb < 25) continue;
-            // indices in the forward query / in X (X = the target, or its reverse complement for a match of the rc query)
-            const int m_first = MA[0], m_last = MA[len - 1], t_first = MB[0], t_last = MB[len - 1];
-            const int a0 = isRc ? sA - 1 - m_last : m_first, aL = isRc ? sA - 1 - m_first : m_last;
-            int startSeed = isRc ? ns - 1 - t_last : t_first, endSeed = isRc ? ns - 1 - t_first : t_last;
-            int startOffset = a_first + L.GA[a0];                  // forward query's GetSeedOffset(MatchA[0])
-            int endOffset = a_last + GA_end - L.GA[aL];            // ... GetSeedOffsetFromEnd(MatchA[last])
-            // X.seg[2t] = S[2t] (forward) or S[2(ns - t)] (reverse complement)
-            while (startSeed > 0) {
-                const int gp = (isRc ? S[2 * (ns - startSeed)] : S[2 * startSeed]) + k;
-                if (startOffset < gp) break;
-                startOffset -= gp;
-                startSeed--;
-            }
-            while (endSeed < ns - 1) {
-                const int gp = (isRc ? S[2 * (ns - endSeed - 1)] : S[2 * endSeed + 2]) + k;
-                if (endOffset < gp) break;
-                endOffset -= gp;
-                endSeed++;
-            }
-            if (startSeed > endSeed) {
+            const u64 keepMask = __ballot(keep);
+            const int incl = wave_incl_sum(keep ? nT : 0);
+            const int total = __shfl(incl, 63, 64);
+            const int nKeep = __popcll(keepMask);
+            if (nseq + nKeep > 64 || tUsed + total > CF_T) {
                 bad = true;
                 break;
             }
-            // X.GetSeedOffset(startSeed), X.GetSeedOffsetFromEnd(endSeed): sums over the forward target
-            int so = 0, se = 0;
-            if (!isRc) {
-                for (int j = 1 + lane; j <= startSeed; j += 64) so += S[2 * j] + k;
-                for (int j = endSeed + 1 + lane; j <= ns - 1; j += 64) se += S[2 * j] + k;
-                so = RFLc(wave_sum(so)) + S[0];
-                se = RFLc(wave_sum(se)) + S[nB - 1];
-            } else {  // R.seedOffset(i) = S.seedOffsetFromEnd(ns-1-i), R.seedOffsetFromEnd(i) = S.seedOffset(ns-1-i)
-                const int fs = ns - 1 - startSeed, fe = ns - 1 - endSeed;
-                for (int j = fs + 1 + lane; j <= ns - 1; j += 64) so += S[2 * j] + k;
-                for (int j = 1 + lane; j <= fe; j += 64) se += S[2 * j] + k;
-                so = RFLc(wave_sum(so)) + S[nB - 1];
-                se = RFLc(wave_sum(se)) + S[0];
+            if (keep) {
+                const int sq = nseq + __popcll(keepMask & lanesBelow);
+                const int tb = tUsed + incl - nT;
+                const dp_seq_meta sm = A.smeta[t];
+                const int nB = 2 * ns + 1;
+                for (int j = 0; j < nT; j++) {
+                    const int x = 2 * startSeed + j;  // index in X
+                    int v;
+                    if (!isRc) v = S[x];
+                    else v = (x & 1) ? A.rc_of[S[nB - 1 - x]] : S[nB - 1 - x];
+                    L.T[tb + j] = v;
+                }
+                L.T[tb] = startOffset;
+                L.T[tb + nT - 1] = endOffset;
+                L.tb[sq] = tb;
+                L.tN[sq] = nT;
+                L.tLen[sq] = sm.length - offset - inset;
+                L.tOff[sq] = isRc ? sm.offset + inset : sm.offset + offset;
+                L.tIns[sq] = isRc ? sm.inset + offset : sm.inset + inset;
+                L.tId[sq] = (int32_t)sm.read;
+                L.tRc[sq] = isRc ? 1 : 0;
             }
-            const int offset = so - startOffset, inset = se - endOffset;
-            const dp_seq_meta sm = A.smeta[t];
-            const int nT = 2 * (endSeed - startSeed) + 3;
-            if (nseq >= 64 || tUsed + nT > CF_T) {
-                bad = true;
-                break;
-            }
-            for (int j = lane; j < nT; j += 64) {
-                const int x = 2 * startSeed + j;  // index in X
-                int v;
-                if (!isRc) v = S[x];
-                else v = (x & 1) ? A.rc_of[S[nB - 1 - x]] : S[nB - 1 - x];
-                if (j == 0) v = startOffset;
-                if (j == nT - 1) v = endOffset;
-                L.T[tUsed + j] = v;
-            }
-            if (lane == 0) {
-                L.tb[nseq] = tUsed;
-                L.tN[nseq] = nT;
-                L.tLen[nseq] = sm.length - offset - inset;
-                L.tOff[nseq] = isRc ? sm.offset + inset : sm.offset + offset;
-                L.tIns[nseq] = isRc ? sm.inset + offset : sm.inset + inset;
-                L.tId[nseq] = (int32_t)sm.read;
-                L.tRc[nseq] = isRc ? 1 : 0;
-            }
-            tUsed += nT;
-            nseq++;
+            nseq += nKeep;
+            tUsed += total;
         }
         if (bad) {
             gm.flag = 1;
@@ -551,105 +567,87 @@ __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A
             continue;
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- 3. seeds shared by >= 2 sequences, Reduced()
+        CF_TICK(2);
+        // ---- 3. seeds shared by >= 2 sequences (GetSharedIDs(.., 2, true)), Reduced() of every sequence (seeds/sequence.go:85):
+        //         one lane per sequence
         for (int i = lane; i < CF_HASH; i += 64) L.hash[i] = 0;
         __builtin_amdgcn_wave_barrier();
-        for (int s = 0; s < nseq; s++) {
-            const int b = L.tb[s], nsT = L.tN[s] >> 1;
-            for (int i = lane; i < nsT; i += 64) {
-                const uint32_t seed = (uint32_t)L.T[b + 2 * i + 1];
-                uint32_t h = (seed * 2654435761u) >> 20;  // 12 bits
-                for (;;) {
-                    const uint32_t e = L.hash[h];
-                    if (e == 0) {
-                        const uint32_t old = atomicCAS(&L.hash[h], 0u, ((seed + 1) << 8) | (uint32_t)s);
-                        if (old == 0) break;
-                        continue;  // somebody else took the slot: look at it again
-                    }
-                    if ((e >> 8) == seed + 1) {
-                        if ((e & 63u) != (uint32_t)s && !(e & 128u)) atomicOr(&L.hash[h], 128u);
-                        break;
-                    }
-                    h = (h + 1) & (CF_HASH - 1);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        int rUsed = 0;
-        for (int s = 0; s < nseq; s++) {
-            const int b = L.tb[s], nT = L.tN[s], nsT = nT >> 1;
-            int kept = 0, prevWl = -1, H = 0, Hkept = 0;  // H = sum_{j=1..i}(T[2j]+k) up to the block start; Hkept = H at the last kept seed
-            bool any = false;
-            for (int base = 0; base < nsT; base += 64) {
-                const int i = base + lane;
-                const bool valid = i < nsT;
-                const int seed = valid ? L.T[b + 2 * i + 1] : -2;
-                bool wl = false;
-                if (valid) {
-                    uint32_t h = ((uint32_t)seed * 2654435761u) >> 20;
-                    for (;;) {
-                        const uint32_t e = L.hash[h];
-                        if (e == 0) break;
-                        if ((e >> 8) == (uint32_t)seed + 1) {
-                            wl = (e & 128u) != 0;
-                            break;
-                        }
-                        h = (h + 1) & (CF_HASH - 1);
-                    }
-                }
-                const u64 wlMask = __ballot(wl);
-                const u64 below = wlMask & lanesBelow;
-                int pseed = __shfl(seed, below ? 63 - __builtin_clzll(below) : 0, 64);
-                if (!below) pseed = prevWl;
-                const bool keep = wl && seed != pseed;  // Reduced(): a whitelisted seed equal to the previous whitelisted one is dropped
-                const u64 keepMask = __ballot(keep);
-                const int Hin = H + wave_incl_sum((valid && i >= 1) ? L.T[b + 2 * i] + k : 0);  // H(i)
-                const u64 kb = keepMask & lanesBelow;
-                int Hq = __shfl(Hin, kb ? 63 - __builtin_clzll(kb) : 0, 64);
-                const bool firstKept = !kb && !any;
-                if (!kb) Hq = Hkept;
-                if (keep) {
-                    const int r = kept + __popcll(kb);
-                    if (rUsed + 2 * r + 2 < CF_R) {
-                        L.R[rUsed + 2 * r] = firstKept ? L.T[b] + Hin : Hin - Hq - k;
-                        L.R[rUsed + 2 * r + 1] = seed;
-                        L.Rmap[(rUsed >> 1) + r] = (uint16_t)i;
-                    }
-                }
-                if (wlMask) prevWl = __shfl(seed, 63 - __builtin_clzll(wlMask), 64);
-                if (keepMask) {
-                    Hkept = __shfl(Hin, 63 - __builtin_clzll(keepMask), 64);
-                    any = true;
-                }
-                H = __shfl(Hin, 63, 64);
-                kept += __popcll(keepMask);
-            }
-            if (rUsed + 2 * kept + 2 >= CF_R) {
-                bad = true;
-                break;
-            }
-            if (kept >= 1) {
-                // final offset: gap after the last kept seed q up to the end = H(nsT) - H(q) - k, H(nsT) includes the final gap
-                const int Hend = H + L.T[b + nT - 1] + k;
-                if (lane == 0) {
-                    L.R[rUsed + 2 * kept] = Hend - Hkept - k;
-                    L.rb[s] = rUsed;
-                    L.rN[s] = 2 * kept + 1;
-                }
-                rUsed += 2 * kept + 2;  // (even: Rmap / cm arrays are indexed by rUsed >> 1)
-            } else if (lane == 0) {
-                L.rb[s] = rUsed;
-                L.rN[s] = 0;
-            }
-        }
-        if (bad) {
-            gm.flag = 1;
-            if (lane == 0) A.gmeta[g] = gm;
-            continue;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- 4. the alignment (multiAligner.Consensus :52-247); lane i owns sequence i.  hash[] is dead from here on.
         const bool mine = lane < nseq;
+        const int tb_ = mine ? L.tb[lane] : 0;
+        const int nsT_ = mine ? (L.tN[lane] >> 1) : 0;
+        for (int i = 0; i < nsT_; i++) {
+            const uint32_t seed = (uint32_t)L.T[tb_ + 2 * i + 1];
+            uint32_t h = (seed * 2654435761u) >> 20;  // 12 bits
+            for (;;) {
+                const uint32_t e = L.hash[h];
+                if (e == 0) {
+                    const uint32_t old = atomicCAS(&L.hash[h], 0u, ((seed + 1) << 8) | (uint32_t)lane);
+                    if (old == 0) break;
+                    continue;  // somebody else took the slot: look at it again
+                }
+                if ((e >> 8) == seed + 1) {
+                    if ((e & 63u) != (uint32_t)lane && !(e & 128u)) atomicOr(&L.hash[h], 128u);
+                    break;
+                }
+                h = (h + 1) & (CF_HASH - 1);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        auto cf_shared = [&](int seed) -> bool {
+            uint32_t h = ((uint32_t)seed * 2654435761u) >> 20;
+            for (;;) {
+                const uint32_t e = L.hash[h];
+                if (e == 0) return false;
+                if ((e >> 8) == (uint32_t)seed + 1) return (e & 128u) != 0;
+                h = (h + 1) & (CF_HASH - 1);
+            }
+        };
+        int kept = 0;
+        {
+            int prev = -1;
+            for (int i = 0; i < nsT_; i++) {
+                const int seed = L.T[tb_ + 2 * i + 1];
+                if (seed != prev && cf_shared(seed)) {
+                    kept++;
+                    prev = seed;
+                }
+            }
+        }
+        {
+            const int slot = kept >= 1 ? 2 * kept + 2 : 0;  // (even: Rmap / cm arrays are indexed by rb >> 1)
+            const int incl = wave_incl_sum(slot);
+            const int totalR = __shfl(incl, 63, 64);
+            if (totalR + 2 >= CF_R) {
+                gm.flag = 1;
+                if (lane == 0) A.gmeta[g] = gm;
+                continue;
+            }
+            if (mine) {
+                const int rb = incl - slot;
+                L.rb[lane] = rb;
+                L.rN[lane] = kept >= 1 ? 2 * kept + 1 : 0;
+                if (kept >= 1) {
+                    int prev = -1, r = 0, offset = L.T[tb_];
+                    for (int i = 0; i < nsT_; i++) {
+                        const int seed = L.T[tb_ + 2 * i + 1];
+                        if (seed != prev && cf_shared(seed)) {
+                            L.R[rb + 2 * r] = offset;
+                            L.R[rb + 2 * r + 1] = seed;
+                            L.Rmap[(rb >> 1) + r] = (uint16_t)i;
+                            r++;
+                            offset = L.T[tb_ + 2 * i + 2];
+                            prev = seed;
+                        } else {
+                            offset += L.T[tb_ + 2 * i + 2] + k;
+                        }
+                    }
+                    L.R[rb + 2 * r] = offset;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        CF_TICK(3);
+        // ---- 4. the alignment (multiAligner.Consensus :52-247); lane i owns sequence i.  hash[] is dead from here on.
         const int b = mine ? L.rb[lane] : 0;
         const int sl = mine ? L.rN[lane] : 0;
         const int mbase = b >> 1;
@@ -662,6 +660,42 @@ __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A
             const int p2s = pos + 1;
             const bool okS = sl > 0 && p2s < sl / 2;
             const int od = okS ? S[b + p2s * 2] - offs : 0;
+            {
+                // Uniform step: every sequence that still has a seed is in step (gap 0) and shows the same seed at the same
+                // distance.  The general code below then does nothing but agree: each of them proposes (d = o0 < near, which
+                // only drops to maxD(o0) > o0), finds the seed in every other one at once (o0 lies inside gapRange(o0) for
+                // every -k < o0), so supported = nValid >= 2 and dist / supported = o0 exactly; the first proposer wins the
+                // selection and the update finds the seed at pos + 1 of every sequence.  Same state, consensus and matches
+                // (the host mirror takes the same short cut, host_seq.cpp; 80 % of the steps at e = 0).
+                const u64 okMask = __ballot(okS);
+                const int nValid = __popcll(okMask);
+                if (nValid >= 2) {
+                    const int f = __builtin_ctzll(okMask);
+                    const int sdNext = okS ? S[b + p2s * 2 + 1] : -1;
+                    const int o0 = CA_RL(od, f), sd0 = CA_RL(sdNext, f);
+                    const bool same = !okS || (od == o0 && sdNext == sd0 && gaps == 0);
+                    if (__ballot(same) == ~0ull && o0 > -k && o0 < 100000) {
+                        if (clen + 2 >= CF_CONS) {
+                            bad = true;
+                            break;
+                        }
+                        if (lane == 0) {
+                            L.cons[clen] = o0;
+                            L.cons[clen + 1] = sd0;
+                        }
+                        clen += 2;
+                        if (okS) {
+                            pos = p2s;
+                            offs = 0;
+                            dist = nValid * o0;  // what the support scan leaves behind (a later step may read it, :170-176)
+                            L.cmA[mbase + mlen] = (uint16_t)(clen / 2 - 1);
+                            L.cmB[mbase + mlen] = L.Rmap[mbase + p2s];
+                            mlen++;
+                        }
+                        continue;
+                    }
+                }
+            }
             supported = 0;
             const bool fin = !mine || sl == 0 || pos >= (sl - 1) / 2 - 1;
             int fCount = __popcll(__ballot(fin && mine));
@@ -825,6 +859,7 @@ __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A
         if (lane == 0) L.cons[clen] = 0;
         if (mine) L.mLen[lane] = mlen;
         __builtin_amdgcn_wave_barrier();
+        CF_TICK(4);
         // ---- 5. parts with fewer than 3 matched seeds leave by swap-with-last, from the back (:258-266)
         int np = nseq;
         if (lane == 0) {
@@ -1003,6 +1038,7 @@ __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A
         gm.bad_back = (uint32_t)__popcll(__ballot(badBack != 0));
         gm.empty_match = (uint32_t)__popcll(__ballot(line && panicPrev));
         if (lane == 0) A.gmeta[g] = gm;
+        CF_TICK(5);
     }
 }
 
@@ -1041,12 +1077,23 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     A.segs = (const int32_t*)ctx->d_segs.p;
     A.smeta = (const dp_seq_meta*)ctx->d_cin.p;
     A.rc_of = (const int32_t*)((const uint8_t*)ctx->d_cin.p + b_meta);
+    {
+        int rc = dp_match_anchors_launch(ctx);
+        if (rc != 0) return rc;
+    }
+    A.anchors = (const int32_t*)ctx->d_manchor.p;
     A.read_len = (const uint32_t*)ctx->d_len.p;
     A.k = k;
     A.overlap_size = overlap_size;
     A.gmeta = (dp_group_meta*)dout;
     A.paf = (dp_paf_rec*)(dout + b_gm);
     A.ignore_ids = (uint32_t*)(dout + b_gm + b_paf);
+    static const bool cons_debug = getenv("DP_CONS_DEBUG") != nullptr;
+    A.dbg = nullptr;
+    if (cons_debug) {
+        DP_HIP(hipMalloc((void**)&A.dbg, (size_t)ng * 64));
+        DP_HIP(hipMemsetAsync(A.dbg, 0, (size_t)ng * 64, ctx->stream));
+    }
     DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(consensus_full_kernel, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), 0, ctx->stream, A);
     DP_HIP(hipGetLastError());
@@ -1056,6 +1103,29 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     float ms = 0;
     hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
     out->kernel_ms = ms;
+    if (cons_debug) {  // per-phase time of the groups that ran to the end: mean and maximum, in microseconds
+        std::vector<unsigned long long> h((size_t)ng * 8);
+        hipMemcpy(h.data(), A.dbg, (size_t)ng * 64, hipMemcpyDeviceToHost);
+        hipFree(A.dbg);
+        double sum[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0}, tot = 0, totmx = 0;
+        uint32_t cnt = 0;
+        for (uint32_t g = 0; g < ng; g++) {
+            if (!h[8 * (size_t)g + 5]) continue;
+            cnt++;
+            for (int i = 0; i < 5; i++) {
+                const double d = (double)(h[8 * (size_t)g + i + 1] - h[8 * (size_t)g + i]) / 100.0;
+                sum[i] += d;
+                mx[i] = std::max(mx[i], d);
+            }
+            const double t = (double)(h[8 * (size_t)g + 5] - h[8 * (size_t)g]) / 100.0;
+            tot += t;
+            totmx = std::max(totmx, t);
+        }
+        if (cnt)
+            fprintf(stderr, "[cons] kernel %.3f ms, %u of %u groups complete | us mean/max: gather+query %.1f/%.1f trim %.1f/%.1f shared+reduce %.1f/%.1f "
+                            "align %.1f/%.1f contig+paf %.1f/%.1f | group total %.1f/%.1f\n",
+                    ms, cnt, ng, sum[0] / cnt, mx[0], sum[1] / cnt, mx[1], sum[2] / cnt, mx[2], sum[3] / cnt, mx[3], sum[4] / cnt, mx[4], tot / cnt, totmx);
+    }
     const uint8_t* h = (const uint8_t*)ctx->h_cout.p;
     out->groups = (const dp_group_meta*)h;
     out->paf = (const dp_paf_rec*)(h + b_gm);

@@ -2019,6 +2019,19 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     return rc;
 }
 
+// Anchors of every final record of the chaining stage (device resident): d_manchor[2 * pair]
+int dp_match_anchors_launch(dp_ctx* ctx) {
+    const uint32_t nslots = ctx->n_pairs;
+    if (dev_reserve(ctx, ctx->d_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
+    if (!nslots) return DP_OK;
+    const u64* d_totals = (const u64*)((const uint8_t*)ctx->d_cursor.p + 64);
+    hipLaunchKernelGGL(match_anchor_kernel, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256), 0, ctx->stream,
+                       (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
+                       (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, ctx->last_k, (int32_t*)ctx->d_manchor.p);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
+}
+
 // Download of the chaining stage's records.  Pair slots are in canonical order already: queries ascending, candidates
 // ascending within a query.
 int dp_fetch_overlaps_impl(dp_ctx* ctx, int want_candidates, dp_match_batch* out) {
