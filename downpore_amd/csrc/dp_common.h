@@ -29,7 +29,8 @@ struct dp_ctx {
     std::atomic<int> n_borrowers{0};  // live contexts created from this one with dp_ctx_create_shared
     dp_kindex* kidx = nullptr;   // resident k-mer position index (dp_kindex.hip), owned by the reads' owner
     DevBuf d_kx_sz, d_kx_lo, d_kx_tmp, d_kx_keys, d_kx_vals;  // per-round scratch of the index path
-    uint32_t kx_hits = 0;
+    uint64_t kx_hits = 0;
+    uint32_t kx_head_reads = 0;  // reads the zeroed extra-item list heads (d_kx_lo) are sized for
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_sync = nullptr;  // blocking-sync event: waiting host threads sleep instead of polling
@@ -110,9 +111,11 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
 int dp_histogram_device(dp_ctx* ctx, int k, uint32_t* d_counts);  // dp_scan.hip
 int dp_kindex_ensure(dp_ctx* ctx, int k);
 void dp_kindex_free(dp_ctx* ctx);
-int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t n_items, uint32_t* d_counts, float* ms);
-int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, const uint32_t* d_sel, uint32_t n_sel, const uint32_t* d_counts,
-                    const uint64_t* d_segoff, int32_t* d_segs);
+int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
+                    uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint64_t* d_totals);
+int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
+                    const uint32_t* d_sel, uint32_t n_sel, uint32_t max_count, const uint32_t* d_counts, const uint64_t* d_segoff,
+                    const uint64_t* d_totals, int32_t* d_segs);
 
 // kernels implemented in other translation units
 int dp_match_anchors_launch(dp_ctx* ctx);  // dp_overlap.hip: GetSeedOffset / GetSeedOffsetFromEnd anchors of the last chaining stage's records

@@ -21,7 +21,7 @@ struct dp_kindex {
     bool unavailable = false;  // k too large for a direct-addressed table, or not enough free HBM: callers scan instead
     uint64_t n_pos = 0;
     DevBuf off;  // uint64 [4^k + 1]
-    DevBuf pos;  // uint64 [n_pos]: absolute k-mer start (boff[read]*4 + position), grouped by k-mer value
+    DevBuf pos;  // uint64 [n_pos]: k-mer start as (read << 32 | position in the read), grouped by k-mer value
 };
 
 // every k-mer start of every read: slot = off[kmer] + (arrival rank inside its bucket); order inside a bucket is arbitrary
@@ -50,7 +50,7 @@ __global__ void kidx_scatter_kernel(const uint8_t* __restrict__ packed, const ui
                 const uint32_t win = rr ? __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * rr) : hi;
                 const uint32_t kmer = win >> sh;
                 const uint32_t slot = atomicAdd(&cursor[kmer], 1u);
-                pos[off[kmer] + slot] = a;
+                pos[off[kmer] + slot] = ((uint64_t)r << 32) | (uint64_t)(a - a0);
             }
         }
     }
@@ -173,143 +173,326 @@ void dp_kindex_free(dp_ctx* ctx) {
 }
 
 // ---- per round -------------------------------------------------------------------------------------------------------
+// The counting step of a round, straight from the index (no sort, no host round trip before the survivors are known):
+//   kidx_count   every occurrence of every seed k-mer bumps the counter of the read item it falls into and of the extra
+//                items (query windows) of its read;
+//   kidx_offsets one single-pass scan (decoupled look-back) over the items: segment offsets of the survivors, their
+//                compacted list, the totals;
+//   kidx_fill    the occurrences of surviving items go, unordered, into the item's own segment slice as (position, seed);
+//   kidx_sortwrite  one wave per survivor sorts its slice by position and turns it into [gap, seed, ..., gap] in place.
 
-__global__ void kidx_seed_sizes(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
-                                uint32_t* __restrict__ sz) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > n_seeds) return;
-    sz[s] = s < n_seeds ? (uint32_t)(off[(uint64_t)seeds[s] + 1] - off[seeds[s]]) : 0u;
+#define KX_PARTS 4  // waves that share one seed's bucket
+
+// extra items (query windows) of a read form a linked list: head[read] = item + 1, next[item] = previous head
+__global__ void kidx_link_extra(const dp_scan_item* __restrict__ items, uint32_t n_read_items, uint32_t n_extra,
+                                uint32_t* __restrict__ head, uint32_t* __restrict__ next) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_extra) return;
+    next[e] = atomicExch(&head[items[n_read_items + e].read], e + 1);
+}
+__global__ void kidx_unlink_extra(const dp_scan_item* __restrict__ items, uint32_t n_read_items, uint32_t n_extra,
+                                  uint32_t* __restrict__ head) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_extra) return;
+    head[items[n_read_items + e].read] = 0;
 }
 
-__global__ void kidx_emit(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
-                          const uint64_t* __restrict__ pos, const uint64_t* __restrict__ base, uint64_t* __restrict__ keys,
-                          uint32_t* __restrict__ vals) {
+template <bool FILL>
+__global__ __launch_bounds__(256) void kidx_walk(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
+                                                 const uint64_t* __restrict__ pos, const dp_scan_item* __restrict__ items,
+                                                 uint32_t lo, uint32_t hi, uint32_t n_read_items, const uint32_t* __restrict__ head,
+                                                 const uint32_t* __restrict__ next, uint32_t* __restrict__ counts,
+                                                 uint32_t* __restrict__ fillc, const uint64_t* __restrict__ segoff,
+                                                 int32_t* __restrict__ segs, unsigned long long* __restrict__ n_hits) {
     const int lane = dp_lane();
-    const uint32_t s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t s = w / KX_PARTS, part = w % KX_PARTS;
     if (s >= n_seeds) return;
     const uint64_t o = off[seeds[s]];
     const uint32_t n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
-    const uint64_t b = base[s];
-    for (uint32_t i = lane; i < n; i += 64) {
-        keys[b + i] = pos[o + i];
-        vals[b + i] = s;
+    const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
+    const uint32_t i0 = part * per, i1 = min(n, i0 + per);
+    if (!FILL && lane == 0 && part == 0 && n) atomicAdd(&n_hits[s & 63u], (unsigned long long)n);  // (64 slots: 10 k same-address atomics serialise)
+    for (uint32_t i = i0 + lane; i < i1; i += 64) {
+        const uint64_t e = pos[o + i];
+        const uint32_t r = (uint32_t)(e >> 32), p = (uint32_t)e;
+        if (r >= lo && r < hi) {
+            const uint32_t it = r - lo;
+            const dp_scan_item item = items[it];
+            if (p < item.n_kmers) {  // (ignored reads carry n_kmers == 0; a top-level read with len % 4 == 0 four k-mers less)
+                if (!FILL) {
+                    atomicAdd(&counts[it], 1u);
+                } else if (counts[it] >= item.min_seeds) {
+                    const uint32_t slot = atomicAdd(&fillc[it], 1u);
+                    const uint64_t at = segoff[it] + 2ull * slot;
+                    segs[at] = (int32_t)p;
+                    segs[at + 1] = (int32_t)s;
+                }
+            }
+        }
+        for (uint32_t x = head[r]; x; x = next[x - 1]) {
+            const uint32_t it = n_read_items + x - 1;
+            const dp_scan_item item = items[it];
+            if (p - item.start < item.n_kmers && p >= item.start) {
+                if (!FILL) {
+                    atomicAdd(&counts[it], 1u);
+                } else if (counts[it] >= item.min_seeds) {
+                    const uint32_t slot = atomicAdd(&fillc[it], 1u);
+                    const uint64_t at = segoff[it] + 2ull * slot;
+                    segs[at] = (int32_t)(p - item.start);
+                    segs[at + 1] = (int32_t)s;
+                }
+            }
+        }
     }
 }
 
-__device__ __forceinline__ uint32_t kidx_lower_bound(const uint64_t* __restrict__ keys, uint32_t n, uint64_t x) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (keys[mid] < x) lo = mid + 1;
-        else hi = mid;
+// status word of a tile: flag << 62 | survivors << 38 | segment ints (flag 1 = the tile's own sums, 2 = inclusive prefix)
+#define KX_TILE 1024
+#define KX_IPT 4
+__global__ __launch_bounds__(KX_TILE) void kidx_offsets(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ counts,
+                                                       uint32_t n, unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket,
+                                                       uint64_t* __restrict__ segoff, uint32_t* __restrict__ s_item,
+                                                       uint32_t* __restrict__ s_count, uint64_t* __restrict__ s_off,
+                                                       uint64_t* __restrict__ totals, uint32_t* __restrict__ max_count,
+                                                       const unsigned long long* __restrict__ n_hits) {
+    __shared__ uint32_t shA[16], shB[16];
+    __shared__ uint32_t tile_s;
+    __shared__ unsigned long long excl_s;
+    if (threadIdx.x == 0) tile_s = atomicAdd(ticket, 1u);  // tiles start in ticket order: a predecessor is always running or done
+    __syncthreads();
+    const uint32_t tile = tile_s;
+    if (tile == 0 && threadIdx.x < 64) {  // seed occurrences of the round (kidx_walk<false> has finished: stream order)
+        unsigned long long h = n_hits[threadIdx.x];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d, 64);
+        if (threadIdx.x == 0) totals[2] = h;
     }
-    return lo;
+    // KX_IPT consecutive items per thread: a quarter of the tiles, a quarter of the look-back chain
+    const uint32_t i0 = (tile * KX_TILE + threadIdx.x) * KX_IPT;
+    uint32_t cc[KX_IPT], seg = 0, fl = 0, segv[KX_IPT], flv[KX_IPT], cmax = 0;
+#pragma unroll
+    for (int u = 0; u < KX_IPT; u++) {
+        const uint32_t i = i0 + u;
+        cc[u] = 0;
+        flv[u] = 0;
+        segv[u] = 0;
+        if (i < n) {
+            cc[u] = counts[i];
+            flv[u] = cc[u] >= items[i].min_seeds ? 1u : 0u;
+            segv[u] = flv[u] ? 2u * cc[u] + 1u : 0u;
+            if (flv[u]) cmax = max(cmax, cc[u]);
+        }
+        seg += segv[u];
+        fl += flv[u];
+    }
+    // block scans of both quantities (segment lengths of a tile stay far below 2^32: checked by the caller's caps)
+    const int lane = dp_lane(), wave = threadIdx.x >> 6;
+    uint32_t xs = (uint32_t)wave_incl_sum((int)seg), xf = (uint32_t)wave_incl_sum((int)fl);
+    if (lane == 63) {
+        shA[wave] = xs;
+        shB[wave] = xf;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t a = lane < 16 ? shA[lane] : 0u, b = lane < 16 ? shB[lane] : 0u;
+        a = (uint32_t)wave_incl_sum((int)a);
+        b = (uint32_t)wave_incl_sum((int)b);
+        if (lane < 16) {
+            shA[lane] = a;
+            shB[lane] = b;
+        }
+    }
+    __syncthreads();
+    if (wave > 0) {
+        xs += shA[wave - 1];
+        xf += shB[wave - 1];
+    }
+    const uint32_t tot_s = shA[15], tot_f = shB[15];
+    if (cmax > 0) atomicMax(max_count, cmax);
+    if (threadIdx.x == 0) {
+        const unsigned long long own = ((unsigned long long)tot_f << 38) | (unsigned long long)tot_s;
+        unsigned long long excl = 0;
+        if (tile == 0) {
+            __hip_atomic_store(&status[0], (2ull << 62) | own, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(&status[tile], (1ull << 62) | own, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t t = (int64_t)tile - 1; t >= 0; t--) {
+                unsigned long long v;
+                do {
+                    v = __hip_atomic_load(&status[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((v >> 62) == 0);
+                excl += v & ((1ull << 62) - 1);
+                if ((v >> 62) == 2) break;
+            }
+            __hip_atomic_store(&status[tile], (2ull << 62) | (excl + own), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        excl_s = excl;
+        if (((uint64_t)tile + 1) * KX_TILE * KX_IPT >= n) {  // last tile: totals
+            const unsigned long long all = excl + own;
+            totals[0] = all & ((1ull << 38) - 1);
+            totals[1] = all >> 38;
+        }
+    }
+    __syncthreads();
+    const unsigned long long excl = excl_s;
+    const uint64_t seg_base = excl & ((1ull << 38) - 1), surv_base = excl >> 38;
+    uint64_t so = seg_base + (uint64_t)(xs - seg), slot = surv_base + (uint64_t)(xf - fl);
+#pragma unroll
+    for (int u = 0; u < KX_IPT; u++) {
+        const uint32_t i = i0 + u;
+        if (i < n) {
+            segoff[i] = so;
+            if (flv[u]) {
+                s_item[slot] = i;
+                s_count[slot] = cc[u];
+                s_off[slot] = so;
+                slot++;
+            }
+            so += segv[u];
+            if (i == n - 1) segoff[n] = so;
+        }
+    }
 }
 
-// counts[it] = seed occurrences whose start lies in the item's k-mer range; hit_lo[it] = index of the first one
-__global__ void kidx_count_items(const dp_scan_item* __restrict__ items, uint32_t n_items, const uint64_t* __restrict__ boff,
-                                 const uint64_t* __restrict__ keys, uint32_t n_hits, uint32_t* __restrict__ counts,
-                                 uint32_t* __restrict__ hit_lo) {
-    const uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
-    if (it >= n_items) return;
-    const dp_scan_item item = items[it];
-    if (item.n_kmers == 0) {
-        counts[it] = 0;
-        hit_lo[it] = 0;
-        return;
-    }
-    const uint64_t a0 = boff[item.read] * 4 + item.start;
-    const uint32_t lo = kidx_lower_bound(keys, n_hits, a0);
-    const uint32_t hi = kidx_lower_bound(keys, n_hits, a0 + item.n_kmers);
-    counts[it] = hi - lo;
-    hit_lo[it] = lo;
-}
-
-// [gap, seed, ..., gap] of every surviving item straight from its slice of the sorted occurrence list
-__global__ void kidx_write(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ sel, uint32_t n_sel,
-                           const uint64_t* __restrict__ boff, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                           const uint32_t* __restrict__ counts, const uint32_t* __restrict__ hit_lo, const uint64_t* __restrict__ segoff,
-                           int32_t* __restrict__ segs, int k) {
+// one wave per survivor: its slice holds c unordered (position, seed) pairs -> sorted by position -> [gap, seed, ..., gap]
+#define KX_SORT_LDS 4096
+__global__ __launch_bounds__(64) void kidx_sortwrite(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ sel,
+                                                     const uint32_t* __restrict__ n_sel_p, const uint32_t* __restrict__ counts,
+                                                     const uint64_t* __restrict__ segoff, int32_t* __restrict__ segs, int k,
+                                                     uint32_t* __restrict__ overflow) {
+    __shared__ unsigned long long keys[KX_SORT_LDS];
     const int lane = dp_lane();
-    const uint32_t sv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (sv >= n_sel) return;
-    const uint32_t it = sel[sv];
-    const dp_scan_item item = items[it];
-    const uint64_t a0 = boff[item.read] * 4 + item.start;
-    const uint32_t c = counts[it], lo = hit_lo[it];
-    const uint64_t out = segoff[it];
-    for (uint32_t j = lane; j < c; j += 64) {
-        const int p = (int)(keys[lo + j] - a0);
-        const int prev = j ? (int)(keys[lo + j - 1] - a0) : -k;  // "-k": the first gap is the hit's own index
-        segs[out + 2 * (uint64_t)j] = p - (prev + k);
-        segs[out + 2 * (uint64_t)j + 1] = (int32_t)vals[lo + j];
-    }
-    if (lane == 0) {
-        const int last = c ? (int)(keys[lo + c - 1] - a0) : -k;
-        segs[out + 2 * (uint64_t)c] = (int)item.n_kmers - last - 1;  // final gap (sequence/asm_amd64.s:387-392)
+    const uint32_t n_sel = *n_sel_p;
+    for (uint32_t sv = blockIdx.x; sv < n_sel; sv += gridDim.x) {
+        const uint32_t it = sel[sv];
+        const uint32_t c = counts[it];
+        const uint64_t out = segoff[it];
+        const int nk = (int)items[it].n_kmers;
+        __syncthreads();
+        if (c <= 64) {
+            unsigned long long key = ~0ull;
+            if ((uint32_t)lane < c) key = ((unsigned long long)(uint32_t)segs[out + 2 * (uint64_t)lane] << 32) | (uint32_t)segs[out + 2 * (uint64_t)lane + 1];
+            int rank = 0;
+            for (uint32_t l = 0; l < c; l++) {
+                const unsigned long long o = __shfl(key, (int)l, 64);
+                rank += o < key ? 1 : 0;
+            }
+            // positions are distinct (one k-mer per position), so the ranks are a permutation
+            __syncthreads();
+            if ((uint32_t)lane < c) keys[rank] = key;
+            __syncthreads();
+        } else if (c <= KX_SORT_LDS) {
+            uint32_t m = 64;
+            while (m < c) m <<= 1;
+            for (uint32_t j = lane; j < m; j += 64)
+                keys[j] = j < c ? (((unsigned long long)(uint32_t)segs[out + 2 * (uint64_t)j] << 32) | (uint32_t)segs[out + 2 * (uint64_t)j + 1]) : ~0ull;
+            __syncthreads();
+            for (uint32_t size = 2; size <= m; size <<= 1) {
+                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (uint32_t j = lane; j < m / 2; j += 64) {
+                        const uint32_t a = 2 * j - (j & (stride - 1));  // index of the lower element of pair j
+                        const uint32_t b = a + stride;
+                        const bool up = ((a & size) == 0);
+                        const unsigned long long x = keys[a], y = keys[b];
+                        if ((x > y) == up) {
+                            keys[a] = y;
+                            keys[b] = x;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        } else {
+            if (lane == 0) atomicExch(overflow, 1u);
+            continue;
+        }
+        for (uint32_t j = lane; j < c; j += 64) {
+            const int p = (int)(keys[j] >> 32);
+            const int prev = j ? (int)(keys[j - 1] >> 32) : -k;  // "-k": the first gap is the hit's own index
+            segs[out + 2 * (uint64_t)j] = p - (prev + k);
+            segs[out + 2 * (uint64_t)j + 1] = (int32_t)(uint32_t)keys[j];
+        }
+        if (lane == 0) {
+            const int last = c ? (int)(keys[c - 1] >> 32) : -k;
+            segs[out + 2 * (uint64_t)c] = nk - last - 1;  // final gap (sequence/asm_amd64.s:387-392)
+        }
     }
 }
 
-// Counting step of a round from the index: fills counts (and the per-item slice starts) for all items.
-// Returns 1 (nothing written) when the round's seeds have more than 2^31 occurrences in the read set - the sort keys and
-// the per-item slices are 32-bit indexed; the caller then answers this round with the scan kernels.
-int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t n_items, uint32_t* d_counts, float* ms) {
+// Counting step of a round from the index: counts, segment offsets, compacted survivor list and totals for all items, with
+// no host round trip.  d_work = [counts n | fill cursors n | tile status (tiles + 1) u64 | ticket, max count] (zeroed here).
+int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
+                    uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint64_t* d_totals) {
     dp_kindex* ix = kidx_owner(ctx)->kidx;
-    const uint32_t S = ctx->n_seeds;
-    if (dev_reserve(ctx, ctx->d_kx_sz, ((size_t)S + 2) * 12 + 16)) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_kx_lo, (size_t)n_items * 4 + 16)) return DP_ERR_HIP;
-    uint64_t* base = (uint64_t*)ctx->d_kx_sz.p;  // 64-bit running totals: dense seed batches over tens of Gbase pass 2^32
-    uint32_t* sz = (uint32_t*)(base + S + 2);
-    DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(kidx_seed_sizes, dim3((S + 1 + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
-                       (const uint64_t*)ix->off.p, sz);
-    size_t tb = 0;
-    rocprim::exclusive_scan(nullptr, tb, sz, base, (uint64_t)0, (size_t)S + 1, rocprim::plus<uint64_t>(), ctx->stream);
-    if (dev_reserve(ctx, ctx->d_kx_tmp, tb + 64)) return DP_ERR_HIP;
-    DP_HIP(rocprim::exclusive_scan(ctx->d_kx_tmp.p, tb, sz, base, (uint64_t)0, (size_t)S + 1, rocprim::plus<uint64_t>(), ctx->stream));
-    if (pin_reserve(ctx, ctx->h_total, 32)) return DP_ERR_HIP;
-    DP_HIP(hipMemcpyAsync((uint8_t*)ctx->h_total.p + 16, base + S, 8, hipMemcpyDeviceToHost, ctx->stream));
-    DP_HIP(dp_stream_sync(ctx));
-    const uint64_t H64 = *(const uint64_t*)((const uint8_t*)ctx->h_total.p + 16);
-    uint64_t cap = (uint64_t)1 << 31;
-    if (const char* e = getenv("DP_KINDEX_MAX_HITS")) cap = std::min<uint64_t>(cap, strtoull(e, nullptr, 10));  // (tests)
-    if (H64 > cap) return 1;
-    const uint32_t H = (uint32_t)H64;
-    ctx->kx_hits = H;
-    if (dev_reserve(ctx, ctx->d_kx_keys, ((size_t)H + 16) * 8 * 2)) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_kx_vals, ((size_t)H + 16) * 4 * 2)) return DP_ERR_HIP;
-    uint64_t* keys = (uint64_t*)ctx->d_kx_keys.p;
-    uint64_t* keys2 = keys + H + 16;
-    uint32_t* vals = (uint32_t*)ctx->d_kx_vals.p;
-    uint32_t* vals2 = vals + H + 16;
-    if (H) {
-        hipLaunchKernelGGL(kidx_emit, dim3((S + 3) / 4), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
-                           (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, (const uint64_t*)base, keys, vals);
-        // positions are below packed_bytes*4: sort only the bits that can differ
-        unsigned bits = 1;
-        while (bits < 64 && ((kidx_owner(ctx)->packed_bytes * 4) >> bits) != 0) bits++;
-        size_t sb = 0;
-        rocprim::radix_sort_pairs(nullptr, sb, keys, keys2, vals, vals2, (size_t)H, 0u, bits, ctx->stream);
-        if (dev_reserve(ctx, ctx->d_kx_tmp, std::max(sb, tb) + 64)) return DP_ERR_HIP;
-        DP_HIP(rocprim::radix_sort_pairs(ctx->d_kx_tmp.p, sb, keys, keys2, vals, vals2, (size_t)H, 0u, bits, ctx->stream));
+    const uint32_t S = ctx->n_seeds, n_items = n_read_items + n_extra;
+    if (n_items >= (1u << 24)) return 1;  // (the scan's status word holds 24 bits of survivors) -> scan kernels
+    const uint32_t n_tiles = (n_items + KX_TILE * KX_IPT - 1) / (KX_TILE * KX_IPT);
+    dp_ctx* ow = kidx_owner(ctx);
+    // linked lists of the extra items: head per read (all zero outside a call), next per extra item
+    {
+        const void* before = ctx->d_kx_lo.p;
+        if (dev_reserve(ctx, ctx->d_kx_lo, (size_t)ow->n_reads * 4 + 64)) return DP_ERR_HIP;
+        if (ctx->d_kx_lo.p != before || ctx->kx_head_reads != ow->n_reads) {
+            DP_HIP(hipMemsetAsync(ctx->d_kx_lo.p, 0, (size_t)ow->n_reads * 4, ctx->stream));
+            ctx->kx_head_reads = ow->n_reads;
+        }
     }
-    hipLaunchKernelGGL(kidx_count_items, dim3((n_items + 255) / 256), dim3(256), 0, ctx->stream, d_items, n_items,
-                       (const uint64_t*)ctx->d_boff.p, (const uint64_t*)keys2, H, d_counts, (uint32_t*)ctx->d_kx_lo.p);
+    if (dev_reserve(ctx, ctx->d_kx_vals, (size_t)n_extra * 4 + 64)) return DP_ERR_HIP;
+    uint32_t* head = (uint32_t*)ctx->d_kx_lo.p;
+    uint32_t* next = (uint32_t*)ctx->d_kx_vals.p;
+    const size_t b_counts = (size_t)n_items * 4;
+    if (dev_reserve(ctx, ctx->d_kx_sz, 2 * b_counts + ((size_t)n_tiles + 2) * 8 + 64 * 8 + 64)) return DP_ERR_HIP;
+    uint32_t* fillc = (uint32_t*)ctx->d_kx_sz.p;
+    unsigned long long* status = (unsigned long long*)((uint8_t*)ctx->d_kx_sz.p + ((b_counts + 7) & ~(size_t)7));
+    uint32_t* ticket = (uint32_t*)(status + n_tiles + 1);
+    uint32_t* maxc = ticket + 1;
+    unsigned long long* n_hits = (unsigned long long*)(ticket + 2);  // [64]
+    DP_HIP(hipMemsetAsync(ctx->d_kx_sz.p, 0, ((b_counts + 7) & ~(size_t)7) + ((size_t)n_tiles + 1) * 8 + 8 + 64 * 8, ctx->stream));
+    DP_HIP(hipMemsetAsync(d_counts, 0, b_counts, ctx->stream));
+    DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    if (n_extra)
+        hipLaunchKernelGGL(kidx_link_extra, dim3((n_extra + 255) / 256), dim3(256), 0, ctx->stream, d_items, n_read_items, n_extra, head, next);
+    if (S)
+        hipLaunchKernelGGL(kidx_walk<false>, dim3((S * KX_PARTS + 3) / 4), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
+                           (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
+                           (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits);
+    hipLaunchKernelGGL(kidx_offsets, dim3(n_tiles), dim3(KX_TILE), 0, ctx->stream, d_items, (const uint32_t*)d_counts, n_items, status, ticket,
+                       d_segoff, s_item, s_count, s_off, d_totals, maxc, (const unsigned long long*)n_hits);
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-    (void)ms;
+    // totals[2] = seed occurrences in the read set (written by the kernel), totals[3] = largest survivor count
+    DP_HIP(hipMemcpyAsync(d_totals + 3, maxc, 4, hipMemcpyDeviceToDevice, ctx->stream));
     (void)k;
     return DP_OK;
 }
 
-int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, const uint32_t* d_sel, uint32_t n_sel,
-                    const uint32_t* d_counts, const uint64_t* d_segoff, int32_t* d_segs) {
-    const uint32_t H = ctx->kx_hits;
-    const uint64_t* keys2 = (const uint64_t*)ctx->d_kx_keys.p + H + 16;
-    const uint32_t* vals2 = (const uint32_t*)ctx->d_kx_vals.p + H + 16;
-    if (n_sel == 0) return DP_OK;
-    hipLaunchKernelGGL(kidx_write, dim3((n_sel + 3) / 4), dim3(256), 0, ctx->stream, d_items, d_sel, n_sel,
-                       (const uint64_t*)ctx->d_boff.p, keys2, vals2, d_counts, (const uint32_t*)ctx->d_kx_lo.p, d_segoff, d_segs, k);
+// Second half, once the caller knows the totals and has sized d_segs: fill + sort/write.  Returns 1 when a survivor has more
+// hits than the LDS sort holds (the caller answers the round with the scan kernels instead).
+int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
+                    const uint32_t* d_sel, uint32_t n_sel, uint32_t max_count, const uint32_t* d_counts, const uint64_t* d_segoff,
+                    const uint64_t* d_totals, int32_t* d_segs) {
+    dp_kindex* ix = kidx_owner(ctx)->kidx;
+    dp_ctx* ow = kidx_owner(ctx);
+    const uint32_t S = ctx->n_seeds;
+    uint32_t* head = (uint32_t*)ctx->d_kx_lo.p;
+    uint32_t* next = (uint32_t*)ctx->d_kx_vals.p;
+    uint32_t* fillc = (uint32_t*)ctx->d_kx_sz.p;
+    (void)ow;
+    int rc = DP_OK;
+    if (max_count > KX_SORT_LDS) {
+        rc = 1;
+    } else if (n_sel) {
+        if (S)
+            hipLaunchKernelGGL(kidx_walk<true>, dim3((S * KX_PARTS + 3) / 4), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
+                               (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
+                               (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(kidx_sortwrite, dim3(std::min<uint32_t>(n_sel, 8192)), dim3(64), 0, ctx->stream, d_items, d_sel,
+                           (const uint32_t*)(d_totals + 1), d_counts, d_segoff, d_segs, k, (uint32_t*)(d_totals + 4));
+        DP_HIP(hipGetLastError());
+    }
+    if (n_extra)
+        hipLaunchKernelGGL(kidx_unlink_extra, dim3((n_extra + 255) / 256), dim3(256), 0, ctx->stream, d_items, n_read_items, n_extra, head);
     DP_HIP(hipGetLastError());
-    return DP_OK;
+    return rc;
 }

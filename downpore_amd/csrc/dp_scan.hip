@@ -1103,8 +1103,20 @@ extern "C" int dp_scan_release(dp_ctx* ctx) {
     return DP_OK;
 }
 
+#define DP_SCAN_AGAIN 1000  // internal: the index could not answer this round, run it again with the scan kernels
+
+static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
+                           uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out, bool allow_index);
+
 extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
                              uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out) {
+    int rc = scan_reads_body(ctx, ignore, ignore_epoch, lo, hi, top_level, min_seeds, extra, n_extra, out, true);
+    if (rc == DP_SCAN_AGAIN) rc = scan_reads_body(ctx, ignore, ignore_epoch, lo, hi, top_level, min_seeds, extra, n_extra, out, false);
+    return rc;
+}
+
+static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
+                           uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out, bool allow_index) {
     if (!ctx || !out || !ignore || lo > hi || hi > ctx->n_reads || (n_extra && !extra)) return DP_ERR_ARG;
     if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_scan_reads before dp_round_begin");
     hipSetDevice(ctx->device);
@@ -1147,7 +1159,7 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     out->index_mode = 0;
     out->index_hits = 0;
     ctx->scan_items = n_items;
-    if (pin_reserve(ctx, ctx->h_total, 32)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_total, 64)) return DP_ERR_HIP;
     if (n_items == 0) {
         ctx->n_segs = 0;
         return DP_OK;
@@ -1184,7 +1196,7 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     // Resident k-mer position index instead of scanning (dp_kindex.hip): DP_SCAN_INDEX=1 forces it, =0 forbids it; by
     // default it is used from 1 Gbase up.  That is the break-even of a whole job: the build costs ~0.13 s per Gbase, a
     // round saves (scan 0.5 ms per Gbase) - (index step 0.25 ms), and a job has ~600 rounds per Gbase of 10 kb reads.
-    bool use_index = scan_wants_index(ctx);
+    bool use_index = allow_index && scan_wants_index(ctx);
     std::unique_lock<ScanGate> scan_lock(g_scan_mu, std::defer_lock);
     if (use_index) {
         int rc = dp_kindex_ensure(ctx, k);
@@ -1193,10 +1205,11 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     }
     out->index_hits = 0;
     if (use_index) {
-        int rc = dp_kindex_count(ctx, k, d_items, n_items, (uint32_t*)ctx->d_counts.p, nullptr);
+        // counts, segment offsets, survivor list and totals in three launches, no sort and no host round trip (dp_kindex.hip)
+        int rc = dp_kindex_count(ctx, k, d_items, lo, hi, n_read_items, n_extra, (uint32_t*)ctx->d_counts.p, (uint64_t*)ctx->d_segoff.p,
+                                 s_item, s_count, s_off, totals);
         if (rc < 0) return rc;
-        if (rc > 0) use_index = false;  // more seed occurrences than the 32-bit sort handles: this round is scanned
-        else out->index_hits = ctx->kx_hits;
+        if (rc > 0) use_index = false;  // more items than its scan handles: this round is scanned
     }
     out->index_mode = use_index ? 1u : 0u;
     if (!use_index) {
@@ -1210,21 +1223,21 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
                            (const uint32_t*)nullptr, 0u);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        hipLaunchKernelGGL(offsets_tile_sums, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
+                           (const uint32_t*)ctx->d_counts.p, n_items, tilesA);
+        hipLaunchKernelGGL(offsets_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tilesA, n_tiles, totals, (uint64_t*)ctx->d_segoff.p, n_items);
+        hipLaunchKernelGGL(offsets_write, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
+                           (const uint32_t*)ctx->d_counts.p, n_items, (const uint64_t*)tilesA, (uint64_t*)ctx->d_segoff.p);
+        hipLaunchKernelGGL(flag_tile_sums, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
+                           (const uint32_t*)ctx->d_counts.p, n_items, tilesB);
+        hipLaunchKernelGGL(offsets_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tilesB, n_tiles, totals + 1, tilesB + n_tiles, 0u);
+        hipLaunchKernelGGL(compact_write, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
+                           (const uint32_t*)ctx->d_counts.p, n_items, (const uint64_t*)tilesB, (const uint64_t*)ctx->d_segoff.p, s_item,
+                           s_count, s_off);
     }
-    hipLaunchKernelGGL(offsets_tile_sums, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
-                       (const uint32_t*)ctx->d_counts.p, n_items, tilesA);
-    hipLaunchKernelGGL(offsets_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tilesA, n_tiles, totals, (uint64_t*)ctx->d_segoff.p, n_items);
-    hipLaunchKernelGGL(offsets_write, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
-                       (const uint32_t*)ctx->d_counts.p, n_items, (const uint64_t*)tilesA, (uint64_t*)ctx->d_segoff.p);
-    hipLaunchKernelGGL(flag_tile_sums, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
-                       (const uint32_t*)ctx->d_counts.p, n_items, tilesB);
-    hipLaunchKernelGGL(offsets_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tilesB, n_tiles, totals + 1, tilesB + n_tiles, 0u);
-    hipLaunchKernelGGL(compact_write, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
-                       (const uint32_t*)ctx->d_counts.p, n_items, (const uint64_t*)tilesB, (const uint64_t*)ctx->d_segoff.p, s_item,
-                       s_count, s_off);
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-    DP_HIP(hipMemcpyAsync(ctx->h_total.p, totals, 16, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->h_total.p, totals, 32, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     {
         // DP_SCAN_RELEASE_EARLY=1 opens the gate here, after the count pass, so that the short write pass overlaps the
@@ -1238,6 +1251,11 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     }
     const uint64_t n_segs = ((uint64_t*)ctx->h_total.p)[0];
     const uint64_t n_surv_all = ((uint64_t*)ctx->h_total.p)[1];  // surviving reads + all extra items
+    if (use_index) {
+        ctx->kx_hits = ((uint64_t*)ctx->h_total.p)[2];
+        out->index_hits = ctx->kx_hits;
+    }
+    const uint32_t kx_max_count = (uint32_t)((uint64_t*)ctx->h_total.p)[3];
     if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_surv, n_surv_all * 16 + 64)) return DP_ERR_HIP;
@@ -1255,9 +1273,14 @@ extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore
     if (n_segs) {
         DP_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
         if (use_index) {
-            int rc = dp_kindex_write(ctx, k, (const dp_scan_item*)d_items, (const uint32_t*)s_item, (uint32_t)n_surv_all,
-                                     (const uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p, (int32_t*)ctx->d_segs.p);
-            if (rc != 0) return rc;
+            int rc = dp_kindex_write(ctx, k, (const dp_scan_item*)d_items, lo, hi, n_read_items, n_extra, (const uint32_t*)s_item,
+                                     (uint32_t)n_surv_all, kx_max_count, (const uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
+                                     (const uint64_t*)totals, (int32_t*)ctx->d_segs.p);
+            if (rc < 0) return rc;
+            if (rc > 0) {  // a survivor with more hits than the in-LDS sort holds: the scan kernels answer this round
+                DP_HIP(dp_stream_sync(ctx));
+                return DP_SCAN_AGAIN;
+            }
         } else {
             // one wave per SURVIVOR (the compacted list), not a strided walk over every item
             const uint32_t wgrid = (uint32_t)std::min<uint64_t>(grid, (n_surv_all + 15) / 16);
