@@ -88,8 +88,11 @@ def main():
     bases, off = gen_reads(args.seed, G, N, L, args.error, False)
     reads = Reads(bases, off, min_len=1000)
     t_gen = time.time() - t0
+    # N > 1, scan-shard (default): the survivor exchange runs inside the library on an RCCL communicator (dp_comm_init +
+    # dp_allgather_survivors, device to device); DP_BENCH_BACKEND=gloo (1-GPU test hook) keeps it on host copies
+    comm = "rccl" if (world > 1 and args.mode == "scan-shard" and torch_device is not None) else None
     pipe = OverlapPipeline(reads, device=local_rank, k=args.k, seed_batch_size=args.seed_batch_size, rank=rank, world=world,
-                           torch_device=torch_device, mode=args.mode, slots=args.slots, defer_init=True)
+                           torch_device=torch_device, mode=args.mode, slots=args.slots, defer_init=True, comm=comm)
     upload = pipe.setup_times()
 
     def sync():

@@ -1,0 +1,395 @@
+// libdownpore_hip.so — multi-GPU entry points of the C ABI: the scan is sharded by read, ranks own
+// ascending contiguous read ranges, and after every round's scan the survivors (read id, hit count, segments) are
+// all-gathered so that every GPU builds the identical index.  The exchange runs device to device on the context's own
+// stream: counts first (variable sizes), then the payloads, concatenated in rank order = file order.
+//   dp_comm_init        one process per GPU: an RCCL communicator over xGMI (librccl is loaded at run time, so a build of this
+//                       library does not depend on it and a process that never calls dp_comm_init never loads it);
+//   dp_comm_init_local  one process driving several contexts (a Go host with one goroutine per GPU, or tests with several
+//                       contexts on one GPU): every rank publishes device pointers, peers copy with hipMemcpyPeerAsync.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "dp_common.h"
+
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // an RCCL the process has loaded already (PyTorch brings its own next to its own HIP runtime) is the one that matches
+        // the HIP runtime in use; otherwise the ROCm installation's
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (api.lib) break;
+        }
+        for (const char* n : names) {
+            if (api.lib) break;
+            api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!api.lib) {
+            api.err = std::string("librccl not found: ") + dlerror();
+            return;
+        }
+        auto sym = [&](const char* s) {
+            void* p = dlsym(api.lib, s);
+            if (!p) api.err = std::string("librccl lacks ") + s;
+            return p;
+        };
+        api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+        api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    });
+    return &api;
+}
+
+// shared state of the ranks of a local (one-process) communicator
+struct LocalGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n = 0, refs = 0;
+    uint64_t gen = 0;       // completed exchanges
+    int arrived = 0, left = 0;
+    struct Pub {
+        int device = 0;
+        const void* counts = nullptr;   // device: uint64[2] = {survivors, segment ints of the survivors}
+        const void* read = nullptr;     // device: uint32[survivors] read ids
+        const void* nseeds = nullptr;   // device: uint32[survivors]
+        const void* segs = nullptr;     // device: int32[segment ints]
+        uint64_t n_surv = 0, n_ints = 0;
+        hipEvent_t ready = nullptr;     // recorded on the publisher's stream once the buffers above are final
+    };
+    std::vector<Pub> pub;
+};
+}  // namespace
+
+struct dp_comm {
+    int n_ranks = 1, rank = 0;
+    ncclComm_t nccl = nullptr;  // RCCL flavour
+    LocalGroup* local = nullptr;  // one-process flavour
+    hipEvent_t ev = nullptr;
+    // per-rank scratch on the owning context's device
+    DevBuf d_cnt, d_pay, d_allpay;
+    PinBuf h_cnt, h_out;
+    std::string err;
+};
+
+extern "C" int dp_comm_unique_id(uint8_t* id_out) {
+    if (!id_out) return DP_ERR_ARG;
+    RcclApi* R = rccl_api();
+    if (!R->err.empty()) return DP_ERR_STATE;
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) return DP_ERR_HIP;
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id_out, &id, 128);
+    return DP_OK;
+}
+
+extern "C" int dp_comm_init(dp_ctx* ctx, int n_ranks, int rank, const uint8_t* unique_id, dp_comm** out) {
+    if (!ctx || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks || !unique_id) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_comm_init: bad arguments") : DP_ERR_ARG;
+    *out = nullptr;
+    RcclApi* R = rccl_api();
+    if (!R->err.empty()) return dp_fail(ctx, DP_ERR_STATE, R->err.c_str());
+    hipSetDevice(ctx->device);
+    dp_comm* c = new dp_comm();
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, 128);
+    const ncclResult_t r = R->CommInitRank(&c->nccl, n_ranks, id, rank);
+    if (r != ncclSuccess) {
+        std::string m = std::string("ncclCommInitRank: ") + R->GetErrorString(r);
+        delete c;
+        return dp_fail(ctx, DP_ERR_HIP, m.c_str());
+    }
+    hipEventCreateWithFlags(&c->ev, hipEventDisableTiming);
+    *out = c;
+    return DP_OK;
+}
+
+extern "C" int dp_comm_init_local(dp_ctx* const* ctxs, int n, dp_comm** out) {
+    if (!ctxs || !out || n < 1) return DP_ERR_ARG;
+    LocalGroup* g = new LocalGroup();
+    g->n = n;
+    g->refs = n;
+    g->pub.resize((size_t)n);
+    for (int r = 0; r < n; r++) {
+        if (!ctxs[r]) {
+            delete g;
+            return DP_ERR_ARG;
+        }
+        dp_comm* c = new dp_comm();
+        c->n_ranks = n;
+        c->rank = r;
+        c->local = g;
+        hipSetDevice(ctxs[r]->device);
+        hipEventCreateWithFlags(&c->ev, hipEventDisableTiming);
+        hipEventCreateWithFlags(&g->pub[(size_t)r].ready, hipEventDisableTiming);
+        g->pub[(size_t)r].device = ctxs[r]->device;
+        out[r] = c;
+    }
+    // peers on different devices copy directly (xGMI) when the runtime allows it; otherwise hipMemcpyPeerAsync stages
+    for (int a = 0; a < n; a++)
+        for (int b = 0; b < n; b++)
+            if (ctxs[a]->device != ctxs[b]->device) {
+                int can = 0;
+                hipDeviceCanAccessPeer(&can, ctxs[a]->device, ctxs[b]->device);
+                if (can) {
+                    hipSetDevice(ctxs[a]->device);
+                    hipDeviceEnablePeerAccess(ctxs[b]->device, 0);  // (already enabled: harmless error)
+                    (void)hipGetLastError();
+                }
+            }
+    return DP_OK;
+}
+
+extern "C" void dp_comm_destroy(dp_comm* c) {
+    if (!c) return;
+    if (c->nccl) rccl_api()->CommDestroy(c->nccl);
+    if (c->local) {
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(c->local->mu);
+            last = --c->local->refs == 0;
+        }
+        if (last) {
+            for (auto& p : c->local->pub)
+                if (p.ready) hipEventDestroy(p.ready);
+            delete c->local;
+        }
+    }
+    if (c->ev) hipEventDestroy(c->ev);
+    for (DevBuf* b : {&c->d_cnt, &c->d_pay, &c->d_allpay})
+        if (b->p) hipFree(b->p);
+    for (PinBuf* b : {&c->h_cnt, &c->h_out})
+        if (b->p) hipHostFree(b->p);
+    delete c;
+}
+
+// gathers read ids / hit counts of the survivors of the local scan (the compacted lists of dp_scan_reads) into one payload
+__global__ void comm_pack_meta(const uint32_t* __restrict__ s_item, const uint32_t* __restrict__ s_count, uint32_t n, uint32_t lo,
+                               uint32_t* __restrict__ read, uint32_t* __restrict__ nseeds) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    read[i] = s_item[i] + lo;
+    nseeds[i] = s_count[i];
+}
+
+static int comm_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) ctx->retired_dev.push_back(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t ncap = (bytes + bytes / 2 + 255) & ~(size_t)255;
+    DP_HIP(hipMalloc(&b.p, ncap));
+    b.cap = ncap;
+    return 0;
+}
+static int comm_pin(dp_ctx* ctx, PinBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) ctx->retired_pin.push_back(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t ncap = (bytes + bytes / 2 + 4095) & ~(size_t)4095;
+    DP_HIP(hipHostMalloc(&b.p, ncap, hipHostMallocDefault));
+    b.cap = ncap;
+    return 0;
+}
+
+// All-gather of the survivors of the last dp_scan_reads on `ctx` (which scanned this rank's read range; the `extra` items -
+// the query windows - are scanned by every rank and are not exchanged).  Afterwards the context's device-resident scan
+// output is [survivors of rank 0 | rank 1 | ... | this rank's extra items], i.e. what a single GPU scanning every read would
+// hold, and `all` describes it the way dp_scan_reads would have (host copies included).
+extern "C" int dp_allgather_survivors(dp_comm* c, dp_ctx* ctx, const dp_survivor_batch* local, dp_survivor_batch* all) {
+    if (!c || !ctx || !local || !all) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_allgather_survivors: bad arguments") : DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    const int N = c->n_ranks, me = c->rank;
+    const uint32_t ns = local->n_survivors, ne = local->n_extra;
+    // local layout of d_segs: survivors' segments first, then the extra items'
+    uint64_t surv_ints = 0;
+    if (ns) surv_ints = local->seg_off[ns - 1] + 2ull * local->n_seeds[ns - 1] + 1;
+    const uint64_t extra_ints = local->n_segs - surv_ints;
+    // ---- sizes
+    if (comm_pin(ctx, c->h_cnt, (size_t)N * 16 + 64)) return DP_ERR_HIP;
+    uint64_t* cnt = (uint64_t*)c->h_cnt.p;  // [N][2] = survivors, ints
+    if (c->nccl) {
+        RcclApi* R = rccl_api();
+        if (comm_reserve(ctx, c->d_cnt, (size_t)(N + 1) * 16)) return DP_ERR_HIP;
+        uint64_t mine[2] = {ns, surv_ints};
+        uint64_t* d_mine = (uint64_t*)c->d_cnt.p + 2 * (size_t)N;
+        DP_HIP(hipMemcpyAsync(d_mine, mine, 16, hipMemcpyHostToDevice, ctx->stream));
+        ncclResult_t r = R->AllGather(d_mine, c->d_cnt.p, 2, ncclUint64, c->nccl, ctx->stream);
+        if (r != ncclSuccess) return dp_fail(ctx, DP_ERR_HIP, R->GetErrorString(r));
+        DP_HIP(hipMemcpyAsync(cnt, c->d_cnt.p, (size_t)N * 16, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
+    }
+    // ---- this rank's payload: [read ids | hit counts] packed on the device; the segments are taken where they lie
+    const uint32_t* s_item = (const uint32_t*)ctx->d_surv.p;
+    const uint32_t* s_count = s_item + ctx->scan_items;
+    if (comm_reserve(ctx, c->d_pay, (size_t)ns * 8 + 64)) return DP_ERR_HIP;
+    uint32_t* d_read = (uint32_t*)c->d_pay.p;
+    uint32_t* d_nseeds = d_read + ns;
+    if (ns) {
+        hipLaunchKernelGGL(comm_pack_meta, dim3((ns + 255) / 256), dim3(256), 0, ctx->stream, s_item, s_count, ns, ctx->cached_lo, d_read,
+                           d_nseeds);
+        DP_HIP(hipGetLastError());
+    }
+    if (c->local) {  // publish, wait for everybody, learn the sizes
+        LocalGroup* g = c->local;
+        DP_HIP(hipEventRecord(g->pub[(size_t)me].ready, ctx->stream));
+        std::unique_lock<std::mutex> lk(g->mu);
+        LocalGroup::Pub& p = g->pub[(size_t)me];
+        p.read = d_read;
+        p.nseeds = d_nseeds;
+        p.segs = ctx->d_segs.p;
+        p.n_surv = ns;
+        p.n_ints = surv_ints;
+        const uint64_t my_gen = g->gen;
+        if (++g->arrived == N) {
+            g->arrived = 0;
+            g->gen++;
+            g->cv.notify_all();
+        } else {
+            g->cv.wait(lk, [&] { return g->gen != my_gen; });
+        }
+        for (int r = 0; r < N; r++) {
+            cnt[2 * r] = g->pub[(size_t)r].n_surv;
+            cnt[2 * r + 1] = g->pub[(size_t)r].n_ints;
+        }
+    }
+    uint64_t tot_surv = 0, tot_ints = 0, my_surv_off = 0, my_int_off = 0;
+    for (int r = 0; r < N; r++) {
+        if (r == me) {
+            my_surv_off = tot_surv;
+            my_int_off = tot_ints;
+        }
+        tot_surv += cnt[2 * r];
+        tot_ints += cnt[2 * r + 1];
+    }
+    if (tot_surv > 0xfffffff0ull) return dp_fail(ctx, DP_ERR_CAPACITY, "dp_allgather_survivors: more than 2^32 survivors");
+    // ---- gathered device buffers: metadata [read ids of all | hit counts of all], segments [all survivors | my extra items]
+    const uint64_t new_ints = tot_ints + extra_ints;
+    if (comm_reserve(ctx, c->d_allpay, (size_t)tot_surv * 8 + (size_t)new_ints * 4 + 256)) return DP_ERR_HIP;
+    uint32_t* a_read = (uint32_t*)c->d_allpay.p;
+    uint32_t* a_nseeds = a_read + tot_surv;
+    int32_t* a_segs = (int32_t*)(((uintptr_t)(a_nseeds + tot_surv) + 15) & ~(uintptr_t)15);
+    if (c->nccl) {
+        // variable sizes: one broadcast per rank and array inside a group (RCCL fuses them); rank order = file order
+        RcclApi* R = rccl_api();
+        R->GroupStart();
+        uint64_t so = 0, io = 0;
+        ncclResult_t r = ncclSuccess;
+        for (int q = 0; q < N && r == ncclSuccess; q++) {
+            const uint64_t qs = cnt[2 * q], qi = cnt[2 * q + 1];
+            if (qs) {
+                r = R->Broadcast(q == me ? (const void*)d_read : (const void*)(a_read + so), a_read + so, qs, ncclUint32, q, c->nccl, ctx->stream);
+                if (r == ncclSuccess)
+                    r = R->Broadcast(q == me ? (const void*)d_nseeds : (const void*)(a_nseeds + so), a_nseeds + so, qs, ncclUint32, q, c->nccl, ctx->stream);
+            }
+            if (qi && r == ncclSuccess)
+                r = R->Broadcast(q == me ? (const void*)ctx->d_segs.p : (const void*)(a_segs + io), a_segs + io, qi, ncclInt32, q, c->nccl, ctx->stream);
+            so += qs;
+            io += qi;
+        }
+        R->GroupEnd();
+        if (r != ncclSuccess) return dp_fail(ctx, DP_ERR_HIP, R->GetErrorString(r));
+    } else {
+        LocalGroup* g = c->local;
+        uint64_t so = 0, io = 0;
+        for (int q = 0; q < N; q++) {
+            const LocalGroup::Pub& p = g->pub[(size_t)q];
+            DP_HIP(hipStreamWaitEvent(ctx->stream, p.ready, 0));
+            if (p.n_surv) {
+                DP_HIP(hipMemcpyPeerAsync(a_read + so, ctx->device, p.read, p.device, p.n_surv * 4, ctx->stream));
+                DP_HIP(hipMemcpyPeerAsync(a_nseeds + so, ctx->device, p.nseeds, p.device, p.n_surv * 4, ctx->stream));
+            }
+            if (p.n_ints) DP_HIP(hipMemcpyPeerAsync(a_segs + io, ctx->device, p.segs, p.device, p.n_ints * 4, ctx->stream));
+            so += p.n_surv;
+            io += p.n_ints;
+        }
+    }
+    // my extra items follow the survivors
+    if (extra_ints)
+        DP_HIP(hipMemcpyAsync(a_segs + tot_ints, (const int32_t*)ctx->d_segs.p + surv_ints, extra_ints * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    // ---- host copies for the caller (chunking runs on the host): metadata + all segments
+    const size_t b_meta = (size_t)tot_surv * 8, b_off = ((size_t)tot_surv + ne + 2) * 8, b_ex = (size_t)ne * 4, b_segs = (size_t)new_ints * 4;
+    if (comm_pin(ctx, c->h_out, b_meta + b_off + b_ex + b_segs + 256)) return DP_ERR_HIP;
+    uint8_t* h = (uint8_t*)c->h_out.p;
+    uint32_t* h_read = (uint32_t*)h;
+    uint32_t* h_nseeds = h_read + tot_surv;
+    uint64_t* h_off = (uint64_t*)(h + ((b_meta + 7) & ~(size_t)7));
+    uint32_t* h_exn = (uint32_t*)((uint8_t*)h_off + b_off);
+    int32_t* h_segs = (int32_t*)(((uintptr_t)((uint8_t*)h_exn + b_ex) + 15) & ~(uintptr_t)15);
+    if (tot_surv) DP_HIP(hipMemcpyAsync(h_read, a_read, b_meta, hipMemcpyDeviceToHost, ctx->stream));
+    if (new_ints) DP_HIP(hipMemcpyAsync(h_segs, a_segs, b_segs, hipMemcpyDeviceToHost, ctx->stream));
+    // the merged array becomes the context's scan output (dp_index_build / dp_find_overlaps read it): swap the buffers
+    DP_HIP(dp_stream_sync(ctx));
+    if (c->local) {  // nobody may reuse its published buffers before every peer has copied from them
+        LocalGroup* g = c->local;
+        std::unique_lock<std::mutex> lk(g->mu);
+        const uint64_t my_gen = g->gen;
+        if (++g->left == N) {
+            g->left = 0;
+            g->gen++;
+            g->cv.notify_all();
+        } else {
+            g->cv.wait(lk, [&] { return g->gen != my_gen; });
+        }
+    }
+    if (dev_reserve(ctx, ctx->d_segs, (size_t)new_ints * 4 + 64)) return DP_ERR_HIP;
+    if (new_ints) DP_HIP(hipMemcpyAsync(ctx->d_segs.p, a_segs, (size_t)new_ints * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    ctx->n_segs = new_ints;
+    uint64_t pos = 0;
+    for (uint64_t i = 0; i < tot_surv; i++) {
+        h_off[i] = pos;
+        pos += 2ull * h_nseeds[i] + 1;
+    }
+    uint64_t* h_exoff = h_off + tot_surv + 1;
+    for (uint32_t i = 0; i < ne; i++) {
+        h_exn[i] = local->extra_n_seeds[i];
+        h_exoff[i] = tot_ints + (local->extra_seg_off[i] - surv_ints);
+    }
+    dp_survivor_batch o = *local;
+    o.n_survivors = (uint32_t)tot_surv;
+    o.read = h_read;
+    o.n_seeds = h_nseeds;
+    o.seg_off = h_off;
+    o.n_extra = ne;
+    o.extra_n_seeds = h_exn;
+    o.extra_seg_off = h_exoff;
+    o.segs = h_segs;
+    o.n_segs = new_ints;
+    *all = o;
+    (void)my_surv_off;
+    (void)my_int_off;
+    return DP_OK;
+}
+
+extern "C" int dp_comm_rank(const dp_comm* c) { return c ? c->rank : -1; }
+extern "C" int dp_comm_size(const dp_comm* c) { return c ? c->n_ranks : 0; }

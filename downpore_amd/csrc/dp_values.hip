@@ -173,3 +173,16 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
 #undef DPV
     return DP_OK;
 }
+
+// The resident value table (dp_kmer_values / dp_values_upload) copied to the host on the calling context's stream: lets a
+// caller overlap the 4^k * 8 byte download with other set-up work on another context (dp_scan_prepare).
+extern "C" int dp_values_download(dp_ctx* ctx, double* values_out, uint64_t n) {
+    if (!ctx || !values_out) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_values_download: bad arguments") : DP_ERR_ARG;
+    const dp_ctx* src = ctx->owner ? ctx->owner : ctx;
+    if (!src->d_values.p || src->n_values != n) return dp_fail(ctx, DP_ERR_STATE, "dp_values_download: no value table of this size resident");
+    hipSetDevice(ctx->device);
+    hipError_t e = hipMemcpyAsync(values_out, src->d_values.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = dp_stream_sync(ctx);
+    if (e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, "dp_values_download", e);
+    return DP_OK;
+}

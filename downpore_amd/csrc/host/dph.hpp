@@ -334,6 +334,9 @@ class Overlapper {
         ignoreEpoch_ = epoch;
     }
     void setWindowCache(WindowCache* c) { cache_ = c; }
+    // multi-GPU: replaces the survivors of ScanLocal (this rank's read range) by the rank-ordered concatenation over all
+    // ranks, exchanged device to device inside the library (dp_allgather_survivors)
+    int ExchangeSurvivors(dp_comm* comm, Survivors& all);
 
    private:
     void chunkAndAdd(SeedSeq* s, uint64_t segBase, Arena& ar, std::vector<SeedSeq*>& seqOut, std::vector<dp_seq_ref>& refOut);
@@ -350,6 +353,7 @@ class Overlapper {
     std::vector<Window> windows_;
     std::vector<int32_t> querySegs_;       // fwd/rc query segments (host)
     std::vector<uint64_t> queryOff_;
+    dp_survivor_batch lastScan_;           // what dp_scan_reads returned for this round (valid until the context scans again)
     std::vector<int32_t> winSegs_;         // scan output of the windows
     std::vector<uint64_t> winOff_;
     const int32_t* allSegs_ = nullptr;     // survivors' segments on the host (device copy is what the index references)
@@ -493,6 +497,9 @@ struct OverlapRun {
     // ---- scan-shard mode (survivor all-gather between the two halves)
     int roundPrepareAndScan();
     int roundFinish(const Survivors& all);
+    // ... with the exchange inside the library (RCCL or in-process peers): one whole round; 1 ran, 0 finished, < 0 error
+    dp_comm* comm = nullptr;  // owned by the caller
+    int roundSharded();
     // ---- round-parallel mode: execute round `r` speculatively against the current flags, commit gathered results
     int executeRound(i64 r, RoundResult& out);
     // returns the number of rounds committed from `results` (in order, all consecutive from `round`), stopping at the
@@ -522,6 +529,7 @@ struct OverlapRun {
     bool stopWorkers_ = false, issueEnd_ = false, draining_ = false;
     std::string workerErr_;
     std::vector<int32_t> flagRound_;  // round whose commit flagged each read, -1 = not flagged by this run
+    Survivors gathered_;              // scan-shard mode: the survivors of all ranks
 };
 
 // ---- mapping.Mapper / `downpore map` (mapping/mapping.go, commands/map.go) ----------------------------------------

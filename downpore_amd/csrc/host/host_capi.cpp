@@ -16,6 +16,7 @@ struct ReadsH {
 struct OverlapH {
     OverlapRun run;
     dp_ctx* ctx = nullptr;
+    dp_comm* comm = nullptr;
     ReadSet* reads = nullptr;
     double tCtx = 0, tUpload = 0, tInit = 0;
     std::string err;
@@ -168,6 +169,7 @@ void dph_overlap_destroy(void* hh) {
     OverlapH* h = (OverlapH*)hh;
     if (!h) return;
     h->run.shutdown();
+    if (h->comm) dp_comm_destroy(h->comm);
     dp_ctx_destroy(h->ctx);
     delete h;
 }
@@ -222,6 +224,40 @@ int dph_overlap_round_finish(void* hh, const uint32_t* read, const uint32_t* nse
     else h->addPaf(h->run.paf);
     return rc;
 }
+// ---- multi-GPU with the exchange inside the library (dp_comm): RCCL across processes, or in-process peers
+int dph_comm_unique_id(uint8_t* id128) { return dp_comm_unique_id(id128); }
+int dph_overlap_comm_init(void* hh, int nRanks, int rank, const uint8_t* id128) {
+    OverlapH* h = (OverlapH*)hh;
+    if (h->comm) dp_comm_destroy(h->comm);
+    h->comm = nullptr;
+    int rc = dp_comm_init(h->ctx, nRanks, rank, id128, &h->comm);
+    if (rc != 0) h->err = dp_last_error(h->ctx);
+    h->run.comm = h->comm;
+    return rc;
+}
+int dph_overlap_comm_init_local(void** handles, int n) {
+    std::vector<dp_ctx*> ctxs;
+    for (int i = 0; i < n; i++) ctxs.push_back(((OverlapH*)handles[i])->ctx);
+    std::vector<dp_comm*> comms((size_t)n, nullptr);
+    int rc = dp_comm_init_local(ctxs.data(), n, comms.data());
+    if (rc != 0) return rc;
+    for (int i = 0; i < n; i++) {
+        OverlapH* h = (OverlapH*)handles[i];
+        if (h->comm) dp_comm_destroy(h->comm);
+        h->comm = comms[(size_t)i];
+        h->run.comm = h->comm;
+    }
+    return 0;
+}
+// one whole round of this rank (collective: every rank calls it, from its own thread / process): 1 ran, 0 finished
+int dph_overlap_round_sharded(void* hh) {
+    OverlapH* h = (OverlapH*)hh;
+    int rc = h->run.roundSharded();
+    if (rc < 0) h->err = h->run.error;
+    else if (rc > 0) h->addPaf(h->run.paf);
+    return rc;
+}
+
 const char* dph_overlap_round_paf(void* hh, int64_t* n) {
     OverlapH* h = (OverlapH*)hh;
     *n = (int64_t)h->run.paf.size();

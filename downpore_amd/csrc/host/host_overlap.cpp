@@ -212,7 +212,7 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
         it.min_seeds = 0;
         items.push_back(it);
     }
-    dp_survivor_batch b;
+    dp_survivor_batch& b = lastScan_;
     const double ts0 = now();
     int rc = dp_scan_reads(ctx_, ignore_, ignoreEpoch_, (uint32_t)lo, (uint32_t)hi, reads_.himem ? 0 : 1, (uint32_t)minSeeds_,
                            items.data(), (uint32_t)items.size(), &b);
@@ -250,6 +250,33 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
     }
     st.n_hits += b.n_segs / 2;  // hits written this scan, for the roofline's algorithmic bytes
     g_prof.add(4, now() - ts1);
+    return 0;
+}
+
+int Overlapper::ExchangeSurvivors(dp_comm* comm, Survivors& all) {
+    dp_survivor_batch g;
+    const int rc = dp_allgather_survivors(comm, ctx_, &lastScan_, &g);
+    if (rc != 0) {
+        err = dp_last_error(ctx_);
+        return rc;
+    }
+    all.read.assign(g.read, g.read + g.n_survivors);
+    all.n_seeds.assign(g.n_seeds, g.n_seeds + g.n_survivors);
+    all.seg_off.assign(g.seg_off, g.seg_off + g.n_survivors);
+    uint64_t survEnd = 0;
+    if (g.n_survivors) survEnd = g.seg_off[g.n_survivors - 1] + 2ull * g.n_seeds[g.n_survivors - 1] + 1;
+    all.seg_off.push_back(survEnd);
+    all.segs.clear();
+    all.segsView = g.segs;
+    all.segsViewLen = survEnd;
+    all.deviceResident = true;  // the library installed the gathered array as the context's scan output
+    winSegs_.clear();
+    winOff_.assign(1, 0);
+    for (uint32_t i = 0; i < g.n_extra; i++) {
+        const uint64_t o = g.extra_seg_off[i];
+        winSegs_.insert(winSegs_.end(), g.segs + o, g.segs + o + 2ull * g.extra_n_seeds[i] + 1);
+        winOff_.push_back(winSegs_.size());
+    }
     return 0;
 }
 

@@ -464,22 +464,49 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         mark("value table (host)");
         values.assign(v.data(), v.size());
     } else {  // KmerOccurrences + value table + 1 % cut on the GPU; the table stays resident for dp_select_seeds
-        int rc = dp_kmer_values(ctx, p.k, values.reserve((size_t)1 << (2 * p.k)));
+        int rc = dp_kmer_values(ctx, p.k, nullptr);
         if (rc != 0) {
             error = dp_last_error(ctx);
             return rc;
         }
         valuesOnDevice = true;
-        mark("value table (device) + copy");
+        mark("value table (device)");
     }
-    mark("values copy");
+    // The host copy of the table (the planner re-selects a window on the host when its speculation did not hold) travels
+    // on a second context while this one builds the k-mer position index.
+    std::thread dl;
+    int dlRc = 0;
+    std::string dlErr;
+    if (valuesOnDevice) {
+        double* dst = values.reserve((size_t)1 << (2 * p.k));
+        dl = std::thread([this, dst, &dlRc, &dlErr] {
+            dp_ctx* c2 = nullptr;
+            dlRc = dp_ctx_create_shared(ctx, &c2);
+            if (dlRc != 0) {
+                dlErr = dp_last_error(nullptr);
+                return;
+            }
+            dlRc = dp_values_download(c2, dst, (uint64_t)1 << (2 * p.k));
+            if (dlRc != 0) dlErr = dp_last_error(c2);
+            dp_ctx_destroy(c2);
+        });
+    }
     {
         int rc = dp_scan_prepare(ctx, p.k);  // the k-mer position index, when this read set gets one (reuses the histogram)
         if (rc != 0) {
+            if (dl.joinable()) dl.join();
             error = dp_last_error(ctx);
             return rc;
         }
         mark("k-mer position index");
+    }
+    if (dl.joinable()) {
+        dl.join();
+        if (dlRc != 0) {
+            error = dlErr;
+            return dlRc;
+        }
+        mark("values copy (overlapped)");
     }
     errText += "Counting complete. Starting indexing and querying...";
     {
@@ -999,6 +1026,23 @@ int OverlapRun::roundPrepareAndScan() {
     }
     cur.st.t_scan = now() - t1;
     return 1;
+}
+
+int OverlapRun::roundSharded() {
+    if (!comm) {
+        error = "roundSharded without a communicator";
+        return -1;
+    }
+    int rc = roundPrepareAndScan();
+    if (rc <= 0) return rc;
+    ExecSlot& sl = *slots[0];
+    rc = sl.lap->ExchangeSurvivors(comm, gathered_);
+    if (rc != 0) {
+        error = sl.lap->err;
+        return rc;
+    }
+    rc = roundFinish(gathered_);
+    return rc < 0 ? rc : 1;
 }
 
 int OverlapRun::roundFinish(const Survivors& all) {

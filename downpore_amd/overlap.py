@@ -78,6 +78,10 @@ def load_host():
     H.dph_overlap_exec_round.argtypes = [vp, C.c_int64, C.POINTER(C.c_uint64)]
     H.dph_overlap_commit_blobs.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_int]
     H.dph_overlap_done.argtypes = [vp]
+    H.dph_comm_unique_id.argtypes = [C.c_void_p]
+    H.dph_overlap_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
+    H.dph_overlap_comm_init_local.argtypes = [C.c_void_p, C.c_int]
+    H.dph_overlap_round_sharded.argtypes = [vp]
     _host = H
     return H
 
@@ -171,7 +175,7 @@ class OverlapPipeline:
 
     def __init__(self, reads, device=0, k=10, overlap_size=1000, num_seeds=15, seed_batch_size=10000, chunk_size=10000,
                  query_batch_size=20000, min_hits=0.25, himem=True, values=None, rank=0, world=1, torch_device=None,
-                 mode="round", slots=1, query_type=1, defer_init=False):
+                 mode="round", slots=1, query_type=1, defer_init=False, comm=None):
         """mode (world > 1): "round" = pipelined round-parallel (rank r's executor pipeline works on the rounds
         r, r+world, ...; per superstep every rank contributes its next round, results are all-gathered and committed in
         order with the speculation check); "round-batch" = the same exchange with batch-synchronous supersteps (every rank
@@ -181,7 +185,10 @@ class OverlapPipeline:
         per-round buffers; the resident reads are shared).
         defer_init: only create the device context and upload + pack the reads; init() then does what `downpore overlap`
         does before its first round (value table, k-mer position index, executor slots, planner) and reset() returns to
-        this state, so whole jobs can be run - and timed - repeatedly on resident reads."""
+        this state, so whole jobs can be run - and timed - repeatedly on resident reads.
+        comm (scan-shard): "rccl" = the survivor exchange runs inside the library over an RCCL communicator (dp_comm_init; the
+        128-byte id travels through torch.distributed once); "local" = in-process peers wired with link_local(); None = the
+        exchange is done here with torch.distributed on host copies (gloo tests)."""
         self.H = load_host()
         if mode == "scan-shard" and world > 1:
             slots = 1
@@ -197,8 +204,11 @@ class OverlapPipeline:
         self.reads = reads
         self.rank, self.world = rank, world
         self.torch_device = torch_device
-        self.mode = mode if world > 1 else "single"
+        self.mode = mode if (world > 1 or (mode == "scan-shard" and comm is not None)) else "single"
         self._lo_hi = shard_bounds(len(reads), rank, world) if self.mode == "scan-shard" else None
+        self.comm = comm if self.mode == "scan-shard" else None
+        if self.comm == "rccl":
+            self._init_rccl()
         if not defer_init:
             self.init()
 
@@ -218,6 +228,32 @@ class OverlapPipeline:
             self.H.dph_overlap_set_ranks(self.h, rank, world)
         if self.mode == "scan-shard":
             self.H.dph_overlap_set_shard(self.h, *self._lo_hi)
+
+    def _init_rccl(self):
+        """dp_comm_init on this rank's context: rank 0 makes the id, everybody gets it through torch.distributed."""
+        idb = np.zeros(128, dtype=np.uint8)
+        if self.rank == 0:
+            if self.H.dph_comm_unique_id(idb.ctypes.data) != 0:
+                raise DpError("dp_comm_unique_id failed (librccl not loadable?)")
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.from_numpy(idb)
+            if self.torch_device is not None:
+                t = t.to(self.torch_device)
+            dist.broadcast(t, 0)
+            idb = t.cpu().numpy().copy()
+        if self.H.dph_overlap_comm_init(self.h, self.world, self.rank, idb.ctypes.data) != 0:
+            raise self._err()
+
+    @staticmethod
+    def link_local(pipes):
+        """Wires pipelines of ONE process (one per rank, created with mode="scan-shard", comm="local") into an in-process
+        communicator: their survivor exchange then copies device to device between the contexts."""
+        H = pipes[0].H
+        arr = (C.c_void_p * len(pipes))(*[p.h for p in pipes])
+        if H.dph_overlap_comm_init_local(arr, len(pipes)) != 0:
+            raise DpError("dp_comm_init_local failed")
 
     def reset(self):
         """Ends the job (executor slots, planner, value table, k-mer index released; ignore flags cleared); the reads stay
@@ -307,6 +343,11 @@ class OverlapPipeline:
                 raise self._err()
             return c
         # scan-shard
+        if self.comm is not None:  # exchange inside the library (RCCL / in-process peers): one collective call per round
+            rc = self.H.dph_overlap_round_sharded(self.h)
+            if rc < 0:
+                raise self._err()
+            return rc
         rc = self.H.dph_overlap_round_scan(self.h)
         if rc < 0:
             raise self._err()

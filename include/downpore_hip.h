@@ -88,6 +88,9 @@ DP_API int dp_kmer_histogram(dp_ctx* ctx, int k, uint64_t* counts_out);
  * dp_values_upload would have installed) and is copied to values_out (4^k doubles) unless that is NULL.  float64,
  * bit-identical to the host computation. */
 DP_API int dp_kmer_values(dp_ctx* ctx, int k, double* values_out);
+/* The resident table (n = 4^k doubles) copied to the host on the CALLING context's stream - a context that borrows the
+ * reads may do it while the owner goes on with dp_scan_prepare. */
+DP_API int dp_values_download(dp_ctx* ctx, double* values_out, uint64_t n);
 
 /* ---- round state: the seed set --------------------------------------------------------------------------
  * Mirrors the per-round SeedIndex tables kmers/kmerMap/seedMap (seeds/seeds.go:13-18): seed id = position in
@@ -322,6 +325,27 @@ DP_API int dp_fetch_overlaps(dp_ctx* ctx, dp_match_batch* out);
 DP_API int dp_index_posting_row(dp_ctx* ctx, uint32_t seed, uint64_t* words, uint32_t cap_words, uint32_t* n_words,
                          uint32_t* count, uint32_t* start, uint32_t* end);
 DP_API int dp_index_seedset_row(dp_ctx* ctx, uint32_t seq, uint64_t* words, uint32_t cap_words, uint32_t* n_words);
+
+/* ---- multi-GPU: scan sharded by read, survivors all-gathered over xGMI -------------------------------
+ * Ranks own ascending contiguous read ranges [lo, hi) (dp_scan_reads) of the same resident read set; after a round's scan
+ * dp_allgather_survivors concatenates every rank's survivors (read id, hit count, segments) in rank order = file order,
+ * device to device on the context's stream (counts first, then the payloads), and installs the result as the context's
+ * scan output, so that dp_index_build / dp_find_overlaps see what a single GPU scanning every read would hold.  The
+ * `extra` items of dp_scan_reads (the query windows) are scanned by every rank and stay local.
+ *   dp_comm_unique_id + dp_comm_init : one process per GPU; an RCCL communicator (librccl is loaded at run time).  Rank 0
+ *       creates the 128-byte id, the caller hands it to the other ranks by whatever means it has.
+ *   dp_comm_init_local : one process driving n contexts (on n devices, or several on one): peer copies, no RCCL.  Every
+ *       rank calls dp_allgather_survivors from its own host thread; the call is collective. */
+typedef struct dp_comm dp_comm;
+DP_API int dp_comm_unique_id(uint8_t* id_out /* [128] */);
+DP_API int dp_comm_init(dp_ctx* ctx, int n_ranks, int rank, const uint8_t* unique_id /* [128] */, dp_comm** out);
+DP_API int dp_comm_init_local(dp_ctx* const* ctxs, int n, dp_comm** out /* [n] */);
+DP_API void dp_comm_destroy(dp_comm* comm);
+DP_API int dp_comm_rank(const dp_comm* comm);
+DP_API int dp_comm_size(const dp_comm* comm);
+/* `local` = what dp_scan_reads just returned on `ctx`; `all` = the same description of the gathered set (host arrays in
+ * library-owned pinned memory, valid until the next call on this communicator). */
+DP_API int dp_allgather_survivors(dp_comm* comm, dp_ctx* ctx, const dp_survivor_batch* local, dp_survivor_batch* all);
 
 /* Device pointers of the last dp_scan output, for a multi-GPU exchange driven by the caller (RCCL all-gather of
  * the survivors).  segs_dev: int32[n_segs]. */

@@ -298,3 +298,44 @@ def test_round_parallel_protocol_matches_oracle(world, seed, G, N, L, variable):
         pipes[r].close()
     if variable:
         assert rs.ignore().sum() > 0
+
+
+def test_scan_shard_exchange_inside_the_library():
+    """The north-star multi-GPU layout through the C ABI's own entry points: ranks own contiguous read ranges,
+    scan them with the HIP kernels, and dp_allgather_survivors exchanges the survivors device to device (no host hop).  Two
+    in-process ranks on one GPU (dp_comm_init_local), with reads short enough that rounds flag reads as ignored, and the
+    1-rank RCCL communicator (dp_comm_init) on the same job; every rank must print the oracle's PAF."""
+    import threading
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(32, 60000, 500, 1500, 0.0, True)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    want = O.OverlapRun(rs, k=10)
+    world = 2
+    readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
+    pipes = [OverlapPipeline(readsets[r], k=10, rank=r, world=world, mode="scan-shard", comm="local") for r in range(world)]
+    OverlapPipeline.link_local(pipes)
+    errs = []
+
+    def run(p):
+        try:
+            p.run()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(p,)) for p in pipes]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    for r in range(world):
+        d = first_diff(pipes[r].all_paf(), want.paf)
+        assert d is None, (r, d)
+        assert np.array_equal(readsets[r].ignore(), rs.ignore())
+        pipes[r].close()
+    assert want.paf.count("\n") > 100 and rs.ignore().sum() > 0
+    # RCCL flavour, world of one (a 1-GPU box): same entry points, same PAF
+    r1 = Reads(bases, off, min_len=1000)
+    p1 = OverlapPipeline(r1, k=10, rank=0, world=1, mode="scan-shard", comm="rccl")
+    p1.run()
+    assert first_diff(p1.all_paf(), want.paf) is None
+    p1.close()
