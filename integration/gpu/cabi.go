@@ -1,0 +1,391 @@
+// Package gpu is the cgo face of libdownpore_hip.so (include/downpore_hip.h): thin Go wrappers around the C ABI that the
+// GPU-backed overlap.Overlapper (overlap/gpu_overlapper.go) and mapping.Mapper (mapping/gpu_mapper.go) are written against.
+// Every slice handed to C is borrowed for the duration of the call only (the library copies), every result is copied out of
+// the library's pinned buffers before the call returns, so no Go pointer is retained by C and no C pointer by Go.
+//
+// Build: CGO_CFLAGS="-I<repo>/include" CGO_LDFLAGS="-L<repo>/downpore_amd/lib -ldownpore_hip -Wl,-rpath,<repo>/downpore_amd/lib"
+package gpu
+
+/*
+#include <stdlib.h>
+#include "downpore_hip.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"runtime"
+	"unsafe"
+)
+
+// Context owns one HIP stream on one device (dp_ctx).  One goroutine at a time.
+type Context struct {
+	h *C.dp_ctx
+}
+
+func fail(h *C.dp_ctx, what string, rc C.int) error {
+	return errors.New(what + ": " + C.GoString(C.dp_last_error(h)) + " (" + itoa(int(rc)) + ")")
+}
+
+func itoa(v int) string {
+	if v == 0 {
+		return "0"
+	}
+	neg := v < 0
+	if neg {
+		v = -v
+	}
+	var b [24]byte
+	i := len(b)
+	for v > 0 {
+		i--
+		b[i] = byte('0' + v%10)
+		v /= 10
+	}
+	if neg {
+		i--
+		b[i] = '-'
+	}
+	return string(b[i:])
+}
+
+// NewContext creates a context on HIP device `device`.  There is no CPU fallback: without a GPU this fails.
+func NewContext(device int) (*Context, error) {
+	var h *C.dp_ctx
+	if rc := C.dp_ctx_create(C.int(device), &h); rc != 0 {
+		return nil, fail(nil, "dp_ctx_create", rc)
+	}
+	c := &Context{h}
+	runtime.SetFinalizer(c, func(c *Context) { c.Close() })
+	return c, nil
+}
+
+// Shared returns a second context on the same device that borrows this one's resident reads (own stream, own per-round
+// state): one per goroutine that drives rounds concurrently.
+func (c *Context) Shared() (*Context, error) {
+	var h *C.dp_ctx
+	if rc := C.dp_ctx_create_shared(c.h, &h); rc != 0 {
+		return nil, fail(nil, "dp_ctx_create_shared", rc)
+	}
+	return &Context{h}, nil
+}
+
+func (c *Context) Close() {
+	if c.h != nil {
+		C.dp_ctx_destroy(c.h)
+		c.h = nil
+	}
+}
+
+// UploadReads makes the read set resident (2-bit packed on the device): bases = concatenated ASCII, read r = bases[off[r]:off[r+1]].
+func (c *Context) UploadReads(bases []byte, off []int64) error {
+	if len(off) < 1 {
+		return errors.New("UploadReads: empty offset table")
+	}
+	var bp *C.uint8_t
+	if len(bases) > 0 {
+		bp = (*C.uint8_t)(unsafe.Pointer(&bases[0]))
+	}
+	rc := C.dp_reads_upload(c.h, bp, (*C.int64_t)(unsafe.Pointer(&off[0])), C.uint32_t(len(off)-1))
+	if rc != 0 {
+		return fail(c.h, "dp_reads_upload", rc)
+	}
+	return nil
+}
+
+// UploadReadsRC stores every read r >= firstPaired twice: forward, then reverse-complemented (`map` scans both strands).
+func (c *Context) UploadReadsRC(bases []byte, off []int64, firstPaired int) error {
+	var bp *C.uint8_t
+	if len(bases) > 0 {
+		bp = (*C.uint8_t)(unsafe.Pointer(&bases[0]))
+	}
+	rc := C.dp_reads_upload_rc(c.h, bp, (*C.int64_t)(unsafe.Pointer(&off[0])), C.uint32_t(len(off)-1), C.uint32_t(firstPaired))
+	if rc != 0 {
+		return fail(c.h, "dp_reads_upload_rc", rc)
+	}
+	return nil
+}
+
+// KmerValues replaces the "Counting all k-mers ... Counting complete" block of the commands: the value table (4^k float64).
+func (c *Context) KmerValues(k int) ([]float64, error) {
+	out := make([]float64, 1<<uint(2*k))
+	if rc := C.dp_kmer_values(c.h, C.int(k), (*C.double)(unsafe.Pointer(&out[0]))); rc != 0 {
+		return nil, fail(c.h, "dp_kmer_values", rc)
+	}
+	return out, nil
+}
+
+// ScanPrepare does the one-off work of the rounds' scans (the resident k-mer position index from 1 Gbase up).
+func (c *Context) ScanPrepare(k int) error {
+	if rc := C.dp_scan_prepare(c.h, C.int(k)); rc != 0 {
+		return fail(c.h, "dp_scan_prepare", rc)
+	}
+	return nil
+}
+
+// RoundBegin installs the round's seed set: seed id = position in seedKmers (SeedIndex.seedMap).
+func (c *Context) RoundBegin(k int, seedKmers []uint32) error {
+	var p *C.uint32_t
+	if len(seedKmers) > 0 {
+		p = (*C.uint32_t)(unsafe.Pointer(&seedKmers[0]))
+	}
+	if rc := C.dp_round_begin(c.h, C.int(k), p, C.uint32_t(len(seedKmers))); rc != 0 {
+		return fail(c.h, "dp_round_begin", rc)
+	}
+	return nil
+}
+
+// ScanItem is one view the reference's scan examines: k-mer start positions [Start, Start+NKmers) of read Read.
+type ScanItem struct {
+	Read, Start, NKmers, MinSeeds uint32
+}
+
+// Survivors is the outcome of ScanReads: the reads of [lo, hi) with at least minSeeds hits (ascending ids) and the extra
+// items, each with its [gap, seed, ..., gap] segments as ints; SegOff are offsets into the DEVICE-resident scan output, which
+// IndexBuild refers to.
+type Survivors struct {
+	Read       []uint32
+	Segments   [][]int
+	SegOff     []uint64
+	Extra      [][]int
+	ExtraOff   []uint64
+	BasesScanned uint64
+}
+
+func cItems(items []ScanItem) *C.dp_scan_item {
+	if len(items) == 0 {
+		return nil
+	}
+	return (*C.dp_scan_item)(unsafe.Pointer(&items[0])) // same layout: four uint32
+}
+
+func segsOf(segs *C.int32_t, off uint64, nSeeds uint32) []int {
+	n := 2*int(nSeeds) + 1
+	src := unsafe.Slice((*int32)(unsafe.Pointer(segs)), int(off)+n)[int(off):]
+	out := make([]int, n)
+	for i := range out {
+		out[i] = int(src[i])
+	}
+	return out
+}
+
+// ScanReads is AddSequences' scan (overlap.go:217-250) for every read of [lo, hi) whose ignore byte is 0, plus `extra`.
+func (c *Context) ScanReads(ignore []byte, epoch uint64, lo, hi int, topLevel bool, minSeeds int, extra []ScanItem) (*Survivors, error) {
+	var b C.dp_survivor_batch
+	tl := C.int(0)
+	if topLevel {
+		tl = 1
+	}
+	rc := C.dp_scan_reads(c.h, (*C.uint8_t)(unsafe.Pointer(&ignore[0])), C.uint64_t(epoch), C.uint32_t(lo), C.uint32_t(hi), tl,
+		C.uint32_t(minSeeds), cItems(extra), C.uint32_t(len(extra)), &b)
+	if rc != 0 {
+		return nil, fail(c.h, "dp_scan_reads", rc)
+	}
+	s := &Survivors{BasesScanned: uint64(b.bases_scanned)}
+	n := int(b.n_survivors)
+	if n > 0 {
+		reads := unsafe.Slice((*uint32)(unsafe.Pointer(b.read)), n)
+		ns := unsafe.Slice((*uint32)(unsafe.Pointer(b.n_seeds)), n)
+		so := unsafe.Slice((*uint64)(unsafe.Pointer(b.seg_off)), n)
+		s.Read = append(s.Read, reads...)
+		s.SegOff = append(s.SegOff, so...)
+		for i := 0; i < n; i++ {
+			s.Segments = append(s.Segments, segsOf(b.segs, so[i], ns[i]))
+		}
+	}
+	ne := int(b.n_extra)
+	if ne > 0 {
+		ns := unsafe.Slice((*uint32)(unsafe.Pointer(b.extra_n_seeds)), ne)
+		so := unsafe.Slice((*uint64)(unsafe.Pointer(b.extra_seg_off)), ne)
+		s.ExtraOff = append(s.ExtraOff, so...)
+		for i := 0; i < ne; i++ {
+			s.Extra = append(s.Extra, segsOf(b.segs, so[i], ns[i]))
+		}
+	}
+	return s, nil
+}
+
+// Scan is NewSeedSequence for a batch of arbitrary views (the `map` windows and reference chunks).
+func (c *Context) Scan(items []ScanItem) (segments [][]int, segOff []uint64, err error) {
+	var b C.dp_seedseq_batch
+	if rc := C.dp_scan(c.h, cItems(items), C.uint32_t(len(items)), &b); rc != 0 {
+		return nil, nil, fail(c.h, "dp_scan", rc)
+	}
+	n := int(b.n_items)
+	if n == 0 {
+		return nil, nil, nil
+	}
+	ns := unsafe.Slice((*uint32)(unsafe.Pointer(b.n_seeds)), n)
+	so := unsafe.Slice((*uint64)(unsafe.Pointer(b.seg_off)), n+1)
+	for i := 0; i < n; i++ {
+		if so[i+1] == so[i] { // below its min_seeds: nothing written
+			segments = append(segments, nil)
+		} else {
+			segments = append(segments, segsOf(b.segs, so[i], ns[i]))
+		}
+		segOff = append(segOff, so[i])
+	}
+	return segments, segOff, nil
+}
+
+// SeqRef is an indexed sequence: a view into the device-resident scan output.
+type SeqRef struct {
+	SegOff   uint64
+	NSeeds   uint32
+	Reserved uint32
+}
+
+// IndexBuild is AddSequence + IndexSequences (seeds.go:272-305,372-384) for the chunks of a round.
+func (c *Context) IndexBuild(refs []SeqRef) error {
+	var p *C.dp_seq_ref
+	if len(refs) > 0 {
+		p = (*C.dp_seq_ref)(unsafe.Pointer(&refs[0]))
+	}
+	if rc := C.dp_index_build(c.h, p, C.uint32_t(len(refs))); rc != 0 {
+		return fail(c.h, "dp_index_build", rc)
+	}
+	return nil
+}
+
+// Match is one chain: query index, indexed-sequence index, and the matched seed indices on both sides.
+type Match struct {
+	Query, Target  int
+	MatchA, MatchB []int
+}
+
+func ints32(p *C.int32_t, from, to uint64) []int {
+	src := unsafe.Slice((*int32)(unsafe.Pointer(p)), int(to))[int(from):]
+	out := make([]int, len(src))
+	for i, v := range src {
+		out[i] = int(v)
+	}
+	return out
+}
+
+// FindOverlaps is matchWorker (overlap.go:346-387) for all queries of a round; matches come back in canonical order
+// (queries ascending, candidates ascending).  qOff has len(queries)+1 entries into qSegs.
+func (c *Context) FindOverlaps(qSegs []int32, qOff []uint64, hitFraction float64, k, maxQueryLen int) ([]Match, error) {
+	var b C.dp_match_batch
+	var sp *C.int32_t
+	if len(qSegs) > 0 {
+		sp = (*C.int32_t)(unsafe.Pointer(&qSegs[0]))
+	}
+	rc := C.dp_find_overlaps(c.h, sp, (*C.uint64_t)(unsafe.Pointer(&qOff[0])), C.uint32_t(len(qOff)-1), C.double(hitFraction), C.int(k),
+		C.uint32_t(maxQueryLen), 0, &b)
+	if rc != 0 {
+		return nil, fail(c.h, "dp_find_overlaps", rc)
+	}
+	n := int(b.n_matches)
+	out := make([]Match, 0, n)
+	if n == 0 {
+		return out, nil
+	}
+	q := unsafe.Slice((*uint32)(unsafe.Pointer(b.query)), n)
+	t := unsafe.Slice((*uint32)(unsafe.Pointer(b.target)), n)
+	off := unsafe.Slice((*uint64)(unsafe.Pointer(b.off)), n+1)
+	for i := 0; i < n; i++ {
+		out = append(out, Match{Query: int(q[i]), Target: int(t[i]), MatchA: ints32(b.match_a, off[i], off[i+1]), MatchB: ints32(b.match_b, off[i], off[i+1])})
+	}
+	return out, nil
+}
+
+// Chain is one kept chain of performMapping: window index (2i forward, 2i+1 reverse complement), reference chunk, indices.
+type Chain struct {
+	Window, Target int
+	MatchA, MatchB []int
+}
+
+// MapWindows is the core of performMapping (mapping.go:489-589) for a batch of (forward, reverse-complement) window pairs.
+func (c *Context) MapWindows(wSegs []int32, wOff []uint64, wLen []uint32, k int) ([]Chain, error) {
+	var b C.dp_chain_batch
+	var sp *C.int32_t
+	if len(wSegs) > 0 {
+		sp = (*C.int32_t)(unsafe.Pointer(&wSegs[0]))
+	}
+	rc := C.dp_map_windows(c.h, sp, (*C.uint64_t)(unsafe.Pointer(&wOff[0])), (*C.uint32_t)(unsafe.Pointer(&wLen[0])), C.uint32_t(len(wLen)), C.int(k), &b)
+	if rc != 0 {
+		return nil, fail(c.h, "dp_map_windows", rc)
+	}
+	n := int(b.n_chains)
+	out := make([]Chain, 0, n)
+	if n == 0 {
+		return out, nil
+	}
+	w := unsafe.Slice((*uint32)(unsafe.Pointer(b.window)), n)
+	t := unsafe.Slice((*uint32)(unsafe.Pointer(b.target)), n)
+	off := unsafe.Slice((*uint64)(unsafe.Pointer(b.off)), n+1)
+	for i := 0; i < n; i++ {
+		out = append(out, Chain{Window: int(w[i]), Target: int(t[i]), MatchA: ints32(b.match_a, off[i], off[i+1]), MatchB: ints32(b.match_b, off[i], off[i+1])})
+	}
+	return out, nil
+}
+
+// Comm is one rank of a multi-GPU job (dp_comm): RCCL across processes, or in-process peers.
+type Comm struct {
+	h *C.dp_comm
+}
+
+// NewLocalComms wires the contexts of ONE process (one per GPU, each driven by its own goroutine) into a communicator.
+func NewLocalComms(ctxs []*Context) ([]*Comm, error) {
+	hs := make([]*C.dp_ctx, len(ctxs))
+	for i, c := range ctxs {
+		hs[i] = c.h
+	}
+	out := make([]*C.dp_comm, len(ctxs))
+	if rc := C.dp_comm_init_local((**C.dp_ctx)(unsafe.Pointer(&hs[0])), C.int(len(ctxs)), (**C.dp_comm)(unsafe.Pointer(&out[0]))); rc != 0 {
+		return nil, errors.New("dp_comm_init_local failed")
+	}
+	comms := make([]*Comm, len(ctxs))
+	for i := range out {
+		comms[i] = &Comm{out[i]}
+	}
+	return comms, nil
+}
+
+func (m *Comm) Close() {
+	if m.h != nil {
+		C.dp_comm_destroy(m.h)
+		m.h = nil
+	}
+}
+
+// ScanReadsSharded is ScanReads on this rank's read range followed by dp_allgather_survivors: the result describes the
+// survivors of ALL ranks in rank order = file order, and the context's device-resident scan output holds exactly them, so
+// the IndexBuild / FindOverlaps that follow see what a single GPU scanning every read would.  Collective: every rank calls it.
+func (c *Context) ScanReadsSharded(m *Comm, ignore []byte, epoch uint64, lo, hi int, topLevel bool, minSeeds int, extra []ScanItem) (*Survivors, error) {
+	var b, g C.dp_survivor_batch
+	tl := C.int(0)
+	if topLevel {
+		tl = 1
+	}
+	rc := C.dp_scan_reads(c.h, (*C.uint8_t)(unsafe.Pointer(&ignore[0])), C.uint64_t(epoch), C.uint32_t(lo), C.uint32_t(hi), tl,
+		C.uint32_t(minSeeds), cItems(extra), C.uint32_t(len(extra)), &b)
+	if rc != 0 {
+		return nil, fail(c.h, "dp_scan_reads", rc)
+	}
+	if rc = C.dp_allgather_survivors(m.h, c.h, &b, &g); rc != 0 {
+		return nil, fail(c.h, "dp_allgather_survivors", rc)
+	}
+	s := &Survivors{BasesScanned: uint64(g.bases_scanned)}
+	n := int(g.n_survivors)
+	if n > 0 {
+		reads := unsafe.Slice((*uint32)(unsafe.Pointer(g.read)), n)
+		ns := unsafe.Slice((*uint32)(unsafe.Pointer(g.n_seeds)), n)
+		so := unsafe.Slice((*uint64)(unsafe.Pointer(g.seg_off)), n)
+		s.Read = append(s.Read, reads...)
+		s.SegOff = append(s.SegOff, so...)
+		for i := 0; i < n; i++ {
+			s.Segments = append(s.Segments, segsOf(g.segs, so[i], ns[i]))
+		}
+	}
+	ne := int(g.n_extra)
+	if ne > 0 {
+		ns := unsafe.Slice((*uint32)(unsafe.Pointer(g.extra_n_seeds)), ne)
+		so := unsafe.Slice((*uint64)(unsafe.Pointer(g.extra_seg_off)), ne)
+		s.ExtraOff = append(s.ExtraOff, so...)
+		for i := 0; i < ne; i++ {
+			s.Extra = append(s.Extra, segsOf(g.segs, so[i], ns[i]))
+		}
+	}
+	return s, nil
+}
