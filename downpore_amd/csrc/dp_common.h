@@ -46,6 +46,7 @@ struct dp_ctx {
     DevBuf d_len;               // uint32 length in bases                      [n_reads]
     DevBuf d_values;            // 4^k doubles (kmerRanks) for dp_select_seeds; shared like the reads
     uint64_t n_values = 0;
+    DevBuf d_qual, d_qualoff, d_hasq;  // FASTQ quality bytes of the reads (dp_quality_upload); shared like the reads
     DevBuf d_selwin, d_seltop;
     PinBuf h_seltop;
     DevBuf d_cin, d_cout;       // dp_consensus_align

@@ -186,6 +186,9 @@ extern "C" int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out) {
     c->h_len = src->h_len;
     c->d_values = src->d_values;
     c->n_values = src->n_values;
+    c->d_qual = src->d_qual;
+    c->d_qualoff = src->d_qualoff;
+    c->d_hasq = src->d_hasq;
     return DP_OK;
 }
 
@@ -206,7 +209,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     dp_stream_sync(ctx);
-    if (ctx->borrowed_reads) ctx->d_packed.p = ctx->d_boff.p = ctx->d_len.p = ctx->d_values.p = nullptr;
+    if (ctx->borrowed_reads) ctx->d_packed.p = ctx->d_boff.p = ctx->d_len.p = ctx->d_values.p = ctx->d_qual.p = ctx->d_qualoff.p = ctx->d_hasq.p = nullptr;
     if (ctx->owner) ctx->owner->n_borrowers--;
     dp_kindex_free(ctx);
     DevBuf* dbs[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len, &ctx->d_bits, &ctx->d_kmap, &ctx->d_seeds, &ctx->d_items,
@@ -214,7 +217,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
                      &ctx->d_seedsets, &ctx->d_pmeta, &ctx->d_qsegs, &ctx->d_qoff, &ctx->d_qsets, &ctx->d_qmeta,
                      &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched, &ctx->d_ignore, &ctx->d_surv, &ctx->d_values, &ctx->d_selwin, &ctx->d_seltop, &ctx->d_cin, &ctx->d_cout,
                      &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals, &ctx->d_manchor, &ctx->d_seeds_applied,
-                     &ctx->d_pbase, &ctx->d_pspec, &ctx->d_clist, &ctx->d_sa, &ctx->d_sb};
+                     &ctx->d_pbase, &ctx->d_pspec, &ctx->d_clist, &ctx->d_sa, &ctx->d_sb, &ctx->d_qual, &ctx->d_qualoff, &ctx->d_hasq};
     for (auto* b : dbs)
         if (b->p) hipFree(b->p);
     if (ctx->d_kcounts) hipFree(ctx->d_kcounts);
@@ -287,6 +290,12 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
     if (first_paired > n_host) first_paired = n_host;
     hipSetDevice(ctx->device);
     dp_kindex_free(ctx);  // a position index of the previous read set is void
+    for (DevBuf* qb : {&ctx->d_qual, &ctx->d_qualoff, &ctx->d_hasq})  // ... and so are its quality bytes
+        if (qb->p) {
+            hipFree(qb->p);
+            qb->p = nullptr;
+            qb->cap = 0;
+        }
     if (ctx->d_kcounts) {   // ... and so is its k-mer histogram
         hipFree(ctx->d_kcounts);
         ctx->d_kcounts = nullptr;
@@ -437,7 +446,8 @@ __device__ __forceinline__ uint32_t valid_mask(uint64_t g, uint64_t a0, uint64_t
 __global__ __launch_bounds__(64) void select_kernel(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ boff,
                                                     const dp_scan_item* __restrict__ win, uint32_t n, int k, int numSeeds,
                                                     const double* __restrict__ values, uint32_t* __restrict__ top,
-                                                    uint32_t* __restrict__ evald, uint32_t stride) {
+                                                    uint32_t* __restrict__ evald, uint32_t stride, const uint8_t* __restrict__ qual,
+                                                    const int64_t* __restrict__ qoff, const uint8_t* __restrict__ hasq) {
     __shared__ double bestV[64];
     __shared__ uint32_t bestS[64];
     __shared__ double topV[SEL_MAXTOP];
@@ -449,6 +459,8 @@ __global__ __launch_bounds__(64) void select_kernel(const uint8_t* __restrict__ 
     const int64_t L = (int64_t)it.n_kmers;  // window length in bases
     const uint64_t A0 = boff[it.read] * 4 + it.start;
     const int sh = 32 - 2 * k;
+    // FASTQ: the value of a k-mer is weighted by the quality byte of its middle base, q[nextIndex - k/2] (seeds.go:99-101)
+    const uint8_t* q = (qual && hasq[it.read]) ? qual + qoff[it.read] + it.start : nullptr;
     if (lane < numSeeds) {
         topV[lane] = 0.0;
         topN[lane] = 0u;
@@ -472,7 +484,8 @@ __global__ __launch_bounds__(64) void select_kernel(const uint8_t* __restrict__ 
                 const Win wv = load_win(packed, a >> 5);
                 const uint32_t kmer = win_at_rt(wv, (int)(a & 31)) >> sh;
                 if (evald && (uint64_t)(b * k + i) < stride) evald[(uint64_t)w * stride + (uint64_t)(b * k + i)] = kmer;
-                const double v = values[kmer];
+                double v = values[kmer];
+                if (q) v *= (double)q[ni + 1 - k / 2];
                 if (v > bv) {
                     bv = v;
                     bs = kmer;
@@ -505,6 +518,27 @@ __global__ __launch_bounds__(64) void select_kernel(const uint8_t* __restrict__ 
     if (lane < numSeeds) top[(uint64_t)w * (uint32_t)numSeeds + lane] = topN[lane];
 }
 
+// FASTQ quality bytes of the resident reads for the selection kernels: qual[off[r] + p] = (phred byte - 33) of base p of
+// read r (same offsets as the ASCII bases of dp_reads_upload), has_qual[r] = 0 for reads without a usable quality line.
+extern "C" int dp_quality_upload(dp_ctx* ctx, const uint8_t* qual, const int64_t* off, const uint8_t* has_qual, uint32_t n_reads) {
+    if (!ctx || !qual || !off || !has_qual) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_quality_upload: bad arguments") : DP_ERR_ARG;
+    if (ctx->borrowed_reads) return dp_fail(ctx, DP_ERR_STATE, "dp_quality_upload on a borrowing context");
+    if (n_reads != ctx->n_reads) return dp_fail(ctx, DP_ERR_ARG, "dp_quality_upload: read count differs from dp_reads_upload");
+    if (ctx->n_borrowers.load() > 0) return dp_fail(ctx, DP_ERR_STATE, "dp_quality_upload while contexts borrowing these reads exist");
+    hipSetDevice(ctx->device);
+    const size_t nb = (size_t)(off[n_reads] - off[0]);
+    if (dev_reserve(ctx, ctx->d_qual, nb + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_qualoff, ((size_t)n_reads + 1) * 8)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_hasq, (size_t)n_reads + 16)) return DP_ERR_HIP;
+    std::vector<int64_t> rel((size_t)n_reads + 1);
+    for (uint32_t r = 0; r <= n_reads; r++) rel[r] = off[r] - off[0];
+    DP_HIP(hipMemcpyAsync(ctx->d_qual.p, qual + off[0], nb, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->d_qualoff.p, rel.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->d_hasq.p, has_qual, n_reads, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    return DP_OK;
+}
+
 extern "C" int dp_values_upload(dp_ctx* ctx, const double* values, uint64_t n) {
     if (!ctx || !values || n == 0) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_values_upload: bad arguments") : DP_ERR_ARG;
     if (ctx->borrowed_reads) return dp_fail(ctx, DP_ERR_STATE, "dp_values_upload on a borrowing context");
@@ -535,7 +569,8 @@ static int select_impl(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, 
     uint32_t* d_ev = stride ? (uint32_t*)((uint8_t*)ctx->d_seltop.p + tb) : nullptr;
     hipLaunchKernelGGL(select_kernel, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
                        (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_selwin.p, n, k, num_seeds,
-                       (const double*)ctx->d_values.p, (uint32_t*)ctx->d_seltop.p, d_ev, stride);
+                       (const double*)ctx->d_values.p, (uint32_t*)ctx->d_seltop.p, d_ev, stride, (const uint8_t*)ctx->d_qual.p,
+                       (const int64_t*)ctx->d_qualoff.p, (const uint8_t*)ctx->d_hasq.p);
     DP_HIP(hipGetLastError());
     DP_HIP(hipMemcpyAsync((uint8_t*)ctx->h_seltop.p + wb, ctx->d_seltop.p, tb + eb, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));

@@ -33,15 +33,21 @@ struct ReadSet {
     std::vector<std::string> names;
     std::vector<i64> off;          // offsets into bases (n+1)
     std::string bases;             // concatenated ASCII of the kept reads
+    // FASTQ (sequence/seqio.go:106-276): phred byte - 33 per base at the same offsets as `bases` (empty for a FASTA);
+    // hasQual[r] = the record's quality line had exactly the read's length (:229-238), else the read carries none
+    std::string qual;
+    std::vector<uint8_t> hasQual;
+    bool isFastq = false;
+    const uint8_t* quality(size_t r) const { return (!qual.empty() && hasQual[r]) ? (const uint8_t*)qual.data() + off[r] : nullptr; }
     std::vector<uint8_t> ignore;   // SetIgnore flags (seqio.go:375)
     bool himem = true;             // cached views (seqio.go:115) vs top-level re-reads (:158)
     size_t maxNameLen = 0;         // longest name (PAF line buffers are sized from it)
     size_t size() const { return names.size(); }
     i64 length(size_t r) const { return off[r + 1] - off[r]; }
     const char* seq(size_t r) const { return bases.data() + off[r]; }
-    void addLine(const std::string& lastName, const char* line, size_t len, i64 minLen);
+    void addLine(const std::string& lastName, const char* line, size_t len, i64 minLen, const char* qualLine = nullptr, size_t qualLen = 0);
     static bool fromFile(const std::string& path, i64 minLen, bool himem, ReadSet& out, std::string& err);
-    static ReadSet fromArrays(const char* bases, const i64* off, size_t n, i64 minLen, bool himem);
+    static ReadSet fromArrays(const char* bases, const i64* off, size_t n, i64 minLen, bool himem, const char* quals = nullptr);
     // k-mers the reference's scan examines for the view a later pass receives
     i64 scanKmers(size_t r, int k) const;
     // GetInset() of the served view: SubSequence's inset is one too large (sequence.go:365)
@@ -158,7 +164,9 @@ struct SeedIndex {
     void grow();
     void addSeedKmer(uint32_t kmer);                                     // seeds.go:132-141
     void addSeeds(const char* s, i64 len, int minSeeds, const double* ranks);  // AddSeeds :62-156
-    void selectSeeds(const char* s, i64 len, int minSeeds, const double* ranks, uint32_t* topN, bool checkIndex) const;
+    // q (may be null): the window's quality bytes (seq.Quality(), seeds.go:73): value *= q[nextIndex - k/2] (:99-101)
+    void selectSeeds(const char* s, i64 len, int minSeeds, const double* ranks, uint32_t* topN, bool checkIndex,
+                     const uint8_t* q = nullptr) const;
     bool touchesSeed(const char* s, i64 len) const;
     bool touchesSeed(const uint32_t* kmers, uint32_t n) const {  // the same test on the window's evaluated k-mers
         bool hit = false;

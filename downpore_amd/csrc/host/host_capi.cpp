@@ -49,6 +49,10 @@ const char* dph_last_error(void* h) { return h ? ((OverlapH*)h)->err.c_str() : g
 void* dph_reads_from_arrays(const char* bases, const int64_t* off, int64_t n, int64_t minLen, int himem) {
     return new ReadsH{ReadSet::fromArrays(bases, off, (size_t)n, minLen, himem != 0)};
 }
+// bases + raw FASTQ quality characters at the same offsets: the set behaves as if it had been read from a FASTQ file
+void* dph_reads_from_arrays_q(const char* bases, const char* quals, const int64_t* off, int64_t n, int64_t minLen, int himem) {
+    return new ReadsH{ReadSet::fromArrays(bases, off, (size_t)n, minLen, himem != 0, quals)};
+}
 void* dph_reads_from_fasta(const char* path, int64_t minLen, int himem) {
     ReadsH* h = new ReadsH();
     if (!ReadSet::fromFile(path, minLen, himem != 0, h->set, g_err)) {
@@ -68,6 +72,13 @@ const char* dph_reads_dump(void* h, int64_t* n) {
         out += '\t';
         const char* b = s.seq(i);
         for (i64 j = 0; j < s.length(i); j++) out += "ACGT"[baseCode((unsigned char)b[j])];
+        if (const uint8_t* q = s.quality(i)) {  // FASTQ: the stored quality bytes (phred - 33), two hex digits each
+            out += '\t';
+            for (i64 j = 0; j < s.length(i); j++) {
+                out += "0123456789abcdef"[q[j] >> 4];
+                out += "0123456789abcdef"[q[j] & 15];
+            }
+        }
         out += '\n';
     }
     *n = (int64_t)out.size();

@@ -35,7 +35,8 @@ int Overlapper::prepareFromCache(int numSeeds, i64 seedLimit, const double* valu
             const uint32_t *spec = nullptr, *kmers = nullptr;
             if (!cache_->get(w, &spec, &kmers, &err)) return -1;
             if (index_.touchesSeed(kmers, cache_->stride)) {
-                index_.selectSeeds(reads_.seq(win.read) + win.start, win.len, numSeeds, values, tmp.data(), true);
+                const uint8_t* q = reads_.quality(win.read);
+                index_.selectSeeds(reads_.seq(win.read) + win.start, win.len, numSeeds, values, tmp.data(), true, q ? q + win.start : nullptr);
                 index_.commitSeeds(tmp.data(), numSeeds);
                 g_prof.reselected++;
             } else {
@@ -151,7 +152,9 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values
                 const size_t w = first + i;
                 const Sel& c = sel[w];
                 const double tw = g_prof.on ? threadCpuNow() : 0;
-                index_.selectSeeds(reads_.seq(c.read) + c.start, c.len, numSeeds, values, &spec[w * (size_t)numSeeds], false);
+                const uint8_t* q = reads_.quality(c.read);
+                index_.selectSeeds(reads_.seq(c.read) + c.start, c.len, numSeeds, values, &spec[w * (size_t)numSeeds], false,
+                                   q ? q + c.start : nullptr);
                 if (g_prof.on) selUs += (long long)((threadCpuNow() - tw) * 1e6);
             });
             g_prof.selectCpuUs += selUs.load();
@@ -182,7 +185,8 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values
             const Sel& sw = sel[si];
             const char* s = reads_.seq(sw.read) + sw.start;
             if (index_.touchesSeed(s, sw.len)) {  // speculation invalid: redo this window against the current seed set
-                index_.selectSeeds(s, sw.len, numSeeds, values, tmp.data(), true);
+                const uint8_t* q = reads_.quality(sw.read);
+                index_.selectSeeds(s, sw.len, numSeeds, values, tmp.data(), true, q ? q + sw.start : nullptr);
                 index_.commitSeeds(tmp.data(), numSeeds);
             } else {
                 index_.commitSeeds(&spec[si * (size_t)numSeeds], numSeeds);

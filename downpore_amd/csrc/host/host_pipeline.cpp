@@ -508,6 +508,14 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         }
         mark("values copy (overlapped)");
     }
+    if (reads->isFastq && !reads->qual.empty()) {  // FASTQ: the selection kernels weight values by the quality bytes
+        int rc = dp_quality_upload(ctx, (const uint8_t*)reads->qual.data(), reads->off.data(), reads->hasQual.data(), (uint32_t)reads->size());
+        if (rc != 0) {
+            error = dp_last_error(ctx);
+            return rc;
+        }
+        mark("quality upload");
+    }
     errText += "Counting complete. Starting indexing and querying...";
     {
         const char* hostsel = getenv("DP_HOST_SELECT");

@@ -28,7 +28,7 @@ static std::string trimSpace(const std::string& s) {
 
 // `line` is one ReadBytes('\n') result including its last byte; kept iff len(line) >= minLen; the stored sequence
 // drops the last byte (seqio.go:210-219).
-void ReadSet::addLine(const std::string& lastName, const char* line, size_t len, i64 minLen) {
+void ReadSet::addLine(const std::string& lastName, const char* line, size_t len, i64 minLen, const char* qualLine, size_t qualLen) {
     if ((i64)len >= minLen) {
         if (off.empty()) off.push_back(0);
         names.push_back(trimSpace(lastName));
@@ -36,6 +36,18 @@ void ReadSet::addLine(const std::string& lastName, const char* line, size_t len,
         bases.append(line, len - 1);
         off.push_back((i64)bases.size());
         ignore.push_back(0);
+        if (isFastq) {
+            // :229-238 the quality line counts only when it is exactly one byte longer than the sequence; every byte has 33
+            // subtracted as a Go byte (modulo 256)
+            const bool ok = qualLine && qualLen == len;
+            qual.resize(bases.size() - (len - 1), 0);
+            if (ok)
+                for (size_t i = 0; i + 1 < len; i++) qual.push_back((char)(uint8_t)((unsigned char)qualLine[i] - 33));
+            else
+                qual.resize(bases.size(), 0);
+            hasQual.resize(names.size() - 1, 0);
+            hasQual.push_back(ok ? 1 : 0);
+        }
     }
 }
 
@@ -79,31 +91,62 @@ bool ReadSet::fromFile(const std::string& path, i64 minLen, bool himem, ReadSet&
         return true;
     };
     size_t b, e;
-    if (next(b, e) && all[e - 1] == '\n') {  // :191-196 first line is always a name line
+    if (next(b, e) && all[e - 1] == '\n') {  // :191-196 first line is always a name line; '@' makes the file a FASTQ
+        if (all[b] == '@') f.isFastq = true;
         std::string lastName(all + b + 1, e - b - 1);
         while (next(b, e)) {
-            const bool eof = all[e - 1] != '\n';
+            bool eof = all[e - 1] != '\n';
             const unsigned char c = (unsigned char)all[b];
-            if (c >= 'A' && c <= 'T') f.addLine(lastName, all + b, e - b, minLen);
-            else lastName.assign(all + b + 1, e - b - 1);
+            if (c >= 'A' && c <= 'T') {
+                if (f.isFastq) {  // :222-238 / :246-255 the '+' line and the quality line follow, kept read or not
+                    size_t pb = 0, pe = 0, qb = 0, qe = 0;
+                    const bool gotPlus = next(pb, pe);
+                    if (!gotPlus || all[pe - 1] != '\n' || all[pb] != '+') {
+                        err = "Invalid fastq format (on + line):" + (gotPlus ? std::string(all + pb, pe - pb) : std::string());
+                        munmap(m, size);
+                        return false;  // the reference calls log.Fatal
+                    }
+                    const bool gotQual = next(qb, qe);
+                    f.addLine(lastName, all + b, e - b, minLen, gotQual ? all + qb : nullptr, gotQual ? qe - qb : 0);
+                    eof = false;  // the loop's `err` is the '+' line's from here on (:224), and that line was complete
+                } else {
+                    f.addLine(lastName, all + b, e - b, minLen);
+                }
+            } else if (c == '@') {
+                f.isFastq = true;
+                lastName.assign(all + b + 1, e - b - 1);
+            } else {
+                lastName.assign(all + b + 1, e - b - 1);
+            }
             if (eof) break;
         }
+    }
+    if (f.isFastq) {  // reads kept before the first '@' line was seen (none in a well-formed file) carry no quality
+        f.qual.resize(f.bases.size(), 0);
+        f.hasQual.resize(f.names.size(), 0);
     }
     munmap(m, size);
     return true;
 }
 
-ReadSet ReadSet::fromArrays(const char* bases, const i64* off, size_t n, i64 minLen, bool himem) {
+ReadSet ReadSet::fromArrays(const char* bases, const i64* off, size_t n, i64 minLen, bool himem, const char* quals) {
     ReadSet f;
     f.himem = himem;
+    f.isFastq = quals != nullptr;
     f.off.push_back(0);
     char nm[32];
-    std::string line;
+    std::string line, ql;
     for (size_t i = 0; i < n; i++) {
         snprintf(nm, sizeof nm, "r%07zu\n", i);
         line.assign(bases + off[i], (size_t)(off[i + 1] - off[i]));
         line.push_back('\n');
-        f.addLine(nm, line.data(), line.size(), minLen);
+        if (quals) {
+            ql.assign(quals + off[i], (size_t)(off[i + 1] - off[i]));
+            ql.push_back('\n');
+            f.addLine(nm, line.data(), line.size(), minLen, ql.data(), ql.size());
+        } else {
+            f.addLine(nm, line.data(), line.size(), minLen);
+        }
     }
     return f;
 }
@@ -259,7 +302,7 @@ int32_t SeedIndex::seedOfRcKmer(int32_t seed) const {
 // selectSeeds() is the selection loop; with checkIndex=false it assumes no evaluated k-mer is a seed yet (the
 // speculative, thread-parallel form used by Overlapper::PrepareQueries), touchesSeed() tests exactly that assumption.
 template <bool CHECK>
-static void selectSeedsT(const SeedIndex& ix, const char* s, i64 L, int minSeeds, const double* ranks, uint32_t* topN) {
+static void selectSeedsT(const SeedIndex& ix, const char* s, i64 L, int minSeeds, const double* ranks, uint32_t* topN, const uint8_t* q) {
     const int k = ix.k;
     const uint32_t mask = (uint32_t)(((uint64_t)1 << (2 * k)) - 1);
     double topVbuf[64];
@@ -298,7 +341,8 @@ static void selectSeedsT(const SeedIndex& ix, const char* s, i64 L, int minSeeds
                 reset = true;
                 break;
             }
-            const double value = ranks[kmer];
+            double value = ranks[kmer];
+            if (q) value *= (double)q[nextIndex - k / 2];  // seeds.go:99-101
             if (value > bestValue) {
                 bestValue = value;
                 bestSeed = kmer;
@@ -323,9 +367,10 @@ static void selectSeedsT(const SeedIndex& ix, const char* s, i64 L, int minSeeds
     }
 }
 
-void SeedIndex::selectSeeds(const char* s, i64 L, int minSeeds, const double* ranks, uint32_t* topN, bool checkIndex) const {
-    if (checkIndex) selectSeedsT<true>(*this, s, L, minSeeds, ranks, topN);
-    else selectSeedsT<false>(*this, s, L, minSeeds, ranks, topN);
+void SeedIndex::selectSeeds(const char* s, i64 L, int minSeeds, const double* ranks, uint32_t* topN, bool checkIndex,
+                            const uint8_t* q) const {
+    if (checkIndex) selectSeedsT<true>(*this, s, L, minSeeds, ranks, topN, q);
+    else selectSeedsT<false>(*this, s, L, minSeeds, ranks, topN, q);
 }
 
 // true iff one of the k-mers AddSeeds would evaluate (with no reset so far) is already a seed

@@ -38,6 +38,8 @@ def load_host():
     H.dph_last_error.argtypes = [vp]
     H.dph_reads_from_arrays.restype = vp
     H.dph_reads_from_arrays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+    H.dph_reads_from_arrays_q.restype = vp
+    H.dph_reads_from_arrays_q.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int]
     H.dph_reads_from_fasta.restype = vp
     H.dph_reads_from_fasta.argtypes = [C.c_char_p, C.c_int64, C.c_int]
     H.dph_reads_free.argtypes = [vp]
@@ -143,7 +145,8 @@ def allgather_bytes(blob, world, device=None):
 
 
 class Reads:
-    def __init__(self, bases=None, off=None, min_len=1000, himem=True, fasta=None):
+    def __init__(self, bases=None, off=None, min_len=1000, himem=True, fasta=None, quals=None):
+        """fasta: a FASTA or FASTQ file (one line per read).  quals: raw FASTQ quality characters at the offsets of bases."""
         H = load_host()
         if fasta is not None:
             self.h = H.dph_reads_from_fasta(fasta.encode(), min_len, 1 if himem else 0)
@@ -152,7 +155,11 @@ class Reads:
         else:
             b = np.ascontiguousarray(bases, dtype=np.uint8)
             o = np.ascontiguousarray(off, dtype=np.int64)
-            self.h = H.dph_reads_from_arrays(b.ctypes.data, o.ctypes.data, len(o) - 1, min_len, 1 if himem else 0)
+            if quals is not None:
+                q = np.ascontiguousarray(quals, dtype=np.uint8)
+                self.h = H.dph_reads_from_arrays_q(b.ctypes.data, q.ctypes.data, o.ctypes.data, len(o) - 1, min_len, 1 if himem else 0)
+            else:
+                self.h = H.dph_reads_from_arrays(b.ctypes.data, o.ctypes.data, len(o) - 1, min_len, 1 if himem else 0)
         self.H = H
 
     def __len__(self):

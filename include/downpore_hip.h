@@ -175,6 +175,12 @@ DP_API int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epo
  * reference).  win[i].read/start/n_kmers describe the window (n_kmers = window length in BASES here); min_seeds is
  * ignored.  num_seeds <= 64. */
 DP_API int dp_values_upload(dp_ctx* ctx, const double* values, uint64_t n);
+/* FASTQ input: AddSeeds weights a k-mer's value by the quality byte of its middle base, value *= q[nextIndex - k/2]
+ * (seeds.go:99-101; the bytes are phred - 33 as sequence/seqio.go:169-173,231-236 stores them).  qual[off[r] + p] belongs
+ * to base p of read r (the offsets of dp_reads_upload), has_qual[r] = 0 marks reads whose record had no usable quality
+ * line.  After this call dp_select_seeds / dp_select_windows apply the weight; contexts created with dp_ctx_create_shared
+ * AFTERWARDS share the bytes. */
+DP_API int dp_quality_upload(dp_ctx* ctx, const uint8_t* qual, const int64_t* off, const uint8_t* has_qual, uint32_t n_reads);
 DP_API int dp_select_seeds(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out);
 /* dp_select_seeds that also hands back every k-mer the selection loop evaluated, `stride` slots per window (slot = block *
  * k + position inside the block; unused slots are 0xffffffff): exactly the k-mers AddSeeds tests against the seed set

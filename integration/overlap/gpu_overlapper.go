@@ -206,3 +206,13 @@ func (lap *gpuOverlapper) FindOverlaps(queries []*SeedQuery) <-chan *seeds.SeedM
 	}()
 	return output
 }
+
+// KmerValues replaces getKmerValues (commands/overlap.go:39-94) when no seed_values file is given: KmerOccurrences, the
+// value per k-mer, the forward + reverse-complement merge and the top-1 % cut, all on the device; bit-identical table.
+func (g *GPUReads) KmerValues(k int) []float64 {
+	v, err := g.ctx.KmerValues(k)
+	if err != nil {
+		log.Fatal(err)
+	}
+	return v
+}

@@ -166,7 +166,13 @@ struct ReadSetH {
     FastaSet set;
 };
 void* dpo_reads_from_fasta(const char* path, int64_t minLen, int himem) {
-    return new ReadSetH{FastaSet::fromFile(path, minLen, himem != 0)};
+    ReadSetH* h = new ReadSetH{FastaSet::fromFile(path, minLen, himem != 0)};
+    if (!h->set.error.empty()) {  // the reference's log.Fatal
+        g_err = h->set.error;
+        delete h;
+        return nullptr;
+    }
+    return h;
 }
 // concatenated ASCII reads + offsets (n+1)
 void* dpo_reads_from_arrays(const char* bases, const int64_t* off, int64_t n, int64_t minLen, int himem) {
@@ -179,6 +185,20 @@ void* dpo_reads_from_arrays(const char* bases, const int64_t* off, int64_t n, in
     }
     return new ReadSetH{FastaSet::fromReads(names, seqs, minLen, himem != 0)};
 }
+// the same with a quality string per read (raw FASTQ bytes, same offsets as the bases): the set behaves as if read from a FASTQ
+void* dpo_reads_from_arrays_q(const char* bases, const char* quals, const int64_t* off, int64_t n, int64_t minLen, int himem) {
+    std::vector<std::string> names, seqs, qs;
+    char nm[32];
+    for (int64_t i = 0; i < n; i++) {
+        snprintf(nm, sizeof nm, "r%07lld", (long long)i);
+        names.push_back(nm);
+        seqs.emplace_back(bases + off[i], (size_t)(off[i + 1] - off[i]));
+        qs.emplace_back(quals + off[i], (size_t)(off[i + 1] - off[i]));
+    }
+    ReadSetH* h = new ReadSetH{FastaSet::fromReads(names, seqs, minLen, himem != 0, &qs)};
+    h->set.isFastq = true;
+    return h;
+}
 void dpo_reads_free(void* h) { delete (ReadSetH*)h; }
 // "name\tACGT...\n" per read (the 2-bit content spelled back): lets tests compare FASTA readers
 const char* dpo_reads_dump(void* h, int64_t* n) {
@@ -189,6 +209,15 @@ const char* dpo_reads_dump(void* h, int64_t* n) {
         out += s.names[i];
         out += '\t';
         out += s.cached[i].str();
+        if (s.cached[i].qual) {  // FASTQ: the stored quality bytes (phred - 33), two hex digits each
+            out += '\t';
+            const PackedSeq& c = s.cached[i];
+            for (i64 j = 0; j < c.length; j++) {
+                const uint8_t q = (*c.qual)[c.qlo + (size_t)j];
+                out += "0123456789abcdef"[q >> 4];
+                out += "0123456789abcdef"[q & 15];
+            }
+        }
         out += '\n';
     }
     *n = (int64_t)out.size();

@@ -62,6 +62,10 @@ int main(int argc, char** argv) {
             p.minHits = atof(args["min_hits"].c_str());
             p.himem = parseBool(args["himem"]);
             FastaSet set = FastaSet::fromFile(args["input"], p.overlapSize, p.himem);
+            if (!set.error.empty()) {
+                fprintf(stderr, "%s\n", set.error.c_str());
+                return 1;
+            }
             OverlapResult r = runOverlap(set, p, nullptr, atoll(args["max_rounds"].c_str()), false);
             fputs(r.err.c_str(), stderr);
             fwrite(r.paf.data(), 1, r.paf.size(), stdout);
@@ -75,6 +79,10 @@ int main(int argc, char** argv) {
             p.seedRate = atoll(args["seed_rate"].c_str());
             FastaSet ref = FastaSet::fromFile(args["reference"], 0, false);
             FastaSet reads = FastaSet::fromFile(args["input"], p.minLength, false);
+            if (!ref.error.empty() || !reads.error.empty()) {
+                fprintf(stderr, "%s\n", (ref.error + reads.error).c_str());
+                return 1;
+            }
             MapResult r = runMap(ref, reads, p);
             fputs(r.err.c_str(), stderr);
             fwrite(r.paf.data(), 1, r.paf.size(), stdout);

@@ -53,6 +53,10 @@ struct PackedSeq {
     std::shared_ptr<std::string> name;          // nil => decimal id
     i64 length = 0;
     int firstLen = 4, finalLen = 0;
+    // FASTQ quality (phred byte - 33, sequence/seqio.go:169-173,231-236); nil unless the record's quality line had exactly
+    // the sequence's length.  A view shares its parent's array (sequence.go:366-368): quality of base i = (*qual)[qlo + i].
+    std::shared_ptr<std::vector<uint8_t>> qual;
+    size_t qlo = 0;
 
     size_t nbytes() const { return hi - lo; }
     const uint8_t* data() const { return buf->data() + lo; }
@@ -193,7 +197,7 @@ SeedSequence* multiAlignerConsensus(Arena& a, std::vector<SeedSequence*>& seqs, 
                                     std::vector<std::unique_ptr<SeedMatch>>& matchesOut);
 
 // ---------------------------------------------------------------------------------------------
-// sequence/seqio.go fastaSequenceSet (FASTA, single line per read; FASTQ quality is out of scope)
+// sequence/seqio.go fastaSequenceSet (FASTA / FASTQ, one line per read)
 struct FastaSet {
     std::vector<PackedSeq> cached;      // top-level sequences in file order
     std::vector<uint8_t> ignore;
@@ -203,8 +207,11 @@ struct FastaSet {
     i64 bases = 0;
     static FastaSet fromFile(const std::string& path, i64 minLen, bool himem);        // readFasta :106
     static FastaSet fromReads(const std::vector<std::string>& names, const std::vector<std::string>& seqs,
-                              i64 minLen, bool himem);
-    void addLine(const std::string& lastName, const std::string& line, i64 minLen);
+                              i64 minLen, bool himem, const std::vector<std::string>* quals = nullptr);
+    // qualLine (FASTQ): the record's quality line as ReadBytes returned it, or nullptr
+    void addLine(const std::string& lastName, const std::string& line, i64 minLen, const std::string* qualLine = nullptr);
+    bool isFastq = false;
+    std::string error;  // "Invalid fastq format ..." (the reference calls log.Fatal)
     // the sequence object a later pass would receive (:115 cached view, or :158 top-level re-read)
     PackedSeq served(size_t id) const;
     size_t size() const { return cached.size(); }

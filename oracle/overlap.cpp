@@ -28,7 +28,7 @@ static std::string trimSpace(const std::string& s) {  // strings.TrimSpace
 }
 
 // One line as bufio.ReadBytes('\n') returns it (including the '\n' when present).
-void FastaSet::addLine(const std::string& lastName, const std::string& line, i64 minLen) {
+void FastaSet::addLine(const std::string& lastName, const std::string& line, i64 minLen, const std::string* qualLine) {
     // :209-245: a line is a sequence iff its first byte is in ['A','T']; kept iff len(line) >= minLen;
     // the stored sequence is line[:len-1] (the last byte is dropped whether or not it is '\n').
     if ((i64)line.size() >= minLen) {
@@ -38,6 +38,14 @@ void FastaSet::addLine(const std::string& lastName, const std::string& line, i64
         names.push_back(trimSpace(lastName));
         auto nm = std::make_shared<std::string>(names.back());
         cached.push_back(newPackedSequence((i64)id, line.substr(0, line.size() - 1), nm));
+        // :229-238 the quality line counts only when it is exactly one byte longer than the sequence (its '\n'); every
+        // byte has 33 subtracted (as a Go byte: modulo 256)
+        if (qualLine && qualLine->size() == line.size()) {
+            auto q = std::make_shared<std::vector<uint8_t>>(line.size() - 1);
+            for (size_t i = 0; i + 1 < line.size(); i++) (*q)[i] = (uint8_t)((unsigned char)(*qualLine)[i] - 33);
+            cached.back().qual = q;
+            cached.back().qlo = 0;
+        }
         bases += (i64)line.size() - 1;
     }
 }
@@ -67,17 +75,34 @@ FastaSet FastaSet::fromFile(const std::string& path, i64 minLen, bool himem) {
         return true;
     };
     std::string line, lastName;
-    // :191-204 the first line is always consumed as a name/comment line
+    // :191-204 the first line is always consumed as a name/comment line; '@' makes the file a FASTQ
     if (!readLine(line)) return f;
     if (line.back() != '\n') return f;  // ReadBytes error (EOF before delimiter) => nothing read
+    if (line[0] == '@') f.isFastq = true;
     lastName = line.substr(1);
     while (readLine(line)) {  // :208-267
         bool eof = line.back() != '\n';
         unsigned char c = (unsigned char)line[0];
         if (c >= 'A' && c <= 'T') {
-            f.addLine(lastName, line, minLen);
+            if (f.isFastq) {  // :222-238 (kept) / :246-255 (skipped): the '+' line and the quality line follow
+                std::string plus, qual;
+                const bool gotPlus = readLine(plus);
+                if (!gotPlus || plus.back() != '\n' || plus[0] != '+') {
+                    // err != nil || buf[0] != plus -> log.Fatal
+                    f.error = "Invalid fastq format (on + line):" + plus;
+                    return f;
+                }
+                const bool gotQual = readLine(qual);  // (its error is discarded)
+                f.addLine(lastName, line, minLen, gotQual ? &qual : nullptr);
+                eof = false;  // `err` is the '+' line's from here on (:224 reassigns it), and that one ended with '\n'
+            } else {
+                f.addLine(lastName, line, minLen);
+            }
+        } else if (c == '@') {
+            f.isFastq = true;
+            lastName = line.substr(1);
         } else {
-            lastName = line.substr(1);  // '@' (fastq) is out of scope here
+            lastName = line.substr(1);
         }
         if (eof) break;
     }
@@ -85,10 +110,17 @@ FastaSet FastaSet::fromFile(const std::string& path, i64 minLen, bool himem) {
 }
 
 FastaSet FastaSet::fromReads(const std::vector<std::string>& names, const std::vector<std::string>& seqs, i64 minLen,
-                             bool himem) {
+                             bool himem, const std::vector<std::string>* quals) {
     FastaSet f;
     f.himem = himem;
-    for (size_t i = 0; i < seqs.size(); i++) f.addLine(names[i] + "\n", seqs[i] + "\n", minLen);
+    for (size_t i = 0; i < seqs.size(); i++) {
+        if (quals) {
+            const std::string q = (*quals)[i] + "\n";
+            f.addLine(names[i] + "\n", seqs[i] + "\n", minLen, &q);
+        } else {
+            f.addLine(names[i] + "\n", seqs[i] + "\n", minLen);
+        }
+    }
     return f;
 }
 

@@ -113,6 +113,10 @@ PackedSeq PackedSeq::subSequence(i64 start, i64 end) const {
     ss.firstLen = (int)(4 - off);
     ss.finalLen = (int)(in + 1);
     ss.length = end - start + 1;
+    if (qual) {  // :366-368 quality[start : end+1]
+        ss.qual = qual;
+        ss.qlo = qlo + (size_t)start;
+    }
     return ss;
 }
 
@@ -136,6 +140,12 @@ PackedSeq PackedSeq::reverseComplement() const {
     rc.finalLen = firstLen;
     rc.name = name;
     rc.length = length;
+    if (qual) {  // :188-195 reversed copy
+        auto q = std::make_shared<std::vector<uint8_t>>((size_t)length);
+        for (i64 i = 0; i < length; i++) (*q)[(size_t)(length - 1 - i)] = (*qual)[qlo + (size_t)i];
+        rc.qual = q;
+        rc.qlo = 0;
+    }
     return rc;
 }
 

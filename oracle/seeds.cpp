@@ -64,7 +64,7 @@ void SeedIndex::addSeedKmer(i64 kmer) {  // :132-141
     }
 }
 
-// seeds/seeds.go:62-156 (FASTA only: quality == nil)
+// seeds/seeds.go:62-156
 void SeedIndex::addSeeds(const PackedSeq& seq, i64 minSeeds, const double* ranks) {
     int k = seedSize;
     i64 mask = ((i64)1 << (2 * k)) - 1;
@@ -88,6 +88,7 @@ void SeedIndex::addSeeds(const PackedSeq& seq, i64 minSeeds, const double* ranks
                     break;
                 }
                 double value = ranks[kmer];
+                if (seq.qual) value *= (double)(*seq.qual)[seq.qlo + (size_t)(nextIndex - k / 2)];  // :99-101
                 if (value > bestValue) {
                     bestValue = value;
                     bestSeed = kmer;

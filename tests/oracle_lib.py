@@ -90,6 +90,8 @@ def lib():
         L.dpo_reads_from_fasta.argtypes = [C.c_char_p, C.c_int64, C.c_int]
         L.dpo_reads_from_arrays.restype = vp
         L.dpo_reads_from_arrays.argtypes = [C.c_char_p, i64p, C.c_int64, C.c_int64, C.c_int]
+        L.dpo_reads_from_arrays_q.restype = vp
+        L.dpo_reads_from_arrays_q.argtypes = [C.c_char_p, C.c_char_p, i64p, C.c_int64, C.c_int64, C.c_int]
         L.dpo_reads_free.argtypes = [vp]
         L.dpo_reads_count.restype = C.c_int64
         L.dpo_reads_count.argtypes = [vp]
@@ -144,6 +146,16 @@ def gen_reads(seed, G, N, L, e=0.0, variable=False):
 def gen_genome(seed, G):
     from tools.synth import gen_genome as _g
     return _g(seed, G)
+
+
+def write_fastq(path, bases, off, quals, prefix="r"):
+    with open(path, "wb") as f:
+        for i in range(len(off) - 1):
+            f.write(b"@%s%07d\n" % (prefix.encode(), i))
+            f.write(bases[off[i]:off[i + 1]].tobytes())
+            f.write(b"\n+\n")
+            f.write(quals[off[i]:off[i + 1]].tobytes())
+            f.write(b"\n")
 
 
 def write_fasta(path, bases, off, prefix="r"):
@@ -313,14 +325,22 @@ def match(seq_seg, q_seg, min_match, k):
 
 
 class ReadSet:
-    def __init__(self, bases=None, off=None, min_len=0, himem=True, fasta=None):
+    def __init__(self, bases=None, off=None, min_len=0, himem=True, fasta=None, quals=None):
+        """quals: raw FASTQ quality characters (uint8, same offsets as bases): the set then behaves like a FASTQ file's."""
         if fasta is not None:
             self.h = lib().dpo_reads_from_fasta(fasta.encode(), min_len, 1 if himem else 0)
+            if not self.h:
+                raise RuntimeError(lib().dpo_last_error().decode())
         else:
             b = np.ascontiguousarray(bases, dtype=np.uint8)
             o = np.ascontiguousarray(off, dtype=np.int64)
-            self.h = lib().dpo_reads_from_arrays(b.ctypes.data_as(C.c_char_p), ptr(o, i64p), len(o) - 1, min_len,
-                                                 1 if himem else 0)
+            if quals is not None:
+                q = np.ascontiguousarray(quals, dtype=np.uint8)
+                self.h = lib().dpo_reads_from_arrays_q(b.ctypes.data_as(C.c_char_p), q.ctypes.data_as(C.c_char_p), ptr(o, i64p),
+                                                       len(o) - 1, min_len, 1 if himem else 0)
+            else:
+                self.h = lib().dpo_reads_from_arrays(b.ctypes.data_as(C.c_char_p), ptr(o, i64p), len(o) - 1, min_len,
+                                                     1 if himem else 0)
 
     def __len__(self):
         return lib().dpo_reads_count(self.h)

@@ -20,6 +20,16 @@ CASES = {
     "header_with_spaces": b">  r1  extra \nACGTACGTACGT\n>\tr2\t\nGGGGCCCCAAAA\n",
     "short_and_long": b">a\nACG\n>b\nACGTACGTACGTACGTACGTACGTACGTACGT\n>c\nA\n>d\nTTTTTTTTTTTTTTTTTTTTTTTTT\n",
     "fastq_like": b"@r1\nACGTACGTAC\n+\nIIIIIIIIII\n@r2\nTTTTGGGGCC\n+\nFFFFFFFFFF\n",
+    # FASTQ (sequence/seqio.go:208-267): '+' and quality lines are consumed with their record, kept read or not; a quality
+    # line counts only when it is exactly one byte longer than the sequence; the bytes are stored minus 33 (modulo 256)
+    "fastq_last_quality_without_newline": b"@r1\nACGTACGTAC\n+\nIIIIIIIIII\n@r2\nTTTTGGGGCC\n+\nFFFFFFFFFF",
+    "fastq_quality_length_mismatch": b"@r1\nACGTACGTAC\n+\nIIII\n@r2\nTTTTGGGGCC\n+r2 again\nFFFFFFFFFFFF\n@r3\nGGGGGGGGGGGG\n+\n!!!!!!!!!!!!\n",
+    "fastq_quality_starts_like_other_lines": b"@r1\nACGTACGTAC\n+\n@AT+>AT@+>\n@r2\nTTTTGGGGCC\n+\nACGTACGTAC\n",
+    "fastq_short_reads_skipped": b"@a\nACG\n+\nIII\n@b\nACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIII\n@c\nAC\n+\nII\n",
+    "fastq_low_bytes_wrap": b"@r1\nACGTACGTAC\n+\n \x01\x02!\"#$%&~\n",
+    "fastq_after_fasta_records": b">r1\nACGTACGTAC\n@r2\nTTTTGGGGCC\n+\nFFFFFFFFFF\n",
+    "fastq_truncated_after_sequence": b"@r1\nACGTACGTAC\n+\nIIIIIIIIII\n@r2\nTTTTGGGGCC\n",
+    "fastq_bad_plus_line": b"@r1\nACGTACGTAC\nIIIIIIIIII\n@r2\nTTTTGGGGCC\n+\nFFFFFFFFFF\n",
 }
 
 
@@ -39,7 +49,13 @@ def test_fasta_reader_matches_oracle(tmp_path, name, min_len):
     path = str(tmp_path / (name + ".fa"))
     with open(path, "wb") as f:
         f.write(CASES[name])
-    want_set = O.ReadSet(fasta=path, min_len=min_len)
+    try:
+        want_set = O.ReadSet(fasta=path, min_len=min_len)
+    except RuntimeError as e:  # the reference calls log.Fatal("Invalid fastq format ...")
+        assert "Invalid fastq" in str(e)
+        with pytest.raises(Exception, match="Invalid fastq"):
+            Reads(fasta=path, min_len=min_len)
+        return
     got_set = Reads(fasta=path, min_len=min_len)
     want = _dump(O.lib().dpo_reads_dump, want_set.h)
     got = _dump(H.dph_reads_dump, got_set.h)

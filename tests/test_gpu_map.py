@@ -80,3 +80,22 @@ def test_map_cli_matches_oracle_cli(tmp_path):
     assert first_diff(a.stdout.decode(), b.stdout.decode()) is None and a.stdout.count(b"\n") > 60
     c = subprocess.run([prod, "map", "-i", reads_fa, "-r", ref_fa, "-k", "11"], capture_output=True, check=True)
     assert first_diff(c.stdout.decode(), a.stdout.decode()) is None
+
+
+def test_map_cli_fastq_reads(tmp_path):
+    """`map` with the reads in a FASTQ file (qualities play no part in mapping, the parser does): product CLI == oracle CLI."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    G = 120000
+    genome = np.frombuffer(O.gen_genome(18, G), dtype=np.uint8)
+    bases, off = O.gen_reads(18, G, 100, 5000, 0.04, True)
+    quals = np.random.default_rng(2).integers(33, 74, len(bases)).astype(np.uint8)
+    ref_fa, reads_fq = str(tmp_path / "ref.fa"), str(tmp_path / "reads.fq")
+    O.write_fasta(ref_fa, genome, np.array([0, G], dtype=np.int64), prefix="chr")
+    O.write_fastq(reads_fq, bases, off, quals)
+    prod = os.path.join(root, "downpore_amd", "bin", "downpore")
+    orac = os.path.join(root, "oracle", "_build", "dp_oracle")
+    a = subprocess.run([prod, "map", "-input", reads_fq, "-reference", ref_fa], capture_output=True, check=True)
+    b = subprocess.run([orac, "map", "-input", reads_fq, "-reference", ref_fa], capture_output=True, check=True)
+    assert first_diff(a.stdout.decode(), b.stdout.decode()) is None and a.stdout.count(b"\n") > 50

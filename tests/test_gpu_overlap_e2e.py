@@ -339,3 +339,46 @@ def test_scan_shard_exchange_inside_the_library():
     p1.run()
     assert first_diff(p1.all_paf(), want.paf) is None
     p1.close()
+
+
+def _fastq_quals(bases, seed):
+    """Quality characters with structure: low-quality stretches, so that the weighting changes which k-mers win."""
+    rng = np.random.default_rng(seed)
+    q = rng.integers(35, 74, len(bases)).astype(np.uint8)  # '#'..'I'
+    for _ in range(len(bases) // 700):
+        a = int(rng.integers(0, max(1, len(bases) - 300)))
+        q[a:a + int(rng.integers(20, 300))] = 33 + int(rng.integers(0, 4))  # phred 0..3
+    return q
+
+
+def test_overlap_fastq_quality_weighted_seeds(tmp_path, monkeypatch):
+    """FASTQ input: AddSeeds weights every k-mer's value by the quality byte of its middle base
+    (seeds/seeds.go:99-101).  The oracle and the product (device selection through the window cache, host re-selection of
+    touched windows; and the per-plan dp_select_seeds path) must print the same PAF - and a different one than without
+    qualities, or the test would prove nothing."""
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(77, 90000, 300, 4000, 0.0, True)
+    quals = _fastq_quals(bases, 5)
+    rs = O.ReadSet(bases, off, min_len=1000, quals=quals)
+    want = O.OverlapRun(rs, k=10)
+    plain = O.OverlapRun(O.ReadSet(bases, off, min_len=1000), k=10)
+    assert want.paf != plain.paf and want.paf.count("\n") > 200
+    for cache in ("1", "0"):
+        monkeypatch.setenv("DP_WINDOW_CACHE", cache)
+        reads = Reads(bases, off, min_len=1000, quals=quals)
+        pipe = OverlapPipeline(reads, k=10, slots=3)
+        pipe.run()
+        d = first_diff(pipe.all_paf(), want.paf)
+        assert d is None, (cache, d)
+        assert np.array_equal(reads.ignore(), rs.ignore())
+        pipe.close()
+    monkeypatch.delenv("DP_WINDOW_CACHE")
+    # the same through the FASTQ reader and the CLI of both sides
+    fq = str(tmp_path / "reads.fq")
+    O.write_fastq(fq, bases, off, quals)
+    a = subprocess.run([os.path.join(ROOT, "downpore_amd", "bin", "downpore"), "overlap", "-input", fq, "-k", "10"],
+                       capture_output=True, check=True)
+    b = subprocess.run([os.path.join(ROOT, "oracle", "_build", "dp_oracle"), "overlap", "-input", fq, "-k", "10"],
+                       capture_output=True, check=True)
+    assert first_diff(a.stdout.decode(), b.stdout.decode()) is None
+    assert first_diff(a.stdout.decode(), want.paf) is None
