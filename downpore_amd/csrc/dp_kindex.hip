@@ -357,11 +357,14 @@ __global__ __launch_bounds__(KX_TILE) void kidx_offsets(const dp_scan_item* __re
 
 // one wave per survivor: its slice holds c unordered (position, seed) pairs -> sorted by position -> [gap, seed, ..., gap]
 #define KX_SORT_LDS 4096
+// CAP = keys the block's LDS holds (the launch picks the smallest that fits the round's largest survivor: a CU then holds
+// eight times as many waves for the usual few dozen hits per read as for the rare thousands)
+template <int CAP>
 __global__ __launch_bounds__(64) void kidx_sortwrite(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ sel,
                                                      const uint32_t* __restrict__ n_sel_p, const uint32_t* __restrict__ counts,
                                                      const uint64_t* __restrict__ segoff, int32_t* __restrict__ segs, int k,
                                                      uint32_t* __restrict__ overflow) {
-    __shared__ unsigned long long keys[KX_SORT_LDS];
+    __shared__ unsigned long long keys[CAP];
     const int lane = dp_lane();
     const uint32_t n_sel = *n_sel_p;
     for (uint32_t sv = blockIdx.x; sv < n_sel; sv += gridDim.x) {
@@ -382,27 +385,24 @@ __global__ __launch_bounds__(64) void kidx_sortwrite(const dp_scan_item* __restr
             __syncthreads();
             if ((uint32_t)lane < c) keys[rank] = key;
             __syncthreads();
-        } else if (c <= KX_SORT_LDS) {
-            uint32_t m = 64;
-            while (m < c) m <<= 1;
-            for (uint32_t j = lane; j < m; j += 64)
-                keys[j] = j < c ? (((unsigned long long)(uint32_t)segs[out + 2 * (uint64_t)j] << 32) | (uint32_t)segs[out + 2 * (uint64_t)j + 1]) : ~0ull;
+        } else if (c <= (uint32_t)CAP / 2) {
+            // rank sort through LDS: every key counts the keys below it (c^2 / 64 broadcast reads per lane; c is a read's hit
+            // count, a few hundred in the dense-seed regime) - no barriers, no index arithmetic
+            unsigned long long* raw = keys + CAP / 2;  // unsorted copy in the upper half
+            for (uint32_t j = lane; j < c; j += 64)
+                raw[j] = ((unsigned long long)(uint32_t)segs[out + 2 * (uint64_t)j] << 32) | (uint32_t)segs[out + 2 * (uint64_t)j + 1];
             __syncthreads();
-            for (uint32_t size = 2; size <= m; size <<= 1) {
-                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (uint32_t j = lane; j < m / 2; j += 64) {
-                        const uint32_t a = 2 * j - (j & (stride - 1));  // index of the lower element of pair j
-                        const uint32_t b = a + stride;
-                        const bool up = ((a & size) == 0);
-                        const unsigned long long x = keys[a], y = keys[b];
-                        if ((x > y) == up) {
-                            keys[a] = y;
-                            keys[b] = x;
-                        }
-                    }
-                    __syncthreads();
-                }
+            for (uint32_t j = lane; j < c; j += 64) {
+                const unsigned long long key = raw[j];
+                uint32_t rank = 0, l = 0;
+                for (; l + 4 <= c; l += 4)
+                    rank += (raw[l] < key ? 1u : 0u) + (raw[l + 1] < key ? 1u : 0u) + (raw[l + 2] < key ? 1u : 0u) + (raw[l + 3] < key ? 1u : 0u);
+                for (; l < c; l++) rank += raw[l] < key ? 1u : 0u;
+                keys[rank] = key;
             }
+            __syncthreads();
+        } else if (c <= (uint32_t)CAP) {
+            uint32_t m = 64;
         } else {
             if (lane == 0) atomicExch(overflow, 1u);
             continue;
@@ -487,8 +487,15 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             hipLaunchKernelGGL(kidx_walk<true>, dim3((S * KX_PARTS + 3) / 4), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
                                (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
                                (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr);
-        hipLaunchKernelGGL(kidx_sortwrite, dim3(std::min<uint32_t>(n_sel, 8192)), dim3(64), 0, ctx->stream, d_items, d_sel,
-                           (const uint32_t*)(d_totals + 1), d_counts, d_segoff, d_segs, k, (uint32_t*)(d_totals + 4));
+        const dim3 sg(std::min<uint32_t>(n_sel, 16384)), sb(64);
+        uint32_t* ovf = (uint32_t*)(d_totals + 4);
+        const uint32_t* nsp = (const uint32_t*)(d_totals + 1);
+        if (max_count <= 128)
+            hipLaunchKernelGGL(kidx_sortwrite<256>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf);
+        else if (max_count <= 512)
+            hipLaunchKernelGGL(kidx_sortwrite<1024>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf);
+        else
+            hipLaunchKernelGGL(kidx_sortwrite<KX_SORT_LDS>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf);
         DP_HIP(hipGetLastError());
     }
     if (n_extra)

@@ -150,7 +150,7 @@ __global__ void qsets_kernel(const int32_t* __restrict__ qsegs, const u64* __res
 // A14 + A5: SeedIndex.Matches -> util.GetSharedIDs
 
 #define Q_MAXSETS 512
-#define Q_WAVES 4
+#define Q_WAVES 8
 
 struct QWave {
     uint32_t setid[Q_MAXSETS];
@@ -163,19 +163,30 @@ struct QWave {
 };
 
 // qmeta per query: {n_sets, minCount, status}; status bit0 = too many sets
+// One WORKGROUP per query: wave 0 prepares the set list (Matches' filter, the early-return cut, the 16-ladder's gather
+// order), then the Q_WAVES waves share the query's word range, 64 words per wave step, so that a dense index (W ~ 3 k words,
+// k = 10) is streamed by thousands of waves instead of one per query.
 __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
                                                              uint32_t nq, const u64* __restrict__ posting,
                                                              const uint32_t* __restrict__ pmeta, uint32_t n_seqs, uint32_t W,
                                                              const int32_t* __restrict__ mc, uint32_t mc_n,
                                                              u64* __restrict__ cand, uint32_t* __restrict__ qmeta,
                                                              u64* __restrict__ words_read, uint32_t* __restrict__ qcnt) {
-    __shared__ QWave sh[Q_WAVES];
-    QWave& S = sh[threadIdx.x >> 6];
+    __shared__ QWave S;
+    __shared__ uint32_t sh_u[8];
+    __shared__ int64_t sh_ilast;
+    __shared__ unsigned long long sh_gathered;
     const int lane = dp_lane();
-    const uint32_t q = blockIdx.x * Q_WAVES + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
+    const uint32_t q = blockIdx.x;
     if (q >= nq) return;
+    if (threadIdx.x == 0) {
+        sh_gathered = 0;
+        sh_u[5] = 0;
+    }
     const int32_t* seg = qsegs + qoff[q];
     const uint32_t ns = (uint32_t)((qoff[q + 1] - qoff[q]) / 2);
+    if (wave == 0) {
 
     // --- Matches(): filtered list of posting sets (seeds/seeds.go:336-347); sequential in the accepted-seed chain
     uint32_t n = 0, start = 0xffffffffu, end = 0, status = 0;
@@ -209,7 +220,15 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
         qmeta[4 * q + 2] = status | (n >= mc_n ? 2u : 0u);
         qmeta[4 * q + 3] = ns;
     }
-    if (n < 5 || status || n >= mc_n) return;  // cand row stays zero
+    if (lane == 0) {
+        sh_u[0] = n;
+        sh_u[1] = start;
+        sh_u[2] = end;
+        sh_u[3] = status;
+        sh_u[4] = (uint32_t)minCount;
+        sh_ilast = end;
+    }
+    if (!(n < 5 || status || n >= mc_n)) {
     __builtin_amdgcn_wave_barrier();
 
     // --- early return of GetSharedIDs (util/bitset.go:335-342): the (n-minCount+1)-th drop ends the scan
@@ -285,12 +304,21 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (lane == 0) sh_ilast = i_last;
+    }  // usable query
+    }  // wave 0
+    __syncthreads();
+    const uint32_t n = sh_u[0], start = sh_u[1], status = sh_u[3];
+    const int minCount = (int)sh_u[4];
+    const int64_t i_last = sh_ilast;
+    if (n < 5 || status || n >= mc_n) return;  // cand row stays zero
+    const bool ladder16 = minCount >= 13;
     const uint32_t n_ev = ladder16 ? S.n_ev : 0;
     const bool exact = minCount > 24;  // fast=false (util/bitset.go:309-311)
 
     u64 gathered = 0;
     int nCand = 0;  // Matches() result size of this query (bits set in its cand row)
-    for (int64_t ib = start; ib <= i_last; ib += 64) {
+    for (int64_t ib = (int64_t)start + 64 * wave; ib <= i_last; ib += 64 * Q_WAVES) {
         const int64_t i = ib + lane;
         if (i > i_last) continue;
         const uint32_t iw = (uint32_t)i;
@@ -298,19 +326,34 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
         if (!ladder16) {
             // 4- and 8-ladders (asm:121-314) are order independent: v_t = bits present in >= t of the live sets
             u64 l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0, l8 = 0;
-            for (uint32_t j = 0; j < n; j++) {
-                if (S.lens[j] <= iw) continue;
-                u64 m = posting[(uint64_t)S.setid[j] * W + iw];
-                gathered++;
-                l8 |= l7 & m;
-                l7 |= l6 & m;
-                l6 |= l5 & m;
-                l5 |= l4 & m;
-                l4 |= l3 & m;
-                l3 |= l2 & m;
-                l2 |= l1 & m;
-                l1 |= m;
+#define Q_STEP(m_)      \
+    l8 |= l7 & (m_);    \
+    l7 |= l6 & (m_);    \
+    l6 |= l5 & (m_);    \
+    l5 |= l4 & (m_);    \
+    l4 |= l3 & (m_);    \
+    l3 |= l2 & (m_);    \
+    l2 |= l1 & (m_);    \
+    l1 |= (m_);
+            // four posting words in flight per lane: a set whose window ends before this word contributes 0, which leaves the
+            // ladder as it is (the order of the words does not matter for the 4- and 8-ladders)
+            uint32_t j = 0;
+            for (; j + 4 <= n; j += 4) {
+                const bool a0 = S.lens[j] > iw, a1 = S.lens[j + 1] > iw, a2 = S.lens[j + 2] > iw, a3 = S.lens[j + 3] > iw;
+                const u64 m0 = a0 ? posting[(uint64_t)S.setid[j] * W + iw] : 0ull;
+                const u64 m1 = a1 ? posting[(uint64_t)S.setid[j + 1] * W + iw] : 0ull;
+                const u64 m2 = a2 ? posting[(uint64_t)S.setid[j + 2] * W + iw] : 0ull;
+                const u64 m3 = a3 ? posting[(uint64_t)S.setid[j + 3] * W + iw] : 0ull;
+                gathered += (u64)a0 + (u64)a1 + (u64)a2 + (u64)a3;
+                Q_STEP(m0) Q_STEP(m1) Q_STEP(m2) Q_STEP(m3)
             }
+            for (; j < n; j++) {
+                if (S.lens[j] <= iw) continue;
+                const u64 m = posting[(uint64_t)S.setid[j] * W + iw];
+                gathered++;
+                Q_STEP(m)
+            }
+#undef Q_STEP
             switch (minCount) {
                 case 0:
                 case 1: v = l1; break;
@@ -385,8 +428,13 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
     gathered = (u64)wave_sum((int)gathered);
     nCand = wave_sum(nCand);
     if (lane == 0) {
-        words_read[q] = gathered;
-        qcnt[q] = (uint32_t)nCand;
+        atomicAdd(&sh_gathered, (unsigned long long)gathered);
+        atomicAdd(&sh_u[5], (uint32_t)nCand);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        words_read[q] = sh_gathered;
+        qcnt[q] = sh_u[5];
     }
 }
 
@@ -1819,7 +1867,7 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
                        (const int32_t*)ctx->d_qsegs.p, (const u64*)ctx->d_qoff.p, nq, (u64*)ctx->d_qsets.p, SW);
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-    hipLaunchKernelGGL(query_kernel, dim3((nq + Q_WAVES - 1) / Q_WAVES), dim3(64 * Q_WAVES), 0, ctx->stream,
+    hipLaunchKernelGGL(query_kernel, dim3(nq), dim3(64 * Q_WAVES), 0, ctx->stream,
                        (const int32_t*)ctx->d_qsegs.p, (const u64*)ctx->d_qoff.p, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, M, W, (const int32_t*)d_mc, mc_n, (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt);
     DP_HIP(hipGetLastError());
