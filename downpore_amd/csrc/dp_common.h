@@ -111,6 +111,8 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
 // resident k-mer position index (dp_kindex.hip)
 int dp_histogram_device(dp_ctx* ctx, int k, uint32_t* d_counts);  // dp_scan.hip
 int dp_kindex_ensure(dp_ctx* ctx, int k);
+int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, uint64_t* d_off, void** d_pos_out, uint64_t* n_pos_out,
+                           float* ms_out);  // dp_kbuild.hip
 void dp_kindex_free(dp_ctx* ctx);
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint64_t* d_totals);

@@ -1,0 +1,436 @@
+// libdownpore_hip.so — building the resident k-mer position index (dp_kindex.hip) and the k-mer histogram (A22) in one
+// go, as a most-significant-digit radix sort whose every pass streams HBM with coalesced traffic.
+//
+// The first version scattered each of the ~10^9 k-mer positions straight to its bucket (one 8-byte store to a random
+// address each: ~95 ms at config 2, 1 % of the HBM roofline) after counting them with 10^9 global atomics (37 ms).  Here
+// an entry (k-mer << 36 | absolute base index) goes through three passes instead:
+//   pass 1  by the k-mer's top B1 bits, straight from the packed reads;
+//   pass 2  by its next B2 bits, inside every pass-1 bucket;
+//   pass 3  one workgroup per (B1+B2)-bit sub-partition: the remaining R = 2k - B1 - B2 bits are counted in LDS - those
+//           counts ARE the k-mer histogram of the sub-partition's 2^R k-mers - and the entries leave in final order as
+//           (read << 32 | position in the read).
+// Passes 1 and 2 sort a tile of 4096 entries by digit in LDS, reserve room in every digit's bucket with one atomic per
+// (tile, digit), and copy runs out: consecutive lanes write consecutive addresses.  Pass 3 places a whole sub-partition in
+// LDS when it fits (<= 8192 entries, the digit widths are chosen for that) and writes it out sequentially.
+// Algorithmic bytes of the build: packed reads once + 8 B per k-mer start written + the 4^k histogram and offset tables;
+// each pass moves 16 B per entry (read + write), which is what its own roofline fraction is computed from.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "dp_common.h"
+
+typedef unsigned long long kb_u64;
+
+#define KB_TILE 4096       // entries per tile of passes 1/2
+#define KB_THREADS 256
+#define KB_P3_CAP 8192     // entries pass 3 sorts inside LDS
+#define KB_POS_BITS 36     // absolute base index bits of an entry in flight
+
+struct KbGeom {
+    int k, b1, b2, r;  // digit widths: b1 + b2 + r = 2k
+};
+
+// read of every 1024-base block of the packed layout (reads start on 64-base boundaries, so a 32-position group never
+// straddles two reads): gread[j] = read whose [boff*4, boff_next*4) range holds base 1024*j
+__global__ void kb_group_table(const uint64_t* __restrict__ boff, uint32_t n_reads, uint32_t* __restrict__ gread) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint64_t a0 = boff[r] * 4, a1 = boff[r + 1] * 4;
+    for (uint64_t j = (a0 + 1023) >> 10; (j << 10) < a1; j++) gread[j] = r;
+}
+
+__device__ __forceinline__ uint32_t kb_read_of(uint64_t a, const uint32_t* __restrict__ gread, const uint64_t* __restrict__ boff) {
+    uint32_t r = gread[a >> 10];
+    while (boff[r + 1] * 4 <= a) r++;
+    return r;
+}
+
+// the up to 16 k-mers a thread owns in passes over the packed reads: half a 32-position group.  Returns the valid mask.
+__device__ __forceinline__ uint32_t kb_load16(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ boff,
+                                              const uint32_t* __restrict__ len, const uint32_t* __restrict__ gread, uint64_t n_groups,
+                                              uint64_t g, int half, int k, uint32_t kmer[16]) {
+    if (g >= n_groups) return 0u;
+    const uint64_t a = g * 32 + (uint64_t)half * 16;
+    const uint32_t r = kb_read_of(g * 32, gread, boff);
+    const uint32_t L = len[r];
+    if (L < (uint32_t)k) return 0u;
+    const uint64_t a0 = boff[r] * 4, a1 = a0 + (L - k + 1);
+    if (a >= a1) return 0u;
+    const uint32_t* p = (const uint32_t*)(packed + g * 8) + half;
+    const uint32_t w0 = __builtin_bswap32(p[0]), w1 = __builtin_bswap32(p[1]);
+    const int sh = 32 - 2 * k;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t win = j ? __builtin_amdgcn_alignbit(w0, w1, 32 - 2 * j) : w0;
+        kmer[j] = win >> sh;
+        if (a + j >= a0 && a + j < a1) mask |= 1u << j;
+    }
+    return mask;
+}
+
+// ---- pass 1 --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KB_THREADS) void kb_count1(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ boff,
+                                                        const uint32_t* __restrict__ len, const uint32_t* __restrict__ gread,
+                                                        uint64_t n_groups, KbGeom G, kb_u64* __restrict__ cnt1) {
+    __shared__ uint32_t hist[1024];
+    const int nb = 1 << G.b1;
+    for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
+    __syncthreads();
+    const int dsh = 2 * G.k - G.b1;
+    const uint64_t tiles = (n_groups * 2 + KB_THREADS - 1) / KB_THREADS;
+    for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const uint64_t h = t * KB_THREADS + threadIdx.x;
+        uint32_t kmer[16];
+        const uint32_t m = kb_load16(packed, boff, len, gread, n_groups, h >> 1, (int)(h & 1), G.k, kmer);
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if ((m >> j) & 1) atomicAdd(&hist[kmer[j] >> dsh], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += KB_THREADS)
+        if (hist[i]) atomicAdd(&cnt1[i], (kb_u64)hist[i]);
+}
+
+// shared tail of passes 1 and 2: the tile's entries sit unsorted in registers `e[]` with validity mask `m`; sort by digit in
+// LDS, reserve room per digit with one atomic, copy runs out
+template <int E>
+__device__ __forceinline__ void kb_tile_out(const kb_u64 (&e)[E], uint32_t m, int dshift, uint32_t dmask, uint32_t* hist /*[1024]*/,
+                                            uint32_t* lstart /*[1024]*/, kb_u64* gbase /*[1024]*/, kb_u64* sorted /*[KB_TILE]*/,
+                                            kb_u64* __restrict__ cursor, kb_u64* __restrict__ out) {
+    const int nb = (int)dmask + 1;
+    for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < E; j++)
+        if ((m >> j) & 1) atomicAdd(&hist[(uint32_t)(e[j] >> dshift) & dmask], 1u);
+    __syncthreads();
+    // exclusive scan of the digit counts (nb <= 1024: four bins per thread), global reservation, cursors back to zero
+    {
+        const int per = (nb + KB_THREADS - 1) / KB_THREADS;
+        uint32_t loc[4] = {0, 0, 0, 0}, s = 0;
+        for (int u = 0; u < per; u++) {
+            const int b = threadIdx.x * per + u;
+            loc[u] = b < nb ? hist[b] : 0u;
+            s += loc[u];
+        }
+        const int lane = dp_lane(), wave = threadIdx.x >> 6;
+        __shared__ uint32_t wsum[KB_THREADS / 64];
+        uint32_t x = (uint32_t)wave_incl_sum((int)s);
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t base = x - s;
+        for (int w = 0; w < wave; w++) base += wsum[w];
+        for (int u = 0; u < per; u++) {
+            const int b = threadIdx.x * per + u;
+            if (b < nb) {
+                lstart[b] = base;
+                if (loc[u]) gbase[b] = atomicAdd(&cursor[b], (kb_u64)loc[u]);
+                hist[b] = 0;
+                base += loc[u];
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < E; j++)
+        if ((m >> j) & 1) {
+            const uint32_t d = (uint32_t)(e[j] >> dshift) & dmask;
+            sorted[lstart[d] + atomicAdd(&hist[d], 1u)] = e[j];
+        }
+    __syncthreads();
+    total = lstart[nb - 1] + hist[nb - 1];
+    for (uint32_t i = threadIdx.x; i < total; i += KB_THREADS) {
+        const kb_u64 v = sorted[i];
+        const uint32_t d = (uint32_t)(v >> dshift) & dmask;
+        out[gbase[d] + (kb_u64)(i - lstart[d])] = v;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(KB_THREADS) void kb_part1(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ boff,
+                                                       const uint32_t* __restrict__ len, const uint32_t* __restrict__ gread,
+                                                       uint64_t n_groups, KbGeom G, kb_u64* __restrict__ cursor, kb_u64* __restrict__ out) {
+    __shared__ uint32_t hist[1024], lstart[1024];
+    __shared__ kb_u64 gbase[1024];
+    __shared__ kb_u64 sorted[KB_TILE];
+    const int dsh = KB_POS_BITS + 2 * G.k - G.b1;
+    const uint32_t dmask = (1u << G.b1) - 1u;
+    const uint64_t tiles = (n_groups * 2 + KB_THREADS - 1) / KB_THREADS;
+    for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const uint64_t h = t * KB_THREADS + threadIdx.x;
+        uint32_t kmer[16];
+        const uint32_t m = kb_load16(packed, boff, len, gread, n_groups, h >> 1, (int)(h & 1), G.k, kmer);
+        kb_u64 e[16];
+        const kb_u64 a = (h >> 1) * 32 + (h & 1) * 16;
+#pragma unroll
+        for (int j = 0; j < 16; j++) e[j] = ((kb_u64)kmer[j] << KB_POS_BITS) | (a + (kb_u64)j);
+        kb_tile_out<16>(e, m, dsh, dmask, hist, lstart, gbase, sorted, cursor, out);
+    }
+}
+
+// ---- pass 2 (inside every pass-1 bucket) ---------------------------------------------------------------------------
+// tile_start[b] = first tile of bucket b (tiles of KB_TILE entries; buckets do not share tiles), [nb1] = total
+__device__ __forceinline__ uint32_t kb_bucket_of_tile(const uint32_t* __restrict__ tile_start, int nb1, uint32_t t) {
+    int lo = 0, hi = nb1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_start[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    return (uint32_t)lo;
+}
+
+__global__ __launch_bounds__(KB_THREADS) void kb_count2(const kb_u64* __restrict__ in, const kb_u64* __restrict__ base1,
+                                                        const uint32_t* __restrict__ tile_start, KbGeom G, kb_u64* __restrict__ cnt2) {
+    __shared__ uint32_t hist[1024];
+    const int nb1 = 1 << G.b1, nb2 = 1 << G.b2;
+    const uint32_t n_tiles = tile_start[nb1];
+    const int dsh = KB_POS_BITS + 2 * G.k - G.b1 - G.b2;
+    const uint32_t dmask = (uint32_t)nb2 - 1u;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t b = kb_bucket_of_tile(tile_start, nb1, t);
+        const kb_u64 lo = base1[b] + (kb_u64)(t - tile_start[b]) * KB_TILE, hi = min(base1[b + 1], lo + KB_TILE);
+        for (int i = threadIdx.x; i < nb2; i += KB_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) atomicAdd(&hist[(uint32_t)(in[i] >> dsh) & dmask], 1u);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb2; i += KB_THREADS)
+            if (hist[i]) atomicAdd(&cnt2[(kb_u64)b * nb2 + i], (kb_u64)hist[i]);
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(KB_THREADS) void kb_part2(const kb_u64* __restrict__ in, const kb_u64* __restrict__ base1,
+                                                       const uint32_t* __restrict__ tile_start, KbGeom G, kb_u64* __restrict__ cursor2,
+                                                       kb_u64* __restrict__ out) {
+    __shared__ uint32_t hist[1024], lstart[1024];
+    __shared__ kb_u64 gbase[1024];
+    __shared__ kb_u64 sorted[KB_TILE];
+    const int nb1 = 1 << G.b1, nb2 = 1 << G.b2;
+    const uint32_t n_tiles = tile_start[nb1];
+    const int dsh = KB_POS_BITS + 2 * G.k - G.b1 - G.b2;
+    const uint32_t dmask = (uint32_t)nb2 - 1u;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t b = kb_bucket_of_tile(tile_start, nb1, t);
+        const kb_u64 lo = base1[b] + (kb_u64)(t - tile_start[b]) * KB_TILE, hi = min(base1[b + 1], lo + KB_TILE);
+        kb_u64 e[KB_TILE / KB_THREADS];
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < KB_TILE / KB_THREADS; j++) {
+            const kb_u64 i = lo + (kb_u64)j * KB_THREADS + threadIdx.x;  // coalesced
+            e[j] = 0;
+            if (i < hi) {
+                e[j] = in[i];
+                m |= 1u << j;
+            }
+        }
+        kb_tile_out<KB_TILE / KB_THREADS>(e, m, dsh, dmask, hist, lstart, gbase, sorted, cursor2 + (kb_u64)b * nb2, out);
+    }
+}
+
+// ---- pass 3: one workgroup per sub-partition ------------------------------------------------------------------------
+// counts[kmer] (the histogram), off[kmer] (bucket starts of the index) and the index entries in final order
+__global__ __launch_bounds__(KB_THREADS) void kb_final(const kb_u64* __restrict__ in, const kb_u64* __restrict__ base2, uint32_t n_sub,
+                                                       KbGeom G, const uint32_t* __restrict__ gread, const uint64_t* __restrict__ boff,
+                                                       uint32_t* __restrict__ counts, kb_u64* __restrict__ off, kb_u64* __restrict__ pos) {
+    extern __shared__ kb_u64 kb_dyn[];  // sorted[KB_P3_CAP] | hist[2^r] | lstart[2^r]
+    const int nb = 1 << G.r;
+    kb_u64* sorted = kb_dyn;
+    uint32_t* hist = (uint32_t*)(kb_dyn + KB_P3_CAP);
+    uint32_t* lstart = hist + nb;
+    const uint32_t dmask = (uint32_t)nb - 1u;
+    for (uint32_t sp = blockIdx.x; sp < n_sub; sp += gridDim.x) {
+        const kb_u64 lo = base2[sp], hi = base2[sp + 1];
+        const kb_u64 n = hi - lo;
+        for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
+        __syncthreads();
+        for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) atomicAdd(&hist[(uint32_t)(in[i] >> KB_POS_BITS) & dmask], 1u);
+        __syncthreads();
+        // histogram + offsets of this sub-partition's 2^r k-mers (k-mer = sp << r | bin): coalesced
+        {
+            const int per = (nb + KB_THREADS - 1) / KB_THREADS;  // <= 16
+            uint32_t s = 0;
+            for (int u = 0; u < per; u++) {
+                const int b = threadIdx.x * per + u;
+                if (b < nb) s += hist[b];
+            }
+            const int lane = dp_lane(), wave = threadIdx.x >> 6;
+            __shared__ uint32_t wsum[KB_THREADS / 64];
+            uint32_t x = (uint32_t)wave_incl_sum((int)s);
+            if (lane == 63) wsum[wave] = x;
+            __syncthreads();
+            uint32_t base = x - s;
+            for (int w = 0; w < wave; w++) base += wsum[w];
+            for (int u = 0; u < per; u++) {
+                const int b = threadIdx.x * per + u;
+                if (b < nb) {
+                    lstart[b] = base;
+                    base += hist[b];
+                }
+            }
+        }
+        __syncthreads();
+        const kb_u64 kbase = (kb_u64)sp << G.r;
+        for (int b = threadIdx.x; b < nb; b += KB_THREADS) {
+            counts[kbase + b] = hist[b];
+            off[kbase + b] = lo + lstart[b];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;  // placement cursors
+        __syncthreads();
+        if (n <= KB_P3_CAP) {
+            for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) {
+                const kb_u64 v = in[i];
+                const uint32_t d = (uint32_t)(v >> KB_POS_BITS) & dmask;
+                sorted[lstart[d] + atomicAdd(&hist[d], 1u)] = v & (((kb_u64)1 << KB_POS_BITS) - 1);
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += KB_THREADS) {
+                const kb_u64 a = sorted[i];
+                const uint32_t r = kb_read_of(a, gread, boff);
+                pos[lo + i] = ((kb_u64)r << 32) | (a - boff[r] * 4);
+            }
+        } else {  // larger than the LDS buffer: entries go straight to their slot (the region is this workgroup's alone)
+            for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) {
+                const kb_u64 v = in[i];
+                const uint32_t d = (uint32_t)(v >> KB_POS_BITS) & dmask;
+                const kb_u64 a = v & (((kb_u64)1 << KB_POS_BITS) - 1);
+                const uint32_t r = kb_read_of(a, gread, boff);
+                pos[lo + lstart[d] + atomicAdd(&hist[d], 1u)] = ((kb_u64)r << 32) | (a - boff[r] * 4);
+            }
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) off[(kb_u64)n_sub << G.r] = base2[n_sub];
+}
+
+__global__ void kb_excl_scan_small(const kb_u64* __restrict__ in, uint32_t n, kb_u64* __restrict__ out) {
+    // n <= 2^20 entries, one workgroup: each thread scans a contiguous slice
+    __shared__ kb_u64 part[1024];
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    kb_u64 s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += in[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        kb_u64 run = 0;
+        for (int i = 0; i < 1024; i++) {
+            const kb_u64 v = part[i];
+            part[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    kb_u64 run = part[threadIdx.x];
+    for (uint32_t i = lo; i < hi; i++) {
+        out[i] = run;
+        run += in[i];
+    }
+    if (threadIdx.x == 1023) out[n] = run;
+}
+
+// Builds counts (uint32 [4^k]), off (uint64 [4^k + 1]) and pos (uint64 [n]) for the context's resident reads.  d_counts, d_off
+// are the caller's; *d_pos_out is allocated here (ownership passes to the caller), the scratch is released before returning.
+// Returns 1 when this path does not apply (k < 9 or > 14, more than 2^36 bases): the caller uses the atomic scatter.
+int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, uint64_t* d_off, void** d_pos_out, uint64_t* n_pos_out,
+                           float* ms_out) {
+    if (k < 9 || k > 14 || ow->packed_bytes * 4 >= ((uint64_t)1 << KB_POS_BITS) || ow->n_reads == 0) return 1;
+    if (getenv("DP_KINDEX_ATOMIC")) return 1;
+    {
+        size_t free_b = 0, total_b = 0;
+        hipMemGetInfo(&free_b, &total_b);
+        if ((uint64_t)free_b < ow->total_bases * 16 + ((uint64_t)6 << 30)) return 1;  // two 8 B/base buffers during the build
+    }
+    const uint64_t n_groups = (ow->packed_bytes * 4 + 31) / 32;
+    KbGeom G;
+    G.k = k;
+    G.b1 = 8;
+    // pass 2's width: sub-partitions of about 6000 entries (they are sorted inside LDS when they hold <= 8192)
+    const uint64_t approx = ow->total_bases;
+    int b2 = 6;
+    while (b2 < 10 && (approx >> (G.b1 + b2)) > 7800) b2++;
+    if (G.b1 + b2 > 2 * k) b2 = 2 * k - G.b1;
+    G.b2 = b2;
+    G.r = 2 * k - G.b1 - G.b2;
+    if (G.r > 12) {  // (k = 14 with a small read set: widen pass 2)
+        G.b2 += G.r - 12;
+        G.r = 12;
+    }
+    if (G.b2 > 10) return 1;
+    const int nb1 = 1 << G.b1, nb2 = 1 << G.b2;
+    const uint32_t n_sub = (uint32_t)nb1 * (uint32_t)nb2;
+    void *d_gread = nullptr, *d_small = nullptr, *d_buf1 = nullptr, *d_buf2 = nullptr;
+    struct Temps {
+        void **a, **b, **c, **d;
+        ~Temps() {
+            for (void** p : {a, b, c, d})
+                if (*p) hipFree(*p);
+        }
+    } temps{&d_gread, &d_small, &d_buf1, &d_buf2};
+    const size_t n_blocks1k = (size_t)((ow->packed_bytes * 4 + 1023) >> 10) + 2;
+    DP_HIP(hipMalloc(&d_gread, n_blocks1k * 4));
+    // small tables: cnt1[nb1], base1[nb1+1], cur1[nb1], cnt2[n_sub], base2[n_sub+1], cur2[n_sub], tile_start[nb1+1]
+    const size_t small_u64 = (size_t)nb1 * 3 + 1 + (size_t)n_sub * 3 + 1;
+    DP_HIP(hipMalloc(&d_small, small_u64 * 8 + ((size_t)nb1 + 1) * 4 + 64));
+    kb_u64* cnt1 = (kb_u64*)d_small;
+    kb_u64* base1 = cnt1 + nb1;
+    kb_u64* cur1 = base1 + nb1 + 1;
+    kb_u64* cnt2 = cur1 + nb1;
+    kb_u64* base2 = cnt2 + n_sub;
+    kb_u64* cur2 = base2 + n_sub + 1;
+    uint32_t* tile_start = (uint32_t*)(cur2 + n_sub);
+    DP_HIP(hipMemsetAsync(d_small, 0, small_u64 * 8 + ((size_t)nb1 + 1) * 4, ctx->stream));
+    hipEvent_t e0 = ctx->ev[2], e1 = ctx->ev[3];
+    DP_HIP(hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(kb_group_table, dim3((ow->n_reads + 255) / 256), dim3(256), 0, ctx->stream, (const uint64_t*)ow->d_boff.p, ow->n_reads,
+                       (uint32_t*)d_gread);
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const uint32_t grid = (uint32_t)cus * 8;
+    hipLaunchKernelGGL(kb_count1, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, (const uint8_t*)ow->d_packed.p, (const uint64_t*)ow->d_boff.p,
+                       (const uint32_t*)ow->d_len.p, (const uint32_t*)d_gread, n_groups, G, cnt1);
+    hipLaunchKernelGGL(kb_excl_scan_small, dim3(1), dim3(1024), 0, ctx->stream, (const kb_u64*)cnt1, (uint32_t)nb1, base1);
+    DP_HIP(hipGetLastError());
+    std::vector<kb_u64> h_base1((size_t)nb1 + 1);
+    DP_HIP(hipMemcpyAsync(h_base1.data(), base1, ((size_t)nb1 + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    const uint64_t n = h_base1[(size_t)nb1];
+    std::vector<uint32_t> h_tiles((size_t)nb1 + 1);
+    uint64_t tt = 0;
+    for (int b = 0; b < nb1; b++) {
+        h_tiles[(size_t)b] = (uint32_t)tt;
+        tt += (h_base1[(size_t)b + 1] - h_base1[(size_t)b] + KB_TILE - 1) / KB_TILE;
+    }
+    h_tiles[(size_t)nb1] = (uint32_t)tt;
+    if (tt >= 0xffffffffull) return 1;
+    DP_HIP(hipMalloc(&d_buf1, n * 8 + 64));
+    DP_HIP(hipMalloc(&d_buf2, n * 8 + 64));
+    DP_HIP(hipMemcpyAsync(tile_start, h_tiles.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(cur1, base1, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(kb_part1, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, (const uint8_t*)ow->d_packed.p, (const uint64_t*)ow->d_boff.p,
+                       (const uint32_t*)ow->d_len.p, (const uint32_t*)d_gread, n_groups, G, cur1, (kb_u64*)d_buf1);
+    hipLaunchKernelGGL(kb_count2, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, (const kb_u64*)d_buf1, (const kb_u64*)base1,
+                       (const uint32_t*)tile_start, G, cnt2);
+    hipLaunchKernelGGL(kb_excl_scan_small, dim3(1), dim3(1024), 0, ctx->stream, (const kb_u64*)cnt2, n_sub, base2);
+    DP_HIP(hipMemcpyAsync(cur2, base2, (size_t)n_sub * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(kb_part2, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, (const kb_u64*)d_buf1, (const kb_u64*)base1,
+                       (const uint32_t*)tile_start, G, cur2, (kb_u64*)d_buf2);
+    // pass 3 writes the final entries over pass 1's output (dead by now)
+    hipLaunchKernelGGL(kb_final, dim3(std::min<uint32_t>(n_sub, (uint32_t)cus * 16)), dim3(KB_THREADS),
+                       (size_t)KB_P3_CAP * 8 + ((size_t)8 << G.r), ctx->stream, (const kb_u64*)d_buf2,
+                       (const kb_u64*)base2, n_sub, G, (const uint32_t*)d_gread, (const uint64_t*)ow->d_boff.p, d_counts, (kb_u64*)d_off,
+                       (kb_u64*)d_buf1);
+    DP_HIP(hipGetLastError());
+    DP_HIP(hipEventRecord(e1, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    if (ms_out) hipEventElapsedTime(ms_out, e0, e1);
+    *d_pos_out = d_buf1;
+    d_buf1 = nullptr;  // ownership to the caller
+    *n_pos_out = n;
+    return DP_OK;
+}

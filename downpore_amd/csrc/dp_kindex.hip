@@ -21,6 +21,7 @@ struct dp_kindex {
     bool unavailable = false;  // k too large for a direct-addressed table, or not enough free HBM: callers scan instead
     uint64_t n_pos = 0;
     DevBuf off;  // uint64 [4^k + 1]
+    float build_ms = 0;  // device time of the sorted build
     DevBuf pos;  // uint64 [n_pos]: k-mer start as (read << 32 | position in the read), grouped by k-mer value
 };
 
@@ -107,6 +108,8 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
         // resident: 8 B per k-mer start + 8 B per table entry; transient: two 4-byte count tables.  Leave 4 GiB for the rounds.
         size_t free_b = 0, total_b = 0;
         hipMemGetInfo(&free_b, &total_b);
+        // (the sorted build holds a second 8 B per base while it runs; when that does not fit, the atomic scatter path is
+        // what is left and needs only the index itself)
         const uint64_t need = ow->total_bases * 8 + (uint64_t)nk * 16 + ((uint64_t)4 << 30);
         int max_k = 14;
         if (const char* e = getenv("DP_KINDEX_MAX_K")) max_k = std::min(14, atoi(e));
@@ -114,6 +117,35 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
             ix->unavailable = true;
             return 1;
         }
+    }
+    // Preferred: the radix-sort build (dp_kbuild.hip) - every pass streams HBM with coalesced traffic, and the k-mer
+    // histogram falls out of its last pass (kept for dp_kmer_values).  DP_KINDEX_ATOMIC=1 or an unsupported k: the
+    // count -> offsets -> atomic scatter below.
+    {
+        if (dev_reserve(ctx, ix->off, (nk + 1) * 8)) return DP_ERR_HIP;
+        void* d_cnt = nullptr;
+        DP_HIP(hipMalloc(&d_cnt, nk * 4));
+        void* d_pos = nullptr;
+        uint64_t n_pos = 0;
+        float ms = 0;
+        const int rc = dp_kindex_build_sorted(ctx, ow, k, (uint32_t*)d_cnt, (uint64_t*)ix->off.p, &d_pos, &n_pos, &ms);
+        if (rc < 0) {
+            hipFree(d_cnt);
+            return rc;
+        }
+        if (rc == 0) {
+            if (ix->pos.p) hipFree(ix->pos.p);
+            ix->pos.p = d_pos;
+            ix->pos.cap = n_pos * 8 + 64;
+            ix->n_pos = n_pos;
+            ix->built = true;
+            ix->build_ms = ms;
+            if (ow->d_kcounts) hipFree(ow->d_kcounts);
+            ow->d_kcounts = d_cnt;  // the histogram of exactly these k-mers: dp_kmer_values takes it from here
+            ow->kcounts_k = k;
+            return DP_OK;
+        }
+        hipFree(d_cnt);
     }
     // count -> offsets -> scatter, on the CALLER's stream (the owner's buffers are only written here, under the mutex)
     void *d_counts = nullptr, *d_tmp = nullptr, *d_counts1 = nullptr;

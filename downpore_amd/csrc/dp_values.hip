@@ -96,14 +96,21 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     if (dev_reserve(ctx, ctx->d_values, n * sizeof(double))) return DP_ERR_HIP;
     ctx->n_values = 0;
     double* values = (double*)ctx->d_values.p;
-    DPV(hipMalloc(&d_counts, n * 4));
     DPV(hipMalloc(&d_merged, n * 8));
     DPV(hipMalloc(&d_small, 64));
-    DPV(hipMemsetAsync(d_counts, 0, n * 4, ctx->stream));
-    int rc = dp_histogram_device(ctx, k, (uint32_t*)d_counts);
-    if (rc != 0) {
-        cleanup();
-        return rc;
+    if (ctx->d_kcounts && ctx->kcounts_k == k) {
+        // the k-mer position index was built first (dp_scan_prepare): its last pass left the histogram of exactly these k-mers
+        d_counts = ctx->d_kcounts;
+        ctx->d_kcounts = nullptr;
+        ctx->kcounts_k = 0;
+    } else {
+        DPV(hipMalloc(&d_counts, n * 4));
+        DPV(hipMemsetAsync(d_counts, 0, n * 4, ctx->stream));
+        int rc = dp_histogram_device(ctx, k, (uint32_t*)d_counts);
+        if (rc != 0) {
+            cleanup();
+            return rc;
+        }
     }
     // tot (overlap.go:60-63)
     size_t tb = 0;

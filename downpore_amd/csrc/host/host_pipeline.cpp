@@ -450,6 +450,16 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         fprintf(stderr, "[setup] %-28s %.1f ms\n", what, 1e3 * (t - tm));
         tm = t;
     };
+    {
+        // The k-mer position index first, when this read set gets one: its radix-sort build leaves the k-mer histogram
+        // behind, which is what the value table starts from (no separate counting pass then).
+        int rc = dp_scan_prepare(ctx, p.k);
+        if (rc != 0) {
+            error = dp_last_error(ctx);
+            return rc;
+        }
+        mark("k-mer position index");
+    }
     if (valuesOrNull) {
         values.assign(valuesOrNull, (size_t)1 << (2 * p.k));
     } else if (const char* hv = getenv("DP_HOST_VALUES"); hv && hv[0] == '1') {  // histogram on the GPU, table on the host
@@ -473,10 +483,16 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         mark("value table (device)");
     }
     // The host copy of the table (the planner re-selects a window on the host when its speculation did not hold) travels
-    // on a second context while this one builds the k-mer position index.
+    // on a second context while the executor slots, the planner's context and the window cache are set up.
     std::thread dl;
     int dlRc = 0;
     std::string dlErr;
+    struct Joiner {  // (error returns below must not leave the thread running)
+        std::thread& t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } joiner{dl};
     if (valuesOnDevice) {
         double* dst = values.reserve((size_t)1 << (2 * p.k));
         dl = std::thread([this, dst, &dlRc, &dlErr] {
@@ -490,23 +506,6 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
             if (dlRc != 0) dlErr = dp_last_error(c2);
             dp_ctx_destroy(c2);
         });
-    }
-    {
-        int rc = dp_scan_prepare(ctx, p.k);  // the k-mer position index, when this read set gets one (reuses the histogram)
-        if (rc != 0) {
-            if (dl.joinable()) dl.join();
-            error = dp_last_error(ctx);
-            return rc;
-        }
-        mark("k-mer position index");
-    }
-    if (dl.joinable()) {
-        dl.join();
-        if (dlRc != 0) {
-            error = dlErr;
-            return dlRc;
-        }
-        mark("values copy (overlapped)");
     }
     if (reads->isFastq && !reads->qual.empty()) {  // FASTQ: the selection kernels weight values by the quality bytes
         int rc = dp_quality_upload(ctx, (const uint8_t*)reads->qual.data(), reads->off.data(), reads->hasQual.data(), (uint32_t)reads->size());
@@ -568,6 +567,14 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         const char* wc = getenv("DP_WINDOW_CACHE");
         if (plannerCtx && p.queryType == 1 && !(wc && wc[0] == '0'))
             winCache.reset(new WindowCache(plannerCtx, *reads, p.overlapSize, p.k, p.numSeeds));
+    }
+    if (dl.joinable()) {
+        dl.join();
+        if (dlRc != 0) {
+            error = dlErr;
+            return dlRc;
+        }
+        mark("values copy (overlapped)");
     }
     planner.reset(new Planner(*reads, p, values.data(), !(nothread && nothread[0] == '1'), plannerCtx, winCache.get()));
     mark("planner");
