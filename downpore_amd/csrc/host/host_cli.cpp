@@ -59,7 +59,7 @@ static int runOverlap(ArgTable& t) {
     int rc = dp_reads_upload(ctx, (const uint8_t*)reads.bases.data(), reads.off.data(), (uint32_t)reads.size());
     OverlapRun run;
     const char* ns = getenv("DP_EXEC_SLOTS");
-    if (rc == 0) rc = run.init(ctx, &reads, p, nullptr, ns ? atoi(ns) : 6);
+    if (rc == 0) rc = run.init(ctx, &reads, p, nullptr, ns ? atoi(ns) : 8);
     if (rc != 0) {
         fprintf(stderr, "downpore: %s\n", run.error.empty() ? dp_last_error(ctx) : run.error.c_str());
         return 2;
@@ -87,6 +87,7 @@ static int runOverlap(ArgTable& t) {
 }
 
 int main(int argc, char** argv) {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);  // one hardware queue per executor slot's stream (the runtime's default is 4)
     ArgTable ov, mp;
     ov.make({"overlap_size", "k", "num_seeds", "seed_batch_size", "chunk_size", "query_batch_size", "min_hits", "num_workers",
              "input", "seed_values", "himem"},
