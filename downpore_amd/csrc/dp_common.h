@@ -46,6 +46,7 @@ struct dp_ctx {
     DevBuf d_len;               // uint32 length in bases                      [n_reads]
     DevBuf d_values;            // 4^k doubles (kmerRanks) for dp_select_seeds; shared like the reads
     uint64_t n_values = 0;
+    uint64_t values_total = 0;  // sum of the k-mer counts the resident table was computed from (0: uploaded table)
     DevBuf d_qual, d_qualoff, d_hasq;  // FASTQ quality bytes of the reads (dp_quality_upload); shared like the reads
     DevBuf d_selwin, d_seltop;
     PinBuf h_seltop;

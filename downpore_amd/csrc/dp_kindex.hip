@@ -434,7 +434,26 @@ __global__ __launch_bounds__(64) void kidx_sortwrite(const dp_scan_item* __restr
             }
             __syncthreads();
         } else if (c <= (uint32_t)CAP) {
-            uint32_t m = 64;
+            // more keys than half the block's LDS: bitonic network in place, padded with ~0 up to a power of two (<= CAP)
+            uint32_t m = 128;
+            while (m < c) m <<= 1;
+            for (uint32_t j = lane; j < m; j += 64)
+                keys[j] = j < c ? ((unsigned long long)(uint32_t)segs[out + 2 * (uint64_t)j] << 32) | (uint32_t)segs[out + 2 * (uint64_t)j + 1] : ~0ull;
+            __syncthreads();
+            for (uint32_t size = 2; size <= m; size <<= 1) {
+                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (uint32_t t = lane; t < m / 2; t += 64) {
+                        const uint32_t i = ((t / stride) * 2 * stride) + (t % stride);
+                        const bool up = (i & size) == 0;
+                        const unsigned long long a = keys[i], b = keys[i + stride];
+                        if ((a > b) == up) {
+                            keys[i] = b;
+                            keys[i + stride] = a;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
         } else {
             if (lane == 0) atomicExch(overflow, 1u);
             continue;

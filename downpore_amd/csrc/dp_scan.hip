@@ -547,6 +547,7 @@ extern "C" int dp_values_upload(dp_ctx* ctx, const double* values, uint64_t n) {
     DP_HIP(hipMemcpyAsync(ctx->d_values.p, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     ctx->n_values = n;
+    ctx->values_total = 0;
     return DP_OK;
 }
 

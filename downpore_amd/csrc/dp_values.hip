@@ -95,6 +95,7 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     } while (0)
     if (dev_reserve(ctx, ctx->d_values, n * sizeof(double))) return DP_ERR_HIP;
     ctx->n_values = 0;
+    ctx->values_total = 0;
     double* values = (double*)ctx->d_values.p;
     DPV(hipMalloc(&d_merged, n * 8));
     DPV(hipMalloc(&d_small, 64));
@@ -177,6 +178,7 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     d_counts = nullptr;
     cleanup();
     ctx->n_values = n;
+    ctx->values_total = tot;
 #undef DPV
     return DP_OK;
 }
@@ -191,5 +193,51 @@ extern "C" int dp_values_download(dp_ctx* ctx, double* values_out, uint64_t n) {
     hipError_t e = hipMemcpyAsync(values_out, src->d_values.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = dp_stream_sync(ctx);
     if (e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, "dp_values_download", e);
+    return DP_OK;
+}
+
+// code of a k-mer = its own count where the table holds a value, 0 where the value is 0 (count < 3, 1 % cut, k-mer 0)
+__global__ void values_codes_kernel(const uint32_t* __restrict__ counts, const double* __restrict__ values, uint64_t n,
+                                    uint16_t* __restrict__ codes, uint32_t* __restrict__ overflow) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = values[i] == 0.0 ? 0u : counts[i];
+    if (c > 65535u) {
+        *overflow = 1u;
+        c = 65535u;
+    }
+    codes[i] = (uint16_t)c;
+}
+
+// The value of a k-mer is a function of its own count and the total alone (overlap.go:73-88), so the table dp_kmer_values
+// left resident travels as 2 bytes per k-mer: codes_out[i] = count of k-mer i, or 0 where its value is 0; *total_out = the
+// sum of all counts (overlap.go:60-63).  A caller rebuilds value(i) = f(codes[i], total) bit for bit from 65536
+// evaluations.  *overflow_out = 1 when a valued k-mer has a count above 65535 (use dp_values_download then).
+// DP_ERR_STATE when the table was uploaded (dp_values_upload) rather than computed here: there is no histogram then.
+extern "C" int dp_values_download_codes(dp_ctx* ctx, uint16_t* codes_out, uint64_t n, uint64_t* total_out, int* overflow_out) {
+    if (!ctx || !codes_out || !total_out || !overflow_out)
+        return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_values_download_codes: bad arguments") : DP_ERR_ARG;
+    const dp_ctx* src = ctx->owner ? ctx->owner : ctx;
+    if (!src->d_values.p || src->n_values != n || !src->d_kcounts || ((uint64_t)1 << (2 * src->kcounts_k)) != n || !src->values_total)
+        return dp_fail(ctx, DP_ERR_STATE, "dp_values_download_codes: no computed value table of this size resident");
+    hipSetDevice(ctx->device);
+    void* d_codes = nullptr;
+    hipError_t e = hipMalloc(&d_codes, n * 2 + 64);
+    if (e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, "dp_values_download_codes: hipMalloc", e);
+    uint32_t* d_flag = (uint32_t*)((char*)d_codes + n * 2);
+    uint32_t flag = 0;
+    e = hipMemsetAsync(d_flag, 0, 4, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(values_codes_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)src->d_kcounts,
+                           (const double*)src->d_values.p, n, (uint16_t*)d_codes, d_flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(codes_out, d_codes, n * 2, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = dp_stream_sync(ctx);
+    hipFree(d_codes);
+    if (e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, "dp_values_download_codes", e);
+    *total_out = src->values_total;
+    *overflow_out = (int)flag;
     return DP_OK;
 }

@@ -127,6 +127,23 @@ struct Arena {
     }
 };
 
+// The k-mer value table (commands/overlap.go:55-93) as the selection loops read it: 4^k doubles, or - a value being a function
+// of the k-mer's own count and the total count alone - one 2-byte code per k-mer (its count; 0 = value 0) with the 65536
+// values the codes stand for (dp_values_download_codes).  Both forms give the same double for every k-mer.
+struct ValueView {
+    const double* full = nullptr;
+    const uint16_t* codes = nullptr;
+    const double* lut = nullptr;
+    ValueView() {}
+    ValueView(const double* f) : full(f) {}
+    ValueView(const uint16_t* c, const double* l) : codes(c), lut(l) {}
+    double at(uint32_t kmer) const { return full ? full[kmer] : lut[codes[kmer]]; }
+    void prefetch(uint32_t kmer) const {
+        if (full) __builtin_prefetch(&full[kmer], 0, 0);
+        else __builtin_prefetch(&codes[kmer], 0, 0);
+    }
+};
+
 // Host mirror of seeds.SeedIndex (seeds/seeds.go:11-21): the seed <-> k-mer maps and the list of indexed sequences.
 // The posting sets / seed sets themselves live on the GPU (dp_index_build).
 struct SeedIndex {
@@ -163,9 +180,9 @@ struct SeedIndex {
     }
     void grow();
     void addSeedKmer(uint32_t kmer);                                     // seeds.go:132-141
-    void addSeeds(const char* s, i64 len, int minSeeds, const double* ranks);  // AddSeeds :62-156
+    void addSeeds(const char* s, i64 len, int minSeeds, ValueView ranks);  // AddSeeds :62-156
     // q (may be null): the window's quality bytes (seq.Quality(), seeds.go:73): value *= q[nextIndex - k/2] (:99-101)
-    void selectSeeds(const char* s, i64 len, int minSeeds, const double* ranks, uint32_t* topN, bool checkIndex,
+    void selectSeeds(const char* s, i64 len, int minSeeds, ValueView ranks, uint32_t* topN, bool checkIndex,
                      const uint8_t* q = nullptr) const;
     bool touchesSeed(const char* s, i64 len) const;
     bool touchesSeed(const uint32_t* kmers, uint32_t n) const {  // the same test on the window's evaluated k-mers
@@ -315,7 +332,7 @@ class Overlapper {
                double hitFraction);
     // PrepareQueries (:157): seed selection over the query windows; returns the windows (queries are completed by
     // AddSequences, which scans them on the GPU together with the reads)
-    int PrepareQueries(int numSeeds, i64 seedLimit, const double* kmerValues, i64 firstSequence, i64 maxSeqs, int queryType = 1);
+    int PrepareQueries(int numSeeds, i64 seedLimit, ValueView kmerValues, i64 firstSequence, i64 maxSeqs, int queryType = 1);
     // AddSequences (:217): GPU scan of every non-ignored read in [shardLo, shardHi) + all query windows
     int ScanLocal(size_t shardLo, size_t shardHi, Survivors& local, RoundStats& st);
     // chunkWorker (:253) + IndexSequences on the GPU, from the (possibly all-gathered) survivors
@@ -351,7 +368,7 @@ class Overlapper {
     const uint8_t* ignore_ = nullptr;
     uint64_t ignoreEpoch_ = 0;
     WindowCache* cache_ = nullptr;
-    int prepareFromCache(int numSeeds, i64 seedLimit, const double* values, i64 firstSequence, i64 maxSeqs);
+    int prepareFromCache(int numSeeds, i64 seedLimit, ValueView values, i64 firstSequence, i64 maxSeqs);
     dp_ctx* ctx_;
     ReadSet& reads_;
     SeedIndex& index_;
@@ -403,7 +420,7 @@ struct RoundPlan {
 class Planner {
    public:
     // selCtx (may be null): device context whose resident reads + value table serve the speculative seed selection
-    Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded, dp_ctx* selCtx = nullptr,
+    Planner(ReadSet& reads, const OverlapParams& p, ValueView values, bool threaded, dp_ctx* selCtx = nullptr,
             WindowCache* cache = nullptr);
     ~Planner();
     std::shared_ptr<const RoundPlan> get(i64 round);
@@ -465,6 +482,13 @@ struct OverlapRun {
         const double* data() const { return p; }
         size_t size() const { return n; }
     } values;
+    // ... or, when the table was computed on the device, its 2-byte form (see ValueView); `values` is then filled on demand
+    HugeTable valueCodes;            // 4^k uint16 codes (the table's storage reused: bytes, not doubles)
+    std::vector<double> valueLut;    // value of every code
+    ValueView valueView() const {
+        return valueLut.empty() ? ValueView(values.data()) : ValueView((const uint16_t*)valueCodes.data(), valueLut.data());
+    }
+    const double* fullValues();      // the 4^k doubles (expands the 2-byte form the first time it is asked for)
     std::vector<std::unique_ptr<ExecSlot>> slots;  // slot 0 drives `ctx`; further slots use contexts that borrow its reads
     std::unique_ptr<WindowCache> winCache;  // QueryEdges: the windows' round-independent part, produced ahead of the planner
     std::unique_ptr<Planner> planner;

@@ -191,8 +191,9 @@ void dph_overlap_set_shard(void* hh, int64_t lo, int64_t hi) {
 }
 const double* dph_overlap_values(void* hh, int64_t* n) {
     OverlapH* h = (OverlapH*)hh;
+    const double* v = h->run.fullValues();
     *n = (int64_t)h->run.values.size();
-    return h->run.values.data();
+    return v;
 }
 // 1 = a round was prepared and the local shard scanned; 0 = no more rounds; <0 error
 int dph_overlap_round_scan(void* hh) {

@@ -21,7 +21,7 @@ Overlapper::Overlapper(dp_ctx* ctx, ReadSet& reads, SeedIndex& index, i64 chunkS
 // PrepareQueries for QueryEdges from the window cache: per window the evaluated k-mers are probed against the seeds
 // committed so far; untouched, the cached selection is what AddSeeds would pick and is committed as is; touched, AddSeeds
 // runs for real (the block that contains the seed is abandoned, seeds.go:94-97, and the walk goes on from there).
-int Overlapper::prepareFromCache(int numSeeds, i64 seedLimit, const double* values, i64 firstSequence, i64 maxSeqs) {
+int Overlapper::prepareFromCache(int numSeeds, i64 seedLimit, ValueView values, i64 firstSequence, i64 maxSeqs) {
     if (firstSequence != 0 && firstSequence >= (i64)reads_.size()) return 0;  // seqio.go:279
     const double t0 = now();
     std::vector<uint32_t> tmp((size_t)numSeeds);
@@ -49,7 +49,7 @@ int Overlapper::prepareFromCache(int numSeeds, i64 seedLimit, const double* valu
     return (int)windows_.size();
 }
 
-int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, const double* values, i64 firstSequence, i64 maxSeqs, int queryType) {
+int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, ValueView values, i64 firstSequence, i64 maxSeqs, int queryType) {
     windows_.clear();
     queries.clear();
     const bool weightSides = (queryType & 8) != 0;  // WeightEdges: seeds come from the two 200-base sides of a window

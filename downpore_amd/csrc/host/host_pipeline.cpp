@@ -157,7 +157,7 @@ void WindowCache::release(size_t belowRead) {
 struct Planner::Impl {
     ReadSet& reads;
     OverlapParams p;
-    const double* values;
+    ValueView values;
     bool threaded;
     dp_ctx* selCtx;
     WindowCache* winCache = nullptr;
@@ -174,11 +174,11 @@ struct Planner::Impl {
     bool stop = false;
     long testDelayUs = 0;     // DPH_TEST_PLAN_DELAY_US: sleep before every compute (tests/test_planner_epoch.py)
     std::thread th;
-    Impl(ReadSet& r, const OverlapParams& pp, const double* v, bool t, dp_ctx* sc)
+    Impl(ReadSet& r, const OverlapParams& pp, ValueView v, bool t, dp_ctx* sc)
         : reads(r), p(pp), values(v), threaded(t), selCtx(sc), index(pp.k) {}
 };
 
-Planner::Planner(ReadSet& reads, const OverlapParams& p, const double* values, bool threaded, dp_ctx* selCtx, WindowCache* cache)
+Planner::Planner(ReadSet& reads, const OverlapParams& p, ValueView values, bool threaded, dp_ctx* selCtx, WindowCache* cache)
     : d(new Impl(reads, p, values, threaded, selCtx)) {
     d->winCache = cache;
     if (const char* e = getenv("DPH_TEST_PLAN_DELAY_US")) d->testDelayUs = atol(e);
@@ -394,6 +394,16 @@ double* OverlapRun::HugeTable::reserve(size_t count) {
     return p;
 }
 
+const double* OverlapRun::fullValues() {
+    if (values.size() == 0 && !valueLut.empty()) {
+        const size_t nk = (size_t)1 << (2 * p.k);
+        double* dst = values.reserve(nk);
+        const uint16_t* codes = (const uint16_t*)valueCodes.data();
+        for (size_t i = 0; i < nk; i++) dst[i] = valueLut[codes[i]];
+    }
+    return values.data();
+}
+
 void OverlapRun::HugeTable::clear() {
     if (base_) munmap(base_, mapped_);
     base_ = nullptr;
@@ -493,16 +503,27 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
             if (t.joinable()) t.join();
         }
     } joiner{dl};
+    valueLut.clear();
+    valueCodes.clear();
+    uint64_t dlTotal = 0;
+    int dlOverflow = 0;
     if (valuesOnDevice) {
-        double* dst = values.reserve((size_t)1 << (2 * p.k));
-        dl = std::thread([this, dst, &dlRc, &dlErr] {
+        // 2 bytes per k-mer instead of 8 (dp_values_download_codes): a quarter of the copy and of the host pages to touch
+        const size_t nk = (size_t)1 << (2 * p.k);
+        values.clear();
+        uint16_t* dst = (uint16_t*)valueCodes.reserve((nk + 3) / 4);
+        dl = std::thread([this, dst, nk, &dlRc, &dlErr, &dlTotal, &dlOverflow] {
             dp_ctx* c2 = nullptr;
             dlRc = dp_ctx_create_shared(ctx, &c2);
             if (dlRc != 0) {
                 dlErr = dp_last_error(nullptr);
                 return;
             }
-            dlRc = dp_values_download(c2, dst, (uint64_t)1 << (2 * p.k));
+            dlRc = dp_values_download_codes(c2, dst, nk, &dlTotal, &dlOverflow);
+            if (dlRc == 0 && dlOverflow) {  // a valued k-mer seen more than 65535 times: the table as doubles
+                double* full = values.reserve(nk);
+                dlRc = dp_values_download(c2, full, nk);
+            }
             if (dlRc != 0) dlErr = dp_last_error(c2);
             dp_ctx_destroy(c2);
         });
@@ -574,9 +595,19 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
             error = dlErr;
             return dlRc;
         }
+        if (valuesOnDevice && !dlOverflow) {  // overlap.go:73-88, once per possible count
+            valueLut.resize(65536);
+            const double tf = (double)dlTotal, targetFreq = 0.000005;
+            for (uint32_t c = 0; c < 65536; c++) {
+                const double freq = (double)c / tf;
+                valueLut[c] = c < 3 ? 0.0 : freq <= targetFreq ? 1.0 - (targetFreq - freq) : 1.0 - (freq - targetFreq);
+            }
+        } else {
+            valueCodes.clear();
+        }
         mark("values copy (overlapped)");
     }
-    planner.reset(new Planner(*reads, p, values.data(), !(nothread && nothread[0] == '1'), plannerCtx, winCache.get()));
+    planner.reset(new Planner(*reads, p, valueView(), !(nothread && nothread[0] == '1'), plannerCtx, winCache.get()));
     mark("planner");
     firstSequence = 0;
     round = 0;

@@ -302,7 +302,7 @@ int32_t SeedIndex::seedOfRcKmer(int32_t seed) const {
 // selectSeeds() is the selection loop; with checkIndex=false it assumes no evaluated k-mer is a seed yet (the
 // speculative, thread-parallel form used by Overlapper::PrepareQueries), touchesSeed() tests exactly that assumption.
 template <bool CHECK>
-static void selectSeedsT(const SeedIndex& ix, const char* s, i64 L, int minSeeds, const double* ranks, uint32_t* topN, const uint8_t* q) {
+static void selectSeedsT(const SeedIndex& ix, const char* s, i64 L, int minSeeds, ValueView ranks, uint32_t* topN, const uint8_t* q) {
     const int k = ix.k;
     const uint32_t mask = (uint32_t)(((uint64_t)1 << (2 * k)) - 1);
     double topVbuf[64];
@@ -331,7 +331,7 @@ static void selectSeedsT(const SeedIndex& ix, const char* s, i64 L, int minSeeds
             uint32_t pk = kmer;
             for (i64 pi = nextIndex, i = 0; pi < L && i < k; i++, pi++) {
                 pk = ((pk << 2) | baseCode((unsigned char)s[pi])) & mask;
-                __builtin_prefetch(&ranks[pk], 0, 0);
+                ranks.prefetch(pk);
             }
         }
         for (int i = 0; nextIndex < L && i < k; i++) {
@@ -341,7 +341,7 @@ static void selectSeedsT(const SeedIndex& ix, const char* s, i64 L, int minSeeds
                 reset = true;
                 break;
             }
-            double value = ranks[kmer];
+            double value = ranks.at(kmer);
             if (q) value *= (double)q[nextIndex - k / 2];  // seeds.go:99-101
             if (value > bestValue) {
                 bestValue = value;
@@ -367,7 +367,7 @@ static void selectSeedsT(const SeedIndex& ix, const char* s, i64 L, int minSeeds
     }
 }
 
-void SeedIndex::selectSeeds(const char* s, i64 L, int minSeeds, const double* ranks, uint32_t* topN, bool checkIndex,
+void SeedIndex::selectSeeds(const char* s, i64 L, int minSeeds, ValueView ranks, uint32_t* topN, bool checkIndex,
                             const uint8_t* q) const {
     if (checkIndex) selectSeedsT<true>(*this, s, L, minSeeds, ranks, topN, q);
     else selectSeedsT<false>(*this, s, L, minSeeds, ranks, topN, q);
@@ -403,7 +403,7 @@ void SeedIndex::commitSeeds(const uint32_t* topN, int n) {  // seeds.go:130-154
     }
 }
 
-void SeedIndex::addSeeds(const char* s, i64 L, int minSeeds, const double* ranks) {
+void SeedIndex::addSeeds(const char* s, i64 L, int minSeeds, ValueView ranks) {
     std::vector<uint32_t> topN((size_t)minSeeds, 0);
     selectSeeds(s, L, minSeeds, ranks, topN.data(), true);
     commitSeeds(topN.data(), minSeeds);

@@ -91,6 +91,13 @@ DP_API int dp_kmer_values(dp_ctx* ctx, int k, double* values_out);
 /* The resident table (n = 4^k doubles) copied to the host on the CALLING context's stream - a context that borrows the
  * reads may do it while the owner goes on with dp_scan_prepare. */
 DP_API int dp_values_download(dp_ctx* ctx, double* values_out, uint64_t n);
+/* The same table at 2 bytes per k-mer.  A value is a function of the k-mer's own count and the total count alone
+ * (commands/overlap.go:73-88), so codes_out[i] = count of k-mer i where the table holds a value and 0 where it holds 0
+ * (count < 3, the 1 % cut of kmers.go:98-110, k-mer 0); *total_out = tot of overlap.go:60-63.  value(i) is then
+ * f(codes_out[i], total) - 65536 evaluations of overlap.go's expression rebuild every entry bit for bit.
+ * *overflow_out = 1 when a k-mer that holds a value was seen more than 65535 times (its code saturates: fetch the table
+ * with dp_values_download instead).  DP_ERR_STATE for a table installed by dp_values_upload (no histogram behind it). */
+DP_API int dp_values_download_codes(dp_ctx* ctx, uint16_t* codes_out, uint64_t n, uint64_t* total_out, int* overflow_out);
 
 /* ---- round state: the seed set --------------------------------------------------------------------------
  * Mirrors the per-round SeedIndex tables kmers/kmerMap/seedMap (seeds/seeds.go:13-18): seed id = position in

@@ -304,6 +304,36 @@ def test_scan_prepare_index_and_scan_modes_agree(ctx):
         ctx.set_priority(False)
 
 
+@pytest.mark.parametrize("n_seeds", [40000, 150000, 400000, 800000])
+def test_index_mode_write_sort_tiers(ctx, n_seeds):
+    """The index-mode write step sorts a read's hits inside one wave's LDS: shuffle ranks up to 64 hits, an LDS rank sort up to
+    half the block's key capacity, a bitonic network above that (three block sizes, picked by the round's largest count).
+    Denser and denser seed sets walk a 3000-base read through every tier; the scan kernels are the check."""
+    k = 10
+    bases, off = O.gen_reads(21, 60000, 200, 3000, 0.01, True)
+    N = 200
+    ctx.upload_reads(bases, off)
+    rng = np.random.default_rng(n_seeds)
+    seeds = rng.choice(np.arange(1, 4 ** k, dtype=np.uint32), size=n_seeds, replace=False)
+    ignore = np.zeros(N, dtype=np.uint8)
+    os.environ["DP_SCAN_INDEX"] = "1"
+    try:
+        ctx.scan_prepare(k)
+        ctx.round_begin(k, np.sort(seeds))
+        outs = {}
+        for mode in ("1", "0"):
+            os.environ["DP_SCAN_INDEX"] = mode
+            got = ctx.scan_reads(ignore, 3, 0, N, False, 20, [(7, 10, 900, 0)])
+            assert got["index_mode"] == int(mode)
+            outs[mode] = {f: np.array(got[f]).copy() for f in ("read", "n_seeds", "seg_off", "extra_n_seeds", "segs")}
+        assert len(outs["1"]["read"]) > 0
+        for f in outs["1"]:
+            assert np.array_equal(outs["1"][f], outs["0"][f]), f
+        print("largest hit count", int(outs["1"]["n_seeds"].max()))
+    finally:
+        del os.environ["DP_SCAN_INDEX"]
+
+
 def test_scan_reads_compaction_matches_itemwise_scan(ctx):
     """dp_scan_reads (items generated and survivors compacted on the device) == dp_scan item by item + host filter."""
     k = 10
