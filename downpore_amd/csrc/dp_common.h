@@ -46,6 +46,7 @@ struct dp_ctx {
     DevBuf d_len;               // uint32 length in bases                      [n_reads]
     DevBuf d_values;            // 4^k doubles (kmerRanks) for dp_select_seeds; shared like the reads
     uint64_t n_values = 0;
+    bool values_computed = false;  // the resident table came from dp_kmer_values (its histogram and total are known)
     uint64_t values_total = 0;  // sum of the k-mer counts the resident table was computed from (0: uploaded table)
     DevBuf d_qual, d_qualoff, d_hasq;  // FASTQ quality bytes of the reads (dp_quality_upload); shared like the reads
     DevBuf d_selwin, d_seltop;
@@ -75,6 +76,17 @@ struct dp_ctx {
     uint64_t cached_bases = 0;
     uint32_t cached_reads = 0, cached_lo = 0, cached_hi = 0;
     int cached_top = -1, cached_k = 0;
+    // the read items on the device (make_read_items_kernel) are regenerated only when what they are made from changes
+    const void* items_ptr = nullptr;
+    uint64_t items_epoch = ~0ull;
+    uint32_t items_lo = 0, items_hi = 0, items_min = 0;
+    int items_top = -1, items_k = 0;
+    // pinned staging of borrowed host inputs whose copies are still in flight when a call returns (dp_stage); every
+    // dp_stream_sync empties it
+    PinBuf h_stage;
+    size_t stage_used = 0;
+    bool timing_on = true;
+    uint64_t round_serial = 0;
 
     // ---- index (A13)
     uint32_t n_seqs = 0, W = 0, SW = 0;
@@ -87,6 +99,8 @@ struct dp_ctx {
     void* d_kcounts = nullptr;  // k-mer histogram (uint32 [4^kcounts_k]) left behind by dp_kmer_values for the k-mer index build
     int kcounts_k = 0;
     std::vector<void*> retired_dev, retired_pin;  // outgrown buffers, released with the context (dev_reserve / pin_reserve)
+    const int32_t* qsegs_dev = nullptr;             // the query segments and offsets of the last dp_query_stage (inside d_qsegs)
+    const uint64_t* qoff_dev = nullptr;
     DevBuf d_qsegs, d_qoff, d_qsets, d_qmeta, d_cand, d_pool, d_mrec, d_ma, d_mb, d_cursor, d_sched, d_manchor;
     DevBuf d_pbase, d_pspec, d_clist, d_sa, d_sb;  // chaining stage: pair offsets, proposals, candidate lists, scratch columns
     uint32_t n_pairs = 0;                          // (query, candidate) pair slots of the last dp_find_overlaps
@@ -102,6 +116,20 @@ int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess);
 hipError_t dp_stream_sync(dp_ctx* ctx);
 int dev_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
 int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
+// kernel timing events of the per-round calls: recorded while ctx->timing_on (DP_KERNEL_TIMING, see dp_round_begin)
+inline hipError_t dp_mark(dp_ctx* ctx, int i) { return ctx->timing_on ? hipEventRecord(ctx->ev[i], ctx->stream) : hipSuccess; }
+inline float dp_elapsed(dp_ctx* ctx, int a, int b) {
+    float ms = 0;
+    if (ctx->timing_on && hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) != hipSuccess) ms = 0;
+    return ms;
+}
+void* dp_stage(dp_ctx* ctx, const void* src, size_t bytes);
+// up to four device regions (8-byte aligned, sizes rounded up to 8 bytes) set to zero by ONE launch on the context's stream
+struct dp_zero_region {
+    void* p;
+    size_t bytes;
+};
+int dp_zero_regions(dp_ctx* ctx, const dp_zero_region* r, int n);  // pinned copy of a caller buffer, valid until the next dp_stream_sync
 
 #define DP_HIP(call)                                                          \
     do {                                                                      \
@@ -116,7 +144,7 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
                            float* ms_out);  // dp_kbuild.hip
 void dp_kindex_free(dp_ctx* ctx);
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
-                    uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint64_t* d_totals);
+                    uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint4* s_pack, uint64_t* d_totals);
 int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     const uint32_t* d_sel, uint32_t n_sel, uint32_t max_count, const uint32_t* d_counts, const uint64_t* d_segoff,
                     const uint64_t* d_totals, int32_t* d_segs);

@@ -274,18 +274,18 @@ extern "C" int dp_consensus_align(dp_ctx* ctx, const int32_t* segs, const uint64
     int32_t* d_mb = (int32_t*)(dout + b_cons + b_clen + b_m);
     uint32_t* d_mlen = (uint32_t*)(dout + b_cons + b_clen + 2 * b_m);
     uint32_t* d_flag = (uint32_t*)(dout + b_cons + b_clen + 2 * b_m + b_mlen);
-    DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    DP_HIP(dp_mark(ctx, 0));
     hipLaunchKernelGGL(consensus_align_kernel, dim3((n_groups + CA_WAVES - 1) / CA_WAVES), dim3(64 * CA_WAVES), 0, ctx->stream,
                        (const int32_t*)(din + b_soff + b_coff), (const uint64_t*)din, (const uint32_t*)(din + b_soff + b_coff + b_segs),
                        n_groups, k, d_cons, (const uint64_t*)(din + b_soff), d_clen, d_ma, d_mb, d_mlen, d_flag);
     DP_HIP(hipGetLastError());
-    DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    DP_HIP(dp_mark(ctx, 1));
     uint8_t* hout = (uint8_t*)ctx->h_cout.p;
     DP_HIP(hipMemcpyAsync(hout, dout, out_bytes - 64, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     memcpy(hout + out_bytes, h_coff, b_coff);
     float ms = 0;
-    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+    ms = dp_elapsed(ctx, 0, 1);
     out->kernel_ms = ms;
     out->cons = (const int32_t*)hout;
     out->cons_len = (const uint32_t*)(hout + b_cons);
@@ -1070,8 +1070,8 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     A.ma = (const int32_t*)ctx->d_ma.p;
     A.mb = (const int32_t*)ctx->d_mb.p;
     A.pbase = (const uint32_t*)((const uint64_t*)ctx->d_pbase.p + nq + 1);
-    A.qsegs = (const int32_t*)ctx->d_qsegs.p;
-    A.qoff = (const uint64_t*)ctx->d_qoff.p;
+    A.qsegs = ctx->qsegs_dev;
+    A.qoff = (const uint64_t*)ctx->qoff_dev;
     A.n_groups = ng;
     A.refs = (const dp_seq_ref*)ctx->d_seqrefs.p;
     A.segs = (const int32_t*)ctx->d_segs.p;
@@ -1094,14 +1094,14 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
         DP_HIP(hipMalloc((void**)&A.dbg, (size_t)ng * 64));
         DP_HIP(hipMemsetAsync(A.dbg, 0, (size_t)ng * 64, ctx->stream));
     }
-    DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    DP_HIP(dp_mark(ctx, 0));
     hipLaunchKernelGGL(consensus_full_kernel, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), 0, ctx->stream, A);
     DP_HIP(hipGetLastError());
-    DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    DP_HIP(dp_mark(ctx, 1));
     DP_HIP(hipMemcpyAsync(ctx->h_cout.p, dout, b_paf + b_ign + b_gm, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     float ms = 0;
-    hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
+    ms = dp_elapsed(ctx, 0, 1);
     out->kernel_ms = ms;
     if (cons_debug) {  // per-phase time of the groups that ran to the end: mean and maximum, in microseconds
         std::vector<unsigned long long> h((size_t)ng * 8);

@@ -222,6 +222,17 @@ __global__ void kidx_link_extra(const dp_scan_item* __restrict__ items, uint32_t
     if (e >= n_extra) return;
     next[e] = atomicExch(&head[items[n_read_items + e].read], e + 1);
 }
+// start of a round's counting step in one launch: the work area (fill cursors, tile status, ticket, hit slots), the item
+// counters and the totals go to zero, and the extra items are linked to their reads (head[] is all zero between calls)
+__global__ void kidx_prepare(uint32_t* __restrict__ work, uint32_t n_work, uint32_t* __restrict__ counts, uint32_t n_counts,
+                             uint32_t* __restrict__ totals16, const dp_scan_item* __restrict__ items, uint32_t n_read_items,
+                             uint32_t n_extra, uint32_t* __restrict__ head, uint32_t* __restrict__ next) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_work) work[i] = 0;
+    if (i < n_counts) counts[i] = 0;
+    if (i < 16) totals16[i] = 0;
+    if (i < n_extra) next[i] = atomicExch(&head[items[n_read_items + i].read], i + 1);
+}
 __global__ void kidx_unlink_extra(const dp_scan_item* __restrict__ items, uint32_t n_read_items, uint32_t n_extra,
                                   uint32_t* __restrict__ head) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -286,7 +297,8 @@ __global__ __launch_bounds__(KX_TILE) void kidx_offsets(const dp_scan_item* __re
                                                        uint32_t n, unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket,
                                                        uint64_t* __restrict__ segoff, uint32_t* __restrict__ s_item,
                                                        uint32_t* __restrict__ s_count, uint64_t* __restrict__ s_off,
-                                                       uint64_t* __restrict__ totals, uint32_t* __restrict__ max_count,
+                                                       uint4* __restrict__ s_pack, uint64_t* __restrict__ totals,
+                                                       uint32_t* __restrict__ max_count,
                                                        const unsigned long long* __restrict__ n_hits) {
     __shared__ uint32_t shA[16], shB[16];
     __shared__ uint32_t tile_s;
@@ -379,6 +391,7 @@ __global__ __launch_bounds__(KX_TILE) void kidx_offsets(const dp_scan_item* __re
                 s_item[slot] = i;
                 s_count[slot] = cc[u];
                 s_off[slot] = so;
+                s_pack[slot] = make_uint4(i, cc[u], (uint32_t)so, (uint32_t)(so >> 32));  // the same triple, as the host fetches it
                 slot++;
             }
             so += segv[u];
@@ -395,10 +408,13 @@ template <int CAP>
 __global__ __launch_bounds__(64) void kidx_sortwrite(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ sel,
                                                      const uint32_t* __restrict__ n_sel_p, const uint32_t* __restrict__ counts,
                                                      const uint64_t* __restrict__ segoff, int32_t* __restrict__ segs, int k,
-                                                     uint32_t* __restrict__ overflow) {
+                                                     uint32_t* __restrict__ overflow, uint32_t n_read_items, uint32_t n_extra,
+                                                     uint32_t* __restrict__ head) {
     __shared__ unsigned long long keys[CAP];
     const int lane = dp_lane();
     const uint32_t n_sel = *n_sel_p;
+    // the fill pass (previous launch) was the last reader of the extra items' lists: head[] back to all zero
+    for (uint32_t e = blockIdx.x * 64 + lane; e < n_extra; e += gridDim.x * 64) head[items[n_read_items + e].read] = 0;
     for (uint32_t sv = blockIdx.x; sv < n_sel; sv += gridDim.x) {
         const uint32_t it = sel[sv];
         const uint32_t c = counts[it];
@@ -474,7 +490,8 @@ __global__ __launch_bounds__(64) void kidx_sortwrite(const dp_scan_item* __restr
 // Counting step of a round from the index: counts, segment offsets, compacted survivor list and totals for all items, with
 // no host round trip.  d_work = [counts n | fill cursors n | tile status (tiles + 1) u64 | ticket, max count] (zeroed here).
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
-                    uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint64_t* d_totals) {
+                    uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint4* s_pack,
+                    uint64_t* d_totals) {
     dp_kindex* ix = kidx_owner(ctx)->kidx;
     const uint32_t S = ctx->n_seeds, n_items = n_read_items + n_extra;
     if (n_items >= (1u << 24)) return 1;  // (the scan's status word holds 24 bits of survivors) -> scan kernels
@@ -497,23 +514,23 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     uint32_t* fillc = (uint32_t*)ctx->d_kx_sz.p;
     unsigned long long* status = (unsigned long long*)((uint8_t*)ctx->d_kx_sz.p + ((b_counts + 7) & ~(size_t)7));
     uint32_t* ticket = (uint32_t*)(status + n_tiles + 1);
-    uint32_t* maxc = ticket + 1;
     unsigned long long* n_hits = (unsigned long long*)(ticket + 2);  // [64]
-    DP_HIP(hipMemsetAsync(ctx->d_kx_sz.p, 0, ((b_counts + 7) & ~(size_t)7) + ((size_t)n_tiles + 1) * 8 + 8 + 64 * 8, ctx->stream));
-    DP_HIP(hipMemsetAsync(d_counts, 0, b_counts, ctx->stream));
-    DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    if (n_extra)
-        hipLaunchKernelGGL(kidx_link_extra, dim3((n_extra + 255) / 256), dim3(256), 0, ctx->stream, d_items, n_read_items, n_extra, head, next);
+    const uint32_t n_work = (uint32_t)((((b_counts + 7) & ~(size_t)7) + ((size_t)n_tiles + 1) * 8 + 8 + 64 * 8) / 4);
+    DP_HIP(dp_mark(ctx, 0));
+    {
+        const uint32_t n_thr = std::max(std::max(n_work, n_items), std::max(n_extra, 16u));
+        hipLaunchKernelGGL(kidx_prepare, dim3((n_thr + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)ctx->d_kx_sz.p, n_work, d_counts, n_items,
+                           (uint32_t*)d_totals, d_items, n_read_items, n_extra, head, next);
+    }
     if (S)
         hipLaunchKernelGGL(kidx_walk<false>, dim3((S * KX_PARTS + 3) / 4), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
                            (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
                            (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits);
+    // totals[2] = seed occurrences in the read set, totals[3] = largest survivor count (both written by the kernel)
     hipLaunchKernelGGL(kidx_offsets, dim3(n_tiles), dim3(KX_TILE), 0, ctx->stream, d_items, (const uint32_t*)d_counts, n_items, status, ticket,
-                       d_segoff, s_item, s_count, s_off, d_totals, maxc, (const unsigned long long*)n_hits);
+                       d_segoff, s_item, s_count, s_off, s_pack, d_totals, (uint32_t*)(d_totals + 3), (const unsigned long long*)n_hits);
     DP_HIP(hipGetLastError());
-    DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-    // totals[2] = seed occurrences in the read set (written by the kernel), totals[3] = largest survivor count
-    DP_HIP(hipMemcpyAsync(d_totals + 3, maxc, 4, hipMemcpyDeviceToDevice, ctx->stream));
+    DP_HIP(dp_mark(ctx, 1));
     (void)k;
     return DP_OK;
 }
@@ -542,14 +559,17 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         uint32_t* ovf = (uint32_t*)(d_totals + 4);
         const uint32_t* nsp = (const uint32_t*)(d_totals + 1);
         if (max_count <= 128)
-            hipLaunchKernelGGL(kidx_sortwrite<256>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf);
+            hipLaunchKernelGGL(kidx_sortwrite<256>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
+                               n_extra, head);
         else if (max_count <= 512)
-            hipLaunchKernelGGL(kidx_sortwrite<1024>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf);
+            hipLaunchKernelGGL(kidx_sortwrite<1024>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
+                               n_extra, head);
         else
-            hipLaunchKernelGGL(kidx_sortwrite<KX_SORT_LDS>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf);
+            hipLaunchKernelGGL(kidx_sortwrite<KX_SORT_LDS>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf,
+                               n_read_items, n_extra, head);
         DP_HIP(hipGetLastError());
     }
-    if (n_extra)
+    if (n_extra && (rc != DP_OK || !n_sel))  // (otherwise the sort kernel has put head[] back to zero)
         hipLaunchKernelGGL(kidx_unlink_extra, dim3((n_extra + 255) / 256), dim3(256), 0, ctx->stream, d_items, n_read_items, n_extra, head);
     DP_HIP(hipGetLastError());
     return rc;

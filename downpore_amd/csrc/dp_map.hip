@@ -362,8 +362,8 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
         if (dev_reserve(ctx, ctx->d_mb, (size_t)int_cap * 4)) return DP_ERR_HIP;
         DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 64, ctx->stream));
         DP_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-        hipLaunchKernelGGL(map_kernel, dim3(blocks), dim3(64 * M_WAVES), 0, ctx->stream, (const int32_t*)ctx->d_qsegs.p,
-                           (const u64*)ctx->d_qoff.p, (const uint32_t*)ctx->d_sched.p, n_pairs, (const u64*)ctx->d_qsets.p,
+        hipLaunchKernelGGL(map_kernel, dim3(blocks), dim3(64 * M_WAVES), 0, ctx->stream, ctx->qsegs_dev,
+                           ctx->qoff_dev, (const uint32_t*)ctx->d_sched.p, n_pairs, (const u64*)ctx->d_qsets.p,
                            (const uint32_t*)d_qmeta, (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p,
                            (const int32_t*)ctx->d_segs.p, (const u64*)ctx->d_seedsets.p, W, SW, k, poolA, poolB, poolLen,
                            (MapRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p, int_cap,

@@ -84,10 +84,14 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
     if (dev_reserve(ctx, ctx->d_posting, (size_t)S * W * 8 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_seedsets, (size_t)n_seqs * SW * 8 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_pmeta, (size_t)S * 16 + 16)) return DP_ERR_HIP;
-    DP_HIP(hipMemsetAsync(ctx->d_posting.p, 0, (size_t)S * W * 8 + 64, ctx->stream));
-    DP_HIP(hipMemsetAsync(ctx->d_seedsets.p, 0, (size_t)n_seqs * SW * 8 + 64, ctx->stream));
-    if (n_seqs) {
-        DP_HIP(hipMemcpyAsync(ctx->d_seqrefs.p, seqs, (size_t)n_seqs * sizeof(dp_seq_ref), hipMemcpyHostToDevice, ctx->stream));
+    {
+        const dp_zero_region z[2] = {{ctx->d_posting.p, (size_t)S * W * 8 + 64}, {ctx->d_seedsets.p, (size_t)n_seqs * SW * 8 + 64}};
+        if (int rc = dp_zero_regions(ctx, z, 2)) return rc;
+    }
+    if (n_seqs) {  // (seqs is borrowed only for the duration of the call: the copy leaves from pinned staging)
+        const void* st = dp_stage(ctx, seqs, (size_t)n_seqs * sizeof(dp_seq_ref));
+        if (!st) return DP_ERR_HIP;
+        DP_HIP(hipMemcpyAsync(ctx->d_seqrefs.p, st, (size_t)n_seqs * sizeof(dp_seq_ref), hipMemcpyHostToDevice, ctx->stream));
         uint32_t blocks = std::min<uint32_t>(2048, (n_seqs + 3) / 4);
         hipLaunchKernelGGL(index_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const dp_seq_ref*)ctx->d_seqrefs.p, n_seqs,
                            (const int32_t*)ctx->d_segs.p, (u64*)ctx->d_posting.p, (u64*)ctx->d_seedsets.p, W, SW);
@@ -99,8 +103,7 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
                            (uint32_t*)ctx->d_pmeta.p);
         DP_HIP(hipGetLastError());
     }
-    DP_HIP(dp_stream_sync(ctx));  // seqs is borrowed only for the duration of the call
-    return DP_OK;
+    return DP_OK;  // (in stream order before everything that reads the index; errors surface at the next synchronising call)
 }
 
 extern "C" int dp_index_build(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
@@ -1841,41 +1844,44 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
         volatile double sum = prod + 0.5;
         mc[n] = (int32_t)sum;
     }
-    if (dev_reserve(ctx, ctx->d_qsegs, nseg * 4 + 64)) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_qoff, ((size_t)nq + 1) * 8)) return DP_ERR_HIP;
+    // what the host sends - query offsets, query segments, the minCount table - is one block on both sides: one copy
+    const size_t up_segs = nseg * 4, up_off = ((size_t)nq + 1) * 8, up_mc = (size_t)mc_n * 4;
+    if (dev_reserve(ctx, ctx->d_qsegs, up_off + up_segs + up_mc + 64)) return DP_ERR_HIP;
+    ctx->qoff_dev = (const u64*)ctx->d_qsegs.p;
+    ctx->qsegs_dev = (const int32_t*)((const uint8_t*)ctx->d_qsegs.p + up_off);
     if (dev_reserve(ctx, ctx->d_qsets, (size_t)nq * SW * 8 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_qmeta, (size_t)nq * 16 + (size_t)nq * 8 + (size_t)nq * 4 + (size_t)mc_n * 4 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_cand, (size_t)nq * W * 8 + 64)) return DP_ERR_HIP;
     uint32_t* d_qmeta = (uint32_t*)ctx->d_qmeta.p;
     u64* d_words = (u64*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 16);
     uint32_t* d_qcnt = (uint32_t*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 24);
-    int32_t* d_mc = (int32_t*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 28);
+    const int32_t* d_mc = (const int32_t*)((const uint8_t*)ctx->d_qsegs.p + up_off + up_segs);
     // stage through pinned memory: copies from pageable buffers stall the stream
-    const size_t up_segs = nseg * 4, up_off = ((size_t)nq + 1) * 8, up_mc = (size_t)mc_n * 4;
     if (pin_reserve(ctx, ctx->h_qup, up_segs + up_off + up_mc + 64)) return DP_ERR_HIP;
     uint8_t* up = (uint8_t*)ctx->h_qup.p;
     memcpy(up, q_off, up_off);
     memcpy(up + up_off, q_segs, up_segs);
     memcpy(up + up_off + up_segs, mc.data(), up_mc);
-    DP_HIP(hipMemcpyAsync(ctx->d_qoff.p, up, up_off, hipMemcpyHostToDevice, ctx->stream));
-    DP_HIP(hipMemcpyAsync(ctx->d_qsegs.p, up + up_off, up_segs, hipMemcpyHostToDevice, ctx->stream));
-    DP_HIP(hipMemcpyAsync(d_mc, up + up_off + up_segs, up_mc, hipMemcpyHostToDevice, ctx->stream));
-    DP_HIP(hipMemsetAsync(ctx->d_qsets.p, 0, (size_t)nq * SW * 8, ctx->stream));
-    DP_HIP(hipMemsetAsync(ctx->d_cand.p, 0, (size_t)nq * W * 8, ctx->stream));
-    DP_HIP(hipMemsetAsync(d_qmeta, 0, (size_t)nq * 28, ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->d_qsegs.p, up, up_off + up_segs + up_mc, hipMemcpyHostToDevice, ctx->stream));
+    if (dev_reserve(ctx, ctx->d_cursor, 128)) return DP_ERR_HIP;
+    {   // (the chaining stage's cursor block rides along: it is zero when the first attempt starts)
+        const dp_zero_region z[4] = {{ctx->d_qsets.p, (size_t)nq * SW * 8}, {ctx->d_cand.p, (size_t)nq * W * 8}, {d_qmeta, (size_t)nq * 28},
+                                     {ctx->d_cursor.p, 128}};
+        if (int rc = dp_zero_regions(ctx, z, 4)) return rc;
+    }
     hipLaunchKernelGGL(qsets_kernel, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), 0, ctx->stream,
-                       (const int32_t*)ctx->d_qsegs.p, (const u64*)ctx->d_qoff.p, nq, (u64*)ctx->d_qsets.p, SW);
+                       ctx->qsegs_dev, ctx->qoff_dev, nq, (u64*)ctx->d_qsets.p, SW);
     DP_HIP(hipGetLastError());
-    DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    DP_HIP(dp_mark(ctx, 4));
     hipLaunchKernelGGL(query_kernel, dim3(nq), dim3(64 * Q_WAVES), 0, ctx->stream,
-                       (const int32_t*)ctx->d_qsegs.p, (const u64*)ctx->d_qoff.p, nq, (const u64*)ctx->d_posting.p,
+                       ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, M, W, (const int32_t*)d_mc, mc_n, (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt);
     DP_HIP(hipGetLastError());
-    DP_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+    DP_HIP(dp_mark(ctx, 5));
 
     *d_qmeta_out = d_qmeta;
     *d_words_out = d_words;
-    *d_mc_out = d_mc;
+    *d_mc_out = (int32_t*)d_mc;
     *mc_n_out = mc_n;
     if (d_qcnt_out) *d_qcnt_out = d_qcnt;
     return DP_OK;
@@ -1898,6 +1904,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     ((uint64_t*)ctx->h_cand_off.p)[0] = 0;
     out->cand_off = (const uint64_t*)ctx->h_cand_off.p;
     if (pin_reserve(ctx, ctx->h_moff, 16)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_qm, (size_t)nq * 28 + 16)) return DP_ERR_HIP;
     ((uint64_t*)ctx->h_moff.p)[0] = 0;
     out->off = (const uint64_t*)ctx->h_moff.p;
     if (nq == 0 || M == 0) {
@@ -1949,8 +1956,8 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         const uint64_t sint_cap = want_sints;
         const uint32_t int_cap = (uint32_t)std::min<uint64_t>(0xfffffff0ull, want_ints);
         ChainArgs A;
-        A.qsegs = (const int32_t*)ctx->d_qsegs.p;
-        A.qoff = (const u64*)ctx->d_qoff.p;
+        A.qsegs = ctx->qsegs_dev;
+        A.qoff = ctx->qoff_dev;
         A.nq = nq;
         A.qsets = (const u64*)ctx->d_qsets.p;
         A.qmeta = d_qmeta;
@@ -1983,9 +1990,9 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         A.sint_cap = sint_cap;
         A.int_cap = int_cap;
         A.cursor = d_cur;
-        DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 128, ctx->stream));
-        DP_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-        hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)d_qcnt, (const u64*)ctx->d_qoff.p, nq,
+        if (attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 128, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
+        DP_HIP(dp_mark(ctx, 6));
+        hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)d_qcnt, ctx->qoff_dev, nq,
                            d_pbase, d_ibase, d_totals);
         hipLaunchKernelGGL(chain_walk_kernel, dim3(walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 0);
         for (int ps = 0; ps < passes; ps++) {
@@ -1996,12 +2003,14 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         A.pass = passes;
         hipLaunchKernelGGL(chain_walk_kernel, dim3(walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 2);
         DP_HIP(hipGetLastError());
-        DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+        DP_HIP(dp_mark(ctx, 7));
         DP_HIP(hipMemcpyAsync(ctx->h_cursor.p, ctx->d_cursor.p, 128, hipMemcpyDeviceToHost, ctx->stream));
+        // status words, per-query posting-word counts and candidate counts come back in any case (a few KB), in the same wait
+        DP_HIP(hipMemcpyAsync(ctx->h_qm.p, d_qmeta, (size_t)nq * 28, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(dp_stream_sync(ctx));
         memcpy(cur, ctx->h_cursor.p, 128);
         float ms = 0;
-        hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]);
+        ms = dp_elapsed(ctx, 6, 7);
         chain_ms += ms;
         uint64_t tot_pairs, tot_sints;
         memcpy(&tot_pairs, &cur[16], 8);
@@ -2025,7 +2034,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         break;
     }
     float qms = 0;
-    hipEventElapsedTime(&qms, ctx->ev[4], ctx->ev[5]);
+    qms = dp_elapsed(ctx, 4, 5);
     out->query_kernel_ms = qms;
     out->chain_kernel_ms = chain_ms;
     out->chain_bytes = (uint64_t)cur[4] | ((uint64_t)cur[5] << 32);
@@ -2034,10 +2043,6 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         snprintf(msg, sizeof msg, "overlap chaining hit a reference capacity limit (bits %u: 1 reduced buffer, 2 state pool, 4 results, 8 nodes)", cur[2]);
         return dp_fail(ctx, DP_ERR_CAPACITY, msg);
     }
-    // status words, per-query posting-word counts and candidate counts come back in any case (a few KB)
-    if (pin_reserve(ctx, ctx->h_qm, (size_t)nq * 28 + 16)) return DP_ERR_HIP;
-    DP_HIP(hipMemcpyAsync(ctx->h_qm.p, d_qmeta, (size_t)nq * 28, hipMemcpyDeviceToHost, ctx->stream));
-    DP_HIP(dp_stream_sync(ctx));
     {
         const uint32_t* qm = (const uint32_t*)ctx->h_qm.p;
         const u64* words = (const u64*)((const uint8_t*)ctx->h_qm.p + (size_t)nq * 16);

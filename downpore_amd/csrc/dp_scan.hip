@@ -70,6 +70,7 @@ hipError_t dp_stream_sync(dp_ctx* ctx) {
         const char* e = getenv("DP_SYNC_POLL_US");
         return (e ? atol(e) : 20L) * 1000L;
     }();
+    ctx->stage_used = 0;  // (copies out of the staging buffer queued so far are done when this returns)
     if (spin || !ctx->ev_sync) return hipStreamSynchronize(ctx->stream);
     hipError_t e = hipEventRecord(ctx->ev_sync, ctx->stream);
     if (e != hipSuccess) return e;
@@ -142,6 +143,49 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes) {
     b.p = np;
     b.cap = ncap;
     return 0;
+}
+
+// A caller's (pageable, borrowed) buffer copied into pinned memory that stays untouched until the context's next
+// dp_stream_sync: the H2D copy out of it can be left in flight when the call returns.  nullptr: allocation failed.
+void* dp_stage(dp_ctx* ctx, const void* src, size_t bytes) {
+    const size_t at = (ctx->stage_used + 63) & ~(size_t)63;
+    if (at + bytes > ctx->h_stage.cap) {
+        // (the outgrown buffer is retired, not freed: copies in flight out of it stay valid)
+        if (pin_reserve(ctx, ctx->h_stage, std::max<size_t>(at + bytes, (size_t)1 << 20))) return nullptr;
+        ctx->stage_used = 0;
+        return dp_stage(ctx, src, bytes);
+    }
+    void* dst = (uint8_t*)ctx->h_stage.p + at;
+    memcpy(dst, src, bytes);
+    ctx->stage_used = at + bytes;
+    return dst;
+}
+
+struct ZeroArgs {
+    unsigned long long* p[4];
+    unsigned long long n8[4];
+};
+__global__ void zero_regions_kernel(const ZeroArgs a) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (unsigned long long)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        for (unsigned long long j = i; j < a.n8[r]; j += stride) a.p[r][j] = 0ull;
+}
+// (a round has a dozen buffers to clear, and every hipMemsetAsync is a dispatch of its own: the command processor, not the
+// memory, is what they cost - tools/micro/launch_rate.hip)
+int dp_zero_regions(dp_ctx* ctx, const dp_zero_region* r, int n) {
+    ZeroArgs a;
+    unsigned long long most = 0;
+    for (int i = 0; i < 4; i++) {
+        a.p[i] = i < n ? (unsigned long long*)r[i].p : nullptr;
+        a.n8[i] = i < n && r[i].p ? (r[i].bytes + 7) / 8 : 0;
+        most = std::max(most, a.n8[i]);
+    }
+    if (!most) return DP_OK;
+    const uint32_t blocks = (uint32_t)std::min<unsigned long long>(4096, (most + 1023) / 1024);
+    hipLaunchKernelGGL(zero_regions_kernel, dim3(std::max(1u, blocks)), dim3(256), 0, ctx->stream, a);
+    DP_HIP(hipGetLastError());
+    return DP_OK;
 }
 
 extern "C" const char* dp_version(void) { return "downpore_hip 0.1 (gfx950)"; }
@@ -224,7 +268,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     for (void* q : ctx->retired_dev) hipFree(q);
     for (void* q : ctx->retired_pin) hipHostFree(q);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
-                     &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
+                     &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout, &ctx->h_stage};
     for (auto* b : pbs)
         if (b->p) hipHostFree(b->p);
     for (auto& ev : ctx->ev)
@@ -337,6 +381,8 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
             }
     }
     ctx->n_reads = n_reads;
+    ctx->ignore_epoch = ~0ull;  // (cached per-read-set state of dp_scan_reads)
+    ctx->items_ptr = nullptr;
     ctx->h_boff.swap(h_boff);
     ctx->h_len.swap(h_len);
     ctx->packed_bytes = pos;
@@ -548,6 +594,7 @@ extern "C" int dp_values_upload(dp_ctx* ctx, const double* values, uint64_t n) {
     DP_HIP(dp_stream_sync(ctx));
     ctx->n_values = n;
     ctx->values_total = 0;
+    ctx->values_computed = false;
     return DP_OK;
 }
 
@@ -697,11 +744,23 @@ extern "C" int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, ui
     for (uint32_t i = 0; i < n_seeds; i++)
         if (seed_kmers[i] >= nk) return dp_fail(ctx, DP_ERR_ARG, "seed k-mer out of range for k");
     if (dev_reserve(ctx, ctx->d_seeds, (size_t)n_seeds * 4 + 4)) return DP_ERR_HIP;
-    if (n_seeds) DP_HIP(hipMemcpyAsync(ctx->d_seeds.p, seed_kmers, (size_t)n_seeds * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n_seeds) {  // seed_kmers is borrowed only for the duration of the call: the copy leaves from pinned staging
+        const void* st = dp_stage(ctx, seed_kmers, (size_t)n_seeds * 4);
+        if (!st) return DP_ERR_HIP;
+        DP_HIP(hipMemcpyAsync(ctx->d_seeds.p, st, (size_t)n_seeds * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     // the membership bits and the k-mer -> seed-id map are only read by the scan kernels: they are brought up to date by
     // seed_tables_ensure() when a scan actually runs (a round served by the k-mer position index never needs them)
     ctx->tables_dirty = true;
-    DP_HIP(dp_stream_sync(ctx));  // seed_kmers is borrowed only for the duration of the call
+    {
+        // DP_KERNEL_TIMING=N: the round's kernels are bracketed by timing events in every N-th round of this context (every
+        // event is a packet of its own for the command processor; 0 = never).  Untimed rounds report 0 ms.
+        static const long every = [] {
+            const char* e = getenv("DP_KERNEL_TIMING");
+            return e ? atol(e) : 1L;
+        }();
+        ctx->timing_on = every > 0 && (ctx->round_serial++ % (uint64_t)every) == 0;
+    }
     ctx->k = k;
     ctx->n_seeds = n_seeds;
     ctx->round_open = true;
@@ -995,6 +1054,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
         ctx->n_segs = 0;
         return DP_OK;
     }
+    ctx->items_ptr = nullptr;  // (dp_scan_reads' resident read items are overwritten)
     DP_HIP(hipMemcpyAsync(ctx->d_items.p, items, (size_t)n_items * sizeof(dp_scan_item), hipMemcpyHostToDevice, ctx->stream));
     int dev_cus = 256;
     hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -1003,13 +1063,13 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     const uint32_t dbg = getenv("DP_SCAN_DEBUG") ? (uint32_t)atoi(getenv("DP_SCAN_DEBUG")) : 0u;
     if (int rc = seed_tables_ensure(ctx)) return rc;
     std::unique_lock<ScanGate> scan_lock(g_scan_mu);
-    DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    DP_HIP(dp_mark(ctx, 0));
     hipLaunchKernelGGL(((dbg & 2) ? scan_kernel<0, 3> : v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
                        (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p, n_items, k,
                        (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
                        (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr, dbg, (const uint32_t*)nullptr, 0u);
     DP_HIP(hipGetLastError());
-    DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    DP_HIP(dp_mark(ctx, 1));
     {
         const uint32_t n_tiles = (n_items + OFF_TILE - 1) / OFF_TILE;
         uint64_t* tiles = (uint64_t*)ctx->d_total.p + 2;
@@ -1021,7 +1081,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
                            (const uint32_t*)ctx->d_counts.p, n_items, (const uint64_t*)tiles, (uint64_t*)ctx->d_segoff.p);
         DP_HIP(hipGetLastError());
     }
-    DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    DP_HIP(dp_mark(ctx, 4));
     DP_HIP(hipMemcpyAsync(ctx->h_total.p, ctx->d_total.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->h_counts.p, ctx->d_counts.p, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->h_segoff.p, ctx->d_segoff.p, ((size_t)n_items + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1030,20 +1090,20 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     float ms0 = 0, ms1 = 0, msoff = 0;
-    hipEventElapsedTime(&ms0, ctx->ev[0], ctx->ev[1]);
-    hipEventElapsedTime(&msoff, ctx->ev[1], ctx->ev[4]);
+    ms0 = dp_elapsed(ctx, 0, 1);
+    msoff = dp_elapsed(ctx, 1, 4);
     if (n_segs) {
-        DP_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+        DP_HIP(dp_mark(ctx, 2));
         hipLaunchKernelGGL((v2 ? scan_kernel<1, 2> : scan_kernel<1, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
                            (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p,
                            n_items, k, (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
                            (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
                            (int32_t*)ctx->d_segs.p, 0u, (const uint32_t*)nullptr, 0u);
         DP_HIP(hipGetLastError());
-        DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+        DP_HIP(dp_mark(ctx, 3));
         DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(dp_stream_sync(ctx));
-        hipEventElapsedTime(&ms1, ctx->ev[2], ctx->ev[3]);
+        ms1 = dp_elapsed(ctx, 2, 3);
     }
     scan_lock.unlock();
     ctx->n_segs = n_segs;
@@ -1095,16 +1155,19 @@ __global__ __launch_bounds__(OFF_TILE) void flag_tile_sums(const dp_scan_item* _
 __global__ __launch_bounds__(OFF_TILE) void compact_write(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ counts,
                                                          uint32_t n, const uint64_t* __restrict__ tile_base,
                                                          const uint64_t* __restrict__ segoff, uint32_t* __restrict__ s_item,
-                                                         uint32_t* __restrict__ s_count, uint64_t* __restrict__ s_off) {
+                                                         uint32_t* __restrict__ s_count, uint64_t* __restrict__ s_off,
+                                                         uint4* __restrict__ s_pack) {
     __shared__ uint32_t sh[16];
     const uint32_t i = blockIdx.x * OFF_TILE + threadIdx.x;
     uint32_t v = (i < n && counts[i] >= items[i].min_seeds) ? 1u : 0u;
     uint32_t x = block_incl_scan_1024(v, sh);
     if (v) {
         const uint64_t slot = tile_base[blockIdx.x] + (uint64_t)(x - 1);
+        const uint64_t so = segoff[i];
         s_item[slot] = i;
         s_count[slot] = counts[i];
-        s_off[slot] = segoff[i];
+        s_off[slot] = so;
+        s_pack[slot] = make_uint4(i, counts[i], (uint32_t)so, (uint32_t)(so >> 32));  // the same triple, as the host fetches it
     }
 }
 
@@ -1205,13 +1268,27 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     if (dev_reserve(ctx, ctx->d_counts, (size_t)n_items * 4 + 16)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_segoff, ((size_t)n_items + 1) * 8)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_total, 64 + ((size_t)n_tiles + 2) * 16)) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_surv, (size_t)n_items * 16 + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_surv, (size_t)n_items * 32 + 128)) return DP_ERR_HIP;
     dp_scan_item* d_items = (dp_scan_item*)ctx->d_items.p;
-    if (n_read_items)
+    // the read items are a function of the read lengths, the flags and these arguments: they stay on the device from round to
+    // round (the kernels only read them; the extra items behind them are this round's)
+    if (n_read_items && (ctx->items_ptr != d_items || ctx->items_epoch != ignore_epoch || ctx->items_lo != lo || ctx->items_hi != hi ||
+                         ctx->items_min != min_seeds || ctx->items_top != top_level || ctx->items_k != k)) {
         hipLaunchKernelGGL(make_read_items_kernel, dim3((n_read_items + 255) / 256), dim3(256), 0, ctx->stream,
                            (const uint32_t*)ctx->d_len.p, (const uint8_t*)ctx->d_ignore.p, lo, hi, k, top_level, min_seeds, d_items);
-    if (n_extra)
-        DP_HIP(hipMemcpyAsync(d_items + n_read_items, extra, (size_t)n_extra * sizeof(dp_scan_item), hipMemcpyHostToDevice, ctx->stream));
+        ctx->items_ptr = d_items;
+        ctx->items_epoch = ignore_epoch;
+        ctx->items_lo = lo;
+        ctx->items_hi = hi;
+        ctx->items_min = min_seeds;
+        ctx->items_top = top_level;
+        ctx->items_k = k;
+    }
+    if (n_extra) {  // (borrowed from the caller: leaves from pinned staging)
+        const void* st = dp_stage(ctx, extra, (size_t)n_extra * sizeof(dp_scan_item));
+        if (!st) return DP_ERR_HIP;
+        DP_HIP(hipMemcpyAsync(d_items + n_read_items, st, (size_t)n_extra * sizeof(dp_scan_item), hipMemcpyHostToDevice, ctx->stream));
+    }
     int dev_cus = 256;
     hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
@@ -1229,6 +1306,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     uint32_t* s_item = (uint32_t*)ctx->d_surv.p;
     uint32_t* s_count = s_item + n_items;
     uint64_t* s_off = (uint64_t*)(s_count + n_items + (n_items & 1));
+    uint4* s_pack = (uint4*)(s_off + n_items + (n_items & 1));  // {item, count, offset} per survivor: what goes to the host, one copy
     // Resident k-mer position index instead of scanning (dp_kindex.hip): DP_SCAN_INDEX=1 forces it, =0 forbids it; by
     // default it is used from 1 Gbase up.  That is the break-even of a whole job: the build costs ~0.13 s per Gbase, a
     // round saves (scan 0.5 ms per Gbase) - (index step 0.25 ms), and a job has ~600 rounds per Gbase of 10 kb reads.
@@ -1243,7 +1321,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     if (use_index) {
         // counts, segment offsets, survivor list and totals in three launches, no sort and no host round trip (dp_kindex.hip)
         int rc = dp_kindex_count(ctx, k, d_items, lo, hi, n_read_items, n_extra, (uint32_t*)ctx->d_counts.p, (uint64_t*)ctx->d_segoff.p,
-                                 s_item, s_count, s_off, totals);
+                                 s_item, s_count, s_off, s_pack, totals);
         if (rc < 0) return rc;
         if (rc > 0) use_index = false;  // more items than its scan handles: this round is scanned
     }
@@ -1251,14 +1329,14 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     if (!use_index) {
         if (int rc = seed_tables_ensure(ctx)) return rc;
         scan_lock.lock();
-        DP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+        DP_HIP(dp_mark(ctx, 0));
         hipLaunchKernelGGL((v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
                            (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)d_items, n_items, k,
                            (const uint32_t*)ctx->d_seeds.p, ctx->n_seeds, (const uint32_t*)ctx->d_bits.p,
                            (const int32_t*)ctx->d_kmap.p, (uint32_t*)ctx->d_counts.p, (const uint64_t*)nullptr, (int32_t*)nullptr, 0u,
                            (const uint32_t*)nullptr, 0u);
         DP_HIP(hipGetLastError());
-        DP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+        DP_HIP(dp_mark(ctx, 1));
         hipLaunchKernelGGL(offsets_tile_sums, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
                            (const uint32_t*)ctx->d_counts.p, n_items, tilesA);
         hipLaunchKernelGGL(offsets_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tilesA, n_tiles, totals, (uint64_t*)ctx->d_segoff.p, n_items);
@@ -1269,10 +1347,10 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         hipLaunchKernelGGL(offsets_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, tilesB, n_tiles, totals + 1, tilesB + n_tiles, 0u);
         hipLaunchKernelGGL(compact_write, dim3(n_tiles), dim3(OFF_TILE), 0, ctx->stream, (const dp_scan_item*)d_items,
                            (const uint32_t*)ctx->d_counts.p, n_items, (const uint64_t*)tilesB, (const uint64_t*)ctx->d_segoff.p, s_item,
-                           s_count, s_off);
+                           s_count, s_off, s_pack);
     }
     DP_HIP(hipGetLastError());
-    DP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    DP_HIP(dp_mark(ctx, 4));
     DP_HIP(hipMemcpyAsync(ctx->h_total.p, totals, 32, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     {
@@ -1294,20 +1372,17 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     const uint32_t kx_max_count = (uint32_t)((uint64_t*)ctx->h_total.p)[3];
     if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
-    if (pin_reserve(ctx, ctx->h_surv, n_surv_all * 16 + 64)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_surv, n_surv_all * 32 + 128)) return DP_ERR_HIP;
     float ms0 = 0, ms1 = 0, msoff = 0;
-    hipEventElapsedTime(&ms0, ctx->ev[0], ctx->ev[1]);
-    hipEventElapsedTime(&msoff, ctx->ev[1], ctx->ev[4]);
+    ms0 = dp_elapsed(ctx, 0, 1);
+    msoff = dp_elapsed(ctx, 1, 4);
     uint32_t* h_item = (uint32_t*)ctx->h_surv.p;
     uint32_t* h_count = h_item + n_surv_all;
     uint64_t* h_off = (uint64_t*)(h_count + n_surv_all + (n_surv_all & 1));
-    if (n_surv_all) {
-        DP_HIP(hipMemcpyAsync(h_item, s_item, n_surv_all * 4, hipMemcpyDeviceToHost, ctx->stream));
-        DP_HIP(hipMemcpyAsync(h_count, s_count, n_surv_all * 4, hipMemcpyDeviceToHost, ctx->stream));
-        DP_HIP(hipMemcpyAsync(h_off, s_off, n_surv_all * 8, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    uint32_t* h_pack = (uint32_t*)(h_off + n_surv_all + (n_surv_all & 1));
+    if (n_surv_all) DP_HIP(hipMemcpyAsync(h_pack, s_pack, n_surv_all * 16, hipMemcpyDeviceToHost, ctx->stream));
     if (n_segs) {
-        DP_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+        DP_HIP(dp_mark(ctx, 2));
         if (use_index) {
             int rc = dp_kindex_write(ctx, k, (const dp_scan_item*)d_items, lo, hi, n_read_items, n_extra, (const uint32_t*)s_item,
                                      (uint32_t)n_surv_all, kx_max_count, (const uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
@@ -1327,18 +1402,24 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
                                (int32_t*)ctx->d_segs.p, 0u, (const uint32_t*)s_item, (uint32_t)n_surv_all);
         }
         DP_HIP(hipGetLastError());
-        DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+        DP_HIP(dp_mark(ctx, 3));
         if (n_segs * 4 > ((uint64_t)8 << 20)) {
             // dense-seed regime: tens of MB go back to the host; let the next slot's scan start while they travel
+            if (!ctx->timing_on) DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
             DP_HIP(hipEventSynchronize(ctx->ev[3]));
             if (scan_lock.owns_lock()) scan_lock.unlock();
         }
         DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     DP_HIP(dp_stream_sync(ctx));
-    if (n_segs) hipEventElapsedTime(&ms1, ctx->ev[2], ctx->ev[3]);
+    if (n_segs) ms1 = dp_elapsed(ctx, 2, 3);
     if (scan_lock.owns_lock()) scan_lock.unlock();
     ctx->n_segs = n_segs;
+    for (uint64_t i = 0; i < n_surv_all; i++) {
+        h_item[i] = h_pack[4 * i];
+        h_count[i] = h_pack[4 * i + 1];
+        h_off[i] = (uint64_t)h_pack[4 * i + 2] | ((uint64_t)h_pack[4 * i + 3] << 32);
+    }
     // survivors of the read range come first (item index < n_read_items), the extra items after them (all present)
     uint64_t ns = 0;
     while (ns < n_surv_all && h_item[ns] < n_read_items) ns++;

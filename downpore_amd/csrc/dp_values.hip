@@ -96,6 +96,7 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     if (dev_reserve(ctx, ctx->d_values, n * sizeof(double))) return DP_ERR_HIP;
     ctx->n_values = 0;
     ctx->values_total = 0;
+    ctx->values_computed = false;
     double* values = (double*)ctx->d_values.p;
     DPV(hipMalloc(&d_merged, n * 8));
     DPV(hipMalloc(&d_small, 64));
@@ -179,6 +180,7 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     cleanup();
     ctx->n_values = n;
     ctx->values_total = tot;
+    ctx->values_computed = true;
 #undef DPV
     return DP_OK;
 }
@@ -218,7 +220,7 @@ extern "C" int dp_values_download_codes(dp_ctx* ctx, uint16_t* codes_out, uint64
     if (!ctx || !codes_out || !total_out || !overflow_out)
         return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_values_download_codes: bad arguments") : DP_ERR_ARG;
     const dp_ctx* src = ctx->owner ? ctx->owner : ctx;
-    if (!src->d_values.p || src->n_values != n || !src->d_kcounts || ((uint64_t)1 << (2 * src->kcounts_k)) != n || !src->values_total)
+    if (!src->d_values.p || src->n_values != n || !src->d_kcounts || ((uint64_t)1 << (2 * src->kcounts_k)) != n || !src->values_computed)
         return dp_fail(ctx, DP_ERR_STATE, "dp_values_download_codes: no computed value table of this size resident");
     hipSetDevice(ctx->device);
     void* d_codes = nullptr;

@@ -623,6 +623,11 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
             if (ignoreOut) ignoreOut->push_back(id);
             else reads_.ignore[(size_t)id] = 1;
         }
+        static const bool expNoText = getenv("DP_EXP_NOTEXT") != nullptr;
+        if (expNoText) {
+            fs.lines += gm.n_lines;
+            continue;
+        }
         for (uint32_t j = 0; j < gm.n_lines; j++) {
             const dp_paf_rec& r = pb.paf[gm.slot + j];
             if (j + 4 < gm.n_lines) __builtin_prefetch(&reads_.names[pb.paf[gm.slot + j + 4].t_read], 0, 1);  // names are hit at random
