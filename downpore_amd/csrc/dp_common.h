@@ -81,10 +81,6 @@ struct dp_ctx {
     uint64_t items_epoch = ~0ull;
     uint32_t items_lo = 0, items_hi = 0, items_min = 0;
     int items_top = -1, items_k = 0;
-    // pinned staging of borrowed host inputs whose copies are still in flight when a call returns (dp_stage); every
-    // dp_stream_sync empties it
-    PinBuf h_stage;
-    size_t stage_used = 0;
     bool timing_on = true;
     uint64_t round_serial = 0;
 
@@ -123,7 +119,6 @@ inline float dp_elapsed(dp_ctx* ctx, int a, int b) {
     if (ctx->timing_on && hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) != hipSuccess) ms = 0;
     return ms;
 }
-void* dp_stage(dp_ctx* ctx, const void* src, size_t bytes);
 // up to four device regions (8-byte aligned, sizes rounded up to 8 bytes) set to zero by ONE launch on the context's stream
 struct dp_zero_region {
     void* p;

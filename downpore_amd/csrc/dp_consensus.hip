@@ -1058,9 +1058,15 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     const size_t b_meta = (size_t)n_seqs * sizeof(dp_seq_meta), b_rc = (size_t)n_seeds * 4;
     if (pin_reserve(ctx, ctx->h_cin, b_meta + b_rc + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_cin, b_meta + b_rc + 64)) return DP_ERR_HIP;
-    memcpy(ctx->h_cin.p, metas, b_meta);
-    memcpy((uint8_t*)ctx->h_cin.p + b_meta, rc_of, b_rc);
-    DP_HIP(hipMemcpyAsync(ctx->d_cin.p, ctx->h_cin.p, b_meta + b_rc, hipMemcpyHostToDevice, ctx->stream));
+    static const bool x_pageable = getenv("DP_X_PAGEABLE_UP") != nullptr;
+    if (x_pageable) {
+        DP_HIP(hipMemcpyAsync(ctx->d_cin.p, metas, b_meta, hipMemcpyHostToDevice, ctx->stream));
+        DP_HIP(hipMemcpyAsync((uint8_t*)ctx->d_cin.p + b_meta, rc_of, b_rc, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        memcpy(ctx->h_cin.p, metas, b_meta);
+        memcpy((uint8_t*)ctx->h_cin.p + b_meta, rc_of, b_rc);
+        DP_HIP(hipMemcpyAsync(ctx->d_cin.p, ctx->h_cin.p, b_meta + b_rc, hipMemcpyHostToDevice, ctx->stream));
+    }
     const size_t b_paf = (size_t)np * sizeof(dp_paf_rec), b_ign = (size_t)np * 4, b_gm = (size_t)ng * sizeof(dp_group_meta);
     if (dev_reserve(ctx, ctx->d_cout, b_paf + b_ign + b_gm + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_cout, b_paf + b_ign + b_gm + 64)) return DP_ERR_HIP;

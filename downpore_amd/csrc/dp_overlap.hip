@@ -88,10 +88,8 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
         const dp_zero_region z[2] = {{ctx->d_posting.p, (size_t)S * W * 8 + 64}, {ctx->d_seedsets.p, (size_t)n_seqs * SW * 8 + 64}};
         if (int rc = dp_zero_regions(ctx, z, 2)) return rc;
     }
-    if (n_seqs) {  // (seqs is borrowed only for the duration of the call: the copy leaves from pinned staging)
-        const void* st = dp_stage(ctx, seqs, (size_t)n_seqs * sizeof(dp_seq_ref));
-        if (!st) return DP_ERR_HIP;
-        DP_HIP(hipMemcpyAsync(ctx->d_seqrefs.p, st, (size_t)n_seqs * sizeof(dp_seq_ref), hipMemcpyHostToDevice, ctx->stream));
+    if (n_seqs) {
+        DP_HIP(hipMemcpyAsync(ctx->d_seqrefs.p, seqs, (size_t)n_seqs * sizeof(dp_seq_ref), hipMemcpyHostToDevice, ctx->stream));
         uint32_t blocks = std::min<uint32_t>(2048, (n_seqs + 3) / 4);
         hipLaunchKernelGGL(index_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const dp_seq_ref*)ctx->d_seqrefs.p, n_seqs,
                            (const int32_t*)ctx->d_segs.p, (u64*)ctx->d_posting.p, (u64*)ctx->d_seedsets.p, W, SW);
@@ -103,7 +101,8 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
                            (uint32_t*)ctx->d_pmeta.p);
         DP_HIP(hipGetLastError());
     }
-    return DP_OK;  // (in stream order before everything that reads the index; errors surface at the next synchronising call)
+    DP_HIP(dp_stream_sync(ctx));  // seqs is borrowed only for the duration of the call
+    return DP_OK;
 }
 
 extern "C" int dp_index_build(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
@@ -1857,8 +1856,11 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     uint32_t* d_qcnt = (uint32_t*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 24);
     const int32_t* d_mc = (const int32_t*)((const uint8_t*)ctx->d_qsegs.p + up_off + up_segs);
     // stage through pinned memory: copies from pageable buffers stall the stream
-    if (pin_reserve(ctx, ctx->h_qup, up_segs + up_off + up_mc + 64)) return DP_ERR_HIP;
-    uint8_t* up = (uint8_t*)ctx->h_qup.p;
+    static const bool x_pageable = getenv("DP_X_PAGEABLE_UP") != nullptr;
+    static thread_local std::vector<uint8_t> up_pageable;
+    if (x_pageable) up_pageable.resize(up_segs + up_off + up_mc + 64);
+    else if (pin_reserve(ctx, ctx->h_qup, up_segs + up_off + up_mc + 64)) return DP_ERR_HIP;
+    uint8_t* up = x_pageable ? up_pageable.data() : (uint8_t*)ctx->h_qup.p;
     memcpy(up, q_off, up_off);
     memcpy(up + up_off, q_segs, up_segs);
     memcpy(up + up_off + up_segs, mc.data(), up_mc);

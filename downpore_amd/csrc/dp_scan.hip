@@ -70,7 +70,6 @@ hipError_t dp_stream_sync(dp_ctx* ctx) {
         const char* e = getenv("DP_SYNC_POLL_US");
         return (e ? atol(e) : 20L) * 1000L;
     }();
-    ctx->stage_used = 0;  // (copies out of the staging buffer queued so far are done when this returns)
     if (spin || !ctx->ev_sync) return hipStreamSynchronize(ctx->stream);
     hipError_t e = hipEventRecord(ctx->ev_sync, ctx->stream);
     if (e != hipSuccess) return e;
@@ -145,22 +144,6 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes) {
     return 0;
 }
 
-// A caller's (pageable, borrowed) buffer copied into pinned memory that stays untouched until the context's next
-// dp_stream_sync: the H2D copy out of it can be left in flight when the call returns.  nullptr: allocation failed.
-void* dp_stage(dp_ctx* ctx, const void* src, size_t bytes) {
-    const size_t at = (ctx->stage_used + 63) & ~(size_t)63;
-    if (at + bytes > ctx->h_stage.cap) {
-        // (the outgrown buffer is retired, not freed: copies in flight out of it stay valid)
-        if (pin_reserve(ctx, ctx->h_stage, std::max<size_t>(at + bytes, (size_t)1 << 20))) return nullptr;
-        ctx->stage_used = 0;
-        return dp_stage(ctx, src, bytes);
-    }
-    void* dst = (uint8_t*)ctx->h_stage.p + at;
-    memcpy(dst, src, bytes);
-    ctx->stage_used = at + bytes;
-    return dst;
-}
-
 struct ZeroArgs {
     unsigned long long* p[4];
     unsigned long long n8[4];
@@ -180,6 +163,12 @@ int dp_zero_regions(dp_ctx* ctx, const dp_zero_region* r, int n) {
         a.p[i] = i < n ? (unsigned long long*)r[i].p : nullptr;
         a.n8[i] = i < n && r[i].p ? (r[i].bytes + 7) / 8 : 0;
         most = std::max(most, a.n8[i]);
+    }
+    static const bool x_memset = getenv("DP_X_ZERO") && getenv("DP_X_ZERO")[0] == '0';
+    if (x_memset) {
+        for (int i = 0; i < n; i++)
+            if (r[i].p && r[i].bytes) DP_HIP(hipMemsetAsync(r[i].p, 0, r[i].bytes, ctx->stream));
+        return DP_OK;
     }
     if (!most) return DP_OK;
     const uint32_t blocks = (uint32_t)std::min<unsigned long long>(4096, (most + 1023) / 1024);
@@ -268,7 +257,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     for (void* q : ctx->retired_dev) hipFree(q);
     for (void* q : ctx->retired_pin) hipHostFree(q);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
-                     &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout, &ctx->h_stage};
+                     &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
     for (auto* b : pbs)
         if (b->p) hipHostFree(b->p);
     for (auto& ev : ctx->ev)
@@ -744,14 +733,13 @@ extern "C" int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, ui
     for (uint32_t i = 0; i < n_seeds; i++)
         if (seed_kmers[i] >= nk) return dp_fail(ctx, DP_ERR_ARG, "seed k-mer out of range for k");
     if (dev_reserve(ctx, ctx->d_seeds, (size_t)n_seeds * 4 + 4)) return DP_ERR_HIP;
-    if (n_seeds) {  // seed_kmers is borrowed only for the duration of the call: the copy leaves from pinned staging
-        const void* st = dp_stage(ctx, seed_kmers, (size_t)n_seeds * 4);
-        if (!st) return DP_ERR_HIP;
-        DP_HIP(hipMemcpyAsync(ctx->d_seeds.p, st, (size_t)n_seeds * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
+    // (pageable source: the runtime stages it and the copy runs as a blit kernel on this stream's own queue - measured faster
+    // with eight slots in flight than a pinned source, which goes through the shared SDMA engines)
+    if (n_seeds) DP_HIP(hipMemcpyAsync(ctx->d_seeds.p, seed_kmers, (size_t)n_seeds * 4, hipMemcpyHostToDevice, ctx->stream));
     // the membership bits and the k-mer -> seed-id map are only read by the scan kernels: they are brought up to date by
     // seed_tables_ensure() when a scan actually runs (a round served by the k-mer position index never needs them)
     ctx->tables_dirty = true;
+    DP_HIP(dp_stream_sync(ctx));  // seed_kmers is borrowed only for the duration of the call
     {
         // DP_KERNEL_TIMING=N: the round's kernels are bracketed by timing events in every N-th round of this context (every
         // event is a packet of its own for the command processor; 0 = never).  Untimed rounds report 0 ms.
@@ -1284,11 +1272,8 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         ctx->items_top = top_level;
         ctx->items_k = k;
     }
-    if (n_extra) {  // (borrowed from the caller: leaves from pinned staging)
-        const void* st = dp_stage(ctx, extra, (size_t)n_extra * sizeof(dp_scan_item));
-        if (!st) return DP_ERR_HIP;
-        DP_HIP(hipMemcpyAsync(d_items + n_read_items, st, (size_t)n_extra * sizeof(dp_scan_item), hipMemcpyHostToDevice, ctx->stream));
-    }
+    if (n_extra)  // (borrowed from the caller; this call waits for its stream before it returns)
+        DP_HIP(hipMemcpyAsync(d_items + n_read_items, extra, (size_t)n_extra * sizeof(dp_scan_item), hipMemcpyHostToDevice, ctx->stream));
     int dev_cus = 256;
     hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
@@ -1380,7 +1365,12 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     uint32_t* h_count = h_item + n_surv_all;
     uint64_t* h_off = (uint64_t*)(h_count + n_surv_all + (n_surv_all & 1));
     uint32_t* h_pack = (uint32_t*)(h_off + n_surv_all + (n_surv_all & 1));
-    if (n_surv_all) DP_HIP(hipMemcpyAsync(h_pack, s_pack, n_surv_all * 16, hipMemcpyDeviceToHost, ctx->stream));
+    static const bool x_nopack = getenv("DP_X_PACK") && getenv("DP_X_PACK")[0] == '0';
+    if (n_surv_all && x_nopack) {
+        DP_HIP(hipMemcpyAsync(h_item, s_item, n_surv_all * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipMemcpyAsync(h_count, s_count, n_surv_all * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipMemcpyAsync(h_off, s_off, n_surv_all * 8, hipMemcpyDeviceToHost, ctx->stream));
+    } else if (n_surv_all) DP_HIP(hipMemcpyAsync(h_pack, s_pack, n_surv_all * 16, hipMemcpyDeviceToHost, ctx->stream));
     if (n_segs) {
         DP_HIP(dp_mark(ctx, 2));
         if (use_index) {
@@ -1415,7 +1405,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     if (n_segs) ms1 = dp_elapsed(ctx, 2, 3);
     if (scan_lock.owns_lock()) scan_lock.unlock();
     ctx->n_segs = n_segs;
-    for (uint64_t i = 0; i < n_surv_all; i++) {
+    for (uint64_t i = 0; i < n_surv_all && !x_nopack; i++) {
         h_item[i] = h_pack[4 * i];
         h_count[i] = h_pack[4 * i + 1];
         h_off[i] = (uint64_t)h_pack[4 * i + 2] | ((uint64_t)h_pack[4 * i + 3] << 32);

@@ -170,12 +170,14 @@ struct SeedIndex {
             h = (h + 1) & hmask;
         }
     }
-    // L1-resident 2^18-bit pre-filter in front of the hash (a miss is the common case during seed selection)
-    std::vector<uint64_t> pre;
-    static uint32_t preHash(uint32_t x) { return (x * 2246822519u) >> 14; }  // 18 bits
+    // 2^21-bit pre-filter in front of the hash (256 KiB: L2 resident; a miss is the common case during seed selection, and with
+    // ~20 k seeds only one probe in a hundred goes on to the hash)
+    static constexpr uint32_t kPreBits = 21;
+    std::vector<uint32_t> pre;
+    static uint32_t preHash(uint32_t x) { return (x * 2246822519u) >> (32 - kPreBits); }
     bool isSeed(uint32_t kmer) const {
         const uint32_t b = preHash(kmer);
-        if (!((pre[b >> 6] >> (b & 63)) & 1)) return false;
+        if (!((pre[b >> 5] >> (b & 31)) & 1)) return false;
         return find(kmer) >= 0;
     }
     void grow();
@@ -185,17 +187,10 @@ struct SeedIndex {
     void selectSeeds(const char* s, i64 len, int minSeeds, ValueView ranks, uint32_t* topN, bool checkIndex,
                      const uint8_t* q = nullptr) const;
     bool touchesSeed(const char* s, i64 len) const;
-    bool touchesSeed(const uint32_t* kmers, uint32_t n) const {  // the same test on the window's evaluated k-mers
-        bool hit = false;
-        for (uint32_t i = 0; i < n; i++) {
-            const uint32_t b = preHash(kmers[i]);
-            hit |= (pre[b >> 6] >> (b & 63)) & 1;
-        }
-        if (!hit) return false;
-        for (uint32_t i = 0; i < n; i++)
-            if (kmers[i] != 0xffffffffu && isSeed(kmers[i])) return true;
-        return false;
-    }
+    // the same test on the window's evaluated k-mers (0xffffffff = unused slot): sixteen pre-filter probes per step where
+    // the CPU has AVX-512 (eight with AVX2), the hash only for the probes that pass
+    bool touchesSeed(const uint32_t* kmers, uint32_t n) const;
+    bool touchesSeedWith(int isa, const uint32_t* kmers, uint32_t n) const;  // tests: 0 scalar, 1 AVX2, 2 AVX-512; false if the CPU lacks it
     void commitSeeds(const uint32_t* topN, int n);
     int32_t seedOfRcKmer(int32_t seed) const;                            // kmerMap[rc(seedMap[seed])]
     // seed id -> seed id of its reverse complement for the complete seed set (call once all seeds of the round are in)

@@ -467,6 +467,28 @@ extern "C" int dph_selftest_planner_flags(void* readsH, int k, int64_t seedBatch
     return 0;
 }
 
+// ---- test hook: SeedIndex::touchesSeed on evaluated k-mers, every instruction-set variant the CPU has against the scalar one.
+// Fills res[w] (w < nWindows; windows of `stride` k-mers) with the scalar answers; returns the number of disagreements, and
+// sets *isaMask to the variants that ran (bit 1 AVX2, bit 2 AVX-512).
+extern "C" int dph_selftest_touch(int k, const uint32_t* seeds, int64_t nSeeds, const uint32_t* kmers, int64_t nWindows, int64_t stride,
+                                  uint8_t* res, int* isaMask) {
+    SeedIndex ix(k);
+    for (int64_t i = 0; i < nSeeds; i++) ix.addSeedKmer(seeds[i]);
+    int bad = 0, mask = 0;
+    if (__builtin_cpu_supports("avx2")) mask |= 2;
+    if (__builtin_cpu_supports("avx512f")) mask |= 4;
+    for (int64_t w = 0; w < nWindows; w++) {
+        const uint32_t* km = kmers + w * stride;
+        const bool a = ix.touchesSeedWith(0, km, (uint32_t)stride);
+        res[w] = a ? 1 : 0;
+        if ((mask & 2) && ix.touchesSeedWith(1, km, (uint32_t)stride) != a) bad++;
+        if ((mask & 4) && ix.touchesSeedWith(2, km, (uint32_t)stride) != a) bad++;
+        if (ix.touchesSeed(km, (uint32_t)stride) != a) bad++;
+    }
+    if (isaMask) *isaMask = mask;
+    return bad;
+}
+
 // ---- host-logic test hook (no GPU needed): finalCheckWorker over externally supplied matches ----------------------
 // Queries and indexed sequences come as flat arrays in the reference's segment layout; matches as (query index,
 // target index, MatchA, MatchB).  Returns the PAF text of the round and applies SetIgnore to `reads`.

@@ -26,6 +26,9 @@ int Overlapper::prepareFromCache(int numSeeds, i64 seedLimit, ValueView values, 
     const double t0 = now();
     std::vector<uint32_t> tmp((size_t)numSeeds);
     i64 sent = 0;
+    const bool prof = g_prof.on;
+    unsigned long long cTouch = 0, cResel = 0, cCommit = 0, c0 = prof ? __rdtsc() : 0;
+    const unsigned long long cStart = c0;
     for (size_t r = (size_t)firstSequence; r < reads_.size() && sent < maxSeqs; r++) {
         if (ignore_[r]) continue;
         sent++;
@@ -34,16 +37,36 @@ int Overlapper::prepareFromCache(int numSeeds, i64 seedLimit, ValueView values, 
             const WindowCache::Win& win = cache_->wins[w];
             const uint32_t *spec = nullptr, *kmers = nullptr;
             if (!cache_->get(w, &spec, &kmers, &err)) return -1;
-            if (index_.touchesSeed(kmers, cache_->stride)) {
+            if (prof) c0 = __rdtsc();
+            const bool touched = index_.touchesSeed(kmers, cache_->stride);
+            if (prof) {
+                const unsigned long long c1 = __rdtsc();
+                cTouch += c1 - c0;
+                c0 = c1;
+            }
+            if (touched) {
                 const uint8_t* q = reads_.quality(win.read);
                 index_.selectSeeds(reads_.seq(win.read) + win.start, win.len, numSeeds, values, tmp.data(), true, q ? q + win.start : nullptr);
+                if (prof) {
+                    const unsigned long long c1 = __rdtsc();
+                    cResel += c1 - c0;
+                    c0 = c1;
+                }
                 index_.commitSeeds(tmp.data(), numSeeds);
                 g_prof.reselected++;
             } else {
                 index_.commitSeeds(spec, numSeeds);
             }
+            if (prof) cCommit += __rdtsc() - c0;
             windows_.push_back({win.read, win.start, win.len});
         }
+    }
+    if (prof) {
+        const unsigned long long all = __rdtsc() - cStart;
+        g_prof.planTouchCyc += (long long)cTouch;
+        g_prof.planReselCyc += (long long)cResel;
+        g_prof.planCommitCyc += (long long)cCommit;
+        g_prof.planOtherCyc += (long long)(all - cTouch - cResel - cCommit);
     }
     g_prof.add(17, now() - t0);
     return (int)windows_.size();

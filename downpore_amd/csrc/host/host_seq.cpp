@@ -1,5 +1,6 @@
 // Host-side seed space for the product (see dph.hpp): read set, value table, seed selection, SeedSequence
 // operations, seed-space consensus and contig building.  File:line citations are into the reference.
+#include <immintrin.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -244,7 +245,7 @@ SeedIndex::SeedIndex(int k_) : k(k_) {
     hkeys.assign(1u << 16, 0xffffffffu);
     hvals.assign(1u << 16, -1);
     hmask = (1u << 16) - 1;
-    pre.assign((1u << 18) / 64, 0);
+    pre.assign((1u << kPreBits) / 32, 0);
 }
 
 void SeedIndex::reset() {
@@ -281,8 +282,83 @@ void SeedIndex::addSeedKmer(uint32_t kmer) {
         hvals[h] = (int32_t)seedMap.size();
         seedMap.push_back(kmer);
         const uint32_t b = preHash(kmer);
-        pre[b >> 6] |= 1ull << (b & 63);
+        pre[b >> 5] |= 1u << (b & 31);
     }
+}
+
+// ---- touchesSeed on a window's evaluated k-mers
+namespace {
+typedef bool (*TouchFn)(const SeedIndex&, const uint32_t*, uint32_t);
+
+bool touchScalar(const SeedIndex& ix, const uint32_t* kmers, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++)
+        if (kmers[i] != 0xffffffffu && ix.isSeed(kmers[i])) return true;
+    return false;
+}
+
+__attribute__((target("avx2"))) bool touchAvx2(const SeedIndex& ix, const uint32_t* kmers, uint32_t n) {
+    const int* pre = (const int*)ix.pre.data();
+    const __m256i mul = _mm256_set1_epi32((int)2246822519u), one = _mm256_set1_epi32(1), m31 = _mm256_set1_epi32(31),
+                  ones = _mm256_set1_epi32(-1);
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const __m256i km = _mm256_loadu_si256((const __m256i*)(kmers + i));
+        const __m256i h = _mm256_srli_epi32(_mm256_mullo_epi32(km, mul), 32 - SeedIndex::kPreBits);
+        const __m256i w = _mm256_i32gather_epi32(pre, _mm256_srli_epi32(h, 5), 4);
+        const __m256i bit = _mm256_sllv_epi32(one, _mm256_and_si256(h, m31));
+        const __m256i hit = _mm256_andnot_si256(_mm256_cmpeq_epi32(km, ones), _mm256_cmpeq_epi32(_mm256_and_si256(w, bit), bit));
+        unsigned m = (unsigned)_mm256_movemask_ps(_mm256_castsi256_ps(hit));
+        while (m) {
+            const int l = __builtin_ctz(m);
+            m &= m - 1;
+            if (ix.find(kmers[i + l]) >= 0) return true;
+        }
+    }
+    return touchScalar(ix, kmers + i, n - i);
+}
+
+__attribute__((target("avx512f"))) bool touchAvx512(const SeedIndex& ix, const uint32_t* kmers, uint32_t n) {
+    const int* pre = (const int*)ix.pre.data();
+    const __m512i mul = _mm512_set1_epi32((int)2246822519u), one = _mm512_set1_epi32(1), m31 = _mm512_set1_epi32(31),
+                  ones = _mm512_set1_epi32(-1);
+    uint32_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const __m512i km = _mm512_loadu_si512((const void*)(kmers + i));
+        const __m512i h = _mm512_srli_epi32(_mm512_mullo_epi32(km, mul), 32 - SeedIndex::kPreBits);
+        const __m512i w = _mm512_i32gather_epi32(_mm512_srli_epi32(h, 5), pre, 4);
+        const __m512i bit = _mm512_sllv_epi32(one, _mm512_and_si512(h, m31));
+        unsigned m = (unsigned)(_mm512_test_epi32_mask(w, bit) & _mm512_cmpneq_epi32_mask(km, ones));
+        while (m) {
+            const int l = __builtin_ctz(m);
+            m &= m - 1;
+            if (ix.find(kmers[i + l]) >= 0) return true;
+        }
+    }
+    return touchScalar(ix, kmers + i, n - i);
+}
+
+TouchFn pickTouch() {
+    if (const char* e = getenv("DPH_TOUCH_ISA")) {  // tests: 0 scalar, 1 AVX2, 2 AVX-512 (only what the CPU has)
+        const int want = atoi(e);
+        if (want >= 2 && __builtin_cpu_supports("avx512f")) return touchAvx512;
+        if (want >= 1 && __builtin_cpu_supports("avx2")) return touchAvx2;
+        return touchScalar;
+    }
+    if (__builtin_cpu_supports("avx512f")) return touchAvx512;
+    if (__builtin_cpu_supports("avx2")) return touchAvx2;
+    return touchScalar;
+}
+}  // namespace
+
+bool SeedIndex::touchesSeed(const uint32_t* kmers, uint32_t n) const {
+    static const TouchFn fn = pickTouch();
+    return fn(*this, kmers, n);
+}
+
+bool SeedIndex::touchesSeedWith(int isa, const uint32_t* kmers, uint32_t n) const {
+    if (isa == 2) return __builtin_cpu_supports("avx512f") ? touchAvx512(*this, kmers, n) : false;
+    if (isa == 1) return __builtin_cpu_supports("avx2") ? touchAvx2(*this, kmers, n) : false;
+    return touchScalar(*this, kmers, n);
 }
 
 void SeedIndex::buildRcTable() {
@@ -323,22 +399,36 @@ static void selectSeedsT(const SeedIndex& ix, const char* s, i64 L, int minSeeds
     };
     uint32_t kmer = kmerAt(0);
     i64 nextIndex = k;
+    bool prefetched = false;  // the lookups of the block about to be walked were issued during the previous block
     while (nextIndex < L - k) {
         bool reset = false;
         double bestValue = 0.0;
         uint32_t bestSeed = 0;
-        {  // the block's k rank lookups hit a 4^k-entry table at random: issue them together (prefetch only)
+        // the block's k value lookups hit a 4^k-entry table at random.  They are prefetched one block ahead (the next block is
+        // known unless this one meets a seed): by the time a block is walked its lines have had a block's worth of time to arrive
+        if (!prefetched) {
             uint32_t pk = kmer;
             for (i64 pi = nextIndex, i = 0; pi < L && i < k; i++, pi++) {
                 pk = ((pk << 2) | baseCode((unsigned char)s[pi])) & mask;
                 ranks.prefetch(pk);
             }
         }
+        prefetched = false;
+        if (nextIndex + 2 * (i64)k < L - k) {  // the block after this one exists (same test as the loop's) if nothing resets
+            const i64 nb = nextIndex + 2 * (i64)k;  // its initial k-mer starts here
+            uint32_t pk = kmerAt(nb);
+            for (i64 pi = nb + k, i = 0; pi < L && i < k; i++, pi++) {
+                pk = ((pk << 2) | baseCode((unsigned char)s[pi])) & mask;
+                ranks.prefetch(pk);
+            }
+            prefetched = true;
+        }
         for (int i = 0; nextIndex < L && i < k; i++) {
             kmer = ((kmer << 2) | baseCode((unsigned char)s[nextIndex])) & mask;
             nextIndex++;
             if (CHECK && ix.isSeed(kmer)) {
                 reset = true;
+                prefetched = false;  // (the walk goes on from a different offset than the one prefetched for)
                 break;
             }
             double value = ranks.at(kmer);

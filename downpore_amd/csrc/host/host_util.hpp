@@ -1,9 +1,7 @@
 // Internal helpers shared by the host translation units (not part of the mirrored reference interface).
 #pragma once
 #include <sys/resource.h>
-#ifdef DPH_FINE
 #include <x86intrin.h>
-#endif
 #include <time.h>
 
 #include <algorithm>
@@ -63,6 +61,7 @@ struct FineScope {
 struct PipeProfile {
     std::atomic<long long> executed{0}, committed{0}, rejected{0}, discarded{0}, ignores{0}, planComputes{0}, planErased{0},
         planDiscarded{0}, hostGroups{0}, reselected{0};  // hostGroups: query windows the device consensus left to the host path
+    std::atomic<long long> planTouchCyc{0}, planReselCyc{0}, planCommitCyc{0}, planOtherCyc{0};  // prepareFromCache, TSC cycles
     std::atomic<long long> cacheWaitUs{0};  // planner waiting for the window cache's producer
     std::atomic<long long> planUs{0}, getWaitUs{0}, execUs{0}, commitUs{0}, consensusCpuUs{0}, selectCpuUs{0}, slotCpuUs{0}, plannerCpuUs{0};
     std::atomic<long long> sub[18];
@@ -95,6 +94,13 @@ struct PipeProfile {
         fprintf(stderr, "[pipe] query windows done by the host consensus path: %lld; planner waited %.1f ms for the window cache\n",
                 hostGroups.load(), cacheWaitUs.load() / 1e3);
         fprintf(stderr, "[pipe] windows re-selected on the host (speculation did not hold): %lld\n", reselected.load());
+        {
+            const double tot = (double)(planTouchCyc.load() + planReselCyc.load() + planCommitCyc.load() + planOtherCyc.load());
+            if (tot > 0)
+                fprintf(stderr, "[pipe] plan from the window cache: touch test %.0f%%, re-selection %.0f%%, seed commits %.0f%%, rest %.0f%% (%.2f Gcycles)\n",
+                        100 * planTouchCyc.load() / tot, 100 * planReselCyc.load() / tot, 100 * planCommitCyc.load() / tot,
+                        100 * planOtherCyc.load() / tot, tot / 1e9);
+        }
         const double n = (double)std::max<long long>(1, executed.load());
         struct rusage ru;
         getrusage(RUSAGE_SELF, &ru);

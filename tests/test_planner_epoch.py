@@ -26,3 +26,31 @@ def test_plan_computed_before_flags_is_discarded():
         assert rc == 0, "planner handed out a plan computed before the flags were set (rc %d)" % rc
     finally:
         del os.environ["DPH_TEST_PLAN_DELAY_US"]
+
+
+def test_touch_test_vector_variants_agree():
+    """SeedIndex::touchesSeed(kmers, n) - the planner's probe of a window's evaluated k-mers against the seeds committed so far -
+    has a scalar, an AVX2 and an AVX-512 form (pre-filter probes gathered 8 / 16 at a time): all must give the scalar answer, for
+    windows with no seed, with one seed in any lane (also in the scalar tail), and with unused 0xffffffff slots."""
+    from downpore_amd.overlap import load_host
+    H = load_host()
+    k, stride, n_windows = 13, 493, 600  # stride not a multiple of 16: the tail loop runs
+    rng = np.random.default_rng(5)
+    seeds = np.unique(rng.integers(1, 4 ** k, 20000)).astype(np.uint32)
+    kmers = rng.integers(1, 4 ** k, (n_windows, stride)).astype(np.uint32)
+    kmers[:, 470:] = 0xffffffff  # unused slots at the end of every window
+    want = np.zeros(n_windows, dtype=np.uint8)
+    seedset = set(seeds.tolist())
+    for w in range(0, n_windows, 3):  # plant one seed at a lane that walks through every position, incl. the tail
+        kmers[w, (w * 7) % 470] = seeds[(w * 31) % len(seeds)]
+    for w in range(n_windows):
+        want[w] = 1 if any(int(x) in seedset for x in kmers[w, :470]) else 0
+    kmers = np.ascontiguousarray(kmers)
+    res = np.zeros(n_windows, dtype=np.uint8)
+    mask = C.c_int(0)
+    H.dph_selftest_touch.restype = C.c_int
+    H.dph_selftest_touch.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int)]
+    bad = H.dph_selftest_touch(k, seeds.ctypes.data, len(seeds), kmers.ctypes.data, n_windows, stride, res.ctypes.data, C.byref(mask))
+    assert bad == 0
+    assert np.array_equal(res, want)
+    assert want.sum() >= n_windows // 3

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""A/B runner for one GPU box: variants are 'label:dir:ENV=V,ENV=V' (dir '.' = working tree, '_ab/prev' = the worktree of the
+previous commit); runs them in alternation REPS times and prints min / median of the rounds-only ms per round and of the whole job.
+Boxes differ by 10 % and some are erratic: only numbers from one call compare."""
+import json, os, statistics, subprocess, sys
+reps = int(os.environ.get("REPS", "4"))
+slots = os.environ.get("SLOTS", "8")
+extra = os.environ.get("BENCH_ARGS", "").split()
+variants = []
+for v in sys.argv[1:]:
+    label, d, envs = (v.split(":") + ["", ""])[:3]
+    variants.append((label, d or ".", dict(e.split("=") for e in envs.split(",") if e)))
+res = {v[0]: [] for v in variants}
+for r in range(reps):
+    for label, d, env in variants:
+        e = dict(os.environ); e.update(env)
+        p = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-rounds", "0", "--scan-leg-rounds", "0",
+                            "--dense-leg-rounds", "0", "--slots", slots] + extra, cwd=d, env=e, capture_output=True, text=True, timeout=900)
+        try:
+            j = json.loads(p.stdout.strip().splitlines()[-1])
+            res[label].append((j["rounds_only"]["ms_per_round"], j["job_breakdown_s"]["whole_job"], j["job_breakdown_s"]["setup_value_table_kmer_index_slots"],
+                               j["parity"]["paf_sha256_matches_oracle_fixture"]))
+        except Exception as ex:
+            print(label, "failed:", ex, p.stderr[-300:])
+for label, v in res.items():
+    if not v: continue
+    ms = sorted(x[0] for x in v); job = sorted(x[1] for x in v)
+    print("%-14s ms/round min %.3f med %.3f | job min %.3f med %.3f | setup med %.3f | parity %s | all %s" %
+          (label, ms[0], statistics.median(ms), job[0], statistics.median(job), statistics.median(x[2] for x in v), all(x[3] for x in v),
+           " ".join("%.3f" % x for x in ms)))

@@ -1,9 +1,8 @@
 #!/bin/bash
-# after the op merges: parity + throughput, with and without timing events
-timeout 1500 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -4
-echo "== 8 slots"; SLOTS_LIST=8 bash tools/gpu_slots.sh
-echo "== 8 slots, no timing events"; DP_KERNEL_TIMING=0 SLOTS_LIST=8 bash tools/gpu_slots.sh
-echo "== 8 slots, Q=4"; GPU_MAX_HW_QUEUES=4 SLOTS_LIST=8 bash tools/gpu_slots.sh
-echo "== 6 slots Q=8"; SLOTS_LIST=6 bash tools/gpu_slots.sh
-echo "== 8 slots again"; SLOTS_LIST=8 bash tools/gpu_slots.sh
-echo "== 8 slots, no timing events"; DP_KERNEL_TIMING=0 SLOTS_LIST=8 bash tools/gpu_slots.sh
+one() { echo -n "$1: "; env $1 SLOTS_LIST=8 bash tools/gpu_slots.sh; }
+for i in 1 2 3; do
+one DP_X_STAGE=1
+one DP_X_STAGE=0
+one DP_X_STAGE=2
+( cd _ab/prev && echo -n "prev: " && SLOTS_LIST=8 bash tools/gpu_slots.sh )
+done
