@@ -49,7 +49,13 @@ def main():
     ap.add_argument("--dense-leg-rounds", type=int, default=12,
                     help="N=1: after the timed region, this many rounds of the dense-seed regime (k=10) where the index query "
                          "carries real traffic (reported as index_query_dense; 0 = skip)")
-    ap.add_argument("--mode", default="scan-shard", choices=["round", "round-batch", "scan-shard"], help="multi-GPU decomposition (N > 1)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "round", "round-batch", "scan-shard"],
+                    help="multi-GPU decomposition (N > 1).  scan-shard: every rank runs every round on its own read range and the "
+                         "survivors' seed index is all-gathered (RCCL, inside the library) - the layout for read sets that do not fit "
+                         "one GPU.  round: the query batches (rounds) are dealt to the ranks, each with the whole read set resident, "
+                         "results all-gathered and committed in order - rounds are the unit that shards without touching the per-round "
+                         "latency, so this is what scales while a GPU holds the reads and their k-mer index (9 B per base).  auto: "
+                         "round if that fits in half of the GPU's memory, else scan-shard")
     args = ap.parse_args()
 
     # the executor slots' streams (plus the planner's and the window cache's) want one hardware queue each: the runtime's
@@ -86,6 +92,9 @@ def main():
     from downpore_amd.overlap import OverlapPipeline, Reads
 
     N, L = args.reads, args.read_len
+    if args.mode == "auto":
+        hbm = torch.cuda.get_device_properties(local_rank).total_memory if torch.cuda.is_available() else 0
+        args.mode = "round" if (world == 1 or 9 * N * L < hbm // 2) else "scan-shard"
     G = N * L // 20
     t0 = time.time()
     bases, off = gen_reads(args.seed, G, N, L, args.error, False)
@@ -93,7 +102,9 @@ def main():
     t_gen = time.time() - t0
     # N > 1, scan-shard (default): the survivor exchange runs inside the library on an RCCL communicator (dp_comm_init +
     # dp_allgather_survivors, device to device); DP_BENCH_BACKEND=gloo (1-GPU test hook) keeps it on host copies
-    comm = "rccl" if (world > 1 and args.mode == "scan-shard" and torch_device is not None) else None
+    # (DP_BENCH_FORCE_SHARD=1, test hook: the sharded batch pipeline with a communicator of one rank on a 1-GPU box)
+    force_shard = world == 1 and os.environ.get("DP_BENCH_FORCE_SHARD") == "1" and args.mode == "scan-shard"
+    comm = "rccl" if ((world > 1 and args.mode == "scan-shard" and torch_device is not None) or force_shard) else None
     pipe = OverlapPipeline(reads, device=local_rank, k=args.k, seed_batch_size=args.seed_batch_size, rank=rank, world=world,
                            torch_device=torch_device, mode=args.mode, slots=args.slots, defer_init=True, comm=comm)
     upload = pipe.setup_times()

@@ -454,6 +454,8 @@ struct ExecSlot {
     std::unique_ptr<SeedIndex> index;  // executor-side seed maps of the running round
     std::unique_ptr<Overlapper> lap;
     Survivors local;
+    dp_comm* comm = nullptr;           // scan-shard mode: this slot's communicator (owned by the caller of OverlapRun)
+    Survivors gathered;                // ... and the survivors of all ranks of the running round
     std::vector<SeedMatch> matchPool;  // reused across rounds
     std::vector<SeedMatch*> matches;
     std::vector<ConsJob> consJobs;     // consensus scratch per query window, reused across rounds
@@ -527,6 +529,14 @@ struct OverlapRun {
     // ... with the exchange inside the library (RCCL or in-process peers): one whole round; 1 ran, 0 finished, < 0 error
     dp_comm* comm = nullptr;  // owned by the caller
     int roundSharded();
+    // ... with executor slots: slot i has its own communicator (slotComms[i], owned by the caller; every rank creates them in
+    // the same order).  One call executes the next slots.size() rounds concurrently - slot i takes round + i: its shard's scan,
+    // the exchange on its communicator, then index, query, consensus - and commits them in order with the speculation check of
+    // commitResults (the rounds ran against the flags committed before the batch).  Every rank sees the same results and
+    // therefore commits the same prefix: the collectives of the ranks stay matched without further agreement.
+    // Returns the number of rounds committed, 0 = finished, <0 error.
+    std::vector<dp_comm*> slotComms;
+    int roundsShardedBatch();
     // ---- round-parallel mode: execute round `r` speculatively against the current flags, commit gathered results
     int executeRound(i64 r, RoundResult& out);
     // returns the number of rounds committed from `results` (in order, all consecutive from `round`), stopping at the

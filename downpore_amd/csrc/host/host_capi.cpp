@@ -17,6 +17,7 @@ struct OverlapH {
     OverlapRun run;
     dp_ctx* ctx = nullptr;
     dp_comm* comm = nullptr;
+    std::vector<dp_comm*> slotComms;  // scan-shard with executor slots: one communicator per slot
     ReadSet* reads = nullptr;
     double tCtx = 0, tUpload = 0, tInit = 0;
     std::string err;
@@ -181,6 +182,7 @@ void dph_overlap_destroy(void* hh) {
     if (!h) return;
     h->run.shutdown();
     if (h->comm) dp_comm_destroy(h->comm);
+    for (dp_comm* c : h->slotComms) dp_comm_destroy(c);
     dp_ctx_destroy(h->ctx);
     delete h;
 }
@@ -260,6 +262,55 @@ int dph_overlap_comm_init_local(void** handles, int n) {
         h->run.comm = h->comm;
     }
     return 0;
+}
+// One communicator per executor slot (ids = nSlots x 128 bytes, made by rank 0 with dph_comm_unique_id and handed to every
+// rank in the same order).  Call before dph_overlap_init: the slots pick their communicators up when they are created.
+int dph_overlap_comm_init_slots(void* hh, int nRanks, int rank, const uint8_t* ids, int nSlots) {
+    OverlapH* h = (OverlapH*)hh;
+    for (dp_comm* c : h->slotComms) dp_comm_destroy(c);
+    h->slotComms.clear();
+    for (int i = 0; i < nSlots; i++) {
+        dp_comm* c = nullptr;
+        int rc = dp_comm_init(h->ctx, nRanks, rank, ids + (size_t)i * 128, &c);
+        if (rc != 0) {
+            h->err = dp_last_error(h->ctx);
+            return rc;
+        }
+        h->slotComms.push_back(c);
+    }
+    h->run.slotComms = h->slotComms;
+    for (size_t i = 0; i < h->run.slots.size() && i < h->slotComms.size(); i++) h->run.slots[i]->comm = h->slotComms[i];
+    return 0;
+}
+int dph_overlap_comm_init_local_slots(void** handles, int n, int nSlots) {
+    std::vector<dp_ctx*> ctxs;
+    for (int i = 0; i < n; i++) ctxs.push_back(((OverlapH*)handles[i])->ctx);
+    for (int i = 0; i < n; i++) {
+        OverlapH* h = (OverlapH*)handles[i];
+        for (dp_comm* c : h->slotComms) dp_comm_destroy(c);
+        h->slotComms.clear();
+    }
+    for (int s = 0; s < nSlots; s++) {
+        std::vector<dp_comm*> comms((size_t)n, nullptr);
+        int rc = dp_comm_init_local(ctxs.data(), n, comms.data());
+        if (rc != 0) return rc;
+        for (int i = 0; i < n; i++) ((OverlapH*)handles[i])->slotComms.push_back(comms[(size_t)i]);
+    }
+    for (int i = 0; i < n; i++) {
+        OverlapH* h = (OverlapH*)handles[i];
+        h->run.slotComms = h->slotComms;
+        for (size_t j = 0; j < h->run.slots.size() && j < h->slotComms.size(); j++) h->run.slots[j]->comm = h->slotComms[j];
+    }
+    return 0;
+}
+// the next slots.size() rounds of this rank, executed concurrently and committed in order (collective: every rank calls it,
+// from its own thread / process): rounds committed, 0 = finished, <0 error
+int dph_overlap_rounds_sharded(void* hh) {
+    OverlapH* h = (OverlapH*)hh;
+    int rc = h->run.roundsShardedBatch();
+    if (rc < 0) h->err = h->run.error;
+    else if (rc > 0) h->addPaf(h->run.paf);
+    return rc;
 }
 // one whole round of this rank (collective: every rank calls it, from its own thread / process): 1 ran, 0 finished
 int dph_overlap_round_sharded(void* hh) {

@@ -563,6 +563,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
             sl->ownsCtx = true;
         }
         sl->index.reset(new SeedIndex(p.k));
+        if ((size_t)i < slotComms.size()) sl->comm = slotComms[(size_t)i];
         slots.push_back(std::move(sl));
     }
     mark("executor slots");
@@ -736,13 +737,15 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     out.st.n_seeds = plan->seedMap.size();
     double t1 = now();
     out.st.t_prepare = t1 - t0;
-    rc = sl.lap->ScanLocal(0, reads->size(), sl.local, out.st);
+    const bool sharded = sl.comm != nullptr;  // scan-shard: this rank scans its reads, the survivors of all ranks are exchanged
+    rc = sl.lap->ScanLocal(sharded ? shardLo : 0, sharded ? shardHi : reads->size(), sl.local, out.st);
+    if (rc == 0 && sharded) rc = sl.lap->ExchangeSurvivors(sl.comm, sl.gathered);
     if (rc != 0) {
         sl.error = sl.lap->err;
         return rc;
     }
     out.st.t_scan = now() - t1;
-    rc = finishRound(sl, sl.local, out);
+    rc = finishRound(sl, sharded ? sl.gathered : sl.local, out);
     if (dbgExec) fprintf(stderr, "[exec] round %lld finished rc %d\n", (long long)r, rc);
     const double t2 = now();
     g_prof.add(14, t2 - t0);
@@ -1089,6 +1092,27 @@ int OverlapRun::roundSharded() {
     }
     rc = roundFinish(gathered_);
     return rc < 0 ? rc : 1;
+}
+
+int OverlapRun::roundsShardedBatch() {
+    if (done) return 0;
+    if (slotComms.size() < slots.size()) {
+        error = "roundsShardedBatch: fewer communicators than executor slots";
+        return -1;
+    }
+    for (int attempt = 0; attempt < 4; attempt++) {
+        std::vector<i64> rounds;
+        for (size_t i = 0; i < slots.size(); i++) rounds.push_back(round + (i64)i);
+        std::vector<RoundResult> outs;
+        int rc = executeRounds(rounds, outs);
+        if (rc != 0) return rc < 0 ? rc : -1;
+        // the first round of a batch ran against the committed flags: it commits, or ends the command (an empty result that
+        // came from a plan of a chain erased meanwhile is executed again - on every rank alike)
+        const int c = commitResults(outs);
+        if (c > 0 || done) return c;
+    }
+    error = "roundsShardedBatch: the first round of a batch keeps being rejected";
+    return -1;
 }
 
 int OverlapRun::roundFinish(const Survivors& all) {

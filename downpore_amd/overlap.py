@@ -84,6 +84,9 @@ def load_host():
     H.dph_overlap_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
     H.dph_overlap_comm_init_local.argtypes = [C.c_void_p, C.c_int]
     H.dph_overlap_round_sharded.argtypes = [vp]
+    H.dph_overlap_rounds_sharded.argtypes = [vp]
+    H.dph_overlap_comm_init_slots.argtypes = [vp, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    H.dph_overlap_comm_init_local_slots.argtypes = [C.c_void_p, C.c_int, C.c_int]
     _host = H
     return H
 
@@ -187,7 +190,8 @@ class OverlapPipeline:
         r, r+world, ...; per superstep every rank contributes its next round, results are all-gathered and committed in
         order with the speculation check); "round-batch" = the same exchange with batch-synchronous supersteps (every rank
         executes `slots` consecutive rounds, then all wait); "scan-shard" = every rank runs every round, the scan is
-        sharded by read and the survivors are all-gathered.
+        sharded by read and the survivors are all-gathered; with comm set and slots > 1 a step runs `slots` consecutive rounds
+        concurrently, slot i exchanging on its own communicator, and commits them in order.
         slots: executor slots of this process = rounds it runs concurrently on its GPU (each slot has its own stream and
         per-round buffers; the resident reads are shared).
         defer_init: only create the device context and upload + pack the reads; init() then does what `downpore overlap`
@@ -197,8 +201,8 @@ class OverlapPipeline:
         128-byte id travels through torch.distributed once); "local" = in-process peers wired with link_local(); None = the
         exchange is done here with torch.distributed on host copies (gloo tests)."""
         self.H = load_host()
-        if mode == "scan-shard" and world > 1:
-            slots = 1
+        if mode == "scan-shard" and world > 1 and comm is None:
+            slots = 1  # (the host-side exchange of the gloo tests is one round at a time)
         # query_type: overlap.QueryEdges=1 (the overlap command), QueryCentre=2, QueryAll=4 (the correct command), +8 WeightEdges
         p = np.array([overlap_size, k, num_seeds, seed_batch_size, chunk_size, query_batch_size,
                       (1 if himem else 0) | (query_type << 8), slots], dtype=np.int64)
@@ -238,10 +242,12 @@ class OverlapPipeline:
 
     def _init_rccl(self):
         """dp_comm_init on this rank's context: rank 0 makes the id, everybody gets it through torch.distributed."""
-        idb = np.zeros(128, dtype=np.uint8)
+        ns = max(1, self.slots)
+        idb = np.zeros(128 * ns, dtype=np.uint8)  # one communicator per executor slot
         if self.rank == 0:
-            if self.H.dph_comm_unique_id(idb.ctypes.data) != 0:
-                raise DpError("dp_comm_unique_id failed (librccl not loadable?)")
+            for i in range(ns):
+                if self.H.dph_comm_unique_id(idb[128 * i:].ctypes.data) != 0:
+                    raise DpError("dp_comm_unique_id failed (librccl not loadable?)")
         if self.world > 1:
             import torch
             import torch.distributed as dist
@@ -250,7 +256,11 @@ class OverlapPipeline:
                 t = t.to(self.torch_device)
             dist.broadcast(t, 0)
             idb = t.cpu().numpy().copy()
-        if self.H.dph_overlap_comm_init(self.h, self.world, self.rank, idb.ctypes.data) != 0:
+        idb = np.ascontiguousarray(idb)
+        if ns > 1:
+            if self.H.dph_overlap_comm_init_slots(self.h, self.world, self.rank, idb.ctypes.data, ns) != 0:
+                raise self._err()
+        elif self.H.dph_overlap_comm_init(self.h, self.world, self.rank, idb.ctypes.data) != 0:
             raise self._err()
 
     @staticmethod
@@ -259,7 +269,11 @@ class OverlapPipeline:
         communicator: their survivor exchange then copies device to device between the contexts."""
         H = pipes[0].H
         arr = (C.c_void_p * len(pipes))(*[p.h for p in pipes])
-        if H.dph_overlap_comm_init_local(arr, len(pipes)) != 0:
+        ns = max(1, pipes[0].slots)
+        if ns > 1:  # one in-process communicator per executor slot
+            if H.dph_overlap_comm_init_local_slots(arr, len(pipes), ns) != 0:
+                raise DpError("dp_comm_init_local failed")
+        elif H.dph_overlap_comm_init_local(arr, len(pipes)) != 0:
             raise DpError("dp_comm_init_local failed")
 
     def reset(self):
@@ -350,6 +364,11 @@ class OverlapPipeline:
                 raise self._err()
             return c
         # scan-shard
+        if self.comm is not None and self.slots > 1:  # `slots` rounds at once, each on its own communicator
+            rc = self.H.dph_overlap_rounds_sharded(self.h)
+            if rc < 0:
+                raise self._err()
+            return rc
         if self.comm is not None:  # exchange inside the library (RCCL / in-process peers): one collective call per round
             rc = self.H.dph_overlap_round_sharded(self.h)
             if rc < 0:

@@ -341,6 +341,48 @@ def test_scan_shard_exchange_inside_the_library():
     p1.close()
 
 
+def test_scan_shard_with_executor_slots():
+    """Scan-shard mode keeps its executor slots: a step runs `slots` consecutive rounds concurrently, slot i exchanging its
+    survivors on its own communicator, and commits them in order with the speculation check (rounds that meet a read flagged by
+    an earlier round of the same batch are run again).  Two in-process ranks x three slots on one GPU, on reads short enough
+    that many rounds flag reads; a 1-rank RCCL job with two slots.  Every rank must print the oracle's PAF."""
+    import threading
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(33, 60000, 700, 1500, 0.0, True)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    want = O.OverlapRun(rs, k=10, seed_batch_size=1500)
+    assert want.rounds >= 8 and rs.ignore().sum() > 0, (want.rounds, int(rs.ignore().sum()))
+    world = 2
+    readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
+    pipes = [OverlapPipeline(readsets[r], k=10, seed_batch_size=1500, rank=r, world=world, mode="scan-shard", comm="local", slots=3)
+             for r in range(world)]
+    OverlapPipeline.link_local(pipes)
+    errs = []
+
+    def run(p):
+        try:
+            p.run()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(p,)) for p in pipes]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    for r in range(world):
+        d = first_diff(pipes[r].all_paf(), want.paf)
+        assert d is None, (r, d)
+        assert np.array_equal(readsets[r].ignore(), rs.ignore())
+        assert pipes[r].committed_rounds() == want.rounds
+        pipes[r].close()
+    r1 = Reads(bases, off, min_len=1000)
+    p1 = OverlapPipeline(r1, k=10, seed_batch_size=1500, rank=0, world=1, mode="scan-shard", comm="rccl", slots=2)
+    p1.run()
+    assert first_diff(p1.all_paf(), want.paf) is None
+    p1.close()
+
+
 def _fastq_quals(bases, seed):
     """Quality characters with structure: low-quality stretches, so that the weighting changes which k-mers win."""
     rng = np.random.default_rng(seed)
