@@ -185,7 +185,7 @@ extern "C" void dp_comm_destroy(dp_comm* c) {
     }
     if (c->ev) hipEventDestroy(c->ev);
     for (DevBuf* b : {&c->d_cnt, &c->d_pay, &c->d_allpay})
-        if (b->p) hipFree(b->p);
+        if (b->p) dp_dev_free(b->p);
     for (PinBuf* b : {&c->h_cnt, &c->h_out})
         if (b->p) hipHostFree(b->p);
     delete c;
@@ -206,7 +206,7 @@ static int comm_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes) {
     b.p = nullptr;
     b.cap = 0;
     const size_t ncap = (bytes + bytes / 2 + 255) & ~(size_t)255;
-    DP_HIP(hipMalloc(&b.p, ncap));
+    DP_HIP(dp_dev_malloc(&b.p, ncap));
     b.cap = ncap;
     return 0;
 }

@@ -112,6 +112,14 @@ int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess);
 hipError_t dp_stream_sync(dp_ctx* ctx);
 int dev_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
 int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
+// hipMalloc / hipFree for the library's large device blocks (k-mer index and its build buffers, value tables: hundreds of MB
+// to tens of GB).  Blocks of 32 MiB and more that are freed stay in a process-wide cache and satisfy later requests of about
+// their size: releasing and re-acquiring gigabytes from the driver costs 0.3-0.6 s every now and then (measured: a 400 MB
+// hipMalloc of 622 ms at the start of a job).  The cache is dropped when an allocation fails and by dp_dev_trim().
+hipError_t dp_dev_malloc(void** p, size_t bytes);
+hipError_t dp_dev_free(void* p);
+void dp_dev_trim();
+size_t dp_dev_cached_bytes();  // device memory parked in that cache (it counts as free for the library's own capacity checks)
 // kernel timing events of the per-round calls: recorded while ctx->timing_on (DP_KERNEL_TIMING, see dp_round_begin)
 inline hipError_t dp_mark(dp_ctx* ctx, int i) { return ctx->timing_on ? hipEventRecord(ctx->ev[i], ctx->stream) : hipSuccess; }
 inline float dp_elapsed(dp_ctx* ctx, int a, int b) {

@@ -1058,15 +1058,9 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     const size_t b_meta = (size_t)n_seqs * sizeof(dp_seq_meta), b_rc = (size_t)n_seeds * 4;
     if (pin_reserve(ctx, ctx->h_cin, b_meta + b_rc + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_cin, b_meta + b_rc + 64)) return DP_ERR_HIP;
-    static const bool x_pageable = getenv("DP_X_PAGEABLE_UP") != nullptr;
-    if (x_pageable) {
-        DP_HIP(hipMemcpyAsync(ctx->d_cin.p, metas, b_meta, hipMemcpyHostToDevice, ctx->stream));
-        DP_HIP(hipMemcpyAsync((uint8_t*)ctx->d_cin.p + b_meta, rc_of, b_rc, hipMemcpyHostToDevice, ctx->stream));
-    } else {
-        memcpy(ctx->h_cin.p, metas, b_meta);
-        memcpy((uint8_t*)ctx->h_cin.p + b_meta, rc_of, b_rc);
-        DP_HIP(hipMemcpyAsync(ctx->d_cin.p, ctx->h_cin.p, b_meta + b_rc, hipMemcpyHostToDevice, ctx->stream));
-    }
+    memcpy(ctx->h_cin.p, metas, b_meta);
+    memcpy((uint8_t*)ctx->h_cin.p + b_meta, rc_of, b_rc);
+    DP_HIP(hipMemcpyAsync(ctx->d_cin.p, ctx->h_cin.p, b_meta + b_rc, hipMemcpyHostToDevice, ctx->stream));
     const size_t b_paf = (size_t)np * sizeof(dp_paf_rec), b_ign = (size_t)np * 4, b_gm = (size_t)ng * sizeof(dp_group_meta);
     if (dev_reserve(ctx, ctx->d_cout, b_paf + b_ign + b_gm + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_cout, b_paf + b_ign + b_gm + 64)) return DP_ERR_HIP;
@@ -1097,7 +1091,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     static const bool cons_debug = getenv("DP_CONS_DEBUG") != nullptr;
     A.dbg = nullptr;
     if (cons_debug) {
-        DP_HIP(hipMalloc((void**)&A.dbg, (size_t)ng * 64));
+        DP_HIP(dp_dev_malloc((void**)&A.dbg, (size_t)ng * 64));
         DP_HIP(hipMemsetAsync(A.dbg, 0, (size_t)ng * 64, ctx->stream));
     }
     DP_HIP(dp_mark(ctx, 0));
@@ -1112,7 +1106,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     if (cons_debug) {  // per-phase time of the groups that ran to the end: mean and maximum, in microseconds
         std::vector<unsigned long long> h((size_t)ng * 8);
         hipMemcpy(h.data(), A.dbg, (size_t)ng * 64, hipMemcpyDeviceToHost);
-        hipFree(A.dbg);
+        dp_dev_free(A.dbg);
         double sum[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0}, tot = 0, totmx = 0;
         uint32_t cnt = 0;
         for (uint32_t g = 0; g < ng; g++) {

@@ -344,6 +344,7 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     {
         size_t free_b = 0, total_b = 0;
         hipMemGetInfo(&free_b, &total_b);
+        free_b += dp_dev_cached_bytes();
         if ((uint64_t)free_b < ow->total_bases * 16 + ((uint64_t)6 << 30)) return 1;  // two 8 B/base buffers during the build
     }
     const uint64_t n_groups = (ow->packed_bytes * 4 + 31) / 32;
@@ -369,14 +370,14 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
         void **a, **b, **c, **d;
         ~Temps() {
             for (void** p : {a, b, c, d})
-                if (*p) hipFree(*p);
+                if (*p) dp_dev_free(*p);
         }
     } temps{&d_gread, &d_small, &d_buf1, &d_buf2};
     const size_t n_blocks1k = (size_t)((ow->packed_bytes * 4 + 1023) >> 10) + 2;
-    DP_HIP(hipMalloc(&d_gread, n_blocks1k * 4));
+    DP_HIP(dp_dev_malloc(&d_gread, n_blocks1k * 4));
     // small tables: cnt1[nb1], base1[nb1+1], cur1[nb1], cnt2[n_sub], base2[n_sub+1], cur2[n_sub], tile_start[nb1+1]
     const size_t small_u64 = (size_t)nb1 * 3 + 1 + (size_t)n_sub * 3 + 1;
-    DP_HIP(hipMalloc(&d_small, small_u64 * 8 + ((size_t)nb1 + 1) * 4 + 64));
+    DP_HIP(dp_dev_malloc(&d_small, small_u64 * 8 + ((size_t)nb1 + 1) * 4 + 64));
     kb_u64* cnt1 = (kb_u64*)d_small;
     kb_u64* base1 = cnt1 + nb1;
     kb_u64* cur1 = base1 + nb1 + 1;
@@ -408,8 +409,8 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     }
     h_tiles[(size_t)nb1] = (uint32_t)tt;
     if (tt >= 0xffffffffull) return 1;
-    DP_HIP(hipMalloc(&d_buf1, n * 8 + 64));
-    DP_HIP(hipMalloc(&d_buf2, n * 8 + 64));
+    DP_HIP(dp_dev_malloc(&d_buf1, n * 8 + 64));
+    DP_HIP(dp_dev_malloc(&d_buf2, n * 8 + 64));
     DP_HIP(hipMemcpyAsync(tile_start, h_tiles.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     DP_HIP(hipMemcpyAsync(cur1, base1, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(kb_part1, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, (const uint8_t*)ow->d_packed.p, (const uint64_t*)ow->d_boff.p,

@@ -108,6 +108,7 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
         // resident: 8 B per k-mer start + 8 B per table entry; transient: two 4-byte count tables.  Leave 4 GiB for the rounds.
         size_t free_b = 0, total_b = 0;
         hipMemGetInfo(&free_b, &total_b);
+        free_b += dp_dev_cached_bytes();
         // (the sorted build holds a second 8 B per base while it runs; when that does not fit, the atomic scatter path is
         // what is left and needs only the index itself)
         const uint64_t need = ow->total_bases * 8 + (uint64_t)nk * 16 + ((uint64_t)4 << 30);
@@ -124,28 +125,28 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
     {
         if (dev_reserve(ctx, ix->off, (nk + 1) * 8)) return DP_ERR_HIP;
         void* d_cnt = nullptr;
-        DP_HIP(hipMalloc(&d_cnt, nk * 4));
+        DP_HIP(dp_dev_malloc(&d_cnt, nk * 4));
         void* d_pos = nullptr;
         uint64_t n_pos = 0;
         float ms = 0;
         const int rc = dp_kindex_build_sorted(ctx, ow, k, (uint32_t*)d_cnt, (uint64_t*)ix->off.p, &d_pos, &n_pos, &ms);
         if (rc < 0) {
-            hipFree(d_cnt);
+            dp_dev_free(d_cnt);
             return rc;
         }
         if (rc == 0) {
-            if (ix->pos.p) hipFree(ix->pos.p);
+            if (ix->pos.p) dp_dev_free(ix->pos.p);
             ix->pos.p = d_pos;
             ix->pos.cap = n_pos * 8 + 64;
             ix->n_pos = n_pos;
             ix->built = true;
             ix->build_ms = ms;
-            if (ow->d_kcounts) hipFree(ow->d_kcounts);
+            if (ow->d_kcounts) dp_dev_free(ow->d_kcounts);
             ow->d_kcounts = d_cnt;  // the histogram of exactly these k-mers: dp_kmer_values takes it from here
             ow->kcounts_k = k;
             return DP_OK;
         }
-        hipFree(d_cnt);
+        dp_dev_free(d_cnt);
     }
     // count -> offsets -> scatter, on the CALLER's stream (the owner's buffers are only written here, under the mutex)
     void *d_counts = nullptr, *d_tmp = nullptr, *d_counts1 = nullptr;
@@ -153,7 +154,7 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
         void **a, **b, **c;
         ~Temps() {
             for (void** p : {a, b, c})
-                if (*p) hipFree(*p);
+                if (*p) dp_dev_free(*p);
         }
     } temps{&d_counts, &d_tmp, &d_counts1};
     if (ow->d_kcounts && ow->kcounts_k == k) {  // dp_kmer_values counted exactly these k-mers already
@@ -161,7 +162,7 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
         ow->d_kcounts = nullptr;
         ow->kcounts_k = 0;
     } else {
-        DP_HIP(hipMalloc(&d_counts, nk * 4));
+        DP_HIP(dp_dev_malloc(&d_counts, nk * 4));
         DP_HIP(hipMemsetAsync(d_counts, 0, nk * 4, ctx->stream));
         if (ow->n_reads)
             hipLaunchKernelGGL(kidx_count_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint8_t*)ow->d_packed.p,
@@ -172,9 +173,9 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
     size_t tmp_bytes = 0;
     rocprim::exclusive_scan(nullptr, tmp_bytes, (uint32_t*)d_counts, (uint64_t*)ix->off.p, (uint64_t)0, nk + 1, rocprim::plus<uint64_t>(),
                             ctx->stream);
-    DP_HIP(hipMalloc(&d_tmp, tmp_bytes + 16));
+    DP_HIP(dp_dev_malloc(&d_tmp, tmp_bytes + 16));
     // nk + 1 outputs: the extra input element is never added into an output, but it must be readable -> the buffer holds nk+1
-    DP_HIP(hipMalloc(&d_counts1, (nk + 1) * 4));
+    DP_HIP(dp_dev_malloc(&d_counts1, (nk + 1) * 4));
     DP_HIP(hipMemcpyAsync(d_counts1, d_counts, nk * 4, hipMemcpyDeviceToDevice, ctx->stream));
     DP_HIP(hipMemsetAsync((uint8_t*)d_counts1 + nk * 4, 0, 4, ctx->stream));
     DP_HIP(rocprim::exclusive_scan(d_tmp, tmp_bytes, (uint32_t*)d_counts1, (uint64_t*)ix->off.p, (uint64_t)0, nk + 1,
@@ -198,8 +199,8 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
 
 void dp_kindex_free(dp_ctx* ctx) {
     if (ctx->owner || !ctx->kidx) return;
-    if (ctx->kidx->off.p) hipFree(ctx->kidx->off.p);
-    if (ctx->kidx->pos.p) hipFree(ctx->kidx->pos.p);
+    if (ctx->kidx->off.p) dp_dev_free(ctx->kidx->off.p);
+    if (ctx->kidx->pos.p) dp_dev_free(ctx->kidx->pos.p);
     delete ctx->kidx;
     ctx->kidx = nullptr;
 }

@@ -1856,11 +1856,9 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     uint32_t* d_qcnt = (uint32_t*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 24);
     const int32_t* d_mc = (const int32_t*)((const uint8_t*)ctx->d_qsegs.p + up_off + up_segs);
     // stage through pinned memory: copies from pageable buffers stall the stream
-    static const bool x_pageable = getenv("DP_X_PAGEABLE_UP") != nullptr;
-    static thread_local std::vector<uint8_t> up_pageable;
-    if (x_pageable) up_pageable.resize(up_segs + up_off + up_mc + 64);
-    else if (pin_reserve(ctx, ctx->h_qup, up_segs + up_off + up_mc + 64)) return DP_ERR_HIP;
-    uint8_t* up = x_pageable ? up_pageable.data() : (uint8_t*)ctx->h_qup.p;
+    // (pinned: for these larger blocks the pinned source measured faster than a pageable one, unlike the small per-round inputs)
+    if (pin_reserve(ctx, ctx->h_qup, up_segs + up_off + up_mc + 64)) return DP_ERR_HIP;
+    uint8_t* up = (uint8_t*)ctx->h_qup.p;
     memcpy(up, q_off, up_off);
     memcpy(up + up_off, q_segs, up_segs);
     memcpy(up + up_off + up_segs, mc.data(), up_mc);

@@ -24,7 +24,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 
 #include "dp_common.h"
 
@@ -120,7 +123,7 @@ int dev_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes, bool keep) {
     size_t ncap = bytes > ((size_t)256 << 20) ? bytes : std::max(bytes + bytes / 2, b.cap * 2);
     ncap = (ncap + 255) & ~(size_t)255;
     void* np = nullptr;
-    DP_HIP(hipMalloc(&np, ncap));
+    DP_HIP(dp_dev_malloc(&np, ncap));
     if (b.p) {
         if (keep) DP_HIP(hipMemcpyAsync(np, b.p, b.cap, hipMemcpyDeviceToDevice, ctx->stream));
         ctx->retired_dev.push_back(b.p);  // (work already queued on the stream may still read it)
@@ -144,6 +147,90 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes) {
     return 0;
 }
 
+// ---- large device blocks
+namespace {
+struct BigCache {
+    std::mutex mu;
+    std::multimap<size_t, void*> free_;         // capacity -> block
+    std::unordered_map<void*, size_t> live;     // blocks handed out by dp_dev_malloc (>= kBig): their capacity
+    size_t cached = 0;
+};
+BigCache& big_cache() {
+    static BigCache* c = new BigCache();  // (never destroyed: contexts may be torn down from static destructors)
+    return *c;
+}
+constexpr size_t kBig = (size_t)32 << 20;
+}  // namespace
+
+size_t dp_dev_cached_bytes() {
+    BigCache& c = big_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    return c.cached;
+}
+
+void dp_dev_trim() {
+    BigCache& c = big_cache();
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (auto& e : c.free_) drop.push_back(e.second);
+        c.free_.clear();
+        c.cached = 0;
+    }
+    for (void* q : drop) hipFree(q);
+}
+
+hipError_t dp_dev_malloc(void** p, size_t bytes) {
+    *p = nullptr;
+    if (bytes < kBig) return hipMalloc(p, bytes);
+    BigCache& c = big_cache();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.free_.lower_bound(bytes);
+        if (it != c.free_.end() && it->first <= bytes + bytes / 4) {
+            *p = it->second;
+            c.live[*p] = it->first;
+            c.cached -= it->first;
+            c.free_.erase(it);
+            return hipSuccess;
+        }
+    }
+    const double t0 = alloc_trace() ? alloc_now() : 0;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {  // out of memory with blocks parked in the cache: give them back and try again
+        (void)hipGetLastError();
+        dp_dev_trim();
+        e = hipMalloc(p, bytes);
+    }
+    if (alloc_trace()) fprintf(stderr, "[alloc] large device block %zu bytes, %.3f ms\n", bytes, 1e3 * (alloc_now() - t0));
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.live[*p] = bytes;
+    }
+    return e;
+}
+
+hipError_t dp_dev_free(void* p) {
+    if (!p) return hipSuccess;
+    BigCache& c = big_cache();
+    size_t cap = 0;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            cap = it->second;
+            c.live.erase(it);
+        }
+    }
+    if (!cap) return hipFree(p);
+    // what hipFree promises its caller: nothing on the device uses the block any more
+    hipError_t e = hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.free_.emplace(cap, p);
+    c.cached += cap;
+    return e;
+}
+
 struct ZeroArgs {
     unsigned long long* p[4];
     unsigned long long n8[4];
@@ -163,12 +250,6 @@ int dp_zero_regions(dp_ctx* ctx, const dp_zero_region* r, int n) {
         a.p[i] = i < n ? (unsigned long long*)r[i].p : nullptr;
         a.n8[i] = i < n && r[i].p ? (r[i].bytes + 7) / 8 : 0;
         most = std::max(most, a.n8[i]);
-    }
-    static const bool x_memset = getenv("DP_X_ZERO") && getenv("DP_X_ZERO")[0] == '0';
-    if (x_memset) {
-        for (int i = 0; i < n; i++)
-            if (r[i].p && r[i].bytes) DP_HIP(hipMemsetAsync(r[i].p, 0, r[i].bytes, ctx->stream));
-        return DP_OK;
     }
     if (!most) return DP_OK;
     const uint32_t blocks = (uint32_t)std::min<unsigned long long>(4096, (most + 1023) / 1024);
@@ -252,9 +333,9 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
                      &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals, &ctx->d_manchor, &ctx->d_seeds_applied,
                      &ctx->d_pbase, &ctx->d_pspec, &ctx->d_clist, &ctx->d_sa, &ctx->d_sb, &ctx->d_qual, &ctx->d_qualoff, &ctx->d_hasq};
     for (auto* b : dbs)
-        if (b->p) hipFree(b->p);
-    if (ctx->d_kcounts) hipFree(ctx->d_kcounts);
-    for (void* q : ctx->retired_dev) hipFree(q);
+        if (b->p) dp_dev_free(b->p);
+    if (ctx->d_kcounts) dp_dev_free(ctx->d_kcounts);
+    for (void* q : ctx->retired_dev) dp_dev_free(q);
     for (void* q : ctx->retired_pin) hipHostFree(q);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
                      &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
@@ -264,7 +345,9 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
         if (ev) hipEventDestroy(ev);
     if (ctx->ev_sync) hipEventDestroy(ctx->ev_sync);
     hipStreamDestroy(ctx->stream);
+    const bool owner = !ctx->borrowed_reads;
     delete ctx;
+    if (owner) dp_dev_trim();  // (a context that owned reads goes: nothing is parked beyond it)
 }
 
 extern "C" uint32_t dp_reads_count(const dp_ctx* ctx) { return ctx ? ctx->n_reads : 0; }
@@ -325,12 +408,12 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
     dp_kindex_free(ctx);  // a position index of the previous read set is void
     for (DevBuf* qb : {&ctx->d_qual, &ctx->d_qualoff, &ctx->d_hasq})  // ... and so are its quality bytes
         if (qb->p) {
-            hipFree(qb->p);
+            dp_dev_free(qb->p);
             qb->p = nullptr;
             qb->cap = 0;
         }
     if (ctx->d_kcounts) {   // ... and so is its k-mer histogram
-        hipFree(ctx->d_kcounts);
+        dp_dev_free(ctx->d_kcounts);
         ctx->d_kcounts = nullptr;
         ctx->kcounts_k = 0;
     }
@@ -364,7 +447,7 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
         const size_t need[] = {(size_t)pos + 64, ((size_t)n_reads + 1) * 8, (size_t)n_reads * 4 + 4};
         for (int i = 0; i < 3; i++)
             if (res[i]->p && need[i] > res[i]->cap) {
-                hipFree(res[i]->p);
+                dp_dev_free(res[i]->p);
                 res[i]->p = nullptr;
                 res[i]->cap = 0;
             }
@@ -395,18 +478,18 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
         ~Temps() {
             hipStreamSynchronize(c->stream);
             for (void** p : {a, b, m})
-                if (*p) hipFree(*p);
+                if (*p) dp_dev_free(*p);
         }
     } temps{ctx, &d_ascii, &d_aoff, &d_map};
     const uint64_t nascii = (uint64_t)(off[n_host] - off[0]);
-    DP_HIP(hipMalloc(&d_ascii, nascii + 16));
-    DP_HIP(hipMalloc(&d_aoff, ((size_t)n_host + 1) * 8));
+    DP_HIP(dp_dev_malloc(&d_ascii, nascii + 16));
+    DP_HIP(dp_dev_malloc(&d_aoff, ((size_t)n_host + 1) * 8));
     std::vector<int64_t> rel((size_t)n_host + 1);
     for (uint32_t r = 0; r <= n_host; r++) rel[r] = off[r] - off[0];
     DP_HIP(hipMemcpyAsync(d_ascii, bases + off[0], nascii, hipMemcpyHostToDevice, ctx->stream));
     DP_HIP(hipMemcpyAsync(d_aoff, rel.data(), ((size_t)n_host + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     if (paired) {
-        DP_HIP(hipMalloc(&d_map, (size_t)n_reads * 4));
+        DP_HIP(dp_dev_malloc(&d_map, (size_t)n_reads * 4));
         DP_HIP(hipMemcpyAsync(d_map, srcmap.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
     }
     uint64_t n_dwords = pos / 4;
@@ -668,16 +751,16 @@ extern "C" int dp_kmer_histogram(dp_ctx* ctx, int k, uint64_t* counts_out) {
     hipSetDevice(ctx->device);
     size_t n = (size_t)1 << (2 * k);
     void* d = nullptr;
-    DP_HIP(hipMalloc(&d, n * 4));
+    DP_HIP(dp_dev_malloc(&d, n * 4));
     DP_HIP(hipMemsetAsync(d, 0, n * 4, ctx->stream));
     if (dp_histogram_device(ctx, k, (uint32_t*)d) != 0) {
-        hipFree(d);
+        dp_dev_free(d);
         return DP_ERR_HIP;
     }
     std::vector<uint32_t> tmp(n);
     DP_HIP(hipMemcpyAsync(tmp.data(), d, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
-    hipFree(d);
+    dp_dev_free(d);
     for (size_t i = 0; i < n; i++) counts_out[i] = tmp[i];
     return DP_OK;
 }
@@ -1183,7 +1266,7 @@ extern "C" int dp_scan_release(dp_ctx* ctx) {
     DP_HIP(dp_stream_sync(ctx));
     dp_kindex_free(ctx);
     if (ctx->d_kcounts) {
-        hipFree(ctx->d_kcounts);
+        dp_dev_free(ctx->d_kcounts);
         ctx->d_kcounts = nullptr;
         ctx->kcounts_k = 0;
     }
@@ -1365,12 +1448,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     uint32_t* h_count = h_item + n_surv_all;
     uint64_t* h_off = (uint64_t*)(h_count + n_surv_all + (n_surv_all & 1));
     uint32_t* h_pack = (uint32_t*)(h_off + n_surv_all + (n_surv_all & 1));
-    static const bool x_nopack = getenv("DP_X_PACK") && getenv("DP_X_PACK")[0] == '0';
-    if (n_surv_all && x_nopack) {
-        DP_HIP(hipMemcpyAsync(h_item, s_item, n_surv_all * 4, hipMemcpyDeviceToHost, ctx->stream));
-        DP_HIP(hipMemcpyAsync(h_count, s_count, n_surv_all * 4, hipMemcpyDeviceToHost, ctx->stream));
-        DP_HIP(hipMemcpyAsync(h_off, s_off, n_surv_all * 8, hipMemcpyDeviceToHost, ctx->stream));
-    } else if (n_surv_all) DP_HIP(hipMemcpyAsync(h_pack, s_pack, n_surv_all * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_surv_all) DP_HIP(hipMemcpyAsync(h_pack, s_pack, n_surv_all * 16, hipMemcpyDeviceToHost, ctx->stream));
     if (n_segs) {
         DP_HIP(dp_mark(ctx, 2));
         if (use_index) {
@@ -1405,7 +1483,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     if (n_segs) ms1 = dp_elapsed(ctx, 2, 3);
     if (scan_lock.owns_lock()) scan_lock.unlock();
     ctx->n_segs = n_segs;
-    for (uint64_t i = 0; i < n_surv_all && !x_nopack; i++) {
+    for (uint64_t i = 0; i < n_surv_all; i++) {
         h_item[i] = h_pack[4 * i];
         h_count[i] = h_pack[4 * i + 1];
         h_off[i] = (uint64_t)h_pack[4 * i + 2] | ((uint64_t)h_pack[4 * i + 3] << 32);

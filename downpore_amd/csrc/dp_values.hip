@@ -83,7 +83,7 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     void *d_counts = nullptr, *d_merged = nullptr, *d_sorted = nullptr, *d_rank = nullptr, *d_tmp = nullptr, *d_small = nullptr;
     auto cleanup = [&] {
         for (void* p : {d_counts, d_merged, d_sorted, d_rank, d_tmp, d_small})
-            if (p) hipFree(p);
+            if (p) dp_dev_free(p);
     };
 #define DPV(x)                                                      \
     do {                                                            \
@@ -98,15 +98,15 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     ctx->values_total = 0;
     ctx->values_computed = false;
     double* values = (double*)ctx->d_values.p;
-    DPV(hipMalloc(&d_merged, n * 8));
-    DPV(hipMalloc(&d_small, 64));
+    DPV(dp_dev_malloc(&d_merged, n * 8));
+    DPV(dp_dev_malloc(&d_small, 64));
     if (ctx->d_kcounts && ctx->kcounts_k == k) {
         // the k-mer position index was built first (dp_scan_prepare): its last pass left the histogram of exactly these k-mers
         d_counts = ctx->d_kcounts;
         ctx->d_kcounts = nullptr;
         ctx->kcounts_k = 0;
     } else {
-        DPV(hipMalloc(&d_counts, n * 4));
+        DPV(dp_dev_malloc(&d_counts, n * 4));
         DPV(hipMemsetAsync(d_counts, 0, n * 4, ctx->stream));
         int rc = dp_histogram_device(ctx, k, (uint32_t*)d_counts);
         if (rc != 0) {
@@ -119,7 +119,7 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     auto in64 = rocprim::make_transform_iterator((const uint32_t*)d_counts, ValuesToU64());
     DPV(rocprim::reduce(nullptr, tb, in64, (uint64_t*)d_small, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), ctx->stream));
     size_t tmpCap = tb + 64;
-    DPV(hipMalloc(&d_tmp, tmpCap));
+    DPV(dp_dev_malloc(&d_tmp, tmpCap));
     DPV(rocprim::reduce(d_tmp, tb, in64, (uint64_t*)d_small, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), ctx->stream));
     uint64_t tot = 0;
     DPV(hipMemcpyAsync(&tot, d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -130,14 +130,14 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     DPV(hipGetLastError());
     const uint64_t topN = n / 100;
     if (topN > 0) {
-        DPV(hipMalloc(&d_sorted, n * 8));
+        DPV(dp_dev_malloc(&d_sorted, n * 8));
         size_t sb = 0;
         DPV(rocprim::radix_sort_keys(nullptr, sb, (const uint64_t*)d_merged, (uint64_t*)d_sorted, (size_t)n, 0u, 34u, ctx->stream));
         if (sb + 64 > tmpCap) {
-            hipFree(d_tmp);
+            dp_dev_free(d_tmp);
             d_tmp = nullptr;
             tmpCap = sb + 64;
-            DPV(hipMalloc(&d_tmp, tmpCap));
+            DPV(dp_dev_malloc(&d_tmp, tmpCap));
         }
         DPV(rocprim::radix_sort_keys(d_tmp, sb, (const uint64_t*)d_merged, (uint64_t*)d_sorted, (size_t)n, 0u, 34u, ctx->stream));
         uint64_t T = 0;
@@ -147,20 +147,20 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
         uint64_t bounds[2] = {0, 0};
         DPV(hipMemcpyAsync(bounds, d_small, 16, hipMemcpyDeviceToHost, ctx->stream));
         DPV(dp_stream_sync(ctx));
-        hipFree(d_sorted);
+        dp_dev_free(d_sorted);
         d_sorted = nullptr;
         const uint64_t totalTies = bounds[1] - bounds[0], above = n - bounds[1];
         const uint64_t zeroTies = topN - above;                       // >= 1: sorted[n - topN] == T
         const uint32_t keepTies = (uint32_t)(totalTies - zeroTies);   // ties with a rank (from index 0) below this keep their value
-        DPV(hipMalloc(&d_rank, n * 4));
+        DPV(dp_dev_malloc(&d_rank, n * 4));
         auto flags = rocprim::make_transform_iterator((const uint64_t*)d_merged, ValuesIsTie{T});
         size_t xb = 0;
         DPV(rocprim::exclusive_scan(nullptr, xb, flags, (uint32_t*)d_rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
         if (xb + 64 > tmpCap) {
-            hipFree(d_tmp);
+            dp_dev_free(d_tmp);
             d_tmp = nullptr;
             tmpCap = xb + 64;
-            DPV(hipMalloc(&d_tmp, tmpCap));
+            DPV(dp_dev_malloc(&d_tmp, tmpCap));
         }
         DPV(rocprim::exclusive_scan(d_tmp, xb, flags, (uint32_t*)d_rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), ctx->stream));
         hipLaunchKernelGGL(values_cut_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint64_t*)d_merged,
@@ -173,7 +173,7 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     DPV(dp_stream_sync(ctx));
     // the histogram is what the k-mer position index build counts first (dp_kindex_ensure): keep it (4^k * 4 bytes) until
     // the index has used it or the reads are replaced
-    if (ctx->d_kcounts) hipFree(ctx->d_kcounts);
+    if (ctx->d_kcounts) dp_dev_free(ctx->d_kcounts);
     ctx->d_kcounts = d_counts;
     ctx->kcounts_k = k;
     d_counts = nullptr;
@@ -224,7 +224,7 @@ extern "C" int dp_values_download_codes(dp_ctx* ctx, uint16_t* codes_out, uint64
         return dp_fail(ctx, DP_ERR_STATE, "dp_values_download_codes: no computed value table of this size resident");
     hipSetDevice(ctx->device);
     void* d_codes = nullptr;
-    hipError_t e = hipMalloc(&d_codes, n * 2 + 64);
+    hipError_t e = dp_dev_malloc(&d_codes, n * 2 + 64);
     if (e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, "dp_values_download_codes: hipMalloc", e);
     uint32_t* d_flag = (uint32_t*)((char*)d_codes + n * 2);
     uint32_t flag = 0;
@@ -237,7 +237,7 @@ extern "C" int dp_values_download_codes(dp_ctx* ctx, uint16_t* codes_out, uint64
     if (e == hipSuccess) e = hipMemcpyAsync(codes_out, d_codes, n * 2, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = dp_stream_sync(ctx);
-    hipFree(d_codes);
+    dp_dev_free(d_codes);
     if (e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, "dp_values_download_codes", e);
     *total_out = src->values_total;
     *overflow_out = (int)flag;

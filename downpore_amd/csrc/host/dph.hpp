@@ -157,7 +157,7 @@ struct SeedIndex {
     std::vector<SeedSeq*> sequences;                // indexed sequences (chunks), index == GPU sequence index
     std::vector<dp_seq_ref> refs;                   // their views into the device-resident scan output
     Arena arena;
-    explicit SeedIndex(int k_);
+    explicit SeedIndex(int k_, int preBits = 18);
     void reset();
     int size() const { return (int)seedMap.size(); }
     static uint32_t hash(uint32_t x) { return (x * 2654435761u) >> 7; }
@@ -170,11 +170,13 @@ struct SeedIndex {
             h = (h + 1) & hmask;
         }
     }
-    // 2^21-bit pre-filter in front of the hash (256 KiB: L2 resident; a miss is the common case during seed selection, and with
-    // ~20 k seeds only one probe in a hundred goes on to the hash)
-    static constexpr uint32_t kPreBits = 21;
+    // bit pre-filter in front of the hash (a miss is the common case during seed selection; with ~20 k seeds and 2^21 bits only
+    // one probe in a hundred goes on to the hash)
+    // (2^21 bits for the planner's index, whose touch test probes ~170 k k-mers per plan; 2^18 - 32 KiB, cleared every round - for
+    // the executor slots' indexes, which only ever insert)
+    uint32_t preShift = 32 - 18;
     std::vector<uint32_t> pre;
-    static uint32_t preHash(uint32_t x) { return (x * 2246822519u) >> (32 - kPreBits); }
+    uint32_t preHash(uint32_t x) const { return (x * 2246822519u) >> preShift; }
     bool isSeed(uint32_t kmer) const {
         const uint32_t b = preHash(kmer);
         if (!((pre[b >> 5] >> (b & 31)) & 1)) return false;

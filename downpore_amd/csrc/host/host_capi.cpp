@@ -523,7 +523,7 @@ extern "C" int dph_selftest_planner_flags(void* readsH, int k, int64_t seedBatch
 // sets *isaMask to the variants that ran (bit 1 AVX2, bit 2 AVX-512).
 extern "C" int dph_selftest_touch(int k, const uint32_t* seeds, int64_t nSeeds, const uint32_t* kmers, int64_t nWindows, int64_t stride,
                                   uint8_t* res, int* isaMask) {
-    SeedIndex ix(k);
+    SeedIndex ix(k, 21);
     for (int64_t i = 0; i < nSeeds; i++) ix.addSeedKmer(seeds[i]);
     int bad = 0, mask = 0;
     if (__builtin_cpu_supports("avx2")) mask |= 2;

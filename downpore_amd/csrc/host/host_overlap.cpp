@@ -622,9 +622,12 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
     for (uint32_t g = 0; g < pb.n_groups; g++) nLines += pb.groups[g].n_lines;
     for (const std::string& hp : hostPaf) hostBytes += hp.size();
     const size_t lineCap = 2 * reads_.maxNameLen + 7 * 21 + 24;  // two names + 7 numbers + fixed text
-    const size_t base = paf.size();
-    paf.resize(base + nLines * lineCap + hostBytes);  // one allocation, one fill; shrunk to what was written below
-    char* w = &paf[base];
+    // the text is written into a buffer this thread keeps (sized for the worst case: no per-round allocation, zero fill or
+    // page faults of a megabyte), then appended at its real size
+    static thread_local std::vector<char> textBuf;
+    if (textBuf.size() < nLines * lineCap + hostBytes + 64) textBuf.resize((nLines * lineCap + hostBytes + 64) * 3 / 2);
+    char* const w0 = textBuf.data();
+    char* w = w0;
     for (uint32_t g = 0; g < pb.n_groups; g++) {
         const dp_group_meta& gm = pb.groups[g];
         hits += gm.n_matches;
@@ -645,11 +648,6 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
             const int id = (int)pb.ignore_ids[gm.slot + j];
             if (ignoreOut) ignoreOut->push_back(id);
             else reads_.ignore[(size_t)id] = 1;
-        }
-        static const bool expNoText = getenv("DP_EXP_NOTEXT") != nullptr;
-        if (expNoText) {
-            fs.lines += gm.n_lines;
-            continue;
         }
         for (uint32_t j = 0; j < gm.n_lines; j++) {
             const dp_paf_rec& r = pb.paf[gm.slot + j];
@@ -682,7 +680,7 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
             fs.lines++;
         }
     }
-    paf.resize((size_t)(w - paf.data()));
+    paf.append(w0, (size_t)(w - w0));
     fs.hits = hits;
     fs.qHits = qHits;
     st.n_matches = hits;

@@ -175,7 +175,7 @@ struct Planner::Impl {
     long testDelayUs = 0;     // DPH_TEST_PLAN_DELAY_US: sleep before every compute (tests/test_planner_epoch.py)
     std::thread th;
     Impl(ReadSet& r, const OverlapParams& pp, ValueView v, bool t, dp_ctx* sc)
-        : reads(r), p(pp), values(v), threaded(t), selCtx(sc), index(pp.k) {}
+        : reads(r), p(pp), values(v), threaded(t), selCtx(sc), index(pp.k, 21) {}
 };
 
 Planner::Planner(ReadSet& reads, const OverlapParams& p, ValueView values, bool threaded, dp_ctx* selCtx, WindowCache* cache)

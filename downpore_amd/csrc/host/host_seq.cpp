@@ -241,11 +241,11 @@ std::vector<double> kmerValuesFromCounts(std::vector<uint64_t>& counts, int k) {
 // ---------------------------------------------------------------------------------------------------------------
 // seeds.SeedIndex host mirror
 
-SeedIndex::SeedIndex(int k_) : k(k_) {
+SeedIndex::SeedIndex(int k_, int preBits) : k(k_), preShift((uint32_t)(32 - preBits)) {
     hkeys.assign(1u << 16, 0xffffffffu);
     hvals.assign(1u << 16, -1);
     hmask = (1u << 16) - 1;
-    pre.assign((1u << kPreBits) / 32, 0);
+    pre.assign(((size_t)1 << preBits) / 32, 0);
 }
 
 void SeedIndex::reset() {
@@ -303,7 +303,7 @@ __attribute__((target("avx2"))) bool touchAvx2(const SeedIndex& ix, const uint32
     uint32_t i = 0;
     for (; i + 8 <= n; i += 8) {
         const __m256i km = _mm256_loadu_si256((const __m256i*)(kmers + i));
-        const __m256i h = _mm256_srli_epi32(_mm256_mullo_epi32(km, mul), 32 - SeedIndex::kPreBits);
+        const __m256i h = _mm256_srl_epi32(_mm256_mullo_epi32(km, mul), _mm_cvtsi32_si128((int)ix.preShift));
         const __m256i w = _mm256_i32gather_epi32(pre, _mm256_srli_epi32(h, 5), 4);
         const __m256i bit = _mm256_sllv_epi32(one, _mm256_and_si256(h, m31));
         const __m256i hit = _mm256_andnot_si256(_mm256_cmpeq_epi32(km, ones), _mm256_cmpeq_epi32(_mm256_and_si256(w, bit), bit));
@@ -324,7 +324,7 @@ __attribute__((target("avx512f"))) bool touchAvx512(const SeedIndex& ix, const u
     uint32_t i = 0;
     for (; i + 16 <= n; i += 16) {
         const __m512i km = _mm512_loadu_si512((const void*)(kmers + i));
-        const __m512i h = _mm512_srli_epi32(_mm512_mullo_epi32(km, mul), 32 - SeedIndex::kPreBits);
+        const __m512i h = _mm512_srl_epi32(_mm512_mullo_epi32(km, mul), _mm_cvtsi32_si128((int)ix.preShift));
         const __m512i w = _mm512_i32gather_epi32(_mm512_srli_epi32(h, 5), pre, 4);
         const __m512i bit = _mm512_sllv_epi32(one, _mm512_and_si512(h, m31));
         unsigned m = (unsigned)(_mm512_test_epi32_mask(w, bit) & _mm512_cmpneq_epi32_mask(km, ones));
