@@ -26,10 +26,13 @@ typedef unsigned long long kb_u64;
 #define KB_TILE 4096       // entries per tile of passes 1/2
 #define KB_THREADS 256
 #define KB_P3_CAP 8192     // entries pass 3 sorts inside LDS
-#define KB_POS_BITS 36     // absolute base index bits of an entry in flight
+// An entry in flight = k-mer << (rbits + pbits) | read << pbits | position in the read: what the index finally stores travels
+// with the k-mer from pass 1 on (the read of a position is known for free there), so the last pass converts nothing.  Needs
+// 2k + rbits + pbits <= 64: 26 + 17 + 14 at config 2, 26 + 21 + 14 at config 5's read set.
 
 struct KbGeom {
     int k, b1, b2, r;  // digit widths: b1 + b2 + r = 2k
+    int pbits, rbits;  // payload below the k-mer: position in the read, read id
 };
 
 // read of every 1024-base block of the packed layout (reads start on 64-base boundaries, so a 32-position group never
@@ -50,13 +53,16 @@ __device__ __forceinline__ uint32_t kb_read_of(uint64_t a, const uint32_t* __res
 // the up to 16 k-mers a thread owns in passes over the packed reads: half a 32-position group.  Returns the valid mask.
 __device__ __forceinline__ uint32_t kb_load16(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ boff,
                                               const uint32_t* __restrict__ len, const uint32_t* __restrict__ gread, uint64_t n_groups,
-                                              uint64_t g, int half, int k, uint32_t kmer[16]) {
+                                              uint64_t g, int half, int k, uint32_t kmer[16], uint32_t* read_out = nullptr,
+                                              uint64_t* start_out = nullptr) {
     if (g >= n_groups) return 0u;
     const uint64_t a = g * 32 + (uint64_t)half * 16;
     const uint32_t r = kb_read_of(g * 32, gread, boff);
     const uint32_t L = len[r];
     if (L < (uint32_t)k) return 0u;
     const uint64_t a0 = boff[r] * 4, a1 = a0 + (L - k + 1);
+    if (read_out) *read_out = r;
+    if (start_out) *start_out = a0;
     if (a >= a1) return 0u;
     const uint32_t* p = (const uint32_t*)(packed + g * 8) + half;
     const uint32_t w0 = __builtin_bswap32(p[0]), w1 = __builtin_bswap32(p[1]);
@@ -157,17 +163,21 @@ __global__ __launch_bounds__(KB_THREADS) void kb_part1(const uint8_t* __restrict
     __shared__ uint32_t hist[1024], lstart[1024];
     __shared__ kb_u64 gbase[1024];
     __shared__ kb_u64 sorted[KB_TILE];
-    const int dsh = KB_POS_BITS + 2 * G.k - G.b1;
+    const int pay = G.pbits + G.rbits;
+    const int dsh = pay + 2 * G.k - G.b1;
     const uint32_t dmask = (1u << G.b1) - 1u;
     const uint64_t tiles = (n_groups * 2 + KB_THREADS - 1) / KB_THREADS;
     for (uint64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
         const uint64_t h = t * KB_THREADS + threadIdx.x;
-        uint32_t kmer[16];
-        const uint32_t m = kb_load16(packed, boff, len, gread, n_groups, h >> 1, (int)(h & 1), G.k, kmer);
+        uint32_t kmer[16], rd = 0;
+        uint64_t a0 = 0;
+        const uint32_t m = kb_load16(packed, boff, len, gread, n_groups, h >> 1, (int)(h & 1), G.k, kmer, &rd, &a0);
         kb_u64 e[16];
         const kb_u64 a = (h >> 1) * 32 + (h & 1) * 16;
+        // (lanes outside the read's k-mer range are masked out: their payload may be anything)
+        const kb_u64 low = ((kb_u64)rd << G.pbits) + (a - a0);
 #pragma unroll
-        for (int j = 0; j < 16; j++) e[j] = ((kb_u64)kmer[j] << KB_POS_BITS) | (a + (kb_u64)j);
+        for (int j = 0; j < 16; j++) e[j] = ((kb_u64)kmer[j] << pay) | (low + (kb_u64)j);
         kb_tile_out<16>(e, m, dsh, dmask, hist, lstart, gbase, sorted, cursor, out);
     }
 }
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_count2(const kb_u64* __restrict
     __shared__ uint32_t hist[1024];
     const int nb1 = 1 << G.b1, nb2 = 1 << G.b2;
     const uint32_t n_tiles = tile_start[nb1];
-    const int dsh = KB_POS_BITS + 2 * G.k - G.b1 - G.b2;
+    const int dsh = G.pbits + G.rbits + 2 * G.k - G.b1 - G.b2;
     const uint32_t dmask = (uint32_t)nb2 - 1u;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint32_t b = kb_bucket_of_tile(tile_start, nb1, t);
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_part2(const kb_u64* __restrict_
     __shared__ kb_u64 sorted[KB_TILE];
     const int nb1 = 1 << G.b1, nb2 = 1 << G.b2;
     const uint32_t n_tiles = tile_start[nb1];
-    const int dsh = KB_POS_BITS + 2 * G.k - G.b1 - G.b2;
+    const int dsh = G.pbits + G.rbits + 2 * G.k - G.b1 - G.b2;
     const uint32_t dmask = (uint32_t)nb2 - 1u;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const uint32_t b = kb_bucket_of_tile(tile_start, nb1, t);
@@ -243,12 +253,14 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const kb_u64* __restrict_
     uint32_t* hist = (uint32_t*)(kb_dyn + KB_P3_CAP);
     uint32_t* lstart = hist + nb;
     const uint32_t dmask = (uint32_t)nb - 1u;
+    const int pay = G.pbits + G.rbits;
+    const kb_u64 pmask = ((kb_u64)1 << G.pbits) - 1, rmask = ((kb_u64)1 << G.rbits) - 1;
     for (uint32_t sp = blockIdx.x; sp < n_sub; sp += gridDim.x) {
         const kb_u64 lo = base2[sp], hi = base2[sp + 1];
         const kb_u64 n = hi - lo;
         for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
         __syncthreads();
-        for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) atomicAdd(&hist[(uint32_t)(in[i] >> KB_POS_BITS) & dmask], 1u);
+        for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) atomicAdd(&hist[(uint32_t)(in[i] >> pay) & dmask], 1u);
         __syncthreads();
         // histogram + offsets of this sub-partition's 2^r k-mers (k-mer = sp << r | bin): coalesced
         {
@@ -285,22 +297,19 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const kb_u64* __restrict_
         if (n <= KB_P3_CAP) {
             for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) {
                 const kb_u64 v = in[i];
-                const uint32_t d = (uint32_t)(v >> KB_POS_BITS) & dmask;
-                sorted[lstart[d] + atomicAdd(&hist[d], 1u)] = v & (((kb_u64)1 << KB_POS_BITS) - 1);
+                const uint32_t d = (uint32_t)(v >> pay) & dmask;
+                sorted[lstart[d] + atomicAdd(&hist[d], 1u)] = v;
             }
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += KB_THREADS) {
-                const kb_u64 a = sorted[i];
-                const uint32_t r = kb_read_of(a, gread, boff);
-                pos[lo + i] = ((kb_u64)r << 32) | (a - boff[r] * 4);
+            for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += KB_THREADS) {  // consecutive lanes, consecutive addresses
+                const kb_u64 v = sorted[i];
+                pos[lo + i] = (((v >> G.pbits) & rmask) << 32) | (v & pmask);
             }
         } else {  // larger than the LDS buffer: entries go straight to their slot (the region is this workgroup's alone)
             for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) {
                 const kb_u64 v = in[i];
-                const uint32_t d = (uint32_t)(v >> KB_POS_BITS) & dmask;
-                const kb_u64 a = v & (((kb_u64)1 << KB_POS_BITS) - 1);
-                const uint32_t r = kb_read_of(a, gread, boff);
-                pos[lo + lstart[d] + atomicAdd(&hist[d], 1u)] = ((kb_u64)r << 32) | (a - boff[r] * 4);
+                const uint32_t d = (uint32_t)(v >> pay) & dmask;
+                pos[lo + lstart[d] + atomicAdd(&hist[d], 1u)] = (((v >> G.pbits) & rmask) << 32) | (v & pmask);
             }
         }
         __syncthreads();
@@ -339,7 +348,7 @@ __global__ void kb_excl_scan_small(const kb_u64* __restrict__ in, uint32_t n, kb
 // Returns 1 when this path does not apply (k < 9 or > 14, more than 2^36 bases): the caller uses the atomic scatter.
 int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, uint64_t* d_off, void** d_pos_out, uint64_t* n_pos_out,
                            float* ms_out) {
-    if (k < 9 || k > 14 || ow->packed_bytes * 4 >= ((uint64_t)1 << KB_POS_BITS) || ow->n_reads == 0) return 1;
+    if (k < 9 || k > 14 || ow->n_reads == 0) return 1;
     if (getenv("DP_KINDEX_ATOMIC")) return 1;
     {
         size_t free_b = 0, total_b = 0;
@@ -350,6 +359,15 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     const uint64_t n_groups = (ow->packed_bytes * 4 + 31) / 32;
     KbGeom G;
     G.k = k;
+    {
+        uint32_t max_len = 1;
+        for (uint32_t r = 0; r < ow->n_reads; r++) max_len = std::max(max_len, ow->h_len[r]);
+        G.pbits = 1;
+        while (((uint64_t)1 << G.pbits) <= max_len) G.pbits++;
+        G.rbits = 1;
+        while (((uint64_t)1 << G.rbits) < ow->n_reads) G.rbits++;
+        if (2 * k + G.pbits + G.rbits > 64) return 1;  // (the entry has no room for read and position: atomic scatter build)
+    }
     G.b1 = 8;
     // pass 2's width: sub-partitions of about 6000 entries (they are sorted inside LDS when they hold <= 8192)
     const uint64_t approx = ow->total_bases;
