@@ -334,7 +334,9 @@ def dense_regime_leg(reads, args, torch):
     round, W ~ 3 k words), so the index query streams hundreds of MB of posting words per round - the regime in which the
     north star's "HBM roofline during index-query" is a meaningful number.  Same reads, same code path."""
     from downpore_amd.overlap import OverlapPipeline
-    pipe = OverlapPipeline(reads, device=0, k=10, seed_batch_size=args.seed_batch_size, slots=args.slots, defer_init=True)
+    # one executor slot: the leg is here for the kernel's own duration (its roofline), and eight rounds in flight would have
+    # eight of these streaming kernels share the HBM bandwidth and each launch take several times longer
+    pipe = OverlapPipeline(reads, device=0, k=10, seed_batch_size=args.seed_batch_size, slots=1, defer_init=True)
     leg = rounds_leg(pipe, args.dense_leg_rounds, torch, warm=4)
     pipe.close()
     m = max(1.0, leg.pop("_rounds"))
@@ -343,7 +345,7 @@ def dense_regime_leg(reads, args, torch):
     leg["query_kernel"] = {"launch_ms": qms, "algorithmic_bytes_per_launch": qb,
                            "achieved_GBs": (qb / 1e9) / (qms / 1e3) if qms > 0 else 0.0,
                            "frac_of_hbm_peak": ((qb / 1e9) / (qms / 1e3)) / HBM_PEAK_GBS if qms > 0 else 0.0}
-    leg["workload"] = "same reads, k=10 (dense seeds): %d rounds" % int(m)
+    leg["workload"] = "same reads, k=10 (dense seeds): %d rounds, one executor slot (kernel durations without other rounds in flight)" % int(m)
     return leg
 
 
