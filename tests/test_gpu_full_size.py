@@ -72,6 +72,27 @@ def test_config3_full_size_map_matches_oracle():
     assert got == want and gerr == werr
 
 
+def test_config5_one_gpu_share_of_the_reference():
+    """BASELINE config 5 is a 3 Gb reference spread over 8 GPUs: 375 Mb of reference per GPU.  One such share at k = 13 -
+    37 880 reference chunks, 2.9 M seeds: posting and seed-set bit matrices of 13.7 GB each, 19 k-mer positions per seed -
+    is indexed on the one GPU here and 15 kb reads (10 % error) are mapped against it; the oracle maps the first 300 of them
+    against the same 375 Mb on the host (40 s).  Identical PAF.  (Joining the shards of a whole 3 Gb reference - global
+    set windows for the index query and the ratchet handed from shard to shard - is not built: DESIGN.md section 8.)"""
+    from downpore_amd.mapping import map_reads
+    from downpore_amd.overlap import Reads
+    G, N, L, e, seed, n_cpu = 375000000, 1000, 15000, 0.1, 5, 300
+    genome = np.frombuffer(O.gen_genome(seed, G), dtype=np.uint8)
+    goff = np.array([0, G], dtype=np.int64)
+    bases, off = O.gen_reads(seed, G, N, L, e, False)
+    got, gerr, st = map_reads(Reads(genome, goff, min_len=0, himem=False), Reads(bases, off, min_len=500, himem=False),
+                              circular=True, k=13)
+    assert st["n_chunks"] > 37000 and st["n_seeds"] > 2000000
+    want, werr = O.map_run(O.ReadSet(genome, goff, min_len=0, himem=False),
+                           O.ReadSet(bases[:off[n_cpu]], off[:n_cpu + 1], min_len=500, himem=False), circular=True, k=13)
+    assert want.count("\n") >= n_cpu * 9 // 10
+    assert got.startswith(want)
+
+
 def test_config4_first_rounds_match_oracle_fixture():
     """BASELINE config 4's read set (1 M x 10 kb = 10 Gbase resident on ONE GPU, positions beyond 2^32, 80 GB k-mer index):
     the first rounds against the oracle's fixture.  (The 8-GPU form of config 4 is the driver's to run.)"""

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--error", type=float, default=0.1)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--cpu-reads", type=int, default=1500)
+    ap.add_argument("--k", type=int, default=11)
     a = ap.parse_args()
     from tools.synth import gen_genome, gen_reads
     from downpore_amd.mapping import map_reads
@@ -31,11 +32,11 @@ def main():
     ref = Reads(genome, goff, min_len=0, himem=False)
     reads = Reads(bases, off, min_len=500, himem=False)
     t0 = time.perf_counter()
-    paf, err, st = map_reads(ref, reads, circular=True, k=11)
+    paf, err, st = map_reads(ref, reads, circular=True, k=a.k)
     dt = time.perf_counter() - t0
     lines = paf.count("\n")
-    out = {"workload": "map: %d reads x %d bp (error %.2f) vs %d bp circular reference, k=11 (BASELINE config 3)" %
-                       (a.reads, a.read_len, a.error, a.genome),
+    out = {"workload": "map: %d reads x %d bp (error %.2f) vs %d bp circular reference, k=%d" %
+                       (a.reads, a.read_len, a.error, a.genome, a.k),
            "wall_s": dt, "reads_per_s": a.reads / dt, "paf_lines": lines, "stats": st,
            "stderr": err.strip().split("\n")[-4:]}
     if a.cpu_reads > 0:
@@ -44,7 +45,7 @@ def main():
         oref = O.ReadSet(genome, goff, min_len=0, himem=False)
         oreads = O.ReadSet(bases[:off[n]], off[:n + 1], min_len=500, himem=False)
         t0 = time.perf_counter()
-        opaf, oerr = O.map_run(oref, oreads, circular=True, k=11)
+        opaf, oerr = O.map_run(oref, oreads, circular=True, k=a.k)
         odt = time.perf_counter() - t0
         out["cpu_baseline"] = {"reads_per_s": n / odt, "sample": "first %d reads (incl. reference indexing), %.1f s" % (n, odt),
                                "cores": 1, "kind": "port", "identical_prefix": paf.startswith(opaf)}
