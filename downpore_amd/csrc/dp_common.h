@@ -86,6 +86,9 @@ struct dp_ctx {
 
     // ---- index (A13)
     uint32_t n_seqs = 0, W = 0, SW = 0;
+    uint32_t map_stage_windows = 0;
+    bool map_stage_valid = false;  // dp_map_windows_shard: the query stage of the forward pass is reused by the reverse pass
+    uint32_t word_base = 0, global_n_seqs = 0;  // dp_index_set_global: this index is the words [word_base, word_base + W) of a larger one
     DevBuf d_seqrefs, d_posting, d_seedsets, d_pmeta;  // pmeta: uint32 {count,start,end,lens} per seed
 
     // ---- overlaps (A14..A8)
@@ -157,8 +160,9 @@ int dp_match_anchors_launch(dp_ctx* ctx);  // dp_overlap.hip: GetSeedOffset / Ge
 int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs);
 int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,
                           uint32_t max_query_len, int want_candidates, dp_match_batch* out);
+// phase 2 = both strands (whole index); 0 / 1 = forward / reverse windows of a shard, thresholds through thr_io[nw]
 int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t nw, int k,
-                        dp_chain_batch* out);
+                        dp_chain_batch* out, int phase = 2, int32_t* thr_io = nullptr);
 int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
                    uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out = nullptr);
 

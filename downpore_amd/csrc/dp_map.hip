@@ -236,7 +236,11 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                                                            uint32_t W, uint32_t SW, int k, uint16_t* __restrict__ poolA,
                                                            uint16_t* __restrict__ poolB, uint16_t* __restrict__ poolLen,
                                                            MapRec* __restrict__ recs, uint32_t rec_cap, int32_t* __restrict__ ma,
-                                                           int32_t* __restrict__ mb, uint32_t int_cap, uint32_t* __restrict__ cursor) {
+                                                           int32_t* __restrict__ mb, uint32_t int_cap, uint32_t* __restrict__ cursor,
+                                                           int phase, int32_t* __restrict__ thr_io) {
+    // phase 2: both strands of every window pair, thresholds from the windows themselves (the whole index is here).
+    // phase 0 / 1 (the index is one shard of the reference, dp_map_windows_shard): only the forward / only the reverse-complement
+    // windows, starting from the thresholds the previous shard left in thr_io[pair][2] (< 0: none yet) and leaving its own there.
     __shared__ MWave sh[M_WAVES];
     MWave& L = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
@@ -253,9 +257,10 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
             const uint32_t w = 2 * pair + s;
             const int ns = (int)((woff[w + 1] - woff[w]) / 2);
             thr[s] = ns / 5 < 5 ? 5 : ns / 5;
+            if (thr_io && thr_io[2 * pair + s] >= 0) thr[s] = thr_io[2 * pair + s];
         }
         uint32_t seq = 0;
-        for (int s = 0; s < 2; s++) {
+        for (int s = (phase == 1 ? 1 : 0); s < (phase == 0 ? 1 : 2); s++) {
             const uint32_t w = 2 * pair + s;
             const int32_t* qSeg = wsegs + woff[w];
             const int qN = (int)(woff[w + 1] - woff[w]);
@@ -321,11 +326,15 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                 }
             }
         }
+        if (thr_io && lane == 0) {
+            thr_io[2 * pair] = thr[0];
+            thr_io[2 * pair + 1] = thr[1];
+        }
     }
 }
 
 int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t nw, int k,
-                        dp_chain_batch* out) {
+                        dp_chain_batch* out, int phase, int32_t* thr_io) {
     if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_map_windows before dp_round_begin");
     if (nw & 1) return dp_fail(ctx, DP_ERR_ARG, "dp_map_windows: windows come in (forward, reverse-complement) pairs");
     hipSetDevice(ctx->device);
@@ -339,8 +348,23 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
     u64* d_words = nullptr;
     int32_t* d_mc = nullptr;
     uint32_t mc_n = 0;
-    int rc = dp_query_stage(ctx, w_segs, w_off, nw, 0.25, &d_qmeta, &d_words, &d_mc, &mc_n);  // Matches(.., 0.25) :502-503
-    if (rc != 0) return rc;
+    uint32_t* d_qcnt_unused = nullptr;
+    int rc = DP_OK;
+    if (phase == 1 && ctx->map_stage_windows == nw && ctx->map_stage_valid) {
+        // the reverse pass of a shard follows its forward pass on the same windows: the query stage's results are still there
+        d_qmeta = (uint32_t*)ctx->d_qmeta.p;
+    } else {
+        rc = dp_query_stage(ctx, w_segs, w_off, nw, 0.25, &d_qmeta, &d_words, &d_mc, &mc_n, &d_qcnt_unused);  // Matches(.., 0.25) :502-503
+        if (rc != 0) return rc;
+        ctx->map_stage_windows = nw;
+        ctx->map_stage_valid = phase == 0;
+    }
+    int32_t* d_thr = nullptr;
+    if (thr_io) {
+        if (dev_reserve(ctx, ctx->d_sa, (size_t)nw * 4 + 64)) return DP_ERR_HIP;
+        d_thr = (int32_t*)ctx->d_sa.p;
+        DP_HIP(hipMemcpyAsync(d_thr, thr_io, (size_t)nw * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     if (dev_reserve(ctx, ctx->d_cursor, 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_sched, (size_t)nw * 4 + 16)) return DP_ERR_HIP;
     DP_HIP(hipMemcpyAsync(ctx->d_sched.p, w_len, (size_t)nw * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -367,7 +391,7 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
                            (const uint32_t*)d_qmeta, (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p,
                            (const int32_t*)ctx->d_segs.p, (const u64*)ctx->d_seedsets.p, W, SW, k, poolA, poolB, poolLen,
                            (MapRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p, int_cap,
-                           (uint32_t*)ctx->d_cursor.p);
+                           (uint32_t*)ctx->d_cursor.p, phase, d_thr);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         DP_HIP(hipMemcpyAsync(cur, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -385,6 +409,7 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
     float qms = 0;
     hipEventElapsedTime(&qms, ctx->ev[4], ctx->ev[5]);
     out->kernel_ms = (double)total_ms + (double)qms;
+    if (thr_io) DP_HIP(hipMemcpy(thr_io, d_thr, (size_t)nw * 4, hipMemcpyDeviceToHost));
     if (cur[2]) {
         char msg[160];
         snprintf(msg, sizeof msg, "map chaining exceeded a device capacity (bits %u: 1 reduced sequence, 2 chain pool, 4 good-chain list)", cur[2]);

@@ -80,6 +80,8 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
     ctx->n_seqs = n_seqs;
     ctx->W = W;
     ctx->SW = SW;
+    ctx->word_base = 0;  // (a fresh index is a whole one until dp_index_set_global says otherwise)
+    ctx->global_n_seqs = 0;
     if (dev_reserve(ctx, ctx->d_seqrefs, (size_t)n_seqs * sizeof(dp_seq_ref) + 16)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_posting, (size_t)S * W * 8 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_seedsets, (size_t)n_seqs * SW * 8 + 64)) return DP_ERR_HIP;
@@ -108,6 +110,25 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
 extern "C" int dp_index_build(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
     if (!ctx || (n_seqs && !seqs)) return DP_ERR_ARG;
     return dp_index_build_impl(ctx, seqs, n_seqs);
+}
+
+// ---- an index that is one shard of a larger one (map against a reference spread over several GPUs) ----------------------
+extern "C" int dp_index_meta(dp_ctx* ctx, uint32_t* meta_out, uint32_t n_seeds) {
+    if (!ctx || !meta_out || n_seeds != ctx->n_seeds) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_index_meta: bad arguments") : DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    DP_HIP(hipMemcpyAsync(meta_out, ctx->d_pmeta.p, (size_t)n_seeds * 16, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    return DP_OK;
+}
+extern "C" int dp_index_set_global(dp_ctx* ctx, const uint32_t* meta_global, uint32_t n_seeds, uint32_t word_base, uint32_t n_seqs_global) {
+    if (!ctx || !meta_global || n_seeds != ctx->n_seeds) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_index_set_global: bad arguments") : DP_ERR_ARG;
+    if (n_seqs_global < (uint64_t)word_base * 64 + ctx->n_seqs) return dp_fail(ctx, DP_ERR_ARG, "dp_index_set_global: the shard does not fit the global index");
+    hipSetDevice(ctx->device);
+    DP_HIP(hipMemcpyAsync(ctx->d_pmeta.p, meta_global, (size_t)n_seeds * 16, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    ctx->word_base = word_base;
+    ctx->global_n_seqs = n_seqs_global;
+    return DP_OK;
 }
 
 extern "C" int dp_index_posting_row(dp_ctx* ctx, uint32_t seed, u64* words, uint32_t cap_words, uint32_t* n_words,
@@ -173,7 +194,11 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
                                                              const uint32_t* __restrict__ pmeta, uint32_t n_seqs, uint32_t W,
                                                              const int32_t* __restrict__ mc, uint32_t mc_n,
                                                              u64* __restrict__ cand, uint32_t* __restrict__ qmeta,
-                                                             u64* __restrict__ words_read, uint32_t* __restrict__ qcnt) {
+                                                             u64* __restrict__ words_read, uint32_t* __restrict__ qcnt,
+                                                             uint32_t word_base) {
+    // word_base: a shard of a larger index (dp_index_set_global) holds the words [word_base, word_base + W) of every set; pmeta
+    // and n_seqs then describe the WHOLE sets (global windows, counts), so the filter, the early-return cut and the gather
+    // order are those of the unsharded query, and this launch fills in the candidate words of its own range.
     __shared__ QWave S;
     __shared__ uint32_t sh_u[8];
     __shared__ int64_t sh_ilast;
@@ -320,9 +345,11 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
 
     u64 gathered = 0;
     int nCand = 0;  // Matches() result size of this query (bits set in its cand row)
-    for (int64_t ib = (int64_t)start + 64 * wave; ib <= i_last; ib += 64 * Q_WAVES) {
+    const int64_t w_lo = max((int64_t)start, (int64_t)word_base), w_hi = min(i_last, (int64_t)word_base + (int64_t)W - 1);
+    posting -= word_base;  // (indexed by the global word below)
+    for (int64_t ib = w_lo + 64 * wave; ib <= w_hi; ib += 64 * Q_WAVES) {
         const int64_t i = ib + lane;
-        if (i > i_last) continue;
+        if (i > w_hi) continue;
         const uint32_t iw = (uint32_t)i;
         u64 v = 0;
         if (!ladder16) {
@@ -424,7 +451,7 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
                 v &= (gt | eq);
             }
         }
-        cand[(uint64_t)q * W + iw] = v;
+        cand[(uint64_t)q * W + (iw - word_base)] = v;
         nCand += __popcll(v);
     }
     gathered = (u64)wave_sum((int)gathered);
@@ -1875,7 +1902,8 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     DP_HIP(dp_mark(ctx, 4));
     hipLaunchKernelGGL(query_kernel, dim3(nq), dim3(64 * Q_WAVES), 0, ctx->stream,
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
-                       (const uint32_t*)ctx->d_pmeta.p, M, W, (const int32_t*)d_mc, mc_n, (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt);
+                       (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
+                       (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 5));
 
@@ -2197,4 +2225,10 @@ extern "C" int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t
                               uint32_t n_windows, int k, dp_chain_batch* out) {
     if (!ctx || !out || (n_windows && (!w_segs || !w_off || !w_len))) return DP_ERR_ARG;
     return dp_map_windows_impl(ctx, w_segs, w_off, w_len, n_windows, k, out);
+}
+
+extern "C" int dp_map_windows_shard(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t n_windows,
+                                    int k, int phase, int32_t* thr_io, dp_chain_batch* out) {
+    if (!ctx || !out || !thr_io || (phase != 0 && phase != 1) || (n_windows && (!w_segs || !w_off || !w_len))) return DP_ERR_ARG;
+    return dp_map_windows_impl(ctx, w_segs, w_off, w_len, n_windows, k, out, phase, thr_io);
 }

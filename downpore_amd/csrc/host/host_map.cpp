@@ -679,8 +679,99 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         M.chunks[i].offset = meta[i].first;
         M.chunks[i].inset = meta[i].second;
     }
-    rc = dp_index_build(ctx, refs.data(), (uint32_t)refs.size());
-    if (rc) return fail(rc);
+    // ---- DP_MAP_SHARDS=N: the reference index spread over N contexts (DP_MAP_DEVICES=0,1,..: their GPUs, round robin;
+    // default all on this one) - what BASELINE config 5 does with a 3 Gb reference on 8 GPUs.  Shard s holds the chunks
+    // [c0, c1) (c0 a multiple of 64): their segments (imported from the chunk scan above), posting and seed-set words.  The
+    // sets' global windows are combined here once (include/downpore_hip.h, dp_index_set_global).
+    struct Shard {
+        dp_ctx* ctx = nullptr;
+        uint32_t c0 = 0, c1 = 0;
+    };
+    std::vector<Shard> shards;
+    struct ShardGuard {
+        std::vector<Shard>& v;
+        ~ShardGuard() {
+            for (Shard& sh : v)
+                if (sh.ctx) dp_ctx_destroy(sh.ctx);
+        }
+    } shardGuard{shards};
+    int nShards = 1;
+    if (const char* e = getenv("DP_MAP_SHARDS")) nShards = std::max(1, atoi(e));
+    if (nShards > 1) {
+        std::vector<int> devs;
+        if (const char* e = getenv("DP_MAP_DEVICES")) {
+            for (const char* q = e; *q;) {
+                devs.push_back(atoi(q));
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+            }
+        }
+        if (devs.empty()) devs.push_back(device);
+        const uint32_t nChunks = (uint32_t)items.size(), S = (uint32_t)index.seedMap.size();
+        const uint32_t per = ((nChunks + (uint32_t)nShards - 1) / (uint32_t)nShards + 63) / 64 * 64;  // whole 64-chunk words
+        std::vector<uint32_t> global((size_t)S * 4), local((size_t)S * 4);
+        for (uint32_t i = 0; i < S; i++) {  // NewIntSet(): count 0, start 1, end 0 (last + 1 = 1)
+            global[4 * (size_t)i + 0] = 0;
+            global[4 * (size_t)i + 1] = 1;
+            global[4 * (size_t)i + 2] = 0;
+            global[4 * (size_t)i + 3] = 1;
+        }
+        for (uint32_t c0 = 0; c0 < nChunks; c0 += per) {
+            Shard sh;
+            sh.c0 = c0;
+            sh.c1 = std::min(nChunks, c0 + per);
+            if (dp_ctx_create(devs[shards.size() % devs.size()], &sh.ctx) != 0) {
+                error = dp_last_error(nullptr);
+                dp_ctx_destroy(ctx);
+                return DP_ERR_NODEVICE;
+            }
+            shards.push_back(sh);
+            dp_ctx* sc = sh.ctx;
+            auto sfail = [&](int rc2) {
+                error = dp_last_error(sc);
+                dp_ctx_destroy(ctx);
+                return rc2;
+            };
+            rc = dp_round_begin(sc, k, index.seedMap.data(), S);
+            if (rc) return sfail(rc);
+            const uint64_t s0 = sb.seg_off[sh.c0], s1 = sb.seg_off[sh.c1];
+            rc = dp_scan_import_segments(sc, M.chunkSegs.data() + s0, s1 - s0);
+            if (rc) return sfail(rc);
+            std::vector<dp_seq_ref> lrefs(refs.begin() + sh.c0, refs.begin() + sh.c1);
+            for (dp_seq_ref& r : lrefs) r.seg_off -= s0;
+            rc = dp_index_build(sc, lrefs.data(), (uint32_t)lrefs.size());
+            if (rc) return sfail(rc);
+            rc = dp_index_meta(sc, local.data(), S);
+            if (rc) return sfail(rc);
+            const uint32_t wb = sh.c0 / 64;
+            for (uint32_t i = 0; i < S; i++) {
+                const uint32_t cnt = local[4 * (size_t)i];
+                if (!cnt) continue;
+                uint32_t* g = &global[4 * (size_t)i];
+                const uint32_t st = local[4 * (size_t)i + 1] + wb, en = local[4 * (size_t)i + 2] + wb;
+                if (g[0] == 0) {
+                    g[1] = st;
+                    g[2] = en;
+                } else {
+                    g[1] = std::min(g[1], st);
+                    g[2] = std::max(g[2], en);
+                }
+                g[0] += cnt;
+                g[3] = g[2] + 1;
+            }
+        }
+        for (Shard& sh : shards) {
+            rc = dp_index_set_global(sh.ctx, global.data(), S, sh.c0 / 64, nChunks);
+            if (rc) {
+                error = dp_last_error(sh.ctx);
+                dp_ctx_destroy(ctx);
+                return rc;
+            }
+        }
+    } else {
+        rc = dp_index_build(ctx, refs.data(), (uint32_t)refs.size());
+        if (rc) return fail(rc);
+    }
     // dp_scan below reuses the device scan buffer: keep the chunk segments in a dedicated import
     // (dp_index_build references the device-resident scan output, so windows must not overwrite it)
     if (stats) stats->n_chunks = items.size(), stats->n_seeds = index.seedMap.size();
@@ -807,15 +898,6 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             woff.push_back(wsegs.size());
             wlen.push_back((uint32_t)(t.req.b - t.req.a));
         }
-        rc = dp_scan_import_segments(ctx, M.chunkSegs.data(), M.chunkSegs.size());
-        if (rc) return fail(rc);
-        dp_chain_batch cb;
-        const double tc0 = wallNow();
-        rc = dp_map_windows(ctx, wsegs.data(), woff.data(), wlen.data(), (uint32_t)witems.size(), k, &cb);
-        if (rc) return fail(rc);
-        tChain += wallNow() - tc0;
-        if (stats) stats->k_map_ms += cb.kernel_ms, stats->n_chains += cb.n_chains, stats->n_batches++;
-        // ---- ... distribute and resume
         for (auto& tp : live) {
             tp->res.seg[0].clear();
             tp->res.seg[1].clear();
@@ -824,14 +906,44 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         }
         for (size_t w = 0; w < witems.size(); w++)
             live[w / 2]->res.seg[w & 1].assign(wsegs.begin() + (i64)woff[w], wsegs.begin() + (i64)woff[w + 1]);
-        for (uint32_t c = 0; c < cb.n_chains; c++) {
-            const uint32_t w = cb.window[c];
-            WindowResult::ChainRef cr;
-            cr.target = cb.target[c];
-            cr.a.assign(cb.match_a + cb.off[c], cb.match_a + cb.off[c + 1]);
-            cr.b.assign(cb.match_b + cb.off[c], cb.match_b + cb.off[c + 1]);
-            live[w / 2]->res.chains[w & 1].push_back(std::move(cr));
+        auto takeChains = [&](const dp_chain_batch& cb, uint32_t chunkBase) {
+            for (uint32_t c = 0; c < cb.n_chains; c++) {
+                const uint32_t w = cb.window[c];
+                WindowResult::ChainRef cr;
+                cr.target = cb.target[c] + chunkBase;
+                cr.a.assign(cb.match_a + cb.off[c], cb.match_a + cb.off[c + 1]);
+                cr.b.assign(cb.match_b + cb.off[c], cb.match_b + cb.off[c + 1]);
+                live[w / 2]->res.chains[w & 1].push_back(std::move(cr));
+            }
+            if (stats) stats->k_map_ms += cb.kernel_ms, stats->n_chains += cb.n_chains;
+        };
+        const double tc0 = wallNow();
+        if (shards.empty()) {
+            rc = dp_scan_import_segments(ctx, M.chunkSegs.data(), M.chunkSegs.size());
+            if (rc) return fail(rc);
+            dp_chain_batch cb;
+            rc = dp_map_windows(ctx, wsegs.data(), woff.data(), wlen.data(), (uint32_t)witems.size(), k, &cb);
+            if (rc) return fail(rc);
+            takeChains(cb, 0);
+        } else {
+            // candidates of a window in ascending chunk id = shard after shard; forward strand over all shards first, its
+            // ratchet raises the reverse threshold too (mapping.go:543-549): the thresholds travel with the batch
+            std::vector<int32_t> thr(witems.size(), -1);
+            for (int phase = 0; phase < 2; phase++)
+                for (Shard& sh : shards) {
+                    dp_chain_batch cb;
+                    rc = dp_map_windows_shard(sh.ctx, wsegs.data(), woff.data(), wlen.data(), (uint32_t)witems.size(), k, phase, thr.data(), &cb);
+                    if (rc) {
+                        error = dp_last_error(sh.ctx);
+                        dp_ctx_destroy(ctx);
+                        return rc;
+                    }
+                    takeChains(cb, sh.c0);
+                }
         }
+        tChain += wallNow() - tc0;
+        if (stats) stats->n_batches++;
+        // ---- ... distribute and resume
         for (auto& tp : live) swapcontext(&sched.main, &tp->uc);
     }
     if (stats) {

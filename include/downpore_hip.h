@@ -265,6 +265,26 @@ typedef struct {
 DP_API int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t n_windows,
                    int k, dp_chain_batch* out);
 
+/* ---- the reference index spread over several contexts / GPUs (BASELINE config 5: mapping/mapping.go:67-109 for a 3 Gb
+ * reference) -----------------------------------------------------------------------------------------------------------
+ * Every shard holds the same seeds (dp_round_begin) and a contiguous range of the reference chunks whose first chunk id is
+ * a multiple of 64 (dp_index_build on that range: posting / seed-set words [word_base, word_base + W) of the whole index).
+ * util.GetSharedIDs works on the sets' windows - a posting set takes part from the scan's first word to its own last word
+ * (util/bitset.go:323-353: the early return, the drops, the gather order of the 16-ladder) - so a shard must know the WHOLE
+ * sets: dp_index_meta returns a shard's rows {count, first word, last word, last + 1} (local word numbers), the caller
+ * combines them over the shards (sum, min, max in global word numbers; an empty set keeps start 1 / end 0) and hands the
+ * result to every shard with dp_index_set_global together with the shard's word_base and the total number of chunks.
+ * dp_map_windows_shard is dp_map_windows for one strand (phase 0 = the forward windows, 1 = the reverse complements) of
+ * every window pair against one shard.  performMapping's ratchets (mapping.go:543-549, 583-586) run over a window's
+ * candidates in ascending chunk id, forward strand first, and the forward ratchet also raises the reverse threshold:
+ * thr_io[2 * pair + strand] carries minMatches / minRCMatches from shard to shard (initialise to -1 = "take the window's
+ * own"); call phase 0 on the shards in ascending chunk order, then phase 1 in the same order.  `target` in `out` is the chunk's
+ * index inside the shard.  Chains of a window: phase 0 results of shard 0, 1, ..., then phase 1 results of shard 0, 1, ... */
+DP_API int dp_index_meta(dp_ctx* ctx, uint32_t* meta_out, uint32_t n_seeds);
+DP_API int dp_index_set_global(dp_ctx* ctx, const uint32_t* meta_global, uint32_t n_seeds, uint32_t word_base, uint32_t n_seqs_global);
+DP_API int dp_map_windows_shard(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t n_windows,
+                         int k, int phase, int32_t* thr_io, dp_chain_batch* out);
+
 /* ---- A16 (part): seed-space multiple alignment of multiAligner.Consensus (seeds/alignment.go:52-247) ------------
  * For each of `n_groups` groups (one per query window) the caller passes the Reduced() seed sequences of the trimmed
  * matched targets (seeds shared by >= 2 of them, alignment.go:45-50), flattened: sequence s = segs[seq_off[s] ..

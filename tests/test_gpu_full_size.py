@@ -72,14 +72,19 @@ def test_config3_full_size_map_matches_oracle():
     assert got == want and gerr == werr
 
 
-def test_config5_one_gpu_share_of_the_reference():
+@pytest.mark.parametrize("shards", [1, 8])
+def test_config5_one_gpu_share_of_the_reference(monkeypatch, shards):
     """BASELINE config 5 is a 3 Gb reference spread over 8 GPUs: 375 Mb of reference per GPU.  One such share at k = 13 -
-    37 880 reference chunks, 2.9 M seeds: posting and seed-set bit matrices of 13.7 GB each, 19 k-mer positions per seed -
-    is indexed on the one GPU here and 15 kb reads (10 % error) are mapped against it; the oracle maps the first 300 of them
-    against the same 375 Mb on the host (40 s).  Identical PAF.  (Joining the shards of a whole 3 Gb reference - global
-    set windows for the index query and the ratchet handed from shard to shard - is not built: DESIGN.md section 8.)"""
+    37 880 reference chunks, 2.9 M seeds: posting and seed-set bit matrices of 13.7 GB each - is indexed on the one GPU here
+    and 15 kb reads (10 % error) are mapped against it; the oracle maps the first 300 of them against the same 375 Mb on the
+    host (40 s).  Identical PAF - with the whole index in one context, and with config 5's own layout at this scale: the
+    chunks dealt to eight contexts (DP_MAP_SHARDS=8; on an 8-GPU node DP_MAP_DEVICES=0,...,7 puts each on its own GPU),
+    global set windows for the index query and the ratchets handed from shard to shard (include/downpore_hip.h,
+    dp_index_set_global / dp_map_windows_shard)."""
     from downpore_amd.mapping import map_reads
     from downpore_amd.overlap import Reads
+    if shards > 1:
+        monkeypatch.setenv("DP_MAP_SHARDS", str(shards))
     G, N, L, e, seed, n_cpu = 375000000, 1000, 15000, 0.1, 5, 300
     genome = np.frombuffer(O.gen_genome(seed, G), dtype=np.uint8)
     goff = np.array([0, G], dtype=np.int64)

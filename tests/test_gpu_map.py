@@ -56,6 +56,19 @@ def test_map_paf_bit_exact(seed, G, N, L, e, variable, circular):
     assert st["n_windows"] >= N
 
 
+@pytest.mark.parametrize("shards,G,k,e", [(3, 6000000, 11, 0.10), (4, 2600000, 9, 0.05), (2, 1500000, 13, 0.0)])
+def test_map_reference_index_in_shards(monkeypatch, shards, G, k, e):
+    """BASELINE config 5's layout on one GPU: the reference chunks are dealt to DP_MAP_SHARDS contexts in contiguous ranges
+    (whole 64-chunk words), every shard answers Matches() for its own words with the sets' GLOBAL windows and counts
+    (dp_index_set_global), and performMapping's ratchets travel from shard to shard, forward strand first
+    (dp_map_windows_shard).  The PAF must be the oracle's - i.e. the unsharded result: k = 9 makes every seed frequent
+    (long windows, the 16-ladder and its gather order), k = 13 makes them rare (short sets, early returns)."""
+    monkeypatch.setenv("DP_MAP_SHARDS", str(shards))
+    want, st = _case(11 + shards, G, 400, 7000, e, True, True, k=k)
+    assert st["n_chunks"] > 64 * (shards - 1)
+    assert want.count("\n") > 200
+
+
 def test_map_short_reads_and_len_mod4_quirks():
     want, st = _case(6, 120000, 100, 5000, 0.02, True, True, short_reads=True)
     assert want.count("\n") > 50
