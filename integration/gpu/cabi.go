@@ -320,6 +320,90 @@ func (c *Context) MapWindows(wSegs []int32, wOff []uint64, wLen []uint32, k int)
 	return out, nil
 }
 
+// ---- the reference index of `map` held in shards (a 3 Gb reference does not fit one GPU) --------------------------------
+// Every shard context has had RoundBegin with the same seeds and IndexBuild on its own contiguous range of reference chunks
+// (first chunk id a multiple of 64).
+
+// IndexMeta returns the shard's {count, first word, last word, last+1} per seed (local word numbers).
+func (c *Context) IndexMeta(nSeeds int) ([]uint32, error) {
+	out := make([]uint32, 4*nSeeds)
+	if nSeeds == 0 {
+		return out, nil
+	}
+	if rc := C.dp_index_meta(c.h, (*C.uint32_t)(unsafe.Pointer(&out[0])), C.uint32_t(nSeeds)); rc != 0 {
+		return nil, fail(c.h, "dp_index_meta", rc)
+	}
+	return out, nil
+}
+
+// CombineIndexMeta joins the shards' rows into the rows of the whole sets: counts add up, windows in global word numbers
+// (wordBase[s] = first chunk of shard s / 64); an empty set keeps NewIntSet()'s start 1 / end 0.
+func CombineIndexMeta(perShard [][]uint32, wordBase []uint32, nSeeds int) []uint32 {
+	g := make([]uint32, 4*nSeeds)
+	for i := 0; i < nSeeds; i++ {
+		g[4*i+1], g[4*i+3] = 1, 1
+	}
+	for s, m := range perShard {
+		for i := 0; i < nSeeds; i++ {
+			cnt := m[4*i]
+			if cnt == 0 {
+				continue
+			}
+			st, en := m[4*i+1]+wordBase[s], m[4*i+2]+wordBase[s]
+			if g[4*i] == 0 || st < g[4*i+1] {
+				g[4*i+1] = st
+			}
+			if g[4*i] == 0 || en > g[4*i+2] {
+				g[4*i+2] = en
+			}
+			g[4*i] += cnt
+			g[4*i+3] = g[4*i+2] + 1
+		}
+	}
+	return g
+}
+
+// IndexSetGlobal installs the whole sets' rows in a shard: its index query then follows util.GetSharedIDs on the global
+// windows (early return, drops, 16-ladder gather order) and fills in the candidate words of its own range.
+func (c *Context) IndexSetGlobal(metaGlobal []uint32, wordBase, nChunksGlobal int) error {
+	if len(metaGlobal) == 0 {
+		return nil
+	}
+	if rc := C.dp_index_set_global(c.h, (*C.uint32_t)(unsafe.Pointer(&metaGlobal[0])), C.uint32_t(len(metaGlobal)/4), C.uint32_t(wordBase), C.uint32_t(nChunksGlobal)); rc != 0 {
+		return fail(c.h, "dp_index_set_global", rc)
+	}
+	return nil
+}
+
+// MapWindowsShard is MapWindows for one strand (phase 0 = forward windows, 1 = reverse complements) against one shard.
+// thr (len = number of windows, -1 = "the window's own minMatches") carries performMapping's ratchets (mapping.go:543-549,
+// 583-586) from shard to shard: call phase 0 on the shards in ascending chunk order, then phase 1 in the same order.
+// Chain.Target is the chunk's index inside the shard.
+func (c *Context) MapWindowsShard(wSegs []int32, wOff []uint64, wLen []uint32, k, phase int, thr []int32) ([]Chain, error) {
+	var b C.dp_chain_batch
+	var sp *C.int32_t
+	if len(wSegs) > 0 {
+		sp = (*C.int32_t)(unsafe.Pointer(&wSegs[0]))
+	}
+	rc := C.dp_map_windows_shard(c.h, sp, (*C.uint64_t)(unsafe.Pointer(&wOff[0])), (*C.uint32_t)(unsafe.Pointer(&wLen[0])), C.uint32_t(len(wLen)), C.int(k), C.int(phase),
+		(*C.int32_t)(unsafe.Pointer(&thr[0])), &b)
+	if rc != 0 {
+		return nil, fail(c.h, "dp_map_windows_shard", rc)
+	}
+	n := int(b.n_chains)
+	out := make([]Chain, 0, n)
+	if n == 0 {
+		return out, nil
+	}
+	w := unsafe.Slice((*uint32)(unsafe.Pointer(b.window)), n)
+	t := unsafe.Slice((*uint32)(unsafe.Pointer(b.target)), n)
+	off := unsafe.Slice((*uint64)(unsafe.Pointer(b.off)), n+1)
+	for i := 0; i < n; i++ {
+		out = append(out, Chain{Window: int(w[i]), Target: int(t[i]), MatchA: ints32(b.match_a, off[i], off[i+1]), MatchB: ints32(b.match_b, off[i], off[i+1])})
+	}
+	return out, nil
+}
+
 // Comm is one rank of a multi-GPU job (dp_comm): RCCL across processes, or in-process peers.
 type Comm struct {
 	h *C.dp_comm
