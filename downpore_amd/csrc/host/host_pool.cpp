@@ -1,4 +1,5 @@
 // Process-wide worker pool (sized from the cgroup CPU quota) and the DPH_PROFILE counters.
+#include <malloc.h>
 #include <pthread.h>
 #include <sched.h>
 #include <unistd.h>
@@ -11,6 +12,20 @@
 #include "host_util.hpp"
 
 namespace dph {
+
+// Eight executor-slot threads allocate and release hundreds of kilobytes to megabytes per round (result text, segment copies,
+// per-round objects).  With glibc's defaults every other free hands memory back to the kernel (heap trim, munmap of large
+// chunks) and the next round faults it in again; those calls take the process-wide mmap lock for writing and stall every
+// thread's page faults - measured as 12 % of the whole job (two processes with four slots each on one GPU ran 19 % faster
+// than one process with eight).  Keep freed memory in the allocator instead.  DPH_MALLOC_DEFAULTS=1 leaves glibc alone.
+static const bool g_malloc_tuned = [] {
+    if (const char* e = getenv("DPH_MALLOC_DEFAULTS"); e && e[0] == '1') return false;
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);      // (the largest value glibc accepts; fixes the threshold)
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
+    return true;
+}();
+
 
 PipeProfile g_prof;
 #ifdef DPH_FINE

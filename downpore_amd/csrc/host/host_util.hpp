@@ -104,8 +104,9 @@ struct PipeProfile {
         const double n = (double)std::max<long long>(1, executed.load());
         struct rusage ru;
         getrusage(RUSAGE_SELF, &ru);
-        fprintf(stderr, "[pipe] host threads %u, process CPU time user %.2f s sys %.2f s\n", hostThreads(),
-                ru.ru_utime.tv_sec + ru.ru_utime.tv_usec / 1e6, ru.ru_stime.tv_sec + ru.ru_stime.tv_usec / 1e6);
+        fprintf(stderr, "[pipe] host threads %u, process CPU time user %.2f s sys %.2f s, page faults minor %ld major %ld, context switches voluntary %ld involuntary %ld\n",
+                hostThreads(), ru.ru_utime.tv_sec + ru.ru_utime.tv_usec / 1e6, ru.ru_stime.tv_sec + ru.ru_stime.tv_usec / 1e6, ru.ru_minflt,
+                ru.ru_majflt, ru.ru_nvcsw, ru.ru_nivcsw);
         {
             const double nn = (double)std::max<long long>(1, executed.load());
             fprintf(stderr, "[pipe] thread CPU per round (ms): consensus items %.2f, seed-selection items %.2f, slot threads %.2f, planner thread %.2f\n",
