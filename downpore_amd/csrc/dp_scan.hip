@@ -20,6 +20,7 @@
 #include <sys/prctl.h>
 #include <time.h>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -58,21 +59,28 @@ struct ScanGate {
 };
 static ScanGate g_scan_mu;
 
-// Waiting for the context's stream.  The runtime's own waits (hipStreamSynchronize, and hipEventSynchronize even on a
-// blocking-sync event) spin on the completion signal for up to 100 us before they sleep; a round has about ten waits of
-// 50-400 us, so with several executor slots that spinning cost 1.7 core-ms per round of a 16-core budget (DPH_PROFILE=1:
-// scan.call 0.70 ms CPU of 0.91 ms wall).  Default: poll the event and sleep DP_SYNC_POLL_US (20) microseconds between
-// polls (timer slack lowered to 1 us for the calling thread).  DP_SYNC_POLL_US=0: blocking hipEventSynchronize;
-// DP_SPIN_SYNC=1: hipStreamSynchronize.
+// Waiting for the context's stream.  Two ways:
+//   spin  hipStreamSynchronize: the runtime busy-waits on the completion signal - the wake-up is immediate, and the waiting
+//         thread occupies a core.  A round has five to seven waits of 50-500 us; with eight executor slots this is 12-18 % faster
+//         per job than polling (0.44 against 0.54 ms per round) and costs about four more cores.
+//   poll  record an event, poll it, sleep DP_SYNC_POLL_US (20) microseconds between polls (timer slack lowered to 1 us): every
+//         wake-up is 50-70 us late, but a waiting thread costs nothing - what a process needs when it has fewer cores than
+//         waiting threads (round 1: five slots, 17 core-ms of host work per round on a 16-core quota).
+// dp_set_stream_wait() chooses (the host pipeline does, from its CPU budget and its number of slots); DP_SPIN_SYNC=0/1 in the
+// environment overrides it.  DP_SYNC_POLL_US=0: blocking hipEventSynchronize instead of the poll loop.
+static std::atomic<int> g_wait_spin{0};
+extern "C" void dp_set_stream_wait(int spin) { g_wait_spin.store(spin ? 1 : 0); }
+
 hipError_t dp_stream_sync(dp_ctx* ctx) {
-    static const bool spin = [] {
+    static const int env_spin = [] {
         const char* e = getenv("DP_SPIN_SYNC");
-        return e && e[0] == '1';
+        return e ? (e[0] == '1' ? 1 : 0) : -1;
     }();
     static const long poll_ns = [] {
         const char* e = getenv("DP_SYNC_POLL_US");
         return (e ? atol(e) : 20L) * 1000L;
     }();
+    const bool spin = env_spin >= 0 ? env_spin == 1 : g_wait_spin.load(std::memory_order_relaxed) != 0;
     if (spin || !ctx->ev_sync) return hipStreamSynchronize(ctx->stream);
     hipError_t e = hipEventRecord(ctx->ev_sync, ctx->stream);
     if (e != hipSuccess) return e;

@@ -550,6 +550,9 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     mark("values upload");
     slots.clear();
     setHostThreadShare((unsigned)std::max(1, nSlots));
+    // every executor slot's thread waits for its stream five to seven times per round: busy waits when this process has the
+    // cores for it (the worker pool's size is the CPU budget: cgroup quota, or DP_HOST_THREADS for ranks sharing a host)
+    dp_set_stream_wait(hostThreads() >= (unsigned)std::max(1, nSlots) + 3u ? 1 : 0);
     for (int i = 0; i < std::max(1, nSlots); i++) {
         std::unique_ptr<ExecSlot> sl(new ExecSlot());
         if (i == 0) {
