@@ -292,6 +292,8 @@ struct Survivors {
     uint64_t segCount() const { return segsView ? segsViewLen : (uint64_t)segs.size(); }
 };
 
+struct TextJob;
+class TextPool;
 struct FinalCheckStats {
     i64 badBack = 0, emptyMatch = 0;
     uint64_t lines = 0, hits = 0, qHits = 0;
@@ -340,8 +342,9 @@ class Overlapper {
     // The same with everything after the chaining kept on the device (dp_find_overlaps without download + dp_consensus_paf):
     // FindOverlaps + the collation and finalCheckWorker of commands/overlap.go:158-233 for all query windows of the round.
     // Windows the device flags (they do not fit its layout) are done by the host path on fetched matches.
+    // textOut != nullptr and a text pool set: the PAF text is left to a formatter thread (*textOut; `paf` stays untouched)
     int FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 overlapSize, std::string& paf, FinalCheckStats& fs,
-                                  std::vector<int>* ignoreOut, RoundStats& st);
+                                  std::vector<int>* ignoreOut, RoundStats& st, std::shared_ptr<TextJob>* textOut = nullptr);
     void SetOverlapSize(i64 size) { overlap_ = size; }
     std::vector<SeedQuery> queries;
     std::string err;
@@ -359,6 +362,7 @@ class Overlapper {
     // multi-GPU: replaces the survivors of ScanLocal (this rank's read range) by the rank-ordered concatenation over all
     // ranks, exchanged device to device inside the library (dp_allgather_survivors)
     int ExchangeSurvivors(dp_comm* comm, Survivors& all);
+    void setTextPool(TextPool* tp) { textPool_ = tp; }
 
    private:
     void chunkAndAdd(SeedSeq* s, uint64_t segBase, Arena& ar, std::vector<SeedSeq*>& seqOut, std::vector<dp_seq_ref>& refOut);
@@ -375,6 +379,7 @@ class Overlapper {
     std::vector<Window> windows_;
     std::vector<int32_t> querySegs_;       // fwd/rc query segments (host)
     std::vector<uint64_t> queryOff_;
+    TextPool* textPool_ = nullptr;
     dp_survivor_batch lastScan_;           // what dp_scan_reads returned for this round (valid until the context scans again)
     std::vector<int32_t> winSegs_;         // scan output of the windows
     std::vector<uint64_t> winOff_;
@@ -434,11 +439,59 @@ class Planner {
     std::unique_ptr<Impl> d;
 };
 
+// The PAF text of a round, written after the executor slot has gone on to its next round: the slot hands the device's 40-byte
+// records over (copied out of the context's pinned buffer) and a formatter thread of the run turns them into lines
+// (commands/overlap.go:223-228); whoever needs the text (the commit, the result exchange of the round-parallel mode) waits.
+struct TextJob {
+    std::vector<dp_paf_rec> recs;
+    std::vector<dp_group_meta> groups;
+    std::vector<std::string> hostPaf;  // text of the windows the host consensus path did, indexed by hostOf[group]
+    std::vector<uint32_t> hostOf;
+    const ReadSet* reads = nullptr;
+    std::string text;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    void format();  // fills `text`
+    void finish() {
+        std::lock_guard<std::mutex> lk(mu);
+        done = true;
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+    }
+};
+// formatter threads of a run (two: a round's text is ~0.3 ms of one thread)
+class TextPool {
+  public:
+    explicit TextPool(int nThreads);
+    ~TextPool();
+    void submit(std::shared_ptr<TextJob> job);
+
+  private:
+    void loop();
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<TextJob>> q_;
+    std::vector<std::thread> th_;
+    bool stop_ = false;
+};
+
 struct RoundResult {
     i64 round = 0;
     bool empty = true;
     i64 firstIn = 0, firstOut = 0, numQuerySeqs = 0;
     std::string paf;
+    std::shared_ptr<TextJob> text;       // pending text of this round (appended to `paf` by takeText())
+    void takeText() {
+        if (!text) return;
+        text->wait();
+        if (paf.empty()) paf = std::move(text->text);
+        else paf += text->text;
+        text.reset();
+    }
     std::vector<int> ignores;            // SetIgnore calls of this round, in order
     std::vector<uint32_t> indexedReads;  // read ids that entered the index (for speculation checks)
     std::vector<uint32_t> queryReads;    // read ids of the query windows
@@ -488,6 +541,7 @@ struct OverlapRun {
         return valueLut.empty() ? ValueView(values.data()) : ValueView((const uint16_t*)valueCodes.data(), valueLut.data());
     }
     const double* fullValues();      // the 4^k doubles (expands the 2-byte form the first time it is asked for)
+    std::unique_ptr<TextPool> textPool;            // formatter threads (PAF text off the executor slots' critical path)
     std::vector<std::unique_ptr<ExecSlot>> slots;  // slot 0 drives `ctx`; further slots use contexts that borrow its reads
     std::unique_ptr<WindowCache> winCache;  // QueryEdges: the windows' round-independent part, produced ahead of the planner
     std::unique_ptr<Planner> planner;

@@ -379,7 +379,8 @@ void dph_overlap_drain(void* hh) { ((OverlapH*)hh)->run.drain(); }
 // ---- round-parallel mode: a rank executes ONE round speculatively and serialises the result; every rank then commits
 // the gathered results in round order with the speculation check (OverlapRun::commitResults).
 static void putv(std::string& b, const void* p, size_t n) { b.append((const char*)p, n); }
-static void serialise(const RoundResult& res, std::string& blob) {
+static void serialise(RoundResult& res, std::string& blob) {
+    res.takeText();  // (the PAF text may still be with a formatter thread)
     int64_t hdr[18] = {res.round, res.empty ? 1 : 0, res.firstIn, res.firstOut, res.numQuerySeqs, (int64_t)res.ignores.size(),
                        (int64_t)res.indexedReads.size(), (int64_t)res.paf.size(), res.fs.badBack, res.fs.emptyMatch,
                        (int64_t)res.fs.lines, (int64_t)res.fs.hits, (int64_t)res.fs.qHits, 0, res.snapshot,
@@ -409,7 +410,7 @@ const uint8_t* dph_overlap_exec_round(void* hh, int64_t first, uint64_t* n) {
         return nullptr;
     }
     blob.clear();
-    for (const RoundResult& r : outs) serialise(r, blob);
+    for (RoundResult& r : outs) serialise(r, blob);
     *n = blob.size();
     return (const uint8_t*)blob.data();
 }

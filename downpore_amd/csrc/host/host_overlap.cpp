@@ -526,7 +526,7 @@ static inline char* putInt(char* w, i64 v) {  // %d
 }
 
 int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 overlapSize, std::string& paf, FinalCheckStats& fs,
-                                          std::vector<int>* ignoreOut, RoundStats& st) {
+                                          std::vector<int>* ignoreOut, RoundStats& st, std::shared_ptr<TextJob>* textOut) {
     querySegs_.clear();
     queryOff_.assign(1, 0);
     for (const SeedQuery& q : queries) {
@@ -616,26 +616,13 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
         }
         g_prof.hostGroups += nFlag;
     }
-    // the text: one line per part after the first (commands/overlap.go:223-228), windows in query order
+    // everything but the text: hit counts, diagnostics, SetIgnore ids (query order)
     uint64_t hits = 0, qHits = 0;
-    size_t nLines = 0, hostBytes = 0;
-    for (uint32_t g = 0; g < pb.n_groups; g++) nLines += pb.groups[g].n_lines;
-    for (const std::string& hp : hostPaf) hostBytes += hp.size();
-    const size_t lineCap = 2 * reads_.maxNameLen + 7 * 21 + 24;  // two names + 7 numbers + fixed text
-    // the text is written into a buffer this thread keeps (sized for the worst case: no per-round allocation, zero fill or
-    // page faults of a megabyte), then appended at its real size
-    static thread_local std::vector<char> textBuf;
-    if (textBuf.size() < nLines * lineCap + hostBytes + 64) textBuf.resize((nLines * lineCap + hostBytes + 64) * 3 / 2);
-    char* const w0 = textBuf.data();
-    char* w = w0;
     for (uint32_t g = 0; g < pb.n_groups; g++) {
         const dp_group_meta& gm = pb.groups[g];
         hits += gm.n_matches;
         if (gm.n_matches >= 2) qHits++;
         if (gm.flag) {
-            const std::string& hp = hostPaf[hostOf[g]];
-            memcpy(w, hp.data(), hp.size());
-            w += hp.size();
             for (int id : hostIgn[hostOf[g]]) {
                 if (ignoreOut) ignoreOut->push_back(id);
                 else reads_.ignore[(size_t)id] = 1;
@@ -644,16 +631,65 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
         }
         fs.badBack += gm.bad_back;
         fs.emptyMatch += gm.empty_match;
+        fs.lines += gm.n_lines;
         for (uint32_t j = 0; j < gm.n_ignore; j++) {
             const int id = (int)pb.ignore_ids[gm.slot + j];
             if (ignoreOut) ignoreOut->push_back(id);
             else reads_.ignore[(size_t)id] = 1;
         }
+    }
+    // the text: one line per part after the first (commands/overlap.go:223-228), windows in query order - here, or on a
+    // formatter thread while this slot starts its next round (the records are copied out of the context's pinned buffer)
+    {
+        size_t nRecs = 0;
+        for (uint32_t g = 0; g < pb.n_groups; g++)
+            if (!pb.groups[g].flag) nRecs = std::max<size_t>(nRecs, (size_t)pb.groups[g].slot + pb.groups[g].n_lines);
+        std::shared_ptr<TextJob> job = std::make_shared<TextJob>();
+        job->reads = &reads_;
+        job->recs.assign(pb.paf, pb.paf + nRecs);
+        job->groups.assign(pb.groups, pb.groups + pb.n_groups);
+        job->hostPaf = std::move(hostPaf);
+        job->hostOf = std::move(hostOf);
+        if (textOut && textPool_) {
+            *textOut = job;
+            textPool_->submit(job);
+        } else {
+            job->format();
+            paf += job->text;
+        }
+    }
+    fs.hits = hits;
+    fs.qHits = qHits;
+    st.n_matches = hits;
+    g_prof.add(12, now() - tq2);
+    return 0;
+}
+
+void TextJob::format() {
+    size_t nLines = 0, hostBytes = 0;
+    for (const dp_group_meta& gm : groups) nLines += gm.n_lines;
+    for (const std::string& hp : hostPaf) hostBytes += hp.size();
+    const ReadSet& rs = *reads;
+    const size_t lineCap = 2 * rs.maxNameLen + 7 * 21 + 24;  // two names + 7 numbers + fixed text
+    // written into a buffer this thread keeps (sized for the worst case: no per-round allocation, zero fill or page faults of
+    // a megabyte), then copied out at its real size
+    static thread_local std::vector<char> textBuf;
+    if (textBuf.size() < nLines * lineCap + hostBytes + 64) textBuf.resize((nLines * lineCap + hostBytes + 64) * 3 / 2);
+    char* const w0 = textBuf.data();
+    char* w = w0;
+    for (size_t g = 0; g < groups.size(); g++) {
+        const dp_group_meta& gm = groups[g];
+        if (gm.flag) {
+            const std::string& hp = hostPaf[hostOf[g]];
+            memcpy(w, hp.data(), hp.size());
+            w += hp.size();
+            continue;
+        }
         for (uint32_t j = 0; j < gm.n_lines; j++) {
-            const dp_paf_rec& r = pb.paf[gm.slot + j];
-            if (j + 4 < gm.n_lines) __builtin_prefetch(&reads_.names[pb.paf[gm.slot + j + 4].t_read], 0, 1);  // names are hit at random
-            const std::string& qName = reads_.names[r.q_read];
-            const std::string& tName = reads_.names[r.t_read];
+            const dp_paf_rec& r = recs[gm.slot + j];
+            if (j + 4 < gm.n_lines) __builtin_prefetch(&rs.names[recs[gm.slot + j + 4].t_read], 0, 1);  // names are hit at random
+            const std::string& qName = rs.names[r.q_read];
+            const std::string& tName = rs.names[r.t_read];
             memcpy(w, qName.data(), qName.size());
             w += qName.size();
             *w++ = '\t';
@@ -677,15 +713,42 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
             w = putInt(w, r.ident);
             memcpy(w, "\t0\t255\n", 7);
             w += 7;
-            fs.lines++;
         }
     }
-    paf.append(w0, (size_t)(w - w0));
-    fs.hits = hits;
-    fs.qHits = qHits;
-    st.n_matches = hits;
-    g_prof.add(12, now() - tq2);
-    return 0;
+    text.assign(w0, (size_t)(w - w0));
+}
+
+TextPool::TextPool(int nThreads) {
+    for (int i = 0; i < std::max(1, nThreads); i++) th_.emplace_back([this] { loop(); });
+}
+TextPool::~TextPool() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+}
+void TextPool::submit(std::shared_ptr<TextJob> job) {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        q_.push_back(std::move(job));
+    }
+    cv_.notify_one();
+}
+void TextPool::loop() {
+    for (;;) {
+        std::shared_ptr<TextJob> job;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+            if (q_.empty()) return;  // (stop requested and nothing left)
+            job = std::move(q_.front());
+            q_.pop_front();
+        }
+        job->format();
+        job->finish();
+    }
 }
 
 // finalCheckWorker commands/overlap.go:197-233 (+ collation :158-173).  Queries are independent (the reference runs

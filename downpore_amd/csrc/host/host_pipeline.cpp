@@ -422,6 +422,7 @@ void OverlapRun::shutdown() {
     workers_.clear();
     ready_.clear();
     redo_.clear();
+    textPool.reset();  // (finishes the jobs still queued; their results are dropped with their rounds)
     if (planner) g_prof.print();
     planner.reset();
     winCache.reset();
@@ -549,6 +550,11 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     }
     mark("values upload");
     slots.clear();
+    {
+        const char* dt = getenv("DP_DEFER_TEXT");  // 0: the executor slots format their rounds' text themselves
+        textPool.reset();
+        if (!(dt && dt[0] == '0')) textPool.reset(new TextPool(2));
+    }
     setHostThreadShare((unsigned)std::max(1, nSlots));
     // every executor slot's thread waits for its stream five to seven times per round: busy waits when this process has the
     // cores for it (the worker pool's size is the CPU budget: cgroup quota, or DP_HOST_THREADS for ranks sharing a host)
@@ -635,6 +641,7 @@ int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
     g_prof.add(0, tb1 - tb0);
     sl.lap.reset(new Overlapper(sl.ctx, *reads, *sl.index, p.chunkSize, p.numWorkers, p.overlapSize, p.numSeeds, p.minHits));
     sl.lap->setWindows(plan.windows);
+    sl.lap->setTextPool(textPool.get());
     sl.lap->setIgnoreView(reads->ignore.data(), planner->ignoreEpoch());
     const double tb2 = now();
     g_prof.add(1, tb2 - tb1);
@@ -669,7 +676,7 @@ int OverlapRun::finishRound(ExecSlot& sl, const Survivors& all, RoundResult& out
     }();
     double t2;
     if (deviceConsensus && (sl.lap->queries.size() % 2) == 0) {
-        rc = sl.lap->FindOverlapsAndFinalCheck(sl.matchPool, p.overlapSize, out.paf, out.fs, &out.ignores, st);
+        rc = sl.lap->FindOverlapsAndFinalCheck(sl.matchPool, p.overlapSize, out.paf, out.fs, &out.ignores, st, &out.text);
         if (rc != 0) {
             sl.error = sl.lap->err;
             return rc;
@@ -783,6 +790,7 @@ int OverlapRun::executeRounds(const std::vector<i64>& rounds, std::vector<RoundR
 
 void OverlapRun::commitOne(RoundResult& r) {
     char line[200];
+    r.takeText();  // (the round's PAF text may still be with a formatter thread)
     firstSequence = r.firstOut;
     numQuerySeqs = r.numQuerySeqs;
     if (round == 0)
