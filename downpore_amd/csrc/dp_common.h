@@ -81,6 +81,10 @@ struct dp_ctx {
     uint64_t items_epoch = ~0ull;
     uint32_t items_lo = 0, items_hi = 0, items_min = 0;
     int items_top = -1, items_k = 0;
+    // pageable staging of borrowed host inputs whose copies are still queued when a call returns (dp_stage); emptied by every
+    // dp_stream_sync
+    std::vector<uint8_t> stage_buf;
+    size_t stage_used = 0;
     bool timing_on = true;
     uint64_t round_serial = 0;
 
@@ -115,6 +119,11 @@ int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess);
 hipError_t dp_stream_sync(dp_ctx* ctx);
 int dev_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
 int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
+// A caller's borrowed buffer copied into memory of the context that stays untouched until the context's next dp_stream_sync,
+// so that the H2D copy out of it can still be queued when the call returns.  PAGEABLE on purpose: the runtime stages small
+// pageable sources itself and copies them with a blit kernel on the stream's own queue, which measured faster under eight
+// concurrent slots than a pinned source (SDMA engines); should it pin the pages and copy later instead, they are still ours.
+const void* dp_stage(dp_ctx* ctx, const void* src, size_t bytes);
 // hipMalloc / hipFree for the library's large device blocks (k-mer index and its build buffers, value tables: hundreds of MB
 // to tens of GB).  Blocks of 32 MiB and more that are freed stay in a process-wide cache and satisfy later requests of about
 // their size: releasing and re-acquiring gigabytes from the driver costs 0.3-0.6 s every now and then (measured: a 400 MB

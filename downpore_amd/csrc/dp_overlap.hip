@@ -91,7 +91,9 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
         if (int rc = dp_zero_regions(ctx, z, 2)) return rc;
     }
     if (n_seqs) {
-        DP_HIP(hipMemcpyAsync(ctx->d_seqrefs.p, seqs, (size_t)n_seqs * sizeof(dp_seq_ref), hipMemcpyHostToDevice, ctx->stream));
+        // (seqs is borrowed only for the duration of the call: the copy leaves from the context's staging block, nothing waits)
+        DP_HIP(hipMemcpyAsync(ctx->d_seqrefs.p, dp_stage(ctx, seqs, (size_t)n_seqs * sizeof(dp_seq_ref)), (size_t)n_seqs * sizeof(dp_seq_ref),
+                              hipMemcpyHostToDevice, ctx->stream));
         uint32_t blocks = std::min<uint32_t>(2048, (n_seqs + 3) / 4);
         hipLaunchKernelGGL(index_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const dp_seq_ref*)ctx->d_seqrefs.p, n_seqs,
                            (const int32_t*)ctx->d_segs.p, (u64*)ctx->d_posting.p, (u64*)ctx->d_seedsets.p, W, SW);
@@ -103,8 +105,7 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
                            (uint32_t*)ctx->d_pmeta.p);
         DP_HIP(hipGetLastError());
     }
-    DP_HIP(dp_stream_sync(ctx));  // seqs is borrowed only for the duration of the call
-    return DP_OK;
+    return DP_OK;  // (errors of the queued work surface at the next call that waits)
 }
 
 extern "C" int dp_index_build(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {

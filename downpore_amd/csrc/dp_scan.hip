@@ -71,7 +71,22 @@ static ScanGate g_scan_mu;
 static std::atomic<int> g_wait_spin{0};
 extern "C" void dp_set_stream_wait(int spin) { g_wait_spin.store(spin ? 1 : 0); }
 
+const void* dp_stage(dp_ctx* ctx, const void* src, size_t bytes) {
+    const size_t at = (ctx->stage_used + 63) & ~(size_t)63;
+    if (at + bytes > ctx->stage_buf.size()) {
+        if (ctx->stage_used) hipStreamSynchronize(ctx->stream);  // (copies out of the old block must be done before it moves)
+        ctx->stage_used = 0;
+        if (bytes > ctx->stage_buf.size()) ctx->stage_buf.resize(std::max<size_t>(bytes * 2, (size_t)4 << 20));
+        return dp_stage(ctx, src, bytes);
+    }
+    uint8_t* dst = ctx->stage_buf.data() + at;
+    memcpy(dst, src, bytes);
+    ctx->stage_used = at + bytes;
+    return dst;
+}
+
 hipError_t dp_stream_sync(dp_ctx* ctx) {
+    ctx->stage_used = 0;  // (everything queued so far, copies out of the staging block included, is done when this returns)
     static const int env_spin = [] {
         const char* e = getenv("DP_SPIN_SYNC");
         return e ? (e[0] == '1' ? 1 : 0) : -1;
@@ -826,11 +841,11 @@ extern "C" int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, ui
     if (dev_reserve(ctx, ctx->d_seeds, (size_t)n_seeds * 4 + 4)) return DP_ERR_HIP;
     // (pageable source: the runtime stages it and the copy runs as a blit kernel on this stream's own queue - measured faster
     // with eight slots in flight than a pinned source, which goes through the shared SDMA engines)
-    if (n_seeds) DP_HIP(hipMemcpyAsync(ctx->d_seeds.p, seed_kmers, (size_t)n_seeds * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n_seeds)  // seed_kmers is borrowed only for the duration of the call: the copy leaves from the context's staging block
+        DP_HIP(hipMemcpyAsync(ctx->d_seeds.p, dp_stage(ctx, seed_kmers, (size_t)n_seeds * 4), (size_t)n_seeds * 4, hipMemcpyHostToDevice, ctx->stream));
     // the membership bits and the k-mer -> seed-id map are only read by the scan kernels: they are brought up to date by
     // seed_tables_ensure() when a scan actually runs (a round served by the k-mer position index never needs them)
     ctx->tables_dirty = true;
-    DP_HIP(dp_stream_sync(ctx));  // seed_kmers is borrowed only for the duration of the call
     {
         // DP_KERNEL_TIMING=N: the round's kernels are bracketed by timing events in every N-th round of this context (every
         // event is a packet of its own for the command processor; 0 = never).  Untimed rounds report 0 ms.
