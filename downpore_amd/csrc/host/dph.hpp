@@ -154,6 +154,11 @@ struct SeedIndex {
     std::vector<int32_t> hvals;
     uint32_t hmask = 0;
     std::vector<uint32_t> seedMap;                  // seed id -> k-mer
+    // adopt(): an executor slot takes a finished plan's seed list and reverse-complement table as they are - it never asks
+    // "is this k-mer a seed" - and the hash is only rebuilt should somebody ask after all (hashValid)
+    bool hashValid = true;
+    void adopt(const std::vector<uint32_t>& seeds, const std::vector<int32_t>& rcTable);
+    void rebuildHash();
     std::vector<SeedSeq*> sequences;                // indexed sequences (chunks), index == GPU sequence index
     std::vector<dp_seq_ref> refs;                   // their views into the device-resident scan output
     Arena arena;
@@ -162,6 +167,7 @@ struct SeedIndex {
     int size() const { return (int)seedMap.size(); }
     static uint32_t hash(uint32_t x) { return (x * 2654435761u) >> 7; }
     int32_t find(uint32_t kmer) const {             // seed id or -1
+        if (__builtin_expect(!hashValid, 0)) const_cast<SeedIndex*>(this)->rebuildHash();
         uint32_t h = hash(kmer) & hmask;
         for (;;) {
             const uint32_t kk = hkeys[h];
@@ -178,6 +184,7 @@ struct SeedIndex {
     std::vector<uint32_t> pre;
     uint32_t preHash(uint32_t x) const { return (x * 2246822519u) >> preShift; }
     bool isSeed(uint32_t kmer) const {
+        if (__builtin_expect(!hashValid, 0)) const_cast<SeedIndex*>(this)->rebuildHash();
         const uint32_t b = preHash(kmer);
         if (!((pre[b >> 5] >> (b & 31)) & 1)) return false;
         return find(kmer) >= 0;
@@ -411,6 +418,7 @@ struct RoundPlan {
     bool empty = true;              // len(queries) == 0 -> the command ends (:130)
     std::vector<Overlapper::Window> windows;
     std::vector<uint32_t> seedMap;  // seed id -> k-mer
+    std::vector<int32_t> rcOf;      // seed id -> seed id of its reverse complement (SeedIndex::buildRcTable)
     bool failed = false;            // a device call of the planner failed; `error` holds the text
     std::string error;
 };

@@ -220,6 +220,8 @@ std::shared_ptr<RoundPlan> Planner::compute(i64 round, i64 firstIn) {
     plan->empty = nw <= 0;
     plan->windows = lap.windows();
     plan->seedMap = d->index.seedMap;
+    d->index.buildRcTable();  // (the executor slot takes both as they are: SeedIndex::adopt)
+    plan->rcOf = d->index.rcOf;
     // firstSequence = max query SequenceID + 1 (commands/overlap.go:135-142); windows are in ascending read order
     plan->firstOut = nw ? (i64)plan->windows.back().read + 1 : firstIn;
     return plan;
@@ -634,9 +636,14 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
 // seeds.NewSeedIndex + the plan's seeds on host and device; queries are built after the scan
 int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
     const double tb0 = now();
-    sl.index->reset();  // seeds.NewSeedIndex(k) per round (:125) — sparse reset instead of reallocating 4^k tables
-    for (uint32_t km : plan.seedMap) sl.index->addSeedKmer(km);
-    sl.index->buildRcTable();
+    // seeds.NewSeedIndex(k) per round (:125): the plan's seed list and reverse-complement table, as the planner left them
+    if (plan.rcOf.size() == plan.seedMap.size()) {
+        sl.index->adopt(plan.seedMap, plan.rcOf);
+    } else {
+        sl.index->reset();
+        for (uint32_t km : plan.seedMap) sl.index->addSeedKmer(km);
+        sl.index->buildRcTable();
+    }
     const double tb1 = now();
     g_prof.add(0, tb1 - tb0);
     sl.lap.reset(new Overlapper(sl.ctx, *reads, *sl.index, p.chunkSize, p.numWorkers, p.overlapSize, p.numSeeds, p.minHits));

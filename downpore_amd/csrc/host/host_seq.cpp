@@ -249,6 +249,7 @@ SeedIndex::SeedIndex(int k_, int preBits) : k(k_), preShift((uint32_t)(32 - preB
 }
 
 void SeedIndex::reset() {
+    hashValid = true;
     std::fill(hkeys.begin(), hkeys.end(), 0xffffffffu);
     std::fill(pre.begin(), pre.end(), 0);
     seedMap.clear();
@@ -257,6 +258,28 @@ void SeedIndex::reset() {
     refs.clear();
     arena.clear();
     for (Arena& a : chunkArenas) a.clear();
+}
+
+void SeedIndex::adopt(const std::vector<uint32_t>& seeds, const std::vector<int32_t>& rcTable) {
+    seedMap = seeds;
+    rcOf = rcTable;
+    hashValid = false;
+    sequences.clear();
+    refs.clear();
+    arena.clear();
+    for (Arena& a : chunkArenas) a.clear();
+}
+
+void SeedIndex::rebuildHash() {
+    std::vector<uint32_t> seeds;
+    seeds.swap(seedMap);
+    std::vector<int32_t> rc;
+    rc.swap(rcOf);
+    std::fill(hkeys.begin(), hkeys.end(), 0xffffffffu);
+    std::fill(pre.begin(), pre.end(), 0);
+    hashValid = true;
+    for (uint32_t km : seeds) addSeedKmer(km);
+    rcOf.swap(rc);
 }
 
 void SeedIndex::grow() {
@@ -273,6 +296,7 @@ void SeedIndex::grow() {
 }
 
 void SeedIndex::addSeedKmer(uint32_t kmer) {
+    if (!hashValid) rebuildHash();
     if (!rcOf.empty()) rcOf.clear();
     if (!isSeed(kmer)) {
         if ((seedMap.size() + 1) * 2 > hkeys.size()) grow();
