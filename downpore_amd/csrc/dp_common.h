@@ -90,6 +90,12 @@ struct dp_ctx {
 
     // ---- index (A13)
     uint32_t n_seqs = 0, W = 0, SW = 0;
+    // dp_index_build_chunked: the chunks were made on the device - n_seqs is then an upper bound (buffer and row sizes), the
+    // exact number lives at d_nseqs[0], the chunks' {read, length, offset, inset} in d_chunk_meta
+    DevBuf d_chunk_meta, d_nseqs;
+    bool chunks_on_device = false;
+    int scan_fetch_extras_only = 0;  // dp_scan_fetch_mode
+    uint32_t last_surv_all = 0;      // survivors + extra items of the last dp_scan_reads (layout of h_surv)
     uint32_t map_stage_windows = 0;
     bool map_stage_valid = false;  // dp_map_windows_shard: the query stage of the forward pass is reused by the reverse pass
     uint32_t word_base = 0, global_n_seqs = 0;  // dp_index_set_global: this index is the words [word_base, word_base + W) of a larger one

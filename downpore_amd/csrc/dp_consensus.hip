@@ -389,6 +389,7 @@ struct ConsFullArgs {
     uint32_t* ignore_ids;      // [pairs]: likewise
     dp_group_meta* gmeta;      // [n_groups]
     unsigned long long* dbg;   // DP_CONS_DEBUG: per group 8 time stamps (wall_clock64, 100 MHz)
+    uint32_t flag_every;       // DP_CONS_FLAG_EVERY=n (test hook): every n-th window is left to the host path
 };
 
 __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A) {
@@ -427,6 +428,7 @@ __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A
         const int nA = RFLc((int)(A.qoff[qf + 1] - A.qoff[qf]));
         const int sA = nA >> 1;
         if (sA > CF_A || sA < 1) tooMany = true;
+        if (A.flag_every && (g % A.flag_every) == 0) tooMany = true;
         if (tooMany) {
             gm.flag = 1;
             if (lane == 0) A.gmeta[g] = gm;
@@ -1049,7 +1051,9 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     hipSetDevice(ctx->device);
     const uint32_t nq = ctx->last_nq, ng = nq / 2, np = ctx->n_pairs;
     out->n_groups = ng;
-    if (n_seqs != ctx->n_seqs || n_seeds != ctx->n_seeds) return dp_fail(ctx, DP_ERR_ARG, "dp_consensus_paf: metas / rc_of do not match the round's index");
+    if ((metas && n_seqs != ctx->n_seqs) || n_seeds != ctx->n_seeds) return dp_fail(ctx, DP_ERR_ARG, "dp_consensus_paf: metas / rc_of do not match the round's index");
+    if (!metas && !ctx->chunks_on_device) return dp_fail(ctx, DP_ERR_ARG, "dp_consensus_paf: metas == NULL needs an index made by dp_index_build_chunked");
+    if (!metas) n_seqs = 0;  // (the chunks' fields are on the device already: only rc_of travels)
     if (nq & 1) return dp_fail(ctx, DP_ERR_ARG, "dp_consensus_paf: queries must come in (forward, reverse complement) pairs");
     if (ng == 0 || !ctx->find_valid) {
         if (!ctx->find_valid && ng) return dp_fail(ctx, DP_ERR_STATE, "dp_consensus_paf before dp_find_overlaps");
@@ -1058,7 +1062,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     const size_t b_meta = (size_t)n_seqs * sizeof(dp_seq_meta), b_rc = (size_t)n_seeds * 4;
     if (pin_reserve(ctx, ctx->h_cin, b_meta + b_rc + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_cin, b_meta + b_rc + 64)) return DP_ERR_HIP;
-    memcpy(ctx->h_cin.p, metas, b_meta);
+    if (metas) memcpy(ctx->h_cin.p, metas, b_meta);
     memcpy((uint8_t*)ctx->h_cin.p + b_meta, rc_of, b_rc);
     DP_HIP(hipMemcpyAsync(ctx->d_cin.p, ctx->h_cin.p, b_meta + b_rc, hipMemcpyHostToDevice, ctx->stream));
     const size_t b_paf = (size_t)np * sizeof(dp_paf_rec), b_ign = (size_t)np * 4, b_gm = (size_t)ng * sizeof(dp_group_meta);
@@ -1075,7 +1079,11 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     A.n_groups = ng;
     A.refs = (const dp_seq_ref*)ctx->d_seqrefs.p;
     A.segs = (const int32_t*)ctx->d_segs.p;
-    A.smeta = (const dp_seq_meta*)ctx->d_cin.p;
+    A.smeta = metas ? (const dp_seq_meta*)ctx->d_cin.p : (const dp_seq_meta*)ctx->d_chunk_meta.p;
+    {
+        static const uint32_t flag_every = getenv("DP_CONS_FLAG_EVERY") ? (uint32_t)atoi(getenv("DP_CONS_FLAG_EVERY")) : 0u;
+        A.flag_every = flag_every;
+    }
     A.rc_of = (const int32_t*)((const uint8_t*)ctx->d_cin.p + b_meta);
     {
         int rc = dp_match_anchors_launch(ctx);
@@ -1099,7 +1107,13 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 1));
     DP_HIP(hipMemcpyAsync(ctx->h_cout.p, dout, b_paf + b_ign + b_gm, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t* h_nseq = (uint32_t*)((uint8_t*)ctx->h_cout.p + ((b_paf + b_ign + b_gm + 15) & ~(size_t)15));
+    h_nseq[0] = ctx->n_seqs;
+    h_nseq[1] = 0;
+    if (ctx->chunks_on_device) DP_HIP(hipMemcpyAsync(h_nseq, ctx->d_nseqs.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
+    if (h_nseq[1]) return dp_fail(ctx, DP_ERR_CAPACITY, "dp_index_build_chunked: chunk bound exceeded");
+    out->n_indexed = h_nseq[0];
     float ms = 0;
     ms = dp_elapsed(ctx, 0, 1);
     out->kernel_ms = ms;

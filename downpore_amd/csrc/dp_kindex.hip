@@ -299,7 +299,7 @@ __global__ __launch_bounds__(KX_TILE) void kidx_offsets(const dp_scan_item* __re
                                                        uint64_t* __restrict__ segoff, uint32_t* __restrict__ s_item,
                                                        uint32_t* __restrict__ s_count, uint64_t* __restrict__ s_off,
                                                        uint4* __restrict__ s_pack, uint64_t* __restrict__ totals,
-                                                       uint32_t* __restrict__ max_count,
+                                                       uint32_t n_read_items, uint32_t* __restrict__ max_count,
                                                        const unsigned long long* __restrict__ n_hits) {
     __shared__ uint32_t shA[16], shB[16];
     __shared__ uint32_t tile_s;
@@ -388,6 +388,7 @@ __global__ __launch_bounds__(KX_TILE) void kidx_offsets(const dp_scan_item* __re
         const uint32_t i = i0 + u;
         if (i < n) {
             segoff[i] = so;
+            if (i == n_read_items) totals[5] = so;  // where the extra items' (query windows') segments start
             if (flv[u]) {
                 s_item[slot] = i;
                 s_count[slot] = cc[u];
@@ -529,7 +530,8 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                            (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits);
     // totals[2] = seed occurrences in the read set, totals[3] = largest survivor count (both written by the kernel)
     hipLaunchKernelGGL(kidx_offsets, dim3(n_tiles), dim3(KX_TILE), 0, ctx->stream, d_items, (const uint32_t*)d_counts, n_items, status, ticket,
-                       d_segoff, s_item, s_count, s_off, s_pack, d_totals, (uint32_t*)(d_totals + 3), (const unsigned long long*)n_hits);
+                       d_segoff, s_item, s_count, s_off, s_pack, d_totals, n_read_items, (uint32_t*)(d_totals + 3),
+                       (const unsigned long long*)n_hits);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 1));
     (void)k;

@@ -21,7 +21,9 @@ typedef uint64_t u64;
 // A13
 
 __global__ void index_fill_kernel(const dp_seq_ref* __restrict__ refs, uint32_t n_seqs, const int32_t* __restrict__ segs,
-                                  u64* __restrict__ posting, u64* __restrict__ seedsets, uint32_t W, uint32_t SW) {
+                                  u64* __restrict__ posting, u64* __restrict__ seedsets, uint32_t W, uint32_t SW,
+                                  const uint32_t* __restrict__ n_seqs_dev) {
+    if (n_seqs_dev) n_seqs = *n_seqs_dev;  // (chunks made on the device: the launch was sized for an upper bound)
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = dp_lane();
@@ -82,6 +84,7 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
     ctx->SW = SW;
     ctx->word_base = 0;  // (a fresh index is a whole one until dp_index_set_global says otherwise)
     ctx->global_n_seqs = 0;
+    ctx->chunks_on_device = false;
     if (dev_reserve(ctx, ctx->d_seqrefs, (size_t)n_seqs * sizeof(dp_seq_ref) + 16)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_posting, (size_t)S * W * 8 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_seedsets, (size_t)n_seqs * SW * 8 + 64)) return DP_ERR_HIP;
@@ -96,7 +99,7 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
                               hipMemcpyHostToDevice, ctx->stream));
         uint32_t blocks = std::min<uint32_t>(2048, (n_seqs + 3) / 4);
         hipLaunchKernelGGL(index_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const dp_seq_ref*)ctx->d_seqrefs.p, n_seqs,
-                           (const int32_t*)ctx->d_segs.p, (u64*)ctx->d_posting.p, (u64*)ctx->d_seedsets.p, W, SW);
+                           (const int32_t*)ctx->d_segs.p, (u64*)ctx->d_posting.p, (u64*)ctx->d_seedsets.p, W, SW, (const uint32_t*)nullptr);
         DP_HIP(hipGetLastError());
     }
     if (S) {
@@ -111,6 +114,241 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
 extern "C" int dp_index_build(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
     if (!ctx || (n_seqs && !seqs)) return DP_ERR_ARG;
     return dp_index_build_impl(ctx, seqs, n_seqs);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A12 on the device: overlap.chunkWorker (overlap/overlap.go:253-318) for every surviving read of the last dp_scan_reads,
+// then AddSequence + IndexSequences.  One workgroup walks the survivors in file order, 1024 at a time: every thread runs the
+// reference's state machine over its read's segments twice (count the chunks, then write them at the position a block
+// scan gives), so chunks come out in the reference's order without any host step.
+struct ChunkParams {
+    const uint32_t* s_item;
+    const uint32_t* s_count;
+    const u64* s_off;
+    uint32_t ns, lo;
+    const uint32_t* read_len;
+    const int32_t* segs;
+    int k;
+    long long chunkSize, overlap;
+    int minSeeds, inset;
+    dp_seq_ref* refs;
+    dp_seq_meta* metas;
+    uint32_t cap;
+    uint32_t* n_out;  // [0] chunks, [1] overflow
+};
+
+template <bool WRITE>
+__device__ uint32_t chunk_one(const ChunkParams& P, uint32_t i, uint32_t at) {
+    const uint32_t read = P.s_item[i] + P.lo;
+    const int numSeeds = (int)P.s_count[i];
+    const u64 segBase = P.s_off[i];
+    const int32_t* seg = P.segs + segBase;
+    const int n = 2 * numSeeds + 1, k = P.k;
+    const long long length = (long long)P.read_len[read];
+    uint32_t made = 0;
+    auto emit = [&](int first, int last, long long len, long long off, long long ins) {
+        if (WRITE) {
+            const uint32_t o = at + made;
+            if (o < P.cap) {
+                dp_seq_ref r;
+                r.seg_off = segBase + 2ull * (uint32_t)first;
+                r.n_seeds = (uint32_t)(last - first + 1);
+                r.reserved = 0;
+                P.refs[o] = r;
+                dp_seq_meta m;
+                m.read = read;
+                m.length = (int32_t)len;
+                m.offset = (int32_t)off;
+                m.inset = (int32_t)ins;
+                P.metas[o] = m;
+            }
+        }
+        made++;
+    };
+    auto whole = [&]() { emit(0, numSeeds - 1, length, 0, (long long)P.inset); };
+    auto nextSeedOffset = [&](int idx) -> long long { return (long long)seg[idx * 2 + 2] + k; };
+    const long long numChunks = length / P.chunkSize + 1;
+    if (numChunks == 1 || numSeeds < P.minSeeds * 3) {
+        if (numSeeds >= P.minSeeds) whole();
+        return made;
+    }
+    int prevSeedIndex = 0;
+    long long totalOffset = seg[0];  // seedOffset(0, k)
+    long long lengthInBases = 0;
+    for (;;) {
+        int seedCount = 0;
+        if (prevSeedIndex >= numSeeds - 150) {
+            if (prevSeedIndex == 0) {
+                whole();
+            } else {
+                const long long newFirstGap = nextSeedOffset(prevSeedIndex - 1) - k;
+                long long fromEnd = seg[n - 1];  // seedOffsetFromEnd(prevSeedIndex, k)
+                for (int x = n - 3; x > prevSeedIndex * 2 + 1; x -= 2) fromEnd += seg[x] + k;
+                lengthInBases += fromEnd + k + newFirstGap;
+                emit(prevSeedIndex, numSeeds - 1, lengthInBases, totalOffset - newFirstGap, 0);
+            }
+            break;
+        }
+        for (; lengthInBases < P.chunkSize && seedCount < 100 && prevSeedIndex + seedCount < numSeeds; seedCount++)
+            lengthInBases += nextSeedOffset(prevSeedIndex + seedCount);
+        if (seedCount >= P.minSeeds) {
+            const long long newFirstGap = nextSeedOffset(prevSeedIndex - 1) - k;
+            lengthInBases += newFirstGap;
+            emit(prevSeedIndex, prevSeedIndex + seedCount - 1, lengthInBases, totalOffset - newFirstGap,
+                 length - totalOffset - lengthInBases + newFirstGap);
+            totalOffset += lengthInBases - newFirstGap;
+            lengthInBases = 0;
+            prevSeedIndex += seedCount;
+            if (prevSeedIndex >= numSeeds) break;
+            for (seedCount = 0; seedCount < 5 && lengthInBases < P.overlap / 2 && prevSeedIndex > 0; seedCount++) {
+                prevSeedIndex--;
+                const long long step = nextSeedOffset(prevSeedIndex);
+                lengthInBases += step;
+                totalOffset -= step;
+            }
+            lengthInBases = 0;
+        } else {
+            prevSeedIndex += seedCount;
+            for (seedCount = 0; lengthInBases < P.overlap / 2 && prevSeedIndex > 0; seedCount++) {
+                prevSeedIndex--;
+                const long long step = nextSeedOffset(prevSeedIndex);
+                lengthInBases += step;
+                totalOffset -= step;
+            }
+            lengthInBases = 0;
+        }
+    }
+    return made;
+}
+
+__global__ __launch_bounds__(1024) void chunk_kernel(const ChunkParams P) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t running_s;
+    if (threadIdx.x == 0) running_s = 0;
+    __syncthreads();
+    const int lane = dp_lane(), wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < P.ns; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t cnt = i < P.ns ? chunk_one<false>(P, i, 0) : 0u;
+        uint32_t x = (uint32_t)wave_incl_sum((int)cnt);
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t before = running_s;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        uint32_t total = 0;
+        for (int w = 0; w < 16; w++) total += wsum[w];
+        if (cnt) chunk_one<true>(P, i, before + x - cnt);
+        __syncthreads();
+        if (threadIdx.x == 0) running_s += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        P.n_out[0] = min(running_s, P.cap);
+        P.n_out[1] = running_s > P.cap ? 1u : 0u;
+    }
+}
+
+// upper bound of the chunks chunkWorker makes of a read with `numSeeds` hits: every chunk but the last holds >= minSeeds seeds
+// and the walk backs up at most 5 seeds (or overlap/2 bases) after each
+static uint32_t chunk_cap_of(uint32_t numSeeds, long long length, long long chunkSize, int minSeeds) {
+    if (length / chunkSize + 1 == 1 || (int)numSeeds < minSeeds * 3 || numSeeds <= 150) return 1;  // (<= 150 seeds: the walk ends at once)
+    const int step = std::max(1, minSeeds - 5);
+    return (numSeeds - 150) / (uint32_t)step + 3;
+}
+
+extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t overlap, uint32_t min_seeds, int32_t inset,
+                                      uint32_t n_survivors, uint32_t* n_seqs_cap) {
+    if (!ctx || chunk_size < 1 || !n_seqs_cap) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_index_build_chunked: bad arguments") : DP_ERR_ARG;
+    if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_index_build_chunked before dp_round_begin");
+    if (!ctx->h_surv.p || !ctx->d_surv.p) return dp_fail(ctx, DP_ERR_STATE, "dp_index_build_chunked: no dp_scan_reads result on this context");
+    hipSetDevice(ctx->device);
+    const uint32_t n_items = ctx->scan_items;
+    if (n_survivors > n_items) return dp_fail(ctx, DP_ERR_ARG, "dp_index_build_chunked: more survivors than scan items");
+    // the library still has the survivors' hit counts and read ids on the host (pinned output of the scan)
+    const uint32_t* s_item = (const uint32_t*)ctx->d_surv.p;
+    const uint32_t* s_count = s_item + n_items;
+    const u64* s_off = (const u64*)(s_count + n_items + (n_items & 1));
+    uint64_t cap64 = 0;
+    {
+        const uint32_t* h_item = (const uint32_t*)ctx->h_surv.p;  // (already turned into read ids by dp_scan_reads)
+        const uint32_t* h_count = h_item + ctx->last_surv_all;
+        const std::vector<uint32_t>& lens = ctx->owner ? ctx->owner->h_len : ctx->h_len;
+        for (uint32_t i = 0; i < n_survivors; i++) cap64 += chunk_cap_of(h_count[i], (long long)lens[h_item[i]], chunk_size, (int)min_seeds);
+    }
+    if (cap64 > 0xfffffff0ull) return dp_fail(ctx, DP_ERR_CAPACITY, "dp_index_build_chunked: more than 2^32 chunks");
+    const uint32_t cap = (uint32_t)cap64;
+    const uint32_t S = ctx->n_seeds;
+    const uint32_t W = std::max<uint32_t>(1, (cap + 63) / 64), SW = std::max<uint32_t>(1, (S + 63) / 64);
+    ctx->n_seqs = cap;
+    ctx->W = W;
+    ctx->SW = SW;
+    ctx->word_base = 0;
+    ctx->global_n_seqs = 0;
+    ctx->chunks_on_device = true;
+    *n_seqs_cap = cap;
+    if (dev_reserve(ctx, ctx->d_seqrefs, (size_t)cap * sizeof(dp_seq_ref) + 16)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_chunk_meta, (size_t)cap * sizeof(dp_seq_meta) + 16)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_nseqs, 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_posting, (size_t)S * W * 8 + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_seedsets, (size_t)cap * SW * 8 + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_pmeta, (size_t)S * 16 + 16)) return DP_ERR_HIP;
+    {
+        const dp_zero_region z[3] = {{ctx->d_posting.p, (size_t)S * W * 8 + 64}, {ctx->d_seedsets.p, (size_t)cap * SW * 8 + 64}, {ctx->d_nseqs.p, 64}};
+        if (int rc = dp_zero_regions(ctx, z, 3)) return rc;
+    }
+    if (n_survivors) {
+        ChunkParams P;
+        P.s_item = s_item;
+        P.s_count = s_count;
+        P.s_off = s_off;
+        P.ns = n_survivors;
+        P.lo = ctx->cached_lo;
+        P.read_len = (const uint32_t*)ctx->d_len.p;
+        P.segs = (const int32_t*)ctx->d_segs.p;
+        P.k = ctx->k;
+        P.chunkSize = chunk_size;
+        P.overlap = overlap;
+        P.minSeeds = (int)min_seeds;
+        P.inset = inset;
+        P.refs = (dp_seq_ref*)ctx->d_seqrefs.p;
+        P.metas = (dp_seq_meta*)ctx->d_chunk_meta.p;
+        P.cap = cap;
+        P.n_out = (uint32_t*)ctx->d_nseqs.p;
+        hipLaunchKernelGGL(chunk_kernel, dim3(1), dim3(1024), 0, ctx->stream, P);
+        DP_HIP(hipGetLastError());
+        if (cap) {
+            const uint32_t blocks = std::min<uint32_t>(2048, (cap + 3) / 4);
+            hipLaunchKernelGGL(index_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const dp_seq_ref*)ctx->d_seqrefs.p, cap,
+                               (const int32_t*)ctx->d_segs.p, (u64*)ctx->d_posting.p, (u64*)ctx->d_seedsets.p, W, SW, (const uint32_t*)ctx->d_nseqs.p);
+            DP_HIP(hipGetLastError());
+        }
+    }
+    if (S) {
+        const uint32_t blocks = std::min<uint32_t>(2048, (S + 3) / 4);
+        hipLaunchKernelGGL(posting_meta_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const u64*)ctx->d_posting.p, S, W, (uint32_t*)ctx->d_pmeta.p);
+        DP_HIP(hipGetLastError());
+    }
+    return DP_OK;
+}
+
+// the chunks dp_index_build_chunked made, for a caller that needs them on the host (the host consensus path of the windows
+// the device flags): exact count, views and {read, length, offset, inset}
+extern "C" int dp_index_chunks(dp_ctx* ctx, dp_seq_ref* refs_out, dp_seq_meta* metas_out, uint32_t cap, uint32_t* n_out) {
+    if (!ctx || !n_out) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_index_chunks: bad arguments") : DP_ERR_ARG;
+    if (!ctx->chunks_on_device) return dp_fail(ctx, DP_ERR_STATE, "dp_index_chunks: the index was not built by dp_index_build_chunked");
+    hipSetDevice(ctx->device);
+    uint32_t nn[2] = {0, 0};
+    DP_HIP(hipMemcpyAsync(nn, ctx->d_nseqs.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    if (nn[1]) return dp_fail(ctx, DP_ERR_CAPACITY, "dp_index_build_chunked: chunk bound exceeded");
+    *n_out = nn[0];
+    if (refs_out && metas_out) {
+        if (cap < nn[0]) return dp_fail(ctx, DP_ERR_ARG, "dp_index_chunks: output too small");
+        DP_HIP(hipMemcpyAsync(refs_out, ctx->d_seqrefs.p, (size_t)nn[0] * sizeof(dp_seq_ref), hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(hipMemcpyAsync(metas_out, ctx->d_chunk_meta.p, (size_t)nn[0] * sizeof(dp_seq_meta), hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
+    }
+    return DP_OK;
 }
 
 // ---- an index that is one shard of a larger one (map against a reference spread over several GPUs) ----------------------
@@ -196,7 +434,8 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
                                                              const int32_t* __restrict__ mc, uint32_t mc_n,
                                                              u64* __restrict__ cand, uint32_t* __restrict__ qmeta,
                                                              u64* __restrict__ words_read, uint32_t* __restrict__ qcnt,
-                                                             uint32_t word_base) {
+                                                             uint32_t word_base, const uint32_t* __restrict__ n_seqs_dev) {
+    if (n_seqs_dev) n_seqs = *n_seqs_dev;  // (chunks made on the device: the host only knows an upper bound)
     // word_base: a shard of a larger index (dp_index_set_global) holds the words [word_base, word_base + W) of every set; pmeta
     // and n_seqs then describe the WHOLE sets (global windows, counts), so the filter, the early-return cut and the gather
     // order are those of the unsharded query, and this launch fills in the candidate words of its own range.
@@ -1904,7 +2143,8 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     hipLaunchKernelGGL(query_kernel, dim3(nq), dim3(64 * Q_WAVES), 0, ctx->stream,
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
-                       (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base);
+                       (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
+                       ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 5));
 

@@ -1442,7 +1442,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     }
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 4));
-    DP_HIP(hipMemcpyAsync(ctx->h_total.p, totals, 32, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(hipMemcpyAsync(ctx->h_total.p, totals, 48, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     {
         // DP_SCAN_RELEASE_EARLY=1 opens the gate here, after the count pass, so that the short write pass overlaps the
@@ -1464,6 +1464,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_surv, n_surv_all * 32 + 128)) return DP_ERR_HIP;
+    ctx->last_surv_all = (uint32_t)n_surv_all;
     float ms0 = 0, ms1 = 0, msoff = 0;
     ms0 = dp_elapsed(ctx, 0, 1);
     msoff = dp_elapsed(ctx, 1, 4);
@@ -1500,7 +1501,16 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
             DP_HIP(hipEventSynchronize(ctx->ev[3]));
             if (scan_lock.owns_lock()) scan_lock.unlock();
         }
-        DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        // dp_scan_fetch_mode(1): the survivors' segments stay on the device (the caller chunks and indexes them there); only the
+        // extra items' - the query windows', which follow the survivors in the scan output - come to the host, at their offsets
+        uint64_t from = 0;
+        if (ctx->scan_fetch_extras_only) {
+            if (!n_extra) from = n_segs;
+            else if (use_index) from = std::min<uint64_t>(n_segs, ((uint64_t*)ctx->h_total.p)[5]);
+        }
+        if (from < n_segs)
+            DP_HIP(hipMemcpyAsync((int32_t*)ctx->h_segs.p + from, (const int32_t*)ctx->d_segs.p + from, (n_segs - from) * 4, hipMemcpyDeviceToHost,
+                                  ctx->stream));
     }
     DP_HIP(dp_stream_sync(ctx));
     if (n_segs) ms1 = dp_elapsed(ctx, 2, 3);
@@ -1527,6 +1537,27 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     out->kernel_ms = (double)ms0 + (double)msoff + (double)ms1;
     out->count_kernel_ms = ms0;
     out->write_kernel_ms = ms1;
+    return DP_OK;
+}
+
+extern "C" int dp_scan_fetch_mode(dp_ctx* ctx, int extras_only) {
+    if (!ctx) return DP_ERR_ARG;
+    ctx->scan_fetch_extras_only = extras_only ? 1 : 0;
+    return DP_OK;
+}
+
+// the whole segment array of the last dp_scan_reads, for a caller that left the survivors' part on the device (fetch mode 1)
+// and needs it after all
+extern "C" int dp_scan_fetch_segments(dp_ctx* ctx, const int32_t** segs_out, uint64_t* n_segs) {
+    if (!ctx || !segs_out) return DP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    if (ctx->n_segs) {
+        if (pin_reserve(ctx, ctx->h_segs, ctx->n_segs * 4 + 64)) return DP_ERR_HIP;
+        DP_HIP(hipMemcpyAsync(ctx->h_segs.p, ctx->d_segs.p, ctx->n_segs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
+    }
+    *segs_out = (const int32_t*)ctx->h_segs.p;
+    if (n_segs) *n_segs = ctx->n_segs;
     return DP_OK;
 }
 

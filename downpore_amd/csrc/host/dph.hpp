@@ -295,6 +295,7 @@ struct Survivors {
     const int32_t* segsView = nullptr;  // ... or a view of the producing context's pinned scan output (valid until that
     uint64_t segsViewLen = 0;           // context scans again): the dense-seed regime moves ~80 MB per round here
     bool deviceResident = false;     // the device scan buffer of the producing context holds exactly these ints at the same offsets
+    bool segsOnHost = true;          // false: the scan left the survivors' segments on the device (dp_scan_fetch_mode): segData() is not valid
     const int32_t* segData() const { return segsView ? segsView : segs.data(); }
     uint64_t segCount() const { return segsView ? segsViewLen : (uint64_t)segs.size(); }
 };
@@ -370,8 +371,18 @@ class Overlapper {
     // ranks, exchanged device to device inside the library (dp_allgather_survivors)
     int ExchangeSurvivors(dp_comm* comm, Survivors& all);
     void setTextPool(TextPool* tp) { textPool_ = tp; }
+    // chunkWorker + index build on the device (dp_index_build_chunked) for the rounds scanned by this object's own context: the
+    // survivors' segments never come to the host (set before ScanLocal; IndexSurvivors falls back to the host chunking for
+    // survivors it did not scan itself - the gathered ones of the multi-GPU scan-shard mode)
+    void setDeviceChunking(bool on) { deviceChunkWanted_ = on; }
+    i64 indexedSequences() const { return chunksOnDevice_ ? (i64)nIndexedExact_ : (i64)index_.sequences.size(); }
 
    private:
+    bool deviceChunkWanted_ = false, chunksOnDevice_ = false;
+    uint32_t nIndexedCap_ = 0, nIndexedExact_ = 0;
+    int materializeChunks();  // the device-made chunks as host SeedSeq objects (index_.sequences), for the host consensus path
+    void buildQueries(RoundStats& st);
+    const Survivors* lastLocal_ = nullptr;  // the survivor set ScanLocal filled last (what this context's scan buffer holds)
     void chunkAndAdd(SeedSeq* s, uint64_t segBase, Arena& ar, std::vector<SeedSeq*>& seqOut, std::vector<dp_seq_ref>& refOut);
     const uint8_t* ignore_ = nullptr;
     uint64_t ignoreEpoch_ = 0;

@@ -241,6 +241,7 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
     }
     dp_survivor_batch& b = lastScan_;
     const double ts0 = now();
+    dp_scan_fetch_mode(ctx_, deviceChunkWanted_ ? 1 : 0);
     int rc = dp_scan_reads(ctx_, ignore_, ignoreEpoch_, (uint32_t)lo, (uint32_t)hi, reads_.himem ? 0 : 1, (uint32_t)minSeeds_,
                            items.data(), (uint32_t)items.size(), &b);
     if (rc != 0) {
@@ -267,6 +268,8 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
     local.segsView = b.segs;  // pinned output of this context, untouched until its next scan (= this slot's next round)
     local.segsViewLen = survEnd;
     local.deviceResident = true;
+    local.segsOnHost = !(deviceChunkWanted_ && b.index_mode);  // (fetch mode 1 is honoured by the index-mode scan only)
+    lastLocal_ = &local;
     // query windows
     winSegs_.clear();
     winOff_.assign(1, 0);
@@ -373,6 +376,38 @@ void Overlapper::chunkAndAdd(SeedSeq* s, uint64_t segBase, Arena& ar, std::vecto
 // AddSequences :217 (chunk + index part) from the complete survivor list (file order).
 int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
     double tp0 = now();
+    chunksOnDevice_ = false;
+    if (deviceChunkWanted_ && all.deviceResident && &all == lastLocal_) {
+        // A12 + A13 on the device: the survivors of this context's own scan, still in its scan buffer
+        index_.sequences.clear();
+        index_.refs.clear();
+        uint32_t cap = 0;
+        int rc = dp_index_build_chunked(ctx_, chunkSize_, overlap_, (uint32_t)minSeeds_, (int32_t)reads_.servedInset(), (uint32_t)all.read.size(), &cap);
+        if (rc != 0) {
+            err = dp_last_error(ctx_);
+            return rc;
+        }
+        chunksOnDevice_ = true;
+        nIndexedCap_ = cap;
+        nIndexedExact_ = 0;
+        st.n_indexed = cap;  // (an upper bound until the consensus call reports the exact number)
+        const double tpd = now();
+        g_prof.add(5, 0);
+        g_prof.add(6, 0);
+        g_prof.add(7, tpd - tp0);
+        buildQueries(st);
+        g_prof.add(8, now() - tpd);
+        return 0;
+    }
+    if (!all.segsOnHost) {  // (left on the device by the scan, but this round is chunked on the host after all)
+        const int32_t* p = nullptr;
+        uint64_t n = 0;
+        int rc = dp_scan_fetch_segments(ctx_, &p, &n);
+        if (rc != 0) {
+            err = dp_last_error(ctx_);
+            return rc;
+        }
+    }
     allSegs_ = all.segData();
     // the device-resident scan output the index refers to must hold exactly this survivor array at the same offsets:
     // true right after a local full scan; after a multi-GPU exchange the gathered array is imported
@@ -430,7 +465,13 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
     double tp3 = now();
     g_prof.add(7, tp3 - tp2);
     st.n_indexed = index_.refs.size();
-    // queries: [fwd, rc] per window (PrepareQueries :189-201)
+    buildQueries(st);
+    g_prof.add(8, now() - tp3);
+    return 0;
+}
+
+// queries: [fwd, rc] per window (PrepareQueries :189-201), from the windows' scan output
+void Overlapper::buildQueries(RoundStats& st) {
     queries.clear();
     int queryID = 0;
     for (size_t w = 0; w < windows_.size(); w++) {
@@ -461,12 +502,50 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
         queryID++;
     }
     st.n_queries = queries.size();
-    g_prof.add(8, now() - tp3);
+}
+
+// the chunks dp_index_build_chunked made, as the host objects the host consensus path works on (windows the device flags)
+int Overlapper::materializeChunks() {
+    if (!chunksOnDevice_ || !index_.sequences.empty()) return 0;
+    uint32_t n = 0;
+    std::vector<dp_seq_ref> refs(nIndexedCap_);
+    std::vector<dp_seq_meta> metas(nIndexedCap_);
+    int rc = dp_index_chunks(ctx_, refs.data(), metas.data(), nIndexedCap_, &n);
+    const int32_t* segs = nullptr;
+    uint64_t nsegs = 0;
+    if (rc == 0) rc = dp_scan_fetch_segments(ctx_, &segs, &nsegs);
+    if (rc != 0) {
+        err = dp_last_error(ctx_);
+        return rc;
+    }
+    allSegs_ = segs;
+    index_.sequences.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+        SeedSeq* s = index_.arena.make();
+        s->seg = segs + refs[i].seg_off;
+        s->n = (int)(2 * refs[i].n_seeds + 1);
+        s->id = (int)metas[i].read;
+        s->length = metas[i].length;
+        s->offset = metas[i].offset;
+        s->inset = metas[i].inset;
+        const i64 L = reads_.length(metas[i].read);
+        if (!(s->offset == 0 && s->inset == reads_.servedInset() && s->length == L)) {  // a chunk: its parent is the read's view
+            SeedSeq* root = index_.arena.make();
+            root->id = s->id;
+            root->length = L;
+            root->offset = 0;
+            root->inset = reads_.servedInset();
+            s->parent = root;
+        }
+        index_.sequences.push_back(s);
+    }
     return 0;
 }
 
 // FindOverlaps :320 + matchWorker :346
 int Overlapper::FindOverlaps(std::vector<SeedMatch>& pool, std::vector<SeedMatch*>& out, RoundStats& st) {
+    if (int rcm = materializeChunks()) return rcm;  // (this path works on host objects)
+    if (chunksOnDevice_) st.n_indexed = index_.sequences.size();
     querySegs_.clear();
     queryOff_.assign(1, 0);
     for (const SeedQuery& q : queries) {
@@ -547,24 +626,33 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
     st.k_chain_ms += mb.chain_kernel_ms;
     st.query_bytes += mb.query_bytes;
     st.chain_bytes += mb.chain_bytes;
-    if (index_.sequences.empty() || queries.empty()) return 0;  // nothing indexed: no candidate, no line
-    // SeedSequence fields of the indexed sequences and the seed -> reverse-complement-seed table of the round
-    static thread_local std::vector<dp_seq_meta> metas;
-    metas.resize(index_.sequences.size());
-    for (size_t i = 0; i < metas.size(); i++) {
-        const SeedSeq* s = index_.sequences[i];
-        metas[i].read = (uint32_t)s->id;
-        metas[i].length = (int32_t)s->length;
-        metas[i].offset = (int32_t)s->offset;
-        metas[i].inset = (int32_t)s->inset;
-    }
+    if ((!chunksOnDevice_ && index_.sequences.empty()) || (chunksOnDevice_ && nIndexedCap_ == 0) || queries.empty())
+        return 0;  // nothing indexed: no candidate, no line
     if (index_.rcOf.size() != index_.seedMap.size()) index_.buildRcTable();
     dp_paf_batch pb;
-    rc = dp_consensus_paf(ctx_, metas.data(), (uint32_t)metas.size(), index_.rcOf.data(), (uint32_t)index_.rcOf.size(), index_.k,
-                          (int)overlapSize, &pb);
+    if (chunksOnDevice_) {  // the chunks' fields are on the device already (dp_index_build_chunked)
+        rc = dp_consensus_paf(ctx_, nullptr, 0, index_.rcOf.data(), (uint32_t)index_.rcOf.size(), index_.k, (int)overlapSize, &pb);
+    } else {
+        // SeedSequence fields of the indexed sequences and the seed -> reverse-complement-seed table of the round
+        static thread_local std::vector<dp_seq_meta> metas;
+        metas.resize(index_.sequences.size());
+        for (size_t i = 0; i < metas.size(); i++) {
+            const SeedSeq* s = index_.sequences[i];
+            metas[i].read = (uint32_t)s->id;
+            metas[i].length = (int32_t)s->length;
+            metas[i].offset = (int32_t)s->offset;
+            metas[i].inset = (int32_t)s->inset;
+        }
+        rc = dp_consensus_paf(ctx_, metas.data(), (uint32_t)metas.size(), index_.rcOf.data(), (uint32_t)index_.rcOf.size(), index_.k,
+                              (int)overlapSize, &pb);
+    }
     if (rc != 0) {
         err = dp_last_error(ctx_);
         return rc;
+    }
+    if (chunksOnDevice_) {
+        nIndexedExact_ = pb.n_indexed;
+        st.n_indexed = pb.n_indexed;
     }
     st.k_cons_ms += pb.kernel_ms;
     const double tq2 = now();
@@ -577,6 +665,8 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
     for (uint32_t g = 0; g < pb.n_groups; g++)
         if (pb.groups[g].flag) hostOf[g] = nFlag++;
     if (nFlag) {
+        // (pb points into the context's pinned output, which the calls below leave alone)
+        if (int rcm = materializeChunks()) return rcm;
         dp_match_batch fb;
         rc = dp_fetch_overlaps(ctx_, &fb);
         if (rc != 0) {

@@ -649,6 +649,15 @@ int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
     sl.lap.reset(new Overlapper(sl.ctx, *reads, *sl.index, p.chunkSize, p.numWorkers, p.overlapSize, p.numSeeds, p.minHits));
     sl.lap->setWindows(plan.windows);
     sl.lap->setTextPool(textPool.get());
+    {
+        // chunkWorker on the device (dp_index_build_chunked) wherever the consensus runs there too; DP_DEVICE_CHUNK=0: host chunks
+        static const bool deviceChunk = [] {
+            const char* e = getenv("DP_DEVICE_CHUNK");
+            const char* c = getenv("DP_DEVICE_CONSENSUS");
+            return !(e && e[0] == '0') && !(c && c[0] == '0');
+        }();
+        sl.lap->setDeviceChunking(deviceChunk && sl.comm == nullptr);
+    }
     sl.lap->setIgnoreView(reads->ignore.data(), planner->ignoreEpoch());
     const double tb2 = now();
     g_prof.add(1, tb2 - tb1);

@@ -350,9 +350,21 @@ typedef struct {
     const dp_paf_rec* paf;
     const uint32_t* ignore_ids;
     double kernel_ms;
+    uint32_t n_indexed;              /* sequences in the round's index (exact also after dp_index_build_chunked) */
 } dp_paf_batch;
 DP_API int dp_consensus_paf(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs, const int32_t* rc_of, uint32_t n_seeds, int k,
                             int overlap_size, dp_paf_batch* out);
+
+/* A12 + A4/A13 without the host: overlap.chunkWorker (overlap/overlap.go:253-318: a read with fewer than 3 * min_seeds hits or of
+ * less than one chunk_size goes in whole; otherwise chunks of >= min_seeds seeds and ~chunk_size bases that back up overlap / 2
+ * bases, the tail from 150 seeds before the end in one piece) for the first `n_survivors` survivors of the context's last
+ * dp_scan_reads, in file order, then AddSequence + IndexSequences as dp_index_build does.  The chunks never leave the device:
+ * *n_seqs_cap is an upper bound of their number (it sizes the bit matrices; dp_consensus_paf reports the exact count and takes
+ * the chunks' {read, length, offset, inset} from the device when its `metas` is NULL; `inset` = the served view's inset);
+ * dp_index_chunks copies them to the host for a caller that needs them there. */
+DP_API int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t overlap, uint32_t min_seeds, int32_t inset, uint32_t n_survivors,
+                           uint32_t* n_seqs_cap);
+DP_API int dp_index_chunks(dp_ctx* ctx, dp_seq_ref* refs_out, dp_seq_meta* metas_out, uint32_t cap, uint32_t* n_out);
 /* The match lists of the last dp_find_overlaps on this context (what that call returns itself unless bit 1 of
  * want_candidates asked it not to). */
 DP_API int dp_fetch_overlaps(dp_ctx* ctx, dp_match_batch* out);
@@ -387,6 +399,11 @@ DP_API int dp_allgather_survivors(dp_comm* comm, dp_ctx* ctx, const dp_survivor_
 /* Device pointers of the last dp_scan output, for a multi-GPU exchange driven by the caller (RCCL all-gather of
  * the survivors).  segs_dev: int32[n_segs]. */
 DP_API int dp_scan_device_buffers(dp_ctx* ctx, void** segs_dev, uint64_t* n_segs);
+/* extras_only != 0: dp_scan_reads leaves the surviving reads' segments on the device (for dp_index_build_chunked) and copies only
+ * the extra items' (the query windows') to the host; `segs` of its result is then valid at the extra items' offsets only.
+ * dp_scan_fetch_segments fetches the whole array of the last scan after all (host consensus path of flagged windows). */
+DP_API int dp_scan_fetch_mode(dp_ctx* ctx, int extras_only);
+DP_API int dp_scan_fetch_segments(dp_ctx* ctx, const int32_t** segs_out, uint64_t* n_segs);
 /* Replace the device-resident scan output with externally gathered segments (host pointer). */
 DP_API int dp_scan_import_segments(dp_ctx* ctx, const int32_t* segs, uint64_t n_segs);
 

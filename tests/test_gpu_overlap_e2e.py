@@ -300,6 +300,22 @@ def test_round_parallel_protocol_matches_oracle(world, seed, G, N, L, variable):
         assert rs.ignore().sum() > 0
 
 
+@pytest.mark.parametrize("env", [{}, {"DP_DEVICE_CHUNK": "0"}, {"DP_CONS_FLAG_EVERY": "3"}, {"DP_SCAN_INDEX": "1", "DP_CONS_FLAG_EVERY": "2"},
+                                 {"DP_SCAN_INDEX": "1"}])
+@pytest.mark.parametrize("L,k,e", [(2500, 10, 0.0), (30000, 10, 0.01)])
+def test_overlap_chunks_made_on_the_device(monkeypatch, env, L, k, e):
+    """chunkWorker (overlap.go:253-318) runs on the device (dp_index_build_chunked): the survivors' segments stay in the scan
+    buffer, the chunks and their {read, length, offset, inset} never visit the host, the consensus takes them from there.
+    Short reads go in whole, 30 kb reads at k = 10 are cut into several chunks with the back-up of overlap / 2 and the
+    150-seed tail rule.  Variants: host chunking (DP_DEVICE_CHUNK=0), the k-mer index or the scan kernels as producer, and
+    every 2nd / 3rd window handed to the host consensus path (DP_CONS_FLAG_EVERY), which then fetches chunks and segments
+    after all.  Same PAF as the oracle everywhere."""
+    for kk, v in env.items():
+        monkeypatch.setenv(kk, v)
+    bases, off = O.gen_reads(41 + L, 120000, 400 if L < 10000 else 120, L, e, True)
+    _run_arrays(bases, off, k=k, slots=2)
+
+
 def test_scan_shard_exchange_inside_the_library():
     """The north-star multi-GPU layout through the C ABI's own entry points: ranks own contiguous read ranges,
     scan them with the HIP kernels, and dp_allgather_survivors exchanges the survivors device to device (no host hop).  Two
