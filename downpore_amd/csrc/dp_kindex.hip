@@ -247,17 +247,38 @@ __global__ __launch_bounds__(256) void kidx_walk(const uint32_t* __restrict__ se
                                                  uint32_t lo, uint32_t hi, uint32_t n_read_items, const uint32_t* __restrict__ head,
                                                  const uint32_t* __restrict__ next, uint32_t* __restrict__ counts,
                                                  uint32_t* __restrict__ fillc, const uint64_t* __restrict__ segoff,
-                                                 int32_t* __restrict__ segs, unsigned long long* __restrict__ n_hits) {
+                                                 int32_t* __restrict__ segs, unsigned long long* __restrict__ n_hits, uint32_t lps) {
     const int lane = dp_lane();
     const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t s = w / KX_PARTS, part = w % KX_PARTS;
-    if (s >= n_seeds) return;
-    const uint64_t o = off[seeds[s]];
-    const uint32_t n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
-    const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
-    const uint32_t i0 = part * per, i1 = min(n, i0 + per);
-    if (!FILL && lane == 0 && part == 0 && n) atomicAdd(&n_hits[s & 63u], (unsigned long long)n);  // (64 slots: 10 k same-address atomics serialise)
-    for (uint32_t i = i0 + lane; i < i1; i += 64) {
+    // lps = lanes per seed.  64: KX_PARTS waves share one seed's bucket (dense seeds: buckets of hundreds to thousands);
+    // 16: four seeds per wave (k = 13 at config 2: ~20 occurrences per seed - a whole wave per quarter bucket left 59 lanes idle
+    // and made 40 k waves of a 10 k-seed round)
+    uint32_t s, i0, i1, step, n;
+    uint64_t o;
+    int first;
+    if (lps == 64) {
+        s = w / KX_PARTS;
+        const uint32_t part = w % KX_PARTS;
+        if (s >= n_seeds) return;
+        o = off[seeds[s]];
+        n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
+        const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
+        i0 = part * per + (uint32_t)lane;
+        i1 = min(n, part * per + per);
+        step = 64;
+        first = lane == 0 && part == 0;
+    } else {
+        s = w * 4 + ((uint32_t)lane >> 4);
+        if (s >= n_seeds) return;
+        o = off[seeds[s]];
+        n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
+        i0 = (uint32_t)lane & 15u;
+        i1 = n;
+        step = 16;
+        first = (lane & 15) == 0;
+    }
+    if (!FILL && first && n) atomicAdd(&n_hits[s & 63u], (unsigned long long)n);  // (64 slots: 10 k same-address atomics serialise)
+    for (uint32_t i = i0; i < i1; i += step) {
         const uint64_t e = pos[o + i];
         const uint32_t r = (uint32_t)(e >> 32), p = (uint32_t)e;
         if (r >= lo && r < hi) {
@@ -489,6 +510,17 @@ __global__ __launch_bounds__(64) void kidx_sortwrite(const dp_scan_item* __restr
     }
 }
 
+// lanes per seed of kidx_walk: by the mean bucket size of the index (positions / 4^k)
+static uint32_t kidx_lps(const dp_kindex* ix, int k) {
+    const uint64_t nk = (uint64_t)1 << (2 * k);
+    const uint64_t n_pos = ix->pos.cap / 8;
+    return n_pos / nk >= 128 ? 64u : 16u;
+}
+static uint32_t kidx_walk_blocks(const dp_kindex* ix, int k, uint32_t S) {
+    const uint32_t waves = kidx_lps(ix, k) == 64 ? S * KX_PARTS : (S + 3) / 4;
+    return (waves + 3) / 4;
+}
+
 // Counting step of a round from the index: counts, segment offsets, compacted survivor list and totals for all items, with
 // no host round trip.  d_work = [counts n | fill cursors n | tile status (tiles + 1) u64 | ticket, max count] (zeroed here).
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
@@ -525,9 +557,9 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                            (uint32_t*)d_totals, d_items, n_read_items, n_extra, head, next);
     }
     if (S)
-        hipLaunchKernelGGL(kidx_walk<false>, dim3((S * KX_PARTS + 3) / 4), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
+        hipLaunchKernelGGL(kidx_walk<false>, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
                            (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
-                           (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits);
+                           (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k));
     // totals[2] = seed occurrences in the read set, totals[3] = largest survivor count (both written by the kernel)
     hipLaunchKernelGGL(kidx_offsets, dim3(n_tiles), dim3(KX_TILE), 0, ctx->stream, d_items, (const uint32_t*)d_counts, n_items, status, ticket,
                        d_segoff, s_item, s_count, s_off, s_pack, d_totals, n_read_items, (uint32_t*)(d_totals + 3),
@@ -555,9 +587,9 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         rc = 1;
     } else if (n_sel) {
         if (S)
-            hipLaunchKernelGGL(kidx_walk<true>, dim3((S * KX_PARTS + 3) / 4), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
+            hipLaunchKernelGGL(kidx_walk<true>, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
                                (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
-                               (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr);
+                               (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr, kidx_lps(ix, k));
         const dim3 sg(std::min<uint32_t>(n_sel, 16384)), sb(64);
         uint32_t* ovf = (uint32_t*)(d_totals + 4);
         const uint32_t* nsp = (const uint32_t*)(d_totals + 1);

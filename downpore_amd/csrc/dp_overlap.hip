@@ -221,31 +221,50 @@ __device__ uint32_t chunk_one(const ChunkParams& P, uint32_t i, uint32_t at) {
     return made;
 }
 
-__global__ __launch_bounds__(1024) void chunk_kernel(const ChunkParams P) {
+// status word of a tile of 1024 survivors: flag << 62 | chunks (flag 1 = the tile's own count, 2 = inclusive prefix); tiles take
+// their number from a ticket, so a predecessor is always running or done (the look-back cannot wait for a tile that has no CU)
+__global__ __launch_bounds__(1024) void chunk_kernel(const ChunkParams P, unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket) {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t running_s;
-    if (threadIdx.x == 0) running_s = 0;
+    __shared__ uint32_t tile_s, base_s;
+    if (threadIdx.x == 0) tile_s = atomicAdd(ticket, 1u);
     __syncthreads();
+    const uint32_t tile = tile_s;
     const int lane = dp_lane(), wave = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < P.ns; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t cnt = i < P.ns ? chunk_one<false>(P, i, 0) : 0u;
-        uint32_t x = (uint32_t)wave_incl_sum((int)cnt);
-        if (lane == 63) wsum[wave] = x;
-        __syncthreads();
-        uint32_t before = running_s;
-        for (int w = 0; w < wave; w++) before += wsum[w];
-        uint32_t total = 0;
-        for (int w = 0; w < 16; w++) total += wsum[w];
-        if (cnt) chunk_one<true>(P, i, before + x - cnt);
-        __syncthreads();
-        if (threadIdx.x == 0) running_s += total;
-        __syncthreads();
+    const uint32_t i = tile * 1024 + threadIdx.x;
+    const uint32_t cnt = i < P.ns ? chunk_one<false>(P, i, 0) : 0u;
+    const uint32_t x = (uint32_t)wave_incl_sum((int)cnt);
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < 16; w++) {
+        if (w < wave) before += wsum[w];
+        total += wsum[w];
     }
     if (threadIdx.x == 0) {
-        P.n_out[0] = min(running_s, P.cap);
-        P.n_out[1] = running_s > P.cap ? 1u : 0u;
+        unsigned long long excl = 0;
+        if (tile == 0) {
+            __hip_atomic_store(&status[0], (2ull << 62) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(&status[tile], (1ull << 62) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (int64_t t = (int64_t)tile - 1; t >= 0; t--) {
+                unsigned long long v;
+                do {
+                    v = __hip_atomic_load(&status[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((v >> 62) == 0);
+                excl += v & ((1ull << 62) - 1);
+                if ((v >> 62) == 2) break;
+            }
+            __hip_atomic_store(&status[tile], (2ull << 62) | (excl + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        base_s = (uint32_t)excl;
+        if ((uint64_t)(tile + 1) * 1024 >= P.ns) {  // last tile: the totals
+            const unsigned long long all = excl + total;
+            P.n_out[0] = (uint32_t)min(all, (unsigned long long)P.cap);
+            P.n_out[1] = all > P.cap ? 1u : 0u;
+        }
     }
+    __syncthreads();
+    if (cnt) chunk_one<true>(P, i, base_s + before + x - cnt);
 }
 
 // upper bound of the chunks chunkWorker makes of a read with `numSeeds` hits: every chunk but the last holds >= minSeeds seeds
@@ -288,12 +307,14 @@ extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t o
     *n_seqs_cap = cap;
     if (dev_reserve(ctx, ctx->d_seqrefs, (size_t)cap * sizeof(dp_seq_ref) + 16)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_chunk_meta, (size_t)cap * sizeof(dp_seq_meta) + 16)) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_nseqs, 64)) return DP_ERR_HIP;
+    const uint32_t n_tiles = (n_survivors + 1023) / 1024;
+    const size_t b_nseqs = 64 + ((size_t)n_tiles + 2) * 8;  // [0] chunks, [1] overflow, [2] ticket | tile status words
+    if (dev_reserve(ctx, ctx->d_nseqs, b_nseqs)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_posting, (size_t)S * W * 8 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_seedsets, (size_t)cap * SW * 8 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_pmeta, (size_t)S * 16 + 16)) return DP_ERR_HIP;
     {
-        const dp_zero_region z[3] = {{ctx->d_posting.p, (size_t)S * W * 8 + 64}, {ctx->d_seedsets.p, (size_t)cap * SW * 8 + 64}, {ctx->d_nseqs.p, 64}};
+        const dp_zero_region z[3] = {{ctx->d_posting.p, (size_t)S * W * 8 + 64}, {ctx->d_seedsets.p, (size_t)cap * SW * 8 + 64}, {ctx->d_nseqs.p, b_nseqs}};
         if (int rc = dp_zero_regions(ctx, z, 3)) return rc;
     }
     if (n_survivors) {
@@ -314,7 +335,8 @@ extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t o
         P.metas = (dp_seq_meta*)ctx->d_chunk_meta.p;
         P.cap = cap;
         P.n_out = (uint32_t*)ctx->d_nseqs.p;
-        hipLaunchKernelGGL(chunk_kernel, dim3(1), dim3(1024), 0, ctx->stream, P);
+        hipLaunchKernelGGL(chunk_kernel, dim3(n_tiles), dim3(1024), 0, ctx->stream, P, (unsigned long long*)((uint8_t*)ctx->d_nseqs.p + 64),
+                           (uint32_t*)ctx->d_nseqs.p + 2);
         DP_HIP(hipGetLastError());
         if (cap) {
             const uint32_t blocks = std::min<uint32_t>(2048, (cap + 3) / 4);
