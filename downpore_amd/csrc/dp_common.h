@@ -23,6 +23,7 @@ struct PinBuf {
 
 struct dp_kindex;
 
+struct FindState;
 struct dp_ctx {
     int device = 0;
     dp_ctx* owner = nullptr;     // context whose reads (and k-mer position index) this one borrows
@@ -85,6 +86,8 @@ struct dp_ctx {
     // dp_stream_sync
     std::vector<uint8_t> stage_buf;
     size_t stage_used = 0;
+    uint32_t cons_prev_pairs = 0;            // pairs of the previous round's chaining stage (output bound of a pending one)
+    struct FindState* find_state = nullptr;  // dp_overlap.hip: the chaining stage between launch and evaluation
     bool timing_on = true;
     uint64_t round_serial = 0;
 
@@ -178,6 +181,11 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
 // phase 2 = both strands (whole index); 0 / 1 = forward / reverse windows of a shard, thresholds through thr_io[nw]
 int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t nw, int k,
                         dp_chain_batch* out, int phase = 2, int32_t* thr_io = nullptr);
+void dp_find_state_free(dp_ctx* ctx);
+bool dp_find_pending(const dp_ctx* ctx);
+uint32_t dp_find_pair_cap(const dp_ctx* ctx);
+int dp_find_complete(dp_ctx* ctx, bool* reran);
+void dp_find_stats(const dp_ctx* ctx, double* query_ms, double* chain_ms, uint64_t* query_bytes, uint64_t* chain_bytes);
 int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
                    uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out = nullptr);
 

@@ -390,6 +390,8 @@ struct ConsFullArgs {
     dp_group_meta* gmeta;      // [n_groups]
     unsigned long long* dbg;   // DP_CONS_DEBUG: per group 8 time stamps (wall_clock64, 100 MHz)
     uint32_t flag_every;       // DP_CONS_FLAG_EVERY=n (test hook): every n-th window is left to the host path
+    uint32_t out_cap;          // slots of paf / ignore_ids (a bound when the chaining stage's pair count is not known yet)
+    uint32_t rec_cap;          // records the chaining stage's buffers hold (its pair count may exceed them: the stage is then repeated)
 };
 
 __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A) {
@@ -402,6 +404,11 @@ __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A
         const uint32_t qf = 2 * g, qr = 2 * g + 1;
         const uint32_t P0 = A.pbase[qf], P1 = A.pbase[qr + 1];
         dp_group_meta gm = {P0, 0, 0, 0, 0, 0, 0, 0};
+        if (P1 > A.rec_cap || P1 < P0) {  // (only with a pending chaining stage that overflowed: everything is redone)
+            gm.flag = 2;
+            if (lane == 0) A.gmeta[g] = gm;
+            continue;
+        }
 #define CF_TICK(i_) if (A.dbg && lane == 0) A.dbg[8 * (size_t)g + (i_)] = wall_clock64()
         CF_TICK(0);
         // ---- 1. matches of the group
@@ -1031,10 +1038,15 @@ __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A
             r.t_end = end;
             r.ident = identPrev;
             r.minus = (q_rc != myRc) ? 1u : 0u;
-            A.paf[P0 + (uint32_t)(lane - 1)] = r;
+            if (P0 + (uint32_t)(lane - 1) < A.out_cap) A.paf[P0 + (uint32_t)(lane - 1)] = r;
         }
         const u64 ignMask = __ballot(ign && part);
-        if (ign && part) A.ignore_ids[P0 + (uint32_t)__popcll(ignMask & lanesBelow)] = (uint32_t)myId;
+        if (ign && part) {
+            const uint32_t at = P0 + (uint32_t)__popcll(ignMask & lanesBelow);
+            if (at < A.out_cap) A.ignore_ids[at] = (uint32_t)myId;
+        }
+        // (slots are the pairs of the window's two queries: P0 .. P1; out_cap is a bound when the pair count is not known yet)
+        if (P1 > A.out_cap) gm.flag = 2;  // output did not fit: the caller repeats the call with the exact size
         gm.n_lines = (uint32_t)(np - 1);
         gm.n_ignore = (uint32_t)__popcll(ignMask);
         gm.bad_back = (uint32_t)__popcll(__ballot(badBack != 0));
@@ -1049,13 +1061,19 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
                           int overlap_size, dp_paf_batch* out) {
     memset(out, 0, sizeof(*out));
     hipSetDevice(ctx->device);
-    const uint32_t nq = ctx->last_nq, ng = nq / 2, np = ctx->n_pairs;
+    // a chaining stage left pending (dp_find_overlaps, want_candidates bit 2) is evaluated in this call's wait: its pair count is
+    // not known yet, so the output is sized from a bound - twice the previous round's count - and the kernel reports a slot
+    // beyond it; then, or when the stage itself had to be run again with larger buffers, this call is simply made once more
+    const bool pending = dp_find_pending(ctx);
+    const uint32_t nq = ctx->last_nq, ng = nq / 2;
+    uint32_t np = ctx->n_pairs;
+    if (pending) np = std::min<uint32_t>(dp_find_pair_cap(ctx), std::max<uint32_t>(4096u, 2 * ctx->cons_prev_pairs));
     out->n_groups = ng;
     if ((metas && n_seqs != ctx->n_seqs) || n_seeds != ctx->n_seeds) return dp_fail(ctx, DP_ERR_ARG, "dp_consensus_paf: metas / rc_of do not match the round's index");
     if (!metas && !ctx->chunks_on_device) return dp_fail(ctx, DP_ERR_ARG, "dp_consensus_paf: metas == NULL needs an index made by dp_index_build_chunked");
     if (!metas) n_seqs = 0;  // (the chunks' fields are on the device already: only rc_of travels)
     if (nq & 1) return dp_fail(ctx, DP_ERR_ARG, "dp_consensus_paf: queries must come in (forward, reverse complement) pairs");
-    if (ng == 0 || !ctx->find_valid) {
+    if (ng == 0 || (!ctx->find_valid && !pending)) {
         if (!ctx->find_valid && ng) return dp_fail(ctx, DP_ERR_STATE, "dp_consensus_paf before dp_find_overlaps");
         return DP_OK;
     }
@@ -1065,9 +1083,9 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     if (metas) memcpy(ctx->h_cin.p, metas, b_meta);
     memcpy((uint8_t*)ctx->h_cin.p + b_meta, rc_of, b_rc);
     DP_HIP(hipMemcpyAsync(ctx->d_cin.p, ctx->h_cin.p, b_meta + b_rc, hipMemcpyHostToDevice, ctx->stream));
-    const size_t b_paf = (size_t)np * sizeof(dp_paf_rec), b_ign = (size_t)np * 4, b_gm = (size_t)ng * sizeof(dp_group_meta);
+    const size_t b_paf = (size_t)np * sizeof(dp_paf_rec), b_ign = (size_t)np * 4, b_gm = ((size_t)ng * sizeof(dp_group_meta) + 15) & ~(size_t)15;
     if (dev_reserve(ctx, ctx->d_cout, b_paf + b_ign + b_gm + 64)) return DP_ERR_HIP;
-    if (pin_reserve(ctx, ctx->h_cout, b_paf + b_ign + b_gm + 64)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_cout, b_paf + b_ign + b_gm + 96)) return DP_ERR_HIP;
     uint8_t* dout = (uint8_t*)ctx->d_cout.p;
     ConsFullArgs A;
     A.recs = (const uint32_t*)ctx->d_mrec.p;
@@ -1096,6 +1114,8 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     A.gmeta = (dp_group_meta*)dout;
     A.paf = (dp_paf_rec*)(dout + b_gm);
     A.ignore_ids = (uint32_t*)(dout + b_gm + b_paf);
+    A.out_cap = np;
+    A.rec_cap = pending ? dp_find_pair_cap(ctx) : ctx->n_pairs;
     static const bool cons_debug = getenv("DP_CONS_DEBUG") != nullptr;
     A.dbg = nullptr;
     if (cons_debug) {
@@ -1113,6 +1133,16 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     if (ctx->chunks_on_device) DP_HIP(hipMemcpyAsync(h_nseq, ctx->d_nseqs.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     if (h_nseq[1]) return dp_fail(ctx, DP_ERR_CAPACITY, "dp_index_build_chunked: chunk bound exceeded");
+    if (pending) {
+        bool reran = false;
+        if (int rc = dp_find_complete(ctx, &reran)) return rc;
+        const bool overflow = ctx->n_pairs > np;  // (some window's slots lay beyond the bound: its group carries flag 2)
+        ctx->cons_prev_pairs = ctx->n_pairs;
+        if (reran || overflow) return dp_consensus_paf_impl(ctx, metas, metas ? ctx->n_seqs : 0, rc_of, n_seeds, k, overlap_size, out);
+    } else {
+        ctx->cons_prev_pairs = ctx->n_pairs;
+    }
+    dp_find_stats(ctx, &out->query_kernel_ms, &out->chain_kernel_ms, &out->query_bytes, &out->chain_bytes);
     out->n_indexed = h_nseq[0];
     float ms = 0;
     ms = dp_elapsed(ctx, 0, 1);

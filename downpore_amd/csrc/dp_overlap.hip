@@ -2180,6 +2180,196 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
 
 int dp_fetch_overlaps_impl(dp_ctx* ctx, int want_candidates, dp_match_batch* out);
 
+// State of a chaining stage between its launch and the evaluation of what it reported (the stage may be left pending:
+// dp_find_overlaps with want_candidates bit 2, finished by dp_consensus_paf in the wait it needs anyway).
+struct FindState {
+    uint32_t nq = 0;
+    int k = 0;
+    uint32_t max_query_len = 0;
+    int chain_tier = 0, passes = 3;
+    uint32_t walk_blocks = 0, spec_blocks = 1024;
+    uint32_t* d_qmeta = nullptr;
+    uint32_t* d_qcnt = nullptr;
+    const int32_t* d_mc = nullptr;
+    uint32_t mc_n = 0;
+    uint64_t want_pairs = 0, want_sints = 0, want_ints = 0;
+    uint32_t pair_cap = 0, int_cap = 0;
+    uint64_t sint_cap = 0;
+    int attempt = 0;
+    float chain_ms = 0;
+    bool pending = false;
+    uint32_t cur[32];
+    double query_ms = 0;
+    uint64_t query_bytes = 0, chain_bytes = 0;
+};
+void dp_find_state_free(dp_ctx* ctx) {
+    delete ctx->find_state;
+    ctx->find_state = nullptr;
+}
+bool dp_find_pending(const dp_ctx* ctx) { return ctx->find_state && ctx->find_state->pending; }
+uint32_t dp_find_pair_cap(const dp_ctx* ctx) { return ctx->find_state ? ctx->find_state->pair_cap : 0; }
+
+// one attempt of the chaining stage with the current capacities: launches and the read-back of what it reports; no wait
+static int chain_enqueue(dp_ctx* ctx, FindState& st) {
+    if (st.attempt > 8) return dp_fail(ctx, DP_ERR_STATE, "dp_find_overlaps: output buffers keep overflowing");
+    const uint32_t nq = st.nq;
+    const uint32_t W = ctx->W, SW = ctx->SW;
+    uint32_t* d_cur = (uint32_t*)ctx->d_cursor.p;
+    u64* d_totals = (u64*)((uint8_t*)ctx->d_cursor.p + 64);
+    u64* d_ibase = (u64*)ctx->d_pbase.p;  // (8-byte aligned first)
+    uint32_t* d_pbase = (uint32_t*)(d_ibase + nq + 1);
+    QState* d_qstate = (QState*)(d_pbase + nq + 1 + ((nq + 1) & 1));
+    {
+        // (a stage left pending is read by the consensus kernel before anybody knows whether it fitted its buffers: records the
+        // stage did not write must at least be harmless - all-zero when the buffer is new, those of an earlier round otherwise)
+        const void* before = ctx->d_mrec.p;
+        if (dev_reserve(ctx, ctx->d_mrec, (size_t)st.want_pairs * sizeof(MRec))) return DP_ERR_HIP;
+        if (ctx->d_mrec.p != before) DP_HIP(hipMemsetAsync(ctx->d_mrec.p, 0, ctx->d_mrec.cap, ctx->stream));
+    }
+    if (dev_reserve(ctx, ctx->d_pspec, (size_t)st.want_pairs * sizeof(PSpec))) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_clist, (size_t)st.want_pairs * 8)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_sa, (size_t)st.want_sints * 4)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_sb, (size_t)st.want_sints * 4)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_ma, (size_t)st.want_ints * 4)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_mb, (size_t)st.want_ints * 4)) return DP_ERR_HIP;
+    st.pair_cap = (uint32_t)std::min<uint64_t>(0xfffffff0ull, st.want_pairs);
+    st.sint_cap = st.want_sints;
+    st.int_cap = (uint32_t)std::min<uint64_t>(0xfffffff0ull, st.want_ints);
+    ChainArgs A;
+    A.qsegs = ctx->qsegs_dev;
+    A.qoff = ctx->qoff_dev;
+    A.nq = nq;
+    A.qsets = (const u64*)ctx->d_qsets.p;
+    A.qmeta = st.d_qmeta;
+    A.qcnt = st.d_qcnt;
+    A.cand = (const u64*)ctx->d_cand.p;
+    A.refs = (const dp_seq_ref*)ctx->d_seqrefs.p;
+    A.segs = (const int32_t*)ctx->d_segs.p;
+    A.seedsets = (const u64*)ctx->d_seedsets.p;
+    A.W = W;
+    A.SW = SW;
+    A.mc = st.d_mc;
+    A.mc_n = st.mc_n;
+    A.k = st.k;
+    A.maxLength = (int)st.max_query_len;
+    A.tier = st.chain_tier;
+    A.pool = (CNode*)ctx->d_pool.p;
+    A.pbase = d_pbase;
+    A.ibase = d_ibase;
+    A.clist = (uint32_t*)ctx->d_clist.p;
+    A.pq = A.clist + st.pair_cap;
+    A.pass = 0;
+    A.pspec = (PSpec*)ctx->d_pspec.p;
+    A.qstate = d_qstate;
+    A.recs = (MRec*)ctx->d_mrec.p;
+    A.sa = (int32_t*)ctx->d_sa.p;
+    A.sb = (int32_t*)ctx->d_sb.p;
+    A.ma = (int32_t*)ctx->d_ma.p;
+    A.mb = (int32_t*)ctx->d_mb.p;
+    A.pair_cap = st.pair_cap;
+    A.sint_cap = st.sint_cap;
+    A.int_cap = st.int_cap;
+    A.cursor = d_cur;
+    if (st.attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 128, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
+    DP_HIP(dp_mark(ctx, 6));
+    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)st.d_qcnt, ctx->qoff_dev, nq, d_pbase, d_ibase,
+                       d_totals);
+    hipLaunchKernelGGL(chain_walk_kernel, dim3(st.walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 0);
+    for (int ps = 0; ps < st.passes; ps++) {
+        A.pass = ps;
+        hipLaunchKernelGGL(chain_spec_kernel, dim3(st.spec_blocks), dim3(64 * S_WAVES), 0, ctx->stream, A, (const u64*)d_totals);
+        hipLaunchKernelGGL(chain_resolve_kernel, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), 0, ctx->stream, A);
+    }
+    A.pass = st.passes;
+    hipLaunchKernelGGL(chain_walk_kernel, dim3(st.walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 2);
+    DP_HIP(hipGetLastError());
+    DP_HIP(dp_mark(ctx, 7));
+    DP_HIP(hipMemcpyAsync(ctx->h_cursor.p, ctx->d_cursor.p, 128, hipMemcpyDeviceToHost, ctx->stream));
+    // status words, per-query posting-word counts and candidate counts come back in any case (a few KB), in the same wait
+    DP_HIP(hipMemcpyAsync(ctx->h_qm.p, st.d_qmeta, (size_t)nq * 28, hipMemcpyDeviceToHost, ctx->stream));
+    st.attempt++;
+    return DP_OK;
+}
+
+// after a wait: what did the attempt report?  *grow: a buffer was too small - capacities raised, run it again
+static int chain_check(dp_ctx* ctx, FindState& st, bool* grow) {
+    memcpy(st.cur, ctx->h_cursor.p, 128);
+    st.chain_ms += dp_elapsed(ctx, 6, 7);
+    uint64_t tot_pairs, tot_sints;
+    memcpy(&tot_pairs, &st.cur[16], 8);
+    memcpy(&tot_sints, &st.cur[18], 8);
+    if (tot_pairs > 0xfffffff0ull) return dp_fail(ctx, DP_ERR_CAPACITY, "more than 2^32 (query, candidate) pairs in one round");
+    *grow = false;
+    if (tot_pairs > st.pair_cap) {
+        st.want_pairs = tot_pairs + tot_pairs / 2 + 1024;
+        *grow = true;
+    }
+    if (tot_sints > st.sint_cap) {
+        st.want_sints = tot_sints + tot_sints / 2 + 1024;
+        *grow = true;
+    }
+    if ((uint64_t)st.cur[0] > st.int_cap) {
+        st.want_ints = std::max<uint64_t>(st.want_ints * 2, (uint64_t)st.cur[0] + 1024);
+        *grow = true;
+    }
+    if (!*grow && st.cur[3]) return dp_fail(ctx, DP_ERR_STATE, "dp_find_overlaps: overflow flag without a total that exceeds a buffer");
+    return DP_OK;
+}
+
+// a checked attempt without overflow: the stage's errors, totals and statistics
+static int chain_finish(dp_ctx* ctx, FindState& st) {
+    st.pending = false;
+    st.query_ms = dp_elapsed(ctx, 4, 5);
+    st.chain_bytes = (uint64_t)st.cur[4] | ((uint64_t)st.cur[5] << 32);
+    if (st.cur[2]) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "overlap chaining hit a reference capacity limit (bits %u: 1 reduced buffer, 2 state pool, 4 results, 8 nodes)", st.cur[2]);
+        return dp_fail(ctx, DP_ERR_CAPACITY, msg);
+    }
+    st.query_bytes = 0;
+    {
+        const uint32_t* qm = (const uint32_t*)ctx->h_qm.p;
+        const u64* words = (const u64*)((const uint8_t*)ctx->h_qm.p + (size_t)st.nq * 16);
+        for (uint32_t q = 0; q < st.nq; q++) {
+            if (qm[4 * q + 2] & 1) return dp_fail(ctx, DP_ERR_CAPACITY, "query with more than 512 usable seeds");
+            st.query_bytes += words[q] * 8;
+        }
+    }
+    uint64_t tp = 0;
+    memcpy(&tp, &st.cur[16], 8);
+    ctx->n_pairs = (uint32_t)tp;
+    ctx->last_nq = st.nq;
+    ctx->last_ni = st.cur[0];
+    ctx->last_k = st.k;
+    ctx->find_valid = true;
+    return DP_OK;
+}
+
+// A pending chaining stage after the caller's own wait on the context's stream: evaluates the attempt; when a buffer was too
+// small the stage is run again (with waits) until it fits.  *reran: whatever the caller queued behind the first attempt read
+// incomplete records and has to be queued again.
+int dp_find_complete(dp_ctx* ctx, bool* reran) {
+    *reran = false;
+    FindState* st = ctx->find_state;
+    if (!st || !st->pending) return DP_OK;
+    for (;;) {
+        bool grow = false;
+        if (int rc = chain_check(ctx, *st, &grow)) return rc;
+        if (!grow) break;
+        *reran = true;
+        if (int rc = chain_enqueue(ctx, *st)) return rc;
+        DP_HIP(dp_stream_sync(ctx));
+    }
+    return chain_finish(ctx, *st);
+}
+void dp_find_stats(const dp_ctx* ctx, double* query_ms, double* chain_ms, uint64_t* query_bytes, uint64_t* chain_bytes) {
+    const FindState* st = ctx->find_state;
+    *query_ms = st ? st->query_ms : 0;
+    *chain_ms = st ? (double)st->chain_ms : 0;
+    *query_bytes = st ? st->query_bytes : 0;
+    *chain_bytes = st ? st->chain_bytes : 0;
+}
+
 int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,
                           uint32_t max_query_len, int want_candidates, dp_match_batch* out) {
     if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_find_overlaps before dp_round_begin");
@@ -2189,7 +2379,9 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     ctx->find_valid = false;
     ctx->n_pairs = 0;
     ctx->last_nq = nq;
-    const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
+    ctx->last_k = k;
+    if (ctx->find_state) ctx->find_state->pending = false;
+    const uint32_t M = ctx->n_seqs;
     if (pin_reserve(ctx, ctx->h_cursor, 128)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_cand_off, ((size_t)nq + 1) * 8)) return DP_ERR_HIP;
     ((uint64_t*)ctx->h_cand_off.p)[0] = 0;
@@ -2202,153 +2394,53 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         for (uint32_t q = 0; q <= nq; q++) ((uint64_t*)ctx->h_cand_off.p)[q] = 0;
         return DP_OK;
     }
-    uint32_t* d_qmeta = nullptr;
+    if (!ctx->find_state) ctx->find_state = new FindState();
+    FindState& st = *ctx->find_state;
+    st = FindState();
+    st.nq = nq;
+    st.k = k;
+    st.max_query_len = max_query_len;
     u64* d_words = nullptr;
     int32_t* d_mc = nullptr;
-    uint32_t* d_qcnt = nullptr;
-    uint32_t mc_n = 0;
     {
-        int rc = dp_query_stage(ctx, q_segs, q_off, nq, hf, &d_qmeta, &d_words, &d_mc, &mc_n, &d_qcnt);
+        int rc = dp_query_stage(ctx, q_segs, q_off, nq, hf, &st.d_qmeta, &d_words, &d_mc, &st.mc_n, &st.d_qcnt);
         if (rc != 0) return rc;
     }
-    if (dev_reserve(ctx, ctx->d_cursor, 128)) return DP_ERR_HIP;
-    // [0..63] cursor words, [64..] totals (u64 pairs, u64 scratch ints)
-    uint32_t* d_cur = (uint32_t*)ctx->d_cursor.p;
-    u64* d_totals = (u64*)((uint8_t*)ctx->d_cursor.p + 64);
-
+    st.d_mc = d_mc;
+    if (dev_reserve(ctx, ctx->d_cursor, 128)) return DP_ERR_HIP;  // [0..63] cursor words, [64..] totals (u64 pairs, u64 scratch ints)
     const char* tier_env = getenv("DP_CHAIN_TIER");  // tests: 2 = lds tier, 3 = one-lane tier for every pair
-    const int chain_tier = tier_env ? atoi(tier_env) : 0;
+    st.chain_tier = tier_env ? atoi(tier_env) : 0;
     const char* pass_env = getenv("DP_CHAIN_PASSES");  // proposal passes (0 = the serial walk alone: the round-1 behaviour)
-    const int passes = pass_env ? std::max(0, std::min(6, atoi(pass_env))) : 3;
-    const uint32_t walk_blocks = std::min<uint32_t>(256, (nq + C_WAVES - 1) / C_WAVES);
-    const uint32_t spec_blocks = 1024;  // 4096 persistent waves, 16 per CU: what CSlim's 8.5 KB per wave lets a CU hold
-    if (dev_reserve(ctx, ctx->d_pool, (size_t)walk_blocks * C_WAVES * C_NODES * sizeof(CNode))) return DP_ERR_HIP;
+    st.passes = pass_env ? std::max(0, std::min(6, atoi(pass_env))) : 3;
+    st.walk_blocks = std::min<uint32_t>(256, (nq + C_WAVES - 1) / C_WAVES);
+    st.spec_blocks = 1024;  // 4096 persistent waves, 16 per CU: what CSlim's 8.5 KB per wave lets a CU hold
+    if (dev_reserve(ctx, ctx->d_pool, (size_t)st.walk_blocks * C_WAVES * C_NODES * sizeof(CNode))) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_pbase, ((size_t)nq + 1) * 4 + ((size_t)nq + 1) * 8 + (size_t)nq * sizeof(QState) + 64)) return DP_ERR_HIP;
-    u64* d_ibase = (u64*)ctx->d_pbase.p;  // (8-byte aligned first)
-    uint32_t* d_pbase = (uint32_t*)(d_ibase + nq + 1);
-    QState* d_qstate = (QState*)(d_pbase + nq + 1 + ((nq + 1) & 1));
     // capacities: what the buffers hold now (at least a floor); a run that needs more reports its totals and is repeated
     // with larger buffers (deterministic: same results)
-    uint64_t want_pairs = std::max<uint64_t>(1u << 14, ctx->d_mrec.cap / sizeof(MRec));
-    uint64_t want_sints = std::max<uint64_t>(1u << 18, ctx->d_sa.cap / 4);
-    uint64_t want_ints = std::max<uint64_t>(1u << 18, ctx->d_ma.cap / 4);
-    uint32_t cur[32];
-    float chain_ms = 0;
-    for (int attempt = 0;; attempt++) {
-        if (attempt > 8) return dp_fail(ctx, DP_ERR_STATE, "dp_find_overlaps: output buffers keep overflowing");
-        if (dev_reserve(ctx, ctx->d_mrec, (size_t)want_pairs * sizeof(MRec))) return DP_ERR_HIP;
-        if (dev_reserve(ctx, ctx->d_pspec, (size_t)want_pairs * sizeof(PSpec))) return DP_ERR_HIP;
-        if (dev_reserve(ctx, ctx->d_clist, (size_t)want_pairs * 8)) return DP_ERR_HIP;
-        if (dev_reserve(ctx, ctx->d_sa, (size_t)want_sints * 4)) return DP_ERR_HIP;
-        if (dev_reserve(ctx, ctx->d_sb, (size_t)want_sints * 4)) return DP_ERR_HIP;
-        if (dev_reserve(ctx, ctx->d_ma, (size_t)want_ints * 4)) return DP_ERR_HIP;
-        if (dev_reserve(ctx, ctx->d_mb, (size_t)want_ints * 4)) return DP_ERR_HIP;
-        const uint32_t pair_cap = (uint32_t)std::min<uint64_t>(0xfffffff0ull, want_pairs);
-        const uint64_t sint_cap = want_sints;
-        const uint32_t int_cap = (uint32_t)std::min<uint64_t>(0xfffffff0ull, want_ints);
-        ChainArgs A;
-        A.qsegs = ctx->qsegs_dev;
-        A.qoff = ctx->qoff_dev;
-        A.nq = nq;
-        A.qsets = (const u64*)ctx->d_qsets.p;
-        A.qmeta = d_qmeta;
-        A.qcnt = d_qcnt;
-        A.cand = (const u64*)ctx->d_cand.p;
-        A.refs = (const dp_seq_ref*)ctx->d_seqrefs.p;
-        A.segs = (const int32_t*)ctx->d_segs.p;
-        A.seedsets = (const u64*)ctx->d_seedsets.p;
-        A.W = W;
-        A.SW = SW;
-        A.mc = d_mc;
-        A.mc_n = mc_n;
-        A.k = k;
-        A.maxLength = (int)max_query_len;
-        A.tier = chain_tier;
-        A.pool = (CNode*)ctx->d_pool.p;
-        A.pbase = d_pbase;
-        A.ibase = d_ibase;
-        A.clist = (uint32_t*)ctx->d_clist.p;
-        A.pq = A.clist + pair_cap;
-        A.pass = 0;
-        A.pspec = (PSpec*)ctx->d_pspec.p;
-        A.qstate = d_qstate;
-        A.recs = (MRec*)ctx->d_mrec.p;
-        A.sa = (int32_t*)ctx->d_sa.p;
-        A.sb = (int32_t*)ctx->d_sb.p;
-        A.ma = (int32_t*)ctx->d_ma.p;
-        A.mb = (int32_t*)ctx->d_mb.p;
-        A.pair_cap = pair_cap;
-        A.sint_cap = sint_cap;
-        A.int_cap = int_cap;
-        A.cursor = d_cur;
-        if (attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 128, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
-        DP_HIP(dp_mark(ctx, 6));
-        hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)d_qcnt, ctx->qoff_dev, nq,
-                           d_pbase, d_ibase, d_totals);
-        hipLaunchKernelGGL(chain_walk_kernel, dim3(walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 0);
-        for (int ps = 0; ps < passes; ps++) {
-            A.pass = ps;
-            hipLaunchKernelGGL(chain_spec_kernel, dim3(spec_blocks), dim3(64 * S_WAVES), 0, ctx->stream, A, (const u64*)d_totals);
-            hipLaunchKernelGGL(chain_resolve_kernel, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), 0, ctx->stream, A);
-        }
-        A.pass = passes;
-        hipLaunchKernelGGL(chain_walk_kernel, dim3(walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 2);
-        DP_HIP(hipGetLastError());
-        DP_HIP(dp_mark(ctx, 7));
-        DP_HIP(hipMemcpyAsync(ctx->h_cursor.p, ctx->d_cursor.p, 128, hipMemcpyDeviceToHost, ctx->stream));
-        // status words, per-query posting-word counts and candidate counts come back in any case (a few KB), in the same wait
-        DP_HIP(hipMemcpyAsync(ctx->h_qm.p, d_qmeta, (size_t)nq * 28, hipMemcpyDeviceToHost, ctx->stream));
+    st.want_pairs = std::max<uint64_t>(1u << 14, ctx->d_mrec.cap / sizeof(MRec));
+    st.want_sints = std::max<uint64_t>(1u << 18, ctx->d_sa.cap / 4);
+    st.want_ints = std::max<uint64_t>(1u << 18, ctx->d_ma.cap / 4);
+    if (int rc = chain_enqueue(ctx, st)) return rc;
+    if ((want_candidates & 6) == 6) {
+        // bit 2: nothing of this call is read before dp_consensus_paf - the stage stays pending and is evaluated in that call's
+        // wait (one wait per round less)
+        st.pending = true;
+        for (uint32_t q = 0; q <= nq; q++) ((uint64_t*)ctx->h_cand_off.p)[q] = 0;
+        return DP_OK;
+    }
+    for (;;) {
         DP_HIP(dp_stream_sync(ctx));
-        memcpy(cur, ctx->h_cursor.p, 128);
-        float ms = 0;
-        ms = dp_elapsed(ctx, 6, 7);
-        chain_ms += ms;
-        uint64_t tot_pairs, tot_sints;
-        memcpy(&tot_pairs, &cur[16], 8);
-        memcpy(&tot_sints, &cur[18], 8);
-        if (tot_pairs > 0xfffffff0ull) return dp_fail(ctx, DP_ERR_CAPACITY, "more than 2^32 (query, candidate) pairs in one round");
         bool grow = false;
-        if (tot_pairs > pair_cap) {
-            want_pairs = tot_pairs + tot_pairs / 2 + 1024;
-            grow = true;
-        }
-        if (tot_sints > sint_cap) {
-            want_sints = tot_sints + tot_sints / 2 + 1024;
-            grow = true;
-        }
-        if ((uint64_t)cur[0] > int_cap) {
-            want_ints = std::max<uint64_t>(want_ints * 2, (uint64_t)cur[0] + 1024);
-            grow = true;
-        }
-        if (grow) continue;
-        if (cur[3]) return dp_fail(ctx, DP_ERR_STATE, "dp_find_overlaps: overflow flag without a total that exceeds a buffer");
-        break;
+        if (int rc = chain_check(ctx, st, &grow)) return rc;
+        if (!grow) break;
+        if (int rc = chain_enqueue(ctx, st)) return rc;
     }
-    float qms = 0;
-    qms = dp_elapsed(ctx, 4, 5);
-    out->query_kernel_ms = qms;
-    out->chain_kernel_ms = chain_ms;
-    out->chain_bytes = (uint64_t)cur[4] | ((uint64_t)cur[5] << 32);
-    if (cur[2]) {
-        char msg[160];
-        snprintf(msg, sizeof msg, "overlap chaining hit a reference capacity limit (bits %u: 1 reduced buffer, 2 state pool, 4 results, 8 nodes)", cur[2]);
-        return dp_fail(ctx, DP_ERR_CAPACITY, msg);
-    }
-    {
-        const uint32_t* qm = (const uint32_t*)ctx->h_qm.p;
-        const u64* words = (const u64*)((const uint8_t*)ctx->h_qm.p + (size_t)nq * 16);
-        for (uint32_t q = 0; q < nq; q++) {
-            if (qm[4 * q + 2] & 1) return dp_fail(ctx, DP_ERR_CAPACITY, "query with more than 512 usable seeds");
-            out->query_bytes += words[q] * 8;
-        }
-    }
-    uint64_t tp = 0;
-    memcpy(&tp, &cur[16], 8);
-    ctx->n_pairs = (uint32_t)tp;
-    ctx->last_nq = nq;
-    ctx->last_ni = cur[0];
-    ctx->last_k = k;
-    ctx->find_valid = true;
+    if (int rc = chain_finish(ctx, st)) return rc;
+    out->query_kernel_ms = st.query_ms;
+    out->chain_kernel_ms = st.chain_ms;
+    out->query_bytes = st.query_bytes;
+    out->chain_bytes = st.chain_bytes;
     if (want_candidates & 2) {
         for (uint32_t q = 0; q <= nq; q++) ((uint64_t*)ctx->h_cand_off.p)[q] = 0;
         return DP_OK;
@@ -2365,7 +2457,8 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
 
 // Anchors of every final record of the chaining stage (device resident): d_manchor[2 * pair]
 int dp_match_anchors_launch(dp_ctx* ctx) {
-    const uint32_t nslots = ctx->n_pairs;
+    // (a pending chaining stage: the pair count is on the device only - the launch covers the stage's capacity)
+    const uint32_t nslots = dp_find_pending(ctx) ? dp_find_pair_cap(ctx) : ctx->n_pairs;
     if (dev_reserve(ctx, ctx->d_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
     if (!nslots) return DP_OK;
     const u64* d_totals = (const u64*)((const uint8_t*)ctx->d_cursor.p + 64);

@@ -349,6 +349,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     if (ctx->borrowed_reads) ctx->d_packed.p = ctx->d_boff.p = ctx->d_len.p = ctx->d_values.p = ctx->d_qual.p = ctx->d_qualoff.p = ctx->d_hasq.p = nullptr;
     if (ctx->owner) ctx->owner->n_borrowers--;
     dp_kindex_free(ctx);
+    dp_find_state_free(ctx);
     DevBuf* dbs[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len, &ctx->d_bits, &ctx->d_kmap, &ctx->d_seeds, &ctx->d_items,
                      &ctx->d_counts, &ctx->d_segoff, &ctx->d_segs, &ctx->d_total, &ctx->d_seqrefs, &ctx->d_posting,
                      &ctx->d_seedsets, &ctx->d_pmeta, &ctx->d_qsegs, &ctx->d_qoff, &ctx->d_qsets, &ctx->d_qmeta,

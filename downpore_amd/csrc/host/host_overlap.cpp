@@ -614,18 +614,26 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
     }
     dp_match_batch mb;
     const double tq0 = now();
+    // want_candidates 6: the matches stay on the device and the stage is left pending - dp_consensus_paf below evaluates it in the
+    // wait it needs anyway (DP_FIND_PENDING=0: wait here, as every other caller of dp_find_overlaps does)
+    static const bool pendingFind = [] {
+        const char* e = getenv("DP_FIND_PENDING");
+        return !(e && e[0] == '0');
+    }();
     int rc = dp_find_overlaps(ctx_, querySegs_.data(), queryOff_.data(), (uint32_t)queries.size(), hitFraction_, index_.k,
-                              (uint32_t)(overlap_ / 2), 2, &mb);
+                              (uint32_t)(overlap_ / 2), pendingFind ? 6 : 2, &mb);
     if (rc != 0) {
         err = dp_last_error(ctx_);
         return rc;
     }
     const double tq1 = now();
     g_prof.add(9, tq1 - tq0);
-    st.k_query_ms += mb.query_kernel_ms;
-    st.k_chain_ms += mb.chain_kernel_ms;
-    st.query_bytes += mb.query_bytes;
-    st.chain_bytes += mb.chain_bytes;
+    if (!pendingFind) {
+        st.k_query_ms += mb.query_kernel_ms;
+        st.k_chain_ms += mb.chain_kernel_ms;
+        st.query_bytes += mb.query_bytes;
+        st.chain_bytes += mb.chain_bytes;
+    }
     if ((!chunksOnDevice_ && index_.sequences.empty()) || (chunksOnDevice_ && nIndexedCap_ == 0) || queries.empty())
         return 0;  // nothing indexed: no candidate, no line
     if (index_.rcOf.size() != index_.seedMap.size()) index_.buildRcTable();
@@ -653,6 +661,12 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
     if (chunksOnDevice_) {
         nIndexedExact_ = pb.n_indexed;
         st.n_indexed = pb.n_indexed;
+    }
+    if (pendingFind) {
+        st.k_query_ms += pb.query_kernel_ms;
+        st.k_chain_ms += pb.chain_kernel_ms;
+        st.query_bytes += pb.query_bytes;
+        st.chain_bytes += pb.chain_bytes;
     }
     st.k_cons_ms += pb.kernel_ms;
     const double tq2 = now();

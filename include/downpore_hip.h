@@ -245,7 +245,9 @@ typedef struct {
 } dp_match_batch;
 
 /* want_candidates: bit 0 = also return Matches()' candidate lists (test hook); bit 1 = leave the matches on the device
- * (only the kernel times / byte counts of `out` are filled in): for dp_consensus_paf, or a later dp_fetch_overlaps. */
+ * (only the kernel times / byte counts of `out` are filled in): for dp_consensus_paf, or a later dp_fetch_overlaps; bit 2
+ * (with bit 1) = do not even wait: the stage stays pending, the next call on the context must be dp_consensus_paf, which
+ * evaluates it in the wait it needs anyway (overflows of either stage are repeated there) and reports its times and bytes. */
 DP_API int dp_find_overlaps(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t n_queries,
                      double hit_fraction, int k, uint32_t max_query_len, int want_candidates, dp_match_batch* out);
 
@@ -351,6 +353,8 @@ typedef struct {
     const uint32_t* ignore_ids;
     double kernel_ms;
     uint32_t n_indexed;              /* sequences in the round's index (exact also after dp_index_build_chunked) */
+    double query_kernel_ms, chain_kernel_ms;  /* the chaining stage this call finished (dp_find_overlaps, want_candidates bit 2) */
+    uint64_t query_bytes, chain_bytes;
 } dp_paf_batch;
 DP_API int dp_consensus_paf(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs, const int32_t* rc_of, uint32_t n_seeds, int k,
                             int overlap_size, dp_paf_batch* out);
