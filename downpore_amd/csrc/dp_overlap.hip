@@ -2414,6 +2414,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     st.passes = pass_env ? std::max(0, std::min(6, atoi(pass_env))) : 3;
     st.walk_blocks = std::min<uint32_t>(256, (nq + C_WAVES - 1) / C_WAVES);
     st.spec_blocks = 1024;  // 4096 persistent waves, 16 per CU: what CSlim's 8.5 KB per wave lets a CU hold
+    if (const char* e = getenv("DP_SPEC_BLOCKS")) st.spec_blocks = (uint32_t)std::max(1, atoi(e));
     if (dev_reserve(ctx, ctx->d_pool, (size_t)st.walk_blocks * C_WAVES * C_NODES * sizeof(CNode))) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_pbase, ((size_t)nq + 1) * 4 + ((size_t)nq + 1) * 8 + (size_t)nq * sizeof(QState) + 64)) return DP_ERR_HIP;
     // capacities: what the buffers hold now (at least a floor); a run that needs more reports its totals and is repeated
