@@ -1092,6 +1092,7 @@ int OverlapRun::roundPrepareAndScan() {
         error = sl.error;
         return rc;
     }
+    sl.lap->setDeviceChunking(false);  // (the survivors of this scan are exchanged: their segments are wanted on the host)
     cur.st.n_seeds = curPlan->seedMap.size();
     double t1 = now();
     cur.st.t_prepare = t1 - t0;

@@ -1,0 +1,40 @@
+"""bench.py as the driver runs it, on the one GPU of the test box: the single-GPU line and - with the two test hooks that let two
+ranks share a GPU (DP_BENCH_SAME_DEVICE=1, exchange over gloo) - both multi-GPU decompositions as real processes under
+torch.distributed.run.  Every run hashes a whole config-2 job against the oracle fixture (parity.paf_sha256_matches_oracle_fixture)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(out):
+    return json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_single_gpu_contract():
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-rounds", "0", "--scan-leg-rounds", "0",
+                        "--dense-leg-rounds", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["higher_is_better"] is True
+    assert d["metric"].startswith("overlaps/sec") and d["unit"] == "overlaps/s" and d["vs_baseline"] is None
+    assert d["parity"]["paf_sha256_matches_oracle_fixture"] is True and d["parity"]["jobs_with_equal_line_count"] == 2
+    assert d["value"] > 1e6 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert "workload" in d["config"]
+
+
+@pytest.mark.parametrize("mode", ["round", "scan-shard"])
+def test_bench_two_ranks_sharing_the_gpu(mode):
+    env = dict(os.environ, DP_BENCH_SAME_DEVICE="1", DP_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-rounds", "0", "--mode", mode,
+                        "--slots", "4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["parity"]["paf_sha256_matches_oracle_fixture"] is True
