@@ -191,6 +191,8 @@ struct SeedIndex {
     }
     void grow();
     void addSeedKmer(uint32_t kmer);                                     // seeds.go:132-141
+    int32_t addSeedKmerId(uint32_t kmer);                                // ... returning the seed's id (new or existing)
+    std::vector<int32_t> rcPair;                                         // commitSeeds: id of each seed's reverse complement
     void addSeeds(const char* s, i64 len, int minSeeds, ValueView ranks);  // AddSeeds :62-156
     // q (may be null): the window's quality bytes (seq.Quality(), seeds.go:73): value *= q[nextIndex - k/2] (:99-101)
     void selectSeeds(const char* s, i64 len, int minSeeds, ValueView ranks, uint32_t* topN, bool checkIndex,

@@ -250,6 +250,7 @@ SeedIndex::SeedIndex(int k_, int preBits) : k(k_), preShift((uint32_t)(32 - preB
 
 void SeedIndex::reset() {
     hashValid = true;
+    rcPair.clear();
     std::fill(hkeys.begin(), hkeys.end(), 0xffffffffu);
     std::fill(pre.begin(), pre.end(), 0);
     seedMap.clear();
@@ -263,6 +264,7 @@ void SeedIndex::reset() {
 void SeedIndex::adopt(const std::vector<uint32_t>& seeds, const std::vector<int32_t>& rcTable) {
     seedMap = seeds;
     rcOf = rcTable;
+    rcPair.clear();
     hashValid = false;
     sequences.clear();
     refs.clear();
@@ -295,20 +297,25 @@ void SeedIndex::grow() {
     }
 }
 
-void SeedIndex::addSeedKmer(uint32_t kmer) {
+int32_t SeedIndex::addSeedKmerId(uint32_t kmer) {
     if (!hashValid) rebuildHash();
     if (!rcOf.empty()) rcOf.clear();
-    if (!isSeed(kmer)) {
-        if ((seedMap.size() + 1) * 2 > hkeys.size()) grow();
-        uint32_t h = hash(kmer) & hmask;
-        while (hkeys[h] != 0xffffffffu) h = (h + 1) & hmask;
-        hkeys[h] = kmer;
-        hvals[h] = (int32_t)seedMap.size();
-        seedMap.push_back(kmer);
-        const uint32_t b = preHash(kmer);
-        pre[b >> 5] |= 1u << (b & 31);
+    const uint32_t b = preHash(kmer);
+    if ((pre[b >> 5] >> (b & 31)) & 1) {
+        const int32_t id = find(kmer);
+        if (id >= 0) return id;
     }
+    if ((seedMap.size() + 1) * 2 > hkeys.size()) grow();
+    uint32_t h = hash(kmer) & hmask;
+    while (hkeys[h] != 0xffffffffu) h = (h + 1) & hmask;
+    hkeys[h] = kmer;
+    const int32_t id = (int32_t)seedMap.size();
+    hvals[h] = id;
+    seedMap.push_back(kmer);
+    pre[b >> 5] |= 1u << (b & 31);
+    return id;
 }
+void SeedIndex::addSeedKmer(uint32_t kmer) { addSeedKmerId(kmer); }
 
 // ---- touchesSeed on a window's evaluated k-mers
 namespace {
@@ -386,6 +393,18 @@ bool SeedIndex::touchesSeedWith(int isa, const uint32_t* kmers, uint32_t n) cons
 }
 
 void SeedIndex::buildRcTable() {
+    if (rcPair.size() == seedMap.size() && hashValid) {  // (all seeds came in through commitSeeds)
+        bool complete = true;
+        for (int32_t v : rcPair)
+            if (v < 0) {
+                complete = false;
+                break;
+            }
+        if (complete) {
+            rcOf = rcPair;
+            return;
+        }
+    }
     rcOf.clear();
     std::vector<int32_t> t(seedMap.size());
     for (size_t i = 0; i < seedMap.size(); i++) t[i] = seedOfRcKmer((int32_t)i);
@@ -511,9 +530,13 @@ bool SeedIndex::touchesSeed(const char* s, i64 L) const {
 }
 
 void SeedIndex::commitSeeds(const uint32_t* topN, int n) {  // seeds.go:130-154
+    // every seed enters together with its reverse complement: the seed -> reverse-complement-seed table falls out of the ids
     for (int i = 0; i < n; i++) {
-        addSeedKmer(topN[i]);
-        addSeedKmer(reverseComplementKmer(topN[i], k));
+        const int32_t a = addSeedKmerId(topN[i]);
+        const int32_t b = addSeedKmerId(reverseComplementKmer(topN[i], k));
+        if (rcPair.size() < seedMap.size()) rcPair.resize(seedMap.size(), -1);
+        rcPair[(size_t)a] = b;
+        rcPair[(size_t)b] = a;
     }
 }
 
