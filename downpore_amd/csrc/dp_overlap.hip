@@ -1688,12 +1688,15 @@ struct ChainArgs {
     u64 sint_cap;
     uint32_t int_cap;
     uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [4..5] algorithmic bytes (u64)
+    uint32_t* qdone;     // [nq] pairs of the query a speculative pass has finished (resolve fused into it), or nullptr
 };
 
 // per-query candidate counts -> pair / scratch offsets (one workgroup; a round has a few hundred to a few ten thousand queries)
 __global__ __launch_bounds__(1024) void pair_scan_kernel(const uint32_t* __restrict__ qcnt, const u64* __restrict__ qoff, uint32_t nq,
-                                                          uint32_t* __restrict__ pbase, u64* __restrict__ ibase, u64* __restrict__ totals) {
+                                                          uint32_t* __restrict__ pbase, u64* __restrict__ ibase, u64* __restrict__ totals,
+                                                          uint32_t* __restrict__ qdone) {
     __shared__ u64 shp[1024], shi[1024];
+    for (uint32_t q = threadIdx.x; q < nq; q += 1024) qdone[q] = 0;
     const uint32_t per = (nq + 1023) / 1024;
     const uint32_t lo = min(nq, threadIdx.x * per), hi = min(nq, lo + per);
     u64 sp = 0, si = 0;
@@ -1972,6 +1975,8 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_walk_kernel(const ChainArg
     }
 }
 
+__device__ void chain_resolve_query(const ChainArgs& A, uint32_t q, int lane);
+
 // one wave per open pair: prefilter + chain with the minMatches its query has reached; stored as a proposal
 #define S_WAVES 4
 __global__ __launch_bounds__(64 * S_WAVES) void chain_spec_kernel(const ChainArgs A, const u64* __restrict__ totals) {
@@ -1985,6 +1990,7 @@ __global__ __launch_bounds__(64 * S_WAVES) void chain_spec_kernel(const ChainArg
     const uint32_t total = (uint32_t)min(totals[0], (u64)A.pair_cap);
     for (uint32_t p = gw; p < total; p += waves) {
         const uint32_t q = A.pq[p];
+        do {  // (a `continue` below leaves this block, not the loop: every pair reports to its query - see the end of the loop body)
         const uint32_t i = p - A.pbase[q];
         if (i >= A.qcnt[q]) continue;  // (beyond a capped query)
         const QState st = A.qstate[q];
@@ -2016,103 +2022,127 @@ __global__ __launch_bounds__(64 * S_WAVES) void chain_spec_kernel(const ChainArg
             A.pspec[p] = o;
         }
         __builtin_amdgcn_wave_barrier();
+        } while (0);
+        if (A.qdone) {
+            // the resolve step of the query, by whichever wave finishes the last of its pairs (instead of a launch of its own
+            // after every pass): each pair counts itself in once its proposal and chain are out (release), the wave that counts
+            // the last one sees them all (acquire) and replays the ratchet.  qdone[q] goes back to 0 for the next pass.
+            uint32_t last = 0;
+            if (lane == 0) {
+                const uint32_t slots = A.pbase[q + 1] - A.pbase[q];
+                const uint32_t seen = __hip_atomic_fetch_add(&A.qdone[q], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+                last = seen == slots ? 1u : 0u;
+                if (last) __hip_atomic_store(&A.qdone[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            last = (uint32_t)__shfl((int)last, 0, 64);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                chain_resolve_query(A, q, lane);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 
 // One wave per query: replays the ratchet over the proposals of its open pairs - 64 pairs at a time, one per lane, the
 // serial part is a register loop - and makes every pair up to the first one that needs another minMatches final: packed
 // chain, record, algorithmic bytes.  Everything that touches memory is lane-parallel.
+// One query of the resolve step: replays the ratchet over the proposals of its open pairs - 64 pairs at a time, one per lane, the
+// serial part is a register loop - and makes every pair up to the first one that needs another minMatches final: packed
+// chain, record, algorithmic bytes.  Everything that touches memory is lane-parallel.
+__device__ void chain_resolve_query(const ChainArgs& A, uint32_t q, int lane) {
+    const uint32_t cnt = A.qcnt[q];
+    if (cnt == 0) return;
+    const QState st = A.qstate[q];
+    int mm = RFL(st.mm);
+    uint32_t next = (uint32_t)RFL((int)st.next);
+    if (next >= cnt) return;
+    const uint32_t pb = A.pbase[q];
+    const int aN = RFL((int)(A.qoff[q + 1] - A.qoff[q]));
+    const uint32_t nSeeds = (uint32_t)aN / 2;
+    const u64 ib = A.ibase[q];
+    if ((u64)pb + cnt > (u64)A.pair_cap || ib + (u64)cnt * nSeeds > A.sint_cap) return;  // (flagged by walk 0)
+    u64 algBytes = 0;
+    bool stopped = false;
+    while (next < cnt && !stopped) {
+        const uint32_t i = next + lane;
+        const bool valid = i < cnt;
+        PSpec sp = {-1, -1, 0, 0};
+        uint32_t t = 0;
+        if (valid) {
+            sp = A.pspec[pb + i];
+            t = A.clist[pb + i];
+        }
+        const int nHere = (int)min(64u, cnt - next);
+        int stop = nHere;  // lanes [0, stop) become final
+        u64 chainedMask = 0, hitMask = 0;
+        for (int l = 0; l < nHere; l++) {
+            const int c = RL(sp.c, l);
+            if (c < 0) {
+                stop = l;
+                break;
+            }
+            if (c < mm) continue;
+            if (RL(sp.mm, l) != mm) {
+                stop = l;
+                break;
+            }
+            chainedMask |= 1ull << l;
+            const int len = RL(sp.len, l);
+            if (len > 0) {
+                hitMask |= 1ull << l;
+                if (len * 2 > mm * 3) mm = (len * 2) / 3;  // ratchet, overlap.go:380-382
+            }
+        }
+        const bool fin = lane < stop;
+        const bool hit = fin && ((hitMask >> lane) & 1ull);
+        const int myLen = hit ? sp.len : 0;
+        const int incl = wave_incl_sum(myLen);
+        const int totalLen = __shfl(incl, 63, 64);
+        uint32_t off0 = 0;
+        if (totalLen > 0) {
+            if (lane == 0) off0 = atomicAdd(&A.cursor[0], (uint32_t)totalLen);
+            off0 = (uint32_t)__shfl((int)off0, 0, 64);
+        }
+        const uint32_t myOff = off0 + (uint32_t)(incl - myLen);
+        const bool room = (u64)off0 + (u64)totalLen <= (u64)A.int_cap;
+        if (!room && lane == 0) A.cursor[3] = 1;
+        if (fin) {
+            int wlen = 0;
+            if (hit && room) {
+                const int32_t* ca = A.sa + ib + (u64)i * nSeeds;
+                const int32_t* cb = A.sb + ib + (u64)i * nSeeds;
+                for (int x = 0; x < myLen; x++) {
+                    A.ma[myOff + x] = ca[x];
+                    A.mb[myOff + x] = cb[x];
+                }
+                wlen = myLen;
+            }
+            MRec rec = {q, t, hit && room ? myOff : 0u, (uint32_t)wlen};
+            A.recs[pb + i] = rec;
+            algBytes += 16ull * A.SW + 8ull * (u64)wlen;
+            if ((chainedMask >> lane) & 1ull) algBytes += 4ull * (u64)(aN + (int)(2 * A.refs[t].n_seeds + 1));
+        }
+        next += (uint32_t)stop;
+        stopped = stop < nHere;
+    }
+    // algBytes is per lane here: reduce
+    unsigned long long ab = algBytes;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ab += __shfl_xor(ab, d, 64);
+    if (lane == 0) {
+        QState o = {mm, next};
+        A.qstate[q] = o;
+        if (ab) atomicAdd((unsigned long long*)(A.cursor + 4), ab);
+        if (next < cnt) atomicAdd(&A.cursor[9 + A.pass], 1u);  // still open: the next pass has work
+    }
+}
+
 __global__ __launch_bounds__(256) void chain_resolve_kernel(const ChainArgs A) {
     const int lane = dp_lane();
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     if (A.cursor[3] != 0 || A.cursor[8 + A.pass] == 0) return;  // buffers overflowed (stage is repeated) / no query was open before this pass
-    for (uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q < A.nq; q += waves) {
-        const uint32_t cnt = A.qcnt[q];
-        if (cnt == 0) continue;
-        const QState st = A.qstate[q];
-        int mm = RFL(st.mm);
-        uint32_t next = (uint32_t)RFL((int)st.next);
-        if (next >= cnt) continue;
-        const uint32_t pb = A.pbase[q];
-        const int aN = RFL((int)(A.qoff[q + 1] - A.qoff[q]));
-        const uint32_t nSeeds = (uint32_t)aN / 2;
-        const u64 ib = A.ibase[q];
-        if ((u64)pb + cnt > (u64)A.pair_cap || ib + (u64)cnt * nSeeds > A.sint_cap) continue;  // (flagged by walk 0)
-        u64 algBytes = 0;
-        bool stopped = false;
-        while (next < cnt && !stopped) {
-            const uint32_t i = next + lane;
-            const bool valid = i < cnt;
-            PSpec sp = {-1, -1, 0, 0};
-            uint32_t t = 0;
-            if (valid) {
-                sp = A.pspec[pb + i];
-                t = A.clist[pb + i];
-            }
-            const int nHere = (int)min(64u, cnt - next);
-            int stop = nHere;  // lanes [0, stop) become final
-            u64 chainedMask = 0, hitMask = 0;
-            for (int l = 0; l < nHere; l++) {
-                const int c = RL(sp.c, l);
-                if (c < 0) {
-                    stop = l;
-                    break;
-                }
-                if (c < mm) continue;
-                if (RL(sp.mm, l) != mm) {
-                    stop = l;
-                    break;
-                }
-                chainedMask |= 1ull << l;
-                const int len = RL(sp.len, l);
-                if (len > 0) {
-                    hitMask |= 1ull << l;
-                    if (len * 2 > mm * 3) mm = (len * 2) / 3;  // ratchet, overlap.go:380-382
-                }
-            }
-            const bool fin = lane < stop;
-            const bool hit = fin && ((hitMask >> lane) & 1ull);
-            const int myLen = hit ? sp.len : 0;
-            const int incl = wave_incl_sum(myLen);
-            const int totalLen = __shfl(incl, 63, 64);
-            uint32_t off0 = 0;
-            if (totalLen > 0) {
-                if (lane == 0) off0 = atomicAdd(&A.cursor[0], (uint32_t)totalLen);
-                off0 = (uint32_t)__shfl((int)off0, 0, 64);
-            }
-            const uint32_t myOff = off0 + (uint32_t)(incl - myLen);
-            const bool room = (u64)off0 + (u64)totalLen <= (u64)A.int_cap;
-            if (!room && lane == 0) A.cursor[3] = 1;
-            if (fin) {
-                int wlen = 0;
-                if (hit && room) {
-                    const int32_t* ca = A.sa + ib + (u64)i * nSeeds;
-                    const int32_t* cb = A.sb + ib + (u64)i * nSeeds;
-                    for (int x = 0; x < myLen; x++) {
-                        A.ma[myOff + x] = ca[x];
-                        A.mb[myOff + x] = cb[x];
-                    }
-                    wlen = myLen;
-                }
-                MRec rec = {q, t, hit && room ? myOff : 0u, (uint32_t)wlen};
-                A.recs[pb + i] = rec;
-                algBytes += 16ull * A.SW + 8ull * (u64)wlen;
-                if ((chainedMask >> lane) & 1ull) algBytes += 4ull * (u64)(aN + (int)(2 * A.refs[t].n_seeds + 1));
-            }
-            next += (uint32_t)stop;
-            stopped = stop < nHere;
-        }
-        // algBytes is per lane here: reduce
-        unsigned long long ab = algBytes;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) ab += __shfl_xor(ab, d, 64);
-        if (lane == 0) {
-            QState o = {mm, next};
-            A.qstate[q] = o;
-            if (ab) atomicAdd((unsigned long long*)(A.cursor + 4), ab);
-            if (next < cnt) atomicAdd(&A.cursor[9 + A.pass], 1u);  // still open: the next pass has work
-        }
-    }
+    for (uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q < A.nq; q += waves) chain_resolve_query(A, q, lane);
 }
 
 // Uploads the queries, builds their seed bitsets and runs the index query (Matches -> GetSharedIDs) for all of them.
@@ -2219,6 +2249,15 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     u64* d_ibase = (u64*)ctx->d_pbase.p;  // (8-byte aligned first)
     uint32_t* d_pbase = (uint32_t*)(d_ibase + nq + 1);
     QState* d_qstate = (QState*)(d_pbase + nq + 1 + ((nq + 1) & 1));
+    uint32_t* d_qdone = (uint32_t*)(d_qstate + nq);
+    // DP_CHAIN_FUSE=1: the resolve step inside the speculative kernel (last wave of a query) instead of a launch of its own.
+    // Bit-identical, three launches fewer per round - and twice as slow (0.73 against 0.38 ms per round): every pair then pays an
+    // agent-scope release and the resolving wave an acquire, i.e. L2 write-backs and invalidates across the eight XCDs, seven
+    // thousand times per pass.  Off.
+    static const bool fuse_resolve = [] {
+        const char* e = getenv("DP_CHAIN_FUSE");
+        return e && e[0] == '1';
+    }();
     {
         // (a stage left pending is read by the consensus kernel before anybody knows whether it fitted its buffers: records the
         // stage did not write must at least be harmless - all-zero when the buffer is new, those of an earlier round otherwise)
@@ -2270,15 +2309,16 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     A.sint_cap = st.sint_cap;
     A.int_cap = st.int_cap;
     A.cursor = d_cur;
+    A.qdone = fuse_resolve ? d_qdone : nullptr;
     if (st.attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 128, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
     DP_HIP(dp_mark(ctx, 6));
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)st.d_qcnt, ctx->qoff_dev, nq, d_pbase, d_ibase,
-                       d_totals);
+                       d_totals, d_qdone);
     hipLaunchKernelGGL(chain_walk_kernel, dim3(st.walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 0);
     for (int ps = 0; ps < st.passes; ps++) {
         A.pass = ps;
         hipLaunchKernelGGL(chain_spec_kernel, dim3(st.spec_blocks), dim3(64 * S_WAVES), 0, ctx->stream, A, (const u64*)d_totals);
-        hipLaunchKernelGGL(chain_resolve_kernel, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), 0, ctx->stream, A);
+        if (!fuse_resolve) hipLaunchKernelGGL(chain_resolve_kernel, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), 0, ctx->stream, A);
     }
     A.pass = st.passes;
     hipLaunchKernelGGL(chain_walk_kernel, dim3(st.walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 2);
@@ -2416,7 +2456,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     st.spec_blocks = 1024;  // 4096 persistent waves, 16 per CU: what CSlim's 8.5 KB per wave lets a CU hold
     if (const char* e = getenv("DP_SPEC_BLOCKS")) st.spec_blocks = (uint32_t)std::max(1, atoi(e));
     if (dev_reserve(ctx, ctx->d_pool, (size_t)st.walk_blocks * C_WAVES * C_NODES * sizeof(CNode))) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_pbase, ((size_t)nq + 1) * 4 + ((size_t)nq + 1) * 8 + (size_t)nq * sizeof(QState) + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_pbase, ((size_t)nq + 1) * 4 + ((size_t)nq + 1) * 8 + (size_t)nq * sizeof(QState) + (size_t)nq * 4 + 128)) return DP_ERR_HIP;
     // capacities: what the buffers hold now (at least a floor); a run that needs more reports its totals and is repeated
     // with larger buffers (deterministic: same results)
     st.want_pairs = std::max<uint64_t>(1u << 14, ctx->d_mrec.cap / sizeof(MRec));
