@@ -377,7 +377,9 @@ void Overlapper::chunkAndAdd(SeedSeq* s, uint64_t segBase, Arena& ar, std::vecto
 int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
     double tp0 = now();
     chunksOnDevice_ = false;
-    if (deviceChunkWanted_ && all.deviceResident && &all == lastLocal_) {
+    // (minSeeds <= 5: the reference's walk backs up as many seeds as a chunk holds - no bound on the number of chunks to size the
+    // device buffers from; the host loop below does what the reference does)
+    if (deviceChunkWanted_ && minSeeds_ > 5 && all.deviceResident && &all == lastLocal_) {
         // A12 + A13 on the device: the survivors of this context's own scan, still in its scan buffer
         index_.sequences.clear();
         index_.refs.clear();
