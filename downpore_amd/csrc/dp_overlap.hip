@@ -477,30 +477,48 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
     const uint32_t ns = (uint32_t)((qoff[q + 1] - qoff[q]) / 2);
     if (wave == 0) {
 
-    // --- Matches(): filtered list of posting sets (seeds/seeds.go:336-347); sequential in the accepted-seed chain
+    // --- Matches(): filtered list of posting sets (seeds/seeds.go:336-347).  The reference walks the query's seeds in order,
+    // accepts a seed that differs from the last ACCEPTED one and whose set does not hold every sequence.  A seed that passes the
+    // second test is rejected only when it equals the last accepted seed, so the last accepted seed always equals the previous
+    // seed that passed the second test: "differs from the previous passing seed" decides, which 64 lanes test at once (with 150+
+    // seeds per query in the dense regime the one-lane walk and its dependent loads were most of this kernel's time).
     uint32_t n = 0, start = 0xffffffffu, end = 0, status = 0;
-    if (lane == 0) {
-        int32_t prevSeed = -1;
-        for (uint32_t i = 0; i < ns; i++) {
-            int32_t seed = seg[2 * i + 1];
-            if (seed != prevSeed && pmeta[4 * (uint32_t)seed] < n_seqs) {
-                if (n < Q_MAXSETS) {
-                    S.setid[n] = (uint32_t)seed;
-                    S.lens[n] = pmeta[4 * (uint32_t)seed + 3];
-                    start = min(start, pmeta[4 * (uint32_t)seed + 1]);
-                    end = max(end, pmeta[4 * (uint32_t)seed + 2]);
-                    n++;
-                } else {
-                    status |= 1;
-                }
-                prevSeed = seed;
+    {
+        const u64 lanesBelow = (1ull << lane) - 1ull;
+        int32_t carrySeed = -1;
+        for (uint32_t base = 0; base < ns; base += 64) {
+            const uint32_t i = base + (uint32_t)lane;
+            const bool valid = i < ns;
+            const int32_t seed = valid ? seg[2 * i + 1] : -1;
+            uint4 pm = make_uint4(0xffffffffu, 0, 0, 0);
+            if (valid) pm = *(const uint4*)(pmeta + 4 * (size_t)(uint32_t)seed);
+            const bool f = valid && pm.x < n_seqs;
+            const u64 fmask = __ballot(f);
+            const u64 below = fmask & lanesBelow;
+            const int src = below ? 63 - __builtin_clzll(below) : 0;
+            const int32_t fromLane = __shfl(seed, src, 64);
+            const int32_t prevPassing = below ? fromLane : carrySeed;
+            const bool acc = f && seed != prevPassing;
+            const u64 amask = __ballot(acc);
+            const uint32_t pos = n + (uint32_t)__popcll(amask & lanesBelow);
+            if (acc && pos < Q_MAXSETS) {
+                S.setid[pos] = (uint32_t)seed;
+                S.lens[pos] = pm.w;
+                start = min(start, pm.y);
+                end = max(end, pm.z);
             }
+            const uint32_t cnt = (uint32_t)__popcll(amask);
+            if (n + cnt > Q_MAXSETS) status |= 1;
+            n = min((uint32_t)Q_MAXSETS, n + cnt);
+            if (fmask) carrySeed = __shfl(seed, 63 - __builtin_clzll(fmask), 64);
         }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            start = min(start, (uint32_t)__shfl_xor((int)start, d, 64));
+            end = max(end, (uint32_t)__shfl_xor((int)end, d, 64));
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    n = __shfl(n, 0, 64);
-    start = __shfl(start, 0, 64);
-    end = __shfl(end, 0, 64);
-    status = __shfl(status, 0, 64);
     int minCount = 0;
     if (n >= 5 && n < mc_n) minCount = mc[n];
     if (lane == 0) {
@@ -629,6 +647,17 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
             // four posting words in flight per lane: a set whose window ends before this word contributes 0, which leaves the
             // ladder as it is (the order of the words does not matter for the 4- and 8-ladders)
             uint32_t j = 0;
+            for (; j + 8 <= n; j += 8) {  // eight posting words in flight per lane
+                u64 m[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const bool a = S.lens[j + u] > iw;
+                    m[u] = a ? posting[(uint64_t)S.setid[j + u] * W + iw] : 0ull;
+                    gathered += (u64)a;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { Q_STEP(m[u]) }
+            }
             for (; j + 4 <= n; j += 4) {
                 const bool a0 = S.lens[j] > iw, a1 = S.lens[j + 1] > iw, a2 = S.lens[j + 2] > iw, a3 = S.lens[j + 3] > iw;
                 const u64 m0 = a0 ? posting[(uint64_t)S.setid[j] * W + iw] : 0ull;
