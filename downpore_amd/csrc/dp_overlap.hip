@@ -416,20 +416,6 @@ extern "C" int dp_index_seedset_row(dp_ctx* ctx, uint32_t seq, u64* words, uint3
 // ---------------------------------------------------------------------------------------------------------------
 // queries: seed bitsets of the queries (matchWorker's seedSet, overlap/overlap.go:351-354)
 
-__global__ void qsets_kernel(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff, uint32_t nq,
-                             u64* __restrict__ qsets, uint32_t SW) {
-    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = dp_lane();
-    for (uint32_t q = gw; q < nq; q += waves) {
-        uint32_t ns = (uint32_t)((qoff[q + 1] - qoff[q]) / 2);
-        for (uint32_t i = lane; i < ns; i += 64) {
-            uint32_t seed = (uint32_t)qsegs[qoff[q] + 2 * (uint64_t)i + 1];
-            atomicOr(&qsets[(uint64_t)q * SW + (seed >> 6)], 1ull << (seed & 63));
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // A14 + A5: SeedIndex.Matches -> util.GetSharedIDs
 
@@ -456,7 +442,8 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
                                                              const int32_t* __restrict__ mc, uint32_t mc_n,
                                                              u64* __restrict__ cand, uint32_t* __restrict__ qmeta,
                                                              u64* __restrict__ words_read, uint32_t* __restrict__ qcnt,
-                                                             uint32_t word_base, const uint32_t* __restrict__ n_seqs_dev) {
+                                                             uint32_t word_base, const uint32_t* __restrict__ n_seqs_dev,
+                                                             u64* __restrict__ qsets, uint32_t SW) {
     if (n_seqs_dev) n_seqs = *n_seqs_dev;  // (chunks made on the device: the host only knows an upper bound)
     // word_base: a shard of a larger index (dp_index_set_global) holds the words [word_base, word_base + W) of every set; pmeta
     // and n_seqs then describe the WHOLE sets (global windows, counts), so the filter, the early-return cut and the gather
@@ -475,6 +462,13 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
     }
     const int32_t* seg = qsegs + qoff[q];
     const uint32_t ns = (uint32_t)((qoff[q + 1] - qoff[q]) / 2);
+    // the query's own seed set (what the chaining stage's prefilter intersects with the targets' sets); its row was zeroed with
+    // the other per-round buffers.  Waves 1.. do it while wave 0 prepares the set list.
+    if (qsets && (wave != 0 || Q_WAVES == 1))
+        for (uint32_t i = threadIdx.x - (Q_WAVES == 1 ? 0 : 64); i < ns; i += 64 * (Q_WAVES == 1 ? 1 : Q_WAVES - 1)) {
+            const uint32_t seed = (uint32_t)seg[2 * i + 1];
+            atomicOr(&qsets[(uint64_t)q * SW + (seed >> 6)], 1ull << (seed & 63));
+        }
     if (wave == 0) {
 
     // --- Matches(): filtered list of posting sets (seeds/seeds.go:336-347).  The reference walks the query's seeds in order,
@@ -2217,15 +2211,12 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
                                      {ctx->d_cursor.p, 128}};
         if (int rc = dp_zero_regions(ctx, z, 4)) return rc;
     }
-    hipLaunchKernelGGL(qsets_kernel, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), 0, ctx->stream,
-                       ctx->qsegs_dev, ctx->qoff_dev, nq, (u64*)ctx->d_qsets.p, SW);
-    DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 4));
     hipLaunchKernelGGL(query_kernel, dim3(nq), dim3(64 * Q_WAVES), 0, ctx->stream,
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
-                       ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr);
+                       ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 5));
 
