@@ -7,6 +7,7 @@
 //
 // This code does not include, link or call anything under oracle/.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -328,8 +329,13 @@ class WindowCache {
     // Blocks until window w has been produced.  The pointers stay valid until release() passes w's read.
     bool get(uint32_t w, const uint32_t** spec, const uint32_t** kmers, std::string* err);
     void release(size_t belowRead);  // reads below are committed: their windows will not be asked for again
+    // Seeds window w adds to an index none of its k-mers touches (its cached selection and the reverse complements, without
+    // repeats), or -1 while w has not been produced: what a planner lane needs to guess where the plan in front of it ends.
+    int seedsOf(uint32_t w) const { return w < producedWins.load(std::memory_order_acquire) ? (int)seedCount[w] : -1; }
 
    private:
+    std::vector<uint16_t> seedCount;
+    std::atomic<uint32_t> producedWins{0};
     void producer();
     struct Impl;
     std::unique_ptr<Impl> d;
@@ -452,10 +458,17 @@ class Planner {
     uint64_t ignoreEpoch();  // bumped whenever a flag is set
     // rounds < round are committed; `round` starts at firstInOfRound (the committed firstSequence)
     void dropBefore(i64 round, i64 firstInOfRound);
+    // planner lanes (threads that compute consecutive plans concurrently, each from a guess of where its predecessor ends)
+    static int lanesFor(int world, int slots);
+    void setLanes(int n);  // grows only
 
    private:
-    std::shared_ptr<RoundPlan> compute(i64 round, i64 firstIn);
-    void threadMain();
+    std::shared_ptr<RoundPlan> compute(i64 round, i64 firstIn, SeedIndex& index);
+    void laneMain(size_t lane);
+    bool chainHead(i64* round, i64* firstIn) const;
+    void promote();
+    bool nextWork(i64* round, i64* firstIn) const;
+    i64 predictFirstOut(i64 firstIn) const;
     struct Impl;
     std::unique_ptr<Impl> d;
 };
@@ -639,6 +652,9 @@ struct OverlapRun {
     std::deque<i64> redo_;
     i64 nextIssue_ = 0;
     int rank_ = 0, world_ = 1;
+   public:
+    i64 roundLimit = -1;  // step() commits no round >= this (-1: no limit)
+   private:
     int inflight_ = 0, workerRc_ = 0;
     bool stopWorkers_ = false, issueEnd_ = false, draining_ = false;
     std::string workerErr_;

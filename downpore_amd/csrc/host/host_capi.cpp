@@ -362,8 +362,15 @@ int dph_overlap_step(void* hh) {
     else if (rc > 0) h->addPaf(h->run.paf);
     return rc;
 }
+// step() stops committing at round n (tests that compare the first n rounds with a fixture); -1 lifts the limit
+void dph_overlap_set_round_limit(void* hh, int64_t n) { ((OverlapH*)hh)->run.roundLimit = n; }
 int64_t dph_overlap_round(void* hh) { return ((OverlapH*)hh)->run.round; }
 void dph_profile_print() { profilePrint(); }
+// process-wide planner counters (tests): 0 plans computed, 1 computed plans thrown away (stale flags, or started from a wrong
+// guess of where the plan before them ends), 2 finished plans erased by a commit's flags
+int64_t dph_planner_counter(int which) {
+    return which == 0 ? g_prof.planComputes.load() : which == 1 ? g_prof.planDiscarded.load() : which == 2 ? g_prof.planErased.load() : -1;
+}
 int64_t dph_overlap_step_lines(void* hh) { return ((OverlapH*)hh)->run.pafLines; }  // PAF lines of the last step
 // host-logic test hook: the value table (commands/overlap.go:55-92) from a k-mer histogram; counts is overwritten with the
 // merged forward + reverse-complement counts like the reference's in-place loop

@@ -54,6 +54,7 @@ WindowCache::WindowCache(dp_ctx* ctx, const ReadSet& reads, i64 overlap, int k, 
         }
     }
     first[reads.size()] = (uint32_t)wins.size();
+    seedCount.assign(wins.size(), 0);
     const i64 blocks = maxLen - 2 * k > 0 ? (maxLen - 2 * k + 3 * k - 1) / (3 * k) : 0;
     stride = (uint32_t)std::max<i64>(1, blocks * k);
     d->nChunks = (uint32_t)((wins.size() + Impl::CW - 1) / Impl::CW);
@@ -80,6 +81,7 @@ void WindowCache::producer() {
             if (d->stop) return;
             if (c < d->released) {  // everything in it is committed already (a job restarted far ahead): nothing to produce
                 d->produced = c + 1;
+                producedWins.store((uint32_t)std::min(wins.size(), ((size_t)c + 1) * Impl::CW), std::memory_order_release);
                 d->cvProduced.notify_all();
                 continue;
             }
@@ -101,7 +103,19 @@ void WindowCache::producer() {
         ch->kmers.resize(n * (size_t)stride);
         const uint32_t* ev = nullptr;
         const int rc = dp_select_windows(d->ctx, items.data(), (uint32_t)n, d->k, numSeeds, ch->spec.data(), &ev, stride);
-        if (rc == 0) memcpy(ch->kmers.data(), ev, n * (size_t)stride * 4);
+        if (rc == 0) {
+            memcpy(ch->kmers.data(), ev, n * (size_t)stride * 4);
+            std::vector<uint32_t> both((size_t)numSeeds * 2);
+            for (size_t i = 0; i < n; i++) {  // commitSeeds enters every selected k-mer and its reverse complement
+                const uint32_t* sp = ch->spec.data() + i * (size_t)numSeeds;
+                for (int j = 0; j < numSeeds; j++) {
+                    both[(size_t)j * 2] = sp[j];
+                    both[(size_t)j * 2 + 1] = reverseComplementKmer(sp[j], d->k);
+                }
+                std::sort(both.begin(), both.end());
+                seedCount[w0 + i] = (uint16_t)(std::unique(both.begin(), both.end()) - both.begin());
+            }
+        }
         std::lock_guard<std::mutex> lk(d->mu);
         if (rc != 0) {
             d->failed = true;
@@ -111,6 +125,7 @@ void WindowCache::producer() {
         }
         d->live[c] = std::move(ch);
         d->produced = c + 1;
+        producedWins.store((uint32_t)w1, std::memory_order_release);
         d->cvProduced.notify_all();
     }
 }
@@ -161,28 +176,65 @@ struct Planner::Impl {
     bool threaded;
     dp_ctx* selCtx;
     WindowCache* winCache = nullptr;
-    SeedIndex index;  // selection-side seed set of the plan being computed
+    SeedIndex index;  // selection-side seed set of the plan being computed (inline mode)
     std::mutex mu;
     std::mutex computeMu;     // inline mode: one caller at a time extends the chain (the selection index is shared)
     std::condition_variable cv;
-    std::map<i64, std::shared_ptr<RoundPlan>> cache;
+    std::map<i64, std::shared_ptr<RoundPlan>> cache;  // the confirmed chain: contiguous from `base`
+    // plans computed ahead of their predecessor, by (round, firstSequence they assumed): they join the chain when the
+    // predecessor's firstOut turns out to be that firstSequence, and are dropped otherwise
+    std::map<std::pair<i64, i64>, std::shared_ptr<RoundPlan>> pending;
     i64 wantUpTo = -1;        // prefetch target (highest requested round + depth)
     i64 base = 0;             // rounds below are committed and gone
     i64 startFirstIn = 0;     // firstSequence of round `base` (the committed state): the chain can always restart here
     uint64_t epoch = 0;       // bumped whenever an ignore flag is set
-    i64 epochMaxId = -1;      // largest read id flagged since the running compute started (-1: none)
     bool stop = false;
+    bool fromCache = false;   // plans come from the window cache (QueryEdges with the cache's numSeeds)
     long testDelayUs = 0;     // DPH_TEST_PLAN_DELAY_US: sleep before every compute (tests/test_planner_epoch.py)
-    std::thread th;
+    struct Lane {
+        std::thread th;
+        SeedIndex index;
+        bool busy = false;
+        i64 round = -1, firstIn = -1;
+        i64 maxFlagged = -1;  // largest read id flagged since this lane's compute started (-1: none)
+        Lane(int k) : index(k, 21) {}
+    };
+    std::vector<std::unique_ptr<Lane>> lanes;
     Impl(ReadSet& r, const OverlapParams& pp, ValueView v, bool t, dp_ctx* sc)
         : reads(r), p(pp), values(v), threaded(t), selCtx(sc), index(pp.k, 21) {}
 };
 
+// Lanes: the plan of round r+1 starts where the plan of round r ends, and where that is is known with certainty only when
+// r's plan is finished - but it can be guessed in a microsecond: the budget test (overlap.go:57-60) looks at the number of
+// seeds once per read, and an untouched window adds exactly the seeds of its cached selection (WindowCache::seedsOf; a
+// re-selected window adds as many, bar a reverse complement that is a seed already).  A free lane therefore starts the
+// next plan from the guessed firstSequence while the one in front of it is still being computed; the guess is checked when
+// the predecessor joins the chain (promote()), and a plan that started from a wrong one is computed again.
 Planner::Planner(ReadSet& reads, const OverlapParams& p, ValueView values, bool threaded, dp_ctx* selCtx, WindowCache* cache)
     : d(new Impl(reads, p, values, threaded, selCtx)) {
     d->winCache = cache;
     if (const char* e = getenv("DPH_TEST_PLAN_DELAY_US")) d->testDelayUs = atol(e);
-    if (threaded) d->th = std::thread([this] { threadMain(); });
+    d->fromCache = cache && (p.queryType & 1) && !(p.queryType & 8) && p.numSeeds == cache->numSeeds;
+    if (threaded) setLanes(1);
+}
+
+// Lanes for a run of `world` ranks (in the round-parallel mode every rank's planner walks the whole chain while its GPU
+// executes one round in `world`, so the chain has to be `world` times faster than a GPU) next to `slots` executor threads.
+int Planner::lanesFor(int world, int slots) {
+    if (const char* e = getenv("DPH_PLAN_LANES")) return std::max(1, std::min(8, atoi(e)));
+    const int spare = (int)hostThreads() - std::max(1, slots) - 4;  // slots, window cache, formatter, commit
+    return std::max(1, std::min(std::min(8, std::max(3, world + 2)), spare));
+}
+
+void Planner::setLanes(int n) {
+    std::lock_guard<std::mutex> lk(d->mu);
+    if (!d->threaded) return;
+    if (!d->fromCache) n = 1;  // guessing needs the window cache's counts
+    while ((int)d->lanes.size() < n) {
+        const size_t i = d->lanes.size();
+        d->lanes.emplace_back(new Impl::Lane(d->p.k));
+        d->lanes[i]->th = std::thread([this, i] { laneMain(i); });
+    }
 }
 
 Planner::~Planner() {
@@ -191,10 +243,11 @@ Planner::~Planner() {
         d->stop = true;
     }
     d->cv.notify_all();
-    if (d->th.joinable()) d->th.join();
+    for (auto& l : d->lanes)
+        if (l->th.joinable()) l->th.join();
 }
 
-std::shared_ptr<RoundPlan> Planner::compute(i64 round, i64 firstIn) {
+std::shared_ptr<RoundPlan> Planner::compute(i64 round, i64 firstIn, SeedIndex& index) {
     const double tc0 = now();
     struct Tick {
         double t0, c0;
@@ -207,10 +260,10 @@ std::shared_ptr<RoundPlan> Planner::compute(i64 round, i64 firstIn) {
     auto plan = std::make_shared<RoundPlan>();
     plan->round = round;
     plan->firstIn = firstIn;
-    d->index.reset();
+    index.reset();
     // the device path needs the window in the resident (cached-view) form and at most 64 list slots
     dp_ctx* sel = (d->selCtx && d->p.numSeeds <= 64) ? d->selCtx : nullptr;
-    Overlapper lap(sel, d->reads, d->index, d->p.chunkSize, d->p.numWorkers, d->p.overlapSize, d->p.numSeeds, d->p.minHits);
+    Overlapper lap(sel, d->reads, index, d->p.chunkSize, d->p.numWorkers, d->p.overlapSize, d->p.numSeeds, d->p.minHits);
     lap.setWindowCache(d->winCache);
     const int nw = lap.PrepareQueries(d->p.numSeeds, d->p.seedBatchSize, d->values, firstIn, d->p.queryBatchSize, d->p.queryType);
     if (nw < 0) {
@@ -219,69 +272,130 @@ std::shared_ptr<RoundPlan> Planner::compute(i64 round, i64 firstIn) {
     }
     plan->empty = nw <= 0;
     plan->windows = lap.windows();
-    plan->seedMap = d->index.seedMap;
-    d->index.buildRcTable();  // (the executor slot takes both as they are: SeedIndex::adopt)
-    plan->rcOf = d->index.rcOf;
+    plan->seedMap = index.seedMap;
+    index.buildRcTable();  // (the executor slot takes both as they are: SeedIndex::adopt)
+    plan->rcOf = index.rcOf;
     // firstSequence = max query SequenceID + 1 (commands/overlap.go:135-142); windows are in ascending read order
     plan->firstOut = nw ? (i64)plan->windows.back().read + 1 : firstIn;
     return plan;
 }
 
-void Planner::threadMain() {
-    std::unique_lock<std::mutex> lk(d->mu);
+// First round the confirmed chain lacks and the firstSequence it starts from; false once the chain has ended.
+bool Planner::chainHead(i64* round, i64* firstIn) const {
+    i64 m = d->base, f = d->startFirstIn;
+    for (;;) {
+        auto it = d->cache.find(m);
+        if (it == d->cache.end()) break;
+        if (it->second->empty) return false;
+        f = it->second->firstOut;
+        m++;
+    }
+    *round = m;
+    *firstIn = f;
+    return true;
+}
+
+// Plans computed ahead join the chain as far as their assumptions hold; what can no longer join is dropped.
+void Planner::promote() {
+    i64 m = 0, f = 0;
+    bool alive;
+    while ((alive = chainHead(&m, &f))) {
+        auto it = d->pending.find({m, f});
+        if (it == d->pending.end()) break;
+        d->cache[m] = it->second;
+        d->pending.erase(it);
+    }
+    for (auto it = d->pending.begin(); it != d->pending.end();) {
+        if (!alive || it->first.first < m || (it->first.first == m && it->first.second != f)) {
+            g_prof.planDiscarded++;
+            it = d->pending.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
+// Where the plan that starts at firstIn will end if none of its windows is re-selected (prepareFromCache's loop with the
+// windows' seed counts); firstIn itself for a plan without windows, -1 while the window cache has not got that far.
+i64 Planner::predictFirstOut(i64 firstIn) const {
+    const WindowCache& wc = *d->winCache;
+    const i64 n = (i64)d->reads.size();
+    if (firstIn != 0 && firstIn >= n) return firstIn;
+    i64 sent = 0, seeds = 0, last = -1;
+    for (i64 r = firstIn; r < n && sent < d->p.queryBatchSize; r++) {
+        if (d->reads.ignore[(size_t)r]) continue;
+        sent++;
+        if (seeds >= d->p.seedBatchSize) break;
+        for (uint32_t w = wc.first[(size_t)r]; w < wc.first[(size_t)r + 1]; w++) {
+            const int c = wc.seedsOf(w);
+            if (c < 0) return -1;
+            seeds += c;
+        }
+        last = r;
+    }
+    return last < 0 ? firstIn : last + 1;
+}
+
+// The first plan nobody has computed or is computing, following the chain through the plans computed ahead and, past a
+// plan still being computed, through the guess of where it ends.
+bool Planner::nextWork(i64* round, i64* firstIn) const {
+    i64 m = 0, f = 0;
+    if (!chainHead(&m, &f)) return false;
+    while (m <= d->wantUpTo) {
+        auto it = d->pending.find({m, f});
+        if (it != d->pending.end()) {
+            if (it->second->empty) return false;
+            f = it->second->firstOut;
+            m++;
+            continue;
+        }
+        bool inFlight = false;
+        for (auto& l : d->lanes)
+            if (l->busy && l->round == m && l->firstIn == f) inFlight = true;
+        if (!inFlight) {
+            *round = m;
+            *firstIn = f;
+            return true;
+        }
+        if (d->lanes.size() < 2) return false;
+        const i64 fo = predictFirstOut(f);
+        if (fo < 0 || fo == f) return false;  // cannot tell yet / the chain is about to end: wait for the real thing
+        f = fo;
+        m++;
+    }
+    return false;
+}
+
+void Planner::laneMain(size_t li) {
+    std::unique_lock<std::mutex> lk(d->mu);  // (setLanes may still be growing the vector)
+    Impl::Lane& me = *d->lanes[li];
     for (;;) {
         if (d->stop) return;
-        // next plan of the chain that is missing
-        i64 m = d->base;
-        i64 firstIn = -1;
-        bool can = false;
-        while (m <= d->wantUpTo) {
-            auto it = d->cache.find(m);
-            if (it == d->cache.end()) {
-                if (m == d->base) {  // first uncommitted round: its firstSequence is the committed state
-                    firstIn = d->startFirstIn;
-                    can = true;
-                } else {
-                    auto pr = d->cache.find(m - 1);
-                    if (pr != d->cache.end() && !pr->second->empty) {
-                        firstIn = pr->second->firstOut;
-                        can = true;
-                    }
-                }
-                break;
-            }
-            if (it->second->empty) break;  // chain ends here
-            m++;
-        }
-        if (!can) {
+        i64 m = 0, firstIn = 0;
+        if (!nextWork(&m, &firstIn)) {
             d->cv.wait(lk);
             continue;
         }
+        me.busy = true;
+        me.round = m;
+        me.firstIn = firstIn;
+        me.maxFlagged = -1;
         const uint64_t e0 = d->epoch;
-        d->epochMaxId = -1;
         lk.unlock();
         static const bool dbg = getenv("DPH_DEBUG_PLANNER") != nullptr;
-        if (dbg) fprintf(stderr, "[planner] computing plan %lld (firstIn %lld, wantUpTo %lld, base %lld)\n", (long long)m, (long long)firstIn, (long long)d->wantUpTo, (long long)d->base);
-        std::shared_ptr<RoundPlan> plan = compute(m, firstIn);
+        if (dbg) fprintf(stderr, "[planner %zu] computing plan %lld (firstIn %lld, wantUpTo %lld, base %lld)\n", li, (long long)m, (long long)firstIn, (long long)d->wantUpTo, (long long)d->base);
+        std::shared_ptr<RoundPlan> plan = compute(m, firstIn, me.index);
         if (d->testDelayUs > 0) usleep((useconds_t)d->testDelayUs);  // test hook: flags arrive after this plan has read them
-        if (dbg) fprintf(stderr, "[planner] plan %lld done: %zu windows, %zu seeds, empty %d failed %d\n", (long long)m, plan->windows.size(), plan->seedMap.size(), (int)plan->empty, (int)plan->failed);
+        if (dbg) fprintf(stderr, "[planner %zu] plan %lld done: %zu windows, %zu seeds, firstOut %lld, empty %d failed %d\n", li, (long long)m, plan->windows.size(), plan->seedMap.size(), (long long)plan->firstOut, (int)plan->empty, (int)plan->failed);
         lk.lock();
+        me.busy = false;
         if (d->stop) return;
-        // discard if flags that could matter changed meanwhile, or if the chain below was invalidated.  PrepareQueries
-        // looks at ignore[r] for every r >= firstIn, so the plan is stale as soon as ANY read flagged during the compute
-        // has id >= firstIn - i.e. when the largest one does (a commit usually flags ids on both sides of firstIn).
-        bool ok = true;
-        if (d->epoch != e0 && d->epochMaxId >= firstIn) ok = false;
-        if (m > d->base) {
-            auto pr = d->cache.find(m - 1);
-            if (pr == d->cache.end() || pr->second->firstOut != firstIn) ok = false;
-        } else if (m == d->base) {
-            if (firstIn != d->startFirstIn) ok = false;
-        } else {
-            ok = false;  // committed meanwhile
-        }
-        if (ok && !d->cache.count(m)) d->cache[m] = plan;
-        else g_prof.planDiscarded++;
+        // discard if flags that could matter changed meanwhile.  PrepareQueries looks at ignore[r] for every r >= firstIn,
+        // so the plan is stale as soon as ANY read flagged during the compute has id >= firstIn - i.e. when the largest
+        // one does (a commit usually flags ids on both sides of firstIn).  Whether it continues the chain is promote()'s test.
+        if ((d->epoch != e0 && me.maxFlagged >= firstIn) || m < d->base) g_prof.planDiscarded++;
+        else d->pending[{m, firstIn}] = plan;
+        promote();
         d->cv.notify_all();
     }
 }
@@ -305,7 +419,7 @@ std::shared_ptr<const RoundPlan> Planner::get(i64 round) {
             }
             if (m > round) return nullptr;
             lk.unlock();
-            auto plan = compute(m, firstIn);
+            auto plan = compute(m, firstIn, d->index);
             lk.lock();
             d->cache[m] = plan;
         }
@@ -337,7 +451,16 @@ i64 Planner::applyIgnores(const std::vector<int>& ids, i64 committedRound) {
     }
     if (maxNew < 0) return -1;
     d->epoch++;
-    if (maxNew > d->epochMaxId) d->epochMaxId = maxNew;
+    for (auto& l : d->lanes)
+        if (maxNew > l->maxFlagged) l->maxFlagged = maxNew;
+    for (auto it = d->pending.begin(); it != d->pending.end();) {  // plans computed ahead looked at the flags too
+        if (it->first.second <= maxNew) {
+            g_prof.planErased++;
+            it = d->pending.erase(it);
+        } else {
+            ++it;
+        }
+    }
     // every cached plan of a later round that starts at or before a newly flagged read may change
     i64 firstBad = -1;
     for (auto it = d->cache.begin(); it != d->cache.end(); ++it) {
@@ -367,9 +490,15 @@ void Planner::dropBefore(i64 round, i64 firstInOfRound) {
     d->cache.erase(d->cache.begin(), d->cache.lower_bound(round));
     d->base = round;
     d->startFirstIn = firstInOfRound;
-    if (d->winCache) d->winCache->release((size_t)firstInOfRound);
+    if (d->winCache) {  // (a lane may still be reading the windows of a plan that started from an older guess)
+        i64 keep = firstInOfRound;
+        for (auto& l : d->lanes)
+            if (l->busy && l->firstIn < keep) keep = l->firstIn;
+        d->winCache->release((size_t)keep);
+    }
     auto it = d->cache.find(round);
     if (it != d->cache.end() && it->second->firstIn != firstInOfRound) d->cache.erase(it, d->cache.end());  // stale chain
+    promote();
     d->cv.notify_all();
 }
 
@@ -620,6 +749,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         mark("values copy (overlapped)");
     }
     planner.reset(new Planner(*reads, p, valueView(), !(nothread && nothread[0] == '1'), plannerCtx, winCache.get()));
+    planner->setLanes(Planner::lanesFor(world_, nSlots));
     mark("planner");
     firstSequence = 0;
     round = 0;
@@ -881,6 +1011,7 @@ int OverlapRun::commitResults(std::vector<RoundResult>& results) {
 void OverlapRun::setRanks(int rank, int world) {
     rank_ = rank;
     world_ = std::max(1, world);
+    if (planner) planner->setLanes(Planner::lanesFor(world_, (int)slots.size()));
 }
 
 void OverlapRun::startWorkers() {
@@ -964,6 +1095,7 @@ int OverlapRun::step() {
             error = workerErr_;
             return workerRc_;
         }
+        if (roundLimit >= 0 && round >= roundLimit) break;  // (a step commits every finished round it finds: callers that want exactly n rounds)
         auto it = ready_.find(round);
         if (it == ready_.end()) {
             if (committed) break;

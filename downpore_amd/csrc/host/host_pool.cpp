@@ -1,5 +1,7 @@
 // Process-wide worker pool (sized from the cgroup CPU quota) and the DPH_PROFILE counters.
+#include <execinfo.h>
 #include <malloc.h>
+#include <signal.h>
 #include <pthread.h>
 #include <sched.h>
 #include <unistd.h>
@@ -26,6 +28,26 @@ static const bool g_malloc_tuned = [] {
     return true;
 }();
 
+
+// DPH_SEGV_TRACE=1: a crashing host thread prints its frames (module + offset: addr2line on the in-tree build) before dying
+static void segvTrace(int sig) {
+    void* frames[48];
+    const int n = backtrace(frames, 48);
+    const char msg[] = "[dph] fatal signal, frames of the crashing thread:\n";
+    if (write(2, msg, sizeof msg - 1) < 0) {}
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static const bool g_segv_trace = [] {
+    if (const char* e = getenv("DPH_SEGV_TRACE"); e && e[0] == '1') {
+        signal(SIGSEGV, segvTrace);
+        signal(SIGBUS, segvTrace);
+        signal(SIGABRT, segvTrace);
+        return true;
+    }
+    return false;
+}();
 
 PipeProfile g_prof;
 #ifdef DPH_FINE

@@ -456,7 +456,12 @@ class OverlapPipeline:
         return self._text(self.H.dph_overlap_errtext)
 
     def run(self, max_rounds=-1):
+        """Commits rounds until the job is finished, or exactly max_rounds of them (a step commits every finished round it finds)."""
         n = 0
+        if self.world == 1:
+            self.H.dph_overlap_set_round_limit.restype = None
+            self.H.dph_overlap_set_round_limit.argtypes = [C.c_void_p, C.c_int64]
+            self.H.dph_overlap_set_round_limit(self.h, max_rounds if max_rounds >= 0 else -1)
         while max_rounds < 0 or n < max_rounds:
             c = self.step()
             if c == 0:

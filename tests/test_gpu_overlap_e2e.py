@@ -238,6 +238,31 @@ def test_overlap_slots_with_ignores():
     assert orun.rounds >= 2
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+@pytest.mark.parametrize("case", ["flags", "crowded", "plain"])
+def test_overlap_planner_lanes(monkeypatch, lanes, case):
+    """Planner lanes compute consecutive plans concurrently, each from a guess of where the plan before it ends (the seed budget
+    is tested once per read, overlap.go:57-60; the guess counts the seeds of the windows' cached selections).  A wrong guess must
+    cost a recomputation, never a different plan: "crowded" (k = 8: a sixth of all k-mers are seeds, nearly every window is
+    re-selected and reverse complements collide) makes guesses fail, "flags" has rounds that flag reads."""
+    import ctypes as C
+    from downpore_amd.overlap import load_host
+    monkeypatch.setenv("DPH_PLAN_LANES", str(lanes))
+    H = load_host()
+    H.dph_planner_counter.restype = C.c_int64
+    H.dph_planner_counter.argtypes = [C.c_int]
+    before = [H.dph_planner_counter(i) for i in range(3)]
+    if case == "flags":
+        orun, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
+    elif case == "crowded":
+        orun, st = _run_both(41, 200000, 600, 4000, 8, slots=3, seed_batch_size=1500)
+    else:
+        orun, st = _run_both(42, 400000, 1200, 5000, 12, slots=4, seed_batch_size=1000)
+    after = [H.dph_planner_counter(i) for i in range(3)]
+    print("lanes %d %s: rounds %d, plans computed %d, thrown away %d, erased %d" % ((lanes, case, orun.rounds) + tuple(a - b for a, b in zip(after, before))))
+    assert orun.rounds >= 2
+
+
 def test_overlap_himem_false_top_level_reads():
     """himem=false: reads are re-read as top-level sequences, len%4==0 scan quirk included."""
     _run_both(7, 100000, 300, 4000, 10, himem=False, max_rounds=3)
