@@ -609,7 +609,8 @@ struct OverlapRun {
     // r % world == rank; per superstep every rank contributes its next owned round (waitOwned), the results are
     // exchanged and commitGathered commits them in round order on every rank
     void setRanks(int rank, int world);
-    int waitOwned(RoundResult& out);                     // blocks until the owned round in [round, round+world) is ready
+    // blocks until the owned round in [round, round+world) is ready; adds the finished owned rounds after it (maxRounds in all)
+    int waitOwned(std::vector<RoundResult>& outs, int maxRounds = 1);
     int commitGathered(std::vector<RoundResult>& results);  // rounds committed; rejected owned rounds are re-queued
     // executes rounds[i] on slot i concurrently (host threads); outs[i] receives the result
     int executeRounds(const std::vector<i64>& rounds, std::vector<RoundResult>& outs);

@@ -462,22 +462,24 @@ static void deserialise(const uint8_t* blobs, const uint64_t* sizes, int count, 
 
 // ---- pipelined round-parallel mode: rank `rank` of `world` owns the rounds r % world == rank
 void dph_overlap_set_ranks(void* hh, int rank, int world) { ((OverlapH*)hh)->run.setRanks(rank, world); }
-// serialised result of this rank's owned round of the current superstep (blocks until its executor pipeline has it)
-const uint8_t* dph_overlap_wait_owned(void* hh, uint64_t* n) {
+// serialised results of this rank's contribution to the current superstep: its next owned round (blocks until its executor
+// pipeline has it) and up to max_rounds - 1 finished owned rounds after it, back to back (each record carries its length)
+const uint8_t* dph_overlap_wait_owned_many(void* hh, int max_rounds, uint64_t* n) {
     OverlapH* h = (OverlapH*)hh;
     static thread_local std::string blob;
-    RoundResult res;
-    int rc = h->run.waitOwned(res);
+    std::vector<RoundResult> res;
+    int rc = h->run.waitOwned(res, max_rounds);
     if (rc != 0) {
         h->err = h->run.error;
         *n = 0;
         return nullptr;
     }
     blob.clear();
-    serialise(res, blob);
+    for (RoundResult& r : res) serialise(r, blob);
     *n = blob.size();
     return (const uint8_t*)blob.data();
 }
+const uint8_t* dph_overlap_wait_owned(void* hh, uint64_t* n) { return dph_overlap_wait_owned_many(hh, 1, n); }
 int dph_overlap_commit_gathered(void* hh, const uint8_t* blobs, const uint64_t* sizes, int count) {
     OverlapH* h = (OverlapH*)hh;
     std::vector<RoundResult> rs;

@@ -1131,7 +1131,11 @@ int OverlapRun::step() {
     return committed;
 }
 
-int OverlapRun::waitOwned(RoundResult& out) {
+// This rank's contribution to a superstep: its next owned round (waited for) and, up to maxRounds in all, the owned rounds
+// after it that are finished already - an exchange that takes as long as several rounds then carries several rounds, and the
+// ranks need not agree on how many: commitGathered commits whatever prefix of the gathered rounds is contiguous and valid,
+// the rest stays with its owner for the next superstep.
+int OverlapRun::waitOwned(std::vector<RoundResult>& outs, int maxRounds) {
     startWorkers();
     std::unique_lock<std::mutex> lk(pmu_);
     i64 mine = round;
@@ -1142,7 +1146,14 @@ int OverlapRun::waitOwned(RoundResult& out) {
         error = workerErr_;
         return workerRc_;
     }
-    out = ready_[mine];  // a copy: the result stays here until it is committed or rejected
+    outs.clear();
+    for (int i = 0; i < std::max(1, maxRounds); i++, mine += world_) {
+        auto it = ready_.find(mine);
+        if (it == ready_.end()) break;
+        it->second.takeText();       // (into the result itself: it may be contributed again if its predecessor is rejected)
+        outs.push_back(it->second);  // a copy: the result stays here until it is committed or rejected
+        if (it->second.empty) break;
+    }
     return 0;
 }
 

@@ -129,22 +129,54 @@ def allgather_survivors(local, world, device=None):
     return dict(read=np.concatenate(reads), n_seeds=np.concatenate(nseeds), segs=np.concatenate(segs).astype(np.int32))
 
 
-def allgather_bytes(blob, world, device=None):
-    """All-gather of one variable-size byte string per rank (torch.distributed; nccl == RCCL on the GPU box)."""
+_FLAT_GATHER = {}
+
+
+def allgather_blobs(blob, world, device=None):
+    """All-gather of one variable-size byte string per rank (torch.distributed; nccl == RCCL on the GPU box).  Returns
+    (cat, sizes): the ranks' strings back to back in one uint8 array and their lengths (uint64).  One host synchronisation
+    for the sizes, one flat collective and one copy back for the payload."""
     import torch
     import torch.distributed as dist
     dev = device if device is not None else torch.device("cpu")
-    n = torch.tensor([len(blob)], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(x.item()) for x in sizes]
-    mx = max(max(sizes), 1)
+    mine = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+    if world == 1 and not dist.is_initialized():
+        return mine.copy(), np.array([len(mine)], dtype=np.uint64)
+    n = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
+    key = str(dev.type)
+    flat = _FLAT_GATHER.get(key, True)
+    sz = torch.empty(world, dtype=torch.int64, device=dev)
+    if flat:
+        try:
+            dist.all_gather_into_tensor(sz, n)
+        except (RuntimeError, NotImplementedError):  # a backend without the flat form
+            flat = _FLAT_GATHER[key] = False
+    if not flat:
+        parts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(parts, n)
+        sz = torch.cat(parts)
+    sizes = np.array(sz.tolist(), dtype=np.uint64)
+    mx = (max(int(sizes.max()), 1) + 4095) // 4096 * 4096
     buf = np.zeros(mx, dtype=np.uint8)
-    buf[:len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+    buf[:len(mine)] = mine
     t = torch.from_numpy(buf).to(dev)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    return [out[r].cpu().numpy()[:sizes[r]].tobytes() for r in range(world)]
+    if flat:
+        out = torch.empty(world * mx, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out, t)
+        host = out.cpu().numpy().reshape(world, mx)
+    else:
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        host = torch.stack(outs).cpu().numpy()
+    cat = np.concatenate([host[r, :int(sizes[r])] for r in range(world)]) if world > 1 else np.ascontiguousarray(host[0, :int(sizes[0])])
+    return cat, sizes
+
+
+def allgather_bytes(blob, world, device=None):
+    """The same as a list of byte strings, one per rank."""
+    cat, sizes = allgather_blobs(blob, world, device)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    return [cat[off[r]:off[r + 1]].tobytes() for r in range(world)]
 
 
 class Reads:
@@ -232,8 +264,8 @@ class OverlapPipeline:
         if self.mode == "round":
             self.H.dph_overlap_set_ranks.restype = None
             self.H.dph_overlap_set_ranks.argtypes = [C.c_void_p, C.c_int, C.c_int]
-            self.H.dph_overlap_wait_owned.restype = C.c_void_p
-            self.H.dph_overlap_wait_owned.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+            self.H.dph_overlap_wait_owned_many.restype = C.c_void_p
+            self.H.dph_overlap_wait_owned_many.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
             self.H.dph_overlap_commit_gathered.restype = C.c_int
             self.H.dph_overlap_commit_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
             self.H.dph_overlap_set_ranks(self.h, rank, world)
@@ -337,13 +369,12 @@ class OverlapPipeline:
                 if self.H.dph_overlap_done(self.h):
                     return 0
                 n = C.c_uint64(0)
-                p = self.H.dph_overlap_wait_owned(self.h, C.byref(n))
+                p = self.H.dph_overlap_wait_owned_many(self.h, max(1, self.slots), C.byref(n))
                 if not p:
                     raise self._err()
-                blobs = allgather_bytes(C.string_at(p, n.value), self.world, self.torch_device)
-                sizes = np.array([len(b) for b in blobs], dtype=np.uint64)
-                cat = np.frombuffer(b"".join(blobs), dtype=np.uint8)
-                c = self.H.dph_overlap_commit_gathered(self.h, cat.ctypes.data, sizes.ctypes.data, len(blobs))
+                mine = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,))
+                cat, sizes = allgather_blobs(mine, self.world, self.torch_device)
+                c = self.H.dph_overlap_commit_gathered(self.h, cat.ctypes.data, sizes.ctypes.data, len(sizes))
                 if c < 0:
                     raise self._err()
                 if c > 0:
@@ -409,9 +440,10 @@ class OverlapPipeline:
         self.H.dph_overlap_step_lines.argtypes = [C.c_void_p]
         return int(self.H.dph_overlap_step_lines(self.h))
 
-    def wait_owned_blob(self):
+    def wait_owned_blob(self, max_rounds=None):
+        """This rank's contribution to a superstep: its next owned round and the finished owned rounds after it (serialised)."""
         n = C.c_uint64(0)
-        p = self.H.dph_overlap_wait_owned(self.h, C.byref(n))
+        p = self.H.dph_overlap_wait_owned_many(self.h, max(1, self.slots) if max_rounds is None else max_rounds, C.byref(n))
         if not p:
             raise self._err()
         return C.string_at(p, n.value)

@@ -75,3 +75,39 @@ def test_shard_bounds_cover_and_are_ascending():
                 assert lo == prev and hi >= lo
                 prev = hi
             assert prev == n
+
+
+def _blob_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from downpore_amd.overlap import allgather_blobs, allgather_bytes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    # the result exchange of the round-parallel mode: one byte string per rank, lengths differ from rank to rank and from
+    # superstep to superstep (a rank contributes one or several serialised rounds), an empty one included
+    for step, lens in enumerate([(5, 70000), (0, 3), (4096, 4096), (123457, 1)]):
+        want = [(np.arange(n, dtype=np.uint64) * (7 + r + step) % 251).astype(np.uint8) for r, n in enumerate(lens)]
+        cat, sizes = allgather_blobs(want[rank].tobytes(), world)
+        ok &= sizes.tolist() == list(lens) and cat.dtype == np.uint8 and np.array_equal(cat, np.concatenate(want))
+        ok &= allgather_bytes(want[rank], world) == [w.tobytes() for w in want]
+    if rank == 0:
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgather_blobs_two_ranks_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_blob_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok
