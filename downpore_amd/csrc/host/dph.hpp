@@ -415,6 +415,10 @@ class Overlapper {
 unsigned hostThreads();  // DP_HOST_THREADS or hardware_concurrency (<= 96): size of the shared worker pool
 void setHostThreadShare(unsigned concurrentUsers);
 void profilePrint();  // DPH_PROFILE counters to stderr
+void sampleProfStart();  // DPH_SAMPLE_PROF=1: CPU-time sampling by HIP API entry (host_pool.cpp), between start and stop
+void sampleProfStop();
+void sampleProfRegister(const char* role);  // a pipeline thread announces itself to the sampler
+void sampleProfUnregister();
 // Runs fn(i) for every i in [0, n) on the process-wide worker pool plus the calling thread and returns when all calls
 // have finished.  Concurrent callers (executor slots, the planner) share the pool; jobs are served oldest first.
 void parallelFor(size_t n, const std::function<void(size_t)>& fn);

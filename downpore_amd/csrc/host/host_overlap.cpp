@@ -843,6 +843,10 @@ void TextPool::submit(std::shared_ptr<TextJob> job) {
     cv_.notify_one();
 }
 void TextPool::loop() {
+    struct Reg {
+        Reg() { sampleProfRegister("text"); }
+        ~Reg() { sampleProfUnregister(); }
+    } reg;
     for (;;) {
         std::shared_ptr<TextJob> job;
         {

@@ -72,6 +72,10 @@ WindowCache::~WindowCache() {
 }
 
 void WindowCache::producer() {
+    struct Reg {
+        Reg() { sampleProfRegister("cache"); }
+        ~Reg() { sampleProfUnregister(); }
+    } reg;
     std::vector<dp_scan_item> items;
     for (uint32_t c = 0; c < d->nChunks; c++) {
         std::unique_ptr<Impl::Chunk> ch;
@@ -367,6 +371,10 @@ bool Planner::nextWork(i64* round, i64* firstIn) const {
 }
 
 void Planner::laneMain(size_t li) {
+    struct Reg {
+        Reg() { sampleProfRegister("lane"); }
+        ~Reg() { sampleProfUnregister(); }
+    } reg;
     std::unique_lock<std::mutex> lk(d->mu);  // (setLanes may still be growing the vector)
     Impl::Lane& me = *d->lanes[li];
     for (;;) {
@@ -549,6 +557,7 @@ void OverlapRun::HugeTable::clear() {
 }
 
 void OverlapRun::shutdown() {
+    sampleProfStop();
     {
         std::lock_guard<std::mutex> lk(pmu_);
         stopWorkers_ = true;
@@ -1021,6 +1030,7 @@ void OverlapRun::setRanks(int rank, int world) {
 }
 
 void OverlapRun::startWorkers() {
+    if (workers_.empty()) sampleProfStart();
     if (!workers_.empty()) return;
     nextIssue_ = round;
     while (nextIssue_ % world_ != rank_) nextIssue_++;  // first round this rank owns
@@ -1028,8 +1038,18 @@ void OverlapRun::startWorkers() {
 }
 
 void OverlapRun::workerMain(size_t si) {
+    struct Reg {
+        Reg() { sampleProfRegister("slot"); }
+        ~Reg() { sampleProfUnregister(); }
+    } reg;
     ExecSlot& sl = *slots[si];
-    const i64 window = ((i64)slots.size() + 2) * world_;  // rounds issued ahead of the commit point (owned ones only)
+    // rounds issued ahead of the commit point (owned ones only): commits are in order, so a round that takes longer than its
+    // neighbours holds the window; DPH_ISSUE_WINDOW = rounds beyond the slot count (config 2, six slots: +2 0.370, +6 0.344, +12 0.338, +24 0.343 ms per round)
+    static const i64 extra = [] {
+        const char* e = getenv("DPH_ISSUE_WINDOW");
+        return e ? std::max(0L, atol(e)) : 10L;
+    }();
+    const i64 window = ((i64)slots.size() + extra) * world_;
     std::unique_lock<std::mutex> lk(pmu_);
     for (;;) {
         cvWork_.wait(lk, [&] {
@@ -1134,6 +1154,7 @@ int OverlapRun::step() {
         cvWork_.notify_all();
     }
     g_prof.execUs += (long long)((now() - t0) * 1e6);
+    if (done) sampleProfStop();
     return committed;
 }
 

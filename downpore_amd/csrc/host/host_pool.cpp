@@ -1,12 +1,19 @@
 // Process-wide worker pool (sized from the cgroup CPU quota) and the DPH_PROFILE counters.
+#include <dlfcn.h>
 #include <execinfo.h>
 #include <malloc.h>
 #include <signal.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/time.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <atomic>
 #include <condition_variable>
+#include <map>
+#include <string>
+#include <vector>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -48,6 +55,124 @@ static const bool g_segv_trace = [] {
     }
     return false;
 }();
+
+// DPH_SAMPLE_PROF=1: wall-clock sampling of the pipeline's threads (executor slots, planner lanes, window cache, formatters):
+// a sampler thread signals each registered thread every 0.2 ms, the thread records its frames.  A sample is attributed to
+// the innermost frame inside our own libraries - the call site of the HIP API call (or host code) the thread is in, as
+// module+offset (tools/sample_resolve.py turns them into file:line with addr2line on the in-tree build; the runtime
+// libraries carry no symbols of their own) - and to the module of the innermost frame overall (runtime, libc, driver).
+namespace {
+struct ProfSample {
+    int n, role;
+    void* f[20];
+};
+constexpr int kProfMax = 1 << 20;
+ProfSample* g_profSamples = nullptr;
+std::atomic<int> g_profCount{0};
+std::atomic<bool> g_profRun{false};
+std::mutex g_profMu;
+std::vector<std::pair<pthread_t, bool>> g_profThreads;  // (thread, alive)
+std::vector<std::string> g_profRoles;
+thread_local int t_profRole = -1;
+std::thread g_profSampler;
+void profTick(int) {
+    const int i = g_profCount.fetch_add(1, std::memory_order_relaxed);
+    if (i < kProfMax) {
+        g_profSamples[i].role = t_profRole;
+        g_profSamples[i].n = backtrace(g_profSamples[i].f, 20);
+    }
+}
+std::string moduleOf(const Dl_info& di) {
+    std::string m = di.dli_fname ? di.dli_fname : "?";
+    const size_t sl = m.rfind('/');
+    return sl == std::string::npos ? m : m.substr(sl + 1);
+}
+void profReport() {
+    g_profRun = false;
+    if (g_profSampler.joinable()) g_profSampler.join();
+    const int n = std::min(g_profCount.load(), kProfMax);
+    std::map<std::string, std::map<std::string, int>> sites;  // role -> "module+off | leaf module" -> samples
+    std::map<std::string, int> perRole;
+    for (int i = 0; i < n; i++) {
+        const ProfSample& sm = g_profSamples[i];
+        std::string role = sm.role >= 0 && (size_t)sm.role < g_profRoles.size() ? g_profRoles[(size_t)sm.role] : "?";
+        std::string leafMod = "?", site;
+        for (int j = 2; j < sm.n; j++) {  // 0 = this handler, 1 = the signal trampoline
+            Dl_info di;
+            if (!dladdr(sm.f[j], &di)) continue;
+            const std::string mod = moduleOf(di);
+            if (j == 2) leafMod = mod;
+            if (mod.find("libdownpore_") != std::string::npos) {
+                char b[64];
+                snprintf(b, sizeof b, "+0x%zx", (size_t)((char*)sm.f[j] - (char*)di.dli_fbase));
+                site = mod + b + (j == 2 ? " own" : "");
+                break;
+            }
+        }
+        if (site.empty()) site = "(no frame of ours)";
+        sites[role][site + " | " + leafMod]++;
+        perRole[role]++;
+    }
+    fprintf(stderr, "[sample] %d samples at 0.2 ms\n", n);
+    for (auto& rs : sites) {
+        std::vector<std::pair<int, std::string>> order;
+        for (auto& kv : rs.second) order.push_back({kv.second, kv.first});
+        std::sort(order.rbegin(), order.rend());
+        const int tot = perRole[rs.first];
+        for (size_t i = 0; i < order.size() && i < 45; i++)
+            fprintf(stderr, "[sample] %-10s %6d %5.1f%%  %s\n", rs.first.c_str(), order[i].first, 100.0 * order[i].first / std::max(1, tot), order[i].second.c_str());
+    }
+}
+const bool g_profOn = [] {
+    const char* e = getenv("DPH_SAMPLE_PROF");
+    if (!(e && e[0] == '1')) return false;
+    g_profSamples = new ProfSample[kProfMax];
+    void* warm[4];
+    backtrace(warm, 4);  // (loads the unwinder now, not inside the first signal)
+    struct sigaction sa = {};
+    sa.sa_handler = profTick;
+    sa.sa_flags = SA_RESTART;
+    sigaction(SIGPROF, &sa, nullptr);
+    atexit(profReport);
+    return true;
+}();
+}  // namespace
+// a pipeline thread announces itself (role: "slot", "lane", "cache", "text", "commit"); unregistered when it ends
+void sampleProfRegister(const char* role) {
+    if (!g_profOn) return;
+    std::lock_guard<std::mutex> lk(g_profMu);
+    size_t r = 0;
+    for (; r < g_profRoles.size(); r++)
+        if (g_profRoles[r] == role) break;
+    if (r == g_profRoles.size()) g_profRoles.push_back(role);
+    t_profRole = (int)r;
+    g_profThreads.push_back({pthread_self(), true});
+}
+void sampleProfUnregister() {
+    if (!g_profOn) return;
+    std::lock_guard<std::mutex> lk(g_profMu);
+    for (auto& t : g_profThreads)
+        if (t.second && pthread_equal(t.first, pthread_self())) t.second = false;
+}
+// sampling runs between these two (the rounds of a job; set-up and everything else of the process stay out of the picture)
+void sampleProfStart() {
+    if (!g_profOn || g_profRun.exchange(true)) return;
+    if (g_profSampler.joinable()) g_profSampler.join();
+    g_profSampler = std::thread([] {
+        while (g_profRun.load()) {
+            {
+                std::lock_guard<std::mutex> lk(g_profMu);
+                for (auto& t : g_profThreads)
+                    if (t.second) pthread_kill(t.first, SIGPROF);
+            }
+            usleep(200);
+        }
+    });
+}
+void sampleProfStop() {
+    if (!g_profOn) return;
+    g_profRun = false;
+}
 
 PipeProfile g_prof;
 #ifdef DPH_FINE
