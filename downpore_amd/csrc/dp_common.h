@@ -69,6 +69,8 @@ struct dp_ctx {
     // ---- scan (A2+A10)
     DevBuf d_items, d_counts, d_segoff, d_segs, d_total;
     PinBuf h_counts, h_segoff, h_segs, h_total;
+    PinBuf h_seeds;                   // the round's seed list as dp_round_begin received it (pinned: kernels may read it in place)
+    bool seeds_uploaded = false;      // d_seeds holds it too (only the scan kernels' tables need that, see dp_seeds_ptr)
     uint64_t n_segs = 0;
     uint32_t scan_items = 0;
     DevBuf d_ignore, d_surv;          // dp_scan_reads: ignore mask; compacted survivor lists
@@ -128,6 +130,12 @@ int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess);
 hipError_t dp_stream_sync(dp_ctx* ctx);
 int dev_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
 int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
+// The round's seed list for a kernel that reads every seed once or twice (the k-mer index walk): the device copy if one was
+// made, else the pinned host block read in place over the link - 80 KB per round that then never travel as a copy (as a
+// pageable hipMemcpyAsync they cost the calling thread 80 us per round inside the runtime).
+static inline const uint32_t* dp_seeds_ptr(const dp_ctx* ctx) {
+    return (const uint32_t*)(ctx->seeds_uploaded ? ctx->d_seeds.p : ctx->h_seeds.p);
+}
 // A caller's borrowed buffer copied into memory of the context that stays untouched until the context's next dp_stream_sync,
 // so that the H2D copy out of it can still be queued when the call returns.  PAGEABLE on purpose: the runtime stages small
 // pageable sources itself and copies them with a blit kernel on the stream's own queue, which measured faster under eight

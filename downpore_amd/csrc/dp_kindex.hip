@@ -557,7 +557,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                            (uint32_t*)d_totals, d_items, n_read_items, n_extra, head, next);
     }
     if (S)
-        hipLaunchKernelGGL(kidx_walk<false>, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
+        hipLaunchKernelGGL(kidx_walk<false>, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), 0, ctx->stream, dp_seeds_ptr(ctx), S,
                            (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
                            (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k));
     // totals[2] = seed occurrences in the read set, totals[3] = largest survivor count (both written by the kernel)
@@ -587,7 +587,7 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         rc = 1;
     } else if (n_sel) {
         if (S)
-            hipLaunchKernelGGL(kidx_walk<true>, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_seeds.p, S,
+            hipLaunchKernelGGL(kidx_walk<true>, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), 0, ctx->stream, dp_seeds_ptr(ctx), S,
                                (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
                                (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr, kidx_lps(ix, k));
         const dim3 sg(std::min<uint32_t>(n_sel, 16384)), sb(64);

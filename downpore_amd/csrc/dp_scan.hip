@@ -362,7 +362,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     for (void* q : ctx->retired_dev) dp_dev_free(q);
     for (void* q : ctx->retired_pin) hipHostFree(q);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
-                     &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
+                     &ctx->h_seeds, &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
     for (auto* b : pbs)
         if (b->p) hipHostFree(b->p);
     for (auto& ev : ctx->ev)
@@ -808,6 +808,10 @@ __global__ void seeds_apply_kernel(const uint32_t* __restrict__ seeds, uint32_t 
 
 // d_bits / d_kmap := the current seed list (clear the list applied last, set this one); called before a scan kernel
 static int seed_tables_ensure(dp_ctx* ctx) {
+    if (!ctx->seeds_uploaded && ctx->n_seeds) {  // the scan kernels read the seed list many times: they get a device copy
+        DP_HIP(hipMemcpyAsync(ctx->d_seeds.p, ctx->h_seeds.p, (size_t)ctx->n_seeds * 4, hipMemcpyHostToDevice, ctx->stream));
+        ctx->seeds_uploaded = true;
+    }
     if (!ctx->tables_dirty) return DP_OK;
     if (ctx->n_applied)
         hipLaunchKernelGGL(seeds_apply_kernel, dim3((ctx->n_applied + 255) / 256), dim3(256), 0, ctx->stream,
@@ -840,10 +844,13 @@ extern "C" int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, ui
     for (uint32_t i = 0; i < n_seeds; i++)
         if (seed_kmers[i] >= nk) return dp_fail(ctx, DP_ERR_ARG, "seed k-mer out of range for k");
     if (dev_reserve(ctx, ctx->d_seeds, (size_t)n_seeds * 4 + 4)) return DP_ERR_HIP;
-    // (pageable source: the runtime stages it and the copy runs as a blit kernel on this stream's own queue - measured faster
-    // with eight slots in flight than a pinned source, which goes through the shared SDMA engines)
-    if (n_seeds)  // seed_kmers is borrowed only for the duration of the call: the copy leaves from the context's staging block
-        DP_HIP(hipMemcpyAsync(ctx->d_seeds.p, dp_stage(ctx, seed_kmers, (size_t)n_seeds * 4), (size_t)n_seeds * 4, hipMemcpyHostToDevice, ctx->stream));
+    // seed_kmers is borrowed only for the duration of the call: it is kept in a pinned block of the context.  Nothing is
+    // copied to the device here - the k-mer index walk reads the block in place (dp_seeds_ptr), the scan kernels upload it
+    // when they run (seed_tables_ensure).  (As a pageable hipMemcpyAsync this was the most expensive call of a round for the
+    // calling thread: 80 us inside the runtime, every round, on every executor slot.)
+    if (pin_reserve(ctx, ctx->h_seeds, (size_t)n_seeds * 4 + 4)) return DP_ERR_HIP;
+    if (n_seeds) memcpy(ctx->h_seeds.p, seed_kmers, (size_t)n_seeds * 4);
+    ctx->seeds_uploaded = false;
     // the membership bits and the k-mer -> seed-id map are only read by the scan kernels: they are brought up to date by
     // seed_tables_ensure() when a scan actually runs (a round served by the k-mer position index never needs them)
     ctx->tables_dirty = true;
