@@ -643,6 +643,8 @@ struct OverlapRun {
     int beginRound(ExecSlot& s, const RoundPlan& plan);
     int finishRound(ExecSlot& s, const Survivors& all, RoundResult& out);
     void commitOne(RoundResult& r);
+    void commitText(RoundResult& r);   // the half of a commit nobody else looks at (text, counters)
+    void commitState(RoundResult& r);  // the half the executor slots and the planner see (under the pipeline's lock)
     // executor pipeline behind step(): every slot has a worker thread that keeps executing the next uncommitted round
     // speculatively; step() commits finished rounds in order and re-queues the ones a later-arriving ignore flag
     // invalidated

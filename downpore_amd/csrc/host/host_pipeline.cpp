@@ -19,8 +19,12 @@ namespace dph {
 struct WindowCache::Impl {
     dp_ctx* ctx;
     int k;
-    static constexpr uint32_t CW = 8192;     // windows per chunk
-    static constexpr uint32_t SOFT_CAP = 8;  // chunks kept ahead of the release point unless somebody waits for more
+    // windows per chunk: 8192 (one selection kernel + one copy back per chunk; the producer is busy half of a config-2 job
+    // with that, with 2048 it could not keep up) - except the first two, which the first plans of a job wait for
+    static constexpr uint32_t CW = 8192, CW0 = 1024;
+    static uint32_t chunkOf(uint32_t w) { return w < CW0 ? 0u : w < CW ? 1u : 1u + w / CW; }
+    static size_t chunkBegin(uint32_t c) { return c == 0 ? 0 : c == 1 ? CW0 : (size_t)(c - 1) * CW; }
+    static constexpr uint32_t SOFT_CAP = 9;  // chunks kept ahead of the release point unless somebody waits for more
     struct Chunk {
         std::vector<uint32_t> spec, kmers;
     };
@@ -57,7 +61,7 @@ WindowCache::WindowCache(dp_ctx* ctx, const ReadSet& reads, i64 overlap, int k, 
     seedCount.assign(wins.size(), 0);
     const i64 blocks = maxLen - 2 * k > 0 ? (maxLen - 2 * k + 3 * k - 1) / (3 * k) : 0;
     stride = (uint32_t)std::max<i64>(1, blocks * k);
-    d->nChunks = (uint32_t)((wins.size() + Impl::CW - 1) / Impl::CW);
+    d->nChunks = wins.empty() ? 0u : Impl::chunkOf((uint32_t)wins.size() - 1) + 1;
     d->th = std::thread([this] { producer(); });
 }
 
@@ -85,7 +89,7 @@ void WindowCache::producer() {
             if (d->stop) return;
             if (c < d->released) {  // everything in it is committed already (a job restarted far ahead): nothing to produce
                 d->produced = c + 1;
-                producedWins.store((uint32_t)std::min(wins.size(), ((size_t)c + 1) * Impl::CW), std::memory_order_release);
+                producedWins.store((uint32_t)std::min(wins.size(), Impl::chunkBegin(c + 1)), std::memory_order_release);
                 d->cvProduced.notify_all();
                 continue;
             }
@@ -95,7 +99,7 @@ void WindowCache::producer() {
             }
         }
         if (!ch) ch.reset(new Impl::Chunk());
-        const size_t w0 = (size_t)c * Impl::CW, w1 = std::min(wins.size(), w0 + Impl::CW), n = w1 - w0;
+        const size_t w0 = Impl::chunkBegin(c), w1 = std::min(wins.size(), Impl::chunkBegin(c + 1)), n = w1 - w0;
         items.resize(n);
         for (size_t i = 0; i < n; i++) {
             items[i].read = wins[w0 + i].read;
@@ -135,7 +139,7 @@ void WindowCache::producer() {
 }
 
 bool WindowCache::get(uint32_t w, const uint32_t** spec, const uint32_t** kmers, std::string* err) {
-    const uint32_t c = w / Impl::CW;
+    const uint32_t c = Impl::chunkOf(w);
     std::unique_lock<std::mutex> lk(d->mu);
     if (c >= d->produced) {
         if (c > d->wanted) {
@@ -151,7 +155,7 @@ bool WindowCache::get(uint32_t w, const uint32_t** spec, const uint32_t** kmers,
         if (err) *err = d->failed ? d->error : "window cache: chunk released before use";
         return false;
     }
-    const size_t i = w - (size_t)c * Impl::CW;
+    const size_t i = w - Impl::chunkBegin(c);
     *spec = it->second->spec.data() + i * (size_t)numSeeds;
     *kmers = it->second->kmers.data() + i * (size_t)stride;
     return true;
@@ -159,7 +163,7 @@ bool WindowCache::get(uint32_t w, const uint32_t** spec, const uint32_t** kmers,
 
 void WindowCache::release(size_t belowRead) {
     const uint32_t w = belowRead < first.size() ? first[belowRead] : (uint32_t)wins.size();
-    const uint32_t c = w / Impl::CW;
+    const uint32_t c = Impl::chunkOf(w);
     std::lock_guard<std::mutex> lk(d->mu);
     if (c <= d->released) return;
     d->released = c;
@@ -432,7 +436,12 @@ std::shared_ptr<const RoundPlan> Planner::get(i64 round) {
             d->cache[m] = plan;
         }
     }
-    const i64 depth = 6;
+    // plans computed beyond the highest round anybody asked for (DPH_PLAN_DEPTH): the slots ask in bursts - a commit that was
+    // holding the issue window releases several rounds at once - and a lane needs 0.3 ms per plan
+    static const i64 depth = [] {
+        const char* e = getenv("DPH_PLAN_DEPTH");
+        return e ? std::max(1L, atol(e)) : 6L;
+    }();
     if (round + depth > d->wantUpTo) d->wantUpTo = round + depth;
     d->cv.notify_all();
     for (;;) {
@@ -949,17 +958,18 @@ int OverlapRun::executeRounds(const std::vector<i64>& rounds, std::vector<RoundR
     return 0;
 }
 
-void OverlapRun::commitOne(RoundResult& r) {
+// A commit has a heavy half that only the committing thread's own data sees (the round's text) and a light half that the
+// executor slots look at (the commit point, the flags, the planner's chain): step() runs the first without the pipeline's
+// lock - a slot that finishes a round meanwhile hands it in at once instead of queueing behind half a megabyte of text.
+void OverlapRun::commitText(RoundResult& r) {
     char line[200];
     r.takeText();  // (the round's PAF text may still be with a formatter thread)
-    firstSequence = r.firstOut;
-    numQuerySeqs = r.numQuerySeqs;
     if (round == 0)
-        snprintf(line, sizeof line, "Using query sets of around %lld sequences against %lld sequences.\n", (long long)firstSequence,
+        snprintf(line, sizeof line, "Using query sets of around %lld sequences against %lld sequences.\n", (long long)r.firstOut,
                  (long long)reads->size());
     else
         snprintf(line, sizeof line, "Using query set with %lld  sequences starting from %lld sequences against %lld sequences.\n",
-                 (long long)numQuerySeqs, (long long)firstSequence, (long long)reads->size());
+                 (long long)r.numQuerySeqs, (long long)r.firstOut, (long long)reads->size());
     errText += line;
     snprintf(line, sizeof line, "Total %lld hits across %lld overlaps.\n", (long long)r.fs.hits, (long long)r.fs.qHits);
     errText += line;
@@ -969,12 +979,22 @@ void OverlapRun::commitOne(RoundResult& r) {
     pafLines += (i64)r.fs.lines;
     last = r.st;
     total.add(r.st);
+}
+
+void OverlapRun::commitState(RoundResult& r) {
+    firstSequence = r.firstOut;
+    numQuerySeqs = r.numQuerySeqs;
     g_prof.ignores += (long long)r.ignores.size();
     for (int id : r.ignores)
         if (!reads->ignore[(size_t)id] && flagRound_[(size_t)id] < 0) flagRound_[(size_t)id] = (int32_t)round;
     planner->applyIgnores(r.ignores, round);
     round++;
     planner->dropBefore(round, firstSequence);
+}
+
+void OverlapRun::commitOne(RoundResult& r) {
+    commitText(r);
+    commitState(r);
 }
 
 int OverlapRun::commitResults(std::vector<RoundResult>& results) {
@@ -1148,7 +1168,10 @@ int OverlapRun::step() {
             cvWork_.notify_all();
             continue;
         }
-        commitOne(res);
+        lk.unlock();
+        commitText(res);
+        lk.lock();
+        commitState(res);
         committed++;
         g_prof.committed++;
         cvWork_.notify_all();
