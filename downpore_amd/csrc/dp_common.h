@@ -75,6 +75,7 @@ struct dp_ctx {
     uint32_t scan_items = 0;
     DevBuf d_ignore, d_surv;          // dp_scan_reads: ignore mask; compacted survivor lists
     PinBuf h_surv;
+    PinBuf h_spack;                   // the survivor list as the compaction kernel writes it (pinned, written by the device)
     uint64_t ignore_epoch = ~0ull;
     uint64_t cached_bases = 0;
     uint32_t cached_reads = 0, cached_lo = 0, cached_hi = 0;

@@ -392,6 +392,8 @@ struct ConsFullArgs {
     uint32_t flag_every;       // DP_CONS_FLAG_EVERY=n (test hook): every n-th window is left to the host path
     uint32_t out_cap;          // slots of paf / ignore_ids (a bound when the chaining stage's pair count is not known yet)
     uint32_t rec_cap;          // records the chaining stage's buffers hold (its pair count may exceed them: the stage is then repeated)
+    const uint32_t* nseq_src;  // chunk count + overflow flag of dp_index_build_chunked (device), or null
+    uint32_t* nseq_dst;        // ... and where the host reads them (pinned, with the rest of the output)
 };
 
 __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A) {
@@ -399,6 +401,7 @@ __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A
     const int lane = dp_lane();
     const int k = A.k;
     const u64 lanesBelow = (1ull << lane) - 1ull;
+    if (blockIdx.x == 0 && lane < 2 && A.nseq_src) A.nseq_dst[lane] = A.nseq_src[lane];
     for (uint32_t g = blockIdx.x; g < A.n_groups; g += gridDim.x) {
         __builtin_amdgcn_wave_barrier();
         const uint32_t qf = 2 * g, qr = 2 * g + 1;
@@ -1084,9 +1087,12 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     memcpy((uint8_t*)ctx->h_cin.p + b_meta, rc_of, b_rc);
     DP_HIP(hipMemcpyAsync(ctx->d_cin.p, ctx->h_cin.p, b_meta + b_rc, hipMemcpyHostToDevice, ctx->stream));
     const size_t b_paf = (size_t)np * sizeof(dp_paf_rec), b_ign = (size_t)np * 4, b_gm = ((size_t)ng * sizeof(dp_group_meta) + 15) & ~(size_t)15;
-    if (dev_reserve(ctx, ctx->d_cout, b_paf + b_ign + b_gm + 64)) return DP_ERR_HIP;
+    // The kernel's output - group records, PAF records, ignore ids: written once, read by nobody on the device - goes straight
+    // into the pinned host block (the kernel's stores cross the link; the wait below is the stream's), and the chunk count of
+    // dp_index_build_chunked rides along: two copies per round that never were submitted (a copy costs more
+    // than its bytes)
     if (pin_reserve(ctx, ctx->h_cout, b_paf + b_ign + b_gm + 96)) return DP_ERR_HIP;
-    uint8_t* dout = (uint8_t*)ctx->d_cout.p;
+    uint8_t* dout = (uint8_t*)ctx->h_cout.p;
     ConsFullArgs A;
     A.recs = (const uint32_t*)ctx->d_mrec.p;
     A.ma = (const int32_t*)ctx->d_ma.p;
@@ -1122,15 +1128,15 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
         DP_HIP(dp_dev_malloc((void**)&A.dbg, (size_t)ng * 64));
         DP_HIP(hipMemsetAsync(A.dbg, 0, (size_t)ng * 64, ctx->stream));
     }
+    uint32_t* h_nseq = (uint32_t*)((uint8_t*)ctx->h_cout.p + ((b_paf + b_ign + b_gm + 15) & ~(size_t)15));
+    h_nseq[0] = ctx->n_seqs;
+    h_nseq[1] = 0;
+    A.nseq_src = ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : nullptr;
+    A.nseq_dst = h_nseq;
     DP_HIP(dp_mark(ctx, 0));
     hipLaunchKernelGGL(consensus_full_kernel, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), 0, ctx->stream, A);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 1));
-    DP_HIP(hipMemcpyAsync(ctx->h_cout.p, dout, b_paf + b_ign + b_gm, hipMemcpyDeviceToHost, ctx->stream));
-    uint32_t* h_nseq = (uint32_t*)((uint8_t*)ctx->h_cout.p + ((b_paf + b_ign + b_gm + 15) & ~(size_t)15));
-    h_nseq[0] = ctx->n_seqs;
-    h_nseq[1] = 0;
-    if (ctx->chunks_on_device) DP_HIP(hipMemcpyAsync(h_nseq, ctx->d_nseqs.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     if (h_nseq[1]) return dp_fail(ctx, DP_ERR_CAPACITY, "dp_index_build_chunked: chunk bound exceeded");
     if (pending) {

@@ -362,7 +362,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     for (void* q : ctx->retired_dev) dp_dev_free(q);
     for (void* q : ctx->retired_pin) hipHostFree(q);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
-                     &ctx->h_seeds, &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
+                     &ctx->h_seeds, &ctx->h_spack, &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
     for (auto* b : pbs)
         if (b->p) hipHostFree(b->p);
     for (auto& ev : ctx->ev)
@@ -1405,7 +1405,10 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     uint32_t* s_item = (uint32_t*)ctx->d_surv.p;
     uint32_t* s_count = s_item + n_items;
     uint64_t* s_off = (uint64_t*)(s_count + n_items + (n_items & 1));
-    uint4* s_pack = (uint4*)(s_off + n_items + (n_items & 1));  // {item, count, offset} per survivor: what goes to the host, one copy
+    // {item, count, offset} per survivor: what the host wants of the compaction.  The kernel that makes the list writes it into a
+    // pinned host block directly (nobody reads it on the device) - a 100 KB copy per round that is never submitted
+    if (pin_reserve(ctx, ctx->h_spack, (size_t)n_items * 16 + 64)) return DP_ERR_HIP;
+    uint4* s_pack = (uint4*)ctx->h_spack.p;
     // Resident k-mer position index instead of scanning (dp_kindex.hip): DP_SCAN_INDEX=1 forces it, =0 forbids it; by
     // default it is used from 1 Gbase up.  That is the break-even of a whole job: the build costs ~0.13 s per Gbase, a
     // round saves (scan 0.5 ms per Gbase) - (index step 0.25 ms), and a job has ~600 rounds per Gbase of 10 kb reads.
@@ -1479,7 +1482,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     uint32_t* h_item = (uint32_t*)ctx->h_surv.p;
     uint32_t* h_count = h_item + n_surv_all;
     uint64_t* h_off = (uint64_t*)(h_count + n_surv_all + (n_surv_all & 1));
-    uint32_t* h_pack = (uint32_t*)(h_off + n_surv_all + (n_surv_all & 1));
+    const uint32_t* h_pack = (const uint32_t*)ctx->h_spack.p;  // (complete since the wait after the count pass)
     if (n_segs) {
         DP_HIP(dp_mark(ctx, 2));
         if (use_index) {
@@ -1519,9 +1522,6 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
             DP_HIP(hipMemcpyAsync((int32_t*)ctx->h_segs.p + from, (const int32_t*)ctx->d_segs.p + from, (n_segs - from) * 4, hipMemcpyDeviceToHost,
                                   ctx->stream));
     }
-    // the survivor list travels behind the write pass, not in front of it: a copy handed to a stream that has nothing queued
-    // costs the calling thread 70-80 us inside the runtime (sampled), one queued behind kernels costs a few
-    if (n_surv_all) DP_HIP(hipMemcpyAsync(h_pack, s_pack, n_surv_all * 16, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     if (n_segs) ms1 = dp_elapsed(ctx, 2, 3);
     if (scan_lock.owns_lock()) scan_lock.unlock();
