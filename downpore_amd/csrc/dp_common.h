@@ -75,6 +75,7 @@ struct dp_ctx {
     uint32_t scan_items = 0;
     DevBuf d_ignore, d_surv;          // dp_scan_reads: ignore mask; compacted survivor lists
     PinBuf h_surv;
+    PinBuf h_extra;                   // the extra scan items (query windows) of a round, staged for the device to fetch
     PinBuf h_spack;                   // the survivor list as the compaction kernel writes it (pinned, written by the device)
     uint64_t ignore_epoch = ~0ull;
     uint64_t cached_bases = 0;
@@ -162,7 +163,16 @@ struct dp_zero_region {
     void* p;
     size_t bytes;
 };
-int dp_zero_regions(dp_ctx* ctx, const dp_zero_region* r, int n);  // pinned copy of a caller buffer, valid until the next dp_stream_sync
+int dp_zero_regions(dp_ctx* ctx, const dp_zero_region* r, int n);
+// The same launch also fetches up to two blocks from PINNED host memory into device buffers (8-byte words; both sides need
+// slack up to the next multiple of 8): an upload done by a kernel of the stream itself instead of a copy handed to the
+// runtime - copies, not kernels, are what the runtime makes expensive with several rounds in flight.
+struct dp_fetch_region {
+    void* dst;        // device
+    const void* src;  // pinned host (hipHostMalloc)
+    size_t bytes;
+};
+int dp_zero_fetch_regions(dp_ctx* ctx, const dp_zero_region* z, int nz, const dp_fetch_region* f, int nf);  // pinned copy of a caller buffer, valid until the next dp_stream_sync
 
 #define DP_HIP(call)                                                          \
     do {                                                                      \

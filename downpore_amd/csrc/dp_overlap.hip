@@ -2204,12 +2204,13 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     memcpy(up, q_off, up_off);
     memcpy(up + up_off, q_segs, up_segs);
     memcpy(up + up_off + up_segs, mc.data(), up_mc);
-    DP_HIP(hipMemcpyAsync(ctx->d_qsegs.p, up, up_off + up_segs + up_mc, hipMemcpyHostToDevice, ctx->stream));
     if (dev_reserve(ctx, ctx->d_cursor, 128)) return DP_ERR_HIP;
-    {   // (the chaining stage's cursor block rides along: it is zero when the first attempt starts)
+    {   // (the chaining stage's cursor block rides along: it is zero when the first attempt starts; and the same launch fetches
+        // the upload block from its pinned staging - no copy is handed to the runtime)
         const dp_zero_region z[4] = {{ctx->d_qsets.p, (size_t)nq * SW * 8}, {ctx->d_cand.p, (size_t)nq * W * 8}, {d_qmeta, (size_t)nq * 28},
                                      {ctx->d_cursor.p, 128}};
-        if (int rc = dp_zero_regions(ctx, z, 4)) return rc;
+        const dp_fetch_region f = {ctx->d_qsegs.p, up, up_off + up_segs + up_mc};
+        if (int rc = dp_zero_fetch_regions(ctx, z, 4, &f, 1)) return rc;
     }
     DP_HIP(dp_mark(ctx, 4));
     hipLaunchKernelGGL(query_kernel, dim3(nq), dim3(64 * Q_WAVES), 0, ctx->stream,

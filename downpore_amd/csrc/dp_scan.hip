@@ -257,22 +257,34 @@ hipError_t dp_dev_free(void* p) {
 struct ZeroArgs {
     unsigned long long* p[4];
     unsigned long long n8[4];
+    unsigned long long* dst[2];
+    const unsigned long long* src[2];
+    unsigned long long m8[2];
 };
 __global__ void zero_regions_kernel(const ZeroArgs a) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (unsigned long long)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int r = 0; r < 2; r++)  // (the fetches first: their loads cross the link while the stores below go out)
+        for (unsigned long long j = i; j < a.m8[r]; j += stride) a.dst[r][j] = __builtin_nontemporal_load(&a.src[r][j]);
 #pragma unroll
     for (int r = 0; r < 4; r++)
         for (unsigned long long j = i; j < a.n8[r]; j += stride) a.p[r][j] = 0ull;
 }
 // (a round has a dozen buffers to clear, and every hipMemsetAsync is a dispatch of its own: the command processor, not the
 // memory, is what they cost - tools/micro/launch_rate.hip)
-int dp_zero_regions(dp_ctx* ctx, const dp_zero_region* r, int n) {
+int dp_zero_fetch_regions(dp_ctx* ctx, const dp_zero_region* z, int nz, const dp_fetch_region* f, int nf) {
     ZeroArgs a;
     unsigned long long most = 0;
     for (int i = 0; i < 4; i++) {
-        a.p[i] = i < n ? (unsigned long long*)r[i].p : nullptr;
-        a.n8[i] = i < n && r[i].p ? (r[i].bytes + 7) / 8 : 0;
+        a.p[i] = i < nz ? (unsigned long long*)z[i].p : nullptr;
+        a.n8[i] = i < nz && z[i].p ? (z[i].bytes + 7) / 8 : 0;
         most = std::max(most, a.n8[i]);
+    }
+    for (int i = 0; i < 2; i++) {
+        a.dst[i] = i < nf ? (unsigned long long*)f[i].dst : nullptr;
+        a.src[i] = i < nf ? (const unsigned long long*)f[i].src : nullptr;
+        a.m8[i] = i < nf && f[i].dst && f[i].src ? (f[i].bytes + 7) / 8 : 0;
+        most = std::max(most, a.m8[i]);
     }
     if (!most) return DP_OK;
     const uint32_t blocks = (uint32_t)std::min<unsigned long long>(4096, (most + 1023) / 1024);
@@ -280,6 +292,7 @@ int dp_zero_regions(dp_ctx* ctx, const dp_zero_region* r, int n) {
     DP_HIP(hipGetLastError());
     return DP_OK;
 }
+int dp_zero_regions(dp_ctx* ctx, const dp_zero_region* r, int n) { return dp_zero_fetch_regions(ctx, r, n, nullptr, 0); }
 
 extern "C" const char* dp_version(void) { return "downpore_hip 0.1 (gfx950)"; }
 
@@ -362,7 +375,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     for (void* q : ctx->retired_dev) dp_dev_free(q);
     for (void* q : ctx->retired_pin) hipHostFree(q);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
-                     &ctx->h_seeds, &ctx->h_spack, &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
+                     &ctx->h_seeds, &ctx->h_spack, &ctx->h_extra, &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
     for (auto* b : pbs)
         if (b->p) hipHostFree(b->p);
     for (auto& ev : ctx->ev)
@@ -1386,8 +1399,12 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         ctx->items_top = top_level;
         ctx->items_k = k;
     }
-    if (n_extra)  // (borrowed from the caller; this call waits for its stream before it returns)
-        DP_HIP(hipMemcpyAsync(d_items + n_read_items, extra, (size_t)n_extra * sizeof(dp_scan_item), hipMemcpyHostToDevice, ctx->stream));
+    if (n_extra) {  // (borrowed from the caller: staged in a pinned block, fetched by a kernel of this stream)
+        if (pin_reserve(ctx, ctx->h_extra, (size_t)n_extra * sizeof(dp_scan_item) + 64)) return DP_ERR_HIP;
+        memcpy(ctx->h_extra.p, extra, (size_t)n_extra * sizeof(dp_scan_item));
+        const dp_fetch_region f = {d_items + n_read_items, ctx->h_extra.p, (size_t)n_extra * sizeof(dp_scan_item)};
+        if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, &f, 1)) return rc;
+    }
     int dev_cus = 256;
     hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
