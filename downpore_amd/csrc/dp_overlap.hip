@@ -2345,9 +2345,13 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     hipLaunchKernelGGL(chain_walk_kernel, dim3(st.walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 2);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 7));
-    DP_HIP(hipMemcpyAsync(ctx->h_cursor.p, ctx->d_cursor.p, 128, hipMemcpyDeviceToHost, ctx->stream));
-    // status words, per-query posting-word counts and candidate counts come back in any case (a few KB), in the same wait
-    DP_HIP(hipMemcpyAsync(ctx->h_qm.p, st.d_qmeta, (size_t)nq * 28, hipMemcpyDeviceToHost, ctx->stream));
+    {
+        // the cursor block and the status words, per-query posting-word counts and candidate counts (a few KB) come back in any
+        // case, in the same wait: stored into their pinned blocks by one small launch of this stream (dp_zero_fetch_regions works
+        // in either direction) instead of two copies handed to the runtime
+        const dp_fetch_region f[2] = {{ctx->h_cursor.p, ctx->d_cursor.p, 128}, {ctx->h_qm.p, st.d_qmeta, (size_t)nq * 28}};
+        if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, f, 2)) return rc;
+    }
     st.attempt++;
     return DP_OK;
 }

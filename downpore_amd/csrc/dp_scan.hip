@@ -1470,7 +1470,10 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     }
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 4));
-    DP_HIP(hipMemcpyAsync(ctx->h_total.p, totals, 48, hipMemcpyDeviceToHost, ctx->stream));
+    {   // (stored into the pinned block by a launch of this stream, not copied by the runtime)
+        const dp_fetch_region f = {ctx->h_total.p, totals, 48};
+        if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, &f, 1)) return rc;
+    }
     DP_HIP(dp_stream_sync(ctx));
     {
         // DP_SCAN_RELEASE_EARLY=1 opens the gate here, after the count pass, so that the short write pass overlaps the
@@ -1535,9 +1538,16 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
             if (!n_extra) from = n_segs;
             else if (use_index) from = std::min<uint64_t>(n_segs, ((uint64_t*)ctx->h_total.p)[5]);
         }
-        if (from < n_segs)
-            DP_HIP(hipMemcpyAsync((int32_t*)ctx->h_segs.p + from, (const int32_t*)ctx->d_segs.p + from, (n_segs - from) * 4, hipMemcpyDeviceToHost,
-                                  ctx->stream));
+        if (from < n_segs) {
+            if (n_segs - from <= ((uint64_t)1 << 20)) {  // a few hundred KB: stored by a launch of this stream (8-byte words)
+                const uint64_t f0 = from & ~(uint64_t)1;
+                const dp_fetch_region f = {(int32_t*)ctx->h_segs.p + f0, (const int32_t*)ctx->d_segs.p + f0, (n_segs - f0) * 4};
+                if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, &f, 1)) return rc;
+            } else {
+                DP_HIP(hipMemcpyAsync((int32_t*)ctx->h_segs.p + from, (const int32_t*)ctx->d_segs.p + from, (n_segs - from) * 4,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+            }
+        }
     }
     DP_HIP(dp_stream_sync(ctx));
     if (n_segs) ms1 = dp_elapsed(ctx, 2, 3);
