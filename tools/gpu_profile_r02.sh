@@ -11,6 +11,7 @@ R=gpurun_out/r02
 rm -rf $R/ktrace
 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/ktrace -- python3 bench.py > $R/ktrace_bench.json 2> $R/ktrace_bench.err; echo "ktrace rc=$?"
 find $R/ktrace -name "*kernel_trace.csv" -size +20M -exec sh -c 'python3 tools/ktrace_digest.py "$1" > "$1.digest.txt"; rm -f "$1"' _ {} \;
+if [ -n "$KTRACE_ONLY" ]; then du -sh $R; ls $R $R/ktrace/*; exit 0; fi
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS"
 COMMON="--steps 1 --warmup 0 --cpu-rounds 0 --scan-leg-rounds 0 --dense-leg-rounds 0"
 run() { # name, counters, bench args...
