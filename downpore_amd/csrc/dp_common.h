@@ -75,6 +75,7 @@ struct dp_ctx {
     uint32_t scan_items = 0;
     DevBuf d_ignore, d_surv;          // dp_scan_reads: ignore mask; compacted survivor lists
     PinBuf h_surv;
+    bool extras_staged = false;       // ... and have not been brought to d_items yet (the index step's first kernel or a fetch launch does)
     PinBuf h_extra;                   // the extra scan items (query windows) of a round, staged for the device to fetch
     PinBuf h_spack;                   // the survivor list as the compaction kernel writes it (pinned, written by the device)
     uint64_t ignore_epoch = ~0ull;
@@ -193,7 +194,7 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                     const uint64_t* d_totals, int32_t* d_segs);
 
 // kernels implemented in other translation units
-int dp_match_anchors_launch(dp_ctx* ctx);  // dp_overlap.hip: GetSeedOffset / GetSeedOffsetFromEnd anchors of the last chaining stage's records
+int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch = nullptr);  // dp_overlap.hip: GetSeedOffset / GetSeedOffsetFromEnd anchors of the last chaining stage's records
 int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs);
 int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,
                           uint32_t max_query_len, int want_candidates, dp_match_batch* out);

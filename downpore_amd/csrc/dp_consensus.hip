@@ -1085,10 +1085,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     if (dev_reserve(ctx, ctx->d_cin, b_meta + b_rc + 64)) return DP_ERR_HIP;
     if (metas) memcpy(ctx->h_cin.p, metas, b_meta);
     memcpy((uint8_t*)ctx->h_cin.p + b_meta, rc_of, b_rc);
-    {
-        const dp_fetch_region f = {ctx->d_cin.p, ctx->h_cin.p, b_meta + b_rc};  // (fetched by a kernel of this stream, not copied by the runtime)
-        if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, &f, 1)) return rc;
-    }
+    const dp_fetch_region cin_fetch = {ctx->d_cin.p, ctx->h_cin.p, b_meta + b_rc};  // (brought over by the anchors launch below)
     const size_t b_paf = (size_t)np * sizeof(dp_paf_rec), b_ign = (size_t)np * 4, b_gm = ((size_t)ng * sizeof(dp_group_meta) + 15) & ~(size_t)15;
     // The kernel's output - group records, PAF records, ignore ids: written once, read by nobody on the device - goes straight
     // into the pinned host block (the kernel's stores cross the link; the wait below is the stream's), and the chunk count of
@@ -1113,7 +1110,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     }
     A.rc_of = (const int32_t*)((const uint8_t*)ctx->d_cin.p + b_meta);
     {
-        int rc = dp_match_anchors_launch(ctx);
+        int rc = dp_match_anchors_launch(ctx, &cin_fetch);
         if (rc != 0) return rc;
     }
     A.anchors = (const int32_t*)ctx->d_manchor.p;

@@ -226,13 +226,20 @@ __global__ void kidx_link_extra(const dp_scan_item* __restrict__ items, uint32_t
 // start of a round's counting step in one launch: the work area (fill cursors, tile status, ticket, hit slots), the item
 // counters and the totals go to zero, and the extra items are linked to their reads (head[] is all zero between calls)
 __global__ void kidx_prepare(uint32_t* __restrict__ work, uint32_t n_work, uint32_t* __restrict__ counts, uint32_t n_counts,
-                             uint32_t* __restrict__ totals16, const dp_scan_item* __restrict__ items, uint32_t n_read_items,
-                             uint32_t n_extra, uint32_t* __restrict__ head, uint32_t* __restrict__ next) {
+                             uint32_t* __restrict__ totals16, dp_scan_item* __restrict__ items, uint32_t n_read_items,
+                             uint32_t n_extra, uint32_t* __restrict__ head, uint32_t* __restrict__ next,
+                             const dp_scan_item* __restrict__ extra_src) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_work) work[i] = 0;
     if (i < n_counts) counts[i] = 0;
     if (i < 16) totals16[i] = 0;
-    if (i < n_extra) next[i] = atomicExch(&head[items[n_read_items + i].read], i + 1);
+    if (i < n_extra) {
+        // extra_src: the round's extra items still sit in the caller's pinned staging block - this thread brings its item over
+        // (no upload of its own for ten kilobytes)
+        dp_scan_item it = extra_src ? extra_src[i] : items[n_read_items + i];
+        if (extra_src) items[n_read_items + i] = it;
+        next[i] = atomicExch(&head[it.read], i + 1);
+    }
 }
 __global__ void kidx_unlink_extra(const dp_scan_item* __restrict__ items, uint32_t n_read_items, uint32_t n_extra,
                                   uint32_t* __restrict__ head) {
@@ -554,7 +561,9 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     {
         const uint32_t n_thr = std::max(std::max(n_work, n_items), std::max(n_extra, 16u));
         hipLaunchKernelGGL(kidx_prepare, dim3((n_thr + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)ctx->d_kx_sz.p, n_work, d_counts, n_items,
-                           (uint32_t*)d_totals, d_items, n_read_items, n_extra, head, next);
+                           (uint32_t*)d_totals, const_cast<dp_scan_item*>(d_items), n_read_items, n_extra, head, next,
+                           ctx->extras_staged ? (const dp_scan_item*)ctx->h_extra.p : (const dp_scan_item*)nullptr);
+        ctx->extras_staged = false;
     }
     if (S)
         hipLaunchKernelGGL(kidx_walk<false>, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), 0, ctx->stream, dp_seeds_ptr(ctx), S,

@@ -1627,8 +1627,12 @@ struct MRec {
 __global__ __launch_bounds__(256) void match_anchor_kernel(const MRec* __restrict__ recs, const uint32_t* __restrict__ n_pairs,
                                                            uint32_t pair_cap, const int32_t* __restrict__ mb,
                                                            const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, int k,
-                                                           int32_t* __restrict__ anchors) {
+                                                           int32_t* __restrict__ anchors, unsigned long long* __restrict__ fetch_dst,
+                                                           const unsigned long long* __restrict__ fetch_src, unsigned long long fetch_n8) {
     const int lane = threadIdx.x & 63;
+    // (the consensus kernel's input block - pinned host memory - is brought over by this launch, which runs just before it)
+    for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < fetch_n8; j += (unsigned long long)gridDim.x * blockDim.x)
+        fetch_dst[j] = __builtin_nontemporal_load(&fetch_src[j]);
     const uint32_t nslots = min(*n_pairs, pair_cap);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     for (uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); slot < nslots; slot += waves) {
@@ -2522,15 +2526,18 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
 }
 
 // Anchors of every final record of the chaining stage (device resident): d_manchor[2 * pair]
-int dp_match_anchors_launch(dp_ctx* ctx) {
+int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch) {
     // (a pending chaining stage: the pair count is on the device only - the launch covers the stage's capacity)
     const uint32_t nslots = dp_find_pending(ctx) ? dp_find_pair_cap(ctx) : ctx->n_pairs;
     if (dev_reserve(ctx, ctx->d_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
-    if (!nslots) return DP_OK;
+    if (!nslots) return fetch ? dp_zero_fetch_regions(ctx, nullptr, 0, fetch, 1) : DP_OK;
     const u64* d_totals = (const u64*)((const uint8_t*)ctx->d_cursor.p + 64);
     hipLaunchKernelGGL(match_anchor_kernel, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256), 0, ctx->stream,
                        (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
-                       (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, ctx->last_k, (int32_t*)ctx->d_manchor.p);
+                       (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, ctx->last_k, (int32_t*)ctx->d_manchor.p,
+                       fetch ? (unsigned long long*)fetch->dst : (unsigned long long*)nullptr,
+                       fetch ? (const unsigned long long*)fetch->src : (const unsigned long long*)nullptr,
+                       fetch ? (unsigned long long)((fetch->bytes + 7) / 8) : 0ull);
     DP_HIP(hipGetLastError());
     return DP_OK;
 }
@@ -2558,7 +2565,8 @@ int dp_fetch_overlaps_impl(dp_ctx* ctx, int want_candidates, dp_match_batch* out
     if (nslots) {
         hipLaunchKernelGGL(match_anchor_kernel, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256), 0, ctx->stream,
                            (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
-                           (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, k, (int32_t*)ctx->d_manchor.p);
+                           (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, k, (int32_t*)ctx->d_manchor.p,
+                           (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0ull);
         DP_HIP(hipGetLastError());
         DP_HIP(hipMemcpyAsync(ctx->h_manchor.p, ctx->d_manchor.p, (size_t)nslots * 8, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_mrec.p, ctx->d_mrec.p, (size_t)nslots * sizeof(MRec), hipMemcpyDeviceToHost, ctx->stream));

@@ -1402,9 +1402,14 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     if (n_extra) {  // (borrowed from the caller: staged in a pinned block, fetched by a kernel of this stream)
         if (pin_reserve(ctx, ctx->h_extra, (size_t)n_extra * sizeof(dp_scan_item) + 64)) return DP_ERR_HIP;
         memcpy(ctx->h_extra.p, extra, (size_t)n_extra * sizeof(dp_scan_item));
-        const dp_fetch_region f = {d_items + n_read_items, ctx->h_extra.p, (size_t)n_extra * sizeof(dp_scan_item)};
-        if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, &f, 1)) return rc;
     }
+    ctx->extras_staged = n_extra > 0;
+    auto fetch_extras = [&]() -> int {  // (the index step's first kernel does this itself: dp_kindex_count)
+        if (!ctx->extras_staged) return DP_OK;
+        ctx->extras_staged = false;
+        const dp_fetch_region f = {d_items + n_read_items, ctx->h_extra.p, (size_t)n_extra * sizeof(dp_scan_item)};
+        return dp_zero_fetch_regions(ctx, nullptr, 0, &f, 1);
+    };
     int dev_cus = 256;
     hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
@@ -1446,6 +1451,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     }
     out->index_mode = use_index ? 1u : 0u;
     if (!use_index) {
+        if (int rc = fetch_extras()) return rc;
         if (int rc = seed_tables_ensure(ctx)) return rc;
         scan_lock.lock();
         DP_HIP(dp_mark(ctx, 0));

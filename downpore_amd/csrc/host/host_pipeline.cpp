@@ -20,11 +20,12 @@ struct WindowCache::Impl {
     dp_ctx* ctx;
     int k;
     // windows per chunk: 8192 (one selection kernel + one copy back per chunk; the producer is busy half of a config-2 job
-    // with that, with 2048 it could not keep up) - except the first two, which the first plans of a job wait for
-    static constexpr uint32_t CW = 8192, CW0 = 1024;
-    static uint32_t chunkOf(uint32_t w) { return w < CW0 ? 0u : w < CW ? 1u : 1u + w / CW; }
-    static size_t chunkBegin(uint32_t c) { return c == 0 ? 0 : c == 1 ? CW0 : (size_t)(c - 1) * CW; }
-    static constexpr uint32_t SOFT_CAP = 9;  // chunks kept ahead of the release point unless somebody waits for more
+    // with that, with 2048 it could not keep up) - except the first four (1024, 1024, 2048, 4096), which the first plans of a
+    // job wait for: every slot stands still until the chunk its first plan needs is there
+    static constexpr uint32_t CW = 8192;
+    static uint32_t chunkOf(uint32_t w) { return w < 1024 ? 0u : w < 2048 ? 1u : w < 4096 ? 2u : w < CW ? 3u : 3u + w / CW; }
+    static size_t chunkBegin(uint32_t c) { return c == 0 ? 0 : c <= 3 ? (size_t)512 << c : (size_t)(c - 3) * CW; }
+    static constexpr uint32_t SOFT_CAP = 11;  // chunks kept ahead of the release point unless somebody waits for more
     struct Chunk {
         std::vector<uint32_t> spec, kmers;
     };

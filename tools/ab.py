@@ -4,7 +4,7 @@ previous commit); runs them in alternation REPS times and prints min / median of
 Boxes differ by 10 % and some are erratic: only numbers from one call compare."""
 import json, os, statistics, subprocess, sys
 reps = int(os.environ.get("REPS", "4"))
-slots = os.environ.get("SLOTS", "8")
+slots = os.environ.get("SLOTS", "5")
 extra = os.environ.get("BENCH_ARGS", "").split()
 variants = []
 for v in sys.argv[1:]:
