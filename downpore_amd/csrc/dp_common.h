@@ -191,7 +191,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                     uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint4* s_pack, uint64_t* d_totals);
 int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     const uint32_t* d_sel, uint32_t n_sel, uint32_t max_count, const uint32_t* d_counts, const uint64_t* d_segoff,
-                    const uint64_t* d_totals, int32_t* d_segs);
+                    const uint64_t* d_totals, int32_t* d_segs, int32_t* host_segs = nullptr);
 
 // kernels implemented in other translation units
 int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch = nullptr);  // dp_overlap.hip: GetSeedOffset / GetSeedOffsetFromEnd anchors of the last chaining stage's records

@@ -439,7 +439,9 @@ __global__ __launch_bounds__(64) void kidx_sortwrite(const dp_scan_item* __restr
                                                      const uint32_t* __restrict__ n_sel_p, const uint32_t* __restrict__ counts,
                                                      const uint64_t* __restrict__ segoff, int32_t* __restrict__ segs, int k,
                                                      uint32_t* __restrict__ overflow, uint32_t n_read_items, uint32_t n_extra,
-                                                     uint32_t* __restrict__ head) {
+                                                     uint32_t* __restrict__ head, int32_t* __restrict__ host_segs) {
+    // host_segs (may be null): pinned host mirror of segs[] - the extra items' (query windows') segments are stored there as
+    // well, at the same offsets: they are what the host wants of this pass, and no copy has to fetch them afterwards
     __shared__ unsigned long long keys[CAP];
     const int lane = dp_lane();
     const uint32_t n_sel = *n_sel_p;
@@ -504,15 +506,21 @@ __global__ __launch_bounds__(64) void kidx_sortwrite(const dp_scan_item* __restr
             if (lane == 0) atomicExch(overflow, 1u);
             continue;
         }
+        const bool mirror = host_segs != nullptr && it >= n_read_items;
         for (uint32_t j = lane; j < c; j += 64) {
             const int p = (int)(keys[j] >> 32);
             const int prev = j ? (int)(keys[j - 1] >> 32) : -k;  // "-k": the first gap is the hit's own index
             segs[out + 2 * (uint64_t)j] = p - (prev + k);
             segs[out + 2 * (uint64_t)j + 1] = (int32_t)(uint32_t)keys[j];
+            if (mirror) {
+                host_segs[out + 2 * (uint64_t)j] = p - (prev + k);
+                host_segs[out + 2 * (uint64_t)j + 1] = (int32_t)(uint32_t)keys[j];
+            }
         }
         if (lane == 0) {
             const int last = c ? (int)(keys[c - 1] >> 32) : -k;
             segs[out + 2 * (uint64_t)c] = nk - last - 1;  // final gap (sequence/asm_amd64.s:387-392)
+            if (mirror) host_segs[out + 2 * (uint64_t)c] = nk - last - 1;
         }
     }
 }
@@ -583,7 +591,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
 // hits than the LDS sort holds (the caller answers the round with the scan kernels instead).
 int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     const uint32_t* d_sel, uint32_t n_sel, uint32_t max_count, const uint32_t* d_counts, const uint64_t* d_segoff,
-                    const uint64_t* d_totals, int32_t* d_segs) {
+                    const uint64_t* d_totals, int32_t* d_segs, int32_t* host_segs) {
     dp_kindex* ix = kidx_owner(ctx)->kidx;
     dp_ctx* ow = kidx_owner(ctx);
     const uint32_t S = ctx->n_seeds;
@@ -604,13 +612,13 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         const uint32_t* nsp = (const uint32_t*)(d_totals + 1);
         if (max_count <= 128)
             hipLaunchKernelGGL(kidx_sortwrite<256>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
-                               n_extra, head);
+                               n_extra, head, host_segs);
         else if (max_count <= 512)
             hipLaunchKernelGGL(kidx_sortwrite<1024>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
-                               n_extra, head);
+                               n_extra, head, host_segs);
         else
             hipLaunchKernelGGL(kidx_sortwrite<KX_SORT_LDS>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf,
-                               n_read_items, n_extra, head);
+                               n_read_items, n_extra, head, host_segs);
         DP_HIP(hipGetLastError());
     }
     if (n_extra && (rc != DP_OK || !n_sel))  // (otherwise the sort kernel has put head[] back to zero)

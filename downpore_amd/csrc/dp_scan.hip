@@ -1509,12 +1509,15 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     uint32_t* h_count = h_item + n_surv_all;
     uint64_t* h_off = (uint64_t*)(h_count + n_surv_all + (n_surv_all & 1));
     const uint32_t* h_pack = (const uint32_t*)ctx->h_spack.p;  // (complete since the wait after the count pass)
+    // dp_scan_fetch_mode(1) with the index step: the only segments the host wants are the extra items' - the sort kernel stores
+    // them into the pinned block as it writes them (no store launch afterwards)
+    const bool mirror_extras = use_index && ctx->scan_fetch_extras_only && n_extra > 0;
     if (n_segs) {
         DP_HIP(dp_mark(ctx, 2));
         if (use_index) {
             int rc = dp_kindex_write(ctx, k, (const dp_scan_item*)d_items, lo, hi, n_read_items, n_extra, (const uint32_t*)s_item,
                                      (uint32_t)n_surv_all, kx_max_count, (const uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
-                                     (const uint64_t*)totals, (int32_t*)ctx->d_segs.p);
+                                     (const uint64_t*)totals, (int32_t*)ctx->d_segs.p, mirror_extras ? (int32_t*)ctx->h_segs.p : (int32_t*)nullptr);
             if (rc < 0) return rc;
             if (rc > 0) {  // a survivor with more hits than the in-LDS sort holds: the scan kernels answer this round
                 DP_HIP(dp_stream_sync(ctx));
@@ -1541,7 +1544,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         // extra items' - the query windows', which follow the survivors in the scan output - come to the host, at their offsets
         uint64_t from = 0;
         if (ctx->scan_fetch_extras_only) {
-            if (!n_extra) from = n_segs;
+            if (!n_extra || mirror_extras) from = n_segs;
             else if (use_index) from = std::min<uint64_t>(n_segs, ((uint64_t*)ctx->h_total.p)[5]);
         }
         if (from < n_segs) {
