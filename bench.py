@@ -223,8 +223,10 @@ def main():
         n = max(1.0, float(rounds))  # per-round averages over every round of every timed job
         main_index = bool(acc.get("idx_rounds"))
 
+        nt = max(1.0, float(acc.get("timed_rounds", 0.0)))  # rounds whose kernels were bracketed by HIP events (every 8th of a slot)
+
         def per_round(key):
-            return acc.get(key, 0.0) / n
+            return acc.get(key, 0.0) / (nt if key.startswith("k_") else n)
 
         def pmc_traffic(name):
             tpath = os.path.join(ROOT, "profiles", name)
@@ -285,6 +287,8 @@ def main():
             "paf_lines": lines, "rounds_per_s": rounds / elapsed if elapsed > 0 else 0.0,
             "phase_ms_per_round": {kk: 1e3 * per_round(kk) for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
             "kernel_ms_per_round": {kk: per_round(kk) for kk in ("k_count_ms", "k_write_ms", "k_scan_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
+            "kernel_event_sampling": {"rounds_with_events": acc.get("timed_rounds", 0.0), "rounds": float(rounds),
+                                      "note": "HIP events bracket the kernels of every 8th round of an executor slot in the timed jobs (every event is a packet of its own: 7 % of a job when every round carries them); the legs time every round"},
             "setup_s": {"generate": t_gen},
             # host side of the timed region: CPU seconds used by this container and time it spent throttled by its CPU quota
             "host": host_info(),
@@ -303,6 +307,15 @@ def main():
 
 def rounds_leg(pipe, n_rounds, torch, warm=8):
     """`n_rounds` rounds of a fresh job on `pipe` (after `warm` untimed ones): rate and per-round kernel times."""
+    from downpore_amd import hip
+    hip.load_library().dp_set_kernel_timing(1)  # (the legs are about kernel durations: every round carries its events)
+    try:
+        return _rounds_leg(pipe, n_rounds, torch, warm)
+    finally:
+        hip.load_library().dp_set_kernel_timing(int(os.environ.get("DP_KERNEL_TIMING", "8")))
+
+
+def _rounds_leg(pipe, n_rounds, torch, warm):
     pipe.init()
     got = w = 0
     while w < warm:
@@ -328,7 +341,8 @@ def rounds_leg(pipe, n_rounds, torch, warm=8):
     m = max(1, got)
     d = {kk: tot.get(kk, 0.0) - base.get(kk, 0.0) for kk in tot}
     return {"value": lines / dt if dt > 0 else 0.0, "unit": "overlaps/s", "rounds": got, "ms_per_round": 1e3 * dt / m,
-            "kernel_ms_per_round": {kk: d.get(kk, 0.0) / m for kk in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms")},
+            "kernel_ms_per_round": {kk: d.get(kk, 0.0) / max(1.0, d.get("timed_rounds", 0.0)) for kk in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms")},
+            "rounds_with_kernel_events": d.get("timed_rounds", 0.0),
             "query_bytes_per_round": d.get("query_bytes", 0.0) / m, "n_indexed_per_round": d.get("n_indexed", 0.0) / m,
             "_rounds": float(got), "_count_bytes": d.get("count_bytes", 0.0)}
 

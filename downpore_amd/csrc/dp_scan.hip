@@ -70,6 +70,11 @@ static ScanGate g_scan_mu;
 // environment overrides it.  DP_SYNC_POLL_US=0: blocking hipEventSynchronize instead of the poll loop.
 static std::atomic<int> g_wait_spin{0};
 extern "C" void dp_set_stream_wait(int spin) { g_wait_spin.store(spin ? 1 : 0); }
+static std::atomic<long> g_timing_every{[] {
+    const char* e = getenv("DP_KERNEL_TIMING");
+    return e ? atol(e) : 8L;
+}()};
+extern "C" void dp_set_kernel_timing(int every) { g_timing_every.store(every < 0 ? 0 : every); }
 
 const void* dp_stage(dp_ctx* ctx, const void* src, size_t bytes) {
     const size_t at = (ctx->stage_used + 63) & ~(size_t)63;
@@ -868,12 +873,9 @@ extern "C" int dp_round_begin(dp_ctx* ctx, int k, const uint32_t* seed_kmers, ui
     // seed_tables_ensure() when a scan actually runs (a round served by the k-mer position index never needs them)
     ctx->tables_dirty = true;
     {
-        // DP_KERNEL_TIMING=N: the round's kernels are bracketed by timing events in every N-th round of this context (every
-        // event is a packet of its own for the command processor; 0 = never).  Untimed rounds report 0 ms.
-        static const long every = [] {
-            const char* e = getenv("DP_KERNEL_TIMING");
-            return e ? atol(e) : 1L;
-        }();
+        // the round's kernels are bracketed by timing events in every N-th round of this context (dp_set_kernel_timing /
+        // DP_KERNEL_TIMING; every event is a packet of its own for the command processor; 0 = never).  Untimed rounds report 0 ms.
+        const long every = g_timing_every.load(std::memory_order_relaxed);
         ctx->timing_on = every > 0 && (ctx->round_serial++ % (uint64_t)every) == 0;
     }
     ctx->k = k;

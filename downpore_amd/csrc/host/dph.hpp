@@ -278,13 +278,14 @@ struct RoundStats {
     uint64_t n_queries = 0, n_indexed = 0, n_hits = 0, n_matches = 0, n_paf = 0, n_seeds = 0;
     uint64_t chain_bytes = 0;               // algorithmic bytes of the prefilter + chaining kernel
     uint64_t idx_rounds = 0, idx_hits = 0;  // rounds served by the resident k-mer position index, and their seed occurrences
+    uint64_t timed_rounds = 0;              // rounds whose kernels were bracketed by timing events (dp_set_kernel_timing): the k_*_ms are theirs
     void add(const RoundStats& o) {
         t_prepare += o.t_prepare, t_scan += o.t_scan, t_index += o.t_index, t_query += o.t_query, t_consensus += o.t_consensus;
         k_scan_ms += o.k_scan_ms, k_query_ms += o.k_query_ms, k_chain_ms += o.k_chain_ms, k_count_ms += o.k_count_ms;
         k_write_ms += o.k_write_ms, k_cons_ms += o.k_cons_ms, count_bytes += o.count_bytes, scan_bases += o.scan_bases;
         scan_items += o.scan_items, scan_bytes += o.scan_bytes, query_bytes += o.query_bytes, n_queries += o.n_queries;
         n_indexed += o.n_indexed, n_hits += o.n_hits, n_matches += o.n_matches, n_paf += o.n_paf, n_seeds += o.n_seeds;
-        chain_bytes += o.chain_bytes, idx_rounds += o.idx_rounds, idx_hits += o.idx_hits;
+        chain_bytes += o.chain_bytes, idx_rounds += o.idx_rounds, idx_hits += o.idx_hits, timed_rounds += o.timed_rounds;
     }
 };
 

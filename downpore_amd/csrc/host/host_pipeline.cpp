@@ -978,6 +978,7 @@ void OverlapRun::commitText(RoundResult& r) {
     emptyMatch += r.fs.emptyMatch;
     paf += r.paf;
     pafLines += (i64)r.fs.lines;
+    r.st.timed_rounds = (r.st.k_chain_ms > 0 || r.st.k_query_ms > 0 || r.st.k_cons_ms > 0 || r.st.k_count_ms > 0 || r.st.k_scan_ms > 0) ? 1 : 0;
     last = r.st;
     total.add(r.st);
 }

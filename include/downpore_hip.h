@@ -59,6 +59,11 @@ DP_API int dp_ctx_set_priority(dp_ctx* ctx, int high);
  * occupies a core), 0 = poll an event every 20 us (the default: a waiting thread costs nothing).  Process-wide; a caller with
  * one executor thread per context and cores to spare wants the first (eight rounds in flight: 0.44 against 0.54 ms per round). */
 DP_API void dp_set_stream_wait(int spin);
+/* Kernel times in the per-call statistics (dp_scan_batch.kernel_ms, dp_paf_batch.*_kernel_ms ...) come from events recorded
+ * around the launches; every event is a packet of its own for the command processor (five rounds in flight: 0.307 ms per
+ * round with every round timed, 0.294 with every eighth, 0.286 with none).  every = N: each context times every N-th of its
+ * rounds and reports 0 ms for the others; 0 = never; the default is 8 (or DP_KERNEL_TIMING).  Process-wide. */
+DP_API void dp_set_kernel_timing(int every);
 DP_API void dp_ctx_destroy(dp_ctx* ctx);
 DP_API const char* dp_last_error(const dp_ctx* ctx); /* ctx may be NULL: error of the last failed dp_ctx_create */
 

@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tools.synth import gen_reads  # noqa: E402
 from downpore_amd.overlap import OverlapPipeline, Reads  # noqa: E402
+from downpore_amd import hip
+hip.load_library().dp_set_kernel_timing(1)  # every round carries its timing events here
 
 N = int(os.environ.get("READS", "100000"))
 k = int(os.environ.get("K", "10"))
