@@ -70,6 +70,21 @@ func (c *Context) Shared() (*Context, error) {
 	return &Context{h}, nil
 }
 
+// SetStreamWait chooses how calls of the library wait for their stream (process-wide): spinning wakes up at once and occupies
+// a core per waiting goroutine, polling costs nothing.  A caller with one goroutine per context and cores to spare wants true.
+func SetStreamWait(spin bool) {
+	v := C.int(0)
+	if spin {
+		v = 1
+	}
+	C.dp_set_stream_wait(v)
+}
+
+// SetKernelTiming: each context brackets the kernels of every n-th of its rounds with timing events (0 = never; the kernel
+// times of the other rounds read 0).  Every event is a packet of its own for the GPU's command processor: with several
+// rounds in flight, timing every round costs 7 % of a job.  Process-wide; the library's default is 8.
+func SetKernelTiming(every int) { C.dp_set_kernel_timing(C.int(every)) }
+
 func (c *Context) Close() {
 	if c.h != nil {
 		C.dp_ctx_destroy(c.h)
