@@ -17,7 +17,9 @@ for t in sys.argv[1:]:
 print("  sum: %.2f rounds/ms -> %.3f ms/round equivalent"%(tot,1/tot if tot else 0))
 PY
 }
-echo "one process, 6 slots"; run 6 6 a; show a
+echo "one process, 5 slots"; run 5 6 a; show a
 echo "two processes, 3 slots each"; DP_HOST_THREADS=8 run 3 10 b1 & DP_HOST_THREADS=8 run 3 10 b2 & wait; show b1 b2
+if [ -n "$ALL" ]; then
 echo "three processes, 2 slots each"; DP_HOST_THREADS=6 run 2 10 c1 & DP_HOST_THREADS=6 run 2 10 c2 & DP_HOST_THREADS=6 run 2 10 c3 & wait; show c1 c2 c3
 echo "two processes, 6 slots each"; DP_HOST_THREADS=9 run 6 10 d1 & DP_HOST_THREADS=9 run 6 10 d2 & wait; show d1 d2
+fi
