@@ -141,7 +141,9 @@ def main():
             if golden is not None and args.max_rounds < 0:
                 checks["paf_sha256_matches_oracle_fixture"] = bool(hashlib.sha256(paf.encode()).hexdigest() == golden["paf_sha256"] and
                                                                    lines == golden["paf_lines"] and rounds == golden["rounds"])
+        t_r = time.perf_counter()
         pipe.reset()
+        res["reset_s"] = res.get("reset_s", 0.0) + (time.perf_counter() - t_r) if not verify else res.get("reset_s", 0.0)
         return lines, rounds, tot, t_init
 
     res = {}
@@ -276,7 +278,7 @@ def main():
             "rounds_only": {"value": lines / max(1e-9, elapsed - t_init_sum), "unit": "overlaps/s",
                             "ms_per_round": 1e3 * (elapsed - t_init_sum) / n,
                             "note": "the same timed jobs without their set-up (value table, k-mer index, slots, planner)"},
-            "job_breakdown_s": {"whole_job": job_s, "setup_value_table_kmer_index_slots": t_init_sum / n_jobs,
+            "job_breakdown_s": {"whole_job": job_s, "setup_value_table_kmer_index_slots": t_init_sum / n_jobs, "reset_end_of_job": res.get("reset_s", 0.0) / n_jobs,
                                 "rounds": (elapsed - t_init_sum) / n_jobs, "upload_pack_once": upload["upload_pack_s"],
                                 "context_once": upload["context_s"], "per_job": per_job},
             "kernels_per_round": {kk: {"ms": v[0], "algorithmic_bytes": v[1], "GBs": (v[1] / 1e9) / (v[0] / 1e3) if v[0] > 0 else 0.0,

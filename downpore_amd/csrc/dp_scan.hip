@@ -715,7 +715,8 @@ extern "C" int dp_values_upload(dp_ctx* ctx, const double* values, uint64_t n) {
 static int select_impl(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, int num_seeds, uint32_t* top_out,
                        const uint32_t** evaluated_out, uint32_t stride) {
     if (k < 1 || k > 16 || num_seeds < 1 || num_seeds > SEL_MAXTOP) return dp_fail(ctx, DP_ERR_ARG, "dp_select_seeds: k in 1..16, num_seeds in 1..64");
-    if (!ctx->d_values.p || ctx->n_values != ((uint64_t)1 << (2 * k))) return dp_fail(ctx, DP_ERR_STATE, "dp_select_seeds: value table for this k not uploaded");
+    const dp_ctx* vsrc = ctx->owner ? ctx->owner : ctx;  // (a borrowing context outlives the owner's value tables: look them up there)
+    if (!vsrc->d_values.p || vsrc->n_values != ((uint64_t)1 << (2 * k))) return dp_fail(ctx, DP_ERR_STATE, "dp_select_seeds: value table for this k not uploaded");
     if (n == 0) return DP_OK;
     hipSetDevice(ctx->device);
     for (uint32_t i = 0; i < n; i++) {
@@ -731,7 +732,7 @@ static int select_impl(dp_ctx* ctx, const dp_scan_item* win, uint32_t n, int k, 
     uint32_t* d_ev = stride ? (uint32_t*)((uint8_t*)ctx->d_seltop.p + tb) : nullptr;
     hipLaunchKernelGGL(select_kernel, dim3(n), dim3(64), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
                        (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_selwin.p, n, k, num_seeds,
-                       (const double*)ctx->d_values.p, (uint32_t*)ctx->d_seltop.p, d_ev, stride, (const uint8_t*)ctx->d_qual.p,
+                       (const double*)vsrc->d_values.p, (uint32_t*)ctx->d_seltop.p, d_ev, stride, (const uint8_t*)ctx->d_qual.p,
                        (const int64_t*)ctx->d_qualoff.p, (const uint8_t*)ctx->d_hasq.p);
     DP_HIP(hipGetLastError());
     DP_HIP(hipMemcpyAsync((uint8_t*)ctx->h_seltop.p + wb, ctx->d_seltop.p, tb + eb, hipMemcpyDeviceToHost, ctx->stream));

@@ -603,7 +603,7 @@ struct OverlapRun {
 
     int init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const double* valuesOrNull, int nSlots = 1);
     ~OverlapRun();
-    void shutdown();
+    void shutdown(bool keepContexts = false);
     Survivors& local() { return slots[0]->local; }
     // ---- whole rounds on this process: plans (prefetched) -> execute (one round per slot, concurrently) -> commit in order.
     // Returns the number of rounds committed, 0 = finished, <0 error

@@ -149,7 +149,7 @@ int dph_overlap_init(void* hh, const int64_t* params, double minHits, const doub
 }
 int dph_overlap_reset(void* hh) {
     OverlapH* h = (OverlapH*)hh;
-    h->run.shutdown();
+    h->run.shutdown(true);  // (the slots' and the planner's contexts serve the handle's next job)
     h->pafChunks.clear();
     h->allPafJoined.clear();
     std::fill(h->reads->ignore.begin(), h->reads->ignore.end(), 0);

@@ -222,6 +222,10 @@ struct Planner::Impl {
 Planner::Planner(ReadSet& reads, const OverlapParams& p, ValueView values, bool threaded, dp_ctx* selCtx, WindowCache* cache)
     : d(new Impl(reads, p, values, threaded, selCtx)) {
     d->winCache = cache;
+    // flag epochs are unique per planner (= per job): device contexts that outlive a job (OverlapRun::shutdown(keepContexts))
+    // remember the epoch of the flags they hold, and a new job's epoch n must not look like the old job's epoch n
+    static std::atomic<uint64_t> serial{0};
+    d->epoch = (serial.fetch_add(1) + 1) << 32;
     if (const char* e = getenv("DPH_TEST_PLAN_DELAY_US")) d->testDelayUs = atol(e);
     d->fromCache = cache && (p.queryType & 1) && !(p.queryType & 8) && p.numSeeds == cache->numSeeds;
     if (threaded) setLanes(1);
@@ -566,7 +570,10 @@ void OverlapRun::HugeTable::clear() {
     n = bytes = mapped_ = 0;
 }
 
-void OverlapRun::shutdown() {
+// keepContexts: the job is over but the handle goes on to another one on the same resident reads (dph_overlap_reset): the
+// executor slots' and the planner's device contexts - streams, per-round device and pinned buffers - stay; tearing them down
+// and building them again cost 25 ms between two jobs of 0.2 s (some sixty buffers per context, every free a device-wide wait).
+void OverlapRun::shutdown(bool keepContexts) {
     sampleProfStop();
     {
         std::lock_guard<std::mutex> lk(pmu_);
@@ -582,11 +589,14 @@ void OverlapRun::shutdown() {
     if (planner) g_prof.print();
     planner.reset();
     winCache.reset();
-    if (plannerCtx) dp_ctx_destroy(plannerCtx);
-    plannerCtx = nullptr;
     for (auto& sl : slots) {
         sl->lap.reset();
         sl->index.reset();
+    }
+    if (keepContexts) return;
+    if (plannerCtx) dp_ctx_destroy(plannerCtx);
+    plannerCtx = nullptr;
+    for (auto& sl : slots) {
         if (sl->ownsCtx && sl->ctx) dp_ctx_destroy(sl->ctx);
         sl->ctx = nullptr;
     }
@@ -705,7 +715,13 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         }
     }
     mark("values upload");
-    slots.clear();
+    // contexts kept by a reset() of this handle are taken over when they fit (same owner context, same number of slots)
+    const bool reuseSlots = !slots.empty() && (int)slots.size() == std::max(1, nSlots) && slots[0]->ctx == ctx;
+    if (!reuseSlots) {
+        for (auto& sl : slots)
+            if (sl->ownsCtx && sl->ctx) dp_ctx_destroy(sl->ctx);
+        slots.clear();
+    }
     {
         const char* dt = getenv("DP_DEFER_TEXT");  // 0: the executor slots format their rounds' text themselves
         textPool.reset();
@@ -716,6 +732,11 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     // cores for it (the worker pool's size is the CPU budget: cgroup quota, or DP_HOST_THREADS for ranks sharing a host)
     dp_set_stream_wait(hostThreads() >= (unsigned)std::max(1, nSlots) + 3u ? 1 : 0);
     for (int i = 0; i < std::max(1, nSlots); i++) {
+        if (reuseSlots) {
+            slots[(size_t)i]->index.reset(new SeedIndex(p.k));
+            slots[(size_t)i]->comm = (size_t)i < slotComms.size() ? slotComms[(size_t)i] : nullptr;
+            continue;
+        }
         std::unique_ptr<ExecSlot> sl(new ExecSlot());
         if (i == 0) {
             sl->ctx = ctx;
@@ -734,7 +755,12 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     mark("executor slots");
     const char* nothread = getenv("DP_NO_PLANNER_THREAD");
     const char* hostsel = getenv("DP_HOST_SELECT");  // 1: keep the speculative seed selection on the host threads
-    if (!(hostsel && hostsel[0] == '1') && p.numSeeds <= 64) {
+    const bool wantPlannerCtx = !(hostsel && hostsel[0] == '1') && p.numSeeds <= 64;
+    if (plannerCtx && !wantPlannerCtx) {
+        dp_ctx_destroy(plannerCtx);
+        plannerCtx = nullptr;
+    }
+    if (wantPlannerCtx && !plannerCtx) {
         int rc = dp_ctx_create_shared(ctx, &plannerCtx);
         if (rc != 0) {
             error = dp_last_error(nullptr);

@@ -263,6 +263,30 @@ def test_overlap_planner_lanes(monkeypatch, lanes, case):
     assert orun.rounds >= 2
 
 
+@pytest.mark.parametrize("slots", [1, 3])
+def test_overlap_jobs_in_a_row_on_one_handle(slots):
+    """reset() ends a job and keeps the handle - and with it the executor slots' and the planner's device contexts (streams,
+    buffers, the flags and read items they hold) - for the next job on the same resident reads: three jobs in a row, the read
+    set has rounds that flag reads (the contexts remember flag epochs: a new job's must not look like the old one's), every
+    job's PAF and flags equal the oracle's."""
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(32, 60000, 500, 1500, 0.0, True)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    orun = O.OverlapRun(rs, k=10)
+    assert rs.ignore().sum() > 0 and orun.rounds >= 2
+    reads = Reads(bases, off, min_len=1000)
+    pipe = OverlapPipeline(reads, k=10, slots=slots, defer_init=True)
+    for job in range(3):
+        pipe.init()
+        rounds = pipe.run()
+        assert rounds == orun.rounds, "job %d" % job
+        assert first_diff(pipe.all_paf(), orun.paf) is None, "job %d" % job
+        assert np.array_equal(reads.ignore(), rs.ignore()), "job %d" % job
+        pipe.reset()
+        assert reads.ignore().sum() == 0
+    pipe.close()
+
+
 def test_overlap_himem_false_top_level_reads():
     """himem=false: reads are re-read as top-level sequences, len%4==0 scan quirk included."""
     _run_both(7, 100000, 300, 4000, 10, himem=False, max_rounds=3)
