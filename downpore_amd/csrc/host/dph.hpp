@@ -321,7 +321,8 @@ class WindowCache {
     struct Win {
         uint32_t read, start, len;
     };
-    WindowCache(dp_ctx* ctx, const ReadSet& reads, i64 overlap, int k, int numSeeds);
+    // ctx == nullptr: the producer selects on the host with hostValues (tests of the plan chain without a GPU)
+    WindowCache(dp_ctx* ctx, const ReadSet& reads, i64 overlap, int k, int numSeeds, ValueView hostValues = ValueView((const double*)nullptr));
     ~WindowCache();
     std::vector<uint32_t> first;  // windows of read r: [first[r], first[r + 1])
     std::vector<Win> wins;

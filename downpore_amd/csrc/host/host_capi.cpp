@@ -528,6 +528,66 @@ extern "C" int dph_selftest_planner_flags(void* readsH, int k, int64_t seedBatch
     return 0;
 }
 
+// ---- host-logic test hook (no GPU needed): the whole plan chain of a read set three ways - the general PrepareQueries path
+// (no window cache), the window-cache path with one planner lane, and with `lanes` lanes that start plans from guesses of
+// where their predecessors end - with the same commits in all three (every `flagEvery`-th round flags two reads ahead of the
+// chain, as a final check would).  The window cache's producer selects on the host here (WindowCache with ctx == nullptr).
+// Returns 0 = all chains equal, r + 1 = they differ in round r, < 0 = set-up problem; *nRounds = plans of the chain.
+extern "C" int dph_selftest_planner_lanes(void* readsH, int k, int64_t seedBatchSize, const double* values, int lanes, int flagEvery,
+                                          int64_t* nRounds) {
+    ReadSet& reads = ((ReadsH*)readsH)->set;
+    OverlapParams p;
+    p.k = k;
+    p.seedBatchSize = seedBatchSize;
+    struct Rec {
+        i64 firstIn, firstOut;
+        std::vector<Overlapper::Window> windows;
+        std::vector<uint32_t> seedMap;
+        bool empty;
+    };
+    auto chain = [&](bool useCache, int nLanes, std::vector<Rec>& out) -> int {
+        std::fill(reads.ignore.begin(), reads.ignore.end(), 0);
+        std::unique_ptr<WindowCache> wc;
+        if (useCache) wc.reset(new WindowCache(nullptr, reads, p.overlapSize, k, p.numSeeds, ValueView(values)));
+        Planner pl(reads, p, ValueView(values), true, nullptr, wc.get());
+        pl.setLanes(nLanes);
+        for (i64 r = 0;; r++) {
+            std::shared_ptr<const RoundPlan> pp = pl.get(r);
+            if (!pp) return -1;
+            if (pp->failed) return -2;
+            out.push_back({pp->firstIn, pp->firstOut, pp->windows, pp->seedMap, pp->empty});
+            if (pp->empty) break;
+            if (r > 100000) return -3;
+            std::vector<int> flags;
+            if (flagEvery > 0 && r % flagEvery == flagEvery - 1) {  // one read a little ahead of the chain, one far ahead
+                const i64 a = pp->firstOut + 3, b = pp->firstOut + 40;
+                if (a < (i64)reads.size()) flags.push_back((int)a);
+                if (b < (i64)reads.size()) flags.push_back((int)b);
+            }
+            pl.applyIgnores(flags, r);
+            pl.dropBefore(r + 1, pp->firstOut);
+        }
+        return 0;
+    };
+    std::vector<Rec> a, b, c;
+    if (int rc = chain(false, 1, a)) return rc;
+    if (int rc = chain(true, 1, b)) return rc - 10;
+    if (int rc = chain(true, lanes, c)) return rc - 20;
+    std::fill(reads.ignore.begin(), reads.ignore.end(), 0);
+    if (nRounds) *nRounds = (int64_t)a.size();
+    auto same = [](const Rec& x, const Rec& y) {
+        if (x.firstIn != y.firstIn || x.firstOut != y.firstOut || x.empty != y.empty || x.seedMap != y.seedMap || x.windows.size() != y.windows.size()) return false;
+        for (size_t i = 0; i < x.windows.size(); i++)
+            if (x.windows[i].read != y.windows[i].read || x.windows[i].start != y.windows[i].start || x.windows[i].len != y.windows[i].len) return false;
+        return true;
+    };
+    for (size_t r = 0; r < std::max(a.size(), std::max(b.size(), c.size())); r++) {
+        if (r >= a.size() || r >= b.size() || r >= c.size()) return (int)r + 1;
+        if (!same(a[r], b[r]) || !same(a[r], c[r])) return (int)r + 1;
+    }
+    return 0;
+}
+
 // ---- test hook: SeedIndex::touchesSeed on evaluated k-mers, every instruction-set variant the CPU has against the scalar one.
 // Fills res[w] (w < nWindows; windows of `stride` k-mers) with the scalar answers; returns the number of disagreements, and
 // sets *isaMask to the variants that ran (bit 1 AVX2, bit 2 AVX-512).

@@ -18,6 +18,8 @@ namespace dph {
 
 struct WindowCache::Impl {
     dp_ctx* ctx;
+    const ReadSet* reads = nullptr;
+    ValueView hostValues = ValueView((const double*)nullptr);
     int k;
     // windows per chunk: 8192 (one selection kernel + one copy back per chunk; the producer is busy half of a config-2 job
     // with that, with 2048 it could not keep up) - except the first four (1024, 1024, 2048, 4096), which the first plans of a
@@ -39,8 +41,10 @@ struct WindowCache::Impl {
     std::thread th;
 };
 
-WindowCache::WindowCache(dp_ctx* ctx, const ReadSet& reads, i64 overlap, int k, int numSeeds_) : d(new Impl()) {
+WindowCache::WindowCache(dp_ctx* ctx, const ReadSet& reads, i64 overlap, int k, int numSeeds_, ValueView hostValues) : d(new Impl()) {
     d->ctx = ctx;
+    d->reads = &reads;
+    d->hostValues = hostValues;
     d->k = k;
     numSeeds = numSeeds_;
     first.resize(reads.size() + 1);
@@ -111,9 +115,41 @@ void WindowCache::producer() {
         ch->spec.resize(n * (size_t)numSeeds);
         ch->kmers.resize(n * (size_t)stride);
         const uint32_t* ev = nullptr;
-        const int rc = dp_select_windows(d->ctx, items.data(), (uint32_t)n, d->k, numSeeds, ch->spec.data(), &ev, stride);
+        int rc = 0;
+        if (d->ctx) {
+            rc = dp_select_windows(d->ctx, items.data(), (uint32_t)n, d->k, numSeeds, ch->spec.data(), &ev, stride);
+        } else {  // host stand-in for the selection kernel: the same walk, block winners and evaluated k-mers (AddSeeds :62-156)
+            SeedIndex none(d->k, 21);
+            const uint32_t mask = (uint32_t)(((uint64_t)1 << (2 * d->k)) - 1);
+            for (size_t i = 0; i < n; i++) {
+                const Win& wn = wins[w0 + i];
+                const char* sq = d->reads->seq(wn.read) + wn.start;
+                const i64 L = wn.len;
+                none.selectSeeds(sq, L, numSeeds, d->hostValues, ch->spec.data() + i * (size_t)numSeeds, false);
+                uint32_t* km = ch->kmers.data() + i * (size_t)stride;
+                std::fill(km, km + stride, 0xffffffffu);
+                uint32_t at = 0, kmer = 0;
+                auto kmerAt = [&](i64 pos) {
+                    uint32_t v = 0;
+                    for (int j = 0; j < d->k; j++) v = (v << 2) | baseCode((unsigned char)sq[pos + j]);
+                    return v;
+                };
+                if (L >= d->k) kmer = kmerAt(0);
+                i64 nextIndex = d->k;
+                while (nextIndex < L - d->k) {
+                    for (int j = 0; nextIndex < L && j < d->k; j++) {
+                        kmer = ((kmer << 2) | baseCode((unsigned char)sq[nextIndex])) & mask;
+                        nextIndex++;
+                        if (at < stride) km[at++] = kmer;
+                    }
+                    nextIndex += d->k;
+                    if (nextIndex < L - d->k) kmer = kmerAt(nextIndex);
+                    nextIndex += d->k;
+                }
+            }
+        }
         if (rc == 0) {
-            memcpy(ch->kmers.data(), ev, n * (size_t)stride * 4);
+            if (d->ctx) memcpy(ch->kmers.data(), ev, n * (size_t)stride * 4);
             std::vector<uint32_t> both((size_t)numSeeds * 2);
             for (size_t i = 0; i < n; i++) {  // commitSeeds enters every selected k-mer and its reverse complement
                 const uint32_t* sp = ch->spec.data() + i * (size_t)numSeeds;

@@ -54,3 +54,31 @@ def test_touch_test_vector_variants_agree():
     assert bad == 0
     assert np.array_equal(res, want)
     assert want.sum() >= n_windows // 3
+
+
+def test_planner_lanes_compute_the_chain_of_one_lane():
+    """Planner lanes start plans from guesses of where their predecessors end.  The whole plan chain of a read set
+    - windows, seed lists, firstSequence of every round - must come out the same from the general PrepareQueries path, from the
+    window-cache path with one lane and from the window-cache path with several lanes, with reads flagged along the way.  The
+    window cache's producer selects on the host here (no GPU).  k = 8 with a large seed budget: a sixth of all k-mers are seeds,
+    nearly every window is re-selected and reverse complements collide, so guesses fail and plans are recomputed."""
+    from downpore_amd.overlap import Reads, load_host
+    H = load_host()
+    H.dph_selftest_planner_lanes.restype = C.c_int
+    H.dph_selftest_planner_lanes.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+    H.dph_planner_counter.restype = C.c_int64
+    H.dph_planner_counter.argtypes = [C.c_int]
+    for (seed, G, N, L, variable, k, budget, lanes, flag_every) in [(7, 60000, 400, 3000, False, 8, 1500, 4, 0),
+                                                                    (8, 80000, 500, 2500, True, 10, 800, 3, 3),
+                                                                    (9, 50000, 300, 4000, False, 8, 4000, 5, 2)]:
+        bases, off = O.gen_reads(seed, G, N, L, 0.0, variable)
+        reads = Reads(bases, off, min_len=1000)
+        rng = np.random.default_rng(seed)
+        values = np.ascontiguousarray(rng.random(4 ** k))
+        values[0] = 0.0
+        n = C.c_int64(0)
+        thrown = H.dph_planner_counter(1)
+        rc = H.dph_selftest_planner_lanes(reads.h, k, budget, values.ctypes.data, lanes, flag_every, C.byref(n))
+        assert rc == 0, "chains differ (rc %d; > 0: first differing round + 1) for k=%d budget=%d lanes=%d" % (rc, k, budget, lanes)
+        assert n.value >= 5, "only %d plans: the case does not exercise the chain" % n.value
+        print("k=%d budget=%d lanes=%d: %d plans, %d computed plans thrown away" % (k, budget, lanes, n.value, H.dph_planner_counter(1) - thrown))
