@@ -307,18 +307,24 @@ def main():
         dist.destroy_process_group()
 
 
-def rounds_leg(pipe, n_rounds, torch, warm=8):
-    """`n_rounds` rounds of a fresh job on `pipe` (after `warm` untimed ones): rate and per-round kernel times."""
+def rounds_leg(pipe, n_rounds, torch, warm=8, fixture=None):
+    """`n_rounds` rounds of a fresh job on `pipe` (after `warm` untimed ones): rate and per-round kernel times.  fixture: an
+    oracle fixture of exactly warm + n_rounds rounds of this job (tests/golden_full) - the leg's PAF is then held to it."""
     from downpore_amd import hip
     hip.load_library().dp_set_kernel_timing(1)  # (the legs are about kernel durations: every round carries its events)
     try:
-        return _rounds_leg(pipe, n_rounds, torch, warm)
+        return _rounds_leg(pipe, n_rounds, torch, warm, fixture)
     finally:
         hip.load_library().dp_set_kernel_timing(int(os.environ.get("DP_KERNEL_TIMING", "8")))
 
 
-def _rounds_leg(pipe, n_rounds, torch, warm):
+def _rounds_leg(pipe, n_rounds, torch, warm, fixture=None):
     pipe.init()
+    if fixture is not None:  # exactly the fixture's rounds are committed (a step commits every finished round it finds)
+        import ctypes as C
+        pipe.H.dph_overlap_set_round_limit.restype = None
+        pipe.H.dph_overlap_set_round_limit.argtypes = [C.c_void_p, C.c_int64]
+        pipe.H.dph_overlap_set_round_limit(pipe.h, warm + n_rounds)
     got = w = 0
     while w < warm:
         c = pipe.step()
@@ -339,10 +345,17 @@ def _rounds_leg(pipe, n_rounds, torch, warm):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tot = pipe.stats_total()
+    parity = None
+    if fixture is not None:
+        paf = pipe.all_paf()
+        parity = {"fixture": fixture["case"],
+                  "paf_sha256_matches_oracle_fixture": bool(pipe.committed_rounds() == fixture["rounds"] and paf.count("\n") == fixture["paf_lines"] and
+                                                            hashlib.sha256(paf.encode()).hexdigest() == fixture["paf_sha256"])}
+        del paf
     pipe.reset()
     m = max(1, got)
     d = {kk: tot.get(kk, 0.0) - base.get(kk, 0.0) for kk in tot}
-    return {"value": lines / dt if dt > 0 else 0.0, "unit": "overlaps/s", "rounds": got, "ms_per_round": 1e3 * dt / m,
+    return {"value": lines / dt if dt > 0 else 0.0, "unit": "overlaps/s", "rounds": got, "ms_per_round": 1e3 * dt / m, "parity": parity,
             "kernel_ms_per_round": {kk: d.get(kk, 0.0) / max(1.0, d.get("timed_rounds", 0.0)) for kk in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms")},
             "rounds_with_kernel_events": d.get("timed_rounds", 0.0),
             "query_bytes_per_round": d.get("query_bytes", 0.0) / m, "n_indexed_per_round": d.get("n_indexed", 0.0) / m,
@@ -357,7 +370,18 @@ def dense_regime_leg(reads, args, torch):
     # one executor slot: the leg is here for the kernel's own duration (its roofline), and eight rounds in flight would have
     # eight of these streaming kernels share the HBM bandwidth and each launch take several times longer
     pipe = OverlapPipeline(reads, device=0, k=10, seed_batch_size=args.seed_batch_size, slots=1, defer_init=True)
-    leg = rounds_leg(pipe, args.dense_leg_rounds, torch, warm=4)
+    # the leg's rounds (4 untimed + the timed ones) are the first rounds of the k = 10 job on these reads: held to the oracle's
+    # fixture for exactly those rounds when one is committed (tests/golden_full/config2_k10_e0_first_16_rounds.json)
+    fixture = None
+    try:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden_full", "config2_k10_e0_first_%d_rounds.json" % (4 + args.dense_leg_rounds))))
+        gen = g["generator"]
+        if (gen["seed"] == args.seed and gen["reads"] == args.reads and gen["read_len"] == args.read_len and gen["error"] == args.error and
+                not gen["variable"] and g["k"] == 10 and args.seed_batch_size == 10000):
+            fixture = g
+    except Exception:
+        fixture = None
+    leg = rounds_leg(pipe, args.dense_leg_rounds, torch, warm=4, fixture=fixture)
     pipe.close()
     m = max(1.0, leg.pop("_rounds"))
     leg.pop("_count_bytes")

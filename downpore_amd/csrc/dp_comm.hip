@@ -3,7 +3,8 @@
 // all-gathered so that every GPU builds the identical index.  The exchange runs device to device on the context's own
 // stream: counts first (variable sizes), then the payloads, concatenated in rank order = file order.
 //   dp_comm_init        one process per GPU: an RCCL communicator over xGMI (librccl is loaded at run time, so a build of this
-//                       library does not depend on it and a process that never calls dp_comm_init never loads it);
+//                       library does not link against it - only its header is needed - and a process that never calls
+//                       dp_comm_init never loads it);
 //   dp_comm_init_local  one process driving several contexts (a Go host with one goroutine per GPU, or tests with several
 //                       contexts on one GPU): every rank publishes device pointers, peers copy with hipMemcpyPeerAsync.
 #include <dlfcn.h>
@@ -11,6 +12,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -25,6 +27,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -59,6 +62,7 @@ RcclApi* rccl_api() {
         api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
         api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
         api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
         api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
@@ -75,6 +79,7 @@ struct LocalGroup {
     int n = 0, refs = 0;
     uint64_t gen = 0;       // completed exchanges
     int arrived = 0, left = 0;
+    bool failed = false;    // a rank left an exchange with an error: every wait of this group returns, now and later (sticky)
     struct Pub {
         int device = 0;
         const void* counts = nullptr;   // device: uint64[2] = {survivors, segment ints of the survivors}
@@ -92,6 +97,7 @@ struct dp_comm {
     int n_ranks = 1, rank = 0;
     ncclComm_t nccl = nullptr;  // RCCL flavour
     LocalGroup* local = nullptr;  // one-process flavour
+    bool dead = false;            // an exchange failed on this rank: the communicator was aborted and refuses further calls
     hipEvent_t ev = nullptr;
     // per-rank scratch on the owning context's device
     DevBuf d_cnt, d_pay, d_allpay;
@@ -170,7 +176,10 @@ extern "C" int dp_comm_init_local(dp_ctx* const* ctxs, int n, dp_comm** out) {
 
 extern "C" void dp_comm_destroy(dp_comm* c) {
     if (!c) return;
-    if (c->nccl) rccl_api()->CommDestroy(c->nccl);
+    if (c->nccl) {  // (a communicator that failed mid-collective cannot be destroyed in the orderly way: that would wait for its peers)
+        if (c->dead && rccl_api()->CommAbort) rccl_api()->CommAbort(c->nccl);
+        else rccl_api()->CommDestroy(c->nccl);
+    }
     if (c->local) {
         bool last;
         {
@@ -225,9 +234,47 @@ static int comm_pin(dp_ctx* ctx, PinBuf& b, size_t bytes) {
 // the query windows - are scanned by every rank and are not exchanged).  Afterwards the context's device-resident scan
 // output is [survivors of rank 0 | rank 1 | ... | this rank's extra items], i.e. what a single GPU scanning every read would
 // hold, and `all` describes it the way dp_scan_reads would have (host copies included).
+static int allgather_survivors_impl(dp_comm* c, dp_ctx* ctx, const dp_survivor_batch* local, dp_survivor_batch* all);
+
+// The caller's own work of a round failed before it reached the exchange (or it gives up for any other reason): its peers
+// must not wait for it.  Marks the communicator dead; peers inside or entering an exchange return DP_ERR_STATE (in-process
+// group) or the error RCCL reports for an aborted communicator.
+extern "C" void dp_comm_abort(dp_comm* c) {
+    if (!c || c->dead) return;
+    c->dead = true;
+    if (c->local) {
+        std::lock_guard<std::mutex> lk(c->local->mu);
+        c->local->failed = true;
+        c->local->cv.notify_all();
+    }
+    if (c->nccl && rccl_api()->CommAbort) {
+        rccl_api()->CommAbort(c->nccl);
+        c->nccl = nullptr;
+    }
+}
+
+// A rank that leaves the exchange with an error must not leave its peers waiting for it: the in-process group is marked failed
+// (both barriers give up, now and in every later call), an RCCL communicator is aborted (ncclCommAbort: the peers' pending
+// collectives return an error instead of hanging) - a per-rank error stays a per-rank error code on every rank.
 extern "C" int dp_allgather_survivors(dp_comm* c, dp_ctx* ctx, const dp_survivor_batch* local, dp_survivor_batch* all) {
     if (!c || !ctx || !local || !all) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_allgather_survivors: bad arguments") : DP_ERR_ARG;
+    if (c->dead) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_survivors: the communicator failed in an earlier exchange");
+    const int rc = allgather_survivors_impl(c, ctx, local, all);
+    if (rc != DP_OK) {
+        c->dead = true;
+        if (c->local) {
+            std::lock_guard<std::mutex> lk(c->local->mu);
+            c->local->failed = true;
+            c->local->cv.notify_all();
+        }
+    }
+    return rc;
+}
+
+static int allgather_survivors_impl(dp_comm* c, dp_ctx* ctx, const dp_survivor_batch* local, dp_survivor_batch* all) {
     hipSetDevice(ctx->device);
+    if (const char* e = getenv("DP_COMM_FAIL_RANK"))  // test hook: this rank fails before it meets its peers
+        if (atoi(e) == c->rank) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_survivors: injected failure (DP_COMM_FAIL_RANK)");
     const int N = c->n_ranks, me = c->rank;
     const uint32_t ns = local->n_survivors, ne = local->n_extra;
     // local layout of d_segs: survivors' segments first, then the extra items'
@@ -270,12 +317,14 @@ extern "C" int dp_allgather_survivors(dp_comm* c, dp_ctx* ctx, const dp_survivor
         p.n_surv = ns;
         p.n_ints = surv_ints;
         const uint64_t my_gen = g->gen;
+        if (g->failed) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_survivors: a peer rank failed");
         if (++g->arrived == N) {
             g->arrived = 0;
             g->gen++;
             g->cv.notify_all();
         } else {
-            g->cv.wait(lk, [&] { return g->gen != my_gen; });
+            g->cv.wait(lk, [&] { return g->gen != my_gen || g->failed; });
+            if (g->gen == my_gen) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_survivors: a peer rank failed");
         }
         for (int r = 0; r < N; r++) {
             cnt[2 * r] = g->pub[(size_t)r].n_surv;
@@ -316,7 +365,8 @@ extern "C" int dp_allgather_survivors(dp_comm* c, dp_ctx* ctx, const dp_survivor
             so += qs;
             io += qi;
         }
-        R->GroupEnd();
+        const ncclResult_t rg = R->GroupEnd();  // (the group is always closed; the first error of either is what is reported)
+        if (r == ncclSuccess) r = rg;
         if (r != ncclSuccess) return dp_fail(ctx, DP_ERR_HIP, R->GetErrorString(r));
     } else {
         LocalGroup* g = c->local;
@@ -353,12 +403,14 @@ extern "C" int dp_allgather_survivors(dp_comm* c, dp_ctx* ctx, const dp_survivor
         LocalGroup* g = c->local;
         std::unique_lock<std::mutex> lk(g->mu);
         const uint64_t my_gen = g->gen;
+        if (g->failed) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_survivors: a peer rank failed");
         if (++g->left == N) {
             g->left = 0;
             g->gen++;
             g->cv.notify_all();
         } else {
-            g->cv.wait(lk, [&] { return g->gen != my_gen; });
+            g->cv.wait(lk, [&] { return g->gen != my_gen || g->failed; });
+            if (g->gen == my_gen) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_survivors: a peer rank failed");
         }
     }
     if (dev_reserve(ctx, ctx->d_segs, (size_t)new_ints * 4 + 64)) return DP_ERR_HIP;

@@ -176,11 +176,17 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes) {
 }
 
 // ---- large device blocks
+// Keyed by device: one process may drive several GPUs (dp_comm_init_local, a Go host with one goroutine per GPU); a block is
+// only ever handed back to the device it was allocated on, and the wait / hipFree that release it run with that device current.
 namespace {
+struct BigBlock {
+    size_t cap;
+    int device;
+};
 struct BigCache {
     std::mutex mu;
-    std::multimap<size_t, void*> free_;         // capacity -> block
-    std::unordered_map<void*, size_t> live;     // blocks handed out by dp_dev_malloc (>= kBig): their capacity
+    std::multimap<std::pair<int, size_t>, void*> free_;  // (device, capacity) -> block
+    std::unordered_map<void*, BigBlock> live;            // blocks handed out by dp_dev_malloc (>= kBig)
     size_t cached = 0;
 };
 BigCache& big_cache() {
@@ -188,6 +194,17 @@ BigCache& big_cache() {
     return *c;
 }
 constexpr size_t kBig = (size_t)32 << 20;
+struct DeviceGuard {  // makes `device` current for the scope, then restores the caller's
+    int prev = -1;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) (void)hipSetDevice(device);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
 }  // namespace
 
 size_t dp_dev_cached_bytes() {
@@ -198,27 +215,32 @@ size_t dp_dev_cached_bytes() {
 
 void dp_dev_trim() {
     BigCache& c = big_cache();
-    std::vector<void*> drop;
+    std::vector<std::pair<int, void*>> drop;
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        for (auto& e : c.free_) drop.push_back(e.second);
+        for (auto& e : c.free_) drop.push_back({e.first.first, e.second});
         c.free_.clear();
         c.cached = 0;
     }
-    for (void* q : drop) hipFree(q);
+    for (auto& q : drop) {
+        DeviceGuard g(q.first);
+        hipFree(q.second);
+    }
 }
 
 hipError_t dp_dev_malloc(void** p, size_t bytes) {
     *p = nullptr;
     if (bytes < kBig) return hipMalloc(p, bytes);
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     BigCache& c = big_cache();
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        auto it = c.free_.lower_bound(bytes);
-        if (it != c.free_.end() && it->first <= bytes + bytes / 4) {
+        auto it = c.free_.lower_bound({dev, bytes});
+        if (it != c.free_.end() && it->first.first == dev && it->first.second <= bytes + bytes / 4) {
             *p = it->second;
-            c.live[*p] = it->first;
-            c.cached -= it->first;
+            c.live[*p] = BigBlock{it->first.second, dev};
+            c.cached -= it->first.second;
             c.free_.erase(it);
             return hipSuccess;
         }
@@ -230,10 +252,10 @@ hipError_t dp_dev_malloc(void** p, size_t bytes) {
         dp_dev_trim();
         e = hipMalloc(p, bytes);
     }
-    if (alloc_trace()) fprintf(stderr, "[alloc] large device block %zu bytes, %.3f ms\n", bytes, 1e3 * (alloc_now() - t0));
+    if (alloc_trace()) fprintf(stderr, "[alloc] large device block %zu bytes on device %d, %.3f ms\n", bytes, dev, 1e3 * (alloc_now() - t0));
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(c.mu);
-        c.live[*p] = bytes;
+        c.live[*p] = BigBlock{bytes, dev};
     }
     return e;
 }
@@ -241,21 +263,25 @@ hipError_t dp_dev_malloc(void** p, size_t bytes) {
 hipError_t dp_dev_free(void* p) {
     if (!p) return hipSuccess;
     BigCache& c = big_cache();
-    size_t cap = 0;
+    BigBlock b{0, 0};
     {
         std::lock_guard<std::mutex> lk(c.mu);
         auto it = c.live.find(p);
         if (it != c.live.end()) {
-            cap = it->second;
+            b = it->second;
             c.live.erase(it);
         }
     }
-    if (!cap) return hipFree(p);
-    // what hipFree promises its caller: nothing on the device uses the block any more
-    hipError_t e = hipDeviceSynchronize();
+    if (!b.cap) return hipFree(p);
+    // what hipFree promises its caller: nothing on the block's device uses it any more
+    hipError_t e;
+    {
+        DeviceGuard g(b.device);
+        e = hipDeviceSynchronize();
+    }
     std::lock_guard<std::mutex> lk(c.mu);
-    c.free_.emplace(cap, p);
-    c.cached += cap;
+    c.free_.emplace(std::make_pair(b.device, b.cap), p);
+    c.cached += b.cap;
     return e;
 }
 

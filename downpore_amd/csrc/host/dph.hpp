@@ -586,6 +586,7 @@ struct OverlapRun {
     std::unique_ptr<WindowCache> winCache;  // QueryEdges: the windows' round-independent part, produced ahead of the planner
     std::unique_ptr<Planner> planner;
     dp_ctx* plannerCtx = nullptr;  // borrows the reads and the value table of `ctx`
+    dp_ctx* qualityCtx = nullptr;  // context whose resident reads carry their FASTQ quality bytes already (dp_quality_upload)
     i64 firstSequence = 0;
     i64 round = 0;  // next round to commit
     i64 numQuerySeqs = 0;
@@ -634,6 +635,7 @@ struct OverlapRun {
     // Returns the number of rounds committed, 0 = finished, <0 error.
     std::vector<dp_comm*> slotComms;
     int roundsShardedBatch();
+    void abortComms();
     // ---- round-parallel mode: execute round `r` speculatively against the current flags, commit gathered results
     int executeRound(i64 r, RoundResult& out);
     // returns the number of rounds committed from `results` (in order, all consecutive from `round`), stopping at the

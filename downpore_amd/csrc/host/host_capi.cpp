@@ -130,6 +130,13 @@ void* dph_overlap_open(void* reads, int device) {
     h->tCtx = tc1 - tc0;
     h->tUpload = now() - tc1;
     if (g_prof.on) fprintf(stderr, "[setup] context %.1f ms, upload + pack %.1f ms\n", 1e3 * h->tCtx, 1e3 * h->tUpload);
+    if (rc == 0 && rs.isFastq && !rs.qual.empty()) {
+        // FASTQ: the selection kernels weight values by the quality bytes (seeds.go:99-101).  Once per read set, here - the bytes
+        // belong to the reads, not to a job, and dp_quality_upload refuses a context that already lends its reads to others
+        // (the contexts a reset() keeps for the handle's next job do)
+        rc = dp_quality_upload(h->ctx, (const uint8_t*)rs.qual.data(), rs.off.data(), rs.hasQual.data(), (uint32_t)rs.size());
+        if (rc == 0) h->run.qualityCtx = h->ctx;
+    }
     if (rc != 0) {
         g_err = dp_last_error(h->ctx);
         dp_ctx_destroy(h->ctx);

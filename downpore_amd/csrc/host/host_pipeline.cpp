@@ -695,6 +695,18 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         valuesOnDevice = true;
         mark("value table (device)");
     }
+    if (reads->isFastq && !reads->qual.empty() && qualityCtx != ctx) {
+        // FASTQ: the selection kernels weight values by the quality bytes.  Normally resident since the reads were uploaded
+        // (dph_overlap_open); a caller that drives init() on its own context gets them here - before any context borrows the
+        // reads (the download thread below does), which dp_quality_upload refuses
+        int rc = dp_quality_upload(ctx, (const uint8_t*)reads->qual.data(), reads->off.data(), reads->hasQual.data(), (uint32_t)reads->size());
+        if (rc != 0) {
+            error = dp_last_error(ctx);
+            return rc;
+        }
+        qualityCtx = ctx;
+        mark("quality upload");
+    }
     // The host copy of the table (the planner re-selects a window on the host when its speculation did not hold) travels
     // on a second context while the executor slots, the planner's context and the window cache are set up.
     std::thread dl;
@@ -730,14 +742,6 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
             if (dlRc != 0) dlErr = dp_last_error(c2);
             dp_ctx_destroy(c2);
         });
-    }
-    if (reads->isFastq && !reads->qual.empty()) {  // FASTQ: the selection kernels weight values by the quality bytes
-        int rc = dp_quality_upload(ctx, (const uint8_t*)reads->qual.data(), reads->off.data(), reads->hasQual.data(), (uint32_t)reads->size());
-        if (rc != 0) {
-            error = dp_last_error(ctx);
-            return rc;
-        }
-        mark("quality upload");
     }
     errText += "Counting complete. Starting indexing and querying...";
     {
@@ -985,6 +989,7 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     if (rc == 0 && sharded) rc = sl.lap->ExchangeSurvivors(sl.comm, sl.gathered);
     if (rc != 0) {
         sl.error = sl.lap->err;
+        if (sharded) dp_comm_abort(sl.comm);  // (the peers of this round's exchange must not wait for a rank that will not come)
         return rc;
     }
     out.st.t_scan = now() - t1;
@@ -1362,20 +1367,31 @@ int OverlapRun::roundPrepareAndScan() {
     return 1;
 }
 
+// A failed rank stops taking part in the survivor exchanges: its communicators are aborted so that the other ranks' exchanges
+// return an error (dp_comm_abort) - a per-rank failure ends the job on every rank instead of hanging it.
+void OverlapRun::abortComms() {
+    if (comm) dp_comm_abort(comm);
+    for (dp_comm* c : slotComms)
+        if (c) dp_comm_abort(c);
+}
+
 int OverlapRun::roundSharded() {
     if (!comm) {
         error = "roundSharded without a communicator";
         return -1;
     }
     int rc = roundPrepareAndScan();
+    if (rc < 0) abortComms();
     if (rc <= 0) return rc;
     ExecSlot& sl = *slots[0];
     rc = sl.lap->ExchangeSurvivors(comm, gathered_);
     if (rc != 0) {
         error = sl.lap->err;
+        abortComms();
         return rc;
     }
     rc = roundFinish(gathered_);
+    if (rc < 0) abortComms();
     return rc < 0 ? rc : 1;
 }
 
@@ -1390,7 +1406,10 @@ int OverlapRun::roundsShardedBatch() {
         for (size_t i = 0; i < slots.size(); i++) rounds.push_back(round + (i64)i);
         std::vector<RoundResult> outs;
         int rc = executeRounds(rounds, outs);
-        if (rc != 0) return rc < 0 ? rc : -1;
+        if (rc != 0) {
+            abortComms();  // this rank leaves the job: the peers' next exchanges fail instead of waiting for it
+            return rc < 0 ? rc : -1;
+        }
         // the first round of a batch ran against the committed flags: it commits, or ends the command (an empty result that
         // came from a plan of a chain erased meanwhile is executed again - on every rank alike)
         const int c = commitResults(outs);

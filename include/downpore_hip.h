@@ -399,6 +399,10 @@ DP_API int dp_comm_unique_id(uint8_t* id_out /* [128] */);
 DP_API int dp_comm_init(dp_ctx* ctx, int n_ranks, int rank, const uint8_t* unique_id /* [128] */, dp_comm** out);
 DP_API int dp_comm_init_local(dp_ctx* const* ctxs, int n, dp_comm** out /* [n] */);
 DP_API void dp_comm_destroy(dp_comm* comm);
+/* The caller gives up on the job (its own work of a round failed before it reached the exchange): peers inside or entering
+ * dp_allgather_survivors return an error instead of waiting for this rank for ever.  The communicator is dead afterwards
+ * (every exchange on it fails); dp_allgather_survivors does the same by itself when it fails on a rank. */
+DP_API void dp_comm_abort(dp_comm* comm);
 DP_API int dp_comm_rank(const dp_comm* comm);
 DP_API int dp_comm_size(const dp_comm* comm);
 /* `local` = what dp_scan_reads just returned on `ctx`; `all` = the same description of the gathered set (host arrays in

@@ -55,6 +55,29 @@ def test_config2_whole_job_scan_kernels(monkeypatch):
     assert st["idx_rounds"] == 0
 
 
+@pytest.mark.parametrize("case,slots", [("config2_k10_e0_first_16_rounds", 1), ("config2_k10_e0_first_16_rounds", 5),
+                                        ("config2_k10_e003_first_6_rounds", 1), ("config2_k10_e003_first_6_rounds", 5)])
+def test_config2_dense_regime_matches_oracle_fixture(case, slots):
+    """SURVEY 8(d)'s dense-seed regime at config 2's size (k = 10, the command's default): every read is indexed (~190 k chunks
+    per round, W ~ 3 k words) and the index query streams ~210 MB of posting words per launch - the regime the north star's
+    "HBM roofline during index-query" is quoted on (bench.py's index_query_dense leg runs these very rounds).  First rounds
+    against the oracle's fixture, error-free and at 3 % errors, with one round in flight and with five."""
+    g = _golden(case)
+    assert g["k"] == 10 and g["paf_lines"] > 20000
+    st = _overlap_against_fixture(g, slots=slots, max_rounds=g["max_rounds"])
+    assert st["n_indexed"] > 100000  # (last round: the dense regime indexes every read, in pieces)
+
+
+@pytest.mark.parametrize("case", ["config2_k13_e0002_first_24_rounds", "config2_k13_variable_first_24_rounds"])
+def test_config2_variants_with_flagged_reads_match_oracle_fixture(case):
+    """SURVEY 8(d)'s other k = 13 inputs at config 2's size: 0.2 % errors, and the L*U[0.5,1.5] length model.  Unlike the error-free
+    fixed-length set these flag reads (SetIgnore, commands/overlap.go:203-223) from the first rounds on, so the speculative executor
+    slots and planner lanes see their guesses fail at full scale; first 24 rounds against the oracle's fixture."""
+    g = _golden(case)
+    assert g["ignored_reads"] > 0
+    _overlap_against_fixture(g, slots=5, max_rounds=g["max_rounds"])
+
+
 def test_config3_full_size_map_matches_oracle():
     """BASELINE config 3: 50 000 reads x 8 kb (10 % error) against a 4.6 Mb circular reference, k=11."""
     from downpore_amd.mapping import map_reads

@@ -406,6 +406,39 @@ def test_scan_shard_exchange_inside_the_library():
     p1.close()
 
 
+@pytest.mark.parametrize("slots", [1, 3])
+def test_scan_shard_rank_failure_does_not_hang_its_peers(monkeypatch, slots):
+    """A rank that fails inside (or before) the survivor exchange must not leave the others waiting for it: the in-process
+    group is marked failed, every rank's step returns an error (dp_allgather_survivors / dp_comm_abort)."""
+    import threading
+    from downpore_amd.hip import DpError
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(32, 60000, 500, 1500, 0.0, True)
+    world = 2
+    readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
+    pipes = [OverlapPipeline(readsets[r], k=10, rank=r, world=world, mode="scan-shard", comm="local", slots=slots) for r in range(world)]
+    OverlapPipeline.link_local(pipes)
+    monkeypatch.setenv("DP_COMM_FAIL_RANK", "1")
+    errs = [None] * world
+
+    def run(r):
+        try:
+            pipes[r].run()
+        except DpError as e:
+            errs[r] = e
+    th = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a rank is still waiting for a peer that failed"
+    assert all(e is not None for e in errs), errs
+    assert "injected failure" in str(errs[1])
+    monkeypatch.delenv("DP_COMM_FAIL_RANK")
+    for p in pipes:
+        p.close()
+
+
 def test_scan_shard_with_executor_slots():
     """Scan-shard mode keeps its executor slots: a step runs `slots` consecutive rounds concurrently, slot i exchanging its
     survivors on its own communicator, and commits them in order with the speculation check (rounds that meet a read flagged by
@@ -480,6 +513,17 @@ def test_overlap_fastq_quality_weighted_seeds(tmp_path, monkeypatch):
         assert np.array_equal(reads.ignore(), rs.ignore())
         pipe.close()
     monkeypatch.delenv("DP_WINDOW_CACHE")
+    # a second and third job on the same handle (reset() keeps the slots' and the planner's contexts, which borrow the reads:
+    # the quality bytes were uploaded once with the reads and must still weight the selection)
+    reads = Reads(bases, off, min_len=1000, quals=quals)
+    pipe = OverlapPipeline(reads, k=10, slots=3, defer_init=True)
+    for job in range(3):
+        pipe.init()
+        pipe.run()
+        d = first_diff(pipe.all_paf(), want.paf)
+        assert d is None, (job, d)
+        pipe.reset()
+    pipe.close()
     # the same through the FASTQ reader and the CLI of both sides
     fq = str(tmp_path / "reads.fq")
     O.write_fastq(fq, bases, off, quals)

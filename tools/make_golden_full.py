@@ -21,9 +21,20 @@ sys.path.insert(0, ROOT)
 from tests import oracle_lib as O  # noqa: E402
 
 CONFIGS = {
-    # name: (seed, reads, read_len, error, k)
-    "config2": (2, 100000, 10000, 0.0, 13),
-    "config4": (4, 1000000, 10000, 0.0, 13),
+    # name: (seed, reads, read_len, error, k, variable read lengths)
+    "config2": (2, 100000, 10000, 0.0, 13, False),
+    "config4": (4, 1000000, 10000, 0.0, 13, False),
+    # SURVEY 8(d)'s other inputs at config 2's size: the dense-seed regime (k = 10, the command's default; the regime in which
+    # the index query streams hundreds of MB per round), k = 13 with 0.2 % errors, and the L*U[0.5,1.5] length model - the
+    # last two flag reads (SetIgnore, commands/overlap.go:203-223) from the first rounds on
+    "config2_k10_e0": (2, 100000, 10000, 0.0, 10, False),
+    "config2_k10_e003": (2, 100000, 10000, 0.03, 10, False),
+    "config2_k13_e0002": (2, 100000, 10000, 0.002, 13, False),
+    "config2_k13_variable": (2, 100000, 10000, 0.0, 13, True),
+    # SetIgnore (commands/overlap.go:203-223) only ever flags a read of at most two overlap sizes (2 000 bases) or one whose
+    # length is within 10 % of the covered span - none of the 10 kb sets above has such reads.  1.2 Gbase of 1.5-4.5 kb reads
+    # (served by the k-mer position index like config 2) flags thousands of them from the first round on
+    "short_variable_k13": (2, 400000, 3000, 0.0, 13, True),
 }
 
 
@@ -34,20 +45,20 @@ def main():
     ap.add_argument("--threads", type=int, default=6)
     ap.add_argument("--reads", type=int, default=0, help="override the read count (smaller surrogate, same generator)")
     a = ap.parse_args()
-    seed, N, L, e, k = CONFIGS[a.config]
+    seed, N, L, e, k, variable = CONFIGS[a.config]
     if a.reads:
         N = a.reads
     O.build_oracle()
     os.environ["DPO_SCAN_THREADS"] = str(a.threads)
     t0 = time.time()
-    bases, off = O.gen_reads(seed, N * L // 20, N, L, e, False)
+    bases, off = O.gen_reads(seed, N * L // 20, N, L, e, variable)
     rs = O.ReadSet(bases, off, min_len=1000)
     t1 = time.time()
     run = O.OverlapRun(rs, k=k, max_rounds=a.rounds, traces=False)
     t2 = time.time()
     paf = run.paf
     out = {"case": a.config + ("" if a.rounds < 0 else "_first_%d_rounds" % a.rounds) + ("_%dreads" % N if a.reads else ""),
-           "generator": {"seed": seed, "genome": N * L // 20, "reads": N, "read_len": L, "error": e, "variable": False},
+           "generator": {"seed": seed, "genome": N * L // 20, "reads": N, "read_len": L, "error": e, "variable": variable},
            "k": k, "rounds": run.rounds, "max_rounds": a.rounds, "paf_lines": paf.count("\n"),
            "paf_sha256": hashlib.sha256(paf.encode()).hexdigest(),
            "ignore_sha256": hashlib.sha256(rs.ignore().tobytes()).hexdigest(), "ignored_reads": int(rs.ignore().sum()),
