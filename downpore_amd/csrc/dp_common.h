@@ -24,8 +24,17 @@ struct PinBuf {
 struct dp_kindex;
 
 struct FindState;
+struct dp_gang;
 struct dp_ctx {
     int device = 0;
+    // gang membership (dp_gang.hip): inside a round the member's per-round launches are deposited and issued together with the
+    // other members'; `stream` is the gang's stream while the context is a member (own_stream: its own, restored afterwards)
+    dp_gang* gang = nullptr;
+    int gang_slot = -1;
+    bool gang_in_round = false;
+    int gang_round_members = 1;      // members that started their rounds together with this one (what a merged launch carries)
+    hipStream_t own_stream = nullptr;
+    bool destroy_pending = false;    // dp_ctx_destroy of an owner whose reads are still borrowed: carried out by the last borrower
     dp_ctx* owner = nullptr;     // context whose reads (and k-mer position index) this one borrows
     std::atomic<int> n_borrowers{0};  // live contexts created from this one with dp_ctx_create_shared
     dp_kindex* kidx = nullptr;   // resident k-mer position index (dp_kindex.hip), owned by the reads' owner

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "dp_common.h"
+#include "dp_gang.h"
 
 #define CA_WAVES 4
 #define CA_CAP 6144  // ints of one group staged in LDS
@@ -396,7 +397,9 @@ struct ConsFullArgs {
     uint32_t* nseq_dst;        // ... and where the host reads them (pinned, with the rest of the output)
 };
 
-__global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A) {
+struct consensus_full_kernel {
+    enum { THREADS = 64 };
+    static __device__ void run(const ConsFullArgs A) {
     __shared__ CFWave L;
     const int lane = dp_lane();
     const int k = A.k;
@@ -1058,6 +1061,7 @@ __global__ __launch_bounds__(64) void consensus_full_kernel(const ConsFullArgs A
         CF_TICK(5);
     }
 }
+};
 
 // Device consensus of the round whose chaining stage (dp_find_overlaps) last ran on this context.
 int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs, const int32_t* rc_of, uint32_t n_seeds, int k,
@@ -1134,7 +1138,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     A.nseq_src = ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : nullptr;
     A.nseq_dst = h_nseq;
     DP_HIP(dp_mark(ctx, 0));
-    hipLaunchKernelGGL(consensus_full_kernel, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), 0, ctx->stream, A);
+    dp_launch<consensus_full_kernel>(ctx, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), A);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 1));
     DP_HIP(dp_stream_sync(ctx));

@@ -13,6 +13,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "dp_common.h"
+#include "dp_gang.h"
 
 struct dp_kindex {
     std::mutex mu;
@@ -97,6 +98,9 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
         if (!ow->kidx) ow->kidx = new dp_kindex();
     }
     dp_kindex* ix = ow->kidx;
+    // (a gang member inside a round steps out of it for the lock and a possible build: the member that builds waits for its
+    // stream on its own, the ones that wait for the lock keep nobody at a launch)
+    DpGangPause gang_pause(ctx);
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->k == k && (ix->built || ix->unavailable)) return ix->built ? DP_OK : 1;
     hipSetDevice(ctx->device);
@@ -225,7 +229,9 @@ __global__ void kidx_link_extra(const dp_scan_item* __restrict__ items, uint32_t
 }
 // start of a round's counting step in one launch: the work area (fill cursors, tile status, ticket, hit slots), the item
 // counters and the totals go to zero, and the extra items are linked to their reads (head[] is all zero between calls)
-__global__ void kidx_prepare(uint32_t* __restrict__ work, uint32_t n_work, uint32_t* __restrict__ counts, uint32_t n_counts,
+struct kidx_prepare {
+    enum { THREADS = 256 };
+    static __device__ void run(uint32_t* __restrict__ work, uint32_t n_work, uint32_t* __restrict__ counts, uint32_t n_counts,
                              uint32_t* __restrict__ totals16, dp_scan_item* __restrict__ items, uint32_t n_read_items,
                              uint32_t n_extra, uint32_t* __restrict__ head, uint32_t* __restrict__ next,
                              const dp_scan_item* __restrict__ extra_src) {
@@ -241,15 +247,21 @@ __global__ void kidx_prepare(uint32_t* __restrict__ work, uint32_t n_work, uint3
         next[i] = atomicExch(&head[it.read], i + 1);
     }
 }
-__global__ void kidx_unlink_extra(const dp_scan_item* __restrict__ items, uint32_t n_read_items, uint32_t n_extra,
+};
+struct kidx_unlink_extra {
+    enum { THREADS = 256 };
+    static __device__ void run(const dp_scan_item* __restrict__ items, uint32_t n_read_items, uint32_t n_extra,
                                   uint32_t* __restrict__ head) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_extra) return;
     head[items[n_read_items + e].read] = 0;
 }
+};
 
 template <bool FILL>
-__global__ __launch_bounds__(256) void kidx_walk(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
+struct kidx_walk {
+    enum { THREADS = 256 };
+    static __device__ void run(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
                                                  const uint64_t* __restrict__ pos, const dp_scan_item* __restrict__ items,
                                                  uint32_t lo, uint32_t hi, uint32_t n_read_items, const uint32_t* __restrict__ head,
                                                  const uint32_t* __restrict__ next, uint32_t* __restrict__ counts,
@@ -318,11 +330,14 @@ __global__ __launch_bounds__(256) void kidx_walk(const uint32_t* __restrict__ se
         }
     }
 }
+};
 
 // status word of a tile: flag << 62 | survivors << 38 | segment ints (flag 1 = the tile's own sums, 2 = inclusive prefix)
 #define KX_TILE 1024
 #define KX_IPT 4
-__global__ __launch_bounds__(KX_TILE) void kidx_offsets(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ counts,
+struct kidx_offsets {
+    enum { THREADS = KX_TILE };
+    static __device__ void run(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ counts,
                                                        uint32_t n, unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket,
                                                        uint64_t* __restrict__ segoff, uint32_t* __restrict__ s_item,
                                                        uint32_t* __restrict__ s_count, uint64_t* __restrict__ s_off,
@@ -332,6 +347,8 @@ __global__ __launch_bounds__(KX_TILE) void kidx_offsets(const dp_scan_item* __re
     __shared__ uint32_t shA[16], shB[16];
     __shared__ uint32_t tile_s;
     __shared__ unsigned long long excl_s;
+    // (a launch shared with other rounds has the largest round's grid: blocks beyond this round's own tiles take no ticket)
+    if (blockIdx.x >= (n + KX_TILE * KX_IPT - 1) / (KX_TILE * KX_IPT)) return;
     if (threadIdx.x == 0) tile_s = atomicAdd(ticket, 1u);  // tiles start in ticket order: a predecessor is always running or done
     __syncthreads();
     const uint32_t tile = tile_s;
@@ -429,13 +446,16 @@ __global__ __launch_bounds__(KX_TILE) void kidx_offsets(const dp_scan_item* __re
         }
     }
 }
+};
 
 // one wave per survivor: its slice holds c unordered (position, seed) pairs -> sorted by position -> [gap, seed, ..., gap]
 #define KX_SORT_LDS 4096
 // CAP = keys the block's LDS holds (the launch picks the smallest that fits the round's largest survivor: a CU then holds
 // eight times as many waves for the usual few dozen hits per read as for the rare thousands)
 template <int CAP>
-__global__ __launch_bounds__(64) void kidx_sortwrite(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ sel,
+struct kidx_sortwrite {
+    enum { THREADS = 64 };
+    static __device__ void run(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ sel,
                                                      const uint32_t* __restrict__ n_sel_p, const uint32_t* __restrict__ counts,
                                                      const uint64_t* __restrict__ segoff, int32_t* __restrict__ segs, int k,
                                                      uint32_t* __restrict__ overflow, uint32_t n_read_items, uint32_t n_extra,
@@ -524,6 +544,7 @@ __global__ __launch_bounds__(64) void kidx_sortwrite(const dp_scan_item* __restr
         }
     }
 }
+};
 
 // lanes per seed of kidx_walk: by the mean bucket size of the index (positions / 4^k)
 static uint32_t kidx_lps(const dp_kindex* ix, int k) {
@@ -568,17 +589,17 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     DP_HIP(dp_mark(ctx, 0));
     {
         const uint32_t n_thr = std::max(std::max(n_work, n_items), std::max(n_extra, 16u));
-        hipLaunchKernelGGL(kidx_prepare, dim3((n_thr + 255) / 256), dim3(256), 0, ctx->stream, (uint32_t*)ctx->d_kx_sz.p, n_work, d_counts, n_items,
+        dp_launch<kidx_prepare>(ctx, dim3((n_thr + 255) / 256), dim3(256), (uint32_t*)ctx->d_kx_sz.p, n_work, d_counts, n_items,
                            (uint32_t*)d_totals, const_cast<dp_scan_item*>(d_items), n_read_items, n_extra, head, next,
                            ctx->extras_staged ? (const dp_scan_item*)ctx->h_extra.p : (const dp_scan_item*)nullptr);
         ctx->extras_staged = false;
     }
     if (S)
-        hipLaunchKernelGGL(kidx_walk<false>, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), 0, ctx->stream, dp_seeds_ptr(ctx), S,
+        dp_launch<kidx_walk<false>>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
                            (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
                            (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k));
     // totals[2] = seed occurrences in the read set, totals[3] = largest survivor count (both written by the kernel)
-    hipLaunchKernelGGL(kidx_offsets, dim3(n_tiles), dim3(KX_TILE), 0, ctx->stream, d_items, (const uint32_t*)d_counts, n_items, status, ticket,
+    dp_launch<kidx_offsets>(ctx, dim3(n_tiles), dim3(KX_TILE), d_items, (const uint32_t*)d_counts, n_items, status, ticket,
                        d_segoff, s_item, s_count, s_off, s_pack, d_totals, n_read_items, (uint32_t*)(d_totals + 3),
                        (const unsigned long long*)n_hits);
     DP_HIP(hipGetLastError());
@@ -604,25 +625,25 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         rc = 1;
     } else if (n_sel) {
         if (S)
-            hipLaunchKernelGGL(kidx_walk<true>, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), 0, ctx->stream, dp_seeds_ptr(ctx), S,
+            dp_launch<kidx_walk<true>>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
                                (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
                                (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr, kidx_lps(ix, k));
         const dim3 sg(std::min<uint32_t>(n_sel, 16384)), sb(64);
         uint32_t* ovf = (uint32_t*)(d_totals + 4);
         const uint32_t* nsp = (const uint32_t*)(d_totals + 1);
         if (max_count <= 128)
-            hipLaunchKernelGGL(kidx_sortwrite<256>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
+            dp_launch<kidx_sortwrite<256>>(ctx, sg, sb, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
                                n_extra, head, host_segs);
         else if (max_count <= 512)
-            hipLaunchKernelGGL(kidx_sortwrite<1024>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
+            dp_launch<kidx_sortwrite<1024>>(ctx, sg, sb, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
                                n_extra, head, host_segs);
         else
-            hipLaunchKernelGGL(kidx_sortwrite<KX_SORT_LDS>, sg, sb, 0, ctx->stream, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf,
+            dp_launch<kidx_sortwrite<KX_SORT_LDS>>(ctx, sg, sb, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf,
                                n_read_items, n_extra, head, host_segs);
         DP_HIP(hipGetLastError());
     }
     if (n_extra && (rc != DP_OK || !n_sel))  // (otherwise the sort kernel has put head[] back to zero)
-        hipLaunchKernelGGL(kidx_unlink_extra, dim3((n_extra + 255) / 256), dim3(256), 0, ctx->stream, d_items, n_read_items, n_extra, head);
+        dp_launch<kidx_unlink_extra>(ctx, dim3((n_extra + 255) / 256), dim3(256), d_items, n_read_items, n_extra, head);
     DP_HIP(hipGetLastError());
     return rc;
 }

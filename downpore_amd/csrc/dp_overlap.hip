@@ -14,13 +14,16 @@
 #include <cstring>
 
 #include "dp_common.h"
+#include "dp_gang.h"
 
 typedef uint64_t u64;
 
 // ---------------------------------------------------------------------------------------------------------------
 // A13
 
-__global__ void index_fill_kernel(const dp_seq_ref* __restrict__ refs, uint32_t n_seqs, const int32_t* __restrict__ segs,
+struct index_fill_kernel {
+    enum { THREADS = 256 };
+    static __device__ void run(const dp_seq_ref* __restrict__ refs, uint32_t n_seqs, const int32_t* __restrict__ segs,
                                   u64* __restrict__ posting, u64* __restrict__ seedsets, uint32_t W, uint32_t SW,
                                   const uint32_t* __restrict__ n_seqs_dev) {
     if (n_seqs_dev) n_seqs = *n_seqs_dev;  // (chunks made on the device: the launch was sized for an upper bound)
@@ -36,8 +39,11 @@ __global__ void index_fill_kernel(const dp_seq_ref* __restrict__ refs, uint32_t 
         }
     }
 }
+};
 
-__global__ void posting_meta_kernel(const u64* __restrict__ posting, uint32_t n_seeds, uint32_t W, uint32_t* __restrict__ pmeta) {
+struct posting_meta_kernel {
+    enum { THREADS = 256 };
+    static __device__ void run(const u64* __restrict__ posting, uint32_t n_seeds, uint32_t W, uint32_t* __restrict__ pmeta) {
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = dp_lane();
@@ -70,6 +76,7 @@ __global__ void posting_meta_kernel(const u64* __restrict__ posting, uint32_t n_
         }
     }
 }
+};
 
 int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
     if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_index_build before dp_round_begin");
@@ -98,13 +105,13 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
         DP_HIP(hipMemcpyAsync(ctx->d_seqrefs.p, dp_stage(ctx, seqs, (size_t)n_seqs * sizeof(dp_seq_ref)), (size_t)n_seqs * sizeof(dp_seq_ref),
                               hipMemcpyHostToDevice, ctx->stream));
         uint32_t blocks = std::min<uint32_t>(2048, (n_seqs + 3) / 4);
-        hipLaunchKernelGGL(index_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const dp_seq_ref*)ctx->d_seqrefs.p, n_seqs,
+        dp_launch<index_fill_kernel>(ctx, dim3(blocks), dim3(256), (const dp_seq_ref*)ctx->d_seqrefs.p, n_seqs,
                            (const int32_t*)ctx->d_segs.p, (u64*)ctx->d_posting.p, (u64*)ctx->d_seedsets.p, W, SW, (const uint32_t*)nullptr);
         DP_HIP(hipGetLastError());
     }
     if (S) {
         uint32_t blocks = std::min<uint32_t>(2048, (S + 3) / 4);
-        hipLaunchKernelGGL(posting_meta_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const u64*)ctx->d_posting.p, S, W,
+        dp_launch<posting_meta_kernel>(ctx, dim3(blocks), dim3(256), (const u64*)ctx->d_posting.p, S, W,
                            (uint32_t*)ctx->d_pmeta.p);
         DP_HIP(hipGetLastError());
     }
@@ -223,9 +230,13 @@ __device__ uint32_t chunk_one(const ChunkParams& P, uint32_t i, uint32_t at) {
 
 // status word of a tile of 1024 survivors: flag << 62 | chunks (flag 1 = the tile's own count, 2 = inclusive prefix); tiles take
 // their number from a ticket, so a predecessor is always running or done (the look-back cannot wait for a tile that has no CU)
-__global__ __launch_bounds__(1024) void chunk_kernel(const ChunkParams P, unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket) {
+struct chunk_kernel {
+    enum { THREADS = 1024 };
+    static __device__ void run(const ChunkParams P, unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t tile_s, base_s;
+    // (a launch shared with other rounds has the largest round's grid: blocks beyond this round's own tiles take no ticket)
+    if (blockIdx.x >= (P.ns + 1023u) / 1024u) return;
     if (threadIdx.x == 0) tile_s = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t tile = tile_s;
@@ -266,6 +277,7 @@ __global__ __launch_bounds__(1024) void chunk_kernel(const ChunkParams P, unsign
     __syncthreads();
     if (cnt) chunk_one<true>(P, i, base_s + before + x - cnt);
 }
+};
 
 // upper bound of the chunks chunkWorker makes of a read with `numSeeds` hits: every chunk but the last holds >= minSeeds seeds
 // and the walk backs up at most 5 seeds (or overlap/2 bases) after each
@@ -335,19 +347,19 @@ extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t o
         P.metas = (dp_seq_meta*)ctx->d_chunk_meta.p;
         P.cap = cap;
         P.n_out = (uint32_t*)ctx->d_nseqs.p;
-        hipLaunchKernelGGL(chunk_kernel, dim3(n_tiles), dim3(1024), 0, ctx->stream, P, (unsigned long long*)((uint8_t*)ctx->d_nseqs.p + 64),
+        dp_launch<chunk_kernel>(ctx, dim3(n_tiles), dim3(1024), P, (unsigned long long*)((uint8_t*)ctx->d_nseqs.p + 64),
                            (uint32_t*)ctx->d_nseqs.p + 2);
         DP_HIP(hipGetLastError());
         if (cap) {
             const uint32_t blocks = std::min<uint32_t>(2048, (cap + 3) / 4);
-            hipLaunchKernelGGL(index_fill_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const dp_seq_ref*)ctx->d_seqrefs.p, cap,
+            dp_launch<index_fill_kernel>(ctx, dim3(blocks), dim3(256), (const dp_seq_ref*)ctx->d_seqrefs.p, cap,
                                (const int32_t*)ctx->d_segs.p, (u64*)ctx->d_posting.p, (u64*)ctx->d_seedsets.p, W, SW, (const uint32_t*)ctx->d_nseqs.p);
             DP_HIP(hipGetLastError());
         }
     }
     if (S) {
         const uint32_t blocks = std::min<uint32_t>(2048, (S + 3) / 4);
-        hipLaunchKernelGGL(posting_meta_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const u64*)ctx->d_posting.p, S, W, (uint32_t*)ctx->d_pmeta.p);
+        dp_launch<posting_meta_kernel>(ctx, dim3(blocks), dim3(256), (const u64*)ctx->d_posting.p, S, W, (uint32_t*)ctx->d_pmeta.p);
         DP_HIP(hipGetLastError());
     }
     return DP_OK;
@@ -436,7 +448,9 @@ struct QWave {
 // One WORKGROUP per query: wave 0 prepares the set list (Matches' filter, the early-return cut, the 16-ladder's gather
 // order), then the Q_WAVES waves share the query's word range, 64 words per wave step, so that a dense index (W ~ 3 k words,
 // k = 10) is streamed by thousands of waves instead of one per query.
-__global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
+struct query_kernel {
+    enum { THREADS = 64 * Q_WAVES };
+    static __device__ void run(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
                                                              uint32_t nq, const u64* __restrict__ posting,
                                                              const uint32_t* __restrict__ pmeta, uint32_t n_seqs, uint32_t W,
                                                              const int32_t* __restrict__ mc, uint32_t mc_n,
@@ -751,6 +765,7 @@ __global__ __launch_bounds__(64 * Q_WAVES) void query_kernel(const int32_t* __re
         qcnt[q] = sh_u[5];
     }
 }
+};
 
 // ---------------------------------------------------------------------------------------------------------------
 // A6 + A7 + A8: matchWorker body
@@ -1624,7 +1639,9 @@ struct MRec {
 // (~6 KB of pinned memory) per match, here it is one wave per match over segments that are resident anyway.
 // anchors[2*slot] = seg[0] + sum_{t=1..first}(seg[2t]+k), anchors[2*slot+1] = seg[n-1] + sum_{t=last+1..ns-1}(seg[2t]+k);
 // -1 when the chain's indices are not inside the target (the host then sums itself).
-__global__ __launch_bounds__(256) void match_anchor_kernel(const MRec* __restrict__ recs, const uint32_t* __restrict__ n_pairs,
+struct match_anchor_kernel {
+    enum { THREADS = 256 };
+    static __device__ void run(const MRec* __restrict__ recs, const uint32_t* __restrict__ n_pairs,
                                                            uint32_t pair_cap, const int32_t* __restrict__ mb,
                                                            const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, int k,
                                                            int32_t* __restrict__ anchors, unsigned long long* __restrict__ fetch_dst,
@@ -1659,6 +1676,7 @@ __global__ __launch_bounds__(256) void match_anchor_kernel(const MRec* __restric
         }
     }
 }
+};
 
 // ---- the chaining stage: matchWorker's candidate loop (overlap/overlap.go:357-383) without its serial latency -------------
 // A query's candidates are chained in ascending order because of the ratchet: a chain longer than 3/2 minMatches raises
@@ -1716,10 +1734,13 @@ struct ChainArgs {
     uint32_t int_cap;
     uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [4..5] algorithmic bytes (u64)
     uint32_t* qdone;     // [nq] pairs of the query a speculative pass has finished (resolve fused into it), or nullptr
+    uint32_t walk_blocks; // grid of chain_walk_kernel for this round (its node pool is sized for it)
 };
 
 // per-query candidate counts -> pair / scratch offsets (one workgroup; a round has a few hundred to a few ten thousand queries)
-__global__ __launch_bounds__(1024) void pair_scan_kernel(const uint32_t* __restrict__ qcnt, const u64* __restrict__ qoff, uint32_t nq,
+struct pair_scan_kernel {
+    enum { THREADS = 1024 };
+    static __device__ void run(const uint32_t* __restrict__ qcnt, const u64* __restrict__ qoff, uint32_t nq,
                                                           uint32_t* __restrict__ pbase, u64* __restrict__ ibase, u64* __restrict__ totals,
                                                           uint32_t* __restrict__ qdone) {
     __shared__ u64 shp[1024], shi[1024];
@@ -1759,6 +1780,7 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(const uint32_t* __restr
         totals[1] = shi[1023];
     }
 }
+};
 
 // Load that goes to L2: for words another lane of this wave has just stored (a plain load may be served from a stale line of
 // the CU's vector L1).
@@ -1884,11 +1906,16 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
 // mode 0: from the query's first candidate up to and including the first pair that is chained; 2 (last kernel of the stage):
 // whatever chain_resolve_kernel left open - proposals are taken where they fit, the rest is chained here, serially.
 // (mode 1 = mode 2 that stops instead of chaining: kept for experiments.)
-__global__ __launch_bounds__(64 * C_WAVES) void chain_walk_kernel(const ChainArgs A, const int mode) {
+struct chain_walk_kernel {
+    enum { THREADS = 64 * C_WAVES };
+    static __device__ void run(const ChainArgs A, const int mode) {
     __shared__ CWave sh[C_WAVES];
     CWave& L = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
-    const uint32_t waves = gridDim.x * C_WAVES;
+    // (every wave owns a slice of the node pool, sized for THIS round's grid: in a launch shared with other rounds - the largest
+    // round's grid - the blocks beyond it have nothing to do)
+    if (blockIdx.x >= A.walk_blocks) return;
+    const uint32_t waves = A.walk_blocks * C_WAVES;
     const uint32_t gw = blockIdx.x * C_WAVES + (threadIdx.x >> 6);
     CNode* nodes = A.pool + (uint64_t)gw * C_NODES;
     if (mode != 0 && (A.cursor[3] != 0 || (A.pass > 0 && A.cursor[8 + A.pass] == 0))) return;  // overflow / every query closed already
@@ -2001,12 +2028,15 @@ __global__ __launch_bounds__(64 * C_WAVES) void chain_walk_kernel(const ChainArg
         }
     }
 }
+};
 
 __device__ void chain_resolve_query(const ChainArgs& A, uint32_t q, int lane);
 
 // one wave per open pair: prefilter + chain with the minMatches its query has reached; stored as a proposal
 #define S_WAVES 4
-__global__ __launch_bounds__(64 * S_WAVES) void chain_spec_kernel(const ChainArgs A, const u64* __restrict__ totals) {
+struct chain_spec_kernel {
+    enum { THREADS = 64 * S_WAVES };
+    static __device__ void run(const ChainArgs A, const u64* __restrict__ totals) {
     __shared__ CSlim sh[S_WAVES];
     CSlim& L = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
@@ -2070,6 +2100,7 @@ __global__ __launch_bounds__(64 * S_WAVES) void chain_spec_kernel(const ChainArg
         }
     }
 }
+};
 
 // One wave per query: replays the ratchet over the proposals of its open pairs - 64 pairs at a time, one per lane, the
 // serial part is a register loop - and makes every pair up to the first one that needs another minMatches final: packed
@@ -2165,12 +2196,15 @@ __device__ void chain_resolve_query(const ChainArgs& A, uint32_t q, int lane) {
     }
 }
 
-__global__ __launch_bounds__(256) void chain_resolve_kernel(const ChainArgs A) {
+struct chain_resolve_kernel {
+    enum { THREADS = 256 };
+    static __device__ void run(const ChainArgs A) {
     const int lane = dp_lane();
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     if (A.cursor[3] != 0 || A.cursor[8 + A.pass] == 0) return;  // buffers overflowed (stage is repeated) / no query was open before this pass
     for (uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); q < A.nq; q += waves) chain_resolve_query(A, q, lane);
 }
+};
 
 // Uploads the queries, builds their seed bitsets and runs the index query (Matches -> GetSharedIDs) for all of them.
 // Leaves d_qsegs/d_qoff/d_qsets/d_cand/d_qmeta on the device.  Events ev[4]/ev[5] bracket the query kernel.
@@ -2217,7 +2251,7 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
         if (int rc = dp_zero_fetch_regions(ctx, z, 4, &f, 1)) return rc;
     }
     DP_HIP(dp_mark(ctx, 4));
-    hipLaunchKernelGGL(query_kernel, dim3(nq), dim3(64 * Q_WAVES), 0, ctx->stream,
+    dp_launch<query_kernel>(ctx, dim3(nq), dim3(64 * Q_WAVES),
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
@@ -2334,19 +2368,20 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     A.sint_cap = st.sint_cap;
     A.int_cap = st.int_cap;
     A.cursor = d_cur;
+    A.walk_blocks = st.walk_blocks;
     A.qdone = fuse_resolve ? d_qdone : nullptr;
     if (st.attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 128, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
     DP_HIP(dp_mark(ctx, 6));
-    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)st.d_qcnt, ctx->qoff_dev, nq, d_pbase, d_ibase,
+    dp_launch<pair_scan_kernel>(ctx, dim3(1), dim3(1024), (const uint32_t*)st.d_qcnt, ctx->qoff_dev, nq, d_pbase, d_ibase,
                        d_totals, d_qdone);
-    hipLaunchKernelGGL(chain_walk_kernel, dim3(st.walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 0);
+    dp_launch<chain_walk_kernel>(ctx, dim3(st.walk_blocks), dim3(64 * C_WAVES), A, 0);
     for (int ps = 0; ps < st.passes; ps++) {
         A.pass = ps;
-        hipLaunchKernelGGL(chain_spec_kernel, dim3(st.spec_blocks), dim3(64 * S_WAVES), 0, ctx->stream, A, (const u64*)d_totals);
-        if (!fuse_resolve) hipLaunchKernelGGL(chain_resolve_kernel, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), 0, ctx->stream, A);
+        dp_launch<chain_spec_kernel>(ctx, dim3(st.spec_blocks), dim3(64 * S_WAVES), A, (const u64*)d_totals);
+        if (!fuse_resolve) dp_launch<chain_resolve_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), A);
     }
     A.pass = st.passes;
-    hipLaunchKernelGGL(chain_walk_kernel, dim3(st.walk_blocks), dim3(64 * C_WAVES), 0, ctx->stream, A, 2);
+    dp_launch<chain_walk_kernel>(ctx, dim3(st.walk_blocks), dim3(64 * C_WAVES), A, 2);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 7));
     {
@@ -2532,7 +2567,7 @@ int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch) {
     if (dev_reserve(ctx, ctx->d_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
     if (!nslots) return fetch ? dp_zero_fetch_regions(ctx, nullptr, 0, fetch, 1) : DP_OK;
     const u64* d_totals = (const u64*)((const uint8_t*)ctx->d_cursor.p + 64);
-    hipLaunchKernelGGL(match_anchor_kernel, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256), 0, ctx->stream,
+    dp_launch<match_anchor_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256),
                        (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
                        (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, ctx->last_k, (int32_t*)ctx->d_manchor.p,
                        fetch ? (unsigned long long*)fetch->dst : (unsigned long long*)nullptr,
@@ -2563,7 +2598,7 @@ int dp_fetch_overlaps_impl(dp_ctx* ctx, int want_candidates, dp_match_batch* out
     const int32_t* ta = (const int32_t*)ctx->h_ta.p;
     const int32_t* tb = (const int32_t*)ctx->h_tb.p;
     if (nslots) {
-        hipLaunchKernelGGL(match_anchor_kernel, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256), 0, ctx->stream,
+        dp_launch<match_anchor_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256),
                            (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
                            (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, k, (int32_t*)ctx->d_manchor.p,
                            (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0ull);

@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "dp_common.h"
+#include "dp_gang.h"
 
 static std::string g_create_err;
 // The scan kernels are persistent and fill every CU: two of them running at once (several contexts on one device) only
@@ -91,6 +92,9 @@ const void* dp_stage(dp_ctx* ctx, const void* src, size_t bytes) {
 }
 
 hipError_t dp_stream_sync(dp_ctx* ctx) {
+    // a gang member inside a round: wait until the other members have reached a wait too (their launches up to there are merged
+    // with this member's and are on the gang's stream by then), then wait for that stream like for one's own
+    if (dp_gang_active(ctx)) dp_gang_sync_point(ctx);
     ctx->stage_used = 0;  // (everything queued so far, copies out of the staging block included, is done when this returns)
     static const int env_spin = [] {
         const char* e = getenv("DP_SPIN_SYNC");
@@ -292,7 +296,9 @@ struct ZeroArgs {
     const unsigned long long* src[2];
     unsigned long long m8[2];
 };
-__global__ void zero_regions_kernel(const ZeroArgs a) {
+struct zero_regions_kernel {
+    enum { THREADS = 256 };
+    static __device__ void run(const ZeroArgs a) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (unsigned long long)gridDim.x * blockDim.x;
 #pragma unroll
     for (int r = 0; r < 2; r++)  // (the fetches first: their loads cross the link while the stores below go out)
@@ -301,6 +307,7 @@ __global__ void zero_regions_kernel(const ZeroArgs a) {
     for (int r = 0; r < 4; r++)
         for (unsigned long long j = i; j < a.n8[r]; j += stride) a.p[r][j] = 0ull;
 }
+};
 // (a round has a dozen buffers to clear, and every hipMemsetAsync is a dispatch of its own: the command processor, not the
 // memory, is what they cost - tools/micro/launch_rate.hip)
 int dp_zero_fetch_regions(dp_ctx* ctx, const dp_zero_region* z, int nz, const dp_fetch_region* f, int nf) {
@@ -319,7 +326,7 @@ int dp_zero_fetch_regions(dp_ctx* ctx, const dp_zero_region* z, int nz, const dp
     }
     if (!most) return DP_OK;
     const uint32_t blocks = (uint32_t)std::min<unsigned long long>(4096, (most + 1023) / 1024);
-    hipLaunchKernelGGL(zero_regions_kernel, dim3(std::max(1u, blocks)), dim3(256), 0, ctx->stream, a);
+    dp_launch<zero_regions_kernel>(ctx, dim3(std::max(1u, blocks)), dim3(256), a);
     DP_HIP(hipGetLastError());
     return DP_OK;
 }
@@ -389,9 +396,22 @@ extern "C" int dp_ctx_set_priority(dp_ctx* ctx, int high) {
 extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->gang) {  // (destroyed as a gang member: the gang must be gone first; be safe and wait on the right stream)
+        ctx->gang_in_round = false;
+        hipStreamSynchronize(ctx->stream);
+        ctx->stream = ctx->own_stream;
+        ctx->gang = nullptr;
+    }
     dp_stream_sync(ctx);
+    if (!ctx->owner && ctx->n_borrowers.load() > 0) {
+        // contexts that borrow these reads (value table, k-mer index) are still alive - a garbage-collected host may finalise
+        // the owner first: the resident data stays until the last borrower has gone, which then carries this call out
+        ctx->destroy_pending = true;
+        return;
+    }
     if (ctx->borrowed_reads) ctx->d_packed.p = ctx->d_boff.p = ctx->d_len.p = ctx->d_values.p = ctx->d_qual.p = ctx->d_qualoff.p = ctx->d_hasq.p = nullptr;
-    if (ctx->owner) ctx->owner->n_borrowers--;
+    dp_ctx* const lender = ctx->owner;
+    const bool last_borrower = lender && --lender->n_borrowers == 0 && lender->destroy_pending;
     dp_kindex_free(ctx);
     dp_find_state_free(ctx);
     DevBuf* dbs[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len, &ctx->d_bits, &ctx->d_kmap, &ctx->d_seeds, &ctx->d_items,
@@ -416,6 +436,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     const bool owner = !ctx->borrowed_reads;
     delete ctx;
     if (owner) dp_dev_trim();  // (a context that owned reads goes: nothing is parked beyond it)
+    if (last_borrower) dp_ctx_destroy(lender);
 }
 
 extern "C" uint32_t dp_reads_count(const dp_ctx* ctx) { return ctx ? ctx->n_reads : 0; }
@@ -1206,7 +1227,10 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus * (v2 ? 2 : 1), ((uint64_t)n_items + 15) / 16);
     const uint32_t dbg = getenv("DP_SCAN_DEBUG") ? (uint32_t)atoi(getenv("DP_SCAN_DEBUG")) : 0u;
     if (int rc = seed_tables_ensure(ctx)) return rc;
-    std::unique_lock<ScanGate> scan_lock(g_scan_mu);
+    // (a gang member inside a round takes no gate: the gang's stream orders its members' scans, and a member waiting for the
+    // gate would keep the members that wait for it at their launches for ever)
+    std::unique_lock<ScanGate> scan_lock(g_scan_mu, std::defer_lock);
+    if (!dp_gang_active(ctx)) scan_lock.lock();
     DP_HIP(dp_mark(ctx, 0));
     hipLaunchKernelGGL(((dbg & 2) ? scan_kernel<0, 3> : v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
                        (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p, n_items, k,
@@ -1249,7 +1273,7 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
         DP_HIP(dp_stream_sync(ctx));
         ms1 = dp_elapsed(ctx, 2, 3);
     }
-    scan_lock.unlock();
+    if (scan_lock.owns_lock()) scan_lock.unlock();
     ctx->n_segs = n_segs;
     out->n_seeds = (const uint32_t*)ctx->h_counts.p;
     out->seg_off = (const uint64_t*)ctx->h_segoff.p;
@@ -1265,7 +1289,9 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
 // ---------------------------------------------------------------------------------------------------------------
 // dp_scan_reads: items generated and survivors compacted on the device
 
-__global__ void make_read_items_kernel(const uint32_t* __restrict__ len, const uint8_t* __restrict__ ignore, uint32_t lo,
+struct make_read_items_kernel {
+    enum { THREADS = 256 };
+    static __device__ void run(const uint32_t* __restrict__ len, const uint8_t* __restrict__ ignore, uint32_t lo,
                                        uint32_t hi, int k, int top_level, uint32_t min_seeds, dp_scan_item* __restrict__ items) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (lo + i >= hi) return;
@@ -1286,6 +1312,7 @@ __global__ void make_read_items_kernel(const uint32_t* __restrict__ len, const u
     }
     items[i] = it;
 }
+};
 
 // tile sums / compaction of the survivor FLAG (count >= min_seeds), same tiling as the offsets scan
 __global__ __launch_bounds__(OFF_TILE) void flag_tile_sums(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ counts,
@@ -1418,7 +1445,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     // round (the kernels only read them; the extra items behind them are this round's)
     if (n_read_items && (ctx->items_ptr != d_items || ctx->items_epoch != ignore_epoch || ctx->items_lo != lo || ctx->items_hi != hi ||
                          ctx->items_min != min_seeds || ctx->items_top != top_level || ctx->items_k != k)) {
-        hipLaunchKernelGGL(make_read_items_kernel, dim3((n_read_items + 255) / 256), dim3(256), 0, ctx->stream,
+        dp_launch<make_read_items_kernel>(ctx, dim3((n_read_items + 255) / 256), dim3(256),
                            (const uint32_t*)ctx->d_len.p, (const uint8_t*)ctx->d_ignore.p, lo, hi, k, top_level, min_seeds, d_items);
         ctx->items_ptr = d_items;
         ctx->items_epoch = ignore_epoch;
@@ -1482,7 +1509,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     if (!use_index) {
         if (int rc = fetch_extras()) return rc;
         if (int rc = seed_tables_ensure(ctx)) return rc;
-        scan_lock.lock();
+        if (!dp_gang_active(ctx)) scan_lock.lock();  // (see dp_scan)
         DP_HIP(dp_mark(ctx, 0));
         hipLaunchKernelGGL((v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
                            (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)d_items, n_items, k,

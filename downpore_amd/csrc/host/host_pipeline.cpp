@@ -630,6 +630,7 @@ void OverlapRun::shutdown(bool keepContexts) {
         sl->index.reset();
     }
     if (keepContexts) return;
+    destroyGangs();
     if (plannerCtx) dp_ctx_destroy(plannerCtx);
     plannerCtx = nullptr;
     for (auto& sl : slots) {
@@ -637,6 +638,11 @@ void OverlapRun::shutdown(bool keepContexts) {
         sl->ctx = nullptr;
     }
     slots.clear();
+}
+
+void OverlapRun::destroyGangs() {
+    for (dp_gang* g : gangs) dp_gang_destroy(g);
+    gangs.clear();
 }
 
 int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const double* valuesOrNull, int nSlots) {
@@ -758,6 +764,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     // contexts kept by a reset() of this handle are taken over when they fit (same owner context, same number of slots)
     const bool reuseSlots = !slots.empty() && (int)slots.size() == std::max(1, nSlots) && slots[0]->ctx == ctx;
     if (!reuseSlots) {
+        destroyGangs();
         for (auto& sl : slots)
             if (sl->ownsCtx && sl->ctx) dp_ctx_destroy(sl->ctx);
         slots.clear();
@@ -791,6 +798,33 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         sl->index.reset(new SeedIndex(p.k));
         if ((size_t)i < slotComms.size()) sl->comm = slotComms[(size_t)i];
         slots.push_back(std::move(sl));
+    }
+    {
+        // gangs of consecutive slots: their rounds begin together and share every launch.  Not in scan-shard mode (a slot's
+        // survivor exchange is a collective of its own on its own communicator).
+        const char* ge = getenv("DPH_GANG");
+        int want = ge ? atoi(ge) : 4;
+        want = std::max(1, std::min(want, 8));
+        bool sharded = false;
+        for (auto& sl : slots) sharded = sharded || sl->comm != nullptr;
+        if (sharded) want = 1;
+        if (want != gangSize || (want > 1 && gangs.empty()) || !reuseSlots) {
+            destroyGangs();
+            gangSize = want;
+            for (size_t i = 0; gangSize > 1 && i < slots.size(); i += (size_t)gangSize) {
+                dp_ctx* m[8];
+                int n = 0;
+                for (size_t j = i; j < slots.size() && n < gangSize; j++) m[n++] = slots[j]->ctx;
+                if (n < 2) break;
+                dp_gang* g = nullptr;
+                int rc = dp_gang_create(m, n, &g);
+                if (rc != 0) {
+                    error = dp_last_error(m[0]);
+                    return rc;
+                }
+                gangs.push_back(g);
+            }
+        }
     }
     mark("executor slots");
     const char* nothread = getenv("DP_NO_PLANNER_THREAD");
@@ -882,6 +916,9 @@ int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
     sl.lap->setIgnoreView(reads->ignore.data(), planner->ignoreEpoch());
     const double tb2 = now();
     g_prof.add(1, tb2 - tb1);
+    // a gang member's round begins together with the rounds of the other members that have one (and ends in executeRoundOn)
+    dp_gang_round_begin(sl.ctx);
+    g_prof.add(18, now() - tb2);
     int rc = dp_round_begin(sl.ctx, p.k, sl.index->seedMap.data(), (uint32_t)sl.index->seedMap.size());
     if (rc != 0) {
         sl.error = dp_last_error(sl.ctx);
@@ -959,6 +996,11 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
             if (g_prof.on) g_prof.slotCpuUs += (long long)((threadCpuNow() - t0) * 1e6);
         }
     } slotCpu{tc0};
+    struct GangRound {  // the slot has a round: the other members of its gang do not start theirs without it; over in any case at the end
+        dp_ctx* c;
+        explicit GangRound(dp_ctx* c_) : c(c_) { dp_gang_round_prepare(c); }
+        ~GangRound() { dp_gang_round_end(c); }
+    } gangRound(sl.ctx);
     static const bool dbgExec = getenv("DPH_DEBUG_PLANNER") != nullptr;
     if (dbgExec) fprintf(stderr, "[exec] round %lld waiting for its plan\n", (long long)r);
     std::shared_ptr<const RoundPlan> plan = planner->get(r);
@@ -982,6 +1024,7 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     int rc = beginRound(sl, *plan);
     if (rc) return rc;
     out.st.n_seeds = plan->seedMap.size();
+    out.st.gang_members = (uint64_t)dp_gang_round_members(sl.ctx);
     double t1 = now();
     out.st.t_prepare = t1 - t0;
     const bool sharded = sl.comm != nullptr;  // scan-shard: this rank scans its reads, the survivors of all ranks are exchanged

@@ -64,11 +64,11 @@ struct PipeProfile {
     std::atomic<long long> planTouchCyc{0}, planReselCyc{0}, planCommitCyc{0}, planOtherCyc{0};  // prepareFromCache, TSC cycles
     std::atomic<long long> cacheWaitUs{0};  // planner waiting for the window cache's producer
     std::atomic<long long> planUs{0}, getWaitUs{0}, execUs{0}, commitUs{0}, consensusCpuUs{0}, selectCpuUs{0}, slotCpuUs{0}, plannerCpuUs{0};
-    std::atomic<long long> sub[18];
-    std::atomic<long long> subCpu[18];  // CPU time of the calling thread since its previous add(): the sections are consecutive
-    const char* subName[18] = {"prep.indexReset", "prep.newOverlapper", "prep.roundBegin", "scan.call", "scan.copy", "idx.copy",
+    std::atomic<long long> sub[19];
+    std::atomic<long long> subCpu[19];  // CPU time of the calling thread since its previous add(): the sections are consecutive
+    const char* subName[19] = {"prep.indexReset", "prep.newOverlapper", "prep.roundBegin", "scan.call", "scan.copy", "idx.copy",
                                "idx.chunk", "idx.build", "idx.queries", "qry.call", "qry.matches", "fc.collate", "fc.parallel",
-                               "fc.merge", "round.total", "round.tail", "plan.speculate", "plan.commitLoop"};
+                               "fc.merge", "round.total", "round.tail", "plan.speculate", "plan.commitLoop", "prep.gangStart"};
     PipeProfile() {
         for (auto& x : sub) x = 0;
         for (auto& x : subCpu) x = 0;
@@ -114,9 +114,9 @@ struct PipeProfile {
                     plannerCpuUs.load() / 1e3 / nn);
         }
         fprintf(stderr, "[pipe] per executed round (ms):");
-        for (int i = 0; i < 18; i++) fprintf(stderr, " %s %.3f", subName[i], sub[i].load() / 1e3 / n);
+        for (int i = 0; i < 19; i++) fprintf(stderr, " %s %.3f", subName[i], sub[i].load() / 1e3 / n);
         fprintf(stderr, "\n[pipe] thread CPU up to the end of each section (ms):");
-        for (int i = 0; i < 18; i++) fprintf(stderr, " %s %.3f", subName[i], subCpu[i].load() / 1e3 / n);
+        for (int i = 0; i < 19; i++) fprintf(stderr, " %s %.3f", subName[i], subCpu[i].load() / 1e3 / n);
         fprintf(stderr, "\n");
     }
 };
