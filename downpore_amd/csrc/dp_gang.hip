@@ -32,9 +32,25 @@ struct dp_gang {
     int state[DP_GANG_MAX] = {};
     const DpDeposit* dep[DP_GANG_MAX] = {};
     std::atomic<uint32_t> released[DP_GANG_MAX];
+    long long off_since_ns[DP_GANG_MAX] = {};  // when the member last left a round (a member between two rounds is about to be back)
     // counters (dp_gang_counters)
     uint64_t deposits = 0, launches = 0, syncs = 0, starts = 0, started_members = 0;
 };
+
+static long long gang_now_ns() {
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (long long)t.tv_sec * 1000000000ll + t.tv_nsec;
+}
+// A member that left its round less than this ago is expected back with its next round: members that are ready to start wait
+// for it (DP_GANG_GRACE_US), so that the rounds of a gang keep beginning - and therefore launching - together.
+static long long gang_grace_ns() {
+    static const long long g = [] {
+        const char* e = getenv("DP_GANG_GRACE_US");
+        return (e ? atoll(e) : 150ll) * 1000ll;
+    }();
+    return g;
+}
 
 hipStream_t dp_ctx_stream(const dp_ctx* ctx) { return ctx->stream; }
 bool dp_gang_active(const dp_ctx* ctx) { return ctx->gang && ctx->gang_in_round; }
@@ -84,6 +100,11 @@ static void gang_resolve(dp_gang* g) {
         return;
     }
     if (n_prep || !n_start) return;
+    if (n_start < g->n) {  // somebody is between two rounds: give it the time to come back (the waiting members ask again)
+        const long long now = gang_now_ns();
+        for (int i = 0; i < g->n; i++)
+            if (g->state[i] == DPG_OFF && g->off_since_ns[i] && now - g->off_since_ns[i] < gang_grace_ns()) return;
+    }
     g->starts++;
     g->started_members += (uint64_t)n_start;
     for (int i = 0; i < g->n; i++)
@@ -100,6 +121,7 @@ static void gang_arrive(dp_ctx* ctx, int st, const DpDeposit* d) {
     const uint32_t tk = g->released[me].load(std::memory_order_relaxed);
     {
         std::lock_guard<std::mutex> lk(g->mu);
+        if (st == DPG_OFF) g->off_since_ns[me] = g->state[me] == DPG_RUN ? gang_now_ns() : 0;  // (0: it had no round after all)
         g->state[me] = st;
         g->dep[me] = d;
         gang_resolve(g);
@@ -115,6 +137,10 @@ static void gang_arrive(dp_ctx* ctx, int st, const DpDeposit* d) {
             continue;
         }
         sched_yield();
+        if (st == DPG_START && (spins & 15) == 0) {  // (held back for a member between two rounds: its grace may be over)
+            std::lock_guard<std::mutex> lk(g->mu);
+            if (g->state[me] == DPG_START) gang_resolve(g);
+        }
         if (debug && !dumped && (spins & 1023) == 0) {  // a member stuck for two seconds: who is where
             timespec t;
             clock_gettime(CLOCK_MONOTONIC, &t);

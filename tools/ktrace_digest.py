@@ -4,7 +4,7 @@ median, max, and the GPU-busy fraction (union of the kernel intervals) between t
 import collections, csv, sys
 tot = collections.defaultdict(int); seq = collections.defaultdict(list); ev = []
 for r in csv.DictReader(open(sys.argv[1])):
-    n = r["Kernel_Name"].split("(")[0][:60]
+    n = r["Kernel_Name"].replace("void dp_multi<", "<").split("(")[0][:60]
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     tot[n] += e - s; seq[n].append(e - s); ev.append((s, e, n.startswith("chain_walk_kernel")))
 print("%-62s %8s %12s %10s %10s %10s" % ("kernel", "calls", "total_ms", "mean_us", "median_us", "max_us"))
