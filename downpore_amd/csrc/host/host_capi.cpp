@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include "downpore_host.h"
 #include "host_util.hpp"
 
 using namespace dph;

@@ -20,7 +20,8 @@ import (
 
 // Context owns one HIP stream on one device (dp_ctx).  One goroutine at a time.
 type Context struct {
-	h *C.dp_ctx
+	h      *C.dp_ctx
+	parent *Context // a Shared() context borrows its parent's resident reads: the parent stays reachable as long as the child is
 }
 
 func fail(h *C.dp_ctx, what string, rc C.int) error {
@@ -55,7 +56,7 @@ func NewContext(device int) (*Context, error) {
 	if rc := C.dp_ctx_create(C.int(device), &h); rc != 0 {
 		return nil, fail(nil, "dp_ctx_create", rc)
 	}
-	c := &Context{h}
+	c := &Context{h: h}
 	runtime.SetFinalizer(c, func(c *Context) { c.Close() })
 	return c, nil
 }
@@ -67,7 +68,11 @@ func (c *Context) Shared() (*Context, error) {
 	if rc := C.dp_ctx_create_shared(c.h, &h); rc != 0 {
 		return nil, fail(nil, "dp_ctx_create_shared", rc)
 	}
-	return &Context{h}, nil
+	// (the child keeps its parent alive for the garbage collector; should the parent be closed first all the same, the
+	// library defers freeing the resident reads until the last borrower has gone - dp_ctx_destroy)
+	ch := &Context{h: h, parent: c}
+	runtime.SetFinalizer(ch, func(c *Context) { c.Close() })
+	return ch, nil
 }
 
 // SetStreamWait chooses how calls of the library wait for their stream (process-wide): spinning wakes up at once and occupies
@@ -487,4 +492,230 @@ func (c *Context) ScanReadsSharded(m *Comm, ignore []byte, epoch uint64, lo, hi 
 		}
 	}
 	return s, nil
+}
+
+// ---- the entry points a pipelined host needs beyond one synchronous round at a time ------------------------------------------
+
+// QualityUpload makes the reads' FASTQ quality bytes (phred - 33, at the offsets of UploadReads; hasQual[r] = 0: the record had
+// no usable quality line) resident: SelectWindows then weights every k-mer's value as AddSeeds does (seeds/seeds.go:99-101).
+// Once per read set, before any Shared() context exists.
+func (c *Context) QualityUpload(qual []byte, off []int64, hasQual []byte) error {
+	rc := C.dp_quality_upload(c.h, (*C.uint8_t)(unsafe.Pointer(&qual[0])), (*C.int64_t)(unsafe.Pointer(&off[0])),
+		(*C.uint8_t)(unsafe.Pointer(&hasQual[0])), C.uint32_t(len(off)-1))
+	if rc != 0 {
+		return fail(c.h, "dp_quality_upload", rc)
+	}
+	return nil
+}
+
+// KmerValuesResident computes the value table on the device and leaves it there (SelectWindows reads it) without copying the
+// 4^k doubles to the host; ValueCodes then fetches it at 2 bytes per k-mer.
+func (c *Context) KmerValuesResident(k int) error {
+	if rc := C.dp_kmer_values(c.h, C.int(k), nil); rc != 0 {
+		return fail(c.h, "dp_kmer_values", rc)
+	}
+	return nil
+}
+
+// ValueCodes returns the resident value table as one count code per k-mer (0 = value 0) and the total count: value(i) =
+// f(codes[i], total) with overlap.go:73-88's expression.  overflow: a valued k-mer was seen more than 65535 times - fetch the
+// doubles with KmerValues instead.
+func (c *Context) ValueCodes(k int) (codes []uint16, total uint64, overflow bool, err error) {
+	n := 1 << uint(2*k)
+	codes = make([]uint16, n)
+	var tot C.uint64_t
+	var ovf C.int
+	if rc := C.dp_values_download_codes(c.h, (*C.uint16_t)(unsafe.Pointer(&codes[0])), C.uint64_t(n), &tot, &ovf); rc != 0 {
+		return nil, 0, false, fail(c.h, "dp_values_download_codes", rc)
+	}
+	return codes, uint64(tot), ovf != 0, nil
+}
+
+// SelectWindows is the selection half of AddSeeds (seeds/seeds.go:62-129) for many query windows at once, assuming no
+// evaluated k-mer is a seed yet: top[w*numSeeds:] = the window's list (untouched slots hold k-mer 0), evaluated[w*stride:] =
+// every k-mer the walk evaluated (0xffffffff = unused): what the caller probes against its committed seeds to learn whether
+// the assumption held (a window it did not hold for is re-selected on the host, exactly as AddSeeds would).
+func (c *Context) SelectWindows(win []ScanItem, k, numSeeds, stride int) (top []uint32, evaluated []uint32, err error) {
+	if len(win) == 0 {
+		return nil, nil, nil
+	}
+	top = make([]uint32, len(win)*numSeeds)
+	var ev *C.uint32_t
+	rc := C.dp_select_windows(c.h, cItems(win), C.uint32_t(len(win)), C.int(k), C.int(numSeeds), (*C.uint32_t)(unsafe.Pointer(&top[0])),
+		&ev, C.uint32_t(stride))
+	if rc != 0 {
+		return nil, nil, fail(c.h, "dp_select_windows", rc)
+	}
+	evaluated = append(evaluated, unsafe.Slice((*uint32)(unsafe.Pointer(ev)), len(win)*stride)...)
+	return top, evaluated, nil
+}
+
+// ScanFetchMode(true): ScanReads leaves the surviving reads' segments on the device (IndexBuildChunked chunks them there) and
+// brings only the extra items' - the query windows' - to the host.
+func (c *Context) ScanFetchMode(extrasOnly bool) error {
+	v := C.int(0)
+	if extrasOnly {
+		v = 1
+	}
+	if rc := C.dp_scan_fetch_mode(c.h, v); rc != 0 {
+		return fail(c.h, "dp_scan_fetch_mode", rc)
+	}
+	return nil
+}
+
+// IndexBuildChunked is chunkWorker (overlap/overlap.go:253-318) + AddSequence + IndexSequences for the first nSurvivors
+// survivors of the last ScanReads, all on the device.  Returns an upper bound of the number of chunks.
+func (c *Context) IndexBuildChunked(chunkSize, overlap int64, minSeeds, inset, nSurvivors int) (int, error) {
+	var cap C.uint32_t
+	rc := C.dp_index_build_chunked(c.h, C.int64_t(chunkSize), C.int64_t(overlap), C.uint32_t(minSeeds), C.int32_t(inset), C.uint32_t(nSurvivors), &cap)
+	if rc != 0 {
+		return 0, fail(c.h, "dp_index_build_chunked", rc)
+	}
+	return int(cap), nil
+}
+
+// FindOverlapsOnDevice is matchWorker (overlap.go:346-387) for all queries of the round with the matches left on the device and
+// the stage left pending: the next call on the context must be ConsensusPAF, which finishes it in the wait it needs anyway.
+func (c *Context) FindOverlapsOnDevice(qSegs []int32, qOff []uint64, hitFraction float64, k, maxQueryLen int) error {
+	var b C.dp_match_batch
+	rc := C.dp_find_overlaps(c.h, (*C.int32_t)(unsafe.Pointer(&qSegs[0])), (*C.uint64_t)(unsafe.Pointer(&qOff[0])), C.uint32_t(len(qOff)-1),
+		C.double(hitFraction), C.int(k), C.uint32_t(maxQueryLen), 6, &b)
+	if rc != 0 {
+		return fail(c.h, "dp_find_overlaps", rc)
+	}
+	return nil
+}
+
+// PAFRecord is one PAF line without its names (commands/overlap.go:223-228); Group one query window's lines and SetIgnore ids.
+type PAFRecord struct {
+	QRead, TRead         uint32
+	QLen, QStart, QEnd   int32
+	TLen, TStart, TEnd   int32
+	Ident                int32
+	Minus                uint32
+}
+type Group struct {
+	Lines   []PAFRecord
+	Ignore  []uint32
+	Flagged bool // the window does not fit the device layout: run BuildConsensus on the host for it (FetchOverlaps)
+	Matches int
+}
+
+// ConsensusPAF is finalCheckWorker + BuildConsensus + multiAligner.Consensus + trimToBestSeed (commands/overlap.go:197-233,
+// overlap/combine.go:21-193, seeds/alignment.go:52-247) for every query window of the round, on the device.  rcOf[s] = seed id of
+// seed s's reverse complement; the chunks' fields come from IndexBuildChunked (metas == nil).
+func (c *Context) ConsensusPAF(rcOf []int32, k, overlapSize int) ([]Group, int, error) {
+	var b C.dp_paf_batch
+	rc := C.dp_consensus_paf(c.h, nil, 0, (*C.int32_t)(unsafe.Pointer(&rcOf[0])), C.uint32_t(len(rcOf)), C.int(k), C.int(overlapSize), &b)
+	if rc != 0 {
+		return nil, 0, fail(c.h, "dp_consensus_paf", rc)
+	}
+	ng := int(b.n_groups)
+	out := make([]Group, ng)
+	if ng == 0 {
+		return out, int(b.n_indexed), nil
+	}
+	gm := unsafe.Slice((*C.dp_group_meta)(unsafe.Pointer(b.groups)), ng)
+	for g := 0; g < ng; g++ {
+		m := gm[g]
+		out[g].Flagged = m.flag != 0
+		out[g].Matches = int(m.n_matches)
+		if m.n_lines > 0 {
+			recs := unsafe.Slice((*PAFRecord)(unsafe.Pointer(b.paf)), int(m.slot)+int(m.n_lines))[int(m.slot):] // same layout: ten 32-bit fields
+			out[g].Lines = append(out[g].Lines, recs...)
+		}
+		if m.n_ignore > 0 {
+			ids := unsafe.Slice((*uint32)(unsafe.Pointer(b.ignore_ids)), int(m.slot)+int(m.n_ignore))[int(m.slot):]
+			out[g].Ignore = append(out[g].Ignore, ids...)
+		}
+	}
+	return out, int(b.n_indexed), nil
+}
+
+// ---- multi-GPU, one process per GPU ------------------------------------------------------------------------------------------
+
+// CommUniqueID makes the 128-byte id of an RCCL communicator on rank 0; the caller hands it to the other ranks.
+func CommUniqueID() ([]byte, error) {
+	id := make([]byte, 128)
+	if rc := C.dp_comm_unique_id((*C.uint8_t)(unsafe.Pointer(&id[0]))); rc != 0 {
+		return nil, errors.New("dp_comm_unique_id failed (librccl not loadable?)")
+	}
+	return id, nil
+}
+
+// NewComm joins this rank's context to the communicator `id` (RCCL over xGMI; collective: every rank calls it).
+func NewComm(c *Context, nRanks, rank int, id []byte) (*Comm, error) {
+	if len(id) != 128 {
+		return nil, errors.New("NewComm: the id has 128 bytes")
+	}
+	var h *C.dp_comm
+	if rc := C.dp_comm_init(c.h, C.int(nRanks), C.int(rank), (*C.uint8_t)(unsafe.Pointer(&id[0])), &h); rc != 0 {
+		return nil, fail(c.h, "dp_comm_init", rc)
+	}
+	return &Comm{h}, nil
+}
+
+// Abort: this rank gives up; its peers' exchanges return an error instead of waiting for it.
+func (m *Comm) Abort() {
+	if m.h != nil {
+		C.dp_comm_abort(m.h)
+	}
+}
+
+// ---- gangs: several rounds in one set of launches ------------------------------------------------------------------------------
+
+// Gang makes contexts of one device share every launch of their rounds (include/downpore_hip.h): one goroutine per member,
+// locked to its thread for the duration of a round (runtime.LockOSThread), RoundBegin / RoundEnd around the per-round calls.
+type Gang struct {
+	h *C.dp_gang
+}
+
+func NewGang(ctxs []*Context) (*Gang, error) {
+	hs := make([]*C.dp_ctx, len(ctxs))
+	for i, c := range ctxs {
+		hs[i] = c.h
+	}
+	var g *C.dp_gang
+	if rc := C.dp_gang_create((**C.dp_ctx)(unsafe.Pointer(&hs[0])), C.int(len(ctxs)), &g); rc != 0 {
+		return nil, fail(hs[0], "dp_gang_create", rc)
+	}
+	return &Gang{g}, nil
+}
+func (g *Gang) Close() {
+	if g.h != nil {
+		C.dp_gang_destroy(g.h)
+		g.h = nil
+	}
+}
+func (c *Context) GangRoundPrepare() { C.dp_gang_round_prepare(c.h) }
+func (c *Context) GangRoundBegin()   { C.dp_gang_round_begin(c.h) }
+func (c *Context) GangRoundEnd()     { C.dp_gang_round_end(c.h) }
+
+// SetPriority gives the context's stream the device's highest (or default) scheduling priority: for the goroutine that runs the
+// PrepareQueries chain and waits for SelectWindows while other contexts keep the GPU busy with whole rounds.
+func (c *Context) SetPriority(high bool) error {
+	v := C.int(0)
+	if high {
+		v = 1
+	}
+	if rc := C.dp_ctx_set_priority(c.h, v); rc != 0 {
+		return fail(c.h, "dp_ctx_set_priority", rc)
+	}
+	return nil
+}
+
+// ScanRelease frees what a job left resident on the context that owns the reads (k-mer position index, histogram).
+func (c *Context) ScanRelease() error {
+	if rc := C.dp_scan_release(c.h); rc != 0 {
+		return fail(c.h, "dp_scan_release", rc)
+	}
+	return nil
+}
+
+// ValuesUpload installs a value table computed elsewhere (the -seed_values path) for SelectWindows.
+func (c *Context) ValuesUpload(values []float64) error {
+	if rc := C.dp_values_upload(c.h, (*C.double)(unsafe.Pointer(&values[0])), C.uint64_t(len(values))); rc != 0 {
+		return fail(c.h, "dp_values_upload", rc)
+	}
+	return nil
 }

@@ -34,6 +34,28 @@ def test_library_exports_nothing_else():
     assert exported == _header_symbols()
 
 
+def _host_header_symbols():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "include", "downpore_host.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dph_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_host_library_exports_exactly_its_header():
+    """libdownpore_host.so - the pipeline the bench measures - has a published boundary of its own (include/downpore_host.h):
+    every declared entry point is exported, and nothing else is (version script: the C++ mirror of the Go layers stays local)."""
+    import subprocess
+    from downpore_amd.overlap import host_lib_path, load_host
+    H = load_host()
+    syms = _host_header_symbols()
+    assert len(syms) > 50
+    for s in syms:
+        assert hasattr(H, s), s
+    out = subprocess.check_output(["nm", "-D", "--defined-only", host_lib_path()], text=True)
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported == syms
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

@@ -533,3 +533,66 @@ def test_overlap_fastq_quality_weighted_seeds(tmp_path, monkeypatch):
                        capture_output=True, check=True)
     assert first_diff(a.stdout.decode(), b.stdout.decode()) is None
     assert first_diff(a.stdout.decode(), want.paf) is None
+
+
+def test_whole_job_through_the_published_host_header_only():
+    """The pipeline bench.py measures has a published boundary (include/downpore_host.h; Go: integration/gpuhost +
+    integration/commands/gpu_overlap.go).  This drives a whole job with raw ctypes calls of entry points that header declares -
+    and of nothing else - the way the Go command does: reads, open, init, step / round_paf until done; PAF and stderr lines
+    against the oracle."""
+    import ctypes as C
+    import re
+    from downpore_amd.overlap import host_lib_path, load_host
+    load_host()
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "downpore_host.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(dph_[a-z_0-9]+)\s*\(", txt))
+
+    class HeaderOnly:
+        def __init__(self, lib):
+            self._lib = lib
+
+        def __getattr__(self, name):
+            assert name in declared, "%s is not declared in include/downpore_host.h" % name
+            return getattr(self._lib, name)
+    H = HeaderOnly(C.CDLL(host_lib_path()))
+    vp = C.c_void_p
+    bases, off = O.gen_reads(1, 250000, 1000, 5000, 0.0, False)  # BASELINE config 1, at the command's default k
+    rs = O.ReadSet(bases, off, min_len=1000)
+    want = O.OverlapRun(rs, k=10)
+    b = np.ascontiguousarray(bases, dtype=np.uint8)
+    o = np.ascontiguousarray(off, dtype=np.int64)
+    H.dph_reads_from_arrays.restype = vp
+    reads = H.dph_reads_from_arrays(C.c_void_p(b.ctypes.data), C.c_void_p(o.ctypes.data), C.c_int64(len(o) - 1), C.c_int64(1000), C.c_int(1))
+    assert reads
+    H.dph_overlap_open.restype = vp
+    h = H.dph_overlap_open(vp(reads), C.c_int(0))
+    assert h
+    params = np.array([1000, 10, 15, 10000, 10000, 20000, 1 | (1 << 8), 8], dtype=np.int64)
+    assert H.dph_overlap_init(vp(h), C.c_void_p(params.ctypes.data), C.c_double(0.25), None) == 0
+    H.dph_overlap_round_paf.restype = C.POINTER(C.c_char)
+    H.dph_overlap_errtext.restype = C.POINTER(C.c_char)
+    H.dph_overlap_step_lines.restype = C.c_int64
+    paf, rounds, lines = [], 0, 0
+    while True:
+        c = H.dph_overlap_step(vp(h))
+        assert c >= 0
+        if c == 0:
+            break
+        rounds += c
+        n = C.c_int64(0)
+        p = H.dph_overlap_round_paf(vp(h), C.byref(n))
+        paf.append(C.string_at(p, n.value).decode())
+        lines += H.dph_overlap_step_lines(vp(h))
+    n = C.c_int64(0)
+    p = H.dph_overlap_errtext(vp(h), C.byref(n))
+    err = C.string_at(p, n.value).decode()
+    got = "".join(paf)
+    assert rounds == want.rounds and H.dph_overlap_done(vp(h)) == 1
+    assert first_diff(got, want.paf) is None and lines == got.count("\n") > 1000
+    assert err.startswith("Counting all 10-mers in the input...") and err.count("\nTotal ") + err.count("sequences.Total ") >= 1
+    assert err.count(" hits across ") == rounds
+    ig = np.zeros(len(o) - 1, dtype=np.uint8)
+    H.dph_reads_get_ignore(vp(reads), C.c_void_p(ig.ctypes.data))
+    assert np.array_equal(ig, rs.ignore())
+    H.dph_overlap_destroy(vp(h))
+    H.dph_reads_free(vp(reads))
