@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--dense-leg-rounds", type=int, default=12,
                     help="N=1: after the timed region, this many rounds of the dense-seed regime (k=10) where the index query "
                          "carries real traffic (reported as index_query_dense; 0 = skip)")
+    ap.add_argument("--map-leg-repeats", type=int, default=3,
+                    help="N=1: after the timed region, BASELINE config 3 (`downpore map`: 50k reads x 8 kb against a 4.6 Mb circular "
+                         "reference, k=11) this many times, reported as map_config3 with its PAF held to the oracle's fixture (0 = skip)")
     ap.add_argument("--mode", default="auto", choices=["auto", "round", "round-batch", "scan-shard"],
                     help="multi-GPU decomposition (N > 1).  scan-shard: every rank runs every round on its own read range and the "
                          "survivors' seed index is all-gathered (RCCL, inside the library) - the layout for read sets that do not fit "
@@ -96,9 +99,18 @@ def main():
     from downpore_amd.overlap import OverlapPipeline, Reads
 
     N, L = args.reads, args.read_len
+    alt_mode_name = None
     if args.mode == "auto":
         hbm = torch.cuda.get_device_properties(local_rank).total_memory if torch.cuda.is_available() else 0
-        args.mode = "round" if (world == 1 or 9 * N * L < hbm // 2) else "scan-shard"
+        if world == 1:
+            args.mode = "round"  # (one rank: the plain executor pipeline)
+        else:
+            # N > 1: the headline is north_star's layout - reads partitioned, every round's survivors (its seed index) all-gathered
+            # over RCCL, identical index on every rank; the round-parallel layout (rounds dealt to the ranks, needs reads + k-mer
+            # index on every GPU: 9 B per base) is run after it and reported as `alt_mode`
+            args.mode = "scan-shard"
+            if 9 * N * L < hbm // 2:
+                alt_mode_name = "round"
     G = N * L // 20
     t0 = time.time()
     bases, off = gen_reads(args.seed, G, N, L, args.error, False)
@@ -108,7 +120,7 @@ def main():
     # dp_allgather_survivors, device to device); DP_BENCH_BACKEND=gloo (1-GPU test hook) keeps it on host copies
     # (DP_BENCH_FORCE_SHARD=1, test hook: the sharded batch pipeline with a communicator of one rank on a 1-GPU box)
     force_shard = world == 1 and os.environ.get("DP_BENCH_FORCE_SHARD") == "1" and args.mode == "scan-shard"
-    comm = "rccl" if ((world > 1 and args.mode == "scan-shard" and torch_device is not None) or force_shard) else None
+    comm = "rccl" if ((world > 1 and torch_device is not None) or force_shard) else None  # (both layouts exchange inside the library)
     pipe = OverlapPipeline(reads, device=local_rank, k=args.k, seed_batch_size=args.seed_batch_size, rank=rank, world=world,
                            torch_device=torch_device, mode=args.mode, slots=args.slots, defer_init=True, comm=comm)
     upload = pipe.setup_times()
@@ -199,8 +211,15 @@ def main():
                                        "algorithmic_bytes_per_launch": cb, "achieved_GBs": (cb / 1e9) / (cms / 1e3) if cms > 0 else 0.0,
                                        "frac_of_hbm_peak": ((cb / 1e9) / (cms / 1e3)) / HBM_PEAK_GBS if cms > 0 else 0.0}
     pipe.close()
+    alt = None
+    if alt_mode_name is not None:  # collective: every rank takes part
+        alt = alt_mode_jobs(alt_mode_name, reads, args, rank, world, local_rank, torch_device, comm, golden, torch, dist)
     if world == 1 and args.dense_leg_rounds > 0:
         dense_leg = dense_regime_leg(reads, args, torch)
+
+    map_leg = None
+    if world == 1 and args.map_leg_repeats > 0:
+        map_leg = map_config3_leg(args.map_leg_repeats)
 
     stream_gbs = None
     if rank == 0:
@@ -264,7 +283,8 @@ def main():
                        "reads": N, "read_len": L, "k": args.k, "seed_batch_size": args.seed_batch_size, "executor_slots_per_gpu": args.slots,
                        "rounds_per_step": rounds / n_jobs, "paf_lines_per_step": lines / n_jobs,
                        "parallelism": ("single GPU" if world == 1 else
-                                       "scan sharded by read over %d GPUs, survivors all-gathered (RCCL), identical index on every rank" % world
+                                       "north_star layout: reads partitioned over %d GPUs, every round's survivors (seed index) all-gathered (RCCL, "
+                                       "device to device inside the library), identical index built on every rank" % world
                                        if args.mode == "scan-shard" else
                                        "round-parallel over %d GPUs: rank r's executor pipeline runs the rounds r, r+N, ...; one round "
                                        "per rank all-gathered (RCCL) per superstep and committed in order" % world)},
@@ -285,7 +305,7 @@ def main():
                                        "frac_of_hbm_peak": ((v[1] / 1e9) / (v[0] / 1e3)) / HBM_PEAK_GBS if v[0] > 0 else 0.0}
                                   for kk, v in kern.items()},
             "scan_mode": "resident k-mer position index" if main_index else "scan kernels",
-            "scan_kernels_leg": scan_leg, "index_query_dense": dense_leg,
+            "scan_kernels_leg": scan_leg, "index_query_dense": dense_leg, "map_config3": map_leg, "alt_mode": alt,
             "paf_lines": lines, "rounds_per_s": rounds / elapsed if elapsed > 0 else 0.0,
             "phase_ms_per_round": {kk: 1e3 * per_round(kk) for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
             "kernel_ms_per_round": {kk: per_round(kk) for kk in ("k_count_ms", "k_write_ms", "k_scan_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
@@ -305,6 +325,58 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def alt_mode_jobs(mode, reads, args, rank, world, local_rank, torch_device, comm, golden, torch, dist):
+    """N > 1: the same whole jobs in the other multi-GPU layout, timed the same way (barrier + synchronize on both sides, MAX over
+    ranks), first job held to the same fixture.  Reported next to the headline as `alt_mode`."""
+    from downpore_amd.overlap import OverlapPipeline
+    pipe = OverlapPipeline(reads, device=local_rank, k=args.k, seed_batch_size=args.seed_batch_size, rank=rank, world=world,
+                           torch_device=torch_device, mode=mode, slots=args.slots, defer_init=True, comm=comm)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def job(verify):
+        pipe.init()
+        lines = rounds = 0
+        while args.max_rounds < 0 or rounds < args.max_rounds:
+            c = pipe.step()
+            if c == 0:
+                break
+            rounds += c
+            lines += pipe.step_lines()
+        ok = None
+        if verify and rank == 0 and golden is not None and args.max_rounds < 0:
+            paf = pipe.all_paf()
+            ok = bool(hashlib.sha256(paf.encode()).hexdigest() == golden["paf_sha256"] and lines == golden["paf_lines"] and rounds == golden["rounds"])
+        pipe.reset()
+        return lines, rounds, ok
+    ok = None
+    for i in range(max(1, args.warmup)):
+        _, _, o = job(i == 0)
+        ok = o if i == 0 else ok
+    sync()
+    t0 = time.perf_counter()
+    lines = rounds = 0
+    for _ in range(args.steps):
+        jl, jr, _ = job(False)
+        lines += jl
+        rounds += jr
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch_device if torch_device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    pipe.close()
+    return {"mode": mode, "value": lines / elapsed if elapsed > 0 else 0.0, "unit": "overlaps/s", "ms_per_step": 1e3 * elapsed / max(1, args.steps),
+            "rounds_per_step": rounds / max(1, args.steps), "paf_sha256_matches_oracle_fixture": ok,
+            "parallelism": "round-parallel over %d GPUs: rank r's executor pipeline runs the rounds r, r+N, ...; finished rounds all-gathered "
+                           "(dp_allgather_blobs, RCCL) per superstep and committed in order on every rank" % world}
 
 
 def rounds_leg(pipe, n_rounds, torch, warm=8, fixture=None):
@@ -391,6 +463,48 @@ def dense_regime_leg(reads, args, torch):
                            "frac_of_hbm_peak": ((qb / 1e9) / (qms / 1e3)) / HBM_PEAK_GBS if qms > 0 else 0.0}
     leg["workload"] = "same reads, k=10 (dense seeds): %d rounds, one executor slot (kernel durations without other rounds in flight)" % int(m)
     return leg
+
+
+def map_config3_leg(repeats):
+    """BASELINE config 3 - the whole `downpore map` command (commands/map.go:33-116) on the GPU: 50 000 reads x 8 kb (10 % error)
+    against a 4.6 Mb circular reference, k = 11, from the reads in host memory to the last PAF line (reference k-mer table,
+    AddSingleSeeds, reference index, upload + packing of both strands, window scans, index query + chaining, mapper control
+    flow, text).  PAF against the oracle's fixture (tests/golden_full/config3_map.json)."""
+    from tools.synth import gen_genome, gen_reads
+    from downpore_amd.mapping import map_reads
+    from downpore_amd.overlap import Reads
+    try:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden_full", "config3_map.json")))
+    except Exception:
+        return None
+    gen = g["generator"]
+    genome = np.frombuffer(gen_genome(gen["seed"], gen["genome"]), dtype=np.uint8)
+    goff = np.array([0, gen["genome"]], dtype=np.int64)
+    bases, off = gen_reads(gen["seed"], gen["genome"], gen["reads"], gen["read_len"], gen["error"], False)
+    ref = Reads(genome, goff, min_len=0, himem=False)
+    reads = Reads(bases, off, min_len=500, himem=False)
+    best, runs, ok, st = None, [], True, None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        paf, err, st_ = map_reads(ref, reads, circular=True, k=g["k"])
+        dt = time.perf_counter() - t0
+        runs.append(dt)
+        ok = ok and paf.count("\n") == g["paf_lines"] and hashlib.sha256(paf.encode()).hexdigest() == g["paf_sha256"] and err == g["stderr"]
+        if best is None or dt < best:
+            best, st = dt, st_
+        del paf
+    n = gen["reads"]
+    total_bases = float(off[-1])
+    return {"workload": "downpore map, BASELINE config 3: %d reads x %d bp (error %.2f) against a %d bp circular reference, k=%d; whole "
+                        "command from reads in host memory to the last PAF line" % (n, gen["read_len"], gen["error"], gen["genome"], g["k"]),
+            "value": n / best, "unit": "reads/s", "wall_s_best": best, "wall_s_runs": runs, "read_bases_per_s": total_bases / best,
+            "paf_sha256_matches_oracle_fixture": bool(ok), "fixture": g["case"],
+            "map_kernel": {"kernel": "map_kernel (A19 + A20: prefilter + SeedSequence.Match of every window pair) + query_kernel", "ms_total": st["k_map_ms"],
+                           "launches": st["n_batches"], "windows": st["n_windows"], "chains": st["n_chains"],
+                           "windows_per_s_in_kernel": st["n_windows"] / (st["k_map_ms"] / 1e3) if st["k_map_ms"] > 0 else 0.0},
+            "scan_kernels_ms_total": st["k_scan_ms"],
+            "breakdown_s": {"setup_reference_index_upload": st["t_setup_s"], "window_scans": st["t_scan_s"], "index_query_chaining": st["t_chain_s"],
+                            "mapper_control_flow_and_text": st["t_host_s"]}}
 
 
 def golden_fixture(args):

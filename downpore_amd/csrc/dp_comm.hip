@@ -80,6 +80,12 @@ struct LocalGroup {
     uint64_t gen = 0;       // completed exchanges
     int arrived = 0, left = 0;
     bool failed = false;    // a rank left an exchange with an error: every wait of this group returns, now and later (sticky)
+    // dp_allgather_blobs: host pointers published by the ranks
+    struct BlobPub {
+        const uint8_t* p = nullptr;
+        uint64_t n = 0;
+    };
+    std::vector<BlobPub> blob;
     struct Pub {
         int device = 0;
         const void* counts = nullptr;   // device: uint64[2] = {survivors, segment ints of the survivors}
@@ -100,8 +106,8 @@ struct dp_comm {
     bool dead = false;            // an exchange failed on this rank: the communicator was aborted and refuses further calls
     hipEvent_t ev = nullptr;
     // per-rank scratch on the owning context's device
-    DevBuf d_cnt, d_pay, d_allpay;
-    PinBuf h_cnt, h_out;
+    DevBuf d_cnt, d_pay, d_allpay, d_allsegs, d_blob;
+    PinBuf h_cnt, h_out, h_blob, h_bsz;
     std::string err;
 };
 
@@ -144,6 +150,7 @@ extern "C" int dp_comm_init_local(dp_ctx* const* ctxs, int n, dp_comm** out) {
     g->n = n;
     g->refs = n;
     g->pub.resize((size_t)n);
+    g->blob.resize((size_t)n);
     for (int r = 0; r < n; r++) {
         if (!ctxs[r]) {
             delete g;
@@ -193,9 +200,9 @@ extern "C" void dp_comm_destroy(dp_comm* c) {
         }
     }
     if (c->ev) hipEventDestroy(c->ev);
-    for (DevBuf* b : {&c->d_cnt, &c->d_pay, &c->d_allpay})
+    for (DevBuf* b : {&c->d_cnt, &c->d_pay, &c->d_allpay, &c->d_allsegs, &c->d_blob})
         if (b->p) dp_dev_free(b->p);
-    for (PinBuf* b : {&c->h_cnt, &c->h_out})
+    for (PinBuf* b : {&c->h_cnt, &c->h_out, &c->h_blob, &c->h_bsz})
         if (b->p) hipHostFree(b->p);
     delete c;
 }
@@ -207,6 +214,34 @@ __global__ void comm_pack_meta(const uint32_t* __restrict__ s_item, const uint32
     if (i >= n) return;
     read[i] = s_item[i] + lo;
     nseeds[i] = s_count[i];
+}
+
+// the gathered survivors as the {read, hit count, segment offset} arrays dp_index_build_chunked works from (one workgroup: a
+// round has a few thousand survivors, a few hundred thousand in the dense-seed regime)
+__global__ __launch_bounds__(1024) void comm_install_survivors(const uint32_t* __restrict__ read, const uint32_t* __restrict__ nseeds, uint32_t n,
+                                                              uint32_t* __restrict__ s_item, uint32_t* __restrict__ s_count,
+                                                              uint64_t* __restrict__ s_off) {
+    __shared__ unsigned long long sh[1024];
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
+    unsigned long long sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += 2ull * nseeds[i] + 1;
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        unsigned long long a = 0;
+        if ((int)threadIdx.x >= d) a = sh[threadIdx.x - d];
+        __syncthreads();
+        sh[threadIdx.x] += a;
+        __syncthreads();
+    }
+    unsigned long long pos = sh[threadIdx.x] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        s_item[i] = read[i];
+        s_count[i] = nseeds[i];
+        s_off[i] = pos;
+        pos += 2ull * nseeds[i] + 1;
+    }
 }
 
 static int comm_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes) {
@@ -341,12 +376,14 @@ static int allgather_survivors_impl(dp_comm* c, dp_ctx* ctx, const dp_survivor_b
         tot_ints += cnt[2 * r + 1];
     }
     if (tot_surv > 0xfffffff0ull) return dp_fail(ctx, DP_ERR_CAPACITY, "dp_allgather_survivors: more than 2^32 survivors");
-    // ---- gathered device buffers: metadata [read ids of all | hit counts of all], segments [all survivors | my extra items]
+    // ---- gathered device buffers: metadata [read ids of all | hit counts of all]; segments [all survivors | my extra items] in a
+    // buffer of their own, which BECOMES the context's scan output at the end (the two buffers change places: no copy)
     const uint64_t new_ints = tot_ints + extra_ints;
-    if (comm_reserve(ctx, c->d_allpay, (size_t)tot_surv * 8 + (size_t)new_ints * 4 + 256)) return DP_ERR_HIP;
+    if (comm_reserve(ctx, c->d_allpay, (size_t)tot_surv * 8 + 256)) return DP_ERR_HIP;
+    if (comm_reserve(ctx, c->d_allsegs, (size_t)new_ints * 4 + 256)) return DP_ERR_HIP;
     uint32_t* a_read = (uint32_t*)c->d_allpay.p;
     uint32_t* a_nseeds = a_read + tot_surv;
-    int32_t* a_segs = (int32_t*)(((uintptr_t)(a_nseeds + tot_surv) + 15) & ~(uintptr_t)15);
+    int32_t* a_segs = (int32_t*)c->d_allsegs.p;
     if (c->nccl) {
         // variable sizes: one broadcast per rank and array inside a group (RCCL fuses them); rank order = file order
         RcclApi* R = rccl_api();
@@ -386,7 +423,22 @@ static int allgather_survivors_impl(dp_comm* c, dp_ctx* ctx, const dp_survivor_b
     // my extra items follow the survivors
     if (extra_ints)
         DP_HIP(hipMemcpyAsync(a_segs + tot_ints, (const int32_t*)ctx->d_segs.p + surv_ints, extra_ints * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    // ---- host copies for the caller (chunking runs on the host): metadata + all segments
+    // The gathered set described on the device the way dp_scan_reads describes its own survivors ({read, hit count, segment
+    // offset} arrays): dp_index_build_chunked then chunks and indexes it where it lies (overlap.chunkWorker on the device)
+    const uint32_t stride = (uint32_t)std::max<uint64_t>(1, tot_surv);
+    if (dev_reserve(ctx, ctx->d_surv, (size_t)stride * 32 + 128)) return DP_ERR_HIP;
+    {
+        uint32_t* s_item = (uint32_t*)ctx->d_surv.p;
+        uint32_t* s_count = s_item + stride;
+        uint64_t* s_off = (uint64_t*)(s_count + stride + (stride & 1));
+        hipLaunchKernelGGL(comm_install_survivors, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)a_read, (const uint32_t*)a_nseeds,
+                           (uint32_t)tot_surv, s_item, s_count, s_off);
+        DP_HIP(hipGetLastError());
+    }
+    // ---- host copies for the caller: the survivors' read ids and hit counts always; their segments only for a caller that
+    // chunks on the host (dp_scan_fetch_mode(0)) - with fetch mode 1 they never leave the device (1-2 MB per round at k = 13,
+    // ~100 MB in the dense regime); the extra items' (query windows') segments are the local scan's, already on the host
+    const bool resident = ctx->scan_fetch_extras_only != 0;
     const size_t b_meta = (size_t)tot_surv * 8, b_off = ((size_t)tot_surv + ne + 2) * 8, b_ex = (size_t)ne * 4, b_segs = (size_t)new_ints * 4;
     if (comm_pin(ctx, c->h_out, b_meta + b_off + b_ex + b_segs + 256)) return DP_ERR_HIP;
     uint8_t* h = (uint8_t*)c->h_out.p;
@@ -396,8 +448,7 @@ static int allgather_survivors_impl(dp_comm* c, dp_ctx* ctx, const dp_survivor_b
     uint32_t* h_exn = (uint32_t*)((uint8_t*)h_off + b_off);
     int32_t* h_segs = (int32_t*)(((uintptr_t)((uint8_t*)h_exn + b_ex) + 15) & ~(uintptr_t)15);
     if (tot_surv) DP_HIP(hipMemcpyAsync(h_read, a_read, b_meta, hipMemcpyDeviceToHost, ctx->stream));
-    if (new_ints) DP_HIP(hipMemcpyAsync(h_segs, a_segs, b_segs, hipMemcpyDeviceToHost, ctx->stream));
-    // the merged array becomes the context's scan output (dp_index_build / dp_find_overlaps read it): swap the buffers
+    if (new_ints && !resident) DP_HIP(hipMemcpyAsync(h_segs, a_segs, b_segs, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     if (c->local) {  // nobody may reuse its published buffers before every peer has copied from them
         LocalGroup* g = c->local;
@@ -413,10 +464,12 @@ static int allgather_survivors_impl(dp_comm* c, dp_ctx* ctx, const dp_survivor_b
             if (g->gen == my_gen) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_survivors: a peer rank failed");
         }
     }
-    if (dev_reserve(ctx, ctx->d_segs, (size_t)new_ints * 4 + 64)) return DP_ERR_HIP;
-    if (new_ints) DP_HIP(hipMemcpyAsync(ctx->d_segs.p, a_segs, (size_t)new_ints * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    DP_HIP(dp_stream_sync(ctx));
+    // the merged array becomes the context's scan output (dp_index_build* / dp_find_overlaps read it): the buffers change places
+    std::swap(ctx->d_segs, c->d_allsegs);
     ctx->n_segs = new_ints;
+    ctx->scan_items = stride;
+    ctx->last_surv_all = stride;
+    ctx->chunk_lo = 0;  // (the installed survivor list holds read ids)
     uint64_t pos = 0;
     for (uint64_t i = 0; i < tot_surv; i++) {
         h_off[i] = pos;
@@ -426,7 +479,13 @@ static int allgather_survivors_impl(dp_comm* c, dp_ctx* ctx, const dp_survivor_b
     for (uint32_t i = 0; i < ne; i++) {
         h_exn[i] = local->extra_n_seeds[i];
         h_exoff[i] = tot_ints + (local->extra_seg_off[i] - surv_ints);
+        if (resident)  // (the query windows' segments: from the local scan's host copy to their place in the gathered layout)
+            memcpy(h_segs + h_exoff[i], local->segs + local->extra_seg_off[i], (2 * (size_t)local->extra_n_seeds[i] + 1) * 4);
     }
+    // (only now: `local` points into h_surv, the scan's own pinned output, which the gathered list replaces)
+    if (pin_reserve(ctx, ctx->h_surv, (size_t)stride * 16 + 64)) return DP_ERR_HIP;
+    memcpy(ctx->h_surv.p, h_read, (size_t)tot_surv * 4);
+    memcpy((uint32_t*)ctx->h_surv.p + stride, h_nseeds, (size_t)tot_surv * 4);
     dp_survivor_batch o = *local;
     o.n_survivors = (uint32_t)tot_surv;
     o.read = h_read;
@@ -441,6 +500,107 @@ static int allgather_survivors_impl(dp_comm* c, dp_ctx* ctx, const dp_survivor_b
     (void)my_surv_off;
     (void)my_int_off;
     return DP_OK;
+}
+
+// ---- all-gather of one variable-size byte string per rank (the round-parallel layout's result exchange) ---------------------
+// Rank r contributes blob[0 .. n); every rank gets the ranks' strings back to back in rank order (*all_out, library-owned pinned
+// memory, valid until the next call on this communicator) and their lengths (*sizes_out[n_ranks]).  RCCL flavour: sizes by
+// ncclAllGather, payloads as one grouped broadcast per rank straight into the concatenation (exact sizes, no padding), one copy
+// back; in-process flavour: host copies between the ranks' buffers.  Collective: every rank calls it.
+static int allgather_blobs_impl(dp_comm* c, dp_ctx* ctx, const uint8_t* blob, uint64_t n, const uint8_t** all_out, const uint64_t** sizes_out) {
+    hipSetDevice(ctx->device);
+    const int N = c->n_ranks, me = c->rank;
+    if (comm_pin(ctx, c->h_bsz, (size_t)N * 8 + 64)) return DP_ERR_HIP;
+    uint64_t* sizes = (uint64_t*)c->h_bsz.p;
+    if (c->local) {
+        LocalGroup* g = c->local;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->blob[(size_t)me].p = blob;
+            g->blob[(size_t)me].n = n;
+            const uint64_t my_gen = g->gen;
+            if (g->failed) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_blobs: a peer rank failed");
+            if (++g->arrived == N) {
+                g->arrived = 0;
+                g->gen++;
+                g->cv.notify_all();
+            } else {
+                g->cv.wait(lk, [&] { return g->gen != my_gen || g->failed; });
+                if (g->gen == my_gen) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_blobs: a peer rank failed");
+            }
+        }
+        uint64_t tot = 0;
+        for (int r = 0; r < N; r++) tot += (sizes[r] = g->blob[(size_t)r].n);
+        if (comm_pin(ctx, c->h_blob, tot + 64)) return DP_ERR_HIP;
+        uint8_t* out = (uint8_t*)c->h_blob.p;
+        uint64_t at = 0;
+        for (int r = 0; r < N; r++) {
+            if (sizes[r]) memcpy(out + at, g->blob[(size_t)r].p, sizes[r]);
+            at += sizes[r];
+        }
+        std::unique_lock<std::mutex> lk(g->mu);  // (nobody may touch its blob again before every peer has copied it)
+        const uint64_t my_gen = g->gen;
+        if (g->failed) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_blobs: a peer rank failed");
+        if (++g->left == N) {
+            g->left = 0;
+            g->gen++;
+            g->cv.notify_all();
+        } else {
+            g->cv.wait(lk, [&] { return g->gen != my_gen || g->failed; });
+            if (g->gen == my_gen) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_blobs: a peer rank failed");
+        }
+        *all_out = out;
+        *sizes_out = sizes;
+        return DP_OK;
+    }
+    if (!c->nccl) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_blobs: communicator without a transport");
+    RcclApi* R = rccl_api();
+    if (comm_reserve(ctx, c->d_cnt, (size_t)(N + 1) * 16)) return DP_ERR_HIP;
+    uint64_t* d_mine = (uint64_t*)c->d_cnt.p + (size_t)N;
+    const uint64_t mine = n;
+    DP_HIP(hipMemcpyAsync(d_mine, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
+    ncclResult_t r = R->AllGather(d_mine, c->d_cnt.p, 1, ncclUint64, c->nccl, ctx->stream);
+    if (r != ncclSuccess) return dp_fail(ctx, DP_ERR_HIP, R->GetErrorString(r));
+    DP_HIP(hipMemcpyAsync(sizes, c->d_cnt.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    uint64_t tot = 0, my_off = 0;
+    for (int q = 0; q < N; q++) {
+        if (q == me) my_off = tot;
+        tot += sizes[q];
+    }
+    if (comm_reserve(ctx, c->d_blob, (size_t)tot + 256)) return DP_ERR_HIP;
+    if (comm_pin(ctx, c->h_blob, (size_t)tot + 64)) return DP_ERR_HIP;
+    uint8_t* d_all = (uint8_t*)c->d_blob.p;
+    if (n) DP_HIP(hipMemcpyAsync(d_all + my_off, blob, n, hipMemcpyHostToDevice, ctx->stream));
+    R->GroupStart();
+    uint64_t at = 0;
+    for (int q = 0; q < N && r == ncclSuccess; q++) {
+        if (sizes[q]) r = R->Broadcast(d_all + at, d_all + at, sizes[q], ncclUint8, q, c->nccl, ctx->stream);
+        at += sizes[q];
+    }
+    const ncclResult_t rg = R->GroupEnd();
+    if (r == ncclSuccess) r = rg;
+    if (r != ncclSuccess) return dp_fail(ctx, DP_ERR_HIP, R->GetErrorString(r));
+    if (tot) DP_HIP(hipMemcpyAsync(c->h_blob.p, d_all, tot, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    *all_out = (const uint8_t*)c->h_blob.p;
+    *sizes_out = sizes;
+    return DP_OK;
+}
+
+extern "C" int dp_allgather_blobs(dp_comm* c, dp_ctx* ctx, const uint8_t* blob, uint64_t n, const uint8_t** all_out, const uint64_t** sizes_out) {
+    if (!c || !ctx || !all_out || !sizes_out || (n && !blob)) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_allgather_blobs: bad arguments") : DP_ERR_ARG;
+    if (c->dead) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_blobs: the communicator failed in an earlier exchange");
+    const int rc = allgather_blobs_impl(c, ctx, blob, n, all_out, sizes_out);
+    if (rc != DP_OK) {
+        c->dead = true;
+        if (c->local) {
+            std::lock_guard<std::mutex> lk(c->local->mu);
+            c->local->failed = true;
+            c->local->cv.notify_all();
+        }
+    }
+    return rc;
 }
 
 extern "C" int dp_comm_rank(const dp_comm* c) { return c ? c->rank : -1; }

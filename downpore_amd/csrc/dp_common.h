@@ -90,6 +90,7 @@ struct dp_ctx {
     uint64_t ignore_epoch = ~0ull;
     uint64_t cached_bases = 0;
     uint32_t cached_reads = 0, cached_lo = 0, cached_hi = 0;
+    uint32_t chunk_lo = 0;            // what turns d_surv's survivor entries into read ids: the scanned range's first read, or 0 once dp_allgather_survivors installed the gathered list
     int cached_top = -1, cached_k = 0;
     // the read items on the device (make_read_items_kernel) are regenerated only when what they are made from changes
     const void* items_ptr = nullptr;

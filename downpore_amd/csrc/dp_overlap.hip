@@ -335,7 +335,7 @@ extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t o
         P.s_count = s_count;
         P.s_off = s_off;
         P.ns = n_survivors;
-        P.lo = ctx->cached_lo;
+        P.lo = ctx->chunk_lo;
         P.read_len = (const uint32_t*)ctx->d_len.p;
         P.segs = (const int32_t*)ctx->d_segs.p;
         P.k = ctx->k;

@@ -1429,6 +1429,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     out->index_mode = 0;
     out->index_hits = 0;
     ctx->scan_items = n_items;
+    ctx->chunk_lo = lo;
     if (pin_reserve(ctx, ctx->h_total, 64)) return DP_ERR_HIP;
     if (n_items == 0) {
         ctx->n_segs = 0;

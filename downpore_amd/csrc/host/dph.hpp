@@ -302,6 +302,8 @@ struct Survivors {
     uint64_t segsViewLen = 0;           // context scans again): the dense-seed regime moves ~80 MB per round here
     bool deviceResident = false;     // the device scan buffer of the producing context holds exactly these ints at the same offsets
     bool segsOnHost = true;          // false: the scan left the survivors' segments on the device (dp_scan_fetch_mode): segData() is not valid
+    const void* chunkCtx = nullptr;  // the context whose device-side survivor list describes exactly this set (its own scan, or the
+                                     // set dp_allgather_survivors installed): dp_index_build_chunked can chunk it where it lies
     const int32_t* segData() const { return segsView ? segsView : segs.data(); }
     uint64_t segCount() const { return segsView ? segsViewLen : (uint64_t)segs.size(); }
 };
@@ -551,6 +553,7 @@ struct ExecSlot {
     std::unique_ptr<SeedIndex> index;  // executor-side seed maps of the running round
     std::unique_ptr<Overlapper> lap;
     Survivors local;
+    int slotNo = 0;                    // position among the run's slots
     dp_comm* comm = nullptr;           // scan-shard mode: this slot's communicator (owned by the caller of OverlapRun)
     Survivors gathered;                // ... and the survivors of all ranks of the running round
     std::vector<SeedMatch> matchPool;  // reused across rounds
@@ -642,6 +645,13 @@ struct OverlapRun {
     // Returns the number of rounds committed, 0 = finished, <0 error.
     std::vector<dp_comm*> slotComms;
     int roundsShardedBatch();
+    // The slots of a batch exchange on their own communicators, all on this rank's one device: RCCL wants collectives of several
+    // communicators that share a device issued in the same order on every rank, so the exchanges of a batch take turns in slot
+    // order (slot i after slot i - 1, on every rank alike); everything else of the rounds still runs concurrently.
+    std::mutex exchangeMu_;
+    std::condition_variable exchangeCv_;
+    int exchangeTurn_ = 0;
+    bool exchangeOrdered_ = false;
     void abortComms();
     // ---- round-parallel mode: execute round `r` speculatively against the current flags, commit gathered results
     int executeRound(i64 r, RoundResult& out);

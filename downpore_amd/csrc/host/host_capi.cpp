@@ -18,6 +18,7 @@ struct OverlapH {
     OverlapRun run;
     dp_ctx* ctx = nullptr;
     dp_comm* comm = nullptr;
+    dp_ctx* xctx = nullptr;           // round-parallel mode: the context (own stream) the result exchange runs on
     std::vector<dp_comm*> slotComms;  // scan-shard with executor slots: one communicator per slot
     ReadSet* reads = nullptr;
     double tCtx = 0, tUpload = 0, tInit = 0;
@@ -191,6 +192,7 @@ void dph_overlap_destroy(void* hh) {
     h->run.shutdown();
     if (h->comm) dp_comm_destroy(h->comm);
     for (dp_comm* c : h->slotComms) dp_comm_destroy(c);
+    if (h->xctx) dp_ctx_destroy(h->xctx);
     dp_ctx_destroy(h->ctx);
     delete h;
 }
@@ -493,6 +495,44 @@ int dph_overlap_commit_gathered(void* hh, const uint8_t* blobs, const uint64_t* 
     std::vector<RoundResult> rs;
     deserialise(blobs, sizes, count, rs);
     int c = h->run.commitGathered(rs);
+    if (c > 0) h->addPaf(h->run.paf);
+    return c;
+}
+
+// One superstep of the round-parallel layout with the exchange inside the library (dp_allgather_blobs on the communicator of
+// dph_overlap_comm_init / _comm_init_local): this rank's next owned round and up to max_rounds - 1 finished ones after it,
+// all-gathered, committed in round order on every rank.  Collective.  Returns the rounds committed (0 = the superstep's first
+// round was rejected and is executed again; call dph_overlap_done to learn whether the command is finished), < 0 on error.
+int dph_overlap_superstep(void* hh, int max_rounds) {
+    OverlapH* h = (OverlapH*)hh;
+    if (!h->comm) {
+        h->err = "dph_overlap_superstep without a communicator (dph_overlap_comm_init)";
+        return -1;
+    }
+    if (!h->xctx && dp_ctx_create_shared(h->ctx, &h->xctx) != 0) {
+        h->err = dp_last_error(nullptr);
+        return -1;
+    }
+    std::vector<RoundResult> res;
+    int rc = h->run.waitOwned(res, max_rounds);
+    if (rc != 0) {
+        h->err = h->run.error;
+        dp_comm_abort(h->comm);  // (the peers must not wait for this rank's contribution)
+        return rc < 0 ? rc : -1;
+    }
+    static thread_local std::string blob;
+    blob.clear();
+    for (RoundResult& r : res) serialise(r, blob);
+    const uint8_t* all = nullptr;
+    const uint64_t* sizes = nullptr;
+    rc = dp_allgather_blobs(h->comm, h->xctx, (const uint8_t*)blob.data(), blob.size(), &all, &sizes);
+    if (rc != 0) {
+        h->err = dp_last_error(h->xctx);
+        return rc;
+    }
+    std::vector<RoundResult> rs;
+    deserialise(all, sizes, dp_comm_size(h->comm), rs);
+    const int c = h->run.commitGathered(rs);
     if (c > 0) h->addPaf(h->run.paf);
     return c;
 }

@@ -269,6 +269,7 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
     local.segsViewLen = survEnd;
     local.deviceResident = true;
     local.segsOnHost = !(deviceChunkWanted_ && b.index_mode);  // (fetch mode 1 is honoured by the index-mode scan only)
+    local.chunkCtx = ctx_;
     lastLocal_ = &local;
     // query windows
     winSegs_.clear();
@@ -300,6 +301,10 @@ int Overlapper::ExchangeSurvivors(dp_comm* comm, Survivors& all) {
     all.segsView = g.segs;
     all.segsViewLen = survEnd;
     all.deviceResident = true;  // the library installed the gathered array as the context's scan output
+    // ... and the gathered survivor list next to it: chunking and indexing run on the device as for a single GPU; with
+    // dp_scan_fetch_mode(1) the survivors' segments never came to the host (only the query windows' are valid in g.segs)
+    all.chunkCtx = ctx_;
+    all.segsOnHost = !deviceChunkWanted_;
     winSegs_.clear();
     winOff_.assign(1, 0);
     for (uint32_t i = 0; i < g.n_extra; i++) {
@@ -379,8 +384,9 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
     chunksOnDevice_ = false;
     // (minSeeds <= 5: the reference's walk backs up as many seeds as a chunk holds - no bound on the number of chunks to size the
     // device buffers from; the host loop below does what the reference does)
-    if (deviceChunkWanted_ && minSeeds_ > 5 && all.deviceResident && &all == lastLocal_) {
-        // A12 + A13 on the device: the survivors of this context's own scan, still in its scan buffer
+    if (deviceChunkWanted_ && minSeeds_ > 5 && all.deviceResident && all.chunkCtx == ctx_) {
+        // A12 + A13 on the device: the survivors of this context's own scan - or the set gathered from every rank - still in
+        // its scan buffer
         index_.sequences.clear();
         index_.refs.clear();
         uint32_t cap = 0;
@@ -401,16 +407,16 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
         g_prof.add(8, now() - tpd);
         return 0;
     }
-    if (!all.segsOnHost) {  // (left on the device by the scan, but this round is chunked on the host after all)
-        const int32_t* p = nullptr;
+    const int32_t* fetched = nullptr;
+    if (!all.segsOnHost) {  // (left on the device by the scan / the exchange, but this round is chunked on the host after all)
         uint64_t n = 0;
-        int rc = dp_scan_fetch_segments(ctx_, &p, &n);
+        int rc = dp_scan_fetch_segments(ctx_, &fetched, &n);
         if (rc != 0) {
             err = dp_last_error(ctx_);
             return rc;
         }
     }
-    allSegs_ = all.segData();
+    allSegs_ = fetched ? fetched : all.segData();  // (same layout: the context's scan output is exactly this survivor array)
     // the device-resident scan output the index refers to must hold exactly this survivor array at the same offsets:
     // true right after a local full scan; after a multi-GPU exchange the gathered array is imported
     int rc = 0;

@@ -785,6 +785,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
             continue;
         }
         std::unique_ptr<ExecSlot> sl(new ExecSlot());
+        sl->slotNo = i;
         if (i == 0) {
             sl->ctx = ctx;
         } else {
@@ -911,7 +912,7 @@ int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
             const char* c = getenv("DP_DEVICE_CONSENSUS");
             return !(e && e[0] == '0') && !(c && c[0] == '0');
         }();
-        sl.lap->setDeviceChunking(deviceChunk && sl.comm == nullptr);
+        sl.lap->setDeviceChunking(deviceChunk);  // (scan-shard mode too: the gathered survivors are chunked where the exchange put them)
     }
     sl.lap->setIgnoreView(reads->ignore.data(), planner->ignoreEpoch());
     const double tb2 = now();
@@ -1001,6 +1002,17 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
         explicit GangRound(dp_ctx* c_) : c(c_) { dp_gang_round_prepare(c); }
         ~GangRound() { dp_gang_round_end(c); }
     } gangRound(sl.ctx);
+    struct ExchangeTurn {  // however this round ends, the slots behind it in the batch's exchange order are not kept waiting
+        OverlapRun* run;
+        int index;
+        bool on;
+        ~ExchangeTurn() {
+            if (!on) return;
+            std::lock_guard<std::mutex> lk(run->exchangeMu_);
+            run->exchangeTurn_ = std::max(run->exchangeTurn_, index + 1);
+            run->exchangeCv_.notify_all();
+        }
+    } exchangeTurn{this, sl.slotNo, sl.comm != nullptr && exchangeOrdered_};
     static const bool dbgExec = getenv("DPH_DEBUG_PLANNER") != nullptr;
     if (dbgExec) fprintf(stderr, "[exec] round %lld waiting for its plan\n", (long long)r);
     std::shared_ptr<const RoundPlan> plan = planner->get(r);
@@ -1029,7 +1041,16 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     out.st.t_prepare = t1 - t0;
     const bool sharded = sl.comm != nullptr;  // scan-shard: this rank scans its reads, the survivors of all ranks are exchanged
     rc = sl.lap->ScanLocal(sharded ? shardLo : 0, sharded ? shardHi : reads->size(), sl.local, out.st);
+    if (sharded && exchangeOrdered_) {  // this slot's turn among the batch's exchanges (taken also by a slot whose scan failed)
+        std::unique_lock<std::mutex> lk(exchangeMu_);
+        exchangeCv_.wait(lk, [&] { return exchangeTurn_ >= sl.slotNo; });
+    }
     if (rc == 0 && sharded) rc = sl.lap->ExchangeSurvivors(sl.comm, sl.gathered);
+    if (sharded && exchangeOrdered_) {
+        std::lock_guard<std::mutex> lk(exchangeMu_);
+        exchangeTurn_ = std::max(exchangeTurn_, sl.slotNo + 1);
+        exchangeCv_.notify_all();
+    }
     if (rc != 0) {
         sl.error = sl.lap->err;
         if (sharded) dp_comm_abort(sl.comm);  // (the peers of this round's exchange must not wait for a rank that will not come)
@@ -1448,7 +1469,13 @@ int OverlapRun::roundsShardedBatch() {
         std::vector<i64> rounds;
         for (size_t i = 0; i < slots.size(); i++) rounds.push_back(round + (i64)i);
         std::vector<RoundResult> outs;
+        {
+            std::lock_guard<std::mutex> lk(exchangeMu_);
+            exchangeTurn_ = 0;
+            exchangeOrdered_ = true;
+        }
         int rc = executeRounds(rounds, outs);
+        exchangeOrdered_ = false;
         if (rc != 0) {
             abortComms();  // this rank leaves the job: the peers' next exchanges fail instead of waiting for it
             return rc < 0 ? rc : -1;

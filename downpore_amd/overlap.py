@@ -87,6 +87,7 @@ def load_host():
     H.dph_overlap_rounds_sharded.argtypes = [vp]
     H.dph_overlap_comm_init_slots.argtypes = [vp, C.c_int, C.c_int, C.c_void_p, C.c_int]
     H.dph_overlap_comm_init_local_slots.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    H.dph_overlap_superstep.argtypes = [vp, C.c_int]
     _host = H
     return H
 
@@ -247,9 +248,9 @@ class OverlapPipeline:
         self.reads = reads
         self.rank, self.world = rank, world
         self.torch_device = torch_device
-        self.mode = mode if (world > 1 or (mode == "scan-shard" and comm is not None)) else "single"
+        self.mode = mode if (world > 1 or (mode in ("scan-shard", "round") and comm is not None)) else "single"
         self._lo_hi = shard_bounds(len(reads), rank, world) if self.mode == "scan-shard" else None
-        self.comm = comm if self.mode == "scan-shard" else None
+        self.comm = comm if self.mode in ("scan-shard", "round") else None
         if self.comm == "rccl":
             self._init_rccl()
         if not defer_init:
@@ -274,7 +275,7 @@ class OverlapPipeline:
 
     def _init_rccl(self):
         """dp_comm_init on this rank's context: rank 0 makes the id, everybody gets it through torch.distributed."""
-        ns = max(1, self.slots)
+        ns = max(1, self.slots) if self.mode == "scan-shard" else 1  # (round-parallel: one communicator for the result exchange)
         idb = np.zeros(128 * ns, dtype=np.uint8)  # one communicator per executor slot
         if self.rank == 0:
             for i in range(ns):
@@ -301,7 +302,7 @@ class OverlapPipeline:
         communicator: their survivor exchange then copies device to device between the contexts."""
         H = pipes[0].H
         arr = (C.c_void_p * len(pipes))(*[p.h for p in pipes])
-        ns = max(1, pipes[0].slots)
+        ns = max(1, pipes[0].slots) if pipes[0].mode == "scan-shard" else 1
         if ns > 1:  # one in-process communicator per executor slot
             if H.dph_overlap_comm_init_local_slots(arr, len(pipes), ns) != 0:
                 raise DpError("dp_comm_init_local failed")
@@ -362,6 +363,17 @@ class OverlapPipeline:
             if rc < 0:
                 raise self._err()
             return rc
+        if self.mode == "round" and self.comm is not None:
+            # the same protocol with the exchange inside the library (dp_allgather_blobs: RCCL, or host copies between the
+            # handles of one process)
+            while True:
+                if self.H.dph_overlap_done(self.h):
+                    return 0
+                c = self.H.dph_overlap_superstep(self.h, max(1, self.slots))
+                if c < 0:
+                    raise self._err()
+                if c > 0:
+                    return c
         if self.mode == "round":
             # pipelined: this rank's executor slots keep working on the rounds r % world == rank; one superstep = every
             # rank contributes its next owned round, all-gather, commit in round order on every rank

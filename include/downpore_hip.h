@@ -438,6 +438,13 @@ DP_API int dp_gang_round_members(const dp_ctx* ctx);
  * out[3] = round starts, out[4] = members released by them */
 DP_API void dp_gang_counters(dp_gang* gang, uint64_t* out /* [5] */);
 
+/* All-gather of one variable-size byte string per rank on the same communicator: the result exchange of the round-parallel
+ * layout (every GPU holds the reads and their index, the rounds - commands/overlap.go:119's loop iterations - are dealt to the
+ * ranks, and a round's PAF text, SetIgnore ids and read lists travel to every rank, which commits them in round order).  *all_out
+ * = the ranks' strings back to back in rank order, *sizes_out[n_ranks] their lengths (library-owned, valid until the next call on
+ * this communicator).  Collective. */
+DP_API int dp_allgather_blobs(dp_comm* comm, dp_ctx* ctx, const uint8_t* blob, uint64_t n, const uint8_t** all_out, const uint64_t** sizes_out);
+
 /* Device pointers of the last dp_scan output, for a multi-GPU exchange driven by the caller (RCCL all-gather of
  * the survivors).  segs_dev: int32[n_segs]. */
 DP_API int dp_scan_device_buffers(dp_ctx* ctx, void** segs_dev, uint64_t* n_segs);

@@ -112,6 +112,9 @@ DPH_API void dph_overlap_set_ranks(void* h, int rank, int world);
 DPH_API const uint8_t* dph_overlap_wait_owned(void* h, uint64_t* n);
 DPH_API const uint8_t* dph_overlap_wait_owned_many(void* h, int max_rounds, uint64_t* n);
 DPH_API int dph_overlap_commit_gathered(void* h, const uint8_t* blobs, const uint64_t* sizes, int count);
+/* the same superstep with the exchange inside the library (dp_allgather_blobs on the communicator of dph_overlap_comm_init):
+ * rounds committed; 0 = the superstep's first round was rejected and runs again (or the command is finished: dph_overlap_done) */
+DPH_API int dph_overlap_superstep(void* h, int max_rounds);
 DPH_API const uint8_t* dph_overlap_exec_round(void* h, int64_t first_round, uint64_t* n);
 DPH_API int dph_overlap_commit_blobs(void* h, const uint8_t* blobs, const uint64_t* sizes, int count);
 

@@ -38,3 +38,32 @@ def test_bench_two_ranks_sharing_the_gpu(mode):
     d = _line(p.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["parity"]["paf_sha256_matches_oracle_fixture"] is True
+
+
+def test_bench_two_ranks_default_reports_both_layouts():
+    """N > 1 without --mode: the headline is north_star's layout (reads partitioned, survivors all-gathered), the round-parallel
+    layout follows as `alt_mode`; each is held to the fixture on its own."""
+    env = dict(os.environ, DP_BENCH_SAME_DEVICE="1", DP_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29518", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-rounds", "0", "--slots", "4"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 2 and "north_star layout" in d["config"]["parallelism"]
+    assert d["parity"]["paf_sha256_matches_oracle_fixture"] is True
+    assert d["alt_mode"]["mode"] == "round" and d["alt_mode"]["paf_sha256_matches_oracle_fixture"] is True and d["alt_mode"]["value"] > 0
+
+
+def test_bench_two_gpus_over_rccl():
+    """Two real ranks, one GPU each, exchanging over RCCL inside the library (dp_comm_init / dp_allgather_survivors /
+    dp_allgather_blobs): what the driver's multi-GPU run does.  Needs a second GPU."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-rounds", "0"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 2 and d["parity"]["paf_sha256_matches_oracle_fixture"] is True
+    assert d["alt_mode"]["paf_sha256_matches_oracle_fixture"] is True

@@ -596,3 +596,43 @@ def test_whole_job_through_the_published_host_header_only():
     assert np.array_equal(ig, rs.ignore())
     H.dph_overlap_destroy(vp(h))
     H.dph_reads_free(vp(reads))
+
+
+def test_round_parallel_exchange_inside_the_library():
+    """The round-parallel layout with its result exchange inside the C ABI (dp_allgather_blobs behind dph_overlap_superstep): two
+    in-process ranks x three slots on one GPU (host copies between the handles) on reads that flag reads, and the 1-rank RCCL
+    communicator; every rank must print the oracle's PAF."""
+    import threading
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(33, 60000, 700, 1500, 0.0, True)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    want = O.OverlapRun(rs, k=10, seed_batch_size=1500)
+    assert want.rounds >= 8 and rs.ignore().sum() > 0
+    world = 2
+    readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
+    pipes = [OverlapPipeline(readsets[r], k=10, seed_batch_size=1500, rank=r, world=world, mode="round", comm="local", slots=3)
+             for r in range(world)]
+    OverlapPipeline.link_local(pipes)
+    errs = []
+
+    def run(p):
+        try:
+            p.run()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(p,)) for p in pipes]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    for r in range(world):
+        d = first_diff(pipes[r].all_paf(), want.paf)
+        assert d is None, (r, d)
+        assert np.array_equal(readsets[r].ignore(), rs.ignore())
+        pipes[r].close()
+    r1 = Reads(bases, off, min_len=1000)
+    p1 = OverlapPipeline(r1, k=10, seed_batch_size=1500, rank=0, world=1, mode="round", comm="rccl", slots=2)
+    p1.run()
+    assert first_diff(p1.all_paf(), want.paf) is None
+    p1.close()

@@ -38,7 +38,27 @@ CONFIGS = {
 }
 
 
+def map_config3():
+    """BASELINE config 3: 50 000 reads x 8 kb (10 % error) mapped against a 4.6 Mb circular reference, k = 11 - the oracle's whole
+    PAF (about two seconds of one core), kept as a hash for bench.py's map leg."""
+    O.build_oracle()
+    G, N, L, e, seed, k = 4600000, 50000, 8000, 0.1, 3, 11
+    genome = np.frombuffer(O.gen_genome(seed, G), dtype=np.uint8)
+    goff = np.array([0, G], dtype=np.int64)
+    bases, off = O.gen_reads(seed, G, N, L, e, False)
+    t0 = time.time()
+    paf, err = O.map_run(O.ReadSet(genome, goff, min_len=0, himem=False), O.ReadSet(bases, off, min_len=500, himem=False), circular=True, k=k)
+    out = {"case": "config3_map", "generator": {"seed": seed, "genome": G, "reads": N, "read_len": L, "error": e, "variable": False},
+           "k": k, "circular": True, "paf_lines": paf.count("\n"), "paf_sha256": hashlib.sha256(paf.encode()).hexdigest(),
+           "stderr": err, "paf_head": paf.split("\n")[:3], "made_by": "tools/make_golden_full.py config3_map (oracle only)",
+           "oracle_s": time.time() - t0}
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden_full", "config3_map.json"), "w"), indent=1)
+    print(json.dumps(out)[:600])
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "config3_map":
+        return map_config3()
     ap = argparse.ArgumentParser()
     ap.add_argument("config", choices=sorted(CONFIGS))
     ap.add_argument("--rounds", type=int, default=-1)
