@@ -290,6 +290,7 @@ int dph_overlap_comm_init_slots(void* hh, int nRanks, int rank, const uint8_t* i
     }
     h->run.slotComms = h->slotComms;
     for (size_t i = 0; i < h->run.slots.size() && i < h->slotComms.size(); i++) h->run.slots[i]->comm = h->slotComms[i];
+    h->run.destroyGangs();  // (slots that exchange on communicators of their own do not share launches: see OverlapRun::init)
     return 0;
 }
 int dph_overlap_comm_init_local_slots(void** handles, int n, int nSlots) {
@@ -310,6 +311,7 @@ int dph_overlap_comm_init_local_slots(void** handles, int n, int nSlots) {
         OverlapH* h = (OverlapH*)handles[i];
         h->run.slotComms = h->slotComms;
         for (size_t j = 0; j < h->run.slots.size() && j < h->slotComms.size(); j++) h->run.slots[j]->comm = h->slotComms[j];
+        h->run.destroyGangs();  // (see dph_overlap_comm_init_slots)
     }
     return 0;
 }

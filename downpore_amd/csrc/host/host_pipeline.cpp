@@ -643,6 +643,7 @@ void OverlapRun::shutdown(bool keepContexts) {
 void OverlapRun::destroyGangs() {
     for (dp_gang* g : gangs) dp_gang_destroy(g);
     gangs.clear();
+    gangSize = 1;
 }
 
 int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const double* valuesOrNull, int nSlots) {
@@ -1041,11 +1042,15 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     out.st.t_prepare = t1 - t0;
     const bool sharded = sl.comm != nullptr;  // scan-shard: this rank scans its reads, the survivors of all ranks are exchanged
     rc = sl.lap->ScanLocal(sharded ? shardLo : 0, sharded ? shardHi : reads->size(), sl.local, out.st);
+    static const bool dbgX = getenv("DPH_DEBUG_EXCHANGE") != nullptr;
+    if (dbgX) fprintf(stderr, "[x %p] slot %d round %lld scanned rc %d, waiting for turn (turn %d)\n", (void*)this, sl.slotNo, (long long)r, rc, exchangeTurn_);
     if (sharded && exchangeOrdered_) {  // this slot's turn among the batch's exchanges (taken also by a slot whose scan failed)
         std::unique_lock<std::mutex> lk(exchangeMu_);
         exchangeCv_.wait(lk, [&] { return exchangeTurn_ >= sl.slotNo; });
     }
+    if (dbgX) fprintf(stderr, "[x %p] slot %d round %lld exchanging\n", (void*)this, sl.slotNo, (long long)r);
     if (rc == 0 && sharded) rc = sl.lap->ExchangeSurvivors(sl.comm, sl.gathered);
+    if (dbgX) fprintf(stderr, "[x %p] slot %d round %lld exchanged rc %d\n", (void*)this, sl.slotNo, (long long)r, rc);
     if (sharded && exchangeOrdered_) {
         std::lock_guard<std::mutex> lk(exchangeMu_);
         exchangeTurn_ = std::max(exchangeTurn_, sl.slotNo + 1);
@@ -1058,6 +1063,7 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     }
     out.st.t_scan = now() - t1;
     rc = finishRound(sl, sharded ? sl.gathered : sl.local, out);
+    if (dbgX) fprintf(stderr, "[x %p] slot %d round %lld finished rc %d\n", (void*)this, sl.slotNo, (long long)r, rc);
     if (dbgExec) fprintf(stderr, "[exec] round %lld finished rc %d\n", (long long)r, rc);
     const double t2 = now();
     g_prof.add(14, t2 - t0);
