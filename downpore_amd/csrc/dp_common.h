@@ -62,6 +62,7 @@ struct dp_ctx {
     DevBuf d_selwin, d_seltop;
     PinBuf h_seltop;
     DevBuf d_cin, d_cout;       // dp_consensus_align
+    DevBuf d_cretry;            // dp_consensus_paf: windows the small LDS layout could not hold ([0] count, [1..] window numbers)
     PinBuf h_cin, h_cout;
     std::vector<uint64_t> h_boff;
     std::vector<uint32_t> h_len;
@@ -204,7 +205,7 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                     const uint64_t* d_totals, int32_t* d_segs, int32_t* host_segs = nullptr);
 
 // kernels implemented in other translation units
-int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch = nullptr);  // dp_overlap.hip: GetSeedOffset / GetSeedOffsetFromEnd anchors of the last chaining stage's records
+int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch = nullptr, uint32_t* zero_word = nullptr);  // dp_overlap.hip: GetSeedOffset / GetSeedOffsetFromEnd anchors of the last chaining stage's records
 int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs);
 int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,
                           uint32_t max_query_len, int want_candidates, dp_match_batch* out);

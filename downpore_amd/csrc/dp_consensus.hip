@@ -312,35 +312,50 @@ extern "C" int dp_consensus_align(dp_ctx* ctx, const int32_t* segs, const uint64
 //      SetIgnore decisions.
 // What does not fit the LDS layout (more than 64 sequences, more than CF_T ints, values outside the 32-bit safe range)
 // is flagged and left to the host path, which then fetches the matches.
-#define CF_T 4096      // ints of trimmed sequences per group
-#define CF_R 4096      // ints of reduced sequences per group
-#define CF_CONS 1024   // ints of the consensus
-#define CF_A 256       // seeds of the query window
-#define CF_M 256       // matches of a group before the 25-base filter
-#define CF_HASH 4096
+// Two layouts of the wave's LDS block.  The small one (int16 elements, a quarter of the capacities' bytes: ~21 KB) holds what a
+// query window of `downpore overlap` nearly always is - twenty to forty trimmed targets of fifteen to thirty seeds - and lets a CU
+// hold seven of these waves instead of two; a window that does not fit it (more ints, a gap or offset beyond 16 bits, more than
+// 32767 seeds in the round) is put on a list and done by a second launch with the large layout (int32, 57 KB: round 2's), and
+// what does not fit that either is flagged for the host path as before.  Same code, same results, whichever layout ran.
+template <bool SMALL>
+struct CFCfg;
+template <>
+struct CFCfg<false> {
+    typedef int32_t elem_t;
+    enum { T = 4096, R = 4096, CONS = 1024, A = 256, M = 256, HASH = 4096, HSHIFT = 20 };
+};
+template <>
+struct CFCfg<true> {
+    typedef int16_t elem_t;
+    enum { T = 2048, R = 2048, CONS = 256, A = 128, M = 128, HASH = 2048, HSHIFT = 21 };
+};
 
-struct CFWave {
-    int32_t T[CF_T];
-    int32_t R[CF_R];
-    uint16_t Rmap[CF_R / 2];
+template <bool SMALL>
+struct CFWaveT {
+    typedef CFCfg<SMALL> C;
+    typedef typename C::elem_t elem_t;
+    elem_t T[C::T];               // trimmed sequences of the group, [gap, seed, ..., gap] each
+    elem_t R[C::R];               // their Reduced() forms
+    uint16_t Rmap[C::R / 2];
     union {
-        uint32_t hash[CF_HASH];  // (seed + 1) << 8 | shared << 7 | first sequence
+        uint32_t hash[C::HASH];  // (seed + 1) << 8 | shared << 7 | first sequence
         struct {
-            uint16_t cmA[CF_R / 2], cmB[CF_R / 2];  // consensus matches of sequence s at [rb[s]/2 .. ): consensus index, index in T_s
-            int32_t cons[CF_CONS + 2];
-            int32_t front[CF_CONS / 8 + 2], backc[CF_CONS / 8 + 2];
+            uint16_t cmA[C::R / 2], cmB[C::R / 2];  // consensus matches of sequence s at [rb[s]/2 .. ): consensus index, index in T_s
+            int32_t cons[C::CONS + 2];
+            int32_t front[C::CONS / 8 + 2], backc[C::CONS / 8 + 2];
         };
     };
-    int32_t GA[CF_A + 2];     // G(i) = sum_{j=1..i} (a[2j] + k) over the forward query
-    uint32_t mpair[CF_M];     // pair slot of every match of the group
-    int32_t tb[64], tN[64], tLen[64], tOff[64], tIns[64], tId[64], rb[64], rN[64], mLen[64];
+    int32_t GA[C::A + 2];     // G(i) = sum_{j=1..i} (a[2j] + k) over the forward query
+    uint32_t mpair[C::M];     // pair slot of every match of the group
+    int32_t tLen[64], tOff[64], tIns[64], tId[64];
+    uint16_t tb[64], tN[64], rb[64], rN[64], mLen[64];
     uint8_t tRc[64], ord[64];
 };
 
-
 // seeds/sequence.go:1190 GetBaseIndex for one part: MA/MB = its consensus matches, sa = consensus, sb = trimmed target
+template <class E>
 __device__ __forceinline__ void cf_base_index(const uint16_t* MA, const uint16_t* MB, int L, int aIndex, const int32_t* sa,
-                                              const int32_t* sb, int nb, int k, int& indexOut, int& basesOut) {
+                                              const E* sb, int nb, int k, int& indexOut, int& basesOut) {
     int before = 0;
     while (before < L && (int)MA[before] <= aIndex) before++;
     if (before == 0) {
@@ -395,17 +410,39 @@ struct ConsFullArgs {
     uint32_t rec_cap;          // records the chaining stage's buffers hold (its pair count may exceed them: the stage is then repeated)
     const uint32_t* nseq_src;  // chunk count + overflow flag of dp_index_build_chunked (device), or null
     uint32_t* nseq_dst;        // ... and where the host reads them (pinned, with the rest of the output)
+    uint32_t* retry;           // [0] = windows the small layout could not hold, [1 ..] = their numbers (zeroed by the anchors launch);
+                               // the large-layout launch works through this list (null: it does every window)
 };
 
+template <bool SMALL>
 struct consensus_full_kernel {
     enum { THREADS = 64 };
     static __device__ void run(const ConsFullArgs A) {
-    __shared__ CFWave L;
+    typedef CFWaveT<SMALL> LW;
+    typedef typename LW::C CF;
+    typedef typename LW::elem_t elem_t;
+    __shared__ LW L;
     const int lane = dp_lane();
     const int k = A.k;
     const u64 lanesBelow = (1ull << lane) - 1ull;
-    if (blockIdx.x == 0 && lane < 2 && A.nseq_src) A.nseq_dst[lane] = A.nseq_src[lane];
-    for (uint32_t g = blockIdx.x; g < A.n_groups; g += gridDim.x) {
+    // the small layout runs first and does every window; the large one takes what the small one listed (or every window when there
+    // was no small launch: A.retry == null)
+    const bool fromList = !SMALL && A.retry != nullptr;
+    const uint32_t nWork = fromList ? min(A.retry[0], A.n_groups) : A.n_groups;
+    if ((SMALL || !A.retry) && blockIdx.x == 0 && lane < 2 && A.nseq_src) A.nseq_dst[lane] = A.nseq_src[lane];
+    // a window the small layout cannot hold: listed for the large one (which writes its group record)
+#define CF_NOFIT()                                                           \
+    {                                                                        \
+        if (SMALL) {                                                         \
+            if (lane == 0) A.retry[1 + atomicAdd(&A.retry[0], 1u)] = g;      \
+        } else {                                                             \
+            gm.flag = 1;                                                     \
+            if (lane == 0) A.gmeta[g] = gm;                                  \
+        }                                                                    \
+        continue;                                                            \
+    }
+    for (uint32_t wi = blockIdx.x; wi < nWork; wi += gridDim.x) {
+        const uint32_t g = fromList ? A.retry[1 + wi] : wi;
         __builtin_amdgcn_wave_barrier();
         const uint32_t qf = 2 * g, qr = 2 * g + 1;
         const uint32_t P0 = A.pbase[qf], P1 = A.pbase[qr + 1];
@@ -426,12 +463,12 @@ struct consensus_full_kernel {
             const u64 m = __ballot(has);
             if (has) {
                 const int at = nm + __popcll(m & lanesBelow);
-                if (at < CF_M) L.mpair[at] = p;
+                if (at < CF::M) L.mpair[at] = p;
             }
             nm += __popcll(m);
         }
         gm.n_matches = (uint32_t)nm;
-        if (nm > CF_M) tooMany = true;
+        if (nm > CF::M) tooMany = true;
         if (nm <= 1) {  // the reference only builds a consensus for queries with more than one hit (commands/overlap.go:170)
             if (lane == 0) A.gmeta[g] = gm;
             continue;
@@ -440,13 +477,10 @@ struct consensus_full_kernel {
         const int32_t* aSeg = A.qsegs + A.qoff[qf];
         const int nA = RFLc((int)(A.qoff[qf + 1] - A.qoff[qf]));
         const int sA = nA >> 1;
-        if (sA > CF_A || sA < 1) tooMany = true;
-        if (A.flag_every && (g % A.flag_every) == 0) tooMany = true;
-        if (tooMany) {
-            gm.flag = 1;
-            if (lane == 0) A.gmeta[g] = gm;
-            continue;
-        }
+        if (sA > CF::A || sA < 1) tooMany = true;
+        if (!SMALL && A.flag_every && (g % A.flag_every) == 0) tooMany = true;
+        if (SMALL && A.flag_every && (g % A.flag_every) == 0) tooMany = true;  // (test hook: goes the whole way to the host path)
+        if (tooMany) CF_NOFIT()
         {
             int run = 0;
             for (int base = 0; base < sA; base += 64) {
@@ -462,7 +496,7 @@ struct consensus_full_kernel {
         CF_TICK(1);
         // ---- 2. per match: filter + Trimmed().  One lane per match; everything a lane does is its own little loop.
         int nseq = 0, tUsed = 0;
-        bool bad = false;
+        bool bad = false, laneWide = false;
         for (int m0 = 0; m0 < nm; m0 += 64) {
             const int mi = m0 + lane;
             bool keep = false, laneBad = false;
@@ -543,7 +577,7 @@ struct consensus_full_kernel {
             const int incl = wave_incl_sum(keep ? nT : 0);
             const int total = __shfl(incl, 63, 64);
             const int nKeep = __popcll(keepMask);
-            if (nseq + nKeep > 64 || tUsed + total > CF_T) {
+            if (nseq + nKeep > 64 || tUsed + total > CF::T) {
                 bad = true;
                 break;
             }
@@ -552,15 +586,19 @@ struct consensus_full_kernel {
                 const int tb = tUsed + incl - nT;
                 const dp_seq_meta sm = A.smeta[t];
                 const int nB = 2 * ns + 1;
+                int wide = 0;  // (small layout: a value that does not fit 16 bits sends the window to the large one)
                 for (int j = 0; j < nT; j++) {
                     const int x = 2 * startSeed + j;  // index in X
                     int v;
                     if (!isRc) v = S[x];
                     else v = (x & 1) ? A.rc_of[S[nB - 1 - x]] : S[nB - 1 - x];
-                    L.T[tb + j] = v;
+                    L.T[tb + j] = (elem_t)v;
+                    wide |= (v != (int)(elem_t)v);
                 }
-                L.T[tb] = startOffset;
-                L.T[tb + nT - 1] = endOffset;
+                L.T[tb] = (elem_t)startOffset;
+                L.T[tb + nT - 1] = (elem_t)endOffset;
+                wide |= (startOffset != (int)(elem_t)startOffset) | (endOffset != (int)(elem_t)endOffset);
+                if (SMALL && wide) laneWide = true;
                 L.tb[sq] = tb;
                 L.tN[sq] = nT;
                 L.tLen[sq] = sm.length - offset - inset;
@@ -572,11 +610,7 @@ struct consensus_full_kernel {
             nseq += nKeep;
             tUsed += total;
         }
-        if (bad) {
-            gm.flag = 1;
-            if (lane == 0) A.gmeta[g] = gm;
-            continue;
-        }
+        if (bad || __ballot(laneWide)) CF_NOFIT()
         if (nseq <= 1) {  // BuildConsensus needs more than one sequence (combine.go:183)
             if (lane == 0) A.gmeta[g] = gm;
             continue;
@@ -585,14 +619,14 @@ struct consensus_full_kernel {
         CF_TICK(2);
         // ---- 3. seeds shared by >= 2 sequences (GetSharedIDs(.., 2, true)), Reduced() of every sequence (seeds/sequence.go:85):
         //         one lane per sequence
-        for (int i = lane; i < CF_HASH; i += 64) L.hash[i] = 0;
+        for (int i = lane; i < CF::HASH; i += 64) L.hash[i] = 0;
         __builtin_amdgcn_wave_barrier();
         const bool mine = lane < nseq;
         const int tb_ = mine ? L.tb[lane] : 0;
         const int nsT_ = mine ? (L.tN[lane] >> 1) : 0;
         for (int i = 0; i < nsT_; i++) {
             const uint32_t seed = (uint32_t)L.T[tb_ + 2 * i + 1];
-            uint32_t h = (seed * 2654435761u) >> 20;  // 12 bits
+            uint32_t h = (seed * 2654435761u) >> CF::HSHIFT;
             for (;;) {
                 const uint32_t e = L.hash[h];
                 if (e == 0) {
@@ -604,17 +638,17 @@ struct consensus_full_kernel {
                     if ((e & 63u) != (uint32_t)lane && !(e & 128u)) atomicOr(&L.hash[h], 128u);
                     break;
                 }
-                h = (h + 1) & (CF_HASH - 1);
+                h = (h + 1) & (CF::HASH - 1);
             }
         }
         __builtin_amdgcn_wave_barrier();
         auto cf_shared = [&](int seed) -> bool {
-            uint32_t h = ((uint32_t)seed * 2654435761u) >> 20;
+            uint32_t h = ((uint32_t)seed * 2654435761u) >> CF::HSHIFT;
             for (;;) {
                 const uint32_t e = L.hash[h];
                 if (e == 0) return false;
                 if ((e >> 8) == (uint32_t)seed + 1) return (e & 128u) != 0;
-                h = (h + 1) & (CF_HASH - 1);
+                h = (h + 1) & (CF::HASH - 1);
             }
         };
         int kept = 0;
@@ -632,11 +666,7 @@ struct consensus_full_kernel {
             const int slot = kept >= 1 ? 2 * kept + 2 : 0;  // (even: Rmap / cm arrays are indexed by rb >> 1)
             const int incl = wave_incl_sum(slot);
             const int totalR = __shfl(incl, 63, 64);
-            if (totalR + 2 >= CF_R) {
-                gm.flag = 1;
-                if (lane == 0) A.gmeta[g] = gm;
-                continue;
-            }
+            if (totalR + 2 >= CF::R) CF_NOFIT()
             if (mine) {
                 const int rb = incl - slot;
                 L.rb[lane] = rb;
@@ -646,8 +676,9 @@ struct consensus_full_kernel {
                     for (int i = 0; i < nsT_; i++) {
                         const int seed = L.T[tb_ + 2 * i + 1];
                         if (seed != prev && cf_shared(seed)) {
-                            L.R[rb + 2 * r] = offset;
-                            L.R[rb + 2 * r + 1] = seed;
+                            L.R[rb + 2 * r] = (elem_t)offset;
+                            laneWide |= SMALL && offset != (int)(elem_t)offset;
+                            L.R[rb + 2 * r + 1] = (elem_t)seed;
                             L.Rmap[(rb >> 1) + r] = (uint16_t)i;
                             r++;
                             offset = L.T[tb_ + 2 * i + 2];
@@ -656,17 +687,19 @@ struct consensus_full_kernel {
                             offset += L.T[tb_ + 2 * i + 2] + k;
                         }
                     }
-                    L.R[rb + 2 * r] = offset;
+                    L.R[rb + 2 * r] = (elem_t)offset;
+                    laneWide |= SMALL && offset != (int)(elem_t)offset;
                 }
             }
         }
+        if (__ballot(laneWide)) CF_NOFIT()
         __builtin_amdgcn_wave_barrier();
         CF_TICK(3);
         // ---- 4. the alignment (multiAligner.Consensus :52-247); lane i owns sequence i.  hash[] is dead from here on.
         const int b = mine ? L.rb[lane] : 0;
         const int sl = mine ? L.rN[lane] : 0;
         const int mbase = b >> 1;
-        const int32_t* S = L.R;
+        const elem_t* S = L.R;
         int pos = -1, offs = 0, gaps = 50, supported = 0, dist = 0, mlen = 0, clen = 0;
         const int kLim = 1 << 28;
         const int ns = nseq;
@@ -690,7 +723,7 @@ struct consensus_full_kernel {
                     const int o0 = CA_RL(od, f), sd0 = CA_RL(sdNext, f);
                     const bool same = !okS || (od == o0 && sdNext == sd0 && gaps == 0);
                     if (__ballot(same) == ~0ull && o0 > -k && o0 < 100000) {
-                        if (clen + 2 >= CF_CONS) {
+                        if (clen + 2 >= CF::CONS) {
                             bad = true;
                             break;
                         }
@@ -813,7 +846,7 @@ struct consensus_full_kernel {
                 }
                 continue;
             }
-            if (clen + 2 >= CF_CONS) {
+            if (clen + 2 >= CF::CONS) {
                 bad = true;
                 break;
             }
@@ -866,11 +899,7 @@ struct consensus_full_kernel {
             }
             if (__popcll(__ballot(finC && mine)) >= ns) break;
         }
-        if (__ballot(bad)) {
-            gm.flag = 1;
-            if (lane == 0) A.gmeta[g] = gm;
-            continue;
-        }
+        if (__ballot(bad)) CF_NOFIT()
         if (lane == 0) L.cons[clen] = 0;
         if (mine) L.mLen[lane] = mlen;
         __builtin_amdgcn_wave_barrier();
@@ -938,7 +967,7 @@ struct consensus_full_kernel {
         if (part) {
             const uint16_t* MA = L.cmA + mb0;
             const uint16_t* MB = L.cmB + mb0;
-            const int32_t* sb = L.T + L.tb[sq];
+            const elem_t* sb = L.T + L.tb[sq];
             const int nT = L.tN[sq], nsT = nT >> 1;
             int index, bases, bIndex, backBases;
             cf_base_index(MA, MB, pl, bestIndex, L.cons, sb, nT, k, index, bases);
@@ -1011,11 +1040,7 @@ struct consensus_full_kernel {
                 }
             }
         }
-        if (__ballot(partBad)) {
-            gm.flag = 1;
-            if (lane == 0) A.gmeta[g] = gm;
-            continue;
-        }
+        if (__ballot(partBad)) CF_NOFIT()
         // contig + PAF numbers (combine.go:113-133, commands/overlap.go:199-231)
         const int myId = part ? L.tId[sq] : 0;
         const int myRc = part ? L.tRc[sq] : 0;
@@ -1060,6 +1085,7 @@ struct consensus_full_kernel {
         if (lane == 0) A.gmeta[g] = gm;
         CF_TICK(5);
     }
+#undef CF_NOFIT
 }
 };
 
@@ -1113,8 +1139,19 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
         A.flag_every = flag_every;
     }
     A.rc_of = (const int32_t*)((const uint8_t*)ctx->d_cin.p + b_meta);
+    // small LDS layout first (int16: needs every seed id below 2^15), the large one for what it lists; DP_CONS_SMALL=0: large only
+    static const bool small_off = [] {
+        const char* e = getenv("DP_CONS_SMALL");
+        return e && e[0] == '0';
+    }();
+    const bool use_small = !small_off && n_seeds <= 32767;
+    A.retry = nullptr;
+    if (use_small) {
+        if (dev_reserve(ctx, ctx->d_cretry, ((size_t)ng + 2) * 4 + 16)) return DP_ERR_HIP;
+        A.retry = (uint32_t*)ctx->d_cretry.p;
+    }
     {
-        int rc = dp_match_anchors_launch(ctx, &cin_fetch);
+        int rc = dp_match_anchors_launch(ctx, &cin_fetch, A.retry);
         if (rc != 0) return rc;
     }
     A.anchors = (const int32_t*)ctx->d_manchor.p;
@@ -1138,7 +1175,8 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     A.nseq_src = ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : nullptr;
     A.nseq_dst = h_nseq;
     DP_HIP(dp_mark(ctx, 0));
-    dp_launch<consensus_full_kernel>(ctx, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), A);
+    if (use_small) dp_launch<consensus_full_kernel<true>>(ctx, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), A);
+    dp_launch<consensus_full_kernel<false>>(ctx, dim3(std::min<uint32_t>(ng, use_small ? 512u : 4096u)), dim3(64), A);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 1));
     DP_HIP(dp_stream_sync(ctx));

@@ -1645,8 +1645,10 @@ struct match_anchor_kernel {
                                                            uint32_t pair_cap, const int32_t* __restrict__ mb,
                                                            const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, int k,
                                                            int32_t* __restrict__ anchors, unsigned long long* __restrict__ fetch_dst,
-                                                           const unsigned long long* __restrict__ fetch_src, unsigned long long fetch_n8) {
+                                                           const unsigned long long* __restrict__ fetch_src, unsigned long long fetch_n8,
+                                                           uint32_t* __restrict__ zero_word) {
     const int lane = threadIdx.x & 63;
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;  // (the consensus stage's retry counter: next launch)
     // (the consensus kernel's input block - pinned host memory - is brought over by this launch, which runs just before it)
     for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < fetch_n8; j += (unsigned long long)gridDim.x * blockDim.x)
         fetch_dst[j] = __builtin_nontemporal_load(&fetch_src[j]);
@@ -2561,18 +2563,21 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
 }
 
 // Anchors of every final record of the chaining stage (device resident): d_manchor[2 * pair]
-int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch) {
+int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch, uint32_t* zero_word) {
     // (a pending chaining stage: the pair count is on the device only - the launch covers the stage's capacity)
     const uint32_t nslots = dp_find_pending(ctx) ? dp_find_pair_cap(ctx) : ctx->n_pairs;
     if (dev_reserve(ctx, ctx->d_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
-    if (!nslots) return fetch ? dp_zero_fetch_regions(ctx, nullptr, 0, fetch, 1) : DP_OK;
+    if (!nslots) {
+        const dp_zero_region z = {zero_word, 8};
+        return (fetch || zero_word) ? dp_zero_fetch_regions(ctx, &z, zero_word ? 1 : 0, fetch, fetch ? 1 : 0) : DP_OK;
+    }
     const u64* d_totals = (const u64*)((const uint8_t*)ctx->d_cursor.p + 64);
     dp_launch<match_anchor_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256),
                        (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
                        (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, ctx->last_k, (int32_t*)ctx->d_manchor.p,
                        fetch ? (unsigned long long*)fetch->dst : (unsigned long long*)nullptr,
                        fetch ? (const unsigned long long*)fetch->src : (const unsigned long long*)nullptr,
-                       fetch ? (unsigned long long)((fetch->bytes + 7) / 8) : 0ull);
+                       fetch ? (unsigned long long)((fetch->bytes + 7) / 8) : 0ull, zero_word);
     DP_HIP(hipGetLastError());
     return DP_OK;
 }
@@ -2601,7 +2606,7 @@ int dp_fetch_overlaps_impl(dp_ctx* ctx, int want_candidates, dp_match_batch* out
         dp_launch<match_anchor_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256),
                            (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
                            (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, k, (int32_t*)ctx->d_manchor.p,
-                           (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0ull);
+                           (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0ull, (uint32_t*)nullptr);
         DP_HIP(hipGetLastError());
         DP_HIP(hipMemcpyAsync(ctx->h_manchor.p, ctx->d_manchor.p, (size_t)nslots * 8, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_mrec.p, ctx->d_mrec.p, (size_t)nslots * sizeof(MRec), hipMemcpyDeviceToHost, ctx->stream));
