@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--seed-batch-size", type=int, default=10000)
     ap.add_argument("--max-rounds", type=int, default=-1, help="cut every job after this many rounds (experiments only)")
     ap.add_argument("--cpu-rounds", type=int, default=2, help="oracle rounds timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--slots", type=int, default=8, help="rounds executed concurrently per GPU (executor slots)")
+    ap.add_argument("--slots", type=int, default=5, help="rounds executed concurrently per GPU (executor slots)")
     ap.add_argument("--scan-leg-rounds", type=int, default=60,
                     help="N=1: after the timed region, this many rounds with the scan kernels instead of the k-mer index "
                          "(reported as scan_kernels_leg with the count pass's achieved GB/s; 0 = skip)")

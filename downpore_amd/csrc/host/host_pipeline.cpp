@@ -804,8 +804,11 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     {
         // gangs of consecutive slots: their rounds begin together and share every launch.  Not in scan-shard mode (a slot's
         // survivor exchange is a collective of its own on its own communicator).
+        // (DPH_GANG = members per gang; default 1 = every slot on its own stream: measured on config 2, five independent slots and
+        // two gangs of eight sustain the same 4 rounds per ms - the GPU is bound by the chaining kernels' wave-time, which a
+        // launch that carries more rounds does not shorten - DESIGN.md)
         const char* ge = getenv("DPH_GANG");
-        int want = ge ? atoi(ge) : 4;
+        int want = ge ? atoi(ge) : 1;
         want = std::max(1, std::min(want, 8));
         bool sharded = false;
         for (auto& sl : slots) sharded = sharded || sl->comm != nullptr;

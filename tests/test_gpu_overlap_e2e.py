@@ -636,3 +636,23 @@ def test_round_parallel_exchange_inside_the_library():
     p1.run()
     assert first_diff(p1.all_paf(), want.paf) is None
     p1.close()
+
+
+@pytest.mark.parametrize("gang,slots", [(2, 4), (4, 4), (4, 6), (8, 8)])
+def test_overlap_executor_slots_in_gangs(monkeypatch, gang, slots):
+    """Gangs (dp_gang_create): the slots of a gang begin their rounds together and every per-round kernel is launched once for
+    all of them (blockIdx.y = member).  Whole jobs with 2, 4 and 8 rounds per launch - one with a slot left outside the gangs, one
+    on reads that flag reads (rounds rejected and run again out of step) - must print the oracle's PAF."""
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    monkeypatch.setenv("DPH_GANG", str(gang))
+    for seed, G, N, L, variable, sbs in ((1, 250000, 1000, 5000, False, 10000), (33, 60000, 700, 1500, True, 1500)):
+        bases, off = O.gen_reads(seed, G, N, L, 0.0, variable)
+        rs = O.ReadSet(bases, off, min_len=1000)
+        want = O.OverlapRun(rs, k=10, seed_batch_size=sbs)
+        reads = Reads(bases, off, min_len=1000)
+        pipe = OverlapPipeline(reads, k=10, seed_batch_size=sbs, slots=slots)
+        pipe.run()
+        d = first_diff(pipe.all_paf(), want.paf)
+        assert d is None, (seed, d)
+        assert np.array_equal(reads.ignore(), rs.ignore())
+        pipe.close()
