@@ -457,7 +457,7 @@ struct query_kernel {
                                                              u64* __restrict__ cand, uint32_t* __restrict__ qmeta,
                                                              u64* __restrict__ words_read, uint32_t* __restrict__ qcnt,
                                                              uint32_t word_base, const uint32_t* __restrict__ n_seqs_dev,
-                                                             u64* __restrict__ qsets, uint32_t SW) {
+                                                             u64* __restrict__ qsets, uint32_t SW, uint32_t dbg_flags) {
     if (n_seqs_dev) n_seqs = *n_seqs_dev;  // (chunks made on the device: the host only knows an upper bound)
     // word_base: a shard of a larger index (dp_index_set_global) holds the words [word_base, word_base + W) of every set; pmeta
     // and n_seqs then describe the WHOLE sets (global windows, counts), so the filter, the early-return cut and the gather
@@ -627,6 +627,7 @@ struct query_kernel {
     const int minCount = (int)sh_u[4];
     const int64_t i_last = sh_ilast;
     if (n < 5 || status || n >= mc_n) return;  // cand row stays zero
+    if (dbg_flags & 1u) return;  // DP_QUERY_DEBUG=1 (timing experiments): the set-up alone, no posting word is read
     const bool ladder16 = minCount >= 13;
     const uint32_t n_ev = ladder16 ? S.n_ev : 0;
     const bool exact = minCount > 24;  // fast=false (util/bitset.go:309-311)
@@ -2208,6 +2209,14 @@ struct chain_resolve_kernel {
 }
 };
 
+static uint32_t query_dbg_flags() {
+    static const uint32_t f = [] {
+        const char* e = getenv("DP_QUERY_DEBUG");
+        return e ? (uint32_t)atoi(e) : 0u;
+    }();
+    return f;
+}
+
 // Uploads the queries, builds their seed bitsets and runs the index query (Matches -> GetSharedIDs) for all of them.
 // Leaves d_qsegs/d_qoff/d_qsets/d_cand/d_qmeta on the device.  Events ev[4]/ev[5] bracket the query kernel.
 int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
@@ -2257,7 +2266,8 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
-                       ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW);
+                       ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
+                       query_dbg_flags());
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 5));
 

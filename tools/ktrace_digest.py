@@ -6,7 +6,7 @@ tot = collections.defaultdict(int); seq = collections.defaultdict(list); ev = []
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"].replace("void dp_multi<", "<").split("(")[0][:60]
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    tot[n] += e - s; seq[n].append(e - s); ev.append((s, e, n.startswith("chain_walk_kernel")))
+    tot[n] += e - s; seq[n].append(e - s); ev.append((s, e, "chain_walk_kernel" in n))
 print("%-62s %8s %12s %10s %10s %10s" % ("kernel", "calls", "total_ms", "mean_us", "median_us", "max_us"))
 for n, v in sorted(tot.items(), key=lambda x: -x[1]):
     s = sorted(seq[n])

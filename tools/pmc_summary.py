@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel means of the round-2 PMC passes (tools/gpu_profile_r02.sh) -> profiles/r02/pmc_<workload>.json and the
+"""Per-kernel means of the round-2 PMC passes (tools/gpu_profile_%s.sh" % ROUND + ") -> profiles/r02/pmc_<workload>.json and the
 per-round traffic files bench.py quotes (profiles/chain_traffic.json, query_traffic.json, kindex_traffic.json,
 scan_traffic.json, dense_query_traffic.json).
 
@@ -10,8 +10,9 @@ Kernels with scattered narrow reads are uncalibrated: for them the corrected fig
 import collections, csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.path.join(ROOT, "gpurun_out", "r02")
-OUT = os.path.join(ROOT, "profiles", "r02")
+ROUND = os.environ.get("ROUND", "r03")
+R = os.path.join(ROOT, "gpurun_out", ROUND)
+OUT = os.path.join(ROOT, "profiles", ROUND)
 os.makedirs(OUT, exist_ok=True)
 SQ = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_ANY",
       "SQ_WAIT_INST_LDS"]
@@ -24,7 +25,11 @@ def short(name):
             n = n[len(pre):]
     if "rocprim" in n:
         n = "rocprim::" + n.split("::")[-1][:60]
-    return n.strip()
+    n = n.strip()
+    if n.startswith("dp_multi<"):  # per-round kernels are dp_multi<kernel, N> (N = rounds the launch can carry): the kernel's own name
+        n = n[len("dp_multi<"):]
+        n = n[:n.rfind(",")] if "," in n else n.rstrip(">")
+    return n
 
 
 def load(run):
@@ -58,7 +63,7 @@ def summarize(workload):
     return out
 
 
-NOTE = ("rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ set> --kernel-trace, one pass each (tools/gpu_profile_r02.sh); means per dispatch; "
+NOTE = ("rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ set> --kernel-trace, one pass each (tools/gpu_profile_%s.sh" % ROUND + "); means per dispatch; "
         "FETCH_SIZE/WRITE_SIZE in KiB; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 correction, MI355X_MICROARCH.md)")
 WORK = {"main": "bench.py --steps 1 --warmup 0 --max-rounds 40 (config 2, resident k-mer position index; set-up kernels at full size)",
         "scan": "DP_SCAN_INDEX=0 bench.py --steps 1 --warmup 0 --max-rounds 40 (config 2, scan kernels)",
@@ -70,7 +75,7 @@ for w in WORK:
         continue
     allw[w] = s
     json.dump({"workload": WORK[w], "note": NOTE, "kernels": s}, open(os.path.join(OUT, "pmc_%s.json" % w), "w"), indent=1, sort_keys=True)
-    print("profiles/r02/pmc_%s.json: %d kernels" % (w, len(s)))
+    print("profiles/%s/pmc_%s.json: %d kernels" % (ROUND, w, len(s)))
 
 
 def per_round(s, kernels, rounds_of):
@@ -103,8 +108,8 @@ def traffic(fn, workload, desc, kernels, rounds_of):
 CHAIN = ["pair_scan_kernel", "chain_walk_kernel", "chain_spec_kernel", "chain_resolve_kernel", "match_anchor_kernel"]
 traffic("chain_traffic.json", "main", "chaining stage (pair_scan + chain_walk + chain_spec + chain_resolve + match_anchor)", CHAIN, "pair_scan_kernel")
 traffic("query_traffic.json", "main", "query_kernel", ["query_kernel"], "query_kernel")
-traffic("kindex_traffic.json", "main", "index-mode counting step (kidx_link_extra + kidx_walk<false> + kidx_offsets)",
-        ["kidx_link_extra", "kidx_walk<false>", "kidx_offsets"], "kidx_offsets")
+traffic("kindex_traffic.json", "main", "index-mode counting step (kidx_prepare + kidx_walk<false> + kidx_offsets)",
+        ["kidx_prepare", "kidx_walk<false>", "kidx_offsets"], "kidx_offsets")
 traffic("scan_traffic.json", "scan", "scan_kernel<0, 2> (count pass)", ["scan_kernel<0, 2>"], "scan_kernel<0, 2>")
 traffic("dense_query_traffic.json", "dense", "query_kernel, k=10", ["query_kernel"], "query_kernel")
 if "main" in allw:
