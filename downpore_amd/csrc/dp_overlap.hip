@@ -444,6 +444,65 @@ struct QWave {
     uint32_t n_ev;
 };
 
+// One word of the soft union for the 4- / 8-ladder regimes: the ladder of util/asm_amd64.s:121-314 over this lane's word of
+// every live posting set, D levels deep.  Per posting word and level the reference does v_j |= v_{j-1} & m: one v_and_or_b32 per
+// 32-bit half here (the compiler emits an AND and an OR for the 64-bit form - 30 VALU instructions per posting word against 2 * D;
+// at 3.4 TB/s of posting words the kernel was as much VALU- as HBM-bound).
+__device__ __forceinline__ uint32_t q_and_or(uint32_t a, uint32_t b, uint32_t c) {  // (a & b) | c
+    uint32_t d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+template <int D>
+__device__ __forceinline__ u64 q_ladder(const QWave& S, const u64* __restrict__ posting, uint32_t W, uint32_t iw, uint32_t n, u64& gathered) {
+    uint32_t lo[D], hi[D];
+#pragma unroll
+    for (int x = 0; x < D; x++) lo[x] = hi[x] = 0;
+#define Q_STEP(m_)                                             \
+    {                                                          \
+        const uint32_t ml_ = (uint32_t)(m_), mh_ = (uint32_t)((m_) >> 32); \
+        _Pragma("unroll") for (int x = D - 1; x >= 1; x--) {   \
+            lo[x] = q_and_or(lo[x - 1], ml_, lo[x]);           \
+            hi[x] = q_and_or(hi[x - 1], mh_, hi[x]);           \
+        }                                                      \
+        lo[0] |= ml_;                                          \
+        hi[0] |= mh_;                                          \
+    }
+    // eight posting words in flight per lane: a set whose window ends before this word contributes 0, which leaves the ladder as
+    // it is (the order of the words does not matter for the 4- and 8-ladders)
+    uint32_t j = 0;
+    for (; j + 8 <= n; j += 8) {
+        u64 m[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool a = S.lens[j + u] > iw;
+            m[u] = a ? posting[(uint64_t)S.setid[j + u] * W + iw] : 0ull;
+            gathered += (u64)a;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) Q_STEP(m[u])
+    }
+    for (; j + 4 <= n; j += 4) {
+        u64 m[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool a = S.lens[j + u] > iw;
+            m[u] = a ? posting[(uint64_t)S.setid[j + u] * W + iw] : 0ull;
+            gathered += (u64)a;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) Q_STEP(m[u])
+    }
+    for (; j < n; j++) {
+        if (S.lens[j] <= iw) continue;
+        const u64 m = posting[(uint64_t)S.setid[j] * W + iw];
+        gathered++;
+        Q_STEP(m)
+    }
+#undef Q_STEP
+    return ((u64)hi[D - 1] << 32) | lo[D - 1];
+}
+
 // qmeta per query: {n_sets, minCount, status}; status bit0 = too many sets
 // One WORKGROUP per query: wave 0 prepares the set list (Matches' filter, the early-return cut, the 16-ladder's gather
 // order), then the Q_WAVES waves share the query's word range, 64 words per wave step, so that a dense index (W ~ 3 k words,
@@ -457,7 +516,7 @@ struct query_kernel {
                                                              u64* __restrict__ cand, uint32_t* __restrict__ qmeta,
                                                              u64* __restrict__ words_read, uint32_t* __restrict__ qcnt,
                                                              uint32_t word_base, const uint32_t* __restrict__ n_seqs_dev,
-                                                             u64* __restrict__ qsets, uint32_t SW, uint32_t dbg_flags) {
+                                                             u64* __restrict__ qsets, uint32_t SW, uint32_t dbg_flags, uint32_t split) {
     if (n_seqs_dev) n_seqs = *n_seqs_dev;  // (chunks made on the device: the host only knows an upper bound)
     // word_base: a shard of a larger index (dp_index_set_global) holds the words [word_base, word_base + W) of every set; pmeta
     // and n_seqs then describe the WHOLE sets (global windows, counts), so the filter, the early-return cut and the gather
@@ -468,7 +527,10 @@ struct query_kernel {
     __shared__ unsigned long long sh_gathered;
     const int lane = dp_lane();
     const int wave = threadIdx.x >> 6;
-    const uint32_t q = blockIdx.x;
+    // `split` workgroups per query can share its word range (64-word pieces dealt round robin; DP_QUERY_SPLIT).  Measured on the
+    // dense regime (W ~ 1.5 k words, 25 sets per query, 668 queries): 1 -> 62.8 us, 2 -> 63.3, 3 -> 64.6, 4 -> 66.0, 8 -> 106: the
+    // kernel is not held back by the 668 workgroups' fit on 256 CUs, so one workgroup per query stays the default
+    const uint32_t q = blockIdx.x / split, part = blockIdx.x % split;
     if (q >= nq) return;
     if (threadIdx.x == 0) {
         sh_gathered = 0;
@@ -478,7 +540,7 @@ struct query_kernel {
     const uint32_t ns = (uint32_t)((qoff[q + 1] - qoff[q]) / 2);
     // the query's own seed set (what the chaining stage's prefilter intersects with the targets' sets); its row was zeroed with
     // the other per-round buffers.  Waves 1.. do it while wave 0 prepares the set list.
-    if (qsets && (wave != 0 || Q_WAVES == 1))
+    if (qsets && part == 0 && (wave != 0 || Q_WAVES == 1))
         for (uint32_t i = threadIdx.x - (Q_WAVES == 1 ? 0 : 64); i < ns; i += 64 * (Q_WAVES == 1 ? 1 : Q_WAVES - 1)) {
             const uint32_t seed = (uint32_t)seg[2 * i + 1];
             atomicOr(&qsets[(uint64_t)q * SW + (seed >> 6)], 1ull << (seed & 63));
@@ -529,7 +591,7 @@ struct query_kernel {
     }
     int minCount = 0;
     if (n >= 5 && n < mc_n) minCount = mc[n];
-    if (lane == 0) {
+    if (lane == 0 && part == 0) {
         qmeta[4 * q + 0] = n;
         qmeta[4 * q + 1] = (uint32_t)minCount;
         qmeta[4 * q + 2] = status | (n >= mc_n ? 2u : 0u);
@@ -636,63 +698,24 @@ struct query_kernel {
     int nCand = 0;  // Matches() result size of this query (bits set in its cand row)
     const int64_t w_lo = max((int64_t)start, (int64_t)word_base), w_hi = min(i_last, (int64_t)word_base + (int64_t)W - 1);
     posting -= word_base;  // (indexed by the global word below)
-    for (int64_t ib = w_lo + 64 * wave; ib <= w_hi; ib += 64 * Q_WAVES) {
+    for (int64_t ib = w_lo + 64 * (int64_t)(wave * split + part); ib <= w_hi; ib += 64 * (int64_t)(Q_WAVES * split)) {
         const int64_t i = ib + lane;
         if (i > w_hi) continue;
         const uint32_t iw = (uint32_t)i;
         u64 v = 0;
         if (!ladder16) {
-            // 4- and 8-ladders (asm:121-314) are order independent: v_t = bits present in >= t of the live sets
-            u64 l1 = 0, l2 = 0, l3 = 0, l4 = 0, l5 = 0, l6 = 0, l7 = 0, l8 = 0;
-#define Q_STEP(m_)      \
-    l8 |= l7 & (m_);    \
-    l7 |= l6 & (m_);    \
-    l6 |= l5 & (m_);    \
-    l5 |= l4 & (m_);    \
-    l4 |= l3 & (m_);    \
-    l3 |= l2 & (m_);    \
-    l2 |= l1 & (m_);    \
-    l1 |= (m_);
-            // four posting words in flight per lane: a set whose window ends before this word contributes 0, which leaves the
-            // ladder as it is (the order of the words does not matter for the 4- and 8-ladders)
-            uint32_t j = 0;
-            for (; j + 8 <= n; j += 8) {  // eight posting words in flight per lane
-                u64 m[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const bool a = S.lens[j + u] > iw;
-                    m[u] = a ? posting[(uint64_t)S.setid[j + u] * W + iw] : 0ull;
-                    gathered += (u64)a;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) { Q_STEP(m[u]) }
-            }
-            for (; j + 4 <= n; j += 4) {
-                const bool a0 = S.lens[j] > iw, a1 = S.lens[j + 1] > iw, a2 = S.lens[j + 2] > iw, a3 = S.lens[j + 3] > iw;
-                const u64 m0 = a0 ? posting[(uint64_t)S.setid[j] * W + iw] : 0ull;
-                const u64 m1 = a1 ? posting[(uint64_t)S.setid[j + 1] * W + iw] : 0ull;
-                const u64 m2 = a2 ? posting[(uint64_t)S.setid[j + 2] * W + iw] : 0ull;
-                const u64 m3 = a3 ? posting[(uint64_t)S.setid[j + 3] * W + iw] : 0ull;
-                gathered += (u64)a0 + (u64)a1 + (u64)a2 + (u64)a3;
-                Q_STEP(m0) Q_STEP(m1) Q_STEP(m2) Q_STEP(m3)
-            }
-            for (; j < n; j++) {
-                if (S.lens[j] <= iw) continue;
-                const u64 m = posting[(uint64_t)S.setid[j] * W + iw];
-                gathered++;
-                Q_STEP(m)
-            }
-#undef Q_STEP
+            // 4- and 8-ladders (asm:121-314) are order independent: v_t = bits present in >= t of the live sets; only the levels up
+            // to the query's minCount are kept (level t depends on the levels below it alone)
             switch (minCount) {
                 case 0:
-                case 1: v = l1; break;
-                case 2: v = l2; break;
-                case 3: v = l3; break;
-                case 4: v = l4; break;
-                case 5: v = l5; break;
-                case 6: v = l6; break;
-                case 7: v = l7; break;
-                default: v = l8; break;  // 8, and 9..12 saturate at 8 (bitset.go:369-372)
+                case 1: v = q_ladder<1>(S, posting, W, iw, n, gathered); break;
+                case 2: v = q_ladder<2>(S, posting, W, iw, n, gathered); break;
+                case 3: v = q_ladder<3>(S, posting, W, iw, n, gathered); break;
+                case 4: v = q_ladder<4>(S, posting, W, iw, n, gathered); break;
+                case 5: v = q_ladder<5>(S, posting, W, iw, n, gathered); break;
+                case 6: v = q_ladder<6>(S, posting, W, iw, n, gathered); break;
+                case 7: v = q_ladder<7>(S, posting, W, iw, n, gathered); break;
+                default: v = q_ladder<8>(S, posting, W, iw, n, gathered); break;  // 8, and 9..12 saturate at 8 (bitset.go:369-372)
             }
         } else {
             // 16-ladder (asm:317-509) in the exact gather order
@@ -762,8 +785,9 @@ struct query_kernel {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        words_read[q] = sh_gathered;
-        qcnt[q] = sh_u[5];
+        // (both were zeroed with the other per-round buffers; the query's workgroups add their shares)
+        if (sh_gathered) atomicAdd((unsigned long long*)&words_read[q], sh_gathered);
+        if (sh_u[5]) atomicAdd(&qcnt[q], sh_u[5]);
     }
 }
 };
@@ -2261,13 +2285,19 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
         const dp_fetch_region f = {ctx->d_qsegs.p, up, up_off + up_segs + up_mc};
         if (int rc = dp_zero_fetch_regions(ctx, z, 4, &f, 1)) return rc;
     }
+    // workgroups per query (DP_QUERY_SPLIT, experiments: see query_kernel)
+    static const int split_env = [] {
+        const char* e = getenv("DP_QUERY_SPLIT");
+        return e ? atoi(e) : 0;
+    }();
+    const uint32_t q_split = split_env > 0 ? (uint32_t)std::min(split_env, 16) : 1u;
     DP_HIP(dp_mark(ctx, 4));
-    dp_launch<query_kernel>(ctx, dim3(nq), dim3(64 * Q_WAVES),
+    dp_launch<query_kernel>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
                        ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
-                       query_dbg_flags());
+                       query_dbg_flags(), q_split);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 5));
 

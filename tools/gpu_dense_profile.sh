@@ -7,7 +7,7 @@ mkdir -p gpurun_out/$OUT; cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 for S in ${SLOTS_LIST:-1 5}; do
   D=gpurun_out/$OUT/dense_s$S
   rm -rf $D
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --k 10 --steps 1 --warmup 0 --max-rounds ${ROUNDS:-12} --scan-leg-rounds 0 --dense-leg-rounds 0 --cpu-rounds 0 --slots $S > $D.json 2> $D.err; echo "dense slots=$S rc=$?"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 bench.py --k 10 --steps 1 --warmup 0 --max-rounds ${ROUNDS:-12} --scan-leg-rounds 0 --dense-leg-rounds 0 --map-leg-repeats 0 --cpu-rounds 0 --slots $S > $D.json 2> $D.err; echo "dense slots=$S rc=$?"
   f=$(find $D -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f gpurun_out/$OUT/dense_s${S}_kernel_stats.csv
   t=$(find $D -name "*kernel_trace.csv" | head -1)
