@@ -453,6 +453,9 @@ __device__ __forceinline__ uint32_t q_and_or(uint32_t a, uint32_t b, uint32_t c)
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+#ifndef Q_INFLIGHT
+#define Q_INFLIGHT 8  // posting words a lane has in flight (16 measured the same: 49.2 against 48.7 us)
+#endif
 template <int D>
 __device__ __forceinline__ u64 q_ladder(const QWave& S, const u64* __restrict__ posting, uint32_t W, uint32_t iw, uint32_t n, u64& gathered) {
     uint32_t lo[D], hi[D];
@@ -468,9 +471,20 @@ __device__ __forceinline__ u64 q_ladder(const QWave& S, const u64* __restrict__ 
         lo[0] |= ml_;                                          \
         hi[0] |= mh_;                                          \
     }
-    // eight posting words in flight per lane: a set whose window ends before this word contributes 0, which leaves the ladder as
+    // Q_INFLIGHT posting words in flight per lane: a set whose window ends before this word contributes 0, which leaves the ladder as
     // it is (the order of the words does not matter for the 4- and 8-ladders)
     uint32_t j = 0;
+    for (; j + Q_INFLIGHT <= n; j += Q_INFLIGHT) {
+        u64 m[Q_INFLIGHT];
+#pragma unroll
+        for (int u = 0; u < Q_INFLIGHT; u++) {
+            const bool a = S.lens[j + u] > iw;
+            m[u] = a ? posting[(uint64_t)S.setid[j + u] * W + iw] : 0ull;
+            gathered += (u64)a;
+        }
+#pragma unroll
+        for (int u = 0; u < Q_INFLIGHT; u++) Q_STEP(m[u])
+    }
     for (; j + 8 <= n; j += 8) {
         u64 m[8];
 #pragma unroll
@@ -507,6 +521,12 @@ __device__ __forceinline__ u64 q_ladder(const QWave& S, const u64* __restrict__ 
 // One WORKGROUP per query: wave 0 prepares the set list (Matches' filter, the early-return cut, the 16-ladder's gather
 // order), then the Q_WAVES waves share the query's word range, 64 words per wave step, so that a dense index (W ~ 3 k words,
 // k = 10) is streamed by thousands of waves instead of one per query.
+// Two variants: the light one handles the queries of the 4- / 8-ladder regimes (minCount <= 12: every query of the overlap command
+// at its defaults) and writes every query's qmeta / seed bitset; the heavy one only the 16-ladder and exact-count regimes
+// (minCount >= 13: queries of fifty seeds and more), whose 17-level ladder and bit-sliced counter need twice the registers.  The
+// light kernel alone then runs at eight waves per SIMD instead of four; the heavy one is launched only when a query of the batch
+// can reach minCount 13 at all.
+template <bool HEAVY>
 struct query_kernel {
     enum { THREADS = 64 * Q_WAVES };
     static __device__ void run(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
@@ -540,7 +560,7 @@ struct query_kernel {
     const uint32_t ns = (uint32_t)((qoff[q + 1] - qoff[q]) / 2);
     // the query's own seed set (what the chaining stage's prefilter intersects with the targets' sets); its row was zeroed with
     // the other per-round buffers.  Waves 1.. do it while wave 0 prepares the set list.
-    if (qsets && part == 0 && (wave != 0 || Q_WAVES == 1))
+    if (!HEAVY && qsets && part == 0 && (wave != 0 || Q_WAVES == 1))
         for (uint32_t i = threadIdx.x - (Q_WAVES == 1 ? 0 : 64); i < ns; i += 64 * (Q_WAVES == 1 ? 1 : Q_WAVES - 1)) {
             const uint32_t seed = (uint32_t)seg[2 * i + 1];
             atomicOr(&qsets[(uint64_t)q * SW + (seed >> 6)], 1ull << (seed & 63));
@@ -591,7 +611,7 @@ struct query_kernel {
     }
     int minCount = 0;
     if (n >= 5 && n < mc_n) minCount = mc[n];
-    if (lane == 0 && part == 0) {
+    if (!HEAVY && lane == 0 && part == 0) {
         qmeta[4 * q + 0] = n;
         qmeta[4 * q + 1] = (uint32_t)minCount;
         qmeta[4 * q + 2] = status | (n >= mc_n ? 2u : 0u);
@@ -636,7 +656,7 @@ struct query_kernel {
     // --- for the 16-ladder the order of the gathered words matters (8th word never reaches v1): simulate the
     //     swap-removals of util/bitset.go:333-353 and record the first eight sets after every event.
     const bool ladder16 = minCount >= 13;
-    if (ladder16) {
+    if (HEAVY && ladder16) {
         if (lane == 0) {
             uint32_t cn = n;
             for (uint32_t j = 0; j < n; j++) {
@@ -691,6 +711,7 @@ struct query_kernel {
     if (n < 5 || status || n >= mc_n) return;  // cand row stays zero
     if (dbg_flags & 1u) return;  // DP_QUERY_DEBUG=1 (timing experiments): the set-up alone, no posting word is read
     const bool ladder16 = minCount >= 13;
+    if (ladder16 != HEAVY) return;  // (the other variant's query)
     const uint32_t n_ev = ladder16 ? S.n_ev : 0;
     const bool exact = minCount > 24;  // fast=false (util/bitset.go:309-311)
 
@@ -703,7 +724,7 @@ struct query_kernel {
         if (i > w_hi) continue;
         const uint32_t iw = (uint32_t)i;
         u64 v = 0;
-        if (!ladder16) {
+        if constexpr (!HEAVY) {
             // 4- and 8-ladders (asm:121-314) are order independent: v_t = bits present in >= t of the live sets; only the levels up
             // to the query's minCount are kept (level t depends on the levels below it alone)
             switch (minCount) {
@@ -2292,7 +2313,14 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     }();
     const uint32_t q_split = split_env > 0 ? (uint32_t)std::min(split_env, 16) : 1u;
     DP_HIP(dp_mark(ctx, 4));
-    dp_launch<query_kernel>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
+    dp_launch<query_kernel<false>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
+                       ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
+                       (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
+                       (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
+                       ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
+                       query_dbg_flags(), q_split);
+    // the 16-ladder / exact-count regimes start at minCount 13: only a batch with a query of that many seeds needs the heavy variant
+    if (mc[maxSeeds] >= 13) dp_launch<query_kernel<true>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
