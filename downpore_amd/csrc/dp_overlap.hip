@@ -1783,6 +1783,8 @@ struct ChainArgs {
     uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [4..5] algorithmic bytes (u64)
     uint32_t* qdone;     // [nq] pairs of the query a speculative pass has finished (resolve fused into it), or nullptr
     uint32_t walk_blocks; // grid of chain_walk_kernel for this round (its node pool is sized for it)
+    uint32_t n_refs;      // entries of refs[] (indexed sequences, or their upper bound)
+    unsigned long long* prof;  // DP_CHAIN_PROF=1: [0] pairs looked at, [1] chained, [2..6] wall-clock ticks (100 MHz) per phase of chain_spec_kernel
 };
 
 // per-query candidate counts -> pair / scratch offsets (one workgroup; a round has a few hundred to a few ten thousand queries)
@@ -1861,16 +1863,33 @@ __device__ __forceinline__ int chain_prefilter(const u64* __restrict__ tset, con
     for (uint32_t w = dp_lane(); w < SW; w += 64) c += __popcll(tset[w] & qs[w]);
     return RFL(wave_sum(c));
 }
+// The same count - CountIntersectionTo(seedSet, matchSet), overlap.go:362: distinct seeds of the query that the target holds -
+// from the query's side: its seeds are staged (L.aSegL), a few dozen of them, so one probe of the target's set per seed (one
+// round of loads, 8 B each) replaces a pass over both sets' rows (157 words each at 10 k seeds: three rounds of two loads, the
+// largest single share of a pair's time in chain_spec_kernel: DP_CHAIN_PROF).  Lanes 0 .. nSeeds-1 (nSeeds <= 64) own one seed
+// each; a seed counts at its first occurrence in the query.  *inMask = membership of every seed (what chain_pair's aFlag holds).
+template <class LW>
+__device__ __forceinline__ int chain_prefilter_seeds(const LW& L, const u64* __restrict__ tset, int nSeeds, u64* inMask) {
+    const int i = dp_lane();
+    bool in = false, dup = false;
+    if (i < nSeeds) {
+        const int32_t seed = L.aSegL[2 * i + 1];
+        in = bs_contains(tset, seed);
+        for (int j = 0; j < i; j++) dup |= L.aSegL[2 * j + 1] == seed;
+    }
+    *inMask = __ballot(in);
+    return __popcll(__ballot(in && !dup));
+}
 
 // PairwiseAlignments(a, b = candidate t, minMatches) by the whole wave; the chain (results[0], the one matchWorker keeps,
 // overlap.go:368-375) goes to the pair's scratch column.  Returns its length (0: none); CSlim only: -1 = does not fit here.
 template <class LW>
 __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, const int32_t* __restrict__ aSeg, int aN, bool aStaged,
                           const u64* qs, const u64* __restrict__ qset, uint32_t t, int minMatches, int32_t* __restrict__ ca,
-                          int32_t* __restrict__ cb) {
+                          int32_t* __restrict__ cb, bool haveAMask = false, u64 aMask = 0, const dp_seq_ref* rPre = nullptr) {
     const int lane = dp_lane();
     const u64* tset = A.seedsets + (uint64_t)t * A.SW;
-    const dp_seq_ref r = A.refs[t];
+    const dp_seq_ref r = rPre ? *rPre : A.refs[t];
     const int32_t* bSeg = A.segs + r.seg_off;
     const int bN = RFL((int)(2 * r.n_seeds + 1));
     const bool staged = aStaged && bN <= C_BCAP;
@@ -1879,12 +1898,16 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
     if (LW::SLIM && (!staged || A.tier != 0)) return -1;  // (a forced tier is the full-size path's business)
     if (staged) {  // stage b and both membership bit vectors with the whole wave
         for (int i = lane; i < bN; i += 64) L.bSegL[i] = bSeg[i];
-        for (int base = 0; base < nSeeds; base += 64) {
-            const int s = base + lane;
-            bool f = false;
-            if (s < nSeeds) f = bs_contains(tset, L.aSegL[2 * s + 1]);
-            const u64 m = __ballot(f);
-            if (lane == 0) L.aFlag[base >> 6] = m;
+        if (haveAMask && nSeeds <= 64) {  // (the prefilter probed the target's set with these very seeds)
+            if (lane == 0) L.aFlag[0] = aMask;
+        } else {
+            for (int base = 0; base < nSeeds; base += 64) {
+                const int s = base + lane;
+                bool f = false;
+                if (s < nSeeds) f = bs_contains(tset, L.aSegL[2 * s + 1]);
+                const u64 m = __ballot(f);
+                if (lane == 0) L.aFlag[base >> 6] = m;
+            }
         }
         for (int base = 0; base < nBSeeds; base += 64) {
             const int s = base + lane;
@@ -2029,7 +2052,16 @@ struct chain_walk_kernel {
             const int spmm = RFL(sp.mm);
             int len;
             bool chained = false;
-            if (c < 0) c = chain_prefilter(A.seedsets + (uint64_t)t * A.SW, qs, A.SW);
+            bool haveMask = false;
+            u64 aMask = 0;
+            if (c < 0) {
+                if (aStaged && nSeeds <= 64) {
+                    c = chain_prefilter_seeds(L, A.seedsets + (uint64_t)t * A.SW, (int)nSeeds, &aMask);
+                    haveMask = true;
+                } else {
+                    c = chain_prefilter(A.seedsets + (uint64_t)t * A.SW, qs, A.SW);
+                }
+            }
             if (c < mm) {
                 len = 0;
             } else if (spmm == mm) {
@@ -2037,7 +2069,7 @@ struct chain_walk_kernel {
             } else if (mode == 1) {
                 break;  // needs chaining with a minMatches nobody proposed for: the next spec pass does it
             } else {
-                len = chain_pair(L, nodes, A, aSeg, aN, aStaged, qs, qset, t, mm, ca, cb);
+                len = chain_pair(L, nodes, A, aSeg, aN, aStaged, qs, qset, t, mm, ca, cb, haveMask, aMask);
                 chained = true;
             }
             algBytes += 16ull * A.SW;
@@ -2093,40 +2125,79 @@ struct chain_spec_kernel {
     // (a query that did not fit the buffers left its pairs' pq / clist unwritten: the host repeats the stage with larger ones)
     if (A.cursor[3] != 0 || A.cursor[8 + A.pass] == 0) return;  // ... or no query is open any more
     const uint32_t total = (uint32_t)min(totals[0], (u64)A.pair_cap);
+#define SP_TICK(i_)                                                                      \
+    if (A.prof) {                                                                        \
+        const unsigned long long now_ = wall_clock64();                                  \
+        if (lane == 0) atomicAdd(&A.prof[i_], now_ - tprev);                             \
+        tprev = now_;                                                                    \
+    }
+    const unsigned long long tkernel0 = A.prof ? wall_clock64() : 0ull;
     for (uint32_t p = gw; p < total; p += waves) {
+        unsigned long long tprev = A.prof ? wall_clock64() : 0ull;
+        const unsigned long long tpair0 = tprev;
+        // A pair is a chain of dependent loads (pair -> query -> its records -> its segments -> probes of the target's set ...) at
+        // 1-2 us per level under this kernel's own load: everything whose address is known is asked for at once, ahead of the
+        // tests that may drop the pair (a load behind a branch waits for the branch), the target's reference included.
         const uint32_t q = A.pq[p];
-        do {  // (a `continue` below leaves this block, not the loop: every pair reports to its query - see the end of the loop body)
-        const uint32_t i = p - A.pbase[q];
-        if (i >= A.qcnt[q]) continue;  // (beyond a capped query)
-        const QState st = A.qstate[q];
-        if (i < st.next) continue;  // final already
+        const uint32_t t = A.clist[p];
         PSpec sp = A.pspec[p];
+        const uint32_t pb_ = A.pbase[q], cnt_ = A.qcnt[q];
+        const QState st = A.qstate[q];
+        const u64 qo0 = A.qoff[q], qo1 = A.qoff[q + 1];
+        const u64 ib = A.ibase[q];
+        const dp_seq_ref rT = A.refs[min(t, A.n_refs - 1)];  // (t is only meaningful for a pair that passes the tests below)
+        do {  // (a `continue` below leaves this block, not the loop: every pair reports to its query - see the end of the loop body)
+        const uint32_t i = p - pb_;
+        if (i >= cnt_) continue;  // (beyond a capped query)
+        if (i < st.next) continue;  // final already
         const int mm = RFL(st.mm);
         if (RFL(sp.mm) == mm) continue;
-        const int aN = RFL((int)(A.qoff[q + 1] - A.qoff[q]));
+        const int aN = RFL((int)(qo1 - qo0));
         const uint32_t nSeeds = (uint32_t)aN / 2;
-        const u64 ib = A.ibase[q];
-        if (ib + (u64)A.qcnt[q] * nSeeds > A.sint_cap) continue;  // (flagged by the walk)
-        const uint32_t t = A.clist[p];
-        const int32_t* aSeg = A.qsegs + A.qoff[q];
+        if (ib + (u64)cnt_ * nSeeds > A.sint_cap) continue;  // (flagged by the walk)
+        const int32_t* aSeg = A.qsegs + qo0;
         const u64* qset = A.qsets + (uint64_t)q * A.SW;
         const bool aStaged = aN <= (int)CSlim::ACAP;
+        if (A.prof && lane == 0) atomicAdd(&A.prof[0], 1ull);
+        SP_TICK(2)  // the pair's own records (query state, proposal, candidate)
         const u64* qs = chain_stage_a(L, aSeg, aN, qset, A.SW, aStaged);
+        SP_TICK(3)  // query side staged
         int c = RFL(sp.c);
-        if (c < 0) c = chain_prefilter(A.seedsets + (uint64_t)t * A.SW, qs, A.SW);
+        bool haveMask = false;
+        u64 aMask = 0;
+        if (c < 0) {
+            if (aStaged && nSeeds <= 64) {
+                c = chain_prefilter_seeds(L, A.seedsets + (uint64_t)t * A.SW, (int)nSeeds, &aMask);
+                haveMask = true;
+            } else {
+                c = chain_prefilter(A.seedsets + (uint64_t)t * A.SW, qs, A.SW);
+            }
+        }
+        SP_TICK(4)  // prefilter
         int len = 0, pmm = mm;
         if (c >= mm) {
-            len = chain_pair(L, (CNode*)nullptr, A, aSeg, aN, aStaged, qs, qset, t, mm, A.sa + ib + (u64)i * nSeeds, A.sb + ib + (u64)i * nSeeds);
+            if (A.prof && lane == 0) atomicAdd(&A.prof[1], 1ull);
+            len = chain_pair(L, (CNode*)nullptr, A, aSeg, aN, aStaged, qs, qset, t, mm, A.sa + ib + (u64)i * nSeeds, A.sb + ib + (u64)i * nSeeds,
+                             haveMask, aMask, &rT);
             if (len < 0) {  // does not fit the slim layout: no proposal, the final walk chains it
                 len = 0;
                 pmm = -1;
             }
         }
+        SP_TICK(5)  // chain_pair
         if (lane == 0) {
             PSpec o = {c, pmm, len, 0};
             A.pspec[p] = o;
         }
         __builtin_amdgcn_wave_barrier();
+        SP_TICK(6)
+        if (A.prof && lane == 0) {
+            const unsigned long long dt = wall_clock64() - tpair0;
+            atomicMax(&A.prof[7], dt);
+            if (dt > 500) atomicAdd(&A.prof[8], 1ull);   // pairs that took more than 5 us
+            if (dt > 1500) atomicAdd(&A.prof[9], 1ull);  // ... more than 15 us
+            atomicMax(&A.prof[10], wall_clock64() - tkernel0);  // latest end of a pair since its wave started
+        }
         } while (0);
         if (A.qdone) {
             // the resolve step of the query, by whichever wave finishes the last of its pairs (instead of a launch of its own
@@ -2439,6 +2510,16 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     A.int_cap = st.int_cap;
     A.cursor = d_cur;
     A.walk_blocks = st.walk_blocks;
+    A.n_refs = std::max<uint32_t>(1, ctx->n_seqs);
+    A.prof = nullptr;
+    static const bool chain_prof = getenv("DP_CHAIN_PROF") != nullptr;
+    if (chain_prof) {
+        if (!ctx->d_sched.p || ctx->d_sched.cap < 128) {
+            if (dev_reserve(ctx, ctx->d_sched, 128)) return DP_ERR_HIP;
+        }
+        A.prof = (unsigned long long*)ctx->d_sched.p;
+        DP_HIP(hipMemsetAsync(A.prof, 0, 128, ctx->stream));
+    }
     A.qdone = fuse_resolve ? d_qdone : nullptr;
     if (st.attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 128, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
     DP_HIP(dp_mark(ctx, 6));
@@ -2493,6 +2574,14 @@ static int chain_check(dp_ctx* ctx, FindState& st, bool* grow) {
 // a checked attempt without overflow: the stage's errors, totals and statistics
 static int chain_finish(dp_ctx* ctx, FindState& st) {
     st.pending = false;
+    static const bool chain_prof = getenv("DP_CHAIN_PROF") != nullptr;
+    if (chain_prof && ctx->d_sched.p) {
+        unsigned long long h[16];
+        if (hipMemcpy(h, ctx->d_sched.p, 128, hipMemcpyDeviceToHost) == hipSuccess && h[0])
+            fprintf(stderr, "[chain prof] spec passes: %llu pairs looked at, %llu chained | us per pair: records %.2f stage a %.2f prefilter %.2f chain %.2f (per chained %.2f) store %.2f | slowest pair %.1f us, %llu pairs > 5 us, %llu > 15 us, last pair done %.1f us after its wave started\n",
+                    h[0], h[1], h[2] / 100.0 / h[0], h[3] / 100.0 / h[0], h[4] / 100.0 / h[0], h[5] / 100.0 / h[0], h[1] ? h[5] / 100.0 / h[1] : 0.0, h[6] / 100.0 / h[0],
+                    h[7] / 100.0, h[8], h[9], h[10] / 100.0);
+    }
     st.query_ms = dp_elapsed(ctx, 4, 5);
     st.chain_bytes = (uint64_t)st.cur[4] | ((uint64_t)st.cur[5] << 32);
     if (st.cur[2]) {
