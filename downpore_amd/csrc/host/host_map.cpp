@@ -519,6 +519,37 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     const int k = p.k;
     const i64 refLen = refSet.length(0);
     const char* ref = refSet.seq(0);
+    // ---- device read set: [0] reference, [1] circular join chunk, then (forward, reverse complement) of every read.  Its host
+    // staging copy is made by a thread of its own while the device computes the reference's k-mer table
+    std::vector<i64> off(1, 0);
+    std::string join;
+    if (p.circular) join = std::string(ref + (refLen - p.querySize), (size_t)p.querySize) + std::string(ref, (size_t)p.querySize);
+    // one staging buffer [reference | join chunk | all reads]; the reads are one contiguous block of the read set, copied
+    // (and its pages first touched) by the worker pool in 4 MiB pieces
+    const size_t head = (size_t)refLen + join.size();
+    const size_t readBytes = reads.size() ? (size_t)(reads.off[reads.size()] - reads.off[0]) : 0;
+    std::unique_ptr<char[]> staging(new char[head + readBytes + 1]);
+    std::thread concatThread([&] {
+        memcpy(staging.get(), ref, (size_t)refLen);
+        memcpy(staging.get() + refLen, join.data(), join.size());
+        off.push_back((i64)refLen);
+        off.push_back((i64)head);
+        const char* src = reads.size() ? reads.seq(0) : nullptr;
+        const size_t piece = (size_t)4 << 20, nPieces = (readBytes + piece - 1) / piece;
+        char* dst = staging.get() + head;
+        parallelFor(nPieces, [&](size_t i) {
+            const size_t b = i * piece, e = std::min(readBytes, b + piece);
+            memcpy(dst + b, src + b, e - b);
+        });
+        const i64 shift = (i64)head - (reads.size() ? reads.off[0] : 0);
+        for (size_t r = 0; r < reads.size(); r++) off.push_back(reads.off[r + 1] + shift);
+    });
+    struct ConcatJoin {
+        std::thread& t;
+        ~ConcatJoin() {
+            if (t.joinable()) t.join();
+        }
+    } concatJoin{concatThread};
     dp_ctx* ctx = nullptr;
     if (dp_ctx_create(device, &ctx) != 0) {
         error = dp_last_error(nullptr);
@@ -539,9 +570,10 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     mark("reference upload + value table");
     errText += "K-mer counting complete. Preparing to start indexing and querying...\n";
 
-    // ---- AddSingleSeeds seeds/seeds.go:160-200 on the (top-level) reference, host, sequential
+    // ---- AddSingleSeeds seeds/seeds.go:160-200 on the (top-level) reference, host, sequential - on a thread of its own while
+    // this one concatenates the reads and the device uploads and packs them (neither needs the seeds)
     SeedIndex index(k);
-    {
+    std::thread seedThread([&] {
         const uint32_t mask = (uint32_t)(((uint64_t)1 << (2 * k)) - 1);
         const int finalLen = (int)(refLen % 4);  // top-level sequence: 0 when len%4 == 0 (sequence.go:70,88)
         const i64 skipBack = 4 - finalLen;
@@ -588,41 +620,23 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
                 index.addSeedKmer(best);
             }
         }
-    }
-    mark("AddSingleSeeds");
-    // ---- device read set: [0] reference, [1] circular join chunk, then (forward, reverse complement) of every read
-    std::string bases;
-    std::vector<i64> off(1, 0);
-    std::string join;
-    if (p.circular) join = std::string(ref + (refLen - p.querySize), (size_t)p.querySize) + std::string(ref, (size_t)p.querySize);
-    // one staging buffer [reference | join chunk | all reads]; the reads are one contiguous block of the read set, copied
-    // (and its pages first touched) by the worker pool in 4 MiB pieces
-    const size_t head = (size_t)refLen + join.size();
-    const size_t readBytes = reads.size() ? (size_t)(reads.off[reads.size()] - reads.off[0]) : 0;
-    std::unique_ptr<char[]> staging(new char[head + readBytes + 1]);
-    memcpy(staging.get(), ref, (size_t)refLen);
-    memcpy(staging.get() + refLen, join.data(), join.size());
-    off.push_back((i64)refLen);
-    off.push_back((i64)head);
-    {
-        const char* src = reads.size() ? reads.seq(0) : nullptr;
-        const size_t piece = (size_t)4 << 20, nPieces = (readBytes + piece - 1) / piece;
-        char* dst = staging.get() + head;
-        parallelFor(nPieces, [&](size_t i) {
-            const size_t b = i * piece, e = std::min(readBytes, b + piece);
-            memcpy(dst + b, src + b, e - b);
-        });
-        const i64 shift = (i64)head - (reads.size() ? reads.off[0] : 0);
-        for (size_t r = 0; r < reads.size(); r++) off.push_back(reads.off[r + 1] + shift);
-    }
-    (void)bases;
+    });
+    struct SeedJoin {  // (every way out of this function waits for the thread)
+        std::thread& t;
+        ~SeedJoin() {
+            if (t.joinable()) t.join();
+        }
+    } seedJoin{seedThread};
     // device ids: 0 reference, 1 join chunk, then (forward, reverse complement) per read; the reverse strands are made
     // on the device
-    mark("concatenate reads");
+    concatThread.join();
+    mark("concatenate reads (waited for)");
     rc = dp_reads_upload_rc(ctx, (const uint8_t*)staging.get(), off.data(), (uint32_t)(off.size() - 1), 2);
     if (rc) return fail(rc);
     mark("upload + pack (both strands)");
     staging.reset();
+    seedThread.join();
+    mark("AddSingleSeeds (waited for)");
     rc = dp_round_begin(ctx, k, index.seedMap.data(), (uint32_t)index.seedMap.size());
     if (rc) return fail(rc);
 
@@ -777,29 +791,51 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     if (stats) stats->n_chunks = items.size(), stats->n_seeds = index.seedMap.size();
 
     mark("round begin + chunk scan + index");
-    // ---- Map every read: coroutines + batched windows
+    // ---- Map every read: coroutines + batched windows.  The reads are dealt to a few host threads in contiguous ranges: every
+    // thread runs this loop on a context of its own (the packed reads are shared, the reference index - half a megabyte of
+    // chunk segments at E. coli scale - is built once per context), so one thread's mapper control flow (mapEnds / mapNext /
+    // findSplitPoint of 4 096 reads in flight) runs while another thread's windows are on the GPU.  Output is per read, in read
+    // order, whatever the thread.  (mapping.go:613-619 MapWorker: the reference does the same with goroutines.)
     auto wallNow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tLoop0 = wallNow();
     if (stats) stats->t_setup_s = tLoop0 - tRun0;
-    double tScan = 0, tChain = 0;
-    Sched sched;
-    M.sched = &sched;
-    const size_t inflight = 4096, stackBytes = 256 * 1024;
     std::vector<std::string> out(reads.size());
     std::vector<int> nmaps(reads.size(), 0);
+    i64 unmapped = 0, mapped = 0, multiple = 0, total = 0;
+    size_t nThreadsPlanned = 1;
+    struct LoopStats {
+        MapStats st;
+        double tScan = 0, tChain = 0, wall = 0;
+        int rc = 0;
+        std::string error;
+    };
+    auto mapLoop = [&](dp_ctx* tctx, MapperImpl& Mt, size_t readLo, size_t readHi, LoopStats& ls) {
+    const double tl0 = wallNow();
+    double tScan = 0, tChain = 0;
+    int rc = 0;
+    MapStats* stats = &ls.st;
+    auto fail = [&](int rc2) {
+        ls.error = dp_last_error(tctx);
+        ls.rc = rc2;
+        return rc2;
+    };
+    dp_ctx* ctx = tctx;
+    MapperImpl& M = Mt;
+    Sched sched;
+    M.sched = &sched;
+    const size_t inflight = std::max<size_t>(1024, 4096 / nThreadsPlanned), stackBytes = 256 * 1024;
     std::vector<std::unique_ptr<Task>> live;
     // coroutine stacks: allocated once (never zero-filled) and recycled — 50 k reads x 256 KiB of fresh zeroed vectors
     // used to be most of the run time
     std::vector<std::unique_ptr<char[]>> stackStore;
     std::vector<char*> freeStacks;
-    size_t nextRead = 0;
-    i64 unmapped = 0, mapped = 0, multiple = 0, total = 0;
+    size_t nextRead = readLo;
     std::vector<dp_scan_item> witems;
     std::vector<int32_t> wsegs;
     std::vector<uint64_t> woff;
     std::vector<uint32_t> wlen;
-    while (nextRead < reads.size() || !live.empty()) {
-        while (live.size() < inflight && nextRead < reads.size()) {
+    while (nextRead < readHi || !live.empty()) {
+        while (live.size() < inflight && nextRead < readHi) {
             std::unique_ptr<Task> t(new Task());
             t->m = &M;
             t->read = (uint32_t)nextRead;
@@ -934,8 +970,8 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
                     dp_chain_batch cb;
                     rc = dp_map_windows_shard(sh.ctx, wsegs.data(), woff.data(), wlen.data(), (uint32_t)witems.size(), k, phase, thr.data(), &cb);
                     if (rc) {
-                        error = dp_last_error(sh.ctx);
-                        dp_ctx_destroy(ctx);
+                        ls.error = dp_last_error(sh.ctx);
+                        ls.rc = rc;
                         return rc;
                     }
                     takeChains(cb, sh.c0);
@@ -946,7 +982,65 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         // ---- ... distribute and resume
         for (auto& tp : live) swapcontext(&sched.main, &tp->uc);
     }
+    ls.tScan = tScan;
+    ls.tChain = tChain;
+    ls.wall = wallNow() - tl0;
+    return 0;
+    };  // mapLoop
+
+    size_t nThreads = 1;
+    if (shards.empty()) {
+        const char* e = getenv("DP_MAP_THREADS");
+        nThreads = (size_t)std::max(1, e ? atoi(e) : 2);
+        nThreads = std::min(nThreads, std::max<size_t>(1, reads.size() / 2048));
+    }
+    nThreadsPlanned = nThreads;
+    std::vector<LoopStats> lstats(nThreads);
+    std::vector<dp_ctx*> tctx(nThreads, nullptr);
+    std::vector<MapperImpl> Ms(nThreads, M);  // (chunks[i].seg keep pointing into M.chunkSegs, which outlives the threads)
+    tctx[0] = ctx;
+    {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nThreads; t++) {
+            const size_t lo = reads.size() * t / nThreads, hi = reads.size() * (t + 1) / nThreads;
+            th.emplace_back([&, t, lo, hi] {
+                LoopStats& ls = lstats[t];
+                if (t > 0) {  // a context of its own: shared packed reads, the same seeds, the reference index from the chunk scan above
+                    int rc2 = dp_ctx_create_shared(ctx, &tctx[t]);
+                    if (rc2 == 0) rc2 = dp_round_begin(tctx[t], k, index.seedMap.data(), (uint32_t)index.seedMap.size());
+                    if (rc2 == 0) rc2 = dp_scan_import_segments(tctx[t], M.chunkSegs.data(), M.chunkSegs.size());
+                    if (rc2 == 0) rc2 = dp_index_build(tctx[t], refs.data(), (uint32_t)refs.size());
+                    if (rc2 != 0) {
+                        ls.rc = rc2;
+                        ls.error = tctx[t] ? dp_last_error(tctx[t]) : dp_last_error(nullptr);
+                        return;
+                    }
+                }
+                Ms[t].ctx = tctx[t];
+                mapLoop(tctx[t], Ms[t], lo, hi, ls);
+            });
+        }
+        for (auto& t : th) t.join();
+    }
+    for (size_t t = 1; t < nThreads; t++)
+        if (tctx[t]) dp_ctx_destroy(tctx[t]);
+    for (size_t t = 0; t < nThreads; t++)
+        if (lstats[t].rc != 0) {
+            error = lstats[t].error;
+            dp_ctx_destroy(ctx);
+            return lstats[t].rc;
+        }
     if (stats) {
+        double tScan = 0, tChain = 0;
+        for (const LoopStats& ls : lstats) {
+            stats->k_scan_ms += ls.st.k_scan_ms;
+            stats->k_map_ms += ls.st.k_map_ms;
+            stats->n_windows += ls.st.n_windows;
+            stats->n_chains += ls.st.n_chains;
+            stats->n_batches += ls.st.n_batches;
+            tScan += ls.tScan / (double)nThreads;   // (means over the threads, which run side by side)
+            tChain += ls.tChain / (double)nThreads;
+        }
         stats->t_scan_s = tScan;
         stats->t_chain_s = tChain;
         stats->t_host_s = (wallNow() - tLoop0) - tScan - tChain;
