@@ -1,0 +1,53 @@
+"""An independent look at the PAF: the synthetic generator knows where every read came from (genome position, strand), so an
+overlap line can be held to the genome itself instead of to another implementation of the reference.  For error-free reads every
+line must join two reads that really overlap, on the right relative strand, and - except where the reference's own trimming
+arithmetic drifts - both parts must cover the same stretch of the genome to within a few bases.  The CPU test
+looks at the oracle's PAF, the GPU test at the product's."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from tools.synth import gen_reads_truth
+
+
+def _check(paf, off, starts, strands, min_exact):
+    L = np.diff(off)
+    lines = [ln.split("\t") for ln in paf.split("\n") if ln]
+    assert len(lines) > 1000
+
+    def gpos(r, x):
+        return starts[r] + x if strands[r] == 0 else starts[r] + L[r] - x
+    strand_bad = apart = exact = reads_apart = 0
+    for f in lines:
+        q, t = int(f[0][1:]), int(f[5][1:])
+        a = sorted((gpos(q, int(f[2])), gpos(q, int(f[3]))))
+        b = sorted((gpos(t, int(f[7])), gpos(t, int(f[8]))))
+        strand_bad += (strands[q] != strands[t]) != (f[4] == "-")
+        apart += min(a[1], b[1]) <= max(a[0], b[0])  # the two parts share no base of the genome
+        exact += abs(a[0] - b[0]) <= 30 and abs(a[1] - b[1]) <= 30
+        # (a line joins the contig's first part with another part: both overlap the query window's consensus, and nearly always
+        # each other)
+        reads_apart += not (starts[q] < starts[t] + L[t] and starts[t] < starts[q] + L[q])
+    print("lines %d: strand mismatches %d, reads that do not overlap on the genome %d, parts without a shared base %d, both ends within "
+          "30 bases %d" % (len(lines), strand_bad, reads_apart, apart, exact))
+    assert strand_bad == 0
+    assert reads_apart <= len(lines) // 100, (reads_apart, len(lines))
+    assert apart <= len(lines) // 200, (apart, len(lines))
+    assert exact >= min_exact * len(lines), (exact, len(lines))
+
+
+def test_oracle_paf_describes_true_overlaps():
+    bases, off, starts, strands = gen_reads_truth(1, 250000, 1000, 5000, 0.0, False)  # BASELINE config 1 at the command's default k
+    run = O.OverlapRun(O.ReadSet(bases, off, min_len=1000), k=10)
+    _check(run.paf, off, starts, strands, 0.9)
+
+
+@pytest.mark.gpu
+def test_product_paf_describes_true_overlaps():
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off, starts, strands = gen_reads_truth(7, 400000, 1500, 6000, 0.0, True)
+    pipe = OverlapPipeline(Reads(bases, off, min_len=1000), k=10, slots=4)
+    pipe.run()
+    paf = pipe.all_paf()
+    pipe.close()
+    _check(paf, off, starts, strands, 0.9)

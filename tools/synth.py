@@ -40,3 +40,18 @@ def gen_genome(seed, G):
     buf = C.create_string_buffer(G)
     _load().dps_genome(seed, G, buf)
     return buf.raw
+
+
+def gen_reads_truth(seed, G, N, L, e=0.0, variable=False):
+    """gen_reads plus where every read came from: (bases, off, starts int64[N] = genome position of the read's template, strands
+    uint8[N] = 1 when the read is the reverse complement of the genome).  The reads are the same as gen_reads'."""
+    cap = int(N * (L * (2 if (variable or e > 0) else 1) + 16))
+    bases = np.zeros(cap, dtype=np.uint8)
+    off = np.zeros(N + 1, dtype=np.int64)
+    starts = np.zeros(N, dtype=np.int64)
+    strands = np.zeros(N, dtype=np.uint8)
+    n = _load().dps_reads(seed, G, N, L, float(e), 1 if variable else 0, bases.ctypes.data, cap, off.ctypes.data, starts.ctypes.data,
+                          strands.ctypes.data)
+    if n < 0:
+        raise RuntimeError("synthetic read buffer too small")
+    return bases[:n], off, starts, strands
