@@ -74,6 +74,72 @@ __device__ int m_reduce(const int32_t* __restrict__ seg, int n, const u64* __res
     return count;
 }
 
+// The same on the whole wave: lane i takes seed base + i of every 64-seed piece; its whitelist probe is one of 64 in flight (on one
+// lane the probes of a 250-seed chunk were 2 x 250 dependent global loads - half a millisecond per candidate).  A seed is kept when
+// it is whitelisted and differs from the last KEPT seed; a whitelisted seed is dropped only when it equals the last kept one, which
+// then stays what it was - so "differs from the previous whitelisted seed" decides, and all lanes decide at once.  The gap written
+// before kept seed a (previous kept seed p, or -1) is sum_{t=p+1..a} gap_t + k (a - p - 1): prefix sums of the gaps.
+template <typename IDX>
+__device__ int m_reduce_wave(const int32_t* __restrict__ seg, int n, const u64* __restrict__ whitelist, int k, int minSeeds, int32_t* out,
+                             IDX* index, int cap, uint32_t* err) {
+    const int lane = dp_lane();
+    const u64 below = (1ull << lane) - 1ull;
+    const int nS = n >> 1;
+    int kept = 0, carrySeed = -1, prevKept = -1;  // seeds kept so far, last whitelisted seed, index of the last kept seed
+    long long gRun = 0, gPrevKept = 0;            // sum of gap_0 .. gap_{base-1}, prefix sum at the last kept seed
+    bool over = false;
+    for (int base = 0; base < nS; base += 64) {
+        const int sI = base + lane;
+        const bool valid = sI < nS;
+        const int seed = valid ? seg[2 * sI + 1] : -1;
+        const int gap = valid ? seg[2 * sI] : 0;
+        const bool c = valid && m_contains(whitelist, seed);
+        const u64 cmask = __ballot(c);
+        const u64 cb = cmask & below;
+        const int srcC = cb ? 63 - __builtin_clzll(cb) : 0;
+        const int fromC = __shfl(seed, srcC, 64);
+        const int prevC = cb ? fromC : carrySeed;
+        const bool keep = c && seed != prevC;
+        const u64 kmask = __ballot(keep);
+        const long long G = gRun + (long long)wave_incl_sum(gap);  // inclusive prefix sum of the gaps up to this seed
+        // the previous kept seed: in this piece (a lane below), or carried over
+        const u64 kb = kmask & below;
+        const int srcK = kb ? 63 - __builtin_clzll(kb) : 0;
+        const long long gFrom = __shfl((long long)G, srcK, 64);
+        const int pIdx = kb ? base + srcK : prevKept;
+        const long long gP = kb ? gFrom : gPrevKept;
+        if (keep) {
+            const int j = kept + __popcll(kb);
+            if (j < cap) {
+                out[2 * j] = (int32_t)(G - gP + (long long)k * (sI - pIdx - 1));
+                out[2 * j + 1] = seed;
+                index[j] = (IDX)sI;
+            } else {
+                over = true;
+            }
+        }
+        kept += __popcll(kmask);
+        if (cmask) carrySeed = __shfl(seed, 63 - __builtin_clzll(cmask), 64);
+        if (kmask) {
+            const int lk = 63 - __builtin_clzll(kmask);
+            prevKept = base + lk;
+            gPrevKept = __shfl((long long)G, lk, 64);
+        }
+        gRun = __shfl((long long)G, 63, 64);
+    }
+    if (kept < minSeeds) return -1;
+    if (__ballot(over) || kept > cap) {
+        *err |= 1;
+        return -1;
+    }
+    if (lane == 0) {  // final gap: everything after the last kept seed
+        const long long gEnd = gRun + (long long)seg[2 * nS];
+        out[2 * kept] = (int32_t)(gEnd - gPrevKept + (long long)k * (nS - 1 - prevKept));
+    }
+    __builtin_amdgcn_wave_barrier();
+    return kept;
+}
+
 struct MChainPool {
     uint16_t* a;  // [M_CHAINS][M_QMAX]
     uint16_t* b;
@@ -283,11 +349,11 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                     const int tN = (int)(2 * r.n_seeds + 1);
                     int thrS = thr[s], thrOther = thr[1 - s];
                     uint32_t err = 0;
+                    // Match (:361-394): s = seq.Reduced(querySet), q = query.Reduced(seqSet) - on all 64 lanes
+                    const int minMatch = thr[s];
+                    const int nT = m_reduce_wave<uint16_t>(tSeg, tN, qset, k, minMatch, L.t, L.tIdx, M_TMAX, &err);
+                    const int nQ = nT < 0 ? -1 : m_reduce_wave<uint16_t>(qSeg, qN, tset, k, minMatch, L.q, L.qIdx, M_QMAX, &err);
                     if (lane == 0) {
-                        // Match (:361-394): s = seq.Reduced(querySet), q = query.Reduced(seqSet)
-                        const int minMatch = thr[s];
-                        const int nT = m_reduce<uint16_t>(tSeg, tN, qset, k, minMatch, L.t, L.tIdx, M_TMAX, &err);
-                        const int nQ = nT < 0 ? -1 : m_reduce<uint16_t>(qSeg, qN, tset, k, minMatch, L.q, L.qIdx, M_QMAX, &err);
                         if (nT >= 0 && nQ >= 0) {
                             const int nGood = m_dynamic_match(L, 2 * nQ + 1, 2 * nT + 1, minMatch, k, P, chainLen, &err);
                             for (int g = 0; g < nGood; g++) {
