@@ -834,7 +834,14 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     std::vector<int32_t> wsegs;
     std::vector<uint64_t> woff;
     std::vector<uint32_t> wlen;
+    double tp[6] = {0, 0, 0, 0, 0, 0};
     while (nextRead < readHi || !live.empty()) {
+        double tq = wallNow();
+        auto lap = [&](int i) {
+            const double t = wallNow();
+            tp[i] += t - tq;
+            tq = t;
+        };
         while (live.size() < inflight && nextRead < readHi) {
             std::unique_ptr<Task> t(new Task());
             t->m = &M;
@@ -870,6 +877,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
                 i++;
             }
         }
+        lap(0);  // new tasks up to their first window + finished ones retired
         if (live.empty()) continue;
         // ---- batch: scan the requested windows (forward, reverse complement) ...
         witems.clear();
@@ -901,6 +909,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         }
         // the chunk segments live in the device scan buffer; window scans must not clobber them -> the window scan uses a
         // second context-independent path: scan, then re-import the chunk segments before the map stage
+        lap(1);  // window items
         dp_seedseq_batch wb;
         const double ts0 = wallNow();
         rc = dp_scan(ctx, witems.data(), (uint32_t)witems.size(), &wb);
@@ -942,6 +951,8 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         }
         for (size_t w = 0; w < witems.size(); w++)
             live[w / 2]->res.seg[w & 1].assign(wsegs.begin() + (i64)woff[w], wsegs.begin() + (i64)woff[w + 1]);
+        tq = ts0 + (wallNow() - ts0);  // (the scan call itself is tScan)
+        tp[3] += wallNow() - ts0;      // scan call + copying its segments out
         auto takeChains = [&](const dp_chain_batch& cb, uint32_t chunkBase) {
             for (uint32_t c = 0; c < cb.n_chains; c++) {
                 const uint32_t w = cb.window[c];
@@ -953,6 +964,8 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             }
             if (stats) stats->k_map_ms += cb.kernel_ms, stats->n_chains += cb.n_chains;
         };
+        tq = wallNow();
+        lap(2);
         const double tc0 = wallNow();
         if (shards.empty()) {
             rc = dp_scan_import_segments(ctx, M.chunkSegs.data(), M.chunkSegs.size());
@@ -979,9 +992,14 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         }
         tChain += wallNow() - tc0;
         if (stats) stats->n_batches++;
+        tq = wallNow();
         // ---- ... distribute and resume
-        for (auto& tp : live) swapcontext(&sched.main, &tp->uc);
+        for (auto& tk : live) swapcontext(&sched.main, &tk->uc);
+        lap(4);  // coroutines resumed: performMapping's tail + the mapper's control flow up to the next window
     }
+    if (prof)
+        fprintf(stderr, "[map loop] reads %zu..%zu: start/retire %.1f ms, items %.1f, scan+copy %.1f (scan call %.1f), map call %.1f, resume %.1f\n", readLo, readHi,
+                1e3 * tp[0], 1e3 * tp[1], 1e3 * tp[3], 1e3 * tScan, 1e3 * tChain, 1e3 * tp[4]);
     ls.tScan = tScan;
     ls.tChain = tChain;
     ls.wall = wallNow() - tl0;
