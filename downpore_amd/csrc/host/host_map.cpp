@@ -1009,7 +1009,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     size_t nThreads = 1;
     if (shards.empty()) {
         const char* e = getenv("DP_MAP_THREADS");
-        nThreads = (size_t)std::max(1, e ? atoi(e) : 2);
+        nThreads = (size_t)std::max(1, e ? atoi(e) : 3);
         nThreads = std::min(nThreads, std::max<size_t>(1, reads.size() / 2048));
     }
     nThreadsPlanned = nThreads;
