@@ -1140,10 +1140,8 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     }
     A.rc_of = (const int32_t*)((const uint8_t*)ctx->d_cin.p + b_meta);
     // small LDS layout first (int16: needs every seed id below 2^15), the large one for what it lists; DP_CONS_SMALL=0: large only
-    static const bool small_off = [] {
-        const char* e = getenv("DP_CONS_SMALL");
-        return e && e[0] == '0';
-    }();
+    const char* small_env = getenv("DP_CONS_SMALL");  // (read per call: tests switch it between jobs of one process)
+    const bool small_off = small_env && small_env[0] == '0';
     const bool use_small = !small_off && n_seeds <= 32767;
     A.retry = nullptr;
     if (use_small) {

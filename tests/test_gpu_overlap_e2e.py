@@ -656,3 +656,23 @@ def test_overlap_executor_slots_in_gangs(monkeypatch, gang, slots):
         assert d is None, (seed, d)
         assert np.array_equal(reads.ignore(), rs.ignore())
         pipe.close()
+
+
+@pytest.mark.parametrize("k,G,N,L,variable", [(10, 250000, 1000, 5000, False), (13, 3000000, 6000, 10000, False)])
+def test_consensus_layouts_agree(monkeypatch, k, G, N, L, variable):
+    """consensus_full_kernel runs in two LDS layouts (int16 small tier first, the large tier for the windows it lists).  The same
+    jobs with the small tier switched off (DP_CONS_SMALL=0: every window in the large layout, round 2's kernel) must print the
+    same PAF as with it - and as the oracle."""
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(11, G, N, L, 0.0, variable)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    want = O.OverlapRun(rs, k=k, max_rounds=4)
+    got = {}
+    for small in ("1", "0"):
+        monkeypatch.setenv("DP_CONS_SMALL", small)
+        pipe = OverlapPipeline(Reads(bases, off, min_len=1000), k=k, slots=3)
+        pipe.run(4)
+        got[small] = pipe.all_paf()
+        pipe.close()
+    assert first_diff(got["1"], want.paf) is None
+    assert first_diff(got["0"], want.paf) is None

@@ -3,7 +3,7 @@
 # processes on the same GPU with 3 / 2 slots each (each runs its own whole jobs; the sum of their rates is what the GPU sustains).
 mkdir -p gpurun_out
 run() { # slots steps tag
-  timeout 600 python3 bench.py --steps $2 --warmup 1 --cpu-rounds 0 --scan-leg-rounds 0 --dense-leg-rounds 0 --slots $1 > gpurun_out/p2_$3.json 2> gpurun_out/p2_$3.err
+  timeout 600 python3 bench.py --steps $2 --warmup 1 --cpu-rounds 0 --scan-leg-rounds 0 --dense-leg-rounds 0 --map-leg-repeats 0 --slots $1 > gpurun_out/p2_$3.json 2> gpurun_out/p2_$3.err
 }
 show() { python3 - "$@" <<'PY'
 import json,sys
