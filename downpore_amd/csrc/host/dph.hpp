@@ -650,8 +650,14 @@ struct OverlapRun {
     // order (slot i after slot i - 1, on every rank alike); everything else of the rounds still runs concurrently.
     std::mutex exchangeMu_;
     std::condition_variable exchangeCv_;
-    int exchangeTurn_ = 0;
+    int exchangeTurn_ = 0, resultTurn_ = 0;
     bool exchangeOrdered_ = false;
+    // scan-shard with per-slot communicators: the query windows of a round are dealt to the ranks as well ("queries
+    // are partitioned by QueryID") - every rank builds the whole index from the gathered survivors but queries, chains and
+    // builds the consensus for its own contiguous share of the windows only; the ranks' PAF text, SetIgnore ids and counters are
+    // all-gathered (dp_allgather_blobs on the slot's communicator) and joined in rank order = query order.  DPH_SHARD_QUERIES=0:
+    // every rank does every window (round 2's behaviour).
+    bool shardQueries = true;
     void abortComms();
     // ---- round-parallel mode: execute round `r` speculatively against the current flags, commit gathered results
     int executeRound(i64 r, RoundResult& out);

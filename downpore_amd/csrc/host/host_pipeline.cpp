@@ -907,7 +907,14 @@ int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
     const double tb1 = now();
     g_prof.add(0, tb1 - tb0);
     sl.lap.reset(new Overlapper(sl.ctx, *reads, *sl.index, p.chunkSize, p.numWorkers, p.overlapSize, p.numSeeds, p.minHits));
-    sl.lap->setWindows(plan.windows);
+    if (sl.comm && shardQueries && exchangeOrdered_) {
+        // this rank's share of the round's query windows (contiguous: the ranks' results joined in rank order are in query order)
+        const size_t nw = plan.windows.size(), nr = (size_t)dp_comm_size(sl.comm), me = (size_t)dp_comm_rank(sl.comm);
+        const size_t w0 = nw * me / nr, w1 = nw * (me + 1) / nr;
+        sl.lap->setWindows(std::vector<Overlapper::Window>(plan.windows.begin() + (i64)w0, plan.windows.begin() + (i64)w1));
+    } else {
+        sl.lap->setWindows(plan.windows);
+    }
     sl.lap->setTextPool(textPool.get());
     {
         // chunkWorker on the device (dp_index_build_chunked) wherever the consensus runs there too; DP_DEVICE_CHUNK=0: host chunks
@@ -1006,15 +1013,20 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
         explicit GangRound(dp_ctx* c_) : c(c_) { dp_gang_round_prepare(c); }
         ~GangRound() { dp_gang_round_end(c); }
     } gangRound(sl.ctx);
-    struct ExchangeTurn {  // however this round ends, the slots behind it in the batch's exchange order are not kept waiting
-        OverlapRun* run;
-        int index;
+    struct ExchangeTurn {  // however this round ends, the slots behind it in the batch's exchange order get their turn - in order:
+        OverlapRun* run;   // a slot passes a baton on only once it holds it (the slots' collectives are issued in the same order on
+        int index;         // every rank, also around a slot whose round turned out empty)
         bool on;
+        void pass(int& turn) {
+            std::unique_lock<std::mutex> lk(run->exchangeMu_);
+            run->exchangeCv_.wait(lk, [&] { return turn >= index; });
+            turn = std::max(turn, index + 1);
+            run->exchangeCv_.notify_all();
+        }
         ~ExchangeTurn() {
             if (!on) return;
-            std::lock_guard<std::mutex> lk(run->exchangeMu_);
-            run->exchangeTurn_ = std::max(run->exchangeTurn_, index + 1);
-            run->exchangeCv_.notify_all();
+            pass(run->exchangeTurn_);
+            pass(run->resultTurn_);
         }
     } exchangeTurn{this, sl.slotNo, sl.comm != nullptr && exchangeOrdered_};
     static const bool dbgExec = getenv("DPH_DEBUG_PLANNER") != nullptr;
@@ -1067,6 +1079,64 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     out.st.t_scan = now() - t1;
     rc = finishRound(sl, sharded ? sl.gathered : sl.local, out);
     if (dbgX) fprintf(stderr, "[x %p] slot %d round %lld finished rc %d\n", (void*)this, sl.slotNo, (long long)r, rc);
+    if (sharded && shardQueries && exchangeOrdered_) {
+        // the ranks' shares of the round joined: [text bytes | ignores | counters] per rank, rank order = query order
+        if (rc == 0) out.takeText();
+        std::string blob;
+        {
+            const uint64_t hdr[8] = {(uint64_t)out.paf.size(), (uint64_t)out.ignores.size(), (uint64_t)out.fs.badBack, (uint64_t)out.fs.emptyMatch,
+                                     out.fs.lines, out.fs.hits, out.fs.qHits, (uint64_t)(rc == 0 ? 1 : 0)};
+            blob.append((const char*)hdr, sizeof hdr);
+            blob.append(out.paf);
+            blob.append((const char*)out.ignores.data(), out.ignores.size() * sizeof(int));
+        }
+        {
+            std::unique_lock<std::mutex> lk(exchangeMu_);
+            exchangeCv_.wait(lk, [&] { return resultTurn_ >= sl.slotNo; });
+        }
+        const uint8_t* all = nullptr;
+        const uint64_t* sizes = nullptr;
+        int rc2 = rc == 0 ? dp_allgather_blobs(sl.comm, sl.ctx, (const uint8_t*)blob.data(), blob.size(), &all, &sizes) : rc;
+        {
+            std::lock_guard<std::mutex> lk(exchangeMu_);
+            resultTurn_ = std::max(resultTurn_, sl.slotNo + 1);
+            exchangeCv_.notify_all();
+        }
+        if (rc == 0 && rc2 != 0) {
+            sl.error = dp_last_error(sl.ctx);
+            rc = rc2;
+        }
+        if (rc != 0) {
+            dp_comm_abort(sl.comm);
+        } else {
+            out.paf.clear();
+            out.ignores.clear();
+            out.fs = FinalCheckStats();
+            const int nr = dp_comm_size(sl.comm);
+            const uint8_t* q = all;
+            for (int i = 0; i < nr; i++) {
+                uint64_t hdr[8];
+                memcpy(hdr, q, sizeof hdr);
+                const uint8_t* body = q + sizeof hdr;
+                if (!hdr[7]) {
+                    sl.error = "a peer rank failed in this round";
+                    rc = -1;
+                    break;
+                }
+                out.paf.append((const char*)body, (size_t)hdr[0]);
+                const int* ig = (const int*)(body + hdr[0]);
+                out.ignores.insert(out.ignores.end(), ig, ig + hdr[1]);
+                out.fs.badBack += (i64)hdr[2];
+                out.fs.emptyMatch += (i64)hdr[3];
+                out.fs.lines += hdr[4];
+                out.fs.hits += hdr[5];
+                out.fs.qHits += hdr[6];
+                q += sizes[i];
+            }
+            out.st.n_paf = out.fs.lines;
+            out.numQuerySeqs = (i64)plan->windows.size();  // (one query id per window, commands/overlap.go:133-142)
+        }
+    }
     if (dbgExec) fprintf(stderr, "[exec] round %lld finished rc %d\n", (long long)r, rc);
     const double t2 = now();
     g_prof.add(14, t2 - t0);
@@ -1470,6 +1540,10 @@ int OverlapRun::roundSharded() {
 
 int OverlapRun::roundsShardedBatch() {
     if (done) return 0;
+    {
+        const char* e = getenv("DPH_SHARD_QUERIES");
+        shardQueries = !(e && e[0] == '0');
+    }
     if (slotComms.size() < slots.size()) {
         error = "roundsShardedBatch: fewer communicators than executor slots";
         return -1;
@@ -1481,6 +1555,7 @@ int OverlapRun::roundsShardedBatch() {
         {
             std::lock_guard<std::mutex> lk(exchangeMu_);
             exchangeTurn_ = 0;
+            resultTurn_ = 0;
             exchangeOrdered_ = true;
         }
         int rc = executeRounds(rounds, outs);

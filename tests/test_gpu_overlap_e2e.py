@@ -439,13 +439,17 @@ def test_scan_shard_rank_failure_does_not_hang_its_peers(monkeypatch, slots):
         p.close()
 
 
-def test_scan_shard_with_executor_slots():
-    """Scan-shard mode keeps its executor slots: a step runs `slots` consecutive rounds concurrently, slot i exchanging its
+@pytest.mark.parametrize("shard_queries", ["1", "0"])
+def test_scan_shard_with_executor_slots(monkeypatch, shard_queries):
+    """(shard_queries: the round's query windows dealt to the ranks as well - every rank chains and builds the consensus for its
+    own share, the ranks' PAF text and SetIgnore ids are all-gathered and joined in rank order - or every rank doing every window.)
+    Scan-shard mode keeps its executor slots: a step runs `slots` consecutive rounds concurrently, slot i exchanging its
     survivors on its own communicator, and commits them in order with the speculation check (rounds that meet a read flagged by
     an earlier round of the same batch are run again).  Two in-process ranks x three slots on one GPU, on reads short enough
     that many rounds flag reads; a 1-rank RCCL job with two slots.  Every rank must print the oracle's PAF."""
     import threading
     from downpore_amd.overlap import OverlapPipeline, Reads
+    monkeypatch.setenv("DPH_SHARD_QUERIES", shard_queries)
     bases, off = O.gen_reads(33, 60000, 700, 1500, 0.0, True)
     rs = O.ReadSet(bases, off, min_len=1000)
     want = O.OverlapRun(rs, k=10, seed_batch_size=1500)
