@@ -107,11 +107,11 @@ def traffic(fn, workload, desc, kernels, rounds_of):
 
 CHAIN = ["pair_scan_kernel", "chain_walk_kernel", "chain_spec_kernel", "chain_resolve_kernel", "match_anchor_kernel"]
 traffic("chain_traffic.json", "main", "chaining stage (pair_scan + chain_walk + chain_spec + chain_resolve + match_anchor)", CHAIN, "pair_scan_kernel")
-traffic("query_traffic.json", "main", "query_kernel", ["query_kernel"], "query_kernel")
+traffic("query_traffic.json", "main", "query_kernel<false> (+ <true> where launched)", ["query_kernel"], "query_kernel<false>")
 traffic("kindex_traffic.json", "main", "index-mode counting step (kidx_prepare + kidx_walk<false> + kidx_offsets)",
         ["kidx_prepare", "kidx_walk<false>", "kidx_offsets"], "kidx_offsets")
 traffic("scan_traffic.json", "scan", "scan_kernel<0, 2> (count pass)", ["scan_kernel<0, 2>"], "scan_kernel<0, 2>")
-traffic("dense_query_traffic.json", "dense", "query_kernel, k=10", ["query_kernel"], "query_kernel")
+traffic("dense_query_traffic.json", "dense", "query_kernel<false>, k=10", ["query_kernel"], "query_kernel<false>")
 if "main" in allw:
     for k in ("pack_kernel", "kb_part1", "kb_part2", "kb_final", "kb_count1", "kb_count2"):
         d = allw["main"].get(k)
