@@ -23,8 +23,8 @@
 
 typedef unsigned long long kb_u64;
 
-#define KB_TILE 4096       // entries per tile of passes 1/2
-#define KB_THREADS 256
+#define KB_TILE 16384       // entries per tile of passes 1/2
+#define KB_THREADS 1024
 #define KB_P3_CAP 8192     // entries pass 3 sorts inside LDS
 // An entry in flight = k-mer << (rbits + pbits) | read << pbits | position in the read: what the index finally stores travels
 // with the k-mer from pass 1 on (the read of a position is known for free there), so the last pass converts nothing.  Needs
