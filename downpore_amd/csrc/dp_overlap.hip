@@ -817,6 +817,7 @@ struct query_kernel {
 // A6 + A7 + A8: matchWorker body
 
 #define C_WAVES 4
+#define S_WAVES 4  // waves per workgroup of the kernels on the slim layout
 #define C_OPEN 500       // len(align.open)          seeds/alignment.go:299
 #define C_RESULTS 500    // len(align.results)
 #define C_POOLSTATES 10000
@@ -1783,6 +1784,7 @@ struct ChainArgs {
     uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [4..5] algorithmic bytes (u64)
     uint32_t* qdone;     // [nq] pairs of the query a speculative pass has finished (resolve fused into it), or nullptr
     uint32_t walk_blocks; // grid of chain_walk_kernel for this round (its node pool is sized for it)
+    uint32_t walk0_blocks; // grid of its slim form (mode 0)
     uint32_t n_refs;      // entries of refs[] (indexed sequences, or their upper bound)
     unsigned long long* prof;  // DP_CHAIN_PROF=1: [0] pairs looked at, [1] chained, [2..6] wall-clock ticks (100 MHz) per phase of chain_spec_kernel
 };
@@ -1977,18 +1979,24 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
 // mode 0: from the query's first candidate up to and including the first pair that is chained; 2 (last kernel of the stage):
 // whatever chain_resolve_kernel left open - proposals are taken where they fit, the rest is chained here, serially.
 // (mode 1 = mode 2 that stops instead of chaining: kept for experiments.)
+// SLIM (mode 0 only): the speculative kernel's 8.6 KB layout, one wave per query with sixteen of them on a CU instead of four
+// (a round's ~1 300 queries are then all resident at once: 45 -> 2x us); a pair that needs the full layout stops its query there
+// - it stays open, the proposal passes skip it and the final walk (full layout) chains it.
+template <bool SLIM>
 struct chain_walk_kernel {
-    enum { THREADS = 64 * C_WAVES };
+    typedef typename std::conditional<SLIM, CSlim, CWave>::type LW;
+    enum { WAVES = SLIM ? S_WAVES : C_WAVES, THREADS = 64 * WAVES };
     static __device__ void run(const ChainArgs A, const int mode) {
-    __shared__ CWave sh[C_WAVES];
-    CWave& L = sh[threadIdx.x >> 6];
+    __shared__ LW sh[WAVES];
+    LW& L = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
     // (every wave owns a slice of the node pool, sized for THIS round's grid: in a launch shared with other rounds - the largest
     // round's grid - the blocks beyond it have nothing to do)
-    if (blockIdx.x >= A.walk_blocks) return;
-    const uint32_t waves = A.walk_blocks * C_WAVES;
-    const uint32_t gw = blockIdx.x * C_WAVES + (threadIdx.x >> 6);
-    CNode* nodes = A.pool + (uint64_t)gw * C_NODES;
+    const uint32_t nblocks = SLIM ? A.walk0_blocks : A.walk_blocks;
+    if (blockIdx.x >= nblocks) return;
+    const uint32_t waves = nblocks * WAVES;
+    const uint32_t gw = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    CNode* nodes = SLIM ? (CNode*)nullptr : A.pool + (uint64_t)gw * C_NODES;
     if (mode != 0 && (A.cursor[3] != 0 || (A.pass > 0 && A.cursor[8 + A.pass] == 0))) return;  // overflow / every query closed already
     for (uint32_t q = gw; q < A.nq; q += waves) {
         const uint32_t cnt = A.qcnt[q];
@@ -2034,7 +2042,7 @@ struct chain_walk_kernel {
         }
         const int32_t* aSeg = A.qsegs + A.qoff[q];
         const u64* qset = A.qsets + (uint64_t)q * A.SW;
-        const bool aStaged = aN <= (int)CWave::ACAP && A.tier != 3;
+        const bool aStaged = aN <= (int)LW::ACAP && A.tier != 3;
         const u64* qs = chain_stage_a(L, aSeg, aN, qset, A.SW, aStaged);
         // algorithmic bytes of this query's share: two bitset rows per candidate (the exact-intersection
         // prefilter), both segment arrays per chained pair (4-byte ints here), the chain written out - counted once per
@@ -2070,6 +2078,7 @@ struct chain_walk_kernel {
                 break;  // needs chaining with a minMatches nobody proposed for: the next spec pass does it
             } else {
                 len = chain_pair(L, nodes, A, aSeg, aN, aStaged, qs, qset, t, mm, ca, cb, haveMask, aMask);
+                if (SLIM && len < 0) break;  // needs the full layout: the query stays open at this pair
                 chained = true;
             }
             algBytes += 16ull * A.SW;
@@ -2113,7 +2122,6 @@ struct chain_walk_kernel {
 __device__ void chain_resolve_query(const ChainArgs& A, uint32_t q, int lane);
 
 // one wave per open pair: prefilter + chain with the minMatches its query has reached; stored as a proposal
-#define S_WAVES 4
 struct chain_spec_kernel {
     enum { THREADS = 64 * S_WAVES };
     static __device__ void run(const ChainArgs A, const u64* __restrict__ totals) {
@@ -2510,6 +2518,7 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     A.int_cap = st.int_cap;
     A.cursor = d_cur;
     A.walk_blocks = st.walk_blocks;
+    A.walk0_blocks = std::max<uint32_t>(1, std::min<uint32_t>(1024, (nq + S_WAVES - 1) / S_WAVES));
     A.n_refs = std::max<uint32_t>(1, ctx->n_seqs);
     A.prof = nullptr;
     static const bool chain_prof = getenv("DP_CHAIN_PROF") != nullptr;
@@ -2525,14 +2534,22 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     DP_HIP(dp_mark(ctx, 6));
     dp_launch<pair_scan_kernel>(ctx, dim3(1), dim3(1024), (const uint32_t*)st.d_qcnt, ctx->qoff_dev, nq, d_pbase, d_ibase,
                        d_totals, d_qdone);
-    dp_launch<chain_walk_kernel>(ctx, dim3(st.walk_blocks), dim3(64 * C_WAVES), A, 0);
+    // mode 0 on the slim layout (DP_WALK0_SLIM=0: the full one; a forced tier is the full layout's business)
+    static const bool walk0_slim = [] {
+        const char* e = getenv("DP_WALK0_SLIM");
+        return !(e && e[0] == '0');
+    }();
+    if (walk0_slim && A.tier == 0 && st.passes > 0)
+        dp_launch<chain_walk_kernel<true>>(ctx, dim3(A.walk0_blocks), dim3(64 * S_WAVES), A, 0);
+    else
+        dp_launch<chain_walk_kernel<false>>(ctx, dim3(st.walk_blocks), dim3(64 * C_WAVES), A, 0);
     for (int ps = 0; ps < st.passes; ps++) {
         A.pass = ps;
         dp_launch<chain_spec_kernel>(ctx, dim3(st.spec_blocks), dim3(64 * S_WAVES), A, (const u64*)d_totals);
         if (!fuse_resolve) dp_launch<chain_resolve_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), A);
     }
     A.pass = st.passes;
-    dp_launch<chain_walk_kernel>(ctx, dim3(st.walk_blocks), dim3(64 * C_WAVES), A, 2);
+    dp_launch<chain_walk_kernel<false>>(ctx, dim3(st.walk_blocks), dim3(64 * C_WAVES), A, 2);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 7));
     {
