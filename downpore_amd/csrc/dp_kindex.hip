@@ -343,7 +343,8 @@ struct kidx_offsets {
                                                        uint32_t* __restrict__ s_count, uint64_t* __restrict__ s_off,
                                                        uint4* __restrict__ s_pack, uint64_t* __restrict__ totals,
                                                        uint32_t n_read_items, uint32_t* __restrict__ max_count,
-                                                       const unsigned long long* __restrict__ n_hits) {
+                                                       const unsigned long long* __restrict__ n_hits,
+                                                       unsigned long long* __restrict__ host_totals) {
     __shared__ uint32_t shA[16], shB[16];
     __shared__ uint32_t tile_s;
     __shared__ unsigned long long excl_s;
@@ -443,6 +444,22 @@ struct kidx_offsets {
             }
             so += segv[u];
             if (i == n - 1) segoff[n] = so;
+        }
+    }
+    // the round's totals go to the host's pinned block with the tile that finishes last (no launch of their own): every tile
+    // publishes its stores and counts itself in; the one that counts the last sees them all
+    if (host_totals) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t n_tiles = (n + KX_TILE * KX_IPT - 1) / (KX_TILE * KX_IPT);
+            __threadfence();
+            const uint32_t seen = __hip_atomic_fetch_add(&ticket[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if (seen == n_tiles) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+                for (int w = 0; w < 6; w++)
+                    host_totals[w] = __hip_atomic_load((const unsigned long long*)&totals[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -561,7 +578,7 @@ static uint32_t kidx_walk_blocks(const dp_kindex* ix, int k, uint32_t S) {
 // no host round trip.  d_work = [counts n | fill cursors n | tile status (tiles + 1) u64 | ticket, max count] (zeroed here).
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint4* s_pack,
-                    uint64_t* d_totals) {
+                    uint64_t* d_totals, unsigned long long* host_totals) {
     dp_kindex* ix = kidx_owner(ctx)->kidx;
     const uint32_t S = ctx->n_seeds, n_items = n_read_items + n_extra;
     if (n_items >= (1u << 24)) return 1;  // (the scan's status word holds 24 bits of survivors) -> scan kernels
@@ -601,7 +618,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     // totals[2] = seed occurrences in the read set, totals[3] = largest survivor count (both written by the kernel)
     dp_launch<kidx_offsets>(ctx, dim3(n_tiles), dim3(KX_TILE), d_items, (const uint32_t*)d_counts, n_items, status, ticket,
                        d_segoff, s_item, s_count, s_off, s_pack, d_totals, n_read_items, (uint32_t*)(d_totals + 3),
-                       (const unsigned long long*)n_hits);
+                       (const unsigned long long*)n_hits, host_totals);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 1));
     (void)k;

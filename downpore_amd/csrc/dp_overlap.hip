@@ -141,7 +141,11 @@ struct ChunkParams {
     dp_seq_ref* refs;
     dp_seq_meta* metas;
     uint32_t cap;
-    uint32_t* n_out;  // [0] chunks, [1] overflow
+    uint32_t* n_out;  // [0] chunks, [1] overflow, [2] ticket, [3] tiles done ([2], [3] and the tile status words are zero between launches)
+    // the bit matrices index_fill_kernel (next launch) sets bits in are cleared by `zero_blocks` extra workgroups of this launch
+    uint4* z_p[2];
+    unsigned long long z_n16[2];
+    uint32_t zero_blocks;
 };
 
 template <bool WRITE>
@@ -236,7 +240,17 @@ struct chunk_kernel {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t tile_s, base_s;
     // (a launch shared with other rounds has the largest round's grid: blocks beyond this round's own tiles take no ticket)
-    if (blockIdx.x >= (P.ns + 1023u) / 1024u) return;
+    const uint32_t n_tiles = (P.ns + 1023u) / 1024u;
+    if (blockIdx.x >= n_tiles) {
+        const uint32_t zb = blockIdx.x - n_tiles;
+        if (zb >= P.zero_blocks) return;
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            for (unsigned long long j = (unsigned long long)zb * 1024 + threadIdx.x; j < P.z_n16[r]; j += (unsigned long long)P.zero_blocks * 1024)
+                P.z_p[r][j] = zero;
+        return;
+    }
     if (threadIdx.x == 0) tile_s = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t tile = tile_s;
@@ -276,6 +290,17 @@ struct chunk_kernel {
     }
     __syncthreads();
     if (cnt) chunk_one<true>(P, i, base_s + before + x - cnt);
+    // the tile that finishes last puts the ticket, the status words and this counter back to zero for the next launch
+    __syncthreads();
+    if (threadIdx.x == 0) tile_s = __hip_atomic_fetch_add(&P.n_out[3], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    __syncthreads();
+    if (tile_s == n_tiles) {
+        for (uint32_t t = threadIdx.x; t < n_tiles; t += 1024) status[t] = 0ull;
+        if (threadIdx.x == 0) {
+            *ticket = 0u;
+            P.n_out[3] = 0u;
+        }
+    }
 }
 };
 
@@ -321,12 +346,18 @@ extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t o
     if (dev_reserve(ctx, ctx->d_chunk_meta, (size_t)cap * sizeof(dp_seq_meta) + 16)) return DP_ERR_HIP;
     const uint32_t n_tiles = (n_survivors + 1023) / 1024;
     const size_t b_nseqs = 64 + ((size_t)n_tiles + 2) * 8;  // [0] chunks, [1] overflow, [2] ticket | tile status words
-    if (dev_reserve(ctx, ctx->d_nseqs, b_nseqs)) return DP_ERR_HIP;
+    {
+        // [2 ..] (ticket, tiles done, tile status) are zero between launches: chunk_kernel's last tile sees to it; a new block starts zero
+        const void* before = ctx->d_nseqs.p;
+        if (dev_reserve(ctx, ctx->d_nseqs, b_nseqs)) return DP_ERR_HIP;
+        if (ctx->d_nseqs.p != before) DP_HIP(hipMemsetAsync(ctx->d_nseqs.p, 0, ctx->d_nseqs.cap, ctx->stream));
+    }
     if (dev_reserve(ctx, ctx->d_posting, (size_t)S * W * 8 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_seedsets, (size_t)cap * SW * 8 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_pmeta, (size_t)S * 16 + 16)) return DP_ERR_HIP;
-    {
-        const dp_zero_region z[3] = {{ctx->d_posting.p, (size_t)S * W * 8 + 64}, {ctx->d_seedsets.p, (size_t)cap * SW * 8 + 64}, {ctx->d_nseqs.p, b_nseqs}};
+    const size_t zb_post = ((size_t)S * W * 8 + 64 + 15) & ~(size_t)15, zb_sets = ((size_t)cap * SW * 8 + 64 + 15) & ~(size_t)15;
+    if (!n_survivors) {  // (no chunk_kernel launch to clear the matrices and to write the chunk count)
+        const dp_zero_region z[3] = {{ctx->d_posting.p, zb_post}, {ctx->d_seedsets.p, zb_sets}, {ctx->d_nseqs.p, 8}};
         if (int rc = dp_zero_regions(ctx, z, 3)) return rc;
     }
     if (n_survivors) {
@@ -347,7 +378,12 @@ extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t o
         P.metas = (dp_seq_meta*)ctx->d_chunk_meta.p;
         P.cap = cap;
         P.n_out = (uint32_t*)ctx->d_nseqs.p;
-        dp_launch<chunk_kernel>(ctx, dim3(n_tiles), dim3(1024), P, (unsigned long long*)((uint8_t*)ctx->d_nseqs.p + 64),
+        P.z_p[0] = (uint4*)ctx->d_posting.p;
+        P.z_n16[0] = zb_post / 16;
+        P.z_p[1] = (uint4*)ctx->d_seedsets.p;
+        P.z_n16[1] = zb_sets / 16;
+        P.zero_blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(512, (std::max(zb_post, zb_sets) / 16 + 4095) / 4096));
+        dp_launch<chunk_kernel>(ctx, dim3(n_tiles + P.zero_blocks), dim3(1024), P, (unsigned long long*)((uint8_t*)ctx->d_nseqs.p + 64),
                            (uint32_t*)ctx->d_nseqs.p + 2);
         DP_HIP(hipGetLastError());
         if (cap) {
@@ -536,7 +572,8 @@ struct query_kernel {
                                                              u64* __restrict__ cand, uint32_t* __restrict__ qmeta,
                                                              u64* __restrict__ words_read, uint32_t* __restrict__ qcnt,
                                                              uint32_t word_base, const uint32_t* __restrict__ n_seqs_dev,
-                                                             u64* __restrict__ qsets, uint32_t SW, uint32_t dbg_flags, uint32_t split) {
+                                                             u64* __restrict__ qsets, uint32_t SW, uint32_t dbg_flags, uint32_t split,
+                                                             u64* __restrict__ own_zero) {
     if (n_seqs_dev) n_seqs = *n_seqs_dev;  // (chunks made on the device: the host only knows an upper bound)
     // word_base: a shard of a larger index (dp_index_set_global) holds the words [word_base, word_base + W) of every set; pmeta
     // and n_seqs then describe the WHOLE sets (global windows, counts), so the filter, the early-return cut and the gather
@@ -555,6 +592,19 @@ struct query_kernel {
     if (threadIdx.x == 0) {
         sh_gathered = 0;
         sh_u[5] = 0;
+    }
+    // own_zero (light variant, one workgroup per query): the query's rows - candidate words, seed bitset, the per-query words - are
+    // cleared here, by the workgroup that owns them, instead of by a launch over all of them before this one; own_zero itself is
+    // the chaining stage's cursor block (16 words), cleared by query 0
+    if (!HEAVY && own_zero) {
+        for (uint32_t w = threadIdx.x; w < W; w += THREADS) cand[(uint64_t)q * W + w] = 0ull;
+        if (qsets)
+            for (uint32_t w = threadIdx.x; w < SW; w += THREADS) qsets[(uint64_t)q * SW + w] = 0ull;
+        if (threadIdx.x < 4) qmeta[4 * q + threadIdx.x] = 0u;
+        if (threadIdx.x == 4) words_read[q] = 0ull;
+        if (threadIdx.x == 5) qcnt[q] = 0u;
+        if (q == 0 && threadIdx.x >= 64 && threadIdx.x < 80) own_zero[threadIdx.x - 64] = 0ull;
+        __syncthreads();
     }
     const int32_t* seg = qsegs + qoff[q];
     const uint32_t ns = (uint32_t)((qoff[q + 1] - qoff[q]) / 2);
@@ -1686,19 +1736,25 @@ struct MRec {
 // (~6 KB of pinned memory) per match, here it is one wave per match over segments that are resident anyway.
 // anchors[2*slot] = seg[0] + sum_{t=1..first}(seg[2t]+k), anchors[2*slot+1] = seg[n-1] + sum_{t=last+1..ns-1}(seg[2t]+k);
 // -1 when the chain's indices are not inside the target (the host then sums itself).
+struct AnchorFetch {  // 8-byte words copied by the launch (either direction: pinned host blocks on one side)
+    unsigned long long* dst[3];
+    const unsigned long long* src[3];
+    unsigned long long n8[3];
+};
 struct match_anchor_kernel {
     enum { THREADS = 256 };
     static __device__ void run(const MRec* __restrict__ recs, const uint32_t* __restrict__ n_pairs,
                                                            uint32_t pair_cap, const int32_t* __restrict__ mb,
                                                            const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, int k,
-                                                           int32_t* __restrict__ anchors, unsigned long long* __restrict__ fetch_dst,
-                                                           const unsigned long long* __restrict__ fetch_src, unsigned long long fetch_n8,
-                                                           uint32_t* __restrict__ zero_word) {
+                                                           int32_t* __restrict__ anchors, const AnchorFetch F, uint32_t* __restrict__ zero_word) {
     const int lane = threadIdx.x & 63;
     if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;  // (the consensus stage's retry counter: next launch)
-    // (the consensus kernel's input block - pinned host memory - is brought over by this launch, which runs just before it)
-    for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < fetch_n8; j += (unsigned long long)gridDim.x * blockDim.x)
-        fetch_dst[j] = __builtin_nontemporal_load(&fetch_src[j]);
+    // (the consensus kernel's input block - pinned host memory - is brought over by this launch, which runs just before it; a
+    // pending chaining stage's cursor block and per-query words go the other way)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        for (unsigned long long j = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; j < F.n8[r]; j += (unsigned long long)gridDim.x * blockDim.x)
+            F.dst[r][j] = __builtin_nontemporal_load(&F.src[r][j]);
     const uint32_t nslots = min(*n_pairs, pair_cap);
     const uint32_t waves = gridDim.x * (blockDim.x >> 6);
     for (uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); slot < nslots; slot += waves) {
@@ -2378,33 +2434,40 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     memcpy(up + up_off, q_segs, up_segs);
     memcpy(up + up_off + up_segs, mc.data(), up_mc);
     if (dev_reserve(ctx, ctx->d_cursor, 128)) return DP_ERR_HIP;
-    {   // (the chaining stage's cursor block rides along: it is zero when the first attempt starts; and the same launch fetches
-        // the upload block from its pinned staging - no copy is handed to the runtime)
-        const dp_zero_region z[4] = {{ctx->d_qsets.p, (size_t)nq * SW * 8}, {ctx->d_cand.p, (size_t)nq * W * 8}, {d_qmeta, (size_t)nq * 28},
-                                     {ctx->d_cursor.p, 128}};
-        const dp_fetch_region f = {ctx->d_qsegs.p, up, up_off + up_segs + up_mc};
-        if (int rc = dp_zero_fetch_regions(ctx, z, 4, &f, 1)) return rc;
-    }
     // workgroups per query (DP_QUERY_SPLIT, experiments: see query_kernel)
     static const int split_env = [] {
         const char* e = getenv("DP_QUERY_SPLIT");
         return e ? atoi(e) : 0;
     }();
     const uint32_t q_split = split_env > 0 ? (uint32_t)std::min(split_env, 16) : 1u;
+    static const bool own_rows_env = [] {
+        const char* e = getenv("DP_QUERY_OWN_ZERO");  // 0: the rows are cleared by the launch before (the round-2 behaviour)
+        return !(e && e[0] == '0');
+    }();
+    const bool own_rows = own_rows_env && q_split == 1;
+    {   // (the chaining stage's cursor block rides along: it is zero when the first attempt starts; and the same launch fetches
+        // the upload block from its pinned staging - no copy is handed to the runtime)
+        // (with one workgroup per query - the default - the light query kernel clears its query's rows itself and this launch only
+        // brings the upload block over)
+        const dp_zero_region z[4] = {{ctx->d_qsets.p, (size_t)nq * SW * 8}, {ctx->d_cand.p, (size_t)nq * W * 8}, {d_qmeta, (size_t)nq * 28},
+                                     {ctx->d_cursor.p, 128}};
+        const dp_fetch_region f = {ctx->d_qsegs.p, up, up_off + up_segs + up_mc};
+        if (int rc = dp_zero_fetch_regions(ctx, z, own_rows ? 0 : 4, &f, 1)) return rc;
+    }
     DP_HIP(dp_mark(ctx, 4));
     dp_launch<query_kernel<false>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
                        ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
-                       query_dbg_flags(), q_split);
+                       query_dbg_flags(), q_split, own_rows ? (u64*)ctx->d_cursor.p : (u64*)nullptr);
     // the 16-ladder / exact-count regimes start at minCount 13: only a batch with a query of that many seeds needs the heavy variant
     if (mc[maxSeeds] >= 13) dp_launch<query_kernel<true>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
                        ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
-                       query_dbg_flags(), q_split);
+                       query_dbg_flags(), q_split, (u64*)nullptr);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 5));
 
@@ -2436,6 +2499,8 @@ struct FindState {
     int attempt = 0;
     float chain_ms = 0;
     bool pending = false;
+    bool defer_fetch = false;  // the first attempt's read-back rides in the anchors launch of the consensus call (a pending stage)
+    bool fetch_owed = false;
     uint32_t cur[32];
     double query_ms = 0;
     uint64_t query_bytes = 0, chain_bytes = 0;
@@ -2556,8 +2621,14 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
         // the cursor block and the status words, per-query posting-word counts and candidate counts (a few KB) come back in any
         // case, in the same wait: stored into their pinned blocks by one small launch of this stream (dp_zero_fetch_regions works
         // in either direction) instead of two copies handed to the runtime
-        const dp_fetch_region f[2] = {{ctx->h_cursor.p, ctx->d_cursor.p, 128}, {ctx->h_qm.p, st.d_qmeta, (size_t)nq * 28}};
-        if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, f, 2)) return rc;
+        // (a stage that stays pending: nobody reads them before the consensus call's wait - its anchors launch, the next one of
+        // this stream, stores them instead: dp_match_anchors_launch)
+        if (st.defer_fetch && st.attempt == 0) {
+            st.fetch_owed = true;
+        } else {
+            const dp_fetch_region f[2] = {{ctx->h_cursor.p, ctx->d_cursor.p, 128}, {ctx->h_qm.p, st.d_qmeta, (size_t)nq * 28}};
+            if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, f, 2)) return rc;
+        }
     }
     st.attempt++;
     return DP_OK;
@@ -2702,6 +2773,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     st.want_pairs = std::max<uint64_t>(1u << 14, ctx->d_mrec.cap / sizeof(MRec));
     st.want_sints = std::max<uint64_t>(1u << 18, ctx->d_sa.cap / 4);
     st.want_ints = std::max<uint64_t>(1u << 18, ctx->d_ma.cap / 4);
+    st.defer_fetch = (want_candidates & 6) == 6;
     if (int rc = chain_enqueue(ctx, st)) return rc;
     if ((want_candidates & 6) == 6) {
         // bit 2: nothing of this call is read before dp_consensus_paf - the stage stays pending and is evaluated in that call's
@@ -2741,17 +2813,32 @@ int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch, uint32_t*
     // (a pending chaining stage: the pair count is on the device only - the launch covers the stage's capacity)
     const uint32_t nslots = dp_find_pending(ctx) ? dp_find_pair_cap(ctx) : ctx->n_pairs;
     if (dev_reserve(ctx, ctx->d_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
+    // what a pending chaining stage still has to report (chain_enqueue): its cursor block and per-query words, into their pinned blocks
+    FindState* fs = ctx->find_state;
+    dp_fetch_region owed[2] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+    if (fs && fs->fetch_owed) {
+        owed[0] = {ctx->h_cursor.p, ctx->d_cursor.p, 128};
+        owed[1] = {ctx->h_qm.p, fs->d_qmeta, (size_t)fs->nq * 28};
+        fs->fetch_owed = false;
+    }
     if (!nslots) {
+        if (owed[0].dst)
+            if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, owed, 2)) return rc;
         const dp_zero_region z = {zero_word, 8};
         return (fetch || zero_word) ? dp_zero_fetch_regions(ctx, &z, zero_word ? 1 : 0, fetch, fetch ? 1 : 0) : DP_OK;
+    }
+    AnchorFetch F;
+    const dp_fetch_region* fr[3] = {fetch, owed[0].dst ? &owed[0] : nullptr, owed[1].dst ? &owed[1] : nullptr};
+    for (int i = 0; i < 3; i++) {
+        F.dst[i] = fr[i] ? (unsigned long long*)fr[i]->dst : nullptr;
+        F.src[i] = fr[i] ? (const unsigned long long*)fr[i]->src : nullptr;
+        F.n8[i] = fr[i] ? (unsigned long long)((fr[i]->bytes + 7) / 8) : 0ull;
     }
     const u64* d_totals = (const u64*)((const uint8_t*)ctx->d_cursor.p + 64);
     dp_launch<match_anchor_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256),
                        (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
                        (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, ctx->last_k, (int32_t*)ctx->d_manchor.p,
-                       fetch ? (unsigned long long*)fetch->dst : (unsigned long long*)nullptr,
-                       fetch ? (const unsigned long long*)fetch->src : (const unsigned long long*)nullptr,
-                       fetch ? (unsigned long long)((fetch->bytes + 7) / 8) : 0ull, zero_word);
+                       F, zero_word);
     DP_HIP(hipGetLastError());
     return DP_OK;
 }
@@ -2780,7 +2867,7 @@ int dp_fetch_overlaps_impl(dp_ctx* ctx, int want_candidates, dp_match_batch* out
         dp_launch<match_anchor_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256),
                            (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
                            (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, k, (int32_t*)ctx->d_manchor.p,
-                           (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 0ull, (uint32_t*)nullptr);
+                           AnchorFetch{{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {0, 0, 0}}, (uint32_t*)nullptr);
         DP_HIP(hipGetLastError());
         DP_HIP(hipMemcpyAsync(ctx->h_manchor.p, ctx->d_manchor.p, (size_t)nslots * 8, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_mrec.p, ctx->d_mrec.p, (size_t)nslots * sizeof(MRec), hipMemcpyDeviceToHost, ctx->stream));

@@ -1599,7 +1599,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     if (use_index) {
         // counts, segment offsets, survivor list and totals in three launches, no sort and no host round trip (dp_kindex.hip)
         int rc = dp_kindex_count(ctx, k, d_items, lo, hi, n_read_items, n_extra, (uint32_t*)ctx->d_counts.p, (uint64_t*)ctx->d_segoff.p,
-                                 s_item, s_count, s_off, s_pack, totals);
+                                 s_item, s_count, s_off, s_pack, totals, (unsigned long long*)ctx->h_total.p);
         if (rc < 0) return rc;
         if (rc > 0) use_index = false;  // more items than its scan handles: this round is scanned
     }
@@ -1630,7 +1630,8 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     }
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 4));
-    {   // (stored into the pinned block by a launch of this stream, not copied by the runtime)
+    if (!use_index) {  // (stored into the pinned block by a launch of this stream, not copied by the runtime; the index step's
+                       // last kernel has stored them itself)
         const dp_fetch_region f = {ctx->h_total.p, totals, 48};
         if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, &f, 1)) return rc;
     }
