@@ -258,6 +258,11 @@ struct kidx_unlink_extra {
 }
 };
 
+#ifdef DP_PROF_BUILD
+#define KX_PROFILING 1
+#else
+#define KX_PROFILING 0
+#endif
 template <bool FILL>
 struct kidx_walk {
     enum { THREADS = 256 };
@@ -266,9 +271,19 @@ struct kidx_walk {
                                                  uint32_t lo, uint32_t hi, uint32_t n_read_items, const uint32_t* __restrict__ head,
                                                  const uint32_t* __restrict__ next, uint32_t* __restrict__ counts,
                                                  uint32_t* __restrict__ fillc, const uint64_t* __restrict__ segoff,
-                                                 int32_t* __restrict__ segs, unsigned long long* __restrict__ n_hits, uint32_t lps) {
+                                                 int32_t* __restrict__ segs, unsigned long long* __restrict__ n_hits, uint32_t lps,
+                                                 unsigned long long* __restrict__ dbg) {
     const int lane = dp_lane();
+    // DP_KX_DEBUG: when a wave started, had its bucket bounds, its entries, its items, and was done (100 MHz ticks since dbg[15],
+    // sums over waves in dbg[0..4], maxima in dbg[5..9], waves in dbg[10])
+#define KX_TICK(i_)                                                                                     \
+    if (KX_PROFILING && dbg) {                                                                          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                      \
+        const unsigned long long n_ = wall_clock64();                                                   \
+        if (lane == 0) dbg[8 * (size_t)w + (i_)] = n_;                                                  \
+    }
     const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    KX_TICK(0)
     // lps = lanes per seed.  64: KX_PARTS waves share one seed's bucket (dense seeds: buckets of hundreds to thousands);
     // 16: four seeds per wave (k = 13 at config 2: ~20 occurrences per seed - a whole wave per quarter bucket left 59 lanes idle
     // and made 40 k waves of a 10 k-seed round)
@@ -296,39 +311,75 @@ struct kidx_walk {
         step = 16;
         first = (lane & 15) == 0;
     }
+    KX_TICK(1)
     if (!FILL && first && n) atomicAdd(&n_hits[s & 63u], (unsigned long long)n);  // (64 slots: 10 k same-address atomics serialise)
-    for (uint32_t i = i0; i < i1; i += step) {
-        const uint64_t e = pos[o + i];
-        const uint32_t r = (uint32_t)(e >> 32), p = (uint32_t)e;
-        if (r >= lo && r < hi) {
-            const uint32_t it = r - lo;
-            const dp_scan_item item = items[it];
-            if (p < item.n_kmers) {  // (ignored reads carry n_kmers == 0; a top-level read with len % 4 == 0 four k-mers less)
-                if (!FILL) {
-                    atomicAdd(&counts[it], 1u);
-                } else if (counts[it] >= item.min_seeds) {
-                    const uint32_t slot = atomicAdd(&fillc[it], 1u);
-                    const uint64_t at = segoff[it] + 2ull * slot;
-                    segs[at] = (int32_t)p;
-                    segs[at + 1] = (int32_t)s;
+    // Four entries per lane and trip: a hit is a chain of dependent loads (entry -> the read's item and list head -> counter), each
+    // link a trip to HBM through a TLB that an 8 GB table defeats; the links of four entries travel together instead of one
+    // after the other (a seed of config 2 has 20-40 entries: one trip of a 16-lane group instead of three)
+    for (uint32_t ib = i0; ib < i1; ib += 4 * step) {
+        uint64_t e[4];
+        bool v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = ib + (uint32_t)u * step;
+            v[u] = i < i1;
+            e[u] = v[u] ? pos[o + i] : 0ull;
+        }
+        KX_TICK(2)
+        dp_scan_item item[4];
+        uint32_t hd[4];
+        bool in[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t r = (uint32_t)(e[u] >> 32);
+            in[u] = v[u] && r >= lo && r < hi;
+            item[u] = in[u] ? items[r - lo] : dp_scan_item{};
+            hd[u] = v[u] ? head[r] : 0u;
+        }
+        KX_TICK(3)
+        uint32_t cnt[4] = {0, 0, 0, 0};
+        uint64_t so[4] = {0, 0, 0, 0};
+        if (FILL) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t r = (uint32_t)(e[u] >> 32);
+                in[u] = in[u] && (uint32_t)e[u] < item[u].n_kmers;
+                if (in[u]) {
+                    cnt[u] = counts[r - lo];
+                    so[u] = segoff[r - lo];
                 }
             }
         }
-        for (uint32_t x = head[r]; x; x = next[x - 1]) {
-            const uint32_t it = n_read_items + x - 1;
-            const dp_scan_item item = items[it];
-            if (p - item.start < item.n_kmers && p >= item.start) {
-                if (!FILL) {
-                    atomicAdd(&counts[it], 1u);
-                } else if (counts[it] >= item.min_seeds) {
-                    const uint32_t slot = atomicAdd(&fillc[it], 1u);
-                    const uint64_t at = segoff[it] + 2ull * slot;
-                    segs[at] = (int32_t)(p - item.start);
-                    segs[at + 1] = (int32_t)s;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t r = (uint32_t)(e[u] >> 32), p = (uint32_t)e[u];
+            if (!FILL) {
+                // (ignored reads carry n_kmers == 0; a top-level read with len % 4 == 0 four k-mers less)
+                if (in[u] && p < item[u].n_kmers) atomicAdd(&counts[r - lo], 1u);
+            } else if (in[u] && cnt[u] >= item[u].min_seeds) {
+                const uint32_t slot = atomicAdd(&fillc[r - lo], 1u);
+                const uint64_t at = so[u] + 2ull * slot;
+                segs[at] = (int32_t)p;
+                segs[at + 1] = (int32_t)s;
+            }
+            for (uint32_t x = hd[u]; x; x = next[x - 1]) {  // the round's extra items on this read (query windows)
+                const uint32_t it = n_read_items + x - 1;
+                const dp_scan_item xi = items[it];
+                if (p - xi.start < xi.n_kmers && p >= xi.start) {
+                    if (!FILL) {
+                        atomicAdd(&counts[it], 1u);
+                    } else if (counts[it] >= xi.min_seeds) {
+                        const uint32_t slot = atomicAdd(&fillc[it], 1u);
+                        const uint64_t at = segoff[it] + 2ull * slot;
+                        segs[at] = (int32_t)(p - xi.start);
+                        segs[at + 1] = (int32_t)s;
+                    }
                 }
             }
         }
     }
+    KX_TICK(4)
+#undef KX_TICK
 }
 };
 
@@ -611,10 +662,42 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                            ctx->extras_staged ? (const dp_scan_item*)ctx->h_extra.p : (const dp_scan_item*)nullptr);
         ctx->extras_staged = false;
     }
+    static const bool kx_debug = getenv("DP_KX_DEBUG") != nullptr;
+    unsigned long long* dbg = nullptr;
+    const size_t n_dbg_waves = (size_t)kidx_walk_blocks(ix, k, S) * 4;
+    if (kx_debug) {
+        DP_HIP(dp_dev_malloc((void**)&dbg, n_dbg_waves * 64));
+        DP_HIP(hipMemsetAsync(dbg, 0, n_dbg_waves * 64, ctx->stream));
+    }
     if (S)
         dp_launch<kidx_walk<false>>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
                            (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
-                           (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k));
+                           (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k), dbg);
+    if (kx_debug) {
+        std::vector<unsigned long long> h(n_dbg_waves * 8);
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpy(h.data(), dbg, n_dbg_waves * 64, hipMemcpyDeviceToHost);
+        dp_dev_free(dbg);
+        unsigned long long first = ~0ull, lastStart = 0, lastEnd = 0;
+        double sum[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0};
+        size_t nw = 0;
+        for (size_t w = 0; w < n_dbg_waves; w++) {
+            const unsigned long long* t = &h[8 * w];
+            if (!t[0] || !t[4]) continue;
+            nw++;
+            first = std::min(first, t[0]);
+            lastStart = std::max(lastStart, t[0]);
+            lastEnd = std::max(lastEnd, t[4]);
+            for (int i = 1; i < 5; i++) {
+                const double d = (double)(t[i] - t[i - 1]) / 100.0;
+                sum[i] += d;
+                mx[i] = std::max(mx[i], d);
+            }
+        }
+        if (nw)
+            fprintf(stderr, "[kx] %zu waves, first start .. last start %.1f us, first start .. last end %.1f us | us per phase mean/max: bounds %.1f/%.1f entries %.1f/%.1f items %.1f/%.1f counters %.1f/%.1f\n",
+                    nw, (lastStart - first) / 100.0, (lastEnd - first) / 100.0, sum[1] / nw, mx[1], sum[2] / nw, mx[2], sum[3] / nw, mx[3], sum[4] / nw, mx[4]);
+    }
     // totals[2] = seed occurrences in the read set, totals[3] = largest survivor count (both written by the kernel)
     dp_launch<kidx_offsets>(ctx, dim3(n_tiles), dim3(KX_TILE), d_items, (const uint32_t*)d_counts, n_items, status, ticket,
                        d_segoff, s_item, s_count, s_off, s_pack, d_totals, n_read_items, (uint32_t*)(d_totals + 3),
@@ -644,7 +727,8 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         if (S)
             dp_launch<kidx_walk<true>>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
                                (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
-                               (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr, kidx_lps(ix, k));
+                               (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr, kidx_lps(ix, k),
+                               (unsigned long long*)nullptr);
         const dim3 sg(std::min<uint32_t>(n_sel, 16384)), sb(64);
         uint32_t* ovf = (uint32_t*)(d_totals + 4);
         const uint32_t* nsp = (const uint32_t*)(d_totals + 1);

@@ -866,6 +866,18 @@ struct query_kernel {
 // ---------------------------------------------------------------------------------------------------------------
 // A6 + A7 + A8: matchWorker body
 
+// Profiling build (make PROF=1): per-wave phase timers of the chaining kernels (DP_CHAIN_PROF=1 prints them).  In the normal
+// build the timers are compiled out - their sums live in a per-thread array that ends up in scratch memory.
+#ifdef DP_PROF_BUILD
+#define DP_PROFILING 1
+#else
+#define DP_PROFILING 0
+#endif
+struct ChainProf {  // ticks of 10 ns, summed per wave (profiling build)
+    unsigned long long pairs, chained, rec, stagea, pre, pair;   // chain_spec_kernel's phases
+    unsigned long long stageb, initial, walk, out, last;          // chain_pair's
+    unsigned long long bev, nev, nperfect;          // wave_chain_reg's
+};
 #define C_WAVES 4
 #define S_WAVES 4  // waves per workgroup of the kernels on the slim layout
 #define C_OPEN 500       // len(align.open)          seeds/alignment.go:299
@@ -1302,26 +1314,67 @@ __device__ int wave_b_events(int bN, int k, LW& L, int cap) {
 // reg tier.  Returns the length of results[0] (its pairs are left in L.rescol as reducedA | bSeed<<6), 0, or -1 when
 // the pair needs the lds tier.
 template <class LW>
-__device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, int k, LW& L, uint32_t* err, bool prof,
-                              u64* tp) {
+__device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, int k, LW& L, uint32_t* err, ChainProf* cp) {
+    const bool prof = DP_PROFILING && cp != nullptr;
     const int lane = dp_lane();
     if (startSize == 0) return 0;  // no initial position: no chain can ever start
     int live = startSize;
     const int initialSize = startSize;
     const int aRedLen = aLen * 2 + 1;
+    const unsigned long long tb0 = prof ? wall_clock64() : 0ull;
     const int nE = wave_b_events<true>(bN, k, L, (int)LW::EVN);
     if (nE > (int)LW::EVN) return -1;
     __builtin_amdgcn_wave_barrier();  // (CSlim: the columns below reuse b's staging area)
-    if (prof) tp[2] += (u64)nE;
-    const int myA = lane < aLen ? L.aRed[2 * lane + 1] : -1;
-    {
-        const int myOff = lane < aLen ? L.aRed[2 * lane] : 0;
-        L.ps[lane] = wave_incl_sum(lane < aLen ? myOff + k : 0);  // g(r) - g(r0) = ps[r] - ps[r0]
+    if (prof) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        cp->bev += wall_clock64() - tb0;
+        cp->nev += (u64)nE;
     }
+    const int myA = lane < aLen ? L.aRed[2 * lane + 1] : -1;
+    const int myOff = lane < aLen ? L.aRed[2 * lane] : 0;                // aRed[2 * lane]: the gap in front of kept seed `lane`
+    L.ps[lane] = wave_incl_sum(lane < aLen ? myOff + k : 0);             // g(r) - g(r0) = ps[r] - ps[r0]
     int st_aPos = 0, st_bPos = 0, st_aGap = 0, st_bGap = 0, st_aGapIndex = 0, st_len = 0;
     int openSize = 0, resultsSize = 0, firstLen = 0;
     int maxBIndex = bN - minMatches * 2 + 1;
     const u64 initMask = initialSize >= 64 ? ~0ull : ((1ull << initialSize) - 1ull);
+
+    // The perfect chain, decided for all events at once (lane e = event e).  An overlap is, nearly always, one chain that starts at
+    // the first event and that every following event extends by the very next kept seed of a.  The walk below finds that in
+    // nE dependent steps of a few hundred instructions each - and a CU's instruction issue, shared by its sixteen waves, is what
+    // bounds this kernel.  Here: event 0 starts exactly one chain (one initial position r0 holds its seed); every event e >= 1 shows
+    // the seed of position r0 + e at a distance inside the gap window (searchMatch's cursor then does not move: aGap >= minGap, the
+    // hit is the cursor's own position, no cumulative-gap test) and matches no OTHER initial position (no second chain is ever
+    // opened; tested for every event whether or not maxBIndex would still allow a start: a sufficient condition).  Then the walk is
+    // known without walking: nE extensions of chain 0, no removal, results[0] = that chain iff nE >= minMatches (the ratchet
+    // only raises minMatches to 2 nE / 3 <= nE).  Anything else: the walk.
+    if (nE >= 2 && nE <= 64 && nE <= (int)LW::COLN && startSize + nE <= C_POOLSTATES) {
+        const int4 myEv = lane < nE ? L.ev[lane] : make_int4(0, 0, -2, 0);  // {bIndex, bOffset, seed, gap after}
+        const u64 m0 = __ballot(myA == RL(myEv.z, 0)) & initMask;
+        if (__popcll(m0) == 1 && RL(myEv.x, 0) <= maxBIndex) {
+            const int r0 = __builtin_ctzll(m0);
+            const int r = r0 + lane;
+            const int aSeedAt = __shfl(myA, r & 63, 64), aGapAt = __shfl(myOff, r & 63, 64);
+            const int prevGapAfter = __shfl_up(myEv.w, 1, 64);
+            bool bad = false;
+            if (lane >= 1 && lane < nE) {
+                int minGap, maxGap;
+                gap_range(prevGapAfter + myEv.y, k, minGap, maxGap);
+                bad = r >= aLen || aSeedAt != myEv.z || aGapAt < minGap || aGapAt > maxGap;
+            }
+            if (!__ballot(bad)) {
+                for (int i = 0; i < initialSize; i++) {
+                    const int ai = RL(myA, i);
+                    if (lane >= 1 && lane < nE && myEv.z == ai && i != r) bad = true;
+                }
+            }
+            if (!__ballot(bad)) {
+                if (prof) cp->nperfect++;
+                if (nE < minMatches) return 0;
+                if (lane < nE) L.rescol[lane] = (uint32_t)r | ((uint32_t)(myEv.x >> 1) << 6);
+                return nE;
+            }
+        }
+    }
 
     // removeOpenState :390-409 for chain i_ (uniform): results[0] keeps a copy of its column
 #define REMOVE_OPEN_R(i_)                                                          \
@@ -1944,8 +1997,18 @@ __device__ __forceinline__ int chain_prefilter_seeds(const LW& L, const u64* __r
 template <class LW>
 __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, const int32_t* __restrict__ aSeg, int aN, bool aStaged,
                           const u64* qs, const u64* __restrict__ qset, uint32_t t, int minMatches, int32_t* __restrict__ ca,
-                          int32_t* __restrict__ cb, bool haveAMask = false, u64 aMask = 0, const dp_seq_ref* rPre = nullptr) {
+                          int32_t* __restrict__ cb, bool haveAMask = false, u64 aMask = 0, const dp_seq_ref* rPre = nullptr,
+                          ChainProf* cp = nullptr) {
     const int lane = dp_lane();
+    // (profiling build: ticks of: b staged + flags, initial positions, b events + chain walk, result out)
+#define CP_TICK(f_)                                                  \
+    if (DP_PROFILING && cp) {                                        \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  \
+        const unsigned long long n_ = wall_clock64();                \
+        cp->f_ += n_ - cp->last;                                     \
+        cp->last = n_;                                               \
+    }
+    if (DP_PROFILING && cp) cp->last = wall_clock64();
     const u64* tset = A.seedsets + (uint64_t)t * A.SW;
     const dp_seq_ref r = rPre ? *rPre : A.refs[t];
     const int32_t* bSeg = A.segs + r.seg_off;
@@ -1977,7 +2040,7 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
     }
     int resLen = 0, resNode = -1, usedTier = 3;
     uint32_t err = 0;
-    u64 tp[3] = {0, 0, 0};
+    CP_TICK(stageb)
     if (staged) {
         const int mm = minMatches == 0 ? 1 : minMatches;
         int aLen = 0, startSize = 0;
@@ -1986,9 +2049,10 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
             err |= 1;
             usedTier = 0;
         } else {
+            CP_TICK(initial)
             resLen = -1;
             if (aLen <= 64 && (A.tier == 0 || LW::SLIM)) {
-                resLen = wave_chain_reg(aLen, startSize, bN, mm, k, L, &err, false, tp);
+                resLen = wave_chain_reg(aLen, startSize, bN, mm, k, L, &err, cp);
                 usedTier = 1;
             }
             if constexpr (LW::SLIM) {
@@ -2008,6 +2072,7 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
             resNode = __shfl(resNode, 0, 64);
         }
     }
+    CP_TICK(walk)
     if (lane == 0 && err) atomicOr(&A.cursor[2], err);
     if (err) resLen = 0;
     if (resLen > 0) {
@@ -2029,6 +2094,8 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
             }
         }
     }
+    CP_TICK(out)
+#undef CP_TICK
     return resLen > 0 ? resLen : 0;
 }
 
@@ -2189,16 +2256,20 @@ struct chain_spec_kernel {
     // (a query that did not fit the buffers left its pairs' pq / clist unwritten: the host repeats the stage with larger ones)
     if (A.cursor[3] != 0 || A.cursor[8 + A.pass] == 0) return;  // ... or no query is open any more
     const uint32_t total = (uint32_t)min(totals[0], (u64)A.pair_cap);
-#define SP_TICK(i_)                                                                      \
-    if (A.prof) {                                                                        \
-        const unsigned long long now_ = wall_clock64();                                  \
-        if (lane == 0) atomicAdd(&A.prof[i_], now_ - tprev);                             \
-        tprev = now_;                                                                    \
+    // DP_CHAIN_PROF: every wave keeps its own sums (ticks of 10 ns) and stores them into its own slot of the pass - no shared
+    // counters (ten thousand atomics on one word take longer than the kernel)
+    ChainProf pf = {};
+    unsigned long long tprev = 0;
+#define SP_TICK(f_)                                                  \
+    if ((DP_PROFILING && A.prof)) {                                  \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  \
+        const unsigned long long now_ = wall_clock64();              \
+        pf.f_ += now_ - tprev;                                       \
+        tprev = now_;                                                \
     }
-    const unsigned long long tkernel0 = A.prof ? wall_clock64() : 0ull;
+    const unsigned long long tkernel0 = (DP_PROFILING && A.prof) ? wall_clock64() : 0ull;
     for (uint32_t p = gw; p < total; p += waves) {
-        unsigned long long tprev = A.prof ? wall_clock64() : 0ull;
-        const unsigned long long tpair0 = tprev;
+        if ((DP_PROFILING && A.prof)) tprev = wall_clock64();
         // A pair is a chain of dependent loads (pair -> query -> its records -> its segments -> probes of the target's set ...) at
         // 1-2 us per level under this kernel's own load: everything whose address is known is asked for at once, ahead of the
         // tests that may drop the pair (a load behind a branch waits for the branch), the target's reference included.
@@ -2222,10 +2293,10 @@ struct chain_spec_kernel {
         const int32_t* aSeg = A.qsegs + qo0;
         const u64* qset = A.qsets + (uint64_t)q * A.SW;
         const bool aStaged = aN <= (int)CSlim::ACAP;
-        if (A.prof && lane == 0) atomicAdd(&A.prof[0], 1ull);
-        SP_TICK(2)  // the pair's own records (query state, proposal, candidate)
+        pf.pairs++;
+        SP_TICK(rec)  // the pair's own records (query state, proposal, candidate)
         const u64* qs = chain_stage_a(L, aSeg, aN, qset, A.SW, aStaged);
-        SP_TICK(3)  // query side staged
+        SP_TICK(stagea)  // query side staged
         int c = RFL(sp.c);
         bool haveMask = false;
         u64 aMask = 0;
@@ -2237,31 +2308,23 @@ struct chain_spec_kernel {
                 c = chain_prefilter(A.seedsets + (uint64_t)t * A.SW, qs, A.SW);
             }
         }
-        SP_TICK(4)  // prefilter
+        SP_TICK(pre)  // prefilter
         int len = 0, pmm = mm;
         if (c >= mm) {
-            if (A.prof && lane == 0) atomicAdd(&A.prof[1], 1ull);
+            pf.chained++;
             len = chain_pair(L, (CNode*)nullptr, A, aSeg, aN, aStaged, qs, qset, t, mm, A.sa + ib + (u64)i * nSeeds, A.sb + ib + (u64)i * nSeeds,
-                             haveMask, aMask, &rT);
+                             haveMask, aMask, &rT, (DP_PROFILING && A.prof) ? &pf : (ChainProf*)nullptr);
             if (len < 0) {  // does not fit the slim layout: no proposal, the final walk chains it
                 len = 0;
                 pmm = -1;
             }
         }
-        SP_TICK(5)  // chain_pair
+        SP_TICK(pair)  // chain_pair
         if (lane == 0) {
             PSpec o = {c, pmm, len, 0};
             A.pspec[p] = o;
         }
         __builtin_amdgcn_wave_barrier();
-        SP_TICK(6)
-        if (A.prof && lane == 0) {
-            const unsigned long long dt = wall_clock64() - tpair0;
-            atomicMax(&A.prof[7], dt);
-            if (dt > 500) atomicAdd(&A.prof[8], 1ull);   // pairs that took more than 5 us
-            if (dt > 1500) atomicAdd(&A.prof[9], 1ull);  // ... more than 15 us
-            atomicMax(&A.prof[10], wall_clock64() - tkernel0);  // latest end of a pair since its wave started
-        }
         } while (0);
         if (A.qdone) {
             // the resolve step of the query, by whichever wave finishes the last of its pairs (instead of a launch of its own
@@ -2282,6 +2345,15 @@ struct chain_spec_kernel {
             __builtin_amdgcn_wave_barrier();
         }
     }
+    if ((DP_PROFILING && A.prof) && lane == 0) {
+        unsigned long long* slot = A.prof + 16 * ((size_t)A.pass * waves + gw);
+        slot[0] = pf.pairs, slot[1] = pf.chained, slot[2] = pf.rec, slot[3] = pf.stagea, slot[4] = pf.pre, slot[5] = pf.pair;
+        slot[6] = pf.stageb, slot[7] = pf.initial, slot[8] = pf.walk, slot[9] = pf.out;
+        slot[10] = tkernel0;
+        slot[11] = wall_clock64();
+        slot[12] = pf.bev, slot[13] = pf.nev, slot[14] = pf.nperfect, slot[15] = 0;
+    }
+#undef SP_TICK
 }
 };
 
@@ -2588,11 +2660,10 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     A.prof = nullptr;
     static const bool chain_prof = getenv("DP_CHAIN_PROF") != nullptr;
     if (chain_prof) {
-        if (!ctx->d_sched.p || ctx->d_sched.cap < 128) {
-            if (dev_reserve(ctx, ctx->d_sched, 128)) return DP_ERR_HIP;
-        }
+        const size_t pb = (size_t)st.passes * st.spec_blocks * S_WAVES * 128;
+        if (dev_reserve(ctx, ctx->d_sched, pb + 128)) return DP_ERR_HIP;
         A.prof = (unsigned long long*)ctx->d_sched.p;
-        DP_HIP(hipMemsetAsync(A.prof, 0, 128, ctx->stream));
+        DP_HIP(hipMemsetAsync(A.prof, 0, pb, ctx->stream));
     }
     A.qdone = fuse_resolve ? d_qdone : nullptr;
     if (st.attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 128, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
@@ -2664,11 +2735,32 @@ static int chain_finish(dp_ctx* ctx, FindState& st) {
     st.pending = false;
     static const bool chain_prof = getenv("DP_CHAIN_PROF") != nullptr;
     if (chain_prof && ctx->d_sched.p) {
-        unsigned long long h[16];
-        if (hipMemcpy(h, ctx->d_sched.p, 128, hipMemcpyDeviceToHost) == hipSuccess && h[0])
-            fprintf(stderr, "[chain prof] spec passes: %llu pairs looked at, %llu chained | us per pair: records %.2f stage a %.2f prefilter %.2f chain %.2f (per chained %.2f) store %.2f | slowest pair %.1f us, %llu pairs > 5 us, %llu > 15 us, last pair done %.1f us after its wave started\n",
-                    h[0], h[1], h[2] / 100.0 / h[0], h[3] / 100.0 / h[0], h[4] / 100.0 / h[0], h[5] / 100.0 / h[0], h[1] ? h[5] / 100.0 / h[1] : 0.0, h[6] / 100.0 / h[0],
-                    h[7] / 100.0, h[8], h[9], h[10] / 100.0);
+        const size_t waves = (size_t)st.spec_blocks * S_WAVES;
+        std::vector<unsigned long long> h((size_t)st.passes * waves * 16);
+        if (hipMemcpy(h.data(), ctx->d_sched.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int ps = 0; ps < st.passes; ps++) {
+                unsigned long long sum[16] = {0}, t0 = ~0ull, t1 = 0, busiest = 0, mostPairs = 0;
+                size_t active = 0;
+                for (size_t w = 0; w < waves; w++) {
+                    const unsigned long long* r = &h[16 * ((size_t)ps * waves + w)];
+                    if (!r[10]) continue;
+                    t0 = std::min(t0, r[10]);
+                    t1 = std::max(t1, r[11]);
+                    if (!r[0]) continue;
+                    active++;
+                    for (int i = 0; i < 10; i++) sum[i] += r[i];
+                    for (int i = 12; i < 16; i++) sum[i] += r[i];
+                    busiest = std::max(busiest, r[11] - r[10]);
+                    mostPairs = std::max(mostPairs, r[0]);
+                }
+                if (!sum[0]) continue;
+                const double n = (double)sum[0], nc = (double)std::max<unsigned long long>(1, sum[1]);
+                fprintf(stderr, "[chain prof] pass %d: %llu pairs (%llu chained) on %zu waves (at most %llu per wave), kernel span %.1f us, busiest wave %.1f us | us per pair: "
+                                "records %.2f stage a %.2f prefilter %.2f chain_pair %.2f | per chained pair: stage b + flags %.2f initial %.2f events + walk %.2f (b events %.2f us; %.1f events; %.1f %% perfect chains) out %.2f\n",
+                        ps, sum[0], sum[1], active, mostPairs, (t1 - t0) / 100.0, busiest / 100.0, sum[2] / 100.0 / n, sum[3] / 100.0 / n, sum[4] / 100.0 / n,
+                        sum[5] / 100.0 / n, sum[6] / 100.0 / nc, sum[7] / 100.0 / nc, sum[8] / 100.0 / nc, sum[12] / 100.0 / nc, sum[13] / nc, 100.0 * sum[14] / nc, sum[9] / 100.0 / nc);
+            }
+        }
     }
     st.query_ms = dp_elapsed(ctx, 4, 5);
     st.chain_bytes = (uint64_t)st.cur[4] | ((uint64_t)st.cur[5] << 32);
