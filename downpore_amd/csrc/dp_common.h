@@ -133,6 +133,8 @@ struct dp_ctx {
     DevBuf d_pbase, d_pspec, d_clist, d_sa, d_sb;  // chaining stage: pair offsets, proposals, candidate lists, scratch columns
     uint32_t n_pairs = 0;                          // (query, candidate) pair slots of the last dp_find_overlaps
     uint32_t last_nq = 0, last_ni = 0;             // its queries / packed chain ints
+    uint64_t last_sints = 0;                       // scratch ints of the last chaining stage (all pairs' columns)
+    bool chains_packed = true;                     // false: the final chains sit in the scratch columns (d_sa/d_sb), see ChainArgs.pack
     int last_k = 0;
     bool find_valid = false;                       // the device still holds that call's records
     PinBuf h_mrec, h_ma, h_mb, h_ta, h_tb, h_qm, h_qup, h_cursor, h_cand, h_cand_off, h_cand_list, h_mq, h_mt, h_moff, h_manchor, h_manout;
@@ -215,6 +217,9 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
                         dp_chain_batch* out, int phase = 2, int32_t* thr_io = nullptr);
 void dp_find_state_free(dp_ctx* ctx);
 bool dp_find_pending(const dp_ctx* ctx);
+// where the chaining stage's final chains are: MRec.off indexes these two arrays (a side, b side)
+static inline const void* dp_chain_a(const dp_ctx* ctx) { return ctx->chains_packed ? ctx->d_ma.p : ctx->d_sa.p; }
+static inline const void* dp_chain_b(const dp_ctx* ctx) { return ctx->chains_packed ? ctx->d_mb.p : ctx->d_sb.p; }
 uint32_t dp_find_pair_cap(const dp_ctx* ctx);
 int dp_find_complete(dp_ctx* ctx, bool* reran);
 void dp_find_stats(const dp_ctx* ctx, double* query_ms, double* chain_ms, uint64_t* query_bytes, uint64_t* chain_bytes);

@@ -1125,8 +1125,8 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     uint8_t* dout = (uint8_t*)ctx->h_cout.p;
     ConsFullArgs A;
     A.recs = (const uint32_t*)ctx->d_mrec.p;
-    A.ma = (const int32_t*)ctx->d_ma.p;
-    A.mb = (const int32_t*)ctx->d_mb.p;
+    A.ma = (const int32_t*)dp_chain_a(ctx);
+    A.mb = (const int32_t*)dp_chain_b(ctx);
     A.pbase = (const uint32_t*)((const uint64_t*)ctx->d_pbase.p + nq + 1);
     A.qsegs = ctx->qsegs_dev;
     A.qoff = (const uint64_t*)ctx->qoff_dev;

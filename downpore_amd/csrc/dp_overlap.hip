@@ -1892,6 +1892,9 @@ struct ChainArgs {
     uint32_t int_cap;
     uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [4..5] algorithmic bytes (u64)
     uint32_t* qdone;     // [nq] pairs of the query a speculative pass has finished (resolve fused into it), or nullptr
+    int pack;             // 1: final chains are copied into ma/mb, densely (what a host fetch wants); 0: they stay where they were
+                          // chained - the pair's scratch column - and the record's offset points there (ma = sa, mb = sb for the
+                          // device consumers; dp_fetch_overlaps packs them then, should a host consumer turn up)
     uint32_t walk_blocks; // grid of chain_walk_kernel for this round (its node pool is sized for it)
     uint32_t walk0_blocks; // grid of its slim form (mode 0)
     uint32_t n_refs;      // entries of refs[] (indexed sequences, or their upper bound)
@@ -2207,7 +2210,10 @@ struct chain_walk_kernel {
             algBytes += 16ull * A.SW;
             if (c >= mm) algBytes += 4ull * (u64)(aN + (int)(2 * A.refs[t].n_seeds + 1));
             uint32_t off = 0;
-            if (len > 0) {
+            if (len > 0 && !A.pack) {
+                off = (uint32_t)(ib + (u64)i * nSeeds);
+                algBytes += 8ull * (u64)len;
+            } else if (len > 0) {
                 if (lane == 0) off = atomicAdd(&A.cursor[0], (uint32_t)len);
                 off = (uint32_t)__shfl((int)off, 0, 64);
                 if ((u64)off + (u64)len <= (u64)A.int_cap) {
@@ -2410,19 +2416,25 @@ __device__ void chain_resolve_query(const ChainArgs& A, uint32_t q, int lane) {
         const bool fin = lane < stop;
         const bool hit = fin && ((hitMask >> lane) & 1ull);
         const int myLen = hit ? sp.len : 0;
-        const int incl = wave_incl_sum(myLen);
-        const int totalLen = __shfl(incl, 63, 64);
-        uint32_t off0 = 0;
-        if (totalLen > 0) {
-            if (lane == 0) off0 = atomicAdd(&A.cursor[0], (uint32_t)totalLen);
-            off0 = (uint32_t)__shfl((int)off0, 0, 64);
+        uint32_t myOff = (uint32_t)(ib + (u64)i * nSeeds);  // (pack == 0: the chain stays in the pair's scratch column)
+        bool room = true;
+        if (A.pack) {
+            const int incl = wave_incl_sum(myLen);
+            const int totalLen = __shfl(incl, 63, 64);
+            uint32_t off0 = 0;
+            if (totalLen > 0) {
+                if (lane == 0) off0 = atomicAdd(&A.cursor[0], (uint32_t)totalLen);
+                off0 = (uint32_t)__shfl((int)off0, 0, 64);
+            }
+            myOff = off0 + (uint32_t)(incl - myLen);
+            room = (u64)off0 + (u64)totalLen <= (u64)A.int_cap;
+            if (!room && lane == 0) A.cursor[3] = 1;
         }
-        const uint32_t myOff = off0 + (uint32_t)(incl - myLen);
-        const bool room = (u64)off0 + (u64)totalLen <= (u64)A.int_cap;
-        if (!room && lane == 0) A.cursor[3] = 1;
         if (fin) {
             int wlen = 0;
-            if (hit && room) {
+            if (hit && !A.pack) {
+                wlen = myLen;
+            } else if (hit && room) {
                 const int32_t* ca = A.sa + ib + (u64)i * nSeeds;
                 const int32_t* cb = A.sb + ib + (u64)i * nSeeds;
                 for (int x = 0; x < myLen; x++) {
@@ -2650,6 +2662,16 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     A.sb = (int32_t*)ctx->d_sb.p;
     A.ma = (int32_t*)ctx->d_ma.p;
     A.mb = (int32_t*)ctx->d_mb.p;
+    {
+        // a stage whose consumers are on the device (it stays pending for dp_consensus_paf) leaves the chains in their scratch
+        // columns: no cursor atomics, no copies in the walk and resolve kernels (DP_CHAIN_PACK=1: always pack)
+        static const bool always_pack = [] {
+            const char* e = getenv("DP_CHAIN_PACK");
+            return e && e[0] == '1';
+        }();
+        A.pack = (st.defer_fetch && !always_pack && st.sint_cap < 0xfffffff0ull) ? 0 : 1;
+        ctx->chains_packed = A.pack != 0;
+    }
     A.pair_cap = st.pair_cap;
     A.sint_cap = st.sint_cap;
     A.int_cap = st.int_cap;
@@ -2783,6 +2805,7 @@ static int chain_finish(dp_ctx* ctx, FindState& st) {
     ctx->n_pairs = (uint32_t)tp;
     ctx->last_nq = st.nq;
     ctx->last_ni = st.cur[0];
+    memcpy(&ctx->last_sints, &st.cur[18], 8);
     ctx->last_k = st.k;
     ctx->find_valid = true;
     return DP_OK;
@@ -2928,7 +2951,7 @@ int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch, uint32_t*
     }
     const u64* d_totals = (const u64*)((const uint8_t*)ctx->d_cursor.p + 64);
     dp_launch<match_anchor_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256),
-                       (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
+                       (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)dp_chain_b(ctx),
                        (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, ctx->last_k, (int32_t*)ctx->d_manchor.p,
                        F, zero_word);
     DP_HIP(hipGetLastError());
@@ -2937,10 +2960,51 @@ int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch, uint32_t*
 
 // Download of the chaining stage's records.  Pair slots are in canonical order already: queries ascending, candidates
 // ascending within a query.
+// Chains left in their scratch columns (ChainArgs.pack == 0), for a host consumer after all: copied into ma/mb densely, the
+// records' offsets rewritten.  One wave per record; the order of the chains in ma/mb is whatever the atomics make it (the
+// records say where each one is).
+struct chain_pack_kernel {
+    enum { THREADS = 256 };
+    static __device__ void run(MRec* __restrict__ recs, uint32_t nslots, const int32_t* __restrict__ sa, const int32_t* __restrict__ sb,
+                               int32_t* __restrict__ ma, int32_t* __restrict__ mb, uint32_t* __restrict__ total) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); slot < nslots; slot += waves) {
+        const MRec r = recs[slot];
+        if (r.len == 0) continue;
+        uint32_t off = 0;
+        if (lane == 0) off = atomicAdd(total, r.len);
+        off = (uint32_t)__shfl((int)off, 0, 64);
+        for (uint32_t x = lane; x < r.len; x += 64) {
+            ma[off + x] = sa[r.off + x];
+            mb[off + x] = sb[r.off + x];
+        }
+        if (lane == 0) recs[slot].off = off;
+    }
+}
+};
+
 int dp_fetch_overlaps_impl(dp_ctx* ctx, int want_candidates, dp_match_batch* out) {
     if (!ctx->find_valid) return dp_fail(ctx, DP_ERR_STATE, "dp_fetch_overlaps: no chaining stage output on this context");
     hipSetDevice(ctx->device);
     memset(out, 0, sizeof(*out));
+    if (!ctx->chains_packed && ctx->n_pairs) {
+        // the stage left its chains in the scratch columns (its consumers were on the device): pack them now
+        const uint64_t bound = std::max<uint64_t>(1, ctx->find_state ? std::min<uint64_t>(ctx->find_state->sint_cap, ctx->last_sints) : 0);
+        if (bound > 0xfffffff0ull) return dp_fail(ctx, DP_ERR_CAPACITY, "dp_fetch_overlaps: more than 2^32 chain ints");
+        if (dev_reserve(ctx, ctx->d_ma, (size_t)bound * 4)) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_mb, (size_t)bound * 4)) return DP_ERR_HIP;
+        uint32_t* d_total = (uint32_t*)ctx->d_cursor.p;  // (the stage's cursor block is free again: word 0 counted packed ints anyway)
+        DP_HIP(hipMemsetAsync(d_total, 0, 4, ctx->stream));
+        dp_launch<chain_pack_kernel>(ctx, dim3(std::min<uint32_t>(2048, (ctx->n_pairs + 3) / 4)), dim3(256), (MRec*)ctx->d_mrec.p, ctx->n_pairs,
+                                     (const int32_t*)ctx->d_sa.p, (const int32_t*)ctx->d_sb.p, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p, d_total);
+        DP_HIP(hipGetLastError());
+        if (pin_reserve(ctx, ctx->h_cursor, 128)) return DP_ERR_HIP;
+        DP_HIP(hipMemcpyAsync(ctx->h_cursor.p, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
+        ctx->last_ni = *(const uint32_t*)ctx->h_cursor.p;
+        ctx->chains_packed = true;
+    }
     const uint32_t nq = ctx->last_nq, nslots = ctx->n_pairs, ni = ctx->last_ni;
     const int k = ctx->last_k;
     out->n_queries = nq;
