@@ -21,6 +21,9 @@ typedef uint64_t u64;
 // ---------------------------------------------------------------------------------------------------------------
 // A13
 
+// the chaining stage's cursor block: 32 words (cursor, flags, totals) + 64 shards of its algorithmic-byte count (one counter
+// would be a thousand same-address atomics per kernel: 12 ns each, in a row)
+#define C_CURSOR_BYTES 640
 struct index_fill_kernel {
     enum { THREADS = 256 };
     static __device__ void run(const dp_seq_ref* __restrict__ refs, uint32_t n_seqs, const int32_t* __restrict__ segs,
@@ -595,7 +598,7 @@ struct query_kernel {
     }
     // own_zero (light variant, one workgroup per query): the query's rows - candidate words, seed bitset, the per-query words - are
     // cleared here, by the workgroup that owns them, instead of by a launch over all of them before this one; own_zero itself is
-    // the chaining stage's cursor block (16 words), cleared by query 0
+    // the chaining stage's cursor block (C_CURSOR_BYTES), cleared by query 0
     if (!HEAVY && own_zero) {
         for (uint32_t w = threadIdx.x; w < W; w += THREADS) cand[(uint64_t)q * W + w] = 0ull;
         if (qsets)
@@ -603,7 +606,7 @@ struct query_kernel {
         if (threadIdx.x < 4) qmeta[4 * q + threadIdx.x] = 0u;
         if (threadIdx.x == 4) words_read[q] = 0ull;
         if (threadIdx.x == 5) qcnt[q] = 0u;
-        if (q == 0 && threadIdx.x >= 64 && threadIdx.x < 80) own_zero[threadIdx.x - 64] = 0ull;
+        if (q == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + C_CURSOR_BYTES / 8) own_zero[threadIdx.x - 64] = 0ull;
         __syncthreads();
     }
     const int32_t* seg = qsegs + qoff[q];
@@ -876,7 +879,7 @@ struct query_kernel {
 struct ChainProf {  // ticks of 10 ns, summed per wave (profiling build)
     unsigned long long pairs, chained, rec, stagea, pre, pair;   // chain_spec_kernel's phases
     unsigned long long stageb, initial, walk, out, last;          // chain_pair's
-    unsigned long long bev, nev, nperfect;          // wave_chain_reg's
+    unsigned long long bev, nev, nperfect, why;  // why: 5 x 12-bit counts of why a pair was not a perfect chain          // wave_chain_reg's
 };
 #define C_WAVES 4
 #define S_WAVES 4  // waves per workgroup of the kernels on the slim layout
@@ -1347,10 +1350,14 @@ __device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, i
     // opened; tested for every event whether or not maxBIndex would still allow a start: a sufficient condition).  Then the walk is
     // known without walking: nE extensions of chain 0, no removal, results[0] = that chain iff nE >= minMatches (the ratchet
     // only raises minMatches to 2 nE / 3 <= nE).  Anything else: the walk.
+    int why = 0;  // (profiling: 0 size limits, 1 event 0 starts no or several chains, 2 start not allowed any more, 3 seed / gap, 4 second start)
     if (nE >= 2 && nE <= 64 && nE <= (int)LW::COLN && startSize + nE <= C_POOLSTATES) {
+        why = 1;
         const int4 myEv = lane < nE ? L.ev[lane] : make_int4(0, 0, -2, 0);  // {bIndex, bOffset, seed, gap after}
         const u64 m0 = __ballot(myA == RL(myEv.z, 0)) & initMask;
+        if (__popcll(m0) == 1 && RL(myEv.x, 0) > maxBIndex) why = 2;
         if (__popcll(m0) == 1 && RL(myEv.x, 0) <= maxBIndex) {
+            why = 3;
             const int r0 = __builtin_ctzll(m0);
             const int r = r0 + lane;
             const int aSeedAt = __shfl(myA, r & 63, 64), aGapAt = __shfl(myOff, r & 63, 64);
@@ -1362,6 +1369,7 @@ __device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, i
                 bad = r >= aLen || aSeedAt != myEv.z || aGapAt < minGap || aGapAt > maxGap;
             }
             if (!__ballot(bad)) {
+                why = 4;
                 for (int i = 0; i < initialSize; i++) {
                     const int ai = RL(myA, i);
                     if (lane >= 1 && lane < nE && myEv.z == ai && i != r) bad = true;
@@ -1375,6 +1383,7 @@ __device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, i
             }
         }
     }
+    if (prof) cp->why += 1ull << (12 * why);
 
     // removeOpenState :390-409 for chain i_ (uniform): results[0] keeps a copy of its column
 #define REMOVE_OPEN_R(i_)                                                          \
@@ -1890,7 +1899,7 @@ struct ChainArgs {
     uint32_t pair_cap;
     u64 sint_cap;
     uint32_t int_cap;
-    uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [4..5] algorithmic bytes (u64)
+    uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [8 + pass] "a query is open" flags, [16..19] totals, [32 ..] 64 shards of the algorithmic bytes (u64)
     uint32_t* qdone;     // [nq] pairs of the query a speculative pass has finished (resolve fused into it), or nullptr
     int pack;             // 1: final chains are copied into ma/mb, densely (what a host fetch wants); 0: they stay where they were
                           // chained - the pair's scratch column - and the record's offset points there (ma = sa, mb = sb for the
@@ -1898,6 +1907,7 @@ struct ChainArgs {
     uint32_t walk_blocks; // grid of chain_walk_kernel for this round (its node pool is sized for it)
     uint32_t walk0_blocks; // grid of its slim form (mode 0)
     uint32_t n_refs;      // entries of refs[] (indexed sequences, or their upper bound)
+    uint32_t prof_walk_slot;   // first per-wave slot of walk(0) in prof[] (behind the passes')
     unsigned long long* prof;  // DP_CHAIN_PROF=1: [0] pairs looked at, [1] chained, [2..6] wall-clock ticks (100 MHz) per phase of chain_spec_kernel
 };
 
@@ -2124,7 +2134,20 @@ struct chain_walk_kernel {
     const uint32_t gw = blockIdx.x * WAVES + (threadIdx.x >> 6);
     CNode* nodes = SLIM ? (CNode*)nullptr : A.pool + (uint64_t)gw * C_NODES;
     if (mode != 0 && (A.cursor[3] != 0 || (A.pass > 0 && A.cursor[8 + A.pass] == 0))) return;  // overflow / every query closed already
+    // (profiling build, mode 0: per-wave sums like chain_spec_kernel's, in the slots behind the passes')
+    const bool wprof = DP_PROFILING && A.prof && mode == 0;
+    ChainProf pf = {};
+    unsigned long long tprev = 0;
+#define WK_TICK(f_)                                                  \
+    if (wprof) {                                                     \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  \
+        const unsigned long long now_ = wall_clock64();              \
+        pf.f_ += now_ - tprev;                                       \
+        tprev = now_;                                                \
+    }
+    const unsigned long long tkernel0 = wprof ? wall_clock64() : 0ull;
     for (uint32_t q = gw; q < A.nq; q += waves) {
+        if (wprof) tprev = wall_clock64();
         const uint32_t cnt = A.qcnt[q];
         if (cnt == 0) continue;
         const uint32_t pb = A.pbase[q];
@@ -2166,10 +2189,12 @@ struct chain_walk_kernel {
             next = (uint32_t)RFL((int)st.next);
             if (next >= cnt) continue;
         }
+        WK_TICK(rec)  // the query's records and (mode 0) its candidate list
         const int32_t* aSeg = A.qsegs + A.qoff[q];
         const u64* qset = A.qsets + (uint64_t)q * A.SW;
         const bool aStaged = aN <= (int)LW::ACAP && A.tier != 3;
         const u64* qs = chain_stage_a(L, aSeg, aN, qset, A.SW, aStaged);
+        WK_TICK(stagea)
         // algorithmic bytes of this query's share: two bitset rows per candidate (the exact-intersection
         // prefilter), both segment arrays per chained pair (4-byte ints here), the chain written out - counted once per
         // pair, when it becomes final
@@ -2196,6 +2221,8 @@ struct chain_walk_kernel {
                     c = chain_prefilter(A.seedsets + (uint64_t)t * A.SW, qs, A.SW);
                 }
             }
+            pf.pairs++;
+            WK_TICK(pre)
             if (c < mm) {
                 len = 0;
             } else if (spmm == mm) {
@@ -2203,9 +2230,11 @@ struct chain_walk_kernel {
             } else if (mode == 1) {
                 break;  // needs chaining with a minMatches nobody proposed for: the next spec pass does it
             } else {
-                len = chain_pair(L, nodes, A, aSeg, aN, aStaged, qs, qset, t, mm, ca, cb, haveMask, aMask);
+                len = chain_pair(L, nodes, A, aSeg, aN, aStaged, qs, qset, t, mm, ca, cb, haveMask, aMask, nullptr, wprof ? &pf : (ChainProf*)nullptr);
                 if (SLIM && len < 0) break;  // needs the full layout: the query stays open at this pair
                 chained = true;
+                pf.chained++;
+                WK_TICK(pair)
             }
             algBytes += 16ull * A.SW;
             if (c >= mm) algBytes += 4ull * (u64)(aN + (int)(2 * A.refs[t].n_seeds + 1));
@@ -2241,10 +2270,20 @@ struct chain_walk_kernel {
         if (lane == 0) {
             QState st = {mm, i};
             A.qstate[q] = st;
-            if (algBytes) atomicAdd((unsigned long long*)(A.cursor + 4), (unsigned long long)algBytes);
-            if (mode == 0 && i < cnt) atomicAdd(&A.cursor[8], 1u);  // open queries ahead of proposal pass 0
+            if (algBytes) atomicAdd((unsigned long long*)(A.cursor + 32) + (q & 63u), (unsigned long long)algBytes);
+            if (mode == 0 && i < cnt) A.cursor[8] = 1u;  // a query is open ahead of proposal pass 0 (a flag: every writer stores 1)
         }
+        WK_TICK(out)
     }
+    if (wprof && lane == 0) {
+        unsigned long long* slot = A.prof + 16 * ((size_t)A.prof_walk_slot + gw);
+        slot[0] = pf.pairs, slot[1] = pf.chained, slot[2] = pf.rec, slot[3] = pf.stagea, slot[4] = pf.pre, slot[5] = pf.pair;
+        slot[6] = pf.stageb, slot[7] = pf.initial, slot[8] = pf.walk, slot[9] = pf.out;
+        slot[10] = tkernel0;
+        slot[11] = wall_clock64();
+        slot[12] = pf.bev, slot[13] = pf.nev, slot[14] = pf.nperfect, slot[15] = pf.why;
+    }
+#undef WK_TICK
 }
 };
 
@@ -2357,7 +2396,7 @@ struct chain_spec_kernel {
         slot[6] = pf.stageb, slot[7] = pf.initial, slot[8] = pf.walk, slot[9] = pf.out;
         slot[10] = tkernel0;
         slot[11] = wall_clock64();
-        slot[12] = pf.bev, slot[13] = pf.nev, slot[14] = pf.nperfect, slot[15] = 0;
+        slot[12] = pf.bev, slot[13] = pf.nev, slot[14] = pf.nperfect, slot[15] = pf.why;
     }
 #undef SP_TICK
 }
@@ -2458,8 +2497,8 @@ __device__ void chain_resolve_query(const ChainArgs& A, uint32_t q, int lane) {
     if (lane == 0) {
         QState o = {mm, next};
         A.qstate[q] = o;
-        if (ab) atomicAdd((unsigned long long*)(A.cursor + 4), ab);
-        if (next < cnt) atomicAdd(&A.cursor[9 + A.pass], 1u);  // still open: the next pass has work
+        if (ab) atomicAdd((unsigned long long*)(A.cursor + 32) + (q & 63u), ab);
+        if (next < cnt) A.cursor[9 + A.pass] = 1u;  // still open: the next pass has work (a flag)
     }
 }
 
@@ -2517,7 +2556,7 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     memcpy(up, q_off, up_off);
     memcpy(up + up_off, q_segs, up_segs);
     memcpy(up + up_off + up_segs, mc.data(), up_mc);
-    if (dev_reserve(ctx, ctx->d_cursor, 128)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_cursor, C_CURSOR_BYTES)) return DP_ERR_HIP;
     // workgroups per query (DP_QUERY_SPLIT, experiments: see query_kernel)
     static const int split_env = [] {
         const char* e = getenv("DP_QUERY_SPLIT");
@@ -2534,7 +2573,7 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
         // (with one workgroup per query - the default - the light query kernel clears its query's rows itself and this launch only
         // brings the upload block over)
         const dp_zero_region z[4] = {{ctx->d_qsets.p, (size_t)nq * SW * 8}, {ctx->d_cand.p, (size_t)nq * W * 8}, {d_qmeta, (size_t)nq * 28},
-                                     {ctx->d_cursor.p, 128}};
+                                     {ctx->d_cursor.p, C_CURSOR_BYTES}};
         const dp_fetch_region f = {ctx->d_qsegs.p, up, up_off + up_segs + up_mc};
         if (int rc = dp_zero_fetch_regions(ctx, z, own_rows ? 0 : 4, &f, 1)) return rc;
     }
@@ -2587,7 +2626,7 @@ struct FindState {
     bool fetch_owed = false;
     uint32_t cur[32];
     double query_ms = 0;
-    uint64_t query_bytes = 0, chain_bytes = 0;
+    uint64_t query_bytes = 0, chain_bytes = 0, alg_bytes = 0;
 };
 void dp_find_state_free(dp_ctx* ctx) {
     delete ctx->find_state;
@@ -2680,15 +2719,17 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     A.walk0_blocks = std::max<uint32_t>(1, std::min<uint32_t>(1024, (nq + S_WAVES - 1) / S_WAVES));
     A.n_refs = std::max<uint32_t>(1, ctx->n_seqs);
     A.prof = nullptr;
+    A.prof_walk_slot = 0;
     static const bool chain_prof = getenv("DP_CHAIN_PROF") != nullptr;
     if (chain_prof) {
-        const size_t pb = (size_t)st.passes * st.spec_blocks * S_WAVES * 128;
+        const size_t pb = ((size_t)st.passes * st.spec_blocks * S_WAVES + (size_t)A.walk0_blocks * S_WAVES) * 128;
         if (dev_reserve(ctx, ctx->d_sched, pb + 128)) return DP_ERR_HIP;
         A.prof = (unsigned long long*)ctx->d_sched.p;
+        A.prof_walk_slot = (uint32_t)(st.passes * st.spec_blocks * S_WAVES);
         DP_HIP(hipMemsetAsync(A.prof, 0, pb, ctx->stream));
     }
     A.qdone = fuse_resolve ? d_qdone : nullptr;
-    if (st.attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 128, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
+    if (st.attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, C_CURSOR_BYTES, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
     DP_HIP(dp_mark(ctx, 6));
     dp_launch<pair_scan_kernel>(ctx, dim3(1), dim3(1024), (const uint32_t*)st.d_qcnt, ctx->qoff_dev, nq, d_pbase, d_ibase,
                        d_totals, d_qdone);
@@ -2719,7 +2760,7 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
         if (st.defer_fetch && st.attempt == 0) {
             st.fetch_owed = true;
         } else {
-            const dp_fetch_region f[2] = {{ctx->h_cursor.p, ctx->d_cursor.p, 128}, {ctx->h_qm.p, st.d_qmeta, (size_t)nq * 28}};
+            const dp_fetch_region f[2] = {{ctx->h_cursor.p, ctx->d_cursor.p, C_CURSOR_BYTES}, {ctx->h_qm.p, st.d_qmeta, (size_t)nq * 28}};
             if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, f, 2)) return rc;
         }
     }
@@ -2730,6 +2771,8 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
 // after a wait: what did the attempt report?  *grow: a buffer was too small - capacities raised, run it again
 static int chain_check(dp_ctx* ctx, FindState& st, bool* grow) {
     memcpy(st.cur, ctx->h_cursor.p, 128);
+    st.alg_bytes = 0;
+    for (int i = 0; i < 64; i++) st.alg_bytes += ((const uint64_t*)((const uint8_t*)ctx->h_cursor.p + 128))[i];
     st.chain_ms += dp_elapsed(ctx, 6, 7);
     uint64_t tot_pairs, tot_sints;
     memcpy(&tot_pairs, &st.cur[16], 8);
@@ -2758,34 +2801,47 @@ static int chain_finish(dp_ctx* ctx, FindState& st) {
     static const bool chain_prof = getenv("DP_CHAIN_PROF") != nullptr;
     if (chain_prof && ctx->d_sched.p) {
         const size_t waves = (size_t)st.spec_blocks * S_WAVES;
-        std::vector<unsigned long long> h((size_t)st.passes * waves * 16);
+        const size_t wwaves = (size_t)std::max<uint32_t>(1, std::min<uint32_t>(1024, (st.nq + S_WAVES - 1) / S_WAVES)) * S_WAVES;
+        std::vector<unsigned long long> h(((size_t)st.passes * waves + wwaves) * 16);
         if (hipMemcpy(h.data(), ctx->d_sched.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-            for (int ps = 0; ps < st.passes; ps++) {
-                unsigned long long sum[16] = {0}, t0 = ~0ull, t1 = 0, busiest = 0, mostPairs = 0;
+            for (int ps = -1; ps < st.passes; ps++) {
+                unsigned long long sum[16] = {0}, mx[16] = {0}, t0 = ~0ull, t1 = 0, busiest = 0, mostPairs = 0;
                 size_t active = 0;
-                for (size_t w = 0; w < waves; w++) {
-                    const unsigned long long* r = &h[16 * ((size_t)ps * waves + w)];
+                for (size_t w = 0; w < (ps < 0 ? wwaves : waves); w++) {
+                    const unsigned long long* r = &h[16 * (ps < 0 ? (size_t)st.passes * waves + w : (size_t)ps * waves + w)];
                     if (!r[10]) continue;
                     t0 = std::min(t0, r[10]);
                     t1 = std::max(t1, r[11]);
                     if (!r[0]) continue;
                     active++;
                     for (int i = 0; i < 10; i++) sum[i] += r[i];
+                    for (int i = 2; i < 10; i++) mx[i] = std::max(mx[i], r[i]);
                     for (int i = 12; i < 16; i++) sum[i] += r[i];
                     busiest = std::max(busiest, r[11] - r[10]);
                     mostPairs = std::max(mostPairs, r[0]);
                 }
                 if (!sum[0]) continue;
                 const double n = (double)sum[0], nc = (double)std::max<unsigned long long>(1, sum[1]);
-                fprintf(stderr, "[chain prof] pass %d: %llu pairs (%llu chained) on %zu waves (at most %llu per wave), kernel span %.1f us, busiest wave %.1f us | us per pair: "
+                fprintf(stderr, "[chain prof] pass %d (-1 = walk 0; its 'records' include the candidate list): %llu pairs (%llu chained) on %zu waves (at most %llu per wave), kernel span %.1f us, busiest wave %.1f us | us per pair: "
                                 "records %.2f stage a %.2f prefilter %.2f chain_pair %.2f | per chained pair: stage b + flags %.2f initial %.2f events + walk %.2f (b events %.2f us; %.1f events; %.1f %% perfect chains) out %.2f\n",
                         ps, sum[0], sum[1], active, mostPairs, (t1 - t0) / 100.0, busiest / 100.0, sum[2] / 100.0 / n, sum[3] / 100.0 / n, sum[4] / 100.0 / n,
                         sum[5] / 100.0 / n, sum[6] / 100.0 / nc, sum[7] / 100.0 / nc, sum[8] / 100.0 / nc, sum[12] / 100.0 / nc, sum[13] / nc, 100.0 * sum[14] / nc, sum[9] / 100.0 / nc);
+                {
+                    unsigned long long w5[5] = {0, 0, 0, 0, 0};
+                    for (size_t w = 0; w < (ps < 0 ? wwaves : waves); w++) {
+                        const unsigned long long v = h[16 * (ps < 0 ? (size_t)st.passes * waves + w : (size_t)ps * waves + w) + 15];
+                        for (int i = 0; i < 5; i++) w5[i] += (v >> (12 * i)) & 0xfff;
+                    }
+                    fprintf(stderr, "[chain prof]   walked, not perfect: %llu size limits, %llu event 0 starts no / several chains, %llu start beyond maxBIndex, %llu seed or gap, %llu second start\n",
+                            w5[0], w5[1], w5[2], w5[3], w5[4]);
+                }
+                fprintf(stderr, "[chain prof]   largest per-wave sums, us: records %.1f stage a %.1f prefilter %.1f chain_pair %.1f (stage b %.1f initial %.1f walk %.1f) out %.1f\n",
+                        mx[2] / 100.0, mx[3] / 100.0, mx[4] / 100.0, mx[5] / 100.0, mx[6] / 100.0, mx[7] / 100.0, mx[8] / 100.0, mx[9] / 100.0);
             }
         }
     }
     st.query_ms = dp_elapsed(ctx, 4, 5);
-    st.chain_bytes = (uint64_t)st.cur[4] | ((uint64_t)st.cur[5] << 32);
+    st.chain_bytes = st.alg_bytes;
     if (st.cur[2]) {
         char msg[160];
         snprintf(msg, sizeof msg, "overlap chaining hit a reference capacity limit (bits %u: 1 reduced buffer, 2 state pool, 4 results, 8 nodes)", st.cur[2]);
@@ -2848,7 +2904,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     ctx->last_k = k;
     if (ctx->find_state) ctx->find_state->pending = false;
     const uint32_t M = ctx->n_seqs;
-    if (pin_reserve(ctx, ctx->h_cursor, 128)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_cursor, C_CURSOR_BYTES)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_cand_off, ((size_t)nq + 1) * 8)) return DP_ERR_HIP;
     ((uint64_t*)ctx->h_cand_off.p)[0] = 0;
     out->cand_off = (const uint64_t*)ctx->h_cand_off.p;
@@ -2873,7 +2929,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
         if (rc != 0) return rc;
     }
     st.d_mc = d_mc;
-    if (dev_reserve(ctx, ctx->d_cursor, 128)) return DP_ERR_HIP;  // [0..63] cursor words, [64..] totals (u64 pairs, u64 scratch ints)
+    if (dev_reserve(ctx, ctx->d_cursor, C_CURSOR_BYTES)) return DP_ERR_HIP;  // [0..63] cursor words, [64..] totals (u64 pairs, u64 scratch ints)
     const char* tier_env = getenv("DP_CHAIN_TIER");  // tests: 2 = lds tier, 3 = one-lane tier for every pair
     st.chain_tier = tier_env ? atoi(tier_env) : 0;
     const char* pass_env = getenv("DP_CHAIN_PASSES");  // proposal passes (0 = the serial walk alone: the round-1 behaviour)
@@ -2932,7 +2988,7 @@ int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch, uint32_t*
     FindState* fs = ctx->find_state;
     dp_fetch_region owed[2] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
     if (fs && fs->fetch_owed) {
-        owed[0] = {ctx->h_cursor.p, ctx->d_cursor.p, 128};
+        owed[0] = {ctx->h_cursor.p, ctx->d_cursor.p, C_CURSOR_BYTES};
         owed[1] = {ctx->h_qm.p, fs->d_qmeta, (size_t)fs->nq * 28};
         fs->fetch_owed = false;
     }
@@ -2999,7 +3055,7 @@ int dp_fetch_overlaps_impl(dp_ctx* ctx, int want_candidates, dp_match_batch* out
         dp_launch<chain_pack_kernel>(ctx, dim3(std::min<uint32_t>(2048, (ctx->n_pairs + 3) / 4)), dim3(256), (MRec*)ctx->d_mrec.p, ctx->n_pairs,
                                      (const int32_t*)ctx->d_sa.p, (const int32_t*)ctx->d_sb.p, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p, d_total);
         DP_HIP(hipGetLastError());
-        if (pin_reserve(ctx, ctx->h_cursor, 128)) return DP_ERR_HIP;
+        if (pin_reserve(ctx, ctx->h_cursor, C_CURSOR_BYTES)) return DP_ERR_HIP;
         DP_HIP(hipMemcpyAsync(ctx->h_cursor.p, d_total, 4, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(dp_stream_sync(ctx));
         ctx->last_ni = *(const uint32_t*)ctx->h_cursor.p;
