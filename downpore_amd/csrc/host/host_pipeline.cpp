@@ -149,17 +149,24 @@ void WindowCache::producer() {
             }
         }
         if (rc == 0) {
-            if (d->ctx) memcpy(ch->kmers.data(), ev, n * (size_t)stride * 4);
-            std::vector<uint32_t> both((size_t)numSeeds * 2);
-            for (size_t i = 0; i < n; i++) {  // commitSeeds enters every selected k-mer and its reverse complement
-                const uint32_t* sp = ch->spec.data() + i * (size_t)numSeeds;
-                for (int j = 0; j < numSeeds; j++) {
-                    both[(size_t)j * 2] = sp[j];
-                    both[(size_t)j * 2 + 1] = reverseComplementKmer(sp[j], d->k);
+            // the evaluated k-mers leave the library's pinned block (11 MB per chunk of 8192 windows at config 2) and every window
+            // gets its seed count, in a few slices on the worker pool: alone, this thread took as long over a chunk as the plan
+            // chain takes to walk it, and the planner waited for the cache a quarter of a job
+            const size_t parts = n >= 1024 ? 6 : 1;
+            parallelFor(parts, [&](size_t part) {
+                const size_t i0 = n * part / parts, i1 = n * (part + 1) / parts;
+                if (d->ctx) memcpy(ch->kmers.data() + i0 * (size_t)stride, ev + i0 * (size_t)stride, (i1 - i0) * (size_t)stride * 4);
+                std::vector<uint32_t> both((size_t)numSeeds * 2);
+                for (size_t i = i0; i < i1; i++) {  // commitSeeds enters every selected k-mer and its reverse complement
+                    const uint32_t* sp = ch->spec.data() + i * (size_t)numSeeds;
+                    for (int j = 0; j < numSeeds; j++) {
+                        both[(size_t)j * 2] = sp[j];
+                        both[(size_t)j * 2 + 1] = reverseComplementKmer(sp[j], d->k);
+                    }
+                    std::sort(both.begin(), both.end());
+                    seedCount[w0 + i] = (uint16_t)(std::unique(both.begin(), both.end()) - both.begin());
                 }
-                std::sort(both.begin(), both.end());
-                seedCount[w0 + i] = (uint16_t)(std::unique(both.begin(), both.end()) - both.begin());
-            }
+            });
         }
         std::lock_guard<std::mutex> lk(d->mu);
         if (rc != 0) {
