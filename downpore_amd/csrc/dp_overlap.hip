@@ -1317,7 +1317,8 @@ __device__ int wave_b_events(int bN, int k, LW& L, int cap) {
 // reg tier.  Returns the length of results[0] (its pairs are left in L.rescol as reducedA | bSeed<<6), 0, or -1 when
 // the pair needs the lds tier.
 template <class LW>
-__device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, int k, LW& L, uint32_t* err, ChainProf* cp) {
+__device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, int k, LW& L, uint32_t* err, ChainProf* cp,
+                              bool walkAlways) {
     const bool prof = DP_PROFILING && cp != nullptr;
     const int lane = dp_lane();
     if (startSize == 0) return 0;  // no initial position: no chain can ever start
@@ -1351,7 +1352,7 @@ __device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, i
     // known without walking: nE extensions of chain 0, no removal, results[0] = that chain iff nE >= minMatches (the ratchet
     // only raises minMatches to 2 nE / 3 <= nE).  Anything else: the walk.
     int why = 0;  // (profiling: 0 size limits, 1 event 0 starts no or several chains, 2 start not allowed any more, 3 seed / gap, 4 second start)
-    if (nE >= 2 && nE <= 64 && nE <= (int)LW::COLN && startSize + nE <= C_POOLSTATES) {
+    if (!walkAlways && nE >= 2 && nE <= 64 && nE <= (int)LW::COLN && startSize + nE <= C_POOLSTATES) {
         why = 1;
         const int4 myEv = lane < nE ? L.ev[lane] : make_int4(0, 0, -2, 0);  // {bIndex, bOffset, seed, gap after}
         const u64 m0 = __ballot(myA == RL(myEv.z, 0)) & initMask;
@@ -1901,6 +1902,7 @@ struct ChainArgs {
     uint32_t int_cap;
     uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [8 + pass] "a query is open" flags, [16..19] totals, [32 ..] 64 shards of the algorithmic bytes (u64)
     uint32_t* qdone;     // [nq] pairs of the query a speculative pass has finished (resolve fused into it), or nullptr
+    int walk_always;      // DP_CHAIN_PERFECT=0 (tests): no pair takes the perfect-chain shortcut of wave_chain_reg
     int pack;             // 1: final chains are copied into ma/mb, densely (what a host fetch wants); 0: they stay where they were
                           // chained - the pair's scratch column - and the record's offset points there (ma = sa, mb = sb for the
                           // device consumers; dp_fetch_overlaps packs them then, should a host consumer turn up)
@@ -2065,7 +2067,7 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
             CP_TICK(initial)
             resLen = -1;
             if (aLen <= 64 && (A.tier == 0 || LW::SLIM)) {
-                resLen = wave_chain_reg(aLen, startSize, bN, mm, k, L, &err, cp);
+                resLen = wave_chain_reg(aLen, startSize, bN, mm, k, L, &err, cp, A.walk_always != 0);
                 usedTier = 1;
             }
             if constexpr (LW::SLIM) {
@@ -2704,11 +2706,11 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     {
         // a stage whose consumers are on the device (it stays pending for dp_consensus_paf) leaves the chains in their scratch
         // columns: no cursor atomics, no copies in the walk and resolve kernels (DP_CHAIN_PACK=1: always pack)
-        static const bool always_pack = [] {
-            const char* e = getenv("DP_CHAIN_PACK");
-            return e && e[0] == '1';
-        }();
+        const char* pk = getenv("DP_CHAIN_PACK");  // (read per call: tests switch it between jobs of one process)
+        const bool always_pack = pk && pk[0] == '1';
         A.pack = (st.defer_fetch && !always_pack && st.sint_cap < 0xfffffff0ull) ? 0 : 1;
+        const char* pe = getenv("DP_CHAIN_PERFECT");  // (read per call: tests switch it between jobs of one process)
+        A.walk_always = pe && pe[0] == '0' ? 1 : 0;
         ctx->chains_packed = A.pack != 0;
     }
     A.pair_cap = st.pair_cap;

@@ -680,3 +680,24 @@ def test_consensus_layouts_agree(monkeypatch, k, G, N, L, variable):
         pipe.close()
     assert first_diff(got["1"], want.paf) is None
     assert first_diff(got["0"], want.paf) is None
+
+
+@pytest.mark.parametrize("k,G,N,L,variable,err", [(10, 250000, 1000, 5000, False, 0.0), (13, 3000000, 6000, 10000, False, 0.0),
+                                                   (13, 1500000, 3000, 8000, True, 0.03)])
+def test_chain_shortcuts_agree(monkeypatch, k, G, N, L, variable, err):
+    """The chaining kernels decide a 'perfect chain' (one chain from the first event that every event extends) for all events at
+    once instead of walking them, and leave final chains in their scratch columns when the consumers are on the device.  The same
+    jobs with the walk forced for every pair (DP_CHAIN_PERFECT=0) and with the chains packed (DP_CHAIN_PACK=1) must print the
+    oracle's PAF as well - error-free reads (nearly every pair perfect) and reads with errors (many are not)."""
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(17, G, N, L, err, variable)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    want = O.OverlapRun(rs, k=k, max_rounds=4)
+    for perfect, pack in (("1", "0"), ("0", "0"), ("1", "1")):
+        monkeypatch.setenv("DP_CHAIN_PERFECT", perfect)
+        monkeypatch.setenv("DP_CHAIN_PACK", pack)
+        pipe = OverlapPipeline(Reads(bases, off, min_len=1000), k=k, slots=3)
+        pipe.run(4)
+        got = pipe.all_paf()
+        pipe.close()
+        assert first_diff(got, want.paf) is None, (perfect, pack)
