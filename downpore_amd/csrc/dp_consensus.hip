@@ -703,6 +703,7 @@ struct consensus_full_kernel {
         int pos = -1, offs = 0, gaps = 50, supported = 0, dist = 0, mlen = 0, clen = 0;
         const int kLim = 1 << 28;
         const int ns = nseq;
+        unsigned dbgUni = 0, dbgGen = 0, dbgProp = 0;  // (DP_CONS_DEBUG: uniform steps, general steps, proposers looked at)
         for (;;) {
             int near = 100000;
             const int p2s = pos + 1;
@@ -732,6 +733,7 @@ struct consensus_full_kernel {
                             L.cons[clen + 1] = sd0;
                         }
                         clen += 2;
+                        dbgUni++;
                         if (okS) {
                             pos = p2s;
                             offs = 0;
@@ -745,6 +747,7 @@ struct consensus_full_kernel {
                 }
             }
             supported = 0;
+            dbgGen++;
             const bool fin = !mine || sl == 0 || pos >= (sl - 1) / 2 - 1;
             int fCount = __popcll(__ballot(fin && mine));
             int d = 0, nextSeed = 0, minD = 0, maxD = 0;
@@ -758,77 +761,89 @@ struct consensus_full_kernel {
             }
             if (od >= kLim || od <= -kLim || gaps >= kLim || d >= kLim || d <= -kLim || dist >= kLim || dist <= -kLim) bad = true;
             if (__ballot(bad)) break;
+            // Support of every proposer, in sequence order (`near` shrinks as proposers are seen, :70-76).  Proposers that follow
+            // each other with the same proposal {d, seed, window} - at e = 0 nearly all of them - are one step here: the first
+            // sets `near`, the others meet the very same test after it (near does not move again inside the run), the search
+            // (which depends on the proposal and the searching lane only) is made once, every accepted member takes its numbers.
             unsigned long long cand = __ballot(!fin);
-            bool memoOk = false;
-            int memoD = 0, memoSeed = 0, memoMin = 0, memoMax = 0, memoCnt = 0, memoSum = 0;
-            bool fnd = false;
-            int val = 0;
+            bool fnd = false, memoOk = false;
+            int val = 0, memoD = 0, memoSeed = 0, memoMin = 0, memoMax = 0, cntAll = 0, sumAll = 0;
             while (cand) {
                 const int i = __builtin_ctzll(cand);
-                cand &= cand - 1;
                 const int di = CA_RL(d, i);
-                if (!(di < near && di > -k)) continue;
                 const int seedI = CA_RL(nextSeed, i), minI = CA_RL(minD, i), maxI = CA_RL(maxD, i);
+                const unsigned long long same = __ballot(!fin && d == di && nextSeed == seedI && minD == minI && maxD == maxI) & cand;
+                const unsigned long long others = cand & ~same;
+                const unsigned long long run = others ? (same & ((1ull << __builtin_ctzll(others)) - 1ull)) : same;  // (holds bit i)
+                cand &= ~run;
+                if (!(di < near && di > -k)) continue;  // (so would every member of the run: same d, same near)
                 if (near > maxI) near = maxI;
-                if (!(memoOk && memoD == di && memoSeed == seedI && memoMin == minI && memoMax == maxI)) {
-                    fnd = false;
-                    val = 0;
-                    if (okS) {
-                        int min2, max2;
-                        ca_gap_range(di + gaps, k, min2, max2);
-                        if (min2 > minI) min2 = minI;
-                        if (max2 < maxI) max2 = maxI;
-                        int p2 = p2s, otherD = od;
-                        while (otherD < min2 && p2 < sl / 2) {
-                            p2++;
-                            otherD += S[b + p2 * 2] + k;
-                        }
-                        while (otherD < max2 && p2 < sl / 2) {
-                            if (S[b + p2 * 2 + 1] == seedI) {
-                                fnd = true;
-                                val = otherD;
-                                break;
-                            }
-                            p2++;
-                            otherD += S[b + p2 * 2] + k;
-                        }
+                const unsigned long long accepted = di < near ? run : (1ull << i);  // the members after the first meet the new near
+                if (!(memoOk && memoD == di && memoSeed == seedI && memoMin == minI && memoMax == maxI)) {  // (else: the search just made)
+                memoOk = true, memoD = di, memoSeed = seedI, memoMin = minI, memoMax = maxI;
+                dbgProp++;
+                fnd = false;
+                val = 0;
+                if (okS) {
+                    int min2, max2;
+                    ca_gap_range(di + gaps, k, min2, max2);
+                    if (min2 > minI) min2 = minI;
+                    if (max2 < maxI) max2 = maxI;
+                    int p2 = p2s, otherD = od;
+                    while (otherD < min2 && p2 < sl / 2) {
+                        p2++;
+                        otherD += S[b + p2 * 2] + k;
                     }
-                    memoCnt = __popcll(__ballot(fnd));
-                    memoSum = wave_sum(fnd ? val : 0);
-                    memoOk = true;
-                    memoD = di;
-                    memoSeed = seedI;
-                    memoMin = minI;
-                    memoMax = maxI;
+                    while (otherD < max2 && p2 < sl / 2) {
+                        if (S[b + p2 * 2 + 1] == seedI) {
+                            fnd = true;
+                            val = otherD;
+                            break;
+                        }
+                        p2++;
+                        otherD += S[b + p2 * 2] + k;
+                    }
                 }
-                if (lane == i) {
-                    supported = 1 + memoCnt - (fnd ? 1 : 0);
-                    dist += memoSum - (fnd ? val : 0);
+                cntAll = __popcll(__ballot(fnd));
+                sumAll = wave_sum(fnd ? val : 0);
+                }
+                if ((accepted >> lane) & 1ull) {
+                    supported = 1 + cntAll - (fnd ? 1 : 0);
+                    dist += sumAll - (fnd ? val : 0);
                 }
             }
             if (fCount >= ns) break;
             int minseed = -1, mindist = 0, minsup = 0, selMin = 0, selMax = 0;
+            // (mean distance and window of every supported proposer at once - one vector division per step instead of one per
+            // proposer; the walk over them keeps the order dependence of :141-160)
+            const int myDv = supported > 1 ? dist / supported : dist;
             {
+                int myMin, myMax;
+                ca_gap_range(myDv + gaps, k, myMin, myMax);
+                myMin -= gaps;
+                myMax -= gaps;
+                int winner = -1;
                 unsigned long long sup = __ballot(supported > 1);
                 while (sup) {
                     const int i = __builtin_ctzll(sup);
                     sup &= sup - 1;
                     const int si = CA_RL(supported, i);
-                    const int dv = CA_RL(dist, i) / si;
+                    const int dv = CA_RL(myDv, i);
                     const int seed = CA_RL(nextSeed, i);
                     if (minseed == -1 || (minseed == seed && si > minsup) || (minseed != seed && mindist > dv)) {
                         minsup = si;
                         mindist = dv;
                         minseed = seed;
-                        const int gi = CA_RL(gaps, i);
-                        ca_gap_range(dv + gi, k, selMin, selMax);
-                        selMin -= gi;
-                        selMax -= gi;
+                        winner = i;
                     }
+                }
+                if (winner >= 0) {
+                    selMin = CA_RL(myMin, winner);
+                    selMax = CA_RL(myMax, winner);
                 }
             }
             if (minseed == -1) {
-                const int dvv = supported > 1 ? dist / supported : dist;
+                const int dvv = myDv;
                 const bool can = mine && sl > 0 && pos < ns / 2;
                 int best = can ? dvv : 0x7fffffff;
 #pragma unroll
@@ -898,6 +913,10 @@ struct consensus_full_kernel {
                 }
             }
             if (__popcll(__ballot(finC && mine)) >= ns) break;
+        }
+        if (A.dbg && lane == 0) {
+            A.dbg[8 * (size_t)g + 6] = ((unsigned long long)dbgUni << 32) | dbgGen;
+            A.dbg[8 * (size_t)g + 7] = ((unsigned long long)nseq << 32) | dbgProp;
         }
         if (__ballot(bad)) CF_NOFIT()
         if (lane == 0) L.cons[clen] = 0;
@@ -1210,6 +1229,24 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
             const double t = (double)(h[8 * (size_t)g + 5] - h[8 * (size_t)g]) / 100.0;
             tot += t;
             totmx = std::max(totmx, t);
+        }
+        {
+            double su = 0, sg = 0, sp = 0, sn = 0;
+            uint32_t slow = 0;
+            double slowT = 0;
+            for (uint32_t g = 0; g < ng; g++) {
+                if (!h[8 * (size_t)g + 5]) continue;
+                su += (double)(h[8 * (size_t)g + 6] >> 32);
+                sg += (double)(h[8 * (size_t)g + 6] & 0xffffffffu);
+                sp += (double)(h[8 * (size_t)g + 7] & 0xffffffffu);
+                sn += (double)(h[8 * (size_t)g + 7] >> 32);
+                const double t = (double)(h[8 * (size_t)g + 4] - h[8 * (size_t)g + 3]);
+                if (t > slowT) slowT = t, slow = g;
+            }
+            if (cnt)
+                fprintf(stderr, "[cons] steps per window: %.1f uniform, %.1f general (%.1f proposer searches), %.1f sequences | slowest align %.1f us: %llu uniform, %llu general, %llu searches, %llu sequences\n",
+                        su / cnt, sg / cnt, sp / cnt, sn / cnt, slowT / 100.0, h[8 * (size_t)slow + 6] >> 32, h[8 * (size_t)slow + 6] & 0xffffffffu,
+                        h[8 * (size_t)slow + 7] & 0xffffffffu, h[8 * (size_t)slow + 7] >> 32);
         }
         if (cnt)
             fprintf(stderr, "[cons] kernel %.3f ms, %u of %u groups complete | us mean/max: gather+query %.1f/%.1f trim %.1f/%.1f shared+reduce %.1f/%.1f "
