@@ -2569,7 +2569,9 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
         const char* e = getenv("DP_QUERY_OWN_ZERO");  // 0: the rows are cleared by the launch before (the round-2 behaviour)
         return !(e && e[0] == '0');
     }();
-    const bool own_rows = own_rows_env && q_split == 1;
+    // (short rows only - the sparse regime: a few hundred words per query; the dense regime's rows - W ~ 3 k words - are cleared
+    // faster by the launch over all of them, and its index query is the kernel the bandwidth figure is quoted on)
+    const bool own_rows = own_rows_env && q_split == 1 && (size_t)W + SW <= 1024;
     {   // (the chaining stage's cursor block rides along: it is zero when the first attempt starts; and the same launch fetches
         // the upload block from its pinned staging - no copy is handed to the runtime)
         // (with one workgroup per query - the default - the light query kernel clears its query's rows itself and this launch only
