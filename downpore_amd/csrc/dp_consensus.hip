@@ -521,19 +521,39 @@ struct consensus_full_kernel {
                 int ca = len * k, cb = len * k;
                 int prevA = MA[0], prevB = MB[0];
                 if (prevA < 0 || prevA >= sA || prevB < 0 || prevB >= ns) laneBad = true;
-                for (int i = 1; i < len && !laneBad; i++) {
-                    const int a1 = MA[i], b1 = MB[i];
-                    if (a1 >= sA || a1 < 0 || b1 >= ns || b1 < 0) {
-                        laneBad = true;  // the reference would panic inside GetBasesCovered: leave the group to the host path
-                        break;
+                // (eight matched pairs per trip: their sixteen loads, then the first gap of each pair's stretch of the target - nearly
+                // always the whole stretch - are issued together; one pair per trip was a chain of two dependent loads per pair)
+                for (int i0 = 1; i0 < len && !laneBad; i0 += 8) {
+                    int av[8], bv[8], g0[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const bool v = i0 + u < len;
+                        av[u] = v ? MA[i0 + u] : 0;
+                        bv[u] = v ? MB[i0 + u] : 0;
                     }
-                    const int dA = isRc ? L.GA[sA - 1 - prevA] - L.GA[sA - 1 - a1] - k : L.GA[a1] - L.GA[prevA] - k;
-                    int dB = -k;
-                    for (int j = prevB + 1; j <= b1; j++) dB += S[2 * j] + k;
-                    if (dA < 0) ca += dA;
-                    if (dB < 0) cb += dB;
-                    prevA = a1;
-                    prevB = b1;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int pb = u == 0 ? prevB : bv[u - 1];
+                        const int j = min(max(pb + 1, 0), ns);  // (clamped: a list the checks below reject must not be followed)
+                        g0[u] = i0 + u < len ? S[2 * j] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (i0 + u >= len || laneBad) continue;
+                        const int a1 = av[u], b1 = bv[u];
+                        if (a1 >= sA || a1 < 0 || b1 >= ns || b1 < 0) {
+                            laneBad = true;  // the reference would panic inside GetBasesCovered: leave the group to the host path
+                            continue;
+                        }
+                        const int dA = isRc ? L.GA[sA - 1 - prevA] - L.GA[sA - 1 - a1] - k : L.GA[a1] - L.GA[prevA] - k;
+                        int dB = -k;
+                        if (b1 >= prevB + 1) dB += g0[u] + k;
+                        for (int j = prevB + 2; j <= b1; j++) dB += S[2 * j] + k;
+                        if (dA < 0) ca += dA;
+                        if (dB < 0) cb += dB;
+                        prevA = a1;
+                        prevB = b1;
+                    }
                 }
                 if (!laneBad && ca >= 25 && cb >= 25) {
                     // indices in the forward query / in X (X = the target, or its reverse complement for a match of the rc query)
@@ -587,13 +607,26 @@ struct consensus_full_kernel {
                 const dp_seq_meta sm = A.smeta[t];
                 const int nB = 2 * ns + 1;
                 int wide = 0;  // (small layout: a value that does not fit 16 bits sends the window to the large one)
-                for (int j = 0; j < nT; j++) {
-                    const int x = 2 * startSeed + j;  // index in X
-                    int v;
-                    if (!isRc) v = S[x];
-                    else v = (x & 1) ? A.rc_of[S[nB - 1 - x]] : S[nB - 1 - x];
-                    L.T[tb + j] = (elem_t)v;
-                    wide |= (v != (int)(elem_t)v);
+                for (int j0 = 0; j0 < nT; j0 += 8) {  // (eight loads in flight per trip, then - reverse complement - their eight look-ups)
+                    int vv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int x = 2 * startSeed + j0 + u;  // index in X
+                        vv[u] = j0 + u < nT ? (isRc ? S[nB - 1 - x] : S[x]) : 0;
+                    }
+                    if (isRc) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int x = 2 * startSeed + j0 + u;
+                            if (j0 + u < nT && (x & 1)) vv[u] = A.rc_of[vv[u]];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (j0 + u >= nT) continue;
+                        L.T[tb + j0 + u] = (elem_t)vv[u];
+                        wide |= (vv[u] != (int)(elem_t)vv[u]);
+                    }
                 }
                 L.T[tb] = (elem_t)startOffset;
                 L.T[tb + nT - 1] = (elem_t)endOffset;
