@@ -1226,7 +1226,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     A.nseq_dst = h_nseq;
     DP_HIP(dp_mark(ctx, 0));
     if (use_small) dp_launch<consensus_full_kernel<true>>(ctx, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), A);
-    dp_launch<consensus_full_kernel<false>>(ctx, dim3(std::min<uint32_t>(ng, use_small ? 512u : 4096u)), dim3(64), A);
+    dp_launch<consensus_full_kernel<false>>(ctx, dim3(std::min<uint32_t>(ng, use_small ? 96u : 4096u)), dim3(64), A);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 1));
     DP_HIP(dp_stream_sync(ctx));

@@ -2752,7 +2752,10 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
         if (!fuse_resolve) dp_launch<chain_resolve_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), A);
     }
     A.pass = st.passes;
-    dp_launch<chain_walk_kernel<false>>(ctx, dim3(st.walk_blocks), dim3(64 * C_WAVES), A, 2);
+    // the final walk rarely has a query to do after the passes: a quarter of the workgroups (each wants 128 KB of a CU's LDS before it
+    // can look whether there is anything to do) - a query that is still open finds a wave among 192
+    if (st.passes > 0) A.walk_blocks = std::min<uint32_t>(st.walk_blocks, 48);
+    dp_launch<chain_walk_kernel<false>>(ctx, dim3(A.walk_blocks), dim3(64 * C_WAVES), A, 2);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 7));
     {
