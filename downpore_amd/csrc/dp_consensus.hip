@@ -685,6 +685,7 @@ struct consensus_full_kernel {
             }
         };
         int kept = 0;
+        u64 keptMask = 0;  // (the first 64 seeds' verdicts: the second walk below does not probe the hash again for them)
         {
             int prev = -1;
             for (int i = 0; i < nsT_; i++) {
@@ -692,6 +693,7 @@ struct consensus_full_kernel {
                 if (seed != prev && cf_shared(seed)) {
                     kept++;
                     prev = seed;
+                    if (i < 64) keptMask |= 1ull << i;
                 }
             }
         }
@@ -708,7 +710,7 @@ struct consensus_full_kernel {
                     int prev = -1, r = 0, offset = L.T[tb_];
                     for (int i = 0; i < nsT_; i++) {
                         const int seed = L.T[tb_ + 2 * i + 1];
-                        if (seed != prev && cf_shared(seed)) {
+                        if (i < 64 ? ((keptMask >> i) & 1ull) != 0 : (seed != prev && cf_shared(seed))) {
                             L.R[rb + 2 * r] = (elem_t)offset;
                             laneWide |= SMALL && offset != (int)(elem_t)offset;
                             L.R[rb + 2 * r + 1] = (elem_t)seed;
