@@ -133,6 +133,10 @@ struct dp_ctx {
     DevBuf d_pbase, d_pspec, d_clist, d_sa, d_sb;  // chaining stage: pair offsets, proposals, candidate lists, scratch columns
     uint32_t n_pairs = 0;                          // (query, candidate) pair slots of the last dp_find_overlaps
     uint32_t last_nq = 0, last_ni = 0;             // its queries / packed chain ints
+    size_t q_pre_bytes = 0;                        // dp_query_prestage: bytes of the announced query block in h_qup (0: none)
+    uint32_t q_pre_nq = 0;
+    double q_pre_hf = 0;
+    bool q_pre_fetched = false;                    // ... and a launch has brought it to d_qsegs
     uint64_t last_sints = 0;                       // scratch ints of the last chaining stage (all pairs' columns)
     bool chains_packed = true;                     // false: the final chains sit in the scratch columns (d_sa/d_sb), see ChainArgs.pack
     int last_k = 0;

@@ -149,6 +149,10 @@ struct ChunkParams {
     uint4* z_p[2];
     unsigned long long z_n16[2];
     uint32_t zero_blocks;
+    // ... and they bring an announced query block over (dp_query_prestage): 16-byte words, pinned host memory -> device
+    uint4* f_dst;
+    const uint4* f_src;
+    unsigned long long f_n16;
 };
 
 template <bool WRITE>
@@ -247,6 +251,8 @@ struct chunk_kernel {
     if (blockIdx.x >= n_tiles) {
         const uint32_t zb = blockIdx.x - n_tiles;
         if (zb >= P.zero_blocks) return;
+        for (unsigned long long j = (unsigned long long)zb * 1024 + threadIdx.x; j < P.f_n16; j += (unsigned long long)P.zero_blocks * 1024)
+            P.f_dst[j] = P.f_src[j];
         const uint4 zero = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 2; r++)
@@ -386,6 +392,15 @@ extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t o
         P.z_p[1] = (uint4*)ctx->d_seedsets.p;
         P.z_n16[1] = zb_sets / 16;
         P.zero_blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(512, (std::max(zb_post, zb_sets) / 16 + 4095) / 4096));
+        P.f_dst = nullptr;
+        P.f_src = nullptr;
+        P.f_n16 = 0;
+        if (ctx->q_pre_bytes && !ctx->q_pre_fetched && ctx->h_qup.p && ctx->d_qsegs.p) {  // (both blocks are 64 bytes longer than the data)
+            P.f_dst = (uint4*)ctx->d_qsegs.p;
+            P.f_src = (const uint4*)ctx->h_qup.p;
+            P.f_n16 = (ctx->q_pre_bytes + 15) / 16;
+            ctx->q_pre_fetched = true;
+        }
         dp_launch<chunk_kernel>(ctx, dim3(n_tiles + P.zero_blocks), dim3(1024), P, (unsigned long long*)((uint8_t*)ctx->d_nseqs.p + 64),
                            (uint32_t*)ctx->d_nseqs.p + 2);
         DP_HIP(hipGetLastError());
@@ -2522,11 +2537,10 @@ static uint32_t query_dbg_flags() {
     return f;
 }
 
-// Uploads the queries, builds their seed bitsets and runs the index query (Matches -> GetSharedIDs) for all of them.
-// Leaves d_qsegs/d_qoff/d_qsets/d_cand/d_qmeta on the device.  Events ev[4]/ev[5] bracket the query kernel.
-int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
-                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out) {
-    const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
+// What the host sends for the query stage - query offsets, query segments, the minCount table - as one block in the context's
+// pinned staging area, laid out as it will lie on the device.  Returns the block's size (0: nothing to send).
+static size_t query_block_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t* mc_n_out,
+                                uint32_t* max_seeds_out, int32_t* mc_last_out, size_t* up_off_out, size_t* up_segs_out) {
     const uint64_t nseg = nq ? q_off[nq] : 0;
     // int(hitFraction*float64(n)+0.5) for every n that can occur (seeds/seeds.go:351, overlap/overlap.go:356);
     // evaluated on the host in IEEE double (this file is built with -ffp-contract=off)
@@ -2539,9 +2553,72 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
         volatile double sum = prod + 0.5;
         mc[n] = (int32_t)sum;
     }
-    // what the host sends - query offsets, query segments, the minCount table - is one block on both sides: one copy
     const size_t up_segs = nseg * 4, up_off = ((size_t)nq + 1) * 8, up_mc = (size_t)mc_n * 4;
-    if (dev_reserve(ctx, ctx->d_qsegs, up_off + up_segs + up_mc + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_qsegs, up_off + up_segs + up_mc + 64)) return 0;
+    // stage through pinned memory: copies from pageable buffers stall the stream
+    if (pin_reserve(ctx, ctx->h_qup, up_segs + up_off + up_mc + 64)) return 0;
+    uint8_t* up = (uint8_t*)ctx->h_qup.p;
+    memcpy(up, q_off, up_off);
+    memcpy(up + up_off, q_segs, up_segs);
+    memcpy(up + up_off + up_segs, mc.data(), up_mc);
+    *mc_n_out = mc_n;
+    *max_seeds_out = maxSeeds;
+    *mc_last_out = mc[maxSeeds];
+    *up_off_out = up_off;
+    *up_segs_out = up_segs;
+    return up_off + up_segs + up_mc;
+}
+
+// The queries of the round's coming dp_find_overlaps, announced before the index is built: they are staged now and the next
+// launch with room for it - dp_index_build_chunked's first kernel - brings them to the device, so that the query stage starts
+// with its kernel (no upload launch, no staging between the index build and the query kernel).  dp_find_overlaps recognises the
+// block by comparing; anything else in between simply makes it upload as before.
+extern "C" int dp_query_prestage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t n_queries, double hit_fraction) {
+    if (!ctx || (n_queries && (!q_segs || !q_off))) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_query_prestage: bad arguments") : DP_ERR_ARG;
+    ctx->q_pre_bytes = 0;
+    ctx->q_pre_fetched = false;
+    if (!n_queries) return DP_OK;
+    hipSetDevice(ctx->device);
+    uint32_t mc_n = 0, maxSeeds = 0;
+    int32_t mcLast = 0;
+    size_t up_off = 0, up_segs = 0;
+    const size_t bytes = query_block_stage(ctx, q_segs, q_off, n_queries, hit_fraction, &mc_n, &maxSeeds, &mcLast, &up_off, &up_segs);
+    if (!bytes) return DP_ERR_HIP;
+    ctx->q_pre_bytes = bytes;
+    ctx->q_pre_nq = n_queries;
+    ctx->q_pre_hf = hit_fraction;
+    return DP_OK;
+}
+
+// Uploads the queries, builds their seed bitsets and runs the index query (Matches -> GetSharedIDs) for all of them.
+// Leaves d_qsegs/d_qoff/d_qsets/d_cand/d_qmeta on the device.  Events ev[4]/ev[5] bracket the query kernel.
+int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
+                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out) {
+    const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
+    // what the host sends - query offsets, query segments, the minCount table - is one block on both sides: one copy.  Announced
+    // and on the device already (dp_query_prestage + the index build's first launch)?  Then it is only compared.
+    uint32_t mc_n = 0, maxSeeds = 0;
+    int32_t mcLast = 0;
+    size_t up_off = ((size_t)nq + 1) * 8, up_segs = (size_t)(nq ? q_off[nq] : 0) * 4;
+    bool on_device = false;
+    if (ctx->q_pre_bytes && ctx->q_pre_fetched && ctx->q_pre_nq == nq && ctx->q_pre_hf == hf && ctx->q_pre_bytes >= up_off + up_segs &&
+        ctx->h_qup.p && memcmp(ctx->h_qup.p, q_off, up_off) == 0 && memcmp((const uint8_t*)ctx->h_qup.p + up_off, q_segs, up_segs) == 0) {
+        for (uint32_t q = 0; q < nq; q++) maxSeeds = std::max<uint32_t>(maxSeeds, (uint32_t)((q_off[q + 1] - q_off[q]) / 2));
+        mc_n = std::max<uint32_t>(maxSeeds + 1, 8);
+        if (ctx->q_pre_bytes == up_off + up_segs + (size_t)mc_n * 4) {
+            mcLast = ((const int32_t*)((const uint8_t*)ctx->h_qup.p + up_off + up_segs))[maxSeeds];
+            on_device = true;
+        }
+    }
+    if (!on_device && ctx->q_pre_fetched) DP_HIP(dp_stream_sync(ctx));  // (a launch may still be copying the announced block)
+    ctx->q_pre_bytes = 0;
+    ctx->q_pre_fetched = false;
+    if (!on_device) {
+        const size_t bytes = query_block_stage(ctx, q_segs, q_off, nq, hf, &mc_n, &maxSeeds, &mcLast, &up_off, &up_segs);
+        if (!bytes) return DP_ERR_HIP;
+    }
+    const size_t up_mc = (size_t)mc_n * 4;
+    uint8_t* up = (uint8_t*)ctx->h_qup.p;
     ctx->qoff_dev = (const u64*)ctx->d_qsegs.p;
     ctx->qsegs_dev = (const int32_t*)((const uint8_t*)ctx->d_qsegs.p + up_off);
     if (dev_reserve(ctx, ctx->d_qsets, (size_t)nq * SW * 8 + 64)) return DP_ERR_HIP;
@@ -2551,13 +2628,6 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     u64* d_words = (u64*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 16);
     uint32_t* d_qcnt = (uint32_t*)((uint8_t*)ctx->d_qmeta.p + (size_t)nq * 24);
     const int32_t* d_mc = (const int32_t*)((const uint8_t*)ctx->d_qsegs.p + up_off + up_segs);
-    // stage through pinned memory: copies from pageable buffers stall the stream
-    // (pinned: for these larger blocks the pinned source measured faster than a pageable one, unlike the small per-round inputs)
-    if (pin_reserve(ctx, ctx->h_qup, up_segs + up_off + up_mc + 64)) return DP_ERR_HIP;
-    uint8_t* up = (uint8_t*)ctx->h_qup.p;
-    memcpy(up, q_off, up_off);
-    memcpy(up + up_off, q_segs, up_segs);
-    memcpy(up + up_off + up_segs, mc.data(), up_mc);
     if (dev_reserve(ctx, ctx->d_cursor, C_CURSOR_BYTES)) return DP_ERR_HIP;
     // workgroups per query (DP_QUERY_SPLIT, experiments: see query_kernel)
     static const int split_env = [] {
@@ -2579,7 +2649,7 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
         const dp_zero_region z[4] = {{ctx->d_qsets.p, (size_t)nq * SW * 8}, {ctx->d_cand.p, (size_t)nq * W * 8}, {d_qmeta, (size_t)nq * 28},
                                      {ctx->d_cursor.p, C_CURSOR_BYTES}};
         const dp_fetch_region f = {ctx->d_qsegs.p, up, up_off + up_segs + up_mc};
-        if (int rc = dp_zero_fetch_regions(ctx, z, own_rows ? 0 : 4, &f, 1)) return rc;
+        if (int rc = dp_zero_fetch_regions(ctx, z, own_rows ? 0 : 4, &f, on_device ? 0 : 1)) return rc;  // (nothing at all: no launch)
     }
     DP_HIP(dp_mark(ctx, 4));
     dp_launch<query_kernel<false>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
@@ -2589,7 +2659,7 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
                        ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
                        query_dbg_flags(), q_split, own_rows ? (u64*)ctx->d_cursor.p : (u64*)nullptr);
     // the 16-ladder / exact-count regimes start at minCount 13: only a batch with a query of that many seeds needs the heavy variant
-    if (mc[maxSeeds] >= 13) dp_launch<query_kernel<true>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
+    if (mcLast >= 13) dp_launch<query_kernel<true>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,

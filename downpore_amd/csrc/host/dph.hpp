@@ -409,6 +409,8 @@ class Overlapper {
     int minSeeds_;
     double hitFraction_;
     std::vector<Window> windows_;
+    void assembleQueries();
+    bool assembled_ = false;  // querySegs_ / queryOff_ hold the current `queries`
     std::vector<int32_t> querySegs_;       // fwd/rc query segments (host)
     std::vector<uint64_t> queryOff_;
     TextPool* textPool_ = nullptr;

@@ -75,6 +75,7 @@ int Overlapper::prepareFromCache(int numSeeds, i64 seedLimit, ValueView values, 
 int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, ValueView values, i64 firstSequence, i64 maxSeqs, int queryType) {
     windows_.clear();
     queries.clear();
+    assembled_ = false;
     const bool weightSides = (queryType & 8) != 0;  // WeightEdges: seeds come from the two 200-base sides of a window
     if (weightSides) numSeeds /= 2;                  // overlap.go:161-163
     if (numSeeds < 1) return 0;
@@ -389,6 +390,23 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
         // its scan buffer
         index_.sequences.clear();
         index_.refs.clear();
+        // the queries first (they come from the scan's output, not from the index): announced to the library, they travel to the
+        // device with the index build's first launch, and the query stage starts with its kernel (dp_query_prestage)
+        const double tq0 = now();
+        buildQueries(st);
+        assembleQueries();
+        static const bool prestage = [] {
+            const char* e = getenv("DP_QUERY_PRESTAGE");
+            return !(e && e[0] == '0');
+        }();
+        if (prestage && !queries.empty()) {
+            int prc = dp_query_prestage(ctx_, querySegs_.data(), queryOff_.data(), (uint32_t)queries.size(), hitFraction_);
+            if (prc != 0) {
+                err = dp_last_error(ctx_);
+                return prc;
+            }
+        }
+        const double tq1 = now();
         uint32_t cap = 0;
         int rc = dp_index_build_chunked(ctx_, chunkSize_, overlap_, (uint32_t)minSeeds_, (int32_t)reads_.servedInset(), (uint32_t)all.read.size(), &cap);
         if (rc != 0) {
@@ -399,12 +417,10 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
         nIndexedCap_ = cap;
         nIndexedExact_ = 0;
         st.n_indexed = cap;  // (an upper bound until the consensus call reports the exact number)
-        const double tpd = now();
         g_prof.add(5, 0);
         g_prof.add(6, 0);
-        g_prof.add(7, tpd - tp0);
-        buildQueries(st);
-        g_prof.add(8, now() - tpd);
+        g_prof.add(7, now() - tq1 + (tq0 - tp0));
+        g_prof.add(8, tq1 - tq0);
         return 0;
     }
     const int32_t* fetched = nullptr;
@@ -479,7 +495,20 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
 }
 
 // queries: [fwd, rc] per window (PrepareQueries :189-201), from the windows' scan output
+// the queries' segment arrays in one block, as dp_find_overlaps / dp_query_prestage take them
+void Overlapper::assembleQueries() {
+    if (assembled_) return;
+    assembled_ = true;
+    querySegs_.clear();
+    queryOff_.assign(1, 0);
+    for (const SeedQuery& q : queries) {
+        querySegs_.insert(querySegs_.end(), q.Query->seg, q.Query->seg + q.Query->n);
+        queryOff_.push_back(querySegs_.size());
+    }
+}
+
 void Overlapper::buildQueries(RoundStats& st) {
+    assembled_ = false;
     queries.clear();
     int queryID = 0;
     for (size_t w = 0; w < windows_.size(); w++) {
@@ -554,12 +583,7 @@ int Overlapper::materializeChunks() {
 int Overlapper::FindOverlaps(std::vector<SeedMatch>& pool, std::vector<SeedMatch*>& out, RoundStats& st) {
     if (int rcm = materializeChunks()) return rcm;  // (this path works on host objects)
     if (chunksOnDevice_) st.n_indexed = index_.sequences.size();
-    querySegs_.clear();
-    queryOff_.assign(1, 0);
-    for (const SeedQuery& q : queries) {
-        querySegs_.insert(querySegs_.end(), q.Query->seg, q.Query->seg + q.Query->n);
-        queryOff_.push_back(querySegs_.size());
-    }
+    assembleQueries();
     dp_match_batch mb;
     const double tq0 = now();
     int rc = dp_find_overlaps(ctx_, querySegs_.data(), queryOff_.data(), (uint32_t)queries.size(), hitFraction_, index_.k,
@@ -614,12 +638,7 @@ static inline char* putInt(char* w, i64 v) {  // %d
 
 int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 overlapSize, std::string& paf, FinalCheckStats& fs,
                                           std::vector<int>* ignoreOut, RoundStats& st, std::shared_ptr<TextJob>* textOut) {
-    querySegs_.clear();
-    queryOff_.assign(1, 0);
-    for (const SeedQuery& q : queries) {
-        querySegs_.insert(querySegs_.end(), q.Query->seg, q.Query->seg + q.Query->n);
-        queryOff_.push_back(querySegs_.size());
-    }
+    assembleQueries();
     dp_match_batch mb;
     const double tq0 = now();
     // want_candidates 6: the matches stay on the device and the stage is left pending - dp_consensus_paf below evaluates it in the

@@ -256,6 +256,13 @@ typedef struct {
 DP_API int dp_find_overlaps(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t n_queries,
                      double hit_fraction, int k, uint32_t max_query_len, int want_candidates, dp_match_batch* out);
 
+/* Optional: announces the queries of the round's coming dp_find_overlaps before the index is built (matchWorker's queries are
+ * known as soon as the scan is: overlap/overlap.go:200-214 builds them from the scan's output).  The library stages them now
+ * and the index build's first launch (dp_index_build_chunked) carries them to the device, so that the query stage starts with
+ * its kernel.  dp_find_overlaps must then be given arrays of the same content; with any other content, or when no launch came
+ * in between, it simply uploads as it always did.  The arrays are borrowed for the duration of the call only. */
+DP_API int dp_query_prestage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t n_queries, double hit_fraction);
+
 /* ---- A19 + A20: map-flavour query (mapping.performMapping core) -----------------------------------------------
  * For each window: Matches(0.25) candidates, CountIntersectionTo prefilter and SeedSequence.Match
  * (Reduced x2 -> dynamicMatch -> extendChain; seeds/sequence.go:361-576) with the minMatches ratchet of

@@ -586,6 +586,21 @@ func (c *Context) FindOverlapsOnDevice(qSegs []int32, qOff []uint64, hitFraction
 	return nil
 }
 
+// QueryPrestage announces the queries of the round's coming FindOverlapsOnDevice before IndexBuildChunked is called: the
+// index build's first launch then carries them to the device and the query stage starts with its kernel.  Optional; the
+// later FindOverlaps* call must be given slices of the same content.
+func (c *Context) QueryPrestage(qSegs []int32, qOff []uint64, hitFraction float64) error {
+	if len(qOff) < 2 || len(qSegs) == 0 {
+		return nil
+	}
+	rc := C.dp_query_prestage(c.h, (*C.int32_t)(unsafe.Pointer(&qSegs[0])), (*C.uint64_t)(unsafe.Pointer(&qOff[0])), C.uint32_t(len(qOff)-1),
+		C.double(hitFraction))
+	if rc != 0 {
+		return fail(c.h, "dp_query_prestage", rc)
+	}
+	return nil
+}
+
 // PAFRecord is one PAF line without its names (commands/overlap.go:223-228); Group one query window's lines and SetIgnore ids.
 type PAFRecord struct {
 	QRead, TRead         uint32
