@@ -861,10 +861,14 @@ struct consensus_full_kernel {
                 unsigned long long sup = __ballot(supported > 1);
                 while (sup) {
                     const int i = __builtin_ctzll(sup);
-                    sup &= sup - 1;
                     const int si = CA_RL(supported, i);
                     const int dv = CA_RL(myDv, i);
                     const int seed = CA_RL(nextSeed, i);
+                    // (supported proposers that follow each other with the same {seed, support, mean distance} are decided by the
+                    // first of them: taken, the rest find their own numbers in place; not taken, the rest meet the same state)
+                    const unsigned long long same = __ballot(supported == si && myDv == dv && nextSeed == seed) & sup;
+                    const unsigned long long others = sup & ~same;
+                    sup &= ~(others ? (same & ((1ull << __builtin_ctzll(others)) - 1ull)) : same);
                     if (minseed == -1 || (minseed == seed && si > minsup) || (minseed != seed && mindist > dv)) {
                         minsup = si;
                         mindist = dv;
@@ -1277,6 +1281,20 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
                 sn += (double)(h[8 * (size_t)g + 7] >> 32);
                 const double t = (double)(h[8 * (size_t)g + 4] - h[8 * (size_t)g + 3]);
                 if (t > slowT) slowT = t, slow = g;
+            }
+            {
+                uint32_t sg2 = 0;
+                double st2 = 0;
+                for (uint32_t g = 0; g < ng; g++) {
+                    if (!h[8 * (size_t)g + 5]) continue;
+                    const double t = (double)(h[8 * (size_t)g + 5] - h[8 * (size_t)g]);
+                    if (t > st2) st2 = t, sg2 = g;
+                }
+                if (cnt)
+                    fprintf(stderr, "[cons] slowest window (%.1f us): gather+query %.1f trim %.1f shared+reduce %.1f align %.1f contig+paf %.1f, %llu sequences\n", st2 / 100.0,
+                            (h[8 * (size_t)sg2 + 1] - h[8 * (size_t)sg2]) / 100.0, (h[8 * (size_t)sg2 + 2] - h[8 * (size_t)sg2 + 1]) / 100.0,
+                            (h[8 * (size_t)sg2 + 3] - h[8 * (size_t)sg2 + 2]) / 100.0, (h[8 * (size_t)sg2 + 4] - h[8 * (size_t)sg2 + 3]) / 100.0,
+                            (h[8 * (size_t)sg2 + 5] - h[8 * (size_t)sg2 + 4]) / 100.0, h[8 * (size_t)sg2 + 7] >> 32);
             }
             if (cnt)
                 fprintf(stderr, "[cons] steps per window: %.1f uniform, %.1f general (%.1f proposer searches), %.1f sequences | slowest align %.1f us: %llu uniform, %llu general, %llu searches, %llu sequences\n",
