@@ -395,10 +395,8 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
         const double tq0 = now();
         buildQueries(st);
         assembleQueries();
-        static const bool prestage = [] {
-            const char* e = getenv("DP_QUERY_PRESTAGE");
-            return !(e && e[0] == '0');
-        }();
+        const char* pe = getenv("DP_QUERY_PRESTAGE");  // (0: dp_find_overlaps uploads them itself; read per round: tests switch it)
+        const bool prestage = !(pe && pe[0] == '0');
         if (prestage && !queries.empty()) {
             int prc = dp_query_prestage(ctx_, querySegs_.data(), queryOff_.data(), (uint32_t)queries.size(), hitFraction_);
             if (prc != 0) {

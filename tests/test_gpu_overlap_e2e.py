@@ -693,11 +693,12 @@ def test_chain_shortcuts_agree(monkeypatch, k, G, N, L, variable, err):
     bases, off = O.gen_reads(17, G, N, L, err, variable)
     rs = O.ReadSet(bases, off, min_len=1000)
     want = O.OverlapRun(rs, k=k, max_rounds=4)
-    for perfect, pack in (("1", "0"), ("0", "0"), ("1", "1")):
+    for perfect, pack, prestage in (("1", "0", "1"), ("0", "0", "1"), ("1", "1", "1"), ("1", "0", "0")):
         monkeypatch.setenv("DP_CHAIN_PERFECT", perfect)
         monkeypatch.setenv("DP_CHAIN_PACK", pack)
+        monkeypatch.setenv("DP_QUERY_PRESTAGE", prestage)  # 0: the query block is uploaded by dp_find_overlaps itself
         pipe = OverlapPipeline(Reads(bases, off, min_len=1000), k=k, slots=3)
         pipe.run(4)
         got = pipe.all_paf()
         pipe.close()
-        assert first_diff(got, want.paf) is None, (perfect, pack)
+        assert first_diff(got, want.paf) is None, (perfect, pack, prestage)
