@@ -1906,7 +1906,7 @@ struct ChainArgs {
     u64* ibase;          // [nq + 1] first scratch int of each query (a pair's column holds nSeeds(q) ints)
     uint32_t* clist;     // [pairs] candidate (indexed-sequence index) of each pair, ascending within a query
     uint32_t* pq;        // [pairs] query of each pair
-    int pass;            // proposal pass this launch belongs to (cursor[8 + pass] counts the queries it leaves open)
+    int pass;            // proposal pass this launch belongs to (cursor[8 + pass] != 0: a query was still open when it started)
     PSpec* pspec;        // [pairs]
     QState* qstate;      // [nq]
     MRec* recs;          // [pairs] final record of each pair; len 0 = no match
