@@ -260,7 +260,21 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const kb_u64* __restrict_
         const kb_u64 n = hi - lo;
         for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
         __syncthreads();
-        for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) atomicAdd(&hist[(uint32_t)(in[i] >> pay) & dmask], 1u);
+        // (a sub-partition that fits the LDS buffer - the digit widths are chosen so that nearly all do - is read once: its entries
+        // stay in registers between the counting and the placing walk)
+        constexpr int KB_HOLD = KB_P3_CAP / KB_THREADS;
+        kb_u64 held[KB_HOLD];
+        const bool hold = n <= KB_P3_CAP;
+        if (hold) {
+#pragma unroll
+            for (int u = 0; u < KB_HOLD; u++) {
+                const kb_u64 i = lo + (kb_u64)u * KB_THREADS + threadIdx.x;
+                held[u] = i < hi ? in[i] : 0;
+                if (i < hi) atomicAdd(&hist[(uint32_t)(held[u] >> pay) & dmask], 1u);
+            }
+        } else {
+            for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) atomicAdd(&hist[(uint32_t)(in[i] >> pay) & dmask], 1u);
+        }
         __syncthreads();
         // histogram + offsets of this sub-partition's 2^r k-mers (k-mer = sp << r | bin): coalesced
         {
@@ -294,11 +308,15 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const kb_u64* __restrict_
         __syncthreads();
         for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;  // placement cursors
         __syncthreads();
-        if (n <= KB_P3_CAP) {
-            for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) {
-                const kb_u64 v = in[i];
-                const uint32_t d = (uint32_t)(v >> pay) & dmask;
-                sorted[lstart[d] + atomicAdd(&hist[d], 1u)] = v;
+        if (hold) {
+#pragma unroll
+            for (int u = 0; u < KB_HOLD; u++) {
+                const kb_u64 i = lo + (kb_u64)u * KB_THREADS + threadIdx.x;
+                if (i < hi) {
+                    const kb_u64 v = held[u];
+                    const uint32_t d = (uint32_t)(v >> pay) & dmask;
+                    sorted[lstart[d] + atomicAdd(&hist[d], 1u)] = v;
+                }
             }
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += KB_THREADS) {  // consecutive lanes, consecutive addresses
