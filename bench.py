@@ -29,6 +29,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run with N ranks on
+    127.0.0.1 as a child process and hand its exit code back."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +77,20 @@ def main():
                          "latency, so this is what scales while a GPU holds the reads and their k-mer index (9 B per base).  auto: "
                          "round if that fits in half of the GPU's memory, else scan-shard")
     args = ap.parse_args()
+
+    # --gpus N is the contract: N ranks, one per GPU.  Started under torch.distributed.run the ranks are there already
+    # (WORLD_SIZE must then equal N); started plainly with N > 1 this process starts them itself - fresh child processes,
+    # before anything here has touched the GPU or torch - relays their output (rank 0 prints the JSON line) and exits with
+    # their exit code.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s\n" % (args.gpus, env_world))
+        sys.exit(2)
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        sys.exit(2)
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
 
     # the executor slots' streams (plus the planner's and the window cache's) want one hardware queue each: the runtime's
     # default of 4 makes streams share queues (measured: 8 slots 9.0 M overlaps/s with 8 queues against 8.7 M with 4)

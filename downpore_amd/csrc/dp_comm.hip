@@ -295,14 +295,7 @@ extern "C" int dp_allgather_survivors(dp_comm* c, dp_ctx* ctx, const dp_survivor
     if (!c || !ctx || !local || !all) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_allgather_survivors: bad arguments") : DP_ERR_ARG;
     if (c->dead) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_survivors: the communicator failed in an earlier exchange");
     const int rc = allgather_survivors_impl(c, ctx, local, all);
-    if (rc != DP_OK) {
-        c->dead = true;
-        if (c->local) {
-            std::lock_guard<std::mutex> lk(c->local->mu);
-            c->local->failed = true;
-            c->local->cv.notify_all();
-        }
-    }
+    if (rc != DP_OK) dp_comm_abort(c);  // (marks the group failed AND aborts an RCCL communicator: the peers' collectives return)
     return rc;
 }
 
@@ -592,14 +585,7 @@ extern "C" int dp_allgather_blobs(dp_comm* c, dp_ctx* ctx, const uint8_t* blob, 
     if (!c || !ctx || !all_out || !sizes_out || (n && !blob)) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_allgather_blobs: bad arguments") : DP_ERR_ARG;
     if (c->dead) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_blobs: the communicator failed in an earlier exchange");
     const int rc = allgather_blobs_impl(c, ctx, blob, n, all_out, sizes_out);
-    if (rc != DP_OK) {
-        c->dead = true;
-        if (c->local) {
-            std::lock_guard<std::mutex> lk(c->local->mu);
-            c->local->failed = true;
-            c->local->cv.notify_all();
-        }
-    }
+    if (rc != DP_OK) dp_comm_abort(c);  // (marks the group failed AND aborts an RCCL communicator: the peers' collectives return)
     return rc;
 }
 

@@ -91,6 +91,8 @@ void dp_gang_sync_point(dp_ctx* ctx);
 hipStream_t dp_ctx_stream(const dp_ctx* ctx);
 // around a section in which the member may block on another member (see dp_gang.hip); pause returns false outside a round
 bool dp_gang_pause(dp_ctx* ctx);
+// dp_ctx_destroy of a context that is still a member: the gang drops it (its slot stays OFF; dp_gang_destroy skips it)
+void dp_gang_forget(dp_ctx* ctx);
 void dp_gang_resume(dp_ctx* ctx);
 struct DpGangPause {
     dp_ctx* ctx;

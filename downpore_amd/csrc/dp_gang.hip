@@ -230,6 +230,30 @@ extern "C" void dp_gang_destroy(dp_gang* g) {
     delete g;
 }
 
+// A member that is destroyed before its gang (finalisers of a garbage-collected host run in any order): the gang forgets it -
+// the slot counts as OFF for good, so the others never wait for it, and dp_gang_destroy no longer touches the freed context.
+void dp_gang_forget(dp_ctx* ctx) {
+    dp_gang* g = ctx->gang;
+    if (!g) return;
+    hipStreamSynchronize(g->stream);  // (launches of this member's last round may still be queued on the shared stream)
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        const int me = ctx->gang_slot;
+        if (me >= 0 && me < g->n && g->member[me] == ctx) {
+            g->member[me] = nullptr;
+            g->state[me] = DPG_OFF;
+            g->dep[me] = nullptr;
+            g->off_since_ns[me] = 0;
+            gang_resolve(g);
+        }
+    }
+    ctx->stream = ctx->own_stream;
+    ctx->own_stream = nullptr;
+    ctx->gang = nullptr;
+    ctx->gang_slot = -1;
+    ctx->gang_in_round = false;
+}
+
 extern "C" int dp_gang_round_prepare(dp_ctx* ctx) {
     if (!ctx) return DP_ERR_ARG;
     if (!ctx->gang || ctx->gang_in_round) return DP_OK;

@@ -337,6 +337,8 @@ extern "C" const char* dp_version(void) { return "downpore_hip 0.1 (gfx950)"; }
 
 extern "C" const char* dp_last_error(const dp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
+static std::mutex g_borrow_mu;  // borrower counts and pending owner destroys (dp_ctx_create_shared / dp_ctx_destroy)
+
 extern "C" int dp_ctx_create(int device, dp_ctx** out) {
     if (!out) return DP_ERR_ARG;
     *out = nullptr;
@@ -364,7 +366,10 @@ extern "C" int dp_ctx_create_shared(dp_ctx* src, dp_ctx** out) {
     dp_ctx* c = *out;
     c->borrowed_reads = true;
     c->owner = src->owner ? src->owner : src;
-    c->owner->n_borrowers++;
+    {
+        std::lock_guard<std::mutex> lk(g_borrow_mu);
+        c->owner->n_borrowers++;
+    }
     c->n_reads = src->n_reads;
     c->total_bases = src->total_bases;
     c->packed_bytes = src->packed_bytes;
@@ -397,22 +402,26 @@ extern "C" int dp_ctx_set_priority(dp_ctx* ctx, int high) {
 extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    if (ctx->gang) {  // (destroyed as a gang member: the gang must be gone first; be safe and wait on the right stream)
-        ctx->gang_in_round = false;
-        hipStreamSynchronize(ctx->stream);
-        ctx->stream = ctx->own_stream;
-        ctx->gang = nullptr;
-    }
+    if (ctx->gang) dp_gang_forget(ctx);  // (destroyed before its gang: the gang forgets the member, the others never wait for it)
     dp_stream_sync(ctx);
-    if (!ctx->owner && ctx->n_borrowers.load() > 0) {
+    {
         // contexts that borrow these reads (value table, k-mer index) are still alive - a garbage-collected host may finalise
-        // the owner first: the resident data stays until the last borrower has gone, which then carries this call out
-        ctx->destroy_pending = true;
-        return;
+        // the owner first: the resident data stays until the last borrower has gone, which then carries this call out.  "Are
+        // there borrowers" + "remember the destroy" on this side and "was I the last" + "is a destroy pending" on the borrower's
+        // side are one decision each, under one lock: exactly one of the two threads frees the owner.
+        std::lock_guard<std::mutex> lk(g_borrow_mu);
+        if (!ctx->owner && ctx->n_borrowers.load() > 0) {
+            ctx->destroy_pending = true;
+            return;
+        }
     }
     if (ctx->borrowed_reads) ctx->d_packed.p = ctx->d_boff.p = ctx->d_len.p = ctx->d_values.p = ctx->d_qual.p = ctx->d_qualoff.p = ctx->d_hasq.p = nullptr;
     dp_ctx* const lender = ctx->owner;
-    const bool last_borrower = lender && --lender->n_borrowers == 0 && lender->destroy_pending;
+    bool last_borrower = false;
+    if (lender) {
+        std::lock_guard<std::mutex> lk(g_borrow_mu);
+        last_borrower = --lender->n_borrowers == 0 && lender->destroy_pending;
+    }
     dp_kindex_free(ctx);
     dp_find_state_free(ctx);
     DevBuf* dbs[] = {&ctx->d_packed, &ctx->d_boff, &ctx->d_len, &ctx->d_bits, &ctx->d_kmap, &ctx->d_seeds, &ctx->d_items,

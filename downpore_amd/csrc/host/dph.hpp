@@ -669,6 +669,7 @@ struct OverlapRun {
 
    private:
     int executeRoundOn(ExecSlot& s, i64 r, RoundResult& out);
+    int executeRoundOnImpl(ExecSlot& s, i64 r, RoundResult& out);
     int beginRound(ExecSlot& s, const RoundPlan& plan);
     int finishRound(ExecSlot& s, const Survivors& all, RoundResult& out);
     void commitOne(RoundResult& r);

@@ -1004,7 +1004,16 @@ int OverlapRun::finishRound(ExecSlot& sl, const Survivors& all, RoundResult& out
     return 0;
 }
 
+// A slot's round in the sharded layouts ends in collectives its peers take part in: whatever made this rank's round fail - the
+// plan, dp_round_begin, the scan, the exchange itself - the slot's communicator is aborted, so that the peers of this round's
+// exchanges (and, behind their batons, of every later one) return an error instead of waiting for a rank that will not come.
 int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
+    const int rc = executeRoundOnImpl(sl, r, out);
+    if (rc != 0 && sl.comm) dp_comm_abort(sl.comm);
+    return rc;
+}
+
+int OverlapRun::executeRoundOnImpl(ExecSlot& sl, i64 r, RoundResult& out) {
     out = RoundResult();
     out.round = r;
     double t0 = now();
@@ -1057,6 +1066,12 @@ int OverlapRun::executeRoundOn(ExecSlot& sl, i64 r, RoundResult& out) {
     out.queryReads.reserve(plan->windows.size());
     for (const auto& w : plan->windows) out.queryReads.push_back(w.read);
     int rc = beginRound(sl, *plan);
+    if (rc == 0 && sl.comm)
+        if (const char* e = getenv("DPH_FAIL_BEGIN_RANK"))  // test hook: this rank's round fails before it reaches any exchange
+            if (atoi(e) == dp_comm_rank(sl.comm)) {
+                sl.error = "injected failure before the exchange (DPH_FAIL_BEGIN_RANK)";
+                rc = -1;
+            }
     if (rc) return rc;
     out.st.n_seeds = plan->seedMap.size();
     out.st.gang_members = (uint64_t)dp_gang_round_members(sl.ctx);

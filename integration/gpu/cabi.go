@@ -686,6 +686,9 @@ type Gang struct {
 }
 
 func NewGang(ctxs []*Context) (*Gang, error) {
+	if len(ctxs) == 0 {
+		return nil, errors.New("NewGang: no contexts")
+	}
 	hs := make([]*C.dp_ctx, len(ctxs))
 	for i, c := range ctxs {
 		hs[i] = c.h

@@ -54,6 +54,18 @@ def test_bench_two_ranks_default_reports_both_layouts():
     assert d["alt_mode"]["mode"] == "round" and d["alt_mode"]["paf_sha256_matches_oracle_fixture"] is True and d["alt_mode"]["value"] > 0
 
 
+def test_bench_plain_launch_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent starts two rank processes itself (fresh children of a
+    process that has not touched the GPU), relays rank 0's line and the exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DP_BENCH_SAME_DEVICE="1", DP_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-rounds", "0", "--mode", "round",
+                        "--slots", "4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 2 and d["parity"]["paf_sha256_matches_oracle_fixture"] is True
+
+
 def test_bench_two_gpus_over_rccl():
     """Two real ranks, one GPU each, exchanging over RCCL inside the library (dp_comm_init / dp_allgather_survivors /
     dp_allgather_blobs): what the driver's multi-GPU run does.  Needs a second GPU."""

@@ -407,6 +407,39 @@ def test_scan_shard_exchange_inside_the_library():
 
 
 @pytest.mark.parametrize("slots", [1, 3])
+def test_scan_shard_rank_failure_before_the_exchange_does_not_hang_its_peers(monkeypatch, slots):
+    """The same for a rank whose round fails BEFORE it reaches the exchange (dp_round_begin out of memory, a failed plan): the
+    slot's communicator is aborted on every non-zero return of a sharded round, not only on the exchange's own failure."""
+    import threading
+    from downpore_amd.hip import DpError
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(32, 60000, 500, 1500, 0.0, True)
+    world = 2
+    readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
+    pipes = [OverlapPipeline(readsets[r], k=10, rank=r, world=world, mode="scan-shard", comm="local", slots=slots) for r in range(world)]
+    OverlapPipeline.link_local(pipes)
+    monkeypatch.setenv("DPH_FAIL_BEGIN_RANK", "1")
+    errs = [None] * world
+
+    def run(r):
+        try:
+            pipes[r].run()
+        except DpError as e:
+            errs[r] = e
+    th = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a rank is still waiting for a peer that failed before the exchange"
+    assert all(e is not None for e in errs), errs
+    assert "injected failure before the exchange" in str(errs[1])
+    monkeypatch.delenv("DPH_FAIL_BEGIN_RANK")
+    for p in pipes:
+        p.close()
+
+
+@pytest.mark.parametrize("slots", [1, 3])
 def test_scan_shard_rank_failure_does_not_hang_its_peers(monkeypatch, slots):
     """A rank that fails inside (or before) the survivor exchange must not leave the others waiting for it: the in-process
     group is marked failed, every rank's step returns an error (dp_allgather_survivors / dp_comm_abort)."""
