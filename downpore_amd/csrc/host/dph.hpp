@@ -27,6 +27,12 @@
 
 namespace dph {
 
+// The SetIgnore flags are bytes that planner lanes and executor slots read without a lock while a commit sets them (what a stale
+// read may cause is caught by the epoch / flag-round validation): relaxed atomic accesses, so that the concurrency is defined
+// behaviour (and ThreadSanitizer-clean: `make host-tsan`, tests/test_planner_epoch.py).
+inline uint8_t flagLoad(const uint8_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+inline void flagStore(uint8_t* p, uint8_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+
 typedef int64_t i64;
 
 // ---- read set (sequence/seqio.go fastaSequenceSet, FASTA subset) -------------------------------------------------
@@ -40,7 +46,7 @@ struct ReadSet {
     std::vector<uint8_t> hasQual;
     bool isFastq = false;
     const uint8_t* quality(size_t r) const { return (!qual.empty() && hasQual[r]) ? (const uint8_t*)qual.data() + off[r] : nullptr; }
-    std::vector<uint8_t> ignore;   // SetIgnore flags (seqio.go:375)
+    std::vector<uint8_t> ignore;   // SetIgnore flags (seqio.go:375); planner lanes read them while a commit sets them: flagLoad / flagStore
     bool himem = true;             // cached views (seqio.go:115) vs top-level re-reads (:158)
     size_t maxNameLen = 0;         // longest name (PAF line buffers are sized from it)
     size_t size() const { return names.size(); }

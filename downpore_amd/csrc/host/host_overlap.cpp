@@ -30,7 +30,7 @@ int Overlapper::prepareFromCache(int numSeeds, i64 seedLimit, ValueView values, 
     unsigned long long cTouch = 0, cResel = 0, cCommit = 0, c0 = prof ? __rdtsc() : 0;
     const unsigned long long cStart = c0;
     for (size_t r = (size_t)firstSequence; r < reads_.size() && sent < maxSeqs; r++) {
-        if (ignore_[r]) continue;
+        if (flagLoad(ignore_ + r)) continue;
         sent++;
         if (index_.size() >= seedLimit) break;  // the budget is tested once per read, before its first window (overlap.go:57-60)
         for (uint32_t w = cache_->first[r]; w < cache_->first[r + 1]; w++) {
@@ -114,7 +114,7 @@ int Overlapper::PrepareQueries(int numSeeds, i64 seedLimit, ValueView values, i6
     auto moreCands = [&](size_t upTo) {
         if (firstSequence != 0 && firstSequence >= (i64)reads_.size()) return;  // seqio.go:279
         for (; rNext < reads_.size() && sent < maxSeqs && sel.size() < upTo; rNext++) {
-            if (ignore_[rNext]) continue;
+            if (flagLoad(ignore_ + rNext)) continue;
             sent++;
             const uint32_t r = (uint32_t)rNext;
             const i64 L = reads_.length(rNext);
@@ -754,7 +754,7 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
         if (gm.flag) {
             for (int id : hostIgn[hostOf[g]]) {
                 if (ignoreOut) ignoreOut->push_back(id);
-                else reads_.ignore[(size_t)id] = 1;
+                else flagStore(&reads_.ignore[(size_t)id], 1);
             }
             continue;
         }
@@ -764,7 +764,7 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
         for (uint32_t j = 0; j < gm.n_ignore; j++) {
             const int id = (int)pb.ignore_ids[gm.slot + j];
             if (ignoreOut) ignoreOut->push_back(id);
-            else reads_.ignore[(size_t)id] = 1;
+            else flagStore(&reads_.ignore[(size_t)id], 1);
         }
     }
     // the text: one line per part after the first (commands/overlap.go:223-228), windows in query order - here, or on a
@@ -1078,7 +1078,7 @@ int finalCheck(Arena& arena, const SeedIndex& index, ReadSet& reads, const std::
         paf += outs[w];
         for (int id : ign[w]) {
             if (ignoreOut) ignoreOut->push_back(id);
-            else reads.ignore[(size_t)id] = 1;
+            else flagStore(&reads.ignore[(size_t)id], 1);
         }
     }
     for (auto& t : tfs) {

@@ -379,7 +379,7 @@ i64 Planner::predictFirstOut(i64 firstIn) const {
     if (firstIn != 0 && firstIn >= n) return firstIn;
     i64 sent = 0, seeds = 0, last = -1;
     for (i64 r = firstIn; r < n && sent < d->p.queryBatchSize; r++) {
-        if (d->reads.ignore[(size_t)r]) continue;
+        if (flagLoad(&d->reads.ignore[(size_t)r])) continue;
         sent++;
         if (seeds >= d->p.seedBatchSize) break;
         for (uint32_t w = wc.first[(size_t)r]; w < wc.first[(size_t)r + 1]; w++) {
@@ -510,7 +510,7 @@ i64 Planner::applyIgnores(const std::vector<int>& ids, i64 committedRound) {
     i64 maxNew = -1;
     for (int id : ids) {
         if (!d->reads.ignore[(size_t)id]) {
-            d->reads.ignore[(size_t)id] = 1;
+            flagStore(&d->reads.ignore[(size_t)id], 1);
             if (id > maxNew) maxNew = id;
         }
     }
@@ -903,6 +903,12 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
 // seeds.NewSeedIndex + the plan's seeds on host and device; queries are built after the scan
 int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
     const double tb0 = now();
+    if (dp_comm* cm = sl.comm ? sl.comm : comm)
+        if (const char* e = getenv("DPH_FAIL_BEGIN_RANK"))  // test hook: this rank's round fails before it reaches any exchange
+            if (atoi(e) == dp_comm_rank(cm)) {
+                sl.error = "injected failure before the exchange (DPH_FAIL_BEGIN_RANK)";
+                return -1;
+            }
     // seeds.NewSeedIndex(k) per round (:125): the plan's seed list and reverse-complement table, as the planner left them
     if (plan.rcOf.size() == plan.seedMap.size()) {
         sl.index->adopt(plan.seedMap, plan.rcOf);
@@ -1066,12 +1072,6 @@ int OverlapRun::executeRoundOnImpl(ExecSlot& sl, i64 r, RoundResult& out) {
     out.queryReads.reserve(plan->windows.size());
     for (const auto& w : plan->windows) out.queryReads.push_back(w.read);
     int rc = beginRound(sl, *plan);
-    if (rc == 0 && sl.comm)
-        if (const char* e = getenv("DPH_FAIL_BEGIN_RANK"))  // test hook: this rank's round fails before it reaches any exchange
-            if (atoi(e) == dp_comm_rank(sl.comm)) {
-                sl.error = "injected failure before the exchange (DPH_FAIL_BEGIN_RANK)";
-                rc = -1;
-            }
     if (rc) return rc;
     out.st.n_seeds = plan->seedMap.size();
     out.st.gang_members = (uint64_t)dp_gang_round_members(sl.ctx);
