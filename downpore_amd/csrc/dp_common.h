@@ -9,6 +9,13 @@
 
 #include "downpore_hip.h"
 
+// make COPYLOG=1: every hipMemcpyAsync of the library is counted per call site (file:line, direction, calls, bytes) and the table is
+// printed when the process ends - the tool that names the call sites behind the runtime's copy kernels in a profile
+#ifdef DP_COPY_LOG
+hipError_t dp_copy_logged(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s, const char* file, int line);
+#define hipMemcpyAsync(d_, s_, n_, k_, st_) dp_copy_logged((void*)(d_), (const void*)(s_), (n_), (k_), (st_), __FILE__, __LINE__)
+#endif
+
 #define DP_WAVE 64
 
 // Growable device / pinned-host buffers owned by a context.
@@ -102,6 +109,7 @@ struct dp_ctx {
     // dp_stream_sync
     std::vector<uint8_t> stage_buf;
     size_t stage_used = 0;
+    bool cons_huge = false;                  // a window of an earlier round did not fit the large consensus layout: the huge one follows it from now on
     uint32_t cons_prev_pairs = 0;            // pairs of the previous round's chaining stage (output bound of a pending one)
     struct FindState* find_state = nullptr;  // dp_overlap.hip: the chaining stage between launch and evaluation
     bool timing_on = true;

@@ -317,22 +317,32 @@ extern "C" int dp_consensus_align(dp_ctx* ctx, const int32_t* segs, const uint64
 // hold seven of these waves instead of two; a window that does not fit it (more ints, a gap or offset beyond 16 bits, more than
 // 32767 seeds in the round) is put on a list and done by a second launch with the large layout (int32, 57 KB: round 2's), and
 // what does not fit that either is flagged for the host path as before.  Same code, same results, whichever layout ran.
-template <bool SMALL>
+// Round 4 - a third, huge layout (int32, 12 288 ints each for the trimmed and the reduced sequences: 144 KB, one wave per CU) for
+// the dense-seed regime (k = 10: every trimmed target of a 1 kb window carries ~100 seeds, twenty to forty of them are 4-8 k ints;
+// nearly every window overflowed the large layout and was done on the host from ~90 MB of fetched segments per round).  It is
+// launched behind the large one once a round of the context has had a window the large layout could not hold.
+// TIER: 0 = small, 1 = large, 2 = huge.  (HASH >= the most seeds T can hold: the open-addressed table must never fill up.)
+template <int TIER>
 struct CFCfg;
 template <>
-struct CFCfg<false> {
+struct CFCfg<1> {
     typedef int32_t elem_t;
     enum { T = 4096, R = 4096, CONS = 1024, A = 256, M = 256, HASH = 4096, HSHIFT = 20 };
 };
 template <>
-struct CFCfg<true> {
+struct CFCfg<0> {
     typedef int16_t elem_t;
     enum { T = 2048, R = 2048, CONS = 256, A = 128, M = 128, HASH = 2048, HSHIFT = 21 };
 };
+template <>
+struct CFCfg<2> {
+    typedef int32_t elem_t;
+    enum { T = 12288, R = 12288, CONS = 1024, A = 256, M = 256, HASH = 8192, HSHIFT = 19 };
+};
 
-template <bool SMALL>
+template <int TIER>
 struct CFWaveT {
-    typedef CFCfg<SMALL> C;
+    typedef CFCfg<TIER> C;
     typedef typename C::elem_t elem_t;
     elem_t T[C::T];               // trimmed sequences of the group, [gap, seed, ..., gap] each
     elem_t R[C::R];               // their Reduced() forms
@@ -410,39 +420,41 @@ struct ConsFullArgs {
     uint32_t rec_cap;          // records the chaining stage's buffers hold (its pair count may exceed them: the stage is then repeated)
     const uint32_t* nseq_src;  // chunk count + overflow flag of dp_index_build_chunked (device), or null
     uint32_t* nseq_dst;        // ... and where the host reads them (pinned, with the rest of the output)
-    uint32_t* retry;           // [0] = windows the small layout could not hold, [1 ..] = their numbers (zeroed by the anchors launch);
-                               // the large-layout launch works through this list (null: it does every window)
+    const uint32_t *in_count, *in_list;  // windows this launch works through: how many, their numbers (null: every window)
+    uint32_t *out_count, *out_list;      // windows this layout cannot hold are listed here for the next one (null: flagged for the host
+                                         // path); the counters are zeroed by the anchors launch
+    bool copy_nseq;            // this launch hands the chunk count of dp_index_build_chunked on to the host's block (the first one)
 };
 
-template <bool SMALL>
+template <int TIER>
 struct consensus_full_kernel {
     enum { THREADS = 64 };
     static __device__ void run(const ConsFullArgs A) {
-    typedef CFWaveT<SMALL> LW;
+    constexpr bool SMALL = TIER == 0;
+    typedef CFWaveT<TIER> LW;
     typedef typename LW::C CF;
     typedef typename LW::elem_t elem_t;
     __shared__ LW L;
     const int lane = dp_lane();
     const int k = A.k;
     const u64 lanesBelow = (1ull << lane) - 1ull;
-    // the small layout runs first and does every window; the large one takes what the small one listed (or every window when there
-    // was no small launch: A.retry == null)
-    const bool fromList = !SMALL && A.retry != nullptr;
-    const uint32_t nWork = fromList ? min(A.retry[0], A.n_groups) : A.n_groups;
-    if ((SMALL || !A.retry) && blockIdx.x == 0 && lane < 2 && A.nseq_src) A.nseq_dst[lane] = A.nseq_src[lane];
-    // a window the small layout cannot hold: listed for the large one (which writes its group record)
-#define CF_NOFIT()                                                           \
-    {                                                                        \
-        if (SMALL) {                                                         \
-            if (lane == 0) A.retry[1 + atomicAdd(&A.retry[0], 1u)] = g;      \
-        } else {                                                             \
-            gm.flag = 1;                                                     \
-            if (lane == 0) A.gmeta[g] = gm;                                  \
-        }                                                                    \
-        continue;                                                            \
+    // the first layout of a call does every window; each later one takes what its predecessor listed
+    const bool fromList = A.in_list != nullptr;
+    const uint32_t nWork = fromList ? min(*A.in_count, A.n_groups) : A.n_groups;
+    if (A.copy_nseq && blockIdx.x == 0 && lane < 2 && A.nseq_src) A.nseq_dst[lane] = A.nseq_src[lane];
+    // a window this layout cannot hold: listed for the next one (which writes its group record), flagged for the host after the last
+#define CF_NOFIT()                                                                   \
+    {                                                                                \
+        if (A.out_list) {                                                            \
+            if (lane == 0) A.out_list[atomicAdd(A.out_count, 1u)] = g;               \
+        } else {                                                                     \
+            gm.flag = 1;                                                             \
+            if (lane == 0) A.gmeta[g] = gm;                                          \
+        }                                                                            \
+        continue;                                                                    \
     }
     for (uint32_t wi = blockIdx.x; wi < nWork; wi += gridDim.x) {
-        const uint32_t g = fromList ? A.retry[1 + wi] : wi;
+        const uint32_t g = fromList ? A.in_list[wi] : wi;
         __builtin_amdgcn_wave_barrier();
         const uint32_t qf = 2 * g, qr = 2 * g + 1;
         const uint32_t P0 = A.pbase[qf], P1 = A.pbase[qr + 1];
@@ -478,8 +490,7 @@ struct consensus_full_kernel {
         const int nA = RFLc((int)(A.qoff[qf + 1] - A.qoff[qf]));
         const int sA = nA >> 1;
         if (sA > CF::A || sA < 1) tooMany = true;
-        if (!SMALL && A.flag_every && (g % A.flag_every) == 0) tooMany = true;
-        if (SMALL && A.flag_every && (g % A.flag_every) == 0) tooMany = true;  // (test hook: goes the whole way to the host path)
+        if (A.flag_every && (g % A.flag_every) == 0) tooMany = true;  // (test hook: goes the whole way through the layouts to the host path)
         if (tooMany) CF_NOFIT()
         {
             int run = 0;
@@ -1197,17 +1208,22 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
         A.flag_every = flag_every;
     }
     A.rc_of = (const int32_t*)((const uint8_t*)ctx->d_cin.p + b_meta);
-    // small LDS layout first (int16: needs every seed id below 2^15), the large one for what it lists; DP_CONS_SMALL=0: large only
+    // small LDS layout first (int16: needs every seed id below 2^15), the large one for what it lists; DP_CONS_SMALL=0: large only.
+    // The huge layout follows the large one from the round after the first in which a window did not fit the large one
+    // (ctx->cons_huge; DP_CONS_HUGE=1 / 0: always / never) - the sparse regime never pays its launch.
     const char* small_env = getenv("DP_CONS_SMALL");  // (read per call: tests switch it between jobs of one process)
     const bool small_off = small_env && small_env[0] == '0';
     const bool use_small = !small_off && n_seeds <= 32767;
-    A.retry = nullptr;
-    if (use_small) {
-        if (dev_reserve(ctx, ctx->d_cretry, ((size_t)ng + 2) * 4 + 16)) return DP_ERR_HIP;
-        A.retry = (uint32_t*)ctx->d_cretry.p;
+    const char* huge_env = getenv("DP_CONS_HUGE");
+    const bool use_huge = huge_env ? huge_env[0] != '0' : ctx->cons_huge;
+    // lists: [count of list 1 | count of list 2 | list 1: ng entries | list 2: ng entries] (both counts zeroed by the anchors launch)
+    uint32_t* lists = nullptr;
+    if (use_small || use_huge) {
+        if (dev_reserve(ctx, ctx->d_cretry, (2 * (size_t)ng + 2) * 4 + 16)) return DP_ERR_HIP;
+        lists = (uint32_t*)ctx->d_cretry.p;
     }
     {
-        int rc = dp_match_anchors_launch(ctx, &cin_fetch, A.retry);
+        int rc = dp_match_anchors_launch(ctx, &cin_fetch, lists);
         if (rc != 0) return rc;
     }
     A.anchors = (const int32_t*)ctx->d_manchor.p;
@@ -1231,8 +1247,37 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     A.nseq_src = ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : nullptr;
     A.nseq_dst = h_nseq;
     DP_HIP(dp_mark(ctx, 0));
-    if (use_small) dp_launch<consensus_full_kernel<true>>(ctx, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), A);
-    dp_launch<consensus_full_kernel<false>>(ctx, dim3(std::min<uint32_t>(ng, use_small ? 96u : 4096u)), dim3(64), A);
+    {
+        // small -> large -> huge: each layout works through what its predecessor listed and lists what it cannot hold for its
+        // successor; the last one flags for the host path.  Only the first launch does every window.
+        const uint32_t *in_count = nullptr, *in_list = nullptr;
+        uint32_t* next_count = lists;
+        uint32_t* next_list = lists ? lists + 2 : nullptr;
+        auto stage = [&](bool last) {
+            A.in_count = in_count;
+            A.in_list = in_list;
+            A.copy_nseq = in_list == nullptr;
+            A.out_count = last ? nullptr : next_count;
+            A.out_list = last ? nullptr : next_list;
+            if (!last) {
+                in_count = next_count;
+                in_list = next_list;
+                next_count = lists + 1;
+                next_list = lists + 2 + ng;
+            }
+        };
+        if (use_small) {
+            stage(false);
+            dp_launch<consensus_full_kernel<0>>(ctx, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), A);
+        }
+        stage(!use_huge);
+        dp_launch<consensus_full_kernel<1>>(ctx, dim3(std::min<uint32_t>(ng, use_small ? 96u : 4096u)), dim3(64), A);
+        if (use_huge) {
+            stage(true);
+            // (144 KB of LDS per wave: one per CU; behind the small + large layouts it mostly finds its list short or empty)
+            dp_launch<consensus_full_kernel<2>>(ctx, dim3(std::min<uint32_t>(ng, use_small ? 64u : 256u)), dim3(64), A);
+        }
+    }
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 1));
     DP_HIP(dp_stream_sync(ctx));
@@ -1307,6 +1352,14 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
                     ms, cnt, ng, sum[0] / cnt, mx[0], sum[1] / cnt, mx[1], sum[2] / cnt, mx[2], sum[3] / cnt, mx[3], sum[4] / cnt, mx[4], tot / cnt, totmx);
     }
     const uint8_t* h = (const uint8_t*)ctx->h_cout.p;
+    if (!ctx->cons_huge) {  // a window left to the host path: the next rounds of this context try the huge layout before that
+        const dp_group_meta* gms = (const dp_group_meta*)h;
+        for (uint32_t g = 0; g < ng; g++)
+            if (gms[g].flag == 1) {
+                ctx->cons_huge = true;
+                break;
+            }
+    }
     out->groups = (const dp_group_meta*)h;
     out->paf = (const dp_paf_rec*)(h + b_gm);
     out->ignore_ids = (const uint32_t*)(h + b_gm + b_paf);

@@ -1826,7 +1826,7 @@ struct match_anchor_kernel {
                                                            const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, int k,
                                                            int32_t* __restrict__ anchors, const AnchorFetch F, uint32_t* __restrict__ zero_word) {
     const int lane = threadIdx.x & 63;
-    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0;  // (the consensus stage's retry counter: next launch)
+    if (zero_word && blockIdx.x == 0 && threadIdx.x < 2) zero_word[threadIdx.x] = 0;  // (the consensus stage's two list counters: next launches)
     // (the consensus kernel's input block - pinned host memory - is brought over by this launch, which runs just before it; a
     // pending chaining stage's cursor block and per-query words go the other way)
 #pragma unroll

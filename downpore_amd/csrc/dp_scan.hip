@@ -78,6 +78,33 @@ static std::atomic<long> g_timing_every{[] {
 }()};
 extern "C" void dp_set_kernel_timing(int every) { g_timing_every.store(every < 0 ? 0 : every); }
 
+#ifdef DP_COPY_LOG
+#undef hipMemcpyAsync
+namespace {
+struct CopyLog {
+    std::mutex mu;
+    std::map<std::pair<std::string, int>, std::pair<uint64_t, uint64_t>> sites[5];
+    ~CopyLog() {
+        static const char* kinds[] = {"H2H", "H2D", "D2H", "D2D", "default"};
+        for (int k = 0; k < 5; k++)
+            for (auto& e : sites[k])
+                fprintf(stderr, "[copylog] %s %s:%d calls %llu bytes %llu\n", kinds[k], e.first.first.c_str(), e.first.second,
+                        (unsigned long long)e.second.first, (unsigned long long)e.second.second);
+    }
+} g_copy_log;
+}  // namespace
+hipError_t dp_copy_logged(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s, const char* file, int line) {
+    {
+        std::lock_guard<std::mutex> lk(g_copy_log.mu);
+        auto& e = g_copy_log.sites[(int)kind < 5 ? (int)kind : 4][{file, line}];
+        e.first++;
+        e.second += n;
+    }
+    return hipMemcpyAsync(dst, src, n, kind, s);
+}
+#define hipMemcpyAsync(d_, s_, n_, k_, st_) dp_copy_logged((void*)(d_), (const void*)(s_), (n_), (k_), (st_), __FILE__, __LINE__)
+#endif
+
 const void* dp_stage(dp_ctx* ctx, const void* src, size_t bytes) {
     const size_t at = (ctx->stage_used + 63) & ~(size_t)63;
     if (at + bytes > ctx->stage_buf.size()) {

@@ -7,8 +7,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def lib_dir():
+    # DP_LIB_DIR: another build of both libraries (make LIB=../lib_prof PROF=1, make LIB=../lib_copylog COPYLOG=1: diagnosis builds)
+    return os.environ.get("DP_LIB_DIR") or os.path.join(_HERE, "lib")
+
+
 def lib_path():
-    return os.path.join(_HERE, "lib", "libdownpore_hip.so")
+    return os.path.join(lib_dir(), "libdownpore_hip.so")
 
 
 class DpError(RuntimeError):

@@ -22,7 +22,8 @@ STAT_FIELDS = ["t_prepare", "t_scan", "t_index", "t_query", "t_consensus", "k_sc
 
 def host_lib_path():
     # DPH_HOST_LIB: another build of the same library (the ThreadSanitizer build of `make host-tsan`, used by the CPU planner tests)
-    return os.environ.get("DPH_HOST_LIB") or os.path.join(_HERE, "lib", "libdownpore_host.so")
+    from .hip import lib_dir
+    return os.environ.get("DPH_HOST_LIB") or os.path.join(lib_dir(), "libdownpore_host.so")
 
 
 def load_host():

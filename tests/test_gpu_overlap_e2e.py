@@ -705,14 +705,17 @@ def test_consensus_layouts_agree(monkeypatch, k, G, N, L, variable):
     rs = O.ReadSet(bases, off, min_len=1000)
     want = O.OverlapRun(rs, k=k, max_rounds=4)
     got = {}
-    for small in ("1", "0"):
+    # (small, huge): huge = "1" puts the 144 KB layout (round 4: the dense regime's windows) behind the large one from the first
+    # round on ("0": never; unset: from the round after the first window that did not fit the large one)
+    for small, huge in (("1", "0"), ("0", "0"), ("1", "1"), ("0", "1")):
         monkeypatch.setenv("DP_CONS_SMALL", small)
+        monkeypatch.setenv("DP_CONS_HUGE", huge)
         pipe = OverlapPipeline(Reads(bases, off, min_len=1000), k=k, slots=3)
         pipe.run(4)
-        got[small] = pipe.all_paf()
+        got[(small, huge)] = pipe.all_paf()
         pipe.close()
-    assert first_diff(got["1"], want.paf) is None
-    assert first_diff(got["0"], want.paf) is None
+        assert first_diff(got[(small, huge)], want.paf) is None, (small, huge)
+    monkeypatch.delenv("DP_CONS_HUGE")
 
 
 @pytest.mark.parametrize("k,G,N,L,variable,err", [(10, 250000, 1000, 5000, False, 0.0), (13, 3000000, 6000, 10000, False, 0.0),
