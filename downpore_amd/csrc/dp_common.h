@@ -220,6 +220,7 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                     const uint64_t* d_totals, int32_t* d_segs, int32_t* host_segs = nullptr);
 
 // kernels implemented in other translation units
+#define DP_NO_ANCHOR ((int32_t)0x80000000)  // match_anchor_kernel: the chain's indices are not inside the target (anchors may be negative)
 int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch = nullptr, uint32_t* zero_word = nullptr);  // dp_overlap.hip: GetSeedOffset / GetSeedOffsetFromEnd anchors of the last chaining stage's records
 int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs);
 int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, int k,

@@ -443,12 +443,13 @@ struct consensus_full_kernel {
     const uint32_t nWork = fromList ? min(*A.in_count, A.n_groups) : A.n_groups;
     if (A.copy_nseq && blockIdx.x == 0 && lane < 2 && A.nseq_src) A.nseq_dst[lane] = A.nseq_src[lane];
     // a window this layout cannot hold: listed for the next one (which writes its group record), flagged for the host after the last
-#define CF_NOFIT()                                                                   \
+#define CF_NOFIT(why_)                                                               \
     {                                                                                \
         if (A.out_list) {                                                            \
             if (lane == 0) A.out_list[atomicAdd(A.out_count, 1u)] = g;               \
         } else {                                                                     \
             gm.flag = 1;                                                             \
+            gm.reserved = (why_); /* (diagnosis: DP_CONS_WHY=1 prints a histogram) */ \
             if (lane == 0) A.gmeta[g] = gm;                                          \
         }                                                                            \
         continue;                                                                    \
@@ -491,7 +492,7 @@ struct consensus_full_kernel {
         const int sA = nA >> 1;
         if (sA > CF::A || sA < 1) tooMany = true;
         if (A.flag_every && (g % A.flag_every) == 0) tooMany = true;  // (test hook: goes the whole way through the layouts to the host path)
-        if (tooMany) CF_NOFIT()
+        if (tooMany) CF_NOFIT(1u)  // more matches / query seeds than the layout holds
         {
             int run = 0;
             for (int base = 0; base < sA; base += 64) {
@@ -508,9 +509,11 @@ struct consensus_full_kernel {
         // ---- 2. per match: filter + Trimmed().  One lane per match; everything a lane does is its own little loop.
         int nseq = 0, tUsed = 0;
         bool bad = false, laneWide = false;
+        uint32_t badWhy = 0;
         for (int m0 = 0; m0 < nm; m0 += 64) {
             const int mi = m0 + lane;
             bool keep = false, laneBad = false;
+            uint32_t laneWhy = 0;  // (diagnosis only: which check sent the window to the host path)
             int nT = 0, startSeed = 0, startOffset = 0, endOffset = 0, offset = 0, inset = 0, ns = 0;
             bool isRc = false;
             const int32_t* S = nullptr;
@@ -531,7 +534,7 @@ struct consensus_full_kernel {
                 // as they came
                 int ca = len * k, cb = len * k;
                 int prevA = MA[0], prevB = MB[0];
-                if (prevA < 0 || prevA >= sA || prevB < 0 || prevB >= ns) laneBad = true;
+                if (prevA < 0 || prevA >= sA || prevB < 0 || prevB >= ns) laneBad = true, laneWhy = 10u;
                 // (eight matched pairs per trip: their sixteen loads, then the first gap of each pair's stretch of the target - nearly
                 // always the whole stretch - are issued together; one pair per trip was a chain of two dependent loads per pair)
                 for (int i0 = 1; i0 < len && !laneBad; i0 += 8) {
@@ -554,6 +557,7 @@ struct consensus_full_kernel {
                         const int a1 = av[u], b1 = bv[u];
                         if (a1 >= sA || a1 < 0 || b1 >= ns || b1 < 0) {
                             laneBad = true;  // the reference would panic inside GetBasesCovered: leave the group to the host path
+                            laneWhy = 11u;
                             continue;
                         }
                         const int dA = isRc ? L.GA[sA - 1 - prevA] - L.GA[sA - 1 - a1] - k : L.GA[a1] - L.GA[prevA] - k;
@@ -577,7 +581,7 @@ struct consensus_full_kernel {
                     // X.GetSeedOffset(startSeed) / X.GetSeedOffsetFromEnd(endSeed) from the match's anchors on the forward
                     // target (match_anchor_kernel): R.seedOffset(i) = S.seedOffsetFromEnd(ns-1-i) and vice versa
                     int anchorStart = A.anchors[2 * (size_t)p + (isRc ? 1 : 0)], anchorEnd = A.anchors[2 * (size_t)p + (isRc ? 0 : 1)];
-                    if (anchorStart < 0 || anchorEnd < 0) laneBad = true;
+                    if (anchorStart == DP_NO_ANCHOR || anchorEnd == DP_NO_ANCHOR) laneBad = true, laneWhy = 12u;
                     // X.seg[2t] = S[2t] (forward) or S[2(ns - t)] (reverse complement)
                     while (startSeed > 0) {
                         const int gp = (isRc ? S[2 * (ns - startSeed)] : S[2 * startSeed]) + k;
@@ -593,7 +597,7 @@ struct consensus_full_kernel {
                         anchorEnd -= gp;
                         endSeed++;
                     }
-                    if (startSeed > endSeed) laneBad = true;
+                    if (startSeed > endSeed) laneBad = true, laneWhy = laneWhy ? laneWhy : 13u;
                     offset = anchorStart - startOffset;
                     inset = anchorEnd - endOffset;
                     nT = 2 * (endSeed - startSeed) + 3;
@@ -602,6 +606,7 @@ struct consensus_full_kernel {
             }
             if (__ballot(laneBad)) {
                 bad = true;
+                badWhy = (uint32_t)__shfl((int)laneWhy, __builtin_ctzll(__ballot(laneBad)), 64);
                 break;
             }
             const u64 keepMask = __ballot(keep);
@@ -610,6 +615,7 @@ struct consensus_full_kernel {
             const int nKeep = __popcll(keepMask);
             if (nseq + nKeep > 64 || tUsed + total > CF::T) {
                 bad = true;
+                badWhy = nseq + nKeep > 64 ? 8u : 9u;
                 break;
             }
             if (keep) {
@@ -654,7 +660,7 @@ struct consensus_full_kernel {
             nseq += nKeep;
             tUsed += total;
         }
-        if (bad || __ballot(laneWide)) CF_NOFIT()
+        if (bad || __ballot(laneWide)) CF_NOFIT(bad ? badWhy : 3u)  // a list the reference would panic on (2), > 64 sequences (8), trimmed ints beyond T (9) | 16-bit overflow
         if (nseq <= 1) {  // BuildConsensus needs more than one sequence (combine.go:183)
             if (lane == 0) A.gmeta[g] = gm;
             continue;
@@ -712,7 +718,7 @@ struct consensus_full_kernel {
             const int slot = kept >= 1 ? 2 * kept + 2 : 0;  // (even: Rmap / cm arrays are indexed by rb >> 1)
             const int incl = wave_incl_sum(slot);
             const int totalR = __shfl(incl, 63, 64);
-            if (totalR + 2 >= CF::R) CF_NOFIT()
+            if (totalR + 2 >= CF::R) CF_NOFIT(4u)
             if (mine) {
                 const int rb = incl - slot;
                 L.rb[lane] = rb;
@@ -738,7 +744,7 @@ struct consensus_full_kernel {
                 }
             }
         }
-        if (__ballot(laneWide)) CF_NOFIT()
+        if (__ballot(laneWide)) CF_NOFIT(5u)
         __builtin_amdgcn_wave_barrier();
         CF_TICK(3);
         // ---- 4. the alignment (multiAligner.Consensus :52-247); lane i owns sequence i.  hash[] is dead from here on.
@@ -968,7 +974,7 @@ struct consensus_full_kernel {
             A.dbg[8 * (size_t)g + 6] = ((unsigned long long)dbgUni << 32) | dbgGen;
             A.dbg[8 * (size_t)g + 7] = ((unsigned long long)nseq << 32) | dbgProp;
         }
-        if (__ballot(bad)) CF_NOFIT()
+        if (__ballot(bad)) CF_NOFIT(6u)  // consensus longer than CONS, a value outside the safe range
         if (lane == 0) L.cons[clen] = 0;
         if (mine) L.mLen[lane] = mlen;
         __builtin_amdgcn_wave_barrier();
@@ -1109,7 +1115,7 @@ struct consensus_full_kernel {
                 }
             }
         }
-        if (__ballot(partBad)) CF_NOFIT()
+        if (__ballot(partBad)) CF_NOFIT(7u)
         // contig + PAF numbers (combine.go:113-133, commands/overlap.go:199-231)
         const int myId = part ? L.tId[sq] : 0;
         const int myRc = part ? L.tRc[sq] : 0;
@@ -1352,6 +1358,18 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
                     ms, cnt, ng, sum[0] / cnt, mx[0], sum[1] / cnt, mx[1], sum[2] / cnt, mx[2], sum[3] / cnt, mx[3], sum[4] / cnt, mx[4], tot / cnt, totmx);
     }
     const uint8_t* h = (const uint8_t*)ctx->h_cout.p;
+    {
+        static const bool why = getenv("DP_CONS_WHY") != nullptr;
+        if (why) {
+            const dp_group_meta* gms = (const dp_group_meta*)h;
+            uint32_t hist[16] = {0}, nf = 0;
+            for (uint32_t g = 0; g < ng; g++)
+                if (gms[g].flag == 1) hist[gms[g].reserved & 15u]++, nf++;
+            if (nf)
+                fprintf(stderr, "[cons] %u of %u windows left to the host (huge layout %s): capacity %u | bad list (first index %u, index %u, anchors %u, start > end %u) | > 64 sequences %u | T %u | 16 bit %u | R %u | 16 bit R %u | consensus %u | parts %u\n",
+                        nf, ng, use_huge ? "on" : "off", hist[1], hist[10], hist[11], hist[12], hist[13], hist[8], hist[9], hist[3], hist[4], hist[5], hist[6], hist[7]);
+        }
+    }
     if (!ctx->cons_huge) {  // a window left to the host path: the next rounds of this context try the huge layout before that
         const dp_group_meta* gms = (const dp_group_meta*)h;
         for (uint32_t g = 0; g < ng; g++)

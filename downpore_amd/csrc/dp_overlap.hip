@@ -1813,7 +1813,11 @@ struct MRec {
 // (overlap/combine.go:171-181) needs both for every match; summing the gaps on the host means streaming the whole chunk
 // (~6 KB of pinned memory) per match, here it is one wave per match over segments that are resident anyway.
 // anchors[2*slot] = seg[0] + sum_{t=1..first}(seg[2t]+k), anchors[2*slot+1] = seg[n-1] + sum_{t=last+1..ns-1}(seg[2t]+k);
-// -1 when the chain's indices are not inside the target (the host then sums itself).
+// DP_NO_ANCHOR (INT32_MIN) when the chain's indices are not inside the target (the host then sums itself).  An anchor itself may
+// be negative: a chunk is a SubSequence of its read's seed sequence, its first gap is the gap in front of its first seed - negative
+// where two seeds overlap, which in the dense-seed regime (k = 10) they mostly do - and so may its last gap be.  (Until round 4
+// the sentinel was -1 and the consensus kernel read every negative anchor as "unknown": five windows per k = 10 round went to
+// the host path for it, each time with the round's whole scan output - 90 MB - fetched behind them.)
 struct AnchorFetch {  // 8-byte words copied by the launch (either direction: pinned host blocks on one side)
     unsigned long long* dst[3];
     const unsigned long long* src[3];
@@ -1843,7 +1847,7 @@ struct match_anchor_kernel {
         const int ns = (int)ref.n_seeds;
         const int32_t* s = segs + ref.seg_off;
         if (first < 0 || last < 0 || first >= ns || last >= ns) {
-            if (lane == 0) anchors[2 * slot] = anchors[2 * slot + 1] = -1;
+            if (lane == 0) anchors[2 * slot] = anchors[2 * slot + 1] = DP_NO_ANCHOR;
             continue;
         }
         int a = 0, b = 0;

@@ -237,7 +237,9 @@ typedef struct {
     const int32_t* target_anchor; /* [2*n_matches]: base offset of the chain's first target seed from the target's start
                                    * (GetSeedOffset(match_b[first])) and of its last one from the end
                                    * (GetSeedOffsetFromEnd(match_b[last])), seeds/sequence.go - what Trimmed()
-                                   * (overlap/combine.go:171-181) would otherwise sum over the whole chunk; -1 = not computed */
+                                   * (overlap/combine.go:171-181) would otherwise sum over the whole chunk; INT32_MIN = not
+                                   * computed.  A chunk's first / last gap may be negative (overlapping seeds), so an anchor may
+                                   * be too: the host mirror sums for itself whenever it sees a negative one */
     /* test hooks */
     uint32_t n_queries;
     const uint64_t* cand_off; /* [n_queries+1] */
