@@ -47,6 +47,11 @@ struct dp_ctx {
     dp_kindex* kidx = nullptr;   // resident k-mer position index (dp_kindex.hip), owned by the reads' owner
     DevBuf d_kx_sz, d_kx_lo, d_kx_tmp, d_kx_keys, d_kx_vals;  // per-round scratch of the index path
     uint64_t kx_hits = 0;
+    uint64_t kx_prev_hits = 0, kx_prev_segs = 0;  // the previous index-mode round of this context: what the one-go step is sized from
+    uint32_t kx_prev_max = 0, kx_prev_surv = 0;
+    uint64_t kx_oneshot_rounds = 0, kx_oneshot_redone = 0;
+    uint32_t kx_maxlen = 0;       // longest read (hit records hold 24 bits of position)
+    size_t kx_maxlen_reads = 0;   // ... of a read set of this many reads
     uint32_t kx_head_reads = 0;  // reads the zeroed extra-item list heads (d_kx_lo) are sized for
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -207,6 +212,15 @@ int dp_zero_fetch_regions(dp_ctx* ctx, const dp_zero_region* z, int nz, const dp
     } while (0)
 
 // resident k-mer position index (dp_kindex.hip)
+struct dp_kindex_oneshot {  // the index step of a round launched in one go, sized from guesses (dp_kindex_count)
+    uint64_t hits_guess;    // seed occurrences expected (sizes the record shards)
+    uint32_t surv_guess;    // survivors expected (grid of the sort pass)
+    uint32_t sort_cap;      // 256 / 1024 / 4096: hits of the largest survivor the sort pass is launched for
+    uint32_t min_seeds;     // chunkWorker's filter for read items (extra items carry their own)
+    int32_t* d_segs;        // segment buffer, seg_cap ints
+    uint64_t seg_cap;
+    int32_t* host_segs;     // pinned mirror for the extra items' segments (or null)
+};
 int dp_histogram_device(dp_ctx* ctx, int k, uint32_t* d_counts);  // dp_scan.hip
 int dp_kindex_ensure(dp_ctx* ctx, int k);
 int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, uint64_t* d_off, void** d_pos_out, uint64_t* n_pos_out,
@@ -214,7 +228,9 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
 void dp_kindex_free(dp_ctx* ctx);
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint4* s_pack, uint64_t* d_totals,
-                    unsigned long long* host_totals /* pinned, 48 bytes: the totals are stored there by the last kernel (or null) */);
+                    unsigned long long* host_totals /* pinned, 64 bytes: the totals are stored there by the last kernel (or null) */,
+                    const struct dp_kindex_oneshot* one = nullptr);
+int dp_kindex_refill(dp_ctx* ctx, const dp_scan_item* d_items, uint32_t n_read_items, uint32_t n_extra);
 int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     const uint32_t* d_sel, uint32_t n_sel, uint32_t max_count, const uint32_t* d_counts, const uint64_t* d_segoff,
                     const uint64_t* d_totals, int32_t* d_segs, int32_t* host_segs = nullptr);

@@ -263,6 +263,89 @@ struct kidx_unlink_extra {
 #else
 #define KX_PROFILING 0
 #endif
+// ---- hit records of the count pass (round 4) -------------------------------------------------------------------------
+// [63] the read carries extra items (query windows)  [62] the hit counts for its read item (in range, inside the item)
+// [61:38] read  [37:24] rank among the read's hits (the counter's value before this hit)  [23:0] position
+#define KX_REC_X (1ull << 63)
+#define KX_REC_V (1ull << 62)
+struct KxRec {
+    unsigned long long* rec;  // [64 * shard_cap] (null: no records this round)
+    uint32_t* kb;             // [2 * groups]: where the group's records start (0xffffffff: its shard was full), how many
+    uint32_t* flags;          // [0] a shard was full
+    uint32_t shard_cap;
+};
+__device__ __forceinline__ unsigned long long kx_rec(bool x, bool v, uint32_t r, uint32_t rank, uint32_t p) {
+    return (x ? KX_REC_X : 0ull) | (v ? KX_REC_V : 0ull) | ((unsigned long long)(r & 0xffffffu) << 38) |
+           ((unsigned long long)(rank & 0x3fffu) << 24) | (unsigned long long)(p & 0xffffffu);
+}
+
+// the fill pass from records: same thread layout as the count pass (a group's lanes over its stretch), no bucket walk
+struct kidx_fill_rec {
+    enum { THREADS = 256 };
+    static __device__ void run(const KxRec R, uint32_t n_groups, uint32_t lps, const dp_scan_item* __restrict__ items, uint32_t lo,
+                               uint32_t n_read_items, uint32_t min_seeds, const uint32_t* __restrict__ head,
+                               const uint32_t* __restrict__ next, const uint32_t* __restrict__ counts, uint32_t* __restrict__ fillc,
+                               const uint64_t* __restrict__ segoff, int32_t* __restrict__ segs, const uint64_t* __restrict__ totals,
+                               uint64_t seg_cap) {
+    if (R.flags[0] || totals[0] > seg_cap) return;  // (the host repeats the fill with the bucket walk / a larger buffer)
+    const int lane = dp_lane();
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t grp, s, j0, step;
+    if (lps == 64) {
+        grp = w;
+        s = w / KX_PARTS;
+        j0 = (uint32_t)lane;
+        step = 64;
+    } else {
+        grp = w * 4 + ((uint32_t)lane >> 4);
+        s = grp;
+        j0 = (uint32_t)lane & 15u;
+        step = 16;
+    }
+    if (grp >= n_groups) return;
+    const uint32_t at = R.kb[2 * (size_t)grp], gn = R.kb[2 * (size_t)grp + 1];
+    if (at == 0xffffffffu) return;
+    for (uint32_t jb = j0; jb < gn; jb += 4 * step) {
+        unsigned long long e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t j = jb + (uint32_t)u * step;
+            e[u] = j < gn ? R.rec[(size_t)at + j] : 0ull;
+        }
+        uint32_t cnt[4];
+        uint64_t so[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t it = (uint32_t)(e[u] >> 38) & 0xffffffu;
+            const bool val = (e[u] & KX_REC_V) != 0;
+            cnt[u] = val ? counts[it - lo] : 0u;
+            so[u] = val ? segoff[it - lo] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t r = (uint32_t)(e[u] >> 38) & 0xffffffu, p = (uint32_t)e[u] & 0xffffffu;
+            if ((e[u] & KX_REC_V) && cnt[u] >= min_seeds) {
+                const uint64_t to = so[u] + 2ull * ((uint32_t)(e[u] >> 24) & 0x3fffu);
+                segs[to] = (int32_t)p;
+                segs[to + 1] = (int32_t)s;
+            }
+            if (e[u] & KX_REC_X) {
+                for (uint32_t x = head[r]; x; x = next[x - 1]) {  // the round's extra items on this read (query windows)
+                    const uint32_t it = n_read_items + x - 1;
+                    const dp_scan_item xi = items[it];
+                    if (p - xi.start < xi.n_kmers && p >= xi.start && counts[it] >= xi.min_seeds) {
+                        const uint32_t slot = atomicAdd(&fillc[it], 1u);
+                        const uint64_t to = segoff[it] + 2ull * slot;
+                        segs[to] = (int32_t)(p - xi.start);
+                        segs[to + 1] = (int32_t)s;
+                    }
+                }
+            }
+        }
+    }
+}
+};
+
 template <bool FILL>
 struct kidx_walk {
     enum { THREADS = 256 };
@@ -272,7 +355,7 @@ struct kidx_walk {
                                                  const uint32_t* __restrict__ next, uint32_t* __restrict__ counts,
                                                  uint32_t* __restrict__ fillc, const uint64_t* __restrict__ segoff,
                                                  int32_t* __restrict__ segs, unsigned long long* __restrict__ n_hits, uint32_t lps,
-                                                 unsigned long long* __restrict__ dbg) {
+                                                 unsigned long long* __restrict__ dbg, const KxRec R) {
     const int lane = dp_lane();
     // DP_KX_DEBUG: when a wave started, had its bucket bounds, its entries, its items, and was done (100 MHz ticks since dbg[15],
     // sums over waves in dbg[0..4], maxima in dbg[5..9], waves in dbg[10])
@@ -287,9 +370,10 @@ struct kidx_walk {
     // lps = lanes per seed.  64: KX_PARTS waves share one seed's bucket (dense seeds: buckets of hundreds to thousands);
     // 16: four seeds per wave (k = 13 at config 2: ~20 occurrences per seed - a whole wave per quarter bucket left 59 lanes idle
     // and made 40 k waves of a 10 k-seed round)
-    uint32_t s, i0, i1, step, n;
+    // a "group" is what walks one stretch of a bucket together: a seed (16 lanes), or one of the KX_PARTS waves of a seed
+    uint32_t s, i0, i1, step, n, grp, gfirst;
     uint64_t o;
-    int first;
+    int gleader;
     if (lps == 64) {
         s = w / KX_PARTS;
         const uint32_t part = w % KX_PARTS;
@@ -297,22 +381,48 @@ struct kidx_walk {
         o = off[seeds[s]];
         n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
         const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
+        gfirst = min(n, part * per);
         i0 = part * per + (uint32_t)lane;
         i1 = min(n, part * per + per);
         step = 64;
-        first = lane == 0 && part == 0;
+        grp = w;
+        gleader = lane == 0;
     } else {
         s = w * 4 + ((uint32_t)lane >> 4);
         if (s >= n_seeds) return;
         o = off[seeds[s]];
         n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
+        gfirst = 0;
         i0 = (uint32_t)lane & 15u;
         i1 = n;
         step = 16;
-        first = (lane & 15) == 0;
+        grp = s;
+        gleader = (lane & 15) == 0;
     }
     KX_TICK(1)
-    if (!FILL && first && n) atomicAdd(&n_hits[s & 63u], (unsigned long long)n);  // (64 slots: 10 k same-address atomics serialise)
+    // Hit records (round 4): the count pass keeps every hit - {read, position, the rank the read's counter returned} - in a
+    // stretch of R.rec of its group's own, so that the fill pass is one streaming pass over records (R.rec[at + j] -> the
+    // survivor's slice at slot `rank`) instead of a second walk over seeds, buckets, items and counters.  Stretches are handed out
+    // from 64 shards (the seed-occurrence counters of before, now read back: one returning atomic per group); a shard that is full
+    // sets R.flags[0] and the round's fill pass walks the buckets as it used to.
+    uint32_t rec_at = 0xffffffffu;
+    if (!FILL) {
+        const uint32_t gn = i1 > gfirst ? i1 - gfirst : 0u;
+        unsigned long long old = 0;
+        if (gleader && gn) old = atomicAdd(&n_hits[grp & 63u], (unsigned long long)gn);  // (64 slots: 10 k same-address atomics serialise)
+        if (R.rec) {
+            if (gleader) {
+                if (old + gn <= R.shard_cap) {
+                    rec_at = (grp & 63u) * R.shard_cap + (uint32_t)old;
+                } else if (gn) {
+                    R.flags[0] = 1u;
+                }
+                R.kb[2 * (size_t)grp] = rec_at;
+                R.kb[2 * (size_t)grp + 1] = gn;
+            }
+            rec_at = (uint32_t)__shfl((int)rec_at, lps == 64 ? 0 : (lane & 48), 64);
+        }
+    }
     // Four entries per lane and trip: a hit is a chain of dependent loads (entry -> the read's item and list head -> counter), each
     // link a trip to HBM through a TLB that an 8 GB table defeats; the links of four entries travel together instead of one
     // after the other (a seed of config 2 has 20-40 entries: one trip of a 16-lane group instead of three)
@@ -355,7 +465,15 @@ struct kidx_walk {
             const uint32_t r = (uint32_t)(e[u] >> 32), p = (uint32_t)e[u];
             if (!FILL) {
                 // (ignored reads carry n_kmers == 0; a top-level read with len % 4 == 0 four k-mers less)
-                if (in[u] && p < item[u].n_kmers) atomicAdd(&counts[r - lo], 1u);
+                const bool valid = in[u] && p < item[u].n_kmers;
+                if (R.rec) {
+                    uint32_t rank = 0;
+                    if (valid) rank = atomicAdd(&counts[r - lo], 1u);
+                    if (v[u] && rec_at != 0xffffffffu)
+                        R.rec[(size_t)rec_at + (ib + (uint32_t)u * step - gfirst)] = kx_rec(hd[u] != 0, valid, r, rank, p);
+                } else if (valid) {
+                    atomicAdd(&counts[r - lo], 1u);
+                }
             } else if (in[u] && cnt[u] >= item[u].min_seeds) {
                 const uint32_t slot = atomicAdd(&fillc[r - lo], 1u);
                 const uint64_t at = so[u] + 2ull * slot;
@@ -508,7 +626,7 @@ struct kidx_offsets {
             if (seen == n_tiles) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
-                for (int w = 0; w < 6; w++)
+                for (int w = 0; w < 8; w++)
                     host_totals[w] = __hip_atomic_load((const unsigned long long*)&totals[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -527,7 +645,8 @@ struct kidx_sortwrite {
                                                      const uint32_t* __restrict__ n_sel_p, const uint32_t* __restrict__ counts,
                                                      const uint64_t* __restrict__ segoff, int32_t* __restrict__ segs, int k,
                                                      uint32_t* __restrict__ overflow, uint32_t n_read_items, uint32_t n_extra,
-                                                     uint32_t* __restrict__ head, int32_t* __restrict__ host_segs) {
+                                                     uint32_t* __restrict__ head, int32_t* __restrict__ host_segs,
+                                                     const uint64_t* __restrict__ totals, uint64_t seg_cap) {
     // host_segs (may be null): pinned host mirror of segs[] - the extra items' (query windows') segments are stored there as
     // well, at the same offsets: they are what the host wants of this pass, and no copy has to fetch them afterwards
     __shared__ unsigned long long keys[CAP];
@@ -535,6 +654,9 @@ struct kidx_sortwrite {
     const uint32_t n_sel = *n_sel_p;
     // the fill pass (previous launch) was the last reader of the extra items' lists: head[] back to all zero
     for (uint32_t e = blockIdx.x * 64 + lane; e < n_extra; e += gridDim.x * 64) head[items[n_read_items + e].read] = 0;
+    // launched without a wait behind the counting step (round 4): the segment buffer was sized from the round before - a round
+    // that needs more, or whose records did not fit, is filled and sorted again by the host's second attempt
+    if (totals && (totals[0] > seg_cap || (uint32_t)totals[6] != 0u)) return;
     for (uint32_t sv = blockIdx.x; sv < n_sel; sv += gridDim.x) {
         const uint32_t it = sel[sv];
         const uint32_t c = counts[it];
@@ -627,9 +749,12 @@ static uint32_t kidx_walk_blocks(const dp_kindex* ix, int k, uint32_t S) {
 
 // Counting step of a round from the index: counts, segment offsets, compacted survivor list and totals for all items, with
 // no host round trip.  d_work = [counts n | fill cursors n | tile status (tiles + 1) u64 | ticket, max count] (zeroed here).
+// `one` (round 4, may be null): the whole index step in one go - the count pass keeps hit records, and behind the offsets scan the
+// fill pass (from the records) and the sort/write pass are launched at once into a segment buffer sized from the round before;
+// the caller waits once and repeats fill + sort (dp_kindex_refill) for the rare round that outgrew a guess.
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint4* s_pack,
-                    uint64_t* d_totals, unsigned long long* host_totals) {
+                    uint64_t* d_totals, unsigned long long* host_totals, const dp_kindex_oneshot* one) {
     dp_kindex* ix = kidx_owner(ctx)->kidx;
     const uint32_t S = ctx->n_seeds, n_items = n_read_items + n_extra;
     if (n_items >= (1u << 24)) return 1;  // (the scan's status word holds 24 bits of survivors) -> scan kernels
@@ -662,6 +787,24 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                            ctx->extras_staged ? (const dp_scan_item*)ctx->h_extra.p : (const dp_scan_item*)nullptr);
         ctx->extras_staged = false;
     }
+    // hit records: 64 shards of (estimated hits / 64) * 1.5 + 4096 records, two words per group
+    KxRec R{nullptr, nullptr, nullptr, 0u};
+    const uint32_t lps = kidx_lps(ix, k);
+    const uint32_t n_groups = lps == 64 ? S * KX_PARTS : S;
+    if (one && S) {
+        // (no round of this context yet: three times the seeds' share of all positions - seeds are the commoner k-mers)
+        const uint64_t first_guess = (uint64_t)((double)S * (double)(ix->n_pos) / (double)((uint64_t)1 << (2 * k)) * 3.0);
+        const uint64_t est = std::max<uint64_t>(one->hits_guess ? one->hits_guess : first_guess, 65536);
+        const uint64_t shard = est / 64 + est / 128 + 4096;
+        if (shard * 64 < 0xfffffff0ull) {
+            if (dev_reserve(ctx, ctx->d_kx_keys, (size_t)shard * 64 * 8 + 64)) return DP_ERR_HIP;
+            if (dev_reserve(ctx, ctx->d_kx_tmp, (size_t)n_groups * 8 + 64)) return DP_ERR_HIP;
+            R.rec = (unsigned long long*)ctx->d_kx_keys.p;
+            R.kb = (uint32_t*)ctx->d_kx_tmp.p;
+            R.flags = (uint32_t*)(d_totals + 6);
+            R.shard_cap = (uint32_t)shard;
+        }
+    }
     static const bool kx_debug = getenv("DP_KX_DEBUG") != nullptr;
     unsigned long long* dbg = nullptr;
     const size_t n_dbg_waves = (size_t)kidx_walk_blocks(ix, k, S) * 4;
@@ -672,7 +815,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     if (S)
         dp_launch<kidx_walk<false>>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
                            (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
-                           (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k), dbg);
+                           (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k), dbg, R);
     if (kx_debug) {
         std::vector<unsigned long long> h(n_dbg_waves * 8);
         hipStreamSynchronize(ctx->stream);
@@ -704,7 +847,44 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                        (const unsigned long long*)n_hits, host_totals);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 1));
+    if (one && R.rec) {
+        DP_HIP(dp_mark(ctx, 2));
+        dp_launch<kidx_fill_rec>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), R, n_groups, lps, d_items, lo, n_read_items, one->min_seeds,
+                                 (const uint32_t*)head, (const uint32_t*)next, (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff,
+                                 one->d_segs, (const uint64_t*)d_totals, one->seg_cap);
+        // (the survivor count is on the device only: the grid covers the most survivors a round of this context has had so far,
+        // the kernel strides over the rest)
+        const dim3 sg(std::max<uint32_t>(256u, std::min<uint32_t>(one->surv_guess, 16384))), sb(64);
+        uint32_t* ovf = (uint32_t*)(d_totals + 4);
+        const uint32_t* nsp = (const uint32_t*)(d_totals + 1);
+        if (one->sort_cap <= 256)
+            dp_launch<kidx_sortwrite<256>>(ctx, sg, sb, d_items, (const uint32_t*)s_item, nsp, (const uint32_t*)d_counts, (const uint64_t*)d_segoff,
+                                           one->d_segs, k, ovf, n_read_items, n_extra, head, one->host_segs, (const uint64_t*)d_totals, one->seg_cap);
+        else if (one->sort_cap <= 1024)
+            dp_launch<kidx_sortwrite<1024>>(ctx, sg, sb, d_items, (const uint32_t*)s_item, nsp, (const uint32_t*)d_counts, (const uint64_t*)d_segoff,
+                                            one->d_segs, k, ovf, n_read_items, n_extra, head, one->host_segs, (const uint64_t*)d_totals, one->seg_cap);
+        else
+            dp_launch<kidx_sortwrite<KX_SORT_LDS>>(ctx, sg, sb, d_items, (const uint32_t*)s_item, nsp, (const uint32_t*)d_counts,
+                                                   (const uint64_t*)d_segoff, one->d_segs, k, ovf, n_read_items, n_extra, head, one->host_segs,
+                                                   (const uint64_t*)d_totals, one->seg_cap);
+        DP_HIP(hipGetLastError());
+        DP_HIP(dp_mark(ctx, 3));
+    }
     (void)k;
+    return (one && !R.rec) ? 2 : DP_OK;  // 2: the one-go form was asked for and could not be launched (no seeds / too many records)
+}
+
+// Second attempt of a round whose one-go fill + sort gave up (segment buffer or record shards too small, a survivor with more hits
+// than the guessed sort holds): the extra items are linked to their reads again (the sort pass has unlinked them), the fill cursors
+// go back to zero, then the bucket-walking fill and the sort with the right capacity - dp_kindex_write as before round 4.
+int dp_kindex_refill(dp_ctx* ctx, const dp_scan_item* d_items, uint32_t n_read_items, uint32_t n_extra) {
+    const uint32_t n_items = n_read_items + n_extra;
+    uint32_t* head = (uint32_t*)ctx->d_kx_lo.p;
+    uint32_t* next = (uint32_t*)ctx->d_kx_vals.p;
+    const dp_zero_region z = {ctx->d_kx_sz.p, (size_t)n_items * 4};
+    if (int rc = dp_zero_regions(ctx, &z, 1)) return rc;
+    if (n_extra) hipLaunchKernelGGL(kidx_link_extra, dim3((n_extra + 255) / 256), dim3(256), 0, ctx->stream, d_items, n_read_items, n_extra, head, next);
+    DP_HIP(hipGetLastError());
     return DP_OK;
 }
 
@@ -728,19 +908,19 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             dp_launch<kidx_walk<true>>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
                                (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
                                (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr, kidx_lps(ix, k),
-                               (unsigned long long*)nullptr);
+                               (unsigned long long*)nullptr, KxRec{nullptr, nullptr, nullptr, 0u});
         const dim3 sg(std::min<uint32_t>(n_sel, 16384)), sb(64);
         uint32_t* ovf = (uint32_t*)(d_totals + 4);
         const uint32_t* nsp = (const uint32_t*)(d_totals + 1);
         if (max_count <= 128)
             dp_launch<kidx_sortwrite<256>>(ctx, sg, sb, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
-                               n_extra, head, host_segs);
+                               n_extra, head, host_segs, (const uint64_t*)nullptr, (uint64_t)0);
         else if (max_count <= 512)
             dp_launch<kidx_sortwrite<1024>>(ctx, sg, sb, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
-                               n_extra, head, host_segs);
+                               n_extra, head, host_segs, (const uint64_t*)nullptr, (uint64_t)0);
         else
             dp_launch<kidx_sortwrite<KX_SORT_LDS>>(ctx, sg, sb, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf,
-                               n_read_items, n_extra, head, host_segs);
+                               n_read_items, n_extra, head, host_segs, (const uint64_t*)nullptr, (uint64_t)0);
         DP_HIP(hipGetLastError());
     }
     if (n_extra && (rc != DP_OK || !n_sel))  // (otherwise the sort kernel has put head[] back to zero)

@@ -1632,13 +1632,52 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         if (rc > 0) use_index = false;  // k > 14 or not enough free HBM for 8 B per base: scan
     }
     out->index_hits = 0;
+    // Round 4: the index step in one go - count (+ hit records), offsets, fill from the records and sort/write are all launched
+    // before the one wait, into buffers sized from this context's previous index-mode round (twice its segments, 1.5 x its hits, the
+    // sort tier of 1.25 x its largest survivor); the rare round that outgrows a guess repeats fill + sort the old way after the
+    // wait.  DP_KX_ONESHOT=0: count, wait, size, fill, sort, wait - as before.
+    static const bool oneshot_env = [] {
+        const char* e = getenv("DP_KX_ONESHOT");
+        return !(e && e[0] == '0');
+    }();
+    bool oneshot = false;
+    dp_kindex_oneshot one;
+    memset(&one, 0, sizeof one);
+    const bool mirror_wanted = ctx->scan_fetch_extras_only && n_extra > 0;
+    if (use_index) {
+        const std::vector<uint32_t>& lens = ctx->owner ? ctx->owner->h_len : ctx->h_len;
+        if (ctx->kx_maxlen_reads != lens.size()) {  // (records hold 24 bits of read id and of position)
+            uint32_t mx = 0;
+            for (uint32_t L : lens) mx = std::max(mx, L);
+            ctx->kx_maxlen = mx;
+            ctx->kx_maxlen_reads = lens.size();
+        }
+        oneshot = oneshot_env && ctx->n_seeds > 0 && ctx->n_reads < (1u << 24) && ctx->kx_maxlen < (1u << 24);
+        if (oneshot) {
+            one.hits_guess = ctx->kx_prev_hits ? ctx->kx_prev_hits + ctx->kx_prev_hits / 2 : 0;
+            one.surv_guess = ctx->kx_prev_surv ? ctx->kx_prev_surv + ctx->kx_prev_surv / 4 : 8192;
+            const uint32_t mxg = ctx->kx_prev_max + ctx->kx_prev_max / 4;
+            one.sort_cap = mxg <= 128 ? 256u : (mxg <= 512 ? 1024u : 4096u);
+            one.min_seeds = min_seeds;
+            const uint64_t want = std::max<uint64_t>(2 * ctx->kx_prev_segs + 65536, 1u << 20);
+            if (dev_reserve(ctx, ctx->d_segs, want * 4 + 64)) return DP_ERR_HIP;
+            one.seg_cap = (ctx->d_segs.cap - 64) / 4;
+            if (mirror_wanted) {
+                if (pin_reserve(ctx, ctx->h_segs, one.seg_cap * 4 + 64)) return DP_ERR_HIP;
+                one.host_segs = (int32_t*)ctx->h_segs.p;
+            }
+            one.d_segs = (int32_t*)ctx->d_segs.p;
+        }
+    }
     if (use_index) {
         // counts, segment offsets, survivor list and totals in three launches, no sort and no host round trip (dp_kindex.hip)
         int rc = dp_kindex_count(ctx, k, d_items, lo, hi, n_read_items, n_extra, (uint32_t*)ctx->d_counts.p, (uint64_t*)ctx->d_segoff.p,
-                                 s_item, s_count, s_off, s_pack, totals, (unsigned long long*)ctx->h_total.p);
+                                 s_item, s_count, s_off, s_pack, totals, (unsigned long long*)ctx->h_total.p, oneshot ? &one : nullptr);
         if (rc < 0) return rc;
-        if (rc > 0) use_index = false;  // more items than its scan handles: this round is scanned
+        if (rc == 2) oneshot = false;   // (records not possible this round: the two-step form follows)
+        else if (rc > 0) use_index = false;  // more items than its scan handles: this round is scanned
     }
+    if (!use_index) oneshot = false;
     out->index_mode = use_index ? 1u : 0u;
     if (!use_index) {
         if (int rc = fetch_extras()) return rc;
@@ -1689,13 +1728,32 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         out->index_hits = ctx->kx_hits;
     }
     const uint32_t kx_max_count = (uint32_t)((uint64_t*)ctx->h_total.p)[3];
+    bool oneshot_done = false;
+    if (oneshot) {
+        // did the guesses hold?  (the kernels behind the count step gave up on their own where a buffer was too small)
+        const bool rec_full = (uint32_t)((uint64_t*)ctx->h_total.p)[6] != 0;
+        oneshot_done = n_segs <= one.seg_cap && !rec_full && kx_max_count <= one.sort_cap;
+        ctx->kx_oneshot_rounds++;
+        if (!oneshot_done) ctx->kx_oneshot_redone++;
+        ctx->kx_prev_hits = ((uint64_t*)ctx->h_total.p)[2];
+        ctx->kx_prev_segs = n_segs;
+        ctx->kx_prev_max = kx_max_count;
+        ctx->kx_prev_surv = (uint32_t)n_surv_all;
+        static const bool dbg1 = getenv("DP_KX_ONESHOT_DEBUG") != nullptr;
+        if (dbg1 && !oneshot_done)
+            fprintf(stderr, "[kx] one-go step repeated: segs %llu / cap %llu, records %s, largest survivor %u / sort %u (%llu of %llu rounds)\n",
+                    (unsigned long long)n_segs, (unsigned long long)one.seg_cap, rec_full ? "full" : "ok", kx_max_count, one.sort_cap,
+                    (unsigned long long)ctx->kx_oneshot_redone, (unsigned long long)ctx->kx_oneshot_rounds);
+        if (!oneshot_done && kx_max_count <= 4096)
+            if (int rc = dp_kindex_refill(ctx, (const dp_scan_item*)d_items, n_read_items, n_extra)) return rc;
+    }
     if (dev_reserve(ctx, ctx->d_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_segs, n_segs * 4 + 64)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_surv, n_surv_all * 32 + 128)) return DP_ERR_HIP;
     ctx->last_surv_all = (uint32_t)n_surv_all;
     float ms0 = 0, ms1 = 0, msoff = 0;
     ms0 = dp_elapsed(ctx, 0, 1);
-    msoff = dp_elapsed(ctx, 1, 4);
+    msoff = oneshot ? 0.f : dp_elapsed(ctx, 1, 4);  // (one-go step: fill + sort lie between these two marks, and are ms1 below)
     uint32_t* h_item = (uint32_t*)ctx->h_surv.p;
     uint32_t* h_count = h_item + n_surv_all;
     uint64_t* h_off = (uint64_t*)(h_count + n_surv_all + (n_surv_all & 1));
@@ -1704,8 +1762,10 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     // them into the pinned block as it writes them (no store launch afterwards)
     const bool mirror_extras = use_index && ctx->scan_fetch_extras_only && n_extra > 0;
     if (n_segs) {
-        DP_HIP(dp_mark(ctx, 2));
-        if (use_index) {
+        if (!oneshot_done) DP_HIP(dp_mark(ctx, 2));
+        if (oneshot_done) {
+            // (fill + sort ran behind the counting step already)
+        } else if (use_index) {
             int rc = dp_kindex_write(ctx, k, (const dp_scan_item*)d_items, lo, hi, n_read_items, n_extra, (const uint32_t*)s_item,
                                      (uint32_t)n_surv_all, kx_max_count, (const uint32_t*)ctx->d_counts.p, (const uint64_t*)ctx->d_segoff.p,
                                      (const uint64_t*)totals, (int32_t*)ctx->d_segs.p, mirror_extras ? (int32_t*)ctx->h_segs.p : (int32_t*)nullptr);
@@ -1724,7 +1784,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
                                (int32_t*)ctx->d_segs.p, 0u, (const uint32_t*)s_item, (uint32_t)n_surv_all);
         }
         DP_HIP(hipGetLastError());
-        DP_HIP(dp_mark(ctx, 3));
+        if (!oneshot_done) DP_HIP(dp_mark(ctx, 3));
         if (n_segs * 4 > ((uint64_t)8 << 20)) {
             // dense-seed regime: tens of MB go back to the host; let the next slot's scan start while they travel
             if (!ctx->timing_on) DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
