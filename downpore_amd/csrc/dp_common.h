@@ -50,6 +50,14 @@ struct dp_ctx {
     uint64_t kx_prev_hits = 0, kx_prev_segs = 0;  // the previous index-mode round of this context: what the one-go step is sized from
     uint32_t kx_prev_max = 0, kx_prev_surv = 0;
     uint64_t kx_oneshot_rounds = 0, kx_oneshot_redone = 0;
+    // dp_index_prechain: the chunk stage launched behind an un-waited scan
+    bool pc_armed = false, pc_launched = false;
+    int64_t pc_chunk_size = 0, pc_overlap = 0;
+    uint32_t pc_min_seeds = 0, pc_cap = 0, pc_tiles = 0, pc_prev_cap = 0, pc_prev_ns = 0;
+    int32_t pc_inset = 0;
+    uint64_t pc_hits = 0, pc_misses = 0;
+    uint32_t last_n_extra = 0;    // extra items of the last dp_scan_reads
+    uint32_t kx_seq = 0;          // sequence number the sort pass of a one-go index step stores into h_total[15] when its output is complete
     uint32_t kx_maxlen = 0;       // longest read (hit records hold 24 bits of position)
     size_t kx_maxlen_reads = 0;   // ... of a read set of this many reads
     uint32_t kx_head_reads = 0;  // reads the zeroed extra-item list heads (d_kx_lo) are sized for
@@ -220,6 +228,8 @@ struct dp_kindex_oneshot {  // the index step of a round launched in one go, siz
     int32_t* d_segs;        // segment buffer, seg_cap ints
     uint64_t seg_cap;
     int32_t* host_segs;     // pinned mirror for the extra items' segments (or null)
+    uint32_t* done_flag;    // pinned: the chunk stage launched behind the step (dp_index_prechain) stores done_seq here as it starts
+    uint32_t done_seq;
 };
 int dp_histogram_device(dp_ctx* ctx, int k, uint32_t* d_counts);  // dp_scan.hip
 int dp_kindex_ensure(dp_ctx* ctx, int k);
@@ -231,6 +241,9 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                     unsigned long long* host_totals /* pinned, 64 bytes: the totals are stored there by the last kernel (or null) */,
                     const struct dp_kindex_oneshot* one = nullptr);
 int dp_kindex_refill(dp_ctx* ctx, const dp_scan_item* d_items, uint32_t n_read_items, uint32_t n_extra);
+int dp_index_prechain_launch(dp_ctx* ctx, const uint64_t* scan_totals, uint32_t n_extra, uint64_t seg_cap, uint32_t* done_flag,
+                             uint32_t done_seq);  // dp_overlap.hip
+void dp_index_prechain_cancel(dp_ctx* ctx);
 int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     const uint32_t* d_sel, uint32_t n_sel, uint32_t max_count, const uint32_t* d_counts, const uint64_t* d_segoff,
                     const uint64_t* d_totals, int32_t* d_segs, int32_t* host_segs = nullptr);

@@ -656,8 +656,8 @@ struct kidx_sortwrite {
     for (uint32_t e = blockIdx.x * 64 + lane; e < n_extra; e += gridDim.x * 64) head[items[n_read_items + e].read] = 0;
     // launched without a wait behind the counting step (round 4): the segment buffer was sized from the round before - a round
     // that needs more, or whose records did not fit, is filled and sorted again by the host's second attempt
-    if (totals && (totals[0] > seg_cap || (uint32_t)totals[6] != 0u)) return;
-    for (uint32_t sv = blockIdx.x; sv < n_sel; sv += gridDim.x) {
+    const bool gave_up = totals && (totals[0] > seg_cap || (uint32_t)totals[6] != 0u);
+    for (uint32_t sv = blockIdx.x; sv < n_sel && !gave_up; sv += gridDim.x) {
         const uint32_t it = sel[sv];
         const uint32_t c = counts[it];
         const uint64_t out = segoff[it];
@@ -773,12 +773,12 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     uint32_t* head = (uint32_t*)ctx->d_kx_lo.p;
     uint32_t* next = (uint32_t*)ctx->d_kx_vals.p;
     const size_t b_counts = (size_t)n_items * 4;
-    if (dev_reserve(ctx, ctx->d_kx_sz, 2 * b_counts + ((size_t)n_tiles + 2) * 8 + 64 * 8 + 64)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_kx_sz, 2 * b_counts + ((size_t)n_tiles + 2) * 8 + 64 * 8 + 128)) return DP_ERR_HIP;
     uint32_t* fillc = (uint32_t*)ctx->d_kx_sz.p;
     unsigned long long* status = (unsigned long long*)((uint8_t*)ctx->d_kx_sz.p + ((b_counts + 7) & ~(size_t)7));
     uint32_t* ticket = (uint32_t*)(status + n_tiles + 1);
     unsigned long long* n_hits = (unsigned long long*)(ticket + 2);  // [64]
-    const uint32_t n_work = (uint32_t)((((b_counts + 7) & ~(size_t)7) + ((size_t)n_tiles + 1) * 8 + 8 + 64 * 8) / 4);
+    const uint32_t n_work = (uint32_t)((((b_counts + 7) & ~(size_t)7) + ((size_t)n_tiles + 1) * 8 + 8 + 64 * 8 + 8) / 4);
     DP_HIP(dp_mark(ctx, 0));
     {
         const uint32_t n_thr = std::max(std::max(n_work, n_items), std::max(n_extra, 16u));

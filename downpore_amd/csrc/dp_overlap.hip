@@ -153,6 +153,16 @@ struct ChunkParams {
     uint4* f_dst;
     const uint4* f_src;
     unsigned long long f_n16;
+    // launched behind a scan that nobody has waited for yet (dp_index_prechain, round 4): the survivor count is read from the scan's
+    // totals (survivors + extra items at [1]), the grid was sized from a guess, and a scan whose own guesses failed (segments
+    // beyond seg_cap at [0], the sort pass's overflow word at [4], record shards full at [6]) left no segments to chunk
+    const u64* scan_totals;  // null: `ns` is exact and the scan's output complete
+    uint32_t n_extra, grid_tiles;
+    u64 seg_cap;
+    // ... and the host does not wait for the stream but for this word (pinned): that this kernel runs says that the scan's kernels
+    // are done and what they wrote - the extra items' segments in the host's pinned block among it - has arrived
+    uint32_t* done_flag;
+    uint32_t done_seq;
 };
 
 template <bool WRITE>
@@ -246,8 +256,27 @@ struct chunk_kernel {
     static __device__ void run(const ChunkParams P, unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t tile_s, base_s;
+    uint32_t ns = P.ns;
+    if (P.done_flag && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(P.done_flag, P.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (P.scan_totals) {
+        const u64 all = P.scan_totals[1];
+        ns = all > P.n_extra ? (uint32_t)(all - P.n_extra) : 0u;
+        const bool scan_failed = P.scan_totals[0] > P.seg_cap || (uint32_t)P.scan_totals[4] != 0u || (uint32_t)P.scan_totals[6] != 0u;
+        if (scan_failed || (ns + 1023u) / 1024u > P.grid_tiles) {  // nothing to chunk / not enough tiles: the host launches again
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                P.n_out[0] = 0u;
+                P.n_out[1] = 2u;
+            }
+            return;
+        }
+    }
     // (a launch shared with other rounds has the largest round's grid: blocks beyond this round's own tiles take no ticket)
-    const uint32_t n_tiles = (P.ns + 1023u) / 1024u;
+    const uint32_t n_tiles = (ns + 1023u) / 1024u;
+    if (n_tiles == 0 && blockIdx.x == 0 && threadIdx.x == 0) {  // (no survivor: no tile writes the count)
+        P.n_out[0] = 0u;
+        P.n_out[1] = 0u;
+    }
     if (blockIdx.x >= n_tiles) {
         const uint32_t zb = blockIdx.x - n_tiles;
         if (zb >= P.zero_blocks) return;
@@ -265,7 +294,7 @@ struct chunk_kernel {
     const uint32_t tile = tile_s;
     const int lane = dp_lane(), wave = threadIdx.x >> 6;
     const uint32_t i = tile * 1024 + threadIdx.x;
-    const uint32_t cnt = i < P.ns ? chunk_one<false>(P, i, 0) : 0u;
+    const uint32_t cnt = i < ns ? chunk_one<false>(P, i, 0) : 0u;
     const uint32_t x = (uint32_t)wave_incl_sum((int)cnt);
     if (lane == 63) wsum[wave] = x;
     __syncthreads();
@@ -291,7 +320,7 @@ struct chunk_kernel {
             __hip_atomic_store(&status[tile], (2ull << 62) | (excl + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
         base_s = (uint32_t)excl;
-        if ((uint64_t)(tile + 1) * 1024 >= P.ns) {  // last tile: the totals
+        if ((uint64_t)(tile + 1) * 1024 >= ns) {  // last tile: the totals
             const unsigned long long all = excl + total;
             P.n_out[0] = (uint32_t)min(all, (unsigned long long)P.cap);
             P.n_out[1] = all > P.cap ? 1u : 0u;
@@ -321,27 +350,16 @@ static uint32_t chunk_cap_of(uint32_t numSeeds, long long length, long long chun
     return (numSeeds - 150) / (uint32_t)step + 3;
 }
 
-extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t overlap, uint32_t min_seeds, int32_t inset,
-                                      uint32_t n_survivors, uint32_t* n_seqs_cap) {
-    if (!ctx || chunk_size < 1 || !n_seqs_cap) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_index_build_chunked: bad arguments") : DP_ERR_ARG;
-    if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_index_build_chunked before dp_round_begin");
-    if (!ctx->h_surv.p || !ctx->d_surv.p) return dp_fail(ctx, DP_ERR_STATE, "dp_index_build_chunked: no dp_scan_reads result on this context");
-    hipSetDevice(ctx->device);
+// Launches chunk_kernel + index_fill_kernel + posting_meta_kernel for `cap` chunks at most.  scan_totals == null: n_survivors is
+// exact (the caller has the scan's result).  Otherwise (dp_index_prechain): behind a scan nobody has waited for - the survivor
+// count is read on the device, n_survivors only sizes the grid.
+static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap, uint32_t min_seeds, int32_t inset, uint32_t n_survivors,
+                                uint32_t cap, const u64* scan_totals, uint32_t n_extra, u64 seg_cap, uint32_t* done_flag = nullptr,
+                                uint32_t done_seq = 0) {
     const uint32_t n_items = ctx->scan_items;
-    if (n_survivors > n_items) return dp_fail(ctx, DP_ERR_ARG, "dp_index_build_chunked: more survivors than scan items");
-    // the library still has the survivors' hit counts and read ids on the host (pinned output of the scan)
     const uint32_t* s_item = (const uint32_t*)ctx->d_surv.p;
     const uint32_t* s_count = s_item + n_items;
     const u64* s_off = (const u64*)(s_count + n_items + (n_items & 1));
-    uint64_t cap64 = 0;
-    {
-        const uint32_t* h_item = (const uint32_t*)ctx->h_surv.p;  // (already turned into read ids by dp_scan_reads)
-        const uint32_t* h_count = h_item + ctx->last_surv_all;
-        const std::vector<uint32_t>& lens = ctx->owner ? ctx->owner->h_len : ctx->h_len;
-        for (uint32_t i = 0; i < n_survivors; i++) cap64 += chunk_cap_of(h_count[i], (long long)lens[h_item[i]], chunk_size, (int)min_seeds);
-    }
-    if (cap64 > 0xfffffff0ull) return dp_fail(ctx, DP_ERR_CAPACITY, "dp_index_build_chunked: more than 2^32 chunks");
-    const uint32_t cap = (uint32_t)cap64;
     const uint32_t S = ctx->n_seeds;
     const uint32_t W = std::max<uint32_t>(1, (cap + 63) / 64), SW = std::max<uint32_t>(1, (S + 63) / 64);
     ctx->n_seqs = cap;
@@ -350,7 +368,6 @@ extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t o
     ctx->word_base = 0;
     ctx->global_n_seqs = 0;
     ctx->chunks_on_device = true;
-    *n_seqs_cap = cap;
     if (dev_reserve(ctx, ctx->d_seqrefs, (size_t)cap * sizeof(dp_seq_ref) + 16)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_chunk_meta, (size_t)cap * sizeof(dp_seq_meta) + 16)) return DP_ERR_HIP;
     const uint32_t n_tiles = (n_survivors + 1023) / 1024;
@@ -395,7 +412,13 @@ extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t o
         P.f_dst = nullptr;
         P.f_src = nullptr;
         P.f_n16 = 0;
-        if (ctx->q_pre_bytes && !ctx->q_pre_fetched && ctx->h_qup.p && ctx->d_qsegs.p) {  // (both blocks are 64 bytes longer than the data)
+        P.scan_totals = scan_totals;
+        P.n_extra = n_extra;
+        P.grid_tiles = n_tiles;
+        P.seg_cap = seg_cap;
+        P.done_flag = done_flag;
+        P.done_seq = done_seq;
+        if (!scan_totals && ctx->q_pre_bytes && !ctx->q_pre_fetched && ctx->h_qup.p && ctx->d_qsegs.p) {  // (both blocks are 64 bytes longer than the data)
             P.f_dst = (uint4*)ctx->d_qsegs.p;
             P.f_src = (const uint4*)ctx->h_qup.p;
             P.f_n16 = (ctx->q_pre_bytes + 15) / 16;
@@ -417,6 +440,80 @@ extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t o
         DP_HIP(hipGetLastError());
     }
     return DP_OK;
+}
+
+// dp_index_prechain: the caller announces the dp_index_build_chunked call it will make after its next dp_scan_reads.  An index-mode
+// scan that runs in one go (dp_kindex.hip) then launches the three kernels itself, directly behind its own and before anybody
+// waits - for the survivors the device finds, in buffers sized from the previous round of this context (1.25 x its chunk bound,
+// 1.5 x its survivors) - and returns as soon as its own output has arrived; the chunk stage runs while the host prepares the
+// queries.  dp_index_build_chunked with the same parameters then only checks the guesses against the exact bound (and launches
+// again, the old way, for the rare round that outgrew them).
+extern "C" int dp_index_prechain(dp_ctx* ctx, int64_t chunk_size, int64_t overlap, uint32_t min_seeds, int32_t inset) {
+    if (!ctx || chunk_size < 1) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_index_prechain: bad arguments") : DP_ERR_ARG;
+    ctx->pc_armed = true;
+    ctx->pc_launched = false;
+    ctx->pc_chunk_size = chunk_size;
+    ctx->pc_overlap = overlap;
+    ctx->pc_min_seeds = min_seeds;
+    ctx->pc_inset = inset;
+    return DP_OK;
+}
+extern "C" int dp_index_prechained(const dp_ctx* ctx) { return ctx && ctx->pc_launched ? 1 : 0; }
+
+// called by the one-go index step of dp_scan_reads once its own kernels are queued (dp_scan.hip)
+int dp_index_prechain_launch(dp_ctx* ctx, const u64* scan_totals, uint32_t n_extra, u64 seg_cap, uint32_t* done_flag, uint32_t done_seq) {
+    ctx->pc_launched = false;
+    static const bool off = [] {
+        const char* e = getenv("DP_INDEX_PRECHAIN");
+        return e && e[0] == '0';
+    }();
+    if (!ctx->pc_armed || off) return DP_OK;
+    ctx->pc_armed = false;
+    if (!ctx->pc_prev_cap) return DP_OK;  // (no round of this context to size from yet)
+    const uint32_t cap = (uint32_t)std::min<u64>(0xfffffff0ull, (((u64)ctx->pc_prev_cap + ctx->pc_prev_cap / 4 + 64) + 63) & ~63ull);
+    const uint32_t ns_guess = std::max<uint32_t>(4096u, ctx->pc_prev_ns + ctx->pc_prev_ns / 2);
+    if (int rc = index_chunked_launch(ctx, ctx->pc_chunk_size, ctx->pc_overlap, ctx->pc_min_seeds, ctx->pc_inset, ns_guess, cap, scan_totals,
+                                      n_extra, seg_cap, done_flag, done_seq))
+        return rc;
+    ctx->pc_launched = true;
+    ctx->pc_cap = cap;
+    ctx->pc_tiles = (ns_guess + 1023) / 1024;
+    return DP_OK;
+}
+void dp_index_prechain_cancel(dp_ctx* ctx) { ctx->pc_launched = false; }
+
+extern "C" int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t overlap, uint32_t min_seeds, int32_t inset,
+                                      uint32_t n_survivors, uint32_t* n_seqs_cap) {
+    if (!ctx || chunk_size < 1 || !n_seqs_cap) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_index_build_chunked: bad arguments") : DP_ERR_ARG;
+    if (!ctx->round_open) return dp_fail(ctx, DP_ERR_STATE, "dp_index_build_chunked before dp_round_begin");
+    if (!ctx->h_surv.p || !ctx->d_surv.p) return dp_fail(ctx, DP_ERR_STATE, "dp_index_build_chunked: no dp_scan_reads result on this context");
+    hipSetDevice(ctx->device);
+    const uint32_t n_items = ctx->scan_items;
+    if (n_survivors > n_items) return dp_fail(ctx, DP_ERR_ARG, "dp_index_build_chunked: more survivors than scan items");
+    // the library still has the survivors' hit counts and read ids on the host (pinned output of the scan)
+    uint64_t cap64 = 0;
+    {
+        const uint32_t* h_item = (const uint32_t*)ctx->h_surv.p;  // (already turned into read ids by dp_scan_reads)
+        const uint32_t* h_count = h_item + ctx->last_surv_all;
+        const std::vector<uint32_t>& lens = ctx->owner ? ctx->owner->h_len : ctx->h_len;
+        for (uint32_t i = 0; i < n_survivors; i++) cap64 += chunk_cap_of(h_count[i], (long long)lens[h_item[i]], chunk_size, (int)min_seeds);
+    }
+    if (cap64 > 0xfffffff0ull) return dp_fail(ctx, DP_ERR_CAPACITY, "dp_index_build_chunked: more than 2^32 chunks");
+    ctx->pc_prev_cap = (uint32_t)cap64;
+    ctx->pc_prev_ns = n_survivors;
+    const bool chained = ctx->pc_launched;
+    ctx->pc_launched = false;
+    if (chained && chunk_size == ctx->pc_chunk_size && overlap == ctx->pc_overlap && min_seeds == ctx->pc_min_seeds && inset == ctx->pc_inset &&
+        n_survivors == ctx->last_surv_all - ctx->last_n_extra && cap64 <= ctx->pc_cap && (n_survivors + 1023) / 1024 <= ctx->pc_tiles) {
+        // launched behind the scan already, for exactly these survivors, with room for every chunk they can make
+        ctx->pc_hits++;
+        *n_seqs_cap = ctx->pc_cap;
+        return DP_OK;
+    }
+    if (chained) ctx->pc_misses++;
+    const uint32_t cap = (uint32_t)cap64;
+    *n_seqs_cap = cap;
+    return index_chunked_launch(ctx, chunk_size, overlap, min_seeds, inset, n_survivors, cap, nullptr, 0, 0);
 }
 
 // the chunks dp_index_build_chunked made, for a caller that needs them on the host (the host consensus path of the windows
@@ -916,7 +1013,7 @@ struct CNode {  // one link of a chain (pairState.prev history), written once
 
 struct CWave {
     typedef uint32_t col_t;
-    enum { COLN = 64, EVN = C_REV, ACAP = C_ACAP, RSEEDS = 255, SLIM = 0 };
+    enum { COLN = 64, EVN = C_REV, ACAP = C_ACAP, RSEEDS = 255, SLIM = 0, ROWS = 64, BCAP = C_BCAP };
     int32_t aRed[512];
     int32_t aMap[256];
     int32_t aSegL[C_ACAP];
@@ -946,7 +1043,7 @@ struct CWave {
 // longer than 32, more than 64 open chains, target > C_BCAP ints) are left to the final walk, which has the full CWave.
 struct CSlim {
     typedef uint16_t col_t;
-    enum { COLN = 32, EVN = 128, ACAP = 256, RSEEDS = 64, SLIM = 1 };
+    enum { COLN = 32, EVN = 128, ACAP = 256, RSEEDS = 64, SLIM = 1, ROWS = 64, BCAP = C_BCAP };
     int32_t aRed[2 * 64 + 2];
     int32_t aMap[64];
     int32_t aSegL[256];
@@ -955,6 +1052,31 @@ struct CSlim {
     union {
         int32_t bSegL[C_BCAP];  // dead once the b events are built
         col_t col[64][COLN];
+    };
+    int4 ev[EVN];
+    int32_t ps[64];
+    uint32_t rescol[64];
+};
+
+// Round 4 - a third of CSlim again, for the stage whose queries are `downpore overlap` windows at a sparse k (at most 31 seeds: the
+// host picks the layout per stage from the longest query): 3.2 KB per wave.  chain_spec_kernel's 1 024 workgroups of four CSlim waves
+// took 35 of the chip's 41 MB of LDS for as long as a pass lasted - every other round's kernels that want LDS (consensus, index
+// query, the walks) waited for it.  With this layout a pass holds 13 MB, and the walk kernel's one wave per query costs 13 KB per
+// workgroup instead of 35.  (Measured: 0.156 against 0.16-0.17 ms per round on a noisy box - within the noise; the waves per CU are
+// bound by the kernel's 112 VGPRs either way.)
+// What does not fit (a target of more than 159 seeds, more than 48 b events, more than 16 open chains, a chain longer than 32) is left
+// to the final walk exactly as with CSlim.
+struct CTiny {
+    typedef uint16_t col_t;
+    enum { COLN = 32, EVN = 48, ACAP = 64, RSEEDS = 32, SLIM = 1, ROWS = 16, BCAP = 320 };
+    int32_t aRed[2 * 32 + 2];
+    int32_t aMap[32];
+    int32_t aSegL[64];
+    u64 aFlag[2];
+    u64 bFlag[BCAP / 128 + 1];
+    union {
+        int32_t bSegL[BCAP];  // dead once the b events are built
+        col_t col[ROWS][COLN];
     };
     int4 ev[EVN];
     int32_t ps[64];
@@ -1535,7 +1657,7 @@ __device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, i
                     if (__ballot(lane < openSize && st_bPos == bIndex && st_aPos == aPos)) found = aPos;
                 }
                 if (found == aPos) continue;
-                if (openSize >= 64) return -1;  // the reference keeps up to 500 open chains: lds tier
+                if (openSize >= (int)LW::ROWS) return -1;  // the reference keeps up to 500 open chains: lds tier
                 if (++live > C_POOLSTATES) {
                     *err |= 2;
                     return 0;
@@ -2047,7 +2169,7 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
     const dp_seq_ref r = rPre ? *rPre : A.refs[t];
     const int32_t* bSeg = A.segs + r.seg_off;
     const int bN = RFL((int)(2 * r.n_seeds + 1));
-    const bool staged = aStaged && bN <= C_BCAP;
+    const bool staged = aStaged && bN <= (int)LW::BCAP;
     const int nSeeds = aN >> 1, nBSeeds = bN >> 1;
     const int k = A.k;
     if (LW::SLIM && (!staged || A.tier != 0)) return -1;  // (a forced tier is the full-size path's business)
@@ -2139,10 +2261,11 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
 // SLIM (mode 0 only): the speculative kernel's 8.6 KB layout, one wave per query with sixteen of them on a CU instead of four
 // (a round's ~1 300 queries are then all resident at once: 45 -> 2x us); a pair that needs the full layout stops its query there
 // - it stays open, the proposal passes skip it and the final walk (full layout) chains it.
-template <bool SLIM>
+// LY: 0 = the full layout (CWave), 1 = CSlim, 2 = CTiny (mode 0 only, as CSlim)
+template <int LY>
 struct chain_walk_kernel {
-    typedef typename std::conditional<SLIM, CSlim, CWave>::type LW;
-    enum { WAVES = SLIM ? S_WAVES : C_WAVES, THREADS = 64 * WAVES };
+    typedef typename std::conditional<LY == 0, CWave, typename std::conditional<LY == 1, CSlim, CTiny>::type>::type LW;
+    enum { SLIM = LY != 0, WAVES = SLIM ? S_WAVES : C_WAVES, THREADS = 64 * WAVES };
     static __device__ void run(const ChainArgs A, const int mode) {
     __shared__ LW sh[WAVES];
     LW& L = sh[threadIdx.x >> 6];
@@ -2311,11 +2434,13 @@ struct chain_walk_kernel {
 __device__ void chain_resolve_query(const ChainArgs& A, uint32_t q, int lane);
 
 // one wave per open pair: prefilter + chain with the minMatches its query has reached; stored as a proposal
+template <bool TINY>
 struct chain_spec_kernel {
+    typedef typename std::conditional<TINY, CTiny, CSlim>::type LW;
     enum { THREADS = 64 * S_WAVES };
     static __device__ void run(const ChainArgs A, const u64* __restrict__ totals) {
-    __shared__ CSlim sh[S_WAVES];
-    CSlim& L = sh[threadIdx.x >> 6];
+    __shared__ LW sh[S_WAVES];
+    LW& L = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
     const uint32_t waves = gridDim.x * S_WAVES;
     const uint32_t gw = blockIdx.x * S_WAVES + (threadIdx.x >> 6);
@@ -2358,7 +2483,7 @@ struct chain_spec_kernel {
         if (ib + (u64)cnt_ * nSeeds > A.sint_cap) continue;  // (flagged by the walk)
         const int32_t* aSeg = A.qsegs + qo0;
         const u64* qset = A.qsets + (uint64_t)q * A.SW;
-        const bool aStaged = aN <= (int)CSlim::ACAP;
+        const bool aStaged = aN <= (int)LW::ACAP;
         pf.pairs++;
         SP_TICK(rec)  // the pair's own records (query state, proposal, candidate)
         const u64* qs = chain_stage_a(L, aSeg, aN, qset, A.SW, aStaged);
@@ -2816,20 +2941,29 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
         const char* e = getenv("DP_WALK0_SLIM");
         return !(e && e[0] == '0');
     }();
-    if (walk0_slim && A.tier == 0 && st.passes > 0)
-        dp_launch<chain_walk_kernel<true>>(ctx, dim3(A.walk0_blocks), dim3(64 * S_WAVES), A, 0);
-    else
-        dp_launch<chain_walk_kernel<false>>(ctx, dim3(st.walk_blocks), dim3(64 * C_WAVES), A, 0);
+    // the tiny layout where every query of the stage fits it (mc_n - 1 >= the longest query's seeds); DP_CHAIN_TINY=0: CSlim as before
+    const char* te = getenv("DP_CHAIN_TINY");  // (read per call: tests switch it between jobs of one process)
+    const bool tiny = !(te && te[0] == '0') && A.mc_n <= 32;
+    // (the same 1 024 workgroups: at 112 VGPRs a CU holds sixteen of these waves whatever their LDS - twice the workgroups
+    // measured 5 % slower, profiles/r04/ab_tiny.txt - but they now leave 108 KB of every CU's LDS to the other rounds' kernels)
+    const uint32_t spec_blocks = st.spec_blocks;
+    if (walk0_slim && A.tier == 0 && st.passes > 0) {
+        if (tiny) dp_launch<chain_walk_kernel<2>>(ctx, dim3(A.walk0_blocks), dim3(64 * S_WAVES), A, 0);
+        else dp_launch<chain_walk_kernel<1>>(ctx, dim3(A.walk0_blocks), dim3(64 * S_WAVES), A, 0);
+    } else {
+        dp_launch<chain_walk_kernel<0>>(ctx, dim3(st.walk_blocks), dim3(64 * C_WAVES), A, 0);
+    }
     for (int ps = 0; ps < st.passes; ps++) {
         A.pass = ps;
-        dp_launch<chain_spec_kernel>(ctx, dim3(st.spec_blocks), dim3(64 * S_WAVES), A, (const u64*)d_totals);
+        if (tiny) dp_launch<chain_spec_kernel<true>>(ctx, dim3(spec_blocks), dim3(64 * S_WAVES), A, (const u64*)d_totals);
+        else dp_launch<chain_spec_kernel<false>>(ctx, dim3(spec_blocks), dim3(64 * S_WAVES), A, (const u64*)d_totals);
         if (!fuse_resolve) dp_launch<chain_resolve_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), A);
     }
     A.pass = st.passes;
     // the final walk rarely has a query to do after the passes: a quarter of the workgroups (each wants 128 KB of a CU's LDS before it
     // can look whether there is anything to do) - a query that is still open finds a wave among 192
     if (st.passes > 0) A.walk_blocks = std::min<uint32_t>(st.walk_blocks, 48);
-    dp_launch<chain_walk_kernel<false>>(ctx, dim3(A.walk_blocks), dim3(64 * C_WAVES), A, 2);
+    dp_launch<chain_walk_kernel<0>>(ctx, dim3(A.walk_blocks), dim3(64 * C_WAVES), A, 2);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 7));
     {

@@ -1511,6 +1511,37 @@ extern "C" int dp_scan_release(dp_ctx* ctx) {
 static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
                            uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out, bool allow_index);
 
+// Waits for the sequence number the sort pass of a one-go index step stores into the pinned flag when the scan's output is
+// complete - not for the stream, which may already carry the chunk stage (dp_index_prechain).  Spins or polls as dp_stream_sync
+// does; a flag that does not arrive within two seconds (a kernel that faulted) is left to the stream's own wait and its error.
+static hipError_t kx_wait_done(dp_ctx* ctx, const uint32_t* flag, uint32_t seq) {
+    static const int env_spin = [] {
+        const char* e = getenv("DP_SPIN_SYNC");
+        return e ? (e[0] == '1' ? 1 : 0) : -1;
+    }();
+    static const long poll_ns = [] {
+        const char* e = getenv("DP_SYNC_POLL_US");
+        return (e ? atol(e) : 20L) * 1000L;
+    }();
+    const bool spin = env_spin >= 0 ? env_spin == 1 : g_wait_spin.load(std::memory_order_relaxed) != 0;
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned it = 1;; it++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return hipSuccess;
+        if (spin) {
+            __builtin_ia32_pause();
+            if (it & 0xfff) continue;
+        } else {
+            timespec ts{0, poll_ns > 0 ? poll_ns : 20000L};
+            nanosleep(&ts, nullptr);
+            if (it & 0x3f) continue;
+        }
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000000L) return dp_stream_sync(ctx);
+    }
+}
+
 extern "C" int dp_scan_reads(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_epoch, uint32_t lo, uint32_t hi, int top_level,
                              uint32_t min_seeds, const dp_scan_item* extra, uint32_t n_extra, dp_survivor_batch* out) {
     int rc = scan_reads_body(ctx, ignore, ignore_epoch, lo, hi, top_level, min_seeds, extra, n_extra, out, true);
@@ -1563,7 +1594,9 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     out->index_hits = 0;
     ctx->scan_items = n_items;
     ctx->chunk_lo = lo;
-    if (pin_reserve(ctx, ctx->h_total, 64)) return DP_ERR_HIP;
+    if (pin_reserve(ctx, ctx->h_total, 128)) return DP_ERR_HIP;
+    ctx->last_n_extra = n_extra;
+    dp_index_prechain_cancel(ctx);
     if (n_items == 0) {
         ctx->n_segs = 0;
         return DP_OK;
@@ -1636,10 +1669,8 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     // before the one wait, into buffers sized from this context's previous index-mode round (twice its segments, 1.5 x its hits, the
     // sort tier of 1.25 x its largest survivor); the rare round that outgrows a guess repeats fill + sort the old way after the
     // wait.  DP_KX_ONESHOT=0: count, wait, size, fill, sort, wait - as before.
-    static const bool oneshot_env = [] {
-        const char* e = getenv("DP_KX_ONESHOT");
-        return !(e && e[0] == '0');
-    }();
+    const char* ose = getenv("DP_KX_ONESHOT");  // (read per call: tests switch it between jobs of one process)
+    const bool oneshot_env = !(ose && ose[0] == '0');
     bool oneshot = false;
     dp_kindex_oneshot one;
     memset(&one, 0, sizeof one);
@@ -1667,6 +1698,10 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
                 one.host_segs = (int32_t*)ctx->h_segs.p;
             }
             one.d_segs = (int32_t*)ctx->d_segs.p;
+            // (where a chunk stage launched behind the step says that the step's own kernels are done)
+            one.done_flag = (uint32_t*)ctx->h_total.p + 30;
+            one.done_seq = ++ctx->kx_seq ? ctx->kx_seq : ++ctx->kx_seq;
+            __atomic_store_n(one.done_flag, 0u, __ATOMIC_RELEASE);  // (whatever an earlier round or a fresh block left there)
         }
     }
     if (use_index) {
@@ -1678,6 +1713,13 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         else if (rc > 0) use_index = false;  // more items than its scan handles: this round is scanned
     }
     if (!use_index) oneshot = false;
+    bool wait_flag = false;
+    if (oneshot) {
+        // dp_index_prechain: the chunk stage of the caller's coming dp_index_build_chunked goes behind the scan right now
+        if (int rc = dp_index_prechain_launch(ctx, totals, n_extra, one.seg_cap, one.done_flag, one.done_seq)) return rc;
+        // (its first kernel tells the host that the scan's own kernels are done: the host waits for that word, not for the stream)
+        wait_flag = ctx->pc_launched && !ctx->timing_on && !dp_gang_active(ctx);
+    }
     out->index_mode = use_index ? 1u : 0u;
     if (!use_index) {
         if (int rc = fetch_extras()) return rc;
@@ -1710,7 +1752,8 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         const dp_fetch_region f = {ctx->h_total.p, totals, 48};
         if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, &f, 1)) return rc;
     }
-    DP_HIP(dp_stream_sync(ctx));
+    if (wait_flag) DP_HIP(kx_wait_done(ctx, one.done_flag, one.done_seq));
+    else DP_HIP(dp_stream_sync(ctx));
     {
         // DP_SCAN_RELEASE_EARLY=1 opens the gate here, after the count pass, so that the short write pass overlaps the
         // next slot's count pass.  Measured: it does not - the count pass is a persistent grid that owns every CU's LDS, so
@@ -1728,7 +1771,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         out->index_hits = ctx->kx_hits;
     }
     const uint32_t kx_max_count = (uint32_t)((uint64_t*)ctx->h_total.p)[3];
-    bool oneshot_done = false;
+    bool oneshot_done = false, queued_more = false;
     if (oneshot) {
         // did the guesses hold?  (the kernels behind the count step gave up on their own where a buffer was too small)
         const bool rec_full = (uint32_t)((uint64_t*)ctx->h_total.p)[6] != 0;
@@ -1744,6 +1787,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
             fprintf(stderr, "[kx] one-go step repeated: segs %llu / cap %llu, records %s, largest survivor %u / sort %u (%llu of %llu rounds)\n",
                     (unsigned long long)n_segs, (unsigned long long)one.seg_cap, rec_full ? "full" : "ok", kx_max_count, one.sort_cap,
                     (unsigned long long)ctx->kx_oneshot_redone, (unsigned long long)ctx->kx_oneshot_rounds);
+        if (!oneshot_done) dp_index_prechain_cancel(ctx);  // (the chunk stage behind it found nothing to chunk and said so)
         if (!oneshot_done && kx_max_count <= 4096)
             if (int rc = dp_kindex_refill(ctx, (const dp_scan_item*)d_items, n_read_items, n_extra)) return rc;
     }
@@ -1785,7 +1829,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         }
         DP_HIP(hipGetLastError());
         if (!oneshot_done) DP_HIP(dp_mark(ctx, 3));
-        if (n_segs * 4 > ((uint64_t)8 << 20)) {
+        if (n_segs * 4 > ((uint64_t)8 << 20) && !oneshot_done) {
             // dense-seed regime: tens of MB go back to the host; let the next slot's scan start while they travel
             if (!ctx->timing_on) DP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
             DP_HIP(hipEventSynchronize(ctx->ev[3]));
@@ -1807,9 +1851,12 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
                 DP_HIP(hipMemcpyAsync((int32_t*)ctx->h_segs.p + from, (const int32_t*)ctx->d_segs.p + from, (n_segs - from) * 4,
                                       hipMemcpyDeviceToHost, ctx->stream));
             }
+            queued_more = true;
         }
     }
-    DP_HIP(dp_stream_sync(ctx));
+    // (a one-go step that held: everything the host reads arrived with the first wait, and what may be queued behind it - the
+    // chunk stage - is not this call's to wait for)
+    if (!oneshot_done || queued_more) DP_HIP(dp_stream_sync(ctx));
     if (n_segs) ms1 = dp_elapsed(ctx, 2, 3);
     if (scan_lock.owns_lock()) scan_lock.unlock();
     ctx->n_segs = n_segs;

@@ -395,10 +395,11 @@ class Overlapper {
     // survivors' segments never come to the host (set before ScanLocal; IndexSurvivors falls back to the host chunking for
     // survivors it did not scan itself - the gathered ones of the multi-GPU scan-shard mode)
     void setDeviceChunking(bool on) { deviceChunkWanted_ = on; }
+    void setPrechain(bool on) { prechainOk_ = on; }  // the survivors of ScanLocal are the ones IndexSurvivors will chunk (no exchange in between)
     i64 indexedSequences() const { return chunksOnDevice_ ? (i64)nIndexedExact_ : (i64)index_.sequences.size(); }
 
    private:
-    bool deviceChunkWanted_ = false, chunksOnDevice_ = false;
+    bool deviceChunkWanted_ = false, chunksOnDevice_ = false, prechainOk_ = false;
     uint32_t nIndexedCap_ = 0, nIndexedExact_ = 0;
     int materializeChunks();  // the device-made chunks as host SeedSeq objects (index_.sequences), for the host consensus path
     void buildQueries(RoundStats& st);

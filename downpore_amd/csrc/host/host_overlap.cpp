@@ -243,6 +243,9 @@ int Overlapper::ScanLocal(size_t lo, size_t hi, Survivors& local, RoundStats& st
     dp_survivor_batch& b = lastScan_;
     const double ts0 = now();
     dp_scan_fetch_mode(ctx_, deviceChunkWanted_ ? 1 : 0);
+    // the chunk stage of IndexSurvivors goes behind the scan's own kernels (dp_index_prechain) when this context will chunk its own
+    // survivors on the device; survivors gathered from other ranks are chunked after the exchange, as before
+    if (deviceChunkWanted_ && minSeeds_ > 5 && prechainOk_) dp_index_prechain(ctx_, chunkSize_, overlap_, (uint32_t)minSeeds_, (int32_t)reads_.servedInset());
     int rc = dp_scan_reads(ctx_, ignore_, ignoreEpoch_, (uint32_t)lo, (uint32_t)hi, reads_.himem ? 0 : 1, (uint32_t)minSeeds_,
                            items.data(), (uint32_t)items.size(), &b);
     if (rc != 0) {
@@ -396,7 +399,7 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
         buildQueries(st);
         assembleQueries();
         const char* pe = getenv("DP_QUERY_PRESTAGE");  // (0: dp_find_overlaps uploads them itself; read per round: tests switch it)
-        const bool prestage = !(pe && pe[0] == '0');
+        const bool prestage = !(pe && pe[0] == '0') && !dp_index_prechained(ctx_);  // (chunk stage launched already: nothing to ride on)
         if (prestage && !queries.empty()) {
             int prc = dp_query_prestage(ctx_, querySegs_.data(), queryOff_.data(), (uint32_t)queries.size(), hitFraction_);
             if (prc != 0) {

@@ -937,6 +937,13 @@ int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
             return !(e && e[0] == '0') && !(c && c[0] == '0');
         }();
         sl.lap->setDeviceChunking(deviceChunk);  // (scan-shard mode too: the gathered survivors are chunked where the exchange put them)
+        // dp_index_prechain (the chunk stage launched behind the un-waited scan) shortens a round's chain of waits: 0.460 -> 0.440 ms
+        // per round with one slot, 0.194 -> 0.186 with three - and nothing with five or six (0.154 / 0.158: the GPU is the limit there,
+        // and the guess-sized bit matrices cost what the wait saved; profiles/r04/ab_prechain_s*.txt).  Default: up to three slots.
+        const char* pce = getenv("DPH_PRECHAIN");  // (read per round: tests switch it between jobs of one process)
+        const int prechainEnv = pce ? (pce[0] == '0' ? 0 : 1) : -1;
+        const bool prechain = prechainEnv >= 0 ? prechainEnv == 1 : slots.size() <= 3;
+        sl.lap->setPrechain(prechain && deviceChunk && sl.comm == nullptr && comm == nullptr);
     }
     sl.lap->setIgnoreView(reads->ignore.data(), planner->ignoreEpoch());
     const double tb2 = now();

@@ -383,6 +383,16 @@ DP_API int dp_consensus_paf(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_se
 DP_API int dp_index_build_chunked(dp_ctx* ctx, int64_t chunk_size, int64_t overlap, uint32_t min_seeds, int32_t inset, uint32_t n_survivors,
                            uint32_t* n_seqs_cap);
 DP_API int dp_index_chunks(dp_ctx* ctx, dp_seq_ref* refs_out, dp_seq_meta* metas_out, uint32_t cap, uint32_t* n_out);
+/* The dp_index_build_chunked call the caller will make after its NEXT dp_scan_reads, announced: a scan answered from the resident
+ * k-mer index then launches the chunk stage itself, directly behind its own kernels and before anybody waits - for the survivors
+ * the device finds, in buffers sized from the context's previous round - and dp_scan_reads returns as soon as its own output has
+ * arrived, so the chunk stage runs while the host prepares the queries (the reference's chunkWorker goroutines likewise start on
+ * a sequence as soon as AddSequences has produced it, overlap/overlap.go:217-250).  dp_index_build_chunked with the same
+ * parameters then only checks the guesses against the exact bound, and launches the old way for the rare round that outgrew them
+ * (or whenever nothing was launched: a scanned round, the first round of a context).  dp_index_prechained: 1 if the last
+ * dp_scan_reads did launch the chunk stage (dp_query_prestage has nothing to ride on then). */
+DP_API int dp_index_prechain(dp_ctx* ctx, int64_t chunk_size, int64_t overlap, uint32_t min_seeds, int32_t inset);
+DP_API int dp_index_prechained(const dp_ctx* ctx);
 /* The match lists of the last dp_find_overlaps on this context (what that call returns itself unless bit 1 of
  * want_candidates asked it not to). */
 DP_API int dp_fetch_overlaps(dp_ctx* ctx, dp_match_batch* out);

@@ -574,6 +574,18 @@ func (c *Context) IndexBuildChunked(chunkSize, overlap int64, minSeeds, inset, n
 	return int(cap), nil
 }
 
+// IndexPrechain announces the IndexBuildChunked call that follows the next ScanReads: an index-mode scan then launches the chunk
+// stage itself, behind its own kernels, and returns as soon as its own output has arrived (dp_index_prechain).
+func (c *Context) IndexPrechain(chunkSize, overlap int64, minSeeds, inset int) error {
+	if rc := C.dp_index_prechain(c.h, C.int64_t(chunkSize), C.int64_t(overlap), C.uint32_t(minSeeds), C.int32_t(inset)); rc != 0 {
+		return fail(c.h, "dp_index_prechain", rc)
+	}
+	return nil
+}
+
+// IndexPrechained reports whether the last ScanReads launched the chunk stage (dp_index_prechained).
+func (c *Context) IndexPrechained() bool { return C.dp_index_prechained(c.h) != 0 }
+
 // FindOverlapsOnDevice is matchWorker (overlap.go:346-387) for all queries of the round with the matches left on the device and
 // the stage left pending: the next call on the context must be ConsensusPAF, which finishes it in the wait it needs anyway.
 func (c *Context) FindOverlapsOnDevice(qSegs []int32, qOff []uint64, hitFraction float64, k, maxQueryLen int) error {

@@ -350,7 +350,8 @@ def test_round_parallel_protocol_matches_oracle(world, seed, G, N, L, variable):
 
 
 @pytest.mark.parametrize("env", [{}, {"DP_DEVICE_CHUNK": "0"}, {"DP_CONS_FLAG_EVERY": "3"}, {"DP_SCAN_INDEX": "1", "DP_CONS_FLAG_EVERY": "2"},
-                                 {"DP_SCAN_INDEX": "1"}])
+                                 {"DP_SCAN_INDEX": "1"}, {"DP_SCAN_INDEX": "1", "DP_KX_ONESHOT": "0"}, {"DP_SCAN_INDEX": "1", "DPH_PRECHAIN": "0"},
+                                 {"DP_SCAN_INDEX": "1", "DPH_PRECHAIN": "1", "DP_CONS_FLAG_EVERY": "3"}])
 @pytest.mark.parametrize("L,k,e", [(2500, 10, 0.0), (30000, 10, 0.01)])
 def test_overlap_chunks_made_on_the_device(monkeypatch, env, L, k, e):
     """chunkWorker (overlap.go:253-318) runs on the device (dp_index_build_chunked): the survivors' segments stay in the scan
@@ -358,7 +359,8 @@ def test_overlap_chunks_made_on_the_device(monkeypatch, env, L, k, e):
     Short reads go in whole, 30 kb reads at k = 10 are cut into several chunks with the back-up of overlap / 2 and the
     150-seed tail rule.  Variants: host chunking (DP_DEVICE_CHUNK=0), the k-mer index or the scan kernels as producer, and
     every 2nd / 3rd window handed to the host consensus path (DP_CONS_FLAG_EVERY), which then fetches chunks and segments
-    after all.  Same PAF as the oracle everywhere."""
+    after all.  Round 4: the index step in one go (hit records; DP_KX_ONESHOT=0: two waits as before) and the chunk stage
+    launched behind the un-waited scan (DPH_PRECHAIN=0 / 1).  Same PAF as the oracle everywhere."""
     for kk, v in env.items():
         monkeypatch.setenv(kk, v)
     bases, off = O.gen_reads(41 + L, 120000, 400 if L < 10000 else 120, L, e, True)
@@ -729,12 +731,17 @@ def test_chain_shortcuts_agree(monkeypatch, k, G, N, L, variable, err):
     bases, off = O.gen_reads(17, G, N, L, err, variable)
     rs = O.ReadSet(bases, off, min_len=1000)
     want = O.OverlapRun(rs, k=k, max_rounds=4)
-    for perfect, pack, prestage in (("1", "0", "1"), ("0", "0", "1"), ("1", "1", "1"), ("1", "0", "0")):
+    # (round 4: tiny = the 3.2 KB chaining layout for stages whose queries have at most 31 seeds, "0" = CSlim for all; prechain = the
+    # chunk stage launched behind the un-waited scan, "0" = after the wait)
+    for perfect, pack, prestage, tiny, prechain in (("1", "0", "1", "1", "1"), ("0", "0", "1", "1", "1"), ("1", "1", "1", "0", "1"),
+                                                    ("1", "0", "0", "1", "0"), ("1", "0", "1", "0", "0")):
         monkeypatch.setenv("DP_CHAIN_PERFECT", perfect)
         monkeypatch.setenv("DP_CHAIN_PACK", pack)
+        monkeypatch.setenv("DP_CHAIN_TINY", tiny)
+        monkeypatch.setenv("DPH_PRECHAIN", prechain)
         monkeypatch.setenv("DP_QUERY_PRESTAGE", prestage)  # 0: the query block is uploaded by dp_find_overlaps itself
         pipe = OverlapPipeline(Reads(bases, off, min_len=1000), k=k, slots=3)
         pipe.run(4)
         got = pipe.all_paf()
         pipe.close()
-        assert first_diff(got, want.paf) is None, (perfect, pack, prestage)
+        assert first_diff(got, want.paf) is None, (perfect, pack, prestage, tiny, prechain)
