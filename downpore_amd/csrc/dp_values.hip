@@ -75,6 +75,172 @@ __global__ void values_cut_kernel(const uint64_t* __restrict__ merged, const uin
 
 __global__ void values_zero_first(double* __restrict__ values) { values[0] = 0.0; }
 
+// ---- round 4: the 1 % cut without a sort ---------------------------------------------------------------------------------
+// The cut needs three numbers - T = the merged count at rank n - n/100 of the ascending order, how many k-mers lie above it, and
+// which of the k-mers AT it are cut (the ones with the highest ids: the tie rule) - not the order itself.  The radix sort of
+// 4^k 8-byte keys was 2.5 of the table's 4.1 ms.  Instead: the value pass also counts the merged counts below VH_BINS into a
+// histogram (LDS per workgroup, its non-empty bins added to the global one), one workgroup reads T and the tie quota off it, a
+// counting pass over the ties finds the k-mer id X from which ties are cut, and the cut is (m > T) | (m == T & i >= X).
+// No wait in between (the total, T and X stay on the device).  T beyond the histogram (a k-mer set where one in a hundred
+// k-mers occurs more than a thousand times): the sort path as before.
+#define VH_BINS 2048
+#define VH_ITEMS 16  // k-mers per thread of the value pass
+// small[0] = total count (input), small[1] = T, small[2] = keepTies, small[3] = 1: T lies beyond the histogram,
+// small[4] = X (first k-mer id whose tie is cut; n: none), small[5] = ties in front of the tile that holds X
+__global__ __launch_bounds__(1024) void values_kernel_hist(const uint32_t* __restrict__ counts, uint64_t n, int k,
+                                                           const uint64_t* __restrict__ small, double* __restrict__ values,
+                                                           uint64_t* __restrict__ merged, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[VH_BINS + 1];
+    for (int b = threadIdx.x; b <= VH_BINS; b += 1024) h[b] = 0;
+    __syncthreads();
+    const double tf = (double)small[0];
+    const uint64_t base = (uint64_t)blockIdx.x * (1024 * VH_ITEMS);
+#pragma unroll 4
+    for (int u = 0; u < VH_ITEMS; u++) {
+        const uint64_t i = base + (uint64_t)u * 1024 + threadIdx.x;
+        if (i >= n) break;
+        const uint32_t a = counts[i];
+        const uint32_t rc = values_rc_kmer((uint32_t)i, k);
+        const uint64_t m = rc == (uint32_t)i ? 2ull * a : 2ull * ((uint64_t)a + counts[rc]);
+        merged[i] = m;
+        const double targetFreq = 0.000005;
+        const double freq = (double)a / tf;
+        double v;
+        if (a < 3) v = 0.0;
+        else if (freq <= targetFreq) v = 1.0 - (targetFreq - freq);
+        else v = 1.0 - (freq - targetFreq);
+        values[i] = v;
+        atomicAdd(&h[m < VH_BINS ? (uint32_t)m : VH_BINS], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= VH_BINS; b += 1024)
+        if (h[b]) atomicAdd(&ghist[b], h[b]);
+}
+
+// one workgroup: T, the tie quota, "beyond the histogram"
+__global__ __launch_bounds__(1024) void values_threshold_kernel(const uint32_t* __restrict__ ghist, uint64_t n, uint64_t topN,
+                                                                uint64_t* __restrict__ small) {
+    __shared__ unsigned long long part[1024];
+    // thread t owns bins [2t, 2t+1]; cumulative counts by a block scan
+    const int b0 = 2 * threadIdx.x;
+    const unsigned long long c0 = b0 < VH_BINS ? ghist[b0] : 0ull, c1 = b0 + 1 < VH_BINS ? ghist[b0 + 1] : 0ull;
+    part[threadIdx.x] = c0 + c1;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long v = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const unsigned long long incl = part[threadIdx.x], before = incl - c0 - c1;
+    // T = the smallest t with #(m <= t) >= n - topN + 1 (the element at index n - topN of the ascending order)
+    const unsigned long long want = n - topN + 1;
+    if (threadIdx.x == 0) small[3] = part[1023] < want ? 1ull : 0ull;  // the rank lies in the overflow bin
+    if (before < want && incl >= want) {
+        const bool first = before + c0 >= want;
+        const unsigned long long T = first ? (unsigned long long)b0 : (unsigned long long)b0 + 1;
+        const unsigned long long below = first ? before : before + c0;          // #(m < T)
+        const unsigned long long ties = first ? c0 : c1;                        // #(m == T)
+        const unsigned long long above = n - below - ties;                      // #(m > T)
+        const unsigned long long zeroTies = topN - above;                       // >= 1
+        small[1] = T;
+        small[2] = ties - zeroTies;                                            // keepTies: ties with a rank below this keep their value
+    }
+}
+
+// ties per tile of 16 384 k-mers
+__global__ __launch_bounds__(1024) void values_tie_count_kernel(const uint64_t* __restrict__ merged, uint64_t n,
+                                                                const uint64_t* __restrict__ small, uint32_t* __restrict__ tileTies) {
+    __shared__ uint32_t wsum[16];
+    if (small[3]) return;
+    const uint64_t T = small[1];
+    const uint64_t base = (uint64_t)blockIdx.x * (1024 * VH_ITEMS);
+    uint32_t c = 0;
+#pragma unroll 4
+    for (int u = 0; u < VH_ITEMS; u++) {
+        const uint64_t i = base + (uint64_t)u * 1024 + threadIdx.x;
+        if (i < n && merged[i] == T) c++;
+    }
+    c = (uint32_t)wave_sum((int)c);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; w++) t += wsum[w];
+        tileTies[blockIdx.x] = t;
+    }
+}
+
+// one workgroup: X = id of the tie with rank keepTies (ranks count from k-mer 0); n when every tie keeps its value
+__global__ __launch_bounds__(1024) void values_tie_locate_kernel(const uint64_t* __restrict__ merged, uint64_t n, uint32_t n_tiles,
+                                                                 const uint32_t* __restrict__ tileTies, uint64_t* __restrict__ small) {
+    __shared__ unsigned long long part[1024];
+    __shared__ uint32_t tile_s;
+    __shared__ unsigned long long before_s;
+    if (small[3]) return;
+    const uint64_t T = small[1], keep = small[2];
+    // tiles: thread t sums a contiguous slice, block scan over the slices, the slice that holds rank `keep` is walked by its thread
+    const uint32_t per = (n_tiles + 1023) / 1024;
+    const uint32_t lo = min(n_tiles, threadIdx.x * per), hi = min(n_tiles, lo + per);
+    unsigned long long s = 0;
+    for (uint32_t t = lo; t < hi; t++) s += tileTies[t];
+    part[threadIdx.x] = s;
+    if (threadIdx.x == 0) tile_s = 0xffffffffu;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned long long v = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const unsigned long long incl = part[threadIdx.x];
+    unsigned long long run = incl - s;
+    if (run <= keep && keep < incl) {
+        for (uint32_t t = lo; t < hi; t++) {
+            if (keep < run + tileTies[t]) {
+                tile_s = t;
+                before_s = run;
+                break;
+            }
+            run += tileTies[t];
+        }
+    }
+    __syncthreads();
+    if (tile_s == 0xffffffffu) {  // keep == all ties: nothing at T is cut
+        if (threadIdx.x == 0) small[4] = n;
+        return;
+    }
+    // inside the tile: rank of every tie = before + ties in front of it (k-mer ids ascending = item order u * 1024 + thread)
+    const uint64_t base = (uint64_t)tile_s * (1024 * VH_ITEMS);
+    unsigned long long seen = before_s;
+    for (int u = 0; u < VH_ITEMS; u++) {
+        const uint64_t i = base + (uint64_t)u * 1024 + threadIdx.x;
+        const bool tie = i < n && merged[i] == T;
+        // ties of this row in front of this thread
+        const unsigned long long m = __ballot(tie);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __shared__ uint32_t rowc[16];
+        if (lane == 0) rowc[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        unsigned long long front = seen;
+        for (int w = 0; w < wave; w++) front += rowc[w];
+        front += (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+        if (tie && front == keep) small[4] = i;
+        unsigned long long row = 0;
+        for (int w = 0; w < 16; w++) row += rowc[w];
+        seen += row;
+        __syncthreads();
+    }
+}
+
+__global__ void values_cut_kernel2(const uint64_t* __restrict__ merged, uint64_t n, const uint64_t* __restrict__ small,
+                                   double* __restrict__ values) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || small[3]) return;
+    const uint64_t m = merged[i], T = small[1], X = small[4];
+    if (m > T || (m == T && i >= X) || i == 0) values[i] = 0.0;
+}
+
 extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     if (!ctx || k < 1 || k > 15) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_kmer_values: k in 1..15") : DP_ERR_ARG;
     if (ctx->borrowed_reads) return dp_fail(ctx, DP_ERR_STATE, "dp_kmer_values on a borrowing context");
@@ -122,14 +288,47 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     DPV(dp_dev_malloc(&d_tmp, tmpCap));
     DPV(rocprim::reduce(d_tmp, tb, in64, (uint64_t*)d_small, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), ctx->stream));
     uint64_t tot = 0;
-    DPV(hipMemcpyAsync(&tot, d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
-    DPV(dp_stream_sync(ctx));
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(values_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_counts, n, k, (double)tot, values,
-                       (uint64_t*)d_merged);
-    DPV(hipGetLastError());
     const uint64_t topN = n / 100;
-    if (topN > 0) {
+    bool cut_done = false;
+    static const bool sort_cut = [] {
+        const char* e = getenv("DP_VALUES_SORT");  // 1: the cut by radix sort, as before round 4
+        return e && e[0] == '1';
+    }();
+    if (topN > 0 && !sort_cut) {
+        // value pass + histogram, threshold, tie count, tie locate, cut: five launches, nothing read back in between
+        const uint32_t tiles = (uint32_t)((n + 1024 * VH_ITEMS - 1) / (1024 * VH_ITEMS));
+        void* d_h = nullptr;
+        DPV(dp_dev_malloc(&d_h, (size_t)(VH_BINS + 1) * 4 + (size_t)tiles * 4 + 64));
+        d_rank = d_h;  // (released by cleanup())
+        uint32_t* ghist = (uint32_t*)d_h;
+        uint32_t* tileTies = ghist + VH_BINS + 1;
+        DPV(hipMemsetAsync(d_h, 0, (size_t)(VH_BINS + 1) * 4, ctx->stream));
+        DPV(hipMemsetAsync((uint64_t*)d_small + 1, 0, 56, ctx->stream));
+        hipLaunchKernelGGL(values_kernel_hist, dim3(tiles), dim3(1024), 0, ctx->stream, (const uint32_t*)d_counts, n, k, (const uint64_t*)d_small,
+                           values, (uint64_t*)d_merged, ghist);
+        hipLaunchKernelGGL(values_threshold_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)ghist, n, topN, (uint64_t*)d_small);
+        hipLaunchKernelGGL(values_tie_count_kernel, dim3(tiles), dim3(1024), 0, ctx->stream, (const uint64_t*)d_merged, n, (const uint64_t*)d_small,
+                           tileTies);
+        hipLaunchKernelGGL(values_tie_locate_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint64_t*)d_merged, n, tiles,
+                           (const uint32_t*)tileTies, (uint64_t*)d_small);
+        hipLaunchKernelGGL(values_cut_kernel2, dim3(blocks), dim3(256), 0, ctx->stream, (const uint64_t*)d_merged, n, (const uint64_t*)d_small, values);
+        DPV(hipGetLastError());
+        uint64_t h_small[4] = {0, 0, 0, 0};
+        DPV(hipMemcpyAsync(h_small, d_small, 32, hipMemcpyDeviceToHost, ctx->stream));
+        DPV(dp_stream_sync(ctx));
+        tot = h_small[0];
+        cut_done = h_small[3] == 0;  // (else: T beyond the histogram - the sort below; values[] and merged[] are as the value pass left them)
+        dp_dev_free(d_h);
+        d_rank = nullptr;
+    } else {
+        DPV(hipMemcpyAsync(&tot, d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+        DPV(dp_stream_sync(ctx));
+        hipLaunchKernelGGL(values_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)d_counts, n, k, (double)tot, values,
+                           (uint64_t*)d_merged);
+        DPV(hipGetLastError());
+    }
+    if (topN > 0 && !cut_done) {
         DPV(dp_dev_malloc(&d_sorted, n * 8));
         size_t sb = 0;
         DPV(rocprim::radix_sort_keys(nullptr, sb, (const uint64_t*)d_merged, (uint64_t*)d_sorted, (size_t)n, 0u, 34u, ctx->stream));
@@ -166,7 +365,7 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
         hipLaunchKernelGGL(values_cut_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint64_t*)d_merged,
                            (const uint32_t*)d_rank, n, T, keepTies, values);
         DPV(hipGetLastError());
-    } else {
+    } else if (topN == 0) {
         hipLaunchKernelGGL(values_zero_first, dim3(1), dim3(1), 0, ctx->stream, values);
     }
     if (values_out) DPV(hipMemcpyAsync(values_out, values, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -211,6 +410,58 @@ __global__ void values_codes_kernel(const uint32_t* __restrict__ counts, const d
     codes[i] = (uint16_t)c;
 }
 
+// codes of one byte (round 4): the 1 % cut takes every common k-mer's value away, so what is left nearly always counts below 255 -
+// half the bytes over the link again (64 MB at k = 13).  *overflow = 1 when a valued k-mer counts 255 or more: the caller asks for
+// the two-byte codes then.
+__global__ void values_codes8_kernel(const uint32_t* __restrict__ counts, const double* __restrict__ values, uint64_t n,
+                                     uint8_t* __restrict__ codes, uint32_t* __restrict__ overflow) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = values[i] == 0.0 ? 0u : counts[i];
+    if (c > 254u) {
+        *overflow = 1u;
+        c = 255u;
+    }
+    codes[i] = (uint8_t)c;
+}
+
+static int values_download_codes_impl(dp_ctx* ctx, void* codes_out, uint64_t n, uint64_t* total_out, int* overflow_out, int bytes) {
+    const dp_ctx* src = ctx->owner ? ctx->owner : ctx;
+    if (!src->d_values.p || src->n_values != n || !src->d_kcounts || ((uint64_t)1 << (2 * src->kcounts_k)) != n || !src->values_computed)
+        return dp_fail(ctx, DP_ERR_STATE, "dp_values_download_codes: no computed value table of this size resident");
+    hipSetDevice(ctx->device);
+    void* d_codes = nullptr;
+    hipError_t e = dp_dev_malloc(&d_codes, n * bytes + 64);
+    if (e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, "dp_values_download_codes: hipMalloc", e);
+    uint32_t* d_flag = (uint32_t*)((char*)d_codes + n * bytes);
+    uint32_t flag = 0;
+    e = hipMemsetAsync(d_flag, 0, 4, ctx->stream);
+    if (e == hipSuccess) {
+        if (bytes == 1)
+            hipLaunchKernelGGL(values_codes8_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)src->d_kcounts,
+                               (const double*)src->d_values.p, n, (uint8_t*)d_codes, d_flag);
+        else
+            hipLaunchKernelGGL(values_codes_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)src->d_kcounts,
+                               (const double*)src->d_values.p, n, (uint16_t*)d_codes, d_flag);
+        e = hipGetLastError();
+    }
+    // (the flag first: a caller of the one-byte form that has to fall back learns it without the codes' copy... which it gets anyway)
+    if (e == hipSuccess) e = hipMemcpyAsync(codes_out, d_codes, n * bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = dp_stream_sync(ctx);
+    dp_dev_free(d_codes);
+    if (e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, "dp_values_download_codes", e);
+    *total_out = src->values_total;
+    *overflow_out = (int)flag;
+    return DP_OK;
+}
+
+extern "C" int dp_values_download_codes8(dp_ctx* ctx, uint8_t* codes_out, uint64_t n, uint64_t* total_out, int* overflow_out) {
+    if (!ctx || !codes_out || !total_out || !overflow_out)
+        return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_values_download_codes8: bad arguments") : DP_ERR_ARG;
+    return values_download_codes_impl(ctx, codes_out, n, total_out, overflow_out, 1);
+}
+
 // The value of a k-mer is a function of its own count and the total alone (overlap.go:73-88), so the table dp_kmer_values
 // left resident travels as 2 bytes per k-mer: codes_out[i] = count of k-mer i, or 0 where its value is 0; *total_out = the
 // sum of all counts (overlap.go:60-63).  A caller rebuilds value(i) = f(codes[i], total) bit for bit from 65536
@@ -219,27 +470,5 @@ __global__ void values_codes_kernel(const uint32_t* __restrict__ counts, const d
 extern "C" int dp_values_download_codes(dp_ctx* ctx, uint16_t* codes_out, uint64_t n, uint64_t* total_out, int* overflow_out) {
     if (!ctx || !codes_out || !total_out || !overflow_out)
         return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_values_download_codes: bad arguments") : DP_ERR_ARG;
-    const dp_ctx* src = ctx->owner ? ctx->owner : ctx;
-    if (!src->d_values.p || src->n_values != n || !src->d_kcounts || ((uint64_t)1 << (2 * src->kcounts_k)) != n || !src->values_computed)
-        return dp_fail(ctx, DP_ERR_STATE, "dp_values_download_codes: no computed value table of this size resident");
-    hipSetDevice(ctx->device);
-    void* d_codes = nullptr;
-    hipError_t e = dp_dev_malloc(&d_codes, n * 2 + 64);
-    if (e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, "dp_values_download_codes: hipMalloc", e);
-    uint32_t* d_flag = (uint32_t*)((char*)d_codes + n * 2);
-    uint32_t flag = 0;
-    e = hipMemsetAsync(d_flag, 0, 4, ctx->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(values_codes_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)src->d_kcounts,
-                           (const double*)src->d_values.p, n, (uint16_t*)d_codes, d_flag);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(codes_out, d_codes, n * 2, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = dp_stream_sync(ctx);
-    dp_dev_free(d_codes);
-    if (e != hipSuccess) return dp_fail(ctx, DP_ERR_HIP, "dp_values_download_codes", e);
-    *total_out = src->values_total;
-    *overflow_out = (int)flag;
-    return DP_OK;
+    return values_download_codes_impl(ctx, codes_out, n, total_out, overflow_out, 2);
 }

@@ -140,13 +140,16 @@ struct Arena {
 struct ValueView {
     const double* full = nullptr;
     const uint16_t* codes = nullptr;
+    const uint8_t* codes8 = nullptr;  // one byte per k-mer where every valued k-mer counts below 255 (dp_values_download_codes8)
     const double* lut = nullptr;
     ValueView() {}
     ValueView(const double* f) : full(f) {}
     ValueView(const uint16_t* c, const double* l) : codes(c), lut(l) {}
-    double at(uint32_t kmer) const { return full ? full[kmer] : lut[codes[kmer]]; }
+    ValueView(const uint8_t* c, const double* l) : codes8(c), lut(l) {}
+    double at(uint32_t kmer) const { return full ? full[kmer] : codes8 ? lut[codes8[kmer]] : lut[codes[kmer]]; }
     void prefetch(uint32_t kmer) const {
         if (full) __builtin_prefetch(&full[kmer], 0, 0);
+        else if (codes8) __builtin_prefetch(&codes8[kmer], 0, 0);
         else __builtin_prefetch(&codes[kmer], 0, 0);
     }
 };
@@ -589,10 +592,13 @@ struct OverlapRun {
         size_t size() const { return n; }
     } values;
     // ... or, when the table was computed on the device, its 2-byte form (see ValueView); `values` is then filled on demand
-    HugeTable valueCodes;            // 4^k uint16 codes (the table's storage reused: bytes, not doubles)
+    HugeTable valueCodes;            // 4^k uint16 (or uint8: codes8_) codes (the table's storage reused: bytes, not doubles)
+    bool codes8_ = false;
     std::vector<double> valueLut;    // value of every code
     ValueView valueView() const {
-        return valueLut.empty() ? ValueView(values.data()) : ValueView((const uint16_t*)valueCodes.data(), valueLut.data());
+        return valueLut.empty() ? ValueView(values.data())
+                                : codes8_ ? ValueView((const uint8_t*)valueCodes.data(), valueLut.data())
+                                          : ValueView((const uint16_t*)valueCodes.data(), valueLut.data());
     }
     const double* fullValues();      // the 4^k doubles (expands the 2-byte form the first time it is asked for)
     std::unique_ptr<TextPool> textPool;            // formatter threads (PAF text off the executor slots' critical path)

@@ -600,8 +600,13 @@ const double* OverlapRun::fullValues() {
     if (values.size() == 0 && !valueLut.empty()) {
         const size_t nk = (size_t)1 << (2 * p.k);
         double* dst = values.reserve(nk);
-        const uint16_t* codes = (const uint16_t*)valueCodes.data();
-        for (size_t i = 0; i < nk; i++) dst[i] = valueLut[codes[i]];
+        if (codes8_) {
+            const uint8_t* codes = (const uint8_t*)valueCodes.data();
+            for (size_t i = 0; i < nk; i++) dst[i] = valueLut[codes[i]];
+        } else {
+            const uint16_t* codes = (const uint16_t*)valueCodes.data();
+            for (size_t i = 0; i < nk; i++) dst[i] = valueLut[codes[i]];
+        }
     }
     return values.data();
 }
@@ -748,7 +753,15 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
                 dlErr = dp_last_error(nullptr);
                 return;
             }
-            dlRc = dp_values_download_codes(c2, dst, nk, &dlTotal, &dlOverflow);
+            // one byte per k-mer where that is enough (DP_VALUE_CODES8=0: two bytes as before round 4), else two, else the doubles
+            const char* c8e = getenv("DP_VALUE_CODES8");
+            codes8_ = false;
+            dlOverflow = 1;
+            if (!(c8e && c8e[0] == '0')) {
+                dlRc = dp_values_download_codes8(c2, (uint8_t*)dst, nk, &dlTotal, &dlOverflow);
+                codes8_ = dlRc == 0 && !dlOverflow;
+            }
+            if (dlRc == 0 && dlOverflow) dlRc = dp_values_download_codes(c2, dst, nk, &dlTotal, &dlOverflow);
             if (dlRc == 0 && dlOverflow) {  // a valued k-mer seen more than 65535 times: the table as doubles
                 double* full = values.reserve(nk);
                 dlRc = dp_values_download(c2, full, nk);

@@ -106,6 +106,9 @@ DP_API int dp_values_download(dp_ctx* ctx, double* values_out, uint64_t n);
  * f(codes_out[i], total) - 65536 evaluations of overlap.go's expression rebuild every entry bit for bit.
  * *overflow_out = 1 when a k-mer that holds a value was seen more than 65535 times (its code saturates: fetch the table
  * with dp_values_download instead).  DP_ERR_STATE for a table installed by dp_values_upload (no histogram behind it). */
+/* The same with one byte per k-mer (0 = value 0, 1..254 = the count): *overflow_out = 1 when a valued k-mer counts 255 or more -
+ * codes_out is not usable then and the caller takes the two-byte form.  With the 1 %% cut in force nearly every table fits. */
+DP_API int dp_values_download_codes8(dp_ctx* ctx, uint8_t* codes_out, uint64_t n, uint64_t* total_out, int* overflow_out);
 DP_API int dp_values_download_codes(dp_ctx* ctx, uint16_t* codes_out, uint64_t n, uint64_t* total_out, int* overflow_out);
 
 /* ---- round state: the seed set --------------------------------------------------------------------------

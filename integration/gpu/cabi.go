@@ -531,6 +531,19 @@ func (c *Context) ValueCodes(k int) (codes []uint16, total uint64, overflow bool
 	return codes, uint64(tot), ovf != 0, nil
 }
 
+// ValueCodes8 is ValueCodes with one byte per k-mer (1..254 = the count); overflow: a valued k-mer counts 255 or more - take
+// ValueCodes instead (dp_values_download_codes8).
+func (c *Context) ValueCodes8(k int) (codes []uint8, total uint64, overflow bool, err error) {
+	n := 1 << uint(2*k)
+	codes = make([]uint8, n)
+	var tot C.uint64_t
+	var ovf C.int
+	if rc := C.dp_values_download_codes8(c.h, (*C.uint8_t)(unsafe.Pointer(&codes[0])), C.uint64_t(n), &tot, &ovf); rc != 0 {
+		return nil, 0, false, fail(c.h, "dp_values_download_codes8", rc)
+	}
+	return codes, uint64(tot), ovf != 0, nil
+}
+
 // SelectWindows is the selection half of AddSeeds (seeds/seeds.go:62-129) for many query windows at once, assuming no
 // evaluated k-mer is a seed yet: top[w*numSeeds:] = the window's list (untouched slots hold k-mer 0), evaluated[w*stride:] =
 // every k-mer the walk evaluated (0xffffffff = unused): what the caller probes against its committed seeds to learn whether
