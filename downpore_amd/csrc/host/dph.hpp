@@ -483,6 +483,15 @@ class Planner {
     // planner lanes (threads that compute consecutive plans concurrently, each from a guess of where its predecessor ends)
     static int lanesFor(int world, int slots);
     void setLanes(int n);  // grows only
+    // Round-parallel runs (rounds dealt to `world` ranks): this planner computes the plans of the rounds its rank executes and
+    // nothing else - where the rounds in between end is GUESSED (predictFirstOut: the window cache's seed counts, a microsecond
+    // per round), so a rank's planner does 1 / world of the chain's work instead of all of it.  get(round) of an owned round then
+    // returns a plan that starts where the guesses say the round starts; whether that is where the committed chain arrives is
+    // checked where every speculative round is checked - at the commit (firstIn == firstSequence) - and a round whose guess
+    // failed is planned again from the committed truth (dropBefore).  Needs the window cache (the guesses are its counts);
+    // without it every rank walks the whole chain as before.
+    void setOwnership(int rank, int world);
+    bool sparse() const;
 
    private:
     std::shared_ptr<RoundPlan> compute(i64 round, i64 firstIn, SeedIndex& index);
@@ -491,6 +500,9 @@ class Planner {
     void promote();
     bool nextWork(i64* round, i64* firstIn) const;
     i64 predictFirstOut(i64 firstIn) const;
+    i64 predictMemo(i64 firstIn) const;
+    bool sparseNext(i64* round, i64* firstIn) const;
+    int sparseEstimate(i64 round, i64* firstIn, std::shared_ptr<RoundPlan>* ended) const;
     struct Impl;
     std::unique_ptr<Impl> d;
 };

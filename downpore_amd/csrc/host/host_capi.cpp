@@ -768,3 +768,123 @@ extern "C" void dph_map_stats(void* h, double* out) {
                   s.k_map_ms, s.t_setup_s, s.t_scan_s, s.t_chain_s, s.t_host_s};
     memcpy(out, v, sizeof v);
 }
+
+// ---- host-logic test hook (no GPU needed): the plan chain of a round-parallel run of `world` ranks whose planners each compute
+// only the plans of their own rounds (Planner::setOwnership) and guess where the rounds in between end.  Every simulated rank has
+// its own copy of the read set (its own flags), its own window cache (host producer) and planner; the driver plays the commit:
+// round r's plan comes from its owner, is accepted iff it starts at the committed firstSequence (what OverlapRun::resultValid
+// checks) - otherwise every rank is told the truth (dropBefore) and the owner is asked again - and is then committed on every
+// rank (flags of every `flagEvery`-th round + dropBefore).  The accepted chain must equal the one a single dense planner walks.
+// Returns 0 = equal, r + 1 = differs in round r, < 0 = set-up problem / a round that never became valid; *nRounds = plans of the
+// chain, *nRedone = plans that had to be asked for again because their guess did not hold.
+extern "C" int dph_selftest_planner_sparse(void* readsH, int k, int64_t seedBatchSize, const double* values, int world, int flagEvery,
+                                           int64_t* nRounds, int64_t* nRedone) {
+    ReadSet& reads = ((ReadsH*)readsH)->set;
+    OverlapParams p;
+    p.k = k;
+    p.seedBatchSize = seedBatchSize;
+    struct Rec {
+        i64 firstIn, firstOut;
+        std::vector<Overlapper::Window> windows;
+        std::vector<uint32_t> seedMap;
+        bool empty;
+    };
+    auto flagsOf = [&](i64 r, i64 firstOut, size_t n) {
+        std::vector<int> flags;
+        if (flagEvery > 0 && r % flagEvery == flagEvery - 1) {
+            const i64 a = firstOut + 3, b = firstOut + 40;
+            if (a < (i64)n) flags.push_back((int)a);
+            if (b < (i64)n) flags.push_back((int)b);
+        }
+        return flags;
+    };
+    std::vector<Rec> ref, got;
+    {
+        std::fill(reads.ignore.begin(), reads.ignore.end(), 0);
+        WindowCache wc(nullptr, reads, p.overlapSize, k, p.numSeeds, ValueView(values));
+        Planner pl(reads, p, ValueView(values), true, nullptr, &wc);
+        for (i64 r = 0;; r++) {
+            std::shared_ptr<const RoundPlan> pp = pl.get(r);
+            if (!pp || pp->failed) return -1;
+            ref.push_back({pp->firstIn, pp->firstOut, pp->windows, pp->seedMap, pp->empty});
+            if (pp->empty) break;
+            if (r > 100000) return -3;
+            pl.applyIgnores(flagsOf(r, pp->firstOut, reads.size()), r);
+            pl.dropBefore(r + 1, pp->firstOut);
+        }
+        std::fill(reads.ignore.begin(), reads.ignore.end(), 0);
+    }
+    i64 redone = 0;
+    {
+        std::vector<std::unique_ptr<ReadSet>> rs;
+        std::vector<std::unique_ptr<WindowCache>> wcs;
+        std::vector<std::unique_ptr<Planner>> pls;
+        for (int w = 0; w < world; w++) {
+            rs.emplace_back(new ReadSet(reads));
+            wcs.emplace_back(new WindowCache(nullptr, *rs[w], p.overlapSize, k, p.numSeeds, ValueView(values)));
+            pls.emplace_back(new Planner(*rs[w], p, ValueView(values), true, nullptr, wcs[w].get()));
+            pls[w]->setLanes(3);
+            pls[w]->setOwnership(w, world);
+            if (!pls[w]->sparse()) return -4;
+        }
+        i64 firstSequence = 0;
+        // (the executor slots of a rank ask for the plans of rounds well ahead of the commit point - that is what makes them
+        // speculative: here every round's plan is fetched from its owner 2 * world rounds before its turn)
+        std::map<i64, std::pair<std::shared_ptr<const RoundPlan>, i64>> ahead;  // plan, commit point when it was fetched
+        std::vector<i64> flagRound(reads.size(), -1);                            // round whose commit flagged the read
+        bool ended = false;
+        for (i64 r = 0;; r++) {
+            Planner& owner = *pls[(size_t)(r % world)];
+            for (i64 j = r; j <= r + 2 * world && !ended; j++) {
+                if (ahead.count(j)) continue;
+                std::shared_ptr<const RoundPlan> q = pls[(size_t)(j % world)]->get(j);
+                if (!q || q->failed) return -5;
+                ahead[j] = {q, r};
+                if (q->empty) break;  // (what lies behind an "end of input" - real or guessed - is asked for once it is settled)
+            }
+            std::shared_ptr<const RoundPlan> pp = ahead.count(r) ? ahead[r].first : owner.get(r);
+            i64 snap = ahead.count(r) ? ahead[r].second : r;
+            ahead.erase(r);
+            for (int attempt = 0;; attempt++) {
+                if (!pp || pp->failed) return -5;
+                // OverlapRun::resultValid / emptyResultValid: the plan starts at the committed firstSequence and none of its query
+                // reads was flagged by a round committed since it was made
+                bool valid = pp->empty ? (pp->round == r && pp->firstIn == firstSequence) : pp->firstIn == firstSequence;
+                for (size_t i = 0; valid && i < pp->windows.size(); i++)
+                    if (flagRound[pp->windows[i].read] >= snap) valid = false;
+                if (valid) break;
+                snap = r;
+                if (attempt >= 3) return -6;
+                redone++;
+                // the commit point has reached r and the plan does not start there: every rank knows where r starts (dropBefore
+                // of the last commit), the owner plans the round again
+                pp = owner.get(r);
+            }
+            ended = pp->empty;
+            got.push_back({pp->firstIn, pp->firstOut, pp->windows, pp->seedMap, pp->empty});
+            if (pp->empty) break;
+            if (r > 100000) return -3;
+            firstSequence = pp->firstOut;
+            const std::vector<int> flags = flagsOf(r, pp->firstOut, reads.size());
+            for (int id : flags)
+                if (flagRound[(size_t)id] < 0) flagRound[(size_t)id] = r;
+            for (auto& q : pls) {
+                q->applyIgnores(flags, r);
+                q->dropBefore(r + 1, firstSequence);
+            }
+        }
+    }
+    if (nRounds) *nRounds = (int64_t)ref.size();
+    if (nRedone) *nRedone = redone;
+    auto same = [](const Rec& x, const Rec& y) {
+        if (x.firstIn != y.firstIn || x.firstOut != y.firstOut || x.empty != y.empty || x.seedMap != y.seedMap || x.windows.size() != y.windows.size()) return false;
+        for (size_t i = 0; i < x.windows.size(); i++)
+            if (x.windows[i].read != y.windows[i].read || x.windows[i].start != y.windows[i].start || x.windows[i].len != y.windows[i].len) return false;
+        return true;
+    };
+    for (size_t r = 0; r < std::max(ref.size(), got.size()); r++) {
+        if (r >= ref.size() || r >= got.size()) return (int)r + 1;
+        if (!same(ref[r], got[r])) return (int)r + 1;
+    }
+    return 0;
+}

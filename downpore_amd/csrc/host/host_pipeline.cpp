@@ -252,6 +252,11 @@ struct Planner::Impl {
         Lane(int k) : index(k, 21) {}
     };
     std::vector<std::unique_ptr<Lane>> lanes;
+    // round-parallel ownership (setOwnership): rounds m with m % ownWorld == ownRank are this planner's to compute
+    int ownRank = 0, ownWorld = 1;
+    mutable std::unordered_map<i64, i64> predMemo;  // firstIn -> predictFirstOut(firstIn) under the flags of predEpoch
+    mutable uint64_t predEpoch = ~0ull;
+    mutable bool predStarved = false;  // a guess was wanted for windows the window cache has not produced yet: whoever waits, waits briefly
     Impl(ReadSet& r, const OverlapParams& pp, ValueView v, bool t, dp_ctx* sc)
         : reads(r), p(pp), values(v), threaded(t), selCtx(sc), index(pp.k, 21) {}
 };
@@ -279,7 +284,11 @@ Planner::Planner(ReadSet& reads, const OverlapParams& p, ValueView values, bool 
 int Planner::lanesFor(int world, int slots) {
     if (const char* e = getenv("DPH_PLAN_LANES")) return std::max(1, std::min(8, atoi(e)));
     const int spare = (int)hostThreads() - std::max(1, slots) - 4;  // slots, window cache, formatter, commit
-    return std::max(1, std::min(std::min(8, std::max(3, world + 2)), spare));
+    // (ownership mode - setOwnership - leaves a rank's planner 1 / world of the chain: three lanes as on one GPU; without it the
+    // whole chain has to be walked `world` times faster than a GPU executes)
+    const char* sp = getenv("DPH_PLAN_SPARSE");
+    const bool sparseOff = sp && sp[0] == '0';
+    return std::max(1, std::min(sparseOff ? std::min(8, std::max(3, world + 2)) : 3, spare));
 }
 
 void Planner::setLanes(int n) {
@@ -392,9 +401,91 @@ i64 Planner::predictFirstOut(i64 firstIn) const {
     return last < 0 ? firstIn : last + 1;
 }
 
+void Planner::setOwnership(int rank, int world) {
+    std::lock_guard<std::mutex> lk(d->mu);
+    static const bool off = [] {
+        const char* e = getenv("DPH_PLAN_SPARSE");  // 0: every rank's planner walks the whole chain (as before round 4)
+        return e && e[0] == '0';
+    }();
+    if (off || world < 2 || !d->threaded || !d->fromCache) {
+        d->ownRank = 0;
+        d->ownWorld = 1;
+    } else {
+        d->ownRank = rank;
+        d->ownWorld = world;
+    }
+    d->cv.notify_all();
+}
+bool Planner::sparse() const { return d->ownWorld > 1; }
+
+i64 Planner::predictMemo(i64 firstIn) const {
+    if (d->predEpoch != d->epoch) {
+        d->predMemo.clear();
+        d->predEpoch = d->epoch;
+    }
+    auto it = d->predMemo.find(firstIn);
+    if (it != d->predMemo.end()) return it->second;
+    const i64 fo = predictFirstOut(firstIn);
+    if (fo >= 0) d->predMemo[firstIn] = fo;
+    return fo;
+}
+
+// Ownership mode: where the chain - committed truth at `base`, this rank's own finished plans where there are some, guesses
+// everywhere else - says round `round` starts.  0: *firstIn is set.  1: the chain ends before `round` (*ended = the owned empty
+// plan that says so, or null when a guess does).  -1: cannot tell yet (the window cache has not got that far).
+int Planner::sparseEstimate(i64 round, i64* firstIn, std::shared_ptr<RoundPlan>* ended) const {
+    i64 m = d->base, f = d->startFirstIn;
+    if (ended) ended->reset();
+    while (m < round) {
+        if (m % d->ownWorld == d->ownRank) {
+            auto it = d->pending.find({m, f});
+            if (it != d->pending.end()) {
+                if (it->second->empty) {
+                    if (ended) *ended = it->second;
+                    return 1;
+                }
+                f = it->second->firstOut;
+                m++;
+                continue;
+            }
+        }
+        const i64 fo = predictMemo(f);
+        if (fo < 0) {
+            d->predStarved = true;
+            return -1;
+        }
+        if (fo == f) return 1;  // (the guess: no window left - whether that is so is the owner's plan to say)
+        f = fo;
+        m++;
+    }
+    *firstIn = f;
+    return 0;
+}
+
+// Ownership mode: the first owned round up to wantUpTo that nobody has planned or is planning from where the chain says it starts.
+bool Planner::sparseNext(i64* round, i64* firstIn) const {
+    i64 m = d->base;
+    while (m % d->ownWorld != d->ownRank) m++;
+    for (; m <= d->wantUpTo; m += d->ownWorld) {
+        i64 f = 0;
+        const int st = sparseEstimate(m, &f, nullptr);
+        if (st != 0) return false;  // the chain ends before m / cannot tell yet
+        if (d->pending.count({m, f})) continue;
+        bool inFlight = false;
+        for (auto& l : d->lanes)
+            if (l->busy && l->round == m && l->firstIn == f) inFlight = true;
+        if (inFlight) continue;
+        *round = m;
+        *firstIn = f;
+        return true;
+    }
+    return false;
+}
+
 // The first plan nobody has computed or is computing, following the chain through the plans computed ahead and, past a
 // plan still being computed, through the guess of where it ends.
 bool Planner::nextWork(i64* round, i64* firstIn) const {
+    if (d->ownWorld > 1) return sparseNext(round, firstIn);
     i64 m = 0, f = 0;
     if (!chainHead(&m, &f)) return false;
     while (m <= d->wantUpTo) {
@@ -432,8 +523,11 @@ void Planner::laneMain(size_t li) {
     for (;;) {
         if (d->stop) return;
         i64 m = 0, firstIn = 0;
+        d->predStarved = false;
         if (!nextWork(&m, &firstIn)) {
-            d->cv.wait(lk);
+            // (the window cache's producer does not announce its progress: a guess that waits for it is asked for again shortly)
+            if (d->predStarved) d->cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(200));  // (system clock: the form ThreadSanitizer follows)
+            else d->cv.wait(lk);
             continue;
         }
         me.busy = true;
@@ -455,7 +549,12 @@ void Planner::laneMain(size_t li) {
         // one does (a commit usually flags ids on both sides of firstIn).  Whether it continues the chain is promote()'s test.
         if ((d->epoch != e0 && me.maxFlagged >= firstIn) || m < d->base) g_prof.planDiscarded++;
         else d->pending[{m, firstIn}] = plan;
-        promote();
+        if (d->ownWorld > 1) {  // (ownership mode: nothing joins a confirmed chain - plans are looked up by (round, where the chain says it starts))
+            for (auto it = d->pending.begin(); it != d->pending.end();)
+                it = it->first.first < d->base ? d->pending.erase(it) : std::next(it);
+        } else {
+            promote();
+        }
         d->cv.notify_all();
     }
 }
@@ -490,6 +589,36 @@ std::shared_ptr<const RoundPlan> Planner::get(i64 round) {
         const char* e = getenv("DPH_PLAN_DEPTH");
         return e ? std::max(1L, atol(e)) : 6L;
     }();
+    if (d->ownWorld > 1 && round % d->ownWorld != d->ownRank) {
+        // somebody asks for a round this rank does not own (not the round-parallel workers): the whole chain from here on
+        d->ownWorld = 1;
+        d->ownRank = 0;
+        promote();
+    }
+    if (d->ownWorld > 1) {
+        // ownership mode: the plan of an owned round from where the chain - truth, own plans, guesses - says it starts
+        const i64 want = round + depth * d->ownWorld;
+        if (want > d->wantUpTo) d->wantUpTo = want;
+        d->cv.notify_all();
+        for (;;) {
+            i64 f = 0;
+            std::shared_ptr<RoundPlan> ended;
+            const int st = sparseEstimate(round, &f, &ended);
+            if (st == 1) {
+                if (ended) return ended;
+                auto e = std::make_shared<RoundPlan>();  // "the input ends before this round" as a guess says it: an empty plan
+                e->round = -3;                           // of no round - a result made from it is never valid at the commit, the
+                e->empty = true;                         // round is simply planned again once the committed chain has reached it
+                return e;
+            }
+            if (st == 0) {
+                auto it = d->pending.find({round, f});
+                if (it != d->pending.end()) return it->second;
+            }
+            if (st < 0) d->cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(200));  // (system clock: the form ThreadSanitizer follows)
+            else d->cv.wait(lk);
+        }
+    }
     if (round + depth > d->wantUpTo) d->wantUpTo = round + depth;
     d->cv.notify_all();
     for (;;) {
@@ -555,6 +684,8 @@ void Planner::dropBefore(i64 round, i64 firstInOfRound) {
     d->cache.erase(d->cache.begin(), d->cache.lower_bound(round));
     d->base = round;
     d->startFirstIn = firstInOfRound;
+    if (d->ownWorld > 1)
+        for (auto it = d->pending.begin(); it != d->pending.end();) it = it->first.first < round ? d->pending.erase(it) : std::next(it);
     if (d->winCache) {  // (a lane may still be reading the windows of a plan that started from an older guess)
         i64 keep = firstInOfRound;
         for (auto& l : d->lanes)
@@ -1308,6 +1439,7 @@ void OverlapRun::startWorkers() {
     if (!workers_.empty()) return;
     nextIssue_ = round;
     while (nextIssue_ % world_ != rank_) nextIssue_++;  // first round this rank owns
+    if (world_ > 1 && planner) planner->setOwnership(rank_, world_);  // (the rounds dealt to the ranks: each plans its own)
     for (size_t i = 0; i < slots.size(); i++) workers_.emplace_back([this, i] { workerMain(i); });
 }
 

@@ -138,6 +138,10 @@ DPH_API int64_t dph_planner_counter(int which);
 DPH_API int dph_selftest_planner_flags(void* reads, int k, int64_t seed_batch_size, const double* values);
 DPH_API int dph_selftest_planner_lanes(void* reads, int k, int64_t seed_batch_size, const double* values, int lanes, int flag_every,
                                        int64_t* n_rounds);
+/* the plan chain of a round-parallel run of `world` ranks whose planners compute only their own rounds' plans and guess the rest
+ * (Planner::setOwnership), played against a commit that accepts a plan iff it starts at the committed firstSequence */
+DPH_API int dph_selftest_planner_sparse(void* reads, int k, int64_t seed_batch_size, const double* values, int world, int flag_every,
+                                        int64_t* n_rounds, int64_t* n_redone);
 DPH_API int dph_selftest_touch(int k, const uint32_t* seeds, int64_t n_seeds, const uint32_t* kmers, int64_t n_windows, int64_t stride,
                                uint8_t* res, int* isa_mask);
 /* finalCheckWorker (commands/overlap.go:197-233) over externally supplied queries, indexed sequences and matches (flat arrays

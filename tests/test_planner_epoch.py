@@ -82,3 +82,28 @@ def test_planner_lanes_compute_the_chain_of_one_lane():
         assert rc == 0, "chains differ (rc %d; > 0: first differing round + 1) for k=%d budget=%d lanes=%d" % (rc, k, budget, lanes)
         assert n.value >= 5, "only %d plans: the case does not exercise the chain" % n.value
         print("k=%d budget=%d lanes=%d: %d plans, %d computed plans thrown away" % (k, budget, lanes, n.value, H.dph_planner_counter(1) - thrown))
+
+
+def test_planner_ownership_computes_a_rank_share_of_the_chain():
+    """Round-parallel runs: every rank's planner computes the plans of the rounds its rank executes only and guesses
+    where the rounds in between end (Planner::setOwnership).  Simulated ranks - each with its own flags, window cache (host
+    producer) and planner - play a commit that accepts a plan iff it starts at the committed firstSequence and otherwise tells
+    every rank the truth and asks the owner again.  The accepted chain must be the chain one dense planner walks: with guesses
+    that hold (k = 10, small budget), with guesses that mostly fail (k = 8: a sixth of all k-mers are seeds) and with reads
+    flagged along the way."""
+    from downpore_amd.overlap import Reads, load_host
+    H = load_host()
+    H.dph_selftest_planner_sparse.restype = C.c_int
+    H.dph_selftest_planner_sparse.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    for (seed, G, N, L, variable, k, budget, world, flag_every) in [(8, 80000, 500, 2500, True, 10, 800, 2, 0), (8, 80000, 500, 2500, True, 10, 800, 4, 3),
+                                                                    (7, 60000, 400, 3000, False, 8, 1500, 3, 0), (9, 50000, 300, 4000, False, 8, 4000, 8, 2)]:
+        bases, off = O.gen_reads(seed, G, N, L, 0.0, variable)
+        reads = Reads(bases, off, min_len=1000)
+        rng = np.random.default_rng(seed)
+        values = np.ascontiguousarray(rng.random(4 ** k))
+        values[0] = 0.0
+        n, redone = C.c_int64(0), C.c_int64(0)
+        rc = H.dph_selftest_planner_sparse(reads.h, k, budget, values.ctypes.data, world, flag_every, C.byref(n), C.byref(redone))
+        assert rc == 0, "chains differ (rc %d; > 0: first differing round + 1) for k=%d budget=%d world=%d" % (rc, k, budget, world)
+        assert n.value >= 5
+        print("k=%d budget=%d world=%d flags every %d: %d plans, %d asked for again" % (k, budget, world, flag_every, n.value, redone.value))
