@@ -206,7 +206,15 @@ def main():
             pass
         return out
 
+    def pipe_counters():
+        H = pipe.H
+        H.dph_planner_counter.restype = __import__("ctypes").c_int64
+        names = ["plans_computed", "plans_thrown_away", "plans_erased_by_flags", "rounds_executed", "rounds_rejected", "rounds_committed",
+                 "plan_compute_us", "slot_wait_for_plan_us"]
+        return {nm: int(H.dph_planner_counter(i)) for i, nm in enumerate(names)}
+
     cs0 = cpu_stat()
+    pc0 = pipe_counters()
     acc, lines, rounds, t_init_sum, per_job = {}, 0, 0, 0.0, []
     t_start = time.perf_counter()
     for _ in range(args.steps):
@@ -220,9 +228,24 @@ def main():
             acc[key] = acc.get(key, 0.0) + v
         if lines == jl * len(per_job):
             checks["jobs_with_equal_line_count"] = len(per_job)
+    t_local = time.perf_counter() - t_start  # (this rank's own: before the barrier)
     sync()
     elapsed = time.perf_counter() - t_start
     cs1 = cpu_stat()
+    # per-rank stage times of the timed jobs, gathered on rank 0 (so that a first multi-GPU run explains itself): set-up, rounds,
+    # what this rank's planner and executor slots did
+    pc1 = pipe_counters()
+    nj = max(1, args.steps)
+    mine = {"rank": rank, "jobs_s": t_local / nj, "setup_s": t_init_sum / nj, "rounds_s": (t_local - t_init_sum) / nj,
+            "kernel_ms_per_job": {k_: acc.get(k_, 0.0) / nj for k_ in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
+            "phase_s_per_job": {k_: acc.get(k_, 0.0) / nj for k_ in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
+            "per_job": {k_: (pc1[k_] - pc0[k_]) / nj for k_ in pc1}, "slots": args.slots,
+            "host_threads": int(os.environ.get("DP_HOST_THREADS", "0")) or None}
+    per_rank = [mine]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch_device if torch_device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -324,6 +347,7 @@ def main():
                          "traffic": pmc_traffic(rl_file), "algorithmic_bytes_per_launch": rl_bytes, "launch_ms": rl_ms,
                          "launches_per_step": rounds / n_jobs, "measured_stream_GBs": stream_gbs},
             "parity": checks,
+            "per_rank": per_rank,
             # the PCIe-inclusive rate: the ASCII reads cross PCIe and are packed on the device once per job (never `value`)
             "value_incl_upload": lines / (elapsed + n_jobs * upload["upload_pack_s"]) if elapsed > 0 else 0.0,
             "rounds_only": {"value": lines / max(1e-9, elapsed - t_init_sum), "unit": "overlaps/s",

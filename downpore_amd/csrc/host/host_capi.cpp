@@ -381,7 +381,19 @@ void dph_profile_print() { profilePrint(); }
 // process-wide planner counters (tests): 0 plans computed, 1 computed plans thrown away (stale flags, or started from a wrong
 // guess of where the plan before them ends), 2 finished plans erased by a commit's flags
 int64_t dph_planner_counter(int which) {
-    return which == 0 ? g_prof.planComputes.load() : which == 1 ? g_prof.planDiscarded.load() : which == 2 ? g_prof.planErased.load() : -1;
+    // 0 plans computed, 1 thrown away, 2 erased by flags, 3 rounds executed, 4 rejected at the commit, 5 committed, 6 microseconds in
+    // plan computes (wall), 7 slots' microseconds waiting for a plan (planComputes etc. count since the process started)
+    switch (which) {
+        case 0: return g_prof.planComputes.load();
+        case 1: return g_prof.planDiscarded.load();
+        case 2: return g_prof.planErased.load();
+        case 3: return g_prof.executed.load();
+        case 4: return g_prof.rejected.load();
+        case 5: return g_prof.committed.load();
+        case 6: return g_prof.planUs.load();
+        case 7: return g_prof.getWaitUs.load();
+        default: return -1;
+    }
 }
 int64_t dph_overlap_step_lines(void* hh) { return ((OverlapH*)hh)->run.pafLines; }  // PAF lines of the last step
 // host-logic test hook: the value table (commands/overlap.go:55-92) from a k-mer histogram; counts is overwritten with the

@@ -362,6 +362,7 @@ bool Planner::chainHead(i64* round, i64* firstIn) const {
 
 // Plans computed ahead join the chain as far as their assumptions hold; what can no longer join is dropped.
 void Planner::promote() {
+    if (d->ownWorld > 1) return;  // (ownership mode: plans stay where get() looks them up - by round and assumed start)
     i64 m = 0, f = 0;
     bool alive;
     while ((alive = chainHead(&m, &f))) {
