@@ -275,6 +275,93 @@ __device__ int m_dynamic_match(MWave& L, int qn, int sn, int minMatch, int k, co
     return nGood;
 }
 
+// dynamicMatch with the whole wave (round 4).  The reference's loop nest is "for every query seed that heads no chain yet: for
+// every target seed: equal?" - |q| x |t| probes (125 x 250 for a 250-seed reference chunk) of which a handful are hits; on one lane
+// that scan WAS map_kernel's time (1.24 ms per launch).  Here the 64 lanes probe 64 target seeds at once (equal to the query seed
+// and not a repeat of the target seed in front of it: both are facts of positions, not of the walk's state), and lane 0 handles
+// the hits in ascending order exactly as the one-lane loop does - the head-chain test at the moment of the hit, extendChain, the
+// 2 len / 3 ratchet (which also shortens both loops' bounds), the "fewer open query seeds than this chain is long" exit.  What
+// lane 0 decides (chain count, good count, minMatch, stop) is broadcast after every hit, so every lane runs the same loops.
+__device__ int m_dynamic_match_wave(MWave& L, int qn, int sn, int minMatch, int k, const MChainPool& P, uint16_t* chainLen,
+                                    uint32_t* err) {
+    const int lane = dp_lane();
+    if (minMatch == 0) minMatch = 1;
+    const int nq = qn / 2, nsT = sn / 2;
+    for (int i = lane; i < nq; i += 64) L.headChain[i] = -1;
+    __builtin_amdgcn_wave_barrier();
+    int nChains = 0, nGood = 0;
+    const int32_t* qs = L.q;
+    const int32_t* ss = L.t;
+    for (int qIndex = 1; qIndex < qn - minMatch * 2 + 2; qIndex += 2) {
+        if (qs[qIndex - 1] < 0 && qIndex > 1 && qs[qIndex + 1] < 0 && qs[qIndex] == qs[qIndex - 2] && qs[qIndex] == qs[qIndex + 2])
+            continue;
+        const int qsi = qIndex / 2;
+        if (L.headChain[qsi] >= 0) continue;
+        const int qseed = qs[qIndex];
+        for (int tb = 0; 2 * tb + 1 < sn - minMatch * 2 + 2; tb += 64) {
+            const int t = tb + lane, i = 2 * t + 1;
+            bool hit = false;
+            if (t < nsT && i < sn - minMatch * 2 + 2) {
+                const int sd = ss[i];
+                hit = sd == qseed && (t == 0 || ss[i - 2] != sd);  // (prevSeed of the reference's scan = the target seed in front)
+            }
+            unsigned long long m = __ballot(hit);
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                const int ti = 2 * (tb + j) + 1;
+                if (ti >= sn - minMatch * 2 + 2) break;  // (a ratchet inside this stretch moved the bound in front of the hit)
+                int stop = 0;
+                if (lane == 0) {
+                    const int hc = L.headChain[qsi];
+                    if (hc < 0 || (int)P.B(hc)[L.headLen[qsi] - 1] != ti / 2) {
+                        if (nChains >= M_CHAINS) {
+                            *err |= 2;
+                            stop = 1;
+                        } else {
+                            const int c = nChains++;
+                            P.A(c)[0] = (uint16_t)qsi;
+                            P.B(c)[0] = (uint16_t)(ti / 2);
+                            L.headChain[qsi] = c;
+                            L.headLen[qsi] = 1;
+                            const int len = m_extend(L, qn, sn, qIndex, ti, k, c, 1, P);
+                            chainLen[c] = (uint16_t)len;
+                            if (len >= minMatch) {
+                                const int nextLength = (len * 2) / 3;
+                                if (nextLength > minMatch) {
+                                    minMatch = nextLength;
+                                    for (int g = nGood - 1; g >= 0; g--) {
+                                        if ((int)chainLen[L.good[g]] < nextLength) {
+                                            L.good[g] = L.good[nGood - 1];
+                                            nGood--;
+                                        }
+                                    }
+                                }
+                                if (nGood >= M_GOOD) {
+                                    *err |= 4;
+                                    stop = 1;
+                                } else {
+                                    L.good[nGood++] = c;
+                                    int remaining = 0;
+                                    for (int x = 0; x < nq; x++) remaining += L.headChain[x] < 0;
+                                    if (remaining < len) stop = 1;
+                                }
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                nChains = __builtin_amdgcn_readfirstlane(nChains);
+                nGood = __builtin_amdgcn_readfirstlane(nGood);
+                minMatch = __builtin_amdgcn_readfirstlane(minMatch);
+                stop = __builtin_amdgcn_readfirstlane(stop);
+                if (stop) return nGood;
+            }
+        }
+    }
+    return nGood;
+}
+
 struct MapRec {
     uint32_t window, target, off, len, seq;
 };
@@ -303,7 +390,7 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                                                            uint16_t* __restrict__ poolB, uint16_t* __restrict__ poolLen,
                                                            MapRec* __restrict__ recs, uint32_t rec_cap, int32_t* __restrict__ ma,
                                                            int32_t* __restrict__ mb, uint32_t int_cap, uint32_t* __restrict__ cursor,
-                                                           int phase, int32_t* __restrict__ thr_io) {
+                                                           int phase, int32_t* __restrict__ thr_io, int one_lane) {
     // phase 2: both strands of every window pair, thresholds from the windows themselves (the whole index is here).
     // phase 0 / 1 (the index is one shard of the reference, dp_map_windows_shard): only the forward / only the reverse-complement
     // windows, starting from the thresholds the previous shard left in thr_io[pair][2] (< 0: none yet) and leaving its own there.
@@ -353,9 +440,13 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                     const int minMatch = thr[s];
                     const int nT = m_reduce_wave<uint16_t>(tSeg, tN, qset, k, minMatch, L.t, L.tIdx, M_TMAX, &err);
                     const int nQ = nT < 0 ? -1 : m_reduce_wave<uint16_t>(qSeg, qN, tset, k, minMatch, L.q, L.qIdx, M_QMAX, &err);
+                    // dynamicMatch: the probes on 64 lanes, the walk's decisions on lane 0 (DP_MAP_ONE_LANE=1: all of it on lane 0 as
+                    // before round 4)
+                    int nGoodW = 0;
+                    if (nT >= 0 && nQ >= 0 && !one_lane) nGoodW = m_dynamic_match_wave(L, 2 * nQ + 1, 2 * nT + 1, minMatch, k, P, chainLen, &err);
                     if (lane == 0) {
                         if (nT >= 0 && nQ >= 0) {
-                            const int nGood = m_dynamic_match(L, 2 * nQ + 1, 2 * nT + 1, minMatch, k, P, chainLen, &err);
+                            const int nGood = one_lane ? m_dynamic_match(L, 2 * nQ + 1, 2 * nT + 1, minMatch, k, P, chainLen, &err) : nGoodW;
                             for (int g = 0; g < nGood; g++) {
                                 const int ch = L.good[g];
                                 const int len = chainLen[ch];
@@ -446,6 +537,8 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
     uint32_t int_cap = std::max<uint32_t>(1u << 21, (uint32_t)(ctx->d_ma.cap / 4));
     uint32_t cur[16];
     float total_ms = 0;
+    const char* ole = getenv("DP_MAP_ONE_LANE");  // (read per call: tests switch it between jobs of one process)
+    const int one_lane = ole && ole[0] == '1' ? 1 : 0;
     for (;;) {
         if (dev_reserve(ctx, ctx->d_mrec, (size_t)rec_cap * sizeof(MapRec))) return DP_ERR_HIP;
         if (dev_reserve(ctx, ctx->d_ma, (size_t)int_cap * 4)) return DP_ERR_HIP;
@@ -457,7 +550,7 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
                            (const uint32_t*)d_qmeta, (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p,
                            (const int32_t*)ctx->d_segs.p, (const u64*)ctx->d_seedsets.p, W, SW, k, poolA, poolB, poolLen,
                            (MapRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p, int_cap,
-                           (uint32_t*)ctx->d_cursor.p, phase, d_thr);
+                           (uint32_t*)ctx->d_cursor.p, phase, d_thr, one_lane);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         DP_HIP(hipMemcpyAsync(cur, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));

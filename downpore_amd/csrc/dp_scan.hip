@@ -937,34 +937,62 @@ extern "C" int dp_select_windows(dp_ctx* ctx, const dp_scan_item* win, uint32_t 
 // ---------------------------------------------------------------------------------------------------------------
 // A22: histogram of every k-mer of every read (util/sequtil/kmers.go:53-69): positions 0..len-k.
 
+// Work items are stretches of 64 groups of 32 positions (2 048 bases) - not reads: `downpore map` counts the k-mers of a reference
+// that is ONE sequence of millions of bases, and a wave per read meant one wave for all of it (8.2 ms for 4.6 Mb; now the chip).
+// coff[r] = first item of read r (host-made prefix sums); the read of an item is found by bisection, once per 2 048 bases.
 __global__ void hist_kernel(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ boff,
-                            const uint32_t* __restrict__ len, uint32_t n_reads, int k, uint32_t* __restrict__ counts) {
+                            const uint32_t* __restrict__ len, uint32_t n_reads, int k, const uint64_t* __restrict__ coff,
+                            uint32_t* __restrict__ counts) {
     const int lane = dp_lane();
-    const uint32_t waves = gridDim.x * (blockDim.x >> 6);
-    const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t gw = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int sh = 32 - 2 * k;
-    for (uint32_t r = gw; r < n_reads; r += waves) {
-        uint32_t L = len[r];
-        if (L < (uint32_t)k) continue;  // the reference would index out of range here; nothing to count
-        uint64_t a0 = boff[r] * 4, a1 = a0 + (L - k + 1);
-        uint64_t g0 = a0 >> 5, g1 = (a1 - 1) >> 5;
-        for (uint64_t gb = g0; gb <= g1; gb += 64) {
-            uint64_t g = gb + lane;
-            if (g > g1) continue;
-            Win w = load_win(packed, g);
-            uint32_t vm = valid_mask(g, a0, a1);
-            for (int j = 0; j < 32; j++)
-                if ((vm >> j) & 1) atomicAdd(&counts[win_at_rt(w, j) >> sh], 1u);
+    const uint64_t n_items = coff[n_reads];
+    for (uint64_t it = gw; it < n_items; it += waves) {
+        uint32_t lo = 0, hi = n_reads;  // largest r with coff[r] <= it
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (coff[mid] <= it) lo = mid;
+            else hi = mid;
         }
+        const uint32_t r = lo;
+        const uint32_t L = len[r];
+        if (L < (uint32_t)k) continue;  // (such a read has no item; kept for safety)
+        const uint64_t a0 = boff[r] * 4, a1 = a0 + (L - k + 1);
+        const uint64_t g0 = a0 >> 5, g1 = (a1 - 1) >> 5;
+        const uint64_t g = g0 + (it - coff[r]) * 64 + (uint64_t)lane;
+        if (g > g1) continue;
+        Win w = load_win(packed, g);
+        uint32_t vm = valid_mask(g, a0, a1);
+        for (int j = 0; j < 32; j++)
+            if ((vm >> j) & 1) atomicAdd(&counts[win_at_rt(w, j) >> sh], 1u);
     }
 }
 
 // adds the k-mer counts of the resident reads to d_counts (4^k zero-initialised uint32 on the device), on the context's stream
 int dp_histogram_device(dp_ctx* ctx, int k, uint32_t* d_counts) {
     if (ctx->n_reads) {
-        hipLaunchKernelGGL(hist_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
-                           (const uint64_t*)ctx->d_boff.p, (const uint32_t*)ctx->d_len.p, ctx->n_reads, k, d_counts);
+        const dp_ctx* ow = ctx->owner ? ctx->owner : ctx;
+        std::vector<uint64_t> coff((size_t)ctx->n_reads + 1);
+        uint64_t run = 0;
+        for (uint32_t r = 0; r < ctx->n_reads; r++) {
+            coff[r] = run;
+            const uint32_t L = ow->h_len[r];
+            if (L < (uint32_t)k) continue;  // the reference would index out of range here; nothing to count
+            const uint64_t a0 = ow->h_boff[r] * 4, a1 = a0 + (L - k + 1);
+            run += (((a1 - 1) >> 5) - (a0 >> 5) + 1 + 63) / 64;
+        }
+        coff[ctx->n_reads] = run;
+        void* d_coff = nullptr;
+        DP_HIP(dp_dev_malloc(&d_coff, coff.size() * 8));
+        DP_HIP(hipMemcpyAsync(d_coff, dp_stage(ctx, coff.data(), coff.size() * 8), coff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(1, (run + 3) / 4));
+        hipLaunchKernelGGL(hist_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
+                           (const uint64_t*)ctx->d_boff.p, (const uint32_t*)ctx->d_len.p, ctx->n_reads, k, (const uint64_t*)d_coff, d_counts);
         DP_HIP(hipGetLastError());
+        // (freed once the kernel has read it: the block goes back to the cache after the stream has passed this point)
+        DP_HIP(dp_stream_sync(ctx));
+        dp_dev_free(d_coff);
     }
     return DP_OK;
 }

@@ -41,17 +41,19 @@ def test_bench_two_ranks_sharing_the_gpu(mode):
 
 
 def test_bench_two_ranks_default_reports_both_layouts():
-    """N > 1 without --mode: the headline is north_star's layout (reads partitioned, survivors all-gathered), the round-parallel
-    layout follows as `alt_mode`; each is held to the fixture on its own."""
+    """N > 1 without --mode: the headline is the layout that scales while a GPU holds the reads (query batches dealt to the ranks,
+    results all-gathered; every rank plans its own rounds only), the reads-partitioned layout (survivors all-gathered) follows as
+    `alt_mode`; each is held to the fixture on its own."""
     env = dict(os.environ, DP_BENCH_SAME_DEVICE="1", DP_BENCH_BACKEND="gloo")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29518", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--cpu-rounds", "0", "--slots", "4"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-3000:]
     d = _line(p.stdout)
-    assert d["n_gpus"] == 2 and "north_star layout" in d["config"]["parallelism"]
+    assert d["n_gpus"] == 2 and "query batches dealt to 2 GPUs" in d["config"]["parallelism"]
     assert d["parity"]["paf_sha256_matches_oracle_fixture"] is True
-    assert d["alt_mode"]["mode"] == "round" and d["alt_mode"]["paf_sha256_matches_oracle_fixture"] is True and d["alt_mode"]["value"] > 0
+    assert d["alt_mode"]["mode"] == "scan-shard" and d["alt_mode"]["paf_sha256_matches_oracle_fixture"] is True and d["alt_mode"]["value"] > 0
+    assert len(d["per_rank"]) == 2 and all(r["per_job"]["plans_computed"] < 0.75 * d["config"]["rounds_per_step"] for r in d["per_rank"])
 
 
 def test_bench_plain_launch_starts_its_own_ranks():

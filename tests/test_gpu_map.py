@@ -56,6 +56,16 @@ def test_map_paf_bit_exact(seed, G, N, L, e, variable, circular):
     assert st["n_windows"] >= N
 
 
+def test_map_dynamic_match_on_one_lane_agrees(monkeypatch):
+    """dynamicMatch probes the target's seeds with 64 lanes at once (round 4); DP_MAP_ONE_LANE=1 runs the reference's loop nest on
+    one lane as before.  Both must print the oracle's PAF - reads with errors, so that chains break, ratchets move and several
+    chains start from one query seed."""
+    monkeypatch.setenv("DP_MAP_ONE_LANE", "1")
+    _case(5, 300000, 200, 9000, 0.10, True, False)
+    monkeypatch.delenv("DP_MAP_ONE_LANE")
+    _case(6, 250000, 250, 7000, 0.15, True, True)
+
+
 @pytest.mark.parametrize("shards,G,k,e", [(3, 6000000, 11, 0.10), (4, 2600000, 9, 0.05), (2, 1500000, 13, 0.0)])
 def test_map_reference_index_in_shards(monkeypatch, shards, G, k, e):
     """BASELINE config 5's layout on one GPU: the reference chunks are dealt to DP_MAP_SHARDS contexts in contiguous ranges
