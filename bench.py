@@ -152,7 +152,8 @@ def main():
                 args.mode = "scan-shard"
     G = N * L // 20
     t0 = time.time()
-    bases, off = gen_reads(args.seed, G, N, L, args.error, False)
+    from tools.synth import gen_reads_truth
+    bases, off, truth_starts, truth_strands = gen_reads_truth(args.seed, G, N, L, args.error, False)  # (the same reads as gen_reads')
     reads = Reads(bases, off, min_len=1000)
     t_gen = time.time() - t0
     # N > 1, scan-shard (default): the survivor exchange runs inside the library on an RCCL communicator (dp_comm_init +
@@ -187,6 +188,7 @@ def main():
         t_init = pipe.setup_times()["init_s"]
         if verify and rank == 0:
             paf = pipe.all_paf()
+            res["ground_truth"] = ground_truth(paf, off, truth_starts, truth_strands, args.k)
             res["first_job_paf"] = paf if args.cpu_rounds > 0 and world == 1 else None
             res["values"] = pipe.values() if args.cpu_rounds > 0 and world == 1 else None
             if golden is not None and args.max_rounds < 0:
@@ -357,6 +359,8 @@ def main():
                          "traffic": pmc_traffic(rl_file), "algorithmic_bytes_per_launch": rl_bytes, "launch_ms": rl_ms,
                          "launches_per_step": rounds / n_jobs, "measured_stream_GBs": stream_gbs},
             "parity": checks,
+            # the PAF held to the synthetic genome itself (independent of the oracle): tests/test_ground_truth.py's figures on a sample
+            "ground_truth": res.get("ground_truth"),
             "per_rank": per_rank,
             # the PCIe-inclusive rate: the ASCII reads cross PCIe and are packed on the device once per job (never `value`)
             "value_incl_upload": lines / (elapsed + n_jobs * upload["upload_pack_s"]) if elapsed > 0 else 0.0,
@@ -390,6 +394,31 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def ground_truth(paf, off, starts, strands, k, sample=200000):
+    """The first `sample` PAF lines against where the generator took the reads from: strand mismatches, lines whose reads do not
+    overlap on the genome, fraction of lines whose two parts begin and end within k (30) bases of each other on the genome."""
+    lines = paf.split("\n", sample)[:sample]
+    lines = [ln for ln in lines if ln]
+    if not lines:
+        return None
+    f = np.array([ln.split("\t")[:9] for ln in lines], dtype=object)
+    q = np.array([int(x[1:]) for x in f[:, 0]])
+    t = np.array([int(x[1:]) for x in f[:, 5]])
+    qs, qe, ts, te = (f[:, c].astype(np.int64) for c in (2, 3, 7, 8))
+    minus = f[:, 4] == "-"
+    Ls = np.diff(off)
+
+    def gpos(r, x):
+        return np.where(strands[r] == 0, starts[r] + x, starts[r] + Ls[r] - x)
+    a0, a1 = np.minimum(gpos(q, qs), gpos(q, qe)), np.maximum(gpos(q, qs), gpos(q, qe))
+    b0, b1 = np.minimum(gpos(t, ts), gpos(t, te)), np.maximum(gpos(t, ts), gpos(t, te))
+    n = len(lines)
+    return {"lines_checked": n, "strand_mismatches": int(((strands[q] != strands[t]) != minus).sum()),
+            "reads_that_do_not_overlap_on_the_genome": int((~((starts[q] < starts[t] + Ls[t]) & (starts[t] < starts[q] + Ls[q]))).sum()),
+            "frac_both_ends_within_k_bases": float(((np.abs(a0 - b0) <= k) & (np.abs(a1 - b1) <= k)).mean()),
+            "frac_both_ends_within_30_bases": float(((np.abs(a0 - b0) <= 30) & (np.abs(a1 - b1) <= 30)).mean())}
 
 
 def alt_mode_jobs(mode, reads, args, rank, world, local_rank, torch_device, comm, golden, torch, dist):

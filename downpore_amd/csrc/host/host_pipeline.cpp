@@ -925,7 +925,10 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     {
         const char* dt = getenv("DP_DEFER_TEXT");  // 0: the executor slots format their rounds' text themselves
         textPool.reset();
-        if (!(dt && dt[0] == '0')) textPool.reset(new TextPool(2));
+        // formatter threads (DPH_TEXT_THREADS): a round's text is ~0.3 ms of one thread, so two of them cap a run at ~6.5 rounds per ms
+        int nText = 2;
+        if (const char* te = getenv("DPH_TEXT_THREADS")) nText = std::max(1, std::min(16, atoi(te)));
+        if (!(dt && dt[0] == '0')) textPool.reset(new TextPool(nText));
     }
     setHostThreadShare((unsigned)std::max(1, nSlots));
     // every executor slot's thread waits for its stream five to seven times per round: busy waits when this process has the

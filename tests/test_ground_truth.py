@@ -10,14 +10,14 @@ from tests import oracle_lib as O
 from tools.synth import gen_reads_truth
 
 
-def _check(paf, off, starts, strands, min_exact):
+def _check(paf, off, starts, strands, min_exact, k=10, min_within_k=None):
     L = np.diff(off)
     lines = [ln.split("\t") for ln in paf.split("\n") if ln]
     assert len(lines) > 1000
 
     def gpos(r, x):
         return starts[r] + x if strands[r] == 0 else starts[r] + L[r] - x
-    strand_bad = apart = exact = reads_apart = 0
+    strand_bad = apart = exact = reads_apart = within_k = 0
     for f in lines:
         q, t = int(f[0][1:]), int(f[5][1:])
         a = sorted((gpos(q, int(f[2])), gpos(q, int(f[3]))))
@@ -25,21 +25,28 @@ def _check(paf, off, starts, strands, min_exact):
         strand_bad += (strands[q] != strands[t]) != (f[4] == "-")
         apart += min(a[1], b[1]) <= max(a[0], b[0])  # the two parts share no base of the genome
         exact += abs(a[0] - b[0]) <= 30 and abs(a[1] - b[1]) <= 30
+        within_k += abs(a[0] - b[0]) <= k and abs(a[1] - b[1]) <= k  # seed-space coordinates: a seed's width is the resolution
         # (a line joins the contig's first part with another part: both overlap the query window's consensus, and nearly always
         # each other)
         reads_apart += not (starts[q] < starts[t] + L[t] and starts[t] < starts[q] + L[q])
     print("lines %d: strand mismatches %d, reads that do not overlap on the genome %d, parts without a shared base %d, both ends within "
-          "30 bases %d" % (len(lines), strand_bad, reads_apart, apart, exact))
+          "30 bases %d (%.1f %%), within k = %d bases %d (%.1f %%)" % (len(lines), strand_bad, reads_apart, apart, exact, 100.0 * exact / len(lines), k,
+                                                                        within_k, 100.0 * within_k / len(lines)))
     assert strand_bad == 0
     assert reads_apart <= len(lines) // 100, (reads_apart, len(lines))
     assert apart <= len(lines) // 200, (apart, len(lines))
     assert exact >= min_exact * len(lines), (exact, len(lines))
+    if min_within_k is not None:
+        assert within_k >= min_within_k * len(lines), (within_k, len(lines))
+    return within_k / len(lines)
 
 
 def test_oracle_paf_describes_true_overlaps():
     bases, off, starts, strands = gen_reads_truth(1, 250000, 1000, 5000, 0.0, False)  # BASELINE config 1 at the command's default k
     run = O.OverlapRun(O.ReadSet(bases, off, min_len=1000), k=10)
-    _check(run.paf, off, starts, strands, 0.9)
+    # (83 % of the oracle's lines have both ends within k bases of each other on the genome: a semantic drift shared by the oracle and
+    # the product's host mirror - written by one author from one reading of the Go - would have to keep that as well)
+    _check(run.paf, off, starts, strands, 0.9, k=10, min_within_k=0.8)
 
 
 @pytest.mark.gpu
@@ -50,4 +57,4 @@ def test_product_paf_describes_true_overlaps():
     pipe.run()
     paf = pipe.all_paf()
     pipe.close()
-    _check(paf, off, starts, strands, 0.9)
+    _check(paf, off, starts, strands, 0.9, k=10, min_within_k=0.78)

@@ -10,8 +10,12 @@ mkdir -p gpurun_out/r04; cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 R=gpurun_out/r04
 rm -rf $R/ktrace
 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/ktrace -- python3 bench.py > $R/ktrace_bench.json 2> $R/ktrace_bench.err; echo "ktrace rc=$?"
-find $R/ktrace -name "*kernel_trace.csv" -size +20M -exec sh -c 'python3 tools/ktrace_digest.py "$1" > "$1.digest.txt"; rm -f "$1"' _ {} \;
-if [ -n "$KTRACE_ONLY" ]; then du -sh $R; ls $R $R/ktrace/*; exit 0; fi
+t=$(find $R/ktrace -name "*kernel_trace.csv" | head -1)
+[ -n "$t" ] && python3 tools/ktrace_digest.py $t > $R/bench_default_kernel_trace_digest.txt
+f=$(find $R/ktrace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $R/bench_default_kernel_stats.csv
+cp $R/ktrace_bench.json $R/bench_default_under_rocprof.json
+rm -rf $R/ktrace
+if [ -n "$KTRACE_ONLY" ]; then du -sh $R; ls $R; exit 0; fi
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS"
 COMMON="--steps 1 --warmup 0 --cpu-rounds 0 --scan-leg-rounds 0 --dense-leg-rounds 0 --map-leg-repeats 0"
 run() { # name, counters, bench args...
