@@ -2941,9 +2941,12 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
         const char* e = getenv("DP_WALK0_SLIM");
         return !(e && e[0] == '0');
     }();
-    // the tiny layout where every query of the stage fits it (mc_n - 1 >= the longest query's seeds); DP_CHAIN_TINY=0: CSlim as before
+    // DP_CHAIN_TINY=1: the tiny layout where every query of the stage fits it (mc_n - 1 >= the longest query's seeds).  Off by
+    // default: alone on the GPU its kernels are SLOWER than CSlim's (one-slot timeline, profiles/r04/round_timeline_one_slot*.txt:
+    // walk 35 against 25 us, passes 37 / 25 / 8 against 29 / 18 / 8) and with five slots the job rate is the same - the LDS it
+    // frees was not what the other rounds' kernels were waiting for.
     const char* te = getenv("DP_CHAIN_TINY");  // (read per call: tests switch it between jobs of one process)
-    const bool tiny = !(te && te[0] == '0') && A.mc_n <= 32;
+    const bool tiny = te && te[0] == '1' && A.mc_n <= 32;
     // (the same 1 024 workgroups: at 112 VGPRs a CU holds sixteen of these waves whatever their LDS - twice the workgroups
     // measured 5 % slower, profiles/r04/ab_tiny.txt - but they now leave 108 KB of every CU's LDS to the other rounds' kernels)
     const uint32_t spec_blocks = st.spec_blocks;

@@ -27,3 +27,45 @@ if cw:
     busy += ce - cs
     print("window first..last chain_walk_kernel: %.1f ms, GPU busy (union of kernel intervals) %.1f ms = %.0f %%, sum of kernel times %.1f ms"
           % ((t1 - t0) / 1e6, busy / 1e6, 100.0 * busy / (t1 - t0), ksum / 1e6))
+
+# concurrency histogram over the same window: how long exactly n kernels were running at once (n = 0: nothing on the GPU)
+if cw:
+    pts = []
+    for s_, e_, _ in ev:
+        if e_ < t0 or s_ > t1: continue
+        pts.append((max(s_, t0), 1)); pts.append((min(e_, t1), -1))
+    pts.sort()
+    hist = collections.defaultdict(int); cur = 0; last = t0
+    for t_, d_ in pts:
+        hist[min(cur, 8)] += t_ - last; last = t_; cur += d_
+    hist[min(cur, 8)] += t1 - last
+    tot_ = float(t1 - t0)
+    print("kernels running at once (share of the window): " + "  ".join("%d%s: %.1f %%" % (n, "+" if n == 8 else "", 100.0 * hist[n] / tot_) for n in sorted(hist)))
+
+# the same inside the stretches of rounds only: the timeline is cut wherever nothing ran for 2 ms or longer (between jobs the host
+# hashes / resets; a job's set-up kernels are long single kernels) and only stretches with >= 100 chain_walk launches count
+if cw:
+    evs = sorted((s_, e_, c_) for s_, e_, c_ in ev)
+    segs = []; cs = ce = None; ncw = 0
+    for s_, e_, c_ in evs:
+        if ce is None or s_ - ce >= 2000000:
+            if ce is not None: segs.append((cs, ce, ncw))
+            cs, ce, ncw = s_, e_, 0
+        ce = max(ce, e_); ncw += 1 if c_ else 0
+    segs.append((cs, ce, ncw))
+    segs = [x for x in segs if x[2] >= 100]
+    tot_len = sum(e_ - s_ for s_, e_, _ in segs)
+    hist = collections.defaultdict(int); ksum2 = 0
+    for a_, b_, _ in segs:
+        pts = []
+        for s_, e_, _c in evs:
+            if e_ <= a_ or s_ >= b_: continue
+            pts.append((max(s_, a_), 1)); pts.append((min(e_, b_), -1)); ksum2 += min(e_, b_) - max(s_, a_)
+        pts.sort(); cur = 0; last = a_
+        for t_, d_ in pts:
+            hist[min(cur, 8)] += t_ - last; last = t_; cur += d_
+        hist[min(cur, 8)] += b_ - last
+    if tot_len:
+        print("stretches of rounds: %d, %.1f ms in all, %d chain_walk launches; kernel-time sum %.1f ms; kernels running at once: %s" %
+              (len(segs), tot_len / 1e6, sum(x[2] for x in segs), ksum2 / 1e6,
+               "  ".join("%d%s: %.1f %%" % (n, "+" if n == 8 else "", 100.0 * hist[n] / tot_len) for n in sorted(hist))))
