@@ -164,6 +164,8 @@ def main():
     pipe = OverlapPipeline(reads, device=local_rank, k=args.k, seed_batch_size=args.seed_batch_size, rank=rank, world=world,
                            torch_device=torch_device, mode=args.mode, slots=args.slots, defer_init=True, comm=comm)
     upload = pipe.setup_times()
+    if world > 1 and rank != 0:
+        pipe.keep_text(False)  # (rank 0 verifies and would print the PAF; the others commit the gathered rounds without their text)
 
     def sync():
         torch.cuda.synchronize()
@@ -427,6 +429,8 @@ def alt_mode_jobs(mode, reads, args, rank, world, local_rank, torch_device, comm
     from downpore_amd.overlap import OverlapPipeline
     pipe = OverlapPipeline(reads, device=local_rank, k=args.k, seed_batch_size=args.seed_batch_size, rank=rank, world=world,
                            torch_device=torch_device, mode=mode, slots=args.slots, defer_init=True, comm=comm)
+    if world > 1 and rank != 0:
+        pipe.keep_text(False)
 
     def sync():
         torch.cuda.synchronize()

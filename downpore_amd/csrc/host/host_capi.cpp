@@ -21,6 +21,7 @@ struct OverlapH {
     dp_ctx* xctx = nullptr;           // round-parallel mode: the context (own stream) the result exchange runs on
     std::vector<dp_comm*> slotComms;  // scan-shard with executor slots: one communicator per slot
     ReadSet* reads = nullptr;
+    bool keepText = true;             // dph_overlap_keep_text(0): gathered rounds of other ranks are committed without their PAF text
     double tCtx = 0, tUpload = 0, tInit = 0;
     std::string err;
     // PAF of every committed round so far.  Kept as one chunk per commit and joined only when somebody asks for the
@@ -447,7 +448,7 @@ const uint8_t* dph_overlap_exec_round(void* hh, int64_t first, uint64_t* n) {
 }
 int dph_overlap_slots(void* hh) { return (int)((OverlapH*)hh)->run.slots.size(); }
 // blobs: concatenation; sizes[i] bytes each.  Returns the number of rounds committed (0..count) or <0.
-static void deserialise(const uint8_t* blobs, const uint64_t* sizes, int count, std::vector<RoundResult>& rs) {
+static void deserialise(const uint8_t* blobs, const uint64_t* sizes, int count, std::vector<RoundResult>& rs, bool keepText = true) {
     uint64_t totalBytes = 0;
     for (int i = 0; i < count; i++) totalBytes += sizes[i];
     const uint8_t* q = blobs;
@@ -469,7 +470,7 @@ static void deserialise(const uint8_t* blobs, const uint64_t* sizes, int count, 
         q += hdr[5] * sizeof(int);
         r.indexedReads.assign((const uint32_t*)q, (const uint32_t*)q + hdr[6]);
         q += hdr[6] * 4;
-        r.paf.assign((const char*)q, (size_t)hdr[7]);
+        if (keepText) r.paf.assign((const char*)q, (size_t)hdr[7]);  // (a rank that prints nothing keeps the counts, not the text)
         q += hdr[7];
         r.snapshot = hdr[14];
         r.planRound = hdr[16];
@@ -507,7 +508,7 @@ const uint8_t* dph_overlap_wait_owned(void* hh, uint64_t* n) { return dph_overla
 int dph_overlap_commit_gathered(void* hh, const uint8_t* blobs, const uint64_t* sizes, int count) {
     OverlapH* h = (OverlapH*)hh;
     std::vector<RoundResult> rs;
-    deserialise(blobs, sizes, count, rs);
+    deserialise(blobs, sizes, count, rs, h->keepText);
     int c = h->run.commitGathered(rs);
     if (c > 0) h->addPaf(h->run.paf);
     return c;
@@ -545,7 +546,7 @@ int dph_overlap_superstep(void* hh, int max_rounds) {
         return rc;
     }
     std::vector<RoundResult> rs;
-    deserialise(all, sizes, dp_comm_size(h->comm), rs);
+    deserialise(all, sizes, dp_comm_size(h->comm), rs, h->keepText);
     const int c = h->run.commitGathered(rs);
     if (c > 0) h->addPaf(h->run.paf);
     return c;
@@ -554,13 +555,17 @@ int dph_overlap_superstep(void* hh, int max_rounds) {
 int dph_overlap_commit_blobs(void* hh, const uint8_t* blobs, const uint64_t* sizes, int count) {
     OverlapH* h = (OverlapH*)hh;
     std::vector<RoundResult> rs;
-    deserialise(blobs, sizes, count, rs);
+    deserialise(blobs, sizes, count, rs, h->keepText);
     std::sort(rs.begin(), rs.end(), [](const RoundResult& a, const RoundResult& b) { return a.round < b.round; });
     int c = h->run.commitResults(rs);
     if (c > 0) h->addPaf(h->run.paf);
     return c;
 }
 int dph_overlap_done(void* hh) { return ((OverlapH*)hh)->run.done ? 1 : 0; }
+// Multi-rank runs: a rank that does not print the PAF (every rank but the one that writes the output) need not keep the other
+// ranks' text - the gathered rounds are committed with their counts, flags and read lists, the text is dropped as it arrives
+// (at 8 ranks every rank would otherwise copy all 235 MB of a config-2 job's PAF three times).  keep != 0 (default): as before.
+void dph_overlap_keep_text(void* hh, int keep) { ((OverlapH*)hh)->keepText = keep != 0; }
 
 }  // extern "C"
 

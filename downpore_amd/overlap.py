@@ -82,6 +82,8 @@ def load_host():
     H.dph_overlap_exec_round.argtypes = [vp, C.c_int64, C.POINTER(C.c_uint64)]
     H.dph_overlap_commit_blobs.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_int]
     H.dph_overlap_done.argtypes = [vp]
+    H.dph_overlap_keep_text.restype = None
+    H.dph_overlap_keep_text.argtypes = [vp, C.c_int]
     H.dph_comm_unique_id.argtypes = [C.c_void_p]
     H.dph_overlap_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]
     H.dph_overlap_comm_init_local.argtypes = [C.c_void_p, C.c_int]
@@ -434,6 +436,10 @@ class OverlapPipeline:
         return 1
 
     # ---- round-parallel building blocks (also used by the single-GPU simulation test)
+    def keep_text(self, keep):
+        """Multi-rank runs: keep=False on a rank that does not print the PAF drops the other ranks' text as it arrives."""
+        self.H.dph_overlap_keep_text(self.h, 1 if keep else 0)
+
     def committed_rounds(self):
         return self.H.dph_overlap_round(self.h)
 

@@ -69,6 +69,9 @@ DPH_API int64_t dph_overlap_step_lines(void* h);
 DPH_API const char* dph_overlap_round_paf(void* h, int64_t* n);
 DPH_API const char* dph_overlap_all_paf(void* h, int64_t* n);
 DPH_API const char* dph_overlap_errtext(void* h, int64_t* n);
+/* multi-rank runs: keep == 0 on a rank that does not print the PAF - gathered rounds are committed with their counts, flags and read
+ * lists, their text is dropped as it arrives (default: kept on every rank) */
+DPH_API void dph_overlap_keep_text(void* h, int keep);
 DPH_API int dph_overlap_done(void* h);
 DPH_API int64_t dph_overlap_round(void* h);                     /* rounds committed so far */
 DPH_API void dph_overlap_set_round_limit(void* h, int64_t n);   /* dph_overlap_step commits no round >= n (-1: no limit) */

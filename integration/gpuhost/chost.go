@@ -187,6 +187,15 @@ func (o *Overlap) ErrText() string {
 }
 
 func (o *Overlap) Done() bool   { return C.dph_overlap_done(o.h) != 0 }
+
+// KeepText(false) on a rank that does not print the PAF: gathered rounds are committed without the other ranks' text.
+func (o *Overlap) KeepText(keep bool) {
+	v := C.int(0)
+	if keep {
+		v = 1
+	}
+	C.dph_overlap_keep_text(o.h, v)
+}
 func (o *Overlap) Rounds() int  { return int(C.dph_overlap_round(o.h)) }
 func (o *Overlap) StepLines() int { return int(C.dph_overlap_step_lines(o.h)) }
 
