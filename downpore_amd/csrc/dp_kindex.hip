@@ -349,7 +349,19 @@ struct kidx_fill_rec {
 template <bool FILL>
 struct kidx_walk {
     enum { THREADS = 256 };
+    // (round 4: a launch may be narrower than its work - `n_waves` wave-sized pieces, walked with the grid's stride: the count
+    // walk's 160 k lanes of dependent random loads and atomics are what slows every other round's kernels)
     static __device__ void run(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
+                               const uint64_t* __restrict__ pos, const dp_scan_item* __restrict__ items, uint32_t lo, uint32_t hi,
+                               uint32_t n_read_items, const uint32_t* __restrict__ head, const uint32_t* __restrict__ next,
+                               uint32_t* __restrict__ counts, uint32_t* __restrict__ fillc, const uint64_t* __restrict__ segoff,
+                               int32_t* __restrict__ segs, unsigned long long* __restrict__ n_hits, uint32_t lps,
+                               unsigned long long* __restrict__ dbg, const KxRec R, uint32_t n_waves) {
+        const uint32_t stride = gridDim.x * (blockDim.x >> 6);
+        for (uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); w < n_waves; w += stride)
+            one(w, seeds, n_seeds, off, pos, items, lo, hi, n_read_items, head, next, counts, fillc, segoff, segs, n_hits, lps, dbg, R);
+    }
+    static __device__ void one(const uint32_t w, const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
                                                  const uint64_t* __restrict__ pos, const dp_scan_item* __restrict__ items,
                                                  uint32_t lo, uint32_t hi, uint32_t n_read_items, const uint32_t* __restrict__ head,
                                                  const uint32_t* __restrict__ next, uint32_t* __restrict__ counts,
@@ -365,7 +377,6 @@ struct kidx_walk {
         const unsigned long long n_ = wall_clock64();                                                   \
         if (lane == 0) dbg[8 * (size_t)w + (i_)] = n_;                                                  \
     }
-    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     KX_TICK(0)
     // lps = lanes per seed.  64: KX_PARTS waves share one seed's bucket (dense seeds: buckets of hundreds to thousands);
     // 16: four seeds per wave (k = 13 at config 2: ~20 occurrences per seed - a whole wave per quarter bucket left 59 lanes idle
@@ -747,6 +758,39 @@ static uint32_t kidx_walk_blocks(const dp_kindex* ix, int k, uint32_t S) {
     return (waves + 3) / 4;
 }
 
+// Diagnosis only (DP_KX_DUMMY=1 / 2): a second kernel behind the count walk that repeats ONE half of its memory behaviour and
+// changes nothing - 1: the dependent random reads (seed -> bucket bounds -> index entries), no atomics; 2: as many scattered
+// returning atomics on a scratch array of the counters' size, no index reads.  How much a whole job slows down with each says
+// which half is what the other rounds' kernels wait for (profiles/r04/ab_walkdummy.txt).
+__global__ void kx_dummy_kernel(int mode, const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
+                                const uint64_t* __restrict__ pos, uint32_t* __restrict__ scratch, uint32_t n_scratch, uint32_t n_ops) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == 1) {
+        const uint32_t s = t >> 4, i0 = t & 15u;
+        if (s >= n_seeds) return;
+        const uint64_t o = off[seeds[s]];
+        const uint32_t n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
+        unsigned long long acc = 0;
+        for (uint32_t i = i0; i < n; i += 16) acc += pos[o + i];
+        if (acc == 0x123456789abcdefull) scratch[0] = 1;  // (never: keeps the loads alive)
+    } else {
+        if (t >= n_ops) return;
+        const uint32_t h = (t * 2654435761u) ^ (t >> 7);
+        const uint32_t old = atomicAdd(&scratch[h % n_scratch], 1u);
+        if (old == 0xffffffffu) scratch[0] = 2;
+    }
+}
+
+// workgroups of the count walk's launch: all of its work at once (default), or DP_KX_WALK_BLOCKS of them striding over it
+static uint32_t kidx_walk_grid(const dp_kindex* ix, int k, uint32_t S) {
+    static const uint32_t lim = [] {
+        const char* e = getenv("DP_KX_WALK_BLOCKS");
+        return e ? (uint32_t)std::max(1, atoi(e)) : 0u;
+    }();
+    const uint32_t all = kidx_walk_blocks(ix, k, S);
+    return lim ? std::min(lim, all) : all;
+}
+
 // Counting step of a round from the index: counts, segment offsets, compacted survivor list and totals for all items, with
 // no host round trip.  d_work = [counts n | fill cursors n | tile status (tiles + 1) u64 | ticket, max count] (zeroed here).
 // `one` (round 4, may be null): the whole index step in one go - the count pass keeps hit records, and behind the offsets scan the
@@ -813,9 +857,22 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         DP_HIP(hipMemsetAsync(dbg, 0, n_dbg_waves * 64, ctx->stream));
     }
     if (S)
-        dp_launch<kidx_walk<false>>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
+        dp_launch<kidx_walk<false>>(ctx, dim3(kidx_walk_grid(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
                            (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
-                           (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k), dbg, R);
+                           (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k), dbg, R,
+                           kidx_walk_blocks(ix, k, S) * 4);
+    {
+        static const int dummy = getenv("DP_KX_DUMMY") ? atoi(getenv("DP_KX_DUMMY")) : 0;
+        if (dummy && S) {
+            if (dev_reserve(ctx, ctx->d_kx_vals, std::max<size_t>((size_t)n_extra * 4 + 64, 0)) ) return DP_ERR_HIP;
+            static void* scratch = nullptr;  // (diagnosis only: one scratch array per process)
+            if (!scratch) DP_HIP(dp_dev_malloc(&scratch, (size_t)n_items * 4 + 64));
+            const uint32_t ops = (uint32_t)std::min<uint64_t>(ctx->kx_prev_hits ? ctx->kx_prev_hits : 450000, 1u << 24);
+            const uint32_t thr = dummy == 1 ? S * 16 : ops;
+            hipLaunchKernelGGL(kx_dummy_kernel, dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, dummy, dp_seeds_ptr(ctx), S,
+                               (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, (uint32_t*)scratch, n_items, ops);
+        }
+    }
     if (kx_debug) {
         std::vector<unsigned long long> h(n_dbg_waves * 8);
         hipStreamSynchronize(ctx->stream);
@@ -908,7 +965,7 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             dp_launch<kidx_walk<true>>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
                                (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
                                (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr, kidx_lps(ix, k),
-                               (unsigned long long*)nullptr, KxRec{nullptr, nullptr, nullptr, 0u});
+                               (unsigned long long*)nullptr, KxRec{nullptr, nullptr, nullptr, 0u}, kidx_walk_blocks(ix, k, S) * 4);
         const dim3 sg(std::min<uint32_t>(n_sel, 16384)), sb(64);
         uint32_t* ovf = (uint32_t*)(d_totals + 4);
         const uint32_t* nsp = (const uint32_t*)(d_totals + 1);
