@@ -44,6 +44,87 @@ struct index_fill_kernel {
 }
 };
 
+// ---- round 4: the two bit matrices without atomics (sparse regime) ----------------------------------------------------------
+// A scattered device-scope atomic costs a five-slot job what it costs alone and index_fill_kernel issued two per
+// indexed seed - 400 k per config-2 round - into matrices that 15 MB of stores had just cleared.  A chunk's seed-set row belongs
+// to ONE wave: it is built in LDS (ds_or) and stored whole - rows need no clearing, rows beyond the chunk count are never read.
+// The posting matrix is the bit transpose of the seed sets: posting[s][w] bit b = seedsets[64 w + b][s / 64] bit (s % 64).
+#define IFR_SW_MAX 256  // seed-set words per row this path holds in LDS (16 384 seeds; the dense regime keeps the atomics)
+struct index_fill_rows_kernel {
+    enum { THREADS = 256 };
+    static __device__ void run(const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, u64* __restrict__ seedsets,
+                               uint32_t SW, const uint32_t* __restrict__ n_seqs_dev) {
+        __shared__ u64 rows[4][IFR_SW_MAX];
+        u64* row = rows[threadIdx.x >> 6];
+        const uint32_t n_seqs = *n_seqs_dev;
+        const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+        const uint32_t gw = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const int lane = dp_lane();
+        for (uint32_t idx = gw; idx < n_seqs; idx += waves) {
+            for (uint32_t x = lane; x < SW; x += 64) row[x] = 0ull;
+            __builtin_amdgcn_wave_barrier();
+            const dp_seq_ref r = refs[idx];
+            for (uint32_t i = lane; i < r.n_seeds; i += 64) {
+                const uint32_t seed = (uint32_t)segs[r.seg_off + 2 * (uint64_t)i + 1];
+                atomicOr(&row[seed >> 6], 1ull << (seed & 63));
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t x = lane; x < SW; x += 64) seedsets[(uint64_t)idx * SW + x] = row[x];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+};
+// one wave per (eight words of posting rows, one word of seed-set rows): eight 64 x 64 bit transposes across the lanes; lane j ends up
+// with the eight words of seed 64 sw + j - one 64-byte store
+struct posting_transpose_kernel {
+    enum { THREADS = 256 };
+    static __device__ void run(const u64* __restrict__ seedsets, u64* __restrict__ posting, uint32_t n_seeds, uint32_t W, uint32_t SW,
+                               const uint32_t* __restrict__ n_seqs_dev) {
+        const uint32_t n_seqs = *n_seqs_dev;
+        const uint32_t wchunks = (W + 7) / 8;
+        const uint32_t tasks = wchunks * SW;
+        const uint32_t waves = gridDim.x * (blockDim.x >> 6);
+        const int lane = dp_lane();
+        for (uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < tasks; t += waves) {
+            const uint32_t sw = t % SW, w0 = (t / SW) * 8;
+            u64 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint64_t rowi = (uint64_t)(w0 + u) * 64 + (uint32_t)lane;
+                x[u] = (w0 + u < W && rowi < n_seqs) ? seedsets[rowi * SW + sw] : 0ull;
+            }
+            // 64 x 64 bit transpose across the lanes (row r of the block in lane r): six exchange stages instead of 64 ballots
+            u64 out[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                u64 v = x[u];
+                if (__ballot(v != 0) != 0) {  // (else: sixty-four chunks none of which holds any of these sixty-four seeds)
+#define PT_STAGE(j_, m_)                                                              \
+    {                                                                                 \
+        const u64 y_ = (u64)__shfl_xor((unsigned long long)v, (j_), 64);              \
+        if ((lane & (j_)) == 0) v ^= ((((v >> (j_)) ^ y_) & (m_)) << (j_));           \
+        else v ^= (((y_ >> (j_)) ^ v) & (m_));                                        \
+    }
+                    PT_STAGE(32, 0x00000000FFFFFFFFull)
+                    PT_STAGE(16, 0x0000FFFF0000FFFFull)
+                    PT_STAGE(8, 0x00FF00FF00FF00FFull)
+                    PT_STAGE(4, 0x0F0F0F0F0F0F0F0Full)
+                    PT_STAGE(2, 0x3333333333333333ull)
+                    PT_STAGE(1, 0x5555555555555555ull)
+#undef PT_STAGE
+                }
+                out[u] = v;
+            }
+            const uint32_t seed = sw * 64 + (uint32_t)lane;
+            if (seed < n_seeds) {
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (w0 + u < W) posting[(uint64_t)seed * W + w0 + u] = out[u];
+            }
+        }
+    }
+};
+
 struct posting_meta_kernel {
     enum { THREADS = 256 };
     static __device__ void run(const u64* __restrict__ posting, uint32_t n_seeds, uint32_t W, uint32_t* __restrict__ pmeta) {
@@ -382,6 +463,13 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
     if (dev_reserve(ctx, ctx->d_seedsets, (size_t)cap * SW * 8 + 64)) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_pmeta, (size_t)S * 16 + 16)) return DP_ERR_HIP;
     const size_t zb_post = ((size_t)S * W * 8 + 64 + 15) & ~(size_t)15, zb_sets = ((size_t)cap * SW * 8 + 64 + 15) & ~(size_t)15;
+    // DP_INDEX_FILL_ROWS=1: the matrices without atomics and without clearing (index_fill_rows_kernel + posting_transpose_kernel)
+    // where a seed-set row fits the wave's LDS buffer.  Built, bit-identical (tests run both) and OFF by default: alone the three
+    // launches take 8.2 + 5.8 + 14.2 us against 10.3 + 12.8 for chunk + fill with atomics (the transpose reads every row word
+    // uncoalesced), and six alternating whole-job runs on one box gave 0.159 ms per round with the atomics against 0.161 without
+    // (profiles/r04/ab_rows3.txt) - the 400 k atomics it removes cost less than the transpose it adds.
+    const char* ife = getenv("DP_INDEX_FILL_ROWS");  // (read per call: tests switch it between jobs of one process)
+    const bool rows_mode = SW <= IFR_SW_MAX && S > 0 && ife && ife[0] == '1';
     if (!n_survivors) {  // (no chunk_kernel launch to clear the matrices and to write the chunk count)
         const dp_zero_region z[3] = {{ctx->d_posting.p, zb_post}, {ctx->d_seedsets.p, zb_sets}, {ctx->d_nseqs.p, 8}};
         if (int rc = dp_zero_regions(ctx, z, 3)) return rc;
@@ -405,10 +493,10 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
         P.cap = cap;
         P.n_out = (uint32_t*)ctx->d_nseqs.p;
         P.z_p[0] = (uint4*)ctx->d_posting.p;
-        P.z_n16[0] = zb_post / 16;
+        P.z_n16[0] = rows_mode ? 0 : zb_post / 16;
         P.z_p[1] = (uint4*)ctx->d_seedsets.p;
-        P.z_n16[1] = zb_sets / 16;
-        P.zero_blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>(512, (std::max(zb_post, zb_sets) / 16 + 4095) / 4096));
+        P.z_n16[1] = rows_mode ? 0 : zb_sets / 16;
+        P.zero_blocks = rows_mode ? 8u : (uint32_t)std::max<size_t>(1, std::min<size_t>(512, (std::max(zb_post, zb_sets) / 16 + 4095) / 4096));
         P.f_dst = nullptr;
         P.f_src = nullptr;
         P.f_n16 = 0;
@@ -427,12 +515,22 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
         dp_launch<chunk_kernel>(ctx, dim3(n_tiles + P.zero_blocks), dim3(1024), P, (unsigned long long*)((uint8_t*)ctx->d_nseqs.p + 64),
                            (uint32_t*)ctx->d_nseqs.p + 2);
         DP_HIP(hipGetLastError());
-        if (cap) {
+        if (cap && rows_mode) {
+            const uint32_t blocks = std::min<uint32_t>(2048, (cap + 3) / 4);
+            dp_launch<index_fill_rows_kernel>(ctx, dim3(blocks), dim3(256), (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p,
+                                              (u64*)ctx->d_seedsets.p, SW, (const uint32_t*)ctx->d_nseqs.p);
+            const uint32_t tasks = ((W + 7) / 8) * SW;
+            dp_launch<posting_transpose_kernel>(ctx, dim3(std::min<uint32_t>(4096, (tasks + 3) / 4)), dim3(256), (const u64*)ctx->d_seedsets.p,
+                                                (u64*)ctx->d_posting.p, S, W, SW, (const uint32_t*)ctx->d_nseqs.p);
+            DP_HIP(hipGetLastError());
+        } else if (cap) {
             const uint32_t blocks = std::min<uint32_t>(2048, (cap + 3) / 4);
             dp_launch<index_fill_kernel>(ctx, dim3(blocks), dim3(256), (const dp_seq_ref*)ctx->d_seqrefs.p, cap,
                                (const int32_t*)ctx->d_segs.p, (u64*)ctx->d_posting.p, (u64*)ctx->d_seedsets.p, W, SW, (const uint32_t*)ctx->d_nseqs.p);
             DP_HIP(hipGetLastError());
         }
+    } else if (rows_mode && S) {
+        // (cap == 0 cannot happen with survivors; no survivors: the matrices were cleared above)
     }
     if (S) {
         const uint32_t blocks = std::min<uint32_t>(2048, (S + 3) / 4);
