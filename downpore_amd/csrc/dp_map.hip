@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cstring>
 
+#include <rocprim/device/device_scan.hpp>
+
 #include "dp_common.h"
 
 typedef uint64_t u64;
@@ -488,6 +490,149 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
             thr_io[2 * pair + 1] = thr[1];
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// A18, the parallel part of AddSingleSeeds (seeds/seeds.go:160-200).  The reference walks the mapping reference in windows of
+// seed_rate bases: a window in which no k-mer is a seed yet gets its best-valued k-mer as a new seed.  "Is a seed yet" makes the
+// walk sequential - but only k-mers that are the BEST of some window can ever be seeds, so everything else about a window can be
+// computed for all windows at once: its best k-mer, and the k-mers of its count region that are the best of ANY window (its
+// candidates: five or six of ~seed_rate).  The host then walks the windows in order and probes only the candidates against the
+// seeds added so far (host_map.cpp): 3.9 s of one host thread per 375 Mb of reference -> a few kernels + 15 M probes.
+// The count region is CountKmersBetween's (sequence.go:332-337 + asm:81-203: whole bytes, the parent's skipBack, the do-while group
+// loop - the arithmetic of the host mirror and the oracle), bases beyond the sequence read as zero.
+struct SsGeom {
+    long long len, seed_rate;
+    int k, skip_back;
+    uint32_t n_windows;
+};
+__device__ __forceinline__ uint32_t ss_code(const uint8_t* __restrict__ p, long long pos, long long len) {
+    return pos < len ? (uint32_t)((p[pos >> 2] >> (6 - 2 * (int)(pos & 3))) & 3u) : 0u;
+}
+__device__ __forceinline__ void ss_region(const SsGeom& G, long long i, long long* p0, long long* P) {
+    const long long startB = (i + 3) / 4, endB = (i + G.seed_rate) / 4;
+    const long long nb = endB - startB;
+    const long long nk = 4 * (nb - 1) - G.skip_back - G.k + 1;
+    long long groups = (nk & ~(long long)3) / 4;
+    if (groups < 1) groups = 1;
+    *p0 = startB * 4;
+    *P = 4 + 4 * groups + (nk & 3);
+}
+// best k-mer of every window (first maximum of the value table over the k-mers that start at i .. i + seed_rate - k) + its bit in `bits`
+__global__ void ss_best_kernel(const uint8_t* __restrict__ packed, SsGeom G, const double* __restrict__ values, uint32_t* __restrict__ best,
+                               uint32_t* __restrict__ bits) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= G.n_windows) return;
+    const long long i = (long long)w * G.seed_rate, end = i + G.seed_rate;
+    const uint32_t mask = (uint32_t)(((unsigned long long)1 << (2 * G.k)) - 1);
+    uint32_t km = 0;
+    for (int j = 0; j < G.k; j++) km = (km << 2) | ss_code(packed, i + j, G.len);
+    double bv = values[km];
+    uint32_t bk = km;
+    for (long long j = i + G.k; j < end; j++) {
+        km = ((km << 2) | ss_code(packed, j, G.len)) & mask;
+        const double v = values[km];
+        if (v > bv) {
+            bv = v;
+            bk = km;
+        }
+    }
+    best[w] = bk;
+    atomicOr(&bits[bk >> 5], 1u << (bk & 31));
+}
+// pass 0: how many k-mers of the window's count region are somebody's best; pass 1: write them at off[w]
+template <bool WRITE>
+__global__ void ss_cand_kernel(const uint8_t* __restrict__ packed, SsGeom G, const uint32_t* __restrict__ bits, uint32_t* __restrict__ cnt,
+                               const uint32_t* __restrict__ off, uint32_t* __restrict__ cand) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= G.n_windows) return;
+    long long p0, P;
+    ss_region(G, (long long)w * G.seed_rate, &p0, &P);
+    const uint32_t mask = (uint32_t)(((unsigned long long)1 << (2 * G.k)) - 1);
+    uint32_t km = 0, n = 0;
+    const uint32_t at = WRITE ? off[w] : 0u;
+    for (int j = 0; j < G.k; j++) km = (km << 2) | ss_code(packed, p0 + j, G.len);
+    for (long long j = 0; j < P; j++) {
+        if (j) km = ((km << 2) | ss_code(packed, p0 + j + G.k - 1, G.len)) & mask;
+        if ((bits[km >> 5] >> (km & 31)) & 1u) {
+            if (WRITE) cand[at + n] = km;
+            n++;
+        }
+    }
+    if (!WRITE) cnt[w] = n;
+}
+
+extern "C" int dp_single_seed_candidates(dp_ctx* ctx, uint32_t read, int k, int64_t seed_rate, dp_single_seed_batch* out) {
+    if (!ctx || !out || k < 4 || k > 15 || seed_rate < 1) return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_single_seed_candidates: bad arguments") : DP_ERR_ARG;
+    if (read >= ctx->n_reads) return dp_fail(ctx, DP_ERR_ARG, "dp_single_seed_candidates: read index out of range");
+    const dp_ctx* src = ctx->owner ? ctx->owner : ctx;
+    const size_t nk = (size_t)1 << (2 * k);
+    if (!src->d_values.p || src->n_values != nk) return dp_fail(ctx, DP_ERR_STATE, "dp_single_seed_candidates: no value table of this k resident");
+    hipSetDevice(ctx->device);
+    memset(out, 0, sizeof(*out));
+    SsGeom G;
+    G.len = (long long)src->h_len[read];
+    G.seed_rate = seed_rate;
+    G.k = k;
+    G.skip_back = 4 - (int)(G.len % 4);  // top-level sequence: finalLen = len % 4 (0 when len % 4 == 0: sequence.go:70,88)
+    // windows: for (i = 0; i < len - seed_rate; i += seed_rate)
+    const long long span = G.len - seed_rate;
+    G.n_windows = span > 0 ? (uint32_t)((span + seed_rate - 1) / seed_rate) : 0u;
+    out->n_windows = G.n_windows;
+    if (!G.n_windows) return DP_OK;
+    const uint8_t* packed = (const uint8_t*)src->d_packed.p + src->h_boff[read];
+    void *d_bits = nullptr, *d_best = nullptr, *d_cnt = nullptr, *d_off = nullptr, *d_cand = nullptr, *d_tmp = nullptr;
+    auto cleanup = [&] {
+        for (void* p : {d_bits, d_best, d_cnt, d_off, d_cand, d_tmp})
+            if (p) dp_dev_free(p);
+    };
+#define DSS(x)                                                                        \
+    do {                                                                              \
+        hipError_t e_ = (x);                                                          \
+        if (e_ != hipSuccess) {                                                       \
+            cleanup();                                                                \
+            return dp_fail(ctx, DP_ERR_HIP, "dp_single_seed_candidates: " #x, e_);    \
+        }                                                                             \
+    } while (0)
+    const uint32_t nw = G.n_windows, blocks = (nw + 255) / 256;
+    DSS(dp_dev_malloc(&d_bits, nk / 8 + 64));
+    DSS(dp_dev_malloc(&d_best, (size_t)nw * 4));
+    DSS(dp_dev_malloc(&d_cnt, ((size_t)nw + 1) * 4));
+    DSS(dp_dev_malloc(&d_off, ((size_t)nw + 1) * 4));
+    DSS(hipMemsetAsync(d_bits, 0, nk / 8 + 64, ctx->stream));
+    DSS(hipMemsetAsync(d_cnt, 0, ((size_t)nw + 1) * 4, ctx->stream));
+    hipLaunchKernelGGL(ss_best_kernel, dim3(blocks), dim3(256), 0, ctx->stream, packed, G, (const double*)src->d_values.p, (uint32_t*)d_best,
+                       (uint32_t*)d_bits);
+    hipLaunchKernelGGL(ss_cand_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, packed, G, (const uint32_t*)d_bits, (uint32_t*)d_cnt,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    DSS(hipGetLastError());
+    size_t tb = 0;
+    DSS(rocprim::exclusive_scan(nullptr, tb, (const uint32_t*)d_cnt, (uint32_t*)d_off, 0u, (size_t)nw + 1, rocprim::plus<uint32_t>(), ctx->stream));
+    DSS(dp_dev_malloc(&d_tmp, tb + 64));
+    DSS(rocprim::exclusive_scan(d_tmp, tb, (const uint32_t*)d_cnt, (uint32_t*)d_off, 0u, (size_t)nw + 1, rocprim::plus<uint32_t>(), ctx->stream));
+    uint32_t total = 0;
+    DSS(hipMemcpyAsync(&total, (const uint32_t*)d_off + nw, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DSS(dp_stream_sync(ctx));
+    DSS(dp_dev_malloc(&d_cand, (size_t)total * 4 + 64));
+    hipLaunchKernelGGL(ss_cand_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, packed, G, (const uint32_t*)d_bits, (uint32_t*)nullptr,
+                       (const uint32_t*)d_off, (uint32_t*)d_cand);
+    DSS(hipGetLastError());
+    // results to the host: [best nw | off nw + 1 | cand total] in one pinned block of the context
+    if (pin_reserve(ctx, ctx->h_ta, ((size_t)2 * nw + 1 + total) * 4 + 64)) {
+        cleanup();
+        return DP_ERR_HIP;
+    }
+    uint32_t* h = (uint32_t*)ctx->h_ta.p;
+    DSS(hipMemcpyAsync(h, d_best, (size_t)nw * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DSS(hipMemcpyAsync(h + nw, d_off, ((size_t)nw + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (total) DSS(hipMemcpyAsync(h + 2 * (size_t)nw + 1, d_cand, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DSS(dp_stream_sync(ctx));
+#undef DSS
+    cleanup();
+    out->best = h;
+    out->cand_off = h + nw;
+    out->cand = h + 2 * (size_t)nw + 1;
+    return DP_OK;
 }
 
 int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t nw, int k,

@@ -573,7 +573,32 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // ---- AddSingleSeeds seeds/seeds.go:160-200 on the (top-level) reference, host, sequential - on a thread of its own while
     // this one concatenates the reads and the device uploads and packs them (neither needs the seeds)
     SeedIndex index(k);
+    // Round 4: everything about a window that does not depend on the seeds added before it - its best k-mer, and which k-mers of
+    // its count region are the best of ANY window (only those can ever be seeds) - comes from the device for all windows at once
+    // (dp_single_seed_candidates: the reference and the value table are resident right now); the thread below then walks the
+    // windows in order and probes five or six candidates per window instead of seed_rate k-mers (3.9 s -> 0.1 s per 375 Mb of
+    // reference).  DP_MAP_SEEDS_HOST=1: the whole walk on the host as before.
+    dp_single_seed_batch ssb;
+    memset(&ssb, 0, sizeof ssb);
+    bool deviceSeeds = false;
+    {
+        const char* e = getenv("DP_MAP_SEEDS_HOST");
+        if (!(e && e[0] == '1') && refLen < ((i64)1 << 32)) {
+            rc = dp_single_seed_candidates(ctx, 0, k, p.seedRate, &ssb);
+            if (rc) return fail(rc);
+            deviceSeeds = true;
+            mark("single-seed candidates (device)");
+        }
+    }
     std::thread seedThread([&] {
+        if (deviceSeeds) {
+            for (uint32_t w = 0; w < ssb.n_windows; w++) {
+                bool any = false;
+                for (uint32_t c = ssb.cand_off[w]; c < ssb.cand_off[w + 1] && !any; c++) any = index.isSeed(ssb.cand[c]);
+                if (!any) index.addSeedKmer(ssb.best[w]);
+            }
+            return;
+        }
         const uint32_t mask = (uint32_t)(((uint64_t)1 << (2 * k)) - 1);
         const int finalLen = (int)(refLen % 4);  // top-level sequence: 0 when len%4 == 0 (sequence.go:70,88)
         const i64 skipBack = 4 - finalLen;

@@ -307,6 +307,21 @@ DP_API int dp_index_meta(dp_ctx* ctx, uint32_t* meta_out, uint32_t n_seeds);
 DP_API int dp_index_set_global(dp_ctx* ctx, const uint32_t* meta_global, uint32_t n_seeds, uint32_t word_base, uint32_t n_seqs_global);
 DP_API int dp_map_windows_shard(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t n_windows,
                          int k, int phase, int32_t* thr_io, dp_chain_batch* out);
+/* The parallel part of SeedIndex.AddSingleSeeds (seeds/seeds.go:160-200; NewMapper calls it on the mapping reference,
+ * mapping/mapping.go:67-109) for resident read `read` (a top-level sequence) and the resident value table of this k: for every
+ * window of seed_rate bases - for (i = 0; i < len - seed_rate; i += seed_rate) - its best-valued k-mer (what the reference adds as a
+ * seed when no k-mer of the window's count region is a seed yet) and the k-mers of its count region that are the best of ANY window
+ * (only those can ever be seeds).  The caller walks the windows in order: a window none of whose candidates is a seed so far adds its
+ * best k-mer - the sequential rule, with five or six probes per window instead of seed_rate.  The arrays are the library's (pinned,
+ * valid until the context's next call that fetches match lists). */
+typedef struct {
+    uint32_t n_windows;
+    const uint32_t* best;      /* [n_windows] */
+    const uint32_t* cand_off;  /* [n_windows + 1] offsets into cand */
+    const uint32_t* cand;      /* candidate k-mers of every window's count region */
+} dp_single_seed_batch;
+DP_API int dp_single_seed_candidates(dp_ctx* ctx, uint32_t read, int k, int64_t seed_rate, dp_single_seed_batch* out);
+
 
 /* ---- A16 (part): seed-space multiple alignment of multiAligner.Consensus (seeds/alignment.go:52-247) ------------
  * For each of `n_groups` groups (one per query window) the caller passes the Reduced() seed sequences of the trimmed

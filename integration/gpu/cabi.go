@@ -544,6 +544,24 @@ func (c *Context) ValueCodes8(k int) (codes []uint8, total uint64, overflow bool
 	return codes, uint64(tot), ovf != 0, nil
 }
 
+// SingleSeedCandidates is the parallel part of SeedIndex.AddSingleSeeds (seeds/seeds.go:160-200) for resident read `read`: per window
+// of seedRate bases its best-valued k-mer and the k-mers of its count region that are the best of any window.  The caller walks the
+// windows in order: a window none of whose candidates is a seed yet adds its best k-mer (dp_single_seed_candidates).
+func (c *Context) SingleSeedCandidates(read uint32, k int, seedRate int64) (best []uint32, candOff []uint32, cand []uint32, err error) {
+	var b C.dp_single_seed_batch
+	if rc := C.dp_single_seed_candidates(c.h, C.uint32_t(read), C.int(k), C.int64_t(seedRate), &b); rc != 0 {
+		return nil, nil, nil, fail(c.h, "dp_single_seed_candidates", rc)
+	}
+	n := int(b.n_windows)
+	if n == 0 {
+		return nil, []uint32{0}, nil, nil
+	}
+	best = append([]uint32(nil), unsafe.Slice((*uint32)(unsafe.Pointer(b.best)), n)...)
+	candOff = append([]uint32(nil), unsafe.Slice((*uint32)(unsafe.Pointer(b.cand_off)), n+1)...)
+	cand = append([]uint32(nil), unsafe.Slice((*uint32)(unsafe.Pointer(b.cand)), int(candOff[n]))...)
+	return best, candOff, cand, nil
+}
+
 // SelectWindows is the selection half of AddSeeds (seeds/seeds.go:62-129) for many query windows at once, assuming no
 // evaluated k-mer is a seed yet: top[w*numSeeds:] = the window's list (untouched slots hold k-mer 0), evaluated[w*stride:] =
 // every k-mer the walk evaluated (0xffffffff = unused): what the caller probes against its committed seeds to learn whether

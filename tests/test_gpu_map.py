@@ -56,6 +56,17 @@ def test_map_paf_bit_exact(seed, G, N, L, e, variable, circular):
     assert st["n_windows"] >= N
 
 
+def test_map_single_seeds_host_walk_agrees(monkeypatch):
+    """AddSingleSeeds: the windows' best k-mers and their count regions' candidates come from the device, the host walks the windows in
+    order and probes the candidates (round 4); DP_MAP_SEEDS_HOST=1 does the whole walk on the host as before.  Same PAF as the oracle
+    either way - linear and circular references, lengths with every len % 4 (the count region's skipBack)."""
+    for G in (200001, 200002, 200003, 200004):
+        _case(3, G, 60, 6000, 0.02, True, G % 2 == 0)
+    monkeypatch.setenv("DP_MAP_SEEDS_HOST", "1")
+    _case(3, 200002, 60, 6000, 0.02, True, True)
+    monkeypatch.delenv("DP_MAP_SEEDS_HOST")
+
+
 def test_map_dynamic_match_on_one_lane_agrees(monkeypatch):
     """dynamicMatch probes the target's seeds with 64 lanes at once (round 4); DP_MAP_ONE_LANE=1 runs the reference's loop nest on
     one lane as before.  Both must print the oracle's PAF - reads with errors, so that chains break, ratchets move and several
