@@ -56,6 +56,7 @@ struct dp_ctx {
     uint32_t pc_min_seeds = 0, pc_cap = 0, pc_tiles = 0, pc_prev_cap = 0, pc_prev_ns = 0;
     int32_t pc_inset = 0;
     uint64_t pc_hits = 0, pc_misses = 0;
+    std::vector<uint32_t> ss_host;  // dp_single_seed_candidates' result (ordinary host memory: read by a sequential host walk)
     uint32_t last_n_extra = 0;    // extra items of the last dp_scan_reads
     uint32_t kx_seq = 0;          // sequence number the sort pass of a one-go index step stores into h_total[15] when its output is complete
     uint32_t kx_maxlen = 0;       // longest read (hit records hold 24 bits of position)

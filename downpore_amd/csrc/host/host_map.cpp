@@ -501,6 +501,32 @@ std::string MapperImpl::asString(const Mapping& m, const std::string& qname, i64
 // ---------------------------------------------------------------------------------------------------------------
 // commands/map.go:33-116 + NewMapper mapping.go:67-109
 
+// the staging block [reference | join chunk | all reads] of the last map command of this process, kept for the next one
+namespace {
+std::mutex g_stagingMu;
+std::unique_ptr<char[]> g_staging;
+size_t g_stagingCap = 0;
+std::unique_ptr<char[]> stagingTake(size_t need, size_t* cap) {
+    {
+        std::lock_guard<std::mutex> lk(g_stagingMu);
+        if (g_staging && g_stagingCap >= need) {
+            *cap = g_stagingCap;
+            g_stagingCap = 0;
+            return std::move(g_staging);
+        }
+    }
+    *cap = need;
+    return std::unique_ptr<char[]>(new char[need]);
+}
+void stagingPut(std::unique_ptr<char[]> p, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_stagingMu);
+    if (cap > g_stagingCap) {  // (the smaller of two blocks goes: its munmap is the caller's 40 ms, once)
+        g_staging = std::move(p);
+        g_stagingCap = cap;
+    }
+}
+}  // namespace
+
 int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int device, std::string& paf, std::string& errText,
            MapStats* stats, std::string& error) {
     const double tRun0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -528,7 +554,8 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // (and its pages first touched) by the worker pool in 4 MiB pieces
     const size_t head = (size_t)refLen + join.size();
     const size_t readBytes = reads.size() ? (size_t)(reads.off[reads.size()] - reads.off[0]) : 0;
-    std::unique_ptr<char[]> staging(new char[head + readBytes + 1]);
+    size_t stagingCap = 0;
+    std::unique_ptr<char[]> staging = stagingTake(head + readBytes + 1, &stagingCap);
     std::thread concatThread([&] {
         memcpy(staging.get(), ref, (size_t)refLen);
         memcpy(staging.get() + refLen, join.data(), join.size());
@@ -592,11 +619,16 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     }
     std::thread seedThread([&] {
         if (deviceSeeds) {
+            const double ts0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
             for (uint32_t w = 0; w < ssb.n_windows; w++) {
                 bool any = false;
                 for (uint32_t c = ssb.cand_off[w]; c < ssb.cand_off[w + 1] && !any; c++) any = index.isSeed(ssb.cand[c]);
                 if (!any) index.addSeedKmer(ssb.best[w]);
             }
+            if (prof)
+                fprintf(stderr, "[map setup] single-seed walk: %u windows, %u candidates, %zu seeds, %.1f ms on its thread\n", ssb.n_windows,
+                        ssb.cand_off[ssb.n_windows], index.seedMap.size(),
+                        1e3 * (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - ts0));
             return;
         }
         const uint32_t mask = (uint32_t)(((uint64_t)1 << (2 * k)) - 1);
@@ -659,7 +691,10 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     rc = dp_reads_upload_rc(ctx, (const uint8_t*)staging.get(), off.data(), (uint32_t)(off.size() - 1), 2);
     if (rc) return fail(rc);
     mark("upload + pack (both strands)");
-    staging.reset();
+    // (giving 400 MB of staging back to the system is 40 ms of munmap - round 3's profile had booked it as "AddSingleSeeds (waited
+    // for)" - and on a thread of its own it holds the address-space lock against this one's allocations just as long: the block is
+    // kept for the process's next map command instead, which then also finds its pages touched)
+    stagingPut(std::move(staging), stagingCap);
     seedThread.join();
     mark("AddSingleSeeds (waited for)");
     rc = dp_round_begin(ctx, k, index.seedMap.data(), (uint32_t)index.seedMap.size());

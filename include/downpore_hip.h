@@ -312,8 +312,8 @@ DP_API int dp_map_windows_shard(dp_ctx* ctx, const int32_t* w_segs, const uint64
  * window of seed_rate bases - for (i = 0; i < len - seed_rate; i += seed_rate) - its best-valued k-mer (what the reference adds as a
  * seed when no k-mer of the window's count region is a seed yet) and the k-mers of its count region that are the best of ANY window
  * (only those can ever be seeds).  The caller walks the windows in order: a window none of whose candidates is a seed so far adds its
- * best k-mer - the sequential rule, with five or six probes per window instead of seed_rate.  The arrays are the library's (pinned,
- * valid until the context's next call that fetches match lists). */
+ * best k-mer - the sequential rule, with five or six probes per window instead of seed_rate.  The arrays are the library's (ordinary
+ * host memory, valid until the context's next dp_single_seed_candidates or its destruction). */
 typedef struct {
     uint32_t n_windows;
     const uint32_t* best;      /* [n_windows] */
