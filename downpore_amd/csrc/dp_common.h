@@ -123,6 +123,7 @@ struct dp_ctx {
     // dp_stream_sync
     std::vector<uint8_t> stage_buf;
     size_t stage_used = 0;
+    uint32_t cons_large_rounds = 0;          // rounds for which the large consensus layout is still launched at once (a recent round listed a window for it)
     bool cons_huge = false;                  // a window of an earlier round did not fit the large consensus layout: the huge one follows it from now on
     uint32_t cons_prev_pairs = 0;            // pairs of the previous round's chaining stage (output bound of a pending one)
     struct FindState* find_state = nullptr;  // dp_overlap.hip: the chaining stage between launch and evaluation

@@ -446,7 +446,11 @@ struct consensus_full_kernel {
 #define CF_NOFIT(why_)                                                               \
     {                                                                                \
         if (A.out_list) {                                                            \
-            if (lane == 0) A.out_list[atomicAdd(A.out_count, 1u)] = g;               \
+            gm.flag = 3; /* listed for the next layout (which overwrites this record) */ \
+            if (lane == 0) {                                                         \
+                A.out_list[atomicAdd(A.out_count, 1u)] = g;                          \
+                A.gmeta[g] = gm;                                                     \
+            }                                                                        \
         } else {                                                                     \
             gm.flag = 1;                                                             \
             gm.reserved = (why_); /* (diagnosis: DP_CONS_WHY=1 prints a histogram) */ \
@@ -1252,6 +1256,9 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     h_nseq[1] = 0;
     A.nseq_src = ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : nullptr;
     A.nseq_dst = h_nseq;
+    bool lazy_large = false;
+    const char* lze = getenv("DP_CONS_LAZY_LARGE");  // (0: the large layout is launched behind the small one in every round, as before)
+    const bool lazy_off = lze && lze[0] == '0';
     DP_HIP(dp_mark(ctx, 0));
     {
         // small -> large -> huge: each layout works through what its predecessor listed and lists what it cannot hold for its
@@ -1276,17 +1283,41 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
             stage(false);
             dp_launch<consensus_full_kernel<0>>(ctx, dim3(std::min<uint32_t>(ng, 4096)), dim3(64), A);
         }
-        stage(!use_huge);
-        dp_launch<consensus_full_kernel<1>>(ctx, dim3(std::min<uint32_t>(ng, use_small ? 96u : 4096u)), dim3(64), A);
-        if (use_huge) {
-            stage(true);
-            // (144 KB of LDS per wave: one per CU; behind the small + large layouts it mostly finds its list short or empty)
-            dp_launch<consensus_full_kernel<2>>(ctx, dim3(std::min<uint32_t>(ng, use_small ? 64u : 256u)), dim3(64), A);
+        // The large layout behind the small one nearly always finds its list empty (config 2: a window in a few hundred rounds) and
+        // still was a launch of 4 us alone, 12 us under five slots, in every round: it is launched at once only while the context's
+        // recent rounds needed it (cons_large_rounds), otherwise after the wait - if the small layout's records say "listed" (flag 3)
+        lazy_large = use_small && !use_huge && ctx->cons_large_rounds == 0 && !lazy_off;
+        if (!lazy_large) {
+            stage(!use_huge);
+            dp_launch<consensus_full_kernel<1>>(ctx, dim3(std::min<uint32_t>(ng, use_small ? 96u : 4096u)), dim3(64), A);
+            if (use_huge) {
+                stage(true);
+                // (144 KB of LDS per wave: one per CU; behind the small + large layouts it mostly finds its list short or empty)
+                dp_launch<consensus_full_kernel<2>>(ctx, dim3(std::min<uint32_t>(ng, use_small ? 64u : 256u)), dim3(64), A);
+            }
         }
     }
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 1));
     DP_HIP(dp_stream_sync(ctx));
+    if (use_small) {
+        // windows the small layout listed: with the large layout not launched yet, it runs now (and the next rounds launch it at once)
+        const dp_group_meta* gms = (const dp_group_meta*)ctx->h_cout.p;
+        bool listed = false;
+        for (uint32_t g = 0; g < ng && !listed; g++) listed = gms[g].flag == 3;
+        if (listed && lazy_large) {
+            A.in_count = lists;
+            A.in_list = lists + 2;
+            A.copy_nseq = false;
+            A.out_count = nullptr;
+            A.out_list = nullptr;
+            dp_launch<consensus_full_kernel<1>>(ctx, dim3(std::min<uint32_t>(ng, 96u)), dim3(64), A);
+            DP_HIP(hipGetLastError());
+            DP_HIP(dp_stream_sync(ctx));
+        }
+        if (listed) ctx->cons_large_rounds = 64;
+        else if (ctx->cons_large_rounds > 0) ctx->cons_large_rounds--;
+    }
     if (h_nseq[1]) return dp_fail(ctx, DP_ERR_CAPACITY, "dp_index_build_chunked: chunk bound exceeded");
     if (pending) {
         bool reran = false;

@@ -710,15 +710,19 @@ def test_consensus_layouts_agree(monkeypatch, k, G, N, L, variable):
     got = {}
     # (small, huge): huge = "1" puts the 144 KB layout (round 4: the dense regime's windows) behind the large one from the first
     # round on ("0": never; unset: from the round after the first window that did not fit the large one)
-    for small, huge in (("1", "0"), ("0", "0"), ("1", "1"), ("0", "1")):
+    # lazy = "0": the large layout launched behind the small one in every round; default: only after the wait, for a round whose small
+    # layout listed a window (and at once for the 64 rounds after such a round)
+    for small, huge, lazy in (("1", "0", "1"), ("0", "0", "1"), ("1", "1", "1"), ("0", "1", "1"), ("1", "0", "0")):
         monkeypatch.setenv("DP_CONS_SMALL", small)
         monkeypatch.setenv("DP_CONS_HUGE", huge)
+        monkeypatch.setenv("DP_CONS_LAZY_LARGE", lazy)
         pipe = OverlapPipeline(Reads(bases, off, min_len=1000), k=k, slots=3)
         pipe.run(4)
-        got[(small, huge)] = pipe.all_paf()
+        got[(small, huge, lazy)] = pipe.all_paf()
         pipe.close()
-        assert first_diff(got[(small, huge)], want.paf) is None, (small, huge)
+        assert first_diff(got[(small, huge, lazy)], want.paf) is None, (small, huge, lazy)
     monkeypatch.delenv("DP_CONS_HUGE")
+    monkeypatch.delenv("DP_CONS_LAZY_LARGE")
 
 
 @pytest.mark.parametrize("k,G,N,L,variable,err", [(10, 250000, 1000, 5000, False, 0.0), (13, 3000000, 6000, 10000, False, 0.0),
