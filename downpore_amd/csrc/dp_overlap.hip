@@ -49,7 +49,7 @@ struct index_fill_kernel {
 // indexed seed - 400 k per config-2 round - into matrices that 15 MB of stores had just cleared.  A chunk's seed-set row belongs
 // to ONE wave: it is built in LDS (ds_or) and stored whole - rows need no clearing, rows beyond the chunk count are never read.
 // The posting matrix is the bit transpose of the seed sets: posting[s][w] bit b = seedsets[64 w + b][s / 64] bit (s % 64).
-#define IFR_SW_MAX 256  // seed-set words per row this path holds in LDS (16 384 seeds; the dense regime keeps the atomics)
+#define IFR_SW_MAX 512  // seed-set words per row this path holds in LDS (32 768 seeds)
 struct index_fill_rows_kernel {
     enum { THREADS = 256 };
     static __device__ void run(const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, u64* __restrict__ seedsets,
@@ -464,12 +464,15 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
     if (dev_reserve(ctx, ctx->d_pmeta, (size_t)S * 16 + 16)) return DP_ERR_HIP;
     const size_t zb_post = ((size_t)S * W * 8 + 64 + 15) & ~(size_t)15, zb_sets = ((size_t)cap * SW * 8 + 64 + 15) & ~(size_t)15;
     // DP_INDEX_FILL_ROWS=1: the matrices without atomics and without clearing (index_fill_rows_kernel + posting_transpose_kernel)
-    // where a seed-set row fits the wave's LDS buffer.  Built, bit-identical (tests run both) and OFF by default: alone the three
+    // where a seed-set row fits the wave's LDS buffer.  Built, bit-identical (tests run both) and OFF in the sparse regime: alone the three
     // launches take 8.2 + 5.8 + 14.2 us against 10.3 + 12.8 for chunk + fill with atomics (the transpose reads every row word
     // uncoalesced), and six alternating whole-job runs on one box gave 0.159 ms per round with the atomics against 0.161 without
     // (profiles/r04/ab_rows3.txt) - the 400 k atomics it removes cost less than the transpose it adds.
-    const char* ife = getenv("DP_INDEX_FILL_ROWS");  // (read per call: tests switch it between jobs of one process)
-    const bool rows_mode = SW <= IFR_SW_MAX && S > 0 && ife && ife[0] == '1';
+    // Where the matrices are large it wins: at k = 10 (100 k chunks x 20 k seeds: 250 MB each, 20 M atomics) a round's index build
+    // and query stage take 1.22 ms instead of 1.67 (profiles/r04/dense_rows.txt) - the default from 4 M seed-set words (32 MB) up.
+    const char* ife = getenv("DP_INDEX_FILL_ROWS");  // (read per call: tests switch it between jobs of one process; 0 / 1 force)
+    const bool rows_fit = SW <= IFR_SW_MAX && S > 0;
+    const bool rows_mode = rows_fit && (ife ? ife[0] == '1' : (uint64_t)cap * SW >= ((uint64_t)4 << 20));
     if (!n_survivors) {  // (no chunk_kernel launch to clear the matrices and to write the chunk count)
         const dp_zero_region z[3] = {{ctx->d_posting.p, zb_post}, {ctx->d_seedsets.p, zb_sets}, {ctx->d_nseqs.p, 8}};
         if (int rc = dp_zero_regions(ctx, z, 3)) return rc;
