@@ -328,6 +328,10 @@ def main():
                              "chain kernels (A6 prefilter + A7 chaining + A8 ratchet of every (query, candidate) pair)"),
             "query_kernel": (per_round("k_query_ms"), per_round("query_bytes"), "query_traffic.json",
                              "query_kernel (A14 + A5: soft union of the posting bitsets)"),
+            # (round 4: the consensus stage is a candidate like the others - its algorithmic bytes are summed by the kernel itself, per
+            # window: records, chains, anchors, trimmed segments, query segments in; PAF records, ignore ids, group record out)
+            "consensus_kernel": (per_round("k_cons_ms"), per_round("cons_bytes"), "consensus_traffic.json",
+                                 "consensus_full_kernel (A15 + A16 + A17 numbers: anchors + seed-space consensus + PAF fields of every query window)"),
         }
         if main_index:
             kern["index_counting_step"] = (per_round("k_count_ms"), per_round("count_bytes"), "kindex_traffic.json",

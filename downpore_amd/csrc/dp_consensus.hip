@@ -514,6 +514,10 @@ struct consensus_full_kernel {
         int nseq = 0, tUsed = 0;
         bool bad = false, laneWide = false;
         uint32_t badWhy = 0;
+        // algorithmic bytes of this window (reported in its group record): per match its record (16), its chain
+        // (two int32 per matched seed), its anchors (8) and its target's view (16); per kept match the chunk's fields (16) and the
+        // trimmed stretch of its segments; the forward query's segments; out: 40 per PAF line, 4 per SetIgnore id, 32 for the record
+        unsigned algB = 0;
         for (int m0 = 0; m0 < nm; m0 += 64) {
             const int mi = m0 + lane;
             bool keep = false, laneBad = false;
@@ -527,6 +531,7 @@ struct consensus_full_kernel {
                 const uint32_t rq = A.recs[4 * (size_t)p], off = A.recs[4 * (size_t)p + 2];
                 t = A.recs[4 * (size_t)p + 1];
                 const int len = (int)A.recs[4 * (size_t)p + 3];
+                algB += 16u + 8u * (unsigned)len + 8u + 16u;
                 isRc = rq == qr;
                 const int32_t* MA = A.ma + off;
                 const int32_t* MB = A.mb + off;
@@ -626,6 +631,7 @@ struct consensus_full_kernel {
                 const int sq = nseq + __popcll(keepMask & lanesBelow);
                 const int tb = tUsed + incl - nT;
                 const dp_seq_meta sm = A.smeta[t];
+                algB += 16u + 4u * (unsigned)nT;
                 const int nB = 2 * ns + 1;
                 int wide = 0;  // (small layout: a value that does not fit 16 bits sends the window to the large one)
                 for (int j0 = 0; j0 < nT; j0 += 8) {  // (eight loads in flight per trip, then - reverse complement - their eight look-ups)
@@ -1159,6 +1165,7 @@ struct consensus_full_kernel {
         if (P1 > A.out_cap) gm.flag = 2;  // output did not fit: the caller repeats the call with the exact size
         gm.n_lines = (uint32_t)(np - 1);
         gm.n_ignore = (uint32_t)__popcll(ignMask);
+        gm.reserved = (uint32_t)wave_sum((int)algB) + 4u * (uint32_t)nA + 40u * gm.n_lines + 4u * gm.n_ignore + 32u;
         gm.bad_back = (uint32_t)__popcll(__ballot(badBack != 0));
         gm.empty_match = (uint32_t)__popcll(__ballot(line && panicPrev));
         if (lane == 0) A.gmeta[g] = gm;

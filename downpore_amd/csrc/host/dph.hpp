@@ -286,6 +286,7 @@ struct RoundStats {
     uint64_t scan_bases = 0, scan_items = 0, scan_bytes = 0, query_bytes = 0;
     uint64_t n_queries = 0, n_indexed = 0, n_hits = 0, n_matches = 0, n_paf = 0, n_seeds = 0;
     uint64_t chain_bytes = 0;               // algorithmic bytes of the prefilter + chaining kernel
+    uint64_t cons_bytes = 0;                // algorithmic bytes of the consensus kernel (sum of its windows' group records)
     uint64_t idx_rounds = 0, idx_hits = 0;  // rounds served by the resident k-mer position index, and their seed occurrences
     uint64_t timed_rounds = 0;              // rounds whose kernels were bracketed by timing events (dp_set_kernel_timing): the k_*_ms are theirs
     uint64_t gang_members = 0;              // rounds that shared this round's launches (dp_gang_round_members), this one included; 1 without a gang
@@ -297,6 +298,7 @@ struct RoundStats {
         n_indexed += o.n_indexed, n_hits += o.n_hits, n_matches += o.n_matches, n_paf += o.n_paf, n_seeds += o.n_seeds;
         chain_bytes += o.chain_bytes, idx_rounds += o.idx_rounds, idx_hits += o.idx_hits, timed_rounds += o.timed_rounds;
         gang_members += o.gang_members;
+        cons_bytes += o.cons_bytes;
     }
 };
 

@@ -764,6 +764,7 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
         fs.badBack += gm.bad_back;
         fs.emptyMatch += gm.empty_match;
         fs.lines += gm.n_lines;
+        st.cons_bytes += gm.reserved;
         for (uint32_t j = 0; j < gm.n_ignore; j++) {
             const int id = (int)pb.ignore_ids[gm.slot + j];
             if (ignoreOut) ignoreOut->push_back(id);

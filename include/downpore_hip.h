@@ -376,7 +376,9 @@ typedef struct {
     uint32_t empty_match;            /* lines whose GetBasesCovered would have panicked (ident printed as 0) */
     uint32_t flag;
     uint32_t n_matches;              /* hits of the two queries of the window (commands/overlap.go:158-173) */
-    uint32_t reserved;
+    uint32_t reserved;               /* flag == 0: algorithmic bytes the window's consensus read and wrote (records, chains, anchors,
+                                      * trimmed segments, query segments in; PAF records, ignore ids, this record out);
+                                      * flag == 1: why the device left the window to the caller (diagnosis) */
 } dp_group_meta;
 typedef struct {
     uint32_t n_groups;

@@ -83,7 +83,7 @@ DPH_API const double* dph_overlap_values(void* h, int64_t* n);
 DPH_API void* dph_overlap_ctx(void* h);
 /* out[3]: seconds spent creating the context, uploading + packing the reads, in the last dph_overlap_init */
 DPH_API void dph_overlap_setup_times(void* h, double* out);
-/* statistics of the last committed round / summed over the job: out[30] doubles in the order of downpore_amd/overlap.py
+/* statistics of the last committed round / summed over the job: out[31] doubles in the order of downpore_amd/overlap.py
  * STAT_FIELDS (host seconds per phase, kernel milliseconds, algorithmic bytes, counts) */
 DPH_API void dph_overlap_stats(void* h, double* out);
 DPH_API void dph_overlap_stats_total(void* h, double* out);
