@@ -222,6 +222,10 @@ int dp_zero_fetch_regions(dp_ctx* ctx, const dp_zero_region* z, int nz, const dp
     } while (0)
 
 // resident k-mer position index (dp_kindex.hip)
+struct dp_kindex_fast {   // the count walk's short cut for views served whole (dp_kindex.hip, KxRec)
+    const uint8_t* ign;   // device: one byte per read, != 0 = ignored (null: the walk reads the items)
+    uint32_t qlo, qspan;  // reads that may carry extra items
+};
 struct dp_kindex_oneshot {  // the index step of a round launched in one go, sized from guesses (dp_kindex_count)
     uint64_t hits_guess;    // seed occurrences expected (sizes the record shards)
     uint32_t surv_guess;    // survivors expected (grid of the sort pass)
@@ -241,7 +245,7 @@ void dp_kindex_free(dp_ctx* ctx);
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint4* s_pack, uint64_t* d_totals,
                     unsigned long long* host_totals /* pinned, 64 bytes: the totals are stored there by the last kernel (or null) */,
-                    const struct dp_kindex_oneshot* one = nullptr);
+                    const struct dp_kindex_oneshot* one = nullptr, const struct dp_kindex_fast* fast = nullptr);
 int dp_kindex_refill(dp_ctx* ctx, const dp_scan_item* d_items, uint32_t n_read_items, uint32_t n_extra);
 int dp_index_prechain_launch(dp_ctx* ctx, const uint64_t* scan_totals, uint32_t n_extra, uint64_t seg_cap, uint32_t* done_flag,
                              uint32_t done_seq);  // dp_overlap.hip

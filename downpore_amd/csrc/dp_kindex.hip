@@ -273,6 +273,11 @@ struct KxRec {
     uint32_t* kb;             // [2 * groups]: where the group's records start (0xffffffff: its shard was full), how many
     uint32_t* flags;          // [0] a shard was full
     uint32_t shard_cap;
+    // the count walk's short cut (round 4): views served whole (not top-level) have a k-mer at every indexed position, so "inside
+    // the item" is "the read is not ignored" - a byte per read instead of its 16-byte item - and only reads in [qlo, qlo + qspan)
+    // carry extra items (the round's query reads are consecutive): two dependent table reads per hit fewer.  ign == null: off.
+    const uint8_t* ign;
+    uint32_t qlo, qspan;
 };
 __device__ __forceinline__ unsigned long long kx_rec(bool x, bool v, uint32_t r, uint32_t rank, uint32_t p) {
     return (x ? KX_REC_X : 0ull) | (v ? KX_REC_V : 0ull) | ((unsigned long long)(r & 0xffffffu) << 38) |
@@ -454,8 +459,14 @@ struct kidx_walk {
         for (int u = 0; u < 4; u++) {
             const uint32_t r = (uint32_t)(e[u] >> 32);
             in[u] = v[u] && r >= lo && r < hi;
-            item[u] = in[u] ? items[r - lo] : dp_scan_item{};
-            hd[u] = v[u] ? head[r] : 0u;
+            if (!FILL && R.ign) {
+                item[u] = dp_scan_item{};
+                item[u].n_kmers = (in[u] && !R.ign[r]) ? 0xffffffffu : 0u;
+                hd[u] = (v[u] && r - R.qlo < R.qspan) ? head[r] : 0u;
+            } else {
+                item[u] = in[u] ? items[r - lo] : dp_scan_item{};
+                hd[u] = v[u] ? head[r] : 0u;
+            }
         }
         KX_TICK(3)
         uint32_t cnt[4] = {0, 0, 0, 0};
@@ -798,7 +809,7 @@ static uint32_t kidx_walk_grid(const dp_kindex* ix, int k, uint32_t S) {
 // the caller waits once and repeats fill + sort (dp_kindex_refill) for the rare round that outgrew a guess.
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint4* s_pack,
-                    uint64_t* d_totals, unsigned long long* host_totals, const dp_kindex_oneshot* one) {
+                    uint64_t* d_totals, unsigned long long* host_totals, const dp_kindex_oneshot* one, const dp_kindex_fast* fast) {
     dp_kindex* ix = kidx_owner(ctx)->kidx;
     const uint32_t S = ctx->n_seeds, n_items = n_read_items + n_extra;
     if (n_items >= (1u << 24)) return 1;  // (the scan's status word holds 24 bits of survivors) -> scan kernels
@@ -832,7 +843,12 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         ctx->extras_staged = false;
     }
     // hit records: 64 shards of (estimated hits / 64) * 1.5 + 4096 records, two words per group
-    KxRec R{nullptr, nullptr, nullptr, 0u};
+    KxRec R{nullptr, nullptr, nullptr, 0u, nullptr, 0u, 0u};
+    if (fast && fast->ign) {
+        R.ign = fast->ign;
+        R.qlo = fast->qlo;
+        R.qspan = fast->qspan;
+    }
     const uint32_t lps = kidx_lps(ix, k);
     const uint32_t n_groups = lps == 64 ? S * KX_PARTS : S;
     if (one && S) {
@@ -965,7 +981,7 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             dp_launch<kidx_walk<true>>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
                                (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
                                (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr, kidx_lps(ix, k),
-                               (unsigned long long*)nullptr, KxRec{nullptr, nullptr, nullptr, 0u}, kidx_walk_blocks(ix, k, S) * 4);
+                               (unsigned long long*)nullptr, KxRec{nullptr, nullptr, nullptr, 0u, nullptr, 0u, 0u}, kidx_walk_blocks(ix, k, S) * 4);
         const dim3 sg(std::min<uint32_t>(n_sel, 16384)), sb(64);
         uint32_t* ovf = (uint32_t*)(d_totals + 4);
         const uint32_t* nsp = (const uint32_t*)(d_totals + 1);

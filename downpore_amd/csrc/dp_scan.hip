@@ -1734,8 +1734,25 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     }
     if (use_index) {
         // counts, segment offsets, survivor list and totals in three launches, no sort and no host round trip (dp_kindex.hip)
+        // (views served whole - top_level == 0 - have a k-mer at every indexed position: the walk tests the ignore byte instead of
+        // reading the read's item, and looks for extra items only on the round's query reads; DP_KX_FAST=0: off)
+        dp_kindex_fast fastArgs = {nullptr, 0u, 0u};
+        static const bool fast_off = [] {
+            const char* e = getenv("DP_KX_FAST");
+            return e && e[0] == '0';
+        }();
+        if (!top_level && !fast_off && ctx->d_ignore.p) {
+            uint32_t qmin = 0xffffffffu, qmax = 0;
+            for (uint32_t i = 0; i < n_extra; i++) {
+                qmin = std::min(qmin, extra[i].read);
+                qmax = std::max(qmax, extra[i].read);
+            }
+            fastArgs.ign = (const uint8_t*)ctx->d_ignore.p;
+            fastArgs.qlo = n_extra ? qmin : 0u;
+            fastArgs.qspan = n_extra ? qmax - qmin + 1 : 0u;
+        }
         int rc = dp_kindex_count(ctx, k, d_items, lo, hi, n_read_items, n_extra, (uint32_t*)ctx->d_counts.p, (uint64_t*)ctx->d_segoff.p,
-                                 s_item, s_count, s_off, s_pack, totals, (unsigned long long*)ctx->h_total.p, oneshot ? &one : nullptr);
+                                 s_item, s_count, s_off, s_pack, totals, (unsigned long long*)ctx->h_total.p, oneshot ? &one : nullptr, &fastArgs);
         if (rc < 0) return rc;
         if (rc == 2) oneshot = false;   // (records not possible this round: the two-step form follows)
         else if (rc > 0) use_index = false;  // more items than its scan handles: this round is scanned
