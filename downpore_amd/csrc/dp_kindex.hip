@@ -525,7 +525,9 @@ struct kidx_walk {
 
 // status word of a tile: flag << 62 | survivors << 38 | segment ints (flag 1 = the tile's own sums, 2 = inclusive prefix)
 #define KX_TILE 1024
+#ifndef KX_IPT
 #define KX_IPT 4
+#endif
 struct kidx_offsets {
     enum { THREADS = KX_TILE };
     static __device__ void run(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ counts,
