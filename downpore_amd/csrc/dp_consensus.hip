@@ -423,6 +423,7 @@ struct ConsFullArgs {
     const uint32_t *in_count, *in_list;  // windows this launch works through: how many, their numbers (null: every window)
     uint32_t *out_count, *out_list;      // windows this layout cannot hold are listed here for the next one (null: flagged for the host
                                          // path); the counters are zeroed by the anchors launch
+    uint32_t spin_ticks;       // DP_CONS_SPIN=us (experiment): every window sleeps this long before it ends
     bool copy_nseq;            // this launch hands the chunk count of dp_index_build_chunked on to the host's block (the first one)
 };
 
@@ -469,7 +470,7 @@ struct consensus_full_kernel {
             if (lane == 0) A.gmeta[g] = gm;
             continue;
         }
-#define CF_TICK(i_) if (A.dbg && lane == 0) A.dbg[8 * (size_t)g + (i_)] = wall_clock64()
+#define CF_TICK(i_) if (A.dbg && lane == 0) A.dbg[16 * (size_t)g + (i_)] = wall_clock64()
         CF_TICK(0);
         // ---- 1. matches of the group
         int nm = 0;
@@ -766,6 +767,9 @@ struct consensus_full_kernel {
         const int kLim = 1 << 28;
         const int ns = nseq;
         unsigned dbgUni = 0, dbgGen = 0, dbgProp = 0;  // (DP_CONS_DEBUG: uniform steps, general steps, proposers looked at)
+        unsigned long long dbgT[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (general steps: ticks before the scan, in it, in the selection, in the update; scan runs, walk trips of the scan, of the update)
+        unsigned long long dbgT0 = 0;
+#define CF_T(i_) if (A.dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = wall_clock64(); dbgT[i_] += n_ - dbgT0; dbgT0 = n_; }
         for (;;) {
             int near = 100000;
             const int p2s = pos + 1;
@@ -810,6 +814,7 @@ struct consensus_full_kernel {
             }
             supported = 0;
             dbgGen++;
+            if (A.dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dbgT0 = wall_clock64(); }
             const bool fin = !mine || sl == 0 || pos >= (sl - 1) / 2 - 1;
             int fCount = __popcll(__ballot(fin && mine));
             int d = 0, nextSeed = 0, minD = 0, maxD = 0;
@@ -827,10 +832,12 @@ struct consensus_full_kernel {
             // each other with the same proposal {d, seed, window} - at e = 0 nearly all of them - are one step here: the first
             // sets `near`, the others meet the very same test after it (near does not move again inside the run), the search
             // (which depends on the proposal and the searching lane only) is made once, every accepted member takes its numbers.
+            CF_T(0)
             unsigned long long cand = __ballot(!fin);
             bool fnd = false, memoOk = false;
             int val = 0, memoD = 0, memoSeed = 0, memoMin = 0, memoMax = 0, cntAll = 0, sumAll = 0;
             while (cand) {
+                dbgT[4]++;
                 const int i = __builtin_ctzll(cand);
                 const int di = CA_RL(d, i);
                 const int seedI = CA_RL(nextSeed, i), minI = CA_RL(minD, i), maxI = CA_RL(maxD, i);
@@ -853,6 +860,7 @@ struct consensus_full_kernel {
                     if (max2 < maxI) max2 = maxI;
                     int p2 = p2s, otherD = od;
                     while (otherD < min2 && p2 < sl / 2) {
+                        if (A.dbg) dbgT[5]++;
                         p2++;
                         otherD += S[b + p2 * 2] + k;
                     }
@@ -867,13 +875,14 @@ struct consensus_full_kernel {
                     }
                 }
                 cntAll = __popcll(__ballot(fnd));
-                sumAll = wave_sum(fnd ? val : 0);
+                sumAll = wave_sum_dpp(fnd ? val : 0);
                 }
                 if ((accepted >> lane) & 1ull) {
                     supported = 1 + cntAll - (fnd ? 1 : 0);
                     dist += sumAll - (fnd ? val : 0);
                 }
             }
+            CF_T(1)
             if (fCount >= ns) break;
             int minseed = -1, mindist = 0, minsup = 0, selMin = 0, selMax = 0;
             // (mean distance and window of every supported proposer at once - one vector division per step instead of one per
@@ -908,7 +917,9 @@ struct consensus_full_kernel {
                     selMax = CA_RL(myMax, winner);
                 }
             }
+            CF_T(2)
             if (minseed == -1) {
+                dbgT[7]++;
                 const int dvv = myDv;
                 const bool can = mine && sl > 0 && pos < ns / 2;
                 int best = can ? dvv : 0x7fffffff;
@@ -966,6 +977,7 @@ struct consensus_full_kernel {
                     }
                     finC = false;
                     if (!found) {
+                        if (A.dbg) dbgT[6]++;
                         gaps += mindist;
                         offs += mindist;
                         int p = pos;
@@ -978,11 +990,18 @@ struct consensus_full_kernel {
                     }
                 }
             }
+            CF_T(3)
             if (__popcll(__ballot(finC && mine)) >= ns) break;
         }
+        if (A.dbg) {
+            int t5 = (int)dbgT[5], t6 = (int)dbgT[6];
+            for (int o = 32; o > 0; o >>= 1) t5 = max(t5, __shfl_xor(t5, o, 64)), t6 = max(t6, __shfl_xor(t6, o, 64));
+            dbgT[5] = (unsigned long long)t5, dbgT[6] = (unsigned long long)t6;
+        }
         if (A.dbg && lane == 0) {
-            A.dbg[8 * (size_t)g + 6] = ((unsigned long long)dbgUni << 32) | dbgGen;
-            A.dbg[8 * (size_t)g + 7] = ((unsigned long long)nseq << 32) | dbgProp;
+            A.dbg[16 * (size_t)g + 6] = ((unsigned long long)dbgUni << 32) | dbgGen;
+            A.dbg[16 * (size_t)g + 7] = ((unsigned long long)nseq << 32) | dbgProp;
+            for (int i = 0; i < 8; i++) A.dbg[16 * (size_t)g + 8 + i] = dbgT[i];
         }
         if (__ballot(bad)) CF_NOFIT(6u)  // consensus longer than CONS, a value outside the safe range
         if (lane == 0) L.cons[clen] = 0;
@@ -1169,6 +1188,10 @@ struct consensus_full_kernel {
         gm.bad_back = (uint32_t)__popcll(__ballot(badBack != 0));
         gm.empty_match = (uint32_t)__popcll(__ballot(line && panicPrev));
         if (lane == 0) A.gmeta[g] = gm;
+        if (A.spin_ticks) {
+            const unsigned long long t0_ = wall_clock64();
+            while (wall_clock64() - t0_ < A.spin_ticks) __builtin_amdgcn_s_sleep(8);
+        }
         CF_TICK(5);
     }
 #undef CF_NOFIT
@@ -1223,6 +1246,8 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     {
         static const uint32_t flag_every = getenv("DP_CONS_FLAG_EVERY") ? (uint32_t)atoi(getenv("DP_CONS_FLAG_EVERY")) : 0u;
         A.flag_every = flag_every;
+        static const uint32_t spin = getenv("DP_CONS_SPIN") ? (uint32_t)atoi(getenv("DP_CONS_SPIN")) * 100u : 0u;
+        A.spin_ticks = spin;
     }
     A.rc_of = (const int32_t*)((const uint8_t*)ctx->d_cin.p + b_meta);
     // small LDS layout first (int16: needs every seed id below 2^15), the large one for what it lists; DP_CONS_SMALL=0: large only.
@@ -1255,8 +1280,8 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     static const bool cons_debug = getenv("DP_CONS_DEBUG") != nullptr;
     A.dbg = nullptr;
     if (cons_debug) {
-        DP_HIP(dp_dev_malloc((void**)&A.dbg, (size_t)ng * 64));
-        DP_HIP(hipMemsetAsync(A.dbg, 0, (size_t)ng * 64, ctx->stream));
+        DP_HIP(dp_dev_malloc((void**)&A.dbg, (size_t)ng * 128));
+        DP_HIP(hipMemsetAsync(A.dbg, 0, (size_t)ng * 128, ctx->stream));
     }
     uint32_t* h_nseq = (uint32_t*)((uint8_t*)ctx->h_cout.p + ((b_paf + b_ign + b_gm + 15) & ~(size_t)15));
     h_nseq[0] = ctx->n_seqs;
@@ -1341,20 +1366,20 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     ms = dp_elapsed(ctx, 0, 1);
     out->kernel_ms = ms;
     if (cons_debug) {  // per-phase time of the groups that ran to the end: mean and maximum, in microseconds
-        std::vector<unsigned long long> h((size_t)ng * 8);
-        hipMemcpy(h.data(), A.dbg, (size_t)ng * 64, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> h((size_t)ng * 16);
+        hipMemcpy(h.data(), A.dbg, (size_t)ng * 128, hipMemcpyDeviceToHost);
         dp_dev_free(A.dbg);
         double sum[5] = {0, 0, 0, 0, 0}, mx[5] = {0, 0, 0, 0, 0}, tot = 0, totmx = 0;
         uint32_t cnt = 0;
         for (uint32_t g = 0; g < ng; g++) {
-            if (!h[8 * (size_t)g + 5]) continue;
+            if (!h[16 * (size_t)g + 5]) continue;
             cnt++;
             for (int i = 0; i < 5; i++) {
-                const double d = (double)(h[8 * (size_t)g + i + 1] - h[8 * (size_t)g + i]) / 100.0;
+                const double d = (double)(h[16 * (size_t)g + i + 1] - h[16 * (size_t)g + i]) / 100.0;
                 sum[i] += d;
                 mx[i] = std::max(mx[i], d);
             }
-            const double t = (double)(h[8 * (size_t)g + 5] - h[8 * (size_t)g]) / 100.0;
+            const double t = (double)(h[16 * (size_t)g + 5] - h[16 * (size_t)g]) / 100.0;
             tot += t;
             totmx = std::max(totmx, t);
         }
@@ -1363,32 +1388,41 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
             uint32_t slow = 0;
             double slowT = 0;
             for (uint32_t g = 0; g < ng; g++) {
-                if (!h[8 * (size_t)g + 5]) continue;
-                su += (double)(h[8 * (size_t)g + 6] >> 32);
-                sg += (double)(h[8 * (size_t)g + 6] & 0xffffffffu);
-                sp += (double)(h[8 * (size_t)g + 7] & 0xffffffffu);
-                sn += (double)(h[8 * (size_t)g + 7] >> 32);
-                const double t = (double)(h[8 * (size_t)g + 4] - h[8 * (size_t)g + 3]);
+                if (!h[16 * (size_t)g + 5]) continue;
+                su += (double)(h[16 * (size_t)g + 6] >> 32);
+                sg += (double)(h[16 * (size_t)g + 6] & 0xffffffffu);
+                sp += (double)(h[16 * (size_t)g + 7] & 0xffffffffu);
+                sn += (double)(h[16 * (size_t)g + 7] >> 32);
+                const double t = (double)(h[16 * (size_t)g + 4] - h[16 * (size_t)g + 3]);
                 if (t > slowT) slowT = t, slow = g;
             }
             {
                 uint32_t sg2 = 0;
                 double st2 = 0;
                 for (uint32_t g = 0; g < ng; g++) {
-                    if (!h[8 * (size_t)g + 5]) continue;
-                    const double t = (double)(h[8 * (size_t)g + 5] - h[8 * (size_t)g]);
+                    if (!h[16 * (size_t)g + 5]) continue;
+                    const double t = (double)(h[16 * (size_t)g + 5] - h[16 * (size_t)g]);
                     if (t > st2) st2 = t, sg2 = g;
                 }
                 if (cnt)
                     fprintf(stderr, "[cons] slowest window (%.1f us): gather+query %.1f trim %.1f shared+reduce %.1f align %.1f contig+paf %.1f, %llu sequences\n", st2 / 100.0,
-                            (h[8 * (size_t)sg2 + 1] - h[8 * (size_t)sg2]) / 100.0, (h[8 * (size_t)sg2 + 2] - h[8 * (size_t)sg2 + 1]) / 100.0,
-                            (h[8 * (size_t)sg2 + 3] - h[8 * (size_t)sg2 + 2]) / 100.0, (h[8 * (size_t)sg2 + 4] - h[8 * (size_t)sg2 + 3]) / 100.0,
-                            (h[8 * (size_t)sg2 + 5] - h[8 * (size_t)sg2 + 4]) / 100.0, h[8 * (size_t)sg2 + 7] >> 32);
+                            (h[16 * (size_t)sg2 + 1] - h[16 * (size_t)sg2]) / 100.0, (h[16 * (size_t)sg2 + 2] - h[16 * (size_t)sg2 + 1]) / 100.0,
+                            (h[16 * (size_t)sg2 + 3] - h[16 * (size_t)sg2 + 2]) / 100.0, (h[16 * (size_t)sg2 + 4] - h[16 * (size_t)sg2 + 3]) / 100.0,
+                            (h[16 * (size_t)sg2 + 5] - h[16 * (size_t)sg2 + 4]) / 100.0, h[16 * (size_t)sg2 + 7] >> 32);
             }
             if (cnt)
                 fprintf(stderr, "[cons] steps per window: %.1f uniform, %.1f general (%.1f proposer searches), %.1f sequences | slowest align %.1f us: %llu uniform, %llu general, %llu searches, %llu sequences\n",
-                        su / cnt, sg / cnt, sp / cnt, sn / cnt, slowT / 100.0, h[8 * (size_t)slow + 6] >> 32, h[8 * (size_t)slow + 6] & 0xffffffffu,
-                        h[8 * (size_t)slow + 7] & 0xffffffffu, h[8 * (size_t)slow + 7] >> 32);
+                        su / cnt, sg / cnt, sp / cnt, sn / cnt, slowT / 100.0, h[16 * (size_t)slow + 6] >> 32, h[16 * (size_t)slow + 6] & 0xffffffffu,
+                        h[16 * (size_t)slow + 7] & 0xffffffffu, h[16 * (size_t)slow + 7] >> 32);
+        }
+        {
+            double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t g = 0; g < ng; g++)
+                if (h[16 * (size_t)g + 5])
+                    for (int i = 0; i < 8; i++) t[i] += (double)h[16 * (size_t)g + 8 + i];
+            if (cnt)
+                fprintf(stderr, "[cons] general steps, per window: before the scan %.2f us, scan %.2f, selection %.2f, update %.2f | scan runs %.1f, lane-trips of the scan's first walk %.1f, lanes not found in the update %.1f, steps without a seed %.1f\n",
+                        t[0] / cnt / 100.0, t[1] / cnt / 100.0, t[2] / cnt / 100.0, t[3] / cnt / 100.0, t[4] / cnt, t[5] / cnt, t[6] / cnt, t[7] / cnt);
         }
         if (cnt)
             fprintf(stderr, "[cons] kernel %.3f ms, %u of %u groups complete | us mean/max: gather+query %.1f/%.1f trim %.1f/%.1f shared+reduce %.1f/%.1f "

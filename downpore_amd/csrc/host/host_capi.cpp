@@ -372,7 +372,11 @@ int dph_overlap_step(void* hh) {
     OverlapH* h = (OverlapH*)hh;
     int rc = h->run.step();
     if (rc < 0) h->err = h->run.error;
-    else if (rc > 0) h->addPaf(h->run.paf);
+    else if (rc > 0) {
+        const double t0 = now();
+        h->addPaf(h->run.paf);
+        g_prof.commitKeepUs += (long long)((now() - t0) * 1e6);
+    }
     return rc;
 }
 // step() stops committing at round n (tests that compare the first n rounds with a fixture); -1 lifts the limit
@@ -393,6 +397,10 @@ int64_t dph_planner_counter(int which) {
         case 5: return g_prof.committed.load();
         case 6: return g_prof.planUs.load();
         case 7: return g_prof.getWaitUs.load();
+        case 8: return g_prof.commitWaitUs.load();   // the committing thread (whoever calls dph_overlap_step): waiting for the next round in order,
+        case 9: return g_prof.commitTextUs.load();   // ... joining its text,
+        case 10: return g_prof.commitStateUs.load();  // ... flags + planner bookkeeping,
+        case 11: return g_prof.commitKeepUs.load();   // ... keeping the step's text for dph_overlap_all_paf
         default: return -1;
     }
 }

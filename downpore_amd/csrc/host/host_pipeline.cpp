@@ -1535,7 +1535,9 @@ int OverlapRun::step() {
         auto it = ready_.find(round);
         if (it == ready_.end()) {
             if (committed) break;
+            const double tw = now();
             cvDone_.wait(lk);
+            g_prof.commitWaitUs += (long long)((now() - tw) * 1e6);
             continue;
         }
         RoundResult res = std::move(it->second);
@@ -1559,9 +1561,13 @@ int OverlapRun::step() {
             continue;
         }
         lk.unlock();
+        const double tc = now();
         commitText(res);
+        const double tc1 = now();
         lk.lock();
         commitState(res);
+        g_prof.commitTextUs += (long long)((tc1 - tc) * 1e6);
+        g_prof.commitStateUs += (long long)((now() - tc1) * 1e6);
         committed++;
         g_prof.committed++;
         cvWork_.notify_all();

@@ -19,12 +19,18 @@ for r in range(reps):
         try:
             j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
             res[label].append((j["rounds_only"]["ms_per_round"], j["job_breakdown_s"]["whole_job"], j["job_breakdown_s"]["setup_value_table_kmer_index_slots"],
-                               j["parity"]["paf_sha256_matches_oracle_fixture"]))
+                               j["parity"]["paf_sha256_matches_oracle_fixture"],
+                               (j.get("per_rank") or [{}])[0].get("per_job", {}).get("slot_wait_for_plan_us", 0) / 1e3,
+                               (j.get("per_rank") or [{}])[0].get("per_job", {}).get("plan_compute_us", 0) / 1e3,
+                               tuple((j.get("per_rank") or [{}])[0].get("per_job", {}).get(k, 0) / 1e3 for k in
+                                     ("commit_thread_wait_us", "commit_text_us", "commit_state_us", "commit_keep_text_us"))))
         except Exception as ex:
             print(label, "failed:", ex, p.stderr[-300:])
 for label, v in res.items():
     if not v: continue
     ms = sorted(x[0] for x in v); job = sorted(x[1] for x in v)
-    print("%-14s ms/round min %.3f med %.3f | job min %.3f med %.3f | setup med %.3f | parity %s | all %s" %
+    print("%-14s ms/round min %.3f med %.3f | job min %.3f med %.3f | setup med %.3f | parity %s | slots waited for plans %.1f ms, plan computes %.1f ms per job | all %s" %
           (label, ms[0], statistics.median(ms), job[0], statistics.median(job), statistics.median(x[2] for x in v), all(x[3] for x in v),
-           " ".join("%.3f" % x for x in ms)))
+           statistics.median(x[4] for x in v), statistics.median(x[5] for x in v), " ".join("%.3f" % x for x in ms)))
+    print("   committing thread, ms per job: waits %.1f, text %.1f, state %.1f, keeps text %.1f" % tuple(statistics.median(x[6][i] for x in v) for i in range(4)))
+print("host threads:", os.cpu_count())
