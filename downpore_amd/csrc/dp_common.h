@@ -239,8 +239,8 @@ struct dp_kindex_oneshot {  // the index step of a round launched in one go, siz
 };
 int dp_histogram_device(dp_ctx* ctx, int k, uint32_t* d_counts);  // dp_scan.hip
 int dp_kindex_ensure(dp_ctx* ctx, int k);
-int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, uint64_t* d_off, void** d_pos_out, uint64_t* n_pos_out,
-                           float* ms_out);  // dp_kbuild.hip
+int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, uint64_t* d_off, void** d_pos_out, void** d_pos_hi_out,
+                           int* fmt_out, int* pbits_out, uint64_t* n_pos_out, float* ms_out);  // dp_kbuild.hip
 void dp_kindex_free(dp_ctx* ctx);
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint4* s_pack, uint64_t* d_totals,
@@ -275,7 +275,20 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
                    uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out = nullptr);
 
 // ---- device helpers ---------------------------------------------------------------------------------------
+// An entry of the resident k-mer position index (dp_kindex.hip; written by dp_kbuild.hip): fmt 8 = read << 32 | position in a
+// 64-bit word; 4 = read << pbits | position in 32 bits; 5 = the same in 40 bits, the top byte in a stream of its own.
+struct KxPos {
+    const void* lo;
+    const uint8_t* hi;
+    uint32_t fmt, pbits;
+};
 #ifdef __HIPCC__
+__device__ __forceinline__ uint64_t kx_entry(const KxPos P, uint64_t i) {  // -> read << 32 | position
+    if (P.fmt == 8) return ((const uint64_t*)P.lo)[i];
+    uint64_t v = ((const uint32_t*)P.lo)[i];
+    if (P.fmt == 5) v |= (uint64_t)P.hi[i] << 32;
+    return ((v >> P.pbits) << 32) | (v & (((uint64_t)1 << P.pbits) - 1));
+}
 __device__ __forceinline__ int dp_lane() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ int wave_incl_sum(int v) {
 #pragma unroll

@@ -35,6 +35,36 @@ struct KbGeom {
     int pbits, rbits;  // payload below the k-mer: position in the read, read id
 };
 
+// Round 4: entries are stored as narrow as their bits allow.  An entry in flight is a 64-bit word in registers and LDS; between the
+// passes it lives in two streams - the low 32 bits, and the bits above them in a stream of 0, 1, 2 or 4 bytes per entry (both written
+// in the same coalesced runs).  After pass 1 an entry needs 2k - b1 + rbits + pbits bits (config 2: 48 - 49: six or eight bytes),
+// after pass 2 r + rbits + pbits (40: five bytes), and the index itself rbits + pbits (31: four bytes; 34 at config 4: five) -
+// 32 bytes moved per entry over the three passes instead of 48, and an index of half the size for the rounds to walk.
+struct KbBuf {
+    uint32_t* lo;
+    void* hi;
+    int hb;  // bytes per entry in `hi`: 0, 1, 2 or 4; 8: `lo` is one stream of 64-bit words
+};
+static inline int kb_hi_bytes(int bits) { return bits <= 32 ? 0 : bits <= 40 ? 1 : bits <= 48 ? 2 : 4; }
+__device__ __forceinline__ kb_u64 kb_ld(const KbBuf B, kb_u64 i) {
+    if (B.hb == 8) return ((const kb_u64*)B.lo)[i];
+    kb_u64 v = B.lo[i];
+    if (B.hb == 1) v |= (kb_u64)((const uint8_t*)B.hi)[i] << 32;
+    else if (B.hb == 2) v |= (kb_u64)((const uint16_t*)B.hi)[i] << 32;
+    else if (B.hb == 4) v |= (kb_u64)((const uint32_t*)B.hi)[i] << 32;
+    return v;
+}
+__device__ __forceinline__ void kb_st(const KbBuf B, kb_u64 i, kb_u64 v) {
+    if (B.hb == 8) {
+        ((kb_u64*)B.lo)[i] = v;
+        return;
+    }
+    B.lo[i] = (uint32_t)v;
+    if (B.hb == 1) ((uint8_t*)B.hi)[i] = (uint8_t)(v >> 32);
+    else if (B.hb == 2) ((uint16_t*)B.hi)[i] = (uint16_t)(v >> 32);
+    else if (B.hb == 4) ((uint32_t*)B.hi)[i] = (uint32_t)(v >> 32);
+}
+
 // read of every 1024-base block of the packed layout (reads start on 64-base boundaries, so a 32-position group never
 // straddles two reads): gread[j] = read whose [boff*4, boff_next*4) range holds base 1024*j
 __global__ void kb_group_table(const uint64_t* __restrict__ boff, uint32_t n_reads, uint32_t* __restrict__ gread) {
@@ -105,7 +135,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_count1(const uint8_t* __restric
 template <int E>
 __device__ __forceinline__ void kb_tile_out(const kb_u64 (&e)[E], uint32_t m, int dshift, uint32_t dmask, uint32_t* hist /*[1024]*/,
                                             uint32_t* lstart /*[1024]*/, kb_u64* gbase /*[1024]*/, kb_u64* sorted /*[KB_TILE]*/,
-                                            kb_u64* __restrict__ cursor, kb_u64* __restrict__ out) {
+                                            kb_u64* __restrict__ cursor, const KbBuf out) {
     const int nb = (int)dmask + 1;
     for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
     __syncthreads();
@@ -152,14 +182,14 @@ __device__ __forceinline__ void kb_tile_out(const kb_u64 (&e)[E], uint32_t m, in
     for (uint32_t i = threadIdx.x; i < total; i += KB_THREADS) {
         const kb_u64 v = sorted[i];
         const uint32_t d = (uint32_t)(v >> dshift) & dmask;
-        out[gbase[d] + (kb_u64)(i - lstart[d])] = v;
+        kb_st(out, gbase[d] + (kb_u64)(i - lstart[d]), v);
     }
     __syncthreads();
 }
 
 __global__ __launch_bounds__(KB_THREADS) void kb_part1(const uint8_t* __restrict__ packed, const uint64_t* __restrict__ boff,
                                                        const uint32_t* __restrict__ len, const uint32_t* __restrict__ gread,
-                                                       uint64_t n_groups, KbGeom G, kb_u64* __restrict__ cursor, kb_u64* __restrict__ out) {
+                                                       uint64_t n_groups, KbGeom G, kb_u64* __restrict__ cursor, const KbBuf out) {
     __shared__ uint32_t hist[1024], lstart[1024];
     __shared__ kb_u64 gbase[1024];
     __shared__ kb_u64 sorted[KB_TILE];
@@ -194,7 +224,7 @@ __device__ __forceinline__ uint32_t kb_bucket_of_tile(const uint32_t* __restrict
     return (uint32_t)lo;
 }
 
-__global__ __launch_bounds__(KB_THREADS) void kb_count2(const kb_u64* __restrict__ in, const kb_u64* __restrict__ base1,
+__global__ __launch_bounds__(KB_THREADS) void kb_count2(const KbBuf in, const kb_u64* __restrict__ base1,
                                                         const uint32_t* __restrict__ tile_start, KbGeom G, kb_u64* __restrict__ cnt2) {
     __shared__ uint32_t hist[1024];
     const int nb1 = 1 << G.b1, nb2 = 1 << G.b2;
@@ -206,7 +236,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_count2(const kb_u64* __restrict
         const kb_u64 lo = base1[b] + (kb_u64)(t - tile_start[b]) * KB_TILE, hi = min(base1[b + 1], lo + KB_TILE);
         for (int i = threadIdx.x; i < nb2; i += KB_THREADS) hist[i] = 0;
         __syncthreads();
-        for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) atomicAdd(&hist[(uint32_t)(in[i] >> dsh) & dmask], 1u);
+        for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) atomicAdd(&hist[(uint32_t)(kb_ld(in, i) >> dsh) & dmask], 1u);
         __syncthreads();
         for (int i = threadIdx.x; i < nb2; i += KB_THREADS)
             if (hist[i]) atomicAdd(&cnt2[(kb_u64)b * nb2 + i], (kb_u64)hist[i]);
@@ -214,9 +244,9 @@ __global__ __launch_bounds__(KB_THREADS) void kb_count2(const kb_u64* __restrict
     }
 }
 
-__global__ __launch_bounds__(KB_THREADS) void kb_part2(const kb_u64* __restrict__ in, const kb_u64* __restrict__ base1,
+__global__ __launch_bounds__(KB_THREADS) void kb_part2(const KbBuf in, const kb_u64* __restrict__ base1,
                                                        const uint32_t* __restrict__ tile_start, KbGeom G, kb_u64* __restrict__ cursor2,
-                                                       kb_u64* __restrict__ out) {
+                                                       const KbBuf out) {
     __shared__ uint32_t hist[1024], lstart[1024];
     __shared__ kb_u64 gbase[1024];
     __shared__ kb_u64 sorted[KB_TILE];
@@ -234,7 +264,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_part2(const kb_u64* __restrict_
             const kb_u64 i = lo + (kb_u64)j * KB_THREADS + threadIdx.x;  // coalesced
             e[j] = 0;
             if (i < hi) {
-                e[j] = in[i];
+                e[j] = kb_ld(in, i);
                 m |= 1u << j;
             }
         }
@@ -244,9 +274,25 @@ __global__ __launch_bounds__(KB_THREADS) void kb_part2(const kb_u64* __restrict_
 
 // ---- pass 3: one workgroup per sub-partition ------------------------------------------------------------------------
 // counts[kmer] (the histogram), off[kmer] (bucket starts of the index) and the index entries in final order
-__global__ __launch_bounds__(KB_THREADS) void kb_final(const kb_u64* __restrict__ in, const kb_u64* __restrict__ base2, uint32_t n_sub,
+// The index entry: fmt 4 = read << pbits | position in 32 bits; 5 = the same in 40 (low 32 in `lo`, the rest in a byte stream);
+// 8 = read << 32 | position in 64 (what the atomic scatter build of dp_kindex.hip writes too)
+struct KbPosOut {
+    void* lo;
+    uint8_t* hi;
+    int fmt;
+};
+__device__ __forceinline__ void kb_pos_st(const KbPosOut P, kb_u64 i, kb_u64 v, const KbGeom& G) {
+    const kb_u64 pay = v & (((kb_u64)1 << (G.pbits + G.rbits)) - 1);
+    if (P.fmt == 8) {
+        ((kb_u64*)P.lo)[i] = ((pay >> G.pbits) << 32) | (pay & (((kb_u64)1 << G.pbits) - 1));
+    } else {
+        ((uint32_t*)P.lo)[i] = (uint32_t)pay;
+        if (P.fmt == 5) P.hi[i] = (uint8_t)(pay >> 32);
+    }
+}
+__global__ __launch_bounds__(KB_THREADS) void kb_final(const KbBuf in, const kb_u64* __restrict__ base2, uint32_t n_sub,
                                                        KbGeom G, const uint32_t* __restrict__ gread, const uint64_t* __restrict__ boff,
-                                                       uint32_t* __restrict__ counts, kb_u64* __restrict__ off, kb_u64* __restrict__ pos) {
+                                                       uint32_t* __restrict__ counts, kb_u64* __restrict__ off, const KbPosOut pos) {
     extern __shared__ kb_u64 kb_dyn[];  // sorted[KB_P3_CAP] | hist[2^r] | lstart[2^r]
     const int nb = 1 << G.r;
     kb_u64* sorted = kb_dyn;
@@ -254,7 +300,6 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const kb_u64* __restrict_
     uint32_t* lstart = hist + nb;
     const uint32_t dmask = (uint32_t)nb - 1u;
     const int pay = G.pbits + G.rbits;
-    const kb_u64 pmask = ((kb_u64)1 << G.pbits) - 1, rmask = ((kb_u64)1 << G.rbits) - 1;
     for (uint32_t sp = blockIdx.x; sp < n_sub; sp += gridDim.x) {
         const kb_u64 lo = base2[sp], hi = base2[sp + 1];
         const kb_u64 n = hi - lo;
@@ -269,11 +314,11 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const kb_u64* __restrict_
 #pragma unroll
             for (int u = 0; u < KB_HOLD; u++) {
                 const kb_u64 i = lo + (kb_u64)u * KB_THREADS + threadIdx.x;
-                held[u] = i < hi ? in[i] : 0;
+                held[u] = i < hi ? kb_ld(in, i) : 0;
                 if (i < hi) atomicAdd(&hist[(uint32_t)(held[u] >> pay) & dmask], 1u);
             }
         } else {
-            for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) atomicAdd(&hist[(uint32_t)(in[i] >> pay) & dmask], 1u);
+            for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) atomicAdd(&hist[(uint32_t)(kb_ld(in, i) >> pay) & dmask], 1u);
         }
         __syncthreads();
         // histogram + offsets of this sub-partition's 2^r k-mers (k-mer = sp << r | bin): coalesced
@@ -320,14 +365,13 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const kb_u64* __restrict_
             }
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += KB_THREADS) {  // consecutive lanes, consecutive addresses
-                const kb_u64 v = sorted[i];
-                pos[lo + i] = (((v >> G.pbits) & rmask) << 32) | (v & pmask);
+                kb_pos_st(pos, lo + i, sorted[i], G);
             }
         } else {  // larger than the LDS buffer: entries go straight to their slot (the region is this workgroup's alone)
             for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) {
-                const kb_u64 v = in[i];
+                const kb_u64 v = kb_ld(in, i);
                 const uint32_t d = (uint32_t)(v >> pay) & dmask;
-                pos[lo + lstart[d] + atomicAdd(&hist[d], 1u)] = (((v >> G.pbits) & rmask) << 32) | (v & pmask);
+                kb_pos_st(pos, lo + lstart[d] + atomicAdd(&hist[d], 1u), v, G);
             }
         }
         __syncthreads();
@@ -361,18 +405,19 @@ __global__ void kb_excl_scan_small(const kb_u64* __restrict__ in, uint32_t n, kb
     if (threadIdx.x == 1023) out[n] = run;
 }
 
-// Builds counts (uint32 [4^k]), off (uint64 [4^k + 1]) and pos (uint64 [n]) for the context's resident reads.  d_counts, d_off
-// are the caller's; *d_pos_out is allocated here (ownership passes to the caller), the scratch is released before returning.
+// Builds counts (uint32 [4^k]), off (uint64 [4^k + 1]) and the index entries for the context's resident reads.  d_counts, d_off
+// are the caller's; *d_pos_out (and *d_pos_hi_out for format 5) are allocated here (ownership passes to the caller), the scratch is
+// released before returning.  *fmt_out / *pbits_out say how an entry is stored (KbPosOut).
 // Returns 1 when this path does not apply (k < 9 or > 14, more than 2^36 bases): the caller uses the atomic scatter.
-int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, uint64_t* d_off, void** d_pos_out, uint64_t* n_pos_out,
-                           float* ms_out) {
+int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, uint64_t* d_off, void** d_pos_out, void** d_pos_hi_out,
+                           int* fmt_out, int* pbits_out, uint64_t* n_pos_out, float* ms_out) {
     if (k < 9 || k > 14 || ow->n_reads == 0) return 1;
     if (getenv("DP_KINDEX_ATOMIC")) return 1;
     {
         size_t free_b = 0, total_b = 0;
         hipMemGetInfo(&free_b, &total_b);
         free_b += dp_dev_cached_bytes();
-        if ((uint64_t)free_b < ow->total_bases * 16 + ((uint64_t)6 << 30)) return 1;  // two 8 B/base buffers during the build
+        if ((uint64_t)free_b < ow->total_bases * 16 + ((uint64_t)6 << 30)) return 1;  // (at most 8 + 8 B/base during the build)
     }
     const uint64_t n_groups = (ow->packed_bytes * 4 + 31) / 32;
     KbGeom G;
@@ -384,12 +429,23 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
         while (((uint64_t)1 << G.pbits) <= max_len) G.pbits++;
         G.rbits = 1;
         while (((uint64_t)1 << G.rbits) < ow->n_reads) G.rbits++;
+        if (const char* e = getenv("DP_KB_MIN_PBITS")) G.pbits = std::max(G.pbits, std::min(32, atoi(e)));  // (test hook: small inputs reach the wider entry formats)
         if (2 * k + G.pbits + G.rbits > 64) return 1;  // (the entry has no room for read and position: atomic scatter build)
     }
+    const int pay = G.pbits + G.rbits;
+    // how the entries travel between the passes.  Default: one stream of 64-bit words.  DP_KB_STREAMS=1: two streams (4 + 0 / 1 / 2 / 4
+    // bytes, as narrow as the bits allow: 6 and 5 bytes per entry after passes 1 and 2 at config 2) - fewer bytes, and SLOWER on
+    // MI355X: a lane's 4 + 1- or 2-byte accesses are two memory instructions for less than one 8-byte access moves (part 2 3.8 ->
+    // 5.3 ms, last pass 4.8 -> 6.1, profiles/r04/kbuild_kernels.txt), the passes were never limited by bytes alone.
+    const bool streams = getenv("DP_KB_STREAMS") != nullptr;
+    // pass 1's width: 8 bits (with two streams: 9 when that brings its output down a size - config 2: 49 -> 48 bits); DP_KB_B1 overrides
     G.b1 = 8;
+    if (streams && kb_hi_bytes(2 * k - 9 + pay) < kb_hi_bytes(2 * k - 8 + pay) && 2 * k >= 9 + 8) G.b1 = 9;
+    if (const char* e = getenv("DP_KB_B1")) G.b1 = std::max(6, std::min(10, atoi(e)));
+    if (G.b1 > 2 * k - 2) G.b1 = 2 * k - 2;
     // pass 2's width: sub-partitions of about 6000 entries (they are sorted inside LDS when they hold <= 8192)
     const uint64_t approx = ow->total_bases;
-    int b2 = 6;
+    int b2 = std::max(1, 14 - G.b1);
     while (b2 < 10 && (approx >> (G.b1 + b2)) > 7800) b2++;
     if (G.b1 + b2 > 2 * k) b2 = 2 * k - G.b1;
     G.b2 = b2;
@@ -401,14 +457,18 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     if (G.b2 > 10) return 1;
     const int nb1 = 1 << G.b1, nb2 = 1 << G.b2;
     const uint32_t n_sub = (uint32_t)nb1 * (uint32_t)nb2;
-    void *d_gread = nullptr, *d_small = nullptr, *d_buf1 = nullptr, *d_buf2 = nullptr;
+    // how the entries are stored after each pass (DP_KINDEX_WIDE=1: eight bytes throughout, the index as read << 32 | position)
+    const bool wide = getenv("DP_KINDEX_WIDE") != nullptr;
+    const int hb1 = !streams ? 8 : wide ? 4 : kb_hi_bytes(2 * k - G.b1 + pay), hb2 = !streams ? 8 : wide ? 4 : kb_hi_bytes(G.r + pay);
+    const int fmt = (wide || pay > 40) ? 8 : pay > 32 ? 5 : 4;
+    void *d_gread = nullptr, *d_small = nullptr, *d_a_lo = nullptr, *d_a_hi = nullptr, *d_b_lo = nullptr, *d_b_hi = nullptr, *d_f_hi = nullptr;
     struct Temps {
-        void **a, **b, **c, **d;
+        std::vector<void**> v;
         ~Temps() {
-            for (void** p : {a, b, c, d})
+            for (void** p : v)
                 if (*p) dp_dev_free(*p);
         }
-    } temps{&d_gread, &d_small, &d_buf1, &d_buf2};
+    } temps{{&d_gread, &d_small, &d_a_lo, &d_a_hi, &d_b_lo, &d_b_hi, &d_f_hi}};
     const size_t n_blocks1k = (size_t)((ow->packed_bytes * 4 + 1023) >> 10) + 2;
     DP_HIP(dp_dev_malloc(&d_gread, n_blocks1k * 4));
     // small tables: cnt1[nb1], base1[nb1+1], cur1[nb1], cnt2[n_sub], base2[n_sub+1], cur2[n_sub], tile_start[nb1+1]
@@ -445,29 +505,41 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     }
     h_tiles[(size_t)nb1] = (uint32_t)tt;
     if (tt >= 0xffffffffull) return 1;
-    DP_HIP(dp_dev_malloc(&d_buf1, n * 8 + 64));
-    DP_HIP(dp_dev_malloc(&d_buf2, n * 8 + 64));
+    // pass 1 writes A, pass 2 reads A and writes B, pass 3 reads B and writes the index over A's low stream (dead by then; the
+    // eight-byte format takes both of A's streams' worth: it gets a buffer of its own size in place of A's low stream)
+    void* d_f_lo = nullptr;
+    temps.v.push_back(&d_f_lo);
+    DP_HIP(dp_dev_malloc(&d_a_lo, n * (size_t)(hb1 == 8 || fmt == 8 ? 8 : 4) + 64));
+    if (hb1 && hb1 != 8) DP_HIP(dp_dev_malloc(&d_a_hi, n * (size_t)hb1 + 64));
+    DP_HIP(dp_dev_malloc(&d_b_lo, n * (size_t)(hb2 == 8 ? 8 : 4) + 64));
+    if (hb2 && hb2 != 8) DP_HIP(dp_dev_malloc(&d_b_hi, n * (size_t)hb2 + 64));
+    if (fmt == 5) DP_HIP(dp_dev_malloc(&d_f_hi, n + 64));
+    // (the index goes over A's low stream when that has its size; a buffer of its own otherwise - A is twice as large then)
+    const bool f_over_a = (fmt == 8) == (hb1 == 8 || fmt == 8);
+    if (!f_over_a) DP_HIP(dp_dev_malloc(&d_f_lo, n * 4 + 64));
+    const KbBuf A = {(uint32_t*)d_a_lo, d_a_hi, hb1}, B = {(uint32_t*)d_b_lo, d_b_hi, hb2};
+    const KbPosOut F = {f_over_a ? d_a_lo : d_f_lo, (uint8_t*)d_f_hi, fmt};
     DP_HIP(hipMemcpyAsync(tile_start, h_tiles.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     DP_HIP(hipMemcpyAsync(cur1, base1, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(kb_part1, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, (const uint8_t*)ow->d_packed.p, (const uint64_t*)ow->d_boff.p,
-                       (const uint32_t*)ow->d_len.p, (const uint32_t*)d_gread, n_groups, G, cur1, (kb_u64*)d_buf1);
-    hipLaunchKernelGGL(kb_count2, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, (const kb_u64*)d_buf1, (const kb_u64*)base1,
-                       (const uint32_t*)tile_start, G, cnt2);
+                       (const uint32_t*)ow->d_len.p, (const uint32_t*)d_gread, n_groups, G, cur1, A);
+    hipLaunchKernelGGL(kb_count2, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, A, (const kb_u64*)base1, (const uint32_t*)tile_start, G, cnt2);
     hipLaunchKernelGGL(kb_excl_scan_small, dim3(1), dim3(1024), 0, ctx->stream, (const kb_u64*)cnt2, n_sub, base2);
     DP_HIP(hipMemcpyAsync(cur2, base2, (size_t)n_sub * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    hipLaunchKernelGGL(kb_part2, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, (const kb_u64*)d_buf1, (const kb_u64*)base1,
-                       (const uint32_t*)tile_start, G, cur2, (kb_u64*)d_buf2);
-    // pass 3 writes the final entries over pass 1's output (dead by now)
+    hipLaunchKernelGGL(kb_part2, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, A, (const kb_u64*)base1, (const uint32_t*)tile_start, G, cur2, B);
     hipLaunchKernelGGL(kb_final, dim3(std::min<uint32_t>(n_sub, (uint32_t)cus * 16)), dim3(KB_THREADS),
-                       (size_t)KB_P3_CAP * 8 + ((size_t)8 << G.r), ctx->stream, (const kb_u64*)d_buf2,
-                       (const kb_u64*)base2, n_sub, G, (const uint32_t*)d_gread, (const uint64_t*)ow->d_boff.p, d_counts, (kb_u64*)d_off,
-                       (kb_u64*)d_buf1);
+                       (size_t)KB_P3_CAP * 8 + ((size_t)8 << G.r), ctx->stream, B, (const kb_u64*)base2, n_sub, G, (const uint32_t*)d_gread,
+                       (const uint64_t*)ow->d_boff.p, d_counts, (kb_u64*)d_off, F);
     DP_HIP(hipGetLastError());
     DP_HIP(hipEventRecord(e1, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     if (ms_out) hipEventElapsedTime(ms_out, e0, e1);
-    *d_pos_out = d_buf1;
-    d_buf1 = nullptr;  // ownership to the caller
+    *d_pos_out = f_over_a ? d_a_lo : d_f_lo;  // ownership to the caller
+    (f_over_a ? d_a_lo : d_f_lo) = nullptr;
+    *d_pos_hi_out = d_f_hi;
+    d_f_hi = nullptr;
+    *fmt_out = fmt;
+    *pbits_out = G.pbits;
     *n_pos_out = n;
     return DP_OK;
 }

@@ -23,7 +23,11 @@ struct dp_kindex {
     uint64_t n_pos = 0;
     DevBuf off;  // uint64 [4^k + 1]
     float build_ms = 0;  // device time of the sorted build
-    DevBuf pos;  // uint64 [n_pos]: k-mer start as (read << 32 | position in the read), grouped by k-mer value
+    DevBuf pos;  // [n_pos] k-mer starts grouped by k-mer value: (read << 32 | position in the read) in 64 bits (pos_fmt 8), or
+                 // (read << pbits | position) in 32 bits (4) / 40 bits with the top byte in pos_hi (5): KxPos, dp_common.h
+    DevBuf pos_hi;
+    int pos_fmt = 8, pbits = 32;
+    KxPos view() const { return KxPos{pos.p, (const uint8_t*)pos_hi.p, (uint32_t)pos_fmt, (uint32_t)pbits}; }
 };
 
 // every k-mer start of every read: slot = off[kmer] + (arrival rank inside its bucket); order inside a bucket is arbitrary
@@ -130,18 +134,24 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
         if (dev_reserve(ctx, ix->off, (nk + 1) * 8)) return DP_ERR_HIP;
         void* d_cnt = nullptr;
         DP_HIP(dp_dev_malloc(&d_cnt, nk * 4));
-        void* d_pos = nullptr;
+        void *d_pos = nullptr, *d_pos_hi = nullptr;
         uint64_t n_pos = 0;
         float ms = 0;
-        const int rc = dp_kindex_build_sorted(ctx, ow, k, (uint32_t*)d_cnt, (uint64_t*)ix->off.p, &d_pos, &n_pos, &ms);
+        int fmt = 8, pbits = 32;
+        const int rc = dp_kindex_build_sorted(ctx, ow, k, (uint32_t*)d_cnt, (uint64_t*)ix->off.p, &d_pos, &d_pos_hi, &fmt, &pbits, &n_pos, &ms);
         if (rc < 0) {
             dp_dev_free(d_cnt);
             return rc;
         }
         if (rc == 0) {
             if (ix->pos.p) dp_dev_free(ix->pos.p);
+            if (ix->pos_hi.p) dp_dev_free(ix->pos_hi.p);
             ix->pos.p = d_pos;
-            ix->pos.cap = n_pos * 8 + 64;
+            ix->pos.cap = n_pos * (fmt == 8 ? 8 : 4) + 64;
+            ix->pos_hi.p = d_pos_hi;
+            ix->pos_hi.cap = d_pos_hi ? n_pos + 64 : 0;
+            ix->pos_fmt = fmt;
+            ix->pbits = pbits;
             ix->n_pos = n_pos;
             ix->built = true;
             ix->build_ms = ms;
@@ -188,6 +198,8 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
     DP_HIP(hipMemcpyAsync(&total, (uint64_t*)ix->off.p + nk, 8, hipMemcpyDeviceToHost, ctx->stream));
     DP_HIP(dp_stream_sync(ctx));
     if (dev_reserve(ctx, ix->pos, total * 8 + 64)) return DP_ERR_HIP;
+    ix->pos_fmt = 8;
+    ix->pbits = 32;
     DP_HIP(hipMemsetAsync(d_counts, 0, nk * 4, ctx->stream));
     if (ow->n_reads)
         hipLaunchKernelGGL(kidx_scatter_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint8_t*)ow->d_packed.p,
@@ -205,6 +217,7 @@ void dp_kindex_free(dp_ctx* ctx) {
     if (ctx->owner || !ctx->kidx) return;
     if (ctx->kidx->off.p) dp_dev_free(ctx->kidx->off.p);
     if (ctx->kidx->pos.p) dp_dev_free(ctx->kidx->pos.p);
+    if (ctx->kidx->pos_hi.p) dp_dev_free(ctx->kidx->pos_hi.p);
     delete ctx->kidx;
     ctx->kidx = nullptr;
 }
@@ -357,7 +370,7 @@ struct kidx_walk {
     // (round 4: a launch may be narrower than its work - `n_waves` wave-sized pieces, walked with the grid's stride: the count
     // walk's 160 k lanes of dependent random loads and atomics are what slows every other round's kernels)
     static __device__ void run(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
-                               const uint64_t* __restrict__ pos, const dp_scan_item* __restrict__ items, uint32_t lo, uint32_t hi,
+                               const KxPos pos, const dp_scan_item* __restrict__ items, uint32_t lo, uint32_t hi,
                                uint32_t n_read_items, const uint32_t* __restrict__ head, const uint32_t* __restrict__ next,
                                uint32_t* __restrict__ counts, uint32_t* __restrict__ fillc, const uint64_t* __restrict__ segoff,
                                int32_t* __restrict__ segs, unsigned long long* __restrict__ n_hits, uint32_t lps,
@@ -367,7 +380,7 @@ struct kidx_walk {
             one(w, seeds, n_seeds, off, pos, items, lo, hi, n_read_items, head, next, counts, fillc, segoff, segs, n_hits, lps, dbg, R);
     }
     static __device__ void one(const uint32_t w, const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
-                                                 const uint64_t* __restrict__ pos, const dp_scan_item* __restrict__ items,
+                                                 const KxPos pos, const dp_scan_item* __restrict__ items,
                                                  uint32_t lo, uint32_t hi, uint32_t n_read_items, const uint32_t* __restrict__ head,
                                                  const uint32_t* __restrict__ next, uint32_t* __restrict__ counts,
                                                  uint32_t* __restrict__ fillc, const uint64_t* __restrict__ segoff,
@@ -449,7 +462,7 @@ struct kidx_walk {
         for (int u = 0; u < 4; u++) {
             const uint32_t i = ib + (uint32_t)u * step;
             v[u] = i < i1;
-            e[u] = v[u] ? pos[o + i] : 0ull;
+            e[u] = v[u] ? kx_entry(pos, o + i) : 0ull;
         }
         KX_TICK(2)
         dp_scan_item item[4];
@@ -763,8 +776,7 @@ struct kidx_sortwrite {
 // lanes per seed of kidx_walk: by the mean bucket size of the index (positions / 4^k)
 static uint32_t kidx_lps(const dp_kindex* ix, int k) {
     const uint64_t nk = (uint64_t)1 << (2 * k);
-    const uint64_t n_pos = ix->pos.cap / 8;
-    return n_pos / nk >= 128 ? 64u : 16u;
+    return ix->n_pos / nk >= 128 ? 64u : 16u;
 }
 static uint32_t kidx_walk_blocks(const dp_kindex* ix, int k, uint32_t S) {
     const uint32_t waves = kidx_lps(ix, k) == 64 ? S * KX_PARTS : (S + 3) / 4;
@@ -776,7 +788,7 @@ static uint32_t kidx_walk_blocks(const dp_kindex* ix, int k, uint32_t S) {
 // returning atomics on a scratch array of the counters' size, no index reads.  How much a whole job slows down with each says
 // which half is what the other rounds' kernels wait for (profiles/r04/ab_walkdummy.txt).
 __global__ void kx_dummy_kernel(int mode, const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
-                                const uint64_t* __restrict__ pos, uint32_t* __restrict__ scratch, uint32_t n_scratch, uint32_t n_ops) {
+                                const KxPos pos, uint32_t* __restrict__ scratch, uint32_t n_scratch, uint32_t n_ops) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (mode >= 10) return;  // (10 + n: n empty launches - what a launch costs the other slots' rounds)
     if (mode == 1) {
@@ -785,7 +797,7 @@ __global__ void kx_dummy_kernel(int mode, const uint32_t* __restrict__ seeds, ui
         const uint64_t o = off[seeds[s]];
         const uint32_t n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
         unsigned long long acc = 0;
-        for (uint32_t i = i0; i < n; i += 16) acc += pos[o + i];
+        for (uint32_t i = i0; i < n; i += 16) acc += kx_entry(pos, o + i);
         if (acc == 0x123456789abcdefull) scratch[0] = 1;  // (never: keeps the loads alive)
     } else {
         if (t >= n_ops) return;
@@ -877,7 +889,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     }
     if (S)
         dp_launch<kidx_walk<false>>(ctx, dim3(kidx_walk_grid(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
-                           (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
+                           (const uint64_t*)ix->off.p, ix->view(), d_items, lo, hi, n_read_items, (const uint32_t*)head,
                            (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k), dbg, R,
                            kidx_walk_blocks(ix, k, S) * 4);
     {
@@ -890,7 +902,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             const uint32_t thr = dummy >= 10 ? 64u : dummy == 1 ? S * 16 : ops;
             for (int rep = 0; rep < (dummy >= 10 ? dummy - 10 : 1); rep++)
                 hipLaunchKernelGGL(kx_dummy_kernel, dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, dummy, dp_seeds_ptr(ctx), S,
-                                   (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, (uint32_t*)scratch, n_items, ops);
+                                   (const uint64_t*)ix->off.p, ix->view(), (uint32_t*)scratch, n_items, ops);
         }
     }
     if (kx_debug) {
@@ -983,7 +995,7 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     } else if (n_sel) {
         if (S)
             dp_launch<kidx_walk<true>>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
-                               (const uint64_t*)ix->off.p, (const uint64_t*)ix->pos.p, d_items, lo, hi, n_read_items, (const uint32_t*)head,
+                               (const uint64_t*)ix->off.p, ix->view(), d_items, lo, hi, n_read_items, (const uint32_t*)head,
                                (const uint32_t*)next, (uint32_t*)d_counts, fillc, d_segoff, d_segs, (unsigned long long*)nullptr, kidx_lps(ix, k),
                                (unsigned long long*)nullptr, KxRec{nullptr, nullptr, nullptr, 0u, nullptr, 0u, 0u}, kidx_walk_blocks(ix, k, S) * 4);
         const dim3 sg(std::min<uint32_t>(n_sel, 16384)), sb(64);

@@ -219,6 +219,24 @@ def test_overlap_kmer_index_mode(mode):
         del os.environ["DP_SCAN_INDEX"]
 
 
+@pytest.mark.parametrize("env", [{"DP_KINDEX_WIDE": "1"}, {"DP_KB_B1": "9"}, {"DP_KB_MIN_PBITS": "22"}, {"DP_KB_MIN_PBITS": "30"},
+                                 {"DP_KB_STREAMS": "1"}, {"DP_KB_STREAMS": "1", "DP_KB_B1": "8"}, {"DP_KB_STREAMS": "1", "DP_KB_MIN_PBITS": "22"},
+                                 {"DP_KB_STREAMS": "1", "DP_KB_MIN_PBITS": "29"}, {"DP_KB_STREAMS": "1", "DP_KB_MIN_PBITS": "22", "DP_KB_B1": "10"},
+                                 {"DP_KB_STREAMS": "1", "DP_KINDEX_WIDE": "1"}, {"DP_KINDEX_ATOMIC": "1"}])
+def test_kmer_index_entry_formats(monkeypatch, env):
+    """The resident k-mer position index stores an entry in 4, 5 or 8 bytes; between the build's passes entries travel as 64-bit
+    words or (DP_KB_STREAMS=1) in two streams of 4 + 0 / 1 / 2 / 4 bytes (dp_kbuild.hip): every format (reached on small inputs
+    through DP_KB_MIN_PBITS, which only wastes bits), other widths of the first pass, the all-eight-bytes build and the atomic
+    scatter build give the oracle's PAF."""
+    monkeypatch.setenv("DP_SCAN_INDEX", "1")
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    _, st = _run_both(114, 1200000, 2000, 12000, 13, 0.002, True, max_rounds=4, slots=2)
+    assert st["idx_rounds"] > 0 and st["idx_hits"] > 0
+    _, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=2)
+    assert st["idx_rounds"] > 0
+
+
 def test_overlap_kmer_index_unavailable_falls_back_to_scan():
     """k above the direct-addressed table's limit (14; lowered here through DP_KINDEX_MAX_K) or too little free HBM: the
     index reports itself unavailable and the rounds scan."""
