@@ -123,6 +123,7 @@ struct dp_ctx {
     // dp_stream_sync
     std::vector<uint8_t> stage_buf;
     size_t stage_used = 0;
+    size_t mcover_off = 0;                   // ints from d_manchor to the matches' covered bases (dp_match_anchors_launch)
     uint32_t cons_large_rounds = 0;          // rounds for which the large consensus layout is still launched at once (a recent round listed a window for it)
     bool cons_huge = false;                  // a window of an earlier round did not fit the large consensus layout: the huge one follows it from now on
     uint32_t cons_prev_pairs = 0;            // pairs of the previous round's chaining stage (output bound of a pending one)
@@ -314,6 +315,18 @@ __device__ __forceinline__ int wave_sum(int v) {
 // The same sum over the data-parallel-primitive path of the vector unit (six VALU instructions and a read-out instead of six
 // trips through the LDS crossbar, which is what __shfl_xor compiles to: ~60 cycles against ~400).  Needs every lane of the wave
 // active (rows take their neighbours' values whether those lanes are live or not).
+// Inclusive prefix sum over the 64 lanes on the same path (the classic row_shr / row_bcast sequence).  Every lane active.
+__device__ __forceinline__ int wave_incl_sum_dpp(int v) {
+    int x = v;
+    x += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, false);  // row_shr:3: sums of up to four neighbours inside a row
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xe, false);  // row_shr:4 into lanes 4-15 of each row
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xc, false);  // row_shr:8 into lanes 8-15: inclusive sums inside rows of 16
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return x;
+}
 __device__ __forceinline__ int wave_sum_dpp(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
     v += __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false);   // quad_perm:[2,3,0,1]
@@ -322,5 +335,39 @@ __device__ __forceinline__ int wave_sum_dpp(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
     return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_dpp(int v) {  // (as wave_sum_dpp; every lane active)
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xb1, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4e, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// Exclusive prefix of tile `tile` from the status words of its predecessors (flag << 62 | value; flag 1 = a tile's own value, 2 = its
+// inclusive prefix), looked back at by a whole wave at once: lane l reads tile - 1 - l.  With a few dozen tiles that all start
+// together - the per-round scans here - a single thread walking back hop by hop (a dependent trip to memory each) WAS the kernel:
+// tile 24 made 24 hops.  The caller's lane 0 has published the tile's own value before; every lane of the wave takes part.
+__device__ __forceinline__ unsigned long long dp_wave_lookback(const unsigned long long* status, uint32_t tile, int lane) {
+    unsigned long long excl = 0;
+    for (long long base = (long long)tile - 1; base >= 0; base -= 64) {
+        const long long t = base - lane;
+        unsigned long long v = 0;
+        if (t >= 0) {
+            do {
+                v = __hip_atomic_load(&status[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((v >> 62) == 0);
+        }
+        const unsigned long long done = __ballot(t >= 0 && (v >> 62) == 2);
+        const int stop = done ? __builtin_ctzll(done) : 63;
+        const unsigned long long x = (t >= 0 && lane <= stop) ? (v & ((1ull << 62) - 1)) : 0ull;
+        // (a 62-bit sum over 64 lanes as three sums of 25 + 25 + 12 bits)
+        const unsigned long long lo = (unsigned)wave_sum_dpp((int)(x & 0x1ffffffull)), mid = (unsigned)wave_sum_dpp((int)((x >> 25) & 0x1ffffffull)),
+                                 hi = (unsigned)wave_sum_dpp((int)(x >> 50));
+        excl += lo + (mid << 25) + (hi << 50);
+        if (done) break;
+    }
+    return excl;
 }
 #endif

@@ -358,7 +358,7 @@ struct CFWaveT {
     int32_t GA[C::A + 2];     // G(i) = sum_{j=1..i} (a[2j] + k) over the forward query
     uint32_t mpair[C::M];     // pair slot of every match of the group
     int32_t tLen[64], tOff[64], tIns[64], tId[64];
-    uint16_t tb[64], tN[64], rb[64], rN[64], mLen[64];
+    uint16_t tb[64], tN[64], rb[64], rN[64], mLen[64], cum[64];
     uint8_t tRc[64], ord[64];
 };
 
@@ -409,6 +409,7 @@ struct ConsFullArgs {
     const dp_seq_meta* smeta;
     const int32_t* rc_of;
     const int32_t* anchors;    // [2 * pairs] match_anchor_kernel
+    const int32_t* cover;      // [2 * pairs] likewise: GetBasesCovered of the match on the query and on the target side (INT32_MIN / + 1: a list the reference would panic on)
     const uint32_t* read_len;
     int k, overlap_size;
     dp_paf_rec* paf;           // [pairs]: lines of group g start at slot pbase[2g]
@@ -511,6 +512,13 @@ struct consensus_full_kernel {
         __builtin_amdgcn_wave_barrier();
         const int a_first = aSeg[0], a_last = aSeg[nA - 1], GA_end = L.GA[sA - 1];
         CF_TICK(1);
+#ifdef CF_TRIMPROF
+        unsigned long long tpT[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp0 = 0;
+#define CF_TP(i_) if (A.dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); const unsigned long long n_ = wall_clock64(); tpT[i_] += n_ - tp0; tp0 = n_; }
+        if (A.dbg) tp0 = wall_clock64();
+#else
+#define CF_TP(i_)
+#endif
         // ---- 2. per match: filter + Trimmed().  One lane per match; everything a lane does is its own little loop.
         int nseq = 0, tUsed = 0;
         bool bad = false, laneWide = false;
@@ -527,6 +535,8 @@ struct consensus_full_kernel {
             bool isRc = false;
             const int32_t* S = nullptr;
             uint32_t t = 0;
+            int anc0 = 0, anc1 = 0;
+            dp_seq_meta sm = {};
             if (mi < nm) {
                 const uint32_t p = L.mpair[mi];
                 const uint32_t rq = A.recs[4 * (size_t)p], off = A.recs[4 * (size_t)p + 2];
@@ -534,52 +544,21 @@ struct consensus_full_kernel {
                 const int len = (int)A.recs[4 * (size_t)p + 3];
                 algB += 16u + 8u * (unsigned)len + 8u + 16u;
                 isRc = rq == qr;
+                // (asked for here, used after the chain walk: two trips to memory that used to start when the walk was over)
+                anc0 = A.anchors[2 * (size_t)p], anc1 = A.anchors[2 * (size_t)p + 1];
+                sm = A.smeta[t];
                 const int32_t* MA = A.ma + off;
                 const int32_t* MB = A.mb + off;
                 const dp_seq_ref ref = A.refs[t];
                 S = A.segs + ref.seg_off;
                 ns = (int)ref.n_seeds;
-                // GetBasesCovered on both sides (seeds/sequence.go:830): len*k plus the negative gaps between consecutive
-                // matched seeds; reversing both sequences (rc query) leaves the set of gaps unchanged, so the lists are used
-                // as they came
-                int ca = len * k, cb = len * k;
-                int prevA = MA[0], prevB = MB[0];
-                if (prevA < 0 || prevA >= sA || prevB < 0 || prevB >= ns) laneBad = true, laneWhy = 10u;
-                // (eight matched pairs per trip: their sixteen loads, then the first gap of each pair's stretch of the target - nearly
-                // always the whole stretch - are issued together; one pair per trip was a chain of two dependent loads per pair)
-                for (int i0 = 1; i0 < len && !laneBad; i0 += 8) {
-                    int av[8], bv[8], g0[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const bool v = i0 + u < len;
-                        av[u] = v ? MA[i0 + u] : 0;
-                        bv[u] = v ? MB[i0 + u] : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int pb = u == 0 ? prevB : bv[u - 1];
-                        const int j = min(max(pb + 1, 0), ns);  // (clamped: a list the checks below reject must not be followed)
-                        g0[u] = i0 + u < len ? S[2 * j] : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        if (i0 + u >= len || laneBad) continue;
-                        const int a1 = av[u], b1 = bv[u];
-                        if (a1 >= sA || a1 < 0 || b1 >= ns || b1 < 0) {
-                            laneBad = true;  // the reference would panic inside GetBasesCovered: leave the group to the host path
-                            laneWhy = 11u;
-                            continue;
-                        }
-                        const int dA = isRc ? L.GA[sA - 1 - prevA] - L.GA[sA - 1 - a1] - k : L.GA[a1] - L.GA[prevA] - k;
-                        int dB = -k;
-                        if (b1 >= prevB + 1) dB += g0[u] + k;
-                        for (int j = prevB + 2; j <= b1; j++) dB += S[2 * j] + k;
-                        if (dA < 0) ca += dA;
-                        if (dB < 0) cb += dB;
-                        prevA = a1;
-                        prevB = b1;
-                    }
-                }
+                // GetBasesCovered on both sides (seeds/sequence.go:830): computed per matched pair by the anchors launch
+                // (match_anchor_kernel, dp_overlap.hip), read here
+                const int ca = A.cover[2 * (size_t)p], cb = A.cover[2 * (size_t)p + 1];
+                if (ca == DP_NO_ANCHOR) laneBad = true, laneWhy = 10u;           // first pair outside the query / the target
+                else if (ca == DP_NO_ANCHOR + 1) laneBad = true, laneWhy = 11u;  // a later one: the reference would panic inside GetBasesCovered
+                CF_TP(0)
+                CF_TP(1)
                 if (!laneBad && ca >= 25 && cb >= 25) {
                     // indices in the forward query / in X (X = the target, or its reverse complement for a match of the rc query)
                     const int m_first = MA[0], m_last = MA[len - 1], t_first = MB[0], t_last = MB[len - 1];
@@ -590,7 +569,7 @@ struct consensus_full_kernel {
                     endOffset = a_last + GA_end - L.GA[aL];    // ... GetSeedOffsetFromEnd(MatchA[last])
                     // X.GetSeedOffset(startSeed) / X.GetSeedOffsetFromEnd(endSeed) from the match's anchors on the forward
                     // target (match_anchor_kernel): R.seedOffset(i) = S.seedOffsetFromEnd(ns-1-i) and vice versa
-                    int anchorStart = A.anchors[2 * (size_t)p + (isRc ? 1 : 0)], anchorEnd = A.anchors[2 * (size_t)p + (isRc ? 0 : 1)];
+                    int anchorStart = isRc ? anc1 : anc0, anchorEnd = isRc ? anc0 : anc1;
                     if (anchorStart == DP_NO_ANCHOR || anchorEnd == DP_NO_ANCHOR) laneBad = true, laneWhy = 12u;
                     // X.seg[2t] = S[2t] (forward) or S[2(ns - t)] (reverse complement)
                     while (startSeed > 0) {
@@ -614,6 +593,7 @@ struct consensus_full_kernel {
                     keep = !laneBad;
                 }
             }
+            CF_TP(2)
             if (__ballot(laneBad)) {
                 bad = true;
                 badWhy = (uint32_t)__shfl((int)laneWhy, __builtin_ctzll(__ballot(laneBad)), 64);
@@ -628,29 +608,29 @@ struct consensus_full_kernel {
                 badWhy = nseq + nKeep > 64 ? 8u : 9u;
                 break;
             }
+            CF_TP(3)
             if (keep) {
                 const int sq = nseq + __popcll(keepMask & lanesBelow);
                 const int tb = tUsed + incl - nT;
-                const dp_seq_meta sm = A.smeta[t];
                 algB += 16u + 4u * (unsigned)nT;
                 const int nB = 2 * ns + 1;
                 int wide = 0;  // (small layout: a value that does not fit 16 bits sends the window to the large one)
-                for (int j0 = 0; j0 < nT; j0 += 8) {  // (eight loads in flight per trip, then - reverse complement - their eight look-ups)
-                    int vv[8];
+                for (int j0 = 0; j0 < nT; j0 += 16) {  // (sixteen loads in flight per trip, then - reverse complement - their look-ups)
+                    int vv[16];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
+                    for (int u = 0; u < 16; u++) {
                         const int x = 2 * startSeed + j0 + u;  // index in X
                         vv[u] = j0 + u < nT ? (isRc ? S[nB - 1 - x] : S[x]) : 0;
                     }
                     if (isRc) {
 #pragma unroll
-                        for (int u = 0; u < 8; u++) {
+                        for (int u = 0; u < 16; u++) {
                             const int x = 2 * startSeed + j0 + u;
                             if (j0 + u < nT && (x & 1)) vv[u] = A.rc_of[vv[u]];
                         }
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
+                    for (int u = 0; u < 16; u++) {
                         if (j0 + u >= nT) continue;
                         L.T[tb + j0 + u] = (elem_t)vv[u];
                         wide |= (vv[u] != (int)(elem_t)vv[u]);
@@ -668,6 +648,7 @@ struct consensus_full_kernel {
                 L.tId[sq] = (int32_t)sm.read;
                 L.tRc[sq] = isRc ? 1 : 0;
             }
+            CF_TP(4)
             nseq += nKeep;
             tUsed += total;
         }
@@ -678,81 +659,140 @@ struct consensus_full_kernel {
         }
         __builtin_amdgcn_wave_barrier();
         CF_TICK(2);
-        // ---- 3. seeds shared by >= 2 sequences (GetSharedIDs(.., 2, true)), Reduced() of every sequence (seeds/sequence.go:85):
-        //         one lane per sequence
-        for (int i = lane; i < CF::HASH; i += 64) L.hash[i] = 0;
-        __builtin_amdgcn_wave_barrier();
+        // ---- 3. seeds shared by >= 2 sequences (GetSharedIDs(.., 2, true)), Reduced() of every sequence (seeds/sequence.go:85).
+        //         Round 4: the hash is filled and asked by ALL lanes over ALL seeds of the window (seed f of the window belongs to
+        //         sequence own[f]; a lane takes every 64th seed - thirteen of a mean window's eight hundred - where a lane per
+        //         sequence walked the forty to sixty of the longest one, one hash probe after the other), the verdict goes into the
+        //         seed's own top bit, and ONE walk per sequence - loads eight seeds ahead, no probes - writes the reduced form
+        //         (its room is sized for "every seed kept", so nobody counts first).
+        {
+            const uint4 z = {0u, 0u, 0u, 0u};
+            for (int i = lane; i < CF::HASH / 4; i += 64) ((uint4*)L.hash)[i] = z;
+        }
         const bool mine = lane < nseq;
         const int tb_ = mine ? L.tb[lane] : 0;
         const int nsT_ = mine ? (L.tN[lane] >> 1) : 0;
-        for (int i = 0; i < nsT_; i++) {
-            const uint32_t seed = (uint32_t)L.T[tb_ + 2 * i + 1];
-            uint32_t h = (seed * 2654435761u) >> CF::HSHIFT;
-            for (;;) {
-                const uint32_t e = L.hash[h];
-                if (e == 0) {
-                    const uint32_t old = atomicCAS(&L.hash[h], 0u, ((seed + 1) << 8) | (uint32_t)lane);
-                    if (old == 0) break;
-                    continue;  // somebody else took the slot: look at it again
-                }
-                if ((e >> 8) == seed + 1) {
-                    if ((e & 63u) != (uint32_t)lane && !(e & 128u)) atomicOr(&L.hash[h], 128u);
-                    break;
-                }
-                h = (h + 1) & (CF::HASH - 1);
+        constexpr uint32_t SHARED_BIT = 1u << (8 * (int)sizeof(elem_t) - 1);  // (seed ids stay below it: 15 bits in the small layout, 31 otherwise)
+        uint8_t* const own = (uint8_t*)L.Rmap;  // (Rmap is written by the walk below, when nobody asks for owners any more)
+        int totalSeeds;
+        {
+            const int incl = wave_incl_sum_dpp(nsT_);
+            totalSeeds = __builtin_amdgcn_readlane(incl, 63);
+            if (mine) L.cum[lane] = (uint16_t)(incl - nsT_);
+            for (int sq_ = 0; sq_ < nseq; sq_++) {
+                const int c0 = __builtin_amdgcn_readlane(incl - nsT_, sq_), n0 = __builtin_amdgcn_readlane(nsT_, sq_);
+                for (int i = lane; i < n0; i += 64) own[c0 + i] = (uint8_t)sq_;
             }
         }
         __builtin_amdgcn_wave_barrier();
-        auto cf_shared = [&](int seed) -> bool {
-            uint32_t h = ((uint32_t)seed * 2654435761u) >> CF::HSHIFT;
-            for (;;) {
-                const uint32_t e = L.hash[h];
-                if (e == 0) return false;
-                if ((e >> 8) == (uint32_t)seed + 1) return (e & 128u) != 0;
-                h = (h + 1) & (CF::HASH - 1);
+        // fill: eight seeds per lane and trip - their owners, then their places, then the seeds themselves are loaded together,
+        // the eight first probes (a compare-and-swap each) travel together; only a probe that met another seed walks on alone
+        for (int f0 = 0; f0 < totalSeeds; f0 += 512) {
+            int sq8[8], at8[8];
+            uint32_t sd8[8], old8[8], h8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int f = f0 + 64 * u + lane;
+                sq8[u] = f < totalSeeds ? (int)own[f] : -1;
             }
-        };
-        int kept = 0;
-        u64 keptMask = 0;  // (the first 64 seeds' verdicts: the second walk below does not probe the hash again for them)
-        {
-            int prev = -1;
-            for (int i = 0; i < nsT_; i++) {
-                const int seed = L.T[tb_ + 2 * i + 1];
-                if (seed != prev && cf_shared(seed)) {
-                    kept++;
-                    prev = seed;
-                    if (i < 64) keptMask |= 1ull << i;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int f = f0 + 64 * u + lane;
+                at8[u] = sq8[u] >= 0 ? (int)L.tb[sq8[u]] + 2 * (f - (int)L.cum[sq8[u]]) + 1 : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) sd8[u] = sq8[u] >= 0 ? (uint32_t)L.T[at8[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                h8[u] = (sd8[u] * 2654435761u) >> CF::HSHIFT;
+                old8[u] = sq8[u] >= 0 ? atomicCAS(&L.hash[h8[u]], 0u, ((sd8[u] + 1) << 8) | (uint32_t)sq8[u]) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (sq8[u] < 0) continue;
+                uint32_t e = old8[u], h = h8[u];
+                const uint32_t mineV = ((sd8[u] + 1) << 8) | (uint32_t)sq8[u];
+                while (e != 0) {  // (0: the slot was free and is this seed's now)
+                    if ((e >> 8) == sd8[u] + 1) {
+                        if ((e & 63u) != (uint32_t)sq8[u] && !(e & 128u)) atomicOr(&L.hash[h], 128u);
+                        break;
+                    }
+                    h = (h + 1) & (CF::HASH - 1);
+                    e = atomicCAS(&L.hash[h], 0u, mineV);
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        // ask: the same walk over all seeds; a shared seed gets its top bit set where it lies
+        for (int f0 = 0; f0 < totalSeeds; f0 += 512) {
+            int sq8[8], at8[8];
+            uint32_t sd8[8], e8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int f = f0 + 64 * u + lane;
+                sq8[u] = f < totalSeeds ? (int)own[f] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int f = f0 + 64 * u + lane;
+                at8[u] = sq8[u] >= 0 ? (int)L.tb[sq8[u]] + 2 * (f - (int)L.cum[sq8[u]]) + 1 : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) sd8[u] = sq8[u] >= 0 ? (uint32_t)L.T[at8[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) e8[u] = sq8[u] >= 0 ? L.hash[(sd8[u] * 2654435761u) >> CF::HSHIFT] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (sq8[u] < 0) continue;
+                uint32_t e = e8[u], h = (sd8[u] * 2654435761u) >> CF::HSHIFT;
+                while (e != 0 && (e >> 8) != sd8[u] + 1) {
+                    h = (h + 1) & (CF::HASH - 1);
+                    e = L.hash[h];
+                }
+                if (e & 128u) L.T[at8[u]] = (elem_t)(sd8[u] | SHARED_BIT);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
         {
-            const int slot = kept >= 1 ? 2 * kept + 2 : 0;  // (even: Rmap / cm arrays are indexed by rb >> 1)
-            const int incl = wave_incl_sum(slot);
-            const int totalR = __shfl(incl, 63, 64);
+            // room for sequence s in R: as if every seed were kept (2 * seeds + 2 ints: even, Rmap / cm arrays are indexed by rb >> 1)
+            const int slot = mine ? 2 * nsT_ + 2 : 0;
+            const int incl = wave_incl_sum_dpp(slot);
+            const int totalR = __builtin_amdgcn_readlane(incl, 63);
             if (totalR + 2 >= CF::R) CF_NOFIT(4u)
             if (mine) {
                 const int rb = incl - slot;
-                L.rb[lane] = rb;
-                L.rN[lane] = kept >= 1 ? 2 * kept + 1 : 0;
-                if (kept >= 1) {
-                    int prev = -1, r = 0, offset = L.T[tb_];
-                    for (int i = 0; i < nsT_; i++) {
-                        const int seed = L.T[tb_ + 2 * i + 1];
-                        if (i < 64 ? ((keptMask >> i) & 1ull) != 0 : (seed != prev && cf_shared(seed))) {
+                int prev = -1, r = 0, offset = nsT_ > 0 ? (int)L.T[tb_] : 0;
+                for (int i0 = 0; i0 < nsT_; i0 += 8) {
+                    int sv[8], gp[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const bool in = i0 + u < nsT_;
+                        sv[u] = in ? (int)L.T[tb_ + 2 * (i0 + u) + 1] : 0;
+                        gp[u] = in ? (int)L.T[tb_ + 2 * (i0 + u) + 2] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (i0 + u >= nsT_) continue;
+                        const int seed = (int)((uint32_t)sv[u] & (SHARED_BIT - 1u));
+                        if (((uint32_t)sv[u] & SHARED_BIT) && seed != prev) {
                             L.R[rb + 2 * r] = (elem_t)offset;
                             laneWide |= SMALL && offset != (int)(elem_t)offset;
                             L.R[rb + 2 * r + 1] = (elem_t)seed;
-                            L.Rmap[(rb >> 1) + r] = (uint16_t)i;
+                            L.Rmap[(rb >> 1) + r] = (uint16_t)(i0 + u);
                             r++;
-                            offset = L.T[tb_ + 2 * i + 2];
+                            offset = gp[u];
                             prev = seed;
                         } else {
-                            offset += L.T[tb_ + 2 * i + 2] + k;
+                            offset += gp[u] + k;
                         }
                     }
+                }
+                if (r >= 1) {
                     L.R[rb + 2 * r] = (elem_t)offset;
                     laneWide |= SMALL && offset != (int)(elem_t)offset;
                 }
+                L.rb[lane] = rb;
+                L.rN[lane] = r >= 1 ? 2 * r + 1 : 0;
             }
         }
         if (__ballot(laneWide)) CF_NOFIT(5u)
@@ -774,6 +814,10 @@ struct consensus_full_kernel {
             int near = 100000;
             const int p2s = pos + 1;
             const bool okS = sl > 0 && p2s < sl / 2;
+            // (the next seed of the sequence and its distance: loaded once per step, together - the uniform test, the proposal, the
+            // first probe of every search and of the update all look at this pair; each used to fetch it again, a trip to the LDS
+            // of ~130 cycles on the step's critical path every time)
+            const int sdNext = okS ? S[b + p2s * 2 + 1] : -1;
             const int od = okS ? S[b + p2s * 2] - offs : 0;
             {
                 // Uniform step: every sequence that still has a seed is in step (gap 0) and shows the same seed at the same
@@ -786,7 +830,6 @@ struct consensus_full_kernel {
                 const int nValid = __popcll(okMask);
                 if (nValid >= 2) {
                     const int f = __builtin_ctzll(okMask);
-                    const int sdNext = okS ? S[b + p2s * 2 + 1] : -1;
                     const int o0 = CA_RL(od, f), sd0 = CA_RL(sdNext, f);
                     const bool same = !okS || (od == o0 && sdNext == sd0 && gaps == 0);
                     if (__ballot(same) == ~0ull && o0 > -k && o0 < 100000) {
@@ -818,10 +861,10 @@ struct consensus_full_kernel {
             const bool fin = !mine || sl == 0 || pos >= (sl - 1) / 2 - 1;
             int fCount = __popcll(__ballot(fin && mine));
             int d = 0, nextSeed = 0, minD = 0, maxD = 0;
-            if (!fin) {
-                d = S[b + pos * 2 + 2] - offs;
+            if (!fin) {  // (!fin == okS: pos + 1 < seeds; so the proposal is the pair above)
+                d = od;
                 dist = d;
-                nextSeed = S[b + pos * 2 + 3];
+                nextSeed = sdNext;
                 ca_gap_range(d + gaps, k, minD, maxD);
                 minD -= gaps;
                 maxD -= gaps;
@@ -858,20 +901,22 @@ struct consensus_full_kernel {
                     ca_gap_range(di + gaps, k, min2, max2);
                     if (min2 > minI) min2 = minI;
                     if (max2 < maxI) max2 = maxI;
-                    int p2 = p2s, otherD = od;
+                    int p2 = p2s, otherD = od, curSeed = sdNext;
                     while (otherD < min2 && p2 < sl / 2) {
                         if (A.dbg) dbgT[5]++;
                         p2++;
                         otherD += S[b + p2 * 2] + k;
+                        curSeed = S[b + p2 * 2 + 1];  // (one int past the sequence when p2 reaches its end: inside its room in R, never used)
                     }
                     while (otherD < max2 && p2 < sl / 2) {
-                        if (S[b + p2 * 2 + 1] == seedI) {
+                        if (curSeed == seedI) {
                             fnd = true;
                             val = otherD;
                             break;
                         }
                         p2++;
                         otherD += S[b + p2 * 2] + k;
+                        curSeed = S[b + p2 * 2 + 1];
                     }
                 }
                 cntAll = __popcll(__ballot(fnd));
@@ -955,14 +1000,15 @@ struct consensus_full_kernel {
                     ca_gap_range(mindist + gaps, k, min2, max2);
                     if (min2 > selMin) min2 = selMin;
                     if (max2 < selMax) max2 = selMax;
-                    int otherD = S[b + matchDex * 2] - offs;
+                    int otherD = od, curSeed = sdNext;  // (matchDex == p2s)
                     while (otherD < min2 && matchDex < sl / 2) {
                         matchDex++;
                         otherD += S[b + matchDex * 2] + k;
+                        curSeed = S[b + matchDex * 2 + 1];
                     }
                     bool found = false;
                     while (otherD < max2 && matchDex < sl / 2) {
-                        if (S[b + matchDex * 2 + 1] == minseed) {
+                        if (curSeed == minseed) {
                             pos = matchDex;
                             offs = 0;
                             gaps = 0;
@@ -974,6 +1020,7 @@ struct consensus_full_kernel {
                         }
                         matchDex++;
                         otherD += S[b + matchDex * 2] + k;
+                        curSeed = S[b + matchDex * 2 + 1];
                     }
                     finC = false;
                     if (!found) {
@@ -1001,7 +1048,11 @@ struct consensus_full_kernel {
         if (A.dbg && lane == 0) {
             A.dbg[16 * (size_t)g + 6] = ((unsigned long long)dbgUni << 32) | dbgGen;
             A.dbg[16 * (size_t)g + 7] = ((unsigned long long)nseq << 32) | dbgProp;
+#ifdef CF_TRIMPROF
+            for (int i = 0; i < 8; i++) A.dbg[16 * (size_t)g + 8 + i] = tpT[i];
+#else
             for (int i = 0; i < 8; i++) A.dbg[16 * (size_t)g + 8 + i] = dbgT[i];
+#endif
         }
         if (__ballot(bad)) CF_NOFIT(6u)  // consensus longer than CONS, a value outside the safe range
         if (lane == 0) L.cons[clen] = 0;
@@ -1269,6 +1320,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
         if (rc != 0) return rc;
     }
     A.anchors = (const int32_t*)ctx->d_manchor.p;
+    A.cover = A.anchors + ctx->mcover_off;
     A.read_len = (const uint32_t*)ctx->d_len.p;
     A.k = k;
     A.overlap_size = overlap_size;

@@ -559,33 +559,31 @@ struct kidx_offsets {
     if (threadIdx.x == 0) tile_s = atomicAdd(ticket, 1u);  // tiles start in ticket order: a predecessor is always running or done
     __syncthreads();
     const uint32_t tile = tile_s;
-    if (tile == 0 && threadIdx.x < 64) {  // seed occurrences of the round (kidx_walk<false> has finished: stream order)
-        unsigned long long h = n_hits[threadIdx.x];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d, 64);
-        if (threadIdx.x == 0) totals[2] = h;
-    }
     // KX_IPT consecutive items per thread: a quarter of the tiles, a quarter of the look-back chain
     const uint32_t i0 = (tile * KX_TILE + threadIdx.x) * KX_IPT;
     uint32_t cc[KX_IPT], seg = 0, fl = 0, segv[KX_IPT], flv[KX_IPT], cmax = 0;
+    // (every item's two loads are asked for before the first is looked at: inside an `if (i < n)` each item was a trip to memory of its
+    // own - a microsecond per item and thread, which is what made 8 and 16 items per thread slower than 4)
+    uint32_t msv[KX_IPT];
 #pragma unroll
     for (int u = 0; u < KX_IPT; u++) {
-        const uint32_t i = i0 + u;
-        cc[u] = 0;
-        flv[u] = 0;
-        segv[u] = 0;
-        if (i < n) {
-            cc[u] = counts[i];
-            flv[u] = cc[u] >= items[i].min_seeds ? 1u : 0u;
-            segv[u] = flv[u] ? 2u * cc[u] + 1u : 0u;
-            if (flv[u]) cmax = max(cmax, cc[u]);
-        }
+        const uint32_t i = min(i0 + (uint32_t)u, n - 1u);
+        cc[u] = counts[i];
+        msv[u] = items[i].min_seeds;
+    }
+#pragma unroll
+    for (int u = 0; u < KX_IPT; u++) {
+        const bool in = i0 + (uint32_t)u < n;
+        cc[u] = in ? cc[u] : 0u;
+        flv[u] = in && cc[u] >= msv[u] ? 1u : 0u;
+        segv[u] = flv[u] ? 2u * cc[u] + 1u : 0u;
+        if (flv[u]) cmax = max(cmax, cc[u]);
         seg += segv[u];
         fl += flv[u];
     }
     // block scans of both quantities (segment lengths of a tile stay far below 2^32: checked by the caller's caps)
     const int lane = dp_lane(), wave = threadIdx.x >> 6;
-    uint32_t xs = (uint32_t)wave_incl_sum((int)seg), xf = (uint32_t)wave_incl_sum((int)fl);
+    uint32_t xs = (uint32_t)wave_incl_sum_dpp((int)seg), xf = (uint32_t)wave_incl_sum_dpp((int)fl);
     if (lane == 63) {
         shA[wave] = xs;
         shB[wave] = xf;
@@ -593,8 +591,8 @@ struct kidx_offsets {
     __syncthreads();
     if (wave == 0) {
         uint32_t a = lane < 16 ? shA[lane] : 0u, b = lane < 16 ? shB[lane] : 0u;
-        a = (uint32_t)wave_incl_sum((int)a);
-        b = (uint32_t)wave_incl_sum((int)b);
+        a = (uint32_t)wave_incl_sum_dpp((int)a);
+        b = (uint32_t)wave_incl_sum_dpp((int)b);
         if (lane < 16) {
             shA[lane] = a;
             shB[lane] = b;
@@ -606,29 +604,29 @@ struct kidx_offsets {
         xf += shB[wave - 1];
     }
     const uint32_t tot_s = shA[15], tot_f = shB[15];
-    if (cmax > 0) atomicMax(max_count, cmax);
-    if (threadIdx.x == 0) {
+    {
+        // (one atomic per wave that has a survivor: every surviving thread's own was thousands of atomics on ONE address, which the
+        // kernel's end waited for)
+        const uint32_t wmax = (uint32_t)wave_max_dpp((int)cmax);
+        if (lane == 0 && wmax > 0) atomicMax(max_count, wmax);
+    }
+    if (wave == 0) {  // (the whole wave looks back: dp_wave_lookback)
         const unsigned long long own = ((unsigned long long)tot_f << 38) | (unsigned long long)tot_s;
         unsigned long long excl = 0;
         if (tile == 0) {
-            __hip_atomic_store(&status[0], (2ull << 62) | own, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&status[0], (2ull << 62) | own, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            __hip_atomic_store(&status[tile], (1ull << 62) | own, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            for (int64_t t = (int64_t)tile - 1; t >= 0; t--) {
-                unsigned long long v;
-                do {
-                    v = __hip_atomic_load(&status[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((v >> 62) == 0);
-                excl += v & ((1ull << 62) - 1);
-                if ((v >> 62) == 2) break;
-            }
-            __hip_atomic_store(&status[tile], (2ull << 62) | (excl + own), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&status[tile], (1ull << 62) | own, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            excl = dp_wave_lookback(status, tile, lane);
+            if (lane == 0) __hip_atomic_store(&status[tile], (2ull << 62) | (excl + own), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
-        excl_s = excl;
-        if (((uint64_t)tile + 1) * KX_TILE * KX_IPT >= n) {  // last tile: totals
-            const unsigned long long all = excl + own;
-            totals[0] = all & ((1ull << 38) - 1);
-            totals[1] = all >> 38;
+        if (lane == 0) {
+            excl_s = excl;
+            if (((uint64_t)tile + 1) * KX_TILE * KX_IPT >= n) {  // last tile: totals
+                const unsigned long long all = excl + own;
+                totals[0] = all & ((1ull << 38) - 1);
+                totals[1] = all >> 38;
+            }
         }
     }
     __syncthreads();
@@ -651,6 +649,13 @@ struct kidx_offsets {
             so += segv[u];
             if (i == n - 1) segoff[n] = so;
         }
+    }
+    if (tile == 0 && threadIdx.x < 64) {  // seed occurrences of the round (kidx_walk<false> has finished: stream order); here, at the
+                                          // end, because every other tile waits for tile 0's prefix
+        unsigned long long h = n_hits[threadIdx.x];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d, 64);
+        if (threadIdx.x == 0) totals[2] = h;
     }
     // the round's totals go to the host's pinned block with the tile that finishes last (no launch of their own): every tile
     // publishes its stores and counts itself in; the one that counts the last sees them all

@@ -376,7 +376,7 @@ struct chunk_kernel {
     const int lane = dp_lane(), wave = threadIdx.x >> 6;
     const uint32_t i = tile * 1024 + threadIdx.x;
     const uint32_t cnt = i < ns ? chunk_one<false>(P, i, 0) : 0u;
-    const uint32_t x = (uint32_t)wave_incl_sum((int)cnt);
+    const uint32_t x = (uint32_t)wave_incl_sum_dpp((int)cnt);
     if (lane == 63) wsum[wave] = x;
     __syncthreads();
     uint32_t before = 0, total = 0;
@@ -384,27 +384,22 @@ struct chunk_kernel {
         if (w < wave) before += wsum[w];
         total += wsum[w];
     }
-    if (threadIdx.x == 0) {
+    if (wave == 0) {  // (the whole wave looks back: dp_wave_lookback)
         unsigned long long excl = 0;
         if (tile == 0) {
-            __hip_atomic_store(&status[0], (2ull << 62) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&status[0], (2ull << 62) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            __hip_atomic_store(&status[tile], (1ull << 62) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            for (int64_t t = (int64_t)tile - 1; t >= 0; t--) {
-                unsigned long long v;
-                do {
-                    v = __hip_atomic_load(&status[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((v >> 62) == 0);
-                excl += v & ((1ull << 62) - 1);
-                if ((v >> 62) == 2) break;
-            }
-            __hip_atomic_store(&status[tile], (2ull << 62) | (excl + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&status[tile], (1ull << 62) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            excl = dp_wave_lookback(status, tile, lane);
+            if (lane == 0) __hip_atomic_store(&status[tile], (2ull << 62) | (excl + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
-        base_s = (uint32_t)excl;
-        if ((uint64_t)(tile + 1) * 1024 >= ns) {  // last tile: the totals
-            const unsigned long long all = excl + total;
-            P.n_out[0] = (uint32_t)min(all, (unsigned long long)P.cap);
-            P.n_out[1] = all > P.cap ? 1u : 0u;
+        if (lane == 0) {
+            base_s = (uint32_t)excl;
+            if ((uint64_t)(tile + 1) * 1024 >= ns) {  // last tile: the totals
+                const unsigned long long all = excl + total;
+                P.n_out[0] = (uint32_t)min(all, (unsigned long long)P.cap);
+                P.n_out[1] = all > P.cap ? 1u : 0u;
+            }
         }
     }
     __syncthreads();
@@ -2051,7 +2046,9 @@ struct match_anchor_kernel {
     static __device__ void run(const MRec* __restrict__ recs, const uint32_t* __restrict__ n_pairs,
                                                            uint32_t pair_cap, const int32_t* __restrict__ mb,
                                                            const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, int k,
-                                                           int32_t* __restrict__ anchors, const AnchorFetch F, uint32_t* __restrict__ zero_word) {
+                                                           int32_t* __restrict__ anchors, const AnchorFetch F, uint32_t* __restrict__ zero_word,
+                                                           const int32_t* __restrict__ ma, const int32_t* __restrict__ qsegs,
+                                                           const u64* __restrict__ qoff, int32_t* __restrict__ cover) {
     const int lane = threadIdx.x & 63;
     if (zero_word && blockIdx.x == 0 && threadIdx.x < 2) zero_word[threadIdx.x] = 0;  // (the consensus stage's two list counters: next launches)
     // (the consensus kernel's input block - pinned host memory - is brought over by this launch, which runs just before it; a
@@ -2070,7 +2067,10 @@ struct match_anchor_kernel {
         const int ns = (int)ref.n_seeds;
         const int32_t* s = segs + ref.seg_off;
         if (first < 0 || last < 0 || first >= ns || last >= ns) {
-            if (lane == 0) anchors[2 * slot] = anchors[2 * slot + 1] = DP_NO_ANCHOR;
+            if (lane == 0) {
+                anchors[2 * slot] = anchors[2 * slot + 1] = DP_NO_ANCHOR;
+                if (cover) cover[2 * slot] = cover[2 * slot + 1] = DP_NO_ANCHOR;
+            }
             continue;
         }
         int a = 0, b = 0;
@@ -2083,6 +2083,46 @@ struct match_anchor_kernel {
         if (lane == 0) {
             anchors[2 * slot] = s[0] + a;
             anchors[2 * slot + 1] = s[2 * ns] + b;
+        }
+        if (!cover) continue;
+        // GetBasesCovered on both sides of the match (seeds/sequence.go:830; the consensus stage's filter, commands/overlap.go:205):
+        // len * k plus the negative gaps between consecutive matched seeds.  One lane per matched pair here; the consensus kernel
+        // used to walk a match's pairs on one lane, two dependent loads per pair (4.5 of a mean window's 41 us).  The query side is
+        // summed on the FORWARD query with flipped indices for a match of the reverse-complement query, exactly as that walk did.
+        {
+            const uint32_t qf = r.q & ~1u;
+            const bool isRc = (r.q & 1u) != 0;
+            const int32_t* aSeg = qsegs + qoff[qf];
+            const int sA = (int)(qoff[qf + 1] - qoff[qf]) >> 1;
+            const int a0 = ma[r.off], b0 = first;
+            const bool bad0 = a0 < 0 || a0 >= sA || b0 < 0 || b0 >= ns;
+            bool badI = false;
+            int ca = 0, cb = 0;
+            for (uint32_t i = 1 + (uint32_t)lane; i < r.len && !bad0; i += 64) {
+                const int pa = ma[r.off + i - 1], a1 = ma[r.off + i], pb = mb[r.off + i - 1], b1 = mb[r.off + i];
+                if (a1 >= sA || a1 < 0 || b1 >= ns || b1 < 0) {
+                    badI = true;
+                    continue;
+                }
+                if (pa >= sA || pa < 0 || pb >= ns || pb < 0) continue;  // (flagged by the lane that owns that pair)
+                const int lo = isRc ? sA - 1 - a1 : pa, hi = isRc ? sA - 1 - pa : a1;
+                int dA = -k;
+                for (int j = lo + 1; j <= hi; j++) dA += aSeg[2 * j] + k;
+                for (int j = hi + 1; j <= lo; j++) dA -= aSeg[2 * j] + k;
+                int dB = -k;
+                for (int j = pb + 1; j <= b1; j++) dB += s[2 * j] + k;
+                if (dA < 0) ca += dA;
+                if (dB < 0) cb += dB;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                ca += __shfl_xor(ca, o);
+                cb += __shfl_xor(cb, o);
+            }
+            const bool anyBad = __ballot(badI) != 0;
+            if (lane == 0) {
+                cover[2 * slot] = bad0 ? DP_NO_ANCHOR : anyBad ? DP_NO_ANCHOR + 1 : ca + (int)r.len * k;
+                cover[2 * slot + 1] = cb + (int)r.len * k;
+            }
         }
     }
 }
@@ -3302,7 +3342,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
 int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch, uint32_t* zero_word) {
     // (a pending chaining stage: the pair count is on the device only - the launch covers the stage's capacity)
     const uint32_t nslots = dp_find_pending(ctx) ? dp_find_pair_cap(ctx) : ctx->n_pairs;
-    if (dev_reserve(ctx, ctx->d_manchor, (size_t)nslots * 8 + 16)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_manchor, (size_t)nslots * 16 + 32)) return DP_ERR_HIP;  // anchors [2 * nslots] | covered bases [2 * nslots]
     // what a pending chaining stage still has to report (chain_enqueue): its cursor block and per-query words, into their pinned blocks
     FindState* fs = ctx->find_state;
     dp_fetch_region owed[2] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
@@ -3325,10 +3365,12 @@ int dp_match_anchors_launch(dp_ctx* ctx, const dp_fetch_region* fetch, uint32_t*
         F.n8[i] = fr[i] ? (unsigned long long)((fr[i]->bytes + 7) / 8) : 0ull;
     }
     const u64* d_totals = (const u64*)((const uint8_t*)ctx->d_cursor.p + 64);
-    dp_launch<match_anchor_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256),
+    dp_launch<match_anchor_kernel>(ctx, dim3(std::min<uint32_t>(8192, (nslots + 3) / 4)), dim3(256),
                        (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)dp_chain_b(ctx),
                        (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, ctx->last_k, (int32_t*)ctx->d_manchor.p,
-                       F, zero_word);
+                       F, zero_word, (const int32_t*)dp_chain_a(ctx), (const int32_t*)ctx->qsegs_dev, (const u64*)ctx->qoff_dev,
+                       (int32_t*)ctx->d_manchor.p + 2 * (size_t)nslots);
+    ctx->mcover_off = 2 * (size_t)nslots;
     DP_HIP(hipGetLastError());
     return DP_OK;
 }
@@ -3398,7 +3440,8 @@ int dp_fetch_overlaps_impl(dp_ctx* ctx, int want_candidates, dp_match_batch* out
         dp_launch<match_anchor_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nslots + 3) / 4)), dim3(256),
                            (const MRec*)ctx->d_mrec.p, (const uint32_t*)d_totals, nslots, (const int32_t*)ctx->d_mb.p,
                            (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p, k, (int32_t*)ctx->d_manchor.p,
-                           AnchorFetch{{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {0, 0, 0}}, (uint32_t*)nullptr);
+                           AnchorFetch{{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {0, 0, 0}}, (uint32_t*)nullptr,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, (const u64*)nullptr, (int32_t*)nullptr);
         DP_HIP(hipGetLastError());
         DP_HIP(hipMemcpyAsync(ctx->h_manchor.p, ctx->d_manchor.p, (size_t)nslots * 8, hipMemcpyDeviceToHost, ctx->stream));
         DP_HIP(hipMemcpyAsync(ctx->h_mrec.p, ctx->d_mrec.p, (size_t)nslots * sizeof(MRec), hipMemcpyDeviceToHost, ctx->stream));
