@@ -222,7 +222,7 @@ def main():
         H = pipe.H
         H.dph_planner_counter.restype = __import__("ctypes").c_int64
         names = ["plans_computed", "plans_thrown_away", "plans_erased_by_flags", "rounds_executed", "rounds_rejected", "rounds_committed",
-                 "plan_compute_us", "slot_wait_for_plan_us", "commit_thread_wait_us", "commit_text_us", "commit_state_us", "commit_keep_text_us"]
+                 "plan_compute_us", "slot_wait_for_plan_us", "commit_thread_wait_us", "commit_text_us", "commit_state_us", "commit_keep_text_us", "formatter_busy_us", "commit_wait_for_formatter_us"]
         return {nm: int(H.dph_planner_counter(i)) for i, nm in enumerate(names)}
 
     cs0 = cpu_stat()

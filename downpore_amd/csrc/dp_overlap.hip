@@ -53,7 +53,9 @@ struct index_fill_kernel {
 struct index_fill_rows_kernel {
     enum { THREADS = 256 };
     static __device__ void run(const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, u64* __restrict__ seedsets,
-                               uint32_t SW, const uint32_t* __restrict__ n_seqs_dev) {
+                               uint32_t SW, const uint32_t* __restrict__ n_seqs_dev, u64* __restrict__ posting, uint32_t W) {
+        // posting != null (DP_INDEX_FILL_ROWS=2): the posting matrix (cleared by chunk_kernel) still gets its bit by an atomic - half
+        // the atomics of index_fill_kernel, no transpose pass
         __shared__ u64 rows[4][IFR_SW_MAX];
         u64* row = rows[threadIdx.x >> 6];
         const uint32_t n_seqs = *n_seqs_dev;
@@ -67,6 +69,7 @@ struct index_fill_rows_kernel {
             for (uint32_t i = lane; i < r.n_seeds; i += 64) {
                 const uint32_t seed = (uint32_t)segs[r.seg_off + 2 * (uint64_t)i + 1];
                 atomicOr(&row[seed >> 6], 1ull << (seed & 63));
+                if (posting) atomicOr(&posting[(uint64_t)seed * W + (idx >> 6)], 1ull << (idx & 63));
             }
             __builtin_amdgcn_wave_barrier();
             for (uint32_t x = lane; x < SW; x += 64) seedsets[(uint64_t)idx * SW + x] = row[x];
@@ -467,7 +470,8 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
     // and query stage take 1.22 ms instead of 1.67 (profiles/r04/dense_rows.txt) - the default from 4 M seed-set words (32 MB) up.
     const char* ife = getenv("DP_INDEX_FILL_ROWS");  // (read per call: tests switch it between jobs of one process; 0 / 1 force)
     const bool rows_fit = SW <= IFR_SW_MAX && S > 0;
-    const bool rows_mode = rows_fit && (ife ? ife[0] == '1' : (uint64_t)cap * SW >= ((uint64_t)4 << 20));
+    const bool rows_mode = rows_fit && (ife ? ife[0] == '1' || ife[0] == '2' : (uint64_t)cap * SW >= ((uint64_t)4 << 20));
+    const bool rows_half = rows_mode && ife && ife[0] == '2';  // seed-set rows from LDS, posting bits by atomics
     if (!n_survivors) {  // (no chunk_kernel launch to clear the matrices and to write the chunk count)
         const dp_zero_region z[3] = {{ctx->d_posting.p, zb_post}, {ctx->d_seedsets.p, zb_sets}, {ctx->d_nseqs.p, 8}};
         if (int rc = dp_zero_regions(ctx, z, 3)) return rc;
@@ -491,10 +495,10 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
         P.cap = cap;
         P.n_out = (uint32_t*)ctx->d_nseqs.p;
         P.z_p[0] = (uint4*)ctx->d_posting.p;
-        P.z_n16[0] = rows_mode ? 0 : zb_post / 16;
+        P.z_n16[0] = rows_mode && !rows_half ? 0 : zb_post / 16;
         P.z_p[1] = (uint4*)ctx->d_seedsets.p;
         P.z_n16[1] = rows_mode ? 0 : zb_sets / 16;
-        P.zero_blocks = rows_mode ? 8u : (uint32_t)std::max<size_t>(1, std::min<size_t>(512, (std::max(zb_post, zb_sets) / 16 + 4095) / 4096));
+        P.zero_blocks = rows_mode && !rows_half ? 8u : (uint32_t)std::max<size_t>(1, std::min<size_t>(512, (std::max(zb_post, rows_half ? (size_t)0 : zb_sets) / 16 + 4095) / 4096));
         P.f_dst = nullptr;
         P.f_src = nullptr;
         P.f_n16 = 0;
@@ -516,10 +520,12 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
         if (cap && rows_mode) {
             const uint32_t blocks = std::min<uint32_t>(2048, (cap + 3) / 4);
             dp_launch<index_fill_rows_kernel>(ctx, dim3(blocks), dim3(256), (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p,
-                                              (u64*)ctx->d_seedsets.p, SW, (const uint32_t*)ctx->d_nseqs.p);
+                                              (u64*)ctx->d_seedsets.p, SW, (const uint32_t*)ctx->d_nseqs.p,
+                                              rows_half ? (u64*)ctx->d_posting.p : (u64*)nullptr, W);
             const uint32_t tasks = ((W + 7) / 8) * SW;
-            dp_launch<posting_transpose_kernel>(ctx, dim3(std::min<uint32_t>(4096, (tasks + 3) / 4)), dim3(256), (const u64*)ctx->d_seedsets.p,
-                                                (u64*)ctx->d_posting.p, S, W, SW, (const uint32_t*)ctx->d_nseqs.p);
+            if (!rows_half)
+                dp_launch<posting_transpose_kernel>(ctx, dim3(std::min<uint32_t>(4096, (tasks + 3) / 4)), dim3(256), (const u64*)ctx->d_seedsets.p,
+                                                    (u64*)ctx->d_posting.p, S, W, SW, (const uint32_t*)ctx->d_nseqs.p);
             DP_HIP(hipGetLastError());
         } else if (cap) {
             const uint32_t blocks = std::min<uint32_t>(2048, (cap + 3) / 4);

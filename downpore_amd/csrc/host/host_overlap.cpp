@@ -883,7 +883,9 @@ void TextPool::loop() {
             job = std::move(q_.front());
             q_.pop_front();
         }
+        const double tf = now();
         job->format();
+        g_prof.formatUs += (long long)((now() - tf) * 1e6);
         job->finish();
     }
 }

@@ -1351,7 +1351,11 @@ int OverlapRun::executeRounds(const std::vector<i64>& rounds, std::vector<RoundR
 // lock - a slot that finishes a round meanwhile hands it in at once instead of queueing behind half a megabyte of text.
 void OverlapRun::commitText(RoundResult& r) {
     char line[200];
-    r.takeText();  // (the round's PAF text may still be with a formatter thread)
+    {
+        const double tw = now();
+        r.takeText();  // (the round's PAF text may still be with a formatter thread)
+        g_prof.textWaitUs += (long long)((now() - tw) * 1e6);
+    }
     if (round == 0)
         snprintf(line, sizeof line, "Using query sets of around %lld sequences against %lld sequences.\n", (long long)r.firstOut,
                  (long long)reads->size());

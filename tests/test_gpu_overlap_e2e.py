@@ -369,7 +369,7 @@ def test_round_parallel_protocol_matches_oracle(world, seed, G, N, L, variable):
 
 @pytest.mark.parametrize("env", [{}, {"DP_DEVICE_CHUNK": "0"}, {"DP_CONS_FLAG_EVERY": "3"}, {"DP_SCAN_INDEX": "1", "DP_CONS_FLAG_EVERY": "2"},
                                  {"DP_SCAN_INDEX": "1"}, {"DP_SCAN_INDEX": "1", "DP_KX_ONESHOT": "0"}, {"DP_SCAN_INDEX": "1", "DPH_PRECHAIN": "0"},
-                                 {"DP_SCAN_INDEX": "1", "DPH_PRECHAIN": "1", "DP_CONS_FLAG_EVERY": "3"}, {"DP_INDEX_FILL_ROWS": "1"},
+                                 {"DP_SCAN_INDEX": "1", "DPH_PRECHAIN": "1", "DP_CONS_FLAG_EVERY": "3"}, {"DP_INDEX_FILL_ROWS": "1"}, {"DP_INDEX_FILL_ROWS": "2"},
                                  {"DP_INDEX_FILL_ROWS": "1", "DP_SCAN_INDEX": "1", "DP_CHAIN_TINY": "1"}])
 @pytest.mark.parametrize("L,k,e", [(2500, 10, 0.0), (30000, 10, 0.01)])
 def test_overlap_chunks_made_on_the_device(monkeypatch, env, L, k, e):

@@ -23,7 +23,7 @@ for r in range(reps):
                                (j.get("per_rank") or [{}])[0].get("per_job", {}).get("slot_wait_for_plan_us", 0) / 1e3,
                                (j.get("per_rank") or [{}])[0].get("per_job", {}).get("plan_compute_us", 0) / 1e3,
                                tuple((j.get("per_rank") or [{}])[0].get("per_job", {}).get(k, 0) / 1e3 for k in
-                                     ("commit_thread_wait_us", "commit_text_us", "commit_state_us", "commit_keep_text_us"))))
+                                     ("commit_thread_wait_us", "commit_text_us", "commit_state_us", "commit_keep_text_us", "formatter_busy_us", "commit_wait_for_formatter_us"))))
         except Exception as ex:
             print(label, "failed:", ex, p.stderr[-300:])
 for label, v in res.items():
@@ -32,5 +32,5 @@ for label, v in res.items():
     print("%-14s ms/round min %.3f med %.3f | job min %.3f med %.3f | setup med %.3f | parity %s | slots waited for plans %.1f ms, plan computes %.1f ms per job | all %s" %
           (label, ms[0], statistics.median(ms), job[0], statistics.median(job), statistics.median(x[2] for x in v), all(x[3] for x in v),
            statistics.median(x[4] for x in v), statistics.median(x[5] for x in v), " ".join("%.3f" % x for x in ms)))
-    print("   committing thread, ms per job: waits %.1f, text %.1f, state %.1f, keeps text %.1f" % tuple(statistics.median(x[6][i] for x in v) for i in range(4)))
+    print("   committing thread, ms per job: waits %.1f, text %.1f, state %.1f, keeps text %.1f | formatter threads busy %.1f, commit waited for them %.1f" % tuple(statistics.median(x[6][i] for x in v) for i in range(6)))
 print("host threads:", os.cpu_count())
