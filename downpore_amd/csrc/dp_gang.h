@@ -83,6 +83,8 @@ struct dp_gang;
 enum { DPG_OFF = 0, DPG_PREP = 1, DPG_START = 2, DPG_RUN = 3, DPG_LAUNCH = 4, DPG_SYNC = 5 };
 // true: the calling context is a gang member inside a round (its launches are deposited)
 bool dp_gang_active(const dp_ctx* ctx);
+// a member reports an error while inside a round: the gang fails for good (dp_gang.hip: dp_gang::failed)
+void dp_gang_mark_failed(dp_ctx* ctx);
 // the member's next launch: returns once the launch (merged with the other members') has been issued on the gang's stream
 void dp_gang_deposit(dp_ctx* ctx, const DpDeposit& d);
 // the member wants to wait for its work: returns when every member inside a round has arrived at a wait as well (the caller

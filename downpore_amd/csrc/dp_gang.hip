@@ -35,6 +35,11 @@ struct dp_gang {
     long long off_since_ns[DP_GANG_MAX] = {};  // when the member last left a round (a member between two rounds is about to be back)
     // counters (dp_gang_counters)
     uint64_t deposits = 0, launches = 0, syncs = 0, starts = 0, started_members = 0;
+    // sticky: a member reported an error inside a round (dp_fail) or a rendezvous waited longer than DP_GANG_TIMEOUT_S (30 s).  Every
+    // waiting member is released, launches and waits of the members are plain ones on the shared stream from then on (in order, so
+    // still correct), and dp_gang_round_begin returns DP_ERR_STATE: a caller that forgets dp_gang_round_end after an error - the
+    // exported C and Go APIs rely on the caller for that - no longer leaves the other members spinning.
+    std::atomic<bool> failed{false};
 };
 
 static long long gang_now_ns() {
@@ -53,7 +58,10 @@ static long long gang_grace_ns() {
 }
 
 hipStream_t dp_ctx_stream(const dp_ctx* ctx) { return ctx->stream; }
-bool dp_gang_active(const dp_ctx* ctx) { return ctx->gang && ctx->gang_in_round; }
+bool dp_gang_active(const dp_ctx* ctx) { return ctx->gang && ctx->gang_in_round && !ctx->gang->failed.load(std::memory_order_acquire); }
+void dp_gang_mark_failed(dp_ctx* ctx) {
+    if (ctx && ctx->gang && ctx->gang_in_round) ctx->gang->failed.store(true, std::memory_order_release);
+}
 
 // with the gang's lock held: acts for the gang if nobody is running host code
 static void gang_resolve(dp_gang* g) {
@@ -129,14 +137,26 @@ static void gang_arrive(dp_ctx* ctx, int st, const DpDeposit* d) {
     if (st == DPG_OFF || st == DPG_PREP) return;
     unsigned spins = 0;
     static const bool debug = getenv("DP_GANG_DEBUG") != nullptr;
+    static const long long timeout_ns = (getenv("DP_GANG_TIMEOUT_S") ? atoll(getenv("DP_GANG_TIMEOUT_S")) : 30ll) * 1000000000ll;
+    long long wait_from = 0;
     timespec t0{0, 0};
     bool dumped = false;
     while (g->released[me].load(std::memory_order_acquire) == tk) {
+        if (g->failed.load(std::memory_order_acquire)) return;  // (the caller goes on with plain launches / waits)
         if (++spins < 4096) {
             __builtin_ia32_pause();
             continue;
         }
         sched_yield();
+        if ((spins & 255) == 0) {  // a rendezvous nobody completes: the gang gives up instead of spinning for ever
+            const long long now = gang_now_ns();
+            if (!wait_from) wait_from = now;
+            else if (now - wait_from > timeout_ns) {
+                g->failed.store(true, std::memory_order_release);
+                ctx->err = "gang rendezvous timed out (a member left a round without dp_gang_round_end?)";
+                return;
+            }
+        }
         if (st == DPG_START && (spins & 15) == 0) {  // (held back for a member between two rounds: its grace may be over)
             std::lock_guard<std::mutex> lk(g->mu);
             if (g->state[me] == DPG_START) gang_resolve(g);
@@ -264,7 +284,9 @@ extern "C" int dp_gang_round_begin(dp_ctx* ctx) {
     if (!ctx) return DP_ERR_ARG;
     if (!ctx->gang || ctx->gang_in_round) return DP_OK;
     ctx->gang_round_members = 1;
+    if (ctx->gang->failed.load(std::memory_order_acquire)) return dp_fail(ctx, DP_ERR_STATE, "dp_gang_round_begin: the gang has failed (a member's error or a rendezvous timeout); destroy it");
     gang_arrive(ctx, DPG_START, nullptr);
+    if (ctx->gang->failed.load(std::memory_order_acquire)) return dp_fail(ctx, DP_ERR_STATE, "dp_gang_round_begin: the gang has failed (a member's error or a rendezvous timeout); destroy it");
     ctx->gang_in_round = true;
     return DP_OK;
 }

@@ -411,7 +411,7 @@ struct kidx_walk {
         n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
         const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
         gfirst = min(n, part * per);
-        i0 = part * per + (uint32_t)lane;
+        i0 = part * per + 4u * (uint32_t)lane;  // (a lane takes FOUR CONSECUTIVE entries per trip: one 16-byte load, kx_entry4)
         i1 = min(n, part * per + per);
         step = 64;
         grp = w;
@@ -422,7 +422,7 @@ struct kidx_walk {
         o = off[seeds[s]];
         n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
         gfirst = 0;
-        i0 = (uint32_t)lane & 15u;
+        i0 = 4u * ((uint32_t)lane & 15u);
         i1 = n;
         step = 16;
         grp = s;
@@ -458,11 +458,11 @@ struct kidx_walk {
     for (uint32_t ib = i0; ib < i1; ib += 4 * step) {
         uint64_t e[4];
         bool v[4];
+        kx_entry4(pos, o + ib, e);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t i = ib + (uint32_t)u * step;
-            v[u] = i < i1;
-            e[u] = v[u] ? kx_entry(pos, o + i) : 0ull;
+            v[u] = ib + (uint32_t)u < i1;
+            e[u] = v[u] ? e[u] : 0ull;
         }
         KX_TICK(2)
         dp_scan_item item[4];
@@ -505,7 +505,7 @@ struct kidx_walk {
                     uint32_t rank = 0;
                     if (valid) rank = atomicAdd(&counts[r - lo], 1u);
                     if (v[u] && rec_at != 0xffffffffu)
-                        R.rec[(size_t)rec_at + (ib + (uint32_t)u * step - gfirst)] = kx_rec(hd[u] != 0, valid, r, rank, p);
+                        R.rec[(size_t)rec_at + (ib + (uint32_t)u - gfirst)] = kx_rec(hd[u] != 0, valid, r, rank, p);
                 } else if (valid) {
                     atomicAdd(&counts[r - lo], 1u);
                 }

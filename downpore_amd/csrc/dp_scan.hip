@@ -158,6 +158,7 @@ int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e) {
     }
     if (ctx) ctx->err = s;
     else g_create_err = s;
+    if (ctx && ctx->gang && code != DP_OK) dp_gang_mark_failed(ctx);  // (inside a round: the other members must not wait for this one)
     return code;
 }
 
