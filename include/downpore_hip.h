@@ -464,7 +464,10 @@ DP_API int dp_allgather_survivors(dp_comm* comm, dp_ctx* ctx, const dp_survivor_
  *                         not waited for.
  *   dp_gang_round_end     after the round's last call (and on every error path): the member no longer holds the others up.
  * Inside a round a member's thread must not wait for another member's thread other than through these calls.  Results are
- * bit-identical with and without a gang. */
+ * bit-identical with and without a gang.
+ * Failure: a call that returns an error on a member inside a round - or a rendezvous nobody completes within DP_GANG_TIMEOUT_S
+ * seconds (30) - fails the gang for good: members waiting for the others are released and carry on with launches and waits of
+ * their own, and dp_gang_round_begin returns DP_ERR_STATE from then on (destroy the gang, create a new one). */
 typedef struct dp_gang dp_gang;
 DP_API int dp_gang_create(dp_ctx* const* ctxs, int n, dp_gang** out);
 DP_API void dp_gang_destroy(dp_gang* gang);
