@@ -312,12 +312,12 @@ struct kidx_fill_rec {
     if (lps == 64) {
         grp = w;
         s = w / KX_PARTS;
-        j0 = (uint32_t)lane;
+        j0 = 4u * (uint32_t)lane;  // (four consecutive records per lane and trip: two 16-byte loads; the buffer ends in 64 bytes of slack)
         step = 64;
     } else {
         grp = w * 4 + ((uint32_t)lane >> 4);
         s = grp;
-        j0 = (uint32_t)lane & 15u;
+        j0 = 4u * ((uint32_t)lane & 15u);
         step = 16;
     }
     if (grp >= n_groups) return;
@@ -325,10 +325,15 @@ struct kidx_fill_rec {
     if (at == 0xffffffffu) return;
     for (uint32_t jb = j0; jb < gn; jb += 4 * step) {
         unsigned long long e[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t j = jb + (uint32_t)u * step;
-            e[u] = j < gn ? R.rec[(size_t)at + j] : 0ull;
+        {
+            struct __attribute__((packed, aligned(8))) Rec4 {
+                unsigned long long a, b, c, d;
+            };
+            const Rec4 q = *(const Rec4*)(R.rec + (size_t)at + jb);
+            e[0] = q.a;
+            e[1] = jb + 1 < gn ? q.b : 0ull;
+            e[2] = jb + 2 < gn ? q.c : 0ull;
+            e[3] = jb + 3 < gn ? q.d : 0ull;
         }
         uint32_t cnt[4];
         uint64_t so[4];
