@@ -512,9 +512,17 @@ class Planner {
 // The PAF text of a round, written after the executor slot has gone on to its next round: the slot hands the device's 40-byte
 // records over (copied out of the context's pinned buffer) and a formatter thread of the run turns them into lines
 // (commands/overlap.go:223-228); whoever needs the text (the commit, the result exchange of the round-parallel mode) waits.
+// (a round's 6-14 k records are a few hundred KB: buffers of that size come from mmap and go back with munmap - page faults on
+// one side, an interrupt to every thread of the process on the other - so a job's two arrays are kept for the next job)
+struct TextJobBuffers {
+    static void take(std::vector<dp_paf_rec>& recs, std::vector<dp_group_meta>& groups);
+    static void give(std::vector<dp_paf_rec>& recs, std::vector<dp_group_meta>& groups);
+};
 struct TextJob {
     std::vector<dp_paf_rec> recs;
     std::vector<dp_group_meta> groups;
+    TextJob() { TextJobBuffers::take(recs, groups); }
+    ~TextJob() { TextJobBuffers::give(recs, groups); }
     std::vector<std::string> hostPaf;  // text of the windows the host consensus path did, indexed by hostOf[group]
     std::vector<uint32_t> hostOf;
     const ReadSet* reads = nullptr;

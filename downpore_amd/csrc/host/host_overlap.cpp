@@ -798,6 +798,33 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
     return 0;
 }
 
+namespace {
+std::mutex g_tjb_mu;
+std::vector<std::pair<std::vector<dp_paf_rec>, std::vector<dp_group_meta>>> g_tjb_free;
+}  // namespace
+static bool tjbOn() {
+    static const bool on = [] {
+        const char* e = getenv("DPH_TEXT_RECYCLE");  // 0: every job allocates its arrays (as before round 4's second half)
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+void TextJobBuffers::take(std::vector<dp_paf_rec>& recs, std::vector<dp_group_meta>& groups) {
+    if (!tjbOn()) return;
+    std::lock_guard<std::mutex> lk(g_tjb_mu);
+    if (g_tjb_free.empty()) return;
+    recs = std::move(g_tjb_free.back().first);
+    groups = std::move(g_tjb_free.back().second);
+    g_tjb_free.pop_back();
+}
+void TextJobBuffers::give(std::vector<dp_paf_rec>& recs, std::vector<dp_group_meta>& groups) {
+    if (!tjbOn() || (recs.capacity() == 0 && groups.capacity() == 0)) return;
+    recs.clear();
+    groups.clear();
+    std::lock_guard<std::mutex> lk(g_tjb_mu);
+    if (g_tjb_free.size() < 32) g_tjb_free.emplace_back(std::move(recs), std::move(groups));
+}
+
 void TextJob::format() {
     size_t nLines = 0, hostBytes = 0;
     for (const dp_group_meta& gm : groups) nLines += gm.n_lines;
