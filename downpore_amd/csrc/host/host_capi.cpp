@@ -27,10 +27,25 @@ struct OverlapH {
     // PAF of every committed round so far.  Kept as one chunk per commit and joined only when somebody asks for the
     // whole text: appending to one growing std::string re-copied up to 128 MB at every doubling (20-30 ms stalls of the
     // committing thread at rounds ~80, ~165, ~330 of a config-2 job).
+    // (round 4: a step's text is MOVED in - it is the buffer a formatter thread filled, never copied, never freed before the job
+    // ends: copying 400 KB per round into fresh memory and freeing the original was an mmap + munmap pair per round on the
+    // committing thread)
     std::vector<std::string> pafChunks;
     std::string allPafJoined;
-    void addPaf(const std::string& s) {
-        if (!s.empty()) pafChunks.push_back(s);
+    std::string lastStepCopy;  // text of the last step once allPaf() has folded the chunks away
+    bool lastStepHasText = false, lastStepInChunks = false;
+    void addPaf(std::string& s) {  // takes s's buffer; s is empty afterwards
+        lastStepHasText = !s.empty();
+        lastStepInChunks = lastStepHasText;
+        if (lastStepHasText) {
+            pafChunks.push_back(std::move(s));
+            s.clear();
+        }
+    }
+    const std::string& lastStepText() const {
+        static const std::string none;
+        if (!lastStepHasText) return none;
+        return lastStepInChunks ? pafChunks.back() : lastStepCopy;
     }
     const std::string& allPaf() {
         if (!pafChunks.empty()) {
@@ -38,6 +53,10 @@ struct OverlapH {
             for (const std::string& c : pafChunks) n += c.size();
             allPafJoined.reserve(n);
             for (const std::string& c : pafChunks) allPafJoined += c;
+            if (lastStepHasText && lastStepInChunks) {
+                lastStepCopy = pafChunks.back();
+                lastStepInChunks = false;
+            }
             pafChunks.clear();
         }
         return allPafJoined;
@@ -162,6 +181,8 @@ int dph_overlap_reset(void* hh) {
     h->run.shutdown(true);  // (the slots' and the planner's contexts serve the handle's next job)
     h->pafChunks.clear();
     h->allPafJoined.clear();
+    h->lastStepCopy.clear();
+    h->lastStepHasText = h->lastStepInChunks = false;
     std::fill(h->reads->ignore.begin(), h->reads->ignore.end(), 0);
     int rc = dp_scan_release(h->ctx);
     if (rc != 0) h->err = dp_last_error(h->ctx);
@@ -322,7 +343,7 @@ int dph_overlap_rounds_sharded(void* hh) {
     OverlapH* h = (OverlapH*)hh;
     int rc = h->run.roundsShardedBatch();
     if (rc < 0) h->err = h->run.error;
-    else if (rc > 0) h->addPaf(h->run.paf);
+    else h->addPaf(h->run.paf);
     return rc;
 }
 // one whole round of this rank (collective: every rank calls it, from its own thread / process): 1 ran, 0 finished
@@ -330,14 +351,15 @@ int dph_overlap_round_sharded(void* hh) {
     OverlapH* h = (OverlapH*)hh;
     int rc = h->run.roundSharded();
     if (rc < 0) h->err = h->run.error;
-    else if (rc > 0) h->addPaf(h->run.paf);
+    else h->addPaf(h->run.paf);
     return rc;
 }
 
 const char* dph_overlap_round_paf(void* hh, int64_t* n) {
     OverlapH* h = (OverlapH*)hh;
-    *n = (int64_t)h->run.paf.size();
-    return h->run.paf.data();
+    const std::string& t = h->lastStepText();
+    *n = (int64_t)t.size();
+    return t.data();
 }
 const char* dph_overlap_all_paf(void* hh, int64_t* n) {
     OverlapH* h = (OverlapH*)hh;
@@ -372,7 +394,7 @@ int dph_overlap_step(void* hh) {
     OverlapH* h = (OverlapH*)hh;
     int rc = h->run.step();
     if (rc < 0) h->err = h->run.error;
-    else if (rc > 0) {
+    else {
         const double t0 = now();
         h->addPaf(h->run.paf);
         g_prof.commitKeepUs += (long long)((now() - t0) * 1e6);
@@ -520,7 +542,7 @@ int dph_overlap_commit_gathered(void* hh, const uint8_t* blobs, const uint64_t* 
     std::vector<RoundResult> rs;
     deserialise(blobs, sizes, count, rs, h->keepText);
     int c = h->run.commitGathered(rs);
-    if (c > 0) h->addPaf(h->run.paf);
+    if (c >= 0) h->addPaf(h->run.paf);
     return c;
 }
 
@@ -558,7 +580,7 @@ int dph_overlap_superstep(void* hh, int max_rounds) {
     std::vector<RoundResult> rs;
     deserialise(all, sizes, dp_comm_size(h->comm), rs, h->keepText);
     const int c = h->run.commitGathered(rs);
-    if (c > 0) h->addPaf(h->run.paf);
+    if (c >= 0) h->addPaf(h->run.paf);
     return c;
 }
 
@@ -568,7 +590,7 @@ int dph_overlap_commit_blobs(void* hh, const uint8_t* blobs, const uint64_t* siz
     deserialise(blobs, sizes, count, rs, h->keepText);
     std::sort(rs.begin(), rs.end(), [](const RoundResult& a, const RoundResult& b) { return a.round < b.round; });
     int c = h->run.commitResults(rs);
-    if (c > 0) h->addPaf(h->run.paf);
+    if (c >= 0) h->addPaf(h->run.paf);
     return c;
 }
 int dph_overlap_done(void* hh) { return ((OverlapH*)hh)->run.done ? 1 : 0; }

@@ -1367,7 +1367,8 @@ void OverlapRun::commitText(RoundResult& r) {
     errText += line;
     badBack += r.fs.badBack;
     emptyMatch += r.fs.emptyMatch;
-    paf += r.paf;
+    if (paf.empty()) paf = std::move(r.paf);  // (the formatter's buffer itself: host_capi.cpp moves it on)
+    else paf += r.paf;
     pafLines += (i64)r.fs.lines;
     r.st.timed_rounds = (r.st.k_chain_ms > 0 || r.st.k_query_ms > 0 || r.st.k_cons_ms > 0 || r.st.k_count_ms > 0 || r.st.k_scan_ms > 0) ? 1 : 0;
     last = r.st;
