@@ -288,7 +288,9 @@ int Planner::lanesFor(int world, int slots) {
     // whole chain has to be walked `world` times faster than a GPU executes)
     const char* sp = getenv("DPH_PLAN_SPARSE");
     const bool sparseOff = sp && sp[0] == '0';
-    return std::max(1, std::min(sparseOff ? std::min(8, std::max(3, world + 2)) : 3, spare));
+    // (five since the end of round 4: on the pool's slower hosts - a third less single-thread speed - a plan takes 0.45 ms instead of
+    // 0.33 and three lanes, 84 % busy, made the slots wait 18 ms each per job; on the fast ones 3 ... 6 lanes measure the same)
+    return std::max(1, std::min(sparseOff ? std::min(8, std::max(3, world + 2)) : 5, spare));
 }
 
 void Planner::setLanes(int n) {
