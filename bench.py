@@ -222,7 +222,7 @@ def main():
         H = pipe.H
         H.dph_planner_counter.restype = __import__("ctypes").c_int64
         names = ["plans_computed", "plans_thrown_away", "plans_erased_by_flags", "rounds_executed", "rounds_rejected", "rounds_committed",
-                 "plan_compute_us", "slot_wait_for_plan_us", "commit_thread_wait_us", "commit_text_us", "commit_state_us", "commit_keep_text_us", "formatter_busy_us", "commit_wait_for_formatter_us"]
+                 "plan_compute_us", "slot_wait_for_plan_us", "commit_thread_wait_us", "commit_text_us", "commit_state_us", "commit_keep_text_us", "formatter_busy_us", "commit_wait_for_formatter_us", "planner_lanes_now"]
         return {nm: int(H.dph_planner_counter(i)) for i, nm in enumerate(names)}
 
     cs0 = cpu_stat()
@@ -251,7 +251,8 @@ def main():
     mine = {"rank": rank, "jobs_s": t_local / nj, "setup_s": t_init_sum / nj, "rounds_s": (t_local - t_init_sum) / nj,
             "kernel_ms_per_job": {k_: acc.get(k_, 0.0) / nj for k_ in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
             "phase_s_per_job": {k_: acc.get(k_, 0.0) / nj for k_ in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
-            "per_job": {k_: (pc1[k_] - pc0[k_]) / nj for k_ in pc1}, "slots": args.slots,
+            "per_job": {k_: (pc1[k_] - pc0[k_]) / nj for k_ in pc1 if k_ != "planner_lanes_now"}, "slots": args.slots,
+            "planner_lanes_at_the_end": pc1.get("planner_lanes_now"),
             "host_threads": int(os.environ.get("DP_HOST_THREADS", "0")) or None}
     per_rank = [mine]
     if dist is not None:

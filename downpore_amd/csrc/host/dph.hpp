@@ -484,6 +484,8 @@ class Planner {
     void dropBefore(i64 round, i64 firstInOfRound);
     // planner lanes (threads that compute consecutive plans concurrently, each from a guess of where its predecessor ends)
     static int lanesFor(int world, int slots);
+    static int lanesMax(int world, int slots);  // what OverlapRun::step may grow the lanes to while slots wait for plans
+    int lanes() const;
     void setLanes(int n);  // grows only
     // Round-parallel runs (rounds dealt to `world` ranks): this planner computes the plans of the rounds its rank executes and
     // nothing else - where the rounds in between end is GUESSED (predictFirstOut: the window cache's seed counts, a microsecond
@@ -640,6 +642,10 @@ struct OverlapRun {
     i64 badBack = 0, emptyMatch = 0;
     bool done = false;
     std::string paf;      // PAF text of the last committed round(s)
+    int adaptRounds_ = 0;           // step(): rounds since the planner's lanes were last looked at
+    double adaptT_ = 0;
+    long long adaptWait_ = 0;
+    int adaptLanes_ = 0;            // lanes the last job grew to (0: none yet)
     i64 pafLines = 0;     // ... and its number of lines
     std::string errText;  // stderr progress lines accumulated
     std::string error;    // failure text

@@ -424,7 +424,8 @@ int64_t dph_planner_counter(int which) {
         case 10: return g_prof.commitStateUs.load();  // ... flags + planner bookkeeping,
         case 11: return g_prof.commitKeepUs.load();   // ... keeping the step's text for dph_overlap_all_paf
         case 12: return g_prof.formatUs.load();       // formatter threads: time in TextJob::format, all threads together
-        case 13: return g_prof.textWaitUs.load();     // the committing thread's share of `text` spent waiting for a formatter thread
+        case 13: return g_prof.textWaitUs.load();
+        case 14: return g_prof.planLanes.load();     // lanes of the planner that was given lanes last (not a sum: bench.py reports it as is)     // the committing thread's share of `text` spent waiting for a formatter thread
         default: return -1;
     }
 }

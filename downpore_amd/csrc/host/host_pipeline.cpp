@@ -288,9 +288,21 @@ int Planner::lanesFor(int world, int slots) {
     // whole chain has to be walked `world` times faster than a GPU executes)
     const char* sp = getenv("DPH_PLAN_SPARSE");
     const bool sparseOff = sp && sp[0] == '0';
-    // (five since the end of round 4: on the pool's slower hosts - a third less single-thread speed - a plan takes 0.45 ms instead of
-    // 0.33 and three lanes, 84 % busy, made the slots wait 18 ms each per job; on the fast ones 3 ... 6 lanes measure the same)
-    return std::max(1, std::min(sparseOff ? std::min(8, std::max(3, world + 2)) : 5, spare));
+    return std::max(1, std::min(sparseOff ? std::min(8, std::max(3, world + 2)) : 3, spare));
+}
+// ... and how many it may grow to while the slots turn out to wait for their plans (OverlapRun::step: a lane more whenever the slots
+// spent more than 10 % of the last 64 rounds waiting - the fast hosts' 2-6 % stay below that, and a fourth lane there makes every plan
+// 10 % slower for nothing (`ab_adapt.txt`)).  The pool's hosts differ by a third in single-thread speed: on the slower ones
+// a plan takes 0.45 ms instead of 0.33, three lanes are 84 % busy and the slots waited 18 ms each per job; on the fast ones three are
+// enough and more threads are only more contention.
+int Planner::lanesMax(int world, int slots) {
+    if (getenv("DPH_PLAN_LANES")) return lanesFor(world, slots);
+    const int spare = (int)hostThreads() - std::max(1, slots) - 4;
+    return std::max(lanesFor(world, slots), std::min(6, spare));
+}
+int Planner::lanes() const {
+    std::lock_guard<std::mutex> lk(d->mu);
+    return (int)d->lanes.size();
 }
 
 void Planner::setLanes(int n) {
@@ -302,6 +314,7 @@ void Planner::setLanes(int n) {
         d->lanes.emplace_back(new Impl::Lane(d->p.k));
         d->lanes[i]->th = std::thread([this, i] { laneMain(i); });
     }
+    g_prof.planLanes = (long long)d->lanes.size();
 }
 
 Planner::~Planner() {
@@ -1036,7 +1049,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         mark("values copy (overlapped)");
     }
     planner.reset(new Planner(*reads, p, valueView(), !(nothread && nothread[0] == '1'), plannerCtx, winCache.get()));
-    planner->setLanes(Planner::lanesFor(world_, nSlots));
+    planner->setLanes(std::max(Planner::lanesFor(world_, nSlots), adaptLanes_));
     mark("planner");
     firstSequence = 0;
     round = 0;
@@ -1442,7 +1455,7 @@ int OverlapRun::commitResults(std::vector<RoundResult>& results) {
 void OverlapRun::setRanks(int rank, int world) {
     rank_ = rank;
     world_ = std::max(1, world);
-    if (planner) planner->setLanes(Planner::lanesFor(world_, (int)slots.size()));
+    if (planner) planner->setLanes(std::max(Planner::lanesFor(world_, (int)slots.size()), adaptLanes_));
 }
 
 void OverlapRun::startWorkers() {
@@ -1578,6 +1591,21 @@ int OverlapRun::step() {
         committed++;
         g_prof.committed++;
         cvWork_.notify_all();
+        if (planner && world_ == 1 && ++adaptRounds_ >= 64) {  // do the slots wait for their plans?  then the planner gets another lane
+            const double tn = now();
+            const long long w = g_prof.getWaitUs.load();
+            if (adaptT_ > 0 && round >= 192) {  // (not the job's first rounds: the slots wait for the first plans whatever the host)
+                const double waited = (double)(w - adaptWait_) * 1e-6, span = (tn - adaptT_) * (double)std::max<size_t>(1, slots.size());
+                const int have = planner->lanes();
+                if (waited > 0.10 * span && have < Planner::lanesMax(world_, (int)slots.size())) {
+                    planner->setLanes(have + 1);
+                    adaptLanes_ = have + 1;  // (kept for the handle's next job: its planner starts with as many)
+                }
+            }
+            adaptT_ = tn;
+            adaptWait_ = w;
+            adaptRounds_ = 0;
+        }
     }
     g_prof.execUs += (long long)((now() - t0) * 1e6);
     if (done) sampleProfStop();

@@ -63,7 +63,7 @@ struct PipeProfile {
         planDiscarded{0}, hostGroups{0}, reselected{0};  // hostGroups: query windows the device consensus left to the host path
     std::atomic<long long> planTouchCyc{0}, planReselCyc{0}, planCommitCyc{0}, planOtherCyc{0};  // prepareFromCache, TSC cycles
     std::atomic<long long> cacheWaitUs{0};  // planner waiting for the window cache's producer
-    std::atomic<long long> commitWaitUs{0}, commitTextUs{0}, commitStateUs{0}, commitKeepUs{0}, formatUs{0}, textWaitUs{0};  // the committing thread: waiting for the next round in order, text, state, handing the text on
+    std::atomic<long long> commitWaitUs{0}, commitTextUs{0}, commitStateUs{0}, commitKeepUs{0}, formatUs{0}, textWaitUs{0}, planLanes{0};  // the committing thread: waiting for the next round in order, text, state, handing the text on
     std::atomic<long long> planUs{0}, getWaitUs{0}, execUs{0}, commitUs{0}, consensusCpuUs{0}, selectCpuUs{0}, slotCpuUs{0}, plannerCpuUs{0};
     std::atomic<long long> sub[19];
     std::atomic<long long> subCpu[19];  // CPU time of the calling thread since its previous add(): the sections are consecutive

@@ -141,7 +141,8 @@ DPH_API void dph_profile_print(void);
    executed, 4 rejected at the commit, 5 committed, 6 us in plan computes (wall, all lanes), 7 us the slots waited for plans,
    8 us the committing thread (the caller of dph_overlap_step) waited for the next round in order, 9 us it spent on a round's text
    (13: of which waiting for a formatter thread), 10 us on flags + planner bookkeeping, 11 us keeping the step's text,
-   12 us the formatter threads spent formatting (all threads together); -1 for any other index */
+   12 us the formatter threads spent formatting (all threads together), 14 the planner's lanes at the moment (a state, not a sum);
+   -1 for any other index */
 DPH_API int64_t dph_planner_counter(int which);
 DPH_API int dph_selftest_planner_flags(void* reads, int k, int64_t seed_batch_size, const double* values);
 DPH_API int dph_selftest_planner_lanes(void* reads, int k, int64_t seed_batch_size, const double* values, int lanes, int flag_every,

@@ -23,7 +23,9 @@ for r in range(reps):
                                (j.get("per_rank") or [{}])[0].get("per_job", {}).get("slot_wait_for_plan_us", 0) / 1e3,
                                (j.get("per_rank") or [{}])[0].get("per_job", {}).get("plan_compute_us", 0) / 1e3,
                                tuple((j.get("per_rank") or [{}])[0].get("per_job", {}).get(k, 0) / 1e3 for k in
-                                     ("commit_thread_wait_us", "commit_text_us", "commit_state_us", "commit_keep_text_us", "formatter_busy_us", "commit_wait_for_formatter_us"))))
+                                     ("commit_thread_wait_us", "commit_text_us", "commit_state_us", "commit_keep_text_us", "formatter_busy_us", "commit_wait_for_formatter_us")),
+                               (j.get("host_cpu") or {}).get("cpu_s", 0) / max(1e-9, (j.get("host_cpu") or {}).get("wall_s", 1)), (j.get("host_cpu") or {}).get("throttled_s", 0),
+                               (j.get("per_rank") or [{}])[0].get("planner_lanes_at_the_end")))
         except Exception as ex:
             print(label, "failed:", ex, p.stderr[-300:])
 for label, v in res.items():
@@ -33,4 +35,5 @@ for label, v in res.items():
           (label, ms[0], statistics.median(ms), job[0], statistics.median(job), statistics.median(x[2] for x in v), all(x[3] for x in v),
            statistics.median(x[4] for x in v), statistics.median(x[5] for x in v), " ".join("%.3f" % x for x in ms)))
     print("   committing thread, ms per job: waits %.1f, text %.1f, state %.1f, keeps text %.1f | formatter threads busy %.1f, commit waited for them %.1f" % tuple(statistics.median(x[6][i] for x in v) for i in range(6)))
+    print("   host: %.1f cores busy on average, throttled %.2f s, planner lanes at the end %s" % (statistics.median(x[7] for x in v), max(x[8] for x in v), [x[9] for x in v]))
 print("host threads:", os.cpu_count())
