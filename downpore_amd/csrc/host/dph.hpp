@@ -345,6 +345,9 @@ class WindowCache {
     int numSeeds = 0;
     // Blocks until window w has been produced.  The pointers stay valid until release() passes w's read.
     bool get(uint32_t w, const uint32_t** spec, const uint32_t** kmers, std::string* err);
+    // the same, and how far the block of windows goes that lies behind these pointers (window w + i: spec + i * numSeeds, kmers + i *
+    // stride, for w + i < *wEnd): a plan walks ~670 consecutive windows and asked - under the cache's lock - for every one of them
+    bool getRun(uint32_t w, const uint32_t** spec, const uint32_t** kmers, uint32_t* wEnd, std::string* err);
     void release(size_t belowRead);  // reads below are committed: their windows will not be asked for again
     // Seeds window w adds to an index none of its k-mers touches (its cached selection and the reverse complements, without
     // repeats), or -1 while w has not been produced: what a planner lane needs to guess where the plan in front of it ends.

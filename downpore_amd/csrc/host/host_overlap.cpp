@@ -29,14 +29,20 @@ int Overlapper::prepareFromCache(int numSeeds, i64 seedLimit, ValueView values, 
     const bool prof = g_prof.on;
     unsigned long long cTouch = 0, cResel = 0, cCommit = 0, c0 = prof ? __rdtsc() : 0;
     const unsigned long long cStart = c0;
+    const uint32_t *runSpec = nullptr, *runKmers = nullptr;  // the cache's block of windows [runLo, runHi) (one lock per block, not per window)
+    uint32_t runLo = 0, runHi = 0;
     for (size_t r = (size_t)firstSequence; r < reads_.size() && sent < maxSeqs; r++) {
         if (flagLoad(ignore_ + r)) continue;
         sent++;
         if (index_.size() >= seedLimit) break;  // the budget is tested once per read, before its first window (overlap.go:57-60)
         for (uint32_t w = cache_->first[r]; w < cache_->first[r + 1]; w++) {
             const WindowCache::Win& win = cache_->wins[w];
-            const uint32_t *spec = nullptr, *kmers = nullptr;
-            if (!cache_->get(w, &spec, &kmers, &err)) return -1;
+            if (w < runLo || w >= runHi) {
+                if (!cache_->getRun(w, &runSpec, &runKmers, &runHi, &err)) return -1;
+                runLo = w;
+            }
+            const uint32_t* spec = runSpec + (size_t)(w - runLo) * (size_t)cache_->numSeeds;
+            const uint32_t* kmers = runKmers + (size_t)(w - runLo) * (size_t)cache_->stride;
             if (prof) c0 = __rdtsc();
             const bool touched = index_.touchesSeed(kmers, cache_->stride);
             if (prof) {

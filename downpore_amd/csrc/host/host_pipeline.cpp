@@ -205,6 +205,12 @@ bool WindowCache::get(uint32_t w, const uint32_t** spec, const uint32_t** kmers,
     return true;
 }
 
+bool WindowCache::getRun(uint32_t w, const uint32_t** spec, const uint32_t** kmers, uint32_t* wEnd, std::string* err) {
+    if (!get(w, spec, kmers, err)) return false;
+    *wEnd = (uint32_t)std::min(wins.size(), Impl::chunkBegin(Impl::chunkOf(w) + 1));
+    return true;
+}
+
 void WindowCache::release(size_t belowRead) {
     const uint32_t w = belowRead < first.size() ? first[belowRead] : (uint32_t)wins.size();
     const uint32_t c = Impl::chunkOf(w);
