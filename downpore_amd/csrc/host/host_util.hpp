@@ -75,6 +75,7 @@ struct PipeProfile {
         for (auto& x : subCpu) x = 0;
     }
     void add(int i, double sec) {
+        if (!on) return;  // (19 counters on two cache lines, bumped twenty times per round by every slot thread: only when somebody reads them)
         sub[i] += (long long)(sec * 1e6);
         if (on) {
             static thread_local double last = 0;
