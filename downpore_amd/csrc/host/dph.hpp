@@ -522,6 +522,10 @@ class Planner {
 struct TextJobBuffers {
     static void take(std::vector<dp_paf_rec>& recs, std::vector<dp_group_meta>& groups);
     static void give(std::vector<dp_paf_rec>& recs, std::vector<dp_group_meta>& groups);
+    // the text itself: a round's ~400 KB string lives until the job's text is given up (dph_overlap_reset), then serves a round of the
+    // handle's next job (no mmap, no page faults, no munmap storm at the reset)
+    static void takeText(std::string& s);
+    static void giveTexts(std::vector<std::string>& v);
 };
 struct TextJob {
     std::vector<dp_paf_rec> recs;

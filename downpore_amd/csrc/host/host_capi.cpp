@@ -179,6 +179,7 @@ int dph_overlap_init(void* hh, const int64_t* params, double minHits, const doub
 int dph_overlap_reset(void* hh) {
     OverlapH* h = (OverlapH*)hh;
     h->run.shutdown(true);  // (the slots' and the planner's contexts serve the handle's next job)
+    TextJobBuffers::giveTexts(h->pafChunks);  // (the rounds' text buffers serve the next job's rounds)
     h->pafChunks.clear();
     h->allPafJoined.clear();
     h->lastStepCopy.clear();

@@ -831,6 +831,32 @@ void TextJobBuffers::give(std::vector<dp_paf_rec>& recs, std::vector<dp_group_me
     if (g_tjb_free.size() < 32) g_tjb_free.emplace_back(std::move(recs), std::move(groups));
 }
 
+namespace {
+std::mutex g_txt_mu;
+std::vector<std::string> g_txt_free;
+}  // namespace
+static bool txtOn() {
+    static const bool on = [] {
+        const char* e = getenv("DPH_TEXT_RECYCLE");  // 1: the record arrays only (not the text buffers)
+        return !(e && (e[0] == '0' || e[0] == '1'));
+    }();
+    return on;
+}
+void TextJobBuffers::takeText(std::string& s) {
+    if (!txtOn()) return;
+    std::lock_guard<std::mutex> lk(g_txt_mu);
+    if (g_txt_free.empty()) return;
+    s = std::move(g_txt_free.back());
+    g_txt_free.pop_back();
+    s.clear();
+}
+void TextJobBuffers::giveTexts(std::vector<std::string>& v) {
+    if (!txtOn()) return;
+    std::lock_guard<std::mutex> lk(g_txt_mu);
+    for (std::string& s : v)
+        if (s.capacity() >= 65536 && g_txt_free.size() < 1024) g_txt_free.push_back(std::move(s));
+}
+
 void TextJob::format() {
     size_t nLines = 0, hostBytes = 0;
     for (const dp_group_meta& gm : groups) nLines += gm.n_lines;
@@ -881,6 +907,7 @@ void TextJob::format() {
             w += 7;
         }
     }
+    TextJobBuffers::takeText(text);
     text.assign(w0, (size_t)(w - w0));
 }
 

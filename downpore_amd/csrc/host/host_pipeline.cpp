@@ -31,6 +31,16 @@ struct WindowCache::Impl {
     struct Chunk {
         std::vector<uint32_t> spec, kmers;
     };
+    // (a chunk's buffers are 11.5 MB at config 2, a dozen of them are alive at a time: a handle's next job takes over the last
+    // job's instead of mapping - and zero-filling - 130 MB again and giving 130 MB back)
+    static std::mutex& sparesMu() {
+        static std::mutex m;
+        return m;
+    }
+    static std::vector<std::unique_ptr<Chunk>>& spares() {
+        static std::vector<std::unique_ptr<Chunk>> v;
+        return v;
+    }
     std::mutex mu;
     std::condition_variable cvProduced, cvSpace;
     std::map<uint32_t, std::unique_ptr<Chunk>> live;  // produced chunks by number
@@ -78,6 +88,12 @@ WindowCache::~WindowCache() {
     d->cvSpace.notify_all();
     d->cvProduced.notify_all();
     if (d->th.joinable()) d->th.join();
+    std::lock_guard<std::mutex> lk(Impl::sparesMu());
+    auto& sp = Impl::spares();
+    for (auto& kv : d->live)
+        if (sp.size() < 16 && kv.second) sp.push_back(std::move(kv.second));
+    for (auto& ch : d->pool)
+        if (sp.size() < 16 && ch) sp.push_back(std::move(ch));
 }
 
 void WindowCache::producer() {
@@ -101,6 +117,14 @@ void WindowCache::producer() {
             if (!d->pool.empty()) {
                 ch = std::move(d->pool.back());
                 d->pool.pop_back();
+            }
+        }
+        if (!ch) {
+            std::lock_guard<std::mutex> lk(Impl::sparesMu());
+            auto& sp = Impl::spares();
+            if (!sp.empty()) {
+                ch = std::move(sp.back());
+                sp.pop_back();
             }
         }
         if (!ch) ch.reset(new Impl::Chunk());
