@@ -46,7 +46,23 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            cpus.update(range(int(a), int(b) + 1))
+        elif part:
+            cpus.add(int(part))
+    return cpus
+
+
 def main():
+    if os.environ.get("DP_BENCH_AFFINITY", "").startswith("node"):  # experiment: every thread of the job on one NUMA node's CPUs
+        try:
+            os.sched_setaffinity(0, parse_cpulist(open("/sys/devices/system/node/%s/cpulist" % os.environ["DP_BENCH_AFFINITY"]).read()))
+        except Exception as ex:
+            print("DP_BENCH_AFFINITY:", ex, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed whole jobs")
