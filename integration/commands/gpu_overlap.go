@@ -12,8 +12,10 @@ package commands
 
 import (
 	"bufio"
+	"errors"
 	"log"
 	"os"
+	"time"
 
 	"github.com/jteutenberg/downpore/gpuhost"
 	"github.com/jteutenberg/downpore/sequence"
@@ -27,9 +29,9 @@ type gpuOverlapCommand struct {
 
 func NewGPUOverlapCommand() Command {
 	args, alias, desc := MakeArgs(
-		[]string{"overlap_size", "k", "num_seeds", "seed_batch_size", "chunk_size", "query_batch_size", "min_hits", "num_workers", "input", "seed_values", "himem", "gpu", "slots"},
-		[]string{"1000", "10", "15", "10000", "10000", "20000", "0.25", "4", "", "", "true", "0", "8"},
-		[]string{"Size of overlap to search for in bases", "Number of bases in each seed", "Minimum number of seeds to generate for each overlap query", "Maximum total unique seeds to use in each query batch", "Size to chop long reads into for querying against, in bases", "Maximum number of queries per batch (if max seeds not reached)", "Minimum proportion of seeds that must match each query", "Number of worker threads to spawn", "Fasta/fastq input file", "File containing values to use during seed selection.", "Whether to cache all reads in memory", "HIP device to run on", "Rounds in flight on the GPU"})
+		[]string{"overlap_size", "k", "num_seeds", "seed_batch_size", "chunk_size", "query_batch_size", "min_hits", "num_workers", "input", "seed_values", "himem", "gpu", "slots", "ranks", "rank", "comm_id"},
+		[]string{"1000", "10", "15", "10000", "10000", "20000", "0.25", "4", "", "", "true", "0", "8", "1", "0", ""},
+		[]string{"Size of overlap to search for in bases", "Number of bases in each seed", "Minimum number of seeds to generate for each overlap query", "Maximum total unique seeds to use in each query batch", "Size to chop long reads into for querying against, in bases", "Maximum number of queries per batch (if max seeds not reached)", "Minimum proportion of seeds that must match each query", "Number of worker threads to spawn", "Fasta/fastq input file", "File containing values to use during seed selection.", "Whether to cache all reads in memory", "HIP device to run on", "Rounds in flight on the GPU", "Processes of this job (one per GPU)", "This process's rank", "File through which rank 0 hands the 128-byte RCCL id to the other ranks"})
 	ov := gpuOverlapCommand{args: args, alias: alias, desc: desc}
 	return &ov
 }
@@ -77,11 +79,40 @@ func (com *gpuOverlapCommand) Run(args map[string]string) {
 		log.Fatal(err)
 	}
 	defer ov.Close()
+	ranks, rank := ParseInt(args["ranks"]), ParseInt(args["rank"])
+	if ranks > 1 {
+		// one process per GPU: the communicator has to exist before Init
+		id, err := exchangeCommID(args["comm_id"], rank)
+		if err != nil {
+			log.Fatal(err)
+		}
+		if err := ov.InitComm(ranks, rank, id); err != nil {
+			log.Fatal(err)
+		}
+	}
 	if err := ov.Init(p, values); err != nil {
 		log.Fatal(err)
 	}
 	out := bufio.NewWriterSize(os.Stdout, 1<<20)
 	defer out.Flush()
+	if ranks > 1 {
+		// query batches dealt to the ranks: rank r plans and runs the rounds r, r + ranks, ...; every superstep all-gathers the
+		// finished rounds over RCCL and commits them in order on every rank; rank 0 prints (the others drop the text as it arrives)
+		ov.SetRanks(rank, ranks)
+		ov.KeepText(rank == 0)
+		err := ov.RunRoundParallel(p.Slots, func(paf []byte) {
+			if rank == 0 {
+				out.Write(paf)
+			}
+		})
+		if err != nil {
+			log.Fatal(err)
+		}
+		if rank == 0 {
+			os.Stderr.WriteString(ov.ErrText())
+		}
+		return
+	}
 	printed := 0
 	for {
 		n, err := ov.Step()
@@ -98,4 +129,29 @@ func (com *gpuOverlapCommand) Run(args map[string]string) {
 		}
 		out.Write(ov.RoundPAF()) // fmt.Print(s) of finalCheckWorker (:225-228), query order
 	}
+}
+
+// exchangeCommID: rank 0 makes the RCCL id and publishes it through a file (written under another name and renamed, so a reader
+// never sees half of it); the other ranks wait for the file.  Any other transport of 128 bytes does as well.
+func exchangeCommID(path string, rank int) ([]byte, error) {
+	if path == "" {
+		return nil, errors.New("-ranks > 1 needs -comm_id <file>")
+	}
+	if rank == 0 {
+		id, err := gpuhost.CommUniqueID()
+		if err != nil {
+			return nil, err
+		}
+		if err := os.WriteFile(path+".tmp", id, 0600); err != nil {
+			return nil, err
+		}
+		return id, os.Rename(path+".tmp", path)
+	}
+	for i := 0; i < 6000; i++ {
+		if id, err := os.ReadFile(path); err == nil && len(id) == 128 {
+			return id, nil
+		}
+		time.Sleep(10 * time.Millisecond)
+	}
+	return nil, errors.New("no RCCL id in " + path + " after 60 s")
 }

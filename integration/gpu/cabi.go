@@ -431,6 +431,9 @@ type Comm struct {
 
 // NewLocalComms wires the contexts of ONE process (one per GPU, each driven by its own goroutine) into a communicator.
 func NewLocalComms(ctxs []*Context) ([]*Comm, error) {
+	if len(ctxs) == 0 {
+		return nil, errors.New("NewLocalComms: no contexts")
+	}
 	hs := make([]*C.dp_ctx, len(ctxs))
 	for i, c := range ctxs {
 		hs[i] = c.h

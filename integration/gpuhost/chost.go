@@ -260,6 +260,58 @@ func (o *Overlap) StepSharded() (int, error) {
 	return int(rc), nil
 }
 
+// ---- multi-GPU, one process per GPU: query batches dealt to the ranks (what bench.py --gpus N leads with) ---------------------
+//
+// Every rank holds the reads and the k-mer position index; rank r plans and runs the rounds r, r + world, ...; a superstep
+// all-gathers the ranks' finished rounds over RCCL inside the library and commits them in round order on every rank (a round
+// whose speculation on the ignore flags failed is rejected by all ranks alike and runs again).  DESIGN.md 7.2.
+
+// InitComm joins this rank to ONE communicator (id = the 128 bytes of CommUniqueID, the same on every rank): the result
+// exchange of Superstep runs on it.  Call before Init.
+func (o *Overlap) InitComm(nRanks, rank int, id []byte) error {
+	if len(id) < 128 {
+		return errors.New("InitComm: need the 128 bytes of CommUniqueID")
+	}
+	if rc := C.dph_overlap_comm_init(o.h, C.int(nRanks), C.int(rank), (*C.uint8_t)(unsafe.Pointer(&id[0]))); rc != 0 {
+		return lastError(o.h, "dph_overlap_comm_init")
+	}
+	return nil
+}
+
+// SetRanks deals the rounds to the ranks (round r belongs to rank r % world).  Call after Init, before the first Superstep.
+func (o *Overlap) SetRanks(rank, world int) {
+	C.dph_overlap_set_ranks(o.h, C.int(rank), C.int(world))
+}
+
+// Superstep contributes up to maxRounds of this rank's finished rounds, exchanges with the other ranks and commits (collective:
+// every rank calls it).  Returns the rounds committed; 0 with Done() false = the superstep's first round was rejected and is
+// being executed again - call again.
+func (o *Overlap) Superstep(maxRounds int) (int, error) {
+	rc := C.dph_overlap_superstep(o.h, C.int(maxRounds))
+	if rc < 0 {
+		return 0, lastError(o.h, "dph_overlap_superstep")
+	}
+	return int(rc), nil
+}
+
+// RunRoundParallel is the whole round loop of one rank: supersteps until the command is finished, emit(RoundPAF()) after each
+// one that committed something (only on a rank that called KeepText(true), i.e. the printing rank).
+func (o *Overlap) RunRoundParallel(slots int, emit func(paf []byte)) error {
+	if slots < 1 {
+		slots = 1
+	}
+	for !o.Done() {
+		n, err := o.Superstep(slots)
+		if err != nil {
+			return err
+		}
+		if n > 0 && emit != nil {
+			emit(o.RoundPAF())
+		}
+	}
+	return nil
+}
+
 // ---- `downpore map` ---------------------------------------------------------------------------------------------------------
 
 // MapParams is the flag table of `downpore map` (commands/map.go:19-20).

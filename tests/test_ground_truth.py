@@ -58,3 +58,63 @@ def test_product_paf_describes_true_overlaps():
     paf = pipe.all_paf()
     pipe.close()
     _check(paf, off, starts, strands, 0.9, k=10, min_within_k=0.78)
+
+
+# ------------------------------------------------------------------------------------------------------------------ map
+def map_truth(paf, off, starts, strands, G, n_reads=None):
+    """`downpore map` PAF against where the generator took every read from (the reference publishes recall / precision of its
+    mapper against a truth set, README.md:220-232).  A mapping is TRUE when its strand is the read's and both ends of its
+    reference interval lie where the read's mapped stretch [qstart, qend) really came from, to within 3 % of the read's length
+    + 100 bases (the generator's insertions and deletions shift coordinates; a circular reference is compared modulo G).
+    Returns dict(mappings, true, precision, reads_mapped, reads_true = reads with at least one true mapping, recall,
+    covered = mean fraction of a truly mapped read's bases inside its true mappings)."""
+    L = np.diff(off)
+    rows = [ln.split("\t") for ln in paf.split("\n") if ln]
+    f = np.array([r[:9] for r in rows], dtype=object)
+    r = np.array([int(x[1:]) for x in f[:, 0]])
+    qs, qe, ts, te = (f[:, c].astype(np.int64) for c in (2, 3, 7, 8))
+    minus = f[:, 4] == "-"
+    exp_s = np.where(strands[r] == 0, starts[r] + qs, starts[r] + L[r] - qe)
+    exp_e = np.where(strands[r] == 0, starts[r] + qe, starts[r] + L[r] - qs)
+    tol = (0.03 * L[r] + 100).astype(np.int64)
+
+    def near(a, b):
+        d = np.abs(a - b) % G
+        return np.minimum(d, G - d) <= tol
+    true = (minus == (strands[r] == 1)) & near(ts, exp_s) & near(te, exp_e)
+    n = len(L) if n_reads is None else n_reads
+    covered = np.zeros(len(L))
+    np.add.at(covered, r[true], (qe - qs)[true])
+    reads_true = np.unique(r[true])
+    return dict(mappings=len(rows), true=int(true.sum()), precision=float(true.mean()), reads_mapped=int(len(np.unique(r))),
+                reads_true=int(len(reads_true)), recall=float(len(reads_true) / n),
+                covered=float((covered[reads_true] / L[reads_true]).mean()))
+
+
+def test_oracle_map_paf_finds_the_true_positions():
+    """The oracle's mapper on 10 % error reads (BASELINE config 3's error rate) against a 1 Mb circular reference: the reference's
+    own figures on E. coli are 99.9 % recall over the input sequences and 99.98 % precision (README.md:222-237)."""
+    G, N = 1000000, 1500
+    bases, off, starts, strands = gen_reads_truth(3, G, N, 8000, 0.1, False)
+    genome = np.frombuffer(O.gen_genome(3, G), dtype=np.uint8)
+    paf, err = O.map_run(O.ReadSet(genome, np.array([0, G], dtype=np.int64), min_len=0, himem=False),
+                         O.ReadSet(bases, off, min_len=500, himem=False), circular=True, k=11)
+    t = map_truth(paf, off, starts, strands, G)
+    print(t)
+    assert t["recall"] >= 0.995 and t["precision"] >= 0.995 and t["covered"] >= 0.9, t
+
+
+@pytest.mark.gpu
+def test_product_map_paf_finds_the_true_positions():
+    """BASELINE config 3 (50 000 reads x 8 kb, 10 % errors, 4.6 Mb circular reference, k = 11) through the product: recall and
+    precision against the generator's true positions - a witness that does not go through the oracle."""
+    from downpore_amd.mapping import map_reads
+    from downpore_amd.overlap import Reads
+    G, N = 4600000, 50000
+    bases, off, starts, strands = gen_reads_truth(3, G, N, 8000, 0.1, False)
+    genome = np.frombuffer(O.gen_genome(3, G), dtype=np.uint8)
+    paf, err, st = map_reads(Reads(genome, np.array([0, G], dtype=np.int64), min_len=0, himem=False),
+                             Reads(bases, off, min_len=500, himem=False), circular=True, k=11)
+    t = map_truth(paf, off, starts, strands, G)
+    print(t)
+    assert t["recall"] >= 0.995 and t["precision"] >= 0.995 and t["covered"] >= 0.9, t
