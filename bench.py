@@ -420,28 +420,9 @@ def main():
 
 
 def ground_truth(paf, off, starts, strands, k, sample=200000):
-    """The first `sample` PAF lines against where the generator took the reads from: strand mismatches, lines whose reads do not
-    overlap on the genome, fraction of lines whose two parts begin and end within k (30) bases of each other on the genome."""
-    lines = paf.split("\n", sample)[:sample]
-    lines = [ln for ln in lines if ln]
-    if not lines:
-        return None
-    f = np.array([ln.split("\t")[:9] for ln in lines], dtype=object)
-    q = np.array([int(x[1:]) for x in f[:, 0]])
-    t = np.array([int(x[1:]) for x in f[:, 5]])
-    qs, qe, ts, te = (f[:, c].astype(np.int64) for c in (2, 3, 7, 8))
-    minus = f[:, 4] == "-"
-    Ls = np.diff(off)
-
-    def gpos(r, x):
-        return np.where(strands[r] == 0, starts[r] + x, starts[r] + Ls[r] - x)
-    a0, a1 = np.minimum(gpos(q, qs), gpos(q, qe)), np.maximum(gpos(q, qs), gpos(q, qe))
-    b0, b1 = np.minimum(gpos(t, ts), gpos(t, te)), np.maximum(gpos(t, ts), gpos(t, te))
-    n = len(lines)
-    return {"lines_checked": n, "strand_mismatches": int(((strands[q] != strands[t]) != minus).sum()),
-            "reads_that_do_not_overlap_on_the_genome": int((~((starts[q] < starts[t] + Ls[t]) & (starts[t] < starts[q] + Ls[q]))).sum()),
-            "frac_both_ends_within_k_bases": float(((np.abs(a0 - b0) <= k) & (np.abs(a1 - b1) <= k)).mean()),
-            "frac_both_ends_within_30_bases": float(((np.abs(a0 - b0) <= 30) & (np.abs(a1 - b1) <= 30)).mean())}
+    """tools/truth.py: the first `sample` PAF lines against where the generator took the reads from."""
+    from tools.truth import overlap_truth
+    return overlap_truth(paf, off, starts, strands, k, sample)
 
 
 def alt_mode_jobs(mode, reads, args, rank, world, local_rank, torch_device, comm, golden, torch, dist):

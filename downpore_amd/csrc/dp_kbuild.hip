@@ -413,12 +413,6 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
                            int* fmt_out, int* pbits_out, uint64_t* n_pos_out, float* ms_out) {
     if (k < 9 || k > 14 || ow->n_reads == 0) return 1;
     if (getenv("DP_KINDEX_ATOMIC")) return 1;
-    {
-        size_t free_b = 0, total_b = 0;
-        hipMemGetInfo(&free_b, &total_b);
-        free_b += dp_dev_cached_bytes();
-        if ((uint64_t)free_b < ow->total_bases * 16 + ((uint64_t)6 << 30)) return 1;  // (at most 8 + 8 B/base during the build)
-    }
     const uint64_t n_groups = (ow->packed_bytes * 4 + 31) / 32;
     KbGeom G;
     G.k = k;
@@ -461,6 +455,20 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     const bool wide = getenv("DP_KINDEX_WIDE") != nullptr;
     const int hb1 = !streams ? 8 : wide ? 4 : kb_hi_bytes(2 * k - G.b1 + pay), hb2 = !streams ? 8 : wide ? 4 : kb_hi_bytes(G.r + pay);
     const int fmt = (wide || pay > 40) ? 8 : pay > 32 ? 5 : 4;
+    // The index is written over A's low stream when that stream has the index's entry size (A is dead by pass 3): both eight bytes
+    // wide (format 8) or both four (two narrow streams, formats 4 / 5).  With the default 8-byte A and a 4- or 5-byte index the index
+    // gets a buffer of its own, live next to A and B.
+    const bool a_lo_wide = hb1 == 8 || fmt == 8;
+    const bool f_over_a = a_lo_wide == (fmt == 8);
+    {
+        // what is live at the build's peak (pass 3), per index entry: A + B + the index where it has a buffer of its own + format 5's
+        // byte stream.  Default path at config 2: 8 + 8 + 4 = 20 B, at config 4 (format 5): 21 B = 210 GB for 10 G entries.
+        const uint64_t per_entry = (uint64_t)((a_lo_wide ? 8 : 4) + (hb1 != 8 ? hb1 : 0)) + (uint64_t)(hb2 == 8 ? 8 : 4 + hb2) + (f_over_a ? 0u : 4u) + (fmt == 5 ? 1u : 0u);
+        size_t free_b = 0, total_b = 0;
+        hipMemGetInfo(&free_b, &total_b);
+        free_b += dp_dev_cached_bytes();
+        if ((uint64_t)free_b < ow->total_bases * per_entry + ((uint64_t)6 << 30)) return 1;  // (the caller builds with the atomic scatter, or scans)
+    }
     void *d_gread = nullptr, *d_small = nullptr, *d_a_lo = nullptr, *d_a_hi = nullptr, *d_b_lo = nullptr, *d_b_hi = nullptr, *d_f_hi = nullptr;
     struct Temps {
         std::vector<void**> v;
@@ -509,14 +517,20 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     // eight-byte format takes both of A's streams' worth: it gets a buffer of its own size in place of A's low stream)
     void* d_f_lo = nullptr;
     temps.v.push_back(&d_f_lo);
-    DP_HIP(dp_dev_malloc(&d_a_lo, n * (size_t)(hb1 == 8 || fmt == 8 ? 8 : 4) + 64));
-    if (hb1 && hb1 != 8) DP_HIP(dp_dev_malloc(&d_a_hi, n * (size_t)hb1 + 64));
-    DP_HIP(dp_dev_malloc(&d_b_lo, n * (size_t)(hb2 == 8 ? 8 : 4) + 64));
-    if (hb2 && hb2 != 8) DP_HIP(dp_dev_malloc(&d_b_hi, n * (size_t)hb2 + 64));
-    if (fmt == 5) DP_HIP(dp_dev_malloc(&d_f_hi, n + 64));
-    // (the index goes over A's low stream when that has its size; a buffer of its own otherwise - A is twice as large then)
-    const bool f_over_a = (fmt == 8) == (hb1 == 8 || fmt == 8);
-    if (!f_over_a) DP_HIP(dp_dev_malloc(&d_f_lo, n * 4 + 64));
+    // (an allocation that fails here - the guard above works from an estimate of the free memory - is not the job's failure: the
+    // temporaries go back and the caller falls back, as it does when the guard says no)
+#define KB_ALLOC(p_, bytes_)                              \
+    if (dp_dev_malloc(&(p_), (bytes_)) != hipSuccess) {   \
+        (void)hipGetLastError();                          \
+        return 1;                                         \
+    }
+    KB_ALLOC(d_a_lo, n * (size_t)(a_lo_wide ? 8 : 4) + 64)
+    if (hb1 && hb1 != 8) KB_ALLOC(d_a_hi, n * (size_t)hb1 + 64)
+    KB_ALLOC(d_b_lo, n * (size_t)(hb2 == 8 ? 8 : 4) + 64)
+    if (hb2 && hb2 != 8) KB_ALLOC(d_b_hi, n * (size_t)hb2 + 64)
+    if (fmt == 5) KB_ALLOC(d_f_hi, n + 64)
+    if (!f_over_a) KB_ALLOC(d_f_lo, n * 4 + 64)
+#undef KB_ALLOC
     const KbBuf A = {(uint32_t*)d_a_lo, d_a_hi, hb1}, B = {(uint32_t*)d_b_lo, d_b_hi, hb2};
     const KbPosOut F = {f_over_a ? d_a_lo : d_f_lo, (uint8_t*)d_f_hi, fmt};
     DP_HIP(hipMemcpyAsync(tile_start, h_tiles.data(), ((size_t)nb1 + 1) * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -1025,9 +1025,14 @@ struct query_kernel {
                 for (int x = 16; x >= 2; x--) L[x] |= L[x - 1] & m;
                 if (p != 7) L[1] |= m;  // step 8 omits "ORQ DX, R8" (asm:407-428)
             }
-            u64 planes[8];
+            // (a count over at most Q_MAXSETS = 512 live sets needs ten bits: with eight - until round 5 - a sequence that holds more than
+            // 255 of a long query's seeds, i.e. its best candidates, wrapped around and was dropped; found by the flag matrix with
+            // overlap_size 2000, num_seeds 30, min_hits 0.4: 315 sets, minCount 126)
+            enum { Q_PLANES = 10 };
+            static_assert((1 << Q_PLANES) > Q_MAXSETS, "the exact count of addSoftUnionIDs must hold Q_MAXSETS");
+            u64 planes[Q_PLANES];
 #pragma unroll
-            for (int x = 0; x < 8; x++) planes[x] = 0;
+            for (int x = 0; x < Q_PLANES; x++) planes[x] = 0;
             for (uint32_t j = 0; j < n; j++) {
                 if (S.lens[j] <= iw) continue;
                 if ((inFirst8[j >> 6] >> (j & 63)) & 1) continue;
@@ -1040,12 +1045,12 @@ struct query_kernel {
             v = minCount >= 16 ? L[16] : minCount == 15 ? L[15] : minCount == 14 ? L[14] : L[13];
             if (exact && v) {
                 // addSoftUnionIDs (bitset.go:509-538): keep a bit only if its true count over the live sets
-                // reaches minCount.  Bit-sliced counter, 8 planes.
+                // reaches minCount.  Bit-sliced counter, Q_PLANES planes.
                 for (uint32_t j = 0; j < n; j++) {
                     if (S.lens[j] <= iw) continue;
                     u64 c = posting[(uint64_t)S.setid[j] * W + iw];
 #pragma unroll
-                    for (int x = 0; x < 8; x++) {
+                    for (int x = 0; x < Q_PLANES; x++) {
                         u64 nc = planes[x] & c;
                         planes[x] ^= c;
                         c = nc;
@@ -1054,7 +1059,7 @@ struct query_kernel {
                 // ge = (count >= minCount), most significant plane first
                 u64 gt = 0, eq = ~0ull;
 #pragma unroll
-                for (int x = 7; x >= 0; x--) {
+                for (int x = Q_PLANES - 1; x >= 0; x--) {
                     u64 bit = ((minCount >> x) & 1) ? ~0ull : 0ull;
                     gt |= eq & planes[x] & ~bit;
                     eq &= ~(planes[x] ^ bit);
@@ -1101,6 +1106,12 @@ struct ChainProf {  // ticks of 10 ns, summed per wave (profiling build)
 #define C_RESULTS 500    // len(align.results)
 #define C_POOLSTATES 10000
 #define C_NODES (1u << 16)
+
+// CNodes of a wave's slice of the pool: its chain links, and - for an aligner whose reduced buffer (maxLength ints + the index map,
+// maxLength / 2) is larger than the LDS copy - room for both behind them
+static inline uint32_t chain_pool_stride(uint32_t max_query_len) {
+    return C_NODES + (max_query_len > 510 ? (uint32_t)(((size_t)max_query_len + max_query_len / 2 + 8) * 4 + 7) / 8 : 0u);
+}
 
 struct CNode {  // one link of a chain (pairState.prev history), written once
     uint16_t a, b;
@@ -1216,8 +1227,14 @@ __device__ __forceinline__ bool bs_contains(const u64* __restrict__ set, int32_t
 // aFlag/bFlag (LDS, may be null): membership bits precomputed by the whole wave, replacing the bitset probes.
 __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, int bN, const u64* __restrict__ aSet,
                               const u64* __restrict__ bSet, const u64* aFlag, const u64* bFlag, int minMatches, int k,
-                              int maxLength, CWave& L, CNode* __restrict__ nodes, int* resNode, uint32_t* err) {
+                              int maxLength, CWave& L, CNode* __restrict__ nodes, int* resNode, uint32_t* err, int32_t* spill = nullptr) {
     if (minMatches == 0) minMatches = 1;
+    // reduced a and its index map: in LDS while the reference's own capacity (maxLength ints = overlap_size / 2, seeds/alignment.go:
+    // 298-302) fits there; a command run with -overlap_size beyond 1024 gets the wave's spill area behind its node pool instead, so
+    // that the only "reduced buffer" limit is the reference's
+    int32_t* const aRed = spill ? spill : L.aRed;
+    int32_t* const aMap = spill ? spill + maxLength + 2 : L.aMap;
+    const int redCap = spill ? maxLength + 2 : 512;
     int nNodes = 0;
     int live = 0;
     // prepareInitial :341-388
@@ -1238,13 +1255,13 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
         }
         prevSeedA = aSeed;
         offset += aSeg[i - 1] + k;
-        if (aLen * 2 + 1 >= maxLength || aLen >= maxLength / 2 || aLen * 2 + 2 >= 512) {
+        if (aLen * 2 + 1 >= maxLength || aLen >= maxLength / 2 || aLen * 2 + 2 >= redCap) {
             *err |= 1;
             return 0;
         }
-        L.aRed[aLen * 2] = offset;
-        L.aRed[aLen * 2 + 1] = aSeed;
-        L.aMap[aLen] = i / 2;
+        aRed[aLen * 2] = offset;
+        aRed[aLen * 2 + 1] = aSeed;
+        aMap[aLen] = i / 2;
         offset = -k;
         if (aLen <= maxAIndex) {
             startSize++;
@@ -1256,7 +1273,7 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
         *err |= 1;
         return 0;
     }
-    L.aRed[aLen * 2] = 0;
+    aRed[aLen * 2] = 0;
     while (startSize > 0 && (2 * (startSize - 1) + 1) > maxAIndex) {
         startSize--;
         live--;
@@ -1320,7 +1337,7 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
                     ended = true;
                     break;
                 }
-                aGap += L.aRed[aGapIndex + 1] + k;
+                aGap += aRed[aGapIndex + 1] + k;
                 aGapIndex += 2;
             }
             L.o_aGap[i] = aGap;
@@ -1333,7 +1350,7 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
             if (aGap <= maxGap) {
                 int g = aGap;
                 for (int j = aGapIndex; j < aRedLen && g <= maxGap; j += 2) {
-                    if (L.aRed[j] == bSeed) {
+                    if (aRed[j] == bSeed) {
                         found = j;
                         if (nNodes >= (int)C_NODES) {
                             *err |= 8;
@@ -1344,7 +1361,7 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
                             return 0;
                         }
                         CNode nd;
-                        nd.a = (uint16_t)L.aMap[j / 2];
+                        nd.a = (uint16_t)aMap[j / 2];
                         nd.b = (uint16_t)(bIndex / 2);
                         nd.prev = L.o_node[i];
                         node_put(L, nodes, nNodes, nd);
@@ -1352,7 +1369,7 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
                         L.o_aPos[i] = j;
                         L.o_bPos[i] = bIndex;
                         L.o_aGapIndex[i] = j + 2;
-                        L.o_aGap[i] = L.aRed[j + 1];
+                        L.o_aGap[i] = aRed[j + 1];
                         L.o_bGap[i] = bSeg[bIndex + 1];
                         L.o_len[i] = nl;
                         L.o_node[i] = nNodes++;
@@ -1363,7 +1380,7 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
                         extended = true;
                         break;
                     }
-                    g += L.aRed[j + 1] + k;
+                    g += aRed[j + 1] + k;
                 }
             }
             if (extended) break;
@@ -1377,7 +1394,7 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
         if (bIndex <= maxBIndex) {  // :550-587
             for (int i = 0; i < initialSize; i++) {
                 const int aPos = 2 * i + 1;
-                if (aPos != found && L.aRed[aPos] == bSeed) {
+                if (aPos != found && aRed[aPos] == bSeed) {
                     if (found != -1) {
                         for (int j = 0; j < openSize; j++) {
                             if (L.o_bPos[j] == bIndex && L.o_aPos[j] == aPos) {
@@ -1396,14 +1413,14 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
                         return 0;
                     }
                     CNode nd;
-                    nd.a = (uint16_t)L.aMap[i];
+                    nd.a = (uint16_t)aMap[i];
                     nd.b = (uint16_t)(bIndex / 2);
                     nd.prev = -1;
                     node_put(L, nodes, nNodes, nd);
                     L.o_aPos[openSize] = aPos;
                     L.o_bPos[openSize] = bIndex;
                     L.o_aGapIndex[openSize] = aPos + 2;
-                    L.o_aGap[openSize] = L.aRed[aPos + 1];
+                    L.o_aGap[openSize] = aRed[aPos + 1];
                     L.o_bGap[openSize] = bSeg[bIndex + 1];
                     L.o_len[openSize] = 1;
                     L.o_node[openSize] = nNodes++;
@@ -1443,8 +1460,9 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
 // bGap).  Chains evaluated in one step cannot influence each other: removals above the break never reach minMatches
 // (length + remaining < minMatches), so minMatches is constant until the break itself.
 
-// prepareInitial :341-388.  Returns 0, or 1 when the reference would overrun `reduced` (err bit 1) / the staging arrays
-// are too small (CSlim: the pair is left to the full-size path).
+// prepareInitial :341-388.  Returns 0; 1 when the reference would overrun `reduced` (err bit 1); 2 when the layout's staging arrays
+// are too small for a reduced a the reference can hold (CSlim / CTiny: the pair is left to the full-size path; CWave: to the one-lane
+// transcription, whose reduced a may live in the wave's spill area).
 template <class LW>
 __device__ int wave_prepare_initial(int aN, int minMatches, int k, int maxLength, LW& L, int* aLenOut, int* startOut) {
     const int lane = dp_lane();
@@ -1453,7 +1471,7 @@ __device__ int wave_prepare_initial(int aN, int minMatches, int k, int maxLength
     int aLen = 0, startSize = 0;
     const int C0 = aN - minMatches * 2 + 1;
     int prevSeed = -1, P = 0, PatKept = 0;
-    bool bad = false;
+    bool bad = false, small = false;
     for (int base = 0; base < nA; base += 64) {
         const int s = base + lane;
         const bool valid = s < nA;
@@ -1477,7 +1495,9 @@ __device__ int wave_prepare_initial(int aN, int minMatches, int k, int maxLength
         const int rank = aLen + __popcll(kb);
         bool isStart = false;
         if (keep) {
-            if (rank * 2 + 1 >= maxLength || rank >= maxLength / 2 || rank >= (int)LW::RSEEDS) {
+            if (rank >= (int)LW::RSEEDS) {
+                small = true;
+            } else if (rank * 2 + 1 >= maxLength || rank >= maxLength / 2) {
                 bad = true;
             } else {
                 L.aRed[2 * rank] = Pin - Pk - k;
@@ -1486,6 +1506,7 @@ __device__ int wave_prepare_initial(int aN, int minMatches, int k, int maxLength
                 isStart = rank <= C0 - (s - rank);
             }
         }
+        if (__ballot(small)) return 2;  // (the fallback finds the reference's own limit, if the pair hits it, by itself)
         if (__ballot(bad)) return 1;
         startSize += __popcll(__ballot(isStart));
         if (inBmask) prevSeed = __shfl(seed, 63 - __builtin_clzll(inBmask), 64);
@@ -2175,6 +2196,7 @@ struct ChainArgs {
     uint32_t mc_n;
     int k, maxLength, tier;
     CNode* pool;
+    uint32_t pool_stride;  // CNodes per wave: C_NODES + room for a reduced query beyond the LDS copy (maxLength > 510)
     uint32_t* pbase;     // [nq + 1] first pair of each query
     u64* ibase;          // [nq + 1] first scratch int of each query (a pair's column holds nSeeds(q) ints)
     uint32_t* clist;     // [pairs] candidate (indexed-sequence index) of each pair, ascending within a query
@@ -2347,9 +2369,20 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
     if (staged) {
         const int mm = minMatches == 0 ? 1 : minMatches;
         int aLen = 0, startSize = 0;
-        if (wave_prepare_initial(aN, mm, k, A.maxLength, L, &aLen, &startSize)) {
+        const int prep = wave_prepare_initial(aN, mm, k, A.maxLength, L, &aLen, &startSize);
+        if (prep) {
             if (LW::SLIM) return -1;
-            err |= 1;
+            if constexpr (!LW::SLIM) {
+                if (prep == 2) {  // more kept seeds than the layout stages, fewer than the reference's buffer holds: one lane, from global memory
+                    if (lane == 0)
+                        resLen = pairwise_align(aSeg, aN, bSeg, bN, qset, tset, nullptr, nullptr, minMatches, k, A.maxLength, L, nodes, &resNode, &err,
+                                                A.maxLength > 510 ? (int32_t*)(nodes + C_NODES) : (int32_t*)nullptr);
+                    resLen = __shfl(resLen, 0, 64);
+                    resNode = __shfl(resNode, 0, 64);
+                } else {
+                    err |= 1;
+                }
+            }
             usedTier = 0;
         } else {
             CP_TICK(initial)
@@ -2370,7 +2403,8 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
     } else {
         if constexpr (!LW::SLIM) {
             if (lane == 0)
-                resLen = pairwise_align(aSeg, aN, bSeg, bN, qset, tset, nullptr, nullptr, minMatches, k, A.maxLength, L, nodes, &resNode, &err);
+                resLen = pairwise_align(aSeg, aN, bSeg, bN, qset, tset, nullptr, nullptr, minMatches, k, A.maxLength, L, nodes, &resNode, &err,
+                                        A.maxLength > 510 ? (int32_t*)(nodes + C_NODES) : (int32_t*)nullptr);
             resLen = __shfl(resLen, 0, 64);
             resNode = __shfl(resNode, 0, 64);
         }
@@ -2423,7 +2457,7 @@ struct chain_walk_kernel {
     if (blockIdx.x >= nblocks) return;
     const uint32_t waves = nblocks * WAVES;
     const uint32_t gw = blockIdx.x * WAVES + (threadIdx.x >> 6);
-    CNode* nodes = SLIM ? (CNode*)nullptr : A.pool + (uint64_t)gw * C_NODES;
+    CNode* nodes = SLIM ? (CNode*)nullptr : A.pool + (uint64_t)gw * A.pool_stride;  // (C_NODES links + the spill area of pairwise_align)
     if (mode != 0 && (A.cursor[3] != 0 || (A.pass > 0 && A.cursor[8 + A.pass] == 0))) return;  // overflow / every query closed already
     // (profiling build, mode 0: per-wave sums like chain_spec_kernel's, in the slots behind the passes')
     const bool wprof = DP_PROFILING && A.prof && mode == 0;
@@ -3039,6 +3073,7 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     A.maxLength = (int)st.max_query_len;
     A.tier = st.chain_tier;
     A.pool = (CNode*)ctx->d_pool.p;
+    A.pool_stride = chain_pool_stride(st.max_query_len);
     A.pbase = d_pbase;
     A.ibase = d_ibase;
     A.clist = (uint32_t*)ctx->d_clist.p;
@@ -3302,7 +3337,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     st.walk_blocks = std::min<uint32_t>(256, (nq + C_WAVES - 1) / C_WAVES);
     st.spec_blocks = 1024;  // 4096 persistent waves, 16 per CU: what CSlim's 8.5 KB per wave lets a CU hold
     if (const char* e = getenv("DP_SPEC_BLOCKS")) st.spec_blocks = (uint32_t)std::max(1, atoi(e));
-    if (dev_reserve(ctx, ctx->d_pool, (size_t)st.walk_blocks * C_WAVES * C_NODES * sizeof(CNode))) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_pool, (size_t)st.walk_blocks * C_WAVES * chain_pool_stride(st.max_query_len) * sizeof(CNode))) return DP_ERR_HIP;
     if (dev_reserve(ctx, ctx->d_pbase, ((size_t)nq + 1) * 4 + ((size_t)nq + 1) * 8 + (size_t)nq * sizeof(QState) + (size_t)nq * 4 + 128)) return DP_ERR_HIP;
     // capacities: what the buffers hold now (at least a floor); a run that needs more reports its totals and is repeated
     // with larger buffers (deterministic: same results)

@@ -349,6 +349,7 @@ class WindowCache {
     // stride, for w + i < *wEnd): a plan walks ~670 consecutive windows and asked - under the cache's lock - for every one of them
     bool getRun(uint32_t w, const uint32_t** spec, const uint32_t** kmers, uint32_t* wEnd, std::string* err);
     void release(size_t belowRead);  // reads below are committed: their windows will not be asked for again
+    static size_t releaseSpares();   // dph_release_caches: the chunk buffers kept for a handle's next job (up to 16 x 11.5 MB)
     // Seeds window w adds to an index none of its k-mers touches (its cached selection and the reverse complements, without
     // repeats), or -1 while w has not been produced: what a planner lane needs to guess where the plan in front of it ends.
     int seedsOf(uint32_t w) const { return w < producedWins.load(std::memory_order_acquire) ? (int)seedCount[w] : -1; }
@@ -526,6 +527,7 @@ struct TextJobBuffers {
     // handle's next job (no mmap, no page faults, no munmap storm at the reset)
     static void takeText(std::string& s);
     static void giveTexts(std::vector<std::string>& v);
+    static size_t releaseAll();  // dph_release_caches: every kept buffer goes back to the allocator; returns the bytes
 };
 struct TextJob {
     std::vector<dp_paf_rec> recs;
@@ -652,6 +654,7 @@ struct OverlapRun {
     int adaptRounds_ = 0;           // step(): rounds since the planner's lanes were last looked at
     double adaptT_ = 0;
     long long adaptWait_ = 0;
+    std::atomic<long long> planWaitUs_{0};  // microseconds this handle's slots waited for plans (executeRoundOnImpl)
     int adaptLanes_ = 0;            // lanes the last job grew to (0: none yet)
     i64 pafLines = 0;     // ... and its number of lines
     std::string errText;  // stderr progress lines accumulated
@@ -761,6 +764,7 @@ struct MapStats {
 };
 // Runs the whole command on HIP device `device`: reference = first sequence of refSet (top-level, cache=false), reads
 // top-level.  paf receives the PAF lines (read order), errText the reference's stderr lines.
+size_t releaseMapStaging();  // dph_release_caches: the staging block kept for the process's next map command
 int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int device, std::string& paf, std::string& errText,
            MapStats* stats, std::string& error);
 

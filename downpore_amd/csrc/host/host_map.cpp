@@ -526,6 +526,13 @@ void stagingPut(std::unique_ptr<char[]> p, size_t cap) {
     }
 }
 }  // namespace
+size_t releaseMapStaging() {
+    std::lock_guard<std::mutex> lk(g_stagingMu);
+    const size_t freed = g_staging ? g_stagingCap : 0;
+    g_staging.reset();
+    g_stagingCap = 0;
+    return freed;
+}
 
 int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int device, std::string& paf, std::string& errText,
            MapStats* stats, std::string& error) {

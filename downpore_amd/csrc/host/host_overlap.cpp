@@ -834,6 +834,7 @@ void TextJobBuffers::give(std::vector<dp_paf_rec>& recs, std::vector<dp_group_me
 namespace {
 std::mutex g_txt_mu;
 std::vector<std::string> g_txt_free;
+size_t g_txt_bytes = 0;  // sum of the kept strings' capacities
 }  // namespace
 static bool txtOn() {
     static const bool on = [] {
@@ -848,13 +849,33 @@ void TextJobBuffers::takeText(std::string& s) {
     if (g_txt_free.empty()) return;
     s = std::move(g_txt_free.back());
     g_txt_free.pop_back();
+    g_txt_bytes -= std::min(g_txt_bytes, s.capacity());
     s.clear();
 }
 void TextJobBuffers::giveTexts(std::vector<std::string>& v) {
     if (!txtOn()) return;
     std::lock_guard<std::mutex> lk(g_txt_mu);
+    // capped by bytes (256 MB: the text of a config-2 job is 235 MB), not by entries: a long-lived embedder keeps at most that
+    // much until dph_release_caches()
+    static constexpr size_t CAP_BYTES = (size_t)256 << 20;
     for (std::string& s : v)
-        if (s.capacity() >= 65536 && g_txt_free.size() < 1024) g_txt_free.push_back(std::move(s));
+        if (s.capacity() >= 65536 && g_txt_bytes + s.capacity() <= CAP_BYTES) {
+            g_txt_bytes += s.capacity();
+            g_txt_free.push_back(std::move(s));
+        }
+}
+size_t TextJobBuffers::releaseAll() {
+    size_t freed = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_txt_mu);
+        freed += g_txt_bytes;
+        std::vector<std::string>().swap(g_txt_free);
+        g_txt_bytes = 0;
+    }
+    std::lock_guard<std::mutex> lk(g_tjb_mu);
+    for (auto& pr : g_tjb_free) freed += pr.first.capacity() * sizeof(dp_paf_rec) + pr.second.capacity() * sizeof(dp_group_meta);
+    decltype(g_tjb_free)().swap(g_tjb_free);
+    return freed;
 }
 
 void TextJob::format() {

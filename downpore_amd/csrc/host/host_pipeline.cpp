@@ -96,6 +96,15 @@ WindowCache::~WindowCache() {
         if (sp.size() < 16 && ch) sp.push_back(std::move(ch));
 }
 
+size_t WindowCache::releaseSpares() {
+    std::lock_guard<std::mutex> lk(Impl::sparesMu());
+    size_t freed = 0;
+    for (auto& ch : Impl::spares())
+        if (ch) freed += (ch->spec.capacity() + ch->kmers.capacity()) * 4;
+    std::vector<std::unique_ptr<Impl::Chunk>>().swap(Impl::spares());
+    return freed;
+}
+
 void WindowCache::producer() {
     struct Reg {
         Reg() { sampleProfRegister("cache"); }
@@ -1085,6 +1094,9 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     round = 0;
     done = false;
     stopWorkers_ = issueEnd_ = draining_ = false;
+    adaptRounds_ = 0;  // (the adaptive lane growth measures inside one job: not across the idle gap since the last one)
+    adaptT_ = 0;
+    adaptWait_ = planWaitUs_.load(std::memory_order_relaxed);
     nextIssue_ = 0;
     inflight_ = workerRc_ = 0;
     flagRound_.assign(reads->size(), -1);
@@ -1255,7 +1267,11 @@ int OverlapRun::executeRoundOnImpl(ExecSlot& sl, i64 r, RoundResult& out) {
     if (dbgExec) fprintf(stderr, "[exec] round %lld waiting for its plan\n", (long long)r);
     std::shared_ptr<const RoundPlan> plan = planner->get(r);
     if (dbgExec) fprintf(stderr, "[exec] round %lld got plan\n", (long long)r);
-    g_prof.getWaitUs += (long long)((now() - t0) * 1e6);
+    {
+        const long long waitedUs = (long long)((now() - t0) * 1e6);
+        g_prof.getWaitUs += waitedUs;
+        planWaitUs_.fetch_add(waitedUs, std::memory_order_relaxed);  // (this handle's own: what its adaptive lane growth looks at)
+    }
     if (plan && plan->failed) {
         sl.error = "seed selection failed: " + plan->error;
         return -1;
@@ -1541,7 +1557,10 @@ void OverlapRun::workerMain(size_t si) {
             workerErr_ = sl.error;
         }
         if (rc == 0) {
-            if (res.empty) issueEnd_ = true;  // flags only accumulate: an exhausted input stays exhausted
+            // flags only accumulate: an exhausted input stays exhausted.  Only a real plan of THIS round says so - an empty result
+            // from a guessed "the input ends here" plan (ownership mode, round -3) or from another round's empty plan is rejected at
+            // the commit anyway, and believing it here drained this rank's pipeline until then
+            if (res.empty && (res.planRound == r || res.planRound == -2)) issueEnd_ = true;
             if (!draining_) ready_[r] = std::move(res);
         }
         cvDone_.notify_all();
@@ -1623,7 +1642,7 @@ int OverlapRun::step() {
         cvWork_.notify_all();
         if (planner && world_ == 1 && ++adaptRounds_ >= 64) {  // do the slots wait for their plans?  then the planner gets another lane
             const double tn = now();
-            const long long w = g_prof.getWaitUs.load();
+            const long long w = planWaitUs_.load(std::memory_order_relaxed);  // (per handle: other handles' waits are not this planner's)
             if (adaptT_ > 0 && round >= 192) {  // (not the job's first rounds: the slots wait for the first plans whatever the host)
                 const double waited = (double)(w - adaptWait_) * 1e-6, span = (tn - adaptT_) * (double)std::max<size_t>(1, slots.size());
                 const int have = planner->lanes();

@@ -112,7 +112,8 @@ def test_index_query_chain_with_flags(ctx, k, kw):
             continue
         ctx.import_segments(isegs)
         ctx.index_build(ioffs[:-1].astype(np.uint64), ((ioffs[1:] - ioffs[:-1]) // 2).astype(np.uint32))
-        out = ctx.find_overlaps(qsegs, qoffs.astype(np.uint64), kw.get("min_hits", 0.25), k, 500, want_candidates=True)
+        out = ctx.find_overlaps(qsegs, qoffs.astype(np.uint64), kw.get("min_hits", 0.25), k, kw.get("overlap_size", 1000) // 2,
+                                want_candidates=True)  # NewSeedAligner(lap.overlap/2), overlap/overlap.go:349
         cdata, coffs = run.trace(rnd, "candidates")
         assert np.array_equal(out["cand_off"].astype(np.int64), coffs), rnd
         assert np.array_equal(out["cand"].astype(np.int64), cdata), rnd
@@ -151,3 +152,34 @@ def test_map_flag(k, kw):
     assert d is None, d
     assert gerr == werr
     assert want.count("\n") > N // 3
+
+
+# ------------------------------------------------------------------------------------------- values beyond a kernel's capacity
+def test_overlap_size_beyond_the_query_kernel_fails_loudly():
+    """query_kernel holds at most 512 posting sets per query in LDS (Q_MAXSETS, dp_overlap.hip): a 6 000-base window over a genome
+    the round's seeds cover three times has ~900 usable seeds.  The reference has no such limit (allSeedSets grows, seeds.go:336-347)
+    - so this is a capacity of the device path, and it must be reported as DP_ERR_CAPACITY, never as a shorter PAF."""
+    from downpore_amd.hip import DpError
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    seed, G, N, L, e, var, _ = INPUTS[10]
+    bases, off = O.gen_reads(seed, G, N, 14000, e, False)
+    reads = Reads(bases, off, min_len=6000)
+    pipe = OverlapPipeline(reads, k=10, slots=1, overlap_size=6000, num_seeds=60)
+    with pytest.raises(DpError, match="more than 512 usable seeds"):
+        while pipe.step():
+            pass
+    pipe.close()
+
+
+def test_map_query_size_beyond_the_map_kernel_fails_loudly():
+    """The same limit on the `map` side (dp_map.hip: "window with more than 512 usable seeds"): -query_size 8000 with a seed every 10
+    bases of the reference is ~800 seeds per window."""
+    from downpore_amd.hip import DpError
+    from downpore_amd.mapping import map_reads
+    from downpore_amd.overlap import Reads
+    G, N = 300000, 50
+    genome = np.frombuffer(O.gen_genome(23, G), dtype=np.uint8)
+    bases, off = O.gen_reads(23, G, N, 20000, 0.02, False)
+    with pytest.raises(DpError, match="512 usable seeds|capacity"):
+        map_reads(Reads(genome, np.array([0, G], dtype=np.int64), min_len=0, himem=False), Reads(bases, off, min_len=500, himem=False),
+                  circular=True, k=11, query_size=8000, seed_rate=10)

@@ -146,3 +146,85 @@ def test_config4_first_rounds_match_oracle_fixture():
     g = _golden(sorted(names)[0])
     st = _overlap_against_fixture(g, slots=3, max_rounds=g["max_rounds"])
     assert st["idx_rounds"] == 1
+
+
+def _stream_job(pipe, sample_every, truth):
+    """Runs the job to its end, taking each step's PAF as bytes: line count, SHA-256 of the whole PAF, SHA-256 of its first
+    `truth["head_lines"]` lines, and the ground-truth figures (tools/truth.py) summed over every `sample_every`-th step's text."""
+    import ctypes as C
+    from tools.truth import overlap_truth
+    H = pipe.H
+    sha, head = hashlib.sha256(), hashlib.sha256()
+    head_left = truth["head_lines"]
+    lines = rounds = steps = 0
+    acc = {}
+    while True:
+        c = pipe.step()
+        if c == 0:
+            break
+        n = C.c_int64(0)
+        p = H.dph_overlap_round_paf(pipe.h, C.byref(n))
+        text = C.string_at(p, n.value)
+        sha.update(text)
+        if head_left > 0:
+            cut, pos = 0, -1
+            while cut < head_left:
+                pos = text.find(b"\n", pos + 1)
+                if pos < 0:
+                    break
+                cut += 1
+            head.update(text[:pos + 1] if pos >= 0 else text)
+            head_left -= cut
+        lines += text.count(b"\n")
+        rounds += c
+        if steps % sample_every == 0:
+            t = overlap_truth(text, truth["off"], truth["starts"], truth["strands"], truth["k"], sample=20000)
+            if t:
+                w = t["lines_checked"]
+                for key, v in t.items():
+                    acc[key] = acc.get(key, 0) + (v * w if key.startswith("frac_") else v)
+        steps += 1
+    for key in list(acc):
+        if key.startswith("frac_"):
+            acc[key] /= acc["lines_checked"]
+    return dict(lines=lines, rounds=rounds, sha=sha.hexdigest(), head_sha=head.hexdigest(), truth=acc)
+
+
+def test_config4_whole_job_on_one_gpu():
+    """BASELINE config 4's whole job on ONE GPU (1 M reads x 10 kb resident, 50 GB k-mer position index, ~6 000 rounds, ~38 M PAF
+    lines): the first 6 rounds against the oracle's fixture as above; then ALL rounds through properties that need no second
+    implementation - every sampled line joins two reads that really overlap on the synthetic genome, on the right relative strand,
+    with both parts on the same stretch (tools/truth.py) - and the same job in a second executor layout (3 slots instead of 5,
+    k-mer index rebuilt) must print the same PAF byte for byte (SHA-256 over ~2.3 GB of text) and flag the same reads."""
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    from tools.synth import gen_reads_truth
+    g = _golden("config4_first_6_rounds")
+    gen = g["generator"]
+    bases, off, starts, strands = gen_reads_truth(gen["seed"], gen["genome"], gen["reads"], gen["read_len"], gen["error"], gen["variable"])
+    reads = Reads(bases, off, min_len=1000)
+    del bases
+    truth = dict(off=off, starts=starts, strands=strands, k=g["k"], head_lines=g["paf_lines"])
+    results, ignores = [], []
+    pipe = OverlapPipeline(reads, device=0, k=g["k"], slots=5, defer_init=True)  # (reads uploaded and packed once)
+    for slots in (5, 3):
+        pipe._params[7] = slots
+        pipe.init()
+        r = _stream_job(pipe, sample_every=16, truth=truth)
+        st = pipe.stats()
+        ignores.append(hashlib.sha256(reads.ignore().tobytes()).hexdigest())
+        pipe.reset()  # (ends the job: slots, planner, value table and k-mer index released, ignore flags cleared)
+        print("config 4, %d slots: %d rounds, %d lines, truth %s" % (slots, r["rounds"], r["lines"], r["truth"]))
+        assert st["idx_rounds"] == 1
+        assert r["head_sha"] == g["paf_sha256"], "the first %d lines are not the oracle's first 6 rounds" % g["paf_lines"]
+        assert r["rounds"] > 5500 and r["lines"] > 30000000
+        t = r["truth"]
+        assert t["lines_checked"] > 500000
+        assert t["strand_mismatches"] == 0
+        assert t["reads_that_do_not_overlap_on_the_genome"] <= t["lines_checked"] // 100
+        assert t["parts_without_a_shared_base"] <= t["lines_checked"] // 200
+        assert t["frac_both_ends_within_30_bases"] >= 0.9 and t["frac_both_ends_within_k_bases"] >= 0.8
+        results.append(r)
+    assert results[0]["lines"] == results[1]["lines"] and results[0]["rounds"] == results[1]["rounds"]
+    assert results[0]["sha"] == results[1]["sha"], "two executor layouts printed different PAF"
+    assert ignores[0] == ignores[1]
+    pipe.close()

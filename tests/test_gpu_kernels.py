@@ -484,6 +484,29 @@ def test_matches_all_ladder_regimes_vs_oracle(ctx, seed):
         assert out["cand"].tolist() == [int(x) for x in want], (seed, hf, min_count)
 
 
+@pytest.mark.parametrize("S", [300, 511])
+def test_matches_exact_count_regime_with_long_queries(ctx, S):
+    """GetSharedIDs with minCount > 24 validates every bit of the 16-ladder's union by counting the sets that hold it
+    (addSoftUnionIDs, util/bitset.go:509-538).  A query of 300 - 511 usable seeds (`overlap` with -overlap_size 2000 -num_seeds 30 on
+    a small genome) has sequences holding more than 255 of them: the device's bit-sliced counter had eight planes until round 5 and
+    dropped exactly those - the best candidates.  Sets in query-seed order, thresholds on both sides of 255."""
+    k = 10
+    ctx.upload_reads(np.frombuffer(b"ACGT" * 30, dtype=np.uint8), np.array([0, 120], dtype=np.int64))
+    rng = np.random.default_rng(S)
+    M = 400
+    dens = rng.choice([0.02, 0.3, 0.6, 0.85, 0.97, 1.0], size=M)
+    member = [[bool(rng.random() < dens[i]) for i in range(M)] for _ in range(S)]
+    assert max(sum(member[s][i] for s in range(S)) for i in range(M)) > 255
+    sets = _index_from_sets(ctx, k, member)
+    qs, qo = _all_seed_query(S)
+    for hf in (0.09, 0.4, 0.8, 0.86, 0.99):
+        min_count = int(hf * S + 0.5)
+        out = ctx.find_overlaps(qs, qo, hf, k, 2 * S + 8, want_candidates=True)
+        want = [int(x) for x in O.shared_ids(sets, min_count, True)]
+        assert len(want) > 0
+        assert out["cand"].tolist() == want, (S, hf, min_count)
+
+
 def test_reference_sequence_test_vectors_on_device(ctx):
     """sequence/sequence_test.go on the device: packBytes("CGGT") = 0x6B (Test9Packing), CountKmers = 27 for k=6 on the
     70-base test sequence with the test's kmerSet (Test6CountKmers), the k=8/k=11 counts on SubSequence(7, len-7), and

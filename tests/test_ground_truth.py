@@ -8,6 +8,7 @@ import pytest
 
 from tests import oracle_lib as O
 from tools.synth import gen_reads_truth
+from tools.truth import map_truth
 
 
 def _check(paf, off, starts, strands, min_exact, k=10, min_within_k=None):
@@ -61,36 +62,6 @@ def test_product_paf_describes_true_overlaps():
 
 
 # ------------------------------------------------------------------------------------------------------------------ map
-def map_truth(paf, off, starts, strands, G, n_reads=None):
-    """`downpore map` PAF against where the generator took every read from (the reference publishes recall / precision of its
-    mapper against a truth set, README.md:220-232).  A mapping is TRUE when its strand is the read's and both ends of its
-    reference interval lie where the read's mapped stretch [qstart, qend) really came from, to within 3 % of the read's length
-    + 100 bases (the generator's insertions and deletions shift coordinates; a circular reference is compared modulo G).
-    Returns dict(mappings, true, precision, reads_mapped, reads_true = reads with at least one true mapping, recall,
-    covered = mean fraction of a truly mapped read's bases inside its true mappings)."""
-    L = np.diff(off)
-    rows = [ln.split("\t") for ln in paf.split("\n") if ln]
-    f = np.array([r[:9] for r in rows], dtype=object)
-    r = np.array([int(x[1:]) for x in f[:, 0]])
-    qs, qe, ts, te = (f[:, c].astype(np.int64) for c in (2, 3, 7, 8))
-    minus = f[:, 4] == "-"
-    exp_s = np.where(strands[r] == 0, starts[r] + qs, starts[r] + L[r] - qe)
-    exp_e = np.where(strands[r] == 0, starts[r] + qe, starts[r] + L[r] - qs)
-    tol = (0.03 * L[r] + 100).astype(np.int64)
-
-    def near(a, b):
-        d = np.abs(a - b) % G
-        return np.minimum(d, G - d) <= tol
-    true = (minus == (strands[r] == 1)) & near(ts, exp_s) & near(te, exp_e)
-    n = len(L) if n_reads is None else n_reads
-    covered = np.zeros(len(L))
-    np.add.at(covered, r[true], (qe - qs)[true])
-    reads_true = np.unique(r[true])
-    return dict(mappings=len(rows), true=int(true.sum()), precision=float(true.mean()), reads_mapped=int(len(np.unique(r))),
-                reads_true=int(len(reads_true)), recall=float(len(reads_true) / n),
-                covered=float((covered[reads_true] / L[reads_true]).mean()))
-
-
 def test_oracle_map_paf_finds_the_true_positions():
     """The oracle's mapper on 10 % error reads (BASELINE config 3's error rate) against a 1 Mb circular reference: the reference's
     own figures on E. coli are 99.9 % recall over the input sequences and 99.98 % precision (README.md:222-237)."""

@@ -34,9 +34,30 @@ def e2e(k, kw, rounds=2):
     orun = O.OverlapRun(rs, k=k, max_rounds=rounds, traces=True, **kw)
     reads = Reads(bases, off, min_len=kw.get("overlap_size", 1000))
     pipe = OverlapPipeline(reads, k=k, slots=1, **kw)
-    n = pipe.run(rounds)
-    d = first_diff(pipe.all_paf(), "".join(orun.trace_paf(r) for r in range(n)))
-    print("   e2e %d rounds: %s" % (n, "EQUAL" if d is None else d), flush=True)
+    pipe.H.dph_overlap_set_round_limit.restype = None
+    import ctypes as C
+    pipe.H.dph_overlap_set_round_limit.argtypes = [C.c_void_p, C.c_int64]
+    pipe.H.dph_overlap_set_round_limit(pipe.h, rounds)
+    n = 0
+    while n < rounds:
+        c = pipe.step()
+        if c == 0:
+            break
+        st = pipe.stats()
+        got = pipe.round_paf()
+        want = "".join(orun.trace_paf(r) for r in range(n, n + c))
+        print("   rounds %d..%d: product queries %d indexed %d matches %d paf %d | oracle queries %d indexed %d matches %d paf %d" % (
+            n, n + c - 1, st["n_queries"], st["n_indexed"], st["n_matches"], got.count("\n"),
+            len(orun.trace(n + c - 1, "queryIDs")), len(orun.trace(n + c - 1, "indexedIds")), len(orun.trace(n + c - 1, "matchTarget")), want.count("\n")))
+        gs, ws = set(got.split("\n")), set(want.split("\n"))
+        only_w = [x for x in want.split("\n") if x not in gs]
+        only_g = [x for x in got.split("\n") if x not in ws]
+        print("     lines only in oracle %d, only in product %d" % (len(only_w), len(only_g)))
+        for x in only_w[:6]:
+            print("       want:", x)
+        for x in only_g[:6]:
+            print("       got: ", x)
+        n += c
     pipe.close()
 
 
@@ -57,7 +78,7 @@ def staged(k, kw, rounds=2):
         ctx.import_segments(isegs)
         nseeds = ((ioffs[1:] - ioffs[:-1]) // 2).astype(np.uint32)
         ctx.index_build(ioffs[:-1].astype(np.uint64), nseeds)
-        out = ctx.find_overlaps(qsegs, qoffs.astype(np.uint64), kw.get("min_hits", 0.25), k, 500, want_candidates=True)
+        out = ctx.find_overlaps(qsegs, qoffs.astype(np.uint64), kw.get("min_hits", 0.25), k, kw.get("overlap_size", 1000) // 2, want_candidates=True)
         cdata, coffs = run.trace(rnd, "candidates")
         print("   round %d: %d seeds, %d indexed, %d queries (max %d seeds), %d candidates, %d matches" % (
             rnd, len(seed_kmers), len(ioffs) - 1, len(qoffs) - 1, int(((qoffs[1:] - qoffs[:-1]) // 2).max()), len(cdata),
@@ -93,8 +114,7 @@ if __name__ == "__main__":
     elif mode == "staged":
         staged(k, kw)
     else:
-        for env in ({}, {"DP_DEVICE_CONSENSUS": "0"}, {"DP_DEVICE_CHUNK": "0"}, {"DP_CHAIN_TIER": "3"}, {"DP_SCAN_INDEX": "0"},
-                    {"DP_CONS_HUGE": "1"}):
+        for env in ({}, {"DP_DEVICE_CONSENSUS": "0", "DP_DEVICE_CHUNK": "0", "DP_FIND_PENDING": "0", "DP_QUERY_PRESTAGE": "0"}):
             print("== e2e with", env, flush=True)
             subprocess.run([sys.executable, __file__, sys.argv[1], sys.argv[2], "e2e"], env=dict(os.environ, **env))
         print("== staged", flush=True)
