@@ -541,6 +541,262 @@ struct kidx_walk {
 }
 };
 
+// ---- round 5: the counting step without scattered atomics - hits binned by read range, counted in LDS ---------------------------
+// The count walk of rounds 1 - 4 bumps a counter per hit: 450 k memory-side atomics per config-2 round (10 M in the dense regime),
+// each a 64-byte request of its own - 6.8 x the step's algorithmic bytes (profiles/kindex_traffic.json, round 4).  Here the walk
+// writes every hit that counts as an 8-byte record into the BIN of its read (bin = item >> bshift: a few hundred bins of 512 .. 16 k
+// consecutive reads) and touches no counter:
+//   kidx_walk_bin   a workgroup of 16 waves walks its seeds' buckets twice.  Sweep 0 counts its hits per bin in LDS; one returning
+//                   atomic per (workgroup, bin touched) reserves a stretch of the bin's records - a few thousand atomics on a few
+//                   hundred addresses per round instead of one per hit; sweep 1 (bucket entries from the L2 now) writes the records.
+//                   Hits on the round's query windows (extra items) are counted as before (a few thousand per round) and kept in a
+//                   list of their own.
+//   kidx_bin_count  one workgroup per bin: its reads' counters live in LDS, every record is one LDS atomic; the counts go to
+//                   memory as plain coalesced stores.
+//   kidx_offsets    unchanged.
+//   kidx_bin_fill   one workgroup per bin again: the survivors' records get their slot from an LDS counter (the rank no longer
+//                   travels inside the record) and go to the read's segment slice; the extra items' list is filled by the blocks
+//                   behind the bins.
+// A bin that is full (sized from the previous round: 1.5 x its hits) counts the rest of its hits the old way and raises the flag
+// that sends the round's fill pass to the bucket-walking form (dp_kindex_refill + dp_kindex_write) - counts are right either way.
+#define KX_MAXBINS 1024
+#define KXB_SEED_BITS 22
+#define KXB_RIB_BITS 14
+struct KxBins {
+    unsigned long long* rec;  // [n_bins * cap]: [59:46] read - first read of the bin, [45:24] seed, [23:0] position in the read
+    uint32_t* cursor;         // [n_bins] records handed out per bin (zeroed with the work area)
+    uint32_t* flags;          // [0] a bin or the extra list was full
+    uint32_t cap, n_bins, bshift;
+    uint4* xrec;              // hits on extra items: {item, position in the item, seed, 0}
+    uint32_t* xcursor;        // [1]
+    uint32_t xcap;
+    const uint8_t* ign;       // the walk's short cut (dp_kindex_fast), or null
+    uint32_t qlo, qspan;
+};
+static_assert(KXB_SEED_BITS + KXB_RIB_BITS + 24 <= 64, "a binned hit record is one 64-bit word");
+static_assert((1u << KXB_RIB_BITS) * 4 <= 65536, "a bin's counters live in one workgroup's LDS");
+__device__ __forceinline__ unsigned long long kxb_rec(uint32_t rib, uint32_t s, uint32_t p) {
+    return ((unsigned long long)rib << (KXB_SEED_BITS + 24)) | ((unsigned long long)s << 24) | (unsigned long long)(p & 0xffffffu);
+}
+
+struct kidx_walk_bin {
+    enum { THREADS = 1024, WAVES = 16 };
+    template <int SWEEP>
+    static __device__ __forceinline__ void sweep(const uint32_t w, const uint32_t* __restrict__ seeds, uint32_t n_seeds,
+                                                 const uint64_t* __restrict__ off, const KxPos pos, const dp_scan_item* __restrict__ items,
+                                                 uint32_t lo, uint32_t hi, uint32_t n_read_items, const uint32_t* __restrict__ head,
+                                                 const uint32_t* __restrict__ next, uint32_t* __restrict__ counts, uint32_t lps, const KxBins B,
+                                                 uint32_t* hist, const uint32_t* base, unsigned long long* sh_hits) {
+        const int lane = dp_lane();
+        uint32_t s, i0, i1, step, n, gfirst;
+        uint64_t o;
+        bool gleader;
+        if (lps == 64) {  // (the groups of kidx_walk: KX_PARTS waves per seed, or four seeds per wave)
+            s = w / KX_PARTS;
+            const uint32_t part = w % KX_PARTS;
+            if (s >= n_seeds) return;
+            o = off[seeds[s]];
+            n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
+            const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
+            gfirst = min(n, part * per);
+            i0 = part * per + 4u * (uint32_t)lane;
+            i1 = min(n, part * per + per);
+            step = 64;
+            gleader = lane == 0;
+        } else {
+            s = w * 4 + ((uint32_t)lane >> 4);
+            if (s >= n_seeds) return;
+            o = off[seeds[s]];
+            n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
+            gfirst = 0;
+            i0 = 4u * ((uint32_t)lane & 15u);
+            i1 = n;
+            step = 16;
+            gleader = (lane & 15) == 0;
+        }
+        if (SWEEP == 0 && gleader && i1 > gfirst) atomicAdd(sh_hits, (unsigned long long)(i1 - gfirst));
+        const uint32_t rmask = (1u << B.bshift) - 1u;
+        for (uint32_t ib = i0; ib < i1; ib += 4 * step) {
+            uint64_t e[4];
+            bool v[4], valid[4];
+            uint32_t hd[4];
+            kx_entry4(pos, o + ib, e);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                v[u] = ib + (uint32_t)u < i1;
+                e[u] = v[u] ? e[u] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t r = (uint32_t)(e[u] >> 32), p = (uint32_t)e[u];
+                const bool in = v[u] && r >= lo && r < hi;
+                if (B.ign) {
+                    valid[u] = in && !B.ign[r];
+                    hd[u] = (SWEEP == 0 && v[u] && r - B.qlo < B.qspan) ? head[r] : 0u;
+                } else {
+                    // (ignored reads carry n_kmers == 0; a top-level read with len % 4 == 0 four k-mers less)
+                    valid[u] = in && p < items[in ? r - lo : 0u].n_kmers;
+                    hd[u] = (SWEEP == 0 && v[u]) ? head[r] : 0u;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t r = (uint32_t)(e[u] >> 32), p = (uint32_t)e[u];
+                if (valid[u]) {
+                    const uint32_t bin = (r - lo) >> B.bshift;
+                    if (SWEEP == 0) {
+                        atomicAdd(&hist[bin], 1u);
+                    } else {
+                        const uint32_t b = base[bin];
+                        if (b != 0xffffffffu) {
+                            const uint32_t rank = atomicAdd(&hist[bin], 1u);
+                            B.rec[(size_t)bin * B.cap + b + rank] = kxb_rec((r - lo) & rmask, s, p);
+                        } else {
+                            atomicAdd(&counts[r - lo], 1u);  // (the bin is full: counted the old way, kidx_bin_count adds its own on top)
+                        }
+                    }
+                }
+                if (SWEEP == 0) {
+                    for (uint32_t x = hd[u]; x; x = next[x - 1]) {  // the round's extra items on this read (query windows)
+                        const uint32_t it = n_read_items + x - 1;
+                        const dp_scan_item xi = items[it];
+                        if (p - xi.start < xi.n_kmers && p >= xi.start) {
+                            atomicAdd(&counts[it], 1u);
+                            const uint32_t at = atomicAdd(B.xcursor, 1u);
+                            if (at < B.xcap)
+                                B.xrec[at] = make_uint4(it, p - xi.start, s, 0u);
+                            else
+                                B.flags[0] = 1u;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    static __device__ void run(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off, const KxPos pos,
+                               const dp_scan_item* __restrict__ items, uint32_t lo, uint32_t hi, uint32_t n_read_items,
+                               const uint32_t* __restrict__ head, const uint32_t* __restrict__ next, uint32_t* __restrict__ counts,
+                               unsigned long long* __restrict__ n_hits, uint32_t lps, const KxBins B, uint32_t n_waves) {
+        __shared__ uint32_t hist[KX_MAXBINS], base[KX_MAXBINS];
+        __shared__ unsigned long long sh_hits;
+        const uint32_t stride = gridDim.x * WAVES;
+        // (every wave of a workgroup makes the same number of trips: the barriers below are the workgroup's)
+        for (uint32_t wb = blockIdx.x * WAVES; wb < n_waves; wb += stride) {
+            for (uint32_t t = threadIdx.x; t < B.n_bins; t += THREADS) hist[t] = 0u;
+            if (threadIdx.x == 0) sh_hits = 0ull;
+            __syncthreads();
+            const uint32_t w = wb + (threadIdx.x >> 6);
+            if (w < n_waves) sweep<0>(w, seeds, n_seeds, off, pos, items, lo, hi, n_read_items, head, next, counts, lps, B, hist, base, &sh_hits);
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < B.n_bins; t += THREADS) {
+                const uint32_t c = hist[t];
+                uint32_t b = 0u;
+                if (c) {
+                    b = atomicAdd(&B.cursor[t], c);
+                    if (b + c > B.cap) {  // (its share of the bin does not fit: the whole share is counted the old way)
+                        b = 0xffffffffu;
+                        B.flags[0] = 1u;
+                    }
+                }
+                base[t] = b;
+                hist[t] = 0u;
+            }
+            if (threadIdx.x == 0 && sh_hits) atomicAdd(&n_hits[blockIdx.x & 63u], sh_hits);  // seed occurrences of the round (totals[2])
+            __syncthreads();
+            if (w < n_waves) sweep<1>(w, seeds, n_seeds, off, pos, items, lo, hi, n_read_items, head, next, counts, lps, B, hist, base, &sh_hits);
+            __syncthreads();
+        }
+    }
+};
+
+// RB = counters a workgroup's LDS holds (reads per bin <= RB)
+template <int RB>
+struct kidx_bin_count {
+    enum { THREADS = 512 };
+    static __device__ void run(const KxBins B, uint32_t* __restrict__ counts, uint32_t n_read_items) {
+        __shared__ uint32_t cnt[RB];
+        const uint32_t bin = blockIdx.x;
+        if (bin >= B.n_bins) return;
+        const uint32_t rb = 1u << B.bshift, first = bin << B.bshift;
+        const uint32_t n = min(B.cursor[bin], B.cap);
+        for (uint32_t i = threadIdx.x; i < rb; i += THREADS) cnt[i] = 0u;
+        __syncthreads();
+        const unsigned long long* rec = B.rec + (size_t)bin * B.cap;
+        for (uint32_t jb = 4u * threadIdx.x; jb < n; jb += 4u * THREADS) {  // (four consecutive records per thread and trip)
+            unsigned long long e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = jb + (uint32_t)u < n ? rec[jb + u] : ~0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (e[u] != ~0ull) atomicAdd(&cnt[(uint32_t)(e[u] >> (KXB_SEED_BITS + 24))], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < rb; i += THREADS) {
+            const uint32_t it = first + i;
+            if (it < n_read_items) {
+                const uint32_t c = cnt[i];
+                if (c) counts[it] += c;  // (zeroed by kidx_prepare; a full bin's overflow was counted there directly)
+            }
+        }
+    }
+};
+
+template <int RB>
+struct kidx_bin_fill {
+    enum { THREADS = 512, XBLOCKS = 8 };
+    static __device__ void run(const KxBins B, const dp_scan_item* __restrict__ items, uint32_t n_read_items,
+                               const uint32_t* __restrict__ counts, uint32_t* __restrict__ fillc, const uint64_t* __restrict__ segoff,
+                               int32_t* __restrict__ segs, const uint64_t* __restrict__ totals, uint64_t seg_cap) {
+        __shared__ uint32_t cnt[RB];
+        if (B.flags[0] || totals[0] > seg_cap) return;  // (the host repeats the fill with the bucket walk / a larger buffer)
+        if (blockIdx.x >= B.n_bins) {  // the extra items' hits: a slot from the item's fill cursor, as ever
+            const uint32_t xb = blockIdx.x - B.n_bins;
+            if (xb >= XBLOCKS) return;
+            const uint32_t nx = min(*B.xcursor, B.xcap);
+            for (uint32_t j = xb * THREADS + threadIdx.x; j < nx; j += XBLOCKS * THREADS) {
+                const uint4 x = B.xrec[j];
+                if (counts[x.x] >= items[x.x].min_seeds) {
+                    const uint32_t slot = atomicAdd(&fillc[x.x], 1u);
+                    const uint64_t to = segoff[x.x] + 2ull * slot;
+                    segs[to] = (int32_t)x.y;
+                    segs[to + 1] = (int32_t)x.z;
+                }
+            }
+            return;
+        }
+        const uint32_t bin = blockIdx.x;
+        const uint32_t rb = 1u << B.bshift, first = bin << B.bshift;
+        const uint32_t n = min(B.cursor[bin], B.cap);
+        // slot counters of the bin's survivors (top bit: the read does not survive - its own min_seeds, what kidx_offsets tested)
+        for (uint32_t i = threadIdx.x; i < rb; i += THREADS) {
+            const uint32_t it = first + i;
+            bool surv = false;
+            if (it < n_read_items) {
+                const uint32_t c = counts[it];
+                surv = c > 0u && c >= items[it].min_seeds;
+            }
+            cnt[i] = surv ? 0u : 0x80000000u;
+        }
+        __syncthreads();
+        const unsigned long long* rec = B.rec + (size_t)bin * B.cap;
+        for (uint32_t jb = 4u * threadIdx.x; jb < n; jb += 4u * THREADS) {
+            unsigned long long e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = jb + (uint32_t)u < n ? rec[jb + u] : ~0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (e[u] == ~0ull) continue;
+                const uint32_t rib = (uint32_t)(e[u] >> (KXB_SEED_BITS + 24));
+                if (cnt[rib] & 0x80000000u) continue;
+                const uint32_t rank = atomicAdd(&cnt[rib], 1u);
+                const uint64_t to = segoff[first + rib] + 2ull * rank;
+                segs[to] = (int32_t)((uint32_t)e[u] & 0xffffffu);
+                segs[to + 1] = (int32_t)((uint32_t)(e[u] >> 24) & ((1u << KXB_SEED_BITS) - 1u));
+            }
+        }
+    }
+};
+
 // status word of a tile: flag << 62 | survivors << 38 | segment ints (flag 1 = the tile's own sums, 2 = inclusive prefix)
 #define KX_TILE 1024
 #ifndef KX_IPT
@@ -853,12 +1109,13 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     uint32_t* head = (uint32_t*)ctx->d_kx_lo.p;
     uint32_t* next = (uint32_t*)ctx->d_kx_vals.p;
     const size_t b_counts = (size_t)n_items * 4;
-    if (dev_reserve(ctx, ctx->d_kx_sz, 2 * b_counts + ((size_t)n_tiles + 2) * 8 + 64 * 8 + 128)) return DP_ERR_HIP;
+    if (dev_reserve(ctx, ctx->d_kx_sz, 2 * b_counts + ((size_t)n_tiles + 2) * 8 + 64 * 8 + (KX_MAXBINS + 2) * 4 + 128)) return DP_ERR_HIP;
     uint32_t* fillc = (uint32_t*)ctx->d_kx_sz.p;
     unsigned long long* status = (unsigned long long*)((uint8_t*)ctx->d_kx_sz.p + ((b_counts + 7) & ~(size_t)7));
     uint32_t* ticket = (uint32_t*)(status + n_tiles + 1);
     unsigned long long* n_hits = (unsigned long long*)(ticket + 2);  // [64]
-    const uint32_t n_work = (uint32_t)((((b_counts + 7) & ~(size_t)7) + ((size_t)n_tiles + 1) * 8 + 8 + 64 * 8 + 8) / 4);
+    uint32_t* bin_cursor = (uint32_t*)(n_hits + 64);                 // [KX_MAXBINS] + the extra list's cursor (round 5, KxBins)
+    const uint32_t n_work = (uint32_t)((((b_counts + 7) & ~(size_t)7) + ((size_t)n_tiles + 1) * 8 + 8 + 64 * 8 + (KX_MAXBINS + 2) * 4) / 4);
     DP_HIP(dp_mark(ctx, 0));
     {
         const uint32_t n_thr = std::max(std::max(n_work, n_items), std::max(n_extra, 16u));
@@ -890,6 +1147,34 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             R.shard_cap = (uint32_t)shard;
         }
     }
+    // round 5: hits binned by read range and counted in LDS instead of one memory-side atomic per hit (DP_KX_BINS=0: the records of
+    // round 4).  Bins of 512 .. 16 k reads, at most 256 of them while that keeps a bin inside the LDS; the bins share the record
+    // buffer of the shards (1.5 x the previous round's hits + 4096 each), the extra items' list lives in the group table's place.
+    KxBins B{};
+    const char* bins_env = getenv("DP_KX_BINS");  // (read per call: tests switch it between jobs of one process)
+    const bool bins_on = !(bins_env && bins_env[0] == '0');
+    if (one && R.rec && bins_on && n_read_items && S < (1u << KXB_SEED_BITS)) {
+        uint32_t bshift = 9;
+        while (((n_read_items + (1u << bshift) - 1) >> bshift) > 256 && bshift < KXB_RIB_BITS) bshift++;
+        const uint32_t n_bins = (n_read_items + (1u << bshift) - 1) >> bshift;
+        const uint64_t total = (uint64_t)R.shard_cap * 64;
+        const uint64_t xcap = std::max<uint64_t>(65536, total / 8);
+        if (n_bins <= KX_MAXBINS && total / n_bins >= 1024) {
+            if (dev_reserve(ctx, ctx->d_kx_tmp, std::max((size_t)n_groups * 8, (size_t)xcap * 16) + 64)) return DP_ERR_HIP;
+            B.rec = R.rec;
+            B.cursor = bin_cursor;
+            B.flags = R.flags;
+            B.cap = (uint32_t)std::min<uint64_t>(total / n_bins, 0x7fffffffu);
+            B.n_bins = n_bins;
+            B.bshift = bshift;
+            B.xrec = (uint4*)ctx->d_kx_tmp.p;
+            B.xcursor = bin_cursor + KX_MAXBINS;
+            B.xcap = (uint32_t)xcap;
+            B.ign = R.ign;
+            B.qlo = R.qlo;
+            B.qspan = R.qspan;
+        }
+    }
     static const bool kx_debug = getenv("DP_KX_DEBUG") != nullptr;
     unsigned long long* dbg = nullptr;
     const size_t n_dbg_waves = (size_t)kidx_walk_blocks(ix, k, S) * 4;
@@ -897,7 +1182,18 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         DP_HIP(dp_dev_malloc((void**)&dbg, n_dbg_waves * 64));
         DP_HIP(hipMemsetAsync(dbg, 0, n_dbg_waves * 64, ctx->stream));
     }
-    if (S)
+    if (S && B.rec) {
+        const uint32_t n_waves = kidx_walk_blocks(ix, k, S) * 4;
+        dp_launch<kidx_walk_bin>(ctx, dim3((n_waves + kidx_walk_bin::WAVES - 1) / kidx_walk_bin::WAVES), dim3(kidx_walk_bin::THREADS),
+                                 dp_seeds_ptr(ctx), S, (const uint64_t*)ix->off.p, ix->view(), d_items, lo, hi, n_read_items, (const uint32_t*)head,
+                                 (const uint32_t*)next, d_counts, n_hits, lps, B, n_waves);
+        if (B.bshift <= 9)
+            dp_launch<kidx_bin_count<512>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items);
+        else if (B.bshift <= 11)
+            dp_launch<kidx_bin_count<2048>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items);
+        else
+            dp_launch<kidx_bin_count<16384>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items);
+    } else if (S)
         dp_launch<kidx_walk<false>>(ctx, dim3(kidx_walk_grid(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
                            (const uint64_t*)ix->off.p, ix->view(), d_items, lo, hi, n_read_items, (const uint32_t*)head,
                            (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k), dbg, R,
@@ -948,6 +1244,18 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     DP_HIP(dp_mark(ctx, 1));
     if (one && R.rec) {
         DP_HIP(dp_mark(ctx, 2));
+        if (B.rec) {
+            const dim3 fg(B.n_bins + kidx_bin_fill<512>::XBLOCKS), fb(512);
+            if (B.bshift <= 9)
+                dp_launch<kidx_bin_fill<512>>(ctx, fg, fb, B, d_items, n_read_items, (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff,
+                                              one->d_segs, (const uint64_t*)d_totals, one->seg_cap);
+            else if (B.bshift <= 11)
+                dp_launch<kidx_bin_fill<2048>>(ctx, fg, fb, B, d_items, n_read_items, (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff,
+                                               one->d_segs, (const uint64_t*)d_totals, one->seg_cap);
+            else
+                dp_launch<kidx_bin_fill<16384>>(ctx, fg, fb, B, d_items, n_read_items, (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff,
+                                                one->d_segs, (const uint64_t*)d_totals, one->seg_cap);
+        } else
         dp_launch<kidx_fill_rec>(ctx, dim3(kidx_walk_blocks(ix, k, S)), dim3(256), R, n_groups, lps, d_items, lo, n_read_items, one->min_seeds,
                                  (const uint32_t*)head, (const uint32_t*)next, (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff,
                                  one->d_segs, (const uint64_t*)d_totals, one->seg_cap);

@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+# DPO_LIB: another build of the same checker (the AddressSanitizer build of `make -C oracle asan`, tests/test_host_asan.py)
+_ORACLE_SO = os.environ.get("DPO_LIB") or os.path.join(ROOT, "oracle", "_build", "liboracle.so")
 _SYNTH_SO = os.path.join(ROOT, "tools", "libdpsynth.so")
 
 i64p = C.POINTER(C.c_int64)
