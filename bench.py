@@ -82,6 +82,11 @@ def main():
     ap.add_argument("--dense-leg-rounds", type=int, default=12,
                     help="N=1: after the timed region, this many rounds of the dense-seed regime (k=10) where the index query "
                          "carries real traffic (reported as index_query_dense; 0 = skip)")
+    ap.add_argument("--dense-job", type=int, default=1,
+                    help="N=1: after the timed region, ONE whole job with the command's default k = 10 on the same reads (every read indexed "
+                         "in every round), reported as overlap_default_k10_job with ground truth and first-16-round fixture parity (0 = skip)")
+    ap.add_argument("--map-cpu-baseline", type=int, default=1,
+                    help="map_config3: also time the oracle's mapper on the host (about 5 s, one core) as its cpu_baseline (0 = skip)")
     ap.add_argument("--map-leg-repeats", type=int, default=3,
                     help="N=1: after the timed region, BASELINE config 3 (`downpore map`: 50k reads x 8 kb against a 4.6 Mb circular "
                          "reference, k=11) this many times, reported as map_config3 with its PAF held to the oracle's fixture (0 = skip)")
@@ -182,6 +187,8 @@ def main():
     upload = pipe.setup_times()
     if world > 1 and rank != 0:
         pipe.keep_text(False)  # (rank 0 verifies and would print the PAF; the others commit the gathered rounds without their text)
+    if world > 1 and comm is not None and getattr(pipe, "mode", "") == "round":
+        pipe.text_root(0)      # (round 5: the text is gathered to rank 0 alone, the rounds' control records - a few KB - to every rank)
 
     def sync():
         torch.cuda.synchronize()
@@ -297,12 +304,17 @@ def main():
     alt = None
     if alt_mode_name is not None:  # collective: every rank takes part
         alt = alt_mode_jobs(alt_mode_name, reads, args, rank, world, local_rank, torch_device, comm, golden, torch, dist)
+    dense_leg5 = dense_job = None
     if world == 1 and args.dense_leg_rounds > 0:
         dense_leg = dense_regime_leg(reads, args, torch)
+        if args.slots > 1:
+            dense_leg5 = dense_regime_leg(reads, args, torch, slots=args.slots)
+    if world == 1 and args.dense_job:
+        dense_job = dense_job_leg(reads, args, torch, off, truth_starts, truth_strands)
 
     map_leg = None
     if world == 1 and args.map_leg_repeats > 0:
-        map_leg = map_config3_leg(args.map_leg_repeats)
+        map_leg = map_config3_leg(args.map_leg_repeats, cpu=bool(args.map_cpu_baseline))
 
     stream_gbs = None
     if rank == 0:
@@ -397,7 +409,7 @@ def main():
                                        "frac_of_hbm_peak": ((v[1] / 1e9) / (v[0] / 1e3)) / HBM_PEAK_GBS if v[0] > 0 else 0.0}
                                   for kk, v in kern.items()},
             "scan_mode": "resident k-mer position index" if main_index else "scan kernels",
-            "scan_kernels_leg": scan_leg, "index_query_dense": dense_leg, "map_config3": map_leg, "alt_mode": alt,
+            "scan_kernels_leg": scan_leg, "index_query_dense": dense_leg, "index_query_dense_slots": dense_leg5, "overlap_default_k10_job": dense_job, "map_config3": map_leg, "alt_mode": alt,
             "paf_lines": lines, "rounds_per_s": rounds / elapsed if elapsed > 0 else 0.0,
             "phase_ms_per_round": {kk: 1e3 * per_round(kk) for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
             "kernel_ms_per_round": {kk: per_round(kk) for kk in ("k_count_ms", "k_write_ms", "k_scan_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
@@ -433,6 +445,8 @@ def alt_mode_jobs(mode, reads, args, rank, world, local_rank, torch_device, comm
                            torch_device=torch_device, mode=mode, slots=args.slots, defer_init=True, comm=comm)
     if world > 1 and rank != 0:
         pipe.keep_text(False)
+    if world > 1 and comm is not None and getattr(pipe, "mode", "") == "round":
+        pipe.text_root(0)
 
     def sync():
         torch.cuda.synchronize()
@@ -536,14 +550,14 @@ def _rounds_leg(pipe, n_rounds, torch, warm, fixture=None):
             "_rounds": float(got), "_count_bytes": d.get("count_bytes", 0.0)}
 
 
-def dense_regime_leg(reads, args, torch):
+def dense_regime_leg(reads, args, torch, slots=1):
     """The dense-seed regime of SURVEY 8(a) (`-k 10`, the command's default k): every read is indexed (~190 k sequences per
     round, W ~ 3 k words), so the index query streams hundreds of MB of posting words per round - the regime in which the
     north star's "HBM roofline during index-query" is a meaningful number.  Same reads, same code path."""
     from downpore_amd.overlap import OverlapPipeline
     # one executor slot: the leg is here for the kernel's own duration (its roofline), and eight rounds in flight would have
     # eight of these streaming kernels share the HBM bandwidth and each launch take several times longer
-    pipe = OverlapPipeline(reads, device=0, k=10, seed_batch_size=args.seed_batch_size, slots=1, defer_init=True)
+    pipe = OverlapPipeline(reads, device=0, k=10, seed_batch_size=args.seed_batch_size, slots=slots, defer_init=True)
     # the leg's rounds (4 untimed + the timed ones) are the first rounds of the k = 10 job on these reads: held to the oracle's
     # fixture for exactly those rounds when one is committed (tests/golden_full/config2_k10_e0_first_16_rounds.json)
     fixture = None
@@ -563,16 +577,80 @@ def dense_regime_leg(reads, args, torch):
     leg["query_kernel"] = {"launch_ms": qms, "algorithmic_bytes_per_launch": qb,
                            "achieved_GBs": (qb / 1e9) / (qms / 1e3) if qms > 0 else 0.0,
                            "frac_of_hbm_peak": ((qb / 1e9) / (qms / 1e3)) / HBM_PEAK_GBS if qms > 0 else 0.0}
-    leg["workload"] = "same reads, k=10 (dense seeds): %d rounds, one executor slot (kernel durations without other rounds in flight)" % int(m)
+    leg["workload"] = ("same reads, k=10 (dense seeds): %d rounds, %s" %
+                       (int(m), "one executor slot (kernel durations without other rounds in flight)" if slots == 1 else
+                        "%d executor slots (what the index query keeps of its rate beside other rounds' kernels)" % slots))
+    leg["slots"] = slots
     return leg
 
 
-def map_config3_leg(repeats):
+def dense_job_leg(reads, args, torch, off, truth_starts, truth_strands):
+    """The command's DEFAULT regime as a whole job: `downpore overlap` with its default k = 10 (commands/overlap.go:25) on the config-2
+    reads - value table, k-mer position index, every round - timed once; its PAF is held to the synthetic genome (tools/truth.py) and
+    its first 16 rounds to the oracle's fixture (the prefix of the job's PAF)."""
+    from downpore_amd.overlap import OverlapPipeline
+    pipe = OverlapPipeline(reads, device=0, k=10, seed_batch_size=args.seed_batch_size, slots=args.slots, defer_init=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.init()
+    t_init = time.perf_counter() - t0
+    sha_head, fixture, head_left = None, None, 0
+    try:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden_full", "config2_k10_e0_first_16_rounds.json")))
+        gen = g["generator"]
+        if (gen["seed"] == args.seed and gen["reads"] == args.reads and gen["read_len"] == args.read_len and gen["error"] == args.error and
+                not gen["variable"] and args.seed_batch_size == 10000):
+            fixture, head_left, sha_head = g, g["paf_lines"], hashlib.sha256()
+    except Exception:
+        fixture = None
+    import ctypes as C
+    lines = rounds = 0
+    sample = []
+    sample_lines = 0
+    while True:
+        c = pipe.step()
+        if c == 0:
+            break
+        rounds += c
+        n = C.c_int64(0)
+        ptr = pipe.H.dph_overlap_round_paf(pipe.h, C.byref(n))
+        text = C.string_at(ptr, n.value)
+        nl = text.count(b"\n")
+        if head_left > 0:  # the fixture's rounds are the first lines of the job
+            cut, pos = 0, -1
+            while cut < head_left:
+                pos = text.find(b"\n", pos + 1)
+                if pos < 0:
+                    break
+                cut += 1
+            sha_head.update(text[:pos + 1] if pos >= 0 else text)
+            head_left -= cut
+        if sample_lines < 200000 and rounds % 7 == 0:  # ground truth on rounds spread over the job
+            sample.append(text)
+            sample_lines += nl
+        lines += nl
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tot = pipe.stats_total()
+    pipe.reset()
+    pipe.close()
+    nt = max(1.0, tot.get("timed_rounds", 0.0))
+    return {"workload": "downpore overlap with the command's default k = 10 on the same reads (dense seeds: every read indexed in every round), whole job, %d executor slots" % args.slots,
+            "value": lines / dt if dt > 0 else 0.0, "unit": "overlaps/s", "wall_s": dt, "setup_s": t_init, "rounds": rounds, "paf_lines": lines,
+            "ms_per_round": 1e3 * (dt - t_init) / max(1, rounds),
+            "kernel_ms_per_round": {kk: tot.get(kk, 0.0) / nt for kk in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
+            "query_kernel_GBs": (tot.get("query_bytes", 0.0) / max(1, rounds) / 1e9) / (tot.get("k_query_ms", 0.0) / nt / 1e3) if tot.get("k_query_ms", 0.0) > 0 else 0.0,
+            "parity": {"first_16_rounds_match_oracle_fixture": bool(fixture is not None and head_left == 0 and sha_head.hexdigest() == fixture["paf_sha256"]) if fixture else None},
+            "ground_truth": ground_truth(b"".join(sample), off, truth_starts, truth_strands, 10) if sample else None}
+
+
+def map_config3_leg(repeats, cpu=True):
     """BASELINE config 3 - the whole `downpore map` command (commands/map.go:33-116) on the GPU: 50 000 reads x 8 kb (10 % error)
     against a 4.6 Mb circular reference, k = 11, from the reads in host memory to the last PAF line (reference k-mer table,
     AddSingleSeeds, reference index, upload + packing of both strands, window scans, index query + chaining, mapper control
     flow, text).  PAF against the oracle's fixture (tests/golden_full/config3_map.json)."""
-    from tools.synth import gen_genome, gen_reads
+    from tools.synth import gen_genome, gen_reads_truth
+    from tools.truth import map_truth
     from downpore_amd.mapping import map_reads
     from downpore_amd.overlap import Reads
     try:
@@ -582,10 +660,10 @@ def map_config3_leg(repeats):
     gen = g["generator"]
     genome = np.frombuffer(gen_genome(gen["seed"], gen["genome"]), dtype=np.uint8)
     goff = np.array([0, gen["genome"]], dtype=np.int64)
-    bases, off = gen_reads(gen["seed"], gen["genome"], gen["reads"], gen["read_len"], gen["error"], False)
+    bases, off, t_starts, t_strands = gen_reads_truth(gen["seed"], gen["genome"], gen["reads"], gen["read_len"], gen["error"], False)
     ref = Reads(genome, goff, min_len=0, himem=False)
     reads = Reads(bases, off, min_len=500, himem=False)
-    best, runs, ok, st = None, [], True, None
+    best, runs, ok, st, truth = None, [], True, None, None
     for _ in range(repeats):
         t0 = time.perf_counter()
         paf, err, st_ = map_reads(ref, reads, circular=True, k=g["k"])
@@ -594,19 +672,46 @@ def map_config3_leg(repeats):
         ok = ok and paf.count("\n") == g["paf_lines"] and hashlib.sha256(paf.encode()).hexdigest() == g["paf_sha256"] and err == g["stderr"]
         if best is None or dt < best:
             best, st = dt, st_
+        if truth is None:  # the mappings held to where the generator took the reads from (the reference's own quality figures: README.md:220-237)
+            truth = map_truth(paf, off, t_starts, t_strands, gen["genome"])
         del paf
     n = gen["reads"]
     total_bases = float(off[-1])
+    cpu = None
+    if cpu_wanted(cpu):
+        from tests import oracle_lib as O
+        t0 = time.perf_counter()
+        want, werr = O.map_run(O.ReadSet(genome, goff, min_len=0, himem=False), O.ReadSet(bases, off, min_len=500, himem=False), circular=True, k=g["k"])
+        dtc = time.perf_counter() - t0
+        cpu = {"value": n / dtc, "unit": "reads/s", "cores": 1, "kind": "port", "wall_s": dtc,
+               "sample": "the whole config-3 command (all %d reads) through the oracle's mapper on one host core" % n,
+               "paf_identical": bool(hashlib.sha256(want.encode()).hexdigest() == g["paf_sha256"])}
+        del want
+    # roofline of the device part ("Map"): per window its packed bases scanned on both strands + the index query's posting
+    # words, the prefilter's set words and the chained pairs' segments against the reference index, over the time of the kernels that
+    # move them (window scans + query_kernel + map_kernel, HIP events summed over the run's launches)
+    k_ms = st["k_map_ms"] + st["k_scan_ms"]
+    alg = st.get("map_bytes", 0.0) + st.get("scan_bytes", 0.0)
     return {"workload": "downpore map, BASELINE config 3: %d reads x %d bp (error %.2f) against a %d bp circular reference, k=%d; whole "
                         "command from reads in host memory to the last PAF line" % (n, gen["read_len"], gen["error"], gen["genome"], g["k"]),
             "value": n / best, "unit": "reads/s", "wall_s_best": best, "wall_s_runs": runs, "read_bases_per_s": total_bases / best,
             "paf_sha256_matches_oracle_fixture": bool(ok), "fixture": g["case"],
+            "ground_truth": truth, "cpu_baseline": cpu,
+            "roofline": {"bound": "hbm", "kernels": "scan_kernel (window scans) + query_kernel + map_kernel", "achieved": (alg / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ((alg / 1e9) / (k_ms / 1e3)) / HBM_PEAK_GBS if k_ms > 0 else 0.0, "traffic": None,
+                         "algorithmic_bytes_per_run": alg, "algorithmic_bytes_map_kernels": st.get("map_bytes", 0.0),
+                         "algorithmic_bytes_window_scans": st.get("scan_bytes", 0.0), "kernel_ms_per_run": k_ms,
+                         "algorithmic_bytes_per_window": alg / max(1.0, st["n_windows"])},
             "map_kernel": {"kernel": "map_kernel (A19 + A20: prefilter + SeedSequence.Match of every window pair) + query_kernel", "ms_total": st["k_map_ms"],
                            "launches": st["n_batches"], "windows": st["n_windows"], "chains": st["n_chains"],
                            "windows_per_s_in_kernel": st["n_windows"] / (st["k_map_ms"] / 1e3) if st["k_map_ms"] > 0 else 0.0},
             "scan_kernels_ms_total": st["k_scan_ms"],
             "breakdown_s": {"setup_reference_index_upload": st["t_setup_s"], "window_scans": st["t_scan_s"], "index_query_chaining": st["t_chain_s"],
                             "mapper_control_flow_and_text": st["t_host_s"]}}
+
+
+def cpu_wanted(flag):
+    return bool(flag)
 
 
 def golden_fixture(args):

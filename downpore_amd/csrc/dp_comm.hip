@@ -30,6 +30,8 @@ struct RcclApi {
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -65,6 +67,8 @@ RcclApi* rccl_api() {
         api.CommAbort = (decltype(api.CommAbort))sym("ncclCommAbort");
         api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
         api.Broadcast = (decltype(api.Broadcast))sym("ncclBroadcast");
+        api.Send = (decltype(api.Send))sym("ncclSend");
+        api.Recv = (decltype(api.Recv))sym("ncclRecv");
         api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
         api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
@@ -586,6 +590,108 @@ extern "C" int dp_allgather_blobs(dp_comm* c, dp_ctx* ctx, const uint8_t* blob, 
     if (c->dead) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_blobs: the communicator failed in an earlier exchange");
     const int rc = allgather_blobs_impl(c, ctx, blob, n, all_out, sizes_out);
     if (rc != DP_OK) dp_comm_abort(c);  // (marks the group failed AND aborts an RCCL communicator: the peers' collectives return)
+    return rc;
+}
+
+// ---- gather of one variable-size byte string per rank to ONE rank (the round-parallel layout's PAF text: only the rank that prints
+// needs it) -------------------------------------------------------------------------------------------------------------------
+// sizes[n_ranks] are known to every rank already (they travel inside the control blobs of dp_allgather_blobs), so there is no size
+// exchange: RCCL flavour = one group of ncclSend (every rank but the root) / ncclRecv (the root, straight into the concatenation) and
+// one copy back on the root; in-process flavour = the root copies from the peers' buffers.  Collective.
+static int gather_blobs_impl(dp_comm* c, dp_ctx* ctx, const uint8_t* blob, uint64_t n, const uint64_t* sizes, int root, const uint8_t** all_out) {
+    hipSetDevice(ctx->device);
+    const int N = c->n_ranks, me = c->rank;
+    if (sizes[me] != n) return dp_fail(ctx, DP_ERR_ARG, "dp_gather_blobs: sizes[rank] is not this rank's size");
+    uint64_t tot = 0, my_off = 0;
+    for (int q = 0; q < N; q++) {
+        if (q == me) my_off = tot;
+        tot += sizes[q];
+    }
+    *all_out = nullptr;
+    if (c->local) {
+        LocalGroup* g = c->local;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->blob[(size_t)me].p = blob;
+            g->blob[(size_t)me].n = n;
+            const uint64_t my_gen = g->gen;
+            if (g->failed) return dp_fail(ctx, DP_ERR_STATE, "dp_gather_blobs: a peer rank failed");
+            if (++g->arrived == N) {
+                g->arrived = 0;
+                g->gen++;
+                g->cv.notify_all();
+            } else {
+                g->cv.wait(lk, [&] { return g->gen != my_gen || g->failed; });
+                if (g->gen == my_gen) return dp_fail(ctx, DP_ERR_STATE, "dp_gather_blobs: a peer rank failed");
+            }
+        }
+        if (me == root) {
+            if (comm_pin(ctx, c->h_blob, tot + 64)) return DP_ERR_HIP;
+            uint8_t* out = (uint8_t*)c->h_blob.p;
+            uint64_t at = 0;
+            for (int r = 0; r < N; r++) {
+                if (g->blob[(size_t)r].n != sizes[r]) return dp_fail(ctx, DP_ERR_ARG, "dp_gather_blobs: a peer's size differs from sizes[]");
+                if (sizes[r]) memcpy(out + at, g->blob[(size_t)r].p, sizes[r]);
+                at += sizes[r];
+            }
+            *all_out = out;
+        }
+        std::unique_lock<std::mutex> lk(g->mu);  // (nobody may touch its blob again before the root has copied it)
+        const uint64_t my_gen = g->gen;
+        if (g->failed) return dp_fail(ctx, DP_ERR_STATE, "dp_gather_blobs: a peer rank failed");
+        if (++g->left == N) {
+            g->left = 0;
+            g->gen++;
+            g->cv.notify_all();
+        } else {
+            g->cv.wait(lk, [&] { return g->gen != my_gen || g->failed; });
+            if (g->gen == my_gen) return dp_fail(ctx, DP_ERR_STATE, "dp_gather_blobs: a peer rank failed");
+        }
+        return DP_OK;
+    }
+    if (!c->nccl) return dp_fail(ctx, DP_ERR_STATE, "dp_gather_blobs: communicator without a transport");
+    RcclApi* R = rccl_api();
+    if (!R->Send || !R->Recv) return dp_fail(ctx, DP_ERR_STATE, "librccl lacks ncclSend / ncclRecv");
+    ncclResult_t r = ncclSuccess;
+    if (me == root) {
+        if (comm_reserve(ctx, c->d_blob, (size_t)tot + 256)) return DP_ERR_HIP;
+        if (comm_pin(ctx, c->h_blob, (size_t)tot + 64)) return DP_ERR_HIP;
+        uint8_t* d_all = (uint8_t*)c->d_blob.p;
+        R->GroupStart();
+        uint64_t at = 0;
+        for (int q = 0; q < N && r == ncclSuccess; q++) {
+            if (q != root && sizes[q]) r = R->Recv(d_all + at, sizes[q], ncclUint8, q, c->nccl, ctx->stream);
+            at += sizes[q];
+        }
+        const ncclResult_t rg = R->GroupEnd();
+        if (r == ncclSuccess) r = rg;
+        if (r != ncclSuccess) return dp_fail(ctx, DP_ERR_HIP, R->GetErrorString(r));
+        // the peers' parts come back from the device; the root's own never left the host
+        uint8_t* out = (uint8_t*)c->h_blob.p;
+        if (my_off) DP_HIP(hipMemcpyAsync(out, d_all, my_off, hipMemcpyDeviceToHost, ctx->stream));
+        if (tot > my_off + n) DP_HIP(hipMemcpyAsync(out + my_off + n, d_all + my_off + n, tot - my_off - n, hipMemcpyDeviceToHost, ctx->stream));
+        if (n) memcpy(out + my_off, blob, n);
+        DP_HIP(dp_stream_sync(ctx));
+        *all_out = out;
+    } else if (n) {
+        if (comm_reserve(ctx, c->d_blob, (size_t)n + 256)) return DP_ERR_HIP;
+        DP_HIP(hipMemcpyAsync(c->d_blob.p, blob, n, hipMemcpyHostToDevice, ctx->stream));
+        R->GroupStart();
+        r = R->Send(c->d_blob.p, n, ncclUint8, root, c->nccl, ctx->stream);
+        const ncclResult_t rg = R->GroupEnd();
+        if (r == ncclSuccess) r = rg;
+        if (r != ncclSuccess) return dp_fail(ctx, DP_ERR_HIP, R->GetErrorString(r));
+        DP_HIP(dp_stream_sync(ctx));  // (blob is the caller's again, d_blob this communicator's next exchange's)
+    }
+    return DP_OK;
+}
+
+extern "C" int dp_gather_blobs(dp_comm* c, dp_ctx* ctx, const uint8_t* blob, uint64_t n, const uint64_t* sizes, int root, const uint8_t** all_out) {
+    if (!c || !ctx || !all_out || !sizes || (n && !blob) || root < 0 || root >= c->n_ranks)
+        return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_gather_blobs: bad arguments") : DP_ERR_ARG;
+    if (c->dead) return dp_fail(ctx, DP_ERR_STATE, "dp_gather_blobs: the communicator failed in an earlier exchange");
+    const int rc = gather_blobs_impl(c, ctx, blob, n, sizes, root, all_out);
+    if (rc != DP_OK) dp_comm_abort(c);
     return rc;
 }
 

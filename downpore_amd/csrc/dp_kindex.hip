@@ -579,95 +579,63 @@ __device__ __forceinline__ unsigned long long kxb_rec(uint32_t rib, uint32_t s, 
     return ((unsigned long long)rib << (KXB_SEED_BITS + 24)) | ((unsigned long long)s << 24) | (unsigned long long)(p & 0xffffffu);
 }
 
+// WAVES waves per workgroup: more waves = fewer (workgroup, bin) reservations per hit, but a workgroup that is harder to place
+// beside the other rounds' kernels and whose waves all wait at its barriers for the slowest one
+template <int WAVES_>
 struct kidx_walk_bin {
-    enum { THREADS = 1024, WAVES = 16 };
-    template <int SWEEP>
-    static __device__ __forceinline__ void sweep(const uint32_t w, const uint32_t* __restrict__ seeds, uint32_t n_seeds,
-                                                 const uint64_t* __restrict__ off, const KxPos pos, const dp_scan_item* __restrict__ items,
-                                                 uint32_t lo, uint32_t hi, uint32_t n_read_items, const uint32_t* __restrict__ head,
-                                                 const uint32_t* __restrict__ next, uint32_t* __restrict__ counts, uint32_t lps, const KxBins B,
-                                                 uint32_t* hist, const uint32_t* base, unsigned long long* sh_hits) {
-        const int lane = dp_lane();
-        uint32_t s, i0, i1, step, n, gfirst;
-        uint64_t o;
-        bool gleader;
-        if (lps == 64) {  // (the groups of kidx_walk: KX_PARTS waves per seed, or four seeds per wave)
-            s = w / KX_PARTS;
-            const uint32_t part = w % KX_PARTS;
-            if (s >= n_seeds) return;
-            o = off[seeds[s]];
-            n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
-            const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
-            gfirst = min(n, part * per);
-            i0 = part * per + 4u * (uint32_t)lane;
-            i1 = min(n, part * per + per);
-            step = 64;
-            gleader = lane == 0;
-        } else {
-            s = w * 4 + ((uint32_t)lane >> 4);
-            if (s >= n_seeds) return;
-            o = off[seeds[s]];
-            n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
-            gfirst = 0;
-            i0 = 4u * ((uint32_t)lane & 15u);
-            i1 = n;
-            step = 16;
-            gleader = (lane & 15) == 0;
-        }
-        if (SWEEP == 0 && gleader && i1 > gfirst) atomicAdd(sh_hits, (unsigned long long)(i1 - gfirst));
+    enum { WAVES = WAVES_, THREADS = 64 * WAVES_ };
+    // four consecutive bucket entries of one lane: counted (WRITE = false) or written as records (WRITE = true)
+    template <bool WRITE>
+    static __device__ __forceinline__ void four(const uint64_t e[4], const bool v[4], uint32_t s, const dp_scan_item* __restrict__ items,
+                                                uint32_t lo, uint32_t hi, uint32_t n_read_items, const uint32_t* __restrict__ head,
+                                                const uint32_t* __restrict__ next, uint32_t* __restrict__ counts, const KxBins& B,
+                                                uint32_t* hist, const uint32_t* base) {
+        bool valid[4];
+        uint32_t hd[4];
         const uint32_t rmask = (1u << B.bshift) - 1u;
-        for (uint32_t ib = i0; ib < i1; ib += 4 * step) {
-            uint64_t e[4];
-            bool v[4], valid[4];
-            uint32_t hd[4];
-            kx_entry4(pos, o + ib, e);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                v[u] = ib + (uint32_t)u < i1;
-                e[u] = v[u] ? e[u] : 0ull;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t r = (uint32_t)(e[u] >> 32), p = (uint32_t)e[u];
+            const bool in = v[u] && r >= lo && r < hi;
+            if (B.ign) {
+                // (the ignore byte is NOT looked at here: another slot's commit may flag the read between the two passes, and a record
+                // slot that was counted and not written would hold a stale word.  kidx_bin_count applies it, once per read)
+                valid[u] = in;
+                hd[u] = (!WRITE && v[u] && r - B.qlo < B.qspan) ? head[r] : 0u;
+            } else {
+                // (ignored reads carry n_kmers == 0; a top-level read with len % 4 == 0 four k-mers less)
+                valid[u] = in && p < items[in ? r - lo : 0u].n_kmers;
+                hd[u] = (!WRITE && v[u]) ? head[r] : 0u;
             }
+        }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t r = (uint32_t)(e[u] >> 32), p = (uint32_t)e[u];
-                const bool in = v[u] && r >= lo && r < hi;
-                if (B.ign) {
-                    valid[u] = in && !B.ign[r];
-                    hd[u] = (SWEEP == 0 && v[u] && r - B.qlo < B.qspan) ? head[r] : 0u;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t r = (uint32_t)(e[u] >> 32), p = (uint32_t)e[u];
+            if (valid[u]) {
+                const uint32_t bin = (r - lo) >> B.bshift;
+                if (!WRITE) {
+                    atomicAdd(&hist[bin], 1u);
                 } else {
-                    // (ignored reads carry n_kmers == 0; a top-level read with len % 4 == 0 four k-mers less)
-                    valid[u] = in && p < items[in ? r - lo : 0u].n_kmers;
-                    hd[u] = (SWEEP == 0 && v[u]) ? head[r] : 0u;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t r = (uint32_t)(e[u] >> 32), p = (uint32_t)e[u];
-                if (valid[u]) {
-                    const uint32_t bin = (r - lo) >> B.bshift;
-                    if (SWEEP == 0) {
-                        atomicAdd(&hist[bin], 1u);
+                    const uint32_t b = base[bin];
+                    if (b != 0xffffffffu) {
+                        const uint32_t rank = atomicAdd(&hist[bin], 1u);
+                        B.rec[(size_t)bin * B.cap + b + rank] = kxb_rec((r - lo) & rmask, s, p);
                     } else {
-                        const uint32_t b = base[bin];
-                        if (b != 0xffffffffu) {
-                            const uint32_t rank = atomicAdd(&hist[bin], 1u);
-                            B.rec[(size_t)bin * B.cap + b + rank] = kxb_rec((r - lo) & rmask, s, p);
-                        } else {
-                            atomicAdd(&counts[r - lo], 1u);  // (the bin is full: counted the old way, kidx_bin_count adds its own on top)
-                        }
+                        atomicAdd(&counts[r - lo], 1u);  // (the bin is full: counted the old way, kidx_bin_count adds its own on top)
                     }
                 }
-                if (SWEEP == 0) {
-                    for (uint32_t x = hd[u]; x; x = next[x - 1]) {  // the round's extra items on this read (query windows)
-                        const uint32_t it = n_read_items + x - 1;
-                        const dp_scan_item xi = items[it];
-                        if (p - xi.start < xi.n_kmers && p >= xi.start) {
-                            atomicAdd(&counts[it], 1u);
-                            const uint32_t at = atomicAdd(B.xcursor, 1u);
-                            if (at < B.xcap)
-                                B.xrec[at] = make_uint4(it, p - xi.start, s, 0u);
-                            else
-                                B.flags[0] = 1u;
-                        }
+            }
+            if (!WRITE) {
+                for (uint32_t x = hd[u]; x; x = next[x - 1]) {  // the round's extra items on this read (query windows)
+                    const uint32_t it = n_read_items + x - 1;
+                    const dp_scan_item xi = items[it];
+                    if (p - xi.start < xi.n_kmers && p >= xi.start) {
+                        atomicAdd(&counts[it], 1u);
+                        const uint32_t at = atomicAdd(B.xcursor, 1u);
+                        if (at < B.xcap)
+                            B.xrec[at] = make_uint4(it, p - xi.start, s, 0u);
+                        else
+                            B.flags[0] = 1u;
                     }
                 }
             }
@@ -679,6 +647,7 @@ struct kidx_walk_bin {
                                unsigned long long* __restrict__ n_hits, uint32_t lps, const KxBins B, uint32_t n_waves) {
         __shared__ uint32_t hist[KX_MAXBINS], base[KX_MAXBINS];
         __shared__ unsigned long long sh_hits;
+        const int lane = dp_lane();
         const uint32_t stride = gridDim.x * WAVES;
         // (every wave of a workgroup makes the same number of trips: the barriers below are the workgroup's)
         for (uint32_t wb = blockIdx.x * WAVES; wb < n_waves; wb += stride) {
@@ -686,7 +655,59 @@ struct kidx_walk_bin {
             if (threadIdx.x == 0) sh_hits = 0ull;
             __syncthreads();
             const uint32_t w = wb + (threadIdx.x >> 6);
-            if (w < n_waves) sweep<0>(w, seeds, n_seeds, off, pos, items, lo, hi, n_read_items, head, next, counts, lps, B, hist, base, &sh_hits);
+            // the groups of kidx_walk: KX_PARTS waves per seed (dense seeds), or four seeds per wave
+            uint32_t s = 0, i0 = 0, i1 = 0, step = 16, gfirst = 0;
+            uint64_t o = 0;
+            bool gleader = false;
+            if (w < n_waves) {
+                if (lps == 64) {
+                    s = w / KX_PARTS;
+                    if (s < n_seeds) {
+                        const uint32_t part = w % KX_PARTS;
+                        o = off[seeds[s]];
+                        const uint32_t n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
+                        const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
+                        gfirst = min(n, part * per);
+                        i0 = part * per + 4u * (uint32_t)lane;
+                        i1 = min(n, part * per + per);
+                        step = 64;
+                        gleader = lane == 0;
+                    }
+                } else {
+                    s = w * 4 + ((uint32_t)lane >> 4);
+                    if (s < n_seeds) {
+                        o = off[seeds[s]];
+                        i0 = 4u * ((uint32_t)lane & 15u);
+                        i1 = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
+                        gleader = (lane & 15) == 0;
+                    }
+                }
+            }
+            if (gleader && i1 > gfirst) atomicAdd(&sh_hits, (unsigned long long)(i1 - gfirst));
+            // the lane's first four entries stay in registers across the barriers (a seed of config 2 has 20 - 60 entries: for most groups
+            // the first trip is the only one, and the second pass reads nothing); later trips are read again (from the L2)
+            uint64_t e0[4] = {0, 0, 0, 0};
+            bool v0[4] = {false, false, false, false};
+            if (i0 < i1) {
+                kx_entry4(pos, o + i0, e0);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    v0[u] = i0 + (uint32_t)u < i1;
+                    e0[u] = v0[u] ? e0[u] : 0ull;
+                }
+                four<false>(e0, v0, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base);
+            }
+            for (uint32_t ib = i0 + 4 * step; ib < i1; ib += 4 * step) {
+                uint64_t e[4];
+                bool v[4];
+                kx_entry4(pos, o + ib, e);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    v[u] = ib + (uint32_t)u < i1;
+                    e[u] = v[u] ? e[u] : 0ull;
+                }
+                four<false>(e, v, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base);
+            }
             __syncthreads();
             for (uint32_t t = threadIdx.x; t < B.n_bins; t += THREADS) {
                 const uint32_t c = hist[t];
@@ -694,6 +715,8 @@ struct kidx_walk_bin {
                 if (c) {
                     b = atomicAdd(&B.cursor[t], c);
                     if (b + c > B.cap) {  // (its share of the bin does not fit: the whole share is counted the old way)
+                        // what it reserved below the bin's end stays unwritten: marked, so that kidx_bin_count skips it
+                        for (uint32_t j = b; j < B.cap; j++) B.rec[(size_t)t * B.cap + j] = ~0ull;
                         b = 0xffffffffu;
                         B.flags[0] = 1u;
                     }
@@ -703,7 +726,18 @@ struct kidx_walk_bin {
             }
             if (threadIdx.x == 0 && sh_hits) atomicAdd(&n_hits[blockIdx.x & 63u], sh_hits);  // seed occurrences of the round (totals[2])
             __syncthreads();
-            if (w < n_waves) sweep<1>(w, seeds, n_seeds, off, pos, items, lo, hi, n_read_items, head, next, counts, lps, B, hist, base, &sh_hits);
+            if (i0 < i1) four<true>(e0, v0, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base);
+            for (uint32_t ib = i0 + 4 * step; ib < i1; ib += 4 * step) {
+                uint64_t e[4];
+                bool v[4];
+                kx_entry4(pos, o + ib, e);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    v[u] = ib + (uint32_t)u < i1;
+                    e[u] = v[u] ? e[u] : 0ull;
+                }
+                four<true>(e, v, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base);
+            }
             __syncthreads();
         }
     }
@@ -713,7 +747,7 @@ struct kidx_walk_bin {
 template <int RB>
 struct kidx_bin_count {
     enum { THREADS = 512 };
-    static __device__ void run(const KxBins B, uint32_t* __restrict__ counts, uint32_t n_read_items) {
+    static __device__ void run(const KxBins B, uint32_t* __restrict__ counts, uint32_t n_read_items, uint32_t lo) {
         __shared__ uint32_t cnt[RB];
         const uint32_t bin = blockIdx.x;
         if (bin >= B.n_bins) return;
@@ -735,7 +769,10 @@ struct kidx_bin_count {
             const uint32_t it = first + i;
             if (it < n_read_items) {
                 const uint32_t c = cnt[i];
-                if (c) counts[it] += c;  // (zeroed by kidx_prepare; a full bin's overflow was counted there directly)
+                // (zeroed by kidx_prepare; a full bin's overflow was counted there directly.  A read ignored by now counts nothing - the
+                // walk's short cut tested this byte per hit; the fill pass goes by the count written here)
+                if (B.ign && B.ign[lo + it]) counts[it] = 0u;
+                else if (c) counts[it] += c;
             }
         }
     }
@@ -1159,12 +1196,19 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         const uint32_t n_bins = (n_read_items + (1u << bshift) - 1) >> bshift;
         const uint64_t total = (uint64_t)R.shard_cap * 64;
         const uint64_t xcap = std::max<uint64_t>(65536, total / 8);
-        if (n_bins <= KX_MAXBINS && total / n_bins >= 1024) {
+        // a bin holds its share of the hits (1.5 x the round before, as the shards) - and ONE bin also holds the round's query reads,
+        // consecutive reads that contain every seed of the round by construction: + 2 S (measured at config 2: mean 2.3 k records per
+        // bin, 7.4 k in the query reads' bin)
+        uint64_t cap = total / n_bins + 2 * (uint64_t)S + 1024;
+        if (const char* e = getenv("DP_KX_BINS_CAP")) cap = (uint64_t)std::max(16, atoi(e));  // (test hook: bins that overflow)
+        if (n_bins <= KX_MAXBINS && cap < 0x7fffffffu) {
             if (dev_reserve(ctx, ctx->d_kx_tmp, std::max((size_t)n_groups * 8, (size_t)xcap * 16) + 64)) return DP_ERR_HIP;
+            if (dev_reserve(ctx, ctx->d_kx_keys, (size_t)cap * n_bins * 8 + 64)) return DP_ERR_HIP;
+            R.rec = (unsigned long long*)ctx->d_kx_keys.p;
             B.rec = R.rec;
             B.cursor = bin_cursor;
             B.flags = R.flags;
-            B.cap = (uint32_t)std::min<uint64_t>(total / n_bins, 0x7fffffffu);
+            B.cap = (uint32_t)cap;
             B.n_bins = n_bins;
             B.bshift = bshift;
             B.xrec = (uint4*)ctx->d_kx_tmp.p;
@@ -1184,15 +1228,34 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     }
     if (S && B.rec) {
         const uint32_t n_waves = kidx_walk_blocks(ix, k, S) * 4;
-        dp_launch<kidx_walk_bin>(ctx, dim3((n_waves + kidx_walk_bin::WAVES - 1) / kidx_walk_bin::WAVES), dim3(kidx_walk_bin::THREADS),
-                                 dp_seeds_ptr(ctx), S, (const uint64_t*)ix->off.p, ix->view(), d_items, lo, hi, n_read_items, (const uint32_t*)head,
-                                 (const uint32_t*)next, d_counts, n_hits, lps, B, n_waves);
+        static const int bin_waves = getenv("DP_KX_BIN_WAVES") ? atoi(getenv("DP_KX_BIN_WAVES")) : 8;
+#define KX_WALK_BIN(W_)                                                                                                                            \
+    dp_launch<kidx_walk_bin<W_>>(ctx, dim3((n_waves + W_ - 1) / W_), dim3(64 * W_), dp_seeds_ptr(ctx), S, (const uint64_t*)ix->off.p, ix->view(), \
+                                 d_items, lo, hi, n_read_items, (const uint32_t*)head, (const uint32_t*)next, d_counts, n_hits, lps, B, n_waves)
+        if (bin_waves <= 4) KX_WALK_BIN(4);
+        else if (bin_waves <= 8) KX_WALK_BIN(8);
+        else KX_WALK_BIN(16);
+#undef KX_WALK_BIN
         if (B.bshift <= 9)
-            dp_launch<kidx_bin_count<512>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items);
-        else if (B.bshift <= 11)
-            dp_launch<kidx_bin_count<2048>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items);
+            dp_launch<kidx_bin_count<512>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items, lo);
+        else if (B.bshift <= 12)
+            dp_launch<kidx_bin_count<4096>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items, lo);
         else
-            dp_launch<kidx_bin_count<16384>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items);
+            dp_launch<kidx_bin_count<16384>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items, lo);
+        static const bool bins_debug = getenv("DP_KX_BINS_DEBUG") != nullptr;
+        if (bins_debug) {  // (diagnosis: waits for the stream) how full the bins and the extra list are
+            std::vector<uint32_t> cur((size_t)KX_MAXBINS + 2);
+            uint64_t fl = 0;
+            hipStreamSynchronize(ctx->stream);
+            hipMemcpy(cur.data(), B.cursor, cur.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(&fl, d_totals + 6, 8, hipMemcpyDeviceToHost);
+            uint32_t mx = 0;
+            uint64_t sum = 0;
+            for (uint32_t b = 0; b < B.n_bins; b++) mx = std::max(mx, cur[b]), sum += cur[b];
+            fprintf(stderr, "[kx bins] seeds %u lps %u waves %u | %u bins of %u reads, cap %u each: fullest %u, records %llu | extra list %u of %u | flag %llu | hits guess %llu\n",
+                    S, lps, n_waves, B.n_bins, 1u << B.bshift, B.cap, mx, (unsigned long long)sum, cur[KX_MAXBINS], B.xcap, (unsigned long long)fl,
+                    (unsigned long long)(one ? one->hits_guess : 0));
+        }
     } else if (S)
         dp_launch<kidx_walk<false>>(ctx, dim3(kidx_walk_grid(ix, k, S)), dim3(256), dp_seeds_ptr(ctx), S,
                            (const uint64_t*)ix->off.p, ix->view(), d_items, lo, hi, n_read_items, (const uint32_t*)head,
@@ -1249,8 +1312,8 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             if (B.bshift <= 9)
                 dp_launch<kidx_bin_fill<512>>(ctx, fg, fb, B, d_items, n_read_items, (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff,
                                               one->d_segs, (const uint64_t*)d_totals, one->seg_cap);
-            else if (B.bshift <= 11)
-                dp_launch<kidx_bin_fill<2048>>(ctx, fg, fb, B, d_items, n_read_items, (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff,
+            else if (B.bshift <= 12)
+                dp_launch<kidx_bin_fill<4096>>(ctx, fg, fb, B, d_items, n_read_items, (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff,
                                                one->d_segs, (const uint64_t*)d_totals, one->seg_cap);
             else
                 dp_launch<kidx_bin_fill<16384>>(ctx, fg, fb, B, d_items, n_read_items, (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff,

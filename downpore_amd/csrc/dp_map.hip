@@ -392,7 +392,8 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                                                            uint16_t* __restrict__ poolB, uint16_t* __restrict__ poolLen,
                                                            MapRec* __restrict__ recs, uint32_t rec_cap, int32_t* __restrict__ ma,
                                                            int32_t* __restrict__ mb, uint32_t int_cap, uint32_t* __restrict__ cursor,
-                                                           int phase, int32_t* __restrict__ thr_io, int one_lane) {
+                                                           int phase, int32_t* __restrict__ thr_io, int one_lane,
+                                                           const u64* __restrict__ words_read) {
     // phase 2: both strands of every window pair, thresholds from the windows themselves (the whole index is here).
     // phase 0 / 1 (the index is one shard of the reference, dp_map_windows_shard): only the forward / only the reverse-complement
     // windows, starting from the thresholds the previous shard left in thr_io[pair][2] (< 0: none yet) and leaving its own there.
@@ -405,6 +406,9 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
     P.a = poolA + (size_t)gw * M_CHAINS * M_QMAX;
     P.b = poolB + (size_t)gw * M_CHAINS * M_QMAX;
     uint16_t* chainLen = poolLen + (size_t)gw * M_CHAINS;
+    // algorithmic bytes of this wave's windows: posting words the index query gathered for them, 2 x 8 x SW per
+    // prefiltered candidate + 4 per candidate out, 8 per seed of both sides of every pair that is chained, 8 per chain link out
+    unsigned long long algb = 0;
     for (uint32_t pair = gw; pair < n_pairs; pair += waves) {
         // performMapping :494-501
         int thr[2];
@@ -422,6 +426,7 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
             const int qLen = (int)wlen[w];
             const u64* qset = wsets + (uint64_t)w * SW;
             if (qmeta[4 * w + 0] < 5 || qmeta[4 * w + 2]) continue;  // Matches() returned nothing
+            if (words_read) algb += 8ull * words_read[w];
             for (uint32_t wi = 0; wi < W; wi++) {
                 u64 mask = cand[(uint64_t)w * W + wi];
                 while (mask) {
@@ -432,10 +437,12 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                     int c = 0;
                     for (uint32_t x = lane; x < SW; x += 64) c += __popcll(tset[x] & qset[x]);
                     c = wave_sum(c);
+                    algb += 16ull * SW + 4ull;
                     if (c < thr[s]) continue;  // CountIntersectionTo(seedSet, min) < min (:521, :560)
                     const dp_seq_ref r = refs[t];
                     const int32_t* tSeg = segs + r.seg_off;
                     const int tN = (int)(2 * r.n_seeds + 1);
+                    algb += 4ull * (unsigned long long)(qN + tN);
                     int thrS = thr[s], thrOther = thr[1 - s];
                     uint32_t err = 0;
                     // Match (:361-394): s = seq.Reduced(querySet), q = query.Reduced(seqSet) - on all 64 lanes
@@ -472,6 +479,7 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                                     cursor[3] = 1;
                                 }
                                 seq++;
+                                algb += 8ull * (unsigned long long)len;
                                 const int limit = (len * 4) / 5;
                                 if (limit > thrS) thrS = limit;
                                 if (s == 0 && limit > thrOther) thrOther = limit;  // forward also raises minRCMatches (:547-549)
@@ -490,6 +498,7 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
             thr_io[2 * pair + 1] = thr[1];
         }
     }
+    if (lane == 0 && algb) atomicAdd((unsigned long long*)(cursor + 8), algb);  // (the chain links were counted on lane 0 only)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -694,7 +703,7 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
                            (const uint32_t*)d_qmeta, (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p,
                            (const int32_t*)ctx->d_segs.p, (const u64*)ctx->d_seedsets.p, W, SW, k, poolA, poolB, poolLen,
                            (MapRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p, int_cap,
-                           (uint32_t*)ctx->d_cursor.p, phase, d_thr, one_lane);
+                           (uint32_t*)ctx->d_cursor.p, phase, d_thr, one_lane, (const u64*)d_words);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         DP_HIP(hipMemcpyAsync(cur, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -712,6 +721,11 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
     float qms = 0;
     hipEventElapsedTime(&qms, ctx->ev[4], ctx->ev[5]);
     out->kernel_ms = (double)total_ms + (double)qms;
+    {
+        unsigned long long ab = 0;
+        memcpy(&ab, &cur[8], 8);
+        out->alg_bytes = (double)ab;
+    }
     if (thr_io) DP_HIP(hipMemcpy(thr_io, d_thr, (size_t)nw * 4, hipMemcpyDeviceToHost));
     if (cur[2]) {
         char msg[160];

@@ -760,6 +760,7 @@ struct MapParams {  // flag table commands/map.go:19-20
 struct MapStats {
     uint64_t n_chunks = 0, n_seeds = 0, n_windows = 0, n_chains = 0, n_batches = 0;
     double k_scan_ms = 0, k_map_ms = 0;
+    double map_bytes = 0, scan_bytes = 0;  // algorithmic bytes: dp_map_windows' query + prefilter + chaining; packed bases of the windows scanned
     double t_setup_s = 0, t_scan_s = 0, t_chain_s = 0, t_host_s = 0;  // wall: indexing the reference / window scans / dp_map_windows / coroutines
 };
 // Runs the whole command on HIP device `device`: reference = first sequence of refSet (top-level, cache=false), reads

@@ -21,6 +21,7 @@ struct OverlapH {
     dp_ctx* xctx = nullptr;           // round-parallel mode: the context (own stream) the result exchange runs on
     std::vector<dp_comm*> slotComms;  // scan-shard with executor slots: one communicator per slot
     ReadSet* reads = nullptr;
+    int textRoot = -1;                // dph_overlap_text_root: >= 0 = a superstep gathers the rounds' PAF text to that rank only
     bool keepText = true;             // dph_overlap_keep_text(0): gathered rounds of other ranks are committed without their PAF text
     double tCtx = 0, tUpload = 0, tInit = 0;
     std::string err;
@@ -449,20 +450,25 @@ void dph_overlap_drain(void* hh) { ((OverlapH*)hh)->run.drain(); }
 // ---- round-parallel mode: a rank executes ONE round speculatively and serialises the result; every rank then commits
 // the gathered results in round order with the speculation check (OverlapRun::commitResults).
 static void putv(std::string& b, const void* p, size_t n) { b.append((const char*)p, n); }
-static void serialise(RoundResult& res, std::string& blob) {
+// text (may be null): the record's PAF text goes there instead of into the record (hdr[17] = 1, hdr[7] still says how long it is):
+// the control part - a few KB per round - is all-gathered, the text travels to the printing rank alone (dp_gather_blobs)
+static void serialise(RoundResult& res, std::string& blob, std::string* text = nullptr) {
     res.takeText();  // (the PAF text may still be with a formatter thread)
     int64_t hdr[18] = {res.round, res.empty ? 1 : 0, res.firstIn, res.firstOut, res.numQuerySeqs, (int64_t)res.ignores.size(),
                        (int64_t)res.indexedReads.size(), (int64_t)res.paf.size(), res.fs.badBack, res.fs.emptyMatch,
                        (int64_t)res.fs.lines, (int64_t)res.fs.hits, (int64_t)res.fs.qHits, 0, res.snapshot,
-                       (int64_t)res.queryReads.size(), res.planRound, 0};
+                       (int64_t)res.queryReads.size(), res.planRound, text ? 1 : 0};
     int64_t total = (int64_t)(sizeof hdr + sizeof(RoundStats) + res.ignores.size() * sizeof(int) + res.indexedReads.size() * 4 +
-                              res.paf.size() + res.queryReads.size() * 4);
+                              (text ? 0 : res.paf.size()) + res.queryReads.size() * 4);
     hdr[13] = total;
     putv(blob, hdr, sizeof hdr);
     putv(blob, &res.st, sizeof(RoundStats));
     putv(blob, res.ignores.data(), res.ignores.size() * sizeof(int));
     putv(blob, res.indexedReads.data(), res.indexedReads.size() * 4);
-    putv(blob, res.paf.data(), res.paf.size());
+    if (text)
+        text->append(res.paf);
+    else
+        putv(blob, res.paf.data(), res.paf.size());
     putv(blob, res.queryReads.data(), res.queryReads.size() * 4);
 }
 // Executes rounds first, first+1, ... (one per executor slot of this process, concurrently) and returns their
@@ -486,12 +492,19 @@ const uint8_t* dph_overlap_exec_round(void* hh, int64_t first, uint64_t* n) {
 }
 int dph_overlap_slots(void* hh) { return (int)((OverlapH*)hh)->run.slots.size(); }
 // blobs: concatenation; sizes[i] bytes each.  Returns the number of rounds committed (0..count) or <0.
-static void deserialise(const uint8_t* blobs, const uint64_t* sizes, int count, std::vector<RoundResult>& rs, bool keepText = true) {
+// textSizes (may be null): per rank, the bytes of text its records announce but do not carry (hdr[17] = 1); the records' own
+// lengths go to textLen in the order the records appear
+static void deserialise(const uint8_t* blobs, const uint64_t* sizes, int count, std::vector<RoundResult>& rs, bool keepText = true,
+                        std::vector<uint64_t>* textSizes = nullptr, std::vector<uint64_t>* textLen = nullptr) {
     uint64_t totalBytes = 0;
     for (int i = 0; i < count; i++) totalBytes += sizes[i];
     const uint8_t* q = blobs;
     const uint8_t* end = blobs + totalBytes;
+    if (textSizes) textSizes->assign((size_t)count, 0);
+    int rankOf = 0;
+    uint64_t rankEnd = count ? sizes[0] : 0;
     while (q < end) {
+        while (rankOf + 1 < count && (uint64_t)(q - blobs) >= rankEnd) rankEnd += sizes[++rankOf];
         const uint8_t* rec = q;
         int64_t hdr[18];
         memcpy(hdr, q, sizeof hdr);
@@ -508,8 +521,14 @@ static void deserialise(const uint8_t* blobs, const uint64_t* sizes, int count, 
         q += hdr[5] * sizeof(int);
         r.indexedReads.assign((const uint32_t*)q, (const uint32_t*)q + hdr[6]);
         q += hdr[6] * 4;
-        if (keepText) r.paf.assign((const char*)q, (size_t)hdr[7]);  // (a rank that prints nothing keeps the counts, not the text)
-        q += hdr[7];
+        if (hdr[17]) {  // the text travels on its own
+            if (textSizes) (*textSizes)[(size_t)rankOf] += (uint64_t)hdr[7];
+            if (textLen) textLen->push_back((uint64_t)hdr[7]);
+        } else {
+            if (keepText) r.paf.assign((const char*)q, (size_t)hdr[7]);  // (a rank that prints nothing keeps the counts, not the text)
+            q += hdr[7];
+            if (textLen) textLen->push_back(0);
+        }
         r.snapshot = hdr[14];
         r.planRound = hdr[16];
         r.queryReads.assign((const uint32_t*)q, (const uint32_t*)q + hdr[15]);
@@ -573,9 +592,11 @@ int dph_overlap_superstep(void* hh, int max_rounds) {
         dp_comm_abort(h->comm);  // (the peers must not wait for this rank's contribution)
         return rc < 0 ? rc : -1;
     }
-    static thread_local std::string blob;
+    static thread_local std::string blob, text;
     blob.clear();
-    for (RoundResult& r : res) serialise(r, blob);
+    text.clear();
+    const bool split = h->textRoot >= 0;
+    for (RoundResult& r : res) serialise(r, blob, split ? &text : nullptr);
     const uint8_t* all = nullptr;
     const uint64_t* sizes = nullptr;
     rc = dp_allgather_blobs(h->comm, h->xctx, (const uint8_t*)blob.data(), blob.size(), &all, &sizes);
@@ -584,7 +605,24 @@ int dph_overlap_superstep(void* hh, int max_rounds) {
         return rc;
     }
     std::vector<RoundResult> rs;
-    deserialise(all, sizes, dp_comm_size(h->comm), rs, h->keepText);
+    std::vector<uint64_t> textSizes, textLen;
+    deserialise(all, sizes, dp_comm_size(h->comm), rs, h->keepText, &textSizes, &textLen);
+    if (split) {
+        // the rounds' text: to the printing rank alone.  Every rank knows every rank's text length from the control records.
+        const uint8_t* allText = nullptr;
+        rc = dp_gather_blobs(h->comm, h->xctx, (const uint8_t*)text.data(), text.size(), textSizes.data(), h->textRoot, &allText);
+        if (rc != 0) {
+            h->err = dp_last_error(h->xctx);
+            return rc;
+        }
+        if (allText && h->keepText) {
+            const char* t = (const char*)allText;
+            for (size_t i = 0; i < rs.size(); i++) {
+                rs[i].paf.assign(t, (size_t)textLen[i]);
+                t += textLen[i];
+            }
+        }
+    }
     const int c = h->run.commitGathered(rs);
     if (c >= 0) h->addPaf(h->run.paf);
     return c;
@@ -604,6 +642,10 @@ int dph_overlap_done(void* hh) { return ((OverlapH*)hh)->run.done ? 1 : 0; }
 // ranks' text - the gathered rounds are committed with their counts, flags and read lists, the text is dropped as it arrives
 // (at 8 ranks every rank would otherwise copy all 235 MB of a config-2 job's PAF three times).  keep != 0 (default): as before.
 void dph_overlap_keep_text(void* hh, int keep) { ((OverlapH*)hh)->keepText = keep != 0; }
+// dph_overlap_superstep: root >= 0 = the rounds' PAF text is gathered to rank `root` alone (dp_gather_blobs) and only their control
+// records - a few KB per round - are all-gathered; every rank of the job must say the same.  -1 (default): text and control records
+// travel together to every rank, as before (what a caller needs that reads the PAF on every rank).
+void dph_overlap_text_root(void* hh, int root) { ((OverlapH*)hh)->textRoot = root; }
 
 }  // extern "C"
 
@@ -820,7 +862,7 @@ extern "C" const char* dph_map_errtext(void* h, int64_t* n) {
 extern "C" void dph_map_stats(void* h, double* out) {
     const MapStats& s = ((MapH*)h)->st;
     double v[] = {(double)s.n_chunks, (double)s.n_seeds, (double)s.n_windows, (double)s.n_chains, (double)s.n_batches, s.k_scan_ms,
-                  s.k_map_ms, s.t_setup_s, s.t_scan_s, s.t_chain_s, s.t_host_s};
+                  s.k_map_ms, s.t_setup_s, s.t_scan_s, s.t_chain_s, s.t_host_s, s.map_bytes, s.scan_bytes};
     memcpy(out, v, sizeof v);
 }
 

@@ -982,7 +982,10 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         rc = dp_scan(ctx, witems.data(), (uint32_t)witems.size(), &wb);
         if (rc) return fail(rc);
         tScan += wallNow() - ts0;
-        if (stats) stats->k_scan_ms += wb.kernel_ms, stats->n_windows += witems.size() / 2;
+        if (stats) {
+            stats->k_scan_ms += wb.kernel_ms, stats->n_windows += witems.size() / 2;
+            for (const dp_scan_item& wi : witems) stats->scan_bytes += (double)((wi.n_kmers + 3) / 4);  // packed bases of the window, both strands
+        }
         wsegs.clear();
         woff.assign(1, 0);
         wlen.clear();
@@ -1029,7 +1032,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
                 cr.b.assign(cb.match_b + cb.off[c], cb.match_b + cb.off[c + 1]);
                 live[w / 2]->res.chains[w & 1].push_back(std::move(cr));
             }
-            if (stats) stats->k_map_ms += cb.kernel_ms, stats->n_chains += cb.n_chains;
+            if (stats) stats->k_map_ms += cb.kernel_ms, stats->n_chains += cb.n_chains, stats->map_bytes += cb.alg_bytes;
         };
         tq = wallNow();
         lap(2);
@@ -1120,6 +1123,8 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         for (const LoopStats& ls : lstats) {
             stats->k_scan_ms += ls.st.k_scan_ms;
             stats->k_map_ms += ls.st.k_map_ms;
+            stats->map_bytes += ls.st.map_bytes;
+            stats->scan_bytes += ls.st.scan_bytes;
             stats->n_windows += ls.st.n_windows;
             stats->n_chains += ls.st.n_chains;
             stats->n_batches += ls.st.n_batches;

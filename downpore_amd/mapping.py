@@ -7,7 +7,7 @@ from .hip import DpError
 from .overlap import load_host
 
 MAP_STAT_FIELDS = ["n_chunks", "n_seeds", "n_windows", "n_chains", "n_batches", "k_scan_ms", "k_map_ms", "t_setup_s", "t_scan_s",
-                   "t_chain_s", "t_host_s"]
+                   "t_chain_s", "t_host_s", "map_bytes", "scan_bytes"]
 
 
 def map_reads(ref, reads, circular=True, k=11, query_size=1000, min_length=500, chunk_size=10000, seed_rate=40, device=0):

@@ -436,6 +436,13 @@ class OverlapPipeline:
         return 1
 
     # ---- round-parallel building blocks (also used by the single-GPU simulation test)
+    def text_root(self, root):
+        """Round-parallel runs with the exchange inside the library: supersteps gather the PAF text to rank `root` alone (every rank
+        must say the same); -1 = text and control records to every rank."""
+        self.H.dph_overlap_text_root.restype = None
+        self.H.dph_overlap_text_root.argtypes = [C.c_void_p, C.c_int]
+        self.H.dph_overlap_text_root(self.h, root)
+
     def keep_text(self, keep):
         """Multi-rank runs: keep=False on a rank that does not print the PAF drops the other ranks' text as it arrives."""
         self.H.dph_overlap_keep_text(self.h, 1 if keep else 0)

@@ -283,6 +283,7 @@ typedef struct {
     const int32_t* match_a;  /* window seed indices */
     const int32_t* match_b;  /* target seed indices */
     double kernel_ms;
+    double alg_bytes;        /* algorithmic bytes of the call's index query + prefilter + chaining: what its roofline is priced on */
 } dp_chain_batch;
 
 DP_API int dp_map_windows(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_off, const uint32_t* w_len, uint32_t n_windows,
@@ -486,6 +487,12 @@ DP_API void dp_gang_counters(dp_gang* gang, uint64_t* out /* [5] */);
  * = the ranks' strings back to back in rank order, *sizes_out[n_ranks] their lengths (library-owned, valid until the next call on
  * this communicator).  Collective. */
 DP_API int dp_allgather_blobs(dp_comm* comm, dp_ctx* ctx, const uint8_t* blob, uint64_t n, const uint8_t** all_out, const uint64_t** sizes_out);
+/* Gather of one variable-size byte string per rank to rank `root` only: the PAF text of the round-parallel layout's rounds, which only
+ * the rank that prints needs (finalCheckWorker's fmt.Print, commands/overlap.go:225-228, happens in one process; at 8 ranks every rank
+ * otherwise receives and copies all 235 MB of a config-2 job's text).  sizes[n_ranks] = every rank's length, the same array on every
+ * rank (the lengths travel inside the control blobs of dp_allgather_blobs: no size exchange here).  *all_out = the concatenation in
+ * rank order on the root (library-owned, valid until the next blob call on this communicator), NULL on the other ranks.  Collective. */
+DP_API int dp_gather_blobs(dp_comm* comm, dp_ctx* ctx, const uint8_t* blob, uint64_t n, const uint64_t* sizes, int root, const uint8_t** all_out);
 
 /* Device pointers of the last dp_scan output, for a multi-GPU exchange driven by the caller (RCCL all-gather of
  * the survivors).  segs_dev: int32[n_segs]. */

@@ -118,6 +118,10 @@ DPH_API int dph_overlap_commit_gathered(void* h, const uint8_t* blobs, const uin
 /* the same superstep with the exchange inside the library (dp_allgather_blobs on the communicator of dph_overlap_comm_init):
  * rounds committed; 0 = the superstep's first round was rejected and runs again (or the command is finished: dph_overlap_done) */
 DPH_API int dph_overlap_superstep(void* h, int max_rounds);
+/* root >= 0: a superstep gathers the rounds' PAF text to rank `root` alone (the rank that prints: commands/overlap.go:225-228 prints
+ * in one process) and all-gathers only the rounds' control records (flags, read lists, counts: a few KB per round); every rank of
+ * the job must pass the same root, before the first superstep.  -1 (the default): text and control travel together to every rank. */
+DPH_API void dph_overlap_text_root(void* h, int root);
 DPH_API const uint8_t* dph_overlap_exec_round(void* h, int64_t first_round, uint64_t* n);
 DPH_API int dph_overlap_commit_blobs(void* h, const uint8_t* blobs, const uint64_t* sizes, int count);
 
@@ -125,8 +129,9 @@ DPH_API int dph_overlap_commit_blobs(void* h, const uint8_t* blobs, const uint64
  * The whole command: reference = first sequence of `ref` (a read set opened with himem = 0), reads top-level.  params[6] =
  * circular, k, query_size, min_length, chunk_size, seed_rate.  DP_MAP_SHARDS / DP_MAP_DEVICES in the environment spread the
  * reference index over several contexts / GPUs (BASELINE config 5).  Returns a handle holding the PAF (read order) and the
- * reference's stderr lines, or NULL.  dph_map_stats: out[11] = chunks, seeds, windows, chains, batches, scan kernel ms, map
- * kernel ms, seconds of set-up / window scans / dp_map_windows / host. */
+ * reference's stderr lines, or NULL.  dph_map_stats: out[13] = chunks, seeds, windows, chains, batches, scan kernel ms, map
+ * kernel ms, seconds of set-up / window scans / dp_map_windows / host, algorithmic bytes of the map kernels (index query +
+ * prefilter + chaining) and of the window scans (packed bases). */
 DPH_API void* dph_map_run(void* ref, void* reads, const int64_t* params, int device);
 DPH_API void dph_map_free(void* m);
 DPH_API const char* dph_map_paf(void* m, int64_t* n);

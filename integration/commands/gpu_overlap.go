@@ -100,6 +100,7 @@ func (com *gpuOverlapCommand) Run(args map[string]string) {
 		// finished rounds over RCCL and commits them in order on every rank; rank 0 prints (the others drop the text as it arrives)
 		ov.SetRanks(rank, ranks)
 		ov.KeepText(rank == 0)
+		ov.TextRoot(0) // the text goes to the printing rank alone, the control records (a few KB per round) to everybody
 		err := ov.RunRoundParallel(p.Slots, func(paf []byte) {
 			if rank == 0 {
 				out.Write(paf)

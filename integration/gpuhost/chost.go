@@ -282,6 +282,10 @@ func (o *Overlap) InitComm(nRanks, rank int, id []byte) error {
 	return nil
 }
 
+// TextRoot(root): supersteps gather the rounds' PAF text to rank root alone and all-gather only their control records (every rank
+// must say the same, before the first Superstep); the default (-1) sends text and control to every rank.
+func (o *Overlap) TextRoot(root int) { C.dph_overlap_text_root(o.h, C.int(root)) }
+
 // SetRanks deals the rounds to the ranks (round r belongs to rank r % world).  Call after Init, before the first Superstep.
 func (o *Overlap) SetRanks(rank, world int) {
 	C.dph_overlap_set_ranks(o.h, C.int(rank), C.int(world))

@@ -70,6 +70,15 @@ def test_overlap_full_run_config1_k10(slots):
     assert orun.rounds >= 5
 
 
+def test_config1_at_its_stated_k13():
+    """BASELINE config 1 as BASELINE.json states it: 1 000 reads x 5 kb, k = 13.  At this size the value table's top-"2 %" cut
+    (commands/overlap.go:73-93) removes every k-mer that occurs at all, so no window finds a seed: the reference's command runs one
+    round and prints nothing (note 7).  The product must do exactly that - same round count, empty PAF, no read flagged -
+    not merely at the command's default k = 10 where the other config-1 tests run."""
+    orun, st = _run_both(1, 250000, 1000, 5000, 13, slots=1)
+    assert orun.paf == "" and orun.rounds <= 1
+
+
 @pytest.mark.parametrize("query_type,slots", [(4, 1), (4, 3), (2, 1), (9, 1), (12, 2)])
 def test_overlap_other_query_types(query_type, slots):
     """PrepareQueries' other window layouts behind the same boundary (overlap.go:18-21,91-155): QueryAll=4 is what the
@@ -217,6 +226,23 @@ def test_overlap_kmer_index_mode(mode):
         _run_both(41, 100000, 400, 5000, 10, max_rounds=3, slots=2, query_type=4)
     finally:
         del os.environ["DP_SCAN_INDEX"]
+
+
+@pytest.mark.parametrize("env", [{"DP_KX_BINS": "0"}, {"DP_KX_BINS_CAP": "300"}, {"DP_KX_BINS_CAP": "40"}, {"DP_KX_ONESHOT": "0"}])
+def test_kmer_index_counting_step_variants(monkeypatch, env):
+    """The counting step of an index-mode round (dp_kindex.hip): hits binned by read range and counted in LDS (round 5, the default),
+    round 4's hit records with one atomic per hit (DP_KX_BINS=0), bins that overflow - a workgroup's share that does not fit is
+    counted the old way, what it reserved is marked unwritten, the fill pass walks the buckets (DP_KX_BINS_CAP: some bins at 300,
+    every bin at 40) - and the two-wait form (DP_KX_ONESHOT=0).  Same PAF, same ignore flags as the oracle: dense seeds (k = 10, hundreds
+    of hits per read), sparse seeds (k = 13), reads that get flagged, five slots."""
+    monkeypatch.setenv("DP_SCAN_INDEX", "1")
+    for kk, vv in env.items():
+        monkeypatch.setenv(kk, vv)
+    _, st = _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
+    assert st["idx_rounds"] > 0
+    _, st = _run_both(114, 1200000, 2000, 12000, 13, 0.002, True, max_rounds=4, slots=5)
+    assert st["idx_rounds"] > 0 and st["idx_hits"] > 0
+    _run_both(7, 100000, 300, 4000, 10, himem=False, max_rounds=3)
 
 
 @pytest.mark.parametrize("env", [{"DP_KINDEX_WIDE": "1"}, {"DP_KB_B1": "9"}, {"DP_KB_MIN_PBITS": "22"}, {"DP_KB_MIN_PBITS": "30"},
@@ -691,6 +717,54 @@ def test_round_parallel_exchange_inside_the_library():
         pipes[r].close()
     r1 = Reads(bases, off, min_len=1000)
     p1 = OverlapPipeline(r1, k=10, seed_batch_size=1500, rank=0, world=1, mode="round", comm="rccl", slots=2)
+    p1.run()
+    assert first_diff(p1.all_paf(), want.paf) is None
+    p1.close()
+
+
+def test_round_parallel_text_goes_to_the_printing_rank_only():
+    """dph_overlap_text_root(0): a superstep all-gathers the rounds' control records (flags, read lists, counts) and gathers their PAF
+    text to rank 0 alone (dp_gather_blobs).  Three in-process ranks x two slots on reads that flag reads: rank 0 prints the oracle's
+    PAF, ranks 1 and 2 print nothing, every rank ends with the oracle's ignore flags and round count; then the same through a
+    1-rank RCCL communicator (ncclSend / ncclRecv are never issued there, the root's own text never leaves the host)."""
+    import threading
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    bases, off = O.gen_reads(33, 60000, 700, 1500, 0.0, True)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    want = O.OverlapRun(rs, k=10, seed_batch_size=1500)
+    assert want.rounds >= 8 and rs.ignore().sum() > 0
+    world = 3
+    readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
+    pipes = [OverlapPipeline(readsets[r], k=10, seed_batch_size=1500, rank=r, world=world, mode="round", comm="local", slots=2)
+             for r in range(world)]
+    OverlapPipeline.link_local(pipes)
+    for r, p in enumerate(pipes):
+        p.text_root(0)
+        p.keep_text(r == 0)
+    errs = []
+
+    def run(p):
+        try:
+            p.run()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(p,)) for p in pipes]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    d = first_diff(pipes[0].all_paf(), want.paf)
+    assert d is None, d
+    for r in range(world):
+        if r:
+            assert pipes[r].all_paf() == ""
+        assert pipes[r].committed_rounds() == want.rounds
+        assert np.array_equal(readsets[r].ignore(), rs.ignore())
+        pipes[r].close()
+    r1 = Reads(bases, off, min_len=1000)
+    p1 = OverlapPipeline(r1, k=10, seed_batch_size=1500, rank=0, world=1, mode="round", comm="rccl", slots=2)
+    p1.text_root(0)
     p1.run()
     assert first_diff(p1.all_paf(), want.paf) is None
     p1.close()

@@ -15,7 +15,7 @@ for r in range(reps):
     for label, d, env in variants:
         e = dict(os.environ); e.update(env)
         p = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-rounds", "0", "--scan-leg-rounds", "0",
-                            "--dense-leg-rounds", "0", "--slots", slots] + extra, cwd=d, env=e, capture_output=True, text=True, timeout=900)
+                            "--dense-leg-rounds", "0", "--dense-job", "0", "--map-leg-repeats", "0", "--slots", slots] + extra, cwd=d, env=e, capture_output=True, text=True, timeout=900)
         try:
             j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
             res[label].append((j["rounds_only"]["ms_per_round"], j["job_breakdown_s"]["whole_job"], j["job_breakdown_s"]["setup_value_table_kmer_index_slots"],

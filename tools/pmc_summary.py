@@ -10,7 +10,7 @@ Kernels with scattered narrow reads are uncalibrated: for them the corrected fig
 import collections, csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r04")
+ROUND = os.environ.get("ROUND", "r05")
 R = os.path.join(ROOT, "gpurun_out", ROUND)
 OUT = os.path.join(ROOT, "profiles", ROUND)
 os.makedirs(OUT, exist_ok=True)
@@ -108,10 +108,12 @@ def traffic(fn, workload, desc, kernels, rounds_of):
 CHAIN = ["pair_scan_kernel", "chain_walk_kernel", "chain_spec_kernel", "chain_resolve_kernel", "match_anchor_kernel"]
 traffic("chain_traffic.json", "main", "chaining stage (pair_scan + chain_walk + chain_spec + chain_resolve + match_anchor)", CHAIN, "pair_scan_kernel")
 traffic("query_traffic.json", "main", "query_kernel<false> (+ <true> where launched)", ["query_kernel"], "query_kernel<false>")
-traffic("kindex_traffic.json", "main", "index-mode counting step (kidx_prepare + kidx_walk<false> + kidx_offsets)",
-        ["kidx_prepare", "kidx_walk<false>", "kidx_offsets"], "kidx_offsets")
-traffic("kindex_write_traffic.json", "main", "index-mode write step (kidx_fill_rec / kidx_walk<true> + kidx_sortwrite)",
-        ["kidx_fill_rec", "kidx_walk<true>", "kidx_sortwrite"], "kidx_offsets")
+traffic("kindex_traffic.json", "main", "index-mode counting step (kidx_prepare + kidx_walk_bin + kidx_bin_count [round 4: kidx_walk<false>] + kidx_offsets)",
+        ["kidx_prepare", "kidx_walk_bin", "kidx_bin_count", "kidx_walk<false>", "kidx_offsets"], "kidx_offsets")
+traffic("kindex_write_traffic.json", "main", "index-mode write step (kidx_bin_fill [round 4: kidx_fill_rec] / kidx_walk<true> + kidx_sortwrite)",
+        ["kidx_bin_fill", "kidx_fill_rec", "kidx_walk<true>", "kidx_sortwrite"], "kidx_offsets")
+traffic("dense_kindex_traffic.json", "dense", "index-mode counting + write steps at k = 10 (all kidx_* kernels)",
+        ["kidx_prepare", "kidx_walk_bin", "kidx_bin_count", "kidx_walk<false>", "kidx_offsets", "kidx_bin_fill", "kidx_fill_rec", "kidx_walk<true>", "kidx_sortwrite"], "kidx_offsets")
 traffic("consensus_traffic.json", "main", "consensus_full_kernel (all layouts)", ["consensus_full_kernel"], "pair_scan_kernel")
 traffic("scan_traffic.json", "scan", "scan_kernel<0, 2> (count pass)", ["scan_kernel<0, 2>"], "scan_kernel<0, 2>")
 traffic("dense_query_traffic.json", "dense", "query_kernel<false>, k=10", ["query_kernel"], "query_kernel<false>")
