@@ -686,6 +686,79 @@ static int gather_blobs_impl(dp_comm* c, dp_ctx* ctx, const uint8_t* blob, uint6
     return DP_OK;
 }
 
+// ---- all-gather of device-resident ranges, in place (round 5: the k-mer position index built in shares, dp_kindex.hip) --------------
+// Every rank holds an array of `total` elements of `elem` bytes at `dst`; rank q owns the elements [first[q], first[q + 1]) - its
+// share sits at `src` (or already in place when src is null).  Afterwards every rank's array is complete.  The shares are known to all
+// ranks (no size exchange).  RCCL flavour: one grouped broadcast per rank straight between the device buffers (xGMI, no host copy);
+// in-process flavour: every rank copies the peers' shares device to device once all have published theirs.  Internal (not part of
+// the C ABI): called on the context's stream, returns after the stream has been waited for.
+int dp_comm_allgather_ranges(dp_comm* c, dp_ctx* ctx, void* dst, size_t elem, const uint64_t* first, const void* src) {
+    if (!c || !ctx || !dst || !first) return DP_ERR_ARG;
+    if (c->dead) return dp_fail(ctx, DP_ERR_STATE, "index all-gather: the communicator failed in an earlier exchange");
+    hipSetDevice(ctx->device);
+    const int N = c->n_ranks, me = c->rank;
+    uint8_t* d = (uint8_t*)dst;
+    const void* mine = src ? src : (const void*)(d + first[me] * elem);
+    int rc = DP_OK;
+    if (c->local) {
+        LocalGroup* g = c->local;
+        auto barrier = [&](const char* what) -> int {
+            std::unique_lock<std::mutex> lk(g->mu);
+            const uint64_t my_gen = g->gen;
+            if (g->failed) return dp_fail(ctx, DP_ERR_STATE, what);
+            if (++g->arrived == N) {
+                g->arrived = 0;
+                g->gen++;
+                g->cv.notify_all();
+            } else {
+                g->cv.wait(lk, [&] { return g->gen != my_gen || g->failed; });
+                if (g->gen == my_gen) return dp_fail(ctx, DP_ERR_STATE, what);
+            }
+            return DP_OK;
+        };
+        // (the share must be final before a peer reads it: this rank's stream is waited for before it publishes)
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = dp_fail(ctx, DP_ERR_HIP, "index all-gather: stream");
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->blob[(size_t)me].p = (const uint8_t*)mine;
+            g->blob[(size_t)me].n = (uint64_t)ctx->device;
+        }
+        if (rc == DP_OK) rc = barrier("index all-gather: a peer rank failed");
+        if (rc == DP_OK) {
+            for (int q = 0; q < N && rc == DP_OK; q++) {
+                const uint64_t bytes = (first[q + 1] - first[q]) * elem;
+                if (!bytes) continue;
+                if (q == me) {
+                    if (src && hipMemcpyAsync(d + first[q] * elem, src, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                        rc = dp_fail(ctx, DP_ERR_HIP, "index all-gather: copy");
+                } else if (hipMemcpyPeerAsync(d + first[q] * elem, ctx->device, g->blob[(size_t)q].p, (int)g->blob[(size_t)q].n, bytes, ctx->stream) != hipSuccess) {
+                    rc = dp_fail(ctx, DP_ERR_HIP, "index all-gather: peer copy");
+                }
+            }
+            if (rc == DP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = dp_fail(ctx, DP_ERR_HIP, "index all-gather: stream");
+        }
+        // (nobody may free or overwrite its share before every peer has copied it)
+        if (rc == DP_OK) rc = barrier("index all-gather: a peer rank failed");
+    } else if (c->nccl) {
+        RcclApi* R = rccl_api();
+        ncclResult_t r = ncclSuccess;
+        R->GroupStart();
+        for (int q = 0; q < N && r == ncclSuccess; q++) {
+            const uint64_t bytes = (first[q + 1] - first[q]) * elem;
+            if (!bytes) continue;
+            r = R->Broadcast(q == me ? mine : (const void*)(d + first[q] * elem), d + first[q] * elem, bytes, ncclUint8, q, c->nccl, ctx->stream);
+        }
+        const ncclResult_t rg = R->GroupEnd();
+        if (r == ncclSuccess) r = rg;
+        if (r != ncclSuccess) rc = dp_fail(ctx, DP_ERR_HIP, R->GetErrorString(r));
+        else if (dp_stream_sync(ctx) != hipSuccess) rc = dp_fail(ctx, DP_ERR_HIP, "index all-gather: stream");
+    } else {
+        rc = dp_fail(ctx, DP_ERR_STATE, "index all-gather: communicator without a transport");
+    }
+    if (rc != DP_OK) dp_comm_abort(c);
+    return rc;
+}
+
 extern "C" int dp_gather_blobs(dp_comm* c, dp_ctx* ctx, const uint8_t* blob, uint64_t n, const uint64_t* sizes, int root, const uint8_t** all_out) {
     if (!c || !ctx || !all_out || !sizes || (n && !blob) || root < 0 || root >= c->n_ranks)
         return ctx ? dp_fail(ctx, DP_ERR_ARG, "dp_gather_blobs: bad arguments") : DP_ERR_ARG;

@@ -45,6 +45,7 @@ struct dp_ctx {
     dp_ctx* owner = nullptr;     // context whose reads (and k-mer position index) this one borrows
     std::atomic<int> n_borrowers{0};  // live contexts created from this one with dp_ctx_create_shared
     dp_kindex* kidx = nullptr;   // resident k-mer position index (dp_kindex.hip), owned by the reads' owner
+    struct dp_comm* kx_comm = nullptr;  // dp_kindex_set_comm: the ranks of this communicator build the index in shares and all-gather them
     DevBuf d_kx_sz, d_kx_lo, d_kx_tmp, d_kx_keys, d_kx_vals;  // per-round scratch of the index path
     uint64_t kx_hits = 0;
     uint64_t kx_prev_hits = 0, kx_prev_segs = 0;  // the previous index-mode round of this context: what the one-go step is sized from
@@ -240,8 +241,20 @@ struct dp_kindex_oneshot {  // the index step of a round launched in one go, siz
 };
 int dp_histogram_device(dp_ctx* ctx, int k, uint32_t* d_counts);  // dp_scan.hip
 int dp_kindex_ensure(dp_ctx* ctx, int k);
+struct dp_comm;
+int dp_comm_allgather_ranges(dp_comm* c, dp_ctx* ctx, void* dst, size_t elem, const uint64_t* first, const void* src);  // dp_comm.hip
+// A rank's share of a k-mer position index built by several ranks (round 5): filled by dp_kindex_build_sorted from the first-digit
+// counts every rank computes alike - rank q sorts the k-mers [digit_first[q] << kmer_shift, digit_first[q + 1] << kmer_shift), which are
+// the entries [entry_first[q], entry_first[q + 1]) of the whole index; the offsets it writes are relative to its own first entry.
+struct dp_kindex_shard {
+    int rank = 0, n_ranks = 1;
+    std::vector<uint32_t> digit_first;  // [n_ranks + 1]
+    std::vector<uint64_t> entry_first;  // [n_ranks + 1]
+    int kmer_shift = 0;
+    uint64_t total = 0;
+};
 int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, uint64_t* d_off, void** d_pos_out, void** d_pos_hi_out,
-                           int* fmt_out, int* pbits_out, uint64_t* n_pos_out, float* ms_out);  // dp_kbuild.hip
+                           int* fmt_out, int* pbits_out, uint64_t* n_pos_out, float* ms_out, dp_kindex_shard* shard = nullptr);  // dp_kbuild.hip
 void dp_kindex_free(dp_ctx* ctx);
 int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo, uint32_t hi, uint32_t n_read_items, uint32_t n_extra,
                     uint32_t* d_counts, uint64_t* d_segoff, uint32_t* s_item, uint32_t* s_count, uint64_t* s_off, uint4* s_pack, uint64_t* d_totals,

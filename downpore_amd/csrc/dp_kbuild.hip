@@ -33,6 +33,9 @@ typedef unsigned long long kb_u64;
 struct KbGeom {
     int k, b1, b2, r;  // digit widths: b1 + b2 + r = 2k
     int pbits, rbits;  // payload below the k-mer: position in the read, read id
+    // round 5: a rank of a multi-GPU job builds the index of the k-mers whose pass-1 digit lies in [dlo, dhi) only (the ranks' parts are
+    // all-gathered afterwards, dp_kindex.hip); one rank: [0, 2^b1)
+    uint32_t dlo, dhi;
 };
 
 // Round 4: entries are stored as narrow as their bits allow.  An entry in flight is a 64-bit word in registers and LDS; between the
@@ -206,9 +209,15 @@ __global__ __launch_bounds__(KB_THREADS) void kb_part1(const uint8_t* __restrict
         const kb_u64 a = (h >> 1) * 32 + (h & 1) * 16;
         // (lanes outside the read's k-mer range are masked out: their payload may be anything)
         const kb_u64 low = ((kb_u64)rd << G.pbits) + (a - a0);
+        uint32_t mine = m;
+        const int ksh = 2 * G.k - G.b1;
 #pragma unroll
-        for (int j = 0; j < 16; j++) e[j] = ((kb_u64)kmer[j] << pay) | (low + (kb_u64)j);
-        kb_tile_out<16>(e, m, dsh, dmask, hist, lstart, gbase, sorted, cursor, out);
+        for (int j = 0; j < 16; j++) {
+            e[j] = ((kb_u64)kmer[j] << pay) | (low + (kb_u64)j);
+            const uint32_t d = kmer[j] >> ksh;
+            if (d < G.dlo || d >= G.dhi) mine &= ~(1u << j);  // (another rank's k-mer)
+        }
+        kb_tile_out<16>(e, mine, dsh, dmask, hist, lstart, gbase, sorted, cursor, out);
     }
 }
 
@@ -379,6 +388,13 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const KbBuf in, const kb_
     if (blockIdx.x == 0 && threadIdx.x == 0) off[(kb_u64)n_sub << G.r] = base2[n_sub];
 }
 
+// a rank's share of the pass-1 buckets: the other ranks' counts go to zero before the scan (their tiles, sub-partitions and k-mers then
+// are empty on this rank and cost nothing in the later passes)
+__global__ void kb_mask_digits(kb_u64* __restrict__ cnt1, uint32_t nb1, uint32_t dlo, uint32_t dhi) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < nb1 && (d < dlo || d >= dhi)) cnt1[d] = 0;
+}
+
 __global__ void kb_excl_scan_small(const kb_u64* __restrict__ in, uint32_t n, kb_u64* __restrict__ out) {
     // n <= 2^20 entries, one workgroup: each thread scans a contiguous slice
     __shared__ kb_u64 part[1024];
@@ -410,7 +426,7 @@ __global__ void kb_excl_scan_small(const kb_u64* __restrict__ in, uint32_t n, kb
 // released before returning.  *fmt_out / *pbits_out say how an entry is stored (KbPosOut).
 // Returns 1 when this path does not apply (k < 9 or > 14, more than 2^36 bases): the caller uses the atomic scatter.
 int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, uint64_t* d_off, void** d_pos_out, void** d_pos_hi_out,
-                           int* fmt_out, int* pbits_out, uint64_t* n_pos_out, float* ms_out) {
+                           int* fmt_out, int* pbits_out, uint64_t* n_pos_out, float* ms_out, dp_kindex_shard* shard) {
     if (k < 9 || k > 14 || ow->n_reads == 0) return 1;
     if (getenv("DP_KINDEX_ATOMIC")) return 1;
     const uint64_t n_groups = (ow->packed_bytes * 4 + 31) / 32;
@@ -450,6 +466,8 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     }
     if (G.b2 > 10) return 1;
     const int nb1 = 1 << G.b1, nb2 = 1 << G.b2;
+    G.dlo = 0;
+    G.dhi = (uint32_t)nb1;
     const uint32_t n_sub = (uint32_t)nb1 * (uint32_t)nb2;
     // how the entries are stored after each pass (DP_KINDEX_WIDE=1: eight bytes throughout, the index as read << 32 | position)
     const bool wide = getenv("DP_KINDEX_WIDE") != nullptr;
@@ -467,7 +485,9 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
         size_t free_b = 0, total_b = 0;
         hipMemGetInfo(&free_b, &total_b);
         free_b += dp_dev_cached_bytes();
-        if ((uint64_t)free_b < ow->total_bases * per_entry + ((uint64_t)6 << 30)) return 1;  // (the caller builds with the atomic scatter, or scans)
+        // (a rank of a sharded build sorts 1 / n_ranks of the entries; the whole index it then gathers is the caller's to fit)
+        const uint64_t mine = shard && shard->n_ranks > 1 ? ow->total_bases / (uint64_t)shard->n_ranks + (ow->total_bases >> 6) : ow->total_bases;
+        if ((uint64_t)free_b < mine * per_entry + ((uint64_t)6 << 30)) return 1;  // (the caller builds with the atomic scatter, or scans)
     }
     void *d_gread = nullptr, *d_small = nullptr, *d_a_lo = nullptr, *d_a_hi = nullptr, *d_b_lo = nullptr, *d_b_hi = nullptr, *d_f_hi = nullptr;
     struct Temps {
@@ -499,6 +519,36 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     const uint32_t grid = (uint32_t)cus * 8;
     hipLaunchKernelGGL(kb_count1, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, (const uint8_t*)ow->d_packed.p, (const uint64_t*)ow->d_boff.p,
                        (const uint32_t*)ow->d_len.p, (const uint32_t*)d_gread, n_groups, G, cnt1);
+    if (shard && shard->n_ranks > 1) {
+        // every rank counts every k-mer's first digit (0.4 ms) and so knows every rank's share without asking: rank q takes the digits
+        // [first[q], first[q + 1]) - consecutive pass-1 buckets holding about 1 / n_ranks of the entries - and sorts those alone
+        std::vector<kb_u64> h_cnt((size_t)nb1);
+        DP_HIP(hipMemcpyAsync(h_cnt.data(), cnt1, (size_t)nb1 * 8, hipMemcpyDeviceToHost, ctx->stream));
+        DP_HIP(dp_stream_sync(ctx));
+        kb_u64 all = 0;
+        for (int b = 0; b < nb1; b++) all += h_cnt[(size_t)b];
+        const int N = shard->n_ranks;
+        shard->digit_first.assign((size_t)N + 1, (uint32_t)nb1);
+        shard->entry_first.assign((size_t)N + 1, all);
+        std::vector<kb_u64> pre((size_t)nb1 + 1, 0);
+        for (int b = 0; b < nb1; b++) pre[(size_t)b + 1] = pre[(size_t)b] + h_cnt[(size_t)b];
+        shard->digit_first[0] = 0;
+        shard->entry_first[0] = 0;
+        for (int q = 1; q < N; q++) {
+            const kb_u64 want = (all * (kb_u64)q + (kb_u64)N - 1) / (kb_u64)N;
+            int b = (int)shard->digit_first[(size_t)q - 1];
+            while (b < nb1 && pre[(size_t)b] < want) b++;
+            shard->digit_first[(size_t)q] = (uint32_t)b;
+            shard->entry_first[(size_t)q] = pre[(size_t)b];
+        }
+        shard->digit_first[(size_t)N] = (uint32_t)nb1;
+        shard->entry_first[(size_t)N] = all;
+        shard->kmer_shift = 2 * k - G.b1;
+        shard->total = all;
+        G.dlo = shard->digit_first[(size_t)shard->rank];
+        G.dhi = shard->digit_first[(size_t)shard->rank + 1];
+        hipLaunchKernelGGL(kb_mask_digits, dim3((nb1 + 255) / 256), dim3(256), 0, ctx->stream, cnt1, (uint32_t)nb1, G.dlo, G.dhi);
+    }
     hipLaunchKernelGGL(kb_excl_scan_small, dim3(1), dim3(1024), 0, ctx->stream, (const kb_u64*)cnt1, (uint32_t)nb1, base1);
     DP_HIP(hipGetLastError());
     std::vector<kb_u64> h_base1((size_t)nb1 + 1);

@@ -92,6 +92,47 @@ __global__ void kidx_count_kernel(const uint8_t* __restrict__ packed, const uint
 
 static dp_ctx* kidx_owner(dp_ctx* ctx) { return ctx->owner ? ctx->owner : ctx; }
 
+// ---- round 5: the index built in shares, one per rank, and all-gathered ---------------------------------------------------------
+__global__ void kidx_off_rebase(uint64_t* __restrict__ off, uint64_t kmer_lo, uint64_t kmer_hi, uint64_t add, uint64_t nk, uint64_t total) {
+    const uint64_t i = kmer_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kmer_hi) off[i] += add;
+    if (blockIdx.x == 0 && threadIdx.x == 0) off[nk] = total;
+}
+// After dp_kindex_build_sorted with a shard: *d_pos / *d_pos_hi hold this rank's entries, `off` the bucket starts of its k-mers
+// relative to its first entry, `counts` its k-mers' counts.  Afterwards all four describe the whole index (the entry arrays are
+// replaced by full-size ones), identical on every rank up to the order of the entries inside a bucket.  Collective.
+static int kidx_gather_shares(dp_ctx* ctx, dp_comm* comm, const dp_kindex_shard& sh, int k, int fmt, uint32_t* counts, uint64_t* off,
+                              void** d_pos, void** d_pos_hi, uint64_t* n_pos) {
+    const int N = sh.n_ranks, me = sh.rank;
+    const uint64_t nk = (uint64_t)1 << (2 * k);
+    std::vector<uint64_t> kfirst((size_t)N + 1);
+    for (int q = 0; q <= N; q++) kfirst[(size_t)q] = std::min<uint64_t>(nk, (uint64_t)sh.digit_first[(size_t)q] << sh.kmer_shift);
+    const size_t elem = fmt == 8 ? 8 : 4;
+    void *full = nullptr, *full_hi = nullptr;
+    auto fail = [&](int rc) {
+        if (full) dp_dev_free(full);
+        if (full_hi) dp_dev_free(full_hi);
+        return rc;
+    };
+    if (dp_dev_malloc(&full, sh.total * elem + 64) != hipSuccess) return fail(dp_fail(ctx, DP_ERR_HIP, "k-mer position index: no memory for the gathered entries"));
+    if (fmt == 5 && dp_dev_malloc(&full_hi, sh.total + 64) != hipSuccess) return fail(dp_fail(ctx, DP_ERR_HIP, "k-mer position index: no memory for the gathered entries"));
+    if (int rc = dp_comm_allgather_ranges(comm, ctx, full, elem, sh.entry_first.data(), *d_pos)) return fail(rc);
+    if (fmt == 5)
+        if (int rc = dp_comm_allgather_ranges(comm, ctx, full_hi, 1, sh.entry_first.data(), *d_pos_hi)) return fail(rc);
+    const uint64_t mine_k = kfirst[(size_t)me + 1] - kfirst[(size_t)me];
+    hipLaunchKernelGGL(kidx_off_rebase, dim3((unsigned)std::max<uint64_t>(1, (mine_k + 255) / 256)), dim3(256), 0, ctx->stream, off, kfirst[(size_t)me],
+                       kfirst[(size_t)me + 1], sh.entry_first[(size_t)me], nk, sh.total);
+    if (hipGetLastError() != hipSuccess) return fail(dp_fail(ctx, DP_ERR_HIP, "kidx_off_rebase"));
+    if (int rc = dp_comm_allgather_ranges(comm, ctx, off, 8, kfirst.data(), nullptr)) return fail(rc);
+    if (int rc = dp_comm_allgather_ranges(comm, ctx, counts, 4, kfirst.data(), nullptr)) return fail(rc);
+    dp_dev_free(*d_pos);
+    if (*d_pos_hi) dp_dev_free(*d_pos_hi);
+    *d_pos = full;
+    *d_pos_hi = full_hi;
+    *n_pos = sh.total;
+    return DP_OK;
+}
+
 // Builds the index for k on the context that owns the reads (once; callers on borrowing contexts wait on its mutex).
 // Returns DP_OK when the index is ready, 1 when it cannot be used for this k / read set (the caller scans), <0 on error.
 int dp_kindex_ensure(dp_ctx* ctx, int k) {
@@ -138,7 +179,47 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
         uint64_t n_pos = 0;
         float ms = 0;
         int fmt = 8, pbits = 32;
-        const int rc = dp_kindex_build_sorted(ctx, ow, k, (uint32_t*)d_cnt, (uint64_t*)ix->off.p, &d_pos, &d_pos_hi, &fmt, &pbits, &n_pos, &ms);
+        // round 5, multi-GPU: every rank sorts the k-mers of its own share of the first-digit buckets and the shares are all-gathered
+        // (RCCL over xGMI, device to device) - 1 / N of the build's three passes per rank instead of all of them on every rank.
+        // DP_KINDEX_SHARD=0: every rank builds everything, as until round 4.
+        dp_kindex_shard shard;
+        const char* se = getenv("DP_KINDEX_SHARD");
+        const bool sharded = ow->kx_comm && dp_comm_size(ow->kx_comm) > 1 && !(se && se[0] == '0');
+        if (sharded) {
+            shard.rank = dp_comm_rank(ow->kx_comm);
+            shard.n_ranks = dp_comm_size(ow->kx_comm);
+        }
+        int rc = dp_kindex_build_sorted(ctx, ow, k, (uint32_t*)d_cnt, (uint64_t*)ix->off.p, &d_pos, &d_pos_hi, &fmt, &pbits, &n_pos, &ms,
+                                        sharded ? &shard : nullptr);
+        if (sharded) {
+            // the ranks agree on how it went before anybody waits in a collective for a rank that fell back
+            const uint8_t mine = (uint8_t)(rc == 0 ? 0 : rc > 0 ? 1 : 2);
+            const uint8_t* all = nullptr;
+            const uint64_t* sizes = nullptr;
+            if (int xr = dp_allgather_blobs(ow->kx_comm, ctx, &mine, 1, &all, &sizes)) {
+                if (rc == 0) {
+                    dp_dev_free(d_pos);
+                    if (d_pos_hi) dp_dev_free(d_pos_hi);
+                }
+                dp_dev_free(d_cnt);
+                return xr;
+            }
+            uint8_t worst = 0;
+            for (int q = 0; q < shard.n_ranks; q++) worst = std::max(worst, all[q]);
+            if (worst == 0) {
+                rc = kidx_gather_shares(ctx, ow->kx_comm, shard, k, fmt, (uint32_t*)d_cnt, (uint64_t*)ix->off.p, &d_pos, &d_pos_hi, &n_pos);
+            } else {
+                if (rc == 0) {
+                    dp_dev_free(d_pos);
+                    if (d_pos_hi) dp_dev_free(d_pos_hi);
+                    d_pos = d_pos_hi = nullptr;
+                }
+                // (a rank could not build its share: everybody builds the whole index on its own, or fails alike)
+                rc = worst == 2 && rc >= 0 ? 1 : rc;
+                if (rc >= 0)
+                    rc = dp_kindex_build_sorted(ctx, ow, k, (uint32_t*)d_cnt, (uint64_t*)ix->off.p, &d_pos, &d_pos_hi, &fmt, &pbits, &n_pos, &ms, nullptr);
+            }
+        }
         if (rc < 0) {
             dp_dev_free(d_cnt);
             return rc;
@@ -210,6 +291,46 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
     ix->n_pos = total;
     ix->k = k;
     ix->built = true;
+    return DP_OK;
+}
+
+extern "C" int dp_kindex_set_comm(dp_ctx* ctx, dp_comm* comm) {
+    if (!ctx) return DP_ERR_ARG;
+    kidx_owner(ctx)->kx_comm = comm;
+    return DP_OK;
+}
+
+__device__ __forceinline__ unsigned long long kidx_mix(unsigned long long x) {  // splitmix64's finaliser
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__global__ void kidx_digest_kernel(const uint64_t* __restrict__ off, const KxPos pos, uint64_t nk, unsigned long long* __restrict__ out) {
+    unsigned long long a = 0, b = 0;
+    for (uint64_t km = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; km < nk; km += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t o0 = off[km], o1 = off[km + 1];
+        a += kidx_mix(km * 0x9e3779b97f4a7c15ull + o0);
+        for (uint64_t i = o0; i < o1; i++) b += kidx_mix(kidx_mix(km + 1) ^ kx_entry(pos, i));
+    }
+    atomicAdd(&out[1], a);
+    atomicAdd(&out[2], b);
+}
+extern "C" int dp_kindex_digest(dp_ctx* ctx, int k, uint64_t* out) {
+    if (!ctx || !out) return DP_ERR_ARG;
+    dp_kindex* ix = kidx_owner(ctx)->kidx;
+    if (!ix || !ix->built || ix->k != k) return dp_fail(ctx, DP_ERR_STATE, "dp_kindex_digest: no index built for this k");
+    hipSetDevice(ctx->device);
+    unsigned long long* d = nullptr;
+    DP_HIP(dp_dev_malloc((void**)&d, 64));
+    DP_HIP(hipMemsetAsync(d, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(kidx_digest_kernel, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t*)ix->off.p, ix->view(), (uint64_t)1 << (2 * k), d);
+    DP_HIP(hipGetLastError());
+    DP_HIP(hipMemcpyAsync(out, d, 24, hipMemcpyDeviceToHost, ctx->stream));
+    DP_HIP(dp_stream_sync(ctx));
+    out[0] = ix->n_pos;
+    dp_dev_free(d);
     return DP_OK;
 }
 
@@ -589,7 +710,7 @@ struct kidx_walk_bin {
     static __device__ __forceinline__ void four(const uint64_t e[4], const bool v[4], uint32_t s, const dp_scan_item* __restrict__ items,
                                                 uint32_t lo, uint32_t hi, uint32_t n_read_items, const uint32_t* __restrict__ head,
                                                 const uint32_t* __restrict__ next, uint32_t* __restrict__ counts, const KxBins& B,
-                                                uint32_t* hist, const uint32_t* base) {
+                                                uint32_t* hist, const uint32_t* base, uint32_t* xs) {
         bool valid[4];
         uint32_t hd[4];
         const uint32_t rmask = (1u << B.bshift) - 1u;
@@ -601,11 +722,11 @@ struct kidx_walk_bin {
                 // (the ignore byte is NOT looked at here: another slot's commit may flag the read between the two passes, and a record
                 // slot that was counted and not written would hold a stale word.  kidx_bin_count applies it, once per read)
                 valid[u] = in;
-                hd[u] = (!WRITE && v[u] && r - B.qlo < B.qspan) ? head[r] : 0u;
+                hd[u] = (v[u] && r - B.qlo < B.qspan) ? head[r] : 0u;
             } else {
                 // (ignored reads carry n_kmers == 0; a top-level read with len % 4 == 0 four k-mers less)
                 valid[u] = in && p < items[in ? r - lo : 0u].n_kmers;
-                hd[u] = (!WRITE && v[u]) ? head[r] : 0u;
+                hd[u] = v[u] ? head[r] : 0u;
             }
         }
 #pragma unroll
@@ -625,19 +746,64 @@ struct kidx_walk_bin {
                     }
                 }
             }
-            if (!WRITE) {
-                for (uint32_t x = hd[u]; x; x = next[x - 1]) {  // the round's extra items on this read (query windows)
-                    const uint32_t it = n_read_items + x - 1;
-                    const dp_scan_item xi = items[it];
-                    if (p - xi.start < xi.n_kmers && p >= xi.start) {
+            // the round's extra items on this read (query windows): counted in the first pass, kept as a list in the second - a stretch of
+            // the list per workgroup (xs[0] counts, then ranks; xs[1] = the stretch's start: ONE returning atomic per workgroup - a
+            // returning atomic per hit, 5 k per round on one address, was 40 us of this kernel)
+            for (uint32_t x = hd[u]; x; x = next[x - 1]) {
+                const uint32_t it = n_read_items + x - 1;
+                const dp_scan_item xi = items[it];
+                if (p - xi.start < xi.n_kmers && p >= xi.start) {
+                    if (!WRITE) {
                         atomicAdd(&counts[it], 1u);
-                        const uint32_t at = atomicAdd(B.xcursor, 1u);
-                        if (at < B.xcap)
-                            B.xrec[at] = make_uint4(it, p - xi.start, s, 0u);
-                        else
-                            B.flags[0] = 1u;
+                        atomicAdd(&xs[0], 1u);
+                    } else if (xs[1] != 0xffffffffu) {
+                        B.xrec[xs[1] + atomicAdd(&xs[0], 1u)] = make_uint4(it, p - xi.start, s, 0u);
                     }
                 }
+            }
+        }
+    }
+    // what lies behind a lane's first four entries.  Dense seeds (a wave per quarter bucket): the wave's stride, as ever.  Four seeds per
+    // wave: a seed's 16 lanes cover 64 entries per trip - and the kernel is as long as its longest bucket (a repeat's k-mer with a few
+    // thousand occurrences was 40+ dependent trips of ONE quarter wave, twice over with two passes): everything beyond a bucket's first
+    // 64 entries is walked by the WHOLE wave, 256 entries per trip, one seed of the wave after the other
+    template <bool WRITE>
+    static __device__ __forceinline__ void tail(uint32_t lps, int lane, uint32_t w, uint32_t s, uint64_t o, uint32_t i0, uint32_t i1, uint32_t step,
+                                                const KxPos pos, const dp_scan_item* __restrict__ items, uint32_t lo, uint32_t hi,
+                                                uint32_t n_read_items, const uint32_t* __restrict__ head, const uint32_t* __restrict__ next,
+                                                uint32_t* __restrict__ counts, const KxBins& B, uint32_t* hist, const uint32_t* base, uint32_t* xs) {
+        if (lps == 64) {
+            for (uint32_t ib = i0 + 4 * step; ib < i1; ib += 4 * step) {
+                uint64_t e[4];
+                bool v[4];
+                kx_entry4(pos, o + ib, e);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    v[u] = ib + (uint32_t)u < i1;
+                    e[u] = v[u] ? e[u] : 0ull;
+                }
+                four<WRITE>(e, v, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+            }
+            return;
+        }
+        if (!__ballot(i1 > 64u)) return;  // (wave-uniform: no bucket of this wave goes beyond its first trip)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t ng = (uint32_t)__shfl((int)i1, 16 * g, 64);
+            if (ng <= 64u) continue;
+            const uint32_t lo32 = (uint32_t)__shfl((int)(uint32_t)o, 16 * g, 64), hi32 = (uint32_t)__shfl((int)(uint32_t)(o >> 32), 16 * g, 64);
+            const uint64_t og = ((uint64_t)hi32 << 32) | lo32;
+            const uint32_t sg = w * 4 + (uint32_t)g;
+            for (uint32_t ib = 64u + 4u * (uint32_t)lane; ib < ng; ib += 256u) {
+                uint64_t e[4];
+                bool v[4];
+                kx_entry4(pos, og + ib, e);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    v[u] = ib + (uint32_t)u < ng;
+                    e[u] = v[u] ? e[u] : 0ull;
+                }
+                four<WRITE>(e, v, sg, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
             }
         }
     }
@@ -646,13 +812,17 @@ struct kidx_walk_bin {
                                const uint32_t* __restrict__ head, const uint32_t* __restrict__ next, uint32_t* __restrict__ counts,
                                unsigned long long* __restrict__ n_hits, uint32_t lps, const KxBins B, uint32_t n_waves) {
         __shared__ uint32_t hist[KX_MAXBINS], base[KX_MAXBINS];
+        __shared__ uint32_t xs[2];
         __shared__ unsigned long long sh_hits;
         const int lane = dp_lane();
         const uint32_t stride = gridDim.x * WAVES;
         // (every wave of a workgroup makes the same number of trips: the barriers below are the workgroup's)
         for (uint32_t wb = blockIdx.x * WAVES; wb < n_waves; wb += stride) {
             for (uint32_t t = threadIdx.x; t < B.n_bins; t += THREADS) hist[t] = 0u;
-            if (threadIdx.x == 0) sh_hits = 0ull;
+            if (threadIdx.x == 0) {
+                sh_hits = 0ull;
+                xs[0] = xs[1] = 0u;
+            }
             __syncthreads();
             const uint32_t w = wb + (threadIdx.x >> 6);
             // the groups of kidx_walk: KX_PARTS waves per seed (dense seeds), or four seeds per wave
@@ -695,19 +865,9 @@ struct kidx_walk_bin {
                     v0[u] = i0 + (uint32_t)u < i1;
                     e0[u] = v0[u] ? e0[u] : 0ull;
                 }
-                four<false>(e0, v0, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base);
+                four<false>(e0, v0, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
             }
-            for (uint32_t ib = i0 + 4 * step; ib < i1; ib += 4 * step) {
-                uint64_t e[4];
-                bool v[4];
-                kx_entry4(pos, o + ib, e);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    v[u] = ib + (uint32_t)u < i1;
-                    e[u] = v[u] ? e[u] : 0ull;
-                }
-                four<false>(e, v, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base);
-            }
+            tail<false>(lps, lane, w, s, o, i0, i1, step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
             __syncthreads();
             for (uint32_t t = threadIdx.x; t < B.n_bins; t += THREADS) {
                 const uint32_t c = hist[t];
@@ -725,19 +885,22 @@ struct kidx_walk_bin {
                 hist[t] = 0u;
             }
             if (threadIdx.x == 0 && sh_hits) atomicAdd(&n_hits[blockIdx.x & 63u], sh_hits);  // seed occurrences of the round (totals[2])
-            __syncthreads();
-            if (i0 < i1) four<true>(e0, v0, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base);
-            for (uint32_t ib = i0 + 4 * step; ib < i1; ib += 4 * step) {
-                uint64_t e[4];
-                bool v[4];
-                kx_entry4(pos, o + ib, e);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    v[u] = ib + (uint32_t)u < i1;
-                    e[u] = v[u] ? e[u] : 0ull;
+            if (threadIdx.x == THREADS - 1) {  // the workgroup's stretch of the extra items' list
+                const uint32_t c = xs[0];
+                uint32_t xb = 0u;
+                if (c) {
+                    xb = atomicAdd(B.xcursor, c);
+                    if (xb + c > B.xcap) {
+                        xb = 0xffffffffu;
+                        B.flags[0] = 1u;
+                    }
                 }
-                four<true>(e, v, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base);
+                xs[1] = xb;
+                xs[0] = 0u;
             }
+            __syncthreads();
+            if (i0 < i1) four<true>(e0, v0, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+            tail<true>(lps, lane, w, s, o, i0, i1, step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
             __syncthreads();
         }
     }

@@ -214,6 +214,7 @@ void dph_overlap_destroy(void* hh) {
     OverlapH* h = (OverlapH*)hh;
     if (!h) return;
     h->run.shutdown();
+    if (h->ctx) dp_kindex_set_comm(h->ctx, nullptr);
     if (h->comm) dp_comm_destroy(h->comm);
     for (dp_comm* c : h->slotComms) dp_comm_destroy(c);
     if (h->xctx) dp_ctx_destroy(h->xctx);
@@ -276,11 +277,14 @@ int dph_overlap_round_finish(void* hh, const uint32_t* read, const uint32_t* nse
 int dph_comm_unique_id(uint8_t* id128) { return dp_comm_unique_id(id128); }
 int dph_overlap_comm_init(void* hh, int nRanks, int rank, const uint8_t* id128) {
     OverlapH* h = (OverlapH*)hh;
+    dp_kindex_set_comm(h->ctx, nullptr);
     if (h->comm) dp_comm_destroy(h->comm);
     h->comm = nullptr;
     int rc = dp_comm_init(h->ctx, nRanks, rank, id128, &h->comm);
     if (rc != 0) h->err = dp_last_error(h->ctx);
     h->run.comm = h->comm;
+    // (round 5: with a communicator in place the job's k-mer position index is built in shares, one per rank, and all-gathered over it)
+    if (rc == 0) dp_kindex_set_comm(h->ctx, h->comm);
     return rc;
 }
 int dph_overlap_comm_init_local(void** handles, int n) {
@@ -291,9 +295,11 @@ int dph_overlap_comm_init_local(void** handles, int n) {
     if (rc != 0) return rc;
     for (int i = 0; i < n; i++) {
         OverlapH* h = (OverlapH*)handles[i];
+        dp_kindex_set_comm(h->ctx, nullptr);
         if (h->comm) dp_comm_destroy(h->comm);
         h->comm = comms[(size_t)i];
         h->run.comm = h->comm;
+        dp_kindex_set_comm(h->ctx, h->comm);
     }
     return 0;
 }
@@ -301,6 +307,7 @@ int dph_overlap_comm_init_local(void** handles, int n) {
 // rank in the same order).  Call before dph_overlap_init: the slots pick their communicators up when they are created.
 int dph_overlap_comm_init_slots(void* hh, int nRanks, int rank, const uint8_t* ids, int nSlots) {
     OverlapH* h = (OverlapH*)hh;
+    if (!h->comm) dp_kindex_set_comm(h->ctx, nullptr);
     for (dp_comm* c : h->slotComms) dp_comm_destroy(c);
     h->slotComms.clear();
     for (int i = 0; i < nSlots; i++) {
@@ -315,6 +322,7 @@ int dph_overlap_comm_init_slots(void* hh, int nRanks, int rank, const uint8_t* i
     h->run.slotComms = h->slotComms;
     for (size_t i = 0; i < h->run.slots.size() && i < h->slotComms.size(); i++) h->run.slots[i]->comm = h->slotComms[i];
     h->run.destroyGangs();  // (slots that exchange on communicators of their own do not share launches: see OverlapRun::init)
+    if (!h->comm && !h->slotComms.empty()) dp_kindex_set_comm(h->ctx, h->slotComms[0]);  // (the index is built in shares over slot 0's)
     return 0;
 }
 int dph_overlap_comm_init_local_slots(void** handles, int n, int nSlots) {
@@ -322,6 +330,7 @@ int dph_overlap_comm_init_local_slots(void** handles, int n, int nSlots) {
     for (int i = 0; i < n; i++) ctxs.push_back(((OverlapH*)handles[i])->ctx);
     for (int i = 0; i < n; i++) {
         OverlapH* h = (OverlapH*)handles[i];
+        if (!h->comm) dp_kindex_set_comm(h->ctx, nullptr);
         for (dp_comm* c : h->slotComms) dp_comm_destroy(c);
         h->slotComms.clear();
     }
@@ -336,6 +345,7 @@ int dph_overlap_comm_init_local_slots(void** handles, int n, int nSlots) {
         h->run.slotComms = h->slotComms;
         for (size_t j = 0; j < h->run.slots.size() && j < h->slotComms.size(); j++) h->run.slots[j]->comm = h->slotComms[j];
         h->run.destroyGangs();  // (see dph_overlap_comm_init_slots)
+        if (!h->comm && !h->slotComms.empty()) dp_kindex_set_comm(h->ctx, h->slotComms[0]);
     }
     return 0;
 }

@@ -487,6 +487,17 @@ DP_API void dp_gang_counters(dp_gang* gang, uint64_t* out /* [5] */);
  * = the ranks' strings back to back in rank order, *sizes_out[n_ranks] their lengths (library-owned, valid until the next call on
  * this communicator).  Collective. */
 DP_API int dp_allgather_blobs(dp_comm* comm, dp_ctx* ctx, const uint8_t* blob, uint64_t n, const uint8_t** all_out, const uint64_t** sizes_out);
+/* The resident k-mer position index of a multi-GPU job (what dp_scan_prepare builds: 4 - 5 bytes per base of the read set, identical on
+ * every rank) is built in shares once a communicator is announced: every rank radix-sorts the k-mers of 1 / n_ranks of the first-digit
+ * buckets (all ranks hold all reads) and the shares - index entries, bucket offsets, k-mer counts - are all-gathered in place, device to
+ * device (RCCL over xGMI, or copies between the contexts of one process).  BASELINE.json's "RCCL all-gather of the seed index".
+ * Call on the context that owns the reads, on every rank, before dp_scan_prepare / dp_kmer_values; comm = NULL: every rank builds
+ * the whole index on its own again.  dp_scan_prepare is then collective. */
+DP_API int dp_kindex_set_comm(dp_ctx* ctx, dp_comm* comm);
+/* Test hook: an order-independent digest of the resident index of `ctx` (built for k): out[0] = entries, out[1] = sum over the k-mers of
+ * mix(k-mer, bucket start), out[2] = sum over the entries of mix(k-mer of the entry's bucket, read, position).  Two builds of the same
+ * reads agree on all three whatever the order of the entries inside a bucket. */
+DP_API int dp_kindex_digest(dp_ctx* ctx, int k, uint64_t* out /* [3] */);
 /* Gather of one variable-size byte string per rank to rank `root` only: the PAF text of the round-parallel layout's rounds, which only
  * the rank that prints needs (finalCheckWorker's fmt.Print, commands/overlap.go:225-228, happens in one process; at 8 ranks every rank
  * otherwise receives and copies all 235 MB of a config-2 job's text).  sizes[n_ranks] = every rank's length, the same array on every

@@ -722,6 +722,111 @@ def test_round_parallel_exchange_inside_the_library():
     p1.close()
 
 
+@pytest.mark.parametrize("world,k,env", [(2, 10, {}), (3, 13, {}), (4, 11, {"DP_KB_MIN_PBITS": "30"}), (3, 10, {"DP_KINDEX_WIDE": "1"})])
+def test_kmer_index_built_in_shares_and_all_gathered(monkeypatch, world, k, env):
+    """BASELINE.json's "RCCL all-gather of the seed index", for the resident k-mer position index (round 5): with a communicator
+    announced (dp_kindex_set_comm) every rank radix-sorts the k-mers of 1 / world of the first-digit buckets and the shares - entries,
+    bucket offsets, k-mer counts - are all-gathered in place (here: contexts of one process on one GPU, device-to-device copies; across
+    processes the same call sequence runs grouped ncclBroadcasts).  Every rank's gathered index must be the single-rank build's:
+    same entry count, same bucket starts, same entries per bucket (order inside a bucket is free) - in the 4-byte, 5-byte and 8-byte
+    entry formats - and the k-mer value table computed from the gathered counts must be bit-identical."""
+    import ctypes as C
+    import threading
+    import downpore_amd
+    from downpore_amd import hip
+    monkeypatch.setenv("DP_SCAN_INDEX", "1")
+    for kk, vv in env.items():
+        monkeypatch.setenv(kk, vv)
+    L = hip.load_library()
+    L.dp_comm_init_local.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.dp_kindex_set_comm.argtypes = [C.c_void_p, C.c_void_p]
+    L.dp_kindex_digest.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.dp_comm_destroy.argtypes = [C.c_void_p]
+    bases, off = O.gen_reads(90 + k, 300000, 900, 4000, 0.01, True)
+    ref = downpore_amd.Context(0)
+    ref.upload_reads(bases, off)
+    ref.scan_prepare(k)
+    want = np.zeros(3, dtype=np.uint64)
+    assert L.dp_kindex_digest(ref.h, k, want.ctypes.data) == 0 and want[0] > 3000000
+    want_values = ref.kmer_values(k)
+    ctxs = [downpore_amd.Context(0) for _ in range(world)]
+    for c in ctxs:
+        c.upload_reads(bases, off)
+    hs = (C.c_void_p * world)(*[c.h for c in ctxs])
+    comms = (C.c_void_p * world)()
+    assert L.dp_comm_init_local(hs, world, comms) == 0
+    for r in range(world):
+        assert L.dp_kindex_set_comm(ctxs[r].h, comms[r]) == 0
+    errs = []
+
+    def build(c):
+        try:
+            c.scan_prepare(k)  # collective
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=build, args=(c,)) for c in ctxs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    for r in range(world):
+        got = np.zeros(3, dtype=np.uint64)
+        assert L.dp_kindex_digest(ctxs[r].h, k, got.ctypes.data) == 0
+        assert got.tolist() == want.tolist(), (r, got, want)
+        v = ctxs[r].kmer_values(k)
+        assert np.array_equal(v.view(np.uint64), want_values.view(np.uint64)), r
+    for r in range(world):
+        L.dp_kindex_set_comm(ctxs[r].h, None)
+        L.dp_comm_destroy(comms[r])
+        ctxs[r].close()
+    ref.close()
+
+
+def test_round_parallel_job_on_an_index_built_in_shares():
+    """The whole round-parallel job (three in-process ranks x two slots, reads that flag reads) with the k-mer position index built in
+    shares and all-gathered before the first round: dph_overlap_init is then collective.  Rank 0 prints the oracle's PAF."""
+    import threading
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    os.environ["DP_SCAN_INDEX"] = "1"
+    try:
+        bases, off = O.gen_reads(33, 60000, 700, 1500, 0.0, True)
+        rs = O.ReadSet(bases, off, min_len=1000)
+        want = O.OverlapRun(rs, k=10, seed_batch_size=1500)
+        world = 3
+        readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
+        pipes = [OverlapPipeline(readsets[r], k=10, seed_batch_size=1500, rank=r, world=world, mode="round", comm="local", slots=2, defer_init=True)
+                 for r in range(world)]
+        OverlapPipeline.link_local(pipes)  # (before init: the index of this job is built in shares over the communicator)
+        for r, p in enumerate(pipes):
+            p.text_root(0)
+            p.keep_text(r == 0)
+        errs = []
+
+        def run(p):
+            try:
+                p.init()
+                p.run()
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=run, args=(p,)) for p in pipes]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        assert not errs, errs
+        d = first_diff(pipes[0].all_paf(), want.paf)
+        assert d is None, d
+        for r in range(world):
+            st = pipes[r].stats_total()
+            assert st["idx_rounds"] > 0
+            assert pipes[r].committed_rounds() == want.rounds
+            assert np.array_equal(readsets[r].ignore(), rs.ignore())
+            pipes[r].close()
+    finally:
+        del os.environ["DP_SCAN_INDEX"]
+
+
 def test_round_parallel_text_goes_to_the_printing_rank_only():
     """dph_overlap_text_root(0): a superstep all-gathers the rounds' control records (flags, read lists, counts) and gathers their PAF
     text to rank 0 alone (dp_gather_blobs).  Three in-process ranks x two slots on reads that flag reads: rank 0 prints the oracle's

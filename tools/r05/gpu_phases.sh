@@ -5,7 +5,7 @@
 R=gpurun_out/r05; mkdir -p $R
 COMMON="--steps 1 --warmup 1 --cpu-rounds 0 --scan-leg-rounds 0 --dense-leg-rounds 0 --dense-job 0 --map-leg-repeats 0 --max-rounds 240"
 for s in 1 5; do
-  DP_LIB_DIR=$PWD/downpore_amd/lib_prof DP_CHAIN_PROF=1 python3 bench.py $COMMON --slots $s > $R/phases_s$s.json 2> $R/phases_s$s.err; echo "slots $s rc $?"
+  DP_KX_BINS=0 DP_LIB_DIR=$PWD/downpore_amd/lib_prof DP_CHAIN_PROF=1 timeout 600 python3 bench.py $COMMON --slots $s > $R/phases_s$s.json 2> $R/phases_s$s.err; echo "slots $s rc $?"
   python3 tools/r05/chainprof_digest.py $R/phases_s$s.err 40 | tee $R/chain_phases_slots$s.txt
   python3 - <<PY
 import json
