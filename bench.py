@@ -677,8 +677,8 @@ def map_config3_leg(repeats, cpu=True):
         del paf
     n = gen["reads"]
     total_bases = float(off[-1])
-    cpu = None
-    if cpu_wanted(cpu):
+    cpu_wanted_flag, cpu = cpu_wanted(cpu), None
+    if cpu_wanted_flag:
         from tests import oracle_lib as O
         t0 = time.perf_counter()
         want, werr = O.map_run(O.ReadSet(genome, goff, min_len=0, himem=False), O.ReadSet(bases, off, min_len=500, himem=False), circular=True, k=g["k"])
