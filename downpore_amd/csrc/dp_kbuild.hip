@@ -519,7 +519,7 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     const uint32_t grid = (uint32_t)cus * 8;
     hipLaunchKernelGGL(kb_count1, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, (const uint8_t*)ow->d_packed.p, (const uint64_t*)ow->d_boff.p,
                        (const uint32_t*)ow->d_len.p, (const uint32_t*)d_gread, n_groups, G, cnt1);
-    if (shard && shard->n_ranks > 1) {
+    if (shard) {
         // every rank counts every k-mer's first digit (0.4 ms) and so knows every rank's share without asking: rank q takes the digits
         // [first[q], first[q + 1]) - consecutive pass-1 buckets holding about 1 / n_ranks of the entries - and sorts those alone
         std::vector<kb_u64> h_cnt((size_t)nb1);

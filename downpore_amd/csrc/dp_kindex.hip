@@ -184,7 +184,9 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
         // DP_KINDEX_SHARD=0: every rank builds everything, as until round 4.
         dp_kindex_shard shard;
         const char* se = getenv("DP_KINDEX_SHARD");
-        const bool sharded = ow->kx_comm && dp_comm_size(ow->kx_comm) > 1 && !(se && se[0] == '0');
+        // (DP_KINDEX_SHARD=force: also with a communicator of ONE rank - the test hook that takes the RCCL flavour of the gather, grouped
+        // ncclBroadcasts between device buffers, through a real librccl on a one-GPU box)
+        const bool sharded = ow->kx_comm && (dp_comm_size(ow->kx_comm) > 1 || (se && se[0] == 'f')) && !(se && se[0] == '0');
         if (sharded) {
             shard.rank = dp_comm_rank(ow->kx_comm);
             shard.n_ranks = dp_comm_size(ow->kx_comm);

@@ -418,7 +418,7 @@ void dph_overlap_set_round_limit(void* hh, int64_t n) { ((OverlapH*)hh)->run.rou
 int64_t dph_overlap_round(void* hh) { return ((OverlapH*)hh)->run.round; }
 void dph_profile_print() { profilePrint(); }
 // Buffers the library keeps between jobs so that a handle's next job need not map and zero-fill them again (PAF text strings and
-// record arrays: up to 256 MB; window-cache chunks: up to 16 x 11.5 MB; the map command's staging block: ~400 MB at config 3)
+// record arrays: up to 512 MB; window-cache chunks: up to 16 x 11.5 MB; the map command's staging block: ~400 MB at config 3)
 // go back to the allocator.  Safe at any time (a running job simply allocates again); returns the bytes released.
 int64_t dph_release_caches() { return (int64_t)(TextJobBuffers::releaseAll() + WindowCache::releaseSpares() + releaseMapStaging()); }
 // process-wide planner counters (tests): 0 plans computed, 1 computed plans thrown away (stale flags, or started from a wrong

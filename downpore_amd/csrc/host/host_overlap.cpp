@@ -855,9 +855,14 @@ void TextJobBuffers::takeText(std::string& s) {
 void TextJobBuffers::giveTexts(std::vector<std::string>& v) {
     if (!txtOn()) return;
     std::lock_guard<std::mutex> lk(g_txt_mu);
-    // capped by bytes (256 MB: the text of a config-2 job is 235 MB), not by entries: a long-lived embedder keeps at most that
-    // much until dph_release_caches()
-    static constexpr size_t CAP_BYTES = (size_t)256 << 20;
+    // capped by bytes, not by entries: a long-lived embedder keeps at most that much until dph_release_caches().  512 MB: the text
+    // of a config-2 job is 235 MB in 599 strings whose capacities add up to a little more - with a cap of 256 MB a tenth of the
+    // rounds of every job allocated (and page-faulted) fresh strings on the committing thread, which a 20-job run showed as 0.15 ->
+    // 0.18 ms per round (DPH_TEXT_POOL_MB: another cap)
+    static const size_t CAP_BYTES = [] {
+        const char* e = getenv("DPH_TEXT_POOL_MB");
+        return (size_t)(e ? std::max(1, atoi(e)) : 512) << 20;
+    }();
     for (std::string& s : v)
         if (s.capacity() >= 65536 && g_txt_bytes + s.capacity() <= CAP_BYTES) {
             g_txt_bytes += s.capacity();

@@ -150,7 +150,7 @@ DPH_API void dph_profile_print(void);
    -1 for any other index */
 DPH_API int64_t dph_planner_counter(int which);
 /* The library keeps some host buffers between jobs (process-wide, shared by all handles, surviving dph_overlap_destroy): PAF text
- * strings and record arrays of finished rounds (at most 256 MB), window-cache chunks (at most 16 x 11.5 MB), the staging block of
+ * strings and record arrays of finished rounds (at most 512 MB), window-cache chunks (at most 16 x 11.5 MB), the staging block of
  * the last `map` command (reference + reads, ~400 MB at BASELINE config 3).  A long-lived embedder calls this after its last job
  * (or whenever it wants the memory back; a running job simply allocates again).  Returns the bytes released. */
 DPH_API int64_t dph_release_caches(void);

@@ -21,7 +21,9 @@ pytestmark = pytest.mark.gpu
 
 OVERLAP_FLAGS = [dict(overlap_size=500), dict(overlap_size=2000), dict(num_seeds=10), dict(num_seeds=30), dict(chunk_size=5000),
                  dict(chunk_size=20000), dict(min_hits=0.1), dict(min_hits=0.4), dict(query_batch_size=50),
-                 dict(num_seeds=30, min_hits=0.4, overlap_size=2000), dict(num_seeds=10, chunk_size=5000, overlap_size=500)]
+                 dict(num_seeds=30, min_hits=0.4, overlap_size=2000), dict(num_seeds=10, chunk_size=5000, overlap_size=500),
+                 # what `downpore correct` asks of the same Overlapper: QueryAll windows with minSeeds = 10 (commands/correct.go:95-97,169)
+                 dict(num_seeds=10, query_type=4)]
 INPUTS = {10: (110, 100000, 400, 5000, 0.01, True, 8), 13: (113, 1500000, 3000, 10000, 0.0, True, 5)}
 
 

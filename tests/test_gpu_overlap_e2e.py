@@ -783,6 +783,25 @@ def test_kmer_index_built_in_shares_and_all_gathered(monkeypatch, world, k, env)
     ref.close()
 
 
+def test_index_share_gather_through_a_real_rccl_communicator(monkeypatch):
+    """DP_KINDEX_SHARD=force: the share / gather path with a communicator of ONE rank made by ncclCommInitRank - the only way a one-GPU
+    box can put the RCCL flavour of dp_comm_allgather_ranges (grouped ncclBroadcasts between device buffers, out of place for the
+    entries, in place for offsets and counts) and of dp_gather_blobs through a real librccl.  Whole job, PAF against the oracle."""
+    from downpore_amd.overlap import OverlapPipeline, Reads
+    monkeypatch.setenv("DP_SCAN_INDEX", "1")
+    monkeypatch.setenv("DP_KINDEX_SHARD", "force")
+    bases, off = O.gen_reads(33, 60000, 700, 1500, 0.0, True)
+    rs = O.ReadSet(bases, off, min_len=1000)
+    want = O.OverlapRun(rs, k=10, seed_batch_size=1500)
+    r1 = Reads(bases, off, min_len=1000)
+    p1 = OverlapPipeline(r1, k=10, seed_batch_size=1500, rank=0, world=1, mode="round", comm="rccl", slots=2)
+    p1.text_root(0)
+    p1.run()
+    assert first_diff(p1.all_paf(), want.paf) is None
+    assert p1.stats_total()["idx_rounds"] > 0
+    p1.close()
+
+
 def test_round_parallel_job_on_an_index_built_in_shares():
     """The whole round-parallel job (three in-process ranks x two slots, reads that flag reads) with the k-mer position index built in
     shares and all-gathered before the first round: dph_overlap_init is then collective.  Rank 0 prints the oracle's PAF."""
