@@ -2,12 +2,12 @@
 //
 // mapping.Mapper.Map is adaptive per read (ends -> one/two steps in -> binary split search), every step being a
 // performMapping of one window.  To batch windows of MANY reads into each GPU call while keeping Map()'s control flow
-// written exactly as the reference's sequential code, each read's Map() runs as a stackful coroutine (ucontext):
+// written exactly as the reference's sequential code, each read's Map() runs as a stackful coroutine (a 20-instruction context
+// switch of its own - round 5: glibc's swapcontext saves and restores the signal mask with a system call per switch, 300 k of them
+// per config-3 run):
 // performMapping() files a window request and yields; when every live coroutine is waiting, the scheduler scans all
 // requested windows (dp_scan), runs the candidate/chaining stage (dp_map_windows) and resumes the coroutines with
 // their chains.  Results are emitted in read order (the canonical single-worker order).
-#include <ucontext.h>
-
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -15,6 +15,33 @@
 #include <chrono>
 
 #include "dph.hpp"
+
+// Switches stacks: the callee-saved registers of the System V x86-64 ABI go to the current stack, its top to *save_sp, and the
+// same registers come back from the stack `load_sp` points at.  A fresh coroutine's stack is laid out by coroStart() so that the
+// first switch to it "returns" into coroTrampoline.
+extern "C" void dph_coro_switch(void** save_sp, void* load_sp);
+__asm__(
+    ".text\n"
+    ".globl dph_coro_switch\n"
+    ".hidden dph_coro_switch\n"
+    ".type dph_coro_switch,@function\n"
+    "dph_coro_switch:\n"
+    "    pushq %rbp\n"
+    "    pushq %rbx\n"
+    "    pushq %r12\n"
+    "    pushq %r13\n"
+    "    pushq %r14\n"
+    "    pushq %r15\n"
+    "    movq %rsp, (%rdi)\n"
+    "    movq %rsi, %rsp\n"
+    "    popq %r15\n"
+    "    popq %r14\n"
+    "    popq %r13\n"
+    "    popq %r12\n"
+    "    popq %rbx\n"
+    "    popq %rbp\n"
+    "    ret\n"
+    ".size dph_coro_switch,.-dph_coro_switch\n");
 
 namespace dph {
 
@@ -88,7 +115,7 @@ struct MapperImpl {
 };
 
 struct Task {
-    ucontext_t uc;
+    void* sp = nullptr;     // the coroutine's saved stack pointer while it is switched out
     char* stack = nullptr;  // from the scheduler's stack pool (uninitialised memory, reused by later reads)
     uint32_t read = 0;
     i64 L = 0;
@@ -105,15 +132,28 @@ struct Task {
 };
 
 struct Sched {
-    ucontext_t main;
-    Task* cur = nullptr;
+    void* main = nullptr;  // the scheduler's saved stack pointer while a coroutine runs
+    Task* cur = nullptr;   // the coroutine being started (coroTrampoline picks it up)
 };
 
-void taskEntry(unsigned lo, unsigned hi) {
-    Task* t = (Task*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+thread_local Sched* g_coroSched = nullptr;
+// first frame of every coroutine: reached by dph_coro_switch's `ret`, never returns (the last switch leaves it for good)
+void coroTrampoline() {
+    Task* t = g_coroSched->cur;
     t->results = t->m->map(*t);
     t->done = true;
-    swapcontext(&t->uc, &t->m->sched->main);
+    dph_coro_switch(&t->sp, t->m->sched->main);
+    __builtin_trap();
+}
+// lays a fresh stack out as dph_coro_switch leaves one: six zeroed callee-saved registers, then the address `ret` jumps to; at
+// that `ret` the stack pointer is 16-byte aligned + 8, as at any function's first instruction
+void coroStart(Task& t, size_t stackBytes) {
+    uintptr_t top = ((uintptr_t)t.stack + stackBytes) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                  // (the slot a return address of the trampoline's caller would take: keeps the alignment)
+    *--sp = (void*)&coroTrampoline;   // popped by `ret`
+    for (int i = 0; i < 6; i++) *--sp = nullptr;
+    t.sp = (void*)sp;
 }
 
 // ---- mapping.go:131-160
@@ -426,7 +466,7 @@ std::vector<Mapping*> MapperImpl::performMapping(Task& t, i64 a, i64 b, bool who
     t.req.b = b;
     t.req.whole = whole;
     t.waiting = true;
-    swapcontext(&t.uc, &sched->main);  // yield until the batch has been processed
+    dph_coro_switch(&t.sp, sched->main);  // yield until the batch has been processed
     t.waiting = false;
     const WindowResult& R = t.res;
     const i64 qlen = b - a;
@@ -920,14 +960,11 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             }
             t->stack = freeStacks.back();
             freeStacks.pop_back();
-            getcontext(&t->uc);
-            t->uc.uc_stack.ss_sp = t->stack;
-            t->uc.uc_stack.ss_size = stackBytes;
-            t->uc.uc_link = &sched.main;
-            uintptr_t ptr = (uintptr_t)t.get();
-            makecontext(&t->uc, (void (*)())taskEntry, 2, (unsigned)(ptr & 0xffffffffu), (unsigned)(ptr >> 32));
+            coroStart(*t, stackBytes);
             nextRead++;
-            swapcontext(&sched.main, &t->uc);  // run until the first window request (or completion)
+            sched.cur = t.get();
+            g_coroSched = &sched;
+            dph_coro_switch(&sched.main, t->sp);  // run until the first window request (or completion)
             live.push_back(std::move(t));
         }
         // retire finished tasks
@@ -1064,7 +1101,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         if (stats) stats->n_batches++;
         tq = wallNow();
         // ---- ... distribute and resume
-        for (auto& tk : live) swapcontext(&sched.main, &tk->uc);
+        for (auto& tk : live) dph_coro_switch(&sched.main, tk->sp);
         lap(4);  // coroutines resumed: performMapping's tail + the mapper's control flow up to the next window
     }
     if (prof)
