@@ -979,8 +979,10 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     {
         const char* dt = getenv("DP_DEFER_TEXT");  // 0: the executor slots format their rounds' text themselves
         textPool.reset();
-        // formatter threads (DPH_TEXT_THREADS): a round's text is ~0.3 ms of one thread, so two of them cap a run at ~6.5 rounds per ms
-        int nText = 2;
+        // formatter threads (DPH_TEXT_THREADS): a round's text is ~0.26 ms of one thread, so two of them cap a run at 7.7 rounds per ms -
+        // which is where the rounds arrived in round 5 (0.135 ms each): three where the host has the threads for it (commit's wait for
+        // its round's text 46 -> 40 ms per job, 0.141 - 0.152 -> 0.133 - 0.141 ms per round; four and six: the same as three)
+        int nText = hostThreads() >= 12 ? 3 : 2;
         if (const char* te = getenv("DPH_TEXT_THREADS")) nText = std::max(1, std::min(16, atoi(te)));
         if (!(dt && dt[0] == '0')) textPool.reset(new TextPool(nText));
     }
