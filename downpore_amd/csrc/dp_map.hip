@@ -382,7 +382,15 @@ __device__ __forceinline__ int m_seed_offset_from_end(const int32_t* seg, int n,
     return o;
 }
 
-// cursor: [0] records, [1] ints, [2] error bits, [3] overflow flag
+// A 16-bit word that ANOTHER lane of this wave has just stored (lane 0 keeps dynamicMatch's chains in the wave's pool): through the L2 -
+// a plain load may be served from a stale line of the CU's vector L1
+__device__ __forceinline__ uint32_t m_ld16_agent(const uint16_t* p) {
+    const uintptr_t a = (uintptr_t)p;
+    const uint32_t w = __hip_atomic_load((const uint32_t*)(a & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (a & 2) ? (w >> 16) : (w & 0xffffu);
+}
+
+// cursor: [0] records, [1] ints, [2] error bits, [3] overflow flag, [8..9] algorithmic bytes
 __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __restrict__ wsegs, const u64* __restrict__ woff,
                                                            const uint32_t* __restrict__ wlen, uint32_t n_pairs,
                                                            const u64* __restrict__ wsets, const uint32_t* __restrict__ qmeta,
@@ -393,14 +401,13 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                                                            MapRec* __restrict__ recs, uint32_t rec_cap, int32_t* __restrict__ ma,
                                                            int32_t* __restrict__ mb, uint32_t int_cap, uint32_t* __restrict__ cursor,
                                                            int phase, int32_t* __restrict__ thr_io, int one_lane,
-                                                           const u64* __restrict__ words_read) {
+                                                           const u64* __restrict__ words_read, unsigned long long* __restrict__ prof) {
     // phase 2: both strands of every window pair, thresholds from the windows themselves (the whole index is here).
     // phase 0 / 1 (the index is one shard of the reference, dp_map_windows_shard): only the forward / only the reverse-complement
     // windows, starting from the thresholds the previous shard left in thr_io[pair][2] (< 0: none yet) and leaving its own there.
     __shared__ MWave sh[M_WAVES];
     MWave& L = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
-    const uint32_t waves = gridDim.x * M_WAVES;
     const uint32_t gw = blockIdx.x * M_WAVES + (threadIdx.x >> 6);
     MChainPool P;
     P.a = poolA + (size_t)gw * M_CHAINS * M_QMAX;
@@ -409,6 +416,24 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
     // algorithmic bytes of this wave's windows: posting words the index query gathered for them, 2 x 8 x SW per
     // prefiltered candidate + 4 per candidate out, 8 per seed of both sides of every pair that is chained, 8 per chain link out
     unsigned long long algb = 0;
+    // profiling build (make PROF=1, DP_MAP_PROF=1 prints them): ticks of 10 ns per phase, summed per wave, added to cursor[16 ..] at the end
+#ifdef DP_PROF_BUILD
+    unsigned long long mp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mlast = wall_clock64();
+    const unsigned long long mstart = mlast;
+#define MP_TICK(i_)                                                  \
+    {                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  \
+        const unsigned long long n_ = wall_clock64();                \
+        mp[i_] += n_ - mlast;                                        \
+        mlast = n_;                                                  \
+    }
+#else
+#define MP_TICK(i_)
+#endif
+    // (pairs dealt out by wave number.  A ticket - one returning atomic per pair on one word - was tried in round 5 to shorten the
+    // launch's slowest wave, 305 us against a mean of 185: 4 096 same-address atomics per launch cost every pair 7 us and the slowest wave
+    // got longer)
+    const uint32_t waves = gridDim.x * M_WAVES;
     for (uint32_t pair = gw; pair < n_pairs; pair += waves) {
         // performMapping :494-501
         int thr[2];
@@ -438,6 +463,7 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                     for (uint32_t x = lane; x < SW; x += 64) c += __popcll(tset[x] & qset[x]);
                     c = wave_sum(c);
                     algb += 16ull * SW + 4ull;
+                    MP_TICK(0)  // candidate word walk + prefilter (two set rows per candidate)
                     if (c < thr[s]) continue;  // CountIntersectionTo(seedSet, min) < min (:521, :560)
                     const dp_seq_ref r = refs[t];
                     const int32_t* tSeg = segs + r.seg_off;
@@ -448,14 +474,66 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                     // Match (:361-394): s = seq.Reduced(querySet), q = query.Reduced(seqSet) - on all 64 lanes
                     const int minMatch = thr[s];
                     const int nT = m_reduce_wave<uint16_t>(tSeg, tN, qset, k, minMatch, L.t, L.tIdx, M_TMAX, &err);
+                    MP_TICK(1)  // Reduced() of the target chunk
                     const int nQ = nT < 0 ? -1 : m_reduce_wave<uint16_t>(qSeg, qN, tset, k, minMatch, L.q, L.qIdx, M_QMAX, &err);
+                    MP_TICK(2)  // Reduced() of the query window
                     // dynamicMatch: the probes on 64 lanes, the walk's decisions on lane 0 (DP_MAP_ONE_LANE=1: all of it on lane 0 as
                     // before round 4)
                     int nGoodW = 0;
                     if (nT >= 0 && nQ >= 0 && !one_lane) nGoodW = m_dynamic_match_wave(L, 2 * nQ + 1, 2 * nT + 1, minMatch, k, P, chainLen, &err);
-                    if (lane == 0) {
+                    MP_TICK(3)  // dynamicMatch + extendChain
+                    if (!one_lane) {
+                        // records and chains out - by the whole wave (round 5: on lane 0 alone this was 42 us of a wave's 185: the two seed
+                        // offsets of the flank test are sums over the query's gaps - up to a hundred dependent global loads each - and the
+                        // chain went out element by element)
+                        const int nsQ = qN >> 1;
+                        // (lane 0 wrote the chains: its stores are made visible at the L2, the other lanes read them there)
+                        // (a workgroup-scope fence: the stores have left the wave - an agent-scope release fence here writes the L2 back and made
+                        // every phase of every wave 1.4 x as long)
+                        if (nGoodW > 0) __threadfence_block();
+                        for (int g = 0; g < nGoodW; g++) {
+                            const int ch = L.good[g];
+                            const int len = (int)m_ld16_agent(&chainLen[ch]);
+                            const uint16_t* ca = P.A(ch);
+                            const uint16_t* cb = P.B(ch);
+                            const int a0 = L.qIdx[m_ld16_agent(&ca[0])], aL = L.qIdx[m_ld16_agent(&ca[len - 1])];
+                            // GetSeedOffset(a0) = seg[0] + sum_{j=1..a0} (seg[2j] + k); GetSeedOffsetFromEnd(aL) = seg[n-1] + sum_{j=aL+1..ns-1} (seg[2j] + k)
+                            int so = 0, se = 0;
+                            for (int j = 1 + lane; j <= a0; j += 64) so += qSeg[2 * j] + k;
+                            for (int j = aL + 1 + lane; j <= nsQ - 1; j += 64) se += qSeg[2 * j] + k;
+                            const int qOffset = qSeg[0] + wave_sum(so);
+                            const int qInset = qSeg[qN - 1] + wave_sum(se);
+                            // qOffset+qInset > (Len*2)/3 -> skipped, and does not ratchet (:536-538, 576-578)
+                            if (qOffset + qInset > (qLen * 2) / 3) continue;
+                            uint32_t ri = 0, off = 0;
+                            if (lane == 0) {
+                                ri = atomicAdd(&cursor[0], 1u);
+                                off = atomicAdd(&cursor[1], (uint32_t)len);
+                            }
+                            ri = (uint32_t)__shfl((int)ri, 0, 64);
+                            off = (uint32_t)__shfl((int)off, 0, 64);
+                            if (ri < rec_cap && off + (uint32_t)len <= int_cap) {
+                                if (lane == 0) {
+                                    MapRec rec = {w, t, off, (uint32_t)len, seq};
+                                    recs[ri] = rec;
+                                }
+                                for (int x = lane; x < len; x += 64) {
+                                    ma[off + x] = L.qIdx[m_ld16_agent(&ca[x])];
+                                    mb[off + x] = L.tIdx[m_ld16_agent(&cb[x])];
+                                }
+                            } else if (lane == 0) {
+                                cursor[3] = 1;
+                            }
+                            seq++;
+                            algb += 8ull * (unsigned long long)len;
+                            const int limit = (len * 4) / 5;
+                            if (limit > thrS) thrS = limit;
+                            if (s == 0 && limit > thrOther) thrOther = limit;  // forward also raises minRCMatches (:547-549)
+                        }
+                        if (lane == 0 && err) atomicOr(&cursor[2], err);
+                    } else if (lane == 0) {
                         if (nT >= 0 && nQ >= 0) {
-                            const int nGood = one_lane ? m_dynamic_match(L, 2 * nQ + 1, 2 * nT + 1, minMatch, k, P, chainLen, &err) : nGoodW;
+                            const int nGood = m_dynamic_match(L, 2 * nQ + 1, 2 * nT + 1, minMatch, k, P, chainLen, &err);
                             for (int g = 0; g < nGood; g++) {
                                 const int ch = L.good[g];
                                 const int len = chainLen[ch];
@@ -490,6 +568,10 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                     thr[s] = __shfl(thrS, 0, 64);
                     thr[1 - s] = __shfl(thrOther, 0, 64);
                     seq = (uint32_t)__shfl((int)seq, 0, 64);
+                    MP_TICK(4)  // flank test, records and chains out (lane 0)
+#ifdef DP_PROF_BUILD
+                    mp[6]++;
+#endif
                 }
             }
         }
@@ -499,6 +581,16 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
         }
     }
     if (lane == 0 && algb) atomicAdd((unsigned long long*)(cursor + 8), algb);  // (the chain links were counted on lane 0 only)
+#ifdef DP_PROF_BUILD
+    if (lane == 0 && prof) {
+        MP_TICK(5)  // whatever is left: thresholds, skipped windows
+        for (int i = 0; i < 7; i++) atomicAdd(&prof[i], mp[i]);
+        atomicAdd(&prof[7], 1ull);                    // waves
+        atomicMax(&prof[8], wall_clock64() - mstart);  // the launch's slowest wave
+        atomicAdd(&prof[9], wall_clock64() - mstart);
+    }
+#endif
+#undef MP_TICK
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -690,6 +782,15 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
     uint32_t int_cap = std::max<uint32_t>(1u << 21, (uint32_t)(ctx->d_ma.cap / 4));
     uint32_t cur[16];
     float total_ms = 0;
+    // profiling build + DP_MAP_PROF=1: per-phase sums of the launch's waves (map_kernel's MP_TICK), printed per call
+    unsigned long long* d_mprof = nullptr;
+#ifdef DP_PROF_BUILD
+    static const bool map_prof = getenv("DP_MAP_PROF") != nullptr;
+    if (map_prof) {
+        if (dev_reserve(ctx, ctx->d_sb, 16 * 8 + 64)) return DP_ERR_HIP;
+        d_mprof = (unsigned long long*)ctx->d_sb.p;
+    }
+#endif
     const char* ole = getenv("DP_MAP_ONE_LANE");  // (read per call: tests switch it between jobs of one process)
     const int one_lane = ole && ole[0] == '1' ? 1 : 0;
     for (;;) {
@@ -697,13 +798,14 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
         if (dev_reserve(ctx, ctx->d_ma, (size_t)int_cap * 4)) return DP_ERR_HIP;
         if (dev_reserve(ctx, ctx->d_mb, (size_t)int_cap * 4)) return DP_ERR_HIP;
         DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 64, ctx->stream));
+        if (d_mprof) DP_HIP(hipMemsetAsync(d_mprof, 0, 16 * 8, ctx->stream));
         DP_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
         hipLaunchKernelGGL(map_kernel, dim3(blocks), dim3(64 * M_WAVES), 0, ctx->stream, ctx->qsegs_dev,
                            ctx->qoff_dev, (const uint32_t*)ctx->d_sched.p, n_pairs, (const u64*)ctx->d_qsets.p,
                            (const uint32_t*)d_qmeta, (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p,
                            (const int32_t*)ctx->d_segs.p, (const u64*)ctx->d_seedsets.p, W, SW, k, poolA, poolB, poolLen,
                            (MapRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p, int_cap,
-                           (uint32_t*)ctx->d_cursor.p, phase, d_thr, one_lane, (const u64*)d_words);
+                           (uint32_t*)ctx->d_cursor.p, phase, d_thr, one_lane, (const u64*)d_words, d_mprof);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         DP_HIP(hipMemcpyAsync(cur, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -721,6 +823,16 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
     float qms = 0;
     hipEventElapsedTime(&qms, ctx->ev[4], ctx->ev[5]);
     out->kernel_ms = (double)total_ms + (double)qms;
+    if (d_mprof) {
+        unsigned long long h[16];
+        if (hipMemcpy(h, d_mprof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[7]) {
+            const double w = (double)h[7];
+            fprintf(stderr, "[map prof] %u window pairs on %llu waves, kernel %.1f us, slowest wave %.1f us, mean wave %.1f us | us per wave: prefilter %.1f reduce target %.1f "
+                            "reduce query %.1f dynamicMatch %.1f out %.1f rest %.1f | candidates chained per wave %.1f\n",
+                    n_pairs, h[7], 1e3 * total_ms, h[8] / 100.0, h[9] / 100.0 / w, h[0] / 100.0 / w, h[1] / 100.0 / w, h[2] / 100.0 / w, h[3] / 100.0 / w,
+                    h[4] / 100.0 / w, h[5] / 100.0 / w, (double)h[6] / w);
+        }
+    }
     {
         unsigned long long ab = 0;
         memcpy(&ab, &cur[8], 8);
