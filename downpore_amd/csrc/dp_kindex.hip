@@ -1006,17 +1006,21 @@ struct kidx_bin_fill {
 #endif
 struct kidx_offsets {
     enum { THREADS = KX_TILE };
-    static __device__ void run(const dp_scan_item* __restrict__ items, const uint32_t* __restrict__ counts,
+    // B.rec != null (round 5, bins of at most a tile's 4 096 reads): the tile counts the records of its own bins in LDS first - what
+    // kidx_bin_count does in a launch of its own (every launch of a round costs a five-slot round 1.5 - 1.9 us whatever it does:
+    // profiles/r05/ab_extra_launches_five_slots.txt) - and stores the counts it then scans
+    static __device__ void run(const dp_scan_item* __restrict__ items, uint32_t* __restrict__ counts,
                                                        uint32_t n, unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket,
                                                        uint64_t* __restrict__ segoff, uint32_t* __restrict__ s_item,
                                                        uint32_t* __restrict__ s_count, uint64_t* __restrict__ s_off,
                                                        uint4* __restrict__ s_pack, uint64_t* __restrict__ totals,
                                                        uint32_t n_read_items, uint32_t* __restrict__ max_count,
                                                        const unsigned long long* __restrict__ n_hits,
-                                                       unsigned long long* __restrict__ host_totals) {
+                                                       unsigned long long* __restrict__ host_totals, const KxBins B, uint32_t lo) {
     __shared__ uint32_t shA[16], shB[16];
     __shared__ uint32_t tile_s;
     __shared__ unsigned long long excl_s;
+    __shared__ uint32_t tcnt[KX_TILE * KX_IPT];
     // (a launch shared with other rounds has the largest round's grid: blocks beyond this round's own tiles take no ticket)
     if (blockIdx.x >= (n + KX_TILE * KX_IPT - 1) / (KX_TILE * KX_IPT)) return;
     if (threadIdx.x == 0) tile_s = atomicAdd(ticket, 1u);  // tiles start in ticket order: a predecessor is always running or done
@@ -1028,11 +1032,41 @@ struct kidx_offsets {
     // (every item's two loads are asked for before the first is looked at: inside an `if (i < n)` each item was a trip to memory of its
     // own - a microsecond per item and thread, which is what made 8 and 16 items per thread slower than 4)
     uint32_t msv[KX_IPT];
+    if (B.rec) {
+        const uint32_t t0 = tile * (KX_TILE * KX_IPT);  // first item of the tile = first read of its first bin
+        for (uint32_t i = threadIdx.x; i < KX_TILE * KX_IPT; i += THREADS) tcnt[i] = 0u;
+        __syncthreads();
+        const uint32_t b0 = t0 >> B.bshift, nb = (KX_TILE * KX_IPT) >> B.bshift;
+        for (uint32_t b = b0; b < b0 + nb && b < B.n_bins; b++) {
+            const uint32_t nrec = min(B.cursor[b], B.cap), base = (b - b0) << B.bshift;
+            const unsigned long long* rec = B.rec + (size_t)b * B.cap;
+            for (uint32_t jb = 4u * threadIdx.x; jb < nrec; jb += 4u * THREADS) {  // (four consecutive records per thread and trip)
+                unsigned long long e[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) e[u] = jb + (uint32_t)u < nrec ? rec[jb + u] : ~0ull;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (e[u] != ~0ull) atomicAdd(&tcnt[base + (uint32_t)(e[u] >> (KXB_SEED_BITS + 24))], 1u);
+            }
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int u = 0; u < KX_IPT; u++) {
         const uint32_t i = min(i0 + (uint32_t)u, n - 1u);
         cc[u] = counts[i];
         msv[u] = items[i].min_seeds;
+    }
+    if (B.rec) {
+        // (a read item's count = its bin's records + what a full bin counted the old way; a read ignored by now counts nothing)
+#pragma unroll
+        for (int u = 0; u < KX_IPT; u++) {
+            const uint32_t i = i0 + (uint32_t)u;
+            if (i < n_read_items) {
+                cc[u] = (B.ign && B.ign[lo + i]) ? 0u : cc[u] + tcnt[threadIdx.x * KX_IPT + u];
+                counts[i] = cc[u];
+            }
+        }
     }
 #pragma unroll
     for (int u = 0; u < KX_IPT; u++) {
@@ -1139,6 +1173,95 @@ struct kidx_offsets {
 }
 };
 
+// One survivor's slice: c unordered (position, seed) pairs at segs[out ..] -> sorted by position -> [gap, seed, ..., gap] in place (and in the
+// host mirror for an extra item).  Executed by ONE wave with `keys` (CAP words of LDS) to itself.  WG1: the wave is the whole workgroup
+// (kidx_sortwrite: its barriers are workgroup barriers, its loads plain); otherwise it is one wave of a larger workgroup whose other
+// waves have just stored the pairs (kidx_bin_fill_sort: wave-level ordering, loads through the L2 - a neighbour workgroup on the same CU
+// may have pulled a shared line into the vector L1 before the pairs were written).
+template <int CAP, bool WG1>
+__device__ __forceinline__ void kx_sort_one(unsigned long long* keys, const int lane, const uint32_t it, const uint32_t c, const uint64_t out,
+                                            const int nk, int32_t* __restrict__ segs, const int k, uint32_t* __restrict__ overflow,
+                                            const uint32_t n_read_items, int32_t* __restrict__ host_segs) {
+#define KX_SYNC()                                 \
+    {                                             \
+        if (WG1) __syncthreads();                 \
+        else __builtin_amdgcn_wave_barrier();     \
+    }
+#define KX_LD(p_) (WG1 ? (uint32_t)*(p_) : (uint32_t)__hip_atomic_load((p_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        KX_SYNC();
+        if (c <= 64) {
+            unsigned long long key = ~0ull;
+            if ((uint32_t)lane < c) key = ((unsigned long long)KX_LD(&segs[out + 2 * (uint64_t)lane]) << 32) | KX_LD(&segs[out + 2 * (uint64_t)lane + 1]);
+            int rank = 0;
+            for (uint32_t l = 0; l < c; l++) {
+                const unsigned long long o = __shfl(key, (int)l, 64);
+                rank += o < key ? 1 : 0;
+            }
+            // positions are distinct (one k-mer per position), so the ranks are a permutation
+            KX_SYNC();
+            if ((uint32_t)lane < c) keys[rank] = key;
+            KX_SYNC();
+        } else if (c <= (uint32_t)CAP / 2) {
+            // rank sort through LDS: every key counts the keys below it (c^2 / 64 broadcast reads per lane; c is a read's hit
+            // count, a few hundred in the dense-seed regime) - no barriers, no index arithmetic
+            unsigned long long* raw = keys + CAP / 2;  // unsorted copy in the upper half
+            for (uint32_t j = lane; j < c; j += 64)
+                raw[j] = ((unsigned long long)KX_LD(&segs[out + 2 * (uint64_t)j]) << 32) | KX_LD(&segs[out + 2 * (uint64_t)j + 1]);
+            KX_SYNC();
+            for (uint32_t j = lane; j < c; j += 64) {
+                const unsigned long long key = raw[j];
+                uint32_t rank = 0, l = 0;
+                for (; l + 4 <= c; l += 4)
+                    rank += (raw[l] < key ? 1u : 0u) + (raw[l + 1] < key ? 1u : 0u) + (raw[l + 2] < key ? 1u : 0u) + (raw[l + 3] < key ? 1u : 0u);
+                for (; l < c; l++) rank += raw[l] < key ? 1u : 0u;
+                keys[rank] = key;
+            }
+            KX_SYNC();
+        } else if (c <= (uint32_t)CAP) {
+            // more keys than half the block's LDS: bitonic network in place, padded with ~0 up to a power of two (<= CAP)
+            uint32_t m = 128;
+            while (m < c) m <<= 1;
+            for (uint32_t j = lane; j < m; j += 64)
+                keys[j] = j < c ? ((unsigned long long)KX_LD(&segs[out + 2 * (uint64_t)j]) << 32) | KX_LD(&segs[out + 2 * (uint64_t)j + 1]) : ~0ull;
+            KX_SYNC();
+            for (uint32_t size = 2; size <= m; size <<= 1) {
+                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (uint32_t t = lane; t < m / 2; t += 64) {
+                        const uint32_t i = ((t / stride) * 2 * stride) + (t % stride);
+                        const bool up = (i & size) == 0;
+                        const unsigned long long a = keys[i], b = keys[i + stride];
+                        if ((a > b) == up) {
+                            keys[i] = b;
+                            keys[i + stride] = a;
+                        }
+                    }
+                    KX_SYNC();
+                }
+            }
+        } else {
+            if (lane == 0) atomicExch(overflow, 1u);
+            return;
+        }
+        const bool mirror = host_segs != nullptr && it >= n_read_items;
+        for (uint32_t j = lane; j < c; j += 64) {
+            const int p = (int)(keys[j] >> 32);
+            const int prev = j ? (int)(keys[j - 1] >> 32) : -k;  // "-k": the first gap is the hit's own index
+            segs[out + 2 * (uint64_t)j] = p - (prev + k);
+            segs[out + 2 * (uint64_t)j + 1] = (int32_t)(uint32_t)keys[j];
+            if (mirror) {
+                host_segs[out + 2 * (uint64_t)j] = p - (prev + k);
+                host_segs[out + 2 * (uint64_t)j + 1] = (int32_t)(uint32_t)keys[j];
+            }
+        }
+        if (lane == 0) {
+            const int last = c ? (int)(keys[c - 1] >> 32) : -k;
+            segs[out + 2 * (uint64_t)c] = nk - last - 1;  // final gap (sequence/asm_amd64.s:387-392)
+            if (mirror) host_segs[out + 2 * (uint64_t)c] = nk - last - 1;
+        }
+#undef KX_SYNC
+#undef KX_LD
+}
+
 // one wave per survivor: its slice holds c unordered (position, seed) pairs -> sorted by position -> [gap, seed, ..., gap]
 #define KX_SORT_LDS 4096
 // CAP = keys the block's LDS holds (the launch picks the smallest that fits the round's largest survivor: a CU then holds
@@ -1164,81 +1287,102 @@ struct kidx_sortwrite {
     const bool gave_up = totals && (totals[0] > seg_cap || (uint32_t)totals[6] != 0u);
     for (uint32_t sv = blockIdx.x; sv < n_sel && !gave_up; sv += gridDim.x) {
         const uint32_t it = sel[sv];
-        const uint32_t c = counts[it];
-        const uint64_t out = segoff[it];
-        const int nk = (int)items[it].n_kmers;
-        __syncthreads();
-        if (c <= 64) {
-            unsigned long long key = ~0ull;
-            if ((uint32_t)lane < c) key = ((unsigned long long)(uint32_t)segs[out + 2 * (uint64_t)lane] << 32) | (uint32_t)segs[out + 2 * (uint64_t)lane + 1];
-            int rank = 0;
-            for (uint32_t l = 0; l < c; l++) {
-                const unsigned long long o = __shfl(key, (int)l, 64);
-                rank += o < key ? 1 : 0;
-            }
-            // positions are distinct (one k-mer per position), so the ranks are a permutation
-            __syncthreads();
-            if ((uint32_t)lane < c) keys[rank] = key;
-            __syncthreads();
-        } else if (c <= (uint32_t)CAP / 2) {
-            // rank sort through LDS: every key counts the keys below it (c^2 / 64 broadcast reads per lane; c is a read's hit
-            // count, a few hundred in the dense-seed regime) - no barriers, no index arithmetic
-            unsigned long long* raw = keys + CAP / 2;  // unsorted copy in the upper half
-            for (uint32_t j = lane; j < c; j += 64)
-                raw[j] = ((unsigned long long)(uint32_t)segs[out + 2 * (uint64_t)j] << 32) | (uint32_t)segs[out + 2 * (uint64_t)j + 1];
-            __syncthreads();
-            for (uint32_t j = lane; j < c; j += 64) {
-                const unsigned long long key = raw[j];
-                uint32_t rank = 0, l = 0;
-                for (; l + 4 <= c; l += 4)
-                    rank += (raw[l] < key ? 1u : 0u) + (raw[l + 1] < key ? 1u : 0u) + (raw[l + 2] < key ? 1u : 0u) + (raw[l + 3] < key ? 1u : 0u);
-                for (; l < c; l++) rank += raw[l] < key ? 1u : 0u;
-                keys[rank] = key;
-            }
-            __syncthreads();
-        } else if (c <= (uint32_t)CAP) {
-            // more keys than half the block's LDS: bitonic network in place, padded with ~0 up to a power of two (<= CAP)
-            uint32_t m = 128;
-            while (m < c) m <<= 1;
-            for (uint32_t j = lane; j < m; j += 64)
-                keys[j] = j < c ? ((unsigned long long)(uint32_t)segs[out + 2 * (uint64_t)j] << 32) | (uint32_t)segs[out + 2 * (uint64_t)j + 1] : ~0ull;
-            __syncthreads();
-            for (uint32_t size = 2; size <= m; size <<= 1) {
-                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (uint32_t t = lane; t < m / 2; t += 64) {
-                        const uint32_t i = ((t / stride) * 2 * stride) + (t % stride);
-                        const bool up = (i & size) == 0;
-                        const unsigned long long a = keys[i], b = keys[i + stride];
-                        if ((a > b) == up) {
-                            keys[i] = b;
-                            keys[i + stride] = a;
-                        }
-                    }
-                    __syncthreads();
-                }
-            }
-        } else {
-            if (lane == 0) atomicExch(overflow, 1u);
-            continue;
-        }
-        const bool mirror = host_segs != nullptr && it >= n_read_items;
-        for (uint32_t j = lane; j < c; j += 64) {
-            const int p = (int)(keys[j] >> 32);
-            const int prev = j ? (int)(keys[j - 1] >> 32) : -k;  // "-k": the first gap is the hit's own index
-            segs[out + 2 * (uint64_t)j] = p - (prev + k);
-            segs[out + 2 * (uint64_t)j + 1] = (int32_t)(uint32_t)keys[j];
-            if (mirror) {
-                host_segs[out + 2 * (uint64_t)j] = p - (prev + k);
-                host_segs[out + 2 * (uint64_t)j + 1] = (int32_t)(uint32_t)keys[j];
-            }
-        }
-        if (lane == 0) {
-            const int last = c ? (int)(keys[c - 1] >> 32) : -k;
-            segs[out + 2 * (uint64_t)c] = nk - last - 1;  // final gap (sequence/asm_amd64.s:387-392)
-            if (mirror) host_segs[out + 2 * (uint64_t)c] = nk - last - 1;
-        }
+        kx_sort_one<CAP, true>(keys, lane, it, counts[it], segoff[it], (int)items[it].n_kmers, segs, k, overflow, n_read_items, host_segs);
     }
 }
+};
+
+// kidx_bin_fill and kidx_sortwrite in one launch (round 5, the sparse regime: bins of 512 reads, survivors of at most CAP hits): a
+// bin's workgroup fills its survivors' slices from the bin's records and then sorts them, a wave per survivor; the workgroup behind
+// the bins does the same for the round's extra items (query windows: list -> slices -> sorted, mirrored to the host, their reads
+// unlinked).  One launch less per round; a workgroup sorts ~30 survivors of ~20 hits on its eight waves.
+template <int RB, int CAP>
+struct kidx_bin_fill_sort {
+    enum { THREADS = 512, WAVES = 8, XW = 32 };  // XW: workgroups that share the round's extra items
+    static __device__ void run(const KxBins B, const dp_scan_item* __restrict__ items, uint32_t n_read_items, uint32_t n_extra,
+                               const uint32_t* __restrict__ counts, uint32_t* __restrict__ fillc, const uint64_t* __restrict__ segoff,
+                               int32_t* __restrict__ segs, const uint64_t* __restrict__ totals, uint64_t seg_cap, int k,
+                               uint32_t* __restrict__ overflow, uint32_t* __restrict__ head, int32_t* __restrict__ host_segs) {
+        __shared__ uint32_t cnt[RB];
+        __shared__ uint16_t slist[RB];
+        __shared__ uint32_t ns_s;
+        __shared__ unsigned long long keys[WAVES][CAP];
+        const int lane = dp_lane(), wave = threadIdx.x >> 6;
+        // blocks n_bins .. n_bins + XW - 1: the extra items, dealt out by item number - each of these workgroups walks the whole list (a few
+        // thousand entries), fills the hits of ITS items and sorts those, so that none of them waits for another (one workgroup for all
+        // 334 windows of a round was the launch's longest by a factor of ten)
+        if (blockIdx.x >= B.n_bins + XW) return;
+        const bool xblock = blockIdx.x >= B.n_bins;
+        const uint32_t xw = xblock ? blockIdx.x - B.n_bins : 0u;
+        if (xblock) {
+            // the walk was the last reader of the extra items' lists: head[] back to all zero (whether the round gave up or not)
+            for (uint32_t e = xw * THREADS + threadIdx.x; e < n_extra; e += XW * THREADS) head[items[n_read_items + e].read] = 0;
+        }
+        if (B.flags[0] || totals[0] > seg_cap) return;  // (the host repeats fill + sort with the bucket walk / a larger buffer)
+        if (xblock) {
+            const uint32_t nx = min(*B.xcursor, B.xcap);
+            for (uint32_t j = threadIdx.x; j < nx; j += THREADS) {
+                const uint4 x = B.xrec[j];
+                if ((x.x - n_read_items) % XW != xw) continue;
+                if (counts[x.x] >= items[x.x].min_seeds) {
+                    const uint32_t slot = atomicAdd(&fillc[x.x], 1u);
+                    const uint64_t to = segoff[x.x] + 2ull * slot;
+                    segs[to] = (int32_t)x.y;
+                    segs[to + 1] = (int32_t)x.z;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            for (uint32_t e = xw + XW * (uint32_t)wave; e < n_extra; e += XW * WAVES) {
+                const uint32_t it = n_read_items + e;
+                const dp_scan_item xi = items[it];
+                const uint32_t c = counts[it];
+                if (c >= xi.min_seeds) kx_sort_one<CAP, false>(keys[wave], lane, it, c, segoff[it], (int)xi.n_kmers, segs, k, overflow, n_read_items, host_segs);
+            }
+            return;
+        }
+        const uint32_t bin = blockIdx.x;
+        const uint32_t rb = 1u << B.bshift, first = bin << B.bshift;
+        const uint32_t n = min(B.cursor[bin], B.cap);
+        if (threadIdx.x == 0) ns_s = 0u;
+        for (uint32_t i = threadIdx.x; i < rb; i += THREADS) {
+            const uint32_t it = first + i;
+            bool surv = false;
+            if (it < n_read_items) {
+                const uint32_t c = counts[it];
+                surv = c > 0u && c >= items[it].min_seeds;
+            }
+            cnt[i] = surv ? 0u : 0x80000000u;
+        }
+        __syncthreads();
+        const unsigned long long* rec = B.rec + (size_t)bin * B.cap;
+        for (uint32_t jb = 4u * threadIdx.x; jb < n; jb += 4u * THREADS) {
+            unsigned long long e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[u] = jb + (uint32_t)u < n ? rec[jb + u] : ~0ull;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (e[u] == ~0ull) continue;
+                const uint32_t rib = (uint32_t)(e[u] >> (KXB_SEED_BITS + 24));
+                if (cnt[rib] & 0x80000000u) continue;
+                const uint32_t rank = atomicAdd(&cnt[rib], 1u);
+                const uint64_t to = segoff[first + rib] + 2ull * rank;
+                segs[to] = (int32_t)((uint32_t)e[u] & 0xffffffu);
+                segs[to + 1] = (int32_t)((uint32_t)(e[u] >> 24) & ((1u << KXB_SEED_BITS) - 1u));
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        // the bin's survivors (their slot counters have arrived at their counts), then a wave per survivor
+        for (uint32_t i = threadIdx.x; i < rb; i += THREADS)
+            if (!(cnt[i] & 0x80000000u)) slist[atomicAdd(&ns_s, 1u)] = (uint16_t)i;
+        __syncthreads();
+        const uint32_t ns = ns_s;
+        for (uint32_t sv = wave; sv < ns; sv += WAVES) {
+            const uint32_t i = slist[sv], it = first + i;
+            kx_sort_one<CAP, false>(keys[wave], lane, it, cnt[i], segoff[it], (int)items[it].n_kmers, segs, k, overflow, n_read_items, host_segs);
+        }
+    }
 };
 
 // lanes per seed of kidx_walk: by the mean bucket size of the index (positions / 4^k)
@@ -1258,6 +1402,13 @@ static uint32_t kidx_walk_blocks(const dp_kindex* ix, int k, uint32_t S) {
 __global__ void kx_dummy_kernel(int mode, const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
                                 const KxPos pos, uint32_t* __restrict__ scratch, uint32_t n_scratch, uint32_t n_ops) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode >= 30) {  // (30 + n: n launches of ~300 workgroups that each occupy a CU slot for ~3 us and touch no memory - what PLACING a
+                       // mid-sized kernel beside four other rounds costs)
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < 300ull) {
+        }
+        return;
+    }
     if (mode >= 10) return;  // (10 + n: n empty launches - what a launch costs the other slots' rounds)
     if (mode == 1) {
         const uint32_t s = t >> 4, i0 = t & 15u;
@@ -1391,6 +1542,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         DP_HIP(dp_dev_malloc((void**)&dbg, n_dbg_waves * 64));
         DP_HIP(hipMemsetAsync(dbg, 0, n_dbg_waves * 64, ctx->stream));
     }
+    bool count_in_offsets = false;
     if (S && B.rec) {
         const uint32_t n_waves = kidx_walk_blocks(ix, k, S) * 4;
         static const int bin_waves = getenv("DP_KX_BIN_WAVES") ? atoi(getenv("DP_KX_BIN_WAVES")) : 8;
@@ -1401,7 +1553,11 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         else if (bin_waves <= 8) KX_WALK_BIN(8);
         else KX_WALK_BIN(16);
 #undef KX_WALK_BIN
-        if (B.bshift <= 9)
+        // bins no larger than a tile of kidx_offsets are counted by that kernel (one launch less per round; DP_KX_FUSE=0: as before)
+        static const bool fuse_off = getenv("DP_KX_FUSE") && getenv("DP_KX_FUSE")[0] == '0';
+        count_in_offsets = !fuse_off && (1u << B.bshift) <= KX_TILE * KX_IPT;
+        if (count_in_offsets) {
+        } else if (B.bshift <= 9)
             dp_launch<kidx_bin_count<512>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items, lo);
         else if (B.bshift <= 12)
             dp_launch<kidx_bin_count<4096>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items, lo);
@@ -1433,8 +1589,8 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             static void* scratch = nullptr;  // (diagnosis only: one scratch array per process)
             if (!scratch) DP_HIP(dp_dev_malloc(&scratch, (size_t)n_items * 4 + 64));
             const uint32_t ops = (uint32_t)std::min<uint64_t>(ctx->kx_prev_hits ? ctx->kx_prev_hits : 450000, 1u << 24);
-            const uint32_t thr = dummy >= 10 ? 64u : dummy == 1 ? S * 16 : ops;
-            for (int rep = 0; rep < (dummy >= 10 ? dummy - 10 : 1); rep++)
+            const uint32_t thr = dummy >= 30 ? 300u * 256u : dummy >= 10 ? 64u : dummy == 1 ? S * 16 : ops;
+            for (int rep = 0; rep < (dummy >= 30 ? dummy - 30 : dummy >= 10 ? dummy - 10 : 1); rep++)
                 hipLaunchKernelGGL(kx_dummy_kernel, dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, dummy, dp_seeds_ptr(ctx), S,
                                    (const uint64_t*)ix->off.p, ix->view(), (uint32_t*)scratch, n_items, ops);
         }
@@ -1465,13 +1621,31 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                     nw, (lastStart - first) / 100.0, (lastEnd - first) / 100.0, sum[1] / nw, mx[1], sum[2] / nw, mx[2], sum[3] / nw, mx[3], sum[4] / nw, mx[4]);
     }
     // totals[2] = seed occurrences in the read set, totals[3] = largest survivor count (both written by the kernel)
-    dp_launch<kidx_offsets>(ctx, dim3(n_tiles), dim3(KX_TILE), d_items, (const uint32_t*)d_counts, n_items, status, ticket,
-                       d_segoff, s_item, s_count, s_off, s_pack, d_totals, n_read_items, (uint32_t*)(d_totals + 3),
-                       (const unsigned long long*)n_hits, host_totals);
+    {
+        KxBins Bo = B;
+        if (!count_in_offsets) Bo.rec = nullptr;
+        dp_launch<kidx_offsets>(ctx, dim3(n_tiles), dim3(KX_TILE), d_items, d_counts, n_items, status, ticket,
+                           d_segoff, s_item, s_count, s_off, s_pack, d_totals, n_read_items, (uint32_t*)(d_totals + 3),
+                           (const unsigned long long*)n_hits, host_totals, Bo, lo);
+    }
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 1));
     if (one && R.rec) {
         DP_HIP(dp_mark(ctx, 2));
+        // the sparse regime (bins of 512 reads, survivors of at most 256 hits): fill and sort in one launch - built, measured and left OFF
+        // (DP_KX_FUSE=2 switches it on): alternating 12-job runs gave 0.149 - 0.157 ms per round with neither fusion, 0.136 - 0.156 with the
+        // count inside kidx_offsets alone, 0.157 - 0.179 with this one on top - a bin's workgroup sorts its ~30 survivors four to a wave
+        // behind its fill (loads through the L2), which is longer than the launch it saves
+        static const bool fuse_fill_sort = getenv("DP_KX_FUSE") && getenv("DP_KX_FUSE")[0] == '2';
+        const bool fill_sort = B.rec && fuse_fill_sort && B.bshift <= 9 && one->sort_cap <= 256 && lps == 16 && n_extra <= 8192;
+        if (fill_sort) {
+            dp_launch<kidx_bin_fill_sort<512, 256>>(ctx, dim3(B.n_bins + kidx_bin_fill_sort<512, 256>::XW), dim3(512), B, d_items, n_read_items, n_extra, (const uint32_t*)d_counts, fillc,
+                                                    (const uint64_t*)d_segoff, one->d_segs, (const uint64_t*)d_totals, one->seg_cap, k, (uint32_t*)(d_totals + 4), head,
+                                                    one->host_segs);
+            DP_HIP(hipGetLastError());
+            DP_HIP(dp_mark(ctx, 3));
+            return DP_OK;
+        }
         if (B.rec) {
             const dim3 fg(B.n_bins + kidx_bin_fill<512>::XBLOCKS), fb(512);
             if (B.bshift <= 9)

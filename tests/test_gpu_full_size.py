@@ -124,13 +124,19 @@ def test_config5_one_gpu_share_of_the_reference(monkeypatch, shards):
     from downpore_amd.overlap import Reads
     if shards > 1:
         monkeypatch.setenv("DP_MAP_SHARDS", str(shards))
+    from tools.synth import gen_reads_truth
+    from tools.truth import map_truth
     G, N, L, e, seed, n_cpu = 375000000, 1000, 15000, 0.1, 5, 300
     genome = np.frombuffer(O.gen_genome(seed, G), dtype=np.uint8)
     goff = np.array([0, G], dtype=np.int64)
-    bases, off = O.gen_reads(seed, G, N, L, e, False)
+    bases, off, starts, strands = gen_reads_truth(seed, G, N, L, e, False)  # (the reads of O.gen_reads, with where they came from)
     got, gerr, st = map_reads(Reads(genome, goff, min_len=0, himem=False), Reads(bases, off, min_len=500, himem=False),
                               circular=True, k=13)
     assert st["n_chunks"] > 37000 and st["n_seeds"] > 2000000
+    # every one of the 1 000 reads held to the position the generator took it from (the oracle below covers the first 300 on the host)
+    t = map_truth(got, off, starts, strands, G)
+    print("config-5 share, %d shard(s): %s" % (shards, t))
+    assert t["recall"] >= 0.99 and t["precision"] >= 0.99, t
     want, werr = O.map_run(O.ReadSet(genome, goff, min_len=0, himem=False),
                            O.ReadSet(bases[:off[n_cpu]], off[:n_cpu + 1], min_len=500, himem=False), circular=True, k=13)
     assert want.count("\n") >= n_cpu * 9 // 10
