@@ -353,6 +353,10 @@ void dp_kindex_free(dp_ctx* ctx) {
 //                compacted list, the totals;
 //   kidx_fill    the occurrences of surviving items go, unordered, into the item's own segment slice as (position, seed);
 //   kidx_sortwrite  one wave per survivor sorts its slice by position and turns it into [gap, seed, ..., gap] in place.
+// Since round 5 the default form of the first three is (see "round 5" below): kidx_walk_bin writes every hit as a record into the bin of
+// its read and touches no counter, kidx_offsets' tiles count their own bins' records in LDS before they scan, kidx_bin_fill places the
+// survivors' records with LDS slot counters; the kernels named above remain as DP_KX_BINS=0 and as the fallback of a round whose bins
+// overflowed.
 
 #define KX_PARTS 4  // waves that share one seed's bucket
 
@@ -1264,6 +1268,9 @@ __device__ __forceinline__ void kx_sort_one(unsigned long long* keys, const int 
 
 // one wave per survivor: its slice holds c unordered (position, seed) pairs -> sorted by position -> [gap, seed, ..., gap]
 #define KX_SORT_LDS 4096
+// (round 4's hit records - DP_KX_BINS=0 - keep a hit's rank among its read's hits in 14 bits, read and position in 24 each: the one-go
+// step is only taken while no survivor has more hits than the LDS sort holds and reads / positions stay below 2^24, dp_scan.hip)
+static_assert(KX_SORT_LDS <= (1 << 14), "kx_rec keeps the rank of a hit in 14 bits: the LDS sort's capacity bounds it");
 // CAP = keys the block's LDS holds (the launch picks the smallest that fits the round's largest survivor: a CU then holds
 // eight times as many waves for the usual few dozen hits per read as for the rare thousands)
 template <int CAP>
