@@ -156,6 +156,7 @@ struct dp_ctx {
     const uint64_t* qoff_dev = nullptr;
     DevBuf d_qsegs, d_qoff, d_qsets, d_qmeta, d_cand, d_pool, d_mrec, d_ma, d_mb, d_cursor, d_sched, d_manchor;
     DevBuf d_pbase, d_pspec, d_clist, d_sa, d_sb;  // chaining stage: pair offsets, proposals, candidate lists, scratch columns
+    DevBuf d_qscan;                                // the index query's workgroup counter (QScan, dp_overlap.hip): zero between launches
     uint32_t n_pairs = 0;                          // (query, candidate) pair slots of the last dp_find_overlaps
     uint32_t last_nq = 0, last_ni = 0;             // its queries / packed chain ints
     size_t q_pre_bytes = 0;                        // dp_query_prestage: bytes of the announced query block in h_qup (0: none)
@@ -285,8 +286,9 @@ static inline const void* dp_chain_b(const dp_ctx* ctx) { return ctx->chains_pac
 uint32_t dp_find_pair_cap(const dp_ctx* ctx);
 int dp_find_complete(dp_ctx* ctx, bool* reran);
 void dp_find_stats(const dp_ctx* ctx, double* query_ms, double* chain_ms, uint64_t* query_bytes, uint64_t* chain_bytes);
+struct QScan;
 int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
-                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out = nullptr);
+                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out = nullptr, const struct QScan* scan_in = nullptr);
 
 // ---- device helpers ---------------------------------------------------------------------------------------
 // An entry of the resident k-mer position index (dp_kindex.hip; written by dp_kbuild.hip): fmt 8 = read << 32 | position in a

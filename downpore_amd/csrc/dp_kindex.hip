@@ -1561,7 +1561,8 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         else KX_WALK_BIN(16);
 #undef KX_WALK_BIN
         // bins no larger than a tile of kidx_offsets are counted by that kernel (one launch less per round; DP_KX_FUSE=0: as before)
-        static const bool fuse_off = getenv("DP_KX_FUSE") && getenv("DP_KX_FUSE")[0] == '0';
+        const char* fuse_env = getenv("DP_KX_FUSE");  // (read per call, like DP_KX_BINS: tests switch it between jobs of one process)
+        const bool fuse_off = fuse_env && fuse_env[0] == '0';
         count_in_offsets = !fuse_off && (1u << B.bshift) <= KX_TILE * KX_IPT;
         if (count_in_offsets) {
         } else if (B.bshift <= 9)
@@ -1643,7 +1644,8 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         // (DP_KX_FUSE=2 switches it on): alternating 12-job runs gave 0.149 - 0.157 ms per round with neither fusion, 0.136 - 0.156 with the
         // count inside kidx_offsets alone, 0.157 - 0.179 with this one on top - a bin's workgroup sorts its ~30 survivors four to a wave
         // behind its fill (loads through the L2), which is longer than the launch it saves
-        static const bool fuse_fill_sort = getenv("DP_KX_FUSE") && getenv("DP_KX_FUSE")[0] == '2';
+        const char* fuse2_env = getenv("DP_KX_FUSE");  // (per call, as above)
+        const bool fuse_fill_sort = fuse2_env && fuse2_env[0] == '2';
         const bool fill_sort = B.rec && fuse_fill_sort && B.bshift <= 9 && one->sort_cap <= 256 && lps == 16 && n_extra <= 8192;
         if (fill_sort) {
             dp_launch<kidx_bin_fill_sort<512, 256>>(ctx, dim3(B.n_bins + kidx_bin_fill_sort<512, 256>::XW), dim3(512), B, d_items, n_read_items, n_extra, (const uint32_t*)d_counts, fillc,

@@ -756,7 +756,7 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
         // the reverse pass of a shard follows its forward pass on the same windows: the query stage's results are still there
         d_qmeta = (uint32_t*)ctx->d_qmeta.p;
     } else {
-        rc = dp_query_stage(ctx, w_segs, w_off, nw, 0.25, &d_qmeta, &d_words, &d_mc, &mc_n, &d_qcnt_unused);  // Matches(.., 0.25) :502-503
+        rc = dp_query_stage(ctx, w_segs, w_off, nw, 0.25, &d_qmeta, &d_words, &d_mc, &mc_n, &d_qcnt_unused, nullptr);  // Matches(.., 0.25) :502-503
         if (rc != 0) return rc;
         ctx->map_stage_windows = nw;
         ctx->map_stage_valid = phase == 0;

@@ -684,6 +684,64 @@ extern "C" int dp_index_seedset_row(dp_ctx* ctx, uint32_t seq, u64* words, uint3
 // ---------------------------------------------------------------------------------------------------------------
 // A14 + A5: SeedIndex.Matches -> util.GetSharedIDs
 
+// Round 5: the chaining stage's pair offsets (pair_scan_kernel: one workgroup's exclusive scan of the queries' candidate counts) as the
+// last act of the index query's LAST workgroup instead of a launch of its own - every dependent launch costs a five-slot round
+// 1.5 - 1.9 us.  Every workgroup of the launch counts itself in when it is done (done_ctr, a word that lives with the
+// context and is back at zero when the last workgroup leaves); enable = 0: nobody counts (the map path, and the light variant when the
+// heavy one follows it).
+struct QScan {
+    uint32_t* pbase;
+    u64* ibase;
+    u64* totals;
+    uint32_t* qdone;
+    uint32_t* done_ctr;
+    uint32_t enable;
+};
+// exclusive scans of qcnt[q] (pairs) and qcnt[q] x seeds of query q (scratch ints) by T threads of one workgroup; qcnt was written by
+// the other workgroups' atomics: read through the L2
+template <int T>
+__device__ __forceinline__ void pair_scan_body(const uint32_t* __restrict__ qcnt, const u64* __restrict__ qoff, uint32_t nq,
+                                               uint32_t* __restrict__ pbase, u64* __restrict__ ibase, u64* __restrict__ totals,
+                                               uint32_t* __restrict__ qdone, u64* shp, u64* shi) {
+    for (uint32_t q = threadIdx.x; q < nq; q += T) qdone[q] = 0;
+    const uint32_t per = (nq + T - 1) / T;
+    const uint32_t lo = min(nq, threadIdx.x * per), hi = min(nq, lo + per);
+    unsigned long long sp = 0, si = 0;
+    for (uint32_t q = lo; q < hi; q++) {
+        const uint32_t c = __hip_atomic_load(&qcnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sp += c;
+        si += (unsigned long long)c * ((qoff[q + 1] - qoff[q]) / 2);
+    }
+    shp[threadIdx.x] = sp;
+    shi[threadIdx.x] = si;
+    __syncthreads();
+    for (int d = 1; d < T; d <<= 1) {
+        unsigned long long ap = 0, ai = 0;
+        if ((int)threadIdx.x >= d) {
+            ap = shp[threadIdx.x - d];
+            ai = shi[threadIdx.x - d];
+        }
+        __syncthreads();
+        shp[threadIdx.x] += ap;
+        shi[threadIdx.x] += ai;
+        __syncthreads();
+    }
+    unsigned long long bp = shp[threadIdx.x] - sp, bi = shi[threadIdx.x] - si;
+    for (uint32_t q = lo; q < hi; q++) {
+        const uint32_t c = __hip_atomic_load(&qcnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pbase[q] = (uint32_t)bp;
+        ibase[q] = bi;
+        bp += c;
+        bi += (unsigned long long)c * ((qoff[q + 1] - qoff[q]) / 2);
+    }
+    if (threadIdx.x == T - 1) {
+        pbase[nq] = (uint32_t)shp[T - 1];
+        ibase[nq] = shi[T - 1];
+        totals[0] = shp[T - 1];
+        totals[1] = shi[T - 1];
+    }
+}
+
 #define Q_MAXSETS 512
 #define Q_WAVES 8
 
@@ -782,7 +840,31 @@ __device__ __forceinline__ u64 q_ladder(const QWave& S, const u64* __restrict__ 
 template <bool HEAVY>
 struct query_kernel {
     enum { THREADS = 64 * Q_WAVES };
-    static __device__ void run(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
+    static __device__ void run(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff, uint32_t nq, const u64* __restrict__ posting,
+                               const uint32_t* __restrict__ pmeta, uint32_t n_seqs, uint32_t W, const int32_t* __restrict__ mc, uint32_t mc_n,
+                               u64* __restrict__ cand, uint32_t* __restrict__ qmeta, u64* __restrict__ words_read, uint32_t* __restrict__ qcnt,
+                               uint32_t word_base, const uint32_t* __restrict__ n_seqs_dev, u64* __restrict__ qsets, uint32_t SW,
+                               uint32_t dbg_flags, uint32_t split, u64* __restrict__ own_zero, const QScan scan) {
+        if (blockIdx.x < nq * split)
+            body(qsegs, qoff, nq, posting, pmeta, n_seqs, W, mc, mc_n, cand, qmeta, words_read, qcnt, word_base, n_seqs_dev, qsets, SW, dbg_flags, split, own_zero);
+        if (!scan.enable || blockIdx.x >= nq * split) return;  // (a launch shared with other rounds has the largest round's grid)
+        // the launch's last workgroup scans the queries' candidate counts (QScan above)
+        __shared__ uint32_t last_s;
+        __shared__ u64 shp[THREADS], shi[THREADS];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // (agent-scope release: one L2 write-back per workgroup, 668 a launch - measured 0.149 -> 0.175 ms per five-slot round.  The
+            // cheaper workgroup-scope fence + relaxed counter ran at the unfused speed and LOST parity: the scan saw stale qcnt)
+            __threadfence();
+            last_s = __hip_atomic_fetch_add(scan.done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == nq * split ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!last_s) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        pair_scan_body<THREADS>(qcnt, qoff, nq, scan.pbase, scan.ibase, scan.totals, scan.qdone, shp, shi);
+        if (threadIdx.x == 0) __hip_atomic_store(scan.done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ void body(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
                                                              uint32_t nq, const u64* __restrict__ posting,
                                                              const uint32_t* __restrict__ pmeta, uint32_t n_seqs, uint32_t W,
                                                              const int32_t* __restrict__ mc, uint32_t mc_n,
@@ -2230,41 +2312,7 @@ struct pair_scan_kernel {
                                                           uint32_t* __restrict__ pbase, u64* __restrict__ ibase, u64* __restrict__ totals,
                                                           uint32_t* __restrict__ qdone) {
     __shared__ u64 shp[1024], shi[1024];
-    for (uint32_t q = threadIdx.x; q < nq; q += 1024) qdone[q] = 0;
-    const uint32_t per = (nq + 1023) / 1024;
-    const uint32_t lo = min(nq, threadIdx.x * per), hi = min(nq, lo + per);
-    u64 sp = 0, si = 0;
-    for (uint32_t q = lo; q < hi; q++) {
-        sp += qcnt[q];
-        si += (u64)qcnt[q] * ((qoff[q + 1] - qoff[q]) / 2);
-    }
-    shp[threadIdx.x] = sp;
-    shi[threadIdx.x] = si;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        u64 ap = 0, ai = 0;
-        if ((int)threadIdx.x >= d) {
-            ap = shp[threadIdx.x - d];
-            ai = shi[threadIdx.x - d];
-        }
-        __syncthreads();
-        shp[threadIdx.x] += ap;
-        shi[threadIdx.x] += ai;
-        __syncthreads();
-    }
-    u64 bp = shp[threadIdx.x] - sp, bi = shi[threadIdx.x] - si;
-    for (uint32_t q = lo; q < hi; q++) {
-        pbase[q] = (uint32_t)bp;
-        ibase[q] = bi;
-        bp += qcnt[q];
-        bi += (u64)qcnt[q] * ((qoff[q + 1] - qoff[q]) / 2);
-    }
-    if (threadIdx.x == 1023) {
-        pbase[nq] = (uint32_t)shp[1023];
-        ibase[nq] = shi[1023];
-        totals[0] = shp[1023];
-        totals[1] = shi[1023];
-    }
+    pair_scan_body<1024>(qcnt, qoff, nq, pbase, ibase, totals, qdone, shp, shi);
 }
 };
 
@@ -2903,7 +2951,10 @@ extern "C" int dp_query_prestage(dp_ctx* ctx, const int32_t* q_segs, const uint6
 // Uploads the queries, builds their seed bitsets and runs the index query (Matches -> GetSharedIDs) for all of them.
 // Leaves d_qsegs/d_qoff/d_qsets/d_cand/d_qmeta on the device.  Events ev[4]/ev[5] bracket the query kernel.
 int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
-                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out) {
+                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out, const QScan* scan_in) {
+    // (scan_in: the overlap path's pair-offset scan rides on the launch's last workgroup; null: the map path)
+    QScan scan_off = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    QScan scan_on = scan_in ? *scan_in : scan_off;
     const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
     // what the host sends - query offsets, query segments, the minCount table - is one block on both sides: one copy.  Announced
     // and on the device already (dp_query_prestage + the index build's first launch)?  Then it is only compared.
@@ -2967,14 +3018,14 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
                        ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
-                       query_dbg_flags(), q_split, own_rows ? (u64*)ctx->d_cursor.p : (u64*)nullptr);
+                       query_dbg_flags(), q_split, own_rows ? (u64*)ctx->d_cursor.p : (u64*)nullptr, mcLast >= 13 ? scan_off : scan_on);
     // the 16-ladder / exact-count regimes start at minCount 13: only a batch with a query of that many seeds needs the heavy variant
     if (mcLast >= 13) dp_launch<query_kernel<true>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
                        ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
-                       query_dbg_flags(), q_split, (u64*)nullptr);
+                       query_dbg_flags(), q_split, (u64*)nullptr, scan_on);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 5));
 
@@ -3008,6 +3059,7 @@ struct FindState {
     bool pending = false;
     bool defer_fetch = false;  // the first attempt's read-back rides in the anchors launch of the consensus call (a pending stage)
     bool fetch_owed = false;
+    bool scan_fused = false;  // the first attempt's pair offsets were computed by the index query's last workgroup (QScan)
     uint32_t cur[32];
     double query_ms = 0;
     uint64_t query_bytes = 0, chain_bytes = 0, alg_bytes = 0;
@@ -3116,8 +3168,9 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     A.qdone = fuse_resolve ? d_qdone : nullptr;
     if (st.attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, C_CURSOR_BYTES, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
     DP_HIP(dp_mark(ctx, 6));
-    dp_launch<pair_scan_kernel>(ctx, dim3(1), dim3(1024), (const uint32_t*)st.d_qcnt, ctx->qoff_dev, nq, d_pbase, d_ibase,
-                       d_totals, d_qdone);
+    if (!(st.scan_fused && st.attempt == 0))  // (a repeated attempt - larger buffers - scans again: the cursor block was cleared)
+        dp_launch<pair_scan_kernel>(ctx, dim3(1), dim3(1024), (const uint32_t*)st.d_qcnt, ctx->qoff_dev, nq, d_pbase, d_ibase,
+                           d_totals, d_qdone);
     // mode 0 on the slim layout (DP_WALK0_SLIM=0: the full one; a forced tier is the full layout's business)
     static const bool walk0_slim = [] {
         const char* e = getenv("DP_WALK0_SLIM");
@@ -3324,12 +3377,33 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     st.max_query_len = max_query_len;
     u64* d_words = nullptr;
     int32_t* d_mc = nullptr;
+    if (dev_reserve(ctx, ctx->d_cursor, C_CURSOR_BYTES)) return DP_ERR_HIP;  // [0..63] cursor words, [64..] totals (u64 pairs, u64 scratch ints)
+    if (dev_reserve(ctx, ctx->d_pbase, ((size_t)nq + 1) * 4 + ((size_t)nq + 1) * 8 + (size_t)nq * sizeof(QState) + (size_t)nq * 4 + 128)) return DP_ERR_HIP;
     {
-        int rc = dp_query_stage(ctx, q_segs, q_off, nq, hf, &st.d_qmeta, &d_words, &d_mc, &st.mc_n, &st.d_qcnt);
+        // DP_QUERY_SCAN=1: the pair-offset scan rides on the index query's last workgroup (QScan) instead of a launch of its own.  Built for
+        // the launch it removes (~1.7 us a five-slot round each); measured SLOWER - its per-workgroup release fence costs more
+        // than the launch (profiles/r05/ab12_query_scan.txt) - so it is off unless asked for; tests/test_gpu_overlap_e2e.py covers it.
+        const char* scan_env = getenv("DP_QUERY_SCAN");  // (read per call: tests switch it between jobs of one process)
+        const bool scan_off_env = !(scan_env && scan_env[0] == '1');
+        QScan qs = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+        if (!scan_off_env) {
+            if (!ctx->d_qscan.p) {
+                if (dev_reserve(ctx, ctx->d_qscan, 64)) return DP_ERR_HIP;
+                DP_HIP(hipMemsetAsync(ctx->d_qscan.p, 0, 64, ctx->stream));
+            }
+            qs.ibase = (u64*)ctx->d_pbase.p;  // (the layout of chain_enqueue)
+            qs.pbase = (uint32_t*)(qs.ibase + nq + 1);
+            QState* qstate = (QState*)(qs.pbase + nq + 1 + ((nq + 1) & 1));
+            qs.qdone = (uint32_t*)(qstate + nq);
+            qs.totals = (u64*)((uint8_t*)ctx->d_cursor.p + 64);
+            qs.done_ctr = (uint32_t*)ctx->d_qscan.p;
+            qs.enable = 1u;
+        }
+        int rc = dp_query_stage(ctx, q_segs, q_off, nq, hf, &st.d_qmeta, &d_words, &d_mc, &st.mc_n, &st.d_qcnt, qs.enable ? &qs : (const QScan*)nullptr);
         if (rc != 0) return rc;
+        st.scan_fused = qs.enable != 0;
     }
     st.d_mc = d_mc;
-    if (dev_reserve(ctx, ctx->d_cursor, C_CURSOR_BYTES)) return DP_ERR_HIP;  // [0..63] cursor words, [64..] totals (u64 pairs, u64 scratch ints)
     const char* tier_env = getenv("DP_CHAIN_TIER");  // tests: 2 = lds tier, 3 = one-lane tier for every pair
     st.chain_tier = tier_env ? atoi(tier_env) : 0;
     const char* pass_env = getenv("DP_CHAIN_PASSES");  // proposal passes (0 = the serial walk alone: the round-1 behaviour)
@@ -3338,7 +3412,6 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     st.spec_blocks = 1024;  // 4096 persistent waves, 16 per CU: what CSlim's 8.5 KB per wave lets a CU hold
     if (const char* e = getenv("DP_SPEC_BLOCKS")) st.spec_blocks = (uint32_t)std::max(1, atoi(e));
     if (dev_reserve(ctx, ctx->d_pool, (size_t)st.walk_blocks * C_WAVES * chain_pool_stride(st.max_query_len) * sizeof(CNode))) return DP_ERR_HIP;
-    if (dev_reserve(ctx, ctx->d_pbase, ((size_t)nq + 1) * 4 + ((size_t)nq + 1) * 8 + (size_t)nq * sizeof(QState) + (size_t)nq * 4 + 128)) return DP_ERR_HIP;
     // capacities: what the buffers hold now (at least a floor); a run that needs more reports its totals and is repeated
     // with larger buffers (deterministic: same results)
     st.want_pairs = std::max<uint64_t>(1u << 14, ctx->d_mrec.cap / sizeof(MRec));
