@@ -250,12 +250,19 @@ def main():
 
     cs0 = cpu_stat()
     pc0 = pipe_counters()
-    acc, lines, rounds, t_init_sum, per_job = {}, 0, 0, 0.0, []
+    acc, lines, rounds, t_init_sum, per_job, per_job_parts = {}, 0, 0, 0.0, [], []
     t_start = time.perf_counter()
+    pcj = pc0
     for _ in range(args.steps):
         tj = time.perf_counter()
         jl, jr, tot, ti = job()
         per_job.append(time.perf_counter() - tj)
+        # (where a slow job lost its time: set-up, slots waiting for plans, the commit thread waiting for the formatters - ms)
+        pcn = pipe_counters()
+        per_job_parts.append([round(ti * 1e3, 2), round((pcn["slot_wait_for_plan_us"] - pcj["slot_wait_for_plan_us"]) / 1e3, 2),
+                              round((pcn["commit_wait_for_formatter_us"] - pcj["commit_wait_for_formatter_us"]) / 1e3, 2),
+                              round((pcn["commit_thread_wait_us"] - pcj["commit_thread_wait_us"]) / 1e3, 2)])
+        pcj = pcn
         lines += jl
         rounds += jr
         t_init_sum += ti
@@ -404,7 +411,8 @@ def main():
                             "note": "the same timed jobs without their set-up (value table, k-mer index, slots, planner)"},
             "job_breakdown_s": {"whole_job": job_s, "setup_value_table_kmer_index_slots": t_init_sum / n_jobs, "reset_end_of_job": res.get("reset_s", 0.0) / n_jobs,
                                 "rounds": (elapsed - t_init_sum) / n_jobs, "upload_pack_once": upload["upload_pack_s"],
-                                "context_once": upload["context_s"], "per_job": per_job},
+                                "context_once": upload["context_s"], "per_job": per_job,
+                                "per_job_ms_setup_waitplan_waitfmt_commitidle": per_job_parts},
             "kernels_per_round": {kk: {"ms": v[0], "algorithmic_bytes": v[1], "GBs": (v[1] / 1e9) / (v[0] / 1e3) if v[0] > 0 else 0.0,
                                        "frac_of_hbm_peak": ((v[1] / 1e9) / (v[0] / 1e3)) / HBM_PEAK_GBS if v[0] > 0 else 0.0}
                                   for kk, v in kern.items()},
