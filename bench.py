@@ -203,8 +203,14 @@ def main():
         """One whole job on the resident reads.  Returns (PAF lines, rounds, per-job kernel/phase totals, seconds of init)."""
         pipe.init()
         lines = rounds = 0
+        t_prev = time.perf_counter()
+        gaps = res["step_gaps"] = []   # (the longest waits for a step of this job: a stall shows as one long gap, a slow job as many)
         while args.max_rounds < 0 or rounds < args.max_rounds:
             c = pipe.step()
+            t_now = time.perf_counter()
+            if t_now - t_prev > 1e-3:
+                gaps.append((round((t_now - t_prev) * 1e3, 2), rounds))
+            t_prev = t_now
             if c == 0:
                 break
             rounds += c
@@ -262,6 +268,7 @@ def main():
         per_job_parts.append([round(ti * 1e3, 2), round((pcn["slot_wait_for_plan_us"] - pcj["slot_wait_for_plan_us"]) / 1e3, 2),
                               round((pcn["commit_wait_for_formatter_us"] - pcj["commit_wait_for_formatter_us"]) / 1e3, 2),
                               round((pcn["commit_thread_wait_us"] - pcj["commit_thread_wait_us"]) / 1e3, 2)])
+        per_job_parts[-1].append(sorted(res.get("step_gaps", []), reverse=True)[:4])
         pcj = pcn
         lines += jl
         rounds += jr
@@ -412,7 +419,7 @@ def main():
             "job_breakdown_s": {"whole_job": job_s, "setup_value_table_kmer_index_slots": t_init_sum / n_jobs, "reset_end_of_job": res.get("reset_s", 0.0) / n_jobs,
                                 "rounds": (elapsed - t_init_sum) / n_jobs, "upload_pack_once": upload["upload_pack_s"],
                                 "context_once": upload["context_s"], "per_job": per_job,
-                                "per_job_ms_setup_waitplan_waitfmt_commitidle": per_job_parts},
+                                "per_job_ms_setup_waitplan_waitfmt_commitidle_longest_step_waits": per_job_parts},
             "kernels_per_round": {kk: {"ms": v[0], "algorithmic_bytes": v[1], "GBs": (v[1] / 1e9) / (v[0] / 1e3) if v[0] > 0 else 0.0,
                                        "frac_of_hbm_peak": ((v[1] / 1e9) / (v[0] / 1e3)) / HBM_PEAK_GBS if v[0] > 0 else 0.0}
                                   for kk, v in kern.items()},

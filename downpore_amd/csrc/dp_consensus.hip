@@ -362,15 +362,13 @@ struct CFWaveT {
     uint8_t tRc[64], ord[64];
 };
 
-// seeds/sequence.go:1190 GetBaseIndex for one part: MA/MB = its consensus matches, sa = consensus, sb = trimmed target
+// seeds/sequence.go:1190 GetBaseIndex for one part: MA/MB = its consensus matches, before = how many of them lie at or before
+// aIndex (MA ascends: the caller bisects), CG = prefix sums of the consensus' (gap + k), sb = trimmed target
 template <class E>
-__device__ __forceinline__ void cf_base_index(const uint16_t* MA, const uint16_t* MB, int L, int aIndex, const int32_t* sa,
+__device__ __forceinline__ void cf_base_index(const uint16_t* MA, const uint16_t* MB, int before, int aIndex, const int32_t* CG,
                                               const E* sb, int nb, int k, int& indexOut, int& basesOut) {
-    int before = 0;
-    while (before < L && (int)MA[before] <= aIndex) before++;
     if (before == 0) {
-        int offset = 0;
-        for (int i = MA[0]; i > aIndex; i--) offset += sa[i * 2] + k;
+        int offset = CG[MA[0]] - CG[aIndex];  // sum over i = aIndex + 1 .. MA[0] of sa[2i] + k
         int bIndex = MB[0];
         for (int i = bIndex * 2; i > 0 && offset > 0; i -= 2) {
             offset -= sb[i] + k;
@@ -382,13 +380,13 @@ __device__ __forceinline__ void cf_base_index(const uint16_t* MA, const uint16_t
     }
     before--;
     int bIndex = MB[before];
-    if (aIndex == (int)MA[before]) {
+    const int ma = MA[before];
+    if (aIndex == ma) {
         indexOut = bIndex;
         basesOut = 0;
         return;
     }
-    int offset = 0;
-    for (int i = MA[before] + 1; i <= aIndex; i++) offset += sa[i * 2] + k;
+    int offset = CG[aIndex] - CG[ma];  // sum over i = ma + 1 .. aIndex
     for (int i = bIndex * 2 + 2; i < nb && offset >= sb[i]; i += 2) {
         offset -= sb[i] + k;
         bIndex++;
@@ -1059,20 +1057,36 @@ struct consensus_full_kernel {
         if (mine) L.mLen[lane] = mlen;
         __builtin_amdgcn_wave_barrier();
         CF_TICK(4);
+#ifdef CF_P5PROF  // (diagnosis build: make EXTRA=-DCF_P5PROF; sub-phase ticks of phase 5 take the place of the general steps' in the debug record)
+        unsigned long long p5T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, p50 = 0;
+#define CF_P5(i_) if (A.dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); const unsigned long long n_ = wall_clock64(); p5T[i_] += n_ - p50; p50 = n_; }
+        if (A.dbg) p50 = wall_clock64();
+#else
+#define CF_P5(i_)
+#endif
         // ---- 5. parts with fewer than 3 matched seeds leave by swap-with-last, from the back (:258-266)
+        // (when the walk reaches slot i, ord[i] still is i - a removal writes the slot being visited, nothing else - so the test needs no
+        // load: one ballot says who leaves, lane 0 moves the last one into each hole, highest hole first)
         int np = nseq;
-        if (lane == 0) {
-            for (int i = 0; i < nseq; i++) L.ord[i] = (uint8_t)i;
-            for (int i = nseq - 1; i >= 0; i--) {
-                const int s = L.ord[i];
-                if (L.rN[s] == 0 || L.mLen[s] < 3) {
-                    L.ord[i] = L.ord[np - 1];
-                    np--;
+        {
+            const bool gone = lane < nseq && (L.rN[lane] == 0 || L.mLen[lane] < 3);
+            u64 holes = __ballot(gone);
+            if (lane < nseq) L.ord[lane] = (uint8_t)lane;
+            __builtin_amdgcn_wave_barrier();
+            if (holes) {
+                if (lane == 0) {
+                    int last = nseq;
+                    while (holes) {
+                        const int i = 63 - __clzll((long long)holes);
+                        L.ord[i] = L.ord[last - 1];
+                        last--;
+                        holes ^= 1ull << i;
+                    }
                 }
+                np = nseq - __popcll(__ballot(gone));
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        np = __shfl(np, 0, 64);
-        __builtin_amdgcn_wave_barrier();
         if (np <= 1) {
             if (lane == 0) A.gmeta[g] = gm;
             continue;
@@ -1086,18 +1100,44 @@ struct consensus_full_kernel {
             L.backc[i] = 0;
         }
         __builtin_amdgcn_wave_barrier();
+        CF_P5(0)
         const bool part = lane < np;
         const int sq = part ? L.ord[lane] : 0;
         const int mb0 = part ? (L.rb[sq] >> 1) : 0;
         int pl = part ? L.mLen[sq] : 0;
+        const int myId = part ? L.tId[sq] : 0;
+        const int mySeqLen = part ? (int)A.read_len[myId] : 0;  // (asked for here, needed at the very end)
+        // CG[i] = sum_{j = 1 .. i} (cons[2j] + k), i = 0 .. cS: every walk over the consensus' gaps below is a difference of two of these
+        // (in the room of the reduced sequences, which nobody reads any more)
+        int32_t* CG = (int32_t*)L.R;
+        static_assert(sizeof(L.R) >= (CF::CONS / 2 + 2) * sizeof(int32_t), "the consensus' prefix sums live in the reduced sequences' room");
+        {
+            int run = 0;
+            for (int base = 0; base <= cS; base += 64) {
+                const int i = base + lane;
+                const int v = (i >= 1 && i <= cS) ? L.cons[2 * i] + k : 0;
+                const int incl = wave_incl_sum(v);
+                if (i <= cS) CG[i] = run + incl;
+                run += __shfl(incl, 63, 64);
+            }
+        }
         if (part) {
+            // a part's consensus indices ascend strictly (one consensus seed per step of the alignment): the front histogram sees a
+            // prefix of them, the back one a suffix
+            const uint16_t* MA = L.cmA + mb0;
             for (int j = 0; j < pl; j++) {
-                const int a = L.cmA[mb0 + j];
-                if (a < upto) atomicAdd(&L.front[a], 1);
-                if (j >= 1 && cS - 1 - a < upto && cS - 1 - a >= 0) atomicAdd(&L.backc[cS - 1 - a], 1);
+                const int a = MA[j];
+                if (a >= upto) break;
+                atomicAdd(&L.front[a], 1);
+            }
+            for (int j = pl - 1; j >= 1; j--) {
+                const int b = cS - 1 - (int)MA[j];
+                if (b >= upto) break;
+                if (b >= 0) atomicAdd(&L.backc[b], 1);
             }
         }
         __builtin_amdgcn_wave_barrier();
+        CF_P5(1)
         int bestCount = 0, bestScore = 0, bestIndex = upto, backCount = 0, backScore = 0, backIndex = cS - upto - 1;
         for (int i = 0; i < upto; i++) {
             const int count = L.front[i], bCount = L.backc[i];
@@ -1119,14 +1159,27 @@ struct consensus_full_kernel {
         const int naC = 2 * cEnd + 3 - 2 * cStart;  // ints of the trimmed consensus
         int pOffset = 0, pInset = 0, pN = 0, ident = 0, badBack = 0;
         bool panic = false, partBad = false;
+        CF_P5(2)
         if (part) {
             const uint16_t* MA = L.cmA + mb0;
             const uint16_t* MB = L.cmB + mb0;
             const elem_t* sb = L.T + L.tb[sq];
             const int nT = L.tN[sq], nsT = nT >> 1;
             int index, bases, bIndex, backBases;
-            cf_base_index(MA, MB, pl, bestIndex, L.cons, sb, nT, k, index, bases);
-            cf_base_index(MA, MB, pl, backIndex, L.cons, sb, nT, k, bIndex, backBases);
+            // GetBaseIndex's "matches up to aIndex", for both ends at once, by bisection
+            int lo1 = 0, n1 = pl, lo2 = 0, n2 = pl;
+            while ((n1 | n2) != 0) {
+                const int h1 = n1 >> 1, h2 = n2 >> 1;
+                const int v1 = MA[lo1 + h1], v2 = MA[lo2 + h2];  // (a finished search reads MA[lo] and moves nothing)
+                const bool le1 = n1 > 0 && v1 <= bestIndex, le2 = n2 > 0 && v2 <= backIndex;
+                lo1 = le1 ? lo1 + h1 + 1 : lo1;
+                n1 = le1 ? n1 - h1 - 1 : h1;
+                lo2 = le2 ? lo2 + h2 + 1 : lo2;
+                n2 = le2 ? n2 - h2 - 1 : h2;
+            }
+            cf_base_index(MA, MB, lo1, bestIndex, CG, sb, nT, k, index, bases);
+            cf_base_index(MA, MB, lo2, backIndex, CG, sb, nT, k, bIndex, backBases);
+            CF_P5(3)
             if (bases > -k && index < nsT - 1) {
                 bases = (sb[2 * index + 2] + k) - bases;
                 index++;
@@ -1154,6 +1207,7 @@ struct consensus_full_kernel {
                 pOffset = rc ? L.tOff[sq] + i2 : L.tOff[sq] + o2;
                 pInset = rc ? L.tIns[sq] + o2 : L.tIns[sq] + i2;
                 pN = 2 * (endSeed - startSeed) + 3;
+                CF_P5(4)
                 // the part's matches: keep [front, back], rebase (combine.go:84-110)
                 int front = 0;
                 while (front < pl && (int)MB[front] < index) front++;
@@ -1170,36 +1224,46 @@ struct consensus_full_kernel {
                     panic = true;
                 } else {
                     int countA = Ln * k;
+                    // a pair of neighbours adds the consensus' gaps between them where those are negative: tc = the trimmed consensus
+                    // (cons from cStart on, its two end gaps 0), so d1 = CG difference - k, less the end gap when the pair ends on it.
+                    // Four pairs a trip: their loads travel together, only the running sum and the "previous" indices are carried
+                    const int mEnd = (naC - 1) >> 1;
                     int prevA = (int)MA[front] - bestIndex, prevB = (int)MB[front] - index;
-                    for (int j = front + 1; j <= back && !panic; j++) {
-                        const int s = (int)MA[j] - bestIndex, s2 = (int)MB[j] - index;
-                        if (s * 2 >= naC || s2 * 2 >= pN || prevA * 2 + 2 >= naC || prevB * 2 + 2 >= pN || prevA < 0 || prevB < 0) {
-                            panic = true;
-                            break;
+                    int cgPrev = CG[min(max(cStart + prevA, 0), cS)];
+                    for (int j = front + 1; j <= back; j += 4) {
+                        int sv[4], s2v[4], cg[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int jj = min(j + u, back);
+                            sv[u] = (int)MA[jj] - bestIndex;
+                            s2v[u] = (int)MB[jj] - index;
                         }
-                        // trimmed consensus ints: tc[x] = cons[2*cStart + x], tc[0] = tc[naC-1] = 0
-                        int d1 = 0;
-                        {
-                            const int x = prevA * 2 + 2;
-                            d1 = (x == 0 || x == naC - 1) ? 0 : L.cons[2 * cStart + x];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) cg[u] = CG[min(max(cStart + sv[u], 0), cS)];
+                        const int endGap = L.cons[2 * (cStart + mEnd)];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            if (j + u <= back) {
+                                const int s = sv[u], s2 = s2v[u];
+                                if (s * 2 >= naC || s2 * 2 >= pN || prevA * 2 + 2 >= naC || prevB * 2 + 2 >= pN || prevA < 0 || prevB < 0) panic = true;
+                                int d1;
+                                if (s > prevA) d1 = cg[u] - cgPrev - k - (s == mEnd ? endGap : 0);
+                                else d1 = (prevA + 1 == mEnd || panic) ? 0 : L.cons[2 * (cStart + prevA + 1)];  // (does not happen: MA ascends)
+                                if (d1 < 0) countA += d1;
+                                prevA = s;
+                                prevB = s2;
+                                cgPrev = cg[u];
+                            }
                         }
-                        for (int jj = prevA + 2; jj <= s; jj++) {
-                            const int x = jj * 2;
-                            d1 += ((x == 0 || x == naC - 1) ? 0 : L.cons[2 * cStart + x]) + k;
-                        }
-                        if (d1 < 0) countA += d1;
-                        prevA = s;
-                        prevB = s2;
                     }
                     ident = panic ? 0 : countA;
                 }
             }
         }
+        CF_P5(5)
         if (__ballot(partBad)) CF_NOFIT(7u)
         // contig + PAF numbers (combine.go:113-133, commands/overlap.go:199-231)
-        const int myId = part ? L.tId[sq] : 0;
         const int myRc = part ? L.tRc[sq] : 0;
-        const int mySeqLen = part ? (int)A.read_len[myId] : 0;
         const int myStart = pOffset, myLen = mySeqLen - pOffset - pInset;
         const int q_id = __shfl(myId, 0, 64), q_rc = __shfl(myRc, 0, 64), q_len = __shfl(mySeqLen, 0, 64);
         const int q_start = __shfl(myStart, 0, 64), q_l = __shfl(myLen, 0, 64);
@@ -1243,6 +1307,11 @@ struct consensus_full_kernel {
             const unsigned long long t0_ = wall_clock64();
             while (wall_clock64() - t0_ < A.spin_ticks) __builtin_amdgcn_s_sleep(8);
         }
+        CF_P5(6)
+#ifdef CF_P5PROF
+        if (A.dbg && lane == 0)
+            for (int i = 0; i < 8; i++) A.dbg[16 * (size_t)g + 8 + i] = p5T[i];
+#endif
         CF_TICK(5);
     }
 #undef CF_NOFIT
@@ -1476,6 +1545,17 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
                 fprintf(stderr, "[cons] general steps, per window: before the scan %.2f us, scan %.2f, selection %.2f, update %.2f | scan runs %.1f, lane-trips of the scan's first walk %.1f, lanes not found in the update %.1f, steps without a seed %.1f\n",
                         t[0] / cnt / 100.0, t[1] / cnt / 100.0, t[2] / cnt / 100.0, t[3] / cnt / 100.0, t[4] / cnt, t[5] / cnt, t[6] / cnt, t[7] / cnt);
         }
+#ifdef CF_P5PROF
+        {
+            double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t g = 0; g < ng; g++)
+                if (h[16 * (size_t)g + 5])
+                    for (int i = 0; i < 8; i++) t[i] += (double)h[16 * (size_t)g + 8 + i];
+            if (cnt)
+                fprintf(stderr, "[cons] contig+paf, us per window: leave %.2f, prefix sums + histograms %.2f, best seeds %.2f, base indices %.2f, trimmed ends + offsets %.2f, kept matches + identity %.2f, lines %.2f\n",
+                        t[0] / cnt / 100.0, t[1] / cnt / 100.0, t[2] / cnt / 100.0, t[3] / cnt / 100.0, t[4] / cnt / 100.0, t[5] / cnt / 100.0, t[6] / cnt / 100.0);
+        }
+#endif
         if (cnt)
             fprintf(stderr, "[cons] kernel %.3f ms, %u of %u groups complete | us mean/max: gather+query %.1f/%.1f trim %.1f/%.1f shared+reduce %.1f/%.1f "
                             "align %.1f/%.1f contig+paf %.1f/%.1f | group total %.1f/%.1f\n",
