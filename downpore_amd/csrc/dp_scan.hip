@@ -200,7 +200,7 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes) {
     ncap = (ncap + 4095) & ~(size_t)4095;
     void* np = nullptr;
     const double t0 = alloc_trace() ? alloc_now() : 0;
-    DP_HIP(hipHostMalloc(&np, ncap, hipHostMallocDefault));
+    DP_HIP(dp_pin_malloc(&np, ncap));
     if (alloc_trace()) fprintf(stderr, "[alloc] pinned %zu -> %zu bytes, %.3f ms\n", b.cap, ncap, 1e3 * (alloc_now() - t0));
     if (b.p) ctx->retired_pin.push_back(b.p);
     b.p = np;
@@ -208,9 +208,13 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes) {
     return 0;
 }
 
-// ---- large device blocks
+// ---- device and pinned blocks that outlive their context
 // Keyed by device: one process may drive several GPUs (dp_comm_init_local, a Go host with one goroutine per GPU); a block is
 // only ever handed back to the device it was allocated on, and the wait / hipFree that release it run with that device current.
+// Round 5: blocks from 256 KiB on (were: from 32 MiB) and the pinned host blocks too.  A context holds some fifty device and
+// twenty-seven pinned buffers; giving them back to the driver one hipFree / hipHostFree at a time cost a `map` run 20 - 27 ms of
+// its 95 (four contexts), and getting them again a part of its set-up.  What stays parked beyond the context that owned the
+// reads is capped (DP_DEV_CACHE_MB, default 4096; DP_PIN_CACHE_MB, default 2048); dp_release_device_caches() empties both.
 namespace {
 struct BigBlock {
     size_t cap;
@@ -219,14 +223,23 @@ struct BigBlock {
 struct BigCache {
     std::mutex mu;
     std::multimap<std::pair<int, size_t>, void*> free_;  // (device, capacity) -> block
-    std::unordered_map<void*, BigBlock> live;            // blocks handed out by dp_dev_malloc (>= kBig)
+    std::unordered_map<void*, BigBlock> live;            // blocks handed out (>= the cache's smallest size)
     size_t cached = 0;
 };
 BigCache& big_cache() {
     static BigCache* c = new BigCache();  // (never destroyed: contexts may be torn down from static destructors)
     return *c;
 }
-constexpr size_t kBig = (size_t)32 << 20;
+BigCache& pin_cache() {
+    static BigCache* c = new BigCache();
+    return *c;
+}
+constexpr size_t kBig = (size_t)256 << 10;
+constexpr size_t kPinMin = (size_t)64 << 10;
+size_t cache_cap(const char* env, size_t dflt_mb) {
+    const char* e = getenv(env);
+    return (size_t)(e ? std::max(0, atoi(e)) : (int)dflt_mb) << 20;
+}
 struct DeviceGuard {  // makes `device` current for the scope, then restores the caller's
     int prev = -1;
     explicit DeviceGuard(int device) {
@@ -238,6 +251,37 @@ struct DeviceGuard {  // makes `device` current for the scope, then restores the
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+// takes a parked block of about `bytes` (at most a quarter more) out of the cache
+void* cache_take(BigCache& c, int dev, size_t bytes) {
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.free_.lower_bound({dev, bytes});
+    if (it == c.free_.end() || it->first.first != dev || it->first.second > bytes + bytes / 4) return nullptr;
+    void* p = it->second;
+    c.live[p] = BigBlock{it->first.second, dev};
+    c.cached -= it->first.second;
+    c.free_.erase(it);
+    return p;
+}
+// parked blocks go back to the driver, largest first, until at most `keep` bytes stay
+template <class F>
+void cache_trim(BigCache& c, size_t keep, F&& release) {
+    std::vector<std::pair<int, void*>> drop;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        while (c.cached > keep && !c.free_.empty()) {
+            auto big = c.free_.begin();
+            for (auto it = c.free_.begin(); it != c.free_.end(); ++it)
+                if (it->first.second > big->first.second) big = it;
+            drop.push_back({big->first.first, big->second});
+            c.cached -= big->first.second;
+            c.free_.erase(big);
+        }
+    }
+    for (auto& q : drop) {
+        DeviceGuard g(q.first);
+        release(q.second);
+    }
+}
 }  // namespace
 
 size_t dp_dev_cached_bytes() {
@@ -247,18 +291,23 @@ size_t dp_dev_cached_bytes() {
 }
 
 void dp_dev_trim() {
-    BigCache& c = big_cache();
-    std::vector<std::pair<int, void*>> drop;
-    {
+    cache_trim(big_cache(), 0, [](void* p) { (void)hipFree(p); });
+}
+// (a context that owned reads goes: what it and its borrowers parked stays for the next one, up to the cap)
+static void dp_dev_trim_to_cap() {
+    static const size_t cap = cache_cap("DP_DEV_CACHE_MB", 4096);
+    cache_trim(big_cache(), cap, [](void* p) { (void)hipFree(p); });
+}
+
+extern "C" int64_t dp_release_device_caches() {
+    const size_t before = dp_dev_cached_bytes() + [] {
+        BigCache& c = pin_cache();
         std::lock_guard<std::mutex> lk(c.mu);
-        for (auto& e : c.free_) drop.push_back({e.first.first, e.second});
-        c.free_.clear();
-        c.cached = 0;
-    }
-    for (auto& q : drop) {
-        DeviceGuard g(q.first);
-        hipFree(q.second);
-    }
+        return c.cached;
+    }();
+    dp_dev_trim();
+    cache_trim(pin_cache(), 0, [](void* p) { (void)hipHostFree(p); });
+    return (int64_t)before;
 }
 
 hipError_t dp_dev_malloc(void** p, size_t bytes) {
@@ -267,17 +316,7 @@ hipError_t dp_dev_malloc(void** p, size_t bytes) {
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     BigCache& c = big_cache();
-    {
-        std::lock_guard<std::mutex> lk(c.mu);
-        auto it = c.free_.lower_bound({dev, bytes});
-        if (it != c.free_.end() && it->first.first == dev && it->first.second <= bytes + bytes / 4) {
-            *p = it->second;
-            c.live[*p] = BigBlock{it->first.second, dev};
-            c.cached -= it->first.second;
-            c.free_.erase(it);
-            return hipSuccess;
-        }
-    }
+    if ((*p = cache_take(c, dev, bytes)) != nullptr) return hipSuccess;
     const double t0 = alloc_trace() ? alloc_now() : 0;
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) {  // out of memory with blocks parked in the cache: give them back and try again
@@ -285,7 +324,7 @@ hipError_t dp_dev_malloc(void** p, size_t bytes) {
         dp_dev_trim();
         e = hipMalloc(p, bytes);
     }
-    if (alloc_trace()) fprintf(stderr, "[alloc] large device block %zu bytes on device %d, %.3f ms\n", bytes, dev, 1e3 * (alloc_now() - t0));
+    if (alloc_trace() && bytes >= ((size_t)32 << 20)) fprintf(stderr, "[alloc] large device block %zu bytes on device %d, %.3f ms\n", bytes, dev, 1e3 * (alloc_now() - t0));
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(c.mu);
         c.live[*p] = BigBlock{bytes, dev};
@@ -293,7 +332,8 @@ hipError_t dp_dev_malloc(void** p, size_t bytes) {
     return e;
 }
 
-hipError_t dp_dev_free(void* p) {
+// quiet: the caller has already waited for everything that could use the block (dp_ctx_destroy: one wait for all its blocks)
+static hipError_t dev_free_impl(void* p, bool quiet) {
     if (!p) return hipSuccess;
     BigCache& c = big_cache();
     BigBlock b{0, 0};
@@ -307,8 +347,8 @@ hipError_t dp_dev_free(void* p) {
     }
     if (!b.cap) return hipFree(p);
     // what hipFree promises its caller: nothing on the block's device uses it any more
-    hipError_t e;
-    {
+    hipError_t e = hipSuccess;
+    if (!quiet) {
         DeviceGuard g(b.device);
         e = hipDeviceSynchronize();
     }
@@ -316,6 +356,46 @@ hipError_t dp_dev_free(void* p) {
     c.free_.emplace(std::make_pair(b.device, b.cap), p);
     c.cached += b.cap;
     return e;
+}
+hipError_t dp_dev_free(void* p) { return dev_free_impl(p, false); }
+
+// pinned host blocks: the same cache (their users are a context's own stream, which the context waits for before it lets go)
+hipError_t dp_pin_malloc(void** p, size_t bytes) {
+    *p = nullptr;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    BigCache& c = pin_cache();
+    if (bytes >= kPinMin && (*p = cache_take(c, dev, bytes)) != nullptr) return hipSuccess;
+    hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        cache_trim(c, 0, [](void* q) { (void)hipHostFree(q); });
+        e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    }
+    if (e == hipSuccess && bytes >= kPinMin) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.live[*p] = BigBlock{bytes, dev};
+    }
+    return e;
+}
+void dp_pin_free(void* p) {
+    if (!p) return;
+    static const size_t cap = cache_cap("DP_PIN_CACHE_MB", 2048);
+    BigCache& c = pin_cache();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const BigBlock b = it->second;
+            c.live.erase(it);
+            if (c.cached + b.cap <= cap) {
+                c.free_.emplace(std::make_pair(b.device, b.cap), p);
+                c.cached += b.cap;
+                return;
+            }
+        }
+    }
+    (void)hipHostFree(p);
 }
 
 struct ZeroArgs {
@@ -459,22 +539,25 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
                      &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals, &ctx->d_manchor, &ctx->d_seeds_applied,
                      &ctx->d_pbase, &ctx->d_qscan, &ctx->d_pspec, &ctx->d_clist, &ctx->d_sa, &ctx->d_sb, &ctx->d_qual, &ctx->d_qualoff, &ctx->d_hasq, &ctx->d_cretry,
                      &ctx->d_chunk_meta, &ctx->d_nseqs};
+    // one wait for everything this context's blocks could still be used by (its own stream is idle since dp_stream_sync above; a
+    // gang's launches and a borrower's copies run on other streams of the device), then its blocks are parked without further waits
+    (void)hipDeviceSynchronize();
     for (auto* b : dbs)
-        if (b->p) dp_dev_free(b->p);
-    if (ctx->d_kcounts) dp_dev_free(ctx->d_kcounts);
-    for (void* q : ctx->retired_dev) dp_dev_free(q);
-    for (void* q : ctx->retired_pin) hipHostFree(q);
+        if (b->p) dev_free_impl(b->p, true);
+    if (ctx->d_kcounts) dev_free_impl(ctx->d_kcounts, true);
+    for (void* q : ctx->retired_dev) dev_free_impl(q, true);
+    for (void* q : ctx->retired_pin) dp_pin_free(q);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
                      &ctx->h_seeds, &ctx->h_spack, &ctx->h_extra, &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
     for (auto* b : pbs)
-        if (b->p) hipHostFree(b->p);
+        if (b->p) dp_pin_free(b->p);
     for (auto& ev : ctx->ev)
         if (ev) hipEventDestroy(ev);
     if (ctx->ev_sync) hipEventDestroy(ctx->ev_sync);
     hipStreamDestroy(ctx->stream);
     const bool owner = !ctx->borrowed_reads;
     delete ctx;
-    if (owner) dp_dev_trim();  // (a context that owned reads goes: nothing is parked beyond it)
+    if (owner) dp_dev_trim_to_cap();  // (a context that owned reads goes: what is parked beyond it is bounded)
     if (last_borrower) dp_ctx_destroy(lender);
 }
 

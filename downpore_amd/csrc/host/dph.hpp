@@ -653,6 +653,7 @@ struct OverlapRun {
     std::string paf;      // PAF text of the last committed round(s)
     int adaptRounds_ = 0;           // step(): rounds since the planner's lanes were last looked at
     double adaptT_ = 0;
+    double initEnd_ = 0;  // when init() returned (DPH_START_TRACE prints a job's first rounds against it)
     long long adaptWait_ = 0;
     std::atomic<long long> planWaitUs_{0};  // microseconds this handle's slots waited for plans (executeRoundOnImpl)
     int adaptLanes_ = 0;            // lanes the last job grew to (0: none yet)

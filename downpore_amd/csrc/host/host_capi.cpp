@@ -420,7 +420,9 @@ void dph_profile_print() { profilePrint(); }
 // Buffers the library keeps between jobs so that a handle's next job need not map and zero-fill them again (PAF text strings and
 // record arrays: up to 512 MB; window-cache chunks: up to 16 x 11.5 MB; the map command's staging block: ~400 MB at config 3)
 // go back to the allocator.  Safe at any time (a running job simply allocates again); returns the bytes released.
-int64_t dph_release_caches() { return (int64_t)(TextJobBuffers::releaseAll() + WindowCache::releaseSpares() + releaseMapStaging()); }
+int64_t dph_release_caches() {
+    return (int64_t)(TextJobBuffers::releaseAll() + WindowCache::releaseSpares() + releaseMapStaging()) + dp_release_device_caches();  // (round 5: + the device library's parked blocks)
+}
 // process-wide planner counters (tests): 0 plans computed, 1 computed plans thrown away (stale flags, or started from a wrong
 // guess of where the plan before them ends), 2 finished plans erased by a commit's flags
 int64_t dph_planner_counter(int which) {

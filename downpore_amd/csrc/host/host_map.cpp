@@ -930,7 +930,14 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     MapperImpl& M = Mt;
     Sched sched;
     M.sched = &sched;
-    const size_t inflight = std::max<size_t>(1024, 4096 / nThreadsPlanned), stackBytes = 256 * 1024;
+    // reads in flight per thread = windows per dp_map_windows call (DP_MAP_INFLIGHT: another number; a coroutine's stack is 256 KiB
+    // of address space, touched pages only)
+    // Measured at config 3 (profiles/r05/map_threads_and_reads_in_flight.txt): 3 threads x 1 365 reads = 120 launches, 20.7 ms of
+    // map_kernel, loops of 60 - 70 ms; 4 x 2 730 = 64 launches, 14.5 ms, loops of 41 - 46 ms; 8 192 and more per thread: fewer launches
+    // still (10.6 ms of kernels) but the threads' control flow no longer fits their caches and runs less beside the GPU's work
+    size_t inflight = std::max<size_t>(1024, 10922 / nThreadsPlanned);
+    if (const char* e = getenv("DP_MAP_INFLIGHT")) inflight = (size_t)std::max(64, atoi(e));
+    const size_t stackBytes = 256 * 1024;
     std::vector<std::unique_ptr<Task>> live;
     // coroutine stacks: allocated once (never zero-filled) and recycled — 50 k reads x 256 KiB of fresh zeroed vectors
     // used to be most of the run time
@@ -1116,7 +1123,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     size_t nThreads = 1;
     if (shards.empty()) {
         const char* e = getenv("DP_MAP_THREADS");
-        nThreads = (size_t)std::max(1, e ? atoi(e) : 3);
+        nThreads = (size_t)std::max(1, e ? atoi(e) : (hostThreads() >= 8 ? 4 : 3));
         nThreads = std::min(nThreads, std::max<size_t>(1, reads.size() / 2048));
     }
     nThreadsPlanned = nThreads;
@@ -1130,6 +1137,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             const size_t lo = reads.size() * t / nThreads, hi = reads.size() * (t + 1) / nThreads;
             th.emplace_back([&, t, lo, hi] {
                 LoopStats& ls = lstats[t];
+                const double tt0 = wallNow();
                 if (t > 0) {  // a context of its own: shared packed reads, the same seeds, the reference index from the chunk scan above
                     int rc2 = dp_ctx_create_shared(ctx, &tctx[t]);
                     if (rc2 == 0) rc2 = dp_round_begin(tctx[t], k, index.seedMap.data(), (uint32_t)index.seedMap.size());
@@ -1142,13 +1150,19 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
                     }
                 }
                 Ms[t].ctx = tctx[t];
+                const double tt1 = wallNow();
                 mapLoop(tctx[t], Ms[t], lo, hi, ls);
+                if (prof)
+                    fprintf(stderr, "[map thread %zu] context + index %.1f ms, loop %.1f (its own clock %.1f), from the loops' start to this thread's end %.1f\n", t, 1e3 * (tt1 - tt0),
+                            1e3 * (wallNow() - tt1), 1e3 * ls.wall, 1e3 * (wallNow() - tLoop0));
             });
         }
         for (auto& t : th) t.join();
     }
+    const double tJoin = wallNow();
     for (size_t t = 1; t < nThreads; t++)
         if (tctx[t]) dp_ctx_destroy(tctx[t]);
+    if (prof) fprintf(stderr, "[map end] threads joined at %.1f ms after the loops' start, their contexts destroyed in %.1f\n", 1e3 * (tJoin - tLoop0), 1e3 * (wallNow() - tJoin));
     for (size_t t = 0; t < nThreads; t++)
         if (lstats[t].rc != 0) {
             error = lstats[t].error;
@@ -1172,6 +1186,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         stats->t_chain_s = tChain;
         stats->t_host_s = (wallNow() - tLoop0) - tScan - tChain;
     }
+    const double tText0 = wallNow();
     for (size_t r = 0; r < reads.size(); r++) {
         paf += out[r];
         if (nmaps[r] > 0) {
@@ -1186,7 +1201,9 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     snprintf(line, sizeof line, "Uniquely mapped: %lld\nMultiple mappings: %lld\ntotal: %lld\nUnmapped: %lld\n", (long long)mapped,
              (long long)multiple, (long long)total, (long long)unmapped);
     errText += line;
+    const double tEnd0 = wallNow();
     dp_ctx_destroy(ctx);
+    if (prof) fprintf(stderr, "[map end] text joined in %.1f ms, context destroyed in %.1f, whole run %.1f\n", 1e3 * (tEnd0 - tText0), 1e3 * (wallNow() - tEnd0), 1e3 * (wallNow() - tRun0));
     return 0;
 }
 

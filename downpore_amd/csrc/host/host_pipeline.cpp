@@ -1104,6 +1104,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     flagRound_.assign(reads->size(), -1);
     shardLo = 0;
     shardHi = reads->size();
+    initEnd_ = now();
     return 0;
 }
 
@@ -1269,6 +1270,8 @@ int OverlapRun::executeRoundOnImpl(ExecSlot& sl, i64 r, RoundResult& out) {
     if (dbgExec) fprintf(stderr, "[exec] round %lld waiting for its plan\n", (long long)r);
     std::shared_ptr<const RoundPlan> plan = planner->get(r);
     if (dbgExec) fprintf(stderr, "[exec] round %lld got plan\n", (long long)r);
+    static const bool startTrace = getenv("DPH_START_TRACE") != nullptr;  // a job's first rounds, in ms since the end of its set-up
+    const double tPlan = now();
     {
         const long long waitedUs = (long long)((now() - t0) * 1e6);
         g_prof.getWaitUs += waitedUs;
@@ -1379,6 +1382,9 @@ int OverlapRun::executeRoundOnImpl(ExecSlot& sl, i64 r, RoundResult& out) {
     }
     if (dbgExec) fprintf(stderr, "[exec] round %lld finished rc %d\n", (long long)r, rc);
     const double t2 = now();
+    if (startTrace && r < 12)
+        fprintf(stderr, "[start] round %lld slot %d: asked for its plan at %.2f ms, had it at %.2f, scanned / counted at %.2f, finished at %.2f\n", (long long)r, sl.slotNo,
+                1e3 * (t0 - initEnd_), 1e3 * (tPlan - initEnd_), 1e3 * (t1 + out.st.t_scan - initEnd_), 1e3 * (t2 - initEnd_));
     g_prof.add(14, t2 - t0);
     g_prof.add(15, (t2 - t0) - (out.st.t_prepare + out.st.t_scan + out.st.t_index + out.st.t_query + out.st.t_consensus));
     return rc;
