@@ -90,6 +90,11 @@ func SetStreamWait(spin bool) {
 // rounds in flight, timing every round costs 7 % of a job.  Process-wide; the library's default is 8.
 func SetKernelTiming(every int) { C.dp_set_kernel_timing(C.int(every)) }
 
+// ReleaseDeviceCaches gives the device blocks and pinned host buffers that destroyed contexts left parked in the library's cache
+// back to the driver (they are kept - up to DP_DEV_CACHE_MB / DP_PIN_CACHE_MB - so that the next context does not pay for them
+// again).  Returns the bytes released.  gpuhost.ReleaseCaches() calls it too.
+func ReleaseDeviceCaches() int64 { return int64(C.dp_release_device_caches()) }
+
 func (c *Context) Close() {
 	if c.h != nil {
 		C.dp_ctx_destroy(c.h)

@@ -226,7 +226,8 @@ func (o *Overlap) Close() {
 }
 
 // ReleaseCaches gives back the host buffers the library keeps between jobs (PAF text, window-cache chunks, the map command's
-// staging block: up to ~0.9 GB after a config-2 overlap job and a config-3 map job).  Returns the bytes released.
+// staging block: up to ~0.9 GB after a config-2 overlap job and a config-3 map job) and, since round 5, the device blocks and
+// pinned buffers that destroyed contexts left parked in the device library (dp_release_device_caches).  Returns the bytes released.
 func ReleaseCaches() int64 { return int64(C.dph_release_caches()) }
 
 // ---- multi-GPU, one process per GPU: the north-star layout (reads partitioned, survivors' seed index all-gathered) ----------

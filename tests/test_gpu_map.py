@@ -67,6 +67,30 @@ def test_map_single_seeds_host_walk_agrees(monkeypatch):
     monkeypatch.delenv("DP_MAP_SEEDS_HOST")
 
 
+def test_map_threads_reads_in_flight_and_parked_blocks(monkeypatch):
+    """The mapper deals its reads to host threads (DP_MAP_THREADS, default 4) that keep DP_MAP_INFLIGHT reads in flight each (one window
+    per read and dp_map_windows call); the contexts of a finished run park their device and pinned blocks in the library's cache and the
+    next run takes them from there (round 5).  Same PAF as the oracle with one thread, many small calls, few large ones, and across
+    dp_release_device_caches() - which returns what was parked, then nothing."""
+    import ctypes as C
+    from downpore_amd.hip import load_library
+    lib = load_library()
+    lib.dp_release_device_caches.restype = C.c_int64
+    args = (5, 300000, 2100, 9000, 0.10, True, False)   # (more than 2 048 reads: the thread count is not clamped to one)
+    _case(*args)
+    assert lib.dp_release_device_caches() > 0
+    assert lib.dp_release_device_caches() == 0
+    for threads, inflight in (("1", "64"), ("2", "500"), ("4", "100000")):
+        monkeypatch.setenv("DP_MAP_THREADS", threads)
+        monkeypatch.setenv("DP_MAP_INFLIGHT", inflight)
+        _case(*args)
+    from downpore_amd.overlap import load_host
+    H = load_host()
+    H.dph_release_caches.restype = C.c_int64
+    assert H.dph_release_caches() > 0   # (the host library's call gives the device library's parked blocks back too)
+    assert lib.dp_release_device_caches() == 0
+
+
 def test_map_dynamic_match_on_one_lane_agrees(monkeypatch):
     """dynamicMatch probes the target's seeds with 64 lanes at once (round 4); DP_MAP_ONE_LANE=1 runs the reference's loop nest on
     one lane as before.  Both must print the oracle's PAF - reads with errors, so that chains break, ratchets move and several
