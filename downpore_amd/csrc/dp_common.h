@@ -188,13 +188,13 @@ static inline const uint32_t* dp_seeds_ptr(const dp_ctx* ctx) {
 // concurrent slots than a pinned source (SDMA engines); should it pin the pages and copy later instead, they are still ours.
 const void* dp_stage(dp_ctx* ctx, const void* src, size_t bytes);
 // hipMalloc / hipFree for the library's large device blocks (k-mer index and its build buffers, value tables: hundreds of MB
-// to tens of GB).  Blocks of 32 MiB and more (round 5: 256 KiB and more) that are freed stay in a process-wide cache and satisfy later requests of about
+// to tens of GB).  Blocks of 32 MiB and more (round 5: 4 KiB and more) that are freed stay in a process-wide cache and satisfy later requests of about
 // their size: releasing and re-acquiring gigabytes from the driver costs 0.3-0.6 s every now and then (measured: a 400 MB
 // hipMalloc of 622 ms at the start of a job).  The cache is dropped when an allocation fails and by dp_dev_trim().
 hipError_t dp_dev_malloc(void** p, size_t bytes);
 hipError_t dp_dev_free(void* p);
 void dp_dev_trim();
-// Round 5: the cache takes blocks from 256 KiB on, and a second one of the same shape holds the contexts' pinned host buffers
+// Round 5: the cache takes blocks from 4 KiB on, and a second one of the same shape holds the contexts' pinned host buffers
 // (dp_pin_malloc / dp_pin_free) - a context that goes parks its blocks instead of paying a hipFree / hipHostFree for each; what
 // stays parked is capped (DP_DEV_CACHE_MB / DP_PIN_CACHE_MB) and dp_release_device_caches() (downpore_hip.h) empties both
 hipError_t dp_pin_malloc(void** p, size_t bytes);

@@ -211,7 +211,8 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes) {
 // ---- device and pinned blocks that outlive their context
 // Keyed by device: one process may drive several GPUs (dp_comm_init_local, a Go host with one goroutine per GPU); a block is
 // only ever handed back to the device it was allocated on, and the wait / hipFree that release it run with that device current.
-// Round 5: blocks from 256 KiB on (were: from 32 MiB) and the pinned host blocks too.  A context holds some fifty device and
+// Round 5: blocks from 4 KiB on (were: from 32 MiB) and the pinned host blocks too (with 256 KiB as the smallest parked block a
+// context's teardown was 2 ms, the ~30 smaller ones it still freed one by one; with 4 KiB 0.4 ms).  A context holds some fifty device and
 // twenty-seven pinned buffers; giving them back to the driver one hipFree / hipHostFree at a time cost a `map` run 20 - 27 ms of
 // its 95 (four contexts), and getting them again a part of its set-up.  What stays parked beyond the context that owned the
 // reads is capped (DP_DEV_CACHE_MB, default 4096; DP_PIN_CACHE_MB, default 2048); dp_release_device_caches() empties both.
@@ -234,8 +235,8 @@ BigCache& pin_cache() {
     static BigCache* c = new BigCache();
     return *c;
 }
-constexpr size_t kBig = (size_t)256 << 10;
-constexpr size_t kPinMin = (size_t)64 << 10;
+constexpr size_t kBig = (size_t)4 << 10;
+constexpr size_t kPinMin = (size_t)4 << 10;
 size_t cache_cap(const char* env, size_t dflt_mb) {
     const char* e = getenv(env);
     return (size_t)(e ? std::max(0, atoi(e)) : (int)dflt_mb) << 20;

@@ -65,7 +65,7 @@ DP_API void dp_set_stream_wait(int spin);
  * rounds and reports 0 ms for the others; 0 = never; the default is 8 (or DP_KERNEL_TIMING).  Process-wide. */
 DP_API void dp_set_kernel_timing(int every);
 DP_API void dp_ctx_destroy(dp_ctx* ctx);
-/* The device blocks (from 256 KiB on) and pinned host buffers of a destroyed context stay parked in a process-wide cache, so that the
+/* The device blocks (from 4 KiB on) and pinned host buffers of a destroyed context stay parked in a process-wide cache, so that the
  * next context - the next `map` run, the next job's index build - does not pay the driver for them again (a context holds some eighty
  * of them; releasing four contexts one hipFree at a time was a quarter of a config-3 `map` run).  What stays parked once the context
  * that owned the reads has gone is capped: DP_DEV_CACHE_MB (default 4096) and DP_PIN_CACHE_MB (default 2048).  This call gives
