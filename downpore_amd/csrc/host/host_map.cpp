@@ -935,7 +935,9 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // Measured at config 3 (profiles/r05/map_threads_and_reads_in_flight.txt): 3 threads x 1 365 reads = 120 launches, 20.7 ms of
     // map_kernel, loops of 60 - 70 ms; 4 x 2 730 = 64 launches, 14.5 ms, loops of 41 - 46 ms; 8 192 and more per thread: fewer launches
     // still (10.6 ms of kernels) but the threads' control flow no longer fits their caches and runs less beside the GPU's work
-    size_t inflight = std::max<size_t>(1024, 10922 / nThreadsPlanned);
+    // and once a context's teardown no longer cost 5 ms, more threads paid: 6 x 2 730 = 78 launches, 18 ms of kernels, a run of 58 - 60 ms
+    // (856 k reads/s) against 64 - 70 ms with 4 x 2 730 and 61 - 70 with 8 x 2 048
+    size_t inflight = std::max<size_t>(2730, 10922 / nThreadsPlanned);
     if (const char* e = getenv("DP_MAP_INFLIGHT")) inflight = (size_t)std::max(64, atoi(e));
     const size_t stackBytes = 256 * 1024;
     std::vector<std::unique_ptr<Task>> live;
@@ -1123,7 +1125,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     size_t nThreads = 1;
     if (shards.empty()) {
         const char* e = getenv("DP_MAP_THREADS");
-        nThreads = (size_t)std::max(1, e ? atoi(e) : (hostThreads() >= 8 ? 4 : 3));
+        nThreads = (size_t)std::max(1, e ? atoi(e) : (hostThreads() >= 12 ? 6 : hostThreads() >= 8 ? 4 : 3));
         nThreads = std::min(nThreads, std::max<size_t>(1, reads.size() / 2048));
     }
     nThreadsPlanned = nThreads;
