@@ -142,9 +142,11 @@ __device__ __forceinline__ void kb_tile_out(const kb_u64 (&e)[E], uint32_t m, in
     const int nb = (int)dmask + 1;
     for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;
     __syncthreads();
+    // (the count's own atomic hands every entry its rank inside its digit - kept in registers, so the placing below is a plain LDS
+    // store: one LDS atomic per entry instead of two, round 5)
+    uint32_t rk[E];
 #pragma unroll
-    for (int j = 0; j < E; j++)
-        if ((m >> j) & 1) atomicAdd(&hist[(uint32_t)(e[j] >> dshift) & dmask], 1u);
+    for (int j = 0; j < E; j++) rk[j] = ((m >> j) & 1) ? atomicAdd(&hist[(uint32_t)(e[j] >> dshift) & dmask], 1u) : 0u;
     __syncthreads();
     // exclusive scan of the digit counts (nb <= 1024: four bins per thread), global reservation, cursors back to zero
     {
@@ -167,7 +169,6 @@ __device__ __forceinline__ void kb_tile_out(const kb_u64 (&e)[E], uint32_t m, in
             if (b < nb) {
                 lstart[b] = base;
                 if (loc[u]) gbase[b] = atomicAdd(&cursor[b], (kb_u64)loc[u]);
-                hist[b] = 0;
                 base += loc[u];
             }
         }
@@ -178,7 +179,7 @@ __device__ __forceinline__ void kb_tile_out(const kb_u64 (&e)[E], uint32_t m, in
     for (int j = 0; j < E; j++)
         if ((m >> j) & 1) {
             const uint32_t d = (uint32_t)(e[j] >> dshift) & dmask;
-            sorted[lstart[d] + atomicAdd(&hist[d], 1u)] = e[j];
+            sorted[lstart[d] + rk[j]] = e[j];
         }
     __syncthreads();
     total = lstart[nb - 1] + hist[nb - 1];
@@ -318,13 +319,14 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const KbBuf in, const kb_
         // stay in registers between the counting and the placing walk)
         constexpr int KB_HOLD = KB_P3_CAP / KB_THREADS;
         kb_u64 held[KB_HOLD];
+        uint32_t rk[KB_HOLD];  // (rank of the entry inside its k-mer, from the counting atomic itself: placing needs no second one)
         const bool hold = n <= KB_P3_CAP;
         if (hold) {
 #pragma unroll
             for (int u = 0; u < KB_HOLD; u++) {
                 const kb_u64 i = lo + (kb_u64)u * KB_THREADS + threadIdx.x;
                 held[u] = i < hi ? kb_ld(in, i) : 0;
-                if (i < hi) atomicAdd(&hist[(uint32_t)(held[u] >> pay) & dmask], 1u);
+                rk[u] = i < hi ? atomicAdd(&hist[(uint32_t)(held[u] >> pay) & dmask], 1u) : 0u;
             }
         } else {
             for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) atomicAdd(&hist[(uint32_t)(kb_ld(in, i) >> pay) & dmask], 1u);
@@ -359,9 +361,6 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const KbBuf in, const kb_
             counts[kbase + b] = hist[b];
             off[kbase + b] = lo + lstart[b];
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;  // placement cursors
-        __syncthreads();
         if (hold) {
 #pragma unroll
             for (int u = 0; u < KB_HOLD; u++) {
@@ -369,7 +368,7 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const KbBuf in, const kb_
                 if (i < hi) {
                     const kb_u64 v = held[u];
                     const uint32_t d = (uint32_t)(v >> pay) & dmask;
-                    sorted[lstart[d] + atomicAdd(&hist[d], 1u)] = v;
+                    sorted[lstart[d] + rk[u]] = v;
                 }
             }
             __syncthreads();
@@ -377,6 +376,9 @@ __global__ __launch_bounds__(KB_THREADS) void kb_final(const KbBuf in, const kb_
                 kb_pos_st(pos, lo + i, sorted[i], G);
             }
         } else {  // larger than the LDS buffer: entries go straight to their slot (the region is this workgroup's alone)
+            __syncthreads();
+            for (int i = threadIdx.x; i < nb; i += KB_THREADS) hist[i] = 0;  // placement cursors
+            __syncthreads();
             for (kb_u64 i = lo + threadIdx.x; i < hi; i += KB_THREADS) {
                 const kb_u64 v = kb_ld(in, i);
                 const uint32_t d = (uint32_t)(v >> pay) & dmask;
