@@ -117,6 +117,61 @@ __global__ __launch_bounds__(1024) void values_kernel_hist(const uint32_t* __res
         if (h[b]) atomicAdd(&ghist[b], h[b]);
 }
 
+// The same pass with the reverse complement's count read from LDS instead of gathered (round 5).  counts[rc(i)] of 64 consecutive
+// k-mers are 64 different cache lines (the last bases of i are the first of rc(i)): 4 useful bytes per 64-byte sector, 4.3 GB of
+// traffic for a 268 MB table at k = 13 and three quarters of this kernel's 1.36 ms.  Split a k-mer into P (first three bases), x
+// (the middle) and S (last three): the 64 x 64 k-mers with one x are 64 rows of 256 contiguous bytes, and their reverse complements
+// are exactly the 64 x 64 k-mers with the middle rc(x) - rows of 256 bytes again.  A workgroup loads both tiles into LDS (rows
+// padded to 65 words: the transposed read is conflict-free) and writes merged[] and values[] of its tile in rows.  VT_PER tiles per
+// workgroup keep the number of flushes of the LDS histogram where it was.
+#define VT_PER 4
+__global__ __launch_bounds__(256) void values_kernel_hist_tiled(const uint32_t* __restrict__ counts, int k, const uint64_t* __restrict__ small,
+                                                                double* __restrict__ values, uint64_t* __restrict__ merged,
+                                                                uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[VH_BINS + 1];
+    __shared__ uint32_t A[64][65], B[64][65];
+    for (int b = threadIdx.x; b <= VH_BINS; b += 256) h[b] = 0;
+    const double tf = (double)small[0];
+    const int mid = k - 6;                            // bases of x
+    const uint32_t n_tiles = 1u << (2 * mid);
+    const int psh = 2 * k - 6;
+    const uint32_t S = threadIdx.x & 63u, rS = values_rc_kmer(S, 3);
+    for (int t = 0; t < VT_PER; t++) {
+        const uint32_t x = blockIdx.x * VT_PER + t;
+        if (x >= n_tiles) break;
+        const uint32_t xr = mid ? values_rc_kmer(x, mid) : 0u;
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+            const uint32_t P = (uint32_t)it * 4 + (threadIdx.x >> 6);
+            A[P][S] = counts[((size_t)P << psh) | ((size_t)x << 6) | S];
+            B[P][S] = counts[((size_t)P << psh) | ((size_t)xr << 6) | S];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+            const uint32_t P = (uint32_t)it * 4 + (threadIdx.x >> 6);
+            const size_t i = ((size_t)P << psh) | ((size_t)x << 6) | S;
+            const uint32_t rP = values_rc_kmer(P, 3);
+            const size_t ri = ((size_t)rS << psh) | ((size_t)xr << 6) | rP;
+            const uint32_t a = A[P][S];
+            const uint64_t m = ri == i ? 2ull * a : 2ull * ((uint64_t)a + B[rS][rP]);
+            merged[i] = m;
+            const double targetFreq = 0.000005;
+            const double freq = (double)a / tf;
+            double v;
+            if (a < 3) v = 0.0;
+            else if (freq <= targetFreq) v = 1.0 - (targetFreq - freq);
+            else v = 1.0 - (freq - targetFreq);
+            values[i] = v;
+            atomicAdd(&h[m < VH_BINS ? (uint32_t)m : VH_BINS], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= VH_BINS; b += 256)
+        if (h[b]) atomicAdd(&ghist[b], h[b]);
+}
+
 // one workgroup: T, the tie quota, "beyond the histogram"
 __global__ __launch_bounds__(1024) void values_threshold_kernel(const uint32_t* __restrict__ ghist, uint64_t n, uint64_t topN,
                                                                 uint64_t* __restrict__ small) {
@@ -305,8 +360,18 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
         uint32_t* tileTies = ghist + VH_BINS + 1;
         DPV(hipMemsetAsync(d_h, 0, (size_t)(VH_BINS + 1) * 4, ctx->stream));
         DPV(hipMemsetAsync((uint64_t*)d_small + 1, 0, 56, ctx->stream));
-        hipLaunchKernelGGL(values_kernel_hist, dim3(tiles), dim3(1024), 0, ctx->stream, (const uint32_t*)d_counts, n, k, (const uint64_t*)d_small,
-                           values, (uint64_t*)d_merged, ghist);
+        static const bool gather = [] {
+            const char* e = getenv("DP_VALUES_GATHER");  // 1: the reverse complement's count gathered from HBM, as before round 5
+            return e && e[0] == '1';
+        }();
+        if (k >= 8 && !gather) {
+            const uint32_t n_tiles = 1u << (2 * (k - 6));
+            hipLaunchKernelGGL(values_kernel_hist_tiled, dim3((n_tiles + VT_PER - 1) / VT_PER), dim3(256), 0, ctx->stream, (const uint32_t*)d_counts, k,
+                               (const uint64_t*)d_small, values, (uint64_t*)d_merged, ghist);
+        } else {
+            hipLaunchKernelGGL(values_kernel_hist, dim3(tiles), dim3(1024), 0, ctx->stream, (const uint32_t*)d_counts, n, k, (const uint64_t*)d_small,
+                               values, (uint64_t*)d_merged, ghist);
+        }
         hipLaunchKernelGGL(values_threshold_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)ghist, n, topN, (uint64_t*)d_small);
         hipLaunchKernelGGL(values_tie_count_kernel, dim3(tiles), dim3(1024), 0, ctx->stream, (const uint64_t*)d_merged, n, (const uint64_t*)d_small,
                            tileTies);
