@@ -398,29 +398,79 @@ __global__ void kb_mask_digits(kb_u64* __restrict__ cnt1, uint32_t nb1, uint32_t
 }
 
 __global__ void kb_excl_scan_small(const kb_u64* __restrict__ in, uint32_t n, kb_u64* __restrict__ out) {
-    // n <= 2^20 entries, one workgroup: each thread scans a contiguous slice
+    // n <= 2^20 entries, one workgroup: each thread scans a contiguous slice, sixteen entries - one cache line - at a time (with one
+    // entry per step the 1 024 slices' lines did not survive in the L1 until their next entry was asked for: 0.25 ms for 2 MB)
     __shared__ kb_u64 part[1024];
-    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t per = (((n + 1023) / 1024) + 15u) & ~15u;
     const uint32_t lo = min(n, threadIdx.x * per), hi = min(n, lo + per);
     kb_u64 s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += in[i];
+    for (uint32_t i = lo; i < hi; i += 16) {
+        kb_u64 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = i + j < hi ? in[i + j] : 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) s += v[j];
+    }
     part[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        kb_u64 run = 0;
-        for (int i = 0; i < 1024; i++) {
-            const kb_u64 v = part[i];
-            part[i] = run;
-            run += v;
+    for (int d = 1; d < 1024; d <<= 1) {  // (ten steps instead of one thread's walk over 1 024 sums)
+        const kb_u64 v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    kb_u64 run = part[threadIdx.x] - s;
+    for (uint32_t i = lo; i < hi; i += 16) {
+        kb_u64 v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = i + j < hi ? in[i + j] : 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (i + j < hi) out[i + j] = run;
+            run += v[j];
         }
     }
-    __syncthreads();
-    kb_u64 run = part[threadIdx.x];
-    for (uint32_t i = lo; i < hi; i++) {
-        out[i] = run;
-        run += in[i];
-    }
     if (threadIdx.x == 1023) out[n] = run;
+}
+
+// The scan of the sub-partition counts (2^18 of them at config 2) on many workgroups: one workgroup needed 0.23 - 0.25 ms for 2 MB in and
+// 2 MB out (a single CU's share of the memory system), three small launches need a tenth of it.  partial[g] = sum of chunk g.
+__global__ __launch_bounds__(1024) void kb_scan_partials(const kb_u64* __restrict__ in, uint32_t n, uint32_t chunk, kb_u64* __restrict__ partial) {
+    __shared__ kb_u64 red[16];
+    const uint32_t lo = min(n, blockIdx.x * chunk), hi = min(n, lo + chunk);
+    kb_u64 s = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) s += in[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (dp_lane() == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        kb_u64 t = 0;
+        for (int w = 0; w < 16; w++) t += red[w];
+        partial[blockIdx.x] = t;
+    }
+}
+// out[i] = pbase[chunk of i] + sum of the chunk's entries in front of i; out[n] = the total
+__global__ __launch_bounds__(1024) void kb_scan_write(const kb_u64* __restrict__ in, uint32_t n, uint32_t chunk, const kb_u64* __restrict__ pbase,
+                                                      kb_u64* __restrict__ out) {
+    __shared__ kb_u64 part[1024];
+    const uint32_t lo = min(n, blockIdx.x * chunk), hi = min(n, lo + chunk);
+    kb_u64 run = pbase[blockIdx.x];
+    for (uint32_t b0 = lo; b0 < hi; b0 += 1024) {
+        const uint32_t i = b0 + threadIdx.x;
+        const kb_u64 v = i < hi ? in[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const kb_u64 u = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += u;
+            __syncthreads();
+        }
+        if (i < hi) out[i] = run + part[threadIdx.x] - v;
+        run += part[1023];
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = run;
 }
 
 // Builds counts (uint32 [4^k]), off (uint64 [4^k + 1]) and the index entries for the context's resident reads.  d_counts, d_off
@@ -590,7 +640,14 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     hipLaunchKernelGGL(kb_part1, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, (const uint8_t*)ow->d_packed.p, (const uint64_t*)ow->d_boff.p,
                        (const uint32_t*)ow->d_len.p, (const uint32_t*)d_gread, n_groups, G, cur1, A);
     hipLaunchKernelGGL(kb_count2, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, A, (const kb_u64*)base1, (const uint32_t*)tile_start, G, cnt2);
-    hipLaunchKernelGGL(kb_excl_scan_small, dim3(1), dim3(1024), 0, ctx->stream, (const kb_u64*)cnt2, n_sub, base2);
+    if (n_sub >= 8192) {  // (cur2 is scratch until the copy below fills it: 256 partial sums and their scan)
+        const uint32_t n_wg = 256, chunk = (((n_sub + n_wg - 1) / n_wg) + 1023u) & ~1023u;
+        hipLaunchKernelGGL(kb_scan_partials, dim3(n_wg), dim3(1024), 0, ctx->stream, (const kb_u64*)cnt2, n_sub, chunk, cur2);
+        hipLaunchKernelGGL(kb_excl_scan_small, dim3(1), dim3(1024), 0, ctx->stream, (const kb_u64*)cur2, n_wg, cur2 + n_wg);
+        hipLaunchKernelGGL(kb_scan_write, dim3(n_wg), dim3(1024), 0, ctx->stream, (const kb_u64*)cnt2, n_sub, chunk, (const kb_u64*)(cur2 + n_wg), base2);
+    } else {
+        hipLaunchKernelGGL(kb_excl_scan_small, dim3(1), dim3(1024), 0, ctx->stream, (const kb_u64*)cnt2, n_sub, base2);
+    }
     DP_HIP(hipMemcpyAsync(cur2, base2, (size_t)n_sub * 8, hipMemcpyDeviceToDevice, ctx->stream));
     hipLaunchKernelGGL(kb_part2, dim3(grid), dim3(KB_THREADS), 0, ctx->stream, A, (const kb_u64*)base1, (const uint32_t*)tile_start, G, cur2, B);
     hipLaunchKernelGGL(kb_final, dim3(std::min<uint32_t>(n_sub, (uint32_t)cus * 16)), dim3(KB_THREADS),
