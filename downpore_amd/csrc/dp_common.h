@@ -68,6 +68,8 @@ struct dp_ctx {
     hipEvent_t ev_sync = nullptr;  // blocking-sync event: waiting host threads sleep instead of polling
     std::string err;
     bool borrowed_reads = false;  // d_packed/d_boff/d_len belong to another context
+    struct ReadsUpload;           // a read set still on its way to the device (dp_reads_upload_rc_begin, dp_scan.hip)
+    ReadsUpload* upload = nullptr;
 
     // ---- reads (A1)
     uint32_t n_reads = 0;

@@ -215,17 +215,23 @@ int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes) {
 // context's teardown was 2 ms, the ~30 smaller ones it still freed one by one; with 4 KiB 0.4 ms).  A context holds some fifty device and
 // twenty-seven pinned buffers; giving them back to the driver one hipFree / hipHostFree at a time cost a `map` run 20 - 27 ms of
 // its 95 (four contexts), and getting them again a part of its set-up.  What stays parked beyond the context that owned the
-// reads is capped (DP_DEV_CACHE_MB, default 4096; DP_PIN_CACHE_MB, default 2048); dp_release_device_caches() empties both.
+// reads is capped (DP_DEV_CACHE_MB, default 16384 - a config-3 `map` run parks 7.5 GB: six threads' contexts with a chain pool of 1 GB
+// each; with 4096 half of it went back to the driver at the end of every run and was fetched again by the next; DP_PIN_CACHE_MB, default 2048); dp_release_device_caches() empties both.
 namespace {
 struct BigBlock {
     size_t cap;
     int device;
 };
+struct Parked {
+    void* p;
+    uint64_t seq;  // when it was parked: trimming lets the blocks go that have been lying here longest
+};
 struct BigCache {
     std::mutex mu;
-    std::multimap<std::pair<int, size_t>, void*> free_;  // (device, capacity) -> block
-    std::unordered_map<void*, BigBlock> live;            // blocks handed out (>= the cache's smallest size)
+    std::multimap<std::pair<int, size_t>, Parked> free_;  // (device, capacity) -> block
+    std::unordered_map<void*, BigBlock> live;             // blocks handed out (>= the cache's smallest size)
     size_t cached = 0;
+    uint64_t seq = 0;
 };
 BigCache& big_cache() {
     static BigCache* c = new BigCache();  // (never destroyed: contexts may be torn down from static destructors)
@@ -252,30 +258,42 @@ struct DeviceGuard {  // makes `device` current for the scope, then restores the
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+// Blocks below 256 MB come in size classes (four per power of two): the per-round buffers grow by factors that depend on what a
+// thread happened to be given, and a cache of exact sizes filled up with blocks nobody asked for again - 0.8 GB per config-3 `map` run.
+size_t size_class(size_t bytes) {
+    if (bytes >= ((size_t)256 << 20) || bytes < 4096) return bytes;
+    size_t p = 4096;
+    while (p * 2 <= bytes) p *= 2;
+    const size_t step = p / 4;
+    return (bytes + step - 1) / step * step;
+}
 // takes a parked block of about `bytes` (at most a quarter more) out of the cache
 void* cache_take(BigCache& c, int dev, size_t bytes) {
     std::lock_guard<std::mutex> lk(c.mu);
     auto it = c.free_.lower_bound({dev, bytes});
     if (it == c.free_.end() || it->first.first != dev || it->first.second > bytes + bytes / 4) return nullptr;
-    void* p = it->second;
+    void* p = it->second.p;
     c.live[p] = BigBlock{it->first.second, dev};
     c.cached -= it->first.second;
     c.free_.erase(it);
     return p;
 }
-// parked blocks go back to the driver, largest first, until at most `keep` bytes stay
+// parked blocks go back to the driver until at most `keep` bytes stay - the ones parked longest ago first: what every run takes out
+// and parks again (the packed reads, the staging copy: hundreds of MB, a hipMalloc of 0.4 - 0.6 s each) is young, what piles up is the
+// buffers whose sizes differ from run to run and that nobody asks for again.  (Largest first - the first version - let exactly the
+// expensive blocks go once the pile reached the cap: every fifth config-3 `map` run of a process took 0.51 s instead of 0.06.)
 template <class F>
 void cache_trim(BigCache& c, size_t keep, F&& release) {
     std::vector<std::pair<int, void*>> drop;
     {
         std::lock_guard<std::mutex> lk(c.mu);
         while (c.cached > keep && !c.free_.empty()) {
-            auto big = c.free_.begin();
+            auto old = c.free_.begin();
             for (auto it = c.free_.begin(); it != c.free_.end(); ++it)
-                if (it->first.second > big->first.second) big = it;
-            drop.push_back({big->first.first, big->second});
-            c.cached -= big->first.second;
-            c.free_.erase(big);
+                if (it->second.seq < old->second.seq) old = it;
+            drop.push_back({old->first.first, old->second.p});
+            c.cached -= old->first.second;
+            c.free_.erase(old);
         }
     }
     for (auto& q : drop) {
@@ -296,7 +314,7 @@ void dp_dev_trim() {
 }
 // (a context that owned reads goes: what it and its borrowers parked stays for the next one, up to the cap)
 static void dp_dev_trim_to_cap() {
-    static const size_t cap = cache_cap("DP_DEV_CACHE_MB", 4096);
+    static const size_t cap = cache_cap("DP_DEV_CACHE_MB", 16384);
     cache_trim(big_cache(), cap, [](void* p) { (void)hipFree(p); });
 }
 
@@ -314,6 +332,7 @@ extern "C" int64_t dp_release_device_caches() {
 hipError_t dp_dev_malloc(void** p, size_t bytes) {
     *p = nullptr;
     if (bytes < kBig) return hipMalloc(p, bytes);
+    bytes = size_class(bytes);
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     BigCache& c = big_cache();
@@ -325,7 +344,7 @@ hipError_t dp_dev_malloc(void** p, size_t bytes) {
         dp_dev_trim();
         e = hipMalloc(p, bytes);
     }
-    if (alloc_trace() && bytes >= ((size_t)32 << 20)) fprintf(stderr, "[alloc] large device block %zu bytes on device %d, %.3f ms\n", bytes, dev, 1e3 * (alloc_now() - t0));
+    if (alloc_trace() && bytes >= ((size_t)1 << 20)) fprintf(stderr, "[alloc] device block %zu bytes on device %d from the driver, %.3f ms (parked now: %zu bytes)\n", bytes, dev, 1e3 * (alloc_now() - t0), dp_dev_cached_bytes());
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(c.mu);
         c.live[*p] = BigBlock{bytes, dev};
@@ -354,7 +373,7 @@ static hipError_t dev_free_impl(void* p, bool quiet) {
         e = hipDeviceSynchronize();
     }
     std::lock_guard<std::mutex> lk(c.mu);
-    c.free_.emplace(std::make_pair(b.device, b.cap), p);
+    c.free_.emplace(std::make_pair(b.device, b.cap), Parked{p, c.seq++});
     c.cached += b.cap;
     return e;
 }
@@ -363,6 +382,7 @@ hipError_t dp_dev_free(void* p) { return dev_free_impl(p, false); }
 // pinned host blocks: the same cache (their users are a context's own stream, which the context waits for before it lets go)
 hipError_t dp_pin_malloc(void** p, size_t bytes) {
     *p = nullptr;
+    if (bytes >= kPinMin) bytes = size_class(bytes);
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     BigCache& c = pin_cache();
@@ -389,14 +409,15 @@ void dp_pin_free(void* p) {
         if (it != c.live.end()) {
             const BigBlock b = it->second;
             c.live.erase(it);
-            if (c.cached + b.cap <= cap) {
-                c.free_.emplace(std::make_pair(b.device, b.cap), p);
+            if (b.cap <= cap) {
+                c.free_.emplace(std::make_pair(b.device, b.cap), Parked{p, c.seq++});
                 c.cached += b.cap;
-                return;
+                p = nullptr;
             }
         }
     }
-    (void)hipHostFree(p);
+    if (p) (void)hipHostFree(p);
+    else cache_trim(c, cap, [](void* q) { (void)hipHostFree(q); });  // (room is made by the blocks parked longest ago)
 }
 
 struct ZeroArgs {
@@ -508,9 +529,11 @@ extern "C" int dp_ctx_set_priority(dp_ctx* ctx, int high) {
     return DP_OK;
 }
 
+static int upload_join(dp_ctx* ctx);  // (dp_reads_upload_rc_begin's thread, below)
 extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->upload) (void)upload_join(ctx);  // (a read set still travelling: its thread uses this context's buffers)
     if (ctx->gang) dp_gang_forget(ctx);  // (destroyed before its gang: the gang forgets the member, the others never wait for it)
     dp_stream_sync(ctx);
     {
@@ -570,8 +593,8 @@ extern "C" uint64_t dp_reads_total_bases(const dp_ctx* ctx) { return ctx ? ctx->
 
 __global__ void pack_kernel(const uint8_t* __restrict__ ascii, const int64_t* __restrict__ aoff,
                             const uint64_t* __restrict__ boff, uint32_t n_reads, uint32_t* __restrict__ packed,
-                            uint64_t n_dwords, const uint32_t* __restrict__ srcmap) {
-    uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                            uint64_t n_dwords, const uint32_t* __restrict__ srcmap, uint64_t d_begin = 0) {
+    uint64_t d = d_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (dwords [d_begin, n_dwords) of the packed layout)
     if (d >= n_dwords) return;
     uint64_t byte = d * 4;
     // binary search: last read with boff[r] <= byte
@@ -614,11 +637,34 @@ __global__ void pack_kernel(const uint8_t* __restrict__ ascii, const int64_t* __
 // stages it piece by piece on one thread: 55-75 ms for config 2's reads); here a few helper threads copy 4 MiB pieces into a ring of
 // pinned blocks and every piece is sent on as soon as it is complete (pinned to device: ~40 GB/s), so the host copies, not the
 // link, set the pace.  Small inputs go the plain way.  DP_UPLOAD_THREADS (default 4; 0 = plain copy; measured at config 2: 54 ms plain, 33-35 ms with 4, 6 or 8 helpers).
-static int upload_ascii(dp_ctx* ctx, void* d_dst, const uint8_t* src, uint64_t n) {
+namespace {
+std::mutex g_ring_mu;  // held by whoever uses the ring, for as long as it does
+uint8_t* g_ring = nullptr;
+size_t g_ring_bytes = 0;
+uint8_t* ring_get(size_t bytes) {  // (caller holds g_ring_mu) null: no pinned memory to be had
+    if (g_ring_bytes < bytes) {
+        if (g_ring) hipHostFree(g_ring);
+        g_ring = nullptr;
+        g_ring_bytes = 0;
+        if (hipHostMalloc((void**)&g_ring, bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            g_ring = nullptr;
+            return nullptr;
+        }
+        g_ring_bytes = bytes;
+    }
+    return g_ring;
+}
+int upload_threads() {
     static const int n_thr = [] {
         const char* e = getenv("DP_UPLOAD_THREADS");
         return e ? std::max(0, std::min(16, atoi(e))) : 4;
     }();
+    return n_thr;
+}
+}  // namespace
+static int upload_ascii(dp_ctx* ctx, void* d_dst, const uint8_t* src, uint64_t n) {
+    const int n_thr = upload_threads();
     constexpr uint64_t kPiece = (uint64_t)4 << 20;
     if (n_thr == 0 || n < 16 * kPiece) {
         DP_HIP(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, ctx->stream));
@@ -626,23 +672,12 @@ static int upload_ascii(dp_ctx* ctx, void* d_dst, const uint8_t* src, uint64_t n
     }
     const int n_slots = 2 * n_thr;
     // the ring is kept for the process (48 MiB pinned; pinning costs ~0.1 ms per MiB) and used by one upload at a time
-    static std::mutex ring_mu;
-    static uint8_t* ring_keep = nullptr;
-    static size_t ring_bytes = 0;
-    std::lock_guard<std::mutex> ring_lock(ring_mu);
-    if (ring_bytes < (size_t)n_slots * kPiece) {
-        if (ring_keep) hipHostFree(ring_keep);
-        ring_keep = nullptr;
-        ring_bytes = 0;
-        if (hipHostMalloc((void**)&ring_keep, (size_t)n_slots * kPiece, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            ring_keep = nullptr;
-            DP_HIP(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, ctx->stream));
-            return DP_OK;
-        }
-        ring_bytes = (size_t)n_slots * kPiece;
+    std::lock_guard<std::mutex> ring_lock(g_ring_mu);
+    uint8_t* ring = ring_get((size_t)n_slots * kPiece);
+    if (!ring) {
+        DP_HIP(hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, ctx->stream));
+        return DP_OK;
     }
-    uint8_t* ring = ring_keep;
     const uint64_t n_pieces = (n + kPiece - 1) / kPiece;
     std::vector<hipEvent_t> sent((size_t)n_slots, nullptr);
     for (auto& e : sent) hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -705,11 +740,23 @@ static int upload_ascii(dp_ctx* ctx, void* d_dst, const uint8_t* src, uint64_t n
     return DP_OK;
 }
 
-static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_host, uint32_t first_paired) {
+// What both forms of the upload do first: the new read set's tables (packed offsets, lengths) resident, room for the packed reads,
+// the staging copies' device blocks and the two small tables the pack kernel reads (ASCII offsets, source map) on their way.
+struct UploadPrep {
+    void *d_ascii = nullptr, *d_aoff = nullptr, *d_map = nullptr;
+    std::vector<int64_t> rel;      // ASCII offset of every host read (relative to the first)
+    std::vector<uint32_t> srcmap;  // device read -> host read << 1 | reverse complement
+    uint64_t nascii = 0, pos = 0;
+    uint32_t n_reads = 0;
+    bool nothing = false;          // no bases at all: the tables are resident, nothing travels
+};
+static int upload_join(dp_ctx* ctx);
+static int reads_upload_prepare(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_host, uint32_t& first_paired, UploadPrep& P) {
     if (!ctx || !bases || !off) return DP_ERR_ARG;
     if (ctx->borrowed_reads) return dp_fail(ctx, DP_ERR_STATE, "dp_reads_upload on a context that borrows its reads");
     // contexts made with dp_ctx_create_shared hold plain copies of the resident buffers' addresses
     if (ctx->n_borrowers.load() > 0) return dp_fail(ctx, DP_ERR_STATE, "dp_reads_upload while contexts borrowing these reads exist");
+    if (int rc = upload_join(ctx)) return rc;  // (a read set that was still travelling)
     if (first_paired > n_host) first_paired = n_host;
     hipSetDevice(ctx->device);
     dp_kindex_free(ctx);  // a position index of the previous read set is void
@@ -730,8 +777,7 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
     const bool paired = first_paired < n_host;
     std::vector<uint64_t> h_boff((size_t)n_reads + 1, 0);
     std::vector<uint32_t> h_len(n_reads, 0);
-    std::vector<uint32_t> srcmap;
-    if (paired) srcmap.resize(n_reads);
+    if (paired) P.srcmap.resize(n_reads);
     uint64_t pos = 0, total = 0;
     for (uint32_t d = 0; d < n_reads; d++) {
         const uint32_t r = d < first_paired ? d : first_paired + (d - first_paired) / 2;
@@ -740,7 +786,7 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
         if (len < 0 || len > 0x7fffffff) return dp_fail(ctx, DP_ERR_ARG, "read length out of range");
         h_boff[d] = pos;
         h_len[d] = (uint32_t)len;
-        if (paired) srcmap[d] = (r << 1) | isrc;
+        if (paired) P.srcmap[d] = (r << 1) | isrc;
         pos += ((uint64_t)(len + 3) / 4 + 15) & ~(uint64_t)15;
         total += (uint64_t)len;
     }
@@ -772,37 +818,45 @@ static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* o
     DP_HIP(hipMemcpyAsync(ctx->d_boff.p, ctx->h_boff.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     DP_HIP(hipMemcpyAsync(ctx->d_len.p, ctx->h_len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
     DP_HIP(hipMemsetAsync((uint8_t*)ctx->d_packed.p + pos, 0, 64, ctx->stream));
+    P.n_reads = n_reads;
+    P.pos = pos;
     if (n_reads == 0 || pos == 0) {
         DP_HIP(dp_stream_sync(ctx));
+        P.nothing = true;
         return DP_OK;
     }
-    void* d_ascii = nullptr;
-    void* d_aoff = nullptr;
-    void* d_map = nullptr;
+    P.nascii = (uint64_t)(off[n_host] - off[0]);
+    DP_HIP(dp_dev_malloc(&P.d_ascii, P.nascii + 16));
+    DP_HIP(dp_dev_malloc(&P.d_aoff, ((size_t)n_host + 1) * 8));
+    P.rel.resize((size_t)n_host + 1);
+    for (uint32_t r = 0; r <= n_host; r++) P.rel[r] = off[r] - off[0];
+    DP_HIP(hipMemcpyAsync(P.d_aoff, P.rel.data(), ((size_t)n_host + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (paired) {
+        DP_HIP(dp_dev_malloc(&P.d_map, (size_t)n_reads * 4));
+        DP_HIP(hipMemcpyAsync(P.d_map, P.srcmap.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return DP_OK;
+}
+
+static int reads_upload_impl(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_host, uint32_t first_paired) {
+    UploadPrep P;
     struct Temps {  // staging copies: released on every way out, error returns included (after the stream has drained)
         dp_ctx* c;
-        void **a, **b, **m;
+        UploadPrep& p;
         ~Temps() {
+            if (!c) return;
             hipStreamSynchronize(c->stream);
-            for (void** p : {a, b, m})
-                if (*p) dp_dev_free(*p);
+            for (void* q : {p.d_ascii, p.d_aoff, p.d_map})
+                if (q) dp_dev_free(q);
         }
-    } temps{ctx, &d_ascii, &d_aoff, &d_map};
-    const uint64_t nascii = (uint64_t)(off[n_host] - off[0]);
-    DP_HIP(dp_dev_malloc(&d_ascii, nascii + 16));
-    DP_HIP(dp_dev_malloc(&d_aoff, ((size_t)n_host + 1) * 8));
-    std::vector<int64_t> rel((size_t)n_host + 1);
-    for (uint32_t r = 0; r <= n_host; r++) rel[r] = off[r] - off[0];
-    if (int rc = upload_ascii(ctx, d_ascii, bases + off[0], nascii)) return rc;
-    DP_HIP(hipMemcpyAsync(d_aoff, rel.data(), ((size_t)n_host + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (paired) {
-        DP_HIP(dp_dev_malloc(&d_map, (size_t)n_reads * 4));
-        DP_HIP(hipMemcpyAsync(d_map, srcmap.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
-    uint64_t n_dwords = pos / 4;
+    } temps{ctx, P};
+    if (int rc = reads_upload_prepare(ctx, bases, off, n_host, first_paired, P)) return rc;
+    if (P.nothing) return DP_OK;
+    if (int rc = upload_ascii(ctx, P.d_ascii, bases + off[0], P.nascii)) return rc;
+    uint64_t n_dwords = P.pos / 4;
     uint32_t blocks = (uint32_t)((n_dwords + 255) / 256);
-    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)d_ascii, (const int64_t*)d_aoff,
-                       (const uint64_t*)ctx->d_boff.p, n_reads, (uint32_t*)ctx->d_packed.p, n_dwords, (const uint32_t*)d_map);
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)P.d_ascii, (const int64_t*)P.d_aoff,
+                       (const uint64_t*)ctx->d_boff.p, P.n_reads, (uint32_t*)ctx->d_packed.p, n_dwords, (const uint32_t*)P.d_map, (uint64_t)0);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_stream_sync(ctx));
     return DP_OK;
@@ -814,6 +868,178 @@ extern "C" int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t*
 
 extern "C" int dp_reads_upload_rc(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads, uint32_t first_paired) {
     return reads_upload_impl(ctx, bases, off, n_reads, first_paired);
+}
+
+// ---- a read set that travels while its first reads are already worked on (round 5: `map` maps read 0 while read 40 000 is on the link)
+struct dp_ctx::ReadsUpload {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t ready = 0;   // host reads [0, ready) are packed on the device (both strands)
+    uint32_t n_host = 0;
+    bool done = false;
+    int rc = DP_OK;
+    std::string error;
+};
+
+static int upload_join(dp_ctx* ctx) {
+    if (!ctx || !ctx->upload) return DP_OK;
+    dp_ctx::ReadsUpload* U = ctx->upload;
+    if (U->th.joinable()) U->th.join();
+    const int rc = U->rc;
+    const std::string err = U->error;
+    ctx->upload = nullptr;
+    delete U;
+    return rc == DP_OK ? DP_OK : dp_fail(ctx, rc, err.c_str());
+}
+
+// The thread that carries an upload: pieces of ASCII through the pinned ring to the device on a stream of its own, behind every piece the
+// pack kernel for the reads that are complete with it, and the host told how far that is whenever a piece's event has fired.
+static void upload_thread(dp_ctx* ctx, dp_ctx::ReadsUpload* U, const uint8_t* src, UploadPrep P, uint32_t first_paired) {
+    auto publish = [&](uint32_t ready, bool done, hipError_t e, const char* what) {
+        {
+            std::lock_guard<std::mutex> lk(U->mu);
+            if (ready > U->ready) U->ready = ready;
+            if (e != hipSuccess && U->rc == DP_OK) {
+                U->rc = DP_ERR_HIP;
+                U->error = std::string(what) + ": " + hipGetErrorString(e);
+            }
+            if (done) U->done = true;
+        }
+        U->cv.notify_all();
+    };
+    hipError_t err = hipSetDevice(ctx->device);
+    hipStream_t st = nullptr;
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    const uint32_t n_host = U->n_host;
+    const uint64_t n = P.nascii, n_dwords_all = P.pos / 4;
+    uint32_t hr_sent = 0;    // host reads whose ASCII has been queued completely
+    uint64_t d_done = 0;     // packed dwords whose pack launch has been queued
+    auto pack_upto = [&](uint64_t ascii_end) {  // queues the pack of every read that is complete with ASCII [0, ascii_end)
+        while (hr_sent < n_host && (uint64_t)P.rel[(size_t)hr_sent + 1] <= ascii_end) hr_sent++;
+        const uint32_t D = hr_sent <= first_paired ? hr_sent : first_paired + 2 * (hr_sent - first_paired);
+        const uint64_t d_end = hr_sent == n_host ? n_dwords_all : ctx->h_boff[D] / 4;
+        if (d_end > d_done) {
+            const uint32_t blocks = (uint32_t)((d_end - d_done + 255) / 256);
+            hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t*)P.d_ascii, (const int64_t*)P.d_aoff,
+                               (const uint64_t*)ctx->d_boff.p, P.n_reads, (uint32_t*)ctx->d_packed.p, d_end, (const uint32_t*)P.d_map, d_done);
+            d_done = d_end;
+            return hipGetLastError();
+        }
+        return hipSuccess;
+    };
+    constexpr uint64_t kPiece = (uint64_t)4 << 20;
+    const int n_thr = std::max(1, upload_threads());
+    const int n_slots = 2 * n_thr;
+    {
+        std::unique_lock<std::mutex> ring_lock(g_ring_mu);
+        uint8_t* ring = err == hipSuccess ? ring_get((size_t)n_slots * kPiece) : nullptr;
+        if (err == hipSuccess && !ring) {  // no ring: one copy, one pack
+            ring_lock.unlock();
+            err = hipMemcpyAsync(P.d_ascii, src, n, hipMemcpyHostToDevice, st);
+            if (err == hipSuccess) err = pack_upto(n);
+        } else if (err == hipSuccess) {
+            const uint64_t n_pieces = (n + kPiece - 1) / kPiece;
+            std::vector<hipEvent_t> sent((size_t)n_slots, nullptr);
+            for (auto& e : sent) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            std::vector<uint32_t> piece_hr((size_t)n_pieces, 0);  // host reads packed once piece i's event has fired
+            std::mutex mu;
+            std::condition_variable cv;
+            std::vector<uint8_t> filled((size_t)n_pieces, 0);
+            uint64_t next_fill = 0, next_send = 0;
+            bool failed = false;
+            auto helper = [&] {
+                for (;;) {
+                    uint64_t i;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return failed || next_fill >= n_pieces || next_fill < next_send + (uint64_t)n_slots; });
+                        if (failed || next_fill >= n_pieces) return;
+                        i = next_fill++;
+                    }
+                    const uint64_t b = i * kPiece, len = std::min(kPiece, n - b);
+                    memcpy(ring + (i % (uint64_t)n_slots) * kPiece, src + b, len);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        filled[(size_t)i] = 1;
+                    }
+                    cv.notify_all();
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 0; t < n_thr; t++) th.emplace_back(helper);
+            for (uint64_t i = 0; i < n_pieces && err == hipSuccess; i++) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return filled[(size_t)i] != 0; });
+                }
+                const uint64_t b = i * kPiece, len = std::min(kPiece, n - b);
+                const size_t slot = (size_t)(i % (uint64_t)n_slots);
+                err = hipMemcpyAsync((uint8_t*)P.d_ascii + b, ring + slot * kPiece, len, hipMemcpyHostToDevice, st);
+                if (err == hipSuccess) err = pack_upto(b + len);
+                piece_hr[(size_t)i] = hr_sent;
+                if (err == hipSuccess) err = hipEventRecord(sent[slot], st);
+                if (err == hipSuccess && i + 1 >= (uint64_t)n_slots / 2) {
+                    const uint64_t done_upto = i + 1 - (uint64_t)n_slots / 2;
+                    err = hipEventSynchronize(sent[(size_t)(done_upto % (uint64_t)n_slots)]);
+                    if (err == hipSuccess) publish(piece_hr[(size_t)done_upto], false, hipSuccess, "");
+                    std::lock_guard<std::mutex> lk(mu);
+                    next_send = done_upto + 1;
+                }
+                cv.notify_all();
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (err != hipSuccess) failed = true;
+                next_send = n_pieces + (uint64_t)n_slots;
+            }
+            cv.notify_all();
+            for (auto& t : th) t.join();
+            if (st) (void)hipStreamSynchronize(st);  // (the ring goes back only when nothing reads it any more)
+            for (auto& e : sent) hipEventDestroy(e);
+        }
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    else if (st) (void)hipStreamSynchronize(st);
+    for (void* q : {P.d_ascii, P.d_aoff, P.d_map})
+        if (q) dev_free_impl(q, true);  // (their only user was this stream, which is idle)
+    if (st) (void)hipStreamDestroy(st);
+    publish(err == hipSuccess ? n_host : 0u, true, err, "dp_reads_upload_rc_begin: staged copy");
+}
+
+extern "C" int dp_reads_upload_rc_begin(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads, uint32_t first_paired, uint32_t ready_first) {
+    UploadPrep P;
+    if (int rc = reads_upload_prepare(ctx, bases, off, n_reads, first_paired, P)) {
+        hipStreamSynchronize(ctx->stream);
+        for (void* q : {P.d_ascii, P.d_aoff, P.d_map})
+            if (q) dp_dev_free(q);
+        return rc;
+    }
+    if (P.nothing) return DP_OK;
+    hipError_t e = dp_stream_sync(ctx);  // (the tables the pack kernel reads are resident; P's host vectors move into the thread)
+    if (e != hipSuccess) {
+        for (void* q : {P.d_ascii, P.d_aoff, P.d_map})
+            if (q) dp_dev_free(q);
+        return dp_fail(ctx, DP_ERR_HIP, "dp_reads_upload_rc_begin", e);
+    }
+    dp_ctx::ReadsUpload* U = new dp_ctx::ReadsUpload();
+    U->n_host = n_reads;
+    ctx->upload = U;
+    const uint8_t* src = bases + off[0];
+    U->th = std::thread([ctx, U, src, first_paired](UploadPrep Pm) { upload_thread(ctx, U, src, std::move(Pm), first_paired); }, std::move(P));
+    return dp_reads_upload_wait(ctx, ready_first);
+}
+
+extern "C" int dp_reads_upload_wait(dp_ctx* ctx, uint32_t host_read_hi) {
+    if (!ctx) return DP_ERR_ARG;
+    dp_ctx* own = ctx->owner ? ctx->owner : ctx;
+    if (!own->upload) return DP_OK;
+    if (host_read_hi == 0xffffffffu) return own == ctx ? upload_join(ctx) : DP_ERR_ARG;  // (everything, and the thread with it: the owner's call)
+    dp_ctx::ReadsUpload* U = own->upload;
+    std::unique_lock<std::mutex> lk(U->mu);
+    const uint32_t want = std::min(host_read_hi, U->n_host);
+    U->cv.wait(lk, [&] { return U->done || U->ready >= want; });
+    return U->rc;  // (the message is handed over by the owner's final wait)
 }
 
 extern "C" int dp_reads_packed(dp_ctx* ctx, uint32_t read, uint8_t* out, uint64_t cap, uint64_t* n_bytes) {

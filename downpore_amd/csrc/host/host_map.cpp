@@ -631,7 +631,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     }
     auto fail = [&](int rc) {
         error = dp_last_error(ctx);
-        dp_ctx_destroy(ctx);
+        dp_ctx_destroy(ctx), ctx = nullptr;
         return rc;
     };
     mark("context");
@@ -735,13 +735,31 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // on the device
     concatThread.join();
     mark("concatenate reads (waited for)");
-    rc = dp_reads_upload_rc(ctx, (const uint8_t*)staging.get(), off.data(), (uint32_t)(off.size() - 1), 2);
-    if (rc) return fail(rc);
-    mark("upload + pack (both strands)");
+    // Round 5, DP_MAP_ASYNC_UPLOAD=1: the reads travel while they are mapped (dp_reads_upload_rc_begin: this call returns when the
+    // reference and the join chunk are packed; the mapper threads wait for "reads below n are packed" block by block).  Built, parity
+    // tested and left OFF: set-up 14.5 -> 8 ms and the best run 56.0 -> 54.4 ms, but the runs of a process spread 55 - 107 ms where
+    // they were 56 - 65 (means of 12 runs 69 / 77 against 62 / 69 ms, profiles/r05/map_threads_and_reads_in_flight.txt): the upload's
+    // copy threads and the link compete with six mapper threads for the same host cores and queues.
+    const bool asyncUpload = [] {
+        const char* e = getenv("DP_MAP_ASYNC_UPLOAD");
+        return e && e[0] == '1';
+    }();
     // (giving 400 MB of staging back to the system is 40 ms of munmap - round 3's profile had booked it as "AddSingleSeeds (waited
     // for)" - and on a thread of its own it holds the address-space lock against this one's allocations just as long: the block is
     // kept for the process's next map command instead, which then also finds its pages touched)
-    stagingPut(std::move(staging), stagingCap);
+    struct StagingBack {  // every way out: the upload's thread has read the last byte before the block changes hands
+        dp_ctx*& c;
+        std::unique_ptr<char[]>& st;
+        size_t& cap;
+        ~StagingBack() {
+            if (c) (void)dp_reads_upload_wait(c, 0xffffffffu);
+            if (st) stagingPut(std::move(st), cap);
+        }
+    } stagingBack{ctx, staging, stagingCap};
+    rc = asyncUpload ? dp_reads_upload_rc_begin(ctx, (const uint8_t*)staging.get(), off.data(), (uint32_t)(off.size() - 1), 2, 2)
+                     : dp_reads_upload_rc(ctx, (const uint8_t*)staging.get(), off.data(), (uint32_t)(off.size() - 1), 2);
+    if (rc) return fail(rc);
+    mark(asyncUpload ? "upload begun (reference packed)" : "upload + pack (both strands)");
     seedThread.join();
     mark("AddSingleSeeds (waited for)");
     rc = dp_round_begin(ctx, k, index.seedMap.data(), (uint32_t)index.seedMap.size());
@@ -843,14 +861,14 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             sh.c1 = std::min(nChunks, c0 + per);
             if (dp_ctx_create(devs[shards.size() % devs.size()], &sh.ctx) != 0) {
                 error = dp_last_error(nullptr);
-                dp_ctx_destroy(ctx);
+                dp_ctx_destroy(ctx), ctx = nullptr;
                 return DP_ERR_NODEVICE;
             }
             shards.push_back(sh);
             dp_ctx* sc = sh.ctx;
             auto sfail = [&](int rc2) {
                 error = dp_last_error(sc);
-                dp_ctx_destroy(ctx);
+                dp_ctx_destroy(ctx), ctx = nullptr;
                 return rc2;
             };
             rc = dp_round_begin(sc, k, index.seedMap.data(), S);
@@ -885,7 +903,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             rc = dp_index_set_global(sh.ctx, global.data(), S, sh.c0 / 64, nChunks);
             if (rc) {
                 error = dp_last_error(sh.ctx);
-                dp_ctx_destroy(ctx);
+                dp_ctx_destroy(ctx), ctx = nullptr;
                 return rc;
             }
         }
@@ -916,7 +934,8 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         int rc = 0;
         std::string error;
     };
-    auto mapLoop = [&](dp_ctx* tctx, MapperImpl& Mt, size_t readLo, size_t readHi, LoopStats& ls) {
+    dp_ctx* const ownerCtx = ctx;  // (owns the reads: the threads ask it how far their upload has come)
+    auto mapLoop = [&](dp_ctx* tctx, MapperImpl& Mt, size_t tIdx, size_t nT, LoopStats& ls) {
     const double tl0 = wallNow();
     double tScan = 0, tChain = 0;
     int rc = 0;
@@ -945,20 +964,34 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // used to be most of the run time
     std::vector<std::unique_ptr<char[]>> stackStore;
     std::vector<char*> freeStacks;
-    size_t nextRead = readLo;
+    // The reads are dealt in blocks of 1 024: thread t takes blocks t, t + nT, ... - so that every thread finds its first block on the
+    // device a fraction of a millisecond into the upload (contiguous shares would leave the last thread waiting for five sixths of it).
+    // Output is per read, in read order, whoever mapped it.
+    const size_t nReads = reads.size(), BL = 1024;
+    size_t myCount = 0;
+    for (size_t blk = tIdx; blk * BL < nReads; blk += nT) myCount += std::min(BL, nReads - blk * BL);
+    auto readOf = [&](size_t seq) { return ((seq / BL) * nT + tIdx) * BL + seq % BL; };
+    size_t nextSeq = 0, waitedBelow = 0;
     std::vector<dp_scan_item> witems;
     std::vector<int32_t> wsegs;
     std::vector<uint64_t> woff;
     std::vector<uint32_t> wlen;
     double tp[6] = {0, 0, 0, 0, 0, 0};
-    while (nextRead < readHi || !live.empty()) {
+    while (nextSeq < myCount || !live.empty()) {
         double tq = wallNow();
         auto lap = [&](int i) {
             const double t = wallNow();
             tp[i] += t - tq;
             tq = t;
         };
-        while (live.size() < inflight && nextRead < readHi) {
+        while (live.size() < inflight && nextSeq < myCount) {
+            const size_t nextRead = readOf(nextSeq);
+            if (nextRead >= waitedBelow) {  // (the block may still be on its way to the device: dp_reads_upload_rc_begin)
+                const size_t upto = std::min(nReads, (nextRead / BL + 1) * BL);
+                rc = dp_reads_upload_wait(ownerCtx, (uint32_t)(2 + upto));  // (host reads 0 and 1: the reference and its join chunk)
+                if (rc) return fail(rc);
+                waitedBelow = upto;
+            }
             std::unique_ptr<Task> t(new Task());
             t->m = &M;
             t->read = (uint32_t)nextRead;
@@ -970,7 +1003,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             t->stack = freeStacks.back();
             freeStacks.pop_back();
             coroStart(*t, stackBytes);
-            nextRead++;
+            nextSeq++;
             sched.cur = t.get();
             g_coroSched = &sched;
             dph_coro_switch(&sched.main, t->sp);  // run until the first window request (or completion)
@@ -1114,7 +1147,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         lap(4);  // coroutines resumed: performMapping's tail + the mapper's control flow up to the next window
     }
     if (prof)
-        fprintf(stderr, "[map loop] reads %zu..%zu: start/retire %.1f ms, items %.1f, scan+copy %.1f (scan call %.1f), map call %.1f, resume %.1f\n", readLo, readHi,
+        fprintf(stderr, "[map loop] thread %zu of %zu: start/retire + upload waits %.1f ms, items %.1f, scan+copy %.1f (scan call %.1f), map call %.1f, resume %.1f\n", tIdx, nT,
                 1e3 * tp[0], 1e3 * tp[1], 1e3 * tp[3], 1e3 * tScan, 1e3 * tChain, 1e3 * tp[4]);
     ls.tScan = tScan;
     ls.tChain = tChain;
@@ -1126,7 +1159,9 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     if (shards.empty()) {
         const char* e = getenv("DP_MAP_THREADS");
         nThreads = (size_t)std::max(1, e ? atoi(e) : (hostThreads() >= 12 ? 6 : hostThreads() >= 8 ? 4 : 3));
-        nThreads = std::min(nThreads, std::max<size_t>(1, reads.size() / 2048));
+        size_t perThread = 2048;  // (fewer reads than that per thread are not worth a context; DP_MAP_MIN_READS_PER_THREAD: test hook)
+        if (const char* e2 = getenv("DP_MAP_MIN_READS_PER_THREAD")) perThread = (size_t)std::max(1, atoi(e2));
+        nThreads = std::min(nThreads, std::max<size_t>(1, reads.size() / perThread));
     }
     nThreadsPlanned = nThreads;
     std::vector<LoopStats> lstats(nThreads);
@@ -1136,8 +1171,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     {
         std::vector<std::thread> th;
         for (size_t t = 0; t < nThreads; t++) {
-            const size_t lo = reads.size() * t / nThreads, hi = reads.size() * (t + 1) / nThreads;
-            th.emplace_back([&, t, lo, hi] {
+            th.emplace_back([&, t] {
                 LoopStats& ls = lstats[t];
                 const double tt0 = wallNow();
                 if (t > 0) {  // a context of its own: shared packed reads, the same seeds, the reference index from the chunk scan above
@@ -1153,7 +1187,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
                 }
                 Ms[t].ctx = tctx[t];
                 const double tt1 = wallNow();
-                mapLoop(tctx[t], Ms[t], lo, hi, ls);
+                mapLoop(tctx[t], Ms[t], t, nThreads, ls);
                 if (prof)
                     fprintf(stderr, "[map thread %zu] context + index %.1f ms, loop %.1f (its own clock %.1f), from the loops' start to this thread's end %.1f\n", t, 1e3 * (tt1 - tt0),
                             1e3 * (wallNow() - tt1), 1e3 * ls.wall, 1e3 * (wallNow() - tLoop0));
@@ -1168,7 +1202,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     for (size_t t = 0; t < nThreads; t++)
         if (lstats[t].rc != 0) {
             error = lstats[t].error;
-            dp_ctx_destroy(ctx);
+            dp_ctx_destroy(ctx), ctx = nullptr;
             return lstats[t].rc;
         }
     if (stats) {
@@ -1204,7 +1238,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
              (long long)multiple, (long long)total, (long long)unmapped);
     errText += line;
     const double tEnd0 = wallNow();
-    dp_ctx_destroy(ctx);
+    dp_ctx_destroy(ctx), ctx = nullptr;
     if (prof) fprintf(stderr, "[map end] text joined in %.1f ms, context destroyed in %.1f, whole run %.1f\n", 1e3 * (tEnd0 - tText0), 1e3 * (wallNow() - tEnd0), 1e3 * (wallNow() - tRun0));
     return 0;
 }

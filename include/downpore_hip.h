@@ -68,7 +68,7 @@ DP_API void dp_ctx_destroy(dp_ctx* ctx);
 /* The device blocks (from 4 KiB on) and pinned host buffers of a destroyed context stay parked in a process-wide cache, so that the
  * next context - the next `map` run, the next job's index build - does not pay the driver for them again (a context holds some eighty
  * of them; releasing four contexts one hipFree at a time was a quarter of a config-3 `map` run).  What stays parked once the context
- * that owned the reads has gone is capped: DP_DEV_CACHE_MB (default 4096) and DP_PIN_CACHE_MB (default 2048).  This call gives
+ * that owned the reads has gone is capped: DP_DEV_CACHE_MB (default 16384) and DP_PIN_CACHE_MB (default 2048).  This call gives
  * everything parked back to the driver and returns the bytes released; safe at any time.  (Infrastructure of the device path: the
  * reference, a CPU program, has no counterpart.) */
 DP_API int64_t dp_release_device_caches(void);
@@ -85,6 +85,19 @@ DP_API int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t* off
  * query window on both strands (mapping.go:497-499); the reverse strands are produced by the pack kernel instead of
  * being built on the host and sent over PCIe. */
 DP_API int dp_reads_upload_rc(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads, uint32_t first_paired);
+/* dp_reads_upload_rc that returns while the reads still travel (round 5: `map` maps its first reads while its last ones are on the link -
+ * 400 MB of ASCII are 11 ms of a 59 ms config-3 run).  The call itself makes the new read set's tables resident and returns once host
+ * reads [0, ready_first) are packed on the device, both strands; a thread of the library sends the rest on piece by piece, on a stream
+ * of its own, and packs every read as soon as its bases have arrived.  `bases` must stay valid until dp_reads_upload_wait(ctx,
+ * 0xffffffff) has returned.  Kernels that read packed reads (dp_scan and everything behind it) may only be given reads a wait has
+ * covered.  Contexts made with dp_ctx_create_shared may be created while the upload runs.  Reference: the same as dp_reads_upload_rc
+ * (sequence/seqio.go:106 `readFasta` + sequence/sequence.go:59-80 `packBytes`; the reverse strands: sequence.go:185-189). */
+DP_API int dp_reads_upload_rc_begin(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads, uint32_t first_paired,
+                                    uint32_t ready_first);
+/* Blocks until host reads [0, host_read_hi) of a dp_reads_upload_rc_begin are packed on the device (at once when no upload is pending).
+ * Callable from any thread, on the owner or on a context that borrows its reads.  host_read_hi = 0xffffffff (owner only): until the
+ * whole set is resident and the library's thread has ended; returns the upload's error, if it had one. */
+DP_API int dp_reads_upload_wait(dp_ctx* ctx, uint32_t host_read_hi);
 /* Copy back the packed bytes of one read (ceil(len/4) bytes) — test hook. */
 DP_API int dp_reads_packed(dp_ctx* ctx, uint32_t read, uint8_t* out, uint64_t cap, uint64_t* n_bytes);
 DP_API uint32_t dp_reads_count(const dp_ctx* ctx);

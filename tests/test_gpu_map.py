@@ -76,13 +76,17 @@ def test_map_threads_reads_in_flight_and_parked_blocks(monkeypatch):
     from downpore_amd.hip import load_library
     lib = load_library()
     lib.dp_release_device_caches.restype = C.c_int64
-    args = (5, 300000, 2100, 9000, 0.10, True, False)   # (more than 2 048 reads: the thread count is not clamped to one)
+    args = (5, 300000, 2600, 9000, 0.10, True, False)
+    monkeypatch.setenv("DP_MAP_MIN_READS_PER_THREAD", "300")   # (2 048 by default: these reads would all go to one thread)
     _case(*args)
     assert lib.dp_release_device_caches() > 0
     assert lib.dp_release_device_caches() == 0
-    for threads, inflight in (("1", "64"), ("2", "500"), ("4", "100000")):
+    # the reads are dealt to the threads in blocks of 1 024 and travel to the device while the first ones are mapped (round 5,
+    # dp_reads_upload_rc_begin; DP_MAP_ASYNC_UPLOAD=0: all of them first): one thread, more threads than blocks, windows per call
+    for threads, inflight, asyn in (("1", "64", "1"), ("2", "500", "1"), ("4", "100000", "1"), ("3", "700", "0"), ("8", "2730", "1")):
         monkeypatch.setenv("DP_MAP_THREADS", threads)
         monkeypatch.setenv("DP_MAP_INFLIGHT", inflight)
+        monkeypatch.setenv("DP_MAP_ASYNC_UPLOAD", asyn)
         _case(*args)
     from downpore_amd.overlap import load_host
     H = load_host()
