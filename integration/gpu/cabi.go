@@ -131,6 +131,35 @@ func (c *Context) UploadReadsRC(bases []byte, off []int64, firstPaired int) erro
 	return nil
 }
 
+// UploadReadsRCBegin is UploadReadsRC that returns while the reads still travel: the read set's tables are resident and host reads
+// [0, readyFirst) packed when it returns, a thread of the library sends the rest on.  `bases` must stay alive (and unmoved: pass memory
+// the Go collector does not manage, or keep it pinned with runtime.Pinner) until WaitReads(-1) has returned; kernels may only be given
+// reads a WaitReads has covered.
+func (c *Context) UploadReadsRCBegin(bases []byte, off []int64, firstPaired, readyFirst int) error {
+	var bp *C.uint8_t
+	if len(bases) > 0 {
+		bp = (*C.uint8_t)(unsafe.Pointer(&bases[0]))
+	}
+	rc := C.dp_reads_upload_rc_begin(c.h, bp, (*C.int64_t)(unsafe.Pointer(&off[0])), C.uint32_t(len(off)-1), C.uint32_t(firstPaired), C.uint32_t(readyFirst))
+	if rc != 0 {
+		return fail(c.h, "dp_reads_upload_rc_begin", rc)
+	}
+	return nil
+}
+
+// WaitReads blocks until host reads [0, upTo) of an UploadReadsRCBegin are packed on the device; upTo < 0: the whole set (ends the
+// library's upload thread and returns its error, if it had one - call it on the context that owns the reads).
+func (c *Context) WaitReads(upTo int) error {
+	hi := C.uint32_t(0xffffffff)
+	if upTo >= 0 {
+		hi = C.uint32_t(upTo)
+	}
+	if rc := C.dp_reads_upload_wait(c.h, hi); rc != 0 {
+		return fail(c.h, "dp_reads_upload_wait", rc)
+	}
+	return nil
+}
+
 // KmerValues replaces the "Counting all k-mers ... Counting complete" block of the commands: the value table (4^k float64).
 func (c *Context) KmerValues(k int) ([]float64, error) {
 	out := make([]float64, 1<<uint(2*k))
