@@ -167,6 +167,7 @@ struct dp_ctx {
     bool q_pre_fetched = false;                    // ... and a launch has brought it to d_qsegs
     uint64_t last_sints = 0;                       // scratch ints of the last chaining stage (all pairs' columns)
     bool chains_packed = true;                     // false: the final chains sit in the scratch columns (d_sa/d_sb), see ChainArgs.pack
+    uint32_t chain_open_ahead[2] = {~0u, ~0u};     // pairs still open ahead of proposal pass 1 / pass 2 in this context's previous chaining stage (~0: unknown)
     int last_k = 0;
     bool find_valid = false;                       // the device still holds that call's records
     PinBuf h_mrec, h_ma, h_mb, h_ta, h_tb, h_qm, h_qup, h_cursor, h_cand, h_cand_off, h_cand_list, h_mq, h_mt, h_moff, h_manchor, h_manout;

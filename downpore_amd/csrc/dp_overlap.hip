@@ -1234,11 +1234,15 @@ struct CWave {
 };
 
 // The reg tier's working set alone, a quarter of CWave: the proposal pass (chain_spec_kernel) runs one wave per PAIR and is
-// bound by how many waves a CU holds.  Pairs that do not fit (query > 128 seeds, reduced a > 64, > 128 b events, a chain
-// longer than 32, more than 64 open chains, target > C_BCAP ints) are left to the final walk, which has the full CWave.
+// bound by how many waves a CU holds.  Pairs that do not fit (query > 128 seeds, reduced a > 64, > 128 b events, more than
+// 32 open chains, target > C_BCAP ints) get no proposal here: the later passes and the final walk have the full CWave.
 struct CSlim {
     typedef uint16_t col_t;
-    enum { COLN = 32, EVN = 128, ACAP = 256, RSEEDS = 64, SLIM = 1, ROWS = 64, BCAP = C_BCAP };
+    // (round 6: 32 open chains of up to 64 links instead of 64 of up to 32 - the same 4 KB.  In the dense regime (k = 10) a query
+    // window holds 40-60 seeds and its real overlaps are chains of 33-60 links with two or three chains open: ~190 pairs a round did
+    // not fit, their queries stopped at them in every pass and the final walk chained those queries' tails one pair after another -
+    // 400 of a round's 670 us of chaining, profiles/r06/k10_chain_phases_slots1.txt)
+    enum { COLN = 64, EVN = 128, ACAP = 256, RSEEDS = 64, SLIM = 1, ROWS = 32, BCAP = C_BCAP };
     int32_t aRed[2 * 64 + 2];
     int32_t aMap[64];
     int32_t aSegL[256];
@@ -1246,31 +1250,6 @@ struct CSlim {
     u64 bFlag[C_BCAP / 128 + 1];
     union {
         int32_t bSegL[C_BCAP];  // dead once the b events are built
-        col_t col[64][COLN];
-    };
-    int4 ev[EVN];
-    int32_t ps[64];
-    uint32_t rescol[64];
-};
-
-// Round 4 - a third of CSlim again, for the stage whose queries are `downpore overlap` windows at a sparse k (at most 31 seeds: the
-// host picks the layout per stage from the longest query): 3.2 KB per wave.  chain_spec_kernel's 1 024 workgroups of four CSlim waves
-// took 35 of the chip's 41 MB of LDS for as long as a pass lasted - every other round's kernels that want LDS (consensus, index
-// query, the walks) waited for it.  With this layout a pass holds 13 MB, and the walk kernel's one wave per query costs 13 KB per
-// workgroup instead of 35.  (Measured: 0.156 against 0.16-0.17 ms per round on a noisy box - within the noise; the waves per CU are
-// bound by the kernel's 112 VGPRs either way.)
-// What does not fit (a target of more than 159 seeds, more than 48 b events, more than 16 open chains, a chain longer than 32) is left
-// to the final walk exactly as with CSlim.
-struct CTiny {
-    typedef uint16_t col_t;
-    enum { COLN = 32, EVN = 48, ACAP = 64, RSEEDS = 32, SLIM = 1, ROWS = 16, BCAP = 320 };
-    int32_t aRed[2 * 32 + 2];
-    int32_t aMap[32];
-    int32_t aSegL[64];
-    u64 aFlag[2];
-    u64 bFlag[BCAP / 128 + 1];
-    union {
-        int32_t bSegL[BCAP];  // dead once the b events are built
         col_t col[ROWS][COLN];
     };
     int4 ev[EVN];
@@ -1543,7 +1522,7 @@ __device__ int pairwise_align(const int32_t* aSeg, int aN, const int32_t* bSeg, 
 // (length + remaining < minMatches), so minMatches is constant until the break itself.
 
 // prepareInitial :341-388.  Returns 0; 1 when the reference would overrun `reduced` (err bit 1); 2 when the layout's staging arrays
-// are too small for a reduced a the reference can hold (CSlim / CTiny: the pair is left to the full-size path; CWave: to the one-lane
+// are too small for a reduced a the reference can hold (CSlim: the pair is left to the full-size path; CWave: to the one-lane
 // transcription, whose reduced a may live in the wave's spill area).
 template <class LW>
 __device__ int wave_prepare_initial(int aN, int minMatches, int k, int maxLength, LW& L, int* aLenOut, int* startOut) {
@@ -1694,7 +1673,7 @@ __device__ int wave_chain_reg(int aLen, int startSize, int bN, int minMatches, i
     // known without walking: nE extensions of chain 0, no removal, results[0] = that chain iff nE >= minMatches (the ratchet
     // only raises minMatches to 2 nE / 3 <= nE).  Anything else: the walk.
     int why = 0;  // (profiling: 0 size limits, 1 event 0 starts no or several chains, 2 start not allowed any more, 3 seed / gap, 4 second start)
-    if (!walkAlways && nE >= 2 && nE <= 64 && nE <= (int)LW::COLN && startSize + nE <= C_POOLSTATES) {
+    if (!walkAlways && nE >= 2 && nE <= 64 && startSize + nE <= C_POOLSTATES) {  // (rescol holds 64 pairs in every layout)
         why = 1;
         const int4 myEv = lane < nE ? L.ev[lane] : make_int4(0, 0, -2, 0);  // {bIndex, bOffset, seed, gap after}
         const u64 m0 = __ballot(myA == RL(myEv.z, 0)) & initMask;
@@ -2292,7 +2271,7 @@ struct ChainArgs {
     uint32_t pair_cap;
     u64 sint_cap;
     uint32_t int_cap;
-    uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [8 + pass] "a query is open" flags, [16..19] totals, [32 ..] 64 shards of the algorithmic bytes (u64)
+    uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [8 + pass] "a query is open" flags, [16..19] totals, [24 + 2 * pass + (q & 1)], pass 0 / 1: pairs left open by the pass's resolve step, [32 ..] 64 shards of the algorithmic bytes (u64)
     uint32_t* qdone;     // [nq] pairs of the query a speculative pass has finished (resolve fused into it), or nullptr
     int walk_always;      // DP_CHAIN_PERFECT=0 (tests): no pair takes the perfect-chain shortcut of wave_chain_reg
     int pack;             // 1: final chains are copied into ma/mb, densely (what a host fetch wants); 0: they stay where they were
@@ -2302,6 +2281,7 @@ struct ChainArgs {
     uint32_t walk0_blocks; // grid of its slim form (mode 0)
     uint32_t n_refs;      // entries of refs[] (indexed sequences, or their upper bound)
     uint32_t prof_walk_slot;   // first per-wave slot of walk(0) in prof[] (behind the passes')
+    uint32_t prof_stride;      // per-wave slots of one pass
     unsigned long long* prof;  // DP_CHAIN_PROF=1: [0] pairs looked at, [1] chained, [2..6] wall-clock ticks (100 MHz) per phase of chain_spec_kernel
 };
 
@@ -2490,10 +2470,10 @@ __device__ int chain_pair(LW& L, CNode* __restrict__ nodes, const ChainArgs& A, 
 // SLIM (mode 0 only): the speculative kernel's 8.6 KB layout, one wave per query with sixteen of them on a CU instead of four
 // (a round's ~1 300 queries are then all resident at once: 45 -> 2x us); a pair that needs the full layout stops its query there
 // - it stays open, the proposal passes skip it and the final walk (full layout) chains it.
-// LY: 0 = the full layout (CWave), 1 = CSlim, 2 = CTiny (mode 0 only, as CSlim)
+// LY: 0 = the full layout (CWave), 1 = CSlim (mode 0 only)
 template <int LY>
 struct chain_walk_kernel {
-    typedef typename std::conditional<LY == 0, CWave, typename std::conditional<LY == 1, CSlim, CTiny>::type>::type LW;
+    typedef typename std::conditional<LY == 0, CWave, CSlim>::type LW;
     enum { SLIM = LY != 0, WAVES = SLIM ? S_WAVES : C_WAVES, THREADS = 64 * WAVES };
     static __device__ void run(const ChainArgs A, const int mode) {
     __shared__ LW sh[WAVES];
@@ -2522,10 +2502,10 @@ struct chain_walk_kernel {
     for (uint32_t q = gw; q < A.nq; q += waves) {
         if (wprof) tprev = wall_clock64();
         const uint32_t cnt = A.qcnt[q];
-        if (cnt == 0) continue;
-        const uint32_t pb = A.pbase[q];
         const int aN = RFL((int)(A.qoff[q + 1] - A.qoff[q]));
         const uint32_t nSeeds = (uint32_t)aN / 2;
+        if (cnt == 0) continue;
+        const uint32_t pb = A.pbase[q];
         const u64 ib = A.ibase[q];
         if ((u64)pb + cnt > (u64)A.pair_cap || ib + (u64)cnt * nSeeds > A.sint_cap) {
             if (lane == 0) A.cursor[3] = 1;
@@ -2604,7 +2584,13 @@ struct chain_walk_kernel {
                 break;  // needs chaining with a minMatches nobody proposed for: the next spec pass does it
             } else {
                 len = chain_pair(L, nodes, A, aSeg, aN, aStaged, qs, qset, t, mm, ca, cb, haveMask, aMask, nullptr, wprof ? &pf : (ChainProf*)nullptr);
-                if (SLIM && len < 0) break;  // needs the full layout: the query stays open at this pair
+                if (SLIM && len < 0) {  // needs the full layout: the query stays open at this pair (marked: slim passes skip it)
+                    if (lane == 0) {
+                        PSpec o = {c, -2, 0, 0};
+                        A.pspec[p] = o;
+                    }
+                    break;
+                }
                 chained = true;
                 pf.chained++;
                 WK_TICK(pair)
@@ -2662,17 +2648,19 @@ struct chain_walk_kernel {
 
 __device__ void chain_resolve_query(const ChainArgs& A, uint32_t q, int lane);
 
-// one wave per open pair: prefilter + chain with the minMatches its query has reached; stored as a proposal
-template <bool TINY>
+// one wave per open pair: prefilter + chain with the minMatches its query has reached; stored as a proposal.
+// (Round 6: the later passes on the full layout - four waves a CU, every pair the slim layout cannot hold chained in parallel instead of
+// by the final walk - were built and measured SLOWER at k = 13 and at k = 10, profiles/r06/ab_launch_diet_k13.txt, ab_full_from_k10.txt:
+// workgroups that want 131 KB of a CU's LDS are placed late.  What made the difference was the slim layout's geometry, see CSlim.)
 struct chain_spec_kernel {
-    typedef typename std::conditional<TINY, CTiny, CSlim>::type LW;
-    enum { THREADS = 64 * S_WAVES };
+    typedef CSlim LW;
+    enum { WAVES = S_WAVES, THREADS = 64 * WAVES };
     static __device__ void run(const ChainArgs A, const u64* __restrict__ totals) {
-    __shared__ LW sh[S_WAVES];
+    __shared__ LW sh[WAVES];
     LW& L = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
-    const uint32_t waves = gridDim.x * S_WAVES;
-    const uint32_t gw = blockIdx.x * S_WAVES + (threadIdx.x >> 6);
+    const uint32_t waves = gridDim.x * WAVES;
+    const uint32_t gw = blockIdx.x * WAVES + (threadIdx.x >> 6);
     // (a query that did not fit the buffers left its pairs' pq / clist unwritten: the host repeats the stage with larger ones)
     if (A.cursor[3] != 0 || A.cursor[8 + A.pass] == 0) return;  // ... or no query is open any more
     const uint32_t total = (uint32_t)min(totals[0], (u64)A.pair_cap);
@@ -2707,6 +2695,7 @@ struct chain_spec_kernel {
         if (i < st.next) continue;  // final already
         const int mm = RFL(st.mm);
         if (RFL(sp.mm) == mm) continue;
+        if (RFL(sp.mm) == -2) continue;  // (an earlier pass found that this pair needs the full layout: the final walk's)
         const int aN = RFL((int)(qo1 - qo0));
         const uint32_t nSeeds = (uint32_t)aN / 2;
         if (ib + (u64)cnt_ * nSeeds > A.sint_cap) continue;  // (flagged by the walk)
@@ -2734,9 +2723,9 @@ struct chain_spec_kernel {
             pf.chained++;
             len = chain_pair(L, (CNode*)nullptr, A, aSeg, aN, aStaged, qs, qset, t, mm, A.sa + ib + (u64)i * nSeeds, A.sb + ib + (u64)i * nSeeds,
                              haveMask, aMask, &rT, (DP_PROFILING && A.prof) ? &pf : (ChainProf*)nullptr);
-            if (len < 0) {  // does not fit the slim layout: no proposal, the final walk chains it
+            if (len < 0) {  // does not fit the slim layout: no proposal (-2: no slim pass tries again), the final walk chains it
                 len = 0;
-                pmm = -1;
+                pmm = -2;
             }
         }
         SP_TICK(pair)  // chain_pair
@@ -2746,27 +2735,9 @@ struct chain_spec_kernel {
         }
         __builtin_amdgcn_wave_barrier();
         } while (0);
-        if (A.qdone) {
-            // the resolve step of the query, by whichever wave finishes the last of its pairs (instead of a launch of its own
-            // after every pass): each pair counts itself in once its proposal and chain are out (release), the wave that counts
-            // the last one sees them all (acquire) and replays the ratchet.  qdone[q] goes back to 0 for the next pass.
-            uint32_t last = 0;
-            if (lane == 0) {
-                const uint32_t slots = A.pbase[q + 1] - A.pbase[q];
-                const uint32_t seen = __hip_atomic_fetch_add(&A.qdone[q], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-                last = seen == slots ? 1u : 0u;
-                if (last) __hip_atomic_store(&A.qdone[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            last = (uint32_t)__shfl((int)last, 0, 64);
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                chain_resolve_query(A, q, lane);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
     }
     if ((DP_PROFILING && A.prof) && lane == 0) {
-        unsigned long long* slot = A.prof + 16 * ((size_t)A.pass * waves + gw);
+        unsigned long long* slot = A.prof + 16 * ((size_t)A.pass * A.prof_stride + gw);
         slot[0] = pf.pairs, slot[1] = pf.chained, slot[2] = pf.rec, slot[3] = pf.stagea, slot[4] = pf.pre, slot[5] = pf.pair;
         slot[6] = pf.stageb, slot[7] = pf.initial, slot[8] = pf.walk, slot[9] = pf.out;
         slot[10] = tkernel0;
@@ -2873,7 +2844,10 @@ __device__ void chain_resolve_query(const ChainArgs& A, uint32_t q, int lane) {
         QState o = {mm, next};
         A.qstate[q] = o;
         if (ab) atomicAdd((unsigned long long*)(A.cursor + 32) + (q & 63u), ab);
-        if (next < cnt) A.cursor[9 + A.pass] = 1u;  // still open: the next pass has work (a flag)
+        if (next < cnt) {
+            A.cursor[9 + A.pass] = 1u;  // still open: the next pass has work (a flag)
+            if (A.pass < 2) atomicAdd(&A.cursor[24 + 2 * A.pass + (q & 1u)], cnt - next);  // (what the host sizes the next round's passes by)
+        }
     }
 }
 
@@ -3082,14 +3056,6 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     uint32_t* d_pbase = (uint32_t*)(d_ibase + nq + 1);
     QState* d_qstate = (QState*)(d_pbase + nq + 1 + ((nq + 1) & 1));
     uint32_t* d_qdone = (uint32_t*)(d_qstate + nq);
-    // DP_CHAIN_FUSE=1: the resolve step inside the speculative kernel (last wave of a query) instead of a launch of its own.
-    // Bit-identical, three launches fewer per round - and twice as slow (0.73 against 0.38 ms per round): every pair then pays an
-    // agent-scope release and the resolving wave an acquire, i.e. L2 write-backs and invalidates across the eight XCDs, seven
-    // thousand times per pass.  Off.
-    static const bool fuse_resolve = [] {
-        const char* e = getenv("DP_CHAIN_FUSE");
-        return e && e[0] == '1';
-    }();
     {
         // (a stage left pending is read by the consensus kernel before anybody knows whether it fitted its buffers: records the
         // stage did not write must at least be harmless - all-zero when the buffer is new, those of an earlier round otherwise)
@@ -3157,45 +3123,33 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     A.n_refs = std::max<uint32_t>(1, ctx->n_seqs);
     A.prof = nullptr;
     A.prof_walk_slot = 0;
+    A.prof_stride = 0;
     static const bool chain_prof = getenv("DP_CHAIN_PROF") != nullptr;
     if (chain_prof) {
         const size_t pb = ((size_t)st.passes * st.spec_blocks * S_WAVES + (size_t)A.walk0_blocks * S_WAVES) * 128;
         if (dev_reserve(ctx, ctx->d_sched, pb + 128)) return DP_ERR_HIP;
         A.prof = (unsigned long long*)ctx->d_sched.p;
         A.prof_walk_slot = (uint32_t)(st.passes * st.spec_blocks * S_WAVES);
+        A.prof_stride = st.spec_blocks * S_WAVES;
         DP_HIP(hipMemsetAsync(A.prof, 0, pb, ctx->stream));
     }
-    A.qdone = fuse_resolve ? d_qdone : nullptr;
+    A.qdone = nullptr;
     if (st.attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, C_CURSOR_BYTES, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
     DP_HIP(dp_mark(ctx, 6));
     if (!(st.scan_fused && st.attempt == 0))  // (a repeated attempt - larger buffers - scans again: the cursor block was cleared)
         dp_launch<pair_scan_kernel>(ctx, dim3(1), dim3(1024), (const uint32_t*)st.d_qcnt, ctx->qoff_dev, nq, d_pbase, d_ibase,
                            d_totals, d_qdone);
-    // mode 0 on the slim layout (DP_WALK0_SLIM=0: the full one; a forced tier is the full layout's business)
-    static const bool walk0_slim = [] {
-        const char* e = getenv("DP_WALK0_SLIM");
-        return !(e && e[0] == '0');
-    }();
-    // DP_CHAIN_TINY=1: the tiny layout where every query of the stage fits it (mc_n - 1 >= the longest query's seeds).  Off by
-    // default: alone on the GPU its kernels are SLOWER than CSlim's (one-slot timeline, profiles/r04/round_timeline_one_slot*.txt:
-    // walk 35 against 25 us, passes 37 / 25 / 8 against 29 / 18 / 8) and with five slots the job rate is the same - the LDS it
-    // frees was not what the other rounds' kernels were waiting for.
-    const char* te = getenv("DP_CHAIN_TINY");  // (read per call: tests switch it between jobs of one process)
-    const bool tiny = te && te[0] == '1' && A.mc_n <= 32;
-    // (the same 1 024 workgroups: at 112 VGPRs a CU holds sixteen of these waves whatever their LDS - twice the workgroups
-    // measured 5 % slower, profiles/r04/ab_tiny.txt - but they now leave 108 KB of every CU's LDS to the other rounds' kernels)
+    // mode 0 on the slim layout (a forced tier is the full layout's business)
     const uint32_t spec_blocks = st.spec_blocks;
-    if (walk0_slim && A.tier == 0 && st.passes > 0) {
-        if (tiny) dp_launch<chain_walk_kernel<2>>(ctx, dim3(A.walk0_blocks), dim3(64 * S_WAVES), A, 0);
-        else dp_launch<chain_walk_kernel<1>>(ctx, dim3(A.walk0_blocks), dim3(64 * S_WAVES), A, 0);
+    if (A.tier == 0 && st.passes > 0) {
+        dp_launch<chain_walk_kernel<1>>(ctx, dim3(A.walk0_blocks), dim3(64 * S_WAVES), A, 0);
     } else {
         dp_launch<chain_walk_kernel<0>>(ctx, dim3(st.walk_blocks), dim3(64 * C_WAVES), A, 0);
     }
     for (int ps = 0; ps < st.passes; ps++) {
         A.pass = ps;
-        if (tiny) dp_launch<chain_spec_kernel<true>>(ctx, dim3(spec_blocks), dim3(64 * S_WAVES), A, (const u64*)d_totals);
-        else dp_launch<chain_spec_kernel<false>>(ctx, dim3(spec_blocks), dim3(64 * S_WAVES), A, (const u64*)d_totals);
-        if (!fuse_resolve) dp_launch<chain_resolve_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), A);
+        dp_launch<chain_spec_kernel>(ctx, dim3(spec_blocks), dim3(64 * S_WAVES), A, (const u64*)d_totals);
+        dp_launch<chain_resolve_kernel>(ctx, dim3(std::min<uint32_t>(1024, (nq + 3) / 4)), dim3(256), A);
     }
     A.pass = st.passes;
     // the final walk rarely has a query to do after the passes: a quarter of the workgroups (each wants 128 KB of a CU's LDS before it
@@ -3309,6 +3263,8 @@ static int chain_finish(dp_ctx* ctx, FindState& st) {
             st.query_bytes += words[q] * 8;
         }
     }
+    ctx->chain_open_ahead[0] = st.passes >= 1 ? st.cur[24] + st.cur[25] : ~0u;
+    ctx->chain_open_ahead[1] = st.passes >= 2 ? st.cur[26] + st.cur[27] : ctx->chain_open_ahead[0];
     uint64_t tp = 0;
     memcpy(&tp, &st.cur[16], 8);
     ctx->n_pairs = (uint32_t)tp;
@@ -3408,6 +3364,10 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     st.chain_tier = tier_env ? atoi(tier_env) : 0;
     const char* pass_env = getenv("DP_CHAIN_PASSES");  // proposal passes (0 = the serial walk alone: the round-1 behaviour)
     st.passes = pass_env ? std::max(0, std::min(6, atoi(pass_env))) : 3;
+    // (round 6) a proposal pass is two launches, and a launch costs a round with other rounds beside it 1.5 - 1.9 us whatever it does:
+    // the third pass is only launched when this context's previous stage left it something to do (at k = 13 it sees ~18 pairs, which the
+    // final walk chains as well - bit-identical for any number of passes, tests run 0, 1 and 3)
+    if (!pass_env && ctx->chain_open_ahead[1] < 64u) st.passes = 2;
     st.walk_blocks = std::min<uint32_t>(256, (nq + C_WAVES - 1) / C_WAVES);
     st.spec_blocks = 1024;  // 4096 persistent waves, 16 per CU: what CSlim's 8.5 KB per wave lets a CU hold
     if (const char* e = getenv("DP_SPEC_BLOCKS")) st.spec_blocks = (uint32_t)std::max(1, atoi(e));
