@@ -686,7 +686,7 @@ struct kidx_walk {
 //                   behind the bins.
 // A bin that is full (sized from the previous round: 1.5 x its hits) counts the rest of its hits the old way and raises the flag
 // that sends the round's fill pass to the bucket-walking form (dp_kindex_refill + dp_kindex_write) - counts are right either way.
-#define KX_MAXBINS 1024
+#define KX_MAXBINS 2048
 #define KXB_SEED_BITS 22
 #define KXB_RIB_BITS 14
 struct KxBins {
@@ -699,6 +699,7 @@ struct KxBins {
     uint32_t xcap;
     const uint8_t* ign;       // the walk's short cut (dp_kindex_fast), or null
     uint32_t qlo, qspan;
+    uint32_t batch;           // trips of a walk workgroup that share one reservation per bin (1; the dense regime: 8)
 };
 static_assert(KXB_SEED_BITS + KXB_RIB_BITS + 24 <= 64, "a binned hit record is one 64-bit word");
 static_assert((1u << KXB_RIB_BITS) * 4 <= 65536, "a bin's counters live in one workgroup's LDS");
@@ -822,58 +823,81 @@ struct kidx_walk_bin {
         __shared__ unsigned long long sh_hits;
         const int lane = dp_lane();
         const uint32_t stride = gridDim.x * WAVES;
+        // B.batch trips of the workgroup share one reservation per bin (round 6, the dense regime: a seed's bucket holds a thousand
+        // entries, a workgroup trip 2 - 4 seeds - a few records per bin and trip, each stretch a returning atomic and a short run of
+        // stores; eight trips a reservation are eight times fewer atomics and runs eight times as long).  Trips behind the first read
+        // their entries again in the second pass (from the L2).
+        const uint32_t T = max(1u, B.batch);
+        // the groups of kidx_walk: KX_PARTS waves per seed (dense seeds), or four seeds per wave
+        struct Grp {
+            uint32_t s, i0, i1, step, gfirst;
+            uint64_t o;
+            bool gleader;
+        };
+        auto group_of = [&](uint32_t w) {
+            Grp g = {0u, 0u, 0u, 16u, 0u, 0ull, false};
+            if (w < n_waves) {
+                if (lps == 64) {
+                    g.s = w / KX_PARTS;
+                    if (g.s < n_seeds) {
+                        const uint32_t part = w % KX_PARTS;
+                        g.o = off[seeds[g.s]];
+                        const uint32_t n = (uint32_t)(off[(uint64_t)seeds[g.s] + 1] - g.o);
+                        const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
+                        g.gfirst = min(n, part * per);
+                        g.i0 = part * per + 4u * (uint32_t)lane;
+                        g.i1 = min(n, part * per + per);
+                        g.step = 64;
+                        g.gleader = lane == 0;
+                    }
+                } else {
+                    g.s = w * 4 + ((uint32_t)lane >> 4);
+                    if (g.s < n_seeds) {
+                        g.o = off[seeds[g.s]];
+                        g.i0 = 4u * ((uint32_t)lane & 15u);
+                        g.i1 = (uint32_t)(off[(uint64_t)seeds[g.s] + 1] - g.o);
+                        g.gleader = (lane & 15) == 0;
+                    }
+                }
+            }
+            return g;
+        };
         // (every wave of a workgroup makes the same number of trips: the barriers below are the workgroup's)
-        for (uint32_t wb = blockIdx.x * WAVES; wb < n_waves; wb += stride) {
+        for (uint32_t wb = blockIdx.x * WAVES * T; wb < n_waves; wb += stride * T) {
             for (uint32_t t = threadIdx.x; t < B.n_bins; t += THREADS) hist[t] = 0u;
             if (threadIdx.x == 0) {
                 sh_hits = 0ull;
                 xs[0] = xs[1] = 0u;
             }
             __syncthreads();
-            const uint32_t w = wb + (threadIdx.x >> 6);
-            // the groups of kidx_walk: KX_PARTS waves per seed (dense seeds), or four seeds per wave
-            uint32_t s = 0, i0 = 0, i1 = 0, step = 16, gfirst = 0;
-            uint64_t o = 0;
-            bool gleader = false;
-            if (w < n_waves) {
-                if (lps == 64) {
-                    s = w / KX_PARTS;
-                    if (s < n_seeds) {
-                        const uint32_t part = w % KX_PARTS;
-                        o = off[seeds[s]];
-                        const uint32_t n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
-                        const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
-                        gfirst = min(n, part * per);
-                        i0 = part * per + 4u * (uint32_t)lane;
-                        i1 = min(n, part * per + per);
-                        step = 64;
-                        gleader = lane == 0;
-                    }
-                } else {
-                    s = w * 4 + ((uint32_t)lane >> 4);
-                    if (s < n_seeds) {
-                        o = off[seeds[s]];
-                        i0 = 4u * ((uint32_t)lane & 15u);
-                        i1 = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
-                        gleader = (lane & 15) == 0;
-                    }
-                }
-            }
-            if (gleader && i1 > gfirst) atomicAdd(&sh_hits, (unsigned long long)(i1 - gfirst));
-            // the lane's first four entries stay in registers across the barriers (a seed of config 2 has 20 - 60 entries: for most groups
-            // the first trip is the only one, and the second pass reads nothing); later trips are read again (from the L2)
+            // the lane's first four entries of the FIRST trip stay in registers across the barriers (a seed of config 2 has 20 - 60
+            // entries: for most groups the first trip is the only one, and the second pass reads nothing)
             uint64_t e0[4] = {0, 0, 0, 0};
             bool v0[4] = {false, false, false, false};
-            if (i0 < i1) {
-                kx_entry4(pos, o + i0, e0);
+            for (uint32_t tr = 0; tr < T; tr++) {
+                const uint32_t w = wb + tr * WAVES + (threadIdx.x >> 6);
+                const Grp g = group_of(w);
+                if (g.gleader && g.i1 > g.gfirst) atomicAdd(&sh_hits, (unsigned long long)(g.i1 - g.gfirst));
+                uint64_t e[4] = {0, 0, 0, 0};
+                bool v[4] = {false, false, false, false};
+                if (g.i0 < g.i1) {
+                    kx_entry4(pos, g.o + g.i0, e);
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    v0[u] = i0 + (uint32_t)u < i1;
-                    e0[u] = v0[u] ? e0[u] : 0ull;
+                    for (int u = 0; u < 4; u++) {
+                        v[u] = g.i0 + (uint32_t)u < g.i1;
+                        e[u] = v[u] ? e[u] : 0ull;
+                    }
+                    four<false>(e, v, g.s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
                 }
-                four<false>(e0, v0, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+                if (tr == 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        e0[u] = e[u];
+                        v0[u] = v[u];
+                    }
+                }
+                tail<false>(lps, lane, w, g.s, g.o, g.i0, g.i1, g.step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
             }
-            tail<false>(lps, lane, w, s, o, i0, i1, step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
             __syncthreads();
             for (uint32_t t = threadIdx.x; t < B.n_bins; t += THREADS) {
                 const uint32_t c = hist[t];
@@ -905,8 +929,26 @@ struct kidx_walk_bin {
                 xs[0] = 0u;
             }
             __syncthreads();
-            if (i0 < i1) four<true>(e0, v0, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
-            tail<true>(lps, lane, w, s, o, i0, i1, step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+            for (uint32_t tr = 0; tr < T; tr++) {
+                const uint32_t w = wb + tr * WAVES + (threadIdx.x >> 6);
+                const Grp g = group_of(w);
+                if (g.i0 < g.i1) {
+                    if (tr == 0) {
+                        four<true>(e0, v0, g.s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+                    } else {
+                        uint64_t e[4];
+                        bool v[4];
+                        kx_entry4(pos, g.o + g.i0, e);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            v[u] = g.i0 + (uint32_t)u < g.i1;
+                            e[u] = v[u] ? e[u] : 0ull;
+                        }
+                        four<true>(e, v, g.s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+                    }
+                }
+                tail<true>(lps, lane, w, g.s, g.o, g.i0, g.i1, g.step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+            }
             __syncthreads();
         }
     }
@@ -1281,7 +1323,9 @@ struct kidx_sortwrite {
                                                      const uint64_t* __restrict__ segoff, int32_t* __restrict__ segs, int k,
                                                      uint32_t* __restrict__ overflow, uint32_t n_read_items, uint32_t n_extra,
                                                      uint32_t* __restrict__ head, int32_t* __restrict__ host_segs,
-                                                     const uint64_t* __restrict__ totals, uint64_t seg_cap) {
+                                                     const uint64_t* __restrict__ totals, uint64_t seg_cap, uint32_t extras_only) {
+    // extras_only (the dense regime: kidx_bin_sort_dense has sorted the read items' slices): the round's extra items alone - the last
+    // n_extra entries of the survivor list (every extra item is on it)
     // host_segs (may be null): pinned host mirror of segs[] - the extra items' (query windows') segments are stored there as
     // well, at the same offsets: they are what the host wants of this pass, and no copy has to fetch them afterwards
     __shared__ unsigned long long keys[CAP];
@@ -1292,7 +1336,8 @@ struct kidx_sortwrite {
     // launched without a wait behind the counting step (round 4): the segment buffer was sized from the round before - a round
     // that needs more, or whose records did not fit, is filled and sorted again by the host's second attempt
     const bool gave_up = totals && (totals[0] > seg_cap || (uint32_t)totals[6] != 0u);
-    for (uint32_t sv = blockIdx.x; sv < n_sel && !gave_up; sv += gridDim.x) {
+    const uint32_t sv0 = (extras_only && n_sel >= n_extra) ? n_sel - n_extra : 0u;
+    for (uint32_t sv = sv0 + blockIdx.x; sv < n_sel && !gave_up; sv += gridDim.x) {
         const uint32_t it = sel[sv];
         kx_sort_one<CAP, true>(keys, lane, it, counts[it], segoff[it], (int)items[it].n_kmers, segs, k, overflow, n_read_items, host_segs);
     }
@@ -1388,6 +1433,174 @@ struct kidx_bin_fill_sort {
         for (uint32_t sv = wave; sv < ns; sv += WAVES) {
             const uint32_t i = slist[sv], it = first + i;
             kx_sort_one<CAP, false>(keys[wave], lane, it, cnt[i], segoff[it], (int)items[it].n_kmers, segs, k, overflow, n_read_items, host_segs);
+        }
+    }
+};
+
+// Round 6 - the dense regime (the command's default k = 10: every read holds ~100 seed occurrences, ten million hits a round).  There
+// kidx_bin_fill scattered 8-byte pairs into the reads' slices and kidx_sortwrite, a wave per read, read them back, sorted them and wrote
+// them again: 80 MB of scattered stores, 80 MB read, 80 MB written, a launch of 100 k single-wave workgroups.  Here a bin is small (64
+// reads, ~6 k records) and its workgroup does both in LDS: the bin's records are dealt to their reads' stretches of an LDS array (slot
+// counters in LDS, as kidx_bin_fill's), a wave per read ranks its stretch (every key counts the keys below it - broadcast reads, no
+// scratch: the ranks wait in registers until the wave has read everything) and the stretch goes out as [gap, seed, ..., gap],
+// contiguous per read and per bin.  A bin with more records than the array holds takes its reads in groups (one more pass over the
+// bin's records per group - the bins of the round's query reads).  A read with more than MAXC hits raises the overflow word, as a
+// survivor beyond the sort pass's capacity always did (the host repeats fill + sort with the right tier).
+// The blocks behind the bins fill the extra items' slices from their list, as kidx_bin_fill's; kidx_sortwrite(extras_only) sorts those.
+template <int CAP>
+struct kidx_bin_sort_dense {
+    enum { THREADS = 512, WAVES = 8, RBMAX = 256, XBLOCKS = 8, MAXC = 1024, RPL = MAXC / 64 };
+    // c <= 64 R keys of one read, sorted in place by one wave: every key counts the keys below it (broadcast reads of the stretch), the
+    // ranks wait in registers until the wave has read everything, then the keys go to their ranks
+    template <int R>
+    static __device__ __forceinline__ void rank_in_place(unsigned long long* my, const uint32_t c, const int lane) {
+        unsigned long long key[R];
+        uint32_t rk[R];
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            const uint32_t j = (uint32_t)lane + 64u * (uint32_t)u;
+            key[u] = j < c ? my[j] : ~0ull;
+            rk[u] = 0u;
+        }
+        uint32_t l = 0;
+        for (; l + 8 <= c; l += 8) {  // (eight broadcast reads in flight: one read at a time is a trip through the LDS per key)
+            unsigned long long o[8];
+#pragma unroll
+            for (int x = 0; x < 8; x++) o[x] = my[l + x];
+#pragma unroll
+            for (int x = 0; x < 8; x++) {
+#pragma unroll
+                for (int u = 0; u < R; u++) rk[u] += o[x] < key[u] ? 1u : 0u;
+            }
+        }
+        for (; l < c; l++) {
+            const unsigned long long o = my[l];
+#pragma unroll
+            for (int u = 0; u < R; u++) rk[u] += o < key[u] ? 1u : 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < R; u++) {
+            const uint32_t j = (uint32_t)lane + 64u * (uint32_t)u;
+            if (j < c) my[rk[u]] = key[u];  // (positions are distinct: the ranks are a permutation)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    static __device__ void run(const KxBins B, const dp_scan_item* __restrict__ items, uint32_t n_read_items,
+                               const uint32_t* __restrict__ counts, uint32_t* __restrict__ fillc, const uint64_t* __restrict__ segoff,
+                               int32_t* __restrict__ segs, const uint64_t* __restrict__ totals, uint64_t seg_cap, int k,
+                               uint32_t* __restrict__ overflow) {
+        __shared__ unsigned long long recs[CAP];
+        __shared__ uint32_t cnt[RBMAX], offs[RBMAX + 1], cur[RBMAX], nks[RBMAX];
+        __shared__ unsigned long long sout[RBMAX];
+        __shared__ uint32_t g_hi_s;
+        if (B.flags[0] || totals[0] > seg_cap) return;  // (the host repeats the fill with the bucket walk / a larger buffer)
+        if (blockIdx.x >= B.n_bins) {  // the extra items' hits: a slot from the item's fill cursor, as ever
+            const uint32_t xb = blockIdx.x - B.n_bins;
+            if (xb >= XBLOCKS) return;
+            const uint32_t nx = min(*B.xcursor, B.xcap);
+            for (uint32_t j = xb * THREADS + threadIdx.x; j < nx; j += XBLOCKS * THREADS) {
+                const uint4 x = B.xrec[j];
+                if (counts[x.x] >= items[x.x].min_seeds) {
+                    const uint32_t slot = atomicAdd(&fillc[x.x], 1u);
+                    const uint64_t to = segoff[x.x] + 2ull * slot;
+                    segs[to] = (int32_t)x.y;
+                    segs[to + 1] = (int32_t)x.z;
+                }
+            }
+            return;
+        }
+        const int lane = dp_lane(), wave = threadIdx.x >> 6;
+        const uint32_t bin = blockIdx.x;
+        const uint32_t rb = 1u << B.bshift, first = bin << B.bshift;
+        const uint32_t n = min(B.cursor[bin], B.cap);
+        for (uint32_t i = threadIdx.x; i < rb; i += THREADS) {
+            const uint32_t it = first + i;
+            uint32_t c = 0u;
+            if (it < n_read_items) {
+                // (everything a read's wave will want of memory, asked for at once: a wave sorts eight reads one after the other)
+                const dp_scan_item item = items[it];
+                const unsigned long long so = segoff[it];
+                c = counts[it];
+                if (c < item.min_seeds) c = 0u;
+                nks[i] = item.n_kmers;
+                sout[i] = so;
+            }
+            if (c > (uint32_t)MAXC || c > (uint32_t)CAP) {
+                atomicExch(overflow, 1u);
+                c = 0u;
+            }
+            cnt[i] = c;
+        }
+        __syncthreads();
+        const unsigned long long* rec = B.rec + (size_t)bin * B.cap;
+        uint32_t g_lo = 0u;
+        while (g_lo < rb) {
+            // the group: reads g_lo .. g_hi - 1, as many as the array holds (every read fits by itself: c <= CAP)
+            if (wave == 0) {
+                uint32_t acc = 0u, i = g_lo;
+                for (;;) {
+                    const uint32_t idx = i + (uint32_t)lane;
+                    const uint32_t c = idx < rb ? cnt[idx] : 0u;
+                    const uint32_t incl = (uint32_t)wave_incl_sum((int)c);
+                    const bool fits = idx < rb && acc + incl <= (uint32_t)CAP;  // (a prefix of the lanes: the sums do not decrease)
+                    const uint32_t nfit = (uint32_t)__popcll(__ballot(fits));
+                    if (fits) offs[idx] = acc + incl - c;
+                    if (nfit) acc += (uint32_t)__shfl((int)incl, (int)nfit - 1, 64);
+                    i += nfit;
+                    if (nfit < 64u) break;
+                }
+                if (lane == 0) {
+                    offs[i] = acc;
+                    g_hi_s = i;
+                }
+            }
+            for (uint32_t i = threadIdx.x; i < rb; i += THREADS) cur[i] = 0u;
+            __syncthreads();
+            const uint32_t g_hi = g_hi_s;
+            const uint32_t staged = offs[g_hi];
+            if (staged) {
+                for (uint32_t jb = 4u * threadIdx.x; jb < n; jb += 4u * THREADS) {
+                    unsigned long long e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) e[u] = jb + (uint32_t)u < n ? rec[jb + u] : ~0ull;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (e[u] == ~0ull) continue;
+                        const uint32_t rib = (uint32_t)(e[u] >> (KXB_SEED_BITS + 24));
+                        if (rib < g_lo || rib >= g_hi) continue;
+                        const uint32_t c = cnt[rib];
+                        if (!c) continue;
+                        const uint32_t rank = atomicAdd(&cur[rib], 1u);
+                        if (rank < c)  // key = position << 32 | seed: what kx_sort_one sorts
+                            recs[offs[rib] + rank] = ((unsigned long long)((uint32_t)e[u] & 0xffffffu) << 32) |
+                                                     (unsigned long long)((uint32_t)(e[u] >> 24) & ((1u << KXB_SEED_BITS) - 1u));
+                    }
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = g_lo + (uint32_t)wave; i < g_hi; i += WAVES) {
+                const uint32_t c = cnt[i];
+                if (!c) continue;
+                unsigned long long* my = recs + offs[i];
+                if (c <= 128u) rank_in_place<2>(my, c, lane);
+                else if (c <= 256u) rank_in_place<4>(my, c, lane);
+                else if (c <= 512u) rank_in_place<8>(my, c, lane);
+                else rank_in_place<RPL>(my, c, lane);
+                const uint64_t out = sout[i];
+                const int nk = (int)nks[i];
+                for (uint32_t j = lane; j < c; j += 64) {
+                    const int p = (int)(my[j] >> 32);
+                    const int prev = j ? (int)(my[j - 1] >> 32) : -k;  // "-k": the first gap is the hit's own index
+                    segs[out + 2 * (uint64_t)j] = p - (prev + k);
+                    segs[out + 2 * (uint64_t)j + 1] = (int32_t)(uint32_t)my[j];
+                }
+                if (lane == 0) segs[out + 2 * (uint64_t)c] = nk - (int)(my[c - 1] >> 32) - 1;  // final gap (sequence/asm_amd64.s:387-392)
+            }
+            __syncthreads();
+            g_lo = g_hi;
         }
     }
 };
@@ -1513,16 +1726,34 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     KxBins B{};
     const char* bins_env = getenv("DP_KX_BINS");  // (read per call: tests switch it between jobs of one process)
     const bool bins_on = !(bins_env && bins_env[0] == '0');
+    // round 6, the dense regime (this context's previous round had 16 and more hits per read - k = 10: ~100): small bins whose
+    // workgroup fills AND sorts in LDS (kidx_bin_sort_dense), eight trips of a walk workgroup per bin reservation, the count as a launch
+    // of its own (one workgroup per bin instead of one per 4 096 reads inside kidx_offsets).  DP_KX_DENSE=0: off (A/B runs)
+    const char* dense_env = getenv("DP_KX_DENSE");  // (read per call: tests switch it between jobs of one process)
+    bool dense = false;
     if (one && R.rec && bins_on && n_read_items && S < (1u << KXB_SEED_BITS)) {
         uint32_t bshift = 9;
         while (((n_read_items + (1u << bshift) - 1) >> bshift) > 256 && bshift < KXB_RIB_BITS) bshift++;
+        // (DP_KX_DENSE=1, tests: whatever the hit density - small inputs reach the dense kernels through it)
+        dense = one->sort_cap <= 1024 && (dense_env && dense_env[0] == '1' ? true
+                                          : !(dense_env && dense_env[0] == '0') && lps == 64 && one->hits_guess >= 16ull * n_read_items &&
+                                            one->hits_guess >= (1ull << 20));
+        if (dense) {
+            bshift = 6;
+            while (((n_read_items + (1u << bshift) - 1) >> bshift) > KX_MAXBINS && bshift < 8) bshift++;
+            if (((n_read_items + (1u << bshift) - 1) >> bshift) > KX_MAXBINS) {  // (more than half a million reads: the bins of round 5)
+                dense = false;
+                bshift = 9;
+                while (((n_read_items + (1u << bshift) - 1) >> bshift) > 256 && bshift < KXB_RIB_BITS) bshift++;
+            }
+        }
         const uint32_t n_bins = (n_read_items + (1u << bshift) - 1) >> bshift;
         const uint64_t total = (uint64_t)R.shard_cap * 64;
         const uint64_t xcap = std::max<uint64_t>(65536, total / 8);
         // a bin holds its share of the hits (1.5 x the round before, as the shards) - and ONE bin also holds the round's query reads,
         // consecutive reads that contain every seed of the round by construction: + 2 S (measured at config 2: mean 2.3 k records per
         // bin, 7.4 k in the query reads' bin)
-        uint64_t cap = total / n_bins + 2 * (uint64_t)S + 1024;
+        uint64_t cap = total / n_bins + std::min<uint64_t>(2 * (uint64_t)S, dense ? ((uint64_t)128 << bshift) : ~0ull) + 1024;
         if (const char* e = getenv("DP_KX_BINS_CAP")) cap = (uint64_t)std::max(16, atoi(e));  // (test hook: bins that overflow)
         if (n_bins <= KX_MAXBINS && cap < 0x7fffffffu) {
             if (dev_reserve(ctx, ctx->d_kx_tmp, std::max((size_t)n_groups * 8, (size_t)xcap * 16) + 64)) return DP_ERR_HIP;
@@ -1540,6 +1771,9 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             B.ign = R.ign;
             B.qlo = R.qlo;
             B.qspan = R.qspan;
+            B.batch = 1u;
+        } else {
+            dense = false;
         }
     }
     static const bool kx_debug = getenv("DP_KX_DEBUG") != nullptr;
@@ -1556,14 +1790,22 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
 #define KX_WALK_BIN(W_)                                                                                                                            \
     dp_launch<kidx_walk_bin<W_>>(ctx, dim3((n_waves + W_ - 1) / W_), dim3(64 * W_), dp_seeds_ptr(ctx), S, (const uint64_t*)ix->off.p, ix->view(), \
                                  d_items, lo, hi, n_read_items, (const uint32_t*)head, (const uint32_t*)next, d_counts, n_hits, lps, B, n_waves)
-        if (bin_waves <= 4) KX_WALK_BIN(4);
+        // (dense: 16 waves - four seeds a trip; measured at k = 10, five slots: 0.582 against 0.606 s per job, profiles/r06/k10_knobs.txt)
+        if (dense) {
+            // (trips per reservation: as many as make ONE workgroup per CU cover the round's waves - a 16-wave workgroup with its 105 VGPRs
+            // is alone on its CU, and 313 of them on 256 CUs were two rounds of workgroups for 1.2 rounds of work)
+            B.batch = std::max<uint32_t>(1u, std::min<uint32_t>(32u, (n_waves + 16u * 256u - 1) / (16u * 256u)));
+            const uint32_t per = 16u * B.batch;
+            dp_launch<kidx_walk_bin<16>>(ctx, dim3((n_waves + per - 1) / per), dim3(64 * 16), dp_seeds_ptr(ctx), S, (const uint64_t*)ix->off.p, ix->view(),
+                                         d_items, lo, hi, n_read_items, (const uint32_t*)head, (const uint32_t*)next, d_counts, n_hits, lps, B, n_waves);
+        } else if (bin_waves <= 4) KX_WALK_BIN(4);
         else if (bin_waves <= 8) KX_WALK_BIN(8);
         else KX_WALK_BIN(16);
 #undef KX_WALK_BIN
         // bins no larger than a tile of kidx_offsets are counted by that kernel (one launch less per round; DP_KX_FUSE=0: as before)
         const char* fuse_env = getenv("DP_KX_FUSE");  // (read per call, like DP_KX_BINS: tests switch it between jobs of one process)
         const bool fuse_off = fuse_env && fuse_env[0] == '0';
-        count_in_offsets = !fuse_off && (1u << B.bshift) <= KX_TILE * KX_IPT;
+        count_in_offsets = !fuse_off && !dense && (1u << B.bshift) <= KX_TILE * KX_IPT;
         if (count_in_offsets) {
         } else if (B.bshift <= 9)
             dp_launch<kidx_bin_count<512>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items, lo);
@@ -1655,7 +1897,11 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             DP_HIP(dp_mark(ctx, 3));
             return DP_OK;
         }
-        if (B.rec) {
+        if (B.rec && dense) {
+            dp_launch<kidx_bin_sort_dense<8192>>(ctx, dim3(B.n_bins + kidx_bin_sort_dense<8192>::XBLOCKS), dim3(512), B, d_items, n_read_items,
+                                                 (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff, one->d_segs, (const uint64_t*)d_totals,
+                                                 one->seg_cap, k, (uint32_t*)(d_totals + 4));
+        } else if (B.rec) {
             const dim3 fg(B.n_bins + kidx_bin_fill<512>::XBLOCKS), fb(512);
             if (B.bshift <= 9)
                 dp_launch<kidx_bin_fill<512>>(ctx, fg, fb, B, d_items, n_read_items, (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff,
@@ -1672,19 +1918,22 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                                  one->d_segs, (const uint64_t*)d_totals, one->seg_cap);
         // (the survivor count is on the device only: the grid covers the most survivors a round of this context has had so far,
         // the kernel strides over the rest)
-        const dim3 sg(std::max<uint32_t>(256u, std::min<uint32_t>(one->surv_guess, 16384))), sb(64);
+        const dim3 sg(dense ? std::max<uint32_t>(64u, std::min<uint32_t>(n_extra, 16384))
+                            : std::max<uint32_t>(256u, std::min<uint32_t>(one->surv_guess, 16384))), sb(64);
         uint32_t* ovf = (uint32_t*)(d_totals + 4);
         const uint32_t* nsp = (const uint32_t*)(d_totals + 1);
         if (one->sort_cap <= 256)
             dp_launch<kidx_sortwrite<256>>(ctx, sg, sb, d_items, (const uint32_t*)s_item, nsp, (const uint32_t*)d_counts, (const uint64_t*)d_segoff,
-                                           one->d_segs, k, ovf, n_read_items, n_extra, head, one->host_segs, (const uint64_t*)d_totals, one->seg_cap);
+                                           one->d_segs, k, ovf, n_read_items, n_extra, head, one->host_segs, (const uint64_t*)d_totals, one->seg_cap,
+                                           dense ? 1u : 0u);
         else if (one->sort_cap <= 1024)
             dp_launch<kidx_sortwrite<1024>>(ctx, sg, sb, d_items, (const uint32_t*)s_item, nsp, (const uint32_t*)d_counts, (const uint64_t*)d_segoff,
-                                            one->d_segs, k, ovf, n_read_items, n_extra, head, one->host_segs, (const uint64_t*)d_totals, one->seg_cap);
+                                            one->d_segs, k, ovf, n_read_items, n_extra, head, one->host_segs, (const uint64_t*)d_totals, one->seg_cap,
+                                            dense ? 1u : 0u);
         else
             dp_launch<kidx_sortwrite<KX_SORT_LDS>>(ctx, sg, sb, d_items, (const uint32_t*)s_item, nsp, (const uint32_t*)d_counts,
                                                    (const uint64_t*)d_segoff, one->d_segs, k, ovf, n_read_items, n_extra, head, one->host_segs,
-                                                   (const uint64_t*)d_totals, one->seg_cap);
+                                                   (const uint64_t*)d_totals, one->seg_cap, 0u);
         DP_HIP(hipGetLastError());
         DP_HIP(dp_mark(ctx, 3));
     }
@@ -1732,13 +1981,13 @@ int dp_kindex_write(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         const uint32_t* nsp = (const uint32_t*)(d_totals + 1);
         if (max_count <= 128)
             dp_launch<kidx_sortwrite<256>>(ctx, sg, sb, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
-                               n_extra, head, host_segs, (const uint64_t*)nullptr, (uint64_t)0);
+                               n_extra, head, host_segs, (const uint64_t*)nullptr, (uint64_t)0, 0u);
         else if (max_count <= 512)
             dp_launch<kidx_sortwrite<1024>>(ctx, sg, sb, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf, n_read_items,
-                               n_extra, head, host_segs, (const uint64_t*)nullptr, (uint64_t)0);
+                               n_extra, head, host_segs, (const uint64_t*)nullptr, (uint64_t)0, 0u);
         else
             dp_launch<kidx_sortwrite<KX_SORT_LDS>>(ctx, sg, sb, d_items, d_sel, nsp, d_counts, d_segoff, d_segs, k, ovf,
-                               n_read_items, n_extra, head, host_segs, (const uint64_t*)nullptr, (uint64_t)0);
+                               n_read_items, n_extra, head, host_segs, (const uint64_t*)nullptr, (uint64_t)0, 0u);
         DP_HIP(hipGetLastError());
     }
     if (n_extra && (rc != DP_OK || !n_sel))  // (otherwise the sort kernel has put head[] back to zero)

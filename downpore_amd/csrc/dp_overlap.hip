@@ -2583,6 +2583,10 @@ struct chain_walk_kernel {
             } else if (mode == 1) {
                 break;  // needs chaining with a minMatches nobody proposed for: the next spec pass does it
             } else {
+                if (DP_PROFILING && A.prof && mode == 2 && lane == 0) {  // (what the final walk still chains, and how much of it because of the slim layout)
+                    atomicAdd(&A.cursor[20], 1u);
+                    if (spmm == -2) atomicAdd(&A.cursor[21], 1u);
+                }
                 len = chain_pair(L, nodes, A, aSeg, aN, aStaged, qs, qset, t, mm, ca, cb, haveMask, aMask, nullptr, wprof ? &pf : (ChainProf*)nullptr);
                 if (SLIM && len < 0) {  // needs the full layout: the query stays open at this pair (marked: slim passes skip it)
                     if (lane == 0) {
@@ -3247,6 +3251,8 @@ static int chain_finish(dp_ctx* ctx, FindState& st) {
             }
         }
     }
+    if (chain_prof) fprintf(stderr, "[chain prof] final walk: %u pairs chained, %u of them marked for the full layout; open ahead of pass 1 / 2: %u / %u, passes %d\n",
+                            st.cur[20], st.cur[21], st.cur[24] + st.cur[25], st.cur[26] + st.cur[27], st.passes);
     st.query_ms = dp_elapsed(ctx, 4, 5);
     st.chain_bytes = st.alg_bytes;
     if (st.cur[2]) {
@@ -3367,7 +3373,9 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     // (round 6) a proposal pass is two launches, and a launch costs a round with other rounds beside it 1.5 - 1.9 us whatever it does:
     // the third pass is only launched when this context's previous stage left it something to do (at k = 13 it sees ~18 pairs, which the
     // final walk chains as well - bit-identical for any number of passes, tests run 0, 1 and 3)
-    if (!pass_env && ctx->chain_open_ahead[1] < 64u) st.passes = 2;
+    // (24 pairs: at k = 13 the third pass sees ~18 pairs, all short; at k = 10 it sees 30 - 60 chains of fifty links, which the final
+    // walk - one wave per QUERY - took 116 us over against a pass's 60, profiles/r06/k10_final_walk_pairs.txt)
+    if (!pass_env && ctx->chain_open_ahead[1] < 24u) st.passes = 2;
     st.walk_blocks = std::min<uint32_t>(256, (nq + C_WAVES - 1) / C_WAVES);
     st.spec_blocks = 1024;  // 4096 persistent waves, 16 per CU: what CSlim's 8.5 KB per wave lets a CU hold
     if (const char* e = getenv("DP_SPEC_BLOCKS")) st.spec_blocks = (uint32_t)std::max(1, atoi(e));

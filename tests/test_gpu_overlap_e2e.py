@@ -229,13 +229,15 @@ def test_overlap_kmer_index_mode(mode):
 
 
 @pytest.mark.parametrize("env", [{"DP_KX_BINS": "0"}, {"DP_KX_BINS_CAP": "300"}, {"DP_KX_BINS_CAP": "40"}, {"DP_KX_ONESHOT": "0"}, {"DP_KX_FUSE": "0"},
-                                 {"DP_KX_FUSE": "2"}, {"DP_KX_FUSE": "2", "DP_KX_BINS_CAP": "300"}, {"DP_QUERY_SCAN": "1"}])
+                                 {"DP_KX_FUSE": "2"}, {"DP_KX_FUSE": "2", "DP_KX_BINS_CAP": "300"}, {"DP_QUERY_SCAN": "1"},
+                                 {"DP_KX_DENSE": "1"}, {"DP_KX_DENSE": "1", "DP_KX_BINS_CAP": "300"}, {"DP_KX_DENSE": "1", "DP_KX_BINS_CAP": "40"}])
 def test_kmer_index_counting_step_variants(monkeypatch, env):
     """The counting step of an index-mode round (dp_kindex.hip): hits binned by read range and counted in LDS (round 5, the default),
     round 4's hit records with one atomic per hit (DP_KX_BINS=0), bins that overflow - a workgroup's share that does not fit is
     counted the old way, what it reserved is marked unwritten, the fill pass walks the buckets (DP_KX_BINS_CAP: some bins at 300,
     every bin at 40) - the two-wait form (DP_KX_ONESHOT=0), the count in a launch of its own instead of inside kidx_offsets (DP_KX_FUSE=0) and
-    fill + sort in one launch (DP_KX_FUSE=2) - and, one step on, the pair-offset scan done by kernel_query's last workgroup
+    fill + sort in one launch (DP_KX_FUSE=2), the dense regime's small bins filled and sorted in LDS with batched reservations (round 6,
+    DP_KX_DENSE=1 forces it on these small inputs; with bins that overflow too) - and, one step on, the pair-offset scan done by kernel_query's last workgroup
     (DP_QUERY_SCAN=1).  All read per call, so a variant set here is the variant that runs.  Same PAF, same ignore flags as the oracle: dense seeds (k = 10, hundreds
     of hits per read), sparse seeds (k = 13), reads that get flagged, five slots."""
     monkeypatch.setenv("DP_SCAN_INDEX", "1")
