@@ -77,52 +77,62 @@ struct index_fill_rows_kernel {
         }
     }
 };
-// one wave per (eight words of posting rows, one word of seed-set rows): eight 64 x 64 bit transposes across the lanes; lane j ends up
-// with the eight words of seed 64 sw + j - one 64-byte store
+// one wave per (eight words of posting rows, FOUR consecutive words of seed-set rows): thirty-two 64 x 64 bit transposes across the lanes;
+// lane j ends up with the eight words of seeds 64 (sw0 + i) + j, i = 0 .. 3 - four 64-byte stores.  (Round 6: one seed-set word per wave
+// and task made every lane's 8-byte load a sector of its own - 64 rows, 2.5 KB apart - of which an eighth was used: the launch
+// fetched 808 MB for a 240 MB matrix at k = 10, profiles/r05/pmc_dense.json.  Four words per lane are a lane's whole 32-byte sector,
+// and the four waves of a workgroup take the four quarters of the rows' 128-byte lines.)
 struct posting_transpose_kernel {
-    enum { THREADS = 256 };
+    enum { THREADS = 256, SWPT = 4 };
     static __device__ void run(const u64* __restrict__ seedsets, u64* __restrict__ posting, uint32_t n_seeds, uint32_t W, uint32_t SW,
                                const uint32_t* __restrict__ n_seqs_dev) {
         const uint32_t n_seqs = *n_seqs_dev;
         const uint32_t wchunks = (W + 7) / 8;
-        const uint32_t tasks = wchunks * SW;
+        const uint32_t swg = (SW + SWPT - 1) / SWPT;
+        const uint32_t tasks = wchunks * swg;
         const uint32_t waves = gridDim.x * (blockDim.x >> 6);
         const int lane = dp_lane();
         for (uint32_t t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < tasks; t += waves) {
-            const uint32_t sw = t % SW, w0 = (t / SW) * 8;
-            u64 x[8];
+            const uint32_t sw0 = (t % swg) * SWPT, w0 = (t / swg) * 8;
+            u64 x[8][SWPT];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const uint64_t rowi = (uint64_t)(w0 + u) * 64 + (uint32_t)lane;
-                x[u] = (w0 + u < W && rowi < n_seqs) ? seedsets[rowi * SW + sw] : 0ull;
-            }
-            // 64 x 64 bit transpose across the lanes (row r of the block in lane r): six exchange stages instead of 64 ballots
-            u64 out[8];
+                const bool rv = w0 + u < W && rowi < n_seqs;
+                const u64* src = seedsets + rowi * SW + sw0;
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                u64 v = x[u];
-                if (__ballot(v != 0) != 0) {  // (else: sixty-four chunks none of which holds any of these sixty-four seeds)
+                for (int i = 0; i < SWPT; i++) x[u][i] = (rv && sw0 + i < SW) ? src[i] : 0ull;
+            }
+#pragma unroll
+            for (int i = 0; i < SWPT; i++) {
+                // 64 x 64 bit transpose across the lanes (row r of the block in lane r): six exchange stages instead of 64 ballots
+                u64 out[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    u64 v = x[u][i];
+                    if (__ballot(v != 0) != 0) {  // (else: sixty-four chunks none of which holds any of these sixty-four seeds)
 #define PT_STAGE(j_, m_)                                                              \
     {                                                                                 \
         const u64 y_ = (u64)__shfl_xor((unsigned long long)v, (j_), 64);              \
         if ((lane & (j_)) == 0) v ^= ((((v >> (j_)) ^ y_) & (m_)) << (j_));           \
         else v ^= (((y_ >> (j_)) ^ v) & (m_));                                        \
     }
-                    PT_STAGE(32, 0x00000000FFFFFFFFull)
-                    PT_STAGE(16, 0x0000FFFF0000FFFFull)
-                    PT_STAGE(8, 0x00FF00FF00FF00FFull)
-                    PT_STAGE(4, 0x0F0F0F0F0F0F0F0Full)
-                    PT_STAGE(2, 0x3333333333333333ull)
-                    PT_STAGE(1, 0x5555555555555555ull)
+                        PT_STAGE(32, 0x00000000FFFFFFFFull)
+                        PT_STAGE(16, 0x0000FFFF0000FFFFull)
+                        PT_STAGE(8, 0x00FF00FF00FF00FFull)
+                        PT_STAGE(4, 0x0F0F0F0F0F0F0F0Full)
+                        PT_STAGE(2, 0x3333333333333333ull)
+                        PT_STAGE(1, 0x5555555555555555ull)
 #undef PT_STAGE
+                    }
+                    out[u] = v;
                 }
-                out[u] = v;
-            }
-            const uint32_t seed = sw * 64 + (uint32_t)lane;
-            if (seed < n_seeds) {
+                const uint32_t seed = (sw0 + (uint32_t)i) * 64 + (uint32_t)lane;
+                if (sw0 + (uint32_t)i < SW && seed < n_seeds) {
 #pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (w0 + u < W) posting[(uint64_t)seed * W + w0 + u] = out[u];
+                    for (int u = 0; u < 8; u++)
+                        if (w0 + u < W) posting[(uint64_t)seed * W + w0 + u] = out[u];
+                }
             }
         }
     }
@@ -249,8 +259,15 @@ struct ChunkParams {
     uint32_t done_seq;
 };
 
+// (round 6) CK_CACHE chunks of a thread's count pass stay in the workgroup's LDS: a read of the dense regime is two chunks, and the
+// write pass used to walk its ~200 seeds a second time (4-byte loads, every lane of a wave in another read's slice)
+#define CK_CACHE 2
+struct ChunkCache {
+    uint4 c[CK_CACHE];   // first seed, seeds, length, offset
+    int32_t ins[CK_CACHE];
+};
 template <bool WRITE>
-__device__ uint32_t chunk_one(const ChunkParams& P, uint32_t i, uint32_t at) {
+__device__ uint32_t chunk_one(const ChunkParams& P, uint32_t i, uint32_t at, ChunkCache* cache = nullptr) {
     const uint32_t read = P.s_item[i] + P.lo;
     const int numSeeds = (int)P.s_count[i];
     const u64 segBase = P.s_off[i];
@@ -274,6 +291,9 @@ __device__ uint32_t chunk_one(const ChunkParams& P, uint32_t i, uint32_t at) {
                 m.inset = (int32_t)ins;
                 P.metas[o] = m;
             }
+        } else if (cache && made < CK_CACHE) {
+            cache->c[made] = make_uint4((uint32_t)first, (uint32_t)(last - first + 1), (uint32_t)(int32_t)len, (uint32_t)(int32_t)off);
+            cache->ins[made] = (int32_t)ins;
         }
         made++;
     };
@@ -340,6 +360,7 @@ struct chunk_kernel {
     static __device__ void run(const ChunkParams P, unsigned long long* __restrict__ status, uint32_t* __restrict__ ticket) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t tile_s, base_s;
+    __shared__ ChunkCache cache[THREADS];
     uint32_t ns = P.ns;
     if (P.done_flag && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(P.done_flag, P.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -378,7 +399,7 @@ struct chunk_kernel {
     const uint32_t tile = tile_s;
     const int lane = dp_lane(), wave = threadIdx.x >> 6;
     const uint32_t i = tile * 1024 + threadIdx.x;
-    const uint32_t cnt = i < ns ? chunk_one<false>(P, i, 0) : 0u;
+    const uint32_t cnt = i < ns ? chunk_one<false>(P, i, 0, &cache[threadIdx.x]) : 0u;
     const uint32_t x = (uint32_t)wave_incl_sum_dpp((int)cnt);
     if (lane == 63) wsum[wave] = x;
     __syncthreads();
@@ -406,7 +427,28 @@ struct chunk_kernel {
         }
     }
     __syncthreads();
-    if (cnt) chunk_one<true>(P, i, base_s + before + x - cnt);
+    if (cnt > CK_CACHE) {
+        chunk_one<true>(P, i, base_s + before + x - cnt);
+    } else if (cnt) {  // from the count pass's cache (own LDS slot: no barrier needed in between)
+        const uint32_t read = P.s_item[i] + P.lo;
+        const u64 segBase = P.s_off[i];
+        for (uint32_t m_ = 0; m_ < cnt; m_++) {
+            const uint32_t o = base_s + before + x - cnt + m_;
+            if (o >= P.cap) break;
+            const uint4 c = cache[threadIdx.x].c[m_];
+            dp_seq_ref r;
+            r.seg_off = segBase + 2ull * c.x;
+            r.n_seeds = c.y;
+            r.reserved = 0;
+            P.refs[o] = r;
+            dp_seq_meta m;
+            m.read = read;
+            m.length = (int32_t)c.z;
+            m.offset = (int32_t)c.w;
+            m.inset = cache[threadIdx.x].ins[m_];
+            P.metas[o] = m;
+        }
+    }
     // the tile that finishes last puts the ticket, the status words and this counter back to zero for the next launch
     __syncthreads();
     if (threadIdx.x == 0) tile_s = __hip_atomic_fetch_add(&P.n_out[3], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -522,7 +564,7 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
             dp_launch<index_fill_rows_kernel>(ctx, dim3(blocks), dim3(256), (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p,
                                               (u64*)ctx->d_seedsets.p, SW, (const uint32_t*)ctx->d_nseqs.p,
                                               rows_half ? (u64*)ctx->d_posting.p : (u64*)nullptr, W);
-            const uint32_t tasks = ((W + 7) / 8) * SW;
+            const uint32_t tasks = ((W + 7) / 8) * ((SW + posting_transpose_kernel::SWPT - 1) / posting_transpose_kernel::SWPT);
             if (!rows_half)
                 dp_launch<posting_transpose_kernel>(ctx, dim3(std::min<uint32_t>(4096, (tasks + 3) / 4)), dim3(256), (const u64*)ctx->d_seedsets.p,
                                                     (u64*)ctx->d_posting.p, S, W, SW, (const uint32_t*)ctx->d_nseqs.p);
