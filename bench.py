@@ -187,8 +187,10 @@ def main():
     upload = pipe.setup_times()
     if world > 1 and rank != 0:
         pipe.keep_text(False)  # (rank 0 verifies and would print the PAF; the others commit the gathered rounds without their text)
-    if world > 1 and comm is not None and getattr(pipe, "mode", "") == "round":
-        pipe.text_root(0)      # (round 5: the text is gathered to rank 0 alone, the rounds' control records - a few KB - to every rank)
+    if world > 1 and comm is not None and getattr(pipe, "mode", "") == "round" and os.environ.get("DP_BENCH_TEXT_ROOT") == "1":
+        # (opt-in until a run with two GPUs has shown parity: the text gathered to rank 0 alone uses ncclSend / ncclRecv, which no run of
+        # this repository has executed with a peer yet; the default exchange is the all-gather of the rounds' blobs, as in round 4)
+        pipe.text_root(0)
 
     def sync():
         torch.cuda.synchronize()
@@ -460,7 +462,7 @@ def alt_mode_jobs(mode, reads, args, rank, world, local_rank, torch_device, comm
                            torch_device=torch_device, mode=mode, slots=args.slots, defer_init=True, comm=comm)
     if world > 1 and rank != 0:
         pipe.keep_text(False)
-    if world > 1 and comm is not None and getattr(pipe, "mode", "") == "round":
+    if world > 1 and comm is not None and getattr(pipe, "mode", "") == "round" and os.environ.get("DP_BENCH_TEXT_ROOT") == "1":
         pipe.text_root(0)
 
     def sync():

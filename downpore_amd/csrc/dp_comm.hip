@@ -768,5 +768,6 @@ extern "C" int dp_gather_blobs(dp_comm* c, dp_ctx* ctx, const uint8_t* blob, uin
     return rc;
 }
 
+bool dp_comm_is_rccl(const dp_comm* c) { return c && c->nccl != nullptr; }  // (the one-process flavour exchanges through peer copies)
 extern "C" int dp_comm_rank(const dp_comm* c) { return c ? c->rank : -1; }
 extern "C" int dp_comm_size(const dp_comm* c) { return c ? c->n_ranks : 0; }

@@ -252,6 +252,7 @@ int dp_histogram_device(dp_ctx* ctx, int k, uint32_t* d_counts);  // dp_scan.hip
 int dp_kindex_ensure(dp_ctx* ctx, int k);
 struct dp_comm;
 int dp_comm_allgather_ranges(dp_comm* c, dp_ctx* ctx, void* dst, size_t elem, const uint64_t* first, const void* src);  // dp_comm.hip
+bool dp_comm_is_rccl(const dp_comm* c);  // dp_comm.hip
 // A rank's share of a k-mer position index built by several ranks (round 5): filled by dp_kindex_build_sorted from the first-digit
 // counts every rank computes alike - rank q sorts the k-mers [digit_first[q] << kmer_shift, digit_first[q + 1] << kmer_shift), which are
 // the entries [entry_first[q], entry_first[q + 1]) of the whole index; the offsets it writes are relative to its own first entry.

@@ -109,9 +109,11 @@ static int kidx_gather_shares(dp_ctx* ctx, dp_comm* comm, const dp_kindex_shard&
     for (int q = 0; q <= N; q++) kfirst[(size_t)q] = std::min<uint64_t>(nk, (uint64_t)sh.digit_first[(size_t)q] << sh.kmer_shift);
     const size_t elem = fmt == 8 ? 8 : 4;
     void *full = nullptr, *full_hi = nullptr;
+    // (a rank that leaves with an error must not leave its peers waiting in the collectives below: dp_comm.hip's rule)
     auto fail = [&](int rc) {
         if (full) dp_dev_free(full);
         if (full_hi) dp_dev_free(full_hi);
+        dp_comm_abort(comm);
         return rc;
     };
     if (dp_dev_malloc(&full, sh.total * elem + 64) != hipSuccess) return fail(dp_fail(ctx, DP_ERR_HIP, "k-mer position index: no memory for the gathered entries"));
@@ -153,6 +155,24 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
     ix->unavailable = false;
     ix->k = k;
     const size_t nk = (size_t)1 << (2 * k);
+    // round 5, multi-GPU: every rank sorts the k-mers of its own share of the first-digit buckets and the shares are all-gathered
+    // (RCCL over xGMI, device to device) - 1 / N of the build's three passes per rank instead of all of them on every rank.
+    // DP_KINDEX_SHARD=0: every rank builds everything, as until round 4.
+    // (DP_KINDEX_SHARD=force: also with a communicator of ONE rank - the test hook that takes the RCCL flavour of the gather, grouped
+    // ncclBroadcasts between device buffers, through a real librccl on a one-GPU box)
+    const char* se = getenv("DP_KINDEX_SHARD");
+    // Over an RCCL communicator the shares are OPT-IN (DP_KINDEX_SHARD=1): their exchange - grouped ncclBroadcasts with several roots -
+    // has run between in-process ranks (peer copies) and through a one-rank librccl, never yet between two GPUs (no multi-GPU node has
+    // been available to this repository); until a run with two ranks has shown the index digests equal, every rank of a multi-process
+    // job builds the whole index itself, as until round 4.
+    const bool opt_in = se && (se[0] == '1' || se[0] == 'f');
+    const bool sharded = ow->kx_comm && (dp_comm_size(ow->kx_comm) > 1 || (se && se[0] == 'f')) && !(se && se[0] == '0') &&
+                         (opt_in || !dp_comm_is_rccl(ow->kx_comm));
+    // With a communicator this call is COLLECTIVE, and what decides a rank's way through it is the rank's own (free HBM differs per
+    // GPU: parked cache blocks, other processes; an allocation fails on one rank only).  Every verdict a rank reaches on its own - no room
+    // for the index, an allocation that failed, a share that could not be built - goes into the byte the ranks exchange BEFORE anybody
+    // leaves: everyone gathers, or everyone builds alone / falls back, or everyone fails; nobody waits for a rank that has left.
+    bool mem_ok = true;
     {
         // resident: 8 B per k-mer start + 8 B per table entry; transient: two 4-byte count tables.  Leave 4 GiB for the rounds.
         size_t free_b = 0, total_b = 0;
@@ -163,7 +183,8 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
         const uint64_t need = ow->total_bases * 8 + (uint64_t)nk * 16 + ((uint64_t)4 << 30);
         int max_k = 14;
         if (const char* e = getenv("DP_KINDEX_MAX_K")) max_k = std::min(14, atoi(e));
-        if (k > max_k || need > free_b + ix->pos.cap + ix->off.cap) {
+        mem_ok = !(k > max_k || need > free_b + ix->pos.cap + ix->off.cap);
+        if (!mem_ok && !sharded) {
             ix->unavailable = true;
             return 1;
         }
@@ -172,38 +193,35 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
     // histogram falls out of its last pass (kept for dp_kmer_values).  DP_KINDEX_ATOMIC=1 or an unsupported k: the
     // count -> offsets -> atomic scatter below.
     {
-        if (dev_reserve(ctx, ix->off, (nk + 1) * 8)) return DP_ERR_HIP;
         void* d_cnt = nullptr;
-        DP_HIP(dp_dev_malloc(&d_cnt, nk * 4));
+        int pre = DP_OK;  // this rank's own verdict before the build: 0 go on, 1 no room (scan instead), < 0 an allocation failed
+        if (!mem_ok) pre = 1;
+        else if (dev_reserve(ctx, ix->off, (nk + 1) * 8)) pre = DP_ERR_HIP;
+        else if (dp_dev_malloc(&d_cnt, nk * 4) != hipSuccess) pre = dp_fail(ctx, DP_ERR_HIP, "k-mer position index: no memory for the count table");
+        if (pre != DP_OK && !sharded) return pre;
         void *d_pos = nullptr, *d_pos_hi = nullptr;
         uint64_t n_pos = 0;
         float ms = 0;
         int fmt = 8, pbits = 32;
-        // round 5, multi-GPU: every rank sorts the k-mers of its own share of the first-digit buckets and the shares are all-gathered
-        // (RCCL over xGMI, device to device) - 1 / N of the build's three passes per rank instead of all of them on every rank.
-        // DP_KINDEX_SHARD=0: every rank builds everything, as until round 4.
         dp_kindex_shard shard;
-        const char* se = getenv("DP_KINDEX_SHARD");
-        // (DP_KINDEX_SHARD=force: also with a communicator of ONE rank - the test hook that takes the RCCL flavour of the gather, grouped
-        // ncclBroadcasts between device buffers, through a real librccl on a one-GPU box)
-        const bool sharded = ow->kx_comm && (dp_comm_size(ow->kx_comm) > 1 || (se && se[0] == 'f')) && !(se && se[0] == '0');
         if (sharded) {
             shard.rank = dp_comm_rank(ow->kx_comm);
             shard.n_ranks = dp_comm_size(ow->kx_comm);
         }
-        int rc = dp_kindex_build_sorted(ctx, ow, k, (uint32_t*)d_cnt, (uint64_t*)ix->off.p, &d_pos, &d_pos_hi, &fmt, &pbits, &n_pos, &ms,
-                                        sharded ? &shard : nullptr);
+        int rc = pre != DP_OK ? pre
+                              : dp_kindex_build_sorted(ctx, ow, k, (uint32_t*)d_cnt, (uint64_t*)ix->off.p, &d_pos, &d_pos_hi, &fmt, &pbits, &n_pos, &ms,
+                                                       sharded ? &shard : nullptr);
         if (sharded) {
             // the ranks agree on how it went before anybody waits in a collective for a rank that fell back
             const uint8_t mine = (uint8_t)(rc == 0 ? 0 : rc > 0 ? 1 : 2);
             const uint8_t* all = nullptr;
             const uint64_t* sizes = nullptr;
-            if (int xr = dp_allgather_blobs(ow->kx_comm, ctx, &mine, 1, &all, &sizes)) {
+            if (int xr = dp_allgather_blobs(ow->kx_comm, ctx, &mine, 1, &all, &sizes)) {  // (aborts the communicator itself)
                 if (rc == 0) {
                     dp_dev_free(d_pos);
                     if (d_pos_hi) dp_dev_free(d_pos_hi);
                 }
-                dp_dev_free(d_cnt);
+                if (d_cnt) dp_dev_free(d_cnt);
                 return xr;
             }
             uint8_t worst = 0;
@@ -216,14 +234,19 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
                     if (d_pos_hi) dp_dev_free(d_pos_hi);
                     d_pos = d_pos_hi = nullptr;
                 }
-                // (a rank could not build its share: everybody builds the whole index on its own, or fails alike)
+                // (a rank could not build its share: everybody builds the whole index on its own - no collective in that - or, where a
+                // rank FAILED, falls back alike; the rank without room scans, as it would have without a communicator)
                 rc = worst == 2 && rc >= 0 ? 1 : rc;
-                if (rc >= 0)
+                if (rc >= 0 && pre == DP_OK)
                     rc = dp_kindex_build_sorted(ctx, ow, k, (uint32_t*)d_cnt, (uint64_t*)ix->off.p, &d_pos, &d_pos_hi, &fmt, &pbits, &n_pos, &ms, nullptr);
+            }
+            if (pre == 1 && rc >= 0) {
+                ix->unavailable = true;
+                return 1;
             }
         }
         if (rc < 0) {
-            dp_dev_free(d_cnt);
+            if (d_cnt) dp_dev_free(d_cnt);
             return rc;
         }
         if (rc == 0) {
@@ -243,7 +266,7 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
             ow->kcounts_k = k;
             return DP_OK;
         }
-        dp_dev_free(d_cnt);
+        if (d_cnt) dp_dev_free(d_cnt);
     }
     // count -> offsets -> scatter, on the CALLER's stream (the owner's buffers are only written here, under the mutex)
     void *d_counts = nullptr, *d_tmp = nullptr, *d_counts1 = nullptr;

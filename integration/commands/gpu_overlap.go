@@ -100,7 +100,11 @@ func (com *gpuOverlapCommand) Run(args map[string]string) {
 		// finished rounds over RCCL and commits them in order on every rank; rank 0 prints (the others drop the text as it arrives)
 		ov.SetRanks(rank, ranks)
 		ov.KeepText(rank == 0)
-		ov.TextRoot(0) // the text goes to the printing rank alone, the control records (a few KB per round) to everybody
+		if os.Getenv("DP_TEXT_ROOT") == "1" {
+			// opt-in until a two-GPU run has shown parity (ncclSend / ncclRecv have not run with a peer yet): the text goes to the
+			// printing rank alone, the control records (a few KB per round) to everybody
+			ov.TextRoot(0)
+		}
 		err := ov.RunRoundParallel(p.Slots, func(paf []byte) {
 			if rank == 0 {
 				out.Write(paf)
