@@ -778,4 +778,8 @@ struct ArgTable {
     bool parse(int argc, char** argv, std::string& err);
 };
 
+// test hooks (host_capi.cpp: dph_hand_*)
+void trimBestIndices(int upto, const std::vector<SeedMatch*>& ms, int minMatch, int length, int* bestOut, int* backOut);  // host_seq.cpp
+bool handIsConsistent(const i64* l, const i64* r, bool circular, i64 refLen);                                                // host_map.cpp
+int handRemoveDominated(const i64* maps, int n, i64 queryLen, int* kept);                                                    // host_map.cpp
 }  // namespace dph

@@ -450,6 +450,24 @@ int64_t dph_planner_counter(int which) {
 int64_t dph_overlap_step_lines(void* hh) { return ((OverlapH*)hh)->run.pafLines; }  // PAF lines of the last step
 // host-logic test hook: the value table (commands/overlap.go:55-92) from a k-mer histogram; counts is overwritten with the
 // merged forward + reverse-complement counts like the reference's in-place loop
+// ---- test hooks: three decision rules of the host side on bare numbers, held to answers worked by hand from the reference's Go
+// text (tests/golden/hand/, tests/test_hand_known_answers.py) - not part of the pipeline's boundary
+int dph_hand_is_consistent(const int64_t* left5, const int64_t* right4, int circular, int64_t ref_len) {
+    return dph::handIsConsistent((const dph::i64*)left5, (const dph::i64*)right4, circular != 0, (dph::i64)ref_len) ? 1 : 0;
+}
+int dph_hand_remove_dominated(const int64_t* maps3, int n, int64_t query_len, int* kept) {
+    return dph::handRemoveDominated((const dph::i64*)maps3, n, (dph::i64)query_len, kept);
+}
+void dph_hand_trim_indices(int upto, const int32_t* match_a, const int64_t* off, int n_matches, int min_match, int length, int* out2) {
+    std::vector<dph::SeedMatch> store((size_t)n_matches);
+    std::vector<dph::SeedMatch*> ms;
+    for (int i = 0; i < n_matches; i++) {
+        store[(size_t)i].MatchA.assign(match_a + off[i], match_a + off[i + 1]);
+        ms.push_back(&store[(size_t)i]);
+    }
+    dph::trimBestIndices(upto, ms, min_match, length, &out2[0], &out2[1]);
+}
+
 void dph_values_from_counts(uint64_t* counts, int k, double* out) {
     std::vector<uint64_t> c(counts, counts + ((size_t)1 << (2 * k)));
     std::vector<double> v = kmerValuesFromCounts(c, k);

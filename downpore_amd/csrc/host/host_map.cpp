@@ -538,6 +538,42 @@ std::string MapperImpl::asString(const Mapping& m, const std::string& qname, i64
 
 }  // namespace
 
+// ---- test hooks: the mapper's two decision rules on bare numbers (tests/test_hand_known_answers.py: answers worked from the Go text)
+// l = {RC, Query.Len(), QueryInset, Start, End}, r = {RC, QueryOffset, Start, End}
+bool handIsConsistent(const i64* l, const i64* r, bool circular, i64 refLen) {
+    MapperImpl m;
+    m.circular = circular;
+    m.refLen = refLen;
+    Mapping L, R;
+    L.RC = l[0] != 0;
+    L.queryLen = l[1];
+    L.hasQuery = true;
+    L.QueryInset = l[2];
+    L.Start = l[3];
+    L.End = l[4];
+    R.RC = r[0] != 0;
+    R.QueryOffset = r[1];
+    R.Start = r[2];
+    R.End = r[3];
+    return m.isConsistent(&L, &R);
+}
+// maps = n x {QueryOffset, QueryInset, ids}; kept[] = indices of the survivors in the order removeDominated returns them
+int handRemoveDominated(const i64* maps, int n, i64 queryLen, int* kept) {
+    std::vector<Mapping> store((size_t)n);
+    std::vector<Mapping*> open;
+    for (int i = 0; i < n; i++) {
+        store[(size_t)i].QueryOffset = maps[3 * i];
+        store[(size_t)i].QueryInset = maps[3 * i + 1];
+        store[(size_t)i].ids = maps[3 * i + 2];
+        open.push_back(&store[(size_t)i]);
+    }
+    std::vector<Mapping*> out = removeDominated(open, queryLen);
+    for (size_t i = 0; i < out.size(); i++) kept[i] = (int)(out[i] - store.data());
+    return (int)out.size();
+}
+namespace {
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------------------------
 // commands/map.go:33-116 + NewMapper mapping.go:67-109
 

@@ -1220,12 +1220,10 @@ static SeedSeq* multiAlignerCore(Arena& arena, std::vector<SeedSeq*>& seqs, std:
 // ---------------------------------------------------------------------------------------------------------------
 // overlap/combine.go
 
-static void trimToBestSeed(Arena& ar, int upto, std::vector<SeedMatch*>& ms, int minMatch, int k, std::vector<SeedSeq*>& parts,
-                           std::vector<uint8_t>& cantTrim, i64* badBack) {  // :21-111
-    parts.assign(ms.size(), nullptr);
-    cantTrim.assign(ms.size(), 0);
+// step 1 of trimToBestSeed (:24-58): the best front and back seeds of the consensus (also what tests/test_hand_known_answers.py holds to
+// answers worked from the Go text: dph_hand_trim_indices)
+void trimBestIndices(int upto, const std::vector<SeedMatch*>& ms, int minMatch, int length, int* bestOut, int* backOut) {
     int bestCount = 0, bestScore = 0, bestIndex = upto, backCount = 0, backScore = 0;
-    const int length = ms[0]->SeqA->numSeeds();
     int backIndex = length - upto - 1;
     // count[i] = matches whose MatchA holds consensus seed i; bCount[i] = ... holds seed length-1-i at a position j >= 1
     // (the reference's backward walk stops before j = 0, :40-46).  MatchA is strictly ascending, so one pass over the
@@ -1279,6 +1277,16 @@ static void trimToBestSeed(Arena& ar, int upto, std::vector<SeedMatch*>& ms, int
             backIndex = length - 1 - i;
         }
     }
+    *bestOut = bestIndex;
+    *backOut = backIndex;
+}
+
+static void trimToBestSeed(Arena& ar, int upto, std::vector<SeedMatch*>& ms, int minMatch, int k, std::vector<SeedSeq*>& parts,
+                           std::vector<uint8_t>& cantTrim, i64* badBack) {  // :21-111
+    parts.assign(ms.size(), nullptr);
+    cantTrim.assign(ms.size(), 0);
+    int bestIndex = 0, backIndex = 0;
+    trimBestIndices(upto, ms, minMatch, ms[0]->SeqA->numSeeds(), &bestIndex, &backIndex);
     SeedSeq* consensus = seqTrimmed(ar, ms[0]->SeqA, 0, bestIndex, 0, backIndex, k);
     for (size_t j = 0; j < ms.size(); j++) {
         SeedMatch* match = ms[j];

@@ -141,6 +141,18 @@ DPH_API void dph_map_stats(void* m, double* out);
 /* ---- test hooks (host logic without a GPU, counters) ------------------------------------------------------------------------ */
 DPH_API const char* dph_reads_dump(void* reads, int64_t* n);
 DPH_API void dph_values_from_counts(uint64_t* counts, int k, double* out);
+
+/* ---- test hooks (not part of the boundary): decision rules of the host side on bare numbers, held by tests/test_hand_known_answers.py
+ * to answers worked by hand from the reference's Go text (the files under tests/golden/hand).
+ * dph_hand_is_consistent   mapping.isConsistent (mapping/mapping.go:131-160): left5 = {RC, Query.Len(), QueryInset, Start, End},
+ *                          right4 = {RC, QueryOffset, Start, End}
+ * dph_hand_remove_dominated  removeDominated (mapping.go:387-428): maps3 = n x {QueryOffset, QueryInset, ids}; kept[] = the survivors'
+ *                          indices in the order the function returns them; returns their number
+ * dph_hand_trim_indices    step 1 of trimToBestSeed (overlap/combine.go:24-58): match i's MatchA = match_a[off[i] .. off[i + 1]);
+ *                          out2 = {bestIndex, backIndex} */
+DPH_API int dph_hand_is_consistent(const int64_t* left5, const int64_t* right4, int circular, int64_t ref_len);
+DPH_API int dph_hand_remove_dominated(const int64_t* maps3, int n, int64_t query_len, int* kept);
+DPH_API void dph_hand_trim_indices(int upto, const int32_t* match_a, const int64_t* off, int n_matches, int min_match, int length, int* out2);
 DPH_API void dph_profile_print(void);
 /* process-wide pipeline counters since the process started: 0 plans computed, 1 thrown away, 2 erased by a commit's flags, 3 rounds
    executed, 4 rejected at the commit, 5 committed, 6 us in plan computes (wall, all lanes), 7 us the slots waited for plans,

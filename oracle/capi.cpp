@@ -161,6 +161,72 @@ int dpo_match(const int64_t* seqSeg, int64_t sN, const int64_t* qSeg, int64_t qN
     });
 }
 
+// ---- decision rules on bare numbers (tests/test_hand_known_answers.py: answers worked by hand from the Go text) ----------------
+// chunkWorker (overlap/overlap.go:253-318) on one seed sequence; out = 5 values per piece handed to AddSequence: first seed, seeds,
+// Len(), GetOffset(), GetInset()
+int dpo_hand_chunks(const int64_t* seg, int64_t n, int64_t length, int64_t offset, int64_t inset, int64_t chunkSize, int64_t overlap,
+                    int64_t minSeeds, int k, int64_t* out, int64_t cap, int64_t* nOut) {
+    return guard([&] {
+        Arena ar;
+        SeedSequence* s = mkSeq(ar, seg, n);
+        s->length = length;
+        s->offset = offset;
+        s->inset = inset;
+        int64_t made = 0;
+        chunkPieces(ar, s, chunkSize, overlap, minSeeds, k, [&](SeedSequence* piece) {
+            if (made < cap) {
+                out[5 * made] = ((int64_t)piece->lo - (int64_t)s->lo) / 2;
+                out[5 * made + 1] = piece->numSeeds();
+                out[5 * made + 2] = piece->length;
+                out[5 * made + 3] = piece->offset;
+                out[5 * made + 4] = piece->inset;
+            }
+            made++;
+        });
+        *nOut = made;
+    });
+}
+// step 1 of trimToBestSeed (overlap/combine.go:24-58): match i's MatchA = matchA[off[i] .. off[i + 1]); out2 = {bestIndex, backIndex}
+int dpo_hand_trim_indices(int64_t upto, const int64_t* matchA, const int64_t* off, int64_t nMatches, int64_t minMatch, int64_t length,
+                          int64_t* out2) {
+    return guard([&] {
+        std::vector<SeedMatch> store((size_t)nMatches);
+        std::vector<SeedMatch*> ms;
+        for (int64_t i = 0; i < nMatches; i++) {
+            store[(size_t)i].MatchA.assign(matchA + off[i], matchA + off[i + 1]);
+            ms.push_back(&store[(size_t)i]);
+        }
+        trimBestIndices(upto, ms, minMatch, length, &out2[0], &out2[1]);
+    });
+}
+// isConsistent (mapping/mapping.go:131-160): left5 = {RC, Query.Len(), QueryInset, Start, End}, right4 = {RC, QueryOffset, Start, End}
+int dpo_hand_is_consistent(const int64_t* left5, const int64_t* right4, int circular, int64_t refLen) {
+    Mapping L, R;
+    L.RC = left5[0] != 0;
+    L.QueryInset = left5[2];
+    L.Start = left5[3];
+    L.End = left5[4];
+    R.RC = right4[0] != 0;
+    R.QueryOffset = right4[1];
+    R.Start = right4[2];
+    R.End = right4[3];
+    return mappingsConsistent(&L, left5[1], &R, circular != 0, refLen) ? 1 : 0;
+}
+// removeDominated (mapping.go:387-428): maps3 = n x {QueryOffset, QueryInset, ids}; kept[] = the survivors' indices in returned order
+int dpo_hand_remove_dominated(const int64_t* maps3, int n, int64_t queryLen, int* kept) {
+    std::vector<Mapping> store((size_t)n);
+    std::vector<Mapping*> open;
+    for (int i = 0; i < n; i++) {
+        store[(size_t)i].QueryOffset = maps3[3 * i];
+        store[(size_t)i].QueryInset = maps3[3 * i + 1];
+        store[(size_t)i].ids = maps3[3 * i + 2];
+        open.push_back(&store[(size_t)i]);
+    }
+    std::vector<Mapping*> out = removeDominated(open, nullptr, queryLen);
+    for (size_t i = 0; i < out.size(); i++) kept[i] = (int)(out[i] - store.data());
+    return (int)out.size();
+}
+
 // ---- k-mer value table -----------------------------------------------------------------------
 struct ReadSetH {
     FastaSet set;

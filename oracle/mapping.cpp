@@ -53,12 +53,15 @@ std::string Mapper::asString(const Mapping& m) const {
 
 // isConsistent :131-160
 bool Mapper::isConsistent(const Mapping* left, const Mapping* right) const {
+    return mappingsConsistent(left, left->Query->length, right, circular, reference.length);
+}
+bool mappingsConsistent(const Mapping* left, i64 leftQueryLen, const Mapping* right, bool circular, i64 referenceLength) {
     if (left->RC != right->RC) return false;
-    i64 expectedDistance = right->QueryOffset - left->Query->length + left->QueryInset;
+    i64 expectedDistance = right->QueryOffset - leftQueryLen + left->QueryInset;
     i64 distance;
     if (!left->RC) distance = right->Start - left->End;
     else distance = left->Start - right->End;
-    if (circular && distance < -50) distance += reference.length;
+    if (circular && distance < -50) distance += referenceLength;
     if (distance < 50 && expectedDistance < 50 && distance > -50) return true;
     if (distance < 500) return (expectedDistance < (distance * 3) / 2 && expectedDistance > (distance * 2) / 3);
     if (distance > 5000) return (expectedDistance < (distance * 10) / 9 && expectedDistance > (distance * 9) / 10);
@@ -68,7 +71,7 @@ bool Mapper::isConsistent(const Mapping* left, const Mapping* right) const {
 }
 
 // removeDominated :387-428
-static std::vector<Mapping*> removeDominated(std::vector<Mapping*> open, const std::vector<Mapping*>* extendedIn,
+std::vector<Mapping*> removeDominated(std::vector<Mapping*> open, const std::vector<Mapping*>* extendedIn,
                                              i64 queryLen) {
     // every call site passes the same slice for open and extended: sorting open reorders extended too.
     if (open.empty()) return open;

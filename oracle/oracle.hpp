@@ -36,6 +36,7 @@
 #include <cstddef>
 #include <memory>
 #include <string>
+#include <functional>
 #include <vector>
 
 namespace dpo {
@@ -249,6 +250,10 @@ struct Overlapper {
     std::vector<std::unique_ptr<SeedMatch>> findOverlaps(const std::vector<SeedQuery>& queries);  // :320 + matchWorker :346
 };
 
+// pieces of overlap.go / combine.go / mapping.go that tests/test_hand_known_answers.py calls on bare numbers (capi.cpp: dpo_hand_*)
+void chunkPieces(Arena& ar, SeedSequence* s, i64 chunkSize, i64 overlap, i64 minSeeds, int k, const std::function<void(SeedSequence*)>& add);  // overlap.go:253-318
+void trimBestIndices(i64 upto, const std::vector<SeedMatch*>& ms, i64 minMatch, i64 length, i64* bestOut, i64* backOut);                    // combine.go:24-58
+
 // overlap/combine.go
 struct SeedContig {
     SeedSequence* Combined = nullptr;
@@ -300,6 +305,8 @@ struct Mapping {
     bool RC = false;
     i64 ids = 0;
 };
+bool mappingsConsistent(const Mapping* left, i64 leftQueryLen, const Mapping* right, bool circular, i64 referenceLength);  // mapping.go:131-160
+std::vector<Mapping*> removeDominated(std::vector<Mapping*> open, const std::vector<Mapping*>* extendedIn, i64 queryLen);  // mapping.go:387-428
 struct Mapper {
     SeedIndex index;
     PackedSeq reference;

@@ -265,13 +265,15 @@ std::vector<SeedQuery> Overlapper::prepareQueries(i64 numSeeds, i64 seedLimit, c
     return queries;
 }
 
-// chunkWorker :253-318 (body for one SeedSequence)
+// chunkWorker :253-318 (body for one SeedSequence); every piece it would hand to AddSequence goes to `add` (the index's, or a test's)
+void chunkPieces(Arena& ar, SeedSequence* s, i64 chunkSize, i64 overlap, i64 minSeeds, int k, const std::function<void(SeedSequence*)>& add);
 void Overlapper::chunkAndAdd(SeedSequence* s) {
-    int k = index.seedSize;
-    Arena& ar = index.arena;
+    chunkPieces(index.arena, s, chunkSize, overlap, minSeeds, index.seedSize, [&](SeedSequence* piece) { index.addSequence(piece); });
+}
+void chunkPieces(Arena& ar, SeedSequence* s, i64 chunkSize, i64 overlap, i64 minSeeds, int k, const std::function<void(SeedSequence*)>& add) {
     i64 numChunks = s->length / chunkSize + 1;
     if (numChunks == 1 || s->numSeeds() < minSeeds * 3) {
-        if (s->numSeeds() >= minSeeds) index.addSequence(s);
+        if (s->numSeeds() >= minSeeds) add(s);
         return;
     }
     i64 prevSeedIndex = 0;
@@ -281,11 +283,11 @@ void Overlapper::chunkAndAdd(SeedSequence* s) {
         i64 seedCount = 0;
         if (prevSeedIndex >= s->numSeeds() - 150) {
             if (prevSeedIndex == 0) {
-                index.addSequence(s);
+                add(s);
             } else {
                 i64 newFirstGap = s->getNextSeedOffset(prevSeedIndex - 1, k) - k;
                 lengthInBases += s->getSeedOffsetFromEnd(prevSeedIndex, k) + k + newFirstGap;
-                index.addSequence(ssSubSequence(ar, s, prevSeedIndex, s->numSeeds() - 1, lengthInBases,
+                add(ssSubSequence(ar, s, prevSeedIndex, s->numSeeds() - 1, lengthInBases,
                                                 totalOffset - newFirstGap, 0));
             }
             break;
@@ -295,7 +297,7 @@ void Overlapper::chunkAndAdd(SeedSequence* s) {
         if (seedCount >= minSeeds) {
             i64 newFirstGap = s->getNextSeedOffset(prevSeedIndex - 1, k) - k;
             lengthInBases += newFirstGap;
-            index.addSequence(ssSubSequence(ar, s, prevSeedIndex, prevSeedIndex + seedCount - 1, lengthInBases,
+            add(ssSubSequence(ar, s, prevSeedIndex, prevSeedIndex + seedCount - 1, lengthInBases,
                                             totalOffset - newFirstGap,
                                             s->length - totalOffset - lengthInBases + newFirstGap));
             totalOffset += lengthInBases - newFirstGap;
@@ -395,14 +397,23 @@ std::vector<std::unique_ptr<SeedMatch>> Overlapper::findOverlaps(const std::vect
 // ---------------------------------------------------------------------------------------------
 // overlap/combine.go
 
+static void trimRest(Arena& ar, std::vector<SeedMatch*>& ms, int k, i64 bestIndex, i64 backIndex, SeedSequence* consensus,
+                     std::vector<SeedSequence*>& parts, std::vector<uint8_t>& cantTrim, i64* badBack);
 // trimToBestSeed :21-111
 static void trimToBestSeed(Arena& ar, i64 upto, std::vector<SeedMatch*>& ms, i64 minMatch, int k,
                            SeedSequence** consensusOut, std::vector<SeedSequence*>& parts,
                            std::vector<uint8_t>& cantTrim, i64* badBack) {
     parts.assign(ms.size(), nullptr);
     cantTrim.assign(ms.size(), 0);
+    i64 bestIndex = 0, backIndex = 0;
+    trimBestIndices(upto, ms, minMatch, ms[0]->SeqA->numSeeds(), &bestIndex, &backIndex);
+    SeedSequence* consensus = ssTrimmed(ar, ms[0]->SeqA, 0, bestIndex, 0, backIndex, k, nullptr);
+    trimRest(ar, ms, k, bestIndex, backIndex, consensus, parts, cantTrim, badBack);
+    *consensusOut = consensus;
+}
+// step 1 of trimToBestSeed, :24-58: the best front and back seeds
+void trimBestIndices(i64 upto, const std::vector<SeedMatch*>& ms, i64 minMatch, i64 length, i64* bestOut, i64* backOut) {
     i64 bestCount = 0, bestScore = 0, bestIndex = upto, backCount = 0, backScore = 0;
-    i64 length = ms[0]->SeqA->numSeeds();
     i64 backIndex = length - upto - 1;
     for (i64 i = 0; i < upto; i++) {
         i64 count = 0, bCount = 0;
@@ -428,7 +439,12 @@ static void trimToBestSeed(Arena& ar, i64 upto, std::vector<SeedMatch*>& ms, i64
             backIndex = length - 1 - i;
         }
     }
-    SeedSequence* consensus = ssTrimmed(ar, ms[0]->SeqA, 0, bestIndex, 0, backIndex, k, nullptr);
+    *bestOut = bestIndex;
+    *backOut = backIndex;
+}
+// step 2, :59-110
+static void trimRest(Arena& ar, std::vector<SeedMatch*>& ms, int k, i64 bestIndex, i64 backIndex, SeedSequence* consensus,
+                     std::vector<SeedSequence*>& parts, std::vector<uint8_t>& cantTrim, i64* badBack) {
     for (size_t j = 0; j < ms.size(); j++) {
         SeedMatch* match = ms[j];
         i64 index, bases, frontDistance, bIndex, backBases, backDistance;
@@ -467,7 +483,6 @@ static void trimToBestSeed(Arena& ar, i64 upto, std::vector<SeedMatch*>& ms, i64
             match->MatchB[n] = oldIndex - index;
         }
     }
-    *consensusOut = consensus;
 }
 
 // NewSeedContig :113-133
