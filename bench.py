@@ -422,14 +422,12 @@ def main():
                                 "rounds": (elapsed - t_init_sum) / n_jobs, "upload_pack_once": upload["upload_pack_s"],
                                 "context_once": upload["context_s"], "per_job": per_job,
                                 "per_job_ms_setup_waitplan_waitfmt_commitidle_longest_step_waits": per_job_parts},
-            "kernels_per_round": {kk: {"ms": v[0], "algorithmic_bytes": v[1], "GBs": (v[1] / 1e9) / (v[0] / 1e3) if v[0] > 0 else 0.0,
-                                       "frac_of_hbm_peak": ((v[1] / 1e9) / (v[0] / 1e3)) / HBM_PEAK_GBS if v[0] > 0 else 0.0}
-                                  for kk, v in kern.items()},
+            "kernels_per_round": kernels_table(acc, rounds, acc.get("timed_rounds", 0.0), index_mode=main_index),
             "scan_mode": "resident k-mer position index" if main_index else "scan kernels",
             "scan_kernels_leg": scan_leg, "index_query_dense": dense_leg, "index_query_dense_slots": dense_leg5, "overlap_default_k10_job": dense_job, "map_config3": map_leg, "alt_mode": alt,
             "paf_lines": lines, "rounds_per_s": rounds / elapsed if elapsed > 0 else 0.0,
             "phase_ms_per_round": {kk: 1e3 * per_round(kk) for kk in ("t_prepare", "t_scan", "t_index", "t_query", "t_consensus")},
-            "kernel_ms_per_round": {kk: per_round(kk) for kk in ("k_count_ms", "k_write_ms", "k_scan_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
+            "kernel_ms_per_round": {kk: per_round(kk) for kk in ("k_count_ms", "k_write_ms", "k_scan_ms", "k_index_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
             "kernel_event_sampling": {"rounds_with_events": acc.get("timed_rounds", 0.0), "rounds": float(rounds),
                                       "note": "HIP events bracket the kernels of every 8th round of an executor slot in the timed jobs (every event is a packet of its own: 7 % of a job when every round carries them); the legs time every round"},
             "setup_s": {"generate": t_gen},
@@ -446,6 +444,44 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def kernels_table(tot, rounds, timed_rounds, index_mode=True):
+    """Per-round kernel groups of a job with their algorithmic bytes, HIP-event times (means over the rounds whose kernels
+    carried events) and what that is of the HBM peak.  Bytes: chain / query / consensus / counting step are summed by the kernels
+    themselves (per pair, per query, per window, per bucket entry); the write step moves 8 B per seed occurrence (a record in, a
+    (gap, seed) pair out: 8 H counted once, as SURVEY's B_scan counts the survivors' pairs); the index build reads those pairs (8 H) and
+    writes the two bit matrices, 8 (S ceil(M / 64) + M ceil(S / 64)) - S seeds, M indexed sequences of the round (means over the job)."""
+    n = max(1.0, float(rounds))
+    nt = max(1.0, float(timed_rounds))
+    H = tot.get("idx_hits", 0.0) / n
+    S = tot.get("n_seeds", 0.0) / n
+    M = tot.get("n_indexed", 0.0) / n
+    build_bytes = 8.0 * H + 8.0 * (S * ((M + 63) // 64) + M * ((S + 63) // 64))
+    rows = {
+        "chain_kernels": (tot.get("k_chain_ms", 0.0) / nt, tot.get("chain_bytes", 0.0) / n, "pair_scan + chain_walk + chain_spec + chain_resolve (A6 + A7 + A8)"),
+        "query_kernel": (tot.get("k_query_ms", 0.0) / nt, tot.get("query_bytes", 0.0) / n, "query_kernel (A14 + A5)"),
+        "consensus_kernel": (tot.get("k_cons_ms", 0.0) / nt, tot.get("cons_bytes", 0.0) / n, "match_anchor + consensus_full_kernel (A15 + A16 + A17 numbers)"),
+        "index_build": (tot.get("k_index_ms", 0.0) / nt, build_bytes, "chunk_kernel + index_fill(_rows) + posting_transpose + posting_meta (A12 + A13)"),
+    }
+    if index_mode:
+        rows["index_counting_step"] = (tot.get("k_count_ms", 0.0) / nt, tot.get("count_bytes", 0.0) / n, "kidx_prepare + kidx_walk_bin + kidx_bin_count + kidx_offsets (A2 / A10 without a scan: count)")
+        rows["index_write_step"] = (tot.get("k_write_ms", 0.0) / nt, 8.0 * H, "kidx_bin_fill + kidx_sortwrite, or kidx_bin_sort_dense (A2 / A10: the survivors' segments)")
+    else:
+        rows["scan_count_pass"] = (tot.get("k_count_ms", 0.0) / nt, tot.get("count_bytes", 0.0) / n, "scan_kernel<0>")
+        rows["scan_write_pass"] = (tot.get("k_write_ms", 0.0) / nt, 8.0 * H, "scan_kernel<1>")
+    return {kk: {"kernels": v[2], "ms": v[0], "algorithmic_bytes": v[1], "GBs": (v[1] / 1e9) / (v[0] / 1e3) if v[0] > 0 else 0.0,
+                 "frac_of_hbm_peak": ((v[1] / 1e9) / (v[0] / 1e3)) / HBM_PEAK_GBS if v[0] > 0 else 0.0} for kk, v in rows.items()}
+
+
+def k10_traffic():
+    """PMC traffic of the k = 10 job's kernels (profiles/r06/pmc_k10.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same job,
+    corrected as MI355X_MICROARCH.md prescribes; bytes per launch), or None where the file is missing."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r06", "pmc_k10.json")))["kernels"]
+        return {kk: v.get("hbm_bytes_per_launch") for kk, v in d.items() if v.get("hbm_bytes_per_launch")}
+    except Exception:
+        return None
 
 
 def ground_truth(paf, off, starts, strands, k, sample=200000):
@@ -659,7 +695,9 @@ def dense_job_leg(reads, args, torch, off, truth_starts, truth_strands):
     return {"workload": "downpore overlap with the command's default k = 10 on the same reads (dense seeds: every read indexed in every round), whole job, %d executor slots" % args.slots,
             "value": lines / dt if dt > 0 else 0.0, "unit": "overlaps/s", "wall_s": dt, "setup_s": t_init, "rounds": rounds, "paf_lines": lines,
             "ms_per_round": 1e3 * (dt - t_init) / max(1, rounds),
-            "kernel_ms_per_round": {kk: tot.get(kk, 0.0) / nt for kk in ("k_count_ms", "k_write_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
+            "kernel_ms_per_round": {kk: tot.get(kk, 0.0) / nt for kk in ("k_count_ms", "k_write_ms", "k_index_ms", "k_query_ms", "k_chain_ms", "k_cons_ms")},
+            "kernels_per_round": kernels_table(tot, rounds, tot.get("timed_rounds", 0.0)),
+            "hbm_traffic_per_launch": k10_traffic(),
             "query_kernel_GBs": (tot.get("query_bytes", 0.0) / max(1, rounds) / 1e9) / (tot.get("k_query_ms", 0.0) / nt / 1e3) if tot.get("k_query_ms", 0.0) > 0 else 0.0,
             "parity": {"first_16_rounds_match_oracle_fixture": bool(fixture is not None and head_left == 0 and sha_head.hexdigest() == fixture["paf_sha256"]) if fixture else None},
             "ground_truth": ground_truth(b"".join(sample), off, truth_starts, truth_strands, 10) if sample else None}

@@ -64,7 +64,8 @@ struct dp_ctx {
     size_t kx_maxlen_reads = 0;   // ... of a read set of this many reads
     uint32_t kx_head_reads = 0;  // reads the zeroed extra-item list heads (d_kx_lo) are sized for
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [8], [9]: around the index build's kernels
+    bool index_marked = false;  // marks 8 / 9 were recorded for the round's index build (dp_consensus_paf reads them)
     hipEvent_t ev_sync = nullptr;  // blocking-sync event: waiting host threads sleep instead of polling
     std::string err;
     bool borrowed_reads = false;  // d_packed/d_boff/d_len belong to another context

@@ -1482,6 +1482,8 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
         ctx->cons_prev_pairs = ctx->n_pairs;
     }
     dp_find_stats(ctx, &out->query_kernel_ms, &out->chain_kernel_ms, &out->query_bytes, &out->chain_bytes);
+    out->index_kernel_ms = ctx->index_marked ? (double)dp_elapsed(ctx, 8, 9) : 0.0;
+    ctx->index_marked = false;
     out->n_indexed = h_nseq[0];
     float ms = 0;
     ms = dp_elapsed(ctx, 0, 1);

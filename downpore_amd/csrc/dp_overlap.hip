@@ -315,14 +315,39 @@ __device__ uint32_t chunk_one(const ChunkParams& P, uint32_t i, uint32_t at, Chu
             } else {
                 const long long newFirstGap = nextSeedOffset(prevSeedIndex - 1) - k;
                 long long fromEnd = seg[n - 1];  // seedOffsetFromEnd(prevSeedIndex, k)
-                for (int x = n - 3; x > prevSeedIndex * 2 + 1; x -= 2) fromEnd += seg[x] + k;
+                {
+                    // (eight loads in flight: one gap per trip to memory was a hundred dependent trips for a read of the dense regime)
+                    int x = n - 3;
+                    const int stop = prevSeedIndex * 2 + 1;
+                    for (; x - 14 > stop; x -= 16) {
+                        int32_t g[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) g[u] = seg[x - 2 * u];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) fromEnd += g[u] + k;
+                    }
+                    for (; x > stop; x -= 2) fromEnd += seg[x] + k;
+                }
                 lengthInBases += fromEnd + k + newFirstGap;
                 emit(prevSeedIndex, numSeeds - 1, lengthInBases, totalOffset - newFirstGap, 0);
             }
             break;
         }
-        for (; lengthInBases < P.chunkSize && seedCount < 100 && prevSeedIndex + seedCount < numSeeds; seedCount++)
-            lengthInBases += nextSeedOffset(prevSeedIndex + seedCount);
+        // (the gaps of the next eight seeds are asked for together; the sums and the three exit tests stay in the reference's order)
+        while (lengthInBases < P.chunkSize && seedCount < 100 && prevSeedIndex + seedCount < numSeeds) {
+            const int at0 = prevSeedIndex + seedCount;
+            const int have = min(8, min(100 - seedCount, numSeeds - at0));
+            int32_t g[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) g[u] = u < have ? seg[(at0 + u) * 2 + 2] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (u < have && lengthInBases < P.chunkSize) {
+                    lengthInBases += (long long)g[u] + k;
+                    seedCount++;
+                }
+            }
+        }
         if (seedCount >= P.minSeeds) {
             const long long newFirstGap = nextSeedOffset(prevSeedIndex - 1) - k;
             lengthInBases += newFirstGap;
@@ -518,6 +543,8 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
         const dp_zero_region z[3] = {{ctx->d_posting.p, zb_post}, {ctx->d_seedsets.p, zb_sets}, {ctx->d_nseqs.p, 8}};
         if (int rc = dp_zero_regions(ctx, z, 3)) return rc;
     }
+    DP_HIP(dp_mark(ctx, 8));
+    ctx->index_marked = ctx->timing_on;
     if (n_survivors) {
         ChunkParams P;
         P.s_item = s_item;
@@ -583,6 +610,7 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
         dp_launch<posting_meta_kernel>(ctx, dim3(blocks), dim3(256), (const u64*)ctx->d_posting.p, S, W, (uint32_t*)ctx->d_pmeta.p);
         DP_HIP(hipGetLastError());
     }
+    DP_HIP(dp_mark(ctx, 9));
     return DP_OK;
 }
 

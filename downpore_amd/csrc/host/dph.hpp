@@ -281,6 +281,7 @@ struct RoundStats {
     double t_prepare = 0, t_scan = 0, t_index = 0, t_query = 0, t_consensus = 0;  // host wall seconds
     double k_scan_ms = 0, k_query_ms = 0, k_chain_ms = 0;                         // device kernel ms
     double k_count_ms = 0, k_write_ms = 0;                                        // scan passes
+    double k_index_ms = 0;                                                        // index build (chunks on the device)
     double k_cons_ms = 0;                                                         // consensus alignment kernel
     uint64_t count_bytes = 0;                                                     // algorithmic bytes of the count pass
     uint64_t scan_bases = 0, scan_items = 0, scan_bytes = 0, query_bytes = 0;
@@ -293,6 +294,7 @@ struct RoundStats {
     void add(const RoundStats& o) {
         t_prepare += o.t_prepare, t_scan += o.t_scan, t_index += o.t_index, t_query += o.t_query, t_consensus += o.t_consensus;
         k_scan_ms += o.k_scan_ms, k_query_ms += o.k_query_ms, k_chain_ms += o.k_chain_ms, k_count_ms += o.k_count_ms;
+        k_index_ms += o.k_index_ms;
         k_write_ms += o.k_write_ms, k_cons_ms += o.k_cons_ms, count_bytes += o.count_bytes, scan_bases += o.scan_bases;
         scan_items += o.scan_items, scan_bytes += o.scan_bytes, query_bytes += o.query_bytes, n_queries += o.n_queries;
         n_indexed += o.n_indexed, n_hits += o.n_hits, n_matches += o.n_matches, n_paf += o.n_paf, n_seeds += o.n_seeds;

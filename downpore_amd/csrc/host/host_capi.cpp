@@ -396,7 +396,7 @@ static void statsOut(OverlapH* h, const RoundStats& s, double* out) {
                   (double)s.scan_bases, (double)s.scan_items, (double)s.scan_bytes, (double)s.query_bytes, (double)s.n_queries,
                   (double)s.n_indexed, (double)s.n_hits, (double)s.n_matches, (double)s.n_paf, (double)s.n_seeds,
                   (double)h->run.round, (double)h->run.badBack, (double)h->run.emptyMatch, s.k_count_ms, s.k_write_ms,
-                  (double)s.count_bytes, s.k_cons_ms, (double)s.idx_rounds, (double)s.idx_hits, (double)s.chain_bytes, (double)s.timed_rounds, (double)s.gang_members, (double)s.cons_bytes};
+                  (double)s.count_bytes, s.k_cons_ms, (double)s.idx_rounds, (double)s.idx_hits, (double)s.chain_bytes, (double)s.timed_rounds, (double)s.gang_members, (double)s.cons_bytes, s.k_index_ms};
     memcpy(out, v, sizeof v);
 }
 void* dph_overlap_ctx(void* hh) { return ((OverlapH*)hh)->ctx; }

@@ -703,6 +703,7 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
         st.chain_bytes += pb.chain_bytes;
     }
     st.k_cons_ms += pb.kernel_ms;
+    st.k_index_ms += pb.index_kernel_ms;
     const double tq2 = now();
     g_prof.add(10, tq2 - tq1);
     // windows the device left to the host: BuildConsensus + finalCheckWorker on the fetched matches, one window at a time

@@ -17,7 +17,7 @@ _host = None
 
 STAT_FIELDS = ["t_prepare", "t_scan", "t_index", "t_query", "t_consensus", "k_scan_ms", "k_query_ms", "k_chain_ms",
                "scan_bases", "scan_items", "scan_bytes", "query_bytes", "n_queries", "n_indexed", "n_hits", "n_matches",
-               "n_paf", "n_seeds", "round", "bad_back", "empty_match", "k_count_ms", "k_write_ms", "count_bytes", "k_cons_ms", "idx_rounds", "idx_hits", "chain_bytes", "timed_rounds", "gang_members", "cons_bytes"]
+               "n_paf", "n_seeds", "round", "bad_back", "empty_match", "k_count_ms", "k_write_ms", "count_bytes", "k_cons_ms", "idx_rounds", "idx_hits", "chain_bytes", "timed_rounds", "gang_members", "cons_bytes", "k_index_ms"]
 
 
 def host_lib_path():

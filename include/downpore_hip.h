@@ -410,6 +410,7 @@ typedef struct {
     uint32_t n_indexed;              /* sequences in the round's index (exact also after dp_index_build_chunked) */
     double query_kernel_ms, chain_kernel_ms;  /* the chaining stage this call finished (dp_find_overlaps, want_candidates bit 2) */
     uint64_t query_bytes, chain_bytes;
+    double index_kernel_ms;          /* device time of the round's index build (dp_index_build_chunked: chunk, seed-set rows, posting matrix, row meta) */
 } dp_paf_batch;
 DP_API int dp_consensus_paf(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs, const int32_t* rc_of, uint32_t n_seeds, int k,
                             int overlap_size, dp_paf_batch* out);
