@@ -305,8 +305,8 @@ extern "C" int dp_allgather_survivors(dp_comm* c, dp_ctx* ctx, const dp_survivor
 
 static int allgather_survivors_impl(dp_comm* c, dp_ctx* ctx, const dp_survivor_batch* local, dp_survivor_batch* all) {
     hipSetDevice(ctx->device);
-    if (const char* e = getenv("DP_COMM_FAIL_RANK"))  // test hook: this rank fails before it meets its peers
-        if (atoi(e) == c->rank) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_survivors: injected failure (DP_COMM_FAIL_RANK)");
+    if (const long fr = dp_tune("comm_fail_rank", -1); fr >= 0)  // test hook: this rank fails before it meets its peers
+        if (fr == c->rank) return dp_fail(ctx, DP_ERR_STATE, "dp_allgather_survivors: injected failure (DP_COMM_FAIL_RANK)");
     const int N = c->n_ranks, me = c->rank;
     const uint32_t ns = local->n_survivors, ne = local->n_extra;
     // local layout of d_segs: survivors' segments first, then the extra items'

@@ -31,15 +31,8 @@ struct PinBuf {
 struct dp_kindex;
 
 struct FindState;
-struct dp_gang;
 struct dp_ctx {
     int device = 0;
-    // gang membership (dp_gang.hip): inside a round the member's per-round launches are deposited and issued together with the
-    // other members'; `stream` is the gang's stream while the context is a member (own_stream: its own, restored afterwards)
-    dp_gang* gang = nullptr;
-    int gang_slot = -1;
-    bool gang_in_round = false;
-    int gang_round_members = 1;      // members that started their rounds together with this one (what a merged launch carries)
     hipStream_t own_stream = nullptr;
     bool destroy_pending = false;    // dp_ctx_destroy of an owner whose reads are still borrowed: carried out by the last borrower
     dp_ctx* owner = nullptr;     // context whose reads (and k-mer position index) this one borrows
@@ -159,7 +152,6 @@ struct dp_ctx {
     const uint64_t* qoff_dev = nullptr;
     DevBuf d_qsegs, d_qoff, d_qsets, d_qmeta, d_cand, d_pool, d_mrec, d_ma, d_mb, d_cursor, d_sched, d_manchor;
     DevBuf d_pbase, d_pspec, d_clist, d_sa, d_sb;  // chaining stage: pair offsets, proposals, candidate lists, scratch columns
-    DevBuf d_qscan;                                // the index query's workgroup counter (QScan, dp_overlap.hip): zero between launches
     uint32_t n_pairs = 0;                          // (query, candidate) pair slots of the last dp_find_overlaps
     uint32_t last_nq = 0, last_ni = 0;             // its queries / packed chain ints
     size_t q_pre_bytes = 0;                        // dp_query_prestage: bytes of the announced query block in h_qup (0: none)
@@ -254,6 +246,10 @@ int dp_kindex_ensure(dp_ctx* ctx, int k);
 struct dp_comm;
 int dp_comm_allgather_ranges(dp_comm* c, dp_ctx* ctx, void* dst, size_t elem, const uint64_t* first, const void* src);  // dp_comm.hip
 bool dp_comm_is_rccl(const dp_comm* c);  // dp_comm.hip
+// DP_DEBUG=a,b,c: diagnosis output of the named parts (no change of behaviour).  DP_TUNE=key=value,...: the numbers experiments vary
+// (grids, pools, polls; the defaults are what the measurements chose).  Both are read once per process.  (dp_scan.hip)
+bool dp_debug(const char* what);
+long dp_tune(const char* key, long dflt);
 // A rank's share of a k-mer position index built by several ranks (round 5): filled by dp_kindex_build_sorted from the first-digit
 // counts every rank computes alike - rank q sorts the k-mers [digit_first[q] << kmer_shift, digit_first[q + 1] << kmer_shift), which are
 // the entries [entry_first[q], entry_first[q + 1]) of the whole index; the offsets it writes are relative to its own first entry.
@@ -296,9 +292,8 @@ static inline const void* dp_chain_b(const dp_ctx* ctx) { return ctx->chains_pac
 uint32_t dp_find_pair_cap(const dp_ctx* ctx);
 int dp_find_complete(dp_ctx* ctx, bool* reran);
 void dp_find_stats(const dp_ctx* ctx, double* query_ms, double* chain_ms, uint64_t* query_bytes, uint64_t* chain_bytes);
-struct QScan;
 int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
-                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out = nullptr, const struct QScan* scan_in = nullptr);
+                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out = nullptr);
 
 // ---- device helpers ---------------------------------------------------------------------------------------
 // An entry of the resident k-mer position index (dp_kindex.hip; written by dp_kbuild.hip): fmt 8 = read << 32 | position in a

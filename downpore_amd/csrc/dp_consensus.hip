@@ -9,7 +9,9 @@
 #include <vector>
 
 #include "dp_common.h"
-#include "dp_gang.h"
+#include <string>
+
+#include "dp_launch.h"
 
 #define CA_WAVES 4
 #define CA_CAP 6144  // ints of one group staged in LDS
@@ -1364,20 +1366,22 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     A.segs = (const int32_t*)ctx->d_segs.p;
     A.smeta = metas ? (const dp_seq_meta*)ctx->d_cin.p : (const dp_seq_meta*)ctx->d_chunk_meta.p;
     {
-        static const uint32_t flag_every = getenv("DP_CONS_FLAG_EVERY") ? (uint32_t)atoi(getenv("DP_CONS_FLAG_EVERY")) : 0u;
+        static const uint32_t flag_every = (uint32_t)dp_tune("cons_flag_every", 0);  // (test hook: every n-th window goes to the host path)
         A.flag_every = flag_every;
-        static const uint32_t spin = getenv("DP_CONS_SPIN") ? (uint32_t)atoi(getenv("DP_CONS_SPIN")) * 100u : 0u;
+        static const uint32_t spin = 0u;
         A.spin_ticks = spin;
     }
     A.rc_of = (const int32_t*)((const uint8_t*)ctx->d_cin.p + b_meta);
-    // small LDS layout first (int16: needs every seed id below 2^15), the large one for what it lists; DP_CONS_SMALL=0: large only.
+    // small LDS layout first (int16: needs every seed id below 2^15), the large one for what it lists; DP_CONS_LAYOUTS=nosmall: large only.
     // The huge layout follows the large one from the round after the first in which a window did not fit the large one
-    // (ctx->cons_huge; DP_CONS_HUGE=1 / 0: always / never) - the sparse regime never pays its launch.
-    const char* small_env = getenv("DP_CONS_SMALL");  // (read per call: tests switch it between jobs of one process)
-    const bool small_off = small_env && small_env[0] == '0';
+    // (ctx->cons_huge; DP_CONS_LAYOUTS=huge / nohuge: always / never) - the sparse regime never pays its launch.
+    // DP_CONS_LAYOUTS (tests; read per call: they switch it between jobs of one process): "nosmall" = the large layout for every window,
+    // "eager" = the large layout launched behind the small one in every round, "huge" / "nohuge" = the huge layout always / never
+    const char* lay_env = getenv("DP_CONS_LAYOUTS");
+    const std::string lay = lay_env ? lay_env : "";
+    const bool small_off = lay.find("nosmall") != std::string::npos;
     const bool use_small = !small_off && n_seeds <= 32767;
-    const char* huge_env = getenv("DP_CONS_HUGE");
-    const bool use_huge = huge_env ? huge_env[0] != '0' : ctx->cons_huge;
+    const bool use_huge = lay.find("nohuge") != std::string::npos ? false : lay.find("huge") != std::string::npos ? true : ctx->cons_huge;
     // lists: [count of list 1 | count of list 2 | list 1: ng entries | list 2: ng entries] (both counts zeroed by the anchors launch)
     uint32_t* lists = nullptr;
     if (use_small || use_huge) {
@@ -1398,7 +1402,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     A.ignore_ids = (uint32_t*)(dout + b_gm + b_paf);
     A.out_cap = np;
     A.rec_cap = pending ? dp_find_pair_cap(ctx) : ctx->n_pairs;
-    static const bool cons_debug = getenv("DP_CONS_DEBUG") != nullptr;
+    static const bool cons_debug = dp_debug("cons");
     A.dbg = nullptr;
     if (cons_debug) {
         DP_HIP(dp_dev_malloc((void**)&A.dbg, (size_t)ng * 128));
@@ -1410,8 +1414,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     A.nseq_src = ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : nullptr;
     A.nseq_dst = h_nseq;
     bool lazy_large = false;
-    const char* lze = getenv("DP_CONS_LAZY_LARGE");  // (0: the large layout is launched behind the small one in every round, as before)
-    const bool lazy_off = lze && lze[0] == '0';
+    const bool lazy_off = lay.find("eager") != std::string::npos;
     DP_HIP(dp_mark(ctx, 0));
     {
         // small -> large -> huge: each layout works through what its predecessor listed and lists what it cannot hold for its
@@ -1565,7 +1568,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     }
     const uint8_t* h = (const uint8_t*)ctx->h_cout.p;
     {
-        static const bool why = getenv("DP_CONS_WHY") != nullptr;
+        static const bool why = dp_debug("cons_why");
         if (why) {
             const dp_group_meta* gms = (const dp_group_meta*)h;
             uint32_t hist[16] = {0}, nf = 0;

@@ -48,7 +48,6 @@ struct KbBuf {
     void* hi;
     int hb;  // bytes per entry in `hi`: 0, 1, 2 or 4; 8: `lo` is one stream of 64-bit words
 };
-static inline int kb_hi_bytes(int bits) { return bits <= 32 ? 0 : bits <= 40 ? 1 : bits <= 48 ? 2 : 4; }
 __device__ __forceinline__ kb_u64 kb_ld(const KbBuf B, kb_u64 i) {
     if (B.hb == 8) return ((const kb_u64*)B.lo)[i];
     kb_u64 v = B.lo[i];
@@ -480,7 +479,7 @@ __global__ __launch_bounds__(1024) void kb_scan_write(const kb_u64* __restrict__
 int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, uint64_t* d_off, void** d_pos_out, void** d_pos_hi_out,
                            int* fmt_out, int* pbits_out, uint64_t* n_pos_out, float* ms_out, dp_kindex_shard* shard) {
     if (k < 9 || k > 14 || ow->n_reads == 0) return 1;
-    if (getenv("DP_KINDEX_ATOMIC")) return 1;
+    if (dp_tune("kindex_atomic", 0)) return 1;  // (tests: the count -> offsets -> atomic scatter build of dp_kindex_ensure)
     const uint64_t n_groups = (ow->packed_bytes * 4 + 31) / 32;
     KbGeom G;
     G.k = k;
@@ -495,15 +494,11 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
         if (2 * k + G.pbits + G.rbits > 64) return 1;  // (the entry has no room for read and position: atomic scatter build)
     }
     const int pay = G.pbits + G.rbits;
-    // how the entries travel between the passes.  Default: one stream of 64-bit words.  DP_KB_STREAMS=1: two streams (4 + 0 / 1 / 2 / 4
-    // bytes, as narrow as the bits allow: 6 and 5 bytes per entry after passes 1 and 2 at config 2) - fewer bytes, and SLOWER on
-    // MI355X: a lane's 4 + 1- or 2-byte accesses are two memory instructions for less than one 8-byte access moves (part 2 3.8 ->
-    // 5.3 ms, last pass 4.8 -> 6.1, profiles/r04/kbuild_kernels.txt), the passes were never limited by bytes alone.
-    const bool streams = getenv("DP_KB_STREAMS") != nullptr;
-    // pass 1's width: 8 bits (with two streams: 9 when that brings its output down a size - config 2: 49 -> 48 bits); DP_KB_B1 overrides
+    // between the passes the entries travel as one stream of 64-bit words (two narrower streams - 4 + 1 or 2 bytes - move fewer bytes
+    // and were SLOWER on MI355X: two memory instructions per lane for less than one 8-byte access moves; profiles/r04/kbuild_kernels.txt;
+    // removed in round 6).  Pass 1's width: 8 bits (DP_TUNE=kb_b1=n overrides: tests)
     G.b1 = 8;
-    if (streams && kb_hi_bytes(2 * k - 9 + pay) < kb_hi_bytes(2 * k - 8 + pay) && 2 * k >= 9 + 8) G.b1 = 9;
-    if (const char* e = getenv("DP_KB_B1")) G.b1 = std::max(6, std::min(10, atoi(e)));
+    G.b1 = (int)std::max(6L, std::min(10L, dp_tune("kb_b1", G.b1)));
     if (G.b1 > 2 * k - 2) G.b1 = 2 * k - 2;
     // pass 2's width: sub-partitions of about 6000 entries (they are sorted inside LDS when they hold <= 8192)
     const uint64_t approx = ow->total_bases;
@@ -523,7 +518,8 @@ int dp_kindex_build_sorted(dp_ctx* ctx, dp_ctx* ow, int k, uint32_t* d_counts, u
     const uint32_t n_sub = (uint32_t)nb1 * (uint32_t)nb2;
     // how the entries are stored after each pass (DP_KINDEX_WIDE=1: eight bytes throughout, the index as read << 32 | position)
     const bool wide = getenv("DP_KINDEX_WIDE") != nullptr;
-    const int hb1 = !streams ? 8 : wide ? 4 : kb_hi_bytes(2 * k - G.b1 + pay), hb2 = !streams ? 8 : wide ? 4 : kb_hi_bytes(G.r + pay);
+    const int hb1 = 8, hb2 = 8;  // (bytes per entry of the two intermediate arrays)
+    (void)wide;
     const int fmt = (wide || pay > 40) ? 8 : pay > 32 ? 5 : 4;
     // The index is written over A's low stream when that stream has the index's entry size (A is dead by pass 3): both eight bytes
     // wide (format 8) or both four (two narrow streams, formats 4 / 5).  With the default 8-byte A and a 4- or 5-byte index the index

@@ -13,7 +13,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "dp_common.h"
-#include "dp_gang.h"
+#include "dp_launch.h"
 
 struct dp_kindex {
     std::mutex mu;
@@ -145,9 +145,6 @@ int dp_kindex_ensure(dp_ctx* ctx, int k) {
         if (!ow->kidx) ow->kidx = new dp_kindex();
     }
     dp_kindex* ix = ow->kidx;
-    // (a gang member inside a round steps out of it for the lock and a possible build: the member that builds waits for its
-    // stream on its own, the ones that wait for the lock keep nobody at a launch)
-    DpGangPause gang_pause(ctx);
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->k == k && (ix->built || ix->unavailable)) return ix->built ? DP_OK : 1;
     hipSetDevice(ctx->device);
@@ -1367,99 +1364,6 @@ struct kidx_sortwrite {
 }
 };
 
-// kidx_bin_fill and kidx_sortwrite in one launch (round 5, the sparse regime: bins of 512 reads, survivors of at most CAP hits): a
-// bin's workgroup fills its survivors' slices from the bin's records and then sorts them, a wave per survivor; the workgroup behind
-// the bins does the same for the round's extra items (query windows: list -> slices -> sorted, mirrored to the host, their reads
-// unlinked).  One launch less per round; a workgroup sorts ~30 survivors of ~20 hits on its eight waves.
-template <int RB, int CAP>
-struct kidx_bin_fill_sort {
-    enum { THREADS = 512, WAVES = 8, XW = 32 };  // XW: workgroups that share the round's extra items
-    static __device__ void run(const KxBins B, const dp_scan_item* __restrict__ items, uint32_t n_read_items, uint32_t n_extra,
-                               const uint32_t* __restrict__ counts, uint32_t* __restrict__ fillc, const uint64_t* __restrict__ segoff,
-                               int32_t* __restrict__ segs, const uint64_t* __restrict__ totals, uint64_t seg_cap, int k,
-                               uint32_t* __restrict__ overflow, uint32_t* __restrict__ head, int32_t* __restrict__ host_segs) {
-        __shared__ uint32_t cnt[RB];
-        __shared__ uint16_t slist[RB];
-        __shared__ uint32_t ns_s;
-        __shared__ unsigned long long keys[WAVES][CAP];
-        const int lane = dp_lane(), wave = threadIdx.x >> 6;
-        // blocks n_bins .. n_bins + XW - 1: the extra items, dealt out by item number - each of these workgroups walks the whole list (a few
-        // thousand entries), fills the hits of ITS items and sorts those, so that none of them waits for another (one workgroup for all
-        // 334 windows of a round was the launch's longest by a factor of ten)
-        if (blockIdx.x >= B.n_bins + XW) return;
-        const bool xblock = blockIdx.x >= B.n_bins;
-        const uint32_t xw = xblock ? blockIdx.x - B.n_bins : 0u;
-        if (xblock) {
-            // the walk was the last reader of the extra items' lists: head[] back to all zero (whether the round gave up or not)
-            for (uint32_t e = xw * THREADS + threadIdx.x; e < n_extra; e += XW * THREADS) head[items[n_read_items + e].read] = 0;
-        }
-        if (B.flags[0] || totals[0] > seg_cap) return;  // (the host repeats fill + sort with the bucket walk / a larger buffer)
-        if (xblock) {
-            const uint32_t nx = min(*B.xcursor, B.xcap);
-            for (uint32_t j = threadIdx.x; j < nx; j += THREADS) {
-                const uint4 x = B.xrec[j];
-                if ((x.x - n_read_items) % XW != xw) continue;
-                if (counts[x.x] >= items[x.x].min_seeds) {
-                    const uint32_t slot = atomicAdd(&fillc[x.x], 1u);
-                    const uint64_t to = segoff[x.x] + 2ull * slot;
-                    segs[to] = (int32_t)x.y;
-                    segs[to + 1] = (int32_t)x.z;
-                }
-            }
-            __threadfence_block();
-            __syncthreads();
-            for (uint32_t e = xw + XW * (uint32_t)wave; e < n_extra; e += XW * WAVES) {
-                const uint32_t it = n_read_items + e;
-                const dp_scan_item xi = items[it];
-                const uint32_t c = counts[it];
-                if (c >= xi.min_seeds) kx_sort_one<CAP, false>(keys[wave], lane, it, c, segoff[it], (int)xi.n_kmers, segs, k, overflow, n_read_items, host_segs);
-            }
-            return;
-        }
-        const uint32_t bin = blockIdx.x;
-        const uint32_t rb = 1u << B.bshift, first = bin << B.bshift;
-        const uint32_t n = min(B.cursor[bin], B.cap);
-        if (threadIdx.x == 0) ns_s = 0u;
-        for (uint32_t i = threadIdx.x; i < rb; i += THREADS) {
-            const uint32_t it = first + i;
-            bool surv = false;
-            if (it < n_read_items) {
-                const uint32_t c = counts[it];
-                surv = c > 0u && c >= items[it].min_seeds;
-            }
-            cnt[i] = surv ? 0u : 0x80000000u;
-        }
-        __syncthreads();
-        const unsigned long long* rec = B.rec + (size_t)bin * B.cap;
-        for (uint32_t jb = 4u * threadIdx.x; jb < n; jb += 4u * THREADS) {
-            unsigned long long e[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) e[u] = jb + (uint32_t)u < n ? rec[jb + u] : ~0ull;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                if (e[u] == ~0ull) continue;
-                const uint32_t rib = (uint32_t)(e[u] >> (KXB_SEED_BITS + 24));
-                if (cnt[rib] & 0x80000000u) continue;
-                const uint32_t rank = atomicAdd(&cnt[rib], 1u);
-                const uint64_t to = segoff[first + rib] + 2ull * rank;
-                segs[to] = (int32_t)((uint32_t)e[u] & 0xffffffu);
-                segs[to + 1] = (int32_t)((uint32_t)(e[u] >> 24) & ((1u << KXB_SEED_BITS) - 1u));
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        // the bin's survivors (their slot counters have arrived at their counts), then a wave per survivor
-        for (uint32_t i = threadIdx.x; i < rb; i += THREADS)
-            if (!(cnt[i] & 0x80000000u)) slist[atomicAdd(&ns_s, 1u)] = (uint16_t)i;
-        __syncthreads();
-        const uint32_t ns = ns_s;
-        for (uint32_t sv = wave; sv < ns; sv += WAVES) {
-            const uint32_t i = slist[sv], it = first + i;
-            kx_sort_one<CAP, false>(keys[wave], lane, it, cnt[i], segoff[it], (int)items[it].n_kmers, segs, k, overflow, n_read_items, host_segs);
-        }
-    }
-};
-
 // Round 6 - the dense regime (the command's default k = 10: every read holds ~100 seed occurrences, ten million hits a round).  There
 // kidx_bin_fill scattered 8-byte pairs into the reads' slices and kidx_sortwrite, a wave per read, read them back, sorted them and wrote
 // them again: 80 MB of scattered stores, 80 MB read, 80 MB written, a launch of 100 k single-wave workgroups.  Here a bin is small (64
@@ -1638,43 +1542,9 @@ static uint32_t kidx_walk_blocks(const dp_kindex* ix, int k, uint32_t S) {
     return (waves + 3) / 4;
 }
 
-// Diagnosis only (DP_KX_DUMMY=1 / 2): a second kernel behind the count walk that repeats ONE half of its memory behaviour and
-// changes nothing - 1: the dependent random reads (seed -> bucket bounds -> index entries), no atomics; 2: as many scattered
-// returning atomics on a scratch array of the counters' size, no index reads.  How much a whole job slows down with each says
-// which half is what the other rounds' kernels wait for (profiles/r04/ab_walkdummy.txt).
-__global__ void kx_dummy_kernel(int mode, const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
-                                const KxPos pos, uint32_t* __restrict__ scratch, uint32_t n_scratch, uint32_t n_ops) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (mode >= 30) {  // (30 + n: n launches of ~300 workgroups that each occupy a CU slot for ~3 us and touch no memory - what PLACING a
-                       // mid-sized kernel beside four other rounds costs)
-        const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < 300ull) {
-        }
-        return;
-    }
-    if (mode >= 10) return;  // (10 + n: n empty launches - what a launch costs the other slots' rounds)
-    if (mode == 1) {
-        const uint32_t s = t >> 4, i0 = t & 15u;
-        if (s >= n_seeds) return;
-        const uint64_t o = off[seeds[s]];
-        const uint32_t n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
-        unsigned long long acc = 0;
-        for (uint32_t i = i0; i < n; i += 16) acc += kx_entry(pos, o + i);
-        if (acc == 0x123456789abcdefull) scratch[0] = 1;  // (never: keeps the loads alive)
-    } else {
-        if (t >= n_ops) return;
-        const uint32_t h = (t * 2654435761u) ^ (t >> 7);
-        const uint32_t old = atomicAdd(&scratch[h % n_scratch], 1u);
-        if (old == 0xffffffffu) scratch[0] = 2;
-    }
-}
-
 // workgroups of the count walk's launch: all of its work at once (default), or DP_KX_WALK_BLOCKS of them striding over it
 static uint32_t kidx_walk_grid(const dp_kindex* ix, int k, uint32_t S) {
-    static const uint32_t lim = [] {
-        const char* e = getenv("DP_KX_WALK_BLOCKS");
-        return e ? (uint32_t)std::max(1, atoi(e)) : 0u;
-    }();
+    static const uint32_t lim = (uint32_t)std::max(0L, dp_tune("kx_walk_blocks", 0));
     const uint32_t all = kidx_walk_blocks(ix, k, S);
     return lim ? std::min(lim, all) : all;
 }
@@ -1799,7 +1669,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             dense = false;
         }
     }
-    static const bool kx_debug = getenv("DP_KX_DEBUG") != nullptr;
+    static const bool kx_debug = dp_debug("kx");
     unsigned long long* dbg = nullptr;
     const size_t n_dbg_waves = (size_t)kidx_walk_blocks(ix, k, S) * 4;
     if (kx_debug) {
@@ -1809,7 +1679,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     bool count_in_offsets = false;
     if (S && B.rec) {
         const uint32_t n_waves = kidx_walk_blocks(ix, k, S) * 4;
-        static const int bin_waves = getenv("DP_KX_BIN_WAVES") ? atoi(getenv("DP_KX_BIN_WAVES")) : 8;
+        static const int bin_waves = (int)dp_tune("kx_bin_waves", 8);
 #define KX_WALK_BIN(W_)                                                                                                                            \
     dp_launch<kidx_walk_bin<W_>>(ctx, dim3((n_waves + W_ - 1) / W_), dim3(64 * W_), dp_seeds_ptr(ctx), S, (const uint64_t*)ix->off.p, ix->view(), \
                                  d_items, lo, hi, n_read_items, (const uint32_t*)head, (const uint32_t*)next, d_counts, n_hits, lps, B, n_waves)
@@ -1825,7 +1695,8 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
         else if (bin_waves <= 8) KX_WALK_BIN(8);
         else KX_WALK_BIN(16);
 #undef KX_WALK_BIN
-        // bins no larger than a tile of kidx_offsets are counted by that kernel (one launch less per round; DP_KX_FUSE=0: as before)
+        // bins no larger than a tile of kidx_offsets are counted by that kernel (one launch less per round; DP_KX_FUSE=0: as before.
+        // Fill + sort in one launch for the sparse regime - DP_KX_FUSE=2 in round 5 - was slower and is gone: profiles/r05/ab12_fusions.txt)
         const char* fuse_env = getenv("DP_KX_FUSE");  // (read per call, like DP_KX_BINS: tests switch it between jobs of one process)
         const bool fuse_off = fuse_env && fuse_env[0] == '0';
         count_in_offsets = !fuse_off && !dense && (1u << B.bshift) <= KX_TILE * KX_IPT;
@@ -1836,7 +1707,7 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
             dp_launch<kidx_bin_count<4096>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items, lo);
         else
             dp_launch<kidx_bin_count<16384>>(ctx, dim3(B.n_bins), dim3(512), B, d_counts, n_read_items, lo);
-        static const bool bins_debug = getenv("DP_KX_BINS_DEBUG") != nullptr;
+        static const bool bins_debug = dp_debug("kx_bins");
         if (bins_debug) {  // (diagnosis: waits for the stream) how full the bins and the extra list are
             std::vector<uint32_t> cur((size_t)KX_MAXBINS + 2);
             uint64_t fl = 0;
@@ -1855,19 +1726,6 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
                            (const uint64_t*)ix->off.p, ix->view(), d_items, lo, hi, n_read_items, (const uint32_t*)head,
                            (const uint32_t*)next, d_counts, fillc, (const uint64_t*)nullptr, (int32_t*)nullptr, n_hits, kidx_lps(ix, k), dbg, R,
                            kidx_walk_blocks(ix, k, S) * 4);
-    {
-        static const int dummy = getenv("DP_KX_DUMMY") ? atoi(getenv("DP_KX_DUMMY")) : 0;
-        if (dummy && S) {
-            if (dev_reserve(ctx, ctx->d_kx_vals, std::max<size_t>((size_t)n_extra * 4 + 64, 0)) ) return DP_ERR_HIP;
-            static void* scratch = nullptr;  // (diagnosis only: one scratch array per process)
-            if (!scratch) DP_HIP(dp_dev_malloc(&scratch, (size_t)n_items * 4 + 64));
-            const uint32_t ops = (uint32_t)std::min<uint64_t>(ctx->kx_prev_hits ? ctx->kx_prev_hits : 450000, 1u << 24);
-            const uint32_t thr = dummy >= 30 ? 300u * 256u : dummy >= 10 ? 64u : dummy == 1 ? S * 16 : ops;
-            for (int rep = 0; rep < (dummy >= 30 ? dummy - 30 : dummy >= 10 ? dummy - 10 : 1); rep++)
-                hipLaunchKernelGGL(kx_dummy_kernel, dim3((thr + 255) / 256), dim3(256), 0, ctx->stream, dummy, dp_seeds_ptr(ctx), S,
-                                   (const uint64_t*)ix->off.p, ix->view(), (uint32_t*)scratch, n_items, ops);
-        }
-    }
     if (kx_debug) {
         std::vector<unsigned long long> h(n_dbg_waves * 8);
         hipStreamSynchronize(ctx->stream);
@@ -1905,21 +1763,6 @@ int dp_kindex_count(dp_ctx* ctx, int k, const dp_scan_item* d_items, uint32_t lo
     DP_HIP(dp_mark(ctx, 1));
     if (one && R.rec) {
         DP_HIP(dp_mark(ctx, 2));
-        // the sparse regime (bins of 512 reads, survivors of at most 256 hits): fill and sort in one launch - built, measured and left OFF
-        // (DP_KX_FUSE=2 switches it on): alternating 12-job runs gave 0.149 - 0.157 ms per round with neither fusion, 0.136 - 0.156 with the
-        // count inside kidx_offsets alone, 0.157 - 0.179 with this one on top - a bin's workgroup sorts its ~30 survivors four to a wave
-        // behind its fill (loads through the L2), which is longer than the launch it saves
-        const char* fuse2_env = getenv("DP_KX_FUSE");  // (per call, as above)
-        const bool fuse_fill_sort = fuse2_env && fuse2_env[0] == '2';
-        const bool fill_sort = B.rec && fuse_fill_sort && B.bshift <= 9 && one->sort_cap <= 256 && lps == 16 && n_extra <= 8192;
-        if (fill_sort) {
-            dp_launch<kidx_bin_fill_sort<512, 256>>(ctx, dim3(B.n_bins + kidx_bin_fill_sort<512, 256>::XW), dim3(512), B, d_items, n_read_items, n_extra, (const uint32_t*)d_counts, fillc,
-                                                    (const uint64_t*)d_segoff, one->d_segs, (const uint64_t*)d_totals, one->seg_cap, k, (uint32_t*)(d_totals + 4), head,
-                                                    one->host_segs);
-            DP_HIP(hipGetLastError());
-            DP_HIP(dp_mark(ctx, 3));
-            return DP_OK;
-        }
         if (B.rec && dense) {
             dp_launch<kidx_bin_sort_dense<8192>>(ctx, dim3(B.n_bins + kidx_bin_sort_dense<8192>::XBLOCKS), dim3(512), B, d_items, n_read_items,
                                                  (const uint32_t*)d_counts, fillc, (const uint64_t*)d_segoff, one->d_segs, (const uint64_t*)d_totals,

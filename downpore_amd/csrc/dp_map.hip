@@ -756,7 +756,7 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
         // the reverse pass of a shard follows its forward pass on the same windows: the query stage's results are still there
         d_qmeta = (uint32_t*)ctx->d_qmeta.p;
     } else {
-        rc = dp_query_stage(ctx, w_segs, w_off, nw, 0.25, &d_qmeta, &d_words, &d_mc, &mc_n, &d_qcnt_unused, nullptr);  // Matches(.., 0.25) :502-503
+        rc = dp_query_stage(ctx, w_segs, w_off, nw, 0.25, &d_qmeta, &d_words, &d_mc, &mc_n, &d_qcnt_unused);  // Matches(.., 0.25) :502-503
         if (rc != 0) return rc;
         ctx->map_stage_windows = nw;
         ctx->map_stage_valid = phase == 0;
@@ -785,14 +785,13 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
     // profiling build + DP_MAP_PROF=1: per-phase sums of the launch's waves (map_kernel's MP_TICK), printed per call
     unsigned long long* d_mprof = nullptr;
 #ifdef DP_PROF_BUILD
-    static const bool map_prof = getenv("DP_MAP_PROF") != nullptr;
+    static const bool map_prof = dp_debug("map_prof");
     if (map_prof) {
         if (dev_reserve(ctx, ctx->d_sb, 16 * 8 + 64)) return DP_ERR_HIP;
         d_mprof = (unsigned long long*)ctx->d_sb.p;
     }
 #endif
-    const char* ole = getenv("DP_MAP_ONE_LANE");  // (read per call: tests switch it between jobs of one process)
-    const int one_lane = ole && ole[0] == '1' ? 1 : 0;
+    const int one_lane = dp_tune("map_one_lane", 0) ? 1 : 0;  // (tests: dynamicMatch on one lane)
     for (;;) {
         if (dev_reserve(ctx, ctx->d_mrec, (size_t)rec_cap * sizeof(MapRec))) return DP_ERR_HIP;
         if (dev_reserve(ctx, ctx->d_ma, (size_t)int_cap * 4)) return DP_ERR_HIP;

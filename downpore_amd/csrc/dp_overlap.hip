@@ -14,7 +14,7 @@
 #include <cstring>
 
 #include "dp_common.h"
-#include "dp_gang.h"
+#include "dp_launch.h"
 
 typedef uint64_t u64;
 
@@ -53,9 +53,7 @@ struct index_fill_kernel {
 struct index_fill_rows_kernel {
     enum { THREADS = 256 };
     static __device__ void run(const dp_seq_ref* __restrict__ refs, const int32_t* __restrict__ segs, u64* __restrict__ seedsets,
-                               uint32_t SW, const uint32_t* __restrict__ n_seqs_dev, u64* __restrict__ posting, uint32_t W) {
-        // posting != null (DP_INDEX_FILL_ROWS=2): the posting matrix (cleared by chunk_kernel) still gets its bit by an atomic - half
-        // the atomics of index_fill_kernel, no transpose pass
+                               uint32_t SW, const uint32_t* __restrict__ n_seqs_dev) {
         __shared__ u64 rows[4][IFR_SW_MAX];
         u64* row = rows[threadIdx.x >> 6];
         const uint32_t n_seqs = *n_seqs_dev;
@@ -69,7 +67,6 @@ struct index_fill_rows_kernel {
             for (uint32_t i = lane; i < r.n_seeds; i += 64) {
                 const uint32_t seed = (uint32_t)segs[r.seg_off + 2 * (uint64_t)i + 1];
                 atomicOr(&row[seed >> 6], 1ull << (seed & 63));
-                if (posting) atomicOr(&posting[(uint64_t)seed * W + (idx >> 6)], 1ull << (idx & 63));
             }
             __builtin_amdgcn_wave_barrier();
             for (uint32_t x = lane; x < SW; x += 64) seedsets[(uint64_t)idx * SW + x] = row[x];
@@ -537,8 +534,7 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
     // and query stage take 1.22 ms instead of 1.67 (profiles/r04/dense_rows.txt) - the default from 4 M seed-set words (32 MB) up.
     const char* ife = getenv("DP_INDEX_FILL_ROWS");  // (read per call: tests switch it between jobs of one process; 0 / 1 force)
     const bool rows_fit = SW <= IFR_SW_MAX && S > 0;
-    const bool rows_mode = rows_fit && (ife ? ife[0] == '1' || ife[0] == '2' : (uint64_t)cap * SW >= ((uint64_t)4 << 20));
-    const bool rows_half = rows_mode && ife && ife[0] == '2';  // seed-set rows from LDS, posting bits by atomics
+    const bool rows_mode = rows_fit && (ife ? ife[0] == '1' : (uint64_t)cap * SW >= ((uint64_t)4 << 20));
     if (!n_survivors) {  // (no chunk_kernel launch to clear the matrices and to write the chunk count)
         const dp_zero_region z[3] = {{ctx->d_posting.p, zb_post}, {ctx->d_seedsets.p, zb_sets}, {ctx->d_nseqs.p, 8}};
         if (int rc = dp_zero_regions(ctx, z, 3)) return rc;
@@ -564,10 +560,10 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
         P.cap = cap;
         P.n_out = (uint32_t*)ctx->d_nseqs.p;
         P.z_p[0] = (uint4*)ctx->d_posting.p;
-        P.z_n16[0] = rows_mode && !rows_half ? 0 : zb_post / 16;
+        P.z_n16[0] = rows_mode ? 0 : zb_post / 16;
         P.z_p[1] = (uint4*)ctx->d_seedsets.p;
         P.z_n16[1] = rows_mode ? 0 : zb_sets / 16;
-        P.zero_blocks = rows_mode && !rows_half ? 8u : (uint32_t)std::max<size_t>(1, std::min<size_t>(512, (std::max(zb_post, rows_half ? (size_t)0 : zb_sets) / 16 + 4095) / 4096));
+        P.zero_blocks = rows_mode ? 8u : (uint32_t)std::max<size_t>(1, std::min<size_t>(512, (std::max(zb_post, zb_sets) / 16 + 4095) / 4096));
         P.f_dst = nullptr;
         P.f_src = nullptr;
         P.f_n16 = 0;
@@ -589,11 +585,9 @@ static int index_chunked_launch(dp_ctx* ctx, int64_t chunk_size, int64_t overlap
         if (cap && rows_mode) {
             const uint32_t blocks = std::min<uint32_t>(2048, (cap + 3) / 4);
             dp_launch<index_fill_rows_kernel>(ctx, dim3(blocks), dim3(256), (const dp_seq_ref*)ctx->d_seqrefs.p, (const int32_t*)ctx->d_segs.p,
-                                              (u64*)ctx->d_seedsets.p, SW, (const uint32_t*)ctx->d_nseqs.p,
-                                              rows_half ? (u64*)ctx->d_posting.p : (u64*)nullptr, W);
+                                              (u64*)ctx->d_seedsets.p, SW, (const uint32_t*)ctx->d_nseqs.p);
             const uint32_t tasks = ((W + 7) / 8) * ((SW + posting_transpose_kernel::SWPT - 1) / posting_transpose_kernel::SWPT);
-            if (!rows_half)
-                dp_launch<posting_transpose_kernel>(ctx, dim3(std::min<uint32_t>(4096, (tasks + 3) / 4)), dim3(256), (const u64*)ctx->d_seedsets.p,
+            dp_launch<posting_transpose_kernel>(ctx, dim3(std::min<uint32_t>(4096, (tasks + 3) / 4)), dim3(256), (const u64*)ctx->d_seedsets.p,
                                                     (u64*)ctx->d_posting.p, S, W, SW, (const uint32_t*)ctx->d_nseqs.p);
             DP_HIP(hipGetLastError());
         } else if (cap) {
@@ -635,10 +629,7 @@ extern "C" int dp_index_prechained(const dp_ctx* ctx) { return ctx && ctx->pc_la
 // called by the one-go index step of dp_scan_reads once its own kernels are queued (dp_scan.hip)
 int dp_index_prechain_launch(dp_ctx* ctx, const u64* scan_totals, uint32_t n_extra, u64 seg_cap, uint32_t* done_flag, uint32_t done_seq) {
     ctx->pc_launched = false;
-    static const bool off = [] {
-        const char* e = getenv("DP_INDEX_PRECHAIN");
-        return e && e[0] == '0';
-    }();
+    static const bool off = false;
     if (!ctx->pc_armed || off) return DP_OK;
     ctx->pc_armed = false;
     if (!ctx->pc_prev_cap) return DP_OK;  // (no round of this context to size from yet)
@@ -754,26 +745,12 @@ extern "C" int dp_index_seedset_row(dp_ctx* ctx, uint32_t seq, u64* words, uint3
 // ---------------------------------------------------------------------------------------------------------------
 // A14 + A5: SeedIndex.Matches -> util.GetSharedIDs
 
-// Round 5: the chaining stage's pair offsets (pair_scan_kernel: one workgroup's exclusive scan of the queries' candidate counts) as the
-// last act of the index query's LAST workgroup instead of a launch of its own - every dependent launch costs a five-slot round
-// 1.5 - 1.9 us.  Every workgroup of the launch counts itself in when it is done (done_ctr, a word that lives with the
-// context and is back at zero when the last workgroup leaves); enable = 0: nobody counts (the map path, and the light variant when the
-// heavy one follows it).
-struct QScan {
-    uint32_t* pbase;
-    u64* ibase;
-    u64* totals;
-    uint32_t* qdone;
-    uint32_t* done_ctr;
-    uint32_t enable;
-};
 // exclusive scans of qcnt[q] (pairs) and qcnt[q] x seeds of query q (scratch ints) by T threads of one workgroup; qcnt was written by
 // the other workgroups' atomics: read through the L2
 template <int T>
 __device__ __forceinline__ void pair_scan_body(const uint32_t* __restrict__ qcnt, const u64* __restrict__ qoff, uint32_t nq,
                                                uint32_t* __restrict__ pbase, u64* __restrict__ ibase, u64* __restrict__ totals,
-                                               uint32_t* __restrict__ qdone, u64* shp, u64* shi) {
-    for (uint32_t q = threadIdx.x; q < nq; q += T) qdone[q] = 0;
+                                               u64* shp, u64* shi) {
     const uint32_t per = (nq + T - 1) / T;
     const uint32_t lo = min(nq, threadIdx.x * per), hi = min(nq, lo + per);
     unsigned long long sp = 0, si = 0;
@@ -914,25 +891,11 @@ struct query_kernel {
                                const uint32_t* __restrict__ pmeta, uint32_t n_seqs, uint32_t W, const int32_t* __restrict__ mc, uint32_t mc_n,
                                u64* __restrict__ cand, uint32_t* __restrict__ qmeta, u64* __restrict__ words_read, uint32_t* __restrict__ qcnt,
                                uint32_t word_base, const uint32_t* __restrict__ n_seqs_dev, u64* __restrict__ qsets, uint32_t SW,
-                               uint32_t dbg_flags, uint32_t split, u64* __restrict__ own_zero, const QScan scan) {
+                               uint32_t dbg_flags, uint32_t split, u64* __restrict__ own_zero) {
+        // (the pair-offset scan as the last act of this launch's last workgroup - round 5's DP_QUERY_SCAN - cost a release fence per
+        // workgroup, more than the launch it saved: profiles/r05/ab12_query_scan.txt; removed in round 6)
         if (blockIdx.x < nq * split)
             body(qsegs, qoff, nq, posting, pmeta, n_seqs, W, mc, mc_n, cand, qmeta, words_read, qcnt, word_base, n_seqs_dev, qsets, SW, dbg_flags, split, own_zero);
-        if (!scan.enable || blockIdx.x >= nq * split) return;  // (a launch shared with other rounds has the largest round's grid)
-        // the launch's last workgroup scans the queries' candidate counts (QScan above)
-        __shared__ uint32_t last_s;
-        __shared__ u64 shp[THREADS], shi[THREADS];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // (agent-scope release: one L2 write-back per workgroup, 668 a launch - measured 0.149 -> 0.175 ms per five-slot round.  The
-            // cheaper workgroup-scope fence + relaxed counter ran at the unfused speed and LOST parity: the scan saw stale qcnt)
-            __threadfence();
-            last_s = __hip_atomic_fetch_add(scan.done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == nq * split ? 1u : 0u;
-        }
-        __syncthreads();
-        if (!last_s) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        pair_scan_body<THREADS>(qcnt, qoff, nq, scan.pbase, scan.ibase, scan.totals, scan.qdone, shp, shi);
-        if (threadIdx.x == 0) __hip_atomic_store(scan.done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     static __device__ void body(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
                                                              uint32_t nq, const u64* __restrict__ posting,
@@ -2342,7 +2305,6 @@ struct ChainArgs {
     u64 sint_cap;
     uint32_t int_cap;
     uint32_t* cursor;    // [0] packed ints used, [2] error bits, [3] overflow flag, [8 + pass] "a query is open" flags, [16..19] totals, [24 + 2 * pass + (q & 1)], pass 0 / 1: pairs left open by the pass's resolve step, [32 ..] 64 shards of the algorithmic bytes (u64)
-    uint32_t* qdone;     // [nq] pairs of the query a speculative pass has finished (resolve fused into it), or nullptr
     int walk_always;      // DP_CHAIN_PERFECT=0 (tests): no pair takes the perfect-chain shortcut of wave_chain_reg
     int pack;             // 1: final chains are copied into ma/mb, densely (what a host fetch wants); 0: they stay where they were
                           // chained - the pair's scratch column - and the record's offset points there (ma = sa, mb = sb for the
@@ -2359,10 +2321,9 @@ struct ChainArgs {
 struct pair_scan_kernel {
     enum { THREADS = 1024 };
     static __device__ void run(const uint32_t* __restrict__ qcnt, const u64* __restrict__ qoff, uint32_t nq,
-                                                          uint32_t* __restrict__ pbase, u64* __restrict__ ibase, u64* __restrict__ totals,
-                                                          uint32_t* __restrict__ qdone) {
+                                                          uint32_t* __restrict__ pbase, u64* __restrict__ ibase, u64* __restrict__ totals) {
     __shared__ u64 shp[1024], shi[1024];
-    pair_scan_body<1024>(qcnt, qoff, nq, pbase, ibase, totals, qdone, shp, shi);
+    pair_scan_body<1024>(qcnt, qoff, nq, pbase, ibase, totals, shp, shi);
 }
 };
 
@@ -2936,10 +2897,7 @@ struct chain_resolve_kernel {
 };
 
 static uint32_t query_dbg_flags() {
-    static const uint32_t f = [] {
-        const char* e = getenv("DP_QUERY_DEBUG");
-        return e ? (uint32_t)atoi(e) : 0u;
-    }();
+    static const uint32_t f = (uint32_t)dp_tune("query_debug", 0);
     return f;
 }
 
@@ -2999,10 +2957,7 @@ extern "C" int dp_query_prestage(dp_ctx* ctx, const int32_t* q_segs, const uint6
 // Uploads the queries, builds their seed bitsets and runs the index query (Matches -> GetSharedIDs) for all of them.
 // Leaves d_qsegs/d_qoff/d_qsets/d_cand/d_qmeta on the device.  Events ev[4]/ev[5] bracket the query kernel.
 int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, uint32_t nq, double hf, uint32_t** d_qmeta_out,
-                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out, const QScan* scan_in) {
-    // (scan_in: the overlap path's pair-offset scan rides on the launch's last workgroup; null: the map path)
-    QScan scan_off = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
-    QScan scan_on = scan_in ? *scan_in : scan_off;
+                   uint64_t** d_words_out, int32_t** d_mc_out, uint32_t* mc_n_out, uint32_t** d_qcnt_out) {
     const uint32_t W = ctx->W, SW = ctx->SW, M = ctx->n_seqs;
     // what the host sends - query offsets, query segments, the minCount table - is one block on both sides: one copy.  Announced
     // and on the device already (dp_query_prestage + the index build's first launch)?  Then it is only compared.
@@ -3039,15 +2994,9 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
     const int32_t* d_mc = (const int32_t*)((const uint8_t*)ctx->d_qsegs.p + up_off + up_segs);
     if (dev_reserve(ctx, ctx->d_cursor, C_CURSOR_BYTES)) return DP_ERR_HIP;
     // workgroups per query (DP_QUERY_SPLIT, experiments: see query_kernel)
-    static const int split_env = [] {
-        const char* e = getenv("DP_QUERY_SPLIT");
-        return e ? atoi(e) : 0;
-    }();
+    static const int split_env = (int)dp_tune("query_split", 0);
     const uint32_t q_split = split_env > 0 ? (uint32_t)std::min(split_env, 16) : 1u;
-    static const bool own_rows_env = [] {
-        const char* e = getenv("DP_QUERY_OWN_ZERO");  // 0: the rows are cleared by the launch before (the round-2 behaviour)
-        return !(e && e[0] == '0');
-    }();
+    static const bool own_rows_env = true;
     // (short rows only - the sparse regime: a few hundred words per query; the dense regime's rows - W ~ 3 k words - are cleared
     // faster by the launch over all of them, and its index query is the kernel the bandwidth figure is quoted on)
     const bool own_rows = own_rows_env && q_split == 1 && (size_t)W + SW <= 1024;
@@ -3066,14 +3015,14 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
                        ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
-                       query_dbg_flags(), q_split, own_rows ? (u64*)ctx->d_cursor.p : (u64*)nullptr, mcLast >= 13 ? scan_off : scan_on);
+                       query_dbg_flags(), q_split, own_rows ? (u64*)ctx->d_cursor.p : (u64*)nullptr);
     // the 16-ladder / exact-count regimes start at minCount 13: only a batch with a query of that many seeds needs the heavy variant
     if (mcLast >= 13) dp_launch<query_kernel<true>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
                        ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
-                       query_dbg_flags(), q_split, (u64*)nullptr, scan_on);
+                       query_dbg_flags(), q_split, (u64*)nullptr);
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 5));
 
@@ -3107,7 +3056,6 @@ struct FindState {
     bool pending = false;
     bool defer_fetch = false;  // the first attempt's read-back rides in the anchors launch of the consensus call (a pending stage)
     bool fetch_owed = false;
-    bool scan_fused = false;  // the first attempt's pair offsets were computed by the index query's last workgroup (QScan)
     uint32_t cur[32];
     double query_ms = 0;
     uint64_t query_bytes = 0, chain_bytes = 0, alg_bytes = 0;
@@ -3129,7 +3077,6 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     u64* d_ibase = (u64*)ctx->d_pbase.p;  // (8-byte aligned first)
     uint32_t* d_pbase = (uint32_t*)(d_ibase + nq + 1);
     QState* d_qstate = (QState*)(d_pbase + nq + 1 + ((nq + 1) & 1));
-    uint32_t* d_qdone = (uint32_t*)(d_qstate + nq);
     {
         // (a stage left pending is read by the consensus kernel before anybody knows whether it fitted its buffers: records the
         // stage did not write must at least be harmless - all-zero when the buffer is new, those of an earlier round otherwise)
@@ -3198,7 +3145,7 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
     A.prof = nullptr;
     A.prof_walk_slot = 0;
     A.prof_stride = 0;
-    static const bool chain_prof = getenv("DP_CHAIN_PROF") != nullptr;
+    static const bool chain_prof = dp_debug("chain_prof");
     if (chain_prof) {
         const size_t pb = ((size_t)st.passes * st.spec_blocks * S_WAVES + (size_t)A.walk0_blocks * S_WAVES) * 128;
         if (dev_reserve(ctx, ctx->d_sched, pb + 128)) return DP_ERR_HIP;
@@ -3207,12 +3154,9 @@ static int chain_enqueue(dp_ctx* ctx, FindState& st) {
         A.prof_stride = st.spec_blocks * S_WAVES;
         DP_HIP(hipMemsetAsync(A.prof, 0, pb, ctx->stream));
     }
-    A.qdone = nullptr;
     if (st.attempt > 0) DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, C_CURSOR_BYTES, ctx->stream));  // (attempt 0: zeroed with the query stage's buffers)
     DP_HIP(dp_mark(ctx, 6));
-    if (!(st.scan_fused && st.attempt == 0))  // (a repeated attempt - larger buffers - scans again: the cursor block was cleared)
-        dp_launch<pair_scan_kernel>(ctx, dim3(1), dim3(1024), (const uint32_t*)st.d_qcnt, ctx->qoff_dev, nq, d_pbase, d_ibase,
-                           d_totals, d_qdone);
+    dp_launch<pair_scan_kernel>(ctx, dim3(1), dim3(1024), (const uint32_t*)st.d_qcnt, ctx->qoff_dev, nq, d_pbase, d_ibase, d_totals);
     // mode 0 on the slim layout (a forced tier is the full layout's business)
     const uint32_t spec_blocks = st.spec_blocks;
     if (A.tier == 0 && st.passes > 0) {
@@ -3279,7 +3223,7 @@ static int chain_check(dp_ctx* ctx, FindState& st, bool* grow) {
 // a checked attempt without overflow: the stage's errors, totals and statistics
 static int chain_finish(dp_ctx* ctx, FindState& st) {
     st.pending = false;
-    static const bool chain_prof = getenv("DP_CHAIN_PROF") != nullptr;
+    static const bool chain_prof = dp_debug("chain_prof");
     if (chain_prof && ctx->d_sched.p) {
         const size_t waves = (size_t)st.spec_blocks * S_WAVES;
         const size_t wwaves = (size_t)std::max<uint32_t>(1, std::min<uint32_t>(1024, (st.nq + S_WAVES - 1) / S_WAVES)) * S_WAVES;
@@ -3411,30 +3355,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     int32_t* d_mc = nullptr;
     if (dev_reserve(ctx, ctx->d_cursor, C_CURSOR_BYTES)) return DP_ERR_HIP;  // [0..63] cursor words, [64..] totals (u64 pairs, u64 scratch ints)
     if (dev_reserve(ctx, ctx->d_pbase, ((size_t)nq + 1) * 4 + ((size_t)nq + 1) * 8 + (size_t)nq * sizeof(QState) + (size_t)nq * 4 + 128)) return DP_ERR_HIP;
-    {
-        // DP_QUERY_SCAN=1: the pair-offset scan rides on the index query's last workgroup (QScan) instead of a launch of its own.  Built for
-        // the launch it removes (~1.7 us a five-slot round each); measured SLOWER - its per-workgroup release fence costs more
-        // than the launch (profiles/r05/ab12_query_scan.txt) - so it is off unless asked for; tests/test_gpu_overlap_e2e.py covers it.
-        const char* scan_env = getenv("DP_QUERY_SCAN");  // (read per call: tests switch it between jobs of one process)
-        const bool scan_off_env = !(scan_env && scan_env[0] == '1');
-        QScan qs = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
-        if (!scan_off_env) {
-            if (!ctx->d_qscan.p) {
-                if (dev_reserve(ctx, ctx->d_qscan, 64)) return DP_ERR_HIP;
-                DP_HIP(hipMemsetAsync(ctx->d_qscan.p, 0, 64, ctx->stream));
-            }
-            qs.ibase = (u64*)ctx->d_pbase.p;  // (the layout of chain_enqueue)
-            qs.pbase = (uint32_t*)(qs.ibase + nq + 1);
-            QState* qstate = (QState*)(qs.pbase + nq + 1 + ((nq + 1) & 1));
-            qs.qdone = (uint32_t*)(qstate + nq);
-            qs.totals = (u64*)((uint8_t*)ctx->d_cursor.p + 64);
-            qs.done_ctr = (uint32_t*)ctx->d_qscan.p;
-            qs.enable = 1u;
-        }
-        int rc = dp_query_stage(ctx, q_segs, q_off, nq, hf, &st.d_qmeta, &d_words, &d_mc, &st.mc_n, &st.d_qcnt, qs.enable ? &qs : (const QScan*)nullptr);
-        if (rc != 0) return rc;
-        st.scan_fused = qs.enable != 0;
-    }
+    if (int rc = dp_query_stage(ctx, q_segs, q_off, nq, hf, &st.d_qmeta, &d_words, &d_mc, &st.mc_n, &st.d_qcnt)) return rc;
     st.d_mc = d_mc;
     const char* tier_env = getenv("DP_CHAIN_TIER");  // tests: 2 = lds tier, 3 = one-lane tier for every pair
     st.chain_tier = tier_env ? atoi(tier_env) : 0;
@@ -3448,7 +3369,7 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     if (!pass_env && ctx->chain_open_ahead[1] < 24u) st.passes = 2;
     st.walk_blocks = std::min<uint32_t>(256, (nq + C_WAVES - 1) / C_WAVES);
     st.spec_blocks = 1024;  // 4096 persistent waves, 16 per CU: what CSlim's 8.5 KB per wave lets a CU hold
-    if (const char* e = getenv("DP_SPEC_BLOCKS")) st.spec_blocks = (uint32_t)std::max(1, atoi(e));
+    st.spec_blocks = (uint32_t)std::max(1L, dp_tune("spec_blocks", st.spec_blocks));
     if (dev_reserve(ctx, ctx->d_pool, (size_t)st.walk_blocks * C_WAVES * chain_pool_stride(st.max_query_len) * sizeof(CNode))) return DP_ERR_HIP;
     // capacities: what the buffers hold now (at least a floor); a run that needs more reports its totals and is repeated
     // with larger buffers (deterministic: same results)

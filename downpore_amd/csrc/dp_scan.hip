@@ -32,20 +32,16 @@
 #include <vector>
 
 #include "dp_common.h"
-#include "dp_gang.h"
+#include "dp_launch.h"
 
 static std::string g_create_err;
 // The scan kernels are persistent and fill every CU: two of them running at once (several contexts on one device) only
 // slow each other down, so the device part of dp_scan is serialised per process.
-// (a counting gate: DP_SCAN_CONCURRENCY scans may be in flight, default 1; it has the lock()/unlock() of a mutex)
+// (a counting gate with the lock()/unlock() of a mutex: one scan in flight)
 struct ScanGate {
     std::mutex mu;
     std::condition_variable cv;
-    int avail = [] {
-        const char* e = getenv("DP_SCAN_CONCURRENCY");
-        const int n = e ? atoi(e) : 1;
-        return n < 1 ? 1 : n;
-    }();
+    int avail = 1;
     void lock() {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return avail > 0; });
@@ -65,11 +61,11 @@ static ScanGate g_scan_mu;
 //   spin  hipStreamSynchronize: the runtime busy-waits on the completion signal - the wake-up is immediate, and the waiting
 //         thread occupies a core.  A round has five to seven waits of 50-500 us; with eight executor slots this is 12-18 % faster
 //         per job than polling (0.44 against 0.54 ms per round) and costs about four more cores.
-//   poll  record an event, poll it, sleep DP_SYNC_POLL_US (20) microseconds between polls (timer slack lowered to 1 us): every
+//   poll  record an event, poll it, sleep 20 microseconds (DP_TUNE=sync_poll_us=n) between polls (timer slack lowered to 1 us): every
 //         wake-up is 50-70 us late, but a waiting thread costs nothing - what a process needs when it has fewer cores than
 //         waiting threads (round 1: five slots, 17 core-ms of host work per round on a 16-core quota).
 // dp_set_stream_wait() chooses (the host pipeline does, from its CPU budget and its number of slots); DP_SPIN_SYNC=0/1 in the
-// environment overrides it.  DP_SYNC_POLL_US=0: blocking hipEventSynchronize instead of the poll loop.
+// environment overrides it.  sync_poll_us=0: blocking hipEventSynchronize instead of the poll loop.
 static std::atomic<int> g_wait_spin{0};
 extern "C" void dp_set_stream_wait(int spin) { g_wait_spin.store(spin ? 1 : 0); }
 static std::atomic<long> g_timing_every{[] {
@@ -119,19 +115,62 @@ const void* dp_stage(dp_ctx* ctx, const void* src, size_t bytes) {
     return dst;
 }
 
+hipStream_t dp_ctx_stream(const dp_ctx* ctx) { return ctx->stream; }
+
+static std::map<std::string, std::string> env_tokens(const char* name) {
+    std::map<std::string, std::string> m;
+    const char* e = getenv(name);
+    if (!e) return m;
+    std::string s(e);
+    size_t at = 0;
+    while (at <= s.size()) {
+        size_t end = s.find(',', at);
+        if (end == std::string::npos) end = s.size();
+        const std::string tok = s.substr(at, end - at);
+        const size_t eq = tok.find('=');
+        if (!tok.empty()) m[eq == std::string::npos ? tok : tok.substr(0, eq)] = eq == std::string::npos ? "1" : tok.substr(eq + 1);
+        at = end + 1;
+    }
+    return m;
+}
+// (parsed again whenever the variable's text has changed: tests set it between jobs of one process)
+struct EnvTokens {
+    const char* name;
+    std::mutex mu;
+    std::string text;
+    bool parsed = false;
+    std::map<std::string, std::string> m;
+    const std::map<std::string, std::string>& get() {  // (call with mu held)
+        const char* e = getenv(name);
+        if (!e) e = "";
+        if (!parsed || text != e) {
+            text = e;
+            m = env_tokens(name);
+            parsed = true;
+        }
+        return m;
+    }
+};
+bool dp_debug(const char* what) {
+    static EnvTokens t{"DP_DEBUG"};
+    std::lock_guard<std::mutex> lk(t.mu);
+    return t.get().count(what) != 0;
+}
+long dp_tune(const char* key, long dflt) {
+    static EnvTokens t{"DP_TUNE"};
+    std::lock_guard<std::mutex> lk(t.mu);
+    const auto& m = t.get();
+    const auto it = m.find(key);
+    return it == m.end() ? dflt : atol(it->second.c_str());
+}
+
 hipError_t dp_stream_sync(dp_ctx* ctx) {
-    // a gang member inside a round: wait until the other members have reached a wait too (their launches up to there are merged
-    // with this member's and are on the gang's stream by then), then wait for that stream like for one's own
-    if (dp_gang_active(ctx)) dp_gang_sync_point(ctx);
     ctx->stage_used = 0;  // (everything queued so far, copies out of the staging block included, is done when this returns)
     static const int env_spin = [] {
         const char* e = getenv("DP_SPIN_SYNC");
         return e ? (e[0] == '1' ? 1 : 0) : -1;
     }();
-    static const long poll_ns = [] {
-        const char* e = getenv("DP_SYNC_POLL_US");
-        return (e ? atol(e) : 20L) * 1000L;
-    }();
+    static const long poll_ns = dp_tune("sync_poll_us", 20) * 1000L;
     const bool spin = env_spin >= 0 ? env_spin == 1 : g_wait_spin.load(std::memory_order_relaxed) != 0;
     if (spin || !ctx->ev_sync) return hipStreamSynchronize(ctx->stream);
     hipError_t e = hipEventRecord(ctx->ev_sync, ctx->stream);
@@ -158,7 +197,6 @@ int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e) {
     }
     if (ctx) ctx->err = s;
     else g_create_err = s;
-    if (ctx && ctx->gang && code != DP_OK) dp_gang_mark_failed(ctx);  // (inside a round: the other members must not wait for this one)
     return code;
 }
 
@@ -168,7 +206,7 @@ int dp_fail(dp_ctx* ctx, int code, const char* what, hipError_t e) {
 // context's retired list and are released with the context (their total is below the live size: geometric growth).
 // DP_ALLOC_TRACE=1: one stderr line per growth (what, bytes, how long the allocation call took)
 static bool alloc_trace() {
-    static const bool on = getenv("DP_ALLOC_TRACE") != nullptr;
+    static const bool on = dp_debug("alloc");
     return on;
 }
 static double alloc_now() {
@@ -534,7 +572,6 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->upload) (void)upload_join(ctx);  // (a read set still travelling: its thread uses this context's buffers)
-    if (ctx->gang) dp_gang_forget(ctx);  // (destroyed before its gang: the gang forgets the member, the others never wait for it)
     dp_stream_sync(ctx);
     {
         // contexts that borrow these reads (value table, k-mer index) are still alive - a garbage-collected host may finalise
@@ -561,7 +598,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
                      &ctx->d_seedsets, &ctx->d_pmeta, &ctx->d_qsegs, &ctx->d_qoff, &ctx->d_qsets, &ctx->d_qmeta,
                      &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched, &ctx->d_ignore, &ctx->d_surv, &ctx->d_values, &ctx->d_selwin, &ctx->d_seltop, &ctx->d_cin, &ctx->d_cout,
                      &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals, &ctx->d_manchor, &ctx->d_seeds_applied,
-                     &ctx->d_pbase, &ctx->d_qscan, &ctx->d_pspec, &ctx->d_clist, &ctx->d_sa, &ctx->d_sb, &ctx->d_qual, &ctx->d_qualoff, &ctx->d_hasq, &ctx->d_cretry,
+                     &ctx->d_pbase, &ctx->d_pspec, &ctx->d_clist, &ctx->d_sa, &ctx->d_sb, &ctx->d_qual, &ctx->d_qualoff, &ctx->d_hasq, &ctx->d_cretry,
                      &ctx->d_chunk_meta, &ctx->d_nseqs};
     // one wait for everything this context's blocks could still be used by (its own stream is idle since dp_stream_sync above; a
     // gang's launches and a borrower's copies run on other streams of the device), then its blocks are parked without further waits
@@ -656,10 +693,7 @@ uint8_t* ring_get(size_t bytes) {  // (caller holds g_ring_mu) null: no pinned m
     return g_ring;
 }
 int upload_threads() {
-    static const int n_thr = [] {
-        const char* e = getenv("DP_UPLOAD_THREADS");
-        return e ? std::max(0, std::min(16, atoi(e))) : 4;
-    }();
+    static const int n_thr = (int)std::max(0L, std::min(16L, dp_tune("upload_threads", 4)));
     return n_thr;
 }
 }  // namespace
@@ -1695,14 +1729,11 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
     DP_HIP(hipMemcpyAsync(ctx->d_items.p, items, (size_t)n_items * sizeof(dp_scan_item), hipMemcpyHostToDevice, ctx->stream));
     int dev_cus = 256;
     hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
+    const bool v2 = k >= 9;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus * (v2 ? 2 : 1), ((uint64_t)n_items + 15) / 16);
-    const uint32_t dbg = getenv("DP_SCAN_DEBUG") ? (uint32_t)atoi(getenv("DP_SCAN_DEBUG")) : 0u;
+    const uint32_t dbg = (uint32_t)dp_tune("scan_debug", 0);
     if (int rc = seed_tables_ensure(ctx)) return rc;
-    // (a gang member inside a round takes no gate: the gang's stream orders its members' scans, and a member waiting for the
-    // gate would keep the members that wait for it at their launches for ever)
-    std::unique_lock<ScanGate> scan_lock(g_scan_mu, std::defer_lock);
-    if (!dp_gang_active(ctx)) scan_lock.lock();
+    std::unique_lock<ScanGate> scan_lock(g_scan_mu);
     DP_HIP(dp_mark(ctx, 0));
     hipLaunchKernelGGL(((dbg & 2) ? scan_kernel<0, 3> : v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream, (const uint8_t*)ctx->d_packed.p,
                        (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)ctx->d_items.p, n_items, k,
@@ -1858,10 +1889,7 @@ static hipError_t kx_wait_done(dp_ctx* ctx, const uint32_t* flag, uint32_t seq) 
         const char* e = getenv("DP_SPIN_SYNC");
         return e ? (e[0] == '1' ? 1 : 0) : -1;
     }();
-    static const long poll_ns = [] {
-        const char* e = getenv("DP_SYNC_POLL_US");
-        return (e ? atol(e) : 20L) * 1000L;
-    }();
+    static const long poll_ns = dp_tune("sync_poll_us", 20) * 1000L;
     const bool spin = env_spin >= 0 ? env_spin == 1 : g_wait_spin.load(std::memory_order_relaxed) != 0;
     timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -1974,14 +2002,10 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     };
     int dev_cus = 256;
     hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const bool v2 = k >= 9 && !getenv("DP_SCAN_FILTER_V1");
+    const bool v2 = k >= 9;
     // persistent workgroups per CU: 2 fill every wave slot and all LDS of the CU (fastest scan in isolation) - and keep every
     // other slot's kernels out until the scan is done; DP_SCAN_WG_PER_CU=1 leaves half of each CU to them
-    static const int wg_per_cu = [] {
-        const char* e = getenv("DP_SCAN_WG_PER_CU");
-        const int n = e ? atoi(e) : 2;
-        return n < 1 ? 1 : (n > 2 ? 2 : n);
-    }();
+    static const int wg_per_cu = (int)std::max(1L, std::min(2L, dp_tune("scan_wg_per_cu", 2)));
     const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)dev_cus * (v2 ? wg_per_cu : 1), ((uint64_t)n_items + 15) / 16);
     uint64_t* totals = (uint64_t*)ctx->d_total.p;  // [0] n_segs, [1] n_survivors
     uint64_t* tilesA = totals + 4;
@@ -2048,10 +2072,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         // (views served whole - top_level == 0 - have a k-mer at every indexed position: the walk tests the ignore byte instead of
         // reading the read's item, and looks for extra items only on the round's query reads; DP_KX_FAST=0: off)
         dp_kindex_fast fastArgs = {nullptr, 0u, 0u};
-        static const bool fast_off = [] {
-            const char* e = getenv("DP_KX_FAST");
-            return e && e[0] == '0';
-        }();
+        static const bool fast_off = false;
         if (!top_level && !fast_off && ctx->d_ignore.p) {
             uint32_t qmin = 0xffffffffu, qmax = 0;
             for (uint32_t i = 0; i < n_extra; i++) {
@@ -2074,13 +2095,13 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         // dp_index_prechain: the chunk stage of the caller's coming dp_index_build_chunked goes behind the scan right now
         if (int rc = dp_index_prechain_launch(ctx, totals, n_extra, one.seg_cap, one.done_flag, one.done_seq)) return rc;
         // (its first kernel tells the host that the scan's own kernels are done: the host waits for that word, not for the stream)
-        wait_flag = ctx->pc_launched && !ctx->timing_on && !dp_gang_active(ctx);
+        wait_flag = ctx->pc_launched && !ctx->timing_on;
     }
     out->index_mode = use_index ? 1u : 0u;
     if (!use_index) {
         if (int rc = fetch_extras()) return rc;
         if (int rc = seed_tables_ensure(ctx)) return rc;
-        if (!dp_gang_active(ctx)) scan_lock.lock();  // (see dp_scan)
+        scan_lock.lock();  // (see dp_scan)
         DP_HIP(dp_mark(ctx, 0));
         hipLaunchKernelGGL((v2 ? scan_kernel<0, 2> : scan_kernel<0, 1>), dim3(grid), dim3(SCAN_THREADS), 0, ctx->stream,
                            (const uint8_t*)ctx->d_packed.p, (const uint64_t*)ctx->d_boff.p, (const dp_scan_item*)d_items, n_items, k,
@@ -2114,10 +2135,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         // DP_SCAN_RELEASE_EARLY=1 opens the gate here, after the count pass, so that the short write pass overlaps the
         // next slot's count pass.  Measured: it does not - the count pass is a persistent grid that owns every CU's LDS, so
         // the write pass queues behind it (0.08 -> 0.2 ms) and the slot only gets slower.  Off by default.
-        static const bool early = [] {
-            const char* e = getenv("DP_SCAN_RELEASE_EARLY");
-            return e && e[0] == '1';
-        }();
+        static const bool early = false;
         if (early && scan_lock.owns_lock()) scan_lock.unlock();
     }
     const uint64_t n_segs = ((uint64_t*)ctx->h_total.p)[0];
@@ -2138,7 +2156,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         ctx->kx_prev_segs = n_segs;
         ctx->kx_prev_max = kx_max_count;
         ctx->kx_prev_surv = (uint32_t)n_surv_all;
-        static const bool dbg1 = getenv("DP_KX_ONESHOT_DEBUG") != nullptr;
+        static const bool dbg1 = dp_debug("kx_oneshot");
         if (dbg1 && !oneshot_done)
             fprintf(stderr, "[kx] one-go step repeated: segs %llu / cap %llu, records %s, largest survivor %u / sort %u (%llu of %llu rounds)\n",
                     (unsigned long long)n_segs, (unsigned long long)one.seg_cap, rec_full ? "full" : "ok", kx_max_count, one.sort_cap,

@@ -346,10 +346,7 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
     const uint64_t topN = n / 100;
     bool cut_done = false;
-    static const bool sort_cut = [] {
-        const char* e = getenv("DP_VALUES_SORT");  // 1: the cut by radix sort, as before round 4
-        return e && e[0] == '1';
-    }();
+    static const bool sort_cut = false;
     if (topN > 0 && !sort_cut) {
         // value pass + histogram, threshold, tie count, tie locate, cut: five launches, nothing read back in between
         const uint32_t tiles = (uint32_t)((n + 1024 * VH_ITEMS - 1) / (1024 * VH_ITEMS));
@@ -360,11 +357,7 @@ extern "C" int dp_kmer_values(dp_ctx* ctx, int k, double* values_out) {
         uint32_t* tileTies = ghist + VH_BINS + 1;
         DPV(hipMemsetAsync(d_h, 0, (size_t)(VH_BINS + 1) * 4, ctx->stream));
         DPV(hipMemsetAsync((uint64_t*)d_small + 1, 0, 56, ctx->stream));
-        static const bool gather = [] {
-            const char* e = getenv("DP_VALUES_GATHER");  // 1: the reverse complement's count gathered from HBM, as before round 5
-            return e && e[0] == '1';
-        }();
-        if (k >= 8 && !gather) {
+        if (k >= 8) {  // (below k = 8 the table is smaller than a tile: the reverse complement's count is gathered from memory)
             const uint32_t n_tiles = 1u << (2 * (k - 6));
             hipLaunchKernelGGL(values_kernel_hist_tiled, dim3((n_tiles + VT_PER - 1) / VT_PER), dim3(256), 0, ctx->stream, (const uint32_t*)d_counts, k,
                                (const uint64_t*)d_small, values, (uint64_t*)d_merged, ghist);

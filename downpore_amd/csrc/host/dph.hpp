@@ -290,7 +290,7 @@ struct RoundStats {
     uint64_t cons_bytes = 0;                // algorithmic bytes of the consensus kernel (sum of its windows' group records)
     uint64_t idx_rounds = 0, idx_hits = 0;  // rounds served by the resident k-mer position index, and their seed occurrences
     uint64_t timed_rounds = 0;              // rounds whose kernels were bracketed by timing events (dp_set_kernel_timing): the k_*_ms are theirs
-    uint64_t gang_members = 0;              // rounds that shared this round's launches (dp_gang_round_members), this one included; 1 without a gang
+    uint64_t gang_members = 0;              // (always 1 per round since round 6: the field keeps the statistics block's layout) ; 1 without a gang
     void add(const RoundStats& o) {
         t_prepare += o.t_prepare, t_scan += o.t_scan, t_index += o.t_index, t_query += o.t_query, t_consensus += o.t_consensus;
         k_scan_ms += o.k_scan_ms, k_query_ms += o.k_query_ms, k_chain_ms += o.k_chain_ms, k_count_ms += o.k_count_ms;
@@ -638,11 +638,6 @@ struct OverlapRun {
     const double* fullValues();      // the 4^k doubles (expands the 2-byte form the first time it is asked for)
     std::unique_ptr<TextPool> textPool;            // formatter threads (PAF text off the executor slots' critical path)
     std::vector<std::unique_ptr<ExecSlot>> slots;  // slot 0 drives `ctx`; further slots use contexts that borrow its reads
-    // Executor slots in gangs (dp_gang_create): consecutive slots whose rounds begin together and share every launch - the
-    // same kernels carry gangSize rounds (DPH_GANG; 1 = every slot on its own stream as in round 2)
-    std::vector<dp_gang*> gangs;
-    int gangSize = 1;
-    void destroyGangs();
     std::unique_ptr<WindowCache> winCache;  // QueryEdges: the windows' round-independent part, produced ahead of the planner
     std::unique_ptr<Planner> planner;
     dp_ctx* plannerCtx = nullptr;  // borrows the reads and the value table of `ctx`

@@ -321,7 +321,6 @@ int dph_overlap_comm_init_slots(void* hh, int nRanks, int rank, const uint8_t* i
     }
     h->run.slotComms = h->slotComms;
     for (size_t i = 0; i < h->run.slots.size() && i < h->slotComms.size(); i++) h->run.slots[i]->comm = h->slotComms[i];
-    h->run.destroyGangs();  // (slots that exchange on communicators of their own do not share launches: see OverlapRun::init)
     if (!h->comm && !h->slotComms.empty()) dp_kindex_set_comm(h->ctx, h->slotComms[0]);  // (the index is built in shares over slot 0's)
     return 0;
 }
@@ -344,7 +343,6 @@ int dph_overlap_comm_init_local_slots(void** handles, int n, int nSlots) {
         OverlapH* h = (OverlapH*)handles[i];
         h->run.slotComms = h->slotComms;
         for (size_t j = 0; j < h->run.slots.size() && j < h->slotComms.size(); j++) h->run.slots[j]->comm = h->slotComms[j];
-        h->run.destroyGangs();  // (see dph_overlap_comm_init_slots)
         if (!h->comm && !h->slotComms.empty()) dp_kindex_set_comm(h->ctx, h->slotComms[0]);
     }
     return 0;
@@ -691,8 +689,7 @@ extern "C" int dph_selftest_planner_flags(void* readsH, int k, int64_t seedBatch
     Planner pl(reads, p, values, true, nullptr);
     std::shared_ptr<const RoundPlan> p0 = pl.get(0);  // the thread goes on with plan 1 (prefetch depth)
     if (!p0 || p0->empty || p0->firstOut <= 1 || p0->firstOut >= (i64)reads.size()) return -1;
-    const char* e = getenv("DPH_TEST_PLAN_DELAY_US");
-    const long delay = e ? atol(e) : 0;
+    const long delay = dph::dph_tune("plan_delay_us", 0);
     if (delay <= 0) return -2;
     usleep((useconds_t)(delay / 2));  // plan 1 is computed by now and sits in the hook's sleep
     const int small = 0, big = (int)p0->firstOut;  // big = first query read of plan 1

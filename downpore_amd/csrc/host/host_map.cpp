@@ -15,6 +15,7 @@
 #include <chrono>
 
 #include "dph.hpp"
+#include "host_util.hpp"
 
 // Switches stacks: the callee-saved registers of the System V x86-64 ABI go to the current stack, its top to *save_sp, and the
 // same registers come back from the stack `load_sp` points at.  A fresh coroutine's stack is laid out by coroStart() so that the
@@ -692,8 +693,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     memset(&ssb, 0, sizeof ssb);
     bool deviceSeeds = false;
     {
-        const char* e = getenv("DP_MAP_SEEDS_HOST");
-        if (!(e && e[0] == '1') && refLen < ((i64)1 << 32)) {
+        if (!dph_tune("map_seeds_host", 0) && refLen < ((i64)1 << 32)) {  // (tests: AddSingleSeeds walked on the host)
             rc = dp_single_seed_candidates(ctx, 0, k, p.seedRate, &ssb);
             if (rc) return fail(rc);
             deviceSeeds = true;
@@ -776,10 +776,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // tested and left OFF: set-up 14.5 -> 8 ms and the best run 56.0 -> 54.4 ms, but the runs of a process spread 55 - 107 ms where
     // they were 56 - 65 (means of 12 runs 69 / 77 against 62 / 69 ms, profiles/r05/map_threads_and_reads_in_flight.txt): the upload's
     // copy threads and the link compete with six mapper threads for the same host cores and queues.
-    const bool asyncUpload = [] {
-        const char* e = getenv("DP_MAP_ASYNC_UPLOAD");
-        return e && e[0] == '1';
-    }();
+    const bool asyncUpload = dph_tune("map_async_upload", 0) != 0;
     // (giving 400 MB of staging back to the system is 40 ms of munmap - round 3's profile had booked it as "AddSingleSeeds (waited
     // for)" - and on a thread of its own it holds the address-space lock against this one's allocations just as long: the block is
     // kept for the process's next map command instead, which then also finds its pages touched)
@@ -1196,7 +1193,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         const char* e = getenv("DP_MAP_THREADS");
         nThreads = (size_t)std::max(1, e ? atoi(e) : (hostThreads() >= 12 ? 6 : hostThreads() >= 8 ? 4 : 3));
         size_t perThread = 2048;  // (fewer reads than that per thread are not worth a context; DP_MAP_MIN_READS_PER_THREAD: test hook)
-        if (const char* e2 = getenv("DP_MAP_MIN_READS_PER_THREAD")) perThread = (size_t)std::max(1, atoi(e2));
+        perThread = (size_t)std::max(1L, dph_tune("map_min_reads_per_thread", (long)perThread));
         nThreads = std::min(nThreads, std::max<size_t>(1, reads.size() / perThread));
     }
     nThreadsPlanned = nThreads;

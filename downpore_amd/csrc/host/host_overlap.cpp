@@ -404,8 +404,7 @@ int Overlapper::IndexSurvivors(const Survivors& all, RoundStats& st) {
         const double tq0 = now();
         buildQueries(st);
         assembleQueries();
-        const char* pe = getenv("DP_QUERY_PRESTAGE");  // (0: dp_find_overlaps uploads them itself; read per round: tests switch it)
-        const bool prestage = !(pe && pe[0] == '0') && !dp_index_prechained(ctx_);  // (chunk stage launched already: nothing to ride on)
+        const bool prestage = !dph_tune("no_query_prestage", 0) && !dp_index_prechained(ctx_);  // (tests: dp_find_overlaps uploads them itself)  // (chunk stage launched already: nothing to ride on)
         if (prestage && !queries.empty()) {
             int prc = dp_query_prestage(ctx_, querySegs_.data(), queryOff_.data(), (uint32_t)queries.size(), hitFraction_);
             if (prc != 0) {
@@ -650,10 +649,7 @@ int Overlapper::FindOverlapsAndFinalCheck(std::vector<SeedMatch>& pool, i64 over
     const double tq0 = now();
     // want_candidates 6: the matches stay on the device and the stage is left pending - dp_consensus_paf below evaluates it in the
     // wait it needs anyway (DP_FIND_PENDING=0: wait here, as every other caller of dp_find_overlaps does)
-    static const bool pendingFind = [] {
-        const char* e = getenv("DP_FIND_PENDING");
-        return !(e && e[0] == '0');
-    }();
+    static const bool pendingFind = true;
     int rc = dp_find_overlaps(ctx_, querySegs_.data(), queryOff_.data(), (uint32_t)queries.size(), hitFraction_, index_.k,
                               (uint32_t)(overlap_ / 2), pendingFind ? 6 : 2, &mb);
     if (rc != 0) {
@@ -810,10 +806,7 @@ std::mutex g_tjb_mu;
 std::vector<std::pair<std::vector<dp_paf_rec>, std::vector<dp_group_meta>>> g_tjb_free;
 }  // namespace
 static bool tjbOn() {
-    static const bool on = [] {
-        const char* e = getenv("DPH_TEXT_RECYCLE");  // 0: every job allocates its arrays (as before round 4's second half)
-        return !(e && e[0] == '0');
-    }();
+    static const bool on = true;
     return on;
 }
 void TextJobBuffers::take(std::vector<dp_paf_rec>& recs, std::vector<dp_group_meta>& groups) {
@@ -838,10 +831,7 @@ std::vector<std::string> g_txt_free;
 size_t g_txt_bytes = 0;  // sum of the kept strings' capacities
 }  // namespace
 static bool txtOn() {
-    static const bool on = [] {
-        const char* e = getenv("DPH_TEXT_RECYCLE");  // 1: the record arrays only (not the text buffers)
-        return !(e && (e[0] == '0' || e[0] == '1'));
-    }();
+    static const bool on = true;
     return on;
 }
 void TextJobBuffers::takeText(std::string& s) {
@@ -860,10 +850,7 @@ void TextJobBuffers::giveTexts(std::vector<std::string>& v) {
     // of a config-2 job is 235 MB in 599 strings whose capacities add up to a little more - with a cap of 256 MB a tenth of the
     // rounds of every job allocated (and page-faulted) fresh strings on the committing thread, which a 20-job run showed as 0.15 ->
     // 0.18 ms per round (DPH_TEXT_POOL_MB: another cap)
-    static const size_t CAP_BYTES = [] {
-        const char* e = getenv("DPH_TEXT_POOL_MB");
-        return (size_t)(e ? std::max(1, atoi(e)) : 512) << 20;
-    }();
+    static const size_t CAP_BYTES = (size_t)std::max(1L, dph_tune("text_pool_mb", 512)) << 20;
     for (std::string& s : v)
         if (s.capacity() >= 65536 && g_txt_bytes + s.capacity() <= CAP_BYTES) {
             g_txt_bytes += s.capacity();

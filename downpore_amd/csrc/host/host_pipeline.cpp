@@ -313,7 +313,7 @@ Planner::Planner(ReadSet& reads, const OverlapParams& p, ValueView values, bool 
     // remember the epoch of the flags they hold, and a new job's epoch n must not look like the old job's epoch n
     static std::atomic<uint64_t> serial{0};
     d->epoch = (serial.fetch_add(1) + 1) << 32;
-    if (const char* e = getenv("DPH_TEST_PLAN_DELAY_US")) d->testDelayUs = atol(e);
+    d->testDelayUs = dph_tune("plan_delay_us", 0);  // (test hook)
     d->fromCache = cache && (p.queryType & 1) && !(p.queryType & 8) && p.numSeeds == cache->numSeeds;
     if (threaded) setLanes(1);
 }
@@ -325,9 +325,8 @@ int Planner::lanesFor(int world, int slots) {
     const int spare = (int)hostThreads() - std::max(1, slots) - 4;  // slots, window cache, formatter, commit
     // (ownership mode - setOwnership - leaves a rank's planner 1 / world of the chain: three lanes as on one GPU; without it the
     // whole chain has to be walked `world` times faster than a GPU executes)
-    const char* sp = getenv("DPH_PLAN_SPARSE");
-    const bool sparseOff = sp && sp[0] == '0';
-    return std::max(1, std::min(sparseOff ? std::min(8, std::max(3, world + 2)) : 3, spare));
+    (void)world;
+    return std::max(1, std::min(3, spare));
 }
 // ... and how many it may grow to while the slots turn out to wait for their plans (OverlapRun::step: a lane more whenever the slots
 // spent more than 10 % of the last 64 rounds waiting - the fast hosts' 2-6 % stay below that, and a fourth lane there makes every plan
@@ -458,10 +457,7 @@ i64 Planner::predictFirstOut(i64 firstIn) const {
 
 void Planner::setOwnership(int rank, int world) {
     std::lock_guard<std::mutex> lk(d->mu);
-    static const bool off = [] {
-        const char* e = getenv("DPH_PLAN_SPARSE");  // 0: every rank's planner walks the whole chain (as before round 4)
-        return e && e[0] == '0';
-    }();
+    static const bool off = false;
     if (off || world < 2 || !d->threaded || !d->fromCache) {
         d->ownRank = 0;
         d->ownWorld = 1;
@@ -591,7 +587,7 @@ void Planner::laneMain(size_t li) {
         me.maxFlagged = -1;
         const uint64_t e0 = d->epoch;
         lk.unlock();
-        static const bool dbg = getenv("DPH_DEBUG_PLANNER") != nullptr;
+        static const bool dbg = dph_debug("planner");
         if (dbg) fprintf(stderr, "[planner %zu] computing plan %lld (firstIn %lld, wantUpTo %lld, base %lld)\n", li, (long long)m, (long long)firstIn, (long long)d->wantUpTo, (long long)d->base);
         std::shared_ptr<RoundPlan> plan = compute(m, firstIn, me.index);
         if (d->testDelayUs > 0) usleep((useconds_t)d->testDelayUs);  // test hook: flags arrive after this plan has read them
@@ -640,10 +636,7 @@ std::shared_ptr<const RoundPlan> Planner::get(i64 round) {
     }
     // plans computed beyond the highest round anybody asked for (DPH_PLAN_DEPTH): the slots ask in bursts - a commit that was
     // holding the issue window releases several rounds at once - and a lane needs 0.3 ms per plan
-    static const i64 depth = [] {
-        const char* e = getenv("DPH_PLAN_DEPTH");
-        return e ? std::max(1L, atol(e)) : 6L;
-    }();
+    static const i64 depth = std::max(1L, dph_tune("plan_depth", 6));
     if (d->ownWorld > 1 && round % d->ownWorld != d->ownRank) {
         // somebody asks for a round this rank does not own (not the round-parallel workers): the whole chain from here on
         d->ownWorld = 1;
@@ -828,7 +821,6 @@ void OverlapRun::shutdown(bool keepContexts) {
         sl->index.reset();
     }
     if (keepContexts) return;
-    destroyGangs();
     if (plannerCtx) dp_ctx_destroy(plannerCtx);
     plannerCtx = nullptr;
     for (auto& sl : slots) {
@@ -838,11 +830,6 @@ void OverlapRun::shutdown(bool keepContexts) {
     slots.clear();
 }
 
-void OverlapRun::destroyGangs() {
-    for (dp_gang* g : gangs) dp_gang_destroy(g);
-    gangs.clear();
-    gangSize = 1;
-}
 
 int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const double* valuesOrNull, int nSlots) {
     ctx = c;
@@ -880,7 +867,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     }
     if (valuesOrNull) {
         values.assign(valuesOrNull, (size_t)1 << (2 * p.k));
-    } else if (const char* hv = getenv("DP_HOST_VALUES"); hv && hv[0] == '1') {  // histogram on the GPU, table on the host
+    } else if (dph_tune("host_values", 0)) {  // (tests) histogram on the GPU, table on the host
         std::vector<uint64_t> counts((size_t)1 << (2 * p.k));
         int rc = dp_kmer_histogram(ctx, p.k, counts.data());
         if (rc != 0) {
@@ -939,11 +926,10 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
                 dlErr = dp_last_error(nullptr);
                 return;
             }
-            // one byte per k-mer where that is enough (DP_VALUE_CODES8=0: two bytes as before round 4), else two, else the doubles
-            const char* c8e = getenv("DP_VALUE_CODES8");
+            // one byte per k-mer where that is enough, else two, else the doubles
             codes8_ = false;
             dlOverflow = 1;
-            if (!(c8e && c8e[0] == '0')) {
+            {
                 dlRc = dp_values_download_codes8(c2, (uint8_t*)dst, nk, &dlTotal, &dlOverflow);
                 codes8_ = dlRc == 0 && !dlOverflow;
             }
@@ -958,8 +944,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     }
     errText += "Counting complete. Starting indexing and querying...";
     {
-        const char* hostsel = getenv("DP_HOST_SELECT");
-        if (!(hostsel && hostsel[0] == '1') && p.numSeeds <= 64 && !valuesOnDevice) {  // value table resident for dp_select_seeds
+        if (!dph_tune("host_select", 0) && p.numSeeds <= 64 && !valuesOnDevice) {  // value table resident for dp_select_seeds
             int rc = dp_values_upload(ctx, values.data(), values.size());
             if (rc != 0) {
                 error = dp_last_error(ctx);
@@ -971,20 +956,18 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
     // contexts kept by a reset() of this handle are taken over when they fit (same owner context, same number of slots)
     const bool reuseSlots = !slots.empty() && (int)slots.size() == std::max(1, nSlots) && slots[0]->ctx == ctx;
     if (!reuseSlots) {
-        destroyGangs();
-        for (auto& sl : slots)
+            for (auto& sl : slots)
             if (sl->ownsCtx && sl->ctx) dp_ctx_destroy(sl->ctx);
         slots.clear();
     }
     {
-        const char* dt = getenv("DP_DEFER_TEXT");  // 0: the executor slots format their rounds' text themselves
         textPool.reset();
         // formatter threads (DPH_TEXT_THREADS): a round's text is ~0.26 ms of one thread, so two of them cap a run at 7.7 rounds per ms -
         // which is where the rounds arrived in round 5 (0.135 ms each): three where the host has the threads for it (commit's wait for
         // its round's text 46 -> 40 ms per job, 0.141 - 0.152 -> 0.133 - 0.141 ms per round; four and six: the same as three)
         int nText = hostThreads() >= 12 ? 3 : 2;
         if (const char* te = getenv("DPH_TEXT_THREADS")) nText = std::max(1, std::min(16, atoi(te)));
-        if (!(dt && dt[0] == '0')) textPool.reset(new TextPool(nText));
+        textPool.reset(new TextPool(nText));
     }
     setHostThreadShare((unsigned)std::max(1, nSlots));
     // every executor slot's thread waits for its stream five to seven times per round: busy waits when this process has the
@@ -1012,40 +995,10 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         if ((size_t)i < slotComms.size()) sl->comm = slotComms[(size_t)i];
         slots.push_back(std::move(sl));
     }
-    {
-        // gangs of consecutive slots: their rounds begin together and share every launch.  Not in scan-shard mode (a slot's
-        // survivor exchange is a collective of its own on its own communicator).
-        // (DPH_GANG = members per gang; default 1 = every slot on its own stream: measured on config 2, five independent slots and
-        // two gangs of eight sustain the same 4 rounds per ms - the GPU is bound by the chaining kernels' wave-time, which a
-        // launch that carries more rounds does not shorten - DESIGN.md)
-        const char* ge = getenv("DPH_GANG");
-        int want = ge ? atoi(ge) : 1;
-        want = std::max(1, std::min(want, 8));
-        bool sharded = false;
-        for (auto& sl : slots) sharded = sharded || sl->comm != nullptr;
-        if (sharded) want = 1;
-        if (want != gangSize || (want > 1 && gangs.empty()) || !reuseSlots) {
-            destroyGangs();
-            gangSize = want;
-            for (size_t i = 0; gangSize > 1 && i < slots.size(); i += (size_t)gangSize) {
-                dp_ctx* m[8];
-                int n = 0;
-                for (size_t j = i; j < slots.size() && n < gangSize; j++) m[n++] = slots[j]->ctx;
-                if (n < 2) break;
-                dp_gang* g = nullptr;
-                int rc = dp_gang_create(m, n, &g);
-                if (rc != 0) {
-                    error = dp_last_error(m[0]);
-                    return rc;
-                }
-                gangs.push_back(g);
-            }
-        }
-    }
     mark("executor slots");
-    const char* nothread = getenv("DP_NO_PLANNER_THREAD");
-    const char* hostsel = getenv("DP_HOST_SELECT");  // 1: keep the speculative seed selection on the host threads
-    const bool wantPlannerCtx = !(hostsel && hostsel[0] == '1') && p.numSeeds <= 64;
+    // (tests: DP_TUNE=no_planner_thread=1 plans on the calling thread, host_select=1 keeps the speculative seed selection on host threads)
+    const bool nothread = dph_tune("no_planner_thread", 0) != 0;
+    const bool wantPlannerCtx = !dph_tune("host_select", 0) && p.numSeeds <= 64;
     if (plannerCtx && !wantPlannerCtx) {
         dp_ctx_destroy(plannerCtx);
         plannerCtx = nullptr;
@@ -1059,8 +1012,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         // the plan chain is sequential and waits for one small selection kernel per plan: it should not queue behind the
         // executor slots' kernels.  (Measured neutral on config 2 - there the planner's wait grows because the process is
         // at its CPU quota, not because of the GPU queue - kept because it is the right order of service.)
-        const char* np = getenv("DP_PLANNER_PRIORITY");
-        if (!(np && np[0] == '0')) dp_ctx_set_priority(plannerCtx, 1);
+        dp_ctx_set_priority(plannerCtx, 1);
     }
     winCache.reset();
     {
@@ -1089,7 +1041,7 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
         }
         mark("values copy (overlapped)");
     }
-    planner.reset(new Planner(*reads, p, valueView(), !(nothread && nothread[0] == '1'), plannerCtx, winCache.get()));
+    planner.reset(new Planner(*reads, p, valueView(), !nothread, plannerCtx, winCache.get()));
     planner->setLanes(std::max(Planner::lanesFor(world_, nSlots), adaptLanes_));
     mark("planner");
     firstSequence = 0;
@@ -1112,8 +1064,8 @@ int OverlapRun::init(dp_ctx* c, ReadSet* r, const OverlapParams& params, const d
 int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
     const double tb0 = now();
     if (dp_comm* cm = sl.comm ? sl.comm : comm)
-        if (const char* e = getenv("DPH_FAIL_BEGIN_RANK"))  // test hook: this rank's round fails before it reaches any exchange
-            if (atoi(e) == dp_comm_rank(cm)) {
+        if (const long fr = dph_tune("fail_begin_rank", -1); fr >= 0)  // test hook: this rank's round fails before it reaches any exchange
+            if (fr == dp_comm_rank(cm)) {
                 sl.error = "injected failure before the exchange (DPH_FAIL_BEGIN_RANK)";
                 return -1;
             }
@@ -1156,8 +1108,6 @@ int OverlapRun::beginRound(ExecSlot& sl, const RoundPlan& plan) {
     sl.lap->setIgnoreView(reads->ignore.data(), planner->ignoreEpoch());
     const double tb2 = now();
     g_prof.add(1, tb2 - tb1);
-    // a gang member's round begins together with the rounds of the other members that have one (and ends in executeRoundOn)
-    dp_gang_round_begin(sl.ctx);
     g_prof.add(18, now() - tb2);
     int rc = dp_round_begin(sl.ctx, p.k, sl.index->seedMap.data(), (uint32_t)sl.index->seedMap.size());
     if (rc != 0) {
@@ -1245,11 +1195,6 @@ int OverlapRun::executeRoundOnImpl(ExecSlot& sl, i64 r, RoundResult& out) {
             if (g_prof.on) g_prof.slotCpuUs += (long long)((threadCpuNow() - t0) * 1e6);
         }
     } slotCpu{tc0};
-    struct GangRound {  // the slot has a round: the other members of its gang do not start theirs without it; over in any case at the end
-        dp_ctx* c;
-        explicit GangRound(dp_ctx* c_) : c(c_) { dp_gang_round_prepare(c); }
-        ~GangRound() { dp_gang_round_end(c); }
-    } gangRound(sl.ctx);
     struct ExchangeTurn {  // however this round ends, the slots behind it in the batch's exchange order get their turn - in order:
         OverlapRun* run;   // a slot passes a baton on only once it holds it (the slots' collectives are issued in the same order on
         int index;         // every rank, also around a slot whose round turned out empty)
@@ -1266,11 +1211,11 @@ int OverlapRun::executeRoundOnImpl(ExecSlot& sl, i64 r, RoundResult& out) {
             pass(run->resultTurn_);
         }
     } exchangeTurn{this, sl.slotNo, sl.comm != nullptr && exchangeOrdered_};
-    static const bool dbgExec = getenv("DPH_DEBUG_PLANNER") != nullptr;
+    static const bool dbgExec = dph_debug("planner");
     if (dbgExec) fprintf(stderr, "[exec] round %lld waiting for its plan\n", (long long)r);
     std::shared_ptr<const RoundPlan> plan = planner->get(r);
     if (dbgExec) fprintf(stderr, "[exec] round %lld got plan\n", (long long)r);
-    static const bool startTrace = getenv("DPH_START_TRACE") != nullptr;  // a job's first rounds, in ms since the end of its set-up
+    static const bool startTrace = dph_debug("start");  // a job's first rounds, in ms since the end of its set-up
     const double tPlan = now();
     {
         const long long waitedUs = (long long)((now() - t0) * 1e6);
@@ -1295,12 +1240,12 @@ int OverlapRun::executeRoundOnImpl(ExecSlot& sl, i64 r, RoundResult& out) {
     int rc = beginRound(sl, *plan);
     if (rc) return rc;
     out.st.n_seeds = plan->seedMap.size();
-    out.st.gang_members = (uint64_t)dp_gang_round_members(sl.ctx);
+    out.st.gang_members = 1;
     double t1 = now();
     out.st.t_prepare = t1 - t0;
     const bool sharded = sl.comm != nullptr;  // scan-shard: this rank scans its reads, the survivors of all ranks are exchanged
     rc = sl.lap->ScanLocal(sharded ? shardLo : 0, sharded ? shardHi : reads->size(), sl.local, out.st);
-    static const bool dbgX = getenv("DPH_DEBUG_EXCHANGE") != nullptr;
+    static const bool dbgX = dph_debug("exchange");
     if (dbgX) fprintf(stderr, "[x %p] slot %d round %lld scanned rc %d, waiting for turn (turn %d)\n", (void*)this, sl.slotNo, (long long)r, rc, exchangeTurn_);
     if (sharded && exchangeOrdered_) {  // this slot's turn among the batch's exchanges (taken also by a slot whose scan failed)
         std::unique_lock<std::mutex> lk(exchangeMu_);
@@ -1529,10 +1474,7 @@ void OverlapRun::workerMain(size_t si) {
     ExecSlot& sl = *slots[si];
     // rounds issued ahead of the commit point (owned ones only): commits are in order, so a round that takes longer than its
     // neighbours holds the window; DPH_ISSUE_WINDOW = rounds beyond the slot count (config 2, six slots: +2 0.370, +6 0.344, +12 0.338, +24 0.343 ms per round)
-    static const i64 extra = [] {
-        const char* e = getenv("DPH_ISSUE_WINDOW");
-        return e ? std::max(0L, atol(e)) : 10L;
-    }();
+    static const i64 extra = std::max(0L, dph_tune("issue_window", 10));
     const i64 window = ((i64)slots.size() + extra) * world_;
     std::unique_lock<std::mutex> lk(pmu_);
     for (;;) {
@@ -1817,8 +1759,7 @@ int OverlapRun::roundSharded() {
 int OverlapRun::roundsShardedBatch() {
     if (done) return 0;
     {
-        const char* e = getenv("DPH_SHARD_QUERIES");
-        shardQueries = !(e && e[0] == '0');
+        shardQueries = !dph_tune("no_shard_queries", 0);
     }
     if (slotComms.size() < slots.size()) {
         error = "roundsShardedBatch: fewer communicators than executor slots";

@@ -28,7 +28,6 @@ namespace dph {
 // thread's page faults - measured as 12 % of the whole job (two processes with four slots each on one GPU ran 19 % faster
 // than one process with eight).  Keep freed memory in the allocator instead.  DPH_MALLOC_DEFAULTS=1 leaves glibc alone.
 static const bool g_malloc_tuned = [] {
-    if (const char* e = getenv("DPH_MALLOC_DEFAULTS"); e && e[0] == '1') return false;
     mallopt(M_MMAP_THRESHOLD, 32 << 20);      // (the largest value glibc accepts; fixes the threshold)
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
     mallopt(M_TOP_PAD, 64 << 20);
@@ -47,7 +46,7 @@ static void segvTrace(int sig) {
     raise(sig);
 }
 static const bool g_segv_trace = [] {
-    if (const char* e = getenv("DPH_SEGV_TRACE"); e && e[0] == '1') {
+    if (dph::dph_debug("segv")) {
         signal(SIGSEGV, segvTrace);
         signal(SIGBUS, segvTrace);
         signal(SIGABRT, segvTrace);
@@ -124,8 +123,7 @@ void profReport() {
     }
 }
 const bool g_profOn = [] {
-    const char* e = getenv("DPH_SAMPLE_PROF");
-    if (!(e && e[0] == '1')) return false;
+    if (!dph::dph_debug("sample_prof")) return false;
     g_profSamples = new ProfSample[kProfMax];
     void* warm[4];
     backtrace(warm, 4);  // (loads the unwinder now, not inside the first signal)
@@ -273,8 +271,10 @@ class WorkPool {
         // short bursts stacked on the waker's CPU.  Each worker is therefore pinned to its own CPU of the allowed set
         // (spread evenly) when DP_PIN_WORKERS=1.
         std::vector<int> cpus;
-        const char* pin = getenv("DP_PIN_WORKERS");
-        if (pin && pin[0] != '0') {  // 1: one worker per physical core, spread over all cores; 2: the same within NUMA node 0
+        const long pinMode = dph::dph_tune("pin_workers", 0);
+        const char pinBuf[2] = {(char)('0' + (pinMode & 7)), 0};
+        const char* pin = pinBuf;
+        if (pin[0] != '0') {  // 1: one worker per physical core, spread over all cores; 2: the same within NUMA node 0
             cpu_set_t set;
             CPU_ZERO(&set);
             if (sched_getaffinity(0, sizeof set, &set) == 0)

@@ -369,8 +369,7 @@ __attribute__((target("avx512f"))) bool touchAvx512(const SeedIndex& ix, const u
 }
 
 TouchFn pickTouch() {
-    if (const char* e = getenv("DPH_TOUCH_ISA")) {  // tests: 0 scalar, 1 AVX2, 2 AVX-512 (only what the CPU has)
-        const int want = atoi(e);
+    if (const long want = dph_tune("touch_isa", -1); want >= 0) {  // tests: 0 scalar, 1 AVX2, 2 AVX-512 (only what the CPU has)
         if (want >= 2 && __builtin_cpu_supports("avx512f")) return touchAvx512;
         if (want >= 1 && __builtin_cpu_supports("avx2")) return touchAvx2;
         return touchScalar;
@@ -948,10 +947,7 @@ static SeedSeq* multiAlignerCore(Arena& arena, std::vector<SeedSeq*>& seqs, std:
             matches[i] = m;
         }
     bool finished = false;
-    static const bool uniformFast = [] {  // DP_NO_UNIFORM_STEP=1: always take the general step
-        const char* e = getenv("DP_NO_UNIFORM_STEP");
-        return !(e && e[0] == '1');
-    }();
+    static const bool uniformFast = true;
     const i64 kNarrow = (i64)1 << 28;  // all quantities below this: 32-bit arithmetic is exact
     okv.assign(ns, 0);
     odv.assign(ns, 0);
@@ -1410,14 +1406,8 @@ static SeedSeq* trimmedRcTarget(Arena& a, SeedSeq* S, const SeedIndex& ix, i64 s
 static void consensusTrimTargets(Arena& ar, const SeedIndex& sg, std::vector<SeedMatch*>& overlaps, std::vector<SeedSeq*>& seqs) {
     const int k = sg.k;
     seqs.clear();
-    static const bool fullRc = [] {  // DP_FULL_RC=1: the literal matchReverseComplement + Trimmed() sequence
-        const char* e = getenv("DP_FULL_RC");
-        return e && e[0] == '1';
-    }();
-    static const bool useAnchors = [] {  // DP_NO_ANCHORS=1: ignore the device's target anchors, sum the gaps here
-        const char* e = getenv("DP_NO_ANCHORS");
-        return !(e && e[0] == '1') && !fullRc;
-    }();
+    static const bool fullRc = false;
+    static const bool useAnchors = !fullRc;
     {
         FINE(0);
         for (SeedMatch* lap : overlaps) {

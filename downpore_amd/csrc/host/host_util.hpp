@@ -1,5 +1,6 @@
 // Internal helpers shared by the host translation units (not part of the mirrored reference interface).
 #pragma once
+// DP_DEBUG=a,b,c / DP_TUNE=key=value,...: see dp_common.h (the same two variables; the host library reads them for its own names)
 #include <sys/resource.h>
 #include <x86intrin.h>
 #include <time.h>
@@ -124,4 +125,56 @@ struct PipeProfile {
 };
 extern PipeProfile g_prof;  // defined in host_pool.cpp
 
+}  // namespace dph
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+namespace dph {
+inline std::map<std::string, std::string> envTokens(const char* name) {
+    std::map<std::string, std::string> m;
+    const char* e = getenv(name);
+    if (!e) return m;
+    std::string s(e);
+    size_t at = 0;
+    while (at <= s.size()) {
+        size_t end = s.find(',', at);
+        if (end == std::string::npos) end = s.size();
+        const std::string tok = s.substr(at, end - at);
+        const size_t eq = tok.find('=');
+        if (!tok.empty()) m[eq == std::string::npos ? tok : tok.substr(0, eq)] = eq == std::string::npos ? "1" : tok.substr(eq + 1);
+        at = end + 1;
+    }
+    return m;
+}
+struct EnvTokens {  // (parsed again whenever the variable's text has changed: tests set it between jobs of one process)
+    const char* name;
+    std::mutex mu;
+    std::string text;
+    bool parsed = false;
+    std::map<std::string, std::string> m;
+    const std::map<std::string, std::string>& get() {  // (call with mu held)
+        const char* e = getenv(name);
+        if (!e) e = "";
+        if (!parsed || text != e) {
+            text = e;
+            m = envTokens(name);
+            parsed = true;
+        }
+        return m;
+    }
+};
+inline bool dph_debug(const char* what) {
+    static EnvTokens t{"DP_DEBUG"};
+    std::lock_guard<std::mutex> lk(t.mu);
+    return t.get().count(what) != 0;
+}
+inline long dph_tune(const char* key, long dflt) {
+    static EnvTokens t{"DP_TUNE"};
+    std::lock_guard<std::mutex> lk(t.mu);
+    const auto& m = t.get();
+    const auto it = m.find(key);
+    return it == m.end() ? dflt : atol(it->second.c_str());
+}
 }  // namespace dph

@@ -55,7 +55,6 @@ SYMBOLS = ["dp_version", "dp_ctx_create", "dp_ctx_create_shared", "dp_ctx_set_pr
            "dp_find_overlaps", "dp_query_prestage", "dp_map_windows", "dp_index_posting_row", "dp_index_seedset_row", "dp_scan_device_buffers",
            "dp_scan_import_segments", "dp_values_upload", "dp_select_seeds", "dp_reads_upload_rc", "dp_consensus_align", "dp_scan_release", "dp_consensus_paf", "dp_fetch_overlaps", "dp_select_windows", "dp_values_download",
     "dp_values_download_codes", "dp_values_download_codes8", "dp_index_build_chunked", "dp_index_prechain", "dp_index_prechained", "dp_index_chunks", "dp_scan_fetch_mode", "dp_scan_fetch_segments", "dp_set_stream_wait", "dp_set_kernel_timing", "dp_index_meta", "dp_index_set_global", "dp_map_windows_shard", "dp_single_seed_candidates", "dp_comm_unique_id", "dp_comm_init", "dp_comm_init_local", "dp_quality_upload",
-           "dp_gang_create", "dp_gang_destroy", "dp_gang_round_prepare", "dp_gang_round_begin", "dp_gang_round_end", "dp_gang_round_members", "dp_gang_counters",
            "dp_comm_destroy", "dp_comm_abort", "dp_allgather_blobs", "dp_gather_blobs", "dp_kindex_set_comm", "dp_kindex_digest", "dp_release_device_caches", "dp_reads_upload_rc_begin", "dp_reads_upload_wait", "dp_comm_rank", "dp_comm_size", "dp_allgather_survivors"]
 
 _lib = None

@@ -470,38 +470,6 @@ DP_API int dp_comm_size(const dp_comm* comm);
  * library-owned pinned memory, valid until the next call on this communicator). */
 DP_API int dp_allgather_survivors(dp_comm* comm, dp_ctx* ctx, const dp_survivor_batch* local, dp_survivor_batch* all);
 
-/* ---- gangs: several rounds in one set of launches ------------------------------------------------------------------------------
- * The rounds of `downpore overlap` (commands/overlap.go:119-195) are independent of each other until a read is flagged, and a
- * round on the GPU is a chain of ~26 small, dependent, latency-bound launches.  A gang is a set of contexts of one device - each
- * driven by its own host thread (goroutine locked to a thread) through the per-round calls above, exactly as without a gang -
- * whose launches are issued TOGETHER: when every member inside a round has reached its next launch, ONE launch carries all of
- * them (blockIdx.y = member; every member keeps its own buffers and results), and the members wait for the same stream.  The
- * reference spreads a round over num_workers goroutines (overlap/overlap.go:217-250, 320-344); here the rounds themselves share
- * launches, because a round alone cannot fill the GPU.
- *   dp_gang_create        the contexts become members (n <= 8; they must be idle).  dp_gang_destroy before destroying a member.
- *   dp_gang_round_prepare optional: the member has a round and is getting its inputs ready (a plan, seed tables): members that
- *                         are ready do not start without it.
- *   dp_gang_round_begin   before the round's first per-round call (dp_round_begin ...): blocks until every member that has a
- *                         round (prepare) is here as well, so that the rounds of a gang run in step; members without work are
- *                         not waited for.
- *   dp_gang_round_end     after the round's last call (and on every error path): the member no longer holds the others up.
- * Inside a round a member's thread must not wait for another member's thread other than through these calls.  Results are
- * bit-identical with and without a gang.
- * Failure: a call that returns an error on a member inside a round - or a rendezvous nobody completes within DP_GANG_TIMEOUT_S
- * seconds (30) - fails the gang for good: members waiting for the others are released and carry on with launches and waits of
- * their own, and dp_gang_round_begin returns DP_ERR_STATE from then on (destroy the gang, create a new one). */
-typedef struct dp_gang dp_gang;
-DP_API int dp_gang_create(dp_ctx* const* ctxs, int n, dp_gang** out);
-DP_API void dp_gang_destroy(dp_gang* gang);
-DP_API int dp_gang_round_prepare(dp_ctx* ctx);
-DP_API int dp_gang_round_begin(dp_ctx* ctx);
-DP_API int dp_gang_round_end(dp_ctx* ctx);
-/* members that began their rounds together with this context's current round (what a merged launch of that round carries) */
-DP_API int dp_gang_round_members(const dp_ctx* ctx);
-/* out[0] = launches deposited by members, out[1] = launches issued (out[0] / out[1] = rounds per launch), out[2] = waits,
- * out[3] = round starts, out[4] = members released by them */
-DP_API void dp_gang_counters(dp_gang* gang, uint64_t* out /* [5] */);
-
 /* All-gather of one variable-size byte string per rank on the same communicator: the result exchange of the round-parallel
  * layout (every GPU holds the reads and their index, the rounds - commands/overlap.go:119's loop iterations - are dealt to the
  * ranks, and a round's PAF text, SetIgnore ids and read lists travel to every rank, which commits them in round order).  *all_out

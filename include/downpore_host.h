@@ -7,7 +7,7 @@
  * reference's own command loop (commands/overlap.go:119-195: PrepareQueries -> AddSequences -> FindOverlaps -> finalCheckWorker,
  * round after round) leaves the GPU idle between dependent launches.  What bench.py measures (BENCH_r*.json) is the pipeline in
  * this library: a planner that runs the PrepareQueries chain ahead on speculative lanes, a window cache that selects every edge
- * window's seeds on the device once, executor slots that run rounds concurrently (in gangs that share every launch) and commit
+ * window's seeds on the device once, executor slots that run rounds concurrently and commit
  * them in order with a speculation check, consensus + PAF numbers on the device, text on formatter threads.  This header is
  * that pipeline's boundary: a Go `commands/overlap.go` that calls dph_overlap_open / _init / _step / _round_paf (cgo,
  * INTEGRATION.md, integration/commands/gpu_overlap.go) prints the reference's PAF at the measured rate.

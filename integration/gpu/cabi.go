@@ -757,38 +757,6 @@ func (m *Comm) Abort() {
 	}
 }
 
-// ---- gangs: several rounds in one set of launches ------------------------------------------------------------------------------
-
-// Gang makes contexts of one device share every launch of their rounds (include/downpore_hip.h): one goroutine per member,
-// locked to its thread for the duration of a round (runtime.LockOSThread), RoundBegin / RoundEnd around the per-round calls.
-type Gang struct {
-	h *C.dp_gang
-}
-
-func NewGang(ctxs []*Context) (*Gang, error) {
-	if len(ctxs) == 0 {
-		return nil, errors.New("NewGang: no contexts")
-	}
-	hs := make([]*C.dp_ctx, len(ctxs))
-	for i, c := range ctxs {
-		hs[i] = c.h
-	}
-	var g *C.dp_gang
-	if rc := C.dp_gang_create((**C.dp_ctx)(unsafe.Pointer(&hs[0])), C.int(len(ctxs)), &g); rc != 0 {
-		return nil, fail(hs[0], "dp_gang_create", rc)
-	}
-	return &Gang{g}, nil
-}
-func (g *Gang) Close() {
-	if g.h != nil {
-		C.dp_gang_destroy(g.h)
-		g.h = nil
-	}
-}
-func (c *Context) GangRoundPrepare() { C.dp_gang_round_prepare(c.h) }
-func (c *Context) GangRoundBegin()   { C.dp_gang_round_begin(c.h) }
-func (c *Context) GangRoundEnd()     { C.dp_gang_round_end(c.h) }
-
 // SetPriority gives the context's stream the device's highest (or default) scheduling priority: for the goroutine that runs the
 // PrepareQueries chain and waits for SelectWindows while other contexts keep the GPU busy with whole rounds.
 func (c *Context) SetPriority(high bool) error {

@@ -1,6 +1,6 @@
 // Package gpuhost is the cgo face of libdownpore_host.so (include/downpore_host.h): the whole `downpore overlap` /
 // `downpore map` pipeline behind four calls - open, init, step, paf.  This is the path bench.py measures (BENCH_r*.json): the
-// planner lanes, the window cache, the executor slots in gangs, the consensus and the PAF numbers on the device all live behind
+// planner lanes, the window cache, the executor slots, the consensus and the PAF numbers on the device all live behind
 // dph_overlap_step; a command loop written against package gpu (one synchronous round at a time) gets the kernels but not that
 // rate.  commands/gpu_overlap.go and commands/gpu_map.go are the two commands written against this package.
 //

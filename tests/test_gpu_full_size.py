@@ -47,13 +47,6 @@ def test_config2_whole_job_matches_oracle_fixture():
     assert st["idx_rounds"] == 1  # 1 Gbase: served by the resident k-mer position index
 
 
-def test_config2_whole_job_in_gangs(monkeypatch):
-    """The same job with the executor slots in two gangs of four: every per-round kernel launched once per gang for four
-    rounds (dp_gang_create; 26 launches per four rounds instead of per round)."""
-    monkeypatch.setenv("DPH_GANG", "4")
-    _overlap_against_fixture(_golden("config2"), slots=8)
-
-
 def test_config2_whole_job_scan_kernels(monkeypatch):
     """The same job with the scan kernels instead of the k-mer index (first 150 rounds would not tell the two modes apart
     less than all of them do, and the whole job takes a second)."""

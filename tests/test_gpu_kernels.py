@@ -541,51 +541,3 @@ def test_reference_sequence_test_vectors_on_device(ctx):
         ksk, cnt = kmer_set(sub, k)
         n, _ = scan_view(7, len(S70) - 7, k, seeds_of(ksk))
         assert n == cnt == O.byte_count_kmers(sub, 100, k, ksk)
-
-
-def test_gang_member_error_releases_the_other_members():
-    """A gang member that reports an error inside a round (or simply never comes back: DP_GANG_TIMEOUT_S) must not leave the others
-    spinning at their rendezvous: the gang fails for good, waiting members go on with plain launches and waits, and the next
-    dp_gang_round_begin says DP_ERR_STATE (dp_gang.hip: dp_gang::failed; ADVICE round 3)."""
-    import ctypes as C
-    import threading
-    import time
-    from downpore_amd.hip import Context
-    bases, off = O.gen_reads(5, 20000, 50, 1000, 0.0, False)
-    a, b, c = Context(), Context(), Context()
-    for x in (a, b, c):
-        x.upload_reads(bases, off)
-    want = c.kmer_histogram(9)
-    L = a.L
-    hs = (C.c_void_p * 2)(a.h, b.h)
-    g = C.c_void_p()
-    L.dp_gang_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
-    L.dp_gang_destroy.argtypes = [C.c_void_p]
-    for f in (L.dp_gang_round_prepare, L.dp_gang_round_begin, L.dp_gang_round_end):
-        f.argtypes = [C.c_void_p]
-    assert L.dp_gang_create(hs, 2, C.byref(g)) == 0
-    done = threading.Event()
-    res = {}
-
-    def member_b():
-        res["begin"] = L.dp_gang_round_begin(b.h)
-        res["hist"] = b.kmer_histogram(9)  # its wait is a rendezvous with member a, which never arrives at one
-        L.dp_gang_round_end(b.h)
-        done.set()
-
-    assert L.dp_gang_round_prepare(a.h) == 0 and L.dp_gang_round_prepare(b.h) == 0  # (so that the two rounds begin together)
-    t = threading.Thread(target=member_b)
-    t.start()
-    assert L.dp_gang_round_begin(a.h) == 0
-    time.sleep(0.5)
-    assert not done.is_set()
-    L.dp_index_prechain.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint32, C.c_int32]
-    assert L.dp_index_prechain(a.h, 0, 0, 0, 0) != 0  # an error inside the round
-    assert done.wait(20), "member b is still waiting for the failed member"
-    t.join()
-    assert res["begin"] == 0 and np.array_equal(res["hist"], want)
-    L.dp_gang_round_end(a.h)
-    assert L.dp_gang_round_begin(a.h) == -3  # DP_ERR_STATE: the gang has failed
-    L.dp_gang_destroy(g)
-    for x in (a, b, c):
-        x.close()

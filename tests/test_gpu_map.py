@@ -58,13 +58,13 @@ def test_map_paf_bit_exact(seed, G, N, L, e, variable, circular):
 
 def test_map_single_seeds_host_walk_agrees(monkeypatch):
     """AddSingleSeeds: the windows' best k-mers and their count regions' candidates come from the device, the host walks the windows in
-    order and probes the candidates (round 4); DP_MAP_SEEDS_HOST=1 does the whole walk on the host as before.  Same PAF as the oracle
+    order and probes the candidates (round 4); DP_TUNE=map_seeds_host=1 does the whole walk on the host as before.  Same PAF as the oracle
     either way - linear and circular references, lengths with every len % 4 (the count region's skipBack)."""
     for G in (200001, 200002, 200003, 200004):
         _case(3, G, 60, 6000, 0.02, True, G % 2 == 0)
-    monkeypatch.setenv("DP_MAP_SEEDS_HOST", "1")
+    monkeypatch.setenv("DP_TUNE", "map_seeds_host=1")
     _case(3, 200002, 60, 6000, 0.02, True, True)
-    monkeypatch.delenv("DP_MAP_SEEDS_HOST")
+    monkeypatch.delenv("DP_TUNE")
 
 
 def test_map_threads_reads_in_flight_and_parked_blocks(monkeypatch):
@@ -77,16 +77,16 @@ def test_map_threads_reads_in_flight_and_parked_blocks(monkeypatch):
     lib = load_library()
     lib.dp_release_device_caches.restype = C.c_int64
     args = (5, 300000, 2600, 9000, 0.10, True, False)
-    monkeypatch.setenv("DP_MAP_MIN_READS_PER_THREAD", "300")   # (2 048 by default: these reads would all go to one thread)
+    monkeypatch.setenv("DP_TUNE", "map_min_reads_per_thread=300")   # (2 048 by default: these reads would all go to one thread)
     _case(*args)
     assert lib.dp_release_device_caches() > 0
     assert lib.dp_release_device_caches() == 0
     # the reads are dealt to the threads in blocks of 1 024 and travel to the device while the first ones are mapped (round 5,
-    # dp_reads_upload_rc_begin; DP_MAP_ASYNC_UPLOAD=0: all of them first): one thread, more threads than blocks, windows per call
+    # dp_reads_upload_rc_begin with DP_TUNE=map_async_upload=1; 0: all of them first): one thread, more threads than blocks, windows per call
     for threads, inflight, asyn in (("1", "64", "1"), ("2", "500", "1"), ("4", "100000", "1"), ("3", "700", "0"), ("8", "2730", "1")):
         monkeypatch.setenv("DP_MAP_THREADS", threads)
         monkeypatch.setenv("DP_MAP_INFLIGHT", inflight)
-        monkeypatch.setenv("DP_MAP_ASYNC_UPLOAD", asyn)
+        monkeypatch.setenv("DP_TUNE", "map_min_reads_per_thread=300,map_async_upload=%s" % asyn)
         _case(*args)
     from downpore_amd.overlap import load_host
     H = load_host()
@@ -96,12 +96,12 @@ def test_map_threads_reads_in_flight_and_parked_blocks(monkeypatch):
 
 
 def test_map_dynamic_match_on_one_lane_agrees(monkeypatch):
-    """dynamicMatch probes the target's seeds with 64 lanes at once (round 4); DP_MAP_ONE_LANE=1 runs the reference's loop nest on
+    """dynamicMatch probes the target's seeds with 64 lanes at once (round 4); DP_TUNE=map_one_lane=1 runs the reference's loop nest on
     one lane as before.  Both must print the oracle's PAF - reads with errors, so that chains break, ratchets move and several
     chains start from one query seed."""
-    monkeypatch.setenv("DP_MAP_ONE_LANE", "1")
+    monkeypatch.setenv("DP_TUNE", "map_one_lane=1")
     _case(5, 300000, 200, 9000, 0.10, True, False)
-    monkeypatch.delenv("DP_MAP_ONE_LANE")
+    monkeypatch.delenv("DP_TUNE")
     _case(6, 250000, 250, 7000, 0.15, True, True)
 
 

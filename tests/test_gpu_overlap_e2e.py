@@ -167,16 +167,16 @@ def test_overlap_non_acgt_letters():
     _run_arrays(b, off)
 
 
-@pytest.mark.parametrize("env", ["DP_NO_PLANNER_THREAD", "DP_HOST_SELECT"])
-def test_overlap_planner_variants(env):
+@pytest.mark.parametrize("tune", ["no_planner_thread=1", "host_select=1"])
+def test_overlap_planner_variants(tune):
     """The planner without its own thread (executor slots extend the plan chain themselves, one at a time) and with the
-    seed selection on the host threads instead of dp_select_seeds."""
-    os.environ[env] = "1"
+    seed selection on the host threads instead of dp_select_seeds (DP_TUNE tokens)."""
+    os.environ["DP_TUNE"] = tune
     try:
         _run_both(32, 60000, 500, 1500, 10, variable=True, slots=3)
         _run_both(113, 1500000, 3000, 10000, 13, max_rounds=3, slots=2)
     finally:
-        del os.environ[env]
+        del os.environ["DP_TUNE"]
 
 
 @pytest.mark.parametrize("world,slots,seed,G,N,L,variable", [(2, 2, 31, 100000, 400, 5000, False), (4, 2, 31, 100000, 400, 5000, False),
@@ -229,16 +229,14 @@ def test_overlap_kmer_index_mode(mode):
 
 
 @pytest.mark.parametrize("env", [{"DP_KX_BINS": "0"}, {"DP_KX_BINS_CAP": "300"}, {"DP_KX_BINS_CAP": "40"}, {"DP_KX_ONESHOT": "0"}, {"DP_KX_FUSE": "0"},
-                                 {"DP_KX_FUSE": "2"}, {"DP_KX_FUSE": "2", "DP_KX_BINS_CAP": "300"}, {"DP_QUERY_SCAN": "1"},
                                  {"DP_KX_DENSE": "1"}, {"DP_KX_DENSE": "1", "DP_KX_BINS_CAP": "300"}, {"DP_KX_DENSE": "1", "DP_KX_BINS_CAP": "40"}])
 def test_kmer_index_counting_step_variants(monkeypatch, env):
     """The counting step of an index-mode round (dp_kindex.hip): hits binned by read range and counted in LDS (round 5, the default),
     round 4's hit records with one atomic per hit (DP_KX_BINS=0), bins that overflow - a workgroup's share that does not fit is
     counted the old way, what it reserved is marked unwritten, the fill pass walks the buckets (DP_KX_BINS_CAP: some bins at 300,
     every bin at 40) - the two-wait form (DP_KX_ONESHOT=0), the count in a launch of its own instead of inside kidx_offsets (DP_KX_FUSE=0) and
-    fill + sort in one launch (DP_KX_FUSE=2), the dense regime's small bins filled and sorted in LDS with batched reservations (round 6,
-    DP_KX_DENSE=1 forces it on these small inputs; with bins that overflow too) - and, one step on, the pair-offset scan done by kernel_query's last workgroup
-    (DP_QUERY_SCAN=1).  All read per call, so a variant set here is the variant that runs.  Same PAF, same ignore flags as the oracle: dense seeds (k = 10, hundreds
+    the dense regime's small bins filled and sorted in LDS with batched reservations (round 6, DP_KX_DENSE=1 forces it on these small
+    inputs; with bins that overflow too).  All read per call, so a variant set here is the variant that runs.  Same PAF, same ignore flags as the oracle: dense seeds (k = 10, hundreds
     of hits per read), sparse seeds (k = 13), reads that get flagged, five slots."""
     monkeypatch.setenv("DP_SCAN_INDEX", "1")
     for kk, vv in env.items():
@@ -250,14 +248,10 @@ def test_kmer_index_counting_step_variants(monkeypatch, env):
     _run_both(7, 100000, 300, 4000, 10, himem=False, max_rounds=3)
 
 
-@pytest.mark.parametrize("env", [{"DP_KINDEX_WIDE": "1"}, {"DP_KB_B1": "9"}, {"DP_KB_MIN_PBITS": "22"}, {"DP_KB_MIN_PBITS": "30"},
-                                 {"DP_KB_STREAMS": "1"}, {"DP_KB_STREAMS": "1", "DP_KB_B1": "8"}, {"DP_KB_STREAMS": "1", "DP_KB_MIN_PBITS": "22"},
-                                 {"DP_KB_STREAMS": "1", "DP_KB_MIN_PBITS": "29"}, {"DP_KB_STREAMS": "1", "DP_KB_MIN_PBITS": "22", "DP_KB_B1": "10"},
-                                 {"DP_KB_STREAMS": "1", "DP_KINDEX_WIDE": "1"}, {"DP_KINDEX_ATOMIC": "1"}])
+@pytest.mark.parametrize("env", [{"DP_KINDEX_WIDE": "1"}, {"DP_TUNE": "kb_b1=9"}, {"DP_KB_MIN_PBITS": "22"}, {"DP_KB_MIN_PBITS": "30"}, {"DP_TUNE": "kindex_atomic=1"}])
 def test_kmer_index_entry_formats(monkeypatch, env):
-    """The resident k-mer position index stores an entry in 4, 5 or 8 bytes; between the build's passes entries travel as 64-bit
-    words or (DP_KB_STREAMS=1) in two streams of 4 + 0 / 1 / 2 / 4 bytes (dp_kbuild.hip): every format (reached on small inputs
-    through DP_KB_MIN_PBITS, which only wastes bits), other widths of the first pass, the all-eight-bytes build and the atomic
+    """The resident k-mer position index stores an entry in 4, 5 or 8 bytes (dp_kbuild.hip): every format (reached on small inputs
+    through DP_KB_MIN_PBITS, which only wastes bits), another width of the first pass, the all-eight-bytes build and the atomic
     scatter build give the oracle's PAF."""
     monkeypatch.setenv("DP_SCAN_INDEX", "1")
     for k_, v_ in env.items():
@@ -398,17 +392,17 @@ def test_round_parallel_protocol_matches_oracle(world, seed, G, N, L, variable):
         assert rs.ignore().sum() > 0
 
 
-@pytest.mark.parametrize("env", [{}, {"DP_DEVICE_CHUNK": "0"}, {"DP_CONS_FLAG_EVERY": "3"}, {"DP_SCAN_INDEX": "1", "DP_CONS_FLAG_EVERY": "2"},
+@pytest.mark.parametrize("env", [{}, {"DP_DEVICE_CHUNK": "0"}, {"DP_TUNE": "cons_flag_every=3"}, {"DP_SCAN_INDEX": "1", "DP_TUNE": "cons_flag_every=2"},
                                  {"DP_SCAN_INDEX": "1"}, {"DP_SCAN_INDEX": "1", "DP_KX_ONESHOT": "0"}, {"DP_SCAN_INDEX": "1", "DPH_PRECHAIN": "0"},
-                                 {"DP_SCAN_INDEX": "1", "DPH_PRECHAIN": "1", "DP_CONS_FLAG_EVERY": "3"}, {"DP_INDEX_FILL_ROWS": "1"}, {"DP_INDEX_FILL_ROWS": "2"},
-                                 {"DP_INDEX_FILL_ROWS": "1", "DP_SCAN_INDEX": "1", "DP_CHAIN_TINY": "1"}])
+                                 {"DP_SCAN_INDEX": "1", "DPH_PRECHAIN": "1", "DP_TUNE": "cons_flag_every=3"}, {"DP_INDEX_FILL_ROWS": "1"},
+                                 {"DP_INDEX_FILL_ROWS": "1", "DP_SCAN_INDEX": "1"}])
 @pytest.mark.parametrize("L,k,e", [(2500, 10, 0.0), (30000, 10, 0.01)])
 def test_overlap_chunks_made_on_the_device(monkeypatch, env, L, k, e):
     """chunkWorker (overlap.go:253-318) runs on the device (dp_index_build_chunked): the survivors' segments stay in the scan
     buffer, the chunks and their {read, length, offset, inset} never visit the host, the consensus takes them from there.
     Short reads go in whole, 30 kb reads at k = 10 are cut into several chunks with the back-up of overlap / 2 and the
     150-seed tail rule.  Variants: host chunking (DP_DEVICE_CHUNK=0), the k-mer index or the scan kernels as producer, and
-    every 2nd / 3rd window handed to the host consensus path (DP_CONS_FLAG_EVERY), which then fetches chunks and segments
+    every 2nd / 3rd window handed to the host consensus path (DP_TUNE=cons_flag_every=n), which then fetches chunks and segments
     after all.  Round 4: the index step in one go (hit records; DP_KX_ONESHOT=0: two waits as before) and the chunk stage
     launched behind the un-waited scan (DPH_PRECHAIN=0 / 1).  Same PAF as the oracle everywhere."""
     for kk, v in env.items():
@@ -470,7 +464,7 @@ def test_scan_shard_rank_failure_before_the_exchange_does_not_hang_its_peers(mon
     readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
     pipes = [OverlapPipeline(readsets[r], k=10, rank=r, world=world, mode="scan-shard", comm="local", slots=slots) for r in range(world)]
     OverlapPipeline.link_local(pipes)
-    monkeypatch.setenv("DPH_FAIL_BEGIN_RANK", "1")
+    monkeypatch.setenv("DP_TUNE", "fail_begin_rank=1")
     errs = [None] * world
 
     def run(r):
@@ -486,7 +480,7 @@ def test_scan_shard_rank_failure_before_the_exchange_does_not_hang_its_peers(mon
     assert not any(t.is_alive() for t in th), "a rank is still waiting for a peer that failed before the exchange"
     assert all(e is not None for e in errs), errs
     assert "injected failure before the exchange" in str(errs[1])
-    monkeypatch.delenv("DPH_FAIL_BEGIN_RANK")
+    monkeypatch.delenv("DP_TUNE")
     for p in pipes:
         p.close()
 
@@ -503,7 +497,7 @@ def test_scan_shard_rank_failure_does_not_hang_its_peers(monkeypatch, slots):
     readsets = [Reads(bases, off, min_len=1000) for _ in range(world)]
     pipes = [OverlapPipeline(readsets[r], k=10, rank=r, world=world, mode="scan-shard", comm="local", slots=slots) for r in range(world)]
     OverlapPipeline.link_local(pipes)
-    monkeypatch.setenv("DP_COMM_FAIL_RANK", "1")
+    monkeypatch.setenv("DP_TUNE", "comm_fail_rank=1")
     errs = [None] * world
 
     def run(r):
@@ -519,7 +513,7 @@ def test_scan_shard_rank_failure_does_not_hang_its_peers(monkeypatch, slots):
     assert not any(t.is_alive() for t in th), "a rank is still waiting for a peer that failed"
     assert all(e is not None for e in errs), errs
     assert "injected failure" in str(errs[1])
-    monkeypatch.delenv("DP_COMM_FAIL_RANK")
+    monkeypatch.delenv("DP_TUNE")
     for p in pipes:
         p.close()
 
@@ -534,7 +528,7 @@ def test_scan_shard_with_executor_slots(monkeypatch, shard_queries):
     that many rounds flag reads; a 1-rank RCCL job with two slots.  Every rank must print the oracle's PAF."""
     import threading
     from downpore_amd.overlap import OverlapPipeline, Reads
-    monkeypatch.setenv("DPH_SHARD_QUERIES", shard_queries)
+    monkeypatch.setenv("DP_TUNE", "no_shard_queries=%d" % (1 if shard_queries == "0" else 0))
     bases, off = O.gen_reads(33, 60000, 700, 1500, 0.0, True)
     rs = O.ReadSet(bases, off, min_len=1000)
     want = O.OverlapRun(rs, k=10, seed_batch_size=1500)
@@ -899,30 +893,10 @@ def test_round_parallel_text_goes_to_the_printing_rank_only():
     p1.close()
 
 
-@pytest.mark.parametrize("gang,slots", [(2, 4), (4, 4), (4, 6), (8, 8)])
-def test_overlap_executor_slots_in_gangs(monkeypatch, gang, slots):
-    """Gangs (dp_gang_create): the slots of a gang begin their rounds together and every per-round kernel is launched once for
-    all of them (blockIdx.y = member).  Whole jobs with 2, 4 and 8 rounds per launch - one with a slot left outside the gangs, one
-    on reads that flag reads (rounds rejected and run again out of step) - must print the oracle's PAF."""
-    from downpore_amd.overlap import OverlapPipeline, Reads
-    monkeypatch.setenv("DPH_GANG", str(gang))
-    for seed, G, N, L, variable, sbs in ((1, 250000, 1000, 5000, False, 10000), (33, 60000, 700, 1500, True, 1500)):
-        bases, off = O.gen_reads(seed, G, N, L, 0.0, variable)
-        rs = O.ReadSet(bases, off, min_len=1000)
-        want = O.OverlapRun(rs, k=10, seed_batch_size=sbs)
-        reads = Reads(bases, off, min_len=1000)
-        pipe = OverlapPipeline(reads, k=10, seed_batch_size=sbs, slots=slots)
-        pipe.run()
-        d = first_diff(pipe.all_paf(), want.paf)
-        assert d is None, (seed, d)
-        assert np.array_equal(reads.ignore(), rs.ignore())
-        pipe.close()
-
-
 @pytest.mark.parametrize("k,G,N,L,variable", [(10, 250000, 1000, 5000, False), (13, 3000000, 6000, 10000, False)])
 def test_consensus_layouts_agree(monkeypatch, k, G, N, L, variable):
     """consensus_full_kernel runs in two LDS layouts (int16 small tier first, the large tier for the windows it lists).  The same
-    jobs with the small tier switched off (DP_CONS_SMALL=0: every window in the large layout, round 2's kernel) must print the
+    jobs with the small tier switched off (DP_CONS_LAYOUTS=nosmall: every window in the large layout, round 2's kernel) must print the
     same PAF as with it - and as the oracle."""
     from downpore_amd.overlap import OverlapPipeline, Reads
     bases, off = O.gen_reads(11, G, N, L, 0.0, variable)
@@ -934,16 +908,13 @@ def test_consensus_layouts_agree(monkeypatch, k, G, N, L, variable):
     # lazy = "0": the large layout launched behind the small one in every round; default: only after the wait, for a round whose small
     # layout listed a window (and at once for the 64 rounds after such a round)
     for small, huge, lazy in (("1", "0", "1"), ("0", "0", "1"), ("1", "1", "1"), ("0", "1", "1"), ("1", "0", "0")):
-        monkeypatch.setenv("DP_CONS_SMALL", small)
-        monkeypatch.setenv("DP_CONS_HUGE", huge)
-        monkeypatch.setenv("DP_CONS_LAZY_LARGE", lazy)
+        monkeypatch.setenv("DP_CONS_LAYOUTS", ",".join((["nosmall"] if small == "0" else []) + ["huge" if huge == "1" else "nohuge"] + (["eager"] if lazy == "0" else [])))
         pipe = OverlapPipeline(Reads(bases, off, min_len=1000), k=k, slots=3)
         pipe.run(4)
         got[(small, huge, lazy)] = pipe.all_paf()
         pipe.close()
         assert first_diff(got[(small, huge, lazy)], want.paf) is None, (small, huge, lazy)
-    monkeypatch.delenv("DP_CONS_HUGE")
-    monkeypatch.delenv("DP_CONS_LAZY_LARGE")
+    monkeypatch.delenv("DP_CONS_LAYOUTS")
 
 
 @pytest.mark.parametrize("k,G,N,L,variable,err", [(10, 250000, 1000, 5000, False, 0.0), (13, 3000000, 6000, 10000, False, 0.0),
@@ -957,17 +928,15 @@ def test_chain_shortcuts_agree(monkeypatch, k, G, N, L, variable, err):
     bases, off = O.gen_reads(17, G, N, L, err, variable)
     rs = O.ReadSet(bases, off, min_len=1000)
     want = O.OverlapRun(rs, k=k, max_rounds=4)
-    # (round 4: tiny = the 3.2 KB chaining layout for stages whose queries have at most 31 seeds, "0" = CSlim for all; prechain = the
-    # chunk stage launched behind the un-waited scan, "0" = after the wait)
-    for perfect, pack, prestage, tiny, prechain in (("1", "0", "1", "1", "1"), ("0", "0", "1", "1", "1"), ("1", "1", "1", "0", "1"),
-                                                    ("1", "0", "0", "1", "0"), ("1", "0", "1", "0", "0")):
+    # (prechain = the chunk stage launched behind the un-waited scan, "0" = after the wait; prestage "0": the query block is uploaded by
+    # dp_find_overlaps itself)
+    for perfect, pack, prestage, prechain in (("1", "0", "1", "1"), ("0", "0", "1", "1"), ("1", "1", "1", "1"), ("1", "0", "0", "0"), ("1", "0", "1", "0")):
         monkeypatch.setenv("DP_CHAIN_PERFECT", perfect)
         monkeypatch.setenv("DP_CHAIN_PACK", pack)
-        monkeypatch.setenv("DP_CHAIN_TINY", tiny)
         monkeypatch.setenv("DPH_PRECHAIN", prechain)
-        monkeypatch.setenv("DP_QUERY_PRESTAGE", prestage)  # 0: the query block is uploaded by dp_find_overlaps itself
+        monkeypatch.setenv("DP_TUNE", "no_query_prestage=%d" % (1 if prestage == "0" else 0))
         pipe = OverlapPipeline(Reads(bases, off, min_len=1000), k=k, slots=3)
         pipe.run(4)
         got = pipe.all_paf()
         pipe.close()
-        assert first_diff(got, want.paf) is None, (perfect, pack, prestage, tiny, prechain)
+        assert first_diff(got, want.paf) is None, (perfect, pack, prestage, prechain)

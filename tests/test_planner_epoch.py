@@ -10,7 +10,7 @@ from tests import oracle_lib as O
 
 
 def test_plan_computed_before_flags_is_discarded():
-    os.environ["DPH_TEST_PLAN_DELAY_US"] = "300000"
+    os.environ["DP_TUNE"] = "plan_delay_us=300000"
     try:
         from downpore_amd.overlap import Reads, load_host
         H = load_host()
@@ -25,7 +25,7 @@ def test_plan_computed_before_flags_is_discarded():
         rc = H.dph_selftest_planner_flags(reads.h, k, 600, values.ctypes.data)
         assert rc == 0, "planner handed out a plan computed before the flags were set (rc %d)" % rc
     finally:
-        del os.environ["DPH_TEST_PLAN_DELAY_US"]
+        del os.environ["DP_TUNE"]
 
 
 def test_touch_test_vector_variants_agree():
