@@ -846,7 +846,7 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
     std::vector<uint32_t> qm((size_t)nw * 4);
     DP_HIP(hipMemcpy(qm.data(), d_qmeta, (size_t)nw * 16, hipMemcpyDeviceToHost));
     for (uint32_t w = 0; w < nw; w++)
-        if (qm[4 * w + 2] & 1) return dp_fail(ctx, DP_ERR_CAPACITY, "window with more than 512 usable seeds");
+        if (qm[4 * w + 2] & 1) return dp_fail(ctx, DP_ERR_CAPACITY, "window with more than 65535 usable seeds");
     const uint32_t nm = cur[0], ni = cur[1];
     if (pin_reserve(ctx, ctx->h_mrec, (size_t)nm * sizeof(MapRec) + 16)) return DP_ERR_HIP;
     if (pin_reserve(ctx, ctx->h_ma, (size_t)ni * 4 + 16)) return DP_ERR_HIP;

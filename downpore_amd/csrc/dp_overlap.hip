@@ -801,6 +801,22 @@ struct QWave {
     uint16_t ev_first8[Q_MAXSETS + 2][8];
     uint32_t n_ev;
 };
+// Round 6: the same lists in global memory, for a query with more usable seeds than QWave holds (Matches() has no limit,
+// seeds/seeds.go:336-347: `-overlap_size 6000 -num_seeds 60`, `map -query_size 8000 -seed_rate 10` are ~900 sets a query).  The BIG
+// variants of the kernel run behind the ordinary ones, only when a query of the batch has more than Q_MAXSETS seeds at all, and only
+// for the queries the ordinary ones flagged; a query's slice holds `stride` sets (the batch's longest query).  Ids travel in 16 bits
+// (ev_first8): 65 535 sets per query.
+struct QBig {
+    uint32_t* setid;
+    uint32_t* lens;
+    uint32_t* tmp_id;
+    uint32_t* tmp_len;
+    uint32_t* ev_word;
+    uint16_t (*ev_first8)[8];
+    uint32_t n_ev;
+};
+#define Q_BIG_WORDS_PER_SET 9u  // 4 + 4 + 4 + 4 + 4 + 16 bytes per set of a slice, as 4-byte words
+#define Q_BIG_MAXSETS 65535u
 
 // One word of the soft union for the 4- / 8-ladder regimes: the ladder of util/asm_amd64.s:121-314 over this lane's word of
 // every live posting set, D levels deep.  Per posting word and level the reference does v_j |= v_{j-1} & m: one v_and_or_b32 per
@@ -814,8 +830,8 @@ __device__ __forceinline__ uint32_t q_and_or(uint32_t a, uint32_t b, uint32_t c)
 #ifndef Q_INFLIGHT
 #define Q_INFLIGHT 8  // posting words a lane has in flight (16 measured the same: 49.2 against 48.7 us)
 #endif
-template <int D>
-__device__ __forceinline__ u64 q_ladder(const QWave& S, const u64* __restrict__ posting, uint32_t W, uint32_t iw, uint32_t n, u64& gathered) {
+template <int D, class ST>
+__device__ __forceinline__ u64 q_ladder(const ST& S, const u64* __restrict__ posting, uint32_t W, uint32_t iw, uint32_t n, u64& gathered) {
     uint32_t lo[D], hi[D];
 #pragma unroll
     for (int x = 0; x < D; x++) lo[x] = hi[x] = 0;
@@ -884,18 +900,21 @@ __device__ __forceinline__ u64 q_ladder(const QWave& S, const u64* __restrict__ 
 // (minCount >= 13: queries of fifty seeds and more), whose 17-level ladder and bit-sliced counter need twice the registers.  The
 // light kernel alone then runs at eight waves per SIMD instead of four; the heavy one is launched only when a query of the batch
 // can reach minCount 13 at all.
-template <bool HEAVY>
+template <bool HEAVY, bool BIG = false>
 struct query_kernel {
     enum { THREADS = 64 * Q_WAVES };
+    typedef typename std::conditional<BIG, QBig, QWave>::type ST;
     static __device__ void run(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff, uint32_t nq, const u64* __restrict__ posting,
                                const uint32_t* __restrict__ pmeta, uint32_t n_seqs, uint32_t W, const int32_t* __restrict__ mc, uint32_t mc_n,
                                u64* __restrict__ cand, uint32_t* __restrict__ qmeta, u64* __restrict__ words_read, uint32_t* __restrict__ qcnt,
                                uint32_t word_base, const uint32_t* __restrict__ n_seqs_dev, u64* __restrict__ qsets, uint32_t SW,
-                               uint32_t dbg_flags, uint32_t split, u64* __restrict__ own_zero) {
+                               uint32_t dbg_flags, uint32_t split, u64* __restrict__ own_zero, uint32_t* __restrict__ big_ws,
+                               uint32_t big_stride) {
         // (the pair-offset scan as the last act of this launch's last workgroup - round 5's DP_QUERY_SCAN - cost a release fence per
         // workgroup, more than the launch it saved: profiles/r05/ab12_query_scan.txt; removed in round 6)
         if (blockIdx.x < nq * split)
-            body(qsegs, qoff, nq, posting, pmeta, n_seqs, W, mc, mc_n, cand, qmeta, words_read, qcnt, word_base, n_seqs_dev, qsets, SW, dbg_flags, split, own_zero);
+            body(qsegs, qoff, nq, posting, pmeta, n_seqs, W, mc, mc_n, cand, qmeta, words_read, qcnt, word_base, n_seqs_dev, qsets, SW, dbg_flags, split, own_zero,
+                 big_ws, big_stride);
     }
     static __device__ void body(const int32_t* __restrict__ qsegs, const u64* __restrict__ qoff,
                                                              uint32_t nq, const u64* __restrict__ posting,
@@ -905,12 +924,12 @@ struct query_kernel {
                                                              u64* __restrict__ words_read, uint32_t* __restrict__ qcnt,
                                                              uint32_t word_base, const uint32_t* __restrict__ n_seqs_dev,
                                                              u64* __restrict__ qsets, uint32_t SW, uint32_t dbg_flags, uint32_t split,
-                                                             u64* __restrict__ own_zero) {
+                                                             u64* __restrict__ own_zero, uint32_t* __restrict__ big_ws, uint32_t big_stride) {
     if (n_seqs_dev) n_seqs = *n_seqs_dev;  // (chunks made on the device: the host only knows an upper bound)
     // word_base: a shard of a larger index (dp_index_set_global) holds the words [word_base, word_base + W) of every set; pmeta
     // and n_seqs then describe the WHOLE sets (global windows, counts), so the filter, the early-return cut and the gather
     // order are those of the unsharded query, and this launch fills in the candidate words of its own range.
-    __shared__ QWave S;
+    __shared__ ST S;
     __shared__ uint32_t sh_u[8];
     __shared__ int64_t sh_ilast;
     __shared__ unsigned long long sh_gathered;
@@ -921,10 +940,22 @@ struct query_kernel {
     // kernel is not held back by the 668 workgroups' fit on 256 CUs, so one workgroup per query stays the default
     const uint32_t q = blockIdx.x / split, part = blockIdx.x % split;
     if (q >= nq) return;
+    const uint32_t set_cap = BIG ? big_stride : (uint32_t)Q_MAXSETS;
     if (threadIdx.x == 0) {
         sh_gathered = 0;
         sh_u[5] = 0;
+        if constexpr (BIG) {  // the query's slice of the workspace: five 4-byte arrays of big_stride + 2 entries, then the 16-byte ones
+            uint32_t* base = big_ws + (size_t)blockIdx.x * ((size_t)big_stride + 2) * Q_BIG_WORDS_PER_SET;
+            S.setid = base;
+            S.lens = base + (big_stride + 2);
+            S.tmp_id = base + 2 * (size_t)(big_stride + 2);
+            S.tmp_len = base + 3 * (size_t)(big_stride + 2);
+            S.ev_word = base + 4 * (size_t)(big_stride + 2);
+            S.ev_first8 = (uint16_t(*)[8])(base + 5 * (size_t)(big_stride + 2));
+            S.n_ev = 0;
+        }
     }
+    if constexpr (BIG) __syncthreads();
     // own_zero (light variant, one workgroup per query): the query's rows - candidate words, seed bitset, the per-query words - are
     // cleared here, by the workgroup that owns them, instead of by a launch over all of them before this one; own_zero itself is
     // the chaining stage's cursor block (C_CURSOR_BYTES), cleared by query 0
@@ -973,15 +1004,15 @@ struct query_kernel {
             const bool acc = f && seed != prevPassing;
             const u64 amask = __ballot(acc);
             const uint32_t pos = n + (uint32_t)__popcll(amask & lanesBelow);
-            if (acc && pos < Q_MAXSETS) {
+            if (acc && pos < set_cap) {
                 S.setid[pos] = (uint32_t)seed;
                 S.lens[pos] = pm.w;
                 start = min(start, pm.y);
                 end = max(end, pm.z);
             }
             const uint32_t cnt = (uint32_t)__popcll(amask);
-            if (n + cnt > Q_MAXSETS) status |= 1;
-            n = min((uint32_t)Q_MAXSETS, n + cnt);
+            if (n + cnt > set_cap) status |= 1;  // (ordinary variants: the BIG ones take this query; BIG: more than 65 535 sets)
+            n = min(set_cap, n + cnt);
             if (fmask) carrySeed = __shfl(seed, 63 - __builtin_clzll(fmask), 64);
         }
 #pragma unroll
@@ -993,7 +1024,11 @@ struct query_kernel {
     }
     int minCount = 0;
     if (n >= 5 && n < mc_n) minCount = mc[n];
-    if (!HEAVY && lane == 0 && part == 0) {
+    if constexpr (BIG) {
+        if (n <= (uint32_t)Q_MAXSETS) status |= 4u;  // (the ordinary variants' query: nothing to do here)
+        __threadfence();                             // (the lists are global memory: the other waves read them behind the barrier)
+    }
+    if (!HEAVY && lane == 0 && part == 0 && !(BIG && (status & 4u))) {
         qmeta[4 * q + 0] = n;
         qmeta[4 * q + 1] = (uint32_t)minCount;
         qmeta[4 * q + 2] = status | (n >= mc_n ? 2u : 0u);
@@ -1127,13 +1162,15 @@ struct query_kernel {
             u64 L[17];
 #pragma unroll
             for (int x = 0; x < 17; x++) L[x] = 0;
-            u64 inFirst8[Q_MAXSETS / 64];
+            u64 inFirst8[BIG ? 1 : Q_MAXSETS / 64];  // (BIG: the eight ids themselves are compared below)
+            uint32_t f8[8];
 #pragma unroll
-            for (int x = 0; x < Q_MAXSETS / 64; x++) inFirst8[x] = 0;
+            for (int x = 0; x < (BIG ? 1 : Q_MAXSETS / 64); x++) inFirst8[x] = 0;
 #pragma unroll
             for (int p = 0; p < 8; p++) {
                 uint32_t j = S.ev_first8[t][p];
-                inFirst8[j >> 6] |= 1ull << (j & 63);
+                f8[p] = j;
+                if constexpr (!BIG) inFirst8[j >> 6] |= 1ull << (j & 63);
                 u64 m = posting[(uint64_t)S.setid[j] * W + iw];
                 gathered++;
 #pragma unroll
@@ -1143,14 +1180,18 @@ struct query_kernel {
             // (a count over at most Q_MAXSETS = 512 live sets needs ten bits: with eight - until round 5 - a sequence that holds more than
             // 255 of a long query's seeds, i.e. its best candidates, wrapped around and was dropped; found by the flag matrix with
             // overlap_size 2000, num_seeds 30, min_hits 0.4: 315 sets, minCount 126)
-            enum { Q_PLANES = 10 };
-            static_assert((1 << Q_PLANES) > Q_MAXSETS, "the exact count of addSoftUnionIDs must hold Q_MAXSETS");
+            enum { Q_PLANES = BIG ? 16 : 10 };
+            static_assert((1 << Q_PLANES) > (BIG ? (int)Q_BIG_MAXSETS : Q_MAXSETS), "the exact count of addSoftUnionIDs must hold the set list");
             u64 planes[Q_PLANES];
 #pragma unroll
             for (int x = 0; x < Q_PLANES; x++) planes[x] = 0;
             for (uint32_t j = 0; j < n; j++) {
                 if (S.lens[j] <= iw) continue;
-                if ((inFirst8[j >> 6] >> (j & 63)) & 1) continue;
+                if constexpr (BIG) {
+                    if (j == f8[0] || j == f8[1] || j == f8[2] || j == f8[3] || j == f8[4] || j == f8[5] || j == f8[6] || j == f8[7]) continue;
+                } else {
+                    if ((inFirst8[j >> 6] >> (j & 63)) & 1) continue;
+                }
                 u64 m = posting[(uint64_t)S.setid[j] * W + iw];
                 gathered++;
 #pragma unroll
@@ -3015,14 +3056,31 @@ int dp_query_stage(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_off, ui
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
                        ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
-                       query_dbg_flags(), q_split, own_rows ? (u64*)ctx->d_cursor.p : (u64*)nullptr);
+                       query_dbg_flags(), q_split, own_rows ? (u64*)ctx->d_cursor.p : (u64*)nullptr, (uint32_t*)nullptr, 0u);
     // the 16-ladder / exact-count regimes start at minCount 13: only a batch with a query of that many seeds needs the heavy variant
     if (mcLast >= 13) dp_launch<query_kernel<true>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
                        ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
                        (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
                        (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
                        ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)ctx->d_qsets.p, SW,
-                       query_dbg_flags(), q_split, (u64*)nullptr);
+                       query_dbg_flags(), q_split, (u64*)nullptr, (uint32_t*)nullptr, 0u);
+    if (maxSeeds > Q_MAXSETS) {
+        // a query may hold more sets than the kernel's LDS lists (round 6): the BIG variants, lists in global memory, for those queries
+        const uint32_t stride = std::min<uint32_t>(maxSeeds, Q_BIG_MAXSETS);
+        if (dev_reserve(ctx, ctx->d_qbig, (size_t)nq * q_split * ((size_t)stride + 2) * Q_BIG_WORDS_PER_SET * 4 + 64)) return DP_ERR_HIP;
+        dp_launch<query_kernel<false, true>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
+                       ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
+                       (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
+                       (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
+                       ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)nullptr, SW,
+                       query_dbg_flags(), q_split, (u64*)nullptr, (uint32_t*)ctx->d_qbig.p, stride);
+        if (mcLast >= 13) dp_launch<query_kernel<true, true>>(ctx, dim3(nq * q_split), dim3(64 * Q_WAVES),
+                       ctx->qsegs_dev, ctx->qoff_dev, nq, (const u64*)ctx->d_posting.p,
+                       (const uint32_t*)ctx->d_pmeta.p, ctx->global_n_seqs ? ctx->global_n_seqs : M, W, (const int32_t*)d_mc, mc_n,
+                       (u64*)ctx->d_cand.p, d_qmeta, d_words, d_qcnt, ctx->word_base,
+                       ctx->chunks_on_device ? (const uint32_t*)ctx->d_nseqs.p : (const uint32_t*)nullptr, (u64*)nullptr, SW,
+                       query_dbg_flags(), q_split, (u64*)nullptr, (uint32_t*)ctx->d_qbig.p, stride);
+    }
     DP_HIP(hipGetLastError());
     DP_HIP(dp_mark(ctx, 5));
 
@@ -3279,7 +3337,7 @@ static int chain_finish(dp_ctx* ctx, FindState& st) {
         const uint32_t* qm = (const uint32_t*)ctx->h_qm.p;
         const u64* words = (const u64*)((const uint8_t*)ctx->h_qm.p + (size_t)st.nq * 16);
         for (uint32_t q = 0; q < st.nq; q++) {
-            if (qm[4 * q + 2] & 1) return dp_fail(ctx, DP_ERR_CAPACITY, "query with more than 512 usable seeds");
+            if (qm[4 * q + 2] & 1) return dp_fail(ctx, DP_ERR_CAPACITY, "query with more than 65535 usable seeds");
             st.query_bytes += words[q] * 8;
         }
     }

@@ -598,7 +598,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
                      &ctx->d_seedsets, &ctx->d_pmeta, &ctx->d_qsegs, &ctx->d_qoff, &ctx->d_qsets, &ctx->d_qmeta,
                      &ctx->d_cand, &ctx->d_pool, &ctx->d_mrec, &ctx->d_ma, &ctx->d_mb, &ctx->d_cursor, &ctx->d_sched, &ctx->d_ignore, &ctx->d_surv, &ctx->d_values, &ctx->d_selwin, &ctx->d_seltop, &ctx->d_cin, &ctx->d_cout,
                      &ctx->d_kx_sz, &ctx->d_kx_lo, &ctx->d_kx_tmp, &ctx->d_kx_keys, &ctx->d_kx_vals, &ctx->d_manchor, &ctx->d_seeds_applied,
-                     &ctx->d_pbase, &ctx->d_pspec, &ctx->d_clist, &ctx->d_sa, &ctx->d_sb, &ctx->d_qual, &ctx->d_qualoff, &ctx->d_hasq, &ctx->d_cretry,
+                     &ctx->d_pbase, &ctx->d_qbig, &ctx->d_pspec, &ctx->d_clist, &ctx->d_sa, &ctx->d_sb, &ctx->d_qual, &ctx->d_qualoff, &ctx->d_hasq, &ctx->d_cretry,
                      &ctx->d_chunk_meta, &ctx->d_nseqs};
     // one wait for everything this context's blocks could still be used by (its own stream is idle since dp_stream_sync above; a
     // gang's launches and a borrower's copies run on other streams of the device), then its blocks are parked without further waits

@@ -9,7 +9,8 @@ same reads.  What the values move inside the kernels:
   overlap_size 500              short windows, more queries per round
   chunk_size 5000 / 20000       chunk_kernel's piece length and overlap back-off (overlap.go:263-314)
   query_batch_size 50           the seed budget is never reached, a round ends by query count (overlap.go:57-60)
-A value beyond a kernel's capacity must come back as DP_ERR_CAPACITY, never as a wrong PAF (the last tests)."""
+A value beyond a kernel's capacity must come back as DP_ERR_CAPACITY, never as a wrong PAF (the last test); query windows of more than
+512 usable seeds - a capacity until round 5 - are a parity case since round 6."""
 import ctypes as C
 
 import numpy as np
@@ -157,20 +158,24 @@ def test_map_flag(k, kw):
 
 
 # ------------------------------------------------------------------------------------------- values beyond a kernel's capacity
-def test_overlap_size_beyond_the_query_kernel_fails_loudly():
-    """query_kernel holds at most 512 posting sets per query in LDS (Q_MAXSETS, dp_overlap.hip): a 6 000-base window over a genome
-    the round's seeds cover three times has ~900 usable seeds.  The reference has no such limit (allSeedSets grows, seeds.go:336-347)
-    - so this is a capacity of the device path, and it must be reported as DP_ERR_CAPACITY, never as a shorter PAF."""
-    from downpore_amd.hip import DpError
-    from downpore_amd.overlap import OverlapPipeline, Reads
+def test_overlap_size_beyond_the_query_kernels_lds_lists():
+    """query_kernel holds 512 posting sets per query in LDS (Q_MAXSETS, dp_overlap.hip); the reference has no such limit (allSeedSets
+    grows, seeds/seeds.go:336-347).  A 6 000-base window over a genome the round's seeds cover three times has ~900 usable seeds: until
+    round 5 that came back as DP_ERR_CAPACITY, since round 6 the BIG variants of the kernel keep such a query's lists in global memory -
+    `-overlap_size 6000 -num_seeds 60` must print the oracle's PAF, round by round, with one slot and with five."""
     seed, G, N, L, e, var, _ = INPUTS[10]
     bases, off = O.gen_reads(seed, G, N, 14000, e, False)
-    reads = Reads(bases, off, min_len=6000)
-    pipe = OverlapPipeline(reads, k=10, slots=1, overlap_size=6000, num_seeds=60)
-    with pytest.raises(DpError, match="more than 512 usable seeds"):
-        while pipe.step():
-            pass
-    pipe.close()
+    kw = dict(overlap_size=6000, num_seeds=60)
+    rs = O.ReadSet(bases, off, min_len=6000)
+    orun = O.OverlapRun(rs, k=10, max_rounds=4 + 8, traces=True, **kw)
+    assert orun.rounds >= 1
+    n_seeds_in_queries = max(len(orun.trace(r, "querySegments")) for r in range(min(orun.rounds, 4)))
+    assert n_seeds_in_queries > 0
+    lines = 0
+    for slots in (1, 5):
+        rounds, st = _product_vs(orun, bases, off, rs, 10, slots, 4, kw)
+        lines = sum(orun.trace_paf(r).count("\n") for r in range(rounds))
+    assert lines > 0
 
 
 def test_map_query_size_beyond_the_map_kernel_fails_loudly():

@@ -484,7 +484,7 @@ def test_matches_all_ladder_regimes_vs_oracle(ctx, seed):
         assert out["cand"].tolist() == [int(x) for x in want], (seed, hf, min_count)
 
 
-@pytest.mark.parametrize("S", [300, 511])
+@pytest.mark.parametrize("S", [300, 511, 513, 900])
 def test_matches_exact_count_regime_with_long_queries(ctx, S):
     """GetSharedIDs with minCount > 24 validates every bit of the 16-ladder's union by counting the sets that hold it
     (addSoftUnionIDs, util/bitset.go:509-538).  A query of 300 - 511 usable seeds (`overlap` with -overlap_size 2000 -num_seeds 30 on
@@ -499,7 +499,9 @@ def test_matches_exact_count_regime_with_long_queries(ctx, S):
     assert max(sum(member[s][i] for s in range(S)) for i in range(M)) > 255
     sets = _index_from_sets(ctx, k, member)
     qs, qo = _all_seed_query(S)
-    for hf in (0.09, 0.4, 0.8, 0.86, 0.99):
+    # (S > 512: more sets than query_kernel's LDS lists hold - the BIG variants, lists in global memory; small fractions take their
+    # 4- / 8-ladder, 0.012 * 900 = 11 the 8-ladder's saturation, 0.016 * 900 = 14 the 16-ladder with its step-8 omission)
+    for hf in (0.005, 0.012, 0.016, 0.09, 0.4, 0.8, 0.86, 0.99):
         min_count = int(hf * S + 0.5)
         out = ctx.find_overlaps(qs, qo, hf, k, 2 * S + 8, want_candidates=True)
         want = [int(x) for x in O.shared_ids(sets, min_count, True)]
