@@ -158,6 +158,7 @@ struct dp_ctx {
     uint32_t q_pre_nq = 0;
     double q_pre_hf = 0;
     bool q_pre_fetched = false;                    // ... and a launch has brought it to d_qsegs
+    uint32_t max_seq_seeds = 0;                    // longest indexed sequence of the last dp_index_build (the map kernel's BIG variant sizes its slices by it)
     DevBuf d_qbig;                                 // set lists of the queries that hold more posting sets than query_kernel's LDS (QBig)
     uint64_t last_sints = 0;                       // scratch ints of the last chaining stage (all pairs' columns)
     bool chains_packed = true;                     // false: the final chains sit in the scratch columns (d_sa/d_sb), see ChainArgs.pack

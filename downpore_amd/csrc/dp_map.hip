@@ -34,7 +34,29 @@ struct MWave {
     int32_t headChain[M_QMAX];  // chain slot recorded for each reduced query seed (-1 none)
     uint16_t headLen[M_QMAX];   // its length at that seed (the Go slice header's len)
     int32_t good[M_GOOD];
+    __device__ __forceinline__ int qmax() const { return M_QMAX; }
+    __device__ __forceinline__ int tmax() const { return M_TMAX; }
 };
+// Round 6: the same working set in global memory, for a batch in which a reduced window or a reduced chunk is larger than MWave's
+// arrays (`map -query_size 8000 -seed_rate 10`: ~800 seeds a window; SeedSequence.Match has no such limit, seeds/sequence.go:361-394):
+// the kernel's BIG variant, run again over the batch when the ordinary one reports the capacity (a wave's slice is sized from the
+// batch's longest window and the index's longest chunk).
+struct MBig {
+    int32_t* q;
+    int32_t* t;
+    uint16_t* qIdx;
+    uint16_t* tIdx;
+    int32_t* headChain;
+    uint16_t* headLen;
+    int32_t good[M_GOOD];
+    int qcap, tcap;
+    __device__ __forceinline__ int qmax() const { return qcap; }
+    __device__ __forceinline__ int tmax() const { return tcap; }
+};
+// 4-byte words of a wave's slice of the BIG workspace
+static __host__ __device__ inline size_t m_big_words(size_t qcap, size_t tcap) {
+    return (2 * qcap + 2) + (2 * tcap + 2) + (qcap + 2) / 2 + (tcap + 2) / 2 + (qcap + 2) + (qcap + 2) / 2 + 8;
+}
 
 __device__ __forceinline__ bool m_contains(const u64* __restrict__ set, int32_t x) { return (set[x >> 6] >> (x & 63)) & 1ull; }
 
@@ -143,14 +165,16 @@ __device__ int m_reduce_wave(const int32_t* __restrict__ seg, int n, const u64* 
 }
 
 struct MChainPool {
-    uint16_t* a;  // [M_CHAINS][M_QMAX]
+    uint16_t* a;  // [M_CHAINS][stride]: stride = the reduced query's capacity (M_QMAX, or the BIG variant's)
     uint16_t* b;
-    __device__ __forceinline__ uint16_t* A(int c) const { return a + (size_t)c * M_QMAX; }
-    __device__ __forceinline__ uint16_t* B(int c) const { return b + (size_t)c * M_QMAX; }
+    uint32_t stride;
+    __device__ __forceinline__ uint16_t* A(int c) const { return a + (size_t)c * stride; }
+    __device__ __forceinline__ uint16_t* B(int c) const { return b + (size_t)c * stride; }
 };
 
 // extendChain (seeds/sequence.go:476-576); a = reduced query, b = reduced target.  Returns the chain's final length.
-__device__ int m_extend(MWave& L, int an, int bn, int aIndex, int bIndex, int k, int cur, int curLen, const MChainPool& P) {
+template <class LT>
+__device__ int m_extend(LT& L, int an, int bn, int aIndex, int bIndex, int k, int cur, int curLen, const MChainPool& P) {
     const int32_t* as = L.q;
     const int32_t* bs = L.t;
     uint16_t* ca = P.A(cur);
@@ -221,7 +245,8 @@ __device__ int m_extend(MWave& L, int an, int bn, int aIndex, int bIndex, int k,
 // dynamicMatch (seeds/sequence.go:401-471).  seq = reduced target (L.t, sn ints), query = reduced query (L.q, qn ints).
 // Fills L.good with chain slots (in the reference's allGoodChains order) and their lengths in goodLen; returns count.
 // err bit 2: chain pool exhausted, bit 4: good list overflow.
-__device__ int m_dynamic_match(MWave& L, int qn, int sn, int minMatch, int k, const MChainPool& P, uint16_t* chainLen,
+template <class LT>
+__device__ int m_dynamic_match(LT& L, int qn, int sn, int minMatch, int k, const MChainPool& P, uint16_t* chainLen,
                                uint32_t* err) {
     if (minMatch == 0) minMatch = 1;
     const int nq = qn / 2;
@@ -284,7 +309,8 @@ __device__ int m_dynamic_match(MWave& L, int qn, int sn, int minMatch, int k, co
 // the hits in ascending order exactly as the one-lane loop does - the head-chain test at the moment of the hit, extendChain, the
 // 2 len / 3 ratchet (which also shortens both loops' bounds), the "fewer open query seeds than this chain is long" exit.  What
 // lane 0 decides (chain count, good count, minMatch, stop) is broadcast after every hit, so every lane runs the same loops.
-__device__ int m_dynamic_match_wave(MWave& L, int qn, int sn, int minMatch, int k, const MChainPool& P, uint16_t* chainLen,
+template <class LT>
+__device__ int m_dynamic_match_wave(LT& L, int qn, int sn, int minMatch, int k, const MChainPool& P, uint16_t* chainLen,
                                     uint32_t* err) {
     const int lane = dp_lane();
     if (minMatch == 0) minMatch = 1;
@@ -391,6 +417,7 @@ __device__ __forceinline__ uint32_t m_ld16_agent(const uint16_t* p) {
 }
 
 // cursor: [0] records, [1] ints, [2] error bits, [3] overflow flag, [8..9] algorithmic bytes
+template <bool BIG>
 __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __restrict__ wsegs, const u64* __restrict__ woff,
                                                            const uint32_t* __restrict__ wlen, uint32_t n_pairs,
                                                            const u64* __restrict__ wsets, const uint32_t* __restrict__ qmeta,
@@ -401,17 +428,36 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                                                            MapRec* __restrict__ recs, uint32_t rec_cap, int32_t* __restrict__ ma,
                                                            int32_t* __restrict__ mb, uint32_t int_cap, uint32_t* __restrict__ cursor,
                                                            int phase, int32_t* __restrict__ thr_io, int one_lane,
-                                                           const u64* __restrict__ words_read, unsigned long long* __restrict__ prof) {
+                                                           const u64* __restrict__ words_read, unsigned long long* __restrict__ prof,
+                                                           uint32_t* __restrict__ big_ws, uint32_t big_q, uint32_t big_t) {
     // phase 2: both strands of every window pair, thresholds from the windows themselves (the whole index is here).
     // phase 0 / 1 (the index is one shard of the reference, dp_map_windows_shard): only the forward / only the reverse-complement
     // windows, starting from the thresholds the previous shard left in thr_io[pair][2] (< 0: none yet) and leaving its own there.
-    __shared__ MWave sh[M_WAVES];
-    MWave& L = sh[threadIdx.x >> 6];
+    typedef typename std::conditional<BIG, MBig, MWave>::type LT;
+    __shared__ LT sh[M_WAVES];
+    LT& L = sh[threadIdx.x >> 6];
     const int lane = dp_lane();
     const uint32_t gw = blockIdx.x * M_WAVES + (threadIdx.x >> 6);
+    const uint32_t pstride = BIG ? big_q : (uint32_t)M_QMAX;
+    if constexpr (BIG) {
+        if (lane == 0) {
+            const size_t qc = big_q, tc = big_t;
+            uint32_t* base = big_ws + (size_t)gw * m_big_words(qc, tc);
+            L.q = (int32_t*)base;
+            L.t = (int32_t*)(base + (2 * qc + 2));
+            L.qIdx = (uint16_t*)(base + (2 * qc + 2) + (2 * tc + 2));
+            L.tIdx = (uint16_t*)(base + (2 * qc + 2) + (2 * tc + 2) + (qc + 2) / 2);
+            L.headChain = (int32_t*)(base + (2 * qc + 2) + (2 * tc + 2) + (qc + 2) / 2 + (tc + 2) / 2);
+            L.headLen = (uint16_t*)(base + (2 * qc + 2) + (2 * tc + 2) + (qc + 2) / 2 + (tc + 2) / 2 + (qc + 2));
+            L.qcap = (int)big_q;
+            L.tcap = (int)big_t;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     MChainPool P;
-    P.a = poolA + (size_t)gw * M_CHAINS * M_QMAX;
-    P.b = poolB + (size_t)gw * M_CHAINS * M_QMAX;
+    P.stride = pstride;
+    P.a = poolA + (size_t)gw * M_CHAINS * pstride;
+    P.b = poolB + (size_t)gw * M_CHAINS * pstride;
     uint16_t* chainLen = poolLen + (size_t)gw * M_CHAINS;
     // algorithmic bytes of this wave's windows: posting words the index query gathered for them, 2 x 8 x SW per
     // prefiltered candidate + 4 per candidate out, 8 per seed of both sides of every pair that is chained, 8 per chain link out
@@ -473,9 +519,9 @@ __global__ __launch_bounds__(64 * M_WAVES) void map_kernel(const int32_t* __rest
                     uint32_t err = 0;
                     // Match (:361-394): s = seq.Reduced(querySet), q = query.Reduced(seqSet) - on all 64 lanes
                     const int minMatch = thr[s];
-                    const int nT = m_reduce_wave<uint16_t>(tSeg, tN, qset, k, minMatch, L.t, L.tIdx, M_TMAX, &err);
+                    const int nT = m_reduce_wave<uint16_t>(tSeg, tN, qset, k, minMatch, L.t, L.tIdx, L.tmax(), &err);
                     MP_TICK(1)  // Reduced() of the target chunk
-                    const int nQ = nT < 0 ? -1 : m_reduce_wave<uint16_t>(qSeg, qN, tset, k, minMatch, L.q, L.qIdx, M_QMAX, &err);
+                    const int nQ = nT < 0 ? -1 : m_reduce_wave<uint16_t>(qSeg, qN, tset, k, minMatch, L.q, L.qIdx, L.qmax(), &err);
                     MP_TICK(2)  // Reduced() of the query window
                     // dynamicMatch: the probes on 64 lanes, the walk's decisions on lane 0 (DP_MAP_ONE_LANE=1: all of it on lane 0 as
                     // before round 4)
@@ -773,11 +819,14 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
     const uint32_t n_pairs = nw / 2;
     const uint32_t blocks = std::min<uint32_t>(256, (n_pairs + M_WAVES - 1) / M_WAVES);
     const size_t waves = (size_t)blocks * M_WAVES;
-    const size_t poolElems = waves * M_CHAINS * M_QMAX;
+    size_t poolElems = waves * M_CHAINS * M_QMAX;
     if (dev_reserve(ctx, ctx->d_pool, poolElems * 2 * 2 + waves * M_CHAINS * 2 + 64)) return DP_ERR_HIP;
     uint16_t* poolA = (uint16_t*)ctx->d_pool.p;
     uint16_t* poolB = poolA + poolElems;
     uint16_t* poolLen = poolB + poolElems;
+    // (round 6) the BIG variant: run again over the batch when the ordinary kernel reports that a reduced window or chunk did not fit
+    bool big = false;
+    uint32_t big_blocks = blocks, big_q = 0, big_t = 0;
     uint32_t rec_cap = std::max<uint32_t>(1u << 16, (uint32_t)(ctx->d_mrec.cap / sizeof(MapRec)));
     uint32_t int_cap = std::max<uint32_t>(1u << 21, (uint32_t)(ctx->d_ma.cap / 4));
     uint32_t cur[16];
@@ -799,12 +848,21 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
         DP_HIP(hipMemsetAsync(ctx->d_cursor.p, 0, 64, ctx->stream));
         if (d_mprof) DP_HIP(hipMemsetAsync(d_mprof, 0, 16 * 8, ctx->stream));
         DP_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
-        hipLaunchKernelGGL(map_kernel, dim3(blocks), dim3(64 * M_WAVES), 0, ctx->stream, ctx->qsegs_dev,
-                           ctx->qoff_dev, (const uint32_t*)ctx->d_sched.p, n_pairs, (const u64*)ctx->d_qsets.p,
-                           (const uint32_t*)d_qmeta, (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p,
-                           (const int32_t*)ctx->d_segs.p, (const u64*)ctx->d_seedsets.p, W, SW, k, poolA, poolB, poolLen,
-                           (MapRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p, int_cap,
-                           (uint32_t*)ctx->d_cursor.p, phase, d_thr, one_lane, (const u64*)d_words, d_mprof);
+        if (!big)
+            hipLaunchKernelGGL(map_kernel<false>, dim3(blocks), dim3(64 * M_WAVES), 0, ctx->stream, ctx->qsegs_dev,
+                               ctx->qoff_dev, (const uint32_t*)ctx->d_sched.p, n_pairs, (const u64*)ctx->d_qsets.p,
+                               (const uint32_t*)d_qmeta, (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p,
+                               (const int32_t*)ctx->d_segs.p, (const u64*)ctx->d_seedsets.p, W, SW, k, poolA, poolB, poolLen,
+                               (MapRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p, int_cap,
+                               (uint32_t*)ctx->d_cursor.p, phase, d_thr, one_lane, (const u64*)d_words, d_mprof, (uint32_t*)nullptr, 0u, 0u);
+        else
+            hipLaunchKernelGGL(map_kernel<true>, dim3(big_blocks), dim3(64 * M_WAVES), 0, ctx->stream, ctx->qsegs_dev,
+                               ctx->qoff_dev, (const uint32_t*)ctx->d_sched.p, n_pairs, (const u64*)ctx->d_qsets.p,
+                               (const uint32_t*)d_qmeta, (const u64*)ctx->d_cand.p, (const dp_seq_ref*)ctx->d_seqrefs.p,
+                               (const int32_t*)ctx->d_segs.p, (const u64*)ctx->d_seedsets.p, W, SW, k, poolA, poolB, poolLen,
+                               (MapRec*)ctx->d_mrec.p, rec_cap, (int32_t*)ctx->d_ma.p, (int32_t*)ctx->d_mb.p, int_cap,
+                               (uint32_t*)ctx->d_cursor.p, phase, d_thr, one_lane, (const u64*)d_words, d_mprof, (uint32_t*)ctx->d_qbig.p,
+                               big_q, big_t);
         DP_HIP(hipGetLastError());
         DP_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
         DP_HIP(hipMemcpyAsync(cur, ctx->d_cursor.p, 64, hipMemcpyDeviceToHost, ctx->stream));
@@ -815,6 +873,25 @@ int dp_map_windows_impl(dp_ctx* ctx, const int32_t* w_segs, const uint64_t* w_of
         if (cur[3] || cur[0] > rec_cap || cur[1] > int_cap) {
             rec_cap = std::max(rec_cap * 2, cur[0] + 1024);
             int_cap = std::max(int_cap * 2, cur[1] + 1024);
+            continue;
+        }
+        if ((cur[2] & 1u) && !big) {
+            // a reduced window or chunk beyond the LDS arrays: the whole batch again with the working set in global memory, sized from the
+            // batch's longest window and the index's longest chunk (16-bit indices: 65 535 seeds)
+            uint64_t mq = 1;
+            for (uint32_t w = 0; w < nw; w++) mq = std::max<uint64_t>(mq, (w_off[w + 1] - w_off[w]) / 2);
+            big_q = (uint32_t)std::min<uint64_t>(65535, mq);
+            big_t = std::min<uint32_t>(65535u, std::max<uint32_t>(1u, ctx->max_seq_seeds));
+            if (big_q <= M_QMAX && big_t <= M_TMAX) break;  // (cannot be: the error stands)
+            big_blocks = std::min<uint32_t>(blocks, 64);
+            const size_t bw = (size_t)big_blocks * M_WAVES;
+            if (dev_reserve(ctx, ctx->d_qbig, bw * m_big_words(big_q, big_t) * 4 + 64)) return DP_ERR_HIP;
+            poolElems = bw * M_CHAINS * big_q;
+            if (dev_reserve(ctx, ctx->d_pool, poolElems * 2 * 2 + bw * M_CHAINS * 2 + 64)) return DP_ERR_HIP;
+            poolA = (uint16_t*)ctx->d_pool.p;
+            poolB = poolA + poolElems;
+            poolLen = poolB + poolElems;
+            big = true;
             continue;
         }
         break;

@@ -180,6 +180,8 @@ int dp_index_build_impl(dp_ctx* ctx, const dp_seq_ref* seqs, uint32_t n_seqs) {
             return dp_fail(ctx, DP_ERR_ARG, "dp_index_build: sequence view outside the scan output");
     const uint32_t S = ctx->n_seeds;
     const uint32_t W = std::max<uint32_t>(1, (n_seqs + 63) / 64), SW = std::max<uint32_t>(1, (S + 63) / 64);
+    ctx->max_seq_seeds = 0;
+    for (uint32_t i = 0; i < n_seqs; i++) ctx->max_seq_seeds = std::max(ctx->max_seq_seeds, seqs[i].n_seeds);
     ctx->n_seqs = n_seqs;
     ctx->W = W;
     ctx->SW = SW;

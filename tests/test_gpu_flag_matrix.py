@@ -178,15 +178,19 @@ def test_overlap_size_beyond_the_query_kernels_lds_lists():
     assert lines > 0
 
 
-def test_map_query_size_beyond_the_map_kernel_fails_loudly():
-    """The same limit on the `map` side (dp_map.hip: "window with more than 512 usable seeds"): -query_size 8000 with a seed every 10
-    bases of the reference is ~800 seeds per window."""
-    from downpore_amd.hip import DpError
+def test_map_query_size_beyond_the_map_kernels_lds_arrays():
+    """`map -query_size 8000 -seed_rate 10`: ~800 seeds per window - more than query_kernel's LDS lists (512 sets) and map_kernel's LDS
+    arrays (256 reduced window seeds) hold.  DP_ERR_CAPACITY until round 5; since round 6 both kernels have a variant with the working
+    set in global memory (query_kernel<.., BIG>, map_kernel<BIG>): the command must print the oracle's PAF and stderr."""
     from downpore_amd.mapping import map_reads
     from downpore_amd.overlap import Reads
     G, N = 300000, 50
     genome = np.frombuffer(O.gen_genome(23, G), dtype=np.uint8)
+    goff = np.array([0, G], dtype=np.int64)
     bases, off = O.gen_reads(23, G, N, 20000, 0.02, False)
-    with pytest.raises(DpError, match="512 usable seeds|capacity"):
-        map_reads(Reads(genome, np.array([0, G], dtype=np.int64), min_len=0, himem=False), Reads(bases, off, min_len=500, himem=False),
-                  circular=True, k=11, query_size=8000, seed_rate=10)
+    kw = dict(circular=True, k=11, query_size=8000, seed_rate=10)
+    want, werr = O.map_run(O.ReadSet(genome, goff, min_len=0, himem=False), O.ReadSet(bases, off, min_len=500, himem=False), **kw)
+    got, gerr, st = map_reads(Reads(genome, goff, min_len=0, himem=False), Reads(bases, off, min_len=500, himem=False), **kw)
+    assert first_diff(got, want) is None
+    assert gerr == werr
+    assert want.count("\n") >= N // 2
