@@ -164,7 +164,7 @@ def main():
             #               shards without touching a round's latency - what scales while a GPU holds the read set;
             #   scan-shard  the reads are partitioned, every rank runs every round on its own range and the round's survivors - its
             #               seed index - are all-gathered over RCCL: the layout for read sets whose index does not fit one GPU.
-            # The headline is the one predicted to scale (round 3.4 x / scan-shard < 2 x at 8 GPUs for config 2) where it
+            # The headline is the one predicted to scale (HISTORY.md 7.3: round 3.4 x / scan-shard < 2 x at 8 GPUs for config 2) where it
             # fits in half of the GPU's memory, the other one runs after it on the same reads and is reported as `alt_mode`.
             if 9 * N * L < hbm // 2:
                 args.mode = "round"

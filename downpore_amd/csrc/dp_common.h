@@ -176,7 +176,7 @@ int dev_reserve(dp_ctx* ctx, DevBuf& b, size_t bytes, bool keep = false);
 int pin_reserve(dp_ctx* ctx, PinBuf& b, size_t bytes);
 // The round's seed list for a kernel that reads every seed once or twice (the k-mer index walk): the device copy if one was
 // made, else the pinned host block read in place over the link - 80 KB per round that then never travel as a copy (as a
-// pageable hipMemcpyAsync they cost the calling thread 80 us per round inside the runtime).
+// pageable hipMemcpyAsync they cost the calling thread 80 us per round inside the runtime, HISTORY.md 5.3).
 static inline const uint32_t* dp_seeds_ptr(const dp_ctx* ctx) {
     return (const uint32_t*)(ctx->seeds_uploaded ? ctx->d_seeds.p : ctx->h_seeds.p);
 }
@@ -213,7 +213,7 @@ struct dp_zero_region {
 int dp_zero_regions(dp_ctx* ctx, const dp_zero_region* r, int n);
 // The same launch also fetches up to two blocks from PINNED host memory into device buffers (8-byte words; both sides need
 // slack up to the next multiple of 8): an upload done by a kernel of the stream itself instead of a copy handed to the
-// runtime - copies, not kernels, are what the runtime makes expensive with several rounds in flight.
+// runtime - copies, not kernels, are what the runtime makes expensive with several rounds in flight (HISTORY.md 5.3).
 struct dp_fetch_region {
     void* dst;        // device
     const void* src;  // pinned host (hipHostMalloc)

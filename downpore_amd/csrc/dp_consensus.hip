@@ -1215,7 +1215,7 @@ struct consensus_full_kernel {
                 while (front < pl && (int)MB[front] < index) front++;
                 int back = pl - 1;
                 while (back >= 0 && (int)MB[back] > bIndex) back--;
-                if (back + 1 > pl || back < front) {  // "Bad back:" diagnostic, suppressed and counted
+                if (back + 1 > pl || back < front) {  // "Bad back:" diagnostic, suppressed and counted (HISTORY.md 2.5)
                     badBack = 1;
                     if (back + 1 < front) back = front - 1;
                 }
@@ -1350,7 +1350,7 @@ int dp_consensus_paf_impl(dp_ctx* ctx, const dp_seq_meta* metas, uint32_t n_seqs
     const size_t b_paf = (size_t)np * sizeof(dp_paf_rec), b_ign = (size_t)np * 4, b_gm = ((size_t)ng * sizeof(dp_group_meta) + 15) & ~(size_t)15;
     // The kernel's output - group records, PAF records, ignore ids: written once, read by nobody on the device - goes straight
     // into the pinned host block (the kernel's stores cross the link; the wait below is the stream's), and the chunk count of
-    // dp_index_build_chunked rides along: two copies per round that never were submitted (a copy costs more
+    // dp_index_build_chunked rides along: two copies per round that never were submitted (HISTORY.md 5.3: a copy costs more
     // than its bytes)
     if (pin_reserve(ctx, ctx->h_cout, b_paf + b_ign + b_gm + 96)) return DP_ERR_HIP;
     uint8_t* dout = (uint8_t*)ctx->h_cout.p;

@@ -520,7 +520,7 @@ template <bool FILL>
 struct kidx_walk {
     enum { THREADS = 256 };
     // (round 4: a launch may be narrower than its work - `n_waves` wave-sized pieces, walked with the grid's stride: the count
-    // walk's 160 k lanes of dependent random loads and atomics are what slows every other round's kernels)
+    // walk's 160 k lanes of dependent random loads and atomics are what slows every other round's kernels, HISTORY.md 5.7)
     static __device__ void run(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off,
                                const KxPos pos, const dp_scan_item* __restrict__ items, uint32_t lo, uint32_t hi,
                                uint32_t n_read_items, const uint32_t* __restrict__ head, const uint32_t* __restrict__ next,

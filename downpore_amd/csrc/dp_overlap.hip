@@ -45,7 +45,7 @@ struct index_fill_kernel {
 };
 
 // ---- round 4: the two bit matrices without atomics (sparse regime) ----------------------------------------------------------
-// A scattered device-scope atomic costs a five-slot job what it costs alone and index_fill_kernel issued two per
+// A scattered device-scope atomic costs a five-slot job what it costs alone (HISTORY.md 5.7) and index_fill_kernel issued two per
 // indexed seed - 400 k per config-2 round - into matrices that 15 MB of stores had just cleared.  A chunk's seed-set row belongs
 // to ONE wave: it is built in LDS (ds_or) and stored whole - rows need no clearing, rows beyond the chunk count are never read.
 // The posting matrix is the bit transpose of the seed sets: posting[s][w] bit b = seedsets[64 w + b][s / 64] bit (s % 64).

@@ -269,7 +269,7 @@ func (o *Overlap) StepSharded() (int, error) {
 //
 // Every rank holds the reads and the k-mer position index; rank r plans and runs the rounds r, r + world, ...; a superstep
 // all-gathers the ranks' finished rounds over RCCL inside the library and commits them in round order on every rank (a round
-// whose speculation on the ignore flags failed is rejected by all ranks alike and runs again).  DESIGN.md 7.2.
+// whose speculation on the ignore flags failed is rejected by all ranks alike and runs again).  HISTORY.md 7.2.
 
 // InitComm joins this rank to ONE communicator (id = the 128 bytes of CommUniqueID, the same on every rank): the result
 // exchange of Superstep runs on it.  Call before Init.

@@ -73,7 +73,7 @@ def test_overlap_full_run_config1_k10(slots):
 def test_config1_at_its_stated_k13():
     """BASELINE config 1 as BASELINE.json states it: 1 000 reads x 5 kb, k = 13.  At this size the value table's top-"2 %" cut
     (commands/overlap.go:73-93) removes every k-mer that occurs at all, so no window finds a seed: the reference's command runs one
-    round and prints nothing (note 7).  The product must do exactly that - same round count, empty PAF, no read flagged -
+    round and prints nothing (HISTORY.md 2, note 7).  The product must do exactly that - same round count, empty PAF, no read flagged -
     not merely at the command's default k = 10 where the other config-1 tests run."""
     orun, st = _run_both(1, 250000, 1000, 5000, 13, slots=1)
     assert orun.paf == "" and orun.rounds <= 1

@@ -1,7 +1,7 @@
 """An independent look at the PAF: the synthetic generator knows where every read came from (genome position, strand), so an
 overlap line can be held to the genome itself instead of to another implementation of the reference.  For error-free reads every
 line must join two reads that really overlap, on the right relative strand, and - except where the reference's own trimming
-arithmetic drifts - both parts must cover the same stretch of the genome to within a few bases.  The CPU test
+arithmetic drifts (HISTORY.md 2, item 9) - both parts must cover the same stretch of the genome to within a few bases.  The CPU test
 looks at the oracle's PAF, the GPU test at the product's."""
 import numpy as np
 import pytest

@@ -57,7 +57,7 @@ def test_touch_test_vector_variants_agree():
 
 
 def test_planner_lanes_compute_the_chain_of_one_lane():
-    """Planner lanes (DESIGN.md 5.1) start plans from guesses of where their predecessors end.  The whole plan chain of a read set
+    """Planner lanes (DESIGN.md 5) start plans from guesses of where their predecessors end.  The whole plan chain of a read set
     - windows, seed lists, firstSequence of every round - must come out the same from the general PrepareQueries path, from the
     window-cache path with one lane and from the window-cache path with several lanes, with reads flagged along the way.  The
     window cache's producer selects on the host here (no GPU).  k = 8 with a large seed budget: a sixth of all k-mers are seeds,

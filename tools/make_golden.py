@@ -21,7 +21,7 @@ CASES = {
     # name: (seed, genome, reads, read_len, error, variable_length, k, max_rounds, extra OverlapRun kwargs)
     "tiny_k10": (11, 30000, 60, 3000, 0.0, False, 10, -1, {}),
     "tiny_k10_noisy_variable": (13, 40000, 80, 3000, 0.02, True, 10, -1, {}),
-    # k=13 needs > 1 % of 4^13 distinct k-mers in the input, or the top-occurrence blacklist leaves no seed
+    # k=13 needs > 1 % of 4^13 distinct k-mers in the input, or the top-occurrence blacklist leaves no seed (HISTORY.md 2.7)
     "k13_3000x10kb_2rounds": (113, 1500000, 3000, 10000, 0.0, False, 13, 2, {}),
     "tiny_k13_degenerate": (12, 6000, 20, 3000, 0.0, False, 13, -1, {}),
     "short_reads_get_ignored_k10": (32, 60000, 500, 1500, 0.0, True, 10, -1, {}),

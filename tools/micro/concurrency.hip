@@ -1,5 +1,5 @@
 // How many kernels of ONE process run at the same time?  S streams, each a chain of kernels that do nothing but sleep `us`
-// microseconds on `blocks` workgroups; concurrency = S * n * us / wall time.  
+// microseconds on `blocks` workgroups; concurrency = S * n * us / wall time.  (HISTORY.md 5.7)
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

@@ -1,4 +1,4 @@
-// How many scattered memory requests per second does an MI355X serve?  (what the rounds' kernels compete for.)
+// How many scattered memory requests per second does an MI355X serve?  (HISTORY.md 5.7: what the rounds' kernels compete for.)
 // Threads draw pseudo-random addresses in a buffer of `gb` GiB and read 4 bytes (or add 1 atomically) at each; `ilp` independent
 // requests are in flight per thread.  Prints giga-requests per second for reads, returning atomics and non-returning atomics.
 #include <hip/hip_runtime.h>
