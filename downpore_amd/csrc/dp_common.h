@@ -4,6 +4,8 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -63,7 +65,8 @@ struct dp_ctx {
     std::string err;
     bool borrowed_reads = false;  // d_packed/d_boff/d_len belong to another context
     struct ReadsUpload;           // a read set still on its way to the device (dp_reads_upload_rc_begin, dp_scan.hip)
-    ReadsUpload* upload = nullptr;
+    std::shared_ptr<ReadsUpload> upload;  // (under upload_mu: a borrower's wait holds its own reference while the owner's final wait lets go)
+    std::mutex upload_mu;
 
     // ---- reads (A1)
     uint32_t n_reads = 0;

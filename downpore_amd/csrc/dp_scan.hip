@@ -266,8 +266,20 @@ struct Parked {
 };
 struct BigCache {
     std::mutex mu;
-    std::multimap<std::pair<int, size_t>, Parked> free_;  // (device, capacity) -> block
-    std::unordered_map<void*, BigBlock> live;             // blocks handed out (>= the cache's smallest size)
+    typedef std::multimap<std::pair<int, size_t>, Parked> Free;
+    Free free_;                                 // (device, capacity) -> block
+    std::map<uint64_t, Free::iterator> by_age;  // parking order -> the same blocks: trimming takes from the front
+    std::unordered_map<void*, BigBlock> live;   // blocks handed out (>= the cache's smallest size)
+    void park(int device, size_t cap, void* p) {  // (under mu)
+        const uint64_t s = seq++;
+        by_age.emplace(s, free_.emplace(std::make_pair(device, cap), Parked{p, s}));
+        cached += cap;
+    }
+    void unpark(Free::iterator it) {  // (under mu)
+        cached -= it->first.second;
+        by_age.erase(it->second.seq);
+        free_.erase(it);
+    }
     size_t cached = 0;
     uint64_t seq = 0;
 };
@@ -312,8 +324,7 @@ void* cache_take(BigCache& c, int dev, size_t bytes) {
     if (it == c.free_.end() || it->first.first != dev || it->first.second > bytes + bytes / 4) return nullptr;
     void* p = it->second.p;
     c.live[p] = BigBlock{it->first.second, dev};
-    c.cached -= it->first.second;
-    c.free_.erase(it);
+    c.unpark(it);
     return p;
 }
 // parked blocks go back to the driver until at most `keep` bytes stay - the ones parked longest ago first: what every run takes out
@@ -325,13 +336,10 @@ void cache_trim(BigCache& c, size_t keep, F&& release) {
     std::vector<std::pair<int, void*>> drop;
     {
         std::lock_guard<std::mutex> lk(c.mu);
-        while (c.cached > keep && !c.free_.empty()) {
-            auto old = c.free_.begin();
-            for (auto it = c.free_.begin(); it != c.free_.end(); ++it)
-                if (it->second.seq < old->second.seq) old = it;
+        while (c.cached > keep && !c.by_age.empty()) {
+            auto old = c.by_age.begin()->second;
             drop.push_back({old->first.first, old->second.p});
-            c.cached -= old->first.second;
-            c.free_.erase(old);
+            c.unpark(old);
         }
     }
     for (auto& q : drop) {
@@ -351,9 +359,15 @@ void dp_dev_trim() {
     cache_trim(big_cache(), 0, [](void* p) { (void)hipFree(p); });
 }
 // (a context that owned reads goes: what it and its borrowers parked stays for the next one, up to the cap)
+// The cap is DP_DEV_CACHE_MB (default 16384) and never more than a quarter of what the device would have free with the cache empty:
+// on a GPU somebody else has filled - torch in the same process, another process - little stays parked.  Embedders that live long
+// call dp_release_device_caches() when they are done with a read set.
 static void dp_dev_trim_to_cap() {
     static const size_t cap = cache_cap("DP_DEV_CACHE_MB", 16384);
-    cache_trim(big_cache(), cap, [](void* p) { (void)hipFree(p); });
+    size_t keep = cap, free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) keep = std::min(keep, (free_b + dp_dev_cached_bytes()) / 4);
+    else (void)hipGetLastError();
+    cache_trim(big_cache(), keep, [](void* p) { (void)hipFree(p); });
 }
 
 extern "C" int64_t dp_release_device_caches() {
@@ -411,8 +425,7 @@ static hipError_t dev_free_impl(void* p, bool quiet) {
         e = hipDeviceSynchronize();
     }
     std::lock_guard<std::mutex> lk(c.mu);
-    c.free_.emplace(std::make_pair(b.device, b.cap), Parked{p, c.seq++});
-    c.cached += b.cap;
+    c.park(b.device, b.cap, p);
     return e;
 }
 hipError_t dp_dev_free(void* p) { return dev_free_impl(p, false); }
@@ -448,8 +461,7 @@ void dp_pin_free(void* p) {
             const BigBlock b = it->second;
             c.live.erase(it);
             if (b.cap <= cap) {
-                c.free_.emplace(std::make_pair(b.device, b.cap), Parked{p, c.seq++});
-                c.cached += b.cap;
+                c.park(b.device, b.cap, p);
                 p = nullptr;
             }
         }
@@ -571,7 +583,7 @@ static int upload_join(dp_ctx* ctx);  // (dp_reads_upload_rc_begin's thread, bel
 extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    if (ctx->upload) (void)upload_join(ctx);  // (a read set still travelling: its thread uses this context's buffers)
+    (void)upload_join(ctx);  // (a read set still travelling: its thread uses this context's buffers)
     dp_stream_sync(ctx);
     {
         // contexts that borrow these reads (value table, k-mer index) are still alive - a garbage-collected host may finalise
@@ -917,14 +929,16 @@ struct dp_ctx::ReadsUpload {
 };
 
 static int upload_join(dp_ctx* ctx) {
-    if (!ctx || !ctx->upload) return DP_OK;
-    dp_ctx::ReadsUpload* U = ctx->upload;
+    if (!ctx) return DP_OK;
+    std::shared_ptr<dp_ctx::ReadsUpload> U;
+    {
+        std::lock_guard<std::mutex> lk(ctx->upload_mu);
+        U.swap(ctx->upload);
+    }
+    if (!U) return DP_OK;
     if (U->th.joinable()) U->th.join();
-    const int rc = U->rc;
-    const std::string err = U->error;
-    ctx->upload = nullptr;
-    delete U;
-    return rc == DP_OK ? DP_OK : dp_fail(ctx, rc, err.c_str());
+    std::lock_guard<std::mutex> lk(U->mu);  // (a borrower still inside its wait reads rc under this lock and keeps U alive)
+    return U->rc == DP_OK ? DP_OK : dp_fail(ctx, U->rc, U->error.c_str());
 }
 
 // The thread that carries an upload: pieces of ASCII through the pinned ring to the device on a stream of its own, behind every piece the
@@ -1042,6 +1056,7 @@ static void upload_thread(dp_ctx* ctx, dp_ctx::ReadsUpload* U, const uint8_t* sr
 }
 
 extern "C" int dp_reads_upload_rc_begin(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads, uint32_t first_paired, uint32_t ready_first) {
+    if (!ctx) return DP_ERR_ARG;
     UploadPrep P;
     if (int rc = reads_upload_prepare(ctx, bases, off, n_reads, first_paired, P)) {
         hipStreamSynchronize(ctx->stream);
@@ -1056,9 +1071,13 @@ extern "C" int dp_reads_upload_rc_begin(dp_ctx* ctx, const uint8_t* bases, const
             if (q) dp_dev_free(q);
         return dp_fail(ctx, DP_ERR_HIP, "dp_reads_upload_rc_begin", e);
     }
-    dp_ctx::ReadsUpload* U = new dp_ctx::ReadsUpload();
+    std::shared_ptr<dp_ctx::ReadsUpload> keep = std::make_shared<dp_ctx::ReadsUpload>();
+    dp_ctx::ReadsUpload* U = keep.get();  // (the thread is joined before the owner's reference goes)
     U->n_host = n_reads;
-    ctx->upload = U;
+    {
+        std::lock_guard<std::mutex> lk(ctx->upload_mu);
+        ctx->upload = keep;
+    }
     const uint8_t* src = bases + off[0];
     U->th = std::thread([ctx, U, src, first_paired](UploadPrep Pm) { upload_thread(ctx, U, src, std::move(Pm), first_paired); }, std::move(P));
     return dp_reads_upload_wait(ctx, ready_first);
@@ -1067,9 +1086,13 @@ extern "C" int dp_reads_upload_rc_begin(dp_ctx* ctx, const uint8_t* bases, const
 extern "C" int dp_reads_upload_wait(dp_ctx* ctx, uint32_t host_read_hi) {
     if (!ctx) return DP_ERR_ARG;
     dp_ctx* own = ctx->owner ? ctx->owner : ctx;
-    if (!own->upload) return DP_OK;
     if (host_read_hi == 0xffffffffu) return own == ctx ? upload_join(ctx) : DP_ERR_ARG;  // (everything, and the thread with it: the owner's call)
-    dp_ctx::ReadsUpload* U = own->upload;
+    std::shared_ptr<dp_ctx::ReadsUpload> U;
+    {
+        std::lock_guard<std::mutex> lk(own->upload_mu);
+        U = own->upload;
+    }
+    if (!U) return DP_OK;
     std::unique_lock<std::mutex> lk(U->mu);
     const uint32_t want = std::min(host_read_hi, U->n_host);
     U->cv.wait(lk, [&] { return U->done || U->ready >= want; });

@@ -777,6 +777,7 @@ struct ArgTable {
 
 // test hooks (host_capi.cpp: dph_hand_*)
 void trimBestIndices(int upto, const std::vector<SeedMatch*>& ms, int minMatch, int length, int* bestOut, int* backOut);  // host_seq.cpp
+long coroSelfTest(int nTasks, int yields);  // host_map.cpp: the read tasks' stack switch by itself
 bool handIsConsistent(const i64* l, const i64* r, bool circular, i64 refLen);                                                // host_map.cpp
 int handRemoveDominated(const i64* maps, int n, i64 queryLen, int* kept);                                                    // host_map.cpp
 }  // namespace dph

@@ -466,6 +466,8 @@ void dph_hand_trim_indices(int upto, const int32_t* match_a, const int64_t* off,
     dph::trimBestIndices(upto, ms, min_match, length, &out2[0], &out2[1]);
 }
 
+long dph_test_coroutines(int n_tasks, int yields) { return dph::coroSelfTest(n_tasks, yields); }
+
 void dph_values_from_counts(uint64_t* counts, int k, double* out) {
     std::vector<uint64_t> c(counts, counts + ((size_t)1 << (2 * k)));
     std::vector<double> v = kmerValuesFromCounts(c, k);

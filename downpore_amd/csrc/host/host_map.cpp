@@ -2,9 +2,7 @@
 //
 // mapping.Mapper.Map is adaptive per read (ends -> one/two steps in -> binary split search), every step being a
 // performMapping of one window.  To batch windows of MANY reads into each GPU call while keeping Map()'s control flow
-// written exactly as the reference's sequential code, each read's Map() runs as a stackful coroutine (a 20-instruction context
-// switch of its own - round 5: glibc's swapcontext saves and restores the signal mask with a system call per switch, 300 k of them
-// per config-3 run):
+// written exactly as the reference's sequential code, each read's Map() runs as a stackful coroutine (host_coro.hpp):
 // performMapping() files a window request and yields; when every live coroutine is waiting, the scheduler scans all
 // requested windows (dp_scan), runs the candidate/chaining stage (dp_map_windows) and resumes the coroutines with
 // their chains.  Results are emitted in read order (the canonical single-worker order).
@@ -17,32 +15,8 @@
 #include "dph.hpp"
 #include "host_util.hpp"
 
-// Switches stacks: the callee-saved registers of the System V x86-64 ABI go to the current stack, its top to *save_sp, and the
-// same registers come back from the stack `load_sp` points at.  A fresh coroutine's stack is laid out by coroStart() so that the
-// first switch to it "returns" into coroTrampoline.
-extern "C" void dph_coro_switch(void** save_sp, void* load_sp);
-__asm__(
-    ".text\n"
-    ".globl dph_coro_switch\n"
-    ".hidden dph_coro_switch\n"
-    ".type dph_coro_switch,@function\n"
-    "dph_coro_switch:\n"
-    "    pushq %rbp\n"
-    "    pushq %rbx\n"
-    "    pushq %r12\n"
-    "    pushq %r13\n"
-    "    pushq %r14\n"
-    "    pushq %r15\n"
-    "    movq %rsp, (%rdi)\n"
-    "    movq %rsi, %rsp\n"
-    "    popq %r15\n"
-    "    popq %r14\n"
-    "    popq %r13\n"
-    "    popq %r12\n"
-    "    popq %rbx\n"
-    "    popq %rbp\n"
-    "    ret\n"
-    ".size dph_coro_switch,.-dph_coro_switch\n");
+#define DPH_CORO_IMPLEMENTATION  // (the switch routine itself lives in this translation unit)
+#include "host_coro.hpp"
 
 namespace dph {
 
@@ -116,7 +90,7 @@ struct MapperImpl {
 };
 
 struct Task {
-    void* sp = nullptr;     // the coroutine's saved stack pointer while it is switched out
+    CoroPoint at;           // where the coroutine stands while it is switched out
     char* stack = nullptr;  // from the scheduler's stack pool (uninitialised memory, reused by later reads)
     uint32_t read = 0;
     i64 L = 0;
@@ -133,28 +107,15 @@ struct Task {
 };
 
 struct Sched {
-    void* main = nullptr;  // the scheduler's saved stack pointer while a coroutine runs
-    Task* cur = nullptr;   // the coroutine being started (coroTrampoline picks it up)
+    CoroPoint main;  // the scheduler's own stack while a coroutine runs
 };
 
-thread_local Sched* g_coroSched = nullptr;
-// first frame of every coroutine: reached by dph_coro_switch's `ret`, never returns (the last switch leaves it for good)
-void coroTrampoline() {
-    Task* t = g_coroSched->cur;
+// first frame of every coroutine: never returns (the last switch leaves it for good)
+void coroTrampoline(void* arg) {
+    Task* t = (Task*)arg;
     t->results = t->m->map(*t);
     t->done = true;
-    dph_coro_switch(&t->sp, t->m->sched->main);
-    __builtin_trap();
-}
-// lays a fresh stack out as dph_coro_switch leaves one: six zeroed callee-saved registers, then the address `ret` jumps to; at
-// that `ret` the stack pointer is 16-byte aligned + 8, as at any function's first instruction
-void coroStart(Task& t, size_t stackBytes) {
-    uintptr_t top = ((uintptr_t)t.stack + stackBytes) & ~(uintptr_t)15;
-    void** sp = (void**)top;
-    *--sp = nullptr;                  // (the slot a return address of the trampoline's caller would take: keeps the alignment)
-    *--sp = (void*)&coroTrampoline;   // popped by `ret`
-    for (int i = 0; i < 6; i++) *--sp = nullptr;
-    t.sp = (void*)sp;
+    coroSwitch(t->at, t->m->sched->main, true);
 }
 
 // ---- mapping.go:131-160
@@ -467,7 +428,7 @@ std::vector<Mapping*> MapperImpl::performMapping(Task& t, i64 a, i64 b, bool who
     t.req.b = b;
     t.req.whole = whole;
     t.waiting = true;
-    dph_coro_switch(&t.sp, sched->main);  // yield until the batch has been processed
+    coroSwitch(t.at, sched->main);  // yield until the batch has been processed
     t.waiting = false;
     const WindowResult& R = t.res;
     const i64 qlen = b - a;
@@ -1035,11 +996,9 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             }
             t->stack = freeStacks.back();
             freeStacks.pop_back();
-            coroStart(*t, stackBytes);
+            coroStart(t->at, t->stack, stackBytes, &coroTrampoline, t.get());
             nextSeq++;
-            sched.cur = t.get();
-            g_coroSched = &sched;
-            dph_coro_switch(&sched.main, t->sp);  // run until the first window request (or completion)
+            coroSwitch(sched.main, t->at);  // run until the first window request (or completion)
             live.push_back(std::move(t));
         }
         // retire finished tasks
@@ -1049,6 +1008,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
                 std::string& o = out[t.read];
                 for (Mapping* mm : t.results) o += M.asString(*mm, reads.names[t.read], t.L) + "\n";
                 nmaps[t.read] = (int)t.results.size();
+                coroRelease(t.at);
                 freeStacks.push_back(t.stack);
                 live[i] = std::move(live.back());
                 live.pop_back();
@@ -1176,7 +1136,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
         if (stats) stats->n_batches++;
         tq = wallNow();
         // ---- ... distribute and resume
-        for (auto& tk : live) dph_coro_switch(&sched.main, tk->sp);
+        for (auto& tk : live) coroSwitch(sched.main, tk->at);
         lap(4);  // coroutines resumed: performMapping's tail + the mapper's control flow up to the next window
     }
     if (prof)
@@ -1274,6 +1234,73 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     dp_ctx_destroy(ctx), ctx = nullptr;
     if (prof) fprintf(stderr, "[map end] text joined in %.1f ms, context destroyed in %.1f, whole run %.1f\n", 1e3 * (tEnd0 - tText0), 1e3 * (wallNow() - tEnd0), 1e3 * (wallNow() - tRun0));
     return 0;
+}
+
+// ---- self-test of the coroutine switch (include/downpore_host.h, test hooks): n_tasks coroutines on recycled stacks, every one adds
+// its number `yields` times with a switch back to the caller in between and touches its stack deeply; returns the sum (-1: a task
+// was resumed with a damaged frame).  What the mapper does with its read tasks, without a GPU - and under the sanitizer builds.
+namespace {
+struct CoroTestTask {
+    CoroPoint at, *main = nullptr;
+    int id = 0, yields = 0;
+    long sum = 0;
+    bool done = false, bad = false;
+};
+void coroTestBody(void* arg) {
+    CoroTestTask* t = (CoroTestTask*)arg;
+    volatile char pad[8192];
+    for (int y = 0; y < t->yields; y++) {
+        for (size_t i = 0; i < sizeof(pad); i += 64) pad[i] = (char)(t->id + y);
+        coroSwitch(t->at, *t->main);
+        for (size_t i = 0; i < sizeof(pad); i += 64)
+            if (pad[i] != (char)(t->id + y)) t->bad = true;
+        t->sum += t->id;
+    }
+    t->done = true;
+    coroSwitch(t->at, *t->main, true);
+}
+}  // namespace
+long coroSelfTest(int nTasks, int yields) {
+    const size_t stackBytes = (size_t)64 << 10;
+    CoroPoint main;
+    std::vector<std::unique_ptr<char[]>> store;
+    std::vector<char*> freeStacks;
+    long sum = 0;
+    const int wave = 7;  // tasks alive at a time: stacks are reused by later tasks
+    for (int base = 0; base < nTasks; base += wave) {
+        std::vector<std::unique_ptr<CoroTestTask>> live;
+        std::vector<char*> mine;
+        for (int i = base; i < std::min(nTasks, base + wave); i++) {
+            if (freeStacks.empty()) {
+                store.emplace_back(new char[stackBytes]);
+                freeStacks.push_back(store.back().get());
+            }
+            live.emplace_back(new CoroTestTask());
+            CoroTestTask& t = *live.back();
+            t.main = &main;
+            t.id = i + 1;
+            t.yields = yields;
+            mine.push_back(freeStacks.back());
+            freeStacks.pop_back();
+            coroStart(t.at, mine.back(), stackBytes, &coroTestBody, &t);
+            coroSwitch(main, t.at);
+        }
+        for (bool any = true; any;) {
+            any = false;
+            for (auto& t : live)
+                if (!t->done) {
+                    coroSwitch(main, t->at);
+                    any = true;
+                }
+        }
+        for (size_t i = 0; i < live.size(); i++) {
+            if (live[i]->bad) return -1;
+            sum += live[i]->sum;
+            coroRelease(live[i]->at);
+            freeStacks.push_back(mine[i]);
+        }
+    }
+    return sum;
 }
 
 }  // namespace dph

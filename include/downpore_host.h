@@ -149,7 +149,11 @@ DPH_API void dph_values_from_counts(uint64_t* counts, int k, double* out);
  * dph_hand_remove_dominated  removeDominated (mapping.go:387-428): maps3 = n x {QueryOffset, QueryInset, ids}; kept[] = the survivors'
  *                          indices in the order the function returns them; returns their number
  * dph_hand_trim_indices    step 1 of trimToBestSeed (overlap/combine.go:24-58): match i's MatchA = match_a[off[i] .. off[i + 1]);
- *                          out2 = {bestIndex, backIndex} */
+ *                          out2 = {bestIndex, backIndex}
+ * dph_test_coroutines     the mapper's read tasks are stackful coroutines (host/host_coro.hpp): n_tasks of them on recycled stacks,
+ *                          each resumed `yields` times; returns the sum of id x yields over the tasks, -1 if a frame came back damaged.
+ */
+DPH_API long dph_test_coroutines(int n_tasks, int yields);
 DPH_API int dph_hand_is_consistent(const int64_t* left5, const int64_t* right4, int circular, int64_t ref_len);
 DPH_API int dph_hand_remove_dominated(const int64_t* maps3, int n, int64_t query_len, int* kept);
 DPH_API void dph_hand_trim_indices(int upto, const int32_t* match_a, const int64_t* off, int n_matches, int min_match, int length, int* out2);

@@ -22,6 +22,7 @@ import (
 type Context struct {
 	h      *C.dp_ctx
 	parent *Context // a Shared() context borrows its parent's resident reads: the parent stays reachable as long as the child is
+	pinned runtime.Pinner // the bases of an UploadReadsRCBegin whose reads still travel (unpinned by WaitReads(-1) and Close)
 }
 
 func fail(h *C.dp_ctx, what string, rc C.int) error {
@@ -97,8 +98,9 @@ func ReleaseDeviceCaches() int64 { return int64(C.dp_release_device_caches()) }
 
 func (c *Context) Close() {
 	if c.h != nil {
-		C.dp_ctx_destroy(c.h)
+		C.dp_ctx_destroy(c.h) // (joins an upload thread that is still running)
 		c.h = nil
+		c.pinned.Unpin()
 	}
 }
 
@@ -132,16 +134,18 @@ func (c *Context) UploadReadsRC(bases []byte, off []int64, firstPaired int) erro
 }
 
 // UploadReadsRCBegin is UploadReadsRC that returns while the reads still travel: the read set's tables are resident and host reads
-// [0, readyFirst) packed when it returns, a thread of the library sends the rest on.  `bases` must stay alive (and unmoved: pass memory
-// the Go collector does not manage, or keep it pinned with runtime.Pinner) until WaitReads(-1) has returned; kernels may only be given
-// reads a WaitReads has covered.
+// [0, readyFirst) packed when it returns, a thread of the library sends the rest on.  Kernels may only be given
+// reads a WaitReads has covered.  The library's thread reads `bases` after this call has returned: the binding pins the slice's array
+// (runtime.Pinner, Go >= 1.21) until WaitReads(-1) or Close, so that the caller only has to keep the slice unmodified.
 func (c *Context) UploadReadsRCBegin(bases []byte, off []int64, firstPaired, readyFirst int) error {
 	var bp *C.uint8_t
 	if len(bases) > 0 {
 		bp = (*C.uint8_t)(unsafe.Pointer(&bases[0]))
+		c.pinned.Pin(&bases[0])
 	}
 	rc := C.dp_reads_upload_rc_begin(c.h, bp, (*C.int64_t)(unsafe.Pointer(&off[0])), C.uint32_t(len(off)-1), C.uint32_t(firstPaired), C.uint32_t(readyFirst))
 	if rc != 0 {
+		c.pinned.Unpin()
 		return fail(c.h, "dp_reads_upload_rc_begin", rc)
 	}
 	return nil
@@ -154,7 +158,11 @@ func (c *Context) WaitReads(upTo int) error {
 	if upTo >= 0 {
 		hi = C.uint32_t(upTo)
 	}
-	if rc := C.dp_reads_upload_wait(c.h, hi); rc != 0 {
+	rc := C.dp_reads_upload_wait(c.h, hi)
+	if upTo < 0 {
+		c.pinned.Unpin() // (the upload thread has ended, with or without an error)
+	}
+	if rc != 0 {
 		return fail(c.h, "dp_reads_upload_wait", rc)
 	}
 	return nil

@@ -33,7 +33,7 @@ def test_host_and_oracle_cpu_tests_are_clean_under_asan_ubsan(tmp_path):
                # (python itself leaks by design; an error must not be lost in a passing exit code: it is found in the log)
                ASAN_OPTIONS="detect_leaks=0:halt_on_error=0:exitcode=0:log_path=" + log,
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=0:log_path=" + log)
-    tests = ["tests/test_planner_epoch.py", "tests/test_host_finalcheck.py", "tests/test_fasta_reader.py", "tests/test_oracle_known_answers.py",
+    tests = ["tests/test_planner_epoch.py", "tests/test_host_coroutines.py::test_library_hook_switches_read_tasks_on_recycled_stacks", "tests/test_host_finalcheck.py", "tests/test_fasta_reader.py", "tests/test_oracle_known_answers.py",
              "tests/test_golden.py"]
     p = subprocess.run([sys.executable, "-m", "pytest"] + tests + ["-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=2400)

@@ -28,7 +28,7 @@ def test_planner_tests_are_race_free_under_tsan(tmp_path):
     log = str(tmp_path / "tsan")
     env = dict(os.environ, LD_PRELOAD=tsan, DPH_HOST_LIB=lib,
                TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0 log_path=" + log)
-    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_planner_epoch.py", "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_planner_epoch.py", "tests/test_host_coroutines.py::test_library_hook_switches_read_tasks_on_recycled_stacks", "-x", "-q", "-p", "no:cacheprovider"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     reports = [open(f).read() for f in glob.glob(log + ".*")]
