@@ -62,6 +62,7 @@ struct dp_ctx {
     hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [8], [9]: around the index build's kernels
     bool index_marked = false;  // marks 8 / 9 were recorded for the round's index build (dp_consensus_paf reads them)
     hipEvent_t ev_sync = nullptr;  // blocking-sync event: waiting host threads sleep instead of polling
+    bool stream_priority_set = false;  // (dp_ctx_set_priority: such a stream is destroyed with its context instead of being parked)
     std::string err;
     bool borrowed_reads = false;  // d_packed/d_boff/d_len belong to another context
     struct ReadsUpload;           // a read set still on its way to the device (dp_reads_upload_rc_begin, dp_scan.hip)

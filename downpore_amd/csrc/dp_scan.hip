@@ -370,6 +370,9 @@ static void dp_dev_trim_to_cap() {
     cache_trim(big_cache(), keep, [](void* p) { (void)hipFree(p); });
 }
 
+namespace {
+void kits_release();  // (parked streams and events, below)
+}
 extern "C" int64_t dp_release_device_caches() {
     const size_t before = dp_dev_cached_bytes() + [] {
         BigCache& c = pin_cache();
@@ -378,6 +381,7 @@ extern "C" int64_t dp_release_device_caches() {
     }();
     dp_dev_trim();
     cache_trim(pin_cache(), 0, [](void* p) { (void)hipHostFree(p); });
+    kits_release();
     return (int64_t)before;
 }
 
@@ -517,6 +521,69 @@ extern "C" const char* dp_version(void) { return "downpore_hip 0.1 (gfx950)"; }
 
 extern "C" const char* dp_last_error(const dp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
+// A context's stream and events outlive it: creating a stream takes the runtime 3 - 4 ms, one after another whatever the thread (a
+// config-3 `map` run creates seven contexts: its sixth mapper thread started 20 ms after the first), so an idle stream is parked with
+// its events when its context goes and handed to the next context on that device.  dp_release_device_caches() destroys the parked
+// ones; streams whose priority was changed (dp_ctx_set_priority) are not kept.
+namespace {
+struct StreamKit {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev[sizeof(dp_ctx::ev) / sizeof(dp_ctx::ev[0])];
+    hipEvent_t ev_sync;
+};
+std::mutex g_kit_mu;
+std::vector<StreamKit> g_kits;
+constexpr size_t kMaxKits = 32;
+bool kit_take(int device, dp_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(g_kit_mu);
+    for (size_t i = g_kits.size(); i-- > 0;)
+        if (g_kits[i].device == device) {
+            ctx->stream = g_kits[i].stream;
+            for (size_t j = 0; j < sizeof(ctx->ev) / sizeof(ctx->ev[0]); j++) ctx->ev[j] = g_kits[i].ev[j];
+            ctx->ev_sync = g_kits[i].ev_sync;
+            g_kits.erase(g_kits.begin() + (long)i);
+            return true;
+        }
+    return false;
+}
+void kit_destroy(StreamKit& k) {
+    for (auto& ev : k.ev)
+        if (ev) hipEventDestroy(ev);
+    if (k.ev_sync) hipEventDestroy(k.ev_sync);
+    if (k.stream) hipStreamDestroy(k.stream);
+}
+// (the context's stream is idle: dp_ctx_destroy has waited for it)
+void kit_put(dp_ctx* ctx) {
+    StreamKit k;
+    k.device = ctx->device;
+    k.stream = ctx->stream;
+    for (size_t j = 0; j < sizeof(ctx->ev) / sizeof(ctx->ev[0]); j++) k.ev[j] = ctx->ev[j];
+    k.ev_sync = ctx->ev_sync;
+    bool all = k.stream != nullptr && k.ev_sync != nullptr && !ctx->stream_priority_set;
+    for (auto& ev : k.ev) all = all && ev != nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_kit_mu);
+        if (all && g_kits.size() < kMaxKits) {
+            g_kits.push_back(k);
+            return;
+        }
+    }
+    kit_destroy(k);
+}
+void kits_release() {
+    std::vector<StreamKit> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_kit_mu);
+        drop.swap(g_kits);
+    }
+    for (StreamKit& k : drop) {
+        DeviceGuard g(k.device);
+        kit_destroy(k);
+    }
+}
+}  // namespace
+
 static std::mutex g_borrow_mu;  // borrower counts and pending owner destroys (dp_ctx_create_shared / dp_ctx_destroy)
 
 extern "C" int dp_ctx_create(int device, dp_ctx** out) {
@@ -528,13 +595,20 @@ extern "C" int dp_ctx_create(int device, dp_ctx** out) {
     if (device < 0 || device >= n) return dp_fail(nullptr, DP_ERR_ARG, "device index out of range");
     dp_ctx* ctx = new dp_ctx();
     ctx->device = device;
-    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
-        dp_fail(nullptr, DP_ERR_HIP, "hipSetDevice/hipStreamCreate", e);
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        dp_fail(nullptr, DP_ERR_HIP, "hipSetDevice", e);
         delete ctx;
         return DP_ERR_HIP;
     }
-    for (auto& ev : ctx->ev) hipEventCreate(&ev);
-    hipEventCreateWithFlags(&ctx->ev_sync, hipEventBlockingSync | hipEventDisableTiming);
+    if (!kit_take(device, ctx)) {
+        if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+            dp_fail(nullptr, DP_ERR_HIP, "hipStreamCreate", e);
+            delete ctx;
+            return DP_ERR_HIP;
+        }
+        for (auto& ev : ctx->ev) hipEventCreate(&ev);
+        hipEventCreateWithFlags(&ctx->ev_sync, hipEventBlockingSync | hipEventDisableTiming);
+    }
     *out = ctx;
     return DP_OK;
 }
@@ -576,6 +650,7 @@ extern "C" int dp_ctx_set_priority(dp_ctx* ctx, int high) {
     DP_HIP(hipStreamCreateWithPriority(&s, hipStreamDefault, high ? greatest : least));
     hipStreamDestroy(ctx->stream);
     ctx->stream = s;
+    ctx->stream_priority_set = true;
     return DP_OK;
 }
 
@@ -624,10 +699,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
                      &ctx->h_seeds, &ctx->h_spack, &ctx->h_extra, &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
     for (auto* b : pbs)
         if (b->p) dp_pin_free(b->p);
-    for (auto& ev : ctx->ev)
-        if (ev) hipEventDestroy(ev);
-    if (ctx->ev_sync) hipEventDestroy(ctx->ev_sync);
-    hipStreamDestroy(ctx->stream);
+    kit_put(ctx);
     const bool owner = !ctx->borrowed_reads;
     delete ctx;
     if (owner) dp_dev_trim_to_cap();  // (a context that owned reads goes: what is parked beyond it is bounded)

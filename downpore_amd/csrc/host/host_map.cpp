@@ -1169,9 +1169,13 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
                 const double tt0 = wallNow();
                 if (t > 0) {  // a context of its own: shared packed reads, the same seeds, the reference index from the chunk scan above
                     int rc2 = dp_ctx_create_shared(ctx, &tctx[t]);
+                    const double ta = wallNow();
                     if (rc2 == 0) rc2 = dp_round_begin(tctx[t], k, index.seedMap.data(), (uint32_t)index.seedMap.size());
+                    const double tb = wallNow();
                     if (rc2 == 0) rc2 = dp_scan_import_segments(tctx[t], M.chunkSegs.data(), M.chunkSegs.size());
+                    const double tc = wallNow();
                     if (rc2 == 0) rc2 = dp_index_build(tctx[t], refs.data(), (uint32_t)refs.size());
+                    if (prof) fprintf(stderr, "[map thread %zu] context %.2f ms, round begin %.2f, import %.2f, index %.2f\n", t, 1e3 * (ta - tt0), 1e3 * (tb - ta), 1e3 * (tc - tb), 1e3 * (wallNow() - tc));
                     if (rc2 != 0) {
                         ls.rc = rc2;
                         ls.error = tctx[t] ? dp_last_error(tctx[t]) : dp_last_error(nullptr);

@@ -38,5 +38,7 @@ def test_every_flavour_of_the_switch(tmp_path, name, flags, expect):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:halt_on_error=1", TSAN_OPTIONS="halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
     env.pop("LD_PRELOAD", None)
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    if name == "tsan" and "unexpected memory mapping" in r.stderr:
+        pytest.skip("this kernel's address-space layout is one the image's ThreadSanitizer runtime refuses to start under")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.startswith(expect), r.stdout
