@@ -867,6 +867,7 @@ struct UploadPrep {
     uint64_t nascii = 0, pos = 0;
     uint32_t n_reads = 0;
     bool nothing = false;          // no bases at all: the tables are resident, nothing travels
+    bool packed_input = false;     // dp_reads_upload_packed_rc: no ASCII staging block
 };
 static int upload_join(dp_ctx* ctx);
 static int reads_upload_prepare(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_host, uint32_t& first_paired, UploadPrep& P) {
@@ -943,12 +944,14 @@ static int reads_upload_prepare(dp_ctx* ctx, const uint8_t* bases, const int64_t
         P.nothing = true;
         return DP_OK;
     }
-    P.nascii = (uint64_t)(off[n_host] - off[0]);
-    DP_HIP(dp_dev_malloc(&P.d_ascii, P.nascii + 16));
-    DP_HIP(dp_dev_malloc(&P.d_aoff, ((size_t)n_host + 1) * 8));
-    P.rel.resize((size_t)n_host + 1);
-    for (uint32_t r = 0; r <= n_host; r++) P.rel[r] = off[r] - off[0];
-    DP_HIP(hipMemcpyAsync(P.d_aoff, P.rel.data(), ((size_t)n_host + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!P.packed_input) {
+        P.nascii = (uint64_t)(off[n_host] - off[0]);
+        DP_HIP(dp_dev_malloc(&P.d_ascii, P.nascii + 16));
+        DP_HIP(dp_dev_malloc(&P.d_aoff, ((size_t)n_host + 1) * 8));
+        P.rel.resize((size_t)n_host + 1);
+        for (uint32_t r = 0; r <= n_host; r++) P.rel[r] = off[r] - off[0];
+        DP_HIP(hipMemcpyAsync(P.d_aoff, P.rel.data(), ((size_t)n_host + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     if (paired) {
         DP_HIP(dp_dev_malloc(&P.d_map, (size_t)n_reads * 4));
         DP_HIP(hipMemcpyAsync(P.d_map, P.srcmap.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -986,6 +989,125 @@ extern "C" int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t*
 
 extern "C" int dp_reads_upload_rc(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads, uint32_t first_paired) {
     return reads_upload_impl(ctx, bases, off, n_reads, first_paired);
+}
+
+// ---- reads that arrive packed (round 6).  The reference keeps a read as 2 bits per base from the moment it is read from its file
+// (sequence.packedSequence, sequence/sequence.go:22-31: data []byte of ceil(len / 4) bytes, first base in a byte's top bits); a host that
+// holds them that way hands them over that way - a quarter of the bytes over PCIe - and the device lays them out and makes the reverse
+// strands from the packed forward ones.
+//
+// place_packed_kernel: one thread per dword of the device layout.  Forward reads are copied; 16 bases of a reverse strand are the
+// 16 bases of the forward strand that end at len - 1 - base0, their order reversed (byte swap, nibble swap, pair swap) and
+// complemented (3 - code = every bit inverted), bases beyond the read's end zero as everywhere in the layout.
+__global__ void place_packed_kernel(const uint32_t* __restrict__ src, const uint64_t* __restrict__ soff, const uint32_t* __restrict__ slen,
+                                    const uint64_t* __restrict__ boff, uint32_t n_reads, uint32_t* __restrict__ packed, uint64_t n_dwords,
+                                    const uint32_t* __restrict__ srcmap) {
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_dwords) return;
+    const uint64_t byte = d * 4;
+    uint32_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (boff[mid] <= byte) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t src_read = srcmap ? (srcmap[lo] >> 1) : lo;
+    const bool rc = srcmap ? (srcmap[lo] & 1u) != 0 : false;
+    const int64_t len = (int64_t)slen[src_read];
+    const uint64_t rel = byte - boff[lo];              // byte of the read this dword starts at
+    const uint64_t sbytes = ((uint64_t)len + 3) / 4;   // packed bytes of the read
+    const uint32_t* sp = src + soff[src_read] / 4;     // (16-byte aligned; its padding up to the next read is zero)
+    uint32_t out = 0;
+    if (!rc) {
+        if (rel < sbytes) {
+            out = sp[rel / 4];
+            const int64_t nb = len - (int64_t)rel * 4;  // bases of the read from this dword on
+            if (nb < 16) out = __builtin_bswap32(__builtin_bswap32(out) & (0xffffffffu << (2 * (uint32_t)(16 - nb))));  // (whatever the host left in the last byte's unused bits)
+        }
+    } else {
+        const int64_t base0 = (int64_t)rel * 4;
+        const int64_t t = len - 16 - base0;  // forward base the window starts at (negative: the window hangs over the read's start)
+        if (t > -16) {
+            const int64_t tt = t < 0 ? 0 : t;
+            const uint64_t b0 = (uint64_t)tt >> 2;                  // byte the window starts in
+            const uint32_t d0 = sp[b0 / 4], d1 = sp[b0 / 4 + 1];    // (the slack behind the last read keeps d1 inside the block)
+            const uint64_t x = ((uint64_t)__builtin_bswap32(d0) << 32) | (uint64_t)__builtin_bswap32(d1);  // the stream, first base on top
+            const uint32_t sh = 8u * (uint32_t)(b0 & 3u) + 2u * (uint32_t)(tt & 3);
+            uint32_t w = (uint32_t)((x << sh) >> 32);               // bases tt .. tt + 15, base tt on top
+            if (t < 0) w >>= 2 * (uint32_t)(-t);                    // ... bases 0 .. 15 + t at the bottom, nothing above them
+            w = __builtin_bswap32(w);
+            w = ((w & 0x0f0f0f0fu) << 4) | ((w >> 4) & 0x0f0f0f0fu);
+            w = ((w & 0x33333333u) << 2) | ((w >> 2) & 0x33333333u);  // base order reversed: forward base len - 1 - base0 on top
+            w = ~w;
+            if (t < 0) w &= 0xffffffffu << (2 * (uint32_t)(-t));    // bases beyond the read's end
+            out = __builtin_bswap32(w);                               // byte b of the stream = byte b of the little-endian dword
+        }
+    }
+    packed[d] = out;
+}
+
+// host memory handed out by dp_host_alloc is pinned: a copy from it needs no staging
+static bool host_block_is_pinned(const void* p) {
+    BigCache& c = pin_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    for (auto& kv : c.live) {
+        const char* b = (const char*)kv.first;
+        if ((const char*)p >= b && (const char*)p < b + kv.second.cap) return true;
+    }
+    return false;
+}
+
+extern "C" void* dp_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (dp_pin_malloc(&p, bytes < kPinMin ? kPinMin : bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void dp_host_free(void* p) { dp_pin_free(p); }
+
+extern "C" int dp_reads_upload_packed_rc(dp_ctx* ctx, const uint8_t* packed, const uint32_t* lens, uint32_t n_host, uint32_t first_paired) {
+    if (!ctx || !lens || (!packed && n_host)) return DP_ERR_ARG;
+    // the host layout: read r at the sum over the reads before it of its packed bytes rounded up to 16
+    std::vector<int64_t> off((size_t)n_host + 1, 0);
+    std::vector<uint64_t> soff((size_t)n_host + 1, 0);
+    for (uint32_t r = 0; r < n_host; r++) {
+        if (lens[r] > 0x7fffffffu) return dp_fail(ctx, DP_ERR_ARG, "read length out of range");
+        off[(size_t)r + 1] = off[r] + (int64_t)lens[r];
+        soff[(size_t)r + 1] = soff[r] + ((((uint64_t)lens[r] + 3) / 4 + 15) & ~(uint64_t)15);
+    }
+    UploadPrep P;
+    P.packed_input = true;
+    struct Temps {
+        dp_ctx* c;
+        UploadPrep& p;
+        void *d_src = nullptr, *d_soff = nullptr, *d_slen = nullptr;
+        ~Temps() {
+            hipStreamSynchronize(c->stream);
+            for (void* q : {p.d_ascii, p.d_aoff, p.d_map, d_src, d_soff, d_slen})
+                if (q) dp_dev_free(q);
+        }
+    } T{ctx, P};
+    static const uint8_t nothing = 0;
+    if (int rc = reads_upload_prepare(ctx, packed ? packed : &nothing, off.data(), n_host, first_paired, P)) return rc;
+    if (P.nothing) return DP_OK;
+    const uint64_t nsrc = soff[n_host];
+    DP_HIP(dp_dev_malloc(&T.d_src, nsrc + 64));
+    DP_HIP(dp_dev_malloc(&T.d_soff, ((size_t)n_host + 1) * 8));
+    DP_HIP(dp_dev_malloc(&T.d_slen, (size_t)n_host * 4 + 4));
+    DP_HIP(hipMemcpyAsync(T.d_soff, soff.data(), ((size_t)n_host + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemcpyAsync(T.d_slen, lens, (size_t)n_host * 4, hipMemcpyHostToDevice, ctx->stream));
+    DP_HIP(hipMemsetAsync((uint8_t*)T.d_src + nsrc, 0, 64, ctx->stream));
+    if (host_block_is_pinned(packed)) DP_HIP(hipMemcpyAsync(T.d_src, packed, nsrc, hipMemcpyHostToDevice, ctx->stream));
+    else if (int rc = upload_ascii(ctx, T.d_src, packed, nsrc)) return rc;
+    const uint64_t n_dwords = P.pos / 4;
+    hipLaunchKernelGGL(place_packed_kernel, dim3((uint32_t)((n_dwords + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)T.d_src,
+                       (const uint64_t*)T.d_soff, (const uint32_t*)T.d_slen, (const uint64_t*)ctx->d_boff.p, P.n_reads, (uint32_t*)ctx->d_packed.p,
+                       n_dwords, (const uint32_t*)P.d_map);
+    DP_HIP(hipGetLastError());
+    DP_HIP(dp_stream_sync(ctx));  // (soff and the caller's lens are read by copies that are through now)
+    return DP_OK;
 }
 
 // ---- a read set that travels while its first reads are already worked on (round 5: `map` maps read 0 while read 40 000 is on the link)

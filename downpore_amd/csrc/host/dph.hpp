@@ -63,6 +63,7 @@ struct ReadSet {
 
 static inline uint32_t baseCode(unsigned char b) { return ((b >> 1) ^ ((b & 4) >> 2)) & 3; }
 uint32_t reverseComplementKmer(uint32_t kmer, int k);  // seeds/sequence.go:125-132
+void packBases(const char* src, size_t n, uint8_t* dst, bool scalarOnly = false);  // packBytes of a whole read (host_seq.cpp); dst: ceil(n / 4) bytes
 
 // ---- value table (commands/overlap.go:39-94, util/sequtil/kmers.go:87-112) ---------------------------------------
 std::vector<double> kmerValuesFromCounts(std::vector<uint64_t>& counts, int k);

@@ -466,6 +466,7 @@ void dph_hand_trim_indices(int upto, const int32_t* match_a, const int64_t* off,
     dph::trimBestIndices(upto, ms, min_match, length, &out2[0], &out2[1]);
 }
 
+void dph_pack_bases(const char* bases, int64_t n, uint8_t* out, int scalar_only) { dph::packBases(bases, (size_t)n, out, scalar_only != 0); }
 long dph_test_coroutines(int n_tasks, int yields) { return dph::coroSelfTest(n_tasks, yields); }
 
 void dph_values_from_counts(uint64_t* counts, int k, double* out) {

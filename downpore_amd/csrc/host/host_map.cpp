@@ -599,9 +599,58 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // (and its pages first touched) by the worker pool in 4 MiB pieces
     const size_t head = (size_t)refLen + join.size();
     const size_t readBytes = reads.size() ? (size_t)(reads.off[reads.size()] - reads.off[0]) : 0;
+    // Round 6: the reads cross PCIe the way the reference holds them - 2 bits per base (sequence.packedSequence) - packed here by
+    // the worker pool straight into a pinned block in the device's own layout (every read on a 16-byte boundary) and put in place by
+    // dp_reads_upload_packed_rc, which also makes the reverse strands: 100 MB instead of 400 at config 3, one copy instead of three
+    // (staging, pinned ring, link).  DP_TUNE=map_ascii_upload=1: the ASCII path below, as before (it is what map_async_upload uses).
+    const bool asyncUpload = dph_tune("map_async_upload", 0) != 0;
+    const bool packedUpload = !asyncUpload && !dph_tune("map_ascii_upload", 0);
+    const bool packScalar = dph_tune("pack_scalar", 0) != 0;  // (tests: the packer without its AVX2 path)
+    std::vector<uint32_t> plens;
+    std::vector<uint64_t> poff;
+    uint8_t* pinned = nullptr;
+    struct PinnedBack {
+        uint8_t*& p;
+        ~PinnedBack() {
+            if (p) dp_host_free(p);
+        }
+    } pinnedBack{pinned};
+    if (packedUpload) {
+        const size_t n = 2 + reads.size();
+        plens.resize(n);
+        poff.assign(n + 1, 0);
+        plens[0] = (uint32_t)refLen;
+        plens[1] = (uint32_t)join.size();
+        for (size_t r = 0; r < reads.size(); r++) plens[2 + r] = (uint32_t)reads.length(r);
+        for (size_t r = 0; r < n; r++) poff[r + 1] = poff[r] + ((((uint64_t)plens[r] + 3) / 4 + 15) & ~(uint64_t)15);
+        pinned = (uint8_t*)dp_host_alloc((size_t)poff[n] + 64);
+        if (!pinned) {
+            error = "dp_host_alloc: no pinned memory for the packed reads";
+            return DP_ERR_HIP;
+        }
+    }
     size_t stagingCap = 0;
-    std::unique_ptr<char[]> staging = stagingTake(head + readBytes + 1, &stagingCap);
+    std::unique_ptr<char[]> staging = packedUpload ? std::unique_ptr<char[]>() : stagingTake(head + readBytes + 1, &stagingCap);
     std::thread concatThread([&] {
+        if (packedUpload) {
+            packBases(ref, (size_t)refLen, pinned + poff[0], packScalar);
+            packBases(join.data(), join.size(), pinned + poff[1], packScalar);
+            // pieces of about 2 M bases: whole reads
+            std::vector<size_t> cut(1, 0);
+            i64 acc = 0;
+            for (size_t r = 0; r < reads.size(); r++) {
+                acc += reads.length(r);
+                if (acc >= ((i64)2 << 20)) {
+                    cut.push_back(r + 1);
+                    acc = 0;
+                }
+            }
+            if (cut.back() != reads.size()) cut.push_back(reads.size());
+            parallelFor(cut.size() - 1, [&](size_t i) {
+                for (size_t r = cut[i]; r < cut[i + 1]; r++) packBases(reads.seq(r), (size_t)reads.length(r), pinned + poff[2 + r], packScalar);
+            });
+            return;
+        }
         memcpy(staging.get(), ref, (size_t)refLen);
         memcpy(staging.get() + refLen, join.data(), join.size());
         off.push_back((i64)refLen);
@@ -737,7 +786,6 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // tested and left OFF: set-up 14.5 -> 8 ms and the best run 56.0 -> 54.4 ms, but the runs of a process spread 55 - 107 ms where
     // they were 56 - 65 (means of 12 runs 69 / 77 against 62 / 69 ms, profiles/r05/map_threads_and_reads_in_flight.txt): the upload's
     // copy threads and the link compete with six mapper threads for the same host cores and queues.
-    const bool asyncUpload = dph_tune("map_async_upload", 0) != 0;
     // (giving 400 MB of staging back to the system is 40 ms of munmap - round 3's profile had booked it as "AddSingleSeeds (waited
     // for)" - and on a thread of its own it holds the address-space lock against this one's allocations just as long: the block is
     // kept for the process's next map command instead, which then also finds its pages touched)
@@ -750,10 +798,11 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
             if (st) stagingPut(std::move(st), cap);
         }
     } stagingBack{ctx, staging, stagingCap};
-    rc = asyncUpload ? dp_reads_upload_rc_begin(ctx, (const uint8_t*)staging.get(), off.data(), (uint32_t)(off.size() - 1), 2, 2)
-                     : dp_reads_upload_rc(ctx, (const uint8_t*)staging.get(), off.data(), (uint32_t)(off.size() - 1), 2);
+    rc = packedUpload  ? dp_reads_upload_packed_rc(ctx, pinned, plens.data(), (uint32_t)plens.size(), 2)
+         : asyncUpload ? dp_reads_upload_rc_begin(ctx, (const uint8_t*)staging.get(), off.data(), (uint32_t)(off.size() - 1), 2, 2)
+                       : dp_reads_upload_rc(ctx, (const uint8_t*)staging.get(), off.data(), (uint32_t)(off.size() - 1), 2);
     if (rc) return fail(rc);
-    mark(asyncUpload ? "upload begun (reference packed)" : "upload + pack (both strands)");
+    mark(packedUpload ? "packed upload + reverse strands" : asyncUpload ? "upload begun (reference packed)" : "upload + pack (both strands)");
     seedThread.join();
     mark("AddSingleSeeds (waited for)");
     rc = dp_round_begin(ctx, k, index.seedMap.data(), (uint32_t)index.seedMap.size());

@@ -1579,4 +1579,47 @@ bool ArgTable::parse(int argc, char** argv, std::string& err) {
     return true;
 }
 
+
+// ---- packBytes for a whole read (sequence/sequence.go:59-93): 2 bits per base, ((b >> 1) ^ ((b & 4) >> 2)) & 3, four bases per byte with
+// the first in the top bits, the last byte's unused bits zero.  `map` hands its reads to the device this way (host_map.cpp): a
+// quarter of the bytes over PCIe.  dst receives ceil(n / 4) bytes.
+namespace {
+size_t packScalar(const unsigned char* src, size_t n, uint8_t* dst) {  // whole groups of four; returns the bases consumed
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4)
+        dst[i / 4] = (uint8_t)((baseCode(src[i]) << 6) | (baseCode(src[i + 1]) << 4) | (baseCode(src[i + 2]) << 2) | baseCode(src[i + 3]));
+    return i;
+}
+__attribute__((target("avx2"))) inline __m256i packCodes32(const unsigned char* p) {  // 32 bases -> one packed byte per 32-bit lane
+    const __m256i x = _mm256_loadu_si256((const __m256i*)p);
+    const __m256i a = _mm256_and_si256(_mm256_srli_epi16(x, 1), _mm256_set1_epi8(0x7f));    // b >> 1
+    const __m256i b = _mm256_srli_epi16(_mm256_and_si256(x, _mm256_set1_epi8(4)), 2);       // (b & 4) >> 2
+    const __m256i c = _mm256_and_si256(_mm256_xor_si256(a, b), _mm256_set1_epi8(3));
+    // per byte pair (first, second): x 4, x 1; then per 16-bit pair: x 16, x 1
+    return _mm256_madd_epi16(_mm256_maddubs_epi16(c, _mm256_set1_epi16(0x0104)), _mm256_set1_epi32(0x00010010));
+}
+__attribute__((target("avx2"))) size_t packAvx2(const unsigned char* src, size_t n, uint8_t* dst) {  // 128 bases -> 32 bytes per step
+    const __m256i order = _mm256_setr_epi32(0, 4, 1, 5, 2, 6, 3, 7);
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i p01 = _mm256_packus_epi32(packCodes32(src + i), packCodes32(src + i + 32));
+        const __m256i p23 = _mm256_packus_epi32(packCodes32(src + i + 64), packCodes32(src + i + 96));
+        const __m256i q = _mm256_permutevar8x32_epi32(_mm256_packus_epi16(p01, p23), order);
+        _mm256_storeu_si256((__m256i*)(dst + i / 4), q);
+    }
+    return i;
+}
+}  // namespace
+void packBases(const char* src, size_t n, uint8_t* dst, bool scalarOnly) {
+    const bool avx2 = !scalarOnly && __builtin_cpu_supports("avx2");
+    const unsigned char* s = (const unsigned char*)src;
+    size_t i = avx2 ? packAvx2(s, n, dst) : 0;
+    i += packScalar(s + i, n - i, dst + i / 4);
+    if (i < n) {  // one to three bases in the last byte
+        uint32_t v = 0;
+        for (size_t j = 0; j < 4; j++) v = (v << 2) | (i + j < n ? baseCode(s[i + j]) : 0u);
+        dst[i / 4] = (uint8_t)v;
+    }
+}
+
 }  // namespace dph

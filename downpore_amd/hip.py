@@ -55,7 +55,7 @@ SYMBOLS = ["dp_version", "dp_ctx_create", "dp_ctx_create_shared", "dp_ctx_set_pr
            "dp_find_overlaps", "dp_query_prestage", "dp_map_windows", "dp_index_posting_row", "dp_index_seedset_row", "dp_scan_device_buffers",
            "dp_scan_import_segments", "dp_values_upload", "dp_select_seeds", "dp_reads_upload_rc", "dp_consensus_align", "dp_scan_release", "dp_consensus_paf", "dp_fetch_overlaps", "dp_select_windows", "dp_values_download",
     "dp_values_download_codes", "dp_values_download_codes8", "dp_index_build_chunked", "dp_index_prechain", "dp_index_prechained", "dp_index_chunks", "dp_scan_fetch_mode", "dp_scan_fetch_segments", "dp_set_stream_wait", "dp_set_kernel_timing", "dp_index_meta", "dp_index_set_global", "dp_map_windows_shard", "dp_single_seed_candidates", "dp_comm_unique_id", "dp_comm_init", "dp_comm_init_local", "dp_quality_upload",
-           "dp_comm_destroy", "dp_comm_abort", "dp_allgather_blobs", "dp_gather_blobs", "dp_kindex_set_comm", "dp_kindex_digest", "dp_release_device_caches", "dp_reads_upload_rc_begin", "dp_reads_upload_wait", "dp_comm_rank", "dp_comm_size", "dp_allgather_survivors"]
+           "dp_comm_destroy", "dp_comm_abort", "dp_allgather_blobs", "dp_gather_blobs", "dp_kindex_set_comm", "dp_kindex_digest", "dp_release_device_caches", "dp_reads_upload_rc_begin", "dp_reads_upload_wait", "dp_reads_upload_packed_rc", "dp_host_alloc", "dp_host_free", "dp_comm_rank", "dp_comm_size", "dp_allgather_survivors"]
 
 _lib = None
 
@@ -148,6 +148,30 @@ class Context:
         self.L.dp_reads_upload_rc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         self._chk(self.L.dp_reads_upload_rc(self.h, bases.ctypes.data, off.ctypes.data, len(off) - 1, first_paired))
         ln = np.diff(off).astype(np.int64)
+        self.read_len = np.concatenate([ln[:first_paired], np.repeat(ln[first_paired:], 2)])
+
+    def upload_reads_packed_rc(self, packed, lens, first_paired, pinned=False):
+        """The reads arrive 2-bit packed (read r at the sum of the 16-byte-rounded packed sizes before it); pinned: through a block of
+        dp_host_alloc, as the mapper does."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        self.L.dp_reads_upload_packed_rc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        self.L.dp_host_alloc.restype = C.c_void_p
+        self.L.dp_host_alloc.argtypes = [C.c_size_t]
+        self.L.dp_host_free.argtypes = [C.c_void_p]
+        blk = None
+        ptr = packed.ctypes.data
+        if pinned:
+            blk = self.L.dp_host_alloc(max(1, packed.size))
+            assert blk
+            C.memmove(blk, packed.ctypes.data, packed.size)
+            ptr = blk
+        try:
+            self._chk(self.L.dp_reads_upload_packed_rc(self.h, ptr, lens.ctypes.data, len(lens), first_paired))
+        finally:
+            if blk:
+                self.L.dp_host_free(blk)
+        ln = lens.astype(np.int64)
         self.read_len = np.concatenate([ln[:first_paired], np.repeat(ln[first_paired:], 2)])
 
     def packed_read(self, r):

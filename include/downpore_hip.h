@@ -21,6 +21,7 @@
 #ifndef DOWNPORE_HIP_H
 #define DOWNPORE_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -85,6 +86,17 @@ DP_API int dp_reads_upload(dp_ctx* ctx, const uint8_t* bases, const int64_t* off
  * query window on both strands (mapping.go:497-499); the reverse strands are produced by the pack kernel instead of
  * being built on the host and sent over PCIe. */
 DP_API int dp_reads_upload_rc(dp_ctx* ctx, const uint8_t* bases, const int64_t* off, uint32_t n_reads, uint32_t first_paired);
+/* dp_reads_upload_rc for a host that holds its reads the way the reference does - packed (sequence.packedSequence,
+ * sequence/sequence.go:22-31: 2 bits per base, ceil(len / 4) bytes, first base in a byte's top bits, made by packBytes when the file is
+ * read) - so that a quarter of the bytes cross PCIe: `packed` holds the reads one after another, read r at the sum over the reads before
+ * it of ceil(lens[r'] / 4) rounded up to a multiple of 16 bytes (the device's own layout of a forward-only read set); the padding bytes
+ * are not looked at.  The device puts the reads in place and makes the reverse strands of the reads >= first_paired from the packed
+ * forward ones (sequence.go:179-198).  From memory of dp_host_alloc (pinned) the bytes travel in one copy, from anywhere else through
+ * the staging ring of dp_reads_upload. */
+DP_API int dp_reads_upload_packed_rc(dp_ctx* ctx, const uint8_t* packed, const uint32_t* lens, uint32_t n_reads, uint32_t first_paired);
+/* Pinned host memory from the library's block cache (kept across contexts up to DP_PIN_CACHE_MB; NULL: none to be had). */
+DP_API void* dp_host_alloc(size_t bytes);
+DP_API void dp_host_free(void* p);
 /* dp_reads_upload_rc that returns while the reads still travel (round 5: `map` maps its first reads while its last ones are on the link -
  * 400 MB of ASCII are 11 ms of a 59 ms config-3 run).  The call itself makes the new read set's tables resident and returns once host
  * reads [0, ready_first) are packed on the device, both strands; a thread of the library sends the rest on piece by piece, on a stream

@@ -154,6 +154,9 @@ DPH_API void dph_values_from_counts(uint64_t* counts, int k, double* out);
  *                          each resumed `yields` times; returns the sum of id x yields over the tasks, -1 if a frame came back damaged.
  */
 DPH_API long dph_test_coroutines(int n_tasks, int yields);
+/* packBytes of a whole read as `map` hands its reads to the device (sequence/sequence.go:59-93); out: ceil(n / 4) bytes; scalar_only:
+   without the AVX2 path */
+DPH_API void dph_pack_bases(const char* bases, int64_t n, uint8_t* out, int scalar_only);
 DPH_API int dph_hand_is_consistent(const int64_t* left5, const int64_t* right4, int circular, int64_t ref_len);
 DPH_API int dph_hand_remove_dominated(const int64_t* maps3, int n, int64_t query_len, int* kept);
 DPH_API void dph_hand_trim_indices(int upto, const int32_t* match_a, const int64_t* off, int n_matches, int min_match, int length, int* out2);

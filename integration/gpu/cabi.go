@@ -133,6 +133,33 @@ func (c *Context) UploadReadsRC(bases []byte, off []int64, firstPaired int) erro
 	return nil
 }
 
+// UploadReadsPackedRC is UploadReadsRC for reads held the way sequence.packedSequence holds them (2 bits per base, first base in a
+// byte's top bits): packed = the reads' bytes one after another, every read on a 16-byte boundary (PackedLayout gives the offsets);
+// a quarter of UploadReadsRC's bytes cross PCIe.
+func (c *Context) UploadReadsPackedRC(packed []byte, lens []uint32, firstPaired int) error {
+	if len(lens) == 0 {
+		return errors.New("UploadReadsPackedRC: no reads")
+	}
+	var bp *C.uint8_t
+	if len(packed) > 0 {
+		bp = (*C.uint8_t)(unsafe.Pointer(&packed[0]))
+	}
+	rc := C.dp_reads_upload_packed_rc(c.h, bp, (*C.uint32_t)(unsafe.Pointer(&lens[0])), C.uint32_t(len(lens)), C.uint32_t(firstPaired))
+	if rc != 0 {
+		return fail(c.h, "dp_reads_upload_packed_rc", rc)
+	}
+	return nil
+}
+
+// PackedLayout returns where read r starts in the buffer UploadReadsPackedRC takes (off[len(lens)] = its size).
+func PackedLayout(lens []uint32) []int64 {
+	off := make([]int64, len(lens)+1)
+	for r, l := range lens {
+		off[r+1] = off[r] + (int64(l+3)/4+15)&^15
+	}
+	return off
+}
+
 // UploadReadsRCBegin is UploadReadsRC that returns while the reads still travel: the read set's tables are resident and host reads
 // [0, readyFirst) packed when it returns, a thread of the library sends the rest on.  Kernels may only be given
 // reads a WaitReads has covered.  The library's thread reads `bases` after this call has returned: the binding pins the slice's array

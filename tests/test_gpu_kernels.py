@@ -68,6 +68,39 @@ def test_pack_reverse_complement_pairs(ctx):
             dev += 1
 
 
+def test_packed_upload_places_reads_and_makes_reverse_strands(ctx):
+    """dp_reads_upload_packed_rc (round 6): the host hands the reads over 2-bit packed, every read on a 16-byte boundary; the device puts
+    them in place and makes the reverse strands from the packed forward ones.  Every device read must equal what dp_reads_upload_rc
+    makes from the ASCII - lengths around every multiple of 4, 16 and 64, empty reads, any byte as a base, garbage in the padding and in
+    the last byte's unused bits, from pageable memory (staged) and from a block of dp_host_alloc (one copy)."""
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 66, 67, 68, 127, 128, 129, 255, 256, 257, 1000, 4099, 0, 7] + list(rng.integers(1, 3000, 60))
+    alphabet = np.frombuffer(b"ACGTacgtNRY", dtype=np.uint8)
+    reads = [alphabet[rng.integers(0, len(alphabet), n)] if i % 3 else rng.integers(0, 256, n, dtype=np.uint8) for i, n in enumerate(lens)]
+    bases = np.concatenate(reads).astype(np.uint8)
+    off = np.cumsum([0] + lens).astype(np.int64)
+    for first_paired in (2, 0, len(lens)):
+        ctx.upload_reads_rc(bases, off, first_paired)
+        n_dev = first_paired + 2 * (len(lens) - first_paired)
+        want = [bytes(ctx.packed_read(d)) for d in range(n_dev)]
+        poff = [0]
+        for n in lens:
+            poff.append(poff[-1] + (((n + 3) // 4 + 15) & ~15))
+        packed = rng.integers(0, 256, poff[-1], dtype=np.uint8)   # garbage wherever no base is
+        for r, b in enumerate(reads):
+            n = len(b)
+            if n:
+                pk = np.array(O.Seq(h=O.lib().dpo_seq_new(b.tobytes(), n)).bytes())
+                if n % 4:
+                    pk[-1] |= int(rng.integers(0, 256)) & ((1 << (2 * (4 - n % 4))) - 1)
+                packed[poff[r]:poff[r] + len(pk)] = pk
+        for pinned in (False, True):
+            ctx.upload_reads_packed_rc(packed, np.array(lens, dtype=np.uint32), first_paired, pinned=pinned)
+            got = [bytes(ctx.packed_read(d)) for d in range(n_dev)]
+            bad = [d for d in range(n_dev) if got[d] != want[d]]
+            assert not bad, (first_paired, pinned, bad[:5])
+
+
 def test_histogram(ctx):
     bases, off = O.gen_reads(12, 50000, 200, 1500, 0.01, True)
     ctx.upload_reads(bases, off)

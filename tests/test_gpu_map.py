@@ -67,6 +67,19 @@ def test_map_single_seeds_host_walk_agrees(monkeypatch):
     monkeypatch.delenv("DP_TUNE")
 
 
+def test_map_reads_travel_packed_or_as_ascii(monkeypatch):
+    """The mapper packs its reads on the host (AVX2 or scalar, the worker pool) and hands them to dp_reads_upload_packed_rc (round 6);
+    DP_TUNE=map_ascii_upload=1 sends the ASCII and packs on the device as before.  The oracle's PAF every way - read lengths of every
+    length mod 4, reads shorter than a window, a circular and a linear reference."""
+    cases = [(4, 150001, 300, 5000, 0.05, True, True), (4, 150002, 300, 700, 0.02, True, False)]
+    for tune in ("", "pack_scalar=1", "map_ascii_upload=1"):
+        if tune:
+            monkeypatch.setenv("DP_TUNE", tune)
+        for c in cases:
+            _case(*c, short_reads=True)
+    monkeypatch.delenv("DP_TUNE")
+
+
 def test_map_threads_reads_in_flight_and_parked_blocks(monkeypatch):
     """The mapper deals its reads to host threads (DP_MAP_THREADS, default 4) that keep DP_MAP_INFLIGHT reads in flight each (one window
     per read and dp_map_windows call); the contexts of a finished run park their device and pinned blocks in the library's cache and the
