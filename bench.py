@@ -87,9 +87,9 @@ def main():
                          "in every round), reported as overlap_default_k10_job with ground truth and first-16-round fixture parity (0 = skip)")
     ap.add_argument("--map-cpu-baseline", type=int, default=1,
                     help="map_config3: also time the oracle's mapper on the host (about 5 s, one core) as its cpu_baseline (0 = skip)")
-    ap.add_argument("--map-leg-repeats", type=int, default=3,
+    ap.add_argument("--map-leg-repeats", type=int, default=8,
                     help="N=1: after the timed region, BASELINE config 3 (`downpore map`: 50k reads x 8 kb against a 4.6 Mb circular "
-                         "reference, k=11) this many times, reported as map_config3 with its PAF held to the oracle's fixture (0 = skip)")
+                         "reference, k=11) this many times (value = the median of the runs after the first), reported as map_config3 with its PAF held to the oracle's fixture (0 = skip)")
     ap.add_argument("--mode", default="auto", choices=["auto", "round", "round-batch", "scan-shard"],
                     help="multi-GPU decomposition (N > 1).  scan-shard: every rank runs every round on its own read range and the "
                          "survivors' seed index is all-gathered (RCCL, inside the library) - the layout for read sets that do not fit "
@@ -722,7 +722,7 @@ def map_config3_leg(repeats, cpu=True):
     bases, off, t_starts, t_strands = gen_reads_truth(gen["seed"], gen["genome"], gen["reads"], gen["read_len"], gen["error"], False)
     ref = Reads(genome, goff, min_len=0, himem=False)
     reads = Reads(bases, off, min_len=500, himem=False)
-    best, runs, ok, st, truth = None, [], True, None, None
+    best, runs, ok, st, truth, all_st = None, [], True, None, None, []
     for _ in range(repeats):
         t0 = time.perf_counter()
         paf, err, st_ = map_reads(ref, reads, circular=True, k=g["k"])
@@ -730,12 +730,17 @@ def map_config3_leg(repeats, cpu=True):
         runs.append(dt)
         ok = ok and paf.count("\n") == g["paf_lines"] and hashlib.sha256(paf.encode()).hexdigest() == g["paf_sha256"] and err == g["stderr"]
         if best is None or dt < best:
-            best, st = dt, st_
+            best = dt
+        all_st.append((dt, st_))
         if truth is None:  # the mappings held to where the generator took the reads from (the reference's own quality figures: README.md:220-237)
             truth = map_truth(paf, off, t_starts, t_strands, gen["genome"])
         del paf
     n = gen["reads"]
     total_bases = float(off[-1])
+    # the figure is the MEDIAN of the runs after the process's first (which pays for the library's first pinned and device blocks);
+    # best and every run are listed beside it
+    timed = sorted(all_st[1:] if len(all_st) > 1 else all_st, key=lambda x: x[0])
+    median, st = timed[len(timed) // 2]
     cpu_wanted_flag, cpu = cpu_wanted(cpu), None
     if cpu_wanted_flag:
         from tests import oracle_lib as O
@@ -753,7 +758,8 @@ def map_config3_leg(repeats, cpu=True):
     alg = st.get("map_bytes", 0.0) + st.get("scan_bytes", 0.0)
     return {"workload": "downpore map, BASELINE config 3: %d reads x %d bp (error %.2f) against a %d bp circular reference, k=%d; whole "
                         "command from reads in host memory to the last PAF line" % (n, gen["read_len"], gen["error"], gen["genome"], g["k"]),
-            "value": n / best, "unit": "reads/s", "wall_s_best": best, "wall_s_runs": runs, "read_bases_per_s": total_bases / best,
+            "value": n / median, "unit": "reads/s", "value_is": "median of the %d runs after the first" % len(timed), "wall_s_median": median,
+            "wall_s_best": best, "best_reads_per_s": n / best, "wall_s_runs": runs, "read_bases_per_s": total_bases / median,
             "paf_sha256_matches_oracle_fixture": bool(ok), "fixture": g["case"],
             "ground_truth": truth, "cpu_baseline": cpu,
             "roofline": {"bound": "hbm", "kernels": "scan_kernel (window scans) + query_kernel + map_kernel", "achieved": (alg / 1e9) / (k_ms / 1e3) if k_ms > 0 else 0.0,
