@@ -10,7 +10,7 @@ Kernels with scattered narrow reads are uncalibrated: for them the corrected fig
 import collections, csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r05")
+ROUND = os.environ.get("ROUND", "r06")
 R = os.path.join(ROOT, "gpurun_out", ROUND)
 OUT = os.path.join(ROOT, "profiles", ROUND)
 os.makedirs(OUT, exist_ok=True)
@@ -76,6 +76,8 @@ for w in WORK:
     allw[w] = s
     json.dump({"workload": WORK[w], "note": NOTE, "kernels": s}, open(os.path.join(OUT, "pmc_%s.json" % w), "w"), indent=1, sort_keys=True)
     print("profiles/%s/pmc_%s.json: %d kernels" % (ROUND, w, len(s)))
+    if w == "dense":  # (bench.py's k = 10 job quotes this file per kernel: overlap_default_k10_job.hbm_traffic_per_launch)
+        json.dump({"workload": WORK[w], "note": NOTE, "kernels": s}, open(os.path.join(OUT, "pmc_k10.json"), "w"), indent=1, sort_keys=True)
 
 
 def per_round(s, kernels, rounds_of):
@@ -113,7 +115,12 @@ traffic("kindex_traffic.json", "main", "index-mode counting step (kidx_prepare +
 traffic("kindex_write_traffic.json", "main", "index-mode write step (kidx_bin_fill [round 4: kidx_fill_rec] / kidx_walk<true> + kidx_sortwrite)",
         ["kidx_bin_fill", "kidx_fill_rec", "kidx_walk<true>", "kidx_sortwrite"], "kidx_offsets")
 traffic("dense_kindex_traffic.json", "dense", "index-mode counting + write steps at k = 10 (all kidx_* kernels)",
-        ["kidx_prepare", "kidx_walk_bin", "kidx_bin_count", "kidx_walk<false>", "kidx_offsets", "kidx_bin_fill", "kidx_fill_rec", "kidx_walk<true>", "kidx_sortwrite"], "kidx_offsets")
+        ["kidx_prepare", "kidx_walk_bin", "kidx_bin_count", "kidx_walk<false>", "kidx_offsets", "kidx_bin_fill", "kidx_fill_rec", "kidx_walk<true>", "kidx_sortwrite",
+         "kidx_bin_sort_dense"], "kidx_offsets")
+INDEX = ["chunk_kernel", "index_fill_kernel", "index_fill_rows_kernel", "posting_transpose_kernel", "posting_meta_kernel", "zero_regions_kernel"]
+traffic("index_build_traffic.json", "main", "index build of a round (chunk + index_fill(_rows) + posting_transpose + posting_meta + zero_regions)", INDEX, "pair_scan_kernel")
+traffic("dense_index_build_traffic.json", "dense", "index build of a round at k = 10 (chunk + index_fill_rows + posting_transpose + posting_meta + zero_regions)", INDEX, "pair_scan_kernel")
+traffic("dense_chain_traffic.json", "dense", "chaining stage at k = 10", CHAIN, "pair_scan_kernel")
 traffic("consensus_traffic.json", "main", "consensus_full_kernel (all layouts)", ["consensus_full_kernel"], "pair_scan_kernel")
 traffic("scan_traffic.json", "scan", "scan_kernel<0, 2> (count pass)", ["scan_kernel<0, 2>"], "scan_kernel<0, 2>")
 traffic("dense_query_traffic.json", "dense", "query_kernel<false>, k=10", ["query_kernel"], "query_kernel<false>")
