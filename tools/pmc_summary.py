@@ -26,6 +26,10 @@ def short(name):
     if "rocprim" in n:
         n = "rocprim::" + n.split("::")[-1][:60]
     n = n.strip()
+    if n.startswith("dp_kernel<"):  # round 6: per-round kernels are dp_kernel<kernel> (dp_launch.h): the kernel's own name
+        n = n[len("dp_kernel<"):].rstrip()
+        if n.endswith(">"):
+            n = n[:-1].rstrip()
     if n.startswith("dp_multi<"):  # per-round kernels are dp_multi<kernel, N> (N = rounds the launch can carry): the kernel's own name
         n = n[len("dp_multi<"):]
         n = n[:n.rfind(",")] if "," in n else n.rstrip(">")
@@ -109,7 +113,7 @@ def traffic(fn, workload, desc, kernels, rounds_of):
 
 CHAIN = ["pair_scan_kernel", "chain_walk_kernel", "chain_spec_kernel", "chain_resolve_kernel", "match_anchor_kernel"]
 traffic("chain_traffic.json", "main", "chaining stage (pair_scan + chain_walk + chain_spec + chain_resolve + match_anchor)", CHAIN, "pair_scan_kernel")
-traffic("query_traffic.json", "main", "query_kernel<false> (+ <true> where launched)", ["query_kernel"], "query_kernel<false>")
+traffic("query_traffic.json", "main", "query_kernel<false> (+ <true> where launched)", ["query_kernel"], "pair_scan_kernel")
 traffic("kindex_traffic.json", "main", "index-mode counting step (kidx_prepare + kidx_walk_bin + kidx_bin_count [round 4: kidx_walk<false>] + kidx_offsets)",
         ["kidx_prepare", "kidx_walk_bin", "kidx_bin_count", "kidx_walk<false>", "kidx_offsets"], "kidx_offsets")
 traffic("kindex_write_traffic.json", "main", "index-mode write step (kidx_bin_fill [round 4: kidx_fill_rec] / kidx_walk<true> + kidx_sortwrite)",
@@ -123,7 +127,7 @@ traffic("dense_index_build_traffic.json", "dense", "index build of a round at k 
 traffic("dense_chain_traffic.json", "dense", "chaining stage at k = 10", CHAIN, "pair_scan_kernel")
 traffic("consensus_traffic.json", "main", "consensus_full_kernel (all layouts)", ["consensus_full_kernel"], "pair_scan_kernel")
 traffic("scan_traffic.json", "scan", "scan_kernel<0, 2> (count pass)", ["scan_kernel<0, 2>"], "scan_kernel<0, 2>")
-traffic("dense_query_traffic.json", "dense", "query_kernel<false>, k=10", ["query_kernel"], "query_kernel<false>")
+traffic("dense_query_traffic.json", "dense", "query_kernel<false>, k=10", ["query_kernel"], "pair_scan_kernel")
 if "main" in allw:
     for k in ("pack_kernel", "kb_part1", "kb_part2", "kb_final", "kb_count1", "kb_count2"):
         d = allw["main"].get(k)
