@@ -847,13 +847,19 @@ struct kidx_walk_bin {
         // entries, a workgroup trip 2 - 4 seeds - a few records per bin and trip, each stretch a returning atomic and a short run of
         // stores; eight trips a reservation are eight times fewer atomics and runs eight times as long).  Trips behind the first read
         // their entries again in the second pass (from the L2).
-        const uint32_t T = max(1u, B.batch);
+        const uint32_t T = min(32u, max(1u, B.batch));  // (the table below holds 32 trips)
         // the groups of kidx_walk: KX_PARTS waves per seed (dense seeds), or four seeds per wave
         struct Grp {
             uint32_t s, i0, i1, step, gfirst;
             uint64_t o;
             bool gleader;
         };
+        // Round 6: where a seed's bucket starts and how long it is comes from an LDS table the whole workgroup fills at once, for
+        // every trip of the reservation (lps == 64: a wave per quarter bucket) - two dependent loads less in front of every trip's
+        // entries - and the entries of the next trip are asked for before the current trip's are worked on (below)
+        __shared__ unsigned long long t_o[WAVES * 32 / KX_PARTS + 2];
+        __shared__ uint32_t t_n[WAVES * 32 / KX_PARTS + 2];
+        uint32_t t_first = 0u;  // seed of the table's first row
         auto group_of = [&](uint32_t w) {
             Grp g = {0u, 0u, 0u, 16u, 0u, 0ull, false};
             if (w < n_waves) {
@@ -861,8 +867,8 @@ struct kidx_walk_bin {
                     g.s = w / KX_PARTS;
                     if (g.s < n_seeds) {
                         const uint32_t part = w % KX_PARTS;
-                        g.o = off[seeds[g.s]];
-                        const uint32_t n = (uint32_t)(off[(uint64_t)seeds[g.s] + 1] - g.o);
+                        g.o = t_o[g.s - t_first];
+                        const uint32_t n = t_n[g.s - t_first];
                         const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
                         g.gfirst = min(n, part * per);
                         g.i0 = part * per + 4u * (uint32_t)lane;
@@ -889,34 +895,65 @@ struct kidx_walk_bin {
                 sh_hits = 0ull;
                 xs[0] = xs[1] = 0u;
             }
+            if (lps == 64) {
+                t_first = wb / KX_PARTS;
+                const uint32_t rows = (WAVES * min(T, 32u) + KX_PARTS - 1) / KX_PARTS + 1u;
+                for (uint32_t t = threadIdx.x; t < rows; t += THREADS) {
+                    const uint32_t sd = t_first + t;
+                    unsigned long long o = 0ull;
+                    uint32_t n = 0u;
+                    if (sd < n_seeds) {
+                        const uint32_t km = seeds[sd];
+                        o = off[km];
+                        n = (uint32_t)(off[(uint64_t)km + 1] - o);
+                    }
+                    t_o[t] = o;
+                    t_n[t] = n;
+                }
+            }
             __syncthreads();
             // the lane's first four entries of the FIRST trip stay in registers across the barriers (a seed of config 2 has 20 - 60
             // entries: for most groups the first trip is the only one, and the second pass reads nothing)
             uint64_t e0[4] = {0, 0, 0, 0};
             bool v0[4] = {false, false, false, false};
-            for (uint32_t tr = 0; tr < T; tr++) {
-                const uint32_t w = wb + tr * WAVES + (threadIdx.x >> 6);
-                const Grp g = group_of(w);
-                if (g.gleader && g.i1 > g.gfirst) atomicAdd(&sh_hits, (unsigned long long)(g.i1 - g.gfirst));
+            {
+                Grp g = group_of(wb + (threadIdx.x >> 6));
                 uint64_t e[4] = {0, 0, 0, 0};
-                bool v[4] = {false, false, false, false};
-                if (g.i0 < g.i1) {
-                    kx_entry4(pos, g.o + g.i0, e);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        v[u] = g.i0 + (uint32_t)u < g.i1;
-                        e[u] = v[u] ? e[u] : 0ull;
+                if (g.i0 < g.i1) kx_entry4(pos, g.o + g.i0, e);
+                for (uint32_t tr = 0; tr < T; tr++) {
+                    const uint32_t w = wb + tr * WAVES + (threadIdx.x >> 6);
+                    // the next trip's entries are on their way while this trip's are counted
+                    Grp gn = g;
+                    uint64_t en[4] = {0, 0, 0, 0};
+                    if (tr + 1 < T) {
+                        gn = group_of(w + WAVES);
+                        if (gn.i0 < gn.i1) kx_entry4(pos, gn.o + gn.i0, en);
                     }
-                    four<false>(e, v, g.s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
-                }
-                if (tr == 0) {
+                    if (g.gleader && g.i1 > g.gfirst) atomicAdd(&sh_hits, (unsigned long long)(g.i1 - g.gfirst));
+                    bool v[4] = {false, false, false, false};
+                    if (g.i0 < g.i1) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        e0[u] = e[u];
-                        v0[u] = v[u];
+                        for (int u = 0; u < 4; u++) {
+                            v[u] = g.i0 + (uint32_t)u < g.i1;
+                            e[u] = v[u] ? e[u] : 0ull;
+                        }
+                        four<false>(e, v, g.s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) e[u] = 0ull;
                     }
+                    if (tr == 0) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            e0[u] = e[u];
+                            v0[u] = v[u];
+                        }
+                    }
+                    tail<false>(lps, lane, w, g.s, g.o, g.i0, g.i1, g.step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+                    g = gn;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) e[u] = en[u];
                 }
-                tail<false>(lps, lane, w, g.s, g.o, g.i0, g.i1, g.step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
             }
             __syncthreads();
             for (uint32_t t = threadIdx.x; t < B.n_bins; t += THREADS) {
@@ -949,25 +986,35 @@ struct kidx_walk_bin {
                 xs[0] = 0u;
             }
             __syncthreads();
-            for (uint32_t tr = 0; tr < T; tr++) {
-                const uint32_t w = wb + tr * WAVES + (threadIdx.x >> 6);
-                const Grp g = group_of(w);
-                if (g.i0 < g.i1) {
-                    if (tr == 0) {
-                        four<true>(e0, v0, g.s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
-                    } else {
-                        uint64_t e[4];
-                        bool v[4];
-                        kx_entry4(pos, g.o + g.i0, e);
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            v[u] = g.i0 + (uint32_t)u < g.i1;
-                            e[u] = v[u] ? e[u] : 0ull;
-                        }
-                        four<true>(e, v, g.s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+            {
+                Grp g = group_of(wb + (threadIdx.x >> 6));
+                uint64_t e[4] = {0, 0, 0, 0};
+                for (uint32_t tr = 0; tr < T; tr++) {
+                    const uint32_t w = wb + tr * WAVES + (threadIdx.x >> 6);
+                    Grp gn = g;
+                    uint64_t en[4] = {0, 0, 0, 0};
+                    if (tr + 1 < T) {  // (the first trip's entries waited in registers; every later trip's are read again - from the L2 - a trip ahead)
+                        gn = group_of(w + WAVES);
+                        if (gn.i0 < gn.i1) kx_entry4(pos, gn.o + gn.i0, en);
                     }
+                    if (g.i0 < g.i1) {
+                        if (tr == 0) {
+                            four<true>(e0, v0, g.s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+                        } else {
+                            bool v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                v[u] = g.i0 + (uint32_t)u < g.i1;
+                                e[u] = v[u] ? e[u] : 0ull;
+                            }
+                            four<true>(e, v, g.s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+                        }
+                    }
+                    tail<true>(lps, lane, w, g.s, g.o, g.i0, g.i1, g.step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+                    g = gn;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) e[u] = en[u];
                 }
-                tail<true>(lps, lane, w, g.s, g.o, g.i0, g.i1, g.step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
             }
             __syncthreads();
         }
@@ -1379,31 +1426,36 @@ struct kidx_bin_sort_dense {
     enum { THREADS = 512, WAVES = 8, RBMAX = 256, XBLOCKS = 8, MAXC = 1024, RPL = MAXC / 64 };
     // c <= 64 R keys of one read, sorted in place by one wave: every key counts the keys below it (broadcast reads of the stretch), the
     // ranks wait in registers until the wave has read everything, then the keys go to their ranks
+    // (a read's hits lie at distinct positions - one k-mer starts at a position - so the position, the key's upper word, ranks alone:
+    // 32-bit compares at full rate where the 64-bit ones took two issue slots each; the kernel is bound by exactly these - 65 M vector
+    // instructions a launch at k = 10, profiles/r06/pmc_k10.json)
     template <int R>
     static __device__ __forceinline__ void rank_in_place(unsigned long long* my, const uint32_t c, const int lane) {
         unsigned long long key[R];
-        uint32_t rk[R];
+        uint32_t kp[R], rk[R];
+        const uint32_t* pos = (const uint32_t*)my + 1;  // position of record l: pos[2 l]
 #pragma unroll
         for (int u = 0; u < R; u++) {
             const uint32_t j = (uint32_t)lane + 64u * (uint32_t)u;
             key[u] = j < c ? my[j] : ~0ull;
+            kp[u] = (uint32_t)(key[u] >> 32);
             rk[u] = 0u;
         }
         uint32_t l = 0;
         for (; l + 8 <= c; l += 8) {  // (eight broadcast reads in flight: one read at a time is a trip through the LDS per key)
-            unsigned long long o[8];
+            uint32_t o[8];
 #pragma unroll
-            for (int x = 0; x < 8; x++) o[x] = my[l + x];
+            for (int x = 0; x < 8; x++) o[x] = pos[2u * (l + (uint32_t)x)];
 #pragma unroll
             for (int x = 0; x < 8; x++) {
 #pragma unroll
-                for (int u = 0; u < R; u++) rk[u] += o[x] < key[u] ? 1u : 0u;
+                for (int u = 0; u < R; u++) rk[u] += o[x] < kp[u] ? 1u : 0u;
             }
         }
         for (; l < c; l++) {
-            const unsigned long long o = my[l];
+            const uint32_t o = pos[2u * l];
 #pragma unroll
-            for (int u = 0; u < R; u++) rk[u] += o < key[u] ? 1u : 0u;
+            for (int u = 0; u < R; u++) rk[u] += o < kp[u] ? 1u : 0u;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
