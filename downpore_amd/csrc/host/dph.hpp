@@ -233,7 +233,7 @@ void matchBaseIndex(const SeedMatch& m, int aIndex, int k, i64* index, i64* base
 void gapRange(i64 gap, int k, i64* mn, i64* mx);                          // seeds/alignment.go:411
 
 // seeds/alignment.go:23-268
-SeedSeq* multiAlignerConsensus(Arena& a, std::vector<SeedSeq*>& seqs, int k, std::vector<std::unique_ptr<SeedMatch>>& out);
+SeedSeq* multiAlignerConsensus(Arena& a, std::vector<SeedSeq*>& seqs, int k, std::vector<SeedMatch*>& out);  // (the matches live in the arena)
 
 // overlap/combine.go
 struct SeedContig {

@@ -466,6 +466,36 @@ void dph_hand_trim_indices(int upto, const int32_t* match_a, const int64_t* off,
     dph::trimBestIndices(upto, ms, min_match, length, &out2[0], &out2[1]);
 }
 
+int dph_hand_consensus(const int32_t* segs, const int64_t* off, int n_seqs, int k, int32_t* cons_out, int64_t cons_cap, int64_t* cons_n,
+                       int* kept, int64_t* out_counts, int32_t* out_a, int32_t* out_b, int64_t cap, int64_t* n_matches) {
+    dph::Arena ar;
+    std::vector<dph::SeedSeq> store((size_t)n_seqs);
+    std::vector<dph::SeedSeq*> seqs;
+    for (int i = 0; i < n_seqs; i++) {
+        store[(size_t)i].seg = segs + off[i];
+        store[(size_t)i].n = (int)(off[i + 1] - off[i]);
+        store[(size_t)i].id = i;
+        seqs.push_back(&store[(size_t)i]);
+    }
+    std::vector<dph::SeedMatch*> ms;
+    dph::SeedSeq* cons = dph::multiAlignerConsensus(ar, seqs, k, ms);
+    if (!cons || cons->n > cons_cap) return -1;
+    for (int i = 0; i < cons->n; i++) cons_out[i] = cons->seg[i];
+    *cons_n = cons->n;
+    *n_matches = (int64_t)ms.size();
+    int64_t at = 0;
+    for (size_t j = 0; j < ms.size(); j++) {
+        kept[j] = ms[j]->SeqB ? ms[j]->SeqB->id : -1;
+        out_counts[j] = (int64_t)ms[j]->MatchA.size();
+        for (size_t x = 0; x < ms[j]->MatchA.size(); x++) {
+            if (at >= cap) return -1;
+            out_a[at] = ms[j]->MatchA[x];
+            out_b[at] = ms[j]->MatchB[x];
+            at++;
+        }
+    }
+    return 0;
+}
 void dph_pack_bases(const char* bases, int64_t n, uint8_t* out, int scalar_only) { dph::packBases(bases, (size_t)n, out, scalar_only != 0); }
 long dph_test_coroutines(int n_tasks, int yields) { return dph::coroSelfTest(n_tasks, yields); }
 

@@ -157,6 +157,10 @@ DPH_API long dph_test_coroutines(int n_tasks, int yields);
 /* packBytes of a whole read as `map` hands its reads to the device (sequence/sequence.go:59-93); out: ceil(n / 4) bytes; scalar_only:
    without the AVX2 path */
 DPH_API void dph_pack_bases(const char* bases, int64_t n, uint8_t* out, int scalar_only);
+/* multiAligner.Consensus of the host's consensus path (seeds/alignment.go:23-268) on raw segment arrays: sequence i = segs[off[i] .. off[i + 1]);
+   the consensus' segments, the indices of the sequences whose match was kept (>= 3 pairs) in the order returned, their pairs */
+DPH_API int dph_hand_consensus(const int32_t* segs, const int64_t* off, int n_seqs, int k, int32_t* cons_out, int64_t cons_cap, int64_t* cons_n,
+                               int* kept, int64_t* out_counts, int32_t* out_a, int32_t* out_b, int64_t cap, int64_t* n_matches);
 DPH_API int dph_hand_is_consistent(const int64_t* left5, const int64_t* right4, int circular, int64_t ref_len);
 DPH_API int dph_hand_remove_dominated(const int64_t* maps3, int n, int64_t query_len, int* kept);
 DPH_API void dph_hand_trim_indices(int upto, const int32_t* match_a, const int64_t* off, int n_matches, int min_match, int length, int* out2);

@@ -161,6 +161,38 @@ int dpo_match(const int64_t* seqSeg, int64_t sN, const int64_t* qSeg, int64_t qN
     });
 }
 
+// multiAligner.Consensus (seeds/alignment.go:23-268) on raw segment arrays: sequence i = segs[off[i] .. off[i + 1]).  cons_out receives the
+// consensus' segments ([dist, seed, ..., 0]); kept[] the indices of the sequences whose match survived (>= 3 pairs) in the order
+// the function returns them, their pairs one after another in outA / outB with outCounts[j] pairs each.
+int dpo_hand_consensus(const int64_t* segs, const int64_t* off, int n_seqs, int k, int64_t* cons_out, int64_t cons_cap, int64_t* cons_n,
+                       int* kept, int64_t* outCounts, int64_t* outA, int64_t* outB, int64_t cap, int64_t* nMatches) {
+    return guard([&] {
+        Arena ar;
+        std::vector<SeedSequence*> seqs;
+        for (int i = 0; i < n_seqs; i++) seqs.push_back(mkSeq(ar, segs + off[i], off[i + 1] - off[i]));
+        std::vector<std::unique_ptr<SeedMatch>> ms;
+        SeedSequence* cons = multiAlignerConsensus(ar, seqs, k, ms);
+        if ((int64_t)cons->n > cons_cap) throw std::runtime_error("dpo_hand_consensus: consensus buffer too small");
+        for (size_t i = 0; i < cons->n; i++) cons_out[i] = cons->seg()[i];
+        *cons_n = (int64_t)cons->n;
+        int64_t at = 0;
+        *nMatches = (int64_t)ms.size();
+        for (size_t j = 0; j < ms.size(); j++) {
+            int which = -1;
+            for (int i = 0; i < n_seqs; i++)
+                if (ms[j]->SeqB == seqs[(size_t)i]) which = i;
+            kept[j] = which;
+            outCounts[j] = (int64_t)ms[j]->MatchA.size();
+            for (size_t x = 0; x < ms[j]->MatchA.size(); x++) {
+                if (at >= cap) throw std::runtime_error("dpo_hand_consensus: match buffer too small");
+                outA[at] = ms[j]->MatchA[x];
+                outB[at] = ms[j]->MatchB[x];
+                at++;
+            }
+        }
+    });
+}
+
 // ---- decision rules on bare numbers (tests/test_hand_known_answers.py: answers worked by hand from the Go text) ----------------
 // chunkWorker (overlap/overlap.go:253-318) on one seed sequence; out = 5 values per piece handed to AddSequence: first seed, seeds,
 // Len(), GetOffset(), GetInset()

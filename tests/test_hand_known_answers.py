@@ -171,6 +171,61 @@ def _device_index(ctx, k, seqs, n_seeds=64):
     ctx.index_build(np.array(offs, dtype=np.uint64), np.array(ns, dtype=np.uint32))
 
 
+CONSENSUS_CASES = ["consensus_three_sequences.json", "consensus_third_sequence_skips_a_seed.json"]
+
+
+def _consensus_case(name):
+    h = hand(name)
+    names = list(h["sequences"].keys())
+    segs = [v for n in names for v in h["sequences"][n]]
+    off = np.cumsum([0] + [len(h["sequences"][n]) for n in names]).astype(np.int64)
+    return h, names, segs, off
+
+
+def _check_consensus(h, names, cons, kept, counts, a, b):
+    e = h["expect"]
+    assert cons == e["consensus"]
+    assert [names[i] for i in kept] == e["kept"]
+    at = 0
+    for j, i in enumerate(kept):
+        n = counts[j]
+        assert a[at:at + n] == e["match_a"][names[i]] and b[at:at + n] == e["match_b"][names[i]], names[i]
+        at += n
+
+
+@pytest.mark.parametrize("name", CONSENSUS_CASES)
+def test_consensus_oracle(name):
+    """multiAligner.Consensus of three sequences, worked by hand step by step (the files' derivations)."""
+    h, names, segs, off = _consensus_case(name)
+    L = O.lib()
+    L.dpo_hand_consensus.argtypes = [i64p, i64p, C.c_int, C.c_int, i64p, C.c_int64, i64p, C.POINTER(C.c_int), i64p, i64p, i64p, C.c_int64, i64p]
+    sg = np.array(segs, dtype=np.int64)
+    cons, ncons = np.zeros(64, dtype=np.int64), np.zeros(1, dtype=np.int64)
+    kept = (C.c_int * 8)()
+    counts, a, b, nm = np.zeros(8, dtype=np.int64), np.zeros(64, dtype=np.int64), np.zeros(64, dtype=np.int64), np.zeros(1, dtype=np.int64)
+    assert L.dpo_hand_consensus(_p(sg), _p(off), len(names), h["k"], _p(cons), 64, _p(ncons), kept, _p(counts), _p(a), _p(b), 64, _p(nm)) == 0
+    n = int(nm[0])
+    _check_consensus(h, names, cons[:int(ncons[0])].tolist(), [kept[j] for j in range(n)], counts[:n].tolist(), a.tolist(), b.tolist())
+
+
+@pytest.mark.parametrize("name", CONSENSUS_CASES)
+def test_consensus_host(name):
+    """The same cases through the product's host consensus (the path of windows no device layout holds)."""
+    h, names, segs, off = _consensus_case(name)
+    H = _host()
+    i32p = C.POINTER(C.c_int32)
+    H.dph_hand_consensus.argtypes = [i32p, i64p, C.c_int, C.c_int, i32p, C.c_int64, i64p, C.POINTER(C.c_int), i64p, i32p, i32p, C.c_int64, i64p]
+    sg = np.array(segs, dtype=np.int32)
+    cons, ncons = np.zeros(64, dtype=np.int32), np.zeros(1, dtype=np.int64)
+    kept = (C.c_int * 8)()
+    counts, a, b, nm = np.zeros(8, dtype=np.int64), np.zeros(64, dtype=np.int32), np.zeros(64, dtype=np.int32), np.zeros(1, dtype=np.int64)
+    rc = H.dph_hand_consensus(sg.ctypes.data_as(i32p), _p(off), len(names), h["k"], cons.ctypes.data_as(i32p), 64, _p(ncons), kept, _p(counts),
+                              a.ctypes.data_as(i32p), b.ctypes.data_as(i32p), 64, _p(nm))
+    assert rc == 0
+    n = int(nm[0])
+    _check_consensus(h, names, cons[:int(ncons[0])].tolist(), [kept[j] for j in range(n)], counts[:n].tolist(), a.tolist(), b.tolist())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["pairwise_two_chains.json", "pairwise_break_after_first_extension.json"])
 def test_pairwise_device(ctx, name):
@@ -241,3 +296,37 @@ def test_extend_chain_skip_device(ctx):
     got = [(int(out["window"][i]), int(out["target"][i]), out["match_a"][int(out["off"][i]):int(out["off"][i + 1])].tolist(),
             out["match_b"][int(out["off"][i]):int(out["off"][i + 1])].tolist()) for i in range(len(out["window"]))]
     assert got == [(0, 0, m["match_a"], m["match_b"]) for m in h["expect"]]
+
+
+class _ConsBatch(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("cons", C.POINTER(C.c_int32)), ("cons_off", C.POINTER(C.c_uint64)), ("cons_len", C.POINTER(C.c_uint32)),
+                ("match_a", C.POINTER(C.c_int32)), ("match_b", C.POINTER(C.c_int32)), ("match_len", C.POINTER(C.c_uint32)),
+                ("flags", C.POINTER(C.c_uint32)), ("kernel_ms", C.c_double)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CONSENSUS_CASES)
+def test_consensus_device(ctx, name):
+    """The same cases on the device's alignment kernel (dp_consensus_align: it takes the Reduced() sequences - here the sequences
+    themselves, every seed being shared - and returns every sequence's pairs; the caller drops the ones with fewer than three)."""
+    h, names, segs, off = _consensus_case(name)
+    sg = np.array(segs, dtype=np.int32)
+    so = off.astype(np.uint64)
+    go = np.array([0, len(names)], dtype=np.uint32)
+    out = _ConsBatch()
+    L = ctx.L
+    L.dp_consensus_align.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.POINTER(_ConsBatch)]
+    assert L.dp_consensus_align(ctx.h, sg.ctypes.data, so.ctypes.data, go.ctypes.data, 1, h["k"], C.byref(out)) == 0
+    assert out.n_groups == 1 and out.flags[0] == 0
+    cons = [out.cons[int(out.cons_off[0]) + i] for i in range(int(out.cons_len[0]))]
+    kept, counts, a, b = [], [], [], []
+    for i in range(len(names)):
+        n = int(out.match_len[i])
+        if n >= 3:   # seeds/alignment.go:258-266
+            kept.append(i)
+            counts.append(n)
+            a += [out.match_a[int(so[i]) + x] for x in range(n)]
+            b += [out.match_b[int(so[i]) + x] for x in range(n)]
+    if "C" not in h["expect"]["kept"]:
+        assert int(out.match_len[names.index("C")]) == 0
+    _check_consensus(h, names, cons, kept, counts, a, b)
