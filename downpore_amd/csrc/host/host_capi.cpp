@@ -466,6 +466,13 @@ void dph_hand_trim_indices(int upto, const int32_t* match_a, const int64_t* off,
     dph::trimBestIndices(upto, ms, min_match, length, &out2[0], &out2[1]);
 }
 
+int dph_hand_add_seeds(const char* bases, int64_t len, int k, int num_seeds, const double* values, uint32_t* seed_map, int cap) {
+    dph::SeedIndex ix(k);
+    ix.addSeeds(bases, (dph::i64)len, num_seeds, dph::ValueView(values));
+    if ((int)ix.seedMap.size() > cap) return -1;
+    for (size_t i = 0; i < ix.seedMap.size(); i++) seed_map[i] = (uint32_t)ix.seedMap[i];
+    return (int)ix.seedMap.size();
+}
 int dph_hand_consensus(const int32_t* segs, const int64_t* off, int n_seqs, int k, int32_t* cons_out, int64_t cons_cap, int64_t* cons_n,
                        int* kept, int64_t* out_counts, int32_t* out_a, int32_t* out_b, int64_t cap, int64_t* n_matches) {
     dph::Arena ar;

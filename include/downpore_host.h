@@ -157,6 +157,9 @@ DPH_API long dph_test_coroutines(int n_tasks, int yields);
 /* packBytes of a whole read as `map` hands its reads to the device (sequence/sequence.go:59-93); out: ceil(n / 4) bytes; scalar_only:
    without the AVX2 path */
 DPH_API void dph_pack_bases(const char* bases, int64_t n, uint8_t* out, int scalar_only);
+/* SeedIndex.AddSeeds (seeds/seeds.go:62-156) of one top-level sequence into an empty index, as the planner's host selection does it: the index's
+   seedMap (k-mers in seed-id order); returns their number, -1 when cap is too small */
+DPH_API int dph_hand_add_seeds(const char* bases, int64_t len, int k, int num_seeds, const double* values, uint32_t* seed_map, int cap);
 /* multiAligner.Consensus of the host's consensus path (seeds/alignment.go:23-268) on raw segment arrays: sequence i = segs[off[i] .. off[i + 1]);
    the consensus' segments, the indices of the sequences whose match was kept (>= 3 pairs) in the order returned, their pairs */
 DPH_API int dph_hand_consensus(const int32_t* segs, const int64_t* off, int n_seqs, int k, int32_t* cons_out, int64_t cons_cap, int64_t* cons_n,

@@ -171,6 +171,39 @@ def _device_index(ctx, k, seqs, n_seeds=64):
     ctx.index_build(np.array(offs, dtype=np.uint64), np.array(ns, dtype=np.uint32))
 
 
+def _add_seeds_case():
+    """-> (k, text, [(values, {minSeeds: expected seed k-mers})]): the case and its variant with a tie between blocks"""
+    h = hand("add_seeds_blocks.json")
+    k, text = h["k"], h["sequence"]
+    runs = []
+    for over, expect in (({}, h["expect"]), (h["tie"]["values_override"], h["tie"]["expect"])):
+        values = np.zeros(4 ** k, dtype=np.float64)
+        for st, v in list(h["values_at_start"].items()) + list(over.items()):
+            values[O.kmer_value(text[int(st):int(st) + k])] = v
+        runs.append((values, expect))
+    return k, text, runs
+
+
+def test_add_seeds_oracle():
+    """AddSeeds of a 100-base sequence into an empty index: blocks, bests, the top-N list, the order of the seeds - worked by hand."""
+    k, text, runs = _add_seeds_case()
+    for values, expect in runs:
+        for n, want in expect.items():
+            got = O.add_seeds_each([O.Seq(text)], k, int(n), values)[0].tolist()
+            assert got == [O.kmer_value(x) for x in want], n
+
+
+def test_add_seeds_host():
+    k, text, runs = _add_seeds_case()
+    H = _host()
+    H.dph_hand_add_seeds.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    for values, expect in runs:
+        for n, want in expect.items():
+            out = np.zeros(64, dtype=np.uint32)
+            m = H.dph_hand_add_seeds(text.encode(), len(text), k, int(n), values.ctypes.data, out.ctypes.data, 64)
+            assert out[:m].tolist() == [O.kmer_value(x) for x in want], n
+
+
 CONSENSUS_CASES = ["consensus_three_sequences.json", "consensus_third_sequence_skips_a_seed.json"]
 
 
@@ -330,3 +363,27 @@ def test_consensus_device(ctx, name):
     if "C" not in h["expect"]["kept"]:
         assert int(out.match_len[names.index("C")]) == 0
     _check_consensus(h, names, cons, kept, counts, a, b)
+
+
+@pytest.mark.gpu
+def test_add_seeds_device(ctx):
+    """The selection kernel (dp_select_seeds) returns the top-N list in slot order; AddSeeds then adds every slot and its reverse
+    complement (seeds.go:130-154) - the hand case's seed order."""
+    k, text, runs = _add_seeds_case()
+    b = np.frombuffer(text.encode(), dtype=np.uint8)
+    ctx.upload_reads(b, np.array([0, len(b)], dtype=np.int64))
+    for values, expect in runs:
+        ctx.values_upload(values)
+        for n, want in expect.items():
+            top = ctx.select_seeds([(0, 0, len(text))], k, int(n))[0].tolist()
+            got, seen = [], set()
+            for km in top:
+                r, x = 0, km
+                for _ in range(k):
+                    r = (r << 2) | (3 - (x & 3))
+                    x >>= 2
+                for y in (km, r):
+                    if y not in seen:
+                        seen.add(y)
+                        got.append(y)
+            assert got == [O.kmer_value(x) for x in want], n
