@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a dropped experiment: the kernels and DP_TUNE keys this script switches were taken out again - profiles/r06/k10_walk_read_ranges_per_xcd.txt)
 # read ranges per XCD in the dense walk: variants on small inputs, then the k = 10 job with and without (alternating)
 R=gpurun_out/r06; mkdir -p $R
 timeout 1500 python3 -m pytest tests/test_gpu_overlap_e2e.py -x -q -k "counting_step_variants" 2>&1 | tail -4

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (record of a dropped experiment: the kernels and DP_TUNE keys this script switches were taken out again - profiles/r06/k10_walk_read_ranges_per_xcd.txt)
 # walk_bin's HBM bytes with and without read ranges per XCD (k = 10, first 6 rounds)
 mkdir -p gpurun_out/r06; cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 R=gpurun_out/r06
