@@ -111,6 +111,8 @@ struct dp_ctx {
     PinBuf h_extra;                   // the extra scan items (query windows) of a round, staged for the device to fetch
     PinBuf h_spack;                   // the survivor list as the compaction kernel writes it (pinned, written by the device)
     uint64_t ignore_epoch = ~0ull;
+    PinBuf h_ignore;              // the flags as the device holds them (pinned: the device's copy is refreshed from here by a kernel of the stream)
+    bool ignore_shadow_valid = false;
     uint64_t cached_bases = 0;
     uint32_t cached_reads = 0, cached_lo = 0, cached_hi = 0;
     uint32_t chunk_lo = 0;            // what turns d_surv's survivor entries into read ids: the scanned range's first read, or 0 once dp_allgather_survivors installed the gathered list

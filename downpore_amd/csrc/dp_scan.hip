@@ -696,7 +696,7 @@ extern "C" void dp_ctx_destroy(dp_ctx* ctx) {
     for (void* q : ctx->retired_dev) dev_free_impl(q, true);
     for (void* q : ctx->retired_pin) dp_pin_free(q);
     PinBuf* pbs[] = {&ctx->h_counts, &ctx->h_segoff, &ctx->h_segs, &ctx->h_total, &ctx->h_mrec, &ctx->h_ma, &ctx->h_mb,
-                     &ctx->h_seeds, &ctx->h_spack, &ctx->h_extra, &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout};
+                     &ctx->h_seeds, &ctx->h_spack, &ctx->h_extra, &ctx->h_cursor, &ctx->h_cand, &ctx->h_cand_off, &ctx->h_cand_list, &ctx->h_mq, &ctx->h_mt, &ctx->h_moff, &ctx->h_surv, &ctx->h_ta, &ctx->h_tb, &ctx->h_qm, &ctx->h_qup, &ctx->h_seltop, &ctx->h_cin, &ctx->h_cout, &ctx->h_manchor, &ctx->h_manout, &ctx->h_ignore};
     for (auto* b : pbs)
         if (b->p) dp_pin_free(b->p);
     kit_put(ctx);
@@ -926,6 +926,7 @@ static int reads_upload_prepare(dp_ctx* ctx, const uint8_t* bases, const int64_t
     }
     ctx->n_reads = n_reads;
     ctx->ignore_epoch = ~0ull;  // (cached per-read-set state of dp_scan_reads)
+    ctx->ignore_shadow_valid = false;
     ctx->items_ptr = nullptr;
     ctx->h_boff.swap(h_boff);
     ctx->h_len.swap(h_len);
@@ -2147,22 +2148,69 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         if ((uint64_t)it.start + it.n_kmers + (it.n_kmers ? k - 1 : 0) > ctx->h_len[it.read])
             return dp_fail(ctx, DP_ERR_ARG, "scan item: k-mer range exceeds the read");
     }
-    // bases examined over the non-ignored reads: recomputed only when the flags (epoch) or the range change
+    // bases examined over the non-ignored reads, and the flags on the device: brought up to date when the flags (epoch) or the range change -
+    // which is nearly every round (a round's commit flags its query reads).  Round 6: the context keeps a pinned copy of the flags as the
+    // device holds them; a call compares the caller's array with it eight bytes at a time, adjusts the two sums by the reads whose flag
+    // changed and lets a kernel of the stream fetch the block - where it walked all reads (100 k branches a round) and handed 100 KB of
+    // pageable memory to the runtime's copy path (a slot thread spent ~0.15 of its round's 0.73 ms there; five slots entering that path
+    // together at a job's start could wait 8 ms for one another: profiles/r06/job_start_stall.txt).
     if (ctx->ignore_epoch != ignore_epoch || ctx->cached_lo != lo || ctx->cached_hi != hi || ctx->cached_top != top_level ||
         ctx->cached_k != k) {
-        uint64_t b = 0;
-        uint32_t nr = 0;
-        for (uint32_t r = lo; r < hi; r++) {
-            if (ignore[r]) continue;
+        const size_t nr8 = ((size_t)ctx->n_reads + 7) & ~(size_t)7;
+        const bool grown = !ctx->h_ignore.p || ctx->h_ignore.cap < nr8 + 64;
+        if (pin_reserve(ctx, ctx->h_ignore, nr8 + 64)) return DP_ERR_HIP;
+        if (dev_reserve(ctx, ctx->d_ignore, nr8 + 16)) return DP_ERR_HIP;
+        uint8_t* shadow = (uint8_t*)ctx->h_ignore.p;
+        auto kmers_of = [&](uint32_t r) -> uint64_t {
             int64_t n = (int64_t)ctx->h_len[r] - k + 1;
             if (top_level && (ctx->h_len[r] & 3u) == 0) n -= 4;
-            if (n > 0) b += (uint64_t)n + k - 1;
-            nr++;
+            return n > 0 ? (uint64_t)n + k - 1 : 0ull;
+        };
+        const bool same_view = ctx->ignore_shadow_valid && !grown && ctx->cached_lo == lo && ctx->cached_hi == hi && ctx->cached_top == top_level &&
+                               ctx->cached_k == k;
+        if (!same_view) {  // a new view (or the first call): everything once
+            memcpy(shadow, ignore, ctx->n_reads);
+            memset(shadow + ctx->n_reads, 0, nr8 + 64 - ctx->n_reads);
+            uint64_t b = 0;
+            uint32_t nr = 0;
+            for (uint32_t r = lo; r < hi; r++) {
+                if (shadow[r]) continue;
+                b += kmers_of(r);
+                nr++;
+            }
+            ctx->cached_bases = b;
+            ctx->cached_reads = nr;
+            ctx->ignore_shadow_valid = true;
+        } else {  // the reads whose flag changed since the last call (the caller's array may change under this loop: what is READ here is
+                  // what the device gets - the commit's speculation check covers flags set after a round's snapshot)
+            const size_t words = (size_t)ctx->n_reads / 8;
+            for (size_t w = 0; w < words; w++) {
+                uint64_t now_w, old_w;
+                memcpy(&now_w, ignore + 8 * w, 8);
+                memcpy(&old_w, shadow + 8 * w, 8);
+                if (now_w == old_w) continue;
+                for (uint32_t r = (uint32_t)(8 * w); r < (uint32_t)(8 * w + 8); r++) {
+                    const uint8_t v = (uint8_t)(now_w >> (8 * (r & 7u)));
+                    if (v == shadow[r]) continue;
+                    if (r >= lo && r < hi && (v != 0) != (shadow[r] != 0)) {
+                        if (v) ctx->cached_bases -= kmers_of(r), ctx->cached_reads--;
+                        else ctx->cached_bases += kmers_of(r), ctx->cached_reads++;
+                    }
+                    shadow[r] = v;
+                }
+            }
+            for (uint32_t r = (uint32_t)(8 * words); r < ctx->n_reads; r++) {
+                const uint8_t v = ignore[r];
+                if (v == shadow[r]) continue;
+                if (r >= lo && r < hi && (v != 0) != (shadow[r] != 0)) {
+                    if (v) ctx->cached_bases -= kmers_of(r), ctx->cached_reads--;
+                    else ctx->cached_bases += kmers_of(r), ctx->cached_reads++;
+                }
+                shadow[r] = v;
+            }
         }
-        ctx->cached_bases = b;
-        ctx->cached_reads = nr;
-        if (dev_reserve(ctx, ctx->d_ignore, (size_t)ctx->n_reads + 16)) return DP_ERR_HIP;
-        DP_HIP(hipMemcpyAsync(ctx->d_ignore.p, ignore, ctx->n_reads, hipMemcpyHostToDevice, ctx->stream));
+        const dp_fetch_region f = {ctx->d_ignore.p, shadow, nr8};
+        if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, &f, 1)) return rc;
         ctx->ignore_epoch = ignore_epoch;
         ctx->cached_lo = lo;
         ctx->cached_hi = hi;
