@@ -999,7 +999,9 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     // still (10.6 ms of kernels) but the threads' control flow no longer fits their caches and runs less beside the GPU's work
     // and once a context's teardown no longer cost 5 ms, more threads paid: 6 x 2 730 = 78 launches, 18 ms of kernels, a run of 58 - 60 ms
     // (856 k reads/s) against 64 - 70 ms with 4 x 2 730 and 61 - 70 with 8 x 2 048
-    size_t inflight = std::max<size_t>(2730, 10922 / nThreadsPlanned);
+    // round 6, once a context no longer costs a thread 4 ms: 8 x 2 048 runs 46 - 47 ms where 6 x 2 730 runs 50 - 51 (three alternations on
+    // one box, profiles/r06/map_threads_sweep.txt)
+    size_t inflight = nThreadsPlanned >= 8 ? 2048 : std::max<size_t>(2730, 10922 / nThreadsPlanned);
     if (const char* e = getenv("DP_MAP_INFLIGHT")) inflight = (size_t)std::max(64, atoi(e));
     const size_t stackBytes = 256 * 1024;
     std::vector<std::unique_ptr<Task>> live;
@@ -1200,7 +1202,7 @@ int runMap(const ReadSet& refSet, const ReadSet& reads, const MapParams& p, int 
     size_t nThreads = 1;
     if (shards.empty()) {
         const char* e = getenv("DP_MAP_THREADS");
-        nThreads = (size_t)std::max(1, e ? atoi(e) : (hostThreads() >= 12 ? 6 : hostThreads() >= 8 ? 4 : 3));
+        nThreads = (size_t)std::max(1, e ? atoi(e) : (hostThreads() >= 16 ? 8 : hostThreads() >= 12 ? 6 : hostThreads() >= 8 ? 4 : 3));
         size_t perThread = 2048;  // (fewer reads than that per thread are not worth a context; DP_MAP_MIN_READS_PER_THREAD: test hook)
         perThread = (size_t)std::max(1L, dph_tune("map_min_reads_per_thread", (long)perThread));
         nThreads = std::min(nThreads, std::max<size_t>(1, reads.size() / perThread));

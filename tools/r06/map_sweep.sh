@@ -1,6 +1,6 @@
 #!/bin/bash
-# `map` config 3: mapper threads x reads in flight, median of 10 runs each (after 2 warm runs), one process per setting
-for cfg in "6 2730" "8 2048" "8 2730" "10 1638" "12 1365" "6 4096"; do set -- $cfg
+# `map` config 3: mapper threads x reads in flight, median of 10 runs each (after 2 warm runs), one process per setting, alternating
+for rep in 1 2 3; do for cfg in "6 2730" "8 2730" "8 2048"; do set -- $cfg
 DP_MAP_THREADS=$1 DP_MAP_INFLIGHT=$2 python3 - <<'PY'
 import os, sys, time, json
 sys.path.insert(0, os.getcwd())
@@ -20,4 +20,4 @@ for i in range(12):
 ts.sort()
 print("threads %s inflight %s: median %.1f ms = %.0f k reads/s, best %.1f, worst %.1f" % (os.environ["DP_MAP_THREADS"], os.environ["DP_MAP_INFLIGHT"], 1e3*ts[len(ts)//2], g["reads"]/ts[len(ts)//2]/1e3, 1e3*ts[0], 1e3*ts[-1]), flush=True)
 PY
-done 2>&1 | grep threads | tee gpurun_out/r06/map_threads_sweep.txt
+done; done 2>&1 | grep threads
