@@ -81,7 +81,7 @@ def test_map_reads_travel_packed_or_as_ascii(monkeypatch):
 
 
 def test_map_threads_reads_in_flight_and_parked_blocks(monkeypatch):
-    """The mapper deals its reads to host threads (DP_MAP_THREADS, default 4) that keep DP_MAP_INFLIGHT reads in flight each (one window
+    """The mapper deals its reads to host threads (DP_MAP_THREADS, default 8 from 16 host cores up) that keep DP_MAP_INFLIGHT reads in flight each (one window
     per read and dp_map_windows call); the contexts of a finished run park their device and pinned blocks in the library's cache and the
     next run takes them from there (round 5).  Same PAF as the oracle with one thread, many small calls, few large ones, and across
     dp_release_device_caches() - which returns what was parked, then nothing."""
