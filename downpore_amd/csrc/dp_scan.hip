@@ -2012,9 +2012,16 @@ extern "C" int dp_scan(dp_ctx* ctx, const dp_scan_item* items, uint32_t n_items,
 
 struct make_read_items_kernel {
     enum { THREADS = 256 };
+    // flag_src (or null): the flags' pinned host copy, newer than the device's - this launch brings the block over as well (eight bytes
+    // per thread, flag_words of them; its own read's flag every thread takes from the source itself)
     static __device__ void run(const uint32_t* __restrict__ len, const uint8_t* __restrict__ ignore, uint32_t lo,
-                                       uint32_t hi, int k, int top_level, uint32_t min_seeds, dp_scan_item* __restrict__ items) {
+                                       uint32_t hi, int k, int top_level, uint32_t min_seeds, dp_scan_item* __restrict__ items,
+                                       const unsigned long long* __restrict__ flag_src, unsigned long long* __restrict__ flag_dst, uint32_t flag_words) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (flag_src) {
+        if (i < flag_words) flag_dst[i] = flag_src[i];
+        ignore = (const uint8_t*)flag_src;
+    }
     if (lo + i >= hi) return;
     const uint32_t r = lo + i;
     const uint32_t L = len[r];
@@ -2154,9 +2161,20 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     // changed and lets a kernel of the stream fetch the block - where it walked all reads (100 k branches a round) and handed 100 KB of
     // pageable memory to the runtime's copy path (a slot thread spent ~0.15 of its round's 0.73 ms there; five slots entering that path
     // together at a job's start could wait 8 ms for one another: profiles/r06/job_start_stall.txt).
+    bool flags_dirty = false;
+    struct FlagsGuard {  // (a way out of this call before the launch that brings the flags over: the next call starts from scratch)
+        dp_ctx* c;
+        bool& dirty;
+        ~FlagsGuard() {
+            if (dirty) {
+                c->ignore_shadow_valid = false;
+                c->ignore_epoch = ~0ull;
+            }
+        }
+    } flagsGuard{ctx, flags_dirty};
+    const size_t nr8 = ((size_t)ctx->n_reads + 7) & ~(size_t)7;
     if (ctx->ignore_epoch != ignore_epoch || ctx->cached_lo != lo || ctx->cached_hi != hi || ctx->cached_top != top_level ||
         ctx->cached_k != k) {
-        const size_t nr8 = ((size_t)ctx->n_reads + 7) & ~(size_t)7;
         const bool grown = !ctx->h_ignore.p || ctx->h_ignore.cap < nr8 + 64;
         if (pin_reserve(ctx, ctx->h_ignore, nr8 + 64)) return DP_ERR_HIP;
         if (dev_reserve(ctx, ctx->d_ignore, nr8 + 16)) return DP_ERR_HIP;
@@ -2209,8 +2227,7 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
                 shadow[r] = v;
             }
         }
-        const dp_fetch_region f = {ctx->d_ignore.p, shadow, nr8};
-        if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, &f, 1)) return rc;
+        flags_dirty = true;  // (brought over by the launch that makes the read items - below - or by one of its own)
         ctx->ignore_epoch = ignore_epoch;
         ctx->cached_lo = lo;
         ctx->cached_hi = hi;
@@ -2244,8 +2261,12 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
     // round (the kernels only read them; the extra items behind them are this round's)
     if (n_read_items && (ctx->items_ptr != d_items || ctx->items_epoch != ignore_epoch || ctx->items_lo != lo || ctx->items_hi != hi ||
                          ctx->items_min != min_seeds || ctx->items_top != top_level || ctx->items_k != k)) {
-        dp_launch<make_read_items_kernel>(ctx, dim3((n_read_items + 255) / 256), dim3(256),
-                           (const uint32_t*)ctx->d_len.p, (const uint8_t*)ctx->d_ignore.p, lo, hi, k, top_level, min_seeds, d_items);
+        const uint32_t fw = flags_dirty ? (uint32_t)(nr8 / 8) : 0u;
+        dp_launch<make_read_items_kernel>(ctx, dim3((std::max(n_read_items, fw) + 255) / 256), dim3(256),
+                           (const uint32_t*)ctx->d_len.p, (const uint8_t*)ctx->d_ignore.p, lo, hi, k, top_level, min_seeds, d_items,
+                           flags_dirty ? (const unsigned long long*)ctx->h_ignore.p : (const unsigned long long*)nullptr,
+                           (unsigned long long*)ctx->d_ignore.p, fw);
+        flags_dirty = false;
         ctx->items_ptr = d_items;
         ctx->items_epoch = ignore_epoch;
         ctx->items_lo = lo;
@@ -2253,6 +2274,11 @@ static int scan_reads_body(dp_ctx* ctx, const uint8_t* ignore, uint64_t ignore_e
         ctx->items_min = min_seeds;
         ctx->items_top = top_level;
         ctx->items_k = k;
+    }
+    if (flags_dirty) {  // (no read items were made in this call)
+        const dp_fetch_region f = {ctx->d_ignore.p, ctx->h_ignore.p, nr8};
+        if (int rc = dp_zero_fetch_regions(ctx, nullptr, 0, &f, 1)) return rc;
+        flags_dirty = false;
     }
     if (n_extra) {  // (borrowed from the caller: staged in a pinned block, fetched by a kernel of this stream)
         if (pin_reserve(ctx, ctx->h_extra, (size_t)n_extra * sizeof(dp_scan_item) + 64)) return DP_ERR_HIP;
