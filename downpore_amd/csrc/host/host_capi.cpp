@@ -473,6 +473,25 @@ int dph_hand_add_seeds(const char* bases, int64_t len, int k, int num_seeds, con
     for (size_t i = 0; i < ix.seedMap.size(); i++) seed_map[i] = (uint32_t)ix.seedMap[i];
     return (int)ix.seedMap.size();
 }
+int dph_hand_bases_covered(const int32_t* a_seg, int a_n, const int32_t* b_seg, int b_n, const int32_t* match_a, const int32_t* match_b, int n,
+                           int k, int64_t* out2) {
+    dph::SeedSeq A, B;
+    A.seg = a_seg;
+    A.n = a_n;
+    B.seg = b_seg;
+    B.n = b_n;
+    dph::SeedMatch m;
+    m.SeqA = &A;
+    m.SeqB = &B;
+    m.MatchA.assign(match_a, match_a + n);
+    m.MatchB.assign(match_b, match_b + n);
+    dph::i64 a = 0, b = 0;
+    bool panic = false;
+    dph::matchBasesCovered(m, k, &a, &b, &panic);
+    out2[0] = a;
+    out2[1] = b;
+    return panic ? 1 : 0;
+}
 int dph_hand_consensus(const int32_t* segs, const int64_t* off, int n_seqs, int k, int32_t* cons_out, int64_t cons_cap, int64_t* cons_n,
                        int* kept, int64_t* out_counts, int32_t* out_a, int32_t* out_b, int64_t cap, int64_t* n_matches) {
     dph::Arena ar;

@@ -160,6 +160,10 @@ DPH_API void dph_pack_bases(const char* bases, int64_t n, uint8_t* out, int scal
 /* SeedIndex.AddSeeds (seeds/seeds.go:62-156) of one top-level sequence into an empty index, as the planner's host selection does it: the index's
    seedMap (k-mers in seed-id order); returns their number, -1 when cap is too small */
 DPH_API int dph_hand_add_seeds(const char* bases, int64_t len, int k, int num_seeds, const double* values, uint32_t* seed_map, int cap);
+/* SeedMatch.GetBasesCovered (seeds/sequence.go:830-858: the PAF line's tenth column) on raw segment arrays and matched seed indices;
+   out2 = {countA, countB}; returns 1 where the reference would panic */
+DPH_API int dph_hand_bases_covered(const int32_t* a_seg, int a_n, const int32_t* b_seg, int b_n, const int32_t* match_a, const int32_t* match_b, int n,
+                                   int k, int64_t* out2);
 /* multiAligner.Consensus of the host's consensus path (seeds/alignment.go:23-268) on raw segment arrays: sequence i = segs[off[i] .. off[i + 1]);
    the consensus' segments, the indices of the sequences whose match was kept (>= 3 pairs) in the order returned, their pairs */
 DPH_API int dph_hand_consensus(const int32_t* segs, const int64_t* off, int n_seqs, int k, int32_t* cons_out, int64_t cons_cap, int64_t* cons_n,

@@ -193,6 +193,26 @@ int dpo_hand_consensus(const int64_t* segs, const int64_t* off, int n_seqs, int 
     });
 }
 
+// SeedMatch.GetBasesCovered (seeds/sequence.go:830-858) on raw segment arrays and a list of matched seed indices; out2 = {countA, countB};
+// returns 1 where the reference would panic (an index out of range)
+int dpo_hand_bases_covered(const int64_t* aSeg, int64_t aN, const int64_t* bSeg, int64_t bN, const int64_t* matchA, const int64_t* matchB,
+                           int64_t n, int k, int64_t* out2) {
+    int panicked = 0;
+    int rc = guard([&] {
+        Arena ar;
+        SeedMatch m;
+        m.SeqA = mkSeq(ar, aSeg, aN);
+        m.SeqB = mkSeq(ar, bSeg, bN);
+        m.MatchA.assign(matchA, matchA + n);
+        m.MatchB.assign(matchB, matchB + n);
+        i64 a = 0, b = 0;
+        if (!smGetBasesCovered(m, k, &a, &b)) panicked = 1;
+        out2[0] = a;
+        out2[1] = b;
+    });
+    return rc ? rc : panicked;
+}
+
 // ---- decision rules on bare numbers (tests/test_hand_known_answers.py: answers worked by hand from the Go text) ----------------
 // chunkWorker (overlap/overlap.go:253-318) on one seed sequence; out = 5 values per piece handed to AddSequence: first seed, seeds,
 // Len(), GetOffset(), GetInset()

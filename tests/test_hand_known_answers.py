@@ -204,6 +204,27 @@ def test_add_seeds_host():
             assert out[:m].tolist() == [O.kmer_value(x) for x in want], n
 
 
+def test_bases_covered_oracle_and_host():
+    """GetBasesCovered - the PAF line's tenth column - on overlapping seeds, a skipped seed, a single seed."""
+    h = hand("bases_covered.json")
+    a, b = np.array(h["a_segments"], dtype=np.int64), np.array(h["b_segments"], dtype=np.int64)
+    a32, b32 = a.astype(np.int32), b.astype(np.int32)
+    L, H = O.lib(), _host()
+    L.dpo_hand_bases_covered.argtypes = [i64p, C.c_int64, i64p, C.c_int64, i64p, i64p, C.c_int64, C.c_int, i64p]
+    i32p = C.POINTER(C.c_int32)
+    H.dph_hand_bases_covered.argtypes = [i32p, C.c_int, i32p, C.c_int, i32p, i32p, C.c_int, C.c_int, i64p]
+    for c in h["cases"]:
+        ma, mb = np.array(c["match_a"], dtype=np.int64), np.array(c["match_b"], dtype=np.int64)
+        out = np.zeros(2, dtype=np.int64)
+        assert L.dpo_hand_bases_covered(_p(a), len(a), _p(b), len(b), _p(ma), _p(mb), len(ma), h["k"], _p(out)) == 0
+        assert out.tolist() == [c["count_a"], c["count_b"]], ("oracle", c)
+        ma32, mb32 = ma.astype(np.int32), mb.astype(np.int32)
+        out[:] = 0
+        assert H.dph_hand_bases_covered(a32.ctypes.data_as(i32p), len(a32), b32.ctypes.data_as(i32p), len(b32), ma32.ctypes.data_as(i32p),
+                                        mb32.ctypes.data_as(i32p), len(ma32), h["k"], _p(out)) == 0
+        assert out.tolist() == [c["count_a"], c["count_b"]], ("host", c)
+
+
 CONSENSUS_CASES = ["consensus_three_sequences.json", "consensus_third_sequence_skips_a_seed.json"]
 
 
