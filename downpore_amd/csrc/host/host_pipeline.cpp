@@ -1327,6 +1327,12 @@ int OverlapRun::executeRoundOnImpl(ExecSlot& sl, i64 r, RoundResult& out) {
     }
     if (dbgExec) fprintf(stderr, "[exec] round %lld finished rc %d\n", (long long)r, rc);
     const double t2 = now();
+    static const bool slowTrace = dph_debug("slow");  // rounds that took a slot more than 3 ms, with where the time went
+    if (slowTrace && t2 - t0 > 3e-3)
+        fprintf(stderr, "[slow] round %lld slot %d at %.1f ms of its job: %.2f ms = plan wait %.2f + prepare %.2f + scan / count %.2f + index %.2f + query / chain / consensus %.2f + rest %.2f\n",
+                (long long)r, sl.slotNo, 1e3 * (t0 - initEnd_), 1e3 * (t2 - t0), 1e3 * (tPlan - t0), 1e3 * (out.st.t_prepare - (tPlan - t0)), 1e3 * out.st.t_scan,
+                1e3 * out.st.t_index, 1e3 * (out.st.t_query + out.st.t_consensus),
+                1e3 * ((t2 - t0) - (out.st.t_prepare + out.st.t_scan + out.st.t_index + out.st.t_query + out.st.t_consensus)));
     if (startTrace && r < 12)
         fprintf(stderr, "[start] round %lld slot %d: asked for its plan at %.2f ms, had it at %.2f, scanned / counted at %.2f, finished at %.2f\n", (long long)r, sl.slotNo,
                 1e3 * (t0 - initEnd_), 1e3 * (tPlan - initEnd_), 1e3 * (t1 + out.st.t_scan - initEnd_), 1e3 * (t2 - initEnd_));
