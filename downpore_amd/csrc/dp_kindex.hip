@@ -834,10 +834,114 @@ struct kidx_walk_bin {
             }
         }
     }
+    // One trip per workgroup and reservation - the sparse regime's form (workgroups of up to 8 waves), as it was before the dense regime's
+    // trips, table and look-ahead were built into run() below: those cost the k = 13 walk 20 us a launch (36 -> 56 us under five slots,
+    // profiles/r06/k13_against_round5.txt) and buy it nothing - its reservations are one trip long.
+    static __device__ void run_one_trip(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off, const KxPos pos,
+                               const dp_scan_item* __restrict__ items, uint32_t lo, uint32_t hi, uint32_t n_read_items,
+                               const uint32_t* __restrict__ head, const uint32_t* __restrict__ next, uint32_t* __restrict__ counts,
+                               unsigned long long* __restrict__ n_hits, uint32_t lps, const KxBins B, uint32_t n_waves) {
+        __shared__ uint32_t hist[KX_MAXBINS], base[KX_MAXBINS];
+        __shared__ uint32_t xs[2];
+        __shared__ unsigned long long sh_hits;
+        const int lane = dp_lane();
+        const uint32_t stride = gridDim.x * WAVES;
+        // (every wave of a workgroup makes the same number of trips: the barriers below are the workgroup's)
+        for (uint32_t wb = blockIdx.x * WAVES; wb < n_waves; wb += stride) {
+            for (uint32_t t = threadIdx.x; t < B.n_bins; t += THREADS) hist[t] = 0u;
+            if (threadIdx.x == 0) {
+                sh_hits = 0ull;
+                xs[0] = xs[1] = 0u;
+            }
+            __syncthreads();
+            const uint32_t w = wb + (threadIdx.x >> 6);
+            // the groups of kidx_walk: KX_PARTS waves per seed (dense seeds), or four seeds per wave
+            uint32_t s = 0, i0 = 0, i1 = 0, step = 16, gfirst = 0;
+            uint64_t o = 0;
+            bool gleader = false;
+            if (w < n_waves) {
+                if (lps == 64) {
+                    s = w / KX_PARTS;
+                    if (s < n_seeds) {
+                        const uint32_t part = w % KX_PARTS;
+                        o = off[seeds[s]];
+                        const uint32_t n = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
+                        const uint32_t per = (n + KX_PARTS - 1) / KX_PARTS;
+                        gfirst = min(n, part * per);
+                        i0 = part * per + 4u * (uint32_t)lane;
+                        i1 = min(n, part * per + per);
+                        step = 64;
+                        gleader = lane == 0;
+                    }
+                } else {
+                    s = w * 4 + ((uint32_t)lane >> 4);
+                    if (s < n_seeds) {
+                        o = off[seeds[s]];
+                        i0 = 4u * ((uint32_t)lane & 15u);
+                        i1 = (uint32_t)(off[(uint64_t)seeds[s] + 1] - o);
+                        gleader = (lane & 15) == 0;
+                    }
+                }
+            }
+            if (gleader && i1 > gfirst) atomicAdd(&sh_hits, (unsigned long long)(i1 - gfirst));
+            // the lane's first four entries stay in registers across the barriers (a seed of config 2 has 20 - 60 entries: for most groups
+            // the first trip is the only one, and the second pass reads nothing); later trips are read again (from the L2)
+            uint64_t e0[4] = {0, 0, 0, 0};
+            bool v0[4] = {false, false, false, false};
+            if (i0 < i1) {
+                kx_entry4(pos, o + i0, e0);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    v0[u] = i0 + (uint32_t)u < i1;
+                    e0[u] = v0[u] ? e0[u] : 0ull;
+                }
+                four<false>(e0, v0, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+            }
+            tail<false>(lps, lane, w, s, o, i0, i1, step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < B.n_bins; t += THREADS) {
+                const uint32_t c = hist[t];
+                uint32_t b = 0u;
+                if (c) {
+                    b = atomicAdd(&B.cursor[t], c);
+                    if (b + c > B.cap) {  // (its share of the bin does not fit: the whole share is counted the old way)
+                        // what it reserved below the bin's end stays unwritten: marked, so that kidx_bin_count skips it
+                        for (uint32_t j = b; j < B.cap; j++) B.rec[(size_t)t * B.cap + j] = ~0ull;
+                        b = 0xffffffffu;
+                        B.flags[0] = 1u;
+                    }
+                }
+                base[t] = b;
+                hist[t] = 0u;
+            }
+            if (threadIdx.x == 0 && sh_hits) atomicAdd(&n_hits[blockIdx.x & 63u], sh_hits);  // seed occurrences of the round (totals[2])
+            if (threadIdx.x == THREADS - 1) {  // the workgroup's stretch of the extra items' list
+                const uint32_t c = xs[0];
+                uint32_t xb = 0u;
+                if (c) {
+                    xb = atomicAdd(B.xcursor, c);
+                    if (xb + c > B.xcap) {
+                        xb = 0xffffffffu;
+                        B.flags[0] = 1u;
+                    }
+                }
+                xs[1] = xb;
+                xs[0] = 0u;
+            }
+            __syncthreads();
+            if (i0 < i1) four<true>(e0, v0, s, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+            tail<true>(lps, lane, w, s, o, i0, i1, step, pos, items, lo, hi, n_read_items, head, next, counts, B, hist, base, xs);
+            __syncthreads();
+        }
+    }
     static __device__ void run(const uint32_t* __restrict__ seeds, uint32_t n_seeds, const uint64_t* __restrict__ off, const KxPos pos,
                                const dp_scan_item* __restrict__ items, uint32_t lo, uint32_t hi, uint32_t n_read_items,
                                const uint32_t* __restrict__ head, const uint32_t* __restrict__ next, uint32_t* __restrict__ counts,
                                unsigned long long* __restrict__ n_hits, uint32_t lps, const KxBins B, uint32_t n_waves) {
+        if constexpr (WAVES != 16) {
+            run_one_trip(seeds, n_seeds, off, pos, items, lo, hi, n_read_items, head, next, counts, n_hits, lps, B, n_waves);
+            return;
+        }
         __shared__ uint32_t hist[KX_MAXBINS], base[KX_MAXBINS];
         __shared__ uint32_t xs[2];
         __shared__ unsigned long long sh_hits;

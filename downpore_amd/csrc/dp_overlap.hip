@@ -3421,12 +3421,10 @@ int dp_find_overlaps_impl(dp_ctx* ctx, const int32_t* q_segs, const uint64_t* q_
     st.chain_tier = tier_env ? atoi(tier_env) : 0;
     const char* pass_env = getenv("DP_CHAIN_PASSES");  // proposal passes (0 = the serial walk alone: the round-1 behaviour)
     st.passes = pass_env ? std::max(0, std::min(6, atoi(pass_env))) : 3;
-    // (round 6) a proposal pass is two launches, and a launch costs a round with other rounds beside it 1.5 - 1.9 us whatever it does:
-    // the third pass is only launched when this context's previous stage left it something to do (at k = 13 it sees ~18 pairs, which the
-    // final walk chains as well - bit-identical for any number of passes, tests run 0, 1 and 3)
-    // (24 pairs: at k = 13 the third pass sees ~18 pairs, all short; at k = 10 it sees 30 - 60 chains of fifty links, which the final
-    // walk - one wave per QUERY - took 116 us over against a pass's 60, profiles/r06/k10_final_walk_pairs.txt)
-    if (!pass_env && ctx->chain_open_ahead[1] < 24u) st.passes = 2;
+    // (round 6) the third pass is left out only when this context's previous stage left it next to nothing.  A threshold of 24 pairs - "at
+    // k = 13 it sees ~18 short pairs, which the final walk chains as well" - saved two launches a round and cost more than it saved: the
+    // final walk, one wave per QUERY, went from 13 to 53 us a launch under five slots (profiles/r06/k13_against_round5.txt).
+    if (!pass_env && ctx->chain_open_ahead[1] < 2u) st.passes = 2;
     st.walk_blocks = std::min<uint32_t>(256, (nq + C_WAVES - 1) / C_WAVES);
     st.spec_blocks = 1024;  // 4096 persistent waves, 16 per CU: what CSlim's 8.5 KB per wave lets a CU hold
     st.spec_blocks = (uint32_t)std::max(1L, dp_tune("spec_blocks", st.spec_blocks));
